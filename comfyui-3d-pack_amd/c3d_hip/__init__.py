@@ -1,0 +1,106 @@
+"""ctypes binding of libc3d_hip.so -- the C-ABI declared in include/c3d_gs.h / include/c3d_mesh.h.
+
+PyTorch is used here only as the owner of device memory and of the current HIP stream; every
+tensor crosses the boundary as a raw device pointer.  There is NO CPU or eager fallback: if the
+library cannot be loaded, or a tensor is not on a HIP device, the call raises.
+"""
+import ctypes as C
+import os
+import threading
+
+import torch
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG, "lib", "libc3d_hip.so")
+_lock = threading.Lock()
+_lib = None
+
+vp, i32, i64, f32, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
+
+
+class GsSettings(C.Structure):
+    """struct c3d_gs_settings (include/c3d_gs.h)"""
+    _fields_ = [("image_height", i32), ("image_width", i32), ("tanfovx", f32), ("tanfovy", f32),
+                ("scale_modifier", f32), ("sh_degree", i32), ("prefiltered", i32), ("debug", i32),
+                ("bg", vp), ("viewmatrix", vp), ("projmatrix", vp), ("campos", vp)]
+
+
+_SIGNATURES = {
+    # name: (restype, argtypes)
+    "c3d_last_error": (C.c_char_p, []),
+    "c3d_version": (C.c_int, []),
+    "c3d_gs_geom_bytes": (sz, [i32]),
+    "c3d_gs_binning_bytes": (sz, [i64, i32, i32]),
+    "c3d_gs_image_bytes": (sz, [i32, i32]),
+    "c3d_gs_forward_project": (C.c_int, [C.POINTER(GsSettings), i32, i32] + [vp] * 7 + [vp, vp, C.POINTER(i64), vp]),
+    "c3d_gs_forward_render": (C.c_int, [C.POINTER(GsSettings), i32, i32, vp, vp, i64, vp, vp, vp, vp, vp, vp]),
+    "c3d_gs_backward": (C.c_int, [C.POINTER(GsSettings), i32, i32] + [vp] * 6 + [vp, vp, i64, vp, vp] + [vp] * 3 + [vp] * 8 + [vp, vp]),
+    "c3d_gs_mark_visible": (C.c_int, [i32, vp, vp, vp, vp, vp]),
+    "c3d_gs_debug_state": (C.c_int, [i32, i32, i32, vp, i64, vp] + [vp] * 7 + [vp]),
+    "c3d_test_scan_u32": (C.c_int, [vp, vp, i64, i32, vp]),
+    "c3d_test_sort_pairs_u32": (C.c_int, [vp, vp, i64, i32, vp]),
+}
+
+
+def exported_symbols():
+    """Names every include/*.h header declares (checked against the .so by the CPU test-suite)."""
+    names = dict(_SIGNATURES)
+    try:
+        from . import mesh_sigs
+        names.update(mesh_sigs.SIGNATURES)
+    except ImportError:
+        pass
+    return names
+
+
+def lib():
+    """Load (building in-tree first if the .so is absent and hipcc exists).  Raises on failure."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            from . import build as _b
+            try:
+                _b.build()
+            except Exception as e:  # loud failure, never a fallback
+                raise RuntimeError("c3d_hip: %s is missing and could not be built: %s" % (LIB_PATH, e))
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in exported_symbols().items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().c3d_last_error()
+        raise RuntimeError("%s failed (code %d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+def ptr(t):
+    """device pointer of a tensor (None -> NULL).  Refuses non-HIP tensors: no CPU fallback."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("c3d_hip: expected a tensor on a HIP device, got %s (the MI355X path has no CPU fallback)" % t.device)
+    if not t.is_contiguous():
+        raise RuntimeError("c3d_hip: tensor must be contiguous")
+    return C.c_void_p(t.data_ptr())
+
+
+def stream(device=None):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def f32c(t):
+    """contiguous float32 view/copy of t (None and empty tensors -> None, like the dependency's 'empty = absent')."""
+    if t is None or t.numel() == 0:
+        return None
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()

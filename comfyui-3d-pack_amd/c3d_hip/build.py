@@ -1,0 +1,66 @@
+"""Build libc3d_hip.so (the C-ABI library of include/c3d_*.h) for gfx950 with hipcc, in-tree.
+
+Usage: python build.py [--force].  hipcc cross-compiles without a GPU; the .so lands in
+comfyui-3d-pack_amd/lib/ and travels with the tree (it is git-ignored, not gpurun-ignored).
+"""
+import hashlib
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(PKG, "csrc")
+LIBDIR = os.path.join(PKG, "lib")
+OBJDIR = os.path.join(PKG, "build")
+LIB = os.path.join(LIBDIR, "libc3d_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-ffp-contract=fast",
+         "-Wall", "-Wno-unused-function"]
+
+
+def _sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _digest():
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)) + ["../../include/c3d_gs.h", "../../include/c3d_mesh.h"]:
+        p = os.path.join(CSRC, f)
+        if os.path.isfile(p):
+            h.update(f.encode())
+            h.update(open(p, "rb").read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build(force=False, verbose=False):
+    os.makedirs(LIBDIR, exist_ok=True)
+    os.makedirs(OBJDIR, exist_ok=True)
+    stamp = os.path.join(LIBDIR, "libc3d_hip.digest")
+    dig = _digest()
+    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == dig:
+        return LIB
+    srcs = _sources()
+
+    def cc(f):
+        obj = os.path.join(OBJDIR, f[:-4] + ".o")
+        cmd = [HIPCC] + FLAGS + ["-c", os.path.join(CSRC, f), "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (f, r.stdout, r.stderr))
+        if verbose and r.stderr.strip():
+            print(r.stderr, file=sys.stderr)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        objs = list(ex.map(cc, srcs))
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    open(stamp, "w").write(dig)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

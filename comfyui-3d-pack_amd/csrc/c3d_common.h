@@ -1,0 +1,60 @@
+// c3d_common.h -- shared device/host helpers for the gfx950 (MI355X / CDNA4) kernels.
+// Wave = 64 lanes everywhere in this tree; no other target is supported.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define C3D_WAVE 64
+#define C3D_TILE_X 16
+#define C3D_TILE_Y 16
+#define C3D_TILE_PIX (C3D_TILE_X * C3D_TILE_Y)
+
+// error plumbing: every extern "C" entry returns 0 on success or a hipError_t / negative code;
+// c3d_last_error() returns a thread-local message.
+void c3d_set_error(const char* fmt, ...);
+#define C3D_CHECK(expr)                                                                   \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess) {                                                           \
+            c3d_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return (int)_e;                                                               \
+        }                                                                                 \
+    } while (0)
+#define C3D_LAUNCH_CHECK() C3D_CHECK(hipGetLastError())
+
+static inline size_t c3d_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+static inline int c3d_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ---- scan / sort primitives (scan_sort.hip) ----
+// Inclusive or exclusive prefix sum of n uint32 values. `tmp` needs c3d_scan_tmp_bytes(n).
+size_t c3d_scan_tmp_bytes(size_t n);
+int c3d_scan_u32(const uint32_t* in, uint32_t* out, size_t n, bool exclusive, void* tmp, hipStream_t s);
+
+// Stable LSD radix sort of (key,val) uint32 pairs over key bits [0, end_bit).
+// keys/vals are ping-pong buffers [2][n]; result index (0 or 1) is returned through *result_buf.
+// vals_in may be null on entry => values are the element indices.  tmp: c3d_sort_tmp_bytes(n).
+size_t c3d_sort_tmp_bytes(size_t n);
+int c3d_sort_pairs_u32(uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32_t* vals1, bool iota_vals,
+                       size_t n, int end_bit, void* tmp, int* result_buf, hipStream_t s);
+
+// ---- device helpers ----
+#ifdef __HIPCC__
+__device__ __forceinline__ int c3d_lane() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// wave-wide inclusive scan (64 lanes) of a uint32
+__device__ __forceinline__ uint32_t c3d_wave_incl_scan(uint32_t v) {
+    const int lane = c3d_lane();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+// wave-wide float sum; every lane gets the total (xor butterfly)
+__device__ __forceinline__ float c3d_wave_sum(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+#endif

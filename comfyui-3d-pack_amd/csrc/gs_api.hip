@@ -1,0 +1,231 @@
+// gs_api.hip -- extern "C" entry points declared in include/c3d_gs.h.
+#include "../../include/c3d_gs.h"
+#include "gs_internal.h"
+#include <stdarg.h>
+#include <stdio.h>
+
+static thread_local char g_err[1024] = "";
+void c3d_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+static int tile_sort_bits(int tiles) {
+    int bits = 0;
+    while ((1ll << bits) < (long long)tiles) bits++;
+    return bits < 1 ? 1 : bits;
+}
+static int sort_result_index(int end_bit) {   // buffer index after ceil(end_bit/8) (>=1) ping-pong passes
+    int passes = (end_bit + 7) / 8;
+    if (passes < 1) passes = 1;
+    return passes & 1;
+}
+
+static int make_params(const c3d_gs_settings* st, int N, int M, GsParams& p) {
+    if (!st) { c3d_set_error("c3d_gs: settings is NULL"); return -1; }
+    if (N < 0 || M < 0 || st->image_height < 0 || st->image_width < 0) { c3d_set_error("c3d_gs: negative size"); return -1; }
+    if (st->sh_degree < 0 || st->sh_degree > 3) { c3d_set_error("c3d_gs: sh_degree %d not in [0,3]", st->sh_degree); return -1; }
+    if (!st->bg || !st->viewmatrix || !st->projmatrix || !st->campos) { c3d_set_error("c3d_gs: settings device pointers must be non-NULL"); return -1; }
+    p.N = N; p.M = M; p.deg = st->sh_degree; p.W = st->image_width; p.H = st->image_height;
+    p.gx = (p.W + C3D_TILE_X - 1) / C3D_TILE_X; p.gy = (p.H + C3D_TILE_Y - 1) / C3D_TILE_Y;
+    p.tanfovx = st->tanfovx; p.tanfovy = st->tanfovy;
+    p.focal_x = p.W / (2.0f * st->tanfovx); p.focal_y = p.H / (2.0f * st->tanfovy);
+    p.scale_modifier = st->scale_modifier;
+    p.bg = st->bg; p.view = st->viewmatrix; p.proj = st->projmatrix; p.campos = st->campos;
+    return 0;
+}
+static int check_inputs(int N, int M, int deg, const float* means3D, const float* shs, const float* colors_precomp,
+                        const float* scales, const float* rotations, const float* cov3D_precomp) {
+    if (N == 0) return 0;
+    if (!means3D) { c3d_set_error("c3d_gs: means3D is NULL"); return -1; }
+    if ((shs == nullptr) == (colors_precomp == nullptr)) { c3d_set_error("Please provide excatly one of either SHs or precomputed colors!"); return -1; }
+    if (((scales == nullptr || rotations == nullptr) && cov3D_precomp == nullptr) || ((scales != nullptr || rotations != nullptr) && cov3D_precomp != nullptr)) {
+        c3d_set_error("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
+        return -1;
+    }
+    if (shs && (deg + 1) * (deg + 1) > M) { c3d_set_error("c3d_gs: sh_degree %d needs %d coefficients, tensor has %d", deg, (deg + 1) * (deg + 1), M); return -1; }
+    return 0;
+}
+
+extern "C" {
+
+const char* c3d_last_error(void) { return g_err; }
+int c3d_version(void) { return 100; }
+
+size_t c3d_gs_geom_bytes(int32_t N) { GsGeom g; gs_carve_geom(nullptr, N, g); return g.bytes; }
+size_t c3d_gs_binning_bytes(int64_t D, int32_t H, int32_t W) {
+    GsBinning b;
+    gs_carve_binning(nullptr, D, ((W + C3D_TILE_X - 1) / C3D_TILE_X) * ((H + C3D_TILE_Y - 1) / C3D_TILE_Y), b);
+    return b.bytes;
+}
+size_t c3d_gs_image_bytes(int32_t H, int32_t W) { GsImage im; gs_carve_image(nullptr, W, H, im); return im.bytes; }
+
+int c3d_gs_forward_project(const c3d_gs_settings* st, int32_t N, int32_t M, const float* means3D, const float* shs,
+                           const float* colors_precomp, const float* opacities, const float* scales,
+                           const float* rotations, const float* cov3D_precomp, int32_t* radii, void* geom_buffer,
+                           int64_t* num_rendered, c3d_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    GsParams p;
+    if (make_params(st, N, M, p)) return -1;
+    if (check_inputs(N, M, p.deg, means3D, shs, colors_precomp, scales, rotations, cov3D_precomp)) return -1;
+    if (!num_rendered) { c3d_set_error("c3d_gs_forward_project: num_rendered (host) is NULL"); return -1; }
+    *num_rendered = 0;
+    if (N == 0) return 0;
+    if (!geom_buffer || !radii || !opacities) { c3d_set_error("c3d_gs_forward_project: NULL buffer"); return -1; }
+    GsGeom g;
+    gs_carve_geom((char*)geom_buffer, N, g);
+    int rc;
+    if ((rc = gs_launch_preprocess(p, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, radii, s))) return rc;
+    // order Gaussians by (view depth, id): stable sort of the depth bits with ids as payload
+    int res = 0;
+    if ((rc = c3d_sort_pairs_u32(g.key[0], g.key[1], g.order[0], g.order[1], true, (size_t)N, 32, g.tmp, &res, s))) return rc;
+    if (res != sort_result_index(32)) { c3d_set_error("internal: depth sort buffer parity"); return -2; }
+    if ((rc = gs_launch_gather_tiles(g, N, res, s))) return rc;
+    if ((rc = c3d_scan_u32(g.tiles_sorted, g.offsets, (size_t)N, false, g.tmp, s))) return rc;
+    uint32_t d32 = 0;
+    C3D_CHECK(hipMemcpyAsync(&d32, g.offsets + (N - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    C3D_CHECK(hipStreamSynchronize(s));
+    *num_rendered = (int64_t)d32;
+    return 0;
+}
+
+int c3d_gs_forward_render(const c3d_gs_settings* st, int32_t N, int32_t M, const int32_t* radii, void* geom_buffer,
+                          int64_t num_rendered, void* binning_buffer, void* image_buffer, float* out_color,
+                          float* out_depth, float* out_alpha, c3d_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    GsParams p;
+    if (make_params(st, N, M, p)) return -1;
+    const int tiles = p.gx * p.gy;
+    if (tiles == 0) return 0;
+    if (!binning_buffer || !image_buffer || !out_color || !out_depth || !out_alpha) { c3d_set_error("c3d_gs_forward_render: NULL buffer"); return -1; }
+    GsGeom g;
+    gs_carve_geom((char*)geom_buffer, N, g);
+    GsBinning b;
+    gs_carve_binning((char*)binning_buffer, num_rendered, tiles, b);
+    GsImage im;
+    gs_carve_image((char*)image_buffer, p.W, p.H, im);
+    int rc, res = 0;
+    if (num_rendered > 0) {
+        if (!geom_buffer || !radii) { c3d_set_error("c3d_gs_forward_render: NULL geometry"); return -1; }
+        if ((rc = gs_launch_emit(p, g, sort_result_index(32), radii, b, s))) return rc;
+        if ((rc = c3d_sort_pairs_u32(b.tkey[0], b.tkey[1], b.tval[0], b.tval[1], false, (size_t)num_rendered, tile_sort_bits(tiles), b.tmp, &res, s))) return rc;
+        if (res != sort_result_index(tile_sort_bits(tiles))) { c3d_set_error("internal: tile sort buffer parity"); return -2; }
+    }
+    if ((rc = gs_launch_ranges(b, res, num_rendered, tiles, s))) return rc;
+    return gs_launch_composite_fwd(p, g, b, res, im, out_color, out_depth, out_alpha, s);
+}
+
+int c3d_gs_backward(const c3d_gs_settings* st, int32_t N, int32_t M, const float* means3D, const float* shs,
+                    const float* colors_precomp, const float* scales, const float* rotations,
+                    const float* cov3D_precomp, const int32_t* radii, const void* geom_buffer, int64_t num_rendered,
+                    const void* binning_buffer, const void* image_buffer, const float* dL_dcolor,
+                    const float* dL_ddepth, const float* dL_dalpha, float* dL_dmeans2D, float* dL_dcolors,
+                    float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscales,
+                    float* dL_drotations, float* scratch, c3d_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    GsParams p;
+    if (make_params(st, N, M, p)) return -1;
+    if (check_inputs(N, M, p.deg, means3D, shs, colors_precomp, scales, rotations, cov3D_precomp)) return -1;
+    if (N == 0) return 0;
+    if (!dL_dcolor || !dL_dmeans2D || !dL_dcolors || !dL_dopacity || !dL_dmeans3D || !scratch || !radii || !geom_buffer) {
+        c3d_set_error("c3d_gs_backward: NULL buffer");
+        return -1;
+    }
+    if (!colors_precomp && !dL_dsh) { c3d_set_error("c3d_gs_backward: dL_dsh is NULL"); return -1; }
+    if (!cov3D_precomp && (!dL_dscales || !dL_drotations)) { c3d_set_error("c3d_gs_backward: dL_dscales/dL_drotations is NULL"); return -1; }
+    const int tiles = p.gx * p.gy;
+    GsGeom g;
+    gs_carve_geom((char*)geom_buffer, N, g);
+    GsBinning b;
+    gs_carve_binning((char*)binning_buffer, num_rendered, tiles, b);
+    GsImage im;
+    gs_carve_image((char*)image_buffer, p.W, p.H, im);
+    float* dL_dconic = scratch;              // [N,4]
+    float* dL_ddepths = scratch + 4 * (size_t)N;  // [N]
+    C3D_CHECK(hipMemsetAsync(scratch, 0, sizeof(float) * 5 * (size_t)N, s));
+    C3D_CHECK(hipMemsetAsync(dL_dmeans2D, 0, sizeof(float) * 3 * (size_t)N, s));
+    C3D_CHECK(hipMemsetAsync(dL_dcolors, 0, sizeof(float) * 3 * (size_t)N, s));
+    C3D_CHECK(hipMemsetAsync(dL_dopacity, 0, sizeof(float) * (size_t)N, s));
+    int rc;
+    if (num_rendered > 0 && tiles > 0) {
+        if (!binning_buffer || !image_buffer) { c3d_set_error("c3d_gs_backward: NULL state buffer"); return -1; }
+        const int res = sort_result_index(tile_sort_bits(tiles));
+        if ((rc = gs_launch_composite_bwd(p, g, b, res, im, dL_dcolor, dL_ddepth, dL_dalpha, dL_dmeans2D, dL_dconic, dL_dopacity,
+                                          dL_dcolors, dL_ddepths, s))) return rc;
+    }
+    return gs_launch_preprocess_bwd(p, g, radii, means3D, shs, colors_precomp, scales, rotations, cov3D_precomp, dL_dmeans2D, dL_dconic,
+                                    dL_dcolors, dL_ddepths, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, s);
+}
+
+int c3d_gs_mark_visible(int32_t N, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present, c3d_stream_t stream) {
+    if (N > 0 && (!means3D || !viewmatrix || !present)) { c3d_set_error("c3d_gs_mark_visible: NULL pointer"); return -1; }
+    return gs_launch_mark_visible(N, means3D, viewmatrix, projmatrix, present, (hipStream_t)stream);
+}
+
+// ---- test / introspection hooks ----
+__global__ void k_debug_unpack(int N, GsGeom g, float* xy, float* depths, float* conic_opacity, float* rgb, uint32_t* tiles) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const bool vis = g.tiles[i] > 0;
+    const float4 a0 = vis ? g.rec0[i] : make_float4(0, 0, 0, 0), a1 = vis ? g.rec1[i] : make_float4(0, 0, 0, 0);
+    const float2 a2 = vis ? g.rec2[i] : make_float2(0, 0);
+    if (xy) { xy[2 * i] = a0.x; xy[2 * i + 1] = a0.y; }
+    if (depths) depths[i] = a2.y;
+    if (conic_opacity) { conic_opacity[4 * i] = a0.z; conic_opacity[4 * i + 1] = a0.w; conic_opacity[4 * i + 2] = a1.x; conic_opacity[4 * i + 3] = a1.y; }
+    if (rgb) { rgb[3 * i] = a1.z; rgb[3 * i + 1] = a1.w; rgb[3 * i + 2] = a2.x; }
+    if (tiles) tiles[i] = g.tiles[i];
+}
+int c3d_gs_debug_state(int32_t N, int32_t H, int32_t W, const void* geom_buffer, int64_t D, const void* binning_buffer,
+                       uint32_t* point_list, uint32_t* ranges, float* xy, float* depths, float* conic_opacity, float* rgb,
+                       uint32_t* tiles_touched, c3d_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    const int tiles = ((W + C3D_TILE_X - 1) / C3D_TILE_X) * ((H + C3D_TILE_Y - 1) / C3D_TILE_Y);
+    if (N > 0 && geom_buffer) {
+        GsGeom g;
+        gs_carve_geom((char*)geom_buffer, N, g);
+        hipLaunchKernelGGL(k_debug_unpack, dim3(c3d_cdiv(N, 256)), dim3(256), 0, s, N, g, xy, depths, conic_opacity, rgb, tiles_touched);
+        C3D_LAUNCH_CHECK();
+    }
+    if (binning_buffer && tiles > 0) {
+        GsBinning b;
+        gs_carve_binning((char*)binning_buffer, D, tiles, b);
+        const int res = sort_result_index(tile_sort_bits(tiles));
+        if (point_list && D > 0) C3D_CHECK(hipMemcpyAsync(point_list, b.tval[res], sizeof(uint32_t) * (size_t)D, hipMemcpyDeviceToDevice, s));
+        if (ranges) C3D_CHECK(hipMemcpyAsync(ranges, b.ranges, sizeof(uint2) * (size_t)tiles, hipMemcpyDeviceToDevice, s));
+    }
+    return 0;
+}
+
+int c3d_test_scan_u32(const uint32_t* in, uint32_t* out, int64_t n, int32_t exclusive, c3d_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (n <= 0) return 0;
+    void* tmp = nullptr;
+    C3D_CHECK(hipMalloc(&tmp, c3d_scan_tmp_bytes((size_t)n)));
+    int rc = c3d_scan_u32(in, out, (size_t)n, exclusive != 0, tmp, s);
+    hipStreamSynchronize(s);
+    hipFree(tmp);
+    return rc;
+}
+int c3d_test_sort_pairs_u32(uint32_t* keys, uint32_t* vals, int64_t n, int32_t end_bit, c3d_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (n <= 0) return 0;
+    if (!keys || !vals) { c3d_set_error("c3d_test_sort_pairs_u32: NULL pointer"); return -1; }
+    uint32_t *k1 = nullptr, *v1 = nullptr;
+    void* tmp = nullptr;
+    C3D_CHECK(hipMalloc(&k1, 4 * (size_t)n));
+    C3D_CHECK(hipMalloc(&v1, 4 * (size_t)n));
+    C3D_CHECK(hipMalloc(&tmp, c3d_sort_tmp_bytes((size_t)n)));
+    int res = 0;
+    int rc = c3d_sort_pairs_u32(keys, k1, vals, v1, false, (size_t)n, end_bit, tmp, &res, s);
+    if (!rc && res == 1) {
+        hipMemcpyAsync(keys, k1, 4 * (size_t)n, hipMemcpyDeviceToDevice, s);
+        if (vals) hipMemcpyAsync(vals, v1, 4 * (size_t)n, hipMemcpyDeviceToDevice, s);
+    }
+    hipStreamSynchronize(s);
+    hipFree(k1); hipFree(v1); hipFree(tmp);
+    return rc;
+}
+
+}  // extern "C"

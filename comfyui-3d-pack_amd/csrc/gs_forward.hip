@@ -1,0 +1,250 @@
+// gs_forward.hip -- 3DGS forward: preprocess (A1), tile binning (A2-A5) and per-tile compositing (A6).
+// Stage names follow SURVEY.md section 2.3-A; the arithmetic contract is Appendix A of that file.
+// Boundary this implements: the rasterizer call at
+// MVs_Algorithms/GaussianSplatting/main_3DGS_renderer.py:927-936 (reference).
+#include "gs_internal.h"
+#include "gs_math.h"
+
+// ------------------------------------------------------------------------------------------
+// A1 preprocess: one lane per Gaussian.  Streams xyz/scale/rot/opacity/SH once, writes the 40-B
+// projected record, the depth-sort key and the tile count.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_preprocess(GsParams p, const float* __restrict__ means3D, const float* __restrict__ shs,
+                                                     const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
+                                                     const float* __restrict__ scales, const float* __restrict__ rotations,
+                                                     const float* __restrict__ cov3D_precomp, GsGeom g, int* __restrict__ radii) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= p.N) return;
+    // defaults for a culled Gaussian
+    radii[idx] = 0;
+    g.tiles[idx] = 0;
+    g.key[0][idx] = 0xFFFFFFFFu;
+
+    const Mat16 V = load_mat16(p.view), PJ = load_mat16(p.proj);
+    const float3 m = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
+    const float3 pv = xform4x3(m, V);
+    if (pv.z <= 0.2f) return;
+    const float4 ph = xform4x4(m, PJ);
+    const float pw = 1.0f / (ph.w + 0.0000001f);
+    const float ppx = ph.x * pw, ppy = ph.y * pw;
+
+    float c3[6];
+    if (cov3D_precomp) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) c3[i] = cov3D_precomp[6 * idx + i];
+    } else {
+        const float3 s = make_float3(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]);
+        const float4 q = *reinterpret_cast<const float4*>(rotations + 4 * idx);
+        cov3d_from_scale_rot(s, p.scale_modifier, q, c3);
+    }
+    float T2[2][3], ST0[3], ST1[3];
+    float3 t; bool xin, yin;
+    ewa_T2(m, V, p.tanfovx, p.tanfovy, p.focal_x, p.focal_y, T2, t, xin, yin);
+    sigma_T(c3, T2, ST0, ST1);
+    const float a = T2[0][0] * ST0[0] + T2[0][1] * ST0[1] + T2[0][2] * ST0[2] + 0.3f;
+    const float b = T2[0][0] * ST1[0] + T2[0][1] * ST1[1] + T2[0][2] * ST1[2];
+    const float c = T2[1][0] * ST1[0] + T2[1][1] * ST1[1] + T2[1][2] * ST1[2] + 0.3f;
+    const float det = a * c - b * b;
+    if (det == 0.0f) return;
+    const float di = 1.f / det;
+    const float mid = 0.5f * (a + c);
+    const float sq = sqrtf(fmaxf(0.1f, mid * mid - det));
+    const int rad = (int)ceilf(3.f * sqrtf(fmaxf(mid + sq, mid - sq)));
+    const float px = ndc2pix(ppx, p.W), py = ndc2pix(ppy, p.H);
+    int x0, y0, x1, y1;
+    tile_rect(px, py, rad, p.gx, p.gy, x0, y0, x1, y1);
+    if ((x1 - x0) * (y1 - y0) == 0) return;
+
+    float rgb[3];
+    uint8_t cl = 0;
+    if (colors_precomp) {
+        rgb[0] = colors_precomp[3 * idx]; rgb[1] = colors_precomp[3 * idx + 1]; rgb[2] = colors_precomp[3 * idx + 2];
+    } else {
+        float dx = m.x - p.campos[0], dy = m.y - p.campos[1], dz = m.z - p.campos[2];
+        const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+        dx /= len; dy /= len; dz /= len;
+        float B[16];
+        sh_basis(p.deg, dx, dy, dz, B);
+        const float* sh = shs + (size_t)idx * p.M * 3;
+        const int nc = sh_ncoef(p.deg);
+        rgb[0] = rgb[1] = rgb[2] = 0.f;
+        for (int k = 0; k < nc; k++) {
+            rgb[0] += B[k] * sh[3 * k]; rgb[1] += B[k] * sh[3 * k + 1]; rgb[2] += B[k] * sh[3 * k + 2];
+        }
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            rgb[ch] += 0.5f;
+            if (rgb[ch] < 0.f) cl |= (uint8_t)(1u << ch);
+            rgb[ch] = fmaxf(rgb[ch], 0.f);
+        }
+    }
+    g.rec0[idx] = make_float4(px, py, c * di, -b * di);
+    g.rec1[idx] = make_float4(a * di, opacities[idx], rgb[0], rgb[1]);
+    g.rec2[idx] = make_float2(rgb[2], pv.z);
+    g.clamped[idx] = cl;
+    radii[idx] = rad;
+    g.tiles[idx] = (uint32_t)((x1 - x0) * (y1 - y0));
+    g.key[0][idx] = __float_as_uint(pv.z);
+}
+
+int gs_launch_preprocess(const GsParams& p, const float* means3D, const float* shs, const float* colors_precomp,
+                         const float* opacities, const float* scales, const float* rotations, const float* cov3D_precomp,
+                         GsGeom& g, int* radii, hipStream_t s) {
+    if (p.N == 0) return 0;
+    hipLaunchKernelGGL(k_preprocess, dim3(c3d_cdiv(p.N, 256)), dim3(256), 0, s, p, means3D, shs, colors_precomp, opacities,
+                       scales, rotations, cov3D_precomp, g, radii);
+    C3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// tiles touched, gathered into depth-rank order (input of the offsets scan)
+__global__ void __launch_bounds__(256) k_gather_tiles(const uint32_t* __restrict__ order, const uint32_t* __restrict__ tiles,
+                                                       uint32_t* __restrict__ out, int N) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < N) out[r] = tiles[order[r]];
+}
+int gs_launch_gather_tiles(const GsGeom& g, int N, int res, hipStream_t s) {
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(k_gather_tiles, dim3(c3d_cdiv(N, 256)), dim3(256), 0, s, g.order[res], g.tiles, g.tiles_sorted, N);
+    C3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// A3 emit: Gaussians are visited in ascending (depth, id) rank, each writes one (tile, id) pair per
+// touched tile.  A stable sort by tile id afterwards leaves every tile's list depth-ordered.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_emit(GsParams p, const uint32_t* __restrict__ order, const uint32_t* __restrict__ offsets,
+                                               const float4* __restrict__ rec0, const int* __restrict__ radii,
+                                               uint32_t* __restrict__ tkey, uint32_t* __restrict__ tval) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= p.N) return;
+    const uint32_t gid = order[r];
+    const int rad = radii[gid];
+    if (rad <= 0) return;
+    uint32_t off = (r == 0) ? 0u : offsets[r - 1];
+    const float4 r0 = rec0[gid];
+    int x0, y0, x1, y1;
+    tile_rect(r0.x, r0.y, rad, p.gx, p.gy, x0, y0, x1, y1);
+    for (int y = y0; y < y1; y++)
+        for (int x = x0; x < x1; x++) {
+            tkey[off] = (uint32_t)(y * p.gx + x);
+            tval[off] = gid;
+            off++;
+        }
+}
+int gs_launch_emit(const GsParams& p, const GsGeom& g, int res, const int* radii, GsBinning& b, hipStream_t s) {
+    if (p.N == 0) return 0;
+    hipLaunchKernelGGL(k_emit, dim3(c3d_cdiv(p.N, 256)), dim3(256), 0, s, p, g.order[res], g.offsets, g.rec0, radii, b.tkey[0], b.tval[0]);
+    C3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// A5: [start,end) of every tile in the sorted pair list
+__global__ void __launch_bounds__(256) k_ranges(const uint32_t* __restrict__ tkey, uint2* __restrict__ ranges, long long D) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D) return;
+    const uint32_t t = tkey[i];
+    if (i == 0 || tkey[i - 1] != t) ranges[t].x = (uint32_t)i;
+    if (i == D - 1 || tkey[i + 1] != t) ranges[t].y = (uint32_t)(i + 1);
+}
+int gs_launch_ranges(const GsBinning& b, int res, long long D, int tiles, hipStream_t s) {
+    C3D_CHECK(hipMemsetAsync(b.ranges, 0, sizeof(uint2) * (size_t)(tiles > 0 ? tiles : 1), s));
+    if (D == 0) return 0;
+    hipLaunchKernelGGL(k_ranges, dim3(c3d_cdiv(D, 256)), dim3(256), 0, s, b.tkey[res], b.ranges, D);
+    C3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// A6 composite forward: one 256-lane workgroup (4 waves) per 16x16 tile, wave w owns pixel rows
+// 4w..4w+3.  Splat records are staged through LDS in rounds of 256; the per-splat data is
+// wave-uniform in the inner loop (LDS broadcast reads).
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_composite_fwd(GsParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+                                                        const float4* __restrict__ rec0, const float4* __restrict__ rec1,
+                                                        const float2* __restrict__ rec2, float* __restrict__ out_color,
+                                                        float* __restrict__ out_depth, float* __restrict__ out_alpha,
+                                                        float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, int chunk) {
+    __shared__ float4 s0[256];
+    __shared__ float4 s1[256];
+    __shared__ float2 s2[256];
+    // XCD-aware tile order: workgroup b runs on XCD b%8; give each XCD a contiguous run of tiles so
+    // neighbouring tiles (which share splats) hit the same L2.  Speed only, never correctness.
+    const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if (tile >= p.gx * p.gy) return;
+    const int tx = tile % p.gx, ty = tile / p.gx;
+    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+    const int pxi = tx * C3D_TILE_X + lx, pyi = ty * C3D_TILE_Y + ly;
+    const bool inside = pxi < p.W && pyi < p.H;
+    const float pxf = (float)pxi, pyf = (float)pyi;
+    const uint2 rg = ranges[tile];
+    int todo = (int)(rg.y - rg.x);
+    bool done = !inside;
+    float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f, A = 0.f;
+    uint32_t contributor = 0, last = 0;
+
+    for (int base = 0; base < todo; base += 256) {
+        if (__syncthreads_count(done) == 256) break;
+        const int n = min(256, todo - base);
+        if ((int)threadIdx.x < n) {
+            const uint32_t gid = point_list[rg.x + base + threadIdx.x];
+            s0[threadIdx.x] = rec0[gid]; s1[threadIdx.x] = rec1[gid]; s2[threadIdx.x] = rec2[gid];
+        }
+        __syncthreads();
+        for (int j = 0; !done && j < n; j++) {
+            contributor++;
+            const float4 a0 = s0[j], a1 = s1[j];
+            const float dx = a0.x - pxf, dy = a0.y - pyf;
+            const float power = -0.5f * (a0.z * dx * dx + a1.x * dy * dy) - a0.w * dx * dy;
+            if (power > 0.f) continue;
+            const float alpha = fminf(0.99f, a1.y * __expf(power));
+            if (alpha < 1.f / 255.f) continue;
+            const float testT = T * (1.f - alpha);
+            if (testT < 0.0001f) { done = true; continue; }
+            const float2 a2 = s2[j];
+            const float w = alpha * T;
+            C0 += a1.z * w; C1 += a1.w * w; C2 += a2.x * w;
+            Dp += a2.y * w; A += w;
+            T = testT;
+            last = contributor;
+        }
+    }
+    if (inside) {
+        const size_t P = (size_t)p.W * p.H, pid = (size_t)pyi * p.W + pxi;
+        final_T[pid] = T;
+        n_contrib[pid] = last;
+        out_color[pid] = C0 + T * p.bg[0];
+        out_color[P + pid] = C1 + T * p.bg[1];
+        out_color[2 * P + pid] = C2 + T * p.bg[2];
+        out_depth[pid] = Dp;
+        out_alpha[pid] = A;
+    }
+}
+
+int gs_launch_composite_fwd(const GsParams& p, const GsGeom& g, const GsBinning& b, int res, GsImage& im,
+                            float* out_color, float* out_depth, float* out_alpha, hipStream_t s) {
+    const int tiles = p.gx * p.gy;
+    if (tiles == 0) return 0;
+    const int chunk = c3d_cdiv(tiles, 8);
+    hipLaunchKernelGGL(k_composite_fwd, dim3(chunk * 8), dim3(256), 0, s, p, b.ranges, b.tval[res], g.rec0, g.rec1, g.rec2,
+                       out_color, out_depth, out_alpha, im.final_T, im.n_contrib, chunk);
+    C3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// A9 mark_visible (exported by the dependency; not called by the reference's MVs path)
+__global__ void __launch_bounds__(256) k_mark_visible(int N, const float* __restrict__ means3D, const float* __restrict__ view, uint8_t* __restrict__ present) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N) return;
+    const Mat16 V = load_mat16(view);
+    const float3 pv = xform4x3(make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]), V);
+    present[idx] = pv.z > 0.2f;
+}
+int gs_launch_mark_visible(int N, const float* means3D, const float* view, const float* proj, uint8_t* present, hipStream_t s) {
+    (void)proj;
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(k_mark_visible, dim3(c3d_cdiv(N, 256)), dim3(256), 0, s, N, means3D, view, present);
+    C3D_LAUNCH_CHECK();
+    return 0;
+}

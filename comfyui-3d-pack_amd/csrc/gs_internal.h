@@ -1,0 +1,103 @@
+// gs_internal.h -- internal types of the 3DGS rasterizer (not part of the C-ABI; see include/c3d_gs.h)
+#pragma once
+#include "c3d_common.h"
+
+struct GsParams {
+    int N, M, deg, W, H, gx, gy;
+    float tanfovx, tanfovy, focal_x, focal_y, scale_modifier;
+    const float* bg;     // [3]   device
+    const float* view;   // [16]  device, row-major storage of w2c^T (camera_utils.py:205)
+    const float* proj;   // [16]  device, full projection, same storage (camera_utils.py:213)
+    const float* campos; // [3]   device
+};
+
+// Per-Gaussian projected record ("geometry state"), SoA of three streams = 40 B / Gaussian:
+//   rec0 = (pix.x, pix.y, conic.xx, conic.xy)   rec1 = (conic.yy, opacity, r, g)   rec2 = (b, view depth)
+struct GsGeom {
+    float4* rec0;
+    float4* rec1;
+    float2* rec2;
+    uint32_t* tiles;        // tiles touched per Gaussian (0 = culled)
+    uint32_t* key[2];       // depth-sort keys (float bits of view depth; 0xFFFFFFFF = culled)
+    uint32_t* order[2];     // Gaussian ids, ping-pong; after stage 1 order[res] is rank -> id
+    uint32_t* tiles_sorted; // tiles touched in rank order
+    uint32_t* offsets;      // inclusive scan of tiles_sorted (rank order)
+    uint8_t* clamped;       // 3 bits per Gaussian: SH colour channel clamped at 0
+    int* meta;              // [0] = result buffer index of the depth sort, [1] = num_rendered (device copy)
+    void* tmp;              // scan / sort scratch
+    size_t bytes;
+};
+static inline void gs_carve_geom(char* base, int N, GsGeom& g) {
+    size_t n = (size_t)(N > 0 ? N : 1), off = 0;
+    auto take = [&](size_t b) { char* p = base ? base + off : nullptr; off += c3d_align(b); return p; };
+    g.rec0 = (float4*)take(16 * n);
+    g.rec1 = (float4*)take(16 * n);
+    g.rec2 = (float2*)take(8 * n);
+    g.tiles = (uint32_t*)take(4 * n);
+    g.key[0] = (uint32_t*)take(4 * n);
+    g.key[1] = (uint32_t*)take(4 * n);
+    g.order[0] = (uint32_t*)take(4 * n);
+    g.order[1] = (uint32_t*)take(4 * n);
+    g.tiles_sorted = (uint32_t*)take(4 * n);
+    g.offsets = (uint32_t*)take(4 * n);
+    g.clamped = (uint8_t*)take(n);
+    g.meta = (int*)take(64);
+    size_t t1 = c3d_sort_tmp_bytes(n), t2 = c3d_scan_tmp_bytes(n);
+    g.tmp = take(t1 > t2 ? t1 : t2);
+    g.bytes = off;
+}
+
+// Binning state (per tile-splat pair): ping-pong (tile id, Gaussian id) + per-tile ranges.
+struct GsBinning {
+    uint32_t* tkey[2];
+    uint32_t* tval[2];
+    uint2* ranges;   // [tiles]
+    int* meta;       // [0] = result buffer index of the tile sort
+    void* tmp;
+    size_t bytes;
+};
+static inline void gs_carve_binning(char* base, long long D, int tiles, GsBinning& b) {
+    size_t d = (size_t)(D > 0 ? D : 1), off = 0;
+    auto take = [&](size_t n) { char* p = base ? base + off : nullptr; off += c3d_align(n); return p; };
+    b.tkey[0] = (uint32_t*)take(4 * d);
+    b.tkey[1] = (uint32_t*)take(4 * d);
+    b.tval[0] = (uint32_t*)take(4 * d);
+    b.tval[1] = (uint32_t*)take(4 * d);
+    b.ranges = (uint2*)take(8 * (size_t)(tiles > 0 ? tiles : 1));
+    b.meta = (int*)take(64);
+    b.tmp = take(c3d_sort_tmp_bytes(d));
+    b.bytes = off;
+}
+
+struct GsImage {
+    float* final_T;        // [H*W]
+    uint32_t* n_contrib;   // [H*W]
+    size_t bytes;
+};
+static inline void gs_carve_image(char* base, int W, int H, GsImage& im) {
+    size_t p = (size_t)W * H, off = 0;
+    if (p == 0) p = 1;
+    auto take = [&](size_t n) { char* q = base ? base + off : nullptr; off += c3d_align(n); return q; };
+    im.final_T = (float*)take(4 * p);
+    im.n_contrib = (uint32_t*)take(4 * p);
+    im.bytes = off;
+}
+
+// kernels' launchers (gs_forward.hip / gs_backward.hip)
+int gs_launch_preprocess(const GsParams& p, const float* means3D, const float* shs, const float* colors_precomp,
+                         const float* opacities, const float* scales, const float* rotations, const float* cov3D_precomp,
+                         GsGeom& g, int* radii, hipStream_t s);
+int gs_launch_gather_tiles(const GsGeom& g, int N, int res, hipStream_t s);
+int gs_launch_emit(const GsParams& p, const GsGeom& g, int res, const int* radii, GsBinning& b, hipStream_t s);
+int gs_launch_ranges(const GsBinning& b, int res, long long D, int tiles, hipStream_t s);
+int gs_launch_composite_fwd(const GsParams& p, const GsGeom& g, const GsBinning& b, int res, GsImage& im,
+                            float* out_color, float* out_depth, float* out_alpha, hipStream_t s);
+int gs_launch_composite_bwd(const GsParams& p, const GsGeom& g, const GsBinning& b, int res, const GsImage& im,
+                            const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
+                            float* dL_dmean2D /*N*3*/, float* dL_dconic /*N*4*/, float* dL_dopacity, float* dL_dcolors /*N*3*/,
+                            float* dL_ddepths, hipStream_t s);
+int gs_launch_preprocess_bwd(const GsParams& p, const GsGeom& g, const int* radii, const float* means3D, const float* shs,
+                             const float* colors_precomp, const float* scales, const float* rotations, const float* cov3D_precomp,
+                             const float* dL_dmean2D, const float* dL_dconic, const float* dL_dcolors, const float* dL_ddepths,
+                             float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscales, float* dL_drots, hipStream_t s);
+int gs_launch_mark_visible(int N, const float* means3D, const float* view, const float* proj, uint8_t* present, hipStream_t s);

@@ -1,0 +1,125 @@
+// gs_math.h -- per-Gaussian projection math shared by the forward and backward preprocess kernels.
+// Semantics: SURVEY.md Appendix A steps 1-7 (EWA splatting contract of the rasterizer that
+// MVs_Algorithms/GaussianSplatting/main_3DGS_renderer.py:927-936 calls); SH basis and signs as in
+// shared_utils/sh_utils.py:26-43,57-100; quaternion (w,x,y,z) as in main_3DGS_renderer.py:84-102.
+#pragma once
+#include "c3d_common.h"
+
+#define GS_SH_C0 0.28209479177387814f
+#define GS_SH_C1 0.4886025119029199f
+#define GS_SH_C2_0 1.0925484305920792f
+#define GS_SH_C2_1 -1.0925484305920792f
+#define GS_SH_C2_2 0.31539156525252005f
+#define GS_SH_C2_3 -1.0925484305920792f
+#define GS_SH_C2_4 0.5462742152960396f
+#define GS_SH_C3_0 -0.5900435899266435f
+#define GS_SH_C3_1 2.890611442640554f
+#define GS_SH_C3_2 -0.4570457994644658f
+#define GS_SH_C3_3 0.3731763325901154f
+#define GS_SH_C3_4 -0.4570457994644658f
+#define GS_SH_C3_5 1.445305721320277f
+#define GS_SH_C3_6 -0.5900435899266435f
+
+struct Mat16 { float m[16]; };
+
+__device__ __forceinline__ Mat16 load_mat16(const float* __restrict__ p) {
+    Mat16 r;
+#pragma unroll
+    for (int i = 0; i < 16; i++) r.m[i] = p[i];   // wave-uniform address -> scalar loads
+    return r;
+}
+// row vector (p,1) times the matrix as stored: out_i = sum_j p_j m[4j+i] + m[12+i]
+__device__ __forceinline__ float3 xform4x3(const float3 p, const Mat16& v) {
+    return make_float3(v.m[0] * p.x + v.m[4] * p.y + v.m[8] * p.z + v.m[12],
+                       v.m[1] * p.x + v.m[5] * p.y + v.m[9] * p.z + v.m[13],
+                       v.m[2] * p.x + v.m[6] * p.y + v.m[10] * p.z + v.m[14]);
+}
+__device__ __forceinline__ float4 xform4x4(const float3 p, const Mat16& v) {
+    return make_float4(v.m[0] * p.x + v.m[4] * p.y + v.m[8] * p.z + v.m[12],
+                       v.m[1] * p.x + v.m[5] * p.y + v.m[9] * p.z + v.m[13],
+                       v.m[2] * p.x + v.m[6] * p.y + v.m[10] * p.z + v.m[14],
+                       v.m[3] * p.x + v.m[7] * p.y + v.m[11] * p.z + v.m[15]);
+}
+
+__device__ __forceinline__ void quat_to_R(const float4 q, float R[3][3]) {
+    const float r = q.x, x = q.y, y = q.z, z = q.w;
+    R[0][0] = 1.f - 2.f * (y * y + z * z); R[0][1] = 2.f * (x * y - r * z); R[0][2] = 2.f * (x * z + r * y);
+    R[1][0] = 2.f * (x * y + r * z); R[1][1] = 1.f - 2.f * (x * x + z * z); R[1][2] = 2.f * (y * z - r * x);
+    R[2][0] = 2.f * (x * z - r * y); R[2][1] = 2.f * (y * z + r * x); R[2][2] = 1.f - 2.f * (x * x + y * y);
+}
+// Sigma3 = R diag(mod*s)^2 R^T, six unique entries (xx,xy,xz,yy,yz,zz)
+__device__ __forceinline__ void cov3d_from_scale_rot(const float3 s, float mod, const float4 q, float c[6]) {
+    float R[3][3];
+    quat_to_R(q, R);
+    const float sv[3] = {mod * s.x, mod * s.y, mod * s.z};
+    float Mm[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) Mm[i][k] = R[i][k] * sv[k];
+    c[0] = Mm[0][0] * Mm[0][0] + Mm[0][1] * Mm[0][1] + Mm[0][2] * Mm[0][2];
+    c[1] = Mm[0][0] * Mm[1][0] + Mm[0][1] * Mm[1][1] + Mm[0][2] * Mm[1][2];
+    c[2] = Mm[0][0] * Mm[2][0] + Mm[0][1] * Mm[2][1] + Mm[0][2] * Mm[2][2];
+    c[3] = Mm[1][0] * Mm[1][0] + Mm[1][1] * Mm[1][1] + Mm[1][2] * Mm[1][2];
+    c[4] = Mm[1][0] * Mm[2][0] + Mm[1][1] * Mm[2][1] + Mm[1][2] * Mm[2][2];
+    c[5] = Mm[2][0] * Mm[2][0] + Mm[2][1] * Mm[2][1] + Mm[2][2] * Mm[2][2];
+}
+
+// T2 = J(2x3) W(3x3) with the +-1.3 tan(fov) clamp; t = clamped view-space position.
+__device__ __forceinline__ void ewa_T2(const float3 mean, const Mat16& v, float tanfovx, float tanfovy, float fx, float fy,
+                                       float T2[2][3], float3& t, bool& xin, bool& yin) {
+    t = xform4x3(mean, v);
+    const float limx = 1.3f * tanfovx, limy = 1.3f * tanfovy;
+    const float txtz = t.x / t.z, tytz = t.y / t.z;
+    xin = !(txtz < -limx || txtz > limx);
+    yin = !(tytz < -limy || tytz > limy);
+    t.x = fminf(limx, fmaxf(-limx, txtz)) * t.z;
+    t.y = fminf(limy, fmaxf(-limy, tytz)) * t.z;
+    const float J00 = fx / t.z, J02 = -(fx * t.x) / (t.z * t.z);
+    const float J11 = fy / t.z, J12 = -(fy * t.y) / (t.z * t.z);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        T2[0][k] = J00 * v.m[4 * k + 0] + J02 * v.m[4 * k + 2];
+        T2[1][k] = J11 * v.m[4 * k + 1] + J12 * v.m[4 * k + 2];
+    }
+}
+// ST_r[i] = sum_j Sigma[i][j] T2[r][j]
+__device__ __forceinline__ void sigma_T(const float c[6], const float T2[2][3], float ST0[3], float ST1[3]) {
+    const float S[3][3] = {{c[0], c[1], c[2]}, {c[1], c[3], c[4]}, {c[2], c[4], c[5]}};
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        ST0[i] = S[i][0] * T2[0][0] + S[i][1] * T2[0][1] + S[i][2] * T2[0][2];
+        ST1[i] = S[i][0] * T2[1][0] + S[i][1] * T2[1][1] + S[i][2] * T2[1][2];
+    }
+}
+
+__device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, float B[16]) {
+    B[0] = GS_SH_C0;
+    if (deg > 0) {
+        B[1] = -GS_SH_C1 * y; B[2] = GS_SH_C1 * z; B[3] = -GS_SH_C1 * x;
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            B[4] = GS_SH_C2_0 * xy; B[5] = GS_SH_C2_1 * yz; B[6] = GS_SH_C2_2 * (2.f * zz - xx - yy);
+            B[7] = GS_SH_C2_3 * xz; B[8] = GS_SH_C2_4 * (xx - yy);
+            if (deg > 2) {
+                B[9] = GS_SH_C3_0 * y * (3.f * xx - yy);
+                B[10] = GS_SH_C3_1 * xy * z;
+                B[11] = GS_SH_C3_2 * y * (4.f * zz - xx - yy);
+                B[12] = GS_SH_C3_3 * z * (2.f * zz - 3.f * xx - 3.f * yy);
+                B[13] = GS_SH_C3_4 * x * (4.f * zz - xx - yy);
+                B[14] = GS_SH_C3_5 * z * (xx - yy);
+                B[15] = GS_SH_C3_6 * x * (xx - 3.f * yy);
+            }
+        }
+    }
+}
+__device__ __forceinline__ int sh_ncoef(int deg) { return (deg + 1) * (deg + 1); }
+
+__device__ __forceinline__ float ndc2pix(float v, int S) { return ((v + 1.f) * S - 1.f) * 0.5f; }
+
+__device__ __forceinline__ void tile_rect(float px, float py, int rad, int gx, int gy, int& x0, int& y0, int& x1, int& y1) {
+    x0 = min(gx, max(0, (int)((px - rad) / C3D_TILE_X)));
+    y0 = min(gy, max(0, (int)((py - rad) / C3D_TILE_Y)));
+    x1 = min(gx, max(0, (int)((px + rad + C3D_TILE_X - 1) / C3D_TILE_X)));
+    y1 = min(gy, max(0, (int)((py + rad + C3D_TILE_Y - 1) / C3D_TILE_Y)));
+}

@@ -1,0 +1,202 @@
+// scan_sort.hip -- device-wide prefix sum and stable LSD radix sort for gfx950.
+//
+// These replace the cub::DeviceScan / cub::DeviceRadixSort calls of the dependency's binning
+// stage.  Written for wave64: digit ranking uses 64-bit ballots
+// (one match mask per lane from 8 ballots) and mbcnt prefix counts instead of 32-lane warp votes.
+#include "c3d_common.h"
+
+#define SCAN_THREADS 256
+#define SCAN_ITEMS 8
+#define SCAN_TILE (SCAN_THREADS * SCAN_ITEMS)
+
+// exclusive prefix of `v` across the 256-thread block; *total = block sum.  lds: >= 4 uints.
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* lds, uint32_t* total) {
+    const int lane = c3d_lane(), wave = threadIdx.x >> 6;
+    uint32_t incl = c3d_wave_incl_scan(v);
+    __syncthreads();  // protect lds reuse across calls
+    if (lane == 63) lds[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < SCAN_THREADS / 64; w++) {
+        uint32_t t = lds[w];
+        if (w < wave) base += t;
+        tot += t;
+    }
+    *total = tot;
+    return base + incl - v;
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_block_sums(const uint32_t* __restrict__ in, uint32_t* __restrict__ sums, size_t n) {
+    __shared__ uint32_t lds[4];
+    size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++)
+        if (base + i < n) s += in[base + i];
+    uint32_t tot;
+    block_excl_scan(s, lds, &tot);
+    if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+
+// single block: exclusive scan of m values in place
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_small_excl(uint32_t* __restrict__ a, size_t m) {
+    __shared__ uint32_t lds[4];
+    uint32_t carry = 0;
+    for (size_t c = 0; c < m; c += SCAN_THREADS * 4) {
+        size_t base = c + (size_t)threadIdx.x * 4;
+        uint32_t v[4];
+        uint32_t s = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { v[i] = (base + i < m) ? a[base + i] : 0u; s += v[i]; }
+        uint32_t tot;
+        uint32_t ex = block_excl_scan(s, lds, &tot) + carry;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { if (base + i < m) a[base + i] = ex; ex += v[i]; }
+        carry += tot;
+    }
+}
+
+template <bool EXCL>
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_apply(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                              const uint32_t* __restrict__ sums, size_t n) {
+    __shared__ uint32_t lds[4];
+    size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS];
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) { v[i] = (base + i < n) ? in[base + i] : 0u; s += v[i]; }
+    uint32_t tot;
+    uint32_t run = block_excl_scan(s, lds, &tot) + sums[blockIdx.x];
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        if (EXCL) { if (base + i < n) out[base + i] = run; run += v[i]; }
+        else      { run += v[i]; if (base + i < n) out[base + i] = run; }
+    }
+}
+
+size_t c3d_scan_tmp_bytes(size_t n) { return c3d_align(sizeof(uint32_t) * (size_t)(c3d_cdiv((long long)n, SCAN_TILE) + 1)); }
+
+int c3d_scan_u32(const uint32_t* in, uint32_t* out, size_t n, bool exclusive, void* tmp, hipStream_t s) {
+    if (n == 0) return 0;
+    int nb = c3d_cdiv((long long)n, SCAN_TILE);
+    uint32_t* sums = (uint32_t*)tmp;
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(SCAN_THREADS), 0, s, in, sums, n);
+    hipLaunchKernelGGL(k_scan_small_excl, dim3(1), dim3(SCAN_THREADS), 0, s, sums, (size_t)nb);
+    if (exclusive) hipLaunchKernelGGL(k_scan_apply<true>, dim3(nb), dim3(SCAN_THREADS), 0, s, in, out, sums, n);
+    else           hipLaunchKernelGGL(k_scan_apply<false>, dim3(nb), dim3(SCAN_THREADS), 0, s, in, out, sums, n);
+    C3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Radix sort pass: 8-bit digits, 4096 keys per 256-thread block, each wave owns a contiguous
+// 1024-key chunk so that ranking is stable by construction.
+// ------------------------------------------------------------------------------------------
+#define RS_THREADS 256
+#define RS_ITEMS 16
+#define RS_TILE (RS_THREADS * RS_ITEMS)
+#define RS_RADIX 256
+
+__global__ void __launch_bounds__(RS_THREADS) k_radix_hist(const uint32_t* __restrict__ keys, uint32_t* __restrict__ table,
+                                                            size_t n, int shift, int nblocks) {
+    __shared__ uint32_t h[RS_RADIX];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    size_t base = (size_t)blockIdx.x * RS_TILE;
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS; i++) {
+        size_t idx = base + (size_t)i * RS_THREADS + threadIdx.x;
+        if (idx < n) atomicAdd(&h[(keys[idx] >> shift) & (RS_RADIX - 1)], 1u);
+    }
+    __syncthreads();
+    table[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];  // digit-major
+}
+
+template <bool IOTA>
+__global__ void __launch_bounds__(RS_THREADS) k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                                               uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                               const uint32_t* __restrict__ table, size_t n, int shift, int nblocks) {
+    __shared__ uint32_t whist[RS_THREADS / 64][RS_RADIX];
+    const int lane = c3d_lane(), wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < (RS_THREADS / 64) * RS_RADIX; i += RS_THREADS) (&whist[0][0])[i] = 0;
+    __syncthreads();
+
+    const size_t wbase = (size_t)blockIdx.x * RS_TILE + (size_t)wave * (RS_TILE / 4);
+    uint32_t key[RS_ITEMS], val[RS_ITEMS], rank[RS_ITEMS];
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS; i++) {
+        size_t idx = wbase + (size_t)i * 64 + lane;
+        bool ok = idx < n;
+        key[i] = ok ? keys_in[idx] : 0xFFFFFFFFu;
+        val[i] = IOTA ? (uint32_t)idx : (ok ? vals_in[idx] : 0u);
+    }
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS; i++) {
+        size_t idx = wbase + (size_t)i * 64 + lane;
+        bool ok = idx < n;
+        uint32_t d = (key[i] >> shift) & (RS_RADIX - 1);
+        uint64_t peers = __ballot(ok);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            uint64_t m = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? m : ~m;
+        }
+        uint32_t prefix = whist[wave][d];
+        uint32_t r = (uint32_t)__popcll(peers & lt_mask);
+        if (ok && r == 0) whist[wave][d] = prefix + (uint32_t)__popcll(peers);  // lowest peer lane updates
+        rank[i] = prefix + r;
+    }
+    __syncthreads();
+    {   // per-digit bases: global base of (digit, block) + counts of earlier waves
+        int d = threadIdx.x;
+        uint32_t run = table[(size_t)d * nblocks + blockIdx.x];
+#pragma unroll
+        for (int w = 0; w < RS_THREADS / 64; w++) { uint32_t c = whist[w][d]; whist[w][d] = run; run += c; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS; i++) {
+        size_t idx = wbase + (size_t)i * 64 + lane;
+        if (idx < n) {
+            uint32_t d = (key[i] >> shift) & (RS_RADIX - 1);
+            uint32_t pos = whist[wave][d] + rank[i];
+            keys_out[pos] = key[i];
+            vals_out[pos] = val[i];
+        }
+    }
+}
+
+size_t c3d_sort_tmp_bytes(size_t n) {
+    size_t nb = (size_t)c3d_cdiv((long long)(n ? n : 1), RS_TILE);
+    size_t tbl = c3d_align(sizeof(uint32_t) * RS_RADIX * nb);
+    return tbl + c3d_scan_tmp_bytes(RS_RADIX * nb);
+}
+
+int c3d_sort_pairs_u32(uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32_t* vals1, bool iota_vals,
+                       size_t n, int end_bit, void* tmp, int* result_buf, hipStream_t s) {
+    *result_buf = 0;
+    if (n == 0) return 0;
+    int nb = c3d_cdiv((long long)n, RS_TILE);
+    uint32_t* table = (uint32_t*)tmp;
+    void* scan_tmp = (char*)tmp + c3d_align(sizeof(uint32_t) * RS_RADIX * (size_t)nb);
+    uint32_t* k[2] = {keys0, keys1};
+    uint32_t* v[2] = {vals0, vals1};
+    int cur = 0;
+    bool first = true;
+    for (int shift = 0; shift < end_bit || first; shift += 8) {
+        hipLaunchKernelGGL(k_radix_hist, dim3(nb), dim3(RS_THREADS), 0, s, k[cur], table, n, shift, nb);
+        int rc = c3d_scan_u32(table, table, (size_t)RS_RADIX * nb, true, scan_tmp, s);
+        if (rc) return rc;
+        if (first && iota_vals)
+            hipLaunchKernelGGL(k_radix_scatter<true>, dim3(nb), dim3(RS_THREADS), 0, s, k[cur], v[cur], k[cur ^ 1], v[cur ^ 1], table, n, shift, nb);
+        else
+            hipLaunchKernelGGL(k_radix_scatter<false>, dim3(nb), dim3(RS_THREADS), 0, s, k[cur], v[cur], k[cur ^ 1], v[cur ^ 1], table, n, shift, nb);
+        C3D_LAUNCH_CHECK();
+        cur ^= 1;
+        first = false;
+    }
+    *result_buf = cur;
+    return 0;
+}

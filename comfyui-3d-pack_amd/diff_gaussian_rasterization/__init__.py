@@ -1,0 +1,156 @@
+"""`diff_gaussian_rasterization` -- drop-in Python boundary over the MI355X HIP rasterizer.
+
+Same names, argument meaning and error behaviour as the package the reference imports at
+MVs_Algorithms/GaussianSplatting/main_3DGS_renderer.py:840-843 and calls at :849-864 / :927-936
+(ashawkey fork: returns colour, radii, depth, alpha).  The arithmetic runs in libc3d_hip.so
+(include/c3d_gs.h); this file only allocates tensors and wires autograd.
+"""
+from typing import NamedTuple
+
+import ctypes as C
+import torch
+import torch.nn as nn
+
+import c3d_hip as _h
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+def _settings_struct(rs, keep):
+    dev = rs.viewmatrix.device
+    bg = _h.f32c(rs.bg.to(dev)); vm = _h.f32c(rs.viewmatrix); pm = _h.f32c(rs.projmatrix.to(dev)); cp = _h.f32c(rs.campos.to(dev))
+    keep.extend([bg, vm, pm, cp])
+    return _h.GsSettings(int(rs.image_height), int(rs.image_width), float(rs.tanfovx), float(rs.tanfovy),
+                         float(rs.scale_modifier), int(rs.sh_degree), int(bool(rs.prefiltered)), int(bool(rs.debug)),
+                         _h.ptr(bg), _h.ptr(vm), _h.ptr(pm), _h.ptr(cp))
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, raster_settings)
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+        lib = _h.lib()
+        rs = raster_settings
+        dev = means3D.device
+        if not means3D.is_cuda:
+            raise RuntimeError("diff_gaussian_rasterization (MI355X): tensors must live on a HIP device; there is no CPU path")
+        H, W = int(rs.image_height), int(rs.image_width)
+        means3D_c = _h.f32c(means3D)
+        N = 0 if means3D_c is None else means3D_c.shape[0]
+        sh_c, col_c = _h.f32c(sh), _h.f32c(colors_precomp)
+        op_c, sc_c, rot_c, cov_c = _h.f32c(opacities), _h.f32c(scales), _h.f32c(rotations), _h.f32c(cov3Ds_precomp)
+        M = 0 if sh_c is None else sh_c.shape[1]
+        keep = []
+        with torch.cuda.device(dev):
+            st = _settings_struct(rs, keep)
+            s = _h.stream(dev)
+            u8 = dict(dtype=torch.uint8, device=dev)
+            radii = torch.empty((N,), dtype=torch.int32, device=dev)
+            geom = torch.empty((lib.c3d_gs_geom_bytes(N),), **u8)
+            nr = C.c_int64(0)
+            _h.check(lib.c3d_gs_forward_project(C.byref(st), N, M, _h.ptr(means3D_c), _h.ptr(sh_c), _h.ptr(col_c), _h.ptr(op_c),
+                                                _h.ptr(sc_c), _h.ptr(rot_c), _h.ptr(cov_c), _h.ptr(radii), _h.ptr(geom),
+                                                C.byref(nr), s), "c3d_gs_forward_project")
+            num_rendered = int(nr.value)
+            binning = torch.empty((lib.c3d_gs_binning_bytes(num_rendered, H, W),), **u8)
+            img = torch.empty((lib.c3d_gs_image_bytes(H, W),), **u8)
+            color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+            depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+            alpha = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+            _h.check(lib.c3d_gs_forward_render(C.byref(st), N, M, _h.ptr(radii), _h.ptr(geom), num_rendered, _h.ptr(binning),
+                                               _h.ptr(img), _h.ptr(color), _h.ptr(depth), _h.ptr(alpha), s), "c3d_gs_forward_render")
+        ctx.raster_settings = rs
+        ctx.num_rendered = num_rendered
+        ctx.sizes = (N, M)
+        ctx.present = (sh_c is not None, col_c is not None, sc_c is not None, cov_c is not None)
+        e = torch.empty(0, device=dev)
+        ctx.save_for_backward(*(t if t is not None else e for t in (col_c, means3D_c, sc_c, rot_c, cov_c, radii, sh_c, geom, binning, img)))
+        ctx.mark_non_differentiable(radii)
+        return color, radii, depth, alpha
+
+    @staticmethod
+    def backward(ctx, grad_color, grad_radii, grad_depth, grad_alpha):
+        lib = _h.lib()
+        rs = ctx.raster_settings
+        N, M = ctx.sizes
+        col_c, means3D_c, sc_c, rot_c, cov_c, radii, sh_c, geom, binning, img = ctx.saved_tensors
+        has_sh, has_col, has_sc, has_cov = ctx.present
+        dev = geom.device
+        keep = []
+        nn_ = lambda t, ok: t if ok else None
+        with torch.cuda.device(dev):
+            st = _settings_struct(rs, keep)
+            s = _h.stream(dev)
+            f = dict(dtype=torch.float32, device=dev)
+            g_means2D = torch.empty((N, 3), **f)
+            g_colors = torch.empty((N, 3), **f)
+            g_opacity = torch.empty((N, 1), **f)
+            g_means3D = torch.empty((N, 3), **f)
+            g_cov3D = torch.empty((N, 6), **f)
+            g_sh = torch.empty((N, M, 3), **f) if has_sh else None
+            g_scales = torch.empty((N, 3), **f) if has_sc else None
+            g_rot = torch.empty((N, 4), **f) if has_sc else None
+            scratch = torch.empty((max(N, 1) * 5,), **f)
+            gc = _h.f32c(grad_color)
+            if gc is None:
+                gc = torch.zeros((3, int(rs.image_height), int(rs.image_width)), **f)
+            _h.check(lib.c3d_gs_backward(C.byref(st), N, M, _h.ptr(means3D_c if N else None), _h.ptr(nn_(sh_c, has_sh)),
+                                         _h.ptr(nn_(col_c, has_col)), _h.ptr(nn_(sc_c, has_sc)), _h.ptr(nn_(rot_c, has_sc)),
+                                         _h.ptr(nn_(cov_c, has_cov)), _h.ptr(radii), _h.ptr(geom), ctx.num_rendered,
+                                         _h.ptr(binning), _h.ptr(img), _h.ptr(gc), _h.ptr(_h.f32c(grad_depth)),
+                                         _h.ptr(_h.f32c(grad_alpha)), _h.ptr(g_means2D), _h.ptr(g_colors), _h.ptr(g_opacity),
+                                         _h.ptr(g_means3D), _h.ptr(g_cov3D), _h.ptr(g_sh), _h.ptr(g_scales), _h.ptr(g_rot),
+                                         _h.ptr(scratch), s), "c3d_gs_backward")
+        return (g_means3D, g_means2D, g_sh, g_colors if has_col else None, g_opacity, g_scales, g_rot,
+                g_cov3D if has_cov else None, None)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        with torch.no_grad():
+            rs = self.raster_settings
+            lib = _h.lib()
+            pos = _h.f32c(positions)
+            N = 0 if pos is None else pos.shape[0]
+            present = torch.empty((N,), dtype=torch.uint8, device=positions.device)
+            vm, pm = _h.f32c(rs.viewmatrix), _h.f32c(rs.projmatrix)
+            with torch.cuda.device(positions.device):
+                _h.check(lib.c3d_gs_mark_visible(N, _h.ptr(pos), _h.ptr(vm), _h.ptr(pm), _h.ptr(present), _h.stream(positions.device)),
+                         "c3d_gs_mark_visible")
+        return present.bool()
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None):
+        rs = self.raster_settings
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        e = torch.Tensor([]).to(means3D.device)
+        shs = e if shs is None else shs
+        colors_precomp = e if colors_precomp is None else colors_precomp
+        scales = e if scales is None else scales
+        rotations = e if rotations is None else rotations
+        cov3D_precomp = e if cov3D_precomp is None else cov3D_precomp
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, rs)

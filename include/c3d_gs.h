@@ -1,0 +1,113 @@
+/*
+ * c3d_gs.h -- C-ABI of the MI355X-native 3D-Gaussian-Splatting rasterizer (libc3d_hip.so).
+ *
+ * Drop-in boundary: these entry points are what a replacement for the native extension of
+ * `diff_gaussian_rasterization` must export.  The reference reaches that extension at
+ *   /root/reference/MVs_Algorithms/GaussianSplatting/main_3DGS_renderer.py:840-843  (import)
+ *   /root/reference/MVs_Algorithms/GaussianSplatting/main_3DGS_renderer.py:849-864  (settings)
+ *   /root/reference/MVs_Algorithms/GaussianSplatting/main_3DGS_renderer.py:927-936  (rasterizer call)
+ * and, through the same Python package, from Gen_3D_Modules/LGM/core/gs.py:27-80,
+ * Gen_3D_Modules/TriplaneGaussian/models/renderer.py:209-270 and
+ * Gen_3D_Modules/TRELLIS/trellis/renderers/gaussian_render.py:62-130.
+ * The dependency's native layer exposes three functions (SURVEY.md 8b "Level 2"):
+ *   rasterize_gaussians           -> c3d_gs_forward_project + c3d_gs_forward_render
+ *   rasterize_gaussians_backward  -> c3d_gs_backward
+ *   mark_visible                  -> c3d_gs_mark_visible
+ * The forward is split in two because the number of (tile, splat) pairs is data dependent: the
+ * caller allocates the binning buffer between the calls (the dependency does the same through a
+ * resize callback into torch's allocator).
+ *
+ * Conventions
+ *  - plain C: pointers + sizes, no torch / C++ types.  All tensor pointers are DEVICE pointers to
+ *    contiguous float32 / int32 arrays unless a parameter says "host".
+ *  - every function launches on `stream` (a hipStream_t passed as void*) and returns 0 on success,
+ *    non-zero otherwise; c3d_last_error() then returns a message (thread-local).
+ *  - "optional" tensors are passed as NULL (exactly one of shs / colors_precomp and one of
+ *    (scales,rotations) / cov3D_precomp must be non-NULL, as the dependency's Python wrapper demands).
+ *  - buffers whose size the library decides are opaque byte buffers owned by the caller; ask the
+ *    *_bytes() functions for their size.  They must be kept until backward has run.
+ *  - matrices use the storage the reference passes: viewmatrix = world_view_transform = w2c^T and
+ *    projmatrix = full_proj_transform, both row-major 4x4 (shared_utils/camera_utils.py:205-213).
+ */
+#ifndef C3D_GS_H
+#define C3D_GS_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* c3d_stream_t; /* hipStream_t */
+
+/* mirrors GaussianRasterizationSettings (main_3DGS_renderer.py:849-862) */
+typedef struct c3d_gs_settings {
+    int32_t image_height;
+    int32_t image_width;
+    float tanfovx;
+    float tanfovy;
+    float scale_modifier;
+    int32_t sh_degree;
+    int32_t prefiltered;
+    int32_t debug;
+    const float* bg;         /* device [3]  */
+    const float* viewmatrix; /* device [16] */
+    const float* projmatrix; /* device [16] */
+    const float* campos;     /* device [3]  */
+} c3d_gs_settings;
+
+const char* c3d_last_error(void);
+int c3d_version(void);
+
+/* sizes (bytes) of the three opaque state buffers (geometry / binning / image) */
+size_t c3d_gs_geom_bytes(int32_t N);
+size_t c3d_gs_binning_bytes(int64_t num_rendered, int32_t image_height, int32_t image_width);
+size_t c3d_gs_image_bytes(int32_t image_height, int32_t image_width);
+
+/* Forward, part 1 (A1 + depth ordering + offsets): projects N Gaussians (SH with M coefficients per
+ * channel, layout [N,M,3]), writes radii[N] (int32, 0 = culled) and the geometry buffer, and returns
+ * the number of (tile, splat) pairs through the HOST pointer num_rendered (the call synchronises the
+ * stream for that one value). */
+int c3d_gs_forward_project(const c3d_gs_settings* st, int32_t N, int32_t M, const float* means3D, const float* shs,
+                           const float* colors_precomp, const float* opacities, const float* scales,
+                           const float* rotations, const float* cov3D_precomp, int32_t* radii, void* geom_buffer,
+                           int64_t* num_rendered /* host */, c3d_stream_t stream);
+
+/* Forward, part 2 (A3-A6): bins, orders and composites.  out_color[3,H,W], out_depth[1,H,W],
+ * out_alpha[1,H,W]. */
+int c3d_gs_forward_render(const c3d_gs_settings* st, int32_t N, int32_t M, const int32_t* radii, void* geom_buffer,
+                          int64_t num_rendered, void* binning_buffer, void* image_buffer, float* out_color,
+                          float* out_depth, float* out_alpha, c3d_stream_t stream);
+
+/* Backward (A7 + A8).  Pixel gradients dL_dcolor[3,H,W], dL_ddepth[1,H,W] (may be NULL),
+ * dL_dalpha[1,H,W] (may be NULL).  Outputs (all written in full by the library, no pre-zeroing needed):
+ * dL_dmeans2D[N,3] dL_dcolors[N,3] dL_dopacity[N,1] dL_dmeans3D[N,3] dL_dcov3D[N,6] dL_dsh[N,M,3]
+ * dL_dscales[N,3] dL_drotations[N,4].  scratch: N*5 floats (conic[4] + depth[1] partials). */
+int c3d_gs_backward(const c3d_gs_settings* st, int32_t N, int32_t M, const float* means3D, const float* shs,
+                    const float* colors_precomp, const float* scales, const float* rotations,
+                    const float* cov3D_precomp, const int32_t* radii, const void* geom_buffer, int64_t num_rendered,
+                    const void* binning_buffer, const void* image_buffer, const float* dL_dcolor,
+                    const float* dL_ddepth, const float* dL_dalpha, float* dL_dmeans2D, float* dL_dcolors,
+                    float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscales,
+                    float* dL_drotations, float* scratch, c3d_stream_t stream);
+
+/* mark_visible: present[N] (uint8) = view-space z > 0.2 */
+int c3d_gs_mark_visible(int32_t N, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                        uint8_t* present, c3d_stream_t stream);
+
+/* introspection used by the parity tests: copies of internal state, all DEVICE pointers, any may be NULL.
+ * point_list[num_rendered] (Gaussian id per sorted pair), ranges[tiles*2], xy[N*2], depths[N],
+ * conic_opacity[N*4], rgb[N*3], tiles_touched[N]. */
+int c3d_gs_debug_state(int32_t N, int32_t image_height, int32_t image_width, const void* geom_buffer,
+                       int64_t num_rendered, const void* binning_buffer, uint32_t* point_list, uint32_t* ranges,
+                       float* xy, float* depths, float* conic_opacity, float* rgb, uint32_t* tiles_touched,
+                       c3d_stream_t stream);
+
+/* primitives exported for unit tests of the binning machinery (device pointers) */
+int c3d_test_scan_u32(const uint32_t* in, uint32_t* out, int64_t n, int32_t exclusive, c3d_stream_t stream);
+int c3d_test_sort_pairs_u32(uint32_t* keys, uint32_t* vals, int64_t n, int32_t end_bit, c3d_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* C3D_GS_H */
