@@ -1,0 +1,235 @@
+#!/usr/bin/env python
+"""bench.py -- Mpixels/s of the 3DGS forward+backward hot path on BASELINE.json's workload.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Workload (config.workload): BASELINE.md section 3 configs 2-4 -- 1,000,000 synthetic Gaussians (seed 1234), SH degree 3,
+1920x1080, the 64-camera orbit.  A "step" = one pass of the hot path over one batch of views on every rank:
+`--views-per-gpu` (default 8) views, each rasterized forward and backward through the C-ABI (the gradients of the shared
+Gaussians accumulate over the views), then -- for N > 1 -- the one gradient exchange of the shared-Gaussian training
+loop (RCCL all-gather of every rank's dense gradient + fixed-order local sum).  Per-GPU work is fixed as N grows
+("weak"): at N = 8 this is config 4 (64 views/step, 8 per GPU).  Inputs are resident in HBM before the timed region.
+
+value = views * W * H over all ranks / wall seconds / 1e6  (wall = max over ranks, barrier + synchronize on both sides).
+roofline = the dominant kernel group (largest share of in-library GPU time inside the timed region, measured with HIP
+events on the launch stream), algorithmic bytes per launch (DESIGN.md "Algorithmic bytes") / its average duration.
+cpu_baseline = the CPU oracle (a port: the reference has no CPU path) on ONE view of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "comfyui-3d-pack_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--mode", choices=["fwdbwd", "fwd", "train"], default="fwdbwd")
+    ap.add_argument("--views-per-gpu", type=int, default=8)
+    ap.add_argument("--gaussians", type=int, default=1_000_000)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--sh-degree", type=int, default=3)
+    ap.add_argument("--cpu-baseline", choices=["auto", "on", "off"], default="auto")
+    ap.add_argument("--exchange", choices=["allgather", "allreduce"], default="allgather")
+    return ap.parse_args()
+
+
+def algorithmic_bytes(N, K, P, n_vis, D):
+    """SURVEY.md 8(d) per-unit figures, split per kernel group (DESIGN.md 'Algorithmic bytes')."""
+    return {
+        "gs_preprocess": N * (44 + 12 * K) + 48 * n_vis,
+        "gs_depth_sort": 8 * n_vis,                       # one (key,id) read of the visible set; passes are overhead
+        "gs_emit": 12 * D + 48 * n_vis * 0,               # key/value emit 12 B per pair
+        "gs_tile_sort": 12 * D,                           # sorted read 12 B per pair; passes are overhead
+        "gs_composite_fwd": 44 * D + 20 * P,              # per-tile splat gather 44 + rgb/depth/alpha stores 20
+        "gs_composite_bwd": 48 * D + 32 * P + 48 * n_vis, # gather 44 + id 4; pixel grads 20 + aux 12; gradient record
+        "gs_preprocess_bwd": 48 * n_vis + 2 * N * (44 + 12 * K),
+    }
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (a.gpus, a.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the MI355X path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    import c3d_hip
+    from c3d_hip import synthetic as S
+    import diff_gaussian_rasterization as dgr
+
+    N, W, H, deg = a.gaussians, a.width, a.height, a.sh_degree
+    K, P = (deg + 1) ** 2, a.width * a.height
+    cloud = S.make_cloud(N, seed=1234, sh_degree=deg, activated=True)
+    params = {k: torch.tensor(v, device=dev, requires_grad=(a.mode != "fwd")) for k, v in cloud.items()}
+    poses = S.orbit_poses_64()
+    my_poses = [poses[(rank * a.views_per_gpu + i) % len(poses)] for i in range(a.views_per_gpu)]
+    settings = []
+    for (r, e, az) in my_poses:
+        st = S.camera_settings(W, H, 49.1, e, az, r, bg=(1.0, 1.0, 1.0), sh_degree=deg)
+        t = lambda x: torch.as_tensor(np.asarray(x, dtype=np.float32)).to(dev)
+        settings.append(dgr.GaussianRasterizationSettings(H, W, st["tanfovx"], st["tanfovy"], t(st["bg"]), 1.0,
+                                                          t(st["viewmatrix"]).reshape(4, 4), t(st["projmatrix"]).reshape(4, 4),
+                                                          deg, t(st["campos"]), False, False))
+    # training targets: renders of the xyz-jittered cloud, made once, untimed
+    targets = []
+    with torch.no_grad():
+        g = torch.Generator(device="cpu").manual_seed(4321)
+        jit = (params["means3D"].detach() + 0.002 * torch.randn(N, 3, generator=g).to(dev))
+        for rs in settings:
+            c, _, _, al = dgr.GaussianRasterizer(rs)(means3D=jit, means2D=None, opacities=params["opacities"].detach(),
+                                                     shs=params["shs"].detach(), scales=params["scales"].detach(),
+                                                     rotations=params["rotations"].detach())
+            targets.append((c.clone(), al.clone()))
+    opt = None
+    if a.mode == "train":
+        lrs = {"means3D": 1.6e-4, "shs": 2.5e-3, "opacities": 0.05, "scales": 5e-3, "rotations": 1e-3}
+        opt = torch.optim.Adam([{"params": [params[k]], "lr": lr} for k, lr in lrs.items()], lr=0.0, eps=1e-15, fused=True)
+    names = ["means3D", "shs", "opacities", "scales", "rotations"]
+    stats = {"n_vis": [], "D": []}
+
+    def step(collect=False):
+        for i, rs in enumerate(settings):
+            rast = dgr.GaussianRasterizer(rs)
+            m2d = torch.zeros_like(params["means3D"], requires_grad=(a.mode != "fwd")) if a.mode != "fwd" else None
+            color, radii, depth, alpha = rast(means3D=params["means3D"], means2D=m2d, opacities=params["opacities"],
+                                              shs=params["shs"], scales=params["scales"], rotations=params["rotations"])
+            if collect:
+                stats["n_vis"].append(int((radii > 0).sum().item()))
+                stats["D"].append(int(dgr.last_num_rendered))
+            if a.mode != "fwd":
+                tc, ta = targets[i]
+                loss = (color - tc).abs().mean() * 0.8 + 3.0 * ((alpha - ta) ** 2).mean()
+                (loss / (a.views_per_gpu * world)).backward()
+        if a.mode != "fwd" and world > 1:
+            flat = torch.cat([params[k].grad.reshape(N, -1) for k in names], dim=1)   # [N, 59] dense gradient
+            if a.exchange == "allgather":
+                buf = torch.empty((world,) + tuple(flat.shape), device=dev)
+                dist.all_gather_into_tensor(buf, flat)
+                flat = buf.sum(dim=0)   # fixed rank order -> bit-identical replicas
+            else:
+                dist.all_reduce(flat)
+            off = 0
+            for k in names:
+                w = params[k].grad[0].numel()
+                params[k].grad.copy_(flat[:, off:off + w].reshape(params[k].grad.shape))
+                off += w
+        if a.mode == "train":
+            opt.step()
+        if a.mode != "fwd":
+            for k in names:
+                params[k].grad = None
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for w in range(a.warmup):
+        step(collect=(w == 0))
+    if a.warmup == 0:
+        with torch.no_grad():
+            pass
+    sync()
+    c3d_hip.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    prof = c3d_hip.prof_read()
+    c3d_hip.prof_enable(False)
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    views_total = a.views_per_gpu * world * a.steps
+    value = views_total * P / dt / 1e6
+    if not stats["D"]:
+        stats = {"n_vis": [0], "D": [0]}
+    n_vis, D = float(np.mean(stats["n_vis"])), float(np.mean(stats["D"]))
+    alg = algorithmic_bytes(N, K, P, n_vis, D)
+    kern = {}
+    for name, (ms, n) in prof.items():
+        avg = ms / n
+        kern[name] = {"avg_ms": round(avg, 4), "launches": n, "share": 0.0,
+                      "alg_GBps": round(alg.get(name, 0) / (avg * 1e-3) / 1e9, 1) if avg > 0 else None}
+    tot = sum(ms for ms, _ in prof.values()) or 1.0
+    for name, (ms, n) in prof.items():
+        kern[name]["share"] = round(ms / tot, 3)
+    roof = None
+    if prof:
+        dom = max(prof, key=lambda k: prof[k][0])
+        avg_s = prof[dom][0] / prof[dom][1] * 1e-3
+        ach = alg.get(dom, 0) / avg_s / 1e9
+        roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None, "avg_ms": round(avg_s * 1e3, 4),
+                "alg_bytes_per_launch": int(alg.get(dom, 0))}
+
+    cpu = None
+    if rank == 0 and world == 1 and a.cpu_baseline != "off":
+        try:
+            from oracle import gs_oracle as O
+            ncore = os.cpu_count() or 1
+            r, e, az = my_poses[0]
+            st = S.camera_settings(W, H, 49.1, e, az, r, bg=(1.0, 1.0, 1.0), sh_degree=deg)
+            t1 = time.perf_counter()
+            oc, orad, od, oa, ost = O.forward(cloud["means3D"], cloud["opacities"], st, shs=cloud["shs"], scales=cloud["scales"],
+                                              rotations=cloud["rotations"], nthreads=ncore)
+            if a.mode != "fwd":
+                O.backward(ost, np.ones((3, H, W), np.float32) / P, nthreads=ncore)
+            tc = time.perf_counter() - t1
+            cpu = {"value": round(P / tc / 1e6, 4), "unit": "Mpixels/s", "cores": ncore, "kind": "port",
+                   "sample": "1 view of the same workload (%d Gaussians, %dx%d, %s) on the CPU oracle, %.1f s" % (N, W, H, a.mode, tc)}
+        except Exception as ex:   # the baseline leg must never take the bench down
+            cpu = {"value": None, "unit": "Mpixels/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (ex,)}
+
+    if rank == 0:
+        out = {
+            "metric": "Mpixels/s 3DGS forward+backward @1M Gaussians 1080p" if a.mode == "fwdbwd" else
+                      ("Mpixels/s 3DGS forward @1M Gaussians 1080p" if a.mode == "fwd" else "Mpixels/s 3DGS forward+backward+Adam @1M Gaussians 1080p"),
+            "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "3DGS %s, %d synthetic Gaussians (seed 1234) SH deg %d, %dx%d, %d orbit views/GPU/step of the 64-camera orbit"
+                                   % (a.mode, N, deg, W, H, a.views_per_gpu),
+                       "global_views_per_step": a.views_per_gpu * world, "parallelism": "view-parallel dp%d" % world,
+                       "exchange": (a.exchange if world > 1 and a.mode != "fwd" else "none"),
+                       "n_visible": n_vis, "tile_splat_pairs": D},
+            "roofline": roof, "cpu_baseline": cpu, "kernels": kern,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

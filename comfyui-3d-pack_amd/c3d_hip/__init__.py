@@ -37,6 +37,10 @@ _SIGNATURES = {
     "c3d_gs_backward": (C.c_int, [C.POINTER(GsSettings), i32, i32] + [vp] * 6 + [vp, vp, i64, vp, vp] + [vp] * 3 + [vp] * 8 + [vp, vp]),
     "c3d_gs_mark_visible": (C.c_int, [i32, vp, vp, vp, vp, vp]),
     "c3d_gs_debug_state": (C.c_int, [i32, i32, i32, vp, i64, vp] + [vp] * 7 + [vp]),
+    "c3d_prof_enable": (C.c_int, [C.c_int]),
+    "c3d_prof_slots": (C.c_int, []),
+    "c3d_prof_name": (C.c_char_p, [C.c_int]),
+    "c3d_prof_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     "c3d_test_scan_u32": (C.c_int, [vp, vp, i64, i32, vp]),
     "c3d_test_sort_pairs_u32": (C.c_int, [vp, vp, i64, i32, vp]),
 }
@@ -104,3 +108,19 @@ def f32c(t):
     if t.dtype != torch.float32:
         t = t.float()
     return t.contiguous()
+
+
+def prof_enable(on=True):
+    lib().c3d_prof_enable(1 if on else 0)
+
+
+def prof_read():
+    """{kernel group name: (total_ms, launches)} accumulated since prof_enable(True)."""
+    l = lib()
+    out = {}
+    for i in range(l.c3d_prof_slots()):
+        ms, n = C.c_double(0), C.c_longlong(0)
+        l.c3d_prof_read(i, C.byref(ms), C.byref(n))
+        if n.value:
+            out[l.c3d_prof_name(i).decode()] = (ms.value, n.value)
+    return out

@@ -77,13 +77,16 @@ int c3d_gs_forward_project(const c3d_gs_settings* st, int32_t N, int32_t M, cons
     GsGeom g;
     gs_carve_geom((char*)geom_buffer, N, g);
     int rc;
-    if ((rc = gs_launch_preprocess(p, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, radii, s))) return rc;
+    { C3dProfScope ps(C3D_P_PREPROCESS, s);
+    if ((rc = gs_launch_preprocess(p, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, radii, s))) return rc; }
     // order Gaussians by (view depth, id): stable sort of the depth bits with ids as payload
     int res = 0;
-    if ((rc = c3d_sort_pairs_u32(g.key[0], g.key[1], g.order[0], g.order[1], true, (size_t)N, 32, g.tmp, &res, s))) return rc;
+    { C3dProfScope ps(C3D_P_DEPTH_SORT, s);
+    if ((rc = c3d_sort_pairs_u32(g.key[0], g.key[1], g.order[0], g.order[1], true, (size_t)N, 32, g.tmp, &res, s))) return rc; }
     if (res != sort_result_index(32)) { c3d_set_error("internal: depth sort buffer parity"); return -2; }
+    { C3dProfScope ps(C3D_P_SCAN, s);
     if ((rc = gs_launch_gather_tiles(g, N, res, s))) return rc;
-    if ((rc = c3d_scan_u32(g.tiles_sorted, g.offsets, (size_t)N, false, g.tmp, s))) return rc;
+    if ((rc = c3d_scan_u32(g.tiles_sorted, g.offsets, (size_t)N, false, g.tmp, s))) return rc; }
     uint32_t d32 = 0;
     C3D_CHECK(hipMemcpyAsync(&d32, g.offsets + (N - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     C3D_CHECK(hipStreamSynchronize(s));
@@ -109,11 +112,15 @@ int c3d_gs_forward_render(const c3d_gs_settings* st, int32_t N, int32_t M, const
     int rc, res = 0;
     if (num_rendered > 0) {
         if (!geom_buffer || !radii) { c3d_set_error("c3d_gs_forward_render: NULL geometry"); return -1; }
-        if ((rc = gs_launch_emit(p, g, sort_result_index(32), radii, b, s))) return rc;
+        { C3dProfScope ps(C3D_P_EMIT, s);
+        if ((rc = gs_launch_emit(p, g, sort_result_index(32), radii, b, s))) return rc; }
+        C3dProfScope ps2(C3D_P_TILE_SORT, s);
         if ((rc = c3d_sort_pairs_u32(b.tkey[0], b.tkey[1], b.tval[0], b.tval[1], false, (size_t)num_rendered, tile_sort_bits(tiles), b.tmp, &res, s))) return rc;
         if (res != sort_result_index(tile_sort_bits(tiles))) { c3d_set_error("internal: tile sort buffer parity"); return -2; }
     }
-    if ((rc = gs_launch_ranges(b, res, num_rendered, tiles, s))) return rc;
+    { C3dProfScope ps(C3D_P_RANGES, s);
+    if ((rc = gs_launch_ranges(b, res, num_rendered, tiles, s))) return rc; }
+    C3dProfScope ps(C3D_P_COMPOSITE_FWD, s);
     return gs_launch_composite_fwd(p, g, b, res, im, out_color, out_depth, out_alpha, s);
 }
 
@@ -152,9 +159,11 @@ int c3d_gs_backward(const c3d_gs_settings* st, int32_t N, int32_t M, const float
     if (num_rendered > 0 && tiles > 0) {
         if (!binning_buffer || !image_buffer) { c3d_set_error("c3d_gs_backward: NULL state buffer"); return -1; }
         const int res = sort_result_index(tile_sort_bits(tiles));
+        C3dProfScope ps(C3D_P_COMPOSITE_BWD, s);
         if ((rc = gs_launch_composite_bwd(p, g, b, res, im, dL_dcolor, dL_ddepth, dL_dalpha, dL_dmeans2D, dL_dconic, dL_dopacity,
                                           dL_dcolors, dL_ddepths, s))) return rc;
     }
+    C3dProfScope ps(C3D_P_PREPROCESS_BWD, s);
     return gs_launch_preprocess_bwd(p, g, radii, means3D, shs, colors_precomp, scales, rotations, cov3D_precomp, dL_dmeans2D, dL_dconic,
                                     dL_dcolors, dL_ddepths, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, s);
 }
@@ -204,8 +213,8 @@ int c3d_test_scan_u32(const uint32_t* in, uint32_t* out, int64_t n, int32_t excl
     void* tmp = nullptr;
     C3D_CHECK(hipMalloc(&tmp, c3d_scan_tmp_bytes((size_t)n)));
     int rc = c3d_scan_u32(in, out, (size_t)n, exclusive != 0, tmp, s);
-    hipStreamSynchronize(s);
-    hipFree(tmp);
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(tmp);
     return rc;
 }
 int c3d_test_sort_pairs_u32(uint32_t* keys, uint32_t* vals, int64_t n, int32_t end_bit, c3d_stream_t stream) {
@@ -220,11 +229,11 @@ int c3d_test_sort_pairs_u32(uint32_t* keys, uint32_t* vals, int64_t n, int32_t e
     int res = 0;
     int rc = c3d_sort_pairs_u32(keys, k1, vals, v1, false, (size_t)n, end_bit, tmp, &res, s);
     if (!rc && res == 1) {
-        hipMemcpyAsync(keys, k1, 4 * (size_t)n, hipMemcpyDeviceToDevice, s);
-        if (vals) hipMemcpyAsync(vals, v1, 4 * (size_t)n, hipMemcpyDeviceToDevice, s);
+        (void)hipMemcpyAsync(keys, k1, 4 * (size_t)n, hipMemcpyDeviceToDevice, s);
+        (void)hipMemcpyAsync(vals, v1, 4 * (size_t)n, hipMemcpyDeviceToDevice, s);
     }
-    hipStreamSynchronize(s);
-    hipFree(k1); hipFree(v1); hipFree(tmp);
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(k1); (void)hipFree(v1); (void)hipFree(tmp);
     return rc;
 }
 

@@ -44,7 +44,6 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
     const bool inside = pxi < p.W && pyi < p.H;
     const float pxf = (float)pxi, pyf = (float)pyi;
     const uint2 rg = ranges[tile];
-    const int todo = (int)(rg.y - rg.x);
     const size_t P = (size_t)p.W * p.H, pid = (size_t)pyi * p.W + pxi;
     const int lane = c3d_lane();
 

@@ -13,6 +13,8 @@ import torch.nn as nn
 
 import c3d_hip as _h
 
+last_num_rendered = 0   # (tile, splat) pairs of the most recent forward -- bench/telemetry only
+
 
 class GaussianRasterizationSettings(NamedTuple):
     image_height: int
@@ -69,6 +71,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                                                 _h.ptr(sc_c), _h.ptr(rot_c), _h.ptr(cov_c), _h.ptr(radii), _h.ptr(geom),
                                                 C.byref(nr), s), "c3d_gs_forward_project")
             num_rendered = int(nr.value)
+            global last_num_rendered
+            last_num_rendered = num_rendered
             binning = torch.empty((lib.c3d_gs_binning_bytes(num_rendered, H, W),), **u8)
             img = torch.empty((lib.c3d_gs_image_bytes(H, W),), **u8)
             color = torch.empty((3, H, W), dtype=torch.float32, device=dev)

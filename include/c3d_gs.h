@@ -103,6 +103,14 @@ int c3d_gs_debug_state(int32_t N, int32_t image_height, int32_t image_width, con
                        float* xy, float* depths, float* conic_opacity, float* rgb, uint32_t* tiles_touched,
                        c3d_stream_t stream);
 
+/* Optional per-kernel timing: HIP events recorded on the launch stream around each kernel group.
+ * c3d_prof_enable(1) resets and starts, c3d_prof_read(slot, &ms, &n) synchronises the recorded events and returns the
+ * accumulated milliseconds / launches of a slot; slot names via c3d_prof_name (e.g. "gs_composite_bwd"). */
+int c3d_prof_enable(int on);
+int c3d_prof_slots(void);
+const char* c3d_prof_name(int slot);
+int c3d_prof_read(int slot, double* total_ms, long long* launches);
+
 /* primitives exported for unit tests of the binning machinery (device pointers) */
 int c3d_test_scan_u32(const uint32_t* in, uint32_t* out, int64_t n, int32_t exclusive, c3d_stream_t stream);
 int c3d_test_sort_pairs_u32(uint32_t* keys, uint32_t* vals, int64_t n, int32_t end_bit, c3d_stream_t stream);

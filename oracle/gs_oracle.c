@@ -235,6 +235,14 @@ static void color_from_sh(const gs_state *st, int idx, const real *means, const 
     }
 }
 
+/* accumulation into per-Gaussian sums; atomic only when the tile loop runs multi-threaded (cpu_baseline leg) */
+static inline void acc(real *p, real v, int par) {
+    if (par) {
+#pragma omp atomic
+        *p += v;
+    } else *p += v;
+}
+
 static uint32_t depth_bits(real d) { float f = (float)d; uint32_t u; memcpy(&u, &f, 4); return u; }
 
 typedef struct { uint64_t key; uint32_t id; } kv_t;
@@ -441,13 +449,14 @@ void gs_oracle_backward(gs_state *st, const real *means3D, const real *shs, cons
                         real *dL_dcolors /*N*3*/, real *dL_ddepths /*N*/, real *dL_dmeans3D /*N*3*/,
                         real *dL_dcov3D /*N*6*/, real *dL_dsh /*N*M*3*/, real *dL_dscales /*N*3*/,
                         real *dL_drots /*N*4*/, int nthreads) {
-    (void)nthreads;
+    const int par = nthreads > 1;
     int N = st->N, W = st->W, H = st->H;
     size_t P = (size_t)W * H;
     int tiles = st->gx * st->gy;
     const real ddelx_dx = (real)0.5 * W, ddely_dy = (real)0.5 * H;
 
-    /* ---- A7 ---- (sequential: summation order = tile-major, row-major pixels, back to front) */
+    /* ---- A7 ---- (nthreads<=1: sequential, summation order = tile-major, row-major pixels, back to front) */
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads > 0 ? nthreads : 1) if (par)
     for (int tile = 0; tile < tiles; tile++) {
         int tx = tile % st->gx, ty = tile / st->gx;
         uint32_t r0 = st->ranges[2 * tile], r1 = st->ranges[2 * tile + 1];
@@ -480,13 +489,13 @@ void gs_oracle_backward(gs_state *st, const real *means3D, const real *shs, cons
                         accum[c] = last_alpha * last_color[c] + ((real)1 - last_alpha) * accum[c];
                         last_color[c] = col;
                         dL_dalpha += (col - accum[c]) * dLp[c];
-                        dL_dcolors[3 * g + c] += dch * dLp[c];
+                        acc(&dL_dcolors[3 * g + c], dch * dLp[c], par);
                     }
                     real cd = st->depths[g];
                     accum_d = last_alpha * last_depth + ((real)1 - last_alpha) * accum_d;
                     last_depth = cd;
                     dL_dalpha += (cd - accum_d) * dLd;
-                    dL_ddepths[g] += dch * dLd;
+                    acc(&dL_ddepths[g], dch * dLd, par);
                     accum_a = last_alpha + ((real)1 - last_alpha) * accum_a;
                     dL_dalpha += ((real)1 - accum_a) * dLa;
                     dL_dalpha *= T;
@@ -496,17 +505,18 @@ void gs_oracle_backward(gs_state *st, const real *means3D, const real *shs, cons
                     real gdx = G * dx, gdy = G * dy;
                     real dG_ddelx = -gdx * co[0] - gdy * co[1];
                     real dG_ddely = -gdy * co[2] - gdx * co[1];
-                    dL_dmeans2D[3 * g] += dL_dG * dG_ddelx * ddelx_dx;
-                    dL_dmeans2D[3 * g + 1] += dL_dG * dG_ddely * ddely_dy;
-                    dL_dconic[4 * g] += -(real)0.5 * gdx * dx * dL_dG;
-                    dL_dconic[4 * g + 1] += -(real)0.5 * gdx * dy * dL_dG;
-                    dL_dconic[4 * g + 3] += -(real)0.5 * gdy * dy * dL_dG;
-                    dL_dopacity[g] += G * dL_dalpha;
+                    acc(&dL_dmeans2D[3 * g], dL_dG * dG_ddelx * ddelx_dx, par);
+                    acc(&dL_dmeans2D[3 * g + 1], dL_dG * dG_ddely * ddely_dy, par);
+                    acc(&dL_dconic[4 * g], -(real)0.5 * gdx * dx * dL_dG, par);
+                    acc(&dL_dconic[4 * g + 1], -(real)0.5 * gdx * dy * dL_dG, par);
+                    acc(&dL_dconic[4 * g + 3], -(real)0.5 * gdy * dy * dL_dG, par);
+                    acc(&dL_dopacity[g], G * dL_dalpha, par);
                 }
             }
     }
 
     /* ---- A8 ---- */
+#pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1) if (par)
     for (int idx = 0; idx < N; idx++) {
         if (st->radii[idx] <= 0) continue;
         const real *mean = means3D + 3 * idx;

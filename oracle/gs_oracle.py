@@ -21,7 +21,7 @@ _LIBS = {}
 
 def build(quiet=True):
     """Compile the oracle shared objects with gcc (Makefile in this directory)."""
-    subprocess.run(["make", "-C", _HERE, "all"], check=True,
+    subprocess.run(["make", "-C", _HERE, "gs"], check=True,
                    stdout=subprocess.DEVNULL if quiet else None)
 
 
@@ -147,7 +147,7 @@ def forward(means3D, opacities, settings, shs=None, colors_precomp=None, scales=
     return color, radii, depth, alpha, st
 
 
-def backward(st, dL_dcolor, dL_ddepth=None, dL_dalpha=None):
+def backward(st, dL_dcolor, dL_ddepth=None, dL_dalpha=None, nthreads=1):
     """-> dict of gradients with the names the dependency's backward returns."""
     lib, dtype, inp = st.lib, st.dtype, st.inputs
     N = inp["N"]
@@ -167,7 +167,7 @@ def backward(st, dL_dcolor, dL_ddepth=None, dL_dalpha=None):
                            _p(inp["scales"]), _p(inp["rotations"]), _p(inp["cov3D_precomp"]),
                            _p(dL_dcolor), _p(dL_ddepth), _p(dL_dalpha),
                            _p(g["means2D"]), _p(g["conic"]), _p(g["opacities"]), _p(g["colors"]), _p(g["depths"]),
-                           _p(g["means3D"]), _p(g["cov3D"]), _p(g["shs"]), _p(g["scales"]), _p(g["rotations"]), 1)
+                           _p(g["means3D"]), _p(g["cov3D"]), _p(g["shs"]), _p(g["scales"]), _p(g["rotations"]), int(nthreads))
     return g
 
 

@@ -1,0 +1,286 @@
+"""Parity tests proper (-m gpu): the HIP path, called through the C-ABI, against the CPU oracle on the same seeded
+inputs.  Tolerances are the north star's: image L1 <= 1e-4, gradients <= 1e-3 relative (max-norm), integers exact."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from c3d_hip import synthetic as S
+from oracle import gs_oracle as O
+from helpers import hip_forward, hip_settings, oracle_forward, rel_err
+
+pytestmark = pytest.mark.gpu
+IMG_L1 = 1e-4
+GRAD_REL = 1e-3
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu(oracle_built):
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a HIP device (no CPU fallback exists)")
+    import c3d_hip
+    c3d_hip.lib()
+
+
+def _dev(a, dtype):
+    return torch.tensor(a, dtype=dtype, device="cuda")
+
+
+# ---------------------------------------------------------------- binning primitives
+@pytest.mark.parametrize("n", [1, 63, 64, 2048, 2049, 5000, 1 << 20, (1 << 22) + 12345])
+@pytest.mark.parametrize("excl", [0, 1])
+def test_scan(n, excl):
+    import c3d_hip as h
+    rng = np.random.default_rng(n)
+    a = rng.integers(0, 9, size=n, dtype=np.uint32)
+    x = torch.tensor(a.astype(np.int64), device="cuda").to(torch.int32)   # same bits
+    y = torch.empty_like(x)
+    h.check(h.lib().c3d_test_scan_u32(h.ptr(x), h.ptr(y), n, excl, h.stream()), "scan")
+    ref = np.cumsum(a.astype(np.uint64))
+    if excl:
+        ref = ref - a
+    got = y.cpu().numpy().view(np.uint32)
+    assert (got == (ref & 0xFFFFFFFF).astype(np.uint32)).all()
+
+
+@pytest.mark.parametrize("n,bits", [(1, 32), (100, 32), (4096, 32), (4097, 8), (100000, 13), (1 << 20, 32), (3000001, 15)])
+def test_sort_pairs_is_stable_and_correct(n, bits):
+    import c3d_hip as h
+    rng = np.random.default_rng(n + bits)
+    hi = (1 << bits) - 1
+    k = rng.integers(0, min(hi, 1 << 31), size=n, dtype=np.uint32) & np.uint32(hi)
+    if n > 10:
+        k[rng.integers(0, n, size=n // 3)] = k[0]          # many ties -> exercises stability
+    v = np.arange(n, dtype=np.uint32)
+    kt = torch.tensor(k.astype(np.int64), device="cuda").to(torch.int32)
+    vt = torch.tensor(v.astype(np.int64), device="cuda").to(torch.int32)
+    h.check(h.lib().c3d_test_sort_pairs_u32(h.ptr(kt), h.ptr(vt), n, bits, h.stream()), "sort")
+    order = np.argsort(k, kind="stable")
+    assert (kt.cpu().numpy().view(np.uint32) == k[order]).all()
+    assert (vt.cpu().numpy().view(np.uint32) == v[order]).all()
+
+
+# ---------------------------------------------------------------- forward parity
+CASES = [
+    dict(N=48, W=48, H=32, el=-20, az=30, rad=2.0, seed=7, deg=3),
+    dict(N=300, W=100, H=70, el=35, az=200, rad=1.6, seed=3, deg=2),     # W,H not multiples of 16
+    dict(N=500, W=64, H=64, el=0, az=0, rad=1.2, seed=11, deg=0),
+    dict(N=2000, W=160, H=96, el=-60, az=-135, rad=2.5, seed=5, deg=1, scale=0.03),
+]
+
+
+def _scene(c):
+    sc = S.make_small_scene(N=c["N"], seed=c["seed"], scale=c.get("scale", 0.08))
+    st = S.camera_settings(c["W"], c["H"], 49.1, c["el"], c["az"], c["rad"], bg=(0.3, 0.7, 0.1), sh_degree=c["deg"])
+    return sc, st
+
+
+@pytest.mark.parametrize("c", CASES)
+def test_forward_matches_oracle(c):
+    sc, st = _scene(c)
+    color, radii, depth, alpha, *_ = hip_forward(sc, st)
+    oc, orad, od, oa, ostate = oracle_forward(sc, st, dtype=np.float32)
+    assert (radii.cpu().numpy() == orad).all()
+    assert np.abs(color.cpu().numpy() - oc).mean() <= IMG_L1
+    assert np.abs(alpha.cpu().numpy() - oa).mean() <= IMG_L1
+    assert np.abs(depth.cpu().numpy() - od).mean() <= IMG_L1
+    assert np.abs(color.cpu().numpy() - oc).max() <= 5e-3   # no isolated wrong pixels either
+
+
+def test_internal_state_matches_oracle():
+    """Projected records, per-tile lists (order!) and ranges are identical to the oracle's."""
+    import c3d_hip as h
+    c = CASES[1]
+    sc, st = _scene(c)
+    N, H, W = c["N"], c["H"], c["W"]
+    lib = h.lib()
+    keep = []
+    import diff_gaussian_rasterization as dgr
+    rs = hip_settings(st, "cuda")
+    stc = dgr._settings_struct(rs, keep)
+    t = {k: _dev(sc[k], torch.float32) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+    radii = torch.empty(N, dtype=torch.int32, device="cuda")
+    geom = torch.empty(lib.c3d_gs_geom_bytes(N), dtype=torch.uint8, device="cuda")
+    nr = C.c_int64(0)
+    h.check(lib.c3d_gs_forward_project(C.byref(stc), N, 16, h.ptr(t["means3D"]), h.ptr(t["shs"]), None, h.ptr(t["opacities"]),
+                                       h.ptr(t["scales"]), h.ptr(t["rotations"]), None, h.ptr(radii), h.ptr(geom), C.byref(nr), h.stream()), "project")
+    D = nr.value
+    binning = torch.empty(lib.c3d_gs_binning_bytes(D, H, W), dtype=torch.uint8, device="cuda")
+    img = torch.empty(lib.c3d_gs_image_bytes(H, W), dtype=torch.uint8, device="cuda")
+    out = [torch.empty(s, device="cuda") for s in ((3, H, W), (1, H, W), (1, H, W))]
+    h.check(lib.c3d_gs_forward_render(C.byref(stc), N, 16, h.ptr(radii), h.ptr(geom), D, h.ptr(binning), h.ptr(img),
+                                      h.ptr(out[0]), h.ptr(out[1]), h.ptr(out[2]), h.stream()), "render")
+    tiles = ((W + 15) // 16) * ((H + 15) // 16)
+    pl = torch.empty(max(D, 1), dtype=torch.int32, device="cuda")
+    rg = torch.empty(tiles * 2, dtype=torch.int32, device="cuda")
+    xy = torch.empty(N * 2, device="cuda"); dep = torch.empty(N, device="cuda"); co = torch.empty(N * 4, device="cuda")
+    rgb = torch.empty(N * 3, device="cuda"); tt = torch.empty(N, dtype=torch.int32, device="cuda")
+    h.check(lib.c3d_gs_debug_state(N, H, W, h.ptr(geom), D, h.ptr(binning), h.ptr(pl), h.ptr(rg), h.ptr(xy), h.ptr(dep), h.ptr(co),
+                                   h.ptr(rgb), h.ptr(tt), h.stream()), "debug_state")
+    oc, orad, od, oa, ostate = oracle_forward(sc, st, dtype=np.float32)
+    assert D == ostate.num_rendered
+    g, b = ostate.geometry(), ostate.binning()
+    assert (tt.cpu().numpy() == g["tiles_touched"]).all()
+    assert (pl.cpu().numpy()[:D].view(np.uint32) == b["point_list"]).all()
+    assert (rg.cpu().numpy().view(np.uint32).reshape(-1, 2) == b["ranges"]).all()
+    vis = orad > 0
+    np.testing.assert_allclose(xy.cpu().numpy().reshape(N, 2)[vis], g["xy"][vis], atol=2e-3)
+    np.testing.assert_allclose(dep.cpu().numpy()[vis], g["depths"][vis], rtol=1e-6)
+    np.testing.assert_allclose(co.cpu().numpy().reshape(N, 4)[vis], g["conic_opacity"][vis], rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose(rgb.cpu().numpy().reshape(N, 3)[vis], g["rgb"][vis], atol=2e-6)
+
+
+def test_precomputed_colour_and_covariance_paths():
+    sc, st = _scene(CASES[0])
+    _, _, _, _, ostate = oracle_forward(sc, st, dtype=np.float64)
+    q = sc["rotations"].astype(np.float64); s = sc["scales"].astype(np.float64)
+    r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    Rm = np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y), 2 * (x * y + r * z), 1 - 2 * (x * x + z * z),
+                   2 * (y * z - r * x), 2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], -1).reshape(-1, 3, 3)
+    Mm = Rm * s[:, None, :]
+    Sg = Mm @ Mm.transpose(0, 2, 1)
+    sc2 = {"means3D": sc["means3D"], "opacities": sc["opacities"], "colors_precomp": ostate.geometry()["rgb"].astype(np.float32),
+           "cov3D_precomp": np.stack([Sg[:, 0, 0], Sg[:, 0, 1], Sg[:, 0, 2], Sg[:, 1, 1], Sg[:, 1, 2], Sg[:, 2, 2]], 1).astype(np.float32)}
+    color, radii, depth, alpha, inp, m2d = hip_forward(sc2, st, requires_grad=True)
+    oc, orad, od, oa, ost = oracle_forward(sc2, st, dtype=np.float64)
+    assert np.abs(color.detach().cpu().numpy() - oc).mean() <= IMG_L1
+    gC = np.random.default_rng(0).normal(size=oc.shape)
+    color.backward(torch.tensor(gC, dtype=torch.float32, device="cuda"))
+    og = O.backward(ost, gC)
+    assert rel_err(inp["colors_precomp"].grad.cpu().numpy(), og["colors"]) <= GRAD_REL
+    assert rel_err(inp["cov3D_precomp"].grad.cpu().numpy(), og["cov3D"]) <= GRAD_REL
+    assert rel_err(inp["means3D"].grad.cpu().numpy(), og["means3D"]) <= GRAD_REL
+
+
+# ---------------------------------------------------------------- backward parity
+@pytest.mark.parametrize("c", CASES)
+def test_backward_matches_oracle(c):
+    sc, st = _scene(c)
+    H, W = c["H"], c["W"]
+    rng = np.random.default_rng(5)
+    gC, gD, gA = (rng.normal(size=s).astype(np.float32) for s in ((3, H, W), (1, H, W), (1, H, W)))
+    color, radii, depth, alpha, inp, m2d = hip_forward(sc, st, requires_grad=True)
+    loss = (color * _dev(gC, torch.float32)).sum() + (depth * _dev(gD, torch.float32)).sum() + (alpha * _dev(gA, torch.float32)).sum()
+    loss.backward()
+    _, _, _, _, ost = oracle_forward(sc, st, dtype=np.float64)
+    og = O.backward(ost, gC, gD, gA)
+    for k in ("means3D", "opacities", "shs", "scales", "rotations"):
+        assert rel_err(inp[k].grad.cpu().numpy(), og[k]) <= GRAD_REL, k
+    assert rel_err(m2d.grad.cpu().numpy(), og["means2D"]) <= GRAD_REL
+    if c["deg"] < 3:
+        assert inp["shs"].grad[:, (c["deg"] + 1) ** 2:].abs().max().item() == 0
+
+
+def test_golden_vectors():
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "gs_small.npz"))
+    sc = {k: z[k] for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+    st = {k: (z["st_" + k].item() if z["st_" + k].ndim == 0 else z["st_" + k]) for k in
+          ("image_height", "image_width", "tanfovx", "tanfovy", "bg", "scale_modifier", "viewmatrix", "projmatrix", "sh_degree", "campos")}
+    color, radii, depth, alpha, inp, m2d = hip_forward(sc, st, requires_grad=True)
+    assert (radii.cpu().numpy() == z["radii"]).all()
+    assert np.abs(color.detach().cpu().numpy() - z["color"]).mean() <= IMG_L1
+    assert np.abs(depth.detach().cpu().numpy() - z["depth"]).mean() <= IMG_L1
+    assert np.abs(alpha.detach().cpu().numpy() - z["alpha"]).mean() <= IMG_L1
+    dv = lambda k: torch.tensor(z[k], device="cuda")
+    ((color * dv("gC")).sum() + (depth * dv("gD")).sum() + (alpha * dv("gA")).sum()).backward()
+    for k in ("means3D", "opacities", "shs", "scales", "rotations"):
+        assert rel_err(inp[k].grad.cpu().numpy(), z["grad_" + k]) <= GRAD_REL, k
+    assert rel_err(m2d.grad.cpu().numpy(), z["grad_means2D"]) <= GRAD_REL
+
+
+# ---------------------------------------------------------------- BASELINE configs at oracle-friendly sizes
+def test_config1_ball_10k_256px_4views():
+    """BASELINE config 1: 10k Gaussians, 256x256, MVDream(4) orbit, white bg."""
+    sc = S.make_ball_cloud(N=10000, seed=0)
+    for az in (0.0, 90.0, 180.0, -90.0):
+        st = S.camera_settings(256, 256, 49.1, 0.0, az, 1.75)
+        color, radii, depth, alpha, *_ = hip_forward(sc, st)
+        oc, orad, od, oa, _ = oracle_forward(sc, st, nthreads=8)
+        assert (radii.cpu().numpy() != orad).sum() <= 2
+        assert np.abs(color.cpu().numpy() - oc).mean() <= IMG_L1
+        assert np.abs(alpha.cpu().numpy() - oa).mean() <= IMG_L1
+
+
+def test_medium_cloud_fwd_bwd():
+    """the 1M-cloud generator at 100k / 640x360: long per-tile lists, early termination, many rounds."""
+    sc = S.make_cloud(100000, seed=1234, log_scale_mean=np.log(0.01))
+    st = S.camera_settings(640, 360, 49.1, 30.0, 45.0, 2.2)
+    color, radii, depth, alpha, inp, m2d = hip_forward(sc, st, requires_grad=True)
+    oc, orad, od, oa, ost = oracle_forward(sc, st, nthreads=8)
+    assert (radii.cpu().numpy() != orad).sum() <= 5
+    assert np.abs(color.detach().cpu().numpy() - oc).mean() <= IMG_L1
+    assert np.abs(alpha.detach().cpu().numpy() - oa).mean() <= IMG_L1
+    rng = np.random.default_rng(1)
+    gC = rng.normal(size=oc.shape).astype(np.float32)
+    color.backward(_dev(gC, torch.float32))
+    og = O.backward(ost, gC)
+    for k in ("means3D", "opacities", "shs", "scales", "rotations"):
+        assert rel_err(inp[k].grad.cpu().numpy(), og[k]) <= 5 * GRAD_REL, k   # f32 oracle + f32 atomics at 100k
+    # mean relative L1 over the whole tensor is far tighter
+    for k in ("means3D", "shs", "opacities"):
+        ref = og[k].astype(np.float64); got = inp[k].grad.cpu().numpy().astype(np.float64)
+        assert np.abs(got - ref).sum() / np.abs(ref).sum() <= GRAD_REL, k
+
+
+# ---------------------------------------------------------------- full size: properties (no oracle run)
+def test_full_size_properties_1M_1080p():
+    sc = S.make_cloud(1_000_000, seed=1234)
+    st = S.camera_settings(1920, 1080, 49.1, 30.0, 22.5, 2.2, bg=(1, 1, 1))
+    c1, r1, d1, a1, *_ = hip_forward(sc, st)
+    c2, r2, d2, a2, *_ = hip_forward(sc, st)
+    assert torch.equal(c1, c2) and torch.equal(r1, r2) and torch.equal(a1, a2)      # forward is deterministic
+    assert a1.min().item() >= 0 and a1.max().item() <= 1 + 1e-5
+    assert torch.isfinite(c1).all()
+    # affine in bg: C(bg) = C(0) + (1 - alpha) * bg
+    st0 = dict(st, bg=np.zeros(3, np.float32))
+    c0, _, _, a0, *_ = hip_forward(sc, st0)
+    assert (c1 - (c0 + (1 - a0))).abs().max().item() <= 2e-6
+    # input order does not matter beyond float association (depth ties are broken by index)
+    perm = np.random.default_rng(0).permutation(1_000_000)
+    scp = {k: v[perm] for k, v in sc.items()}
+    cp, rp, dp, ap, *_ = hip_forward(scp, st)
+    assert (cp - c1).abs().mean().item() <= 1e-6
+    assert torch.equal(rp.cpu(), r1.cpu()[torch.tensor(perm)])
+    assert (r1 > 0).sum().item() > 500000
+
+
+# ---------------------------------------------------------------- edge cases
+def test_edge_cases():
+    from diff_gaussian_rasterization import GaussianRasterizer
+    st = S.camera_settings(40, 24, 49.1, 0, 0, 2.0, bg=(0.1, 0.2, 0.3))
+    bgv = torch.tensor([0.1, 0.2, 0.3], device="cuda").reshape(3, 1, 1)
+    # N = 0
+    sc0 = {"means3D": np.zeros((0, 3), np.float32), "opacities": np.zeros((0, 1), np.float32), "shs": np.zeros((0, 16, 3), np.float32),
+           "scales": np.zeros((0, 3), np.float32), "rotations": np.zeros((0, 4), np.float32)}
+    color, radii, depth, alpha, *_ = hip_forward(sc0, st)
+    assert torch.allclose(color, bgv.expand_as(color)) and alpha.abs().max().item() == 0 and radii.numel() == 0
+    # all culled (behind the camera) -> background, zero gradients
+    sc = S.make_small_scene(N=10)
+    sc["means3D"] = sc["means3D"] + np.array([0, 0, 10], np.float32)
+    color, radii, depth, alpha, inp, m2d = hip_forward(sc, st, requires_grad=True)
+    assert (radii == 0).all() and torch.allclose(color, bgv.expand_as(color))
+    color.sum().backward()
+    assert all(inp[k].grad.abs().max().item() == 0 for k in ("means3D", "opacities", "shs", "scales", "rotations"))
+    # one huge Gaussian covering every tile
+    big = {"means3D": np.zeros((1, 3), np.float32), "opacities": np.full((1, 1), 0.9, np.float32), "shs": np.ones((1, 16, 3), np.float32),
+           "scales": np.full((1, 3), 5.0, np.float32), "rotations": np.array([[1, 0, 0, 0]], np.float32)}
+    color, radii, depth, alpha, *_ = hip_forward(big, st)
+    oc, orad, od, oa, _ = oracle_forward(big, st)
+    assert (radii.cpu().numpy() == orad).all() and np.abs(alpha.cpu().numpy() - oa).max() < 1e-5
+    # argument rules keep the dependency's messages
+    rast = GaussianRasterizer(hip_settings(st, "cuda"))
+    t = {k: _dev(sc[k], torch.float32) for k in sc}
+    with pytest.raises(Exception, match="excatly one of either SHs"):
+        rast(means3D=t["means3D"], means2D=None, opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"])
+    with pytest.raises(Exception, match="scale/rotation pair or precomputed 3D covariance"):
+        rast(means3D=t["means3D"], means2D=None, opacities=t["opacities"], shs=t["shs"])
+    # markVisible
+    vis = rast.markVisible(_dev(S.make_small_scene(N=100)["means3D"] * 3, torch.float32))
+    ref = O.mark_visible(S.make_small_scene(N=100)["means3D"] * 3, st["viewmatrix"], st["projmatrix"])
+    assert (vis.cpu().numpy() == ref).all()
+    # works under inference_mode (the orbit-renderer nodes run that way: nodes.py worker thread)
+    with torch.inference_mode():
+        c, *_ = hip_forward(S.make_small_scene(N=20), st)
+    assert torch.isfinite(c).all()
