@@ -32,6 +32,7 @@ _SIGNATURES = {
     "c3d_gs_geom_bytes": (sz, [i32]),
     "c3d_gs_binning_bytes": (sz, [i64, i32, i32]),
     "c3d_gs_image_bytes": (sz, [i32, i32]),
+    "c3d_gs_backward_scratch_bytes": (sz, [i32, i64]),
     "c3d_gs_forward_project": (C.c_int, [C.POINTER(GsSettings), i32, i32] + [vp] * 7 + [vp, vp, C.POINTER(i64), vp]),
     "c3d_gs_forward_render": (C.c_int, [C.POINTER(GsSettings), i32, i32, vp, vp, i64, vp, vp, vp, vp, vp, vp]),
     "c3d_gs_backward": (C.c_int, [C.POINTER(GsSettings), i32, i32] + [vp] * 6 + [vp, vp, i64, vp, vp] + [vp] * 3 + [vp] * 8 + [vp, vp]),

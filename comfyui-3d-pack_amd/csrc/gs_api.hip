@@ -61,6 +61,7 @@ size_t c3d_gs_binning_bytes(int64_t D, int32_t H, int32_t W) {
     return b.bytes;
 }
 size_t c3d_gs_image_bytes(int32_t H, int32_t W) { GsImage im; gs_carve_image(nullptr, W, H, im); return im.bytes; }
+size_t c3d_gs_backward_scratch_bytes(int32_t N, int64_t D) { (void)N; return c3d_align(sizeof(float) * GS_PAIR_FLOATS * (size_t)(D > 0 ? D : 1)); }
 
 int c3d_gs_forward_project(const c3d_gs_settings* st, int32_t N, int32_t M, const float* means3D, const float* shs,
                            const float* colors_precomp, const float* opacities, const float* scales,
@@ -115,7 +116,7 @@ int c3d_gs_forward_render(const c3d_gs_settings* st, int32_t N, int32_t M, const
         { C3dProfScope ps(C3D_P_EMIT, s);
         if ((rc = gs_launch_emit(p, g, sort_result_index(32), radii, b, s))) return rc; }
         C3dProfScope ps2(C3D_P_TILE_SORT, s);
-        if ((rc = c3d_sort_pairs_u32(b.tkey[0], b.tkey[1], b.tval[0], b.tval[1], false, (size_t)num_rendered, tile_sort_bits(tiles), b.tmp, &res, s))) return rc;
+        if ((rc = c3d_sort_pairs_u32(b.tkey[0], b.tkey[1], b.tval[0], b.tval[1], true, (size_t)num_rendered, tile_sort_bits(tiles), b.tmp, &res, s))) return rc;
         if (res != sort_result_index(tile_sort_bits(tiles))) { c3d_set_error("internal: tile sort buffer parity"); return -2; }
     }
     { C3dProfScope ps(C3D_P_RANGES, s);
@@ -130,7 +131,7 @@ int c3d_gs_backward(const c3d_gs_settings* st, int32_t N, int32_t M, const float
                     const void* binning_buffer, const void* image_buffer, const float* dL_dcolor,
                     const float* dL_ddepth, const float* dL_dalpha, float* dL_dmeans2D, float* dL_dcolors,
                     float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscales,
-                    float* dL_drotations, float* scratch, c3d_stream_t stream) {
+                    float* dL_drotations, void* scratch, c3d_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     GsParams p;
     if (make_params(st, N, M, p)) return -1;
@@ -149,23 +150,17 @@ int c3d_gs_backward(const c3d_gs_settings* st, int32_t N, int32_t M, const float
     gs_carve_binning((char*)binning_buffer, num_rendered, tiles, b);
     GsImage im;
     gs_carve_image((char*)image_buffer, p.W, p.H, im);
-    float* dL_dconic = scratch;              // [N,4]
-    float* dL_ddepths = scratch + 4 * (size_t)N;  // [N]
-    C3D_CHECK(hipMemsetAsync(scratch, 0, sizeof(float) * 5 * (size_t)N, s));
-    C3D_CHECK(hipMemsetAsync(dL_dmeans2D, 0, sizeof(float) * 3 * (size_t)N, s));
-    C3D_CHECK(hipMemsetAsync(dL_dcolors, 0, sizeof(float) * 3 * (size_t)N, s));
-    C3D_CHECK(hipMemsetAsync(dL_dopacity, 0, sizeof(float) * (size_t)N, s));
+    float* pairgrad = (float*)scratch;   // [num_rendered][GS_PAIR_FLOATS]
     int rc;
     if (num_rendered > 0 && tiles > 0) {
         if (!binning_buffer || !image_buffer) { c3d_set_error("c3d_gs_backward: NULL state buffer"); return -1; }
         const int res = sort_result_index(tile_sort_bits(tiles));
         C3dProfScope ps(C3D_P_COMPOSITE_BWD, s);
-        if ((rc = gs_launch_composite_bwd(p, g, b, res, im, dL_dcolor, dL_ddepth, dL_dalpha, dL_dmeans2D, dL_dconic, dL_dopacity,
-                                          dL_dcolors, dL_ddepths, s))) return rc;
+        if ((rc = gs_launch_composite_bwd(p, g, b, res, im, dL_dcolor, dL_ddepth, dL_dalpha, pairgrad, s))) return rc;
     }
     C3dProfScope ps(C3D_P_PREPROCESS_BWD, s);
-    return gs_launch_preprocess_bwd(p, g, radii, means3D, shs, colors_precomp, scales, rotations, cov3D_precomp, dL_dmeans2D, dL_dconic,
-                                    dL_dcolors, dL_ddepths, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, s);
+    return gs_launch_preprocess_bwd(p, g, radii, means3D, shs, colors_precomp, scales, rotations, cov3D_precomp, pairgrad, dL_dmeans2D,
+                                    dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, s);
 }
 
 int c3d_gs_mark_visible(int32_t N, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present, c3d_stream_t stream) {
@@ -177,9 +172,9 @@ int c3d_gs_mark_visible(int32_t N, const float* means3D, const float* viewmatrix
 __global__ void k_debug_unpack(int N, GsGeom g, float* xy, float* depths, float* conic_opacity, float* rgb, uint32_t* tiles) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
-    const bool vis = g.tiles[i] > 0;
+    const bool vis = g.key[0] != nullptr;   // records of culled Gaussians are never written; callers mask with radii
     const float4 a0 = vis ? g.rec0[i] : make_float4(0, 0, 0, 0), a1 = vis ? g.rec1[i] : make_float4(0, 0, 0, 0);
-    const float2 a2 = vis ? g.rec2[i] : make_float2(0, 0);
+    const float4 a2 = vis ? g.rec2[i] : make_float4(0, 0, 0, 0);
     if (xy) { xy[2 * i] = a0.x; xy[2 * i + 1] = a0.y; }
     if (depths) depths[i] = a2.y;
     if (conic_opacity) { conic_opacity[4 * i] = a0.z; conic_opacity[4 * i + 1] = a0.w; conic_opacity[4 * i + 2] = a1.x; conic_opacity[4 * i + 3] = a1.y; }
@@ -201,7 +196,8 @@ int c3d_gs_debug_state(int32_t N, int32_t H, int32_t W, const void* geom_buffer,
         GsBinning b;
         gs_carve_binning((char*)binning_buffer, D, tiles, b);
         const int res = sort_result_index(tile_sort_bits(tiles));
-        if (point_list && D > 0) C3D_CHECK(hipMemcpyAsync(point_list, b.tval[res], sizeof(uint32_t) * (size_t)D, hipMemcpyDeviceToDevice, s));
+        (void)res;
+        if (point_list && D > 0) C3D_CHECK(hipMemcpyAsync(point_list, b.point_list, sizeof(uint32_t) * (size_t)D, hipMemcpyDeviceToDevice, s));
         if (ranges) C3D_CHECK(hipMemcpyAsync(ranges, b.ranges, sizeof(uint2) * (size_t)tiles, hipMemcpyDeviceToDevice, s));
     }
     return 0;

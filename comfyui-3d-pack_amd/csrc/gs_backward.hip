@@ -3,49 +3,81 @@
 // Function behind main_3DGS_renderer.py:927-936 (reference call site) must return.
 #include "gs_internal.h"
 #include "gs_math.h"
+#include <stdlib.h>
 
-// --- wave64 sum via DPP: result valid in lanes 48..63 (read lane 63) ---------------------------------
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_f(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+// --- wave64 reductions -------------------------------------------------------------------------------
+// Four per-lane values are summed across the 64 lanes for the price of ~2.5 VALU ops per value:
+// v_permlane32_swap / v_permlane16_swap (gfx950) fold two registers into one while halving the lane span,
+// then four DPP adds finish inside each 16-lane row.  Result register: every lane of row 0 holds sum(a),
+// row 1 sum(c), row 2 sum(b), row 3 sum(d).   (The swaps are issued as inline asm: hipcc 7.2's builtins
+// __builtin_amdgcn_permlane{16,32}_swap return the first result in both elements.)
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
 }
-__device__ __forceinline__ float wave_sum_to_lane63(float v) {
-    v += dpp_f<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
-    v += dpp_f<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
-    v += dpp_f<0x141, 0xF>(v);  // row_half_mirror
-    v += dpp_f<0x140, 0xF>(v);  // row_mirror      -> every lane holds its 16-lane row sum
-    v += dpp_f<0x142, 0xA>(v);  // row_bcast15 into rows 1,3
-    v += dpp_f<0x143, 0xC>(v);  // row_bcast31 into rows 2,3 -> row 3 holds the wave sum
-    return v;
+__device__ __forceinline__ void swap32(float& a, float& b) {   // a[32..63] <-> b[0..31]
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void swap16(float& a, float& b) {   // rows 1,3 of a <-> rows 0,2 of b
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float wave_reduce4(float a, float b, float c, float d) {
+    swap32(a, b); float p = a + b;      // lanes 0-31: a folded to 32 partials | lanes 32-63: b
+    swap32(c, d); float q = c + d;      // c | d
+    swap16(p, q); float t = p + q;      // rows: a, c, b, d  (16 partials each)
+    t = dpp_add<0xB1>(t);               // quad_perm [1,0,3,2]
+    t = dpp_add<0x4E>(t);               // quad_perm [2,3,0,1]
+    t = dpp_add<0x141>(t);              // row_half_mirror
+    t = dpp_add<0x140>(t);              // row_mirror
+    return t;
 }
 
 // ------------------------------------------------------------------------------------------
-// A7 composite backward: same tiling as the forward pass, splats visited back to front.  Every lane
-// re-derives alpha/T for its pixel; the ten per-splat partial gradients are summed across the wave
-// with DPP adds and leave the wave as ONE atomic per quantity (256x fewer atomics than one per pixel).
+// A7 composite backward: same tiling and per-wave ballot-compacted splat lists as the forward pass
+// (wave w = 8x8 quadrant, one pixel per lane), splats visited back to front in rounds of 128.
+// Every lane re-derives alpha/T for its pixel.  The ten per-splat partial gradients are summed across the
+// wave (wave_reduce4), parked in LDS per (wave, splat), summed over the four waves in a fixed order and
+// written ONCE as a 48-byte record per (tile, splat) pair at the pair's emit index.  The pairs of one
+// Gaussian are contiguous there, so the per-Gaussian kernel (A8) sums them without a single atomic:
+// the whole backward pass is deterministic.
+// record layout (GS_PAIR_FLOATS = 12): [c0, c2, c1, depth | mean.x, conic.xx, mean.y, conic.xy | conic.yy, 0, opacity, 0]
 // ------------------------------------------------------------------------------------------
+#define BWD_ROUND 128
+
+__device__ __forceinline__ uint32_t quadrant_mask_b(const float4 a0, const float4 a2, int X0, int Y0) {
+    const float xl = a0.x - a2.z, xh = a0.x + a2.z, yl = a0.y - a2.w, yh = a0.y + a2.w;
+    const bool cx0 = (xh >= (float)X0) && (xl <= (float)(X0 + 7));
+    const bool cx1 = (xh >= (float)(X0 + 8)) && (xl <= (float)(X0 + 15));
+    const bool cy0 = (yh >= (float)Y0) && (yl <= (float)(Y0 + 7));
+    const bool cy1 = (yh >= (float)(Y0 + 8)) && (yl <= (float)(Y0 + 15));
+    return (uint32_t)(cx0 && cy0) | ((uint32_t)(cx1 && cy0) << 1) | ((uint32_t)(cx0 && cy1) << 2) | ((uint32_t)(cx1 && cy1) << 3);
+}
+
 __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+                                                        const uint32_t* __restrict__ e_sorted,
                                                         const float4* __restrict__ rec0, const float4* __restrict__ rec1,
-                                                        const float2* __restrict__ rec2, const float* __restrict__ final_T,
+                                                        const float4* __restrict__ rec2, const float* __restrict__ final_T,
                                                         const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor,
                                                         const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha_px,
-                                                        float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic,
-                                                        float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolors,
-                                                        float* __restrict__ dL_ddepths, int chunk) {
-    __shared__ float4 s0[256];
-    __shared__ float4 s1[256];
-    __shared__ float2 s2[256];
-    __shared__ uint32_t sid[256];
+                                                        float4* __restrict__ pairgrad, int chunk) {
+    __shared__ float4 s0[BWD_ROUND];
+    __shared__ float4 s1[BWD_ROUND];
+    __shared__ float4 s2[BWD_ROUND];
+    __shared__ uint32_t se[BWD_ROUND];
+    __shared__ uint32_t smask[BWD_ROUND];
+    __shared__ float acc[4][GS_PAIR_FLOATS][BWD_ROUND];
+    __shared__ int s_maxlast;
     const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
     if (tile >= p.gx * p.gy) return;
     const int tx = tile % p.gx, ty = tile / p.gx;
-    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
-    const int pxi = tx * C3D_TILE_X + lx, pyi = ty * C3D_TILE_Y + ly;
+    const int lane = c3d_lane(), wave = threadIdx.x >> 6;
+    const int X0 = tx * C3D_TILE_X, Y0 = ty * C3D_TILE_Y;
+    const int pxi = X0 + ((wave & 1) << 3) + (lane & 7), pyi = Y0 + ((wave >> 1) << 3) + (lane >> 3);
     const bool inside = pxi < p.W && pyi < p.H;
     const float pxf = (float)pxi, pyf = (float)pyi;
     const uint2 rg = ranges[tile];
+    const int todo = (int)(rg.y - rg.x);
     const size_t P = (size_t)p.W * p.H, pid = (size_t)pyi * p.W + pxi;
-    const int lane = c3d_lane();
 
     const float T_final = inside ? final_T[pid] : 0.f;
     float T = T_final;
@@ -61,93 +93,111 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
     float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, ld = 0.f;
     const float ddelx_dx = 0.5f * p.W, ddely_dy = 0.5f * p.H;
 
-    // the whole tile can skip list positions no pixel reached
-    __shared__ int s_maxlast;
+    // list positions no pixel of the tile reached need no work beyond a zero record
     if (threadIdx.x == 0) s_maxlast = 0;
     __syncthreads();
     atomicMax(&s_maxlast, last);
     __syncthreads();
     const int upto = s_maxlast;   // positions [0, upto) matter
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int pos = upto + (int)threadIdx.x; pos < todo; pos += 256) {
+        float4* r = pairgrad + (size_t)e_sorted[rg.x + pos] * 3;
+        r[0] = z4; r[1] = z4; r[2] = z4;
+    }
 
-    for (int base = 0; base < upto; base += 256) {
+    for (int base = 0; base < upto; base += BWD_ROUND) {
         __syncthreads();
-        const int n = min(256, upto - base);
+        const int n = min(BWD_ROUND, upto - base);
         if ((int)threadIdx.x < n) {
-            const uint32_t gid = point_list[rg.x + (upto - 1 - base - threadIdx.x)];
-            sid[threadIdx.x] = gid;
-            s0[threadIdx.x] = rec0[gid]; s1[threadIdx.x] = rec1[gid]; s2[threadIdx.x] = rec2[gid];
+            const int pos = rg.x + (upto - 1 - base - threadIdx.x);
+            const uint32_t gid = point_list[pos];
+            const float4 a0 = rec0[gid], a2 = rec2[gid];
+            se[threadIdx.x] = e_sorted[pos];
+            s0[threadIdx.x] = a0; s1[threadIdx.x] = rec1[gid]; s2[threadIdx.x] = a2;
+            smask[threadIdx.x] = quadrant_mask_b(a0, a2, X0, Y0);
         }
         __syncthreads();
-        for (int j = 0; j < n; j++) {
-            const int k = upto - 1 - base - j;   // list position of this splat
-            const float4 a0 = s0[j], a1 = s1[j];
-            const float2 a2 = s2[j];
-            const float dx = a0.x - pxf, dy = a0.y - pyf;
-            const float power = -0.5f * (a0.z * dx * dx + a1.x * dy * dy) - a0.w * dx * dy;
-            const float G = __expf(power);
-            const float alpha = fminf(0.99f, a1.y * G);
-            const bool act = (k < last) && (power <= 0.f) && (alpha >= 1.f / 255.f);
-            if (__ballot(act) == 0ull) continue;   // wave-uniform skip
-
-            float g_c0 = 0.f, g_c1 = 0.f, g_c2 = 0.f, g_d = 0.f, g_mx = 0.f, g_my = 0.f, g_cx = 0.f, g_cy = 0.f, g_cw = 0.f, g_o = 0.f;
-            if (act) {
-                T = T / (1.f - alpha);
-                const float dch = alpha * T;
-                float dL_dalpha;
-                acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0; lc0 = a1.z;
-                acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1; lc1 = a1.w;
-                acc2 = last_alpha * lc2 + (1.f - last_alpha) * acc2; lc2 = a2.x;
-                dL_dalpha = (a1.z - acc0) * dLp0 + (a1.w - acc1) * dLp1 + (a2.x - acc2) * dLp2;
-                g_c0 = dch * dLp0; g_c1 = dch * dLp1; g_c2 = dch * dLp2;
-                accd = last_alpha * ld + (1.f - last_alpha) * accd; ld = a2.y;
-                dL_dalpha += (a2.y - accd) * dLd;
-                g_d = dch * dLd;
-                acca = last_alpha + (1.f - last_alpha) * acca;
-                dL_dalpha += (1.f - acca) * dLa;
-                dL_dalpha *= T;
-                last_alpha = alpha;
-                dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
-                const float dL_dG = a1.y * dL_dalpha;
-                const float gdx = G * dx, gdy = G * dy;
-                g_mx = dL_dG * (-gdx * a0.z - gdy * a0.w) * ddelx_dx;
-                g_my = dL_dG * (-gdy * a1.x - gdx * a0.w) * ddely_dy;
-                g_cx = -0.5f * gdx * dx * dL_dG;
-                g_cy = -0.5f * gdx * dy * dL_dG;
-                g_cw = -0.5f * gdy * dy * dL_dG;
-                g_o = G * dL_dalpha;
+        for (int c = 0; c < n; c += 64) {
+            const int jj = c + lane;
+            uint64_t m = __ballot(jj < n && ((smask[jj] >> wave) & 1u));
+            while (m) {
+                const int j = c + (int)__builtin_ctzll(m);
+                m &= m - 1;
+                const int k = upto - 1 - base - j;   // list position of this splat
+                const float4 a0 = s0[j], a1 = s1[j], a2 = s2[j];
+                const float dx = a0.x - pxf, dy = a0.y - pyf;
+                const float power = -0.5f * (a0.z * dx * dx + a1.x * dy * dy) - a0.w * dx * dy;
+                const float G = __expf(power);
+                const float alpha = fminf(0.99f, a1.y * G);
+                const bool act = (k < last) && (power <= 0.f) && (alpha >= 1.f / 255.f);
+                float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+                if (__ballot(act) != 0ull) {   // wave-uniform
+                    float g_c0 = 0.f, g_c1 = 0.f, g_c2 = 0.f, g_d = 0.f, g_mx = 0.f, g_my = 0.f, g_cx = 0.f, g_cy = 0.f, g_cw = 0.f, g_o = 0.f;
+                    if (act) {
+                        T = T / (1.f - alpha);
+                        const float dch = alpha * T;
+                        float dL_dalpha;
+                        acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0; lc0 = a1.z;
+                        acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1; lc1 = a1.w;
+                        acc2 = last_alpha * lc2 + (1.f - last_alpha) * acc2; lc2 = a2.x;
+                        dL_dalpha = (a1.z - acc0) * dLp0 + (a1.w - acc1) * dLp1 + (a2.x - acc2) * dLp2;
+                        g_c0 = dch * dLp0; g_c1 = dch * dLp1; g_c2 = dch * dLp2;
+                        accd = last_alpha * ld + (1.f - last_alpha) * accd; ld = a2.y;
+                        dL_dalpha += (a2.y - accd) * dLd;
+                        g_d = dch * dLd;
+                        acca = last_alpha + (1.f - last_alpha) * acca;
+                        dL_dalpha += (1.f - acca) * dLa;
+                        dL_dalpha *= T;
+                        last_alpha = alpha;
+                        dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
+                        const float dL_dG = a1.y * dL_dalpha;
+                        const float gdx = G * dx, gdy = G * dy;
+                        g_mx = dL_dG * (-gdx * a0.z - gdy * a0.w) * ddelx_dx;
+                        g_my = dL_dG * (-gdy * a1.x - gdx * a0.w) * ddely_dy;
+                        g_cx = -0.5f * gdx * dx * dL_dG;
+                        g_cy = -0.5f * gdx * dy * dL_dG;
+                        g_cw = -0.5f * gdy * dy * dL_dG;
+                        g_o = G * dL_dalpha;
+                    }
+                    t0 = wave_reduce4(g_c0, g_c1, g_c2, g_d);      // rows: c0, c2, c1, depth
+                    t1 = wave_reduce4(g_mx, g_my, g_cx, g_cy);     // rows: mx, cx, my, cy
+                    t2 = wave_reduce4(g_cw, g_o, 0.f, 0.f);        // rows: cw, 0, o, 0
+                }
+                if ((lane & 15) == 0) {   // lanes 0,16,32,48: one row each
+                    const int row = lane >> 4;
+                    acc[wave][row][j] = t0; acc[wave][4 + row][j] = t1; acc[wave][8 + row][j] = t2;
+                }
             }
-            g_c0 = wave_sum_to_lane63(g_c0); g_c1 = wave_sum_to_lane63(g_c1); g_c2 = wave_sum_to_lane63(g_c2);
-            g_d = wave_sum_to_lane63(g_d);
-            g_mx = wave_sum_to_lane63(g_mx); g_my = wave_sum_to_lane63(g_my);
-            g_cx = wave_sum_to_lane63(g_cx); g_cy = wave_sum_to_lane63(g_cy); g_cw = wave_sum_to_lane63(g_cw);
-            g_o = wave_sum_to_lane63(g_o);
-            if (lane == 63) {
-                const uint32_t gid = sid[j];
-                atomicAdd(&dL_dcolors[3 * gid + 0], g_c0);
-                atomicAdd(&dL_dcolors[3 * gid + 1], g_c1);
-                atomicAdd(&dL_dcolors[3 * gid + 2], g_c2);
-                atomicAdd(&dL_ddepths[gid], g_d);
-                atomicAdd(&dL_dmean2D[3 * gid + 0], g_mx);
-                atomicAdd(&dL_dmean2D[3 * gid + 1], g_my);
-                atomicAdd(&dL_dconic[4 * gid + 0], g_cx);
-                atomicAdd(&dL_dconic[4 * gid + 1], g_cy);
-                atomicAdd(&dL_dconic[4 * gid + 3], g_cw);
-                atomicAdd(&dL_dopacity[gid], g_o);
-            }
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < n) {   // one record per (tile, splat): fixed-order sum over the waves that handled it
+            const int j = threadIdx.x;
+            const uint32_t mk = smask[j];
+            float r[GS_PAIR_FLOATS];
+#pragma unroll
+            for (int q = 0; q < GS_PAIR_FLOATS; q++) r[q] = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; w++)
+                if ((mk >> w) & 1u) {
+#pragma unroll
+                    for (int q = 0; q < GS_PAIR_FLOATS; q++) r[q] += acc[w][q][j];
+                }
+            float4* out = pairgrad + (size_t)se[j] * 3;
+            out[0] = make_float4(r[0], r[1], r[2], r[3]);
+            out[1] = make_float4(r[4], r[5], r[6], r[7]);
+            out[2] = make_float4(r[8], r[9], r[10], r[11]);
         }
     }
 }
 
 int gs_launch_composite_bwd(const GsParams& p, const GsGeom& g, const GsBinning& b, int res, const GsImage& im,
                             const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
-                            float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolors,
-                            float* dL_ddepths, hipStream_t s) {
+                            float* pairgrad, hipStream_t s) {
     const int tiles = p.gx * p.gy;
     if (tiles == 0) return 0;
     const int chunk = c3d_cdiv(tiles, 8);
-    hipLaunchKernelGGL(k_composite_bwd, dim3(chunk * 8), dim3(256), 0, s, p, b.ranges, b.tval[res], g.rec0, g.rec1, g.rec2,
-                       im.final_T, im.n_contrib, dL_dcolor, dL_ddepth, dL_dalpha, dL_dmean2D, dL_dconic, dL_dopacity,
-                       dL_dcolors, dL_ddepths, chunk);
+    hipLaunchKernelGGL(k_composite_bwd, dim3(chunk * 8), dim3(256), 0, s, p, b.ranges, b.point_list, b.tval[res], g.rec0, g.rec1, g.rec2,
+                       im.final_T, im.n_contrib, dL_dcolor, dL_ddepth, dL_dalpha, (float4*)pairgrad, chunk);
     C3D_LAUNCH_CHECK();
     return 0;
 }
@@ -183,15 +233,18 @@ __device__ __forceinline__ void sh_basis_grad(int deg, float x, float y, float z
 __global__ void __launch_bounds__(256) k_preprocess_bwd(GsParams p, GsGeom g, const int* __restrict__ radii, const float* __restrict__ means3D,
                                                          const float* __restrict__ shs, const float* __restrict__ colors_precomp,
                                                          const float* __restrict__ scales, const float* __restrict__ rotations,
-                                                         const float* __restrict__ cov3D_precomp, const float* __restrict__ dL_dmean2D,
-                                                         const float* __restrict__ dL_dconic, const float* __restrict__ dL_dcolors,
-                                                         const float* __restrict__ dL_ddepths, float* __restrict__ dL_dmeans3D,
+                                                         const float* __restrict__ cov3D_precomp, const float4* __restrict__ pairgrad,
+                                                         float* __restrict__ dL_dmean2D, float* __restrict__ dL_dcolors,
+                                                         float* __restrict__ dL_dopacity, float* __restrict__ dL_dmeans3D,
                                                          float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
                                                          float* __restrict__ dL_dscales, float* __restrict__ dL_drots) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= p.N) return;
     if (radii[idx] <= 0) {
         // culled: this kernel owns its outputs (callers allocate them uninitialised)
+        dL_dmean2D[3 * idx] = 0.f; dL_dmean2D[3 * idx + 1] = 0.f; dL_dmean2D[3 * idx + 2] = 0.f;
+        dL_dcolors[3 * idx] = 0.f; dL_dcolors[3 * idx + 1] = 0.f; dL_dcolors[3 * idx + 2] = 0.f;
+        dL_dopacity[idx] = 0.f;
         dL_dmeans3D[3 * idx] = 0.f; dL_dmeans3D[3 * idx + 1] = 0.f; dL_dmeans3D[3 * idx + 2] = 0.f;
         if (dL_dcov3D) {
 #pragma unroll
@@ -207,6 +260,28 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GsParams p, GsGeom g, co
         }
         return;
     }
+    // sum this Gaussian's (tile, splat) records: contiguous in emit order, fixed order -> deterministic
+    float pr[GS_PAIR_FLOATS];
+#pragma unroll
+    for (int q = 0; q < GS_PAIR_FLOATS; q++) pr[q] = 0.f;
+    {
+        const uint32_t r = g.rank_of[idx];
+        const uint32_t e0 = r ? g.offsets[r - 1] : 0u, e1 = g.offsets[r];
+        for (uint32_t e = e0; e < e1; e++) {
+            const float4 v0 = pairgrad[(size_t)e * 3], v1 = pairgrad[(size_t)e * 3 + 1], v2 = pairgrad[(size_t)e * 3 + 2];
+            pr[0] += v0.x; pr[1] += v0.y; pr[2] += v0.z; pr[3] += v0.w;
+            pr[4] += v1.x; pr[5] += v1.y; pr[6] += v1.z; pr[7] += v1.w;
+            pr[8] += v2.x; pr[10] += v2.z;
+        }
+    }
+    const float gcol[3] = {pr[0], pr[2], pr[1]};          // record rows: c0, c2, c1
+    const float g_depth = pr[3];
+    const float g2x = pr[4], g2y = pr[6];
+    const float dcx = pr[5], dcy = pr[7], dcz = pr[8];
+    dL_dmean2D[3 * idx] = g2x; dL_dmean2D[3 * idx + 1] = g2y; dL_dmean2D[3 * idx + 2] = 0.f;
+    dL_dcolors[3 * idx] = gcol[0]; dL_dcolors[3 * idx + 1] = gcol[1]; dL_dcolors[3 * idx + 2] = gcol[2];
+    dL_dopacity[idx] = pr[10];
+
     const Mat16 V = load_mat16(p.view), PJ = load_mat16(p.proj);
     const float3 m = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
     float c3[6];
@@ -227,7 +302,6 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GsParams p, GsGeom g, co
     const float a = T2[0][0] * ST0[0] + T2[0][1] * ST0[1] + T2[0][2] * ST0[2] + 0.3f;
     const float b = T2[0][0] * ST1[0] + T2[0][1] * ST1[1] + T2[0][2] * ST1[2];
     const float c = T2[1][0] * ST1[0] + T2[1][1] * ST1[1] + T2[1][2] * ST1[2] + 0.3f;
-    const float dcx = dL_dconic[4 * idx], dcy = dL_dconic[4 * idx + 1], dcz = dL_dconic[4 * idx + 3];
     const float denom = a * c - b * b;
     const float d2i = 1.f / (denom * denom + 0.0000001f);
     float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
@@ -269,14 +343,13 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GsParams p, GsGeom g, co
     const float4 mh = xform4x4(m, PJ);
     const float mw = 1.f / (mh.w + 0.0000001f);
     const float mul1 = mh.x * mw * mw, mul2 = mh.y * mw * mw;
-    const float g2x = dL_dmean2D[3 * idx], g2y = dL_dmean2D[3 * idx + 1];
 #pragma unroll
     for (int j = 0; j < 3; j++)
         dmean[j] += (PJ.m[4 * j] * mw - PJ.m[4 * j + 3] * mul1) * g2x + (PJ.m[4 * j + 1] * mw - PJ.m[4 * j + 3] * mul2) * g2y;
     // depth output -> 3D mean
     {
         const float mul3 = V.m[2] * m.x + V.m[6] * m.y + V.m[10] * m.z + V.m[14];
-        const float gd = dL_ddepths[idx];
+        const float gd = g_depth;
 #pragma unroll
         for (int j = 0; j < 3; j++) dmean[j] += (V.m[4 * j + 2] - V.m[4 * j + 3] * mul3) * gd;
     }
@@ -290,7 +363,7 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GsParams p, GsGeom g, co
         sh_basis(p.deg, dxn, dyn, dzn, B);
         sh_basis_grad(p.deg, dxn, dyn, dzn, dB);
         const uint8_t cl = g.clamped[idx];
-        const float dRGB[3] = {(cl & 1) ? 0.f : dL_dcolors[3 * idx], (cl & 2) ? 0.f : dL_dcolors[3 * idx + 1], (cl & 4) ? 0.f : dL_dcolors[3 * idx + 2]};
+        const float dRGB[3] = {(cl & 1) ? 0.f : gcol[0], (cl & 2) ? 0.f : gcol[1], (cl & 4) ? 0.f : gcol[2]};
         const float* sh = shs + (size_t)idx * p.M * 3;
         float* dsh = dL_dsh + (size_t)idx * p.M * 3;
         const int nc = sh_ncoef(p.deg);
@@ -340,11 +413,11 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GsParams p, GsGeom g, co
 
 int gs_launch_preprocess_bwd(const GsParams& p, const GsGeom& g, const int* radii, const float* means3D, const float* shs,
                              const float* colors_precomp, const float* scales, const float* rotations, const float* cov3D_precomp,
-                             const float* dL_dmean2D, const float* dL_dconic, const float* dL_dcolors, const float* dL_ddepths,
+                             const float* pairgrad, float* dL_dmean2D, float* dL_dcolors, float* dL_dopacity,
                              float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscales, float* dL_drots, hipStream_t s) {
     if (p.N == 0) return 0;
     hipLaunchKernelGGL(k_preprocess_bwd, dim3(c3d_cdiv(p.N, 256)), dim3(256), 0, s, p, g, radii, means3D, shs, colors_precomp, scales,
-                       rotations, cov3D_precomp, dL_dmean2D, dL_dconic, dL_dcolors, dL_ddepths, dL_dmeans3D, dL_dcov3D, dL_dsh,
+                       rotations, cov3D_precomp, (const float4*)pairgrad, dL_dmean2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh,
                        dL_dscales, dL_drots);
     C3D_LAUNCH_CHECK();
     return 0;

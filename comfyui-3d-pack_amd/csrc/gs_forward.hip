@@ -6,7 +6,7 @@
 #include "gs_math.h"
 
 // ------------------------------------------------------------------------------------------
-// A1 preprocess: one lane per Gaussian.  Streams xyz/scale/rot/opacity/SH once, writes the 40-B
+// A1 preprocess: one lane per Gaussian.  Streams xyz/scale/rot/opacity/SH once, writes the 48-B
 // projected record, the depth-sort key and the tile count.
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_preprocess(GsParams p, const float* __restrict__ means3D, const float* __restrict__ shs,
@@ -54,6 +54,12 @@ __global__ void __launch_bounds__(256) k_preprocess(GsParams p, const float* __r
     int x0, y0, x1, y1;
     tile_rect(px, py, rad, p.gx, p.gy, x0, y0, x1, y1);
     if ((x1 - x0) * (y1 - y0) == 0) return;
+    // from here on the Gaussian counts as visible (radii > 0), exactly as in the dependency; the tile list
+    // it is emitted to is narrowed to the tiles where alpha can reach 1/255 (exact, see tile_rect_tight)
+    const float opac = opacities[idx];
+    const float ex = alpha_extent(opac, a), ey = alpha_extent(opac, c);
+    if (ex >= 0.f) tile_rect_tight(px, py, rad, ex, ey, p.gx, p.gy, x0, y0, x1, y1);
+    else { x1 = x0; y1 = y0; }
 
     float rgb[3];
     uint8_t cl = 0;
@@ -79,12 +85,13 @@ __global__ void __launch_bounds__(256) k_preprocess(GsParams p, const float* __r
         }
     }
     g.rec0[idx] = make_float4(px, py, c * di, -b * di);
-    g.rec1[idx] = make_float4(a * di, opacities[idx], rgb[0], rgb[1]);
-    g.rec2[idx] = make_float2(rgb[2], pv.z);
+    g.rec1[idx] = make_float4(a * di, opac, rgb[0], rgb[1]);
+    g.rec2[idx] = make_float4(rgb[2], pv.z, ex, ey);
     g.clamped[idx] = cl;
     radii[idx] = rad;
-    g.tiles[idx] = (uint32_t)((x1 - x0) * (y1 - y0));
-    g.key[0][idx] = __float_as_uint(pv.z);
+    const uint32_t nt = (uint32_t)((x1 - x0) * (y1 - y0));
+    g.tiles[idx] = nt;
+    g.key[0][idx] = nt ? __float_as_uint(pv.z) : 0xFFFFFFFFu;
 }
 
 int gs_launch_preprocess(const GsParams& p, const float* means3D, const float* shs, const float* colors_precomp,
@@ -99,13 +106,13 @@ int gs_launch_preprocess(const GsParams& p, const float* means3D, const float* s
 
 // tiles touched, gathered into depth-rank order (input of the offsets scan)
 __global__ void __launch_bounds__(256) k_gather_tiles(const uint32_t* __restrict__ order, const uint32_t* __restrict__ tiles,
-                                                       uint32_t* __restrict__ out, int N) {
+                                                       uint32_t* __restrict__ out, uint32_t* __restrict__ rank_of, int N) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < N) out[r] = tiles[order[r]];
+    if (r < N) { const uint32_t gid = order[r]; out[r] = tiles[gid]; rank_of[gid] = (uint32_t)r; }
 }
 int gs_launch_gather_tiles(const GsGeom& g, int N, int res, hipStream_t s) {
     if (N == 0) return 0;
-    hipLaunchKernelGGL(k_gather_tiles, dim3(c3d_cdiv(N, 256)), dim3(256), 0, s, g.order[res], g.tiles, g.tiles_sorted, N);
+    hipLaunchKernelGGL(k_gather_tiles, dim3(c3d_cdiv(N, 256)), dim3(256), 0, s, g.order[res], g.tiles, g.tiles_sorted, g.rank_of, N);
     C3D_LAUNCH_CHECK();
     return 0;
 }
@@ -115,35 +122,40 @@ int gs_launch_gather_tiles(const GsGeom& g, int N, int res, hipStream_t s) {
 // touched tile.  A stable sort by tile id afterwards leaves every tile's list depth-ordered.
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_emit(GsParams p, const uint32_t* __restrict__ order, const uint32_t* __restrict__ offsets,
-                                               const float4* __restrict__ rec0, const int* __restrict__ radii,
-                                               uint32_t* __restrict__ tkey, uint32_t* __restrict__ tval) {
+                                               const float4* __restrict__ rec0, const float4* __restrict__ rec2,
+                                               const int* __restrict__ radii, uint32_t* __restrict__ tkey, uint32_t* __restrict__ gid_emit) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= p.N) return;
     const uint32_t gid = order[r];
     const int rad = radii[gid];
     if (rad <= 0) return;
     uint32_t off = (r == 0) ? 0u : offsets[r - 1];
+    if (offsets[r] == off) return;   // narrowed to no tiles
     const float4 r0 = rec0[gid];
+    const float4 r2 = rec2[gid];
     int x0, y0, x1, y1;
-    tile_rect(r0.x, r0.y, rad, p.gx, p.gy, x0, y0, x1, y1);
+    tile_rect_tight(r0.x, r0.y, rad, r2.z, r2.w, p.gx, p.gy, x0, y0, x1, y1);
     for (int y = y0; y < y1; y++)
         for (int x = x0; x < x1; x++) {
             tkey[off] = (uint32_t)(y * p.gx + x);
-            tval[off] = gid;
+            gid_emit[off] = gid;
             off++;
         }
 }
 int gs_launch_emit(const GsParams& p, const GsGeom& g, int res, const int* radii, GsBinning& b, hipStream_t s) {
     if (p.N == 0) return 0;
-    hipLaunchKernelGGL(k_emit, dim3(c3d_cdiv(p.N, 256)), dim3(256), 0, s, p, g.order[res], g.offsets, g.rec0, radii, b.tkey[0], b.tval[0]);
+    hipLaunchKernelGGL(k_emit, dim3(c3d_cdiv(p.N, 256)), dim3(256), 0, s, p, g.order[res], g.offsets, g.rec0, g.rec2, radii, b.tkey[0], b.gid_emit);
     C3D_LAUNCH_CHECK();
     return 0;
 }
 
-// A5: [start,end) of every tile in the sorted pair list
-__global__ void __launch_bounds__(256) k_ranges(const uint32_t* __restrict__ tkey, uint2* __restrict__ ranges, long long D) {
+// A5: [start,end) of every tile in the sorted pair list; also resolves sorted position -> Gaussian id
+__global__ void __launch_bounds__(256) k_ranges(const uint32_t* __restrict__ tkey, const uint32_t* __restrict__ e_sorted,
+                                                 const uint32_t* __restrict__ gid_emit, uint32_t* __restrict__ point_list,
+                                                 uint2* __restrict__ ranges, long long D) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= D) return;
+    point_list[i] = gid_emit[e_sorted[i]];
     const uint32_t t = tkey[i];
     if (i == 0 || tkey[i - 1] != t) ranges[t].x = (uint32_t)i;
     if (i == D - 1 || tkey[i + 1] != t) ranges[t].y = (uint32_t)(i + 1);
@@ -151,63 +163,87 @@ __global__ void __launch_bounds__(256) k_ranges(const uint32_t* __restrict__ tke
 int gs_launch_ranges(const GsBinning& b, int res, long long D, int tiles, hipStream_t s) {
     C3D_CHECK(hipMemsetAsync(b.ranges, 0, sizeof(uint2) * (size_t)(tiles > 0 ? tiles : 1), s));
     if (D == 0) return 0;
-    hipLaunchKernelGGL(k_ranges, dim3(c3d_cdiv(D, 256)), dim3(256), 0, s, b.tkey[res], b.ranges, D);
+    hipLaunchKernelGGL(k_ranges, dim3(c3d_cdiv(D, 256)), dim3(256), 0, s, b.tkey[res], b.tval[res], b.gid_emit, b.point_list, b.ranges, D);
     C3D_LAUNCH_CHECK();
     return 0;
 }
 
 // ------------------------------------------------------------------------------------------
-// A6 composite forward: one 256-lane workgroup (4 waves) per 16x16 tile, wave w owns pixel rows
-// 4w..4w+3.  Splat records are staged through LDS in rounds of 256; the per-splat data is
+// A6 composite forward.  One 256-lane workgroup per 16x16 tile; wave w owns the 8x8 pixel quadrant
+// (w&1, w>>1), one pixel per lane.  Splat records are staged through LDS in rounds of 256 together
+// with a 4-bit "quadrants this splat can touch" mask (alpha >= 1/255 box vs quadrant).  Each wave turns
+// the masks into a 64-bit ballot per 64 staged splats and walks only its set bits (scalar loop), so a
+// wave never evaluates a splat that cannot contribute to its quadrant; the per-splat data is
 // wave-uniform in the inner loop (LDS broadcast reads).
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t quadrant_mask(const float4 a0, const float4 a2, int X0, int Y0) {
+    // quadrant q = (qx, qy) covers pixel columns X0+8qx .. X0+8qx+7 (integer pixel centres)
+    const float xl = a0.x - a2.z, xh = a0.x + a2.z, yl = a0.y - a2.w, yh = a0.y + a2.w;
+    const bool cx0 = (xh >= (float)X0) && (xl <= (float)(X0 + 7));
+    const bool cx1 = (xh >= (float)(X0 + 8)) && (xl <= (float)(X0 + 15));
+    const bool cy0 = (yh >= (float)Y0) && (yl <= (float)(Y0 + 7));
+    const bool cy1 = (yh >= (float)(Y0 + 8)) && (yl <= (float)(Y0 + 15));
+    return (uint32_t)(cx0 && cy0) | ((uint32_t)(cx1 && cy0) << 1) | ((uint32_t)(cx0 && cy1) << 2) | ((uint32_t)(cx1 && cy1) << 3);
+}
+
 __global__ void __launch_bounds__(256) k_composite_fwd(GsParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                                                         const float4* __restrict__ rec0, const float4* __restrict__ rec1,
-                                                        const float2* __restrict__ rec2, float* __restrict__ out_color,
+                                                        const float4* __restrict__ rec2, float* __restrict__ out_color,
                                                         float* __restrict__ out_depth, float* __restrict__ out_alpha,
                                                         float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, int chunk) {
     __shared__ float4 s0[256];
     __shared__ float4 s1[256];
-    __shared__ float2 s2[256];
+    __shared__ float4 s2[256];
+    __shared__ uint32_t smask[256];
     // XCD-aware tile order: workgroup b runs on XCD b%8; give each XCD a contiguous run of tiles so
     // neighbouring tiles (which share splats) hit the same L2.  Speed only, never correctness.
     const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
     if (tile >= p.gx * p.gy) return;
     const int tx = tile % p.gx, ty = tile / p.gx;
-    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
-    const int pxi = tx * C3D_TILE_X + lx, pyi = ty * C3D_TILE_Y + ly;
+    const int lane = c3d_lane(), wave = threadIdx.x >> 6;
+    const int X0 = tx * C3D_TILE_X, Y0 = ty * C3D_TILE_Y;
+    const int pxi = X0 + ((wave & 1) << 3) + (lane & 7), pyi = Y0 + ((wave >> 1) << 3) + (lane >> 3);
     const bool inside = pxi < p.W && pyi < p.H;
     const float pxf = (float)pxi, pyf = (float)pyi;
     const uint2 rg = ranges[tile];
-    int todo = (int)(rg.y - rg.x);
+    const int todo = (int)(rg.y - rg.x);
     bool done = !inside;
     float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f, A = 0.f;
-    uint32_t contributor = 0, last = 0;
+    uint32_t last = 0;
 
     for (int base = 0; base < todo; base += 256) {
         if (__syncthreads_count(done) == 256) break;
         const int n = min(256, todo - base);
         if ((int)threadIdx.x < n) {
             const uint32_t gid = point_list[rg.x + base + threadIdx.x];
-            s0[threadIdx.x] = rec0[gid]; s1[threadIdx.x] = rec1[gid]; s2[threadIdx.x] = rec2[gid];
+            const float4 a0 = rec0[gid], a2 = rec2[gid];
+            s0[threadIdx.x] = a0; s1[threadIdx.x] = rec1[gid]; s2[threadIdx.x] = a2;
+            smask[threadIdx.x] = quadrant_mask(a0, a2, X0, Y0);
         }
         __syncthreads();
-        for (int j = 0; !done && j < n; j++) {
-            contributor++;
-            const float4 a0 = s0[j], a1 = s1[j];
-            const float dx = a0.x - pxf, dy = a0.y - pyf;
-            const float power = -0.5f * (a0.z * dx * dx + a1.x * dy * dy) - a0.w * dx * dy;
-            if (power > 0.f) continue;
-            const float alpha = fminf(0.99f, a1.y * __expf(power));
-            if (alpha < 1.f / 255.f) continue;
-            const float testT = T * (1.f - alpha);
-            if (testT < 0.0001f) { done = true; continue; }
-            const float2 a2 = s2[j];
-            const float w = alpha * T;
-            C0 += a1.z * w; C1 += a1.w * w; C2 += a2.x * w;
-            Dp += a2.y * w; A += w;
-            T = testT;
-            last = contributor;
+        for (int c = 0; c < n; c += 64) {
+            const int jj = c + lane;
+            uint64_t m = __ballot(jj < n && ((smask[jj] >> wave) & 1u));
+            if (__ballot(!done) == 0ull) break;           // every pixel of this quadrant has saturated
+            while (m) {
+                const int j = c + (int)__builtin_ctzll(m);
+                m &= m - 1;
+                const float4 a0 = s0[j], a1 = s1[j];
+                const float dx = a0.x - pxf, dy = a0.y - pyf;
+                const float power = -0.5f * (a0.z * dx * dx + a1.x * dy * dy) - a0.w * dx * dy;
+                const float alpha = fminf(0.99f, a1.y * __expf(power));
+                const bool ok = !done && power <= 0.f && alpha >= 1.f / 255.f;
+                const float testT = T * (1.f - alpha);
+                if (ok && testT < 0.0001f) done = true;
+                if (ok && !done) {
+                    const float4 a2 = s2[j];
+                    const float w = alpha * T;
+                    C0 += a1.z * w; C1 += a1.w * w; C2 += a2.x * w;
+                    Dp += a2.y * w; A += w;
+                    T = testT;
+                    last = (uint32_t)(base + j + 1);
+                }
+            }
         }
     }
     if (inside) {
@@ -227,7 +263,7 @@ int gs_launch_composite_fwd(const GsParams& p, const GsGeom& g, const GsBinning&
     const int tiles = p.gx * p.gy;
     if (tiles == 0) return 0;
     const int chunk = c3d_cdiv(tiles, 8);
-    hipLaunchKernelGGL(k_composite_fwd, dim3(chunk * 8), dim3(256), 0, s, p, b.ranges, b.tval[res], g.rec0, g.rec1, g.rec2,
+    hipLaunchKernelGGL(k_composite_fwd, dim3(chunk * 8), dim3(256), 0, s, p, b.ranges, b.point_list, g.rec0, g.rec1, g.rec2,
                        out_color, out_depth, out_alpha, im.final_T, im.n_contrib, chunk);
     C3D_LAUNCH_CHECK();
     return 0;

@@ -2,6 +2,8 @@
 #pragma once
 #include "c3d_common.h"
 
+#define GS_PAIR_FLOATS 12   // per (tile, splat) gradient record: colour3, depth, mean2D2, conic3, opacity (+2 pad)
+
 struct GsParams {
     int N, M, deg, W, H, gx, gy;
     float tanfovx, tanfovy, focal_x, focal_y, scale_modifier;
@@ -11,17 +13,20 @@ struct GsParams {
     const float* campos; // [3]   device
 };
 
-// Per-Gaussian projected record ("geometry state"), SoA of three streams = 40 B / Gaussian:
-//   rec0 = (pix.x, pix.y, conic.xx, conic.xy)   rec1 = (conic.yy, opacity, r, g)   rec2 = (b, view depth)
+// Per-Gaussian projected record ("geometry state"), SoA of three 16-B streams = 48 B / Gaussian:
+//   rec0 = (pix.x, pix.y, conic.xx, conic.xy)   rec1 = (conic.yy, opacity, r, g)   rec2 = (b, view depth, ex, ey)
+// (ex, ey) = half extents, in pixels, of the axis-aligned box outside which alpha < 1/255 for certain
+// (sqrt(2 ln(255 o) Sigma_xx), ... plus a safety margin): used to drop tiles / 8x8 quadrants that cannot contribute.
 struct GsGeom {
     float4* rec0;
     float4* rec1;
-    float2* rec2;
+    float4* rec2;
     uint32_t* tiles;        // tiles touched per Gaussian (0 = culled)
     uint32_t* key[2];       // depth-sort keys (float bits of view depth; 0xFFFFFFFF = culled)
     uint32_t* order[2];     // Gaussian ids, ping-pong; after stage 1 order[res] is rank -> id
     uint32_t* tiles_sorted; // tiles touched in rank order
     uint32_t* offsets;      // inclusive scan of tiles_sorted (rank order)
+    uint32_t* rank_of;      // Gaussian id -> depth rank (inverse of order[res])
     uint8_t* clamped;       // 3 bits per Gaussian: SH colour channel clamped at 0
     int* meta;              // [0] = result buffer index of the depth sort, [1] = num_rendered (device copy)
     void* tmp;              // scan / sort scratch
@@ -32,7 +37,7 @@ static inline void gs_carve_geom(char* base, int N, GsGeom& g) {
     auto take = [&](size_t b) { char* p = base ? base + off : nullptr; off += c3d_align(b); return p; };
     g.rec0 = (float4*)take(16 * n);
     g.rec1 = (float4*)take(16 * n);
-    g.rec2 = (float2*)take(8 * n);
+    g.rec2 = (float4*)take(16 * n);
     g.tiles = (uint32_t*)take(4 * n);
     g.key[0] = (uint32_t*)take(4 * n);
     g.key[1] = (uint32_t*)take(4 * n);
@@ -40,6 +45,7 @@ static inline void gs_carve_geom(char* base, int N, GsGeom& g) {
     g.order[1] = (uint32_t*)take(4 * n);
     g.tiles_sorted = (uint32_t*)take(4 * n);
     g.offsets = (uint32_t*)take(4 * n);
+    g.rank_of = (uint32_t*)take(4 * n);
     g.clamped = (uint8_t*)take(n);
     g.meta = (int*)take(64);
     size_t t1 = c3d_sort_tmp_bytes(n), t2 = c3d_scan_tmp_bytes(n);
@@ -47,10 +53,15 @@ static inline void gs_carve_geom(char* base, int N, GsGeom& g) {
     g.bytes = off;
 }
 
-// Binning state (per tile-splat pair): ping-pong (tile id, Gaussian id) + per-tile ranges.
+// Binning state (per tile-splat pair).  Pairs are emitted in depth-rank order (emit index e: the pairs of one
+// Gaussian are contiguous in e), then stably sorted by tile id with e as payload.  After the sort:
+//   tval[res][pos]  = emit index of the pair at sorted position pos      (backward writes its record there)
+//   point_list[pos] = Gaussian id of that pair                          (what the compositing kernels gather)
 struct GsBinning {
     uint32_t* tkey[2];
     uint32_t* tval[2];
+    uint32_t* gid_emit;    // [D] Gaussian id per emit index
+    uint32_t* point_list;  // [D] Gaussian id per sorted position
     uint2* ranges;   // [tiles]
     int* meta;       // [0] = result buffer index of the tile sort
     void* tmp;
@@ -63,6 +74,8 @@ static inline void gs_carve_binning(char* base, long long D, int tiles, GsBinnin
     b.tkey[1] = (uint32_t*)take(4 * d);
     b.tval[0] = (uint32_t*)take(4 * d);
     b.tval[1] = (uint32_t*)take(4 * d);
+    b.gid_emit = (uint32_t*)take(4 * d);
+    b.point_list = (uint32_t*)take(4 * d);
     b.ranges = (uint2*)take(8 * (size_t)(tiles > 0 ? tiles : 1));
     b.meta = (int*)take(64);
     b.tmp = take(c3d_sort_tmp_bytes(d));
@@ -94,10 +107,9 @@ int gs_launch_composite_fwd(const GsParams& p, const GsGeom& g, const GsBinning&
                             float* out_color, float* out_depth, float* out_alpha, hipStream_t s);
 int gs_launch_composite_bwd(const GsParams& p, const GsGeom& g, const GsBinning& b, int res, const GsImage& im,
                             const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
-                            float* dL_dmean2D /*N*3*/, float* dL_dconic /*N*4*/, float* dL_dopacity, float* dL_dcolors /*N*3*/,
-                            float* dL_ddepths, hipStream_t s);
+                            float* pairgrad /* [D][12] */, hipStream_t s);
 int gs_launch_preprocess_bwd(const GsParams& p, const GsGeom& g, const int* radii, const float* means3D, const float* shs,
                              const float* colors_precomp, const float* scales, const float* rotations, const float* cov3D_precomp,
-                             const float* dL_dmean2D, const float* dL_dconic, const float* dL_dcolors, const float* dL_ddepths,
+                             const float* pairgrad, float* dL_dmean2D, float* dL_dcolors, float* dL_dopacity,
                              float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscales, float* dL_drots, hipStream_t s);
 int gs_launch_mark_visible(int N, const float* means3D, const float* view, const float* proj, uint8_t* present, hipStream_t s);

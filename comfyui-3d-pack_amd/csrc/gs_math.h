@@ -123,3 +123,24 @@ __device__ __forceinline__ void tile_rect(float px, float py, int rad, int gx, i
     x1 = min(gx, max(0, (int)((px + rad + C3D_TILE_X - 1) / C3D_TILE_X)));
     y1 = min(gy, max(0, (int)((py + rad + C3D_TILE_Y - 1) / C3D_TILE_Y)));
 }
+
+// Tiles that can receive a non-zero contribution: the dependency's bounding square (radius from the
+// larger eigenvalue) intersected with the alpha >= 1/255 box [p - e, p + e] (integer pixel centres).
+// Dropping the other tiles is exact: every pixel in them fails the alpha >= 1/255 test.
+__device__ __forceinline__ void tile_rect_tight(float px, float py, int rad, float ex, float ey, int gx, int gy,
+                                                int& x0, int& y0, int& x1, int& y1) {
+    tile_rect(px, py, rad, gx, gy, x0, y0, x1, y1);
+    const int lox = (int)ceilf(px - ex), hix = (int)floorf(px + ex);
+    const int loy = (int)ceilf(py - ey), hiy = (int)floorf(py + ey);
+    x0 = max(x0, max(lox, 0) >> 4); x1 = min(x1, (hix >> 4) + 1);
+    y0 = max(y0, max(loy, 0) >> 4); y1 = min(y1, (hiy >> 4) + 1);
+    if (x1 < x0) x1 = x0;
+    if (y1 < y0) y1 = y0;
+}
+// half extent of the alpha >= 1/255 box along one axis; var = Sigma_xx (or yy) of the blurred 2D covariance.
+// Returns < 0 when the splat can never reach 1/255.  The margin keeps the test conservative under rounding.
+__device__ __forceinline__ float alpha_extent(float opacity, float var) {
+    const float t = 255.f * opacity;
+    if (!(t > 1.f)) return -1.f;
+    return sqrtf(2.f * __logf(t) * var) * 1.0005f + 0.02f;
+}

@@ -111,7 +111,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             g_sh = torch.empty((N, M, 3), **f) if has_sh else None
             g_scales = torch.empty((N, 3), **f) if has_sc else None
             g_rot = torch.empty((N, 4), **f) if has_sc else None
-            scratch = torch.empty((max(N, 1) * 5,), **f)
+            scratch = torch.empty((lib.c3d_gs_backward_scratch_bytes(N, ctx.num_rendered),), dtype=torch.uint8, device=dev)
             gc = _h.f32c(grad_color)
             if gc is None:
                 gc = torch.zeros((3, int(rs.image_height), int(rs.image_width)), **f)

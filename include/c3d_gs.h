@@ -63,6 +63,7 @@ int c3d_version(void);
 size_t c3d_gs_geom_bytes(int32_t N);
 size_t c3d_gs_binning_bytes(int64_t num_rendered, int32_t image_height, int32_t image_width);
 size_t c3d_gs_image_bytes(int32_t image_height, int32_t image_width);
+size_t c3d_gs_backward_scratch_bytes(int32_t N, int64_t num_rendered);
 
 /* Forward, part 1 (A1 + depth ordering + offsets): projects N Gaussians (SH with M coefficients per
  * channel, layout [N,M,3]), writes radii[N] (int32, 0 = culled) and the geometry buffer, and returns
@@ -82,14 +83,15 @@ int c3d_gs_forward_render(const c3d_gs_settings* st, int32_t N, int32_t M, const
 /* Backward (A7 + A8).  Pixel gradients dL_dcolor[3,H,W], dL_ddepth[1,H,W] (may be NULL),
  * dL_dalpha[1,H,W] (may be NULL).  Outputs (all written in full by the library, no pre-zeroing needed):
  * dL_dmeans2D[N,3] dL_dcolors[N,3] dL_dopacity[N,1] dL_dmeans3D[N,3] dL_dcov3D[N,6] dL_dsh[N,M,3]
- * dL_dscales[N,3] dL_drotations[N,4].  scratch: N*5 floats (conic[4] + depth[1] partials). */
+ * dL_dscales[N,3] dL_drotations[N,4].  scratch: c3d_gs_backward_scratch_bytes(N, num_rendered) bytes (one 48-byte gradient
+ * record per (tile, splat) pair; the backward pass uses no atomics and is bit-reproducible). */
 int c3d_gs_backward(const c3d_gs_settings* st, int32_t N, int32_t M, const float* means3D, const float* shs,
                     const float* colors_precomp, const float* scales, const float* rotations,
                     const float* cov3D_precomp, const int32_t* radii, const void* geom_buffer, int64_t num_rendered,
                     const void* binning_buffer, const void* image_buffer, const float* dL_dcolor,
                     const float* dL_ddepth, const float* dL_dalpha, float* dL_dmeans2D, float* dL_dcolors,
                     float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscales,
-                    float* dL_drotations, float* scratch, c3d_stream_t stream);
+                    float* dL_drotations, void* scratch, c3d_stream_t stream);
 
 /* mark_visible: present[N] (uint8) = view-space z > 0.2 */
 int c3d_gs_mark_visible(int32_t N, const float* means3D, const float* viewmatrix, const float* projmatrix,
