@@ -16,10 +16,10 @@ __device__ __forceinline__ float dpp_add(float v) {
     return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
 }
 __device__ __forceinline__ void swap32(float& a, float& b) {   // a[32..63] <-> b[0..31]
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));   // s_nop: VALU write -> permlane read hazard
 }
 __device__ __forceinline__ void swap16(float& a, float& b) {   // rows 1,3 of a <-> rows 0,2 of b
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
 __device__ __forceinline__ float wave_reduce4(float a, float b, float c, float d) {
     swap32(a, b); float p = a + b;      // lanes 0-31: a folded to 32 partials | lanes 32-63: b
@@ -40,7 +40,7 @@ __device__ __forceinline__ float wave_reduce4(float a, float b, float c, float d
 // written ONCE as a 48-byte record per (tile, splat) pair at the pair's emit index.  The pairs of one
 // Gaussian are contiguous there, so the per-Gaussian kernel (A8) sums them without a single atomic:
 // the whole backward pass is deterministic.
-// record layout (GS_PAIR_FLOATS = 12): [c0, c2, c1, depth | mean.x, conic.xx, mean.y, conic.xy | conic.yy, 0, opacity, 0]
+// record layout (GS_PAIR_FLOATS = 12): [c0, c2, c1, depth | m0, m1y, m1x, m2xx | m2xy, 0, m2yy, 0]  (m* = moments of dL/dG*G about the pixel)
 // ------------------------------------------------------------------------------------------
 #define BWD_ROUND 128
 
@@ -89,9 +89,7 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
         dLa = dL_dalpha_px ? dL_dalpha_px[pid] : 0.f;
     }
     const float bg_dot = p.bg[0] * dLp0 + p.bg[1] * dLp1 + p.bg[2] * dLp2;
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, accd = 0.f, acca = 0.f;
-    float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, ld = 0.f;
-    const float ddelx_dx = 0.5f * p.W, ddely_dy = 0.5f * p.H;
+    float Rdot = T_final * bg_dot;
 
     // list positions no pixel of the tile reached need no work beyond a zero record
     if (threadIdx.x == 0) s_maxlast = 0;
@@ -132,36 +130,25 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
                 const bool act = (k < last) && (power <= 0.f) && (alpha >= 1.f / 255.f);
                 float t0 = 0.f, t1 = 0.f, t2 = 0.f;
                 if (__ballot(act) != 0ull) {   // wave-uniform
-                    float g_c0 = 0.f, g_c1 = 0.f, g_c2 = 0.f, g_d = 0.f, g_mx = 0.f, g_my = 0.f, g_cx = 0.f, g_cy = 0.f, g_cw = 0.f, g_o = 0.f;
+                    float g_c0 = 0.f, g_c1 = 0.f, g_c2 = 0.f, g_d = 0.f, m0 = 0.f, m1x = 0.f, m1y = 0.f, m2xx = 0.f, m2xy = 0.f, m2yy = 0.f;
                     if (act) {
-                        T = T / (1.f - alpha);
-                        const float dch = alpha * T;
-                        float dL_dalpha;
-                        acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0; lc0 = a1.z;
-                        acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1; lc1 = a1.w;
-                        acc2 = last_alpha * lc2 + (1.f - last_alpha) * acc2; lc2 = a2.x;
-                        dL_dalpha = (a1.z - acc0) * dLp0 + (a1.w - acc1) * dLp1 + (a2.x - acc2) * dLp2;
-                        g_c0 = dch * dLp0; g_c1 = dch * dLp1; g_c2 = dch * dLp2;
-                        accd = last_alpha * ld + (1.f - last_alpha) * accd; ld = a2.y;
-                        dL_dalpha += (a2.y - accd) * dLd;
-                        g_d = dch * dLd;
-                        acca = last_alpha + (1.f - last_alpha) * acca;
-                        dL_dalpha += (1.f - acca) * dLa;
-                        dL_dalpha *= T;
-                        last_alpha = alpha;
-                        dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
-                        const float dL_dG = a1.y * dL_dalpha;
-                        const float gdx = G * dx, gdy = G * dy;
-                        g_mx = dL_dG * (-gdx * a0.z - gdy * a0.w) * ddelx_dx;
-                        g_my = dL_dG * (-gdy * a1.x - gdx * a0.w) * ddely_dy;
-                        g_cx = -0.5f * gdx * dx * dL_dG;
-                        g_cy = -0.5f * gdx * dy * dL_dG;
-                        g_cw = -0.5f * gdy * dy * dL_dG;
-                        g_o = G * dL_dalpha;
+                        // dL/dalpha_k = T_k (c_k . dL) - [sum_{j behind k} (c_j . dL) alpha_j T_j + T_final bg . dL] / (1 - alpha_k)
+                        // with (c . dL) taken over colour, depth and alpha channels; Rdot carries the bracket.
+                        const float inv = __builtin_amdgcn_rcpf(1.f - alpha);
+                        T *= inv;
+                        const float w = alpha * T;
+                        const float sdot = a1.z * dLp0 + a1.w * dLp1 + a2.x * dLp2 + a2.y * dLd + dLa;
+                        const float dL_dalpha = T * sdot - Rdot * inv;
+                        Rdot += w * sdot;
+                        g_c0 = w * dLp0; g_c1 = w * dLp1; g_c2 = w * dLp2; g_d = w * dLd;
+                        // screen-space part as raw moments of w2 = dL/dG * G; turned into mean/conic/opacity gradients per Gaussian in A8
+                        m0 = a1.y * G * dL_dalpha;
+                        m1x = m0 * dx; m1y = m0 * dy;
+                        m2xx = m1x * dx; m2xy = m1x * dy; m2yy = m1y * dy;
                     }
                     t0 = wave_reduce4(g_c0, g_c1, g_c2, g_d);      // rows: c0, c2, c1, depth
-                    t1 = wave_reduce4(g_mx, g_my, g_cx, g_cy);     // rows: mx, cx, my, cy
-                    t2 = wave_reduce4(g_cw, g_o, 0.f, 0.f);        // rows: cw, 0, o, 0
+                    t1 = wave_reduce4(m0, m1x, m1y, m2xx);         // rows: m0, m1y, m1x, m2xx
+                    t2 = wave_reduce4(m2xy, m2yy, 0.f, 0.f);       // rows: m2xy, 0, m2yy, 0
                 }
                 if ((lane & 15) == 0) {   // lanes 0,16,32,48: one row each
                     const int row = lane >> 4;
@@ -205,31 +192,7 @@ int gs_launch_composite_bwd(const GsParams& p, const GsGeom& g, const GsBinning&
 // ------------------------------------------------------------------------------------------
 // A8 preprocess backward: one lane per Gaussian, pure streaming.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void sh_basis_grad(int deg, float x, float y, float z, float dB[16][3]) {
-#pragma unroll
-    for (int k = 0; k < 16; k++) { dB[k][0] = 0.f; dB[k][1] = 0.f; dB[k][2] = 0.f; }
-    if (deg > 0) {
-        dB[1][1] = -GS_SH_C1; dB[2][2] = GS_SH_C1; dB[3][0] = -GS_SH_C1;
-        if (deg > 1) {
-            const float xx = x * x, yy = y * y, zz = z * z;
-            dB[4][0] = GS_SH_C2_0 * y; dB[4][1] = GS_SH_C2_0 * x;
-            dB[5][1] = GS_SH_C2_1 * z; dB[5][2] = GS_SH_C2_1 * y;
-            dB[6][0] = GS_SH_C2_2 * (-2.f * x); dB[6][1] = GS_SH_C2_2 * (-2.f * y); dB[6][2] = GS_SH_C2_2 * (4.f * z);
-            dB[7][0] = GS_SH_C2_3 * z; dB[7][2] = GS_SH_C2_3 * x;
-            dB[8][0] = GS_SH_C2_4 * (2.f * x); dB[8][1] = GS_SH_C2_4 * (-2.f * y);
-            if (deg > 2) {
-                dB[9][0] = GS_SH_C3_0 * 6.f * x * y; dB[9][1] = GS_SH_C3_0 * (3.f * xx - 3.f * yy);
-                dB[10][0] = GS_SH_C3_1 * y * z; dB[10][1] = GS_SH_C3_1 * x * z; dB[10][2] = GS_SH_C3_1 * x * y;
-                dB[11][0] = GS_SH_C3_2 * (-2.f * x * y); dB[11][1] = GS_SH_C3_2 * (4.f * zz - xx - 3.f * yy); dB[11][2] = GS_SH_C3_2 * (8.f * y * z);
-                dB[12][0] = GS_SH_C3_3 * (-6.f * x * z); dB[12][1] = GS_SH_C3_3 * (-6.f * y * z); dB[12][2] = GS_SH_C3_3 * (6.f * zz - 3.f * xx - 3.f * yy);
-                dB[13][0] = GS_SH_C3_4 * (4.f * zz - 3.f * xx - yy); dB[13][1] = GS_SH_C3_4 * (-2.f * x * y); dB[13][2] = GS_SH_C3_4 * (8.f * x * z);
-                dB[14][0] = GS_SH_C3_5 * (2.f * x * z); dB[14][1] = GS_SH_C3_5 * (-2.f * y * z); dB[14][2] = GS_SH_C3_5 * (xx - yy);
-                dB[15][0] = GS_SH_C3_6 * (3.f * xx - 3.f * yy); dB[15][1] = GS_SH_C3_6 * (-6.f * x * y);
-            }
-        }
-    }
-}
-
+template <bool STAGED>
 __global__ void __launch_bounds__(256) k_preprocess_bwd(GsParams p, GsGeom g, const int* __restrict__ radii, const float* __restrict__ means3D,
                                                          const float* __restrict__ shs, const float* __restrict__ colors_precomp,
                                                          const float* __restrict__ scales, const float* __restrict__ rotations,
@@ -238,9 +201,23 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GsParams p, GsGeom g, co
                                                          float* __restrict__ dL_dopacity, float* __restrict__ dL_dmeans3D,
                                                          float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
                                                          float* __restrict__ dL_dscales, float* __restrict__ dL_drots) {
+    extern __shared__ float sh_lds[];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= p.N) return;
-    if (radii[idx] <= 0) {
+    const size_t g0 = (size_t)blockIdx.x * blockDim.x;
+    const int gcount = min((int)blockDim.x, p.N - (int)g0);
+    float* shl = sh_lds + threadIdx.x * SH_ROW;
+    if (STAGED) {
+        sh_stage_in(shs, g0, gcount, sh_lds);
+        __syncthreads();
+    }
+    const bool culled = idx < p.N && radii[idx] <= 0;
+    if (STAGED && (idx >= p.N || culled)) {
+        if (idx < p.N) {
+#pragma unroll
+            for (int k = 0; k < SH_M3; k++) shl[k] = 0.f;
+        }
+    }
+    if (idx < p.N && culled) {
         // culled: this kernel owns its outputs (callers allocate them uninitialised)
         dL_dmean2D[3 * idx] = 0.f; dL_dmean2D[3 * idx + 1] = 0.f; dL_dmean2D[3 * idx + 2] = 0.f;
         dL_dcolors[3 * idx] = 0.f; dL_dcolors[3 * idx + 1] = 0.f; dL_dcolors[3 * idx + 2] = 0.f;
@@ -250,7 +227,7 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GsParams p, GsGeom g, co
 #pragma unroll
             for (int i = 0; i < 6; i++) dL_dcov3D[6 * idx + i] = 0.f;
         }
-        if (!colors_precomp) {
+        if (!colors_precomp && !STAGED) {
             float* dsh = dL_dsh + (size_t)idx * p.M * 3;
             for (int k = 0; k < 3 * p.M; k++) dsh[k] = 0.f;
         }
@@ -258,8 +235,8 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GsParams p, GsGeom g, co
             dL_dscales[3 * idx] = 0.f; dL_dscales[3 * idx + 1] = 0.f; dL_dscales[3 * idx + 2] = 0.f;
             *reinterpret_cast<float4*>(dL_drots + 4 * idx) = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        return;
     }
+    if (idx < p.N && !culled) {
     // sum this Gaussian's (tile, splat) records: contiguous in emit order, fixed order -> deterministic
     float pr[GS_PAIR_FLOATS];
 #pragma unroll
@@ -276,11 +253,15 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GsParams p, GsGeom g, co
     }
     const float gcol[3] = {pr[0], pr[2], pr[1]};          // record rows: c0, c2, c1
     const float g_depth = pr[3];
-    const float g2x = pr[4], g2y = pr[6];
-    const float dcx = pr[5], dcy = pr[7], dcz = pr[8];
+    // moments -> gradients of the projected mean (NDC-scaled), conic and opacity
+    const float4 q0 = g.rec0[idx], q1 = g.rec1[idx];
+    const float cA = q0.z, cB = q0.w, cC = q1.x, opac = q1.y;
+    const float m0 = pr[4], m1y = pr[5], m1x = pr[6], m2xx = pr[7], m2xy = pr[8], m2yy = pr[10];
+    const float g2x = -(cA * m1x + cB * m1y) * (0.5f * p.W), g2y = -(cC * m1y + cB * m1x) * (0.5f * p.H);
+    const float dcx = -0.5f * m2xx, dcy = -0.5f * m2xy, dcz = -0.5f * m2yy;
     dL_dmean2D[3 * idx] = g2x; dL_dmean2D[3 * idx + 1] = g2y; dL_dmean2D[3 * idx + 2] = 0.f;
     dL_dcolors[3 * idx] = gcol[0]; dL_dcolors[3 * idx + 1] = gcol[1]; dL_dcolors[3 * idx + 2] = gcol[2];
-    dL_dopacity[idx] = pr[10];
+    dL_dopacity[idx] = (opac > 0.f) ? m0 / opac : 0.f;
 
     const Mat16 V = load_mat16(p.view), PJ = load_mat16(p.proj);
     const float3 m = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
@@ -359,28 +340,34 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GsParams p, GsGeom g, co
         const float s2 = vx * vx + vy * vy + vz * vz;
         const float len = sqrtf(s2);
         const float dxn = vx / len, dyn = vy / len, dzn = vz / len;
-        float B[16], dB[16][3];
-        sh_basis(p.deg, dxn, dyn, dzn, B);
-        sh_basis_grad(p.deg, dxn, dyn, dzn, dB);
         const uint8_t cl = g.clamped[idx];
-        const float dRGB[3] = {(cl & 1) ? 0.f : gcol[0], (cl & 2) ? 0.f : gcol[1], (cl & 4) ? 0.f : gcol[2]};
-        const float* sh = shs + (size_t)idx * p.M * 3;
-        float* dsh = dL_dsh + (size_t)idx * p.M * 3;
+        const float dR0 = (cl & 1) ? 0.f : gcol[0], dR1 = (cl & 2) ? 0.f : gcol[1], dR2 = (cl & 4) ? 0.f : gcol[2];
+        const float* shg = shs + (size_t)idx * p.M * 3;
+        float* dshg = dL_dsh + (size_t)idx * p.M * 3;
+        float dd0 = 0.f, dd1 = 0.f, dd2 = 0.f;
+        // in the staged variant each lane overwrites its own LDS row in place: coefficient in, gradient out
+#define GS_BWD_TERM(k, Bk, dBx, dBy, dBz)                                                                        \
+    {                                                                                                            \
+        const float b_ = (Bk);                                                                                   \
+        float w_;                                                                                                \
+        if (STAGED) {                                                                                            \
+            w_ = shl[3 * (k)] * dR0 + shl[3 * (k) + 1] * dR1 + shl[3 * (k) + 2] * dR2;                           \
+            shl[3 * (k)] = b_ * dR0; shl[3 * (k) + 1] = b_ * dR1; shl[3 * (k) + 2] = b_ * dR2;                   \
+        } else {                                                                                                 \
+            w_ = shg[3 * (k)] * dR0 + shg[3 * (k) + 1] * dR1 + shg[3 * (k) + 2] * dR2;                           \
+            dshg[3 * (k)] = b_ * dR0; dshg[3 * (k) + 1] = b_ * dR1; dshg[3 * (k) + 2] = b_ * dR2;                \
+        }                                                                                                        \
+        dd0 += (dBx) * w_; dd1 += (dBy) * w_; dd2 += (dBz) * w_;                                                 \
+    }
+        SH_FOREACH(p.deg, dxn, dyn, dzn, GS_BWD_TERM);
+#undef GS_BWD_TERM
         const int nc = sh_ncoef(p.deg);
-        float dd[3] = {0.f, 0.f, 0.f};
-        for (int k = 0; k < nc; k++) {
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++) {
-                dsh[3 * k + ch] = B[k] * dRGB[ch];
-                const float w = sh[3 * k + ch] * dRGB[ch];
-                dd[0] += dB[k][0] * w; dd[1] += dB[k][1] * w; dd[2] += dB[k][2] * w;
-            }
-        }
-        for (int k = 3 * nc; k < 3 * p.M; k++) dsh[k] = 0.f;   // coefficients above the active degree
+        if (STAGED) { for (int k = 3 * nc; k < SH_M3; k++) shl[k] = 0.f; }
+        else        { for (int k = 3 * nc; k < 3 * p.M; k++) dshg[k] = 0.f; }   // coefficients above the active degree
         const float inv32 = 1.f / sqrtf(s2 * s2 * s2);
-        dmean[0] += ((s2 - vx * vx) * dd[0] - vy * vx * dd[1] - vz * vx * dd[2]) * inv32;
-        dmean[1] += (-vx * vy * dd[0] + (s2 - vy * vy) * dd[1] - vz * vy * dd[2]) * inv32;
-        dmean[2] += (-vx * vz * dd[0] - vy * vz * dd[1] + (s2 - vz * vz) * dd[2]) * inv32;
+        dmean[0] += ((s2 - vx * vx) * dd0 - vy * vx * dd1 - vz * vx * dd2) * inv32;
+        dmean[1] += (-vx * vy * dd0 + (s2 - vy * vy) * dd1 - vz * vy * dd2) * inv32;
+        dmean[2] += (-vx * vz * dd0 - vy * vz * dd1 + (s2 - vz * vz) * dd2) * inv32;
     }
     dL_dmeans3D[3 * idx] = dmean[0]; dL_dmeans3D[3 * idx + 1] = dmean[1]; dL_dmeans3D[3 * idx + 2] = dmean[2];
 
@@ -409,6 +396,11 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GsParams p, GsGeom g, co
         dq.w = 2.f * (-2.f * z * dR[0][0] - r * dR[0][1] + x * dR[0][2] + r * dR[1][0] - 2.f * z * dR[1][1] + y * dR[1][2] + x * dR[2][0] + y * dR[2][1]);
         *reinterpret_cast<float4*>(dL_drots + 4 * idx) = dq;
     }
+    }   // visible Gaussian
+    if (STAGED) {
+        __syncthreads();
+        sh_stage_out(dL_dsh, g0, gcount, sh_lds);
+    }
 }
 
 int gs_launch_preprocess_bwd(const GsParams& p, const GsGeom& g, const int* radii, const float* means3D, const float* shs,
@@ -416,9 +408,15 @@ int gs_launch_preprocess_bwd(const GsParams& p, const GsGeom& g, const int* radi
                              const float* pairgrad, float* dL_dmean2D, float* dL_dcolors, float* dL_dopacity,
                              float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscales, float* dL_drots, hipStream_t s) {
     if (p.N == 0) return 0;
-    hipLaunchKernelGGL(k_preprocess_bwd, dim3(c3d_cdiv(p.N, 256)), dim3(256), 0, s, p, g, radii, means3D, shs, colors_precomp, scales,
-                       rotations, cov3D_precomp, (const float4*)pairgrad, dL_dmean2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh,
-                       dL_dscales, dL_drots);
+    const bool staged = shs && !colors_precomp && p.M == 16 && ((uintptr_t)shs % 16 == 0) && ((uintptr_t)dL_dsh % 16 == 0);
+    if (staged)
+        hipLaunchKernelGGL(k_preprocess_bwd<true>, dim3(c3d_cdiv(p.N, 256)), dim3(256), 256 * SH_ROW * sizeof(float), s, p, g, radii, means3D, shs,
+                           colors_precomp, scales, rotations, cov3D_precomp, (const float4*)pairgrad, dL_dmean2D, dL_dcolors, dL_dopacity,
+                           dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drots);
+    else
+        hipLaunchKernelGGL(k_preprocess_bwd<false>, dim3(c3d_cdiv(p.N, 256)), dim3(256), 0, s, p, g, radii, means3D, shs,
+                           colors_precomp, scales, rotations, cov3D_precomp, (const float4*)pairgrad, dL_dmean2D, dL_dcolors, dL_dopacity,
+                           dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drots);
     C3D_LAUNCH_CHECK();
     return 0;
 }

@@ -7,13 +7,22 @@
 
 // ------------------------------------------------------------------------------------------
 // A1 preprocess: one lane per Gaussian.  Streams xyz/scale/rot/opacity/SH once, writes the 48-B
-// projected record, the depth-sort key and the tile count.
+// projected record, the depth-sort key and the tile count.  STAGED: the workgroup's 48 KiB of SH
+// coefficients are brought in with fully coalesced 16-B loads through LDS (sh_stage_in) instead of
+// 64 lanes striding 192 B apart.
 // ------------------------------------------------------------------------------------------
+template <bool STAGED>
 __global__ void __launch_bounds__(256) k_preprocess(GsParams p, const float* __restrict__ means3D, const float* __restrict__ shs,
                                                      const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
                                                      const float* __restrict__ scales, const float* __restrict__ rotations,
                                                      const float* __restrict__ cov3D_precomp, GsGeom g, int* __restrict__ radii) {
+    extern __shared__ float sh_lds[];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (STAGED) {
+        const size_t g0 = (size_t)blockIdx.x * blockDim.x;
+        sh_stage_in(shs, g0, min((int)blockDim.x, p.N - (int)g0), sh_lds);
+        __syncthreads();
+    }
     if (idx >= p.N) return;
     // defaults for a culled Gaussian
     radii[idx] = 0;
@@ -61,32 +70,31 @@ __global__ void __launch_bounds__(256) k_preprocess(GsParams p, const float* __r
     if (ex >= 0.f) tile_rect_tight(px, py, rad, ex, ey, p.gx, p.gy, x0, y0, x1, y1);
     else { x1 = x0; y1 = y0; }
 
-    float rgb[3];
+    float r0 = 0.f, r1 = 0.f, r2 = 0.f;
     uint8_t cl = 0;
     if (colors_precomp) {
-        rgb[0] = colors_precomp[3 * idx]; rgb[1] = colors_precomp[3 * idx + 1]; rgb[2] = colors_precomp[3 * idx + 2];
+        r0 = colors_precomp[3 * idx]; r1 = colors_precomp[3 * idx + 1]; r2 = colors_precomp[3 * idx + 2];
     } else {
         float dx = m.x - p.campos[0], dy = m.y - p.campos[1], dz = m.z - p.campos[2];
         const float len = sqrtf(dx * dx + dy * dy + dz * dz);
         dx /= len; dy /= len; dz /= len;
-        float B[16];
-        sh_basis(p.deg, dx, dy, dz, B);
-        const float* sh = shs + (size_t)idx * p.M * 3;
-        const int nc = sh_ncoef(p.deg);
-        rgb[0] = rgb[1] = rgb[2] = 0.f;
-        for (int k = 0; k < nc; k++) {
-            rgb[0] += B[k] * sh[3 * k]; rgb[1] += B[k] * sh[3 * k + 1]; rgb[2] += B[k] * sh[3 * k + 2];
-        }
-#pragma unroll
-        for (int ch = 0; ch < 3; ch++) {
-            rgb[ch] += 0.5f;
-            if (rgb[ch] < 0.f) cl |= (uint8_t)(1u << ch);
-            rgb[ch] = fmaxf(rgb[ch], 0.f);
-        }
+        const float* shg = shs + (size_t)idx * p.M * 3;
+        const float* shl = sh_lds + threadIdx.x * SH_ROW;
+#define GS_FWD_TERM(k, Bk, dBx, dBy, dBz)                                                             \
+    {                                                                                                 \
+        const float b_ = (Bk);                                                                        \
+        if (STAGED) { r0 += b_ * shl[3 * (k)]; r1 += b_ * shl[3 * (k) + 1]; r2 += b_ * shl[3 * (k) + 2]; } \
+        else        { r0 += b_ * shg[3 * (k)]; r1 += b_ * shg[3 * (k) + 1]; r2 += b_ * shg[3 * (k) + 2]; } \
+    }
+        SH_FOREACH(p.deg, dx, dy, dz, GS_FWD_TERM);
+#undef GS_FWD_TERM
+        r0 += 0.5f; r1 += 0.5f; r2 += 0.5f;
+        if (r0 < 0.f) cl |= 1; if (r1 < 0.f) cl |= 2; if (r2 < 0.f) cl |= 4;
+        r0 = fmaxf(r0, 0.f); r1 = fmaxf(r1, 0.f); r2 = fmaxf(r2, 0.f);
     }
     g.rec0[idx] = make_float4(px, py, c * di, -b * di);
-    g.rec1[idx] = make_float4(a * di, opac, rgb[0], rgb[1]);
-    g.rec2[idx] = make_float4(rgb[2], pv.z, ex, ey);
+    g.rec1[idx] = make_float4(a * di, opac, r0, r1);
+    g.rec2[idx] = make_float4(r2, pv.z, ex, ey);
     g.clamped[idx] = cl;
     radii[idx] = rad;
     const uint32_t nt = (uint32_t)((x1 - x0) * (y1 - y0));
@@ -98,8 +106,13 @@ int gs_launch_preprocess(const GsParams& p, const float* means3D, const float* s
                          const float* opacities, const float* scales, const float* rotations, const float* cov3D_precomp,
                          GsGeom& g, int* radii, hipStream_t s) {
     if (p.N == 0) return 0;
-    hipLaunchKernelGGL(k_preprocess, dim3(c3d_cdiv(p.N, 256)), dim3(256), 0, s, p, means3D, shs, colors_precomp, opacities,
-                       scales, rotations, cov3D_precomp, g, radii);
+    const bool staged = shs && !colors_precomp && p.M == 16 && ((uintptr_t)shs % 16 == 0);
+    if (staged)
+        hipLaunchKernelGGL(k_preprocess<true>, dim3(c3d_cdiv(p.N, 256)), dim3(256), 256 * SH_ROW * sizeof(float), s, p, means3D, shs,
+                           colors_precomp, opacities, scales, rotations, cov3D_precomp, g, radii);
+    else
+        hipLaunchKernelGGL(k_preprocess<false>, dim3(c3d_cdiv(p.N, 256)), dim3(256), 0, s, p, means3D, shs, colors_precomp, opacities,
+                           scales, rotations, cov3D_precomp, g, radii);
     C3D_LAUNCH_CHECK();
     return 0;
 }

@@ -144,3 +144,58 @@ __device__ __forceinline__ float alpha_extent(float opacity, float var) {
     if (!(t > 1.f)) return -1.f;
     return sqrtf(2.f * __logf(t) * var) * 1.0005f + 0.02f;
 }
+
+// ---- spherical harmonics without arrays (keeps the per-Gaussian kernels out of scratch) -------------------
+// SH_FOREACH(deg, x, y, z, TERM) invokes TERM(k, B_k, dB_k/dx, dB_k/dy, dB_k/dz) for every active coefficient.
+#define SH_FOREACH(deg, x, y, z, TERM)                                                                                    \
+    do {                                                                                                                  \
+        TERM(0, GS_SH_C0, 0.f, 0.f, 0.f);                                                                                 \
+        if ((deg) > 0) {                                                                                                  \
+            TERM(1, -GS_SH_C1 * (y), 0.f, -GS_SH_C1, 0.f);                                                                \
+            TERM(2, GS_SH_C1 * (z), 0.f, 0.f, GS_SH_C1);                                                                  \
+            TERM(3, -GS_SH_C1 * (x), -GS_SH_C1, 0.f, 0.f);                                                                \
+            if ((deg) > 1) {                                                                                              \
+                const float xx_ = (x) * (x), yy_ = (y) * (y), zz_ = (z) * (z);                                            \
+                TERM(4, GS_SH_C2_0 * (x) * (y), GS_SH_C2_0 * (y), GS_SH_C2_0 * (x), 0.f);                                 \
+                TERM(5, GS_SH_C2_1 * (y) * (z), 0.f, GS_SH_C2_1 * (z), GS_SH_C2_1 * (y));                                 \
+                TERM(6, GS_SH_C2_2 * (2.f * zz_ - xx_ - yy_), GS_SH_C2_2 * (-2.f * (x)), GS_SH_C2_2 * (-2.f * (y)), GS_SH_C2_2 * (4.f * (z))); \
+                TERM(7, GS_SH_C2_3 * (x) * (z), GS_SH_C2_3 * (z), 0.f, GS_SH_C2_3 * (x));                                 \
+                TERM(8, GS_SH_C2_4 * (xx_ - yy_), GS_SH_C2_4 * (2.f * (x)), GS_SH_C2_4 * (-2.f * (y)), 0.f);              \
+                if ((deg) > 2) {                                                                                          \
+                    TERM(9, GS_SH_C3_0 * (y) * (3.f * xx_ - yy_), GS_SH_C3_0 * 6.f * (x) * (y), GS_SH_C3_0 * (3.f * xx_ - 3.f * yy_), 0.f); \
+                    TERM(10, GS_SH_C3_1 * (x) * (y) * (z), GS_SH_C3_1 * (y) * (z), GS_SH_C3_1 * (x) * (z), GS_SH_C3_1 * (x) * (y)); \
+                    TERM(11, GS_SH_C3_2 * (y) * (4.f * zz_ - xx_ - yy_), GS_SH_C3_2 * (-2.f * (x) * (y)), GS_SH_C3_2 * (4.f * zz_ - xx_ - 3.f * yy_), GS_SH_C3_2 * (8.f * (y) * (z))); \
+                    TERM(12, GS_SH_C3_3 * (z) * (2.f * zz_ - 3.f * xx_ - 3.f * yy_), GS_SH_C3_3 * (-6.f * (x) * (z)), GS_SH_C3_3 * (-6.f * (y) * (z)), GS_SH_C3_3 * (6.f * zz_ - 3.f * xx_ - 3.f * yy_)); \
+                    TERM(13, GS_SH_C3_4 * (x) * (4.f * zz_ - xx_ - yy_), GS_SH_C3_4 * (4.f * zz_ - 3.f * xx_ - yy_), GS_SH_C3_4 * (-2.f * (x) * (y)), GS_SH_C3_4 * (8.f * (x) * (z))); \
+                    TERM(14, GS_SH_C3_5 * (z) * (xx_ - yy_), GS_SH_C3_5 * (2.f * (x) * (z)), GS_SH_C3_5 * (-2.f * (y) * (z)), GS_SH_C3_5 * (xx_ - yy_)); \
+                    TERM(15, GS_SH_C3_6 * (x) * (xx_ - 3.f * yy_), GS_SH_C3_6 * (3.f * xx_ - 3.f * yy_), GS_SH_C3_6 * (-6.f * (x) * (y)), 0.f); \
+                }                                                                                                         \
+            }                                                                                                             \
+        }                                                                                                                 \
+    } while (0)
+
+// ---- block-cooperative staging of the [N][16][3] SH tensor through LDS ------------------------------------
+// A 256-lane workgroup owns 256 consecutive Gaussians = 48 KiB of contiguous SH data.  It is moved with
+// 16-byte loads/stores, consecutive lanes on consecutive addresses (1 KiB per wave instruction), into a
+// row-padded LDS image (49 floats per Gaussian: lane t then reads its own row conflict-free).
+#define SH_ROW 49
+#define SH_M3 48
+__device__ __forceinline__ void sh_stage_in(const float* __restrict__ shs, size_t g0, int count, float* lds) {
+    const float4* src = reinterpret_cast<const float4*>(shs + g0 * SH_M3);
+    const int n4 = count * (SH_M3 / 4);
+    for (int e4 = threadIdx.x; e4 < n4; e4 += blockDim.x) {
+        const float4 v = src[e4];
+        const int e = e4 * 4, gl = e / SH_M3, k = e - gl * SH_M3;   // 48 % 4 == 0: the four floats stay in one row
+        float* d = lds + gl * SH_ROW + k;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+}
+__device__ __forceinline__ void sh_stage_out(float* __restrict__ dst_sh, size_t g0, int count, const float* lds) {
+    float4* dst = reinterpret_cast<float4*>(dst_sh + g0 * SH_M3);
+    const int n4 = count * (SH_M3 / 4);
+    for (int e4 = threadIdx.x; e4 < n4; e4 += blockDim.x) {
+        const int e = e4 * 4, gl = e / SH_M3, k = e - gl * SH_M3;
+        const float* d = lds + gl * SH_ROW + k;
+        dst[e4] = make_float4(d[0], d[1], d[2], d[3]);
+    }
+}

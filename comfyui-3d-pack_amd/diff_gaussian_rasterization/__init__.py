@@ -107,7 +107,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             g_colors = torch.empty((N, 3), **f)
             g_opacity = torch.empty((N, 1), **f)
             g_means3D = torch.empty((N, 3), **f)
-            g_cov3D = torch.empty((N, 6), **f)
+            g_cov3D = torch.empty((N, 6), **f) if has_cov else None   # NULL -> the kernel skips the 24 B/Gaussian store
             g_sh = torch.empty((N, M, 3), **f) if has_sh else None
             g_scales = torch.empty((N, 3), **f) if has_sc else None
             g_rot = torch.empty((N, 4), **f) if has_sc else None

@@ -305,3 +305,17 @@ def test_edge_cases():
     with torch.inference_mode():
         c, *_ = hip_forward(S.make_small_scene(N=20), st)
     assert torch.isfinite(c).all()
+
+
+def test_backward_is_bit_reproducible():
+    """no atomics anywhere in the backward pass: two runs give identical bits"""
+    sc = S.make_cloud(200000, seed=3, log_scale_mean=np.log(0.008))
+    st = S.camera_settings(800, 450, 49.1, 10.0, 100.0, 2.2)
+    gC = _dev(np.random.default_rng(2).normal(size=(3, 450, 800)).astype(np.float32), torch.float32)
+    grads = []
+    for _ in range(2):
+        color, radii, depth, alpha, inp, m2d = hip_forward(sc, st, requires_grad=True)
+        ((color * gC).sum() + alpha.sum() + depth.sum()).backward()
+        grads.append({k: inp[k].grad.clone() for k in ("means3D", "opacities", "shs", "scales", "rotations")})
+    for k in grads[0]:
+        assert torch.equal(grads[0][k], grads[1][k]), k
