@@ -116,7 +116,7 @@ int c3d_gs_forward_render(const c3d_gs_settings* st, int32_t N, int32_t M, const
         { C3dProfScope ps(C3D_P_EMIT, s);
         if ((rc = gs_launch_emit(p, g, sort_result_index(32), radii, b, s))) return rc; }
         C3dProfScope ps2(C3D_P_TILE_SORT, s);
-        if ((rc = c3d_sort_pairs_u32(b.tkey[0], b.tkey[1], b.tval[0], b.tval[1], true, (size_t)num_rendered, tile_sort_bits(tiles), b.tmp, &res, s))) return rc;
+        if ((rc = c3d_sort_pairs_u32(b.tkey[0], b.tkey[1], b.tval[0], b.tval[1], false, (size_t)num_rendered, tile_sort_bits(tiles), b.tmp, &res, s))) return rc;
         if (res != sort_result_index(tile_sort_bits(tiles))) { c3d_set_error("internal: tile sort buffer parity"); return -2; }
     }
     { C3dProfScope ps(C3D_P_RANGES, s);
@@ -196,8 +196,7 @@ int c3d_gs_debug_state(int32_t N, int32_t H, int32_t W, const void* geom_buffer,
         GsBinning b;
         gs_carve_binning((char*)binning_buffer, D, tiles, b);
         const int res = sort_result_index(tile_sort_bits(tiles));
-        (void)res;
-        if (point_list && D > 0) C3D_CHECK(hipMemcpyAsync(point_list, b.point_list, sizeof(uint32_t) * (size_t)D, hipMemcpyDeviceToDevice, s));
+        if (point_list && D > 0) C3D_CHECK(hipMemcpyAsync(point_list, b.tval[res], sizeof(uint32_t) * (size_t)D, hipMemcpyDeviceToDevice, s));
         if (ranges) C3D_CHECK(hipMemcpyAsync(ranges, b.ranges, sizeof(uint2) * (size_t)tiles, hipMemcpyDeviceToDevice, s));
     }
     return 0;

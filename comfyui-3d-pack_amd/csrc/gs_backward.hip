@@ -54,7 +54,7 @@ __device__ __forceinline__ uint32_t quadrant_mask_b(const float4 a0, const float
 }
 
 __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-                                                        const uint32_t* __restrict__ e_sorted,
+                                                        const uint4* __restrict__ einfo,
                                                         const float4* __restrict__ rec0, const float4* __restrict__ rec1,
                                                         const float4* __restrict__ rec2, const float* __restrict__ final_T,
                                                         const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor,
@@ -98,8 +98,14 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
     __syncthreads();
     const int upto = s_maxlast;   // positions [0, upto) matter
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // emit index of the pair (this tile, Gaussian gid): row-major position of the tile inside the Gaussian's rect
+    auto emit_index = [&](uint32_t gid) -> uint32_t {
+        const uint4 ei = einfo[gid];
+        const int ex0 = (int)(ei.y & 0xFFFFu), ey0 = (int)(ei.y >> 16), ex1 = (int)(ei.z & 0xFFFFu);
+        return ei.x + (uint32_t)((ty - ey0) * (ex1 - ex0) + (tx - ex0));
+    };
     for (int pos = upto + (int)threadIdx.x; pos < todo; pos += 256) {
-        float4* r = pairgrad + (size_t)e_sorted[rg.x + pos] * 3;
+        float4* r = pairgrad + (size_t)emit_index(point_list[rg.x + pos]) * 3;
         r[0] = z4; r[1] = z4; r[2] = z4;
     }
 
@@ -110,7 +116,7 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
             const int pos = rg.x + (upto - 1 - base - threadIdx.x);
             const uint32_t gid = point_list[pos];
             const float4 a0 = rec0[gid], a2 = rec2[gid];
-            se[threadIdx.x] = e_sorted[pos];
+            se[threadIdx.x] = emit_index(gid);
             s0[threadIdx.x] = a0; s1[threadIdx.x] = rec1[gid]; s2[threadIdx.x] = a2;
             smask[threadIdx.x] = quadrant_mask_b(a0, a2, X0, Y0);
         }
@@ -183,7 +189,7 @@ int gs_launch_composite_bwd(const GsParams& p, const GsGeom& g, const GsBinning&
     const int tiles = p.gx * p.gy;
     if (tiles == 0) return 0;
     const int chunk = c3d_cdiv(tiles, 8);
-    hipLaunchKernelGGL(k_composite_bwd, dim3(chunk * 8), dim3(256), 0, s, p, b.ranges, b.point_list, b.tval[res], g.rec0, g.rec1, g.rec2,
+    hipLaunchKernelGGL(k_composite_bwd, dim3(chunk * 8), dim3(256), 0, s, p, b.ranges, b.tval[res], g.einfo, g.rec0, g.rec1, g.rec2,
                        im.final_T, im.n_contrib, dL_dcolor, dL_ddepth, dL_dalpha, (float4*)pairgrad, chunk);
     C3D_LAUNCH_CHECK();
     return 0;
@@ -242,8 +248,8 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GsParams p, GsGeom g, co
 #pragma unroll
     for (int q = 0; q < GS_PAIR_FLOATS; q++) pr[q] = 0.f;
     {
-        const uint32_t r = g.rank_of[idx];
-        const uint32_t e0 = r ? g.offsets[r - 1] : 0u, e1 = g.offsets[r];
+        const uint32_t cnt = g.tiles[idx];
+        const uint32_t e0 = cnt ? g.einfo[idx].x : 0u, e1 = e0 + cnt;
         for (uint32_t e = e0; e < e1; e++) {
             const float4 v0 = pairgrad[(size_t)e * 3], v1 = pairgrad[(size_t)e * 3 + 1], v2 = pairgrad[(size_t)e * 3 + 2];
             pr[0] += v0.x; pr[1] += v0.y; pr[2] += v0.z; pr[3] += v0.w;

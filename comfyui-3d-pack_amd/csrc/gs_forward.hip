@@ -119,13 +119,13 @@ int gs_launch_preprocess(const GsParams& p, const float* means3D, const float* s
 
 // tiles touched, gathered into depth-rank order (input of the offsets scan)
 __global__ void __launch_bounds__(256) k_gather_tiles(const uint32_t* __restrict__ order, const uint32_t* __restrict__ tiles,
-                                                       uint32_t* __restrict__ out, uint32_t* __restrict__ rank_of, int N) {
+                                                       uint32_t* __restrict__ out, int N) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < N) { const uint32_t gid = order[r]; out[r] = tiles[gid]; rank_of[gid] = (uint32_t)r; }
+    if (r < N) out[r] = tiles[order[r]];
 }
 int gs_launch_gather_tiles(const GsGeom& g, int N, int res, hipStream_t s) {
     if (N == 0) return 0;
-    hipLaunchKernelGGL(k_gather_tiles, dim3(c3d_cdiv(N, 256)), dim3(256), 0, s, g.order[res], g.tiles, g.tiles_sorted, g.rank_of, N);
+    hipLaunchKernelGGL(k_gather_tiles, dim3(c3d_cdiv(N, 256)), dim3(256), 0, s, g.order[res], g.tiles, g.tiles_sorted, N);
     C3D_LAUNCH_CHECK();
     return 0;
 }
@@ -136,7 +136,7 @@ int gs_launch_gather_tiles(const GsGeom& g, int N, int res, hipStream_t s) {
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_emit(GsParams p, const uint32_t* __restrict__ order, const uint32_t* __restrict__ offsets,
                                                const float4* __restrict__ rec0, const float4* __restrict__ rec2,
-                                               const int* __restrict__ radii, uint32_t* __restrict__ tkey, uint32_t* __restrict__ gid_emit) {
+                                               const int* __restrict__ radii, uint4* __restrict__ einfo, uint32_t* __restrict__ tkey, uint32_t* __restrict__ tval) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= p.N) return;
     const uint32_t gid = order[r];
@@ -148,27 +148,25 @@ __global__ void __launch_bounds__(256) k_emit(GsParams p, const uint32_t* __rest
     const float4 r2 = rec2[gid];
     int x0, y0, x1, y1;
     tile_rect_tight(r0.x, r0.y, rad, r2.z, r2.w, p.gx, p.gy, x0, y0, x1, y1);
+    einfo[gid] = make_uint4(off, (uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)x1 | ((uint32_t)y1 << 16), 0u);
     for (int y = y0; y < y1; y++)
         for (int x = x0; x < x1; x++) {
             tkey[off] = (uint32_t)(y * p.gx + x);
-            gid_emit[off] = gid;
+            tval[off] = gid;
             off++;
         }
 }
 int gs_launch_emit(const GsParams& p, const GsGeom& g, int res, const int* radii, GsBinning& b, hipStream_t s) {
     if (p.N == 0) return 0;
-    hipLaunchKernelGGL(k_emit, dim3(c3d_cdiv(p.N, 256)), dim3(256), 0, s, p, g.order[res], g.offsets, g.rec0, g.rec2, radii, b.tkey[0], b.gid_emit);
+    hipLaunchKernelGGL(k_emit, dim3(c3d_cdiv(p.N, 256)), dim3(256), 0, s, p, g.order[res], g.offsets, g.rec0, g.rec2, radii, g.einfo, b.tkey[0], b.tval[0]);
     C3D_LAUNCH_CHECK();
     return 0;
 }
 
-// A5: [start,end) of every tile in the sorted pair list; also resolves sorted position -> Gaussian id
-__global__ void __launch_bounds__(256) k_ranges(const uint32_t* __restrict__ tkey, const uint32_t* __restrict__ e_sorted,
-                                                 const uint32_t* __restrict__ gid_emit, uint32_t* __restrict__ point_list,
-                                                 uint2* __restrict__ ranges, long long D) {
+// A5: [start,end) of every tile in the sorted pair list
+__global__ void __launch_bounds__(256) k_ranges(const uint32_t* __restrict__ tkey, uint2* __restrict__ ranges, long long D) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= D) return;
-    point_list[i] = gid_emit[e_sorted[i]];
     const uint32_t t = tkey[i];
     if (i == 0 || tkey[i - 1] != t) ranges[t].x = (uint32_t)i;
     if (i == D - 1 || tkey[i + 1] != t) ranges[t].y = (uint32_t)(i + 1);
@@ -176,7 +174,7 @@ __global__ void __launch_bounds__(256) k_ranges(const uint32_t* __restrict__ tke
 int gs_launch_ranges(const GsBinning& b, int res, long long D, int tiles, hipStream_t s) {
     C3D_CHECK(hipMemsetAsync(b.ranges, 0, sizeof(uint2) * (size_t)(tiles > 0 ? tiles : 1), s));
     if (D == 0) return 0;
-    hipLaunchKernelGGL(k_ranges, dim3(c3d_cdiv(D, 256)), dim3(256), 0, s, b.tkey[res], b.tval[res], b.gid_emit, b.point_list, b.ranges, D);
+    hipLaunchKernelGGL(k_ranges, dim3(c3d_cdiv(D, 256)), dim3(256), 0, s, b.tkey[res], b.ranges, D);
     C3D_LAUNCH_CHECK();
     return 0;
 }
@@ -276,7 +274,7 @@ int gs_launch_composite_fwd(const GsParams& p, const GsGeom& g, const GsBinning&
     const int tiles = p.gx * p.gy;
     if (tiles == 0) return 0;
     const int chunk = c3d_cdiv(tiles, 8);
-    hipLaunchKernelGGL(k_composite_fwd, dim3(chunk * 8), dim3(256), 0, s, p, b.ranges, b.point_list, g.rec0, g.rec1, g.rec2,
+    hipLaunchKernelGGL(k_composite_fwd, dim3(chunk * 8), dim3(256), 0, s, p, b.ranges, b.tval[res], g.rec0, g.rec1, g.rec2,
                        out_color, out_depth, out_alpha, im.final_T, im.n_contrib, chunk);
     C3D_LAUNCH_CHECK();
     return 0;

@@ -26,7 +26,7 @@ struct GsGeom {
     uint32_t* order[2];     // Gaussian ids, ping-pong; after stage 1 order[res] is rank -> id
     uint32_t* tiles_sorted; // tiles touched in rank order
     uint32_t* offsets;      // inclusive scan of tiles_sorted (rank order)
-    uint32_t* rank_of;      // Gaussian id -> depth rank (inverse of order[res])
+    uint4* einfo;           // per emitted Gaussian: {first emit index, x0 | y0<<16, x1 | y1<<16, 0} of its tile rect
     uint8_t* clamped;       // 3 bits per Gaussian: SH colour channel clamped at 0
     int* meta;              // [0] = result buffer index of the depth sort, [1] = num_rendered (device copy)
     void* tmp;              // scan / sort scratch
@@ -45,7 +45,7 @@ static inline void gs_carve_geom(char* base, int N, GsGeom& g) {
     g.order[1] = (uint32_t*)take(4 * n);
     g.tiles_sorted = (uint32_t*)take(4 * n);
     g.offsets = (uint32_t*)take(4 * n);
-    g.rank_of = (uint32_t*)take(4 * n);
+    g.einfo = (uint4*)take(16 * n);
     g.clamped = (uint8_t*)take(n);
     g.meta = (int*)take(64);
     size_t t1 = c3d_sort_tmp_bytes(n), t2 = c3d_scan_tmp_bytes(n);
@@ -54,14 +54,12 @@ static inline void gs_carve_geom(char* base, int N, GsGeom& g) {
 }
 
 // Binning state (per tile-splat pair).  Pairs are emitted in depth-rank order (emit index e: the pairs of one
-// Gaussian are contiguous in e), then stably sorted by tile id with e as payload.  After the sort:
-//   tval[res][pos]  = emit index of the pair at sorted position pos      (backward writes its record there)
-//   point_list[pos] = Gaussian id of that pair                          (what the compositing kernels gather)
+// Gaussian are contiguous in e, row-major over its tile rect), then stably sorted by tile id with the Gaussian
+// id as payload: tval[res] is the per-tile, depth-ordered splat list.  The emit index of a (tile, Gaussian) pair
+// is recomputed from GsGeom::einfo wherever it is needed (backward gradient records).
 struct GsBinning {
     uint32_t* tkey[2];
     uint32_t* tval[2];
-    uint32_t* gid_emit;    // [D] Gaussian id per emit index
-    uint32_t* point_list;  // [D] Gaussian id per sorted position
     uint2* ranges;   // [tiles]
     int* meta;       // [0] = result buffer index of the tile sort
     void* tmp;
@@ -74,8 +72,6 @@ static inline void gs_carve_binning(char* base, long long D, int tiles, GsBinnin
     b.tkey[1] = (uint32_t*)take(4 * d);
     b.tval[0] = (uint32_t*)take(4 * d);
     b.tval[1] = (uint32_t*)take(4 * d);
-    b.gid_emit = (uint32_t*)take(4 * d);
-    b.point_list = (uint32_t*)take(4 * d);
     b.ranges = (uint2*)take(8 * (size_t)(tiles > 0 ? tiles : 1));
     b.meta = (int*)take(64);
     b.tmp = take(c3d_sort_tmp_bytes(d));

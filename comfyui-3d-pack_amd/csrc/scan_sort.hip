@@ -91,7 +91,10 @@ int c3d_scan_u32(const uint32_t* in, uint32_t* out, size_t n, bool exclusive, vo
 
 // ------------------------------------------------------------------------------------------
 // Radix sort pass: 8-bit digits, 4096 keys per 256-thread block, each wave owns a contiguous
-// 1024-key chunk so that ranking is stable by construction.
+// 1024-key chunk so that ranking is stable by construction.  Three kernels per pass:
+//   k_radix_hist     per-block digit histogram -> table[digit][block], digit totals by integer atomics
+//   k_radix_rowscan  one wave per digit: exclusive scan of its table row on top of the digit's base
+//   k_radix_scatter  ballot ranking, block-local reorder in LDS, then run-contiguous global stores
 // ------------------------------------------------------------------------------------------
 #define RS_THREADS 256
 #define RS_ITEMS 16
@@ -99,7 +102,7 @@ int c3d_scan_u32(const uint32_t* in, uint32_t* out, size_t n, bool exclusive, vo
 #define RS_RADIX 256
 
 __global__ void __launch_bounds__(RS_THREADS) k_radix_hist(const uint32_t* __restrict__ keys, uint32_t* __restrict__ table,
-                                                            size_t n, int shift, int nblocks) {
+                                                            uint32_t* __restrict__ total, size_t n, int shift, int nblocks) {
     __shared__ uint32_t h[RS_RADIX];
     h[threadIdx.x] = 0;
     __syncthreads();
@@ -110,7 +113,28 @@ __global__ void __launch_bounds__(RS_THREADS) k_radix_hist(const uint32_t* __res
         if (idx < n) atomicAdd(&h[(keys[idx] >> shift) & (RS_RADIX - 1)], 1u);
     }
     __syncthreads();
-    table[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];  // digit-major
+    const uint32_t c = h[threadIdx.x];
+    table[(size_t)threadIdx.x * nblocks + blockIdx.x] = c;  // digit-major
+    if (c) atomicAdd(&total[threadIdx.x], c);
+}
+
+__global__ void __launch_bounds__(RS_THREADS) k_radix_rowscan(uint32_t* __restrict__ table, const uint32_t* __restrict__ total, int nblocks) {
+    const int lane = c3d_lane();
+    const int d = blockIdx.x * (RS_THREADS / 64) + (threadIdx.x >> 6);   // one wave per digit
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < RS_RADIX / 64; i++) { const int dd = i * 64 + lane; if (dd < d) s += total[dd]; }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+    uint32_t carry = s;
+    uint32_t* row = table + (size_t)d * nblocks;
+    for (int b0 = 0; b0 < nblocks; b0 += 64) {
+        const int b = b0 + lane;
+        const uint32_t v = (b < nblocks) ? row[b] : 0u;
+        const uint32_t incl = c3d_wave_incl_scan(v);
+        if (b < nblocks) row[b] = carry + incl - v;
+        carry += __shfl(incl, 63, 64);
+    }
 }
 
 template <bool IOTA>
@@ -118,11 +142,17 @@ __global__ void __launch_bounds__(RS_THREADS) k_radix_scatter(const uint32_t* __
                                                                uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                                const uint32_t* __restrict__ table, size_t n, int shift, int nblocks) {
     __shared__ uint32_t whist[RS_THREADS / 64][RS_RADIX];
+    __shared__ uint32_t lstart[RS_RADIX];    // first local slot of each digit
+    __shared__ uint32_t gbase[RS_RADIX];     // global position of that slot
+    __shared__ uint32_t skey[RS_TILE];
+    __shared__ uint32_t sval[RS_TILE];
+    __shared__ uint32_t scan_lds[4];
     const int lane = c3d_lane(), wave = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < (RS_THREADS / 64) * RS_RADIX; i += RS_THREADS) (&whist[0][0])[i] = 0;
     __syncthreads();
 
-    const size_t wbase = (size_t)blockIdx.x * RS_TILE + (size_t)wave * (RS_TILE / 4);
+    const size_t bbase = (size_t)blockIdx.x * RS_TILE;
+    const size_t wbase = bbase + (size_t)wave * (RS_TILE / 4);
     uint32_t key[RS_ITEMS], val[RS_ITEMS], rank[RS_ITEMS];
 #pragma unroll
     for (int i = 0; i < RS_ITEMS; i++) {
@@ -149,11 +179,17 @@ __global__ void __launch_bounds__(RS_THREADS) k_radix_scatter(const uint32_t* __
         rank[i] = prefix + r;
     }
     __syncthreads();
-    {   // per-digit bases: global base of (digit, block) + counts of earlier waves
-        int d = threadIdx.x;
-        uint32_t run = table[(size_t)d * nblocks + blockIdx.x];
+    {   // thread d: digit count over the 4 waves -> block-local exclusive start; per-wave offsets
+        const int d = threadIdx.x;
+        uint32_t c[RS_THREADS / 64], tot = 0;
 #pragma unroll
-        for (int w = 0; w < RS_THREADS / 64; w++) { uint32_t c = whist[w][d]; whist[w][d] = run; run += c; }
+        for (int w = 0; w < RS_THREADS / 64; w++) { c[w] = whist[w][d]; tot += c[w]; }
+        uint32_t blk_total;
+        uint32_t ls = block_excl_scan(tot, scan_lds, &blk_total);
+        lstart[d] = ls;
+        gbase[d] = table[(size_t)d * nblocks + blockIdx.x];
+#pragma unroll
+        for (int w = 0; w < RS_THREADS / 64; w++) { whist[w][d] = ls; ls += c[w]; }
     }
     __syncthreads();
 #pragma unroll
@@ -161,34 +197,49 @@ __global__ void __launch_bounds__(RS_THREADS) k_radix_scatter(const uint32_t* __
         size_t idx = wbase + (size_t)i * 64 + lane;
         if (idx < n) {
             uint32_t d = (key[i] >> shift) & (RS_RADIX - 1);
-            uint32_t pos = whist[wave][d] + rank[i];
-            keys_out[pos] = key[i];
-            vals_out[pos] = val[i];
+            uint32_t lp = whist[wave][d] + rank[i];
+            skey[lp] = key[i];
+            sval[lp] = val[i];
+        }
+    }
+    __syncthreads();
+    const int cnt = (int)((n - bbase) < (size_t)RS_TILE ? (n - bbase) : (size_t)RS_TILE);
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS; i++) {
+        const int lp = i * RS_THREADS + threadIdx.x;     // consecutive lanes -> consecutive slots of a digit run
+        if (lp < cnt) {
+            const uint32_t k = skey[lp];
+            const uint32_t d = (k >> shift) & (RS_RADIX - 1);
+            const uint32_t pos = gbase[d] + ((uint32_t)lp - lstart[d]);
+            keys_out[pos] = k;
+            vals_out[pos] = sval[lp];
         }
     }
 }
 
+#define RS_MAX_PASSES 4
 size_t c3d_sort_tmp_bytes(size_t n) {
     size_t nb = (size_t)c3d_cdiv((long long)(n ? n : 1), RS_TILE);
-    size_t tbl = c3d_align(sizeof(uint32_t) * RS_RADIX * nb);
-    return tbl + c3d_scan_tmp_bytes(RS_RADIX * nb);
+    return c3d_align(sizeof(uint32_t) * RS_RADIX * nb) + c3d_align(sizeof(uint32_t) * RS_RADIX * RS_MAX_PASSES);
 }
 
 int c3d_sort_pairs_u32(uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32_t* vals1, bool iota_vals,
                        size_t n, int end_bit, void* tmp, int* result_buf, hipStream_t s) {
     *result_buf = 0;
     if (n == 0) return 0;
+    if (end_bit > 8 * RS_MAX_PASSES) { c3d_set_error("c3d_sort_pairs_u32: end_bit %d > %d", end_bit, 8 * RS_MAX_PASSES); return -1; }
     int nb = c3d_cdiv((long long)n, RS_TILE);
     uint32_t* table = (uint32_t*)tmp;
-    void* scan_tmp = (char*)tmp + c3d_align(sizeof(uint32_t) * RS_RADIX * (size_t)nb);
+    uint32_t* totals = (uint32_t*)((char*)tmp + c3d_align(sizeof(uint32_t) * RS_RADIX * (size_t)nb));
+    C3D_CHECK(hipMemsetAsync(totals, 0, sizeof(uint32_t) * RS_RADIX * RS_MAX_PASSES, s));
     uint32_t* k[2] = {keys0, keys1};
     uint32_t* v[2] = {vals0, vals1};
-    int cur = 0;
+    int cur = 0, pass = 0;
     bool first = true;
-    for (int shift = 0; shift < end_bit || first; shift += 8) {
-        hipLaunchKernelGGL(k_radix_hist, dim3(nb), dim3(RS_THREADS), 0, s, k[cur], table, n, shift, nb);
-        int rc = c3d_scan_u32(table, table, (size_t)RS_RADIX * nb, true, scan_tmp, s);
-        if (rc) return rc;
+    for (int shift = 0; shift < end_bit || first; shift += 8, pass++) {
+        uint32_t* tot = totals + pass * RS_RADIX;
+        hipLaunchKernelGGL(k_radix_hist, dim3(nb), dim3(RS_THREADS), 0, s, k[cur], table, tot, n, shift, nb);
+        hipLaunchKernelGGL(k_radix_rowscan, dim3(RS_RADIX / (RS_THREADS / 64)), dim3(RS_THREADS), 0, s, table, tot, nb);
         if (first && iota_vals)
             hipLaunchKernelGGL(k_radix_scatter<true>, dim3(nb), dim3(RS_THREADS), 0, s, k[cur], v[cur], k[cur ^ 1], v[cur ^ 1], table, n, shift, nb);
         else
