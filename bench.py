@@ -60,6 +60,7 @@ def algorithmic_bytes(N, K, P, n_vis, D):
         "gs_composite_fwd": 44 * D + 20 * P,              # per-tile splat gather 44 + rgb/depth/alpha stores 20
         "gs_composite_bwd": 48 * D + 32 * P + 48 * n_vis, # gather 44 + id 4; pixel grads 20 + aux 12; gradient record
         "gs_preprocess_bwd": 48 * n_vis + 2 * N * (44 + 12 * K),
+        "adam": 28 * N * (11 + 3 * K),                    # p,g,m,v read + p,m,v write
     }
 
 
@@ -110,7 +111,8 @@ def main():
     opt = None
     if a.mode == "train":
         lrs = {"means3D": 1.6e-4, "shs": 2.5e-3, "opacities": 0.05, "scales": 5e-3, "rotations": 1e-3}
-        opt = torch.optim.Adam([{"params": [params[k]], "lr": lr} for k, lr in lrs.items()], lr=0.0, eps=1e-15, fused=True)
+        from c3d_hip.optim import FusedAdam
+        opt = FusedAdam([{"params": [params[k]], "lr": lr} for k, lr in lrs.items()], lr=0.0, eps=1e-15)
     names = ["means3D", "shs", "opacities", "scales", "rotations"]
     stats = {"n_vis": [], "D": []}
 
@@ -130,9 +132,12 @@ def main():
         if a.mode != "fwd" and world > 1:
             flat = torch.cat([params[k].grad.reshape(N, -1) for k in names], dim=1)   # [N, 59] dense gradient
             if a.exchange == "allgather":
-                buf = torch.empty((world,) + tuple(flat.shape), device=dev)
+                buf = torch.empty((world * N, flat.shape[1]), device=dev)
                 dist.all_gather_into_tensor(buf, flat)
-                flat = buf.sum(dim=0)   # fixed rank order -> bit-identical replicas
+                buf = buf.view(world, N, -1)
+                flat = buf[0].clone()
+                for r in range(1, world):   # fixed rank order -> bit-identical replicas
+                    flat += buf[r]
             else:
                 dist.all_reduce(flat)
             off = 0

@@ -1,0 +1,136 @@
+"""3DGS trainer: GSParams, GaussianSplattingCameraController, GaussianSplatting3D.
+
+Host-side mirror of /root/reference/MVs_Algorithms/GaussianSplatting/main_3DGS.py: GSParams defaults :15-42,
+controller :76-82, training loop :129-232 (per step: LR update :154, `batch_size` random views :158-174, loss =
+(1-l_ssim) L1 + l_alpha MSE(alpha, mask) + l_ssim (1 - MS-SSIM) :184-192, backward + Adam :205-207).
+Differences, all additive: device is a parameter; the optimizer is the fused HIP Adam; `process_group` shards the
+step's views over ranks with one gradient exchange (c3d_hip/parallel.py); densify/prune (:210-224) is a SURVEY 8f row
+and is not built yet -- the trainer refuses to run with it enabled instead of silently skipping it.
+"""
+import random
+from dataclasses import dataclass
+
+import torch
+import torch.nn.functional as F
+
+from c3d_hip import parallel
+from shared_utils.camera_utils import BaseCameraController, MiniCam, get_projection_matrix
+from shared_utils.msssim import MS_SSIM
+from .main_3DGS_renderer import GaussianSplattingRenderer
+
+
+@dataclass
+class GSParams:
+    # training
+    training_iterations: int = 30_000
+    batch_size: int = 1
+    lambda_ssim: float = 0.2
+    lambda_alpha: float = 3
+    lambda_offset: float = 0
+    lambda_offset_opacity: float = 0
+    invert_bg_prob: float = 0.5
+    # learning rates
+    feature_lr: float = 0.0025
+    opacity_lr: float = 0.05
+    scaling_lr: float = 0.005
+    rotation_lr: float = 0.001
+    position_lr_init: float = 0.00016
+    position_lr_final: float = 0.0000016
+    position_lr_delay_mult: float = 0.01
+    position_lr_max_steps: int = 30_000
+    # densify / prune
+    num_pts: int = 10_000
+    K: int = 3
+    percent_dense: float = 0.01
+    density_start_iter: int = 500
+    density_end_iter: int = 15_000
+    densification_interval: int = 100
+    opacity_reset_interval: int = 3000
+    densify_grad_threshold: float = 0.0002
+    # model
+    sh_degree: int = 3
+
+
+class GaussianSplattingCameraController(BaseCameraController):
+    def post_init(self):
+        self.projection_matrix = get_projection_matrix(self.cam.near, self.cam.far, self.cam.fovx, self.cam.fovy).transpose(0, 1).to(self.device)
+
+    def get_render_result(self, render_pose, bg_color, **kwargs):
+        cam = MiniCam(render_pose, self.cam.W, self.cam.H, self.cam.fovy, self.cam.fovx, self.cam.near, self.cam.far,
+                      self.projection_matrix, device=self.device)
+        return self.renderer.render(cam, bg_color=bg_color, **kwargs)
+
+
+def _fit(img, H, W, device):
+    """[1,H0,W0,C] in [0,1] -> [1,C,H,W] on device (bilinear when the size differs; image_utils.py:8-14)"""
+    t = img.permute(0, 3, 1, 2).contiguous().float().to(device)
+    return t if t.shape[-2:] == (H, W) else F.interpolate(t, (H, W), mode="bilinear", align_corners=False)
+
+
+class GaussianSplatting3D:
+    def __init__(self, gs_params=None, init_input=None, device='cuda', process_group=None, exchange="allgather"):
+        self.device = torch.device(device)
+        self.gs_params = gs_params = gs_params or GSParams()
+        self.group, self.exchange = process_group, exchange
+        self.renderer = GaussianSplattingRenderer(sh_degree=gs_params.sh_degree, device=device)
+        self.renderer.initialize(init_input, num_pts=gs_params.num_pts)
+        g = self.renderer.gaussians
+        g.training_setup(gs_params)
+        g.active_sh_degree = g.max_sh_degree          # no progressive SH level, as the reference
+        self.optimizer = g.optimizer
+        self.ms_ssim_loss = MS_SSIM(data_range=1, size_average=True, channel=3)
+        self.params = [g._xyz, g._features_dc, g._features_rest, g._opacity, g._scaling, g._rotation]
+        parallel.broadcast_parameters(self.params, src=0, group=process_group)
+
+    def prepare_training(self, reference_images, reference_masks, reference_orbit_camera_poses, reference_orbit_camera_fovy):
+        self.ref_imgs_num = len(reference_images)
+        self.ref_size_H, self.ref_size_W = reference_images[0].shape[0], reference_images[0].shape[1]
+        self.cam_controller = GaussianSplattingCameraController(self.renderer, self.ref_size_W, self.ref_size_H,
+                                                                reference_orbit_camera_fovy, self.gs_params.invert_bg_prob, None, self.device)
+        self.all_ref_cam_poses = reference_orbit_camera_poses
+        H, W = self.ref_size_H, self.ref_size_W
+        self.ref_imgs_torch = torch.cat([_fit(im.unsqueeze(0), H, W, self.device) for im in reference_images], dim=0)            # [V,3,H,W]
+        self.ref_masks_torch = torch.cat([_fit(m.unsqueeze(2).unsqueeze(0), H, W, self.device) for m in reference_masks], dim=0)  # [V,1,H,W]
+
+    def training_step(self, step, view_indices):
+        """one optimisation step over `view_indices` (the GLOBAL batch; this rank renders its shard). -> loss value tensor"""
+        p = self.gs_params
+        if p.density_start_iter <= step <= p.density_end_iter:
+            raise NotImplementedError("densify/prune is not built yet (SURVEY 8f-3): run with density_end_iter < density_start_iter")
+        world = torch.distributed.get_world_size(self.group) if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
+        rank = torch.distributed.get_rank(self.group) if world > 1 else 0
+        self.renderer.gaussians.update_learning_rate(step)
+        mine = parallel.shard_views(view_indices, rank, world)
+        imgs, refs, alphas, masks = [], [], [], []
+        for i in mine:
+            out = self.cam_controller.render_at_pose(self.all_ref_cam_poses[i])
+            m = self.ref_masks_torch[i]
+            imgs.append((out["image"] * m).unsqueeze(0)); refs.append((self.ref_imgs_torch[i] * m).unsqueeze(0))
+            alphas.append(out["alpha"].unsqueeze(0)); masks.append(m.unsqueeze(0))
+        imgs, refs, alphas, masks = torch.cat(imgs), torch.cat(refs), torch.cat(alphas), torch.cat(masks)
+        loss = (1 - p.lambda_ssim) * F.l1_loss(imgs, refs) + p.lambda_alpha * F.mse_loss(alphas, masks) \
+            + p.lambda_ssim * (1 - self.ms_ssim_loss(refs, imgs))
+        g = self.renderer.gaussians
+        if p.lambda_offset > 0 or p.lambda_offset_opacity > 0:
+            off = (g.init_xyz - g._xyz).norm(dim=-1, keepdim=True)
+            if p.lambda_offset > 0:
+                loss = loss + p.lambda_offset * off.mean()
+            if p.lambda_offset_opacity > 0:
+                loss = loss + p.lambda_offset_opacity * (off.detach() * g.get_opacity).mean()
+        loss.backward()
+        # batch losses are means over views: equal shards => the global gradient is the mean of the ranks' gradients
+        parallel.exchange_gradients(self.params, self.group, self.exchange, average=True)
+        self.optimizer.step()
+        self.optimizer.zero_grad()
+        return loss.detach()
+
+    def training(self, progress=None):
+        rng = random.Random(0) if self.group is not None else random   # ranks must draw the same views
+        for step in range(self.gs_params.training_iterations):
+            idx = [rng.randint(0, self.ref_imgs_num - 1) for _ in range(self.gs_params.batch_size)]
+            self.training_step(step, idx)
+            if progress is not None:
+                progress(step + 1)
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        self.need_update = True

@@ -25,7 +25,7 @@ def _sources():
 
 def _digest():
     h = hashlib.sha256()
-    for f in sorted(os.listdir(CSRC)) + ["../../include/c3d_gs.h", "../../include/c3d_mesh.h"]:
+    for f in sorted(os.listdir(CSRC)) + ["../../include/c3d_gs.h", "../../include/c3d_optim.h", "../../include/c3d_mesh.h"]:
         p = os.path.join(CSRC, f)
         if os.path.isfile(p):
             h.update(f.encode())

@@ -38,7 +38,10 @@
 extern "C" {
 #endif
 
+#ifndef C3D_STREAM_T
+#define C3D_STREAM_T
 typedef void* c3d_stream_t; /* hipStream_t */
+#endif
 
 /* mirrors GaussianRasterizationSettings (main_3DGS_renderer.py:849-862) */
 typedef struct c3d_gs_settings {

@@ -1,0 +1,27 @@
+/*
+ * c3d_optim.h -- C-ABI of the fused optimizer step used by the shared-Gaussian training loop (libc3d_hip.so).
+ *
+ * Replaces, for this path, the torch.optim.Adam step the reference takes at
+ *   /root/reference/MVs_Algorithms/GaussianSplatting/main_3DGS.py:206            (optimizer.step())
+ * over the parameter groups declared at
+ *   /root/reference/MVs_Algorithms/GaussianSplatting/main_3DGS_renderer.py:435-453 (Adam, lr per group, eps = 1e-15).
+ * Semantics are torch.optim.Adam's (no weight decay, no amsgrad, bias correction by `step`), one call per tensor:
+ *   m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+ * All pointers are DEVICE pointers to contiguous float32, 16-byte aligned; the call is asynchronous on `stream`.
+ */
+#ifndef C3D_OPTIM_H
+#define C3D_OPTIM_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+#ifndef C3D_STREAM_T
+#define C3D_STREAM_T
+typedef void* c3d_stream_t; /* hipStream_t */
+#endif
+int c3d_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                  float beta2, float eps, int64_t step, c3d_stream_t stream);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -319,3 +319,55 @@ def test_backward_is_bit_reproducible():
         grads.append({k: inp[k].grad.clone() for k in ("means3D", "opacities", "shs", "scales", "rotations")})
     for k in grads[0]:
         assert torch.equal(grads[0][k], grads[1][k]), k
+
+
+# ---------------------------------------------------------------- training-step pieces
+def test_fused_adam_matches_torch():
+    from c3d_hip.optim import FusedAdam
+    torch.manual_seed(0)
+    shapes = [(1000, 3), (1000, 1, 3), (1000, 15, 3), (1000, 1), (1003,)]   # incl. a size that is not a multiple of 4
+    a = [torch.nn.Parameter(torch.randn(s, device="cuda")) for s in shapes]
+    b = [torch.nn.Parameter(p.detach().clone()) for p in a]
+    lrs = [1.6e-3, 2.5e-3, 1.25e-4, 0.05, 5e-3]
+    oa = FusedAdam([{"params": [p], "lr": lr} for p, lr in zip(a, lrs)], lr=0.0, eps=1e-15)
+    ob = torch.optim.Adam([{"params": [p], "lr": lr} for p, lr in zip(b, lrs)], lr=0.0, eps=1e-15)
+    for it in range(5):
+        for p, q in zip(a, b):
+            g = torch.randn_like(p) * (10.0 ** (it - 2))
+            p.grad, q.grad = g.clone(), g.clone()
+        oa.step(); ob.step()
+    for p, q in zip(a, b):
+        assert torch.allclose(p, q, rtol=2e-5, atol=1e-7), (p - q).abs().max().item()
+        assert torch.allclose(oa.state[p]["exp_avg_sq"], ob.state[q]["exp_avg_sq"], rtol=1e-6, atol=1e-12)
+
+
+def test_renderer_and_trainer_mirror_reduce_the_loss():
+    """GaussianSplattingRenderer.render through the controller (the reference's call stack) and a few
+    optimisation steps of GaussianSplatting3D: the loss must go down and parameters must stay finite."""
+    from MVs_Algorithms.GaussianSplatting.main_3DGS import GSParams, GaussianSplatting3D, GaussianSplattingCameraController
+    from MVs_Algorithms.GaussianSplatting.main_3DGS_renderer import GaussianSplattingRenderer
+    np.random.seed(0); torch.manual_seed(0)
+    H = W = 192
+    poses = [[1.75, 0.0, az, 0.0, 0.0, 0.0] for az in (0.0, 90.0, 180.0, -90.0)]
+    # targets: a denser, more opaque ball rendered with the same stack
+    tgt = GaussianSplattingRenderer(sh_degree=3, device="cuda")
+    tgt.initialize(None, num_pts=4000)
+    with torch.no_grad():
+        tgt.gaussians._opacity += 3.0
+        tgt.gaussians._features_dc += 1.0
+    tgt.gaussians.active_sh_degree = 3
+    ctl = GaussianSplattingCameraController(tgt, W, H, 49.1, static_bg=[1.0, 1.0, 1.0], device="cuda")
+    with torch.no_grad():
+        imgs, masks, extra = ctl.render_all_pose(poses)
+    assert imgs.shape == (4, 3, H, W) and masks.shape == (4, 1, H, W) and extra["radii"].shape == (4, 4000)
+    assert 0.02 < masks.mean().item() < 0.9
+    ref_images = [imgs[i].permute(1, 2, 0).cpu() for i in range(4)]       # ComfyUI IMAGE layout [H,W,3]
+    ref_masks = [masks[i, 0].cpu() for i in range(4)]
+    p = GSParams(training_iterations=30, batch_size=2, num_pts=3000, density_start_iter=10 ** 9, density_end_iter=-1, invert_bg_prob=1.0)
+    tr = GaussianSplatting3D(p, None, device="cuda")
+    tr.prepare_training(ref_images, ref_masks, poses, 49.1)
+    losses = [tr.training_step(s, [s % 4, (s + 1) % 4]).item() for s in range(30)]
+    assert np.isfinite(losses).all()
+    assert np.mean(losses[-5:]) < 0.9 * np.mean(losses[:5]), losses
+    for q in tr.params:
+        assert torch.isfinite(q).all()
