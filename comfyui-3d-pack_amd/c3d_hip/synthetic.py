@@ -86,3 +86,44 @@ def make_small_scene(N=48, seed=7, sh_degree=3, scale=0.08, spread=0.6):
             "scales": np.exp(rng.normal(math.log(scale), 0.4, size=(N, 3))).astype(np.float32),
             "rotations": rot.astype(np.float32),
             "opacities": rng.uniform(0.05, 0.95, size=(N, 1)).astype(np.float32)}
+
+
+# ---------------------------------------------------------------------------------------------- mesh workloads
+def make_uv_sphere(n_lat=24, n_lon=48, radius=0.6, displacement=0.05, seed=5):
+    """lat-long sphere displaced by seeded low-frequency noise (BASELINE config 5 uses 500x500 -> 499,000 triangles).
+    Returns v [V,3] f32, f [T,3] i32, vt [V,2] f32 (lat-long UVs, one per vertex), vn [V,3] f32."""
+    rng = np.random.default_rng(seed)
+    lat = np.linspace(0.0, np.pi, n_lat + 1)[1:-1]                      # interior rings
+    lon = np.linspace(0.0, 2 * np.pi, n_lon, endpoint=False)
+    th, ph = np.meshgrid(lat, lon, indexing="ij")
+    dirs = np.stack([np.sin(th) * np.cos(ph), np.cos(th), np.sin(th) * np.sin(ph)], -1).reshape(-1, 3)
+    dirs = np.concatenate([dirs, [[0, 1, 0]], [[0, -1, 0]]], 0)
+    k = rng.normal(size=(4, 3)) * 2.0
+    phs = rng.uniform(0, 2 * np.pi, size=4)
+    disp = sum(np.sin(dirs @ k[i] + phs[i]) for i in range(4)) / 4.0
+    v = dirs * (radius * (1.0 + displacement * disp))[:, None]
+    R = n_lat - 1
+    idx = lambda r, c: r * n_lon + (c % n_lon)
+    f = []
+    for r in range(R - 1):
+        for c in range(n_lon):
+            f.append([idx(r, c), idx(r + 1, c), idx(r, c + 1)])
+            f.append([idx(r, c + 1), idx(r + 1, c), idx(r + 1, c + 1)])
+    top, bot = R * n_lon, R * n_lon + 1
+    for c in range(n_lon):
+        f.append([top, idx(0, c), idx(0, c + 1)])
+        f.append([bot, idx(R - 1, c + 1), idx(R - 1, c)])
+    vt = np.concatenate([np.stack([ph / (2 * np.pi), th / np.pi], -1).reshape(-1, 2), [[0.5, 0.0]], [[0.5, 1.0]]], 0)
+    vn = v / np.linalg.norm(v, axis=1, keepdims=True)
+    return v.astype(np.float32), np.asarray(f, dtype=np.int32), vt.astype(np.float32), vn.astype(np.float32)
+
+
+def mesh_clip_positions(v, elevation, azimuth, radius, W, H, fovy_deg=49.1, near=0.01, far=100):
+    """clip-space vertices exactly as DiffRastRenderer.render builds them (diff_mesh_renderer.py:90-95):
+    v_cam = [v,1] @ inv(pose)^T ; v_clip = v_cam @ proj^T with proj = OrbitCamera.perspective (y flipped)."""
+    cam = OrbitCamera(W, H, fovy=fovy_deg, near=near, far=far)
+    pose = orbit_camera(elevation, azimuth, radius).astype(np.float32)
+    vh = np.concatenate([v, np.ones((v.shape[0], 1), np.float32)], 1)
+    v_cam = vh @ np.linalg.inv(pose).T.astype(np.float32)
+    v_clip = v_cam @ cam.perspective.T
+    return v_clip.astype(np.float32)[None], v_cam.astype(np.float32)[None], pose

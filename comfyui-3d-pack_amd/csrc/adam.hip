@@ -6,7 +6,7 @@
 #include "c3d_common.h"
 
 __global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                                               long long n, float lr_over_bc1, float inv_sqrt_bc2, float b1, float b2, float eps) {
+                                               long long n, float lr_over_bc1, float inv_sqrt_bc2, float b1, float b2, float omb1, float omb2, float eps) {
     const long long n4 = n >> 2;
     const long long stride = (long long)gridDim.x * blockDim.x;
     float4* p4 = reinterpret_cast<float4*>(p); const float4* g4 = reinterpret_cast<const float4*>(g);
@@ -15,8 +15,8 @@ __global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float
         float4 pp = p4[i], mm = m4[i], vv = v4[i];
         const float4 gg = g4[i];
 #define C3D_ADAM1(c)                                                  \
-    mm.c = b1 * mm.c + (1.f - b1) * gg.c;                             \
-    vv.c = b2 * vv.c + (1.f - b2) * gg.c * gg.c;                      \
+    mm.c = b1 * mm.c + omb1 * gg.c;                                   \
+    vv.c = b2 * vv.c + omb2 * gg.c * gg.c;                            \
     pp.c -= lr_over_bc1 * mm.c / (sqrtf(vv.c) * inv_sqrt_bc2 + eps);
         C3D_ADAM1(x) C3D_ADAM1(y) C3D_ADAM1(z) C3D_ADAM1(w)
         p4[i] = pp; m4[i] = mm; v4[i] = vv;
@@ -24,27 +24,27 @@ __global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float
     // tail (n % 4) by the first lanes of block 0
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const long long i = (n4 << 2) + threadIdx.x;
-        float mm = b1 * m[i] + (1.f - b1) * g[i];
-        float vv = b2 * v[i] + (1.f - b2) * g[i] * g[i];
+        float mm = b1 * m[i] + omb1 * g[i];
+        float vv = b2 * v[i] + omb2 * g[i] * g[i];
         m[i] = mm; v[i] = vv;
         p[i] -= lr_over_bc1 * mm / (sqrtf(vv) * inv_sqrt_bc2 + eps);
     }
 }
 
-extern "C" int c3d_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
-                             float beta2, float eps, int64_t step, c3d_stream_t stream) {
+extern "C" int c3d_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1,
+                             double beta2, double eps, int64_t step, c3d_stream_t stream) {
     if (n <= 0) return 0;
     if (!param || !grad || !exp_avg || !exp_avg_sq) { c3d_set_error("c3d_adam_step: NULL pointer"); return -1; }
     if (step < 1) { c3d_set_error("c3d_adam_step: step must be >= 1"); return -1; }
     if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) { c3d_set_error("c3d_adam_step: pointers must be 16-byte aligned"); return -1; }
-    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
     hipStream_t s = (hipStream_t)stream;
     C3dProfScope ps(C3D_P_ADAM, s);
     long long blocks = ((n >> 2) + 255) / 256;
     if (blocks > 256 * 8) blocks = 256 * 8;   // 8 workgroups per CU, grid-stride the rest
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq, (long long)n,
-                       (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), beta1, beta2, eps);
+                       (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps);
     C3D_LAUNCH_CHECK();
     return 0;
 }

@@ -7,7 +7,8 @@
  *   /root/reference/MVs_Algorithms/GaussianSplatting/main_3DGS_renderer.py:435-453 (Adam, lr per group, eps = 1e-15).
  * Semantics are torch.optim.Adam's (no weight decay, no amsgrad, bias correction by `step`), one call per tensor:
  *   m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
- * All pointers are DEVICE pointers to contiguous float32, 16-byte aligned; the call is asynchronous on `stream`.
+ * Hyper-parameters are doubles so that (1 - beta) is formed in double like torch does (beta2 = 0.999: 1e-5 relative
+ * difference otherwise).  All pointers are DEVICE pointers to contiguous float32, 16-byte aligned; the call is asynchronous on `stream`.
  */
 #ifndef C3D_OPTIM_H
 #define C3D_OPTIM_H
@@ -19,8 +20,8 @@ extern "C" {
 #define C3D_STREAM_T
 typedef void* c3d_stream_t; /* hipStream_t */
 #endif
-int c3d_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
-                  float beta2, float eps, int64_t step, c3d_stream_t stream);
+int c3d_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1,
+                  double beta2, double eps, int64_t step, c3d_stream_t stream);
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,453 @@
+/*
+ * mesh_oracle.c -- CPU restatement of the four differentiable mesh-rendering ops that
+ * ComfyUI-3D-Pack's DiffRastRenderer calls through `nvdiffrast.torch`:
+ *   rasterize, interpolate, texture (linear / nearest), antialias -- forward and backward.
+ *
+ * THIS IS TEST INFRASTRUCTURE (only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may load it; the product under comfyui-3d-pack_amd/ never does).
+ *
+ * PARITY UNPINNED: nvdiffrast is an un-vendored third-party wheel
+ * (/root/reference/_Pre_Builds/_Build_Scripts/dependencies.txt:3, my-reqs.txt:74: nvdiffrast 0.3.3)
+ * and the reference ships no tests or golden vectors for this path.  This
+ * file restates the published semantics of those ops anchored
+ * on the reference's call sites:
+ *   /root/reference/MVs_Algorithms/DiffRastMesh/diff_mesh_renderer.py:97   rasterize(ctx, v_clip[1,V,4], f, (h,w))
+ *   :101,138  antialias(color, rast, v_clip, f)         :104,110,131  interpolate(attr, rast, tri[, rast_db, diff_attrs='all'])
+ *   :105      texture(tex[1,Ht,Wt,3], uv, uv_da=..., filter_mode='linear')  (uv_da is ignored for 'linear')
+ * Conventions restated: clip-space input; pixel (x,y) centre at NDC ((x+.5)2/W-1, (y+.5)2/H-1), row 0 at
+ * NDC y = -1; rast = (u, v, z/w, tri_id+1), u,v weight vertices 0 and 1, perspective correct; rast_db =
+ * (du/dX, du/dY, dv/dX, dv/dY) per pixel; coverage on vertices snapped to 1/16 pixel with exact integer
+ * edge functions and a top-left style tie rule; nearest z/w wins, ties to the lower triangle index;
+ * texture: texel centres at half integers, boundary wrap/clamp; antialias: for horizontally/vertically
+ * adjacent pixels with different triangle ids, the nearer triangle's silhouette edge that crosses the
+ * segment between the pixel centres blends the two colours linearly by the crossing position.
+ * Gradients: u,v -> clip x,y,w; attributes; texels and uv; colours and the silhouette edge's vertices.
+ * (Gradients w.r.t. rast_db / out_da are not propagated: no consumer on the reference's path.)
+ * Pinned by analytic cases, invariants and central finite differences in float64 (tests/test_mesh_oracle.py).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifndef REAL
+#define REAL float
+#endif
+typedef REAL real;
+
+static real clampr(real v, real lo, real hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+int mesh_oracle_sizeof_real(void) { return (int)sizeof(real); }
+
+/* ------------------------------------------------------------------ rasterize */
+static int64_t snap(real ndc, int S) {   /* 1/16-pixel units from the lower/left border, round to nearest even */
+    double v = (double)((real)(ndc * (real)(S * 8))) + (double)S * 8.0;
+    return (int64_t)nearbyint(v);
+}
+/* tie rule for a pixel centre exactly on an edge with (orientation-normalised) direction (dx,dy) */
+static int edge_owns_tie(int64_t dx, int64_t dy) { return dy > 0 || (dy == 0 && dx < 0); }
+
+typedef struct { real b0, b1, zw, iw; real dudx, dudy, dvdx, dvdy; } frag_t;
+
+static void shade(const real *p0, const real *p1, const real *p2, real fx, real fy, real xs, real ys, frag_t *f) {
+    real p0x = p0[0] - fx * p0[3], p0y = p0[1] - fy * p0[3];
+    real p1x = p1[0] - fx * p1[3], p1y = p1[1] - fy * p1[3];
+    real p2x = p2[0] - fx * p2[3], p2y = p2[1] - fy * p2[3];
+    real a0 = p1x * p2y - p1y * p2x, a1 = p2x * p0y - p2y * p0x, a2 = p0x * p1y - p0y * p1x;
+    real iw = (real)1 / (a0 + a1 + a2);
+    f->iw = iw;
+    f->b0 = a0 * iw; f->b1 = a1 * iw;
+    real z = p0[2] * a0 + p1[2] * a1 + p2[2] * a2, w = p0[3] * a0 + p1[3] * a1 + p2[3] * a2;
+    f->zw = z / w;
+    real dfxdx = xs * iw, dfydy = ys * iw;
+    real da0dx = p2[1] * p1[3] - p1[1] * p2[3], da0dy = p1[0] * p2[3] - p2[0] * p1[3];
+    real da1dx = p0[1] * p2[3] - p2[1] * p0[3], da1dy = p2[0] * p0[3] - p0[0] * p2[3];
+    real da2dx = p1[1] * p0[3] - p0[1] * p1[3], da2dy = p0[0] * p1[3] - p1[0] * p0[3];
+    real datdx = da0dx + da1dx + da2dx, datdy = da0dy + da1dy + da2dy;
+    f->dudx = dfxdx * (f->b0 * datdx - da0dx); f->dudy = dfydy * (f->b0 * datdy - da0dy);
+    f->dvdx = dfxdx * (f->b1 * datdx - da1dx); f->dvdy = dfydy * (f->b1 * datdy - da1dy);
+}
+
+void mesh_rasterize_fwd(const real *pos, const int32_t *tri, int B, int V, int T, int H, int W, real *rast, real *rast_db) {
+    const real xs = (real)2 / W, ys = (real)2 / H;
+    size_t P = (size_t)H * W;
+    real *zbest = (real *)malloc(P * sizeof(real));
+    int32_t *tbest = (int32_t *)malloc(P * sizeof(int32_t));
+    for (int b = 0; b < B; b++) {
+        const real *pb = pos + (size_t)b * V * 4;
+        for (size_t i = 0; i < P; i++) { zbest[i] = 0; tbest[i] = -1; }
+        for (int t = 0; t < T; t++) {
+            int i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
+            if (i0 < 0 || i0 >= V || i1 < 0 || i1 >= V || i2 < 0 || i2 >= V) continue;
+            const real *p0 = pb + 4 * i0, *p1 = pb + 4 * i1, *p2 = pb + 4 * i2;
+            if (!(p0[3] > 0 && p1[3] > 0 && p2[3] > 0)) continue;   /* triangles touching the w<=0 half space are dropped */
+            int64_t X[3], Y[3];
+            const real *pp[3] = {p0, p1, p2};
+            int bad = 0;
+            for (int k = 0; k < 3; k++) {
+                real nx = pp[k][0] / pp[k][3], ny = pp[k][1] / pp[k][3];
+                if (!(fabs((double)nx) < 1e4 && fabs((double)ny) < 1e4)) { bad = 1; break; }
+                X[k] = snap(nx, W); Y[k] = snap(ny, H);
+            }
+            if (bad) continue;
+            int64_t area = (X[1] - X[0]) * (Y[2] - Y[0]) - (Y[1] - Y[0]) * (X[2] - X[0]);
+            if (area == 0) continue;
+            int64_t s = area > 0 ? 1 : -1;
+            int64_t xmin = X[0] < X[1] ? X[0] : X[1]; if (X[2] < xmin) xmin = X[2];
+            int64_t xmax = X[0] > X[1] ? X[0] : X[1]; if (X[2] > xmax) xmax = X[2];
+            int64_t ymin = Y[0] < Y[1] ? Y[0] : Y[1]; if (Y[2] < ymin) ymin = Y[2];
+            int64_t ymax = Y[0] > Y[1] ? Y[0] : Y[1]; if (Y[2] > ymax) ymax = Y[2];
+            /* pixel centre c = 16*px + 8 */
+            int64_t px0 = (xmin - 8 + 15) >> 4, px1 = (xmax - 8) >> 4, py0 = (ymin - 8 + 15) >> 4, py1 = (ymax - 8) >> 4;
+            if (px0 < 0) px0 = 0; if (py0 < 0) py0 = 0; if (px1 > W - 1) px1 = W - 1; if (py1 > H - 1) py1 = H - 1;
+            for (int64_t py = py0; py <= py1; py++)
+                for (int64_t px = px0; px <= px1; px++) {
+                    int64_t cx = 16 * px + 8, cy = 16 * py + 8;
+                    int inside = 1;
+                    for (int k = 0; k < 3 && inside; k++) {
+                        int a = k, c = (k + 1) % 3;
+                        int64_t dx = (X[c] - X[a]) * s, dy = (Y[c] - Y[a]) * s;
+                        int64_t e = dx * (cy - Y[a]) - dy * (cx - X[a]);
+                        if (e < 0 || (e == 0 && !edge_owns_tie(dx, dy))) inside = 0;
+                    }
+                    if (!inside) continue;
+                    frag_t f;
+                    shade(p0, p1, p2, xs * ((real)px + (real)0.5) - (real)1, ys * ((real)py + (real)0.5) - (real)1, xs, ys, &f);
+                    if (!(f.zw >= -1 && f.zw <= 1)) continue;   /* per-pixel near/far clip */
+                    size_t pid = (size_t)py * W + px;
+                    if (tbest[pid] < 0 || f.zw < zbest[pid]) { zbest[pid] = f.zw; tbest[pid] = t; }
+                }
+        }
+        for (int py = 0; py < H; py++)
+            for (int px = 0; px < W; px++) {
+                size_t pid = (size_t)py * W + px, o = ((size_t)b * P + pid) * 4;
+                int t = tbest[pid];
+                if (t < 0) { for (int k = 0; k < 4; k++) { rast[o + k] = 0; if (rast_db) rast_db[o + k] = 0; } continue; }
+                const real *p0 = pb + 4 * tri[3 * t], *p1 = pb + 4 * tri[3 * t + 1], *p2 = pb + 4 * tri[3 * t + 2];
+                frag_t f;
+                shade(p0, p1, p2, xs * ((real)px + (real)0.5) - (real)1, ys * ((real)py + (real)0.5) - (real)1, xs, ys, &f);
+                rast[o] = clampr(f.b0, 0, 1); rast[o + 1] = clampr(f.b1, 0, 1); rast[o + 2] = clampr(f.zw, -1, 1); rast[o + 3] = (real)(t + 1);
+                if (rast_db) { rast_db[o] = f.dudx; rast_db[o + 1] = f.dudy; rast_db[o + 2] = f.dvdx; rast_db[o + 3] = f.dvdy; }
+            }
+    }
+    free(zbest); free(tbest);
+}
+
+/* dL/dpos from dL/d(u,v) (dy[...,0:2]); dpos [B,V,4] must be zero-initialised */
+void mesh_rasterize_bwd(const real *pos, const int32_t *tri, const real *rast, const real *dy, int B, int V, int T, int H, int W, real *dpos) {
+    (void)T;
+    const real xs = (real)2 / W, ys = (real)2 / H;
+    size_t P = (size_t)H * W;
+    for (int b = 0; b < B; b++)
+        for (int py = 0; py < H; py++)
+            for (int px = 0; px < W; px++) {
+                size_t o = ((size_t)b * P + (size_t)py * W + px) * 4;
+                int t = (int)rast[o + 3] - 1;
+                if (t < 0) continue;
+                real g0 = dy[o], g1 = dy[o + 1];
+                if (g0 == 0 && g1 == 0) continue;
+                int vi[3] = {tri[3 * t], tri[3 * t + 1], tri[3 * t + 2]};
+                const real *pb = pos + (size_t)b * V * 4;
+                const real *p0 = pb + 4 * vi[0], *p1 = pb + 4 * vi[1], *p2 = pb + 4 * vi[2];
+                real fx = xs * ((real)px + (real)0.5) - (real)1, fy = ys * ((real)py + (real)0.5) - (real)1;
+                real p0x = p0[0] - fx * p0[3], p0y = p0[1] - fy * p0[3];
+                real p1x = p1[0] - fx * p1[3], p1y = p1[1] - fy * p1[3];
+                real p2x = p2[0] - fx * p2[3], p2y = p2[1] - fy * p2[3];
+                real a0 = p1x * p2y - p1y * p2x, a1 = p2x * p0y - p2y * p0x, a2 = p0x * p1y - p0y * p1x;
+                real iw = (real)1 / (a0 + a1 + a2), b0 = a0 * iw, b1 = a1 * iw;
+                if (b0 < 0 || b0 > 1) g0 = 0;   /* the forward pass clamps u, v to [0,1]: no gradient through a clamped value */
+                if (b1 < 0 || b1 > 1) g1 = 0;
+                real da0 = (g0 * ((real)1 - b0) - g1 * b1) * iw;
+                real da1 = (-g0 * b0 + g1 * ((real)1 - b1)) * iw;
+                real da2 = (-g0 * b0 - g1 * b1) * iw;
+                /* a0 = p1x p2y - p1y p2x ; a1 = p2x p0y - p2y p0x ; a2 = p0x p1y - p0y p1x */
+                real d0x = da1 * (-p2y) + da2 * p1y, d0y = da1 * p2x + da2 * (-p1x);
+                real d1x = da0 * p2y + da2 * (-p0y), d1y = da0 * (-p2x) + da2 * p0x;
+                real d2x = da0 * (-p1y) + da1 * p0y, d2y = da0 * p1x + da1 * (-p0x);
+                real dxs[3] = {d0x, d1x, d2x}, dys[3] = {d0y, d1y, d2y};
+                for (int k = 0; k < 3; k++) {
+                    real *d = dpos + ((size_t)b * V + vi[k]) * 4;
+                    d[0] += dxs[k]; d[1] += dys[k]; d[3] += -fx * dxs[k] - fy * dys[k];
+                }
+            }
+}
+
+/* ------------------------------------------------------------------ interpolate */
+/* attr [Ba,V,A] with Ba in {1,B}; diff list: nd indices into [0,A) (nd = 0 -> no out_da) */
+void mesh_interpolate_fwd(const real *attr, int Ba, const real *rast, const int32_t *tri, const real *rast_db, const int32_t *diff, int nd,
+                          int B, int V, int A, int H, int W, real *out, real *out_da) {
+    size_t P = (size_t)H * W;
+    for (int b = 0; b < B; b++)
+        for (size_t pid = 0; pid < P; pid++) {
+            size_t o = (size_t)b * P + pid;
+            int t = (int)rast[4 * o + 3] - 1;
+            real *po = out + o * A;
+            if (t < 0) { for (int a = 0; a < A; a++) po[a] = 0; if (nd) for (int a = 0; a < 2 * nd; a++) out_da[o * 2 * nd + a] = 0; continue; }
+            const real *ab = attr + (size_t)(Ba > 1 ? b : 0) * V * A;
+            const real *a0 = ab + (size_t)tri[3 * t] * A, *a1 = ab + (size_t)tri[3 * t + 1] * A, *a2 = ab + (size_t)tri[3 * t + 2] * A;
+            real u = rast[4 * o], v = rast[4 * o + 1], w2 = (real)1 - u - v;
+            for (int a = 0; a < A; a++) po[a] = u * a0[a] + v * a1[a] + w2 * a2[a];
+            if (nd) {
+                real dudx = rast_db[4 * o], dudy = rast_db[4 * o + 1], dvdx = rast_db[4 * o + 2], dvdy = rast_db[4 * o + 3];
+                for (int k = 0; k < nd; k++) {
+                    int a = diff[k];
+                    real dsdu = a0[a] - a2[a], dsdv = a1[a] - a2[a];
+                    out_da[(o * nd + k) * 2] = dsdu * dudx + dsdv * dvdx;
+                    out_da[(o * nd + k) * 2 + 1] = dsdu * dudy + dsdv * dvdy;
+                }
+            }
+        }
+}
+/* dattr [Ba,V,A] and drast [B,H,W,4] zero-initialised by the caller */
+void mesh_interpolate_bwd(const real *attr, int Ba, const real *rast, const int32_t *tri, const real *dy, int B, int V, int A, int H, int W,
+                          real *dattr, real *drast) {
+    size_t P = (size_t)H * W;
+    for (int b = 0; b < B; b++)
+        for (size_t pid = 0; pid < P; pid++) {
+            size_t o = (size_t)b * P + pid;
+            int t = (int)rast[4 * o + 3] - 1;
+            if (t < 0) continue;
+            size_t ab = (size_t)(Ba > 1 ? b : 0) * V * A;
+            size_t i0 = ab + (size_t)tri[3 * t] * A, i1 = ab + (size_t)tri[3 * t + 1] * A, i2 = ab + (size_t)tri[3 * t + 2] * A;
+            real u = rast[4 * o], v = rast[4 * o + 1], w2 = (real)1 - u - v;
+            real gu = 0, gv = 0;
+            for (int a = 0; a < A; a++) {
+                real g = dy[o * A + a];
+                dattr[i0 + a] += u * g; dattr[i1 + a] += v * g; dattr[i2 + a] += w2 * g;
+                gu += g * (attr[i0 + a] - attr[i2 + a]); gv += g * (attr[i1 + a] - attr[i2 + a]);
+            }
+            drast[4 * o] += gu; drast[4 * o + 1] += gv;
+        }
+}
+
+/* ------------------------------------------------------------------ texture */
+static int wrapi(int i, int n, int boundary) {   /* boundary: 0 wrap, 1 clamp */
+    if (boundary == 0) { i %= n; if (i < 0) i += n; return i; }
+    return i < 0 ? 0 : (i >= n ? n - 1 : i);
+}
+/* tex [Bt,Ht,Wt,C] with Bt in {1,B}; filter: 0 nearest, 1 linear */
+void mesh_texture_fwd(const real *tex, int Bt, const real *uv, int B, int H, int W, int Ht, int Wt, int C, int filter, int boundary, real *out) {
+    size_t P = (size_t)H * W;
+    for (int b = 0; b < B; b++) {
+        const real *tb = tex + (size_t)(Bt > 1 ? b : 0) * Ht * Wt * C;
+        for (size_t pid = 0; pid < P; pid++) {
+            size_t o = (size_t)b * P + pid;
+            real u = uv[2 * o] * Wt, v = uv[2 * o + 1] * Ht;
+            real *po = out + o * C;
+            if (filter == 0) {
+                int iu = wrapi((int)floor((double)u), Wt, boundary), iv = wrapi((int)floor((double)v), Ht, boundary);
+                for (int c = 0; c < C; c++) po[c] = tb[((size_t)iv * Wt + iu) * C + c];
+            } else {
+                u -= (real)0.5; v -= (real)0.5;
+                real fu0 = (real)floor((double)u), fv0 = (real)floor((double)v);
+                real fu = u - fu0, fv = v - fv0;
+                int iu0 = wrapi((int)fu0, Wt, boundary), iu1 = wrapi((int)fu0 + 1, Wt, boundary);
+                int iv0 = wrapi((int)fv0, Ht, boundary), iv1 = wrapi((int)fv0 + 1, Ht, boundary);
+                for (int c = 0; c < C; c++) {
+                    real t00 = tb[((size_t)iv0 * Wt + iu0) * C + c], t10 = tb[((size_t)iv0 * Wt + iu1) * C + c];
+                    real t01 = tb[((size_t)iv1 * Wt + iu0) * C + c], t11 = tb[((size_t)iv1 * Wt + iu1) * C + c];
+                    real top = t00 + fu * (t10 - t00), bot = t01 + fu * (t11 - t01);
+                    po[c] = top + fv * (bot - top);
+                }
+            }
+        }
+    }
+}
+/* dtex [Bt,Ht,Wt,C], duv [B,H,W,2] zero-initialised */
+void mesh_texture_bwd(const real *tex, int Bt, const real *uv, const real *dy, int B, int H, int W, int Ht, int Wt, int C, int filter, int boundary,
+                      real *dtex, real *duv) {
+    size_t P = (size_t)H * W;
+    for (int b = 0; b < B; b++) {
+        size_t tbo = (size_t)(Bt > 1 ? b : 0) * Ht * Wt * C;
+        for (size_t pid = 0; pid < P; pid++) {
+            size_t o = (size_t)b * P + pid;
+            real u = uv[2 * o] * Wt, v = uv[2 * o + 1] * Ht;
+            const real *g = dy + o * C;
+            if (filter == 0) {
+                int iu = wrapi((int)floor((double)u), Wt, boundary), iv = wrapi((int)floor((double)v), Ht, boundary);
+                for (int c = 0; c < C; c++) dtex[tbo + ((size_t)iv * Wt + iu) * C + c] += g[c];
+            } else {
+                u -= (real)0.5; v -= (real)0.5;
+                real fu0 = (real)floor((double)u), fv0 = (real)floor((double)v);
+                real fu = u - fu0, fv = v - fv0;
+                int iu0 = wrapi((int)fu0, Wt, boundary), iu1 = wrapi((int)fu0 + 1, Wt, boundary);
+                int iv0 = wrapi((int)fv0, Ht, boundary), iv1 = wrapi((int)fv0 + 1, Ht, boundary);
+                real gu = 0, gv = 0;
+                for (int c = 0; c < C; c++) {
+                    size_t i00 = tbo + ((size_t)iv0 * Wt + iu0) * C + c, i10 = tbo + ((size_t)iv0 * Wt + iu1) * C + c;
+                    size_t i01 = tbo + ((size_t)iv1 * Wt + iu0) * C + c, i11 = tbo + ((size_t)iv1 * Wt + iu1) * C + c;
+                    real t00 = tex[i00], t10 = tex[i10], t01 = tex[i01], t11 = tex[i11];
+                    dtex[i00] += g[c] * ((real)1 - fu) * ((real)1 - fv); dtex[i10] += g[c] * fu * ((real)1 - fv);
+                    dtex[i01] += g[c] * ((real)1 - fu) * fv; dtex[i11] += g[c] * fu * fv;
+                    gu += g[c] * ((t10 - t00) * ((real)1 - fv) + (t11 - t01) * fv);
+                    gv += g[c] * ((t01 - t00) * ((real)1 - fu) + (t11 - t10) * fu);
+                }
+                duv[2 * o] += gu * Wt; duv[2 * o + 1] += gv * Ht;
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ antialias */
+typedef struct { int32_t va, vb, tri, opp; } edge_t;
+static int edge_cmp(const void *x, const void *y) {
+    const edge_t *a = (const edge_t *)x, *b = (const edge_t *)y;
+    if (a->va != b->va) return a->va < b->va ? -1 : 1;
+    if (a->vb != b->vb) return a->vb < b->vb ? -1 : 1;
+    return a->tri < b->tri ? -1 : (a->tri > b->tri);
+}
+/* opposite vertex of the OTHER triangle on edge (va,vb) of triangle `tri`: -1 boundary, -2 more than two triangles */
+static int other_opposite(const edge_t *edges, int ne, int va, int vb, int tri) {
+    if (va > vb) { int t = va; va = vb; vb = t; }
+    int lo = 0, hi = ne;
+    while (lo < hi) { int mid = (lo + hi) / 2; if (edges[mid].va < va || (edges[mid].va == va && edges[mid].vb < vb)) lo = mid + 1; else hi = mid; }
+    int cnt = 0, res = -1;
+    for (int i = lo; i < ne && edges[i].va == va && edges[i].vb == vb; i++) { cnt++; if (edges[i].tri != tri && res == -1) res = edges[i].opp; }
+    if (cnt > 2) return -2;
+    return res;
+}
+static edge_t *build_edges(const int32_t *tri, int T, int *ne) {
+    edge_t *e = (edge_t *)malloc(sizeof(edge_t) * 3 * (size_t)(T > 0 ? T : 1));
+    int n = 0;
+    for (int t = 0; t < T; t++)
+        for (int k = 0; k < 3; k++) {
+            int a = tri[3 * t + k], b = tri[3 * t + (k + 1) % 3], o = tri[3 * t + (k + 2) % 3];
+            if (a == b) continue;
+            e[n].va = a < b ? a : b; e[n].vb = a < b ? b : a; e[n].tri = t; e[n].opp = o; n++;
+        }
+    qsort(e, (size_t)n, sizeof(edge_t), edge_cmp);
+    *ne = n;
+    return e;
+}
+
+/* analysis of one pixel pair; returns 1 and fills (pa = pixel of the chosen triangle, pb = the other, va, vb, s) when a silhouette
+ * edge of the nearer triangle crosses the centre-to-centre segment at parameter s in [0,1] (measured from pa towards pb) */
+typedef struct { int ax, ay, bx, by, va, vb; real s; int d; real sgn; } aa_hit_t;
+static int aa_analyze(const real *pb_, const int32_t *tri, const edge_t *edges, int ne, const real *rast, int H, int W, int b, int px, int py, int d, aa_hit_t *hit) {
+    int qx = px + (d == 0), qy = py + (d == 1);
+    if (qx >= W || qy >= H) return 0;
+    size_t P = (size_t)H * W;
+    size_t o0 = ((size_t)b * P + (size_t)py * W + px) * 4, o1 = ((size_t)b * P + (size_t)qy * W + qx) * 4;
+    int id0 = (int)rast[o0 + 3], id1 = (int)rast[o1 + 3];
+    if (id0 == id1) return 0;
+    int t;
+    int a_is_p;
+    if (id0 > 0 && id1 > 0) a_is_p = rast[o0 + 2] < rast[o1 + 2];
+    else a_is_p = id0 > 0;
+    t = (a_is_p ? id0 : id1) - 1;
+    int ax = a_is_p ? px : qx, ay = a_is_p ? py : qy, bx = a_is_p ? qx : px, by = a_is_p ? qy : py;
+    real sgn = a_is_p ? (real)1 : (real)-1;
+    int vi[3] = {tri[3 * t], tri[3 * t + 1], tri[3 * t + 2]};
+    real nx[3], ny[3];
+    for (int k = 0; k < 3; k++) {
+        const real *p = pb_ + 4 * (size_t)vi[k];
+        if (!(p[3] > 0)) return 0;
+        nx[k] = p[0] / p[3]; ny[k] = p[1] / p[3];
+    }
+    real cx = ((real)ax + (real)0.5) * ((real)2 / W) - (real)1, cy = ((real)ay + (real)0.5) * ((real)2 / H) - (real)1;
+    real h = d == 0 ? (real)2 / W : (real)2 / H;
+    int found = 0;
+    real best = 0;
+    for (int k = 0; k < 3; k++) {
+        int ia = k, ib = (k + 1) % 3, io = (k + 2) % 3;
+        int opp = other_opposite(edges, ne, vi[ia], vi[ib], t);
+        if (opp == -2) continue;
+        real ex = nx[ib] - nx[ia], ey = ny[ib] - ny[ia];
+        if (opp >= 0) {   /* interior edge: silhouette only if both triangles lie on the same side of it */
+            const real *q = pb_ + 4 * (size_t)opp;
+            if (!(q[3] > 0)) continue;
+            real ox = q[0] / q[3], oy = q[1] / q[3];
+            real s_this = ex * (ny[io] - ny[ia]) - ey * (nx[io] - nx[ia]);
+            real s_other = ex * (oy - ny[ia]) - ey * (ox - nx[ia]);
+            if (!(s_this * s_other > 0)) continue;
+        }
+        /* crossing of the edge with the axis-aligned segment from A's centre towards B's centre */
+        real s;
+        if (d == 0) {
+            real da = ny[ia] - cy, db = ny[ib] - cy;
+            if (!((da <= 0 && db > 0) || (db <= 0 && da > 0))) continue;
+            real te = da / (da - db);
+            real xc = nx[ia] + te * ex;
+            s = sgn * (xc - cx) / h;
+        } else {
+            real da = nx[ia] - cx, db = nx[ib] - cx;
+            if (!((da <= 0 && db > 0) || (db <= 0 && da > 0))) continue;
+            real te = da / (da - db);
+            real yc = ny[ia] + te * ey;
+            s = sgn * (yc - cy) / h;
+        }
+        if (!(s >= 0 && s <= 1)) continue;
+        if (!found || s < best) { found = 1; best = s; hit->va = vi[ia]; hit->vb = vi[ib]; }
+    }
+    if (!found) return 0;
+    hit->ax = ax; hit->ay = ay; hit->bx = bx; hit->by = by; hit->s = best; hit->d = d; hit->sgn = sgn;
+    return 1;
+}
+
+void mesh_antialias_fwd(const real *color, const real *rast, const real *pos, const int32_t *tri, int B, int V, int T, int H, int W, int C, real *out) {
+    size_t P = (size_t)H * W;
+    memcpy(out, color, sizeof(real) * (size_t)B * P * C);
+    int ne; edge_t *edges = build_edges(tri, T, &ne);
+    for (int b = 0; b < B; b++)
+        for (int py = 0; py < H; py++)
+            for (int px = 0; px < W; px++)
+                for (int d = 0; d < 2; d++) {
+                    aa_hit_t h;
+                    if (!aa_analyze(pos + (size_t)b * V * 4, tri, edges, ne, rast, H, W, b, px, py, d, &h)) continue;
+                    real alpha = h.s - (real)0.5;
+                    const real *ca = color + ((size_t)b * P + (size_t)h.ay * W + h.ax) * C, *cb = color + ((size_t)b * P + (size_t)h.by * W + h.bx) * C;
+                    if (alpha > 0) { real *o = out + ((size_t)b * P + (size_t)h.by * W + h.bx) * C; for (int c = 0; c < C; c++) o[c] += alpha * (ca[c] - cb[c]); }
+                    else           { real *o = out + ((size_t)b * P + (size_t)h.ay * W + h.ax) * C; for (int c = 0; c < C; c++) o[c] += -alpha * (cb[c] - ca[c]); }
+                }
+    free(edges);
+}
+/* dcolor [B,H,W,C] and dpos [B,V,4]: dcolor is written in full; dpos must be zero-initialised */
+void mesh_antialias_bwd(const real *color, const real *rast, const real *pos, const int32_t *tri, const real *dy, int B, int V, int T, int H, int W, int C,
+                        real *dcolor, real *dpos) {
+    size_t P = (size_t)H * W;
+    memcpy(dcolor, dy, sizeof(real) * (size_t)B * P * C);
+    int ne; edge_t *edges = build_edges(tri, T, &ne);
+    for (int b = 0; b < B; b++)
+        for (int py = 0; py < H; py++)
+            for (int px = 0; px < W; px++)
+                for (int d = 0; d < 2; d++) {
+                    aa_hit_t h;
+                    const real *pb_ = pos + (size_t)b * V * 4;
+                    if (!aa_analyze(pb_, tri, edges, ne, rast, H, W, b, px, py, d, &h)) continue;
+                    real alpha = h.s - (real)0.5;
+                    size_t ia = ((size_t)b * P + (size_t)h.ay * W + h.ax) * C, ib = ((size_t)b * P + (size_t)h.by * W + h.bx) * C;
+                    /* out[dst] += alpha (cA - cB) with dst = B if alpha > 0 else A  (same expression in both cases) */
+                    size_t idst = alpha > 0 ? ib : ia;
+                    real dalpha = 0;
+                    for (int c = 0; c < C; c++) {
+                        real g = dy[idst + c];
+                        dcolor[ia + c] += alpha * g; dcolor[ib + c] -= alpha * g;
+                        dalpha += g * (color[ia + c] - color[ib + c]);
+                    }
+                    /* alpha = s - 0.5;  s = sgn (xc - cx)/h (d=0) with xc = xa + te (xb - xa), te = da/(da - db), da = ya - cy, db = yb - cy */
+                    const real *pa = pb_ + 4 * (size_t)h.va, *pbv = pb_ + 4 * (size_t)h.vb;
+                    real xa = pa[0] / pa[3], ya = pa[1] / pa[3], xb = pbv[0] / pbv[3], yb = pbv[1] / pbv[3];
+                    real cx = ((real)h.ax + (real)0.5) * ((real)2 / W) - (real)1, cy = ((real)h.ay + (real)0.5) * ((real)2 / H) - (real)1;
+                    real hh = d == 0 ? (real)2 / W : (real)2 / H;
+                    real gs = dalpha * h.sgn / hh;   /* dL/d(crossing coordinate) */
+                    real gxa, gya, gxb, gyb;
+                    if (d == 0) {
+                        real da = ya - cy, db = yb - cy, den = da - db, te = da / den;
+                        /* xc = xa + te (xb - xa) */
+                        real gte = gs * (xb - xa);
+                        gxa = gs * ((real)1 - te); gxb = gs * te;
+                        /* te = da/(da-db): dte/dda = -db/den^2 ; dte/ddb = da/den^2 */
+                        gya = gte * (-db / (den * den)); gyb = gte * (da / (den * den));
+                    } else {
+                        real da = xa - cx, db = xb - cx, den = da - db, te = da / den;
+                        real gte = gs * (yb - ya);
+                        gya = gs * ((real)1 - te); gyb = gs * te;
+                        gxa = gte * (-db / (den * den)); gxb = gte * (da / (den * den));
+                    }
+                    /* n = p.xy / p.w */
+                    real *dA = dpos + ((size_t)b * V + h.va) * 4, *dB = dpos + ((size_t)b * V + h.vb) * 4;
+                    dA[0] += gxa / pa[3]; dA[1] += gya / pa[3]; dA[3] += -(gxa * xa + gya * ya) / pa[3];
+                    dB[0] += gxb / pbv[3]; dB[1] += gyb / pbv[3]; dB[3] += -(gxb * xb + gyb * yb) / pbv[3];
+                }
+    free(edges);
+}

@@ -1,0 +1,137 @@
+"""ctypes front-end of oracle/mesh_oracle.c (TEST INFRASTRUCTURE; PARITY UNPINNED -- see that file's header).
+Function names and argument meaning follow `nvdiffrast.torch` as the reference calls it
+(/root/reference/MVs_Algorithms/DiffRastMesh/diff_mesh_renderer.py:97-138)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBS = {}
+
+
+def build(quiet=True):
+    subprocess.run(["make", "-C", _HERE, "mesh"], check=True, stdout=subprocess.DEVNULL if quiet else None)
+
+
+def _lib(dtype):
+    dtype = np.dtype(dtype)
+    if dtype not in _LIBS:
+        path = os.path.join(_HERE, "_build", "libmesh_oracle_f32.so" if dtype == np.float32 else "libmesh_oracle_f64.so")
+        if not os.path.exists(path):
+            build()
+        lib = C.CDLL(path)
+        assert lib.mesh_oracle_sizeof_real() == dtype.itemsize
+        _LIBS[dtype] = lib
+    return _LIBS[dtype]
+
+
+def _a(x, dt):
+    return np.ascontiguousarray(np.asarray(x, dtype=dt))
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+I = C.c_int
+
+
+def rasterize(pos, tri, resolution, dtype=np.float32):
+    """pos [B,V,4] clip space, tri [T,3] int32, resolution (H,W) -> rast [B,H,W,4], rast_db [B,H,W,4]"""
+    lib = _lib(dtype)
+    pos, tri = _a(pos, dtype), _a(tri, np.int32)
+    B, V, _ = pos.shape
+    H, W = resolution
+    rast = np.zeros((B, H, W, 4), dtype); db = np.zeros((B, H, W, 4), dtype)
+    lib.mesh_rasterize_fwd(_p(pos), _p(tri), I(B), I(V), I(tri.shape[0]), I(H), I(W), _p(rast), _p(db))
+    return rast, db
+
+
+def rasterize_bwd(pos, tri, rast, dy, dtype=np.float32):
+    lib = _lib(dtype)
+    pos, tri, rast, dy = _a(pos, dtype), _a(tri, np.int32), _a(rast, dtype), _a(dy, dtype)
+    B, V, _ = pos.shape
+    _, H, W, _ = rast.shape
+    dpos = np.zeros_like(pos)
+    lib.mesh_rasterize_bwd(_p(pos), _p(tri), _p(rast), _p(dy), I(B), I(V), I(tri.shape[0]), I(H), I(W), _p(dpos))
+    return dpos
+
+
+def interpolate(attr, rast, tri, rast_db=None, diff_attrs=None, dtype=np.float32):
+    """attr [Ba,V,A] -> out [B,H,W,A], out_da [B,H,W,2*nd] (empty when diff_attrs is None)"""
+    lib = _lib(dtype)
+    attr, rast, tri = _a(attr, dtype), _a(rast, dtype), _a(tri, np.int32)
+    if attr.ndim == 2:
+        attr = attr[None]
+    Ba, V, A = attr.shape
+    B, H, W, _ = rast.shape
+    if diff_attrs is None:
+        diff = np.zeros((0,), np.int32)
+    elif isinstance(diff_attrs, str):
+        assert diff_attrs == "all"
+        diff = np.arange(A, dtype=np.int32)
+    else:
+        diff = _a(diff_attrs, np.int32)
+    nd = diff.shape[0]
+    out = np.zeros((B, H, W, A), dtype); out_da = np.zeros((B, H, W, 2 * nd), dtype)
+    db = _a(rast_db, dtype) if nd else None
+    lib.mesh_interpolate_fwd(_p(attr), I(Ba), _p(rast), _p(tri), _p(db), _p(diff), I(nd), I(B), I(V), I(A), I(H), I(W), _p(out), _p(out_da))
+    return out, out_da
+
+
+def interpolate_bwd(attr, rast, tri, dy, dtype=np.float32):
+    lib = _lib(dtype)
+    attr, rast, tri, dy = _a(attr, dtype), _a(rast, dtype), _a(tri, np.int32), _a(dy, dtype)
+    squeeze = attr.ndim == 2
+    if squeeze:
+        attr = attr[None]
+    Ba, V, A = attr.shape
+    B, H, W, _ = rast.shape
+    dattr = np.zeros_like(attr); drast = np.zeros_like(rast)
+    lib.mesh_interpolate_bwd(_p(attr), I(Ba), _p(rast), _p(tri), _p(dy), I(B), I(V), I(A), I(H), I(W), _p(dattr), _p(drast))
+    return (dattr[0] if squeeze else dattr), drast
+
+
+_FILTER = {"nearest": 0, "linear": 1}
+_BOUNDARY = {"wrap": 0, "clamp": 1}
+
+
+def texture(tex, uv, filter_mode="linear", boundary_mode="wrap", dtype=np.float32):
+    lib = _lib(dtype)
+    tex, uv = _a(tex, dtype), _a(uv, dtype)
+    Bt, Ht, Wt, Cc = tex.shape
+    B, H, W, _ = uv.shape
+    out = np.zeros((B, H, W, Cc), dtype)
+    lib.mesh_texture_fwd(_p(tex), I(Bt), _p(uv), I(B), I(H), I(W), I(Ht), I(Wt), I(Cc), I(_FILTER[filter_mode]), I(_BOUNDARY[boundary_mode]), _p(out))
+    return out
+
+
+def texture_bwd(tex, uv, dy, filter_mode="linear", boundary_mode="wrap", dtype=np.float32):
+    lib = _lib(dtype)
+    tex, uv, dy = _a(tex, dtype), _a(uv, dtype), _a(dy, dtype)
+    Bt, Ht, Wt, Cc = tex.shape
+    B, H, W, _ = uv.shape
+    dtex = np.zeros_like(tex); duv = np.zeros_like(uv)
+    lib.mesh_texture_bwd(_p(tex), I(Bt), _p(uv), _p(dy), I(B), I(H), I(W), I(Ht), I(Wt), I(Cc), I(_FILTER[filter_mode]), I(_BOUNDARY[boundary_mode]),
+                         _p(dtex), _p(duv))
+    return dtex, duv
+
+
+def antialias(color, rast, pos, tri, dtype=np.float32):
+    lib = _lib(dtype)
+    color, rast, pos, tri = _a(color, dtype), _a(rast, dtype), _a(pos, dtype), _a(tri, np.int32)
+    B, H, W, Cc = color.shape
+    out = np.zeros_like(color)
+    lib.mesh_antialias_fwd(_p(color), _p(rast), _p(pos), _p(tri), I(B), I(pos.shape[1]), I(tri.shape[0]), I(H), I(W), I(Cc), _p(out))
+    return out
+
+
+def antialias_bwd(color, rast, pos, tri, dy, dtype=np.float32):
+    lib = _lib(dtype)
+    color, rast, pos, tri, dy = _a(color, dtype), _a(rast, dtype), _a(pos, dtype), _a(tri, np.int32), _a(dy, dtype)
+    B, H, W, Cc = color.shape
+    dcolor = np.zeros_like(color); dpos = np.zeros_like(pos)
+    lib.mesh_antialias_bwd(_p(color), _p(rast), _p(pos), _p(tri), _p(dy), I(B), I(pos.shape[1]), I(tri.shape[0]), I(H), I(W), I(Cc), _p(dcolor), _p(dpos))
+    return dcolor, dpos

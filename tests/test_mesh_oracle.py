@@ -1,0 +1,193 @@
+"""CPU tests pinning oracle/mesh_oracle.c: analytic known answers, invariants, float64 finite differences."""
+import numpy as np
+import pytest
+
+from c3d_hip import synthetic as S
+from oracle import mesh_oracle as M
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    M.build()
+
+
+def _quad(z=0.0, w=1.0):
+    pos = np.array([[[-1, -1, z, w], [1, -1, z, w], [1, 1, z, w], [-1, 1, z, w]]], np.float64)
+    pos[..., :2] *= w
+    return pos, np.array([[0, 1, 2], [0, 2, 3]], np.int32)
+
+
+def test_fullscreen_quad_covers_every_pixel_once():
+    pos, tri = _quad()
+    for (H, W) in [(8, 8), (7, 13), (16, 16)]:
+        rast, db = M.rasterize(pos, tri, (H, W), dtype=np.float64)
+        ids = rast[0, :, :, 3]
+        assert (ids > 0).all()                                   # no holes on the shared diagonal (tie rule)
+        assert set(np.unique(ids)) <= {1.0, 2.0}
+        # barycentrics reproduce the pixel centre: x = sum b_i x_i
+        u, v = rast[0, ..., 0], rast[0, ..., 1]
+        xs = (np.arange(W) + 0.5) * 2 / W - 1; ys = (np.arange(H) + 0.5) * 2 / H - 1
+        for t in (0, 1):
+            vx = pos[0, tri[t], 0]; vy = pos[0, tri[t], 1]
+            m = ids == t + 1
+            X = u * vx[0] + v * vx[1] + (1 - u - v) * vx[2]; Y = u * vy[0] + v * vy[1] + (1 - u - v) * vy[2]
+            np.testing.assert_allclose(X[m], np.broadcast_to(xs[None, :], (H, W))[m], atol=1e-12)
+            np.testing.assert_allclose(Y[m], np.broadcast_to(ys[:, None], (H, W))[m], atol=1e-12)
+        assert np.all(rast[0, ..., 2] == 0.0)
+        m = ids == 1
+        assert np.allclose(db[0][m], db[0][m][0])                # affine map: constant screen-space derivatives per triangle
+
+
+def test_depth_test_and_row_convention():
+    # near triangle (z=-0.5) over far quad (z=0.5); row 0 is NDC y=-1
+    posq, triq = _quad(z=0.5)
+    near = np.array([[-1, -1, -0.5, 1], [1, -1, -0.5, 1], [-1, 0.0, -0.5, 1]], np.float64)   # lower-left corner
+    pos = np.concatenate([posq[0], near], 0)[None]
+    tri = np.concatenate([triq, [[4, 5, 6]]], 0).astype(np.int32)
+    rast, _ = M.rasterize(pos, tri, (16, 16), dtype=np.float64)
+    assert rast[0, 0, 0, 3] == 3 and rast[0, 15, 0, 3] != 3 and rast[0, 0, 15, 3] != 3
+    assert rast[0, 0, 0, 2] == -0.5 and rast[0, 15, 15, 2] == 0.5
+    # perspective-correct barycentrics: w varies along the triangle
+    pos2 = np.array([[[-1, -1, 0, 1], [3, -1, 0, 3], [-1, 3, 0, 1]]], np.float64)    # NDC (-1,-1), (1,-1), (-1,3)
+    rast2, _ = M.rasterize(pos2, np.array([[0, 1, 2]], np.int32), (4, 4), dtype=np.float64)
+    u, v = rast2[0, 0, 1, 0], rast2[0, 0, 1, 1]                                      # pixel (x=1,y=0): ndc (-0.25,-0.75)
+    b = np.array([u, v, 1 - u - v]); p = pos2[0]
+    np.testing.assert_allclose((b @ p[:, :2]) / (b @ p[:, 3]), [-0.25, -0.75], atol=1e-12)
+
+
+def test_interpolate_texture_known_answers():
+    pos, tri = _quad()
+    rast, db = M.rasterize(pos, tri, (8, 8), dtype=np.float64)
+    attr = np.array([[0.0, 0.0], [1.0, 0.0], [1.0, 1.0], [0.0, 1.0]])            # uv = (x+1)/2, (y+1)/2
+    out, da = M.interpolate(attr, rast, tri, db, "all", dtype=np.float64)
+    xs = (np.arange(8) + 0.5) / 8
+    np.testing.assert_allclose(out[0, :, :, 0], np.broadcast_to(xs[None], (8, 8)), atol=1e-12)
+    np.testing.assert_allclose(out[0, :, :, 1], np.broadcast_to(xs[:, None], (8, 8)), atol=1e-12)
+    np.testing.assert_allclose(da[0, ..., 0], 1 / 8, atol=1e-12); np.testing.assert_allclose(da[0, ..., 3], 1 / 8, atol=1e-12)   # du/dX, dv/dY
+    np.testing.assert_allclose(da[0, ..., 1], 0, atol=1e-12)
+    c, _ = M.interpolate(np.full((4, 3), 2.5), rast, tri, dtype=np.float64)        # weights sum to one
+    assert np.allclose(c, 2.5)
+    tex = np.random.default_rng(0).normal(size=(1, 8, 8, 3))
+    t = M.texture(tex, out, "linear", "wrap", dtype=np.float64)                   # sampled at texel centres -> the texels
+    np.testing.assert_allclose(t[0], tex[0], atol=1e-12)
+    uvs = np.array([[[[0.0, 0.5 / 8]]]])                                           # u = 0: halfway between texel 7 (wrapped) and texel 0
+    np.testing.assert_allclose(M.texture(tex, uvs, "linear", "wrap", dtype=np.float64)[0, 0, 0], 0.5 * (tex[0, 0, 7] + tex[0, 0, 0]), atol=1e-12)
+    np.testing.assert_allclose(M.texture(tex, uvs, "linear", "clamp", dtype=np.float64)[0, 0, 0], tex[0, 0, 0], atol=1e-12)
+    np.testing.assert_allclose(M.texture(tex, out, "nearest", "wrap", dtype=np.float64)[0], tex[0], atol=0)
+
+
+def test_antialias_vertical_edge_known_blend():
+    """a half-plane whose boundary edge sits at a known sub-pixel position: the two pixels next to it blend by that position"""
+    W = H = 8
+    tri = np.array([[0, 1, 2], [0, 2, 3]], np.int32)
+
+    def run(xe_px):
+        xe = xe_px * 2 / W - 1
+        pos = np.array([[[-3, -3, 0, 1], [xe, -3, 0, 1], [xe, 3, 0, 1], [-3, 3, 0, 1]]], np.float64)
+        rast, _ = M.rasterize(pos, tri, (H, W), dtype=np.float64)
+        col = (rast[..., 3:] > 0).astype(np.float64)
+        return rast, M.antialias(col, rast, pos, tri, dtype=np.float64)
+    rast, out = run(5.25)      # covers centre 4.5 and reaches 0.75 towards centre 5.5: pixel 5 receives 0.25
+    assert (rast[0, :, 4, 3] > 0).all() and (rast[0, :, 5, 3] == 0).all()
+    np.testing.assert_allclose(out[0, :, 5, 0], 0.25, atol=1e-12); np.testing.assert_allclose(out[0, :, 4, 0], 1.0, atol=1e-12)
+    np.testing.assert_allclose(out[0, :, :4, 0], 1.0, atol=1e-12); np.testing.assert_allclose(out[0, :, 6:, 0], 0.0, atol=1e-12)
+    rast, out = run(4.6)       # crossing 0.1 past centre 4.5: the covered pixel itself loses 0.5 - 0.1
+    assert (rast[0, :, 4, 3] > 0).all() and (rast[0, :, 5, 3] == 0).all()
+    np.testing.assert_allclose(out[0, :, 4, 0], 0.6, atol=1e-12); np.testing.assert_allclose(out[0, :, 5, 0], 0.0, atol=1e-12)
+    rast, out = run(5.0)       # exactly half way: nothing changes
+    np.testing.assert_allclose(out[0, :, 4, 0], 1.0, atol=1e-12); np.testing.assert_allclose(out[0, :, 5, 0], 0.0, atol=1e-12)
+
+
+def _sphere_scene(H=48, W=64, n_lat=10, n_lon=16, dtype=np.float64):
+    v, f, vt, vn = S.make_uv_sphere(n_lat, n_lon, radius=0.7, displacement=0.15)
+    pos, vcam, pose = S.mesh_clip_positions(v, -20.0, 35.0, 2.0, W, H)
+    return pos.astype(dtype), f, vt.astype(dtype), vn.astype(dtype)
+
+
+def test_sphere_invariants():
+    pos, f, vt, vn = _sphere_scene()
+    rast, db = M.rasterize(pos, f, (48, 64), dtype=np.float64)
+    cov = rast[0, ..., 3] > 0
+    assert 0.15 < cov.mean() < 0.6
+    # coverage is decided on 1/16-px snapped vertices, barycentrics on the exact ones: u+v may exceed 1 by a snap's worth
+    assert (rast[0, ..., 0][cov] >= 0).all() and (rast[0, ..., 0] + rast[0, ..., 1] <= 1 + 0.05).all()
+    col = cov[None, ..., None].astype(np.float64)
+    aa = M.antialias(col, rast, pos, f, dtype=np.float64)
+    assert ((aa >= -1e-12) & (aa <= 1 + 1e-12)).all()
+    changed = np.abs(aa - col)[0, ..., 0] > 1e-12
+    edge = np.zeros_like(cov)                                   # pixels next to a coverage change
+    edge[:, 1:] |= cov[:, 1:] != cov[:, :-1]; edge[:, :-1] |= cov[:, 1:] != cov[:, :-1]
+    edge[1:, :] |= cov[1:, :] != cov[:-1, :]; edge[:-1, :] |= cov[1:, :] != cov[:-1, :]
+    assert changed.sum() > 20 and (changed <= edge).all()       # antialias only touches the silhouette
+    assert np.abs(aa - col)[0, ..., 0][cov & ~edge].max() == 0  # interior id discontinuities are not silhouettes
+
+
+def _fd(f, x, g_out, eps, idx):
+    """central finite differences of sum(f(x) * g_out) w.r.t. the listed flat entries of x"""
+    flat = x.reshape(-1)
+    out = {}
+    for i in idx:
+        old = flat[i]
+        flat[i] = old + eps; a = (f(x) * g_out).sum()
+        flat[i] = old - eps; b = (f(x) * g_out).sum()
+        flat[i] = old
+        out[i] = (a - b) / (2 * eps)
+    return out
+
+
+def test_gradients_by_finite_differences():
+    rng = np.random.default_rng(0)
+    H, W = 24, 32
+    pos, f, vt, vn = _sphere_scene(H, W, 8, 12)
+    V = pos.shape[1]
+    rast, db = M.rasterize(pos, f, (H, W), dtype=np.float64)
+    ids = rast[..., 3].copy()
+    # ---- rasterize: d(sum g*(u,v)) / dpos
+    g = rng.normal(size=rast.shape); g[..., 2:] = 0
+    dpos = M.rasterize_bwd(pos, f, rast, g, dtype=np.float64)
+
+    def ras(p):
+        r, _ = M.rasterize(p, f, (H, W), dtype=np.float64)
+        r = r.copy(); r[r[..., 3] != ids] = 0; r[..., 2:] = 0          # coverage is piecewise constant: compare on unchanged pixels
+        return r
+    gm = g.copy()
+    pick = [int(i) for i in rng.choice(V * 4, 40, replace=False) if i % 4 != 2]
+    num = _fd(ras, pos.copy(), gm, 1e-7, pick)
+    for i in pick:
+        assert abs(num[i] - dpos.reshape(-1)[i]) <= 1e-5 * max(1.0, abs(num[i])), (i, num[i], dpos.reshape(-1)[i])
+    assert np.abs(dpos[..., 2]).max() == 0                           # z gets no gradient from (u, v)
+    # ---- interpolate
+    attr = rng.normal(size=(V, 3))
+    out, _ = M.interpolate(attr, rast, f, dtype=np.float64)
+    gy = rng.normal(size=out.shape)
+    dattr, drast = M.interpolate_bwd(attr, rast, f, gy, dtype=np.float64)
+    num = _fd(lambda a: M.interpolate(a, rast, f, dtype=np.float64)[0], attr.copy(), gy, 1e-6, range(0, V * 3, 7))
+    for i, v_ in num.items():
+        assert abs(v_ - dattr.reshape(-1)[i]) < 1e-7
+    cov_idx = np.flatnonzero((rast[..., 3] > 0).reshape(-1))[:: 17]
+    num = _fd(lambda r: M.interpolate(attr, r, f, dtype=np.float64)[0], rast.copy(), gy, 1e-6, [4 * i for i in cov_idx] + [4 * i + 1 for i in cov_idx])
+    for i, v_ in num.items():
+        assert abs(v_ - drast.reshape(-1)[i]) < 1e-7
+    # ---- texture
+    tex = rng.normal(size=(1, 16, 16, 3)); uv = rng.uniform(-0.5, 1.5, size=(1, H, W, 2))
+    to = M.texture(tex, uv, dtype=np.float64); gt = rng.normal(size=to.shape)
+    dtex, duv = M.texture_bwd(tex, uv, gt, dtype=np.float64)
+    num = _fd(lambda t: M.texture(t, uv, dtype=np.float64), tex.copy(), gt, 1e-6, range(0, tex.size, 11))
+    for i, v_ in num.items():
+        assert abs(v_ - dtex.reshape(-1)[i]) < 1e-6
+    num = _fd(lambda u_: M.texture(tex, u_, dtype=np.float64), uv.copy(), gt, 1e-7, range(0, uv.size, 29))
+    for i, v_ in num.items():
+        assert abs(v_ - duv.reshape(-1)[i]) < 1e-4 * max(1, abs(v_))
+    # ---- antialias: colour and position gradients
+    col = rng.uniform(size=(1, H, W, 3))
+    ao = M.antialias(col, rast, pos, f, dtype=np.float64); ga = rng.normal(size=ao.shape)
+    dcol, dpa = M.antialias_bwd(col, rast, pos, f, ga, dtype=np.float64)
+    num = _fd(lambda c: M.antialias(c, rast, pos, f, dtype=np.float64), col.copy(), ga, 1e-6, range(0, col.size, 53))
+    for i, v_ in num.items():
+        assert abs(v_ - dcol.reshape(-1)[i]) < 1e-7
+    nz = np.flatnonzero(np.abs(dpa.reshape(-1)) > 0)
+    assert nz.size > 20
+    pick = [int(i) for i in nz[:: max(1, nz.size // 30)]] + [i for i in range(0, V * 4, 13) if i % 4 != 2][:10]
+    num = _fd(lambda p: M.antialias(col, rast, p, f, dtype=np.float64), pos.copy(), ga, 1e-7, pick)
+    for i in pick:
+        assert abs(num[i] - dpa.reshape(-1)[i]) <= 2e-4 * max(1.0, abs(num[i])), (i, num[i], dpa.reshape(-1)[i])
