@@ -1,0 +1,123 @@
+"""Mesh fitting trainer: DiffMeshCameraController and DiffMesh.
+
+Host-side mirror of /root/reference/MVs_Algorithms/DiffRastMesh/diff_mesh.py: controller :18-22, constructor
+:26-56 (Adam over raw_albedo [+ v_offsets]), prepare_training :58-78, training loop :81-159 (per step `batch_size` random
+views, loss = (1-l) MSE + l (1 - MS-SSIM) on masked images, geometry regularisers when the geometry trains).
+Additive differences: `device` / `process_group` parameters (view-parallel gradient exchange, c3d_hip/parallel.py).  The periodic
+CPU remesh (:134-141, pymeshlab through kiui) is asset tooling outside the hot path: the trainer refuses to reach it."""
+import random
+
+import torch
+import torch.nn.functional as F
+
+from c3d_hip import parallel
+from shared_utils.camera_utils import BaseCameraController
+from shared_utils.msssim import MS_SSIM
+from .diff_mesh_renderer import DiffRastRenderer
+
+
+class DiffMeshCameraController(BaseCameraController):
+    def get_render_result(self, render_pose, bg_color, **kwargs):
+        return self.renderer.render(render_pose, self.cam.perspective, self.cam.H, self.cam.W, ssaa=1, bg_color=bg_color, **kwargs)
+
+
+def laplacian_smooth_loss(v, f):
+    """mean squared length of the uniform (umbrella) Laplacian -- stands in for kiui.mesh_utils.laplacian_smooth_loss"""
+    fl = f.long()
+    e = torch.cat([fl[:, [0, 1]], fl[:, [1, 2]], fl[:, [2, 0]]], 0)
+    e = torch.cat([e, e.flip(1)], 0)
+    nbr_sum = torch.zeros_like(v).index_add_(0, e[:, 0], v[e[:, 1]])
+    deg = torch.zeros(v.shape[0], device=v.device).index_add_(0, e[:, 0], torch.ones(e.shape[0], device=v.device)).clamp_min(1)
+    lap = nbr_sum / deg[:, None] - v
+    return (lap ** 2).sum(-1).mean()
+
+
+def normal_consistency(v, f):
+    """1 - cos of the dihedral normals over shared edges -- stands in for kiui.mesh_utils.normal_consistency"""
+    fl = f.long()
+    n = F.normalize(torch.cross(v[fl[:, 1]] - v[fl[:, 0]], v[fl[:, 2]] - v[fl[:, 0]], dim=-1), dim=-1)
+    T = fl.shape[0]
+    e = torch.cat([fl[:, [0, 1]], fl[:, [1, 2]], fl[:, [2, 0]]], 0)
+    key = torch.minimum(e[:, 0], e[:, 1]) * v.shape[0] + torch.maximum(e[:, 0], e[:, 1])
+    tri = torch.arange(T, device=v.device).repeat(3)
+    order = torch.argsort(key)
+    key, tri = key[order], tri[order]
+    same = key[1:] == key[:-1]
+    return (1 - (n[tri[:-1][same]] * n[tri[1:][same]]).sum(-1)).mean() if same.any() else v.sum() * 0
+
+
+class DiffMesh:
+    def __init__(self, mesh, training_iterations, batch_size, texture_learning_rate, train_mesh_geometry, geometry_learning_rate,
+                 ms_ssim_loss_weight, remesh_after_n_iteration, invert_bg_prob, force_cuda_rasterize, device="cuda", process_group=None,
+                 exchange="allgather"):
+        self.device = torch.device(device)
+        self.train_mesh_geometry, self.remesh_after_n_iteration = train_mesh_geometry, remesh_after_n_iteration
+        self.renderer = DiffRastRenderer(mesh, force_cuda_rasterize).to(self.device)
+        groups = self.renderer.get_params(texture_learning_rate, train_mesh_geometry, geometry_learning_rate)
+        if self.device.type == "cuda":
+            from c3d_hip.optim import FusedAdam
+            self.optimizer = FusedAdam(groups)
+        else:
+            self.optimizer = torch.optim.Adam(groups)
+        self.ms_ssim_loss = MS_SSIM(data_range=1, size_average=True, channel=3)
+        self.lambda_ssim, self.training_iterations, self.batch_size, self.invert_bg_prob = ms_ssim_loss_weight, training_iterations, batch_size, invert_bg_prob
+        self.group, self.exchange = process_group, exchange
+        self.params = [p for g in groups for p in ([g['params']] if torch.is_tensor(g['params']) else g['params'])]
+
+    def prepare_training(self, reference_images, reference_masks, reference_orbit_camera_poses, reference_orbit_camera_fovy):
+        self.ref_imgs_num = len(reference_images)
+        self.ref_size_H, self.ref_size_W = reference_images[0].shape[0], reference_images[0].shape[1]
+        self.cam_controller = DiffMeshCameraController(self.renderer, self.ref_size_W, self.ref_size_H, reference_orbit_camera_fovy,
+                                                       self.invert_bg_prob, None, self.device)
+        self.all_ref_cam_poses = reference_orbit_camera_poses
+        to = lambda t: t.permute(0, 3, 1, 2).contiguous().float().to(self.device)
+        self.ref_imgs_torch = torch.cat([to(im.unsqueeze(0)) for im in reference_images], dim=0)                  # [V,3,H,W]
+        self.ref_masks_torch = torch.cat([to(m.unsqueeze(2).unsqueeze(0)) for m in reference_masks], dim=0)      # [V,1,H,W]
+
+    def training_step(self, step, view_indices):
+        world = torch.distributed.get_world_size(self.group) if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
+        rank = torch.distributed.get_rank(self.group) if world > 1 else 0
+        imgs, refs = [], []
+        for i in parallel.shard_views(view_indices, rank, world):
+            out = self.cam_controller.render_at_pose(self.all_ref_cam_poses[i])
+            m = self.ref_masks_torch[i]
+            imgs.append((out["image"].permute(2, 0, 1).contiguous() * m).unsqueeze(0))
+            refs.append((self.ref_imgs_torch[i] * m).unsqueeze(0))
+        imgs, refs = torch.cat(imgs), torch.cat(refs)
+        loss = (1 - self.lambda_ssim) * F.mse_loss(imgs, refs) + self.lambda_ssim * (1 - self.ms_ssim_loss(refs, imgs))
+        if self.train_mesh_geometry:
+            r = self.renderer
+            cur = r.mesh.v + r.v_offsets
+            loss = loss + 0.01 * laplacian_smooth_loss(cur, r.mesh.f) + 0.001 * normal_consistency(cur, r.mesh.f) + 0.1 * (r.v_offsets ** 2).sum(-1).mean()
+            if step > 0 and self.remesh_after_n_iteration and step % self.remesh_after_n_iteration == 0:
+                raise NotImplementedError("periodic CPU remeshing (pymeshlab) is asset tooling outside the hot path; set remesh_after_n_iteration "
+                                          "above training_iterations")
+        loss.backward()
+        self._exchange(world)
+        self.optimizer.step()
+        self.optimizer.zero_grad()
+        return loss.detach()
+
+    def _exchange(self, world):
+        if world <= 1:
+            return
+        for p in self.params:   # tensors of different row counts: one exchange each (12 MB albedo, 12 B/vertex offsets)
+            flat = p.grad.reshape(1, -1)
+            holder = torch.nn.Parameter(torch.empty_like(flat), requires_grad=False)
+            holder.grad = flat.clone()
+            parallel.exchange_gradients([holder], self.group, self.exchange, average=True)
+            p.grad.copy_(holder.grad.reshape(p.grad.shape))
+
+    def training(self, decimate_target=5e4, progress=None):
+        rng = random.Random(0) if self.group is not None else random
+        for step in range(self.training_iterations):
+            self.training_step(step, [rng.randint(0, self.ref_imgs_num - 1) for _ in range(self.batch_size)])
+            if progress is not None:
+                progress(step + 1)
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        self.need_update = True
+        self.renderer.update_mesh()
+
+    def get_mesh_and_texture(self):
+        return self.renderer.mesh, self.renderer.mesh.albedo

@@ -1,0 +1,116 @@
+"""DiffRastRenderer: differentiable textured-mesh renderer over the `nvdiffrast.torch` boundary.
+
+Host-side mirror of /root/reference/MVs_Algorithms/DiffRastMesh/diff_mesh_renderer.py: constructor :38-54,
+get_params :56-66, update_mesh :68-70, render :72-159 -- the same op sequence with the same arguments
+(MVP transform -> rasterize -> antialias(alpha) -> interpolate(uv, diff all) -> texture(linear) -> sigmoid ->
+interpolate(depth / normal) -> antialias(albedo) -> composite -> optional SSAA resize), the same result dict.
+Written from scratch; the ops resolve to the MI355X HIP kernels (nvdiffrast/torch/__init__.py)."""
+import math
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+import nvdiffrast.torch as dr
+
+from mesh_processer.mesh import safe_normalize
+
+
+def inverse_sigmoid(x):
+    return torch.log(x / (1 - x))
+
+
+def scale_img_nhwc(x, size, mag='bilinear', min='bilinear'):
+    """resize NHWC; magnification with align_corners like the reference (:14-26); never mixed mag/min"""
+    up = x.shape[1] < size[0] and x.shape[2] < size[1]
+    down = x.shape[1] >= size[0] and x.shape[2] >= size[1]
+    assert up or down, "Trying to magnify image in one dimension and minify in the other"
+    y = x.permute(0, 3, 1, 2)
+    if x.shape[1] > size[0] and x.shape[2] > size[1]:
+        y = F.interpolate(y, size, mode=min)
+    elif mag in ('bilinear', 'bicubic'):
+        y = F.interpolate(y, size, mode=mag, align_corners=True)
+    else:
+        y = F.interpolate(y, size, mode=mag)
+    return y.permute(0, 2, 3, 1).contiguous()
+
+
+def scale_img_hwc(x, size, mag='bilinear', min='bilinear'):
+    return scale_img_nhwc(x[None, ...], size, mag, min)[0]
+
+
+def make_divisible(x, m=8):
+    return int(math.ceil(x / m) * m)
+
+
+class DiffRastRenderer(nn.Module):
+    def __init__(self, mesh, force_cuda_rast):
+        super().__init__()
+        self.mesh = mesh
+        self.glctx = dr.RasterizeCudaContext() if (force_cuda_rast or os.name != 'nt') else dr.RasterizeGLContext()
+        self.v_offsets = nn.Parameter(torch.zeros_like(self.mesh.v), requires_grad=True)
+        self.raw_albedo = nn.Parameter(inverse_sigmoid(self.mesh.albedo), requires_grad=True)
+        self.train_geo = False
+
+    def get_params(self, texture_lr, train_geo, geom_lr):
+        params = [{'params': self.raw_albedo, 'lr': texture_lr}]
+        self.train_geo = train_geo
+        if train_geo:
+            params.append({'params': self.v_offsets, 'lr': geom_lr})
+        return params
+
+    def update_mesh(self):
+        self.mesh.v = (self.mesh.v + self.v_offsets).detach()
+        self.mesh.albedo = torch.sigmoid(self.raw_albedo.detach())
+
+    def render(self, pose, proj, h0, w0, ssaa=1, bg_color=1, texture_filter='linear', optional_render_types=['depth', 'normal']):
+        h, w = (make_divisible(h0 * ssaa, 8), make_divisible(w0 * ssaa, 8)) if ssaa != 1 else (h0, w0)
+        mesh = self.mesh
+        v = mesh.v + self.v_offsets if self.train_geo else mesh.v
+        pose = torch.from_numpy(pose.astype(np.float32)).to(v.device)
+        proj = torch.from_numpy(proj.astype(np.float32)).to(v.device)
+        v_cam = torch.matmul(F.pad(v, pad=(0, 1), mode='constant', value=1.0), torch.inverse(pose).T).float().unsqueeze(0)
+        v_clip = v_cam @ proj.T
+
+        rast, rast_db = dr.rasterize(self.glctx, v_clip, mesh.f, (h, w))
+        alpha = torch.clamp(rast[..., -1:], 0, 1).contiguous()                                   # [1,H,W,1]
+        alpha = dr.antialias(alpha, rast, v_clip, mesh.f).clamp(0, 1).squeeze(0)                 # silhouette gradients enter here
+        texc, texc_db = dr.interpolate(mesh.vt.unsqueeze(0).contiguous(), rast, mesh.ft, rast_db=rast_db, diff_attrs='all')
+        albedo = torch.sigmoid(dr.texture(self.raw_albedo.unsqueeze(0), texc, uv_da=texc_db, filter_mode=texture_filter))
+
+        results = {}
+        if 'depth' in optional_render_types:
+            depth, _ = dr.interpolate(-v_cam[..., [2]], rast, mesh.f)
+            depth = depth.squeeze(0)
+        if 'normal' in optional_render_types:
+            if self.train_geo:
+                i0, i1, i2 = (mesh.f[:, k].long() for k in range(3))
+                face_n = safe_normalize(torch.cross(v[i1] - v[i0], v[i2] - v[i0], dim=-1))
+                vn = torch.zeros_like(v)
+                for idx in (i0, i1, i2):
+                    vn.scatter_add_(0, idx[:, None].repeat(1, 3), face_n)
+                vn = torch.where(torch.sum(vn * vn, -1, keepdim=True) > 1e-20, vn, torch.tensor([0.0, 0.0, 1.0], dtype=torch.float32, device=vn.device))
+            else:
+                vn = mesh.vn
+            normal, _ = dr.interpolate(vn.unsqueeze(0).contiguous(), rast, mesh.fn)
+            normal = safe_normalize(normal[0])
+            viewcos = normal @ pose[:3, :3]                                                       # [0,0,1] faces the camera
+
+        albedo = dr.antialias(albedo, rast, v_clip, mesh.f).squeeze(0).contiguous()
+        albedo = alpha * albedo + (1 - alpha) * bg_color
+
+        if ssaa != 1:
+            albedo, alpha = scale_img_hwc(albedo, (h0, w0)), scale_img_hwc(alpha, (h0, w0))
+            if 'depth' in optional_render_types:
+                depth = scale_img_hwc(depth, (h0, w0))
+            if 'normal' in optional_render_types:
+                normal, viewcos = scale_img_hwc(normal, (h0, w0)), scale_img_hwc(viewcos, (h0, w0))
+        results['image'] = albedo.clamp(0, 1)
+        results['alpha'] = alpha
+        if 'depth' in optional_render_types:
+            results['depth'] = depth
+        if 'normal' in optional_render_types:
+            results['normal'] = (normal + 1) / 2
+            results['viewcos'] = (viewcos + 1) / 2
+        return results

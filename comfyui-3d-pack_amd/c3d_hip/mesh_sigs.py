@@ -1,0 +1,17 @@
+"""ctypes signatures of include/c3d_mesh.h"""
+import ctypes as C
+
+vp, i32, sz = C.c_void_p, C.c_int32, C.c_size_t
+
+SIGNATURES = {
+    "c3d_mesh_raster_scratch_bytes": (sz, [i32, i32, i32, i32]),
+    "c3d_mesh_rasterize_fwd": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
+    "c3d_mesh_rasterize_bwd": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
+    "c3d_mesh_interpolate_fwd": (C.c_int, [vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
+    "c3d_mesh_interpolate_bwd": (C.c_int, [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]),
+    "c3d_mesh_texture_fwd": (C.c_int, [vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "c3d_mesh_texture_bwd": (C.c_int, [vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
+    "c3d_mesh_antialias_scratch_bytes": (sz, [i32]),
+    "c3d_mesh_antialias_fwd": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
+    "c3d_mesh_antialias_bwd": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
+}

@@ -1,0 +1,625 @@
+// mesh.hip -- differentiable triangle-mesh ops for gfx950: rasterize, interpolate, texture, antialias (fwd + bwd).
+// C-ABI: include/c3d_mesh.h.  Boundary implemented: the `nvdiffrast.torch` calls of
+// /root/reference/MVs_Algorithms/DiffRastMesh/diff_mesh_renderer.py:97-138.
+//
+// Rasterizer design (not the dependency's bin/coarse/fine software pipeline): the reference's meshes are dense
+// (config 5: 5e5 triangles on 1024^2, a few pixels per triangle), so the fast path is one lane per triangle that
+// walks its own small bounding box and resolves visibility with ONE 64-bit atomicMin per covered pixel on a packed
+// (ordered z/w bits << 32 | triangle id) word -- nearest depth, ties to the lower id, order independent, deterministic.
+// Triangles with a large bounding box are queued and rasterized by a whole workgroup each.  A resolve pass turns the
+// winning id into perspective-correct barycentrics and their screen-space derivatives.
+// Coverage is evaluated exactly: vertices snapped to 1/16 pixel, 64-bit integer edge functions, top-left style tie rule.
+#include "../../include/c3d_mesh.h"
+#include "c3d_common.h"
+
+#define MESH_BIG_BBOX 256          // bounding boxes with more pixels than this go to the workgroup-per-triangle path
+#define MESH_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
+
+struct Frag { float b0, b1, zw, dudx, dudy, dvdx, dvdy; };
+
+__device__ __forceinline__ Frag mesh_shade(const float4 p0, const float4 p1, const float4 p2, float fx, float fy, float xs, float ys) {
+    const float p0x = p0.x - fx * p0.w, p0y = p0.y - fy * p0.w;
+    const float p1x = p1.x - fx * p1.w, p1y = p1.y - fy * p1.w;
+    const float p2x = p2.x - fx * p2.w, p2y = p2.y - fy * p2.w;
+    const float a0 = p1x * p2y - p1y * p2x, a1 = p2x * p0y - p2y * p0x, a2 = p0x * p1y - p0y * p1x;
+    const float iw = 1.f / (a0 + a1 + a2);
+    Frag f;
+    f.b0 = a0 * iw; f.b1 = a1 * iw;
+    const float z = p0.z * a0 + p1.z * a1 + p2.z * a2, w = p0.w * a0 + p1.w * a1 + p2.w * a2;
+    f.zw = z / w;
+    const float dfxdx = xs * iw, dfydy = ys * iw;
+    const float da0dx = p2.y * p1.w - p1.y * p2.w, da0dy = p1.x * p2.w - p2.x * p1.w;
+    const float da1dx = p0.y * p2.w - p2.y * p0.w, da1dy = p2.x * p0.w - p0.x * p2.w;
+    const float da2dx = p1.y * p0.w - p0.y * p1.w, da2dy = p0.x * p1.w - p1.x * p0.w;
+    const float datdx = da0dx + da1dx + da2dx, datdy = da0dy + da1dy + da2dy;
+    f.dudx = dfxdx * (f.b0 * datdx - da0dx); f.dudy = dfydy * (f.b0 * datdy - da0dy);
+    f.dvdx = dfxdx * (f.b1 * datdx - da1dx); f.dvdy = dfydy * (f.b1 * datdy - da1dy);
+    return f;
+}
+__device__ __forceinline__ uint32_t ordered_bits(float f) {   // monotone float -> uint; -0 and +0 coincide
+    uint32_t u = __float_as_uint(f);
+    if (u == 0x80000000u) u = 0u;
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ bool edge_owns_tie(long long dx, long long dy) { return dy > 0 || (dy == 0 && dx < 0); }
+
+struct TriSetup { long long X[3], Y[3], s; int px0, px1, py0, py1; bool ok; };
+
+__device__ __forceinline__ TriSetup mesh_setup(const float4 p0, const float4 p1, const float4 p2, int W, int H) {
+    TriSetup t;
+    t.ok = false;
+    if (!(p0.w > 0.f && p1.w > 0.f && p2.w > 0.f)) return t;
+    const float4 pp[3] = {p0, p1, p2};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float nx = pp[k].x / pp[k].w, ny = pp[k].y / pp[k].w;
+        if (!(fabsf(nx) < 1e4f && fabsf(ny) < 1e4f)) return t;
+        t.X[k] = (long long)__float2int_rn(nx * (float)(W * 8)) + (long long)W * 8;
+        t.Y[k] = (long long)__float2int_rn(ny * (float)(H * 8)) + (long long)H * 8;
+    }
+    const long long area = (t.X[1] - t.X[0]) * (t.Y[2] - t.Y[0]) - (t.Y[1] - t.Y[0]) * (t.X[2] - t.X[0]);
+    if (area == 0) return t;
+    t.s = area > 0 ? 1 : -1;
+    const long long xmin = min(t.X[0], min(t.X[1], t.X[2])), xmax = max(t.X[0], max(t.X[1], t.X[2]));
+    const long long ymin = min(t.Y[0], min(t.Y[1], t.Y[2])), ymax = max(t.Y[0], max(t.Y[1], t.Y[2]));
+    long long px0 = (xmin - 8 + 15) >> 4, px1 = (xmax - 8) >> 4, py0 = (ymin - 8 + 15) >> 4, py1 = (ymax - 8) >> 4;
+    t.px0 = (int)max(px0, 0ll); t.py0 = (int)max(py0, 0ll);
+    t.px1 = (int)min(px1, (long long)W - 1); t.py1 = (int)min(py1, (long long)H - 1);
+    t.ok = t.px0 <= t.px1 && t.py0 <= t.py1;
+    return t;
+}
+__device__ __forceinline__ bool mesh_covers(const TriSetup& t, int px, int py) {
+    const long long cx = 16ll * px + 8, cy = 16ll * py + 8;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int a = k, c = (k + 1) % 3;
+        const long long dx = (t.X[c] - t.X[a]) * t.s, dy = (t.Y[c] - t.Y[a]) * t.s;
+        const long long e = dx * (cy - t.Y[a]) - dy * (cx - t.X[a]);
+        if (e < 0 || (e == 0 && !edge_owns_tie(dx, dy))) return false;
+    }
+    return true;
+}
+__device__ __forceinline__ void mesh_plot(const float4 p0, const float4 p1, const float4 p2, int px, int py, int W, int H, float xs, float ys,
+                                          uint32_t t, unsigned long long* zbuf) {
+    const Frag f = mesh_shade(p0, p1, p2, xs * ((float)px + 0.5f) - 1.f, ys * ((float)py + 0.5f) - 1.f, xs, ys);
+    if (!(f.zw >= -1.f && f.zw <= 1.f)) return;
+    atomicMin(&zbuf[(size_t)py * W + px], ((unsigned long long)ordered_bits(f.zw) << 32) | t);
+}
+
+__global__ void __launch_bounds__(256) k_ras_tri(const float4* __restrict__ pos, const int3* __restrict__ tri, int B, int V, int T, int H, int W,
+                                                  unsigned long long* __restrict__ zbuf, uint32_t* __restrict__ big_queue, uint32_t* __restrict__ big_count) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long long)B * T) return;
+    const int b = (int)(gid / T), t = (int)(gid % T);
+    const int3 vi = tri[t];
+    if ((unsigned)vi.x >= (unsigned)V || (unsigned)vi.y >= (unsigned)V || (unsigned)vi.z >= (unsigned)V) return;
+    const float4* pb = pos + (size_t)b * V;
+    const float4 p0 = pb[vi.x], p1 = pb[vi.y], p2 = pb[vi.z];
+    const TriSetup ts = mesh_setup(p0, p1, p2, W, H);
+    if (!ts.ok) return;
+    const long long area = (long long)(ts.px1 - ts.px0 + 1) * (ts.py1 - ts.py0 + 1);
+    if (area > MESH_BIG_BBOX) { big_queue[atomicAdd(big_count, 1u)] = (uint32_t)gid; return; }
+    const float xs = 2.f / W, ys = 2.f / H;
+    unsigned long long* zb = zbuf + (size_t)b * H * W;
+    for (int py = ts.py0; py <= ts.py1; py++)
+        for (int px = ts.px0; px <= ts.px1; px++)
+            if (mesh_covers(ts, px, py)) mesh_plot(p0, p1, p2, px, py, W, H, xs, ys, (uint32_t)t, zb);
+}
+// one workgroup per queued large triangle (grid-stride over the queue; the queue length is read on the device)
+__global__ void __launch_bounds__(256) k_ras_big(const float4* __restrict__ pos, const int3* __restrict__ tri, int V, int T, int H, int W,
+                                                  unsigned long long* __restrict__ zbuf, const uint32_t* __restrict__ big_queue,
+                                                  const uint32_t* __restrict__ big_count) {
+    const uint32_t n = *big_count;
+    const float xs = 2.f / W, ys = 2.f / H;
+    for (uint32_t q = blockIdx.x; q < n; q += gridDim.x) {
+        const uint32_t gid = big_queue[q];
+        const int b = (int)(gid / (uint32_t)T), t = (int)(gid % (uint32_t)T);
+        const int3 vi = tri[t];
+        const float4* pb = pos + (size_t)b * V;
+        const float4 p0 = pb[vi.x], p1 = pb[vi.y], p2 = pb[vi.z];
+        const TriSetup ts = mesh_setup(p0, p1, p2, W, H);
+        const int bw = ts.px1 - ts.px0 + 1;
+        const long long area = (long long)bw * (ts.py1 - ts.py0 + 1);
+        unsigned long long* zb = zbuf + (size_t)b * H * W;
+        for (long long i = threadIdx.x; i < area; i += blockDim.x) {
+            const int px = ts.px0 + (int)(i % bw), py = ts.py0 + (int)(i / bw);
+            if (mesh_covers(ts, px, py)) mesh_plot(p0, p1, p2, px, py, W, H, xs, ys, (uint32_t)t, zb);
+        }
+    }
+}
+__global__ void __launch_bounds__(256) k_ras_resolve(const float4* __restrict__ pos, const int3* __restrict__ tri, int B, int V, int H, int W,
+                                                      const unsigned long long* __restrict__ zbuf, float4* __restrict__ rast, float4* __restrict__ rast_db) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long P = (long long)H * W;
+    if (gid >= (long long)B * P) return;
+    const unsigned long long key = zbuf[gid];
+    if (key == MESH_EMPTY_KEY) {
+        rast[gid] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rast_db) rast_db[gid] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    const int b = (int)(gid / P), pid = (int)(gid % P), px = pid % W, py = pid / W;
+    const uint32_t t = (uint32_t)(key & 0xFFFFFFFFull);
+    const int3 vi = tri[t];
+    const float4* pb = pos + (size_t)b * V;
+    const float xs = 2.f / W, ys = 2.f / H;
+    const Frag f = mesh_shade(pb[vi.x], pb[vi.y], pb[vi.z], xs * ((float)px + 0.5f) - 1.f, ys * ((float)py + 0.5f) - 1.f, xs, ys);
+    rast[gid] = make_float4(fminf(fmaxf(f.b0, 0.f), 1.f), fminf(fmaxf(f.b1, 0.f), 1.f), fminf(fmaxf(f.zw, -1.f), 1.f), (float)(t + 1));
+    if (rast_db) rast_db[gid] = make_float4(f.dudx, f.dudy, f.dvdx, f.dvdy);
+}
+
+__global__ void __launch_bounds__(256) k_ras_bwd(const float4* __restrict__ pos, const int3* __restrict__ tri, const float4* __restrict__ rast,
+                                                  const float4* __restrict__ dy, int B, int V, int H, int W, float* __restrict__ dpos) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long P = (long long)H * W;
+    if (gid >= (long long)B * P) return;
+    const float4 r = rast[gid];
+    const int t = (int)r.w - 1;
+    if (t < 0) return;
+    const float4 g = dy[gid];
+    float g0 = g.x, g1 = g.y;
+    if (g0 == 0.f && g1 == 0.f) return;
+    const int b = (int)(gid / P), pid = (int)(gid % P), px = pid % W, py = pid / W;
+    const int3 vi = tri[t];
+    const float4* pb = pos + (size_t)b * V;
+    const float4 p0 = pb[vi.x], p1 = pb[vi.y], p2 = pb[vi.z];
+    const float fx = (2.f / W) * ((float)px + 0.5f) - 1.f, fy = (2.f / H) * ((float)py + 0.5f) - 1.f;
+    const float p0x = p0.x - fx * p0.w, p0y = p0.y - fy * p0.w;
+    const float p1x = p1.x - fx * p1.w, p1y = p1.y - fy * p1.w;
+    const float p2x = p2.x - fx * p2.w, p2y = p2.y - fy * p2.w;
+    const float a0 = p1x * p2y - p1y * p2x, a1 = p2x * p0y - p2y * p0x, a2 = p0x * p1y - p0y * p1x;
+    const float iw = 1.f / (a0 + a1 + a2), b0 = a0 * iw, b1 = a1 * iw;
+    if (b0 < 0.f || b0 > 1.f) g0 = 0.f;   // forward clamps u,v: no gradient through a clamped value
+    if (b1 < 0.f || b1 > 1.f) g1 = 0.f;
+    const float da0 = (g0 * (1.f - b0) - g1 * b1) * iw, da1 = (-g0 * b0 + g1 * (1.f - b1)) * iw, da2 = (-g0 * b0 - g1 * b1) * iw;
+    const float dx[3] = {da1 * (-p2y) + da2 * p1y, da0 * p2y + da2 * (-p0y), da0 * (-p1y) + da1 * p0y};
+    const float dyv[3] = {da1 * p2x + da2 * (-p1x), da0 * (-p2x) + da2 * p0x, da0 * p1x + da1 * (-p0x)};
+    const int vv[3] = {vi.x, vi.y, vi.z};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float* d = dpos + ((size_t)b * V + vv[k]) * 4;
+        atomicAdd(d + 0, dx[k]); atomicAdd(d + 1, dyv[k]); atomicAdd(d + 3, -fx * dx[k] - fy * dyv[k]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ interpolate
+__global__ void __launch_bounds__(256) k_interp_fwd(const float* __restrict__ attr, int Ba, const float4* __restrict__ rast, const int3* __restrict__ tri,
+                                                     const float4* __restrict__ rast_db, const int* __restrict__ diff, int nd, long long BP, long long P,
+                                                     int V, int A, float* __restrict__ out, float* __restrict__ out_da) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= BP) return;
+    const float4 r = rast[gid];
+    const int t = (int)r.w - 1;
+    float* po = out + gid * A;
+    if (t < 0) {
+        for (int a = 0; a < A; a++) po[a] = 0.f;
+        for (int a = 0; a < 2 * nd; a++) out_da[gid * 2 * nd + a] = 0.f;
+        return;
+    }
+    const int b = (int)(gid / P);
+    const float* ab = attr + (size_t)(Ba > 1 ? b : 0) * V * A;
+    const int3 vi = tri[t];
+    const float *a0 = ab + (size_t)vi.x * A, *a1 = ab + (size_t)vi.y * A, *a2 = ab + (size_t)vi.z * A;
+    const float u = r.x, v = r.y, w2 = 1.f - u - v;
+    for (int a = 0; a < A; a++) po[a] = u * a0[a] + v * a1[a] + w2 * a2[a];
+    if (nd) {
+        const float4 db = rast_db[gid];
+        for (int k = 0; k < nd; k++) {
+            const int a = diff[k];
+            const float dsdu = a0[a] - a2[a], dsdv = a1[a] - a2[a];
+            out_da[(gid * nd + k) * 2] = dsdu * db.x + dsdv * db.z;
+            out_da[(gid * nd + k) * 2 + 1] = dsdu * db.y + dsdv * db.w;
+        }
+    }
+}
+__global__ void __launch_bounds__(256) k_interp_bwd(const float* __restrict__ attr, int Ba, const float4* __restrict__ rast, const int3* __restrict__ tri,
+                                                     const float* __restrict__ dy, long long BP, long long P, int V, int A, float* __restrict__ dattr,
+                                                     float4* __restrict__ drast) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= BP) return;
+    const float4 r = rast[gid];
+    const int t = (int)r.w - 1;
+    if (t < 0) { drast[gid] = make_float4(0.f, 0.f, 0.f, 0.f); return; }
+    const int b = (int)(gid / P);
+    const size_t ab = (size_t)(Ba > 1 ? b : 0) * V * A;
+    const int3 vi = tri[t];
+    const size_t i0 = ab + (size_t)vi.x * A, i1 = ab + (size_t)vi.y * A, i2 = ab + (size_t)vi.z * A;
+    const float u = r.x, v = r.y, w2 = 1.f - u - v;
+    float gu = 0.f, gv = 0.f;
+    for (int a = 0; a < A; a++) {
+        const float g = dy[gid * A + a];
+        if (g != 0.f) { atomicAdd(&dattr[i0 + a], u * g); atomicAdd(&dattr[i1 + a], v * g); atomicAdd(&dattr[i2 + a], w2 * g); }
+        gu += g * (attr[i0 + a] - attr[i2 + a]); gv += g * (attr[i1 + a] - attr[i2 + a]);
+    }
+    drast[gid] = make_float4(gu, gv, 0.f, 0.f);
+}
+
+// ------------------------------------------------------------------------------------------ texture
+__device__ __forceinline__ int wrapi(int i, int n, int boundary) {
+    if (boundary == 0) { i %= n; if (i < 0) i += n; return i; }
+    return min(max(i, 0), n - 1);
+}
+__global__ void __launch_bounds__(256) k_tex_fwd(const float* __restrict__ tex, int Bt, const float2* __restrict__ uv, long long BP, long long P,
+                                                  int Ht, int Wt, int C, int filter, int boundary, float* __restrict__ out) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= BP) return;
+    const float* tb = tex + (size_t)(Bt > 1 ? (gid / P) : 0) * Ht * Wt * C;
+    const float2 q = uv[gid];
+    float u = q.x * Wt, v = q.y * Ht;
+    float* po = out + gid * C;
+    if (filter == 0) {
+        const int iu = wrapi((int)floorf(u), Wt, boundary), iv = wrapi((int)floorf(v), Ht, boundary);
+        for (int c = 0; c < C; c++) po[c] = tb[((size_t)iv * Wt + iu) * C + c];
+        return;
+    }
+    u -= 0.5f; v -= 0.5f;
+    const float fu0 = floorf(u), fv0 = floorf(v), fu = u - fu0, fv = v - fv0;
+    const int iu0 = wrapi((int)fu0, Wt, boundary), iu1 = wrapi((int)fu0 + 1, Wt, boundary);
+    const int iv0 = wrapi((int)fv0, Ht, boundary), iv1 = wrapi((int)fv0 + 1, Ht, boundary);
+    const float *t00 = tb + ((size_t)iv0 * Wt + iu0) * C, *t10 = tb + ((size_t)iv0 * Wt + iu1) * C;
+    const float *t01 = tb + ((size_t)iv1 * Wt + iu0) * C, *t11 = tb + ((size_t)iv1 * Wt + iu1) * C;
+    for (int c = 0; c < C; c++) {
+        const float top = t00[c] + fu * (t10[c] - t00[c]), bot = t01[c] + fu * (t11[c] - t01[c]);
+        po[c] = top + fv * (bot - top);
+    }
+}
+__global__ void __launch_bounds__(256) k_tex_bwd(const float* __restrict__ tex, int Bt, const float2* __restrict__ uv, const float* __restrict__ dy,
+                                                  long long BP, long long P, int Ht, int Wt, int C, int filter, int boundary, float* __restrict__ dtex,
+                                                  float2* __restrict__ duv) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= BP) return;
+    const size_t tbo = (size_t)(Bt > 1 ? (gid / P) : 0) * Ht * Wt * C;
+    const float2 q = uv[gid];
+    float u = q.x * Wt, v = q.y * Ht;
+    const float* g = dy + gid * C;
+    if (filter == 0) {
+        const int iu = wrapi((int)floorf(u), Wt, boundary), iv = wrapi((int)floorf(v), Ht, boundary);
+        for (int c = 0; c < C; c++) if (g[c] != 0.f) atomicAdd(&dtex[tbo + ((size_t)iv * Wt + iu) * C + c], g[c]);
+        duv[gid] = make_float2(0.f, 0.f);
+        return;
+    }
+    u -= 0.5f; v -= 0.5f;
+    const float fu0 = floorf(u), fv0 = floorf(v), fu = u - fu0, fv = v - fv0;
+    const int iu0 = wrapi((int)fu0, Wt, boundary), iu1 = wrapi((int)fu0 + 1, Wt, boundary);
+    const int iv0 = wrapi((int)fv0, Ht, boundary), iv1 = wrapi((int)fv0 + 1, Ht, boundary);
+    const size_t i00 = tbo + ((size_t)iv0 * Wt + iu0) * C, i10 = tbo + ((size_t)iv0 * Wt + iu1) * C;
+    const size_t i01 = tbo + ((size_t)iv1 * Wt + iu0) * C, i11 = tbo + ((size_t)iv1 * Wt + iu1) * C;
+    float gu = 0.f, gv = 0.f;
+    for (int c = 0; c < C; c++) {
+        const float gc = g[c];
+        const float t00 = tex[i00 + c], t10 = tex[i10 + c], t01 = tex[i01 + c], t11 = tex[i11 + c];
+        if (gc != 0.f) {
+            atomicAdd(&dtex[i00 + c], gc * (1.f - fu) * (1.f - fv)); atomicAdd(&dtex[i10 + c], gc * fu * (1.f - fv));
+            atomicAdd(&dtex[i01 + c], gc * (1.f - fu) * fv); atomicAdd(&dtex[i11 + c], gc * fu * fv);
+        }
+        gu += gc * ((t10 - t00) * (1.f - fv) + (t11 - t01) * fv);
+        gv += gc * ((t01 - t00) * (1.f - fu) + (t11 - t10) * fu);
+    }
+    duv[gid] = make_float2(gu * Wt, gv * Ht);
+}
+
+// ------------------------------------------------------------------------------------------ antialias
+// Topology hash: open addressing on the 64-bit (min vertex, max vertex) key; each slot records up to two incident
+// (triangle, opposite vertex) pairs and the total count.
+struct EdgeSlot { unsigned long long key; uint32_t count; int32_t tri0, opp0, tri1, opp1; uint32_t pad; };   // 32 bytes
+__device__ __forceinline__ uint32_t edge_hash(unsigned long long k, uint32_t mask) {
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+    return (uint32_t)k & mask;
+}
+static inline uint32_t edge_table_size(int T) {
+    uint32_t need = (uint32_t)(T > 0 ? T : 1) * 3u * 2u, n = 1024;
+    while (n < need) n <<= 1;
+    return n;
+}
+__global__ void __launch_bounds__(256) k_aa_hash_init(EdgeSlot* __restrict__ table, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { table[i].key = MESH_EMPTY_KEY; table[i].count = 0u; }
+}
+__global__ void __launch_bounds__(256) k_aa_hash_build(const int3* __restrict__ tri, int T, EdgeSlot* __restrict__ table, uint32_t mask) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= 3 * T) return;
+    const int t = gid / 3, k = gid % 3;
+    const int3 vi = tri[t];
+    const int vv[3] = {vi.x, vi.y, vi.z};
+    const int a = vv[k], b = vv[(k + 1) % 3], o = vv[(k + 2) % 3];
+    if (a == b) return;
+    const unsigned long long key = ((unsigned long long)(uint32_t)min(a, b) << 32) | (uint32_t)max(a, b);
+    uint32_t h = edge_hash(key, mask);
+    for (uint32_t probe = 0; probe <= mask; probe++, h = (h + 1) & mask) {
+        const unsigned long long old = atomicCAS(&table[h].key, MESH_EMPTY_KEY, key);
+        if (old == MESH_EMPTY_KEY || old == key) {
+            const uint32_t i = atomicAdd(&table[h].count, 1u);
+            if (i == 0) { table[h].tri0 = t; table[h].opp0 = o; }
+            else if (i == 1) { table[h].tri1 = t; table[h].opp1 = o; }
+            return;
+        }
+    }
+}
+// opposite vertex of the other triangle on edge (a,b) of `t`: -1 boundary, -2 non-manifold (> 2 triangles)
+__device__ __forceinline__ int other_opposite(const EdgeSlot* __restrict__ table, uint32_t mask, int a, int b, int t) {
+    const unsigned long long key = ((unsigned long long)(uint32_t)min(a, b) << 32) | (uint32_t)max(a, b);
+    uint32_t h = edge_hash(key, mask);
+    for (uint32_t probe = 0; probe <= mask; probe++, h = (h + 1) & mask) {
+        const unsigned long long kk = table[h].key;
+        if (kk == key) {
+            const uint32_t c = table[h].count;
+            if (c > 2) return -2;
+            if (c < 2) return -1;
+            // with two entries: the one that is not `t`; if the lower-index one is t, the other; order-independent
+            const int t0 = table[h].tri0, t1 = table[h].tri1;
+            if (t0 != t && t1 != t) return (t0 < t1) ? table[h].opp0 : table[h].opp1;
+            return (t0 != t) ? table[h].opp0 : ((t1 != t) ? table[h].opp1 : -1);
+        }
+        if (kk == MESH_EMPTY_KEY) return -1;
+    }
+    return -1;
+}
+
+struct AaHit { int ax, ay, bx, by, va, vb; float s, sgn; };
+__device__ __forceinline__ bool aa_analyze(const float4* __restrict__ pb, const int3* __restrict__ tri, const EdgeSlot* __restrict__ table, uint32_t mask,
+                                           const float4* __restrict__ rast_b, int H, int W, int px, int py, int d, AaHit& hit) {
+    const int qx = px + (d == 0), qy = py + (d == 1);
+    if (qx >= W || qy >= H) return false;
+    const float4 r0 = rast_b[(size_t)py * W + px], r1 = rast_b[(size_t)qy * W + qx];
+    const int id0 = (int)r0.w, id1 = (int)r1.w;
+    if (id0 == id1) return false;
+    bool a_is_p;
+    if (id0 > 0 && id1 > 0) a_is_p = r0.z < r1.z;
+    else a_is_p = id0 > 0;
+    const int t = (a_is_p ? id0 : id1) - 1;
+    const int ax = a_is_p ? px : qx, ay = a_is_p ? py : qy;
+    const float sgn = a_is_p ? 1.f : -1.f;
+    const int3 vi3 = tri[t];
+    const int vi[3] = {vi3.x, vi3.y, vi3.z};
+    float nx[3], ny[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float4 p = pb[vi[k]];
+        if (!(p.w > 0.f)) return false;
+        nx[k] = p.x / p.w; ny[k] = p.y / p.w;
+    }
+    const float cx = ((float)ax + 0.5f) * (2.f / W) - 1.f, cy = ((float)ay + 0.5f) * (2.f / H) - 1.f;
+    const float h = d == 0 ? 2.f / W : 2.f / H;
+    bool found = false;
+    float best = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int ia = k, ib = (k + 1) % 3, io = (k + 2) % 3;
+        const float ex = nx[ib] - nx[ia], ey = ny[ib] - ny[ia];
+        // cheap geometric test first, hash lookup only for edges that cross the centre-to-centre segment
+        float s;
+        if (d == 0) {
+            const float da = ny[ia] - cy, db = ny[ib] - cy;
+            if (!((da <= 0.f && db > 0.f) || (db <= 0.f && da > 0.f))) continue;
+            const float te = da / (da - db);
+            s = sgn * ((nx[ia] + te * ex) - cx) / h;
+        } else {
+            const float da = nx[ia] - cx, db = nx[ib] - cx;
+            if (!((da <= 0.f && db > 0.f) || (db <= 0.f && da > 0.f))) continue;
+            const float te = da / (da - db);
+            s = sgn * ((ny[ia] + te * ey) - cy) / h;
+        }
+        if (!(s >= 0.f && s <= 1.f)) continue;
+        const int opp = other_opposite(table, mask, vi[ia], vi[ib], t);
+        if (opp == -2) continue;
+        if (opp >= 0) {   // interior edge: silhouette only if both triangles lie on the same side of it
+            const float4 q = pb[opp];
+            if (!(q.w > 0.f)) continue;
+            const float ox = q.x / q.w, oy = q.y / q.w;
+            const float s_this = ex * (ny[io] - ny[ia]) - ey * (nx[io] - nx[ia]);
+            const float s_other = ex * (oy - ny[ia]) - ey * (ox - nx[ia]);
+            if (!(s_this * s_other > 0.f)) continue;
+        }
+        if (!found || s < best) { found = true; best = s; hit.va = vi[ia]; hit.vb = vi[ib]; }
+    }
+    if (!found) return false;
+    hit.ax = ax; hit.ay = ay; hit.bx = a_is_p ? qx : px; hit.by = a_is_p ? qy : py; hit.s = best; hit.sgn = sgn;
+    return true;
+}
+
+__global__ void __launch_bounds__(256) k_aa_fwd(const float* __restrict__ color, const float4* __restrict__ rast, const float4* __restrict__ pos,
+                                                 const int3* __restrict__ tri, const EdgeSlot* __restrict__ table, uint32_t mask, int B, int V, int H, int W,
+                                                 int C, float* __restrict__ out) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long P = (long long)H * W;
+    if (gid >= (long long)B * P * 2) return;
+    const int d = (int)(gid & 1);
+    const long long pg = gid >> 1;
+    const int b = (int)(pg / P), pid = (int)(pg % P), px = pid % W, py = pid / W;
+    AaHit h;
+    if (!aa_analyze(pos + (size_t)b * V, tri, table, mask, rast + (size_t)b * P, H, W, px, py, d, h)) return;
+    const float alpha = h.s - 0.5f;
+    const float* ca = color + ((size_t)b * P + (size_t)h.ay * W + h.ax) * C;
+    const float* cb = color + ((size_t)b * P + (size_t)h.by * W + h.bx) * C;
+    float* o = out + ((size_t)b * P + (alpha > 0.f ? ((size_t)h.by * W + h.bx) : ((size_t)h.ay * W + h.ax))) * C;
+    for (int c = 0; c < C; c++) atomicAdd(&o[c], alpha * (ca[c] - cb[c]));
+}
+__global__ void __launch_bounds__(256) k_aa_bwd(const float* __restrict__ color, const float4* __restrict__ rast, const float4* __restrict__ pos,
+                                                 const int3* __restrict__ tri, const EdgeSlot* __restrict__ table, uint32_t mask, const float* __restrict__ dy,
+                                                 int B, int V, int H, int W, int C, float* __restrict__ dcolor, float* __restrict__ dpos) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long P = (long long)H * W;
+    if (gid >= (long long)B * P * 2) return;
+    const int d = (int)(gid & 1);
+    const long long pg = gid >> 1;
+    const int b = (int)(pg / P), pid = (int)(pg % P), px = pid % W, py = pid / W;
+    const float4* pb = pos + (size_t)b * V;
+    AaHit h;
+    if (!aa_analyze(pb, tri, table, mask, rast + (size_t)b * P, H, W, px, py, d, h)) return;
+    const float alpha = h.s - 0.5f;
+    const size_t ia = ((size_t)b * P + (size_t)h.ay * W + h.ax) * C, ib = ((size_t)b * P + (size_t)h.by * W + h.bx) * C;
+    const size_t idst = alpha > 0.f ? ib : ia;
+    float dalpha = 0.f;
+    for (int c = 0; c < C; c++) {
+        const float g = dy[idst + c];
+        atomicAdd(&dcolor[ia + c], alpha * g); atomicAdd(&dcolor[ib + c], -alpha * g);
+        dalpha += g * (color[ia + c] - color[ib + c]);
+    }
+    const float4 pa = pb[h.va], pv = pb[h.vb];
+    const float xa = pa.x / pa.w, ya = pa.y / pa.w, xb = pv.x / pv.w, yb = pv.y / pv.w;
+    const float cx = ((float)h.ax + 0.5f) * (2.f / W) - 1.f, cy = ((float)h.ay + 0.5f) * (2.f / H) - 1.f;
+    const float hh = d == 0 ? 2.f / W : 2.f / H;
+    const float gs = dalpha * h.sgn / hh;
+    float gxa, gya, gxb, gyb;
+    if (d == 0) {
+        const float da = ya - cy, db = yb - cy, den = da - db, te = da / den, gte = gs * (xb - xa);
+        gxa = gs * (1.f - te); gxb = gs * te;
+        gya = gte * (-db / (den * den)); gyb = gte * (da / (den * den));
+    } else {
+        const float da = xa - cx, db = xb - cx, den = da - db, te = da / den, gte = gs * (yb - ya);
+        gya = gs * (1.f - te); gyb = gs * te;
+        gxa = gte * (-db / (den * den)); gxb = gte * (da / (den * den));
+    }
+    float* dA = dpos + ((size_t)b * V + h.va) * 4;
+    float* dB = dpos + ((size_t)b * V + h.vb) * 4;
+    atomicAdd(dA + 0, gxa / pa.w); atomicAdd(dA + 1, gya / pa.w); atomicAdd(dA + 3, -(gxa * xa + gya * ya) / pa.w);
+    atomicAdd(dB + 0, gxb / pv.w); atomicAdd(dB + 1, gyb / pv.w); atomicAdd(dB + 3, -(gxb * xb + gyb * yb) / pv.w);
+}
+
+// ------------------------------------------------------------------------------------------ C-ABI
+#define MESH_REQUIRE(cond, msg) do { if (!(cond)) { c3d_set_error("c3d_mesh: " msg); return -1; } } while (0)
+static inline size_t zbuf_bytes(int B, int H, int W) { return c3d_align(8 * (size_t)B * H * W); }
+
+extern "C" {
+
+size_t c3d_mesh_raster_scratch_bytes(int32_t B, int32_t H, int32_t W, int32_t T) {
+    return zbuf_bytes(B, H, W) + c3d_align(4 * ((size_t)B * (size_t)(T > 0 ? T : 1))) + 256;
+}
+
+int c3d_mesh_rasterize_fwd(const float* pos, const int32_t* tri, int32_t B, int32_t V, int32_t T, int32_t H, int32_t W, void* scratch, float* rast,
+                           float* rast_db, c3d_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    MESH_REQUIRE(B >= 0 && V >= 0 && T >= 0 && H >= 0 && W >= 0, "negative size");
+    MESH_REQUIRE(H <= 32768 && W <= 32768, "resolution above 32768 is not supported");
+    const long long BP = (long long)B * H * W;
+    if (BP == 0) return 0;
+    MESH_REQUIRE(rast && scratch, "NULL buffer");
+    MESH_REQUIRE((long long)B * T < (1ll << 32), "B*T must fit 32 bits");
+    C3dProfScope ps(C3D_P_MESH_RASTERIZE, s);
+    unsigned long long* zbuf = (unsigned long long*)scratch;
+    uint32_t* queue = (uint32_t*)((char*)scratch + zbuf_bytes(B, H, W));
+    uint32_t* count = (uint32_t*)((char*)queue + c3d_align(4 * ((size_t)B * (size_t)(T > 0 ? T : 1))));
+    C3D_CHECK(hipMemsetAsync(zbuf, 0xFF, 8 * (size_t)BP, s));
+    C3D_CHECK(hipMemsetAsync(count, 0, 4, s));
+    if (T > 0 && V > 0) {
+        MESH_REQUIRE(pos && tri, "NULL geometry");
+        hipLaunchKernelGGL(k_ras_tri, dim3(c3d_cdiv((long long)B * T, 256)), dim3(256), 0, s, (const float4*)pos, (const int3*)tri, B, V, T, H, W, zbuf, queue, count);
+        hipLaunchKernelGGL(k_ras_big, dim3(2048), dim3(256), 0, s, (const float4*)pos, (const int3*)tri, V, T, H, W, zbuf, queue, count);
+    }
+    hipLaunchKernelGGL(k_ras_resolve, dim3(c3d_cdiv(BP, 256)), dim3(256), 0, s, (const float4*)pos, (const int3*)tri, B, V, H, W, zbuf, (float4*)rast, (float4*)rast_db);
+    C3D_LAUNCH_CHECK();
+    return 0;
+}
+
+int c3d_mesh_rasterize_bwd(const float* pos, const int32_t* tri, const float* rast, const float* dy, int32_t B, int32_t V, int32_t T, int32_t H,
+                           int32_t W, float* dpos, c3d_stream_t stream) {
+    (void)T;
+    hipStream_t s = (hipStream_t)stream;
+    if ((long long)B * V == 0) return 0;
+    MESH_REQUIRE(dpos, "NULL dpos");
+    C3dProfScope ps(C3D_P_MESH_BWD, s);
+    C3D_CHECK(hipMemsetAsync(dpos, 0, sizeof(float) * 4 * (size_t)B * V, s));
+    const long long BP = (long long)B * H * W;
+    if (BP == 0) return 0;
+    MESH_REQUIRE(pos && tri && rast && dy, "NULL pointer");
+    hipLaunchKernelGGL(k_ras_bwd, dim3(c3d_cdiv(BP, 256)), dim3(256), 0, s, (const float4*)pos, (const int3*)tri, (const float4*)rast, (const float4*)dy, B, V, H, W, dpos);
+    C3D_LAUNCH_CHECK();
+    return 0;
+}
+
+int c3d_mesh_interpolate_fwd(const float* attr, int32_t Ba, const float* rast, const int32_t* tri, const float* rast_db, const int32_t* diff, int32_t nd,
+                             int32_t B, int32_t V, int32_t A, int32_t H, int32_t W, float* out, float* out_da, c3d_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    const long long P = (long long)H * W, BP = P * B;
+    if (BP == 0 || A == 0) return 0;
+    MESH_REQUIRE(attr && rast && tri && out, "NULL pointer");
+    MESH_REQUIRE(Ba == 1 || Ba == B, "attribute batch must be 1 or B");
+    MESH_REQUIRE(nd == 0 || (rast_db && diff && out_da), "diff_attrs needs rast_db");
+    C3dProfScope ps(C3D_P_MESH_INTERPOLATE, s);
+    hipLaunchKernelGGL(k_interp_fwd, dim3(c3d_cdiv(BP, 256)), dim3(256), 0, s, attr, Ba, (const float4*)rast, (const int3*)tri, (const float4*)rast_db, diff, nd, BP, P, V, A, out, out_da);
+    C3D_LAUNCH_CHECK();
+    return 0;
+}
+int c3d_mesh_interpolate_bwd(const float* attr, int32_t Ba, const float* rast, const int32_t* tri, const float* dy, int32_t B, int32_t V, int32_t A,
+                             int32_t H, int32_t W, float* dattr, float* drast, c3d_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    const long long P = (long long)H * W, BP = P * B;
+    MESH_REQUIRE(Ba == 1 || Ba == B, "attribute batch must be 1 or B");
+    C3dProfScope ps(C3D_P_MESH_BWD, s);
+    if ((long long)Ba * V * A > 0) { MESH_REQUIRE(dattr, "NULL dattr"); C3D_CHECK(hipMemsetAsync(dattr, 0, sizeof(float) * (size_t)Ba * V * A, s)); }
+    if (BP == 0) return 0;
+    MESH_REQUIRE(attr && rast && tri && dy && drast, "NULL pointer");
+    hipLaunchKernelGGL(k_interp_bwd, dim3(c3d_cdiv(BP, 256)), dim3(256), 0, s, attr, Ba, (const float4*)rast, (const int3*)tri, dy, BP, P, V, A, dattr, (float4*)drast);
+    C3D_LAUNCH_CHECK();
+    return 0;
+}
+
+int c3d_mesh_texture_fwd(const float* tex, int32_t Bt, const float* uv, int32_t B, int32_t H, int32_t W, int32_t Ht, int32_t Wt, int32_t C, int32_t filter,
+                         int32_t boundary, float* out, c3d_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    const long long P = (long long)H * W, BP = P * B;
+    if (BP == 0 || C == 0) return 0;
+    MESH_REQUIRE(tex && uv && out && Ht > 0 && Wt > 0, "NULL pointer / empty texture");
+    MESH_REQUIRE(Bt == 1 || Bt == B, "texture batch must be 1 or B");
+    MESH_REQUIRE((filter == 0 || filter == 1) && (boundary == 0 || boundary == 1), "unsupported filter/boundary mode");
+    C3dProfScope ps(C3D_P_MESH_TEXTURE, s);
+    hipLaunchKernelGGL(k_tex_fwd, dim3(c3d_cdiv(BP, 256)), dim3(256), 0, s, tex, Bt, (const float2*)uv, BP, P, Ht, Wt, C, filter, boundary, out);
+    C3D_LAUNCH_CHECK();
+    return 0;
+}
+int c3d_mesh_texture_bwd(const float* tex, int32_t Bt, const float* uv, const float* dy, int32_t B, int32_t H, int32_t W, int32_t Ht, int32_t Wt, int32_t C,
+                         int32_t filter, int32_t boundary, float* dtex, float* duv, c3d_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    const long long P = (long long)H * W, BP = P * B;
+    MESH_REQUIRE(Bt == 1 || Bt == B, "texture batch must be 1 or B");
+    MESH_REQUIRE((filter == 0 || filter == 1) && (boundary == 0 || boundary == 1), "unsupported filter/boundary mode");
+    C3dProfScope ps(C3D_P_MESH_BWD, s);
+    if ((long long)Bt * Ht * Wt * C > 0) { MESH_REQUIRE(dtex, "NULL dtex"); C3D_CHECK(hipMemsetAsync(dtex, 0, sizeof(float) * (size_t)Bt * Ht * Wt * C, s)); }
+    if (BP == 0 || C == 0) return 0;
+    MESH_REQUIRE(tex && uv && dy && duv, "NULL pointer");
+    hipLaunchKernelGGL(k_tex_bwd, dim3(c3d_cdiv(BP, 256)), dim3(256), 0, s, tex, Bt, (const float2*)uv, dy, BP, P, Ht, Wt, C, filter, boundary, dtex, (float2*)duv);
+    C3D_LAUNCH_CHECK();
+    return 0;
+}
+
+size_t c3d_mesh_antialias_scratch_bytes(int32_t T) { return c3d_align(sizeof(EdgeSlot) * (size_t)edge_table_size(T)); }
+
+int c3d_mesh_antialias_fwd(const float* color, const float* rast, const float* pos, const int32_t* tri, int32_t B, int32_t V, int32_t T, int32_t H, int32_t W,
+                           int32_t C, void* scratch, float* out, c3d_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    const long long P = (long long)H * W, BP = P * B;
+    if (BP == 0 || C == 0) return 0;
+    MESH_REQUIRE(color && rast && out && scratch, "NULL pointer");
+    C3dProfScope ps(C3D_P_MESH_ANTIALIAS, s);
+    C3D_CHECK(hipMemcpyAsync(out, color, sizeof(float) * (size_t)BP * C, hipMemcpyDeviceToDevice, s));
+    const uint32_t n = edge_table_size(T);
+    EdgeSlot* table = (EdgeSlot*)scratch;
+    hipLaunchKernelGGL(k_aa_hash_init, dim3(c3d_cdiv((long long)n, 256)), dim3(256), 0, s, table, n);
+    if (T > 0) {
+        MESH_REQUIRE(pos && tri, "NULL geometry");
+        hipLaunchKernelGGL(k_aa_hash_build, dim3(c3d_cdiv(3ll * T, 256)), dim3(256), 0, s, (const int3*)tri, T, table, n - 1);
+        hipLaunchKernelGGL(k_aa_fwd, dim3(c3d_cdiv(BP * 2, 256)), dim3(256), 0, s, color, (const float4*)rast, (const float4*)pos, (const int3*)tri, table, n - 1, B, V, H, W, C, out);
+    }
+    C3D_LAUNCH_CHECK();
+    return 0;
+}
+int c3d_mesh_antialias_bwd(const float* color, const float* rast, const float* pos, const int32_t* tri, const float* dy, int32_t B, int32_t V, int32_t T,
+                           int32_t H, int32_t W, int32_t C, const void* scratch, float* dcolor, float* dpos, c3d_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    const long long P = (long long)H * W, BP = P * B;
+    C3dProfScope ps(C3D_P_MESH_BWD, s);
+    if ((long long)B * V > 0) { MESH_REQUIRE(dpos, "NULL dpos"); C3D_CHECK(hipMemsetAsync(dpos, 0, sizeof(float) * 4 * (size_t)B * V, s)); }
+    if (BP == 0 || C == 0) return 0;
+    MESH_REQUIRE(color && rast && dy && dcolor && scratch, "NULL pointer");
+    C3D_CHECK(hipMemcpyAsync(dcolor, dy, sizeof(float) * (size_t)BP * C, hipMemcpyDeviceToDevice, s));
+    if (T > 0) {
+        MESH_REQUIRE(pos && tri, "NULL geometry");
+        const uint32_t n = edge_table_size(T);
+        hipLaunchKernelGGL(k_aa_bwd, dim3(c3d_cdiv(BP * 2, 256)), dim3(256), 0, s, color, (const float4*)rast, (const float4*)pos, (const int3*)tri,
+                           (const EdgeSlot*)scratch, n - 1, dy, B, V, H, W, C, dcolor, dpos);
+    }
+    C3D_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

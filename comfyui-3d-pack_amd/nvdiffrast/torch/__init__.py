@@ -1,0 +1,245 @@
+"""`nvdiffrast.torch` -- drop-in Python boundary over the MI355X HIP mesh ops (include/c3d_mesh.h).
+
+Same function names, argument meaning and return shapes as the module the reference imports as `dr`
+(/root/reference/MVs_Algorithms/DiffRastMesh/diff_mesh_renderer.py:8, call sites :46,97,101,104,105,110,131,138;
+ also MVs_Algorithms/FlexiCubes/flexicubes_renderer.py:46-66 and mesh_processer/mesh_utils.py:527-541):
+    RasterizeCudaContext(device=None) / RasterizeGLContext(...)      rasterize(glctx, pos, tri, resolution, ranges=None, grad_db=True)
+    interpolate(attr, rast, tri, rast_db=None, diff_attrs=None)      texture(tex, uv, uv_da=None, ..., filter_mode='auto', boundary_mode='wrap')
+    antialias(color, rast, pos, tri, topology_hash=None, pos_gradient_boost=1.0)
+The arithmetic runs in libc3d_hip.so; this file allocates tensors and wires autograd.  There is no CPU path.
+Not built (raise NotImplementedError): range mode (`ranges`), mip-mapped filter modes, cube maps, DepthPeeler; gradients w.r.t.
+rast_db / out_da are not propagated (no consumer on the reference's path: `texture(..., 'linear')` ignores uv_da).
+"""
+import torch
+
+import c3d_hip as _h
+
+_FILTER = {"nearest": 0, "linear": 1}
+_BOUNDARY = {"wrap": 0, "clamp": 1}
+
+
+def _dev_check(t, what):
+    if not t.is_cuda:
+        raise RuntimeError("nvdiffrast.torch (MI355X): %s must live on a HIP device; there is no CPU path" % what)
+
+
+class RasterizeCudaContext:
+    """Owns the rasterizer's scratch (64-bit depth|id buffer + large-triangle queue), grown on demand."""
+
+    def __init__(self, device=None):
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self._scratch = None
+        self.active_depth_peeler = None
+
+    def scratch(self, nbytes, device):
+        if self._scratch is None or self._scratch.numel() < nbytes or self._scratch.device != device:
+            self._scratch = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+        return self._scratch
+
+
+class RasterizeGLContext(RasterizeCudaContext):
+    """The reference picks the GL context on Windows unless force_cuda_rast (diff_mesh_renderer.py:45-48): same engine here."""
+
+    def __init__(self, output_db=True, mode='automatic', device=None):
+        super().__init__(device)
+
+
+class _Rasterize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, glctx, pos, tri, resolution, grad_db):
+        lib = _h.lib()
+        _dev_check(pos, "pos")
+        if pos.dim() != 3 or pos.shape[-1] != 4:
+            raise ValueError("rasterize: pos must be [B,V,4] (range mode is not built)")
+        pos_c, tri_c = _h.f32c(pos), tri.to(torch.int32).contiguous()
+        B, V = pos.shape[0], pos.shape[1]
+        T = tri_c.shape[0]
+        H, W = int(resolution[0]), int(resolution[1])
+        dev = pos.device
+        with torch.cuda.device(dev):
+            scratch = glctx.scratch(lib.c3d_mesh_raster_scratch_bytes(B, H, W, T), dev)
+            rast = torch.empty((B, H, W, 4), dtype=torch.float32, device=dev)
+            rast_db = torch.empty((B, H, W, 4), dtype=torch.float32, device=dev)
+            _h.check(lib.c3d_mesh_rasterize_fwd(_h.ptr(pos_c), _h.ptr(tri_c if T else None), B, V, T, H, W, _h.ptr(scratch), _h.ptr(rast),
+                                                _h.ptr(rast_db), _h.stream(dev)), "c3d_mesh_rasterize_fwd")
+        ctx.save_for_backward(pos_c if pos_c is not None else pos, tri_c, rast)
+        ctx.dims = (B, V, T, H, W)
+        return rast, rast_db
+
+    @staticmethod
+    def backward(ctx, dy, ddb):
+        lib = _h.lib()
+        pos, tri, rast = ctx.saved_tensors
+        B, V, T, H, W = ctx.dims
+        dev = pos.device
+        with torch.cuda.device(dev):
+            dpos = torch.empty((B, V, 4), dtype=torch.float32, device=dev)
+            _h.check(lib.c3d_mesh_rasterize_bwd(_h.ptr(pos), _h.ptr(tri if T else None), _h.ptr(rast), _h.ptr(_h.f32c(dy)), B, V, T, H, W,
+                                                _h.ptr(dpos), _h.stream(dev)), "c3d_mesh_rasterize_bwd")
+        return None, dpos, None, None, None
+
+
+def rasterize(glctx, pos, tri, resolution, ranges=None, grad_db=True):
+    """-> (rast [B,H,W,4] = (u, v, z/w, triangle_id+1), rast_db [B,H,W,4] = (du/dX, du/dY, dv/dX, dv/dY))"""
+    if ranges is not None:
+        raise NotImplementedError("rasterize(ranges=...) (instanced range mode) is not built")
+    if not isinstance(glctx, RasterizeCudaContext):
+        raise TypeError("rasterize: glctx must be a RasterizeCudaContext / RasterizeGLContext")
+    return _Rasterize.apply(glctx, pos, tri, resolution, grad_db)
+
+
+class _Interpolate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, attr, rast, tri, rast_db, diff):
+        lib = _h.lib()
+        _dev_check(attr, "attr")
+        a = _h.f32c(attr)
+        a3 = a if a.dim() == 3 else a.unsqueeze(0)
+        Ba, V, A = a3.shape
+        rast_c, tri_c = _h.f32c(rast), tri.to(torch.int32).contiguous()
+        B, H, W, _ = rast_c.shape
+        dev = rast_c.device
+        nd = 0 if diff is None else int(diff.numel())
+        with torch.cuda.device(dev):
+            out = torch.empty((B, H, W, A), dtype=torch.float32, device=dev)
+            out_da = torch.empty((B, H, W, 2 * nd), dtype=torch.float32, device=dev)
+            _h.check(lib.c3d_mesh_interpolate_fwd(_h.ptr(a3), Ba, _h.ptr(rast_c), _h.ptr(tri_c), _h.ptr(_h.f32c(rast_db)) if nd else None,
+                                                  _h.ptr(diff) if nd else None, nd, B, V, A, H, W, _h.ptr(out), _h.ptr(out_da) if nd else None,
+                                                  _h.stream(dev)), "c3d_mesh_interpolate_fwd")
+        ctx.save_for_backward(a3, rast_c, tri_c)
+        ctx.attr_shape = tuple(attr.shape)
+        return out, out_da
+
+    @staticmethod
+    def backward(ctx, dy, dda):
+        lib = _h.lib()
+        a3, rast, tri = ctx.saved_tensors
+        Ba, V, A = a3.shape
+        B, H, W, _ = rast.shape
+        dev = rast.device
+        with torch.cuda.device(dev):
+            dattr = torch.empty_like(a3)
+            drast = torch.empty_like(rast)
+            _h.check(lib.c3d_mesh_interpolate_bwd(_h.ptr(a3), Ba, _h.ptr(rast), _h.ptr(tri), _h.ptr(_h.f32c(dy)), B, V, A, H, W, _h.ptr(dattr),
+                                                  _h.ptr(drast), _h.stream(dev)), "c3d_mesh_interpolate_bwd")
+        return dattr.reshape(ctx.attr_shape), drast, None, None, None
+
+
+def interpolate(attr, rast, tri, rast_db=None, diff_attrs=None):
+    """-> (out [B,H,W,A], out_da [B,H,W,2*len(diff_attrs)])   (out_da empty when diff_attrs is None)"""
+    diff = None
+    if diff_attrs is not None:
+        if rast_db is None:
+            raise ValueError("interpolate: diff_attrs requires rast_db")
+        A = attr.shape[-1]
+        idx = list(range(A)) if (isinstance(diff_attrs, str) and diff_attrs == 'all') else list(diff_attrs)
+        if len(idx):
+            diff = torch.tensor(idx, dtype=torch.int32, device=rast.device)
+    return _Interpolate.apply(attr, rast, tri, rast_db, diff)
+
+
+class _Texture(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tex, uv, filter_id, boundary_id):
+        lib = _h.lib()
+        _dev_check(tex, "tex")
+        tex_c, uv_c = _h.f32c(tex), _h.f32c(uv)
+        Bt, Ht, Wt, C = tex_c.shape
+        B, H, W, _ = uv_c.shape
+        dev = uv_c.device
+        with torch.cuda.device(dev):
+            out = torch.empty((B, H, W, C), dtype=torch.float32, device=dev)
+            _h.check(lib.c3d_mesh_texture_fwd(_h.ptr(tex_c), Bt, _h.ptr(uv_c), B, H, W, Ht, Wt, C, filter_id, boundary_id, _h.ptr(out), _h.stream(dev)),
+                     "c3d_mesh_texture_fwd")
+        ctx.save_for_backward(tex_c, uv_c)
+        ctx.modes = (filter_id, boundary_id)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _h.lib()
+        tex, uv = ctx.saved_tensors
+        Bt, Ht, Wt, C = tex.shape
+        B, H, W, _ = uv.shape
+        dev = uv.device
+        with torch.cuda.device(dev):
+            dtex, duv = torch.empty_like(tex), torch.empty_like(uv)
+            _h.check(lib.c3d_mesh_texture_bwd(_h.ptr(tex), Bt, _h.ptr(uv), _h.ptr(_h.f32c(dy)), B, H, W, Ht, Wt, C, ctx.modes[0], ctx.modes[1],
+                                              _h.ptr(dtex), _h.ptr(duv), _h.stream(dev)), "c3d_mesh_texture_bwd")
+        return dtex, duv, None, None
+
+
+def texture(tex, uv, uv_da=None, mip_level_bias=None, mip=None, filter_mode='auto', boundary_mode='wrap', max_mip_level=None):
+    """-> [B,H,W,C].  'auto' = 'linear' without uv_da (the dependency would pick a mip-mapped mode with uv_da: not built)."""
+    if filter_mode == 'auto':
+        filter_mode = 'linear' if (uv_da is None and mip_level_bias is None) else 'linear-mipmap-linear'
+    if filter_mode not in _FILTER:
+        raise NotImplementedError("texture: filter_mode %r (mip-mapped modes) is not built" % (filter_mode,))
+    if boundary_mode not in _BOUNDARY:
+        raise NotImplementedError("texture: boundary_mode %r is not built" % (boundary_mode,))
+    if tex.dim() != 4:
+        raise NotImplementedError("texture: cube maps are not built")
+    return _Texture.apply(tex, uv, _FILTER[filter_mode], _BOUNDARY[boundary_mode])
+
+
+class _Antialias(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, color, rast, pos, tri, pos_gradient_boost):
+        lib = _h.lib()
+        _dev_check(color, "color")
+        color_c, rast_c, pos_c, tri_c = _h.f32c(color), _h.f32c(rast), _h.f32c(pos), tri.to(torch.int32).contiguous()
+        B, H, W, C = color_c.shape
+        V, T = pos_c.shape[1], tri_c.shape[0]
+        dev = color_c.device
+        with torch.cuda.device(dev):
+            table = torch.empty((lib.c3d_mesh_antialias_scratch_bytes(T),), dtype=torch.uint8, device=dev)
+            out = torch.empty_like(color_c)
+            _h.check(lib.c3d_mesh_antialias_fwd(_h.ptr(color_c), _h.ptr(rast_c), _h.ptr(pos_c), _h.ptr(tri_c if T else None), B, V, T, H, W, C,
+                                                _h.ptr(table), _h.ptr(out), _h.stream(dev)), "c3d_mesh_antialias_fwd")
+        ctx.save_for_backward(color_c, rast_c, pos_c, tri_c, table)
+        ctx.boost = float(pos_gradient_boost)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _h.lib()
+        color, rast, pos, tri, table = ctx.saved_tensors
+        B, H, W, C = color.shape
+        V, T = pos.shape[1], tri.shape[0]
+        dev = color.device
+        with torch.cuda.device(dev):
+            dcolor, dpos = torch.empty_like(color), torch.empty_like(pos)
+            _h.check(lib.c3d_mesh_antialias_bwd(_h.ptr(color), _h.ptr(rast), _h.ptr(pos), _h.ptr(tri if T else None), _h.ptr(_h.f32c(dy)), B, V, T,
+                                                H, W, C, _h.ptr(table), _h.ptr(dcolor), _h.ptr(dpos), _h.stream(dev)), "c3d_mesh_antialias_bwd")
+        if ctx.boost != 1.0:
+            dpos = dpos * ctx.boost
+        return dcolor, None, dpos, None, None
+
+
+def antialias(color, rast, pos, tri, topology_hash=None, pos_gradient_boost=1.0):
+    """-> antialiased colour [B,H,W,C].  topology_hash is accepted and ignored (the edge hash is rebuilt per call, as it is
+    for the reference, which never passes one)."""
+    if pos.dim() != 3:
+        raise NotImplementedError("antialias: range-mode positions [V,4] are not built")
+    return _Antialias.apply(color, rast, pos, tri, pos_gradient_boost)
+
+
+def antialias_construct_topology_hash(tri):
+    return None
+
+
+def texture_construct_mip(tex, max_mip_level=None, cube_mode=False):
+    raise NotImplementedError("mip-mapped texture modes are not built")
+
+
+class DepthPeeler:
+    def __init__(self, *a, **k):
+        raise NotImplementedError("DepthPeeler is not built")
+
+
+def get_log_level():
+    return 1
+
+
+def set_log_level(level):
+    pass

@@ -1,0 +1,70 @@
+/*
+ * c3d_mesh.h -- C-ABI of the MI355X-native differentiable triangle-mesh ops (libc3d_hip.so).
+ *
+ * Drop-in boundary: what a native replacement of `nvdiffrast.torch` must provide for the calls the reference makes at
+ *   /root/reference/MVs_Algorithms/DiffRastMesh/diff_mesh_renderer.py:46     dr.RasterizeCudaContext()
+ *   :97    dr.rasterize(glctx, v_clip[1,V,4], f[T,3], (h, w))            -> c3d_mesh_rasterize_fwd / _bwd
+ *   :101   dr.antialias(alpha[1,H,W,1], rast, v_clip, f)                  -> c3d_mesh_antialias_fwd / _bwd
+ *   :104   dr.interpolate(vt[1,V,2], rast, ft, rast_db, diff_attrs='all') -> c3d_mesh_interpolate_fwd / _bwd
+ *   :105   dr.texture(raw_albedo[1,Ht,Wt,3], texc, uv_da=texc_db, filter_mode='linear') -> c3d_mesh_texture_fwd / _bwd
+ *   :110,131 dr.interpolate(depth / normals ...)   :138 dr.antialias(albedo[1,H,W,3], ...)
+ * (also Gen_3D_Modules users of the same ops, and MVs_Algorithms/FlexiCubes/flexicubes_renderer.py:46-66).
+ *
+ * Conventions (identical to the dependency's): clip-space positions [B,V,4]; triangles int32 [T,3]; images NHWC fp32;
+ * pixel (x,y) centre at NDC ((x+.5)2/W-1, (y+.5)2/H-1), row 0 at NDC y=-1; rast = (u, v, z/w, triangle_id+1) with 0 =
+ * background; rast_db = (du/dX, du/dY, dv/dX, dv/dY).  All pointers are DEVICE pointers to contiguous arrays; every call is
+ * asynchronous on `stream` and returns 0 or an error code (message via c3d_last_error()).
+ * Gradient outputs documented as "accumulated" are zeroed by the library before the kernel runs (callers pass
+ * uninitialised memory).  Gradients w.r.t. rast_db / out_da are not propagated (no consumer on the reference's path).
+ */
+#ifndef C3D_MESH_H
+#define C3D_MESH_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+#ifndef C3D_STREAM_T
+#define C3D_STREAM_T
+typedef void* c3d_stream_t; /* hipStream_t */
+#endif
+
+/* rasterize: scratch = per-pixel 64-bit depth|id buffer + large-triangle queue (the "context" the Python object owns) */
+size_t c3d_mesh_raster_scratch_bytes(int32_t B, int32_t H, int32_t W, int32_t T);
+int c3d_mesh_rasterize_fwd(const float* pos, const int32_t* tri, int32_t B, int32_t V, int32_t T, int32_t H, int32_t W,
+                           void* scratch, float* rast, float* rast_db, c3d_stream_t stream);
+/* dy = dL/drast [B,H,W,4] (only u,v channels are differentiable); dpos [B,V,4] accumulated */
+int c3d_mesh_rasterize_bwd(const float* pos, const int32_t* tri, const float* rast, const float* dy, int32_t B, int32_t V,
+                           int32_t T, int32_t H, int32_t W, float* dpos, c3d_stream_t stream);
+
+/* interpolate: attr [Ba,V,A], Ba in {1,B}; diff = nd attribute indices for which pixel differentials are produced
+ * (out_da [B,H,W,2*nd], pairs (d/dX, d/dY)); nd = 0 -> rast_db/diff/out_da may be NULL */
+int c3d_mesh_interpolate_fwd(const float* attr, int32_t Ba, const float* rast, const int32_t* tri, const float* rast_db,
+                             const int32_t* diff, int32_t nd, int32_t B, int32_t V, int32_t A, int32_t H, int32_t W,
+                             float* out, float* out_da, c3d_stream_t stream);
+/* dattr [Ba,V,A] accumulated; drast [B,H,W,4] written in full (channels 2,3 = 0) */
+int c3d_mesh_interpolate_bwd(const float* attr, int32_t Ba, const float* rast, const int32_t* tri, const float* dy,
+                             int32_t B, int32_t V, int32_t A, int32_t H, int32_t W, float* dattr, float* drast,
+                             c3d_stream_t stream);
+
+/* texture: tex [Bt,Ht,Wt,C], Bt in {1,B}; uv [B,H,W,2]; filter 0 = nearest, 1 = linear; boundary 0 = wrap, 1 = clamp */
+int c3d_mesh_texture_fwd(const float* tex, int32_t Bt, const float* uv, int32_t B, int32_t H, int32_t W, int32_t Ht,
+                         int32_t Wt, int32_t C, int32_t filter, int32_t boundary, float* out, c3d_stream_t stream);
+/* dtex accumulated; duv [B,H,W,2] written in full */
+int c3d_mesh_texture_bwd(const float* tex, int32_t Bt, const float* uv, const float* dy, int32_t B, int32_t H, int32_t W,
+                         int32_t Ht, int32_t Wt, int32_t C, int32_t filter, int32_t boundary, float* dtex, float* duv,
+                         c3d_stream_t stream);
+
+/* antialias: scratch = edge hash of the topology (built by the forward call, reused by the backward call) */
+size_t c3d_mesh_antialias_scratch_bytes(int32_t T);
+int c3d_mesh_antialias_fwd(const float* color, const float* rast, const float* pos, const int32_t* tri, int32_t B, int32_t V,
+                           int32_t T, int32_t H, int32_t W, int32_t C, void* scratch, float* out, c3d_stream_t stream);
+/* dcolor [B,H,W,C] written in full; dpos [B,V,4] accumulated */
+int c3d_mesh_antialias_bwd(const float* color, const float* rast, const float* pos, const int32_t* tri, const float* dy,
+                           int32_t B, int32_t V, int32_t T, int32_t H, int32_t W, int32_t C, const void* scratch,
+                           float* dcolor, float* dpos, c3d_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* C3D_MESH_H */
