@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--sh-degree", type=int, default=3)
     ap.add_argument("--cpu-baseline", choices=["auto", "on", "off"], default="auto")
     ap.add_argument("--exchange", choices=["allgather", "allreduce"], default="allgather")
+    ap.add_argument("--workload", choices=["gs", "mesh"], default="gs", help="gs = BASELINE configs 2-4 (the metric); mesh = config 5 (DiffRastMesh)")
     return ap.parse_args()
 
 
@@ -62,6 +63,84 @@ def algorithmic_bytes(N, K, P, n_vis, D):
         "gs_preprocess_bwd": 48 * n_vis + 2 * N * (44 + 12 * K),
         "adam": 28 * N * (11 + 3 * K),                    # p,g,m,v read + p,m,v write
     }
+
+
+def main_mesh(a, world, rank, dev, dist):
+    """BASELINE config 5: 499,000-triangle displaced lat-long sphere, 1024^2 albedo, 1024x1024, 32 cameras (elev {-20,20} x 16
+    azimuths, radius 2.0); one step = `--views-per-gpu` views of DiffRastRenderer.render forward + backward w.r.t. raw_albedo
+    and v_offsets (rasterize + 2x antialias + 3x interpolate + texture + the torch elementwise ops around them)."""
+    import c3d_hip
+    from c3d_hip import synthetic as S
+    from mesh_processer.mesh import Mesh
+    from MVs_Algorithms.DiffRastMesh.diff_mesh_renderer import DiffRastRenderer
+    from shared_utils.camera_utils import OrbitCamera, orbit_camera
+    H = W = 1024
+    v, f, vt, vn = S.make_uv_sphere(500, 500, radius=0.7, displacement=0.05)
+    t = lambda x, dt=torch.float32: torch.tensor(x, dtype=dt, device=dev)
+    mesh = Mesh(v=t(v), f=t(f, torch.int32), vt=t(vt), ft=t(f, torch.int32), device=dev)
+    mesh.auto_normal()
+    g = torch.Generator(device="cpu").manual_seed(7)
+    mesh.albedo = torch.sigmoid(torch.randn((1024, 1024, 3), generator=g)).to(dev)
+    r = DiffRastRenderer(mesh, True).to(dev)
+    r.train_geo = True
+    cam = OrbitCamera(W, H, fovy=49.1)
+    poses = [orbit_camera(e, az, 2.0) for e in (-20.0, 20.0) for az in np.arange(16) * 22.5]
+    mine = [poses[(rank * a.views_per_gpu + i) % len(poses)] for i in range(a.views_per_gpu)]
+    targets = []
+    with torch.no_grad():
+        for p in mine:
+            targets.append(r.render(p, cam.perspective, H, W)["image"].clone() * 0.9)
+
+    def step():
+        for p, tg in zip(mine, targets):
+            out = r.render(p, cam.perspective, H, W)
+            loss = ((out["image"] - tg) ** 2).mean() + 0.1 * ((out["alpha"] - 0.5) ** 2).mean()
+            (loss / (a.views_per_gpu * world)).backward()
+        if world > 1:
+            for q in (r.raw_albedo, r.v_offsets):
+                dist.all_reduce(q.grad)
+        r.raw_albedo.grad = None; r.v_offsets.grad = None
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier(); torch.cuda.synchronize(dev)
+    for _ in range(a.warmup):
+        step()
+    sync()
+    c3d_hip.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    prof = c3d_hip.prof_read()
+    c3d_hip.prof_enable(False)
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt = float(tt.item())
+    P, V, T = H * W, v.shape[0], f.shape[0]
+    # SURVEY 8(d) mesh formula, per view and per kernel group (launch counts differ: see 'launches')
+    alg = {"mesh_rasterize": 16 * V + 12 * T + 32 * P, "mesh_interpolate": (32 + 24) * P, "mesh_texture": (8 + 12) * P,
+           "mesh_antialias": (16 + 4 * 2 + 4 * 2) * P,
+           "mesh_rasterize_bwd": 32 * P + 16 * V, "mesh_interpolate_bwd": (16 + 24 + 16) * P + 24 * V, "mesh_texture_bwd": (8 + 12 + 8) * P + 12 * 1024 * 1024,
+           "mesh_antialias_bwd": (16 + 16 + 16) * P + 16 * V}
+    kern = {k: {"avg_ms": round(ms / n, 4), "launches": n, "ms_per_view": round(ms / (a.steps * a.views_per_gpu), 4)} for k, (ms, n) in prof.items()}
+    dom = max(prof, key=lambda k: prof[k][0]) if prof else None
+    roof = None
+    if dom:
+        per_view_ms = prof[dom][0] / (a.steps * a.views_per_gpu)
+        ach = alg.get(dom, 0) / (per_view_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
+                "traffic": None, "avg_ms": round(per_view_ms, 4), "alg_bytes_per_launch": int(alg.get(dom, 0)), "note": "per view (a view issues several launches of this group)"}
+    if rank == 0:
+        print(json.dumps({"metric": "Mpixels/s DiffRastMesh forward+backward @500k triangles 1024x1024", "value": round(a.views_per_gpu * world * a.steps * P / dt / 1e6, 2),
+                          "unit": "Mpixels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "DiffRastMesh fwd+bwd, %d-triangle displaced sphere, 1024^2 albedo, 1024x1024, %d views/GPU/step" % (T, a.views_per_gpu),
+                                     "parallelism": "view-parallel dp%d" % world},
+                          "roofline": roof, "cpu_baseline": None, "kernels": kern}))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
@@ -81,6 +160,8 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
+    if a.workload == "mesh":
+        return main_mesh(a, world, rank, dev, dist)
     import c3d_hip
     from c3d_hip import synthetic as S
     import diff_gaussian_rasterization as dgr

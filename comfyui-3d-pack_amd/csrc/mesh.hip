@@ -307,7 +307,7 @@ __device__ __forceinline__ uint32_t edge_hash(unsigned long long k, uint32_t mas
     return (uint32_t)k & mask;
 }
 static inline uint32_t edge_table_size(int T) {
-    uint32_t need = (uint32_t)(T > 0 ? T : 1) * 3u * 2u, n = 1024;
+    uint32_t need = (uint32_t)(T > 0 ? T : 1) * 3u, n = 1024;   // <= 1.5 T distinct edges on a manifold mesh: load factor <= 0.5
     while (n < need) n <<= 1;
     return n;
 }
@@ -517,7 +517,7 @@ int c3d_mesh_rasterize_bwd(const float* pos, const int32_t* tri, const float* ra
     hipStream_t s = (hipStream_t)stream;
     if ((long long)B * V == 0) return 0;
     MESH_REQUIRE(dpos, "NULL dpos");
-    C3dProfScope ps(C3D_P_MESH_BWD, s);
+    C3dProfScope ps(C3D_P_MESH_RASTERIZE_BWD, s);
     C3D_CHECK(hipMemsetAsync(dpos, 0, sizeof(float) * 4 * (size_t)B * V, s));
     const long long BP = (long long)B * H * W;
     if (BP == 0) return 0;
@@ -545,7 +545,7 @@ int c3d_mesh_interpolate_bwd(const float* attr, int32_t Ba, const float* rast, c
     hipStream_t s = (hipStream_t)stream;
     const long long P = (long long)H * W, BP = P * B;
     MESH_REQUIRE(Ba == 1 || Ba == B, "attribute batch must be 1 or B");
-    C3dProfScope ps(C3D_P_MESH_BWD, s);
+    C3dProfScope ps(C3D_P_MESH_INTERPOLATE_BWD, s);
     if ((long long)Ba * V * A > 0) { MESH_REQUIRE(dattr, "NULL dattr"); C3D_CHECK(hipMemsetAsync(dattr, 0, sizeof(float) * (size_t)Ba * V * A, s)); }
     if (BP == 0) return 0;
     MESH_REQUIRE(attr && rast && tri && dy && drast, "NULL pointer");
@@ -573,7 +573,7 @@ int c3d_mesh_texture_bwd(const float* tex, int32_t Bt, const float* uv, const fl
     const long long P = (long long)H * W, BP = P * B;
     MESH_REQUIRE(Bt == 1 || Bt == B, "texture batch must be 1 or B");
     MESH_REQUIRE((filter == 0 || filter == 1) && (boundary == 0 || boundary == 1), "unsupported filter/boundary mode");
-    C3dProfScope ps(C3D_P_MESH_BWD, s);
+    C3dProfScope ps(C3D_P_MESH_TEXTURE_BWD, s);
     if ((long long)Bt * Ht * Wt * C > 0) { MESH_REQUIRE(dtex, "NULL dtex"); C3D_CHECK(hipMemsetAsync(dtex, 0, sizeof(float) * (size_t)Bt * Ht * Wt * C, s)); }
     if (BP == 0 || C == 0) return 0;
     MESH_REQUIRE(tex && uv && dy && duv, "NULL pointer");
@@ -584,21 +584,34 @@ int c3d_mesh_texture_bwd(const float* tex, int32_t Bt, const float* uv, const fl
 
 size_t c3d_mesh_antialias_scratch_bytes(int32_t T) { return c3d_align(sizeof(EdgeSlot) * (size_t)edge_table_size(T)); }
 
+int c3d_mesh_antialias_build_topology(const int32_t* tri, int32_t T, void* scratch, c3d_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    MESH_REQUIRE(scratch, "NULL scratch");
+    C3dProfScope ps(C3D_P_MESH_ANTIALIAS, s);
+    const uint32_t n = edge_table_size(T);
+    EdgeSlot* table = (EdgeSlot*)scratch;
+    hipLaunchKernelGGL(k_aa_hash_init, dim3(c3d_cdiv((long long)n, 256)), dim3(256), 0, s, table, n);
+    if (T > 0) {
+        MESH_REQUIRE(tri, "NULL tri");
+        hipLaunchKernelGGL(k_aa_hash_build, dim3(c3d_cdiv(3ll * T, 256)), dim3(256), 0, s, (const int3*)tri, T, table, n - 1);
+    }
+    C3D_LAUNCH_CHECK();
+    return 0;
+}
+
 int c3d_mesh_antialias_fwd(const float* color, const float* rast, const float* pos, const int32_t* tri, int32_t B, int32_t V, int32_t T, int32_t H, int32_t W,
-                           int32_t C, void* scratch, float* out, c3d_stream_t stream) {
+                           int32_t C, const void* scratch, float* out, c3d_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     const long long P = (long long)H * W, BP = P * B;
     if (BP == 0 || C == 0) return 0;
     MESH_REQUIRE(color && rast && out && scratch, "NULL pointer");
     C3dProfScope ps(C3D_P_MESH_ANTIALIAS, s);
     C3D_CHECK(hipMemcpyAsync(out, color, sizeof(float) * (size_t)BP * C, hipMemcpyDeviceToDevice, s));
-    const uint32_t n = edge_table_size(T);
-    EdgeSlot* table = (EdgeSlot*)scratch;
-    hipLaunchKernelGGL(k_aa_hash_init, dim3(c3d_cdiv((long long)n, 256)), dim3(256), 0, s, table, n);
     if (T > 0) {
         MESH_REQUIRE(pos && tri, "NULL geometry");
-        hipLaunchKernelGGL(k_aa_hash_build, dim3(c3d_cdiv(3ll * T, 256)), dim3(256), 0, s, (const int3*)tri, T, table, n - 1);
-        hipLaunchKernelGGL(k_aa_fwd, dim3(c3d_cdiv(BP * 2, 256)), dim3(256), 0, s, color, (const float4*)rast, (const float4*)pos, (const int3*)tri, table, n - 1, B, V, H, W, C, out);
+        const uint32_t n = edge_table_size(T);
+        hipLaunchKernelGGL(k_aa_fwd, dim3(c3d_cdiv(BP * 2, 256)), dim3(256), 0, s, color, (const float4*)rast, (const float4*)pos, (const int3*)tri,
+                           (const EdgeSlot*)scratch, n - 1, B, V, H, W, C, out);
     }
     C3D_LAUNCH_CHECK();
     return 0;
@@ -607,7 +620,7 @@ int c3d_mesh_antialias_bwd(const float* color, const float* rast, const float* p
                            int32_t H, int32_t W, int32_t C, const void* scratch, float* dcolor, float* dpos, c3d_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     const long long P = (long long)H * W, BP = P * B;
-    C3dProfScope ps(C3D_P_MESH_BWD, s);
+    C3dProfScope ps(C3D_P_MESH_ANTIALIAS_BWD, s);
     if ((long long)B * V > 0) { MESH_REQUIRE(dpos, "NULL dpos"); C3D_CHECK(hipMemsetAsync(dpos, 0, sizeof(float) * 4 * (size_t)B * V, s)); }
     if (BP == 0 || C == 0) return 0;
     MESH_REQUIRE(color && rast && dy && dcolor && scratch, "NULL pointer");

@@ -182,6 +182,28 @@ def texture(tex, uv, uv_da=None, mip_level_bias=None, mip=None, filter_mode='aut
     return _Texture.apply(tex, uv, _FILTER[filter_mode], _BOUNDARY[boundary_mode])
 
 
+# topology (edge hash) cache: the reference rebuilds it on every antialias call because it never passes topology_hash; the table only
+# depends on `tri`, so it is kept per (storage, version, shape) of the triangle tensor and rebuilt when that changes.
+_TOPO_CACHE = {}
+
+
+def _topology(tri_c):
+    lib = _h.lib()
+    key = (tri_c.data_ptr(), tri_c._version, tuple(tri_c.shape), tri_c.device)
+    hit = _TOPO_CACHE.get(key)
+    if hit is not None:
+        return hit[0]
+    T = tri_c.shape[0]
+    table = torch.empty((lib.c3d_mesh_antialias_scratch_bytes(T),), dtype=torch.uint8, device=tri_c.device)
+    with torch.cuda.device(tri_c.device):
+        _h.check(lib.c3d_mesh_antialias_build_topology(_h.ptr(tri_c if T else None), T, _h.ptr(table), _h.stream(tri_c.device)),
+                 "c3d_mesh_antialias_build_topology")
+    if len(_TOPO_CACHE) >= 8:
+        _TOPO_CACHE.pop(next(iter(_TOPO_CACHE)))
+    _TOPO_CACHE[key] = (table, tri_c)     # keeps tri_c alive so the pointer in the key cannot be recycled
+    return table
+
+
 class _Antialias(torch.autograd.Function):
     @staticmethod
     def forward(ctx, color, rast, pos, tri, pos_gradient_boost):
@@ -192,7 +214,7 @@ class _Antialias(torch.autograd.Function):
         V, T = pos_c.shape[1], tri_c.shape[0]
         dev = color_c.device
         with torch.cuda.device(dev):
-            table = torch.empty((lib.c3d_mesh_antialias_scratch_bytes(T),), dtype=torch.uint8, device=dev)
+            table = _topology(tri_c)
             out = torch.empty_like(color_c)
             _h.check(lib.c3d_mesh_antialias_fwd(_h.ptr(color_c), _h.ptr(rast_c), _h.ptr(pos_c), _h.ptr(tri_c if T else None), B, V, T, H, W, C,
                                                 _h.ptr(table), _h.ptr(out), _h.stream(dev)), "c3d_mesh_antialias_fwd")
@@ -225,7 +247,8 @@ def antialias(color, rast, pos, tri, topology_hash=None, pos_gradient_boost=1.0)
 
 
 def antialias_construct_topology_hash(tri):
-    return None
+    """builds (and caches) the edge hash of `tri`; the returned handle may be passed as topology_hash (it is looked up again anyway)"""
+    return _topology(tri.to(torch.int32).contiguous())
 
 
 def texture_construct_mip(tex, max_mip_level=None, cube_mode=False):

@@ -55,10 +55,12 @@ int c3d_mesh_texture_bwd(const float* tex, int32_t Bt, const float* uv, const fl
                          int32_t Ht, int32_t Wt, int32_t C, int32_t filter, int32_t boundary, float* dtex, float* duv,
                          c3d_stream_t stream);
 
-/* antialias: scratch = edge hash of the topology (built by the forward call, reused by the backward call) */
+/* antialias: scratch = edge hash of the topology.  c3d_mesh_antialias_build_topology fills it from `tri` (the dependency's
+ * antialias_construct_topology_hash); it stays valid for as long as `tri` is unchanged and is shared by forward and backward. */
 size_t c3d_mesh_antialias_scratch_bytes(int32_t T);
+int c3d_mesh_antialias_build_topology(const int32_t* tri, int32_t T, void* scratch, c3d_stream_t stream);
 int c3d_mesh_antialias_fwd(const float* color, const float* rast, const float* pos, const int32_t* tri, int32_t B, int32_t V,
-                           int32_t T, int32_t H, int32_t W, int32_t C, void* scratch, float* out, c3d_stream_t stream);
+                           int32_t T, int32_t H, int32_t W, int32_t C, const void* scratch, float* out, c3d_stream_t stream);
 /* dcolor [B,H,W,C] written in full; dpos [B,V,4] accumulated */
 int c3d_mesh_antialias_bwd(const float* color, const float* rast, const float* pos, const int32_t* tri, const float* dy,
                            int32_t B, int32_t V, int32_t T, int32_t H, int32_t W, int32_t C, const void* scratch,
