@@ -14,6 +14,8 @@ import numpy as np
 import torch
 from torch import nn
 
+from c3d_hip.ply import PlyData
+from mesh_processer.mesh_utils import construct_list_of_gs_attributes, read_gs_ply, write_gs_ply
 from shared_utils.sh_utils import RGB2SH, SH2RGB
 
 
@@ -113,6 +115,21 @@ class GaussianModel:
         self._set(xyz, features[:, :1], features[:, 1:], scaling_raw, rotation_raw, opacity_raw)
         self.active_sh_degree = self.max_sh_degree
 
+    # ---- PLY wire format (reference to_ply :475-484, create_from_ply :486-498) ----
+    def to_ply(self):
+        n = lambda t: t.detach().cpu().numpy()
+        xyz = n(self._xyz)
+        f_dc = n(self._features_dc.detach().transpose(1, 2).flatten(start_dim=1).contiguous())      # channel-major
+        f_rest = n(self._features_rest.detach().transpose(1, 2).flatten(start_dim=1).contiguous())
+        return write_gs_ply(xyz, np.zeros_like(xyz), f_dc, f_rest, n(self._opacity), n(self._scaling), n(self._rotation),
+                            construct_list_of_gs_attributes(self._features_dc, self._features_rest, self._scaling, self._rotation))
+
+    def create_from_ply(self, plydata):
+        xyz, f_dc, f_extra, opac, scales, rots = read_gs_ply(plydata)
+        t = lambda a: torch.tensor(a, dtype=torch.float)
+        self._set(t(xyz), t(f_dc).transpose(1, 2).contiguous(), t(f_extra).transpose(1, 2).contiguous(), t(scales), t(rots), t(opac))
+        self.active_sh_degree = self.max_sh_degree
+
     # ---- optimisation (reference :435-461) ----
     def training_setup(self, training_args):
         self.percent_dense = training_args.percent_dense
@@ -162,10 +179,12 @@ class GaussianSplattingRenderer:
             # mean nearest-neighbour spacing of a uniform ball as the isotropic scale (distCUDA2 stand-in)
             spacing = radius * (4.0 / 3.0 * np.pi / max(num_pts, 1)) ** (1.0 / 3.0)
             self.gaussians.create_from_arrays(xyz, SH2RGB(shs), np.full((num_pts,), spacing), spatial_lr_scale=10)
+        elif isinstance(input, PlyData):
+            self.gaussians.create_from_ply(input)
         elif isinstance(input, dict):
             self.gaussians.create_from_tensors(**input)
         else:
-            raise TypeError("initialize(): pass None or a dict of raw tensors (mesh / PLY / point-cloud inputs are SURVEY 8f rows)")
+            raise TypeError("initialize(): pass None, a GS PlyData or a dict of raw tensors (mesh / point-cloud initialisers need simple_knn: out of scope)")
 
     def render(self, viewpoint_camera, scaling_modifier=1.0, gaussain_idx=None, bg_color=None, override_color=None,
                compute_cov3D_python=False, convert_SHs_python=False):

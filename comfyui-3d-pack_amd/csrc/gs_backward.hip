@@ -44,15 +44,6 @@ __device__ __forceinline__ float wave_reduce4(float a, float b, float c, float d
 // ------------------------------------------------------------------------------------------
 #define BWD_ROUND 128
 
-__device__ __forceinline__ uint32_t quadrant_mask_b(const float4 a0, const float4 a2, int X0, int Y0) {
-    const float xl = a0.x - a2.z, xh = a0.x + a2.z, yl = a0.y - a2.w, yh = a0.y + a2.w;
-    const bool cx0 = (xh >= (float)X0) && (xl <= (float)(X0 + 7));
-    const bool cx1 = (xh >= (float)(X0 + 8)) && (xl <= (float)(X0 + 15));
-    const bool cy0 = (yh >= (float)Y0) && (yl <= (float)(Y0 + 7));
-    const bool cy1 = (yh >= (float)(Y0 + 8)) && (yl <= (float)(Y0 + 15));
-    return (uint32_t)(cx0 && cy0) | ((uint32_t)(cx1 && cy0) << 1) | ((uint32_t)(cx0 && cy1) << 2) | ((uint32_t)(cx1 && cy1) << 3);
-}
-
 __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                                                         const uint4* __restrict__ einfo,
                                                         const float4* __restrict__ rec0, const float4* __restrict__ rec1,
@@ -115,10 +106,10 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
         if ((int)threadIdx.x < n) {
             const int pos = rg.x + (upto - 1 - base - threadIdx.x);
             const uint32_t gid = point_list[pos];
-            const float4 a0 = rec0[gid], a2 = rec2[gid];
+            const float4 a0 = rec0[gid], a1 = rec1[gid], a2 = rec2[gid];
             se[threadIdx.x] = emit_index(gid);
-            s0[threadIdx.x] = a0; s1[threadIdx.x] = rec1[gid]; s2[threadIdx.x] = a2;
-            smask[threadIdx.x] = quadrant_mask_b(a0, a2, X0, Y0);
+            s0[threadIdx.x] = a0; s1[threadIdx.x] = a1; s2[threadIdx.x] = a2;
+            smask[threadIdx.x] = gs_quadrant_mask(a0, a1, a2, X0, Y0);
         }
         __syncthreads();
         for (int c = 0; c < n; c += 64) {

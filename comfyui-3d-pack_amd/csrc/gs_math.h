@@ -145,6 +145,44 @@ __device__ __forceinline__ float alpha_extent(float opacity, float var) {
     return sqrtf(2.f * __logf(t) * var) * 1.0005f + 0.02f;
 }
 
+// ---- which of a tile's four 8x8 quadrants can a splat touch? ---------------------------------------------
+// Exact test: alpha >= 1/255  <=>  q(d) = A dx^2 + 2B dx dy + C dy^2 <= 2 ln(255 o); a quadrant is kept iff the minimum of the
+// (convex) form q over its pixel rectangle is below that bound.  The cheap alpha-box test rejects most quadrants first.
+// Conservative by construction (margin on the bound), so skipping a quadrant never changes a pixel.
+__device__ __forceinline__ float quad_form_min_on_rect(float A, float B, float C, float X, float Y, float xl, float xh, float yl, float yh) {
+    const float cxp = fminf(fmaxf(X, xl), xh), cyp = fminf(fmaxf(Y, yl), yh);
+    if (cxp == X && cyp == Y) return 0.f;                       // centre inside the rectangle
+    float best = 3.0e38f;
+    const float invC = 1.f / C, invA = 1.f / A;
+#pragma unroll
+    for (int e = 0; e < 2; e++) {                               // vertical edges x = xl, xh: minimise over y
+        const float dx = (e ? xh : xl) - X;
+        const float dy = fminf(fmaxf(-B * dx * invC, yl - Y), yh - Y);
+        best = fminf(best, A * dx * dx + 2.f * B * dx * dy + C * dy * dy);
+    }
+#pragma unroll
+    for (int e = 0; e < 2; e++) {                               // horizontal edges y = yl, yh: minimise over x
+        const float dy = (e ? yh : yl) - Y;
+        const float dx = fminf(fmaxf(-B * dy * invA, xl - X), xh - X);
+        best = fminf(best, A * dx * dx + 2.f * B * dx * dy + C * dy * dy);
+    }
+    return best;
+}
+__device__ __forceinline__ uint32_t gs_quadrant_mask(const float4 a0, const float4 a1, const float4 a2, int X0, int Y0) {
+    // a0 = (px, py, A, B)  a1 = (C, opacity, ..)  a2 = (.., .., ex, ey)
+    const float xl = a0.x - a2.z, xh = a0.x + a2.z, yl = a0.y - a2.w, yh = a0.y + a2.w;
+    const float thr = 2.f * __logf(255.f * a1.y) * 1.0005f + 1e-3f;
+    uint32_t m = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const float rx0 = (float)(X0 + 8 * (q & 1)), ry0 = (float)(Y0 + 8 * (q >> 1));
+        if (xh >= rx0 && xl <= rx0 + 7.f && yh >= ry0 && yl <= ry0 + 7.f) {
+            if (quad_form_min_on_rect(a0.z, a0.w, a1.x, a0.x, a0.y, rx0, rx0 + 7.f, ry0, ry0 + 7.f) <= thr) m |= 1u << q;
+        }
+    }
+    return m;
+}
+
 // ---- spherical harmonics without arrays (keeps the per-Gaussian kernels out of scratch) -------------------
 // SH_FOREACH(deg, x, y, z, TERM) invokes TERM(k, B_k, dB_k/dx, dB_k/dy, dB_k/dz) for every active coefficient.
 #define SH_FOREACH(deg, x, y, z, TERM)                                                                                    \

@@ -119,3 +119,73 @@ def test_gradient_exchange_world2_gloo(mode):
     assert torch.allclose(f0, ref, atol=1e-6)
     if mode == "allgather":
         assert torch.equal(f0, ref)                            # fixed rank-order summation
+
+
+def test_gs_ply_wire_format_roundtrip(tmp_path):
+    """3DGS PLY schema: property order/names, float32, channel-major SH; file round trip; model round trip."""
+    from c3d_hip.ply import PlyData
+    from mesh_processer.mesh_utils import calculate_max_sh_degree_from_gs_ply, read_gs_ply, switch_ply_axis_and_scale
+    from MVs_Algorithms.GaussianSplatting.main_3DGS_renderer import GaussianModel
+    torch.manual_seed(0)
+    N, deg = 37, 2
+    K = (deg + 1) ** 2
+    g = GaussianModel(deg, device="cpu")
+    g.create_from_tensors(torch.randn(N, 3), torch.randn(N, K, 3), torch.randn(N, 3), torch.randn(N, 4), torch.randn(N, 1))
+    ply = g.to_ply()
+    names = [p.name for p in ply.elements[0].properties]
+    assert names[:9] == ['x', 'y', 'z', 'nx', 'ny', 'nz', 'f_dc_0', 'f_dc_1', 'f_dc_2']
+    assert names[9:9 + 3 * (K - 1)] == ['f_rest_%d' % i for i in range(3 * (K - 1))]
+    assert names[-8:] == ['opacity', 'scale_0', 'scale_1', 'scale_2', 'rot_0', 'rot_1', 'rot_2', 'rot_3']
+    assert all(p.dtype == 'f4' for p in ply.elements[0].properties)
+    assert calculate_max_sh_degree_from_gs_ply(ply)[0] == deg
+    # channel-major: f_rest_j for j < K-1 is channel 0
+    np.testing.assert_allclose(np.asarray(ply.elements[0]['f_rest_1']), g._features_rest[:, 1, 0].detach().numpy())
+    np.testing.assert_allclose(np.asarray(ply.elements[0]['f_rest_%d' % (K - 1)]), g._features_rest[:, 0, 1].detach().numpy())
+    path = tmp_path / "cloud.ply"
+    ply.write(str(path))
+    head = open(path, "rb").read(200)
+    assert head.startswith(b"ply\nformat binary_little_endian 1.0\nelement vertex 37\nproperty float x\n")
+    back = PlyData.read(str(path))
+    g2 = GaussianModel(deg, device="cpu")
+    g2.create_from_ply(back)
+    for a, b in ((g._xyz, g2._xyz), (g._features_dc, g2._features_dc), (g._features_rest, g2._features_rest), (g._opacity, g2._opacity),
+                 (g._scaling, g2._scaling), (g._rotation, g2._rotation)):
+        assert torch.equal(a.detach(), b.detach())
+    # ascii variant reads back too
+    ply.text = True
+    ply.write(str(tmp_path / "a.ply"))
+    xyz2 = read_gs_ply(PlyData.read(str(tmp_path / "a.ply")))[0]
+    np.testing.assert_allclose(xyz2, g._xyz.detach().numpy(), rtol=1e-6)
+    # axis switch: identity is a no-op, a cyclic permutation applied three times returns to the start
+    same = switch_ply_axis_and_scale(ply, [0, 1, 2], [1, 1, 1], 0)
+    np.testing.assert_allclose(read_gs_ply(same)[0], read_gs_ply(ply)[0], atol=1e-6)
+    q0 = read_gs_ply(ply)[5]; q0 = q0 / np.linalg.norm(q0, axis=1, keepdims=True)
+    q1 = read_gs_ply(same)[5]
+    np.testing.assert_allclose(np.abs((q0 * q1).sum(1)), 1.0, atol=1e-5)        # same rotation up to sign
+    p3 = ply
+    for _ in range(3):
+        p3 = switch_ply_axis_and_scale(p3, [1, 2, 0], [1, 1, 1], 0)
+    np.testing.assert_allclose(read_gs_ply(p3)[0], read_gs_ply(ply)[0], atol=1e-5)
+    np.testing.assert_allclose(read_gs_ply(p3)[4], read_gs_ply(ply)[4], atol=1e-5)
+
+
+def test_node_layer_contract_and_pose_stacking():
+    """hot-path node classes keep the reference's names, input keys and the example workflow's 45-pose stack"""
+    import nodes as N
+    assert set(N.NODE_CLASS_MAPPINGS) >= {"[Comfy3D] Gaussian Splatting Orbit Renderer", "[Comfy3D] Gaussian Splatting 3D",
+                                           "[Comfy3D] Mesh Orbit Renderer", "[Comfy3D] Fitting Mesh With Multiview Images",
+                                           "[Comfy3D] Load 3DGS", "[Comfy3D] Save 3DGS", "[Comfy3D] Switch 3DGS Axis", "[Comfy3D] Stack Orbit Camera Poses"}
+    req = N.Gaussian_Splatting_3D.INPUT_TYPES()["required"]
+    assert list(req)[:6] == ["reference_images", "reference_masks", "reference_orbit_camera_poses", "reference_orbit_camera_fovy", "training_iterations", "batch_size"]
+    assert req["training_iterations"][1]["default"] == 30000 and req["gaussian_sh_degree"][1]["default"] == 3 and len(req) == 28
+    assert N.Gaussian_Splatting_Orbit_Renderer.RETURN_NAMES == ("rendered_gs_images", "rendered_gs_masks", "rendered_gs_depths")
+    assert N.Mesh_Orbit_Renderer.FUNCTION == "render_mesh" and N.Fitting_Mesh_With_Multiview_Images.INPUT_TYPES()["required"]["batch_size"][1]["default"] == 3
+    # example workflow (Render_Mesh_and_3DGS_Example.json): radius 1.75, elevation -45..45 step 45, azimuth 0 -> -0.01 step 24 (wraps): 3 x 15
+    poses, r, e, a, cx, cy, cz = N.Stack_Orbit_Camera_Poses().get_camposes(1.75, 1.75, 0.1, -45.0, 45.0, 45.0, 0.0, -0.01, 24.0, 0, 0, 0.1, 0, 0, 0.1, 0, 0, 0.1)
+    assert len(poses) == 45 and sorted(set(e)) == [-45.0, 0.0, 45.0] and len(set(round(x, 6) for x in a)) == 15
+    assert all(len(p) == 6 and p[0] == 1.75 for p in poses) and min(a) >= -180.0 and max(a) <= 180.0
+    az = [p[2] for p in poses if p[1] == -45.0]
+    assert az[:8] == [0.0, 24.0, 48.0, 72.0, 96.0, 120.0, 144.0, 168.0] and abs(az[8] - (-168.0)) < 1e-6 and abs(az[-1] - (-24.0)) < 1e-6
+    # simple linear case
+    poses2, *_ = N.Stack_Orbit_Camera_Poses().get_camposes(1.0, 2.0, 0.5, 0, 0, 0, 0, 90, 45, 0, 0, 0.1, 0, 0, 0.1, 0, 0, 0.1)
+    assert [p[2] for p in poses2[:3]] == [0, 45, 90] and [p[0] for p in poses2[::3]] == [1.0, 1.5, 2.0] and len(poses2) == 9   # radius slowest
