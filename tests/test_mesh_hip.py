@@ -242,3 +242,34 @@ def test_diffrast_renderer_mirror_and_trainer():
     losses = [tr.training_step(s, [s % 4, (s + 2) % 4]).item() for s in range(40)]
     assert np.isfinite(losses).all() and np.mean(losses[-5:]) < 0.7 * np.mean(losses[:5]), losses
     assert torch.isfinite(tr.renderer.v_offsets).all() and tr.renderer.v_offsets.abs().max().item() > 0
+
+
+def test_config1_example_workflow_through_the_nodes(tmp_path):
+    """BASELINE config 1 (Render_Mesh_and_3DGS_Example): Load 3DGS -> GS Orbit Renderer and Mesh Orbit Renderer, 256x256, the
+    MVDream(4) orbit, driven through the node classes; checked against the oracles."""
+    import nodes as N
+    from oracle import gs_oracle as O
+    from mesh_processer.mesh_utils import construct_list_of_gs_attributes, write_gs_ply
+    sc = S.make_ball_cloud(N=10000, seed=0)
+    raw_scale = np.log(sc["scales"]); raw_op = np.log(sc["opacities"] / (1 - sc["opacities"]))
+    f_dc = sc["shs"][:, :1].transpose(0, 2, 1).reshape(10000, -1); f_rest = sc["shs"][:, 1:].transpose(0, 2, 1).reshape(10000, -1)
+    ply = write_gs_ply(sc["means3D"], np.zeros_like(sc["means3D"]), f_dc, f_rest, raw_op, raw_scale, sc["rotations"],
+                       construct_list_of_gs_attributes(np.zeros((1, 1, 3)), np.zeros((1, 15, 3)), raw_scale, sc["rotations"]))
+    path = str(tmp_path / "ball.ply")
+    assert N.Save_3DGS().save_gs(ply, path)[0] == path
+    (gs_ply,) = N.Load_3DGS().load_gs(path)
+    poses = [[1.75, 0.0, az, 0.0, 0.0, 0.0] for az in (0.0, 90.0, 180.0, -90.0)]
+    with torch.inference_mode():
+        imgs, masks, depths = N.Gaussian_Splatting_Orbit_Renderer().render_gs(gs_ply, 256, 256, poses, 49.1, 1.0, 1.0, 1.0)
+    assert imgs.shape == (4, 256, 256, 3) and masks.shape == (4, 256, 256) and depths.shape == (4, 256, 256, 3)
+    for i, az in enumerate((0.0, 90.0, 180.0, -90.0)):
+        st = S.camera_settings(256, 256, 49.1, 0.0, az, 1.75)
+        oc, orad, od, oa, _ = O.forward(sc["means3D"], sc["opacities"], st, shs=sc["shs"], scales=sc["scales"], rotations=sc["rotations"], nthreads=8)
+        assert np.abs(imgs[i].cpu().numpy() - np.clip(oc, 0, 1).transpose(1, 2, 0)).mean() <= IMG_L1
+        assert np.abs(masks[i].cpu().numpy() - oa[0]).mean() <= IMG_L1
+    # mesh half
+    mesh = _torch_mesh(24, 48, tex=32)
+    with torch.inference_mode():
+        mi, mm, md, mn, mv = N.Mesh_Orbit_Renderer().render_mesh(mesh, 256, 256, poses, 49.1, 0.0, 0.0, 0.0, True, render_depth=True, render_normal=True)
+    assert mi.shape == (4, 256, 256, 3) and mm.shape == (4, 256, 256) and md.shape == (4, 256, 256, 3) and mn.shape == (4, 256, 256, 3)
+    assert 0.05 < mm.mean().item() < 0.9 and torch.isfinite(mi).all() and (mi[mm == 0] == 0).all()
