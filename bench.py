@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--sh-degree", type=int, default=3)
     ap.add_argument("--cpu-baseline", choices=["auto", "on", "off"], default="auto")
     ap.add_argument("--exchange", choices=["allgather", "allreduce"], default="allgather")
+    ap.add_argument("--render-path", choices=["fused", "accessor", "boundary"], default="fused",
+                    help="fused: GaussianSplattingRenderer.render with activations folded into the kernels (product default); accessor: the same "
+                         "API through the reference's op-by-op accessors; boundary: bare diff_gaussian_rasterization call on pre-activated leaves")
     ap.add_argument("--workload", choices=["gs", "mesh"], default="gs", help="gs = BASELINE configs 2-4 (the metric); mesh = config 5 (DiffRastMesh)")
     return ap.parse_args()
 
@@ -168,41 +171,68 @@ def main():
 
     N, W, H, deg = a.gaussians, a.width, a.height, a.sh_degree
     K, P = (deg + 1) ** 2, a.width * a.height
-    cloud = S.make_cloud(N, seed=1234, sh_degree=deg, activated=True)
-    params = {k: torch.tensor(v, device=dev, requires_grad=(a.mode != "fwd")) for k, v in cloud.items()}
+    use_renderer = a.render_path != "boundary"
+    cloud = S.make_cloud(N, seed=1234, sh_degree=deg, activated=True)          # what the rasterizer consumes (cpu_baseline leg, boundary path)
     poses = S.orbit_poses_64()
     my_poses = [poses[(rank * a.views_per_gpu + i) % len(poses)] for i in range(a.views_per_gpu)]
-    settings = []
+    t = lambda x: torch.as_tensor(np.asarray(x, dtype=np.float32)).to(dev)
+    settings, cams = [], []
     for (r, e, az) in my_poses:
         st = S.camera_settings(W, H, 49.1, e, az, r, bg=(1.0, 1.0, 1.0), sh_degree=deg)
-        t = lambda x: torch.as_tensor(np.asarray(x, dtype=np.float32)).to(dev)
         settings.append(dgr.GaussianRasterizationSettings(H, W, st["tanfovx"], st["tanfovy"], t(st["bg"]), 1.0,
                                                           t(st["viewmatrix"]).reshape(4, 4), t(st["projmatrix"]).reshape(4, 4),
                                                           deg, t(st["campos"]), False, False))
+        cams.append(type("Cam", (), dict(image_height=H, image_width=W, FoVx=2 * np.arctan(st["tanfovx"]), FoVy=2 * np.arctan(st["tanfovy"]),
+                                         world_view_transform=settings[-1].viewmatrix, full_proj_transform=settings[-1].projmatrix,
+                                         camera_center=settings[-1].campos))())
+    white = torch.ones(3, device=dev)
+    if use_renderer:
+        # the reference's call stack: GaussianSplattingRenderer.render over GaussianModel's raw parameters
+        from MVs_Algorithms.GaussianSplatting.main_3DGS_renderer import GaussianSplattingRenderer
+        raw = S.make_cloud(N, seed=1234, sh_degree=deg, activated=False)
+        renderer = GaussianSplattingRenderer(sh_degree=deg, device=dev)
+        renderer.initialize({"xyz": raw["means3D"], "features": raw["shs"], "scaling_raw": raw["scales"], "rotation_raw": raw["rotations"],
+                             "opacity_raw": raw["opacities"]})
+        renderer.force_unfused = a.render_path == "accessor"
+        gm = renderer.gaussians
+        plist = [gm._xyz, gm._features_dc, gm._features_rest, gm._opacity, gm._scaling, gm._rotation]
+        if a.mode == "fwd":
+            for q in plist:
+                q.requires_grad_(False)
+        lr_list = [1.6e-4, 2.5e-3, 1.25e-4, 0.05, 5e-3, 1e-3]
+    else:
+        params = {k: torch.tensor(v, device=dev, requires_grad=(a.mode != "fwd")) for k, v in cloud.items()}
+        names = ["means3D", "shs", "opacities", "scales", "rotations"]
+        plist = [params[k] for k in names]
+        lr_list = [1.6e-4, 2.5e-3, 0.05, 5e-3, 1e-3]
+
+    def render(i):
+        if use_renderer:
+            out = renderer.render(cams[i], bg_color=white)
+            return out["image"], out["radii"], out["depth"], out["alpha"]
+        m2d = torch.zeros_like(params["means3D"], requires_grad=True) if a.mode != "fwd" else None
+        return dgr.GaussianRasterizer(settings[i])(means3D=params["means3D"], means2D=m2d, opacities=params["opacities"], shs=params["shs"],
+                                                   scales=params["scales"], rotations=params["rotations"])
+
     # training targets: renders of the xyz-jittered cloud, made once, untimed
     targets = []
     with torch.no_grad():
         g = torch.Generator(device="cpu").manual_seed(4321)
-        jit = (params["means3D"].detach() + 0.002 * torch.randn(N, 3, generator=g).to(dev))
-        for rs in settings:
-            c, _, _, al = dgr.GaussianRasterizer(rs)(means3D=jit, means2D=None, opacities=params["opacities"].detach(),
-                                                     shs=params["shs"].detach(), scales=params["scales"].detach(),
-                                                     rotations=params["rotations"].detach())
+        jit = 0.002 * torch.randn(N, 3, generator=g).to(dev)
+        plist[0].data.add_(jit)
+        for i in range(len(settings)):
+            c, _, _, al = render(i)
             targets.append((c.clone(), al.clone()))
+        plist[0].data.sub_(jit)
     opt = None
     if a.mode == "train":
-        lrs = {"means3D": 1.6e-4, "shs": 2.5e-3, "opacities": 0.05, "scales": 5e-3, "rotations": 1e-3}
         from c3d_hip.optim import FusedAdam
-        opt = FusedAdam([{"params": [params[k]], "lr": lr} for k, lr in lrs.items()], lr=0.0, eps=1e-15)
-    names = ["means3D", "shs", "opacities", "scales", "rotations"]
+        opt = FusedAdam([{"params": [q], "lr": lr} for q, lr in zip(plist, lr_list)], lr=0.0, eps=1e-15)
     stats = {"n_vis": [], "D": []}
 
     def step(collect=False):
-        for i, rs in enumerate(settings):
-            rast = dgr.GaussianRasterizer(rs)
-            m2d = torch.zeros_like(params["means3D"], requires_grad=(a.mode != "fwd")) if a.mode != "fwd" else None
-            color, radii, depth, alpha = rast(means3D=params["means3D"], means2D=m2d, opacities=params["opacities"],
-                                              shs=params["shs"], scales=params["scales"], rotations=params["rotations"])
+        for i in range(len(settings)):
+            color, radii, depth, alpha = render(i)
             if collect:
                 stats["n_vis"].append(int((radii > 0).sum().item()))
                 stats["D"].append(int(dgr.last_num_rendered))
@@ -211,7 +241,7 @@ def main():
                 loss = (color - tc).abs().mean() * 0.8 + 3.0 * ((alpha - ta) ** 2).mean()
                 (loss / (a.views_per_gpu * world)).backward()
         if a.mode != "fwd" and world > 1:
-            flat = torch.cat([params[k].grad.reshape(N, -1) for k in names], dim=1)   # [N, 59] dense gradient
+            flat = torch.cat([q.grad.reshape(N, -1) for q in plist], dim=1)   # [N, 59] dense gradient
             if a.exchange == "allgather":
                 buf = torch.empty((world * N, flat.shape[1]), device=dev)
                 dist.all_gather_into_tensor(buf, flat)
@@ -222,15 +252,15 @@ def main():
             else:
                 dist.all_reduce(flat)
             off = 0
-            for k in names:
-                w = params[k].grad[0].numel()
-                params[k].grad.copy_(flat[:, off:off + w].reshape(params[k].grad.shape))
+            for q in plist:
+                w = q.grad[0].numel()
+                q.grad.copy_(flat[:, off:off + w].reshape(q.grad.shape))
                 off += w
         if a.mode == "train":
             opt.step()
         if a.mode != "fwd":
-            for k in names:
-                params[k].grad = None
+            for q in plist:
+                q.grad = None
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -308,7 +338,7 @@ def main():
             "config": {"workload": "3DGS %s, %d synthetic Gaussians (seed 1234) SH deg %d, %dx%d, %d orbit views/GPU/step of the 64-camera orbit"
                                    % (a.mode, N, deg, W, H, a.views_per_gpu),
                        "global_views_per_step": a.views_per_gpu * world, "parallelism": "view-parallel dp%d" % world,
-                       "exchange": (a.exchange if world > 1 and a.mode != "fwd" else "none"),
+                       "exchange": (a.exchange if world > 1 and a.mode != "fwd" else "none"), "render_path": a.render_path,
                        "n_visible": n_vis, "tile_splat_pairs": D},
             "roofline": roof, "cpu_baseline": cpu, "kernels": kern,
         }

@@ -167,6 +167,7 @@ class GaussianSplattingRenderer:
         self.device = torch.device(device)
         self.gaussians = GaussianModel(sh_degree, device=device)
         self.bg_color = torch.tensor([1, 1, 1] if white_background else [0, 0, 0], dtype=torch.float32, device=self.device)
+        self.force_unfused = False   # True: take the reference's op-by-op accessor path (tests compare both)
 
     def initialize(self, input=None, num_pts=5000, radius=0.5):
         """input None -> the reference's random ball (:811-826): r = radius * cbrt(U), colours U/255, lr scale 10."""
@@ -199,18 +200,26 @@ class GaussianSplattingRenderer:
             bg=self.bg_color if bg_color is None else bg_color, scale_modifier=scaling_modifier,
             viewmatrix=viewpoint_camera.world_view_transform, projmatrix=viewpoint_camera.full_proj_transform,
             sh_degree=g.active_sh_degree, campos=viewpoint_camera.camera_center, prefiltered=False, debug=False)
-        xyz, feats, opac, scales, rots = g.get_xyz, g.get_features, g.get_opacity, g.get_scaling, g.get_rotation
-        if gaussain_idx is not None:
-            xyz, feats, opac, scales, rots = xyz[gaussain_idx], feats[gaussain_idx], opac[gaussain_idx], scales[gaussain_idx], rots[gaussain_idx]
+        fused = (gaussain_idx is None and override_color is None and g.max_sh_degree == 3 and g._xyz.is_cuda and not self.force_unfused)
+        xyz = g.get_xyz if gaussain_idx is None else g.get_xyz[gaussain_idx]
         # zero tensor whose gradient is the screen-space positional gradient (densification statistic)
         screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
         try:
             screenspace_points.retain_grad()
         except Exception:
             pass
-        shs, colors = (feats, None) if override_color is None else (None, override_color)
-        image, radii, depth, alpha = GaussianRasterizer(raster_settings=settings)(
-            means3D=xyz, means2D=screenspace_points, shs=shs, colors_precomp=colors, opacities=opac,
-            scales=scales, rotations=rots, cov3D_precomp=None)
+        if fused:
+            # same result as the accessor path below; exp / sigmoid / normalize / cat are folded into the projection kernels
+            from diff_gaussian_rasterization import rasterize_gaussians_raw
+            image, radii, depth, alpha = rasterize_gaussians_raw(xyz, screenspace_points, g._features_dc, g._features_rest, g._opacity,
+                                                                 g._scaling, g._rotation, settings)
+        else:
+            feats, opac, scales, rots = g.get_features, g.get_opacity, g.get_scaling, g.get_rotation
+            if gaussain_idx is not None:
+                feats, opac, scales, rots = feats[gaussain_idx], opac[gaussain_idx], scales[gaussain_idx], rots[gaussain_idx]
+            shs, colors = (feats, None) if override_color is None else (None, override_color)
+            image, radii, depth, alpha = GaussianRasterizer(raster_settings=settings)(
+                means3D=xyz, means2D=screenspace_points, shs=shs, colors_precomp=colors, opacities=opac,
+                scales=scales, rotations=rots, cov3D_precomp=None)
         return {"image": image.clamp(0, 1), "depth": depth, "alpha": alpha, "viewspace_points": screenspace_points,
                 "visibility_filter": radii > 0, "radii": radii}

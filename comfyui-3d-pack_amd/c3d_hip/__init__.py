@@ -36,6 +36,8 @@ _SIGNATURES = {
     "c3d_gs_forward_project": (C.c_int, [C.POINTER(GsSettings), i32, i32] + [vp] * 7 + [vp, vp, C.POINTER(i64), vp]),
     "c3d_gs_forward_render": (C.c_int, [C.POINTER(GsSettings), i32, i32, vp, vp, i64, vp, vp, vp, vp, vp, vp]),
     "c3d_gs_backward": (C.c_int, [C.POINTER(GsSettings), i32, i32] + [vp] * 6 + [vp, vp, i64, vp, vp] + [vp] * 3 + [vp] * 8 + [vp, vp]),
+    "c3d_gs_forward_project_raw": (C.c_int, [C.POINTER(GsSettings), i32] + [vp] * 6 + [vp, vp, C.POINTER(i64), vp]),
+    "c3d_gs_backward_raw": (C.c_int, [C.POINTER(GsSettings), i32] + [vp] * 5 + [vp, vp, i64, vp, vp] + [vp] * 3 + [vp] * 7 + [vp, i32, vp]),
     "c3d_gs_mark_visible": (C.c_int, [i32, vp, vp, vp, vp, vp]),
     "c3d_gs_debug_state": (C.c_int, [i32, i32, i32, vp, i64, vp] + [vp] * 7 + [vp]),
     "c3d_adam_step": (C.c_int, [vp, vp, vp, vp, i64, C.c_double, C.c_double, C.c_double, C.c_double, i64, vp]),

@@ -49,6 +49,22 @@ static int check_inputs(int N, int M, int deg, const float* means3D, const float
     return 0;
 }
 
+// depth ordering + offsets shared by both projection entry points; the single D2H read of the pair count lives here
+static int project_tail(GsGeom& g, int N, int64_t* num_rendered, hipStream_t s) {
+    int rc, res = 0;
+    { C3dProfScope ps(C3D_P_DEPTH_SORT, s);
+    if ((rc = c3d_sort_pairs_u32(g.key[0], g.key[1], g.order[0], g.order[1], true, (size_t)N, 32, g.tmp, &res, s))) return rc; }
+    if (res != sort_result_index(32)) { c3d_set_error("internal: depth sort buffer parity"); return -2; }
+    { C3dProfScope ps(C3D_P_SCAN, s);
+    if ((rc = gs_launch_gather_tiles(g, N, res, s))) return rc;
+    if ((rc = c3d_scan_u32(g.tiles_sorted, g.offsets, (size_t)N, false, g.tmp, s))) return rc; }
+    uint32_t d32 = 0;
+    C3D_CHECK(hipMemcpyAsync(&d32, g.offsets + (N - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    C3D_CHECK(hipStreamSynchronize(s));
+    *num_rendered = (int64_t)d32;
+    return 0;
+}
+
 extern "C" {
 
 const char* c3d_last_error(void) { return g_err; }
@@ -80,19 +96,26 @@ int c3d_gs_forward_project(const c3d_gs_settings* st, int32_t N, int32_t M, cons
     int rc;
     { C3dProfScope ps(C3D_P_PREPROCESS, s);
     if ((rc = gs_launch_preprocess(p, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, radii, s))) return rc; }
-    // order Gaussians by (view depth, id): stable sort of the depth bits with ids as payload
-    int res = 0;
-    { C3dProfScope ps(C3D_P_DEPTH_SORT, s);
-    if ((rc = c3d_sort_pairs_u32(g.key[0], g.key[1], g.order[0], g.order[1], true, (size_t)N, 32, g.tmp, &res, s))) return rc; }
-    if (res != sort_result_index(32)) { c3d_set_error("internal: depth sort buffer parity"); return -2; }
-    { C3dProfScope ps(C3D_P_SCAN, s);
-    if ((rc = gs_launch_gather_tiles(g, N, res, s))) return rc;
-    if ((rc = c3d_scan_u32(g.tiles_sorted, g.offsets, (size_t)N, false, g.tmp, s))) return rc; }
-    uint32_t d32 = 0;
-    C3D_CHECK(hipMemcpyAsync(&d32, g.offsets + (N - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    C3D_CHECK(hipStreamSynchronize(s));
-    *num_rendered = (int64_t)d32;
-    return 0;
+    return project_tail(g, N, num_rendered, s);
+}
+
+int c3d_gs_forward_project_raw(const c3d_gs_settings* st, int32_t N, const float* means3D, const float* f_dc, const float* f_rest,
+                               const float* opacity_raw, const float* scaling_raw, const float* rotation_raw, int32_t* radii,
+                               void* geom_buffer, int64_t* num_rendered, c3d_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    GsParams p;
+    if (make_params(st, N, 16, p)) return -1;
+    if (!num_rendered) { c3d_set_error("c3d_gs_forward_project_raw: num_rendered (host) is NULL"); return -1; }
+    *num_rendered = 0;
+    if (N == 0) return 0;
+    if (!means3D || !f_dc || !f_rest || !opacity_raw || !scaling_raw || !rotation_raw || !radii || !geom_buffer) { c3d_set_error("c3d_gs_forward_project_raw: NULL pointer"); return -1; }
+    if ((uintptr_t)f_rest % 16 || (uintptr_t)rotation_raw % 16) { c3d_set_error("c3d_gs_forward_project_raw: f_rest / rotation must be 16-byte aligned"); return -1; }
+    GsGeom g;
+    gs_carve_geom((char*)geom_buffer, N, g);
+    int rc;
+    { C3dProfScope ps(C3D_P_PREPROCESS, s);
+    if ((rc = gs_launch_preprocess_raw(p, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, g, radii, s))) return rc; }
+    return project_tail(g, N, num_rendered, s);
 }
 
 int c3d_gs_forward_render(const c3d_gs_settings* st, int32_t N, int32_t M, const int32_t* radii, void* geom_buffer,
@@ -161,6 +184,38 @@ int c3d_gs_backward(const c3d_gs_settings* st, int32_t N, int32_t M, const float
     C3dProfScope ps(C3D_P_PREPROCESS_BWD, s);
     return gs_launch_preprocess_bwd(p, g, radii, means3D, shs, colors_precomp, scales, rotations, cov3D_precomp, pairgrad, dL_dmeans2D,
                                     dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, s);
+}
+
+int c3d_gs_backward_raw(const c3d_gs_settings* st, int32_t N, const float* means3D, const float* f_dc, const float* f_rest,
+                        const float* scaling_raw, const float* rotation_raw, const int32_t* radii, const void* geom_buffer, int64_t num_rendered,
+                        const void* binning_buffer, const void* image_buffer, const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
+                        float* dL_dmeans2D, float* dL_dmeans3D, float* dL_df_dc, float* dL_df_rest, float* dL_dopacity_raw, float* dL_dscaling_raw,
+                        float* dL_drotation_raw, void* scratch, int32_t accumulate, c3d_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    GsParams p;
+    if (make_params(st, N, 16, p)) return -1;
+    if (N == 0) return 0;
+    if (!means3D || !f_dc || !f_rest || !scaling_raw || !rotation_raw || !radii || !geom_buffer || !dL_dcolor || !dL_dmeans2D || !dL_dmeans3D ||
+        !dL_df_dc || !dL_df_rest || !dL_dopacity_raw || !dL_dscaling_raw || !dL_drotation_raw || !scratch) { c3d_set_error("c3d_gs_backward_raw: NULL pointer"); return -1; }
+    if ((uintptr_t)f_rest % 16 || (uintptr_t)dL_df_rest % 16 || (uintptr_t)rotation_raw % 16 || (uintptr_t)dL_drotation_raw % 16) { c3d_set_error("c3d_gs_backward_raw: f_rest / rotation tensors must be 16-byte aligned"); return -1; }
+    const int tiles = p.gx * p.gy;
+    GsGeom g;
+    gs_carve_geom((char*)geom_buffer, N, g);
+    GsBinning b;
+    gs_carve_binning((char*)binning_buffer, num_rendered, tiles, b);
+    GsImage im;
+    gs_carve_image((char*)image_buffer, p.W, p.H, im);
+    float* pairgrad = (float*)scratch;
+    int rc;
+    if (num_rendered > 0 && tiles > 0) {
+        if (!binning_buffer || !image_buffer) { c3d_set_error("c3d_gs_backward_raw: NULL state buffer"); return -1; }
+        const int res = sort_result_index(tile_sort_bits(tiles));
+        C3dProfScope ps(C3D_P_COMPOSITE_BWD, s);
+        if ((rc = gs_launch_composite_bwd(p, g, b, res, im, dL_dcolor, dL_ddepth, dL_dalpha, pairgrad, s))) return rc;
+    }
+    C3dProfScope ps(C3D_P_PREPROCESS_BWD, s);
+    return gs_launch_preprocess_bwd_raw(p, g, radii, means3D, f_dc, f_rest, scaling_raw, rotation_raw, pairgrad, dL_dmeans2D, dL_dopacity_raw,
+                                        dL_dmeans3D, dL_df_dc, dL_df_rest, dL_dscaling_raw, dL_drotation_raw, accumulate != 0, s);
 }
 
 int c3d_gs_mark_visible(int32_t N, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present, c3d_stream_t stream) {

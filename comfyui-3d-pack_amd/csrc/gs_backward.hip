@@ -189,14 +189,17 @@ int gs_launch_composite_bwd(const GsParams& p, const GsGeom& g, const GsBinning&
 // ------------------------------------------------------------------------------------------
 // A8 preprocess backward: one lane per Gaussian, pure streaming.
 // ------------------------------------------------------------------------------------------
-template <bool STAGED>
+// RAW: inputs are the raw parameters (see k_preprocess) and the outputs are gradients w.r.t. them: the exp / sigmoid / normalize
+// backward passes of the GaussianModel accessors are applied here; dL/dSH goes to the split dL_dsh (= d f_dc) / dL_df_rest pair.
+// ACC: add into the existing contents of the parameter-gradient outputs (view loops) instead of overwriting.
+template <bool STAGED, bool RAW, bool ACC>
 __global__ void __launch_bounds__(256) k_preprocess_bwd(GsParams p, GsGeom g, const int* __restrict__ radii, const float* __restrict__ means3D,
-                                                         const float* __restrict__ shs, const float* __restrict__ colors_precomp,
+                                                         const float* __restrict__ shs, const float* __restrict__ f_rest, const float* __restrict__ colors_precomp,
                                                          const float* __restrict__ scales, const float* __restrict__ rotations,
                                                          const float* __restrict__ cov3D_precomp, const float4* __restrict__ pairgrad,
                                                          float* __restrict__ dL_dmean2D, float* __restrict__ dL_dcolors,
                                                          float* __restrict__ dL_dopacity, float* __restrict__ dL_dmeans3D,
-                                                         float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
+                                                         float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh, float* __restrict__ dL_df_rest,
                                                          float* __restrict__ dL_dscales, float* __restrict__ dL_drots) {
     extern __shared__ float sh_lds[];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -204,7 +207,8 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GsParams p, GsGeom g, co
     const int gcount = min((int)blockDim.x, p.N - (int)g0);
     float* shl = sh_lds + threadIdx.x * SH_ROW;
     if (STAGED) {
-        sh_stage_in(shs, g0, gcount, sh_lds);
+        if (RAW) sh_stage_in_split(shs, f_rest, g0, gcount, sh_lds);
+        else     sh_stage_in(shs, g0, gcount, sh_lds);
         __syncthreads();
     }
     const bool culled = idx < p.N && radii[idx] <= 0;
@@ -215,22 +219,24 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GsParams p, GsGeom g, co
         }
     }
     if (idx < p.N && culled) {
-        // culled: this kernel owns its outputs (callers allocate them uninitialised)
+        // culled: this kernel owns its outputs (callers allocate them uninitialised); with ACC the parameter gradients just stay as they are
         dL_dmean2D[3 * idx] = 0.f; dL_dmean2D[3 * idx + 1] = 0.f; dL_dmean2D[3 * idx + 2] = 0.f;
-        dL_dcolors[3 * idx] = 0.f; dL_dcolors[3 * idx + 1] = 0.f; dL_dcolors[3 * idx + 2] = 0.f;
-        dL_dopacity[idx] = 0.f;
-        dL_dmeans3D[3 * idx] = 0.f; dL_dmeans3D[3 * idx + 1] = 0.f; dL_dmeans3D[3 * idx + 2] = 0.f;
-        if (dL_dcov3D) {
+        if (dL_dcolors) { dL_dcolors[3 * idx] = 0.f; dL_dcolors[3 * idx + 1] = 0.f; dL_dcolors[3 * idx + 2] = 0.f; }
+        if (!ACC) {
+            dL_dopacity[idx] = 0.f;
+            dL_dmeans3D[3 * idx] = 0.f; dL_dmeans3D[3 * idx + 1] = 0.f; dL_dmeans3D[3 * idx + 2] = 0.f;
+            if (dL_dcov3D) {
 #pragma unroll
-            for (int i = 0; i < 6; i++) dL_dcov3D[6 * idx + i] = 0.f;
-        }
-        if (!colors_precomp && !STAGED) {
-            float* dsh = dL_dsh + (size_t)idx * p.M * 3;
-            for (int k = 0; k < 3 * p.M; k++) dsh[k] = 0.f;
-        }
-        if (!cov3D_precomp) {
-            dL_dscales[3 * idx] = 0.f; dL_dscales[3 * idx + 1] = 0.f; dL_dscales[3 * idx + 2] = 0.f;
-            *reinterpret_cast<float4*>(dL_drots + 4 * idx) = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int i = 0; i < 6; i++) dL_dcov3D[6 * idx + i] = 0.f;
+            }
+            if (!colors_precomp && !STAGED) {
+                float* dsh = dL_dsh + (size_t)idx * p.M * 3;
+                for (int k = 0; k < 3 * p.M; k++) dsh[k] = 0.f;
+            }
+            if (!cov3D_precomp) {
+                dL_dscales[3 * idx] = 0.f; dL_dscales[3 * idx + 1] = 0.f; dL_dscales[3 * idx + 2] = 0.f;
+                *reinterpret_cast<float4*>(dL_drots + 4 * idx) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
     }
     if (idx < p.N && !culled) {
@@ -257,20 +263,31 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GsParams p, GsGeom g, co
     const float g2x = -(cA * m1x + cB * m1y) * (0.5f * p.W), g2y = -(cC * m1y + cB * m1x) * (0.5f * p.H);
     const float dcx = -0.5f * m2xx, dcy = -0.5f * m2xy, dcz = -0.5f * m2yy;
     dL_dmean2D[3 * idx] = g2x; dL_dmean2D[3 * idx + 1] = g2y; dL_dmean2D[3 * idx + 2] = 0.f;
-    dL_dcolors[3 * idx] = gcol[0]; dL_dcolors[3 * idx + 1] = gcol[1]; dL_dcolors[3 * idx + 2] = gcol[2];
-    dL_dopacity[idx] = (opac > 0.f) ? m0 / opac : 0.f;
+    if (dL_dcolors) { dL_dcolors[3 * idx] = gcol[0]; dL_dcolors[3 * idx + 1] = gcol[1]; dL_dcolors[3 * idx + 2] = gcol[2]; }
+    {
+        float go = (opac > 0.f) ? m0 / opac : 0.f;
+        if (RAW) go *= opac * (1.f - opac);                      // sigmoid'
+        dL_dopacity[idx] = ACC ? dL_dopacity[idx] + go : go;
+    }
 
     const Mat16 V = load_mat16(p.view), PJ = load_mat16(p.proj);
     const float3 m = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
     float c3[6];
     float3 sc = make_float3(0, 0, 0);
     float4 q = make_float4(1, 0, 0, 0);
+    float qnorm = 1.f;
     if (cov3D_precomp) {
 #pragma unroll
         for (int i = 0; i < 6; i++) c3[i] = cov3D_precomp[6 * idx + i];
     } else {
         sc = make_float3(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]);
         q = *reinterpret_cast<const float4*>(rotations + 4 * idx);
+        if (RAW) {
+            sc = make_float3(expf(sc.x), expf(sc.y), expf(sc.z));
+            qnorm = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
+            const float inv = 1.f / qnorm;
+            q = make_float4(q.x * inv, q.y * inv, q.z * inv, q.w * inv);
+        }
         cov3d_from_scale_rot(sc, p.scale_modifier, q, c3);
     }
     float T2[2][3], ST0[3], ST1[3];
@@ -366,6 +383,7 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GsParams p, GsGeom g, co
         dmean[1] += (-vx * vy * dd0 + (s2 - vy * vy) * dd1 - vz * vy * dd2) * inv32;
         dmean[2] += (-vx * vz * dd0 - vy * vz * dd1 + (s2 - vz * vz) * dd2) * inv32;
     }
+    if (ACC) { dmean[0] += dL_dmeans3D[3 * idx]; dmean[1] += dL_dmeans3D[3 * idx + 1]; dmean[2] += dL_dmeans3D[3 * idx + 2]; }
     dL_dmeans3D[3 * idx] = dmean[0]; dL_dmeans3D[3 * idx + 1] = dmean[1]; dL_dmeans3D[3 * idx + 2] = dmean[2];
 
     // cov3D -> scale, rotation (exact derivative; d/dscale carries scale_modifier)
@@ -381,7 +399,9 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GsParams p, GsGeom g, co
             for (int k = 0; k < 3; k++) dM[i][k] = 2.f * (Gm[i][0] * R[0][k] + Gm[i][1] * R[1][k] + Gm[i][2] * R[2][k]) * s[k];
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            dL_dscales[3 * idx + k] = p.scale_modifier * (dM[0][k] * R[0][k] + dM[1][k] * R[1][k] + dM[2][k] * R[2][k]);
+            float gs_ = p.scale_modifier * (dM[0][k] * R[0][k] + dM[1][k] * R[1][k] + dM[2][k] * R[2][k]);
+            if (RAW) gs_ *= (k == 0 ? sc.x : (k == 1 ? sc.y : sc.z));          // exp'
+            dL_dscales[3 * idx + k] = ACC ? dL_dscales[3 * idx + k] + gs_ : gs_;
 #pragma unroll
             for (int i = 0; i < 3; i++) dR[i][k] = dM[i][k] * s[k];
         }
@@ -391,12 +411,18 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GsParams p, GsGeom g, co
         dq.y = 2.f * (y * dR[0][1] + z * dR[0][2] + y * dR[1][0] - 2.f * x * dR[1][1] - r * dR[1][2] + z * dR[2][0] + r * dR[2][1] - 2.f * x * dR[2][2]);
         dq.z = 2.f * (-2.f * y * dR[0][0] + x * dR[0][1] + r * dR[0][2] + x * dR[1][0] + z * dR[1][2] - r * dR[2][0] + z * dR[2][1] - 2.f * y * dR[2][2]);
         dq.w = 2.f * (-2.f * z * dR[0][0] - r * dR[0][1] + x * dR[0][2] + r * dR[1][0] - 2.f * z * dR[1][1] + y * dR[1][2] + x * dR[2][0] + y * dR[2][1]);
+        if (RAW) {   // through q = raw / |raw|: (g - q (q.g)) / |raw|
+            const float dot = dq.x * q.x + dq.y * q.y + dq.z * q.z + dq.w * q.w, inv = 1.f / qnorm;
+            dq = make_float4((dq.x - q.x * dot) * inv, (dq.y - q.y * dot) * inv, (dq.z - q.z * dot) * inv, (dq.w - q.w * dot) * inv);
+        }
+        if (ACC) { const float4 o4 = *reinterpret_cast<const float4*>(dL_drots + 4 * idx); dq.x += o4.x; dq.y += o4.y; dq.z += o4.z; dq.w += o4.w; }
         *reinterpret_cast<float4*>(dL_drots + 4 * idx) = dq;
     }
     }   // visible Gaussian
     if (STAGED) {
         __syncthreads();
-        sh_stage_out(dL_dsh, g0, gcount, sh_lds);
+        if (RAW) sh_stage_out_split<ACC>(dL_dsh, dL_df_rest, g0, gcount, sh_lds);
+        else     sh_stage_out(dL_dsh, g0, gcount, sh_lds);
     }
 }
 
@@ -407,13 +433,29 @@ int gs_launch_preprocess_bwd(const GsParams& p, const GsGeom& g, const int* radi
     if (p.N == 0) return 0;
     const bool staged = shs && !colors_precomp && p.M == 16 && ((uintptr_t)shs % 16 == 0) && ((uintptr_t)dL_dsh % 16 == 0);
     if (staged)
-        hipLaunchKernelGGL(k_preprocess_bwd<true>, dim3(c3d_cdiv(p.N, 256)), dim3(256), 256 * SH_ROW * sizeof(float), s, p, g, radii, means3D, shs,
-                           colors_precomp, scales, rotations, cov3D_precomp, (const float4*)pairgrad, dL_dmean2D, dL_dcolors, dL_dopacity,
-                           dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drots);
+        hipLaunchKernelGGL((k_preprocess_bwd<true, false, false>), dim3(c3d_cdiv(p.N, 256)), dim3(256), 256 * SH_ROW * sizeof(float), s, p, g, radii, means3D, shs,
+                           (const float*)nullptr, colors_precomp, scales, rotations, cov3D_precomp, (const float4*)pairgrad, dL_dmean2D, dL_dcolors, dL_dopacity,
+                           dL_dmeans3D, dL_dcov3D, dL_dsh, (float*)nullptr, dL_dscales, dL_drots);
     else
-        hipLaunchKernelGGL(k_preprocess_bwd<false>, dim3(c3d_cdiv(p.N, 256)), dim3(256), 0, s, p, g, radii, means3D, shs,
-                           colors_precomp, scales, rotations, cov3D_precomp, (const float4*)pairgrad, dL_dmean2D, dL_dcolors, dL_dopacity,
-                           dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drots);
+        hipLaunchKernelGGL((k_preprocess_bwd<false, false, false>), dim3(c3d_cdiv(p.N, 256)), dim3(256), 0, s, p, g, radii, means3D, shs,
+                           (const float*)nullptr, colors_precomp, scales, rotations, cov3D_precomp, (const float4*)pairgrad, dL_dmean2D, dL_dcolors, dL_dopacity,
+                           dL_dmeans3D, dL_dcov3D, dL_dsh, (float*)nullptr, dL_dscales, dL_drots);
+    C3D_LAUNCH_CHECK();
+    return 0;
+}
+int gs_launch_preprocess_bwd_raw(const GsParams& p, const GsGeom& g, const int* radii, const float* means3D, const float* f_dc, const float* f_rest,
+                                 const float* scaling_raw, const float* rotation_raw, const float* pairgrad, float* dL_dmean2D,
+                                 float* dL_dopacity_raw, float* dL_dmeans3D, float* dL_df_dc, float* dL_df_rest, float* dL_dscaling_raw,
+                                 float* dL_drotation_raw, bool accumulate, hipStream_t s) {
+    if (p.N == 0) return 0;
+    if (accumulate)
+        hipLaunchKernelGGL((k_preprocess_bwd<true, true, true>), dim3(c3d_cdiv(p.N, 256)), dim3(256), 256 * SH_ROW * sizeof(float), s, p, g, radii, means3D, f_dc, f_rest,
+                           (const float*)nullptr, scaling_raw, rotation_raw, (const float*)nullptr, (const float4*)pairgrad, dL_dmean2D, (float*)nullptr,
+                           dL_dopacity_raw, dL_dmeans3D, (float*)nullptr, dL_df_dc, dL_df_rest, dL_dscaling_raw, dL_drotation_raw);
+    else
+        hipLaunchKernelGGL((k_preprocess_bwd<true, true, false>), dim3(c3d_cdiv(p.N, 256)), dim3(256), 256 * SH_ROW * sizeof(float), s, p, g, radii, means3D, f_dc, f_rest,
+                           (const float*)nullptr, scaling_raw, rotation_raw, (const float*)nullptr, (const float4*)pairgrad, dL_dmean2D, (float*)nullptr,
+                           dL_dopacity_raw, dL_dmeans3D, (float*)nullptr, dL_df_dc, dL_df_rest, dL_dscaling_raw, dL_drotation_raw);
     C3D_LAUNCH_CHECK();
     return 0;
 }

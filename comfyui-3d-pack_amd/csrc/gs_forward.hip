@@ -11,8 +11,11 @@
 // coefficients are brought in with fully coalesced 16-B loads through LDS (sh_stage_in) instead of
 // 64 lanes striding 192 B apart.
 // ------------------------------------------------------------------------------------------
-template <bool STAGED>
+// RAW: the inputs are the reference's raw parameters -- scales = exp(.), opacity = sigmoid(.), rotation = normalize(.) are applied here
+// (GaussianModel accessors, main_3DGS_renderer.py:294-321) and SH comes as the split f_dc / f_rest pair (`shs` = f_dc, `f_rest` extra).
+template <bool STAGED, bool RAW>
 __global__ void __launch_bounds__(256) k_preprocess(GsParams p, const float* __restrict__ means3D, const float* __restrict__ shs,
+                                                     const float* __restrict__ f_rest,
                                                      const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
                                                      const float* __restrict__ scales, const float* __restrict__ rotations,
                                                      const float* __restrict__ cov3D_precomp, GsGeom g, int* __restrict__ radii) {
@@ -20,7 +23,8 @@ __global__ void __launch_bounds__(256) k_preprocess(GsParams p, const float* __r
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (STAGED) {
         const size_t g0 = (size_t)blockIdx.x * blockDim.x;
-        sh_stage_in(shs, g0, min((int)blockDim.x, p.N - (int)g0), sh_lds);
+        if (RAW) sh_stage_in_split(shs, f_rest, g0, min((int)blockDim.x, p.N - (int)g0), sh_lds);
+        else     sh_stage_in(shs, g0, min((int)blockDim.x, p.N - (int)g0), sh_lds);
         __syncthreads();
     }
     if (idx >= p.N) return;
@@ -42,8 +46,13 @@ __global__ void __launch_bounds__(256) k_preprocess(GsParams p, const float* __r
 #pragma unroll
         for (int i = 0; i < 6; i++) c3[i] = cov3D_precomp[6 * idx + i];
     } else {
-        const float3 s = make_float3(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]);
-        const float4 q = *reinterpret_cast<const float4*>(rotations + 4 * idx);
+        float3 s = make_float3(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]);
+        float4 q = *reinterpret_cast<const float4*>(rotations + 4 * idx);
+        if (RAW) {
+            s = make_float3(expf(s.x), expf(s.y), expf(s.z));
+            const float inv = 1.f / fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
+            q = make_float4(q.x * inv, q.y * inv, q.z * inv, q.w * inv);
+        }
         cov3d_from_scale_rot(s, p.scale_modifier, q, c3);
     }
     float T2[2][3], ST0[3], ST1[3];
@@ -65,7 +74,7 @@ __global__ void __launch_bounds__(256) k_preprocess(GsParams p, const float* __r
     if ((x1 - x0) * (y1 - y0) == 0) return;
     // from here on the Gaussian counts as visible (radii > 0), exactly as in the dependency; the tile list
     // it is emitted to is narrowed to the tiles where alpha can reach 1/255 (exact, see tile_rect_tight)
-    const float opac = opacities[idx];
+    const float opac = RAW ? 1.f / (1.f + expf(-opacities[idx])) : opacities[idx];
     const float ex = alpha_extent(opac, a), ey = alpha_extent(opac, c);
     if (ex >= 0.f) tile_rect_tight(px, py, rad, ex, ey, p.gx, p.gy, x0, y0, x1, y1);
     else { x1 = x0; y1 = y0; }
@@ -108,11 +117,19 @@ int gs_launch_preprocess(const GsParams& p, const float* means3D, const float* s
     if (p.N == 0) return 0;
     const bool staged = shs && !colors_precomp && p.M == 16 && ((uintptr_t)shs % 16 == 0);
     if (staged)
-        hipLaunchKernelGGL(k_preprocess<true>, dim3(c3d_cdiv(p.N, 256)), dim3(256), 256 * SH_ROW * sizeof(float), s, p, means3D, shs,
-                           colors_precomp, opacities, scales, rotations, cov3D_precomp, g, radii);
+        hipLaunchKernelGGL((k_preprocess<true, false>), dim3(c3d_cdiv(p.N, 256)), dim3(256), 256 * SH_ROW * sizeof(float), s, p, means3D, shs,
+                           (const float*)nullptr, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, radii);
     else
-        hipLaunchKernelGGL(k_preprocess<false>, dim3(c3d_cdiv(p.N, 256)), dim3(256), 0, s, p, means3D, shs, colors_precomp, opacities,
-                           scales, rotations, cov3D_precomp, g, radii);
+        hipLaunchKernelGGL((k_preprocess<false, false>), dim3(c3d_cdiv(p.N, 256)), dim3(256), 0, s, p, means3D, shs, (const float*)nullptr,
+                           colors_precomp, opacities, scales, rotations, cov3D_precomp, g, radii);
+    C3D_LAUNCH_CHECK();
+    return 0;
+}
+int gs_launch_preprocess_raw(const GsParams& p, const float* means3D, const float* f_dc, const float* f_rest, const float* opacity_raw,
+                             const float* scaling_raw, const float* rotation_raw, GsGeom& g, int* radii, hipStream_t s) {
+    if (p.N == 0) return 0;
+    hipLaunchKernelGGL((k_preprocess<true, true>), dim3(c3d_cdiv(p.N, 256)), dim3(256), 256 * SH_ROW * sizeof(float), s, p, means3D, f_dc, f_rest,
+                       (const float*)nullptr, opacity_raw, scaling_raw, rotation_raw, (const float*)nullptr, g, radii);
     C3D_LAUNCH_CHECK();
     return 0;
 }

@@ -96,6 +96,12 @@ static inline void gs_carve_image(char* base, int W, int H, GsImage& im) {
 int gs_launch_preprocess(const GsParams& p, const float* means3D, const float* shs, const float* colors_precomp,
                          const float* opacities, const float* scales, const float* rotations, const float* cov3D_precomp,
                          GsGeom& g, int* radii, hipStream_t s);
+int gs_launch_preprocess_raw(const GsParams& p, const float* means3D, const float* f_dc, const float* f_rest, const float* opacity_raw,
+                             const float* scaling_raw, const float* rotation_raw, GsGeom& g, int* radii, hipStream_t s);
+int gs_launch_preprocess_bwd_raw(const GsParams& p, const GsGeom& g, const int* radii, const float* means3D, const float* f_dc, const float* f_rest,
+                                 const float* scaling_raw, const float* rotation_raw, const float* pairgrad, float* dL_dmean2D,
+                                 float* dL_dopacity_raw, float* dL_dmeans3D, float* dL_df_dc, float* dL_df_rest, float* dL_dscaling_raw,
+                                 float* dL_drotation_raw, bool accumulate, hipStream_t s);
 int gs_launch_gather_tiles(const GsGeom& g, int N, int res, hipStream_t s);
 int gs_launch_emit(const GsParams& p, const GsGeom& g, int res, const int* radii, GsBinning& b, hipStream_t s);
 int gs_launch_ranges(const GsBinning& b, int res, long long D, int tiles, hipStream_t s);

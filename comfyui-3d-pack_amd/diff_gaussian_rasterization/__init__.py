@@ -126,6 +126,81 @@ class _RasterizeGaussians(torch.autograd.Function):
                 g_cov3D if has_cov else None, None)
 
 
+class _RasterizeGaussiansRaw(torch.autograd.Function):
+    """Extension: the same rasterizer fed with GaussianModel's RAW parameters; exp / sigmoid / normalize / cat and their backward
+    passes run inside the projection kernels (c3d_gs_forward_project_raw / c3d_gs_backward_raw)."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, raster_settings):
+        lib = _h.lib()
+        rs = raster_settings
+        dev = means3D.device
+        if not means3D.is_cuda:
+            raise RuntimeError("diff_gaussian_rasterization (MI355X): tensors must live on a HIP device; there is no CPU path")
+        if f_rest.shape[1:] != (15, 3) or f_dc.shape[1:] != (1, 3):
+            raise ValueError("rasterize_gaussians_raw needs SH degree 3 storage: f_dc [N,1,3], f_rest [N,15,3]")
+        H, W = int(rs.image_height), int(rs.image_width)
+        t = [_h.f32c(x) for x in (means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw)]
+        N = means3D.shape[0]
+        keep = []
+        with torch.cuda.device(dev):
+            st = _settings_struct(rs, keep)
+            s = _h.stream(dev)
+            u8 = dict(dtype=torch.uint8, device=dev)
+            radii = torch.empty((N,), dtype=torch.int32, device=dev)
+            geom = torch.empty((lib.c3d_gs_geom_bytes(N),), **u8)
+            nr = C.c_int64(0)
+            _h.check(lib.c3d_gs_forward_project_raw(C.byref(st), N, *[_h.ptr(x) for x in t], _h.ptr(radii), _h.ptr(geom), C.byref(nr), s),
+                     "c3d_gs_forward_project_raw")
+            num_rendered = int(nr.value)
+            global last_num_rendered
+            last_num_rendered = num_rendered
+            binning = torch.empty((lib.c3d_gs_binning_bytes(num_rendered, H, W),), **u8)
+            img = torch.empty((lib.c3d_gs_image_bytes(H, W),), **u8)
+            color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+            depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+            alpha = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+            _h.check(lib.c3d_gs_forward_render(C.byref(st), N, 16, _h.ptr(radii), _h.ptr(geom), num_rendered, _h.ptr(binning), _h.ptr(img),
+                                               _h.ptr(color), _h.ptr(depth), _h.ptr(alpha), s), "c3d_gs_forward_render")
+        ctx.raster_settings, ctx.num_rendered, ctx.N = rs, num_rendered, N
+        e = torch.empty(0, device=dev)
+        ctx.save_for_backward(*(x if x is not None else e for x in t), radii, geom, binning, img)
+        ctx.mark_non_differentiable(radii)
+        return color, radii, depth, alpha
+
+    @staticmethod
+    def backward(ctx, grad_color, grad_radii, grad_depth, grad_alpha):
+        lib = _h.lib()
+        rs, N = ctx.raster_settings, ctx.N
+        means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, radii, geom, binning, img = ctx.saved_tensors
+        dev = geom.device
+        keep = []
+        with torch.cuda.device(dev):
+            st = _settings_struct(rs, keep)
+            f = dict(dtype=torch.float32, device=dev)
+            g_m2d, g_m3d = torch.empty((N, 3), **f), torch.empty((N, 3), **f)
+            g_dc, g_rest = torch.empty((N, 1, 3), **f), torch.empty((N, 15, 3), **f)
+            g_op, g_sc, g_rot = torch.empty((N, 1), **f), torch.empty((N, 3), **f), torch.empty((N, 4), **f)
+            scratch = torch.empty((lib.c3d_gs_backward_scratch_bytes(N, ctx.num_rendered),), dtype=torch.uint8, device=dev)
+            gc = _h.f32c(grad_color)
+            if gc is None:
+                gc = torch.zeros((3, int(rs.image_height), int(rs.image_width)), **f)
+            nz = lambda x: x if N else None
+            _h.check(lib.c3d_gs_backward_raw(C.byref(st), N, _h.ptr(nz(means3D)), _h.ptr(nz(f_dc)), _h.ptr(nz(f_rest)), _h.ptr(nz(scaling_raw)),
+                                             _h.ptr(nz(rotation_raw)), _h.ptr(radii), _h.ptr(geom), ctx.num_rendered, _h.ptr(binning), _h.ptr(img),
+                                             _h.ptr(gc), _h.ptr(_h.f32c(grad_depth)), _h.ptr(_h.f32c(grad_alpha)), _h.ptr(g_m2d), _h.ptr(g_m3d),
+                                             _h.ptr(g_dc), _h.ptr(g_rest), _h.ptr(g_op), _h.ptr(g_sc), _h.ptr(g_rot), _h.ptr(scratch), 0,
+                                             _h.stream(dev)), "c3d_gs_backward_raw")
+        return g_m3d, g_m2d, g_dc, g_rest, g_op, g_sc, g_rot, None
+
+
+def rasterize_gaussians_raw(means3D, means2D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, raster_settings):
+    """(color, radii, depth, alpha) from RAW GaussianModel parameters (SH degree 3 storage).  Equivalent to
+    GaussianRasterizer(settings)(means3D, means2D, sigmoid(opacity_raw), shs=cat(f_dc, f_rest), scales=exp(scaling_raw),
+    rotations=normalize(rotation_raw)) -- one kernel instead of five torch ops each way."""
+    return _RasterizeGaussiansRaw.apply(means3D, means2D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, raster_settings)
+
+
 class GaussianRasterizer(nn.Module):
     def __init__(self, raster_settings):
         super().__init__()

@@ -96,6 +96,23 @@ int c3d_gs_backward(const c3d_gs_settings* st, int32_t N, int32_t M, const float
                     float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscales,
                     float* dL_drotations, void* scratch, c3d_stream_t stream);
 
+/* ---- fused-activation variants (extension) -------------------------------------------------------------
+ * The reference applies exp / sigmoid / normalize and concatenates f_dc with f_rest in separate torch ops on every render
+ * (GaussianModel accessors, main_3DGS_renderer.py:294-321, called from render() :866-868) and back-propagates through them.
+ * These two entry points take the RAW parameters of GaussianModel (SH degree 3 storage: f_dc [N,1,3], f_rest [N,15,3]) and fold
+ * those activations and their backward passes into the projection kernels; outputs and state buffers are exactly those of the
+ * plain entry points, c3d_gs_forward_render is shared.  `accumulate` != 0 adds the parameter gradients into the given buffers
+ * (loops over views) instead of overwriting them; dL_dmeans2D is always overwritten. */
+int c3d_gs_forward_project_raw(const c3d_gs_settings* st, int32_t N, const float* means3D, const float* f_dc, const float* f_rest,
+                               const float* opacity_raw, const float* scaling_raw, const float* rotation_raw, int32_t* radii,
+                               void* geom_buffer, int64_t* num_rendered /* host */, c3d_stream_t stream);
+int c3d_gs_backward_raw(const c3d_gs_settings* st, int32_t N, const float* means3D, const float* f_dc, const float* f_rest,
+                        const float* scaling_raw, const float* rotation_raw, const int32_t* radii, const void* geom_buffer,
+                        int64_t num_rendered, const void* binning_buffer, const void* image_buffer, const float* dL_dcolor,
+                        const float* dL_ddepth, const float* dL_dalpha, float* dL_dmeans2D, float* dL_dmeans3D, float* dL_df_dc,
+                        float* dL_df_rest, float* dL_dopacity_raw, float* dL_dscaling_raw, float* dL_drotation_raw, void* scratch,
+                        int32_t accumulate, c3d_stream_t stream);
+
 /* mark_visible: present[N] (uint8) = view-space z > 0.2 */
 int c3d_gs_mark_visible(int32_t N, const float* means3D, const float* viewmatrix, const float* projmatrix,
                         uint8_t* present, c3d_stream_t stream);

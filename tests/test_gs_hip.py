@@ -371,3 +371,32 @@ def test_renderer_and_trainer_mirror_reduce_the_loss():
     assert np.mean(losses[-5:]) < 0.9 * np.mean(losses[:5]), losses
     for q in tr.params:
         assert torch.isfinite(q).all()
+
+
+def test_fused_activation_path_equals_accessor_path():
+    """rasterize_gaussians_raw (exp / sigmoid / normalize / cat folded into the kernels) against the op-by-op accessor path of
+    GaussianSplattingRenderer.render: same images, same gradients on the raw parameters."""
+    from MVs_Algorithms.GaussianSplatting.main_3DGS_renderer import GaussianSplattingRenderer
+    from shared_utils.camera_utils import MiniCam, OrbitCamera, orbit_camera
+    raw = S.make_cloud(30000, seed=11, log_scale_mean=np.log(0.02), activated=False)
+    W, H = 320, 200
+    cam = OrbitCamera(W, H, fovy=49.1)
+    mc = MiniCam(orbit_camera(-15.0, 50.0, 2.2), W, H, cam.fovy, cam.fovx, 0.01, 100, device="cuda")
+    gC = _dev(np.random.default_rng(4).normal(size=(3, H, W)).astype(np.float32), torch.float32)
+    outs = []
+    for unfused in (False, True):
+        r = GaussianSplattingRenderer(sh_degree=3, device="cuda")
+        r.initialize({"xyz": raw["means3D"], "features": raw["shs"], "scaling_raw": raw["scales"], "rotation_raw": raw["rotations"] * 3.0,
+                      "opacity_raw": raw["opacities"]})
+        r.force_unfused = unfused
+        out = r.render(mc, scaling_modifier=0.9)
+        ((out["image"] * gC).sum() + out["alpha"].sum() + 0.1 * out["depth"].sum()).backward()
+        g = r.gaussians
+        outs.append((out, [t.grad.clone() for t in (g._xyz, g._features_dc, g._features_rest, g._opacity, g._scaling, g._rotation)],
+                     out["viewspace_points"].grad.clone()))
+    (o1, g1, v1), (o2, g2, v2) = outs
+    assert torch.equal(o1["radii"], o2["radii"])
+    assert (o1["image"] - o2["image"]).abs().mean().item() <= 1e-6 and (o1["alpha"] - o2["alpha"]).abs().max().item() <= 1e-5
+    for a, b, name in zip(g1, g2, ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")):
+        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) <= 2e-4, name
+    assert rel_err(v1.cpu().numpy(), v2.cpu().numpy()) <= 2e-4
