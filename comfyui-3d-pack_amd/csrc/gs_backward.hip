@@ -31,6 +31,44 @@ __device__ __forceinline__ float wave_reduce4(float a, float b, float c, float d
     t = dpp_add<0x140>(t);              // row_mirror
     return t;
 }
+// Ten values at once (the backward pass's per-splat sums): the permlane swaps of the three groups are issued back to back so that
+// the VALU-write -> permlane-read wait state is paid once per level instead of once per swap.
+// t0 rows: v0, v2, v1, v3   t1 rows: v4, v6, v5, v7   t2 rows: v8, 0, v9, 0
+__device__ __forceinline__ void wave_reduce10(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7, float v8, float v9,
+                                              float& t0, float& t1, float& t2) {
+    asm volatile("s_nop 1\n\t"
+                 "v_permlane32_swap_b32 %0, %1\n\t"
+                 "v_permlane32_swap_b32 %2, %3\n\t"
+                 "v_permlane32_swap_b32 %4, %5\n\t"
+                 "v_permlane32_swap_b32 %6, %7\n\t"
+                 "v_permlane32_swap_b32 %8, %9"
+                 : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7), "+v"(v8), "+v"(v9));
+    float p0 = v0 + v1, q0 = v2 + v3, p1 = v4 + v5, q1 = v6 + v7, p2 = v8 + v9, q2 = 0.f;
+    asm volatile("s_nop 1\n\t"
+                 "v_permlane16_swap_b32 %0, %1\n\t"
+                 "v_permlane16_swap_b32 %2, %3\n\t"
+                 "v_permlane16_swap_b32 %4, %5"
+                 : "+v"(p0), "+v"(q0), "+v"(p1), "+v"(q1), "+v"(p2), "+v"(q2));
+    t0 = p0 + q0; t1 = p1 + q1; t2 = p2 + q2;
+    // in-row butterflies as single DPP adds (hipcc -O3 would SLP-pack them into v_pk_add_f32 + v_mov_dpp + zero moves: twice the
+    // instructions).  The three chains are interleaved, so the 2 wait states a DPP read needs after the VALU write of its source are
+    // covered by the other two chains; only the first level needs an explicit s_nop.
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %2, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %2, %2, %2 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1"
+                 : "+v"(t0), "+v"(t1), "+v"(t2));
+}
 
 // ------------------------------------------------------------------------------------------
 // A7 composite backward: same tiling and per-wave ballot-compacted splat lists as the forward pass
@@ -127,25 +165,21 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
                 const bool act = (k < last) && (power <= 0.f) && (alpha >= 1.f / 255.f);
                 float t0 = 0.f, t1 = 0.f, t2 = 0.f;
                 if (__ballot(act) != 0ull) {   // wave-uniform
-                    float g_c0 = 0.f, g_c1 = 0.f, g_c2 = 0.f, g_d = 0.f, m0 = 0.f, m1x = 0.f, m1y = 0.f, m2xx = 0.f, m2xy = 0.f, m2yy = 0.f;
-                    if (act) {
-                        // dL/dalpha_k = T_k (c_k . dL) - [sum_{j behind k} (c_j . dL) alpha_j T_j + T_final bg . dL] / (1 - alpha_k)
-                        // with (c . dL) taken over colour, depth and alpha channels; Rdot carries the bracket.
-                        const float inv = __builtin_amdgcn_rcpf(1.f - alpha);
-                        T *= inv;
-                        const float w = alpha * T;
-                        const float sdot = a1.z * dLp0 + a1.w * dLp1 + a2.x * dLp2 + a2.y * dLd + dLa;
-                        const float dL_dalpha = T * sdot - Rdot * inv;
-                        Rdot += w * sdot;
-                        g_c0 = w * dLp0; g_c1 = w * dLp1; g_c2 = w * dLp2; g_d = w * dLd;
-                        // screen-space part as raw moments of w2 = dL/dG * G; turned into mean/conic/opacity gradients per Gaussian in A8
-                        m0 = a1.y * G * dL_dalpha;
-                        m1x = m0 * dx; m1y = m0 * dy;
-                        m2xx = m1x * dx; m2xy = m1x * dy; m2yy = m1y * dy;
-                    }
-                    t0 = wave_reduce4(g_c0, g_c1, g_c2, g_d);      // rows: c0, c2, c1, depth
-                    t1 = wave_reduce4(m0, m1x, m1y, m2xx);         // rows: m0, m1y, m1x, m2xx
-                    t2 = wave_reduce4(m2xy, m2yy, 0.f, 0.f);       // rows: m2xy, 0, m2yy, 0
+                    // dL/dalpha_k = T_k (c_k . dL) - [sum_{j behind k} (c_j . dL) alpha_j T_j + T_final bg . dL] / (1 - alpha_k)
+                    // with (c . dL) taken over colour, depth and alpha channels; Rdot carries the bracket.  Inactive lanes run the
+                    // same instructions with a zero weight (no exec-masked branch, no zero-initialised temporaries).
+                    const float inv = __builtin_amdgcn_rcpf(1.f - alpha);
+                    const float Tn = T * inv;
+                    T = act ? Tn : T;
+                    const float w = act ? alpha * Tn : 0.f;
+                    const float sdot = a1.z * dLp0 + a1.w * dLp1 + a2.x * dLp2 + a2.y * dLd + dLa;
+                    const float dL_dalpha = Tn * sdot - Rdot * inv;
+                    Rdot += w * sdot;
+                    // screen-space part as raw moments of w2 = dL/dG * G; turned into mean/conic/opacity gradients per Gaussian in A8
+                    const float m0 = act ? a1.y * G * dL_dalpha : 0.f;
+                    const float m1x = m0 * dx, m1y = m0 * dy;
+                    wave_reduce10(w * dLp0, w * dLp1, w * dLp2, w * dLd, m0, m1x, m1y, m1x * dx, m1x * dy, m1y * dy, t0, t1, t2);
+                    // t0 rows: c0, c2, c1, depth   t1 rows: m0, m1y, m1x, m2xx   t2 rows: m2xy, 0, m2yy, 0
                 }
                 if ((lane & 15) == 0) {   // lanes 0,16,32,48: one row each
                     const int row = lane >> 4;
