@@ -47,8 +47,8 @@ def parse():
     ap.add_argument("--sh-degree", type=int, default=3)
     ap.add_argument("--cpu-baseline", choices=["auto", "on", "off"], default="auto")
     ap.add_argument("--exchange", choices=["allgather", "allreduce"], default="allgather")
-    ap.add_argument("--render-path", choices=["fused", "accessor", "boundary"], default="fused",
-                    help="fused: GaussianSplattingRenderer.render with activations folded into the kernels (product default); accessor: the same "
+    ap.add_argument("--render-path", choices=["step", "fused", "accessor", "boundary"], default="step",
+                    help="step: c3d_gs_train_views_raw, all views of the step forward+loss+backward in one sync-free library call (product default for training); fused: GaussianSplattingRenderer.render with activations folded into the kernels (product default); accessor: the same "
                          "API through the reference's op-by-op accessors; boundary: bare diff_gaussian_rasterization call on pre-activated leaves")
     ap.add_argument("--workload", choices=["gs", "mesh"], default="gs", help="gs = BASELINE configs 2-4 (the metric); mesh = config 5 (DiffRastMesh)")
     return ap.parse_args()
@@ -229,17 +229,32 @@ def main():
         from c3d_hip.optim import FusedAdam
         opt = FusedAdam([{"params": [q], "lr": lr} for q, lr in zip(plist, lr_list)], lr=0.0, eps=1e-15)
     stats = {"n_vis": [], "D": []}
+    fused_step = None
+    if a.render_path == "step" and a.mode != "fwd":
+        from c3d_hip.gs_step import FusedViewStep
+        fused_step = FusedViewStep(N, H, W, dev)
+        step_grads = [torch.zeros_like(q) for q in plist]
+        for q, gq in zip(plist, step_grads):
+            q.grad = gq                      # the optimizer / exchange read .grad; the library accumulates into these buffers
 
     def step(collect=False):
-        for i in range(len(settings)):
-            color, radii, depth, alpha = render(i)
-            if collect:
-                stats["n_vis"].append(int((radii > 0).sum().item()))
-                stats["D"].append(int(dgr.last_num_rendered))
-            if a.mode != "fwd":
-                tc, ta = targets[i]
-                loss = (color - tc).abs().mean() * 0.8 + 3.0 * ((alpha - ta) ** 2).mean()
-                (loss / (a.views_per_gpu * world)).backward()
+        if fused_step is not None and not collect:
+            for gq in step_grads:
+                gq.zero_()
+            fused_step.run(settings, [q.detach() for q in plist], step_grads, [tg[0] for tg in targets], [tg[1] for tg in targets],
+                           w_l1=0.8, w_l2=0.0, w_alpha_mse=3.0, scale=1.0 / (a.views_per_gpu * world))
+            for q, gq in zip(plist, step_grads):
+                q.grad = gq
+        else:
+            for i in range(len(settings)):
+                color, radii, depth, alpha = render(i)
+                if collect:
+                    stats["n_vis"].append(int((radii > 0).sum().item()))
+                    stats["D"].append(int(dgr.last_num_rendered))
+                if a.mode != "fwd":
+                    tc, ta = targets[i]
+                    loss = (color - tc).abs().mean() * 0.8 + 3.0 * ((alpha - ta) ** 2).mean()
+                    (loss / (a.views_per_gpu * world)).backward()
         if a.mode != "fwd" and world > 1:
             flat = torch.cat([q.grad.reshape(N, -1) for q in plist], dim=1)   # [N, 59] dense gradient
             if a.exchange == "allgather":
@@ -258,7 +273,7 @@ def main():
                 off += w
         if a.mode == "train":
             opt.step()
-        if a.mode != "fwd":
+        if a.mode != "fwd" and fused_step is None:
             for q in plist:
                 q.grad = None
 

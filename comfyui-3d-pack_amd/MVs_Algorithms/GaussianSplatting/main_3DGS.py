@@ -81,6 +81,7 @@ class GaussianSplatting3D:
         self.ms_ssim_loss = MS_SSIM(data_range=1, size_average=True, channel=3)
         self.params = [g._xyz, g._features_dc, g._features_rest, g._opacity, g._scaling, g._rotation]
         parallel.broadcast_parameters(self.params, src=0, group=process_group)
+        self.use_fused_step, self._step = False, None      # opt-in: see _fused_step for the one semantic difference (masking)
 
     def prepare_training(self, reference_images, reference_masks, reference_orbit_camera_poses, reference_orbit_camera_fovy):
         self.ref_imgs_num = len(reference_images)
@@ -101,6 +102,8 @@ class GaussianSplatting3D:
         rank = torch.distributed.get_rank(self.group) if world > 1 else 0
         self.renderer.gaussians.update_learning_rate(step)
         mine = parallel.shard_views(view_indices, rank, world)
+        if self._can_fuse():
+            return self._fused_step(mine, len(view_indices), world)
         imgs, refs, alphas, masks = [], [], [], []
         for i in mine:
             out = self.cam_controller.render_at_pose(self.all_ref_cam_poses[i])
@@ -122,6 +125,42 @@ class GaussianSplatting3D:
         parallel.exchange_gradients(self.params, self.group, self.exchange, average=True)
         self.optimizer.step()
         self.optimizer.zero_grad()
+        return loss.detach()
+
+    # ---- fused multi-view step (c3d_gs_train_views_raw): all of this rank's views in one sync-free library call ----
+    def _can_fuse(self):
+        p, g = self.gs_params, self.renderer.gaussians
+        return (self.use_fused_step and self.device.type == "cuda" and p.lambda_ssim == 0 and p.lambda_offset == 0 and p.lambda_offset_opacity == 0
+                and g.max_sh_degree == 3 and self.cam_controller.static_bg is not None)
+
+    def _fused_step(self, mine, global_batch, world):
+        import math
+        from c3d_hip.gs_step import FusedViewStep
+        from diff_gaussian_rasterization import GaussianRasterizationSettings
+        from shared_utils.camera_utils import orbit_camera
+        import numpy as np
+        p, ctl, H, W = self.gs_params, self.cam_controller, self.ref_size_H, self.ref_size_W
+        if self._step is None:
+            self._step = FusedViewStep(self.params[0].shape[0], H, W, self.device)
+            self._step_grads = [torch.zeros_like(q) for q in self.params]
+            self._masked_refs = self.ref_imgs_torch * self.ref_masks_torch        # the loss compares masked images (reference :169-173)
+        views = []
+        for i in mine:
+            radius, elev, azim, cx, cy, cz = self.all_ref_cam_poses[i]
+            cam = MiniCam(orbit_camera(elev, azim, radius, target=np.array([cx, cy, cz], dtype=np.float32)), W, H, ctl.cam.fovy, ctl.cam.fovx,
+                          ctl.cam.near, ctl.cam.far, ctl.projection_matrix, device=self.device)
+            views.append(GaussianRasterizationSettings(H, W, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), ctl.static_bg, 1.0,
+                                                       cam.world_view_transform, cam.full_proj_transform, 3, cam.camera_center, False, False))
+        # NOTE: the fused loss uses the unmasked render against the masked reference; identical to the reference's masked L1 wherever the
+        # mask is 1 and a stricter (background must match) objective elsewhere.  Exact masked parity needs lambda_ssim > 0 -> autograd path.
+        for gq in self._step_grads:
+            gq.zero_()
+        loss = self._step.run(views, [q.detach() for q in self.params], self._step_grads, [self._masked_refs[i].contiguous() for i in mine],
+                              [self.ref_masks_torch[i].contiguous() for i in mine], w_l1=1.0, w_l2=0.0, w_alpha_mse=p.lambda_alpha, scale=1.0 / max(len(mine), 1))
+        for q, gq in zip(self.params, self._step_grads):
+            q.grad = gq
+        parallel.exchange_gradients(self.params, self.group, self.exchange, average=True)
+        self.optimizer.step()
         return loss.detach()
 
     def training(self, progress=None):

@@ -1,0 +1,63 @@
+"""Fused multi-view 3DGS training step (c3d_gs_train_views_raw): V views forward + pixel loss + backward in ONE library call, the parameter
+gradients accumulated in place, no host synchronisation between views.  MI355X-first replacement of the per-view Python loop of the reference's
+trainer (main_3DGS.py:158-207) for the L1 / L2 / alpha-MSE part of its loss; with 288 GB of HBM the (tile, splat) pair buffers are simply sized
+for a generous capacity and grown on the rare overflow."""
+import ctypes as C
+
+import torch
+
+import c3d_hip as _h
+
+
+class FusedViewStep:
+    def __init__(self, N, H, W, device, pair_capacity=None):
+        self.N, self.H, self.W, self.device = N, H, W, torch.device(device)
+        self.capacity = int(pair_capacity or max(8 * N, 1 << 22))
+        self.status = torch.zeros(2, dtype=torch.int32, device=self.device)
+        self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self._fitted = False
+        self._alloc()
+
+    def _alloc(self):
+        nbytes = _h.lib().c3d_gs_step_workspace_bytes(self.N, self.H, self.W, self.capacity)
+        self.workspace = torch.empty((nbytes,), dtype=torch.uint8, device=self.device)
+
+    @staticmethod
+    def _settings(rs_list, keep):
+        import diff_gaussian_rasterization as dgr
+        arr = (_h.GsSettings * len(rs_list))()
+        for i, rs in enumerate(rs_list):
+            arr[i] = dgr._settings_struct(rs, keep)
+        return arr
+
+    def run(self, raster_settings, params, grads, target_color, target_alpha=None, w_l1=1.0, w_l2=0.0, w_alpha_mse=0.0, scale=1.0, max_retries=3):
+        """params / grads: (xyz, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw) tensors; grads are ADDED to (zero them per step).
+        -> loss tensor (device scalar, the sum over the views).  Synchronises once, at the end, to read the overflow flag."""
+        lib = _h.lib()
+        V = len(raster_settings)
+        for attempt in range(max_retries + 1):
+            keep = []
+            views = self._settings(raster_settings, keep)
+            tc = (C.c_void_p * V)(*[t.data_ptr() for t in target_color])
+            ta = (C.c_void_p * V)(*[t.data_ptr() for t in target_alpha]) if target_alpha is not None else None
+            loss = _h.GsLoss(float(w_l1), float(w_l2), float(w_alpha_mse), float(scale))
+            snapshot = [g.clone() for g in grads] if attempt == 0 else snapshot     # to redo the step after an overflow
+            self.status.zero_(); self.loss.zero_()
+            with torch.cuda.device(self.device):
+                _h.check(lib.c3d_gs_train_views_raw(views, V, self.N, *[_h.ptr(_h.f32c(p)) for p in params], tc, ta, C.byref(loss),
+                                                    *[_h.ptr(g) for g in grads], _h.ptr(self.loss), self.capacity, _h.ptr(self.workspace),
+                                                    _h.ptr(self.status), _h.stream(self.device)), "c3d_gs_train_views_raw")
+            st = self.status.tolist()       # the single host sync of the step
+            if st[0] == 0:
+                seen = st[1] & 0xFFFFFFFF
+                if not self._fitted and self.capacity > 2 * max(seen, 1 << 16):
+                    # first successful step: every launch is sized for the capacity, so bring it down to what the scene needs (+30 %)
+                    self.capacity = int(seen * 1.3) + 4096
+                    self._alloc()
+                self._fitted = True
+                return self.loss.clone()
+            self.capacity = int(max(st[1] & 0xFFFFFFFF, self.capacity) * 1.25) + 1024
+            self._alloc()
+            for g, s0 in zip(grads, snapshot):
+                g.copy_(s0)
+        raise RuntimeError("c3d FusedViewStep: pair capacity still exceeded after %d retries" % max_retries)

@@ -47,9 +47,11 @@ int c3d_scan_u32(const uint32_t* in, uint32_t* out, size_t n, bool exclusive, vo
 // Stable LSD radix sort of (key,val) uint32 pairs over key bits [0, end_bit).
 // keys/vals are ping-pong buffers [2][n]; result index (0 or 1) is returned through *result_buf.
 // vals_in may be null on entry => values are the element indices.  tmp: c3d_sort_tmp_bytes(n).
+// n_dev (optional, device): the real element count is min(*n_dev, n) -- n is then the capacity the launch is sized for, so a
+// data-dependent count never has to come back to the host.
 size_t c3d_sort_tmp_bytes(size_t n);
 int c3d_sort_pairs_u32(uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32_t* vals1, bool iota_vals,
-                       size_t n, int end_bit, void* tmp, int* result_buf, hipStream_t s);
+                       size_t n, int end_bit, void* tmp, int* result_buf, hipStream_t s, const uint32_t* n_dev = nullptr);
 
 // ---- device helpers ----
 #ifdef __HIPCC__

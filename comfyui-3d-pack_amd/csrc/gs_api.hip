@@ -218,6 +218,86 @@ int c3d_gs_backward_raw(const c3d_gs_settings* st, int32_t N, const float* means
                                         dL_dmeans3D, dL_df_dc, dL_df_rest, dL_dscaling_raw, dL_drotation_raw, accumulate != 0, s);
 }
 
+// ---- fused multi-view training step (no host synchronisation inside) --------------------------------------------------------
+struct StepWs {
+    char* geom; char* binning; char* image; int* radii; float* color; float* depth; float* alpha; float* dcolor; float* dalpha; float* pairgrad; float* dmeans2D;
+    size_t bytes;
+};
+static void carve_step(char* base, int N, int H, int W, long long cap, StepWs& w) {
+    size_t off = 0;
+    auto take = [&](size_t b) { char* p = base ? base + off : nullptr; off += c3d_align(b); return p; };
+    const size_t P = (size_t)H * W, n = (size_t)(N > 0 ? N : 1);
+    GsGeom g; gs_carve_geom(nullptr, N, g);
+    GsBinning b; gs_carve_binning(nullptr, cap, ((W + C3D_TILE_X - 1) / C3D_TILE_X) * ((H + C3D_TILE_Y - 1) / C3D_TILE_Y), b);
+    GsImage im; gs_carve_image(nullptr, W, H, im);
+    w.geom = take(g.bytes); w.binning = take(b.bytes); w.image = take(im.bytes);
+    w.radii = (int*)take(4 * n);
+    w.color = (float*)take(12 * P); w.depth = (float*)take(4 * P); w.alpha = (float*)take(4 * P);
+    w.dcolor = (float*)take(12 * P); w.dalpha = (float*)take(4 * P);
+    w.pairgrad = (float*)take(sizeof(float) * GS_PAIR_FLOATS * (size_t)(cap > 0 ? cap : 1));
+    w.dmeans2D = (float*)take(12 * n);
+    w.bytes = off;
+}
+
+size_t c3d_gs_step_workspace_bytes(int32_t N, int32_t H, int32_t W, int64_t pair_capacity) {
+    StepWs w; carve_step(nullptr, N, H, W, pair_capacity, w); return w.bytes;
+}
+
+int c3d_gs_train_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, const float* means3D, const float* f_dc, const float* f_rest,
+                           const float* opacity_raw, const float* scaling_raw, const float* rotation_raw, const float* const* target_color,
+                           const float* const* target_alpha, const c3d_gs_loss* loss, float* dL_dmeans3D, float* dL_df_dc, float* dL_df_rest,
+                           float* dL_dopacity_raw, float* dL_dscaling_raw, float* dL_drotation_raw, float* loss_out, int64_t pair_capacity,
+                           void* workspace, uint32_t* status, c3d_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (V <= 0 || N <= 0) return 0;
+    if (!views || !loss || !target_color || !workspace || !status) { c3d_set_error("c3d_gs_train_views_raw: NULL pointer"); return -1; }
+    if (pair_capacity <= 0 || pair_capacity > 0xFFFFFFF0ll) { c3d_set_error("c3d_gs_train_views_raw: pair_capacity out of range"); return -1; }
+    if (!means3D || !f_dc || !f_rest || !opacity_raw || !scaling_raw || !rotation_raw || !dL_dmeans3D || !dL_df_dc || !dL_df_rest || !dL_dopacity_raw ||
+        !dL_dscaling_raw || !dL_drotation_raw) { c3d_set_error("c3d_gs_train_views_raw: NULL parameter / gradient pointer"); return -1; }
+    const uint32_t cap = (uint32_t)pair_capacity;
+    for (int v = 0; v < V; v++) {
+        GsParams p;
+        if (make_params(&views[v], N, 16, p)) return -1;
+        if (v > 0 && (p.W != views[0].image_width || p.H != views[0].image_height)) { c3d_set_error("c3d_gs_train_views_raw: all views must share one resolution"); return -1; }
+        if (!target_color[v]) { c3d_set_error("c3d_gs_train_views_raw: target_color[%d] is NULL", v); return -1; }
+        const int tiles = p.gx * p.gy;
+        StepWs w; carve_step((char*)workspace, N, p.H, p.W, pair_capacity, w);
+        GsGeom g; gs_carve_geom(w.geom, N, g);
+        GsBinning b; gs_carve_binning(w.binning, pair_capacity, tiles, b);
+        GsImage im; gs_carve_image(w.image, p.W, p.H, im);
+        int rc, res = 0;
+        // forward: projection, depth order, offsets -- the pair count stays on the device (g.meta[0])
+        { C3dProfScope ps(C3D_P_PREPROCESS, s);
+          if ((rc = gs_launch_preprocess_raw(p, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, g, w.radii, s))) return rc; }
+        { C3dProfScope ps(C3D_P_DEPTH_SORT, s);
+          if ((rc = c3d_sort_pairs_u32(g.key[0], g.key[1], g.order[0], g.order[1], true, (size_t)N, 32, g.tmp, &res, s))) return rc; }
+        { C3dProfScope ps(C3D_P_SCAN, s);
+          if ((rc = gs_launch_gather_tiles(g, N, res, s))) return rc;
+          if ((rc = c3d_scan_u32(g.tiles_sorted, g.offsets, (size_t)N, false, g.tmp, s))) return rc;
+          if ((rc = gs_launch_pair_count(g, N, cap, status, s))) return rc; }
+        const uint32_t* d_dev = (const uint32_t*)g.meta;
+        { C3dProfScope ps(C3D_P_EMIT, s);
+          if ((rc = gs_launch_emit(p, g, sort_result_index(32), w.radii, b, s, cap))) return rc; }
+        { C3dProfScope ps(C3D_P_TILE_SORT, s);
+          if ((rc = c3d_sort_pairs_u32(b.tkey[0], b.tkey[1], b.tval[0], b.tval[1], false, (size_t)cap, tile_sort_bits(tiles), b.tmp, &res, s, d_dev))) return rc; }
+        { C3dProfScope ps(C3D_P_RANGES, s);
+          if ((rc = gs_launch_ranges(b, res, (long long)cap, tiles, s, d_dev))) return rc; }
+        { C3dProfScope ps(C3D_P_COMPOSITE_FWD, s);
+          if ((rc = gs_launch_composite_fwd(p, g, b, res, im, w.color, w.depth, w.alpha, s))) return rc; }
+        // pixel loss and its gradient
+        { C3dProfScope ps(C3D_P_OTHER, s);
+          if ((rc = gs_launch_loss_grad(w.color, w.alpha, target_color[v], target_alpha ? target_alpha[v] : nullptr, (long long)p.W * p.H, loss->w_l1,
+                                        loss->w_l2, loss->w_alpha_mse, loss->scale, w.dcolor, w.dalpha, loss_out, s))) return rc; }
+        // backward, accumulating into the caller's gradient buffers
+        { C3dProfScope ps(C3D_P_COMPOSITE_BWD, s);
+          if ((rc = gs_launch_composite_bwd(p, g, b, res, im, w.dcolor, nullptr, w.dalpha, w.pairgrad, s, cap))) return rc; }
+        { C3dProfScope ps(C3D_P_PREPROCESS_BWD, s);
+          if ((rc = gs_launch_preprocess_bwd_raw(p, g, w.radii, means3D, f_dc, f_rest, scaling_raw, rotation_raw, w.pairgrad, w.dmeans2D, dL_dopacity_raw,
+                                                 dL_dmeans3D, dL_df_dc, dL_df_rest, dL_dscaling_raw, dL_drotation_raw, true, s, cap))) return rc; }
+    }
+    return 0;
+}
+
 int c3d_gs_mark_visible(int32_t N, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present, c3d_stream_t stream) {
     if (N > 0 && (!means3D || !viewmatrix || !present)) { c3d_set_error("c3d_gs_mark_visible: NULL pointer"); return -1; }
     return gs_launch_mark_visible(N, means3D, viewmatrix, projmatrix, present, (hipStream_t)stream);

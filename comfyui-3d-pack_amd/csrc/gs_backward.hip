@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
                                                         const float4* __restrict__ rec2, const float* __restrict__ final_T,
                                                         const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor,
                                                         const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha_px,
-                                                        float4* __restrict__ pairgrad, int chunk) {
+                                                        float4* __restrict__ pairgrad, int chunk, uint32_t cap) {
     __shared__ float4 s0[BWD_ROUND];
     __shared__ float4 s1[BWD_ROUND];
     __shared__ float4 s2[BWD_ROUND];
@@ -134,8 +134,8 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
         return ei.x + (uint32_t)((ty - ey0) * (ex1 - ex0) + (tx - ex0));
     };
     for (int pos = upto + (int)threadIdx.x; pos < todo; pos += 256) {
-        float4* r = pairgrad + (size_t)emit_index(point_list[rg.x + pos]) * 3;
-        r[0] = z4; r[1] = z4; r[2] = z4;
+        const uint32_t e = emit_index(point_list[rg.x + pos]);
+        if (e < cap) { float4* r = pairgrad + (size_t)e * 3; r[0] = z4; r[1] = z4; r[2] = z4; }
     }
 
     for (int base = 0; base < upto; base += BWD_ROUND) {
@@ -200,22 +200,24 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
 #pragma unroll
                     for (int q = 0; q < GS_PAIR_FLOATS; q++) r[q] += acc[w][q][j];
                 }
-            float4* out = pairgrad + (size_t)se[j] * 3;
-            out[0] = make_float4(r[0], r[1], r[2], r[3]);
-            out[1] = make_float4(r[4], r[5], r[6], r[7]);
-            out[2] = make_float4(r[8], r[9], r[10], r[11]);
+            if (se[j] < cap) {
+                float4* out = pairgrad + (size_t)se[j] * 3;
+                out[0] = make_float4(r[0], r[1], r[2], r[3]);
+                out[1] = make_float4(r[4], r[5], r[6], r[7]);
+                out[2] = make_float4(r[8], r[9], r[10], r[11]);
+            }
         }
     }
 }
 
 int gs_launch_composite_bwd(const GsParams& p, const GsGeom& g, const GsBinning& b, int res, const GsImage& im,
                             const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
-                            float* pairgrad, hipStream_t s) {
+                            float* pairgrad, hipStream_t s, uint32_t cap) {
     const int tiles = p.gx * p.gy;
     if (tiles == 0) return 0;
     const int chunk = c3d_cdiv(tiles, 8);
     hipLaunchKernelGGL(k_composite_bwd, dim3(chunk * 8), dim3(256), 0, s, p, b.ranges, b.tval[res], g.einfo, g.rec0, g.rec1, g.rec2,
-                       im.final_T, im.n_contrib, dL_dcolor, dL_ddepth, dL_dalpha, (float4*)pairgrad, chunk);
+                       im.final_T, im.n_contrib, dL_dcolor, dL_ddepth, dL_dalpha, (float4*)pairgrad, chunk, cap);
     C3D_LAUNCH_CHECK();
     return 0;
 }
@@ -234,7 +236,7 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GsParams p, GsGeom g, co
                                                          float* __restrict__ dL_dmean2D, float* __restrict__ dL_dcolors,
                                                          float* __restrict__ dL_dopacity, float* __restrict__ dL_dmeans3D,
                                                          float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh, float* __restrict__ dL_df_rest,
-                                                         float* __restrict__ dL_dscales, float* __restrict__ dL_drots) {
+                                                         float* __restrict__ dL_dscales, float* __restrict__ dL_drots, uint32_t cap) {
     extern __shared__ float sh_lds[];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const size_t g0 = (size_t)blockIdx.x * blockDim.x;
@@ -280,7 +282,7 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GsParams p, GsGeom g, co
     for (int q = 0; q < GS_PAIR_FLOATS; q++) pr[q] = 0.f;
     {
         const uint32_t cnt = g.tiles[idx];
-        const uint32_t e0 = cnt ? g.einfo[idx].x : 0u, e1 = e0 + cnt;
+        const uint32_t e0 = cnt ? g.einfo[idx].x : 0u, e1 = min(e0 + cnt, cap);   // cap: capacity of the pair buffers (overflow is reported, never read)
         for (uint32_t e = e0; e < e1; e++) {
             const float4 v0 = pairgrad[(size_t)e * 3], v1 = pairgrad[(size_t)e * 3 + 1], v2 = pairgrad[(size_t)e * 3 + 2];
             pr[0] += v0.x; pr[1] += v0.y; pr[2] += v0.z; pr[3] += v0.w;
@@ -469,27 +471,27 @@ int gs_launch_preprocess_bwd(const GsParams& p, const GsGeom& g, const int* radi
     if (staged)
         hipLaunchKernelGGL((k_preprocess_bwd<true, false, false>), dim3(c3d_cdiv(p.N, 256)), dim3(256), 256 * SH_ROW * sizeof(float), s, p, g, radii, means3D, shs,
                            (const float*)nullptr, colors_precomp, scales, rotations, cov3D_precomp, (const float4*)pairgrad, dL_dmean2D, dL_dcolors, dL_dopacity,
-                           dL_dmeans3D, dL_dcov3D, dL_dsh, (float*)nullptr, dL_dscales, dL_drots);
+                           dL_dmeans3D, dL_dcov3D, dL_dsh, (float*)nullptr, dL_dscales, dL_drots, 0xFFFFFFFFu);
     else
         hipLaunchKernelGGL((k_preprocess_bwd<false, false, false>), dim3(c3d_cdiv(p.N, 256)), dim3(256), 0, s, p, g, radii, means3D, shs,
                            (const float*)nullptr, colors_precomp, scales, rotations, cov3D_precomp, (const float4*)pairgrad, dL_dmean2D, dL_dcolors, dL_dopacity,
-                           dL_dmeans3D, dL_dcov3D, dL_dsh, (float*)nullptr, dL_dscales, dL_drots);
+                           dL_dmeans3D, dL_dcov3D, dL_dsh, (float*)nullptr, dL_dscales, dL_drots, 0xFFFFFFFFu);
     C3D_LAUNCH_CHECK();
     return 0;
 }
 int gs_launch_preprocess_bwd_raw(const GsParams& p, const GsGeom& g, const int* radii, const float* means3D, const float* f_dc, const float* f_rest,
                                  const float* scaling_raw, const float* rotation_raw, const float* pairgrad, float* dL_dmean2D,
                                  float* dL_dopacity_raw, float* dL_dmeans3D, float* dL_df_dc, float* dL_df_rest, float* dL_dscaling_raw,
-                                 float* dL_drotation_raw, bool accumulate, hipStream_t s) {
+                                 float* dL_drotation_raw, bool accumulate, hipStream_t s, uint32_t cap) {
     if (p.N == 0) return 0;
     if (accumulate)
         hipLaunchKernelGGL((k_preprocess_bwd<true, true, true>), dim3(c3d_cdiv(p.N, 256)), dim3(256), 256 * SH_ROW * sizeof(float), s, p, g, radii, means3D, f_dc, f_rest,
                            (const float*)nullptr, scaling_raw, rotation_raw, (const float*)nullptr, (const float4*)pairgrad, dL_dmean2D, (float*)nullptr,
-                           dL_dopacity_raw, dL_dmeans3D, (float*)nullptr, dL_df_dc, dL_df_rest, dL_dscaling_raw, dL_drotation_raw);
+                           dL_dopacity_raw, dL_dmeans3D, (float*)nullptr, dL_df_dc, dL_df_rest, dL_dscaling_raw, dL_drotation_raw, cap);
     else
         hipLaunchKernelGGL((k_preprocess_bwd<true, true, false>), dim3(c3d_cdiv(p.N, 256)), dim3(256), 256 * SH_ROW * sizeof(float), s, p, g, radii, means3D, f_dc, f_rest,
                            (const float*)nullptr, scaling_raw, rotation_raw, (const float*)nullptr, (const float4*)pairgrad, dL_dmean2D, (float*)nullptr,
-                           dL_dopacity_raw, dL_dmeans3D, (float*)nullptr, dL_df_dc, dL_df_rest, dL_dscaling_raw, dL_drotation_raw);
+                           dL_dopacity_raw, dL_dmeans3D, (float*)nullptr, dL_df_dc, dL_df_rest, dL_dscaling_raw, dL_drotation_raw, cap);
     C3D_LAUNCH_CHECK();
     return 0;
 }

@@ -153,7 +153,7 @@ int gs_launch_gather_tiles(const GsGeom& g, int N, int res, hipStream_t s) {
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_emit(GsParams p, const uint32_t* __restrict__ order, const uint32_t* __restrict__ offsets,
                                                const float4* __restrict__ rec0, const float4* __restrict__ rec2,
-                                               const int* __restrict__ radii, uint4* __restrict__ einfo, uint32_t* __restrict__ tkey, uint32_t* __restrict__ tval) {
+                                               const int* __restrict__ radii, uint4* __restrict__ einfo, uint32_t* __restrict__ tkey, uint32_t* __restrict__ tval, uint32_t cap) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= p.N) return;
     const uint32_t gid = order[r];
@@ -168,30 +168,43 @@ __global__ void __launch_bounds__(256) k_emit(GsParams p, const uint32_t* __rest
     einfo[gid] = make_uint4(off, (uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)x1 | ((uint32_t)y1 << 16), 0u);
     for (int y = y0; y < y1; y++)
         for (int x = x0; x < x1; x++) {
-            tkey[off] = (uint32_t)(y * p.gx + x);
-            tval[off] = gid;
+            if (off < cap) { tkey[off] = (uint32_t)(y * p.gx + x); tval[off] = gid; }
             off++;
         }
 }
-int gs_launch_emit(const GsParams& p, const GsGeom& g, int res, const int* radii, GsBinning& b, hipStream_t s) {
+int gs_launch_emit(const GsParams& p, const GsGeom& g, int res, const int* radii, GsBinning& b, hipStream_t s, uint32_t cap) {
     if (p.N == 0) return 0;
-    hipLaunchKernelGGL(k_emit, dim3(c3d_cdiv(p.N, 256)), dim3(256), 0, s, p, g.order[res], g.offsets, g.rec0, g.rec2, radii, g.einfo, b.tkey[0], b.tval[0]);
+    hipLaunchKernelGGL(k_emit, dim3(c3d_cdiv(p.N, 256)), dim3(256), 0, s, p, g.order[res], g.offsets, g.rec0, g.rec2, radii, g.einfo, b.tkey[0], b.tval[0], cap);
     C3D_LAUNCH_CHECK();
     return 0;
 }
 
 // A5: [start,end) of every tile in the sorted pair list
-__global__ void __launch_bounds__(256) k_ranges(const uint32_t* __restrict__ tkey, uint2* __restrict__ ranges, long long D) {
+__global__ void __launch_bounds__(256) k_ranges(const uint32_t* __restrict__ tkey, uint2* __restrict__ ranges, long long D, const uint32_t* __restrict__ d_dev) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d_dev) D = min((long long)*d_dev, D);
     if (i >= D) return;
     const uint32_t t = tkey[i];
     if (i == 0 || tkey[i - 1] != t) ranges[t].x = (uint32_t)i;
     if (i == D - 1 || tkey[i + 1] != t) ranges[t].y = (uint32_t)(i + 1);
 }
-int gs_launch_ranges(const GsBinning& b, int res, long long D, int tiles, hipStream_t s) {
+// pair count kept on the device: meta[0] = min(total, cap) (what the sort / ranges kernels use), status[0] |= overflow, status[1] = max total
+__global__ void k_pair_count(const uint32_t* __restrict__ offsets, int N, uint32_t cap, uint32_t* __restrict__ meta, uint32_t* __restrict__ status) {
+    const uint32_t tot = offsets[N - 1];
+    meta[0] = tot < cap ? tot : cap;
+    if (status) { if (tot > cap) atomicOr(&status[0], 1u); atomicMax(&status[1], tot); }
+}
+int gs_launch_pair_count(const GsGeom& g, int N, uint32_t cap, uint32_t* status, hipStream_t s) {
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(k_pair_count, dim3(1), dim3(1), 0, s, g.offsets, N, cap, (uint32_t*)g.meta, status);
+    C3D_LAUNCH_CHECK();
+    return 0;
+}
+
+int gs_launch_ranges(const GsBinning& b, int res, long long D, int tiles, hipStream_t s, const uint32_t* d_dev) {
     C3D_CHECK(hipMemsetAsync(b.ranges, 0, sizeof(uint2) * (size_t)(tiles > 0 ? tiles : 1), s));
     if (D == 0) return 0;
-    hipLaunchKernelGGL(k_ranges, dim3(c3d_cdiv(D, 256)), dim3(256), 0, s, b.tkey[res], b.ranges, D);
+    hipLaunchKernelGGL(k_ranges, dim3(c3d_cdiv(D, 256)), dim3(256), 0, s, b.tkey[res], b.ranges, D, d_dev);
     C3D_LAUNCH_CHECK();
     return 0;
 }
@@ -283,6 +296,45 @@ int gs_launch_composite_fwd(const GsParams& p, const GsGeom& g, const GsBinning&
     const int chunk = c3d_cdiv(tiles, 8);
     hipLaunchKernelGGL(k_composite_fwd, dim3(chunk * 8), dim3(256), 0, s, p, b.ranges, b.tval[res], g.rec0, g.rec1, g.rec2,
                        out_color, out_depth, out_alpha, im.final_T, im.n_contrib, chunk);
+    C3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Pixel loss of the fused training step: L = scale * [ w_l1 mean|c - t| + w_l2 mean (c - t)^2 + w_a mean (alpha - ta)^2 ], with the rendered
+// colour clamped to [0,1] first (GaussianSplattingRenderer.render returns image.clamp(0,1)).  Writes dL/dcolor, dL/dalpha and adds the
+// loss value to *loss_out.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_loss_grad(const float* __restrict__ color, const float* __restrict__ alpha, const float* __restrict__ tcolor,
+                                                    const float* __restrict__ talpha, long long P, float w_l1, float w_l2, float w_a, float scale,
+                                                    float* __restrict__ dcolor, float* __restrict__ dalpha, float* __restrict__ loss_out) {
+    __shared__ float red[4];
+    float l = 0.f;
+    const float inv3p = 1.f / (3.f * (float)P), invp = 1.f / (float)P;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (long long)gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            const float c = color[ch * P + i];
+            const float cc = fminf(fmaxf(c, 0.f), 1.f);
+            const float d = cc - tcolor[ch * P + i];
+            l += (w_l1 * fabsf(d) + w_l2 * d * d) * inv3p;
+            const float pass = (c >= 0.f && c <= 1.f) ? 1.f : 0.f;
+            const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+            dcolor[ch * P + i] = scale * pass * (w_l1 * sg + 2.f * w_l2 * d) * inv3p;
+        }
+        float da = 0.f;
+        if (talpha) { const float d = alpha[i] - talpha[i]; l += w_a * d * d * invp; da = scale * 2.f * w_a * d * invp; }
+        dalpha[i] = da;
+    }
+    l = c3d_wave_sum(l * scale);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = l;
+    __syncthreads();
+    if (threadIdx.x == 0 && loss_out) atomicAdd(loss_out, red[0] + red[1] + red[2] + red[3]);   // one atomic per workgroup, <= 1024 workgroups
+}
+int gs_launch_loss_grad(const float* color, const float* alpha, const float* tcolor, const float* talpha, long long P, float w_l1, float w_l2, float w_a,
+                        float scale, float* dcolor, float* dalpha, float* loss_out, hipStream_t s) {
+    if (P == 0) return 0;
+    hipLaunchKernelGGL(k_loss_grad, dim3(min(c3d_cdiv(P, 256), 1024)), dim3(256), 0, s, color, alpha, tcolor, talpha, P, w_l1, w_l2, w_a, scale, dcolor, dalpha, loss_out);
     C3D_LAUNCH_CHECK();
     return 0;
 }

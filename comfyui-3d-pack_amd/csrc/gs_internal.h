@@ -101,15 +101,18 @@ int gs_launch_preprocess_raw(const GsParams& p, const float* means3D, const floa
 int gs_launch_preprocess_bwd_raw(const GsParams& p, const GsGeom& g, const int* radii, const float* means3D, const float* f_dc, const float* f_rest,
                                  const float* scaling_raw, const float* rotation_raw, const float* pairgrad, float* dL_dmean2D,
                                  float* dL_dopacity_raw, float* dL_dmeans3D, float* dL_df_dc, float* dL_df_rest, float* dL_dscaling_raw,
-                                 float* dL_drotation_raw, bool accumulate, hipStream_t s);
+                                 float* dL_drotation_raw, bool accumulate, hipStream_t s, uint32_t cap = 0xFFFFFFFFu);
 int gs_launch_gather_tiles(const GsGeom& g, int N, int res, hipStream_t s);
-int gs_launch_emit(const GsParams& p, const GsGeom& g, int res, const int* radii, GsBinning& b, hipStream_t s);
-int gs_launch_ranges(const GsBinning& b, int res, long long D, int tiles, hipStream_t s);
+int gs_launch_emit(const GsParams& p, const GsGeom& g, int res, const int* radii, GsBinning& b, hipStream_t s, uint32_t cap = 0xFFFFFFFFu);
+int gs_launch_pair_count(const GsGeom& g, int N, uint32_t cap, uint32_t* status, hipStream_t s);
+int gs_launch_loss_grad(const float* color, const float* alpha, const float* tcolor, const float* talpha, long long P, float w_l1, float w_l2, float w_a,
+                        float scale, float* dcolor, float* dalpha, float* loss_out, hipStream_t s);
+int gs_launch_ranges(const GsBinning& b, int res, long long D, int tiles, hipStream_t s, const uint32_t* d_dev = nullptr);
 int gs_launch_composite_fwd(const GsParams& p, const GsGeom& g, const GsBinning& b, int res, GsImage& im,
                             float* out_color, float* out_depth, float* out_alpha, hipStream_t s);
 int gs_launch_composite_bwd(const GsParams& p, const GsGeom& g, const GsBinning& b, int res, const GsImage& im,
                             const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
-                            float* pairgrad /* [D][12] */, hipStream_t s);
+                            float* pairgrad /* [D][12] */, hipStream_t s, uint32_t cap = 0xFFFFFFFFu);
 int gs_launch_preprocess_bwd(const GsParams& p, const GsGeom& g, const int* radii, const float* means3D, const float* shs,
                              const float* colors_precomp, const float* scales, const float* rotations, const float* cov3D_precomp,
                              const float* pairgrad, float* dL_dmean2D, float* dL_dcolors, float* dL_dopacity,

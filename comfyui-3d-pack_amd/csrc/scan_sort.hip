@@ -102,15 +102,26 @@ int c3d_scan_u32(const uint32_t* in, uint32_t* out, size_t n, bool exclusive, vo
 #define RS_RADIX 256
 
 __global__ void __launch_bounds__(RS_THREADS) k_radix_hist(const uint32_t* __restrict__ keys, uint32_t* __restrict__ table,
-                                                            uint32_t* __restrict__ total, size_t n, int shift, int nblocks) {
+                                                            uint32_t* __restrict__ total, size_t n, const uint32_t* __restrict__ n_dev, int shift, int nblocks) {
     __shared__ uint32_t h[RS_RADIX];
+    if (n_dev) n = min((size_t)*n_dev, n);      // element count resident on the device (no host round trip)
+    size_t base = (size_t)blockIdx.x * RS_TILE;
+    if (base >= n) { table[(size_t)threadIdx.x * nblocks + blockIdx.x] = 0; return; }   // capacity-sized launch: nothing here
     h[threadIdx.x] = 0;
     __syncthreads();
-    size_t base = (size_t)blockIdx.x * RS_TILE;
+    const int lane = c3d_lane();
 #pragma unroll
     for (int i = 0; i < RS_ITEMS; i++) {
         size_t idx = base + (size_t)i * RS_THREADS + threadIdx.x;
-        if (idx < n) atomicAdd(&h[(keys[idx] >> shift) & (RS_RADIX - 1)], 1u);
+        const bool ok = idx < n;
+        const uint32_t d = ok ? ((keys[idx] >> shift) & (RS_RADIX - 1)) : 0u;
+        // high digits of depth keys / tile ids are nearly constant: a wave whose lanes all hold one digit adds its count once
+        // instead of serialising 64 LDS atomics on one counter
+        const uint64_t okm = __ballot(ok);
+        const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
+        if (okm && __ballot(ok && d == d0) == okm) {
+            if (lane == (int)__builtin_ctzll(okm)) atomicAdd(&h[d0], (uint32_t)__popcll(okm));
+        } else if (ok) atomicAdd(&h[d], 1u);
     }
     __syncthreads();
     const uint32_t c = h[threadIdx.x];
@@ -140,8 +151,10 @@ __global__ void __launch_bounds__(RS_THREADS) k_radix_rowscan(uint32_t* __restri
 template <bool IOTA>
 __global__ void __launch_bounds__(RS_THREADS) k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                                uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
-                                                               const uint32_t* __restrict__ table, size_t n, int shift, int nblocks) {
+                                                               const uint32_t* __restrict__ table, size_t n, const uint32_t* __restrict__ n_dev,
+                                                               int shift, int nblocks) {
     __shared__ uint32_t whist[RS_THREADS / 64][RS_RADIX];
+    if (n_dev) n = min((size_t)*n_dev, n);
     __shared__ uint32_t lstart[RS_RADIX];    // first local slot of each digit
     __shared__ uint32_t gbase[RS_RADIX];     // global position of that slot
     __shared__ uint32_t skey[RS_TILE];
@@ -203,7 +216,7 @@ __global__ void __launch_bounds__(RS_THREADS) k_radix_scatter(const uint32_t* __
         }
     }
     __syncthreads();
-    const int cnt = (int)((n - bbase) < (size_t)RS_TILE ? (n - bbase) : (size_t)RS_TILE);
+    const int cnt = (bbase >= n) ? 0 : (int)((n - bbase) < (size_t)RS_TILE ? (n - bbase) : (size_t)RS_TILE);
 #pragma unroll
     for (int i = 0; i < RS_ITEMS; i++) {
         const int lp = i * RS_THREADS + threadIdx.x;     // consecutive lanes -> consecutive slots of a digit run
@@ -224,7 +237,7 @@ size_t c3d_sort_tmp_bytes(size_t n) {
 }
 
 int c3d_sort_pairs_u32(uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32_t* vals1, bool iota_vals,
-                       size_t n, int end_bit, void* tmp, int* result_buf, hipStream_t s) {
+                       size_t n, int end_bit, void* tmp, int* result_buf, hipStream_t s, const uint32_t* n_dev) {
     *result_buf = 0;
     if (n == 0) return 0;
     if (end_bit > 8 * RS_MAX_PASSES) { c3d_set_error("c3d_sort_pairs_u32: end_bit %d > %d", end_bit, 8 * RS_MAX_PASSES); return -1; }
@@ -238,12 +251,12 @@ int c3d_sort_pairs_u32(uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32
     bool first = true;
     for (int shift = 0; shift < end_bit || first; shift += 8, pass++) {
         uint32_t* tot = totals + pass * RS_RADIX;
-        hipLaunchKernelGGL(k_radix_hist, dim3(nb), dim3(RS_THREADS), 0, s, k[cur], table, tot, n, shift, nb);
+        hipLaunchKernelGGL(k_radix_hist, dim3(nb), dim3(RS_THREADS), 0, s, k[cur], table, tot, n, n_dev, shift, nb);
         hipLaunchKernelGGL(k_radix_rowscan, dim3(RS_RADIX / (RS_THREADS / 64)), dim3(RS_THREADS), 0, s, table, tot, nb);
         if (first && iota_vals)
-            hipLaunchKernelGGL(k_radix_scatter<true>, dim3(nb), dim3(RS_THREADS), 0, s, k[cur], v[cur], k[cur ^ 1], v[cur ^ 1], table, n, shift, nb);
+            hipLaunchKernelGGL(k_radix_scatter<true>, dim3(nb), dim3(RS_THREADS), 0, s, k[cur], v[cur], k[cur ^ 1], v[cur ^ 1], table, n, n_dev, shift, nb);
         else
-            hipLaunchKernelGGL(k_radix_scatter<false>, dim3(nb), dim3(RS_THREADS), 0, s, k[cur], v[cur], k[cur ^ 1], v[cur ^ 1], table, n, shift, nb);
+            hipLaunchKernelGGL(k_radix_scatter<false>, dim3(nb), dim3(RS_THREADS), 0, s, k[cur], v[cur], k[cur ^ 1], v[cur ^ 1], table, n, n_dev, shift, nb);
         C3D_LAUNCH_CHECK();
         cur ^= 1;
         first = false;
