@@ -241,7 +241,7 @@ def main():
         if fused_step is not None and not collect:
             for gq in step_grads:
                 gq.zero_()
-            fused_step.run(settings, [q.detach() for q in plist], step_grads, [tg[0] for tg in targets], [tg[1] for tg in targets],
+            fused_step.run(settings, [q.detach() for q in plist], step_grads, [tg[0] for tg in targets], [tg[1] for tg in targets], None,
                            w_l1=0.8, w_l2=0.0, w_alpha_mse=3.0, scale=1.0 / (a.views_per_gpu * world))
             for q, gq in zip(plist, step_grads):
                 q.grad = gq

@@ -81,7 +81,7 @@ class GaussianSplatting3D:
         self.ms_ssim_loss = MS_SSIM(data_range=1, size_average=True, channel=3)
         self.params = [g._xyz, g._features_dc, g._features_rest, g._opacity, g._scaling, g._rotation]
         parallel.broadcast_parameters(self.params, src=0, group=process_group)
-        self.use_fused_step, self._step = False, None      # opt-in: see _fused_step for the one semantic difference (masking)
+        self.use_fused_step, self._step = True, None       # taken whenever the loss has no MS-SSIM / offset terms (see _can_fuse)
 
     def prepare_training(self, reference_images, reference_masks, reference_orbit_camera_poses, reference_orbit_camera_fovy):
         self.ref_imgs_num = len(reference_images)
@@ -111,8 +111,9 @@ class GaussianSplatting3D:
             imgs.append((out["image"] * m).unsqueeze(0)); refs.append((self.ref_imgs_torch[i] * m).unsqueeze(0))
             alphas.append(out["alpha"].unsqueeze(0)); masks.append(m.unsqueeze(0))
         imgs, refs, alphas, masks = torch.cat(imgs), torch.cat(refs), torch.cat(alphas), torch.cat(masks)
-        loss = (1 - p.lambda_ssim) * F.l1_loss(imgs, refs) + p.lambda_alpha * F.mse_loss(alphas, masks) \
-            + p.lambda_ssim * (1 - self.ms_ssim_loss(refs, imgs))
+        loss = (1 - p.lambda_ssim) * F.l1_loss(imgs, refs) + p.lambda_alpha * F.mse_loss(alphas, masks)
+        if p.lambda_ssim > 0:
+            loss = loss + p.lambda_ssim * (1 - self.ms_ssim_loss(refs, imgs))
         g = self.renderer.gaussians
         if p.lambda_offset > 0 or p.lambda_offset_opacity > 0:
             off = (g.init_xyz - g._xyz).norm(dim=-1, keepdim=True)
@@ -131,7 +132,7 @@ class GaussianSplatting3D:
     def _can_fuse(self):
         p, g = self.gs_params, self.renderer.gaussians
         return (self.use_fused_step and self.device.type == "cuda" and p.lambda_ssim == 0 and p.lambda_offset == 0 and p.lambda_offset_opacity == 0
-                and g.max_sh_degree == 3 and self.cam_controller.static_bg is not None)
+                and g.max_sh_degree == 3 and (self.cam_controller.static_bg is not None or p.invert_bg_prob in (0.0, 1.0)))
 
     def _fused_step(self, mine, global_batch, world):
         import math
@@ -149,14 +150,14 @@ class GaussianSplatting3D:
             radius, elev, azim, cx, cy, cz = self.all_ref_cam_poses[i]
             cam = MiniCam(orbit_camera(elev, azim, radius, target=np.array([cx, cy, cz], dtype=np.float32)), W, H, ctl.cam.fovy, ctl.cam.fovx,
                           ctl.cam.near, ctl.cam.far, ctl.projection_matrix, device=self.device)
-            views.append(GaussianRasterizationSettings(H, W, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), ctl.static_bg, 1.0,
+            bg = ctl.static_bg if ctl.static_bg is not None else (ctl.white_bg if p.invert_bg_prob == 0.0 else ctl.black_bg)
+            views.append(GaussianRasterizationSettings(H, W, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), bg, 1.0,
                                                        cam.world_view_transform, cam.full_proj_transform, 3, cam.camera_center, False, False))
-        # NOTE: the fused loss uses the unmasked render against the masked reference; identical to the reference's masked L1 wherever the
-        # mask is 1 and a stricter (background must match) objective elsewhere.  Exact masked parity needs lambda_ssim > 0 -> autograd path.
         for gq in self._step_grads:
             gq.zero_()
         loss = self._step.run(views, [q.detach() for q in self.params], self._step_grads, [self._masked_refs[i].contiguous() for i in mine],
-                              [self.ref_masks_torch[i].contiguous() for i in mine], w_l1=1.0, w_l2=0.0, w_alpha_mse=p.lambda_alpha, scale=1.0 / max(len(mine), 1))
+                              [self.ref_masks_torch[i].contiguous() for i in mine], [self.ref_masks_torch[i].contiguous() for i in mine],
+                              w_l1=1.0 - p.lambda_ssim, w_l2=0.0, w_alpha_mse=p.lambda_alpha, scale=1.0 / max(len(mine), 1))
         for q, gq in zip(self.params, self._step_grads):
             q.grad = gq
         parallel.exchange_gradients(self.params, self.group, self.exchange, average=True)

@@ -30,7 +30,7 @@ class FusedViewStep:
             arr[i] = dgr._settings_struct(rs, keep)
         return arr
 
-    def run(self, raster_settings, params, grads, target_color, target_alpha=None, w_l1=1.0, w_l2=0.0, w_alpha_mse=0.0, scale=1.0, max_retries=3):
+    def run(self, raster_settings, params, grads, target_color, target_alpha=None, color_mask=None, w_l1=1.0, w_l2=0.0, w_alpha_mse=0.0, scale=1.0, max_retries=3):
         """params / grads: (xyz, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw) tensors; grads are ADDED to (zero them per step).
         -> loss tensor (device scalar, the sum over the views).  Synchronises once, at the end, to read the overflow flag."""
         lib = _h.lib()
@@ -40,11 +40,12 @@ class FusedViewStep:
             views = self._settings(raster_settings, keep)
             tc = (C.c_void_p * V)(*[t.data_ptr() for t in target_color])
             ta = (C.c_void_p * V)(*[t.data_ptr() for t in target_alpha]) if target_alpha is not None else None
+            cm = (C.c_void_p * V)(*[t.data_ptr() for t in color_mask]) if color_mask is not None else None
             loss = _h.GsLoss(float(w_l1), float(w_l2), float(w_alpha_mse), float(scale))
             snapshot = [g.clone() for g in grads] if attempt == 0 else snapshot     # to redo the step after an overflow
             self.status.zero_(); self.loss.zero_()
             with torch.cuda.device(self.device):
-                _h.check(lib.c3d_gs_train_views_raw(views, V, self.N, *[_h.ptr(_h.f32c(p)) for p in params], tc, ta, C.byref(loss),
+                _h.check(lib.c3d_gs_train_views_raw(views, V, self.N, *[_h.ptr(_h.f32c(p)) for p in params], tc, ta, cm, C.byref(loss),
                                                     *[_h.ptr(g) for g in grads], _h.ptr(self.loss), self.capacity, _h.ptr(self.workspace),
                                                     _h.ptr(self.status), _h.stream(self.device)), "c3d_gs_train_views_raw")
             st = self.status.tolist()       # the single host sync of the step

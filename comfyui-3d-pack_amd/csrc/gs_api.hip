@@ -245,7 +245,7 @@ size_t c3d_gs_step_workspace_bytes(int32_t N, int32_t H, int32_t W, int64_t pair
 
 int c3d_gs_train_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, const float* means3D, const float* f_dc, const float* f_rest,
                            const float* opacity_raw, const float* scaling_raw, const float* rotation_raw, const float* const* target_color,
-                           const float* const* target_alpha, const c3d_gs_loss* loss, float* dL_dmeans3D, float* dL_df_dc, float* dL_df_rest,
+                           const float* const* target_alpha, const float* const* color_mask, const c3d_gs_loss* loss, float* dL_dmeans3D, float* dL_df_dc, float* dL_df_rest,
                            float* dL_dopacity_raw, float* dL_dscaling_raw, float* dL_drotation_raw, float* loss_out, int64_t pair_capacity,
                            void* workspace, uint32_t* status, c3d_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
@@ -286,7 +286,7 @@ int c3d_gs_train_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, c
           if ((rc = gs_launch_composite_fwd(p, g, b, res, im, w.color, w.depth, w.alpha, s))) return rc; }
         // pixel loss and its gradient
         { C3dProfScope ps(C3D_P_OTHER, s);
-          if ((rc = gs_launch_loss_grad(w.color, w.alpha, target_color[v], target_alpha ? target_alpha[v] : nullptr, (long long)p.W * p.H, loss->w_l1,
+          if ((rc = gs_launch_loss_grad(w.color, w.alpha, target_color[v], target_alpha ? target_alpha[v] : nullptr, color_mask ? color_mask[v] : nullptr, (long long)p.W * p.H, loss->w_l1,
                                         loss->w_l2, loss->w_alpha_mse, loss->scale, w.dcolor, w.dalpha, loss_out, s))) return rc; }
         // backward, accumulating into the caller's gradient buffers
         { C3dProfScope ps(C3D_P_COMPOSITE_BWD, s);

@@ -306,7 +306,7 @@ int gs_launch_composite_fwd(const GsParams& p, const GsGeom& g, const GsBinning&
 // loss value to *loss_out.
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_loss_grad(const float* __restrict__ color, const float* __restrict__ alpha, const float* __restrict__ tcolor,
-                                                    const float* __restrict__ talpha, long long P, float w_l1, float w_l2, float w_a, float scale,
+                                                    const float* __restrict__ talpha, const float* __restrict__ cmask, long long P, float w_l1, float w_l2, float w_a, float scale,
                                                     float* __restrict__ dcolor, float* __restrict__ dalpha, float* __restrict__ loss_out) {
     __shared__ float red[4];
     float l = 0.f;
@@ -316,11 +316,12 @@ __global__ void __launch_bounds__(256) k_loss_grad(const float* __restrict__ col
         for (int ch = 0; ch < 3; ch++) {
             const float c = color[ch * P + i];
             const float cc = fminf(fmaxf(c, 0.f), 1.f);
-            const float d = cc - tcolor[ch * P + i];
+            const float mk = cmask ? cmask[i] : 1.f;              // optional per-pixel weight: loss on (image * mask) vs (target * mask)
+            const float d = (cc - tcolor[ch * P + i]) * mk;
             l += (w_l1 * fabsf(d) + w_l2 * d * d) * inv3p;
             const float pass = (c >= 0.f && c <= 1.f) ? 1.f : 0.f;
             const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-            dcolor[ch * P + i] = scale * pass * (w_l1 * sg + 2.f * w_l2 * d) * inv3p;
+            dcolor[ch * P + i] = scale * pass * mk * (w_l1 * sg + 2.f * w_l2 * d) * inv3p;
         }
         float da = 0.f;
         if (talpha) { const float d = alpha[i] - talpha[i]; l += w_a * d * d * invp; da = scale * 2.f * w_a * d * invp; }
@@ -331,10 +332,10 @@ __global__ void __launch_bounds__(256) k_loss_grad(const float* __restrict__ col
     __syncthreads();
     if (threadIdx.x == 0 && loss_out) atomicAdd(loss_out, red[0] + red[1] + red[2] + red[3]);   // one atomic per workgroup, <= 1024 workgroups
 }
-int gs_launch_loss_grad(const float* color, const float* alpha, const float* tcolor, const float* talpha, long long P, float w_l1, float w_l2, float w_a,
+int gs_launch_loss_grad(const float* color, const float* alpha, const float* tcolor, const float* talpha, const float* cmask, long long P, float w_l1, float w_l2, float w_a,
                         float scale, float* dcolor, float* dalpha, float* loss_out, hipStream_t s) {
     if (P == 0) return 0;
-    hipLaunchKernelGGL(k_loss_grad, dim3(min(c3d_cdiv(P, 256), 1024)), dim3(256), 0, s, color, alpha, tcolor, talpha, P, w_l1, w_l2, w_a, scale, dcolor, dalpha, loss_out);
+    hipLaunchKernelGGL(k_loss_grad, dim3(min(c3d_cdiv(P, 256), 1024)), dim3(256), 0, s, color, alpha, tcolor, talpha, cmask, P, w_l1, w_l2, w_a, scale, dcolor, dalpha, loss_out);
     C3D_LAUNCH_CHECK();
     return 0;
 }

@@ -105,7 +105,7 @@ int gs_launch_preprocess_bwd_raw(const GsParams& p, const GsGeom& g, const int* 
 int gs_launch_gather_tiles(const GsGeom& g, int N, int res, hipStream_t s);
 int gs_launch_emit(const GsParams& p, const GsGeom& g, int res, const int* radii, GsBinning& b, hipStream_t s, uint32_t cap = 0xFFFFFFFFu);
 int gs_launch_pair_count(const GsGeom& g, int N, uint32_t cap, uint32_t* status, hipStream_t s);
-int gs_launch_loss_grad(const float* color, const float* alpha, const float* tcolor, const float* talpha, long long P, float w_l1, float w_l2, float w_a,
+int gs_launch_loss_grad(const float* color, const float* alpha, const float* tcolor, const float* talpha, const float* cmask, long long P, float w_l1, float w_l2, float w_a,
                         float scale, float* dcolor, float* dalpha, float* loss_out, hipStream_t s);
 int gs_launch_ranges(const GsBinning& b, int res, long long D, int tiles, hipStream_t s, const uint32_t* d_dev = nullptr);
 int gs_launch_composite_fwd(const GsParams& p, const GsGeom& g, const GsBinning& b, int res, GsImage& im,

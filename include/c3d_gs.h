@@ -121,12 +121,14 @@ int c3d_gs_backward_raw(const c3d_gs_settings* st, int32_t N, const float* means
  * launch is sized for `pair_capacity`.  status[0] becomes non-zero if a view needed more pairs than that (results are then
  * invalid: enlarge and redo the step), status[1] holds the largest pair count seen.  loss_out (device float) accumulates the value
  *   scale * sum_v [ w_l1 mean|clamp(C_v,0,1) - Ct_v| + w_l2 mean(clamp(C_v,0,1) - Ct_v)^2 + w_alpha_mse mean(A_v - At_v)^2 ].
- * target_color / target_alpha: HOST arrays of V device pointers ([3,H,W] / [1,H,W]; target_alpha may be NULL). */
+ * target_color / target_alpha / color_mask: HOST arrays of V device pointers ([3,H,W] / [1,H,W] / [1,H,W]); target_alpha and color_mask may be
+ * NULL.  With color_mask the colour terms compare (C * mask) with (Ct * mask), the reference's masked loss (main_3DGS.py:169-186). */
 typedef struct c3d_gs_loss { float w_l1; float w_l2; float w_alpha_mse; float scale; } c3d_gs_loss;
 size_t c3d_gs_step_workspace_bytes(int32_t N, int32_t image_height, int32_t image_width, int64_t pair_capacity);
 int c3d_gs_train_views_raw(const c3d_gs_settings* views /* host [V] */, int32_t V, int32_t N, const float* means3D, const float* f_dc,
                            const float* f_rest, const float* opacity_raw, const float* scaling_raw, const float* rotation_raw,
-                           const float* const* target_color, const float* const* target_alpha, const c3d_gs_loss* loss,
+                           const float* const* target_color, const float* const* target_alpha, const float* const* color_mask,
+                           const c3d_gs_loss* loss,
                            float* dL_dmeans3D, float* dL_df_dc, float* dL_df_rest, float* dL_dopacity_raw, float* dL_dscaling_raw,
                            float* dL_drotation_raw, float* loss_out, int64_t pair_capacity, void* workspace,
                            uint32_t* status /* device [2] */, c3d_stream_t stream);

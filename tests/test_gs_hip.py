@@ -438,12 +438,37 @@ def test_fused_multi_view_step_matches_autograd():
     # fused step, deliberately tiny capacity first to exercise the regrow path
     step = FusedViewStep(40000, H, W, "cuda", pair_capacity=5000)
     grads = [torch.zeros_like(p) for p in plist]
-    lv = step.run(rs_list, [p.detach() for p in plist], grads, tcs, tas, w_l1=0.8, w_l2=0.3, w_alpha_mse=3.0, scale=0.5)
+    lv = step.run(rs_list, [p.detach() for p in plist], grads, tcs, tas, None, w_l1=0.8, w_l2=0.3, w_alpha_mse=3.0, scale=0.5)
     assert step.capacity > 5000
     assert abs(lv.item() - total) <= 1e-4 * max(1.0, abs(total))
     for a, b, name in zip(grads, ref, ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")):
         assert rel_err(a.cpu().numpy(), b.cpu().numpy()) <= 5e-4, name
     # second call accumulates on top
-    lv2 = step.run(rs_list, [p.detach() for p in plist], grads, tcs, tas, w_l1=0.8, w_l2=0.3, w_alpha_mse=3.0, scale=0.5)
+    lv2 = step.run(rs_list, [p.detach() for p in plist], grads, tcs, tas, None, w_l1=0.8, w_l2=0.3, w_alpha_mse=3.0, scale=0.5)
     for a, b in zip(grads, ref):
         assert rel_err(a.cpu().numpy(), 2 * b.cpu().numpy()) <= 5e-4
+
+
+def test_trainer_fused_step_equals_autograd_step():
+    """GaussianSplatting3D.training_step with lambda_ssim = 0: the fused library step and the per-view autograd path produce the same
+    loss and leave the same parameters after an Adam step (masked L1 + alpha MSE of main_3DGS.py:169-190)."""
+    from MVs_Algorithms.GaussianSplatting.main_3DGS import GSParams, GaussianSplatting3D
+    H = W = 160
+    poses = [[1.75, -10.0, az, 0.0, 0.0, 0.0] for az in (0.0, 120.0, -120.0)]
+    rng = np.random.default_rng(1)
+    refs = [torch.tensor(rng.uniform(size=(H, W, 3)).astype(np.float32)) for _ in poses]
+    masks = [torch.tensor((rng.uniform(size=(H, W)) > 0.4).astype(np.float32)) for _ in poses]
+    results = []
+    for fused in (True, False):
+        np.random.seed(3); torch.manual_seed(3)
+        p = GSParams(training_iterations=2, batch_size=3, lambda_ssim=0.0, num_pts=5000, density_start_iter=10 ** 9, density_end_iter=-1, invert_bg_prob=1.0)
+        tr = GaussianSplatting3D(p, None, device="cuda")
+        tr.use_fused_step = fused
+        tr.prepare_training(refs, masks, poses, 49.1)
+        assert tr._can_fuse() == fused
+        losses = [tr.training_step(s, [0, 1, 2]).item() for s in range(2)]
+        results.append((losses, [q.detach().clone() for q in tr.params]))
+    (l1, p1), (l2, p2) = results
+    assert abs(l1[0] - l2[0]) <= 1e-5 * max(1, abs(l2[0])) and abs(l1[1] - l2[1]) <= 1e-4 * max(1, abs(l2[1]))
+    for a, b in zip(p1, p2):
+        assert (a - b).abs().max().item() <= 2e-4 * max(1.0, b.abs().max().item())
