@@ -317,6 +317,18 @@ def main():
     for name, (ms, n) in prof.items():
         kern[name]["share"] = round(ms / tot, 3)
     roof = None
+    # HBM traffic of the dominant kernel: rocprofv3 PMC counters cannot be read from inside the process, so the per-launch figure comes
+    # from the committed summary of two separate --pmc passes over this same command (profiles/summarize_pmc.py; FETCH_SIZE raw + WRITE_SIZE,
+    # MI355X_MICROARCH.md: FETCH_SIZE under-reports wide streaming reads by 2x on gfx950 -- both figures are in the file).
+    pmc = {}
+    try:
+        cand = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))
+        if cand:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", cand[-1])))
+    except Exception:
+        pmc = {}
+    pmc_name = {"gs_composite_bwd": "k_composite_bwd", "gs_composite_fwd": "k_composite_fwd", "gs_preprocess": "k_preprocess<true, true>",
+                "gs_preprocess_bwd": "k_preprocess_bwd<true, true, true>", "gs_emit": "k_emit"}
     if prof:
         dom = max(prof, key=lambda k: prof[k][0])
         avg_s = prof[dom][0] / prof[dom][1] * 1e-3
@@ -324,6 +336,10 @@ def main():
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None, "avg_ms": round(avg_s * 1e3, 4),
                 "alg_bytes_per_launch": int(alg.get(dom, 0))}
+        rec = pmc.get(pmc_name.get(dom, ""))
+        if rec and a.workload == "gs" and N == 1_000_000 and (W, H) == (1920, 1080):
+            roof["traffic"] = int((rec["fetch_MB_raw"] + rec["write_MB"]) * 1e6)
+            roof["traffic_note"] = "FETCH_SIZE(raw)+WRITE_SIZE per launch from profiles/%s; fetch x2-corrected: %d" % (cand[-1], int((rec["fetch_MB_x2"] + rec["write_MB"]) * 1e6))
 
     cpu = None
     if rank == 0 and world == 1 and a.cpu_baseline != "off":
