@@ -10,8 +10,10 @@ import c3d_hip as _h
 
 
 class FusedViewStep:
-    def __init__(self, N, H, W, device, pair_capacity=None):
+    def __init__(self, N, H, W, device, pair_capacity=None, lanes=4):
+        """lanes: number of HIP streams the views of a step are dealt onto (1..8); see include/c3d_gs.h."""
         self.N, self.H, self.W, self.device = N, H, W, torch.device(device)
+        self.lanes = max(1, min(8, int(lanes)))
         self.capacity = int(pair_capacity or max(8 * N, 1 << 22))
         self.status = torch.zeros(2, dtype=torch.int32, device=self.device)
         self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
@@ -19,7 +21,7 @@ class FusedViewStep:
         self._alloc()
 
     def _alloc(self):
-        nbytes = _h.lib().c3d_gs_step_workspace_bytes(self.N, self.H, self.W, self.capacity)
+        nbytes = _h.lib().c3d_gs_step_workspace_bytes(self.N, self.H, self.W, self.capacity, self.lanes)
         self.workspace = torch.empty((nbytes,), dtype=torch.uint8, device=self.device)
 
     @staticmethod
@@ -46,7 +48,7 @@ class FusedViewStep:
             self.status.zero_(); self.loss.zero_()
             with torch.cuda.device(self.device):
                 _h.check(lib.c3d_gs_train_views_raw(views, V, self.N, *[_h.ptr(_h.f32c(p)) for p in params], tc, ta, cm, C.byref(loss),
-                                                    *[_h.ptr(g) for g in grads], _h.ptr(self.loss), self.capacity, _h.ptr(self.workspace),
+                                                    *[_h.ptr(g) for g in grads], _h.ptr(self.loss), self.capacity, self.lanes, _h.ptr(self.workspace),
                                                     _h.ptr(self.status), _h.stream(self.device)), "c3d_gs_train_views_raw")
             st = self.status.tolist()       # the single host sync of the step
             if st[0] == 0:

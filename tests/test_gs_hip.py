@@ -402,9 +402,10 @@ def test_fused_activation_path_equals_accessor_path():
     assert rel_err(v1.cpu().numpy(), v2.cpu().numpy()) <= 2e-4
 
 
-def test_fused_multi_view_step_matches_autograd():
-    """c3d_gs_train_views_raw (V views, pixel loss and backward in one sync-free call) against the per-view autograd path with the
-    same loss; also the overflow / regrow path."""
+@pytest.mark.parametrize("lanes", [1, 2, 3])
+def test_fused_multi_view_step_matches_autograd(lanes):
+    """c3d_gs_train_views_raw (V views, pixel loss and backward in one sync-free call, views dealt onto `lanes` HIP streams) against the
+    per-view autograd path with the same loss; also the overflow / regrow path and run-to-run bit reproducibility."""
     from MVs_Algorithms.GaussianSplatting.main_3DGS_renderer import GaussianSplattingRenderer
     from c3d_hip.gs_step import FusedViewStep
     import diff_gaussian_rasterization as dgr
@@ -436,7 +437,7 @@ def test_fused_multi_view_step_matches_autograd():
     for p in plist:
         p.grad = None
     # fused step, deliberately tiny capacity first to exercise the regrow path
-    step = FusedViewStep(40000, H, W, "cuda", pair_capacity=5000)
+    step = FusedViewStep(40000, H, W, "cuda", pair_capacity=5000, lanes=lanes)
     grads = [torch.zeros_like(p) for p in plist]
     lv = step.run(rs_list, [p.detach() for p in plist], grads, tcs, tas, None, w_l1=0.8, w_l2=0.3, w_alpha_mse=3.0, scale=0.5)
     assert step.capacity > 5000
@@ -447,6 +448,14 @@ def test_fused_multi_view_step_matches_autograd():
     lv2 = step.run(rs_list, [p.detach() for p in plist], grads, tcs, tas, None, w_l1=0.8, w_l2=0.3, w_alpha_mse=3.0, scale=0.5)
     for a, b in zip(grads, ref):
         assert rel_err(a.cpu().numpy(), 2 * b.cpu().numpy()) <= 5e-4
+    # fixed lane count -> fixed summation order -> identical bits from run to run
+    runs = []
+    for _ in range(2):
+        gz = [torch.zeros_like(p) for p in plist]
+        step.run(rs_list, [p.detach() for p in plist], gz, tcs, tas, None, w_l1=0.8, w_l2=0.3, w_alpha_mse=3.0, scale=0.5)
+        runs.append(gz)
+    for a, b in zip(*runs):
+        assert torch.equal(a, b)
 
 
 def test_trainer_fused_step_equals_autograd_step():
