@@ -127,7 +127,7 @@ def main_mesh(a, world, rank, dev, dist):
     prof_conc = None
     if fused_step is not None and fused_step.lanes > 1:
         prof_conc = prof
-        lanes_step, fused_step = fused_step, FusedViewStep(N, H, W, dev, lanes=1, pair_capacity=fused_step.capacity)
+        lanes_step, fused_step = fused_step, FusedViewStep(N, H, W, dev, lanes=1, pair_capacity=fused_step.capacity, views=len(settings))
         fused_step._fitted = True
         step()
         sync()
@@ -251,17 +251,15 @@ def main():
     fused_step = None
     if a.render_path == "step" and a.mode != "fwd":
         from c3d_hip.gs_step import FusedViewStep
-        fused_step = FusedViewStep(N, H, W, dev, lanes=a.lanes)
+        fused_step = FusedViewStep(N, H, W, dev, lanes=a.lanes, views=len(settings))
         step_grads = [torch.zeros_like(q) for q in plist]
         for q, gq in zip(plist, step_grads):
             q.grad = gq                      # the optimizer / exchange read .grad; the library accumulates into these buffers
 
     def step(collect=False):
         if fused_step is not None and not collect:
-            for gq in step_grads:
-                gq.zero_()
             fused_step.run(settings, [q.detach() for q in plist], step_grads, [tg[0] for tg in targets], [tg[1] for tg in targets], None,
-                           w_l1=0.8, w_l2=0.0, w_alpha_mse=3.0, scale=1.0 / (a.views_per_gpu * world))
+                           w_l1=0.8, w_l2=0.0, w_alpha_mse=3.0, scale=1.0 / (a.views_per_gpu * world), accumulate=False)
             for q, gq in zip(plist, step_grads):
                 q.grad = gq
         else:
@@ -322,7 +320,7 @@ def main():
     prof_conc = None
     if fused_step is not None and fused_step.lanes > 1:
         prof_conc = prof
-        lanes_step, fused_step = fused_step, FusedViewStep(N, H, W, dev, lanes=1, pair_capacity=fused_step.capacity)
+        lanes_step, fused_step = fused_step, FusedViewStep(N, H, W, dev, lanes=1, pair_capacity=fused_step.capacity, views=len(settings))
         fused_step._fitted = True
         step()
         sync()

@@ -153,11 +153,10 @@ class GaussianSplatting3D:
             bg = ctl.static_bg if ctl.static_bg is not None else (ctl.white_bg if p.invert_bg_prob == 0.0 else ctl.black_bg)
             views.append(GaussianRasterizationSettings(H, W, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), bg, 1.0,
                                                        cam.world_view_transform, cam.full_proj_transform, 3, cam.camera_center, False, False))
-        for gq in self._step_grads:
-            gq.zero_()
         loss = self._step.run(views, [q.detach() for q in self.params], self._step_grads, [self._masked_refs[i].contiguous() for i in mine],
                               [self.ref_masks_torch[i].contiguous() for i in mine], [self.ref_masks_torch[i].contiguous() for i in mine],
-                              w_l1=1.0 - p.lambda_ssim, w_l2=0.0, w_alpha_mse=p.lambda_alpha, scale=1.0 / max(len(mine), 1))
+                              w_l1=1.0 - p.lambda_ssim, w_l2=0.0, w_alpha_mse=p.lambda_alpha, scale=1.0 / max(len(mine), 1),
+                              accumulate=False)      # every gradient is written exactly once: no zero-fill
         for q, gq in zip(self.params, self._step_grads):
             q.grad = gq
         parallel.exchange_gradients(self.params, self.group, self.exchange, average=True)

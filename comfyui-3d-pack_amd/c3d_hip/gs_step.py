@@ -10,10 +10,12 @@ import c3d_hip as _h
 
 
 class FusedViewStep:
-    def __init__(self, N, H, W, device, pair_capacity=None, lanes=4):
-        """lanes: number of HIP streams the views of a step are dealt onto (1..8); see include/c3d_gs.h."""
+    def __init__(self, N, H, W, device, pair_capacity=None, lanes=4, views=1):
+        """lanes: number of HIP streams the views of a step are dealt onto (1..8); views: views per step the workspace is sized for
+        (it grows on demand); see include/c3d_gs.h."""
         self.N, self.H, self.W, self.device = N, H, W, torch.device(device)
         self.lanes = max(1, min(8, int(lanes)))
+        self.views = max(1, int(views))
         self.capacity = int(pair_capacity or max(8 * N, 1 << 22))
         self.status = torch.zeros(2, dtype=torch.int32, device=self.device)
         self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
@@ -21,7 +23,7 @@ class FusedViewStep:
         self._alloc()
 
     def _alloc(self):
-        nbytes = _h.lib().c3d_gs_step_workspace_bytes(self.N, self.H, self.W, self.capacity, self.lanes)
+        nbytes = _h.lib().c3d_gs_step_workspace_bytes(self.N, self.H, self.W, self.capacity, self.views)
         self.workspace = torch.empty((nbytes,), dtype=torch.uint8, device=self.device)
 
     @staticmethod
@@ -32,11 +34,21 @@ class FusedViewStep:
             arr[i] = dgr._settings_struct(rs, keep)
         return arr
 
-    def run(self, raster_settings, params, grads, target_color, target_alpha=None, color_mask=None, w_l1=1.0, w_l2=0.0, w_alpha_mse=0.0, scale=1.0, max_retries=3):
-        """params / grads: (xyz, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw) tensors; grads are ADDED to (zero them per step).
-        -> loss tensor (device scalar, the sum over the views).  Synchronises once, at the end, to read the overflow flag."""
+    def run(self, raster_settings, params, grads, target_color, target_alpha=None, color_mask=None, w_l1=1.0, w_l2=0.0, w_alpha_mse=0.0, scale=1.0, max_retries=3,
+            accumulate=True):
+        """params / grads: (xyz, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw) tensors; accumulate=True adds to the grads (zero them per
+        step), False overwrites them (no zero-fill needed).  -> loss tensor (device scalar, the sum over the views).  Synchronises once, at
+        the end, to read the overflow flag."""
         lib = _h.lib()
         V = len(raster_settings)
+        if V == 0:                       # a rank without views this step still owns well-defined gradients
+            if not accumulate:
+                for g in grads:
+                    g.zero_()
+            return torch.zeros(1, dtype=torch.float32, device=self.device)
+        if V > self.views:
+            self.views = V
+            self._alloc()
         for attempt in range(max_retries + 1):
             keep = []
             views = self._settings(raster_settings, keep)
@@ -44,11 +56,12 @@ class FusedViewStep:
             ta = (C.c_void_p * V)(*[t.data_ptr() for t in target_alpha]) if target_alpha is not None else None
             cm = (C.c_void_p * V)(*[t.data_ptr() for t in color_mask]) if color_mask is not None else None
             loss = _h.GsLoss(float(w_l1), float(w_l2), float(w_alpha_mse), float(scale))
-            snapshot = [g.clone() for g in grads] if attempt == 0 else snapshot     # to redo the step after an overflow
+            if accumulate:
+                snapshot = [g.clone() for g in grads] if attempt == 0 else snapshot     # to redo the step after an overflow
             self.status.zero_(); self.loss.zero_()
             with torch.cuda.device(self.device):
                 _h.check(lib.c3d_gs_train_views_raw(views, V, self.N, *[_h.ptr(_h.f32c(p)) for p in params], tc, ta, cm, C.byref(loss),
-                                                    *[_h.ptr(g) for g in grads], _h.ptr(self.loss), self.capacity, self.lanes, _h.ptr(self.workspace),
+                                                    *[_h.ptr(g) for g in grads], _h.ptr(self.loss), self.capacity, self.lanes, 1 if accumulate else 0, _h.ptr(self.workspace),
                                                     _h.ptr(self.status), _h.stream(self.device)), "c3d_gs_train_views_raw")
             st = self.status.tolist()       # the single host sync of the step
             if st[0] == 0:
@@ -61,6 +74,7 @@ class FusedViewStep:
                 return self.loss.clone()
             self.capacity = int(max(st[1] & 0xFFFFFFFF, self.capacity) * 1.25) + 1024
             self._alloc()
-            for g, s0 in zip(grads, snapshot):
-                g.copy_(s0)
+            if accumulate:
+                for g, s0 in zip(grads, snapshot):
+                    g.copy_(s0)
         raise RuntimeError("c3d FusedViewStep: pair capacity still exceeded after %d retries" % max_retries)

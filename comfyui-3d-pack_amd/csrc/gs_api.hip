@@ -240,18 +240,10 @@ static void carve_step(char* base, int N, int H, int W, long long cap, StepWs& w
     w.bytes = off;
 }
 
-// ---- view lanes: V views are dealt round-robin onto `lanes` HIP streams (lane 0 = the caller's stream) so that the latency-bound
-// sort / scan chains of one view run underneath the VALU-bound compositing kernels of another.  Each lane owns a workspace and, for
-// lanes > 0, a private gradient set; the sets are folded into the caller's buffers in lane order at the join (bit-reproducible).
+// ---- view lanes: the V views of a step are dealt round-robin onto `lanes` HIP streams (lane 0 = the caller's stream) so that the latency-bound
+// sort / scan chains of one view run underneath the VALU-bound compositing kernels of another.  Every view owns a workspace slice; after the
+// join ONE pass over the Gaussians (k_preprocess_bwd_views) turns all views' pair records into the parameter gradients.
 #define C3D_MAX_LANES 8
-struct GradSet { float* p[6]; size_t bytes; };   // means3D, f_dc, f_rest, opacity, scaling, rotation
-static const int kGradWidth[6] = {3, 3, 45, 1, 3, 4};
-static void carve_gradset(char* base, int N, GradSet& gs) {
-    size_t off = 0;
-    const size_t n = (size_t)(N > 0 ? N : 1);
-    for (int i = 0; i < 6; i++) { gs.p[i] = base ? (float*)(base + off) : nullptr; off += c3d_align(sizeof(float) * kGradWidth[i] * n); }
-    gs.bytes = off;
-}
 namespace {
 struct LanePool { bool init = false; hipStream_t st[C3D_MAX_LANES - 1]; hipEvent_t fork, join[C3D_MAX_LANES - 1]; };
 LanePool g_lanes[16];
@@ -275,44 +267,16 @@ int lane_pool(LanePool** out) {
 }
 }  // namespace
 
-// dst[arr] += src[0][arr] + src[1][arr] + ... in lane order, one pass over all sets
-struct MergeArgs { float* dst[6]; const float* src[C3D_MAX_LANES - 1][6]; int nsrc; };
-__global__ void __launch_bounds__(256) k_grad_merge(MergeArgs a, int N) {
-    const int arr = blockIdx.y;
-    const size_t total = (size_t)N * (size_t)(arr == 2 ? 45 : arr == 3 ? 1 : arr == 5 ? 4 : 3);
-    float* __restrict__ d = a.dst[arr];
-    uintptr_t bits = (uintptr_t)d;
-    for (int l = 0; l < a.nsrc; l++) bits |= (uintptr_t)a.src[l][arr];
-    const size_t stride = (size_t)gridDim.x * blockDim.x, t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t n4 = (bits & 15) == 0 ? total / 4 : 0;
-    for (size_t i = t0; i < n4; i += stride) {
-        float4 x = reinterpret_cast<float4*>(d)[i];
-        for (int l = 0; l < a.nsrc; l++) {
-            const float4 y = reinterpret_cast<const float4*>(a.src[l][arr])[i];
-            x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
-        }
-        reinterpret_cast<float4*>(d)[i] = x;
-    }
-    for (size_t i = n4 * 4 + t0; i < total; i += stride) {
-        float x = d[i];
-        for (int l = 0; l < a.nsrc; l++) x += a.src[l][arr][i];
-        d[i] = x;
-    }
-}
-
-size_t c3d_gs_step_workspace_bytes(int32_t N, int32_t H, int32_t W, int64_t pair_capacity, int32_t lanes) {
-    if (lanes < 1) lanes = 1;
-    if (lanes > C3D_MAX_LANES) lanes = C3D_MAX_LANES;
+size_t c3d_gs_step_workspace_bytes(int32_t N, int32_t H, int32_t W, int64_t pair_capacity, int32_t views) {
     StepWs w; carve_step(nullptr, N, H, W, pair_capacity, w);
-    GradSet gs; carve_gradset(nullptr, N, gs);
-    return (size_t)lanes * w.bytes + (size_t)(lanes - 1) * gs.bytes;
+    return (size_t)(views > 0 ? views : 1) * w.bytes;
 }
 
 int c3d_gs_train_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, const float* means3D, const float* f_dc, const float* f_rest,
                            const float* opacity_raw, const float* scaling_raw, const float* rotation_raw, const float* const* target_color,
                            const float* const* target_alpha, const float* const* color_mask, const c3d_gs_loss* loss, float* dL_dmeans3D, float* dL_df_dc, float* dL_df_rest,
                            float* dL_dopacity_raw, float* dL_dscaling_raw, float* dL_drotation_raw, float* loss_out, int64_t pair_capacity, int32_t lanes,
-                           void* workspace, uint32_t* status, c3d_stream_t stream) {
+                           int32_t accumulate, void* workspace, uint32_t* status, c3d_stream_t stream) {
     hipStream_t s0 = (hipStream_t)stream;
     if (V <= 0 || N <= 0) return 0;
     if (!views || !loss || !target_color || !workspace || !status) { c3d_set_error("c3d_gs_train_views_raw: NULL pointer"); return -1; }
@@ -320,11 +284,10 @@ int c3d_gs_train_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, c
     if (lanes < 1 || lanes > C3D_MAX_LANES) { c3d_set_error("c3d_gs_train_views_raw: lanes must be in [1, %d]", C3D_MAX_LANES); return -1; }
     if (!means3D || !f_dc || !f_rest || !opacity_raw || !scaling_raw || !rotation_raw || !dL_dmeans3D || !dL_df_dc || !dL_df_rest || !dL_dopacity_raw ||
         !dL_dscaling_raw || !dL_drotation_raw) { c3d_set_error("c3d_gs_train_views_raw: NULL parameter / gradient pointer"); return -1; }
+    if ((uintptr_t)f_rest % 16 || (uintptr_t)dL_df_rest % 16 || (uintptr_t)rotation_raw % 16 || (uintptr_t)dL_drotation_raw % 16) { c3d_set_error("c3d_gs_train_views_raw: f_rest / rotation tensors must be 16-byte aligned"); return -1; }
     const uint32_t cap = (uint32_t)pair_capacity;
-    const int L = lanes < V ? lanes : V;   // lanes actually used (the workspace layout still follows `lanes`)
+    const int L = lanes < V ? lanes : V;
     StepWs w0; carve_step(nullptr, N, views[0].image_height, views[0].image_width, pair_capacity, w0);
-    GradSet gs0; carve_gradset(nullptr, N, gs0);
-    char* const grad_base = (char*)workspace + (size_t)lanes * w0.bytes;
     LanePool* lp = nullptr;
     hipStream_t ls[C3D_MAX_LANES] = {s0};
     if (L > 1) {
@@ -333,23 +296,21 @@ int c3d_gs_train_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, c
         for (int l = 1; l < L; l++) { ls[l] = lp->st[l - 1]; C3D_CHECK(hipStreamWaitEvent(ls[l], lp->fork, 0)); }
     }
     int rc_all = 0;
+    GsParams p_first{};
     for (int v = 0; v < V && !rc_all; v++) {
-        const int lane = v % L;
-        hipStream_t s = ls[lane];
+        hipStream_t s = ls[v % L];
         GsParams p;
         if (make_params(&views[v], N, 16, p)) { rc_all = -1; break; }
-        if (v > 0 && (p.W != views[0].image_width || p.H != views[0].image_height)) { c3d_set_error("c3d_gs_train_views_raw: all views must share one resolution"); rc_all = -1; break; }
+        if (v == 0) p_first = p;
+        if (v > 0 && (p.W != views[0].image_width || p.H != views[0].image_height || p.deg != p_first.deg || p.scale_modifier != p_first.scale_modifier)) {
+            c3d_set_error("c3d_gs_train_views_raw: all views must share resolution, sh_degree and scale_modifier"); rc_all = -1; break;
+        }
         if (!target_color[v]) { c3d_set_error("c3d_gs_train_views_raw: target_color[%d] is NULL", v); rc_all = -1; break; }
         const int tiles = p.gx * p.gy;
-        StepWs w; carve_step((char*)workspace + (size_t)lane * w0.bytes, N, p.H, p.W, pair_capacity, w);
+        StepWs w; carve_step((char*)workspace + (size_t)v * w0.bytes, N, p.H, p.W, pair_capacity, w);
         GsGeom g; gs_carve_geom(w.geom, N, g);
         GsBinning b; gs_carve_binning(w.binning, pair_capacity, tiles, b);
         GsImage im; gs_carve_image(w.image, p.W, p.H, im);
-        // lane 0 adds into the caller's buffers; the other lanes own a gradient set (overwritten by their first view, then added to)
-        GradSet gset;
-        if (lane == 0) { gset.p[0] = dL_dmeans3D; gset.p[1] = dL_df_dc; gset.p[2] = dL_df_rest; gset.p[3] = dL_dopacity_raw; gset.p[4] = dL_dscaling_raw; gset.p[5] = dL_drotation_raw; }
-        else carve_gradset(grad_base + (size_t)(lane - 1) * gs0.bytes, N, gset);
-        const bool acc = lane == 0 || v >= L;
         int rc = 0, res = 0;
         do {
             // forward: projection, depth order, offsets -- the pair count stays on the device (g.meta[0])
@@ -374,12 +335,9 @@ int c3d_gs_train_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, c
             { C3dProfScope ps(C3D_P_OTHER, s);
               if ((rc = gs_launch_loss_grad(w.color, w.alpha, target_color[v], target_alpha ? target_alpha[v] : nullptr, color_mask ? color_mask[v] : nullptr, (long long)p.W * p.H, loss->w_l1,
                                             loss->w_l2, loss->w_alpha_mse, loss->scale, w.dcolor, w.dalpha, loss_out, s))) break; }
-            // backward into the lane's gradient set
+            // backward down to the per-(tile, splat) records of this view
             { C3dProfScope ps(C3D_P_COMPOSITE_BWD, s);
               if ((rc = gs_launch_composite_bwd(p, g, b, res, im, w.dcolor, nullptr, w.dalpha, w.pairgrad, s, cap))) break; }
-            { C3dProfScope ps(C3D_P_PREPROCESS_BWD, s);
-              if ((rc = gs_launch_preprocess_bwd_raw(p, g, w.radii, means3D, f_dc, f_rest, scaling_raw, rotation_raw, w.pairgrad, w.dmeans2D, gset.p[3],
-                                                     gset.p[0], gset.p[1], gset.p[2], gset.p[4], gset.p[5], acc, s, cap))) break; }
         } while (0);
         rc_all = rc;
     }
@@ -391,19 +349,24 @@ int c3d_gs_train_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, c
         }
     }
     if (rc_all) return rc_all;
-    if (L > 1) {
-        MergeArgs a;
-        float* dst[6] = {dL_dmeans3D, dL_df_dc, dL_df_rest, dL_dopacity_raw, dL_dscaling_raw, dL_drotation_raw};
-        for (int i = 0; i < 6; i++) a.dst[i] = dst[i];
-        a.nsrc = L - 1;
-        for (int l = 1; l < L; l++) {
-            GradSet gset; carve_gradset(grad_base + (size_t)(l - 1) * gs0.bytes, N, gset);
-            for (int i = 0; i < 6; i++) a.src[l - 1][i] = gset.p[i];
+    // per-Gaussian chain rule over all views, every gradient written once (chunks of GS_MAX_BWD_VIEWS views)
+    for (int v0 = 0; v0 < V; v0 += GS_MAX_BWD_VIEWS) {
+        GsBwdViews bv;
+        bv.V = (V - v0) < GS_MAX_BWD_VIEWS ? (V - v0) : GS_MAX_BWD_VIEWS;
+        for (int i = 0; i < bv.V; i++) {
+            GsParams p;
+            if (make_params(&views[v0 + i], N, 16, p)) return -1;
+            StepWs w; carve_step((char*)workspace + (size_t)(v0 + i) * w0.bytes, N, p.H, p.W, pair_capacity, w);
+            GsGeom g; gs_carve_geom(w.geom, N, g);
+            GsBwdView& o = bv.v[i];
+            o.view = p.view; o.proj = p.proj; o.campos = p.campos; o.radii = w.radii; o.rec0 = g.rec0; o.rec1 = g.rec1; o.tiles = g.tiles; o.einfo = g.einfo;
+            o.clamped = g.clamped; o.pairgrad = (const float4*)w.pairgrad; o.dmean2D = w.dmeans2D;
+            o.tanfovx = p.tanfovx; o.tanfovy = p.tanfovy; o.focal_x = p.focal_x; o.focal_y = p.focal_y;
         }
-        for (int l = L; l < C3D_MAX_LANES; l++) for (int i = 0; i < 6; i++) a.src[l - 1][i] = nullptr;
-        C3dProfScope ps(C3D_P_OTHER, s0);
-        hipLaunchKernelGGL(k_grad_merge, dim3(1024, 6), dim3(256), 0, s0, a, N);
-        C3D_LAUNCH_CHECK();
+        int rc;
+        C3dProfScope ps(C3D_P_PREPROCESS_BWD, s0);
+        if ((rc = gs_launch_preprocess_bwd_views(p_first, bv, means3D, f_dc, f_rest, scaling_raw, rotation_raw, dL_dopacity_raw, dL_dmeans3D, dL_df_dc, dL_df_rest,
+                                                 dL_dscaling_raw, dL_drotation_raw, accumulate != 0 || v0 > 0, s0, cap))) return rc;
     }
     return 0;
 }

@@ -223,6 +223,92 @@ int gs_launch_composite_bwd(const GsParams& p, const GsGeom& g, const GsBinning&
 }
 
 // ------------------------------------------------------------------------------------------
+// Per-view geometric chain rule shared by the A8 kernels: summed moments of one Gaussian in one view -> gradient of the projected mean
+// (NDC-scaled, g2x/g2y), contribution to the 3D mean (EWA Jacobian, projection, depth output) and to the 3D covariance.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bwd_geom_chain(const float3 m, const float c3[6], const Mat16& V, const Mat16& PJ, float tanfovx, float tanfovy,
+                                               float focal_x, float focal_y, int W, int H, float cA, float cB, float cC, float m1x, float m1y,
+                                               float m2xx, float m2xy, float m2yy, float g_depth, float& g2x, float& g2y, float dmean[3], float dcov[6]) {
+    g2x = -(cA * m1x + cB * m1y) * (0.5f * W);
+    g2y = -(cC * m1y + cB * m1x) * (0.5f * H);
+    const float dcx = -0.5f * m2xx, dcy = -0.5f * m2xy, dcz = -0.5f * m2yy;
+    float T2[2][3], ST0[3], ST1[3];
+    float3 t; bool xin, yin;
+    ewa_T2(m, V, tanfovx, tanfovy, focal_x, focal_y, T2, t, xin, yin);
+    sigma_T(c3, T2, ST0, ST1);
+    const float a = T2[0][0] * ST0[0] + T2[0][1] * ST0[1] + T2[0][2] * ST0[2] + 0.3f;
+    const float b = T2[0][0] * ST1[0] + T2[0][1] * ST1[1] + T2[0][2] * ST1[2];
+    const float c = T2[1][0] * ST1[0] + T2[1][1] * ST1[1] + T2[1][2] * ST1[2] + 0.3f;
+    const float denom = a * c - b * b;
+    const float d2i = 1.f / (denom * denom + 0.0000001f);
+    float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; i++) dcov[i] = 0.f;
+    if (d2i != 0.f) {
+        dL_da = d2i * (-c * c * dcx + 2.f * b * c * dcy + (denom - a * c) * dcz);
+        dL_dc = d2i * (-a * a * dcz + 2.f * a * b * dcy + (denom - a * c) * dcx);
+        dL_db = d2i * 2.f * (b * c * dcx - (denom + 2.f * b * b) * dcy + a * b * dcz);
+        dcov[0] = T2[0][0] * T2[0][0] * dL_da + T2[0][0] * T2[1][0] * dL_db + T2[1][0] * T2[1][0] * dL_dc;
+        dcov[3] = T2[0][1] * T2[0][1] * dL_da + T2[0][1] * T2[1][1] * dL_db + T2[1][1] * T2[1][1] * dL_dc;
+        dcov[5] = T2[0][2] * T2[0][2] * dL_da + T2[0][2] * T2[1][2] * dL_db + T2[1][2] * T2[1][2] * dL_dc;
+        dcov[1] = 2.f * T2[0][0] * T2[0][1] * dL_da + (T2[0][0] * T2[1][1] + T2[0][1] * T2[1][0]) * dL_db + 2.f * T2[1][0] * T2[1][1] * dL_dc;
+        dcov[2] = 2.f * T2[0][0] * T2[0][2] * dL_da + (T2[0][0] * T2[1][2] + T2[0][2] * T2[1][0]) * dL_db + 2.f * T2[1][0] * T2[1][2] * dL_dc;
+        dcov[4] = 2.f * T2[0][2] * T2[0][1] * dL_da + (T2[0][1] * T2[1][2] + T2[0][2] * T2[1][1]) * dL_db + 2.f * T2[1][1] * T2[1][2] * dL_dc;
+    }
+    float dT[2][3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        dT[0][k] = 2.f * ST0[k] * dL_da + ST1[k] * dL_db;
+        dT[1][k] = 2.f * ST1[k] * dL_dc + ST0[k] * dL_db;
+    }
+    const float dJ00 = V.m[0] * dT[0][0] + V.m[4] * dT[0][1] + V.m[8] * dT[0][2];
+    const float dJ02 = V.m[2] * dT[0][0] + V.m[6] * dT[0][1] + V.m[10] * dT[0][2];
+    const float dJ11 = V.m[1] * dT[1][0] + V.m[5] * dT[1][1] + V.m[9] * dT[1][2];
+    const float dJ12 = V.m[2] * dT[1][0] + V.m[6] * dT[1][1] + V.m[10] * dT[1][2];
+    const float tz = 1.f / t.z, tz2 = tz * tz, tz3 = tz2 * tz;
+    const float dtx = (xin ? 1.f : 0.f) * (-focal_x * tz2 * dJ02);
+    const float dty = (yin ? 1.f : 0.f) * (-focal_y * tz2 * dJ12);
+    const float dtz = -focal_x * tz2 * dJ00 - focal_y * tz2 * dJ11 + (2.f * focal_x * t.x) * tz3 * dJ02 + (2.f * focal_y * t.y) * tz3 * dJ12;
+#pragma unroll
+    for (int j = 0; j < 3; j++) dmean[j] = V.m[4 * j] * dtx + V.m[4 * j + 1] * dty + V.m[4 * j + 2] * dtz;
+    // screen-space mean (NDC-scaled gradient) -> 3D mean
+    const float4 mh = xform4x4(m, PJ);
+    const float mw = 1.f / (mh.w + 0.0000001f);
+    const float mul1 = mh.x * mw * mw, mul2 = mh.y * mw * mw;
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+        dmean[j] += (PJ.m[4 * j] * mw - PJ.m[4 * j + 3] * mul1) * g2x + (PJ.m[4 * j + 1] * mw - PJ.m[4 * j + 3] * mul2) * g2y;
+    // depth output -> 3D mean
+    const float mul3 = V.m[2] * m.x + V.m[6] * m.y + V.m[10] * m.z + V.m[14];
+#pragma unroll
+    for (int j = 0; j < 3; j++) dmean[j] += (V.m[4 * j + 2] - V.m[4 * j + 3] * mul3) * g_depth;
+}
+
+// cov3D gradient -> scale and (unnormalised-quaternion) rotation gradients; exact derivative, d/dscale carries scale_modifier
+__device__ __forceinline__ void bwd_cov_to_scale_rot(const float dcov[6], const float3 sc, const float4 q, float scale_modifier, float gs3[3], float4& dq) {
+    float R[3][3];
+    quat_to_R(q, R);
+    const float s[3] = {scale_modifier * sc.x, scale_modifier * sc.y, scale_modifier * sc.z};
+    const float Gm[3][3] = {{dcov[0], 0.5f * dcov[1], 0.5f * dcov[2]}, {0.5f * dcov[1], dcov[3], 0.5f * dcov[4]}, {0.5f * dcov[2], 0.5f * dcov[4], dcov[5]}};
+    float dM[3][3], dR[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) dM[i][k] = 2.f * (Gm[i][0] * R[0][k] + Gm[i][1] * R[1][k] + Gm[i][2] * R[2][k]) * s[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        gs3[k] = scale_modifier * (dM[0][k] * R[0][k] + dM[1][k] * R[1][k] + dM[2][k] * R[2][k]);
+#pragma unroll
+        for (int i = 0; i < 3; i++) dR[i][k] = dM[i][k] * s[k];
+    }
+    const float r = q.x, x = q.y, y = q.z, z = q.w;
+    dq.x = 2.f * (-z * dR[0][1] + y * dR[0][2] + z * dR[1][0] - x * dR[1][2] - y * dR[2][0] + x * dR[2][1]);
+    dq.y = 2.f * (y * dR[0][1] + z * dR[0][2] + y * dR[1][0] - 2.f * x * dR[1][1] - r * dR[1][2] + z * dR[2][0] + r * dR[2][1] - 2.f * x * dR[2][2]);
+    dq.z = 2.f * (-2.f * y * dR[0][0] + x * dR[0][1] + r * dR[0][2] + x * dR[1][0] + z * dR[1][2] - r * dR[2][0] + z * dR[2][1] - 2.f * y * dR[2][2]);
+    dq.w = 2.f * (-2.f * z * dR[0][0] - r * dR[0][1] + x * dR[0][2] + r * dR[1][0] - 2.f * z * dR[1][1] + y * dR[1][2] + x * dR[2][0] + y * dR[2][1]);
+}
+
+// ------------------------------------------------------------------------------------------
 // A8 preprocess backward: one lane per Gaussian, pure streaming.
 // ------------------------------------------------------------------------------------------
 // RAW: inputs are the raw parameters (see k_preprocess) and the outputs are gradients w.r.t. them: the exp / sigmoid / normalize
@@ -296,9 +382,6 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GsParams p, GsGeom g, co
     const float4 q0 = g.rec0[idx], q1 = g.rec1[idx];
     const float cA = q0.z, cB = q0.w, cC = q1.x, opac = q1.y;
     const float m0 = pr[4], m1y = pr[5], m1x = pr[6], m2xx = pr[7], m2xy = pr[8], m2yy = pr[10];
-    const float g2x = -(cA * m1x + cB * m1y) * (0.5f * p.W), g2y = -(cC * m1y + cB * m1x) * (0.5f * p.H);
-    const float dcx = -0.5f * m2xx, dcy = -0.5f * m2xy, dcz = -0.5f * m2yy;
-    dL_dmean2D[3 * idx] = g2x; dL_dmean2D[3 * idx + 1] = g2y; dL_dmean2D[3 * idx + 2] = 0.f;
     if (dL_dcolors) { dL_dcolors[3 * idx] = gcol[0]; dL_dcolors[3 * idx + 1] = gcol[1]; dL_dcolors[3 * idx + 2] = gcol[2]; }
     {
         float go = (opac > 0.f) ? m0 / opac : 0.f;
@@ -326,63 +409,12 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GsParams p, GsGeom g, co
         }
         cov3d_from_scale_rot(sc, p.scale_modifier, q, c3);
     }
-    float T2[2][3], ST0[3], ST1[3];
-    float3 t; bool xin, yin;
-    ewa_T2(m, V, p.tanfovx, p.tanfovy, p.focal_x, p.focal_y, T2, t, xin, yin);
-    sigma_T(c3, T2, ST0, ST1);
-    const float a = T2[0][0] * ST0[0] + T2[0][1] * ST0[1] + T2[0][2] * ST0[2] + 0.3f;
-    const float b = T2[0][0] * ST1[0] + T2[0][1] * ST1[1] + T2[0][2] * ST1[2];
-    const float c = T2[1][0] * ST1[0] + T2[1][1] * ST1[1] + T2[1][2] * ST1[2] + 0.3f;
-    const float denom = a * c - b * b;
-    const float d2i = 1.f / (denom * denom + 0.0000001f);
-    float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
-    float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (d2i != 0.f) {
-        dL_da = d2i * (-c * c * dcx + 2.f * b * c * dcy + (denom - a * c) * dcz);
-        dL_dc = d2i * (-a * a * dcz + 2.f * a * b * dcy + (denom - a * c) * dcx);
-        dL_db = d2i * 2.f * (b * c * dcx - (denom + 2.f * b * b) * dcy + a * b * dcz);
-        dcov[0] = T2[0][0] * T2[0][0] * dL_da + T2[0][0] * T2[1][0] * dL_db + T2[1][0] * T2[1][0] * dL_dc;
-        dcov[3] = T2[0][1] * T2[0][1] * dL_da + T2[0][1] * T2[1][1] * dL_db + T2[1][1] * T2[1][1] * dL_dc;
-        dcov[5] = T2[0][2] * T2[0][2] * dL_da + T2[0][2] * T2[1][2] * dL_db + T2[1][2] * T2[1][2] * dL_dc;
-        dcov[1] = 2.f * T2[0][0] * T2[0][1] * dL_da + (T2[0][0] * T2[1][1] + T2[0][1] * T2[1][0]) * dL_db + 2.f * T2[1][0] * T2[1][1] * dL_dc;
-        dcov[2] = 2.f * T2[0][0] * T2[0][2] * dL_da + (T2[0][0] * T2[1][2] + T2[0][2] * T2[1][0]) * dL_db + 2.f * T2[1][0] * T2[1][2] * dL_dc;
-        dcov[4] = 2.f * T2[0][2] * T2[0][1] * dL_da + (T2[0][1] * T2[1][2] + T2[0][2] * T2[1][1]) * dL_db + 2.f * T2[1][1] * T2[1][2] * dL_dc;
-    }
+    float g2x, g2y, dmean[3], dcov[6];
+    bwd_geom_chain(m, c3, V, PJ, p.tanfovx, p.tanfovy, p.focal_x, p.focal_y, p.W, p.H, cA, cB, cC, m1x, m1y, m2xx, m2xy, m2yy, g_depth, g2x, g2y, dmean, dcov);
+    dL_dmean2D[3 * idx] = g2x; dL_dmean2D[3 * idx + 1] = g2y; dL_dmean2D[3 * idx + 2] = 0.f;
     if (dL_dcov3D) {
 #pragma unroll
         for (int i = 0; i < 6; i++) dL_dcov3D[6 * idx + i] = dcov[i];
-    }
-    float dT[2][3];
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        dT[0][k] = 2.f * ST0[k] * dL_da + ST1[k] * dL_db;
-        dT[1][k] = 2.f * ST1[k] * dL_dc + ST0[k] * dL_db;
-    }
-    const float dJ00 = V.m[0] * dT[0][0] + V.m[4] * dT[0][1] + V.m[8] * dT[0][2];
-    const float dJ02 = V.m[2] * dT[0][0] + V.m[6] * dT[0][1] + V.m[10] * dT[0][2];
-    const float dJ11 = V.m[1] * dT[1][0] + V.m[5] * dT[1][1] + V.m[9] * dT[1][2];
-    const float dJ12 = V.m[2] * dT[1][0] + V.m[6] * dT[1][1] + V.m[10] * dT[1][2];
-    const float tz = 1.f / t.z, tz2 = tz * tz, tz3 = tz2 * tz;
-    const float dtx = (xin ? 1.f : 0.f) * (-p.focal_x * tz2 * dJ02);
-    const float dty = (yin ? 1.f : 0.f) * (-p.focal_y * tz2 * dJ12);
-    const float dtz = -p.focal_x * tz2 * dJ00 - p.focal_y * tz2 * dJ11 + (2.f * p.focal_x * t.x) * tz3 * dJ02 + (2.f * p.focal_y * t.y) * tz3 * dJ12;
-    float dmean[3];
-#pragma unroll
-    for (int j = 0; j < 3; j++) dmean[j] = V.m[4 * j] * dtx + V.m[4 * j + 1] * dty + V.m[4 * j + 2] * dtz;
-
-    // screen-space mean (NDC-scaled gradient) -> 3D mean
-    const float4 mh = xform4x4(m, PJ);
-    const float mw = 1.f / (mh.w + 0.0000001f);
-    const float mul1 = mh.x * mw * mw, mul2 = mh.y * mw * mw;
-#pragma unroll
-    for (int j = 0; j < 3; j++)
-        dmean[j] += (PJ.m[4 * j] * mw - PJ.m[4 * j + 3] * mul1) * g2x + (PJ.m[4 * j + 1] * mw - PJ.m[4 * j + 3] * mul2) * g2y;
-    // depth output -> 3D mean
-    {
-        const float mul3 = V.m[2] * m.x + V.m[6] * m.y + V.m[10] * m.z + V.m[14];
-        const float gd = g_depth;
-#pragma unroll
-        for (int j = 0; j < 3; j++) dmean[j] += (V.m[4 * j + 2] - V.m[4 * j + 3] * mul3) * gd;
     }
     // colour -> SH coefficients and view direction
     if (!colors_precomp) {
@@ -424,29 +456,15 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GsParams p, GsGeom g, co
 
     // cov3D -> scale, rotation (exact derivative; d/dscale carries scale_modifier)
     if (!cov3D_precomp) {
-        float R[3][3];
-        quat_to_R(q, R);
-        const float s[3] = {p.scale_modifier * sc.x, p.scale_modifier * sc.y, p.scale_modifier * sc.z};
-        const float Gm[3][3] = {{dcov[0], 0.5f * dcov[1], 0.5f * dcov[2]}, {0.5f * dcov[1], dcov[3], 0.5f * dcov[4]}, {0.5f * dcov[2], 0.5f * dcov[4], dcov[5]}};
-        float dM[3][3], dR[3][3];
-#pragma unroll
-        for (int i = 0; i < 3; i++)
-#pragma unroll
-            for (int k = 0; k < 3; k++) dM[i][k] = 2.f * (Gm[i][0] * R[0][k] + Gm[i][1] * R[1][k] + Gm[i][2] * R[2][k]) * s[k];
+        float gs3[3];
+        float4 dq;
+        bwd_cov_to_scale_rot(dcov, sc, q, p.scale_modifier, gs3, dq);
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            float gs_ = p.scale_modifier * (dM[0][k] * R[0][k] + dM[1][k] * R[1][k] + dM[2][k] * R[2][k]);
+            float gs_ = gs3[k];
             if (RAW) gs_ *= (k == 0 ? sc.x : (k == 1 ? sc.y : sc.z));          // exp'
             dL_dscales[3 * idx + k] = ACC ? dL_dscales[3 * idx + k] + gs_ : gs_;
-#pragma unroll
-            for (int i = 0; i < 3; i++) dR[i][k] = dM[i][k] * s[k];
         }
-        const float r = q.x, x = q.y, y = q.z, z = q.w;
-        float4 dq;
-        dq.x = 2.f * (-z * dR[0][1] + y * dR[0][2] + z * dR[1][0] - x * dR[1][2] - y * dR[2][0] + x * dR[2][1]);
-        dq.y = 2.f * (y * dR[0][1] + z * dR[0][2] + y * dR[1][0] - 2.f * x * dR[1][1] - r * dR[1][2] + z * dR[2][0] + r * dR[2][1] - 2.f * x * dR[2][2]);
-        dq.z = 2.f * (-2.f * y * dR[0][0] + x * dR[0][1] + r * dR[0][2] + x * dR[1][0] + z * dR[1][2] - r * dR[2][0] + z * dR[2][1] - 2.f * y * dR[2][2]);
-        dq.w = 2.f * (-2.f * z * dR[0][0] - r * dR[0][1] + x * dR[0][2] + r * dR[1][0] - 2.f * z * dR[1][1] + y * dR[1][2] + x * dR[2][0] + y * dR[2][1]);
         if (RAW) {   // through q = raw / |raw|: (g - q (q.g)) / |raw|
             const float dot = dq.x * q.x + dq.y * q.y + dq.z * q.z + dq.w * q.w, inv = 1.f / qnorm;
             dq = make_float4((dq.x - q.x * dot) * inv, (dq.y - q.y * dot) * inv, (dq.z - q.z * dot) * inv, (dq.w - q.w * dot) * inv);
@@ -460,6 +478,138 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GsParams p, GsGeom g, co
         if (RAW) sh_stage_out_split<ACC>(dL_dsh, dL_df_rest, g0, gcount, sh_lds);
         else     sh_stage_out(dL_dsh, g0, gcount, sh_lds);
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// A8 over all the views of a training step in ONE pass (fused step, raw parameters, SH degree storage 16): a lane owns a Gaussian, walks the
+// views, sums that view's pair records and applies the view's chain rule, and writes every parameter gradient exactly once.  Against V
+// launches of k_preprocess_bwd<.,.,ACC> this removes (V-1) read-modify-write sweeps over the 236 B/Gaussian gradient set and (V-1) reads of
+// the 192 B/Gaussian SH coefficients.  View-independent work (exp / normalize, cov3D, cov3D -> scale / quaternion chain, activation
+// derivatives) is done once, on the summed covariance gradient (the chain is linear in it).
+// SH: coefficients stay in the block's LDS image (read per view); the 48 gradient sums live in registers and replace the row at the end.
+// ------------------------------------------------------------------------------------------
+template <bool ACC>
+__global__ void __launch_bounds__(256, 2) k_preprocess_bwd_views(GsParams p, GsBwdViews vs, const float* __restrict__ means3D, const float* __restrict__ f_dc,
+                                                               const float* __restrict__ f_rest, const float* __restrict__ scales, const float* __restrict__ rotations,
+                                                               float* __restrict__ dL_dopacity, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_df_dc,
+                                                               float* __restrict__ dL_df_rest, float* __restrict__ dL_dscales, float* __restrict__ dL_drots, uint32_t cap) {
+    extern __shared__ float sh_lds[];
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t g0 = (size_t)blockIdx.x * blockDim.x;
+    const int gcount = min((int)blockDim.x, p.N - (int)g0);
+    float* shl = sh_lds + threadIdx.x * SH_ROW;
+    sh_stage_in_split(f_dc, f_rest, g0, gcount, sh_lds);
+    __syncthreads();
+    float gsh[SH_M3];
+#pragma unroll
+    for (int k = 0; k < SH_M3; k++) gsh[k] = 0.f;
+    if (idx < p.N) {
+        const float3 m = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
+        float3 sc = make_float3(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]);
+        float4 q = *reinterpret_cast<const float4*>(rotations + 4 * idx);
+        sc = make_float3(expf(sc.x), expf(sc.y), expf(sc.z));
+        const float qnorm = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
+        {
+            const float inv = 1.f / qnorm;
+            q = make_float4(q.x * inv, q.y * inv, q.z * inv, q.w * inv);
+        }
+        float c3[6];
+        cov3d_from_scale_rot(sc, p.scale_modifier, q, c3);
+        float dmean[3] = {0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dopac = 0.f;
+        for (int v = 0; v < vs.V; v++) {
+            const GsBwdView& vw = vs.v[v];
+            float* d2 = vw.dmean2D + 3 * (size_t)idx;
+            if (vw.radii[idx] <= 0) { d2[0] = 0.f; d2[1] = 0.f; d2[2] = 0.f; continue; }
+            float pr[GS_PAIR_FLOATS];
+#pragma unroll
+            for (int k = 0; k < GS_PAIR_FLOATS; k++) pr[k] = 0.f;
+            {
+                const uint32_t cnt = vw.tiles[idx];
+                const uint32_t e0 = cnt ? vw.einfo[idx].x : 0u, e1 = min(e0 + cnt, cap);
+                for (uint32_t e = e0; e < e1; e++) {
+                    const float4 v0 = vw.pairgrad[(size_t)e * 3], v1 = vw.pairgrad[(size_t)e * 3 + 1], v2 = vw.pairgrad[(size_t)e * 3 + 2];
+                    pr[0] += v0.x; pr[1] += v0.y; pr[2] += v0.z; pr[3] += v0.w;
+                    pr[4] += v1.x; pr[5] += v1.y; pr[6] += v1.z; pr[7] += v1.w;
+                    pr[8] += v2.x; pr[10] += v2.z;
+                }
+            }
+            const float gcol[3] = {pr[0], pr[2], pr[1]};          // record rows: c0, c2, c1
+            const float4 q0 = vw.rec0[idx], q1 = vw.rec1[idx];
+            const float opac = q1.y;
+            {
+                const float go = (opac > 0.f) ? pr[4] / opac : 0.f;
+                dopac += go * opac * (1.f - opac);                  // sigmoid'
+            }
+            const Mat16 V = load_mat16(vw.view), PJ = load_mat16(vw.proj);
+            float g2x, g2y, dm[3], dc[6];
+            bwd_geom_chain(m, c3, V, PJ, vw.tanfovx, vw.tanfovy, vw.focal_x, vw.focal_y, p.W, p.H, q0.z, q0.w, q1.x, pr[6], pr[5], pr[7], pr[8], pr[10], pr[3], g2x, g2y, dm, dc);
+            d2[0] = g2x; d2[1] = g2y; d2[2] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 6; i++) dcov[i] += dc[i];
+            // colour -> SH coefficients and view direction
+            const float vx = m.x - vw.campos[0], vy = m.y - vw.campos[1], vz = m.z - vw.campos[2];
+            const float s2 = vx * vx + vy * vy + vz * vz;
+            const float len = sqrtf(s2);
+            const float dxn = vx / len, dyn = vy / len, dzn = vz / len;
+            const uint8_t cl = vw.clamped[idx];
+            const float dR0 = (cl & 1) ? 0.f : gcol[0], dR1 = (cl & 2) ? 0.f : gcol[1], dR2 = (cl & 4) ? 0.f : gcol[2];
+            float dd0 = 0.f, dd1 = 0.f, dd2 = 0.f;
+#define GS_BWDV_TERM(k, Bk, dBx, dBy, dBz)                                                              \
+    {                                                                                                   \
+        const float b_ = (Bk);                                                                          \
+        const float w_ = shl[3 * (k)] * dR0 + shl[3 * (k) + 1] * dR1 + shl[3 * (k) + 2] * dR2;          \
+        gsh[3 * (k)] += b_ * dR0; gsh[3 * (k) + 1] += b_ * dR1; gsh[3 * (k) + 2] += b_ * dR2;           \
+        dd0 += (dBx) * w_; dd1 += (dBy) * w_; dd2 += (dBz) * w_;                                        \
+    }
+            SH_FOREACH(p.deg, dxn, dyn, dzn, GS_BWDV_TERM);
+#undef GS_BWDV_TERM
+            const float inv32 = 1.f / sqrtf(s2 * s2 * s2);
+            dmean[0] += dm[0] + ((s2 - vx * vx) * dd0 - vy * vx * dd1 - vz * vx * dd2) * inv32;
+            dmean[1] += dm[1] + (-vx * vy * dd0 + (s2 - vy * vy) * dd1 - vz * vy * dd2) * inv32;
+            dmean[2] += dm[2] + (-vx * vz * dd0 - vy * vz * dd1 + (s2 - vz * vz) * dd2) * inv32;
+        }
+        // view-independent tail: cov3D -> scale (exp') and quaternion (normalisation), then the single write of every gradient
+        float gs3[3];
+        float4 dq;
+        bwd_cov_to_scale_rot(dcov, sc, q, p.scale_modifier, gs3, dq);
+        gs3[0] *= sc.x; gs3[1] *= sc.y; gs3[2] *= sc.z;
+        {
+            const float dot = dq.x * q.x + dq.y * q.y + dq.z * q.z + dq.w * q.w, inv = 1.f / qnorm;
+            dq = make_float4((dq.x - q.x * dot) * inv, (dq.y - q.y * dot) * inv, (dq.z - q.z * dot) * inv, (dq.w - q.w * dot) * inv);
+        }
+        if (ACC) {
+            dopac += dL_dopacity[idx];
+#pragma unroll
+            for (int j = 0; j < 3; j++) { dmean[j] += dL_dmeans3D[3 * idx + j]; gs3[j] += dL_dscales[3 * idx + j]; }
+            const float4 o4 = *reinterpret_cast<const float4*>(dL_drots + 4 * idx);
+            dq.x += o4.x; dq.y += o4.y; dq.z += o4.z; dq.w += o4.w;
+        }
+        dL_dopacity[idx] = dopac;
+#pragma unroll
+        for (int j = 0; j < 3; j++) { dL_dmeans3D[3 * idx + j] = dmean[j]; dL_dscales[3 * idx + j] = gs3[j]; }
+        *reinterpret_cast<float4*>(dL_drots + 4 * idx) = dq;
+    }
+    // the coefficients are no longer needed: the gradient sums take their place in the LDS image (own row only: no barrier needed before)
+#pragma unroll
+    for (int k = 0; k < SH_M3; k++) shl[k] = gsh[k];
+    __syncthreads();
+    sh_stage_out_split<ACC>(dL_df_dc, dL_df_rest, g0, gcount, sh_lds);
+}
+
+int gs_launch_preprocess_bwd_views(const GsParams& p0, const GsBwdViews& views, const float* means3D, const float* f_dc, const float* f_rest,
+                                   const float* scaling_raw, const float* rotation_raw, float* dL_dopacity_raw, float* dL_dmeans3D, float* dL_df_dc,
+                                   float* dL_df_rest, float* dL_dscaling_raw, float* dL_drotation_raw, bool accumulate, hipStream_t s, uint32_t cap) {
+    if (p0.N == 0 || views.V == 0) return 0;
+    const dim3 grid(c3d_cdiv(p0.N, 256)), block(256);
+    const size_t lds = 256 * SH_ROW * sizeof(float);
+    if (accumulate)
+        hipLaunchKernelGGL((k_preprocess_bwd_views<true>), grid, block, lds, s, p0, views, means3D, f_dc, f_rest, scaling_raw, rotation_raw, dL_dopacity_raw,
+                           dL_dmeans3D, dL_df_dc, dL_df_rest, dL_dscaling_raw, dL_drotation_raw, cap);
+    else
+        hipLaunchKernelGGL((k_preprocess_bwd_views<false>), grid, block, lds, s, p0, views, means3D, f_dc, f_rest, scaling_raw, rotation_raw, dL_dopacity_raw,
+                           dL_dmeans3D, dL_df_dc, dL_df_rest, dL_dscaling_raw, dL_drotation_raw, cap);
+    C3D_LAUNCH_CHECK();
+    return 0;
 }
 
 int gs_launch_preprocess_bwd(const GsParams& p, const GsGeom& g, const int* radii, const float* means3D, const float* shs,

@@ -92,7 +92,23 @@ static inline void gs_carve_image(char* base, int W, int H, GsImage& im) {
     im.bytes = off;
 }
 
+// A8 over several views at once (fused training step): what the kernel needs of each view's state.  Passed by value (kernel argument).
+#define GS_MAX_BWD_VIEWS 16
+struct GsBwdView {
+    const float* view; const float* proj; const float* campos;   // device matrices of the view
+    const int* radii;
+    const float4* rec0; const float4* rec1;
+    const uint32_t* tiles; const uint4* einfo; const uint8_t* clamped;
+    const float4* pairgrad;
+    float* dmean2D;                                              // [N,3] per-view screen-space gradient (densification statistic)
+    float tanfovx, tanfovy, focal_x, focal_y;
+};
+struct GsBwdViews { int V; GsBwdView v[GS_MAX_BWD_VIEWS]; };
+
 // kernels' launchers (gs_forward.hip / gs_backward.hip)
+int gs_launch_preprocess_bwd_views(const GsParams& p0, const GsBwdViews& views, const float* means3D, const float* f_dc, const float* f_rest,
+                                   const float* scaling_raw, const float* rotation_raw, float* dL_dopacity_raw, float* dL_dmeans3D, float* dL_df_dc,
+                                   float* dL_df_rest, float* dL_dscaling_raw, float* dL_drotation_raw, bool accumulate, hipStream_t s, uint32_t cap);
 int gs_launch_preprocess(const GsParams& p, const float* means3D, const float* shs, const float* colors_precomp,
                          const float* opacities, const float* scales, const float* rotations, const float* cov3D_precomp,
                          GsGeom& g, int* radii, hipStream_t s);

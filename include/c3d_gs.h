@@ -124,17 +124,19 @@ int c3d_gs_backward_raw(const c3d_gs_settings* st, int32_t N, const float* means
  * target_color / target_alpha / color_mask: HOST arrays of V device pointers ([3,H,W] / [1,H,W] / [1,H,W]); target_alpha and color_mask may be
  * NULL.  With color_mask the colour terms compare (C * mask) with (Ct * mask), the reference's masked loss (main_3DGS.py:169-186). */
 typedef struct c3d_gs_loss { float w_l1; float w_l2; float w_alpha_mse; float scale; } c3d_gs_loss;
-/* lanes (1..8): the V views are dealt round-robin onto `lanes` HIP streams (lane 0 = `stream`; the others are library-owned, forked from and
+/* The workspace holds one slice per view (state of every view stays alive until the single per-Gaussian backward pass at the end).
+ * lanes (1..8): the V views are dealt round-robin onto `lanes` HIP streams (lane 0 = `stream`; the others are library-owned, forked from and
  * joined back into `stream` with events, so the call keeps stream semantics) -- the latency-bound sort/scan chain of one view then runs underneath
- * the compositing kernels of another.  Lanes > 0 accumulate into private gradient sets inside the workspace which are added to the caller's buffers
- * in lane order at the join: results are bit-reproducible for a fixed `lanes`. */
-size_t c3d_gs_step_workspace_bytes(int32_t N, int32_t image_height, int32_t image_width, int64_t pair_capacity, int32_t lanes);
+ * the compositing kernels of another.  After the join ONE kernel walks the Gaussians, sums each view's (tile, splat) gradient records in a fixed
+ * order and writes every parameter gradient once: results are bit-reproducible and independent of `lanes`.
+ * accumulate != 0: add to the contents of the gradient buffers; 0: overwrite them (no zero-fill needed). */
+size_t c3d_gs_step_workspace_bytes(int32_t N, int32_t image_height, int32_t image_width, int64_t pair_capacity, int32_t views);
 int c3d_gs_train_views_raw(const c3d_gs_settings* views /* host [V] */, int32_t V, int32_t N, const float* means3D, const float* f_dc,
                            const float* f_rest, const float* opacity_raw, const float* scaling_raw, const float* rotation_raw,
                            const float* const* target_color, const float* const* target_alpha, const float* const* color_mask,
                            const c3d_gs_loss* loss,
                            float* dL_dmeans3D, float* dL_df_dc, float* dL_df_rest, float* dL_dopacity_raw, float* dL_dscaling_raw,
-                           float* dL_drotation_raw, float* loss_out, int64_t pair_capacity, int32_t lanes, void* workspace,
+                           float* dL_drotation_raw, float* loss_out, int64_t pair_capacity, int32_t lanes, int32_t accumulate, void* workspace,
                            uint32_t* status /* device [2] */, c3d_stream_t stream);
 
 /* mark_visible: present[N] (uint8) = view-space z > 0.2 */
