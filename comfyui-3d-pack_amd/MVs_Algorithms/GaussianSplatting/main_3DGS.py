@@ -96,15 +96,14 @@ class GaussianSplatting3D:
     def training_step(self, step, view_indices):
         """one optimisation step over `view_indices` (the GLOBAL batch; this rank renders its shard). -> loss value tensor"""
         p = self.gs_params
-        if p.density_start_iter <= step <= p.density_end_iter:
-            raise NotImplementedError("densify/prune is not built yet (SURVEY 8f-3): run with density_end_iter < density_start_iter")
         world = torch.distributed.get_world_size(self.group) if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
         rank = torch.distributed.get_rank(self.group) if world > 1 else 0
         self.renderer.gaussians.update_learning_rate(step)
         mine = parallel.shard_views(view_indices, rank, world)
         if self._can_fuse():
-            return self._fused_step(mine, len(view_indices), world)
+            return self._fused_step(mine, len(view_indices), world, step)
         imgs, refs, alphas, masks = [], [], [], []
+        out = None
         for i in mine:
             out = self.cam_controller.render_at_pose(self.all_ref_cam_poses[i])
             m = self.ref_masks_torch[i]
@@ -125,8 +124,53 @@ class GaussianSplatting3D:
         # batch losses are means over views: equal shards => the global gradient is the mean of the ranks' gradients
         parallel.exchange_gradients(self.params, self.group, self.exchange, average=True)
         self.optimizer.step()
+        stats = None
+        if out is not None and self._in_density_window(step):
+            vg = out["viewspace_points"].grad
+            stats = (out["radii"], vg if vg is not None else torch.zeros_like(out["viewspace_points"]))
         self.optimizer.zero_grad()
+        self._densify(step, stats)
         return loss.detach()
+
+    # ---- densify / prune schedule (reference :209-224) ----
+    def _in_density_window(self, step):
+        p = self.gs_params
+        return p.density_start_iter <= step <= p.density_end_iter
+
+    def _densify(self, step, stats):
+        """stats = (radii [N], dL/dmeans2D [N,3]) of this rank's LAST view of the step (the reference looks at the last view only, :210-213),
+        or None when the rank rendered nothing.  With several ranks the statistics are combined (sum / max) so that replicas stay identical."""
+        p, g = self.gs_params, self.renderer.gaussians
+        if not self._in_density_window(step):
+            return
+        n = g._xyz.shape[0]
+        if stats is None:
+            radii, vg = torch.zeros((n,), dtype=torch.int32, device=self.device), torch.zeros((n, 3), device=self.device)
+        else:
+            radii, vg = stats
+        vis = radii > 0
+        if self.group is not None and torch.distributed.get_world_size(self.group) > 1:
+            add = torch.cat((torch.norm(vg[:, :2], dim=-1, keepdim=True) * vis.unsqueeze(-1), vis.unsqueeze(-1).float()), dim=1)
+            torch.distributed.all_reduce(add, group=self.group)
+            rmax = torch.where(vis, radii, torch.zeros_like(radii)).float()
+            torch.distributed.all_reduce(rmax, op=torch.distributed.ReduceOp.MAX, group=self.group)
+            g.xyz_gradient_accum += add[:, :1]
+            g.denom += add[:, 1:]
+            g.max_radii2D = torch.maximum(g.max_radii2D, rmax)
+        else:
+            g.add_densification_stats(vg, vis, radii)
+        changed = False
+        if step % p.densification_interval == 0:
+            gen = torch.Generator(device=self.device)
+            gen.manual_seed(0x3D65 + step)                 # identical draws on every rank
+            self.last_densify = g.densify_and_prune(p.densify_grad_threshold, min_opacity=0.005, extent=4, max_screen_size=1, generator=gen)
+            changed = True
+        if step % p.opacity_reset_interval == 0:
+            g.reset_opacity()
+            changed = True
+        if changed:
+            self.params = [g._xyz, g._features_dc, g._features_rest, g._opacity, g._scaling, g._rotation]
+            self._step = None                                # pair buffers / gradient buffers are sized by N
 
     # ---- fused multi-view step (c3d_gs_train_views_raw): all of this rank's views in one sync-free library call ----
     def _can_fuse(self):
@@ -134,7 +178,7 @@ class GaussianSplatting3D:
         return (self.use_fused_step and self.device.type == "cuda" and p.lambda_ssim == 0 and p.lambda_offset == 0 and p.lambda_offset_opacity == 0
                 and g.max_sh_degree == 3 and (self.cam_controller.static_bg is not None or p.invert_bg_prob in (0.0, 1.0)))
 
-    def _fused_step(self, mine, global_batch, world):
+    def _fused_step(self, mine, global_batch, world, step=-1):
         import math
         from c3d_hip.gs_step import FusedViewStep
         from diff_gaussian_rasterization import GaussianRasterizationSettings
@@ -161,6 +205,11 @@ class GaussianSplatting3D:
             q.grad = gq
         parallel.exchange_gradients(self.params, self.group, self.exchange, average=True)
         self.optimizer.step()
+        step_obj = self._step
+        for q in self.params:
+            q.grad = None
+        if self._in_density_window(step):
+            self._densify(step, step_obj.read_view(len(mine) - 1) if len(mine) else None)
         return loss.detach()
 
     def training(self, progress=None):

@@ -160,6 +160,142 @@ class GaussianModel:
                 group['lr'] = lr = self.xyz_scheduler_args(iteration)
                 return lr
 
+    # ---- densify / prune (reference :543-781).  The reference runs clone -> split -> prune as three rounds of boolean-mask indexing and
+    # torch.cat over 6 parameters + 12 Adam moments + 4 side arrays.  Here the three rounds are folded into ONE source-index list: every
+    # surviving point of the result names the point it is copied from and what it is (kept / clone / split child), and each array is
+    # rebuilt with a single gather.  The outcome (set and order of points, parameter values, optimizer state, statistics) is the reference's.
+    _NAMES = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")
+
+    def _param_dict(self):
+        return dict(zip(self._NAMES, (self._xyz, self._features_dc, self._features_rest, self._opacity, self._scaling, self._rotation)))
+
+    def _install(self, new_tensors, moments_fn):
+        """swap every parameter for new_tensors[name]; moments_fn(old_moment) -> new moment (or None to zero-fill)"""
+        out = {}
+        for group in self.optimizer.param_groups:
+            old = group["params"][0]
+            newp = nn.Parameter(new_tensors[group["name"]].contiguous().requires_grad_(True))
+            st = self.optimizer.state.pop(old, None)
+            if st is not None and len(st):
+                for k in ("exp_avg", "exp_avg_sq"):
+                    m = moments_fn(st[k])
+                    st[k] = torch.zeros_like(newp) if m is None else m.contiguous()
+                self.optimizer.state[newp] = st
+            group["params"][0] = newp
+            out[group["name"]] = newp
+        self._xyz, self._features_dc, self._features_rest = out["xyz"], out["f_dc"], out["f_rest"]
+        self._opacity, self._scaling, self._rotation = out["opacity"], out["scaling"], out["rotation"]
+
+    def add_densification_stats(self, viewspace_point_grad, update_filter, radii=None):
+        """viewspace_point_grad [N,>=2]: gradient of the loss w.r.t. the screen-space means of ONE view (reference :767-769)"""
+        norm = torch.norm(viewspace_point_grad[:, :2], dim=-1, keepdim=True)
+        f = update_filter.to(norm.dtype).unsqueeze(-1)
+        self.xyz_gradient_accum += norm * f
+        self.denom += f
+        if radii is not None:
+            self.max_radii2D = torch.where(update_filter, torch.maximum(self.max_radii2D, radii.to(self.max_radii2D.dtype)), self.max_radii2D)
+
+    def reset_opacity(self):
+        new = inverse_sigmoid(torch.clamp_max(self.get_opacity.detach(), 0.01))
+        tensors = {k: v.detach() for k, v in self._param_dict().items()}
+        keep_names = {"opacity"}
+        tensors["opacity"] = new
+        # only the opacity group loses its moments (reference replace_tensor_to_optimizer :543-556)
+        for group in self.optimizer.param_groups:
+            if group["name"] not in keep_names:
+                continue
+            old = group["params"][0]
+            newp = nn.Parameter(new.contiguous().requires_grad_(True))
+            st = self.optimizer.state.pop(old, None)
+            if st is not None and len(st):
+                st["exp_avg"], st["exp_avg_sq"] = torch.zeros_like(newp), torch.zeros_like(newp)
+                self.optimizer.state[newp] = st
+            group["params"][0] = newp
+            self._opacity = newp
+
+    def prune_points(self, mask):
+        """drop the points where mask is True (reference :575-590)"""
+        src = torch.nonzero(~mask, as_tuple=False).squeeze(-1)
+        self._gather(src, None)
+        self.xyz_gradient_accum, self.denom = self.xyz_gradient_accum[src], self.denom[src]
+        self.max_radii2D = self.max_radii2D[src]
+
+    def _gather(self, src, fresh):
+        """rebuild every per-point array as old[src]; fresh [len(src)] bool marks points that start with zero Adam moments"""
+        tensors = {k: v.detach().index_select(0, src) for k, v in self._param_dict().items()}
+        if fresh is None:
+            mom = lambda m: m.index_select(0, src)
+        else:
+            def mom(m):
+                g = m.index_select(0, src)
+                return g * (~fresh).to(g.dtype).view(-1, *([1] * (g.ndim - 1)))
+        self.init_xyz = self.init_xyz.index_select(0, src)
+        self._install(tensors, mom)
+        return tensors
+
+    def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size, generator=None):
+        """clone small / split large high-gradient points, then prune (reference densify_and_prune :748-750 = clone :672-690, split
+        :641-670 with N=2, prune :771-781), in one pass.  Statistics are zeroed as densification_postfix does (:634-637) -- which is
+        also why the reference's screen-size criterion never fires: max_radii2D is all zero by the time prune() looks at it."""
+        N = self._xyz.shape[0]
+        dev = self._xyz.device
+        with torch.no_grad():
+            g = self.xyz_gradient_accum / self.denom
+            g[g.isnan()] = 0.0
+            g = g.norm(dim=-1)                                              # [N]
+            scal = self.get_scaling.detach()
+            smax = scal.max(dim=1).values
+            opac = self.get_opacity.detach().squeeze(-1)
+            hot = g >= max_grad
+            small = smax <= self.percent_dense * extent
+            clone, split = hot & small, hot & ~small
+            ar = torch.arange(N, device=dev)
+            i_keep, i_clone, i_split = ar[~split], ar[clone], ar[split]
+            nK, nC, nS = i_keep.numel(), i_clone.numel(), i_split.numel()
+            # candidate list in the reference's final order: survivors, clones, first children, second children
+            src = torch.cat((i_keep, i_clone, i_split, i_split))
+            kind = torch.cat((torch.zeros(nK, dtype=torch.int8, device=dev), torch.ones(nC, dtype=torch.int8, device=dev),
+                              torch.full((2 * nS,), 2, dtype=torch.int8, device=dev)))
+            child = kind == 2
+            # prune criteria evaluated on what each candidate will be (children are 1.6x smaller)
+            c_smax = torch.where(child, smax[src] / 1.6, smax[src])
+            dead = opac[src] < min_opacity
+            if max_screen_size:
+                dead = dead | (c_smax > 0.1 * extent)                       # (max_radii2D > max_screen_size) is identically False, see above
+            # split children: position sampled from the parent's Gaussian, scale / (0.8 * 2)
+            if nS:
+                std = scal[i_split].repeat(2, 1)
+                noise = torch.randn(std.shape, device=dev, generator=generator) * std
+                rot = build_rotation(self._rotation.detach()[i_split]).repeat(2, 1, 1)
+                child_xyz = torch.bmm(rot, noise.unsqueeze(-1)).squeeze(-1) + self._xyz.detach()[i_split].repeat(2, 1)
+                child_scaling = self.scaling_inverse_activation(std / 1.6)
+            alive = ~dead
+            sel = torch.nonzero(alive, as_tuple=False).squeeze(-1)
+            final_src, fresh = src[sel], (kind != 0)[sel]
+            tensors = self._gather(final_src, fresh)
+            if nS:
+                pos = torch.cumsum(alive.to(torch.int64), 0) - 1                # candidate index -> index in the result
+                cidx = torch.arange(nK + nC, nK + nC + 2 * nS, device=dev)
+                ok = alive[cidx]
+                with torch.no_grad():
+                    self._xyz.data[pos[cidx][ok]] = child_xyz[ok]
+                    self._scaling.data[pos[cidx][ok]] = child_scaling[ok]
+            n = self._xyz.shape[0]
+            self.xyz_gradient_accum = torch.zeros((n, 1), device=dev)
+            self.denom = torch.zeros((n, 1), device=dev)
+            self.max_radii2D = torch.zeros((n,), device=dev)
+        return {"cloned": int(nC), "split": int(nS), "pruned": int((~alive).sum().item()), "points": int(n)}
+
+
+def build_rotation(r):
+    """unit-normalised quaternions (w, x, y, z) [M,4] -> rotation matrices [M,3,3] (reference general_utils build_rotation)"""
+    q = r / r.norm(dim=1, keepdim=True)
+    w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = torch.stack((1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                     2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                     2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)), dim=1)
+    return R.view(-1, 3, 3)
+
 
 class GaussianSplattingRenderer:
     def __init__(self, sh_degree=3, white_background=True, radius=1, device="cuda"):

@@ -66,6 +66,7 @@ class FusedViewStep:
             st = self.status.tolist()       # the single host sync of the step
             if st[0] == 0:
                 seen = st[1] & 0xFFFFFFFF
+                self._last = (self.workspace, self.capacity)     # what read_view() looks into
                 if not self._fitted and self.capacity > 2 * max(seen, 1 << 16):
                     # first successful step: every launch is sized for the capacity, so bring it down to what the scene needs (+30 %)
                     self.capacity = int(seen * 1.3) + 4096
@@ -78,3 +79,13 @@ class FusedViewStep:
                 for g, s0 in zip(grads, snapshot):
                     g.copy_(s0)
         raise RuntimeError("c3d FusedViewStep: pair capacity still exceeded after %d retries" % max_retries)
+
+    def read_view(self, view):
+        """-> (radii [N] int32, dL/dmeans2D [N,3]) of view `view` of the last run(): the densification statistics of the reference trainer"""
+        ws, cap = self._last
+        radii = torch.empty((self.N,), dtype=torch.int32, device=self.device)
+        g2 = torch.empty((self.N, 3), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _h.check(_h.lib().c3d_gs_step_read_view(self.N, self.H, self.W, cap, _h.ptr(ws), int(view), _h.ptr(radii), _h.ptr(g2),
+                                                    _h.stream(self.device)), "c3d_gs_step_read_view")
+        return radii, g2

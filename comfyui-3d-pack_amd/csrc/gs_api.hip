@@ -371,6 +371,18 @@ int c3d_gs_train_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, c
     return 0;
 }
 
+int c3d_gs_step_read_view(int32_t N, int32_t H, int32_t W, int64_t pair_capacity, const void* workspace, int32_t view, int32_t* radii_out,
+                          float* dL_dmeans2D_out, c3d_stream_t stream) {
+    if (N <= 0) return 0;
+    if (!workspace || view < 0) { c3d_set_error("c3d_gs_step_read_view: bad argument"); return -1; }
+    StepWs w0; carve_step(nullptr, N, H, W, pair_capacity, w0);
+    StepWs w; carve_step((char*)workspace + (size_t)view * w0.bytes, N, H, W, pair_capacity, w);
+    hipStream_t s = (hipStream_t)stream;
+    if (radii_out) C3D_CHECK(hipMemcpyAsync(radii_out, w.radii, sizeof(int) * (size_t)N, hipMemcpyDeviceToDevice, s));
+    if (dL_dmeans2D_out) C3D_CHECK(hipMemcpyAsync(dL_dmeans2D_out, w.dmeans2D, sizeof(float) * 3 * (size_t)N, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
 int c3d_gs_mark_visible(int32_t N, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present, c3d_stream_t stream) {
     if (N > 0 && (!means3D || !viewmatrix || !present)) { c3d_set_error("c3d_gs_mark_visible: NULL pointer"); return -1; }
     return gs_launch_mark_visible(N, means3D, viewmatrix, projmatrix, present, (hipStream_t)stream);

@@ -139,6 +139,12 @@ int c3d_gs_train_views_raw(const c3d_gs_settings* views /* host [V] */, int32_t 
                            float* dL_drotation_raw, float* loss_out, int64_t pair_capacity, int32_t lanes, int32_t accumulate, void* workspace,
                            uint32_t* status /* device [2] */, c3d_stream_t stream);
 
+/* Per-view by-products of the last c3d_gs_train_views_raw call, copied out of its workspace (same N / H / W / pair_capacity): radii [N] (int32)
+ * and the screen-space positional gradient dL/dmeans2D [N,3] of view `view` -- the densification statistics of the reference's trainer
+ * (main_3DGS.py:210-213, main_3DGS_renderer.py:767-769).  Either output may be NULL. */
+int c3d_gs_step_read_view(int32_t N, int32_t image_height, int32_t image_width, int64_t pair_capacity, const void* workspace, int32_t view,
+                          int32_t* radii_out, float* dL_dmeans2D_out, c3d_stream_t stream);
+
 /* mark_visible: present[N] (uint8) = view-space z > 0.2 */
 int c3d_gs_mark_visible(int32_t N, const float* means3D, const float* viewmatrix, const float* projmatrix,
                         uint8_t* present, c3d_stream_t stream);

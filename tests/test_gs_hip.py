@@ -481,3 +481,52 @@ def test_trainer_fused_step_equals_autograd_step():
     assert abs(l1[0] - l2[0]) <= 1e-5 * max(1, abs(l2[0])) and abs(l1[1] - l2[1]) <= 1e-4 * max(1, abs(l2[1]))
     for a, b in zip(p1, p2):
         assert (a - b).abs().max().item() <= 2e-4 * max(1.0, b.abs().max().item())
+
+
+def test_trainer_densify_prune_schedule():
+    """The reference's default schedule densifies (main_3DGS.py:209-224): statistics from the step's last view, clone/split/prune at the
+    interval, opacity reset -- through the fused step (statistics read back with c3d_gs_step_read_view) and through the autograd path.
+    N changes mid-training; buffers, optimizer state and the fused workspace follow."""
+    from MVs_Algorithms.GaussianSplatting.main_3DGS import GSParams, GaussianSplatting3D
+    H = W = 160
+    poses = [[1.75, -10.0, az, 0.0, 0.0, 0.0] for az in (0.0, 120.0, -120.0)]
+    rng = np.random.default_rng(4)
+    refs = [torch.tensor(rng.uniform(size=(H, W, 3)).astype(np.float32)) for _ in poses]
+    masks = [torch.tensor((rng.uniform(size=(H, W)) > 0.4).astype(np.float32)) for _ in poses]
+    counts = []
+    for fused in (True, False):
+        np.random.seed(3); torch.manual_seed(3)
+        p = GSParams(training_iterations=7, batch_size=3, lambda_ssim=0.0, num_pts=4000, density_start_iter=1, density_end_iter=100,
+                     densification_interval=2, opacity_reset_interval=4, densify_grad_threshold=2e-6, invert_bg_prob=1.0)
+        tr = GaussianSplatting3D(p, None, device="cuda")
+        tr.use_fused_step = fused
+        tr.prepare_training(refs, masks, poses, 49.1)
+        ns, losses = [], []
+        for s in range(7):
+            losses.append(tr.training_step(s, [0, 1, 2]).item())
+            g = tr.renderer.gaussians
+            ns.append(g._xyz.shape[0])
+            n = ns[-1]
+            for q in (g._features_dc, g._features_rest, g._opacity, g._scaling, g._rotation, g.xyz_gradient_accum, g.denom, g.max_radii2D, g.init_xyz):
+                assert q.shape[0] == n
+            for grp in tr.optimizer.param_groups:
+                st = tr.optimizer.state[grp["params"][0]]
+                assert st["exp_avg"].shape == grp["params"][0].shape
+        assert all(np.isfinite(losses))
+        assert ns[0] == 4000 and ns[1] == 4000                  # step 0 outside the window, step 1 collects statistics only
+        assert ns[2] != 4000 and tr.last_densify["cloned"] + tr.last_densify["split"] > 0
+        assert float(g.get_opacity.detach().max()) <= 0.6                # step 4 reset the opacities to <= 0.01; two Adam steps since
+        out = tr.renderer.render(_minicam_for(tr, poses[0]), bg_color=torch.ones(3, device="cuda"))
+        assert out["image"].shape == (3, H, W) and torch.isfinite(out["image"]).all()
+        counts.append(ns)
+    # same schedule, same random draws, gradients equal to ~1e-4: the two paths grow alike
+    for a, b in zip(*counts):
+        assert abs(a - b) <= 0.02 * b
+
+
+def _minicam_for(tr, pose):
+    from shared_utils.camera_utils import MiniCam, orbit_camera
+    ctl = tr.cam_controller
+    radius, elev, azim, cx, cy, cz = pose
+    return MiniCam(orbit_camera(elev, azim, radius, target=np.array([cx, cy, cz], dtype=np.float32)), tr.ref_size_W, tr.ref_size_H, ctl.cam.fovy, ctl.cam.fovx,
+                   ctl.cam.near, ctl.cam.far, ctl.projection_matrix, device=tr.device)

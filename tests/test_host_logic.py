@@ -189,3 +189,101 @@ def test_node_layer_contract_and_pose_stacking():
     # simple linear case
     poses2, *_ = N.Stack_Orbit_Camera_Poses().get_camposes(1.0, 2.0, 0.5, 0, 0, 0, 0, 90, 45, 0, 0, 0.1, 0, 0, 0.1, 0, 0, 0.1)
     assert [p[2] for p in poses2[:3]] == [0, 45, 90] and [p[0] for p in poses2[::3]] == [1.0, 1.5, 2.0] and len(poses2) == 9   # radius slowest
+
+
+def _three_round_reference(P, mom, stats, thr, percent_dense, extent, min_opacity, noise):
+    """Literal restatement of the reference's densify_and_prune (main_3DGS_renderer.py:641-690, :748-781) on plain tensors: clone round
+    (append copies), split round (append 2 children per selected point, drop the parents), prune round.  P / mom: dicts of per-point
+    arrays (mom = (exp_avg, exp_avg_sq) per name); noise [2*nS,3] = the unit normal draws of the split round."""
+    accum, denom = stats
+    g = accum / denom
+    g[g.isnan()] = 0.0
+    n0 = P["xyz"].shape[0]
+    smax = torch.exp(P["scaling"]).max(dim=1).values
+    sel = (g.norm(dim=-1) >= thr) & (smax <= percent_dense * extent)
+    cat = lambda d, add: {k: torch.cat((d[k], add[k]), dim=0) for k in d}
+    P = cat(P, {k: v[sel] for k, v in P.items()})
+    mom = {k: tuple(torch.cat((m, torch.zeros_like(m[sel])), dim=0) for m in mom[k]) for k in mom}
+    padded = torch.zeros(P["xyz"].shape[0])
+    padded[:n0] = g.squeeze()
+    smax = torch.exp(P["scaling"]).max(dim=1).values
+    sel = (padded >= thr) & (smax > percent_dense * extent)
+    stds = torch.exp(P["scaling"][sel]).repeat(2, 1)
+    q = P["rotation"][sel] / P["rotation"][sel].norm(dim=1, keepdim=True)
+    w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = torch.stack((1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y), 2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                     2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)), dim=1).view(-1, 3, 3).repeat(2, 1, 1)
+    child = {k: v[sel].repeat(2, *([1] * (v.ndim - 1))) for k, v in P.items()}
+    child["xyz"] = torch.bmm(R, (noise * stds).unsqueeze(-1)).squeeze(-1) + P["xyz"][sel].repeat(2, 1)
+    child["scaling"] = torch.log(stds / (0.8 * 2))
+    P = cat(P, child)
+    mom = {k: tuple(torch.cat((m, torch.zeros_like(child[k])), dim=0) for m in mom[k]) for k in mom}
+    drop = torch.cat((sel, torch.zeros(2 * int(sel.sum()), dtype=torch.bool)))
+    P = {k: v[~drop] for k, v in P.items()}
+    mom = {k: tuple(m[~drop] for m in mom[k]) for k in mom}
+    # prune round: the statistics were reset by the two rounds above, so only opacity and world size can fire
+    dead = (torch.sigmoid(P["opacity"]).squeeze(-1) < min_opacity) | (torch.exp(P["scaling"]).max(dim=1).values > 0.1 * extent)
+    return {k: v[~dead] for k, v in P.items()}, {k: tuple(m[~dead] for m in mom[k]) for k in mom}
+
+
+def test_densify_and_prune_one_pass_equals_three_rounds():
+    """GaussianModel.densify_and_prune (one source-index list, one gather per array) against the clone -> split -> prune rounds of the
+    reference; also reset_opacity and the optimizer-state surgery (moments follow their points, new points start at zero)."""
+    from MVs_Algorithms.GaussianSplatting.main_3DGS_renderer import GaussianModel
+    from MVs_Algorithms.GaussianSplatting.main_3DGS import GSParams
+    torch.manual_seed(5)
+    n = 400
+    gm = GaussianModel(3, device="cpu")
+    feats = torch.randn(n, 16, 3) * 0.2
+    scal = torch.log((torch.rand(n, 1) * 0.09 + 0.005) * (0.8 + 0.2 * torch.rand(n, 3)))   # around the percent_dense * extent = 0.04 split/clone boundary
+    scal[:10] = torch.log(torch.tensor(0.5))                        # world-size prune (> 0.1 * extent)
+    opac = torch.randn(n, 1) * 2.0
+    opac[10:30] = -7.0                                              # opacity prune
+    gm.create_from_tensors(torch.randn(n, 3) * 0.3, feats, scal, torch.randn(n, 4), opac)
+    gm.training_setup(GSParams())
+    names = GaussianModel._NAMES
+    for _ in range(3):                                              # populate the Adam moments
+        for t in gm._param_dict().values():
+            t.grad = torch.randn_like(t)
+        gm.optimizer.step()
+    gm.xyz_gradient_accum = torch.rand(n, 1) * 0.001
+    gm.denom = torch.randint(0, 3, (n, 1)).float()                  # zeros -> NaN -> 0 as in the reference
+    P0 = {k: v.detach().clone() for k, v in gm._param_dict().items()}
+    M0 = {grp["name"]: (gm.optimizer.state[grp["params"][0]]["exp_avg"].clone(), gm.optimizer.state[grp["params"][0]]["exp_avg_sq"].clone())
+          for grp in gm.optimizer.param_groups}
+    stats0 = (gm.xyz_gradient_accum.clone(), gm.denom.clone())
+    gen = torch.Generator().manual_seed(11)
+    info = gm.densify_and_prune(0.0002, min_opacity=0.005, extent=4, max_screen_size=1, generator=gen)
+    assert info["cloned"] > 20 and info["split"] > 20 and info["pruned"] >= 30
+    noise = torch.randn((2 * info["split"], 3), generator=torch.Generator().manual_seed(11))
+    P1, M1 = _three_round_reference(P0, M0, stats0, 0.0002, 0.01, 4, 0.005, noise)
+    got = gm._param_dict()
+    assert got["xyz"].shape[0] == P1["xyz"].shape[0] == info["points"]
+    for k in names:
+        assert torch.allclose(got[k].detach(), P1[k], rtol=1e-6, atol=1e-7), k
+        assert got[k].requires_grad and got[k].is_leaf
+    for grp in gm.optimizer.param_groups:
+        st = gm.optimizer.state[grp["params"][0]]
+        assert grp["params"][0] is got[grp["name"]]
+        assert torch.equal(st["exp_avg"], M1[grp["name"]][0]) and torch.equal(st["exp_avg_sq"], M1[grp["name"]][1])
+        assert int(st["step"]) == 3
+    assert gm.init_xyz.shape == got["xyz"].shape
+    assert gm.xyz_gradient_accum.shape == (info["points"], 1) and float(gm.xyz_gradient_accum.abs().sum()) == 0.0
+    assert gm.max_radii2D.shape == (info["points"],) and gm.denom.shape == (info["points"], 1)
+    # the optimizer keeps working on the new tensors
+    for t in gm._param_dict().values():
+        t.grad = torch.ones_like(t)
+    gm.optimizer.step()
+    # reset_opacity: opacity <= 0.01 afterwards, only that group loses its moments
+    before = gm.optimizer.state[gm._xyz]["exp_avg"].clone()
+    gm.reset_opacity()
+    assert float(gm.get_opacity.detach().max()) <= 0.01 + 1e-6
+    assert float(gm.optimizer.state[gm._opacity]["exp_avg"].abs().sum()) == 0.0
+    assert torch.equal(gm.optimizer.state[gm._xyz]["exp_avg"], before)
+    # statistics accumulate like the reference's add_densification_stats + max_radii2D update
+    m = gm._xyz.shape[0]
+    vg, radii = torch.randn(m, 3), torch.randint(0, 5, (m,))
+    gm.add_densification_stats(vg, radii > 0, radii)
+    vis = radii > 0
+    assert torch.allclose(gm.xyz_gradient_accum[vis], vg[vis, :2].norm(dim=-1, keepdim=True)) and float(gm.xyz_gradient_accum[~vis].abs().sum()) == 0
+    assert torch.equal(gm.denom.squeeze(-1), vis.float()) and torch.equal(gm.max_radii2D, torch.where(vis, radii, torch.zeros_like(radii)).float())
