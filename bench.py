@@ -412,6 +412,7 @@ def main():
                                    % (a.mode, N, deg, W, H, a.views_per_gpu),
                        "global_views_per_step": a.views_per_gpu * world, "parallelism": "view-parallel dp%d" % world,
                        "exchange": (a.exchange if world > 1 and a.mode != "fwd" else "none"), "render_path": a.render_path, "view_lanes": (a.lanes if a.render_path == "step" and a.mode != "fwd" else 1),
+                       "host_enqueue_ms_per_step": (round(fused_step.last_host_ms, 3) if fused_step is not None else None),
                        "n_visible": n_vis, "tile_splat_pairs": D},
             "roofline": roof, "cpu_baseline": cpu, "kernels": kern, "kernels_concurrent_avg_ms": kern_conc,
         }

@@ -3,6 +3,7 @@ gradients accumulated in place, no host synchronisation between views.  MI355X-f
 trainer (main_3DGS.py:158-207) for the L1 / L2 / alpha-MSE part of its loss; with 288 GB of HBM the (tile, splat) pair buffers are simply sized
 for a generous capacity and grown on the rare overflow."""
 import ctypes as C
+import time
 
 import torch
 
@@ -59,10 +60,12 @@ class FusedViewStep:
             if accumulate:
                 snapshot = [g.clone() for g in grads] if attempt == 0 else snapshot     # to redo the step after an overflow
             self.status.zero_(); self.loss.zero_()
+            t_host = time.perf_counter()
             with torch.cuda.device(self.device):
                 _h.check(lib.c3d_gs_train_views_raw(views, V, self.N, *[_h.ptr(_h.f32c(p)) for p in params], tc, ta, cm, C.byref(loss),
                                                     *[_h.ptr(g) for g in grads], _h.ptr(self.loss), self.capacity, self.lanes, 1 if accumulate else 0, _h.ptr(self.workspace),
                                                     _h.ptr(self.status), _h.stream(self.device)), "c3d_gs_train_views_raw")
+            self.last_host_ms = (time.perf_counter() - t_host) * 1e3      # host time to enqueue the whole step (no sync inside)
             st = self.status.tolist()       # the single host sync of the step
             if st[0] == 0:
                 seen = st[1] & 0xFFFFFFFF
