@@ -21,6 +21,19 @@ __device__ __forceinline__ void swap32(float& a, float& b) {   // a[32..63] <-> 
 __device__ __forceinline__ void swap16(float& a, float& b) {   // rows 1,3 of a <-> rows 0,2 of b
     asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
+// lane select on a wave mask held in an SGPR pair (a ballot).  Written as asm because hipcc picks the VOP2 form that reads VCC
+// (v_cndmask_b32_e32 ..., vcc), which issues ~5x slower on gfx950 than the VOP3 form with an SGPR-pair mask
+// (profiles/r01f_valu_rate_microbench.txt: 22.9 vs 4.7 cycles per wave-instruction).
+__device__ __forceinline__ float sel64(uint64_t m, float if_set, float otherwise) {
+    float r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(otherwise), "v"(if_set), "s"(m));
+    return r;
+}
+__device__ __forceinline__ float sel64z(uint64_t m, float if_set) {   // 0 where the mask is clear
+    float r;
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(if_set), "s"(m));
+    return r;
+}
 __device__ __forceinline__ float wave_reduce4(float a, float b, float c, float d) {
     swap32(a, b); float p = a + b;      // lanes 0-31: a folded to 32 partials | lanes 32-63: b
     swap32(c, d); float q = c + d;      // c | d
@@ -88,7 +101,7 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
                                                         const float4* __restrict__ rec2, const float* __restrict__ final_T,
                                                         const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor,
                                                         const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha_px,
-                                                        float4* __restrict__ pairgrad, int chunk, uint32_t cap) {
+                                                        float4* __restrict__ pairgrad, uint32_t cap) {
     __shared__ float4 s0[BWD_ROUND];
     __shared__ float4 s1[BWD_ROUND];
     __shared__ float4 s2[BWD_ROUND];
@@ -96,9 +109,10 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
     __shared__ uint32_t smask[BWD_ROUND];
     __shared__ float acc[4][GS_PAIR_FLOATS][BWD_ROUND];
     __shared__ int s_maxlast;
-    const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-    if (tile >= p.gx * p.gy) return;
-    const int tx = tile % p.gx, ty = tile / p.gx;
+    __shared__ int s_wlast[4];
+    int tx, ty;
+    if (!gs_block_tile(blockIdx.x, p.gx, p.gy, tx, ty)) return;
+    const int tile = ty * p.gx + tx;
     const int lane = c3d_lane(), wave = threadIdx.x >> 6;
     const int X0 = tx * C3D_TILE_X, Y0 = ty * C3D_TILE_Y;
     const int pxi = X0 + ((wave & 1) << 3) + (lane & 7), pyi = Y0 + ((wave >> 1) << 3) + (lane >> 3);
@@ -126,6 +140,13 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
     atomicMax(&s_maxlast, last);
     __syncthreads();
     const int upto = s_maxlast;   // positions [0, upto) matter
+    // ... and for this wave's quadrant only positions below the deepest of ITS pixels: a splat further back cannot have contributed to any of
+    // them, so the wave skips it without evaluating anything (the tile-level bound alone leaves ~half of the walked pairs without an active lane)
+    int wlast = last;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wlast = max(wlast, __shfl_xor(wlast, o));
+    wlast = __builtin_amdgcn_readfirstlane(wlast);
+    if (lane == 0) s_wlast[wave] = wlast;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     // emit index of the pair (this tile, Gaussian gid): row-major position of the tile inside the Gaussian's rect
     auto emit_index = [&](uint32_t gid) -> uint32_t {
@@ -153,6 +174,10 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
         for (int c = 0; c < n; c += 64) {
             const int jj = c + lane;
             uint64_t m = __ballot(jj < n && ((smask[jj] >> wave) & 1u));
+            {   // list position of slot j is k = upto - 1 - base - j; keep k < wlast  <=>  j >= jmin
+                const int jmin = upto - base - wlast - c;
+                if (jmin > 0) m = jmin >= 64 ? 0ull : (m & (~0ull << jmin));
+            }
             while (m) {
                 const int j = c + (int)__builtin_ctzll(m);
                 m &= m - 1;
@@ -162,21 +187,30 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
                 const float power = -0.5f * (a0.z * dx * dx + a1.x * dy * dy) - a0.w * dx * dy;
                 const float G = __expf(power);
                 const float alpha = fminf(0.99f, a1.y * G);
-                const bool act = (k < last) && (power <= 0.f) && (alpha >= 1.f / 255.f);
+                // act = (k < last) && (power <= 0) && (alpha >= 1/255) as a wave mask in an SGPR pair: the compares are written as asm so that the
+                // mask can feed v_cndmask_b32_e64 directly (a ballot of the C++ bool costs a select + compare round trip through a VGPR)
+                uint64_t am;
+                {
+                    uint64_t c0, c1, c2;
+                    asm("v_cmp_lt_i32_e64 %0, %1, %2" : "=s"(c0) : "v"(k), "v"(last));
+                    asm("v_cmp_ge_f32_e64 %0, 0, %1" : "=s"(c1) : "v"(power));
+                    asm("v_cmp_le_f32_e64 %0, %1, %2" : "=s"(c2) : "v"(1.f / 255.f), "v"(alpha));
+                    am = c0 & c1 & c2;
+                }
                 float t0 = 0.f, t1 = 0.f, t2 = 0.f;
-                if (__ballot(act) != 0ull) {   // wave-uniform
+                if (am != 0ull) {   // wave-uniform
                     // dL/dalpha_k = T_k (c_k . dL) - [sum_{j behind k} (c_j . dL) alpha_j T_j + T_final bg . dL] / (1 - alpha_k)
                     // with (c . dL) taken over colour, depth and alpha channels; Rdot carries the bracket.  Inactive lanes run the
                     // same instructions with a zero weight (no exec-masked branch, no zero-initialised temporaries).
                     const float inv = __builtin_amdgcn_rcpf(1.f - alpha);
                     const float Tn = T * inv;
-                    T = act ? Tn : T;
-                    const float w = act ? alpha * Tn : 0.f;
+                    T = sel64(am, Tn, T);
+                    const float w = sel64z(am, alpha * Tn);
                     const float sdot = a1.z * dLp0 + a1.w * dLp1 + a2.x * dLp2 + a2.y * dLd + dLa;
                     const float dL_dalpha = Tn * sdot - Rdot * inv;
                     Rdot += w * sdot;
                     // screen-space part as raw moments of w2 = dL/dG * G; turned into mean/conic/opacity gradients per Gaussian in A8
-                    const float m0 = act ? a1.y * G * dL_dalpha : 0.f;
+                    const float m0 = sel64z(am, a1.y * G * dL_dalpha);
                     const float m1x = m0 * dx, m1y = m0 * dy;
                     wave_reduce10(w * dLp0, w * dLp1, w * dLp2, w * dLd, m0, m1x, m1y, m1x * dx, m1x * dy, m1y * dy, t0, t1, t2);
                     // t0 rows: c0, c2, c1, depth   t1 rows: m0, m1y, m1x, m2xx   t2 rows: m2xy, 0, m2yy, 0
@@ -194,9 +228,10 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
             float r[GS_PAIR_FLOATS];
 #pragma unroll
             for (int q = 0; q < GS_PAIR_FLOATS; q++) r[q] = 0.f;
+            const int kj = upto - 1 - base - j;
 #pragma unroll
             for (int w = 0; w < 4; w++)
-                if ((mk >> w) & 1u) {
+                if (((mk >> w) & 1u) && kj < s_wlast[w]) {   // waves that skipped the slot left nothing in acc
 #pragma unroll
                     for (int q = 0; q < GS_PAIR_FLOATS; q++) r[q] += acc[w][q][j];
                 }
@@ -215,9 +250,8 @@ int gs_launch_composite_bwd(const GsParams& p, const GsGeom& g, const GsBinning&
                             float* pairgrad, hipStream_t s, uint32_t cap) {
     const int tiles = p.gx * p.gy;
     if (tiles == 0) return 0;
-    const int chunk = c3d_cdiv(tiles, 8);
-    hipLaunchKernelGGL(k_composite_bwd, dim3(chunk * 8), dim3(256), 0, s, p, b.ranges, b.tval[res], g.einfo, g.rec0, g.rec1, g.rec2,
-                       im.final_T, im.n_contrib, dL_dcolor, dL_ddepth, dL_dalpha, (float4*)pairgrad, chunk, cap);
+    hipLaunchKernelGGL(k_composite_bwd, dim3(gs_block_count(p.gx, p.gy)), dim3(256), 0, s, p, b.ranges, b.tval[res], g.einfo, g.rec0, g.rec1, g.rec2,
+                       im.final_T, im.n_contrib, dL_dcolor, dL_ddepth, dL_dalpha, (float4*)pairgrad, cap);
     C3D_LAUNCH_CHECK();
     return 0;
 }

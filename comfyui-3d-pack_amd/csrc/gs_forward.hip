@@ -221,16 +221,14 @@ __global__ void __launch_bounds__(256) k_composite_fwd(GsParams p, const uint2* 
                                                         const float4* __restrict__ rec0, const float4* __restrict__ rec1,
                                                         const float4* __restrict__ rec2, float* __restrict__ out_color,
                                                         float* __restrict__ out_depth, float* __restrict__ out_alpha,
-                                                        float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, int chunk) {
+                                                        float* __restrict__ final_T, uint32_t* __restrict__ n_contrib) {
     __shared__ float4 s0[256];
     __shared__ float4 s1[256];
     __shared__ float4 s2[256];
     __shared__ uint32_t smask[256];
-    // XCD-aware tile order: workgroup b runs on XCD b%8; give each XCD a contiguous run of tiles so
-    // neighbouring tiles (which share splats) hit the same L2.  Speed only, never correctness.
-    const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-    if (tile >= p.gx * p.gy) return;
-    const int tx = tile % p.gx, ty = tile / p.gx;
+    int tx, ty;   // XCD-aware, load-balanced tile order (gs_block_tile).  Speed only, never correctness.
+    if (!gs_block_tile(blockIdx.x, p.gx, p.gy, tx, ty)) return;
+    const int tile = ty * p.gx + tx;
     const int lane = c3d_lane(), wave = threadIdx.x >> 6;
     const int X0 = tx * C3D_TILE_X, Y0 = ty * C3D_TILE_Y;
     const int pxi = X0 + ((wave & 1) << 3) + (lane & 7), pyi = Y0 + ((wave >> 1) << 3) + (lane >> 3);
@@ -293,9 +291,8 @@ int gs_launch_composite_fwd(const GsParams& p, const GsGeom& g, const GsBinning&
                             float* out_color, float* out_depth, float* out_alpha, hipStream_t s) {
     const int tiles = p.gx * p.gy;
     if (tiles == 0) return 0;
-    const int chunk = c3d_cdiv(tiles, 8);
-    hipLaunchKernelGGL(k_composite_fwd, dim3(chunk * 8), dim3(256), 0, s, p, b.ranges, b.tval[res], g.rec0, g.rec1, g.rec2,
-                       out_color, out_depth, out_alpha, im.final_T, im.n_contrib, chunk);
+    hipLaunchKernelGGL(k_composite_fwd, dim3(gs_block_count(p.gx, p.gy)), dim3(256), 0, s, p, b.ranges, b.tval[res], g.rec0, g.rec1, g.rec2,
+                       out_color, out_depth, out_alpha, im.final_T, im.n_contrib);
     C3D_LAUNCH_CHECK();
     return 0;
 }

@@ -145,6 +145,23 @@ __device__ __forceinline__ float alpha_extent(float opacity, float var) {
     return sqrtf(2.f * __logf(t) * var) * 1.0005f + 0.02f;
 }
 
+// ---- block -> tile ------------------------------------------------------------------------------------------
+// The dispatcher deals workgroups to the 8 XCDs round-robin (b & 7).  Each XCD walks the 2x2-tile supertiles q = xcd, xcd + 8, ... in row-major
+// order: neighbouring tiles, which share most of their splats, meet in one XCD's L2, while every XCD covers the whole image -- with contiguous
+// bands per XCD a centred object loads the XCDs that own the middle rows and idles the rest.
+__device__ __forceinline__ bool gs_block_tile(int b, int gx, int gy, int& tx, int& ty) {
+    const int sgx = (gx + 1) >> 1;
+    const int i = b >> 3, q = (b & 7) + 8 * (i >> 2), sub = i & 3;
+    const int sy = q / sgx, sx = q - sy * sgx;
+    tx = 2 * sx + (sub & 1);
+    ty = 2 * sy + (sub >> 1);
+    return tx < gx && ty < gy;
+}
+static inline int gs_block_count(int gx, int gy) {
+    const int S = ((gx + 1) >> 1) * ((gy + 1) >> 1);
+    return 32 * ((S + 7) / 8);
+}
+
 // ---- which of a tile's four 8x8 quadrants can a splat touch? ---------------------------------------------
 // Exact test: alpha >= 1/255  <=>  q(d) = A dx^2 + 2B dx dy + C dy^2 <= 2 ln(255 o); a quadrant is kept iff the minimum of the
 // (convex) form q over its pixel rectangle is below that bound.  The cheap alpha-box test rejects most quadrants first.

@@ -8,11 +8,10 @@
 #include <stdlib.h>
 #include <vector>
 
-#define ITER 2000
 #define REP16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
 
 template <int OP>
-__global__ void __launch_bounds__(256) k_rate(float* out, unsigned long long* cyc, float seed) {
+__global__ void __launch_bounds__(256) k_rate(float* out, unsigned long long* cyc, float seed, int ITER, unsigned long long msk_in) {
     float r[16];
     typedef float f2 __attribute__((ext_vector_type(2)));
     f2 p[16];
@@ -20,6 +19,7 @@ __global__ void __launch_bounds__(256) k_rate(float* out, unsigned long long* cy
     for (int i = 0; i < 16; i++) { r[i] = seed + i * 0.001f + threadIdx.x * 1e-6f; p[i] = f2{r[i], r[i] * 0.5f}; }
     float a = 1.0001f + seed, b = 0.0001f;
     f2 a2 = {a, a}, b2 = {b, b};
+    unsigned long long msk = msk_in, msk2 = 0;
     __syncthreads();
     const unsigned long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < ITER; it++) {
@@ -39,6 +39,13 @@ __global__ void __launch_bounds__(256) k_rate(float* out, unsigned long long* cy
 #define MIN(i) asm volatile("v_min_f32 %0, %0, %1" : "+v"(r[i]) : "v"(a));
 #define FMAC_S(i) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(r[i]) : "v"(a), "v"(b));
 #define MOV(i) asm volatile("v_mov_b32 %0, %1" : "=v"(r[i]) : "v"(a));
+#define CNDMASK64(i) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(r[i]) : "v"(a), "s"(msk));
+#define CMPI(i) asm volatile("v_cmp_lt_i32 vcc, %0, %1" : : "v"(r[i]), "v"(a) : "vcc");
+#define CMP64(i) asm volatile("v_cmp_lt_f32_e64 %0, %1, %2" : "=s"(msk2) : "v"(r[i]), "v"(a));
+#define MAXF(i) asm volatile("v_max_f32 %0, %0, %1" : "+v"(r[i]) : "v"(a));
+#define SWAP16(i) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(r[i]), "+v"(r[(i + 1) & 15]));
+#define MOVDPP(i) asm volatile("v_mov_b32_dpp %0, %1 row_ror:8 row_mask:0xf bank_mask:0xf" : "+v"(r[i]) : "v"(a));
+#define ANDOR(i) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(r[i]) : "v"(a), "v"(b));
         if (OP == 0) { REP16(FMA) }
         if (OP == 1) { REP16(MUL) }
         if (OP == 2) { REP16(ADD) }
@@ -55,37 +62,44 @@ __global__ void __launch_bounds__(256) k_rate(float* out, unsigned long long* cy
         if (OP == 13) { REP16(MIN) }
         if (OP == 14) { REP16(FMAC_S) }
         if (OP == 15) { REP16(MOV) }
+        if (OP == 16) { REP16(CNDMASK64) }
+        if (OP == 17) { REP16(CMPI) }
+        if (OP == 18) { REP16(CMP64) }
+        if (OP == 19) { REP16(MAXF) }
+        if (OP == 20) { REP16(SWAP16) }
+        if (OP == 21) { REP16(MOVDPP) }
+        if (OP == 22) { REP16(ANDOR) }
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; i++) s += r[i] + p[i].x + p[i].y;
-    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s + (float)(msk2 & 1);
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
 template <int OP>
-void run(const char* name, float* out, unsigned long long* cyc, int blocks) {
+double once(float* out, unsigned long long* cyc, int blocks, int iter) {
     hipEvent_t e0, e1;
-    hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(k_rate<OP>, dim3(blocks), dim3(256), 0, 0, out, cyc, 0.5f);
-    hipDeviceSynchronize();
-    hipEventRecord(e0, 0);
-    hipLaunchKernelGGL(k_rate<OP>, dim3(blocks), dim3(256), 0, 0, out, cyc, 0.5f);
-    hipEventRecord(e1, 0);
-    hipEventSynchronize(e1);
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL(k_rate<OP>, dim3(blocks), dim3(256), 0, 0, out, cyc, 0.5f, iter, 0x5555555555555555ull);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(k_rate<OP>, dim3(blocks), dim3(256), 0, 0, out, cyc, 0.5f, iter, 0x5555555555555555ull);
+    (void)hipEventRecord(e1, 0);
+    (void)hipEventSynchronize(e1);
     float ms = 0;
-    hipEventElapsedTime(&ms, e0, e1);
-    std::vector<unsigned long long> h(blocks);
-    hipMemcpy(h.data(), cyc, sizeof(unsigned long long) * blocks, hipMemcpyDeviceToHost);
-    double mean = 0;
-    for (auto v : h) mean += (double)v;
-    mean /= blocks;
-    // 8 blocks per CU resident (256 threads = one wave per SIMD each) -> 8 waves per SIMD share the issue port
-    const double instr_per_wave = (double)ITER * 16;
-    const double total_wave_instr = instr_per_wave * blocks * 4;
-    printf("%-22s wall %.3f ms  -> %.2f G wave-instr/s chip-wide ; counter ticks per wave-instr (8 waves/SIMD): %.2f (x8 waves => %.2f per SIMD slot)\n", name, ms,
-           total_wave_instr / (ms * 1e-3) / 1e9, mean / instr_per_wave, mean / instr_per_wave / 8.0);
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    return ms;
+}
+template <int OP>
+void run(const char* name, float* out, unsigned long long* cyc, int blocks) {
+    const int i0 = 2000, i1 = 12000;
+    const double t0 = once<OP>(out, cyc, blocks, i0), t1 = once<OP>(out, cyc, blocks, i1);
+    // slope: time of (i1 - i0) * 16 instructions per wave, 8 waves per SIMD, one SIMD issue port
+    const double instr_per_simd = (double)(i1 - i0) * 16 * 8;
+    const double ns_per_instr = (t1 - t0) * 1e6 / instr_per_simd;
+    printf("%-26s %7.3f ms / %7.3f ms  -> %.3f ns per wave-instruction per SIMD = %.2f cycles at 2.4 GHz\n", name, t0, t1, ns_per_instr, ns_per_instr * 2.4);
 }
 
 int main() {
@@ -114,5 +128,12 @@ int main() {
     run<12>("v_cmp_lt_f32", out, cyc, blocks);
     run<13>("v_min_f32", out, cyc, blocks);
     run<15>("v_mov_b32", out, cyc, blocks);
+    run<16>("v_cndmask_b32_e64 sgpr", out, cyc, blocks);
+    run<17>("v_cmp_lt_i32 vcc", out, cyc, blocks);
+    run<18>("v_cmp_lt_f32_e64 sgpr", out, cyc, blocks);
+    run<19>("v_max_f32", out, cyc, blocks);
+    run<20>("v_permlane16_swap", out, cyc, blocks);
+    run<21>("v_mov_b32_dpp row_ror", out, cyc, blocks);
+    run<22>("v_and_or_b32", out, cyc, blocks);
     return 0;
 }
