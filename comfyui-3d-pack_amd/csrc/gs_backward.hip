@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
                                                         const float4* __restrict__ rec2, const float* __restrict__ final_T,
                                                         const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor,
                                                         const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha_px,
-                                                        float4* __restrict__ pairgrad, uint32_t cap) {
+                                                        float4* __restrict__ pairgrad, uint32_t cap, int sh) {
     __shared__ float4 s0[BWD_ROUND];
     __shared__ float4 s1[BWD_ROUND];
     __shared__ float4 s2[BWD_ROUND];
@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
     __shared__ int s_maxlast;
     __shared__ int s_wlast[4];
     int tx, ty;
-    if (!gs_block_tile(blockIdx.x, p.gx, p.gy, tx, ty)) return;
+    if (!gs_block_tile(blockIdx.x, p.gx, p.gy, tx, ty, sh)) return;
     const int tile = ty * p.gx + tx;
     const int lane = c3d_lane(), wave = threadIdx.x >> 6;
     const int X0 = tx * C3D_TILE_X, Y0 = ty * C3D_TILE_Y;
@@ -250,8 +250,8 @@ int gs_launch_composite_bwd(const GsParams& p, const GsGeom& g, const GsBinning&
                             float* pairgrad, hipStream_t s, uint32_t cap) {
     const int tiles = p.gx * p.gy;
     if (tiles == 0) return 0;
-    hipLaunchKernelGGL(k_composite_bwd, dim3(gs_block_count(p.gx, p.gy)), dim3(256), 0, s, p, b.ranges, b.tval[res], g.einfo, g.rec0, g.rec1, g.rec2,
-                       im.final_T, im.n_contrib, dL_dcolor, dL_ddepth, dL_dalpha, (float4*)pairgrad, cap);
+    hipLaunchKernelGGL(k_composite_bwd, dim3(gs_block_count(p.gx, p.gy, gs_supertile_shift())), dim3(256), 0, s, p, b.ranges, b.tval[res], g.einfo, g.rec0, g.rec1, g.rec2,
+                       im.final_T, im.n_contrib, dL_dcolor, dL_ddepth, dL_dalpha, (float4*)pairgrad, cap, gs_supertile_shift());
     C3D_LAUNCH_CHECK();
     return 0;
 }

@@ -221,13 +221,13 @@ __global__ void __launch_bounds__(256) k_composite_fwd(GsParams p, const uint2* 
                                                         const float4* __restrict__ rec0, const float4* __restrict__ rec1,
                                                         const float4* __restrict__ rec2, float* __restrict__ out_color,
                                                         float* __restrict__ out_depth, float* __restrict__ out_alpha,
-                                                        float* __restrict__ final_T, uint32_t* __restrict__ n_contrib) {
+                                                        float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, int sh) {
     __shared__ float4 s0[256];
     __shared__ float4 s1[256];
     __shared__ float4 s2[256];
     __shared__ uint32_t smask[256];
     int tx, ty;   // XCD-aware, load-balanced tile order (gs_block_tile).  Speed only, never correctness.
-    if (!gs_block_tile(blockIdx.x, p.gx, p.gy, tx, ty)) return;
+    if (!gs_block_tile(blockIdx.x, p.gx, p.gy, tx, ty, sh)) return;
     const int tile = ty * p.gx + tx;
     const int lane = c3d_lane(), wave = threadIdx.x >> 6;
     const int X0 = tx * C3D_TILE_X, Y0 = ty * C3D_TILE_Y;
@@ -291,8 +291,8 @@ int gs_launch_composite_fwd(const GsParams& p, const GsGeom& g, const GsBinning&
                             float* out_color, float* out_depth, float* out_alpha, hipStream_t s) {
     const int tiles = p.gx * p.gy;
     if (tiles == 0) return 0;
-    hipLaunchKernelGGL(k_composite_fwd, dim3(gs_block_count(p.gx, p.gy)), dim3(256), 0, s, p, b.ranges, b.tval[res], g.rec0, g.rec1, g.rec2,
-                       out_color, out_depth, out_alpha, im.final_T, im.n_contrib);
+    hipLaunchKernelGGL(k_composite_fwd, dim3(gs_block_count(p.gx, p.gy, gs_supertile_shift())), dim3(256), 0, s, p, b.ranges, b.tval[res], g.rec0, g.rec1, g.rec2,
+                       out_color, out_depth, out_alpha, im.final_T, im.n_contrib, gs_supertile_shift());
     C3D_LAUNCH_CHECK();
     return 0;
 }

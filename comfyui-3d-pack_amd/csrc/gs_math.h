@@ -3,6 +3,7 @@
 // MVs_Algorithms/GaussianSplatting/main_3DGS_renderer.py:927-936 calls); SH basis and signs as in
 // shared_utils/sh_utils.py:26-43,57-100; quaternion (w,x,y,z) as in main_3DGS_renderer.py:84-102.
 #pragma once
+#include <stdlib.h>
 #include "c3d_common.h"
 
 #define GS_SH_C0 0.28209479177387814f
@@ -149,17 +150,23 @@ __device__ __forceinline__ float alpha_extent(float opacity, float var) {
 // The dispatcher deals workgroups to the 8 XCDs round-robin (b & 7).  Each XCD walks the 2x2-tile supertiles q = xcd, xcd + 8, ... in row-major
 // order: neighbouring tiles, which share most of their splats, meet in one XCD's L2, while every XCD covers the whole image -- with contiguous
 // bands per XCD a centred object loads the XCDs that own the middle rows and idles the rest.
-__device__ __forceinline__ bool gs_block_tile(int b, int gx, int gy, int& tx, int& ty) {
-    const int sgx = (gx + 1) >> 1;
-    const int i = b >> 3, q = (b & 7) + 8 * (i >> 2), sub = i & 3;
+__device__ __forceinline__ bool gs_block_tile(int b, int gx, int gy, int& tx, int& ty, int sh = 1) {
+    const int sgx = (gx + (1 << sh) - 1) >> sh;
+    const int per = 1 << (2 * sh);
+    const int i = b >> 3, q = (b & 7) + 8 * (i >> (2 * sh)), sub = i & (per - 1);
     const int sy = q / sgx, sx = q - sy * sgx;
-    tx = 2 * sx + (sub & 1);
-    ty = 2 * sy + (sub >> 1);
+    tx = (sx << sh) + (sub & ((1 << sh) - 1));
+    ty = (sy << sh) + (sub >> sh);
     return tx < gx && ty < gy;
 }
-static inline int gs_block_count(int gx, int gy) {
-    const int S = ((gx + 1) >> 1) * ((gy + 1) >> 1);
-    return 32 * ((S + 7) / 8);
+static inline int gs_supertile_shift() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("C3D_SUPERTILE_SHIFT"); v = e ? atoi(e) : 1; if (v < 0 || v > 3) v = 1; }
+    return v;
+}
+static inline int gs_block_count(int gx, int gy, int sh = 1) {
+    const int S = ((gx + (1 << sh) - 1) >> sh) * ((gy + (1 << sh) - 1) >> sh);
+    return 8 * (1 << (2 * sh)) * ((S + 7) / 8);
 }
 
 // ---- which of a tile's four 8x8 quadrants can a splat touch? ---------------------------------------------
