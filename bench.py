@@ -121,23 +121,6 @@ def main_mesh(a, world, rank, dev, dist):
     dt = time.perf_counter() - t0
     prof = c3d_hip.prof_read() if a.timed_prof == "on" else {}
     c3d_hip.prof_enable(False)
-    # With view lanes > 1 the kernels of different views share the CUs, so a kernel's wall duration inside the timed region is no longer
-    # its own cost.  The roofline figure therefore comes from an extra, untimed single-lane pass over the same step (same inputs, same
-    # kernels); the concurrent durations of the timed region are reported next to it as "kernels_concurrent".
-    prof_conc = None
-    if fused_step is not None and fused_step.lanes > 1:
-        prof_conc = prof
-        lanes_step, fused_step = fused_step, FusedViewStep(N, H, W, dev, lanes=1, pair_capacity=fused_step.capacity, views=len(settings))
-        fused_step._fitted = True
-        step()
-        sync()
-        c3d_hip.prof_enable(True)
-        for _ in range(min(a.steps, 4)):
-            step()
-        sync()
-        prof = c3d_hip.prof_read()
-        c3d_hip.prof_enable(False)
-        fused_step = lanes_step
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt = float(tt.item())
     P, V, T = H * W, v.shape[0], f.shape[0]
@@ -252,9 +235,11 @@ def main():
     if a.render_path == "step" and a.mode != "fwd":
         from c3d_hip.gs_step import FusedViewStep
         fused_step = FusedViewStep(N, H, W, dev, lanes=a.lanes, views=len(settings))
-        step_grads = [torch.zeros_like(q) for q in plist]
+        from c3d_hip.parallel import FlatGrads
+        flat_grads = FlatGrads(plist)        # one buffer: the kernels write into what the collective sends
+        step_grads = flat_grads.views
         for q, gq in zip(plist, step_grads):
-            q.grad = gq                      # the optimizer / exchange read .grad; the library accumulates into these buffers
+            q.grad = gq                      # the optimizer reads .grad
 
     def step(collect=False):
         if fused_step is not None and not collect:
@@ -272,7 +257,9 @@ def main():
                     tc, ta = targets[i]
                     loss = (color - tc).abs().mean() * 0.8 + 3.0 * ((alpha - ta) ** 2).mean()
                     (loss / (a.views_per_gpu * world)).backward()
-        if a.mode != "fwd" and world > 1:
+        if a.mode != "fwd" and world > 1 and fused_step is not None and not collect:
+            flat_grads.exchange(None, a.exchange, average=False)
+        elif a.mode != "fwd" and world > 1:
             flat = torch.cat([q.grad.reshape(N, -1) for q in plist], dim=1)   # [N, 59] dense gradient
             if a.exchange == "allgather":
                 buf = torch.empty((world * N, flat.shape[1]), device=dev)

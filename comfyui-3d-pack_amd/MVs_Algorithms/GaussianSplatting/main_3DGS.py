@@ -187,7 +187,8 @@ class GaussianSplatting3D:
         p, ctl, H, W = self.gs_params, self.cam_controller, self.ref_size_H, self.ref_size_W
         if self._step is None:
             self._step = FusedViewStep(self.params[0].shape[0], H, W, self.device)
-            self._step_grads = [torch.zeros_like(q) for q in self.params]
+            self._flat_grads = parallel.FlatGrads(self.params)       # the kernels write into what the collective sends
+            self._step_grads = self._flat_grads.views
             self._masked_refs = self.ref_imgs_torch * self.ref_masks_torch        # the loss compares masked images (reference :169-173)
         views = []
         for i in mine:
@@ -201,9 +202,9 @@ class GaussianSplatting3D:
                               [self.ref_masks_torch[i].contiguous() for i in mine], [self.ref_masks_torch[i].contiguous() for i in mine],
                               w_l1=1.0 - p.lambda_ssim, w_l2=0.0, w_alpha_mse=p.lambda_alpha, scale=1.0 / max(len(mine), 1),
                               accumulate=False)      # every gradient is written exactly once: no zero-fill
+        self._flat_grads.exchange(self.group, self.exchange, average=True)
         for q, gq in zip(self.params, self._step_grads):
             q.grad = gq
-        parallel.exchange_gradients(self.params, self.group, self.exchange, average=True)
         self.optimizer.step()
         step_obj = self._step
         for q in self.params:

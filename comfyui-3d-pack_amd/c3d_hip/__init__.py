@@ -49,6 +49,7 @@ _SIGNATURES = {
     "c3d_gs_mark_visible": (C.c_int, [i32, vp, vp, vp, vp, vp]),
     "c3d_gs_debug_state": (C.c_int, [i32, i32, i32, vp, i64, vp] + [vp] * 7 + [vp]),
     "c3d_adam_step": (C.c_int, [vp, vp, vp, vp, i64, C.c_double, C.c_double, C.c_double, C.c_double, i64, vp]),
+    "c3d_reduce_ranks_f32": (C.c_int, [vp, vp, i32, i64, C.c_float, vp]),
     "c3d_prof_enable": (C.c_int, [C.c_int]),
     "c3d_prof_slots": (C.c_int, []),
     "c3d_prof_name": (C.c_char_p, [C.c_int]),

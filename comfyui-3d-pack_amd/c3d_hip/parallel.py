@@ -60,6 +60,51 @@ def exchange_gradients(params, group=None, mode="allgather", average=False):
     unflatten_into_grads(total, params)
 
 
+class FlatGrads:
+    """One flat fp32 buffer holding the gradients of all parameter tensors (16-byte aligned segments); `views[i]` has the shape of
+    params[i] and aliases the buffer, so the kernels that produce the gradients write straight into what the collective sends:
+    no torch.cat before the exchange and no copy back after it."""
+
+    def __init__(self, params):
+        sizes = [(p.numel() + 3) // 4 * 4 for p in params]
+        self.flat = torch.zeros((sum(sizes),), dtype=torch.float32, device=params[0].device)
+        self.views, off = [], 0
+        for p, sz in zip(params, sizes):
+            self.views.append(self.flat[off:off + p.numel()].view(p.shape))
+            off += sz
+        self._gathered = None
+
+    def exchange(self, group=None, mode="allgather", average=False):
+        """sum (or mean) over the ranks of `group`, in place; identical bits on every rank"""
+        if not dist.is_available() or not dist.is_initialized():
+            return
+        world = dist.get_world_size(group)
+        if world == 1:
+            return
+        flat, n = self.flat, self.flat.numel()
+        scale = 1.0 / world if average else 1.0
+        if mode == "allgather":
+            if self._gathered is None or self._gathered.numel() != world * n:
+                self._gathered = torch.empty((world * n,), dtype=flat.dtype, device=flat.device)
+            dist.all_gather_into_tensor(self._gathered, flat, group=group)
+            if flat.is_cuda:        # one streaming pass, ranks added in rank order
+                import c3d_hip as _h
+                with torch.cuda.device(flat.device):
+                    _h.check(_h.lib().c3d_reduce_ranks_f32(_h.ptr(flat), _h.ptr(self._gathered), world, n, scale, _h.stream(flat.device)), "c3d_reduce_ranks_f32")
+            else:                   # gloo / CPU tensors (host-logic tests): same order, torch ops
+                g = self._gathered.view(world, n)
+                total = g[0].clone()
+                for r in range(1, world):
+                    total += g[r]
+                flat.copy_(total * scale if average else total)
+        elif mode == "allreduce":
+            dist.all_reduce(flat, group=group)
+            if average:
+                flat.mul_(scale)
+        else:
+            raise ValueError("mode must be 'allgather' or 'allreduce'")
+
+
 def broadcast_parameters(params, src=0, group=None):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         for p in params:

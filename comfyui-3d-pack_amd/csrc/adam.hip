@@ -48,3 +48,35 @@ extern "C" int c3d_adam_step(float* param, const float* grad, float* exp_avg, fl
     C3D_LAUNCH_CHECK();
     return 0;
 }
+
+// dst = scale * sum over ranks (rank order) of the gathered gradient copies; see include/c3d_optim.h
+__global__ void __launch_bounds__(256) k_reduce_ranks(float* __restrict__ dst, const float* __restrict__ src, int world, long long n, float scale) {
+    const long long n4 = n >> 2, stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 a = reinterpret_cast<const float4*>(src)[i];
+        for (int r = 1; r < world; r++) {
+            const float4 b = reinterpret_cast<const float4*>(src + (size_t)r * n)[i];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        reinterpret_cast<float4*>(dst)[i] = make_float4(a.x * scale, a.y * scale, a.z * scale, a.w * scale);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const long long i = (n4 << 2) + threadIdx.x;
+        float a = src[i];
+        for (int r = 1; r < world; r++) a += src[(size_t)r * n + i];
+        dst[i] = a * scale;
+    }
+}
+extern "C" int c3d_reduce_ranks_f32(float* dst, const float* gathered, int32_t world, int64_t n, float scale, c3d_stream_t stream) {
+    if (n <= 0 || world <= 0) return 0;
+    if (!dst || !gathered) { c3d_set_error("c3d_reduce_ranks_f32: NULL pointer"); return -1; }
+    if ((((uintptr_t)dst | (uintptr_t)gathered) & 15) || (world > 1 && (n & 3))) { c3d_set_error("c3d_reduce_ranks_f32: pointers must be 16-byte aligned and n a multiple of 4"); return -1; }
+    hipStream_t s = (hipStream_t)stream;
+    C3dProfScope ps(C3D_P_OTHER, s);
+    long long blocks = ((n >> 2) + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_reduce_ranks, dim3((unsigned)blocks), dim3(256), 0, s, dst, gathered, world, (long long)n, scale);
+    C3D_LAUNCH_CHECK();
+    return 0;
+}

@@ -22,6 +22,12 @@ typedef void* c3d_stream_t; /* hipStream_t */
 #endif
 int c3d_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1,
                   double beta2, double eps, int64_t step, c3d_stream_t stream);
+
+/* Fixed-order sum of the per-rank gradient copies an all-gather delivered (view-parallel training):
+ *   dst[i] = scale * (gathered[0*n + i] + gathered[1*n + i] + ... + gathered[(world-1)*n + i]),  ranks added in that order,
+ * so that every replica computes the same bits.  One streaming pass (world reads + 1 write per element) instead of world-1
+ * read-modify-write sweeps.  dst must not overlap gathered; pointers 16-byte aligned. */
+int c3d_reduce_ranks_f32(float* dst, const float* gathered, int32_t world, int64_t n, float scale, c3d_stream_t stream);
 #ifdef __cplusplus
 }
 #endif

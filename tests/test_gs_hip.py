@@ -530,3 +530,25 @@ def _minicam_for(tr, pose):
     radius, elev, azim, cx, cy, cz = pose
     return MiniCam(orbit_camera(elev, azim, radius, target=np.array([cx, cy, cz], dtype=np.float32)), tr.ref_size_W, tr.ref_size_H, ctl.cam.fovy, ctl.cam.fovx,
                    ctl.cam.near, ctl.cam.far, ctl.projection_matrix, device=tr.device)
+
+
+def test_reduce_ranks_fixed_order_sum():
+    """c3d_reduce_ranks_f32: the local half of the all-gather gradient exchange -- rank-ordered sum of the gathered copies in one pass,
+    bit-equal to adding the copies one after another."""
+    import c3d_hip as h
+    world, n = 8, 4 * 50001
+    g = torch.randn(world * n, device="cuda")
+    dst = torch.empty(n, device="cuda")
+    h.check(h.lib().c3d_reduce_ranks_f32(h.ptr(dst), h.ptr(g), world, n, 0.125, h.stream(dst.device)), "c3d_reduce_ranks_f32")
+    ref = g[:n].clone()
+    for r in range(1, world):
+        ref += g[r * n:(r + 1) * n]
+    assert torch.equal(dst, ref * 0.125)
+    # FlatGrads: views alias one 16-byte aligned buffer in parameter order
+    from c3d_hip.parallel import FlatGrads
+    ps = [torch.zeros(1001, *s, device="cuda") for s in ((3,), (1, 3), (15, 3), (1,), (3,), (4,))]
+    fg = FlatGrads(ps)
+    for i, v in enumerate(fg.views):
+        assert v.shape == ps[i].shape and v.is_contiguous() and v.data_ptr() % 16 == 0
+        v.fill_(float(i + 1))
+    assert float(fg.flat.sum()) == sum((i + 1) * p.numel() for i, p in enumerate(ps))

@@ -87,9 +87,17 @@ def _worker(rank, world, port, mode, out):
     g = torch.Generator().manual_seed(100 + rank)
     for p in params:   # stand-in for "this rank's views' gradients"
         p.grad = sum(torch.randn(p.shape, generator=torch.Generator().manual_seed(1000 * v + i)) for i, v in enumerate(mine)) * 1.0
+    # the same exchange through the flat gradient buffer the fused step writes into (no cat / copy-back)
+    fg = parallel.FlatGrads(params)
+    for v_, p in zip(fg.views, params):
+        v_.copy_(p.grad)
+    assert all(v_.data_ptr() % 16 == 0 for v_ in fg.views)
+    fg.exchange(None, mode, average=False)
     parallel.exchange_gradients(params, None, mode, average=False)
     flat = parallel.flatten_grads(params)
     assert flat.shape == (N, 59)
+    for v_, p in zip(fg.views, params):
+        assert torch.equal(v_, p.grad)
     out[rank] = (flat.clone(), mine)
     dist.destroy_process_group()
 
