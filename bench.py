@@ -241,8 +241,17 @@ def main():
         for q, gq in zip(plist, step_grads):
             q.grad = gq                      # the optimizer reads .grad
 
+    view_render = None
+    if a.render_path == "step" and a.mode == "fwd":
+        from c3d_hip.gs_step import FusedViewRender
+        view_render = FusedViewRender(N, H, W, dev, lanes=a.lanes)     # all views of the step in one library call
+
     def step(collect=False):
-        if fused_step is not None and not collect:
+        nonlocal fused_step, view_render
+        if view_render is not None and not collect:
+            with torch.no_grad():
+                view_render.run(settings, plist)
+        elif fused_step is not None and not collect:
             fused_step.run(settings, [q.detach() for q in plist], step_grads, [tg[0] for tg in targets], [tg[1] for tg in targets], None,
                            w_l1=0.8, w_l2=0.0, w_alpha_mse=3.0, scale=1.0 / (a.views_per_gpu * world), accumulate=False)
             for q, gq in zip(plist, step_grads):
@@ -305,10 +314,15 @@ def main():
     # its own cost.  The roofline figure therefore comes from an extra, untimed single-lane pass over the same step (same inputs, same
     # kernels); the concurrent durations of the timed region are reported next to it as "kernels_concurrent".
     prof_conc = None
-    if fused_step is not None and fused_step.lanes > 1:
+    multi = fused_step if fused_step is not None else view_render
+    if multi is not None and multi.lanes > 1:
         prof_conc = prof
-        lanes_step, fused_step = fused_step, FusedViewStep(N, H, W, dev, lanes=1, pair_capacity=fused_step.capacity, views=len(settings))
-        fused_step._fitted = True
+        if fused_step is not None:
+            keep_obj, fused_step = fused_step, FusedViewStep(N, H, W, dev, lanes=1, pair_capacity=fused_step.capacity, views=len(settings))
+            fused_step._fitted = True
+        else:
+            keep_obj, view_render = view_render, FusedViewRender(N, H, W, dev, lanes=1, pair_capacity=view_render.capacity)
+            view_render._fitted = True
         step()
         sync()
         c3d_hip.prof_enable(True)
@@ -317,7 +331,10 @@ def main():
         sync()
         prof = c3d_hip.prof_read()
         c3d_hip.prof_enable(False)
-        fused_step = lanes_step
+        if fused_step is not None:
+            fused_step = keep_obj
+        else:
+            view_render = keep_obj
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -398,7 +415,7 @@ def main():
             "config": {"workload": "3DGS %s, %d synthetic Gaussians (seed 1234) SH deg %d, %dx%d, %d orbit views/GPU/step of the 64-camera orbit"
                                    % (a.mode, N, deg, W, H, a.views_per_gpu),
                        "global_views_per_step": a.views_per_gpu * world, "parallelism": "view-parallel dp%d" % world,
-                       "exchange": (a.exchange if world > 1 and a.mode != "fwd" else "none"), "render_path": a.render_path, "view_lanes": (a.lanes if a.render_path == "step" and a.mode != "fwd" else 1),
+                       "exchange": (a.exchange if world > 1 and a.mode != "fwd" else "none"), "render_path": a.render_path, "view_lanes": (a.lanes if a.render_path == "step" else 1),
                        "host_enqueue_ms_per_step": (round(fused_step.last_host_ms, 3) if fused_step is not None else None),
                        "n_visible": n_vis, "tile_splat_pairs": D},
             "roofline": roof, "cpu_baseline": cpu, "kernels": kern, "kernels_concurrent_avg_ms": kern_conc,

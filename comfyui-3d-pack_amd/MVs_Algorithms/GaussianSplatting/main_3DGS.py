@@ -10,11 +10,12 @@ and is not built yet -- the trainer refuses to run with it enabled instead of si
 import random
 from dataclasses import dataclass
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
 from c3d_hip import parallel
-from shared_utils.camera_utils import BaseCameraController, MiniCam, get_projection_matrix
+from shared_utils.camera_utils import BaseCameraController, MiniCam, get_projection_matrix, orbit_camera
 from shared_utils.msssim import MS_SSIM
 from .main_3DGS_renderer import GaussianSplattingRenderer
 
@@ -59,6 +60,20 @@ class GaussianSplattingCameraController(BaseCameraController):
         cam = MiniCam(render_pose, self.cam.W, self.cam.H, self.cam.fovy, self.cam.fovx, self.cam.near, self.cam.far,
                       self.projection_matrix, device=self.device)
         return self.renderer.render(cam, bg_color=bg_color, **kwargs)
+
+    def render_all_pose(self, all_cam_poses, **kwargs):
+        """orbit rendering (reference camera_utils.py:160-175 via the renderer nodes): without autograd and without per-view options the whole
+        orbit goes through ONE batched library call; otherwise the reference's per-view loop."""
+        g = self.renderer.gaussians
+        if kwargs or torch.is_grad_enabled() or not (g._xyz.is_cuda and g.max_sh_degree == 3) or len(all_cam_poses) == 0:
+            return super().render_all_pose(all_cam_poses, **kwargs)
+        cams, bgs = [], []
+        for radius, elevation, azimuth, cx, cy, cz in all_cam_poses:
+            pose = orbit_camera(elevation, azimuth, radius, target=np.array([cx, cy, cz], dtype=np.float32))
+            cams.append(MiniCam(pose, self.cam.W, self.cam.H, self.cam.fovy, self.cam.fovx, self.cam.near, self.cam.far, self.projection_matrix, device=self.device))
+            bgs.append(self.static_bg if self.static_bg is not None else (self.white_bg if np.random.rand() > self.invert_bg_prob else self.black_bg))
+        out = self.renderer.render_views(cams, bgs)
+        return out["image"], out["alpha"], out
 
 
 def _fit(img, H, W, device):

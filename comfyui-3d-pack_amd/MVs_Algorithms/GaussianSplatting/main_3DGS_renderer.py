@@ -323,6 +323,30 @@ class GaussianSplattingRenderer:
         else:
             raise TypeError("initialize(): pass None, a GS PlyData or a dict of raw tensors (mesh / point-cloud initialisers need simple_knn: out of scope)")
 
+    def render_views(self, viewpoint_cameras, bg_colors=None, scaling_modifier=1.0, lanes=4):
+        """Inference-only batch of render(): all cameras in ONE library call (c3d_gs_render_views_raw; views dealt onto `lanes` HIP
+        streams, no host synchronisation between views).  Same per-view results as render() -- the orbit-renderer loop of the reference's
+        nodes without its per-view launch gaps.  bg_colors: None, one [3] tensor or one per camera.
+        -> dict(image [V,3,H,W] clamped, depth [V,1,H,W], alpha [V,1,H,W], radii [V,N], visibility_filter [V,N])"""
+        from diff_gaussian_rasterization import GaussianRasterizationSettings
+        from c3d_hip.gs_step import FusedViewRender
+        g = self.gaussians
+        if not (g._xyz.is_cuda and g.max_sh_degree == 3):
+            raise RuntimeError("render_views needs a HIP-resident model with SH degree-3 storage; use render() otherwise")
+        V = len(viewpoint_cameras)
+        if bg_colors is None or torch.is_tensor(bg_colors):
+            bg_colors = [self.bg_color if bg_colors is None else bg_colors] * V
+        H, W = int(viewpoint_cameras[0].image_height), int(viewpoint_cameras[0].image_width)
+        settings = [GaussianRasterizationSettings(H, W, math.tan(c.FoVx * 0.5), math.tan(c.FoVy * 0.5), bg, scaling_modifier, c.world_view_transform,
+                                                  c.full_proj_transform, g.active_sh_degree, c.camera_center, False, False)
+                    for c, bg in zip(viewpoint_cameras, bg_colors)]
+        key = (g._xyz.shape[0], H, W, int(lanes))
+        if getattr(self, "_view_render_key", None) != key:
+            self._view_render, self._view_render_key = FusedViewRender(key[0], H, W, self.device, lanes=lanes), key
+        with torch.no_grad():
+            color, depth, alpha, radii = self._view_render.run(settings, [g._xyz, g._features_dc, g._features_rest, g._opacity, g._scaling, g._rotation], want_radii=True)
+            return {"image": color.clamp_(0, 1), "depth": depth, "alpha": alpha, "radii": radii, "visibility_filter": radii > 0}
+
     def render(self, viewpoint_camera, scaling_modifier=1.0, gaussain_idx=None, bg_color=None, override_color=None,
                compute_cov3D_python=False, convert_SHs_python=False):
         """-> dict(image[3,H,W] clamped, depth[1,H,W], alpha[1,H,W], viewspace_points[N,3], visibility_filter[N], radii[N])"""

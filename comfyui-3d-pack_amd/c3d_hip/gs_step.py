@@ -92,3 +92,50 @@ class FusedViewStep:
             _h.check(_h.lib().c3d_gs_step_read_view(self.N, self.H, self.W, cap, _h.ptr(ws), int(view), _h.ptr(radii), _h.ptr(g2),
                                                     _h.stream(self.device)), "c3d_gs_step_read_view")
         return radii, g2
+
+
+class FusedViewRender:
+    """Forward only: V views of one cloud per library call (c3d_gs_render_views_raw), views dealt onto `lanes` HIP streams, no host
+    synchronisation between views -- the orbit-rendering loop of the reference's renderer nodes in one call."""
+
+    def __init__(self, N, H, W, device, pair_capacity=None, lanes=4):
+        self.N, self.H, self.W, self.device = N, H, W, torch.device(device)
+        self.lanes = max(1, min(8, int(lanes)))
+        self.capacity = int(pair_capacity or max(8 * N, 1 << 22))
+        self.status = torch.zeros(2, dtype=torch.int32, device=self.device)
+        self._fitted = False
+        self._alloc()
+
+    def _alloc(self):
+        nbytes = _h.lib().c3d_gs_step_workspace_bytes(self.N, self.H, self.W, self.capacity, self.lanes)
+        self.workspace = torch.empty((nbytes,), dtype=torch.uint8, device=self.device)
+
+    def run(self, raster_settings, params, want_radii=False, max_retries=3):
+        """params: (xyz, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw) -> color [V,3,H,W], depth [V,1,H,W], alpha [V,1,H,W], radii [V,N] | None"""
+        lib = _h.lib()
+        V = len(raster_settings)
+        f32 = dict(dtype=torch.float32, device=self.device)
+        color, depth, alpha = torch.empty((V, 3, self.H, self.W), **f32), torch.empty((V, 1, self.H, self.W), **f32), torch.empty((V, 1, self.H, self.W), **f32)
+        radii = torch.empty((V, self.N), dtype=torch.int32, device=self.device) if want_radii else None
+        if V == 0:
+            return color, depth, alpha, radii
+        arr = lambda t: (C.c_void_p * V)(*[t[i].data_ptr() for i in range(V)])
+        for attempt in range(max_retries + 1):
+            keep = []
+            views = FusedViewStep._settings(raster_settings, keep)
+            self.status.zero_()
+            with torch.cuda.device(self.device):
+                _h.check(lib.c3d_gs_render_views_raw(views, V, self.N, *[_h.ptr(_h.f32c(p)) for p in params], arr(color), arr(depth), arr(alpha),
+                                                     arr(radii) if want_radii else None, self.capacity, self.lanes, _h.ptr(self.workspace), _h.ptr(self.status),
+                                                     _h.stream(self.device)), "c3d_gs_render_views_raw")
+            st = self.status.tolist()       # the single host sync of the call
+            seen = st[1] & 0xFFFFFFFF
+            if st[0] == 0:
+                if not self._fitted and self.capacity > 2 * max(seen, 1 << 16):
+                    self.capacity = int(seen * 1.3) + 4096
+                    self._alloc()
+                self._fitted = True
+                return color, depth, alpha, radii
+            self.capacity = int(max(seen, self.capacity) * 1.25) + 1024
+            self._alloc()
+        raise RuntimeError("c3d FusedViewRender: pair capacity still exceeded after %d retries" % max_retries)

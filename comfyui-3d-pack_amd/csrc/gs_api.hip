@@ -267,6 +267,34 @@ int lane_pool(LanePool** out) {
 }
 }  // namespace
 
+// forward of one view of the fused paths (A1-A6), everything on stream s, no host synchronisation: the pair count stays on the device
+// (g.meta[0]) and every launch that depends on it is sized for the pair capacity.
+static int step_view_forward(const GsParams& p, const float* means3D, const float* f_dc, const float* f_rest, const float* opacity_raw, const float* scaling_raw,
+                             const float* rotation_raw, GsGeom& g, GsBinning& b, GsImage& im, int* radii, uint32_t cap, uint32_t* status, float* color, float* depth,
+                             float* alpha, hipStream_t s, int* res_out) {
+    const int tiles = p.gx * p.gy;
+    int rc, res = 0;
+    { C3dProfScope ps(C3D_P_PREPROCESS, s);
+      if ((rc = gs_launch_preprocess_raw(p, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, g, radii, s))) return rc; }
+    { C3dProfScope ps(C3D_P_DEPTH_SORT, s);
+      if ((rc = c3d_sort_pairs_u32(g.key[0], g.key[1], g.order[0], g.order[1], true, (size_t)p.N, 32, g.tmp, &res, s))) return rc; }
+    { C3dProfScope ps(C3D_P_SCAN, s);
+      if ((rc = gs_launch_gather_tiles(g, p.N, res, s))) return rc;
+      if ((rc = c3d_scan_u32(g.tiles_sorted, g.offsets, (size_t)p.N, false, g.tmp, s))) return rc;
+      if ((rc = gs_launch_pair_count(g, p.N, cap, status, s))) return rc; }
+    const uint32_t* d_dev = (const uint32_t*)g.meta;
+    { C3dProfScope ps(C3D_P_EMIT, s);
+      if ((rc = gs_launch_emit(p, g, sort_result_index(32), radii, b, s, cap))) return rc; }
+    { C3dProfScope ps(C3D_P_TILE_SORT, s);
+      if ((rc = c3d_sort_pairs_u32(b.tkey[0], b.tkey[1], b.tval[0], b.tval[1], false, (size_t)cap, tile_sort_bits(tiles), b.tmp, &res, s, d_dev))) return rc; }
+    { C3dProfScope ps(C3D_P_RANGES, s);
+      if ((rc = gs_launch_ranges(b, res, (long long)cap, tiles, s, d_dev))) return rc; }
+    { C3dProfScope ps(C3D_P_COMPOSITE_FWD, s);
+      if ((rc = gs_launch_composite_fwd(p, g, b, res, im, color, depth, alpha, s))) return rc; }
+    *res_out = res;
+    return 0;
+}
+
 size_t c3d_gs_step_workspace_bytes(int32_t N, int32_t H, int32_t W, int64_t pair_capacity, int32_t views) {
     StepWs w; carve_step(nullptr, N, H, W, pair_capacity, w);
     return (size_t)(views > 0 ? views : 1) * w.bytes;
@@ -313,24 +341,7 @@ int c3d_gs_train_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, c
         GsImage im; gs_carve_image(w.image, p.W, p.H, im);
         int rc = 0, res = 0;
         do {
-            // forward: projection, depth order, offsets -- the pair count stays on the device (g.meta[0])
-            { C3dProfScope ps(C3D_P_PREPROCESS, s);
-              if ((rc = gs_launch_preprocess_raw(p, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, g, w.radii, s))) break; }
-            { C3dProfScope ps(C3D_P_DEPTH_SORT, s);
-              if ((rc = c3d_sort_pairs_u32(g.key[0], g.key[1], g.order[0], g.order[1], true, (size_t)N, 32, g.tmp, &res, s))) break; }
-            { C3dProfScope ps(C3D_P_SCAN, s);
-              if ((rc = gs_launch_gather_tiles(g, N, res, s))) break;
-              if ((rc = c3d_scan_u32(g.tiles_sorted, g.offsets, (size_t)N, false, g.tmp, s))) break;
-              if ((rc = gs_launch_pair_count(g, N, cap, status, s))) break; }
-            const uint32_t* d_dev = (const uint32_t*)g.meta;
-            { C3dProfScope ps(C3D_P_EMIT, s);
-              if ((rc = gs_launch_emit(p, g, sort_result_index(32), w.radii, b, s, cap))) break; }
-            { C3dProfScope ps(C3D_P_TILE_SORT, s);
-              if ((rc = c3d_sort_pairs_u32(b.tkey[0], b.tkey[1], b.tval[0], b.tval[1], false, (size_t)cap, tile_sort_bits(tiles), b.tmp, &res, s, d_dev))) break; }
-            { C3dProfScope ps(C3D_P_RANGES, s);
-              if ((rc = gs_launch_ranges(b, res, (long long)cap, tiles, s, d_dev))) break; }
-            { C3dProfScope ps(C3D_P_COMPOSITE_FWD, s);
-              if ((rc = gs_launch_composite_fwd(p, g, b, res, im, w.color, w.depth, w.alpha, s))) break; }
+            if ((rc = step_view_forward(p, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, g, b, im, w.radii, cap, status, w.color, w.depth, w.alpha, s, &res))) break;
             // pixel loss and its gradient
             { C3dProfScope ps(C3D_P_OTHER, s);
               if ((rc = gs_launch_loss_grad(w.color, w.alpha, target_color[v], target_alpha ? target_alpha[v] : nullptr, color_mask ? color_mask[v] : nullptr, (long long)p.W * p.H, loss->w_l1,
@@ -369,6 +380,51 @@ int c3d_gs_train_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, c
                                                  dL_dscaling_raw, dL_drotation_raw, accumulate != 0 || v0 > 0, s0, cap))) return rc;
     }
     return 0;
+}
+
+int c3d_gs_render_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, const float* means3D, const float* f_dc, const float* f_rest,
+                             const float* opacity_raw, const float* scaling_raw, const float* rotation_raw, float* const* out_color, float* const* out_depth,
+                             float* const* out_alpha, int32_t* const* out_radii, int64_t pair_capacity, int32_t lanes, void* workspace, uint32_t* status,
+                             c3d_stream_t stream) {
+    hipStream_t s0 = (hipStream_t)stream;
+    if (V <= 0 || N <= 0) return 0;
+    if (!views || !out_color || !out_depth || !out_alpha || !workspace || !status) { c3d_set_error("c3d_gs_render_views_raw: NULL pointer"); return -1; }
+    if (pair_capacity <= 0 || pair_capacity > 0xFFFFFFF0ll) { c3d_set_error("c3d_gs_render_views_raw: pair_capacity out of range"); return -1; }
+    if (lanes < 1 || lanes > C3D_MAX_LANES) { c3d_set_error("c3d_gs_render_views_raw: lanes must be in [1, %d]", C3D_MAX_LANES); return -1; }
+    if (!means3D || !f_dc || !f_rest || !opacity_raw || !scaling_raw || !rotation_raw) { c3d_set_error("c3d_gs_render_views_raw: NULL parameter pointer"); return -1; }
+    if ((uintptr_t)f_rest % 16 || (uintptr_t)rotation_raw % 16) { c3d_set_error("c3d_gs_render_views_raw: f_rest / rotation tensors must be 16-byte aligned"); return -1; }
+    const uint32_t cap = (uint32_t)pair_capacity;
+    const int L = lanes < V ? lanes : V;
+    StepWs w0; carve_step(nullptr, N, views[0].image_height, views[0].image_width, pair_capacity, w0);
+    LanePool* lp = nullptr;
+    hipStream_t ls[C3D_MAX_LANES] = {s0};
+    if (L > 1) {
+        if (lane_pool(&lp)) return -1;
+        C3D_CHECK(hipEventRecord(lp->fork, s0));
+        for (int l = 1; l < L; l++) { ls[l] = lp->st[l - 1]; C3D_CHECK(hipStreamWaitEvent(ls[l], lp->fork, 0)); }
+    }
+    int rc_all = 0;
+    for (int v = 0; v < V && !rc_all; v++) {
+        const int lane = v % L;     // a lane reuses its workspace slice view after view (stream order)
+        GsParams p;
+        if (make_params(&views[v], N, 16, p)) { rc_all = -1; break; }
+        if (p.W != views[0].image_width || p.H != views[0].image_height) { c3d_set_error("c3d_gs_render_views_raw: all views must share one resolution"); rc_all = -1; break; }
+        if (!out_color[v] || !out_depth[v] || !out_alpha[v]) { c3d_set_error("c3d_gs_render_views_raw: output %d is NULL", v); rc_all = -1; break; }
+        StepWs w; carve_step((char*)workspace + (size_t)lane * w0.bytes, N, p.H, p.W, pair_capacity, w);
+        GsGeom g; gs_carve_geom(w.geom, N, g);
+        GsBinning b; gs_carve_binning(w.binning, pair_capacity, p.gx * p.gy, b);
+        GsImage im; gs_carve_image(w.image, p.W, p.H, im);
+        int res = 0;
+        int* radii = (out_radii && out_radii[v]) ? out_radii[v] : w.radii;
+        rc_all = step_view_forward(p, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, g, b, im, radii, cap, status, out_color[v], out_depth[v], out_alpha[v], ls[lane], &res);
+    }
+    for (int l = 1; l < L; l++) {
+        if (hipEventRecord(lp->join[l - 1], ls[l]) != hipSuccess || hipStreamWaitEvent(s0, lp->join[l - 1], 0) != hipSuccess) {
+            (void)hipDeviceSynchronize();
+            if (!rc_all) { c3d_set_error("c3d_gs_render_views_raw: lane join failed"); rc_all = -1; }
+        }
+    }
+    return rc_all;
 }
 
 int c3d_gs_step_read_view(int32_t N, int32_t H, int32_t W, int64_t pair_capacity, const void* workspace, int32_t view, int32_t* radii_out,

@@ -207,7 +207,8 @@ class Gaussian_Splatting_Orbit_Renderer:
         renderer.initialize(gs_ply)
         ctl = GaussianSplattingCameraController(renderer, render_image_width, render_image_height, render_orbit_camera_fovy,
                                                 static_bg=[render_background_color_r, render_background_color_g, render_background_color_b])
-        images, masks, extra = ctl.render_all_pose(render_orbit_camera_poses)
+        with torch.no_grad():        # nodes run without autograd (ComfyUI executes them in inference mode): the whole orbit is one batched call
+            images, masks, extra = ctl.render_all_pose(render_orbit_camera_poses)
         depths = extra['depth'].permute(0, 2, 3, 1).repeat(1, 1, 1, 3) if 'depth' in extra else None
         return (images.permute(0, 2, 3, 1), masks.squeeze(1), depths)                    # [N,H,W,3], [N,H,W], [N,H,W,3]
 

@@ -139,6 +139,16 @@ int c3d_gs_train_views_raw(const c3d_gs_settings* views /* host [V] */, int32_t 
                            float* dL_drotation_raw, float* loss_out, int64_t pair_capacity, int32_t lanes, int32_t accumulate, void* workspace,
                            uint32_t* status /* device [2] */, c3d_stream_t stream);
 
+/* Forward only, V views of the same cloud in one call (orbit rendering of a trained model: the per-camera loop of the reference's
+ * orbit-renderer node over GaussianSplattingRenderer.render, main_3DGS_renderer.py:927-936), raw parameters, no host synchronisation,
+ * views dealt onto `lanes` streams as above.  HOST arrays of V device pointers: out_color [3,H,W], out_depth [1,H,W], out_alpha [1,H,W];
+ * out_radii (array or entries may be NULL) [N] int32.  The workspace needs c3d_gs_step_workspace_bytes(N, H, W, pair_capacity, lanes)
+ * bytes (one slice per lane).  status as for c3d_gs_train_views_raw: on overflow the images of the affected views are incomplete. */
+int c3d_gs_render_views_raw(const c3d_gs_settings* views /* host [V] */, int32_t V, int32_t N, const float* means3D, const float* f_dc,
+                            const float* f_rest, const float* opacity_raw, const float* scaling_raw, const float* rotation_raw,
+                            float* const* out_color, float* const* out_depth, float* const* out_alpha, int32_t* const* out_radii,
+                            int64_t pair_capacity, int32_t lanes, void* workspace, uint32_t* status /* device [2] */, c3d_stream_t stream);
+
 /* Per-view by-products of the last c3d_gs_train_views_raw call, copied out of its workspace (same N / H / W / pair_capacity): radii [N] (int32)
  * and the screen-space positional gradient dL/dmeans2D [N,3] of view `view` -- the densification statistics of the reference's trainer
  * (main_3DGS.py:210-213, main_3DGS_renderer.py:767-769).  Either output may be NULL. */

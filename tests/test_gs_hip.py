@@ -552,3 +552,36 @@ def test_reduce_ranks_fixed_order_sum():
         assert v.shape == ps[i].shape and v.is_contiguous() and v.data_ptr() % 16 == 0
         v.fill_(float(i + 1))
     assert float(fg.flat.sum()) == sum((i + 1) * p.numel() for i, p in enumerate(ps))
+
+
+@pytest.mark.parametrize("lanes", [1, 3])
+def test_render_views_equals_per_view_render(lanes):
+    """c3d_gs_render_views_raw (a whole orbit in one call, views on `lanes` streams) gives exactly what the per-view render() gives;
+    the camera controller takes that path when autograd is off."""
+    from MVs_Algorithms.GaussianSplatting.main_3DGS_renderer import GaussianSplattingRenderer
+    from MVs_Algorithms.GaussianSplatting.main_3DGS import GaussianSplattingCameraController
+    raw = S.make_cloud(30000, seed=8, log_scale_mean=np.log(0.02), activated=False)
+    r = GaussianSplattingRenderer(sh_degree=3, device="cuda")
+    r.initialize({"xyz": raw["means3D"], "features": raw["shs"], "scaling_raw": raw["scales"], "rotation_raw": raw["rotations"], "opacity_raw": raw["opacities"]})
+    W, H = 200, 136
+    ctl = GaussianSplattingCameraController(r, W, H, 49.1, static_bg=[0.2, 0.5, 0.9])
+    poses = [[2.2, el, az, 0.0, 0.0, 0.0] for el, az in ((-30.0, 0.0), (0.0, 75.0), (30.0, 150.0), (60.0, -120.0), (10.0, -45.0))]
+    with torch.no_grad():
+        per_view = [ctl.render_at_pose(p) for p in poses]
+        r._view_render_key = None
+        cams = []
+        from shared_utils.camera_utils import MiniCam, orbit_camera
+        for radius, el, az, cx, cy, cz in poses:
+            cams.append(MiniCam(orbit_camera(el, az, radius, target=np.array([cx, cy, cz], dtype=np.float32)), W, H, ctl.cam.fovy, ctl.cam.fovx, ctl.cam.near, ctl.cam.far,
+                                ctl.projection_matrix, device="cuda"))
+        out = r.render_views(cams, ctl.static_bg, lanes=lanes)
+        images, masks, extra = ctl.render_all_pose(poses)            # autograd off -> batched path
+    for i, pv in enumerate(per_view):
+        for k in ("image", "depth", "alpha"):
+            assert torch.equal(out[k][i], pv[k]), (k, i)
+        assert torch.equal(out["radii"][i], pv["radii"]) and torch.equal(out["visibility_filter"][i], pv["visibility_filter"])
+        assert torch.equal(images[i], pv["image"]) and torch.equal(masks[i], pv["alpha"])
+    assert float(out["alpha"].max()) > 0.5
+    # with autograd on the controller falls back to the per-view loop and keeps the graph
+    images2, _, extra2 = ctl.render_all_pose(poses[:2])
+    assert images2.requires_grad and "viewspace_points" in extra2
