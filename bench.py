@@ -46,7 +46,8 @@ def parse():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--sh-degree", type=int, default=3)
     ap.add_argument("--cpu-baseline", choices=["auto", "on", "off"], default="auto")
-    ap.add_argument("--exchange", choices=["allgather", "allreduce"], default="allgather")
+    ap.add_argument("--exchange", choices=["allgather", "allreduce"], default="allreduce",
+                    help="gradient exchange of the shared-Gaussian step: one RCCL all-reduce (default: 2*(n-1)/n * 236 MB per rank on the wire) or the literal all-gather of every rank's gradient + rank-ordered local sum (7 * 236 MB received per rank at n = 8)")
     ap.add_argument("--timed-prof", choices=["on", "off"], default="on", help="HIP-event kernel timing inside the timed region")
     ap.add_argument("--lanes", type=int, default=4, help="HIP streams the views of a step are dealt onto (fused step path)")
     ap.add_argument("--render-path", choices=["step", "fused", "accessor", "boundary"], default="step",
@@ -158,12 +159,19 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (a.gpus, a.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the MI355X path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # test hook: C3D_BENCH_SHARE_DEVICE=1 puts every rank on GPU 0 and talks gloo, so the N>1 control flow (sharding, barriers, exchange,
+    # max-over-ranks timing) can be exercised on a 1-GPU box; numbers from such a run mean nothing
+    share = os.environ.get("C3D_BENCH_SHARE_DEVICE") == "1"
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     if a.workload == "mesh":
         return main_mesh(a, world, rank, dev, dist)

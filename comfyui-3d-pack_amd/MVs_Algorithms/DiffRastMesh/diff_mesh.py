@@ -49,7 +49,7 @@ def normal_consistency(v, f):
 class DiffMesh:
     def __init__(self, mesh, training_iterations, batch_size, texture_learning_rate, train_mesh_geometry, geometry_learning_rate,
                  ms_ssim_loss_weight, remesh_after_n_iteration, invert_bg_prob, force_cuda_rasterize, device="cuda", process_group=None,
-                 exchange="allgather"):
+                 exchange="allreduce"):
         self.device = torch.device(device)
         self.train_mesh_geometry, self.remesh_after_n_iteration = train_mesh_geometry, remesh_after_n_iteration
         self.renderer = DiffRastRenderer(mesh, force_cuda_rasterize).to(self.device)

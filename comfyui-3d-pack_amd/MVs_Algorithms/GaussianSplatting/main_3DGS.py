@@ -83,7 +83,7 @@ def _fit(img, H, W, device):
 
 
 class GaussianSplatting3D:
-    def __init__(self, gs_params=None, init_input=None, device='cuda', process_group=None, exchange="allgather"):
+    def __init__(self, gs_params=None, init_input=None, device='cuda', process_group=None, exchange="allreduce"):
         self.device = torch.device(device)
         self.gs_params = gs_params = gs_params or GSParams()
         self.group, self.exchange = process_group, exchange
