@@ -53,6 +53,8 @@ static int check_inputs(int N, int M, int deg, const float* means3D, const float
 // depth ordering + offsets shared by both projection entry points; the single D2H read of the pair count lives here
 static int project_tail(GsGeom& g, int N, int64_t* num_rendered, hipStream_t s) {
     int rc, res = 0;
+    { C3dProfScope ps(C3D_P_SCAN, s);   // record bases of the backward pass: tiles touched, scanned in Gaussian-id order
+    if ((rc = c3d_scan_u32(g.tiles, g.rbase, (size_t)N, true, g.tmp, s))) return rc; }
     { C3dProfScope ps(C3D_P_DEPTH_SORT, s);
     if ((rc = c3d_sort_pairs_u32(g.key[0], g.key[1], g.order[0], g.order[1], true, (size_t)N, 32, g.tmp, &res, s))) return rc; }
     if (res != sort_result_index(32)) { c3d_set_error("internal: depth sort buffer parity"); return -2; }
@@ -221,7 +223,7 @@ int c3d_gs_backward_raw(const c3d_gs_settings* st, int32_t N, const float* means
 
 // ---- fused multi-view training step (no host synchronisation inside) --------------------------------------------------------
 struct StepWs {
-    char* geom; char* binning; char* image; int* radii; float* color; float* depth; float* alpha; float* dcolor; float* dalpha; float* pairgrad; float* dmeans2D;
+    char* geom; char* binning; char* image; int* radii; float* color; float* depth; float* alpha; float* dcolor; float* dalpha; float* pairgrad; float* dmeans2D; float* gcol;
     size_t bytes;
 };
 static void carve_step(char* base, int N, int H, int W, long long cap, StepWs& w) {
@@ -237,6 +239,7 @@ static void carve_step(char* base, int N, int H, int W, long long cap, StepWs& w
     w.dcolor = (float*)take(12 * P); w.dalpha = (float*)take(4 * P);
     w.pairgrad = (float*)take(sizeof(float) * GS_PAIR_FLOATS * (size_t)(cap > 0 ? cap : 1));
     w.dmeans2D = (float*)take(12 * n);
+    w.gcol = (float*)take(12 * n);
     w.bytes = off;
 }
 
@@ -276,6 +279,8 @@ static int step_view_forward(const GsParams& p, const float* means3D, const floa
     int rc, res = 0;
     { C3dProfScope ps(C3D_P_PREPROCESS, s);
       if ((rc = gs_launch_preprocess_raw(p, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, g, radii, s))) return rc; }
+    { C3dProfScope ps(C3D_P_SCAN, s);   // record bases of the backward pass: tiles touched, scanned in Gaussian-id order
+      if ((rc = c3d_scan_u32(g.tiles, g.rbase, (size_t)p.N, true, g.tmp, s))) return rc; }
     { C3dProfScope ps(C3D_P_DEPTH_SORT, s);
       if ((rc = c3d_sort_pairs_u32(g.key[0], g.key[1], g.order[0], g.order[1], true, (size_t)p.N, 32, g.tmp, &res, s))) return rc; }
     { C3dProfScope ps(C3D_P_SCAN, s);
@@ -370,8 +375,8 @@ int c3d_gs_train_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, c
             StepWs w; carve_step((char*)workspace + (size_t)(v0 + i) * w0.bytes, N, p.H, p.W, pair_capacity, w);
             GsGeom g; gs_carve_geom(w.geom, N, g);
             GsBwdView& o = bv.v[i];
-            o.view = p.view; o.proj = p.proj; o.campos = p.campos; o.radii = w.radii; o.rec0 = g.rec0; o.rec1 = g.rec1; o.tiles = g.tiles; o.einfo = g.einfo;
-            o.clamped = g.clamped; o.pairgrad = (const float4*)w.pairgrad; o.dmean2D = w.dmeans2D;
+            o.view = p.view; o.proj = p.proj; o.campos = p.campos; o.radii = w.radii; o.rec0 = g.rec0; o.rec1 = g.rec1; o.tiles = g.tiles; o.rbase = g.rbase;
+            o.clamped = g.clamped; o.pairgrad = (const float4*)w.pairgrad; o.dmean2D = w.dmeans2D; o.gcol = w.gcol;
             o.tanfovx = p.tanfovx; o.tanfovy = p.tanfovy; o.focal_x = p.focal_x; o.focal_y = p.focal_y;
         }
         int rc;

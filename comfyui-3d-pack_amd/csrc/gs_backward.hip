@@ -148,11 +148,11 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
     wlast = __builtin_amdgcn_readfirstlane(wlast);
     if (lane == 0) s_wlast[wave] = wlast;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    // emit index of the pair (this tile, Gaussian gid): row-major position of the tile inside the Gaussian's rect
+    // record index of the pair (this tile, Gaussian gid): the Gaussian's record base + row-major position of the tile inside its rect
     auto emit_index = [&](uint32_t gid) -> uint32_t {
         const uint4 ei = einfo[gid];
         const int ex0 = (int)(ei.y & 0xFFFFu), ey0 = (int)(ei.y >> 16), ex1 = (int)(ei.z & 0xFFFFu);
-        return ei.x + (uint32_t)((ty - ey0) * (ex1 - ex0) + (tx - ex0));
+        return ei.w + (uint32_t)((ty - ey0) * (ex1 - ex0) + (tx - ex0));
     };
     for (int pos = upto + (int)threadIdx.x; pos < todo; pos += 256) {
         const uint32_t e = emit_index(point_list[rg.x + pos]);
@@ -402,7 +402,7 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GsParams p, GsGeom g, co
     for (int q = 0; q < GS_PAIR_FLOATS; q++) pr[q] = 0.f;
     {
         const uint32_t cnt = g.tiles[idx];
-        const uint32_t e0 = cnt ? g.einfo[idx].x : 0u, e1 = min(e0 + cnt, cap);   // cap: capacity of the pair buffers (overflow is reported, never read)
+        const uint32_t e0 = g.rbase[idx], e1 = min(e0 + cnt, cap);   // cap: capacity of the pair buffers (overflow is reported, never read)
         for (uint32_t e = e0; e < e1; e++) {
             const float4 v0 = pairgrad[(size_t)e * 3], v1 = pairgrad[(size_t)e * 3 + 1], v2 = pairgrad[(size_t)e * 3 + 2];
             pr[0] += v0.x; pr[1] += v0.y; pr[2] += v0.z; pr[3] += v0.w;
@@ -559,7 +559,7 @@ __global__ void __launch_bounds__(256, 2) k_preprocess_bwd_views(GsParams p, GsB
             for (int k = 0; k < GS_PAIR_FLOATS; k++) pr[k] = 0.f;
             {
                 const uint32_t cnt = vw.tiles[idx];
-                const uint32_t e0 = cnt ? vw.einfo[idx].x : 0u, e1 = min(e0 + cnt, cap);
+                const uint32_t e0 = vw.rbase[idx], e1 = min(e0 + cnt, cap);
                 for (uint32_t e = e0; e < e1; e++) {
                     const float4 v0 = vw.pairgrad[(size_t)e * 3], v1 = vw.pairgrad[(size_t)e * 3 + 1], v2 = vw.pairgrad[(size_t)e * 3 + 2];
                     pr[0] += v0.x; pr[1] += v0.y; pr[2] += v0.z; pr[3] += v0.w;
@@ -630,12 +630,163 @@ __global__ void __launch_bounds__(256, 2) k_preprocess_bwd_views(GsParams p, GsB
     sh_stage_out_split<ACC>(dL_df_dc, dL_df_rest, g0, gcount, sh_lds);
 }
 
+// ---- the same pass as two lighter kernels ----------------------------------------------------------------------------------------------
+// k_preprocess_bwd_views holds 48 SH gradient sums per lane next to the whole geometric chain: 256 VGPRs, two waves per SIMD, and it streams
+// at ~2.3 TB/s.  Split: (G) the geometric chain, which needs no LDS and ~100 VGPRs, hands the masked colour gradient of every view over in a
+// 12 B/Gaussian/view array; (S) the SH part keeps the coefficients in LDS and only the 48 sums + a direction in registers.
+template <bool ACC>
+__global__ void __launch_bounds__(256) k_bwd_views_geom(GsParams p, GsBwdViews vs, const float* __restrict__ means3D, const float* __restrict__ scales,
+                                                          const float* __restrict__ rotations, float* __restrict__ dL_dopacity, float* __restrict__ dL_dmeans3D,
+                                                          float* __restrict__ dL_dscales, float* __restrict__ dL_drots, uint32_t cap) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= p.N) return;
+    const float3 m = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
+    float3 sc = make_float3(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]);
+    float4 q = *reinterpret_cast<const float4*>(rotations + 4 * idx);
+    sc = make_float3(expf(sc.x), expf(sc.y), expf(sc.z));
+    const float qnorm = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
+    {
+        const float inv = 1.f / qnorm;
+        q = make_float4(q.x * inv, q.y * inv, q.z * inv, q.w * inv);
+    }
+    float c3[6];
+    cov3d_from_scale_rot(sc, p.scale_modifier, q, c3);
+    float dmean[3] = {0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dopac = 0.f;
+    for (int v = 0; v < vs.V; v++) {
+        const GsBwdView& vw = vs.v[v];
+        float* d2 = vw.dmean2D + 3 * (size_t)idx;
+        float* gc = vw.gcol + 3 * (size_t)idx;
+        if (vw.radii[idx] <= 0) { d2[0] = 0.f; d2[1] = 0.f; d2[2] = 0.f; gc[0] = 0.f; gc[1] = 0.f; gc[2] = 0.f; continue; }
+        float pr[GS_PAIR_FLOATS];
+#pragma unroll
+        for (int k = 0; k < GS_PAIR_FLOATS; k++) pr[k] = 0.f;
+        {
+            const uint32_t cnt = vw.tiles[idx];
+            const uint32_t e0 = vw.rbase[idx], e1 = min(e0 + cnt, cap);
+            for (uint32_t e = e0; e < e1; e++) {
+                const float4 v0 = vw.pairgrad[(size_t)e * 3], v1 = vw.pairgrad[(size_t)e * 3 + 1], v2 = vw.pairgrad[(size_t)e * 3 + 2];
+                pr[0] += v0.x; pr[1] += v0.y; pr[2] += v0.z; pr[3] += v0.w;
+                pr[4] += v1.x; pr[5] += v1.y; pr[6] += v1.z; pr[7] += v1.w;
+                pr[8] += v2.x; pr[10] += v2.z;
+            }
+        }
+        {   // colour gradient, zeroed where the forward clamped the channel at 0 (record rows: c0, c2, c1)
+            const uint8_t cl = vw.clamped[idx];
+            gc[0] = (cl & 1) ? 0.f : pr[0]; gc[1] = (cl & 2) ? 0.f : pr[2]; gc[2] = (cl & 4) ? 0.f : pr[1];
+        }
+        const float4 q0 = vw.rec0[idx], q1 = vw.rec1[idx];
+        const float opac = q1.y;
+        {
+            const float go = (opac > 0.f) ? pr[4] / opac : 0.f;
+            dopac += go * opac * (1.f - opac);
+        }
+        const Mat16 V = load_mat16(vw.view), PJ = load_mat16(vw.proj);
+        float g2x, g2y, dm[3], dc[6];
+        bwd_geom_chain(m, c3, V, PJ, vw.tanfovx, vw.tanfovy, vw.focal_x, vw.focal_y, p.W, p.H, q0.z, q0.w, q1.x, pr[6], pr[5], pr[7], pr[8], pr[10], pr[3], g2x, g2y, dm, dc);
+        d2[0] = g2x; d2[1] = g2y; d2[2] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 6; i++) dcov[i] += dc[i];
+#pragma unroll
+        for (int j = 0; j < 3; j++) dmean[j] += dm[j];
+    }
+    float gs3[3];
+    float4 dq;
+    bwd_cov_to_scale_rot(dcov, sc, q, p.scale_modifier, gs3, dq);
+    gs3[0] *= sc.x; gs3[1] *= sc.y; gs3[2] *= sc.z;
+    {
+        const float dot = dq.x * q.x + dq.y * q.y + dq.z * q.z + dq.w * q.w, inv = 1.f / qnorm;
+        dq = make_float4((dq.x - q.x * dot) * inv, (dq.y - q.y * dot) * inv, (dq.z - q.z * dot) * inv, (dq.w - q.w * dot) * inv);
+    }
+    if (ACC) {
+        dopac += dL_dopacity[idx];
+#pragma unroll
+        for (int j = 0; j < 3; j++) { dmean[j] += dL_dmeans3D[3 * idx + j]; gs3[j] += dL_dscales[3 * idx + j]; }
+        const float4 o4 = *reinterpret_cast<const float4*>(dL_drots + 4 * idx);
+        dq.x += o4.x; dq.y += o4.y; dq.z += o4.z; dq.w += o4.w;
+    }
+    dL_dopacity[idx] = dopac;
+#pragma unroll
+    for (int j = 0; j < 3; j++) { dL_dmeans3D[3 * idx + j] = dmean[j]; dL_dscales[3 * idx + j] = gs3[j]; }
+    *reinterpret_cast<float4*>(dL_drots + 4 * idx) = dq;
+}
+
+struct GsShViews { int V; const float* campos[GS_MAX_BWD_VIEWS]; const float* gcol[GS_MAX_BWD_VIEWS]; };
+// dL/dSH over all views + the view-direction term of dL/dmean (added to what k_bwd_views_geom wrote)
+template <bool ACC>
+__global__ void __launch_bounds__(256) k_bwd_views_sh(int N, int deg, GsShViews vs, const float* __restrict__ means3D, const float* __restrict__ f_dc,
+                                                        const float* __restrict__ f_rest, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_df_dc,
+                                                        float* __restrict__ dL_df_rest) {
+    extern __shared__ float sh_lds[];
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t g0 = (size_t)blockIdx.x * blockDim.x;
+    const int gcount = min((int)blockDim.x, N - (int)g0);
+    float* shl = sh_lds + threadIdx.x * SH_ROW;
+    sh_stage_in_split(f_dc, f_rest, g0, gcount, sh_lds);
+    __syncthreads();
+    float gsh[SH_M3];
+#pragma unroll
+    for (int k = 0; k < SH_M3; k++) gsh[k] = 0.f;
+    if (idx < N) {
+        const float3 m = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
+        float dmx = 0.f, dmy = 0.f, dmz = 0.f;
+        for (int v = 0; v < vs.V; v++) {
+            const float* gc = vs.gcol[v] + 3 * (size_t)idx;
+            const float dR0 = gc[0], dR1 = gc[1], dR2 = gc[2];
+            if (dR0 == 0.f && dR1 == 0.f && dR2 == 0.f) continue;
+            const float* cp = vs.campos[v];
+            const float vx = m.x - cp[0], vy = m.y - cp[1], vz = m.z - cp[2];
+            const float s2 = vx * vx + vy * vy + vz * vz;
+            const float len = sqrtf(s2);
+            const float dxn = vx / len, dyn = vy / len, dzn = vz / len;
+            float dd0 = 0.f, dd1 = 0.f, dd2 = 0.f;
+#define GS_BWDS_TERM(k, Bk, dBx, dBy, dBz)                                                              \
+    {                                                                                                   \
+        const float b_ = (Bk);                                                                          \
+        const float w_ = shl[3 * (k)] * dR0 + shl[3 * (k) + 1] * dR1 + shl[3 * (k) + 2] * dR2;          \
+        gsh[3 * (k)] += b_ * dR0; gsh[3 * (k) + 1] += b_ * dR1; gsh[3 * (k) + 2] += b_ * dR2;           \
+        dd0 += (dBx) * w_; dd1 += (dBy) * w_; dd2 += (dBz) * w_;                                        \
+    }
+            SH_FOREACH(deg, dxn, dyn, dzn, GS_BWDS_TERM);
+#undef GS_BWDS_TERM
+            const float inv32 = 1.f / sqrtf(s2 * s2 * s2);
+            dmx += ((s2 - vx * vx) * dd0 - vy * vx * dd1 - vz * vx * dd2) * inv32;
+            dmy += (-vx * vy * dd0 + (s2 - vy * vy) * dd1 - vz * vy * dd2) * inv32;
+            dmz += (-vx * vz * dd0 - vy * vz * dd1 + (s2 - vz * vz) * dd2) * inv32;
+        }
+        dL_dmeans3D[3 * idx] += dmx; dL_dmeans3D[3 * idx + 1] += dmy; dL_dmeans3D[3 * idx + 2] += dmz;
+    }
+#pragma unroll
+    for (int k = 0; k < SH_M3; k++) shl[k] = gsh[k];
+    __syncthreads();
+    sh_stage_out_split<ACC>(dL_df_dc, dL_df_rest, g0, gcount, sh_lds);
+}
+
+static bool gs_a8_split() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("C3D_A8_SPLIT"); v = e ? atoi(e) != 0 : 1; }
+    return v != 0;
+}
+
 int gs_launch_preprocess_bwd_views(const GsParams& p0, const GsBwdViews& views, const float* means3D, const float* f_dc, const float* f_rest,
                                    const float* scaling_raw, const float* rotation_raw, float* dL_dopacity_raw, float* dL_dmeans3D, float* dL_df_dc,
                                    float* dL_df_rest, float* dL_dscaling_raw, float* dL_drotation_raw, bool accumulate, hipStream_t s, uint32_t cap) {
     if (p0.N == 0 || views.V == 0) return 0;
     const dim3 grid(c3d_cdiv(p0.N, 256)), block(256);
     const size_t lds = 256 * SH_ROW * sizeof(float);
+    if (gs_a8_split()) {
+        GsShViews sv;
+        sv.V = views.V;
+        for (int i = 0; i < views.V; i++) { sv.campos[i] = views.v[i].campos; sv.gcol[i] = views.v[i].gcol; }
+        if (accumulate) {
+            hipLaunchKernelGGL((k_bwd_views_geom<true>), grid, block, 0, s, p0, views, means3D, scaling_raw, rotation_raw, dL_dopacity_raw, dL_dmeans3D, dL_dscaling_raw, dL_drotation_raw, cap);
+            hipLaunchKernelGGL((k_bwd_views_sh<true>), grid, block, lds, s, p0.N, p0.deg, sv, means3D, f_dc, f_rest, dL_dmeans3D, dL_df_dc, dL_df_rest);
+        } else {
+            hipLaunchKernelGGL((k_bwd_views_geom<false>), grid, block, 0, s, p0, views, means3D, scaling_raw, rotation_raw, dL_dopacity_raw, dL_dmeans3D, dL_dscaling_raw, dL_drotation_raw, cap);
+            hipLaunchKernelGGL((k_bwd_views_sh<false>), grid, block, lds, s, p0.N, p0.deg, sv, means3D, f_dc, f_rest, dL_dmeans3D, dL_df_dc, dL_df_rest);
+        }
+        C3D_LAUNCH_CHECK();
+        return 0;
+    }
     if (accumulate)
         hipLaunchKernelGGL((k_preprocess_bwd_views<true>), grid, block, lds, s, p0, views, means3D, f_dc, f_rest, scaling_raw, rotation_raw, dL_dopacity_raw,
                            dL_dmeans3D, dL_df_dc, dL_df_rest, dL_dscaling_raw, dL_drotation_raw, cap);

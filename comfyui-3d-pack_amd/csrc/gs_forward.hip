@@ -153,7 +153,7 @@ int gs_launch_gather_tiles(const GsGeom& g, int N, int res, hipStream_t s) {
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_emit(GsParams p, const uint32_t* __restrict__ order, const uint32_t* __restrict__ offsets,
                                                const float4* __restrict__ rec0, const float4* __restrict__ rec2,
-                                               const int* __restrict__ radii, uint4* __restrict__ einfo, uint32_t* __restrict__ tkey, uint32_t* __restrict__ tval, uint32_t cap) {
+                                               const int* __restrict__ radii, const uint32_t* __restrict__ rbase, uint4* __restrict__ einfo, uint32_t* __restrict__ tkey, uint32_t* __restrict__ tval, uint32_t cap) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= p.N) return;
     const uint32_t gid = order[r];
@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(256) k_emit(GsParams p, const uint32_t* __rest
     const float4 r2 = rec2[gid];
     int x0, y0, x1, y1;
     tile_rect_tight(r0.x, r0.y, rad, r2.z, r2.w, p.gx, p.gy, x0, y0, x1, y1);
-    einfo[gid] = make_uint4(off, (uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)x1 | ((uint32_t)y1 << 16), 0u);
+    einfo[gid] = make_uint4(off, (uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)x1 | ((uint32_t)y1 << 16), rbase[gid]);
     for (int y = y0; y < y1; y++)
         for (int x = x0; x < x1; x++) {
             if (off < cap) { tkey[off] = (uint32_t)(y * p.gx + x); tval[off] = gid; }
@@ -174,7 +174,7 @@ __global__ void __launch_bounds__(256) k_emit(GsParams p, const uint32_t* __rest
 }
 int gs_launch_emit(const GsParams& p, const GsGeom& g, int res, const int* radii, GsBinning& b, hipStream_t s, uint32_t cap) {
     if (p.N == 0) return 0;
-    hipLaunchKernelGGL(k_emit, dim3(c3d_cdiv(p.N, 256)), dim3(256), 0, s, p, g.order[res], g.offsets, g.rec0, g.rec2, radii, g.einfo, b.tkey[0], b.tval[0], cap);
+    hipLaunchKernelGGL(k_emit, dim3(c3d_cdiv(p.N, 256)), dim3(256), 0, s, p, g.order[res], g.offsets, g.rec0, g.rec2, radii, g.rbase, g.einfo, b.tkey[0], b.tval[0], cap);
     C3D_LAUNCH_CHECK();
     return 0;
 }

@@ -26,7 +26,8 @@ struct GsGeom {
     uint32_t* order[2];     // Gaussian ids, ping-pong; after stage 1 order[res] is rank -> id
     uint32_t* tiles_sorted; // tiles touched in rank order
     uint32_t* offsets;      // inclusive scan of tiles_sorted (rank order)
-    uint4* einfo;           // per emitted Gaussian: {first emit index, x0 | y0<<16, x1 | y1<<16, 0} of its tile rect
+    uint4* einfo;           // per emitted Gaussian: {first emit index, x0 | y0<<16, x1 | y1<<16, record base} of its tile rect
+    uint32_t* rbase;        // exclusive scan of `tiles` in Gaussian-id order: where this Gaussian's backward gradient records start
     uint8_t* clamped;       // 3 bits per Gaussian: SH colour channel clamped at 0
     int* meta;              // [0] = result buffer index of the depth sort, [1] = num_rendered (device copy)
     void* tmp;              // scan / sort scratch
@@ -46,6 +47,7 @@ static inline void gs_carve_geom(char* base, int N, GsGeom& g) {
     g.tiles_sorted = (uint32_t*)take(4 * n);
     g.offsets = (uint32_t*)take(4 * n);
     g.einfo = (uint4*)take(16 * n);
+    g.rbase = (uint32_t*)take(4 * n);
     g.clamped = (uint8_t*)take(n);
     g.meta = (int*)take(64);
     size_t t1 = c3d_sort_tmp_bytes(n), t2 = c3d_scan_tmp_bytes(n);
@@ -56,7 +58,8 @@ static inline void gs_carve_geom(char* base, int N, GsGeom& g) {
 // Binning state (per tile-splat pair).  Pairs are emitted in depth-rank order (emit index e: the pairs of one
 // Gaussian are contiguous in e, row-major over its tile rect), then stably sorted by tile id with the Gaussian
 // id as payload: tval[res] is the per-tile, depth-ordered splat list.  The emit index of a (tile, Gaussian) pair
-// is recomputed from GsGeom::einfo wherever it is needed (backward gradient records).
+// is recomputed from GsGeom::einfo wherever it is needed.  The backward gradient records of a Gaussian sit at rbase[id] + (row-major position
+// of the tile inside its rect): Gaussian-id order, so that the per-Gaussian pass streams them with consecutive lanes on consecutive records.
 struct GsBinning {
     uint32_t* tkey[2];
     uint32_t* tval[2];
@@ -98,9 +101,10 @@ struct GsBwdView {
     const float* view; const float* proj; const float* campos;   // device matrices of the view
     const int* radii;
     const float4* rec0; const float4* rec1;
-    const uint32_t* tiles; const uint4* einfo; const uint8_t* clamped;
+    const uint32_t* tiles; const uint32_t* rbase; const uint8_t* clamped;
     const float4* pairgrad;
     float* dmean2D;                                              // [N,3] per-view screen-space gradient (densification statistic)
+    float* gcol;                                                 // [N,3] per-view dL/dcolour after the clamp mask (hand-over between the two A8 kernels)
     float tanfovx, tanfovy, focal_x, focal_y;
 };
 struct GsBwdViews { int V; GsBwdView v[GS_MAX_BWD_VIEWS]; };
