@@ -182,6 +182,140 @@ __global__ void __launch_bounds__(256) k_ras_bwd(const float4* __restrict__ pos,
     }
 }
 
+// ---- atomic-free, bit-reproducible variant --------------------------------------------------------------------------------------------
+// Scatter-adds from pixels to vertices are the expensive part of every mesh backward op on this chip (device-scope float atomics execute
+// beyond the XCD-private L2, and neighbouring pixels hit the same vertices).  The gather formulation needs none: (1) triangle-parallel, as in
+// the forward pass: a lane re-walks its triangle's bounding box, keeps the pixels it OWNS (rast id == its id), and accumulates the gradient
+// of its three corners in registers -> one 16-byte record per (triangle, corner); (2) vertex-parallel: a lane sums the records of its
+// vertex through the vertex -> corner adjacency (CSR, built once per topology with the radix sort of the binning stage).  Fixed summation
+// order on both levels: the result is deterministic.
+struct VertexTopo { uint32_t* start; uint32_t* key[2]; uint32_t* val[2]; int* meta; void* tmp; size_t bytes; };
+static void carve_vertex_topo(char* base, int V, int T, VertexTopo& t) {
+    size_t off = 0;
+    auto take = [&](size_t b) { char* p = base ? base + off : nullptr; off += c3d_align(b); return p; };
+    const size_t n = 3 * (size_t)(T > 0 ? T : 1);
+    t.start = (uint32_t*)take(4 * ((size_t)(V > 0 ? V : 0) + 2));
+    t.key[0] = (uint32_t*)take(4 * n); t.key[1] = (uint32_t*)take(4 * n);
+    t.val[0] = (uint32_t*)take(4 * n); t.val[1] = (uint32_t*)take(4 * n);
+    t.meta = (int*)take(64);
+    t.tmp = take(c3d_sort_tmp_bytes(n));
+    t.bytes = off;
+}
+__global__ void __launch_bounds__(256) k_topo_keys(const int* __restrict__ tri, int n3, int V, uint32_t* __restrict__ key) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n3) { const int v = tri[i]; key[i] = (unsigned)v < (unsigned)V ? (uint32_t)v : (uint32_t)V; }   // out-of-range ids park behind the last vertex
+}
+__global__ void __launch_bounds__(256) k_topo_starts(const uint32_t* __restrict__ skey, int n3, int V, uint32_t* __restrict__ start, int* __restrict__ meta, int res) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) meta[0] = res;
+    if (i > n3) return;
+    const long long prev = i ? (long long)skey[i - 1] : -1ll, cur = i < n3 ? (long long)skey[i] : (long long)V + 1;
+    for (long long v = prev + 1; v <= cur && v <= (long long)V + 1; v++) start[v] = (uint32_t)i;   // start[v] = first sorted slot with key >= v
+}
+
+#define RB_ACC(k, dxk, dyk) { ax[k] += (dxk); ay[k] += (dyk); aw[k] += -fx * (dxk) - fy * (dyk); }
+// gradient of one owned pixel w.r.t. the three clip-space corners (same algebra as k_ras_bwd)
+__device__ __forceinline__ void ras_bwd_pixel(const float4 p0, const float4 p1, const float4 p2, float fx, float fy, float g0, float g1, float ax[3], float ay[3], float aw[3]) {
+    const float p0x = p0.x - fx * p0.w, p0y = p0.y - fy * p0.w;
+    const float p1x = p1.x - fx * p1.w, p1y = p1.y - fy * p1.w;
+    const float p2x = p2.x - fx * p2.w, p2y = p2.y - fy * p2.w;
+    const float a0 = p1x * p2y - p1y * p2x, a1 = p2x * p0y - p2y * p0x, a2 = p0x * p1y - p0y * p1x;
+    const float iw = 1.f / (a0 + a1 + a2), b0 = a0 * iw, b1 = a1 * iw;
+    if (b0 < 0.f || b0 > 1.f) g0 = 0.f;   // forward clamps u,v: no gradient through a clamped value
+    if (b1 < 0.f || b1 > 1.f) g1 = 0.f;
+    const float da0 = (g0 * (1.f - b0) - g1 * b1) * iw, da1 = (-g0 * b0 + g1 * (1.f - b1)) * iw, da2 = (-g0 * b0 - g1 * b1) * iw;
+    RB_ACC(0, da1 * (-p2y) + da2 * p1y, da1 * p2x + da2 * (-p1x));
+    RB_ACC(1, da0 * p2y + da2 * (-p0y), da0 * (-p2x) + da2 * p0x);
+    RB_ACC(2, da0 * (-p1y) + da1 * p0y, da0 * p1x + da1 * (-p0x));
+}
+__global__ void __launch_bounds__(256) k_ras_bwd_tri(const float4* __restrict__ pos, const int3* __restrict__ tri, const float4* __restrict__ rast,
+                                                      const float4* __restrict__ dy, int B, int V, int T, int H, int W, float4* __restrict__ rec,
+                                                      uint32_t* __restrict__ big_queue, uint32_t* __restrict__ big_count) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long long)B * T) return;
+    const int b = (int)(gid / T), t = (int)(gid % T);
+    float4* out = rec + (size_t)gid * 3;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int3 vi = tri[t];
+    if ((unsigned)vi.x >= (unsigned)V || (unsigned)vi.y >= (unsigned)V || (unsigned)vi.z >= (unsigned)V) { out[0] = z4; out[1] = z4; out[2] = z4; return; }
+    const float4* pb = pos + (size_t)b * V;
+    const float4 p0 = pb[vi.x], p1 = pb[vi.y], p2 = pb[vi.z];
+    const TriSetup ts = mesh_setup(p0, p1, p2, W, H);
+    if (!ts.ok) { out[0] = z4; out[1] = z4; out[2] = z4; return; }
+    const long long area = (long long)(ts.px1 - ts.px0 + 1) * (ts.py1 - ts.py0 + 1);
+    if (area > MESH_BIG_BBOX) { big_queue[atomicAdd(big_count, 1u)] = (uint32_t)gid; return; }   // records written by k_ras_bwd_big
+    const float xs = 2.f / W, ys = 2.f / H, idf = (float)(t + 1);
+    const size_t pbase = (size_t)b * H * W;
+    float ax[3] = {0.f, 0.f, 0.f}, ay[3] = {0.f, 0.f, 0.f}, aw[3] = {0.f, 0.f, 0.f};
+    for (int py = ts.py0; py <= ts.py1; py++)
+        for (int px = ts.px0; px <= ts.px1; px++) {
+            const size_t pid = pbase + (size_t)py * W + px;
+            if (rast[pid].w != idf) continue;
+            const float4 g = dy[pid];
+            if (g.x == 0.f && g.y == 0.f) continue;
+            ras_bwd_pixel(p0, p1, p2, xs * ((float)px + 0.5f) - 1.f, ys * ((float)py + 0.5f) - 1.f, g.x, g.y, ax, ay, aw);
+        }
+#pragma unroll
+    for (int k = 0; k < 3; k++) out[k] = make_float4(ax[k], ay[k], 0.f, aw[k]);
+}
+__global__ void __launch_bounds__(256) k_ras_bwd_big(const float4* __restrict__ pos, const int3* __restrict__ tri, const float4* __restrict__ rast,
+                                                      const float4* __restrict__ dy, int V, int T, int H, int W, float4* __restrict__ rec,
+                                                      const uint32_t* __restrict__ big_queue, const uint32_t* __restrict__ big_count) {
+    __shared__ float red[4][9];
+    const uint32_t n = *big_count;
+    const float xs = 2.f / W, ys = 2.f / H;
+    for (uint32_t qi = blockIdx.x; qi < n; qi += gridDim.x) {
+        const uint32_t gid = big_queue[qi];
+        const int b = (int)(gid / (uint32_t)T), t = (int)(gid % (uint32_t)T);
+        const int3 vi = tri[t];
+        const float4* pb = pos + (size_t)b * V;
+        const float4 p0 = pb[vi.x], p1 = pb[vi.y], p2 = pb[vi.z];
+        const TriSetup ts = mesh_setup(p0, p1, p2, W, H);
+        const int bw = ts.px1 - ts.px0 + 1;
+        const long long area = (long long)bw * (ts.py1 - ts.py0 + 1);
+        const size_t pbase = (size_t)b * H * W;
+        const float idf = (float)(t + 1);
+        float ax[3] = {0.f, 0.f, 0.f}, ay[3] = {0.f, 0.f, 0.f}, aw[3] = {0.f, 0.f, 0.f};
+        for (long long i = threadIdx.x; i < area; i += blockDim.x) {
+            const int px = ts.px0 + (int)(i % bw), py = ts.py0 + (int)(i / bw);
+            const size_t pid = pbase + (size_t)py * W + px;
+            if (rast[pid].w != idf) continue;
+            const float4 g = dy[pid];
+            if (g.x == 0.f && g.y == 0.f) continue;
+            ras_bwd_pixel(p0, p1, p2, xs * ((float)px + 0.5f) - 1.f, ys * ((float)py + 0.5f) - 1.f, g.x, g.y, ax, ay, aw);
+        }
+        float v9[9] = {ax[0], ay[0], aw[0], ax[1], ay[1], aw[1], ax[2], ay[2], aw[2]};
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 9; q++) {
+            const float sum = c3d_wave_sum(v9[q]);
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][q] = sum;
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            const int k = threadIdx.x;
+            float r3[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) r3[c] = red[0][3 * k + c] + red[1][3 * k + c] + red[2][3 * k + c] + red[3][3 * k + c];
+            rec[(size_t)gid * 3 + k] = make_float4(r3[0], r3[1], 0.f, r3[2]);
+        }
+    }
+}
+// out[b][v] = sum of the corner records of vertex v, in corner-id order (the adjacency is sorted stably)
+__global__ void __launch_bounds__(256) k_vertex_gather4(const float4* __restrict__ rec, const uint32_t* __restrict__ start, const uint32_t* __restrict__ corner,
+                                                         int B, int V, int T, float4* __restrict__ out) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long long)B * V) return;
+    const int b = (int)(gid / V), v = (int)(gid % V);
+    const float4* rb = rec + (size_t)b * T * 3;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (uint32_t i = start[v], e = start[v + 1]; i < e; i++) {
+        const float4 r = rb[corner[i]];
+        a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w;
+    }
+    out[gid] = a;
+}
+
 // ------------------------------------------------------------------------------------------ interpolate
 __global__ void __launch_bounds__(256) k_interp_fwd(const float* __restrict__ attr, int Ba, const float4* __restrict__ rast, const int3* __restrict__ tri,
                                                      const float4* __restrict__ rast_db, const int* __restrict__ diff, int nd, long long BP, long long P,
@@ -228,7 +362,7 @@ __global__ void __launch_bounds__(256) k_interp_bwd(const float* __restrict__ at
     float gu = 0.f, gv = 0.f;
     for (int a = 0; a < A; a++) {
         const float g = dy[gid * A + a];
-        if (g != 0.f) { atomicAdd(&dattr[i0 + a], u * g); atomicAdd(&dattr[i1 + a], v * g); atomicAdd(&dattr[i2 + a], w2 * g); }
+        if (dattr && g != 0.f) { atomicAdd(&dattr[i0 + a], u * g); atomicAdd(&dattr[i1 + a], v * g); atomicAdd(&dattr[i2 + a], w2 * g); }
         gu += g * (attr[i0 + a] - attr[i2 + a]); gv += g * (attr[i1 + a] - attr[i2 + a]);
     }
     drast[gid] = make_float4(gu, gv, 0.f, 0.f);
@@ -527,6 +661,54 @@ int c3d_mesh_rasterize_bwd(const float* pos, const int32_t* tri, const float* ra
     return 0;
 }
 
+size_t c3d_mesh_vertex_topology_bytes(int32_t V, int32_t T) { VertexTopo t; carve_vertex_topo(nullptr, V, T, t); return t.bytes; }
+int c3d_mesh_build_vertex_topology(const int32_t* tri, int32_t V, int32_t T, void* topology, c3d_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    MESH_REQUIRE(topology, "NULL topology buffer");
+    VertexTopo t; carve_vertex_topo((char*)topology, V, T, t);
+    const int n3 = 3 * T;
+    if (V <= 0 || T <= 0) { C3D_CHECK(hipMemsetAsync(t.start, 0, 4 * ((size_t)(V > 0 ? V : 0) + 2), s)); C3D_CHECK(hipMemsetAsync(t.meta, 0, 64, s)); return 0; }
+    MESH_REQUIRE(tri, "NULL tri");
+    hipLaunchKernelGGL(k_topo_keys, dim3(c3d_cdiv(n3, 256)), dim3(256), 0, s, (const int*)tri, n3, V, t.key[0]);
+    int bits = 1;
+    while ((1ll << bits) <= (long long)V) bits++;
+    int res = 0, rc;
+    if ((rc = c3d_sort_pairs_u32(t.key[0], t.key[1], t.val[0], t.val[1], true, (size_t)n3, bits, t.tmp, &res, s))) return rc;
+    hipLaunchKernelGGL(k_topo_starts, dim3(c3d_cdiv(n3 + 1, 256)), dim3(256), 0, s, t.key[res], n3, V, t.start, t.meta, res);
+    C3D_LAUNCH_CHECK();
+    return 0;
+}
+size_t c3d_mesh_rasterize_bwd_scratch_bytes(int32_t B, int32_t T) {
+    const size_t bt = (size_t)(B > 0 ? B : 1) * (size_t)(T > 0 ? T : 1);
+    return c3d_align(sizeof(float4) * 3 * bt) + c3d_align(4 * bt) + c3d_align(64);
+}
+int c3d_mesh_rasterize_bwd_gather(const float* pos, const int32_t* tri, const float* rast, const float* dy, int32_t B, int32_t V, int32_t T, int32_t H,
+                                  int32_t W, const void* topology, void* scratch, float* dpos, c3d_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if ((long long)B * V == 0) return 0;
+    MESH_REQUIRE(dpos, "NULL dpos");
+    C3dProfScope ps(C3D_P_MESH_RASTERIZE_BWD, s);
+    const long long BP = (long long)B * H * W;
+    if (BP == 0 || T == 0) { C3D_CHECK(hipMemsetAsync(dpos, 0, sizeof(float) * 4 * (size_t)B * V, s)); return 0; }
+    MESH_REQUIRE(pos && tri && rast && dy && topology && scratch, "NULL pointer");
+    VertexTopo t; carve_vertex_topo((char*)topology, V, T, t);
+    const size_t bt = (size_t)B * T;
+    float4* rec = (float4*)scratch;
+    uint32_t* queue = (uint32_t*)((char*)scratch + c3d_align(sizeof(float4) * 3 * bt));
+    uint32_t* count = (uint32_t*)((char*)queue + c3d_align(4 * bt));
+    C3D_CHECK(hipMemsetAsync(count, 0, 4, s));
+    hipLaunchKernelGGL(k_ras_bwd_tri, dim3(c3d_cdiv((long long)bt, 256)), dim3(256), 0, s, (const float4*)pos, (const int3*)tri, (const float4*)rast, (const float4*)dy,
+                       B, V, T, H, W, rec, queue, count);
+    hipLaunchKernelGGL(k_ras_bwd_big, dim3(1024), dim3(256), 0, s, (const float4*)pos, (const int3*)tri, (const float4*)rast, (const float4*)dy, V, T, H, W, rec, queue, count);
+    // the sorted corner list sits in val[res]; res is a host constant of the build (same digit count): recompute it instead of reading meta
+    int bits = 1;
+    while ((1ll << bits) <= (long long)V) bits++;
+    const int res = ((bits + 7) / 8) & 1;
+    hipLaunchKernelGGL(k_vertex_gather4, dim3(c3d_cdiv((long long)B * V, 256)), dim3(256), 0, s, (const float4*)rec, t.start, t.val[res], B, V, T, (float4*)dpos);
+    C3D_LAUNCH_CHECK();
+    return 0;
+}
+
 int c3d_mesh_interpolate_fwd(const float* attr, int32_t Ba, const float* rast, const int32_t* tri, const float* rast_db, const int32_t* diff, int32_t nd,
                              int32_t B, int32_t V, int32_t A, int32_t H, int32_t W, float* out, float* out_da, c3d_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
@@ -546,7 +728,7 @@ int c3d_mesh_interpolate_bwd(const float* attr, int32_t Ba, const float* rast, c
     const long long P = (long long)H * W, BP = P * B;
     MESH_REQUIRE(Ba == 1 || Ba == B, "attribute batch must be 1 or B");
     C3dProfScope ps(C3D_P_MESH_INTERPOLATE_BWD, s);
-    if ((long long)Ba * V * A > 0) { MESH_REQUIRE(dattr, "NULL dattr"); C3D_CHECK(hipMemsetAsync(dattr, 0, sizeof(float) * (size_t)Ba * V * A, s)); }
+    if (dattr && (long long)Ba * V * A > 0) C3D_CHECK(hipMemsetAsync(dattr, 0, sizeof(float) * (size_t)Ba * V * A, s));   // NULL: attribute gradient not wanted
     if (BP == 0) return 0;
     MESH_REQUIRE(attr && rast && tri && dy && drast, "NULL pointer");
     hipLaunchKernelGGL(k_interp_bwd, dim3(c3d_cdiv(BP, 256)), dim3(256), 0, s, attr, Ba, (const float4*)rast, (const int3*)tri, dy, BP, P, V, A, dattr, (float4*)drast);

@@ -23,6 +23,9 @@ def _dev_check(t, what):
         raise RuntimeError("nvdiffrast.torch (MI355X): %s must live on a HIP device; there is no CPU path" % what)
 
 
+ATOMIC_FREE_BACKWARD = True     # False: the scatter-add (float atomics) formulation of rasterize backward, kept for comparison
+
+
 class RasterizeCudaContext:
     """Owns the rasterizer's scratch (64-bit depth|id buffer + large-triangle queue), grown on demand."""
 
@@ -35,6 +38,18 @@ class RasterizeCudaContext:
         if self._scratch is None or self._scratch.numel() < nbytes or self._scratch.device != device:
             self._scratch = torch.empty((nbytes,), dtype=torch.uint8, device=device)
         return self._scratch
+
+    def vertex_topology(self, tri, V):
+        """vertex -> (triangle, corner) adjacency of `tri` for the atomic-free backward; built once per index buffer"""
+        key = (tri.data_ptr(), tri._version, int(tri.shape[0]), int(V), tri.device)
+        if getattr(self, "_vtopo_key", None) != key:
+            lib = _h.lib()
+            T = int(tri.shape[0])
+            buf = torch.empty((lib.c3d_mesh_vertex_topology_bytes(V, T),), dtype=torch.uint8, device=tri.device)
+            with torch.cuda.device(tri.device):
+                _h.check(lib.c3d_mesh_build_vertex_topology(_h.ptr(tri if T else None), V, T, _h.ptr(buf), _h.stream(tri.device)), "c3d_mesh_build_vertex_topology")
+            self._vtopo, self._vtopo_key, self._vtopo_tri = buf, key, tri      # keep `tri` alive: the key holds its address
+        return self._vtopo
 
 
 class RasterizeGLContext(RasterizeCudaContext):
@@ -64,6 +79,7 @@ class _Rasterize(torch.autograd.Function):
                                                 _h.ptr(rast_db), _h.stream(dev)), "c3d_mesh_rasterize_fwd")
         ctx.save_for_backward(pos_c if pos_c is not None else pos, tri_c, rast)
         ctx.dims = (B, V, T, H, W)
+        ctx.glctx = glctx
         return rast, rast_db
 
     @staticmethod
@@ -74,8 +90,15 @@ class _Rasterize(torch.autograd.Function):
         dev = pos.device
         with torch.cuda.device(dev):
             dpos = torch.empty((B, V, 4), dtype=torch.float32, device=dev)
-            _h.check(lib.c3d_mesh_rasterize_bwd(_h.ptr(pos), _h.ptr(tri if T else None), _h.ptr(rast), _h.ptr(_h.f32c(dy)), B, V, T, H, W,
-                                                _h.ptr(dpos), _h.stream(dev)), "c3d_mesh_rasterize_bwd")
+            if ATOMIC_FREE_BACKWARD and T > 0:
+                # gather formulation: per-triangle corner records, then a fixed-order sum per vertex (no atomics, bit-reproducible)
+                topo = ctx.glctx.vertex_topology(tri, V)
+                scratch = torch.empty((lib.c3d_mesh_rasterize_bwd_scratch_bytes(B, T),), dtype=torch.uint8, device=dev)
+                _h.check(lib.c3d_mesh_rasterize_bwd_gather(_h.ptr(pos), _h.ptr(tri), _h.ptr(rast), _h.ptr(_h.f32c(dy)), B, V, T, H, W, _h.ptr(topo),
+                                                           _h.ptr(scratch), _h.ptr(dpos), _h.stream(dev)), "c3d_mesh_rasterize_bwd_gather")
+            else:
+                _h.check(lib.c3d_mesh_rasterize_bwd(_h.ptr(pos), _h.ptr(tri if T else None), _h.ptr(rast), _h.ptr(_h.f32c(dy)), B, V, T, H, W,
+                                                    _h.ptr(dpos), _h.stream(dev)), "c3d_mesh_rasterize_bwd")
         return None, dpos, None, None, None
 
 
@@ -117,12 +140,13 @@ class _Interpolate(torch.autograd.Function):
         Ba, V, A = a3.shape
         B, H, W, _ = rast.shape
         dev = rast.device
+        need_attr = ctx.needs_input_grad[0]      # constant attributes (texture coordinates) need no vertex scatter at all
         with torch.cuda.device(dev):
-            dattr = torch.empty_like(a3)
+            dattr = torch.empty_like(a3) if need_attr else None
             drast = torch.empty_like(rast)
-            _h.check(lib.c3d_mesh_interpolate_bwd(_h.ptr(a3), Ba, _h.ptr(rast), _h.ptr(tri), _h.ptr(_h.f32c(dy)), B, V, A, H, W, _h.ptr(dattr),
-                                                  _h.ptr(drast), _h.stream(dev)), "c3d_mesh_interpolate_bwd")
-        return dattr.reshape(ctx.attr_shape), drast, None, None, None
+            _h.check(lib.c3d_mesh_interpolate_bwd(_h.ptr(a3), Ba, _h.ptr(rast), _h.ptr(tri), _h.ptr(_h.f32c(dy)), B, V, A, H, W,
+                                                  _h.ptr(dattr) if need_attr else None, _h.ptr(drast), _h.stream(dev)), "c3d_mesh_interpolate_bwd")
+        return (dattr.reshape(ctx.attr_shape) if need_attr else None), drast, None, None, None
 
 
 def interpolate(attr, rast, tri, rast_db=None, diff_attrs=None):

@@ -37,12 +37,25 @@ int c3d_mesh_rasterize_fwd(const float* pos, const int32_t* tri, int32_t B, int3
 int c3d_mesh_rasterize_bwd(const float* pos, const int32_t* tri, const float* rast, const float* dy, int32_t B, int32_t V,
                            int32_t T, int32_t H, int32_t W, float* dpos, c3d_stream_t stream);
 
+/* Atomic-free, bit-reproducible rasterize backward.  topology = vertex -> (triangle, corner) adjacency of `tri`
+ * (c3d_mesh_build_vertex_topology; valid while `tri` is unchanged, like the antialias edge hash); scratch holds one 16-byte
+ * record per (triangle, corner) and a queue for large triangles.  A lane per triangle re-walks its bounding box, keeps the
+ * pixels it owns and sums its corners' gradients in registers; a lane per vertex then sums its corners' records in a fixed
+ * order.  Same result as c3d_mesh_rasterize_bwd up to summation order; dpos is written in full (no zero-fill needed). */
+size_t c3d_mesh_vertex_topology_bytes(int32_t V, int32_t T);
+int c3d_mesh_build_vertex_topology(const int32_t* tri, int32_t V, int32_t T, void* topology, c3d_stream_t stream);
+size_t c3d_mesh_rasterize_bwd_scratch_bytes(int32_t B, int32_t T);
+int c3d_mesh_rasterize_bwd_gather(const float* pos, const int32_t* tri, const float* rast, const float* dy, int32_t B, int32_t V,
+                                  int32_t T, int32_t H, int32_t W, const void* topology, void* scratch, float* dpos,
+                                  c3d_stream_t stream);
+
 /* interpolate: attr [Ba,V,A], Ba in {1,B}; diff = nd attribute indices for which pixel differentials are produced
  * (out_da [B,H,W,2*nd], pairs (d/dX, d/dY)); nd = 0 -> rast_db/diff/out_da may be NULL */
 int c3d_mesh_interpolate_fwd(const float* attr, int32_t Ba, const float* rast, const int32_t* tri, const float* rast_db,
                              const int32_t* diff, int32_t nd, int32_t B, int32_t V, int32_t A, int32_t H, int32_t W,
                              float* out, float* out_da, c3d_stream_t stream);
-/* dattr [Ba,V,A] accumulated; drast [B,H,W,4] written in full (channels 2,3 = 0) */
+/* dattr [Ba,V,A] accumulated, or NULL when the attribute gradient is not wanted (constant attributes such as texture coordinates: no vertex
+ * scatter at all); drast [B,H,W,4] written in full (channels 2,3 = 0) */
 int c3d_mesh_interpolate_bwd(const float* attr, int32_t Ba, const float* rast, const int32_t* tri, const float* dy,
                              int32_t B, int32_t V, int32_t A, int32_t H, int32_t W, float* dattr, float* drast,
                              c3d_stream_t stream);
