@@ -44,6 +44,33 @@ def make_divisible(x, m=8):
     return int(math.ceil(x / m) * m)
 
 
+class LazyResults(dict):
+    """dict whose deferred entries are computed on first access; iteration / `in` / len see every key"""
+
+    def __init__(self):
+        super().__init__()
+        self._thunks = {}
+
+    def defer(self, key, fn):
+        self._thunks[key] = fn
+        super().__setitem__(key, None)
+
+    def __getitem__(self, key):
+        fn = self._thunks.pop(key, None)
+        if fn is not None:
+            super().__setitem__(key, fn())
+        return super().__getitem__(key)
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def items(self):
+        return [(k, self[k]) for k in list(self.keys())]
+
+    def values(self):
+        return [self[k] for k in list(self.keys())]
+
+
 class DiffRastRenderer(nn.Module):
     def __init__(self, mesh, force_cuda_rast):
         super().__init__()
@@ -68,9 +95,12 @@ class DiffRastRenderer(nn.Module):
         h, w = (make_divisible(h0 * ssaa, 8), make_divisible(w0 * ssaa, 8)) if ssaa != 1 else (h0, w0)
         mesh = self.mesh
         v = mesh.v + self.v_offsets if self.train_geo else mesh.v
-        pose = torch.from_numpy(pose.astype(np.float32)).to(v.device)
-        proj = torch.from_numpy(proj.astype(np.float32)).to(v.device)
-        v_cam = torch.matmul(F.pad(v, pad=(0, 1), mode='constant', value=1.0), torch.inverse(pose).T).float().unsqueeze(0)
+        # the 4x4 inverse is taken on the host (the reference calls torch.inverse on the device: a solver launch + sync per view);
+        # one upload carries pose, its inverse and the projection
+        pose_np = pose.astype(np.float32)
+        mats = torch.from_numpy(np.stack((pose_np, np.linalg.inv(pose_np).astype(np.float32), proj.astype(np.float32)))).to(v.device)
+        pose, pose_inv, proj = mats[0], mats[1], mats[2]
+        v_cam = torch.matmul(F.pad(v, pad=(0, 1), mode='constant', value=1.0), pose_inv.T).float().unsqueeze(0)
         v_clip = v_cam @ proj.T
 
         rast, rast_db = dr.rasterize(self.glctx, v_clip, mesh.f, (h, w))
@@ -79,38 +109,45 @@ class DiffRastRenderer(nn.Module):
         texc, texc_db = dr.interpolate(mesh.vt.unsqueeze(0).contiguous(), rast, mesh.ft, rast_db=rast_db, diff_attrs='all')
         albedo = torch.sigmoid(dr.texture(self.raw_albedo.unsqueeze(0), texc, uv_da=texc_db, filter_mode=texture_filter))
 
-        results = {}
-        if 'depth' in optional_render_types:
-            depth, _ = dr.interpolate(-v_cam[..., [2]], rast, mesh.f)
-            depth = depth.squeeze(0)
-        if 'normal' in optional_render_types:
-            if self.train_geo:
-                i0, i1, i2 = (mesh.f[:, k].long() for k in range(3))
-                face_n = safe_normalize(torch.cross(v[i1] - v[i0], v[i2] - v[i0], dim=-1))
-                vn = torch.zeros_like(v)
-                for idx in (i0, i1, i2):
-                    vn.scatter_add_(0, idx[:, None].repeat(1, 3), face_n)
-                vn = torch.where(torch.sum(vn * vn, -1, keepdim=True) > 1e-20, vn, torch.tensor([0.0, 0.0, 1.0], dtype=torch.float32, device=vn.device))
-            else:
-                vn = mesh.vn
-            normal, _ = dr.interpolate(vn.unsqueeze(0).contiguous(), rast, mesh.fn)
-            normal = safe_normalize(normal[0])
-            viewcos = normal @ pose[:3, :3]                                                       # [0,0,1] faces the camera
+        # depth / normal / viewcos are produced on first access (LazyResults): the reference's trainer asks for them by default
+        # (optional_render_types) and then only reads 'image' (diff_mesh.py:104-106) -- two interpolations, the vertex-normal rebuild and
+        # their backward passes per view for nothing.  Accessing a key gives exactly the tensor the eager code would have returned.
+        def depth_fn():
+            d, _ = dr.interpolate(-v_cam[..., [2]], rast, mesh.f)
+            d = d.squeeze(0)
+            return scale_img_hwc(d, (h0, w0)) if ssaa != 1 else d
+
+        shading = {}
+
+        def normal_pair():
+            if not shading:
+                if self.train_geo:
+                    i0, i1, i2 = (mesh.f[:, k].long() for k in range(3))
+                    face_n = safe_normalize(torch.cross(v[i1] - v[i0], v[i2] - v[i0], dim=-1))
+                    vn = torch.zeros_like(v)
+                    for idx in (i0, i1, i2):
+                        vn.scatter_add_(0, idx[:, None].repeat(1, 3), face_n)
+                    vn = torch.where(torch.sum(vn * vn, -1, keepdim=True) > 1e-20, vn, torch.tensor([0.0, 0.0, 1.0], dtype=torch.float32, device=vn.device))
+                else:
+                    vn = mesh.vn
+                normal, _ = dr.interpolate(vn.unsqueeze(0).contiguous(), rast, mesh.fn)
+                normal = safe_normalize(normal[0])
+                viewcos = normal @ pose[:3, :3]                                                   # [0,0,1] faces the camera
+                if ssaa != 1:
+                    normal, viewcos = scale_img_hwc(normal, (h0, w0)), scale_img_hwc(viewcos, (h0, w0))
+                shading['normal'], shading['viewcos'] = (normal + 1) / 2, (viewcos + 1) / 2
+            return shading
 
         albedo = dr.antialias(albedo, rast, v_clip, mesh.f).squeeze(0).contiguous()
         albedo = alpha * albedo + (1 - alpha) * bg_color
-
         if ssaa != 1:
             albedo, alpha = scale_img_hwc(albedo, (h0, w0)), scale_img_hwc(alpha, (h0, w0))
-            if 'depth' in optional_render_types:
-                depth = scale_img_hwc(depth, (h0, w0))
-            if 'normal' in optional_render_types:
-                normal, viewcos = scale_img_hwc(normal, (h0, w0)), scale_img_hwc(viewcos, (h0, w0))
+        results = LazyResults()
         results['image'] = albedo.clamp(0, 1)
         results['alpha'] = alpha
         if 'depth' in optional_render_types:
-            results['depth'] = depth
+            results.defer('depth', depth_fn)
         if 'normal' in optional_render_types:
-            results['normal'] = (normal + 1) / 2
-            results['viewcos'] = (viewcos + 1) / 2
+            results.defer('normal', lambda: normal_pair()['normal'])
+            results.defer('viewcos', lambda: normal_pair()['viewcos'])
         return results
