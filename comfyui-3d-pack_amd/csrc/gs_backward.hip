@@ -167,7 +167,8 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
             const uint32_t gid = point_list[pos];
             const float4 a0 = rec0[gid], a1 = rec1[gid], a2 = rec2[gid];
             se[threadIdx.x] = emit_index(gid);
-            s0[threadIdx.x] = a0; s1[threadIdx.x] = a1; s2[threadIdx.x] = a2;
+            s0[threadIdx.x] = make_float4(a0.x, a0.y, GS_CONIC_HALF * a0.z, GS_CONIC_FULL * a0.w);   // conic pre-scaled as in the forward pass
+            s1[threadIdx.x] = make_float4(GS_CONIC_HALF * a1.x, a1.y, a1.z, a1.w); s2[threadIdx.x] = a2;
             smask[threadIdx.x] = gs_quadrant_mask(a0, a1, a2, X0, Y0);
         }
         __syncthreads();
@@ -184,8 +185,8 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
                 const int k = upto - 1 - base - j;   // list position of this splat
                 const float4 a0 = s0[j], a1 = s1[j], a2 = s2[j];
                 const float dx = a0.x - pxf, dy = a0.y - pyf;
-                const float power = -0.5f * (a0.z * dx * dx + a1.x * dy * dy) - a0.w * dx * dy;
-                const float G = __expf(power);
+                const float power = dx * (a0.z * dx + a0.w * dy) + (a1.x * dy) * dy;      // log2(e) * (-q/2)
+                const float G = __builtin_amdgcn_exp2f(power);
                 const float alpha = fminf(0.99f, a1.y * G);
                 // act = (k < last) && (power <= 0) && (alpha >= 1/255) as a wave mask in an SGPR pair: the compares are written as asm so that the
                 // mask can feed v_cndmask_b32_e64 directly (a ballot of the C++ bool costs a select + compare round trip through a VGPR)

@@ -234,6 +234,7 @@ __global__ void __launch_bounds__(256) k_composite_fwd(GsParams p, const uint2* 
     const int pxi = X0 + ((wave & 1) << 3) + (lane & 7), pyi = Y0 + ((wave >> 1) << 3) + (lane >> 3);
     const bool inside = pxi < p.W && pyi < p.H;
     const float pxf = (float)pxi, pyf = (float)pyi;
+    const size_t pid = (size_t)pyi * p.W + pxi;     // formed here so that only the float coordinates stay live in the loop
     const uint2 rg = ranges[tile];
     const int todo = (int)(rg.y - rg.x);
     bool done = !inside;
@@ -246,7 +247,9 @@ __global__ void __launch_bounds__(256) k_composite_fwd(GsParams p, const uint2* 
         if ((int)threadIdx.x < n) {
             const uint32_t gid = point_list[rg.x + base + threadIdx.x];
             const float4 a0 = rec0[gid], a1 = rec1[gid], a2 = rec2[gid];
-            s0[threadIdx.x] = a0; s1[threadIdx.x] = a1; s2[threadIdx.x] = a2;
+            // the conic goes into LDS pre-scaled by -log2(e)/2 (xx, yy) and -log2(e) (xy): the loop then feeds v_exp_f32 directly
+            s0[threadIdx.x] = make_float4(a0.x, a0.y, GS_CONIC_HALF * a0.z, GS_CONIC_FULL * a0.w);
+            s1[threadIdx.x] = make_float4(GS_CONIC_HALF * a1.x, a1.y, a1.z, a1.w); s2[threadIdx.x] = a2;
             smask[threadIdx.x] = gs_quadrant_mask(a0, a1, a2, X0, Y0);
         }
         __syncthreads();
@@ -259,8 +262,8 @@ __global__ void __launch_bounds__(256) k_composite_fwd(GsParams p, const uint2* 
                 m &= m - 1;
                 const float4 a0 = s0[j], a1 = s1[j];
                 const float dx = a0.x - pxf, dy = a0.y - pyf;
-                const float power = -0.5f * (a0.z * dx * dx + a1.x * dy * dy) - a0.w * dx * dy;
-                const float alpha = fminf(0.99f, a1.y * __expf(power));
+                const float power = dx * (a0.z * dx + a0.w * dy) + (a1.x * dy) * dy;      // log2(e) * (-q/2): same sign as the exponent
+                const float alpha = fminf(0.99f, a1.y * __builtin_amdgcn_exp2f(power));
                 const bool ok = !done && power <= 0.f && alpha >= 1.f / 255.f;
                 const float testT = T * (1.f - alpha);
                 if (ok && testT < 0.0001f) done = true;
@@ -276,7 +279,7 @@ __global__ void __launch_bounds__(256) k_composite_fwd(GsParams p, const uint2* 
         }
     }
     if (inside) {
-        const size_t P = (size_t)p.W * p.H, pid = (size_t)pyi * p.W + pxi;
+        const size_t P = (size_t)p.W * p.H;
         final_T[pid] = T;
         n_contrib[pid] = last;
         out_color[pid] = C0 + T * p.bg[0];

@@ -146,6 +146,10 @@ __device__ __forceinline__ float alpha_extent(float opacity, float var) {
     return sqrtf(2.f * __logf(t) * var) * 1.0005f + 0.02f;
 }
 
+// conic coefficients as staged in LDS by the compositing kernels: exp(-q/2) = exp2(GS_CONIC_HALF * (A dx^2 + C dy^2) + GS_CONIC_FULL * B dx dy)
+#define GS_CONIC_HALF (-0.72134752044448170368f)   // -log2(e) / 2
+#define GS_CONIC_FULL (-1.44269504088896340736f)   // -log2(e)
+
 // ---- block -> tile ------------------------------------------------------------------------------------------
 // The dispatcher deals workgroups to the 8 XCDs round-robin (b & 7).  Each XCD walks the 2x2-tile supertiles q = xcd, xcd + 8, ... in row-major
 // order: neighbouring tiles, which share most of their splats, meet in one XCD's L2, while every XCD covers the whole image -- with contiguous
