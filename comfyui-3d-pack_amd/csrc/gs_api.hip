@@ -454,8 +454,8 @@ __global__ void k_debug_unpack(int N, GsGeom g, float* xy, float* depths, float*
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     const bool vis = g.key[0] != nullptr;   // records of culled Gaussians are never written; callers mask with radii
-    const float4 a0 = vis ? g.rec0[i] : make_float4(0, 0, 0, 0), a1 = vis ? g.rec1[i] : make_float4(0, 0, 0, 0);
-    const float4 a2 = vis ? g.rec2[i] : make_float4(0, 0, 0, 0);
+    const float4 a0 = vis ? g.rec0[GS_REC(i)] : make_float4(0, 0, 0, 0), a1 = vis ? g.rec1[GS_REC(i)] : make_float4(0, 0, 0, 0);
+    const float4 a2 = vis ? g.rec2[GS_REC(i)] : make_float4(0, 0, 0, 0);
     if (xy) { xy[2 * i] = a0.x; xy[2 * i + 1] = a0.y; }
     if (depths) depths[i] = a2.y;
     if (conic_opacity) { conic_opacity[4 * i] = a0.z; conic_opacity[4 * i + 1] = a0.w; conic_opacity[4 * i + 2] = a1.x; conic_opacity[4 * i + 3] = a1.y; }

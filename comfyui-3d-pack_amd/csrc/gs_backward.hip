@@ -162,14 +162,14 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
     for (int base = 0; base < upto; base += BWD_ROUND) {
         __syncthreads();
         const int n = min(BWD_ROUND, upto - base);
+        gs_stage_round(point_list + rg.x + (upto - 1 - base), n, rec0, s0, s1, s2, -1);   // slot t <- list position upto-1-base-t
+        if ((int)threadIdx.x < n) se[threadIdx.x] = emit_index(point_list[rg.x + (upto - 1 - base - threadIdx.x)]);
+        __syncthreads();
         if ((int)threadIdx.x < n) {
-            const int pos = rg.x + (upto - 1 - base - threadIdx.x);
-            const uint32_t gid = point_list[pos];
-            const float4 a0 = rec0[gid], a1 = rec1[gid], a2 = rec2[gid];
-            se[threadIdx.x] = emit_index(gid);
-            s0[threadIdx.x] = make_float4(a0.x, a0.y, GS_CONIC_HALF * a0.z, GS_CONIC_FULL * a0.w);   // conic pre-scaled as in the forward pass
-            s1[threadIdx.x] = make_float4(GS_CONIC_HALF * a1.x, a1.y, a1.z, a1.w); s2[threadIdx.x] = a2;
+            const float4 a0 = s0[threadIdx.x], a1 = s1[threadIdx.x], a2 = s2[threadIdx.x];
             smask[threadIdx.x] = gs_quadrant_mask(a0, a1, a2, X0, Y0);
+            s0[threadIdx.x] = make_float4(a0.x, a0.y, GS_CONIC_HALF * a0.z, GS_CONIC_FULL * a0.w);   // conic pre-scaled as in the forward pass
+            s1[threadIdx.x].x = GS_CONIC_HALF * a1.x;
         }
         __syncthreads();
         for (int c = 0; c < n; c += 64) {
@@ -414,7 +414,7 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GsParams p, GsGeom g, co
     const float gcol[3] = {pr[0], pr[2], pr[1]};          // record rows: c0, c2, c1
     const float g_depth = pr[3];
     // moments -> gradients of the projected mean (NDC-scaled), conic and opacity
-    const float4 q0 = g.rec0[idx], q1 = g.rec1[idx];
+    const float4 q0 = g.rec0[GS_REC(idx)], q1 = g.rec1[GS_REC(idx)];
     const float cA = q0.z, cB = q0.w, cC = q1.x, opac = q1.y;
     const float m0 = pr[4], m1y = pr[5], m1x = pr[6], m2xx = pr[7], m2xy = pr[8], m2yy = pr[10];
     if (dL_dcolors) { dL_dcolors[3 * idx] = gcol[0]; dL_dcolors[3 * idx + 1] = gcol[1]; dL_dcolors[3 * idx + 2] = gcol[2]; }
@@ -569,7 +569,7 @@ __global__ void __launch_bounds__(256, 2) k_preprocess_bwd_views(GsParams p, GsB
                 }
             }
             const float gcol[3] = {pr[0], pr[2], pr[1]};          // record rows: c0, c2, c1
-            const float4 q0 = vw.rec0[idx], q1 = vw.rec1[idx];
+            const float4 q0 = vw.rec0[GS_REC(idx)], q1 = vw.rec1[GS_REC(idx)];
             const float opac = q1.y;
             {
                 const float go = (opac > 0.f) ? pr[4] / opac : 0.f;
@@ -675,7 +675,7 @@ __global__ void __launch_bounds__(256) k_bwd_views_geom(GsParams p, GsBwdViews v
             const uint8_t cl = vw.clamped[idx];
             gc[0] = (cl & 1) ? 0.f : pr[0]; gc[1] = (cl & 2) ? 0.f : pr[2]; gc[2] = (cl & 4) ? 0.f : pr[1];
         }
-        const float4 q0 = vw.rec0[idx], q1 = vw.rec1[idx];
+        const float4 q0 = vw.rec0[GS_REC(idx)], q1 = vw.rec1[GS_REC(idx)];
         const float opac = q1.y;
         {
             const float go = (opac > 0.f) ? pr[4] / opac : 0.f;

@@ -101,9 +101,9 @@ __global__ void __launch_bounds__(256) k_preprocess(GsParams p, const float* __r
         if (r0 < 0.f) cl |= 1; if (r1 < 0.f) cl |= 2; if (r2 < 0.f) cl |= 4;
         r0 = fmaxf(r0, 0.f); r1 = fmaxf(r1, 0.f); r2 = fmaxf(r2, 0.f);
     }
-    g.rec0[idx] = make_float4(px, py, c * di, -b * di);
-    g.rec1[idx] = make_float4(a * di, opac, r0, r1);
-    g.rec2[idx] = make_float4(r2, pv.z, ex, ey);
+    g.rec0[GS_REC(idx)] = make_float4(px, py, c * di, -b * di);
+    g.rec1[GS_REC(idx)] = make_float4(a * di, opac, r0, r1);
+    g.rec2[GS_REC(idx)] = make_float4(r2, pv.z, ex, ey);
     g.clamped[idx] = cl;
     radii[idx] = rad;
     const uint32_t nt = (uint32_t)((x1 - x0) * (y1 - y0));
@@ -161,8 +161,8 @@ __global__ void __launch_bounds__(256) k_emit(GsParams p, const uint32_t* __rest
     if (rad <= 0) return;
     uint32_t off = (r == 0) ? 0u : offsets[r - 1];
     if (offsets[r] == off) return;   // narrowed to no tiles
-    const float4 r0 = rec0[gid];
-    const float4 r2 = rec2[gid];
+    const float4 r0 = rec0[GS_REC(gid)];
+    const float4 r2 = rec2[GS_REC(gid)];
     int x0, y0, x1, y1;
     tile_rect_tight(r0.x, r0.y, rad, r2.z, r2.w, p.gx, p.gy, x0, y0, x1, y1);
     einfo[gid] = make_uint4(off, (uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)x1 | ((uint32_t)y1 << 16), rbase[gid]);
@@ -244,13 +244,14 @@ __global__ void __launch_bounds__(256) k_composite_fwd(GsParams p, const uint2* 
     for (int base = 0; base < todo; base += 256) {
         if (__syncthreads_count(done) == 256) break;
         const int n = min(256, todo - base);
+        gs_stage_round(point_list + rg.x + base, n, rec0, s0, s1, s2);
+        __syncthreads();
         if ((int)threadIdx.x < n) {
-            const uint32_t gid = point_list[rg.x + base + threadIdx.x];
-            const float4 a0 = rec0[gid], a1 = rec1[gid], a2 = rec2[gid];
-            // the conic goes into LDS pre-scaled by -log2(e)/2 (xx, yy) and -log2(e) (xy): the loop then feeds v_exp_f32 directly
-            s0[threadIdx.x] = make_float4(a0.x, a0.y, GS_CONIC_HALF * a0.z, GS_CONIC_FULL * a0.w);
-            s1[threadIdx.x] = make_float4(GS_CONIC_HALF * a1.x, a1.y, a1.z, a1.w); s2[threadIdx.x] = a2;
+            const float4 a0 = s0[threadIdx.x], a1 = s1[threadIdx.x], a2 = s2[threadIdx.x];
             smask[threadIdx.x] = gs_quadrant_mask(a0, a1, a2, X0, Y0);
+            // the conic stays in LDS pre-scaled by -log2(e)/2 (xx, yy) and -log2(e) (xy): the loop then feeds v_exp_f32 directly
+            s0[threadIdx.x] = make_float4(a0.x, a0.y, GS_CONIC_HALF * a0.z, GS_CONIC_FULL * a0.w);
+            s1[threadIdx.x].x = GS_CONIC_HALF * a1.x;
         }
         __syncthreads();
         for (int c = 0; c < n; c += 64) {

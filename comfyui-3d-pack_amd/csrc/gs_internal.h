@@ -13,10 +13,13 @@ struct GsParams {
     const float* campos; // [3]   device
 };
 
-// Per-Gaussian projected record ("geometry state"), SoA of three 16-B streams = 48 B / Gaussian:
-//   rec0 = (pix.x, pix.y, conic.xx, conic.xy)   rec1 = (conic.yy, opacity, r, g)   rec2 = (b, view depth, ex, ey)
+// Per-Gaussian projected record ("geometry state"): ONE 64-byte line per Gaussian, three 16-B parts used
+//   part 0 = (pix.x, pix.y, conic.xx, conic.xy)   part 1 = (conic.yy, opacity, r, g)   part 2 = (b, view depth, ex, ey)   part 3 = spare
 // (ex, ey) = half extents, in pixels, of the axis-aligned box outside which alpha < 1/255 for certain
 // (sqrt(2 ln(255 o) Sigma_xx), ... plus a safety margin): used to drop tiles / 8x8 quadrants that cannot contribute.
+// Array-of-structures on purpose: the compositing kernels gather records by Gaussian id (random), and the memory system serves such
+// gathers per 64-B line -- one line per splat instead of three.  rec0/rec1/rec2 point at parts 0/1/2 of record 0; index with GS_REC(i).
+#define GS_REC(i) (4 * (size_t)(i))
 struct GsGeom {
     float4* rec0;
     float4* rec1;
@@ -36,9 +39,9 @@ struct GsGeom {
 static inline void gs_carve_geom(char* base, int N, GsGeom& g) {
     size_t n = (size_t)(N > 0 ? N : 1), off = 0;
     auto take = [&](size_t b) { char* p = base ? base + off : nullptr; off += c3d_align(b); return p; };
-    g.rec0 = (float4*)take(16 * n);
-    g.rec1 = (float4*)take(16 * n);
-    g.rec2 = (float4*)take(16 * n);
+    g.rec0 = (float4*)take(64 * n);
+    g.rec1 = g.rec0 ? g.rec0 + 1 : nullptr;
+    g.rec2 = g.rec0 ? g.rec0 + 2 : nullptr;
     g.tiles = (uint32_t*)take(4 * n);
     g.key[0] = (uint32_t*)take(4 * n);
     g.key[1] = (uint32_t*)take(4 * n);

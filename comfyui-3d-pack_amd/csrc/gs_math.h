@@ -150,6 +150,19 @@ __device__ __forceinline__ float alpha_extent(float opacity, float var) {
 #define GS_CONIC_HALF (-0.72134752044448170368f)   // -log2(e) / 2
 #define GS_CONIC_FULL (-1.44269504088896340736f)   // -log2(e)
 
+// ---- staging one round of a tile's splat list through LDS --------------------------------------------------------------------------------
+// `n` (<= blockDim.x) list entries; each record is one 64-B line (gs_internal.h) of which 48 B are used.  Lane q fetches 16-B part q % 3 of
+// entry q / 3: consecutive lanes sit on consecutive parts of one record, so a wave instruction touches 22 lines instead of the 64 a
+// one-lane-per-record gather of a separate array would, and the whole round needs one line per splat instead of three.
+// dir = +1: entries list[0], list[1], ...; dir = -1: list[0], list[-1], ... (the backward pass walks a tile's list back to front).
+__device__ __forceinline__ void gs_stage_round(const uint32_t* __restrict__ list, int n, const float4* __restrict__ rec, float4* s0, float4* s1, float4* s2, int dir = 1) {
+    for (int q = threadIdx.x; q < 3 * n; q += blockDim.x) {
+        const int e = q / 3, part = q - 3 * e;
+        const float4 v = rec[4 * (size_t)list[e * dir] + part];
+        (part == 0 ? s0 : (part == 1 ? s1 : s2))[e] = v;
+    }
+}
+
 // ---- block -> tile ------------------------------------------------------------------------------------------
 // The dispatcher deals workgroups to the 8 XCDs round-robin (b & 7).  Each XCD walks the 2x2-tile supertiles q = xcd, xcd + 8, ... in row-major
 // order: neighbouring tiles, which share most of their splats, meet in one XCD's L2, while every XCD covers the whole image -- with contiguous
