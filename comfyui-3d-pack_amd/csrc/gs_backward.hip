@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
     __shared__ float4 s2[BWD_ROUND];
     __shared__ uint32_t se[BWD_ROUND];
     __shared__ uint32_t smask[BWD_ROUND];
-    __shared__ float acc[4][GS_PAIR_FLOATS][BWD_ROUND];
+    __shared__ float acc[4][GS_PAIR_FLOATS][BWD_ROUND + 1];   // +1: the four row-writers of a wave (lanes 0,16,32,48) land in different banks
     __shared__ int s_maxlast;
     __shared__ int s_wlast[4];
     int tx, ty;
