@@ -15,7 +15,7 @@ LIBDIR = os.path.join(PKG, "lib")
 OBJDIR = os.path.join(PKG, "build")
 LIB = os.path.join(LIBDIR, "libc3d_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-ffp-contract=fast",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-ffp-contract=fast"] + os.environ.get("C3D_EXTRA_HIPCC_FLAGS", "").split() + [
          "-Wall", "-Wno-unused-function"]
 
 

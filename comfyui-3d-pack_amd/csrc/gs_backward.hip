@@ -180,8 +180,9 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
                 if (jmin > 0) m = jmin >= 64 ? 0ull : (m & (~0ull << jmin));
             }
             while (m) {
-                const int j = c + (int)__builtin_ctzll(m);
-                m &= m - 1;
+                const int bitpos = (int)__builtin_ctzll(m);
+                const int j = c + bitpos;
+                m = gs_clear_bit64(m, bitpos);
                 const int k = upto - 1 - base - j;   // list position of this splat
                 const float4 a0 = s0[j], a1 = s1[j], a2 = s2[j];
                 const float dx = a0.x - pxf, dy = a0.y - pyf;

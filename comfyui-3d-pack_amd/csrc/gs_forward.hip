@@ -233,16 +233,19 @@ __global__ void __launch_bounds__(256) k_composite_fwd(GsParams p, const uint2* 
     const int X0 = tx * C3D_TILE_X, Y0 = ty * C3D_TILE_Y;
     const int pxi = X0 + ((wave & 1) << 3) + (lane & 7), pyi = Y0 + ((wave >> 1) << 3) + (lane >> 3);
     const bool inside = pxi < p.W && pyi < p.H;
-    const float pxf = (float)pxi, pyf = (float)pyi;
+    // A finished pixel (saturated, or outside the image) is parked at x = GS_PARKED: every later splat then evaluates to alpha = 0 there and
+    // fails the 1/255 test by itself, so the walk needs no per-splat bookkeeping of a `done` lane mask (the kernel is bound by instruction
+    // issue, scalar instructions included: this removes 9 of them per evaluation).
+    float pxf = inside ? (float)pxi : GS_PARKED;
+    const float pyf = (float)pyi;
     const size_t pid = (size_t)pyi * p.W + pxi;     // formed here so that only the float coordinates stay live in the loop
     const uint2 rg = ranges[tile];
     const int todo = (int)(rg.y - rg.x);
-    bool done = !inside;
     float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f, A = 0.f;
     uint32_t last = 0;
 
     for (int base = 0; base < todo; base += 256) {
-        if (__syncthreads_count(done) == 256) break;
+        if (__syncthreads_count(pxf == GS_PARKED) == 256) break;
         const int n = min(256, todo - base);
         gs_stage_round(point_list + rg.x + base, n, rec0, s0, s1, s2);
         __syncthreads();
@@ -257,18 +260,20 @@ __global__ void __launch_bounds__(256) k_composite_fwd(GsParams p, const uint2* 
         for (int c = 0; c < n; c += 64) {
             const int jj = c + lane;
             uint64_t m = __ballot(jj < n && ((smask[jj] >> wave) & 1u));
-            if (__ballot(!done) == 0ull) break;           // every pixel of this quadrant has saturated
+            if (__ballot(pxf != GS_PARKED) == 0ull) break;           // every pixel of this quadrant has saturated
             while (m) {
-                const int j = c + (int)__builtin_ctzll(m);
-                m &= m - 1;
+                const int bitpos = (int)__builtin_ctzll(m);
+                const int j = c + bitpos;
+                m = gs_clear_bit64(m, bitpos);
                 const float4 a0 = s0[j], a1 = s1[j];
                 const float dx = a0.x - pxf, dy = a0.y - pyf;
                 const float power = dx * (a0.z * dx + a0.w * dy) + (a1.x * dy) * dy;      // log2(e) * (-q/2): same sign as the exponent
                 const float alpha = fminf(0.99f, a1.y * __builtin_amdgcn_exp2f(power));
-                const bool ok = !done && power <= 0.f && alpha >= 1.f / 255.f;
+                const bool ok = power <= 0.f && alpha >= 1.f / 255.f;
                 const float testT = T * (1.f - alpha);
-                if (ok && testT < 0.0001f) done = true;
-                if (ok && !done) {
+                const bool stop = ok && testT < 0.0001f;
+                pxf = stop ? GS_PARKED : pxf;
+                if (ok && !stop) {
                     const float4 a2 = s2[j];
                     const float w = alpha * T;
                     C0 += a1.z * w; C1 += a1.w * w; C2 += a2.x * w;

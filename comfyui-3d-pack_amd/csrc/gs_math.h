@@ -150,6 +150,16 @@ __device__ __forceinline__ float alpha_extent(float opacity, float var) {
 #define GS_CONIC_HALF (-0.72134752044448170368f)   // -log2(e) / 2
 #define GS_CONIC_FULL (-1.44269504088896340736f)   // -log2(e)
 
+// x coordinate of a pixel that takes no further splats (k_composite_fwd): far enough that any conic gives exp2(-huge) = 0, small enough that
+// nothing overflows (1e9^2 * |conic| stays far below FLT_MAX, so no inf - inf)
+#define GS_PARKED 1.0e9f
+
+// clear one bit of a wave-uniform 64-bit mask: one scalar instruction (hipcc expands m &= m - 1 into add / addc / and)
+__device__ __forceinline__ uint64_t gs_clear_bit64(uint64_t m, int bit) {
+    asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(bit));
+    return m;
+}
+
 // ---- staging one round of a tile's splat list through LDS --------------------------------------------------------------------------------
 // `n` (<= blockDim.x) list entries; each record is one 64-B line (gs_internal.h) of which 48 B are used.  Lane q fetches 16-B part q % 3 of
 // entry q / 3: consecutive lanes sit on consecutive parts of one record, so a wave instruction touches 22 lines instead of the 64 a
