@@ -15,7 +15,10 @@ LIBDIR = os.path.join(PKG, "lib")
 OBJDIR = os.path.join(PKG, "build")
 LIB = os.path.join(LIBDIR, "libc3d_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-ffp-contract=fast"] + os.environ.get("C3D_EXTRA_HIPCC_FLAGS", "").split() + [
+# -fno-slp-vectorize: hipcc -O3 packs neighbouring scalar f32 multiplies / adds into v_pk_*_f32 (+ moves and s_nop padding); on gfx950 a packed op
+# issues in 4.3-4.9 cycles against 2.9 for a plain one (profiles/r01f_valu_rate_microbench.txt), and the compositing kernels are issue bound:
+# forward compositing 0.182 -> 0.164 ms, backward 0.497 -> 0.479 ms, per-Gaussian pass 0.88 -> 0.81 ms without it.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-ffp-contract=fast", "-fno-slp-vectorize"] + os.environ.get("C3D_EXTRA_HIPCC_FLAGS", "").split() + [
          "-Wall", "-Wno-unused-function"]
 
 
