@@ -49,38 +49,45 @@ __device__ __forceinline__ float wave_reduce4(float a, float b, float c, float d
 // t0 rows: v0, v2, v1, v3   t1 rows: v4, v6, v5, v7   t2 rows: v8, 0, v9, 0
 __device__ __forceinline__ void wave_reduce10(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7, float v8, float v9,
                                               float& t0, float& t1, float& t2) {
+    // One asm block: the kernel is bound by instruction issue, and split into C++-level pieces this reduction carried seven s_nop (four of
+    // ours, three from the compiler's hazard recogniser around the blocks).  Inside one block every producer is >= 2 instructions ahead of its
+    // consumer (VALU write -> permlane / DPP read needs 2 wait states), so a single s_nop for the freshly multiplied inputs remains:
+    //   level 32: five swaps, then the five folds (the first fold reads what the first swap wrote four instructions earlier);
+    //   level 16: three swaps on (v0,v2) (v4,v6) (v8,v9 = 0), then three folds -> v0, v4, v8;
+    //   rows    : the three DPP butterfly chains interleaved.
     asm volatile("s_nop 1\n\t"
                  "v_permlane32_swap_b32 %0, %1\n\t"
                  "v_permlane32_swap_b32 %2, %3\n\t"
                  "v_permlane32_swap_b32 %4, %5\n\t"
                  "v_permlane32_swap_b32 %6, %7\n\t"
-                 "v_permlane32_swap_b32 %8, %9"
-                 : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7), "+v"(v8), "+v"(v9));
-    float p0 = v0 + v1, q0 = v2 + v3, p1 = v4 + v5, q1 = v6 + v7, p2 = v8 + v9, q2 = 0.f;
-    asm volatile("s_nop 1\n\t"
-                 "v_permlane16_swap_b32 %0, %1\n\t"
-                 "v_permlane16_swap_b32 %2, %3\n\t"
-                 "v_permlane16_swap_b32 %4, %5"
-                 : "+v"(p0), "+v"(q0), "+v"(p1), "+v"(q1), "+v"(p2), "+v"(q2));
-    t0 = p0 + q0; t1 = p1 + q1; t2 = p2 + q2;
-    // in-row butterflies as single DPP adds (hipcc -O3 would SLP-pack them into v_pk_add_f32 + v_mov_dpp + zero moves: twice the
-    // instructions).  The three chains are interleaved, so the 2 wait states a DPP read needs after the VALU write of its source are
-    // covered by the other two chains; only the first level needs an explicit s_nop.
-    asm volatile("s_nop 1\n\t"
+                 "v_permlane32_swap_b32 %8, %9\n\t"
+                 "v_add_f32 %0, %0, %1\n\t"
+                 "v_add_f32 %2, %2, %3\n\t"
+                 "v_add_f32 %4, %4, %5\n\t"
+                 "v_add_f32 %6, %6, %7\n\t"
+                 "v_add_f32 %8, %8, %9\n\t"
+                 "v_mov_b32 %9, 0\n\t"
+                 "v_permlane16_swap_b32 %0, %2\n\t"
+                 "v_permlane16_swap_b32 %4, %6\n\t"
+                 "v_permlane16_swap_b32 %8, %9\n\t"
+                 "v_add_f32 %0, %0, %2\n\t"
+                 "v_add_f32 %4, %4, %6\n\t"
+                 "v_add_f32 %8, %8, %9\n\t"
                  "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                 "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                 "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %4, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %8, %8, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
                  "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                 "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                 "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %4, %4, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %8, %8, %8 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
                  "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-                 "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-                 "v_add_f32_dpp %2, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %4, %4, %4 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %8, %8, %8 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
                  "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
-                 "v_add_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n\t"
-                 "v_add_f32_dpp %2, %2, %2 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %4, %4, %4 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %8, %8, %8 row_mirror row_mask:0xf bank_mask:0xf\n\t"
                  "s_nop 1"
-                 : "+v"(t0), "+v"(t1), "+v"(t2));
+                 : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7), "+v"(v8), "+v"(v9));
+    t0 = v0; t1 = v4; t2 = v8;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -194,7 +201,7 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
                 uint64_t am;
                 {
                     uint64_t c0, c1, c2;
-                    asm("v_cmp_lt_i32_e64 %0, %1, %2" : "=s"(c0) : "v"(k), "v"(last));
+                    asm("v_cmp_lt_i32_e64 %0, %1, %2" : "=s"(c0) : "s"(k), "v"(last));     // k is wave-uniform: scalar operand, no v_mov
                     asm("v_cmp_ge_f32_e64 %0, 0, %1" : "=s"(c1) : "v"(power));
                     asm("v_cmp_le_f32_e64 %0, %1, %2" : "=s"(c2) : "v"(1.f / 255.f), "v"(alpha));
                     am = c0 & c1 & c2;
