@@ -305,6 +305,13 @@ def test_edge_cases():
     with torch.inference_mode():
         c, *_ = hip_forward(S.make_small_scene(N=20), st)
     assert torch.isfinite(c).all()
+    # ... and inside the float32 autocast wrapper one external caller uses (TriplaneGaussian/models/renderer.py:261,295): same bits
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with torch.autocast("cuda", dtype=torch.float32):
+            c2, *_ = hip_forward(S.make_small_scene(N=20), st)
+    assert torch.equal(c, c2)
 
 
 def test_backward_is_bit_reproducible():
