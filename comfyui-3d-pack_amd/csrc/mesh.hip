@@ -432,6 +432,80 @@ __global__ void __launch_bounds__(256) k_tex_bwd(const float* __restrict__ tex, 
     duv[gid] = make_float2(gu * Wt, gv * Ht);
 }
 
+// Linear-filter texture gradient with the scatter pre-combined per 16x16-pixel tile.  Device-scope float atomics are executed beyond the
+// XCD-private L2 at a packet rate of ~10-20 G/s on this chip (profiles/microbench/xcd_atomics.hip), and the 12 atomics a pixel issues
+// (4 taps x 3 channels) land on the same few texel lines as its neighbours': 0.27 ms per 1024^2 view, 0.02 ms of it arithmetic.  A tile
+// first sums its taps per texel in an LDS hash table (LDS float atomics), then issues one global atomic per (distinct texel, channel).
+#define TEXT_SLOTS 1024
+#define TEXT_EMPTY 0xFFFFFFFFu
+template <int C>
+__global__ void __launch_bounds__(256) k_tex_bwd_tiled(const float* __restrict__ tex, int Bt, const float2* __restrict__ uv, const float* __restrict__ dy,
+                                                        int H, int W, int Ht, int Wt, int boundary, float* __restrict__ dtex, float2* __restrict__ duv) {
+    __shared__ uint32_t keys[TEXT_SLOTS];
+    __shared__ float vals[TEXT_SLOTS][C];
+    for (int i = threadIdx.x; i < TEXT_SLOTS; i += 256) {
+        keys[i] = TEXT_EMPTY;
+#pragma unroll
+        for (int c = 0; c < C; c++) vals[i][c] = 0.f;
+    }
+    __syncthreads();
+    const int b = blockIdx.z;
+    const int px = blockIdx.x * 16 + (threadIdx.x & 15), py = blockIdx.y * 16 + (threadIdx.x >> 4);
+    const size_t tbo = (size_t)(Bt > 1 ? b : 0) * Ht * Wt * C;
+    if (px < W && py < H) {
+        const size_t gid = ((size_t)b * H + py) * W + px;
+        const float2 q = uv[gid];
+        const float u = q.x * Wt - 0.5f, v = q.y * Ht - 0.5f;
+        const float fu0 = floorf(u), fv0 = floorf(v), fu = u - fu0, fv = v - fv0;
+        const int iu0 = wrapi((int)fu0, Wt, boundary), iu1 = wrapi((int)fu0 + 1, Wt, boundary);
+        const int iv0 = wrapi((int)fv0, Ht, boundary), iv1 = wrapi((int)fv0 + 1, Ht, boundary);
+        const uint32_t tk[4] = {(uint32_t)(iv0 * Wt + iu0), (uint32_t)(iv0 * Wt + iu1), (uint32_t)(iv1 * Wt + iu0), (uint32_t)(iv1 * Wt + iu1)};
+        const float tw[4] = {(1.f - fu) * (1.f - fv), fu * (1.f - fv), (1.f - fu) * fv, fu * fv};
+        float g[C];
+        bool any = false;
+#pragma unroll
+        for (int c = 0; c < C; c++) { g[c] = dy[gid * C + c]; any = any || g[c] != 0.f; }
+        float gu = 0.f, gv = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const float t00 = tex[tbo + (size_t)tk[0] * C + c], t10 = tex[tbo + (size_t)tk[1] * C + c];
+            const float t01 = tex[tbo + (size_t)tk[2] * C + c], t11 = tex[tbo + (size_t)tk[3] * C + c];
+            gu += g[c] * ((t10 - t00) * (1.f - fv) + (t11 - t01) * fv);
+            gv += g[c] * ((t01 - t00) * (1.f - fu) + (t11 - t10) * fu);
+        }
+        duv[gid] = make_float2(gu * Wt, gv * Ht);
+        if (any) {
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                uint32_t h = (tk[t] * 2654435761u) >> 22;           // 10 bits
+                int slot = -1;
+                for (int probe = 0; probe < 32; probe++) {           // bounded: a full table falls back to the direct scatter
+                    const uint32_t old = atomicCAS(&keys[h], TEXT_EMPTY, tk[t]);
+                    if (old == TEXT_EMPTY || old == tk[t]) { slot = (int)h; break; }
+                    h = (h + 1) & (TEXT_SLOTS - 1);
+                }
+#pragma unroll
+                for (int c = 0; c < C; c++) {
+                    const float w = g[c] * tw[t];
+                    if (w == 0.f) continue;
+                    if (slot >= 0) atomicAdd(&vals[slot][c], w);
+                    else atomicAdd(&dtex[tbo + (size_t)tk[t] * C + c], w);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < TEXT_SLOTS; i += 256) {
+        const uint32_t k = keys[i];
+        if (k == TEXT_EMPTY) continue;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const float v = vals[i][c];
+            if (v != 0.f) atomicAdd(&dtex[tbo + (size_t)k * C + c], v);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ antialias
 // Topology hash: open addressing on the 64-bit (min vertex, max vertex) key; each slot records up to two incident
 // (triangle, opposite vertex) pairs and the total count.
@@ -759,7 +833,14 @@ int c3d_mesh_texture_bwd(const float* tex, int32_t Bt, const float* uv, const fl
     if ((long long)Bt * Ht * Wt * C > 0) { MESH_REQUIRE(dtex, "NULL dtex"); C3D_CHECK(hipMemsetAsync(dtex, 0, sizeof(float) * (size_t)Bt * Ht * Wt * C, s)); }
     if (BP == 0 || C == 0) return 0;
     MESH_REQUIRE(tex && uv && dy && duv, "NULL pointer");
-    hipLaunchKernelGGL(k_tex_bwd, dim3(c3d_cdiv(BP, 256)), dim3(256), 0, s, tex, Bt, (const float2*)uv, dy, BP, P, Ht, Wt, C, filter, boundary, dtex, (float2*)duv);
+    if (filter == 1 && (C == 1 || C == 3 || C == 4) && (long long)Ht * Wt < 0xFFFFFFFFll) {
+        const dim3 grid(c3d_cdiv(W, 16), c3d_cdiv(H, 16), B);
+        if (C == 1) hipLaunchKernelGGL((k_tex_bwd_tiled<1>), grid, dim3(256), 0, s, tex, Bt, (const float2*)uv, dy, H, W, Ht, Wt, boundary, dtex, (float2*)duv);
+        else if (C == 3) hipLaunchKernelGGL((k_tex_bwd_tiled<3>), grid, dim3(256), 0, s, tex, Bt, (const float2*)uv, dy, H, W, Ht, Wt, boundary, dtex, (float2*)duv);
+        else hipLaunchKernelGGL((k_tex_bwd_tiled<4>), grid, dim3(256), 0, s, tex, Bt, (const float2*)uv, dy, H, W, Ht, Wt, boundary, dtex, (float2*)duv);
+    } else {
+        hipLaunchKernelGGL(k_tex_bwd, dim3(c3d_cdiv(BP, 256)), dim3(256), 0, s, tex, Bt, (const float2*)uv, dy, BP, P, Ht, Wt, C, filter, boundary, dtex, (float2*)duv);
+    }
     C3D_LAUNCH_CHECK();
     return 0;
 }
