@@ -301,19 +301,43 @@ __global__ void __launch_bounds__(256) k_ras_bwd_big(const float4* __restrict__ 
         }
     }
 }
-// out[b][v] = sum of the corner records of vertex v, in corner-id order (the adjacency is sorted stably)
+// out[b][v] = sum of the corner records of vertex v, in corner-id order (the adjacency is sorted stably).  Vertices with more than
+// VG_HEAVY corners (the poles of a lat-long sphere have hundreds) are queued for a wave each: one lane walking such a list serially set the
+// kernel's duration (0.14 ms for two pole vertices).
+#define VG_HEAVY 32
 __global__ void __launch_bounds__(256) k_vertex_gather4(const float4* __restrict__ rec, const uint32_t* __restrict__ start, const uint32_t* __restrict__ corner,
-                                                         int B, int V, int T, float4* __restrict__ out) {
+                                                         int B, int V, int T, float4* __restrict__ out, uint32_t* __restrict__ heavy_queue, uint32_t* __restrict__ heavy_count) {
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (long long)B * V) return;
     const int b = (int)(gid / V), v = (int)(gid % V);
+    const uint32_t i0 = start[v], i1 = start[v + 1];
+    if (i1 - i0 > VG_HEAVY) { heavy_queue[atomicAdd(heavy_count, 1u)] = (uint32_t)gid; return; }
     const float4* rb = rec + (size_t)b * T * 3;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (uint32_t i = start[v], e = start[v + 1]; i < e; i++) {
+    for (uint32_t i = i0; i < i1; i++) {
         const float4 r = rb[corner[i]];
         a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w;
     }
     out[gid] = a;
+}
+// one wave per queued vertex: lane l takes corners l, l + 64, ... (fixed assignment), then a fixed-shape wave reduction -> still deterministic
+__global__ void __launch_bounds__(256) k_vertex_gather4_heavy(const float4* __restrict__ rec, const uint32_t* __restrict__ start, const uint32_t* __restrict__ corner,
+                                                               int V, int T, float4* __restrict__ out, const uint32_t* __restrict__ heavy_queue,
+                                                               const uint32_t* __restrict__ heavy_count) {
+    const uint32_t n = *heavy_count;
+    const int lane = threadIdx.x & 63;
+    for (uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6); q < n; q += gridDim.x * 4) {
+        const uint32_t gid = heavy_queue[q];
+        const int b = (int)(gid / (uint32_t)V), v = (int)(gid % (uint32_t)V);
+        const float4* rb = rec + (size_t)b * T * 3;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (uint32_t i = start[v] + lane, e = start[v + 1]; i < e; i += 64) {
+            const float4 r = rb[corner[i]];
+            a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w;
+        }
+        a.x = c3d_wave_sum(a.x); a.y = c3d_wave_sum(a.y); a.z = c3d_wave_sum(a.z); a.w = c3d_wave_sum(a.w);
+        if (lane == 0) out[gid] = a;
+    }
 }
 
 // ------------------------------------------------------------------------------------------ interpolate
@@ -770,7 +794,7 @@ int c3d_mesh_rasterize_bwd_gather(const float* pos, const int32_t* tri, const fl
     float4* rec = (float4*)scratch;
     uint32_t* queue = (uint32_t*)((char*)scratch + c3d_align(sizeof(float4) * 3 * bt));
     uint32_t* count = (uint32_t*)((char*)queue + c3d_align(4 * bt));
-    C3D_CHECK(hipMemsetAsync(count, 0, 4, s));
+    C3D_CHECK(hipMemsetAsync(count, 0, 8, s));
     hipLaunchKernelGGL(k_ras_bwd_tri, dim3(c3d_cdiv((long long)bt, 256)), dim3(256), 0, s, (const float4*)pos, (const int3*)tri, (const float4*)rast, (const float4*)dy,
                        B, V, T, H, W, rec, queue, count);
     hipLaunchKernelGGL(k_ras_bwd_big, dim3(1024), dim3(256), 0, s, (const float4*)pos, (const int3*)tri, (const float4*)rast, (const float4*)dy, V, T, H, W, rec, queue, count);
@@ -778,7 +802,9 @@ int c3d_mesh_rasterize_bwd_gather(const float* pos, const int32_t* tri, const fl
     int bits = 1;
     while ((1ll << bits) <= (long long)V) bits++;
     const int res = ((bits + 7) / 8) & 1;
-    hipLaunchKernelGGL(k_vertex_gather4, dim3(c3d_cdiv((long long)B * V, 256)), dim3(256), 0, s, (const float4*)rec, t.start, t.val[res], B, V, T, (float4*)dpos);
+    // the large-triangle queue has been consumed: its storage and the second counter word serve the heavy-vertex queue
+    hipLaunchKernelGGL(k_vertex_gather4, dim3(c3d_cdiv((long long)B * V, 256)), dim3(256), 0, s, (const float4*)rec, t.start, t.val[res], B, V, T, (float4*)dpos, queue, count + 1);
+    hipLaunchKernelGGL(k_vertex_gather4_heavy, dim3(64), dim3(256), 0, s, (const float4*)rec, t.start, t.val[res], V, T, (float4*)dpos, queue, count + 1);
     C3D_LAUNCH_CHECK();
     return 0;
 }
