@@ -15,6 +15,7 @@ import torch.nn.functional as F
 import nvdiffrast.torch as dr
 
 from mesh_processer.mesh import safe_normalize
+from c3d_hip.mesh_fused import shade, transform_vertices
 
 
 def inverse_sigmoid(x):
@@ -79,6 +80,7 @@ class DiffRastRenderer(nn.Module):
         self.v_offsets = nn.Parameter(torch.zeros_like(self.mesh.v), requires_grad=True)
         self.raw_albedo = nn.Parameter(inverse_sigmoid(self.mesh.albedo), requires_grad=True)
         self.train_geo = False
+        self.fused_glue = True          # False: the reference's torch op chain around the nvdiffrast calls (tests compare both)
 
     def get_params(self, texture_lr, train_geo, geom_lr):
         params = [{'params': self.raw_albedo, 'lr': texture_lr}]
@@ -98,14 +100,24 @@ class DiffRastRenderer(nn.Module):
         # the 4x4 inverse is taken on the host (the reference calls torch.inverse on the device: a solver launch + sync per view);
         # one upload carries pose, its inverse and the projection
         pose_np = pose.astype(np.float32)
-        mats = torch.from_numpy(np.stack((pose_np, np.linalg.inv(pose_np).astype(np.float32), proj.astype(np.float32)))).to(v.device)
-        pose, pose_inv, proj = mats[0], mats[1], mats[2]
-        v_cam = torch.matmul(F.pad(v, pad=(0, 1), mode='constant', value=1.0), pose_inv.T).float().unsqueeze(0)
-        v_clip = v_cam @ proj.T
+        pose_inv_np = np.linalg.inv(pose_np).astype(np.float32)
+        proj_np = proj.astype(np.float32)
+        fused = v.is_cuda and ssaa == 1 and self.fused_glue
+        mats = torch.from_numpy(np.stack((pose_np, pose_inv_np, proj_np, proj_np @ pose_inv_np))).to(v.device)
+        pose, pose_inv, proj, clip_from_world = mats[0], mats[1], mats[2], mats[3]
+        if fused:
+            # pad + two GEMMs of the reference as one kernel each way (c3d_mesh_transform_*); camera-space positions only if depth is asked for
+            v_clip = transform_vertices(v, clip_from_world).unsqueeze(0)
+            v_cam = None
+        else:
+            v_cam = torch.matmul(F.pad(v, pad=(0, 1), mode='constant', value=1.0), pose_inv.T).float().unsqueeze(0)
+            v_clip = v_cam @ proj.T
 
         rast, rast_db = dr.rasterize(self.glctx, v_clip, mesh.f, (h, w))
         alpha = torch.clamp(rast[..., -1:], 0, 1).contiguous()                                   # [1,H,W,1]
-        alpha = dr.antialias(alpha, rast, v_clip, mesh.f).clamp(0, 1).squeeze(0)                 # silhouette gradients enter here
+        alpha = dr.antialias(alpha, rast, v_clip, mesh.f)                                        # silhouette gradients enter here
+        if not fused:
+            alpha = alpha.clamp(0, 1).squeeze(0)
         texc, texc_db = dr.interpolate(mesh.vt.unsqueeze(0).contiguous(), rast, mesh.ft, rast_db=rast_db, diff_attrs='all')
         albedo = torch.sigmoid(dr.texture(self.raw_albedo.unsqueeze(0), texc, uv_da=texc_db, filter_mode=texture_filter))
 
@@ -113,7 +125,8 @@ class DiffRastRenderer(nn.Module):
         # (optional_render_types) and then only reads 'image' (diff_mesh.py:104-106) -- two interpolations, the vertex-normal rebuild and
         # their backward passes per view for nothing.  Accessing a key gives exactly the tensor the eager code would have returned.
         def depth_fn():
-            d, _ = dr.interpolate(-v_cam[..., [2]], rast, mesh.f)
+            vc = v_cam if v_cam is not None else transform_vertices(v, pose_inv).unsqueeze(0)
+            d, _ = dr.interpolate(-vc[..., [2]], rast, mesh.f)
             d = d.squeeze(0)
             return scale_img_hwc(d, (h0, w0)) if ssaa != 1 else d
 
@@ -139,11 +152,17 @@ class DiffRastRenderer(nn.Module):
             return shading
 
         albedo = dr.antialias(albedo, rast, v_clip, mesh.f).squeeze(0).contiguous()
-        albedo = alpha * albedo + (1 - alpha) * bg_color
-        if ssaa != 1:
-            albedo, alpha = scale_img_hwc(albedo, (h0, w0)), scale_img_hwc(alpha, (h0, w0))
         results = LazyResults()
-        results['image'] = albedo.clamp(0, 1)
+        if fused:
+            # clamp(alpha), composite over the background and the final clamp in one kernel each way (c3d_mesh_shade_*)
+            bg = bg_color if torch.is_tensor(bg_color) else torch.full((3,), float(bg_color), dtype=torch.float32, device=albedo.device)
+            image, alpha = shade(albedo, alpha.squeeze(0), bg.to(albedo.device, torch.float32).reshape(-1)[:3].expand(3).contiguous())
+            results['image'] = image
+        else:
+            albedo = alpha * albedo + (1 - alpha) * bg_color
+            if ssaa != 1:
+                albedo, alpha = scale_img_hwc(albedo, (h0, w0)), scale_img_hwc(alpha, (h0, w0))
+            results['image'] = albedo.clamp(0, 1)
         results['alpha'] = alpha
         if 'depth' in optional_render_types:
             results.defer('depth', depth_fn)

@@ -15,6 +15,10 @@ SIGNATURES = {
     "c3d_mesh_interpolate_bwd": (C.c_int, [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]),
     "c3d_mesh_texture_fwd": (C.c_int, [vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
     "c3d_mesh_texture_bwd": (C.c_int, [vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
+    "c3d_mesh_transform_fwd": (C.c_int, [vp, vp, i32, vp, vp]),
+    "c3d_mesh_transform_bwd": (C.c_int, [vp, vp, i32, vp, vp]),
+    "c3d_mesh_shade_fwd": (C.c_int, [vp, vp, vp, C.c_int64, vp, vp, vp]),
+    "c3d_mesh_shade_bwd": (C.c_int, [vp, vp, vp, C.c_int64, vp, vp, vp, vp, vp]),
     "c3d_mesh_antialias_scratch_bytes": (sz, [i32]),
     "c3d_mesh_antialias_build_topology": (C.c_int, [vp, i32, vp, vp]),
     "c3d_mesh_antialias_fwd": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]),

@@ -708,6 +708,51 @@ __global__ void __launch_bounds__(256) k_aa_bwd(const float* __restrict__ color,
     atomicAdd(dB + 0, gxb / pv.w); atomicAdd(dB + 1, gyb / pv.w); atomicAdd(dB + 3, -(gxb * xb + gyb * yb) / pv.w);
 }
 
+// ------------------------------------------------------------------------------------------ renderer glue
+// The elementwise chain around the ops in DiffRastRenderer.render (diff_mesh_renderer.py:94-96, 139-151) as two small kernels each way:
+// vertex transform (pad + two 4x4 GEMMs in the reference) and the final shade (clamp alpha, composite over the background, clamp).
+__global__ void __launch_bounds__(256) k_transform_fwd(const float* __restrict__ v, const float* __restrict__ M, int V, float4* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= V) return;
+    const float x = v[3 * i], y = v[3 * i + 1], z = v[3 * i + 2];
+    out[i] = make_float4(M[0] * x + M[1] * y + M[2] * z + M[3], M[4] * x + M[5] * y + M[6] * z + M[7],
+                         M[8] * x + M[9] * y + M[10] * z + M[11], M[12] * x + M[13] * y + M[14] * z + M[15]);
+}
+__global__ void __launch_bounds__(256) k_transform_bwd(const float* __restrict__ M, const float4* __restrict__ dout, int V, float* __restrict__ dv) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= V) return;
+    const float4 g = dout[i];
+    dv[3 * i] = M[0] * g.x + M[4] * g.y + M[8] * g.z + M[12] * g.w;
+    dv[3 * i + 1] = M[1] * g.x + M[5] * g.y + M[9] * g.z + M[13] * g.w;
+    dv[3 * i + 2] = M[2] * g.x + M[6] * g.y + M[10] * g.z + M[14] * g.w;
+}
+// image = clamp(a * albedo + (1 - a) * bg, 0, 1), a = clamp(alpha, 0, 1)
+__global__ void __launch_bounds__(256) k_shade_fwd(const float* __restrict__ albedo, const float* __restrict__ alpha, const float* __restrict__ bg, long long P,
+                                                    float* __restrict__ image, float* __restrict__ alpha_out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const float a = fminf(fmaxf(alpha[i], 0.f), 1.f);
+    alpha_out[i] = a;
+#pragma unroll
+    for (int c = 0; c < 3; c++) image[3 * i + c] = fminf(fmaxf(a * albedo[3 * i + c] + (1.f - a) * bg[c], 0.f), 1.f);
+}
+__global__ void __launch_bounds__(256) k_shade_bwd(const float* __restrict__ albedo, const float* __restrict__ alpha, const float* __restrict__ bg, long long P,
+                                                    const float* __restrict__ dimage, const float* __restrict__ dalpha_out, float* __restrict__ dalbedo,
+                                                    float* __restrict__ dalpha) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const float ar = alpha[i], a = fminf(fmaxf(ar, 0.f), 1.f);
+    float da = dalpha_out ? dalpha_out[i] : 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float al = albedo[3 * i + c], val = a * al + (1.f - a) * bg[c];
+        const float g = (val >= 0.f && val <= 1.f) ? (dimage ? dimage[3 * i + c] : 0.f) : 0.f;     // torch.clamp passes the gradient on the closed interval
+        dalbedo[3 * i + c] = g * a;
+        da += g * (al - bg[c]);
+    }
+    dalpha[i] = (ar >= 0.f && ar <= 1.f) ? da : 0.f;
+}
+
 // ------------------------------------------------------------------------------------------ C-ABI
 #define MESH_REQUIRE(cond, msg) do { if (!(cond)) { c3d_set_error("c3d_mesh: " msg); return -1; } } while (0)
 static inline size_t zbuf_bytes(int B, int H, int W) { return c3d_align(8 * (size_t)B * H * W); }
@@ -867,6 +912,36 @@ int c3d_mesh_texture_bwd(const float* tex, int32_t Bt, const float* uv, const fl
     } else {
         hipLaunchKernelGGL(k_tex_bwd, dim3(c3d_cdiv(BP, 256)), dim3(256), 0, s, tex, Bt, (const float2*)uv, dy, BP, P, Ht, Wt, C, filter, boundary, dtex, (float2*)duv);
     }
+    C3D_LAUNCH_CHECK();
+    return 0;
+}
+
+int c3d_mesh_transform_fwd(const float* v, const float* M, int32_t V, float* out, c3d_stream_t stream) {
+    if (V <= 0) return 0;
+    MESH_REQUIRE(v && M && out, "NULL pointer");
+    hipLaunchKernelGGL(k_transform_fwd, dim3(c3d_cdiv(V, 256)), dim3(256), 0, (hipStream_t)stream, v, M, V, (float4*)out);
+    C3D_LAUNCH_CHECK();
+    return 0;
+}
+int c3d_mesh_transform_bwd(const float* M, const float* dout, int32_t V, float* dv, c3d_stream_t stream) {
+    if (V <= 0) return 0;
+    MESH_REQUIRE(M && dout && dv, "NULL pointer");
+    hipLaunchKernelGGL(k_transform_bwd, dim3(c3d_cdiv(V, 256)), dim3(256), 0, (hipStream_t)stream, M, (const float4*)dout, V, dv);
+    C3D_LAUNCH_CHECK();
+    return 0;
+}
+int c3d_mesh_shade_fwd(const float* albedo, const float* alpha, const float* bg, int64_t P, float* image, float* alpha_out, c3d_stream_t stream) {
+    if (P <= 0) return 0;
+    MESH_REQUIRE(albedo && alpha && bg && image && alpha_out, "NULL pointer");
+    hipLaunchKernelGGL(k_shade_fwd, dim3(c3d_cdiv(P, 256)), dim3(256), 0, (hipStream_t)stream, albedo, alpha, bg, (long long)P, image, alpha_out);
+    C3D_LAUNCH_CHECK();
+    return 0;
+}
+int c3d_mesh_shade_bwd(const float* albedo, const float* alpha, const float* bg, int64_t P, const float* dimage, const float* dalpha_out, float* dalbedo,
+                       float* dalpha, c3d_stream_t stream) {
+    if (P <= 0) return 0;
+    MESH_REQUIRE(albedo && alpha && bg && dalbedo && dalpha, "NULL pointer");
+    hipLaunchKernelGGL(k_shade_bwd, dim3(c3d_cdiv(P, 256)), dim3(256), 0, (hipStream_t)stream, albedo, alpha, bg, (long long)P, dimage, dalpha_out, dalbedo, dalpha);
     C3D_LAUNCH_CHECK();
     return 0;
 }

@@ -79,6 +79,17 @@ int c3d_mesh_antialias_bwd(const float* color, const float* rast, const float* p
                            int32_t B, int32_t V, int32_t T, int32_t H, int32_t W, int32_t C, const void* scratch,
                            float* dcolor, float* dpos, c3d_stream_t stream);
 
+/* Renderer glue of DiffRastRenderer.render (/root/reference/MVs_Algorithms/DiffRastMesh/diff_mesh_renderer.py:94-96 and :139-151): the
+ * elementwise torch chain around the ops above, as one kernel each way.
+ * transform: out[V,4] = [v, 1] . M^T for a row-major 4x4 M on the DEVICE (the reference pads v and runs two GEMMs: inverse(pose), then proj);
+ * shade:     alpha_out = clamp(alpha, 0, 1); image = clamp(alpha_out * albedo + (1 - alpha_out) * bg, 0, 1)  ([P,3], [P], bg[3] on the device);
+ *            backward with torch.clamp's convention (gradient passes on the closed interval); dimage / dalpha_out may be NULL (= zero). */
+int c3d_mesh_transform_fwd(const float* v, const float* M, int32_t V, float* out, c3d_stream_t stream);
+int c3d_mesh_transform_bwd(const float* M, const float* dout, int32_t V, float* dv, c3d_stream_t stream);
+int c3d_mesh_shade_fwd(const float* albedo, const float* alpha, const float* bg, int64_t P, float* image, float* alpha_out, c3d_stream_t stream);
+int c3d_mesh_shade_bwd(const float* albedo, const float* alpha, const float* bg, int64_t P, const float* dimage, const float* dalpha_out,
+                       float* dalbedo, float* dalpha, c3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -301,3 +301,33 @@ def test_rasterize_backward_gather_equals_scatter(sc):
     orast, _ = M.rasterize(pos, f, (H, W))
     od = M.rasterize_bwd(pos, f, rast.detach().cpu().numpy(), gy)      # the oracle on the SAME winners (depth near-ties may differ)
     assert rel_err(a.cpu().numpy(), np.asarray(od).reshape(a.shape)) <= GRAD_REL
+
+
+def test_renderer_fused_glue_equals_torch_chain():
+    """DiffRastRenderer with the fused vertex transform / shade kernels (c3d_mesh_transform_*, c3d_mesh_shade_*) against the reference's torch
+    op chain around the same nvdiffrast calls: images, alpha, lazily produced depth / normal, and the gradients of texture and geometry."""
+    from MVs_Algorithms.DiffRastMesh.diff_mesh_renderer import DiffRastRenderer
+    from shared_utils.camera_utils import OrbitCamera, orbit_camera
+    H = W = 160
+    cam = OrbitCamera(W, H, fovy=49.1)
+    pose = orbit_camera(-15.0, 40.0, 2.0)
+    bg = torch.tensor([0.2, 0.6, 0.9], device="cuda")
+    rng = np.random.default_rng(9)
+    gi = torch.tensor(rng.normal(size=(H, W, 3)).astype(np.float32), device="cuda")
+    ga = torch.tensor(rng.normal(size=(H, W, 1)).astype(np.float32), device="cuda")
+    outs = []
+    for fused in (True, False):
+        r = DiffRastRenderer(_torch_mesh(), force_cuda_rast=True).cuda()
+        r.train_geo, r.fused_glue = True, fused
+        with torch.no_grad():
+            r.raw_albedo.mul_(3.0)                     # push part of the composite outside [0,1]: the clamps must agree too
+        out = r.render(pose, cam.perspective, H, W, bg_color=bg)
+        ((out["image"] * gi).sum() + (out["alpha"] * ga).sum()).backward()
+        outs.append((out["image"].detach(), out["alpha"].detach(), out["depth"].detach(), out["normal"].detach(), r.raw_albedo.grad.clone(), r.v_offsets.grad.clone()))
+    a, b = outs
+    assert a[0].shape == (H, W, 3) and a[1].shape == (H, W, 1)
+    # one combined 4x4 instead of two successive ones: clip coordinates differ in the last bits, the silhouette blend amplifies that by 1/pixel
+    for x, y, name in zip(a[:4], b[:4], ("image", "alpha", "depth", "normal")):
+        assert (x - y).abs().mean().item() <= 1e-5 and (x - y).abs().max().item() <= 2e-3, name
+    assert rel_err(a[4].cpu().numpy(), b[4].cpu().numpy()) <= GRAD_REL
+    assert rel_err(a[5].cpu().numpy(), b[5].cpu().numpy()) <= 5e-3
