@@ -99,7 +99,10 @@ void mesh_rasterize_fwd(const real *pos, const int32_t *tri, int B, int V, int T
             int64_t ymax = Y[0] > Y[1] ? Y[0] : Y[1]; if (Y[2] > ymax) ymax = Y[2];
             /* pixel centre c = 16*px + 8 */
             int64_t px0 = (xmin - 8 + 15) >> 4, px1 = (xmax - 8) >> 4, py0 = (ymin - 8 + 15) >> 4, py1 = (ymax - 8) >> 4;
-            if (px0 < 0) px0 = 0; if (py0 < 0) py0 = 0; if (px1 > W - 1) px1 = W - 1; if (py1 > H - 1) py1 = H - 1;
+            if (px0 < 0) px0 = 0;
+            if (py0 < 0) py0 = 0;
+            if (px1 > W - 1) px1 = W - 1;
+            if (py1 > H - 1) py1 = H - 1;
             for (int64_t py = py0; py <= py1; py++)
                 for (int64_t px = px0; px <= px1; px++) {
                     int64_t cx = 16 * px + 8, cy = 16 * py + 8;
