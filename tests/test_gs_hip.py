@@ -561,8 +561,8 @@ def test_reduce_ranks_fixed_order_sum():
     assert float(fg.flat.sum()) == sum((i + 1) * p.numel() for i, p in enumerate(ps))
 
 
-@pytest.mark.parametrize("lanes", [1, 3])
-def test_render_views_equals_per_view_render(lanes):
+@pytest.mark.parametrize("lanes,res", [(1, (200, 136)), (3, (200, 136)), (4, (251, 143))])
+def test_render_views_equals_per_view_render(lanes, res):
     """c3d_gs_render_views_raw (a whole orbit in one call, views on `lanes` streams) gives exactly what the per-view render() gives;
     the camera controller takes that path when autograd is off."""
     from MVs_Algorithms.GaussianSplatting.main_3DGS_renderer import GaussianSplattingRenderer
@@ -570,7 +570,7 @@ def test_render_views_equals_per_view_render(lanes):
     raw = S.make_cloud(30000, seed=8, log_scale_mean=np.log(0.02), activated=False)
     r = GaussianSplattingRenderer(sh_degree=3, device="cuda")
     r.initialize({"xyz": raw["means3D"], "features": raw["shs"], "scaling_raw": raw["scales"], "rotation_raw": raw["rotations"], "opacity_raw": raw["opacities"]})
-    W, H = 200, 136
+    W, H = res                     # (251, 143): odd tile grid (16 x 9 tiles, partial tiles on both borders, odd supertile counts)
     ctl = GaussianSplattingCameraController(r, W, H, 49.1, static_bg=[0.2, 0.5, 0.9])
     poses = [[2.2, el, az, 0.0, 0.0, 0.0] for el, az in ((-30.0, 0.0), (0.0, 75.0), (30.0, 150.0), (60.0, -120.0), (10.0, -45.0))]
     with torch.no_grad():
