@@ -100,7 +100,9 @@ __device__ __forceinline__ void wave_reduce10(float v0, float v1, float v2, floa
 // the whole backward pass is deterministic.
 // record layout (GS_PAIR_FLOATS = 12): [c0, c2, c1, depth | m0, m1y, m1x, m2xx | m2xy, 0, m2yy, 0]  (m* = moments of dL/dG*G about the pixel)
 // ------------------------------------------------------------------------------------------
-#define BWD_ROUND 128
+// Splats per staging round.  64 keeps a workgroup at 16 KB of LDS: with 128 (31.7 KB) five resident workgroups fill a CU's 160 KB and the small
+// kernels of the other view lanes (radix scatter 38 KB, preprocess 50 KB) cannot co-reside with the compositing: 2100 -> 2170 Mpixels/s; 32 is slower again.
+#define BWD_ROUND 64
 
 __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                                                         const uint4* __restrict__ einfo,

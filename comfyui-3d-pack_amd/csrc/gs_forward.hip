@@ -217,15 +217,16 @@ int gs_launch_ranges(const GsBinning& b, int res, long long D, int tiles, hipStr
 // wave never evaluates a splat that cannot contribute to its quadrant; the per-splat data is
 // wave-uniform in the inner loop (LDS broadcast reads).
 // ------------------------------------------------------------------------------------------
+#define FWD_ROUND 256   // splats staged per round (128 measures the same within noise)
 __global__ void __launch_bounds__(256) k_composite_fwd(GsParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                                                         const float4* __restrict__ rec0, const float4* __restrict__ rec1,
                                                         const float4* __restrict__ rec2, float* __restrict__ out_color,
                                                         float* __restrict__ out_depth, float* __restrict__ out_alpha,
                                                         float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, int sh) {
-    __shared__ float4 s0[256];
-    __shared__ float4 s1[256];
-    __shared__ float4 s2[256];
-    __shared__ uint32_t smask[256];
+    __shared__ float4 s0[FWD_ROUND];
+    __shared__ float4 s1[FWD_ROUND];
+    __shared__ float4 s2[FWD_ROUND];
+    __shared__ uint32_t smask[FWD_ROUND];
     int tx, ty;   // XCD-aware, load-balanced tile order (gs_block_tile).  Speed only, never correctness.
     if (!gs_block_tile(blockIdx.x, p.gx, p.gy, tx, ty, sh)) return;
     const int tile = ty * p.gx + tx;
@@ -244,9 +245,9 @@ __global__ void __launch_bounds__(256) k_composite_fwd(GsParams p, const uint2* 
     float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f, A = 0.f;
     uint32_t last = 0;
 
-    for (int base = 0; base < todo; base += 256) {
+    for (int base = 0; base < todo; base += FWD_ROUND) {
         if (__syncthreads_count(pxf == GS_PARKED) == 256) break;
-        const int n = min(256, todo - base);
+        const int n = min(FWD_ROUND, todo - base);
         gs_stage_round(point_list + rg.x + base, n, rec0, s0, s1, s2);
         __syncthreads();
         if ((int)threadIdx.x < n) {
