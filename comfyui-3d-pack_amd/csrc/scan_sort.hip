@@ -157,8 +157,8 @@ __global__ void __launch_bounds__(RS_THREADS) k_radix_scatter(const uint32_t* __
     if (n_dev) n = min((size_t)*n_dev, n);
     __shared__ uint32_t lstart[RS_RADIX];    // first local slot of each digit
     __shared__ uint32_t gbase[RS_RADIX];     // global position of that slot
-    __shared__ uint32_t sbuf[RS_TILE];       // block-local reorder buffer, used for the keys and then again for the values: 22 KB of LDS in total
-                                             // instead of 38 KB, so that a workgroup still fits beside the compositing kernels of the other view lanes
+    __shared__ uint32_t skey[RS_TILE];
+    __shared__ uint32_t sval[RS_TILE];
     __shared__ uint32_t scan_lds[4];
     const int lane = c3d_lane(), wave = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < (RS_THREADS / 64) * RS_RADIX; i += RS_THREADS) (&whist[0][0])[i] = 0;
@@ -205,39 +205,28 @@ __global__ void __launch_bounds__(RS_THREADS) k_radix_scatter(const uint32_t* __
         for (int w = 0; w < RS_THREADS / 64; w++) { whist[w][d] = ls; ls += c[w]; }
     }
     __syncthreads();
-    uint32_t lpos[RS_ITEMS];                 // local slot of this thread's items
 #pragma unroll
     for (int i = 0; i < RS_ITEMS; i++) {
         size_t idx = wbase + (size_t)i * 64 + lane;
-        lpos[i] = 0xFFFFFFFFu;
         if (idx < n) {
             uint32_t d = (key[i] >> shift) & (RS_RADIX - 1);
-            lpos[i] = whist[wave][d] + rank[i];
-            sbuf[lpos[i]] = key[i];
+            uint32_t lp = whist[wave][d] + rank[i];
+            skey[lp] = key[i];
+            sval[lp] = val[i];
         }
     }
     __syncthreads();
     const int cnt = (bbase >= n) ? 0 : (int)((n - bbase) < (size_t)RS_TILE ? (n - bbase) : (size_t)RS_TILE);
-    uint32_t gpos[RS_ITEMS];                 // global position of slot i * RS_THREADS + tid (consecutive lanes -> consecutive slots of a digit run)
 #pragma unroll
     for (int i = 0; i < RS_ITEMS; i++) {
-        const int lp = i * RS_THREADS + threadIdx.x;
+        const int lp = i * RS_THREADS + threadIdx.x;     // consecutive lanes -> consecutive slots of a digit run
         if (lp < cnt) {
-            const uint32_t k = sbuf[lp];
+            const uint32_t k = skey[lp];
             const uint32_t d = (k >> shift) & (RS_RADIX - 1);
-            gpos[i] = gbase[d] + ((uint32_t)lp - lstart[d]);
-            keys_out[gpos[i]] = k;
+            const uint32_t pos = gbase[d] + ((uint32_t)lp - lstart[d]);
+            keys_out[pos] = k;
+            vals_out[pos] = sval[lp];
         }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < RS_ITEMS; i++)
-        if (lpos[i] != 0xFFFFFFFFu) sbuf[lpos[i]] = val[i];
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < RS_ITEMS; i++) {
-        const int lp = i * RS_THREADS + threadIdx.x;
-        if (lp < cnt) vals_out[gpos[i]] = sbuf[lp];
     }
 }
 
