@@ -387,6 +387,20 @@ def main():
             roof["traffic"] = int((rec["fetch_MB_raw"] + rec["write_MB"]) * 1e6)
             roof["traffic_note"] = "FETCH_SIZE(raw)+WRITE_SIZE per launch from profiles/%s; fetch x2-corrected: %d" % (cand[-1], int((rec["fetch_MB_x2"] + rec["write_MB"]) * 1e6))
 
+        # instruction-issue view of the same kernel (it is what actually bounds the compositing kernels): SQ counters of a
+        # single-lane rocprofv3 pass, committed like the PMC traffic (per SIMD: counters are per shader engine = 32 SIMDs)
+        try:
+            import csv
+            sq = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_sq_instruction_mix_lanes1.csv"))
+            if sq and pmc_name.get(dom):
+                for row in csv.DictReader(open(os.path.join(ROOT, "profiles", sq[-1]))):
+                    if row["kernel"] == pmc_name[dom]:
+                        n_ins = sum(float(row[c]) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_BRANCH", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM")) / 32.0
+                        roof["issue"] = {"instructions_per_simd": int(n_ins), "valu": int(float(row["SQ_INSTS_VALU"]) / 32), "salu": int(float(row["SQ_INSTS_SALU"]) / 32),
+                                         "busy_cycles": int(float(row["SQ_BUSY_CYCLES"])), "cycles_per_instruction": round(float(row["SQ_BUSY_CYCLES"]) / n_ins, 2),
+                                         "source": "profiles/" + sq[-1]}
+        except Exception:
+            pass
         if prof_conc is not None:
             roof["measured"] = "single-lane pass after the timed region (kernels run alone); timed region used %d view lanes" % a.lanes
             if prof_conc:
