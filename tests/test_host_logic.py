@@ -295,3 +295,29 @@ def test_densify_and_prune_one_pass_equals_three_rounds():
     vis = radii > 0
     assert torch.allclose(gm.xyz_gradient_accum[vis], vg[vis, :2].norm(dim=-1, keepdim=True)) and float(gm.xyz_gradient_accum[~vis].abs().sum()) == 0
     assert torch.equal(gm.denom.squeeze(-1), vis.float()) and torch.equal(gm.max_radii2D, torch.where(vis, radii, torch.zeros_like(radii)).float())
+
+
+def test_lazy_results_and_flat_grads_layout():
+    """LazyResults (DiffRastRenderer's result dict): deferred entries are computed once, on first access, and behave like ordinary items;
+    FlatGrads: parameter-shaped views alias one 16-byte-aligned buffer in order."""
+    from MVs_Algorithms.DiffRastMesh.diff_mesh_renderer import LazyResults
+    from c3d_hip.parallel import FlatGrads
+    calls = []
+    r = LazyResults()
+    r["image"] = 1
+    r.defer("depth", lambda: calls.append("d") or 42)
+    r.defer("normal", lambda: calls.append("n") or 7)
+    assert set(r.keys()) == {"image", "depth", "normal"} and "depth" in r and len(r) == 3 and calls == []
+    assert r["depth"] == 42 and r["depth"] == 42 and calls == ["d"]
+    assert r.get("normal") == 7 and r.get("missing", 5) == 5
+    assert dict(r.items()) == {"image": 1, "depth": 42, "normal": 7} and calls == ["d", "n"]
+    ps = [torch.zeros(7, *s) for s in ((3,), (1, 3), (15, 3), (1,), (3,), (4,))]
+    fg = FlatGrads(ps)
+    assert fg.flat.numel() % 4 == 0 and fg.flat.numel() >= sum(p.numel() for p in ps)
+    off = 0
+    for p, v in zip(ps, fg.views):
+        assert v.shape == p.shape and v.data_ptr() == fg.flat.data_ptr() + 4 * off and (4 * off) % 16 == 0
+        off += (p.numel() + 3) // 4 * 4
+    fg.views[2].fill_(2.0)
+    assert float(fg.flat.sum()) == 2.0 * ps[2].numel()
+    fg.exchange(None, "allreduce")            # no process group: a no-op
