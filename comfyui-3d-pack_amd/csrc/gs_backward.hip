@@ -171,6 +171,18 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
     for (int base = 0; base < upto; base += BWD_ROUND) {
         __syncthreads();
         const int n = min(BWD_ROUND, upto - base);
+        // the round's per-wave sums start at zero, so that a pair without an active lane costs the walk nothing but its test (each wave clears its
+        // own 12 rows: 12 LDS stores per round instead of three per inactive pair plus the branch around them)
+        if (lane < BWD_ROUND + 1) {
+#pragma unroll
+            for (int q = 0; q < GS_PAIR_FLOATS; q++) acc[wave][q][lane] = 0.f;
+        }
+#if BWD_ROUND > 63
+        for (int l = 64 + lane; l < BWD_ROUND + 1; l += 64) {
+#pragma unroll
+            for (int q = 0; q < GS_PAIR_FLOATS; q++) acc[wave][q][l] = 0.f;
+        }
+#endif
         gs_stage_round(point_list + rg.x + (upto - 1 - base), n, rec0, s0, s1, s2, -1);   // slot t <- list position upto-1-base-t
         if ((int)threadIdx.x < n) se[threadIdx.x] = emit_index(point_list[rg.x + (upto - 1 - base - threadIdx.x)]);
         __syncthreads();
@@ -208,8 +220,8 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
                     asm("v_cmp_le_f32_e64 %0, %1, %2" : "=s"(c2) : "v"(1.f / 255.f), "v"(alpha));
                     am = c0 & c1 & c2;
                 }
-                float t0 = 0.f, t1 = 0.f, t2 = 0.f;
                 if (am != 0ull) {   // wave-uniform
+                    float t0, t1, t2;
                     // dL/dalpha_k = T_k (c_k . dL) - [sum_{j behind k} (c_j . dL) alpha_j T_j + T_final bg . dL] / (1 - alpha_k)
                     // with (c . dL) taken over colour, depth and alpha channels; Rdot carries the bracket.  Inactive lanes run the
                     // same instructions with a zero weight (no exec-masked branch, no zero-initialised temporaries).
@@ -225,10 +237,10 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
                     const float m1x = m0 * dx, m1y = m0 * dy;
                     wave_reduce10(w * dLp0, w * dLp1, w * dLp2, w * dLd, m0, m1x, m1y, m1x * dx, m1x * dy, m1y * dy, t0, t1, t2);
                     // t0 rows: c0, c2, c1, depth   t1 rows: m0, m1y, m1x, m2xx   t2 rows: m2xy, 0, m2yy, 0
-                }
-                if ((lane & 15) == 0) {   // lanes 0,16,32,48: one row each
-                    const int row = lane >> 4;
-                    acc[wave][row][j] = t0; acc[wave][4 + row][j] = t1; acc[wave][8 + row][j] = t2;
+                    if ((lane & 15) == 0) {   // lanes 0,16,32,48: one row each
+                        const int row = lane >> 4;
+                        acc[wave][row][j] = t0; acc[wave][4 + row][j] = t1; acc[wave][8 + row][j] = t2;
+                    }
                 }
             }
         }
