@@ -9,6 +9,7 @@ reference hard-codes "cuda"), and the optimizer is the fused HIP Adam.  Densify 
 not in this file yet.
 """
 import math
+from typing import NamedTuple
 
 import numpy as np
 import torch
@@ -17,6 +18,13 @@ from torch import nn
 from c3d_hip.ply import PlyData
 from mesh_processer.mesh_utils import construct_list_of_gs_attributes, read_gs_ply, write_gs_ply
 from shared_utils.sh_utils import RGB2SH, SH2RGB
+
+
+class PointCloud(NamedTuple):
+    """points / colours / normals, all [N,3] arrays (reference :51-54)"""
+    points: np.ndarray
+    colors: np.ndarray
+    normals: np.ndarray
 
 
 def inverse_sigmoid(x):
@@ -107,6 +115,37 @@ class GaussianModel:
         rot = torch.zeros((n, 4)); rot[:, 0] = 1
         op = inverse_sigmoid(opacity * torch.ones((n, 1)))
         self._set(xyz, feats[:, :1], feats[:, 1:], sc, rot, op)
+
+    def create_from_pcd(self, pcd, spatial_lr_scale=1.0):
+        """points + colours -> model, as the reference (:407-433): SH DC from the colours, isotropic scale = sqrt of the mean squared distance to
+        the 3 nearest neighbours (simple_knn.distCUDA2 -> the HIP kernel behind include/c3d_knn.h), identity rotation, opacity 0.1.
+        `pcd` has .points [N,3] and .colors [N,3] (the reference's PointCloud NamedTuple or anything shaped like it)."""
+        from simple_knn._C import distCUDA2
+        self.spatial_lr_scale = spatial_lr_scale
+        pts = torch.tensor(np.asarray(pcd.points)).float().to(self.device)
+        n, K = pts.shape[0], (self.max_sh_degree + 1) ** 2
+        feats = torch.zeros((n, K, 3), dtype=torch.float32, device=self.device)
+        feats[:, 0] = RGB2SH(torch.tensor(np.asarray(pcd.colors)).float().to(self.device))
+        dist2 = torch.clamp_min(distCUDA2(pts), 0.0000001)
+        scales = torch.log(torch.sqrt(dist2))[..., None].repeat(1, 3)
+        rots = torch.zeros((n, 4), device=self.device)
+        rots[:, 0] = 1
+        opac = inverse_sigmoid(0.1 * torch.ones((n, 1), dtype=torch.float32, device=self.device))
+        self._set(pts, feats[:, :1], feats[:, 1:], scales, rots, opac)
+
+    def create_from_mesh(self, mesh, num_pts):
+        """ceil(num_pts / F) uniformly sampled points per face (v0 (1 - sqrt r1) + v1 (1 - r2) sqrt r1 + v2 r2 sqrt r1), random near-black
+        colours, then create_from_pcd (reference :500-524, vectorised).  Deviation: the reference prepends a dummy vertex "because .obj indices
+        start at 1" and then indexes it with the loader's 0-based faces, which shifts every face by one vertex; faces are used as they are here."""
+        v = mesh.v.detach().cpu().numpy().astype(np.float64)
+        f = mesh.f.detach().cpu().numpy().astype(np.int64)
+        per = int(math.ceil(num_pts / max(f.shape[0], 1)))
+        r1, r2 = np.random.random((f.shape[0], per, 1)), np.random.random((f.shape[0], per, 1))
+        s1 = np.sqrt(r1)
+        v0, v1, v2 = (v[f[:, k]][:, None, :] for k in range(3))
+        xyz = (v0 * (1.0 - s1) + v1 * (1.0 - r2) * s1 + v2 * r2 * s1).reshape(-1, 3)
+        shs = np.random.random((xyz.shape[0], 3)) / 255.0
+        self.create_from_pcd(PointCloud(points=xyz, colors=SH2RGB(shs), normals=np.zeros_like(xyz)), 10)
 
     def create_from_tensors(self, xyz, features, scaling_raw, rotation_raw, opacity_raw, spatial_lr_scale=1.0):
         """raw tensors in the layout create_from_ply produces (:486-498): features [N,K,3]"""
@@ -313,15 +352,22 @@ class GaussianSplattingRenderer:
             r = radius * np.cbrt(np.random.random((num_pts,)))
             xyz = np.stack((r * np.sin(thetas) * np.cos(phis), r * np.sin(thetas) * np.sin(phis), r * np.cos(thetas)), axis=1)
             shs = np.random.random((num_pts, 3)) / 255.0
-            # mean nearest-neighbour spacing of a uniform ball as the isotropic scale (distCUDA2 stand-in)
-            spacing = radius * (4.0 / 3.0 * np.pi / max(num_pts, 1)) ** (1.0 / 3.0)
-            self.gaussians.create_from_arrays(xyz, SH2RGB(shs), np.full((num_pts,), spacing), spatial_lr_scale=10)
+            if self.device.type == "cuda":
+                # the reference's path: PointCloud -> create_from_pcd with the 3-nearest-neighbour scale (:823-828)
+                self.gaussians.create_from_pcd(PointCloud(points=xyz, colors=SH2RGB(shs), normals=np.zeros((num_pts, 3))), 10)
+            else:   # host-logic tests: mean nearest-neighbour spacing of a uniform ball as the isotropic scale
+                spacing = radius * (4.0 / 3.0 * np.pi / max(num_pts, 1)) ** (1.0 / 3.0)
+                self.gaussians.create_from_arrays(xyz, SH2RGB(shs), np.full((num_pts,), spacing), spatial_lr_scale=10)
         elif isinstance(input, PlyData):
             self.gaussians.create_from_ply(input)
+        elif isinstance(input, PointCloud):
+            self.gaussians.create_from_pcd(input, 1)
         elif isinstance(input, dict):
             self.gaussians.create_from_tensors(**input)
+        elif hasattr(input, "v") and hasattr(input, "f"):        # mesh_processer.mesh.Mesh
+            self.gaussians.create_from_mesh(input, num_pts)
         else:
-            raise TypeError("initialize(): pass None, a GS PlyData or a dict of raw tensors (mesh / point-cloud initialisers need simple_knn: out of scope)")
+            raise TypeError("initialize(): pass None, a GS PlyData, a PointCloud, a Mesh or a dict of raw tensors (the UV-grid initialiser is not built)")
 
     def render_views(self, viewpoint_cameras, bg_colors=None, scaling_modifier=1.0, lanes=4):
         """Inference-only batch of render(): all cameras in ONE library call (c3d_gs_render_views_raw; views dealt onto `lanes` HIP

@@ -50,6 +50,8 @@ _SIGNATURES = {
     "c3d_gs_mark_visible": (C.c_int, [i32, vp, vp, vp, vp, vp]),
     "c3d_gs_debug_state": (C.c_int, [i32, i32, i32, vp, i64, vp] + [vp] * 7 + [vp]),
     "c3d_adam_step": (C.c_int, [vp, vp, vp, vp, i64, C.c_double, C.c_double, C.c_double, C.c_double, i64, vp]),
+    "c3d_knn_scratch_bytes": (sz, [i32]),
+    "c3d_knn3_mean_dist2": (C.c_int, [vp, i32, C.POINTER(C.c_float), C.POINTER(C.c_float), vp, vp, vp]),
     "c3d_reduce_ranks_f32": (C.c_int, [vp, vp, i32, i64, C.c_float, vp]),
     "c3d_prof_enable": (C.c_int, [C.c_int]),
     "c3d_prof_slots": (C.c_int, []),
