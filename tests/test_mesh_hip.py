@@ -331,3 +331,53 @@ def test_renderer_fused_glue_equals_torch_chain():
         assert (x - y).abs().mean().item() <= 1e-5 and (x - y).abs().max().item() <= 2e-3, name
     assert rel_err(a[4].cpu().numpy(), b[4].cpu().numpy()) <= GRAD_REL
     assert rel_err(a[5].cpu().numpy(), b[5].cpu().numpy()) <= 5e-3
+
+
+def test_other_in_tree_consumers_op_sequences():
+    """The two other in-tree users of the same ops, restated call for call against the oracle:
+    FlexiCubes' render_mesh (flexicubes_renderer.py:41-74: mask antialias, per-face normals through an (i,i,i) index buffer, vertex normals +
+    antialias, two views in one batch) and the UV bake of color_func_to_albedo (mesh_utils.py:533-541: rasterize in UV space with `ft`,
+    interpolate positions with `f`)."""
+    import nvdiffrast.torch as dr
+    H, W = 120, 136
+    v, f, vt, vn = S.make_uv_sphere(20, 32, radius=0.7, displacement=0.1)
+    pos = np.concatenate([S.mesh_clip_positions(v, el, az, 2.0, W, H)[0] for el, az in ((-10.0, 20.0), (25.0, 200.0))], 0)     # [2,V,4]
+    fi = f.astype(np.int32)
+    fnrm = np.cross(v[fi[:, 1]] - v[fi[:, 0]], v[fi[:, 2]] - v[fi[:, 0]]); fnrm /= np.linalg.norm(fnrm, axis=1, keepdims=True) + 1e-20
+    nidx = np.repeat(np.arange(fi.shape[0], dtype=np.int32)[:, None], 3, 1)
+    ctx = dr.RasterizeCudaContext()
+    tp, tf = T(pos), T(fi, torch.int32)
+    rast, db = dr.rasterize(ctx, tp, tf.int(), [H, W])
+    alpha = (rast[..., -1:] > 0).float()
+    mask = dr.antialias(alpha, rast, tp, tf)
+    fn_img, _ = dr.interpolate(T(fnrm.astype(np.float32)).unsqueeze(0).contiguous(), rast, T(nidx, torch.int32))
+    vn_img, _ = dr.interpolate(T(vn).unsqueeze(0).contiguous(), rast, tf)
+    vn_aa = dr.antialias((vn_img + 1) * 0.5, rast, tp, tf)
+    orast, _ = M.rasterize(pos, fi, (H, W))
+    r = rast.cpu().numpy()
+    same = r[..., 3] == orast[..., 3]
+    assert (~same).mean() <= 2e-4
+    use = rast.cpu().numpy()                                   # feed the oracle the same winners
+    oalpha = (use[..., 3:] > 0).astype(np.float32)
+    assert np.abs(mask.cpu().numpy() - M.antialias(oalpha, use, pos, fi)).mean() <= IMG_L1
+    ofn, _ = M.interpolate(fnrm.astype(np.float32)[None], use, nidx)
+    assert np.abs(fn_img.cpu().numpy() - ofn).max() <= 1e-5      # all three corners carry the same value: exactly the face normal
+    covered = use[..., 3] > 0
+    assert np.allclose(np.linalg.norm(fn_img.cpu().numpy()[covered], axis=-1), 1.0, atol=1e-5)
+    ovn, _ = M.interpolate(vn[None], use, fi)
+    assert np.abs(vn_aa.cpu().numpy() - M.antialias((ovn + 1) * 0.5, use, pos, fi)).mean() <= IMG_L1
+    # UV bake: positions as a texture
+    res = 96
+    uv = vt * 2.0 - 1.0
+    uv4 = np.concatenate([uv, np.zeros_like(uv[:, :1]), np.ones_like(uv[:, :1])], -1).astype(np.float32)[None]
+    rast_uv, _ = dr.rasterize(ctx, T(uv4), tf, (res, res))
+    xyzs, _ = dr.interpolate(T(v).unsqueeze(0), rast_uv, tf)
+    ones, _ = dr.interpolate(torch.ones_like(T(v)[:, :1]).unsqueeze(0), rast_uv, tf)
+    use_uv = rast_uv.cpu().numpy()
+    orast_uv, _ = M.rasterize(uv4, fi, (res, res))
+    assert (use_uv[..., 3] != orast_uv[..., 3]).mean() <= 5e-4
+    oxyz, _ = M.interpolate(v[None], use_uv, fi)
+    assert np.abs(xyzs.cpu().numpy() - oxyz).max() <= 1e-5
+    m = ones.cpu().numpy()[..., 0] > 0
+    assert m.mean() > 0.8 and np.array_equal(m, use_uv[..., 3] > 0)      # the lat-long chart fills most of the texture
+    assert np.abs(np.linalg.norm(xyzs.cpu().numpy()[0][m[0]], axis=-1) - 0.7).max() <= 0.1 + 1e-3     # baked positions lie on the displaced sphere
