@@ -592,3 +592,34 @@ def test_render_views_equals_per_view_render(lanes, res):
     # with autograd on the controller falls back to the per-view loop and keeps the graph
     images2, _, extra2 = ctl.render_all_pose(poses[:2])
     assert images2.requires_grad and "viewspace_points" in extra2
+
+
+@pytest.mark.parametrize("lambda_ssim", [0.0, 0.2])
+def test_trainer_longer_run_with_densification(lambda_ssim):
+    """60 steps of the trainer at 100k points / 256^2 with the densification schedule running (fused step for lambda_ssim = 0, autograd + MS-SSIM
+    otherwise): the loss goes down, N changes several times, nothing goes non-finite, buffers keep following N."""
+    from MVs_Algorithms.GaussianSplatting.main_3DGS import GSParams, GaussianSplatting3D
+    H = W = 256
+    rng = np.random.default_rng(11)
+    poses = [[1.75, float(el), float(az), 0.0, 0.0, 0.0] for el in (-20, 20) for az in (0, 90, 180, 270)]
+    yy, xx = np.meshgrid(np.linspace(-1, 1, H), np.linspace(-1, 1, W), indexing="ij")
+    disk = ((xx ** 2 + yy ** 2) < 0.45).astype(np.float32)
+    refs = [torch.tensor(np.stack([disk * (0.3 + 0.1 * i), disk * 0.5, disk * (0.9 - 0.1 * i)], -1).astype(np.float32)) for i in range(len(poses))]
+    masks = [torch.tensor(disk) for _ in poses]
+    np.random.seed(5); torch.manual_seed(5)
+    p = GSParams(training_iterations=60, batch_size=4, lambda_ssim=lambda_ssim, num_pts=100000, density_start_iter=5, density_end_iter=55,
+                 densification_interval=10, opacity_reset_interval=30, densify_grad_threshold=5e-7, invert_bg_prob=1.0)
+    tr = GaussianSplatting3D(p, None, device="cuda")
+    tr.prepare_training(refs, masks, poses, 49.1)
+    assert tr._can_fuse() == (lambda_ssim == 0.0)
+    rs = np.random.RandomState(0)
+    losses, ns = [], []
+    for s in range(60):
+        losses.append(tr.training_step(s, [int(i) for i in rs.randint(0, len(poses), 4)]).item())
+        ns.append(tr.renderer.gaussians._xyz.shape[0])
+    assert np.isfinite(losses).all()
+    assert np.mean(losses[-10:]) < np.mean(losses[:10])
+    assert len(set(ns)) >= 3 and ns[-1] != 100000
+    g = tr.renderer.gaussians
+    for t in (g._xyz, g._features_dc, g._features_rest, g._opacity, g._scaling, g._rotation):
+        assert torch.isfinite(t).all() and t.shape[0] == ns[-1]
