@@ -92,7 +92,7 @@ __device__ __forceinline__ void wave_reduce10(float v0, float v1, float v2, floa
 
 // ------------------------------------------------------------------------------------------
 // A7 composite backward: same tiling and per-wave ballot-compacted splat lists as the forward pass
-// (wave w = 8x8 quadrant, one pixel per lane), splats visited back to front in rounds of 128.
+// (wave w = 8x8 quadrant, one pixel per lane), splats visited back to front in rounds of BWD_ROUND (64).
 // Every lane re-derives alpha/T for its pixel.  The ten per-splat partial gradients are summed across the
 // wave (wave_reduce4), parked in LDS per (wave, splat), summed over the four waves in a fixed order and
 // written ONCE as a 48-byte record per (tile, splat) pair at the pair's emit index.  The pairs of one
