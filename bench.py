@@ -6,14 +6,21 @@
 
 Workload (config.workload): BASELINE.md section 3 configs 2-4 -- 1,000,000 synthetic Gaussians (seed 1234), SH degree 3,
 1920x1080, the 64-camera orbit.  A "step" = one pass of the hot path over one batch of views on every rank:
-`--views-per-gpu` (default 8) views, each rasterized forward and backward through the C-ABI (the gradients of the shared
-Gaussians accumulate over the views), then -- for N > 1 -- the one gradient exchange of the shared-Gaussian training
-loop (RCCL all-gather of every rank's dense gradient + fixed-order local sum).  Per-GPU work is fixed as N grows
-("weak"): at N = 8 this is config 4 (64 views/step, 8 per GPU).  Inputs are resident in HBM before the timed region.
+`--views-per-gpu` (default 8) views rasterized forward and backward through the C-ABI -- by default in ONE fused library call
+(`--render-path step`: c3d_gs_train_views_raw, views dealt onto `--lanes` HIP streams, pixel loss and its gradient inside, one
+per-Gaussian backward pass for all views); `--render-path boundary | fused | accessor` time the plain drop-in API one autograd call
+per view instead.  For N > 1 the step ends with the one gradient exchange of the shared-Gaussian training loop (`--exchange allreduce`,
+default, or `allgather`: every rank's dense gradient + fixed-order local sum).  Per-GPU work is fixed as N grows ("weak"): at N = 8
+this is config 4 (64 views/step, 8 per GPU).  Inputs are resident in HBM before the timed region.
+`--mode fwd` (config 2: forward only, c3d_gs_render_views_raw) and `--mode train` (config 3: + fused Adam) change what a step contains
+and say so in `metric`; `--workload mesh` runs BASELINE config 5 (DiffRastMesh).
 
 value = views * W * H over all ranks / wall seconds / 1e6  (wall = max over ranks, barrier + synchronize on both sides).
-roofline = the dominant kernel group (largest share of in-library GPU time inside the timed region, measured with HIP
-events on the launch stream), algorithmic bytes per launch (DESIGN.md "Algorithmic bytes") / its average duration.
+roofline = the dominant kernel group (largest share of in-library GPU time, measured with HIP events on the launch streams),
+algorithmic bytes per launch (DESIGN.md "Algorithmic bytes") / its average duration.  With view lanes > 1 the kernels of different views
+share the CUs inside the timed region, so the duration used is that of an extra single-lane pass over the same step (kernels alone);
+the in-region figures are reported as `kernels_concurrent_avg_ms` / `roofline.avg_ms_concurrent`.  `roofline.traffic` (PMC) and
+`roofline.issue` (SQ counters) come from the newest committed rocprofv3 summaries under profiles/.
 cpu_baseline = the CPU oracle (a port: the reference has no CPU path) on ONE view of the same workload.
 """
 import argparse
