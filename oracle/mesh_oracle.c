@@ -6,7 +6,9 @@
  * THIS IS TEST INFRASTRUCTURE (only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
  * leg may load it; the product under comfyui-3d-pack_amd/ never does).
  *
- * PARITY UNPINNED: nvdiffrast is an un-vendored third-party wheel
+ * PARITY UNPINNED except rasterize + interpolate forward, which tests/test_ref_pin.py holds to outputs of the
+ * reference's own custom_rasterizer (compiled by oracle/ref_build.py, vectors in tests/golden/mesh_hy_raster.npz).
+ * nvdiffrast itself is an un-vendored third-party wheel
  * (/root/reference/_Pre_Builds/_Build_Scripts/dependencies.txt:3, my-reqs.txt:74: nvdiffrast 0.3.3)
  * and the reference ships no tests or golden vectors for this path.  This
  * file restates the published semantics of those ops anchored

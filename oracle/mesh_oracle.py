@@ -1,4 +1,4 @@
-"""ctypes front-end of oracle/mesh_oracle.c (TEST INFRASTRUCTURE; PARITY UNPINNED -- see that file's header).
+"""ctypes front-end of oracle/mesh_oracle.c (TEST INFRASTRUCTURE; PARITY UNPINNED except rasterize/interpolate forward -- see that file's header).
 Function names and argument meaning follow `nvdiffrast.torch` as the reference calls it
 (/root/reference/MVs_Algorithms/DiffRastMesh/diff_mesh_renderer.py:97-138)."""
 import ctypes as C
