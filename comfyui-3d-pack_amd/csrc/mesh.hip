@@ -80,14 +80,20 @@ __device__ __forceinline__ bool mesh_covers(const TriSetup& t, int px, int py) {
     return true;
 }
 __device__ __forceinline__ void mesh_plot(const float4 p0, const float4 p1, const float4 p2, int px, int py, int W, int H, float xs, float ys,
-                                          uint32_t t, unsigned long long* zbuf) {
+                                          uint32_t t, unsigned long long* zbuf, const unsigned long long* peel) {
     const Frag f = mesh_shade(p0, p1, p2, xs * ((float)px + 0.5f) - 1.f, ys * ((float)py + 0.5f) - 1.f, xs, ys);
     if (!(f.zw >= -1.f && f.zw <= 1.f)) return;
-    atomicMin(&zbuf[(size_t)py * W + px], ((unsigned long long)ordered_bits(f.zw) << 32) | t);
+    const uint32_t zb = ordered_bits(f.zw);
+    if (peel) {   // depth peeling: only what lies strictly behind the previous layer's surface, and only where that layer had one
+        const unsigned long long pk = peel[(size_t)py * W + px];
+        if (pk == MESH_EMPTY_KEY || zb <= (uint32_t)(pk >> 32)) return;
+    }
+    atomicMin(&zbuf[(size_t)py * W + px], ((unsigned long long)zb << 32) | t);
 }
 
 __global__ void __launch_bounds__(256) k_ras_tri(const float4* __restrict__ pos, const int3* __restrict__ tri, int B, int V, int T, int H, int W,
-                                                  unsigned long long* __restrict__ zbuf, uint32_t* __restrict__ big_queue, uint32_t* __restrict__ big_count) {
+                                                  unsigned long long* __restrict__ zbuf, uint32_t* __restrict__ big_queue, uint32_t* __restrict__ big_count,
+                                                  const unsigned long long* __restrict__ peel) {
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (long long)B * T) return;
     const int b = (int)(gid / T), t = (int)(gid % T);
@@ -101,14 +107,15 @@ __global__ void __launch_bounds__(256) k_ras_tri(const float4* __restrict__ pos,
     if (area > MESH_BIG_BBOX) { big_queue[atomicAdd(big_count, 1u)] = (uint32_t)gid; return; }
     const float xs = 2.f / W, ys = 2.f / H;
     unsigned long long* zb = zbuf + (size_t)b * H * W;
+    const unsigned long long* pl = peel ? peel + (size_t)b * H * W : nullptr;
     for (int py = ts.py0; py <= ts.py1; py++)
         for (int px = ts.px0; px <= ts.px1; px++)
-            if (mesh_covers(ts, px, py)) mesh_plot(p0, p1, p2, px, py, W, H, xs, ys, (uint32_t)t, zb);
+            if (mesh_covers(ts, px, py)) mesh_plot(p0, p1, p2, px, py, W, H, xs, ys, (uint32_t)t, zb, pl);
 }
 // one workgroup per queued large triangle (grid-stride over the queue; the queue length is read on the device)
 __global__ void __launch_bounds__(256) k_ras_big(const float4* __restrict__ pos, const int3* __restrict__ tri, int V, int T, int H, int W,
                                                   unsigned long long* __restrict__ zbuf, const uint32_t* __restrict__ big_queue,
-                                                  const uint32_t* __restrict__ big_count) {
+                                                  const uint32_t* __restrict__ big_count, const unsigned long long* __restrict__ peel) {
     const uint32_t n = *big_count;
     const float xs = 2.f / W, ys = 2.f / H;
     for (uint32_t q = blockIdx.x; q < n; q += gridDim.x) {
@@ -121,9 +128,10 @@ __global__ void __launch_bounds__(256) k_ras_big(const float4* __restrict__ pos,
         const int bw = ts.px1 - ts.px0 + 1;
         const long long area = (long long)bw * (ts.py1 - ts.py0 + 1);
         unsigned long long* zb = zbuf + (size_t)b * H * W;
+        const unsigned long long* pl = peel ? peel + (size_t)b * H * W : nullptr;
         for (long long i = threadIdx.x; i < area; i += blockDim.x) {
             const int px = ts.px0 + (int)(i % bw), py = ts.py0 + (int)(i / bw);
-            if (mesh_covers(ts, px, py)) mesh_plot(p0, p1, p2, px, py, W, H, xs, ys, (uint32_t)t, zb);
+            if (mesh_covers(ts, px, py)) mesh_plot(p0, p1, p2, px, py, W, H, xs, ys, (uint32_t)t, zb, pl);
         }
     }
 }
@@ -531,6 +539,223 @@ __global__ void __launch_bounds__(256) k_tex_bwd_tiled(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------ antialias
+// ------------------------------------------------------------------------------------------ mip-mapped texture
+// 'linear-mipmap-linear' / 'linear-mipmap-nearest' (what `dr.texture(tex, uv, uv_da)` selects under filter_mode='auto').  The pyramid is the
+// base texture plus one packed buffer `stack` = levels 1..L back to back per batch item; level l is max(Ht >> l, 1) x max(Wt >> l, 1) (the
+// host refuses pyramids that would have to halve an odd extent), so kernels derive every level's shape and offset from (Ht, Wt) alone --
+// no per-lane table lookups.  A texel of the pyramid is named by one 32-bit "virtual" index: [0, Ht*Wt) = base, Ht*Wt + off_l + ... = stack.
+#define MIP_MAX 16
+struct MipShape { int L; long long total; int w[MIP_MAX + 1], h[MIP_MAX + 1]; long long off[MIP_MAX + 1]; };
+static int mip_shape(int Ht, int Wt, int max_level, MipShape& m) {
+    m.L = 0; m.total = 0; m.w[0] = Wt; m.h[0] = Ht; m.off[0] = 0;
+    int w = Wt, h = Ht;
+    while ((w > 1 || h > 1) && m.L < MIP_MAX && (max_level < 0 || m.L < max_level)) {
+        if ((w > 1 && (w & 1)) || (h > 1 && (h & 1))) return -1;
+        if (w > 1) w >>= 1;
+        if (h > 1) h >>= 1;
+        m.L++; m.w[m.L] = w; m.h[m.L] = h; m.off[m.L] = m.total; m.total += (long long)w * h;
+    }
+    return 0;
+}
+__device__ __forceinline__ int mip_w(int Wt, int l) { return max(Wt >> l, 1); }
+// texels of levels 1 .. l-1 (offset of level l inside the stack)
+__device__ __forceinline__ uint32_t mip_off(int Ht, int Wt, int l) {
+    uint32_t o = 0;
+    for (int k = 1; k < l; k++) o += (uint32_t)mip_w(Wt, k) * (uint32_t)mip_w(Ht, k);
+    return o;
+}
+// level selection from the pixel footprint: (du/dX, du/dY, dv/dX, dv/dY) scaled to texels, level = log2(major axis); + bias; clamp to [0, L]
+__device__ __forceinline__ int mip_select(const float4* __restrict__ da, const float* __restrict__ bias, long long gid, int Ht, int Wt, int L, int filter,
+                                          int& l1, float& f) {
+    float fl = 0.f;
+    if (da) {
+        const float4 d = da[gid];
+        const float dsdx = d.x * Wt, dsdy = d.y * Wt, dtdx = d.z * Ht, dtdy = d.w * Ht;
+        const float A = dsdx * dsdx + dtdx * dtdx, Bq = dsdy * dsdy + dtdy * dtdy, Cq = dsdx * dsdy + dtdx * dtdy;
+        const float l2b = 0.5f * (A + Bq), l2n = 0.25f * (A - Bq) * (A - Bq) + Cq * Cq;
+        fl = 0.5f * log2f(l2b + sqrtf(l2n));
+    }
+    if (bias) fl += bias[gid];
+    if (!(fl > 0.f)) fl = 0.f;                     // also NaN, -inf
+    fl = fminf(fl, (float)L);
+    if (filter == 2) { const int l0 = min((int)floorf(fl + 0.5f), L); l1 = l0; f = 0.f; return l0; }
+    const int l0 = min((int)floorf(fl), L);
+    l1 = min(l0 + 1, L);
+    f = fl - (float)l0;
+    return l0;
+}
+// the four bilinear taps of one level as virtual texel indices + weights
+struct MipTaps { uint32_t k[4]; float fu, fv; int w, h; };
+__device__ __forceinline__ MipTaps mip_taps(float2 q, int Ht, int Wt, int l, int boundary) {
+    MipTaps t;
+    t.w = mip_w(Wt, l); t.h = mip_w(Ht, l);
+    const uint32_t base = l == 0 ? 0u : (uint32_t)Ht * (uint32_t)Wt + mip_off(Ht, Wt, l);
+    const float u = q.x * t.w - 0.5f, v = q.y * t.h - 0.5f;
+    const float fu0 = floorf(u), fv0 = floorf(v);
+    t.fu = u - fu0; t.fv = v - fv0;
+    const int iu0 = wrapi((int)fu0, t.w, boundary), iu1 = wrapi((int)fu0 + 1, t.w, boundary);
+    const int iv0 = wrapi((int)fv0, t.h, boundary), iv1 = wrapi((int)fv0 + 1, t.h, boundary);
+    t.k[0] = base + (uint32_t)(iv0 * t.w + iu0); t.k[1] = base + (uint32_t)(iv0 * t.w + iu1);
+    t.k[2] = base + (uint32_t)(iv1 * t.w + iu0); t.k[3] = base + (uint32_t)(iv1 * t.w + iu1);
+    return t;
+}
+// address of channel 0 of virtual texel k: tb = this batch item's base texture, sb = its stack, HW = Ht*Wt
+template <typename T>
+__device__ __forceinline__ T* mip_texel(T* tb, T* sb, uint32_t HW, uint32_t k, int C) {
+    return k < HW ? tb + (size_t)k * C : sb + (size_t)(k - HW) * C;
+}
+
+__global__ void __launch_bounds__(256) k_mip_down(const float* __restrict__ src, float* __restrict__ dst, int Bt, int hs, int ws, int hd, int wd, int C,
+                                                   size_t src_bstride, size_t dst_bstride) {
+    const long long n = (long long)Bt * hd * wd * C, gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n) return;
+    const int c = (int)(gid % C); long long r = gid / C;
+    const int x = (int)(r % wd); r /= wd;
+    const int y = (int)(r % hd); const int b = (int)(r / hd);
+    const int sx = ws > 1 ? 2 : 1, sy = hs > 1 ? 2 : 1;
+    const float* sp = src + (size_t)b * src_bstride;
+    float a = 0.f;
+    for (int j = 0; j < sy; j++) for (int i = 0; i < sx; i++) a += sp[((size_t)(y * sy + j) * ws + (x * sx + i)) * C + c];
+    dst[(size_t)b * dst_bstride + ((size_t)y * wd + x) * C + c] = a / (float)(sx * sy);
+}
+// transpose of k_mip_down: fine[b][y][x][c] += coarse[b][y / sy][x / sx][c] / (sx * sy)
+__global__ void __launch_bounds__(256) k_mip_fold(const float* __restrict__ coarse, float* __restrict__ fine, int Bt, int hf, int wf, int hc, int wc, int C,
+                                                   size_t coarse_bstride, size_t fine_bstride) {
+    (void)hc;
+    const long long n = (long long)Bt * hf * wf * C, gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n) return;
+    const int c = (int)(gid % C); long long r = gid / C;
+    const int x = (int)(r % wf); r /= wf;
+    const int y = (int)(r % hf); const int b = (int)(r / hf);
+    const int sx = wf > 1 ? 2 : 1, sy = hf > 1 ? 2 : 1;
+    fine[(size_t)b * fine_bstride + ((size_t)y * wf + x) * C + c] +=
+        coarse[(size_t)b * coarse_bstride + ((size_t)(y / sy) * wc + (x / sx)) * C + c] / (float)(sx * sy);
+}
+
+__global__ void __launch_bounds__(256) k_tex_mip_fwd(const float* __restrict__ tex, const float* __restrict__ stack, int Bt, const float2* __restrict__ uv,
+                                                      const float4* __restrict__ da, const float* __restrict__ bias, long long BP, long long P, int Ht, int Wt,
+                                                      int C, int L, long long total, int filter, int boundary, float* __restrict__ out) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= BP) return;
+    const size_t bt = Bt > 1 ? (size_t)(gid / P) : 0;
+    const uint32_t HW = (uint32_t)Ht * (uint32_t)Wt;
+    const float* tb = tex + bt * HW * C;
+    const float* sb = stack + bt * (size_t)total * C;
+    int l1; float f;
+    const int l0 = mip_select(da, bias, gid, Ht, Wt, L, filter, l1, f);
+    const float2 q = uv[gid];
+    const MipTaps a = mip_taps(q, Ht, Wt, l0, boundary);
+    const float *a00 = mip_texel(tb, sb, HW, a.k[0], C), *a10 = mip_texel(tb, sb, HW, a.k[1], C);
+    const float *a01 = mip_texel(tb, sb, HW, a.k[2], C), *a11 = mip_texel(tb, sb, HW, a.k[3], C);
+    float* po = out + gid * C;
+    const bool two = l1 != l0 && f != 0.f;
+    if (!two) {
+        for (int c = 0; c < C; c++) {
+            const float top = a00[c] + a.fu * (a10[c] - a00[c]), bot = a01[c] + a.fu * (a11[c] - a01[c]);
+            po[c] = top + a.fv * (bot - top);
+        }
+        return;
+    }
+    const MipTaps b = mip_taps(q, Ht, Wt, l1, boundary);
+    const float *b00 = mip_texel(tb, sb, HW, b.k[0], C), *b10 = mip_texel(tb, sb, HW, b.k[1], C);
+    const float *b01 = mip_texel(tb, sb, HW, b.k[2], C), *b11 = mip_texel(tb, sb, HW, b.k[3], C);
+    for (int c = 0; c < C; c++) {
+        const float ta = a00[c] + a.fu * (a10[c] - a00[c]), ba = a01[c] + a.fu * (a11[c] - a01[c]);
+        const float tb_ = b00[c] + b.fu * (b10[c] - b00[c]), bb = b01[c] + b.fu * (b11[c] - b01[c]);
+        po[c] = (1.f - f) * (ta + a.fv * (ba - ta)) + f * (tb_ + b.fv * (bb - tb_));
+    }
+}
+
+// Gradient of the mip-mapped fetch.  Same structure as k_tex_bwd_tiled: a 16x16-pixel tile sums its (up to 8) taps per virtual texel in an
+// LDS hash table and issues one global atomic per distinct (texel, channel); coarse levels, where a whole tile lands on a handful of
+// texels, are exactly where the pre-combination pays most.  CT = 0: any channel count, direct global atomics.
+#define MIPT_SLOTS 2048
+template <int CT>
+__global__ void __launch_bounds__(256) k_tex_mip_bwd(const float* __restrict__ tex, const float* __restrict__ stack, int Bt, const float2* __restrict__ uv,
+                                                      const float4* __restrict__ da, const float* __restrict__ bias, const float* __restrict__ dy, int H, int W,
+                                                      int Ht, int Wt, int Crt, int L, long long total, int filter, int boundary, float* __restrict__ dtex,
+                                                      float* __restrict__ dstack, float2* __restrict__ duv) {
+    constexpr int CS = CT > 0 ? CT : 1;
+    __shared__ uint32_t keys[CT > 0 ? MIPT_SLOTS : 1];
+    __shared__ float vals[CT > 0 ? MIPT_SLOTS : 1][CS];
+    const int C = CT > 0 ? CT : Crt;
+    if (CT > 0) {
+        for (int i = threadIdx.x; i < MIPT_SLOTS; i += 256) {
+            keys[i] = TEXT_EMPTY;
+#pragma unroll
+            for (int c = 0; c < CS; c++) vals[i][c] = 0.f;
+        }
+        __syncthreads();
+    }
+    const int b = blockIdx.z;
+    const int px = blockIdx.x * 16 + (threadIdx.x & 15), py = blockIdx.y * 16 + (threadIdx.x >> 4);
+    const size_t bt = Bt > 1 ? (size_t)b : 0;
+    const uint32_t HW = (uint32_t)Ht * (uint32_t)Wt;
+    const float* tb = tex + bt * HW * C;
+    const float* sb = stack + bt * (size_t)total * C;
+    float* dtb = dtex + bt * HW * C;
+    float* dsb = dstack + bt * (size_t)total * C;
+    if (px < W && py < H) {
+        const long long gid = ((long long)b * H + py) * W + px;
+        int l1; float f;
+        const int l0 = mip_select(da, bias, gid, Ht, Wt, L, filter, l1, f);
+        const float2 q = uv[gid];
+        const float* g = dy + gid * C;
+        float gu = 0.f, gv = 0.f;
+        const int nl = (l1 != l0 && f != 0.f) ? 2 : 1;
+        for (int lev = 0; lev < nl; lev++) {
+            const MipTaps t = mip_taps(q, Ht, Wt, lev ? l1 : l0, boundary);
+            const float wl = nl == 1 ? 1.f : (lev ? f : 1.f - f);
+            const float tw[4] = {(1.f - t.fu) * (1.f - t.fv), t.fu * (1.f - t.fv), (1.f - t.fu) * t.fv, t.fu * t.fv};
+            const float *p00 = mip_texel(tb, sb, HW, t.k[0], C), *p10 = mip_texel(tb, sb, HW, t.k[1], C);
+            const float *p01 = mip_texel(tb, sb, HW, t.k[2], C), *p11 = mip_texel(tb, sb, HW, t.k[3], C);
+            float lu = 0.f, lv = 0.f;
+            bool any = false;
+            for (int c = 0; c < C; c++) {
+                const float gc = g[c] * wl;
+                any = any || gc != 0.f;
+                lu += gc * ((p10[c] - p00[c]) * (1.f - t.fv) + (p11[c] - p01[c]) * t.fv);
+                lv += gc * ((p01[c] - p00[c]) * (1.f - t.fu) + (p11[c] - p10[c]) * t.fu);
+            }
+            gu += lu * t.w; gv += lv * t.h;
+            if (!any) continue;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                int slot = -1;
+                if (CT > 0) {
+                    uint32_t h = (t.k[k] * 2654435761u) >> 21;       // 11 bits
+                    for (int probe = 0; probe < 32; probe++) {       // bounded: a full table falls back to the direct scatter
+                        const uint32_t old = atomicCAS(&keys[h], TEXT_EMPTY, t.k[k]);
+                        if (old == TEXT_EMPTY || old == t.k[k]) { slot = (int)h; break; }
+                        h = (h + 1) & (MIPT_SLOTS - 1);
+                    }
+                }
+                float* dp = mip_texel(dtb, dsb, HW, t.k[k], C);
+                for (int c = 0; c < C; c++) {
+                    const float w = g[c] * wl * tw[k];
+                    if (w == 0.f) continue;
+                    if (slot >= 0) atomicAdd(&vals[slot][CT > 0 ? c : 0], w);
+                    else atomicAdd(&dp[c], w);
+                }
+            }
+        }
+        duv[gid] = make_float2(gu, gv);
+    }
+    if (CT > 0) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < MIPT_SLOTS; i += 256) {
+            const uint32_t k = keys[i];
+            if (k == TEXT_EMPTY) continue;
+            float* dp = mip_texel(dtb, dsb, HW, k, C);
+#pragma unroll
+            for (int c = 0; c < CS; c++) {
+                const float v = vals[i][c];
+                if (v != 0.f) atomicAdd(&dp[c], v);
+            }
+        }
+    }
+}
+
 // Topology hash: open addressing on the 64-bit (min vertex, max vertex) key; each slot records up to two incident
 // (triangle, opposite vertex) pairs and the total count.
 struct EdgeSlot { unsigned long long key; uint32_t count; int32_t tri0, opp0, tri1, opp1; uint32_t pad; };   // 32 bytes
@@ -765,7 +990,13 @@ size_t c3d_mesh_raster_scratch_bytes(int32_t B, int32_t H, int32_t W, int32_t T)
 
 int c3d_mesh_rasterize_fwd(const float* pos, const int32_t* tri, int32_t B, int32_t V, int32_t T, int32_t H, int32_t W, void* scratch, float* rast,
                            float* rast_db, c3d_stream_t stream) {
+    return c3d_mesh_rasterize_peel_fwd(pos, tri, B, V, T, H, W, nullptr, scratch, rast, rast_db, stream);
+}
+int c3d_mesh_rasterize_peel_fwd(const float* pos, const int32_t* tri, int32_t B, int32_t V, int32_t T, int32_t H, int32_t W, const void* prev_scratch,
+                                void* scratch, float* rast, float* rast_db, c3d_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
+    const unsigned long long* peel = (const unsigned long long*)prev_scratch;   // the previous layer's depth|id words lead its scratch
+    MESH_REQUIRE(prev_scratch != scratch || !scratch, "depth peeling needs two scratch buffers");
     MESH_REQUIRE(B >= 0 && V >= 0 && T >= 0 && H >= 0 && W >= 0, "negative size");
     MESH_REQUIRE(H <= 32768 && W <= 32768, "resolution above 32768 is not supported");
     const long long BP = (long long)B * H * W;
@@ -780,8 +1011,8 @@ int c3d_mesh_rasterize_fwd(const float* pos, const int32_t* tri, int32_t B, int3
     C3D_CHECK(hipMemsetAsync(count, 0, 4, s));
     if (T > 0 && V > 0) {
         MESH_REQUIRE(pos && tri, "NULL geometry");
-        hipLaunchKernelGGL(k_ras_tri, dim3(c3d_cdiv((long long)B * T, 256)), dim3(256), 0, s, (const float4*)pos, (const int3*)tri, B, V, T, H, W, zbuf, queue, count);
-        hipLaunchKernelGGL(k_ras_big, dim3(2048), dim3(256), 0, s, (const float4*)pos, (const int3*)tri, V, T, H, W, zbuf, queue, count);
+        hipLaunchKernelGGL(k_ras_tri, dim3(c3d_cdiv((long long)B * T, 256)), dim3(256), 0, s, (const float4*)pos, (const int3*)tri, B, V, T, H, W, zbuf, queue, count, peel);
+        hipLaunchKernelGGL(k_ras_big, dim3(2048), dim3(256), 0, s, (const float4*)pos, (const int3*)tri, V, T, H, W, zbuf, queue, count, peel);
     }
     hipLaunchKernelGGL(k_ras_resolve, dim3(c3d_cdiv(BP, 256)), dim3(256), 0, s, (const float4*)pos, (const int3*)tri, B, V, H, W, zbuf, (float4*)rast, (float4*)rast_db);
     C3D_LAUNCH_CHECK();
@@ -912,6 +1143,102 @@ int c3d_mesh_texture_bwd(const float* tex, int32_t Bt, const float* uv, const fl
     } else {
         hipLaunchKernelGGL(k_tex_bwd, dim3(c3d_cdiv(BP, 256)), dim3(256), 0, s, tex, Bt, (const float2*)uv, dy, BP, P, Ht, Wt, C, filter, boundary, dtex, (float2*)duv);
     }
+    C3D_LAUNCH_CHECK();
+    return 0;
+}
+
+int32_t c3d_mesh_mip_info(int32_t Ht, int32_t Wt, int32_t max_mip_level, int32_t* levels_hw, int64_t* stack_texels) {
+    MipShape m;
+    if (Ht <= 0 || Wt <= 0) { c3d_set_error("c3d_mesh_mip_info: empty texture"); return -1; }
+    if (mip_shape(Ht, Wt, max_mip_level, m)) {
+        c3d_set_error("mip pyramid: an odd extent > 1 would have to be halved (limit the depth with max_mip_level)");
+        return -1;
+    }
+    if (levels_hw) for (int l = 0; l <= m.L; l++) { levels_hw[2 * l] = m.h[l]; levels_hw[2 * l + 1] = m.w[l]; }
+    if (stack_texels) *stack_texels = m.total;
+    return m.L;
+}
+#define MIP_SHAPE(m)                                                                                              \
+    MipShape m;                                                                                                   \
+    MESH_REQUIRE(Ht > 0 && Wt > 0, "empty texture");                                                              \
+    MESH_REQUIRE(mip_shape(Ht, Wt, max_mip_level, m) == 0, "mip pyramid: an odd extent > 1 would have to be halved"); \
+    MESH_REQUIRE((long long)Ht * Wt + m.total < 0xFFFFFFFFll, "texture too large for 32-bit texel indices")
+int c3d_mesh_mip_build(const float* tex, int32_t Bt, int32_t Ht, int32_t Wt, int32_t C, int32_t max_mip_level, float* stack, c3d_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    MIP_SHAPE(m);
+    if (m.L == 0 || (long long)Bt * C == 0) return 0;
+    MESH_REQUIRE(tex && stack, "NULL pointer");
+    C3dProfScope ps(C3D_P_MESH_TEXTURE, s);
+    for (int l = 1; l <= m.L; l++) {
+        const float* src = l == 1 ? tex : stack + (size_t)m.off[l - 1] * C;
+        const size_t sstride = l == 1 ? (size_t)Ht * Wt * C : (size_t)m.total * C;
+        const long long n = (long long)Bt * m.h[l] * m.w[l] * C;
+        hipLaunchKernelGGL(k_mip_down, dim3(c3d_cdiv(n, 256)), dim3(256), 0, s, src, stack + (size_t)m.off[l] * C, Bt, m.h[l - 1], m.w[l - 1], m.h[l], m.w[l], C,
+                           sstride, (size_t)m.total * C);
+    }
+    C3D_LAUNCH_CHECK();
+    return 0;
+}
+int c3d_mesh_mip_build_bwd(float* dstack, int32_t Bt, int32_t Ht, int32_t Wt, int32_t C, int32_t max_mip_level, float* dtex, c3d_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    MIP_SHAPE(m);
+    if ((long long)Bt * C == 0) return 0;
+    MESH_REQUIRE(dtex, "NULL dtex");
+    C3dProfScope ps(C3D_P_MESH_TEXTURE_BWD, s);
+    C3D_CHECK(hipMemsetAsync(dtex, 0, sizeof(float) * (size_t)Bt * Ht * Wt * C, s));
+    if (m.L == 0) return 0;
+    MESH_REQUIRE(dstack, "NULL dstack");
+    for (int l = m.L; l >= 1; l--) {
+        float* fine = l == 1 ? dtex : dstack + (size_t)m.off[l - 1] * C;
+        const size_t fstride = l == 1 ? (size_t)Ht * Wt * C : (size_t)m.total * C;
+        const long long n = (long long)Bt * m.h[l - 1] * m.w[l - 1] * C;
+        hipLaunchKernelGGL(k_mip_fold, dim3(c3d_cdiv(n, 256)), dim3(256), 0, s, dstack + (size_t)m.off[l] * C, fine, Bt, m.h[l - 1], m.w[l - 1], m.h[l], m.w[l], C,
+                           (size_t)m.total * C, fstride);
+    }
+    C3D_LAUNCH_CHECK();
+    return 0;
+}
+int c3d_mesh_texture_mip_fwd(const float* tex, const float* stack, int32_t Bt, const float* uv, const float* uv_da, const float* mip_level_bias, int32_t B,
+                             int32_t H, int32_t W, int32_t Ht, int32_t Wt, int32_t C, int32_t filter, int32_t boundary, int32_t max_mip_level, float* out,
+                             c3d_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    const long long P = (long long)H * W, BP = P * B;
+    if (BP == 0 || C == 0) return 0;
+    MIP_SHAPE(m);
+    MESH_REQUIRE(tex && uv && out && (stack || m.L == 0), "NULL pointer");
+    MESH_REQUIRE(uv_da || mip_level_bias, "mip-mapped filter modes need uv_da or mip_level_bias");
+    MESH_REQUIRE(Bt == 1 || Bt == B, "texture batch must be 1 or B");
+    MESH_REQUIRE((filter == 2 || filter == 3) && (boundary == 0 || boundary == 1), "unsupported filter/boundary mode");
+    C3dProfScope ps(C3D_P_MESH_TEXTURE, s);
+    hipLaunchKernelGGL(k_tex_mip_fwd, dim3(c3d_cdiv(BP, 256)), dim3(256), 0, s, tex, stack ? stack : tex, Bt, (const float2*)uv, (const float4*)uv_da, mip_level_bias,
+                       BP, P, Ht, Wt, C, m.L, m.total, filter, boundary, out);
+    C3D_LAUNCH_CHECK();
+    return 0;
+}
+int c3d_mesh_texture_mip_bwd(const float* tex, const float* stack, int32_t Bt, const float* uv, const float* uv_da, const float* mip_level_bias, const float* dy,
+                             int32_t B, int32_t H, int32_t W, int32_t Ht, int32_t Wt, int32_t C, int32_t filter, int32_t boundary, int32_t max_mip_level,
+                             float* dtex, float* dstack, float* duv, c3d_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    const long long P = (long long)H * W, BP = P * B;
+    MIP_SHAPE(m);
+    MESH_REQUIRE(Bt == 1 || Bt == B, "texture batch must be 1 or B");
+    MESH_REQUIRE((filter == 2 || filter == 3) && (boundary == 0 || boundary == 1), "unsupported filter/boundary mode");
+    C3dProfScope ps(C3D_P_MESH_TEXTURE_BWD, s);
+    if ((long long)Bt * C > 0) {
+        MESH_REQUIRE(dtex && (dstack || m.L == 0), "NULL dtex / dstack");
+        C3D_CHECK(hipMemsetAsync(dtex, 0, sizeof(float) * (size_t)Bt * Ht * Wt * C, s));
+        if (m.total) C3D_CHECK(hipMemsetAsync(dstack, 0, sizeof(float) * (size_t)Bt * m.total * C, s));
+    }
+    if (BP == 0 || C == 0) return 0;
+    MESH_REQUIRE(tex && uv && dy && duv && (stack || m.L == 0), "NULL pointer");
+    MESH_REQUIRE(uv_da || mip_level_bias, "mip-mapped filter modes need uv_da or mip_level_bias");
+    const dim3 grid(c3d_cdiv(W, 16), c3d_cdiv(H, 16), B);
+    const float* st = stack ? stack : tex;
+    float* dst = dstack ? dstack : dtex;
+#define MIP_BWD(CT) hipLaunchKernelGGL((k_tex_mip_bwd<CT>), grid, dim3(256), 0, s, tex, st, Bt, (const float2*)uv, (const float4*)uv_da, mip_level_bias, dy, H, W, \
+                                       Ht, Wt, C, m.L, m.total, filter, boundary, dtex, dst, (float2*)duv)
+    if (C == 1) MIP_BWD(1); else if (C == 3) MIP_BWD(3); else if (C == 4) MIP_BWD(4); else MIP_BWD(0);
+#undef MIP_BWD
     C3D_LAUNCH_CHECK();
     return 0;
 }

@@ -6,9 +6,11 @@ Same function names, argument meaning and return shapes as the module the refere
     RasterizeCudaContext(device=None) / RasterizeGLContext(...)      rasterize(glctx, pos, tri, resolution, ranges=None, grad_db=True)
     interpolate(attr, rast, tri, rast_db=None, diff_attrs=None)      texture(tex, uv, uv_da=None, ..., filter_mode='auto', boundary_mode='wrap')
     antialias(color, rast, pos, tri, topology_hash=None, pos_gradient_boost=1.0)
+    texture_construct_mip(tex, max_mip_level=None)                    filter modes nearest | linear | linear-mipmap-nearest | linear-mipmap-linear
+    DepthPeeler(glctx, pos, tri, resolution).rasterize_next_layer()
 The arithmetic runs in libc3d_hip.so; this file allocates tensors and wires autograd.  There is no CPU path.
-Not built (raise NotImplementedError): range mode (`ranges`), mip-mapped filter modes, cube maps, DepthPeeler; gradients w.r.t.
-rast_db / out_da are not propagated (no consumer on the reference's path: `texture(..., 'linear')` ignores uv_da).
+Not built (raise NotImplementedError): range mode (`ranges`), cube maps, boundary modes 'zero' / 'cube'; gradients w.r.t.
+rast_db / out_da / uv_da / mip_level_bias are not propagated (no consumer on the reference's path).
 """
 import torch
 
@@ -61,7 +63,7 @@ class RasterizeGLContext(RasterizeCudaContext):
 
 class _Rasterize(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, glctx, pos, tri, resolution, grad_db):
+    def forward(ctx, glctx, pos, tri, resolution, grad_db, peeler=None):
         lib = _h.lib()
         _dev_check(pos, "pos")
         if pos.dim() != 3 or pos.shape[-1] != 4:
@@ -72,11 +74,17 @@ class _Rasterize(torch.autograd.Function):
         H, W = int(resolution[0]), int(resolution[1])
         dev = pos.device
         with torch.cuda.device(dev):
-            scratch = glctx.scratch(lib.c3d_mesh_raster_scratch_bytes(B, H, W, T), dev)
+            nbytes = lib.c3d_mesh_raster_scratch_bytes(B, H, W, T)
             rast = torch.empty((B, H, W, 4), dtype=torch.float32, device=dev)
             rast_db = torch.empty((B, H, W, 4), dtype=torch.float32, device=dev)
-            _h.check(lib.c3d_mesh_rasterize_fwd(_h.ptr(pos_c), _h.ptr(tri_c if T else None), B, V, T, H, W, _h.ptr(scratch), _h.ptr(rast),
-                                                _h.ptr(rast_db), _h.stream(dev)), "c3d_mesh_rasterize_fwd")
+            if peeler is None:
+                scratch = glctx.scratch(nbytes, dev)
+                _h.check(lib.c3d_mesh_rasterize_fwd(_h.ptr(pos_c), _h.ptr(tri_c if T else None), B, V, T, H, W, _h.ptr(scratch), _h.ptr(rast),
+                                                    _h.ptr(rast_db), _h.stream(dev)), "c3d_mesh_rasterize_fwd")
+            else:
+                prev, scratch = peeler._next_buffers(nbytes, dev)       # the previous layer's depth|id words, and where this layer's go
+                _h.check(lib.c3d_mesh_rasterize_peel_fwd(_h.ptr(pos_c), _h.ptr(tri_c if T else None), B, V, T, H, W, _h.ptr(prev), _h.ptr(scratch),
+                                                         _h.ptr(rast), _h.ptr(rast_db), _h.stream(dev)), "c3d_mesh_rasterize_peel_fwd")
         ctx.save_for_backward(pos_c if pos_c is not None else pos, tri_c, rast)
         ctx.dims = (B, V, T, H, W)
         ctx.glctx = glctx
@@ -99,7 +107,7 @@ class _Rasterize(torch.autograd.Function):
             else:
                 _h.check(lib.c3d_mesh_rasterize_bwd(_h.ptr(pos), _h.ptr(tri if T else None), _h.ptr(rast), _h.ptr(_h.f32c(dy)), B, V, T, H, W,
                                                     _h.ptr(dpos), _h.stream(dev)), "c3d_mesh_rasterize_bwd")
-        return None, dpos, None, None, None
+        return None, dpos, None, None, None, None
 
 
 def rasterize(glctx, pos, tri, resolution, ranges=None, grad_db=True):
@@ -108,7 +116,48 @@ def rasterize(glctx, pos, tri, resolution, ranges=None, grad_db=True):
         raise NotImplementedError("rasterize(ranges=...) (instanced range mode) is not built")
     if not isinstance(glctx, RasterizeCudaContext):
         raise TypeError("rasterize: glctx must be a RasterizeCudaContext / RasterizeGLContext")
-    return _Rasterize.apply(glctx, pos, tri, resolution, grad_db)
+    if glctx.active_depth_peeler is not None:
+        raise RuntimeError("rasterize: cannot be called on a context while a DepthPeeler is active on it")
+    return _Rasterize.apply(glctx, pos, tri, resolution, grad_db, None)
+
+
+class DepthPeeler:
+    """`with DepthPeeler(glctx, pos, tri, resolution) as peeler: rast, db = peeler.rasterize_next_layer()` -- layer 0 is what rasterize()
+    returns; every further layer keeps, per pixel, the nearest surface strictly behind the previous layer's (empty where that layer was
+    empty).  Layers are differentiable like rasterize() outputs.  (Reference use: InstantMesh/models/geometry/render/neural_render.py:103.)"""
+
+    def __init__(self, glctx, pos, tri, resolution, ranges=None, grad_db=True):
+        if ranges is not None:
+            raise NotImplementedError("DepthPeeler(ranges=...) (instanced range mode) is not built")
+        if not isinstance(glctx, RasterizeCudaContext):
+            raise TypeError("DepthPeeler: glctx must be a RasterizeCudaContext / RasterizeGLContext")
+        self.raster_ctx, self.pos, self.tri, self.resolution, self.grad_db = glctx, pos, tri, resolution, grad_db
+        self._bufs, self._layer, self._active = [None, None], 0, False
+
+    def __enter__(self):
+        if self.raster_ctx.active_depth_peeler is not None:
+            raise RuntimeError("DepthPeeler: another depth peeling operation is active on this context")
+        self.raster_ctx.active_depth_peeler = self
+        self._layer, self._active = 0, True
+        return self
+
+    def __exit__(self, *args):
+        self.raster_ctx.active_depth_peeler = None
+        self._bufs, self._active = [None, None], False
+        return False
+
+    def _next_buffers(self, nbytes, device):
+        cur = self._layer & 1
+        if self._bufs[cur] is None or self._bufs[cur].numel() < nbytes or self._bufs[cur].device != device:
+            self._bufs[cur] = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+        prev = self._bufs[cur ^ 1] if self._layer > 0 else None
+        self._layer += 1
+        return prev, self._bufs[cur]
+
+    def rasterize_next_layer(self):
+        if not self._active:
+            raise RuntimeError("DepthPeeler: rasterize_next_layer() must be called inside the `with` block")
+        return _Rasterize.apply(self.raster_ctx, self.pos, self.tri, self.resolution, self.grad_db, self)
 
 
 class _Interpolate(torch.autograd.Function):
@@ -193,17 +242,147 @@ class _Texture(torch.autograd.Function):
         return dtex, duv, None, None
 
 
+_MIP_FILTER = {"linear-mipmap-nearest": 2, "linear-mipmap-linear": 3}
+
+
+def _mip_levels(Ht, Wt, max_mip_level):
+    """[(h, w)] per level including the base, texels of levels 1..L.  ValueError where an odd extent > 1 would have to be halved."""
+    import ctypes
+    hw = (ctypes.c_int32 * 34)()
+    tot = ctypes.c_int64(0)
+    L = _h.lib().c3d_mesh_mip_info(Ht, Wt, -1 if max_mip_level is None else int(max_mip_level), ctypes.addressof(hw), ctypes.addressof(tot))
+    if L < 0:
+        msg = _h.lib().c3d_last_error()
+        raise ValueError("texture mip pyramid for %dx%d: %s" % (Ht, Wt, msg.decode() if msg else "?"))
+    return [(hw[2 * l], hw[2 * l + 1]) for l in range(L + 1)], int(tot.value)
+
+
+class _MipBuild(torch.autograd.Function):
+    """tex [Bt,Ht,Wt,C] -> stack [Bt, texels of levels 1..L, C] (2x2 box pyramid); backward = its transpose"""
+
+    @staticmethod
+    def forward(ctx, tex, max_level):
+        lib = _h.lib()
+        _dev_check(tex, "tex")
+        tex_c = _h.f32c(tex)
+        Bt, Ht, Wt, C = tex_c.shape
+        _, total = _mip_levels(Ht, Wt, None if max_level < 0 else max_level)
+        dev = tex_c.device
+        with torch.cuda.device(dev):
+            stack = torch.empty((Bt, total, C), dtype=torch.float32, device=dev)
+            _h.check(lib.c3d_mesh_mip_build(_h.ptr(tex_c), Bt, Ht, Wt, C, max_level, _h.ptr(stack), _h.stream(dev)), "c3d_mesh_mip_build")
+        ctx.shape, ctx.max_level = (Bt, Ht, Wt, C), max_level
+        return stack
+
+    @staticmethod
+    def backward(ctx, dstack):
+        lib = _h.lib()
+        Bt, Ht, Wt, C = ctx.shape
+        dev = dstack.device
+        with torch.cuda.device(dev):
+            scratch = _h.f32c(dstack).clone()                      # the fold runs in place, level by level
+            dtex = torch.empty(ctx.shape, dtype=torch.float32, device=dev)
+            _h.check(lib.c3d_mesh_mip_build_bwd(_h.ptr(scratch), Bt, Ht, Wt, C, ctx.max_level, _h.ptr(dtex), _h.stream(dev)), "c3d_mesh_mip_build_bwd")
+        return dtex, None
+
+
+class TextureMipWrapper:
+    """What texture_construct_mip returns: the packed levels 1..L of `tex` (differentiable w.r.t. `tex`) and the shape they belong to."""
+
+    def __init__(self, stack, shape, max_mip_level):
+        self.stack, self.shape, self.max_mip_level = stack, tuple(shape), max_mip_level
+
+
+def texture_construct_mip(tex, max_mip_level=None, cube_mode=False):
+    """Pre-built mip stack for texture(..., mip=...), reusable across calls while `tex` is unchanged."""
+    if cube_mode or tex.dim() != 4:
+        raise NotImplementedError("texture_construct_mip: cube maps are not built")
+    return TextureMipWrapper(_MipBuild.apply(tex, -1 if max_mip_level is None else int(max_mip_level)), tex.shape, max_mip_level)
+
+
+class _TextureMip(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tex, stack, uv, uv_da, bias, filter_id, boundary_id, max_level):
+        lib = _h.lib()
+        _dev_check(tex, "tex")
+        tex_c, stack_c, uv_c = _h.f32c(tex), _h.f32c(stack), _h.f32c(uv)
+        da_c = None if uv_da is None else _h.f32c(uv_da)
+        bias_c = None if bias is None else _h.f32c(bias)
+        Bt, Ht, Wt, C = tex_c.shape
+        B, H, W, _ = uv_c.shape
+        dev = uv_c.device
+        with torch.cuda.device(dev):
+            out = torch.empty((B, H, W, C), dtype=torch.float32, device=dev)
+            _h.check(lib.c3d_mesh_texture_mip_fwd(_h.ptr(tex_c), _h.ptr(stack_c), Bt, _h.ptr(uv_c), _h.ptr(da_c), _h.ptr(bias_c),
+                                                  B, H, W, Ht, Wt, C, filter_id, boundary_id, max_level, _h.ptr(out), _h.stream(dev)), "c3d_mesh_texture_mip_fwd")
+        ctx.save_for_backward(tex_c, stack_c, uv_c, da_c, bias_c)
+        ctx.modes = (filter_id, boundary_id, max_level)
+        ctx.stack_shape = tuple(stack.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _h.lib()
+        tex, stack, uv, da, bias = ctx.saved_tensors
+        Bt, Ht, Wt, C = tex.shape
+        B, H, W, _ = uv.shape
+        dev = uv.device
+        with torch.cuda.device(dev):
+            dtex, duv = torch.empty_like(tex), torch.empty_like(uv)
+            dstack = torch.empty(ctx.stack_shape, dtype=torch.float32, device=dev)
+            _h.check(lib.c3d_mesh_texture_mip_bwd(_h.ptr(tex), _h.ptr(stack), Bt, _h.ptr(uv), _h.ptr(da), _h.ptr(bias), _h.ptr(_h.f32c(dy)),
+                                                  B, H, W, Ht, Wt, C, ctx.modes[0], ctx.modes[1], ctx.modes[2], _h.ptr(dtex),
+                                                  _h.ptr(dstack if dstack.numel() else None), _h.ptr(duv), _h.stream(dev)), "c3d_mesh_texture_mip_bwd")
+        return dtex, dstack, duv, None, None, None, None, None
+
+
+def _mip_stack(tex, mip, max_mip_level):
+    """-> (stack [Bt, texels, C], max level for the kernels) from None / a TextureMipWrapper / a list of custom level tensors"""
+    Bt, Ht, Wt, C = tex.shape
+    ml = -1 if max_mip_level is None else int(max_mip_level)
+    if mip is None:
+        return _MipBuild.apply(tex, ml), ml
+    if isinstance(mip, TextureMipWrapper):
+        if mip.shape != tuple(tex.shape):
+            raise ValueError("texture: mip stack was built for a texture of shape %s, got %s" % (mip.shape, tuple(tex.shape)))
+        wl = -1 if mip.max_mip_level is None else int(mip.max_mip_level)
+        if ml >= 0 and (wl < 0 or ml < wl):
+            raise ValueError("texture: max_mip_level must match the one the mip stack was built with")
+        return mip.stack, wl
+    # custom stack: a list of level tensors [Bt, h_l, w_l, C], l = 1..L; they receive their own gradients (not folded into `tex`)
+    levels = list(mip)
+    L = len(levels)
+    if ml >= 0:
+        L = min(L, ml)
+    shapes, _ = _mip_levels(Ht, Wt, L)
+    if len(shapes) - 1 != L:
+        raise ValueError("texture: %d custom mip levels given, the texture supports %d" % (L, len(shapes) - 1))
+    for l in range(L):
+        if tuple(levels[l].shape) != (Bt, shapes[l + 1][0], shapes[l + 1][1], C):
+            raise ValueError("texture: custom mip level %d has shape %s, expected %s" % (l + 1, tuple(levels[l].shape), (Bt,) + shapes[l + 1] + (C,)))
+    if L == 0:
+        return tex.new_zeros((Bt, 0, C)), 0
+    return torch.cat([_h.f32c(levels[l]).reshape(Bt, -1, C) for l in range(L)], dim=1), L
+
+
 def texture(tex, uv, uv_da=None, mip_level_bias=None, mip=None, filter_mode='auto', boundary_mode='wrap', max_mip_level=None):
-    """-> [B,H,W,C].  'auto' = 'linear' without uv_da (the dependency would pick a mip-mapped mode with uv_da: not built)."""
+    """-> [B,H,W,C].  'auto' = 'linear' without uv_da / mip_level_bias, 'linear-mipmap-linear' with (as the dependency documents).
+    Mip-mapped modes propagate gradients to `tex` (through every level of the pyramid), to a custom `mip` list and to `uv`; uv_da and
+    mip_level_bias receive none."""
     if filter_mode == 'auto':
         filter_mode = 'linear' if (uv_da is None and mip_level_bias is None) else 'linear-mipmap-linear'
-    if filter_mode not in _FILTER:
-        raise NotImplementedError("texture: filter_mode %r (mip-mapped modes) is not built" % (filter_mode,))
+    if filter_mode not in _FILTER and filter_mode not in _MIP_FILTER:
+        raise ValueError("texture: unknown filter_mode %r" % (filter_mode,))
     if boundary_mode not in _BOUNDARY:
         raise NotImplementedError("texture: boundary_mode %r is not built" % (boundary_mode,))
     if tex.dim() != 4:
         raise NotImplementedError("texture: cube maps are not built")
-    return _Texture.apply(tex, uv, _FILTER[filter_mode], _BOUNDARY[boundary_mode])
+    if filter_mode in _FILTER:
+        return _Texture.apply(tex, uv, _FILTER[filter_mode], _BOUNDARY[boundary_mode])
+    if uv_da is None and mip_level_bias is None:
+        raise ValueError("texture: filter_mode %r needs uv_da or mip_level_bias" % (filter_mode,))
+    stack, ml = _mip_stack(tex, mip, max_mip_level)
+    return _TextureMip.apply(tex, stack, uv, uv_da, mip_level_bias, _MIP_FILTER[filter_mode], _BOUNDARY[boundary_mode], ml)
 
 
 # topology (edge hash) cache: the reference rebuilds it on every antialias call because it never passes topology_hash; the table only
@@ -273,15 +452,6 @@ def antialias(color, rast, pos, tri, topology_hash=None, pos_gradient_boost=1.0)
 def antialias_construct_topology_hash(tri):
     """builds (and caches) the edge hash of `tri`; the returned handle may be passed as topology_hash (it is looked up again anyway)"""
     return _topology(tri.to(torch.int32).contiguous())
-
-
-def texture_construct_mip(tex, max_mip_level=None, cube_mode=False):
-    raise NotImplementedError("mip-mapped texture modes are not built")
-
-
-class DepthPeeler:
-    def __init__(self, *a, **k):
-        raise NotImplementedError("DepthPeeler is not built")
 
 
 def get_log_level():

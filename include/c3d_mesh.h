@@ -33,6 +33,12 @@ typedef void* c3d_stream_t; /* hipStream_t */
 size_t c3d_mesh_raster_scratch_bytes(int32_t B, int32_t H, int32_t W, int32_t T);
 int c3d_mesh_rasterize_fwd(const float* pos, const int32_t* tri, int32_t B, int32_t V, int32_t T, int32_t H, int32_t W,
                            void* scratch, float* rast, float* rast_db, c3d_stream_t stream);
+/* Depth peeling (the dependency's DepthPeeler.rasterize_next_layer; reference use: Gen_3D_Modules/InstantMesh/models/geometry/render/
+ * neural_render.py:103-106): like c3d_mesh_rasterize_fwd, but a fragment is kept only where the previous layer had a surface and only
+ * if its z/w is strictly greater than that surface's.  prev_scratch = the scratch buffer the previous layer was rasterized with
+ * (untouched since); NULL = first layer = c3d_mesh_rasterize_fwd.  prev_scratch and scratch must be different buffers. */
+int c3d_mesh_rasterize_peel_fwd(const float* pos, const int32_t* tri, int32_t B, int32_t V, int32_t T, int32_t H, int32_t W,
+                                const void* prev_scratch, void* scratch, float* rast, float* rast_db, c3d_stream_t stream);
 /* dy = dL/drast [B,H,W,4] (only u,v channels are differentiable); dpos [B,V,4] accumulated */
 int c3d_mesh_rasterize_bwd(const float* pos, const int32_t* tri, const float* rast, const float* dy, int32_t B, int32_t V,
                            int32_t T, int32_t H, int32_t W, float* dpos, c3d_stream_t stream);
@@ -67,6 +73,30 @@ int c3d_mesh_texture_fwd(const float* tex, int32_t Bt, const float* uv, int32_t 
 int c3d_mesh_texture_bwd(const float* tex, int32_t Bt, const float* uv, const float* dy, int32_t B, int32_t H, int32_t W,
                          int32_t Ht, int32_t Wt, int32_t C, int32_t filter, int32_t boundary, float* dtex, float* duv,
                          c3d_stream_t stream);
+
+/* Mip-mapped texture: the dependency's filter modes 'linear-mipmap-nearest' (filter 2) and 'linear-mipmap-linear' (filter 3), i.e. what
+ * dr.texture(tex, uv, uv_da) selects under filter_mode='auto' (reference call sites: Gen_3D_Modules/LGM/nerf_marching_cubes_converter.py:232,
+ * Gen_3D_Modules/TRELLIS/trellis/utils/postprocessing_utils.py:384, Gen_3D_Modules/Stable3DGen/trellis/utils/_rasterization.py:88) and
+ * dr.texture_construct_mip.
+ *   pyramid: level l+1 = 2x2 box average of level l (an extent that reached 1 stays 1); levels until 1x1, max_mip_level (< 0: no limit) or 16.
+ *            `stack` [Bt][sum_{l>=1} h_l*w_l][C] holds levels 1..L back to back.  A pyramid that would have to halve an odd extent > 1 is an error.
+ *   level  : uv_da [B,H,W,4] = (du/dX, du/dY, dv/dX, dv/dY) -> log2 of the footprint's major axis in texels, + mip_level_bias [B,H,W] (either may
+ *            be NULL, not both), clamped to [0, L]; filter 3 blends floor(level) and the next level, filter 2 samples floor(level + .5).
+ * c3d_mesh_mip_info is host-only: returns L (or -1), levels_hw[2*(L+1)] = (h, w) per level incl. the base (room for 34 ints), *stack_texels. */
+int32_t c3d_mesh_mip_info(int32_t Ht, int32_t Wt, int32_t max_mip_level, int32_t* levels_hw, int64_t* stack_texels);
+int c3d_mesh_mip_build(const float* tex, int32_t Bt, int32_t Ht, int32_t Wt, int32_t C, int32_t max_mip_level, float* stack,
+                       c3d_stream_t stream);
+/* dtex [Bt,Ht,Wt,C] written in full = transpose of the pyramid applied to dstack; dstack is used as scratch and modified */
+int c3d_mesh_mip_build_bwd(float* dstack, int32_t Bt, int32_t Ht, int32_t Wt, int32_t C, int32_t max_mip_level, float* dtex,
+                           c3d_stream_t stream);
+int c3d_mesh_texture_mip_fwd(const float* tex, const float* stack, int32_t Bt, const float* uv, const float* uv_da,
+                             const float* mip_level_bias, int32_t B, int32_t H, int32_t W, int32_t Ht, int32_t Wt, int32_t C,
+                             int32_t filter, int32_t boundary, int32_t max_mip_level, float* out, c3d_stream_t stream);
+/* dtex (level-0 taps) and dstack (levels >= 1) accumulated; duv [B,H,W,2] written in full; uv_da / bias receive no gradient */
+int c3d_mesh_texture_mip_bwd(const float* tex, const float* stack, int32_t Bt, const float* uv, const float* uv_da,
+                             const float* mip_level_bias, const float* dy, int32_t B, int32_t H, int32_t W, int32_t Ht, int32_t Wt,
+                             int32_t C, int32_t filter, int32_t boundary, int32_t max_mip_level, float* dtex, float* dstack, float* duv,
+                             c3d_stream_t stream);
 
 /* antialias: scratch = edge hash of the topology.  c3d_mesh_antialias_build_topology fills it from `tri` (the dependency's
  * antialias_construct_topology_hash); it stays valid for as long as `tri` is unchanged and is shared by forward and backward. */

@@ -70,7 +70,10 @@ static void shade(const real *p0, const real *p1, const real *p2, real fx, real 
     f->dvdx = dfxdx * (f->b1 * datdx - da1dx); f->dvdy = dfydy * (f->b1 * datdy - da1dy);
 }
 
-void mesh_rasterize_fwd(const real *pos, const int32_t *tri, int B, int V, int T, int H, int W, real *rast, real *rast_db) {
+/* prev = the previous depth-peeling layer's rast output, or NULL: with it, a fragment survives only where that layer had a surface and
+ * only if its z/w is strictly greater than that surface's (the dependency's DepthPeeler.rasterize_next_layer as documented; reference
+ * use: Gen_3D_Modules/InstantMesh/models/geometry/render/neural_render.py:103-106) */
+static void rasterize_impl(const real *pos, const int32_t *tri, int B, int V, int T, int H, int W, const real *prev, real *rast, real *rast_db) {
     const real xs = (real)2 / W, ys = (real)2 / H;
     size_t P = (size_t)H * W;
     real *zbest = (real *)malloc(P * sizeof(real));
@@ -120,6 +123,10 @@ void mesh_rasterize_fwd(const real *pos, const int32_t *tri, int B, int V, int T
                     shade(p0, p1, p2, xs * ((real)px + (real)0.5) - (real)1, ys * ((real)py + (real)0.5) - (real)1, xs, ys, &f);
                     if (!(f.zw >= -1 && f.zw <= 1)) continue;   /* per-pixel near/far clip */
                     size_t pid = (size_t)py * W + px;
+                    if (prev) {
+                        const real *pr = prev + ((size_t)b * P + pid) * 4;
+                        if (pr[3] == 0 || !(f.zw > pr[2])) continue;
+                    }
                     if (tbest[pid] < 0 || f.zw < zbest[pid]) { zbest[pid] = f.zw; tbest[pid] = t; }
                 }
         }
@@ -136,6 +143,12 @@ void mesh_rasterize_fwd(const real *pos, const int32_t *tri, int B, int V, int T
             }
     }
     free(zbest); free(tbest);
+}
+void mesh_rasterize_fwd(const real *pos, const int32_t *tri, int B, int V, int T, int H, int W, real *rast, real *rast_db) {
+    rasterize_impl(pos, tri, B, V, T, H, W, NULL, rast, rast_db);
+}
+void mesh_rasterize_peel_fwd(const real *pos, const int32_t *tri, int B, int V, int T, int H, int W, const real *prev_rast, real *rast, real *rast_db) {
+    rasterize_impl(pos, tri, B, V, T, H, W, prev_rast, rast, rast_db);
 }
 
 /* dL/dpos from dL/d(u,v) (dy[...,0:2]); dpos [B,V,4] must be zero-initialised */
@@ -291,6 +304,161 @@ void mesh_texture_bwd(const real *tex, int Bt, const real *uv, const real *dy, i
             }
         }
     }
+}
+
+/* ------------------------------------------------------------------ mip-mapped texture
+ * Restates the dependency's mip-mapped filter modes as its documentation and public source describe them (nvdiffrast 0.3.3
+ * `texture(tex, uv, uv_da, mip_level_bias, mip, filter_mode='linear-mipmap-linear'|'linear-mipmap-nearest')`; reference call sites that
+ * reach them through filter_mode='auto' + uv_da: Gen_3D_Modules/LGM/nerf_marching_cubes_converter.py:232,
+ * Gen_3D_Modules/TRELLIS/trellis/utils/postprocessing_utils.py:384, Gen_3D_Modules/Stable3DGen/trellis/utils/_rasterization.py:88).
+ *   pyramid: level l+1 = 2x2 box average of level l; an extent that has reached 1 stays 1 (2x1 / 1x2 averages); levels until 1x1 or
+ *            max_mip_level.  `stack` holds levels 1..L back to back per batch item: [Bt][sum_l h_l*w_l][C].
+ *   level:   with uv_da = (du/dX, du/dY, dv/dX, dv/dY): J = [[du/dX*Wt, du/dY*Wt],[dv/dX*Ht, dv/dY*Ht]], lambda = largest eigenvalue of
+ *            J J^T (squared major axis of the pixel footprint in texels), level = log2(lambda)/2 (+ bias); without uv_da, level = bias.
+ *            Clamped to [0, L]; NaN -> 0.  'linear-mipmap-linear' blends floor(level) and the next level by the fraction;
+ *            'linear-mipmap-nearest' samples level floor(level + 0.5).  Each level is sampled bilinearly (texel centres at half integers).
+ * Gradients: texels of both levels (dtex for level 0, dstack for levels >= 1; the pyramid's own backward folds dstack down), uv.
+ * uv_da / bias receive no gradient (as for rast_db / out_da above: no consumer). */
+#define MIP_MAX 16
+typedef struct { int L; int w[MIP_MAX + 1], h[MIP_MAX + 1]; long long off[MIP_MAX + 1]; long long total; } mip_t;
+/* returns 0, or -1 when an extent > 1 is odd at a level that still has to be halved */
+static int mip_info(int Ht, int Wt, int max_level, mip_t *m) {
+    m->L = 0; m->w[0] = Wt; m->h[0] = Ht; m->off[0] = 0; m->total = 0;
+    int w = Wt, h = Ht;
+    while ((w > 1 || h > 1) && m->L < MIP_MAX && (max_level < 0 || m->L < max_level)) {
+        if ((w > 1 && (w & 1)) || (h > 1 && (h & 1))) return -1;
+        if (w > 1) w >>= 1;
+        if (h > 1) h >>= 1;
+        m->L++; m->w[m->L] = w; m->h[m->L] = h; m->off[m->L] = m->total; m->total += (long long)w * h;
+    }
+    return 0;
+}
+/* levels_hw [2*(MIP_MAX+1)] receives (h, w) per level incl. the base; returns L (or -1), *stack_texels = texels of levels 1..L */
+int mesh_mip_info(int Ht, int Wt, int max_level, int *levels_hw, long long *stack_texels) {
+    mip_t m; if (mip_info(Ht, Wt, max_level, &m)) return -1;
+    for (int l = 0; l <= m.L; l++) { levels_hw[2 * l] = m.h[l]; levels_hw[2 * l + 1] = m.w[l]; }
+    *stack_texels = m.total;
+    return m.L;
+}
+static const real *mip_level_c(const real *tex, const real *stack, const mip_t *m, int l, int bt, int C) {
+    return l == 0 ? tex + (size_t)bt * m->h[0] * m->w[0] * C : stack + ((size_t)bt * m->total + m->off[l]) * C;
+}
+static real *mip_level(real *tex, real *stack, const mip_t *m, int l, int bt, int C) {
+    return l == 0 ? tex + (size_t)bt * m->h[0] * m->w[0] * C : stack + ((size_t)bt * m->total + m->off[l]) * C;
+}
+int mesh_mip_build(const real *tex, int Bt, int Ht, int Wt, int C, int max_level, real *stack) {
+    mip_t m; if (mip_info(Ht, Wt, max_level, &m)) return -1;
+    for (int b = 0; b < Bt; b++)
+        for (int l = 1; l <= m.L; l++) {
+            const real *src = mip_level_c(tex, stack, &m, l - 1, b, C);
+            real *dst = mip_level((real *)tex, stack, &m, l, b, C);
+            int sx = m.w[l - 1] > 1 ? 2 : 1, sy = m.h[l - 1] > 1 ? 2 : 1, ws = m.w[l - 1];
+            for (int y = 0; y < m.h[l]; y++) for (int x = 0; x < m.w[l]; x++) for (int c = 0; c < C; c++) {
+                real a = 0;
+                for (int j = 0; j < sy; j++) for (int i = 0; i < sx; i++) a += src[((size_t)(y * sy + j) * ws + (x * sx + i)) * C + c];
+                dst[((size_t)y * m.w[l] + x) * C + c] = a / (real)(sx * sy);
+            }
+        }
+    return 0;
+}
+/* dtex [Bt,Ht,Wt,C] += the pyramid's transposed filters applied to dstack (dstack is used as scratch and modified) */
+int mesh_mip_build_bwd(real *dstack, int Bt, int Ht, int Wt, int C, int max_level, real *dtex) {
+    mip_t m; if (mip_info(Ht, Wt, max_level, &m)) return -1;
+    for (int b = 0; b < Bt; b++)
+        for (int l = m.L; l >= 1; l--) {
+            const real *src = mip_level_c(dtex, dstack, &m, l, b, C);
+            real *dst = mip_level(dtex, dstack, &m, l - 1, b, C);
+            int sx = m.w[l - 1] > 1 ? 2 : 1, sy = m.h[l - 1] > 1 ? 2 : 1, wd = m.w[l - 1];
+            for (int y = 0; y < m.h[l - 1]; y++) for (int x = 0; x < wd; x++) for (int c = 0; c < C; c++)
+                dst[((size_t)y * wd + x) * C + c] += src[((size_t)(y / sy) * m.w[l] + (x / sx)) * C + c] / (real)(sx * sy);
+        }
+    return 0;
+}
+/* level selection: returns level0, *level1, *frac */
+static int mip_select(const real *da, const real *bias, int Ht, int Wt, int L, int filter, int *level1, real *frac) {
+    real fl = 0;
+    if (da) {
+        real dsdx = da[0] * Wt, dsdy = da[1] * Wt, dtdx = da[2] * Ht, dtdy = da[3] * Ht;
+        real A = dsdx * dsdx + dtdx * dtdx, Bq = dsdy * dsdy + dtdy * dtdy, Cq = dsdx * dsdy + dtdx * dtdy;
+        real l2b = (real)0.5 * (A + Bq), l2n = (real)0.25 * (A - Bq) * (A - Bq) + Cq * Cq;
+        real major = l2b + (real)sqrt((double)l2n);
+        fl = (real)0.5 * (real)log2((double)major);
+    }
+    if (bias) fl += *bias;
+    if (!(fl > 0)) fl = 0;                /* also NaN and -inf */
+    if (fl > (real)L) fl = (real)L;
+    int l0;
+    if (filter == 2) { l0 = (int)floor((double)fl + 0.5); if (l0 > L) l0 = L; *level1 = l0; *frac = 0; return l0; }
+    l0 = (int)floor((double)fl); if (l0 > L) l0 = L;
+    *level1 = l0 + 1 > L ? L : l0 + 1;
+    *frac = fl - (real)l0;
+    return l0;
+}
+/* filter: 2 = linear-mipmap-nearest, 3 = linear-mipmap-linear.  uv_da [B,H,W,4] or NULL, bias [B,H,W] or NULL (not both NULL). */
+int mesh_texture_mip_fwd(const real *tex, const real *stack, int Bt, const real *uv, const real *uv_da, const real *bias, int B, int H, int W,
+                         int Ht, int Wt, int C, int filter, int boundary, int max_level, real *out) {
+    mip_t m; if (mip_info(Ht, Wt, max_level, &m)) return -1;
+    size_t P = (size_t)H * W;
+    for (int b = 0; b < B; b++) for (size_t pid = 0; pid < P; pid++) {
+        size_t o = (size_t)b * P + pid;
+        int l1; real f;
+        int l0 = mip_select(uv_da ? uv_da + 4 * o : NULL, bias ? bias + o : NULL, Ht, Wt, m.L, filter, &l1, &f);
+        real *po = out + o * C;
+        for (int c = 0; c < C; c++) po[c] = 0;
+        for (int k = 0; k < 2; k++) {
+            int l = k ? l1 : l0; real wl = k ? f : (real)1 - f;
+            if (k && (l1 == l0 || f == 0)) break;
+            const real *tb = mip_level_c(tex, stack, &m, l, Bt > 1 ? b : 0, C);
+            int wl_ = m.w[l], hl_ = m.h[l];
+            real u = uv[2 * o] * wl_ - (real)0.5, v = uv[2 * o + 1] * hl_ - (real)0.5;
+            real fu0 = (real)floor((double)u), fv0 = (real)floor((double)v), fu = u - fu0, fv = v - fv0;
+            int iu0 = wrapi((int)fu0, wl_, boundary), iu1 = wrapi((int)fu0 + 1, wl_, boundary);
+            int iv0 = wrapi((int)fv0, hl_, boundary), iv1 = wrapi((int)fv0 + 1, hl_, boundary);
+            for (int c = 0; c < C; c++) {
+                real t00 = tb[((size_t)iv0 * wl_ + iu0) * C + c], t10 = tb[((size_t)iv0 * wl_ + iu1) * C + c];
+                real t01 = tb[((size_t)iv1 * wl_ + iu0) * C + c], t11 = tb[((size_t)iv1 * wl_ + iu1) * C + c];
+                real top = t00 + fu * (t10 - t00), bot = t01 + fu * (t11 - t01);
+                po[c] += wl * (top + fv * (bot - top));
+            }
+        }
+    }
+    return 0;
+}
+/* dtex [Bt,Ht,Wt,C], dstack [Bt,total,C], duv [B,H,W,2]: zero-initialised by the caller */
+int mesh_texture_mip_bwd(const real *tex, const real *stack, int Bt, const real *uv, const real *uv_da, const real *bias, const real *dy,
+                         int B, int H, int W, int Ht, int Wt, int C, int filter, int boundary, int max_level, real *dtex, real *dstack, real *duv) {
+    mip_t m; if (mip_info(Ht, Wt, max_level, &m)) return -1;
+    size_t P = (size_t)H * W;
+    for (int b = 0; b < B; b++) for (size_t pid = 0; pid < P; pid++) {
+        size_t o = (size_t)b * P + pid;
+        int l1; real f;
+        int l0 = mip_select(uv_da ? uv_da + 4 * o : NULL, bias ? bias + o : NULL, Ht, Wt, m.L, filter, &l1, &f);
+        const real *g = dy + o * C;
+        for (int k = 0; k < 2; k++) {
+            int l = k ? l1 : l0; real wl = k ? f : (real)1 - f;
+            if (k && (l1 == l0 || f == 0)) break;
+            int bt = Bt > 1 ? b : 0;
+            const real *tb = mip_level_c(tex, stack, &m, l, bt, C);
+            real *db = mip_level(dtex, dstack, &m, l, bt, C);
+            int wl_ = m.w[l], hl_ = m.h[l];
+            real u = uv[2 * o] * wl_ - (real)0.5, v = uv[2 * o + 1] * hl_ - (real)0.5;
+            real fu0 = (real)floor((double)u), fv0 = (real)floor((double)v), fu = u - fu0, fv = v - fv0;
+            int iu0 = wrapi((int)fu0, wl_, boundary), iu1 = wrapi((int)fu0 + 1, wl_, boundary);
+            int iv0 = wrapi((int)fv0, hl_, boundary), iv1 = wrapi((int)fv0 + 1, hl_, boundary);
+            real gu = 0, gv = 0;
+            for (int c = 0; c < C; c++) {
+                size_t i00 = ((size_t)iv0 * wl_ + iu0) * C + c, i10 = ((size_t)iv0 * wl_ + iu1) * C + c;
+                size_t i01 = ((size_t)iv1 * wl_ + iu0) * C + c, i11 = ((size_t)iv1 * wl_ + iu1) * C + c;
+                real gc = g[c] * wl;
+                db[i00] += gc * ((real)1 - fu) * ((real)1 - fv); db[i10] += gc * fu * ((real)1 - fv);
+                db[i01] += gc * ((real)1 - fu) * fv; db[i11] += gc * fu * fv;
+                gu += gc * ((tb[i10] - tb[i00]) * ((real)1 - fv) + (tb[i11] - tb[i01]) * fv);
+                gv += gc * ((tb[i01] - tb[i00]) * ((real)1 - fu) + (tb[i11] - tb[i10]) * fu);
+            }
+            duv[2 * o] += gu * wl_; duv[2 * o + 1] += gv * hl_;
+        }
+    }
+    return 0;
 }
 
 /* ------------------------------------------------------------------ antialias */

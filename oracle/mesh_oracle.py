@@ -49,6 +49,18 @@ def rasterize(pos, tri, resolution, dtype=np.float32):
     return rast, db
 
 
+def rasterize_next_layer(pos, tri, resolution, prev_rast, dtype=np.float32):
+    """one depth-peeling step: prev_rast = the previous layer's rast (None: first layer = rasterize)"""
+    lib = _lib(dtype)
+    pos, tri = _a(pos, dtype), _a(tri, np.int32)
+    B, V, _ = pos.shape
+    H, W = resolution
+    rast = np.zeros((B, H, W, 4), dtype); db = np.zeros((B, H, W, 4), dtype)
+    prev = None if prev_rast is None else _a(prev_rast, dtype)
+    lib.mesh_rasterize_peel_fwd(_p(pos), _p(tri), I(B), I(V), I(tri.shape[0]), I(H), I(W), _p(prev), _p(rast), _p(db))
+    return rast, db
+
+
 def rasterize_bwd(pos, tri, rast, dy, dtype=np.float32):
     lib = _lib(dtype)
     pos, tri, rast, dy = _a(pos, dtype), _a(tri, np.int32), _a(rast, dtype), _a(dy, dtype)
@@ -117,6 +129,73 @@ def texture_bwd(tex, uv, dy, filter_mode="linear", boundary_mode="wrap", dtype=n
     lib.mesh_texture_bwd(_p(tex), I(Bt), _p(uv), _p(dy), I(B), I(H), I(W), I(Ht), I(Wt), I(Cc), I(_FILTER[filter_mode]), I(_BOUNDARY[boundary_mode]),
                          _p(dtex), _p(duv))
     return dtex, duv
+
+
+_MIP_FILTER = {"linear-mipmap-nearest": 2, "linear-mipmap-linear": 3}
+LL = C.c_longlong
+
+
+def mip_info(Ht, Wt, max_mip_level=None):
+    """-> [(h, w)] per level including the base, texels in levels 1..L.  Raises ValueError where an odd extent > 1 would have to be halved."""
+    lib = _lib(np.float32)
+    hw = (C.c_int * 34)(); tot = LL(0)
+    L = lib.mesh_mip_info(I(Ht), I(Wt), I(-1 if max_mip_level is None else max_mip_level), hw, C.byref(tot))
+    if L < 0:
+        raise ValueError("mip pyramid: odd extent > 1 in %dx%d (limit the depth with max_mip_level)" % (Ht, Wt))
+    return [(hw[2 * l], hw[2 * l + 1]) for l in range(L + 1)], int(tot.value)
+
+
+def mip_build(tex, max_mip_level=None, dtype=np.float32):
+    """tex [Bt,Ht,Wt,C] -> stack [Bt, texels of levels 1..L, C]"""
+    lib = _lib(dtype)
+    tex = _a(tex, dtype)
+    Bt, Ht, Wt, Cc = tex.shape
+    _, tot = mip_info(Ht, Wt, max_mip_level)
+    stack = np.zeros((Bt, tot, Cc), dtype)
+    assert lib.mesh_mip_build(_p(tex), I(Bt), I(Ht), I(Wt), I(Cc), I(-1 if max_mip_level is None else max_mip_level), _p(stack)) == 0
+    return stack
+
+
+def mip_build_bwd(dstack, tex_shape, max_mip_level=None, dtype=np.float32):
+    lib = _lib(dtype)
+    dstack = _a(dstack, dtype).copy()
+    Bt, Ht, Wt, Cc = tex_shape
+    dtex = np.zeros(tex_shape, dtype)
+    assert lib.mesh_mip_build_bwd(_p(dstack), I(Bt), I(Ht), I(Wt), I(Cc), I(-1 if max_mip_level is None else max_mip_level), _p(dtex)) == 0
+    return dtex
+
+
+def texture_mip(tex, uv, uv_da=None, mip_level_bias=None, stack=None, filter_mode="linear-mipmap-linear", boundary_mode="wrap", max_mip_level=None,
+                dtype=np.float32):
+    lib = _lib(dtype)
+    tex, uv = _a(tex, dtype), _a(uv, dtype)
+    Bt, Ht, Wt, Cc = tex.shape
+    B, H, W, _ = uv.shape
+    stack = mip_build(tex, max_mip_level, dtype) if stack is None else _a(stack, dtype)
+    da = None if uv_da is None else _a(uv_da, dtype)
+    bias = None if mip_level_bias is None else _a(mip_level_bias, dtype)
+    out = np.zeros((B, H, W, Cc), dtype)
+    assert lib.mesh_texture_mip_fwd(_p(tex), _p(stack), I(Bt), _p(uv), _p(da), _p(bias), I(B), I(H), I(W), I(Ht), I(Wt), I(Cc), I(_MIP_FILTER[filter_mode]),
+                                    I(_BOUNDARY[boundary_mode]), I(-1 if max_mip_level is None else max_mip_level), _p(out)) == 0
+    return out
+
+
+def texture_mip_bwd(tex, uv, dy, uv_da=None, mip_level_bias=None, stack=None, filter_mode="linear-mipmap-linear", boundary_mode="wrap",
+                    max_mip_level=None, dtype=np.float32):
+    """-> dtex (level-0 taps only), dstack (levels >= 1), duv.  The gradient of the base texture of an internally built pyramid is
+    dtex + mip_build_bwd(dstack)."""
+    lib = _lib(dtype)
+    tex, uv, dy = _a(tex, dtype), _a(uv, dtype), _a(dy, dtype)
+    Bt, Ht, Wt, Cc = tex.shape
+    B, H, W, _ = uv.shape
+    stack = mip_build(tex, max_mip_level, dtype) if stack is None else _a(stack, dtype)
+    da = None if uv_da is None else _a(uv_da, dtype)
+    bias = None if mip_level_bias is None else _a(mip_level_bias, dtype)
+    dtex = np.zeros_like(tex); dstack = np.zeros_like(stack); duv = np.zeros_like(uv)
+    assert lib.mesh_texture_mip_bwd(_p(tex), _p(stack), I(Bt), _p(uv), _p(da), _p(bias), _p(dy), I(B), I(H), I(W), I(Ht), I(Wt), I(Cc),
+                                    I(_MIP_FILTER[filter_mode]), I(_BOUNDARY[boundary_mode]), I(-1 if max_mip_level is None else max_mip_level),
+                                    _p(dtex), _p(dstack), _p(duv)) == 0
+    return dtex, dstack, duv
 
 
 def antialias(color, rast, pos, tri, dtype=np.float32):

@@ -143,8 +143,10 @@ def test_texture_modes_and_batches():
     (dr.texture(tt, tu, filter_mode="linear") * T(g)).sum().backward()
     dtex, duv = M.texture_bwd(tex, uv, g, dtype=np.float64)
     assert rel_err(tt.grad.cpu().numpy(), dtex) <= GRAD_REL and rel_err(tu.grad.cpu().numpy(), duv) <= GRAD_REL
+    with pytest.raises(ValueError):
+        dr.texture(T(tex), T(uv), filter_mode="linear-mipmap-linear")       # mip-mapped modes need uv_da or mip_level_bias
     with pytest.raises(NotImplementedError):
-        dr.texture(T(tex), T(uv), filter_mode="linear-mipmap-linear")
+        dr.texture(T(tex), T(uv), boundary_mode="zero")
 
 
 def test_interpolate_variants():

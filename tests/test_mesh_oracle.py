@@ -191,3 +191,141 @@ def test_gradients_by_finite_differences():
     num = _fd(lambda p: M.antialias(col, rast, p, f, dtype=np.float64), pos.copy(), ga, 1e-7, pick)
     for i in pick:
         assert abs(num[i] - dpa.reshape(-1)[i]) <= 2e-4 * max(1.0, abs(num[i])), (i, num[i], dpa.reshape(-1)[i])
+
+
+# ------------------------------------------------------------------------------------------------ mip-mapped texture
+def _da(H, W, J, Ht, Wt):
+    """uv_da [1,H,W,4] = (du/dX, du/dY, dv/dX, dv/dY) whose footprint Jacobian in texels is J"""
+    da = np.zeros((1, H, W, 4))
+    da[..., 0] = J[0][0] / Wt; da[..., 1] = J[0][1] / Wt; da[..., 2] = J[1][0] / Ht; da[..., 3] = J[1][1] / Ht
+    return da
+
+
+def test_mip_pyramid_layout_and_box_filter():
+    levels, total = M.mip_info(8, 4)
+    assert levels == [(8, 4), (4, 2), (2, 1), (1, 1)] and total == 8 + 2 + 1
+    assert M.mip_info(8, 4, max_mip_level=1) == ([(8, 4), (4, 2)], 8)
+    assert M.mip_info(1, 1) == ([(1, 1)], 0)
+    with pytest.raises(ValueError):
+        M.mip_info(6, 6)                                    # 3x3 cannot be halved
+    assert M.mip_info(6, 6, max_mip_level=1)[0] == [(6, 6), (3, 3)]
+    rng = np.random.default_rng(3)
+    tex = rng.normal(size=(2, 8, 4, 3))
+    st = M.mip_build(tex, dtype=np.float64)
+    l1 = tex.reshape(2, 4, 2, 2, 2, 3).mean(axis=(2, 4))
+    l2 = l1.reshape(2, 2, 2, 1, 2, 3).mean(axis=(2, 4))
+    l3 = l2.reshape(2, 1, 2, 1, 1, 3).mean(axis=(2, 4))    # 2x1 -> 1x1: average along the remaining axis only
+    np.testing.assert_allclose(st[:, :8].reshape(2, 4, 2, 3), l1, atol=1e-15)
+    np.testing.assert_allclose(st[:, 8:10].reshape(2, 2, 1, 3), l2, atol=1e-15)
+    np.testing.assert_allclose(st[:, 10:].reshape(2, 1, 1, 3), l3, atol=1e-15)
+    # the backward of the pyramid is its transpose
+    y = rng.normal(size=st.shape)
+    np.testing.assert_allclose((st * y).sum(), (tex * M.mip_build_bwd(y, tex.shape, dtype=np.float64)).sum(), rtol=1e-13)
+
+
+def test_mip_level_selection_known_answers():
+    rng = np.random.default_rng(4)
+    Ht, Wt, H, W = 16, 32, 5, 7
+    tex = rng.normal(size=(1, Ht, Wt, 3)); uv = rng.uniform(-0.3, 1.3, size=(1, H, W, 2))
+    st = M.mip_build(tex, dtype=np.float64)
+    lv = [tex, st[:, :8 * 16].reshape(1, 8, 16, 3), st[:, 128:128 + 32].reshape(1, 4, 8, 3)]
+    s = [M.texture(t, uv, "linear", "wrap", dtype=np.float64) for t in lv]
+    f = lambda **k: M.texture_mip(tex, uv, dtype=np.float64, **k)
+    np.testing.assert_allclose(f(uv_da=_da(H, W, [[1, 0], [0, 1]], Ht, Wt)), s[0], atol=1e-14)             # 1 texel / pixel -> level 0
+    np.testing.assert_allclose(f(uv_da=_da(H, W, [[2, 0], [0, 2]], Ht, Wt)), s[1], atol=1e-14)             # 2 texels / pixel -> level 1
+    np.testing.assert_allclose(f(uv_da=_da(H, W, [[4, 0], [0, 1]], Ht, Wt)), s[2], atol=1e-14)             # anisotropic: the major axis decides
+    np.testing.assert_allclose(f(uv_da=_da(H, W, [[0, 4], [1, 0]], Ht, Wt)), s[2], atol=1e-14)             # ... whichever way it points
+    r2 = np.sqrt(2.0)
+    np.testing.assert_allclose(f(uv_da=_da(H, W, [[r2, -r2], [r2, r2]], Ht, Wt)), s[1], atol=1e-13)        # rotation by 45 deg of 2x
+    np.testing.assert_allclose(f(uv_da=_da(H, W, [[r2, 0], [0, r2]], Ht, Wt)), 0.5 * (s[0] + s[1]), atol=1e-13)   # level 0.5
+    np.testing.assert_allclose(f(uv_da=_da(H, W, [[0, 0], [0, 0]], Ht, Wt)), s[0], atol=1e-14)             # log2(0) clamps to level 0
+    np.testing.assert_allclose(f(uv_da=_da(H, W, [[1, 0], [0, 1]], Ht, Wt), mip_level_bias=np.full((1, H, W), 1.25)), 0.75 * s[1] + 0.25 * s[2], atol=1e-13)
+    np.testing.assert_allclose(f(mip_level_bias=np.full((1, H, W), 2.0)), s[2], atol=1e-14)                # bias alone is the level
+    np.testing.assert_allclose(f(mip_level_bias=np.full((1, H, W), 1.4), filter_mode="linear-mipmap-nearest"), s[1], atol=1e-14)
+    np.testing.assert_allclose(f(mip_level_bias=np.full((1, H, W), 1.6), filter_mode="linear-mipmap-nearest"), s[2], atol=1e-14)
+    np.testing.assert_allclose(f(mip_level_bias=np.full((1, H, W), 9.0), max_mip_level=2), s[2], atol=1e-14)    # clamped to the last level
+    top = M.texture_mip(tex, uv, mip_level_bias=np.full((1, H, W), 99.0), dtype=np.float64)                # 1x1 level: the mean texel
+    np.testing.assert_allclose(top, np.broadcast_to(tex.mean(axis=(1, 2)), top.shape), atol=1e-13)
+    const = np.full((1, Ht, Wt, 2), 0.37)
+    da = rng.normal(size=(1, H, W, 4)) * 0.2
+    np.testing.assert_allclose(M.texture_mip(const, uv, uv_da=da, dtype=np.float64), 0.37, atol=1e-14)
+
+
+@pytest.mark.parametrize("boundary", ["wrap", "clamp"])
+@pytest.mark.parametrize("filter_mode", ["linear-mipmap-linear", "linear-mipmap-nearest"])
+def test_mip_gradients_by_finite_differences(boundary, filter_mode):
+    rng = np.random.default_rng(5)
+    Ht, Wt, H, W = 8, 16, 6, 9
+    tex = rng.normal(size=(1, Ht, Wt, 3)); uv = rng.uniform(-0.4, 1.4, size=(1, H, W, 2))
+    da = rng.normal(size=(1, H, W, 4)) * 0.08                  # levels 0 .. 2 and fractions in between
+    bias = rng.uniform(-0.5, 0.5, size=(1, H, W))
+    kw = dict(uv_da=da, mip_level_bias=bias, filter_mode=filter_mode, boundary_mode=boundary, dtype=np.float64)
+    out = M.texture_mip(tex, uv, **kw); g = rng.normal(size=out.shape)
+    dtex, dstack, duv = M.texture_mip_bwd(tex, uv, g, **kw)
+    assert np.abs(dstack).sum() > 0 and np.abs(dtex).sum() > 0
+    total = dtex + M.mip_build_bwd(dstack, tex.shape, dtype=np.float64)
+    num = _fd(lambda t: M.texture_mip(t, uv, **kw), tex.copy(), g, 1e-6, range(0, tex.size, 7))
+    for i, v_ in num.items():
+        assert abs(v_ - total.reshape(-1)[i]) < 1e-8, (i, v_, total.reshape(-1)[i])
+    num = _fd(lambda u_: M.texture_mip(tex, u_, **kw), uv.copy(), g, 1e-7, range(0, uv.size, 5))
+    for i, v_ in num.items():
+        assert abs(v_ - duv.reshape(-1)[i]) < 1e-5 * max(1.0, abs(v_)), (i, v_, duv.reshape(-1)[i])
+    # a caller-supplied stack is an independent input with its own gradient
+    stack = rng.normal(size=M.mip_build(tex, dtype=np.float64).shape)
+    _, dstack2, _ = M.texture_mip_bwd(tex, uv, g, stack=stack, **kw)
+    num = _fd(lambda s_: M.texture_mip(tex, uv, stack=s_, **kw), stack.copy(), g, 1e-6, range(0, stack.size, 5))
+    for i, v_ in num.items():
+        assert abs(v_ - dstack2.reshape(-1)[i]) < 1e-8
+
+
+# ------------------------------------------------------------------------------------------------ depth peeling
+def test_depth_peeling_known_answers():
+    near, tri = _quad(z=-0.5)
+    far, _ = _quad(z=0.3)
+    small = np.array([[[-0.5, -0.5, 0.8, 1], [0.5, -0.5, 0.8, 1], [0.5, 0.5, 0.8, 1], [-0.5, 0.5, 0.8, 1]]], np.float64)
+    pos = np.concatenate([far, small, near], axis=1)                 # submission order is not depth order
+    tris = np.concatenate([tri, tri + 4, tri + 8]).astype(np.int32)
+    H = W = 16
+    l0, _ = M.rasterize_next_layer(pos, tris, (H, W), None, dtype=np.float64)
+    assert np.array_equal(l0, M.rasterize(pos, tris, (H, W), dtype=np.float64)[0])        # layer 0 is rasterize()
+    assert set(np.unique(l0[..., 3])) == {5.0, 6.0} and np.allclose(l0[..., 2], -0.5)
+    l1, _ = M.rasterize_next_layer(pos, tris, (H, W), l0, dtype=np.float64)
+    assert set(np.unique(l1[..., 3])) == {1.0, 2.0} and np.allclose(l1[..., 2], 0.3)
+    l2, _ = M.rasterize_next_layer(pos, tris, (H, W), l1, dtype=np.float64)
+    inner = np.zeros((H, W), bool); inner[4:12, 4:12] = True
+    assert (l2[0, ..., 3][inner] >= 3).all() and (l2[0, ..., 3][~inner] == 0).all() and np.allclose(l2[0, ..., 2][inner], 0.8)
+    l3, _ = M.rasterize_next_layer(pos, tris, (H, W), l2, dtype=np.float64)
+    assert (l3 == 0).all()
+    l4, _ = M.rasterize_next_layer(pos, tris, (H, W), l3, dtype=np.float64)               # an empty layer stays empty
+    assert (l4 == 0).all()
+    # a coincident duplicate of the near quad is never shown: equal depth is not "behind"
+    pos2 = np.concatenate([near, near], axis=1); tris2 = np.concatenate([tri, tri + 4]).astype(np.int32)
+    a, _ = M.rasterize_next_layer(pos2, tris2, (H, W), None, dtype=np.float64)
+    b, _ = M.rasterize_next_layer(pos2, tris2, (H, W), a, dtype=np.float64)
+    assert set(np.unique(a[..., 3])) == {1.0, 2.0} and (b == 0).all()
+
+
+def test_depth_peeling_enumerates_every_fragment_in_depth_order():
+    rng = np.random.default_rng(8)
+    Tn, H, W = 25, 32, 32
+    xy = rng.uniform(-0.8, 0.8, (Tn, 1, 2)) + rng.normal(0, 0.35, (Tn, 3, 2))
+    z = rng.uniform(-0.7, 0.7, (Tn, 1, 1)) + rng.normal(0, 0.05, (Tn, 3, 1))
+    w = rng.uniform(0.7, 2.0, (Tn, 3, 1))
+    pos = np.concatenate([np.concatenate([xy, z], -1) * w, w], -1).reshape(1, Tn * 3, 4)
+    tris = np.arange(Tn * 3, dtype=np.int32).reshape(Tn, 3)
+    frags = [[[] for _ in range(W)] for _ in range(H)]
+    for t in range(Tn):                                               # every triangle alone -> all fragments of every pixel
+        r, _ = M.rasterize(pos, tris[t:t + 1], (H, W), dtype=np.float64)
+        for y, x in np.argwhere(r[0, ..., 3] > 0):
+            frags[y][x].append((r[0, y, x, 2], t + 1))
+    depth = max(len(frags[y][x]) for y in range(H) for x in range(W))
+    assert depth >= 4
+    prev = None
+    for k in range(depth + 1):
+        prev, _ = M.rasterize_next_layer(pos, tris, (H, W), prev, dtype=np.float64)
+        for y in range(H):
+            for x in range(W):
+                fr = sorted(frags[y][x])
+                want = fr[k] if k < len(fr) else (0.0, 0)
+                assert prev[0, y, x, 3] == want[1] and prev[0, y, x, 2] == want[0], (k, y, x)
+    assert (prev == 0).all()

@@ -1,0 +1,210 @@
+"""The wider `nvdiffrast.torch` surface other consumers in the reference use: mip-mapped texture modes
+('linear-mipmap-linear', 'linear-mipmap-nearest', texture_construct_mip) and DepthPeeler -- HIP through the C-ABI against
+oracle/mesh_oracle.c (-m gpu), plus the host-side checks that run without a device.
+Reference call sites that reach these modes via filter_mode='auto' + uv_da: Gen_3D_Modules/LGM/nerf_marching_cubes_converter.py:232,
+Gen_3D_Modules/TRELLIS/trellis/utils/postprocessing_utils.py:384, Gen_3D_Modules/Stable3DGen/trellis/utils/_rasterization.py:88."""
+import numpy as np
+import pytest
+import torch
+
+from c3d_hip import synthetic as S
+from oracle import mesh_oracle as M
+from helpers import rel_err
+
+IMG_L1 = 1e-4
+GRAD_REL = 1e-3
+
+
+def T(a, dtype=torch.float32, grad=False):
+    return torch.tensor(np.asarray(a), dtype=dtype, device="cuda", requires_grad=grad)
+
+
+def test_level_table_matches_the_oracle_and_cpu_tensors_are_refused():
+    import nvdiffrast.torch as dr
+    M.build()
+    for (h, w, ml) in [(8, 4, None), (64, 64, None), (64, 64, 3), (6, 6, 1), (1, 1, None), (2, 32, None), (1024, 2048, None)]:
+        assert dr._mip_levels(h, w, ml) == M.mip_info(h, w, ml)
+    with pytest.raises(ValueError):
+        dr._mip_levels(6, 6, None)
+    with pytest.raises(ValueError):
+        dr.texture(torch.zeros(1, 4, 4, 3), torch.zeros(1, 2, 2, 2), filter_mode="linear-mipmap-linear")     # no uv_da / bias
+    with pytest.raises(RuntimeError, match="HIP device"):
+        dr.texture(torch.zeros(1, 4, 4, 3), torch.zeros(1, 2, 2, 2), uv_da=torch.zeros(1, 2, 2, 4))          # 'auto' -> mip mode; no CPU path
+    with pytest.raises(RuntimeError, match="HIP device"):
+        dr.texture_construct_mip(torch.zeros(1, 4, 4, 3))
+
+
+@pytest.fixture()
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a HIP device (no CPU fallback exists)")
+    M.build()
+
+
+def _inputs(rng, Bt, B, Ht, Wt, C, H, W, spread=0.08):
+    tex = rng.normal(size=(Bt, Ht, Wt, C)).astype(np.float32)
+    uv = rng.uniform(-0.6, 1.6, size=(B, H, W, 2)).astype(np.float32)
+    da = (rng.normal(size=(B, H, W, 4)) * spread).astype(np.float32)
+    bias = rng.uniform(-0.5, 0.5, size=(B, H, W)).astype(np.float32)
+    return tex, uv, da, bias
+
+
+@pytest.mark.gpu
+def test_pyramid_matches_oracle_and_its_backward_is_the_transpose(gpu):
+    import nvdiffrast.torch as dr
+    rng = np.random.default_rng(0)
+    for shape, ml in [((2, 64, 32, 3), None), ((1, 16, 16, 4), 2), ((1, 2, 64, 1), None), ((1, 1, 1, 3), None), ((1, 12, 20, 2), 2)]:
+        tex = rng.normal(size=shape).astype(np.float32)
+        tt = T(tex, grad=True)
+        mip = dr.texture_construct_mip(tt, max_mip_level=ml)
+        ref = M.mip_build(tex, ml)
+        assert tuple(mip.stack.shape) == ref.shape
+        if ref.size == 0:
+            continue
+        assert np.abs(mip.stack.detach().cpu().numpy() - ref).max() <= 1e-6
+        g = rng.normal(size=ref.shape).astype(np.float32)
+        (mip.stack * T(g)).sum().backward()
+        assert rel_err(tt.grad.cpu().numpy(), M.mip_build_bwd(g, shape, ml, dtype=np.float64)) <= 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,Bt", [(3, 1), (4, 2), (2, 2), (1, 1)])
+@pytest.mark.parametrize("boundary", ["wrap", "clamp"])
+def test_trilinear_forward_and_gradients(gpu, C, Bt, boundary):
+    """C = 1, 3, 4 take the LDS-combined backward, C = 2 the direct-atomics one."""
+    import nvdiffrast.torch as dr
+    rng = np.random.default_rng(10 + C)
+    tex, uv, da, bias = _inputs(rng, Bt, 2, 32, 64, C, 37, 45)
+    tt, tu = T(tex, grad=True), T(uv, grad=True)
+    out = dr.texture(tt, tu, uv_da=T(da), mip_level_bias=T(bias), boundary_mode=boundary)           # 'auto' -> linear-mipmap-linear
+    ref = M.texture_mip(tex, uv, da, bias, boundary_mode=boundary)
+    assert np.abs(out.detach().cpu().numpy() - ref).mean() <= 1e-6
+    assert np.abs(out.detach().cpu().numpy() - ref).max() <= 1e-4
+    g = rng.normal(size=ref.shape).astype(np.float32)
+    (out * T(g)).sum().backward()
+    dtex, dstack, duv = M.texture_mip_bwd(tex, uv, g, da, bias, boundary_mode=boundary, dtype=np.float64)
+    total = dtex + M.mip_build_bwd(dstack, tex.shape, dtype=np.float64)
+    assert rel_err(tt.grad.cpu().numpy(), total) <= GRAD_REL
+    assert rel_err(tu.grad.cpu().numpy(), duv) <= GRAD_REL
+    # uv_da alone, bias alone
+    o2 = dr.texture(T(tex), T(uv), uv_da=T(da), boundary_mode=boundary)
+    assert np.abs(o2.cpu().numpy() - M.texture_mip(tex, uv, da, None, boundary_mode=boundary)).max() <= 1e-4
+    o3 = dr.texture(T(tex), T(uv), mip_level_bias=T(bias + 1.5), boundary_mode=boundary)
+    assert np.abs(o3.cpu().numpy() - M.texture_mip(tex, uv, None, bias + 1.5, boundary_mode=boundary)).max() <= 1e-4
+
+
+@pytest.mark.gpu
+def test_nearest_level_mode_prebuilt_and_custom_stacks(gpu):
+    import nvdiffrast.torch as dr
+    rng = np.random.default_rng(20)
+    tex, uv, da, _ = _inputs(rng, 1, 1, 16, 16, 3, 33, 31)
+    lv = rng.integers(0, 5, size=(1, 33, 31)).astype(np.float32) + rng.uniform(-0.3, 0.3, size=(1, 33, 31)).astype(np.float32)   # never near x.5
+    out = dr.texture(T(tex), T(uv), mip_level_bias=T(lv), filter_mode="linear-mipmap-nearest")
+    assert np.abs(out.cpu().numpy() - M.texture_mip(tex, uv, None, lv, filter_mode="linear-mipmap-nearest")).max() <= 2e-5
+    # max_mip_level limits the pyramid; a pre-built stack gives the same result as the internal one and carries the gradient to tex
+    tt = T(tex, grad=True)
+    mip = dr.texture_construct_mip(tt, max_mip_level=2)
+    a = dr.texture(tt, T(uv), uv_da=T(da * 4), mip=mip, max_mip_level=2)
+    b = dr.texture(T(tex), T(uv), uv_da=T(da * 4), max_mip_level=2)
+    assert torch.equal(a.detach(), b)
+    assert np.abs(b.cpu().numpy() - M.texture_mip(tex, uv, da * 4, None, max_mip_level=2)).max() <= 1e-4
+    g = rng.normal(size=(1, 33, 31, 3)).astype(np.float32)
+    (a * T(g)).sum().backward()
+    dtex, dstack, _ = M.texture_mip_bwd(tex, uv, g, da * 4, None, max_mip_level=2, dtype=np.float64)
+    assert rel_err(tt.grad.cpu().numpy(), dtex + M.mip_build_bwd(dstack, tex.shape, 2, dtype=np.float64)) <= GRAD_REL
+    with pytest.raises(ValueError):
+        dr.texture(T(np.zeros((1, 8, 8, 3))), T(uv), uv_da=T(da), mip=mip)                            # stack of another texture
+    # custom stack: a list of level tensors that receive their own gradients; tex only gets its level-0 taps
+    levels, _ = M.mip_info(16, 16, 2)
+    custom = [rng.normal(size=(1, h, w, 3)).astype(np.float32) for (h, w) in levels[1:]]
+    tc = [T(c, grad=True) for c in custom]
+    tt2 = T(tex, grad=True)
+    o = dr.texture(tt2, T(uv), uv_da=T(da * 4), mip=tc)
+    stack = np.concatenate([c.reshape(1, -1, 3) for c in custom], axis=1)
+    assert np.abs(o.detach().cpu().numpy() - M.texture_mip(tex, uv, da * 4, None, stack=stack, max_mip_level=2)).max() <= 1e-4
+    (o * T(g)).sum().backward()
+    dtex, dstack, _ = M.texture_mip_bwd(tex, uv, g, da * 4, None, stack=stack, max_mip_level=2, dtype=np.float64)
+    assert rel_err(tt2.grad.cpu().numpy(), dtex) <= GRAD_REL
+    assert rel_err(tc[0].grad.cpu().numpy().reshape(-1), dstack[:, :64].reshape(-1)) <= GRAD_REL
+    assert rel_err(tc[1].grad.cpu().numpy().reshape(-1), dstack[:, 64:].reshape(-1)) <= GRAD_REL
+    with pytest.raises(ValueError):
+        dr.texture(T(np.zeros((1, 6, 6, 3))), T(uv), uv_da=T(da))                                     # 3x3 cannot be halved
+    assert dr.texture(T(np.ones((1, 6, 6, 3))), T(uv), uv_da=T(da), max_mip_level=1).shape == (1, 33, 31, 3)
+
+
+@pytest.mark.gpu
+def test_textured_mesh_with_auto_mipmapping(gpu):
+    """rasterize -> interpolate(uv, diff 'all') -> texture(tex, uv, uv_da): the sequence of LGM's mesh refiner
+    (nerf_marching_cubes_converter.py:215-232) and TRELLIS's texture baker (postprocessing_utils.py:376-384)."""
+    import nvdiffrast.torch as dr
+    H, W = 96, 128
+    v, f, vt, vn = S.make_uv_sphere(24, 40, radius=0.7, displacement=0.15)
+    pos, _, _ = S.mesh_clip_positions(v, -20.0, 35.0, 2.0, W, H)
+    rng = np.random.default_rng(2)
+    tex = rng.normal(size=(1, 256, 256, 3)).astype(np.float32)                                          # minified: several texels per pixel
+    ctx = dr.RasterizeCudaContext()
+    ttex, tvt, ttri = T(tex, grad=True), T(vt[None], grad=True), T(f, torch.int32)
+    rast, db = dr.rasterize(ctx, T(pos), ttri, (H, W))
+    texc, texd = dr.interpolate(tvt, rast, ttri, rast_db=db, diff_attrs='all')
+    col = dr.texture(ttex, texc, texd)                                                                   # uv_da positional, filter 'auto'
+    orast, odb = M.rasterize(pos, f, (H, W))
+    otexc, otexd = M.interpolate(vt[None], orast, f, odb, "all")
+    ocol = M.texture_mip(tex, otexc, otexd)
+    assert (rast.cpu().numpy()[..., 3] != orast[..., 3]).sum() <= 2
+    assert np.abs(col.detach().cpu().numpy() - ocol).mean() <= IMG_L1
+    lin = M.texture(tex, otexc)
+    assert np.abs(ocol - lin).mean() > 0.05                                                              # the pyramid is really in play
+    g = rng.normal(size=ocol.shape).astype(np.float32)
+    (col * T(g)).sum().backward()
+    d = np.float64
+    r64, db64 = M.rasterize(pos, f, (H, W), dtype=d)
+    texc64, texd64 = M.interpolate(vt[None], r64, f, db64, "all", dtype=d)
+    dtex, dstack, duv = M.texture_mip_bwd(tex, texc64, g, texd64, None, dtype=d)
+    dvt, _ = M.interpolate_bwd(vt[None], r64, f, duv, dtype=d)
+    assert rel_err(ttex.grad.cpu().numpy(), dtex + M.mip_build_bwd(dstack, tex.shape, dtype=d)) <= GRAD_REL
+    assert rel_err(tvt.grad.cpu().numpy(), dvt) <= GRAD_REL
+
+
+@pytest.mark.gpu
+def test_depth_peeler_layers_match_oracle_and_are_differentiable(gpu):
+    """InstantMesh's use (models/geometry/render/neural_render.py:103-106) plus what it does not exercise: layers > 0."""
+    import nvdiffrast.torch as dr
+    H, W = 96, 80
+    v, f, vt, vn = S.make_uv_sphere(16, 24, radius=0.7, displacement=0.25)
+    pos, _, _ = S.mesh_clip_positions(v, -20.0, 35.0, 2.0, W, H)
+    ctx = dr.RasterizeCudaContext()
+    tpos, ttri = T(pos, grad=True), T(f, torch.int32)
+    plain, plain_db = dr.rasterize(ctx, tpos, ttri, (H, W))
+    layers, oprev = [], None
+    with dr.DepthPeeler(ctx, tpos, ttri, (H, W)) as peeler:
+        with pytest.raises(RuntimeError):
+            dr.rasterize(ctx, tpos, ttri, (H, W))                    # the context is busy peeling
+        for k in range(4):
+            rast, db = peeler.rasterize_next_layer()
+            orast, odb = M.rasterize_next_layer(pos, f, (H, W), oprev)
+            r = rast.detach().cpu().numpy()
+            same = r[..., 3] == orast[..., 3]
+            assert (~same).sum() <= 4, (k, (~same).sum())            # depth near-ties between float32 pipelines
+            assert np.abs(r[same][:, :3] - orast[same][:, :3]).max() <= 1e-3
+            assert np.abs(db.cpu().numpy()[same] - odb[same]).max() <= 1e-3 * max(1.0, np.abs(odb).max())
+            layers.append(rast)
+            oprev = orast                                            # each pipeline peels against its own previous layer
+    assert torch.equal(layers[0], plain)                             # layer 0 is rasterize()
+    dr.rasterize(ctx, tpos, ttri, (H, W))                            # and the context is free again
+    cov = [(l[..., 3] > 0) for l in layers]
+    assert cov[1].sum() > 0.5 * cov[0].sum()                         # the back of the sphere
+    for k in range(1, 4):
+        assert (cov[k] & ~cov[k - 1]).sum() == 0                     # nothing appears where the previous layer was empty
+        both = cov[k]
+        assert (layers[k][..., 2][both] > layers[k - 1][..., 2][both]).all()     # strictly behind
+    with pytest.raises(RuntimeError):
+        peeler.rasterize_next_layer()                                # outside the with block
+    # gradients flow through a peeled layer exactly as through rasterize(): d(sum g*(u,v)) / dpos against the float64 oracle
+    g = np.random.default_rng(4).normal(size=(1, H, W, 4)).astype(np.float32); g[..., 2:] = 0
+    r64_0, _ = M.rasterize_next_layer(pos, f, (H, W), None, dtype=np.float64)
+    r64_1, _ = M.rasterize_next_layer(pos, f, (H, W), r64_0, dtype=np.float64)
+    ok = r64_1[..., 3] == layers[1].detach().cpu().numpy()[..., 3]
+    g64 = g.astype(np.float64) * ok[..., None]
+    dpos = M.rasterize_bwd(pos, f, r64_1, g64, dtype=np.float64)
+    (layers[1] * T(g64.astype(np.float32))).sum().backward()
+    assert rel_err(tpos.grad.cpu().numpy(), dpos) <= 2 * GRAD_REL
