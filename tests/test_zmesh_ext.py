@@ -186,7 +186,7 @@ def test_depth_peeler_layers_match_oracle_and_are_differentiable(gpu):
             same = r[..., 3] == orast[..., 3]
             assert (~same).sum() <= 4, (k, (~same).sum())            # depth near-ties between float32 pipelines
             assert np.abs(r[same][:, :3] - orast[same][:, :3]).max() <= 1e-3
-            assert np.abs(db.cpu().numpy()[same] - odb[same]).max() <= 1e-3 * max(1.0, np.abs(odb).max())
+            assert np.abs(db.detach().cpu().numpy()[same] - odb[same]).max() <= 1e-3 * max(1.0, np.abs(odb).max())
             layers.append(rast)
             oprev = orast                                            # each pipeline peels against its own previous layer
     assert torch.equal(layers[0], plain)                             # layer 0 is rasterize()
