@@ -470,6 +470,21 @@ __global__ void __launch_bounds__(256) k_tex_bwd(const float* __restrict__ tex, 
 // first sums its taps per texel in an LDS hash table (LDS float atomics), then issues one global atomic per (distinct texel, channel).
 #define TEXT_SLOTS 1024
 #define TEXT_EMPTY 0xFFFFFFFFu
+// Pre-combining pays only where neighbouring pixels hit the same texels (magnification, coarse mip levels).  Under minification every tap
+// is its own texel: the table saturates (256 pixels x 4 taps = its 1024 slots) and the probing costs 3-4x the plain scatter (2048^2 texture
+// at 3 texels / pixel: 0.64 ms hashed).  A wave decides for itself: does a lane share any of its four taps with its right-hand neighbour?
+// Fewer than a quarter do -> scatter directly.  (Heuristic only: both routes add the same values.)
+__device__ __forceinline__ bool tex_taps_shared(const uint32_t tk[4]) {
+    uint32_t nk[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) nk[i] = (uint32_t)__shfl_down((int)tk[i], 1);
+    bool share = false;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) share = share || nk[i] == tk[j];
+    return 4 * __popcll(__ballot(share)) >= __popcll(__ballot(true));
+}
 template <int C>
 __global__ void __launch_bounds__(256) k_tex_bwd_tiled(const float* __restrict__ tex, int Bt, const float2* __restrict__ uv, const float* __restrict__ dy,
                                                         int H, int W, int Ht, int Wt, int boundary, float* __restrict__ dtex, float2* __restrict__ duv) {
@@ -506,12 +521,13 @@ __global__ void __launch_bounds__(256) k_tex_bwd_tiled(const float* __restrict__
             gv += g[c] * ((t01 - t00) * (1.f - fu) + (t11 - t10) * fu);
         }
         duv[gid] = make_float2(gu * Wt, gv * Ht);
+        const bool use_hash = tex_taps_shared(tk);
         if (any) {
 #pragma unroll
             for (int t = 0; t < 4; t++) {
                 uint32_t h = (tk[t] * 2654435761u) >> 22;           // 10 bits
                 int slot = -1;
-                for (int probe = 0; probe < 32; probe++) {           // bounded: a full table falls back to the direct scatter
+                for (int probe = 0; use_hash && probe < 32; probe++) {   // bounded: a full table falls back to the direct scatter
                     const uint32_t old = atomicCAS(&keys[h], TEXT_EMPTY, tk[t]);
                     if (old == TEXT_EMPTY || old == tk[t]) { slot = (int)h; break; }
                     h = (h + 1) & (TEXT_SLOTS - 1);
@@ -703,8 +719,10 @@ __global__ void __launch_bounds__(256) k_tex_mip_bwd(const float* __restrict__ t
         const float* g = dy + gid * C;
         float gu = 0.f, gv = 0.f;
         const int nl = (l1 != l0 && f != 0.f) ? 2 : 1;
+        const MipTaps t0 = mip_taps(q, Ht, Wt, l0, boundary);
+        const bool use_hash = CT > 0 && tex_taps_shared(t0.k);        // decided on the finer level: the coarser one shares at least as much
         for (int lev = 0; lev < nl; lev++) {
-            const MipTaps t = mip_taps(q, Ht, Wt, lev ? l1 : l0, boundary);
+            const MipTaps t = lev ? mip_taps(q, Ht, Wt, l1, boundary) : t0;
             const float wl = nl == 1 ? 1.f : (lev ? f : 1.f - f);
             const float tw[4] = {(1.f - t.fu) * (1.f - t.fv), t.fu * (1.f - t.fv), (1.f - t.fu) * t.fv, t.fu * t.fv};
             const float *p00 = mip_texel(tb, sb, HW, t.k[0], C), *p10 = mip_texel(tb, sb, HW, t.k[1], C);
@@ -722,7 +740,7 @@ __global__ void __launch_bounds__(256) k_tex_mip_bwd(const float* __restrict__ t
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 int slot = -1;
-                if (CT > 0) {
+                if (use_hash) {
                     uint32_t h = (t.k[k] * 2654435761u) >> 21;       // 11 bits
                     for (int probe = 0; probe < 32; probe++) {       // bounded: a full table falls back to the direct scatter
                         const uint32_t old = atomicCAS(&keys[h], TEXT_EMPTY, t.k[k]);
