@@ -9,7 +9,8 @@ Same function names, argument meaning and return shapes as the module the refere
     texture_construct_mip(tex, max_mip_level=None)                    filter modes nearest | linear | linear-mipmap-nearest | linear-mipmap-linear
     DepthPeeler(glctx, pos, tri, resolution).rasterize_next_layer()
 The arithmetic runs in libc3d_hip.so; this file allocates tensors and wires autograd.  There is no CPU path.
-Not built (raise NotImplementedError): range mode (`ranges`), cube maps, boundary modes 'zero' / 'cube'; gradients w.r.t.
+    rasterize(..., ranges=[B,2]) / antialias with pos [V,4]: range (instanced) mode, composed on the host from the B = 1 kernels
+Not built (raise NotImplementedError): cube maps, boundary modes 'zero' / 'cube', DepthPeeler(ranges=...); gradients w.r.t.
 rast_db / out_da / uv_da / mip_level_bias are not propagated (no consumer on the reference's path).
 """
 import torch
@@ -98,7 +99,9 @@ class _Rasterize(torch.autograd.Function):
         dev = pos.device
         with torch.cuda.device(dev):
             dpos = torch.empty((B, V, 4), dtype=torch.float32, device=dev)
-            if ATOMIC_FREE_BACKWARD and T > 0:
+            if T == 0:
+                dpos.zero_()                                          # nothing was drawn (an empty range)
+            elif ATOMIC_FREE_BACKWARD:
                 # gather formulation: per-triangle corner records, then a fixed-order sum per vertex (no atomics, bit-reproducible)
                 topo = ctx.glctx.vertex_topology(tri, V)
                 scratch = torch.empty((lib.c3d_mesh_rasterize_bwd_scratch_bytes(B, T),), dtype=torch.uint8, device=dev)
@@ -112,13 +115,41 @@ class _Rasterize(torch.autograd.Function):
 
 def rasterize(glctx, pos, tri, resolution, ranges=None, grad_db=True):
     """-> (rast [B,H,W,4] = (u, v, z/w, triangle_id+1), rast_db [B,H,W,4] = (du/dX, du/dY, dv/dX, dv/dY))"""
-    if ranges is not None:
-        raise NotImplementedError("rasterize(ranges=...) (instanced range mode) is not built")
     if not isinstance(glctx, RasterizeCudaContext):
         raise TypeError("rasterize: glctx must be a RasterizeCudaContext / RasterizeGLContext")
     if glctx.active_depth_peeler is not None:
         raise RuntimeError("rasterize: cannot be called on a context while a DepthPeeler is active on it")
+    if ranges is not None:
+        return _rasterize_ranges(glctx, pos, tri, resolution, ranges, grad_db)
     return _Rasterize.apply(glctx, pos, tri, resolution, grad_db, None)
+
+
+def _rasterize_ranges(glctx, pos, tri, resolution, ranges, grad_db):
+    """Range ("instanced") mode: one vertex buffer pos [V,4]; minibatch item b draws triangles tri[start_b : start_b + count_b]
+    (ranges [B,2] int32 on the CPU); triangle ids in the output index the full `tri`.  Composed on the host from the B = 1 kernels:
+    the items share nothing but the vertex buffer, whose gradient autograd sums over the items."""
+    if pos.dim() != 2 or pos.shape[-1] != 4:
+        raise ValueError("rasterize: with ranges, pos must be [V,4]")
+    r = torch.as_tensor(ranges)
+    if r.is_cuda or r.dim() != 2 or r.shape[1] != 2 or r.dtype not in (torch.int32, torch.int64):
+        raise ValueError("rasterize: ranges must be an integer CPU tensor of shape [B,2]")
+    tri_c = tri.to(torch.int32).contiguous()
+    T = int(tri_c.shape[0])
+    rasts, dbs = [], []
+    for start, count in r.tolist():
+        if start < 0 or count < 0 or start + count > T:
+            raise ValueError("rasterize: range (%d, %d) does not fit the %d triangles" % (start, count, T))
+        rast, db = _Rasterize.apply(glctx, pos.unsqueeze(0), tri_c[start:start + count], resolution, grad_db, None)
+        if start:
+            shift = torch.zeros_like(rast)
+            shift[..., 3] = (rast[..., 3] > 0).to(rast.dtype) * float(start)
+            rast = rast + shift
+        rasts.append(rast); dbs.append(db)
+    if not rasts:
+        H, W = int(resolution[0]), int(resolution[1])
+        z = pos.new_zeros((0, H, W, 4), dtype=torch.float32)
+        return z, z.clone()
+    return torch.cat(rasts, 0), torch.cat(dbs, 0)
 
 
 class DepthPeeler:
@@ -444,8 +475,10 @@ class _Antialias(torch.autograd.Function):
 def antialias(color, rast, pos, tri, topology_hash=None, pos_gradient_boost=1.0):
     """-> antialiased colour [B,H,W,C].  topology_hash is accepted and ignored (the edge hash is rebuilt per call, as it is
     for the reference, which never passes one)."""
-    if pos.dim() != 3:
-        raise NotImplementedError("antialias: range-mode positions [V,4] are not built")
+    if pos.dim() == 2:      # range mode: one vertex buffer shared by the minibatch (see _rasterize_ranges)
+        p1 = pos.unsqueeze(0)
+        return torch.cat([_Antialias.apply(color[b:b + 1].contiguous(), rast[b:b + 1].contiguous(), p1, tri, pos_gradient_boost)
+                          for b in range(color.shape[0])], 0) if color.shape[0] else color
     return _Antialias.apply(color, rast, pos, tri, pos_gradient_boost)
 
 

@@ -49,6 +49,18 @@ def rasterize(pos, tri, resolution, dtype=np.float32):
     return rast, db
 
 
+def rasterize_ranges(pos, tri, resolution, ranges, dtype=np.float32):
+    """range ("instanced") mode as the dependency documents it: pos [V,4] shared; item b draws tri[start_b : start_b + count_b];
+    ids index the full `tri`"""
+    pos, tri = _a(pos, dtype), _a(tri, np.int32)
+    rasts, dbs = [], []
+    for start, count in np.asarray(ranges).tolist():
+        r, d = rasterize(pos[None], tri[start:start + count], resolution, dtype=dtype)
+        r[..., 3] += (r[..., 3] > 0) * start
+        rasts.append(r); dbs.append(d)
+    return np.concatenate(rasts, 0), np.concatenate(dbs, 0)
+
+
 def rasterize_next_layer(pos, tri, resolution, prev_rast, dtype=np.float32):
     """one depth-peeling step: prev_rast = the previous layer's rast (None: first layer = rasterize)"""
     lib = _lib(dtype)

@@ -172,7 +172,7 @@ def test_edge_cases_and_errors():
     pos = torch.zeros((1, 3, 4))
     with pytest.raises(RuntimeError, match="HIP device"):
         dr.rasterize(ctx, pos, torch.zeros((1, 3), dtype=torch.int32), (8, 8))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):      # range mode takes one shared vertex buffer [V,4]
         dr.rasterize(ctx, pos.cuda(), torch.zeros((1, 3), dtype=torch.int32).cuda(), (8, 8), ranges=torch.zeros((1, 2), dtype=torch.int32))
     assert isinstance(dr.RasterizeGLContext(), dr.RasterizeCudaContext)
     # antialias is the identity when there is no triangle-id discontinuity (full-screen single triangle)

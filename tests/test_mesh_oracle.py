@@ -329,3 +329,16 @@ def test_depth_peeling_enumerates_every_fragment_in_depth_order():
                 want = fr[k] if k < len(fr) else (0.0, 0)
                 assert prev[0, y, x, 3] == want[1] and prev[0, y, x, 2] == want[0], (k, y, x)
     assert (prev == 0).all()
+
+
+def test_range_mode_known_answers():
+    pos, tri = _quad()
+    r, d = M.rasterize_ranges(pos[0], tri, (6, 6), [[0, 1], [1, 1], [0, 2], [1, 0]], dtype=np.float64)
+    full, dfull = M.rasterize(pos, tri, (6, 6), dtype=np.float64)
+    assert r.shape == (4, 6, 6, 4)
+    assert set(np.unique(r[0, ..., 3])) == {0.0, 1.0} and set(np.unique(r[1, ..., 3])) == {0.0, 2.0}     # ids index the full index buffer
+    assert ((r[0, ..., 3] > 0) ^ (r[1, ..., 3] > 0)).all()                                              # the two halves of the quad
+    assert np.array_equal(r[2], full[0]) and np.array_equal(d[2], dfull[0]) and (r[3] == 0).all()
+    for b, t in ((0, 1), (1, 2)):
+        m = r[b, ..., 3] == t
+        assert np.array_equal(r[b][m], full[0][m])

@@ -1,5 +1,5 @@
 """The wider `nvdiffrast.torch` surface other consumers in the reference use: mip-mapped texture modes
-('linear-mipmap-linear', 'linear-mipmap-nearest', texture_construct_mip) and DepthPeeler -- HIP through the C-ABI against
+('linear-mipmap-linear', 'linear-mipmap-nearest', texture_construct_mip), DepthPeeler and range mode -- HIP through the C-ABI against
 oracle/mesh_oracle.c (-m gpu), plus the host-side checks that run without a device.
 Reference call sites that reach these modes via filter_mode='auto' + uv_da: Gen_3D_Modules/LGM/nerf_marching_cubes_converter.py:232,
 Gen_3D_Modules/TRELLIS/trellis/utils/postprocessing_utils.py:384, Gen_3D_Modules/Stable3DGen/trellis/utils/_rasterization.py:88."""
@@ -32,6 +32,16 @@ def test_level_table_matches_the_oracle_and_cpu_tensors_are_refused():
         dr.texture(torch.zeros(1, 4, 4, 3), torch.zeros(1, 2, 2, 2), uv_da=torch.zeros(1, 2, 2, 4))          # 'auto' -> mip mode; no CPU path
     with pytest.raises(RuntimeError, match="HIP device"):
         dr.texture_construct_mip(torch.zeros(1, 4, 4, 3))
+    ctx = dr.RasterizeCudaContext(device="cuda:0")
+    tri = torch.zeros((2, 3), dtype=torch.int32)
+    with pytest.raises(ValueError):
+        dr.rasterize(ctx, torch.zeros(1, 4, 4), tri, (8, 8), ranges=torch.tensor([[0, 1]], dtype=torch.int32))     # range mode: pos is [V,4]
+    with pytest.raises(ValueError):
+        dr.rasterize(ctx, torch.zeros(4, 4), tri, (8, 8), ranges=torch.tensor([[1, 2]], dtype=torch.int32))        # range past the end
+    with pytest.raises(ValueError):
+        dr.rasterize(ctx, torch.zeros(4, 4), tri, (8, 8), ranges=torch.tensor([0, 1], dtype=torch.int32))          # not [B,2]
+    with pytest.raises(RuntimeError, match="HIP device"):
+        dr.rasterize(ctx, torch.zeros(4, 4), tri, (8, 8), ranges=torch.tensor([[0, 2]], dtype=torch.int32))
 
 
 @pytest.fixture()
@@ -208,3 +218,48 @@ def test_depth_peeler_layers_match_oracle_and_are_differentiable(gpu):
     dpos = M.rasterize_bwd(pos, f, r64_1, g64, dtype=np.float64)
     (layers[1] * T(g64.astype(np.float32))).sum().backward()
     assert rel_err(tpos.grad.cpu().numpy(), dpos) <= 2 * GRAD_REL
+
+
+@pytest.mark.gpu
+def test_range_mode_rasterize_interpolate_antialias(gpu):
+    """rasterize(pos [V,4], tri, res, ranges) -> interpolate(attr [V,A]) -> antialias(pos [V,4]): forward against the oracle's range
+    mode, gradients (summed over the minibatch by autograd) against the float64 oracle chain."""
+    import nvdiffrast.torch as dr
+    H, W = 64, 72
+    v, f, vt, vn = S.make_uv_sphere(12, 20, radius=0.7, displacement=0.2)
+    pos3, _, _ = S.mesh_clip_positions(v, -20.0, 35.0, 2.0, W, H)
+    pos = pos3[0]
+    Tn = f.shape[0]
+    ranges = np.array([[0, Tn // 3], [Tn // 3, Tn - Tn // 3], [0, Tn], [5, 0], [Tn // 4, Tn // 2]], np.int32)
+    rng = np.random.default_rng(6)
+    attr = rng.normal(size=(pos.shape[0], 3)).astype(np.float32)
+    ctx = dr.RasterizeCudaContext()
+    tpos, tattr, ttri = T(pos, grad=True), T(attr, grad=True), T(f, torch.int32)
+    rast, db = dr.rasterize(ctx, tpos, ttri, (H, W), ranges=torch.tensor(ranges))
+    col, _ = dr.interpolate(tattr, rast, ttri)
+    aa = dr.antialias(col, rast, tpos, ttri)
+    orast, odb = M.rasterize_ranges(pos, f, (H, W), ranges)
+    r = rast.detach().cpu().numpy()
+    assert r.shape == orast.shape == (5, H, W, 4)
+    same = r[..., 3] == orast[..., 3]
+    assert (~same).sum() <= 6 and (r[3] == 0).all()
+    assert np.abs(r[same][:, :3] - orast[same][:, :3]).max() <= 1e-3
+    full, _ = dr.rasterize(ctx, tpos.detach()[None], ttri, (H, W))
+    assert torch.equal(rast[2].detach(), full[0])                      # the range covering everything is the plain call
+    ocol, _ = M.interpolate(attr, orast, f)
+    oaa = np.concatenate([M.antialias(ocol[b:b + 1], orast[b:b + 1], pos[None], f) for b in range(5)], 0)
+    assert np.abs(col.detach().cpu().numpy() - ocol).mean() <= IMG_L1 and np.abs(aa.detach().cpu().numpy() - oaa).mean() <= IMG_L1
+    g = rng.normal(size=oaa.shape).astype(np.float32)
+    d = np.float64
+    r64, _ = M.rasterize_ranges(pos, f, (H, W), ranges, dtype=d)
+    g64 = g.astype(d) * (r64[..., 3:] == r[..., 3:])                   # compare where both pipelines drew the same triangle
+    (aa * T(g64.astype(np.float32))).sum().backward()
+    col64, _ = M.interpolate(attr, r64, f, dtype=d)
+    dpos = np.zeros((1,) + pos.shape, d); dattr = np.zeros(attr.shape, d)
+    for b in range(5):
+        dcol, dp = M.antialias_bwd(col64[b:b + 1], r64[b:b + 1], pos[None], f, g64[b:b + 1], dtype=d)
+        da, drast = M.interpolate_bwd(attr, r64[b:b + 1], f, dcol, dtype=d)
+        dpos += dp + M.rasterize_bwd(pos[None], f, r64[b:b + 1], drast, dtype=d)
+        dattr += da
+    assert rel_err(tattr.grad.cpu().numpy(), dattr) <= GRAD_REL
+    assert rel_err(tpos.grad.cpu().numpy(), dpos[0]) <= 2 * GRAD_REL
