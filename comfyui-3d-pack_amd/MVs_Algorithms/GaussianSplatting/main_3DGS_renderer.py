@@ -63,6 +63,7 @@ class GaussianModel:
         self.scaling_activation, self.scaling_inverse_activation = torch.exp, torch.log
         self.opacity_activation, self.inverse_opacity_activation = torch.sigmoid, inverse_sigmoid
         self.rotation_activation = torch.nn.functional.normalize
+        self.covariance_activation = lambda scaling, modifier, rotation: build_covariance_from_scaling_rotation(scaling, modifier, rotation)
 
     # ---- accessors (reference :294-321) ----
     @property
@@ -88,6 +89,12 @@ class GaussianModel:
     @property
     def get_opacity(self):
         return self.opacity_activation(self._opacity)
+
+    def get_covariance(self, scaling_modifier=1, gaussain_idx=None):
+        """[N,6] world covariances (reference :397-401; the keyword keeps the reference's spelling)"""
+        if gaussain_idx is None:
+            return build_covariance_from_scaling_rotation(self.get_scaling, scaling_modifier, self._rotation)
+        return build_covariance_from_scaling_rotation(self.get_scaling[gaussain_idx], scaling_modifier, self._rotation[gaussain_idx])
 
     def oneupSHdegree(self):
         if self.active_sh_degree < self.max_sh_degree:
@@ -334,6 +341,25 @@ def build_rotation(r):
                      2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
                      2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)), dim=1)
     return R.view(-1, 3, 3)
+
+
+def build_scaling_rotation(s, r):
+    """L = R(q) diag(s) [M,3,3] (reference :104-113)"""
+    return build_rotation(r) * s[:, None, :]
+
+
+def strip_symmetric(sym):
+    """upper triangle of symmetric [M,3,3] as [M,6] = (xx, xy, xz, yy, yz, zz): the cov3D_precomp layout of the rasterizer (reference :46-58)"""
+    return torch.stack((sym[:, 0, 0], sym[:, 0, 1], sym[:, 0, 2], sym[:, 1, 1], sym[:, 1, 2], sym[:, 2, 2]), dim=1)
+
+
+strip_lowerdiag = strip_symmetric
+
+
+def build_covariance_from_scaling_rotation(scaling, scaling_modifier, rotation):
+    """the reference's covariance_activation (:219-224): Sigma = L L^T with L = R(q) diag(modifier * s), as a 6-vector"""
+    L = build_scaling_rotation(scaling_modifier * scaling, rotation)
+    return strip_symmetric(L @ L.transpose(1, 2))
 
 
 class GaussianSplattingRenderer:

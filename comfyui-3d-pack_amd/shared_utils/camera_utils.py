@@ -65,18 +65,63 @@ def calculate_fovX(H, W, fovy):
     return 2 * np.arctan(np.tan(fovy / 2) * W / H)
 
 
+def _axis_angle(rotvec):
+    """rotation matrix of a rotation vector (Rodrigues), float64"""
+    rotvec = np.asarray(rotvec, dtype=np.float64)
+    a = float(np.linalg.norm(rotvec))
+    if a < 1e-300:
+        return np.eye(3)
+    k = rotvec / a
+    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.eye(3) + np.sin(a) * K + (1 - np.cos(a)) * (K @ K)
+
+
 class OrbitCamera:
-    """Only the parts the renderers read: size, fovy/fovx (radians), near/far, perspective."""
+    """Size, fovy/fovx (radians), near/far and perspective are what the renderers read; pose / view / mvp and the orbit / scale / pan
+    controls follow the reference's interactive camera (camera_utils.py:105-169), with the orientation kept as a plain 3x3 matrix."""
 
     def __init__(self, W, H, r=2, fovy=60, near=0.01, far=100):
         self.W, self.H, self.radius = W, H, r
         self.fovy = np.deg2rad(fovy)
         self.near, self.far = near, far
         self.center = np.zeros(3, dtype=np.float32)
+        self.rot_matrix = np.eye(3)
+        self.up = np.array([0, 1, 0], dtype=np.float32)
 
     @property
     def fovx(self):
         return calculate_fovX(self.H, self.W, self.fovy)
+
+    @property
+    def pose(self):
+        """camera-to-world: back off by the radius along the camera's z, rotate, then shift by -center (as the reference does)"""
+        c2w = np.eye(4, dtype=np.float32)
+        c2w[:3, :3] = self.rot_matrix
+        c2w[:3, 3] = self.rot_matrix[:, 2] * self.radius - self.center
+        return c2w
+
+    @property
+    def campos(self):
+        return self.pose[:3, 3]
+
+    @property
+    def view(self):
+        return np.linalg.inv(self.pose)
+
+    @property
+    def mvp(self):
+        return self.perspective @ np.linalg.inv(self.pose)
+
+    def orbit(self, dx, dy):
+        """mouse drag: 0.05 degrees per unit about the world up axis (dx) and the camera's side axis (dy)"""
+        side = self.rot_matrix[:, 0]
+        self.rot_matrix = _axis_angle(self.up * np.radians(-0.05 * dx)) @ _axis_angle(side * np.radians(-0.05 * dy)) @ self.rot_matrix
+
+    def scale(self, delta):
+        self.radius *= 1.1 ** (-delta)
+
+    def pan(self, dx, dy, dz=0):
+        self.center += (0.0005 * self.rot_matrix @ np.array([-dx, -dy, dz])).astype(np.float32)
 
     @property
     def perspective(self):

@@ -21,9 +21,16 @@
  *   - SH basis and sign pattern: shared_utils/sh_utils.py:26-43,57-100
  *   - quaternion (w,x,y,z) -> rotation: main_3DGS_renderer.py:84-102
  *   - covariance = L L^T, L = R*S: main_3DGS_renderer.py:104-113,220-224
- * It is pinned instead by analytic known-answer cases, by an independent
- * float64 torch-autograd restatement (oracle/gs_torch_ref.py) and by
- * finite differences (tests/test_gs_oracle.py).
+ * Those four conventions ARE pinned against the reference's own Python, run in
+ * the build container (tests/golden/make_golden_ref_py.py ->
+ * tests/golden/ref_py_conventions.npz -> tests/test_ref_conventions.py): the
+ * per-Gaussian colour, view depth, pixel position and conic this file computes
+ * agree with eval_sh / MiniCam / covariance_activation of the reference.
+ * Everything the CUDA kernel adds on top (culling constants, EWA projection,
+ * tile binning, the blending loop, every gradient) stays unpinned and is held
+ * instead by analytic known-answer cases, by an independent float64
+ * torch-autograd restatement (oracle/gs_torch_ref.py) and by finite
+ * differences (tests/test_gs_oracle.py).
  *
  * Build twice: -DREAL=float (arithmetic class of the product) and
  * -DREAL=double (tight truth for gradient checks).

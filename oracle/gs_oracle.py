@@ -1,7 +1,8 @@
 """ctypes front-end of oracle/gs_oracle.c  (TEST INFRASTRUCTURE -- see that file's header).
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
-PARITY UNPINNED: the reference ships no golden vectors for this path.
+PARITY UNPINNED (the reference ships no golden vectors for this path) except the input conventions, which
+tests/test_ref_conventions.py holds to the reference's own Python (see gs_oracle.c).
 
 The call signature mirrors the boundary the reference uses
 (MVs_Algorithms/GaussianSplatting/main_3DGS_renderer.py:849-862, 927-936):
