@@ -178,7 +178,70 @@ def generate():
     out["lr_default"] = np.array([f1(int(t)) for t in steps], np.float64)
     out["lr_delayed"] = np.array([f2(int(t)) for t in steps], np.float64)
     out["lr_constant"] = np.array([f3(int(t)) for t in steps], np.float64)
+    out.update(densify_case(ren, rng))
     return {k: np.asarray(v) for k, v in out.items()}
+
+
+DENSIFY_ARGS = dict(max_grad=2e-4, min_opacity=0.02, extent=2.0, max_screen_size=20)
+
+
+def densify_inputs(rng, N=300):
+    """a small cloud in the state a trainer would hand to densify_and_prune: mixed scales either side of percent_dense * extent,
+    some transparent points, some oversized ones, gradient statistics with never-seen points (denominator 0)"""
+    d = {}
+    d["xyz"] = rng.uniform(-1, 1, (N, 3)).astype(np.float32)
+    d["f_dc"] = rng.normal(size=(N, 1, 3)).astype(np.float32)
+    d["f_rest"] = (rng.normal(size=(N, 15, 3)) * 0.1).astype(np.float32)
+    d["scaling"] = rng.normal(np.log(0.02), 0.9, (N, 3)).astype(np.float32)          # raw = log
+    d["rotation"] = rng.normal(size=(N, 4)).astype(np.float32)
+    d["opacity"] = rng.normal(0.0, 2.5, (N, 1)).astype(np.float32)                   # raw = logit
+    d["max_radii2D"] = rng.integers(0, 60, N).astype(np.float32)
+    d["denom"] = rng.integers(0, 4, (N, 1)).astype(np.float32)
+    d["xyz_gradient_accum"] = (rng.exponential(2.5e-4, (N, 1)) * d["denom"]).astype(np.float32)
+    d["step_grads"] = [rng.normal(size=d[k].shape).astype(np.float32) for k in ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")]
+    return d
+
+
+def densify_case(ren, rng):
+    """GaussianModel.densify_and_prune (:759-761 = clone :670-687, split :641-668, prune :771-781 + the optimizer surgery :558-614) of
+    the reference itself, on the CPU, with torch.manual_seed(0) for the split samples"""
+    from types import SimpleNamespace
+    d = densify_inputs(rng)
+    gm = ren.GaussianModel(3)
+    P = lambda a: torch.nn.Parameter(torch.from_numpy(a.copy()).requires_grad_(True))
+    gm._xyz, gm._features_dc, gm._features_rest = P(d["xyz"]), P(d["f_dc"]), P(d["f_rest"])
+    gm._scaling, gm._rotation, gm._opacity = P(d["scaling"]), P(d["rotation"]), P(d["opacity"])
+    gm.init_xyz = torch.from_numpy(d["xyz"].copy())
+    gm.spatial_lr_scale = 1.0
+    gm.training_setup(SimpleNamespace(percent_dense=0.01, position_lr_init=1.6e-4, position_lr_final=1.6e-6, position_lr_delay_mult=0.01,
+                                      position_lr_max_steps=30000, feature_lr=2.5e-3, opacity_lr=0.05, scaling_lr=5e-3, rotation_lr=1e-3))
+    for prm, gr in zip((gm._xyz, gm._features_dc, gm._features_rest, gm._opacity, gm._scaling, gm._rotation), d["step_grads"]):
+        prm.grad = torch.from_numpy(gr.copy())
+    gm.optimizer.step()                                                              # Adam moments exist, as mid-training
+    gm.optimizer.zero_grad(set_to_none=True)
+    gm.max_radii2D = torch.from_numpy(d["max_radii2D"].copy())
+    gm.xyz_gradient_accum = torch.from_numpy(d["xyz_gradient_accum"].copy())
+    gm.denom = torch.from_numpy(d["denom"].copy())
+    before = {k: getattr(gm, "_" + k).detach().numpy().copy() for k in ("xyz", "features_dc", "features_rest", "scaling", "rotation", "opacity")}
+    torch.manual_seed(0)
+    gm.densify_and_prune(**DENSIFY_ARGS)
+    out = {"dens_in_" + k: v for k, v in d.items() if k != "step_grads"}
+    for i, gr in enumerate(d["step_grads"]):
+        out["dens_in_step_grad%d" % i] = gr
+    for k, v in before.items():
+        out["dens_stepped_" + k] = v
+    for k in ("xyz", "features_dc", "features_rest", "scaling", "rotation", "opacity"):
+        out["dens_out_" + k] = getattr(gm, "_" + k).detach().numpy()
+    out["dens_out_init_xyz"] = gm.init_xyz.numpy()
+    out["dens_out_max_radii2D"] = gm.max_radii2D.numpy()
+    out["dens_out_xyz_gradient_accum"], out["dens_out_denom"] = gm.xyz_gradient_accum.numpy(), gm.denom.numpy()
+    for grp in gm.optimizer.param_groups:
+        st = gm.optimizer.state[grp["params"][0]]
+        out["dens_out_exp_avg_" + grp["name"]] = st["exp_avg"].numpy()
+        out["dens_out_exp_avg_sq_" + grp["name"]] = st["exp_avg_sq"].numpy()
+        assert grp["params"][0] is getattr(gm, {"xyz": "_xyz", "f_dc": "_features_dc", "f_rest": "_features_rest", "opacity": "_opacity",
+                                                 "scaling": "_scaling", "rotation": "_rotation"}[grp["name"]])
+    return out
 
 
 def main():

@@ -4,7 +4,8 @@ tests/golden/ref_py_conventions.npz was produced by importing the reference's mo
 helper functions (tests/golden/make_golden_ref_py.py lists them with file:line).  They fix every convention the rasterizer's inputs
 follow: SH basis / coefficient order (eval_sh), the camera matrices exactly as the rasterizer receives them (MiniCam: transposed,
 row-vector, "rectified" w2c, camera_center), quaternion layout and the 6-vector covariance order (build_rotation,
-covariance_activation), the learning-rate schedule.  What stays unpinned is the un-vendored CUDA kernel itself: culling constants, the
+covariance_activation), the learning-rate schedule -- and one full run of the reference's GaussianModel.densify_and_prune with its optimizer
+surgery, which the one-pass formulation of this repo must reproduce point for point.  What stays unpinned is the un-vendored CUDA kernel itself: culling constants, the
 EWA projection, tile binning and the blending loop (oracle/gs_oracle.c header).
 """
 import math
@@ -154,3 +155,42 @@ def test_oracle_covariance_follows_the_reference_quaternion_and_6vector_layout(g
     np.testing.assert_allclose(ga["conic_opacity"], gb["conic_opacity"], rtol=2e-4)
     np.testing.assert_allclose(ga["xy"], gb["xy"], atol=1e-9)
     assert np.abs(ra - rb).max() <= 1
+
+
+# ------------------------------------------------------------------------------------------------ densify / prune
+def test_densify_and_prune_matches_a_run_of_the_reference(g):
+    """The fixture holds a run of the reference's OWN GaussianModel.densify_and_prune (clone -> split -> prune with its optimizer
+    surgery, main_3DGS_renderer.py:558-781) on the CPU.  The one-pass formulation here must reproduce it: same points in the same order,
+    same Adam moments, the same split samples (one normal draw of shape [2S,3] from a generator seeded like torch.manual_seed(0))."""
+    sys.path.insert(0, GOLD_DIR)
+    from make_golden_ref_py import DENSIFY_ARGS
+    from MVs_Algorithms.GaussianSplatting.main_3DGS_renderer import GaussianModel
+    from MVs_Algorithms.GaussianSplatting.main_3DGS import GSParams
+    T = lambda k: torch.from_numpy(g[k].copy())
+    gm = GaussianModel(3, device="cpu")
+    gm.create_from_tensors(T("dens_in_xyz"), torch.cat((T("dens_in_f_dc"), T("dens_in_f_rest")), dim=1), T("dens_in_scaling"), T("dens_in_rotation"),
+                           T("dens_in_opacity"), spatial_lr_scale=1.0)
+    gm.training_setup(GSParams())
+    P = gm._param_dict()
+    for i, name in enumerate(("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")):
+        P[name].grad = T("dens_in_step_grad%d" % i)
+    gm.optimizer.step()                                               # same Adam configuration -> same parameters after one step
+    long = {"xyz": "xyz", "f_dc": "features_dc", "f_rest": "features_rest", "opacity": "opacity", "scaling": "scaling", "rotation": "rotation"}
+    for name, t in gm._param_dict().items():
+        np.testing.assert_allclose(t.detach().numpy(), g["dens_stepped_" + long[name]], rtol=1e-6, atol=1e-7, err_msg=name)
+        t.grad = None
+    gm.max_radii2D = T("dens_in_max_radii2D")
+    gm.xyz_gradient_accum, gm.denom = T("dens_in_xyz_gradient_accum"), T("dens_in_denom")
+    info = gm.densify_and_prune(generator=torch.Generator().manual_seed(0), **DENSIFY_ARGS)
+    n = g["dens_out_xyz"].shape[0]
+    assert info["points"] == n and info["cloned"] > 10 and info["split"] > 10 and info["pruned"] > 10
+    for name, t in gm._param_dict().items():
+        assert t.shape[0] == n and t.requires_grad and t.is_leaf
+        np.testing.assert_allclose(t.detach().numpy(), g["dens_out_" + long[name]], rtol=1e-6, atol=1e-7, err_msg=name)
+    for grp in gm.optimizer.param_groups:
+        st = gm.optimizer.state[grp["params"][0]]
+        np.testing.assert_allclose(st["exp_avg"].numpy(), g["dens_out_exp_avg_" + grp["name"]], rtol=1e-6, atol=1e-12, err_msg=grp["name"])
+        np.testing.assert_allclose(st["exp_avg_sq"].numpy(), g["dens_out_exp_avg_sq_" + grp["name"]], rtol=1e-6, atol=1e-15, err_msg=grp["name"])
+    np.testing.assert_allclose(gm.init_xyz.numpy(), g["dens_out_init_xyz"], atol=0)
+    assert np.array_equal(gm.max_radii2D.numpy(), g["dens_out_max_radii2D"])          # all zero: the reference's screen-size criterion never fires
+    assert np.array_equal(gm.xyz_gradient_accum.numpy(), g["dens_out_xyz_gradient_accum"]) and np.array_equal(gm.denom.numpy(), g["dens_out_denom"])
