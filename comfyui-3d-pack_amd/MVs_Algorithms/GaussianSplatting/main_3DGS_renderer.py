@@ -423,8 +423,8 @@ class GaussianSplattingRenderer:
                compute_cov3D_python=False, convert_SHs_python=False):
         """-> dict(image[3,H,W] clamped, depth[1,H,W], alpha[1,H,W], viewspace_points[N,3], visibility_filter[N], radii[N])"""
         from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
-        if compute_cov3D_python or convert_SHs_python:
-            raise NotImplementedError("python SH / covariance paths are dead code in the reference (SURVEY 3.1 note a)")
+        if convert_SHs_python:
+            raise NotImplementedError("convert_SHs_python is dead code in the reference (:902 reads an attribute that does not exist)")
         g = self.gaussians
         settings = GaussianRasterizationSettings(
             image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
@@ -432,7 +432,8 @@ class GaussianSplattingRenderer:
             bg=self.bg_color if bg_color is None else bg_color, scale_modifier=scaling_modifier,
             viewmatrix=viewpoint_camera.world_view_transform, projmatrix=viewpoint_camera.full_proj_transform,
             sh_degree=g.active_sh_degree, campos=viewpoint_camera.camera_center, prefiltered=False, debug=False)
-        fused = (gaussain_idx is None and override_color is None and g.max_sh_degree == 3 and g._xyz.is_cuda and not self.force_unfused)
+        fused = (gaussain_idx is None and override_color is None and not compute_cov3D_python and g.max_sh_degree == 3 and g._xyz.is_cuda
+                 and not self.force_unfused)
         xyz = g.get_xyz if gaussain_idx is None else g.get_xyz[gaussain_idx]
         # zero tensor whose gradient is the screen-space positional gradient (densification statistic)
         screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
@@ -450,8 +451,11 @@ class GaussianSplattingRenderer:
             if gaussain_idx is not None:
                 feats, opac, scales, rots = feats[gaussain_idx], opac[gaussain_idx], scales[gaussain_idx], rots[gaussain_idx]
             shs, colors = (feats, None) if override_color is None else (None, override_color)
+            cov = None
+            if compute_cov3D_python:         # world covariances from the model (already carrying the modifier) instead of scales + rotations
+                cov, scales, rots = g.get_covariance(scaling_modifier, gaussain_idx), None, None
             image, radii, depth, alpha = GaussianRasterizer(raster_settings=settings)(
                 means3D=xyz, means2D=screenspace_points, shs=shs, colors_precomp=colors, opacities=opac,
-                scales=scales, rotations=rots, cov3D_precomp=None)
+                scales=scales, rotations=rots, cov3D_precomp=cov)
         return {"image": image.clamp(0, 1), "depth": depth, "alpha": alpha, "viewspace_points": screenspace_points,
                 "visibility_filter": radii > 0, "radii": radii}

@@ -73,7 +73,7 @@ def _install_stubs():
 def _cpu_redirect():
     """the reference hard-codes CUDA placement; run the same arithmetic on the CPU"""
     torch.Tensor.cuda = lambda self, *a, **k: self
-    for fn in ("zeros", "ones", "empty", "tensor", "eye", "full"):
+    for fn in ("zeros", "ones", "empty", "tensor", "eye", "full", "zeros_like", "ones_like", "empty_like", "arange", "rand", "randn"):
         orig = getattr(torch, fn)
 
         def wrapped(*a, _orig=orig, **k):
