@@ -176,8 +176,10 @@ class GaussianSplatting3D:
             g.add_densification_stats(vg, vis, radii)
         changed = False
         if step % p.densification_interval == 0:
-            gen = torch.Generator(device=self.device)
-            gen.manual_seed(0x3D65 + step)                 # identical draws on every rank
+            gen = None                                     # one process: torch's global generator, exactly as the reference draws
+            if self.group is not None and torch.distributed.get_world_size(self.group) > 1:
+                gen = torch.Generator(device=self.device)
+                gen.manual_seed(0x3D65 + step)             # identical draws on every rank
             self.last_densify = g.densify_and_prune(p.densify_grad_threshold, min_opacity=0.005, extent=4, max_screen_size=1, generator=gen)
             changed = True
         if step % p.opacity_reset_interval == 0:

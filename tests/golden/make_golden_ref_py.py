@@ -68,6 +68,10 @@ def _install_stubs():
                 m = _Stub(name)
                 m.__path__ = []
                 sys.modules[name] = m
+        if "." in name:                                               # `import a.b` then `a.b.x`: the parent must expose the child
+            parent, child = name.rsplit(".", 1)
+            if isinstance(sys.modules.get(parent), _Stub):
+                setattr(sys.modules[parent], child, sys.modules[name])
 
 
 def _cpu_redirect():

@@ -128,4 +128,4 @@ def test_gs_mirror_hands_the_rasterizer_what_the_reference_does(gg, case, monkey
         assert got.shape == want.shape and got.dtype == want.dtype, (k, got.dtype, want.dtype)
         np.testing.assert_allclose(got.astype(np.float64), want.astype(np.float64), rtol=0, atol=2e-6, err_msg=k)
     assert bool(res["viewspace_points"].requires_grad) == bool(gg[pre + "viewspace_requires_grad"])
-    assert float(res["image"].max()) <= 1.0 and float(res["image"].min()) >= 0.0
+    assert float(res["image"].detach().max()) <= 1.0 and float(res["image"].detach().min()) >= 0.0
