@@ -84,7 +84,9 @@ class DiffMesh:
             imgs.append((out["image"].permute(2, 0, 1).contiguous() * m).unsqueeze(0))
             refs.append((self.ref_imgs_torch[i] * m).unsqueeze(0))
         imgs, refs = torch.cat(imgs), torch.cat(refs)
-        loss = (1 - self.lambda_ssim) * F.mse_loss(imgs, refs) + self.lambda_ssim * (1 - self.ms_ssim_loss(refs, imgs))
+        loss = (1 - self.lambda_ssim) * F.mse_loss(imgs, refs)
+        if self.lambda_ssim > 0:      # weight 0: the term contributes nothing to value or gradient (and 5-scale MS-SSIM needs sides > 160 px)
+            loss = loss + self.lambda_ssim * (1 - self.ms_ssim_loss(refs, imgs))
         if self.train_mesh_geometry:
             r = self.renderer
             cur = r.mesh.v + r.v_offsets

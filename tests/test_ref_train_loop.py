@@ -66,3 +66,45 @@ def test_trainer_follows_the_reference_training_loop_step_by_step(monkeypatch):
     P = g._param_dict()
     for k, name in long.items():
         np.testing.assert_allclose(P[name].detach().numpy(), z["final_" + k], rtol=1e-4, atol=2e-6, err_msg=k)
+
+
+# ------------------------------------------------------------------------------------------------ the mesh trainer
+def test_mesh_fixture_is_what_the_reference_produces_now():
+    if not os.path.isdir("/root/reference/MVs_Algorithms"):
+        pytest.skip("/root/reference is not mounted here")
+    r = subprocess.run([sys.executable, os.path.join(GOLD_DIR, "make_golden_ref_mesh_train.py"), "--check"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_mesh_trainer_follows_the_reference_training_loop_step_by_step(monkeypatch):
+    """DiffMesh.training of the reference (diff_mesh.py:81-159: view sampling, controller, render, masked MSE + geometry regularisers,
+    Adam over raw_albedo and v_offsets, update_mesh) ran 10 steps on the CPU over tests/fake_dr.py with the geometry training, i.e. with
+    gradients through antialias / interpolate / rasterize; the mirror over the same stand-in must retrace it."""
+    from types import SimpleNamespace
+    import fake_dr
+    from make_golden_ref_mesh_train import ARGS, FOVY, SEEDS
+    from MVs_Algorithms.DiffRastMesh import diff_mesh as DM, diff_mesh_renderer as MR
+    monkeypatch.setattr(MR, "dr", fake_dr)
+    z = np.load(os.path.join(GOLD_DIR, "ref_mesh_train.npz"))
+    T = lambda k: torch.from_numpy(z["scene_" + k].copy())
+    mesh = SimpleNamespace(v=T("v"), f=T("f"), vt=T("vt"), ft=T("f"), vn=T("vn"), fn=T("f"), albedo=T("albedo"))
+    t = DM.DiffMesh(mesh, device="cpu", **ARGS)
+    with torch.no_grad():
+        t.renderer.raw_albedo.add_(T("raw_albedo_noise"))
+    t.prepare_training([T("ref_images")[i] for i in range(3)], [T("ref_masks")[i] for i in range(3)], [tuple(p) for p in z["scene_poses"]], FOVY)
+    rows = []
+
+    def snapshot(value):
+        r = t.renderer
+        rows.append([value, float(r.raw_albedo.detach().double().sum()), float(r.raw_albedo.detach().double().abs().sum()),
+                     float(r.v_offsets.detach().double().sum()), float(r.v_offsets.detach().double().abs().sum())])
+    random.seed(SEEDS["python"]); np.random.seed(SEEDS["numpy"]); torch.manual_seed(SEEDS["torch"])
+    t.training(progress=snapshot)
+    got, want = np.asarray(rows), z["trajectory"]
+    assert got.shape == want.shape
+    assert want[-1, 4] > 4.0                                           # the geometry really moved in the reference run
+    np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(t.renderer.raw_albedo.detach().numpy(), z["final_raw_albedo"], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(t.renderer.v_offsets.detach().numpy(), z["final_v_offsets"], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(t.renderer.mesh.v.numpy(), z["final_mesh_v"], rtol=1e-5, atol=1e-6)            # update_mesh() at the end of training
+    np.testing.assert_allclose(t.renderer.mesh.albedo.numpy(), z["final_mesh_albedo"], rtol=1e-5, atol=1e-6)
