@@ -161,6 +161,11 @@ class GaussianModel:
         self._set(xyz, features[:, :1], features[:, 1:], scaling_raw, rotation_raw, opacity_raw)
         self.active_sh_degree = self.max_sh_degree
 
+    def get_points_cloud(self):
+        """positions + SH2RGB of the full [N,K,3] feature block, zero normals (reference :468-473)"""
+        xyz = self._xyz.detach().cpu().numpy()
+        return PointCloud(points=xyz, colors=SH2RGB(self.get_features.detach().cpu().numpy()), normals=np.zeros_like(xyz))
+
     # ---- PLY wire format (reference to_ply :475-484, create_from_ply :486-498) ----
     def to_ply(self):
         n = lambda t: t.detach().cpu().numpy()
