@@ -1,7 +1,7 @@
 """Minimal torch `Mesh` container: the data contract DiffRastRenderer reads.
 
 Mirrors the attribute names and tensor layouts of /root/reference/mesh_processer/mesh.py:15-66 (v [V,3] f32, f [T,3] i32,
-vn/fn, vt/ft, albedo [Ht,Wt,3] in [0,1]) plus `auto_normal` (:471-494) and `set_new_albedo` (:442-447).  Asset I/O
+vn/fn, vt/ft, albedo [Ht,Wt,3] in [0,1]) plus `auto_normal` (:471-494), `aabb` / `auto_size` (:450-469) and `set_new_albedo` (:442-447).  Asset I/O
 (obj/glb/ply, xatlas UV unwrapping) is out of scope for the hot path."""
 import torch
 
@@ -37,5 +37,23 @@ class Mesh:
         self.vn = safe_normalize(vn)
         self.fn = self.f
 
-    def set_new_albedo(self, w, h):
-        self.albedo = torch.ones((h, w, 3), dtype=torch.float32, device=self.device) * 0.5
+    def aabb(self):
+        """(min xyz, max xyz) of the vertices (reference :450-457)"""
+        return torch.min(self.v, dim=0).values, torch.max(self.v, dim=0).values
+
+    @torch.no_grad()
+    def auto_size(self, bound=0.9):
+        """centre the box and scale its longest side to [-bound, bound] (reference :460-469); remembers ori_center / ori_scale"""
+        vmin, vmax = self.aabb()
+        self.ori_center = (vmax + vmin) / 2
+        self.ori_scale = 2 * bound / torch.max(vmax - vmin).item()
+        self.v = (self.v - self.ori_center) * self.ori_scale
+
+    def set_new_albedo(self, res_H, res_W):
+        """no texture yet: mid-grey [res_H, res_W, 3]; otherwise the existing one resized bilinearly (reference :442-447)"""
+        if self.albedo is None:
+            self.albedo = torch.full((res_H, res_W, 3), 0.5, dtype=torch.float32, device=self.device)
+        else:
+            t = self.albedo.unsqueeze(0).permute(0, 3, 1, 2).to(self.device)
+            t = torch.nn.functional.interpolate(t, (res_H, res_W), mode="bilinear", align_corners=False)
+            self.albedo = t.squeeze(0).permute(1, 2, 0).contiguous()

@@ -233,6 +233,7 @@ def test_diffrast_renderer_mirror_and_trainer():
     ref_images = [imgs[i].cpu() for i in range(4)]
     ref_masks = [masks[i, ..., 0].cpu() for i in range(4)]
     m2 = _torch_mesh()
+    m2.albedo = None                                                # set_new_albedo resizes an existing texture (as the reference's does): drop it first
     m2.set_new_albedo(64, 64)
     with torch.no_grad():
         m2.v *= 1.03

@@ -77,3 +77,28 @@ def test_model_construction_and_ply_round_trip_match_the_reference(z, deg, monke
         n2, m2 = _ply_matrix(MU.switch_ply_axis_and_scale(pd, axis, scale, inv))
         assert n2 == list(z[pre + tag + "_names"])
         np.testing.assert_allclose(m2, z[pre + tag + "_data"], rtol=1e-5, atol=1e-6, err_msg=tag)
+
+
+def test_mesh_container_methods_match_the_reference():
+    """Mesh.auto_normal / aabb / auto_size / set_new_albedo against a run of the reference's class (tests/golden/make_golden_ref_mesh_class.py)"""
+    from mesh_processer.mesh import Mesh
+    if os.path.isdir("/root/reference/mesh_processer"):
+        r = subprocess.run([sys.executable, os.path.join(GOLD_DIR, "make_golden_ref_mesh_class.py"), "--check"], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    z = np.load(os.path.join(GOLD_DIR, "ref_mesh_class.npz"))
+    T = lambda k: torch.from_numpy(z[k].copy())
+    m = Mesh(v=T("v"), f=T("f"), device="cpu")
+    m.auto_normal()
+    np.testing.assert_allclose(m.vn.numpy(), z["vn"], rtol=1e-6, atol=1e-7)
+    assert np.array_equal(m.fn.numpy(), z["fn"])
+    lo, hi = m.aabb()
+    assert np.array_equal(lo.numpy(), z["aabb_min"]) and np.array_equal(hi.numpy(), z["aabb_max"])
+    m.auto_size(bound=0.9)
+    np.testing.assert_allclose(m.v.numpy(), z["sized_v"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(np.asarray(m.ori_center), z["ori_center"], atol=1e-7)
+    assert abs(m.ori_scale - float(z["ori_scale"])) <= 1e-6 * float(z["ori_scale"])
+    m.set_new_albedo(6, 10)
+    assert m.albedo.shape == (6, 10, 3) and np.array_equal(m.albedo.numpy(), z["gray_albedo"])
+    m2 = Mesh(v=T("v"), f=T("f"), albedo=T("tex"), device="cpu")
+    m2.set_new_albedo(12, 10)
+    np.testing.assert_allclose(m2.albedo.numpy(), z["resized_albedo"], rtol=1e-6, atol=1e-7)
