@@ -205,6 +205,19 @@ class GaussianModel:
                                                     lr_delay_mult=training_args.position_lr_delay_mult,
                                                     max_steps=training_args.position_lr_max_steps)
 
+    # ---- checkpoint / resume (reference :255-288: the same 12-tuple in the same order) ----
+    def capture(self):
+        return (self.active_sh_degree, self._xyz, self._features_dc, self._features_rest, self._scaling, self._rotation, self._opacity,
+                self.max_radii2D, self.xyz_gradient_accum, self.denom, self.optimizer.state_dict(), self.spatial_lr_scale)
+
+    def restore(self, model_args, training_args):
+        (self.active_sh_degree, self._xyz, self._features_dc, self._features_rest, self._scaling, self._rotation, self._opacity,
+         self.max_radii2D, xyz_gradient_accum, denom, opt_dict, self.spatial_lr_scale) = model_args
+        self.init_xyz = self._xyz.detach().clone() if self.init_xyz.shape != self._xyz.shape else self.init_xyz
+        self.training_setup(training_args)
+        self.xyz_gradient_accum, self.denom = xyz_gradient_accum, denom
+        self.optimizer.load_state_dict(opt_dict)
+
     def update_learning_rate(self, iteration):
         for group in self.optimizer.param_groups:
             if group["name"] == "xyz":

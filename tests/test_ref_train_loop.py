@@ -108,3 +108,47 @@ def test_mesh_trainer_follows_the_reference_training_loop_step_by_step(monkeypat
     np.testing.assert_allclose(t.renderer.v_offsets.detach().numpy(), z["final_v_offsets"], rtol=1e-4, atol=2e-6)
     np.testing.assert_allclose(t.renderer.mesh.v.numpy(), z["final_mesh_v"], rtol=1e-5, atol=1e-6)            # update_mesh() at the end of training
     np.testing.assert_allclose(t.renderer.mesh.albedo.numpy(), z["final_mesh_albedo"], rtol=1e-5, atol=1e-6)
+
+
+def test_capture_restore_resumes_the_trajectory(monkeypatch):
+    """GaussianModel.capture / restore (reference main_3DGS_renderer.py:255-288): a run interrupted after 11 steps -- past a densification and an
+    opacity reset -- and resumed in a fresh trainer from the captured tuple ends exactly where the uninterrupted run ends."""
+    import copy
+    import fake_dgr
+    from make_golden_ref_gs_train import FOVY, PARAMS, SEEDS
+    monkeypatch.setattr(fake_dgr, "RECORD", False)
+    monkeypatch.setitem(sys.modules, "diff_gaussian_rasterization", fake_dgr)
+    from MVs_Algorithms.GaussianSplatting.main_3DGS import GaussianSplatting3D, GSParams
+    z = np.load(os.path.join(GOLD_DIR, "ref_gs_train.npz"))
+    T = lambda k: torch.from_numpy(z["scene_" + k].copy())
+    gp = GSParams()
+    for k, v in PARAMS.items():
+        setattr(gp, k, v)
+
+    def trainer():
+        init = dict(xyz=T("xyz"), features=torch.cat((T("f_dc"), T("f_rest")), dim=1), scaling_raw=T("scaling"), rotation_raw=T("rotation"),
+                    opacity_raw=T("opacity"), spatial_lr_scale=1.0)
+        t = GaussianSplatting3D(gp, init, device="cpu")
+        t.prepare_training([T("ref_images")[i] for i in range(4)], [T("ref_masks")[i] for i in range(4)], [tuple(p) for p in z["scene_poses"]], FOVY)
+        return t
+    views = [[s % 4, (s + 1) % 4] for s in range(16)]
+    np.random.seed(1); torch.manual_seed(1)
+    a = trainer()
+    for s in range(16):
+        a.training_step(s, views[s])
+        if s == 10:
+            state = copy.deepcopy(a.renderer.gaussians.capture())
+            rng_np, rng_t = np.random.get_state(), torch.get_rng_state()
+    assert len(state) == 12 and state[0] == 3 and state[1].shape[0] > 160 and "param_groups" in state[10]
+    b = trainer()
+    b.renderer.gaussians.restore(state, gp)
+    b.optimizer = b.renderer.gaussians.optimizer
+    g = b.renderer.gaussians
+    b.params = [g._xyz, g._features_dc, g._features_rest, g._opacity, g._scaling, g._rotation]
+    np.random.set_state(rng_np); torch.set_rng_state(rng_t)
+    for s in range(11, 16):
+        b.training_step(s, views[s])
+    ga = a.renderer.gaussians
+    assert g._xyz.shape == ga._xyz.shape
+    for name in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"):
+        assert torch.equal(getattr(g, name).detach(), getattr(ga, name).detach()), name
