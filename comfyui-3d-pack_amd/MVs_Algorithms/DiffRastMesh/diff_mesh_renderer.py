@@ -23,26 +23,47 @@ def inverse_sigmoid(x):
 
 
 def scale_img_nhwc(x, size, mag='bilinear', min='bilinear'):
-    """resize NHWC; magnification with align_corners like the reference (:14-26); never mixed mag/min"""
-    up = x.shape[1] < size[0] and x.shape[2] < size[1]
-    down = x.shape[1] >= size[0] and x.shape[2] >= size[1]
-    assert up or down, "Trying to magnify image in one dimension and minify in the other"
-    y = x.permute(0, 3, 1, 2)
-    if x.shape[1] > size[0] and x.shape[2] > size[1]:
-        y = F.interpolate(y, size, mode=min)
-    elif mag in ('bilinear', 'bicubic'):
-        y = F.interpolate(y, size, mode=mag, align_corners=True)
+    """resize an NHWC batch.  Shrinking in both directions uses `min`; everything else `mag`, with align_corners for the two smooth
+    modes (what the reference does, :14-26); magnifying one side while minifying the other is refused."""
+    src_h, src_w = int(x.shape[1]), int(x.shape[2])
+    dst_h, dst_w = int(size[0]), int(size[1])
+    grows = src_h < dst_h and src_w < dst_w
+    if not (grows or (src_h >= dst_h and src_w >= dst_w)):
+        raise AssertionError("Trying to magnify image in one dimension and minify in the other")
+    if src_h > dst_h and src_w > dst_w:
+        mode, extra = min, {}
     else:
-        y = F.interpolate(y, size, mode=mag)
-    return y.permute(0, 2, 3, 1).contiguous()
+        mode, extra = mag, ({"align_corners": True} if mag in ("bilinear", "bicubic") else {})
+    return F.interpolate(x.permute(0, 3, 1, 2), (dst_h, dst_w), mode=mode, **extra).permute(0, 2, 3, 1).contiguous()
 
 
 def scale_img_hwc(x, size, mag='bilinear', min='bilinear'):
-    return scale_img_nhwc(x[None, ...], size, mag, min)[0]
+    return scale_img_nhwc(x.unsqueeze(0), size, mag, min).squeeze(0)
+
+
+def scale_img_nhw(x, size, mag='bilinear', min='bilinear'):
+    return scale_img_nhwc(x.unsqueeze(-1), size, mag, min).squeeze(-1)
+
+
+def scale_img_hw(x, size, mag='bilinear', min='bilinear'):
+    return scale_img_nhwc(x[None, ..., None], size, mag, min)[0, ..., 0]
 
 
 def make_divisible(x, m=8):
-    return int(math.ceil(x / m) * m)
+    """the next multiple of m at or above x"""
+    return -int(-x // m) * m if float(x).is_integer() else int(math.ceil(x / m)) * m
+
+
+def vertex_normals_from_faces(v, f):
+    """unit face normals summed onto their three vertices (not re-normalised here: the caller normalises after interpolation); vertices
+    that collect nothing get +z -- the reference's rebuild when the geometry trains (:119-131)"""
+    corner = [f[:, k].long() for k in range(3)]
+    face_n = safe_normalize(torch.cross(v[corner[1]] - v[corner[0]], v[corner[2]] - v[corner[0]], dim=-1))
+    acc = torch.zeros_like(v)
+    for idx in corner:
+        acc.index_add_(0, idx, face_n)
+    empty = (acc * acc).sum(-1, keepdim=True) <= 1e-20
+    return torch.where(empty, acc.new_tensor([0.0, 0.0, 1.0]), acc)
 
 
 class LazyResults(dict):
@@ -134,15 +155,7 @@ class DiffRastRenderer(nn.Module):
 
         def normal_pair():
             if not shading:
-                if self.train_geo:
-                    i0, i1, i2 = (mesh.f[:, k].long() for k in range(3))
-                    face_n = safe_normalize(torch.cross(v[i1] - v[i0], v[i2] - v[i0], dim=-1))
-                    vn = torch.zeros_like(v)
-                    for idx in (i0, i1, i2):
-                        vn.scatter_add_(0, idx[:, None].repeat(1, 3), face_n)
-                    vn = torch.where(torch.sum(vn * vn, -1, keepdim=True) > 1e-20, vn, torch.tensor([0.0, 0.0, 1.0], dtype=torch.float32, device=vn.device))
-                else:
-                    vn = mesh.vn
+                vn = vertex_normals_from_faces(v, mesh.f) if self.train_geo else mesh.vn
                 normal, _ = dr.interpolate(vn.unsqueeze(0).contiguous(), rast, mesh.fn)
                 normal = safe_normalize(normal[0])
                 viewcos = normal @ pose[:3, :3]                                                   # [0,0,1] faces the camera
