@@ -152,3 +152,129 @@ def test_capture_restore_resumes_the_trajectory(monkeypatch):
     assert g._xyz.shape == ga._xyz.shape
     for name in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"):
         assert torch.equal(getattr(g, name).detach(), getattr(ga, name).detach()), name
+
+
+# ------------------------------------------------------------------------------------------------ view-parallel training over gloo (world 2)
+def _free_port():
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _build_cpu_trainer(group, exchange):
+    import fake_dgr
+    from make_golden_ref_gs_train import FOVY, PARAMS
+    fake_dgr.RECORD = False
+    sys.modules["diff_gaussian_rasterization"] = fake_dgr
+    from MVs_Algorithms.GaussianSplatting.main_3DGS import GaussianSplatting3D, GSParams
+    z = np.load(os.path.join(GOLD_DIR, "ref_gs_train.npz"))
+    T = lambda k: torch.from_numpy(z["scene_" + k].copy())
+    gp = GSParams()
+    for k, v in PARAMS.items():
+        setattr(gp, k, v)
+    gp.invert_bg_prob = 1.0                                           # a fixed background: ranks render different numbers of views per step
+    init = dict(xyz=T("xyz"), features=torch.cat((T("f_dc"), T("f_rest")), dim=1), scaling_raw=T("scaling"), rotation_raw=T("rotation"),
+                opacity_raw=T("opacity"), spatial_lr_scale=1.0)
+    t = GaussianSplatting3D(gp, init, device="cpu", process_group=group, exchange=exchange)
+    t.prepare_training([T("ref_images")[i] for i in range(4)], [T("ref_masks")[i] for i in range(4)], [tuple(p) for p in z["scene_poses"]], FOVY)
+    return t
+
+
+VIEWS = [[s % 4, (s + 2) % 4] for s in range(10)]
+
+
+def _snap(t):
+    g = t.renderer.gaussians
+    return [q.detach().clone() for q in (g._xyz, g._features_dc, g._features_rest, g._opacity, g._scaling, g._rotation)]
+
+
+def _rank_worker(rank, world, port, exchange, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    sys.path[:0] = [root, os.path.join(root, "comfyui-3d-pack_amd"), here, os.path.join(here, "golden")]
+    np.random.seed(7); torch.manual_seed(7)
+    t = _build_cpu_trainer(dist.group.WORLD, exchange)
+    early = None
+    for s, v in enumerate(VIEWS):
+        t.training_step(s, v)
+        if s == 5:
+            early = _snap(t)
+    out[rank] = (early, _snap(t), t.renderer.gaussians._xyz.shape[0])
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("exchange", ["allreduce", "allgather"])
+def test_two_gloo_ranks_train_like_one_process_and_stay_identical(exchange):
+    """N > 1 on the CPU: two ranks, one view each per step, one gradient exchange per step.  Until the first densification the replicas
+    follow the single-process run of the same global batch (mean-of-means = mean over equal shards); through densification -- whose
+    statistics are combined over ranks and whose split samples come from a per-step seeded generator -- they stay bit-identical."""
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_rank_worker, args=(world, port, exchange, out), nprocs=world, join=True)
+    (e0, f0, n0), (e1, f1, n1) = out[0], out[1]
+    assert n0 == n1 and n0 > 160                                      # densified (step 6), same count on both ranks
+    for a, b in zip(f0, f1):
+        assert torch.equal(a, b)                                      # replicas bit-identical at the end
+    for a, b in zip(e0, e1):
+        assert torch.equal(a, b)
+    np.random.seed(7); torch.manual_seed(7)
+    t = _build_cpu_trainer(None, exchange)
+    for s in range(6):
+        t.training_step(s, VIEWS[s])
+    for a, b in zip(_snap(t), e0):
+        assert a.shape == b.shape
+        torch.testing.assert_close(a, b, rtol=2e-5, atol=2e-6)
+
+
+def _build_cpu_mesh_trainer(group, exchange):
+    from types import SimpleNamespace
+    import fake_dr
+    from make_golden_ref_mesh_train import ARGS, FOVY
+    from MVs_Algorithms.DiffRastMesh import diff_mesh as DM, diff_mesh_renderer as MR
+    MR.dr = fake_dr
+    z = np.load(os.path.join(GOLD_DIR, "ref_mesh_train.npz"))
+    T = lambda k: torch.from_numpy(z["scene_" + k].copy())
+    mesh = SimpleNamespace(v=T("v"), f=T("f"), vt=T("vt"), ft=T("f"), vn=T("vn"), fn=T("f"), albedo=T("albedo"))
+    a = dict(ARGS); a["invert_bg_prob"] = 1.0
+    t = DM.DiffMesh(mesh, device="cpu", process_group=group, exchange=exchange, **a)
+    t.prepare_training([T("ref_images")[i] for i in range(3)], [T("ref_masks")[i] for i in range(3)], [tuple(p) for p in z["scene_poses"]], FOVY)
+    return t
+
+
+MESH_VIEWS = [[s % 3, (s + 1) % 3] for s in range(6)]
+
+
+def _mesh_rank_worker(rank, world, port, exchange, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    sys.path[:0] = [root, os.path.join(root, "comfyui-3d-pack_amd"), here, os.path.join(here, "golden")]
+    np.random.seed(3); torch.manual_seed(3)
+    t = _build_cpu_mesh_trainer(dist.group.WORLD, exchange)
+    for s, v in enumerate(MESH_VIEWS):
+        t.training_step(s, v)
+    out[rank] = (t.renderer.raw_albedo.detach().clone(), t.renderer.v_offsets.detach().clone())
+    dist.destroy_process_group()
+
+
+def test_two_gloo_ranks_fit_the_mesh_like_one_process():
+    """the mesh trainer's view-parallel path: texture and vertex-offset gradients exchanged once per step, replicas identical and equal to
+    the single-process run of the same global batch"""
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_mesh_rank_worker, args=(world, port, "allreduce", out), nprocs=world, join=True)
+    (a0, o0), (a1, o1) = out[0], out[1]
+    assert torch.equal(a0, a1) and torch.equal(o0, o1)
+    np.random.seed(3); torch.manual_seed(3)
+    t = _build_cpu_mesh_trainer(None, "allreduce")
+    for s, v in enumerate(MESH_VIEWS):
+        t.training_step(s, v)
+    torch.testing.assert_close(t.renderer.raw_albedo.detach(), a0, rtol=2e-5, atol=2e-6)
+    torch.testing.assert_close(t.renderer.v_offsets.detach(), o0, rtol=2e-4, atol=2e-6)
+    assert float(o0.abs().max()) > 0
