@@ -96,7 +96,53 @@ def generate():
         for k, v in res.items():
             out[name + "_out_" + k] = v.detach().numpy()
         out[name + "_viewspace_requires_grad"] = np.asarray(bool(res["viewspace_points"].requires_grad))
+    out.update(orbit_case(ren, cam, sc, fake))
     return {k: np.asarray(v) for k, v in out.items()}
+
+
+ORBIT_POSES = [(2.2, -15.0, 30.0, 0.0, 0.0, 0.0), (2.0, 20.0, 150.0, 0.05, 0.0, 0.0), (2.4, 0.0, -80.0, 0.0, -0.05, 0.1)]
+
+
+def orbit_case(ren, cam, sc, fake):
+    """the orbit loop the renderer nodes use: GaussianSplattingCameraController(...).render_all_pose (main_3DGS.py:76-82 on top of
+    BaseCameraController.render_at_pose / render_all_pose, camera_utils.py:240-274), with kiui.cam.orbit_camera restated as in
+    make_golden_ref_gs_train.py and the background drawn from numpy's global generator (seed 4)"""
+    import make_golden_ref_gs_train as GT
+    import types as _t
+    sys.modules["kiui.cam"].orbit_camera = GT.orbit_camera
+    sys.modules["comfy.utils"].ProgressBar = lambda *a, **k: None
+    sys.modules["pytorch_msssim"].MS_SSIM = lambda *a, **k: None
+    sys.modules["pytorch_msssim"].SSIM = lambda *a, **k: None
+    for name in ("torchvision", "torchvision.transforms", "torchvision.transforms.functional", "PIL", "PIL.Image"):
+        if name not in sys.modules:
+            try:
+                __import__(name)
+            except Exception:
+                m = G._Stub(name); m.__path__ = []
+                sys.modules[name] = m
+    G._load("shared_utils.image_utils", "shared_utils/image_utils.py")
+    cam.orbit_camera = GT.orbit_camera                                # camera_utils bound the stub's name at import
+    pkg = _t.ModuleType("ref_gs_pkg2"); pkg.__path__ = [os.path.join(G.REF, "MVs_Algorithms", "GaussianSplatting")]
+    sys.modules["ref_gs_pkg2"] = pkg
+    sys.modules["ref_gs_pkg2.main_3DGS_renderer"] = ren
+    tr = G._load("ref_gs_pkg2.main_3DGS", "MVs_Algorithms/GaussianSplatting/main_3DGS.py")
+    P = lambda a: torch.nn.Parameter(torch.from_numpy(a.copy()))
+    r = ren.GaussianSplattingRenderer(sh_degree=3, white_background=True, radius=1)
+    g = r.gaussians
+    g._xyz, g._features_dc, g._features_rest = P(sc["xyz"]), P(sc["f_dc"]), P(sc["f_rest"])
+    g._scaling, g._rotation, g._opacity = P(sc["scaling"]), P(sc["rotation"]), P(sc["opacity"])
+    g.active_sh_degree = 3
+    ctl = tr.GaussianSplattingCameraController(r, 72, 48, 49.1, 0.5, None, torch.device("cpu"))
+    np.random.seed(4)
+    del fake.CALLS[:]
+    with torch.no_grad():
+        images, masks, extra = ctl.render_all_pose(ORBIT_POSES)
+    out = {"orbit_images": images.numpy(), "orbit_masks": masks.numpy(), "orbit_extra_keys": np.asarray(sorted(extra.keys()))}
+    for k, v in extra.items():
+        out["orbit_extra_" + k] = v.numpy()
+    out["orbit_bg_per_view"] = np.stack([c["settings"]["bg"] for c in fake.CALLS])
+    out["orbit_viewmatrix_per_view"] = np.stack([c["settings"]["viewmatrix"] for c in fake.CALLS])
+    return out
 
 
 def main():

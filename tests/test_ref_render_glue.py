@@ -129,3 +129,30 @@ def test_gs_mirror_hands_the_rasterizer_what_the_reference_does(gg, case, monkey
         np.testing.assert_allclose(got.astype(np.float64), want.astype(np.float64), rtol=0, atol=2e-6, err_msg=k)
     assert bool(res["viewspace_points"].requires_grad) == bool(gg[pre + "viewspace_requires_grad"])
     assert float(res["image"].detach().max()) <= 1.0 and float(res["image"].detach().min()) >= 0.0
+
+
+def test_gs_orbit_loop_matches_the_reference_controller(gg, monkeypatch):
+    """GaussianSplattingCameraController.render_all_pose (the renderer nodes' orbit loop) of the mirror over tests/fake_dgr.py against the
+    reference's controller: orbit poses -> MiniCam, the random black / white background per view, stacked images / masks / extras."""
+    import fake_dgr
+    from make_golden_ref_gs_render import ORBIT_POSES
+    monkeypatch.setitem(sys.modules, "diff_gaussian_rasterization", fake_dgr)
+    monkeypatch.setattr(fake_dgr, "RECORD", True)
+    from MVs_Algorithms.GaussianSplatting.main_3DGS import GaussianSplattingCameraController
+    from MVs_Algorithms.GaussianSplatting.main_3DGS_renderer import GaussianSplattingRenderer
+    T = lambda k: torch.from_numpy(gg["scene_" + k].copy())
+    r = GaussianSplattingRenderer(sh_degree=3, white_background=True, radius=1, device="cpu")
+    r.gaussians.create_from_tensors(T("xyz"), torch.cat((T("f_dc"), T("f_rest")), dim=1), T("scaling"), T("rotation"), T("opacity"))
+    ctl = GaussianSplattingCameraController(r, 72, 48, 49.1, 0.5, None, "cpu")
+    np.random.seed(4)
+    del fake_dgr.CALLS[:]
+    with torch.no_grad():
+        images, masks, extra = ctl.render_all_pose(ORBIT_POSES)
+    np.testing.assert_allclose(np.stack([c["settings"]["bg"] for c in fake_dgr.CALLS]), gg["orbit_bg_per_view"], atol=0)
+    np.testing.assert_allclose(np.stack([c["settings"]["viewmatrix"] for c in fake_dgr.CALLS]), gg["orbit_viewmatrix_per_view"], atol=1e-6)
+    assert images.shape == gg["orbit_images"].shape and masks.shape == gg["orbit_masks"].shape
+    np.testing.assert_allclose(images.numpy(), gg["orbit_images"], atol=2e-6)
+    np.testing.assert_allclose(masks.numpy(), gg["orbit_masks"], atol=2e-6)
+    assert sorted(extra.keys()) == list(gg["orbit_extra_keys"])
+    for k in extra:
+        np.testing.assert_allclose(extra[k].numpy().astype(np.float64), gg["orbit_extra_" + k].astype(np.float64), atol=2e-6, err_msg=k)
