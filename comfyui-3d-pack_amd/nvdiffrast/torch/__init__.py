@@ -68,7 +68,7 @@ class _Rasterize(torch.autograd.Function):
         lib = _h.lib()
         _dev_check(pos, "pos")
         if pos.dim() != 3 or pos.shape[-1] != 4:
-            raise ValueError("rasterize: pos must be [B,V,4] (range mode is not built)")
+            raise ValueError("rasterize: pos must be [B,V,4] (pass ranges=... for one shared vertex buffer [V,4])")
         pos_c, tri_c = _h.f32c(pos), tri.to(torch.int32).contiguous()
         B, V = pos.shape[0], pos.shape[1]
         T = tri_c.shape[0]
