@@ -10,7 +10,8 @@ Same function names, argument meaning and return shapes as the module the refere
     DepthPeeler(glctx, pos, tri, resolution).rasterize_next_layer()
 The arithmetic runs in libc3d_hip.so; this file allocates tensors and wires autograd.  There is no CPU path.
     rasterize(..., ranges=[B,2]) / antialias with pos [V,4]: range (instanced) mode, composed on the host from the B = 1 kernels
-Not built (raise NotImplementedError): cube maps, boundary modes 'zero' / 'cube', DepthPeeler(ranges=...); gradients w.r.t.
+    boundary modes 'wrap' | 'clamp' | 'zero' ('zero' for the nearest / linear filters, composed from a zero-padded texture + 'clamp')
+Not built (raise NotImplementedError): cube maps (boundary 'cube'), 'zero' with the mip-mapped filters, DepthPeeler(ranges=...); gradients w.r.t.
 rast_db / out_da / uv_da / mip_level_bias are not propagated (no consumer on the reference's path).
 """
 import torch
@@ -396,6 +397,17 @@ def _mip_stack(tex, mip, max_mip_level):
     return torch.cat([_h.f32c(levels[l]).reshape(Bt, -1, C) for l in range(L)], dim=1), L
 
 
+def zero_boundary_as_clamp(tex, uv):
+    """boundary_mode='zero' (the texture continued by zeros in every direction) expressed with what the kernels have: the texture padded
+    by one zero texel per side and fetched in 'clamp' mode at coordinates moved by that texel -- every tap that falls outside lands on,
+    or is clamped to, the zero border.  -> (padded texture [Bt,Ht+2,Wt+2,C], remapped uv); differentiable through both."""
+    Ht, Wt = int(tex.shape[1]), int(tex.shape[2])
+    padded = torch.nn.functional.pad(tex, (0, 0, 1, 1, 1, 1))
+    scale = uv.new_tensor([Wt / (Wt + 2.0), Ht / (Ht + 2.0)])
+    shift = uv.new_tensor([1.0 / (Wt + 2.0), 1.0 / (Ht + 2.0)])
+    return padded, uv * scale + shift
+
+
 def texture(tex, uv, uv_da=None, mip_level_bias=None, mip=None, filter_mode='auto', boundary_mode='wrap', max_mip_level=None):
     """-> [B,H,W,C].  'auto' = 'linear' without uv_da / mip_level_bias, 'linear-mipmap-linear' with (as the dependency documents).
     Mip-mapped modes propagate gradients to `tex` (through every level of the pyramid), to a custom `mip` list and to `uv`; uv_da and
@@ -404,10 +416,15 @@ def texture(tex, uv, uv_da=None, mip_level_bias=None, mip=None, filter_mode='aut
         filter_mode = 'linear' if (uv_da is None and mip_level_bias is None) else 'linear-mipmap-linear'
     if filter_mode not in _FILTER and filter_mode not in _MIP_FILTER:
         raise ValueError("texture: unknown filter_mode %r" % (filter_mode,))
-    if boundary_mode not in _BOUNDARY:
+    if boundary_mode not in _BOUNDARY and boundary_mode != 'zero':
         raise NotImplementedError("texture: boundary_mode %r is not built" % (boundary_mode,))
     if tex.dim() != 4:
         raise NotImplementedError("texture: cube maps are not built")
+    if boundary_mode == 'zero':
+        if filter_mode not in _FILTER:
+            raise NotImplementedError("texture: boundary_mode 'zero' is built for the 'nearest' and 'linear' filters only")
+        padded, uv_p = zero_boundary_as_clamp(tex, uv)
+        return _Texture.apply(padded, uv_p, _FILTER[filter_mode], _BOUNDARY['clamp'])
     if filter_mode in _FILTER:
         return _Texture.apply(tex, uv, _FILTER[filter_mode], _BOUNDARY[boundary_mode])
     if uv_da is None and mip_level_bias is None:

@@ -239,10 +239,13 @@ void mesh_interpolate_bwd(const real *attr, int Ba, const real *rast, const int3
 }
 
 /* ------------------------------------------------------------------ texture */
-static int wrapi(int i, int n, int boundary) {   /* boundary: 0 wrap, 1 clamp */
+static int wrapi(int i, int n, int boundary) {   /* boundary: 0 wrap, 1 clamp, 2 zero (-1 = a texel of the all-zero extension) */
     if (boundary == 0) { i %= n; if (i < 0) i += n; return i; }
+    if (boundary == 2) return (i < 0 || i >= n) ? -1 : i;
     return i < 0 ? 0 : (i >= n ? n - 1 : i);
 }
+/* texel (iv, iu) channel c of one texture, 0 outside (boundary mode 'zero' hands out index -1) */
+static real texel(const real *tb, int iv, int iu, int Wt, int C, int c) { return (iv < 0 || iu < 0) ? (real)0 : tb[((size_t)iv * Wt + iu) * C + c]; }
 /* tex [Bt,Ht,Wt,C] with Bt in {1,B}; filter: 0 nearest, 1 linear */
 void mesh_texture_fwd(const real *tex, int Bt, const real *uv, int B, int H, int W, int Ht, int Wt, int C, int filter, int boundary, real *out) {
     size_t P = (size_t)H * W;
@@ -254,7 +257,7 @@ void mesh_texture_fwd(const real *tex, int Bt, const real *uv, int B, int H, int
             real *po = out + o * C;
             if (filter == 0) {
                 int iu = wrapi((int)floor((double)u), Wt, boundary), iv = wrapi((int)floor((double)v), Ht, boundary);
-                for (int c = 0; c < C; c++) po[c] = tb[((size_t)iv * Wt + iu) * C + c];
+                for (int c = 0; c < C; c++) po[c] = texel(tb, iv, iu, Wt, C, c);
             } else {
                 u -= (real)0.5; v -= (real)0.5;
                 real fu0 = (real)floor((double)u), fv0 = (real)floor((double)v);
@@ -262,8 +265,8 @@ void mesh_texture_fwd(const real *tex, int Bt, const real *uv, int B, int H, int
                 int iu0 = wrapi((int)fu0, Wt, boundary), iu1 = wrapi((int)fu0 + 1, Wt, boundary);
                 int iv0 = wrapi((int)fv0, Ht, boundary), iv1 = wrapi((int)fv0 + 1, Ht, boundary);
                 for (int c = 0; c < C; c++) {
-                    real t00 = tb[((size_t)iv0 * Wt + iu0) * C + c], t10 = tb[((size_t)iv0 * Wt + iu1) * C + c];
-                    real t01 = tb[((size_t)iv1 * Wt + iu0) * C + c], t11 = tb[((size_t)iv1 * Wt + iu1) * C + c];
+                    real t00 = texel(tb, iv0, iu0, Wt, C, c), t10 = texel(tb, iv0, iu1, Wt, C, c);
+                    real t01 = texel(tb, iv1, iu0, Wt, C, c), t11 = texel(tb, iv1, iu1, Wt, C, c);
                     real top = t00 + fu * (t10 - t00), bot = t01 + fu * (t11 - t01);
                     po[c] = top + fv * (bot - top);
                 }
@@ -283,7 +286,7 @@ void mesh_texture_bwd(const real *tex, int Bt, const real *uv, const real *dy, i
             const real *g = dy + o * C;
             if (filter == 0) {
                 int iu = wrapi((int)floor((double)u), Wt, boundary), iv = wrapi((int)floor((double)v), Ht, boundary);
-                for (int c = 0; c < C; c++) dtex[tbo + ((size_t)iv * Wt + iu) * C + c] += g[c];
+                if (iv >= 0 && iu >= 0) for (int c = 0; c < C; c++) dtex[tbo + ((size_t)iv * Wt + iu) * C + c] += g[c];
             } else {
                 u -= (real)0.5; v -= (real)0.5;
                 real fu0 = (real)floor((double)u), fv0 = (real)floor((double)v);
@@ -292,11 +295,14 @@ void mesh_texture_bwd(const real *tex, int Bt, const real *uv, const real *dy, i
                 int iv0 = wrapi((int)fv0, Ht, boundary), iv1 = wrapi((int)fv0 + 1, Ht, boundary);
                 real gu = 0, gv = 0;
                 for (int c = 0; c < C; c++) {
-                    size_t i00 = tbo + ((size_t)iv0 * Wt + iu0) * C + c, i10 = tbo + ((size_t)iv0 * Wt + iu1) * C + c;
-                    size_t i01 = tbo + ((size_t)iv1 * Wt + iu0) * C + c, i11 = tbo + ((size_t)iv1 * Wt + iu1) * C + c;
-                    real t00 = tex[i00], t10 = tex[i10], t01 = tex[i01], t11 = tex[i11];
-                    dtex[i00] += g[c] * ((real)1 - fu) * ((real)1 - fv); dtex[i10] += g[c] * fu * ((real)1 - fv);
-                    dtex[i01] += g[c] * ((real)1 - fu) * fv; dtex[i11] += g[c] * fu * fv;
+                    const real *tbb = tex + tbo;
+                    real *dtb = dtex + tbo;
+                    real t00 = texel(tbb, iv0, iu0, Wt, C, c), t10 = texel(tbb, iv0, iu1, Wt, C, c);
+                    real t01 = texel(tbb, iv1, iu0, Wt, C, c), t11 = texel(tbb, iv1, iu1, Wt, C, c);
+                    if (iv0 >= 0 && iu0 >= 0) dtb[((size_t)iv0 * Wt + iu0) * C + c] += g[c] * ((real)1 - fu) * ((real)1 - fv);
+                    if (iv0 >= 0 && iu1 >= 0) dtb[((size_t)iv0 * Wt + iu1) * C + c] += g[c] * fu * ((real)1 - fv);
+                    if (iv1 >= 0 && iu0 >= 0) dtb[((size_t)iv1 * Wt + iu0) * C + c] += g[c] * ((real)1 - fu) * fv;
+                    if (iv1 >= 0 && iu1 >= 0) dtb[((size_t)iv1 * Wt + iu1) * C + c] += g[c] * fu * fv;
                     gu += g[c] * ((t10 - t00) * ((real)1 - fv) + (t11 - t01) * fv);
                     gv += g[c] * ((t01 - t00) * ((real)1 - fu) + (t11 - t10) * fu);
                 }
@@ -397,6 +403,7 @@ static int mip_select(const real *da, const real *bias, int Ht, int Wt, int L, i
 /* filter: 2 = linear-mipmap-nearest, 3 = linear-mipmap-linear.  uv_da [B,H,W,4] or NULL, bias [B,H,W] or NULL (not both NULL). */
 int mesh_texture_mip_fwd(const real *tex, const real *stack, int Bt, const real *uv, const real *uv_da, const real *bias, int B, int H, int W,
                          int Ht, int Wt, int C, int filter, int boundary, int max_level, real *out) {
+    if (boundary != 0 && boundary != 1) return -1;                   /* 'zero' exists for the plain fetch only */
     mip_t m; if (mip_info(Ht, Wt, max_level, &m)) return -1;
     size_t P = (size_t)H * W;
     for (int b = 0; b < B; b++) for (size_t pid = 0; pid < P; pid++) {
@@ -427,6 +434,7 @@ int mesh_texture_mip_fwd(const real *tex, const real *stack, int Bt, const real 
 /* dtex [Bt,Ht,Wt,C], dstack [Bt,total,C], duv [B,H,W,2]: zero-initialised by the caller */
 int mesh_texture_mip_bwd(const real *tex, const real *stack, int Bt, const real *uv, const real *uv_da, const real *bias, const real *dy,
                          int B, int H, int W, int Ht, int Wt, int C, int filter, int boundary, int max_level, real *dtex, real *dstack, real *duv) {
+    if (boundary != 0 && boundary != 1) return -1;
     mip_t m; if (mip_info(Ht, Wt, max_level, &m)) return -1;
     size_t P = (size_t)H * W;
     for (int b = 0; b < B; b++) for (size_t pid = 0; pid < P; pid++) {

@@ -119,7 +119,7 @@ def interpolate_bwd(attr, rast, tri, dy, dtype=np.float32):
 
 
 _FILTER = {"nearest": 0, "linear": 1}
-_BOUNDARY = {"wrap": 0, "clamp": 1}
+_BOUNDARY = {"wrap": 0, "clamp": 1, "zero": 2}
 
 
 def texture(tex, uv, filter_mode="linear", boundary_mode="wrap", dtype=np.float32):

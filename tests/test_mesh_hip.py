@@ -145,8 +145,15 @@ def test_texture_modes_and_batches():
     assert rel_err(tt.grad.cpu().numpy(), dtex) <= GRAD_REL and rel_err(tu.grad.cpu().numpy(), duv) <= GRAD_REL
     with pytest.raises(ValueError):
         dr.texture(T(tex), T(uv), filter_mode="linear-mipmap-linear")       # mip-mapped modes need uv_da or mip_level_bias
+    # 'zero': composed in the shim from a zero-padded texture fetched in 'clamp' mode (the composition itself is checked on the CPU)
+    tz, uz = T(tex, grad=True), T(uv, grad=True)
+    out = dr.texture(tz, uz, filter_mode="linear", boundary_mode="zero")
+    assert np.abs(out.detach().cpu().numpy() - M.texture(tex, uv, "linear", "zero")).max() <= 5e-5
+    (out * T(g)).sum().backward()
+    dtex, duv = M.texture_bwd(tex, uv, g, "linear", "zero", dtype=np.float64)
+    assert rel_err(tz.grad.cpu().numpy(), dtex) <= GRAD_REL and rel_err(uz.grad.cpu().numpy(), duv) <= GRAD_REL
     with pytest.raises(NotImplementedError):
-        dr.texture(T(tex), T(uv), boundary_mode="zero")
+        dr.texture(T(tex), T(uv), boundary_mode="cube")
 
 
 def test_interpolate_variants():

@@ -342,3 +342,42 @@ def test_range_mode_known_answers():
     for b, t in ((0, 1), (1, 2)):
         m = r[b, ..., 3] == t
         assert np.array_equal(r[b][m], full[0][m])
+
+
+# ------------------------------------------------------------------------------------------------ boundary mode 'zero'
+def test_texture_zero_boundary_known_answers_gradients_and_the_clamp_composition():
+    import torch
+    import nvdiffrast.torch as dr
+    rng = np.random.default_rng(12)
+    Ht, Wt = 6, 9
+    tex = rng.normal(size=(2, Ht, Wt, 3))
+    uv = rng.uniform(-0.6, 1.6, size=(2, 11, 13, 2))
+    d = np.float64
+    for fm in ("linear", "nearest"):
+        z = M.texture(tex, uv, fm, "zero", dtype=d)
+        c = M.texture(tex, uv, fm, "clamp", dtype=d)
+        far = (uv[..., 0] < -1.0 / Wt) | (uv[..., 0] > 1 + 1.0 / Wt) | (uv[..., 1] < -1.0 / Ht) | (uv[..., 1] > 1 + 1.0 / Ht)
+        assert far.any() and (z[far] == 0).all()                       # more than a texel outside: nothing but zeros
+        inner = (uv[..., 0] > 0.5 / Wt) & (uv[..., 0] < 1 - 0.5 / Wt) & (uv[..., 1] > 0.5 / Ht) & (uv[..., 1] < 1 - 0.5 / Ht)
+        assert inner.any() and np.allclose(z[inner], c[inner], atol=1e-14)     # all four taps inside: any boundary mode agrees
+        # the composition the HIP shim uses: zero-padded texture, 'clamp', coordinates moved by one texel
+        padded, uv_p = dr.zero_boundary_as_clamp(torch.from_numpy(tex), torch.from_numpy(uv))
+        assert padded.shape == (2, Ht + 2, Wt + 2, 3) and float(padded[:, 0].abs().sum() + padded[:, :, 0].abs().sum()) == 0.0
+        comp = M.texture(padded.numpy(), uv_p.numpy(), fm, "clamp", dtype=d)
+        if fm == "linear":
+            np.testing.assert_allclose(comp, z, atol=1e-12)
+        else:
+            assert (np.abs(comp - z).max(axis=-1) > 1e-12).mean() <= 0.01        # 'nearest' may flip where u*W lands within rounding of an integer
+    one = np.ones((1, 4, 4, 1))
+    edge = np.array([[[[0.0, 0.5], [1.0 / 8, 0.5], [-1.0 / 8, 0.5]]]])          # on the border, half a texel inside, half a texel outside
+    np.testing.assert_allclose(M.texture(one, edge, "linear", "zero", dtype=d)[0, 0, :, 0], [0.5, 1.0, 0.0], atol=1e-14)
+    g = rng.normal(size=(2, 11, 13, 3))
+    dtex, duv = M.texture_bwd(tex, uv, g, "linear", "zero", dtype=d)
+    num = _fd(lambda t: M.texture(t, uv, "linear", "zero", dtype=d), tex.copy(), g, 1e-6, range(0, tex.size, 5))
+    for i, v_ in num.items():
+        assert abs(v_ - dtex.reshape(-1)[i]) < 1e-8
+    num = _fd(lambda u_: M.texture(tex, u_, "linear", "zero", dtype=d), uv.copy(), g, 1e-7, range(0, uv.size, 7))
+    for i, v_ in num.items():
+        assert abs(v_ - duv.reshape(-1)[i]) < 1e-5 * max(1.0, abs(v_))
+    with pytest.raises(AssertionError):
+        M.texture_mip(tex, uv, mip_level_bias=np.zeros((2, 11, 13)), boundary_mode="zero", max_mip_level=0, dtype=d)
