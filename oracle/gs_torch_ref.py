@@ -11,8 +11,6 @@ Two places where the dependency's backward is *not* the autograd derivative are 
 comparison is exact: the alpha cap min(0.99, .) passes gradient straight through, and the
 +-1.3 tan(fov) clamp of the projected centre blocks the gradient only of the clamped coordinate.
 """
-import math
-
 import torch
 
 C0 = 0.28209479177387814

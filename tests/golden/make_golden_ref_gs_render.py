@@ -12,7 +12,6 @@ One function of the third-party `kiui` package that the model's constructor bind
 """
 import os
 import sys
-import types
 
 import numpy as np
 import torch

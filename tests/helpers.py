@@ -1,7 +1,6 @@
 """Shared helpers for the parity tests: scene -> oracle call, scene -> HIP call."""
 import numpy as np
 
-from c3d_hip import synthetic as S
 from oracle import gs_oracle as O
 
 GS_KEYS = ("means3D", "opacities", "shs", "scales", "rotations")

@@ -63,8 +63,6 @@ def test_python_boundary_names():
 
 def test_no_cpu_fallback():
     """CPU tensors must be refused loudly -- the product path never routes around the HIP library."""
-    import numpy as np
-    import torch
     from c3d_hip import synthetic as S
     from helpers import hip_forward
     sc = S.make_small_scene(N=4)
