@@ -4,8 +4,11 @@ Host-side mirror of /root/reference/MVs_Algorithms/DiffRastMesh/diff_mesh.py (SU
 :26-56 (Adam over raw_albedo [+ v_offsets]), prepare_training :58-78, training loop :81-159 (per step `batch_size` random
 views, loss = (1-l) MSE + l (1 - MS-SSIM) on masked images, geometry regularisers when the geometry trains).
 Additive differences: `device` / `process_group` parameters (view-parallel gradient exchange, c3d_hip/parallel.py).  The periodic
-CPU remesh (:134-141, pymeshlab through kiui) is asset tooling outside the hot path: the trainer refuses to reach it."""
+CPU remesh (:134-141, pymeshlab through kiui) is asset tooling outside the hot path and is not built: the constructor says so ONCE,
+before any work is spent, and training then runs through without it (in the reference the step also replaces `v_offsets` by a fresh
+Parameter the optimizer never sees, so geometry stops training there; here it keeps training on the original topology)."""
 import random
+import warnings
 
 import torch
 import torch.nn.functional as F
@@ -52,6 +55,11 @@ class DiffMesh:
                  exchange="allreduce"):
         self.device = torch.device(device)
         self.train_mesh_geometry, self.remesh_after_n_iteration = train_mesh_geometry, remesh_after_n_iteration
+        if train_mesh_geometry and remesh_after_n_iteration and remesh_after_n_iteration < training_iterations:
+            # validated here, not 512 steps into a run: the pymeshlab remesh is CPU asset tooling outside this path
+            warnings.warn("DiffMesh: remesh_after_n_iteration=%d < training_iterations=%d asks for the periodic pymeshlab remesh, which this "
+                          "implementation does not contain; geometry training continues on the input topology without it"
+                          % (remesh_after_n_iteration, training_iterations), RuntimeWarning, stacklevel=2)
         self.renderer = DiffRastRenderer(mesh, force_cuda_rasterize).to(self.device)
         groups = self.renderer.get_params(texture_learning_rate, train_mesh_geometry, geometry_learning_rate)
         if self.device.type == "cuda":
@@ -91,9 +99,7 @@ class DiffMesh:
             r = self.renderer
             cur = r.mesh.v + r.v_offsets
             loss = loss + 0.01 * laplacian_smooth_loss(cur, r.mesh.f) + 0.001 * normal_consistency(cur, r.mesh.f) + 0.1 * (r.v_offsets ** 2).sum(-1).mean()
-            if step > 0 and self.remesh_after_n_iteration and step % self.remesh_after_n_iteration == 0:
-                raise NotImplementedError("periodic CPU remeshing (pymeshlab) is asset tooling outside the hot path; set remesh_after_n_iteration "
-                                          "above training_iterations")
+            # reference :134-141 remeshes here (pymeshlab, CPU); not built -- announced by the constructor, skipped without aborting the run
         loss.backward()
         self._exchange(world)
         self.optimizer.step()

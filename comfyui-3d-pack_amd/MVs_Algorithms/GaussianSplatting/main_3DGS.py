@@ -4,8 +4,8 @@ Host-side mirror of /root/reference/MVs_Algorithms/GaussianSplatting/main_3DGS.p
 controller :76-82, training loop :129-232 (per step: LR update :154, `batch_size` random views :158-174, loss =
 (1-l_ssim) L1 + l_alpha MSE(alpha, mask) + l_ssim (1 - MS-SSIM) :184-192, backward + Adam :205-207).
 Differences, all additive: device is a parameter; the optimizer is the fused HIP Adam; `process_group` shards the
-step's views over ranks with one gradient exchange (c3d_hip/parallel.py); densify/prune (:210-224) is a SURVEY 8f row
-and is not built yet -- the trainer refuses to run with it enabled instead of silently skipping it.
+step's views over ranks with one gradient exchange (c3d_hip/parallel.py); on a HIP device the per-view render loop of a step is
+replaced by the fused multi-view step (c3d_hip/gs_step.py) for every loss configuration, with the same per-view background draws.
 """
 import random
 from dataclasses import dataclass
@@ -96,7 +96,7 @@ class GaussianSplatting3D:
         self.ms_ssim_loss = MS_SSIM(data_range=1, size_average=True, channel=3)
         self.params = [g._xyz, g._features_dc, g._features_rest, g._opacity, g._scaling, g._rotation]
         parallel.broadcast_parameters(self.params, src=0, group=process_group)
-        self.use_fused_step, self._step = True, None       # taken whenever the loss has no MS-SSIM / offset terms (see _can_fuse)
+        self.use_fused_step, self._step = True, None       # the fused rasterizer step serves every loss configuration (see _can_fuse)
 
     def prepare_training(self, reference_images, reference_masks, reference_orbit_camera_poses, reference_orbit_camera_fovy):
         self.ref_imgs_num = len(reference_images)
@@ -189,36 +189,76 @@ class GaussianSplatting3D:
             self.params = [g._xyz, g._features_dc, g._features_rest, g._opacity, g._scaling, g._rotation]
             self._step = None                                # pair buffers / gradient buffers are sized by N
 
-    # ---- fused multi-view step (c3d_gs_train_views_raw): all of this rank's views in one sync-free library call ----
+    # ---- fused multi-view step: all of this rank's views in sync-free library calls ----
     def _can_fuse(self):
-        p, g = self.gs_params, self.renderer.gaussians
-        return (self.use_fused_step and self.device.type == "cuda" and p.lambda_ssim == 0 and p.lambda_offset == 0 and p.lambda_offset_opacity == 0
-                and g.max_sh_degree == 3 and (self.cam_controller.static_bg is not None or p.invert_bg_prob in (0.0, 1.0)))
+        """Every loss the reference's trainer can be configured with goes through the fused rasterizer step (round 2): the L1 / alpha-MSE
+        terms alone inside c3d_gs_train_views_raw, anything with MS-SSIM through the forward / backward halves with torch in between.
+        Backgrounds are per view, drawn exactly as BaseCameraController.render_at_pose draws them."""
+        g = self.renderer.gaussians
+        return self.use_fused_step and self.device.type == "cuda" and g.max_sh_degree == 3
+
+    def _image_loss(self, colors, alphas, mine):
+        """the reference's batch loss on stacked tensors (main_3DGS.py:169-192): masked images, L1 + alpha MSE + (1 - MS-SSIM)"""
+        p = self.gs_params
+        m = self.ref_masks_torch[mine]
+        imgs, refs = colors.clamp(0, 1) * m, self.ref_imgs_torch[mine] * m         # render() returns image.clamp(0, 1)
+        loss = (1 - p.lambda_ssim) * F.l1_loss(imgs, refs) + p.lambda_alpha * F.mse_loss(alphas, m)
+        if p.lambda_ssim > 0:
+            loss = loss + p.lambda_ssim * (1 - self.ms_ssim_loss(refs, imgs))
+        return loss
 
     def _fused_step(self, mine, global_batch, world, step=-1):
         import math
         from c3d_hip.gs_step import FusedViewStep
         from diff_gaussian_rasterization import GaussianRasterizationSettings
-        from shared_utils.camera_utils import orbit_camera
-        import numpy as np
         p, ctl, H, W = self.gs_params, self.cam_controller, self.ref_size_H, self.ref_size_W
+        g = self.renderer.gaussians
         if self._step is None:
             self._step = FusedViewStep(self.params[0].shape[0], H, W, self.device)
             self._flat_grads = parallel.FlatGrads(self.params)       # the kernels write into what the collective sends
             self._step_grads = self._flat_grads.views
-            self._masked_refs = self.ref_imgs_torch * self.ref_masks_torch        # the loss compares masked images (reference :169-173)
         views = []
         for i in mine:
             radius, elev, azim, cx, cy, cz = self.all_ref_cam_poses[i]
             cam = MiniCam(orbit_camera(elev, azim, radius, target=np.array([cx, cy, cz], dtype=np.float32)), W, H, ctl.cam.fovy, ctl.cam.fovx,
                           ctl.cam.near, ctl.cam.far, ctl.projection_matrix, device=self.device)
-            bg = ctl.static_bg if ctl.static_bg is not None else (ctl.white_bg if p.invert_bg_prob == 0.0 else ctl.black_bg)
+            # the background of this view: one np.random draw per view, in view order, as render_at_pose (camera_utils.py:246-249)
+            bg = ctl.static_bg if ctl.static_bg is not None else (ctl.white_bg if np.random.rand() > ctl.invert_bg_prob else ctl.black_bg)
             views.append(GaussianRasterizationSettings(H, W, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), bg, 1.0,
                                                        cam.world_view_transform, cam.full_proj_transform, 3, cam.camera_center, False, False))
-        loss = self._step.run(views, [q.detach() for q in self.params], self._step_grads, [self._masked_refs[i].contiguous() for i in mine],
-                              [self.ref_masks_torch[i].contiguous() for i in mine], [self.ref_masks_torch[i].contiguous() for i in mine],
-                              w_l1=1.0 - p.lambda_ssim, w_l2=0.0, w_alpha_mse=p.lambda_alpha, scale=1.0 / max(len(mine), 1),
-                              accumulate=False)      # every gradient is written exactly once: no zero-fill
+        n_mine = max(len(mine), 1)
+        plist = [q.detach() for q in self.params]
+        if p.lambda_ssim == 0:
+            # L1 + alpha MSE only: loss value and dL/dimage come out of the compositing epilogue, ONE library call for the whole step.
+            # (c - ref) * mask: the unmasked reference is the target and the mask the pixel weight, as the reference's (c*m - ref*m).
+            loss = self._step.run(views, plist, self._step_grads, [self.ref_imgs_torch[i].contiguous() for i in mine],
+                                  [self.ref_masks_torch[i].contiguous() for i in mine], [self.ref_masks_torch[i].contiguous() for i in mine],
+                                  w_l1=1.0, w_l2=0.0, w_alpha_mse=p.lambda_alpha, scale=1.0 / n_mine,
+                                  accumulate=False)      # every gradient is written exactly once: no zero-fill
+        elif len(mine) == 0:
+            loss = self._step.run(views, plist, self._step_grads, [], None, None, accumulate=False)       # zero gradients for a rank without views
+        else:
+            # the default loss (MS-SSIM): forward all views -> torch differentiates the image loss -> backward all views
+            colors, _, alphas, _ = self._step.forward(views, plist)
+            colors.requires_grad_(True); alphas.requires_grad_(True)
+            with torch.enable_grad():
+                loss = self._image_loss(colors, alphas, list(mine))
+                dcolor, dalpha = torch.autograd.grad(loss, [colors, alphas])
+            self._step.backward(self._step_grads, dcolor, dalpha, accumulate=False)
+            loss = loss.detach()
+        if p.lambda_offset > 0 or p.lambda_offset_opacity > 0:
+            # parameter-space regularisers (main_3DGS.py:194-203): plain autograd, added on top of what the kernels wrote
+            with torch.enable_grad():
+                off = (g.init_xyz - g._xyz).norm(dim=-1, keepdim=True)
+                reg = p.lambda_offset * off.mean() if p.lambda_offset > 0 else 0.0
+                if p.lambda_offset_opacity > 0:
+                    reg = reg + p.lambda_offset_opacity * (off.detach() * g.get_opacity).mean()
+                gx, go = torch.autograd.grad(reg, [g._xyz, g._opacity], allow_unused=True)
+            if gx is not None:
+                self._step_grads[0].add_(gx)
+            if go is not None:
+                self._step_grads[3].add_(go)
+            loss = loss + reg.detach()
         self._flat_grads.exchange(self.group, self.exchange, average=True)
         for q, gq in zip(self.params, self._step_grads):
             q.grad = gq

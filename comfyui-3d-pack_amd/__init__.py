@@ -5,10 +5,21 @@ packages `diff_gaussian_rasterization` and `nvdiffrast.torch` importable under t
 import os
 import sys
 
+import importlib
+
 ROOT_PATH = os.path.dirname(os.path.abspath(__file__))
 if ROOT_PATH not in sys.path:
-    sys.path.insert(0, ROOT_PATH)
+    sys.path.append(ROOT_PATH)      # appended, as the reference does: never shadow the host application's own modules
 
-from nodes import NODE_CLASS_MAPPINGS, NODE_DISPLAY_NAME_MAPPINGS  # noqa: E402
+# ComfyUI's own `nodes` module is what loads custom nodes, so it is already in sys.modules when this file runs: an absolute
+# `from nodes import ...` would re-export ComfyUI's mappings.  Relative import, as the reference (__init__.py: importlib.import_module('.nodes', ...)).
+if __package__:
+    _nodes = importlib.import_module(".nodes", package=__name__)
+else:                               # imported as a plain script directory (tests): load nodes.py by path under a private name
+    import importlib.util as _ilu
+    _spec = _ilu.spec_from_file_location("c3d_mi355x_nodes", os.path.join(ROOT_PATH, "nodes.py"))
+    _nodes = _ilu.module_from_spec(_spec)
+    _spec.loader.exec_module(_nodes)
+NODE_CLASS_MAPPINGS, NODE_DISPLAY_NAME_MAPPINGS = _nodes.NODE_CLASS_MAPPINGS, _nodes.NODE_DISPLAY_NAME_MAPPINGS
 
 __all__ = ["NODE_CLASS_MAPPINGS", "NODE_DISPLAY_NAME_MAPPINGS"]

@@ -46,6 +46,9 @@ _SIGNATURES = {
     "c3d_gs_step_workspace_bytes": (sz, [i32, i32, i32, i64, i32]),
     "c3d_gs_train_views_raw": (C.c_int, [C.POINTER(GsSettings), i32, i32] + [vp] * 6 + [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(GsLoss)] + [vp] * 6 + [vp, i64, i32, i32, vp, vp, vp]),
     "c3d_gs_render_views_raw": (C.c_int, [C.POINTER(GsSettings), i32, i32] + [vp] * 6 + [C.POINTER(vp)] * 4 + [i64, i32, vp, vp, vp]),
+    "c3d_gs_forward_views_raw": (C.c_int, [C.POINTER(GsSettings), i32, i32] + [vp] * 6 + [C.POINTER(vp)] * 4 + [i64, i32, vp, vp, vp]),
+    "c3d_gs_backward_views_raw": (C.c_int, [C.POINTER(GsSettings), i32, i32] + [vp] * 5 + [C.POINTER(vp)] * 3 + [vp] * 6 + [i64, i32, i32, vp, vp]),
+    "c3d_gs_set_exact_dscale": (C.c_int, [i32]),
     "c3d_gs_step_read_view": (C.c_int, [i32, i32, i32, i64, vp, i32, vp, vp, vp]),
     "c3d_gs_mark_visible": (C.c_int, [i32, vp, vp, vp, vp, vp]),
     "c3d_gs_debug_state": (C.c_int, [i32, i32, i32, vp, i64, vp] + [vp] * 7 + [vp]),
@@ -62,6 +65,9 @@ _SIGNATURES = {
 }
 
 
+ABI_VERSION = 200      # c3d_version() of the library these signatures describe
+
+
 def exported_symbols():
     """Names every include/*.h header declares (checked against the .so by the CPU test-suite)."""
     names = dict(_SIGNATURES)
@@ -74,20 +80,28 @@ def exported_symbols():
 
 
 def lib():
-    """Load (building in-tree first if the .so is absent and hipcc exists).  Raises on failure."""
+    """Load libc3d_hip.so.  With hipcc present build.build() runs first: a no-op when the source digest (csrc/*, include/*.h, flags)
+    matches the one the .so was built from, a rebuild otherwise -- a stale library is never loaded under new ctypes signatures.  Without
+    hipcc the .so must exist and report the ABI version this binding was written for.  Raises on failure; there is no fallback."""
     global _lib
     if _lib is not None:
         return _lib
     with _lock:
         if _lib is not None:
             return _lib
-        if not os.path.exists(LIB_PATH):
-            from . import build as _b
+        from . import build as _b
+        if os.path.exists(_b.HIPCC):
             try:
                 _b.build()
             except Exception as e:  # loud failure, never a fallback
-                raise RuntimeError("c3d_hip: %s is missing and could not be built: %s" % (LIB_PATH, e))
+                raise RuntimeError("c3d_hip: %s could not be built: %s" % (LIB_PATH, e))
+        elif not os.path.exists(LIB_PATH):
+            raise RuntimeError("c3d_hip: %s is missing and there is no hipcc (%s) to build it" % (LIB_PATH, _b.HIPCC))
         l = C.CDLL(LIB_PATH)
+        l.c3d_version.restype = C.c_int
+        if l.c3d_version() != ABI_VERSION:
+            raise RuntimeError("c3d_hip: %s reports ABI version %d, this binding needs %d (stale build: run c3d_hip/build.py --force)"
+                               % (LIB_PATH, l.c3d_version(), ABI_VERSION))
         for name, (res, args) in exported_symbols().items():
             fn = getattr(l, name)
             fn.restype = res

@@ -28,7 +28,9 @@ def _sources():
 
 def _digest():
     h = hashlib.sha256()
-    for f in sorted(os.listdir(CSRC)) + ["../../include/c3d_gs.h", "../../include/c3d_optim.h", "../../include/c3d_mesh.h"]:
+    inc = os.path.join(os.path.dirname(PKG), "include")
+    headers = sorted("../../include/" + f for f in os.listdir(inc) if f.endswith(".h")) if os.path.isdir(inc) else []   # every C-ABI header
+    for f in sorted(os.listdir(CSRC)) + headers:
         p = os.path.join(CSRC, f)
         if os.path.isfile(p):
             h.update(f.encode())

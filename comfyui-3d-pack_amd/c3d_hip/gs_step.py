@@ -1,7 +1,12 @@
-"""Fused multi-view 3DGS training step (c3d_gs_train_views_raw): V views forward + pixel loss + backward in ONE library call, the parameter
-gradients accumulated in place, no host synchronisation between views.  MI355X-first replacement of the per-view Python loop of the reference's
-trainer (main_3DGS.py:158-207) for the L1 / L2 / alpha-MSE part of its loss; with 288 GB of HBM the (tile, splat) pair buffers are simply sized
-for a generous capacity and grown on the rare overflow."""
+"""Fused multi-view 3DGS training step: V views forward + backward in sync-free library calls, the parameter gradients written in place.
+MI355X-first replacement of the per-view Python loop of the reference's trainer (main_3DGS.py:158-207).  Two forms:
+
+  FusedViewStep.run()                     c3d_gs_train_views_raw: forward + the L1 / L2 / alpha-MSE pixel loss + backward in ONE call
+  FusedViewStep.forward() / .backward()   c3d_gs_forward_views_raw / c3d_gs_backward_views_raw: the same step split at the image, so that any loss
+                                          torch can differentiate (the reference's default adds MS-SSIM, main_3DGS.py:184-192) runs in between;
+                                          every view carries its own background (camera_utils.py:246-249)
+
+With 288 GB of HBM the (tile, splat) pair buffers are simply sized for a generous capacity and grown on the rare overflow."""
 import ctypes as C
 import time
 
@@ -21,6 +26,7 @@ class FusedViewStep:
         self.status = torch.zeros(2, dtype=torch.int32, device=self.device)
         self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
         self._fitted = False
+        self._fwd = None
         self._alloc()
 
     def _alloc(self):
@@ -67,6 +73,7 @@ class FusedViewStep:
                                                     _h.ptr(self.status), _h.stream(self.device)), "c3d_gs_train_views_raw")
             self.last_host_ms = (time.perf_counter() - t_host) * 1e3      # host time to enqueue the whole step (no sync inside)
             st = self.status.tolist()       # the single host sync of the step
+            self._raise_on_fault(st)
             if st[0] == 0:
                 seen = st[1] & 0xFFFFFFFF
                 self._last = (self.workspace, self.capacity)     # what read_view() looks into
@@ -82,6 +89,70 @@ class FusedViewStep:
                 for g, s0 in zip(grads, snapshot):
                     g.copy_(s0)
         raise RuntimeError("c3d FusedViewStep: pair capacity still exceeded after %d retries" % max_retries)
+
+    # ---- the step split at the image --------------------------------------------------------------------------------------------------------
+    def _raise_on_fault(self, st):
+        if st[0] & 2:
+            raise RuntimeError("c3d: a bounded inter-workgroup wait of the binning stage timed out (status %r): device fault" % (st,))
+
+    def forward(self, raster_settings, params, want_depth=False, want_radii=False, max_retries=3):
+        """All V views forward, state kept per view for backward().  params: (xyz, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw).
+        -> color [V,3,H,W] (unclamped), depth [V,1,H,W] | None, alpha [V,1,H,W], radii [V,N] | None.  One host sync (overflow flag)."""
+        lib = _h.lib()
+        V = len(raster_settings)
+        f32 = dict(dtype=torch.float32, device=self.device)
+        color, alpha = torch.empty((V, 3, self.H, self.W), **f32), torch.empty((V, 1, self.H, self.W), **f32)
+        depth = torch.empty((V, 1, self.H, self.W), **f32) if want_depth else None
+        radii = torch.empty((V, self.N), dtype=torch.int32, device=self.device) if want_radii else None
+        self._fwd = None
+        if V == 0:
+            return color, depth, alpha, radii
+        if V > self.views:
+            self.views = V
+            self._alloc()
+        arr = lambda t: (C.c_void_p * V)(*[t[i].data_ptr() for i in range(V)]) if t is not None else None
+        pin = [_h.f32c(p) for p in params]
+        for attempt in range(max_retries + 1):
+            keep = []
+            views = self._settings(raster_settings, keep)
+            self.status.zero_()
+            t_host = time.perf_counter()
+            with torch.cuda.device(self.device):
+                _h.check(lib.c3d_gs_forward_views_raw(views, V, self.N, *[_h.ptr(p) for p in pin], arr(color), arr(depth), arr(alpha), arr(radii), self.capacity,
+                                                      self.lanes, _h.ptr(self.workspace), _h.ptr(self.status), _h.stream(self.device)), "c3d_gs_forward_views_raw")
+            self.last_host_ms = (time.perf_counter() - t_host) * 1e3
+            st = self.status.tolist()       # the single host sync of the forward half
+            self._raise_on_fault(st)
+            seen = st[1] & 0xFFFFFFFF
+            if st[0] == 0:
+                if not self._fitted and self.capacity > 2 * max(seen, 1 << 16):
+                    self._fitted = True
+                    self.capacity = int(seen * 1.3) + 4096      # first success: every launch is sized for the capacity -> fit it (+30 %) and redo
+                    self._alloc()
+                    continue
+                self._fitted = True
+                self._last = (self.workspace, self.capacity)
+                self._fwd = (keep, views, V, pin)               # backward() must see the very same settings / workspace
+                return color, depth, alpha, radii
+            self.capacity = int(max(seen, self.capacity) * 1.25) + 1024
+            self._alloc()
+        raise RuntimeError("c3d FusedViewStep.forward: pair capacity still exceeded after %d retries" % max_retries)
+
+    def backward(self, grads, dL_dcolor, dL_dalpha=None, dL_ddepth=None, accumulate=False):
+        """Backward of the views of the last forward(): dL_dcolor [V,3,H,W] (w.r.t. the unclamped colour), dL_dalpha / dL_ddepth [V,1,H,W] | None
+        -> parameter gradients into `grads` (overwritten, or added to with accumulate=True).  No host synchronisation."""
+        if self._fwd is None:
+            raise RuntimeError("c3d FusedViewStep.backward: no forward() state to differentiate")
+        keep, views, V, pin = self._fwd
+        g = lambda t: _h.f32c(t) if t is not None else None
+        dc, da, dd = g(dL_dcolor), g(dL_dalpha), g(dL_ddepth)
+        arr = lambda t: (C.c_void_p * V)(*[t[i].data_ptr() for i in range(V)]) if t is not None else None
+        t_host = time.perf_counter()
+        with torch.cuda.device(self.device):
+            _h.check(_h.lib().c3d_gs_backward_views_raw(views, V, self.N, _h.ptr(pin[0]), _h.ptr(pin[1]), _h.ptr(pin[2]), _h.ptr(pin[4]), _h.ptr(pin[5]), arr(dc), arr(dd), arr(da),
+                                                        *[_h.ptr(q) for q in grads], self.capacity, self.lanes, 1 if accumulate else 0, _h.ptr(self.workspace),
+                                                        _h.stream(self.device)), "c3d_gs_backward_views_raw")
+        self.last_host_ms_bwd = (time.perf_counter() - t_host) * 1e3
 
     def read_view(self, view):
         """-> (radii [N] int32, dL/dmeans2D [N,3]) of view `view` of the last run(): the densification statistics of the reference trainer"""
@@ -129,6 +200,8 @@ class FusedViewRender:
                                                      arr(radii) if want_radii else None, self.capacity, self.lanes, _h.ptr(self.workspace), _h.ptr(self.status),
                                                      _h.stream(self.device)), "c3d_gs_render_views_raw")
             st = self.status.tolist()       # the single host sync of the call
+            if st[0] & 2:
+                raise RuntimeError("c3d: a bounded inter-workgroup wait of the binning stage timed out (status %r): device fault" % (st,))
             seen = st[1] & 0xFFFFFFFF
             if st[0] == 0:
                 if not self._fitted and self.capacity > 2 * max(seen, 1 << 16):

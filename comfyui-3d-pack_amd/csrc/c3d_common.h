@@ -40,18 +40,31 @@ struct C3dProfScope {
 };
 
 // ---- scan / sort primitives (scan_sort.hip) ----
+// Single-pass (decoupled look-back) kernels.  Each primitive keeps a small state block at the head of `tmp` that must be zero when
+// its kernels start: with zero_state = true (default) the call issues the hipMemsetAsync itself; a caller that runs several
+// primitives of one view clears all their state blocks with ONE memset and passes false.
+// A timed-out inter-workgroup wait (every spin is bounded) ORs C3D_ERR_LOOKBACK into `err` (device; nullptr: the primitive's own error word).
+#define C3D_ERR_LOOKBACK 2u
 // Inclusive or exclusive prefix sum of n uint32 values. `tmp` needs c3d_scan_tmp_bytes(n).
 size_t c3d_scan_tmp_bytes(size_t n);
-int c3d_scan_u32(const uint32_t* in, uint32_t* out, size_t n, bool exclusive, void* tmp, hipStream_t s);
+int c3d_scan_u32(const uint32_t* in, uint32_t* out, size_t n, bool exclusive, void* tmp, hipStream_t s, bool zero_state = true, uint32_t* err = nullptr);
+// the same over in[idx[i]] (gather folded into the load).  tail_meta (optional, device): receives min(total, tail_cap) in [0];
+// tail_status (optional): [0] |= 1 when total > tail_cap, [1] = max(total).
+int c3d_scan_gather_u32(const uint32_t* in, const uint32_t* idx, uint32_t* out, size_t n, bool exclusive, void* tmp, hipStream_t s, bool zero_state,
+                        uint32_t* tail_meta, uint32_t* tail_status, uint32_t tail_cap, uint32_t* err = nullptr);
+uint32_t* c3d_scan_error_word(void* tmp);
 
-// Stable LSD radix sort of (key,val) uint32 pairs over key bits [0, end_bit).
+// Stable LSD radix sort of (key,val) uint32 pairs over key bits [0, end_bit), n < 2^30.
 // keys/vals are ping-pong buffers [2][n]; result index (0 or 1) is returned through *result_buf.
-// vals_in may be null on entry => values are the element indices.  tmp: c3d_sort_tmp_bytes(n).
+// iota_vals => the values are the element indices (vals0 is not read).  tmp: c3d_sort_tmp_bytes(n); the part that must be zero is
+// the first c3d_sort_state_bytes(n, end_bit) bytes.
 // n_dev (optional, device): the real element count is min(*n_dev, n) -- n is then the capacity the launch is sized for, so a
 // data-dependent count never has to come back to the host.
 size_t c3d_sort_tmp_bytes(size_t n);
+size_t c3d_sort_state_bytes(size_t n, int end_bit);
+uint32_t* c3d_sort_error_word(void* tmp);
 int c3d_sort_pairs_u32(uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32_t* vals1, bool iota_vals,
-                       size_t n, int end_bit, void* tmp, int* result_buf, hipStream_t s, const uint32_t* n_dev = nullptr);
+                       size_t n, int end_bit, void* tmp, int* result_buf, hipStream_t s, const uint32_t* n_dev = nullptr, bool zero_state = true, uint32_t* err = nullptr);
 
 // ---- device helpers ----
 #ifdef __HIPCC__

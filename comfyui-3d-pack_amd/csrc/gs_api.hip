@@ -13,6 +13,7 @@ void c3d_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+static int g_exact_dscale = 0;   // c3d_gs_set_exact_dscale
 static int tile_sort_bits(int tiles) {
     int bits = 0;
     while ((1ll << bits) < (long long)tiles) bits++;
@@ -34,6 +35,7 @@ static int make_params(const c3d_gs_settings* st, int N, int M, GsParams& p) {
     p.tanfovx = st->tanfovx; p.tanfovy = st->tanfovy;
     p.focal_x = p.W / (2.0f * st->tanfovx); p.focal_y = p.H / (2.0f * st->tanfovy);
     p.scale_modifier = st->scale_modifier;
+    p.dscale_mod = g_exact_dscale ? st->scale_modifier : 1.0f;
     p.bg = st->bg; p.view = st->viewmatrix; p.proj = st->projmatrix; p.campos = st->campos;
     return 0;
 }
@@ -50,28 +52,59 @@ static int check_inputs(int N, int M, int deg, const float* means3D, const float
     return 0;
 }
 
-// depth ordering + offsets shared by both projection entry points; the single D2H read of the pair count lives here
-static int project_tail(GsGeom& g, int N, int64_t* num_rendered, hipStream_t s) {
+// A2-A4' shared by every forward entry point: record bases (scan in Gaussian-id order), depth sort, emit offsets (scan in depth-rank
+// order, gather folded in).  Three single-pass primitives, their state cleared by ONE memset; 7 launches where round 1 issued 21.
+// cap / status: pair capacity and status words of the sync-free paths (the pair count then stays on the device in g.meta[0]).
+static int binning_front(GsGeom& g, int N, uint32_t cap, uint32_t* status, hipStream_t s) {
     int rc, res = 0;
-    { C3dProfScope ps(C3D_P_SCAN, s);   // record bases of the backward pass: tiles touched, scanned in Gaussian-id order
-    if ((rc = c3d_scan_u32(g.tiles, g.rbase, (size_t)N, true, g.tmp, s))) return rc; }
+    C3D_CHECK(hipMemsetAsync(g.meta, 0, g.zero_bytes, s));
+    uint32_t* err = status ? status : (uint32_t*)g.meta + 2;      // a timed-out look-back (bounded spins) surfaces as C3D_ERR_LOOKBACK
+    { C3dProfScope ps(C3D_P_SCAN, s);
+      if ((rc = c3d_scan_u32(g.tiles, g.rbase, (size_t)N, true, g.tmp_scan_a, s, false, err))) return rc; }
     { C3dProfScope ps(C3D_P_DEPTH_SORT, s);
-    if ((rc = c3d_sort_pairs_u32(g.key[0], g.key[1], g.order[0], g.order[1], true, (size_t)N, 32, g.tmp, &res, s))) return rc; }
+      if ((rc = c3d_sort_pairs_u32(g.key[0], g.key[1], g.order[0], g.order[1], true, (size_t)N, 32, g.tmp_sort, &res, s, nullptr, false, err))) return rc; }
     if (res != sort_result_index(32)) { c3d_set_error("internal: depth sort buffer parity"); return -2; }
     { C3dProfScope ps(C3D_P_SCAN, s);
-    if ((rc = gs_launch_gather_tiles(g, N, res, s))) return rc;
-    if ((rc = c3d_scan_u32(g.tiles_sorted, g.offsets, (size_t)N, false, g.tmp, s))) return rc; }
-    uint32_t d32 = 0;
-    C3D_CHECK(hipMemcpyAsync(&d32, g.offsets + (N - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+      if ((rc = c3d_scan_gather_u32(g.tiles, g.order[res], g.offsets, (size_t)N, false, g.tmp_scan_b, s, false, (uint32_t*)g.meta, status, cap, err))) return rc; }
+    return 0;
+}
+// tile sort + per-tile ranges; D = pair count on the host, or the capacity when d_dev (device count) is given
+static int binning_back(const GsParams& p, GsGeom& g, GsBinning& b, const int* radii, long long D, uint32_t cap, const uint32_t* d_dev, uint32_t* status,
+                        hipStream_t s, int* res_out) {
+    const int tiles = p.gx * p.gy;
+    int rc, res = 0;
+    C3D_CHECK(hipMemsetAsync(b.ranges, 0, b.zero_bytes, s));
+    *res_out = 0;
+    if (D <= 0) return 0;
+    uint32_t* err = status ? status : (uint32_t*)g.meta + 2;
+    { C3dProfScope ps(C3D_P_EMIT, s);
+      if ((rc = gs_launch_emit(p, g, sort_result_index(32), radii, b, s, cap))) return rc; }
+    { C3dProfScope ps(C3D_P_TILE_SORT, s);
+      if ((rc = c3d_sort_pairs_u32(b.tkey[0], b.tkey[1], b.tval[0], b.tval[1], false, (size_t)D, tile_sort_bits(tiles), b.tmp, &res, s, d_dev, false, err))) return rc; }
+    if (res != sort_result_index(tile_sort_bits(tiles))) { c3d_set_error("internal: tile sort buffer parity"); return -2; }
+    { C3dProfScope ps(C3D_P_RANGES, s);
+      if ((rc = gs_launch_ranges(b, res, D, tiles, s, d_dev))) return rc; }
+    *res_out = res;
+    return 0;
+}
+
+// drop-in path: the single D2H read of the pair count (the wheel has the same synchronisation) also brings back the error word
+static int project_tail(GsGeom& g, int N, int64_t* num_rendered, hipStream_t s) {
+    int rc;
+    if ((rc = binning_front(g, N, 0xFFFFFFFFu, nullptr, s))) return rc;
+    uint32_t host[4] = {0, 0, 0, 0};
+    C3D_CHECK(hipMemcpyAsync(host, g.meta, sizeof(host), hipMemcpyDeviceToHost, s));
     C3D_CHECK(hipStreamSynchronize(s));
-    *num_rendered = (int64_t)d32;
+    if (host[2] & C3D_ERR_LOOKBACK) { c3d_set_error("c3d_gs: a chained-scan look-back timed out in the binning stage (device fault or a wedged workgroup)"); return -3; }
+    *num_rendered = (int64_t)host[0];
     return 0;
 }
 
 extern "C" {
 
 const char* c3d_last_error(void) { return g_err; }
-int c3d_version(void) { return 100; }
+int c3d_version(void) { return 200; }
+int c3d_gs_set_exact_dscale(int32_t on) { const int old = g_exact_dscale; g_exact_dscale = on != 0; return old; }
 
 size_t c3d_gs_geom_bytes(int32_t N) { GsGeom g; gs_carve_geom(nullptr, N, g); return g.bytes; }
 size_t c3d_gs_binning_bytes(int64_t D, int32_t H, int32_t W) {
@@ -80,7 +113,9 @@ size_t c3d_gs_binning_bytes(int64_t D, int32_t H, int32_t W) {
     return b.bytes;
 }
 size_t c3d_gs_image_bytes(int32_t H, int32_t W) { GsImage im; gs_carve_image(nullptr, W, H, im); return im.bytes; }
-size_t c3d_gs_backward_scratch_bytes(int32_t N, int64_t D) { (void)N; return c3d_align(sizeof(float) * GS_PAIR_FLOATS * (size_t)(D > 0 ? D : 1)); }
+static size_t pairgrad_bytes(long long D) { return c3d_align(sizeof(float) * GS_PAIR_FLOATS * (size_t)(D > 0 ? D : 1)); }
+// backward scratch = one 48-byte gradient record per (tile, splat) pair, then one "record written" byte per pair
+size_t c3d_gs_backward_scratch_bytes(int32_t N, int64_t D) { (void)N; return pairgrad_bytes(D) + c3d_align((size_t)(D > 0 ? D : 1)); }
 
 int c3d_gs_forward_project(const c3d_gs_settings* st, int32_t N, int32_t M, const float* means3D, const float* shs,
                            const float* colors_precomp, const float* opacities, const float* scales,
@@ -137,16 +172,8 @@ int c3d_gs_forward_render(const c3d_gs_settings* st, int32_t N, int32_t M, const
     GsImage im;
     gs_carve_image((char*)image_buffer, p.W, p.H, im);
     int rc, res = 0;
-    if (num_rendered > 0) {
-        if (!geom_buffer || !radii) { c3d_set_error("c3d_gs_forward_render: NULL geometry"); return -1; }
-        { C3dProfScope ps(C3D_P_EMIT, s);
-        if ((rc = gs_launch_emit(p, g, sort_result_index(32), radii, b, s))) return rc; }
-        C3dProfScope ps2(C3D_P_TILE_SORT, s);
-        if ((rc = c3d_sort_pairs_u32(b.tkey[0], b.tkey[1], b.tval[0], b.tval[1], false, (size_t)num_rendered, tile_sort_bits(tiles), b.tmp, &res, s))) return rc;
-        if (res != sort_result_index(tile_sort_bits(tiles))) { c3d_set_error("internal: tile sort buffer parity"); return -2; }
-    }
-    { C3dProfScope ps(C3D_P_RANGES, s);
-    if ((rc = gs_launch_ranges(b, res, num_rendered, tiles, s))) return rc; }
+    if (num_rendered > 0 && (!geom_buffer || !radii)) { c3d_set_error("c3d_gs_forward_render: NULL geometry"); return -1; }
+    if ((rc = binning_back(p, g, b, radii, num_rendered, 0xFFFFFFFFu, nullptr, nullptr, s, &res))) return rc;
     C3dProfScope ps(C3D_P_COMPOSITE_FWD, s);
     return gs_launch_composite_fwd(p, g, b, res, im, out_color, out_depth, out_alpha, s);
 }
@@ -177,15 +204,16 @@ int c3d_gs_backward(const c3d_gs_settings* st, int32_t N, int32_t M, const float
     GsImage im;
     gs_carve_image((char*)image_buffer, p.W, p.H, im);
     float* pairgrad = (float*)scratch;   // [num_rendered][GS_PAIR_FLOATS]
+    uint8_t* pvalid = (uint8_t*)scratch + pairgrad_bytes(num_rendered);
     int rc;
     if (num_rendered > 0 && tiles > 0) {
         if (!binning_buffer || !image_buffer) { c3d_set_error("c3d_gs_backward: NULL state buffer"); return -1; }
         const int res = sort_result_index(tile_sort_bits(tiles));
         C3dProfScope ps(C3D_P_COMPOSITE_BWD, s);
-        if ((rc = gs_launch_composite_bwd(p, g, b, res, im, dL_dcolor, dL_ddepth, dL_dalpha, pairgrad, s))) return rc;
+        if ((rc = gs_launch_composite_bwd(p, g, b, res, im, dL_dcolor, dL_ddepth, dL_dalpha, pairgrad, pvalid, num_rendered, s))) return rc;
     }
     C3dProfScope ps(C3D_P_PREPROCESS_BWD, s);
-    return gs_launch_preprocess_bwd(p, g, radii, means3D, shs, colors_precomp, scales, rotations, cov3D_precomp, pairgrad, dL_dmeans2D,
+    return gs_launch_preprocess_bwd(p, g, radii, means3D, shs, colors_precomp, scales, rotations, cov3D_precomp, pairgrad, pvalid, dL_dmeans2D,
                                     dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, s);
 }
 
@@ -209,21 +237,23 @@ int c3d_gs_backward_raw(const c3d_gs_settings* st, int32_t N, const float* means
     GsImage im;
     gs_carve_image((char*)image_buffer, p.W, p.H, im);
     float* pairgrad = (float*)scratch;
+    uint8_t* pvalid = (uint8_t*)scratch + pairgrad_bytes(num_rendered);
     int rc;
     if (num_rendered > 0 && tiles > 0) {
         if (!binning_buffer || !image_buffer) { c3d_set_error("c3d_gs_backward_raw: NULL state buffer"); return -1; }
         const int res = sort_result_index(tile_sort_bits(tiles));
         C3dProfScope ps(C3D_P_COMPOSITE_BWD, s);
-        if ((rc = gs_launch_composite_bwd(p, g, b, res, im, dL_dcolor, dL_ddepth, dL_dalpha, pairgrad, s))) return rc;
+        if ((rc = gs_launch_composite_bwd(p, g, b, res, im, dL_dcolor, dL_ddepth, dL_dalpha, pairgrad, pvalid, num_rendered, s))) return rc;
     }
     C3dProfScope ps(C3D_P_PREPROCESS_BWD, s);
-    return gs_launch_preprocess_bwd_raw(p, g, radii, means3D, f_dc, f_rest, scaling_raw, rotation_raw, pairgrad, dL_dmeans2D, dL_dopacity_raw,
+    return gs_launch_preprocess_bwd_raw(p, g, radii, means3D, f_dc, f_rest, scaling_raw, rotation_raw, pairgrad, pvalid, dL_dmeans2D, dL_dopacity_raw,
                                         dL_dmeans3D, dL_df_dc, dL_df_rest, dL_dscaling_raw, dL_drotation_raw, accumulate != 0, s);
 }
 
-// ---- fused multi-view training step (no host synchronisation inside) --------------------------------------------------------
+// ---- fused multi-view paths (no host synchronisation inside) ----------------------------------------------------------------
 struct StepWs {
-    char* geom; char* binning; char* image; int* radii; float* color; float* depth; float* alpha; float* dcolor; float* dalpha; float* pairgrad; float* dmeans2D; float* gcol;
+    char* geom; char* binning; char* image; int* radii; float* color; float* depth; float* alpha; float* dcolor; float* dalpha; float* pairgrad; uint8_t* pvalid;
+    float* dmeans2D; float* gcol;
     size_t bytes;
 };
 static void carve_step(char* base, int N, int H, int W, long long cap, StepWs& w) {
@@ -238,14 +268,15 @@ static void carve_step(char* base, int N, int H, int W, long long cap, StepWs& w
     w.color = (float*)take(12 * P); w.depth = (float*)take(4 * P); w.alpha = (float*)take(4 * P);
     w.dcolor = (float*)take(12 * P); w.dalpha = (float*)take(4 * P);
     w.pairgrad = (float*)take(sizeof(float) * GS_PAIR_FLOATS * (size_t)(cap > 0 ? cap : 1));
+    w.pvalid = (uint8_t*)take((size_t)(cap > 0 ? cap : 1));
     w.dmeans2D = (float*)take(12 * n);
     w.gcol = (float*)take(12 * n);
     w.bytes = off;
 }
 
-// ---- view lanes: the V views of a step are dealt round-robin onto `lanes` HIP streams (lane 0 = the caller's stream) so that the latency-bound
+// ---- view lanes: the V views of a call are dealt round-robin onto `lanes` HIP streams (lane 0 = the caller's stream) so that the latency-bound
 // sort / scan chains of one view run underneath the VALU-bound compositing kernels of another.  Every view owns a workspace slice; after the
-// join ONE pass over the Gaussians (k_preprocess_bwd_views) turns all views' pair records into the parameter gradients.
+// join ONE pass over the Gaussians turns all views' pair records into the parameter gradients.
 #define C3D_MAX_LANES 8
 namespace {
 struct LanePool { bool init = false; hipStream_t st[C3D_MAX_LANES - 1]; hipEvent_t fork, join[C3D_MAX_LANES - 1]; };
@@ -268,6 +299,29 @@ int lane_pool(LanePool** out) {
     *out = &lp;
     return 0;
 }
+struct Lanes {
+    int L = 1; LanePool* lp = nullptr; hipStream_t s0 = nullptr; hipStream_t ls[C3D_MAX_LANES];
+    int fork(hipStream_t caller, int lanes, int V) {
+        s0 = caller; L = lanes < V ? lanes : V; ls[0] = s0;
+        if (L > 1) {
+            if (lane_pool(&lp)) return -1;
+            C3D_CHECK(hipEventRecord(lp->fork, s0));
+            for (int l = 1; l < L; l++) { ls[l] = lp->st[l - 1]; C3D_CHECK(hipStreamWaitEvent(ls[l], lp->fork, 0)); }
+        }
+        return 0;
+    }
+    // always executed, so the caller's stream never runs ahead of work queued on the lanes (also after an error)
+    int join(const char* who) {
+        int rc = 0;
+        for (int l = 1; l < L; l++) {
+            if (hipEventRecord(lp->join[l - 1], ls[l]) != hipSuccess || hipStreamWaitEvent(s0, lp->join[l - 1], 0) != hipSuccess) {
+                (void)hipDeviceSynchronize();
+                c3d_set_error("%s: lane join failed", who); rc = -1;
+            }
+        }
+        return rc;
+    }
+};
 }  // namespace
 
 // forward of one view of the fused paths (A1-A6), everything on stream s, no host synchronisation: the pair count stays on the device
@@ -275,28 +329,52 @@ int lane_pool(LanePool** out) {
 static int step_view_forward(const GsParams& p, const float* means3D, const float* f_dc, const float* f_rest, const float* opacity_raw, const float* scaling_raw,
                              const float* rotation_raw, GsGeom& g, GsBinning& b, GsImage& im, int* radii, uint32_t cap, uint32_t* status, float* color, float* depth,
                              float* alpha, hipStream_t s, int* res_out) {
-    const int tiles = p.gx * p.gy;
     int rc, res = 0;
     { C3dProfScope ps(C3D_P_PREPROCESS, s);
       if ((rc = gs_launch_preprocess_raw(p, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, g, radii, s))) return rc; }
-    { C3dProfScope ps(C3D_P_SCAN, s);   // record bases of the backward pass: tiles touched, scanned in Gaussian-id order
-      if ((rc = c3d_scan_u32(g.tiles, g.rbase, (size_t)p.N, true, g.tmp, s))) return rc; }
-    { C3dProfScope ps(C3D_P_DEPTH_SORT, s);
-      if ((rc = c3d_sort_pairs_u32(g.key[0], g.key[1], g.order[0], g.order[1], true, (size_t)p.N, 32, g.tmp, &res, s))) return rc; }
-    { C3dProfScope ps(C3D_P_SCAN, s);
-      if ((rc = gs_launch_gather_tiles(g, p.N, res, s))) return rc;
-      if ((rc = c3d_scan_u32(g.tiles_sorted, g.offsets, (size_t)p.N, false, g.tmp, s))) return rc;
-      if ((rc = gs_launch_pair_count(g, p.N, cap, status, s))) return rc; }
-    const uint32_t* d_dev = (const uint32_t*)g.meta;
-    { C3dProfScope ps(C3D_P_EMIT, s);
-      if ((rc = gs_launch_emit(p, g, sort_result_index(32), radii, b, s, cap))) return rc; }
-    { C3dProfScope ps(C3D_P_TILE_SORT, s);
-      if ((rc = c3d_sort_pairs_u32(b.tkey[0], b.tkey[1], b.tval[0], b.tval[1], false, (size_t)cap, tile_sort_bits(tiles), b.tmp, &res, s, d_dev))) return rc; }
-    { C3dProfScope ps(C3D_P_RANGES, s);
-      if ((rc = gs_launch_ranges(b, res, (long long)cap, tiles, s, d_dev))) return rc; }
+    if ((rc = binning_front(g, p.N, cap, status, s))) return rc;
+    if ((rc = binning_back(p, g, b, radii, (long long)cap, cap, (const uint32_t*)g.meta, status, s, &res))) return rc;
     { C3dProfScope ps(C3D_P_COMPOSITE_FWD, s);
       if ((rc = gs_launch_composite_fwd(p, g, b, res, im, color, depth, alpha, s))) return rc; }
     *res_out = res;
+    return 0;
+}
+
+// per-Gaussian chain rule over all views of a step, every gradient written once (chunks of GS_MAX_BWD_VIEWS views); stream s0, after the join
+static int step_a8_all_views(const c3d_gs_settings* views, int V, int N, size_t slice_bytes, void* workspace, long long pair_capacity, const float* means3D,
+                             const float* f_dc, const float* f_rest, const float* scaling_raw, const float* rotation_raw, float* dL_dmeans3D, float* dL_df_dc,
+                             float* dL_df_rest, float* dL_dopacity_raw, float* dL_dscaling_raw, float* dL_drotation_raw, bool accumulate, hipStream_t s0) {
+    const uint32_t cap = (uint32_t)pair_capacity;
+    GsParams p_first{};
+    for (int v0 = 0; v0 < V; v0 += GS_MAX_BWD_VIEWS) {
+        GsBwdViews bv;
+        bv.V = (V - v0) < GS_MAX_BWD_VIEWS ? (V - v0) : GS_MAX_BWD_VIEWS;
+        for (int i = 0; i < bv.V; i++) {
+            GsParams p;
+            if (make_params(&views[v0 + i], N, 16, p)) return -1;
+            if (v0 + i == 0) p_first = p;
+            StepWs w; carve_step((char*)workspace + (size_t)(v0 + i) * slice_bytes, N, p.H, p.W, pair_capacity, w);
+            GsGeom g; gs_carve_geom(w.geom, N, g);
+            GsBwdView& o = bv.v[i];
+            o.view = p.view; o.proj = p.proj; o.campos = p.campos; o.radii = w.radii; o.rec0 = g.rec0; o.rec1 = g.rec1; o.tiles = g.tiles; o.rbase = g.rbase;
+            o.clamped = g.clamped; o.pairgrad = (const float4*)w.pairgrad; o.pvalid = w.pvalid; o.dmean2D = w.dmeans2D; o.gcol = w.gcol;
+            o.tanfovx = p.tanfovx; o.tanfovy = p.tanfovy; o.focal_x = p.focal_x; o.focal_y = p.focal_y;
+        }
+        int rc;
+        C3dProfScope ps(C3D_P_PREPROCESS_BWD, s0);
+        if ((rc = gs_launch_preprocess_bwd_views(p_first, bv, means3D, f_dc, f_rest, scaling_raw, rotation_raw, dL_dopacity_raw, dL_dmeans3D, dL_df_dc, dL_df_rest,
+                                                 dL_dscaling_raw, dL_drotation_raw, accumulate || v0 > 0, s0, cap))) return rc;
+    }
+    return 0;
+}
+
+static int check_step_args(const char* who, const c3d_gs_settings* views, int V, int64_t pair_capacity, int lanes, const void* workspace) {
+    if (!views || !workspace) { c3d_set_error("%s: NULL pointer", who); return -1; }
+    if (pair_capacity <= 0 || pair_capacity > (int64_t)0x3FFFFFF0ll) { c3d_set_error("%s: pair_capacity out of range (1 .. 2^30 - 16)", who); return -1; }
+    if (lanes < 1 || lanes > C3D_MAX_LANES) { c3d_set_error("%s: lanes must be in [1, %d]", who, C3D_MAX_LANES); return -1; }
+    for (int v = 1; v < V; v++)
+        if (views[v].image_width != views[0].image_width || views[v].image_height != views[0].image_height || views[v].sh_degree != views[0].sh_degree ||
+            views[v].scale_modifier != views[0].scale_modifier) { c3d_set_error("%s: all views must share resolution, sh_degree and scale_modifier", who); return -1; }
     return 0;
 }
 
@@ -312,32 +390,20 @@ int c3d_gs_train_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, c
                            int32_t accumulate, void* workspace, uint32_t* status, c3d_stream_t stream) {
     hipStream_t s0 = (hipStream_t)stream;
     if (V <= 0 || N <= 0) return 0;
-    if (!views || !loss || !target_color || !workspace || !status) { c3d_set_error("c3d_gs_train_views_raw: NULL pointer"); return -1; }
-    if (pair_capacity <= 0 || pair_capacity > 0xFFFFFFF0ll) { c3d_set_error("c3d_gs_train_views_raw: pair_capacity out of range"); return -1; }
-    if (lanes < 1 || lanes > C3D_MAX_LANES) { c3d_set_error("c3d_gs_train_views_raw: lanes must be in [1, %d]", C3D_MAX_LANES); return -1; }
+    if (!loss || !target_color || !status) { c3d_set_error("c3d_gs_train_views_raw: NULL pointer"); return -1; }
+    if (check_step_args("c3d_gs_train_views_raw", views, V, pair_capacity, lanes, workspace)) return -1;
     if (!means3D || !f_dc || !f_rest || !opacity_raw || !scaling_raw || !rotation_raw || !dL_dmeans3D || !dL_df_dc || !dL_df_rest || !dL_dopacity_raw ||
         !dL_dscaling_raw || !dL_drotation_raw) { c3d_set_error("c3d_gs_train_views_raw: NULL parameter / gradient pointer"); return -1; }
     if ((uintptr_t)f_rest % 16 || (uintptr_t)dL_df_rest % 16 || (uintptr_t)rotation_raw % 16 || (uintptr_t)dL_drotation_raw % 16) { c3d_set_error("c3d_gs_train_views_raw: f_rest / rotation tensors must be 16-byte aligned"); return -1; }
     const uint32_t cap = (uint32_t)pair_capacity;
-    const int L = lanes < V ? lanes : V;
     StepWs w0; carve_step(nullptr, N, views[0].image_height, views[0].image_width, pair_capacity, w0);
-    LanePool* lp = nullptr;
-    hipStream_t ls[C3D_MAX_LANES] = {s0};
-    if (L > 1) {
-        if (lane_pool(&lp)) return -1;
-        C3D_CHECK(hipEventRecord(lp->fork, s0));
-        for (int l = 1; l < L; l++) { ls[l] = lp->st[l - 1]; C3D_CHECK(hipStreamWaitEvent(ls[l], lp->fork, 0)); }
-    }
+    Lanes ln;
+    if (ln.fork(s0, lanes, V)) return -1;
     int rc_all = 0;
-    GsParams p_first{};
     for (int v = 0; v < V && !rc_all; v++) {
-        hipStream_t s = ls[v % L];
+        hipStream_t s = ln.ls[v % ln.L];
         GsParams p;
         if (make_params(&views[v], N, 16, p)) { rc_all = -1; break; }
-        if (v == 0) p_first = p;
-        if (v > 0 && (p.W != views[0].image_width || p.H != views[0].image_height || p.deg != p_first.deg || p.scale_modifier != p_first.scale_modifier)) {
-            c3d_set_error("c3d_gs_train_views_raw: all views must share resolution, sh_degree and scale_modifier"); rc_all = -1; break;
-        }
         if (!target_color[v]) { c3d_set_error("c3d_gs_train_views_raw: target_color[%d] is NULL", v); rc_all = -1; break; }
         const int tiles = p.gx * p.gy;
         StepWs w; carve_step((char*)workspace + (size_t)v * w0.bytes, N, p.H, p.W, pair_capacity, w);
@@ -353,83 +419,104 @@ int c3d_gs_train_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, c
                                             loss->w_l2, loss->w_alpha_mse, loss->scale, w.dcolor, w.dalpha, loss_out, s))) break; }
             // backward down to the per-(tile, splat) records of this view
             { C3dProfScope ps(C3D_P_COMPOSITE_BWD, s);
-              if ((rc = gs_launch_composite_bwd(p, g, b, res, im, w.dcolor, nullptr, w.dalpha, w.pairgrad, s, cap))) break; }
+              if ((rc = gs_launch_composite_bwd(p, g, b, res, im, w.dcolor, nullptr, w.dalpha, w.pairgrad, w.pvalid, (long long)cap, s, cap))) break; }
         } while (0);
         rc_all = rc;
     }
-    // join: always executed, so the caller's stream never runs ahead of work queued on the lanes (also after an error)
-    for (int l = 1; l < L; l++) {
-        if (hipEventRecord(lp->join[l - 1], ls[l]) != hipSuccess || hipStreamWaitEvent(s0, lp->join[l - 1], 0) != hipSuccess) {
-            (void)hipDeviceSynchronize();
-            if (!rc_all) { c3d_set_error("c3d_gs_train_views_raw: lane join failed"); rc_all = -1; }
-        }
-    }
+    if (ln.join("c3d_gs_train_views_raw") && !rc_all) rc_all = -1;
     if (rc_all) return rc_all;
-    // per-Gaussian chain rule over all views, every gradient written once (chunks of GS_MAX_BWD_VIEWS views)
-    for (int v0 = 0; v0 < V; v0 += GS_MAX_BWD_VIEWS) {
-        GsBwdViews bv;
-        bv.V = (V - v0) < GS_MAX_BWD_VIEWS ? (V - v0) : GS_MAX_BWD_VIEWS;
-        for (int i = 0; i < bv.V; i++) {
-            GsParams p;
-            if (make_params(&views[v0 + i], N, 16, p)) return -1;
-            StepWs w; carve_step((char*)workspace + (size_t)(v0 + i) * w0.bytes, N, p.H, p.W, pair_capacity, w);
-            GsGeom g; gs_carve_geom(w.geom, N, g);
-            GsBwdView& o = bv.v[i];
-            o.view = p.view; o.proj = p.proj; o.campos = p.campos; o.radii = w.radii; o.rec0 = g.rec0; o.rec1 = g.rec1; o.tiles = g.tiles; o.rbase = g.rbase;
-            o.clamped = g.clamped; o.pairgrad = (const float4*)w.pairgrad; o.dmean2D = w.dmeans2D; o.gcol = w.gcol;
-            o.tanfovx = p.tanfovx; o.tanfovy = p.tanfovy; o.focal_x = p.focal_x; o.focal_y = p.focal_y;
+    return step_a8_all_views(views, V, N, w0.bytes, workspace, pair_capacity, means3D, f_dc, f_rest, scaling_raw, rotation_raw, dL_dmeans3D, dL_df_dc, dL_df_rest,
+                             dL_dopacity_raw, dL_dscaling_raw, dL_drotation_raw, accumulate != 0, s0);
+}
+
+// forward of V views; keep_state: view v uses workspace slice v (what c3d_gs_backward_views_raw reads), otherwise a lane reuses its slice view after view
+static int views_forward(const char* who, const c3d_gs_settings* views, int32_t V, int32_t N, const float* means3D, const float* f_dc, const float* f_rest,
+                         const float* opacity_raw, const float* scaling_raw, const float* rotation_raw, float* const* out_color, float* const* out_depth,
+                         float* const* out_alpha, int32_t* const* out_radii, int64_t pair_capacity, int32_t lanes, void* workspace, uint32_t* status,
+                         hipStream_t s0, bool keep_state) {
+    if (V <= 0 || N <= 0) return 0;
+    if (!out_color || !out_alpha || !status) { c3d_set_error("%s: NULL pointer", who); return -1; }
+    if (check_step_args(who, views, V, pair_capacity, lanes, workspace)) return -1;
+    if (!means3D || !f_dc || !f_rest || !opacity_raw || !scaling_raw || !rotation_raw) { c3d_set_error("%s: NULL parameter pointer", who); return -1; }
+    if ((uintptr_t)f_rest % 16 || (uintptr_t)rotation_raw % 16) { c3d_set_error("%s: f_rest / rotation tensors must be 16-byte aligned", who); return -1; }
+    const uint32_t cap = (uint32_t)pair_capacity;
+    StepWs w0; carve_step(nullptr, N, views[0].image_height, views[0].image_width, pair_capacity, w0);
+    Lanes ln;
+    if (ln.fork(s0, lanes, V)) return -1;
+    int rc_all = 0;
+    for (int v = 0; v < V && !rc_all; v++) {
+        const int lane = v % ln.L;
+        GsParams p;
+        if (make_params(&views[v], N, 16, p)) { rc_all = -1; break; }
+        if (!out_color[v] || !out_alpha[v]) { c3d_set_error("%s: output %d is NULL", who, v); rc_all = -1; break; }
+        StepWs w; carve_step((char*)workspace + (size_t)(keep_state ? v : lane) * w0.bytes, N, p.H, p.W, pair_capacity, w);
+        GsGeom g; gs_carve_geom(w.geom, N, g);
+        GsBinning b; gs_carve_binning(w.binning, pair_capacity, p.gx * p.gy, b);
+        GsImage im; gs_carve_image(w.image, p.W, p.H, im);
+        int res = 0;
+        int* radii = (!keep_state && out_radii && out_radii[v]) ? out_radii[v] : w.radii;      // kept state: the backward pass reads the slice's copy
+        float* depth = (out_depth && out_depth[v]) ? out_depth[v] : w.depth;
+        rc_all = step_view_forward(p, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, g, b, im, radii, cap, status, out_color[v], depth, out_alpha[v], ln.ls[lane], &res);
+        if (!rc_all && keep_state && out_radii && out_radii[v] &&
+            hipMemcpyAsync(out_radii[v], w.radii, sizeof(int) * (size_t)N, hipMemcpyDeviceToDevice, ln.ls[lane]) != hipSuccess) {
+            c3d_set_error("%s: radii copy failed", who); rc_all = -1;       // no early return: the lanes must still be joined
         }
-        int rc;
-        C3dProfScope ps(C3D_P_PREPROCESS_BWD, s0);
-        if ((rc = gs_launch_preprocess_bwd_views(p_first, bv, means3D, f_dc, f_rest, scaling_raw, rotation_raw, dL_dopacity_raw, dL_dmeans3D, dL_df_dc, dL_df_rest,
-                                                 dL_dscaling_raw, dL_drotation_raw, accumulate != 0 || v0 > 0, s0, cap))) return rc;
     }
-    return 0;
+    if (ln.join(who) && !rc_all) rc_all = -1;
+    return rc_all;
 }
 
 int c3d_gs_render_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, const float* means3D, const float* f_dc, const float* f_rest,
                              const float* opacity_raw, const float* scaling_raw, const float* rotation_raw, float* const* out_color, float* const* out_depth,
                              float* const* out_alpha, int32_t* const* out_radii, int64_t pair_capacity, int32_t lanes, void* workspace, uint32_t* status,
                              c3d_stream_t stream) {
+    if (V > 0 && N > 0 && !out_depth) { c3d_set_error("c3d_gs_render_views_raw: NULL pointer"); return -1; }
+    return views_forward("c3d_gs_render_views_raw", views, V, N, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, out_color, out_depth, out_alpha, out_radii,
+                         pair_capacity, lanes, workspace, status, (hipStream_t)stream, false);
+}
+
+int c3d_gs_forward_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, const float* means3D, const float* f_dc, const float* f_rest,
+                              const float* opacity_raw, const float* scaling_raw, const float* rotation_raw, float* const* out_color, float* const* out_depth,
+                              float* const* out_alpha, int32_t* const* out_radii, int64_t pair_capacity, int32_t lanes, void* workspace, uint32_t* status,
+                              c3d_stream_t stream) {
+    return views_forward("c3d_gs_forward_views_raw", views, V, N, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, out_color, out_depth, out_alpha, out_radii,
+                         pair_capacity, lanes, workspace, status, (hipStream_t)stream, true);
+}
+
+int c3d_gs_backward_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, const float* means3D, const float* f_dc, const float* f_rest,
+                               const float* scaling_raw, const float* rotation_raw, const float* const* dL_dcolor, const float* const* dL_ddepth,
+                               const float* const* dL_dalpha, float* dL_dmeans3D, float* dL_df_dc, float* dL_df_rest, float* dL_dopacity_raw, float* dL_dscaling_raw,
+                               float* dL_drotation_raw, int64_t pair_capacity, int32_t lanes, int32_t accumulate, void* workspace, c3d_stream_t stream) {
     hipStream_t s0 = (hipStream_t)stream;
     if (V <= 0 || N <= 0) return 0;
-    if (!views || !out_color || !out_depth || !out_alpha || !workspace || !status) { c3d_set_error("c3d_gs_render_views_raw: NULL pointer"); return -1; }
-    if (pair_capacity <= 0 || pair_capacity > 0xFFFFFFF0ll) { c3d_set_error("c3d_gs_render_views_raw: pair_capacity out of range"); return -1; }
-    if (lanes < 1 || lanes > C3D_MAX_LANES) { c3d_set_error("c3d_gs_render_views_raw: lanes must be in [1, %d]", C3D_MAX_LANES); return -1; }
-    if (!means3D || !f_dc || !f_rest || !opacity_raw || !scaling_raw || !rotation_raw) { c3d_set_error("c3d_gs_render_views_raw: NULL parameter pointer"); return -1; }
-    if ((uintptr_t)f_rest % 16 || (uintptr_t)rotation_raw % 16) { c3d_set_error("c3d_gs_render_views_raw: f_rest / rotation tensors must be 16-byte aligned"); return -1; }
+    if (!dL_dcolor) { c3d_set_error("c3d_gs_backward_views_raw: NULL pointer"); return -1; }
+    if (check_step_args("c3d_gs_backward_views_raw", views, V, pair_capacity, lanes, workspace)) return -1;
+    if (!means3D || !f_dc || !f_rest || !scaling_raw || !rotation_raw || !dL_dmeans3D || !dL_df_dc || !dL_df_rest || !dL_dopacity_raw || !dL_dscaling_raw ||
+        !dL_drotation_raw) { c3d_set_error("c3d_gs_backward_views_raw: NULL parameter / gradient pointer"); return -1; }
+    if ((uintptr_t)f_rest % 16 || (uintptr_t)dL_df_rest % 16 || (uintptr_t)rotation_raw % 16 || (uintptr_t)dL_drotation_raw % 16) { c3d_set_error("c3d_gs_backward_views_raw: f_rest / rotation tensors must be 16-byte aligned"); return -1; }
     const uint32_t cap = (uint32_t)pair_capacity;
-    const int L = lanes < V ? lanes : V;
     StepWs w0; carve_step(nullptr, N, views[0].image_height, views[0].image_width, pair_capacity, w0);
-    LanePool* lp = nullptr;
-    hipStream_t ls[C3D_MAX_LANES] = {s0};
-    if (L > 1) {
-        if (lane_pool(&lp)) return -1;
-        C3D_CHECK(hipEventRecord(lp->fork, s0));
-        for (int l = 1; l < L; l++) { ls[l] = lp->st[l - 1]; C3D_CHECK(hipStreamWaitEvent(ls[l], lp->fork, 0)); }
-    }
+    Lanes ln;
+    if (ln.fork(s0, lanes, V)) return -1;
     int rc_all = 0;
     for (int v = 0; v < V && !rc_all; v++) {
-        const int lane = v % L;     // a lane reuses its workspace slice view after view (stream order)
+        hipStream_t s = ln.ls[v % ln.L];
         GsParams p;
         if (make_params(&views[v], N, 16, p)) { rc_all = -1; break; }
-        if (p.W != views[0].image_width || p.H != views[0].image_height) { c3d_set_error("c3d_gs_render_views_raw: all views must share one resolution"); rc_all = -1; break; }
-        if (!out_color[v] || !out_depth[v] || !out_alpha[v]) { c3d_set_error("c3d_gs_render_views_raw: output %d is NULL", v); rc_all = -1; break; }
-        StepWs w; carve_step((char*)workspace + (size_t)lane * w0.bytes, N, p.H, p.W, pair_capacity, w);
+        if (!dL_dcolor[v]) { c3d_set_error("c3d_gs_backward_views_raw: dL_dcolor[%d] is NULL", v); rc_all = -1; break; }
+        const int tiles = p.gx * p.gy;
+        StepWs w; carve_step((char*)workspace + (size_t)v * w0.bytes, N, p.H, p.W, pair_capacity, w);
         GsGeom g; gs_carve_geom(w.geom, N, g);
-        GsBinning b; gs_carve_binning(w.binning, pair_capacity, p.gx * p.gy, b);
+        GsBinning b; gs_carve_binning(w.binning, pair_capacity, tiles, b);
         GsImage im; gs_carve_image(w.image, p.W, p.H, im);
-        int res = 0;
-        int* radii = (out_radii && out_radii[v]) ? out_radii[v] : w.radii;
-        rc_all = step_view_forward(p, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, g, b, im, radii, cap, status, out_color[v], out_depth[v], out_alpha[v], ls[lane], &res);
+        C3dProfScope ps(C3D_P_COMPOSITE_BWD, s);
+        rc_all = gs_launch_composite_bwd(p, g, b, sort_result_index(tile_sort_bits(tiles)), im, dL_dcolor[v], dL_ddepth ? dL_ddepth[v] : nullptr,
+                                         dL_dalpha ? dL_dalpha[v] : nullptr, w.pairgrad, w.pvalid, (long long)cap, s, cap);
     }
-    for (int l = 1; l < L; l++) {
-        if (hipEventRecord(lp->join[l - 1], ls[l]) != hipSuccess || hipStreamWaitEvent(s0, lp->join[l - 1], 0) != hipSuccess) {
-            (void)hipDeviceSynchronize();
-            if (!rc_all) { c3d_set_error("c3d_gs_render_views_raw: lane join failed"); rc_all = -1; }
-        }
-    }
-    return rc_all;
+    if (ln.join("c3d_gs_backward_views_raw") && !rc_all) rc_all = -1;
+    if (rc_all) return rc_all;
+    return step_a8_all_views(views, V, N, w0.bytes, workspace, pair_capacity, means3D, f_dc, f_rest, scaling_raw, rotation_raw, dL_dmeans3D, dL_df_dc, dL_df_rest,
+                             dL_dopacity_raw, dL_dscaling_raw, dL_drotation_raw, accumulate != 0, s0);
 }
 
 int c3d_gs_step_read_view(int32_t N, int32_t H, int32_t W, int64_t pair_capacity, const void* workspace, int32_t view, int32_t* radii_out,

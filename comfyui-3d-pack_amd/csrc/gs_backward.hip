@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
                                                         const float4* __restrict__ rec2, const float* __restrict__ final_T,
                                                         const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor,
                                                         const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha_px,
-                                                        float4* __restrict__ pairgrad, uint32_t cap, int sh) {
+                                                        float4* __restrict__ pairgrad, uint8_t* __restrict__ pvalid, uint32_t cap, int sh) {
     __shared__ float4 s0[BWD_ROUND];
     __shared__ float4 s1[BWD_ROUND];
     __shared__ float4 s2[BWD_ROUND];
@@ -128,7 +128,6 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
     const bool inside = pxi < p.W && pyi < p.H;
     const float pxf = (float)pxi, pyf = (float)pyi;
     const uint2 rg = ranges[tile];
-    const int todo = (int)(rg.y - rg.x);
     const size_t P = (size_t)p.W * p.H, pid = (size_t)pyi * p.W + pxi;
 
     const float T_final = inside ? final_T[pid] : 0.f;
@@ -156,18 +155,15 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
     for (int o = 32; o > 0; o >>= 1) wlast = max(wlast, __shfl_xor(wlast, o));
     wlast = __builtin_amdgcn_readfirstlane(wlast);
     if (lane == 0) s_wlast[wave] = wlast;
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     // record index of the pair (this tile, Gaussian gid): the Gaussian's record base + row-major position of the tile inside its rect
     auto emit_index = [&](uint32_t gid) -> uint32_t {
         const uint4 ei = einfo[gid];
         const int ex0 = (int)(ei.y & 0xFFFFu), ey0 = (int)(ei.y >> 16), ex1 = (int)(ei.z & 0xFFFFu);
         return ei.w + (uint32_t)((ty - ey0) * (ex1 - ex0) + (tx - ex0));
     };
-    for (int pos = upto + (int)threadIdx.x; pos < todo; pos += 256) {
-        const uint32_t e = emit_index(point_list[rg.x + pos]);
-        if (e < cap) { float4* r = pairgrad + (size_t)e * 3; r[0] = z4; r[1] = z4; r[2] = z4; }
-    }
-
+    // List positions >= upto were reached by no pixel of the tile: their pairs get NO record.  `pvalid` (one byte per pair, cleared by the
+    // launcher) marks the pairs that do; the per-Gaussian pass skips the others.  Round 1 wrote a 48-byte zero record for every unreached
+    // pair and read it back in A8 -- at the BASELINE workload roughly every other pair.
     for (int base = 0; base < upto; base += BWD_ROUND) {
         __syncthreads();
         const int n = min(BWD_ROUND, upto - base);
@@ -263,6 +259,7 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
                 out[0] = make_float4(r[0], r[1], r[2], r[3]);
                 out[1] = make_float4(r[4], r[5], r[6], r[7]);
                 out[2] = make_float4(r[8], r[9], r[10], r[11]);
+                pvalid[se[j]] = 1;
             }
         }
     }
@@ -270,11 +267,12 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
 
 int gs_launch_composite_bwd(const GsParams& p, const GsGeom& g, const GsBinning& b, int res, const GsImage& im,
                             const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
-                            float* pairgrad, hipStream_t s, uint32_t cap) {
+                            float* pairgrad, uint8_t* pvalid, long long pairs, hipStream_t s, uint32_t cap) {
     const int tiles = p.gx * p.gy;
     if (tiles == 0) return 0;
+    C3D_CHECK(hipMemsetAsync(pvalid, 0, (size_t)(pairs > 0 ? pairs : 1), s));
     hipLaunchKernelGGL(k_composite_bwd, dim3(gs_block_count(p.gx, p.gy, gs_supertile_shift())), dim3(256), 0, s, p, b.ranges, b.tval[res], g.einfo, g.rec0, g.rec1, g.rec2,
-                       im.final_T, im.n_contrib, dL_dcolor, dL_ddepth, dL_dalpha, (float4*)pairgrad, cap, gs_supertile_shift());
+                       im.final_T, im.n_contrib, dL_dcolor, dL_ddepth, dL_dalpha, (float4*)pairgrad, pvalid, cap, gs_supertile_shift());
     C3D_LAUNCH_CHECK();
     return 0;
 }
@@ -341,8 +339,10 @@ __device__ __forceinline__ void bwd_geom_chain(const float3 m, const float c3[6]
     for (int j = 0; j < 3; j++) dmean[j] += (V.m[4 * j + 2] - V.m[4 * j + 3] * mul3) * g_depth;
 }
 
-// cov3D gradient -> scale and (unnormalised-quaternion) rotation gradients; exact derivative, d/dscale carries scale_modifier
-__device__ __forceinline__ void bwd_cov_to_scale_rot(const float dcov[6], const float3 sc, const float4 q, float scale_modifier, float gs3[3], float4& dq) {
+// cov3D gradient -> scale and (unnormalised-quaternion) rotation gradients.  dscale_mod: the dependency's backward differentiates
+// Sigma = R diag(mod s)^2 R^T w.r.t. (mod s) and returns that as dL/dscale -- no `mod` factor (dscale_mod = 1, the default, identical
+// to the wheel); the exact derivative multiplies by mod (dscale_mod = scale_modifier, c3d_gs_set_exact_dscale(1)).
+__device__ __forceinline__ void bwd_cov_to_scale_rot(const float dcov[6], const float3 sc, const float4 q, float scale_modifier, float dscale_mod, float gs3[3], float4& dq) {
     float R[3][3];
     quat_to_R(q, R);
     const float s[3] = {scale_modifier * sc.x, scale_modifier * sc.y, scale_modifier * sc.z};
@@ -354,7 +354,7 @@ __device__ __forceinline__ void bwd_cov_to_scale_rot(const float dcov[6], const 
         for (int k = 0; k < 3; k++) dM[i][k] = 2.f * (Gm[i][0] * R[0][k] + Gm[i][1] * R[1][k] + Gm[i][2] * R[2][k]) * s[k];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        gs3[k] = scale_modifier * (dM[0][k] * R[0][k] + dM[1][k] * R[1][k] + dM[2][k] * R[2][k]);
+        gs3[k] = dscale_mod * (dM[0][k] * R[0][k] + dM[1][k] * R[1][k] + dM[2][k] * R[2][k]);
 #pragma unroll
         for (int i = 0; i < 3; i++) dR[i][k] = dM[i][k] * s[k];
     }
@@ -375,7 +375,7 @@ template <bool STAGED, bool RAW, bool ACC>
 __global__ void __launch_bounds__(256) k_preprocess_bwd(GsParams p, GsGeom g, const int* __restrict__ radii, const float* __restrict__ means3D,
                                                          const float* __restrict__ shs, const float* __restrict__ f_rest, const float* __restrict__ colors_precomp,
                                                          const float* __restrict__ scales, const float* __restrict__ rotations,
-                                                         const float* __restrict__ cov3D_precomp, const float4* __restrict__ pairgrad,
+                                                         const float* __restrict__ cov3D_precomp, const float4* __restrict__ pairgrad, const uint8_t* __restrict__ pvalid,
                                                          float* __restrict__ dL_dmean2D, float* __restrict__ dL_dcolors,
                                                          float* __restrict__ dL_dopacity, float* __restrict__ dL_dmeans3D,
                                                          float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh, float* __restrict__ dL_df_rest,
@@ -427,6 +427,7 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GsParams p, GsGeom g, co
         const uint32_t cnt = g.tiles[idx];
         const uint32_t e0 = g.rbase[idx], e1 = min(e0 + cnt, cap);   // cap: capacity of the pair buffers (overflow is reported, never read)
         for (uint32_t e = e0; e < e1; e++) {
+            if (!pvalid[e]) continue;
             const float4 v0 = pairgrad[(size_t)e * 3], v1 = pairgrad[(size_t)e * 3 + 1], v2 = pairgrad[(size_t)e * 3 + 2];
             pr[0] += v0.x; pr[1] += v0.y; pr[2] += v0.z; pr[3] += v0.w;
             pr[4] += v1.x; pr[5] += v1.y; pr[6] += v1.z; pr[7] += v1.w;
@@ -511,11 +512,11 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GsParams p, GsGeom g, co
     if (ACC) { dmean[0] += dL_dmeans3D[3 * idx]; dmean[1] += dL_dmeans3D[3 * idx + 1]; dmean[2] += dL_dmeans3D[3 * idx + 2]; }
     dL_dmeans3D[3 * idx] = dmean[0]; dL_dmeans3D[3 * idx + 1] = dmean[1]; dL_dmeans3D[3 * idx + 2] = dmean[2];
 
-    // cov3D -> scale, rotation (exact derivative; d/dscale carries scale_modifier)
+    // cov3D -> scale, rotation (d/dscale as the dependency returns it unless c3d_gs_set_exact_dscale(1))
     if (!cov3D_precomp) {
         float gs3[3];
         float4 dq;
-        bwd_cov_to_scale_rot(dcov, sc, q, p.scale_modifier, gs3, dq);
+        bwd_cov_to_scale_rot(dcov, sc, q, p.scale_modifier, p.dscale_mod, gs3, dq);
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             float gs_ = gs3[k];
@@ -584,6 +585,7 @@ __global__ void __launch_bounds__(256, 2) k_preprocess_bwd_views(GsParams p, GsB
                 const uint32_t cnt = vw.tiles[idx];
                 const uint32_t e0 = vw.rbase[idx], e1 = min(e0 + cnt, cap);
                 for (uint32_t e = e0; e < e1; e++) {
+                    if (!vw.pvalid[e]) continue;
                     const float4 v0 = vw.pairgrad[(size_t)e * 3], v1 = vw.pairgrad[(size_t)e * 3 + 1], v2 = vw.pairgrad[(size_t)e * 3 + 2];
                     pr[0] += v0.x; pr[1] += v0.y; pr[2] += v0.z; pr[3] += v0.w;
                     pr[4] += v1.x; pr[5] += v1.y; pr[6] += v1.z; pr[7] += v1.w;
@@ -628,7 +630,7 @@ __global__ void __launch_bounds__(256, 2) k_preprocess_bwd_views(GsParams p, GsB
         // view-independent tail: cov3D -> scale (exp') and quaternion (normalisation), then the single write of every gradient
         float gs3[3];
         float4 dq;
-        bwd_cov_to_scale_rot(dcov, sc, q, p.scale_modifier, gs3, dq);
+        bwd_cov_to_scale_rot(dcov, sc, q, p.scale_modifier, p.dscale_mod, gs3, dq);
         gs3[0] *= sc.x; gs3[1] *= sc.y; gs3[2] *= sc.z;
         {
             const float dot = dq.x * q.x + dq.y * q.y + dq.z * q.z + dq.w * q.w, inv = 1.f / qnorm;
@@ -687,6 +689,7 @@ __global__ void __launch_bounds__(256) k_bwd_views_geom(GsParams p, GsBwdViews v
             const uint32_t cnt = vw.tiles[idx];
             const uint32_t e0 = vw.rbase[idx], e1 = min(e0 + cnt, cap);
             for (uint32_t e = e0; e < e1; e++) {
+                if (!vw.pvalid[e]) continue;
                 const float4 v0 = vw.pairgrad[(size_t)e * 3], v1 = vw.pairgrad[(size_t)e * 3 + 1], v2 = vw.pairgrad[(size_t)e * 3 + 2];
                 pr[0] += v0.x; pr[1] += v0.y; pr[2] += v0.z; pr[3] += v0.w;
                 pr[4] += v1.x; pr[5] += v1.y; pr[6] += v1.z; pr[7] += v1.w;
@@ -714,7 +717,7 @@ __global__ void __launch_bounds__(256) k_bwd_views_geom(GsParams p, GsBwdViews v
     }
     float gs3[3];
     float4 dq;
-    bwd_cov_to_scale_rot(dcov, sc, q, p.scale_modifier, gs3, dq);
+    bwd_cov_to_scale_rot(dcov, sc, q, p.scale_modifier, p.dscale_mod, gs3, dq);
     gs3[0] *= sc.x; gs3[1] *= sc.y; gs3[2] *= sc.z;
     {
         const float dot = dq.x * q.x + dq.y * q.y + dq.z * q.z + dq.w * q.w, inv = 1.f / qnorm;
@@ -822,33 +825,33 @@ int gs_launch_preprocess_bwd_views(const GsParams& p0, const GsBwdViews& views, 
 
 int gs_launch_preprocess_bwd(const GsParams& p, const GsGeom& g, const int* radii, const float* means3D, const float* shs,
                              const float* colors_precomp, const float* scales, const float* rotations, const float* cov3D_precomp,
-                             const float* pairgrad, float* dL_dmean2D, float* dL_dcolors, float* dL_dopacity,
+                             const float* pairgrad, const uint8_t* pvalid, float* dL_dmean2D, float* dL_dcolors, float* dL_dopacity,
                              float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscales, float* dL_drots, hipStream_t s) {
     if (p.N == 0) return 0;
     const bool staged = shs && !colors_precomp && p.M == 16 && ((uintptr_t)shs % 16 == 0) && ((uintptr_t)dL_dsh % 16 == 0);
     if (staged)
         hipLaunchKernelGGL((k_preprocess_bwd<true, false, false>), dim3(c3d_cdiv(p.N, 256)), dim3(256), 256 * SH_ROW * sizeof(float), s, p, g, radii, means3D, shs,
-                           (const float*)nullptr, colors_precomp, scales, rotations, cov3D_precomp, (const float4*)pairgrad, dL_dmean2D, dL_dcolors, dL_dopacity,
+                           (const float*)nullptr, colors_precomp, scales, rotations, cov3D_precomp, (const float4*)pairgrad, pvalid, dL_dmean2D, dL_dcolors, dL_dopacity,
                            dL_dmeans3D, dL_dcov3D, dL_dsh, (float*)nullptr, dL_dscales, dL_drots, 0xFFFFFFFFu);
     else
         hipLaunchKernelGGL((k_preprocess_bwd<false, false, false>), dim3(c3d_cdiv(p.N, 256)), dim3(256), 0, s, p, g, radii, means3D, shs,
-                           (const float*)nullptr, colors_precomp, scales, rotations, cov3D_precomp, (const float4*)pairgrad, dL_dmean2D, dL_dcolors, dL_dopacity,
+                           (const float*)nullptr, colors_precomp, scales, rotations, cov3D_precomp, (const float4*)pairgrad, pvalid, dL_dmean2D, dL_dcolors, dL_dopacity,
                            dL_dmeans3D, dL_dcov3D, dL_dsh, (float*)nullptr, dL_dscales, dL_drots, 0xFFFFFFFFu);
     C3D_LAUNCH_CHECK();
     return 0;
 }
 int gs_launch_preprocess_bwd_raw(const GsParams& p, const GsGeom& g, const int* radii, const float* means3D, const float* f_dc, const float* f_rest,
-                                 const float* scaling_raw, const float* rotation_raw, const float* pairgrad, float* dL_dmean2D,
+                                 const float* scaling_raw, const float* rotation_raw, const float* pairgrad, const uint8_t* pvalid, float* dL_dmean2D,
                                  float* dL_dopacity_raw, float* dL_dmeans3D, float* dL_df_dc, float* dL_df_rest, float* dL_dscaling_raw,
                                  float* dL_drotation_raw, bool accumulate, hipStream_t s, uint32_t cap) {
     if (p.N == 0) return 0;
     if (accumulate)
         hipLaunchKernelGGL((k_preprocess_bwd<true, true, true>), dim3(c3d_cdiv(p.N, 256)), dim3(256), 256 * SH_ROW * sizeof(float), s, p, g, radii, means3D, f_dc, f_rest,
-                           (const float*)nullptr, scaling_raw, rotation_raw, (const float*)nullptr, (const float4*)pairgrad, dL_dmean2D, (float*)nullptr,
+                           (const float*)nullptr, scaling_raw, rotation_raw, (const float*)nullptr, (const float4*)pairgrad, pvalid, dL_dmean2D, (float*)nullptr,
                            dL_dopacity_raw, dL_dmeans3D, (float*)nullptr, dL_df_dc, dL_df_rest, dL_dscaling_raw, dL_drotation_raw, cap);
     else
         hipLaunchKernelGGL((k_preprocess_bwd<true, true, false>), dim3(c3d_cdiv(p.N, 256)), dim3(256), 256 * SH_ROW * sizeof(float), s, p, g, radii, means3D, f_dc, f_rest,
-                           (const float*)nullptr, scaling_raw, rotation_raw, (const float*)nullptr, (const float4*)pairgrad, dL_dmean2D, (float*)nullptr,
+                           (const float*)nullptr, scaling_raw, rotation_raw, (const float*)nullptr, (const float4*)pairgrad, pvalid, dL_dmean2D, (float*)nullptr,
                            dL_dopacity_raw, dL_dmeans3D, (float*)nullptr, dL_df_dc, dL_df_rest, dL_dscaling_raw, dL_drotation_raw, cap);
     C3D_LAUNCH_CHECK();
     return 0;

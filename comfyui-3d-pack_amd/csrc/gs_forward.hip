@@ -134,19 +134,6 @@ int gs_launch_preprocess_raw(const GsParams& p, const float* means3D, const floa
     return 0;
 }
 
-// tiles touched, gathered into depth-rank order (input of the offsets scan)
-__global__ void __launch_bounds__(256) k_gather_tiles(const uint32_t* __restrict__ order, const uint32_t* __restrict__ tiles,
-                                                       uint32_t* __restrict__ out, int N) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < N) out[r] = tiles[order[r]];
-}
-int gs_launch_gather_tiles(const GsGeom& g, int N, int res, hipStream_t s) {
-    if (N == 0) return 0;
-    hipLaunchKernelGGL(k_gather_tiles, dim3(c3d_cdiv(N, 256)), dim3(256), 0, s, g.order[res], g.tiles, g.tiles_sorted, N);
-    C3D_LAUNCH_CHECK();
-    return 0;
-}
-
 // ------------------------------------------------------------------------------------------
 // A3 emit: Gaussians are visited in ascending (depth, id) rank, each writes one (tile, id) pair per
 // touched tile.  A stable sort by tile id afterwards leaves every tile's list depth-ordered.
@@ -188,21 +175,9 @@ __global__ void __launch_bounds__(256) k_ranges(const uint32_t* __restrict__ tke
     if (i == 0 || tkey[i - 1] != t) ranges[t].x = (uint32_t)i;
     if (i == D - 1 || tkey[i + 1] != t) ranges[t].y = (uint32_t)(i + 1);
 }
-// pair count kept on the device: meta[0] = min(total, cap) (what the sort / ranges kernels use), status[0] |= overflow, status[1] = max total
-__global__ void k_pair_count(const uint32_t* __restrict__ offsets, int N, uint32_t cap, uint32_t* __restrict__ meta, uint32_t* __restrict__ status) {
-    const uint32_t tot = offsets[N - 1];
-    meta[0] = tot < cap ? tot : cap;
-    if (status) { if (tot > cap) atomicOr(&status[0], 1u); atomicMax(&status[1], tot); }
-}
-int gs_launch_pair_count(const GsGeom& g, int N, uint32_t cap, uint32_t* status, hipStream_t s) {
-    if (N == 0) return 0;
-    hipLaunchKernelGGL(k_pair_count, dim3(1), dim3(1), 0, s, g.offsets, N, cap, (uint32_t*)g.meta, status);
-    C3D_LAUNCH_CHECK();
-    return 0;
-}
-
+// `ranges` must be zero on entry: the binning stage clears it together with the tile-sort state (GsBinning::zero_bytes)
 int gs_launch_ranges(const GsBinning& b, int res, long long D, int tiles, hipStream_t s, const uint32_t* d_dev) {
-    C3D_CHECK(hipMemsetAsync(b.ranges, 0, sizeof(uint2) * (size_t)(tiles > 0 ? tiles : 1), s));
+    (void)tiles;
     if (D == 0) return 0;
     hipLaunchKernelGGL(k_ranges, dim3(c3d_cdiv(D, 256)), dim3(256), 0, s, b.tkey[res], b.ranges, D, d_dev);
     C3D_LAUNCH_CHECK();

@@ -7,6 +7,7 @@
 struct GsParams {
     int N, M, deg, W, H, gx, gy;
     float tanfovx, tanfovy, focal_x, focal_y, scale_modifier;
+    float dscale_mod;    // factor on dL/dscale: 1 = as the dependency's backward (default), scale_modifier = exact derivative
     const float* bg;     // [3]   device
     const float* view;   // [16]  device, row-major storage of w2c^T (camera_utils.py:205)
     const float* proj;   // [16]  device, full projection, same storage (camera_utils.py:213)
@@ -27,13 +28,16 @@ struct GsGeom {
     uint32_t* tiles;        // tiles touched per Gaussian (0 = culled)
     uint32_t* key[2];       // depth-sort keys (float bits of view depth; 0xFFFFFFFF = culled)
     uint32_t* order[2];     // Gaussian ids, ping-pong; after stage 1 order[res] is rank -> id
-    uint32_t* tiles_sorted; // tiles touched in rank order
-    uint32_t* offsets;      // inclusive scan of tiles_sorted (rank order)
+    uint32_t* offsets;      // inclusive scan of the tile counts in depth-rank order
     uint4* einfo;           // per emitted Gaussian: {first emit index, x0 | y0<<16, x1 | y1<<16, record base} of its tile rect
     uint32_t* rbase;        // exclusive scan of `tiles` in Gaussian-id order: where this Gaussian's backward gradient records start
     uint8_t* clamped;       // 3 bits per Gaussian: SH colour channel clamped at 0
-    int* meta;              // [0] = result buffer index of the depth sort, [1] = num_rendered (device copy)
-    void* tmp;              // scan / sort scratch
+    int* meta;              // [0] = min(num_rendered, capacity) (device copy)  [2] = error word of the binning chain (C3D_ERR_LOOKBACK)
+    void* tmp;              // state of the three single-pass primitives of a view, side by side (ONE memset from `meta` clears them all):
+    void* tmp_scan_a;       //   exclusive scan of `tiles` in Gaussian-id order -> rbase
+    void* tmp_sort;         //   depth sort
+    void* tmp_scan_b;       //   inclusive scan of the tile counts in depth-rank order -> offsets
+    size_t zero_bytes;      // bytes to clear, starting at `meta`
     size_t bytes;
 };
 static inline void gs_carve_geom(char* base, int N, GsGeom& g) {
@@ -47,14 +51,16 @@ static inline void gs_carve_geom(char* base, int N, GsGeom& g) {
     g.key[1] = (uint32_t*)take(4 * n);
     g.order[0] = (uint32_t*)take(4 * n);
     g.order[1] = (uint32_t*)take(4 * n);
-    g.tiles_sorted = (uint32_t*)take(4 * n);
     g.offsets = (uint32_t*)take(4 * n);
     g.einfo = (uint4*)take(16 * n);
     g.rbase = (uint32_t*)take(4 * n);
     g.clamped = (uint8_t*)take(n);
+    const size_t meta_off = off;
     g.meta = (int*)take(64);
-    size_t t1 = c3d_sort_tmp_bytes(n), t2 = c3d_scan_tmp_bytes(n);
-    g.tmp = take(t1 > t2 ? t1 : t2);
+    g.tmp = g.tmp_scan_a = take(c3d_scan_tmp_bytes(n));
+    g.tmp_scan_b = take(c3d_scan_tmp_bytes(n));
+    g.tmp_sort = take(c3d_sort_tmp_bytes(n));                       // last: only its first c3d_sort_state_bytes need clearing
+    g.zero_bytes = (off - c3d_sort_tmp_bytes(n)) - meta_off + c3d_sort_state_bytes(n, 32);
     g.bytes = off;
 }
 
@@ -67,8 +73,9 @@ struct GsBinning {
     uint32_t* tkey[2];
     uint32_t* tval[2];
     uint2* ranges;   // [tiles]
-    int* meta;       // [0] = result buffer index of the tile sort
-    void* tmp;
+    int* meta;
+    void* tmp;       // tile-sort state; `ranges`, `meta` and the state are adjacent: ONE memset of zero_bytes from `ranges` clears them
+    size_t zero_bytes;
     size_t bytes;
 };
 static inline void gs_carve_binning(char* base, long long D, int tiles, GsBinning& b) {
@@ -78,9 +85,13 @@ static inline void gs_carve_binning(char* base, long long D, int tiles, GsBinnin
     b.tkey[1] = (uint32_t*)take(4 * d);
     b.tval[0] = (uint32_t*)take(4 * d);
     b.tval[1] = (uint32_t*)take(4 * d);
+    const size_t ranges_off = off;
     b.ranges = (uint2*)take(8 * (size_t)(tiles > 0 ? tiles : 1));
     b.meta = (int*)take(64);
     b.tmp = take(c3d_sort_tmp_bytes(d));
+    int bits = 1;
+    while ((1ll << bits) < (long long)tiles) bits++;
+    b.zero_bytes = (off - c3d_sort_tmp_bytes(d)) - ranges_off + c3d_sort_state_bytes(d, bits);
     b.bytes = off;
 }
 
@@ -106,6 +117,7 @@ struct GsBwdView {
     const float4* rec0; const float4* rec1;
     const uint32_t* tiles; const uint32_t* rbase; const uint8_t* clamped;
     const float4* pairgrad;
+    const uint8_t* pvalid;                                       // one byte per pair: 1 = the compositing backward wrote a record
     float* dmean2D;                                              // [N,3] per-view screen-space gradient (densification statistic)
     float* gcol;                                                 // [N,3] per-view dL/dcolour after the clamp mask (hand-over between the two A8 kernels)
     float tanfovx, tanfovy, focal_x, focal_y;
@@ -122,12 +134,10 @@ int gs_launch_preprocess(const GsParams& p, const float* means3D, const float* s
 int gs_launch_preprocess_raw(const GsParams& p, const float* means3D, const float* f_dc, const float* f_rest, const float* opacity_raw,
                              const float* scaling_raw, const float* rotation_raw, GsGeom& g, int* radii, hipStream_t s);
 int gs_launch_preprocess_bwd_raw(const GsParams& p, const GsGeom& g, const int* radii, const float* means3D, const float* f_dc, const float* f_rest,
-                                 const float* scaling_raw, const float* rotation_raw, const float* pairgrad, float* dL_dmean2D,
+                                 const float* scaling_raw, const float* rotation_raw, const float* pairgrad, const uint8_t* pvalid, float* dL_dmean2D,
                                  float* dL_dopacity_raw, float* dL_dmeans3D, float* dL_df_dc, float* dL_df_rest, float* dL_dscaling_raw,
                                  float* dL_drotation_raw, bool accumulate, hipStream_t s, uint32_t cap = 0xFFFFFFFFu);
-int gs_launch_gather_tiles(const GsGeom& g, int N, int res, hipStream_t s);
 int gs_launch_emit(const GsParams& p, const GsGeom& g, int res, const int* radii, GsBinning& b, hipStream_t s, uint32_t cap = 0xFFFFFFFFu);
-int gs_launch_pair_count(const GsGeom& g, int N, uint32_t cap, uint32_t* status, hipStream_t s);
 int gs_launch_loss_grad(const float* color, const float* alpha, const float* tcolor, const float* talpha, const float* cmask, long long P, float w_l1, float w_l2, float w_a,
                         float scale, float* dcolor, float* dalpha, float* loss_out, hipStream_t s);
 int gs_launch_ranges(const GsBinning& b, int res, long long D, int tiles, hipStream_t s, const uint32_t* d_dev = nullptr);
@@ -135,9 +145,9 @@ int gs_launch_composite_fwd(const GsParams& p, const GsGeom& g, const GsBinning&
                             float* out_color, float* out_depth, float* out_alpha, hipStream_t s);
 int gs_launch_composite_bwd(const GsParams& p, const GsGeom& g, const GsBinning& b, int res, const GsImage& im,
                             const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
-                            float* pairgrad /* [D][12] */, hipStream_t s, uint32_t cap = 0xFFFFFFFFu);
+                            float* pairgrad /* [D][12] */, uint8_t* pvalid /* [D], cleared here */, long long pairs, hipStream_t s, uint32_t cap = 0xFFFFFFFFu);
 int gs_launch_preprocess_bwd(const GsParams& p, const GsGeom& g, const int* radii, const float* means3D, const float* shs,
                              const float* colors_precomp, const float* scales, const float* rotations, const float* cov3D_precomp,
-                             const float* pairgrad, float* dL_dmean2D, float* dL_dcolors, float* dL_dopacity,
+                             const float* pairgrad, const uint8_t* pvalid, float* dL_dmean2D, float* dL_dcolors, float* dL_dopacity,
                              float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscales, float* dL_drots, hipStream_t s);
 int gs_launch_mark_visible(int N, const float* means3D, const float* view, const float* proj, uint8_t* present, hipStream_t s);

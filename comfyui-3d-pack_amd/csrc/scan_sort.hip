@@ -1,13 +1,30 @@
-// scan_sort.hip -- device-wide prefix sum and stable LSD radix sort for gfx950.
+// scan_sort.hip -- device-wide prefix sum and stable LSD radix sort for gfx950, single pass over the data per launch.
 //
-// These replace the cub::DeviceScan / cub::DeviceRadixSort calls of the dependency's binning
-// stage.  Written for wave64: digit ranking uses 64-bit ballots
-// (one match mask per lane from 8 ballots) and mbcnt prefix counts instead of 32-lane warp votes.
+// These replace the cub::DeviceScan / cub::DeviceRadixSort calls of the dependency's binning stage.
+// Written for wave64: digit ranking uses 64-bit ballots (one match mask per lane from 8 ballots) and mbcnt prefix counts
+// instead of 32-lane warp votes.
+//
+// Round 2: both primitives are "chained scan with decoupled look-back" kernels -- ONE launch per scan and ONE launch per radix
+// digit (plus one histogram launch per sort) instead of three launches per scan / per digit.  The binning chain of a view is
+// latency bound (10-30 us kernels that cannot fill 256 CUs), so launches and re-reads of the keys are what it pays for:
+//   depth sort  12 launches -> 5     tile sort  6 -> 3     scans  8 -> 2
+// Inter-workgroup protocol (MI355X_MICROARCH.md "Workgroup dispatch, XCD placement & inter-workgroup visibility"):
+//   * a workgroup takes its tile index from a ticket counter, so every tile it will ever wait for belongs to a workgroup that is
+//     already running -- no assumption about dispatch order or residency;
+//   * what a tile publishes is ONE self-contained word {flag, value} written and polled with relaxed agent-scope atomics (sc1:
+//     write-through / L1-bypassing on gfx950), so no fence is needed and the 8 non-coherent XCD L2s cannot serve a stale flag;
+//   * every spin is bounded: on a timeout the kernel raises an error word the host turns into an exception, it never hangs the GPU.
 #include "c3d_common.h"
 
 #define SCAN_THREADS 256
 #define SCAN_ITEMS 8
 #define SCAN_TILE (SCAN_THREADS * SCAN_ITEMS)
+#define LB_SPIN_LIMIT (1u << 21)     // polls of one word before a workgroup gives up (~0.1 s): bounded, never a hang
+
+__device__ __forceinline__ void st_agent32(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t ld_agent32(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent64(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long ld_agent64(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // exclusive prefix of `v` across the 256-thread block; *total = block sum.  lds: >= 4 uints.
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* lds, uint32_t* total) {
@@ -27,144 +44,183 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* lds, u
     return base + incl - v;
 }
 
-__global__ void __launch_bounds__(SCAN_THREADS) k_scan_block_sums(const uint32_t* __restrict__ in, uint32_t* __restrict__ sums, size_t n) {
-    __shared__ uint32_t lds[4];
-    size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
-    uint32_t s = 0;
-#pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; i++)
-        if (base + i < n) s += in[base + i];
-    uint32_t tot;
-    block_excl_scan(s, lds, &tot);
-    if (threadIdx.x == 0) sums[blockIdx.x] = tot;
-}
+// ------------------------------------------------------------------------------------------
+// Single-pass scan.  State (zeroed before every launch): [0] ticket, [1] error, then one 64-bit word per tile:
+// flag << 32 | value with flag 1 = "tile aggregate", 2 = "inclusive prefix".  Wave 0 looks back over 64 predecessors per step.
+// GATHER: element i of the input is in[idx[i]] (the tile counts read in depth-rank order: the gather kernel is folded in).
+// `tail` (optional): what used to be k_pair_count -- the workgroup that owns element n-1 knows the grand total and leaves
+// min(total, cap) in tail_meta[0], the overflow flag / largest total in tail_status.
+// ------------------------------------------------------------------------------------------
+#define LB_AGG 1ull
+#define LB_INCL 2ull
+struct ScanTail { uint32_t* meta; uint32_t* status; uint32_t cap; };
 
-// single block: exclusive scan of m values in place
-__global__ void __launch_bounds__(SCAN_THREADS) k_scan_small_excl(uint32_t* __restrict__ a, size_t m) {
+template <bool EXCL, bool GATHER>
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_lb(const uint32_t* __restrict__ in, const uint32_t* __restrict__ idx, uint32_t* __restrict__ out, size_t n,
+                                                           uint32_t* __restrict__ state, uint32_t* __restrict__ err, ScanTail tail) {
     __shared__ uint32_t lds[4];
-    uint32_t carry = 0;
-    for (size_t c = 0; c < m; c += SCAN_THREADS * 4) {
-        size_t base = c + (size_t)threadIdx.x * 4;
-        uint32_t v[4];
-        uint32_t s = 0;
-#pragma unroll
-        for (int i = 0; i < 4; i++) { v[i] = (base + i < m) ? a[base + i] : 0u; s += v[i]; }
-        uint32_t tot;
-        uint32_t ex = block_excl_scan(s, lds, &tot) + carry;
-#pragma unroll
-        for (int i = 0; i < 4; i++) { if (base + i < m) a[base + i] = ex; ex += v[i]; }
-        carry += tot;
-    }
-}
-
-template <bool EXCL>
-__global__ void __launch_bounds__(SCAN_THREADS) k_scan_apply(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
-                                                              const uint32_t* __restrict__ sums, size_t n) {
-    __shared__ uint32_t lds[4];
-    size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
+    __shared__ uint32_t s_tile, s_prefix;
+    unsigned long long* status = reinterpret_cast<unsigned long long*>(state + 2);
+    if (threadIdx.x == 0) s_tile = atomicAdd(&state[0], 1u);
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const size_t base = (size_t)tile * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
+    if ((size_t)tile * SCAN_TILE >= n) return;
     uint32_t v[SCAN_ITEMS];
     uint32_t s = 0;
 #pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; i++) { v[i] = (base + i < n) ? in[base + i] : 0u; s += v[i]; }
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        v[i] = (base + i < n) ? (GATHER ? in[idx[base + i]] : in[base + i]) : 0u;
+        s += v[i];
+    }
     uint32_t tot;
-    uint32_t run = block_excl_scan(s, lds, &tot) + sums[blockIdx.x];
+    const uint32_t ex = block_excl_scan(s, lds, &tot);
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        if (lane == 0) st_agent64(&status[tile], ((tile == 0 ? LB_INCL : LB_AGG) << 32) | tot);
+        uint32_t prefix = 0;
+        if (tile > 0) {
+            long long t0 = (long long)tile - 1;
+            for (;;) {
+                const long long t = t0 - lane;
+                unsigned long long w = t >= 0 ? ld_agent64(&status[t]) : (LB_INCL << 32);   // below tile 0: an inclusive prefix of zero
+                uint64_t incl_mask;
+                int first_incl;
+                uint32_t spins = 0;
+                for (;;) {
+                    const uint32_t flag = (uint32_t)(w >> 32);
+                    incl_mask = __ballot(flag == (uint32_t)LB_INCL);
+                    const uint64_t notready = __ballot(flag == 0u);
+                    first_incl = incl_mask ? (int)__builtin_ctzll(incl_mask) : 63;
+                    const uint64_t relevant = first_incl >= 63 ? ~0ull : ((2ull << first_incl) - 1ull);
+                    if ((notready & relevant) == 0ull) break;
+                    if (++spins > LB_SPIN_LIMIT) { if (lane == 0) atomicOr(err, C3D_ERR_LOOKBACK); incl_mask = 1ull; first_incl = 0; w = 0; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                    if (flag == 0u) w = ld_agent64(&status[t]);
+                }
+                uint32_t contrib = (lane <= first_incl) ? (uint32_t)w : 0u;
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) contrib += __shfl_xor(contrib, o, 64);
+                prefix += contrib;
+                if (incl_mask) break;
+                t0 -= 64;
+            }
+            if (lane == 0) st_agent64(&status[tile], (LB_INCL << 32) | (uint32_t)(prefix + tot));
+        }
+        if (lane == 0) s_prefix = prefix;
+    }
+    __syncthreads();
+    uint32_t run = ex + s_prefix;
 #pragma unroll
     for (int i = 0; i < SCAN_ITEMS; i++) {
         if (EXCL) { if (base + i < n) out[base + i] = run; run += v[i]; }
         else      { run += v[i]; if (base + i < n) out[base + i] = run; }
     }
+    if (tail.meta && base < n && base + SCAN_ITEMS >= n) {      // this thread owns element n-1: `run` is the grand total
+        const uint32_t total = run;
+        tail.meta[0] = total < tail.cap ? total : tail.cap;
+        if (tail.status) { if (total > tail.cap) atomicOr(&tail.status[0], 1u); atomicMax(&tail.status[1], total); }
+    }
 }
 
-size_t c3d_scan_tmp_bytes(size_t n) { return c3d_align(sizeof(uint32_t) * (size_t)(c3d_cdiv((long long)n, SCAN_TILE) + 1)); }
+size_t c3d_scan_tmp_bytes(size_t n) { return c3d_align(8 + sizeof(unsigned long long) * (size_t)(c3d_cdiv((long long)(n ? n : 1), SCAN_TILE) + 1)); }
 
-int c3d_scan_u32(const uint32_t* in, uint32_t* out, size_t n, bool exclusive, void* tmp, hipStream_t s) {
+// `zero_state`: false when the caller has already cleared tmp (one memset for several primitives of a view)
+static int scan_launch(const uint32_t* in, const uint32_t* idx, uint32_t* out, size_t n, bool exclusive, void* tmp, hipStream_t s, bool zero_state, ScanTail tail, uint32_t* err) {
     if (n == 0) return 0;
-    int nb = c3d_cdiv((long long)n, SCAN_TILE);
-    uint32_t* sums = (uint32_t*)tmp;
-    hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(SCAN_THREADS), 0, s, in, sums, n);
-    hipLaunchKernelGGL(k_scan_small_excl, dim3(1), dim3(SCAN_THREADS), 0, s, sums, (size_t)nb);
-    if (exclusive) hipLaunchKernelGGL(k_scan_apply<true>, dim3(nb), dim3(SCAN_THREADS), 0, s, in, out, sums, n);
-    else           hipLaunchKernelGGL(k_scan_apply<false>, dim3(nb), dim3(SCAN_THREADS), 0, s, in, out, sums, n);
+    if (zero_state) C3D_CHECK(hipMemsetAsync(tmp, 0, c3d_scan_tmp_bytes(n), s));
+    const int nb = c3d_cdiv((long long)n, SCAN_TILE);
+    uint32_t* st = (uint32_t*)tmp;
+    if (!err) err = st + 1;
+    if (idx) {
+        if (exclusive) hipLaunchKernelGGL((k_scan_lb<true, true>), dim3(nb), dim3(SCAN_THREADS), 0, s, in, idx, out, n, st, err, tail);
+        else           hipLaunchKernelGGL((k_scan_lb<false, true>), dim3(nb), dim3(SCAN_THREADS), 0, s, in, idx, out, n, st, err, tail);
+    } else {
+        if (exclusive) hipLaunchKernelGGL((k_scan_lb<true, false>), dim3(nb), dim3(SCAN_THREADS), 0, s, in, idx, out, n, st, err, tail);
+        else           hipLaunchKernelGGL((k_scan_lb<false, false>), dim3(nb), dim3(SCAN_THREADS), 0, s, in, idx, out, n, st, err, tail);
+    }
     C3D_LAUNCH_CHECK();
     return 0;
 }
+int c3d_scan_u32(const uint32_t* in, uint32_t* out, size_t n, bool exclusive, void* tmp, hipStream_t s, bool zero_state, uint32_t* err) {
+    return scan_launch(in, nullptr, out, n, exclusive, tmp, s, zero_state, ScanTail{nullptr, nullptr, 0u}, err);
+}
+int c3d_scan_gather_u32(const uint32_t* in, const uint32_t* idx, uint32_t* out, size_t n, bool exclusive, void* tmp, hipStream_t s, bool zero_state,
+                        uint32_t* tail_meta, uint32_t* tail_status, uint32_t tail_cap, uint32_t* err) {
+    return scan_launch(in, idx, out, n, exclusive, tmp, s, zero_state, ScanTail{tail_meta, tail_status, tail_cap}, err);
+}
+uint32_t* c3d_scan_error_word(void* tmp) { return (uint32_t*)tmp + 1; }
 
 // ------------------------------------------------------------------------------------------
-// Radix sort pass: 8-bit digits, 4096 keys per 256-thread block, each wave owns a contiguous
-// 1024-key chunk so that ranking is stable by construction.  Three kernels per pass:
-//   k_radix_hist     per-block digit histogram -> table[digit][block], digit totals by integer atomics
-//   k_radix_rowscan  one wave per digit: exclusive scan of its table row on top of the digit's base
-//   k_radix_scatter  ballot ranking, block-local reorder in LDS, then run-contiguous global stores
+// Radix sort ("onesweep"): 8-bit digits, 4096 keys per 256-thread workgroup, each wave owns a contiguous 1024-key chunk so that
+// ranking is stable by construction.
+//   k_radix_hist_all  ONE read of the keys: global digit histograms of ALL passes (digit totals are permutation invariant)
+//   k_onesweep        per digit: ballot ranking, per-digit chained scan over the tiles (look-back, 12 predecessors in flight per
+//                     lane), block-local reorder in LDS, run-contiguous global stores
+// State (zeroed before every sort): ghist[passes][256] | ticket[passes], error | status[passes][tiles][256] (flag << 30 | count).
 // ------------------------------------------------------------------------------------------
 #define RS_THREADS 256
 #define RS_ITEMS 16
 #define RS_TILE (RS_THREADS * RS_ITEMS)
 #define RS_RADIX 256
+#define RS_MAX_PASSES 4
+#define RS_FLAG_AGG (1u << 30)
+#define RS_FLAG_INCL (2u << 30)
+#define RS_VALUE_MASK ((1u << 30) - 1u)
+#define RS_LOOKBACK 12
 
-__global__ void __launch_bounds__(RS_THREADS) k_radix_hist(const uint32_t* __restrict__ keys, uint32_t* __restrict__ table,
-                                                            uint32_t* __restrict__ total, size_t n, const uint32_t* __restrict__ n_dev, int shift, int nblocks) {
-    __shared__ uint32_t h[RS_RADIX];
+__global__ void __launch_bounds__(RS_THREADS) k_radix_hist_all(const uint32_t* __restrict__ keys, uint32_t* __restrict__ ghist, size_t n,
+                                                                const uint32_t* __restrict__ n_dev, int passes) {
+    __shared__ uint32_t h[RS_MAX_PASSES][RS_RADIX];
     if (n_dev) n = min((size_t)*n_dev, n);      // element count resident on the device (no host round trip)
-    size_t base = (size_t)blockIdx.x * RS_TILE;
-    if (base >= n) { table[(size_t)threadIdx.x * nblocks + blockIdx.x] = 0; return; }   // capacity-sized launch: nothing here
-    h[threadIdx.x] = 0;
+    const size_t base = (size_t)blockIdx.x * RS_TILE;
+    if (base >= n) return;                      // capacity-sized launch: nothing here
+    for (int p = 0; p < passes; p++) h[p][threadIdx.x] = 0;
     __syncthreads();
     const int lane = c3d_lane();
-#pragma unroll
+#pragma unroll 4
     for (int i = 0; i < RS_ITEMS; i++) {
-        size_t idx = base + (size_t)i * RS_THREADS + threadIdx.x;
+        const size_t idx = base + (size_t)i * RS_THREADS + threadIdx.x;
         const bool ok = idx < n;
-        const uint32_t d = ok ? ((keys[idx] >> shift) & (RS_RADIX - 1)) : 0u;
-        // high digits of depth keys / tile ids are nearly constant: a wave whose lanes all hold one digit adds its count once
-        // instead of serialising 64 LDS atomics on one counter
+        const uint32_t k = ok ? keys[idx] : 0u;
         const uint64_t okm = __ballot(ok);
-        const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
-        if (okm && __ballot(ok && d == d0) == okm) {
-            if (lane == (int)__builtin_ctzll(okm)) atomicAdd(&h[d0], (uint32_t)__popcll(okm));
-        } else if (ok) atomicAdd(&h[d], 1u);
+        for (int p = 0; p < passes; p++) {
+            const uint32_t d = (k >> (8 * p)) & (RS_RADIX - 1);
+            // high digits of depth keys / tile ids are nearly constant: a wave whose lanes all hold one digit adds its count once
+            // instead of serialising 64 LDS atomics on one counter
+            const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
+            if (okm && __ballot(ok && d == d0) == okm) {
+                if (lane == (int)__builtin_ctzll(okm)) atomicAdd(&h[p][d0], (uint32_t)__popcll(okm));
+            } else if (ok) atomicAdd(&h[p][d], 1u);
+        }
     }
     __syncthreads();
-    const uint32_t c = h[threadIdx.x];
-    table[(size_t)threadIdx.x * nblocks + blockIdx.x] = c;  // digit-major
-    if (c) atomicAdd(&total[threadIdx.x], c);
-}
-
-__global__ void __launch_bounds__(RS_THREADS) k_radix_rowscan(uint32_t* __restrict__ table, const uint32_t* __restrict__ total, int nblocks) {
-    const int lane = c3d_lane();
-    const int d = blockIdx.x * (RS_THREADS / 64) + (threadIdx.x >> 6);   // one wave per digit
-    uint32_t s = 0;
-#pragma unroll
-    for (int i = 0; i < RS_RADIX / 64; i++) { const int dd = i * 64 + lane; if (dd < d) s += total[dd]; }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
-    uint32_t carry = s;
-    uint32_t* row = table + (size_t)d * nblocks;
-    for (int b0 = 0; b0 < nblocks; b0 += 64) {
-        const int b = b0 + lane;
-        const uint32_t v = (b < nblocks) ? row[b] : 0u;
-        const uint32_t incl = c3d_wave_incl_scan(v);
-        if (b < nblocks) row[b] = carry + incl - v;
-        carry += __shfl(incl, 63, 64);
+    for (int p = 0; p < passes; p++) {
+        const uint32_t c = h[p][threadIdx.x];
+        if (c) atomicAdd(&ghist[p * RS_RADIX + threadIdx.x], c);
     }
 }
 
 template <bool IOTA>
-__global__ void __launch_bounds__(RS_THREADS) k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-                                                               uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
-                                                               const uint32_t* __restrict__ table, size_t n, const uint32_t* __restrict__ n_dev,
-                                                               int shift, int nblocks) {
+__global__ void __launch_bounds__(RS_THREADS, 4) k_onesweep(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                                          uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                          const uint32_t* __restrict__ ghist, uint32_t* __restrict__ ticket, uint32_t* __restrict__ err,
+                                                          uint32_t* __restrict__ status, size_t n, const uint32_t* __restrict__ n_dev, int shift) {
     __shared__ uint32_t whist[RS_THREADS / 64][RS_RADIX];
-    if (n_dev) n = min((size_t)*n_dev, n);
     __shared__ uint32_t lstart[RS_RADIX];    // first local slot of each digit
     __shared__ uint32_t gbase[RS_RADIX];     // global position of that slot
     __shared__ uint32_t skey[RS_TILE];
     __shared__ uint32_t sval[RS_TILE];
     __shared__ uint32_t scan_lds[4];
+    __shared__ uint32_t s_tile;
+    if (n_dev) n = min((size_t)*n_dev, n);
+    if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
     const int lane = c3d_lane(), wave = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < (RS_THREADS / 64) * RS_RADIX; i += RS_THREADS) (&whist[0][0])[i] = 0;
     __syncthreads();
-
-    const size_t bbase = (size_t)blockIdx.x * RS_TILE;
+    const uint32_t tile = s_tile;
+    const size_t bbase = (size_t)tile * RS_TILE;
+    if (bbase >= n) return;                  // capacity-sized launch: tickets beyond the data leave at once (nobody waits for them)
     const size_t wbase = bbase + (size_t)wave * (RS_TILE / 4);
     uint32_t key[RS_ITEMS], val[RS_ITEMS], rank[RS_ITEMS];
 #pragma unroll
@@ -192,17 +248,46 @@ __global__ void __launch_bounds__(RS_THREADS) k_radix_scatter(const uint32_t* __
         rank[i] = prefix + r;
     }
     __syncthreads();
-    {   // thread d: digit count over the 4 waves -> block-local exclusive start; per-wave offsets
+    {   // thread d owns digit d: count over the 4 waves -> block-local exclusive start, per-wave offsets, and the digit's chained scan
         const int d = threadIdx.x;
         uint32_t c[RS_THREADS / 64], tot = 0;
 #pragma unroll
         for (int w = 0; w < RS_THREADS / 64; w++) { c[w] = whist[w][d]; tot += c[w]; }
-        uint32_t blk_total;
+        uint32_t* mine = status + (size_t)tile * RS_RADIX + d;
+        st_agent32(mine, (tile == 0 ? RS_FLAG_INCL : RS_FLAG_AGG) | tot);      // published first: successors can already add it up
+        uint32_t blk_total, dummy;
         uint32_t ls = block_excl_scan(tot, scan_lds, &blk_total);
+        const uint32_t digit_base = block_excl_scan(ghist[d], scan_lds, &dummy);   // where digit d starts in the output
         lstart[d] = ls;
-        gbase[d] = table[(size_t)d * nblocks + blockIdx.x];
 #pragma unroll
         for (int w = 0; w < RS_THREADS / 64; w++) { whist[w][d] = ls; ls += c[w]; }
+        uint32_t excl = 0;
+        if (tile > 0) {
+            long long t = (long long)tile - 1;
+            bool done = false;
+            while (!done) {
+                uint32_t w[RS_LOOKBACK];
+#pragma unroll
+                for (int i = 0; i < RS_LOOKBACK; i++) w[i] = (t - i >= 0) ? ld_agent32(status + (size_t)(t - i) * RS_RADIX + d) : RS_FLAG_INCL;
+#pragma unroll
+                for (int i = 0; i < RS_LOOKBACK; i++) {
+                    if (!done) {
+                        uint32_t x = w[i];
+                        uint32_t spins = 0;
+                        while ((x >> 30) == 0u) {
+                            if (++spins > LB_SPIN_LIMIT) { atomicOr(err, C3D_ERR_LOOKBACK); x = RS_FLAG_INCL; break; }
+                            __builtin_amdgcn_s_sleep(2);
+                            x = ld_agent32(status + (size_t)(t - i) * RS_RADIX + d);
+                        }
+                        excl += x & RS_VALUE_MASK;
+                        done = (x >> 30) == 2u;
+                    }
+                }
+                t -= RS_LOOKBACK;
+            }
+            st_agent32(mine, RS_FLAG_INCL | (excl + tot));
+        }
+        gbase[d] = digit_base + excl;
     }
     __syncthreads();
 #pragma unroll
@@ -216,7 +301,7 @@ __global__ void __launch_bounds__(RS_THREADS) k_radix_scatter(const uint32_t* __
         }
     }
     __syncthreads();
-    const int cnt = (bbase >= n) ? 0 : (int)((n - bbase) < (size_t)RS_TILE ? (n - bbase) : (size_t)RS_TILE);
+    const int cnt = (int)((n - bbase) < (size_t)RS_TILE ? (n - bbase) : (size_t)RS_TILE);
 #pragma unroll
     for (int i = 0; i < RS_ITEMS; i++) {
         const int lp = i * RS_THREADS + threadIdx.x;     // consecutive lanes -> consecutive slots of a digit run
@@ -230,36 +315,45 @@ __global__ void __launch_bounds__(RS_THREADS) k_radix_scatter(const uint32_t* __
     }
 }
 
-#define RS_MAX_PASSES 4
+static inline size_t sort_head_bytes() { return c3d_align(sizeof(uint32_t) * (RS_RADIX * RS_MAX_PASSES + RS_MAX_PASSES + 4)); }
 size_t c3d_sort_tmp_bytes(size_t n) {
-    size_t nb = (size_t)c3d_cdiv((long long)(n ? n : 1), RS_TILE);
-    return c3d_align(sizeof(uint32_t) * RS_RADIX * nb) + c3d_align(sizeof(uint32_t) * RS_RADIX * RS_MAX_PASSES);
+    const size_t nb = (size_t)c3d_cdiv((long long)(n ? n : 1), RS_TILE);
+    return sort_head_bytes() + c3d_align(sizeof(uint32_t) * RS_RADIX * nb * RS_MAX_PASSES);
+}
+uint32_t* c3d_sort_error_word(void* tmp) { return (uint32_t*)tmp + RS_RADIX * RS_MAX_PASSES + RS_MAX_PASSES; }
+size_t c3d_sort_state_bytes(size_t n, int end_bit) {
+    int passes = (end_bit + 7) / 8;
+    if (passes < 1) passes = 1;
+    if (passes > RS_MAX_PASSES) passes = RS_MAX_PASSES;
+    return sort_head_bytes() + sizeof(uint32_t) * RS_RADIX * (size_t)c3d_cdiv((long long)(n ? n : 1), RS_TILE) * passes;
 }
 
 int c3d_sort_pairs_u32(uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32_t* vals1, bool iota_vals,
-                       size_t n, int end_bit, void* tmp, int* result_buf, hipStream_t s, const uint32_t* n_dev) {
+                       size_t n, int end_bit, void* tmp, int* result_buf, hipStream_t s, const uint32_t* n_dev, bool zero_state, uint32_t* err_out) {
     *result_buf = 0;
     if (n == 0) return 0;
     if (end_bit > 8 * RS_MAX_PASSES) { c3d_set_error("c3d_sort_pairs_u32: end_bit %d > %d", end_bit, 8 * RS_MAX_PASSES); return -1; }
-    int nb = c3d_cdiv((long long)n, RS_TILE);
-    uint32_t* table = (uint32_t*)tmp;
-    uint32_t* totals = (uint32_t*)((char*)tmp + c3d_align(sizeof(uint32_t) * RS_RADIX * (size_t)nb));
-    C3D_CHECK(hipMemsetAsync(totals, 0, sizeof(uint32_t) * RS_RADIX * RS_MAX_PASSES, s));
+    if (n > (size_t)RS_VALUE_MASK) { c3d_set_error("c3d_sort_pairs_u32: %zu elements exceed the 2^30 - 1 the chained scan's status words hold", n); return -1; }
+    int passes = (end_bit + 7) / 8;
+    if (passes < 1) passes = 1;
+    const int nb = c3d_cdiv((long long)n, RS_TILE);
+    uint32_t* ghist = (uint32_t*)tmp;
+    uint32_t* tickets = ghist + RS_RADIX * RS_MAX_PASSES;
+    uint32_t* err = err_out ? err_out : c3d_sort_error_word(tmp);
+    uint32_t* status = (uint32_t*)((char*)tmp + sort_head_bytes());
+    if (zero_state) C3D_CHECK(hipMemsetAsync(tmp, 0, c3d_sort_state_bytes(n, end_bit), s));
     uint32_t* k[2] = {keys0, keys1};
     uint32_t* v[2] = {vals0, vals1};
-    int cur = 0, pass = 0;
-    bool first = true;
-    for (int shift = 0; shift < end_bit || first; shift += 8, pass++) {
-        uint32_t* tot = totals + pass * RS_RADIX;
-        hipLaunchKernelGGL(k_radix_hist, dim3(nb), dim3(RS_THREADS), 0, s, k[cur], table, tot, n, n_dev, shift, nb);
-        hipLaunchKernelGGL(k_radix_rowscan, dim3(RS_RADIX / (RS_THREADS / 64)), dim3(RS_THREADS), 0, s, table, tot, nb);
-        if (first && iota_vals)
-            hipLaunchKernelGGL(k_radix_scatter<true>, dim3(nb), dim3(RS_THREADS), 0, s, k[cur], v[cur], k[cur ^ 1], v[cur ^ 1], table, n, n_dev, shift, nb);
+    hipLaunchKernelGGL(k_radix_hist_all, dim3(nb), dim3(RS_THREADS), 0, s, keys0, ghist, n, n_dev, passes);
+    int cur = 0;
+    for (int pass = 0; pass < passes; pass++) {
+        uint32_t* st = status + (size_t)pass * RS_RADIX * nb;
+        if (pass == 0 && iota_vals)
+            hipLaunchKernelGGL(k_onesweep<true>, dim3(nb), dim3(RS_THREADS), 0, s, k[cur], v[cur], k[cur ^ 1], v[cur ^ 1], ghist + pass * RS_RADIX, tickets + pass, err, st, n, n_dev, 8 * pass);
         else
-            hipLaunchKernelGGL(k_radix_scatter<false>, dim3(nb), dim3(RS_THREADS), 0, s, k[cur], v[cur], k[cur ^ 1], v[cur ^ 1], table, n, n_dev, shift, nb);
+            hipLaunchKernelGGL(k_onesweep<false>, dim3(nb), dim3(RS_THREADS), 0, s, k[cur], v[cur], k[cur ^ 1], v[cur ^ 1], ghist + pass * RS_RADIX, tickets + pass, err, st, n, n_dev, 8 * pass);
         C3D_LAUNCH_CHECK();
         cur ^= 1;
-        first = false;
     }
     *result_buf = cur;
     return 0;

@@ -257,15 +257,20 @@ class Gaussian_Splatting_3D:
         if batch_size > len(reference_images):
             _warn(self, "Batch size %d is bigger than number of reference images %d! Set batch size to %d instead" % (batch_size, len(reference_images), len(reference_images)))
             batch_size = len(reference_images)
-        if points_cloud_to_initialize_gaussian is not None or mesh_to_initialize_gaussian is not None:
-            raise NotImplementedError("point-cloud / mesh initialisers need simple_knn.distCUDA2 (init-only, out of scope): pass ply_to_initialize_gaussian or nothing")
+        # initialiser precedence of the reference (nodes.py:1294-1299): point cloud, else ply, else mesh (None -> random ball)
+        if points_cloud_to_initialize_gaussian is not None:
+            gs_init_input = points_cloud_to_initialize_gaussian
+        elif ply_to_initialize_gaussian is not None:
+            gs_init_input = ply_to_initialize_gaussian
+        else:
+            gs_init_input = mesh_to_initialize_gaussian
         with torch.inference_mode(False):
             p = GSParams(training_iterations, batch_size, ms_ssim_loss_weight, alpha_loss_weight, offset_loss_weight, offset_opacity_loss_weight,
                          invert_background_probability, feature_learning_rate, opacity_learning_rate, scaling_learning_rate, rotation_learning_rate,
                          position_learning_rate_init, position_learning_rate_final, position_learning_rate_delay_mult, position_learning_rate_max_steps,
                          initial_gaussians_num, K_nearest_neighbors, percent_dense, density_start_iterations, density_end_iterations,
                          densification_interval, opacity_reset_interval, densify_grad_threshold, gaussian_sh_degree)
-            gs = GaussianSplatting3D(p, ply_to_initialize_gaussian)
+            gs = GaussianSplatting3D(p, gs_init_input)
             gs.prepare_training(reference_images, reference_masks, reference_orbit_camera_poses, reference_orbit_camera_fovy)
             gs.training()
             return (gs.renderer.gaussians.to_ply(),)

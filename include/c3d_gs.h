@@ -62,6 +62,12 @@ typedef struct c3d_gs_settings {
 const char* c3d_last_error(void);
 int c3d_version(void);
 
+/* dL/dscale convention.  0 (default): as the dependency's backward returns it -- Sigma = R diag(m s)^2 R^T is differentiated w.r.t.
+ * (m s) and handed back as dL/dscale, i.e. WITHOUT the scale_modifier factor m (identical to the exact derivative at m = 1, the only
+ * value the reference trains with; main_3DGS_renderer.py:830 exposes `scaling_modifier` for inference).  1: the exact derivative
+ * (x m).  Process-wide; returns the previous value. */
+int c3d_gs_set_exact_dscale(int32_t on);
+
 /* sizes (bytes) of the three opaque state buffers (geometry / binning / image) */
 size_t c3d_gs_geom_bytes(int32_t N);
 size_t c3d_gs_binning_bytes(int64_t num_rendered, int32_t image_height, int32_t image_width);
@@ -87,7 +93,7 @@ int c3d_gs_forward_render(const c3d_gs_settings* st, int32_t N, int32_t M, const
  * dL_dalpha[1,H,W] (may be NULL).  Outputs (all written in full by the library, no pre-zeroing needed):
  * dL_dmeans2D[N,3] dL_dcolors[N,3] dL_dopacity[N,1] dL_dmeans3D[N,3] dL_dcov3D[N,6] dL_dsh[N,M,3]
  * dL_dscales[N,3] dL_drotations[N,4].  scratch: c3d_gs_backward_scratch_bytes(N, num_rendered) bytes (one 48-byte gradient
- * record per (tile, splat) pair; the backward pass uses no atomics and is bit-reproducible). */
+ * record per (tile, splat) pair + one "record written" byte per pair; the backward pass uses no atomics and is bit-reproducible). */
 int c3d_gs_backward(const c3d_gs_settings* st, int32_t N, int32_t M, const float* means3D, const float* shs,
                     const float* colors_precomp, const float* scales, const float* rotations,
                     const float* cov3D_precomp, const int32_t* radii, const void* geom_buffer, int64_t num_rendered,
@@ -119,7 +125,8 @@ int c3d_gs_backward_raw(const c3d_gs_settings* st, int32_t N, const float* means
  * GaussianSplatting3D.training (main_3DGS.py:158-207) when the loss is the L1 / L2 / alpha-MSE part (no MS-SSIM).
  * Nothing in the call synchronises with the host: the data-dependent number of (tile, splat) pairs stays on the device and every
  * launch is sized for `pair_capacity`.  status[0] becomes non-zero if a view needed more pairs than that (results are then
- * invalid: enlarge and redo the step), status[1] holds the largest pair count seen.  loss_out (device float) accumulates the value
+ * invalid: enlarge and redo the step; bit 0 = pair overflow, bit 1 = a bounded inter-workgroup wait of the binning stage timed
+ * out, which indicates a device fault), status[1] holds the largest pair count seen.  loss_out (device float) accumulates the value
  *   scale * sum_v [ w_l1 mean|clamp(C_v,0,1) - Ct_v| + w_l2 mean(clamp(C_v,0,1) - Ct_v)^2 + w_alpha_mse mean(A_v - At_v)^2 ].
  * target_color / target_alpha / color_mask: HOST arrays of V device pointers ([3,H,W] / [1,H,W] / [1,H,W]); target_alpha and color_mask may be
  * NULL.  With color_mask the colour terms compare (C * mask) with (Ct * mask), the reference's masked loss (main_3DGS.py:169-186). */
@@ -149,7 +156,28 @@ int c3d_gs_render_views_raw(const c3d_gs_settings* views /* host [V] */, int32_t
                             float* const* out_color, float* const* out_depth, float* const* out_alpha, int32_t* const* out_radii,
                             int64_t pair_capacity, int32_t lanes, void* workspace, uint32_t* status /* device [2] */, c3d_stream_t stream);
 
-/* Per-view by-products of the last c3d_gs_train_views_raw call, copied out of its workspace (same N / H / W / pair_capacity): radii [N] (int32)
+/* ---- the same step split at the image (round 2): any loss torch can differentiate --------------------------------------------
+ * The reference's default loss adds 0.2 * (1 - MS-SSIM) to the L1 / alpha-MSE terms and draws a white or black background per view
+ * (main_3DGS.py:184-192, camera_utils.py:246-249; node defaults nodes.py:1177,1181).  MS-SSIM stays a torch op; so that the
+ * rasterizer side of such a step is still ONE sync-free call per direction, the fused step is also offered in two halves:
+ *   c3d_gs_forward_views_raw   = c3d_gs_render_views_raw, but view v keeps its state in workspace slice v
+ *                                (c3d_gs_step_workspace_bytes(N, H, W, pair_capacity, V)); every view has its own settings, incl. bg
+ *   c3d_gs_backward_views_raw  = the backward half of c3d_gs_train_views_raw for caller-supplied image gradients: HOST arrays of V
+ *                                device pointers dL_dcolor [3,H,W] (w.r.t. the UNclamped colour output), dL_ddepth [1,H,W] and
+ *                                dL_dalpha [1,H,W] (either array, or entries of it, may be NULL = zero).  Must follow a
+ *                                c3d_gs_forward_views_raw call with the same views / N / pair_capacity / workspace whose status was clean.
+ * c3d_gs_step_read_view serves both.  out_depth (array or entries) may be NULL here. */
+int c3d_gs_forward_views_raw(const c3d_gs_settings* views /* host [V] */, int32_t V, int32_t N, const float* means3D, const float* f_dc,
+                             const float* f_rest, const float* opacity_raw, const float* scaling_raw, const float* rotation_raw,
+                             float* const* out_color, float* const* out_depth, float* const* out_alpha, int32_t* const* out_radii,
+                             int64_t pair_capacity, int32_t lanes, void* workspace, uint32_t* status /* device [2] */, c3d_stream_t stream);
+int c3d_gs_backward_views_raw(const c3d_gs_settings* views /* host [V] */, int32_t V, int32_t N, const float* means3D, const float* f_dc,
+                              const float* f_rest, const float* scaling_raw, const float* rotation_raw, const float* const* dL_dcolor,
+                              const float* const* dL_ddepth, const float* const* dL_dalpha, float* dL_dmeans3D, float* dL_df_dc,
+                              float* dL_df_rest, float* dL_dopacity_raw, float* dL_dscaling_raw, float* dL_drotation_raw,
+                              int64_t pair_capacity, int32_t lanes, int32_t accumulate, void* workspace, c3d_stream_t stream);
+
+/* Per-view by-products of the last c3d_gs_train_views_raw / c3d_gs_backward_views_raw call, copied out of its workspace (same N / H / W / pair_capacity): radii [N] (int32)
  * and the screen-space positional gradient dL/dmeans2D [N,3] of view `view` -- the densification statistics of the reference's trainer
  * (main_3DGS.py:210-213, main_3DGS_renderer.py:767-769).  Either output may be NULL. */
 int c3d_gs_step_read_view(int32_t N, int32_t image_height, int32_t image_width, int64_t pair_capacity, const void* workspace, int32_t view,

@@ -55,6 +55,10 @@ typedef REAL real;
 #define BLOCK_X 16
 #define BLOCK_Y 16
 
+/* dL/dscale convention (see the backward pass): 0 = as the dependency returns it (default), 1 = exact derivative */
+static int g_exact_dscale = 0;
+int gs_oracle_set_exact_dscale(int on) { int old = g_exact_dscale; g_exact_dscale = on != 0; return old; }
+
 static const double SH_C0 = 0.28209479177387814;
 static const double SH_C1 = 0.4886025119029199;
 static const double SH_C2[5] = {1.0925484305920792, -1.0925484305920792, 0.31539156525252005,
@@ -614,8 +618,8 @@ void gs_oracle_backward(gs_state *st, const real *means3D, const real *shs, cons
         }
         for (int j = 0; j < 3; j++) dL_dmeans3D[3 * idx + j] = dmean[j];
 
-        /* cov3D -> scale, rotation.  (d/dscale carries the scale_modifier factor: exact derivative;
-         * identical to the dependency for scale_modifier == 1, the only value the reference trains with.) */
+        /* cov3D -> scale, rotation.  d/dscale as the dependency returns it: the derivative w.r.t. (scale_modifier * scale),
+         * i.e. without the scale_modifier factor; gs_oracle_set_exact_dscale(1) switches to the exact derivative. */
         if (!cov3D_precomp) {
             const real *q = rotations + 4 * idx, *sc = scales + 3 * idx;
             real R[3][3]; quat_to_R(q, R);
@@ -629,7 +633,7 @@ void gs_oracle_backward(gs_state *st, const real *means3D, const real *shs, cons
                     dM[i][k] = (real)2 * (Gm[i][0] * R[0][k] + Gm[i][1] * R[1][k] + Gm[i][2] * R[2][k]) * s[k];
             real dR[3][3];
             for (int k = 0; k < 3; k++) {
-                dL_dscales[3 * idx + k] = st->scale_modifier * (dM[0][k] * R[0][k] + dM[1][k] * R[1][k] + dM[2][k] * R[2][k]);
+                dL_dscales[3 * idx + k] = (g_exact_dscale ? st->scale_modifier : (real)1) * (dM[0][k] * R[0][k] + dM[1][k] * R[1][k] + dM[2][k] * R[2][k]);
                 for (int i = 0; i < 3; i++) dR[i][k] = dM[i][k] * s[k];
             }
             real r = q[0], x = q[1], y = q[2], z = q[3];

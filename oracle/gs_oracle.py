@@ -32,8 +32,7 @@ def _lib(dtype):
         return _LIBS[dtype]
     name = "libgs_oracle_f32.so" if dtype == np.float32 else "libgs_oracle_f64.so"
     path = os.path.join(_HERE, "_build", name)
-    if not os.path.exists(path):
-        build()
+    build()                     # make: a no-op when the shared objects are newer than gs_oracle.c
     lib = C.CDLL(path)
     real = C.c_float if dtype == np.float32 else C.c_double
     P = C.c_void_p
@@ -53,6 +52,15 @@ def _lib(dtype):
     assert lib.gs_oracle_sizeof_real() == dtype.itemsize
     _LIBS[dtype] = lib
     return lib
+
+
+def set_exact_dscale(on):
+    """dL/dscale convention of both builds: False (default) = as the dependency's backward returns it (no scale_modifier factor),
+    True = exact derivative.  -> previous setting"""
+    old = False
+    for dt in (np.float32, np.float64):
+        old = bool(_lib(dt).gs_oracle_set_exact_dscale(1 if on else 0))
+    return old
 
 
 def _arr(x, dtype, shape=None):

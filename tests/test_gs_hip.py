@@ -1,5 +1,7 @@
 """Parity tests proper (-m gpu): the HIP path, called through the C-ABI, against the CPU oracle on the same seeded
-inputs.  Tolerances are the north star's: image L1 <= 1e-4, gradients <= 1e-3 relative (max-norm), integers exact."""
+inputs.  Tolerances are the north star's: image L1 <= 1e-4, gradients <= 1e-3 relative, integers exact.  "Relative" for gradients is
+held three ways against the FLOAT64 oracle (helpers.assert_grad_close): per-tensor relative L2, the element-wise bound
+|got - ref| <= 1e-3 |ref| + 1e-6 max|ref|, and the max-norm of round 1."""
 import ctypes as C
 import os
 
@@ -9,11 +11,16 @@ import torch
 
 from c3d_hip import synthetic as S
 from oracle import gs_oracle as O
-from helpers import hip_forward, hip_settings, oracle_forward, rel_err
+from helpers import assert_grad_close, hip_forward, hip_settings, oracle_forward, rel_err
 
 pytestmark = pytest.mark.gpu
 IMG_L1 = 1e-4
 GRAD_REL = 1e-3
+# element-wise gradient bound (helpers.assert_grad_close): share of elements allowed outside 1e-3 |ref| + 1e-6 max|ref| and the hard cap in
+# units of that tolerance.  The float32 ORACLE itself (same arithmetic on the CPU) leaves 0 .. 2e-4 of the elements outside at worst 1.1 x
+# on these scenes (measured in the build container); the kernels add v_exp_f32 / v_rcp_f32 (1 ulp) on top.
+SMALL_FRAC, SMALL_HARD = 2e-3, 20.0
+LARGE_FRAC, LARGE_HARD = 1e-2, 200.0
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -189,7 +196,9 @@ def test_backward_matches_oracle(c):
     og = O.backward(ost, gC, gD, gA)
     for k in ("means3D", "opacities", "shs", "scales", "rotations"):
         assert rel_err(inp[k].grad.cpu().numpy(), og[k]) <= GRAD_REL, k
+        assert_grad_close(inp[k].grad.cpu().numpy(), og[k], "%s N=%d" % (k, c["N"]), max_frac=SMALL_FRAC, hard=SMALL_HARD)
     assert rel_err(m2d.grad.cpu().numpy(), og["means2D"]) <= GRAD_REL
+    assert_grad_close(m2d.grad.cpu().numpy(), og["means2D"], "means2D N=%d" % c["N"], max_frac=SMALL_FRAC, hard=SMALL_HARD)
     if c["deg"] < 3:
         assert inp["shs"].grad[:, (c["deg"] + 1) ** 2:].abs().max().item() == 0
 
@@ -229,20 +238,74 @@ def test_medium_cloud_fwd_bwd():
     sc = S.make_cloud(100000, seed=1234, log_scale_mean=np.log(0.01))
     st = S.camera_settings(640, 360, 49.1, 30.0, 45.0, 2.2)
     color, radii, depth, alpha, inp, m2d = hip_forward(sc, st, requires_grad=True)
-    oc, orad, od, oa, ost = oracle_forward(sc, st, nthreads=8)
+    oc, orad, od, oa, ost = oracle_forward(sc, st, dtype=np.float64, nthreads=os.cpu_count() or 8)
     assert (radii.cpu().numpy() != orad).sum() <= 5
     assert np.abs(color.detach().cpu().numpy() - oc).mean() <= IMG_L1
     assert np.abs(alpha.detach().cpu().numpy() - oa).mean() <= IMG_L1
     rng = np.random.default_rng(1)
     gC = rng.normal(size=oc.shape).astype(np.float32)
     color.backward(_dev(gC, torch.float32))
-    og = O.backward(ost, gC)
+    og = O.backward(ost, gC, nthreads=os.cpu_count() or 8)
     for k in ("means3D", "opacities", "shs", "scales", "rotations"):
-        assert rel_err(inp[k].grad.cpu().numpy(), og[k]) <= 5 * GRAD_REL, k   # f32 oracle + f32 atomics at 100k
-    # mean relative L1 over the whole tensor is far tighter
-    for k in ("means3D", "shs", "opacities"):
-        ref = og[k].astype(np.float64); got = inp[k].grad.cpu().numpy().astype(np.float64)
-        assert np.abs(got - ref).sum() / np.abs(ref).sum() <= GRAD_REL, k
+        assert rel_err(inp[k].grad.cpu().numpy(), og[k]) <= GRAD_REL, k       # against the float64 oracle: no slack factor
+        assert_grad_close(inp[k].grad.cpu().numpy(), og[k], "%s 100k" % k, max_frac=LARGE_FRAC, hard=LARGE_HARD)
+
+
+def test_baseline_size_1M_1080p_forward_backward_vs_float64_oracle():
+    """BASELINE configs 2 / 3 at FULL size: one view (elevation 30, azimuth 22.5) of the 1,000,000-Gaussian cloud (seed 1234, SH degree 3) at
+    1920 x 1080, forward and backward, HIP against the float64 oracle.  The oracle takes seconds on the GPU box's
+    host cores."""
+    sc = S.make_cloud(1_000_000, seed=1234)
+    st = S.camera_settings(1920, 1080, 49.1, 30.0, 22.5, 2.2, bg=(1, 1, 1))
+    nt = os.cpu_count() or 8
+    color, radii, depth, alpha, inp, m2d = hip_forward(sc, st, requires_grad=True)
+    oc, orad, od, oa, ost = oracle_forward(sc, st, dtype=np.float64, nthreads=nt)
+    assert (radii.cpu().numpy() != orad).sum() <= 20                 # ceil(3 sigma) on a float32 / float64 boundary
+    assert np.abs(color.detach().cpu().numpy() - oc).mean() <= IMG_L1
+    assert np.abs(alpha.detach().cpu().numpy() - oa).mean() <= IMG_L1
+    assert np.abs(depth.detach().cpu().numpy() - od).mean() <= IMG_L1
+    assert np.abs(color.detach().cpu().numpy() - oc).max() <= 2e-2     # no isolated wrong pixels (a flipped 1/255 or 1e-4 decision moves one pixel by < this)
+    rng = np.random.default_rng(7)
+    gC = rng.normal(size=oc.shape).astype(np.float32)
+    gA = rng.normal(size=oa.shape).astype(np.float32)
+    ((color * _dev(gC, torch.float32)).sum() + (alpha * _dev(gA, torch.float32)).sum()).backward()
+    og = O.backward(ost, gC, None, gA, nthreads=nt)
+    for k in ("means3D", "opacities", "shs", "scales", "rotations"):
+        assert rel_err(inp[k].grad.cpu().numpy(), og[k]) <= GRAD_REL, k
+        assert_grad_close(inp[k].grad.cpu().numpy(), og[k], "%s 1M/1080p" % k, max_frac=LARGE_FRAC, hard=LARGE_HARD)
+    assert_grad_close(m2d.grad.cpu().numpy(), og["means2D"], "means2D 1M/1080p", max_frac=LARGE_FRAC, hard=LARGE_HARD)
+
+
+@pytest.mark.parametrize("exact", [False, True])
+def test_scaling_modifier_gradient_convention(exact):
+    """scaling_modifier != 1 (a public argument of render(), main_3DGS_renderer.py:830): dL/dscale as the dependency's backward returns it
+    (no modifier factor; the default) and the exact derivative behind c3d_gs_set_exact_dscale -- kernel and oracle switch together."""
+    import c3d_hip as h
+    c = CASES[3]
+    sc = S.make_small_scene(N=c["N"], seed=c["seed"], scale=c.get("scale", 0.08))
+    st = S.camera_settings(c["W"], c["H"], 49.1, c["el"], c["az"], c["rad"], bg=(0.3, 0.7, 0.1), sh_degree=c["deg"])
+    st["scale_modifier"] = 0.7
+    gC = np.random.default_rng(9).normal(size=(3, c["H"], c["W"])).astype(np.float32)
+    old_k, old_o = h.lib().c3d_gs_set_exact_dscale(1 if exact else 0), O.set_exact_dscale(exact)
+    try:
+        color, radii, depth, alpha, inp, m2d = hip_forward(sc, st, requires_grad=True)
+        oc, orad, od, oa, ost = oracle_forward(sc, st, dtype=np.float64)
+        assert (radii.cpu().numpy() == orad).all() and np.abs(color.detach().cpu().numpy() - oc).mean() <= IMG_L1
+        color.backward(_dev(gC, torch.float32))
+        og = O.backward(ost, gC)
+        for k in ("means3D", "opacities", "shs", "scales", "rotations"):
+            assert_grad_close(inp[k].grad.cpu().numpy(), og[k], "%s mod=0.7 exact=%s" % (k, exact), max_frac=SMALL_FRAC, hard=SMALL_HARD)
+        gs = inp["scales"].grad.clone()
+    finally:
+        h.lib().c3d_gs_set_exact_dscale(old_k); O.set_exact_dscale(old_o)
+    if not exact:      # and the two conventions differ by exactly the modifier
+        h.lib().c3d_gs_set_exact_dscale(1)
+        try:
+            color, _, _, _, inp2, _ = hip_forward(sc, st, requires_grad=True)
+            color.backward(_dev(gC, torch.float32))
+        finally:
+            h.lib().c3d_gs_set_exact_dscale(0)
+        assert torch.allclose(inp2["scales"].grad, 0.7 * gs, rtol=1e-6, atol=0)
 
 
 # ---------------------------------------------------------------- full size: properties (no oracle run)
@@ -465,29 +528,83 @@ def test_fused_multi_view_step_matches_autograd(lanes):
         assert torch.equal(a, b)
 
 
-def test_trainer_fused_step_equals_autograd_step():
-    """GaussianSplatting3D.training_step with lambda_ssim = 0: the fused library step and the per-view autograd path produce the same
-    loss and leave the same parameters after an Adam step (masked L1 + alpha MSE of main_3DGS.py:169-190)."""
+@pytest.mark.parametrize("lambda_ssim,offsets", [(0.0, False), (0.2, False), (0.2, True)])
+def test_trainer_fused_step_equals_autograd_step(lambda_ssim, offsets):
+    """GaussianSplatting3D.training_step with the reference's node defaults -- lambda_ssim 0.2, invert_bg_prob 0.5 (nodes.py:1177,1181) -- and
+    without MS-SSIM: the fused library step and the per-view autograd path draw the same backgrounds, produce the same loss and leave the
+    same parameters after an Adam step.  Masks are SOFT (rembg alpha / the bilinear resize of _fit): (c - ref) * mask, not c*mask - ref*mask^2."""
     from MVs_Algorithms.GaussianSplatting.main_3DGS import GSParams, GaussianSplatting3D
-    H = W = 160
+    H = W = 192                                                     # 5-scale MS-SSIM needs sides > 160
     poses = [[1.75, -10.0, az, 0.0, 0.0, 0.0] for az in (0.0, 120.0, -120.0)]
     rng = np.random.default_rng(1)
     refs = [torch.tensor(rng.uniform(size=(H, W, 3)).astype(np.float32)) for _ in poses]
-    masks = [torch.tensor((rng.uniform(size=(H, W)) > 0.4).astype(np.float32)) for _ in poses]
+    masks = [torch.tensor(np.clip(rng.uniform(size=(H, W)) * 1.6 - 0.3, 0, 1).astype(np.float32)) for _ in poses]
     results = []
     for fused in (True, False):
         np.random.seed(3); torch.manual_seed(3)
-        p = GSParams(training_iterations=2, batch_size=3, lambda_ssim=0.0, num_pts=5000, density_start_iter=10 ** 9, density_end_iter=-1, invert_bg_prob=1.0)
+        p = GSParams(training_iterations=2, batch_size=3, lambda_ssim=lambda_ssim, num_pts=5000, density_start_iter=10 ** 9, density_end_iter=-1, invert_bg_prob=0.5,
+                     lambda_offset=0.5 if offsets else 0.0, lambda_offset_opacity=0.3 if offsets else 0.0)
         tr = GaussianSplatting3D(p, None, device="cuda")
         tr.use_fused_step = fused
         tr.prepare_training(refs, masks, poses, 49.1)
         assert tr._can_fuse() == fused
+        np.random.seed(17)                                           # the per-view background draws
         losses = [tr.training_step(s, [0, 1, 2]).item() for s in range(2)]
         results.append((losses, [q.detach().clone() for q in tr.params]))
     (l1, p1), (l2, p2) = results
     assert abs(l1[0] - l2[0]) <= 1e-5 * max(1, abs(l2[0])) and abs(l1[1] - l2[1]) <= 1e-4 * max(1, abs(l2[1]))
     for a, b in zip(p1, p2):
         assert (a - b).abs().max().item() <= 2e-4 * max(1.0, b.abs().max().item())
+
+
+def test_fused_forward_backward_halves_match_autograd():
+    """c3d_gs_forward_views_raw + c3d_gs_backward_views_raw (the fused step split at the image, per-view backgrounds, caller-supplied
+    dL/dcolor, dL/ddepth, dL/dalpha) against the per-view autograd path over the same renderer."""
+    from MVs_Algorithms.GaussianSplatting.main_3DGS_renderer import GaussianSplattingRenderer
+    from c3d_hip.gs_step import FusedViewStep
+    raw = S.make_cloud(40000, seed=21, log_scale_mean=np.log(0.015), activated=False)
+    W, H, V = 256, 160, 5
+    r = GaussianSplattingRenderer(sh_degree=3, device="cuda")
+    r.initialize({"xyz": raw["means3D"], "features": raw["shs"], "scaling_raw": raw["scales"], "rotation_raw": raw["rotations"], "opacity_raw": raw["opacities"]})
+    g = r.gaussians
+    plist = [g._xyz, g._features_dc, g._features_rest, g._opacity, g._scaling, g._rotation]
+    rs_list, cams, bgs = [], [], []
+    for i, (el, az) in enumerate([(-20.0, 10.0), (15.0, 130.0), (40.0, -100.0), (0.0, 60.0), (-35.0, -30.0)]):
+        bg = (1.0, 1.0, 1.0) if i % 2 == 0 else (0.0, 0.0, 0.0)
+        st = S.camera_settings(W, H, 49.1, el, az, 2.2, bg=bg)
+        rs = hip_settings(st, "cuda")
+        rs_list.append(rs); bgs.append(rs.bg)
+        cams.append(type("Cam", (), dict(image_height=H, image_width=W, FoVx=2 * np.arctan(st["tanfovx"]), FoVy=2 * np.arctan(st["tanfovy"]),
+                                         world_view_transform=rs.viewmatrix, full_proj_transform=rs.projmatrix, camera_center=rs.campos))())
+    rng = np.random.default_rng(0)
+    gC = _dev(rng.normal(size=(V, 3, H, W)).astype(np.float32), torch.float32)
+    gD = _dev(rng.normal(size=(V, 1, H, W)).astype(np.float32), torch.float32)
+    gA = _dev(rng.normal(size=(V, 1, H, W)).astype(np.float32), torch.float32)
+    imgs = []
+    for i in range(V):
+        out = r.render(cams[i], bg_color=bgs[i])
+        imgs.append((out["image"].detach().clone(), out["alpha"].detach().clone(), out["depth"].detach().clone(), out["radii"].clone()))
+        # render() clamps the image; the fused halves hand out the unclamped colour, so differentiate through the same clamp on both sides
+        ((out["image"] * gC[i]).sum() + (out["depth"] * gD[i]).sum() + (out["alpha"] * gA[i]).sum()).backward()
+    ref = [p.grad.clone() for p in plist]
+    for p in plist:
+        p.grad = None
+    for lanes in (1, 4):
+        step = FusedViewStep(40000, H, W, "cuda", pair_capacity=5000, lanes=lanes)      # tiny capacity: the regrow path of forward()
+        color, depth, alpha, radii = step.forward(rs_list, [p.detach() for p in plist], want_depth=True, want_radii=True)
+        assert step.capacity > 5000
+        for i in range(V):
+            assert torch.equal(color[i].clamp(0, 1), imgs[i][0]) and torch.equal(alpha[i], imgs[i][1]) and torch.equal(depth[i], imgs[i][2]) and torch.equal(radii[i], imgs[i][3])
+        dcolor = gC * ((color >= 0) & (color <= 1))                  # d clamp
+        grads = [torch.empty_like(p) for p in plist]
+        step.backward(grads, dcolor, gA, gD, accumulate=False)
+        for a, b, name in zip(grads, ref, ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")):
+            assert rel_err(a.cpu().numpy(), b.cpu().numpy()) <= 5e-4, (name, lanes)
+        step.backward(grads, dcolor, gA, gD, accumulate=True)        # ... and on top
+        for a, b in zip(grads, ref):
+            assert rel_err(a.cpu().numpy(), 2 * b.cpu().numpy()) <= 5e-4
+        rg, g2 = step.read_view(V - 1)
+        assert torch.equal(rg, imgs[V - 1][3]) and torch.isfinite(g2).all()
 
 
 def test_trainer_densify_prune_schedule():
@@ -596,8 +713,8 @@ def test_render_views_equals_per_view_render(lanes, res):
 
 @pytest.mark.parametrize("lambda_ssim", [0.0, 0.2])
 def test_trainer_longer_run_with_densification(lambda_ssim):
-    """60 steps of the trainer at 100k points / 256^2 with the densification schedule running (fused step for lambda_ssim = 0, autograd + MS-SSIM
-    otherwise): the loss goes down, N changes several times, nothing goes non-finite, buffers keep following N."""
+    """60 steps of the trainer at 100k points / 256^2 with the densification schedule running (fused step: in-kernel loss for lambda_ssim = 0,
+    forward / torch MS-SSIM / backward halves otherwise): the loss goes down, N changes several times, nothing goes non-finite, buffers keep following N."""
     from MVs_Algorithms.GaussianSplatting.main_3DGS import GSParams, GaussianSplatting3D
     H = W = 256
     rng = np.random.default_rng(11)
@@ -611,7 +728,7 @@ def test_trainer_longer_run_with_densification(lambda_ssim):
                  densification_interval=10, opacity_reset_interval=30, densify_grad_threshold=5e-7, invert_bg_prob=1.0)
     tr = GaussianSplatting3D(p, None, device="cuda")
     tr.prepare_training(refs, masks, poses, 49.1)
-    assert tr._can_fuse() == (lambda_ssim == 0.0)
+    assert tr._can_fuse()                                            # round 2: also with MS-SSIM
     rs = np.random.RandomState(0)
     losses, ns = [], []
     for s in range(60):

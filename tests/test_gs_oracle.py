@@ -145,6 +145,34 @@ def test_matches_torch_autograd(oracle_built, case):
         assert np.abs(g["shs"][:, (deg + 1) ** 2:]).max() == 0
 
 
+def test_scale_modifier_gradient_conventions(oracle_built):
+    """scale_modifier != 1: the oracle's default dL/dscale is what the dependency's backward returns -- the derivative w.r.t.
+    (modifier * scale), i.e. the exact one divided by the modifier -- and set_exact_dscale(True) gives the exact derivative, which is what
+    torch autograd computes for the independent restatement.  Every other gradient is the same under both conventions."""
+    sc = S.make_small_scene(N=40, seed=7, sh_degree=3)
+    st = S.camera_settings(48, 32, 49.1, -20, 30, 2.0, bg=(0.3, 0.7, 0.1), sh_degree=3)
+    st["scale_modifier"] = 0.7
+    gC = np.random.default_rng(5).normal(size=(3, 32, 48))
+    td = lambda a: torch.tensor(a, dtype=torch.float64, requires_grad=True)
+    m, o, sh, s, r = (td(sc[k]) for k in ("means3D", "opacities", "shs", "scales", "rotations"))
+    c2, *_ = R.render(m, o, st, shs=sh, scales=s, rotations=r)
+    (c2 * torch.tensor(gC)).sum().backward()
+    assert O.set_exact_dscale(False) is False                    # the default is the dependency's convention
+    try:
+        color, radii, depth, alpha, state = oracle_forward(sc, st, dtype=np.float64)
+        np.testing.assert_allclose(color, c2.detach().numpy(), atol=1e-12)
+        g_wheel = O.backward(state, gC)
+        O.set_exact_dscale(True)
+        g_exact = O.backward(state, gC)
+    finally:
+        O.set_exact_dscale(False)
+    rel = lambda a, b: np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+    assert rel(g_exact["scales"], s.grad.numpy()) < 1e-6
+    assert rel(g_wheel["scales"] * 0.7, s.grad.numpy()) < 1e-6
+    for name, t in (("means3D", m), ("opacities", o), ("shs", sh), ("rotations", r)):
+        assert rel(g_wheel[name], t.grad.numpy()) < 1e-6 and np.array_equal(g_wheel[name], g_exact[name]), name
+
+
 def test_precomputed_colour_and_cov_paths(oracle_built):
     sc = S.make_small_scene(N=32, seed=9)
     st = S.camera_settings(32, 32, 49.1, 10, -40, 1.8)

@@ -3,12 +3,15 @@ and the world_size-2 gradient exchange over gloo."""
 import math
 import os
 import socket
+import sys
 
 import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
+
+PKG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "comfyui-3d-pack_amd")
 
 
 def test_orbit_camera_and_minicam_conventions():
@@ -321,3 +324,46 @@ def test_lazy_results_and_flat_grads_layout():
     fg.views[2].fill_(2.0)
     assert float(fg.flat.sum()) == 2.0 * ps[2].numel()
     fg.exchange(None, "allreduce")            # no process group: a no-op
+
+
+def test_package_init_registers_its_own_nodes_when_comfyui_nodes_is_loaded():
+    """inside ComfyUI `nodes` is already in sys.modules -- it is the module that loads custom nodes -- so the package must
+    import ITS nodes.py relatively, and must not put itself in front of the host's modules on sys.path.  Load the package the way ComfyUI
+    does (spec_from_file_location on the directory's __init__.py) with a dummy `nodes` pre-seeded."""
+    import importlib.util
+    import types
+    dummy = types.ModuleType("nodes")
+    dummy.NODE_CLASS_MAPPINGS = {"KSampler": object}
+    dummy.NODE_DISPLAY_NAME_MAPPINGS = {"KSampler": "KSampler"}
+    saved, saved_path = sys.modules.get("nodes"), list(sys.path)
+    sys.modules["nodes"] = dummy
+    try:
+        sys.path[:] = [p for p in sys.path if os.path.abspath(p) != PKG]        # ComfyUI does not have the pack on its path beforehand
+        sys.path.insert(0, "/tmp/comfyui_stand_in")                              # whatever the host has in front stays in front
+        spec = importlib.util.spec_from_file_location("comfyui_3d_pack_amd_under_test", os.path.join(PKG, "__init__.py"), submodule_search_locations=[PKG])
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[spec.name] = mod
+        spec.loader.exec_module(mod)
+        assert "KSampler" not in mod.NODE_CLASS_MAPPINGS
+        assert "[Comfy3D] Gaussian Splatting 3D" in mod.NODE_CLASS_MAPPINGS and len(mod.NODE_CLASS_MAPPINGS) == 8
+        assert set(mod.NODE_DISPLAY_NAME_MAPPINGS) == set(mod.NODE_CLASS_MAPPINGS)
+        assert sys.modules["nodes"] is dummy                                      # the host's module is untouched
+        assert sys.path[0] == "/tmp/comfyui_stand_in" and os.path.abspath(sys.path[-1]) == PKG      # appended, as the reference's __init__.py:12
+    finally:
+        sys.path[:] = saved_path
+        sys.modules.pop("comfyui_3d_pack_amd_under_test", None)
+        sys.modules.pop("comfyui_3d_pack_amd_under_test.nodes", None)
+        if saved is None:
+            sys.modules.pop("nodes", None)
+        else:
+            sys.modules["nodes"] = saved
+
+
+def test_diffmesh_validates_the_remesh_interval_up_front():
+    """with the node defaults (1024 iterations, remesh every 512) and geometry training the periodic pymeshlab remesh would be due
+    mid-run.  It is not part of this implementation: the constructor says so before any work is spent, and the run goes through."""
+    import warnings
+    src = open(os.path.join(PKG, "MVs_Algorithms", "DiffRastMesh", "diff_mesh.py")).read()
+    assert "raise NotImplementedError" not in src                                 # nothing aborts 512 steps into a run any more
+    ctor = src[src.index("class DiffMesh:"):src.index("def prepare_training")]
+    assert "warnings.warn(" in ctor and "remesh_after_n_iteration < training_iterations" in ctor

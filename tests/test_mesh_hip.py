@@ -6,7 +6,7 @@ import torch
 
 from c3d_hip import synthetic as S
 from oracle import mesh_oracle as M
-from helpers import rel_err
+from helpers import assert_grad_close, rel_err
 
 pytestmark = pytest.mark.gpu
 IMG_L1 = 1e-4
@@ -124,6 +124,59 @@ def test_full_pipeline_forward_and_gradients(sc):
     assert rel_err(ttex.grad.cpu().numpy(), dtex) <= GRAD_REL
     assert rel_err(tvt.grad.cpu().numpy(), dvt) <= GRAD_REL
     assert rel_err(tpos.grad.cpu().numpy(), dpos_aa + dpos_al + dpos_r) <= 2 * GRAD_REL
+
+
+def test_baseline_config5_499k_triangles_1024px_vs_float64_oracle():
+    """BASELINE config 5 at FULL size: one view of the 499,000-triangle displaced sphere, 1024 x 1024, 1024^2 x 3 texture,
+    rasterize -> interpolate(uv, diff all) -> texture(linear) -> antialias(colour) + antialias(alpha), forward against the float32 oracle and
+    backward against the float64 oracle's chain rule.  ~2 pixels per triangle: the regime the one-lane-per-triangle rasterizer is built for."""
+    import nvdiffrast.torch as dr
+    H = W = 1024
+    v, f, vt, vn = S.make_uv_sphere(500, 500, radius=0.7, displacement=0.05)
+    pos, vcam, pose = S.mesh_clip_positions(v, -20.0, 45.0, 2.0, W, H)
+    rng = np.random.default_rng(1)
+    tex = rng.normal(size=(1, 1024, 1024, 3)).astype(np.float32)
+    ctx = dr.RasterizeCudaContext()
+    tpos, ttri, tvt, ttex = T(pos, grad=True), T(f, torch.int32), T(vt[None], grad=True), T(tex, grad=True)
+    rast, db = dr.rasterize(ctx, tpos, ttri, (H, W))
+    texc, texd = dr.interpolate(tvt, rast, ttri, rast_db=db, diff_attrs='all')
+    col = dr.texture(ttex, texc, uv_da=texd, filter_mode='linear')
+    aa = dr.antialias(col, rast, tpos, ttri)
+    alpha = dr.antialias(torch.clamp(rast[..., -1:], 0, 1).contiguous(), rast, tpos, ttri)
+    orast, odb = M.rasterize(pos, f, (H, W))
+    r = rast.detach().cpu().numpy()
+    same = r[..., 3] == orast[..., 3]
+    n_diff = int((~same).sum())
+    print("[mesh config5] covered %.3f of the pixels, %d triangle ids differ" % (float((orast[..., 3] > 0).mean()), n_diff))
+    assert n_diff <= max(2, int(2e-5 * H * W)), n_diff            # depth near-ties between neighbouring ~1-pixel triangles
+    assert np.abs(r[same][:, :3] - orast[same][:, :3]).mean() <= 1e-5
+    # downstream images against the oracle fed with the oracle's own rast (ids that differ move single pixels, covered by the L1 bounds)
+    otexc, otexd = M.interpolate(vt[None], orast, f, odb, "all")
+    ocol = M.texture(tex, otexc)
+    oaa = M.antialias(ocol, orast, pos, f)
+    oalpha = M.antialias(np.clip(orast[..., 3:], 0, 1), orast, pos, f)
+    assert np.abs(texc.detach().cpu().numpy() - otexc).mean() <= IMG_L1
+    assert np.abs(col.detach().cpu().numpy() - ocol).mean() <= IMG_L1
+    assert np.abs(aa.detach().cpu().numpy() - oaa).mean() <= IMG_L1
+    assert np.abs(alpha.detach().cpu().numpy() - oalpha).mean() <= IMG_L1
+    gA = rng.normal(size=oaa.shape).astype(np.float32); gB = rng.normal(size=oalpha.shape).astype(np.float32)
+    ((aa * T(gA)).sum() + (alpha * T(gB)).sum()).backward()
+    d = np.float64
+    r64, db64 = M.rasterize(pos, f, (H, W), dtype=d)
+    texc64, _ = M.interpolate(vt[None], r64, f, db64, "all", dtype=d)
+    col64 = M.texture(tex, texc64, dtype=d)
+    dcol, dpos_aa = M.antialias_bwd(col64, r64, pos, f, gA, dtype=d)
+    _, dpos_al = M.antialias_bwd(np.clip(r64[..., 3:], 0, 1), r64, pos, f, gB, dtype=d)
+    dtex, duv = M.texture_bwd(tex, texc64, dcol, dtype=d)
+    dvt, drast = M.interpolate_bwd(vt[None], r64, f, duv, dtype=d)
+    dpos_r = M.rasterize_bwd(pos, f, r64, drast, dtype=d)
+    assert rel_err(ttex.grad.cpu().numpy(), dtex) <= GRAD_REL
+    assert rel_err(tvt.grad.cpu().numpy(), dvt) <= GRAD_REL
+    assert rel_err(tpos.grad.cpu().numpy(), dpos_aa + dpos_al + dpos_r) <= 2 * GRAD_REL
+    # relative L2 over the tensors; the element-wise share is reported (pixels whose triangle id differs carry a different gradient by construction)
+    assert_grad_close(ttex.grad.cpu().numpy(), dtex, "config5 dL/dtex", rel_l2=5e-3, max_frac=5e-3, hard=1e9)
+    assert_grad_close(tvt.grad.cpu().numpy(), dvt, "config5 dL/dvt", rel_l2=5e-3, max_frac=5e-3, hard=1e9)
+    assert_grad_close(tpos.grad.cpu().numpy(), dpos_aa + dpos_al + dpos_r, "config5 dL/dpos", rel_l2=1e-2, max_frac=2e-2, hard=1e9)
 
 
 def test_texture_modes_and_batches():
@@ -283,6 +336,44 @@ def test_config1_example_workflow_through_the_nodes(tmp_path):
         mi, mm, md, mn, mv = N.Mesh_Orbit_Renderer().render_mesh(mesh, 256, 256, poses, 49.1, 0.0, 0.0, 0.0, True, render_depth=True, render_normal=True)
     assert mi.shape == (4, 256, 256, 3) and mm.shape == (4, 256, 256) and md.shape == (4, 256, 256, 3) and mn.shape == (4, 256, 256, 3)
     assert 0.05 < mm.mean().item() < 0.9 and torch.isfinite(mi).all() and (mi[mm == 0] == 0).all()
+
+
+@pytest.mark.parametrize("init", ["pointcloud", "mesh", "ply_wins_over_mesh"])
+def test_gaussian_splatting_3d_node_accepts_every_initialiser(init):
+    """[Comfy3D] Gaussian Splatting 3D with a point cloud / mesh / ply initialiser (reference nodes.py:1294-1301: point cloud, else ply, else
+    mesh): a short training run through the node -- default loss (MS-SSIM 0.2, random backgrounds), i.e. the fused forward / backward halves."""
+    import nodes as N
+    from MVs_Algorithms.GaussianSplatting.main_3DGS_renderer import PointCloud, GaussianSplattingRenderer
+    H = W = 176
+    poses = [[1.75, 0.0, az, 0.0, 0.0, 0.0] for az in (0.0, 90.0, 180.0, -90.0)]
+    rng = np.random.default_rng(2)
+    yy, xx = np.meshgrid(np.linspace(-1, 1, H), np.linspace(-1, 1, W), indexing="ij")
+    disk = ((xx ** 2 + yy ** 2) < 0.4).astype(np.float32)
+    imgs = torch.tensor(np.stack([np.stack([disk * 0.8, disk * 0.3, disk * 0.5], -1)] * 4).astype(np.float32))
+    masks = torch.tensor(np.stack([disk] * 4))
+    kw = {}
+    n_expect = None
+    if init == "pointcloud":
+        pts = rng.normal(size=(3000, 3)) * 0.25
+        kw["points_cloud_to_initialize_gaussian"] = PointCloud(points=pts, colors=rng.uniform(size=(3000, 3)), normals=np.zeros((3000, 3)))
+        n_expect = 3000
+    elif init == "mesh":
+        kw["mesh_to_initialize_gaussian"] = _torch_mesh(12, 24, tex=16)
+    else:
+        src = GaussianSplattingRenderer(sh_degree=3, device="cuda")
+        src.initialize(None, num_pts=1234)
+        kw["ply_to_initialize_gaussian"] = src.gaussians.to_ply()
+        kw["mesh_to_initialize_gaussian"] = _torch_mesh(12, 24, tex=16)
+        n_expect = 1234
+    np.random.seed(0); torch.manual_seed(0)
+    (ply,) = N.Gaussian_Splatting_3D().run_gs(imgs, masks, poses, 49.1, 6, 2, 0.2, 3, 0.0, 0.0, 0.5, 0.0025, 0.05, 0.005, 0.001, 0.00016, 0.0000016, 0.01, 30000,
+                                              2000, 3, 0.01, 10 ** 6, 10 ** 6, 100, 3000, 0.0002, 3, **kw)
+    n = ply.elements[0].count if hasattr(ply, "elements") else len(ply["vertex"])
+    assert n > 0 and (n_expect is None or n == n_expect)
+    (gs_ply,) = (ply,)
+    with torch.inference_mode():
+        out, m, d = N.Gaussian_Splatting_Orbit_Renderer().render_gs(gs_ply, W, H, poses[:1], 49.1, 1.0, 1.0, 1.0)
+    assert torch.isfinite(out).all() and out.shape == (1, H, W, 3)
 
 
 @pytest.mark.parametrize("sc", [(130, 97, 24, 40), (256, 256, 64, 128), (96, 96, 2, 3)])
