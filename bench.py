@@ -61,6 +61,10 @@ def parse():
                     help="step: c3d_gs_train_views_raw, all views of the step forward+loss+backward in one sync-free library call (product default for training); fused: GaussianSplattingRenderer.render with activations folded into the kernels (product default); accessor: the same "
                          "API through the reference's op-by-op accessors; boundary: bare diff_gaussian_rasterization call on pre-activated leaves")
     ap.add_argument("--workload", choices=["gs", "mesh"], default="gs", help="gs = BASELINE configs 2-4 (the metric); mesh = config 5 (DiffRastMesh)")
+    ap.add_argument("--loss", choices=["auto", "l1alpha", "full"], default="auto",
+                    help="pixel loss of the step path: l1alpha = 0.8 L1 + 3 MSE(alpha) inside c3d_gs_train_views_raw; full = BASELINE config 3's loss, the reference's default "
+                         "(main_3DGS.py:184-192): + 0.2 (1 - MS-SSIM), masked by the target alpha, through c3d_gs_forward_views_raw -> torch -> c3d_gs_backward_views_raw.  "
+                         "auto: full for --mode train, l1alpha for --mode fwdbwd")
     return ap.parse_args()
 
 
@@ -76,6 +80,27 @@ def algorithmic_bytes(N, K, P, n_vis, D):
         "gs_preprocess_bwd": 48 * n_vis + 2 * N * (44 + 12 * K),
         "adam": 28 * N * (11 + 3 * K),                    # p,g,m,v read + p,m,v write
     }
+
+
+def code_digest():
+    import c3d_hip
+    return c3d_hip.code_digest()
+
+
+def load_profile_json(suffix):
+    """newest committed profiles/*<suffix> whose `_meta.code_digest` is the digest of the code that is running -> (dict, file name, stale digest | None).
+    Traffic measured on other kernel code is refused (VERDICT r1, weak #8): the line then says traffic: null, stale: <digest>."""
+    try:
+        cand = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith(suffix))
+        if not cand:
+            return {}, None, None
+        d = json.load(open(os.path.join(ROOT, "profiles", cand[-1])))
+        dig = (d.get("_meta") or {}).get("code_digest")
+        if dig != code_digest():
+            return {}, cand[-1], dig or "unstamped"
+        return d, cand[-1], None
+    except Exception:
+        return {}, None, None
 
 
 def main_mesh(a, world, rank, dev, dist):
@@ -145,15 +170,52 @@ def main_mesh(a, world, rank, dev, dist):
         ach = alg.get(dom, 0) / (per_view_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
                 "traffic": None, "avg_ms": round(per_view_ms, 4), "alg_bytes_per_launch": int(alg.get(dom, 0)), "note": "per view (a view issues several launches of this group)"}
+        pmc, pmc_file, stale = load_profile_json("_mesh_pmc_traffic.json")
+        grp = (pmc.get("_groups") or {}).get(dom)
+        if grp:
+            roof["traffic"] = int((grp["fetch_MB_raw"] + grp["write_MB"]) * 1e6)
+            roof["traffic_note"] = "FETCH_SIZE(raw)+WRITE_SIZE per view over the kernels of this group, profiles/%s; fetch x2-corrected: %d" % (pmc_file, int((grp["fetch_MB_x2"] + grp["write_MB"]) * 1e6))
+        elif stale:
+            roof["stale"] = "profiles/%s was measured on code %s" % (pmc_file, stale)
+    cpu = None
+    if rank == 0 and world == 1 and a.cpu_baseline != "off":
+        cpu = mesh_cpu_baseline(v, f, vt, H, W)
     if rank == 0:
         print(json.dumps({"metric": "Mpixels/s DiffRastMesh forward+backward @500k triangles 1024x1024", "value": round(a.views_per_gpu * world * a.steps * P / dt / 1e6, 2),
                           "unit": "Mpixels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                           "config": {"workload": "DiffRastMesh fwd+bwd, %d-triangle displaced sphere, 1024^2 albedo, 1024x1024, %d views/GPU/step" % (T, a.views_per_gpu),
                                      "parallelism": "view-parallel dp%d" % world},
-                          "roofline": roof, "cpu_baseline": None, "kernels": kern}))
+                          "roofline": roof, "cpu_baseline": cpu, "kernels": kern, "code_digest": code_digest()}))
     if world > 1:
         dist.destroy_process_group()
+
+
+def mesh_cpu_baseline(v, f, vt, H, W):
+    """the mesh oracle (a port: nvdiffrast has no CPU path) on ONE view of config 5: rasterize -> interpolate -> texture -> 2x antialias, forward and backward"""
+    try:
+        from oracle import mesh_oracle as MO
+        from c3d_hip import synthetic as S
+        MO.build()
+        pos, _, _ = S.mesh_clip_positions(v, -20.0, 0.0, 2.0, W, H)
+        rng = np.random.default_rng(1)
+        tex = rng.normal(size=(1, 1024, 1024, 3)).astype(np.float32)
+        t1 = time.perf_counter()
+        rast, db = MO.rasterize(pos, f, (H, W))
+        texc, _ = MO.interpolate(vt[None], rast, f, db, "all")
+        col = MO.texture(tex, texc)
+        aa = MO.antialias(col, rast, pos, f)
+        al = MO.antialias(np.clip(rast[..., 3:], 0, 1), rast, pos, f)
+        dcol, dpos = MO.antialias_bwd(col, rast, pos, f, np.ones_like(aa))
+        MO.antialias_bwd(np.clip(rast[..., 3:], 0, 1), rast, pos, f, np.ones_like(al))
+        dtex, duv = MO.texture_bwd(tex, texc, dcol)
+        dvt, drast = MO.interpolate_bwd(vt[None], rast, f, duv)
+        MO.rasterize_bwd(pos, f, rast, drast)
+        tc = time.perf_counter() - t1
+        return {"value": round(H * W / tc / 1e6, 4), "unit": "Mpixels/s", "cores": os.cpu_count() or 1, "kind": "port",
+                "sample": "1 view of config 5 (%d triangles, %dx%d) through the CPU mesh oracle, forward + backward, %.1f s (OpenMP loops over pixels / triangles)" % (f.shape[0], W, H, tc)}
+    except Exception as ex:
+        return {"value": None, "unit": "Mpixels/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (ex,)}
 
 
 def main():
@@ -241,12 +303,19 @@ def main():
             c, _, _, al = render(i)
             targets.append((c.clone(), al.clone()))
         plist[0].data.sub_(jit)
+    tgt_alpha = torch.stack([tg[1] for tg in targets])                 # [V,1,H,W]: the masks of config 3 ("masks = its alpha")
+    tgt_masked = torch.stack([tg[0] for tg in targets]) * tgt_alpha
     opt = None
     if a.mode == "train":
         from c3d_hip.optim import FusedAdam
         opt = FusedAdam([{"params": [q], "lr": lr} for q, lr in zip(plist, lr_list)], lr=0.0, eps=1e-15)
     stats = {"n_vis": [], "D": []}
     fused_step = None
+    loss_kind = a.loss if a.loss != "auto" else ("full" if a.mode == "train" else "l1alpha")
+    ms_ssim = None
+    if loss_kind == "full" and a.render_path == "step" and a.mode != "fwd":
+        from shared_utils.msssim import MS_SSIM
+        ms_ssim = MS_SSIM(data_range=1, size_average=True, channel=3)
     if a.render_path == "step" and a.mode != "fwd":
         from c3d_hip.gs_step import FusedViewStep
         fused_step = FusedViewStep(N, H, W, dev, lanes=a.lanes, views=len(settings))
@@ -266,9 +335,21 @@ def main():
         if view_render is not None and not collect:
             with torch.no_grad():
                 view_render.run(settings, plist)
-        elif fused_step is not None and not collect:
+        elif fused_step is not None and not collect and ms_ssim is None:
             fused_step.run(settings, [q.detach() for q in plist], step_grads, [tg[0] for tg in targets], [tg[1] for tg in targets], None,
                            w_l1=0.8, w_l2=0.0, w_alpha_mse=3.0, scale=1.0 / (a.views_per_gpu * world), accumulate=False)
+            for q, gq in zip(plist, step_grads):
+                q.grad = gq
+        elif fused_step is not None and not collect:
+            # BASELINE config 3's loss, exactly the reference's step (main_3DGS.py:169-192): images and references masked by the target alpha,
+            # 0.8 L1 + 3 MSE(alpha) + 0.2 (1 - MS-SSIM) over the batch; the rasterizer runs as two sync-free library calls around torch's loss
+            colors, _, alphas, _ = fused_step.forward(settings, [q.detach() for q in plist])
+            colors.requires_grad_(True); alphas.requires_grad_(True)
+            with torch.enable_grad():
+                imgs, refs = colors.clamp(0, 1) * tgt_alpha, tgt_masked
+                loss = 0.8 * (imgs - refs).abs().mean() + 3.0 * ((alphas - tgt_alpha) ** 2).mean() + 0.2 * (1.0 - ms_ssim(refs, imgs))
+                dcolor, dalpha = torch.autograd.grad(loss / world, [colors, alphas])
+            fused_step.backward(step_grads, dcolor, dalpha, accumulate=False)
             for q, gq in zip(plist, step_grads):
                 q.grad = gq
         else:
@@ -373,13 +454,7 @@ def main():
     # HBM traffic of the dominant kernel: rocprofv3 PMC counters cannot be read from inside the process, so the per-launch figure comes
     # from the committed summary of two separate --pmc passes over this same command (profiles/summarize_pmc.py; FETCH_SIZE raw + WRITE_SIZE,
     # MI355X_MICROARCH.md: FETCH_SIZE under-reports wide streaming reads by 2x on gfx950 -- both figures are in the file).
-    pmc = {}
-    try:
-        cand = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))
-        if cand:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", cand[-1])))
-    except Exception:
-        pmc = {}
+    pmc, pmc_file, pmc_stale = load_profile_json("_pmc_traffic.json")
     pmc_name = {"gs_composite_bwd": "k_composite_bwd", "gs_composite_fwd": "k_composite_fwd", "gs_preprocess": "k_preprocess<true, true>",
                 "gs_preprocess_bwd": "k_preprocess_bwd<true, true, true>", "gs_emit": "k_emit"}
     if prof:
@@ -392,13 +467,19 @@ def main():
         rec = pmc.get(pmc_name.get(dom, ""))
         if rec and a.workload == "gs" and N == 1_000_000 and (W, H) == (1920, 1080):
             roof["traffic"] = int((rec["fetch_MB_raw"] + rec["write_MB"]) * 1e6)
-            roof["traffic_note"] = "FETCH_SIZE(raw)+WRITE_SIZE per launch from profiles/%s; fetch x2-corrected: %d" % (cand[-1], int((rec["fetch_MB_x2"] + rec["write_MB"]) * 1e6))
+            roof["traffic_note"] = "FETCH_SIZE(raw)+WRITE_SIZE per launch from profiles/%s (same code digest); fetch x2-corrected: %d" % (pmc_file, int((rec["fetch_MB_x2"] + rec["write_MB"]) * 1e6))
+        elif pmc_stale:
+            roof["stale"] = "profiles/%s was measured on code %s, this is %s" % (pmc_file, pmc_stale, code_digest())
 
         # instruction-issue view of the same kernel (it is what actually bounds the compositing kernels): SQ counters of a
         # single-lane rocprofv3 pass, committed like the PMC traffic (per SIMD: counters are per shader engine = 32 SIMDs)
         try:
             import csv
             sq = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_sq_instruction_mix_lanes1.csv"))
+            sq_meta = os.path.join(ROOT, "profiles", sq[-1] + ".meta.json") if sq else None
+            if sq and not (os.path.exists(sq_meta) and json.load(open(sq_meta)).get("code_digest") == code_digest()):
+                roof["issue"] = {"stale": "profiles/%s describes other kernel code" % sq[-1]}
+                sq = []
             if sq and pmc_name.get(dom):
                 for row in csv.DictReader(open(os.path.join(ROOT, "profiles", sq[-1]))):
                     if row["kernel"] == pmc_name[dom]:
@@ -412,6 +493,17 @@ def main():
             roof["measured"] = "single-lane pass after the timed region (kernels run alone); timed region used %d view lanes" % a.lanes
             if prof_conc:
                 roof["avg_ms_concurrent"] = round(prof_conc[dom][0] / prof_conc[dom][1], 4)
+    # whole-chain figure: SURVEY 8(d)'s algorithmic bytes of a VIEW over the wall time a view takes in the timed
+    # region -- the number the north star's ">= 60 % of HBM roofline on forward raster" is about
+    chain = None
+    per_view_s = dt / max(a.steps * a.views_per_gpu, 1)
+    b_fwd = N * (44 + 12 * K) + 96 * n_vis + 68 * D + 20 * P
+    b_bwd = 32 * P + 48 * D + 96 * n_vis + 2 * N * (44 + 12 * K)
+    b_view = b_fwd if a.mode == "fwd" else b_fwd + b_bwd
+    if per_view_s > 0:
+        chain = {"what": "SURVEY 8(d) algorithmic bytes of one view (%s) / wall time per view in the timed region" % ("B_fwd" if a.mode == "fwd" else "B_fwd + B_bwd"),
+                 "bytes_per_view": int(b_view), "ms_per_view": round(per_view_s * 1e3, 4), "achieved": round(b_view / per_view_s / 1e9, 1), "peak": HBM_PEAK_GBPS,
+                 "unit": "GB/s", "frac": round(b_view / per_view_s / 1e9 / HBM_PEAK_GBPS, 4), "target_frac": 0.6 if a.mode == "fwd" else None}
     kern_conc = None
     if prof_conc:
         kern_conc = {name: round(ms / n, 4) for name, (ms, n) in prof_conc.items()}
@@ -430,24 +522,27 @@ def main():
                 O.backward(ost, np.ones((3, H, W), np.float32) / P, nthreads=ncore)
             tc = time.perf_counter() - t1
             cpu = {"value": round(P / tc / 1e6, 4), "unit": "Mpixels/s", "cores": ncore, "kind": "port",
-                   "sample": "1 view of the same workload (%d Gaussians, %dx%d, %s) on the CPU oracle, %.1f s" % (N, W, H, a.mode, tc)}
+                   "sample": "1 view of the same workload (%d Gaussians, %dx%d, %s) on the CPU oracle, %.1f s; OpenMP over Gaussians / tiles, but the pair sort is ONE "
+                             "serial qsort, so `cores` overstates what runs in parallel -- a stated baseline, not a target" % (N, W, H, a.mode, tc)}
         except Exception as ex:   # the baseline leg must never take the bench down
             cpu = {"value": None, "unit": "Mpixels/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (ex,)}
 
     if rank == 0:
         out = {
             "metric": "Mpixels/s 3DGS forward+backward @1M Gaussians 1080p" if a.mode == "fwdbwd" else
-                      ("Mpixels/s 3DGS forward @1M Gaussians 1080p" if a.mode == "fwd" else "Mpixels/s 3DGS forward+backward+Adam @1M Gaussians 1080p"),
+                      ("Mpixels/s 3DGS forward @1M Gaussians 1080p" if a.mode == "fwd" else "Mpixels/s 3DGS training step (forward+loss+backward+Adam) @1M Gaussians 1080p"),
             "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "3DGS %s, %d synthetic Gaussians (seed 1234) SH deg %d, %dx%d, %d orbit views/GPU/step of the 64-camera orbit"
                                    % (a.mode, N, deg, W, H, a.views_per_gpu),
                        "global_views_per_step": a.views_per_gpu * world, "parallelism": "view-parallel dp%d" % world,
-                       "exchange": (a.exchange if world > 1 and a.mode != "fwd" else "none"), "render_path": a.render_path, "view_lanes": (a.lanes if a.render_path == "step" else 1),
+                       "exchange": (a.exchange if world > 1 and a.mode != "fwd" else "none"), "render_path": a.render_path,
+                       "loss": (None if a.mode == "fwd" else ("0.8 L1 + 3 MSE(alpha) + 0.2 (1 - MS-SSIM), masked (BASELINE config 3)" if ms_ssim is not None else "0.8 L1 + 3 MSE(alpha)")), "view_lanes": (a.lanes if a.render_path == "step" else 1),
                        "host_enqueue_ms_per_step": (round(fused_step.last_host_ms, 3) if fused_step is not None else None),
                        "n_visible": n_vis, "tile_splat_pairs": D},
-            "roofline": roof, "cpu_baseline": cpu, "kernels": kern, "kernels_concurrent_avg_ms": kern_conc,
+            "roofline": roof, "roofline_chain": chain, "cpu_baseline": cpu, "kernels": kern, "kernels_concurrent_avg_ms": kern_conc,
+            "code_digest": code_digest(),
         }
         print(json.dumps(out))
     if world > 1:

@@ -110,6 +110,12 @@ def lib():
     return _lib
 
 
+def code_digest():
+    """first 16 hex digits of the source digest of libc3d_hip.so (csrc/*, include/*.h, flags): stamped into every bench line and profile summary"""
+    from . import build as _b
+    return _b.code_digest()[:16]
+
+
 def check(rc, what):
     if rc != 0:
         msg = lib().c3d_last_error()

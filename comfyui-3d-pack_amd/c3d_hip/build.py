@@ -67,5 +67,10 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def code_digest():
+    """sha256 over csrc/*, include/*.h and the compile flags: identifies the kernel code a measurement belongs to (the GPU box has no .git)"""
+    return _digest()
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))

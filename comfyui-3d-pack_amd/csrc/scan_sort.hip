@@ -155,9 +155,18 @@ uint32_t* c3d_scan_error_word(void* tmp) { return (uint32_t*)tmp + 1; }
 // Radix sort ("onesweep"): 8-bit digits, 4096 keys per 256-thread workgroup, each wave owns a contiguous 1024-key chunk so that
 // ranking is stable by construction.
 //   k_radix_hist_all  ONE read of the keys: global digit histograms of ALL passes (digit totals are permutation invariant)
-//   k_onesweep        per digit: ballot ranking, per-digit chained scan over the tiles (look-back, 12 predecessors in flight per
-//                     lane), block-local reorder in LDS, run-contiguous global stores
-// State (zeroed before every sort): ghist[passes][256] | ticket[passes], error | status[passes][tiles][256] (flag << 30 | count).
+//   k_onesweep        per digit: ballot ranking, block-local reorder in LDS, per-digit chained scan over the tiles, run-contiguous
+//                     global stores
+// The chained scan is TWO-LEVEL.  At these sizes (245 - 1000 tiles on 256 CUs) every workgroup of a pass is resident at once and
+// reaches the scan at the same moment, the regime in which a flat look-back walks ~100 predecessors per tile (1 KB of status words each)
+// before it meets an inclusive prefix: 130 MB of polling per pass at 4 M keys.  Tiles are therefore grouped by 16:
+//   a tile adds up the aggregates of the <= 15 tiles before it IN ITS GROUP (one batch of independent loads) and takes the rest from the
+//   inclusive prefix of the previous group; the last tile of a group publishes the group aggregate, looks back over the GROUP records
+//   (32 in flight per lane: 1000 tiles = 62 groups = two batches) and publishes the group's inclusive prefix.
+// Three dependent hand-offs whatever the tile count, ~17 KB of status reads per tile.  Every wait is on a tile with a LOWER ticket.
+// Digits that do not occur in this pass (ghist == 0: most of the high bytes) skip the scan altogether.
+// State (zeroed before every sort): ghist[passes][256] | ticket[passes], error | per pass: tile words [tiles][256] then group words
+// [tiles/16 + 1][256]; a word = flag << 30 | count, flag 1 = aggregate, 2 = inclusive.
 // ------------------------------------------------------------------------------------------
 #define RS_THREADS 256
 #define RS_ITEMS 16
@@ -167,7 +176,9 @@ uint32_t* c3d_scan_error_word(void* tmp) { return (uint32_t*)tmp + 1; }
 #define RS_FLAG_AGG (1u << 30)
 #define RS_FLAG_INCL (2u << 30)
 #define RS_VALUE_MASK ((1u << 30) - 1u)
-#define RS_LOOKBACK 12
+#define RS_GROUP 16
+#define RS_LOOKBACK 32
+static inline size_t sort_pass_words(size_t nb) { return RS_RADIX * (nb + nb / RS_GROUP + 1); }
 
 __global__ void __launch_bounds__(RS_THREADS) k_radix_hist_all(const uint32_t* __restrict__ keys, uint32_t* __restrict__ ghist, size_t n,
                                                                 const uint32_t* __restrict__ n_dev, int passes) {
@@ -201,11 +212,23 @@ __global__ void __launch_bounds__(RS_THREADS) k_radix_hist_all(const uint32_t* _
     }
 }
 
+// poll one status word until its flag is at least `need` (1 = any, 2 = inclusive); bounded
+__device__ __forceinline__ uint32_t rs_wait(const uint32_t* p, uint32_t x, uint32_t need, uint32_t* err) {
+    uint32_t spins = 0;
+    while ((x >> 30) < need) {
+        if (++spins > LB_SPIN_LIMIT) { atomicOr(err, C3D_ERR_LOOKBACK); return RS_FLAG_INCL; }
+        __builtin_amdgcn_s_sleep(2);
+        x = ld_agent32(p);
+    }
+    return x;
+}
+
 template <bool IOTA>
 __global__ void __launch_bounds__(RS_THREADS, 4) k_onesweep(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-                                                          uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
-                                                          const uint32_t* __restrict__ ghist, uint32_t* __restrict__ ticket, uint32_t* __restrict__ err,
-                                                          uint32_t* __restrict__ status, size_t n, const uint32_t* __restrict__ n_dev, int shift) {
+                                                             uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                             const uint32_t* __restrict__ ghist, uint32_t* __restrict__ ticket, uint32_t* __restrict__ err,
+                                                             uint32_t* __restrict__ tile_words, uint32_t* __restrict__ group_words, size_t n,
+                                                             const uint32_t* __restrict__ n_dev, int shift) {
     __shared__ uint32_t whist[RS_THREADS / 64][RS_RADIX];
     __shared__ uint32_t lstart[RS_RADIX];    // first local slot of each digit
     __shared__ uint32_t gbase[RS_RADIX];     // global position of that slot
@@ -248,57 +271,78 @@ __global__ void __launch_bounds__(RS_THREADS, 4) k_onesweep(const uint32_t* __re
         rank[i] = prefix + r;
     }
     __syncthreads();
-    {   // thread d owns digit d: count over the 4 waves -> block-local exclusive start, per-wave offsets, and the digit's chained scan
-        const int d = threadIdx.x;
-        uint32_t c[RS_THREADS / 64], tot = 0;
+    // thread d owns digit d: count over the 4 waves, published at once (successors can already add it up), then the block-local layout
+    const int d = threadIdx.x;
+    const uint32_t grp = tile / RS_GROUP, gr = tile % RS_GROUP;
+    const bool leader = gr == RS_GROUP - 1;
+    const uint32_t gtotal = ghist[d];                    // occurrences of this digit in the whole input
+    uint32_t tot = 0;
+    {
+        uint32_t c[RS_THREADS / 64];
 #pragma unroll
         for (int w = 0; w < RS_THREADS / 64; w++) { c[w] = whist[w][d]; tot += c[w]; }
-        uint32_t* mine = status + (size_t)tile * RS_RADIX + d;
-        st_agent32(mine, (tile == 0 ? RS_FLAG_INCL : RS_FLAG_AGG) | tot);      // published first: successors can already add it up
+        if (gtotal) st_agent32(tile_words + (size_t)tile * RS_RADIX + d, RS_FLAG_AGG | tot);
         uint32_t blk_total, dummy;
         uint32_t ls = block_excl_scan(tot, scan_lds, &blk_total);
-        const uint32_t digit_base = block_excl_scan(ghist[d], scan_lds, &dummy);   // where digit d starts in the output
+        const uint32_t digit_base = block_excl_scan(gtotal, scan_lds, &dummy);   // where digit d starts in the output
         lstart[d] = ls;
+        gbase[d] = digit_base;
 #pragma unroll
         for (int w = 0; w < RS_THREADS / 64; w++) { whist[w][d] = ls; ls += c[w]; }
-        uint32_t excl = 0;
-        if (tile > 0) {
-            long long t = (long long)tile - 1;
-            bool done = false;
-            while (!done) {
-                uint32_t w[RS_LOOKBACK];
-#pragma unroll
-                for (int i = 0; i < RS_LOOKBACK; i++) w[i] = (t - i >= 0) ? ld_agent32(status + (size_t)(t - i) * RS_RADIX + d) : RS_FLAG_INCL;
-#pragma unroll
-                for (int i = 0; i < RS_LOOKBACK; i++) {
-                    if (!done) {
-                        uint32_t x = w[i];
-                        uint32_t spins = 0;
-                        while ((x >> 30) == 0u) {
-                            if (++spins > LB_SPIN_LIMIT) { atomicOr(err, C3D_ERR_LOOKBACK); x = RS_FLAG_INCL; break; }
-                            __builtin_amdgcn_s_sleep(2);
-                            x = ld_agent32(status + (size_t)(t - i) * RS_RADIX + d);
-                        }
-                        excl += x & RS_VALUE_MASK;
-                        done = (x >> 30) == 2u;
-                    }
-                }
-                t -= RS_LOOKBACK;
-            }
-            st_agent32(mine, RS_FLAG_INCL | (excl + tot));
-        }
-        gbase[d] = digit_base + excl;
     }
     __syncthreads();
+    // block-local reorder first: it needs no global prefix and frees the key / val / rank registers for the scan's loads
 #pragma unroll
     for (int i = 0; i < RS_ITEMS; i++) {
         size_t idx = wbase + (size_t)i * 64 + lane;
         if (idx < n) {
-            uint32_t d = (key[i] >> shift) & (RS_RADIX - 1);
-            uint32_t lp = whist[wave][d] + rank[i];
+            uint32_t dd = (key[i] >> shift) & (RS_RADIX - 1);
+            uint32_t lp = whist[wave][dd] + rank[i];
             skey[lp] = key[i];
             sval[lp] = val[i];
         }
+    }
+    // chained scan of digit d over the tiles (two-level, see the header of this section)
+    if (gtotal) {
+        uint32_t sum_in = 0;
+        {   // aggregates of the tiles before this one in its group: all loads first, then resolve
+            const uint32_t* base = tile_words + (size_t)grp * RS_GROUP * RS_RADIX + d;
+            uint32_t w[RS_GROUP - 1];
+#pragma unroll
+            for (int i = 0; i < RS_GROUP - 1; i++) w[i] = ((uint32_t)i < gr) ? ld_agent32(base + (size_t)i * RS_RADIX) : RS_FLAG_AGG;
+#pragma unroll
+            for (int i = 0; i < RS_GROUP - 1; i++)
+                if ((uint32_t)i < gr) sum_in += rs_wait(base + (size_t)i * RS_RADIX, w[i], 1u, err) & RS_VALUE_MASK;
+        }
+        uint32_t gexcl = 0;          // everything in earlier groups
+        uint32_t* gw = group_words + d;
+        if (leader) {
+            const uint32_t gtot = sum_in + tot;
+            st_agent32(gw + (size_t)grp * RS_RADIX, (grp == 0 ? RS_FLAG_INCL : RS_FLAG_AGG) | gtot);
+            if (grp > 0) {
+                long long t = (long long)grp - 1;
+                bool done = false;
+                while (!done) {
+                    uint32_t w[RS_LOOKBACK];
+#pragma unroll
+                    for (int i = 0; i < RS_LOOKBACK; i++) w[i] = (t - i >= 0) ? ld_agent32(gw + (size_t)(t - i) * RS_RADIX) : RS_FLAG_INCL;
+#pragma unroll
+                    for (int i = 0; i < RS_LOOKBACK; i++) {
+                        if (!done) {
+                            const uint32_t x = (t - i >= 0) ? rs_wait(gw + (size_t)(t - i) * RS_RADIX, w[i], 1u, err) : RS_FLAG_INCL;
+                            gexcl += x & RS_VALUE_MASK;
+                            done = (x >> 30) == 2u;
+                        }
+                    }
+                    t -= RS_LOOKBACK;
+                }
+                st_agent32(gw + (size_t)grp * RS_RADIX, RS_FLAG_INCL | (gexcl + gtot));
+            }
+        } else if (grp > 0) {
+            const uint32_t* p = gw + (size_t)(grp - 1) * RS_RADIX;
+            gexcl = rs_wait(p, ld_agent32(p), 2u, err) & RS_VALUE_MASK;
+        }
+        gbase[d] += gexcl + sum_in;
     }
     __syncthreads();
     const int cnt = (int)((n - bbase) < (size_t)RS_TILE ? (n - bbase) : (size_t)RS_TILE);
@@ -307,8 +351,8 @@ __global__ void __launch_bounds__(RS_THREADS, 4) k_onesweep(const uint32_t* __re
         const int lp = i * RS_THREADS + threadIdx.x;     // consecutive lanes -> consecutive slots of a digit run
         if (lp < cnt) {
             const uint32_t k = skey[lp];
-            const uint32_t d = (k >> shift) & (RS_RADIX - 1);
-            const uint32_t pos = gbase[d] + ((uint32_t)lp - lstart[d]);
+            const uint32_t dd = (k >> shift) & (RS_RADIX - 1);
+            const uint32_t pos = gbase[dd] + ((uint32_t)lp - lstart[dd]);
             keys_out[pos] = k;
             vals_out[pos] = sval[lp];
         }
@@ -318,14 +362,14 @@ __global__ void __launch_bounds__(RS_THREADS, 4) k_onesweep(const uint32_t* __re
 static inline size_t sort_head_bytes() { return c3d_align(sizeof(uint32_t) * (RS_RADIX * RS_MAX_PASSES + RS_MAX_PASSES + 4)); }
 size_t c3d_sort_tmp_bytes(size_t n) {
     const size_t nb = (size_t)c3d_cdiv((long long)(n ? n : 1), RS_TILE);
-    return sort_head_bytes() + c3d_align(sizeof(uint32_t) * RS_RADIX * nb * RS_MAX_PASSES);
+    return sort_head_bytes() + c3d_align(sizeof(uint32_t) * sort_pass_words(nb) * RS_MAX_PASSES);
 }
 uint32_t* c3d_sort_error_word(void* tmp) { return (uint32_t*)tmp + RS_RADIX * RS_MAX_PASSES + RS_MAX_PASSES; }
 size_t c3d_sort_state_bytes(size_t n, int end_bit) {
     int passes = (end_bit + 7) / 8;
     if (passes < 1) passes = 1;
     if (passes > RS_MAX_PASSES) passes = RS_MAX_PASSES;
-    return sort_head_bytes() + sizeof(uint32_t) * RS_RADIX * (size_t)c3d_cdiv((long long)(n ? n : 1), RS_TILE) * passes;
+    return sort_head_bytes() + sizeof(uint32_t) * sort_pass_words((size_t)c3d_cdiv((long long)(n ? n : 1), RS_TILE)) * passes;
 }
 
 int c3d_sort_pairs_u32(uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32_t* vals1, bool iota_vals,
@@ -347,11 +391,12 @@ int c3d_sort_pairs_u32(uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32
     hipLaunchKernelGGL(k_radix_hist_all, dim3(nb), dim3(RS_THREADS), 0, s, keys0, ghist, n, n_dev, passes);
     int cur = 0;
     for (int pass = 0; pass < passes; pass++) {
-        uint32_t* st = status + (size_t)pass * RS_RADIX * nb;
+        uint32_t* tw = status + (size_t)pass * sort_pass_words((size_t)nb);
+        uint32_t* gw = tw + (size_t)RS_RADIX * nb;
         if (pass == 0 && iota_vals)
-            hipLaunchKernelGGL(k_onesweep<true>, dim3(nb), dim3(RS_THREADS), 0, s, k[cur], v[cur], k[cur ^ 1], v[cur ^ 1], ghist + pass * RS_RADIX, tickets + pass, err, st, n, n_dev, 8 * pass);
+            hipLaunchKernelGGL(k_onesweep<true>, dim3(nb), dim3(RS_THREADS), 0, s, k[cur], v[cur], k[cur ^ 1], v[cur ^ 1], ghist + pass * RS_RADIX, tickets + pass, err, tw, gw, n, n_dev, 8 * pass);
         else
-            hipLaunchKernelGGL(k_onesweep<false>, dim3(nb), dim3(RS_THREADS), 0, s, k[cur], v[cur], k[cur ^ 1], v[cur ^ 1], ghist + pass * RS_RADIX, tickets + pass, err, st, n, n_dev, 8 * pass);
+            hipLaunchKernelGGL(k_onesweep<false>, dim3(nb), dim3(RS_THREADS), 0, s, k[cur], v[cur], k[cur ^ 1], v[cur ^ 1], ghist + pass * RS_RADIX, tickets + pass, err, tw, gw, n, n_dev, 8 * pass);
         C3D_LAUNCH_CHECK();
         cur ^= 1;
     }

@@ -17,3 +17,12 @@ for k in sorted(tab, key=lambda k: -tab[k]["launches"] * tab[k]["avg_us"]):
 print("\n".join(lines))
 if len(sys.argv) > 2:
     open(sys.argv[2], "w").write("\n".join(lines) + "\n")
+    import json
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "comfyui-3d-pack_amd"))
+    try:
+        import c3d_hip
+        dig = c3d_hip.code_digest()
+    except Exception:
+        dig = None
+    json.dump({"code_digest": dig}, open(sys.argv[2] + ".meta.json", "w"))      # sidecar: which kernel code these counters describe

@@ -171,12 +171,24 @@ def test_baseline_config5_499k_triangles_1024px_vs_float64_oracle():
     dvt, drast = M.interpolate_bwd(vt[None], r64, f, duv, dtype=d)
     dpos_r = M.rasterize_bwd(pos, f, r64, drast, dtype=d)
     assert rel_err(ttex.grad.cpu().numpy(), dtex) <= GRAD_REL
-    assert rel_err(tvt.grad.cpu().numpy(), dvt) <= GRAD_REL
-    assert rel_err(tpos.grad.cpu().numpy(), dpos_aa + dpos_al + dpos_r) <= 2 * GRAD_REL
-    # relative L2 over the tensors; the element-wise share is reported (pixels whose triangle id differs carry a different gradient by construction)
-    assert_grad_close(ttex.grad.cpu().numpy(), dtex, "config5 dL/dtex", rel_l2=5e-3, max_frac=5e-3, hard=1e9)
-    assert_grad_close(tvt.grad.cpu().numpy(), dvt, "config5 dL/dvt", rel_l2=5e-3, max_frac=5e-3, hard=1e9)
-    assert_grad_close(tpos.grad.cpu().numpy(), dpos_aa + dpos_al + dpos_r, "config5 dL/dpos", rel_l2=1e-2, max_frac=2e-2, hard=1e9)
+    # A pixel whose triangle id differs (depth near-tie; n_diff above) hands its whole gradient to other vertices, by construction: the vertices of
+    # both candidate triangles of such pixels and of their 8 neighbours (antialias pairs) are left out of the per-vertex comparisons.
+    keep = np.ones(v.shape[0], bool)
+    ys, xs = np.nonzero(~same[0])
+    for y, x in zip(ys, xs):
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                yy, xx = min(max(y + dy, 0), H - 1), min(max(x + dx, 0), W - 1)
+                for ids in (r[0, yy, xx, 3], orast[0, yy, xx, 3]):
+                    if ids > 0:
+                        keep[f[int(ids) - 1]] = False
+    print("[mesh config5] %d vertices excluded around %d differing pixels" % (int((~keep).sum()), n_diff))
+    gvt, gpos, rpos = tvt.grad.cpu().numpy()[0], tpos.grad.cpu().numpy()[0], (dpos_aa + dpos_al + dpos_r)[0]
+    assert rel_err(gvt[keep], dvt[0][keep]) <= GRAD_REL
+    assert rel_err(gpos[keep], rpos[keep]) <= 2 * GRAD_REL
+    assert_grad_close(ttex.grad.cpu().numpy(), dtex, "config5 dL/dtex", rel_l2=2e-3, max_frac=5e-3, hard=1e9)
+    assert_grad_close(gvt[keep], dvt[0][keep], "config5 dL/dvt", rel_l2=2e-3, max_frac=5e-3, hard=1e9)
+    assert_grad_close(gpos[keep], rpos[keep], "config5 dL/dpos", rel_l2=5e-3, max_frac=2e-2, hard=1e9)
 
 
 def test_texture_modes_and_batches():
