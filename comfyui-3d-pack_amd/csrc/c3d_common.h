@@ -63,6 +63,7 @@ uint32_t* c3d_scan_error_word(void* tmp);
 size_t c3d_sort_tmp_bytes(size_t n);
 size_t c3d_sort_state_bytes(size_t n, int end_bit);
 uint32_t* c3d_sort_error_word(void* tmp);
+int c3d_sort_set_debug(unsigned long long* stamps);   // profiling hook (nullptr = off): [pass][tile][8] wall_clock64 stamps
 int c3d_sort_pairs_u32(uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32_t* vals1, bool iota_vals,
                        size_t n, int end_bit, void* tmp, int* result_buf, hipStream_t s, const uint32_t* n_dev = nullptr, bool zero_state = true, uint32_t* err = nullptr);
 

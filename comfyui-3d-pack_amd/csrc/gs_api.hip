@@ -580,6 +580,7 @@ int c3d_test_scan_u32(const uint32_t* in, uint32_t* out, int64_t n, int32_t excl
     (void)hipFree(tmp);
     return rc;
 }
+int c3d_test_sort_phases(uint64_t* stamps) { return c3d_sort_set_debug((unsigned long long*)stamps); }
 int c3d_test_sort_pairs_u32(uint32_t* keys, uint32_t* vals, int64_t n, int32_t end_bit, c3d_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     if (n <= 0) return 0;

@@ -165,7 +165,7 @@ uint32_t* c3d_scan_error_word(void* tmp) { return (uint32_t*)tmp + 1; }
 //   (32 in flight per lane: 1000 tiles = 62 groups = two batches) and publishes the group's inclusive prefix.
 // Three dependent hand-offs whatever the tile count, ~17 KB of status reads per tile.  Every wait is on a tile with a LOWER ticket.
 // Digits that do not occur in this pass (ghist == 0: most of the high bytes) skip the scan altogether.
-// State (zeroed before every sort): ghist[passes][256] | ticket[passes], error | per pass: tile words [tiles][256] then group words
+// State (zeroed before every sort): ghist[16 copies][passes][256] | ticket[passes], error | per pass: tile words [tiles][256] then group words
 // [tiles/16 + 1][256]; a word = flag << 30 | count, flag 1 = aggregate, 2 = inclusive.
 // ------------------------------------------------------------------------------------------
 #define RS_THREADS 256
@@ -178,6 +178,8 @@ uint32_t* c3d_scan_error_word(void* tmp) { return (uint32_t*)tmp + 1; }
 #define RS_VALUE_MASK ((1u << 30) - 1u)
 #define RS_GROUP 16
 #define RS_LOOKBACK 32
+#define RS_HIST_SPLIT 16      // copies of the global histogram (workgroup b adds to copy b % 16): 245 - 1000 workgroups adding to ONE set of 256 counters serialise at the
+                              // memory-side atomic unit (measured: 23 us for 1 M keys, profiles/r02c); consumers add the 16 copies up
 static inline size_t sort_pass_words(size_t nb) { return RS_RADIX * (nb + nb / RS_GROUP + 1); }
 
 __global__ void __launch_bounds__(RS_THREADS) k_radix_hist_all(const uint32_t* __restrict__ keys, uint32_t* __restrict__ ghist, size_t n,
@@ -206,9 +208,10 @@ __global__ void __launch_bounds__(RS_THREADS) k_radix_hist_all(const uint32_t* _
         }
     }
     __syncthreads();
+    uint32_t* mine = ghist + (size_t)(blockIdx.x % RS_HIST_SPLIT) * RS_MAX_PASSES * RS_RADIX;
     for (int p = 0; p < passes; p++) {
         const uint32_t c = h[p][threadIdx.x];
-        if (c) atomicAdd(&ghist[p * RS_RADIX + threadIdx.x], c);
+        if (c) atomicAdd(&mine[p * RS_RADIX + threadIdx.x], c);
     }
 }
 
@@ -228,7 +231,7 @@ __global__ void __launch_bounds__(RS_THREADS, 4) k_onesweep(const uint32_t* __re
                                                              uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                              const uint32_t* __restrict__ ghist, uint32_t* __restrict__ ticket, uint32_t* __restrict__ err,
                                                              uint32_t* __restrict__ tile_words, uint32_t* __restrict__ group_words, size_t n,
-                                                             const uint32_t* __restrict__ n_dev, int shift) {
+                                                             const uint32_t* __restrict__ n_dev, int shift, unsigned long long* __restrict__ dbg) {
     __shared__ uint32_t whist[RS_THREADS / 64][RS_RADIX];
     __shared__ uint32_t lstart[RS_RADIX];    // first local slot of each digit
     __shared__ uint32_t gbase[RS_RADIX];     // global position of that slot
@@ -244,6 +247,8 @@ __global__ void __launch_bounds__(RS_THREADS, 4) k_onesweep(const uint32_t* __re
     const uint32_t tile = s_tile;
     const size_t bbase = (size_t)tile * RS_TILE;
     if (bbase >= n) return;                  // capacity-sized launch: tickets beyond the data leave at once (nobody waits for them)
+#define RS_STAMP(k) do { if (dbg && threadIdx.x == 0) dbg[(size_t)tile * 8 + (k)] = (unsigned long long)wall_clock64(); } while (0)   // profiling hook (profiles/microbench/sort_phases.py)
+    RS_STAMP(0);
     const size_t wbase = bbase + (size_t)wave * (RS_TILE / 4);
     uint32_t key[RS_ITEMS], val[RS_ITEMS], rank[RS_ITEMS];
 #pragma unroll
@@ -254,6 +259,8 @@ __global__ void __launch_bounds__(RS_THREADS, 4) k_onesweep(const uint32_t* __re
         val[i] = IOTA ? (uint32_t)idx : (ok ? vals_in[idx] : 0u);
     }
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    if (dbg) { uint32_t x = 0; for (int i = 0; i < RS_ITEMS; i++) x ^= key[i] ^ val[i]; if (x == 0x12345u) dbg[7] = 1; }   // wait for the loads before stamping
+    RS_STAMP(1);
 #pragma unroll
     for (int i = 0; i < RS_ITEMS; i++) {
         size_t idx = wbase + (size_t)i * 64 + lane;
@@ -271,11 +278,14 @@ __global__ void __launch_bounds__(RS_THREADS, 4) k_onesweep(const uint32_t* __re
         rank[i] = prefix + r;
     }
     __syncthreads();
+    RS_STAMP(2);
     // thread d owns digit d: count over the 4 waves, published at once (successors can already add it up), then the block-local layout
     const int d = threadIdx.x;
     const uint32_t grp = tile / RS_GROUP, gr = tile % RS_GROUP;
     const bool leader = gr == RS_GROUP - 1;
-    const uint32_t gtotal = ghist[d];                    // occurrences of this digit in the whole input
+    uint32_t gtotal = 0;                                 // occurrences of this digit in the whole input
+#pragma unroll
+    for (int c = 0; c < RS_HIST_SPLIT; c++) gtotal += ghist[(size_t)c * RS_MAX_PASSES * RS_RADIX + d];
     uint32_t tot = 0;
     {
         uint32_t c[RS_THREADS / 64];
@@ -302,6 +312,7 @@ __global__ void __launch_bounds__(RS_THREADS, 4) k_onesweep(const uint32_t* __re
             sval[lp] = val[i];
         }
     }
+    RS_STAMP(3);
     // chained scan of digit d over the tiles (two-level, see the header of this section)
     if (gtotal) {
         uint32_t sum_in = 0;
@@ -345,6 +356,7 @@ __global__ void __launch_bounds__(RS_THREADS, 4) k_onesweep(const uint32_t* __re
         gbase[d] += gexcl + sum_in;
     }
     __syncthreads();
+    RS_STAMP(4);
     const int cnt = (int)((n - bbase) < (size_t)RS_TILE ? (n - bbase) : (size_t)RS_TILE);
 #pragma unroll
     for (int i = 0; i < RS_ITEMS; i++) {
@@ -357,14 +369,17 @@ __global__ void __launch_bounds__(RS_THREADS, 4) k_onesweep(const uint32_t* __re
             vals_out[pos] = sval[lp];
         }
     }
+    RS_STAMP(5);
+#undef RS_STAMP
 }
 
-static inline size_t sort_head_bytes() { return c3d_align(sizeof(uint32_t) * (RS_RADIX * RS_MAX_PASSES + RS_MAX_PASSES + 4)); }
+static unsigned long long* g_sort_dbg = nullptr;     // profiling hook: [pass][tile][8] wall_clock64 stamps (100 MHz), see c3d_test_sort_phases
+static inline size_t sort_head_bytes() { return c3d_align(sizeof(uint32_t) * (RS_HIST_SPLIT * RS_RADIX * RS_MAX_PASSES + RS_MAX_PASSES + 4)); }
 size_t c3d_sort_tmp_bytes(size_t n) {
     const size_t nb = (size_t)c3d_cdiv((long long)(n ? n : 1), RS_TILE);
     return sort_head_bytes() + c3d_align(sizeof(uint32_t) * sort_pass_words(nb) * RS_MAX_PASSES);
 }
-uint32_t* c3d_sort_error_word(void* tmp) { return (uint32_t*)tmp + RS_RADIX * RS_MAX_PASSES + RS_MAX_PASSES; }
+uint32_t* c3d_sort_error_word(void* tmp) { return (uint32_t*)tmp + RS_HIST_SPLIT * RS_RADIX * RS_MAX_PASSES + RS_MAX_PASSES; }
 size_t c3d_sort_state_bytes(size_t n, int end_bit) {
     int passes = (end_bit + 7) / 8;
     if (passes < 1) passes = 1;
@@ -382,7 +397,7 @@ int c3d_sort_pairs_u32(uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32
     if (passes < 1) passes = 1;
     const int nb = c3d_cdiv((long long)n, RS_TILE);
     uint32_t* ghist = (uint32_t*)tmp;
-    uint32_t* tickets = ghist + RS_RADIX * RS_MAX_PASSES;
+    uint32_t* tickets = ghist + RS_HIST_SPLIT * RS_RADIX * RS_MAX_PASSES;
     uint32_t* err = err_out ? err_out : c3d_sort_error_word(tmp);
     uint32_t* status = (uint32_t*)((char*)tmp + sort_head_bytes());
     if (zero_state) C3D_CHECK(hipMemsetAsync(tmp, 0, c3d_sort_state_bytes(n, end_bit), s));
@@ -394,12 +409,15 @@ int c3d_sort_pairs_u32(uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32
         uint32_t* tw = status + (size_t)pass * sort_pass_words((size_t)nb);
         uint32_t* gw = tw + (size_t)RS_RADIX * nb;
         if (pass == 0 && iota_vals)
-            hipLaunchKernelGGL(k_onesweep<true>, dim3(nb), dim3(RS_THREADS), 0, s, k[cur], v[cur], k[cur ^ 1], v[cur ^ 1], ghist + pass * RS_RADIX, tickets + pass, err, tw, gw, n, n_dev, 8 * pass);
+            hipLaunchKernelGGL(k_onesweep<true>, dim3(nb), dim3(RS_THREADS), 0, s, k[cur], v[cur], k[cur ^ 1], v[cur ^ 1], ghist + pass * RS_RADIX, tickets + pass, err, tw, gw, n, n_dev, 8 * pass, g_sort_dbg ? g_sort_dbg + (size_t)pass * nb * 8 : nullptr);
         else
-            hipLaunchKernelGGL(k_onesweep<false>, dim3(nb), dim3(RS_THREADS), 0, s, k[cur], v[cur], k[cur ^ 1], v[cur ^ 1], ghist + pass * RS_RADIX, tickets + pass, err, tw, gw, n, n_dev, 8 * pass);
+            hipLaunchKernelGGL(k_onesweep<false>, dim3(nb), dim3(RS_THREADS), 0, s, k[cur], v[cur], k[cur ^ 1], v[cur ^ 1], ghist + pass * RS_RADIX, tickets + pass, err, tw, gw, n, n_dev, 8 * pass, g_sort_dbg ? g_sort_dbg + (size_t)pass * nb * 8 : nullptr);
         C3D_LAUNCH_CHECK();
         cur ^= 1;
     }
     *result_buf = cur;
     return 0;
 }
+
+// test / profiling hook: one sort with per-tile phase stamps -> stamps[passes][tiles][8] (device), wall_clock64 ticks
+int c3d_sort_set_debug(unsigned long long* stamps) { g_sort_dbg = stamps; return 0; }
