@@ -61,10 +61,11 @@ def parse():
                     help="step: c3d_gs_train_views_raw, all views of the step forward+loss+backward in one sync-free library call (product default for training); fused: GaussianSplattingRenderer.render with activations folded into the kernels (product default); accessor: the same "
                          "API through the reference's op-by-op accessors; boundary: bare diff_gaussian_rasterization call on pre-activated leaves")
     ap.add_argument("--workload", choices=["gs", "mesh"], default="gs", help="gs = BASELINE configs 2-4 (the metric); mesh = config 5 (DiffRastMesh)")
-    ap.add_argument("--loss", choices=["auto", "l1alpha", "full"], default="auto",
+    ap.add_argument("--loss", choices=["auto", "l1alpha", "full", "full-torch"], default="auto",
                     help="pixel loss of the step path: l1alpha = 0.8 L1 + 3 MSE(alpha) inside c3d_gs_train_views_raw; full = BASELINE config 3's loss, the reference's default "
                          "(main_3DGS.py:184-192): + 0.2 (1 - MS-SSIM), masked by the target alpha, through c3d_gs_forward_views_raw -> torch -> c3d_gs_backward_views_raw.  "
-                         "auto: full for --mode train, l1alpha for --mode fwdbwd")
+                         "auto: full for --mode train, l1alpha for --mode fwdbwd; full = the MS-SSIM term by the fused HIP kernels inside the same library call, full-torch = the step "
+                         "split at the image with torch's op chain for the loss (what round 2 started from: 65 ms of MS-SSIM per step)")
     return ap.parse_args()
 
 
@@ -313,7 +314,7 @@ def main():
     fused_step = None
     loss_kind = a.loss if a.loss != "auto" else ("full" if a.mode == "train" else "l1alpha")
     ms_ssim = None
-    if loss_kind == "full" and a.render_path == "step" and a.mode != "fwd":
+    if loss_kind == "full-torch" and a.render_path == "step" and a.mode != "fwd":
         from shared_utils.msssim import MS_SSIM
         ms_ssim = MS_SSIM(data_range=1, size_average=True, channel=3)
     if a.render_path == "step" and a.mode != "fwd":
@@ -336,8 +337,9 @@ def main():
             with torch.no_grad():
                 view_render.run(settings, plist)
         elif fused_step is not None and not collect and ms_ssim is None:
-            fused_step.run(settings, [q.detach() for q in plist], step_grads, [tg[0] for tg in targets], [tg[1] for tg in targets], None,
-                           w_l1=0.8, w_l2=0.0, w_alpha_mse=3.0, scale=1.0 / (a.views_per_gpu * world), accumulate=False)
+            full = loss_kind == "full"      # BASELINE config 3's loss: masked by the target alpha, + 0.2 (1 - MS-SSIM), all inside the library call
+            fused_step.run(settings, [q.detach() for q in plist], step_grads, [tg[0] for tg in targets], [tg[1] for tg in targets], ([tg[1] for tg in targets] if full else None),
+                           w_l1=0.8, w_l2=0.0, w_alpha_mse=3.0, scale=1.0 / (a.views_per_gpu * world), accumulate=False, w_ssim=(0.2 if full else 0.0))
             for q, gq in zip(plist, step_grads):
                 q.grad = gq
         elif fused_step is not None and not collect:
@@ -538,7 +540,8 @@ def main():
                                    % (a.mode, N, deg, W, H, a.views_per_gpu),
                        "global_views_per_step": a.views_per_gpu * world, "parallelism": "view-parallel dp%d" % world,
                        "exchange": (a.exchange if world > 1 and a.mode != "fwd" else "none"), "render_path": a.render_path,
-                       "loss": (None if a.mode == "fwd" else ("0.8 L1 + 3 MSE(alpha) + 0.2 (1 - MS-SSIM), masked (BASELINE config 3)" if ms_ssim is not None else "0.8 L1 + 3 MSE(alpha)")), "view_lanes": (a.lanes if a.render_path == "step" else 1),
+                       "loss": (None if a.mode == "fwd" else ("0.8 L1 + 3 MSE(alpha) + 0.2 (1 - MS-SSIM), masked (BASELINE config 3)%s" % (", MS-SSIM by torch ops" if ms_ssim is not None else ", fused HIP")
+                                                                if loss_kind != "l1alpha" and a.render_path == "step" else "0.8 L1 + 3 MSE(alpha)")), "view_lanes": (a.lanes if a.render_path == "step" else 1),
                        "host_enqueue_ms_per_step": (round(fused_step.last_host_ms, 3) if fused_step is not None else None),
                        "n_visible": n_vis, "tile_splat_pairs": D},
             "roofline": roof, "roofline_chain": chain, "cpu_baseline": cpu, "kernels": kern, "kernels_concurrent_avg_ms": kern_conc,

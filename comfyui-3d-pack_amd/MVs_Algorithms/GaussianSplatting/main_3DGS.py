@@ -97,6 +97,7 @@ class GaussianSplatting3D:
         self.params = [g._xyz, g._features_dc, g._features_rest, g._opacity, g._scaling, g._rotation]
         parallel.broadcast_parameters(self.params, src=0, group=process_group)
         self.use_fused_step, self._step = True, None       # the fused rasterizer step serves every loss configuration (see _can_fuse)
+        self.image_loss_in_torch = False                     # True: fused forward / backward halves with the image loss (incl. MS-SSIM) as torch ops in between
 
     def prepare_training(self, reference_images, reference_masks, reference_orbit_camera_poses, reference_orbit_camera_fovy):
         self.ref_imgs_num = len(reference_images)
@@ -191,8 +192,8 @@ class GaussianSplatting3D:
 
     # ---- fused multi-view step: all of this rank's views in sync-free library calls ----
     def _can_fuse(self):
-        """Every loss the reference's trainer can be configured with goes through the fused rasterizer step (round 2): the L1 / alpha-MSE
-        terms alone inside c3d_gs_train_views_raw, anything with MS-SSIM through the forward / backward halves with torch in between.
+        """Every loss the reference's trainer can be configured with goes through the fused rasterizer step (round 2): L1, alpha MSE and
+        MS-SSIM inside c3d_gs_train_views_raw (`image_loss_in_torch` switches to the forward / backward halves with torch's loss in between).
         Backgrounds are per view, drawn exactly as BaseCameraController.render_at_pose draws them."""
         g = self.renderer.gaussians
         return self.use_fused_step and self.device.type == "cuda" and g.max_sh_degree == 3
@@ -228,17 +229,16 @@ class GaussianSplatting3D:
                                                        cam.world_view_transform, cam.full_proj_transform, 3, cam.camera_center, False, False))
         n_mine = max(len(mine), 1)
         plist = [q.detach() for q in self.params]
-        if p.lambda_ssim == 0:
-            # L1 + alpha MSE only: loss value and dL/dimage come out of the compositing epilogue, ONE library call for the whole step.
-            # (c - ref) * mask: the unmasked reference is the target and the mask the pixel weight, as the reference's (c*m - ref*m).
+        if len(mine) == 0 or not self.image_loss_in_torch:
+            # The whole image loss of main_3DGS.py:184-192 inside ONE library call: loss value and dL/dimage of the L1 / alpha-MSE terms come out of
+            # a fused pixel pass, the MS-SSIM term (weight lambda_ssim, include/c3d_loss.h) from the HIP multi-scale SSIM kernels on the view's lane.
+            # (c - ref) * mask: the unmasked reference is the target and the mask the pixel weight, as the reference's (c * m - ref * m).
             loss = self._step.run(views, plist, self._step_grads, [self.ref_imgs_torch[i].contiguous() for i in mine],
                                   [self.ref_masks_torch[i].contiguous() for i in mine], [self.ref_masks_torch[i].contiguous() for i in mine],
-                                  w_l1=1.0, w_l2=0.0, w_alpha_mse=p.lambda_alpha, scale=1.0 / n_mine,
+                                  w_l1=1.0 - p.lambda_ssim, w_l2=0.0, w_alpha_mse=p.lambda_alpha, scale=1.0 / n_mine, w_ssim=p.lambda_ssim,
                                   accumulate=False)      # every gradient is written exactly once: no zero-fill
-        elif len(mine) == 0:
-            loss = self._step.run(views, plist, self._step_grads, [], None, None, accumulate=False)       # zero gradients for a rank without views
         else:
-            # the default loss (MS-SSIM): forward all views -> torch differentiates the image loss -> backward all views
+            # the same step split at the image: forward all views -> torch differentiates the image loss -> backward all views (any loss torch can express)
             colors, _, alphas, _ = self._step.forward(views, plist)
             colors.requires_grad_(True); alphas.requires_grad_(True)
             with torch.enable_grad():

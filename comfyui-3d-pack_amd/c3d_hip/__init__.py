@@ -27,7 +27,7 @@ class GsSettings(C.Structure):
 
 class GsLoss(C.Structure):
     """struct c3d_gs_loss"""
-    _fields_ = [("w_l1", f32), ("w_l2", f32), ("w_alpha_mse", f32), ("scale", f32)]
+    _fields_ = [("w_l1", f32), ("w_l2", f32), ("w_alpha_mse", f32), ("scale", f32), ("w_ssim", f32)]
 
 
 _SIGNATURES = {
@@ -55,6 +55,8 @@ _SIGNATURES = {
     "c3d_adam_step": (C.c_int, [vp, vp, vp, vp, i64, C.c_double, C.c_double, C.c_double, C.c_double, i64, vp]),
     "c3d_knn_scratch_bytes": (sz, [i32]),
     "c3d_knn3_mean_dist2": (C.c_int, [vp, i32, C.POINTER(C.c_float), C.POINTER(C.c_float), vp, vp, vp]),
+    "c3d_msssim_workspace_bytes": (sz, [i32, i32, i32, i32]),
+    "c3d_msssim_value_grad": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp]),
     "c3d_reduce_ranks_f32": (C.c_int, [vp, vp, i32, i64, C.c_float, vp]),
     "c3d_prof_enable": (C.c_int, [C.c_int]),
     "c3d_prof_slots": (C.c_int, []),

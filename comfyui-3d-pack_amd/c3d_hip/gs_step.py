@@ -42,7 +42,7 @@ class FusedViewStep:
         return arr
 
     def run(self, raster_settings, params, grads, target_color, target_alpha=None, color_mask=None, w_l1=1.0, w_l2=0.0, w_alpha_mse=0.0, scale=1.0, max_retries=3,
-            accumulate=True):
+            accumulate=True, w_ssim=0.0):
         """params / grads: (xyz, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw) tensors; accumulate=True adds to the grads (zero them per
         step), False overwrites them (no zero-fill needed).  -> loss tensor (device scalar, the sum over the views).  Synchronises once, at
         the end, to read the overflow flag."""
@@ -62,7 +62,7 @@ class FusedViewStep:
             tc = (C.c_void_p * V)(*[t.data_ptr() for t in target_color])
             ta = (C.c_void_p * V)(*[t.data_ptr() for t in target_alpha]) if target_alpha is not None else None
             cm = (C.c_void_p * V)(*[t.data_ptr() for t in color_mask]) if color_mask is not None else None
-            loss = _h.GsLoss(float(w_l1), float(w_l2), float(w_alpha_mse), float(scale))
+            loss = _h.GsLoss(float(w_l1), float(w_l2), float(w_alpha_mse), float(scale), float(w_ssim))
             if accumulate:
                 snapshot = [g.clone() for g in grads] if attempt == 0 else snapshot     # to redo the step after an overflow
             self.status.zero_(); self.loss.zero_()

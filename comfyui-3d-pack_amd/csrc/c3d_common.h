@@ -26,11 +26,11 @@ static inline size_t c3d_align(size_t x, size_t a = 256) { return (x + a - 1) / 
 static inline int c3d_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // ---- optional event timing (prof.hip) ----
-#define C3D_PROF_SLOTS 20
+#define C3D_PROF_SLOTS 21
 enum { C3D_P_PREPROCESS = 0, C3D_P_DEPTH_SORT, C3D_P_SCAN, C3D_P_EMIT, C3D_P_TILE_SORT, C3D_P_RANGES, C3D_P_COMPOSITE_FWD,
        C3D_P_COMPOSITE_BWD, C3D_P_PREPROCESS_BWD, C3D_P_ADAM, C3D_P_MESH_RASTERIZE, C3D_P_MESH_INTERPOLATE, C3D_P_MESH_TEXTURE,
        C3D_P_MESH_ANTIALIAS, C3D_P_MESH_BWD, C3D_P_OTHER, C3D_P_MESH_RASTERIZE_BWD, C3D_P_MESH_INTERPOLATE_BWD,
-       C3D_P_MESH_TEXTURE_BWD, C3D_P_MESH_ANTIALIAS_BWD };
+       C3D_P_MESH_TEXTURE_BWD, C3D_P_MESH_ANTIALIAS_BWD, C3D_P_MSSSIM };
 void* c3d_prof_begin(int slot, hipStream_t s);
 void c3d_prof_end(void* h, hipStream_t s);
 struct C3dProfScope {

@@ -1,5 +1,6 @@
 // gs_api.hip -- extern "C" entry points declared in include/c3d_gs.h.
 #include "../../include/c3d_gs.h"
+#include "../../include/c3d_loss.h"
 #include "gs_internal.h"
 #include <mutex>
 #include <stdarg.h>
@@ -13,6 +14,9 @@ void c3d_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+// msssim.hip: out_word += va + vb * mean MS-SSIM(x, y_eff), dL_dy (+)= grad_scale * d mean / dy
+int ms_value_grad(const float* x, const float* y, const float* mask, int clamp_y, int B, int C, int H, int W, float grad_scale, int accumulate, float* dL_dy,
+                  float va, float vb, float* ms_out, void* workspace, hipStream_t s);
 static int g_exact_dscale = 0;   // c3d_gs_set_exact_dscale
 static int tile_sort_bits(int tiles) {
     int bits = 0;
@@ -253,7 +257,7 @@ int c3d_gs_backward_raw(const c3d_gs_settings* st, int32_t N, const float* means
 // ---- fused multi-view paths (no host synchronisation inside) ----------------------------------------------------------------
 struct StepWs {
     char* geom; char* binning; char* image; int* radii; float* color; float* depth; float* alpha; float* dcolor; float* dalpha; float* pairgrad; uint8_t* pvalid;
-    float* dmeans2D; float* gcol;
+    float* dmeans2D; float* gcol; char* ms_ws;
     size_t bytes;
 };
 static void carve_step(char* base, int N, int H, int W, long long cap, StepWs& w) {
@@ -271,6 +275,7 @@ static void carve_step(char* base, int N, int H, int W, long long cap, StepWs& w
     w.pvalid = (uint8_t*)take((size_t)(cap > 0 ? cap : 1));
     w.dmeans2D = (float*)take(12 * n);
     w.gcol = (float*)take(12 * n);
+    w.ms_ws = take(c3d_msssim_workspace_bytes(1, 3, H, W));       // MS-SSIM term of the pixel loss (w_ssim != 0)
     w.bytes = off;
 }
 
@@ -416,7 +421,13 @@ int c3d_gs_train_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, c
             // pixel loss and its gradient
             { C3dProfScope ps(C3D_P_OTHER, s);
               if ((rc = gs_launch_loss_grad(w.color, w.alpha, target_color[v], target_alpha ? target_alpha[v] : nullptr, color_mask ? color_mask[v] : nullptr, (long long)p.W * p.H, loss->w_l1,
-                                            loss->w_l2, loss->w_alpha_mse, loss->scale, w.dcolor, w.dalpha, loss_out, s))) break; }
+                                            loss->w_l2, loss->w_alpha_mse, loss->scale, w.dcolor, w.dalpha, loss_out, s))) break;
+              // + scale * w_ssim * (1 - MS-SSIM(target * mask, clamp(C) * mask)) of this view (the batch mean of the reference, main_3DGS.py:192, is the mean of
+              // the per-image values): value into loss_out, gradient added to dL/dcolor -- ~20 launches on this view's lane, no torch op, no sync
+              if (loss->w_ssim != 0.f) {
+                  const float ws_ = loss->scale * loss->w_ssim;
+                  if ((rc = ms_value_grad(target_color[v], w.color, color_mask ? color_mask[v] : nullptr, 1, 1, 3, p.H, p.W, -ws_, 1, w.dcolor, ws_, -ws_, loss_out, w.ms_ws, s))) break;
+              } }
             // backward down to the per-(tile, splat) records of this view
             { C3dProfScope ps(C3D_P_COMPOSITE_BWD, s);
               if ((rc = gs_launch_composite_bwd(p, g, b, res, im, w.dcolor, nullptr, w.dalpha, w.pairgrad, w.pvalid, (long long)cap, s, cap))) break; }

@@ -1,0 +1,322 @@
+// msssim.hip -- multi-scale SSIM value + gradient (include/c3d_loss.h) for the trainers' loss term
+//   loss += lambda * (1 - MS_SSIM(refs, imgs))        main_3DGS.py:192, diff_mesh.py:123 (reference)
+// One workgroup = one 32 x 32 tile of one (image, channel) plane; the five 11-tap separable Gaussian filters of a level (x, y, x^2, y^2, xy)
+// run through LDS: a 42 x 42 input tile, a horizontal pass into a 5 x 42 x 32 intermediate, a vertical pass of four outputs per lane.
+// Backward: the three per-pixel derivative maps the forward pass leaves behind (d map / d mu_y, d map / d E[y^2], d map / d E[xy]) are
+// filtered with the transposed (= same, the window is symmetric) filters, zero padded, and combined with x, y and the level's scalar
+// dL/d(mean map); the 2 x 2 average pooling between levels is chained by reading the parent level's finished gradient.
+// No atomics: tile sums are reduced in a fixed order, so value and gradient are bit-reproducible.
+#include "../../include/c3d_loss.h"
+#include "c3d_common.h"
+#include <math.h>
+
+#define MS_LEVELS 5
+#define MS_T 32
+#define MS_R 5
+#define MS_IN (MS_T + 2 * MS_R)
+#define MS_C1 (0.01f * 0.01f)
+#define MS_C2 (0.03f * 0.03f)
+
+struct MsWin { float w[2 * MS_R + 1]; };
+struct MsLevel { int H, W, Hv, Wv, tx, ty; };          // image size, valid (filtered) size, tiles over the valid size
+
+// level-0 input transform: x * mask, clamp(y) * mask
+template <bool L0>
+__device__ __forceinline__ void ms_load(const float* __restrict__ X, const float* __restrict__ Y, const float* __restrict__ mask, int clamp_y, int C,
+                                        int plane, size_t HW, size_t off, float& x, float& y) {
+    x = X[(size_t)plane * HW + off];
+    y = Y[(size_t)plane * HW + off];
+    if (L0) {
+        if (clamp_y) y = fminf(fmaxf(y, 0.f), 1.f);
+        if (mask) { const float m = mask[(size_t)(plane / C) * HW + off]; x *= m; y *= m; }
+    }
+}
+
+// 2 x 2 average pooling with padding = size % 2 on both sides, zeros counted (torch avg_pool2d defaults): level l -> l + 1, x and y together
+template <bool L0>
+__global__ void __launch_bounds__(256) k_ms_pool(const float* __restrict__ X, const float* __restrict__ Y, const float* __restrict__ mask, int clamp_y, int C,
+                                                 int H, int W, int H2, int W2, float* __restrict__ X2, float* __restrict__ Y2) {
+    const int plane = blockIdx.z;
+    const int j = blockIdx.x * 64 + (threadIdx.x & 63), i = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (i >= H2 || j >= W2) return;
+    const int py = H & 1, px = W & 1;
+    float sx = 0.f, sy = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            const int r = 2 * i - py + a, c = 2 * j - px + b;
+            if (r >= 0 && r < H && c >= 0 && c < W) {
+                float x, y;
+                ms_load<L0>(X, Y, mask, clamp_y, C, plane, (size_t)H * W, (size_t)r * W + c, x, y);
+                sx += x; sy += y;
+            }
+        }
+    X2[((size_t)plane * H2 + i) * W2 + j] = 0.25f * sx;
+    Y2[((size_t)plane * H2 + i) * W2 + j] = 0.25f * sy;
+}
+
+// forward of one level: derivative maps + the tile's sum of cs (levels 0-3) or ssim (last level)
+template <bool LAST, bool L0>
+__global__ void __launch_bounds__(256) k_ms_fwd(const float* __restrict__ X, const float* __restrict__ Y, const float* __restrict__ mask, int clamp_y, int C,
+                                                MsLevel lv, MsWin win, float* __restrict__ mapA, float* __restrict__ mapB, float* __restrict__ mapC,
+                                                float* __restrict__ partial) {
+    __shared__ float sx[MS_IN][MS_IN + 1];
+    __shared__ float sy[MS_IN][MS_IN + 1];
+    __shared__ float hh[5][MS_IN][MS_T + 1];
+    __shared__ float red[4];
+    const int plane = blockIdx.z, ox = blockIdx.x * MS_T, oy = blockIdx.y * MS_T;
+    const size_t HW = (size_t)lv.H * lv.W;
+    for (int e = threadIdx.x; e < MS_IN * MS_IN; e += 256) {
+        const int r = e / MS_IN, c = e - r * MS_IN;
+        const int iy = oy + r, ix = ox + c;
+        float x = 0.f, y = 0.f;
+        if (iy < lv.H && ix < lv.W) ms_load<L0>(X, Y, mask, clamp_y, C, plane, HW, (size_t)iy * lv.W + ix, x, y);
+        sx[r][c] = x; sy[r][c] = y;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < MS_IN * MS_T; e += 256) {
+        const int r = e >> 5, c = e & 31;
+        float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 2 * MS_R + 1; k++) {
+            const float x = sx[r][c + k], y = sy[r][c + k], w = win.w[k];
+            const float wx = w * x, wy = w * y;
+            m1 += wx; m2 += wy; e11 += wx * x; e22 += wy * y; e12 += wx * y;
+        }
+        hh[0][r][c] = m1; hh[1][r][c] = m2; hh[2][r][c] = e11; hh[3][r][c] = e22; hh[4][r][c] = e12;
+    }
+    __syncthreads();
+    const int c = threadIdx.x & 31;
+    float local = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int r = (threadIdx.x >> 5) + 8 * j;
+        float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 2 * MS_R + 1; k++) {
+            const float w = win.w[k];
+            m1 += w * hh[0][r + k][c]; m2 += w * hh[1][r + k][c]; e11 += w * hh[2][r + k][c]; e22 += w * hh[3][r + k][c]; e12 += w * hh[4][r + k][c];
+        }
+        const int vy = oy + r, vx = ox + c;
+        if (vy < lv.Hv && vx < lv.Wv) {
+            const float s1 = e11 - m1 * m1, s2 = e22 - m2 * m2, s12 = e12 - m1 * m2;
+            const float dcs = 1.f / (s1 + s2 + MS_C2);
+            const float cs = (2.f * s12 + MS_C2) * dcs;
+            // d cs / d E[xy] = 2 / D,  d cs / d E[y^2] = -cs / D,  d cs / d mu_y = (2 cs mu_y - 2 mu_x) / D
+            float dA = (2.f * cs * m2 - 2.f * m1) * dcs, dB = -cs * dcs, dC = 2.f * dcs, val = cs;
+            if (LAST) {
+                const float dl = 1.f / (m1 * m1 + m2 * m2 + MS_C1);
+                const float l = (2.f * m1 * m2 + MS_C1) * dl;
+                dA = l * dA + cs * (2.f * m1 - 2.f * l * m2) * dl;      // ssim = l * cs
+                dB *= l; dC *= l; val = l * cs;
+            }
+            const size_t o = ((size_t)plane * lv.Hv + vy) * lv.Wv + vx;
+            mapA[o] = dA; mapB[o] = dB; mapC[o] = dC;
+            local += val;
+        }
+    }
+    // fixed-order block sum
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) local += __shfl_xor(local, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[((size_t)plane * lv.ty + blockIdx.y) * lv.tx + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// per plane: level means (fixed-order sums of the tile partials) -> ms, and the scalar dL/d(map pixel) of every level
+struct MsFinal { const float* partial[MS_LEVELS]; int tiles[MS_LEVELS]; float inv_npix[MS_LEVELS]; float wts[MS_LEVELS]; };
+__global__ void __launch_bounds__(256) k_ms_finalize(MsFinal f, int P, float grad_scale, float* __restrict__ g /* [levels][P] */, float* __restrict__ ms_plane) {
+    __shared__ float red[256];
+    const int plane = blockIdx.x;
+    float v[MS_LEVELS];
+    for (int l = 0; l < MS_LEVELS; l++) {
+        float s = 0.f;
+        for (int t = threadIdx.x; t < f.tiles[l]; t += 256) s += f.partial[l][(size_t)plane * f.tiles[l] + t];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int o = 128; o >= 1; o >>= 1) {
+            if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+        v[l] = fmaxf(red[0] * f.inv_npix[l], 0.f);       // relu(mean)
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        float ms = 1.f;
+        bool pos = true;
+        for (int l = 0; l < MS_LEVELS; l++) { pos = pos && v[l] > 0.f; ms *= powf(v[l], f.wts[l]); }
+        if (!pos) ms = 0.f;
+        ms_plane[plane] = ms;
+        for (int l = 0; l < MS_LEVELS; l++) g[(size_t)l * P + plane] = pos ? grad_scale * (f.wts[l] * ms / v[l]) * f.inv_npix[l] / (float)P : 0.f;
+    }
+}
+// value: out += a + b * mean(ms) (fixed-order mean; the add is atomic because several view lanes of a training step share one loss word)
+__global__ void k_ms_mean(const float* __restrict__ ms_plane, int P, float a, float b, float* __restrict__ out) {
+    float s = 0.f;
+    for (int p = 0; p < P; p++) s += ms_plane[p];
+    atomicAdd(out, a + b * (s / (float)P));
+}
+
+// backward of one level: gradient w.r.t. the level's y over the whole image (+ the pooled parent level's gradient)
+template <bool L0>
+__global__ void __launch_bounds__(256) k_ms_bwd(const float* __restrict__ X, const float* __restrict__ Y, const float* __restrict__ mask, int clamp_y, int C,
+                                                MsLevel lv, MsWin win, const float* __restrict__ mapA, const float* __restrict__ mapB, const float* __restrict__ mapC,
+                                                const float* __restrict__ g, const float* __restrict__ parent, int H2, int W2, float* __restrict__ out, int accumulate) {
+    __shared__ float sm[3][MS_IN][MS_IN + 1];
+    __shared__ float hh[3][MS_IN][MS_T + 1];
+    const int plane = blockIdx.z, ox = blockIdx.x * MS_T, oy = blockIdx.y * MS_T;
+    // d in(q) = sum_k w[k] M(q - 10 + k): LDS row 0 <-> map row oy - 10
+    for (int e = threadIdx.x; e < MS_IN * MS_IN; e += 256) {
+        const int r = e / MS_IN, c = e - r * MS_IN;
+        const int uy = oy - 2 * MS_R + r, ux = ox - 2 * MS_R + c;
+        float a = 0.f, b = 0.f, cc = 0.f;
+        if (uy >= 0 && uy < lv.Hv && ux >= 0 && ux < lv.Wv) {
+            const size_t o = ((size_t)plane * lv.Hv + uy) * lv.Wv + ux;
+            a = mapA[o]; b = mapB[o]; cc = mapC[o];
+        }
+        sm[0][r][c] = a; sm[1][r][c] = b; sm[2][r][c] = cc;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < MS_IN * MS_T; e += 256) {
+        const int r = e >> 5, c = e & 31;
+        float fa = 0.f, fb = 0.f, fc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 2 * MS_R + 1; k++) {
+            const float w = win.w[k];
+            fa += w * sm[0][r][c + k]; fb += w * sm[1][r][c + k]; fc += w * sm[2][r][c + k];
+        }
+        hh[0][r][c] = fa; hh[1][r][c] = fb; hh[2][r][c] = fc;
+    }
+    __syncthreads();
+    const int c = threadIdx.x & 31;
+    const float gl = g[plane];
+    const size_t HW = (size_t)lv.H * lv.W;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int r = (threadIdx.x >> 5) + 8 * j;
+        const int qy = oy + r, qx = ox + c;
+        if (qy >= lv.H || qx >= lv.W) continue;
+        float fa = 0.f, fb = 0.f, fc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 2 * MS_R + 1; k++) {
+            const float w = win.w[k];
+            fa += w * hh[0][r + k][c]; fb += w * hh[1][r + k][c]; fc += w * hh[2][r + k][c];
+        }
+        float x, y;
+        const size_t off = (size_t)qy * lv.W + qx;
+        ms_load<L0>(X, Y, mask, clamp_y, C, plane, HW, off, x, y);
+        float gr = gl * (fa + 2.f * y * fb + x * fc);
+        if (parent) gr += 0.25f * parent[((size_t)plane * H2 + ((qy + (lv.H & 1)) >> 1)) * W2 + ((qx + (lv.W & 1)) >> 1)];
+        if (L0) {   // chain through y_eff = clamp(y) * mask
+            if (mask) gr *= mask[(size_t)(plane / C) * HW + off];
+            if (clamp_y) { const float yr = Y[(size_t)plane * HW + off]; if (!(yr >= 0.f && yr <= 1.f)) gr = 0.f; }
+        }
+        float* o = out + (size_t)plane * HW + off;
+        *o = accumulate ? *o + gr : gr;
+    }
+}
+
+namespace {
+struct MsPlan {
+    MsLevel lv[MS_LEVELS];
+    size_t off_x[MS_LEVELS], off_y[MS_LEVELS], off_map[MS_LEVELS], off_grad[MS_LEVELS], off_part[MS_LEVELS], off_g, off_ms, bytes;
+};
+void ms_plan(int P, int H, int W, MsPlan& pl) {
+    size_t off = 0;
+    auto take = [&](size_t b) { size_t o = off; off += c3d_align(b); return o; };
+    int h = H, w = W;
+    for (int l = 0; l < MS_LEVELS; l++) {
+        MsLevel& L = pl.lv[l];
+        L.H = h; L.W = w; L.Hv = h - 2 * MS_R; L.Wv = w - 2 * MS_R;
+        L.tx = (L.Wv + MS_T - 1) / MS_T; L.ty = (L.Hv + MS_T - 1) / MS_T;
+        const size_t img = sizeof(float) * (size_t)P * h * w, val = sizeof(float) * (size_t)P * (size_t)(L.Hv > 0 ? L.Hv : 0) * (size_t)(L.Wv > 0 ? L.Wv : 0);
+        pl.off_x[l] = l ? take(img) : 0; pl.off_y[l] = l ? take(img) : 0;
+        pl.off_map[l] = take(3 * val);
+        pl.off_grad[l] = l ? take(img) : 0;
+        pl.off_part[l] = take(sizeof(float) * (size_t)P * (size_t)(L.tx > 0 ? L.tx : 1) * (size_t)(L.ty > 0 ? L.ty : 1));
+        const int py = h & 1, px = w & 1;
+        h = (h + 2 * py - 2) / 2 + 1; w = (w + 2 * px - 2) / 2 + 1;
+    }
+    pl.off_g = take(sizeof(float) * MS_LEVELS * (size_t)P);
+    pl.off_ms = take(sizeof(float) * (size_t)P);
+    pl.bytes = off;
+}
+MsWin ms_window() {
+    MsWin w;
+    double g[2 * MS_R + 1], s = 0;
+    for (int k = 0; k <= 2 * MS_R; k++) { const double x = k - MS_R; g[k] = exp(-(x * x) / (2.0 * 1.5 * 1.5)); s += g[k]; }
+    for (int k = 0; k <= 2 * MS_R; k++) w.w[k] = (float)(g[k] / s);
+    return w;
+}
+}  // namespace
+
+int ms_value_grad(const float* x, const float* y, const float* mask, int clamp_y, int B, int C, int H, int W, float grad_scale, int accumulate, float* dL_dy,
+                  float va, float vb, float* ms_out, void* workspace, hipStream_t s);
+
+extern "C" {
+
+size_t c3d_msssim_workspace_bytes(int32_t B, int32_t C, int32_t H, int32_t W) {
+    MsPlan pl;
+    ms_plan(B * C, H, W, pl);
+    return pl.bytes;
+}
+
+int c3d_msssim_value_grad(const float* x, const float* y, const float* mask, int32_t clamp_y, int32_t B, int32_t C, int32_t H, int32_t W,
+                          float grad_scale, int32_t accumulate, float* dL_dy, float* ms_out, void* workspace, c3d_stream_t stream) {
+    return ms_value_grad(x, y, mask, clamp_y, B, C, H, W, grad_scale, accumulate, dL_dy, 0.f, 1.f, ms_out, workspace, (hipStream_t)stream);
+}
+
+}  // extern "C"
+
+// out_word += va + vb * mean MS-SSIM  (va = 0, vb = 1: the plain value; the fused training step passes the loss term's weights)
+int ms_value_grad(const float* x, const float* y, const float* mask, int clamp_y, int B, int C, int H, int W, float grad_scale, int accumulate, float* dL_dy,
+                  float va, float vb, float* ms_out, void* workspace, hipStream_t s) {
+    if (B <= 0 || C <= 0) return 0;
+    if (!x || !y || !dL_dy || !workspace) { c3d_set_error("c3d_msssim_value_grad: NULL pointer"); return -1; }
+    if ((H < W ? H : W) <= (2 * MS_R) * (1 << (MS_LEVELS - 1))) { c3d_set_error("c3d_msssim_value_grad: image sides must exceed %d for %d scales", (2 * MS_R) << (MS_LEVELS - 1), MS_LEVELS); return -1; }
+    const int P = B * C;
+    MsPlan pl;
+    ms_plan(P, H, W, pl);
+    char* ws = (char*)workspace;
+    const MsWin win = ms_window();
+    const float* X[MS_LEVELS]; const float* Y[MS_LEVELS];
+    X[0] = x; Y[0] = y;
+    for (int l = 1; l < MS_LEVELS; l++) { X[l] = (const float*)(ws + pl.off_x[l]); Y[l] = (const float*)(ws + pl.off_y[l]); }
+    static const float wts[MS_LEVELS] = {0.0448f, 0.2856f, 0.3001f, 0.2363f, 0.1333f};
+    MsFinal fin;
+    C3dProfScope ps(C3D_P_MSSSIM, s);
+    for (int l = 0; l < MS_LEVELS; l++) {
+        const MsLevel& L = pl.lv[l];
+        const size_t val = (size_t)P * L.Hv * L.Wv;
+        float* mA = (float*)(ws + pl.off_map[l]); float* mB = mA + val; float* mC = mB + val;
+        float* part = (float*)(ws + pl.off_part[l]);
+        const dim3 grid(L.tx, L.ty, P);
+        if (l == 0)                    hipLaunchKernelGGL((k_ms_fwd<false, true>), grid, dim3(256), 0, s, X[l], Y[l], mask, clamp_y, C, L, win, mA, mB, mC, part);
+        else if (l < MS_LEVELS - 1)    hipLaunchKernelGGL((k_ms_fwd<false, false>), grid, dim3(256), 0, s, X[l], Y[l], (const float*)nullptr, 0, C, L, win, mA, mB, mC, part);
+        else                           hipLaunchKernelGGL((k_ms_fwd<true, false>), grid, dim3(256), 0, s, X[l], Y[l], (const float*)nullptr, 0, C, L, win, mA, mB, mC, part);
+        fin.partial[l] = part; fin.tiles[l] = L.tx * L.ty; fin.inv_npix[l] = 1.f / ((float)L.Hv * (float)L.Wv); fin.wts[l] = wts[l];
+        if (l < MS_LEVELS - 1) {
+            const MsLevel& N = pl.lv[l + 1];
+            const dim3 pg(c3d_cdiv(N.W, 64), c3d_cdiv(N.H, 4), P);
+            if (l == 0) hipLaunchKernelGGL((k_ms_pool<true>), pg, dim3(256), 0, s, X[l], Y[l], mask, clamp_y, C, L.H, L.W, N.H, N.W, (float*)(ws + pl.off_x[l + 1]), (float*)(ws + pl.off_y[l + 1]));
+            else        hipLaunchKernelGGL((k_ms_pool<false>), pg, dim3(256), 0, s, X[l], Y[l], (const float*)nullptr, 0, C, L.H, L.W, N.H, N.W, (float*)(ws + pl.off_x[l + 1]), (float*)(ws + pl.off_y[l + 1]));
+        }
+    }
+    float* g = (float*)(ws + pl.off_g);
+    float* msp = (float*)(ws + pl.off_ms);
+    hipLaunchKernelGGL(k_ms_finalize, dim3(P), dim3(256), 0, s, fin, P, grad_scale, g, msp);
+    if (ms_out) hipLaunchKernelGGL(k_ms_mean, dim3(1), dim3(1), 0, s, msp, P, va, vb, ms_out);
+    for (int l = MS_LEVELS - 1; l >= 0; l--) {
+        const MsLevel& L = pl.lv[l];
+        const size_t val = (size_t)P * L.Hv * L.Wv;
+        const float* mA = (const float*)(ws + pl.off_map[l]); const float* mB = mA + val; const float* mC = mB + val;
+        const float* parent = l < MS_LEVELS - 1 ? (const float*)(ws + pl.off_grad[l + 1]) : nullptr;
+        const int H2 = l < MS_LEVELS - 1 ? pl.lv[l + 1].H : 0, W2 = l < MS_LEVELS - 1 ? pl.lv[l + 1].W : 0;
+        const dim3 grid(c3d_cdiv(L.W, MS_T), c3d_cdiv(L.H, MS_T), P);
+        if (l == 0) hipLaunchKernelGGL((k_ms_bwd<true>), grid, dim3(256), 0, s, X[l], Y[l], mask, clamp_y, C, L, win, mA, mB, mC, g + (size_t)l * P, parent, H2, W2, dL_dy, accumulate);
+        else        hipLaunchKernelGGL((k_ms_bwd<false>), grid, dim3(256), 0, s, X[l], Y[l], (const float*)nullptr, 0, C, L, win, mA, mB, mC, g + (size_t)l * P, parent, H2, W2, (float*)(ws + pl.off_grad[l]), 0);
+    }
+    C3D_LAUNCH_CHECK();
+    return 0;
+}

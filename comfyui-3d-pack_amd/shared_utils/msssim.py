@@ -1,7 +1,13 @@
-"""Multi-scale SSIM in plain torch (dense separable convolutions -> MIOpen; SURVEY 2.3-C keeps this in torch).
-Stand-in for pytorch_msssim.MS_SSIM(data_range=1, size_average=True, channel=3) used at
+"""Multi-scale SSIM.  Stand-in for pytorch_msssim.MS_SSIM(data_range=1, size_average=True, channel=3) used at
 /root/reference/MVs_Algorithms/GaussianSplatting/main_3DGS.py:102,192 (the wheel is not vendored): Gaussian window 11,
-sigma 1.5, five scales with the standard weights, 2x2 average pooling between scales."""
+sigma 1.5, five scales with the standard weights, 2x2 average pooling between scales.
+
+Two implementations of the same published algorithm:
+  * plain torch (dense separable grouped convolutions), the restatement everything is checked against and the path for CPU tensors and for
+    gradients w.r.t. the first argument;
+  * the fused HIP kernels of include/c3d_loss.h (csrc/msssim.hip) for the trainers' call pattern MS_SSIM(reference, rendered) on a HIP
+    device -- value and d/d(rendered) in one library call: at 8 x 3 x 1080 x 1920 the torch chain costs 65 ms per step, nine times the
+    rasterizer step it is the loss of (profiles/r02b)."""
 import torch
 import torch.nn.functional as F
 
@@ -29,13 +35,44 @@ def _ssim_cs(x, y, w, data_range):
     return ssim.flatten(2).mean(-1), cs.flatten(2).mean(-1)   # per image, per channel
 
 
+class _MsSsimHip(torch.autograd.Function):
+    """mean MS-SSIM(x, y) with the gradient w.r.t. y from c3d_msssim_value_grad (x is a constant: the reference image)"""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        import c3d_hip as _h
+        B, C, H, W = y.shape
+        lib = _h.lib()
+        ws = torch.empty((lib.c3d_msssim_workspace_bytes(B, C, H, W),), dtype=torch.uint8, device=y.device)
+        grad = torch.empty_like(y)
+        val = torch.zeros((1,), dtype=torch.float32, device=y.device)
+        with torch.cuda.device(y.device):
+            _h.check(lib.c3d_msssim_value_grad(_h.ptr(x), _h.ptr(y), None, 0, B, C, H, W, 1.0, 0, _h.ptr(grad), _h.ptr(val), _h.ptr(ws), _h.stream(y.device)),
+                     "c3d_msssim_value_grad")
+        ctx.save_for_backward(grad)
+        return val[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return None, grad * g
+
+
+def _hip_ok(x, y, weights, win_size, win_sigma, data_range):
+    return (y.is_cuda and x.is_cuda and x.dtype == torch.float32 and y.dtype == torch.float32 and x.dim() == 4 and x.shape == y.shape and not x.requires_grad
+            and tuple(weights) == _WEIGHTS and win_size == 11 and win_sigma == 1.5 and data_range == 1)
+
+
 class MS_SSIM(torch.nn.Module):
     def __init__(self, data_range=1.0, size_average=True, channel=3, win_size=11, win_sigma=1.5, weights=_WEIGHTS):
         super().__init__()
         self.data_range, self.size_average, self.win_size, self.win_sigma, self.weights = data_range, size_average, win_size, win_sigma, weights
+        self.use_hip = True             # False: always the torch restatement (tests compare the two)
 
     def forward(self, x, y):
         assert min(x.shape[-2:]) > (self.win_size - 1) * 2 ** (len(self.weights) - 1), "image too small for 5-scale MS-SSIM"
+        if self.use_hip and self.size_average and _hip_ok(x, y, self.weights, self.win_size, self.win_sigma, self.data_range):
+            return _MsSsimHip.apply(x.contiguous(), y.contiguous())
         w = _window(self.win_size, self.win_sigma, x.device, x.dtype)
         mcs = []
         for i in range(len(self.weights)):

@@ -122,15 +122,16 @@ int c3d_gs_backward_raw(const c3d_gs_settings* st, int32_t N, const float* means
 /* ---- fused multi-view training step (extension) ----------------------------------------------------
  * One call = for each of V views: project -> bin -> composite -> pixel loss -> backward, the parameter gradients ADDED into the
  * caller's buffers (zero them before the first call of a step).  Replaces the per-view Python loop of
- * GaussianSplatting3D.training (main_3DGS.py:158-207) when the loss is the L1 / L2 / alpha-MSE part (no MS-SSIM).
+ * GaussianSplatting3D.training (main_3DGS.py:158-207): the whole loss of main_3DGS.py:184-192 (L1, alpha MSE, MS-SSIM) is inside.
  * Nothing in the call synchronises with the host: the data-dependent number of (tile, splat) pairs stays on the device and every
  * launch is sized for `pair_capacity`.  status[0] becomes non-zero if a view needed more pairs than that (results are then
  * invalid: enlarge and redo the step; bit 0 = pair overflow, bit 1 = a bounded inter-workgroup wait of the binning stage timed
  * out, which indicates a device fault), status[1] holds the largest pair count seen.  loss_out (device float) accumulates the value
- *   scale * sum_v [ w_l1 mean|clamp(C_v,0,1) - Ct_v| + w_l2 mean(clamp(C_v,0,1) - Ct_v)^2 + w_alpha_mse mean(A_v - At_v)^2 ].
+ *   scale * sum_v [ w_l1 mean|clamp(C_v,0,1) - Ct_v| + w_l2 mean(clamp(C_v,0,1) - Ct_v)^2 + w_alpha_mse mean(A_v - At_v)^2
+ *                   + w_ssim (1 - MS_SSIM(Ct_v, clamp(C_v,0,1))) ]      (w_ssim != 0: include/c3d_loss.h, image sides > 160; masked like the other colour terms).
  * target_color / target_alpha / color_mask: HOST arrays of V device pointers ([3,H,W] / [1,H,W] / [1,H,W]); target_alpha and color_mask may be
  * NULL.  With color_mask the colour terms compare (C * mask) with (Ct * mask), the reference's masked loss (main_3DGS.py:169-186). */
-typedef struct c3d_gs_loss { float w_l1; float w_l2; float w_alpha_mse; float scale; } c3d_gs_loss;
+typedef struct c3d_gs_loss { float w_l1; float w_l2; float w_alpha_mse; float scale; float w_ssim; } c3d_gs_loss;
 /* The workspace holds one slice per view (state of every view stays alive until the single per-Gaussian backward pass at the end).
  * lanes (1..8): the V views are dealt round-robin onto `lanes` HIP streams (lane 0 = `stream`; the others are library-owned, forked from and
  * joined back into `stream` with events, so the call keeps stream semantics) -- the latency-bound sort/scan chain of one view then runs underneath

@@ -546,21 +546,73 @@ def test_trainer_fused_step_equals_autograd_step(lambda_ssim, offsets):
     refs = [torch.tensor(rng.uniform(size=(H, W, 3)).astype(np.float32)) for _ in poses]
     masks = [torch.tensor(np.clip(rng.uniform(size=(H, W)) * 1.6 - 0.3, 0, 1).astype(np.float32)) for _ in poses]
     results = []
-    for fused in (True, False):
+    for variant in ("library", "halves", "autograd"):
+        fused = variant != "autograd"
         np.random.seed(3); torch.manual_seed(3)
         p = GSParams(training_iterations=2, batch_size=3, lambda_ssim=lambda_ssim, num_pts=5000, density_start_iter=10 ** 9, density_end_iter=-1, invert_bg_prob=0.5,
                      lambda_offset=0.5 if offsets else 0.0, lambda_offset_opacity=0.3 if offsets else 0.0)
         tr = GaussianSplatting3D(p, None, device="cuda")
         tr.use_fused_step = fused
+        tr.image_loss_in_torch = variant == "halves"        # library: L1 + alpha MSE + MS-SSIM inside c3d_gs_train_views_raw; halves: torch's loss between the two halves
+        tr.ms_ssim_loss.use_hip = False                      # wherever torch computes the loss here it is the plain-torch MS-SSIM: an independent check of the HIP one
         tr.prepare_training(refs, masks, poses, 49.1)
         assert tr._can_fuse() == fused
         np.random.seed(17)                                           # the per-view background draws
         losses = [tr.training_step(s, [0, 1, 2]).item() for s in range(2)]
         results.append((losses, [q.detach().clone() for q in tr.params]))
-    (l1, p1), (l2, p2) = results
-    assert abs(l1[0] - l2[0]) <= 1e-5 * max(1, abs(l2[0])) and abs(l1[1] - l2[1]) <= 1e-4 * max(1, abs(l2[1]))
-    for a, b in zip(p1, p2):
-        assert (a - b).abs().max().item() <= 2e-4 * max(1.0, b.abs().max().item())
+    (l2, p2) = results[-1]
+    for (l1, p1) in results[:-1]:
+        assert abs(l1[0] - l2[0]) <= 1e-5 * max(1, abs(l2[0])) and abs(l1[1] - l2[1]) <= 1e-4 * max(1, abs(l2[1])), (l1, l2)
+        for a, b in zip(p1, p2):
+            assert (a - b).abs().max().item() <= 2e-4 * max(1.0, b.abs().max().item())
+
+
+@pytest.mark.parametrize("shape,masked", [((2, 3, 201, 183), False), ((2, 3, 201, 183), True), ((1, 3, 1080, 1920), True), ((3, 1, 176, 320), False)])
+def test_msssim_hip_matches_the_torch_restatement(shape, masked):
+    """include/c3d_loss.h: value and d/dy of mean MS-SSIM(x, y) from the fused HIP kernels against the plain-torch restatement of the published
+    algorithm (shared_utils/msssim.py, the stand-in for pytorch_msssim.MS_SSIM the reference calls at main_3DGS.py:192) -- odd sizes (the padded
+    2 x 2 pooling), the level-0 transform x * mask, clamp(y) * mask with its chain rule, gradient accumulation, bit reproducibility."""
+    import c3d_hip as h
+    from shared_utils.msssim import MS_SSIM
+    B, C, H, W = shape
+    gen = torch.Generator(device="cpu").manual_seed(B * H + W)
+    base = torch.rand((B, C, H, W), generator=gen)
+    x = (0.6 * base + 0.4 * torch.rand((B, C, H, W), generator=gen)).cuda()
+    y = (0.6 * base + 0.4 * torch.rand((B, C, H, W), generator=gen) * 1.3 - 0.1).cuda()      # some values outside [0, 1]: the clamp matters
+    m = torch.rand((B, 1, H, W), generator=gen).cuda() if masked else None
+    ms = MS_SSIM(data_range=1, size_average=True, channel=C)
+    ms.use_hip = False
+    yt = y.clone().requires_grad_(True)
+    ref = ms(x * m, yt.clamp(0, 1) * m) if masked else ms(x, yt)
+    ref.backward()
+    lib = h.lib()
+    ws = torch.empty((lib.c3d_msssim_workspace_bytes(B, C, H, W),), dtype=torch.uint8, device="cuda")
+    grads = []
+    for rep in range(2):
+        g = torch.full_like(y, 7.0)
+        val = torch.zeros(1, device="cuda")
+        h.check(lib.c3d_msssim_value_grad(h.ptr(x), h.ptr(y), h.ptr(m) if masked else None, 1 if masked else 0, B, C, H, W, 1.0, 0, h.ptr(g), h.ptr(val), h.ptr(ws), h.stream()), "msssim")
+        grads.append(g)
+    assert torch.equal(grads[0], grads[1])                              # no atomics: identical bits
+    assert abs(val.item() - ref.item()) <= 2e-5 * max(abs(ref.item()), 1e-3), (val.item(), ref.item())
+    err = (grads[0] - yt.grad).abs()
+    scale = yt.grad.abs().max().item()
+    print("[msssim %s masked=%s] value %.6f (torch %.6f), grad max err %.2e of max %.2e, rel L2 %.2e"
+          % (shape, masked, val.item(), ref.item(), err.max().item(), scale, (err.norm() / yt.grad.norm()).item()))
+    assert (err.norm() / yt.grad.norm()).item() <= 1e-3 and err.max().item() <= 2e-3 * scale
+    # accumulate with a scale
+    g = torch.ones_like(y)
+    h.check(lib.c3d_msssim_value_grad(h.ptr(x), h.ptr(y), h.ptr(m) if masked else None, 1 if masked else 0, B, C, H, W, -0.5, 1, h.ptr(g), None, h.ptr(ws), h.stream()), "msssim")
+    assert torch.allclose(g, 1.0 - 0.5 * grads[0], rtol=1e-5, atol=1e-7 * max(scale, 1e-30) + 1e-12)
+    # the autograd front end (what the trainers call): MS_SSIM(x, y) -> HIP, gradient through backward()
+    ms_h = MS_SSIM(data_range=1, size_average=True, channel=C)
+    yh = (y.clamp(0, 1) * m if masked else y).detach().clone().requires_grad_(True)
+    v = ms_h(x * m if masked else x, yh)
+    (3.0 * v).backward()
+    yr = yh.detach().clone().requires_grad_(True)
+    vr = ms(x * m if masked else x, yr)
+    vr.backward()
+    assert abs(v.item() - vr.item()) <= 2e-5 and ((yh.grad - 3.0 * yr.grad).norm() / (3.0 * yr.grad.norm())).item() <= 1e-3
 
 
 def test_fused_forward_backward_halves_match_autograd():
