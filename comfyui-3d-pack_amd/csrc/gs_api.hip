@@ -64,7 +64,7 @@ static int binning_front(GsGeom& g, int N, uint32_t cap, uint32_t* status, hipSt
     C3D_CHECK(hipMemsetAsync(g.meta, 0, g.zero_bytes, s));
     uint32_t* err = status ? status : (uint32_t*)g.meta + 2;      // a timed-out look-back (bounded spins) surfaces as C3D_ERR_LOOKBACK
     { C3dProfScope ps(C3D_P_SCAN, s);
-      if ((rc = c3d_scan_u32(g.tiles, g.rbase, (size_t)N, true, g.tmp_scan_a, s, false, err))) return rc; }
+      if ((rc = c3d_scan_u32_einfo(g.tiles, g.rbase, (size_t)N, g.tmp_scan_a, s, false, err, g.rect, g.einfo))) return rc; }
     { C3dProfScope ps(C3D_P_DEPTH_SORT, s);
       if ((rc = c3d_sort_pairs_u32(g.key[0], g.key[1], g.order[0], g.order[1], true, (size_t)N, 32, g.tmp_sort, &res, s, nullptr, false, err))) return rc; }
     if (res != sort_result_index(32)) { c3d_set_error("internal: depth sort buffer parity"); return -2; }

@@ -108,6 +108,7 @@ __global__ void __launch_bounds__(256) k_preprocess(GsParams p, const float* __r
     radii[idx] = rad;
     const uint32_t nt = (uint32_t)((x1 - x0) * (y1 - y0));
     g.tiles[idx] = nt;
+    g.rect[idx] = make_uint2((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)x1 | ((uint32_t)y1 << 16));
     g.key[0][idx] = nt ? __float_as_uint(pv.z) : 0xFFFFFFFFu;
 }
 
@@ -125,10 +126,18 @@ int gs_launch_preprocess(const GsParams& p, const float* means3D, const float* s
     C3D_LAUNCH_CHECK();
     return 0;
 }
+// workgroup size of the raw-parameter preprocess (experiment knob C3D_PRE_THREADS = 64 | 128 | 256): the kernel stages 196 B of SH per lane in LDS, so smaller
+// workgroups interleave the load and compute phases of more workgroups per CU at the same wave count
+static int gs_pre_threads() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("C3D_PRE_THREADS"); v = e ? atoi(e) : 256; if (v != 64 && v != 128 && v != 256) v = 256; }
+    return v;
+}
 int gs_launch_preprocess_raw(const GsParams& p, const float* means3D, const float* f_dc, const float* f_rest, const float* opacity_raw,
                              const float* scaling_raw, const float* rotation_raw, GsGeom& g, int* radii, hipStream_t s) {
     if (p.N == 0) return 0;
-    hipLaunchKernelGGL((k_preprocess<true, true>), dim3(c3d_cdiv(p.N, 256)), dim3(256), 256 * SH_ROW * sizeof(float), s, p, means3D, f_dc, f_rest,
+    const int T = gs_pre_threads();
+    hipLaunchKernelGGL((k_preprocess<true, true>), dim3(c3d_cdiv(p.N, T)), dim3(T), T * SH_ROW * sizeof(float), s, p, means3D, f_dc, f_rest,
                        (const float*)nullptr, opacity_raw, scaling_raw, rotation_raw, (const float*)nullptr, g, radii);
     C3D_LAUNCH_CHECK();
     return 0;
@@ -139,20 +148,14 @@ int gs_launch_preprocess_raw(const GsParams& p, const float* means3D, const floa
 // touched tile.  A stable sort by tile id afterwards leaves every tile's list depth-ordered.
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_emit(GsParams p, const uint32_t* __restrict__ order, const uint32_t* __restrict__ offsets,
-                                               const float4* __restrict__ rec0, const float4* __restrict__ rec2,
-                                               const int* __restrict__ radii, const uint32_t* __restrict__ rbase, uint4* __restrict__ einfo, uint32_t* __restrict__ tkey, uint32_t* __restrict__ tval, uint32_t cap) {
+                                               const uint4* __restrict__ einfo, uint32_t* __restrict__ tkey, uint32_t* __restrict__ tval, uint32_t cap) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= p.N) return;
-    const uint32_t gid = order[r];
-    const int rad = radii[gid];
-    if (rad <= 0) return;
     uint32_t off = (r == 0) ? 0u : offsets[r - 1];
-    if (offsets[r] == off) return;   // narrowed to no tiles
-    const float4 r0 = rec0[GS_REC(gid)];
-    const float4 r2 = rec2[GS_REC(gid)];
-    int x0, y0, x1, y1;
-    tile_rect_tight(r0.x, r0.y, rad, r2.z, r2.w, p.gx, p.gy, x0, y0, x1, y1);
-    einfo[gid] = make_uint4(off, (uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)x1 | ((uint32_t)y1 << 16), rbase[gid]);
+    if (offsets[r] == off) return;   // culled, or narrowed to no tiles
+    const uint32_t gid = order[r];
+    const uint4 ei = einfo[gid];     // ONE 16-byte gather per Gaussian: the tile rect (record-base scan, c3d_scan_u32's epilogue)
+    const int x0 = (int)(ei.y & 0xFFFFu), y0 = (int)(ei.y >> 16), x1 = (int)(ei.z & 0xFFFFu), y1 = (int)(ei.z >> 16);
     for (int y = y0; y < y1; y++)
         for (int x = x0; x < x1; x++) {
             if (off < cap) { tkey[off] = (uint32_t)(y * p.gx + x); tval[off] = gid; }
@@ -160,8 +163,9 @@ __global__ void __launch_bounds__(256) k_emit(GsParams p, const uint32_t* __rest
         }
 }
 int gs_launch_emit(const GsParams& p, const GsGeom& g, int res, const int* radii, GsBinning& b, hipStream_t s, uint32_t cap) {
+    (void)radii;
     if (p.N == 0) return 0;
-    hipLaunchKernelGGL(k_emit, dim3(c3d_cdiv(p.N, 256)), dim3(256), 0, s, p, g.order[res], g.offsets, g.rec0, g.rec2, radii, g.rbase, g.einfo, b.tkey[0], b.tval[0], cap);
+    hipLaunchKernelGGL(k_emit, dim3(c3d_cdiv(p.N, 256)), dim3(256), 0, s, p, g.order[res], g.offsets, g.einfo, b.tkey[0], b.tval[0], cap);
     C3D_LAUNCH_CHECK();
     return 0;
 }

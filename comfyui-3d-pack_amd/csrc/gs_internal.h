@@ -26,10 +26,11 @@ struct GsGeom {
     float4* rec1;
     float4* rec2;
     uint32_t* tiles;        // tiles touched per Gaussian (0 = culled)
+    uint2* rect;            // the tile rect those tiles form: {x0 | y0 << 16, x1 | y1 << 16} (written with `tiles`; undefined for culled Gaussians)
     uint32_t* key[2];       // depth-sort keys (float bits of view depth; 0xFFFFFFFF = culled)
     uint32_t* order[2];     // Gaussian ids, ping-pong; after stage 1 order[res] is rank -> id
     uint32_t* offsets;      // inclusive scan of the tile counts in depth-rank order
-    uint4* einfo;           // per emitted Gaussian: {first emit index, x0 | y0<<16, x1 | y1<<16, record base} of its tile rect
+    uint4* einfo;           // per Gaussian with tiles: {0, x0 | y0<<16, x1 | y1<<16, record base} of its tile rect -- written by the record-base scan (coalesced)
     uint32_t* rbase;        // exclusive scan of `tiles` in Gaussian-id order: where this Gaussian's backward gradient records start
     uint8_t* clamped;       // 3 bits per Gaussian: SH colour channel clamped at 0
     int* meta;              // [0] = min(num_rendered, capacity) (device copy)  [2] = error word of the binning chain (C3D_ERR_LOOKBACK)
@@ -47,6 +48,7 @@ static inline void gs_carve_geom(char* base, int N, GsGeom& g) {
     g.rec1 = g.rec0 ? g.rec0 + 1 : nullptr;
     g.rec2 = g.rec0 ? g.rec0 + 2 : nullptr;
     g.tiles = (uint32_t*)take(4 * n);
+    g.rect = (uint2*)take(8 * n);
     g.key[0] = (uint32_t*)take(4 * n);
     g.key[1] = (uint32_t*)take(4 * n);
     g.order[0] = (uint32_t*)take(4 * n);

@@ -53,7 +53,7 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* lds, u
 // ------------------------------------------------------------------------------------------
 #define LB_AGG 1ull
 #define LB_INCL 2ull
-struct ScanTail { uint32_t* meta; uint32_t* status; uint32_t cap; };
+struct ScanTail { uint32_t* meta; uint32_t* status; uint32_t cap; const uint2* rect; uint4* einfo; };   // rect / einfo: see c3d_scan_u32_einfo
 
 template <bool EXCL, bool GATHER>
 __global__ void __launch_bounds__(SCAN_THREADS) k_scan_lb(const uint32_t* __restrict__ in, const uint32_t* __restrict__ idx, uint32_t* __restrict__ out, size_t n,
@@ -116,6 +116,14 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_lb(const uint32_t* __rest
         if (EXCL) { if (base + i < n) out[base + i] = run; run += v[i]; }
         else      { run += v[i]; if (base + i < n) out[base + i] = run; }
     }
+    if (tail.einfo) {   // epilogue of the record-base scan: {0, tile rect, record base} per element, coalesced (what k_emit and the backward pass gather)
+        uint32_t rb = ex + s_prefix;
+#pragma unroll
+        for (int i = 0; i < SCAN_ITEMS; i++) {
+            if (base + i < n && v[i]) { const uint2 rc = tail.rect[base + i]; tail.einfo[base + i] = make_uint4(0u, rc.x, rc.y, rb); }
+            rb += v[i];
+        }
+    }
     if (tail.meta && base < n && base + SCAN_ITEMS >= n) {      // this thread owns element n-1: `run` is the grand total
         const uint32_t total = run;
         tail.meta[0] = total < tail.cap ? total : tail.cap;
@@ -143,11 +151,15 @@ static int scan_launch(const uint32_t* in, const uint32_t* idx, uint32_t* out, s
     return 0;
 }
 int c3d_scan_u32(const uint32_t* in, uint32_t* out, size_t n, bool exclusive, void* tmp, hipStream_t s, bool zero_state, uint32_t* err) {
-    return scan_launch(in, nullptr, out, n, exclusive, tmp, s, zero_state, ScanTail{nullptr, nullptr, 0u}, err);
+    return scan_launch(in, nullptr, out, n, exclusive, tmp, s, zero_state, ScanTail{nullptr, nullptr, 0u, nullptr, nullptr}, err);
+}
+// exclusive scan of `in` (tile counts in Gaussian-id order) -> out (record bases), plus einfo[i] = {0, rect[i].x, rect[i].y, out[i]} where in[i] != 0
+int c3d_scan_u32_einfo(const uint32_t* in, uint32_t* out, size_t n, void* tmp, hipStream_t s, bool zero_state, uint32_t* err, const uint2* rect, uint4* einfo) {
+    return scan_launch(in, nullptr, out, n, true, tmp, s, zero_state, ScanTail{nullptr, nullptr, 0u, rect, einfo}, err);
 }
 int c3d_scan_gather_u32(const uint32_t* in, const uint32_t* idx, uint32_t* out, size_t n, bool exclusive, void* tmp, hipStream_t s, bool zero_state,
                         uint32_t* tail_meta, uint32_t* tail_status, uint32_t tail_cap, uint32_t* err) {
-    return scan_launch(in, idx, out, n, exclusive, tmp, s, zero_state, ScanTail{tail_meta, tail_status, tail_cap}, err);
+    return scan_launch(in, idx, out, n, exclusive, tmp, s, zero_state, ScanTail{tail_meta, tail_status, tail_cap, nullptr, nullptr}, err);
 }
 uint32_t* c3d_scan_error_word(void* tmp) { return (uint32_t*)tmp + 1; }
 
