@@ -126,11 +126,11 @@ int gs_launch_preprocess(const GsParams& p, const float* means3D, const float* s
     C3D_LAUNCH_CHECK();
     return 0;
 }
-// workgroup size of the raw-parameter preprocess (experiment knob C3D_PRE_THREADS = 64 | 128 | 256): the kernel stages 196 B of SH per lane in LDS, so smaller
+// workgroup size of the raw-parameter preprocess (C3D_PRE_THREADS = 64 | 128 (default) | 256): the kernel stages 196 B of SH per lane in LDS, so smaller
 // workgroups interleave the load and compute phases of more workgroups per CU at the same wave count
 static int gs_pre_threads() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("C3D_PRE_THREADS"); v = e ? atoi(e) : 256; if (v != 64 && v != 128 && v != 256) v = 256; }
+    if (v < 0) { const char* e = getenv("C3D_PRE_THREADS"); v = e ? atoi(e) : 128; if (v != 64 && v != 128 && v != 256) v = 128; }
     return v;
 }
 int gs_launch_preprocess_raw(const GsParams& p, const float* means3D, const float* f_dc, const float* f_rest, const float* opacity_raw,

@@ -9,5 +9,5 @@ i=0
 for args in "$@"; do
   i=$((i+1))
   echo "== $MODE $args"
-  env $(echo "$args" | tr ' ' '\n' | grep '=' | grep -v '^--' | tr '\n' ' ') timeout 300 python bench.py --mode $MODE --cpu-baseline off $(echo "$args" | tr ' ' '\n' | grep -v '^[A-Z_]*=' | tr '\n' ' ') 2>$OUT/sweep_$i.err | tee $OUT/sweep_${MODE}_$i.json | python profiles/benchline.py
+  env $(echo "$args" | tr ' ' '\n' | grep '=' | grep -v '^--' | tr '\n' ' ') timeout 300 python bench.py --mode $MODE --cpu-baseline off $(echo "$args" | tr ' ' '\n' | grep -v '^[A-Z0-9_]*=' | tr '\n' ' ') 2>$OUT/sweep_$i.err | tee $OUT/sweep_${MODE}_$i.json | python profiles/benchline.py
 done
