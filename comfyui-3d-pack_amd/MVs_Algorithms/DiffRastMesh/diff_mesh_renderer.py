@@ -15,7 +15,7 @@ import torch.nn.functional as F
 import nvdiffrast.torch as dr
 
 from mesh_processer.mesh import safe_normalize
-from c3d_hip.mesh_fused import shade, transform_vertices
+from c3d_hip.mesh_fused import render_view, shade, transform_vertices, view_state_tensors
 
 
 def inverse_sigmoid(x):
@@ -102,6 +102,7 @@ class DiffRastRenderer(nn.Module):
         self.raw_albedo = nn.Parameter(inverse_sigmoid(self.mesh.albedo), requires_grad=True)
         self.train_geo = False
         self.fused_glue = True          # False: the reference's torch op chain around the nvdiffrast calls (tests compare both)
+        self.fused_view = True          # the whole view as one library call each way (c3d_mesh_view_*); False: op by op over nvdiffrast.torch
 
     def get_params(self, texture_lr, train_geo, geom_lr):
         params = [{'params': self.raw_albedo, 'lr': texture_lr}]
@@ -114,6 +115,64 @@ class DiffRastRenderer(nn.Module):
         self.mesh.v = (self.mesh.v + self.v_offsets).detach()
         self.mesh.albedo = torch.sigmoid(self.raw_albedo.detach())
 
+    @staticmethod
+    def _bg_host(bg_color):
+        """background as three host floats without a device round trip per view: a tensor's values are read once and kept on the tensor object
+        (the camera controller hands the same white / black tensors over every step)"""
+        if not torch.is_tensor(bg_color):
+            return (float(bg_color),) * 3
+        host = getattr(bg_color, "_c3d_host", None)
+        if host is None or host[0] != bg_color._version:
+            vals = [float(x) for x in bg_color.detach().reshape(-1).cpu().tolist()]
+            host = (bg_color._version, tuple((vals * 3)[:3]))
+            try:
+                bg_color._c3d_host = host
+            except AttributeError:
+                pass
+        return host[1]
+
+    def _render_fused_view(self, v, pose_np, pose_inv_np, proj_np, h, w, bg_color, optional_render_types):
+        """ssaa = 1, linear filter, HIP device: one library call forward (and one backward) for the whole op sequence of `render`"""
+        import nvdiffrast.torch as _dr
+        mesh = self.mesh
+        f, ft = mesh.f.to(torch.int32).contiguous(), mesh.ft.to(torch.int32).contiguous()
+        vt = mesh.vt.to(torch.float32).contiguous()
+        clip = (proj_np @ pose_inv_np).astype(np.float32)
+        image, alpha, hold = render_view(mesh.v, self.v_offsets if self.train_geo else None, self.raw_albedo, f, vt, ft, clip, self._bg_host(bg_color), h, w, self.glctx,
+                                         _dr._topology(f))
+        results = LazyResults()
+        results['image'], results['alpha'] = image, alpha
+
+        def raster():
+            # depth / normal are produced on demand; with autograd on and trainable geometry they get their own (differentiable) rasterization,
+            # otherwise the one the fused call left in its state
+            if torch.is_grad_enabled() and self.train_geo:
+                v_clip = transform_vertices(v, torch.from_numpy(clip).to(v.device)).unsqueeze(0)
+                return dr.rasterize(self.glctx, v_clip, mesh.f, (h, w))[0]
+            return view_state_tensors(hold, h, w)[0]
+
+        def depth_fn():
+            vc = transform_vertices(v, torch.from_numpy(pose_inv_np).to(v.device)).unsqueeze(0)
+            d, _ = dr.interpolate(-vc[..., [2]], raster(), mesh.f)
+            return d.squeeze(0)
+
+        shading = {}
+
+        def normal_pair():
+            if not shading:
+                vn = vertex_normals_from_faces(v, mesh.f) if self.train_geo else mesh.vn
+                normal, _ = dr.interpolate(vn.unsqueeze(0).contiguous(), raster(), mesh.fn)
+                normal = safe_normalize(normal[0])
+                viewcos = normal @ torch.from_numpy(pose_np[:3, :3].copy()).to(v.device)
+                shading['normal'], shading['viewcos'] = (normal + 1) / 2, (viewcos + 1) / 2
+            return shading
+        if 'depth' in optional_render_types:
+            results.defer('depth', depth_fn)
+        if 'normal' in optional_render_types:
+            results.defer('normal', lambda: normal_pair()['normal'])
+            results.defer('viewcos', lambda: normal_pair()['viewcos'])
+        return results
+
     def render(self, pose, proj, h0, w0, ssaa=1, bg_color=1, texture_filter='linear', optional_render_types=['depth', 'normal']):
         h, w = (make_divisible(h0 * ssaa, 8), make_divisible(w0 * ssaa, 8)) if ssaa != 1 else (h0, w0)
         mesh = self.mesh
@@ -124,6 +183,8 @@ class DiffRastRenderer(nn.Module):
         pose_inv_np = np.linalg.inv(pose_np).astype(np.float32)
         proj_np = proj.astype(np.float32)
         fused = v.is_cuda and ssaa == 1 and self.fused_glue
+        if fused and self.fused_view and texture_filter == 'linear':
+            return self._render_fused_view(v, pose_np, pose_inv_np, proj_np, h, w, bg_color, optional_render_types)
         mats = torch.from_numpy(np.stack((pose_np, pose_inv_np, proj_np, proj_np @ pose_inv_np))).to(v.device)
         pose, pose_inv, proj, clip_from_world = mats[0], mats[1], mats[2], mats[3]
         if fused:

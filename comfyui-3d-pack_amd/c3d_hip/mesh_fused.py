@@ -60,3 +60,66 @@ class _Shade(torch.autograd.Function):
 def shade(albedo, alpha, bg):
     """albedo [H,W,3], alpha [H,W,1] (before its clamp), bg [3] -> (clamp(a*albedo + (1-a)*bg, 0, 1), a = clamp(alpha, 0, 1))"""
     return _Shade.apply(albedo, alpha, bg)
+
+
+# ---------------------------------------------------------------------------------------------------- one view, one call each way (round 2)
+class _RenderView(torch.autograd.Function):
+    """DiffRastRenderer.render for ssaa = 1 as c3d_mesh_view_fwd / c3d_mesh_view_bwd (include/c3d_mesh.h): the whole op sequence of a view
+    enqueued from C.  Inputs that carry gradients: v_offsets (or None) and raw_albedo; everything else is a constant of the view."""
+
+    @staticmethod
+    def forward(ctx, v, v_offsets, raw_albedo, f, vt, ft, clip_from_world, bg, H, W, glctx, aa_table, hold):
+        import ctypes as C
+        from c3d_hip.mesh_sigs import MeshView
+        lib = _h.lib()
+        dev = v.device
+        V, T, Vt = int(v.shape[0]), int(f.shape[0]), int(vt.shape[0])
+        Ht, Wt = int(raw_albedo.shape[0]), int(raw_albedo.shape[1])
+        d = MeshView(V, T, Vt, int(H), int(W), Ht, Wt, (C.c_float * 16)(*[float(x) for x in clip_from_world.reshape(-1)]), (C.c_float * 3)(*[float(x) for x in bg]))
+        state = torch.empty((lib.c3d_mesh_view_state_bytes(V, H, W),), dtype=torch.uint8, device=dev)
+        image = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
+        alpha = torch.empty((H, W, 1), dtype=torch.float32, device=dev)
+        scratch = glctx.scratch(lib.c3d_mesh_raster_scratch_bytes(1, H, W, T), dev)
+        v_c, ra_c = _h.f32c(v), _h.f32c(raw_albedo)
+        vo_c = _h.f32c(v_offsets) if v_offsets is not None else None
+        with torch.cuda.device(dev):
+            _h.check(lib.c3d_mesh_view_fwd(C.byref(d), _h.ptr(v_c), _h.ptr(vo_c), _h.ptr(f), _h.ptr(vt), _h.ptr(ft), _h.ptr(ra_c), _h.ptr(aa_table), _h.ptr(scratch),
+                                           _h.ptr(state), _h.ptr(image), _h.ptr(alpha), _h.stream(dev)), "c3d_mesh_view_fwd")
+        ctx.d, ctx.glctx, ctx.aa_table, ctx.geo = d, glctx, aa_table, v_offsets is not None and v_offsets.requires_grad
+        ctx.save_for_backward(v_c, vo_c if vo_c is not None else v_c.new_empty(0), ra_c, f, vt, ft, state)
+        hold["state"], hold["V"] = state, V            # the renderer reads rast / v_clip out of it for the outputs it produces on demand
+        return image, alpha
+
+    @staticmethod
+    def backward(ctx, dimage, dalpha):
+        import ctypes as C
+        lib = _h.lib()
+        v_c, vo_c, ra_c, f, vt, ft, state = ctx.saved_tensors
+        d, dev = ctx.d, v_c.device
+        d_ra = torch.empty_like(ra_c)
+        d_v = torch.empty_like(v_c) if ctx.geo else None
+        topo = ctx.glctx.vertex_topology(f, d.V) if ctx.geo else None
+        scratch = torch.empty((lib.c3d_mesh_view_bwd_scratch_bytes(d.V, d.T, d.H, d.W),), dtype=torch.uint8, device=dev)
+        di = _h.f32c(dimage) if dimage is not None else None
+        da = _h.f32c(dalpha) if dalpha is not None else None
+        with torch.cuda.device(dev):
+            _h.check(lib.c3d_mesh_view_bwd(C.byref(d), _h.ptr(v_c), _h.ptr(vo_c) if vo_c.numel() else None, _h.ptr(f), _h.ptr(vt), _h.ptr(ft), _h.ptr(ra_c), _h.ptr(ctx.aa_table),
+                                           _h.ptr(topo), _h.ptr(scratch), _h.ptr(state), _h.ptr(di), _h.ptr(da), _h.ptr(d_ra), _h.ptr(d_v), _h.stream(dev)), "c3d_mesh_view_bwd")
+        return None, d_v, d_ra, None, None, None, None, None, None, None, None, None, None
+
+
+def render_view(v, v_offsets, raw_albedo, f, vt, ft, clip_from_world, bg, H, W, glctx, aa_table):
+    """-> image [H,W,3], alpha [H,W,1], hold (dict with the saved state: see view_state_tensors)"""
+    hold = {}
+    image, alpha = _RenderView.apply(v, v_offsets, raw_albedo, f, vt, ft, clip_from_world, bg, H, W, glctx, aa_table, hold)
+    return image, alpha, hold
+
+
+def view_state_tensors(hold, H, W):
+    """rast [1,H,W,4] and v_clip [1,V,4] as tensor views of a fused view's saved state (layout: include/c3d_mesh.h, c3d_mesh_view_state_bytes)"""
+    state, V = hold["state"], hold["V"]
+    a = lambda n: (n + 255) // 256 * 256
+    o_rast = a(16 * max(V, 1))
+    vclip = state[:16 * V].view(torch.float32).view(1, V, 4)
+    rast = state[o_rast:o_rast + 16 * H * W].view(torch.float32).view(1, H, W, 4)
+    return rast, vclip

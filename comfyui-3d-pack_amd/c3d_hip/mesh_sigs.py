@@ -3,6 +3,12 @@ import ctypes as C
 
 vp, i32, sz = C.c_void_p, C.c_int32, C.c_size_t
 
+
+class MeshView(C.Structure):
+    """struct c3d_mesh_view"""
+    _fields_ = [("V", i32), ("T", i32), ("Vt", i32), ("H", i32), ("W", i32), ("Ht", i32), ("Wt", i32), ("clip_from_world", C.c_float * 16), ("bg", C.c_float * 3)]
+
+
 SIGNATURES = {
     "c3d_mesh_raster_scratch_bytes": (sz, [i32, i32, i32, i32]),
     "c3d_mesh_rasterize_fwd": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
@@ -28,5 +34,9 @@ SIGNATURES = {
     "c3d_mesh_antialias_scratch_bytes": (sz, [i32]),
     "c3d_mesh_antialias_build_topology": (C.c_int, [vp, i32, vp, vp]),
     "c3d_mesh_antialias_fwd": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
+    "c3d_mesh_view_state_bytes": (sz, [i32, i32, i32]),
+    "c3d_mesh_view_bwd_scratch_bytes": (sz, [i32, i32, i32, i32]),
+    "c3d_mesh_view_fwd": (C.c_int, [C.POINTER(MeshView), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "c3d_mesh_view_bwd": (C.c_int, [C.POINTER(MeshView), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "c3d_mesh_antialias_bwd": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
 }

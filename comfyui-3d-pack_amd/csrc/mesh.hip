@@ -1345,3 +1345,224 @@ int c3d_mesh_antialias_bwd(const float* color, const float* rast, const float* p
 }
 
 }  // extern "C"
+
+// ================================================================================================ fused view (round 2)
+// DiffRastRenderer.render (reference diff_mesh_renderer.py:72-159) for one view as ONE library call each way.  Round 1 issued the seven
+// nvdiffrast ops + ~15 torch elementwise ops of a view as separate autograd nodes: 1.07 ms per view of which 0.5 ms were kernels
+// (profiles/r01k_bench_mesh_n1.json).  Here the op sequence -- transform, rasterize, interpolate(uv), texture(linear), sigmoid, antialias,
+// composite over the background, clamps -- is enqueued from C without returning to Python, the camera matrix and background travel as kernel
+// arguments (no upload), and the two antialias calls of the reference (coverage, :105; albedo, :138) share ONE silhouette analysis per pixel
+// pair, forward and backward: the coverage "colour" is just (triangle id > 0) and is never materialised.
+struct ViewMat { float m[16]; };
+__global__ void __launch_bounds__(256) k_view_transform_fwd(const float* __restrict__ v, const float* __restrict__ voff, ViewMat M, int V, float4* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= V) return;
+    float x = v[3 * i], y = v[3 * i + 1], z = v[3 * i + 2];
+    if (voff) { x += voff[3 * i]; y += voff[3 * i + 1]; z += voff[3 * i + 2]; }
+    out[i] = make_float4(M.m[0] * x + M.m[1] * y + M.m[2] * z + M.m[3], M.m[4] * x + M.m[5] * y + M.m[6] * z + M.m[7],
+                         M.m[8] * x + M.m[9] * y + M.m[10] * z + M.m[11], M.m[12] * x + M.m[13] * y + M.m[14] * z + M.m[15]);
+}
+// dv += M^T (d_a + d_b): the two position gradients (antialias: scattered; rasterize: gathered) are summed on the way
+__global__ void __launch_bounds__(256) k_view_transform_bwd(ViewMat M, const float4* __restrict__ da, const float4* __restrict__ db, int V, float* __restrict__ dv) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= V) return;
+    float4 g = da[i];
+    if (db) { const float4 h = db[i]; g.x += h.x; g.y += h.y; g.z += h.z; g.w += h.w; }
+    dv[3 * i] = M.m[0] * g.x + M.m[4] * g.y + M.m[8] * g.z + M.m[12] * g.w;
+    dv[3 * i + 1] = M.m[1] * g.x + M.m[5] * g.y + M.m[9] * g.z + M.m[13] * g.w;
+    dv[3 * i + 2] = M.m[2] * g.x + M.m[6] * g.y + M.m[10] * g.z + M.m[14] * g.w;
+}
+// albedo = sigmoid(texture fetch), in place; also seeds the antialias outputs: albedo_aa = albedo, cov_aa = (id > 0)
+__global__ void __launch_bounds__(256) k_view_sigmoid_seed(float* __restrict__ albedo, const float4* __restrict__ rast, long long P, float* __restrict__ albedo_aa,
+                                                           float* __restrict__ cov_aa) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+#pragma unroll
+    for (int c = 0; c < 3; c++) { const float s = 1.f / (1.f + __expf(-albedo[3 * i + c])); albedo[3 * i + c] = s; albedo_aa[3 * i + c] = s; }
+    cov_aa[i] = rast[i].w > 0.f ? 1.f : 0.f;
+}
+// both antialias calls of the view in one pass over the pixel pairs
+__global__ void __launch_bounds__(256) k_aa2_fwd(const float* __restrict__ albedo, const float4* __restrict__ rast, const float4* __restrict__ pos,
+                                                  const int3* __restrict__ tri, const EdgeSlot* __restrict__ table, uint32_t mask, int H, int W,
+                                                  float* __restrict__ albedo_aa, float* __restrict__ cov_aa) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long P = (long long)H * W;
+    if (gid >= P * 2) return;
+    const int d = (int)(gid & 1), pid = (int)(gid >> 1), px = pid % W, py = pid / W;
+    AaHit h;
+    if (!aa_analyze(pos, tri, table, mask, rast, H, W, px, py, d, h)) return;
+    const float alpha = h.s - 0.5f;
+    const size_t ia = (size_t)h.ay * W + h.ax, ib = (size_t)h.by * W + h.bx, idst = alpha > 0.f ? ib : ia;
+#pragma unroll
+    for (int c = 0; c < 3; c++) atomicAdd(&albedo_aa[3 * idst + c], alpha * (albedo[3 * ia + c] - albedo[3 * ib + c]));
+    const float cb = rast[ib].w > 0.f ? 1.f : 0.f;         // pixel a owns the nearer triangle: its coverage is 1
+    if (cb != 1.f) atomicAdd(&cov_aa[idst], alpha * (1.f - cb));
+}
+__global__ void __launch_bounds__(256) k_aa2_bwd(const float* __restrict__ albedo, const float4* __restrict__ rast, const float4* __restrict__ pos,
+                                                  const int3* __restrict__ tri, const EdgeSlot* __restrict__ table, uint32_t mask, const float* __restrict__ dy3,
+                                                  const float* __restrict__ dy1, int V, int H, int W, float* __restrict__ dalbedo, float* __restrict__ dpos) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long P = (long long)H * W;
+    if (gid >= P * 2) return;
+    const int d = (int)(gid & 1), pid = (int)(gid >> 1), px = pid % W, py = pid / W;
+    AaHit h;
+    if (!aa_analyze(pos, tri, table, mask, rast, H, W, px, py, d, h)) return;
+    const float alpha = h.s - 0.5f;
+    const size_t ia = (size_t)h.ay * W + h.ax, ib = (size_t)h.by * W + h.bx, idst = alpha > 0.f ? ib : ia;
+    float dalpha = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float g = dy3[3 * idst + c];
+        atomicAdd(&dalbedo[3 * ia + c], alpha * g); atomicAdd(&dalbedo[3 * ib + c], -alpha * g);
+        dalpha += g * (albedo[3 * ia + c] - albedo[3 * ib + c]);
+    }
+    const float cb = rast[ib].w > 0.f ? 1.f : 0.f;
+    dalpha += dy1[idst] * (1.f - cb);
+    if (!dpos) return;
+    const float4 pa = pos[h.va], pv = pos[h.vb];
+    const float xa = pa.x / pa.w, ya = pa.y / pa.w, xb = pv.x / pv.w, yb = pv.y / pv.w;
+    const float cx = ((float)h.ax + 0.5f) * (2.f / W) - 1.f, cy = ((float)h.ay + 0.5f) * (2.f / H) - 1.f;
+    const float hh = d == 0 ? 2.f / W : 2.f / H;
+    const float gs = dalpha * h.sgn / hh;
+    float gxa, gya, gxb, gyb;
+    if (d == 0) {
+        const float da = ya - cy, db = yb - cy, den = da - db, te = da / den, gte = gs * (xb - xa);
+        gxa = gs * (1.f - te); gxb = gs * te;
+        gya = gte * (-db / (den * den)); gyb = gte * (da / (den * den));
+    } else {
+        const float da = xa - cx, db = xb - cx, den = da - db, te = da / den, gte = gs * (yb - ya);
+        gya = gs * (1.f - te); gyb = gs * te;
+        gxa = gte * (-db / (den * den)); gxb = gte * (da / (den * den));
+    }
+    float* dA = dpos + (size_t)h.va * 4;
+    float* dB = dpos + (size_t)h.vb * 4;
+    atomicAdd(dA + 0, gxa / pa.w); atomicAdd(dA + 1, gya / pa.w); atomicAdd(dA + 3, -(gxa * xa + gya * ya) / pa.w);
+    atomicAdd(dB + 0, gxb / pv.w); atomicAdd(dB + 1, gyb / pv.w); atomicAdd(dB + 3, -(gxb * xb + gyb * yb) / pv.w);
+}
+// shade with the background as a kernel argument; backward also seeds the antialias backward (dalbedo0 = dalbedo_aa) and applies nothing else
+struct ViewBg { float c[3]; };
+__global__ void __launch_bounds__(256) k_view_shade_fwd(const float* __restrict__ albedo, const float* __restrict__ alpha, ViewBg bg, long long P,
+                                                        float* __restrict__ image, float* __restrict__ alpha_out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const float a = fminf(fmaxf(alpha[i], 0.f), 1.f);
+    alpha_out[i] = a;
+#pragma unroll
+    for (int c = 0; c < 3; c++) image[3 * i + c] = fminf(fmaxf(a * albedo[3 * i + c] + (1.f - a) * bg.c[c], 0.f), 1.f);
+}
+__global__ void __launch_bounds__(256) k_view_shade_bwd(const float* __restrict__ albedo, const float* __restrict__ alpha, ViewBg bg, long long P,
+                                                        const float* __restrict__ dimage, const float* __restrict__ dalpha_out, float* __restrict__ dalbedo_aa,
+                                                        float* __restrict__ dalbedo0, float* __restrict__ dalpha) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const float ar = alpha[i], a = fminf(fmaxf(ar, 0.f), 1.f);
+    float da = dalpha_out ? dalpha_out[i] : 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float al = albedo[3 * i + c], val = a * al + (1.f - a) * bg.c[c];
+        const float g = (val >= 0.f && val <= 1.f) ? (dimage ? dimage[3 * i + c] : 0.f) : 0.f;     // torch.clamp passes the gradient on the closed interval
+        dalbedo_aa[3 * i + c] = g * a;
+        dalbedo0[3 * i + c] = g * a;        // antialias backward: dcolor starts as a copy of dy, the blends are added on top
+        da += g * (al - bg.c[c]);
+    }
+    dalpha[i] = (ar >= 0.f && ar <= 1.f) ? da : 0.f;
+}
+__global__ void __launch_bounds__(256) k_view_sigmoid_bwd(const float* __restrict__ s, float* __restrict__ g, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const float v = s[i]; g[i] *= v * (1.f - v); }
+}
+
+namespace {
+struct ViewState { float* vclip; float* rast; float* rast_db; float* texc; float* albedo0; float* albedo_aa; float* cov_aa; size_t bytes; };
+void carve_view_state(char* base, int V, int H, int W, ViewState& st) {
+    size_t off = 0;
+    const size_t P = (size_t)H * W;
+    auto take = [&](size_t b) { char* p = base ? base + off : nullptr; off += c3d_align(b); return (float*)p; };
+    st.vclip = take(16 * (size_t)(V > 0 ? V : 1)); st.rast = take(16 * P); st.rast_db = take(16 * P); st.texc = take(8 * P);
+    st.albedo0 = take(12 * P); st.albedo_aa = take(12 * P); st.cov_aa = take(4 * P);
+    st.bytes = off;
+}
+struct ViewBwdScratch { float* dalbedo_aa; float* dalbedo0; float* dcov; float* duv; float* drast; float* dpos_aa; float* dpos_r; void* ras; size_t bytes; };
+void carve_view_bwd(char* base, int V, int T, int H, int W, ViewBwdScratch& sc) {
+    size_t off = 0;
+    const size_t P = (size_t)H * W, v = (size_t)(V > 0 ? V : 1);
+    auto take = [&](size_t b) { char* p = base ? base + off : nullptr; off += c3d_align(b); return p; };
+    sc.dalbedo_aa = (float*)take(12 * P); sc.dalbedo0 = (float*)take(12 * P); sc.dcov = (float*)take(4 * P); sc.duv = (float*)take(8 * P); sc.drast = (float*)take(16 * P);
+    sc.dpos_aa = (float*)take(16 * v); sc.dpos_r = (float*)take(16 * v);
+    sc.ras = take(c3d_mesh_rasterize_bwd_scratch_bytes(1, T));
+    sc.bytes = off;
+}
+}  // namespace
+
+extern "C" {
+
+size_t c3d_mesh_view_state_bytes(int32_t V, int32_t H, int32_t W) { ViewState st; carve_view_state(nullptr, V, H, W, st); return st.bytes; }
+size_t c3d_mesh_view_bwd_scratch_bytes(int32_t V, int32_t T, int32_t H, int32_t W) { ViewBwdScratch sc; carve_view_bwd(nullptr, V, T, H, W, sc); return sc.bytes; }
+
+int c3d_mesh_view_fwd(const c3d_mesh_view* d, const float* v, const float* v_offsets, const int32_t* f, const float* vt, const int32_t* ft, const float* raw_albedo,
+                      const void* aa_topology, void* raster_scratch, void* state, float* image, float* alpha, c3d_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    MESH_REQUIRE(d && v && f && vt && ft && raw_albedo && aa_topology && raster_scratch && state && image && alpha, "c3d_mesh_view_fwd: NULL pointer");
+    MESH_REQUIRE(d->V > 0 && d->T > 0 && d->H > 0 && d->W > 0 && d->Ht > 0 && d->Wt > 0 && d->Vt > 0, "c3d_mesh_view_fwd: empty mesh / image / texture");
+    const int V = d->V, T = d->T, H = d->H, W = d->W;
+    const long long P = (long long)H * W;
+    ViewState st; carve_view_state((char*)state, V, H, W, st);
+    ViewMat M; for (int i = 0; i < 16; i++) M.m[i] = d->clip_from_world[i];
+    ViewBg bg; for (int i = 0; i < 3; i++) bg.c[i] = d->bg[i];
+    int rc;
+    hipLaunchKernelGGL(k_view_transform_fwd, dim3(c3d_cdiv(V, 256)), dim3(256), 0, s, v, v_offsets, M, V, (float4*)st.vclip);
+    if ((rc = c3d_mesh_rasterize_fwd(st.vclip, f, 1, V, T, H, W, raster_scratch, st.rast, st.rast_db, stream))) return rc;
+    // texture(..., filter_mode='linear') ignores uv_da (diff_mesh_renderer.py:110 passes it all the same): no pixel differentials are produced here
+    if ((rc = c3d_mesh_interpolate_fwd(vt, 1, st.rast, ft, nullptr, nullptr, 0, 1, d->Vt, 2, H, W, st.texc, nullptr, stream))) return rc;
+    if ((rc = c3d_mesh_texture_fwd(raw_albedo, 1, st.texc, 1, H, W, d->Ht, d->Wt, 3, 1, 0, st.albedo0, stream))) return rc;
+    {
+        C3dProfScope ps(C3D_P_MESH_ANTIALIAS, s);
+        hipLaunchKernelGGL(k_view_sigmoid_seed, dim3(c3d_cdiv(P, 256)), dim3(256), 0, s, st.albedo0, (const float4*)st.rast, P, st.albedo_aa, st.cov_aa);
+        hipLaunchKernelGGL(k_aa2_fwd, dim3(c3d_cdiv(P * 2, 256)), dim3(256), 0, s, st.albedo0, (const float4*)st.rast, (const float4*)st.vclip, (const int3*)f,
+                           (const EdgeSlot*)aa_topology, edge_table_size(T) - 1, H, W, st.albedo_aa, st.cov_aa);
+    }
+    {
+        C3dProfScope ps(C3D_P_OTHER, s);
+        hipLaunchKernelGGL(k_view_shade_fwd, dim3(c3d_cdiv(P, 256)), dim3(256), 0, s, st.albedo_aa, st.cov_aa, bg, P, image, alpha);
+    }
+    C3D_LAUNCH_CHECK();
+    return 0;
+}
+
+int c3d_mesh_view_bwd(const c3d_mesh_view* d, const float* v, const float* v_offsets, const int32_t* f, const float* vt, const int32_t* ft, const float* raw_albedo,
+                      const void* aa_topology, const void* vertex_topology, void* scratch, const void* state, const float* dimage, const float* dalpha,
+                      float* d_raw_albedo, float* d_v, c3d_stream_t stream) {
+    (void)v; (void)v_offsets;
+    hipStream_t s = (hipStream_t)stream;
+    MESH_REQUIRE(d && f && vt && ft && raw_albedo && aa_topology && scratch && state && d_raw_albedo, "c3d_mesh_view_bwd: NULL pointer");
+    MESH_REQUIRE(dimage || dalpha, "c3d_mesh_view_bwd: no upstream gradient");
+    MESH_REQUIRE(!d_v || vertex_topology, "c3d_mesh_view_bwd: the geometry gradient needs the vertex topology");
+    const int V = d->V, T = d->T, H = d->H, W = d->W;
+    const long long P = (long long)H * W;
+    ViewState st; carve_view_state((char*)state, V, H, W, st);
+    ViewBwdScratch sc; carve_view_bwd((char*)scratch, V, T, H, W, sc);
+    ViewMat M; for (int i = 0; i < 16; i++) M.m[i] = d->clip_from_world[i];
+    ViewBg bg; for (int i = 0; i < 3; i++) bg.c[i] = d->bg[i];
+    int rc;
+    {
+        C3dProfScope ps(C3D_P_OTHER, s);
+        hipLaunchKernelGGL(k_view_shade_bwd, dim3(c3d_cdiv(P, 256)), dim3(256), 0, s, st.albedo_aa, st.cov_aa, bg, P, dimage, dalpha, sc.dalbedo_aa, sc.dalbedo0, sc.dcov);
+    }
+    {
+        C3dProfScope ps(C3D_P_MESH_ANTIALIAS_BWD, s);
+        if (d_v) C3D_CHECK(hipMemsetAsync(sc.dpos_aa, 0, 16 * (size_t)V, s));
+        hipLaunchKernelGGL(k_aa2_bwd, dim3(c3d_cdiv(P * 2, 256)), dim3(256), 0, s, st.albedo0, (const float4*)st.rast, (const float4*)st.vclip, (const int3*)f,
+                           (const EdgeSlot*)aa_topology, edge_table_size(T) - 1, sc.dalbedo_aa, sc.dcov, V, H, W, sc.dalbedo0, d_v ? sc.dpos_aa : nullptr);
+        hipLaunchKernelGGL(k_view_sigmoid_bwd, dim3(c3d_cdiv(P * 3, 256)), dim3(256), 0, s, st.albedo0, sc.dalbedo0, P * 3);
+    }
+    if ((rc = c3d_mesh_texture_bwd(raw_albedo, 1, st.texc, sc.dalbedo0, 1, H, W, d->Ht, d->Wt, 3, 1, 0, d_raw_albedo, sc.duv, stream))) return rc;
+    if (d_v) {
+        if ((rc = c3d_mesh_interpolate_bwd(vt, 1, st.rast, ft, sc.duv, 1, d->Vt, 2, H, W, nullptr, sc.drast, stream))) return rc;
+        if ((rc = c3d_mesh_rasterize_bwd_gather(st.vclip, f, st.rast, sc.drast, 1, V, T, H, W, vertex_topology, sc.ras, sc.dpos_r, stream))) return rc;
+        hipLaunchKernelGGL(k_view_transform_bwd, dim3(c3d_cdiv(V, 256)), dim3(256), 0, s, M, (const float4*)sc.dpos_aa, (const float4*)sc.dpos_r, V, d_v);
+    }
+    C3D_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -120,6 +120,33 @@ int c3d_mesh_shade_fwd(const float* albedo, const float* alpha, const float* bg,
 int c3d_mesh_shade_bwd(const float* albedo, const float* alpha, const float* bg, int64_t P, const float* dimage, const float* dalpha_out,
                        float* dalbedo, float* dalpha, c3d_stream_t stream);
 
+
+/* ---- one view of DiffRastRenderer.render as ONE call each way (round 2) ------------------------------------------------------
+ * The op sequence of /root/reference/MVs_Algorithms/DiffRastMesh/diff_mesh_renderer.py:94-151 for ssaa = 1:
+ *   v_clip = [v (+ v_offsets), 1] . clip_from_world^T;  rast = rasterize(v_clip, f);  alpha = antialias(clamp(rast.w, 0, 1));
+ *   albedo = antialias(sigmoid(texture(raw_albedo, interpolate(vt, rast, ft), 'linear')));
+ *   a = clamp(alpha, 0, 1);  image = clamp(a * albedo + (1 - a) * bg, 0, 1)            -> image [H,W,3], alpha [H,W,1] (= a)
+ * enqueued from C without returning to the host language, camera matrix and background as plain struct fields (no upload), and the two
+ * antialias calls sharing one silhouette analysis per pixel pair.  Same values as the op-by-op path (tests/test_mesh_hip.py).
+ *   state   : c3d_mesh_view_state_bytes(V, H, W) bytes written by _fwd and read by _bwd (v_clip, rast, rast_db, uv, albedo, ...); the caller
+ *             may read rast ([H,W,4] floats at byte offset align256(16 V)) for the depth / normal outputs the reference produces on demand
+ *   aa_topology / vertex_topology : c3d_mesh_antialias_build_topology / c3d_mesh_build_vertex_topology of `f`
+ *   _bwd    : dimage [H,W,3], dalpha [H,W,1] (either may be NULL) -> d_raw_albedo [Ht,Wt,3] WRITTEN IN FULL, d_v [V,3] written in full
+ *             (NULL: geometry not trained; vertex_topology may then be NULL).  scratch: c3d_mesh_view_bwd_scratch_bytes(V, T, H, W). */
+typedef struct c3d_mesh_view {
+    int32_t V, T, Vt, H, W, Ht, Wt;
+    float clip_from_world[16];      /* row-major 4x4 */
+    float bg[3];
+} c3d_mesh_view;
+size_t c3d_mesh_view_state_bytes(int32_t V, int32_t H, int32_t W);
+size_t c3d_mesh_view_bwd_scratch_bytes(int32_t V, int32_t T, int32_t H, int32_t W);
+int c3d_mesh_view_fwd(const c3d_mesh_view* d, const float* v, const float* v_offsets, const int32_t* f, const float* vt, const int32_t* ft,
+                      const float* raw_albedo, const void* aa_topology, void* raster_scratch, void* state, float* image, float* alpha,
+                      c3d_stream_t stream);
+int c3d_mesh_view_bwd(const c3d_mesh_view* d, const float* v, const float* v_offsets, const int32_t* f, const float* vt, const int32_t* ft,
+                      const float* raw_albedo, const void* aa_topology, const void* vertex_topology, void* scratch, const void* state,
+                      const float* dimage, const float* dalpha, float* d_raw_albedo, float* d_v, c3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -438,21 +438,35 @@ def test_renderer_fused_glue_equals_torch_chain():
     gi = torch.tensor(rng.normal(size=(H, W, 3)).astype(np.float32), device="cuda")
     ga = torch.tensor(rng.normal(size=(H, W, 1)).astype(np.float32), device="cuda")
     outs = []
-    for fused in (True, False):
+    # three ways: the whole view as one library call each way (c3d_mesh_view_*, the default), op by op with the fused glue kernels, the torch chain
+    for fused_view, fused in ((True, True), (False, True), (False, False)):
         r = DiffRastRenderer(_torch_mesh(), force_cuda_rast=True).cuda()
-        r.train_geo, r.fused_glue = True, fused
+        r.train_geo, r.fused_glue, r.fused_view = True, fused, fused_view
         with torch.no_grad():
             r.raw_albedo.mul_(3.0)                     # push part of the composite outside [0,1]: the clamps must agree too
+            r.v_offsets.add_(torch.tensor(rng.normal(size=tuple(r.v_offsets.shape)).astype(np.float32), device="cuda") * 0.004 if fused_view else 0.0)
+            if not fused_view:
+                r.v_offsets.copy_(outs[0][6])          # the same offsets in all three
         out = r.render(pose, cam.perspective, H, W, bg_color=bg)
         ((out["image"] * gi).sum() + (out["alpha"] * ga).sum()).backward()
-        outs.append((out["image"].detach(), out["alpha"].detach(), out["depth"].detach(), out["normal"].detach(), r.raw_albedo.grad.clone(), r.v_offsets.grad.clone()))
-    a, b = outs
-    assert a[0].shape == (H, W, 3) and a[1].shape == (H, W, 1)
-    # one combined 4x4 instead of two successive ones: clip coordinates differ in the last bits, the silhouette blend amplifies that by 1/pixel
-    for x, y, name in zip(a[:4], b[:4], ("image", "alpha", "depth", "normal")):
-        assert (x - y).abs().mean().item() <= 1e-5 and (x - y).abs().max().item() <= 2e-3, name
-    assert rel_err(a[4].cpu().numpy(), b[4].cpu().numpy()) <= GRAD_REL
-    assert rel_err(a[5].cpu().numpy(), b[5].cpu().numpy()) <= 5e-3
+        outs.append((out["image"].detach(), out["alpha"].detach(), out["depth"].detach(), out["normal"].detach(), r.raw_albedo.grad.clone(), r.v_offsets.grad.clone(),
+                     r.v_offsets.detach().clone()))
+    b = outs[2]
+    for a in outs[:2]:
+        assert a[0].shape == (H, W, 3) and a[1].shape == (H, W, 1)
+        # one combined 4x4 instead of two successive ones: clip coordinates differ in the last bits, the silhouette blend amplifies that by 1/pixel
+        for x, y, name in zip(a[:4], b[:4], ("image", "alpha", "depth", "normal")):
+            assert (x - y).abs().mean().item() <= 1e-5 and (x - y).abs().max().item() <= 2e-3, name
+        assert rel_err(a[4].cpu().numpy(), b[4].cpu().numpy()) <= GRAD_REL
+        assert rel_err(a[5].cpu().numpy(), b[5].cpu().numpy()) <= 5e-3
+    # texture-only training (no geometry gradient, no vertex topology) and a scalar background through the fused view
+    r = DiffRastRenderer(_torch_mesh(), force_cuda_rast=True).cuda()
+    r2 = DiffRastRenderer(_torch_mesh(), force_cuda_rast=True).cuda()
+    r2.fused_view = False
+    o1, o2 = r.render(pose, cam.perspective, H, W, bg_color=1), r2.render(pose, cam.perspective, H, W, bg_color=1)
+    (o1["image"] * gi).sum().backward(); (o2["image"] * gi).sum().backward()
+    assert (o1["image"] - o2["image"]).abs().max().item() <= 2e-3 and rel_err(r.raw_albedo.grad.cpu().numpy(), r2.raw_albedo.grad.cpu().numpy()) <= GRAD_REL
+    assert r.v_offsets.grad is None or r.v_offsets.grad.abs().max().item() == 0
 
 
 def test_other_in_tree_consumers_op_sequences():
