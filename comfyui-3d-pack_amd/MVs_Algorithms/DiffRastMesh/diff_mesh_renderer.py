@@ -121,10 +121,14 @@ class DiffRastRenderer(nn.Module):
         (the camera controller hands the same white / black tensors over every step)"""
         if not torch.is_tensor(bg_color):
             return (float(bg_color),) * 3
-        host = getattr(bg_color, "_c3d_host", None)
-        if host is None or host[0] != bg_color._version:
+        try:
+            ver = bg_color._version
+        except RuntimeError:                 # inference tensors (the orbit-renderer nodes run under torch.inference_mode) keep no version counter
+            ver = None
+        host = getattr(bg_color, "_c3d_host", None) if ver is not None else None
+        if host is None or host[0] != ver:
             vals = [float(x) for x in bg_color.detach().reshape(-1).cpu().tolist()]
-            host = (bg_color._version, tuple((vals * 3)[:3]))
+            host = (ver, tuple((vals * 3)[:3]))
             try:
                 bg_color._c3d_host = host
             except AttributeError:
