@@ -43,12 +43,58 @@ __device__ __forceinline__ uint32_t ordered_bits(float f) {   // monotone float 
 }
 __device__ __forceinline__ bool edge_owns_tie(long long dx, long long dy) { return dy > 0 || (dy == 0 && dx < 0); }
 
-struct TriSetup { long long X[3], Y[3], s; int px0, px1, py0, py1; bool ok; };
+struct TriSetup { long long X[3], Y[3], s; int px0, px1, py0, py1; bool ok, clip; };
+
+// A vertex at or behind the camera plane (w <= 0): the dependency clips such a triangle against the view volume; restated per pixel, the part in
+// front of the near plane z = -w survives.  Pixel bounding box of the polygon clipped against z + w >= 0 (false: nothing survives).
+__device__ __forceinline__ bool mesh_clip_bbox(const float4 p0, const float4 p1, const float4 p2, int W, int H, int& px0, int& px1, int& py0, int& py1) {
+    const float4 pp[3] = {p0, p1, p2};
+    float bx0 = 0.f, bx1 = 0.f, by0 = 0.f, by1 = 0.f;
+    bool any = false, full = false;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float4 a = pp[k], c = pp[(k + 1) % 3];
+        const float da = a.z + a.w, dc = c.z + c.w;
+        float4 cand[2];
+        int nc = 0;
+        if (da >= 0.f) cand[nc++] = a;
+        if ((da >= 0.f) != (dc >= 0.f)) { const float tt = da / (da - dc); cand[nc++] = make_float4(a.x + tt * (c.x - a.x), a.y + tt * (c.y - a.y), a.z + tt * (c.z - a.z), a.w + tt * (c.w - a.w)); }
+        for (int q = 0; q < nc; q++) {
+            if (!(cand[q].w > 1e-12f)) { full = true; continue; }
+            const float nx = cand[q].x / cand[q].w, ny = cand[q].y / cand[q].w;
+            if (!any) { bx0 = bx1 = nx; by0 = by1 = ny; any = true; }
+            else { bx0 = fminf(bx0, nx); bx1 = fmaxf(bx1, nx); by0 = fminf(by0, ny); by1 = fmaxf(by1, ny); }
+        }
+    }
+    if (!any && !full) return false;
+    px0 = 0; py0 = 0; px1 = W - 1; py1 = H - 1;
+    if (!full) {
+        const float fx0 = (bx0 + 1.f) * 0.5f * W - 1.5f, fx1 = (bx1 + 1.f) * 0.5f * W + 0.5f, fy0 = (by0 + 1.f) * 0.5f * H - 1.5f, fy1 = (by1 + 1.f) * 0.5f * H + 0.5f;
+        if (fx0 > 0.f) px0 = fx0 > (float)W ? W : (int)fx0;
+        if (fy0 > 0.f) py0 = fy0 > (float)H ? H : (int)fy0;
+        if (fx1 < (float)(W - 1)) px1 = fx1 < -1.f ? -1 : (int)fx1;
+        if (fy1 < (float)(H - 1)) py1 = fy1 < -1.f ? -1 : (int)fy1;
+    }
+    return px0 <= px1 && py0 <= py1;
+}
+// coverage of a clipped triangle: homogeneous barycentrics all >= 0 (inclusive) and interpolated w > 0
+__device__ __forceinline__ bool mesh_covers_clip(const float4 p0, const float4 p1, const float4 p2, float fx, float fy) {
+    const float p0x = p0.x - fx * p0.w, p0y = p0.y - fy * p0.w, p1x = p1.x - fx * p1.w, p1y = p1.y - fy * p1.w, p2x = p2.x - fx * p2.w, p2y = p2.y - fy * p2.w;
+    const float a0 = p1x * p2y - p1y * p2x, a1 = p2x * p0y - p2y * p0x, a2 = p0x * p1y - p0y * p1x, sum = a0 + a1 + a2;
+    if (sum == 0.f) return false;
+    const float b0 = a0 / sum, b1 = a1 / sum, b2 = a2 / sum;
+    if (!(b0 >= 0.f && b1 >= 0.f && b2 >= 0.f)) return false;
+    return b0 * p0.w + b1 * p1.w + b2 * p2.w > 0.f;
+}
 
 __device__ __forceinline__ TriSetup mesh_setup(const float4 p0, const float4 p1, const float4 p2, int W, int H) {
     TriSetup t;
-    t.ok = false;
-    if (!(p0.w > 0.f && p1.w > 0.f && p2.w > 0.f)) return t;
+    t.ok = false; t.clip = false;
+    if (!(p0.w > 0.f && p1.w > 0.f && p2.w > 0.f)) {
+        t.s = 1;
+        t.ok = t.clip = mesh_clip_bbox(p0, p1, p2, W, H, t.px0, t.px1, t.py0, t.py1);
+        return t;
+    }
     const float4 pp[3] = {p0, p1, p2};
 #pragma unroll
     for (int k = 0; k < 3; k++) {
@@ -104,7 +150,7 @@ __global__ void __launch_bounds__(256) k_ras_tri(const float4* __restrict__ pos,
     const TriSetup ts = mesh_setup(p0, p1, p2, W, H);
     if (!ts.ok) return;
     const long long area = (long long)(ts.px1 - ts.px0 + 1) * (ts.py1 - ts.py0 + 1);
-    if (area > MESH_BIG_BBOX) { big_queue[atomicAdd(big_count, 1u)] = (uint32_t)gid; return; }
+    if (area > MESH_BIG_BBOX || ts.clip) { big_queue[atomicAdd(big_count, 1u)] = (uint32_t)gid; return; }   // near-plane clipped triangles: rare, a workgroup each
     const float xs = 2.f / W, ys = 2.f / H;
     unsigned long long* zb = zbuf + (size_t)b * H * W;
     const unsigned long long* pl = peel ? peel + (size_t)b * H * W : nullptr;
@@ -131,7 +177,8 @@ __global__ void __launch_bounds__(256) k_ras_big(const float4* __restrict__ pos,
         const unsigned long long* pl = peel ? peel + (size_t)b * H * W : nullptr;
         for (long long i = threadIdx.x; i < area; i += blockDim.x) {
             const int px = ts.px0 + (int)(i % bw), py = ts.py0 + (int)(i / bw);
-            if (mesh_covers(ts, px, py)) mesh_plot(p0, p1, p2, px, py, W, H, xs, ys, (uint32_t)t, zb, pl);
+            const bool in = ts.clip ? mesh_covers_clip(p0, p1, p2, xs * ((float)px + 0.5f) - 1.f, ys * ((float)py + 0.5f) - 1.f) : mesh_covers(ts, px, py);
+            if (in) mesh_plot(p0, p1, p2, px, py, W, H, xs, ys, (uint32_t)t, zb, pl);
         }
     }
 }
@@ -251,7 +298,7 @@ __global__ void __launch_bounds__(256) k_ras_bwd_tri(const float4* __restrict__ 
     const TriSetup ts = mesh_setup(p0, p1, p2, W, H);
     if (!ts.ok) { out[0] = z4; out[1] = z4; out[2] = z4; return; }
     const long long area = (long long)(ts.px1 - ts.px0 + 1) * (ts.py1 - ts.py0 + 1);
-    if (area > MESH_BIG_BBOX) { big_queue[atomicAdd(big_count, 1u)] = (uint32_t)gid; return; }   // records written by k_ras_bwd_big
+    if (area > MESH_BIG_BBOX || ts.clip) { big_queue[atomicAdd(big_count, 1u)] = (uint32_t)gid; return; }   // records written by k_ras_bwd_big
     const float xs = 2.f / W, ys = 2.f / H, idf = (float)(t + 1);
     const size_t pbase = (size_t)b * H * W;
     float ax[3] = {0.f, 0.f, 0.f}, ay[3] = {0.f, 0.f, 0.f}, aw[3] = {0.f, 0.f, 0.f};

@@ -85,7 +85,59 @@ static void rasterize_impl(const real *pos, const int32_t *tri, int B, int V, in
             int i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
             if (i0 < 0 || i0 >= V || i1 < 0 || i1 >= V || i2 < 0 || i2 >= V) continue;
             const real *p0 = pb + 4 * i0, *p1 = pb + 4 * i1, *p2 = pb + 4 * i2;
-            if (!(p0[3] > 0 && p1[3] > 0 && p2[3] > 0)) continue;   /* triangles touching the w<=0 half space are dropped */
+            if (!(p0[3] > 0 && p1[3] > 0 && p2[3] > 0)) {
+                /* A vertex at or behind the camera plane (w <= 0): the dependency clips such a triangle against the view volume.  Restated per
+                 * pixel: the part in front of the near plane z = -w is what survives.  Pixel bounding box from the polygon clipped against
+                 * z + w >= 0; coverage by the homogeneous barycentrics (all >= 0, inclusive) with interpolated w > 0; the usual per-pixel
+                 * -1 <= z/w <= 1 test; barycentrics / depth from the ORIGINAL vertices (the homogeneous form needs no divide by a vertex w). */
+                const real *pp[3] = {p0, p1, p2};
+                real bx0 = 0, bx1 = 0, by0 = 0, by1 = 0;
+                int nb = 0, full = 0;
+                for (int k = 0; k < 3; k++) {
+                    const real *a = pp[k], *c = pp[(k + 1) % 3];
+                    real da = a[2] + a[3], dc = c[2] + c[3];
+                    real cand[2][4];
+                    int nc = 0;
+                    if (da >= 0) { for (int j = 0; j < 4; j++) cand[nc][j] = a[j]; nc++; }
+                    if ((da >= 0) != (dc >= 0)) { real tt = da / (da - dc); for (int j = 0; j < 4; j++) cand[nc][j] = a[j] + tt * (c[j] - a[j]); nc++; }
+                    for (int q = 0; q < nc; q++) {
+                        if (!(cand[q][3] > (real)1e-12)) { full = 1; continue; }
+                        real nx = cand[q][0] / cand[q][3], ny = cand[q][1] / cand[q][3];
+                        if (!nb) { bx0 = bx1 = nx; by0 = by1 = ny; nb = 1; }
+                        else { if (nx < bx0) bx0 = nx; if (nx > bx1) bx1 = nx; if (ny < by0) by0 = ny; if (ny > by1) by1 = ny; }
+                    }
+                }
+                if (!nb && !full) continue;                                   /* entirely in front of the near plane's wrong side */
+                int64_t cpx0 = 0, cpx1 = W - 1, cpy0 = 0, cpy1 = H - 1;
+                if (!full) {
+                    double fx0 = ((double)bx0 + 1) * 0.5 * W - 1.5, fx1 = ((double)bx1 + 1) * 0.5 * W + 0.5, fy0 = ((double)by0 + 1) * 0.5 * H - 1.5, fy1 = ((double)by1 + 1) * 0.5 * H + 0.5;
+                    if (fx0 > 0) cpx0 = fx0 > W ? W : (int64_t)fx0;
+                    if (fy0 > 0) cpy0 = fy0 > H ? H : (int64_t)fy0;
+                    if (fx1 < W - 1) cpx1 = fx1 < -1 ? -1 : (int64_t)fx1;
+                    if (fy1 < H - 1) cpy1 = fy1 < -1 ? -1 : (int64_t)fy1;
+                }
+                for (int64_t py = cpy0; py <= cpy1; py++)
+                    for (int64_t px = cpx0; px <= cpx1; px++) {
+                        real fx = xs * ((real)px + (real)0.5) - (real)1, fy = ys * ((real)py + (real)0.5) - (real)1;
+                        real q0x = p0[0] - fx * p0[3], q0y = p0[1] - fy * p0[3], q1x = p1[0] - fx * p1[3], q1y = p1[1] - fy * p1[3];
+                        real q2x = p2[0] - fx * p2[3], q2y = p2[1] - fy * p2[3];
+                        real a0 = q1x * q2y - q1y * q2x, a1 = q2x * q0y - q2y * q0x, a2 = q0x * q1y - q0y * q1x, sum = a0 + a1 + a2;
+                        if (sum == 0) continue;
+                        real b0 = a0 / sum, b1 = a1 / sum, b2 = a2 / sum;
+                        if (!(b0 >= 0 && b1 >= 0 && b2 >= 0)) continue;
+                        if (!(b0 * p0[3] + b1 * p1[3] + b2 * p2[3] > 0)) continue;
+                        frag_t f;
+                        shade(p0, p1, p2, fx, fy, xs, ys, &f);
+                        if (!(f.zw >= -1 && f.zw <= 1)) continue;
+                        size_t pid = (size_t)py * W + px;
+                        if (prev) {
+                            const real *pr = prev + ((size_t)b * P + pid) * 4;
+                            if (pr[3] == 0 || !(f.zw > pr[2])) continue;
+                        }
+                        if (tbest[pid] < 0 || f.zw < zbest[pid]) { zbest[pid] = f.zw; tbest[pid] = t; }
+                    }
+                continue;
+            }
             int64_t X[3], Y[3];
             const real *pp[3] = {p0, p1, p2};
             int bad = 0;

@@ -381,3 +381,72 @@ def test_texture_zero_boundary_known_answers_gradients_and_the_clamp_composition
         assert abs(v_ - duv.reshape(-1)[i]) < 1e-5 * max(1.0, abs(v_))
     with pytest.raises(AssertionError):
         M.texture_mip(tex, uv, mip_level_bias=np.zeros((2, 11, 13)), boundary_mode="zero", max_mip_level=0, dtype=d)
+
+
+def _near_plane_scene():
+    """a ground plane under an orbit camera: the two triangles run from in front of the camera to BEHIND it (w <= 0 on two of four vertices)"""
+    from shared_utils.camera_utils import OrbitCamera, orbit_camera
+    H, W = 96, 128
+    cam = OrbitCamera(W, H, fovy=60.0)
+    pose = orbit_camera(-25.0, 20.0, 1.2)
+    g = np.array([[-3.0, -0.35, -4.0], [3.0, -0.35, -4.0], [3.0, -0.35, 4.0], [-3.0, -0.35, 4.0], [0.2, 0.3, 0.1], [0.6, -0.2, 0.2], [-0.1, -0.3, 0.5]], np.float64)
+    vh = np.concatenate([g, np.ones((g.shape[0], 1))], 1)
+    clip = (vh @ np.linalg.inv(pose).T) @ cam.perspective.astype(np.float64).T
+    tri = np.array([[0, 1, 2], [0, 2, 3], [4, 5, 6]], np.int32)
+    return clip[None], tri, (H, W)
+
+
+def _clip_polygon_w(verts, wmin):
+    """Sutherland-Hodgman against w >= wmin -> list of clip-space vertices"""
+    out = []
+    n = len(verts)
+    for k in range(n):
+        a, c = verts[k], verts[(k + 1) % n]
+        ia, ic = a[3] >= wmin, c[3] >= wmin
+        if ia:
+            out.append(a)
+        if ia != ic:
+            t = (a[3] - wmin) / (a[3] - c[3])
+            out.append(a + t * (c - a))
+    return out
+
+
+def test_near_plane_clipping_equals_rasterizing_the_preclipped_geometry():
+    """Triangles with vertices at / behind the camera plane (w <= 0) are clipped, not dropped (what the dependency does; reference users
+    with free cameras: the ~30 `dr.*` call sites of Gen_3D_Modules).  Known answer: the same triangles clipped by hand against w >= eps (well
+    inside the near plane, so nothing visible is lost) and fanned into all-positive-w triangles must rasterize to the same coverage, depth and
+    interpolated attributes through the ordinary path -- up to the pixels on the new fan edges and on the outline (1/16-px snapping there)."""
+    pos, tri, (H, W) = _near_plane_scene()
+    assert (pos[0, :4, 3] <= 0).sum() >= 1 and (pos[0, :4, 3] > 0).sum() >= 1
+    rast, _ = M.rasterize(pos, tri, (H, W), dtype=np.float64)
+    attr = np.concatenate([np.arange(7, dtype=np.float64)[:, None], np.linspace(-1, 1, 7)[:, None] ** 2], 1)
+    out, _ = M.interpolate(attr[None], rast, tri, dtype=np.float64)
+    # by hand
+    verts, tris, src = [], [], []
+    for t in range(tri.shape[0]):
+        poly = _clip_polygon_w([pos[0, i] for i in tri[t]], 1e-3)
+        # attributes of the new vertices: barycentric w.r.t. the original triangle (solve in clip space)
+        A = np.stack([pos[0, i] for i in tri[t]], 1)                  # 4 x 3
+        base = len(verts)
+        for p in poly:
+            b = np.linalg.lstsq(A, p, rcond=None)[0]
+            verts.append((p, b @ attr[tri[t]]))
+        for k in range(1, len(poly) - 1):
+            tris.append([base, base + k, base + k + 1]); src.append(t)
+    pos2 = np.stack([v[0] for v in verts])[None]
+    attr2 = np.stack([v[1] for v in verts])
+    tri2 = np.asarray(tris, np.int32)
+    assert (pos2[0, :, 3] > 0).all()
+    rast2, _ = M.rasterize(pos2, tri2, (H, W), dtype=np.float64)
+    out2, _ = M.interpolate(attr2[None], rast2, tri2, dtype=np.float64)
+    id1 = rast[0, ..., 3].astype(int)
+    id2 = np.where(rast2[0, ..., 3] > 0, np.asarray(src)[np.maximum(rast2[0, ..., 3].astype(int) - 1, 0)] + 1, 0)
+    assert (id1 > 0).mean() > 0.3                                     # the ground really fills a good part of the image
+    differ = id1 != id2
+    assert differ.mean() <= 0.01, differ.mean()                       # outline / fan-edge pixels only
+    m = ~differ & (id1 > 0)
+    np.testing.assert_allclose(rast[0, ..., 2][m], rast2[0, ..., 2][m], atol=1e-9)       # z/w
+    np.testing.assert_allclose(out[0][m], out2[0][m], atol=5e-5)                         # perspective-correct attributes from the ORIGINAL vertices (u, v are clamped to [0,1] per path: 1e-5 on edge pixels)
+    # ... and without the behind-camera vertices nothing changed: all-positive-w triangles take the ordinary path
+    r3, _ = M.rasterize(pos[:, 4:], np.array([[0, 1, 2]], np.int32), (H, W), dtype=np.float64)
+    assert ((r3[0, ..., 3] > 0) <= (id1 > 0)).all()
