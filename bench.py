@@ -88,11 +88,11 @@ def code_digest():
     return c3d_hip.code_digest()
 
 
-def load_profile_json(suffix):
+def load_profile_json(suffix, exclude=None):
     """newest committed profiles/*<suffix> whose `_meta.code_digest` is the digest of the code that is running -> (dict, file name, stale digest | None).
     Traffic measured on other kernel code is refused (VERDICT r1, weak #8): the line then says traffic: null, stale: <digest>."""
     try:
-        cand = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith(suffix))
+        cand = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith(suffix) and not (exclude and exclude in f))
         if not cand:
             return {}, None, None
         d = json.load(open(os.path.join(ROOT, "profiles", cand[-1])))
@@ -456,7 +456,7 @@ def main():
     # HBM traffic of the dominant kernel: rocprofv3 PMC counters cannot be read from inside the process, so the per-launch figure comes
     # from the committed summary of two separate --pmc passes over this same command (profiles/summarize_pmc.py; FETCH_SIZE raw + WRITE_SIZE,
     # MI355X_MICROARCH.md: FETCH_SIZE under-reports wide streaming reads by 2x on gfx950 -- both figures are in the file).
-    pmc, pmc_file, pmc_stale = load_profile_json("_pmc_traffic.json")
+    pmc, pmc_file, pmc_stale = load_profile_json("_pmc_traffic.json", exclude="_mesh_")
     pmc_name = {"gs_composite_bwd": "k_composite_bwd", "gs_composite_fwd": "k_composite_fwd", "gs_preprocess": "k_preprocess<true, true>",
                 "gs_preprocess_bwd": "k_preprocess_bwd<true, true, true>", "gs_emit": "k_emit"}
     if prof:

@@ -2,7 +2,9 @@
 MI355X_MICROARCH.md prescribes: both do not fit the TCC slots of one pass).  Units: the counters are in KiB.
 gfx950 correction from the guide: FETCH_SIZE reports exactly half of a wide coalesced streaming read (16 B/lane) --
 both the raw and the x2-corrected figure are printed; WRITE_SIZE is uncalibrated.
-usage: python profiles/summarize_pmc.py <fetch.db> <write.db> [out.json]
+usage: python profiles/summarize_pmc.py <fetch.db> <write.db> [out.json] [mesh]
+`mesh`: additionally sum the kernels of each bench.py profiling group of the DiffRastMesh workload ("_groups": traffic per VIEW, every kernel
+of a group runs once per view), which is what bench.py --workload mesh reports as roofline.traffic.
 The JSON carries "_meta": {"code_digest": ...} (c3d_hip.code_digest()): bench.py refuses traffic figures measured on other kernel code."""
 import json
 import os
@@ -30,6 +32,23 @@ for k in sorted(f, key=lambda k: -f[k][1] * f[k][0]):
     wr = w.get(k, (0, 0, 0))[1] * 1024 / 1e6
     out[k] = {"launches": f[k][0], "fetch_MB_raw": round(fe, 2), "fetch_MB_x2": round(2 * fe, 2), "write_MB": round(wr, 2), "avg_us": round(f[k][2] / 1e3, 1)}
     print("%s,%d,%.2f,%.2f,%.2f,%.1f" % (k, f[k][0], fe, 2 * fe, wr, f[k][2] / 1e3))
+MESH_GROUPS = {
+    "mesh_rasterize": ("k_ras_tri", "k_ras_big", "k_ras_resolve", "k_view_transform_fwd"), "mesh_interpolate": ("k_interp_fwd",), "mesh_texture": ("k_tex_fwd",),
+    "mesh_antialias": ("k_view_sigmoid_seed", "k_aa2_fwd", "k_aa_fwd"), "other": ("k_view_shade_fwd", "k_view_shade_bwd", "k_shade_fwd", "k_shade_bwd"),
+    "mesh_antialias_bwd": ("k_aa2_bwd", "k_view_sigmoid_bwd", "k_aa_bwd"), "mesh_texture_bwd": ("k_tex_bwd_tiled", "k_tex_bwd"), "mesh_interpolate_bwd": ("k_interp_bwd",),
+    "mesh_rasterize_bwd": ("k_ras_bwd_tri", "k_ras_bwd_big", "k_vertex_gather4", "k_vertex_gather4_heavy", "k_view_transform_bwd")}
+if len(sys.argv) > 4 and sys.argv[4] == "mesh":
+    groups = {}
+    for g, names in MESH_GROUPS.items():
+        acc = {"fetch_MB_raw": 0.0, "fetch_MB_x2": 0.0, "write_MB": 0.0, "avg_us": 0.0, "kernels": []}
+        for k, rec in out.items():
+            base = k.split("<")[0].strip()
+            if base in names:
+                for f_ in ("fetch_MB_raw", "fetch_MB_x2", "write_MB", "avg_us"):
+                    acc[f_] = round(acc[f_] + rec[f_], 3)
+                acc["kernels"].append(k)
+        groups[g] = acc
+    out["_groups"] = groups
 if len(sys.argv) > 3:
     try:
         import c3d_hip
