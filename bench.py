@@ -317,6 +317,7 @@ def main():
     if loss_kind == "full-torch" and a.render_path == "step" and a.mode != "fwd":
         from shared_utils.msssim import MS_SSIM
         ms_ssim = MS_SSIM(data_range=1, size_average=True, channel=3)
+        ms_ssim.use_hip = False       # the comparison point: torch's op chain all the way (grouped convolutions + elementwise ops)
     if a.render_path == "step" and a.mode != "fwd":
         from c3d_hip.gs_step import FusedViewStep
         fused_step = FusedViewStep(N, H, W, dev, lanes=a.lanes, views=len(settings))

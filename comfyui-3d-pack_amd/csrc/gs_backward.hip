@@ -271,7 +271,7 @@ int gs_launch_composite_bwd(const GsParams& p, const GsGeom& g, const GsBinning&
     const int tiles = p.gx * p.gy;
     if (tiles == 0) return 0;
     C3D_CHECK(hipMemsetAsync(pvalid, 0, (size_t)(pairs > 0 ? pairs : 1), s));
-    hipLaunchKernelGGL(k_composite_bwd, dim3(gs_block_count(p.gx, p.gy, gs_supertile_shift())), dim3(256), 0, s, p, b.ranges, b.tval[res], g.einfo, g.rec0, g.rec1, g.rec2,
+    hipLaunchKernelGGL(k_composite_bwd, dim3(gs_block_count(p.gx, p.gy, gs_supertile_shift())), dim3(256), gs_lds_pad(true), s, p, b.ranges, b.tval[res], g.einfo, g.rec0, g.rec1, g.rec2,
                        im.final_T, im.n_contrib, dL_dcolor, dL_ddepth, dL_dalpha, (float4*)pairgrad, pvalid, cap, gs_supertile_shift());
     C3D_LAUNCH_CHECK();
     return 0;

@@ -280,7 +280,7 @@ int gs_launch_composite_fwd(const GsParams& p, const GsGeom& g, const GsBinning&
                             float* out_color, float* out_depth, float* out_alpha, hipStream_t s) {
     const int tiles = p.gx * p.gy;
     if (tiles == 0) return 0;
-    hipLaunchKernelGGL(k_composite_fwd, dim3(gs_block_count(p.gx, p.gy, gs_supertile_shift())), dim3(256), 0, s, p, b.ranges, b.tval[res], g.rec0, g.rec1, g.rec2,
+    hipLaunchKernelGGL(k_composite_fwd, dim3(gs_block_count(p.gx, p.gy, gs_supertile_shift())), dim3(256), gs_lds_pad(false), s, p, b.ranges, b.tval[res], g.rec0, g.rec1, g.rec2,
                        out_color, out_depth, out_alpha, im.final_T, im.n_contrib, gs_supertile_shift());
     C3D_LAUNCH_CHECK();
     return 0;

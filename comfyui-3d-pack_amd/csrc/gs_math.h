@@ -191,6 +191,14 @@ static inline int gs_supertile_shift() {
     if (v < 0) { const char* e = getenv("C3D_SUPERTILE_SHIFT"); v = e ? atoi(e) : 1; if (v < 0 || v > 3) v = 1; }
     return v;
 }
+// Extra (unused) dynamic LDS per compositing workgroup: caps how many of them a CU holds, so that the kernels of the other view lanes
+// (latency-bound sorts, streaming preprocess) find wave slots beside them instead of waiting for the compositing grid to drain.
+// C3D_FWD_LDS_PAD / C3D_BWD_LDS_PAD in bytes (experiment knobs; defaults chosen from profiles/r02*_lds_pad_sweep.txt).
+static inline int gs_lds_pad(bool bwd) {
+    static int v[2] = {-1, -1};
+    if (v[bwd] < 0) { const char* e = getenv(bwd ? "C3D_BWD_LDS_PAD" : "C3D_FWD_LDS_PAD"); v[bwd] = e ? atoi(e) : 0; if (v[bwd] < 0 || v[bwd] > 100000) v[bwd] = 0; }
+    return v[bwd];
+}
 static inline int gs_block_count(int gx, int gy, int sh = 1) {
     const int S = ((gx + (1 << sh) - 1) >> sh) * ((gy + (1 << sh) - 1) >> sh);
     return 8 * (1 << (2 * sh)) * ((S + 7) / 8);

@@ -1431,13 +1431,17 @@ __global__ void __launch_bounds__(256) k_view_sigmoid_seed(float* __restrict__ a
 // both antialias calls of the view in one pass over the pixel pairs
 __global__ void __launch_bounds__(256) k_aa2_fwd(const float* __restrict__ albedo, const float4* __restrict__ rast, const float4* __restrict__ pos,
                                                   const int3* __restrict__ tri, const EdgeSlot* __restrict__ table, uint32_t mask, int H, int W,
-                                                  float* __restrict__ albedo_aa, float* __restrict__ cov_aa) {
+                                                  float* __restrict__ albedo_aa, float* __restrict__ cov_aa, uint8_t* __restrict__ hit) {
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long P = (long long)H * W;
     if (gid >= P * 2) return;
     const int d = (int)(gid & 1), pid = (int)(gid >> 1), px = pid % W, py = pid / W;
     AaHit h;
-    if (!aa_analyze(pos, tri, table, mask, rast, H, W, px, py, d, h)) return;
+    // On a mesh of ~2-pixel triangles nearly EVERY pixel pair has two different ids and runs the whole analysis (vertex loads, edge-hash lookups)
+    // only to find an interior, non-silhouette edge.  One byte per pair remembers the outcome: the backward pass re-analyses the hits only.
+    const bool found = aa_analyze(pos, tri, table, mask, rast, H, W, px, py, d, h);
+    hit[gid] = found ? 1 : 0;
+    if (!found) return;
     const float alpha = h.s - 0.5f;
     const size_t ia = (size_t)h.ay * W + h.ax, ib = (size_t)h.by * W + h.bx, idst = alpha > 0.f ? ib : ia;
 #pragma unroll
@@ -1447,10 +1451,12 @@ __global__ void __launch_bounds__(256) k_aa2_fwd(const float* __restrict__ albed
 }
 __global__ void __launch_bounds__(256) k_aa2_bwd(const float* __restrict__ albedo, const float4* __restrict__ rast, const float4* __restrict__ pos,
                                                   const int3* __restrict__ tri, const EdgeSlot* __restrict__ table, uint32_t mask, const float* __restrict__ dy3,
-                                                  const float* __restrict__ dy1, int V, int H, int W, float* __restrict__ dalbedo, float* __restrict__ dpos) {
+                                                  const float* __restrict__ dy1, int V, int H, int W, float* __restrict__ dalbedo, float* __restrict__ dpos,
+                                                  const uint8_t* __restrict__ hit) {
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long P = (long long)H * W;
     if (gid >= P * 2) return;
+    if (!hit[gid]) return;
     const int d = (int)(gid & 1), pid = (int)(gid >> 1), px = pid % W, py = pid / W;
     AaHit h;
     if (!aa_analyze(pos, tri, table, mask, rast, H, W, px, py, d, h)) return;
@@ -1520,13 +1526,14 @@ __global__ void __launch_bounds__(256) k_view_sigmoid_bwd(const float* __restric
 }
 
 namespace {
-struct ViewState { float* vclip; float* rast; float* rast_db; float* texc; float* albedo0; float* albedo_aa; float* cov_aa; size_t bytes; };
+struct ViewState { float* vclip; float* rast; float* rast_db; float* texc; float* albedo0; float* albedo_aa; float* cov_aa; uint8_t* hit; size_t bytes; };
 void carve_view_state(char* base, int V, int H, int W, ViewState& st) {
     size_t off = 0;
     const size_t P = (size_t)H * W;
     auto take = [&](size_t b) { char* p = base ? base + off : nullptr; off += c3d_align(b); return (float*)p; };
     st.vclip = take(16 * (size_t)(V > 0 ? V : 1)); st.rast = take(16 * P); st.rast_db = take(16 * P); st.texc = take(8 * P);
     st.albedo0 = take(12 * P); st.albedo_aa = take(12 * P); st.cov_aa = take(4 * P);
+    st.hit = (uint8_t*)take(2 * P);
     st.bytes = off;
 }
 struct ViewBwdScratch { float* dalbedo_aa; float* dalbedo0; float* dcov; float* duv; float* drast; float* dpos_aa; float* dpos_r; void* ras; size_t bytes; };
@@ -1566,7 +1573,7 @@ int c3d_mesh_view_fwd(const c3d_mesh_view* d, const float* v, const float* v_off
         C3dProfScope ps(C3D_P_MESH_ANTIALIAS, s);
         hipLaunchKernelGGL(k_view_sigmoid_seed, dim3(c3d_cdiv(P, 256)), dim3(256), 0, s, st.albedo0, (const float4*)st.rast, P, st.albedo_aa, st.cov_aa);
         hipLaunchKernelGGL(k_aa2_fwd, dim3(c3d_cdiv(P * 2, 256)), dim3(256), 0, s, st.albedo0, (const float4*)st.rast, (const float4*)st.vclip, (const int3*)f,
-                           (const EdgeSlot*)aa_topology, edge_table_size(T) - 1, H, W, st.albedo_aa, st.cov_aa);
+                           (const EdgeSlot*)aa_topology, edge_table_size(T) - 1, H, W, st.albedo_aa, st.cov_aa, st.hit);
     }
     {
         C3dProfScope ps(C3D_P_OTHER, s);
@@ -1599,7 +1606,7 @@ int c3d_mesh_view_bwd(const c3d_mesh_view* d, const float* v, const float* v_off
         C3dProfScope ps(C3D_P_MESH_ANTIALIAS_BWD, s);
         if (d_v) C3D_CHECK(hipMemsetAsync(sc.dpos_aa, 0, 16 * (size_t)V, s));
         hipLaunchKernelGGL(k_aa2_bwd, dim3(c3d_cdiv(P * 2, 256)), dim3(256), 0, s, st.albedo0, (const float4*)st.rast, (const float4*)st.vclip, (const int3*)f,
-                           (const EdgeSlot*)aa_topology, edge_table_size(T) - 1, sc.dalbedo_aa, sc.dcov, V, H, W, sc.dalbedo0, d_v ? sc.dpos_aa : nullptr);
+                           (const EdgeSlot*)aa_topology, edge_table_size(T) - 1, sc.dalbedo_aa, sc.dcov, V, H, W, sc.dalbedo0, d_v ? sc.dpos_aa : nullptr, st.hit);
         hipLaunchKernelGGL(k_view_sigmoid_bwd, dim3(c3d_cdiv(P * 3, 256)), dim3(256), 0, s, st.albedo0, sc.dalbedo0, P * 3);
     }
     if ((rc = c3d_mesh_texture_bwd(raw_albedo, 1, st.texc, sc.dalbedo0, 1, H, W, d->Ht, d->Wt, 3, 1, 0, d_raw_albedo, sc.duv, stream))) return rc;
