@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--render-path", choices=["step", "fused", "accessor", "boundary"], default="step",
                     help="step: c3d_gs_train_views_raw, all views of the step forward+loss+backward in one sync-free library call (product default for training); fused: GaussianSplattingRenderer.render with activations folded into the kernels (product default); accessor: the same "
                          "API through the reference's op-by-op accessors; boundary: bare diff_gaussian_rasterization call on pre-activated leaves")
+    ap.add_argument("--defer-status", choices=["on", "off"], default="on",
+                    help="fused step: examine a step's overflow / fault words when the next step starts instead of waiting for them (what the trainer does; the last "
+                         "step is examined before the timed region ends).  off: one host synchronisation per step")
     ap.add_argument("--workload", choices=["gs", "mesh"], default="gs", help="gs = BASELINE configs 2-4 (the metric); mesh = config 5 (DiffRastMesh)")
     ap.add_argument("--loss", choices=["auto", "l1alpha", "full", "full-torch"], default="auto",
                     help="pixel loss of the step path: l1alpha = 0.8 L1 + 3 MSE(alpha) inside c3d_gs_train_views_raw; full = BASELINE config 3's loss, the reference's default "
@@ -321,6 +324,8 @@ def main():
     if a.render_path == "step" and a.mode != "fwd":
         from c3d_hip.gs_step import FusedViewStep
         fused_step = FusedViewStep(N, H, W, dev, lanes=a.lanes, views=len(settings))
+        fused_step.time_events = True
+        fused_step.defer_status = a.defer_status == "on"
         from c3d_hip.parallel import FlatGrads
         flat_grads = FlatGrads(plist)        # one buffer: the kernels write into what the collective sends
         step_grads = flat_grads.views
@@ -390,6 +395,8 @@ def main():
                 q.grad = None
 
     def sync():
+        if fused_step is not None:
+            fused_step.finish()              # a deferred step's status words: examined INSIDE the timed region
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
@@ -544,6 +551,8 @@ def main():
                        "loss": (None if a.mode == "fwd" else ("0.8 L1 + 3 MSE(alpha) + 0.2 (1 - MS-SSIM), masked (BASELINE config 3)%s" % (", MS-SSIM by torch ops" if ms_ssim is not None else ", fused HIP")
                                                                 if loss_kind != "l1alpha" and a.render_path == "step" else "0.8 L1 + 3 MSE(alpha)")), "view_lanes": (a.lanes if a.render_path == "step" else 1),
                        "host_enqueue_ms_per_step": (round(fused_step.last_host_ms, 3) if fused_step is not None else None),
+                       "defer_status": (fused_step.defer_status if fused_step is not None else None),
+                       "gpu_span_ms_last_step": (round(getattr(fused_step, "last_gpu_ms", 0.0), 3) if fused_step is not None else None),
                        "n_visible": n_vis, "tile_splat_pairs": D},
             "roofline": roof, "roofline_chain": chain, "cpu_baseline": cpu, "kernels": kern, "kernels_concurrent_avg_ms": kern_conc,
             "code_digest": code_digest(),

@@ -97,6 +97,7 @@ class GaussianSplatting3D:
         self.params = [g._xyz, g._features_dc, g._features_rest, g._opacity, g._scaling, g._rotation]
         parallel.broadcast_parameters(self.params, src=0, group=process_group)
         self.use_fused_step, self._step = True, None       # the fused rasterizer step serves every loss configuration (see _can_fuse)
+        self.defer_step_status = True                        # fused step: no host synchronisation per step once the pair capacity is fitted (c3d_hip/gs_step.py)
         self.image_loss_in_torch = False                     # True: fused forward / backward halves with the image loss (incl. MS-SSIM) as torch ops in between
 
     def prepare_training(self, reference_images, reference_masks, reference_orbit_camera_poses, reference_orbit_camera_fovy):
@@ -216,6 +217,7 @@ class GaussianSplatting3D:
         g = self.renderer.gaussians
         if self._step is None:
             self._step = FusedViewStep(self.params[0].shape[0], H, W, self.device)
+            self._step.defer_status = self.defer_step_status
             self._flat_grads = parallel.FlatGrads(self.params)       # the kernels write into what the collective sends
             self._step_grads = self._flat_grads.views
         views = []
@@ -277,6 +279,8 @@ class GaussianSplatting3D:
             self.training_step(step, idx)
             if progress is not None:
                 progress(step + 1)
+        if self._step is not None:
+            self._step.finish()
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
         self.need_update = True

@@ -535,6 +535,49 @@ def test_fused_multi_view_step_matches_autograd(lanes):
 
 
 @pytest.mark.parametrize("lambda_ssim,offsets", [(0.0, False), (0.2, False), (0.2, True)])
+def test_fused_step_deferred_status():
+    """defer_status: a fitted step does not wait for its own overflow / fault words; the next run() (or finish()) examines them.  Same gradients as the
+    synchronous mode; an overflow between two steps is noticed one step late, loudly, and the capacity regrown."""
+    import warnings
+    from MVs_Algorithms.GaussianSplatting.main_3DGS_renderer import GaussianSplattingRenderer
+    from c3d_hip.gs_step import FusedViewStep
+    raw = S.make_cloud(30000, seed=5, log_scale_mean=np.log(0.015), activated=False)
+    W, H = 192, 128
+    r = GaussianSplattingRenderer(sh_degree=3, device="cuda")
+    r.initialize({"xyz": raw["means3D"], "features": raw["shs"], "scaling_raw": raw["scales"], "rotation_raw": raw["rotations"], "opacity_raw": raw["opacities"]})
+    g = r.gaussians
+    plist = [q.detach() for q in (g._xyz, g._features_dc, g._features_rest, g._opacity, g._scaling, g._rotation)]
+    rs = [hip_settings(S.camera_settings(W, H, 49.1, el, az, 2.2, bg=(1, 1, 1)), "cuda") for el, az in ((-20.0, 10.0), (15.0, 130.0), (40.0, -100.0))]
+    rng = np.random.default_rng(0)
+    tcs = [_dev(rng.uniform(size=(3, H, W)).astype(np.float32), torch.float32) for _ in rs]
+    tas = [_dev(rng.uniform(size=(1, H, W)).astype(np.float32), torch.float32) for _ in rs]
+    outs = []
+    for defer in (False, True):
+        step = FusedViewStep(30000, H, W, "cuda", lanes=2)
+        step.defer_status = defer
+        grads = [torch.empty_like(q) for q in plist]
+        losses = [step.run(rs, plist, grads, tcs, tas, None, w_l1=0.8, w_alpha_mse=3.0, scale=1 / 3, accumulate=False) for _ in range(3)]
+        assert (step._pending is not None) == defer               # the first run fits the capacity synchronously, later ones are deferred
+        step.finish()
+        assert step._pending is None
+        outs.append(([l.item() for l in losses], [q.clone() for q in grads]))
+    assert outs[0][0] == outs[1][0]
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert torch.equal(a, b)
+    # overflow noticed one step late
+    step.capacity = 2000
+    step._alloc()
+    step.run(rs, plist, grads, tcs, tas, None, w_l1=0.8, w_alpha_mse=3.0, scale=1 / 3, accumulate=False)
+    with warnings.catch_warnings(record=True) as wlist:
+        warnings.simplefilter("always")
+        step.finish()
+    assert any("incomplete" in str(w.message) for w in wlist) and step.capacity > 2000
+    step.run(rs, plist, grads, tcs, tas, None, w_l1=0.8, w_alpha_mse=3.0, scale=1 / 3, accumulate=False)
+    step.finish()
+    for a, b in zip(grads, outs[0][1]):
+        assert torch.equal(a, b)
+
+
 def test_trainer_fused_step_equals_autograd_step(lambda_ssim, offsets):
     """GaussianSplatting3D.training_step with the reference's node defaults -- lambda_ssim 0.2, invert_bg_prob 0.5 (nodes.py:1177,1181) -- and
     without MS-SSIM: the fused library step and the per-view autograd path draw the same backgrounds, produce the same loss and leave the
