@@ -36,6 +36,7 @@ class FusedViewStep:
         self.defer_status = False
         self._pending = None
         self._pinned = None
+        self._flip = 0
         self._alloc()
 
     def _alloc(self):
@@ -57,8 +58,9 @@ class FusedViewStep:
         the end, to read the overflow flag."""
         lib = _h.lib()
         V = len(raster_settings)
-        self.finish()                    # status of a deferred previous step, before anything of this one is enqueued
-        if V == 0:                       # a rank without views this step still owns well-defined gradients
+        prev, self._pending = self._pending, None      # a deferred previous step: examined AFTER this one is enqueued, so the GPU never waits for the host
+        if V == 0:
+            self._examine(prev)                       # a rank without views this step still owns well-defined gradients
             if not accumulate:
                 for g in grads:
                     g.zero_()
@@ -89,13 +91,23 @@ class FusedViewStep:
                 ev1.record(torch.cuda.current_stream(self.device))
             if self.defer_status and self._fitted and not accumulate:
                 if self._pinned is None:
-                    self._pinned = torch.empty((2,), dtype=torch.int32).pin_memory()
-                self._pinned.copy_(self.status, non_blocking=True)
+                    self._pinned = [torch.empty((2,), dtype=torch.int32).pin_memory() for _ in range(2)]
+                self._flip ^= 1
+                pin = self._pinned[self._flip]
+                pin.copy_(self.status, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream(self.device))
-                self._pending = (ev, (ev0, ev1) if self.time_events else None)
+                self._pending = (ev, (ev0, ev1) if self.time_events else None, pin)
                 self._last = (self.workspace, self.capacity)
-                return self.loss.clone()
+                out = self.loss.clone()
+                if prev is not None and not self._examine(prev):
+                    prev = None
+                    self._pending = None
+                    continue             # the previous step had overflowed (capacity regrown): this one certainly did too -- redo it, synchronously
+                return out
+            if prev is not None:
+                self._examine(prev)
+                prev = None
             st = self.status.tolist()       # the single host sync of the step
             if self.time_events:
                 self.last_gpu_ms = ev0.elapsed_time(ev1)                  # GPU span of the library call: wall time beyond it is host-side bubble
@@ -117,15 +129,19 @@ class FusedViewStep:
         raise RuntimeError("c3d FusedViewStep: pair capacity still exceeded after %d retries" % max_retries)
 
     def finish(self):
-        """examine the status of a deferred run() (see defer_status); called by the next run() and by whoever needs the step to be known-good"""
-        if self._pending is None:
-            return
-        ev, tev = self._pending
-        self._pending = None
+        """examine the status of a deferred run() (see defer_status): whoever needs the last step to be known-good calls this"""
+        prev, self._pending = self._pending, None
+        self._examine(prev)
+
+    def _examine(self, pending):
+        """-> True when the deferred step was clean (or there was none)"""
+        if pending is None:
+            return True
+        ev, tev, pin = pending
         ev.synchronize()
         if tev is not None:
             self.last_gpu_ms = tev[0].elapsed_time(tev[1])
-        st = self._pinned.tolist()
+        st = pin.tolist()
         self._raise_on_fault(st)
         if st[0] != 0:
             import warnings
@@ -134,6 +150,8 @@ class FusedViewStep:
             self._alloc()
             warnings.warn("c3d FusedViewStep: the previous step needed %d (tile, splat) pairs, more than the fitted capacity; its gradient was incomplete "
                           "(noticed one step late because defer_status is on); capacity regrown to %d" % (seen, self.capacity), RuntimeWarning)
+            return False
+        return True
 
     # ---- the step split at the image --------------------------------------------------------------------------------------------------------
     def _raise_on_fault(self, st):
