@@ -560,7 +560,7 @@ def test_fused_step_deferred_status():
         step.finish()
         assert step._pending is None
         outs.append(([l.item() for l in losses], [q.clone() for q in grads]))
-    assert outs[0][0] == outs[1][0]
+    assert np.allclose(outs[0][0], outs[1][0], rtol=1e-6)            # the loss VALUE is summed with float atomics (one per workgroup): last-bit differences
     for a, b in zip(outs[0][1], outs[1][1]):
         assert torch.equal(a, b)
     # overflow noticed one step late: by the next run() (which then redoes itself with the regrown capacity) ...
