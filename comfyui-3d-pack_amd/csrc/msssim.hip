@@ -75,29 +75,47 @@ __global__ void __launch_bounds__(256) k_ms_fwd(const float* __restrict__ X, con
         sx[r][c] = x; sy[r][c] = y;
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < MS_IN * MS_T; e += 256) {
-        const int r = e >> 5, c = e & 31;
-        float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+    // horizontal pass, four adjacent outputs per item: the 14 inputs of x and y they share are read once (7 LDS reads per output instead of 22)
+    for (int e = threadIdx.x; e < MS_IN * (MS_T / 4); e += 256) {
+        const int r = e >> 3, c0 = (e & 7) * 4;
+        float xv[14], yv[14];
 #pragma unroll
-        for (int k = 0; k < 2 * MS_R + 1; k++) {
-            const float x = sx[r][c + k], y = sy[r][c + k], w = win.w[k];
-            const float wx = w * x, wy = w * y;
-            m1 += wx; m2 += wy; e11 += wx * x; e22 += wy * y; e12 += wx * y;
+        for (int k = 0; k < 14; k++) { xv[k] = sx[r][c0 + k]; yv[k] = sy[r][c0 + k]; }
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+            float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 2 * MS_R + 1; k++) {
+                const float x = xv[o + k], y = yv[o + k], w = win.w[k];
+                const float wx = w * x, wy = w * y;
+                m1 += wx; m2 += wy; e11 += wx * x; e22 += wy * y; e12 += wx * y;
+            }
+            hh[0][r][c0 + o] = m1; hh[1][r][c0 + o] = m2; hh[2][r][c0 + o] = e11; hh[3][r][c0 + o] = e22; hh[4][r][c0 + o] = e12;
         }
-        hh[0][r][c] = m1; hh[1][r][c] = m2; hh[2][r][c] = e11; hh[3][r][c] = e22; hh[4][r][c] = e12;
     }
     __syncthreads();
-    const int c = threadIdx.x & 31;
+    // vertical pass, four vertically adjacent outputs per lane: 14 rows of the intermediate per quantity for 4 outputs (17.5 reads per output instead of 55)
+    const int c = threadIdx.x & 31, r0 = (threadIdx.x >> 5) * 4;
+    float acc[4][5];
+#pragma unroll
+    for (int o = 0; o < 4; o++)
+#pragma unroll
+        for (int q = 0; q < 5; q++) acc[o][q] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 5; q++) {
+        float col[14];
+#pragma unroll
+        for (int k = 0; k < 14; k++) col[k] = hh[q][r0 + k][c];
+#pragma unroll
+        for (int o = 0; o < 4; o++)
+#pragma unroll
+            for (int k = 0; k < 2 * MS_R + 1; k++) acc[o][q] += win.w[k] * col[o + k];
+    }
     float local = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const int r = (threadIdx.x >> 5) + 8 * j;
-        float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
-#pragma unroll
-        for (int k = 0; k < 2 * MS_R + 1; k++) {
-            const float w = win.w[k];
-            m1 += w * hh[0][r + k][c]; m2 += w * hh[1][r + k][c]; e11 += w * hh[2][r + k][c]; e22 += w * hh[3][r + k][c]; e12 += w * hh[4][r + k][c];
-        }
+        const int r = r0 + j;
+        const float m1 = acc[j][0], m2 = acc[j][1], e11 = acc[j][2], e22 = acc[j][3], e12 = acc[j][4];
         const int vy = oy + r, vx = ox + c;
         if (vy < lv.Hv && vx < lv.Wv) {
             const float s1 = e11 - m1 * m1, s2 = e22 - m2 * m2, s12 = e12 - m1 * m2;
@@ -178,31 +196,45 @@ __global__ void __launch_bounds__(256) k_ms_bwd(const float* __restrict__ X, con
         sm[0][r][c] = a; sm[1][r][c] = b; sm[2][r][c] = cc;
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < MS_IN * MS_T; e += 256) {
-        const int r = e >> 5, c = e & 31;
-        float fa = 0.f, fb = 0.f, fc = 0.f;
+    for (int e = threadIdx.x; e < MS_IN * (MS_T / 4); e += 256) {      // horizontal, four adjacent outputs per item
+        const int r = e >> 3, c0 = (e & 7) * 4;
 #pragma unroll
-        for (int k = 0; k < 2 * MS_R + 1; k++) {
-            const float w = win.w[k];
-            fa += w * sm[0][r][c + k]; fb += w * sm[1][r][c + k]; fc += w * sm[2][r][c + k];
+        for (int q = 0; q < 3; q++) {
+            float v[14];
+#pragma unroll
+            for (int k = 0; k < 14; k++) v[k] = sm[q][r][c0 + k];
+#pragma unroll
+            for (int o = 0; o < 4; o++) {
+                float f = 0.f;
+#pragma unroll
+                for (int k = 0; k < 2 * MS_R + 1; k++) f += win.w[k] * v[o + k];
+                hh[q][r][c0 + o] = f;
+            }
         }
-        hh[0][r][c] = fa; hh[1][r][c] = fb; hh[2][r][c] = fc;
     }
     __syncthreads();
-    const int c = threadIdx.x & 31;
+    const int c = threadIdx.x & 31, r0 = (threadIdx.x >> 5) * 4;     // vertical, four vertically adjacent outputs per lane
+    float acc[4][3];
+#pragma unroll
+    for (int o = 0; o < 4; o++) { acc[o][0] = 0.f; acc[o][1] = 0.f; acc[o][2] = 0.f; }
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        float col[14];
+#pragma unroll
+        for (int k = 0; k < 14; k++) col[k] = hh[q][r0 + k][c];
+#pragma unroll
+        for (int o = 0; o < 4; o++)
+#pragma unroll
+            for (int k = 0; k < 2 * MS_R + 1; k++) acc[o][q] += win.w[k] * col[o + k];
+    }
     const float gl = g[plane];
     const size_t HW = (size_t)lv.H * lv.W;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const int r = (threadIdx.x >> 5) + 8 * j;
+        const int r = r0 + j;
         const int qy = oy + r, qx = ox + c;
         if (qy >= lv.H || qx >= lv.W) continue;
-        float fa = 0.f, fb = 0.f, fc = 0.f;
-#pragma unroll
-        for (int k = 0; k < 2 * MS_R + 1; k++) {
-            const float w = win.w[k];
-            fa += w * hh[0][r + k][c]; fb += w * hh[1][r + k][c]; fc += w * hh[2][r + k][c];
-        }
+        const float fa = acc[j][0], fb = acc[j][1], fc = acc[j][2];
         float x, y;
         const size_t off = (size_t)qy * lv.W + qx;
         ms_load<L0>(X, Y, mask, clamp_y, C, plane, HW, off, x, y);
