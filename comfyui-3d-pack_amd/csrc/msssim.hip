@@ -67,12 +67,22 @@ __global__ void __launch_bounds__(256) k_ms_fwd(const float* __restrict__ X, con
     __shared__ float red[4];
     const int plane = blockIdx.z, ox = blockIdx.x * MS_T, oy = blockIdx.y * MS_T;
     const size_t HW = (size_t)lv.H * lv.W;
-    for (int e = threadIdx.x; e < MS_IN * MS_IN; e += 256) {
-        const int r = e / MS_IN, c = e - r * MS_IN;
-        const int iy = oy + r, ix = ox + c;
-        float x = 0.f, y = 0.f;
-        if (iy < lv.H && ix < lv.W) ms_load<L0>(X, Y, mask, clamp_y, C, plane, HW, (size_t)iy * lv.W + ix, x, y);
-        sx[r][c] = x; sy[r][c] = y;
+    {   // all of a lane's loads are issued before the first LDS store (an un-unrolled loop waits for each load in turn: 7 memory latencies per workgroup)
+        constexpr int NL = (MS_IN * MS_IN + 255) / 256;
+        float xs_[NL], ys_[NL];
+#pragma unroll
+        for (int i = 0; i < NL; i++) {
+            const int e = threadIdx.x + 256 * i;
+            const int r = e / MS_IN, c = e - r * MS_IN;
+            const int iy = oy + r, ix = ox + c;
+            xs_[i] = 0.f; ys_[i] = 0.f;
+            if (e < MS_IN * MS_IN && iy < lv.H && ix < lv.W) ms_load<L0>(X, Y, mask, clamp_y, C, plane, HW, (size_t)iy * lv.W + ix, xs_[i], ys_[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < NL; i++) {
+            const int e = threadIdx.x + 256 * i;
+            if (e < MS_IN * MS_IN) { const int r = e / MS_IN, c = e - r * MS_IN; sx[r][c] = xs_[i]; sy[r][c] = ys_[i]; }
+        }
     }
     __syncthreads();
     // horizontal pass, four adjacent outputs per item: the 14 inputs of x and y they share are read once (7 LDS reads per output instead of 22)
@@ -185,15 +195,25 @@ __global__ void __launch_bounds__(256) k_ms_bwd(const float* __restrict__ X, con
     __shared__ float hh[3][MS_IN][MS_T + 1];
     const int plane = blockIdx.z, ox = blockIdx.x * MS_T, oy = blockIdx.y * MS_T;
     // d in(q) = sum_k w[k] M(q - 10 + k): LDS row 0 <-> map row oy - 10
-    for (int e = threadIdx.x; e < MS_IN * MS_IN; e += 256) {
-        const int r = e / MS_IN, c = e - r * MS_IN;
-        const int uy = oy - 2 * MS_R + r, ux = ox - 2 * MS_R + c;
-        float a = 0.f, b = 0.f, cc = 0.f;
-        if (uy >= 0 && uy < lv.Hv && ux >= 0 && ux < lv.Wv) {
-            const size_t o = ((size_t)plane * lv.Hv + uy) * lv.Wv + ux;
-            a = mapA[o]; b = mapB[o]; cc = mapC[o];
+    {   // loads first, LDS stores after (see k_ms_fwd)
+        constexpr int NL = (MS_IN * MS_IN + 255) / 256;
+        float a_[NL], b_[NL], c_[NL];
+#pragma unroll
+        for (int i = 0; i < NL; i++) {
+            const int e = threadIdx.x + 256 * i;
+            const int r = e / MS_IN, c = e - r * MS_IN;
+            const int uy = oy - 2 * MS_R + r, ux = ox - 2 * MS_R + c;
+            a_[i] = 0.f; b_[i] = 0.f; c_[i] = 0.f;
+            if (e < MS_IN * MS_IN && uy >= 0 && uy < lv.Hv && ux >= 0 && ux < lv.Wv) {
+                const size_t o = ((size_t)plane * lv.Hv + uy) * lv.Wv + ux;
+                a_[i] = mapA[o]; b_[i] = mapB[o]; c_[i] = mapC[o];
+            }
         }
-        sm[0][r][c] = a; sm[1][r][c] = b; sm[2][r][c] = cc;
+#pragma unroll
+        for (int i = 0; i < NL; i++) {
+            const int e = threadIdx.x + 256 * i;
+            if (e < MS_IN * MS_IN) { const int r = e / MS_IN, c = e - r * MS_IN; sm[0][r][c] = a_[i]; sm[1][r][c] = b_[i]; sm[2][r][c] = c_[i]; }
+        }
     }
     __syncthreads();
     for (int e = threadIdx.x; e < MS_IN * (MS_T / 4); e += 256) {      // horizontal, four adjacent outputs per item
