@@ -179,7 +179,7 @@ int c3d_gs_forward_render(const c3d_gs_settings* st, int32_t N, int32_t M, const
     if (num_rendered > 0 && (!geom_buffer || !radii)) { c3d_set_error("c3d_gs_forward_render: NULL geometry"); return -1; }
     if ((rc = binning_back(p, g, b, radii, num_rendered, 0xFFFFFFFFu, nullptr, nullptr, s, &res))) return rc;
     C3dProfScope ps(C3D_P_COMPOSITE_FWD, s);
-    return gs_launch_composite_fwd(p, g, b, res, im, out_color, out_depth, out_alpha, s);
+    return gs_launch_composite_fwd(p, g, b, res, im, out_color, out_depth, out_alpha, true, s);   // a backward call may follow: record the blended (quadrant, splat) pairs
 }
 
 int c3d_gs_backward(const c3d_gs_settings* st, int32_t N, int32_t M, const float* means3D, const float* shs,
@@ -333,14 +333,14 @@ struct Lanes {
 // (g.meta[0]) and every launch that depends on it is sized for the pair capacity.
 static int step_view_forward(const GsParams& p, const float* means3D, const float* f_dc, const float* f_rest, const float* opacity_raw, const float* scaling_raw,
                              const float* rotation_raw, GsGeom& g, GsBinning& b, GsImage& im, int* radii, uint32_t cap, uint32_t* status, float* color, float* depth,
-                             float* alpha, hipStream_t s, int* res_out) {
+                             float* alpha, bool record_activity, hipStream_t s, int* res_out) {
     int rc, res = 0;
     { C3dProfScope ps(C3D_P_PREPROCESS, s);
       if ((rc = gs_launch_preprocess_raw(p, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, g, radii, s))) return rc; }
     if ((rc = binning_front(g, p.N, cap, status, s))) return rc;
     if ((rc = binning_back(p, g, b, radii, (long long)cap, cap, (const uint32_t*)g.meta, status, s, &res))) return rc;
     { C3dProfScope ps(C3D_P_COMPOSITE_FWD, s);
-      if ((rc = gs_launch_composite_fwd(p, g, b, res, im, color, depth, alpha, s))) return rc; }
+      if ((rc = gs_launch_composite_fwd(p, g, b, res, im, color, depth, alpha, record_activity, s))) return rc; }
     *res_out = res;
     return 0;
 }
@@ -417,7 +417,7 @@ int c3d_gs_train_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, c
         GsImage im; gs_carve_image(w.image, p.W, p.H, im);
         int rc = 0, res = 0;
         do {
-            if ((rc = step_view_forward(p, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, g, b, im, w.radii, cap, status, w.color, w.depth, w.alpha, s, &res))) break;
+            if ((rc = step_view_forward(p, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, g, b, im, w.radii, cap, status, w.color, w.depth, w.alpha, true, s, &res))) break;
             // pixel loss and its gradient
             { C3dProfScope ps(C3D_P_OTHER, s);
               if ((rc = gs_launch_loss_grad(w.color, w.alpha, target_color[v], target_alpha ? target_alpha[v] : nullptr, color_mask ? color_mask[v] : nullptr, (long long)p.W * p.H, loss->w_l1,
@@ -467,7 +467,7 @@ static int views_forward(const char* who, const c3d_gs_settings* views, int32_t 
         int res = 0;
         int* radii = (!keep_state && out_radii && out_radii[v]) ? out_radii[v] : w.radii;      // kept state: the backward pass reads the slice's copy
         float* depth = (out_depth && out_depth[v]) ? out_depth[v] : w.depth;
-        rc_all = step_view_forward(p, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, g, b, im, radii, cap, status, out_color[v], depth, out_alpha[v], ln.ls[lane], &res);
+        rc_all = step_view_forward(p, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, g, b, im, radii, cap, status, out_color[v], depth, out_alpha[v], keep_state, ln.ls[lane], &res);
         if (!rc_all && keep_state && out_radii && out_radii[v] &&
             hipMemcpyAsync(out_radii[v], w.radii, sizeof(int) * (size_t)N, hipMemcpyDeviceToDevice, ln.ls[lane]) != hipSuccess) {
             c3d_set_error("%s: radii copy failed", who); rc_all = -1;       // no early return: the lanes must still be joined

@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
                                                         const float4* __restrict__ rec2, const float* __restrict__ final_T,
                                                         const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor,
                                                         const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha_px,
-                                                        float4* __restrict__ pairgrad, uint8_t* __restrict__ pvalid, uint32_t cap, int sh) {
+                                                        const uint8_t* __restrict__ pact, float4* __restrict__ pairgrad, uint8_t* __restrict__ pvalid, uint32_t cap, int sh) {
     __shared__ float4 s0[BWD_ROUND];
     __shared__ float4 s1[BWD_ROUND];
     __shared__ float4 s2[BWD_ROUND];
@@ -118,7 +118,6 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
     __shared__ uint32_t smask[BWD_ROUND];
     __shared__ float acc[4][GS_PAIR_FLOATS][BWD_ROUND + 1];   // +1: the four row-writers of a wave (lanes 0,16,32,48) land in different banks
     __shared__ int s_maxlast;
-    __shared__ int s_wlast[4];
     int tx, ty;
     if (!gs_block_tile(blockIdx.x, p.gx, p.gy, tx, ty, sh)) return;
     const int tile = ty * p.gx + tx;
@@ -142,60 +141,41 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
     const float bg_dot = p.bg[0] * dLp0 + p.bg[1] * dLp1 + p.bg[2] * dLp2;
     float Rdot = T_final * bg_dot;
 
-    // list positions no pixel of the tile reached need no work beyond a zero record
+    // list positions no pixel of the tile reached need no work and get no record
     if (threadIdx.x == 0) s_maxlast = 0;
     __syncthreads();
     atomicMax(&s_maxlast, last);
     __syncthreads();
     const int upto = s_maxlast;   // positions [0, upto) matter
-    // ... and for this wave's quadrant only positions below the deepest of ITS pixels: a splat further back cannot have contributed to any of
-    // them, so the wave skips it without evaluating anything (the tile-level bound alone leaves ~half of the walked pairs without an active lane)
-    int wlast = last;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) wlast = max(wlast, __shfl_xor(wlast, o));
-    wlast = __builtin_amdgcn_readfirstlane(wlast);
-    if (lane == 0) s_wlast[wave] = wlast;
     // record index of the pair (this tile, Gaussian gid): the Gaussian's record base + row-major position of the tile inside its rect
     auto emit_index = [&](uint32_t gid) -> uint32_t {
         const uint4 ei = einfo[gid];
         const int ex0 = (int)(ei.y & 0xFFFFu), ey0 = (int)(ei.y >> 16), ex1 = (int)(ei.z & 0xFFFFu);
         return ei.w + (uint32_t)((ty - ey0) * (ex1 - ex0) + (tx - ex0));
     };
-    // List positions >= upto were reached by no pixel of the tile: their pairs get NO record.  `pvalid` (one byte per pair, cleared by the
-    // launcher) marks the pairs that do; the per-Gaussian pass skips the others.  Round 1 wrote a 48-byte zero record for every unreached
-    // pair and read it back in A8 -- at the BASELINE workload roughly every other pair.
+    // Which (quadrant, splat) pairs to walk comes from the forward pass (`pact`, k_composite_fwd<true>): exactly those that blended the splat
+    // into at least one pixel.  Everything else -- the geometric quadrant test, "behind the deepest pixel of the quadrant", occluded, below
+    // 1/255 on the pixel grid -- is implied, so a walked pair always has an active lane.  A pair no quadrant blended gets NO record: `pvalid`
+    // (one byte per pair, cleared by the launcher) marks the pairs that do; the per-Gaussian pass skips the others.
     for (int base = 0; base < upto; base += BWD_ROUND) {
         __syncthreads();
         const int n = min(BWD_ROUND, upto - base);
-        // the round's per-wave sums start at zero, so that a pair without an active lane costs the walk nothing but its test (each wave clears its
-        // own 12 rows: 12 LDS stores per round instead of three per inactive pair plus the branch around them)
-        if (lane < BWD_ROUND + 1) {
-#pragma unroll
-            for (int q = 0; q < GS_PAIR_FLOATS; q++) acc[wave][q][lane] = 0.f;
-        }
-#if BWD_ROUND > 63
-        for (int l = 64 + lane; l < BWD_ROUND + 1; l += 64) {
-#pragma unroll
-            for (int q = 0; q < GS_PAIR_FLOATS; q++) acc[wave][q][l] = 0.f;
-        }
-#endif
         gs_stage_round(point_list + rg.x + (upto - 1 - base), n, rec0, s0, s1, s2, -1);   // slot t <- list position upto-1-base-t
-        if ((int)threadIdx.x < n) se[threadIdx.x] = emit_index(point_list[rg.x + (upto - 1 - base - threadIdx.x)]);
+        if ((int)threadIdx.x < n) {
+            const uint32_t kpos = rg.x + (uint32_t)(upto - 1 - base - (int)threadIdx.x);
+            smask[threadIdx.x] = pact[kpos];
+            se[threadIdx.x] = emit_index(point_list[kpos]);   // unconditionally: the two dependent loads overlap the activity byte's
+        }
         __syncthreads();
         if ((int)threadIdx.x < n) {
-            const float4 a0 = s0[threadIdx.x], a1 = s1[threadIdx.x], a2 = s2[threadIdx.x];
-            smask[threadIdx.x] = gs_quadrant_mask(a0, a1, a2, X0, Y0);
+            const float4 a0 = s0[threadIdx.x];
             s0[threadIdx.x] = make_float4(a0.x, a0.y, GS_CONIC_HALF * a0.z, GS_CONIC_FULL * a0.w);   // conic pre-scaled as in the forward pass
-            s1[threadIdx.x].x = GS_CONIC_HALF * a1.x;
+            s1[threadIdx.x].x = GS_CONIC_HALF * s1[threadIdx.x].x;
         }
         __syncthreads();
         for (int c = 0; c < n; c += 64) {
             const int jj = c + lane;
             uint64_t m = __ballot(jj < n && ((smask[jj] >> wave) & 1u));
-            {   // list position of slot j is k = upto - 1 - base - j; keep k < wlast  <=>  j >= jmin
-                const int jmin = upto - base - wlast - c;
-                if (jmin > 0) m = jmin >= 64 ? 0ull : (m & (~0ull << jmin));
-            }
             while (m) {
                 const int bitpos = (int)__builtin_ctzll(m);
                 const int j = c + bitpos;
@@ -203,7 +183,7 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
                 const int k = upto - 1 - base - j;   // list position of this splat
                 const float4 a0 = s0[j], a1 = s1[j], a2 = s2[j];
                 const float dx = a0.x - pxf, dy = a0.y - pyf;
-                const float power = dx * (a0.z * dx + a0.w * dy) + (a1.x * dy) * dy;      // log2(e) * (-q/2)
+                const float power = gs_power(a0, a1.x, dx, dy);      // log2(e) * (-q/2)
                 const float G = __builtin_amdgcn_exp2f(power);
                 const float alpha = fminf(0.99f, a1.y * G);
                 // act = (k < last) && (power <= 0) && (alpha >= 1/255) as a wave mask in an SGPR pair: the compares are written as asm so that the
@@ -216,7 +196,7 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
                     asm("v_cmp_le_f32_e64 %0, %1, %2" : "=s"(c2) : "v"(1.f / 255.f), "v"(alpha));
                     am = c0 & c1 & c2;
                 }
-                if (am != 0ull) {   // wave-uniform
+                {   // no branch on am: it is non-zero for every recorded pair (and were it not, the sums below would come out as zeros)
                     float t0, t1, t2;
                     // dL/dalpha_k = T_k (c_k . dL) - [sum_{j behind k} (c_j . dL) alpha_j T_j + T_final bg . dL] / (1 - alpha_k)
                     // with (c . dL) taken over colour, depth and alpha channels; Rdot carries the bracket.  Inactive lanes run the
@@ -244,17 +224,16 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
         if ((int)threadIdx.x < n) {   // one record per (tile, splat): fixed-order sum over the waves that handled it
             const int j = threadIdx.x;
             const uint32_t mk = smask[j];
-            float r[GS_PAIR_FLOATS];
+            if (mk && se[j] < cap) {
+                float r[GS_PAIR_FLOATS];
 #pragma unroll
-            for (int q = 0; q < GS_PAIR_FLOATS; q++) r[q] = 0.f;
-            const int kj = upto - 1 - base - j;
+                for (int q = 0; q < GS_PAIR_FLOATS; q++) r[q] = 0.f;
 #pragma unroll
-            for (int w = 0; w < 4; w++)
-                if (((mk >> w) & 1u) && kj < s_wlast[w]) {   // waves that skipped the slot left nothing in acc
+                for (int w = 0; w < 4; w++)
+                    if ((mk >> w) & 1u) {   // the other waves left nothing in acc
 #pragma unroll
-                    for (int q = 0; q < GS_PAIR_FLOATS; q++) r[q] += acc[w][q][j];
-                }
-            if (se[j] < cap) {
+                        for (int q = 0; q < GS_PAIR_FLOATS; q++) r[q] += acc[w][q][j];
+                    }
                 float4* out = pairgrad + (size_t)se[j] * 3;
                 out[0] = make_float4(r[0], r[1], r[2], r[3]);
                 out[1] = make_float4(r[4], r[5], r[6], r[7]);
@@ -272,7 +251,7 @@ int gs_launch_composite_bwd(const GsParams& p, const GsGeom& g, const GsBinning&
     if (tiles == 0) return 0;
     C3D_CHECK(hipMemsetAsync(pvalid, 0, (size_t)(pairs > 0 ? pairs : 1), s));
     hipLaunchKernelGGL(k_composite_bwd, dim3(gs_block_count(p.gx, p.gy, gs_supertile_shift())), dim3(256), gs_lds_pad(true), s, p, b.ranges, b.tval[res], g.einfo, g.rec0, g.rec1, g.rec2,
-                       im.final_T, im.n_contrib, dL_dcolor, dL_ddepth, dL_dalpha, (float4*)pairgrad, pvalid, cap, gs_supertile_shift());
+                       im.final_T, im.n_contrib, dL_dcolor, dL_ddepth, dL_dalpha, gs_pair_activity(b, res), (float4*)pairgrad, pvalid, cap, gs_supertile_shift());
     C3D_LAUNCH_CHECK();
     return 0;
 }

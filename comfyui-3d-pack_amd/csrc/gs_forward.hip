@@ -197,15 +197,21 @@ int gs_launch_ranges(const GsBinning& b, int res, long long D, int tiles, hipStr
 // wave-uniform in the inner loop (LDS broadcast reads).
 // ------------------------------------------------------------------------------------------
 #define FWD_ROUND 256   // splats staged per round (128 measures the same within noise)
+// RECORD: the walk also notes, per list position, which of the four quadrants blended the splat into at least one pixel (`pact`, one byte
+// per (tile, splat) pair, bit w = wave w).  The backward pass walks exactly those (quadrant, splat) pairs: at the BASELINE workload half of
+// the pairs that pass the geometric quadrant test are blended nowhere (occluded, or below 1/255 on the pixel grid), and deciding that
+// again cost the backward kernel a sixth of its VALU time.  Inference launches use RECORD = false and are unchanged.
+template <bool RECORD>
 __global__ void __launch_bounds__(256) k_composite_fwd(GsParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                                                         const float4* __restrict__ rec0, const float4* __restrict__ rec1,
                                                         const float4* __restrict__ rec2, float* __restrict__ out_color,
                                                         float* __restrict__ out_depth, float* __restrict__ out_alpha,
-                                                        float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, int sh) {
+                                                        float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, uint8_t* __restrict__ pact, int sh) {
     __shared__ float4 s0[FWD_ROUND];
     __shared__ float4 s1[FWD_ROUND];
     __shared__ float4 s2[FWD_ROUND];
     __shared__ uint32_t smask[FWD_ROUND];
+    __shared__ uint32_t sact[RECORD ? FWD_ROUND : 1];   // byte w of sact[j]: wave w blended slot j
     int tx, ty;   // XCD-aware, load-balanced tile order (gs_block_tile).  Speed only, never correctness.
     if (!gs_block_tile(blockIdx.x, p.gx, p.gy, tx, ty, sh)) return;
     const int tile = ty * p.gx + tx;
@@ -236,6 +242,7 @@ __global__ void __launch_bounds__(256) k_composite_fwd(GsParams p, const uint2* 
             s0[threadIdx.x] = make_float4(a0.x, a0.y, GS_CONIC_HALF * a0.z, GS_CONIC_FULL * a0.w);
             s1[threadIdx.x].x = GS_CONIC_HALF * a1.x;
         }
+        if (RECORD) sact[threadIdx.x] = 0u;
         __syncthreads();
         for (int c = 0; c < n; c += 64) {
             const int jj = c + lane;
@@ -247,13 +254,14 @@ __global__ void __launch_bounds__(256) k_composite_fwd(GsParams p, const uint2* 
                 m = gs_clear_bit64(m, bitpos);
                 const float4 a0 = s0[j], a1 = s1[j];
                 const float dx = a0.x - pxf, dy = a0.y - pyf;
-                const float power = dx * (a0.z * dx + a0.w * dy) + (a1.x * dy) * dy;      // log2(e) * (-q/2): same sign as the exponent
+                const float power = gs_power(a0, a1.x, dx, dy);      // log2(e) * (-q/2): same sign as the exponent
                 const float alpha = fminf(0.99f, a1.y * __builtin_amdgcn_exp2f(power));
                 const bool ok = power <= 0.f && alpha >= 1.f / 255.f;
                 const float testT = T * (1.f - alpha);
                 const bool stop = ok && testT < 0.0001f;
                 pxf = stop ? GS_PARKED : pxf;
                 if (ok && !stop) {
+                    if (RECORD) ((uint8_t*)sact)[4 * j + wave] = 1;   // every blending lane stores the same byte: one LDS pass, no ballot
                     const float4 a2 = s2[j];
                     const float w = alpha * T;
                     C0 += a1.z * w; C1 += a1.w * w; C2 += a2.x * w;
@@ -261,6 +269,13 @@ __global__ void __launch_bounds__(256) k_composite_fwd(GsParams p, const uint2* 
                     T = testT;
                     last = (uint32_t)(base + j + 1);
                 }
+            }
+        }
+        if (RECORD) {
+            __syncthreads();
+            if ((int)threadIdx.x < n) {
+                const uint32_t a = sact[threadIdx.x];
+                pact[rg.x + base + threadIdx.x] = (uint8_t)((a & 1u) | ((a >> 7) & 2u) | ((a >> 14) & 4u) | ((a >> 21) & 8u));
             }
         }
     }
@@ -277,11 +292,15 @@ __global__ void __launch_bounds__(256) k_composite_fwd(GsParams p, const uint2* 
 }
 
 int gs_launch_composite_fwd(const GsParams& p, const GsGeom& g, const GsBinning& b, int res, GsImage& im,
-                            float* out_color, float* out_depth, float* out_alpha, hipStream_t s) {
+                            float* out_color, float* out_depth, float* out_alpha, bool record_activity, hipStream_t s) {
     const int tiles = p.gx * p.gy;
     if (tiles == 0) return 0;
-    hipLaunchKernelGGL(k_composite_fwd, dim3(gs_block_count(p.gx, p.gy, gs_supertile_shift())), dim3(256), gs_lds_pad(false), s, p, b.ranges, b.tval[res], g.rec0, g.rec1, g.rec2,
-                       out_color, out_depth, out_alpha, im.final_T, im.n_contrib, gs_supertile_shift());
+    if (record_activity)
+        hipLaunchKernelGGL(k_composite_fwd<true>, dim3(gs_block_count(p.gx, p.gy, gs_supertile_shift())), dim3(256), gs_lds_pad(false), s, p, b.ranges, b.tval[res], g.rec0, g.rec1, g.rec2,
+                           out_color, out_depth, out_alpha, im.final_T, im.n_contrib, gs_pair_activity(b, res), gs_supertile_shift());
+    else
+        hipLaunchKernelGGL(k_composite_fwd<false>, dim3(gs_block_count(p.gx, p.gy, gs_supertile_shift())), dim3(256), gs_lds_pad(false), s, p, b.ranges, b.tval[res], g.rec0, g.rec1, g.rec2,
+                           out_color, out_depth, out_alpha, im.final_T, im.n_contrib, (uint8_t*)nullptr, gs_supertile_shift());
     C3D_LAUNCH_CHECK();
     return 0;
 }

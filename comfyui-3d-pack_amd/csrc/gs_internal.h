@@ -97,6 +97,10 @@ static inline void gs_carve_binning(char* base, long long D, int tiles, GsBinnin
     b.bytes = off;
 }
 
+// One byte per sorted (tile, splat) pair, written by the recording forward compositing and read by the backward one: bit w = quadrant w blended
+// the splat.  Lives in the key buffer the tile sort did NOT finish in (dead once the ranges are found; 4 bytes per pair, one used).
+static inline uint8_t* gs_pair_activity(const GsBinning& b, int res) { return (uint8_t*)b.tkey[1 - res]; }
+
 struct GsImage {
     float* final_T;        // [H*W]
     uint32_t* n_contrib;   // [H*W]
@@ -144,7 +148,7 @@ int gs_launch_loss_grad(const float* color, const float* alpha, const float* tco
                         float scale, float* dcolor, float* dalpha, float* loss_out, hipStream_t s);
 int gs_launch_ranges(const GsBinning& b, int res, long long D, int tiles, hipStream_t s, const uint32_t* d_dev = nullptr);
 int gs_launch_composite_fwd(const GsParams& p, const GsGeom& g, const GsBinning& b, int res, GsImage& im,
-                            float* out_color, float* out_depth, float* out_alpha, hipStream_t s);
+                            float* out_color, float* out_depth, float* out_alpha, bool record_activity, hipStream_t s);
 int gs_launch_composite_bwd(const GsParams& p, const GsGeom& g, const GsBinning& b, int res, const GsImage& im,
                             const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
                             float* pairgrad /* [D][12] */, uint8_t* pvalid /* [D], cleared here */, long long pairs, hipStream_t s, uint32_t cap = 0xFFFFFFFFu);

@@ -227,6 +227,12 @@ __device__ __forceinline__ float quad_form_min_on_rect(float A, float B, float C
     }
     return best;
 }
+// Exponent of a splat at a pixel, scaled by log2(e): a0 = (.., .., -log2e/2 A, -log2e B), c = -log2e/2 C, (dx, dy) = splat centre - pixel.
+// ONE spelling with the contractions written out, shared by the forward and the backward compositing kernels: the backward pass walks the
+// (quadrant, splat) pairs the forward pass recorded as blended, so both must reach bit-identical alpha decisions.
+__device__ __forceinline__ float gs_power(const float4 a0, float c, float dx, float dy) {
+    return __builtin_fmaf(dx, __builtin_fmaf(a0.z, dx, a0.w * dy), (c * dy) * dy);
+}
 __device__ __forceinline__ uint32_t gs_quadrant_mask(const float4 a0, const float4 a1, const float4 a2, int X0, int Y0) {
     // a0 = (px, py, A, B)  a1 = (C, opacity, ..)  a2 = (.., .., ex, ey)
     const float xl = a0.x - a2.z, xh = a0.x + a2.z, yl = a0.y - a2.w, yh = a0.y + a2.w;
