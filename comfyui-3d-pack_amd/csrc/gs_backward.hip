@@ -656,25 +656,45 @@ __global__ void __launch_bounds__(256) k_bwd_views_geom(GsParams p, GsBwdViews v
     float c3[6];
     cov3d_from_scale_rot(sc, p.scale_modifier, q, c3);
     float dmean[3] = {0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dopac = 0.f;
+    // The walk over views is a chain of dependent gathers per lane (radius / record span -> valid bytes -> records -> splat record): the span of
+    // the NEXT view is fetched while this one is worked on, the valid bytes and the records of four pairs are in flight together, and a Gaussian
+    // that no pixel of the view blended (no valid record: roughly every other one at the BASELINE workload) skips the splat record, the two
+    // matrices and the whole geometric chain -- all its sums are zero.
+    int n_rad = vs.v[0].radii[idx];
+    uint32_t n_cnt = vs.v[0].tiles[idx], n_e0 = vs.v[0].rbase[idx];
     for (int v = 0; v < vs.V; v++) {
         const GsBwdView& vw = vs.v[v];
         float* d2 = vw.dmean2D + 3 * (size_t)idx;
         float* gc = vw.gcol + 3 * (size_t)idx;
-        if (vw.radii[idx] <= 0) { d2[0] = 0.f; d2[1] = 0.f; d2[2] = 0.f; gc[0] = 0.f; gc[1] = 0.f; gc[2] = 0.f; continue; }
+        const int rad = n_rad;
+        const uint32_t cnt = n_cnt, e0 = n_e0;
+        if (v + 1 < vs.V) { const GsBwdView& nx = vs.v[v + 1]; n_rad = nx.radii[idx]; n_cnt = nx.tiles[idx]; n_e0 = nx.rbase[idx]; }
         float pr[GS_PAIR_FLOATS];
 #pragma unroll
         for (int k = 0; k < GS_PAIR_FLOATS; k++) pr[k] = 0.f;
-        {
-            const uint32_t cnt = vw.tiles[idx];
-            const uint32_t e0 = vw.rbase[idx], e1 = min(e0 + cnt, cap);
-            for (uint32_t e = e0; e < e1; e++) {
-                if (!vw.pvalid[e]) continue;
-                const float4 v0 = vw.pairgrad[(size_t)e * 3], v1 = vw.pairgrad[(size_t)e * 3 + 1], v2 = vw.pairgrad[(size_t)e * 3 + 2];
-                pr[0] += v0.x; pr[1] += v0.y; pr[2] += v0.z; pr[3] += v0.w;
-                pr[4] += v1.x; pr[5] += v1.y; pr[6] += v1.z; pr[7] += v1.w;
-                pr[8] += v2.x; pr[10] += v2.z;
+        bool any = false;
+        if (rad > 0) {
+            const uint32_t e1 = min(e0 + cnt, cap);
+            for (uint32_t e = e0; e < e1; e += 4) {
+                uint8_t pv[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) pv[i] = (e + i < e1) ? vw.pvalid[e + i] : (uint8_t)0;
+                float4 r0[4], r1[4], r2[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    r0[i] = r1[i] = r2[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (pv[i]) { const float4* rp = vw.pairgrad + (size_t)(e + i) * 3; r0[i] = rp[0]; r1[i] = rp[1]; r2[i] = rp[2]; }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++) {   // adding the zeros of an invalid slot changes nothing (x + 0 = x; the sums start at +0)
+                    any = any || pv[i];
+                    pr[0] += r0[i].x; pr[1] += r0[i].y; pr[2] += r0[i].z; pr[3] += r0[i].w;
+                    pr[4] += r1[i].x; pr[5] += r1[i].y; pr[6] += r1[i].z; pr[7] += r1[i].w;
+                    pr[8] += r2[i].x; pr[10] += r2[i].z;
+                }
             }
         }
+        if (!any) { d2[0] = 0.f; d2[1] = 0.f; d2[2] = 0.f; gc[0] = 0.f; gc[1] = 0.f; gc[2] = 0.f; continue; }
         {   // colour gradient, zeroed where the forward clamped the channel at 0 (record rows: c0, c2, c1)
             const uint8_t cl = vw.clamped[idx];
             gc[0] = (cl & 1) ? 0.f : pr[0]; gc[1] = (cl & 2) ? 0.f : pr[2]; gc[2] = (cl & 4) ? 0.f : pr[1];
