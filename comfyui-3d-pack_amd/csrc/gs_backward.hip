@@ -638,8 +638,8 @@ __global__ void __launch_bounds__(256, 2) k_preprocess_bwd_views(GsParams p, GsB
 // k_preprocess_bwd_views holds 48 SH gradient sums per lane next to the whole geometric chain: 256 VGPRs, two waves per SIMD, and it streams
 // at ~2.3 TB/s.  Split: (G) the geometric chain, which needs no LDS and ~100 VGPRs, hands the masked colour gradient of every view over in a
 // 12 B/Gaussian/view array; (S) the SH part keeps the coefficients in LDS and only the 48 sums + a direction in registers.
-template <bool ACC>
-__global__ void __launch_bounds__(256) k_bwd_views_geom(GsParams p, GsBwdViews vs, const float* __restrict__ means3D, const float* __restrict__ scales,
+template <bool ACC, int CHUNK, int MINB>
+__global__ void __launch_bounds__(256, MINB) k_bwd_views_geom(GsParams p, GsBwdViews vs, const float* __restrict__ means3D, const float* __restrict__ scales,
                                                           const float* __restrict__ rotations, float* __restrict__ dL_dopacity, float* __restrict__ dL_dmeans3D,
                                                           float* __restrict__ dL_dscales, float* __restrict__ dL_drots, uint32_t cap) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -675,18 +675,18 @@ __global__ void __launch_bounds__(256) k_bwd_views_geom(GsParams p, GsBwdViews v
         bool any = false;
         if (rad > 0) {
             const uint32_t e1 = min(e0 + cnt, cap);
-            for (uint32_t e = e0; e < e1; e += 4) {
-                uint8_t pv[4];
+            for (uint32_t e = e0; e < e1; e += CHUNK) {
+                uint8_t pv[CHUNK];
 #pragma unroll
-                for (int i = 0; i < 4; i++) pv[i] = (e + i < e1) ? vw.pvalid[e + i] : (uint8_t)0;
-                float4 r0[4], r1[4], r2[4];
+                for (int i = 0; i < CHUNK; i++) pv[i] = (e + i < e1) ? vw.pvalid[e + i] : (uint8_t)0;
+                float4 r0[CHUNK], r1[CHUNK], r2[CHUNK];
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
+                for (int i = 0; i < CHUNK; i++) {
                     r0[i] = r1[i] = r2[i] = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (pv[i]) { const float4* rp = vw.pairgrad + (size_t)(e + i) * 3; r0[i] = rp[0]; r1[i] = rp[1]; r2[i] = rp[2]; }
                 }
 #pragma unroll
-                for (int i = 0; i < 4; i++) {   // adding the zeros of an invalid slot changes nothing (x + 0 = x; the sums start at +0)
+                for (int i = 0; i < CHUNK; i++) {   // adding the zeros of an invalid slot changes nothing (x + 0 = x; the sums start at +0)
                     any = any || pv[i];
                     pr[0] += r0[i].x; pr[1] += r0[i].y; pr[2] += r0[i].z; pr[3] += r0[i].w;
                     pr[4] += r1[i].x; pr[5] += r1[i].y; pr[6] += r1[i].z; pr[7] += r1[i].w;
@@ -802,13 +802,16 @@ int gs_launch_preprocess_bwd_views(const GsParams& p0, const GsBwdViews& views, 
         GsShViews sv;
         sv.V = views.V;
         for (int i = 0; i < views.V; i++) { sv.campos[i] = views.v[i].campos; sv.gcol[i] = views.v[i].gcol; }
+        // four pairs in flight, four workgroups per CU (128 VGPRs): eight in flight (160 VGPRs) and two or three (96, spilling) measure the same or worse
+#define GS_A8_GEOM(ACC_) hipLaunchKernelGGL((k_bwd_views_geom<ACC_, 4, 4>), grid, block, 0, s, p0, views, means3D, scaling_raw, rotation_raw, dL_dopacity_raw, dL_dmeans3D, dL_dscaling_raw, dL_drotation_raw, cap)
         if (accumulate) {
-            hipLaunchKernelGGL((k_bwd_views_geom<true>), grid, block, 0, s, p0, views, means3D, scaling_raw, rotation_raw, dL_dopacity_raw, dL_dmeans3D, dL_dscaling_raw, dL_drotation_raw, cap);
+            GS_A8_GEOM(true);
             hipLaunchKernelGGL((k_bwd_views_sh<true>), grid, block, lds, s, p0.N, p0.deg, sv, means3D, f_dc, f_rest, dL_dmeans3D, dL_df_dc, dL_df_rest);
         } else {
-            hipLaunchKernelGGL((k_bwd_views_geom<false>), grid, block, 0, s, p0, views, means3D, scaling_raw, rotation_raw, dL_dopacity_raw, dL_dmeans3D, dL_dscaling_raw, dL_drotation_raw, cap);
+            GS_A8_GEOM(false);
             hipLaunchKernelGGL((k_bwd_views_sh<false>), grid, block, lds, s, p0.N, p0.deg, sv, means3D, f_dc, f_rest, dL_dmeans3D, dL_df_dc, dL_df_rest);
         }
+#undef GS_A8_GEOM
         C3D_LAUNCH_CHECK();
         return 0;
     }
