@@ -331,17 +331,47 @@ struct Lanes {
 
 // forward of one view of the fused paths (A1-A6), everything on stream s, no host synchronisation: the pair count stays on the device
 // (g.meta[0]) and every launch that depends on it is sized for the pair capacity.
+// `projected`: A1 of this view has already run (step_preprocess_all)
 static int step_view_forward(const GsParams& p, const float* means3D, const float* f_dc, const float* f_rest, const float* opacity_raw, const float* scaling_raw,
                              const float* rotation_raw, GsGeom& g, GsBinning& b, GsImage& im, int* radii, uint32_t cap, uint32_t* status, float* color, float* depth,
-                             float* alpha, bool record_activity, hipStream_t s, int* res_out) {
+                             float* alpha, bool record_activity, hipStream_t s, int* res_out, bool projected = false) {
     int rc, res = 0;
-    { C3dProfScope ps(C3D_P_PREPROCESS, s);
-      if ((rc = gs_launch_preprocess_raw(p, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, g, radii, s))) return rc; }
+    if (!projected) {
+        C3dProfScope ps(C3D_P_PREPROCESS, s);
+        if ((rc = gs_launch_preprocess_raw(p, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, g, radii, s))) return rc;
+    }
     if ((rc = binning_front(g, p.N, cap, status, s))) return rc;
     if ((rc = binning_back(p, g, b, radii, (long long)cap, cap, (const uint32_t*)g.meta, status, s, &res))) return rc;
     { C3dProfScope ps(C3D_P_COMPOSITE_FWD, s);
       if ((rc = gs_launch_composite_fwd(p, g, b, res, im, color, depth, alpha, record_activity, s))) return rc; }
     *res_out = res;
+    return 0;
+}
+
+// A1 of every view of a step whose views keep their own workspace slice: the parameters are streamed once for up to GS_MAX_BWD_VIEWS views
+// (k_preprocess_views) instead of once per view.  Runs on the caller's stream BEFORE the lanes fork.  C3D_PRE_MULTIVIEW=0 keeps the per-view launches.
+static bool pre_multiview() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("C3D_PRE_MULTIVIEW"); v = e ? atoi(e) != 0 : 1; }
+    return v != 0;
+}
+static int step_preprocess_all(const c3d_gs_settings* views, int V, int N, size_t slice_bytes, void* workspace, long long pair_capacity, const float* means3D,
+                               const float* f_dc, const float* f_rest, const float* opacity_raw, const float* scaling_raw, const float* rotation_raw, hipStream_t s0) {
+    for (int v0 = 0; v0 < V; v0 += GS_MAX_BWD_VIEWS) {
+        const int nv = (V - v0) < GS_MAX_BWD_VIEWS ? (V - v0) : GS_MAX_BWD_VIEWS;
+        GsParams ps[GS_MAX_BWD_VIEWS];
+        GsGeom gs[GS_MAX_BWD_VIEWS];
+        int* radii[GS_MAX_BWD_VIEWS];
+        for (int i = 0; i < nv; i++) {
+            if (make_params(&views[v0 + i], N, 16, ps[i])) return -1;
+            StepWs w; carve_step((char*)workspace + (size_t)(v0 + i) * slice_bytes, N, ps[i].H, ps[i].W, pair_capacity, w);
+            gs_carve_geom(w.geom, N, gs[i]);
+            radii[i] = w.radii;
+        }
+        C3dProfScope sc(C3D_P_PREPROCESS, s0);
+        int rc;
+        if ((rc = gs_launch_preprocess_views(ps, nv, gs, radii, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, s0))) return rc;
+    }
     return 0;
 }
 
@@ -402,6 +432,8 @@ int c3d_gs_train_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, c
     if ((uintptr_t)f_rest % 16 || (uintptr_t)dL_df_rest % 16 || (uintptr_t)rotation_raw % 16 || (uintptr_t)dL_drotation_raw % 16) { c3d_set_error("c3d_gs_train_views_raw: f_rest / rotation tensors must be 16-byte aligned"); return -1; }
     const uint32_t cap = (uint32_t)pair_capacity;
     StepWs w0; carve_step(nullptr, N, views[0].image_height, views[0].image_width, pair_capacity, w0);
+    const bool projected = pre_multiview();
+    if (projected && step_preprocess_all(views, V, N, w0.bytes, workspace, pair_capacity, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, s0)) return -1;
     Lanes ln;
     if (ln.fork(s0, lanes, V)) return -1;
     int rc_all = 0;
@@ -417,7 +449,7 @@ int c3d_gs_train_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, c
         GsImage im; gs_carve_image(w.image, p.W, p.H, im);
         int rc = 0, res = 0;
         do {
-            if ((rc = step_view_forward(p, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, g, b, im, w.radii, cap, status, w.color, w.depth, w.alpha, true, s, &res))) break;
+            if ((rc = step_view_forward(p, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, g, b, im, w.radii, cap, status, w.color, w.depth, w.alpha, true, s, &res, projected))) break;
             // pixel loss and its gradient
             { C3dProfScope ps(C3D_P_OTHER, s);
               if ((rc = gs_launch_loss_grad(w.color, w.alpha, target_color[v], target_alpha ? target_alpha[v] : nullptr, color_mask ? color_mask[v] : nullptr, (long long)p.W * p.H, loss->w_l1,
@@ -452,6 +484,8 @@ static int views_forward(const char* who, const c3d_gs_settings* views, int32_t 
     if ((uintptr_t)f_rest % 16 || (uintptr_t)rotation_raw % 16) { c3d_set_error("%s: f_rest / rotation tensors must be 16-byte aligned", who); return -1; }
     const uint32_t cap = (uint32_t)pair_capacity;
     StepWs w0; carve_step(nullptr, N, views[0].image_height, views[0].image_width, pair_capacity, w0);
+    const bool projected = keep_state && pre_multiview();
+    if (projected && step_preprocess_all(views, V, N, w0.bytes, workspace, pair_capacity, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, s0)) return -1;
     Lanes ln;
     if (ln.fork(s0, lanes, V)) return -1;
     int rc_all = 0;
@@ -467,7 +501,7 @@ static int views_forward(const char* who, const c3d_gs_settings* views, int32_t 
         int res = 0;
         int* radii = (!keep_state && out_radii && out_radii[v]) ? out_radii[v] : w.radii;      // kept state: the backward pass reads the slice's copy
         float* depth = (out_depth && out_depth[v]) ? out_depth[v] : w.depth;
-        rc_all = step_view_forward(p, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, g, b, im, radii, cap, status, out_color[v], depth, out_alpha[v], keep_state, ln.ls[lane], &res);
+        rc_all = step_view_forward(p, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, g, b, im, radii, cap, status, out_color[v], depth, out_alpha[v], keep_state, ln.ls[lane], &res, projected);
         if (!rc_all && keep_state && out_radii && out_radii[v] &&
             hipMemcpyAsync(out_radii[v], w.radii, sizeof(int) * (size_t)N, hipMemcpyDeviceToDevice, ln.ls[lane]) != hipSuccess) {
             c3d_set_error("%s: radii copy failed", who); rc_all = -1;       // no early return: the lanes must still be joined

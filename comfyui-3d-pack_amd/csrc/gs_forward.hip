@@ -6,6 +6,81 @@
 #include "gs_math.h"
 
 // ------------------------------------------------------------------------------------------
+// A1, the part that depends on the view: projection, EWA covariance, radius, tile rect, SH colour of ONE Gaussian (mean m, 3D covariance c3,
+// opacity as given by `opacity()`, SH row `sh` with stride 3 per coefficient) -> the projected state arrays of that view.  Shared by the
+// per-view kernel and the all-views-of-a-step kernel, so the two cannot drift apart.
+// ------------------------------------------------------------------------------------------
+struct GsPreCam { const float* view; const float* proj; const float* campos; float tanfovx, tanfovy, focal_x, focal_y; };
+struct GsPreOut { float4* rec0; uint32_t* tiles; uint2* rect; uint32_t* key0; uint8_t* clamped; int* radii; };
+template <class OpacityFn>
+__device__ __forceinline__ void gs_project_one(int idx, const float3 m, const float c3[6], OpacityFn opacity, const float* __restrict__ sh, const float* __restrict__ colors_precomp,
+                                               const GsPreCam& cam, int W, int H, int gx, int gy, int deg, const GsPreOut& o) {
+    int rad = 0;
+    uint32_t nt = 0, key = 0xFFFFFFFFu;
+    do {   // `break` = culled: radius 0, no tiles, key 0xFFFFFFFF
+        const Mat16 V = load_mat16(cam.view), PJ = load_mat16(cam.proj);
+        const float3 pv = xform4x3(m, V);
+        if (pv.z <= 0.2f) break;
+        const float4 ph = xform4x4(m, PJ);
+        const float pw = 1.0f / (ph.w + 0.0000001f);
+        const float ppx = ph.x * pw, ppy = ph.y * pw;
+        float T2[2][3], ST0[3], ST1[3];
+        float3 t; bool xin, yin;
+        ewa_T2(m, V, cam.tanfovx, cam.tanfovy, cam.focal_x, cam.focal_y, T2, t, xin, yin);
+        sigma_T(c3, T2, ST0, ST1);
+        const float a = T2[0][0] * ST0[0] + T2[0][1] * ST0[1] + T2[0][2] * ST0[2] + 0.3f;
+        const float b = T2[0][0] * ST1[0] + T2[0][1] * ST1[1] + T2[0][2] * ST1[2];
+        const float c = T2[1][0] * ST1[0] + T2[1][1] * ST1[1] + T2[1][2] * ST1[2] + 0.3f;
+        const float det = a * c - b * b;
+        if (det == 0.0f) break;
+        const float di = 1.f / det;
+        const float mid = 0.5f * (a + c);
+        const float sq = sqrtf(fmaxf(0.1f, mid * mid - det));
+        const int r = (int)ceilf(3.f * sqrtf(fmaxf(mid + sq, mid - sq)));
+        const float px = ndc2pix(ppx, W), py = ndc2pix(ppy, H);
+        int x0, y0, x1, y1;
+        tile_rect(px, py, r, gx, gy, x0, y0, x1, y1);
+        if ((x1 - x0) * (y1 - y0) == 0) break;
+        // from here on the Gaussian counts as visible (radii > 0), exactly as in the dependency; the tile list
+        // it is emitted to is narrowed to the tiles where alpha can reach 1/255 (exact, see tile_rect_tight)
+        const float opac = opacity();
+        const float ex = alpha_extent(opac, a), ey = alpha_extent(opac, c);
+        if (ex >= 0.f) tile_rect_tight(px, py, r, ex, ey, gx, gy, x0, y0, x1, y1);
+        else { x1 = x0; y1 = y0; }
+        float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+        uint8_t cl = 0;
+        if (colors_precomp) {
+            r0 = colors_precomp[3 * idx]; r1 = colors_precomp[3 * idx + 1]; r2 = colors_precomp[3 * idx + 2];
+        } else {
+            float dx = m.x - cam.campos[0], dy = m.y - cam.campos[1], dz = m.z - cam.campos[2];
+            const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+            dx /= len; dy /= len; dz /= len;
+#define GS_FWD_TERM(k, Bk, dBx, dBy, dBz)                                                             \
+    {                                                                                                 \
+        const float b_ = (Bk);                                                                        \
+        r0 += b_ * sh[3 * (k)]; r1 += b_ * sh[3 * (k) + 1]; r2 += b_ * sh[3 * (k) + 2];               \
+    }
+            SH_FOREACH(deg, dx, dy, dz, GS_FWD_TERM);
+#undef GS_FWD_TERM
+            r0 += 0.5f; r1 += 0.5f; r2 += 0.5f;
+            if (r0 < 0.f) cl |= 1; if (r1 < 0.f) cl |= 2; if (r2 < 0.f) cl |= 4;
+            r0 = fmaxf(r0, 0.f); r1 = fmaxf(r1, 0.f); r2 = fmaxf(r2, 0.f);
+        }
+        o.rec0[GS_REC(idx)] = make_float4(px, py, c * di, -b * di);
+        o.rec0[GS_REC(idx) + 1] = make_float4(a * di, opac, r0, r1);
+        o.rec0[GS_REC(idx) + 2] = make_float4(r2, pv.z, ex, ey);
+        o.clamped[idx] = cl;
+        rad = r;
+        nt = (uint32_t)((x1 - x0) * (y1 - y0));
+        o.rect[idx] = make_uint2((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)x1 | ((uint32_t)y1 << 16));
+        key = nt ? __float_as_uint(pv.z) : 0xFFFFFFFFu;
+    } while (false);
+    o.radii[idx] = rad;
+    o.tiles[idx] = nt;
+    o.key0[idx] = key;
+}
+
+// ------------------------------------------------------------------------------------------
 // A1 preprocess: one lane per Gaussian.  Streams xyz/scale/rot/opacity/SH once, writes the 48-B
 // projected record, the depth-sort key and the tile count.  STAGED: the workgroup's 48 KiB of SH
 // coefficients are brought in with fully coalesced 16-B loads through LDS (sh_stage_in) instead of
@@ -28,19 +103,7 @@ __global__ void __launch_bounds__(256) k_preprocess(GsParams p, const float* __r
         __syncthreads();
     }
     if (idx >= p.N) return;
-    // defaults for a culled Gaussian
-    radii[idx] = 0;
-    g.tiles[idx] = 0;
-    g.key[0][idx] = 0xFFFFFFFFu;
-
-    const Mat16 V = load_mat16(p.view), PJ = load_mat16(p.proj);
     const float3 m = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
-    const float3 pv = xform4x3(m, V);
-    if (pv.z <= 0.2f) return;
-    const float4 ph = xform4x4(m, PJ);
-    const float pw = 1.0f / (ph.w + 0.0000001f);
-    const float ppx = ph.x * pw, ppy = ph.y * pw;
-
     float c3[6];
     if (cov3D_precomp) {
 #pragma unroll
@@ -55,61 +118,10 @@ __global__ void __launch_bounds__(256) k_preprocess(GsParams p, const float* __r
         }
         cov3d_from_scale_rot(s, p.scale_modifier, q, c3);
     }
-    float T2[2][3], ST0[3], ST1[3];
-    float3 t; bool xin, yin;
-    ewa_T2(m, V, p.tanfovx, p.tanfovy, p.focal_x, p.focal_y, T2, t, xin, yin);
-    sigma_T(c3, T2, ST0, ST1);
-    const float a = T2[0][0] * ST0[0] + T2[0][1] * ST0[1] + T2[0][2] * ST0[2] + 0.3f;
-    const float b = T2[0][0] * ST1[0] + T2[0][1] * ST1[1] + T2[0][2] * ST1[2];
-    const float c = T2[1][0] * ST1[0] + T2[1][1] * ST1[1] + T2[1][2] * ST1[2] + 0.3f;
-    const float det = a * c - b * b;
-    if (det == 0.0f) return;
-    const float di = 1.f / det;
-    const float mid = 0.5f * (a + c);
-    const float sq = sqrtf(fmaxf(0.1f, mid * mid - det));
-    const int rad = (int)ceilf(3.f * sqrtf(fmaxf(mid + sq, mid - sq)));
-    const float px = ndc2pix(ppx, p.W), py = ndc2pix(ppy, p.H);
-    int x0, y0, x1, y1;
-    tile_rect(px, py, rad, p.gx, p.gy, x0, y0, x1, y1);
-    if ((x1 - x0) * (y1 - y0) == 0) return;
-    // from here on the Gaussian counts as visible (radii > 0), exactly as in the dependency; the tile list
-    // it is emitted to is narrowed to the tiles where alpha can reach 1/255 (exact, see tile_rect_tight)
-    const float opac = RAW ? 1.f / (1.f + expf(-opacities[idx])) : opacities[idx];
-    const float ex = alpha_extent(opac, a), ey = alpha_extent(opac, c);
-    if (ex >= 0.f) tile_rect_tight(px, py, rad, ex, ey, p.gx, p.gy, x0, y0, x1, y1);
-    else { x1 = x0; y1 = y0; }
-
-    float r0 = 0.f, r1 = 0.f, r2 = 0.f;
-    uint8_t cl = 0;
-    if (colors_precomp) {
-        r0 = colors_precomp[3 * idx]; r1 = colors_precomp[3 * idx + 1]; r2 = colors_precomp[3 * idx + 2];
-    } else {
-        float dx = m.x - p.campos[0], dy = m.y - p.campos[1], dz = m.z - p.campos[2];
-        const float len = sqrtf(dx * dx + dy * dy + dz * dz);
-        dx /= len; dy /= len; dz /= len;
-        const float* shg = shs + (size_t)idx * p.M * 3;
-        const float* shl = sh_lds + threadIdx.x * SH_ROW;
-#define GS_FWD_TERM(k, Bk, dBx, dBy, dBz)                                                             \
-    {                                                                                                 \
-        const float b_ = (Bk);                                                                        \
-        if (STAGED) { r0 += b_ * shl[3 * (k)]; r1 += b_ * shl[3 * (k) + 1]; r2 += b_ * shl[3 * (k) + 2]; } \
-        else        { r0 += b_ * shg[3 * (k)]; r1 += b_ * shg[3 * (k) + 1]; r2 += b_ * shg[3 * (k) + 2]; } \
-    }
-        SH_FOREACH(p.deg, dx, dy, dz, GS_FWD_TERM);
-#undef GS_FWD_TERM
-        r0 += 0.5f; r1 += 0.5f; r2 += 0.5f;
-        if (r0 < 0.f) cl |= 1; if (r1 < 0.f) cl |= 2; if (r2 < 0.f) cl |= 4;
-        r0 = fmaxf(r0, 0.f); r1 = fmaxf(r1, 0.f); r2 = fmaxf(r2, 0.f);
-    }
-    g.rec0[GS_REC(idx)] = make_float4(px, py, c * di, -b * di);
-    g.rec1[GS_REC(idx)] = make_float4(a * di, opac, r0, r1);
-    g.rec2[GS_REC(idx)] = make_float4(r2, pv.z, ex, ey);
-    g.clamped[idx] = cl;
-    radii[idx] = rad;
-    const uint32_t nt = (uint32_t)((x1 - x0) * (y1 - y0));
-    g.tiles[idx] = nt;
-    g.rect[idx] = make_uint2((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)x1 | ((uint32_t)y1 << 16));
-    g.key[0][idx] = nt ? __float_as_uint(pv.z) : 0xFFFFFFFFu;
+    const float* sh = STAGED ? sh_lds + threadIdx.x * SH_ROW : shs + (size_t)idx * p.M * 3;
+    gs_project_one(idx, m, c3, [&]() { return RAW ? 1.f / (1.f + expf(-opacities[idx])) : opacities[idx]; }, sh, colors_precomp,
+                   GsPreCam{p.view, p.proj, p.campos, p.tanfovx, p.tanfovy, p.focal_x, p.focal_y}, p.W, p.H, p.gx, p.gy, p.deg,
+                   GsPreOut{g.rec0, g.tiles, g.rect, g.key[0], g.clamped, radii});
 }
 
 int gs_launch_preprocess(const GsParams& p, const float* means3D, const float* shs, const float* colors_precomp,
@@ -126,6 +138,58 @@ int gs_launch_preprocess(const GsParams& p, const float* means3D, const float* s
     C3D_LAUNCH_CHECK();
     return 0;
 }
+// ---- A1 for all views of a step at once ---------------------------------------------------------------------------------------------------
+// The per-view kernel streams 44 + 192 B of parameters per Gaussian for every view; over the 8 views of a training step that is 1.9 GB of the
+// same 236 MB.  Here a lane keeps its Gaussian (mean, 3D covariance, opacity in registers, the 48 SH coefficients in LDS) and walks the views:
+// parameters are read once per step, what is left per view is the 93 B of projected state it writes.  Same arithmetic, statement by statement,
+// as k_preprocess<true, true> (the per-view paths and the tests hold the two together).
+struct GsPreView { GsPreCam cam; GsPreOut out; };
+struct GsPreViews { int V; GsPreView v[GS_MAX_BWD_VIEWS]; };
+__global__ void __launch_bounds__(128) k_preprocess_views(GsParams p, GsPreViews vs, const float* __restrict__ means3D, const float* __restrict__ f_dc,
+                                                           const float* __restrict__ f_rest, const float* __restrict__ opacities,
+                                                           const float* __restrict__ scales, const float* __restrict__ rotations) {
+    extern __shared__ float sh_lds[];
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    {
+        const size_t g0 = (size_t)blockIdx.x * blockDim.x;
+        sh_stage_in_split(f_dc, f_rest, g0, min((int)blockDim.x, p.N - (int)g0), sh_lds);
+        __syncthreads();
+    }
+    if (idx >= p.N) return;
+    const float3 m = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
+    float c3[6];
+    {
+        float3 s = make_float3(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]);
+        float4 q = *reinterpret_cast<const float4*>(rotations + 4 * idx);
+        s = make_float3(expf(s.x), expf(s.y), expf(s.z));
+        const float inv = 1.f / fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
+        q = make_float4(q.x * inv, q.y * inv, q.z * inv, q.w * inv);
+        cov3d_from_scale_rot(s, p.scale_modifier, q, c3);
+    }
+    const float opac = 1.f / (1.f + expf(-opacities[idx]));
+    const float* sh = sh_lds + threadIdx.x * SH_ROW;
+    for (int v = 0; v < vs.V; v++)
+        gs_project_one(idx, m, c3, [&]() { return opac; }, sh, (const float*)nullptr, vs.v[v].cam, p.W, p.H, p.gx, p.gy, p.deg, vs.v[v].out);
+}
+// geoms[v] / radii[v]: the state buffers of view v; views[v]: its camera (GsParams of that view; N, W, H, scale_modifier, deg must agree)
+int gs_launch_preprocess_views(const GsParams* views, int V, const GsGeom* geoms, int* const* radii, const float* means3D, const float* f_dc, const float* f_rest,
+                               const float* opacity_raw, const float* scaling_raw, const float* rotation_raw, hipStream_t s) {
+    if (V == 0 || views[0].N == 0) return 0;
+    if (V > GS_MAX_BWD_VIEWS) { c3d_set_error("gs_launch_preprocess_views: too many views in one launch"); return -1; }
+    GsPreViews pv;
+    pv.V = V;
+    for (int i = 0; i < V; i++) {
+        const GsParams& q = views[i];
+        pv.v[i] = GsPreView{GsPreCam{q.view, q.proj, q.campos, q.tanfovx, q.tanfovy, q.focal_x, q.focal_y},
+                            GsPreOut{geoms[i].rec0, geoms[i].tiles, geoms[i].rect, geoms[i].key[0], geoms[i].clamped, radii[i]}};
+    }
+    const int T = 128;
+    hipLaunchKernelGGL(k_preprocess_views, dim3(c3d_cdiv(views[0].N, T)), dim3(T), T * SH_ROW * sizeof(float), s, views[0], pv, means3D, f_dc, f_rest,
+                       opacity_raw, scaling_raw, rotation_raw);
+    C3D_LAUNCH_CHECK();
+    return 0;
+}
+
 // workgroup size of the raw-parameter preprocess (C3D_PRE_THREADS = 64 | 128 (default) | 256): the kernel stages 196 B of SH per lane in LDS, so smaller
 // workgroups interleave the load and compute phases of more workgroups per CU at the same wave count
 static int gs_pre_threads() {

@@ -139,6 +139,8 @@ int gs_launch_preprocess(const GsParams& p, const float* means3D, const float* s
                          GsGeom& g, int* radii, hipStream_t s);
 int gs_launch_preprocess_raw(const GsParams& p, const float* means3D, const float* f_dc, const float* f_rest, const float* opacity_raw,
                              const float* scaling_raw, const float* rotation_raw, GsGeom& g, int* radii, hipStream_t s);
+int gs_launch_preprocess_views(const GsParams* views, int V, const GsGeom* geoms, int* const* radii, const float* means3D, const float* f_dc, const float* f_rest,
+                               const float* opacity_raw, const float* scaling_raw, const float* rotation_raw, hipStream_t s);
 int gs_launch_preprocess_bwd_raw(const GsParams& p, const GsGeom& g, const int* radii, const float* means3D, const float* f_dc, const float* f_rest,
                                  const float* scaling_raw, const float* rotation_raw, const float* pairgrad, const uint8_t* pvalid, float* dL_dmean2D,
                                  float* dL_dopacity_raw, float* dL_dmeans3D, float* dL_df_dc, float* dL_df_rest, float* dL_dscaling_raw,

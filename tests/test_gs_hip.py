@@ -695,7 +695,12 @@ def test_fused_forward_backward_halves_match_autograd():
         color, depth, alpha, radii = step.forward(rs_list, [p.detach() for p in plist], want_depth=True, want_radii=True)
         assert step.capacity > 5000
         for i in range(V):
-            assert torch.equal(color[i].clamp(0, 1), imgs[i][0]) and torch.equal(alpha[i], imgs[i][1]) and torch.equal(depth[i], imgs[i][2]) and torch.equal(radii[i], imgs[i][3])
+            # the step projects all its views in one kernel (k_preprocess_views), the renderer one view per launch: the same statements, but two
+            # compilations of them (float32 contraction / ordering may differ in the last bit), hence "equal to a few ulp" and not torch.equal
+            for got, want in ((color[i].clamp(0, 1), imgs[i][0]), (alpha[i], imgs[i][1]), (depth[i], imgs[i][2])):
+                assert torch.allclose(got, want, rtol=1e-5, atol=1e-5), float((got - want).abs().max())
+            assert int((radii[i] != imgs[i][3]).sum()) <= 2
+            print("[halves] view %d lanes %d: max |dcolor| %.1e, bit-equal %s" % (i, lanes, float((color[i].clamp(0, 1) - imgs[i][0]).abs().max()), torch.equal(color[i].clamp(0, 1), imgs[i][0])))
         dcolor = gC * ((color >= 0) & (color <= 1))                  # d clamp
         grads = [torch.empty_like(p) for p in plist]
         step.backward(grads, dcolor, gA, gD, accumulate=False)
@@ -705,7 +710,7 @@ def test_fused_forward_backward_halves_match_autograd():
         for a, b in zip(grads, ref):
             assert rel_err(a.cpu().numpy(), 2 * b.cpu().numpy()) <= 5e-4
         rg, g2 = step.read_view(V - 1)
-        assert torch.equal(rg, imgs[V - 1][3]) and torch.isfinite(g2).all()
+        assert int((rg != imgs[V - 1][3]).sum()) <= 2 and torch.isfinite(g2).all()
 
 
 def test_trainer_densify_prune_schedule():
