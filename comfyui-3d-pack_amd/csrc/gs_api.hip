@@ -433,6 +433,8 @@ int c3d_gs_train_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, c
     const uint32_t cap = (uint32_t)pair_capacity;
     StepWs w0; carve_step(nullptr, N, views[0].image_height, views[0].image_width, pair_capacity, w0);
     const bool projected = pre_multiview();
+    static int fuse_loss = -1;
+    if (fuse_loss < 0) { const char* e = getenv("C3D_FUSE_LOSS"); fuse_loss = e ? atoi(e) != 0 : 1; }
     if (projected && step_preprocess_all(views, V, N, w0.bytes, workspace, pair_capacity, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, s0)) return -1;
     Lanes ln;
     if (ln.fork(s0, lanes, V)) return -1;
@@ -450,19 +452,31 @@ int c3d_gs_train_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, c
         int rc = 0, res = 0;
         do {
             if ((rc = step_view_forward(p, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, g, b, im, w.radii, cap, status, w.color, w.depth, w.alpha, true, s, &res, projected))) break;
-            // pixel loss and its gradient
-            { C3dProfScope ps(C3D_P_OTHER, s);
-              if ((rc = gs_launch_loss_grad(w.color, w.alpha, target_color[v], target_alpha ? target_alpha[v] : nullptr, color_mask ? color_mask[v] : nullptr, (long long)p.W * p.H, loss->w_l1,
-                                            loss->w_l2, loss->w_alpha_mse, loss->scale, w.dcolor, w.dalpha, loss_out, s))) break;
-              // + scale * w_ssim * (1 - MS-SSIM(target * mask, clamp(C) * mask)) of this view (the batch mean of the reference, main_3DGS.py:192, is the mean of
-              // the per-image values): value into loss_out, gradient added to dL/dcolor -- ~20 launches on this view's lane, no torch op, no sync
-              if (loss->w_ssim != 0.f) {
-                  const float ws_ = loss->scale * loss->w_ssim;
-                  if ((rc = ms_value_grad(target_color[v], w.color, color_mask ? color_mask[v] : nullptr, 1, 1, 3, p.H, p.W, -ws_, 1, w.dcolor, ws_, -ws_, loss_out, w.ms_ws, s))) break;
-              } }
+            // pixel loss and its gradient.  Default: inside the backward compositing kernel (GsPixelLoss); C3D_FUSE_LOSS=0 keeps the separate launch.
+            const float* tal = target_alpha ? target_alpha[v] : nullptr;
+            const float* cmk = color_mask ? color_mask[v] : nullptr;
+            const bool ssim = loss->w_ssim != 0.f;
+            if (!fuse_loss) {
+                C3dProfScope ps(C3D_P_OTHER, s);
+                if ((rc = gs_launch_loss_grad(w.color, w.alpha, target_color[v], tal, cmk, (long long)p.W * p.H, loss->w_l1, loss->w_l2, loss->w_alpha_mse, loss->scale,
+                                              w.dcolor, w.dalpha, loss_out, s))) break;
+            }
+            // + scale * w_ssim * (1 - MS-SSIM(target * mask, clamp(C) * mask)) of this view (the batch mean of the reference, main_3DGS.py:192, is the mean of
+            // the per-image values): value into loss_out, gradient into (fused loss) / added to (separate launch) dL/dcolor -- ~20 launches on this view's lane
+            if (ssim) {
+                C3dProfScope ps(C3D_P_OTHER, s);
+                const float ws_ = loss->scale * loss->w_ssim;
+                if ((rc = ms_value_grad(target_color[v], w.color, cmk, 1, 1, 3, p.H, p.W, -ws_, fuse_loss ? 0 : 1, w.dcolor, ws_, -ws_, loss_out, w.ms_ws, s))) break;
+            }
             // backward down to the per-(tile, splat) records of this view
             { C3dProfScope ps(C3D_P_COMPOSITE_BWD, s);
-              if ((rc = gs_launch_composite_bwd(p, g, b, res, im, w.dcolor, nullptr, w.dalpha, w.pairgrad, w.pvalid, (long long)cap, s, cap))) break; }
+              if (fuse_loss) {
+                  const GsPixelLoss pl{w.color, w.alpha, target_color[v], tal, cmk, loss->w_l1, loss->w_l2, loss->w_alpha_mse, loss->scale, loss_out};
+                  rc = gs_launch_composite_bwd(p, g, b, res, im, ssim ? w.dcolor : nullptr, nullptr, nullptr, w.pairgrad, w.pvalid, (long long)cap, s, cap, &pl);
+              } else {
+                  rc = gs_launch_composite_bwd(p, g, b, res, im, w.dcolor, nullptr, w.dalpha, w.pairgrad, w.pvalid, (long long)cap, s, cap);
+              }
+              if (rc) break; }
         } while (0);
         rc_all = rc;
     }

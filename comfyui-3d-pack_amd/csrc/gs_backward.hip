@@ -104,13 +104,15 @@ __device__ __forceinline__ void wave_reduce10(float v0, float v1, float v2, floa
 // kernels of the other view lanes (radix scatter 38 KB, preprocess 50 KB) cannot co-reside with the compositing: 2100 -> 2170 Mpixels/s; 32 is slower again.
 #define BWD_ROUND 64
 
+template <bool LOSS>
 __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                                                         const uint4* __restrict__ einfo,
                                                         const float4* __restrict__ rec0, const float4* __restrict__ rec1,
                                                         const float4* __restrict__ rec2, const float* __restrict__ final_T,
                                                         const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor,
                                                         const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha_px,
-                                                        const uint8_t* __restrict__ pact, float4* __restrict__ pairgrad, uint8_t* __restrict__ pvalid, uint32_t cap, int sh) {
+                                                        const uint8_t* __restrict__ pact, float4* __restrict__ pairgrad, uint8_t* __restrict__ pvalid, uint32_t cap, int sh,
+                                                        GsPixelLoss pl) {
     __shared__ float4 s0[BWD_ROUND];
     __shared__ float4 s1[BWD_ROUND];
     __shared__ float4 s2[BWD_ROUND];
@@ -134,9 +136,34 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
     const int last = inside ? (int)n_contrib[pid] : 0;
     float dLp0 = 0.f, dLp1 = 0.f, dLp2 = 0.f, dLd = 0.f, dLa = 0.f;
     if (inside) {
-        dLp0 = dL_dcolor[pid]; dLp1 = dL_dcolor[P + pid]; dLp2 = dL_dcolor[2 * P + pid];
+        if (dL_dcolor) { dLp0 = dL_dcolor[pid]; dLp1 = dL_dcolor[P + pid]; dLp2 = dL_dcolor[2 * P + pid]; }
         dLd = dL_ddepth ? dL_ddepth[pid] : 0.f;
         dLa = dL_dalpha_px ? dL_dalpha_px[pid] : 0.f;
+    }
+    if (LOSS) {   // the step's pixel loss, term by term as k_loss_grad
+        __shared__ float s_loss[4];
+        float l = 0.f;
+        if (inside) {
+            const float inv3p = 1.f / (3.f * (float)P), invp = 1.f / (float)P;
+            const float mk = pl.cmask ? pl.cmask[pid] : 1.f;
+            float gch[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                const float c = pl.color[ch * P + pid];
+                const float cc = fminf(fmaxf(c, 0.f), 1.f);
+                const float d = (cc - pl.tcolor[ch * P + pid]) * mk;
+                l += (pl.w_l1 * fabsf(d) + pl.w_l2 * d * d) * inv3p;
+                const float pass = (c >= 0.f && c <= 1.f) ? 1.f : 0.f;
+                const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+                gch[ch] = pl.scale * pass * mk * (pl.w_l1 * sg + 2.f * pl.w_l2 * d) * inv3p;
+            }
+            dLp0 += gch[0]; dLp1 += gch[1]; dLp2 += gch[2];
+            if (pl.talpha) { const float d = pl.alpha[pid] - pl.talpha[pid]; l += pl.w_a * d * d * invp; dLa += pl.scale * 2.f * pl.w_a * d * invp; }
+        }
+        l = c3d_wave_sum(l * pl.scale);
+        if (lane == 0) s_loss[wave] = l;
+        __syncthreads();
+        if (threadIdx.x == 0 && pl.loss_out) atomicAdd(pl.loss_out, s_loss[0] + s_loss[1] + s_loss[2] + s_loss[3]);   // one atomic per tile
     }
     const float bg_dot = p.bg[0] * dLp0 + p.bg[1] * dLp1 + p.bg[2] * dLp2;
     float Rdot = T_final * bg_dot;
@@ -246,12 +273,17 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
 
 int gs_launch_composite_bwd(const GsParams& p, const GsGeom& g, const GsBinning& b, int res, const GsImage& im,
                             const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
-                            float* pairgrad, uint8_t* pvalid, long long pairs, hipStream_t s, uint32_t cap) {
+                            float* pairgrad, uint8_t* pvalid, long long pairs, hipStream_t s, uint32_t cap, const GsPixelLoss* pixel_loss) {
     const int tiles = p.gx * p.gy;
     if (tiles == 0) return 0;
     C3D_CHECK(hipMemsetAsync(pvalid, 0, (size_t)(pairs > 0 ? pairs : 1), s));
-    hipLaunchKernelGGL(k_composite_bwd, dim3(gs_block_count(p.gx, p.gy, gs_supertile_shift())), dim3(256), gs_lds_pad(true), s, p, b.ranges, b.tval[res], g.einfo, g.rec0, g.rec1, g.rec2,
-                       im.final_T, im.n_contrib, dL_dcolor, dL_ddepth, dL_dalpha, gs_pair_activity(b, res), (float4*)pairgrad, pvalid, cap, gs_supertile_shift());
+    const dim3 grid(gs_block_count(p.gx, p.gy, gs_supertile_shift()));
+    if (pixel_loss)
+        hipLaunchKernelGGL(k_composite_bwd<true>, grid, dim3(256), gs_lds_pad(true), s, p, b.ranges, b.tval[res], g.einfo, g.rec0, g.rec1, g.rec2, im.final_T, im.n_contrib,
+                           dL_dcolor, dL_ddepth, dL_dalpha, gs_pair_activity(b, res), (float4*)pairgrad, pvalid, cap, gs_supertile_shift(), *pixel_loss);
+    else
+        hipLaunchKernelGGL(k_composite_bwd<false>, grid, dim3(256), gs_lds_pad(true), s, p, b.ranges, b.tval[res], g.einfo, g.rec0, g.rec1, g.rec2, im.final_T, im.n_contrib,
+                           dL_dcolor, dL_ddepth, dL_dalpha, gs_pair_activity(b, res), (float4*)pairgrad, pvalid, cap, gs_supertile_shift(), GsPixelLoss{});
     C3D_LAUNCH_CHECK();
     return 0;
 }

@@ -151,9 +151,15 @@ int gs_launch_loss_grad(const float* color, const float* alpha, const float* tco
 int gs_launch_ranges(const GsBinning& b, int res, long long D, int tiles, hipStream_t s, const uint32_t* d_dev = nullptr);
 int gs_launch_composite_fwd(const GsParams& p, const GsGeom& g, const GsBinning& b, int res, GsImage& im,
                             float* out_color, float* out_depth, float* out_alpha, bool record_activity, hipStream_t s);
+// Pixel loss of the fused training step, evaluated inside the backward compositing kernel's prologue (every lane owns one pixel there):
+//   L = scale * [ w_l1 mean|clamp(c) - t| m + w_l2 mean((clamp(c) - t) m)^2 + w_a mean(alpha - ta)^2 ],  m = cmask or 1
+// its gradient is ADDED to what dL_dcolor holds (NULL = nothing: the MS-SSIM term's gradient, when there is one) and the value to *loss_out.
+// Replaces a separate launch that wrote dL/dcolor, dL/dalpha (16 B per pixel) for this kernel to read back.
+struct GsPixelLoss { const float* color; const float* alpha; const float* tcolor; const float* talpha; const float* cmask; float w_l1, w_l2, w_a, scale; float* loss_out; };
 int gs_launch_composite_bwd(const GsParams& p, const GsGeom& g, const GsBinning& b, int res, const GsImage& im,
                             const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
-                            float* pairgrad /* [D][12] */, uint8_t* pvalid /* [D], cleared here */, long long pairs, hipStream_t s, uint32_t cap = 0xFFFFFFFFu);
+                            float* pairgrad /* [D][12] */, uint8_t* pvalid /* [D], cleared here */, long long pairs, hipStream_t s, uint32_t cap = 0xFFFFFFFFu,
+                            const GsPixelLoss* pixel_loss = nullptr);
 int gs_launch_preprocess_bwd(const GsParams& p, const GsGeom& g, const int* radii, const float* means3D, const float* shs,
                              const float* colors_precomp, const float* scales, const float* rotations, const float* cov3D_precomp,
                              const float* pairgrad, const uint8_t* pvalid, float* dL_dmean2D, float* dL_dcolors, float* dL_dopacity,
