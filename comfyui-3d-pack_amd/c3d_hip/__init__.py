@@ -68,7 +68,7 @@ _SIGNATURES = {
 }
 
 
-ABI_VERSION = 200      # c3d_version() of the library these signatures describe
+ABI_VERSION = 201      # c3d_version() of the library these signatures describe
 
 
 def exported_symbols():

@@ -107,7 +107,7 @@ static int project_tail(GsGeom& g, int N, int64_t* num_rendered, hipStream_t s) 
 extern "C" {
 
 const char* c3d_last_error(void) { return g_err; }
-int c3d_version(void) { return 200; }
+int c3d_version(void) { return 201; }
 int c3d_gs_set_exact_dscale(int32_t on) { const int old = g_exact_dscale; g_exact_dscale = on != 0; return old; }
 
 size_t c3d_gs_geom_bytes(int32_t N) { GsGeom g; gs_carve_geom(nullptr, N, g); return g.bytes; }
@@ -284,7 +284,11 @@ static void carve_step(char* base, int N, int H, int W, long long cap, StepWs& w
 // join ONE pass over the Gaussians turns all views' pair records into the parameter gradients.
 #define C3D_MAX_LANES 8
 namespace {
-struct LanePool { bool init = false; hipStream_t st[C3D_MAX_LANES - 1]; hipEvent_t fork, join[C3D_MAX_LANES - 1]; };
+struct LanePool {
+    bool init = false; hipStream_t st[C3D_MAX_LANES - 1]; hipEvent_t fork, join[C3D_MAX_LANES - 1];
+    // forward-only rendering in groups of L views: a projection stream running two groups ahead of the lanes (render_views_grouped)
+    hipStream_t pre; hipEvent_t pre_done[2], lane_done[2][C3D_MAX_LANES];
+};
 LanePool g_lanes[16];
 std::mutex g_lane_mu;
 int lane_pool(LanePool** out) {
@@ -298,6 +302,11 @@ int lane_pool(LanePool** out) {
         for (int i = 0; i < C3D_MAX_LANES - 1; i++) {
             C3D_CHECK(hipStreamCreateWithFlags(&lp.st[i], hipStreamNonBlocking));
             C3D_CHECK(hipEventCreateWithFlags(&lp.join[i], hipEventDisableTiming));
+        }
+        C3D_CHECK(hipStreamCreateWithFlags(&lp.pre, hipStreamNonBlocking));
+        for (int i = 0; i < 2; i++) {
+            C3D_CHECK(hipEventCreateWithFlags(&lp.pre_done[i], hipEventDisableTiming));
+            for (int l = 0; l < C3D_MAX_LANES; l++) C3D_CHECK(hipEventCreateWithFlags(&lp.lane_done[i][l], hipEventDisableTiming));
         }
         lp.init = true;
     }
@@ -315,6 +324,7 @@ struct Lanes {
         }
         return 0;
     }
+    int need_pool() { return lp ? 0 : lane_pool(&lp); }
     // always executed, so the caller's stream never runs ahead of work queued on the lanes (also after an error)
     int join(const char* who) {
         int rc = 0;
@@ -498,28 +508,72 @@ static int views_forward(const char* who, const c3d_gs_settings* views, int32_t 
     if ((uintptr_t)f_rest % 16 || (uintptr_t)rotation_raw % 16) { c3d_set_error("%s: f_rest / rotation tensors must be 16-byte aligned", who); return -1; }
     const uint32_t cap = (uint32_t)pair_capacity;
     StepWs w0; carve_step(nullptr, N, views[0].image_height, views[0].image_width, pair_capacity, w0);
-    const bool projected = keep_state && pre_multiview();
-    if (projected && step_preprocess_all(views, V, N, w0.bytes, workspace, pair_capacity, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, s0)) return -1;
+    const bool projected = pre_multiview();
+    if (projected && keep_state && step_preprocess_all(views, V, N, w0.bytes, workspace, pair_capacity, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, s0)) return -1;
     Lanes ln;
     if (ln.fork(s0, lanes, V)) return -1;
+    const int L = ln.L;
     int rc_all = 0;
+    // Forward only (no state kept): a lane reuses workspace slices view after view.  The views go in groups of L (one per lane); group k lives in
+    // slice set k % 2, and a projection stream runs k_preprocess_views for whole groups two ahead of the lanes: parameters are streamed once per
+    // L views, and group k + 2 is projected as soon as every lane has finished its view of group k.
+    const bool grouped = projected && !keep_state;
+    hipStream_t sp = nullptr;
+    auto project_group = [&](int k) -> int {
+        const int v0 = k * L, nv = (V - v0) < L ? (V - v0) : L;
+        GsParams ps[C3D_MAX_LANES]; GsGeom gs[C3D_MAX_LANES]; int* rd[C3D_MAX_LANES];
+        for (int i = 0; i < nv; i++) {
+            if (make_params(&views[v0 + i], N, 16, ps[i])) return -1;
+            StepWs w; carve_step((char*)workspace + (size_t)((k & 1) * L + i) * w0.bytes, N, ps[i].H, ps[i].W, pair_capacity, w);
+            gs_carve_geom(w.geom, N, gs[i]);
+            rd[i] = (out_radii && out_radii[v0 + i]) ? out_radii[v0 + i] : w.radii;
+        }
+        { C3dProfScope sc(C3D_P_PREPROCESS, sp);
+          if (gs_launch_preprocess_views(ps, nv, gs, rd, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, sp)) return -1; }
+        C3D_CHECK(hipEventRecord(ln.lp->pre_done[k & 1], sp));
+        return 0;
+    };
+    const int groups = (V + L - 1) / L;
+    if (grouped) {
+        if (ln.need_pool()) rc_all = -1;
+        else {
+            sp = ln.lp->pre;
+            if (hipEventRecord(ln.lp->fork, s0) != hipSuccess || hipStreamWaitEvent(sp, ln.lp->fork, 0) != hipSuccess) { c3d_set_error("%s: fork failed", who); rc_all = -1; }
+            for (int k = 0; k < 2 && k < groups && !rc_all; k++) rc_all = project_group(k);
+        }
+    }
     for (int v = 0; v < V && !rc_all; v++) {
-        const int lane = v % ln.L;
+        const int lane = v % L, k = v / L;
+        hipStream_t s = ln.ls[lane];
         GsParams p;
         if (make_params(&views[v], N, 16, p)) { rc_all = -1; break; }
         if (!out_color[v] || !out_alpha[v]) { c3d_set_error("%s: output %d is NULL", who, v); rc_all = -1; break; }
-        StepWs w; carve_step((char*)workspace + (size_t)(keep_state ? v : lane) * w0.bytes, N, p.H, p.W, pair_capacity, w);
+        const int slice = keep_state ? v : (grouped ? (k & 1) * L + lane : lane);
+        StepWs w; carve_step((char*)workspace + (size_t)slice * w0.bytes, N, p.H, p.W, pair_capacity, w);
         GsGeom g; gs_carve_geom(w.geom, N, g);
         GsBinning b; gs_carve_binning(w.binning, pair_capacity, p.gx * p.gy, b);
         GsImage im; gs_carve_image(w.image, p.W, p.H, im);
         int res = 0;
         int* radii = (!keep_state && out_radii && out_radii[v]) ? out_radii[v] : w.radii;      // kept state: the backward pass reads the slice's copy
         float* depth = (out_depth && out_depth[v]) ? out_depth[v] : w.depth;
-        rc_all = step_view_forward(p, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, g, b, im, radii, cap, status, out_color[v], depth, out_alpha[v], keep_state, ln.ls[lane], &res, projected);
+        if (grouped && hipStreamWaitEvent(s, ln.lp->pre_done[k & 1], 0) != hipSuccess) { c3d_set_error("%s: wait failed", who); rc_all = -1; break; }
+        rc_all = step_view_forward(p, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, g, b, im, radii, cap, status, out_color[v], depth, out_alpha[v], keep_state, s, &res, projected);
         if (!rc_all && keep_state && out_radii && out_radii[v] &&
-            hipMemcpyAsync(out_radii[v], w.radii, sizeof(int) * (size_t)N, hipMemcpyDeviceToDevice, ln.ls[lane]) != hipSuccess) {
+            hipMemcpyAsync(out_radii[v], w.radii, sizeof(int) * (size_t)N, hipMemcpyDeviceToDevice, s) != hipSuccess) {
             c3d_set_error("%s: radii copy failed", who); rc_all = -1;       // no early return: the lanes must still be joined
         }
+        if (grouped && !rc_all) {
+            if (hipEventRecord(ln.lp->lane_done[k & 1][lane], s) != hipSuccess) { c3d_set_error("%s: record failed", who); rc_all = -1; break; }
+            const bool last_of_group = (lane == L - 1) || (v == V - 1);
+            if (last_of_group && k + 2 < groups) {      // slice set k % 2 is free once every lane is through group k: project group k + 2 into it
+                for (int l = 0; l <= lane && !rc_all; l++)
+                    if (hipStreamWaitEvent(sp, ln.lp->lane_done[k & 1][l], 0) != hipSuccess) { c3d_set_error("%s: wait failed", who); rc_all = -1; }
+                if (!rc_all) rc_all = project_group(k + 2);
+            }
+        }
+    }
+    if (grouped && sp) {   // nothing may be left running on the projection stream when the caller's stream continues (error paths included)
+        if (hipEventRecord(ln.lp->pre_done[0], sp) != hipSuccess || hipStreamWaitEvent(s0, ln.lp->pre_done[0], 0) != hipSuccess) { (void)hipDeviceSynchronize(); if (!rc_all) { c3d_set_error("%s: join failed", who); rc_all = -1; } }
     }
     if (ln.join(who) && !rc_all) rc_all = -1;
     return rc_all;

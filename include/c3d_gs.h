@@ -150,8 +150,9 @@ int c3d_gs_train_views_raw(const c3d_gs_settings* views /* host [V] */, int32_t 
 /* Forward only, V views of the same cloud in one call (orbit rendering of a trained model: the per-camera loop of the reference's
  * orbit-renderer node over GaussianSplattingRenderer.render, main_3DGS_renderer.py:927-936), raw parameters, no host synchronisation,
  * views dealt onto `lanes` streams as above.  HOST arrays of V device pointers: out_color [3,H,W], out_depth [1,H,W], out_alpha [1,H,W];
- * out_radii (array or entries may be NULL) [N] int32.  The workspace needs c3d_gs_step_workspace_bytes(N, H, W, pair_capacity, lanes)
- * bytes (one slice per lane).  status as for c3d_gs_train_views_raw: on overflow the images of the affected views are incomplete. */
+ * out_radii (array or entries may be NULL) [N] int32.  The workspace needs c3d_gs_step_workspace_bytes(N, H, W, pair_capacity, 2 * lanes)
+ * bytes (TWO slices per lane since ABI 201: the views go in groups of `lanes`, and while the lanes bin and composite group k a projection
+ * stream already fills the other slice set with groups k + 1 / k + 2 -- one pass over the parameters per group instead of one per view).  status as for c3d_gs_train_views_raw: on overflow the images of the affected views are incomplete. */
 int c3d_gs_render_views_raw(const c3d_gs_settings* views /* host [V] */, int32_t V, int32_t N, const float* means3D, const float* f_dc,
                             const float* f_rest, const float* opacity_raw, const float* scaling_raw, const float* rotation_raw,
                             float* const* out_color, float* const* out_depth, float* const* out_alpha, int32_t* const* out_radii,
