@@ -408,7 +408,11 @@ def main():
         with torch.no_grad():
             pass
     sync()
-    c3d_hip.prof_enable(a.timed_prof == "on")
+    # Inside the timed region only the dominant kernel is timed (two event records per timed launch; timing all ~20 launches of a view costs
+    # the multi-stream schedule ~2.5 %, profiles/README.md); the full per-kernel table comes from the separate pass below.
+    multi = fused_step if fused_step is not None else view_render
+    only_dom = ["gs_composite_fwd" if a.mode == "fwd" else "gs_composite_bwd"] if (multi is not None and multi.lanes > 1) else None
+    c3d_hip.prof_enable(a.timed_prof == "on", only=only_dom)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
@@ -420,9 +424,9 @@ def main():
     # its own cost.  The roofline figure therefore comes from an extra, untimed single-lane pass over the same step (same inputs, same
     # kernels); the concurrent durations of the timed region are reported next to it as "kernels_concurrent".
     prof_conc = None
-    multi = fused_step if fused_step is not None else view_render
+    prof_views = a.steps * a.views_per_gpu          # views the `prof` table covers
     if multi is not None and multi.lanes > 1:
-        prof_conc = prof
+        prof_conc = {k: v for k, v in prof.items() if v[1]}
         if fused_step is not None:
             keep_obj, fused_step = fused_step, FusedViewStep(N, H, W, dev, lanes=1, pair_capacity=fused_step.capacity, views=len(settings))
             fused_step._fitted = True
@@ -436,6 +440,7 @@ def main():
             step()
         sync()
         prof = c3d_hip.prof_read()
+        prof_views = min(a.steps, 4) * a.views_per_gpu
         c3d_hip.prof_enable(False)
         if fused_step is not None:
             fused_step = keep_obj
@@ -455,8 +460,9 @@ def main():
     kern = {}
     for name, (ms, n) in prof.items():
         avg = ms / n
-        kern[name] = {"avg_ms": round(avg, 4), "launches": n, "share": 0.0,
-                      "alg_GBps": round(alg.get(name, 0) / (avg * 1e-3) / 1e9, 1) if avg > 0 else None}
+        vpl = prof_views / n if name in ("gs_preprocess", "gs_preprocess_bwd") else 1.0     # these two cover several views per launch (all views of a step / of a group)
+        kern[name] = {"avg_ms": round(avg, 4), "launches": n, "share": 0.0, "ms_per_view": round(ms / max(prof_views, 1), 4),
+                      "alg_GBps": round(alg.get(name, 0) * vpl / (avg * 1e-3) / 1e9, 1) if avg > 0 else None}
     tot = sum(ms for ms, _ in prof.values()) or 1.0
     for name, (ms, n) in prof.items():
         kern[name]["share"] = round(ms / tot, 3)
@@ -501,7 +507,7 @@ def main():
             pass
         if prof_conc is not None:
             roof["measured"] = "single-lane pass after the timed region (kernels run alone); timed region used %d view lanes" % a.lanes
-            if prof_conc:
+            if prof_conc and dom in prof_conc:
                 roof["avg_ms_concurrent"] = round(prof_conc[dom][0] / prof_conc[dom][1], 4)
     # whole-chain figure: SURVEY 8(d)'s algorithmic bytes of a VIEW over the wall time a view takes in the timed
     # region -- the number the north star's ">= 60 % of HBM roofline on forward raster" is about

@@ -59,6 +59,7 @@ _SIGNATURES = {
     "c3d_msssim_value_grad": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp]),
     "c3d_reduce_ranks_f32": (C.c_int, [vp, vp, i32, i64, C.c_float, vp]),
     "c3d_prof_enable": (C.c_int, [C.c_int]),
+    "c3d_prof_select": (C.c_int, [C.c_ulonglong]),
     "c3d_prof_slots": (C.c_int, []),
     "c3d_prof_name": (C.c_char_p, [C.c_int]),
     "c3d_prof_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
@@ -149,8 +150,17 @@ def f32c(t):
     return t.contiguous()
 
 
-def prof_enable(on=True):
-    lib().c3d_prof_enable(1 if on else 0)
+def prof_enable(on=True, only=None):
+    """only: names of the kernel groups to time (None = all).  Every timed launch costs two event records on its stream."""
+    l = lib()
+    mask = (1 << 64) - 1
+    if only is not None:
+        names = [l.c3d_prof_name(i).decode() for i in range(l.c3d_prof_slots())]
+        mask = 0
+        for n in only:
+            mask |= 1 << names.index(n)
+    l.c3d_prof_select(mask)
+    l.c3d_prof_enable(1 if on else 0)
 
 
 def prof_read():

@@ -201,6 +201,9 @@ int c3d_gs_debug_state(int32_t N, int32_t image_height, int32_t image_width, con
  * c3d_prof_enable(1) resets and starts, c3d_prof_read(slot, &ms, &n) synchronises the recorded events and returns the
  * accumulated milliseconds / launches of a slot; slot names via c3d_prof_name (e.g. "gs_composite_bwd"). */
 int c3d_prof_enable(int on);
+/* time only the slots whose bit is set in `mask` (all bits = everything, the default).  Each timed launch costs two event records on its
+ * stream, which perturbs a multi-stream schedule by a few percent when every launch of a step is timed. */
+int c3d_prof_select(unsigned long long mask);
 int c3d_prof_slots(void);
 const char* c3d_prof_name(int slot);
 int c3d_prof_read(int slot, double* total_ms, long long* launches);
