@@ -257,7 +257,7 @@ int c3d_gs_backward_raw(const c3d_gs_settings* st, int32_t N, const float* means
 // ---- fused multi-view paths (no host synchronisation inside) ----------------------------------------------------------------
 struct StepWs {
     char* geom; char* binning; char* image; int* radii; float* color; float* depth; float* alpha; float* dcolor; float* dalpha; float* pairgrad; uint8_t* pvalid;
-    float* dmeans2D; float* gcol; char* ms_ws;
+    float* dmeans2D; float* gcol; char* ms_ws; float* tile_loss;
     size_t bytes;
 };
 static void carve_step(char* base, int N, int H, int W, long long cap, StepWs& w) {
@@ -276,6 +276,7 @@ static void carve_step(char* base, int N, int H, int W, long long cap, StepWs& w
     w.dmeans2D = (float*)take(12 * n);
     w.gcol = (float*)take(12 * n);
     w.ms_ws = take(c3d_msssim_workspace_bytes(1, 3, H, W));       // MS-SSIM term of the pixel loss (w_ssim != 0)
+    w.tile_loss = (float*)take(4 * (size_t)(((W + C3D_TILE_X - 1) / C3D_TILE_X) * ((H + C3D_TILE_Y - 1) / C3D_TILE_Y)));   // per-tile partial sums of the pixel loss
     w.bytes = off;
 }
 
@@ -481,7 +482,7 @@ int c3d_gs_train_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, c
             // backward down to the per-(tile, splat) records of this view
             { C3dProfScope ps(C3D_P_COMPOSITE_BWD, s);
               if (fuse_loss) {
-                  const GsPixelLoss pl{w.color, w.alpha, target_color[v], tal, cmk, loss->w_l1, loss->w_l2, loss->w_alpha_mse, loss->scale, loss_out};
+                  const GsPixelLoss pl{w.color, w.alpha, target_color[v], tal, cmk, loss->w_l1, loss->w_l2, loss->w_alpha_mse, loss->scale, loss_out ? w.tile_loss : nullptr};
                   rc = gs_launch_composite_bwd(p, g, b, res, im, ssim ? w.dcolor : nullptr, nullptr, nullptr, w.pairgrad, w.pvalid, (long long)cap, s, cap, &pl);
               } else {
                   rc = gs_launch_composite_bwd(p, g, b, res, im, w.dcolor, nullptr, w.dalpha, w.pairgrad, w.pvalid, (long long)cap, s, cap);
@@ -492,6 +493,11 @@ int c3d_gs_train_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, c
     }
     if (ln.join("c3d_gs_train_views_raw") && !rc_all) rc_all = -1;
     if (rc_all) return rc_all;
+    if (fuse_loss && loss_out) {   // the views' per-tile partial sums of the pixel loss -> loss_out, in a fixed order
+        StepWs wf; carve_step((char*)workspace, N, views[0].image_height, views[0].image_width, pair_capacity, wf);
+        const int tiles = ((views[0].image_width + C3D_TILE_X - 1) / C3D_TILE_X) * ((views[0].image_height + C3D_TILE_Y - 1) / C3D_TILE_Y);
+        if (gs_launch_sum_tile_loss(wf.tile_loss, w0.bytes, V, tiles, loss_out, s0)) return -1;
+    }
     return step_a8_all_views(views, V, N, w0.bytes, workspace, pair_capacity, means3D, f_dc, f_rest, scaling_raw, rotation_raw, dL_dmeans3D, dL_df_dc, dL_df_rest,
                              dL_dopacity_raw, dL_dscaling_raw, dL_drotation_raw, accumulate != 0, s0);
 }

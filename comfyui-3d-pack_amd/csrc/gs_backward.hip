@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
         l = c3d_wave_sum(l * pl.scale);
         if (lane == 0) s_loss[wave] = l;
         __syncthreads();
-        if (threadIdx.x == 0 && pl.loss_out) atomicAdd(pl.loss_out, s_loss[0] + s_loss[1] + s_loss[2] + s_loss[3]);   // one atomic per tile
+        if (threadIdx.x == 0 && pl.tile_loss) pl.tile_loss[tile] = s_loss[0] + s_loss[1] + s_loss[2] + s_loss[3];
     }
     const float bg_dot = p.bg[0] * dLp0 + p.bg[1] * dLp1 + p.bg[2] * dLp2;
     float Rdot = T_final * bg_dot;
@@ -269,6 +269,28 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
             }
         }
     }
+}
+
+__global__ void __launch_bounds__(1024) k_sum_tile_loss(const float* __restrict__ first_view, size_t stride, int V, int tiles, float* __restrict__ loss_out) {
+    __shared__ float red[16];
+    float acc = 0.f;
+    for (int v = 0; v < V; v++) {   // views in order, tiles strided over the lanes, then a fixed tree: the same sum every run
+        const float* t = (const float*)((const char*)first_view + (size_t)v * stride);
+        float l = 0.f;
+        for (int i = threadIdx.x; i < tiles; i += 1024) l += t[i];
+        l = c3d_wave_sum(l);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = l;
+        __syncthreads();
+        if (threadIdx.x == 0) { float q = 0.f; for (int w = 0; w < 16; w++) q += red[w]; acc += q; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(loss_out, acc);   // one atomic per step; other terms (MS-SSIM) add theirs
+}
+int gs_launch_sum_tile_loss(const float* first_view, size_t view_stride_bytes, int V, int tiles, float* loss_out, hipStream_t s) {
+    if (V == 0 || tiles == 0 || !loss_out) return 0;
+    hipLaunchKernelGGL(k_sum_tile_loss, dim3(1), dim3(1024), 0, s, first_view, view_stride_bytes, V, tiles, loss_out);
+    C3D_LAUNCH_CHECK();
+    return 0;
 }
 
 int gs_launch_composite_bwd(const GsParams& p, const GsGeom& g, const GsBinning& b, int res, const GsImage& im,
