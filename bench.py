@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--cpu-baseline", choices=["auto", "on", "off"], default="auto")
     ap.add_argument("--exchange", choices=["allgather", "allreduce"], default="allreduce",
                     help="gradient exchange of the shared-Gaussian step: one RCCL all-reduce (default: 2*(n-1)/n * 236 MB per rank on the wire) or the literal all-gather of every rank's gradient + rank-ordered local sum (7 * 236 MB received per rank at n = 8)")
+    ap.add_argument("--exchange-chunks", type=int, default=4,
+                    help="N > 1, --exchange allreduce: Gaussian ranges of the per-Gaussian backward pass, each range's collective overlapping the next range's kernels (1 = one all-reduce after the step)")
     ap.add_argument("--timed-prof", choices=["on", "off"], default="on", help="HIP-event kernel timing inside the timed region")
     ap.add_argument("--lanes", type=int, default=4, help="HIP streams the views of a step are dealt onto (fused step path)")
     ap.add_argument("--render-path", choices=["step", "fused", "accessor", "boundary"], default="step",
@@ -339,13 +341,21 @@ def main():
 
     def step(collect=False):
         nonlocal fused_step, view_render
+        exchanged = False
         if view_render is not None and not collect:
             with torch.no_grad():
                 view_render.run(settings, plist)
         elif fused_step is not None and not collect and ms_ssim is None:
             full = loss_kind == "full"      # BASELINE config 3's loss: masked by the target alpha, + 0.2 (1 - MS-SSIM), all inside the library call
+            # N > 1, all-reduce mode: the per-Gaussian backward pass runs in `--exchange-chunks` Gaussian ranges and each range's f_rest rows (76 % of the
+            # gradient bytes) start their all-reduce as soon as they are enqueued, underneath the next range's kernels (FlatGrads.exchange_rows)
+            overlap = world > 1 and a.exchange == "allreduce" and a.exchange_chunks > 1
             fused_step.run(settings, [q.detach() for q in plist], step_grads, [tg[0] for tg in targets], [tg[1] for tg in targets], ([tg[1] for tg in targets] if full else None),
-                           w_l1=0.8, w_l2=0.0, w_alpha_mse=3.0, scale=1.0 / (a.views_per_gpu * world), accumulate=False, w_ssim=(0.2 if full else 0.0))
+                           w_l1=0.8, w_l2=0.0, w_alpha_mse=3.0, scale=1.0 / (a.views_per_gpu * world), accumulate=False, w_ssim=(0.2 if full else 0.0),
+                           param_chunks=(a.exchange_chunks if overlap else 1), after_chunk=(flat_grads.exchange_rows if overlap else None))
+            if overlap:
+                flat_grads.exchange_finish()
+                exchanged = True
             for q, gq in zip(plist, step_grads):
                 q.grad = gq
         elif fused_step is not None and not collect:
@@ -370,7 +380,9 @@ def main():
                     tc, ta = targets[i]
                     loss = (color - tc).abs().mean() * 0.8 + 3.0 * ((alpha - ta) ** 2).mean()
                     (loss / (a.views_per_gpu * world)).backward()
-        if a.mode != "fwd" and world > 1 and fused_step is not None and not collect:
+        if exchanged:
+            pass
+        elif a.mode != "fwd" and world > 1 and fused_step is not None and not collect:
             flat_grads.exchange(None, a.exchange, average=False)
         elif a.mode != "fwd" and world > 1:
             flat = torch.cat([q.grad.reshape(N, -1) for q in plist], dim=1)   # [N, 59] dense gradient
@@ -553,7 +565,8 @@ def main():
             "config": {"workload": "3DGS %s, %d synthetic Gaussians (seed 1234) SH deg %d, %dx%d, %d orbit views/GPU/step of the 64-camera orbit"
                                    % (a.mode, N, deg, W, H, a.views_per_gpu),
                        "global_views_per_step": a.views_per_gpu * world, "parallelism": "view-parallel dp%d" % world,
-                       "exchange": (a.exchange if world > 1 and a.mode != "fwd" else "none"), "render_path": a.render_path,
+                       "exchange": (a.exchange if world > 1 and a.mode != "fwd" else "none"),
+                       "exchange_chunks": (a.exchange_chunks if world > 1 and a.mode != "fwd" and a.exchange == "allreduce" and fused_step is not None else 1), "render_path": a.render_path,
                        "loss": (None if a.mode == "fwd" else ("0.8 L1 + 3 MSE(alpha) + 0.2 (1 - MS-SSIM), masked (BASELINE config 3)%s" % (", MS-SSIM by torch ops" if ms_ssim is not None else ", fused HIP")
                                                                 if loss_kind != "l1alpha" and a.render_path == "step" else "0.8 L1 + 3 MSE(alpha)")), "view_lanes": (a.lanes if a.render_path == "step" else 1),
                        "host_enqueue_ms_per_step": (round(fused_step.last_host_ms, 3) if fused_step is not None else None),

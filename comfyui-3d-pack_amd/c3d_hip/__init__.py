@@ -47,6 +47,7 @@ _SIGNATURES = {
     "c3d_gs_train_views_raw": (C.c_int, [C.POINTER(GsSettings), i32, i32] + [vp] * 6 + [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(GsLoss)] + [vp] * 6 + [vp, i64, i32, i32, vp, vp, vp]),
     "c3d_gs_render_views_raw": (C.c_int, [C.POINTER(GsSettings), i32, i32] + [vp] * 6 + [C.POINTER(vp)] * 4 + [i64, i32, vp, vp, vp]),
     "c3d_gs_forward_views_raw": (C.c_int, [C.POINTER(GsSettings), i32, i32] + [vp] * 6 + [C.POINTER(vp)] * 4 + [i64, i32, vp, vp, vp]),
+    "c3d_gs_step_param_backward_range": (C.c_int, [C.POINTER(GsSettings), i32, i32] + [vp] * 5 + [vp] * 6 + [i64, i32, vp, i32, i32, vp]),
     "c3d_gs_backward_views_raw": (C.c_int, [C.POINTER(GsSettings), i32, i32] + [vp] * 5 + [C.POINTER(vp)] * 3 + [vp] * 6 + [i64, i32, i32, vp, vp]),
     "c3d_gs_set_exact_dscale": (C.c_int, [i32]),
     "c3d_gs_step_read_view": (C.c_int, [i32, i32, i32, i64, vp, i32, vp, vp, vp]),

@@ -26,6 +26,7 @@ class FusedViewStep:
         self.status = torch.zeros(2, dtype=torch.int32, device=self.device)
         self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
         self._fitted = False
+        self._chunks_went_out = False
         self._fwd = None
         self.time_events = False
         # defer_status: once the capacity is fitted, run() does not wait for its own status words -- they are copied to pinned memory asynchronously and
@@ -52,10 +53,13 @@ class FusedViewStep:
         return arr
 
     def run(self, raster_settings, params, grads, target_color, target_alpha=None, color_mask=None, w_l1=1.0, w_l2=0.0, w_alpha_mse=0.0, scale=1.0, max_retries=3,
-            accumulate=True, w_ssim=0.0):
+            accumulate=True, w_ssim=0.0, param_chunks=1, after_chunk=None):
         """params / grads: (xyz, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw) tensors; accumulate=True adds to the grads (zero them per
         step), False overwrites them (no zero-fill needed).  -> loss tensor (device scalar, the sum over the views).  Synchronises once, at
-        the end, to read the overflow flag."""
+        the end, to read the overflow flag.
+        after_chunk(g0, g1): called when the gradient rows [g0, g1) of every tensor have been ENQUEUED in final form on the current stream --
+        with param_chunks > 1 (and a fitted capacity, accumulate=False) the per-Gaussian pass runs range by range and the callback follows each
+        range (the multi-GPU trainer starts that range's collective there, underneath the next range's kernels); otherwise once, with (0, N)."""
         lib = _h.lib()
         V = len(raster_settings)
         prev, self._pending = self._pending, None      # a deferred previous step: examined AFTER this one is enqueued, so the GPU never waits for the host
@@ -82,10 +86,19 @@ class FusedViewStep:
             if self.time_events:
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record(torch.cuda.current_stream(self.device))
+            chunked = param_chunks > 1 and after_chunk is not None and self._fitted and not accumulate and self.N >= 1024 * param_chunks
+            self._chunks_went_out = chunked
             with torch.cuda.device(self.device):
-                _h.check(lib.c3d_gs_train_views_raw(views, V, self.N, *[_h.ptr(_h.f32c(p)) for p in params], tc, ta, cm, C.byref(loss),
-                                                    *[_h.ptr(g) for g in grads], _h.ptr(self.loss), self.capacity, self.lanes, 1 if accumulate else 0, _h.ptr(self.workspace),
-                                                    _h.ptr(self.status), _h.stream(self.device)), "c3d_gs_train_views_raw")
+                pp = [_h.ptr(_h.f32c(p)) for p in params]
+                _h.check(lib.c3d_gs_train_views_raw(views, V, self.N, *pp, tc, ta, cm, C.byref(loss),
+                                                    *[_h.ptr(g) for g in grads], _h.ptr(self.loss), self.capacity, self.lanes, (1 if accumulate else 0) | (2 if chunked else 0),
+                                                    _h.ptr(self.workspace), _h.ptr(self.status), _h.stream(self.device)), "c3d_gs_train_views_raw")
+                if chunked:
+                    bounds = [min(self.N, (self.N * i // param_chunks + 255) // 256 * 256) for i in range(param_chunks)] + [self.N]
+                    for g0, g1 in zip(bounds[:-1], bounds[1:]):
+                        _h.check(lib.c3d_gs_step_param_backward_range(views, V, self.N, pp[0], pp[1], pp[2], pp[4], pp[5], *[_h.ptr(g) for g in grads], self.capacity, 0,
+                                                                      _h.ptr(self.workspace), g0, g1 - g0, _h.stream(self.device)), "c3d_gs_step_param_backward_range")
+                        after_chunk(g0, g1)
             self.last_host_ms = (time.perf_counter() - t_host) * 1e3      # host time to enqueue the whole step (no sync inside)
             if self.time_events:
                 ev1.record(torch.cuda.current_stream(self.device))
@@ -104,6 +117,8 @@ class FusedViewStep:
                     prev = None
                     self._pending = None
                     continue             # the previous step had overflowed (capacity regrown): this one certainly did too -- redo it, synchronously
+                if after_chunk is not None and not chunked:
+                    after_chunk(0, self.N)
                 return out
             if prev is not None:
                 self._examine(prev)
@@ -120,7 +135,11 @@ class FusedViewStep:
                     self.capacity = int(seen * 1.3) + 4096
                     self._alloc()
                 self._fitted = True
+                if after_chunk is not None and not chunked:
+                    after_chunk(0, self.N)
                 return self.loss.clone()
+            if chunked:
+                raise RuntimeError("c3d FusedViewStep: a step whose gradient ranges had already been handed to after_chunk exceeded the pair capacity (%d pairs)" % (st[1] & 0xFFFFFFFF))
             self.capacity = int(max(st[1] & 0xFFFFFFFF, self.capacity) * 1.25) + 1024
             self._alloc()
             if accumulate:
@@ -148,6 +167,9 @@ class FusedViewStep:
             seen = st[1] & 0xFFFFFFFF
             self.capacity = int(max(seen, self.capacity) * 1.25) + 1024
             self._alloc()
+            if self._chunks_went_out:      # a redo would issue the ranges' collectives a second time on this rank only: fail here, not in a hung collective
+                raise RuntimeError("c3d FusedViewStep: a step whose gradient ranges had already been handed to after_chunk needed %d (tile, splat) pairs, more "
+                                   "than the fitted capacity; size pair_capacity explicitly for chunked multi-GPU steps" % seen)
             warnings.warn("c3d FusedViewStep: the previous step needed %d (tile, splat) pairs, more than the fitted capacity; its gradient was incomplete "
                           "(noticed one step late because defer_status is on); capacity regrown to %d" % (seen, self.capacity), RuntimeWarning)
             return False

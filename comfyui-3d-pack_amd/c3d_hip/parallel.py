@@ -73,6 +73,21 @@ class FlatGrads:
             self.views.append(self.flat[off:off + p.numel()].view(p.shape))
             off += sz
         self._gathered = None
+        # chunked, overlapped exchange (exchange_rows / exchange_finish): the row-sliceable "big" tensors -- those holding most of the bytes (f_rest: 45 of the
+        # 59 floats per Gaussian) -- go range by range; what is left forms a few contiguous spans of the flat buffer, reduced once at the end
+        total = float(sum(p.numel() for p in params)) or 1.0
+        self._big = [i for i, p in enumerate(params) if p.numel() / total >= 0.25]
+        self._rest_spans, off, start = [], 0, None
+        for i, (p, sz) in enumerate(zip(params, sizes)):
+            if i in self._big:
+                if start is not None:
+                    self._rest_spans.append((start, off)); start = None
+            elif start is None:
+                start = off
+            off += sz
+        if start is not None:
+            self._rest_spans.append((start, off))
+        self._works = []
 
     def exchange(self, group=None, mode="allgather", average=False):
         """sum (or mean) over the ranks of `group`, in place; identical bits on every rank"""
@@ -103,6 +118,32 @@ class FlatGrads:
                 flat.mul_(scale)
         else:
             raise ValueError("mode must be 'allgather' or 'allreduce'")
+
+
+    # ---- chunked exchange, overlapped with the kernels that produce the gradients (all-reduce mode) ------------------------------------------
+    def exchange_rows(self, g0, g1, group=None):
+        """Rows [g0, g1) of the big gradient tensors are final on the current stream: start their all-reduce now (async: the backend's stream waits
+        for what the current stream has enqueued so far, then runs underneath whatever is enqueued next -- the next Gaussian range of the
+        per-Gaussian backward pass).  Pair with exchange_finish()."""
+        if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1 or g1 <= g0:
+            return
+        for i in self._big:
+            self._works.append(dist.all_reduce(self.views[i][g0:g1], group=group, async_op=True))
+
+    def exchange_finish(self, group=None, average=False):
+        """all-reduce everything exchange_rows() does not cover (contiguous spans of the flat buffer), then make the current stream wait for all of it"""
+        if not dist.is_available() or not dist.is_initialized():
+            return
+        world = dist.get_world_size(group)
+        if world == 1:
+            return
+        for a, b in self._rest_spans:
+            self._works.append(dist.all_reduce(self.flat[a:b], group=group, async_op=True))
+        for w in self._works:
+            w.wait()
+        self._works = []
+        if average:
+            self.flat.mul_(1.0 / world)
 
 
 def broadcast_parameters(params, src=0, group=None):

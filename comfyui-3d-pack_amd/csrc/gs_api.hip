@@ -389,7 +389,8 @@ static int step_preprocess_all(const c3d_gs_settings* views, int V, int N, size_
 // per-Gaussian chain rule over all views of a step, every gradient written once (chunks of GS_MAX_BWD_VIEWS views); stream s0, after the join
 static int step_a8_all_views(const c3d_gs_settings* views, int V, int N, size_t slice_bytes, void* workspace, long long pair_capacity, const float* means3D,
                              const float* f_dc, const float* f_rest, const float* scaling_raw, const float* rotation_raw, float* dL_dmeans3D, float* dL_df_dc,
-                             float* dL_df_rest, float* dL_dopacity_raw, float* dL_dscaling_raw, float* dL_drotation_raw, bool accumulate, hipStream_t s0) {
+                             float* dL_df_rest, float* dL_dopacity_raw, float* dL_dscaling_raw, float* dL_drotation_raw, bool accumulate, hipStream_t s0,
+                             int first = 0, int count = -1) {
     const uint32_t cap = (uint32_t)pair_capacity;
     GsParams p_first{};
     for (int v0 = 0; v0 < V; v0 += GS_MAX_BWD_VIEWS) {
@@ -409,7 +410,7 @@ static int step_a8_all_views(const c3d_gs_settings* views, int V, int N, size_t 
         int rc;
         C3dProfScope ps(C3D_P_PREPROCESS_BWD, s0);
         if ((rc = gs_launch_preprocess_bwd_views(p_first, bv, means3D, f_dc, f_rest, scaling_raw, rotation_raw, dL_dopacity_raw, dL_dmeans3D, dL_df_dc, dL_df_rest,
-                                                 dL_dscaling_raw, dL_drotation_raw, accumulate || v0 > 0, s0, cap))) return rc;
+                                                 dL_dscaling_raw, dL_drotation_raw, accumulate || v0 > 0, s0, cap, first, count))) return rc;
     }
     return 0;
 }
@@ -498,8 +499,24 @@ int c3d_gs_train_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, c
         const int tiles = ((views[0].image_width + C3D_TILE_X - 1) / C3D_TILE_X) * ((views[0].image_height + C3D_TILE_Y - 1) / C3D_TILE_Y);
         if (gs_launch_sum_tile_loss(wf.tile_loss, w0.bytes, V, tiles, loss_out, s0)) return -1;
     }
+    if (accumulate & 2) return 0;   // the caller runs the per-Gaussian pass itself, range by range (c3d_gs_step_param_backward_range)
     return step_a8_all_views(views, V, N, w0.bytes, workspace, pair_capacity, means3D, f_dc, f_rest, scaling_raw, rotation_raw, dL_dmeans3D, dL_df_dc, dL_df_rest,
-                             dL_dopacity_raw, dL_dscaling_raw, dL_drotation_raw, accumulate != 0, s0);
+                             dL_dopacity_raw, dL_dscaling_raw, dL_drotation_raw, (accumulate & 1) != 0, s0);
+}
+
+int c3d_gs_step_param_backward_range(const c3d_gs_settings* views, int32_t V, int32_t N, const float* means3D, const float* f_dc, const float* f_rest,
+                                     const float* scaling_raw, const float* rotation_raw, float* dL_dmeans3D, float* dL_df_dc, float* dL_df_rest, float* dL_dopacity_raw,
+                                     float* dL_dscaling_raw, float* dL_drotation_raw, int64_t pair_capacity, int32_t accumulate, void* workspace, int32_t first,
+                                     int32_t count, c3d_stream_t stream) {
+    if (V <= 0 || N <= 0 || count == 0) return 0;
+    if (check_step_args("c3d_gs_step_param_backward_range", views, V, pair_capacity, 1, workspace)) return -1;
+    if (!means3D || !f_dc || !f_rest || !scaling_raw || !rotation_raw || !dL_dmeans3D || !dL_df_dc || !dL_df_rest || !dL_dopacity_raw || !dL_dscaling_raw || !dL_drotation_raw) {
+        c3d_set_error("c3d_gs_step_param_backward_range: NULL parameter / gradient pointer"); return -1; }
+    if ((uintptr_t)f_rest % 16 || (uintptr_t)dL_df_rest % 16 || (uintptr_t)rotation_raw % 16 || (uintptr_t)dL_drotation_raw % 16) { c3d_set_error("c3d_gs_step_param_backward_range: f_rest / rotation tensors must be 16-byte aligned"); return -1; }
+    if (first < 0 || count < 0 || (first & 3) || (long long)first + count > N) { c3d_set_error("c3d_gs_step_param_backward_range: range [%d, %d + %d) must lie inside [0, N) and start at a multiple of 4", first, first, count); return -1; }
+    StepWs w0; carve_step(nullptr, N, views[0].image_height, views[0].image_width, pair_capacity, w0);
+    return step_a8_all_views(views, V, N, w0.bytes, workspace, pair_capacity, means3D, f_dc, f_rest, scaling_raw, rotation_raw, dL_dmeans3D, dL_df_dc, dL_df_rest,
+                             dL_dopacity_raw, dL_dscaling_raw, dL_drotation_raw, accumulate != 0, (hipStream_t)stream, first, count);
 }
 
 // forward of V views; keep_state: view v uses workspace slice v (what c3d_gs_backward_views_raw reads), otherwise a lane reuses its slice view after view

@@ -695,9 +695,9 @@ __global__ void __launch_bounds__(256, 2) k_preprocess_bwd_views(GsParams p, GsB
 template <bool ACC, int CHUNK, int MINB>
 __global__ void __launch_bounds__(256, MINB) k_bwd_views_geom(GsParams p, GsBwdViews vs, const float* __restrict__ means3D, const float* __restrict__ scales,
                                                           const float* __restrict__ rotations, float* __restrict__ dL_dopacity, float* __restrict__ dL_dmeans3D,
-                                                          float* __restrict__ dL_dscales, float* __restrict__ dL_drots, uint32_t cap) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= p.N) return;
+                                                          float* __restrict__ dL_dscales, float* __restrict__ dL_drots, uint32_t cap, int first, int last) {
+    const int idx = first + blockIdx.x * blockDim.x + threadIdx.x;   // Gaussians [first, last): the whole cloud, or one range of a chunked pass
+    if (idx >= last) return;
     const float3 m = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
     float3 sc = make_float3(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]);
     float4 q = *reinterpret_cast<const float4*>(rotations + 4 * idx);
@@ -792,12 +792,13 @@ __global__ void __launch_bounds__(256, MINB) k_bwd_views_geom(GsParams p, GsBwdV
 struct GsShViews { int V; const float* campos[GS_MAX_BWD_VIEWS]; const float* gcol[GS_MAX_BWD_VIEWS]; };
 // dL/dSH over all views + the view-direction term of dL/dmean (added to what k_bwd_views_geom wrote)
 template <bool ACC>
-__global__ void __launch_bounds__(256) k_bwd_views_sh(int N, int deg, GsShViews vs, const float* __restrict__ means3D, const float* __restrict__ f_dc,
+__global__ void __launch_bounds__(256) k_bwd_views_sh(int first, int last, int deg, GsShViews vs, const float* __restrict__ means3D, const float* __restrict__ f_dc,
                                                         const float* __restrict__ f_rest, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_df_dc,
                                                         float* __restrict__ dL_df_rest) {
     extern __shared__ float sh_lds[];
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t g0 = (size_t)blockIdx.x * blockDim.x;
+    const int N = last;                                              // Gaussians [first, last); `first` is a multiple of 4 (16-byte rows of f_rest)
+    const int idx = first + blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t g0 = (size_t)first + (size_t)blockIdx.x * blockDim.x;
     const int gcount = min((int)blockDim.x, N - (int)g0);
     float* shl = sh_lds + threadIdx.x * SH_ROW;
     sh_stage_in_split(f_dc, f_rest, g0, gcount, sh_lds);
@@ -848,22 +849,27 @@ static bool gs_a8_split() {
 
 int gs_launch_preprocess_bwd_views(const GsParams& p0, const GsBwdViews& views, const float* means3D, const float* f_dc, const float* f_rest,
                                    const float* scaling_raw, const float* rotation_raw, float* dL_dopacity_raw, float* dL_dmeans3D, float* dL_df_dc,
-                                   float* dL_df_rest, float* dL_dscaling_raw, float* dL_drotation_raw, bool accumulate, hipStream_t s, uint32_t cap) {
+                                   float* dL_df_rest, float* dL_dscaling_raw, float* dL_drotation_raw, bool accumulate, hipStream_t s, uint32_t cap, int first, int count) {
     if (p0.N == 0 || views.V == 0) return 0;
-    const dim3 grid(c3d_cdiv(p0.N, 256)), block(256);
+    const bool whole = (first == 0 && (count < 0 || count >= p0.N));
+    if (count < 0) count = p0.N - first;
+    if (first < 0 || count < 0 || first + count > p0.N || (first & 3)) { c3d_set_error("gs_launch_preprocess_bwd_views: bad Gaussian range [%d, %d + %d)", first, first, count); return -1; }
+    if (count == 0) return 0;
+    const int last = first + count;
+    const dim3 grid(c3d_cdiv(count, 256)), block(256);
     const size_t lds = 256 * SH_ROW * sizeof(float);
-    if (gs_a8_split()) {
+    if (gs_a8_split() || !whole) {
         GsShViews sv;
         sv.V = views.V;
         for (int i = 0; i < views.V; i++) { sv.campos[i] = views.v[i].campos; sv.gcol[i] = views.v[i].gcol; }
         // four pairs in flight, four workgroups per CU (128 VGPRs): eight in flight (160 VGPRs) and two or three (96, spilling) measure the same or worse
-#define GS_A8_GEOM(ACC_) hipLaunchKernelGGL((k_bwd_views_geom<ACC_, 4, 4>), grid, block, 0, s, p0, views, means3D, scaling_raw, rotation_raw, dL_dopacity_raw, dL_dmeans3D, dL_dscaling_raw, dL_drotation_raw, cap)
+#define GS_A8_GEOM(ACC_) hipLaunchKernelGGL((k_bwd_views_geom<ACC_, 4, 4>), grid, block, 0, s, p0, views, means3D, scaling_raw, rotation_raw, dL_dopacity_raw, dL_dmeans3D, dL_dscaling_raw, dL_drotation_raw, cap, first, last)
         if (accumulate) {
             GS_A8_GEOM(true);
-            hipLaunchKernelGGL((k_bwd_views_sh<true>), grid, block, lds, s, p0.N, p0.deg, sv, means3D, f_dc, f_rest, dL_dmeans3D, dL_df_dc, dL_df_rest);
+            hipLaunchKernelGGL((k_bwd_views_sh<true>), grid, block, lds, s, first, last, p0.deg, sv, means3D, f_dc, f_rest, dL_dmeans3D, dL_df_dc, dL_df_rest);
         } else {
             GS_A8_GEOM(false);
-            hipLaunchKernelGGL((k_bwd_views_sh<false>), grid, block, lds, s, p0.N, p0.deg, sv, means3D, f_dc, f_rest, dL_dmeans3D, dL_df_dc, dL_df_rest);
+            hipLaunchKernelGGL((k_bwd_views_sh<false>), grid, block, lds, s, first, last, p0.deg, sv, means3D, f_dc, f_rest, dL_dmeans3D, dL_df_dc, dL_df_rest);
         }
 #undef GS_A8_GEOM
         C3D_LAUNCH_CHECK();

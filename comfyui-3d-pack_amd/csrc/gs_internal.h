@@ -133,7 +133,8 @@ struct GsBwdViews { int V; GsBwdView v[GS_MAX_BWD_VIEWS]; };
 // kernels' launchers (gs_forward.hip / gs_backward.hip)
 int gs_launch_preprocess_bwd_views(const GsParams& p0, const GsBwdViews& views, const float* means3D, const float* f_dc, const float* f_rest,
                                    const float* scaling_raw, const float* rotation_raw, float* dL_dopacity_raw, float* dL_dmeans3D, float* dL_df_dc,
-                                   float* dL_df_rest, float* dL_dscaling_raw, float* dL_drotation_raw, bool accumulate, hipStream_t s, uint32_t cap);
+                                   float* dL_df_rest, float* dL_dscaling_raw, float* dL_drotation_raw, bool accumulate, hipStream_t s, uint32_t cap,
+                                   int first = 0, int count = -1);   // Gaussians [first, first + count): a chunked pass (first % 4 == 0); default = all
 int gs_launch_preprocess(const GsParams& p, const float* means3D, const float* shs, const float* colors_precomp,
                          const float* opacities, const float* scales, const float* rotations, const float* cov3D_precomp,
                          GsGeom& g, int* radii, hipStream_t s);

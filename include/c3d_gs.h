@@ -137,7 +137,11 @@ typedef struct c3d_gs_loss { float w_l1; float w_l2; float w_alpha_mse; float sc
  * joined back into `stream` with events, so the call keeps stream semantics) -- the latency-bound sort/scan chain of one view then runs underneath
  * the compositing kernels of another.  After the join ONE kernel walks the Gaussians, sums each view's (tile, splat) gradient records in a fixed
  * order and writes every parameter gradient once: results are bit-reproducible and independent of `lanes`.
- * accumulate != 0: add to the contents of the gradient buffers; 0: overwrite them (no zero-fill needed). */
+ * accumulate bit 0: add to the contents of the gradient buffers; clear: overwrite them (no zero-fill needed).
+ * accumulate bit 1 (value 2): stop after the per-view passes -- the per-(tile, splat) records of all views are then in the workspace and the caller
+ * runs the per-Gaussian pass itself with c3d_gs_step_param_backward_range, one Gaussian range after the other, e.g. to start the gradient
+ * exchange of a range (multi-GPU) while the next range is still being computed.  The ranges together must cover [0, N) once; each
+ * starts at a multiple of 4.  Results are bit-identical to the unchunked call. */
 size_t c3d_gs_step_workspace_bytes(int32_t N, int32_t image_height, int32_t image_width, int64_t pair_capacity, int32_t views);
 int c3d_gs_train_views_raw(const c3d_gs_settings* views /* host [V] */, int32_t V, int32_t N, const float* means3D, const float* f_dc,
                            const float* f_rest, const float* opacity_raw, const float* scaling_raw, const float* rotation_raw,
@@ -146,6 +150,11 @@ int c3d_gs_train_views_raw(const c3d_gs_settings* views /* host [V] */, int32_t 
                            float* dL_dmeans3D, float* dL_df_dc, float* dL_df_rest, float* dL_dopacity_raw, float* dL_dscaling_raw,
                            float* dL_drotation_raw, float* loss_out, int64_t pair_capacity, int32_t lanes, int32_t accumulate, void* workspace,
                            uint32_t* status /* device [2] */, c3d_stream_t stream);
+
+int c3d_gs_step_param_backward_range(const c3d_gs_settings* views /* host [V] */, int32_t V, int32_t N, const float* means3D, const float* f_dc,
+                                     const float* f_rest, const float* scaling_raw, const float* rotation_raw, float* dL_dmeans3D, float* dL_df_dc,
+                                     float* dL_df_rest, float* dL_dopacity_raw, float* dL_dscaling_raw, float* dL_drotation_raw, int64_t pair_capacity,
+                                     int32_t accumulate, void* workspace, int32_t first, int32_t count, c3d_stream_t stream);
 
 /* Forward only, V views of the same cloud in one call (orbit rendering of a trained model: the per-camera loop of the reference's
  * orbit-renderer node over GaussianSplattingRenderer.render, main_3DGS_renderer.py:927-936), raw parameters, no host synchronisation,

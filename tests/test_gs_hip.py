@@ -577,6 +577,49 @@ def test_fused_step_deferred_status():
         assert torch.equal(a, b)
 
 
+def test_fused_step_param_backward_by_gaussian_ranges():
+    """run(param_chunks=K, after_chunk=...): the per-Gaussian backward pass range by range (c3d_gs_step_param_backward_range) -- what the multi-GPU
+    step uses to start a range's gradient exchange underneath the next range's kernels.  Same bits as the one-launch pass; the callback sees
+    every row exactly once, in order, and (here) checks that the rows it is handed are already final on the stream."""
+    from MVs_Algorithms.GaussianSplatting.main_3DGS_renderer import GaussianSplattingRenderer
+    from c3d_hip.gs_step import FusedViewStep
+    N = 30001                                                           # not a multiple of the 256-Gaussian range granularity
+    raw = S.make_cloud(N, seed=6, log_scale_mean=np.log(0.015), activated=False)
+    W, H = 192, 128
+    r = GaussianSplattingRenderer(sh_degree=3, device="cuda")
+    r.initialize({"xyz": raw["means3D"], "features": raw["shs"], "scaling_raw": raw["scales"], "rotation_raw": raw["rotations"], "opacity_raw": raw["opacities"]})
+    g = r.gaussians
+    plist = [q.detach() for q in (g._xyz, g._features_dc, g._features_rest, g._opacity, g._scaling, g._rotation)]
+    rs = [hip_settings(S.camera_settings(W, H, 49.1, el, az, 2.2, bg=(1, 1, 1)), "cuda") for el, az in ((-20.0, 10.0), (15.0, 130.0), (40.0, -100.0))]
+    rng = np.random.default_rng(0)
+    tcs = [_dev(rng.uniform(size=(3, H, W)).astype(np.float32), torch.float32) for _ in rs]
+    tas = [_dev(rng.uniform(size=(1, H, W)).astype(np.float32), torch.float32) for _ in rs]
+    step = FusedViewStep(N, H, W, "cuda", lanes=2)
+    ref = [torch.empty_like(q) for q in plist]
+    l0 = step.run(rs, plist, ref, tcs, tas, None, w_l1=0.8, w_alpha_mse=3.0, scale=1 / 3, accumulate=False)      # fits the capacity; one launch
+    assert step._fitted
+    for chunks in (1, 3, 7):
+        grads = [torch.full_like(q, float("nan")) for q in plist]
+        seen, snaps = [], []
+
+        def after(g0, g1):
+            seen.append((g0, g1))
+            snaps.append([q[g0:g1].clone() for q in grads])             # stream-ordered copy: what a collective launched here would read
+        l1 = step.run(rs, plist, grads, tcs, tas, None, w_l1=0.8, w_alpha_mse=3.0, scale=1 / 3, accumulate=False, param_chunks=chunks, after_chunk=after)
+        assert len(seen) == chunks and seen[0][0] == 0 and seen[-1][1] == N and all(a[1] == b[0] for a, b in zip(seen[:-1], seen[1:]))
+        assert all(a % 256 == 0 for a, _ in seen)
+        assert torch.equal(l0, l1)
+        for a, b in zip(grads, ref):
+            assert torch.equal(a, b)
+        for (g0, g1), snap in zip(seen, snaps):
+            for a, b in zip(snap, ref):
+                assert torch.equal(a, b[g0:g1])
+    import c3d_hip
+    lib = c3d_hip.lib()
+    assert lib.c3d_gs_step_param_backward_range(None, 1, N, *([None] * 5), *([None] * 6), 100, 0, None, 2, 10, None) != 0      # argument checks come first
+    assert b"NULL" in lib.c3d_last_error()
+
+
 @pytest.mark.parametrize("lambda_ssim,offsets", [(0.0, False), (0.2, False), (0.2, True)])
 def test_trainer_fused_step_equals_autograd_step(lambda_ssim, offsets):
     """GaussianSplatting3D.training_step with the reference's node defaults -- lambda_ssim 0.2, invert_bg_prob 0.5 (nodes.py:1177,1181) -- and

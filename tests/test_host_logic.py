@@ -95,7 +95,16 @@ def _worker(rank, world, port, mode, out):
     for v_, p in zip(fg.views, params):
         v_.copy_(p.grad)
     assert all(v_.data_ptr() % 16 == 0 for v_ in fg.views)
+    fg2 = parallel.FlatGrads(params)        # the chunked, overlapped form of the all-reduce: big tensors range by range, the rest at the end
+    for v_, p in zip(fg2.views, params):
+        v_.copy_(p.grad)
     fg.exchange(None, mode, average=False)
+    if mode == "allreduce":
+        assert fg2._big == [2] and len(fg2._rest_spans) == 2          # f_rest goes by rows; [xyz | f_dc] and [opacity | scaling | rotation] are the two spans left
+        for g0, g1 in ((0, 100), (100, 256), (256, 257)):
+            fg2.exchange_rows(g0, g1)
+        fg2.exchange_finish()
+        assert torch.equal(fg2.flat, fg.flat)
     parallel.exchange_gradients(params, None, mode, average=False)
     flat = parallel.flatten_grads(params)
     assert flat.shape == (N, 59)
