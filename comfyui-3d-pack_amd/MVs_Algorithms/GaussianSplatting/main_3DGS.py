@@ -87,6 +87,7 @@ class GaussianSplatting3D:
         self.device = torch.device(device)
         self.gs_params = gs_params = gs_params or GSParams()
         self.group, self.exchange = process_group, exchange
+        self.exchange_chunks = 1      # > 1 (fused step, world > 1, "allreduce"): overlap the gradient exchange with the per-Gaussian backward pass, range by range
         self.renderer = GaussianSplattingRenderer(sh_degree=gs_params.sh_degree, device=device)
         self.renderer.initialize(init_input, num_pts=gs_params.num_pts)
         g = self.renderer.gaussians
@@ -230,15 +231,21 @@ class GaussianSplatting3D:
             views.append(GaussianRasterizationSettings(H, W, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), bg, 1.0,
                                                        cam.world_view_transform, cam.full_proj_transform, 3, cam.camera_center, False, False))
         n_mine = max(len(mine), 1)
+        overlapped = False
         plist = [q.detach() for q in self.params]
         if len(mine) == 0 or not self.image_loss_in_torch:
             # The whole image loss of main_3DGS.py:184-192 inside ONE library call: loss value and dL/dimage of the L1 / alpha-MSE terms come out of
             # a fused pixel pass, the MS-SSIM term (weight lambda_ssim, include/c3d_loss.h) from the HIP multi-scale SSIM kernels on the view's lane.
             # (c - ref) * mask: the unmasked reference is the target and the mask the pixel weight, as the reference's (c * m - ref * m).
+            # world > 1, all-reduce mode, exchange_chunks > 1: the per-Gaussian backward pass goes by Gaussian ranges and each range's f_rest rows
+            # start their all-reduce underneath the next range's kernels (FlatGrads.exchange_rows); the rest follows in exchange_finish below
+            overlapped = world > 1 and self.exchange == "allreduce" and self.exchange_chunks > 1
             loss = self._step.run(views, plist, self._step_grads, [self.ref_imgs_torch[i].contiguous() for i in mine],
                                   [self.ref_masks_torch[i].contiguous() for i in mine], [self.ref_masks_torch[i].contiguous() for i in mine],
                                   w_l1=1.0 - p.lambda_ssim, w_l2=0.0, w_alpha_mse=p.lambda_alpha, scale=1.0 / n_mine, w_ssim=p.lambda_ssim,
-                                  accumulate=False)      # every gradient is written exactly once: no zero-fill
+                                  accumulate=False,      # every gradient is written exactly once: no zero-fill
+                                  param_chunks=(self.exchange_chunks if overlapped else 1),
+                                  after_chunk=((lambda g0, g1: self._flat_grads.exchange_rows(g0, g1, self.group)) if overlapped else None))
         else:
             # the same step split at the image: forward all views -> torch differentiates the image loss -> backward all views (any loss torch can express)
             colors, _, alphas, _ = self._step.forward(views, plist)
@@ -261,7 +268,10 @@ class GaussianSplatting3D:
             if go is not None:
                 self._step_grads[3].add_(go)
             loss = loss + reg.detach()
-        self._flat_grads.exchange(self.group, self.exchange, average=True)
+        if overlapped:
+            self._flat_grads.exchange_finish(self.group, average=True)
+        else:
+            self._flat_grads.exchange(self.group, self.exchange, average=True)
         for q, gq in zip(self.params, self._step_grads):
             q.grad = gq
         self.optimizer.step()

@@ -57,17 +57,28 @@ class FusedViewStep:
         """params / grads: (xyz, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw) tensors; accumulate=True adds to the grads (zero them per
         step), False overwrites them (no zero-fill needed).  -> loss tensor (device scalar, the sum over the views).  Synchronises once, at
         the end, to read the overflow flag.
-        after_chunk(g0, g1): called when the gradient rows [g0, g1) of every tensor have been ENQUEUED in final form on the current stream --
-        with param_chunks > 1 (and a fitted capacity, accumulate=False) the per-Gaussian pass runs range by range and the callback follows each
-        range (the multi-GPU trainer starts that range's collective there, underneath the next range's kernels); otherwise once, with (0, N)."""
+        after_chunk(g0, g1): called when the gradient rows [g0, g1) of every tensor have been ENQUEUED in final form on the current stream, for the
+        SAME sequence of `param_chunks` ranges on every call (so that ranks which start a collective per range stay in step, whatever their local
+        state): with a fitted capacity and accumulate=False the per-Gaussian pass runs range by range and the callback follows each range (the
+        multi-GPU trainer starts that range's collective there, underneath the next range's kernels); otherwise -- first step, no views on this
+        rank -- the ranges are handed over one after the other once the whole pass has been enqueued and found good."""
         lib = _h.lib()
         V = len(raster_settings)
+        K = max(1, int(param_chunks)) if self.N >= 1024 * max(1, int(param_chunks)) else 1
+        bounds = [min(self.N, (self.N * i // K + 255) // 256 * 256) for i in range(K)] + [self.N]
+        ranges = list(zip(bounds[:-1], bounds[1:]))
+
+        def hand_over():
+            if after_chunk is not None:
+                for g0, g1 in ranges:
+                    after_chunk(g0, g1)
         prev, self._pending = self._pending, None      # a deferred previous step: examined AFTER this one is enqueued, so the GPU never waits for the host
         if V == 0:
             self._examine(prev)                       # a rank without views this step still owns well-defined gradients
             if not accumulate:
                 for g in grads:
                     g.zero_()
+            hand_over()
             return torch.zeros(1, dtype=torch.float32, device=self.device)
         if V > self.views:
             self.views = V
@@ -86,7 +97,7 @@ class FusedViewStep:
             if self.time_events:
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record(torch.cuda.current_stream(self.device))
-            chunked = param_chunks > 1 and after_chunk is not None and self._fitted and not accumulate and self.N >= 1024 * param_chunks
+            chunked = K > 1 and after_chunk is not None and self._fitted and not accumulate
             self._chunks_went_out = chunked
             with torch.cuda.device(self.device):
                 pp = [_h.ptr(_h.f32c(p)) for p in params]
@@ -94,8 +105,7 @@ class FusedViewStep:
                                                     *[_h.ptr(g) for g in grads], _h.ptr(self.loss), self.capacity, self.lanes, (1 if accumulate else 0) | (2 if chunked else 0),
                                                     _h.ptr(self.workspace), _h.ptr(self.status), _h.stream(self.device)), "c3d_gs_train_views_raw")
                 if chunked:
-                    bounds = [min(self.N, (self.N * i // param_chunks + 255) // 256 * 256) for i in range(param_chunks)] + [self.N]
-                    for g0, g1 in zip(bounds[:-1], bounds[1:]):
+                    for g0, g1 in ranges:
                         _h.check(lib.c3d_gs_step_param_backward_range(views, V, self.N, pp[0], pp[1], pp[2], pp[4], pp[5], *[_h.ptr(g) for g in grads], self.capacity, 0,
                                                                       _h.ptr(self.workspace), g0, g1 - g0, _h.stream(self.device)), "c3d_gs_step_param_backward_range")
                         after_chunk(g0, g1)
@@ -117,8 +127,8 @@ class FusedViewStep:
                     prev = None
                     self._pending = None
                     continue             # the previous step had overflowed (capacity regrown): this one certainly did too -- redo it, synchronously
-                if after_chunk is not None and not chunked:
-                    after_chunk(0, self.N)
+                if not chunked:
+                    hand_over()
                 return out
             if prev is not None:
                 self._examine(prev)
@@ -135,8 +145,8 @@ class FusedViewStep:
                     self.capacity = int(seen * 1.3) + 4096
                     self._alloc()
                 self._fitted = True
-                if after_chunk is not None and not chunked:
-                    after_chunk(0, self.N)
+                if not chunked:
+                    hand_over()
                 return self.loss.clone()
             if chunked:
                 raise RuntimeError("c3d FusedViewStep: a step whose gradient ranges had already been handed to after_chunk exceeded the pair capacity (%d pairs)" % (st[1] & 0xFFFFFFFF))
