@@ -483,8 +483,14 @@ def main():
     # from the committed summary of two separate --pmc passes over this same command (profiles/summarize_pmc.py; FETCH_SIZE raw + WRITE_SIZE,
     # MI355X_MICROARCH.md: FETCH_SIZE under-reports wide streaming reads by 2x on gfx950 -- both figures are in the file).
     pmc, pmc_file, pmc_stale = load_profile_json("_pmc_traffic.json", exclude="_mesh_")
-    pmc_name = {"gs_composite_bwd": "k_composite_bwd", "gs_composite_fwd": "k_composite_fwd", "gs_preprocess": "k_preprocess<true, true>",
-                "gs_preprocess_bwd": "k_preprocess_bwd<true, true, true>", "gs_emit": "k_emit"}
+    # kernel behind a profiling group; template instances ("k_composite_bwd<true>": with the fused pixel loss) are matched by base name, most launches first
+    pmc_base = {"gs_composite_bwd": "k_composite_bwd", "gs_composite_fwd": "k_composite_fwd", "gs_preprocess": "k_preprocess_views",
+                "gs_preprocess_bwd": "k_bwd_views_geom", "gs_emit": "k_emit"}
+
+    def kernel_row(table, group, launches=lambda r: r.get("launches", 0)):
+        base = pmc_base.get(group)
+        cand = [k for k in table if not k.startswith("_") and k.split("<")[0].strip() == base]
+        return max(cand, key=lambda k: float(launches(table[k]))) if cand else None
     if prof:
         dom = max(prof, key=lambda k: prof[k][0])
         avg_s = prof[dom][0] / prof[dom][1] * 1e-3
@@ -492,10 +498,11 @@ def main():
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None, "avg_ms": round(avg_s * 1e3, 4),
                 "alg_bytes_per_launch": int(alg.get(dom, 0))}
-        rec = pmc.get(pmc_name.get(dom, ""))
+        rec_name = kernel_row(pmc, dom)
+        rec = pmc.get(rec_name) if rec_name else None
         if rec and a.workload == "gs" and N == 1_000_000 and (W, H) == (1920, 1080):
             roof["traffic"] = int((rec["fetch_MB_raw"] + rec["write_MB"]) * 1e6)
-            roof["traffic_note"] = "FETCH_SIZE(raw)+WRITE_SIZE per launch from profiles/%s (same code digest); fetch x2-corrected: %d" % (pmc_file, int((rec["fetch_MB_x2"] + rec["write_MB"]) * 1e6))
+            roof["traffic_note"] = "FETCH_SIZE(raw)+WRITE_SIZE per launch of %s from profiles/%s (same code digest); fetch x2-corrected: %d" % (rec_name, pmc_file, int((rec["fetch_MB_x2"] + rec["write_MB"]) * 1e6))
         elif pmc_stale:
             roof["stale"] = "profiles/%s was measured on code %s, this is %s" % (pmc_file, pmc_stale, code_digest())
 
@@ -508,13 +515,15 @@ def main():
             if sq and not (os.path.exists(sq_meta) and json.load(open(sq_meta)).get("code_digest") == code_digest()):
                 roof["issue"] = {"stale": "profiles/%s describes other kernel code" % sq[-1]}
                 sq = []
-            if sq and pmc_name.get(dom):
-                for row in csv.DictReader(open(os.path.join(ROOT, "profiles", sq[-1]))):
-                    if row["kernel"] == pmc_name[dom]:
+            if sq and pmc_base.get(dom):
+                rows = {row["kernel"]: row for row in csv.DictReader(open(os.path.join(ROOT, "profiles", sq[-1])))}
+                hit = kernel_row(rows, dom, launches=lambda r: r.get("launches", 0))
+                for row in ([rows[hit]] if hit else []):
+                    if True:
                         n_ins = sum(float(row[c]) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_BRANCH", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM")) / 32.0
                         roof["issue"] = {"instructions_per_simd": int(n_ins), "valu": int(float(row["SQ_INSTS_VALU"]) / 32), "salu": int(float(row["SQ_INSTS_SALU"]) / 32),
                                          "busy_cycles": int(float(row["SQ_BUSY_CYCLES"])), "cycles_per_instruction": round(float(row["SQ_BUSY_CYCLES"]) / n_ins, 2),
-                                         "source": "profiles/" + sq[-1]}
+                                         "kernel": hit, "source": "profiles/" + sq[-1]}
         except Exception:
             pass
         if prof_conc is not None:

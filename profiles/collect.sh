@@ -44,6 +44,7 @@ if [ -z "$QUICK" ]; then
   python bench.py --render-path fused --cpu-baseline off 2>/dev/null | tail -1 > $OUT/${TAG}_bench_renderer_api_n1.json
   python bench.py --render-path boundary --cpu-baseline off 2>/dev/null | tail -1 > $OUT/${TAG}_bench_boundary_api_n1.json
   python profiles/microbench/sort_phases.py > $OUT/${TAG}_sort_phases.txt 2>&1
+  python profiles/microbench/pair_activity.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_pair_activity.txt
 fi
 head -12 $OUT/${TAG}_fwdbwd_kernel_stats.csv
 head -12 $OUT/${TAG}_pmc_traffic.csv
