@@ -1,7 +1,8 @@
 // msssim.hip -- multi-scale SSIM value + gradient (include/c3d_loss.h) for the trainers' loss term
 //   loss += lambda * (1 - MS_SSIM(refs, imgs))        main_3DGS.py:192, diff_mesh.py:123 (reference)
-// One workgroup = one 32 x 32 tile of one (image, channel) plane; the five 11-tap separable Gaussian filters of a level (x, y, x^2, y^2, xy)
-// run through LDS: a 42 x 42 input tile, a horizontal pass into a 5 x 42 x 32 intermediate, a vertical pass of four outputs per lane.
+// One workgroup = one 32 x 16 tile of one (image, channel) plane; the five 11-tap separable Gaussian filters of a level (x, y, x^2, y^2, xy)
+// run through LDS: a 42 x 26 input tile, a horizontal pass into a 5 x 26 x 32 intermediate (four outputs per item), a vertical pass of two
+// outputs per lane.
 // Backward: the three per-pixel derivative maps the forward pass leaves behind (d map / d mu_y, d map / d E[y^2], d map / d E[xy]) are
 // filtered with the transposed (= same, the window is symmetric) filters, zero padded, and combined with x, y and the level's scalar
 // dL/d(mean map); the 2 x 2 average pooling between levels is chained by reading the parent level's finished gradient.
@@ -11,12 +12,22 @@
 #include <math.h>
 
 #define MS_LEVELS 5
-#define MS_T 32
+// Tile: 32 wide x 16 tall.  A 32 x 32 tile needs 42 KB of LDS (three workgroups per CU): its phases -- global loads, horizontal pass, vertical
+// pass, each behind a barrier -- then run almost unoverlapped and the level-0 kernels sat at twice their VALU time.  The half-height tile takes
+// 26 KB (six workgroups per CU) for 24 % more halo loads and the same filter arithmetic per output (the horizontal pass is one full-width sweep
+// of 26 x 8 items instead of two of 256 + 80).
+#define MS_T 32                         // tile width
+#define MS_TY 16                        // tile height
 #define MS_R 5
-#define MS_IN (MS_T + 2 * MS_R)
+#define MS_IN (MS_T + 2 * MS_R)         // input columns of a tile
+#define MS_INY (MS_TY + 2 * MS_R)       // input rows
+#define MS_VO (MS_TY / 8)               // vertically adjacent outputs per lane in the vertical pass (256 lanes = 32 columns x 8 row groups)
 #define MS_C1 (0.01f * 0.01f)
 #define MS_C2 (0.03f * 0.03f)
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+// w * a + b on two lanes of a register pair: v_pk_fma_f32 with the scalar weight broadcast
+__device__ __forceinline__ v2f ms_fma2(float w, v2f a, v2f b) { return __builtin_elementwise_fma(v2f{w, w}, a, b); }
 struct MsWin { float w[2 * MS_R + 1]; };
 struct MsLevel { int H, W, Hv, Wv, tx, ty; };          // image size, valid (filtered) size, tiles over the valid size
 
@@ -61,14 +72,17 @@ template <bool LAST, bool L0>
 __global__ void __launch_bounds__(256) k_ms_fwd(const float* __restrict__ X, const float* __restrict__ Y, const float* __restrict__ mask, int clamp_y, int C,
                                                 MsLevel lv, MsWin win, float* __restrict__ mapA, float* __restrict__ mapB, float* __restrict__ mapC,
                                                 float* __restrict__ partial) {
-    __shared__ float sx[MS_IN][MS_IN + 1];
-    __shared__ float sy[MS_IN][MS_IN + 1];
-    __shared__ float hh[5][MS_IN][MS_T + 1];
+    // Quantities travel in pairs -- (x, y), (x^2, y^2) -- so that one v_pk_fma_f32 filters two of them (the kernel is VALU bound: 3 instructions
+    // per tap and output instead of the 7 of the scalar form with its products inside the loop); xy goes alone.
+    __shared__ v2f sxy[MS_INY][MS_IN + 1];
+    __shared__ v2f h01[MS_INY][MS_T + 1];      // horizontally filtered (x, y)
+    __shared__ v2f h23[MS_INY][MS_T + 1];      //                       (x^2, y^2)
+    __shared__ float h4[MS_INY][MS_T + 1];     //                       xy
     __shared__ float red[4];
-    const int plane = blockIdx.z, ox = blockIdx.x * MS_T, oy = blockIdx.y * MS_T;
+    const int plane = blockIdx.z, ox = blockIdx.x * MS_T, oy = blockIdx.y * MS_TY;
     const size_t HW = (size_t)lv.H * lv.W;
-    {   // all of a lane's loads are issued before the first LDS store (an un-unrolled loop waits for each load in turn: 7 memory latencies per workgroup)
-        constexpr int NL = (MS_IN * MS_IN + 255) / 256;
+    {   // all of a lane's loads are issued before the first LDS store (an un-unrolled loop waits for each load in turn)
+        constexpr int NL = (MS_INY * MS_IN + 255) / 256;
         float xs_[NL], ys_[NL];
 #pragma unroll
         for (int i = 0; i < NL; i++) {
@@ -76,54 +90,58 @@ __global__ void __launch_bounds__(256) k_ms_fwd(const float* __restrict__ X, con
             const int r = e / MS_IN, c = e - r * MS_IN;
             const int iy = oy + r, ix = ox + c;
             xs_[i] = 0.f; ys_[i] = 0.f;
-            if (e < MS_IN * MS_IN && iy < lv.H && ix < lv.W) ms_load<L0>(X, Y, mask, clamp_y, C, plane, HW, (size_t)iy * lv.W + ix, xs_[i], ys_[i]);
+            if (e < MS_INY * MS_IN && iy < lv.H && ix < lv.W) ms_load<L0>(X, Y, mask, clamp_y, C, plane, HW, (size_t)iy * lv.W + ix, xs_[i], ys_[i]);
         }
 #pragma unroll
         for (int i = 0; i < NL; i++) {
             const int e = threadIdx.x + 256 * i;
-            if (e < MS_IN * MS_IN) { const int r = e / MS_IN, c = e - r * MS_IN; sx[r][c] = xs_[i]; sy[r][c] = ys_[i]; }
+            if (e < MS_INY * MS_IN) { const int r = e / MS_IN, c = e - r * MS_IN; sxy[r][c] = v2f{xs_[i], ys_[i]}; }
         }
     }
     __syncthreads();
-    // horizontal pass, four adjacent outputs per item: the 14 inputs of x and y they share are read once (7 LDS reads per output instead of 22)
-    for (int e = threadIdx.x; e < MS_IN * (MS_T / 4); e += 256) {
+    // horizontal pass, four adjacent outputs per item: the 14 inputs they share are read once (one 8-byte LDS read each) and squared once
+    for (int e = threadIdx.x; e < MS_INY * (MS_T / 4); e += 256) {
         const int r = e >> 3, c0 = (e & 7) * 4;
-        float xv[14], yv[14];
+        v2f p[14], q[14];
+        float xy[14];
 #pragma unroll
-        for (int k = 0; k < 14; k++) { xv[k] = sx[r][c0 + k]; yv[k] = sy[r][c0 + k]; }
+        for (int k = 0; k < 14; k++) { p[k] = sxy[r][c0 + k]; q[k] = p[k] * p[k]; xy[k] = p[k].x * p[k].y; }
 #pragma unroll
         for (int o = 0; o < 4; o++) {
-            float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+            v2f a01 = v2f{0.f, 0.f}, a23 = v2f{0.f, 0.f};
+            float a4 = 0.f;
 #pragma unroll
             for (int k = 0; k < 2 * MS_R + 1; k++) {
-                const float x = xv[o + k], y = yv[o + k], w = win.w[k];
-                const float wx = w * x, wy = w * y;
-                m1 += wx; m2 += wy; e11 += wx * x; e22 += wy * y; e12 += wx * y;
+                const float w = win.w[k];
+                a01 = ms_fma2(w, p[o + k], a01); a23 = ms_fma2(w, q[o + k], a23); a4 = __builtin_fmaf(w, xy[o + k], a4);
             }
-            hh[0][r][c0 + o] = m1; hh[1][r][c0 + o] = m2; hh[2][r][c0 + o] = e11; hh[3][r][c0 + o] = e22; hh[4][r][c0 + o] = e12;
+            h01[r][c0 + o] = a01; h23[r][c0 + o] = a23; h4[r][c0 + o] = a4;
         }
     }
     __syncthreads();
-    // vertical pass, four vertically adjacent outputs per lane: 14 rows of the intermediate per quantity for 4 outputs (17.5 reads per output instead of 55)
-    const int c = threadIdx.x & 31, r0 = (threadIdx.x >> 5) * 4;
-    float acc[4][5];
+    // vertical pass, MS_VO vertically adjacent outputs per lane: 10 + MS_VO rows of the intermediate per quantity
+    const int c = threadIdx.x & 31, r0 = (threadIdx.x >> 5) * MS_VO;
+    float acc[MS_VO][5];
+    {
+        v2f c01[2 * MS_R + MS_VO], c23[2 * MS_R + MS_VO];
+        float c4[2 * MS_R + MS_VO];
 #pragma unroll
-    for (int o = 0; o < 4; o++)
+        for (int k = 0; k < 2 * MS_R + MS_VO; k++) { c01[k] = h01[r0 + k][c]; c23[k] = h23[r0 + k][c]; c4[k] = h4[r0 + k][c]; }
 #pragma unroll
-        for (int q = 0; q < 5; q++) acc[o][q] = 0.f;
+        for (int o = 0; o < MS_VO; o++) {
+            v2f a01 = v2f{0.f, 0.f}, a23 = v2f{0.f, 0.f};
+            float a4 = 0.f;
 #pragma unroll
-    for (int q = 0; q < 5; q++) {
-        float col[14];
-#pragma unroll
-        for (int k = 0; k < 14; k++) col[k] = hh[q][r0 + k][c];
-#pragma unroll
-        for (int o = 0; o < 4; o++)
-#pragma unroll
-            for (int k = 0; k < 2 * MS_R + 1; k++) acc[o][q] += win.w[k] * col[o + k];
+            for (int k = 0; k < 2 * MS_R + 1; k++) {
+                const float w = win.w[k];
+                a01 = ms_fma2(w, c01[o + k], a01); a23 = ms_fma2(w, c23[o + k], a23); a4 = __builtin_fmaf(w, c4[o + k], a4);
+            }
+            acc[o][0] = a01.x; acc[o][1] = a01.y; acc[o][2] = a23.x; acc[o][3] = a23.y; acc[o][4] = a4;
+        }
     }
     float local = 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < MS_VO; j++) {
         const int r = r0 + j;
         const float m1 = acc[j][0], m2 = acc[j][1], e11 = acc[j][2], e22 = acc[j][3], e12 = acc[j][4];
         const int vy = oy + r, vx = ox + c;
@@ -191,12 +209,14 @@ template <bool L0>
 __global__ void __launch_bounds__(256) k_ms_bwd(const float* __restrict__ X, const float* __restrict__ Y, const float* __restrict__ mask, int clamp_y, int C,
                                                 MsLevel lv, MsWin win, const float* __restrict__ mapA, const float* __restrict__ mapB, const float* __restrict__ mapC,
                                                 const float* __restrict__ g, const float* __restrict__ parent, int H2, int W2, float* __restrict__ out, int accumulate) {
-    __shared__ float sm[3][MS_IN][MS_IN + 1];
-    __shared__ float hh[3][MS_IN][MS_T + 1];
-    const int plane = blockIdx.z, ox = blockIdx.x * MS_T, oy = blockIdx.y * MS_T;
+    __shared__ v2f smab[MS_INY][MS_IN + 1];    // maps A, B as a pair (one packed FMA filters both), C alone
+    __shared__ float smc[MS_INY][MS_IN + 1];
+    __shared__ v2f hab[MS_INY][MS_T + 1];
+    __shared__ float hc[MS_INY][MS_T + 1];
+    const int plane = blockIdx.z, ox = blockIdx.x * MS_T, oy = blockIdx.y * MS_TY;
     // d in(q) = sum_k w[k] M(q - 10 + k): LDS row 0 <-> map row oy - 10
     {   // loads first, LDS stores after (see k_ms_fwd)
-        constexpr int NL = (MS_IN * MS_IN + 255) / 256;
+        constexpr int NL = (MS_INY * MS_IN + 255) / 256;
         float a_[NL], b_[NL], c_[NL];
 #pragma unroll
         for (int i = 0; i < NL; i++) {
@@ -204,7 +224,7 @@ __global__ void __launch_bounds__(256) k_ms_bwd(const float* __restrict__ X, con
             const int r = e / MS_IN, c = e - r * MS_IN;
             const int uy = oy - 2 * MS_R + r, ux = ox - 2 * MS_R + c;
             a_[i] = 0.f; b_[i] = 0.f; c_[i] = 0.f;
-            if (e < MS_IN * MS_IN && uy >= 0 && uy < lv.Hv && ux >= 0 && ux < lv.Wv) {
+            if (e < MS_INY * MS_IN && uy >= 0 && uy < lv.Hv && ux >= 0 && ux < lv.Wv) {
                 const size_t o = ((size_t)plane * lv.Hv + uy) * lv.Wv + ux;
                 a_[i] = mapA[o]; b_[i] = mapB[o]; c_[i] = mapC[o];
             }
@@ -212,45 +232,46 @@ __global__ void __launch_bounds__(256) k_ms_bwd(const float* __restrict__ X, con
 #pragma unroll
         for (int i = 0; i < NL; i++) {
             const int e = threadIdx.x + 256 * i;
-            if (e < MS_IN * MS_IN) { const int r = e / MS_IN, c = e - r * MS_IN; sm[0][r][c] = a_[i]; sm[1][r][c] = b_[i]; sm[2][r][c] = c_[i]; }
+            if (e < MS_INY * MS_IN) { const int r = e / MS_IN, c = e - r * MS_IN; smab[r][c] = v2f{a_[i], b_[i]}; smc[r][c] = c_[i]; }
         }
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < MS_IN * (MS_T / 4); e += 256) {      // horizontal, four adjacent outputs per item
+    for (int e = threadIdx.x; e < MS_INY * (MS_T / 4); e += 256) {     // horizontal, four adjacent outputs per item
         const int r = e >> 3, c0 = (e & 7) * 4;
+        v2f vab[14];
+        float vc[14];
 #pragma unroll
-        for (int q = 0; q < 3; q++) {
-            float v[14];
+        for (int k = 0; k < 14; k++) { vab[k] = smab[r][c0 + k]; vc[k] = smc[r][c0 + k]; }
 #pragma unroll
-            for (int k = 0; k < 14; k++) v[k] = sm[q][r][c0 + k];
+        for (int o = 0; o < 4; o++) {
+            v2f fab = v2f{0.f, 0.f};
+            float fc = 0.f;
 #pragma unroll
-            for (int o = 0; o < 4; o++) {
-                float f = 0.f;
-#pragma unroll
-                for (int k = 0; k < 2 * MS_R + 1; k++) f += win.w[k] * v[o + k];
-                hh[q][r][c0 + o] = f;
-            }
+            for (int k = 0; k < 2 * MS_R + 1; k++) { fab = ms_fma2(win.w[k], vab[o + k], fab); fc = __builtin_fmaf(win.w[k], vc[o + k], fc); }
+            hab[r][c0 + o] = fab; hc[r][c0 + o] = fc;
         }
     }
     __syncthreads();
-    const int c = threadIdx.x & 31, r0 = (threadIdx.x >> 5) * 4;     // vertical, four vertically adjacent outputs per lane
-    float acc[4][3];
+    const int c = threadIdx.x & 31, r0 = (threadIdx.x >> 5) * MS_VO;     // vertical, MS_VO vertically adjacent outputs per lane
+    float acc[MS_VO][3];
+    {
+        v2f cab[2 * MS_R + MS_VO];
+        float cc[2 * MS_R + MS_VO];
 #pragma unroll
-    for (int o = 0; o < 4; o++) { acc[o][0] = 0.f; acc[o][1] = 0.f; acc[o][2] = 0.f; }
+        for (int k = 0; k < 2 * MS_R + MS_VO; k++) { cab[k] = hab[r0 + k][c]; cc[k] = hc[r0 + k][c]; }
 #pragma unroll
-    for (int q = 0; q < 3; q++) {
-        float col[14];
+        for (int o = 0; o < MS_VO; o++) {
+            v2f fab = v2f{0.f, 0.f};
+            float fc = 0.f;
 #pragma unroll
-        for (int k = 0; k < 14; k++) col[k] = hh[q][r0 + k][c];
-#pragma unroll
-        for (int o = 0; o < 4; o++)
-#pragma unroll
-            for (int k = 0; k < 2 * MS_R + 1; k++) acc[o][q] += win.w[k] * col[o + k];
+            for (int k = 0; k < 2 * MS_R + 1; k++) { fab = ms_fma2(win.w[k], cab[o + k], fab); fc = __builtin_fmaf(win.w[k], cc[o + k], fc); }
+            acc[o][0] = fab.x; acc[o][1] = fab.y; acc[o][2] = fc;
+        }
     }
     const float gl = g[plane];
     const size_t HW = (size_t)lv.H * lv.W;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < MS_VO; j++) {
         const int r = r0 + j;
         const int qy = oy + r, qx = ox + c;
         if (qy >= lv.H || qx >= lv.W) continue;
@@ -281,7 +302,7 @@ void ms_plan(int P, int H, int W, MsPlan& pl) {
     for (int l = 0; l < MS_LEVELS; l++) {
         MsLevel& L = pl.lv[l];
         L.H = h; L.W = w; L.Hv = h - 2 * MS_R; L.Wv = w - 2 * MS_R;
-        L.tx = (L.Wv + MS_T - 1) / MS_T; L.ty = (L.Hv + MS_T - 1) / MS_T;
+        L.tx = (L.Wv + MS_T - 1) / MS_T; L.ty = (L.Hv + MS_TY - 1) / MS_TY;
         const size_t img = sizeof(float) * (size_t)P * h * w, val = sizeof(float) * (size_t)P * (size_t)(L.Hv > 0 ? L.Hv : 0) * (size_t)(L.Wv > 0 ? L.Wv : 0);
         pl.off_x[l] = l ? take(img) : 0; pl.off_y[l] = l ? take(img) : 0;
         pl.off_map[l] = take(3 * val);
@@ -365,7 +386,7 @@ int ms_value_grad(const float* x, const float* y, const float* mask, int clamp_y
         const float* mA = (const float*)(ws + pl.off_map[l]); const float* mB = mA + val; const float* mC = mB + val;
         const float* parent = l < MS_LEVELS - 1 ? (const float*)(ws + pl.off_grad[l + 1]) : nullptr;
         const int H2 = l < MS_LEVELS - 1 ? pl.lv[l + 1].H : 0, W2 = l < MS_LEVELS - 1 ? pl.lv[l + 1].W : 0;
-        const dim3 grid(c3d_cdiv(L.W, MS_T), c3d_cdiv(L.H, MS_T), P);
+        const dim3 grid(c3d_cdiv(L.W, MS_T), c3d_cdiv(L.H, MS_TY), P);
         if (l == 0) hipLaunchKernelGGL((k_ms_bwd<true>), grid, dim3(256), 0, s, X[l], Y[l], mask, clamp_y, C, L, win, mA, mB, mC, g + (size_t)l * P, parent, H2, W2, dL_dy, accumulate);
         else        hipLaunchKernelGGL((k_ms_bwd<false>), grid, dim3(256), 0, s, X[l], Y[l], (const float*)nullptr, 0, C, L, win, mA, mB, mC, g + (size_t)l * P, parent, H2, W2, (float*)(ws + pl.off_grad[l]), 0);
     }
