@@ -397,6 +397,50 @@ def test_backward_is_bit_reproducible():
         assert torch.equal(grads[0][k], grads[1][k]), k
 
 
+def test_recorded_pair_activity_loses_nothing():
+    """The forward compositing pass records, one byte per sorted (tile, splat) pair, which of the tile's four 8x8 quadrants blended the splat; the
+    backward pass walks exactly those (quadrant, splat) pairs.  Overwriting the bytes with 'all four quadrants of every pair' makes the backward
+    pass walk a superset -- lanes that did not blend contribute exact zeros -- so the gradients must come out bit for bit the same; and the
+    recording must really prune (most pairs of a dense scene are blended nowhere or in part of the tile only)."""
+    import diff_gaussian_rasterization as dgr
+    sc = S.make_cloud(200000, seed=3, log_scale_mean=np.log(0.008))
+    W, H = 800, 450
+    st = S.camera_settings(W, H, 49.1, 10.0, 100.0, 2.2)
+    gC = _dev(np.random.default_rng(2).normal(size=(3, H, W)).astype(np.float32), torch.float32)
+    color, radii, depth, alpha, inp, m2d = hip_forward(sc, st, requires_grad=True)
+    D = int(dgr.last_num_rendered)
+    node, seen, stack = None, set(), [color.grad_fn]
+    while stack and node is None:
+        f_ = stack.pop()
+        if f_ is None or id(f_) in seen:
+            continue
+        seen.add(id(f_))
+        if "Rasterize" in type(f_).__name__:
+            node = f_
+        stack.extend(x[0] for x in f_.next_functions)
+    binning = node.saved_tensors[-2]
+    # binning buffer (csrc/gs_internal.h: gs_carve_binning): tkey[0] | tkey[1] | tval[0] | tval[1] | ...; the sorted keys ended in one key buffer, the bytes live in the other
+    d_al = (4 * D + 255) // 256 * 256
+    keys = [binning.data[i * d_al:i * d_al + 4 * D].view(torch.int32) for i in range(2)]
+    res = 0 if bool((keys[0][1:] >= keys[0][:-1]).all()) else 1
+    assert bool((keys[res][1:] >= keys[res][:-1]).all())
+    act = binning.data[(1 - res) * d_al:(1 - res) * d_al + D]      # .data: the in-place overwrite below must not trip autograd's version check of the saved buffer
+    loss = (color * gC).sum() + alpha.sum() + depth.sum()
+    names = ("means3D", "opacities", "shs", "scales", "rotations")
+    g1 = torch.autograd.grad(loss, [inp[k] for k in names] + [m2d], retain_graph=True)
+    before = act.clone()
+    act.fill_(0x0F)
+    g2 = torch.autograd.grad(loss, [inp[k] for k in names] + [m2d], retain_graph=True)
+    for a, b, k in zip(g1, g2, names + ("means2D",)):
+        assert torch.equal(a, b), k
+    # what the recording pruned: bytes are written for the list positions the tiles walked; count over those that hold a valid quadrant mask
+    walked = before[before < 16]
+    pop = torch.tensor([bin(i).count("1") for i in range(16)], device=before.device)[walked.long()]
+    frac_any, quads = float((walked > 0).float().mean()), float(pop.sum()) / max(int((walked > 0).sum()), 1)
+    print("[activity] %d pairs; of the walked list positions %.0f %% blended somewhere, %.2f quadrants each" % (D, 100 * frac_any, quads))
+    assert 0.05 < frac_any < 0.95 and 1.0 <= quads < 3.5
+
+
 # ---------------------------------------------------------------- training-step pieces (SURVEY 8a a6/a7)
 def test_fused_adam_matches_torch():
     from c3d_hip.optim import FusedAdam
