@@ -146,17 +146,23 @@ class DiffRastRenderer(nn.Module):
                                          _dr._topology(f))
         results = LazyResults()
         results['image'], results['alpha'] = image, alpha
+        lazy_v = {}
+
+        def cur_v():
+            if 'v' not in lazy_v:
+                lazy_v['v'] = v if v is not None else (mesh.v + self.v_offsets if self.train_geo else mesh.v)
+            return lazy_v['v']
 
         def raster():
             # depth / normal are produced on demand; with autograd on and trainable geometry they get their own (differentiable) rasterization,
             # otherwise the one the fused call left in its state
             if torch.is_grad_enabled() and self.train_geo:
-                v_clip = transform_vertices(v, torch.from_numpy(clip).to(v.device)).unsqueeze(0)
+                v_clip = transform_vertices(cur_v(), torch.from_numpy(clip).to(mesh.v.device)).unsqueeze(0)
                 return dr.rasterize(self.glctx, v_clip, mesh.f, (h, w))[0]
             return view_state_tensors(hold, h, w)[0]
 
         def depth_fn():
-            vc = transform_vertices(v, torch.from_numpy(pose_inv_np).to(v.device)).unsqueeze(0)
+            vc = transform_vertices(cur_v(), torch.from_numpy(pose_inv_np).to(mesh.v.device)).unsqueeze(0)
             d, _ = dr.interpolate(-vc[..., [2]], raster(), mesh.f)
             return d.squeeze(0)
 
@@ -164,10 +170,10 @@ class DiffRastRenderer(nn.Module):
 
         def normal_pair():
             if not shading:
-                vn = vertex_normals_from_faces(v, mesh.f) if self.train_geo else mesh.vn
+                vn = vertex_normals_from_faces(cur_v(), mesh.f) if self.train_geo else mesh.vn
                 normal, _ = dr.interpolate(vn.unsqueeze(0).contiguous(), raster(), mesh.fn)
                 normal = safe_normalize(normal[0])
-                viewcos = normal @ torch.from_numpy(pose_np[:3, :3].copy()).to(v.device)
+                viewcos = normal @ torch.from_numpy(pose_np[:3, :3].copy()).to(mesh.v.device)
                 shading['normal'], shading['viewcos'] = (normal + 1) / 2, (viewcos + 1) / 2
             return shading
         if 'depth' in optional_render_types:
@@ -180,15 +186,16 @@ class DiffRastRenderer(nn.Module):
     def render(self, pose, proj, h0, w0, ssaa=1, bg_color=1, texture_filter='linear', optional_render_types=['depth', 'normal']):
         h, w = (make_divisible(h0 * ssaa, 8), make_divisible(w0 * ssaa, 8)) if ssaa != 1 else (h0, w0)
         mesh = self.mesh
-        v = mesh.v + self.v_offsets if self.train_geo else mesh.v
         # the 4x4 inverse is taken on the host (the reference calls torch.inverse on the device: a solver launch + sync per view);
         # one upload carries pose, its inverse and the projection
         pose_np = pose.astype(np.float32)
         pose_inv_np = np.linalg.inv(pose_np).astype(np.float32)
         proj_np = proj.astype(np.float32)
-        fused = v.is_cuda and ssaa == 1 and self.fused_glue
+        fused = mesh.v.is_cuda and ssaa == 1 and self.fused_glue
         if fused and self.fused_view and texture_filter == 'linear':
-            return self._render_fused_view(v, pose_np, pose_inv_np, proj_np, h, w, bg_color, optional_render_types)
+            # the fused view adds the offsets inside its transform kernel; `v` (one more launch and autograd node per view) only exists if depth / normal are read
+            return self._render_fused_view(None, pose_np, pose_inv_np, proj_np, h, w, bg_color, optional_render_types)
+        v = mesh.v + self.v_offsets if self.train_geo else mesh.v
         mats = torch.from_numpy(np.stack((pose_np, pose_inv_np, proj_np, proj_np @ pose_inv_np))).to(v.device)
         pose, pose_inv, proj, clip_from_world = mats[0], mats[1], mats[2], mats[3]
         if fused:
