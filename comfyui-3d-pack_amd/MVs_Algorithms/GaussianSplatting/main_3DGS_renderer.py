@@ -413,7 +413,7 @@ class GaussianSplattingRenderer:
         else:
             raise TypeError("initialize(): pass None, a GS PlyData, a PointCloud, a Mesh or a dict of raw tensors (the UV-grid initialiser is not built)")
 
-    def render_views(self, viewpoint_cameras, bg_colors=None, scaling_modifier=1.0, lanes=4):
+    def render_views(self, viewpoint_cameras, bg_colors=None, scaling_modifier=1.0, lanes=8):
         """Inference-only batch of render(): all cameras in ONE library call (c3d_gs_render_views_raw; views dealt onto `lanes` HIP
         streams, no host synchronisation between views).  Same per-view results as render() -- the orbit-renderer loop of the reference's
         nodes without its per-view launch gaps.  bg_colors: None, one [3] tensor or one per camera.
