@@ -139,8 +139,25 @@ def main_mesh(a, world, rank, dev, dist):
     import torch.nn.functional as F
     half = torch.full((H, W, 1), 0.5, device=dev)
     seed_grad = torch.tensor(1.0 / (a.views_per_gpu * world), device=dev)      # d(step loss) / d(view loss): the 1 / views factor without a division kernel per view
+    # --render-path step (default): the whole step -- render, image loss (MSE against the target images), backward of every view, gradients summed -- as ONE
+    # library call on view lanes (c3d_mesh_train_views, what DiffMesh.training_step uses on a HIP device); fused: one autograd call per view, loss in torch
+    use_step = a.render_path == "step"
+    if use_step:
+        from c3d_hip.mesh_step import FusedMeshStep
+        mstep = FusedMeshStep(dev, lanes=(a.lanes if a.lanes > 0 else 4))
+        proj32 = cam.perspective.astype(np.float32)
+        sviews = [((proj32 @ np.linalg.inv(p.astype(np.float32)).astype(np.float32)).astype(np.float32), (1.0, 1.0, 1.0)) for p in mine]
+        tg_chw = [tg.permute(2, 0, 1).contiguous() for tg in targets]
+        f32i, ft32i, vt32 = mesh.f.to(torch.int32).contiguous(), mesh.ft.to(torch.int32).contiguous(), mesh.vt.to(torch.float32).contiguous()
+        d_ra, d_vo = torch.empty_like(r.raw_albedo), torch.empty_like(r.v_offsets)
 
     def step():
+        if use_step:
+            mstep.run(sviews, mesh.v, r.v_offsets, f32i, vt32, ft32i, r.raw_albedo, r.glctx, tg_chw, None, d_ra, d_vo, H, W, w_mse=1.0, w_ssim=0.0,
+                      scale=1.0 / (a.views_per_gpu * world), accumulate=False)
+            if world > 1:
+                dist.all_reduce(d_ra); dist.all_reduce(d_vo)
+            return
         # the step is host bound (~45 launches per view at 5-8 us each against 0.40 ms of kernels): the image loss is spelled with the library ops the
         # reference's trainer uses (F.mse_loss, diff_mesh.py:121) instead of sub / pow / mean chains -- 8 launches fewer per view, the same arithmetic
         for p, tg in zip(mine, targets):
@@ -211,6 +228,7 @@ def main_mesh(a, world, rank, dev, dist):
                           "unit": "Mpixels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                           "config": {"workload": "DiffRastMesh fwd+bwd, %d-triangle displaced sphere, 1024^2 albedo, 1024x1024, %d views/GPU/step" % (T, a.views_per_gpu),
+                                     "render_path": ("step: c3d_mesh_train_views, %d view lanes" % mstep.lanes) if use_step else "fused: one autograd call per view",
                                      "parallelism": "view-parallel dp%d" % world, "host_enqueue_ms_per_step": round(t_enq / a.steps * 1e3, 3)},
                           "roofline": roof, "cpu_baseline": cpu, "kernels": kern, "code_digest": code_digest()}))
     if world > 1:

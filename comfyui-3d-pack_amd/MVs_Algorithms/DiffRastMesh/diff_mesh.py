@@ -3,18 +3,20 @@
 Host-side mirror of /root/reference/MVs_Algorithms/DiffRastMesh/diff_mesh.py: controller :18-22, constructor
 :26-56 (Adam over raw_albedo [+ v_offsets]), prepare_training :58-78, training loop :81-159 (per step `batch_size` random
 views, loss = (1-l) MSE + l (1 - MS-SSIM) on masked images, geometry regularisers when the geometry trains).
-Additive differences: `device` / `process_group` parameters (view-parallel gradient exchange, c3d_hip/parallel.py).  The periodic
+Additive differences: `device` / `process_group` parameters (view-parallel gradient exchange, c3d_hip/parallel.py); on a HIP device the whole step --
+render, image loss, backward of all views -- is one library call (`_fused_step`, c3d_hip/mesh_step.py; `use_fused_step = False` keeps the per-view autograd path).  The periodic
 CPU remesh (:134-141, pymeshlab through kiui) is asset tooling outside the hot path and is not built: the constructor says so ONCE,
 before any work is spent, and training then runs through without it (in the reference the step also replaces `v_offsets` by a fresh
 Parameter the optimizer never sees, so geometry stops training there; here it keeps training on the original topology)."""
 import random
 import warnings
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
 from c3d_hip import parallel
-from shared_utils.camera_utils import BaseCameraController
+from shared_utils.camera_utils import BaseCameraController, orbit_camera
 from shared_utils.msssim import MS_SSIM
 from .diff_mesh_renderer import DiffRastRenderer
 
@@ -70,6 +72,7 @@ class DiffMesh:
         self.ms_ssim_loss = MS_SSIM(data_range=1, size_average=True, channel=3)
         self.lambda_ssim, self.training_iterations, self.batch_size, self.invert_bg_prob = ms_ssim_loss_weight, training_iterations, batch_size, invert_bg_prob
         self.group, self.exchange = process_group, exchange
+        self.use_fused_step, self.view_lanes, self._mesh_step = True, 4, None      # the step as one library call on a HIP device (_can_fuse); False: per-view autograd
         self.params = [p for g in groups for p in ([g['params']] if torch.is_tensor(g['params']) else g['params'])]
 
     def prepare_training(self, reference_images, reference_masks, reference_orbit_camera_poses, reference_orbit_camera_fovy):
@@ -82,9 +85,58 @@ class DiffMesh:
         self.ref_imgs_torch = torch.cat([to(im.unsqueeze(0)) for im in reference_images], dim=0)                  # [V,3,H,W]
         self.ref_masks_torch = torch.cat([to(m.unsqueeze(2).unsqueeze(0)) for m in reference_masks], dim=0)      # [V,1,H,W]
 
+    def _can_fuse(self):
+        """the whole step as one library call (c3d_hip.mesh_step.FusedMeshStep): HIP device, the fused view path of the renderer, and -- with an MS-SSIM
+        term -- images large enough for its five scales"""
+        r = self.renderer
+        return (self.use_fused_step and self.device.type == "cuda" and r.fused_view and r.fused_glue
+                and (self.lambda_ssim == 0 or min(self.ref_size_H, self.ref_size_W) > 160))
+
+    def _fused_step(self, mine):
+        """render -> image loss -> backward of all views of the step in ONE sync-free library call, the views dealt onto view lanes; the geometry
+        regularisers (plain autograd) are added on top of the gradients the kernels wrote.  Same loss, same per-view background draws (one np.random
+        draw per view, in view order, as BaseCameraController.render_at_pose) as the per-view path below."""
+        from c3d_hip.mesh_step import FusedMeshStep
+        r, ctl = self.renderer, self.cam_controller
+        mesh = r.mesh
+        if self._mesh_step is None:
+            self._mesh_step = FusedMeshStep(self.device, lanes=self.view_lanes)
+        proj = ctl.cam.perspective.astype(np.float32)
+        views = []
+        for i in mine:
+            radius, elevation, azimuth, cx, cy, cz = self.all_ref_cam_poses[i]
+            pose = orbit_camera(elevation, azimuth, radius, target=np.array([cx, cy, cz], dtype=np.float32)).astype(np.float32)
+            bg = ctl.static_bg if ctl.static_bg is not None else (ctl.white_bg if np.random.rand() > ctl.invert_bg_prob else ctl.black_bg)
+            views.append(((proj @ np.linalg.inv(pose).astype(np.float32)).astype(np.float32), r._bg_host(bg)))
+        f, ft = mesh.f.to(torch.int32).contiguous(), mesh.ft.to(torch.int32).contiguous()
+        vt = mesh.vt.to(torch.float32).contiguous()
+        geo = bool(r.train_geo)
+        d_ra = torch.empty_like(r.raw_albedo)
+        d_vo = torch.empty_like(r.v_offsets) if geo else None
+        loss = self._mesh_step.run(views, mesh.v, r.v_offsets if geo else None, f, vt, ft, r.raw_albedo, r.glctx, [self.ref_imgs_torch[i] for i in mine],
+                                   [self.ref_masks_torch[i] for i in mine], d_ra, d_vo, self.ref_size_H, self.ref_size_W, w_mse=1.0 - self.lambda_ssim,
+                                   w_ssim=self.lambda_ssim, scale=1.0 / max(len(mine), 1), accumulate=False).clone()
+        r.raw_albedo.grad = d_ra
+        if geo:
+            r.v_offsets.grad = d_vo
+        return loss.reshape(())
+
     def training_step(self, step, view_indices):
         world = torch.distributed.get_world_size(self.group) if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
         rank = torch.distributed.get_rank(self.group) if world > 1 else 0
+        if self._can_fuse():
+            mine = list(parallel.shard_views(view_indices, rank, world))
+            loss = self._fused_step(mine)
+            if self.train_mesh_geometry:
+                r = self.renderer
+                cur = r.mesh.v + r.v_offsets
+                reg = 0.01 * laplacian_smooth_loss(cur, r.mesh.f) + 0.001 * normal_consistency(cur, r.mesh.f) + 0.1 * (r.v_offsets ** 2).sum(-1).mean()
+                reg.backward()                       # adds to the .grad the kernels wrote
+                loss = loss + reg.detach()
+            self._exchange(world)
+            self.optimizer.step()
+            self.optimizer.zero_grad()
+            return loss.detach()
         imgs, refs = [], []
         for i in parallel.shard_views(view_indices, rank, world):
             out = self.cam_controller.render_at_pose(self.all_ref_cam_poses[i])

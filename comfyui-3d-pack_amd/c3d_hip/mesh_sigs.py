@@ -9,6 +9,11 @@ class MeshView(C.Structure):
     _fields_ = [("V", i32), ("T", i32), ("Vt", i32), ("H", i32), ("W", i32), ("Ht", i32), ("Wt", i32), ("clip_from_world", C.c_float * 16), ("bg", C.c_float * 3)]
 
 
+class MeshStepLoss(C.Structure):
+    """struct c3d_mesh_step_loss"""
+    _fields_ = [("w_mse", C.c_float), ("w_ssim", C.c_float), ("scale", C.c_float)]
+
+
 SIGNATURES = {
     "c3d_mesh_raster_scratch_bytes": (sz, [i32, i32, i32, i32]),
     "c3d_mesh_rasterize_fwd": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
@@ -38,5 +43,7 @@ SIGNATURES = {
     "c3d_mesh_view_bwd_scratch_bytes": (sz, [i32, i32, i32, i32]),
     "c3d_mesh_view_fwd": (C.c_int, [C.POINTER(MeshView), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "c3d_mesh_view_bwd": (C.c_int, [C.POINTER(MeshView), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "c3d_mesh_step_workspace_bytes": (sz, [i32] * 8),
+    "c3d_mesh_train_views": (C.c_int, [C.POINTER(MeshView), i32] + [vp] * 8 + [C.POINTER(vp), C.POINTER(vp), C.POINTER(MeshStepLoss), vp, vp, vp, i32, i32, vp, vp]),
     "c3d_mesh_antialias_bwd": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
 }

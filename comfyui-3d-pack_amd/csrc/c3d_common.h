@@ -25,6 +25,12 @@ void c3d_set_error(const char* fmt, ...);
 static inline size_t c3d_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 static inline int c3d_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// ---- view lanes (gs_api.hip): library-owned HIP streams forked from / joined into the caller's stream; shared by the 3DGS and the mesh multi-view steps ----
+#define C3D_MAX_LANES 8
+// streams[0] = caller; returns the number of lanes L = min(lanes, n_views) through *L, or -1
+int c3d_lanes_fork(hipStream_t caller, int lanes, int n_views, hipStream_t* streams, int* L);
+int c3d_lanes_join(hipStream_t caller, const hipStream_t* streams, int L, const char* who);   // always call after a fork, also on error paths
+
 // ---- optional event timing (prof.hip) ----
 #define C3D_PROF_SLOTS 21
 enum { C3D_P_PREPROCESS = 0, C3D_P_DEPTH_SORT, C3D_P_SCAN, C3D_P_EMIT, C3D_P_TILE_SORT, C3D_P_RANGES, C3D_P_COMPOSITE_FWD,

@@ -283,7 +283,6 @@ static void carve_step(char* base, int N, int H, int W, long long cap, StepWs& w
 // ---- view lanes: the V views of a call are dealt round-robin onto `lanes` HIP streams (lane 0 = the caller's stream) so that the latency-bound
 // sort / scan chains of one view run underneath the VALU-bound compositing kernels of another.  Every view owns a workspace slice; after the
 // join ONE pass over the Gaussians turns all views' pair records into the parameter gradients.
-#define C3D_MAX_LANES 8
 namespace {
 struct LanePool {
     bool init = false; hipStream_t st[C3D_MAX_LANES - 1]; hipEvent_t fork, join[C3D_MAX_LANES - 1];
@@ -339,6 +338,24 @@ struct Lanes {
     }
 };
 }  // namespace
+
+// the same lanes for the other multi-view step of the library (mesh.hip)
+extern "C++" {
+int c3d_lanes_fork(hipStream_t caller, int lanes, int n_views, hipStream_t* streams, int* L) {
+    Lanes ln;
+    if (ln.fork(caller, lanes, n_views)) return -1;
+    for (int l = 0; l < ln.L; l++) streams[l] = ln.ls[l];
+    *L = ln.L;
+    return 0;
+}
+int c3d_lanes_join(hipStream_t caller, const hipStream_t* streams, int L, const char* who) {
+    Lanes ln;
+    ln.s0 = caller; ln.L = L;
+    for (int l = 0; l < L; l++) ln.ls[l] = streams[l];
+    if (L > 1 && ln.need_pool()) return -1;
+    return ln.join(who);
+}
+}  // extern "C++"
 
 // forward of one view of the fused paths (A1-A6), everything on stream s, no host synchronisation: the pair count stays on the device
 // (g.meta[0]) and every launch that depends on it is sized for the pair capacity.

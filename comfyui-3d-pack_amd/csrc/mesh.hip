@@ -1190,14 +1190,21 @@ int c3d_mesh_texture_fwd(const float* tex, int32_t Bt, const float* uv, int32_t 
     C3D_LAUNCH_CHECK();
     return 0;
 }
+static int mesh_texture_bwd(const float* tex, int32_t Bt, const float* uv, const float* dy, int32_t B, int32_t H, int32_t W, int32_t Ht, int32_t Wt, int32_t C,
+                            int32_t filter, int32_t boundary, float* dtex, float* duv, c3d_stream_t stream, bool zero_dtex);
 int c3d_mesh_texture_bwd(const float* tex, int32_t Bt, const float* uv, const float* dy, int32_t B, int32_t H, int32_t W, int32_t Ht, int32_t Wt, int32_t C,
                          int32_t filter, int32_t boundary, float* dtex, float* duv, c3d_stream_t stream) {
+    return mesh_texture_bwd(tex, Bt, uv, dy, B, H, W, Ht, Wt, C, filter, boundary, dtex, duv, stream, true);
+}
+// zero_dtex = false: the texel gradients are ADDED to what dtex holds (the multi-view step accumulates the views of a lane in one buffer)
+static int mesh_texture_bwd(const float* tex, int32_t Bt, const float* uv, const float* dy, int32_t B, int32_t H, int32_t W, int32_t Ht, int32_t Wt, int32_t C,
+                            int32_t filter, int32_t boundary, float* dtex, float* duv, c3d_stream_t stream, bool zero_dtex) {
     hipStream_t s = (hipStream_t)stream;
     const long long P = (long long)H * W, BP = P * B;
     MESH_REQUIRE(Bt == 1 || Bt == B, "texture batch must be 1 or B");
     MESH_REQUIRE((filter == 0 || filter == 1) && (boundary == 0 || boundary == 1), "unsupported filter/boundary mode");
     C3dProfScope ps(C3D_P_MESH_TEXTURE_BWD, s);
-    if ((long long)Bt * Ht * Wt * C > 0) { MESH_REQUIRE(dtex, "NULL dtex"); C3D_CHECK(hipMemsetAsync(dtex, 0, sizeof(float) * (size_t)Bt * Ht * Wt * C, s)); }
+    if ((long long)Bt * Ht * Wt * C > 0) { MESH_REQUIRE(dtex, "NULL dtex"); if (zero_dtex) C3D_CHECK(hipMemsetAsync(dtex, 0, sizeof(float) * (size_t)Bt * Ht * Wt * C, s)); }
     if (BP == 0 || C == 0) return 0;
     MESH_REQUIRE(tex && uv && dy && duv, "NULL pointer");
     if (filter == 1 && (C == 1 || C == 3 || C == 4) && (long long)Ht * Wt < 0xFFFFFFFFll) {
@@ -1583,10 +1590,18 @@ int c3d_mesh_view_fwd(const c3d_mesh_view* d, const float* v, const float* v_off
     return 0;
 }
 
+static int mesh_view_bwd(const c3d_mesh_view* d, const int32_t* f, const float* vt, const int32_t* ft, const float* raw_albedo,
+                         const void* aa_topology, const void* vertex_topology, void* scratch, const void* state, const float* dimage, const float* dalpha,
+                         float* d_raw_albedo, float* d_v, c3d_stream_t stream, bool zero_dtex);
 int c3d_mesh_view_bwd(const c3d_mesh_view* d, const float* v, const float* v_offsets, const int32_t* f, const float* vt, const int32_t* ft, const float* raw_albedo,
                       const void* aa_topology, const void* vertex_topology, void* scratch, const void* state, const float* dimage, const float* dalpha,
                       float* d_raw_albedo, float* d_v, c3d_stream_t stream) {
     (void)v; (void)v_offsets;
+    return mesh_view_bwd(d, f, vt, ft, raw_albedo, aa_topology, vertex_topology, scratch, state, dimage, dalpha, d_raw_albedo, d_v, stream, true);
+}
+static int mesh_view_bwd(const c3d_mesh_view* d, const int32_t* f, const float* vt, const int32_t* ft, const float* raw_albedo,
+                         const void* aa_topology, const void* vertex_topology, void* scratch, const void* state, const float* dimage, const float* dalpha,
+                         float* d_raw_albedo, float* d_v, c3d_stream_t stream, bool zero_dtex) {
     hipStream_t s = (hipStream_t)stream;
     MESH_REQUIRE(d && f && vt && ft && raw_albedo && aa_topology && scratch && state && d_raw_albedo, "c3d_mesh_view_bwd: NULL pointer");
     MESH_REQUIRE(dimage || dalpha, "c3d_mesh_view_bwd: no upstream gradient");
@@ -1609,11 +1624,159 @@ int c3d_mesh_view_bwd(const c3d_mesh_view* d, const float* v, const float* v_off
                            (const EdgeSlot*)aa_topology, edge_table_size(T) - 1, sc.dalbedo_aa, sc.dcov, V, H, W, sc.dalbedo0, d_v ? sc.dpos_aa : nullptr, st.hit);
         hipLaunchKernelGGL(k_view_sigmoid_bwd, dim3(c3d_cdiv(P * 3, 256)), dim3(256), 0, s, st.albedo0, sc.dalbedo0, P * 3);
     }
-    if ((rc = c3d_mesh_texture_bwd(raw_albedo, 1, st.texc, sc.dalbedo0, 1, H, W, d->Ht, d->Wt, 3, 1, 0, d_raw_albedo, sc.duv, stream))) return rc;
+    if ((rc = mesh_texture_bwd(raw_albedo, 1, st.texc, sc.dalbedo0, 1, H, W, d->Ht, d->Wt, 3, 1, 0, d_raw_albedo, sc.duv, stream, zero_dtex))) return rc;
     if (d_v) {
         if ((rc = c3d_mesh_interpolate_bwd(vt, 1, st.rast, ft, sc.duv, 1, d->Vt, 2, H, W, nullptr, sc.drast, stream))) return rc;
         if ((rc = c3d_mesh_rasterize_bwd_gather(st.vclip, f, st.rast, sc.drast, 1, V, T, H, W, vertex_topology, sc.ras, sc.dpos_r, stream))) return rc;
         hipLaunchKernelGGL(k_view_transform_bwd, dim3(c3d_cdiv(V, 256)), dim3(256), 0, s, M, (const float4*)sc.dpos_aa, (const float4*)sc.dpos_r, V, d_v);
+    }
+    C3D_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------------------------------------
+// Fused multi-view training step of DiffMesh (include/c3d_mesh.h: c3d_mesh_train_views): what DiffMesh.training_step does per step --
+// render every view of the batch, image loss, backward, gradients summed over the views (diff_mesh.py:98-125 in the reference) -- as ONE
+// library call.  The per-view autograd path is host bound at this size (~35 launches per view enqueued from Python, plus torch's own for the
+// loss and the gradient accumulation); here the views are dealt onto the library's view lanes and nothing returns to the host language.
+// ------------------------------------------------------------------------------------------------------------------------------------------
+#include "../../include/c3d_loss.h"
+int ms_value_grad(const float* x, const float* y, const float* mask, int clamp_y, int B, int C, int H, int W, float grad_scale, int accumulate, float* dL_dy,
+                  float va, float vb, float* ms_out, void* workspace, hipStream_t s);
+
+// image [H,W,3] -> planes [3,H,W] (what the MS-SSIM kernels read)
+__global__ void __launch_bounds__(256) k_mesh_hwc_to_chw(const float* __restrict__ hwc, long long P, float* __restrict__ chw) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+#pragma unroll
+    for (int c = 0; c < 3; c++) chw[c * P + i] = hwc[3 * i + c];
+}
+// L_v = scale * w_mse * mean_{c,p} ((image - target) m)^2: value into *loss_out, d/dimage [H,W,3] = that gradient + (dssim [3,H,W], or nothing)
+__global__ void __launch_bounds__(256) k_mesh_pixel_loss(const float* __restrict__ image, const float* __restrict__ target_chw, const float* __restrict__ mask, long long P,
+                                                          float w, const float* __restrict__ dssim_chw, float* __restrict__ dimage, float* __restrict__ loss_out) {
+    __shared__ float red[4];
+    float l = 0.f;
+    const float inv = 1.f / (3.f * (float)P);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (long long)gridDim.x * blockDim.x) {
+        const float m = mask ? mask[i] : 1.f;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float d = (image[3 * i + c] - target_chw[c * P + i]) * m;
+            l += d * d;
+            dimage[3 * i + c] = 2.f * w * inv * d * m + (dssim_chw ? dssim_chw[c * P + i] : 0.f);
+        }
+    }
+    l = c3d_wave_sum(l * w * inv);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = l;
+    __syncthreads();
+    if (threadIdx.x == 0 && loss_out) atomicAdd(loss_out, red[0] + red[1] + red[2] + red[3]);
+}
+// out (+)= sum_k in_k, k in fixed order (lane buffers of the texture gradient; per-view buffers of the vertex gradient)
+struct MeshSumSrc { int n; const float* p[64]; };
+__global__ void __launch_bounds__(256) k_mesh_sum(MeshSumSrc src, long long count, int accumulate, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    float a = accumulate ? out[i] : 0.f;
+    for (int k = 0; k < src.n; k++) a += src.p[k][i];
+    out[i] = a;
+}
+
+namespace {
+struct MeshStepLane { char* state; char* bwd; char* raster; float* image; float* alpha; float* image_chw; float* dssim; float* dimage; char* ms_ws; float* d_ra; };
+struct MeshStepWs { MeshStepLane lane[C3D_MAX_LANES]; float* d_v; size_t d_v_stride; size_t bytes; };
+void carve_mesh_step(char* base, int V, int T, int H, int W, int Ht, int Wt, int n_views, int lanes, MeshStepWs& w) {
+    size_t off = 0;
+    const size_t P = (size_t)H * W;
+    auto take = [&](size_t b) { char* p = base ? base + off : nullptr; off += c3d_align(b); return p; };
+    for (int l = 0; l < lanes; l++) {
+        MeshStepLane& q = w.lane[l];
+        q.state = take(c3d_mesh_view_state_bytes(V, H, W));
+        q.bwd = take(c3d_mesh_view_bwd_scratch_bytes(V, T, H, W));
+        q.raster = take(c3d_mesh_raster_scratch_bytes(1, H, W, T));
+        q.image = (float*)take(12 * P); q.alpha = (float*)take(4 * P); q.image_chw = (float*)take(12 * P); q.dssim = (float*)take(12 * P); q.dimage = (float*)take(12 * P);
+        q.ms_ws = take(c3d_msssim_workspace_bytes(1, 3, H, W));
+        q.d_ra = (float*)take(12 * (size_t)Ht * Wt);
+    }
+    w.d_v_stride = c3d_align(12 * (size_t)(V > 0 ? V : 1));
+    w.d_v = (float*)take(w.d_v_stride * (size_t)(n_views > 0 ? n_views : 1));
+    w.bytes = off;
+}
+}  // namespace
+
+extern "C" {
+
+size_t c3d_mesh_step_workspace_bytes(int32_t V, int32_t T, int32_t H, int32_t W, int32_t Ht, int32_t Wt, int32_t n_views, int32_t lanes) {
+    MeshStepWs w;
+    carve_mesh_step(nullptr, V, T, H, W, Ht, Wt, n_views, lanes < 1 ? 1 : (lanes > C3D_MAX_LANES ? C3D_MAX_LANES : lanes), w);
+    return w.bytes;
+}
+
+int c3d_mesh_train_views(const c3d_mesh_view* views, int32_t n_views, const float* v, const float* v_offsets, const int32_t* f, const float* vt, const int32_t* ft,
+                         const float* raw_albedo, const void* aa_topology, const void* vertex_topology, const float* const* target_chw, const float* const* mask,
+                         const c3d_mesh_step_loss* loss, float* d_raw_albedo, float* d_v_offsets, float* loss_out, int32_t accumulate, int32_t lanes, void* workspace,
+                         c3d_stream_t stream) {
+    hipStream_t s0 = (hipStream_t)stream;
+    if (n_views <= 0) return 0;
+    MESH_REQUIRE(views && v && f && vt && ft && raw_albedo && aa_topology && target_chw && loss && d_raw_albedo && workspace, "c3d_mesh_train_views: NULL pointer");
+    MESH_REQUIRE(!d_v_offsets || vertex_topology, "c3d_mesh_train_views: the geometry gradient needs the vertex topology");
+    MESH_REQUIRE(lanes >= 1 && lanes <= C3D_MAX_LANES, "c3d_mesh_train_views: lanes must be in [1, 8]");
+    MESH_REQUIRE(n_views <= 64, "c3d_mesh_train_views: at most 64 views per call");
+    const c3d_mesh_view& d0 = views[0];
+    for (int i = 0; i < n_views; i++) {
+        const c3d_mesh_view& d = views[i];
+        MESH_REQUIRE(d.V == d0.V && d.T == d0.T && d.Vt == d0.Vt && d.H == d0.H && d.W == d0.W && d.Ht == d0.Ht && d.Wt == d0.Wt, "c3d_mesh_train_views: all views must share the mesh and the resolution");
+        MESH_REQUIRE(target_chw[i], "c3d_mesh_train_views: NULL target");
+    }
+    MESH_REQUIRE(d0.V > 0 && d0.T > 0 && d0.H > 0 && d0.W > 0 && d0.Ht > 0 && d0.Wt > 0 && d0.Vt > 0, "c3d_mesh_train_views: empty mesh / image / texture");
+    const bool ssim = loss->w_ssim != 0.f;
+    MESH_REQUIRE(!ssim || (d0.H > 160 && d0.W > 160), "c3d_mesh_train_views: the MS-SSIM term needs image sides > 160");
+    const long long P = (long long)d0.H * d0.W;
+    const size_t ntex = 3 * (size_t)d0.Ht * d0.Wt;
+    hipStream_t ls[C3D_MAX_LANES];
+    int L = 1;
+    if (c3d_lanes_fork(s0, lanes, n_views, ls, &L)) return -1;
+    MeshStepWs w;
+    carve_mesh_step((char*)workspace, d0.V, d0.T, d0.H, d0.W, d0.Ht, d0.Wt, n_views, L, w);
+    int rc_all = 0;
+    for (int l = 0; l < L && !rc_all; l++)
+        if (hipMemsetAsync(w.lane[l].d_ra, 0, sizeof(float) * ntex, ls[l]) != hipSuccess) { c3d_set_error("c3d_mesh_train_views: memset failed"); rc_all = -1; }
+    for (int i = 0; i < n_views && !rc_all; i++) {
+        hipStream_t s = ls[i % L];
+        MeshStepLane& q = w.lane[i % L];
+        const c3d_mesh_view* d = &views[i];
+        const float* mk = mask ? mask[i] : nullptr;
+        int rc = 0;
+        do {
+            if ((rc = c3d_mesh_view_fwd(d, v, v_offsets, f, vt, ft, raw_albedo, aa_topology, q.raster, q.state, q.image, q.alpha, (c3d_stream_t)s))) break;
+            {
+                C3dProfScope ps(C3D_P_OTHER, s);
+                if (ssim) {   // + scale * w_ssim * (1 - MS-SSIM(target m, image m)) of this view: value into loss_out, gradient (planes) into q.dssim
+                    const float ws_ = loss->scale * loss->w_ssim;
+                    hipLaunchKernelGGL(k_mesh_hwc_to_chw, dim3(c3d_cdiv(P, 256)), dim3(256), 0, s, q.image, P, q.image_chw);
+                    if ((rc = ms_value_grad(target_chw[i], q.image_chw, mk, 0, 1, 3, d->H, d->W, -ws_, 0, q.dssim, ws_, -ws_, loss_out, q.ms_ws, s))) break;
+                }
+                hipLaunchKernelGGL(k_mesh_pixel_loss, dim3((unsigned)(c3d_cdiv(P, 256) < 1024 ? c3d_cdiv(P, 256) : 1024)), dim3(256), 0, s, q.image, target_chw[i], mk, P,
+                                   loss->scale * loss->w_mse, ssim ? q.dssim : (const float*)nullptr, q.dimage, loss_out);
+            }
+            float* dv = d_v_offsets ? (float*)((char*)w.d_v + (size_t)i * w.d_v_stride) : nullptr;
+            if ((rc = mesh_view_bwd(d, f, vt, ft, raw_albedo, aa_topology, vertex_topology, q.bwd, q.state, q.dimage, nullptr, q.d_ra, dv, (c3d_stream_t)s, false))) break;
+        } while (0);
+        rc_all = rc;
+    }
+    if (c3d_lanes_join(s0, ls, L, "c3d_mesh_train_views") && !rc_all) rc_all = -1;
+    if (rc_all) return rc_all;
+    {
+        C3dProfScope ps(C3D_P_OTHER, s0);
+        MeshSumSrc a; a.n = L;
+        for (int l = 0; l < L; l++) a.p[l] = w.lane[l].d_ra;
+        hipLaunchKernelGGL(k_mesh_sum, dim3(c3d_cdiv((long long)ntex, 256)), dim3(256), 0, s0, a, (long long)ntex, accumulate, d_raw_albedo);
+        if (d_v_offsets) {
+            MeshSumSrc b; b.n = n_views;
+            for (int i = 0; i < n_views; i++) b.p[i] = (const float*)((const char*)w.d_v + (size_t)i * w.d_v_stride);
+            hipLaunchKernelGGL(k_mesh_sum, dim3(c3d_cdiv(3ll * d0.V, 256)), dim3(256), 0, s0, b, 3ll * d0.V, accumulate, d_v_offsets);
+        }
     }
     C3D_LAUNCH_CHECK();
     return 0;

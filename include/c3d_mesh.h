@@ -147,6 +147,23 @@ int c3d_mesh_view_bwd(const c3d_mesh_view* d, const float* v, const float* v_off
                       const float* raw_albedo, const void* aa_topology, const void* vertex_topology, void* scratch, const void* state,
                       const float* dimage, const float* dalpha, float* d_raw_albedo, float* d_v, c3d_stream_t stream);
 
+/* ---- fused multi-view training step (extension) ----------------------------------------------------------------------------------------
+ * One call = what DiffMesh.training_step does for the views of a step (reference: MVs_Algorithms/DiffRastMesh/diff_mesh.py:98-125): for each view
+ * c3d_mesh_view_fwd -> image loss -> backward, the gradients summed over the views.  The views are dealt onto `lanes` (1..8) library-owned HIP
+ * streams forked from / joined into `stream`; nothing synchronises with the host.  Loss, per view v of n:
+ *   scale * [ w_mse * mean_{c,p} ((image_v - target_v) m_v)^2  +  w_ssim * (1 - MS_SSIM(target_v m_v, image_v m_v)) ]        (include/c3d_loss.h; sides > 160)
+ * with scale = 1 / n this is the reference's batch loss (1 - lambda) F.mse_loss(imgs, refs) + lambda (1 - ms_ssim(refs, imgs)), lambda = w_ssim.
+ * target_chw / mask: HOST arrays of n DEVICE pointers, [3,H,W] / [1,H,W] (mask or its entries may be NULL = 1).  loss_out (device float) accumulates
+ * the value.  d_raw_albedo [Ht,Wt,3], d_v_offsets [V,3] (NULL: geometry not trained): overwritten, or added to when accumulate != 0.  The texture
+ * gradient of a lane's views accumulates with float atomics (as in c3d_mesh_texture_bwd); lanes and views are summed in a fixed order.
+ * workspace: c3d_mesh_step_workspace_bytes(V, T, H, W, Ht, Wt, n_views, lanes).  At most 64 views per call. */
+typedef struct c3d_mesh_step_loss { float w_mse; float w_ssim; float scale; } c3d_mesh_step_loss;
+size_t c3d_mesh_step_workspace_bytes(int32_t V, int32_t T, int32_t H, int32_t W, int32_t Ht, int32_t Wt, int32_t n_views, int32_t lanes);
+int c3d_mesh_train_views(const c3d_mesh_view* views /* host [n_views] */, int32_t n_views, const float* v, const float* v_offsets, const int32_t* f,
+                         const float* vt, const int32_t* ft, const float* raw_albedo, const void* aa_topology, const void* vertex_topology,
+                         const float* const* target_chw, const float* const* mask, const c3d_mesh_step_loss* loss, float* d_raw_albedo,
+                         float* d_v_offsets, float* loss_out, int32_t accumulate, int32_t lanes, void* workspace, c3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

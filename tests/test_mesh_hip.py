@@ -328,6 +328,64 @@ def test_diffrast_renderer_mirror_and_trainer():
     assert torch.isfinite(tr.renderer.v_offsets).all() and tr.renderer.v_offsets.abs().max().item() > 0
 
 
+@pytest.mark.parametrize("lam,geo,lanes", [(0.0, True, 1), (0.2, True, 3), (0.5, False, 4)])
+def test_diffmesh_fused_step_equals_per_view_autograd_step(lam, geo, lanes):
+    """DiffMesh.training_step as ONE library call (c3d_mesh_train_views: render, image loss incl. MS-SSIM, backward of every view on view lanes,
+    gradients summed over the views) against the per-view autograd path of the same trainer: same loss, same gradients (the texture gradient sums
+    with float atomics on both sides: equal to rounding), same per-view background draws, same parameters after the Adam step."""
+    from MVs_Algorithms.DiffRastMesh.diff_mesh import DiffMesh, DiffMeshCameraController
+    from MVs_Algorithms.DiffRastMesh.diff_mesh_renderer import DiffRastRenderer
+    H = W = 192
+    mesh = _torch_mesh()
+    r0 = DiffRastRenderer(mesh, force_cuda_rast=True).cuda()
+    ctl = DiffMeshCameraController(r0, W, H, 49.1, static_bg=[1.0, 1.0, 1.0], device="cuda")
+    poses = [[2.0, -20.0, az, 0.0, 0.0, 0.0] for az in (0.0, 90.0, 180.0, -90.0, 45.0)]
+    with torch.no_grad():
+        imgs, masks, _ = ctl.render_all_pose(poses)
+    rng = np.random.default_rng(5)
+    ref_images = [(imgs[i].cpu() * 0.8 + 0.1 * torch.tensor(rng.uniform(size=(H, W, 3)).astype(np.float32))) for i in range(5)]
+    ref_masks = [torch.tensor((rng.uniform(size=(H, W)) * 0.5 + 0.5).astype(np.float32)) * masks[i, ..., 0].cpu() for i in range(5)]     # soft masks
+    out = []
+    for fused in (False, True):
+        m2 = _torch_mesh()
+        m2.albedo = None
+        m2.set_new_albedo(64, 64)
+        tr = DiffMesh(m2, training_iterations=3, batch_size=5, texture_learning_rate=0.05, train_mesh_geometry=geo, geometry_learning_rate=2e-4,
+                      ms_ssim_loss_weight=lam, remesh_after_n_iteration=10 ** 9, invert_bg_prob=0.5, force_cuda_rasterize=True)
+        tr.use_fused_step, tr.view_lanes = fused, lanes
+        tr.prepare_training(ref_images, ref_masks, poses, 49.1)
+        assert tr._can_fuse() == fused
+        with torch.no_grad():
+            tr.renderer.raw_albedo.add_(torch.tensor(np.random.default_rng(1).normal(size=tuple(tr.renderer.raw_albedo.shape)).astype(np.float32), device="cuda"))
+        np.random.seed(11)                                           # the background of every view: one np.random draw per view, in view order
+        grads = {}
+        hooks = [q.register_hook(lambda g, k=k: grads.__setitem__(k, g.clone())) for k, q in (("albedo", tr.renderer.raw_albedo), ("offsets", tr.renderer.v_offsets))] if not fused else []
+        losses = []
+        for s_ in range(2):
+            if fused:                                                  # the kernels write .grad directly: read it before the optimizer clears it
+                opt_step = tr.optimizer.step
+                def spy(*a_, _o=opt_step, **k_):
+                    grads["albedo"] = tr.renderer.raw_albedo.grad.clone()
+                    if geo:
+                        grads["offsets"] = tr.renderer.v_offsets.grad.clone()
+                    return _o(*a_, **k_)
+                tr.optimizer.step = spy
+            losses.append(tr.training_step(s_, [0, 1, 2, 3, 4]).item())
+            if s_ == 0:
+                first = {k: v.clone() for k, v in grads.items()}
+        for h in hooks:
+            h.remove()
+        out.append((losses, first, tr.renderer.raw_albedo.detach().clone(), tr.renderer.v_offsets.detach().clone()))
+    (l0, g0, a0, o0), (l1, g1, a1, o1) = out
+    print("[mesh step] lam %.1f geo %s lanes %d: losses %s vs %s" % (lam, geo, lanes, l0, l1))
+    assert np.allclose(l0, l1, rtol=2e-4, atol=1e-6)
+    assert rel_err(g1["albedo"].cpu().numpy(), g0["albedo"].cpu().numpy()) <= 1e-3
+    if geo:
+        assert rel_err(g1["offsets"].cpu().numpy(), g0["offsets"].cpu().numpy()) <= 2e-3
+        assert float(o0.abs().max()) > 0 and torch.allclose(o0, o1, atol=3e-4)      # Adam turns tiny gradient differences near zero into +-lr steps (lr 2e-4)
+    assert torch.allclose(a0, a1, atol=0.11) and float((a0 - a1).abs().mean()) <= 2e-3
+
+
 def test_config1_example_workflow_through_the_nodes(tmp_path):
     """BASELINE config 1 (Render_Mesh_and_3DGS_Example): Load 3DGS -> GS Orbit Renderer and Mesh Orbit Renderer, 256x256, the
     MVDream(4) orbit, driven through the node classes; checked against the oracles."""
