@@ -38,6 +38,7 @@ python bench.py --mode fwd --cpu-baseline off 2>/dev/null | tail -1 > $OUT/${TAG
 python bench.py --mode fwd --views-per-gpu 64 --steps 3 --cpu-baseline off 2>/dev/null | tail -1 > $OUT/${TAG}_bench_fwd64_n1.json
 python bench.py --mode train --cpu-baseline off 2>/dev/null | tail -1 > $OUT/${TAG}_bench_train_n1.json
 python bench.py --workload mesh 2>/dev/null | tail -1 > $OUT/${TAG}_bench_mesh_n1.json
+python bench.py --workload mesh --render-path fused --cpu-baseline off 2>/dev/null | tail -1 > $OUT/${TAG}_bench_mesh_view_api_n1.json
 if [ -z "$QUICK" ]; then
   python bench.py --mode train --loss full-torch --steps 3 --warmup 3 --cpu-baseline off 2>/dev/null | tail -1 > $OUT/${TAG}_bench_train_torchloss_n1.json
   python bench.py --mode train --loss l1alpha --cpu-baseline off 2>/dev/null | tail -1 > $OUT/${TAG}_bench_train_l1alpha_n1.json
