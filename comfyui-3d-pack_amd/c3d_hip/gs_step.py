@@ -294,7 +294,7 @@ class FusedViewRender:
             self.status.zero_()
             with torch.cuda.device(self.device):
                 _h.check(lib.c3d_gs_render_views_raw(views, V, self.N, *[_h.ptr(_h.f32c(p)) for p in params], arr(color), arr(depth), arr(alpha),
-                                                     arr(radii) if want_radii else None, self.capacity, self.lanes, _h.ptr(self.workspace), _h.ptr(self.status),
+                                                     arr(radii) if want_radii else None, self.capacity, self.lanes, _h.ptr(self.workspace), self.workspace.numel(), _h.ptr(self.status),
                                                      _h.stream(self.device)), "c3d_gs_render_views_raw")
             st = self.status.tolist()       # the single host sync of the call
             if st[0] & 2:

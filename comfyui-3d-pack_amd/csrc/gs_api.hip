@@ -107,7 +107,7 @@ static int project_tail(GsGeom& g, int N, int64_t* num_rendered, hipStream_t s) 
 extern "C" {
 
 const char* c3d_last_error(void) { return g_err; }
-int c3d_version(void) { return 201; }
+int c3d_version(void) { return 202; }
 int c3d_gs_set_exact_dscale(int32_t on) { const int old = g_exact_dscale; g_exact_dscale = on != 0; return old; }
 
 size_t c3d_gs_geom_bytes(int32_t N) { GsGeom g; gs_carve_geom(nullptr, N, g); return g.bytes; }
@@ -540,7 +540,7 @@ int c3d_gs_step_param_backward_range(const c3d_gs_settings* views, int32_t V, in
 static int views_forward(const char* who, const c3d_gs_settings* views, int32_t V, int32_t N, const float* means3D, const float* f_dc, const float* f_rest,
                          const float* opacity_raw, const float* scaling_raw, const float* rotation_raw, float* const* out_color, float* const* out_depth,
                          float* const* out_alpha, int32_t* const* out_radii, int64_t pair_capacity, int32_t lanes, void* workspace, uint32_t* status,
-                         hipStream_t s0, bool keep_state) {
+                         hipStream_t s0, bool keep_state, bool two_slice_sets = false) {
     if (V <= 0 || N <= 0) return 0;
     if (!out_color || !out_alpha || !status) { c3d_set_error("%s: NULL pointer", who); return -1; }
     if (check_step_args(who, views, V, pair_capacity, lanes, workspace)) return -1;
@@ -557,7 +557,7 @@ static int views_forward(const char* who, const c3d_gs_settings* views, int32_t 
     // Forward only (no state kept): a lane reuses workspace slices view after view.  The views go in groups of L (one per lane); group k lives in
     // slice set k % 2, and a projection stream runs k_preprocess_views for whole groups two ahead of the lanes: parameters are streamed once per
     // L views, and group k + 2 is projected as soon as every lane has finished its view of group k.
-    const bool grouped = projected && !keep_state;
+    const bool grouped = projected && !keep_state && two_slice_sets;      // forward only, and the workspace has the second slice set the projection stream fills ahead
     hipStream_t sp = nullptr;
     auto project_group = [&](int k) -> int {
         const int v0 = k * L, nv = (V - v0) < L ? (V - v0) : L;
@@ -597,7 +597,7 @@ static int views_forward(const char* who, const c3d_gs_settings* views, int32_t 
         int* radii = (!keep_state && out_radii && out_radii[v]) ? out_radii[v] : w.radii;      // kept state: the backward pass reads the slice's copy
         float* depth = (out_depth && out_depth[v]) ? out_depth[v] : w.depth;
         if (grouped && hipStreamWaitEvent(s, ln.lp->pre_done[k & 1], 0) != hipSuccess) { c3d_set_error("%s: wait failed", who); rc_all = -1; break; }
-        rc_all = step_view_forward(p, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, g, b, im, radii, cap, status, out_color[v], depth, out_alpha[v], keep_state, s, &res, projected);
+        rc_all = step_view_forward(p, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, g, b, im, radii, cap, status, out_color[v], depth, out_alpha[v], keep_state, s, &res, keep_state ? projected : grouped);
         if (!rc_all && keep_state && out_radii && out_radii[v] &&
             hipMemcpyAsync(out_radii[v], w.radii, sizeof(int) * (size_t)N, hipMemcpyDeviceToDevice, s) != hipSuccess) {
             c3d_set_error("%s: radii copy failed", who); rc_all = -1;       // no early return: the lanes must still be joined
@@ -621,11 +621,19 @@ static int views_forward(const char* who, const c3d_gs_settings* views, int32_t 
 
 int c3d_gs_render_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, const float* means3D, const float* f_dc, const float* f_rest,
                              const float* opacity_raw, const float* scaling_raw, const float* rotation_raw, float* const* out_color, float* const* out_depth,
-                             float* const* out_alpha, int32_t* const* out_radii, int64_t pair_capacity, int32_t lanes, void* workspace, uint32_t* status,
-                             c3d_stream_t stream) {
+                             float* const* out_alpha, int32_t* const* out_radii, int64_t pair_capacity, int32_t lanes, void* workspace, int64_t workspace_bytes,
+                             uint32_t* status, c3d_stream_t stream) {
     if (V > 0 && N > 0 && !out_depth) { c3d_set_error("c3d_gs_render_views_raw: NULL pointer"); return -1; }
+    if (V > 0 && N > 0 && views && lanes >= 1 && pair_capacity > 0) {      // the slice count decides the schedule: say what the buffer holds instead of trusting a convention
+        const size_t one = c3d_gs_step_workspace_bytes(N, views[0].image_height, views[0].image_width, pair_capacity, 1);
+        const int L = lanes < V ? lanes : V;
+        if (workspace_bytes < (int64_t)(one * (size_t)L)) { c3d_set_error("c3d_gs_render_views_raw: workspace of %lld bytes holds fewer than %d slices of %zu bytes", (long long)workspace_bytes, L, one); return -1; }
+        const bool two_sets = workspace_bytes >= (int64_t)(one * (size_t)(2 * L));
+        return views_forward("c3d_gs_render_views_raw", views, V, N, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, out_color, out_depth, out_alpha, out_radii,
+                             pair_capacity, lanes, workspace, status, (hipStream_t)stream, false, two_sets);
+    }
     return views_forward("c3d_gs_render_views_raw", views, V, N, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, out_color, out_depth, out_alpha, out_radii,
-                         pair_capacity, lanes, workspace, status, (hipStream_t)stream, false);
+                         pair_capacity, lanes, workspace, status, (hipStream_t)stream, false, false);
 }
 
 int c3d_gs_forward_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, const float* means3D, const float* f_dc, const float* f_rest,

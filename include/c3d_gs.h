@@ -159,13 +159,15 @@ int c3d_gs_step_param_backward_range(const c3d_gs_settings* views /* host [V] */
 /* Forward only, V views of the same cloud in one call (orbit rendering of a trained model: the per-camera loop of the reference's
  * orbit-renderer node over GaussianSplattingRenderer.render, main_3DGS_renderer.py:927-936), raw parameters, no host synchronisation,
  * views dealt onto `lanes` streams as above.  HOST arrays of V device pointers: out_color [3,H,W], out_depth [1,H,W], out_alpha [1,H,W];
- * out_radii (array or entries may be NULL) [N] int32.  The workspace needs c3d_gs_step_workspace_bytes(N, H, W, pair_capacity, 2 * lanes)
- * bytes (TWO slices per lane since ABI 201: the views go in groups of `lanes`, and while the lanes bin and composite group k a projection
- * stream already fills the other slice set with groups k + 1 / k + 2 -- one pass over the parameters per group instead of one per view).  status as for c3d_gs_train_views_raw: on overflow the images of the affected views are incomplete. */
+ * out_radii (array or entries may be NULL) [N] int32.  workspace_bytes says what the workspace holds (ABI 202): with
+ * c3d_gs_step_workspace_bytes(N, H, W, pair_capacity, 2 * lanes) bytes -- two slices per lane -- the views go in groups of `lanes`, and while the lanes bin
+ * and composite group k a projection stream already fills the other slice set with groups k + 1 / k + 2 (one pass over the parameters per group instead
+ * of one per view); with one slice per lane every view is projected by its own launch; less is an error.  status as for c3d_gs_train_views_raw: on overflow the images of the affected views are incomplete. */
 int c3d_gs_render_views_raw(const c3d_gs_settings* views /* host [V] */, int32_t V, int32_t N, const float* means3D, const float* f_dc,
                             const float* f_rest, const float* opacity_raw, const float* scaling_raw, const float* rotation_raw,
                             float* const* out_color, float* const* out_depth, float* const* out_alpha, int32_t* const* out_radii,
-                            int64_t pair_capacity, int32_t lanes, void* workspace, uint32_t* status /* device [2] */, c3d_stream_t stream);
+                            int64_t pair_capacity, int32_t lanes, void* workspace, int64_t workspace_bytes, uint32_t* status /* device [2] */,
+                            c3d_stream_t stream);
 
 /* ---- the same step split at the image (round 2): any loss torch can differentiate --------------------------------------------
  * The reference's default loss adds 0.2 * (1 - MS-SSIM) to the L1 / alpha-MSE terms and draws a white or black background per view

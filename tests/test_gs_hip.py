@@ -902,6 +902,22 @@ def test_render_views_equals_per_view_render(lanes, res):
     # with autograd on the controller falls back to the per-view loop and keeps the graph
     images2, _, extra2 = ctl.render_all_pose(poses[:2])
     assert images2.requires_grad and "viewspace_points" in extra2
+    # the workspace's size picks the schedule: one slice per lane = every view projected by its own launch (same images); less than that is refused
+    with torch.no_grad():
+        r.render_views(cams, ctl.static_bg, lanes=lanes)              # (the controller call above left an 8-lane object behind: make the `lanes` one current)
+    vr = r._view_render
+    assert vr.lanes == lanes and vr._fitted
+    full = vr.workspace
+    one = vr.workspace.numel() // (2 * vr.lanes)
+    with torch.no_grad():
+        vr.workspace = full[:one * vr.lanes]
+        out1 = r.render_views(cams, ctl.static_bg, lanes=lanes)
+        for k in ("image", "depth", "alpha"):
+            assert torch.equal(out1[k], out[k]), k
+        vr.workspace = full[:one * min(vr.lanes, len(cams)) - 256]
+        with pytest.raises(RuntimeError, match="fewer than"):
+            r.render_views(cams, ctl.static_bg, lanes=lanes)
+        vr.workspace = full
 
 
 @pytest.mark.parametrize("lambda_ssim", [0.0, 0.2])
