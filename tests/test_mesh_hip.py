@@ -1,5 +1,7 @@
 """Parity tests (-m gpu) of the HIP mesh ops behind `nvdiffrast.torch`, through the C-ABI, against oracle/mesh_oracle.c.
 Integers (triangle ids) exact up to a vanishing number of depth near-ties; images L1 <= 1e-4; gradients <= 1e-3 relative."""
+import ctypes as C
+
 import numpy as np
 import pytest
 import torch
@@ -384,6 +386,61 @@ def test_diffmesh_fused_step_equals_per_view_autograd_step(lam, geo, lanes):
         assert rel_err(g1["offsets"].cpu().numpy(), g0["offsets"].cpu().numpy()) <= 2e-3
         assert float(o0.abs().max()) > 0 and torch.allclose(o0, o1, atol=3e-4)      # Adam turns tiny gradient differences near zero into +-lr steps (lr 2e-4)
     assert torch.allclose(a0, a1, atol=0.11) and float((a0 - a1).abs().mean()) <= 2e-3
+
+
+def test_fused_mesh_step_accumulate_lanes_and_argument_checks():
+    """c3d_mesh_train_views through FusedMeshStep: accumulate=True adds to the gradient buffers, the result does not depend on the number of view
+    lanes beyond the rounding of the texture gradient's float atomics, a rank without views leaves zero gradients, and bad arguments are refused
+    with a message (NULL pointers, the MS-SSIM term on images that are too small for its five scales)."""
+    from c3d_hip.mesh_step import FusedMeshStep
+    from c3d_hip.mesh_sigs import MeshStepLoss, MeshView
+    from shared_utils.camera_utils import OrbitCamera, orbit_camera
+    import nvdiffrast.torch as dr
+    H = W = 192
+    mesh = _torch_mesh()
+    mesh.albedo = None
+    mesh.set_new_albedo(64, 64)
+    raw = torch.randn((64, 64, 3), device="cuda") * 0.5
+    off = torch.randn_like(mesh.v) * 1e-3
+    cam = OrbitCamera(W, H, fovy=49.1)
+    proj = cam.perspective.astype(np.float32)
+    views = [((proj @ np.linalg.inv(orbit_camera(-20.0, az, 2.0).astype(np.float32)).astype(np.float32)).astype(np.float32), bg) for az, bg in ((0.0, (1, 1, 1)), (100.0, (0, 0, 0)), (-130.0, (1, 1, 1)))]
+    rng = np.random.default_rng(3)
+    targets = [T(rng.uniform(size=(3, H, W)).astype(np.float32)) for _ in views]
+    masks = [T(rng.uniform(0.3, 1.0, size=(1, H, W)).astype(np.float32)), None, T(np.ones((1, H, W), np.float32))]
+    f, ft, vt = mesh.f.to(torch.int32).contiguous(), mesh.ft.to(torch.int32).contiguous(), mesh.vt.float().contiguous()
+    glctx = dr.RasterizeCudaContext()
+    res = {}
+    for lanes in (1, 3):
+        st = FusedMeshStep("cuda", lanes=lanes)
+        d_ra, d_vo = torch.empty_like(raw), torch.empty_like(off)
+        loss = st.run(views, mesh.v, off, f, vt, ft, raw, glctx, targets, masks, d_ra, d_vo, H, W, w_mse=0.7, w_ssim=0.3, scale=1 / 3).clone()
+        res[lanes] = (loss, d_ra.clone(), d_vo.clone())
+        loss2 = st.run(views, mesh.v, off, f, vt, ft, raw, glctx, targets, masks, d_ra, d_vo, H, W, w_mse=0.7, w_ssim=0.3, scale=1 / 3, accumulate=True).clone()
+        assert torch.allclose(loss2, loss, rtol=1e-5)
+        assert rel_err(d_ra.cpu().numpy(), 2 * res[lanes][1].cpu().numpy()) <= 1e-5 and rel_err(d_vo.cpu().numpy(), 2 * res[lanes][2].cpu().numpy()) <= 1e-5
+        # no views on this rank: zero gradients, zero loss
+        z = st.run([], mesh.v, off, f, vt, ft, raw, glctx, [], None, d_ra, d_vo, H, W)
+        assert float(z) == 0.0 and float(d_ra.abs().max()) == 0.0 and float(d_vo.abs().max()) == 0.0
+    assert torch.allclose(res[1][0], res[3][0], rtol=1e-5) and float(res[1][1].abs().max()) > 0 and float(res[1][2].abs().max()) > 0
+    assert rel_err(res[3][1].cpu().numpy(), res[1][1].cpu().numpy()) <= 1e-5 and rel_err(res[3][2].cpu().numpy(), res[1][2].cpu().numpy()) <= 1e-5
+    # geometry not trained: no vertex gradient is produced, the texture gradient is the same
+    st = FusedMeshStep("cuda", lanes=2)
+    d_ra = torch.empty_like(raw)
+    st.run(views, mesh.v, off, f, vt, ft, raw, glctx, targets, masks, d_ra, None, H, W, w_mse=0.7, w_ssim=0.3, scale=1 / 3)
+    assert rel_err(d_ra.cpu().numpy(), res[1][1].cpu().numpy()) <= 1e-5
+    # argument checks
+    import c3d_hip
+    lib = c3d_hip.lib()
+    one = (MeshView * 1)(MeshView(int(mesh.v.shape[0]), int(f.shape[0]), int(vt.shape[0]), 128, 128, 64, 64, (C.c_float * 16)(*[float(x) for x in views[0][0].reshape(-1)]), (C.c_float * 3)(1, 1, 1)))
+    assert lib.c3d_mesh_train_views(one, 1, *([None] * 8), None, None, None, None, None, None, 0, 1, None, None) != 0 and b"NULL" in lib.c3d_last_error()
+    tg = (C.c_void_p * 1)(targets[0].data_ptr())
+    ws = torch.empty((lib.c3d_mesh_step_workspace_bytes(one[0].V, one[0].T, 128, 128, 64, 64, 1, 1),), dtype=torch.uint8, device="cuda")
+    bad = MeshStepLoss(1.0, 0.5, 1.0)
+    p = c3d_hip.ptr
+    rc = lib.c3d_mesh_train_views(one, 1, p(mesh.v), p(off), p(f), p(vt), p(ft), p(raw), p(dr._topology(f)), p(glctx.vertex_topology(f, one[0].V)), tg, None, C.byref(bad), p(d_ra),
+                                  None, None, 0, 1, p(ws), None)
+    assert rc != 0 and b"160" in lib.c3d_last_error()
 
 
 def test_config1_example_workflow_through_the_nodes(tmp_path):
