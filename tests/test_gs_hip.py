@@ -182,6 +182,79 @@ def test_precomputed_colour_and_covariance_paths():
     assert rel_err(inp["means3D"].grad.cpu().numpy(), og["means3D"]) <= GRAD_REL
 
 
+def test_call_patterns_of_the_other_consumers_in_the_reference():
+    """The rasterizer has three more callers in the reference tree besides the MVs path; each drives it a little differently.  Their call sequences,
+    statement by statement, against the oracle (forward and, where the caller differentiates, backward):
+      LGM            Gen_3D_Modules/LGM/core/gs.py:27-90            per (batch, view) loop, sh_degree = 0, colours given (colors_precomp), plain zeros for means2D
+      TriplaneGaussian  .../TriplaneGaussian/models/renderer.py:205-275   means2D = zeros(requires_grad) + 0 with retain_grad() (a NON-leaf), float32 autocast around the call
+      TRELLIS        .../TRELLIS/trellis/renderers/gaussian_render.py:55-135   covariance built in Python (cov3D_precomp, with a scaling modifier), colours from a Python SH evaluation"""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    sc = S.make_small_scene(N=300)
+    st = S.camera_settings(160, 112, 49.1, 15.0, 40.0, 2.2, sh_degree=0)
+    dev = "cuda"
+    t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device=dev)
+    rgb = np.clip(sc["shs"][:, 0, :] * 0.28209479177387814 + 0.5, 0, None).astype(np.float32)
+    # --- LGM: a [B, N, 14] tensor sliced per batch entry, two views per entry
+    gauss = torch.cat([t(sc["means3D"]), t(sc["opacities"]), t(sc["scales"]), t(sc["rotations"]), t(rgb)], dim=1)[None].repeat(2, 1, 1)
+    for b in range(2):
+        means3D, opacity = gauss[b, :, 0:3].contiguous().float(), gauss[b, :, 3:4].contiguous().float()
+        scales, rotations, rgbs = gauss[b, :, 4:7].contiguous().float(), gauss[b, :, 7:11].contiguous().float(), gauss[b, :, 11:].contiguous().float()
+        for az in (40.0, 160.0):
+            stv = S.camera_settings(160, 112, 49.1, 15.0, az, 2.2, sh_degree=0)
+            rs = GaussianRasterizationSettings(image_height=112, image_width=160, tanfovx=stv["tanfovx"], tanfovy=stv["tanfovy"], bg=t(stv["bg"]), scale_modifier=1,
+                                               viewmatrix=t(stv["viewmatrix"]).reshape(4, 4).float(), projmatrix=t(stv["projmatrix"]).reshape(4, 4).float(), sh_degree=0,
+                                               campos=t(stv["campos"]).float(), prefiltered=False, debug=False)
+            img, radii, depth, alpha = GaussianRasterizer(raster_settings=rs)(means3D=means3D, means2D=torch.zeros_like(means3D, dtype=torch.float32, device=dev), shs=None,
+                                                                               colors_precomp=rgbs, opacities=opacity, scales=scales, rotations=rotations, cov3D_precomp=None)
+            oc, orad, od, oa, _ = O.forward(sc["means3D"], sc["opacities"], stv, colors_precomp=rgb, scales=sc["scales"], rotations=sc["rotations"])
+            assert np.abs(img.cpu().numpy() - oc).mean() <= IMG_L1 and (radii.cpu().numpy() == orad).all() and np.abs(alpha.cpu().numpy() - oa).mean() <= IMG_L1
+    # --- TriplaneGaussian: non-leaf screen-space points that keep their gradient, autocast(float32) around the rasterizer
+    st3 = S.camera_settings(160, 112, 49.1, 15.0, 40.0, 2.2, sh_degree=3)
+    xyz = t(sc["means3D"]).requires_grad_(True)
+    shs, op, scl, rot = (t(sc[k]).requires_grad_(True) for k in ("shs", "opacities", "scales", "rotations"))
+    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=dev) + 0
+    screenspace_points.retain_grad()
+    rs = GaussianRasterizationSettings(image_height=112, image_width=160, tanfovx=st3["tanfovx"], tanfovy=st3["tanfovy"], bg=t(st3["bg"]), scale_modifier=1.0,
+                                       viewmatrix=t(st3["viewmatrix"]).reshape(4, 4), projmatrix=t(st3["projmatrix"]).reshape(4, 4).float(), sh_degree=3, campos=t(st3["campos"]),
+                                       prefiltered=False, debug=False)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with torch.autocast(device_type="cuda", dtype=torch.float32):
+            img, radii, depth, alpha = GaussianRasterizer(raster_settings=rs)(means3D=xyz, means2D=screenspace_points, shs=shs, colors_precomp=None, opacities=op, scales=scl,
+                                                                               rotations=rot, cov3D_precomp=None)
+    gC = np.random.default_rng(3).normal(size=(3, 112, 160)).astype(np.float32)
+    (img.permute(1, 2, 0) * t(gC).permute(1, 2, 0)).sum().backward()
+    oc, orad, od, oa, ost = O.forward(sc["means3D"], sc["opacities"], st3, shs=sc["shs"], scales=sc["scales"], rotations=sc["rotations"], dtype=np.float64)
+    og = O.backward(ost, gC)
+    assert np.abs(img.detach().cpu().numpy() - oc).mean() <= IMG_L1
+    assert screenspace_points.grad is not None and rel_err(screenspace_points.grad.cpu().numpy(), og["means2D"]) <= GRAD_REL
+    for k, q in (("means3D", xyz), ("shs", shs), ("opacities", op), ("scales", scl), ("rotations", rot)):
+        assert rel_err(q.grad.cpu().numpy(), og[k]) <= GRAD_REL, k
+    # --- TRELLIS: covariance and colours computed in Python (scaling modifier 0.8 folded into the covariance), override colour path
+    m = 0.8
+    q, s_ = sc["rotations"].astype(np.float64), sc["scales"].astype(np.float64) * m
+    r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    Rm = np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y), 2 * (x * y + r * z), 1 - 2 * (x * x + z * z),
+                   2 * (y * z - r * x), 2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], -1).reshape(-1, 3, 3)
+    Mm = Rm * s_[:, None, :]
+    Sg = Mm @ Mm.transpose(0, 2, 1)
+    cov6 = np.stack([Sg[:, 0, 0], Sg[:, 0, 1], Sg[:, 0, 2], Sg[:, 1, 1], Sg[:, 1, 2], Sg[:, 2, 2]], 1).astype(np.float32)
+    ocol = O.forward(sc["means3D"], sc["opacities"], st3, shs=sc["shs"], scales=sc["scales"], rotations=sc["rotations"])[4].geometry()["rgb"].astype(np.float32)   # = clamp_min(eval_sh + 0.5, 0)
+    rs = GaussianRasterizationSettings(image_height=112, image_width=160, tanfovx=st3["tanfovx"], tanfovy=st3["tanfovy"], bg=t(st3["bg"]), scale_modifier=m,
+                                       viewmatrix=t(st3["viewmatrix"]).reshape(4, 4), projmatrix=t(st3["projmatrix"]).reshape(4, 4), sh_degree=3, campos=t(st3["campos"]),
+                                       prefiltered=False, debug=False)
+    cov_t, col_t = t(cov6).requires_grad_(True), t(ocol).requires_grad_(True)
+    img, radii, depth, alpha = GaussianRasterizer(raster_settings=rs)(means3D=t(sc["means3D"]), means2D=torch.zeros((300, 3), device=dev, requires_grad=True) + 0, shs=None,
+                                                                       colors_precomp=col_t, opacities=t(sc["opacities"]), scales=None, rotations=None, cov3D_precomp=cov_t)
+    st_m = dict(st3, scale_modifier=m)
+    oc, orad, od, oa, ost = O.forward(sc["means3D"], sc["opacities"], st_m, colors_precomp=ocol, cov3D_precomp=cov6, dtype=np.float64)
+    assert np.abs(img.detach().cpu().numpy() - oc).mean() <= IMG_L1 and (radii.cpu().numpy() == orad).all()
+    (img * t(gC)).sum().backward()
+    og = O.backward(ost, gC)
+    assert rel_err(cov_t.grad.cpu().numpy(), og["cov3D"]) <= GRAD_REL and rel_err(col_t.grad.cpu().numpy(), og["colors"]) <= GRAD_REL
+
+
 # ---------------------------------------------------------------- backward parity
 @pytest.mark.parametrize("c", CASES)
 def test_backward_matches_oracle(c):
