@@ -11,7 +11,7 @@ Same function names, argument meaning and return shapes as the module the refere
 The arithmetic runs in libc3d_hip.so; this file allocates tensors and wires autograd.  There is no CPU path.
     rasterize(..., ranges=[B,2]) / antialias with pos [V,4]: range (instanced) mode, composed on the host from the B = 1 kernels
     boundary modes 'wrap' | 'clamp' | 'zero' ('zero' for the nearest / linear filters, composed from a zero-padded texture + 'clamp')
-Not built (raise NotImplementedError): cube maps (boundary 'cube'), 'zero' with the mip-mapped filters, DepthPeeler(ranges=...); gradients w.r.t.
+Not built (raise NotImplementedError): cube maps (boundary 'cube'), 'zero' with the mip-mapped filters; gradients w.r.t.
 rast_db / out_da / uv_da / mip_level_bias are not propagated (no consumer on the reference's path).
 """
 import torch
@@ -159,23 +159,44 @@ class DepthPeeler:
     empty).  Layers are differentiable like rasterize() outputs.  (Reference use: InstantMesh/models/geometry/render/neural_render.py:103.)"""
 
     def __init__(self, glctx, pos, tri, resolution, ranges=None, grad_db=True):
-        if ranges is not None:
-            raise NotImplementedError("DepthPeeler(ranges=...) (instanced range mode) is not built")
         if not isinstance(glctx, RasterizeCudaContext):
             raise TypeError("DepthPeeler: glctx must be a RasterizeCudaContext / RasterizeGLContext")
         self.raster_ctx, self.pos, self.tri, self.resolution, self.grad_db = glctx, pos, tri, resolution, grad_db
         self._bufs, self._layer, self._active = [None, None], 0, False
+        # range ("instanced") mode, as rasterize(..., ranges=): one vertex buffer pos [V,4], item b peels triangles tri[start_b : start_b + count_b].
+        # Composed on the host from B = 1 peelers that share nothing but the vertex buffer (whose gradient autograd sums over the items).
+        self._items = None
+        if ranges is not None:
+            if pos.dim() != 2 or pos.shape[-1] != 4:
+                raise ValueError("DepthPeeler: with ranges, pos must be [V,4]")
+            r = torch.as_tensor(ranges)
+            if r.is_cuda or r.dim() != 2 or r.shape[1] != 2 or r.dtype not in (torch.int32, torch.int64):
+                raise ValueError("DepthPeeler: ranges must be an integer CPU tensor of shape [B,2]")
+            tri_c = tri.to(torch.int32).contiguous()
+            T = int(tri_c.shape[0])
+            self._items = []
+            for start, count in r.tolist():
+                if start < 0 or count < 0 or start + count > T:
+                    raise ValueError("DepthPeeler: range (%d, %d) does not fit the %d triangles" % (start, count, T))
+                sub = DepthPeeler.__new__(DepthPeeler)
+                sub.raster_ctx, sub.pos, sub.tri, sub.resolution, sub.grad_db = glctx, pos.unsqueeze(0), tri_c[start:start + count], resolution, grad_db
+                sub._bufs, sub._layer, sub._active, sub._items = [None, None], 0, False, None
+                self._items.append((int(start), sub))
 
     def __enter__(self):
         if self.raster_ctx.active_depth_peeler is not None:
             raise RuntimeError("DepthPeeler: another depth peeling operation is active on this context")
         self.raster_ctx.active_depth_peeler = self
         self._layer, self._active = 0, True
+        for _, sub in (self._items or []):
+            sub._layer, sub._active = 0, True
         return self
 
     def __exit__(self, *args):
         self.raster_ctx.active_depth_peeler = None
         self._bufs, self._active = [None, None], False
+        for _, sub in (self._items or []):
+            sub._bufs, sub._active = [None, None], False
         return False
 
     def _next_buffers(self, nbytes, device):
@@ -189,7 +210,21 @@ class DepthPeeler:
     def rasterize_next_layer(self):
         if not self._active:
             raise RuntimeError("DepthPeeler: rasterize_next_layer() must be called inside the `with` block")
-        return _Rasterize.apply(self.raster_ctx, self.pos, self.tri, self.resolution, self.grad_db, self)
+        if self._items is None:
+            return _Rasterize.apply(self.raster_ctx, self.pos, self.tri, self.resolution, self.grad_db, self)
+        rasts, dbs = [], []
+        for start, sub in self._items:          # every item peels its own triangle range; ids in the output index the full `tri`
+            rast, db = _Rasterize.apply(sub.raster_ctx, sub.pos, sub.tri, sub.resolution, sub.grad_db, sub)
+            if start:
+                shift = torch.zeros_like(rast)
+                shift[..., 3] = (rast[..., 3] > 0).to(rast.dtype) * float(start)
+                rast = rast + shift
+            rasts.append(rast); dbs.append(db)
+        if not rasts:
+            H, W = int(self.resolution[0]), int(self.resolution[1])
+            z = self.pos.new_zeros((0, H, W, 4), dtype=torch.float32)
+            return z, z.clone()
+        return torch.cat(rasts, 0), torch.cat(dbs, 0)
 
 
 class _Interpolate(torch.autograd.Function):

@@ -221,6 +221,66 @@ def test_depth_peeler_layers_match_oracle_and_are_differentiable(gpu):
 
 
 @pytest.mark.gpu
+def test_depth_peeler_in_range_mode(gpu):
+    """DepthPeeler(glctx, pos [V,4], tri, res, ranges): every minibatch item peels its own triangle range of one shared vertex buffer; triangle ids index
+    the full index buffer.  Each item and layer against the oracle peeling that sub-mesh alone; the vertex gradient is the sum over the items."""
+    import nvdiffrast.torch as dr
+    H, W = 80, 72
+    v, f, vt, vn = S.make_uv_sphere(14, 20, radius=0.7, displacement=0.25)
+    pos3, _, _ = S.mesh_clip_positions(v, -20.0, 35.0, 2.0, W, H)
+    pos = pos3[0]
+    Tn = f.shape[0]
+    ranges = np.array([[0, Tn], [Tn // 3, Tn - Tn // 3], [7, 0], [0, Tn // 2]], np.int32)
+    ctx = dr.RasterizeCudaContext()
+    tpos, ttri = T(pos, grad=True), T(f, torch.int32)
+    with pytest.raises(ValueError):
+        dr.DepthPeeler(ctx, tpos[None], ttri, (H, W), ranges=torch.tensor(ranges))          # range mode wants pos [V,4]
+    with pytest.raises(ValueError):
+        dr.DepthPeeler(ctx, tpos, ttri, (H, W), ranges=torch.tensor([[0, Tn + 1]]))
+    oprev = [None] * len(ranges)
+    layers = []
+    with dr.DepthPeeler(ctx, tpos, ttri, (H, W), ranges=torch.tensor(ranges)) as peeler:
+        for k in range(3):
+            rast, db = peeler.rasterize_next_layer()
+            assert rast.shape == (len(ranges), H, W, 4) and db.shape == rast.shape
+            r = rast.detach().cpu().numpy()
+            for b, (start, count) in enumerate(ranges.tolist()):
+                if count == 0:
+                    assert (r[b] == 0).all()
+                    continue
+                orast, odb = M.rasterize_next_layer(pos[None], f[start:start + count], (H, W), oprev[b])
+                oprev[b] = orast
+                oid = np.where(orast[0, ..., 3] > 0, orast[0, ..., 3] + start, 0)                # ids index the full `tri`
+                same = r[b, ..., 3] == oid
+                assert (~same).sum() <= 4, (k, b, (~same).sum())
+                assert np.abs(r[b][same][:, :3] - orast[0][same][:, :3]).max() <= 1e-3
+            layers.append(rast)
+    plain, _ = dr.rasterize(ctx, tpos, ttri, (H, W), ranges=torch.tensor(ranges))
+    assert torch.equal(layers[0], plain)                              # layer 0 is rasterize(..., ranges)
+    with dr.DepthPeeler(ctx, tpos.detach()[None], ttri, (H, W)) as whole:
+        whole.rasterize_next_layer()
+        second, _ = whole.rasterize_next_layer()
+    assert torch.equal(layers[1][0].detach(), second[0])              # the item that covers everything peels like the plain peeler
+    # gradient of a peeled layer w.r.t. the shared vertex buffer: sum over the items (float64 oracle, where both pipelines drew the same triangle)
+    g = np.random.default_rng(8).normal(size=(len(ranges), H, W, 4)).astype(np.float32); g[..., 2:] = 0
+    d = np.float64
+    dpos = np.zeros((1,) + pos.shape, d)
+    r1 = layers[1].detach().cpu().numpy()
+    gm = np.zeros_like(g)
+    for b, (start, count) in enumerate(ranges.tolist()):
+        if count == 0:
+            continue
+        fs = f[start:start + count]
+        o0, _ = M.rasterize_next_layer(pos[None], fs, (H, W), None, dtype=d)
+        o1, _ = M.rasterize_next_layer(pos[None], fs, (H, W), o0, dtype=d)
+        ok = np.where(o1[0, ..., 3] > 0, o1[0, ..., 3] + start, 0) == r1[b, ..., 3]
+        gm[b] = g[b] * ok[..., None]
+        dpos += M.rasterize_bwd(pos[None], fs, o1, gm[b:b + 1].astype(d), dtype=d)
+    (layers[1] * T(gm)).sum().backward()
+    assert rel_err(tpos.grad.cpu().numpy(), dpos[0]) <= 2 * GRAD_REL
+
+
+@pytest.mark.gpu
 def test_range_mode_rasterize_interpolate_antialias(gpu):
     """rasterize(pos [V,4], tri, res, ranges) -> interpolate(attr [V,A]) -> antialias(pos [V,4]): forward against the oracle's range
     mode, gradients (summed over the minibatch by autograd) against the float64 oracle chain."""
