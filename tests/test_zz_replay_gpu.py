@@ -106,23 +106,25 @@ def test_bench_two_ranks_sharing_the_device():
     """The N > 1 control flow of bench.py itself: two ranks launched exactly as the driver launches them
     (python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2), both on GPU 0 and talking gloo (C3D_BENCH_SHARE_DEVICE=1,
     the hook for 1-GPU boxes): view sharding, barriers, the gradient exchange on the flat buffer, max-over-ranks timing, ONE JSON line from
-    rank 0.  The numbers of such a run mean nothing; that it runs, shards and reports is the test.  Both exchange modes."""
+    rank 0.  The numbers of such a run mean nothing; that it runs, shards and reports is the test.  Both exchange modes (all-reduce = the chunked exchange
+    overlapped with the per-Gaussian backward pass), and the training mode on top."""
     import json
     import socket
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for exchange in ("allreduce", "allgather"):
+    for exchange, mode in (("allreduce", "fwdbwd"), ("allgather", "fwdbwd"), ("allreduce", "train")):      # train: the overlapped exchange feeding the fused Adam
         s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
         env = dict(os.environ, C3D_BENCH_SHARE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
                os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--gaussians", "200000", "--width", "640", "--height", "360",
-               "--views-per-gpu", "2", "--cpu-baseline", "off", "--exchange", exchange]
+               "--views-per-gpu", "2", "--cpu-baseline", "off", "--exchange", exchange, "--mode", mode]
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         assert len(lines) == 1, r.stdout[-2000:]                      # rank 0 only
         d = json.loads(lines[0])
         assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 2 and d["warmup"] == 1
+        assert d["config"]["exchange_chunks"] == (4 if exchange == "allreduce" else 1)
         assert d["config"]["global_views_per_step"] == 4 and d["config"]["exchange"] == exchange and d["config"]["parallelism"] == "view-parallel dp2"
         assert d["value"] > 0 and abs(d["value"] - 4 * 640 * 360 / (d["ms_per_step"] * 1e-3) / 1e6) <= 0.01 * d["value"]
         assert d["roofline"] is not None and d["cpu_baseline"] is None and d["vs_baseline"] is None
