@@ -22,7 +22,10 @@ class GsSettings(C.Structure):
     """struct c3d_gs_settings (include/c3d_gs.h)"""
     _fields_ = [("image_height", i32), ("image_width", i32), ("tanfovx", f32), ("tanfovy", f32),
                 ("scale_modifier", f32), ("sh_degree", i32), ("prefiltered", i32), ("debug", i32),
-                ("bg", vp), ("viewmatrix", vp), ("projmatrix", vp), ("campos", vp)]
+                ("bg", vp), ("viewmatrix", vp), ("projmatrix", vp), ("campos", vp), ("flags", i32), ("reserved0", i32)]
+
+
+GS_FLAG_EXACT_DSCALE = 1      # C3D_GS_FLAG_EXACT_DSCALE
 
 
 class GsLoss(C.Structure):
@@ -49,7 +52,6 @@ _SIGNATURES = {
     "c3d_gs_forward_views_raw": (C.c_int, [C.POINTER(GsSettings), i32, i32] + [vp] * 6 + [C.POINTER(vp)] * 4 + [i64, i32, vp, vp, vp]),
     "c3d_gs_step_param_backward_range": (C.c_int, [C.POINTER(GsSettings), i32, i32] + [vp] * 5 + [vp] * 6 + [i64, i32, vp, i32, i32, vp]),
     "c3d_gs_backward_views_raw": (C.c_int, [C.POINTER(GsSettings), i32, i32] + [vp] * 5 + [C.POINTER(vp)] * 3 + [vp] * 6 + [i64, i32, i32, vp, vp]),
-    "c3d_gs_set_exact_dscale": (C.c_int, [i32]),
     "c3d_gs_step_read_view": (C.c_int, [i32, i32, i32, i64, vp, i32, vp, vp, vp]),
     "c3d_gs_mark_visible": (C.c_int, [i32, vp, vp, vp, vp, vp]),
     "c3d_gs_debug_state": (C.c_int, [i32, i32, i32, vp, i64, vp] + [vp] * 7 + [vp]),
@@ -70,7 +72,7 @@ _SIGNATURES = {
 }
 
 
-ABI_VERSION = 202      # c3d_version() of the library these signatures describe
+ABI_VERSION = 300      # c3d_version() of the library these signatures describe
 
 
 def exported_symbols():

@@ -17,7 +17,6 @@ void c3d_set_error(const char* fmt, ...) {
 // msssim.hip: out_word += va + vb * mean MS-SSIM(x, y_eff), dL_dy (+)= grad_scale * d mean / dy
 int ms_value_grad(const float* x, const float* y, const float* mask, int clamp_y, int B, int C, int H, int W, float grad_scale, int accumulate, float* dL_dy,
                   float va, float vb, float* ms_out, void* workspace, hipStream_t s);
-static int g_exact_dscale = 0;   // c3d_gs_set_exact_dscale
 static int tile_sort_bits(int tiles) {
     int bits = 0;
     while ((1ll << bits) < (long long)tiles) bits++;
@@ -39,7 +38,7 @@ static int make_params(const c3d_gs_settings* st, int N, int M, GsParams& p) {
     p.tanfovx = st->tanfovx; p.tanfovy = st->tanfovy;
     p.focal_x = p.W / (2.0f * st->tanfovx); p.focal_y = p.H / (2.0f * st->tanfovy);
     p.scale_modifier = st->scale_modifier;
-    p.dscale_mod = g_exact_dscale ? st->scale_modifier : 1.0f;
+    p.dscale_mod = (st->flags & C3D_GS_FLAG_EXACT_DSCALE) ? st->scale_modifier : 1.0f;
     p.bg = st->bg; p.view = st->viewmatrix; p.proj = st->projmatrix; p.campos = st->campos;
     return 0;
 }
@@ -107,8 +106,7 @@ static int project_tail(GsGeom& g, int N, int64_t* num_rendered, hipStream_t s) 
 extern "C" {
 
 const char* c3d_last_error(void) { return g_err; }
-int c3d_version(void) { return 202; }
-int c3d_gs_set_exact_dscale(int32_t on) { const int old = g_exact_dscale; g_exact_dscale = on != 0; return old; }
+int c3d_version(void) { return 300; }
 
 size_t c3d_gs_geom_bytes(int32_t N) { GsGeom g; gs_carve_geom(nullptr, N, g); return g.bytes; }
 size_t c3d_gs_binning_bytes(int64_t D, int32_t H, int32_t W) {

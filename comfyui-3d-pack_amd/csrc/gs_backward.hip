@@ -21,19 +21,6 @@ __device__ __forceinline__ void swap32(float& a, float& b) {   // a[32..63] <-> 
 __device__ __forceinline__ void swap16(float& a, float& b) {   // rows 1,3 of a <-> rows 0,2 of b
     asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
-// lane select on a wave mask held in an SGPR pair (a ballot).  Written as asm because hipcc picks the VOP2 form that reads VCC
-// (v_cndmask_b32_e32 ..., vcc), which issues ~5x slower on gfx950 than the VOP3 form with an SGPR-pair mask
-// (profiles/r01f_valu_rate_microbench.txt: 22.9 vs 4.7 cycles per wave-instruction).
-__device__ __forceinline__ float sel64(uint64_t m, float if_set, float otherwise) {
-    float r;
-    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(otherwise), "v"(if_set), "s"(m));
-    return r;
-}
-__device__ __forceinline__ float sel64z(uint64_t m, float if_set) {   // 0 where the mask is clear
-    float r;
-    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(if_set), "s"(m));
-    return r;
-}
 __device__ __forceinline__ float wave_reduce4(float a, float b, float c, float d) {
     swap32(a, b); float p = a + b;      // lanes 0-31: a folded to 32 partials | lanes 32-63: b
     swap32(c, d); float q = c + d;      // c | d
@@ -104,14 +91,16 @@ __device__ __forceinline__ void wave_reduce10(float v0, float v1, float v2, floa
 // kernels of the other view lanes (radix scatter 38 KB, preprocess 50 KB) cannot co-reside with the compositing: 2100 -> 2170 Mpixels/s; 32 is slower again.
 #define BWD_ROUND 64
 
-template <bool LOSS>
+// DEPTH: some caller-supplied dL/ddepth exists.  The fused training step has none (the reference's loss reads image and alpha only, main_3DGS.py:184-192):
+// its instance drops the depth channel from the per-splat dot product, from the products and from the ten-value reduction (nine values).
+template <bool LOSS, bool DEPTH>
 __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                                                         const uint4* __restrict__ einfo,
                                                         const float4* __restrict__ rec0, const float4* __restrict__ rec1,
                                                         const float4* __restrict__ rec2, const float* __restrict__ final_T,
                                                         const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor,
                                                         const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha_px,
-                                                        const uint8_t* __restrict__ pact, float4* __restrict__ pairgrad, uint8_t* __restrict__ pvalid, uint32_t cap, int sh,
+                                                        const uint8_t* __restrict__ pact, size_t pstride, float4* __restrict__ pairgrad, uint8_t* __restrict__ pvalid, uint32_t cap, int sh,
                                                         GsPixelLoss pl) {
     __shared__ float4 s0[BWD_ROUND];
     __shared__ float4 s1[BWD_ROUND];
@@ -119,7 +108,7 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
     __shared__ uint32_t se[BWD_ROUND];
     __shared__ uint32_t smask[BWD_ROUND];
     __shared__ float acc[4][GS_PAIR_FLOATS][BWD_ROUND + 1];   // +1: the four row-writers of a wave (lanes 0,16,32,48) land in different banks
-    __shared__ int s_maxlast;
+    __shared__ int s_uptow[4];   // per quadrant: the deepest list position (+1) one of its pixels blended = how far its plane of the activity record is valid
     int tx, ty;
     if (!gs_block_tile(blockIdx.x, p.gx, p.gy, tx, ty, sh)) return;
     const int tile = ty * p.gx + tx;
@@ -137,7 +126,7 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
     float dLp0 = 0.f, dLp1 = 0.f, dLp2 = 0.f, dLd = 0.f, dLa = 0.f;
     if (inside) {
         if (dL_dcolor) { dLp0 = dL_dcolor[pid]; dLp1 = dL_dcolor[P + pid]; dLp2 = dL_dcolor[2 * P + pid]; }
-        dLd = dL_ddepth ? dL_ddepth[pid] : 0.f;
+        dLd = (DEPTH && dL_ddepth) ? dL_ddepth[pid] : 0.f;
         dLa = dL_dalpha_px ? dL_dalpha_px[pid] : 0.f;
     }
     if (LOSS) {   // the step's pixel loss, term by term as k_loss_grad
@@ -169,11 +158,12 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
     float Rdot = T_final * bg_dot;
 
     // list positions no pixel of the tile reached need no work and get no record
-    if (threadIdx.x == 0) s_maxlast = 0;
+    if (threadIdx.x < 4) s_uptow[threadIdx.x] = 0;
     __syncthreads();
-    atomicMax(&s_maxlast, last);
+    atomicMax(&s_uptow[wave], last);
     __syncthreads();
-    const int upto = s_maxlast;   // positions [0, upto) matter
+    const int up0 = s_uptow[0], up1 = s_uptow[1], up2 = s_uptow[2], up3 = s_uptow[3];
+    const int upto = max(max(up0, up1), max(up2, up3));   // positions [0, upto) matter
     // record index of the pair (this tile, Gaussian gid): the Gaussian's record base + row-major position of the tile inside its rect
     auto emit_index = [&](uint32_t gid) -> uint32_t {
         const uint4 ei = einfo[gid];
@@ -189,8 +179,11 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
         const int n = min(BWD_ROUND, upto - base);
         gs_stage_round(point_list + rg.x + (upto - 1 - base), n, rec0, s0, s1, s2, -1);   // slot t <- list position upto-1-base-t
         if ((int)threadIdx.x < n) {
-            const uint32_t kpos = rg.x + (uint32_t)(upto - 1 - base - (int)threadIdx.x);
-            smask[threadIdx.x] = pact[kpos];
+            const int kk = upto - 1 - base - (int)threadIdx.x;          // position in the tile's list
+            const uint32_t kpos = rg.x + (uint32_t)kk;
+            // plane w is read only where quadrant w's forward wave certainly wrote it (gs_pair_activity)
+            smask[threadIdx.x] = (kk < up0 ? (uint32_t)(pact[kpos] & 1u) : 0u) | (kk < up1 ? (uint32_t)(pact[pstride + kpos] & 1u) << 1 : 0u) |
+                                 (kk < up2 ? (uint32_t)(pact[2 * pstride + kpos] & 1u) << 2 : 0u) | (kk < up3 ? (uint32_t)(pact[3 * pstride + kpos] & 1u) << 3 : 0u);
             se[threadIdx.x] = emit_index(point_list[kpos]);   // unconditionally: the two dependent loads overlap the activity byte's
         }
         __syncthreads();
@@ -232,13 +225,13 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
                     const float Tn = T * inv;
                     T = sel64(am, Tn, T);
                     const float w = sel64z(am, alpha * Tn);
-                    const float sdot = a1.z * dLp0 + a1.w * dLp1 + a2.x * dLp2 + a2.y * dLd + dLa;
+                    const float sdot = DEPTH ? a1.z * dLp0 + a1.w * dLp1 + a2.x * dLp2 + a2.y * dLd + dLa : a1.z * dLp0 + a1.w * dLp1 + a2.x * dLp2 + dLa;
                     const float dL_dalpha = Tn * sdot - Rdot * inv;
                     Rdot += w * sdot;
                     // screen-space part as raw moments of w2 = dL/dG * G; turned into mean/conic/opacity gradients per Gaussian in A8
                     const float m0 = sel64z(am, a1.y * G * dL_dalpha);
                     const float m1x = m0 * dx, m1y = m0 * dy;
-                    wave_reduce10(w * dLp0, w * dLp1, w * dLp2, w * dLd, m0, m1x, m1y, m1x * dx, m1x * dy, m1y * dy, t0, t1, t2);
+                    wave_reduce10(w * dLp0, w * dLp1, w * dLp2, DEPTH ? w * dLd : 0.f, m0, m1x, m1y, m1x * dx, m1x * dy, m1y * dy, t0, t1, t2);
                     // t0 rows: c0, c2, c1, depth   t1 rows: m0, m1y, m1x, m2xx   t2 rows: m2xy, 0, m2yy, 0
                     if ((lane & 15) == 0) {   // lanes 0,16,32,48: one row each
                         const int row = lane >> 4;
@@ -300,12 +293,12 @@ int gs_launch_composite_bwd(const GsParams& p, const GsGeom& g, const GsBinning&
     if (tiles == 0) return 0;
     C3D_CHECK(hipMemsetAsync(pvalid, 0, (size_t)(pairs > 0 ? pairs : 1), s));
     const dim3 grid(gs_block_count(p.gx, p.gy, gs_supertile_shift()));
-    if (pixel_loss)
-        hipLaunchKernelGGL(k_composite_bwd<true>, grid, dim3(256), gs_lds_pad(true), s, p, b.ranges, b.tval[res], g.einfo, g.rec0, g.rec1, g.rec2, im.final_T, im.n_contrib,
-                           dL_dcolor, dL_ddepth, dL_dalpha, gs_pair_activity(b, res), (float4*)pairgrad, pvalid, cap, gs_supertile_shift(), *pixel_loss);
-    else
-        hipLaunchKernelGGL(k_composite_bwd<false>, grid, dim3(256), gs_lds_pad(true), s, p, b.ranges, b.tval[res], g.einfo, g.rec0, g.rec1, g.rec2, im.final_T, im.n_contrib,
-                           dL_dcolor, dL_ddepth, dL_dalpha, gs_pair_activity(b, res), (float4*)pairgrad, pvalid, cap, gs_supertile_shift(), GsPixelLoss{});
+#define GS_BWD_LAUNCH(LOSS_, DEPTH_, PL_)                                                                                                                        \
+    hipLaunchKernelGGL((k_composite_bwd<LOSS_, DEPTH_>), grid, dim3(256), gs_lds_pad(true), s, p, b.ranges, b.tval[res], g.einfo, g.rec0, g.rec1, g.rec2, im.final_T, \
+                       im.n_contrib, dL_dcolor, dL_ddepth, dL_dalpha, gs_pair_activity(b, res), b.pair_stride, (float4*)pairgrad, pvalid, cap, gs_supertile_shift(), PL_)
+    if (pixel_loss) { if (dL_ddepth) GS_BWD_LAUNCH(true, true, *pixel_loss); else GS_BWD_LAUNCH(true, false, *pixel_loss); }
+    else            { if (dL_ddepth) GS_BWD_LAUNCH(false, true, GsPixelLoss{}); else GS_BWD_LAUNCH(false, false, GsPixelLoss{}); }
+#undef GS_BWD_LAUNCH
     C3D_LAUNCH_CHECK();
     return 0;
 }
@@ -374,7 +367,7 @@ __device__ __forceinline__ void bwd_geom_chain(const float3 m, const float c3[6]
 
 // cov3D gradient -> scale and (unnormalised-quaternion) rotation gradients.  dscale_mod: the dependency's backward differentiates
 // Sigma = R diag(mod s)^2 R^T w.r.t. (mod s) and returns that as dL/dscale -- no `mod` factor (dscale_mod = 1, the default, identical
-// to the wheel); the exact derivative multiplies by mod (dscale_mod = scale_modifier, c3d_gs_set_exact_dscale(1)).
+// to the wheel); the exact derivative multiplies by mod (dscale_mod = scale_modifier, C3D_GS_FLAG_EXACT_DSCALE in the settings).
 __device__ __forceinline__ void bwd_cov_to_scale_rot(const float dcov[6], const float3 sc, const float4 q, float scale_modifier, float dscale_mod, float gs3[3], float4& dq) {
     float R[3][3];
     quat_to_R(q, R);
@@ -545,7 +538,7 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GsParams p, GsGeom g, co
     if (ACC) { dmean[0] += dL_dmeans3D[3 * idx]; dmean[1] += dL_dmeans3D[3 * idx + 1]; dmean[2] += dL_dmeans3D[3 * idx + 2]; }
     dL_dmeans3D[3 * idx] = dmean[0]; dL_dmeans3D[3 * idx + 1] = dmean[1]; dL_dmeans3D[3 * idx + 2] = dmean[2];
 
-    // cov3D -> scale, rotation (d/dscale as the dependency returns it unless c3d_gs_set_exact_dscale(1))
+    // cov3D -> scale, rotation (d/dscale as the dependency returns it unless the settings carry C3D_GS_FLAG_EXACT_DSCALE)
     if (!cov3D_precomp) {
         float gs3[3];
         float4 dq;

@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(256) k_composite_fwd(GsParams p, const uint2* 
                                                         const float4* __restrict__ rec0, const float4* __restrict__ rec1,
                                                         const float4* __restrict__ rec2, float* __restrict__ out_color,
                                                         float* __restrict__ out_depth, float* __restrict__ out_alpha,
-                                                        float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, uint8_t* __restrict__ pact, int sh) {
+                                                        float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, uint8_t* __restrict__ pact, size_t pstride, int sh) {
     __shared__ float4 s0[FWD_ROUND];
     __shared__ float4 s1[FWD_ROUND];
     __shared__ float4 s2[FWD_ROUND];
@@ -339,7 +339,8 @@ __global__ void __launch_bounds__(256) k_composite_fwd(GsParams p, const uint2* 
             __syncthreads();
             if ((int)threadIdx.x < n) {
                 const uint32_t a = sact[threadIdx.x];
-                pact[rg.x + base + threadIdx.x] = (uint8_t)((a & 1u) | ((a >> 7) & 2u) | ((a >> 14) & 4u) | ((a >> 21) & 8u));
+#pragma unroll
+                for (int w = 0; w < 4; w++) pact[(size_t)w * pstride + rg.x + base + threadIdx.x] = (uint8_t)((a >> (8 * w)) & 1u);   // one byte plane per quadrant (gs_pair_activity)
             }
         }
     }
@@ -355,16 +356,164 @@ __global__ void __launch_bounds__(256) k_composite_fwd(GsParams p, const uint2* 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// A6, wave-autonomous form (round 3, the default): ONE WAVE per 8x8 pixel quadrant of a 16x16 tile -- a 64-lane workgroup, no workgroup-level
+// staging, no barrier, nothing shared with the other three quadrants of the tile but the tile's sorted splat list.
+// Why: profiles/r02z_sq_instruction_mix_lanes1.csv -- the 256-lane kernel above issues 26 VALU + 16-20 scalar + 4 LDS instructions per walked
+// (quadrant, splat) pair: a third of its issue slots are the scalar walk over a ballot (find-first-set, clear, address, exec save / restore around
+// the blend) and every round costs three workgroup barriers.  Here a wave
+//   * takes 64 list entries at a time, one per lane (id + the 48-B record straight into registers; the NEXT chunk's loads are issued before the
+//     current chunk is walked, so the gathers' latency hides under the walk),
+//   * tests its own quadrant only (gs_rect_hit: exact ellipse-vs-rectangle, the same test as gs_quadrant_mask), and COMPACTS the hits -- records,
+//     conic pre-scaled for v_exp_f32 -- into a wave-private LDS list (ballot + mbcnt), padded to a multiple of four with zero-opacity dummies,
+//   * walks that list with a counted, 4x unrolled loop of LDS broadcast reads at immediate offsets: no ballot walk, no per-splat scalar address
+//     arithmetic, and the blend is branch-free (lane masks live in SGPR pairs and feed v_cndmask_b32_e64); the one rare event, a pixel that
+//     saturates at this splat, is a uniform branch that is almost never taken.
+// RECORD: one scalar bit per walked list entry ("some lane blended it": s_cmp_lg_u64 + two s_addc_u32 shift it into a 64-bit mask), written out as
+// the quadrant's byte plane of the pair-activity record (gs_pair_activity) -- one coalesced byte store per 64 list entries.
+// Arithmetic, statement by statement, as k_composite_fwd: the two produce identical images (tests/test_gs_hip.py::test_forward_kernels_agree).
+// ------------------------------------------------------------------------------------------
+#define FWQ_PAD 4
+template <bool RECORD>
+__global__ void __launch_bounds__(64, 8) k_composite_fwd_w(GsParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+                                                         const float4* __restrict__ rec, float* __restrict__ out_color, float* __restrict__ out_depth,
+                                                         float* __restrict__ out_alpha, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+                                                         uint8_t* __restrict__ pact, size_t pstride, int sh) {
+    __shared__ float4 c0[64 + FWQ_PAD];     // (px, py, -log2e/2 A, -log2e B)
+    __shared__ float4 c1[64 + FWQ_PAD];     // (-log2e/2 C, opacity, r, g)
+    __shared__ float2 c2[64 + FWQ_PAD];     // (b, view depth)
+    __shared__ uint8_t cmap[64 + FWQ_PAD];  // compact position -> lane (= position inside the chunk)
+    const int b = blockIdx.x, q = (b >> 3) & 3;   // the four quadrants of a tile sit on ONE XCD (b & 7): they gather the same records
+    int tx, ty;
+    if (!gs_block_tile((b & 7) | ((b >> 5) << 3), p.gx, p.gy, tx, ty, sh)) return;
+    const int tile = ty * p.gx + tx, lane = (int)threadIdx.x;
+    const int QX = tx * C3D_TILE_X + ((q & 1) << 3), QY = ty * C3D_TILE_Y + ((q >> 1) << 3);
+    const int pxi = QX + (lane & 7), pyi = QY + (lane >> 3);
+    const bool inside = pxi < p.W && pyi < p.H;
+    float pxf = inside ? (float)pxi : GS_PARKED;     // a finished pixel is parked where every splat evaluates to alpha = 0 (see k_composite_fwd)
+    const float pyf = (float)pyi;
+    const size_t pid = (size_t)pyi * p.W + pxi;
+    const float rx0 = (float)QX, ry0 = (float)QY;
+    const uint2 rg = ranges[tile];
+    const int todo = (int)(rg.y - rg.x);
+    float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f, A = 0.f;
+    uint32_t last = 0;
+    bool done = __ballot(pxf != GS_PARKED) == 0ull;
+    const float k255 = 1.f / 255.f, kT = 0.0001f;
+
+    float4 n0 = make_float4(0, 0, 0, 0), n1 = n0, n2 = n0;
+    auto fetch = [&](int base) {
+        const int e = base + lane;
+        if (e < todo) {
+            const size_t id = point_list[rg.x + e];
+            n0 = rec[4 * id]; n1 = rec[4 * id + 1]; n2 = rec[4 * id + 2];
+        }
+    };
+    if (!done && todo > 0) fetch(0);
+    for (int base = 0; base < todo && !done; base += 64) {
+        const float4 a0 = n0, a1 = n1, a2 = n2;
+        const bool have = base + lane < todo;
+        if (base + 64 < todo) fetch(base + 64);                       // in flight while this chunk is walked
+        const bool hit = have && gs_rect_hit(a0, a1, a2, rx0, ry0);
+        const uint64_t m = __ballot(hit);
+        const int n = __popcll(m);
+        const int pos = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        uint32_t act_lo = 0, act_hi = 0;
+        int walked = 0;
+        if (n) {
+            __syncthreads();                                           // one wave: orders this chunk's LDS writes behind the last chunk's reads
+            if (hit) {
+                c0[pos] = make_float4(a0.x, a0.y, GS_CONIC_HALF * a0.z, GS_CONIC_FULL * a0.w);
+                c1[pos] = make_float4(GS_CONIC_HALF * a1.x, a1.y, a1.z, a1.w);
+                c2[pos] = make_float2(a2.x, a2.y);
+                cmap[pos] = (uint8_t)lane;
+            }
+            const int npad = (n + 3) & ~3;
+            if (lane < npad - n) {                                     // zero-opacity dummies: alpha = 0 fails the 1/255 test on every pixel
+                c0[n + lane] = make_float4(0.f, 0.f, 0.f, 0.f); c1[n + lane] = make_float4(0.f, 0.f, 0.f, 0.f); c2[n + lane] = make_float2(0.f, 0.f);
+            }
+            __syncthreads();
+            int lastc = -1;
+            int i = 0;
+            for (; i < npad && !done; i += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const float4 s0 = c0[i + u], s1 = c1[i + u];
+                    const float2 s2 = c2[i + u];
+                    const float dx = s0.x - pxf, dy = s0.y - pyf;
+                    const float power = gs_power(s0, s1.x, dx, dy);          // log2(e) * (-q/2)
+                    const float alpha = fminf(0.99f, s1.y * __builtin_amdgcn_exp2f(power));
+                    uint64_t ok, k1, st;
+                    asm("v_cmp_ge_f32_e64 %0, 0, %1" : "=s"(ok) : "v"(power));
+                    asm("v_cmp_le_f32_e64 %0, %1, %2" : "=s"(k1) : "s"(k255), "v"(alpha));
+                    ok &= k1;
+                    float ae = sel64z(ok, alpha);
+                    float testT = T * (1.f - ae);
+                    asm("v_cmp_gt_f32_e64 %0, %1, %2" : "=s"(st) : "s"(kT), "v"(testT));
+                    st &= ok;
+                    if (st) {                                                // rare: a pixel saturates AT this splat -- it does not take it and is parked
+                        ae = sel64(st, 0.f, ae);
+                        testT = sel64(st, T, testT);
+                        pxf = sel64(st, GS_PARKED, pxf);
+                        ok &= ~st;
+                        if (__ballot(pxf != GS_PARKED) == 0ull) done = true;   // the rest of this group of four runs on parked pixels: no effect
+                    }
+                    const float w = ae * T;
+                    C0 += s1.z * w; C1 += s1.w * w; C2 += s2.x * w;
+                    Dp += s2.y * w; A += w;
+                    T = testT;
+                    lastc = sel64i(ok, i + u, lastc);
+                    if (RECORD)                                              // act = (act << 1) | (some lane blended this entry): SCC rides the carry chain
+                        asm volatile("s_cmp_lg_u64 %2, 0\n\ts_addc_u32 %0, %0, %0\n\ts_addc_u32 %1, %1, %1" : "+s"(act_lo), "+s"(act_hi) : "s"(ok) : "scc");
+                }
+            }
+            walked = i;
+            if (lastc >= 0) last = (uint32_t)(base + (int)cmap[lastc] + 1);
+        }
+        if (RECORD && have) {
+            // entry k of the compact list sits at bit (walked - 1 - k) of act; entries the walk never reached blended nothing
+            const uint64_t act = ((uint64_t)act_hi << 32) | act_lo;
+            const uint32_t bit = (hit && pos < walked) ? (uint32_t)((act >> (walked - 1 - pos)) & 1ull) : 0u;
+            pact[(size_t)q * pstride + rg.x + base + lane] = (uint8_t)bit;
+        }
+    }
+    if (inside) {
+        const size_t P = (size_t)p.W * p.H;
+        final_T[pid] = T;
+        n_contrib[pid] = last;
+        out_color[pid] = C0 + T * p.bg[0];
+        out_color[P + pid] = C1 + T * p.bg[1];
+        out_color[2 * P + pid] = C2 + T * p.bg[2];
+        out_depth[pid] = Dp;
+        out_alpha[pid] = A;
+    }
+}
+
+// which forward compositing kernel: C3D_FWD_KERNEL = 1 (default) wave per quadrant (k_composite_fwd_w) | 0 workgroup per tile (k_composite_fwd)
+static int gs_fwd_kernel() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("C3D_FWD_KERNEL"); v = e ? atoi(e) : 1; if (v != 0 && v != 1) v = 1; }
+    return v;
+}
 int gs_launch_composite_fwd(const GsParams& p, const GsGeom& g, const GsBinning& b, int res, GsImage& im,
                             float* out_color, float* out_depth, float* out_alpha, bool record_activity, hipStream_t s) {
     const int tiles = p.gx * p.gy;
     if (tiles == 0) return 0;
-    if (record_activity)
+    uint8_t* pact = record_activity ? gs_pair_activity(b, res) : nullptr;
+    if (gs_fwd_kernel() == 1) {
+        const dim3 grid(4 * gs_block_count(p.gx, p.gy, gs_supertile_shift()));
+        if (record_activity)
+            hipLaunchKernelGGL(k_composite_fwd_w<true>, grid, dim3(64), 0, s, p, b.ranges, b.tval[res], g.rec0, out_color, out_depth, out_alpha, im.final_T, im.n_contrib,
+                               pact, b.pair_stride, gs_supertile_shift());
+        else
+            hipLaunchKernelGGL(k_composite_fwd_w<false>, grid, dim3(64), 0, s, p, b.ranges, b.tval[res], g.rec0, out_color, out_depth, out_alpha, im.final_T, im.n_contrib,
+                               pact, b.pair_stride, gs_supertile_shift());
+    } else if (record_activity)
         hipLaunchKernelGGL(k_composite_fwd<true>, dim3(gs_block_count(p.gx, p.gy, gs_supertile_shift())), dim3(256), gs_lds_pad(false), s, p, b.ranges, b.tval[res], g.rec0, g.rec1, g.rec2,
-                           out_color, out_depth, out_alpha, im.final_T, im.n_contrib, gs_pair_activity(b, res), gs_supertile_shift());
+                           out_color, out_depth, out_alpha, im.final_T, im.n_contrib, pact, b.pair_stride, gs_supertile_shift());
     else
         hipLaunchKernelGGL(k_composite_fwd<false>, dim3(gs_block_count(p.gx, p.gy, gs_supertile_shift())), dim3(256), gs_lds_pad(false), s, p, b.ranges, b.tval[res], g.rec0, g.rec1, g.rec2,
-                           out_color, out_depth, out_alpha, im.final_T, im.n_contrib, (uint8_t*)nullptr, gs_supertile_shift());
+                           out_color, out_depth, out_alpha, im.final_T, im.n_contrib, pact, b.pair_stride, gs_supertile_shift());
     C3D_LAUNCH_CHECK();
     return 0;
 }

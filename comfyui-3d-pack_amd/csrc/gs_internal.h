@@ -77,6 +77,7 @@ struct GsBinning {
     uint2* ranges;   // [tiles]
     int* meta;
     void* tmp;       // tile-sort state; `ranges`, `meta` and the state are adjacent: ONE memset of zero_bytes from `ranges` clears them
+    size_t pair_stride;   // elements between the four byte planes of the pair-activity record (gs_pair_activity)
     size_t zero_bytes;
     size_t bytes;
 };
@@ -85,6 +86,7 @@ static inline void gs_carve_binning(char* base, long long D, int tiles, GsBinnin
     auto take = [&](size_t n) { char* p = base ? base + off : nullptr; off += c3d_align(n); return p; };
     b.tkey[0] = (uint32_t*)take(4 * d);
     b.tkey[1] = (uint32_t*)take(4 * d);
+    b.pair_stride = c3d_align(4 * d) / 4;
     b.tval[0] = (uint32_t*)take(4 * d);
     b.tval[1] = (uint32_t*)take(4 * d);
     const size_t ranges_off = off;
@@ -97,8 +99,10 @@ static inline void gs_carve_binning(char* base, long long D, int tiles, GsBinnin
     b.bytes = off;
 }
 
-// One byte per sorted (tile, splat) pair, written by the recording forward compositing and read by the backward one: bit w = quadrant w blended
-// the splat.  Lives in the key buffer the tile sort did NOT finish in (dead once the ranges are found; 4 bytes per pair, one used).
+// Pair activity, written by the recording forward compositing and read by the backward one: FOUR byte planes of b.pair_stride bytes each, plane w
+// byte i = quadrant w blended the splat at sorted list position i into at least one of its pixels.  A quadrant's wave writes its plane only for the
+// list positions it walked; the backward pass reads plane w only below the deepest position a pixel of quadrant w reached (max n_contrib), which
+// the wave always walked.  Lives in the key buffer the tile sort did NOT finish in (dead once the ranges are found; 4 bytes per pair).
 static inline uint8_t* gs_pair_activity(const GsBinning& b, int res) { return (uint8_t*)b.tkey[1 - res]; }
 
 struct GsImage {

@@ -233,19 +233,39 @@ __device__ __forceinline__ float quad_form_min_on_rect(float A, float B, float C
 __device__ __forceinline__ float gs_power(const float4 a0, float c, float dx, float dy) {
     return __builtin_fmaf(dx, __builtin_fmaf(a0.z, dx, a0.w * dy), (c * dy) * dy);
 }
-__device__ __forceinline__ uint32_t gs_quadrant_mask(const float4 a0, const float4 a1, const float4 a2, int X0, int Y0) {
+// one pixel rectangle [rx0, rx0 + w] x [ry0, ry0 + h] (inclusive pixel centres): can the splat reach alpha >= 1/255 anywhere on it?
+__device__ __forceinline__ bool gs_rect_hit(const float4 a0, const float4 a1, const float4 a2, float rx0, float ry0, float w = 7.f, float h = 7.f) {
     // a0 = (px, py, A, B)  a1 = (C, opacity, ..)  a2 = (.., .., ex, ey)
     const float xl = a0.x - a2.z, xh = a0.x + a2.z, yl = a0.y - a2.w, yh = a0.y + a2.w;
+    if (!(xh >= rx0 && xl <= rx0 + w && yh >= ry0 && yl <= ry0 + h)) return false;
     const float thr = 2.f * __logf(255.f * a1.y) * 1.0005f + 1e-3f;
+    return quad_form_min_on_rect(a0.z, a0.w, a1.x, a0.x, a0.y, rx0, rx0 + w, ry0, ry0 + h) <= thr;
+}
+__device__ __forceinline__ uint32_t gs_quadrant_mask(const float4 a0, const float4 a1, const float4 a2, int X0, int Y0) {
     uint32_t m = 0;
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const float rx0 = (float)(X0 + 8 * (q & 1)), ry0 = (float)(Y0 + 8 * (q >> 1));
-        if (xh >= rx0 && xl <= rx0 + 7.f && yh >= ry0 && yl <= ry0 + 7.f) {
-            if (quad_form_min_on_rect(a0.z, a0.w, a1.x, a0.x, a0.y, rx0, rx0 + 7.f, ry0, ry0 + 7.f) <= thr) m |= 1u << q;
-        }
-    }
+    for (int q = 0; q < 4; q++)
+        if (gs_rect_hit(a0, a1, a2, (float)(X0 + 8 * (q & 1)), (float)(Y0 + 8 * (q >> 1)))) m |= 1u << q;
     return m;
+}
+
+// ---- lane selects on wave masks held in SGPR pairs ----------------------------------------------------------------------------------
+// Written as asm because hipcc picks the VOP2 form that reads VCC (v_cndmask_b32_e32 ..., vcc), which issues ~5x slower on gfx950 than the
+// VOP3 form with an SGPR-pair mask (profiles/r01f_valu_rate_microbench.txt: 22.9 vs 4.7 cycles per wave-instruction).
+__device__ __forceinline__ float sel64(uint64_t m, float if_set, float otherwise) {
+    float r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(otherwise), "v"(if_set), "s"(m));
+    return r;
+}
+__device__ __forceinline__ float sel64z(uint64_t m, float if_set) {   // 0 where the mask is clear
+    float r;
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(if_set), "s"(m));
+    return r;
+}
+__device__ __forceinline__ int sel64i(uint64_t m, int if_set, int otherwise) {
+    int r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(otherwise), "v"(if_set), "s"(m));
+    return r;
 }
 
 // ---- spherical harmonics without arrays (keeps the per-Gaussian kernels out of scratch) -------------------

@@ -37,7 +37,18 @@ def _settings_struct(rs, keep):
     keep.extend([bg, vm, pm, cp])
     return _h.GsSettings(int(rs.image_height), int(rs.image_width), float(rs.tanfovx), float(rs.tanfovy),
                          float(rs.scale_modifier), int(rs.sh_degree), int(bool(rs.prefiltered)), int(bool(rs.debug)),
-                         _h.ptr(bg), _h.ptr(vm), _h.ptr(pm), _h.ptr(cp))
+                         _h.ptr(bg), _h.ptr(vm), _h.ptr(pm), _h.ptr(cp), _h.GS_FLAG_EXACT_DSCALE if getattr(rs, "exact_dscale", False) else 0, 0)
+
+
+class _ExactDscaleSettings(GaussianRasterizationSettings):
+    """the 12-field settings tuple of the dependency plus one attribute the C-ABI carries per call (C3D_GS_FLAG_EXACT_DSCALE)"""
+    exact_dscale = True
+
+
+def with_exact_dscale(rs):
+    """-> the same raster settings, asking the backward pass for the exact d/dscale (x scale_modifier) instead of the dependency's convention.
+    Extension; a plain GaussianRasterizationSettings keeps the dependency's behaviour.  No process-wide switch exists."""
+    return _ExactDscaleSettings(*rs)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):

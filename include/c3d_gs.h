@@ -57,16 +57,19 @@ typedef struct c3d_gs_settings {
     const float* viewmatrix; /* device [16] */
     const float* projmatrix; /* device [16] */
     const float* campos;     /* device [3]  */
+    int32_t flags;           /* C3D_GS_FLAG_*; 0 = the dependency's behaviour */
+    int32_t reserved0;       /* must be 0 */
 } c3d_gs_settings;
+
+/* flags.  C3D_GS_FLAG_EXACT_DSCALE -- dL/dscale convention of the backward entry points that receive these settings.  Clear (default): as the
+ * dependency's backward returns it -- Sigma = R diag(m s)^2 R^T is differentiated w.r.t. (m s) and handed back as dL/dscale, i.e. WITHOUT the
+ * scale_modifier factor m (identical to the exact derivative at m = 1, the only value the reference trains with; main_3DGS_renderer.py:830
+ * exposes `scaling_modifier` for inference).  Set: the exact derivative (x m).  Per call, carried by the settings: the library keeps no
+ * process-wide switches ("no global state besides per-device contexts"). */
+#define C3D_GS_FLAG_EXACT_DSCALE 1
 
 const char* c3d_last_error(void);
 int c3d_version(void);
-
-/* dL/dscale convention.  0 (default): as the dependency's backward returns it -- Sigma = R diag(m s)^2 R^T is differentiated w.r.t.
- * (m s) and handed back as dL/dscale, i.e. WITHOUT the scale_modifier factor m (identical to the exact derivative at m = 1, the only
- * value the reference trains with; main_3DGS_renderer.py:830 exposes `scaling_modifier` for inference).  1: the exact derivative
- * (x m).  Process-wide; returns the previous value. */
-int c3d_gs_set_exact_dscale(int32_t on);
 
 /* sizes (bytes) of the three opaque state buffers (geometry / binning / image) */
 size_t c3d_gs_geom_bytes(int32_t N);

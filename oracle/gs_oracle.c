@@ -450,6 +450,34 @@ gs_state *gs_oracle_forward(int N, int M, int deg, int W, int H, real tanfovx, r
     return st;
 }
 
+/* Test support: which Gaussians are blended into a flagged pixel?  The parity tests flag the pixels where a float32 kernel and this oracle in
+ * float64 visibly took different per-splat decisions (alpha >= 1/255, T < 1e-4, ceil(3 sigma): one flipped decision moves the pixel's alpha by a
+ * multiple of rounding noise) and then show that the gradient entries outside tolerance belong to exactly those Gaussians.
+ * pixel_flags [H*W] (non-zero = flagged)  ->  gauss_flags [N] |= 1 for every Gaussian the composite loop blends into a flagged pixel, walking the
+ * pixel's list to its END (a flipped early termination makes the kernel blend splats behind this oracle's stopping point). */
+void gs_oracle_taint(const gs_state *st, const unsigned char *pixel_flags, unsigned char *gauss_flags) {
+    int W = st->W, H = st->H;
+    int tiles = st->gx * st->gy;
+    for (int tile = 0; tile < tiles; tile++) {
+        int tx = tile % st->gx, ty = tile / st->gx;
+        uint32_t r0 = st->ranges[2 * tile], r1 = st->ranges[2 * tile + 1];
+        for (int py = ty * BLOCK_Y; py < imin(H, (ty + 1) * BLOCK_Y); py++)
+            for (int px = tx * BLOCK_X; px < imin(W, (tx + 1) * BLOCK_X); px++) {
+                if (!pixel_flags[(size_t)py * W + px]) continue;
+                for (uint32_t j = r0; j < r1; j++) {
+                    uint32_t g = st->point_list[j];
+                    real dx = st->xy[2 * g] - (real)px, dy = st->xy[2 * g + 1] - (real)py;
+                    const real *co = st->conic_opacity + 4 * g;
+                    real power = -(real)0.5 * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                    if (power > (real)1e-6) continue;
+                    real alpha = rmin((real)0.99, co[3] * (real)exp((double)power));
+                    if (alpha < (real)0.98 / (real)255) continue;      /* a little below the threshold: the splats whose decision can flip count */
+                    gauss_flags[g] |= 1;
+                }
+            }
+    }
+}
+
 /* Backward: A7 composite (back to front), A8 preprocess.  All outputs must be zero-initialised
  * by the caller except where noted.  dL_dconic has 4 entries per Gaussian (xx, xy/2-convention,
  * unused, yy) exactly like the upstream scratch layout. */

@@ -49,6 +49,8 @@ def _lib(dtype):
         f.restype = P
         f.argtypes = [P]
     lib.gs_oracle_mark_visible.argtypes = [C.c_int, P, P, P, P]
+    lib.gs_oracle_taint.restype = None
+    lib.gs_oracle_taint.argtypes = [P, P, P]
     assert lib.gs_oracle_sizeof_real() == dtype.itemsize
     _LIBS[dtype] = lib
     return lib
@@ -178,6 +180,16 @@ def backward(st, dL_dcolor, dL_ddepth=None, dL_dalpha=None, nthreads=1):
                            _p(g["means2D"]), _p(g["conic"]), _p(g["opacities"]), _p(g["colors"]), _p(g["depths"]),
                            _p(g["means3D"]), _p(g["cov3D"]), _p(g["shs"]), _p(g["scales"]), _p(g["rotations"]), int(nthreads))
     return g
+
+
+def taint(st, pixel_flags, gauss_flags=None):
+    """pixel_flags [H,W] bool -> gauss_flags [N] bool, OR-ed into `gauss_flags` when given: the Gaussians this view's composite loop can blend into a
+    flagged pixel (gs_oracle.c: gs_oracle_taint).  Used by the full-size parity tests to attribute the float32-vs-float64 gradient tail."""
+    H, W = st.settings["image_height"], st.settings["image_width"]
+    pf = np.ascontiguousarray(np.asarray(pixel_flags).reshape(H, W).astype(np.uint8))
+    gf = np.zeros((st.inputs["N"],), np.uint8) if gauss_flags is None else np.ascontiguousarray(gauss_flags.astype(np.uint8))
+    st.lib.gs_oracle_taint(st.handle, _p(pf), _p(gf))
+    return gf.astype(bool)
 
 
 def mark_visible(means3D, viewmatrix, projmatrix, dtype=np.float32):

@@ -39,6 +39,18 @@ def test_binding_table_matches_headers():
     assert declared == bound, (declared ^ bound)
 
 
+def test_no_process_wide_switches_in_the_abi():
+    """no global state besides per-device contexts.  Conventions travel per call (c3d_gs_settings.flags); nothing named *_set_* may be
+    exported except the profiling hooks of the c3d_prof_ / c3d_test_ families, which change what is MEASURED, never what is computed."""
+    import c3d_hip
+    setters = [n for n in c3d_hip.exported_symbols() if "_set_" in n or n.endswith("_set")]
+    assert setters == [], setters
+    src = open(os.path.join(ROOT, "comfyui-3d-pack_amd", "csrc", "gs_api.hip")).read()
+    assert "g_exact_dscale" not in src
+    hdr = open(os.path.join(ROOT, "include", "c3d_gs.h")).read()
+    assert "C3D_GS_FLAG_EXACT_DSCALE" in hdr and "int32_t flags;" in hdr
+
+
 def test_state_buffer_sizes_are_host_callable():
     import c3d_hip
     lib = c3d_hip.lib()

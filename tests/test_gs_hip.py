@@ -11,7 +11,7 @@ import torch
 
 from c3d_hip import synthetic as S
 from oracle import gs_oracle as O
-from helpers import assert_grad_close, hip_forward, hip_settings, oracle_forward, rel_err
+from helpers import GS_KEYS, assert_grad_close, hip_forward, hip_settings, oracle_forward, rel_err
 
 pytestmark = pytest.mark.gpu
 IMG_L1 = 1e-4
@@ -358,33 +358,40 @@ def test_baseline_size_1M_1080p_forward_backward_vs_float64_oracle():
 @pytest.mark.parametrize("exact", [False, True])
 def test_scaling_modifier_gradient_convention(exact):
     """scaling_modifier != 1 (a public argument of render(), main_3DGS_renderer.py:830): dL/dscale as the dependency's backward returns it
-    (no modifier factor; the default) and the exact derivative behind c3d_gs_set_exact_dscale -- kernel and oracle switch together."""
-    import c3d_hip as h
+    (no modifier factor; the default) and the exact derivative, asked for PER CALL through the settings (C3D_GS_FLAG_EXACT_DSCALE,
+    diff_gaussian_rasterization.with_exact_dscale) -- the library keeps no process-wide switch.  Kernel and oracle agree in both conventions."""
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization import GaussianRasterizer
     c = CASES[3]
     sc = S.make_small_scene(N=c["N"], seed=c["seed"], scale=c.get("scale", 0.08))
     st = S.camera_settings(c["W"], c["H"], 49.1, c["el"], c["az"], c["rad"], bg=(0.3, 0.7, 0.1), sh_degree=c["deg"])
     st["scale_modifier"] = 0.7
     gC = np.random.default_rng(9).normal(size=(3, c["H"], c["W"])).astype(np.float32)
-    old_k, old_o = h.lib().c3d_gs_set_exact_dscale(1 if exact else 0), O.set_exact_dscale(exact)
-    try:
-        color, radii, depth, alpha, inp, m2d = hip_forward(sc, st, requires_grad=True)
-        oc, orad, od, oa, ost = oracle_forward(sc, st, dtype=np.float64)
-        assert (radii.cpu().numpy() == orad).all() and np.abs(color.detach().cpu().numpy() - oc).mean() <= IMG_L1
+
+    def run(rs):
+        inp = {k: torch.tensor(sc[k], dtype=torch.float32, device="cuda", requires_grad=True) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+        m2d = torch.zeros_like(inp["means3D"], requires_grad=True)
+        color, radii, depth, alpha = GaussianRasterizer(rs)(means3D=inp["means3D"], means2D=m2d, opacities=inp["opacities"], shs=inp["shs"], scales=inp["scales"],
+                                                            rotations=inp["rotations"])
         color.backward(_dev(gC, torch.float32))
+        return color, radii, inp
+
+    rs = hip_settings(st, "cuda")
+    color, radii, inp = run(dgr.with_exact_dscale(rs) if exact else rs)
+    old_o = O.set_exact_dscale(exact)
+    try:
+        oc, orad, od, oa, ost = oracle_forward(sc, st, dtype=np.float64)
         og = O.backward(ost, gC)
-        for k in ("means3D", "opacities", "shs", "scales", "rotations"):
-            assert_grad_close(inp[k].grad.cpu().numpy(), og[k], "%s mod=0.7 exact=%s" % (k, exact), max_frac=SMALL_FRAC, hard=SMALL_HARD)
-        gs = inp["scales"].grad.clone()
     finally:
-        h.lib().c3d_gs_set_exact_dscale(old_k); O.set_exact_dscale(old_o)
-    if not exact:      # and the two conventions differ by exactly the modifier
-        h.lib().c3d_gs_set_exact_dscale(1)
-        try:
-            color, _, _, _, inp2, _ = hip_forward(sc, st, requires_grad=True)
-            color.backward(_dev(gC, torch.float32))
-        finally:
-            h.lib().c3d_gs_set_exact_dscale(0)
-        assert torch.allclose(inp2["scales"].grad, 0.7 * gs, rtol=1e-6, atol=0)
+        O.set_exact_dscale(old_o)
+    assert (radii.cpu().numpy() == orad).all() and np.abs(color.detach().cpu().numpy() - oc).mean() <= IMG_L1
+    for k in ("means3D", "opacities", "shs", "scales", "rotations"):
+        assert_grad_close(inp[k].grad.cpu().numpy(), og[k], "%s mod=0.7 exact=%s" % (k, exact), max_frac=SMALL_FRAC, hard=SMALL_HARD)
+    if not exact:      # the two conventions differ by exactly the modifier, and asking for one call does not change the next
+        _, _, inp2 = run(dgr.with_exact_dscale(rs))
+        assert torch.allclose(inp2["scales"].grad, 0.7 * inp["scales"].grad, rtol=1e-6, atol=0)
+        _, _, inp3 = run(rs)
+        assert torch.equal(inp3["scales"].grad, inp["scales"].grad)
 
 
 # ---------------------------------------------------------------- full size: properties (no oracle run)
@@ -470,18 +477,7 @@ def test_backward_is_bit_reproducible():
         assert torch.equal(grads[0][k], grads[1][k]), k
 
 
-def test_recorded_pair_activity_loses_nothing():
-    """The forward compositing pass records, one byte per sorted (tile, splat) pair, which of the tile's four 8x8 quadrants blended the splat; the
-    backward pass walks exactly those (quadrant, splat) pairs.  Overwriting the bytes with 'all four quadrants of every pair' makes the backward
-    pass walk a superset -- lanes that did not blend contribute exact zeros -- so the gradients must come out bit for bit the same; and the
-    recording must really prune (most pairs of a dense scene are blended nowhere or in part of the tile only)."""
-    import diff_gaussian_rasterization as dgr
-    sc = S.make_cloud(200000, seed=3, log_scale_mean=np.log(0.008))
-    W, H = 800, 450
-    st = S.camera_settings(W, H, 49.1, 10.0, 100.0, 2.2)
-    gC = _dev(np.random.default_rng(2).normal(size=(3, H, W)).astype(np.float32), torch.float32)
-    color, radii, depth, alpha, inp, m2d = hip_forward(sc, st, requires_grad=True)
-    D = int(dgr.last_num_rendered)
+def _rasterize_node(color):
     node, seen, stack = None, set(), [color.grad_fn]
     while stack and node is None:
         f_ = stack.pop()
@@ -491,27 +487,85 @@ def test_recorded_pair_activity_loses_nothing():
         if "Rasterize" in type(f_).__name__:
             node = f_
         stack.extend(x[0] for x in f_.next_functions)
-    binning = node.saved_tensors[-2]
-    # binning buffer (csrc/gs_internal.h: gs_carve_binning): tkey[0] | tkey[1] | tval[0] | tval[1] | ...; the sorted keys ended in one key buffer, the bytes live in the other
+    return node
+
+
+def test_recorded_pair_activity_loses_nothing():
+    """The forward compositing pass records, per sorted (tile, splat) pair and 8x8 quadrant of the tile (four byte planes, csrc/gs_internal.h:
+    gs_pair_activity), whether the quadrant blended the splat into at least one pixel; the backward pass walks exactly those (quadrant, splat) pairs.
+    Overwriting the planes with 'every quadrant blended every pair' makes the backward pass walk a superset -- lanes that did not blend contribute
+    exact zeros -- so the gradients must come out bit for bit the same; and the recording must really prune (most pairs of a dense scene are blended
+    nowhere or in part of the tile only)."""
+    import diff_gaussian_rasterization as dgr
+    sc = S.make_cloud(200000, seed=3, log_scale_mean=np.log(0.008))
+    W, H = 800, 450
+    st = S.camera_settings(W, H, 49.1, 10.0, 100.0, 2.2)
+    gC = _dev(np.random.default_rng(2).normal(size=(3, H, W)).astype(np.float32), torch.float32)
+    color, radii, depth, alpha, inp, m2d = hip_forward(sc, st, requires_grad=True)
+    D = int(dgr.last_num_rendered)
+    node = _rasterize_node(color)
+    binning, img = node.saved_tensors[-2], node.saved_tensors[-1]
+    # binning buffer (gs_carve_binning): tkey[0] | tkey[1] | tval[0] | tval[1] | ...; the sorted keys ended in one key buffer, the four planes live in the other
     d_al = (4 * D + 255) // 256 * 256
     keys = [binning.data[i * d_al:i * d_al + 4 * D].view(torch.int32) for i in range(2)]
     res = 0 if bool((keys[0][1:] >= keys[0][:-1]).all()) else 1
     assert bool((keys[res][1:] >= keys[res][:-1]).all())
-    act = binning.data[(1 - res) * d_al:(1 - res) * d_al + D]      # .data: the in-place overwrite below must not trip autograd's version check of the saved buffer
+    stride = d_al // 4
+    dead = binning.data[(1 - res) * d_al:(2 - res) * d_al]      # .data: the in-place overwrite below must not trip autograd's version check of the saved buffer
+    planes = [dead[w * stride:w * stride + D] for w in range(4)]
     loss = (color * gC).sum() + alpha.sum() + depth.sum()
     names = ("means3D", "opacities", "shs", "scales", "rotations")
     g1 = torch.autograd.grad(loss, [inp[k] for k in names] + [m2d], retain_graph=True)
-    before = act.clone()
-    act.fill_(0x0F)
+    before = [pl.clone() for pl in planes]
+    dead.fill_(0x01)
     g2 = torch.autograd.grad(loss, [inp[k] for k in names] + [m2d], retain_graph=True)
     for a, b, k in zip(g1, g2, names + ("means2D",)):
         assert torch.equal(a, b), k
-    # what the recording pruned: bytes are written for the list positions the tiles walked; count over those that hold a valid quadrant mask
-    walked = before[before < 16]
-    pop = torch.tensor([bin(i).count("1") for i in range(16)], device=before.device)[walked.long()]
-    frac_any, quads = float((walked > 0).float().mean()), float(pop.sum()) / max(int((walked > 0).sum()), 1)
-    print("[activity] %d pairs; of the walked list positions %.0f %% blended somewhere, %.2f quadrants each" % (D, 100 * frac_any, quads))
-    assert 0.05 < frac_any < 0.95 and 1.0 <= quads < 3.5
+    # what the recording pruned, over the list positions a quadrant is read at: below the deepest position one of its pixels blended (n_contrib)
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    ncon = img.data[(4 * W * H + 255) // 256 * 256:][:4 * W * H].view(torch.int32).reshape(H, W)
+    pad = torch.zeros((gy * 16, gx * 16), dtype=torch.int32, device="cuda")
+    pad[:H, :W] = ncon
+    upto = pad.reshape(gy, 2, 8, gx, 2, 8).permute(0, 3, 1, 4, 2, 5).reshape(gy * gx, 4, 64).max(dim=2).values      # [tile, quadrant]
+    ranges = binning.data[4 * d_al:4 * d_al + 8 * gx * gy].view(torch.int32).reshape(gx * gy, 2)
+    tile_of = keys[res].long()
+    posn = torch.arange(D, device="cuda") - ranges[tile_of, 0].long()
+    valid = torch.stack([posn < upto[tile_of, w].long() for w in range(4)])
+    bits = torch.stack([(before[w] & 1).bool() for w in range(4)]) & valid
+    reached = valid.any(0)
+    frac_any = float(bits.any(0)[reached].float().mean())
+    quads = float(bits.sum()) / max(int(bits.any(0).sum()), 1)
+    print("[activity] %d pairs; of the %d list positions a tile reached %.0f %% blended somewhere, %.2f quadrants each" % (D, int(reached.sum()), 100 * frac_any, quads))
+    assert 0.05 < frac_any < 0.98 and 1.0 <= quads < 3.5
+
+
+def test_forward_kernels_agree():
+    """The wave-per-quadrant forward compositing kernel (default) and the workgroup-per-tile one (C3D_FWD_KERNEL=0) are the same arithmetic statement
+    by statement: identical images, n_contrib and gradients.  The switch is an environment variable read at first use, so the other kernel runs in a
+    child process."""
+    import subprocess, sys, tempfile
+    sc = S.make_cloud(150000, seed=9, log_scale_mean=np.log(0.01))
+    W, H = 500, 300                                   # not multiples of 16: partial tiles and fully outside quadrants
+    st = S.camera_settings(W, H, 49.1, -25.0, 200.0, 2.2, bg=(0.2, 0.5, 0.9))
+    gC = np.random.default_rng(4).normal(size=(3, H, W)).astype(np.float32)
+    color, radii, depth, alpha, inp, m2d = hip_forward(sc, st, requires_grad=True)
+    ((color * _dev(gC, torch.float32)).sum() + alpha.sum() + depth.sum()).backward()
+    mine = dict(color=color.detach().cpu().numpy(), alpha=alpha.detach().cpu().numpy(), depth=depth.detach().cpu().numpy(),
+                **{"g_" + k: inp[k].grad.cpu().numpy() for k in GS_KEYS})
+    here = os.path.dirname(os.path.abspath(__file__))
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "o.npz")
+        code = ("import sys, os, numpy as np, torch; sys.path[:0] = [%r, %r, %r]; from c3d_hip import synthetic as S; from helpers import hip_forward, GS_KEYS\n"
+                "sc = S.make_cloud(150000, seed=9, log_scale_mean=np.log(0.01)); st = S.camera_settings(%d, %d, 49.1, -25.0, 200.0, 2.2, bg=(0.2, 0.5, 0.9))\n"
+                "gC = torch.tensor(np.random.default_rng(4).normal(size=(3, %d, %d)).astype(np.float32), device='cuda')\n"
+                "color, radii, depth, alpha, inp, m2d = hip_forward(sc, st, requires_grad=True); ((color * gC).sum() + alpha.sum() + depth.sum()).backward()\n"
+                "np.savez(%r, color=color.detach().cpu().numpy(), alpha=alpha.detach().cpu().numpy(), depth=depth.detach().cpu().numpy(), **{'g_' + k: inp[k].grad.cpu().numpy() for k in GS_KEYS})\n"
+                % (here, os.path.dirname(here), os.path.join(os.path.dirname(here), "comfyui-3d-pack_amd"), W, H, H, W, out))
+        env = dict(os.environ, C3D_FWD_KERNEL="0")
+        subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=600)
+        other = np.load(out)
+        for k, v in mine.items():
+            assert np.array_equal(v, other[k]), k
 
 
 # ---------------------------------------------------------------- training-step pieces (SURVEY 8a a6/a7)
