@@ -53,8 +53,9 @@ def parse():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--sh-degree", type=int, default=3)
     ap.add_argument("--cpu-baseline", choices=["auto", "on", "off"], default="auto")
-    ap.add_argument("--exchange", choices=["allgather", "allreduce"], default="allreduce",
-                    help="gradient exchange of the shared-Gaussian step: one RCCL all-reduce (default: 2*(n-1)/n * 236 MB per rank on the wire) or the literal all-gather of every rank's gradient + rank-ordered local sum (7 * 236 MB received per rank at n = 8)")
+    ap.add_argument("--exchange", choices=["allgather", "allreduce", "zero1"], default="allreduce",
+                    help="gradient exchange of the shared-Gaussian step: one RCCL all-reduce (default: 2*(n-1)/n * 236 MB per rank on the wire), the literal all-gather of every rank's gradient + rank-ordered local sum (7 * 236 MB received per rank at n = 8), or zero1 (--mode train only): "
+                         "all-to-all reduce-scatter in rank order -> Adam on the owned 1/n -> all-gather of the parameters (c3d_hip.parallel.ZeroOneAdam)")
     ap.add_argument("--exchange-chunks", type=int, default=4,
                     help="N > 1, --exchange allreduce: Gaussian ranges of the per-Gaussian backward pass, each range's collective overlapping the next range's kernels (1 = one all-reduce after the step)")
     ap.add_argument("--timed-prof", choices=["on", "off"], default="on", help="HIP-event kernel timing inside the timed region")
@@ -362,9 +363,15 @@ def main():
     tgt_alpha = torch.stack([tg[1] for tg in targets])                 # [V,1,H,W]: the masks of config 3 ("masks = its alpha")
     tgt_masked = torch.stack([tg[0] for tg in targets]) * tgt_alpha
     opt = None
+    zero = None
+    if a.exchange == "zero1" and (a.mode != "train" or a.render_path != "step"):
+        raise SystemExit("--exchange zero1 contains the optimizer step: use it with --mode train (fused step path)")
     if a.mode == "train":
         from c3d_hip.optim import FusedAdam
         opt = FusedAdam([{"params": [q], "lr": lr} for q, lr in zip(plist, lr_list)], lr=0.0, eps=1e-15)
+        if a.exchange == "zero1":
+            from c3d_hip.parallel import ZeroOneAdam
+            zero = ZeroOneAdam(opt, plist, None, average=False)     # parameters re-pointed into one flat buffer, gradients in another, moments for the owned 1/n only
     stats = {"n_vis": [], "D": []}
     fused_step = None
     loss_kind = a.loss if a.loss != "auto" else ("full" if a.mode == "train" else "l1alpha")
@@ -379,8 +386,8 @@ def main():
         fused_step.time_events = True
         fused_step.defer_status = a.defer_status == "on"
         from c3d_hip.parallel import FlatGrads
-        flat_grads = FlatGrads(plist)        # one buffer: the kernels write into what the collective sends
-        step_grads = flat_grads.views
+        flat_grads = FlatGrads(plist) if zero is None else None        # one buffer: the kernels write into what the collective sends
+        step_grads = flat_grads.views if zero is None else zero.grads
         for q, gq in zip(plist, step_grads):
             q.grad = gq                      # the optimizer reads .grad
 
@@ -430,6 +437,9 @@ def main():
                     tc, ta = targets[i]
                     loss = (color - tc).abs().mean() * 0.8 + 3.0 * ((alpha - ta) ** 2).mean()
                     (loss / (a.views_per_gpu * world)).backward()
+        if zero is not None and not collect:
+            zero.step()                      # reduce-scatter (all-to-all + rank-ordered sum) -> Adam on the owned slice -> all-gather(parameters)
+            return
         if exchanged:
             pass
         elif a.mode != "fwd" and world > 1 and fused_step is not None and not collect:
@@ -450,7 +460,7 @@ def main():
                 w = q.grad[0].numel()
                 q.grad.copy_(flat[:, off:off + w].reshape(q.grad.shape))
                 off += w
-        if a.mode == "train":
+        if a.mode == "train" and zero is None:
             opt.step()
         if a.mode != "fwd" and fused_step is None:
             for q in plist:

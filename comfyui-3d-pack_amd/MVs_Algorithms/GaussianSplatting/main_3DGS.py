@@ -98,6 +98,7 @@ class GaussianSplatting3D:
         self.params = [g._xyz, g._features_dc, g._features_rest, g._opacity, g._scaling, g._rotation]
         parallel.broadcast_parameters(self.params, src=0, group=process_group)
         self.use_fused_step, self._step = True, None       # the fused rasterizer step serves every loss configuration (see _can_fuse)
+        self._zero = None                                    # exchange == "zero1": parallel.ZeroOneAdam (sharded moments; rebuilt after every densification)
         self.defer_step_status = True                        # fused step: no host synchronisation per step once the pair capacity is fitted (c3d_hip/gs_step.py)
         self.image_loss_in_torch = False                     # True: fused forward / backward halves with the image loss (incl. MS-SSIM) as torch ops in between
 
@@ -140,8 +141,14 @@ class GaussianSplatting3D:
                 loss = loss + p.lambda_offset_opacity * (off.detach() * g.get_opacity).mean()
         loss.backward()
         # batch losses are means over views: equal shards => the global gradient is the mean of the ranks' gradients
-        parallel.exchange_gradients(self.params, self.group, self.exchange, average=True)
-        self.optimizer.step()
+        if self.exchange == "zero1":
+            z = self._zero_adam()
+            for dst, q in zip(z.grads, self.params):
+                dst.copy_(q.grad) if q.grad is not None else dst.zero_()
+            z.step()                                           # reduce-scatter -> Adam on the owned slice -> all-gather(parameters)
+        else:
+            parallel.exchange_gradients(self.params, self.group, self.exchange, average=True)
+            self.optimizer.step()
         stats = None
         if out is not None and self._in_density_window(step):
             vg = out["viewspace_points"].grad
@@ -149,6 +156,11 @@ class GaussianSplatting3D:
         self.optimizer.zero_grad()
         self._densify(step, stats)
         return loss.detach()
+
+    def _zero_adam(self):
+        if self._zero is None:
+            self._zero = parallel.ZeroOneAdam(self.optimizer, self.params, self.group, average=True)
+        return self._zero
 
     # ---- densify / prune schedule (reference :209-224) ----
     def _in_density_window(self, step):
@@ -178,6 +190,9 @@ class GaussianSplatting3D:
         else:
             g.add_densification_stats(vg, vis, radii)
         changed = False
+        if self._zero is not None and (step % p.densification_interval == 0 or step % p.opacity_reset_interval == 0):
+            self._zero.unshard()                             # the surgery below edits whole moments (torch.optim layout); a new ZeroOneAdam adopts them afterwards
+            self._zero = None
         if step % p.densification_interval == 0:
             gen = None                                     # one process: torch's global generator, exactly as the reference draws
             if self.group is not None and torch.distributed.get_world_size(self.group) > 1:
@@ -190,6 +205,8 @@ class GaussianSplatting3D:
             changed = True
         if changed:
             self.params = [g._xyz, g._features_dc, g._features_rest, g._opacity, g._scaling, g._rotation]
+            if self._step is not None:
+                self._step.finish()                          # a deferred step's status is examined BEFORE the object goes away: an overflow on the last step is still reported
             self._step = None                                # pair buffers / gradient buffers are sized by N
 
     # ---- fused multi-view step: all of this rank's views in sync-free library calls ----
@@ -219,8 +236,11 @@ class GaussianSplatting3D:
         if self._step is None:
             self._step = FusedViewStep(self.params[0].shape[0], H, W, self.device)
             self._step.defer_status = self.defer_step_status
-            self._flat_grads = parallel.FlatGrads(self.params)       # the kernels write into what the collective sends
-            self._step_grads = self._flat_grads.views
+            if self.exchange == "zero1":
+                self._flat_grads, self._step_grads = None, self._zero_adam().grads      # the kernels write into what the all-to-all sends
+            else:
+                self._flat_grads = parallel.FlatGrads(self.params)       # the kernels write into what the collective sends
+                self._step_grads = self._flat_grads.views
         views = []
         for i in mine:
             radius, elev, azim, cx, cy, cz = self.all_ref_cam_poses[i]
@@ -240,6 +260,8 @@ class GaussianSplatting3D:
             # world > 1, all-reduce mode, exchange_chunks > 1: the per-Gaussian backward pass goes by Gaussian ranges and each range's f_rest rows
             # start their all-reduce underneath the next range's kernels (FlatGrads.exchange_rows); the rest follows in exchange_finish below
             overlapped = world > 1 and self.exchange == "allreduce" and self.exchange_chunks > 1
+            if self.exchange == "zero1":
+                self._step_grads = self._zero_adam().grads            # (re-pointed after a densification rebuilt the object)
             loss = self._step.run(views, plist, self._step_grads, [self.ref_imgs_torch[i].contiguous() for i in mine],
                                   [self.ref_masks_torch[i].contiguous() for i in mine], [self.ref_masks_torch[i].contiguous() for i in mine],
                                   w_l1=1.0 - p.lambda_ssim, w_l2=0.0, w_alpha_mse=p.lambda_alpha, scale=1.0 / n_mine, w_ssim=p.lambda_ssim,
@@ -268,13 +290,16 @@ class GaussianSplatting3D:
             if go is not None:
                 self._step_grads[3].add_(go)
             loss = loss + reg.detach()
-        if overlapped:
-            self._flat_grads.exchange_finish(self.group, average=True)
+        if self.exchange == "zero1":
+            self._zero_adam().step()
         else:
-            self._flat_grads.exchange(self.group, self.exchange, average=True)
-        for q, gq in zip(self.params, self._step_grads):
-            q.grad = gq
-        self.optimizer.step()
+            if overlapped:
+                self._flat_grads.exchange_finish(self.group, average=True)
+            else:
+                self._flat_grads.exchange(self.group, self.exchange, average=True)
+            for q, gq in zip(self.params, self._step_grads):
+                q.grad = gq
+            self.optimizer.step()
         step_obj = self._step
         for q in self.params:
             q.grad = None

@@ -39,17 +39,45 @@ def _digest():
     return h.hexdigest()
 
 
+def _current(stamp, dig):
+    try:
+        return os.path.exists(LIB) and open(stamp).read() == dig
+    except OSError:
+        return False
+
+
 def build(force=False, verbose=False):
+    """Several processes may call this at once (every rank of a multi-GPU launch imports c3d_hip): the rebuild runs under an exclusive file lock, objects
+    go to a per-process directory, and both the library and its digest stamp are written to temporary names and renamed into place -- a concurrent
+    CDLL sees either the old file or the complete new one, never a half-written library."""
+    import fcntl
+    import shutil
+    import tempfile
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
     stamp = os.path.join(LIBDIR, "libc3d_hip.digest")
     dig = _digest()
-    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == dig:
+    if not force and _current(stamp, dig):
         return LIB
+    with open(os.path.join(LIBDIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and _current(stamp, dig):      # another process built it while this one waited for the lock
+                return LIB
+            objdir = tempfile.mkdtemp(prefix="obj.", dir=OBJDIR)
+            try:
+                return _build_locked(objdir, stamp, dig, verbose)
+            finally:
+                shutil.rmtree(objdir, ignore_errors=True)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(objdir, stamp, dig, verbose):
     srcs = _sources()
 
     def cc(f):
-        obj = os.path.join(OBJDIR, f[:-4] + ".o")
+        obj = os.path.join(objdir, f[:-4] + ".o")
         cmd = [HIPCC] + FLAGS + ["-c", os.path.join(CSRC, f), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
@@ -60,10 +88,15 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         objs = list(ex.map(cc, srcs))
-    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs, capture_output=True, text=True)
+    tmp_lib = os.path.join(objdir, "libc3d_hip.so")
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp_lib] + objs, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
-    open(stamp, "w").write(dig)
+    os.replace(tmp_lib, LIB)                          # same filesystem (objdir lives under the package): atomic
+    tmp_stamp = stamp + ".%d.tmp" % os.getpid()
+    with open(tmp_stamp, "w") as f:
+        f.write(dig)
+    os.replace(tmp_stamp, stamp)
     return LIB
 
 

@@ -32,17 +32,27 @@ class FusedViewStep:
         # defer_status: once the capacity is fitted, run() does not wait for its own status words -- they are copied to pinned memory asynchronously and
         # examined when the NEXT run() (or finish()) starts, so the host enqueues step k+1 while the GPU still works on step k (the single sync per step
         # left a 0.26 ms bubble at every step boundary, 3.5 % of the 8-view step).  A device fault still raises; a pair overflow between two consecutive
-        # steps of a fitted scene (> 30 % more pairs from one step to the next) is then noticed one step late: the capacity is regrown and a warning says
-        # that the previous step's gradient was incomplete.  Off by default; the trainer and bench.py turn it on.
+        # steps of a fitted scene is then noticed one step late: the capacity is regrown and a warning says that the previous step's gradient was
+        # incomplete.  To make that rare the capacity follows the scene: whenever a step is seen to use more than GROW_AT of it (the status word carries
+        # the largest pair count of the step), it is regrown to 1.3 x that count BEFORE the next step -- splat footprints that grow gradually over a run
+        # never reach the limit; only a jump of > 25 % between two consecutive steps can still overflow.  Off by default; the trainer and bench.py turn it on.
         self.defer_status = False
         self._pending = None
         self._pinned = None
         self._flip = 0
         self._alloc()
 
+    GROW_AT = 0.8      # regrow the pair capacity when a step used more than this share of it
+
     def _alloc(self):
         nbytes = _h.lib().c3d_gs_step_workspace_bytes(self.N, self.H, self.W, self.capacity, self.views)
         self.workspace = torch.empty((nbytes,), dtype=torch.uint8, device=self.device)
+
+    def _follow(self, seen):
+        """keep headroom above what the scene needs: called with the largest pair count of a CLEAN step"""
+        if self._fitted and seen > self.GROW_AT * self.capacity:
+            self.capacity = int(seen * 1.3) + 4096
+            self._alloc()       # the finished step's buffers stay alive through self._last until the next step replaces them
 
     @staticmethod
     def _settings(rs_list, keep):
@@ -145,6 +155,7 @@ class FusedViewStep:
                     self.capacity = int(seen * 1.3) + 4096
                     self._alloc()
                 self._fitted = True
+                self._follow(seen)
                 if not chunked:
                     hand_over()
                 return self.loss.clone()
@@ -183,6 +194,7 @@ class FusedViewStep:
             warnings.warn("c3d FusedViewStep: the previous step needed %d (tile, splat) pairs, more than the fitted capacity; its gradient was incomplete "
                           "(noticed one step late because defer_status is on); capacity regrown to %d" % (seen, self.capacity), RuntimeWarning)
             return False
+        self._follow(st[1] & 0xFFFFFFFF)
         return True
 
     # ---- the step split at the image --------------------------------------------------------------------------------------------------------

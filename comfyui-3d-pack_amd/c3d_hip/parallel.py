@@ -7,7 +7,15 @@ and the only exchange per step is the dense parameter gradient.  Two exchange mo
                fixed summation order -> replicas stay bit-identical, and the backward kernels are deterministic);
   "allreduce": one RCCL all-reduce (sum order chosen by the library).
 xGMI is point-to-point (7 links per GPU), so the all-gather sends one gradient copy per link concurrently.
+  "zero1":     ZeRO stage 1 (class ZeroOneAdam below): every rank owns 1/n of the flat parameter vector.  The gradient is
+               reduce-scattered as ONE all-to-all (each rank sends slice j of its gradient straight to rank j: seven concurrent single-hop
+               transfers on the seven xGMI links instead of a ring) followed by a fixed-rank-order sum of the n received copies of the owned
+               slice; Adam runs on the owned slice only (moments: 1/n of the memory, 1/n of the 1.65 GB the replicated step streams); one
+               all-gather returns the updated parameters.  Same bytes on the wire as the ring all-reduce (2 (n-1)/n x 236 MB per rank), same
+               bits as the replicated "allgather" step.
 """
+import math
+
 import torch
 import torch.distributed as dist
 
@@ -144,6 +152,129 @@ class FlatGrads:
         self._works = []
         if average:
             self.flat.mul_(1.0 / world)
+
+
+def adam_reference_(p, g, m, v, lr, b1, b2, eps, t):
+    """torch.optim.Adam's single-tensor update (no weight decay, no amsgrad), statement by statement, on CPU tensors or slices of them:
+    what ZeroOneAdam runs on its owned slice where there is no HIP device (the gloo tests); bit-identical to torch.optim.Adam(foreach=False)"""
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    bc1, bc2 = 1 - b1 ** t, 1 - b2 ** t
+    denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+    p.addcdiv_(m, denom, value=-(lr / bc1))
+
+
+class ZeroOneAdam:
+    """ZeRO-1 step of the shared-Gaussian loop: reduce-scatter(gradient) -> Adam on the owned 1/n -> all-gather(parameters).
+
+    `optimizer` supplies the hyper-parameters (param_groups: lr / betas / eps per tensor, as GaussianModel.training_setup builds them and the LR
+    schedule updates them); its `state` is NOT used while this object lives: the moments exist only for the owned slice.  `params` are re-pointed
+    into one flat buffer (`p.data` becomes a view), the gradients live in a second one (`grads[i]`, shaped like params[i]: the kernels / autograd
+    write straight into what the all-to-all sends).  Both buffers are padded so that every rank owns the same number of elements, a multiple of 4
+    (16-byte aligned slices for the float4 kernels).
+
+    step():  all_to_all_single  ->  fixed-order sum of the n copies of the owned slice (c3d_reduce_ranks_f32 on a HIP device)  ->  Adam on the
+    intersections of the owned slice with each parameter tensor (c3d_adam_step on a HIP device, adam_reference_ on the CPU)  ->  all_gather_into_tensor
+    of the parameter buffer.  Every element is summed in rank order and updated by the same elementwise rule as in the replicated step, so the
+    parameters are bit-identical to mode "allgather" + a full Adam step (tests/test_host_logic.py, worlds 2 and 4).
+
+    Densification / opacity reset / checkpoints need whole moments: unshard() all-gathers them into optimizer.state (torch.optim layout); a new
+    ZeroOneAdam built afterwards adopts that state and drops it again."""
+
+    def __init__(self, optimizer, params, group=None, average=True):
+        self.opt, self.params, self.group, self.average = optimizer, list(params), group, average
+        on = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if on else 1
+        self.rank = dist.get_rank(group) if on else 0
+        dev = self.params[0].device
+        sizes = [(p.numel() + 3) // 4 * 4 for p in self.params]
+        q = 4 * self.world
+        total = (sum(sizes) + q - 1) // q * q
+        self.total, self.chunk = total, total // self.world
+        self.lo, self.hi = self.rank * self.chunk, (self.rank + 1) * self.chunk
+        self.flat_p = torch.zeros((total,), dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros((total,), dtype=torch.float32, device=dev)
+        self.grads, self.offsets, off = [], [], 0
+        for p, sz in zip(self.params, sizes):
+            self.flat_p[off:off + p.numel()].copy_(p.data.reshape(-1))
+            p.data = self.flat_p[off:off + p.numel()].view(p.shape)
+            self.grads.append(self.flat_g[off:off + p.numel()].view(p.shape))
+            self.offsets.append(off)
+            off += sz
+        self.m = torch.zeros((self.chunk,), dtype=torch.float32, device=dev)
+        self.v = torch.zeros((self.chunk,), dtype=torch.float32, device=dev)
+        self.gsum = torch.zeros((self.chunk,), dtype=torch.float32, device=dev)
+        self.recv = torch.empty((total,), dtype=torch.float32, device=dev) if self.world > 1 else None
+        self.t = 0
+        self.group_of = {}
+        for gr in optimizer.param_groups:
+            for p in gr["params"]:
+                self.group_of[id(p)] = gr
+        self._adopt()
+
+    def _segments(self):
+        """(param index, a, b): the element range [a, b) of the flat buffers where params[i] meets the owned slice"""
+        for i, (p, off) in enumerate(zip(self.params, self.offsets)):
+            a, b = max(off, self.lo), min(off + p.numel(), self.hi)
+            if a < b:
+                yield i, a, b
+
+    def _adopt(self):
+        for i, a, b in self._segments():
+            st = self.opt.state.get(self.params[i])
+            if st and "exp_avg" in st:
+                off = self.offsets[i]
+                self.m[a - self.lo:b - self.lo].copy_(st["exp_avg"].reshape(-1)[a - off:b - off])
+                self.v[a - self.lo:b - self.lo].copy_(st["exp_avg_sq"].reshape(-1)[a - off:b - off])
+        steps = [int(st["step"]) for st in (self.opt.state.get(p) for p in self.params) if st and "step" in st]
+        self.t = max(steps) if steps else 0
+        for p in self.params:
+            if p in self.opt.state:
+                del self.opt.state[p]
+
+    def zero_grad(self):
+        self.flat_g.zero_()
+
+    def step(self):
+        scale = 1.0 / self.world if self.average else 1.0
+        if self.world > 1:
+            dist.all_to_all_single(self.recv, self.flat_g, group=self.group)       # recv[r * chunk : (r + 1) * chunk] = rank r's copy of MY slice
+            if self.flat_g.is_cuda:
+                import c3d_hip as _h
+                with torch.cuda.device(self.flat_g.device):
+                    _h.check(_h.lib().c3d_reduce_ranks_f32(_h.ptr(self.gsum), _h.ptr(self.recv), self.world, self.chunk, scale, _h.stream(self.flat_g.device)), "c3d_reduce_ranks_f32")
+            else:
+                r = self.recv.view(self.world, self.chunk)
+                total = r[0].clone()
+                for k in range(1, self.world):
+                    total += r[k]
+                self.gsum.copy_(total * scale if self.average else total)
+        else:
+            self.gsum.copy_(self.flat_g[self.lo:self.hi])
+        self.t += 1
+        for i, a, b in self._segments():
+            gr = self.group_of[id(self.params[i])]
+            b1, b2 = gr["betas"]
+            ps, gs, ms, vs = self.flat_p[a:b], self.gsum[a - self.lo:b - self.lo], self.m[a - self.lo:b - self.lo], self.v[a - self.lo:b - self.lo]
+            if ps.is_cuda:
+                import c3d_hip as _h
+                with torch.cuda.device(ps.device):
+                    _h.check(_h.lib().c3d_adam_step(_h.ptr(ps), _h.ptr(gs), _h.ptr(ms), _h.ptr(vs), b - a, float(gr["lr"]), float(b1), float(b2), float(gr["eps"]),
+                                                    int(self.t), _h.stream(ps.device)), "c3d_adam_step")
+            else:
+                adam_reference_(ps, gs, ms, vs, float(gr["lr"]), float(b1), float(b2), float(gr["eps"]), self.t)
+        if self.world > 1:
+            dist.all_gather_into_tensor(self.flat_p, self.flat_p[self.lo:self.hi].clone(), group=self.group)
+
+    def unshard(self):
+        """all-gather the moments and hand them to the wrapped optimizer in torch.optim.Adam's layout (densification surgery, checkpoints)"""
+        fm, fv = self.m, self.v
+        if self.world > 1:
+            fm, fv = torch.empty_like(self.flat_p), torch.empty_like(self.flat_p)
+            dist.all_gather_into_tensor(fm, self.m, group=self.group)
+            dist.all_gather_into_tensor(fv, self.v, group=self.group)
+        for p, off in zip(self.params, self.offsets):
+            self.opt.state[p] = {"step": self.t, "exp_avg": fm[off:off + p.numel()].view(p.shape).clone(), "exp_avg_sq": fv[off:off + p.numel()].view(p.shape).clone()}
 
 
 def broadcast_parameters(params, src=0, group=None):

@@ -5,6 +5,13 @@
 #include "../../include/c3d_optim.h"
 #include "c3d_common.h"
 
+// ONE spelling of the update for the float4 body and the tail: a tensor updated as a whole and the same tensor updated slice by slice (ZeRO-1:
+// c3d_hip/parallel.py ZeroOneAdam, slices start at multiples of 4 elements) give the same bits for every element.
+__device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, float lr_over_bc1, float inv_sqrt_bc2, float b1, float b2, float omb1, float omb2, float eps) {
+    m = __builtin_fmaf(b1, m, omb1 * g);
+    v = __builtin_fmaf(b2, v, (omb2 * g) * g);
+    p = p - (lr_over_bc1 * m) / __builtin_fmaf(sqrtf(v), inv_sqrt_bc2, eps);
+}
 __global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                long long n, float lr_over_bc1, float inv_sqrt_bc2, float b1, float b2, float omb1, float omb2, float eps) {
     const long long n4 = n >> 2;
@@ -14,20 +21,18 @@ __global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
         float4 pp = p4[i], mm = m4[i], vv = v4[i];
         const float4 gg = g4[i];
-#define C3D_ADAM1(c)                                                  \
-    mm.c = b1 * mm.c + omb1 * gg.c;                                   \
-    vv.c = b2 * vv.c + omb2 * gg.c * gg.c;                            \
-    pp.c -= lr_over_bc1 * mm.c / (sqrtf(vv.c) * inv_sqrt_bc2 + eps);
-        C3D_ADAM1(x) C3D_ADAM1(y) C3D_ADAM1(z) C3D_ADAM1(w)
+        adam1(pp.x, gg.x, mm.x, vv.x, lr_over_bc1, inv_sqrt_bc2, b1, b2, omb1, omb2, eps);
+        adam1(pp.y, gg.y, mm.y, vv.y, lr_over_bc1, inv_sqrt_bc2, b1, b2, omb1, omb2, eps);
+        adam1(pp.z, gg.z, mm.z, vv.z, lr_over_bc1, inv_sqrt_bc2, b1, b2, omb1, omb2, eps);
+        adam1(pp.w, gg.w, mm.w, vv.w, lr_over_bc1, inv_sqrt_bc2, b1, b2, omb1, omb2, eps);
         p4[i] = pp; m4[i] = mm; v4[i] = vv;
     }
     // tail (n % 4) by the first lanes of block 0
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const long long i = (n4 << 2) + threadIdx.x;
-        float mm = b1 * m[i] + omb1 * g[i];
-        float vv = b2 * v[i] + omb2 * g[i] * g[i];
-        m[i] = mm; v[i] = vv;
-        p[i] -= lr_over_bc1 * mm / (sqrtf(vv) * inv_sqrt_bc2 + eps);
+        float pp = p[i], mm = m[i], vv = v[i];
+        adam1(pp, g[i], mm, vv, lr_over_bc1, inv_sqrt_bc2, b1, b2, omb1, omb2, eps);
+        p[i] = pp; m[i] = mm; v[i] = vv;
     }
 }
 

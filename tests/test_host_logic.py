@@ -376,3 +376,143 @@ def test_diffmesh_validates_the_remesh_interval_up_front():
     assert "raise NotImplementedError" not in src                                 # nothing aborts 512 steps into a run any more
     ctor = src[src.index("class DiffMesh:"):src.index("def prepare_training")]
     assert "warnings.warn(" in ctor and "remesh_after_n_iteration < training_iterations" in ctor
+
+
+# ---------------------------------------------------------------- ZeRO-1 and wider worlds
+_SHAPES = ((3,), (1, 3), (15, 3), (1,), (3,), (4,))
+_LRS = (1.6e-4, 2.5e-3, 1.25e-4, 0.05, 5e-3, 1e-3)
+
+
+def _rank_grads(N, views, step):
+    """stand-in for 'the gradient of this rank's views at this step': a function of the view ids only, so any sharding sums to the same total"""
+    out = []
+    for i, s in enumerate(_SHAPES):
+        t = torch.zeros((N,) + s)
+        for v in views:
+            t += torch.randn((N,) + s, generator=torch.Generator().manual_seed(100000 * step + 1000 * v + i))
+        out.append(t)
+    return out
+
+
+def _zero1_worker(rank, world, port, N, steps, n_views, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "comfyui-3d-pack_amd")]
+    from c3d_hip import parallel
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.randn(N, *s)) for s in _SHAPES]
+    parallel.broadcast_parameters(params, src=0)
+    opt = torch.optim.Adam([{"params": [p], "lr": lr, "name": str(i)} for i, (p, lr) in enumerate(zip(params, _LRS))], lr=0.0, eps=1e-15)
+    z = parallel.ZeroOneAdam(opt, params, None, average=True)
+    assert z.chunk % 4 == 0 and z.chunk * world == z.total and all(g.data_ptr() % 16 == 0 for g in z.grads)
+    mid = None
+    for step in range(steps):
+        mine = parallel.shard_views(list(range(n_views)), rank, world)      # n_views < world: some ranks have no views this step
+        for dst, g in zip(z.grads, _rank_grads(N, mine, step)):
+            dst.copy_(g)
+        opt.param_groups[0]["lr"] = _LRS[0] * (0.9 ** step)                   # the LR schedule moves a group's lr between steps
+        z.step()
+        if step == steps // 2:                                                # densification / checkpoint boundary: whole moments out, a fresh object adopts them
+            z.unshard()
+            mid = [opt.state[p]["exp_avg"].clone() for p in params]
+            z = parallel.ZeroOneAdam(opt, params, None, average=True)
+            assert all(p not in opt.state for p in params) and z.t == step + 1
+    z.unshard()
+    out[rank] = ([p.data.clone() for p in params], [opt.state[p]["exp_avg"].clone() for p in params], [opt.state[p]["exp_avg_sq"].clone() for p in params], mid)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_views", [(2, 8), (4, 8), (4, 3)])
+def test_zero1_equals_replicated_adam_bit_for_bit(world, n_views):
+    """ZeRO-1 (all-to-all reduce-scatter in rank order -> Adam on the owned slice -> all-gather of the parameters) over gloo, worlds 2 and 4, also with
+    ranks that hold no view: parameters AND moments equal, bit for bit, those of the replicated step -- every rank summing all ranks' gradients in rank
+    order (exchange mode 'allgather') and running Adam on every element -- including across an unshard / re-adopt boundary and a changing lr."""
+    N, steps, port = 203, 5, _free_port()          # 59 * 203 elements: neither tensors nor slices end on chunk boundaries
+    out = mp.Manager().dict()
+    mp.spawn(_zero1_worker, args=(world, port, N, steps, n_views, out), nprocs=world, join=True)
+    from c3d_hip import parallel
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.randn(N, *s)) for s in _SHAPES]
+    twin = [torch.nn.Parameter(p.detach().clone()) for p in params]          # the same run through torch.optim.Adam itself (its exp_avg update is a lerp_: equal to rounding)
+    opt = torch.optim.Adam([{"params": [p], "lr": lr} for p, lr in zip(twin, _LRS)], lr=0.0, eps=1e-15)
+    ms, vs = [torch.zeros_like(p) for p in params], [torch.zeros_like(p) for p in params]
+    for step in range(steps):
+        per_rank = [_rank_grads(N, list(range(n_views))[r::world], step) for r in range(world)]
+        for i, (p, q) in enumerate(zip(params, twin)):
+            tot = per_rank[0][i].clone()
+            for r in range(1, world):
+                tot += per_rank[r][i]
+            g = tot * (1.0 / world)
+            q.grad = g.clone()
+            lr = _LRS[i] * (0.9 ** step) if i == 0 else _LRS[i]
+            parallel.adam_reference_(p.data, g, ms[i], vs[i], lr, 0.9, 0.999, 1e-15, step + 1)     # the replicated step: every element, one process
+        opt.param_groups[0]["lr"] = _LRS[0] * (0.9 ** step)
+        opt.step()
+    for p, q in zip(params, twin):
+        assert torch.allclose(p.data, q.data, rtol=1e-5, atol=1e-7)                                # adam_reference_ IS torch.optim.Adam's rule
+    for r in range(world):
+        ps, m_r, v_r, mid = out[r]
+        for a, b in zip(ps, params):
+            assert torch.equal(a, b.data), "rank %d parameters" % r
+        for a, b in zip(m_r, ms):
+            assert torch.equal(a, b), "rank %d exp_avg" % r
+        for a, b in zip(v_r, vs):
+            assert torch.equal(a, b), "rank %d exp_avg_sq" % r
+        assert mid is not None
+
+
+def _world8_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "comfyui-3d-pack_amd")]
+    from c3d_hip import parallel
+    N = 1030
+    params = [torch.nn.Parameter(torch.zeros(N, *s)) for s in _SHAPES]
+    res = {}
+    for n_views in (64, 5):                       # 8 per rank; then 5 views on 8 ranks: ranks 5-7 exchange zeros, and still issue the same sequence of ranges
+        mine = parallel.shard_views(list(range(n_views)), rank, world)
+        grads = _rank_grads(N, mine, 0)
+        fa, fb, fc = parallel.FlatGrads(params), parallel.FlatGrads(params), parallel.FlatGrads(params)
+        for f in (fa, fb, fc):
+            for v_, g in zip(f.views, grads):
+                v_.copy_(g)
+        fa.exchange(None, "allgather")
+        fb.exchange(None, "allreduce")
+        for g0, g1 in ((0, 256), (256, 512), (512, 768), (768, N)):
+            fc.exchange_rows(g0, g1)
+        fc.exchange_finish()
+        # a library all-reduce picks its own summation order per message, so beyond two ranks the chunked form equals the one-message form only to
+        # rounding; what matters -- and is asserted by the parent -- is that each form leaves the SAME bits on every rank
+        assert torch.allclose(fb.flat, fc.flat, rtol=1e-5, atol=1e-5) and torch.allclose(fa.flat, fb.flat, rtol=1e-5, atol=1e-5)
+        res[n_views] = (fa.flat.clone(), fb.flat.clone(), mine, fc.flat.clone())
+    out[rank] = res
+    dist.destroy_process_group()
+
+
+def test_exchange_world8_gloo_including_ranks_without_views():
+    """The shape of the driver's 8-GPU run on CPU: eight gloo ranks, 8 views each (config 4) and then 5 views in total (three ranks have none).  All three
+    exchange forms -- all-gather + rank-ordered sum, all-reduce, all-reduce by Gaussian ranges -- leave identical bits on every rank (replicas cannot drift);
+    only the all-gather form has a summation order the caller controls: it equals the rank-ordered sum computed in one process bit for bit, the two
+    all-reduce forms equal it (and each other) to rounding."""
+    world, port = 8, _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_world8_worker, args=(world, port, out), nprocs=world, join=True)
+    for n_views in (64, 5):
+        views = [out[r][n_views][2] for r in range(world)]
+        assert sorted(sum(views, [])) == list(range(n_views))
+        for r in range(1, world):
+            assert torch.equal(out[r][n_views][0], out[0][n_views][0]) and torch.equal(out[r][n_views][1], out[0][n_views][1]) and torch.equal(out[r][n_views][3], out[0][n_views][3])
+        per_rank = [_rank_grads(1030, views[r], 0) for r in range(world)]
+        tot = [per_rank[0][i].clone() for i in range(6)]
+        for r in range(1, world):
+            for i in range(6):
+                tot[i] += per_rank[r][i]
+        from c3d_hip import parallel
+        ref = parallel.FlatGrads([torch.zeros_like(t) for t in tot])
+        for v_, t in zip(ref.views, tot):
+            v_.copy_(t)
+        assert torch.equal(out[0][n_views][0], ref.flat)

@@ -205,7 +205,7 @@ def _rank_worker(rank, world, port, exchange, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("exchange", ["allreduce", "allgather"])
+@pytest.mark.parametrize("exchange", ["allreduce", "allgather", "zero1"])
 def test_two_gloo_ranks_train_like_one_process_and_stay_identical(exchange):
     """N > 1 on the CPU: two ranks, one view each per step, one gradient exchange per step.  Until the first densification the replicas
     follow the single-process run of the same global batch (mean-of-means = mean over equal shards); through densification -- whose

@@ -112,7 +112,7 @@ def test_bench_two_ranks_sharing_the_device():
     import socket
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for exchange, mode in (("allreduce", "fwdbwd"), ("allgather", "fwdbwd"), ("allreduce", "train")):      # train: the overlapped exchange feeding the fused Adam
+    for exchange, mode in (("allreduce", "fwdbwd"), ("allgather", "fwdbwd"), ("allreduce", "train"), ("zero1", "train")):      # train: the overlapped exchange feeding the fused Adam; zero1: all-to-all + sharded Adam + all-gather
         s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
         env = dict(os.environ, C3D_BENCH_SHARE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
