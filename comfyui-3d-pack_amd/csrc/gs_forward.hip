@@ -367,22 +367,26 @@ __global__ void __launch_bounds__(256) k_composite_fwd(GsParams p, const uint2* 
 //   * tests its own quadrant only (gs_rect_hit: exact ellipse-vs-rectangle, the same test as gs_quadrant_mask), and COMPACTS the hits -- records,
 //     conic pre-scaled for v_exp_f32 -- into a wave-private LDS list (ballot + mbcnt), padded to a multiple of four with zero-opacity dummies,
 //   * walks that list with a counted, 4x unrolled loop of LDS broadcast reads at immediate offsets: no ballot walk, no per-splat scalar address
-//     arithmetic, and the blend is branch-free (lane masks live in SGPR pairs and feed v_cndmask_b32_e64); the one rare event, a pixel that
-//     saturates at this splat, is a uniform branch that is almost never taken.
+//     arithmetic, and the blend is branch-free: which pixels still take splats (`alive`), which pass the alpha test, which saturate at this splat
+//     are lane masks in SGPR pairs, combined by scalar instructions and fed to v_cndmask_b32_e64.
+// What bounds it (profiles/r03*): the VALU pipe at the measured issue cost of its instructions on gfx950 (profiles/r01f_valu_rate_microbench.txt:
+// 2.9 cycles for add / mul / fma, 4.5 for compares and min, 4.7 for an SGPR-mask select, 8.3 for v_exp_f32) -- about 80 cycles per walked
+// (quadrant, splat) pair of which 44 % of the lanes blend.  Fewer instructions per pair is the only lever left in this decomposition.
 // RECORD: one scalar bit per walked list entry ("some lane blended it": s_cmp_lg_u64 + two s_addc_u32 shift it into a 64-bit mask), written out as
 // the quadrant's byte plane of the pair-activity record (gs_pair_activity) -- one coalesced byte store per 64 list entries.
-// Arithmetic, statement by statement, as k_composite_fwd: the two produce identical images (tests/test_gs_hip.py::test_forward_kernels_agree).
+// Per-pixel arithmetic as k_composite_fwd (same images, n_contrib and gradients: tests/test_gs_hip.py::test_forward_kernels_agree) except the alpha
+// output, which this kernel takes from the telescoped sum 1 - T_final instead of a sixth accumulator (equal to rounding).
 // ------------------------------------------------------------------------------------------
 #define FWQ_PAD 4
+#define FWQ_SLOTS (64 + FWQ_PAD)
 template <bool RECORD>
 __global__ void __launch_bounds__(64, 8) k_composite_fwd_w(GsParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-                                                         const float4* __restrict__ rec, float* __restrict__ out_color, float* __restrict__ out_depth,
-                                                         float* __restrict__ out_alpha, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-                                                         uint8_t* __restrict__ pact, size_t pstride, int sh) {
-    __shared__ float4 c0[64 + FWQ_PAD];     // (px, py, -log2e/2 A, -log2e B)
-    __shared__ float4 c1[64 + FWQ_PAD];     // (-log2e/2 C, opacity, r, g)
-    __shared__ float2 c2[64 + FWQ_PAD];     // (b, view depth)
-    __shared__ uint8_t cmap[64 + FWQ_PAD];  // compact position -> lane (= position inside the chunk)
+                                                            const float4* __restrict__ rec, float* __restrict__ out_color, float* __restrict__ out_depth,
+                                                            float* __restrict__ out_alpha, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+                                                            uint8_t* __restrict__ pact, size_t pstride, int sh) {
+    // the wave's compacted splat list, three 16-byte parts per entry at ONE running offset:
+    //   part 0 (px, py, -log2e/2 A, -log2e B)   part 1 (-log2e/2 C, opacity, r, g)   part 2 (b, view depth, list position + 1 as int bits, -)
+    __shared__ float4 cl[3][FWQ_SLOTS];
     const int b = blockIdx.x, q = (b >> 3) & 3;   // the four quadrants of a tile sit on ONE XCD (b & 7): they gather the same records
     int tx, ty;
     if (!gs_block_tile((b & 7) | ((b >> 5) << 3), p.gx, p.gy, tx, ty, sh)) return;
@@ -390,15 +394,16 @@ __global__ void __launch_bounds__(64, 8) k_composite_fwd_w(GsParams p, const uin
     const int QX = tx * C3D_TILE_X + ((q & 1) << 3), QY = ty * C3D_TILE_Y + ((q >> 1) << 3);
     const int pxi = QX + (lane & 7), pyi = QY + (lane >> 3);
     const bool inside = pxi < p.W && pyi < p.H;
-    float pxf = inside ? (float)pxi : GS_PARKED;     // a finished pixel is parked where every splat evaluates to alpha = 0 (see k_composite_fwd)
-    const float pyf = (float)pyi;
+    const float pxf = (float)pxi, pyf = (float)pyi;
     const size_t pid = (size_t)pyi * p.W + pxi;
     const float rx0 = (float)QX, ry0 = (float)QY;
     const uint2 rg = ranges[tile];
     const int todo = (int)(rg.y - rg.x);
-    float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f, A = 0.f;
-    uint32_t last = 0;
-    bool done = __ballot(pxf != GS_PARKED) == 0ull;
+    float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
+    int last = 0;
+    // `alive`: the pixels that still take splats, as a lane mask in an SGPR pair.  A pixel dies when a splat would push its transmittance below 1e-4
+    // (it does not take that splat) or when it lies outside the image; dead lanes run the same instructions with every select closed.
+    uint64_t alive = __ballot(inside);
     const float k255 = 1.f / 255.f, kT = 0.0001f;
 
     float4 n0 = make_float4(0, 0, 0, 0), n1 = n0, n2 = n0;
@@ -409,8 +414,8 @@ __global__ void __launch_bounds__(64, 8) k_composite_fwd_w(GsParams p, const uin
             n0 = rec[4 * id]; n1 = rec[4 * id + 1]; n2 = rec[4 * id + 2];
         }
     };
-    if (!done && todo > 0) fetch(0);
-    for (int base = 0; base < todo && !done; base += 64) {
+    if (alive && todo > 0) fetch(0);
+    for (int base = 0; base < todo && alive; base += 64) {
         const float4 a0 = n0, a1 = n1, a2 = n2;
         const bool have = base + lane < todo;
         if (base + 64 < todo) fetch(base + 64);                       // in flight while this chunk is walked
@@ -423,52 +428,50 @@ __global__ void __launch_bounds__(64, 8) k_composite_fwd_w(GsParams p, const uin
         if (n) {
             __syncthreads();                                           // one wave: orders this chunk's LDS writes behind the last chunk's reads
             if (hit) {
-                c0[pos] = make_float4(a0.x, a0.y, GS_CONIC_HALF * a0.z, GS_CONIC_FULL * a0.w);
-                c1[pos] = make_float4(GS_CONIC_HALF * a1.x, a1.y, a1.z, a1.w);
-                c2[pos] = make_float2(a2.x, a2.y);
-                cmap[pos] = (uint8_t)lane;
+                cl[0][pos] = make_float4(a0.x, a0.y, GS_CONIC_HALF * a0.z, GS_CONIC_FULL * a0.w);
+                cl[1][pos] = make_float4(GS_CONIC_HALF * a1.x, a1.y, a1.z, a1.w);
+                cl[2][pos] = make_float4(a2.x, a2.y, __int_as_float(base + lane + 1), 0.f);
             }
             const int npad = (n + 3) & ~3;
             if (lane < npad - n) {                                     // zero-opacity dummies: alpha = 0 fails the 1/255 test on every pixel
-                c0[n + lane] = make_float4(0.f, 0.f, 0.f, 0.f); c1[n + lane] = make_float4(0.f, 0.f, 0.f, 0.f); c2[n + lane] = make_float2(0.f, 0.f);
+                cl[0][n + lane] = make_float4(0.f, 0.f, 0.f, 0.f); cl[1][n + lane] = make_float4(0.f, 0.f, 0.f, 0.f); cl[2][n + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
             __syncthreads();
-            int lastc = -1;
+            // running byte offset into cl[0], kept in a VGPR on purpose (one v_add per group of four; the three parts and the four entries of a group are
+            // immediate offsets of the ds_read): with a scalar index hipcc re-materialises the address with v_mov for every read
+            uint32_t vo;
+            asm volatile("v_mov_b32 %0, 0" : "=v"(vo));
+            const char* lbase = reinterpret_cast<const char*>(&cl[0][0]);
             int i = 0;
-            for (; i < npad && !done; i += 4) {
+            for (; i < npad && alive; i += 4, vo += 64) {
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
-                    const float4 s0 = c0[i + u], s1 = c1[i + u];
-                    const float2 s2 = c2[i + u];
+                    const float4 s0 = *reinterpret_cast<const float4*>(lbase + vo + 16 * u);
+                    const float4 s1 = *reinterpret_cast<const float4*>(lbase + vo + 16 * u + sizeof(float4) * FWQ_SLOTS);
+                    const float4 s2 = *reinterpret_cast<const float4*>(lbase + vo + 16 * u + 2 * sizeof(float4) * FWQ_SLOTS);
                     const float dx = s0.x - pxf, dy = s0.y - pyf;
                     const float power = gs_power(s0, s1.x, dx, dy);          // log2(e) * (-q/2)
                     const float alpha = fminf(0.99f, s1.y * __builtin_amdgcn_exp2f(power));
                     uint64_t ok, k1, st;
                     asm("v_cmp_ge_f32_e64 %0, 0, %1" : "=s"(ok) : "v"(power));
                     asm("v_cmp_le_f32_e64 %0, %1, %2" : "=s"(k1) : "s"(k255), "v"(alpha));
-                    ok &= k1;
-                    float ae = sel64z(ok, alpha);
-                    float testT = T * (1.f - ae);
+                    ok &= k1 & alive;
+                    const float testT = T * (1.f - alpha);
+                    asm volatile("" ::"v"(s2.w));                            // keeps part 2 a 16-byte read: ds_read_b96 takes twice the LDS cycles of ds_read_b128 on gfx950
                     asm("v_cmp_gt_f32_e64 %0, %1, %2" : "=s"(st) : "s"(kT), "v"(testT));
-                    st &= ok;
-                    if (st) {                                                // rare: a pixel saturates AT this splat -- it does not take it and is parked
-                        ae = sel64(st, 0.f, ae);
-                        testT = sel64(st, T, testT);
-                        pxf = sel64(st, GS_PARKED, pxf);
-                        ok &= ~st;
-                        if (__ballot(pxf != GS_PARKED) == 0ull) done = true;   // the rest of this group of four runs on parked pixels: no effect
-                    }
-                    const float w = ae * T;
+                    st &= ok;                                                // these pixels saturate AT this splat: they do not take it, and die
+                    alive &= ~st;
+                    ok &= ~st;                                               // = the lanes that blend it
+                    const float w = sel64z(ok, alpha * T);
+                    T = sel64(ok, testT, T);
                     C0 += s1.z * w; C1 += s1.w * w; C2 += s2.x * w;
-                    Dp += s2.y * w; A += w;
-                    T = testT;
-                    lastc = sel64i(ok, i + u, lastc);
+                    Dp += s2.y * w;
+                    last = sel64i(ok, __float_as_int(s2.z), last);
                     if (RECORD)                                              // act = (act << 1) | (some lane blended this entry): SCC rides the carry chain
                         asm volatile("s_cmp_lg_u64 %2, 0\n\ts_addc_u32 %0, %0, %0\n\ts_addc_u32 %1, %1, %1" : "+s"(act_lo), "+s"(act_hi) : "s"(ok) : "scc");
                 }
             }
             walked = i;
-            if (lastc >= 0) last = (uint32_t)(base + (int)cmap[lastc] + 1);
         }
         if (RECORD && have) {
             // entry k of the compact list sits at bit (walked - 1 - k) of act; entries the walk never reached blended nothing
@@ -480,12 +483,12 @@ __global__ void __launch_bounds__(64, 8) k_composite_fwd_w(GsParams p, const uin
     if (inside) {
         const size_t P = (size_t)p.W * p.H;
         final_T[pid] = T;
-        n_contrib[pid] = last;
+        n_contrib[pid] = (uint32_t)last;
         out_color[pid] = C0 + T * p.bg[0];
         out_color[P + pid] = C1 + T * p.bg[1];
         out_color[2 * P + pid] = C2 + T * p.bg[2];
         out_depth[pid] = Dp;
-        out_alpha[pid] = A;
+        out_alpha[pid] = 1.f - T;                 // sum of the blend weights alpha_i T_i = T_0 - T_final, telescoped (the weights are T_i - T_{i+1})
     }
 }
 

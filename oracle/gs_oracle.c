@@ -450,11 +450,11 @@ gs_state *gs_oracle_forward(int N, int M, int deg, int W, int H, real tanfovx, r
     return st;
 }
 
-/* Test support: which Gaussians are blended into a flagged pixel?  The parity tests flag the pixels where a float32 kernel and this oracle in
- * float64 visibly took different per-splat decisions (alpha >= 1/255, T < 1e-4, ceil(3 sigma): one flipped decision moves the pixel's alpha by a
- * multiple of rounding noise) and then show that the gradient entries outside tolerance belong to exactly those Gaussians.
- * pixel_flags [H*W] (non-zero = flagged)  ->  gauss_flags [N] |= 1 for every Gaussian the composite loop blends into a flagged pixel, walking the
- * pixel's list to its END (a flipped early termination makes the kernel blend splats behind this oracle's stopping point). */
+/* Test support: which Gaussians are blended into a flagged pixel?  The full-size parity tests flag the pixels where a float32 rasterizer and this
+ * oracle in float64 took a different per-splat decision (alpha >= 1/255, T < 1e-4, ceil(3 sigma)) and then show where the gradient entries outside
+ * tolerance come from.  pixel_flags [H*W] (non-zero = flagged)  ->  gauss_flags [N] |= 1 for every Gaussian the composite loop blends into a flagged
+ * pixel.  The walk is the forward loop with both thresholds loosened (alpha from 0.98/255, termination at T < 0.5e-4): the splats whose own decision
+ * can flip, and the few behind this oracle's stopping point a kernel that stops one splat later still blends, count. */
 void gs_oracle_taint(const gs_state *st, const unsigned char *pixel_flags, unsigned char *gauss_flags) {
     int W = st->W, H = st->H;
     int tiles = st->gx * st->gy;
@@ -464,6 +464,7 @@ void gs_oracle_taint(const gs_state *st, const unsigned char *pixel_flags, unsig
         for (int py = ty * BLOCK_Y; py < imin(H, (ty + 1) * BLOCK_Y); py++)
             for (int px = tx * BLOCK_X; px < imin(W, (tx + 1) * BLOCK_X); px++) {
                 if (!pixel_flags[(size_t)py * W + px]) continue;
+                real T = 1;
                 for (uint32_t j = r0; j < r1; j++) {
                     uint32_t g = st->point_list[j];
                     real dx = st->xy[2 * g] - (real)px, dy = st->xy[2 * g + 1] - (real)py;
@@ -471,8 +472,11 @@ void gs_oracle_taint(const gs_state *st, const unsigned char *pixel_flags, unsig
                     real power = -(real)0.5 * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
                     if (power > (real)1e-6) continue;
                     real alpha = rmin((real)0.99, co[3] * (real)exp((double)power));
-                    if (alpha < (real)0.98 / (real)255) continue;      /* a little below the threshold: the splats whose decision can flip count */
+                    if (alpha < (real)0.98 / (real)255) continue;
                     gauss_flags[g] |= 1;
+                    real testT = T * ((real)1 - alpha);
+                    if (testT < (real)0.00005) break;
+                    T = testT;
                 }
             }
     }
