@@ -27,28 +27,53 @@ class DiffMeshCameraController(BaseCameraController):
 
 
 def laplacian_smooth_loss(v, f):
-    """mean squared length of the uniform (umbrella) Laplacian -- stands in for kiui.mesh_utils.laplacian_smooth_loss"""
+    """kiui.mesh_utils.laplacian_smooth_loss (kiui 0.2.x, the package /root/reference/MVs_Algorithms/DiffRastMesh/diff_mesh.py:12,126 imports; the wheel
+    is not vendored), restated from its published source: L = the UNIFORM combinatorial Laplacian of the unique edge set (laplacian_uniform:
+    L_ii = number of distinct neighbours, L_ij = -1 for every edge), loss = mean over vertices of || (L v)_i ||_2 -- neither squared nor divided by the
+    degree.  Here without the sparse matrix: (L v)_i = deg_i v_i - sum over distinct neighbours."""
+    V = v.shape[0]
+    i, j = _unique_directed_edges(f, V)
+    deg = torch.zeros(V, device=v.device, dtype=v.dtype).index_add_(0, i, torch.ones(i.shape[0], device=v.device, dtype=v.dtype))
+    lv = deg[:, None] * v - torch.zeros_like(v).index_add_(0, i, v[j])
+    return lv.norm(dim=1).mean()
+
+
+def _unique_directed_edges(f, V):
+    """every ordered vertex pair (i, j) joined by a triangle edge, once -- the index set of kiui.mesh_utils.laplacian_uniform's adjacency
+    (built there as cat(ii, jj) / cat(jj, ii) followed by .unique(dim=1))"""
     fl = f.long()
-    e = torch.cat([fl[:, [0, 1]], fl[:, [1, 2]], fl[:, [2, 0]]], 0)
-    e = torch.cat([e, e.flip(1)], 0)
-    nbr_sum = torch.zeros_like(v).index_add_(0, e[:, 0], v[e[:, 1]])
-    deg = torch.zeros(v.shape[0], device=v.device).index_add_(0, e[:, 0], torch.ones(e.shape[0], device=v.device)).clamp_min(1)
-    lap = nbr_sum / deg[:, None] - v
-    return (lap ** 2).sum(-1).mean()
+    ii, jj = fl[:, [1, 2, 0]].flatten(), fl[:, [2, 0, 1]].flatten()
+    key = torch.unique(torch.cat([ii * V + jj, jj * V + ii]))
+    return key // V, key % V
+
+
+def edge_to_face_mapping(f):
+    """kiui.mesh_utils.compute_edge_to_face_mapping (from nvdiffrec's regularizer): [E, 2] face ids per unique undirected edge -- column 0 the face that
+    walks the edge from its smaller to its larger vertex index, column 1 the face that walks it the other way.  The table starts as zeros, so the
+    missing side of a BOUNDARY edge (and both sides' collisions on non-manifold edges: last writer wins) reads face 0, exactly as published."""
+    fl = f.long()
+    T = fl.shape[0]
+    e = torch.stack([fl[:, [0, 1]], fl[:, [1, 2]], fl[:, [2, 0]]], dim=1).reshape(-1, 2)       # packed by triangle: (t, 0), (t, 1), (t, 2)
+    swapped = e[:, 0] > e[:, 1]
+    lo, hi = torch.minimum(e[:, 0], e[:, 1]), torch.maximum(e[:, 0], e[:, 1])
+    uniq, inv = torch.unique(torch.stack([lo, hi], dim=1), dim=0, return_inverse=True)
+    tris = torch.arange(T, device=f.device).repeat_interleave(3)
+    tpe = torch.zeros((uniq.shape[0], 2), dtype=torch.long, device=f.device)
+    tpe[inv[~swapped], 0] = tris[~swapped]
+    tpe[inv[swapped], 1] = tris[swapped]
+    return tpe
 
 
 def normal_consistency(v, f):
-    """1 - cos of the dihedral normals over shared edges -- stands in for kiui.mesh_utils.normal_consistency"""
+    """kiui.mesh_utils.normal_consistency(verts, faces) as the reference calls it (diff_mesh.py:127), restated from the published source: unit face
+    normals (safe_normalize: x / sqrt(max(x.x, 1e-20))), mean over the unique edges of |1 - clamp(n0 . n1, -1, 1)| with (n0, n1) the two faces of
+    edge_to_face_mapping -- boundary edges included, paired with face 0 as published."""
     fl = f.long()
-    n = F.normalize(torch.cross(v[fl[:, 1]] - v[fl[:, 0]], v[fl[:, 2]] - v[fl[:, 0]], dim=-1), dim=-1)
-    T = fl.shape[0]
-    e = torch.cat([fl[:, [0, 1]], fl[:, [1, 2]], fl[:, [2, 0]]], 0)
-    key = torch.minimum(e[:, 0], e[:, 1]) * v.shape[0] + torch.maximum(e[:, 0], e[:, 1])
-    tri = torch.arange(T, device=v.device).repeat(3)
-    order = torch.argsort(key)
-    key, tri = key[order], tri[order]
-    same = key[1:] == key[:-1]
-    return (1 - (n[tri[:-1][same]] * n[tri[1:][same]]).sum(-1)).mean() if same.any() else v.sum() * 0
+    n = torch.cross(v[fl[:, 1]] - v[fl[:, 0]], v[fl[:, 2]] - v[fl[:, 0]], dim=-1)
+    n = n / torch.sqrt(torch.clamp((n * n).sum(-1, keepdim=True), min=1e-20))
+    tpe = edge_to_face_mapping(f)
+    term = torch.clamp((n[tpe[:, 0]] * n[tpe[:, 1]]).sum(-1, keepdim=True), min=-1.0, max=1.0)
+    return torch.mean(torch.abs(1.0 - term))
 
 
 class DiffMesh:

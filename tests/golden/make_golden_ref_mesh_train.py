@@ -6,9 +6,9 @@ after every step.  Geometry trains (train_mesh_geometry=True), so gradients flow
 Replaced, because they are third-party packages this image lacks:
   * nvdiffrast.torch             -> tests/fake_dr.py: the CPU mesh oracle's forward and backward per op as autograd functions;
   * pytorch_msssim.MS_SSIM       -> a constant 0; the run uses ms_ssim_loss_weight = 0 (loss = MSE + regularisers);
-  * kiui.mesh_utils.laplacian_smooth_loss / normal_consistency -> this repo's stand-ins for them (the same functions the mirror's trainer
-    calls: they are identical on both sides and therefore not pinned by this fixture -- the weights 0.01 / 0.001 / 0.1 and what they are
-    applied to are);
+  * kiui.mesh_utils.laplacian_smooth_loss / normal_consistency -> this repo's restatements of the published kiui source (the same functions the
+    mirror's trainer calls: they are identical on both sides and therefore not pinned by this fixture -- the weights 0.01 / 0.001 / 0.1 and what
+    they are applied to are; tests/test_host_logic.py holds the restatements to a literal sparse-matrix / edge-table form in float64);
   * kiui.cam.orbit_camera, kiui.op.inverse_sigmoid / safe_normalize -> restated as in make_golden_ref_gs_train.py / _render.py;
   * comfy.utils.ProgressBar      -> the per-step recorder.
 DiffMesh.__init__ (:26-56) is reproduced line by line with the device set to the CPU; remeshing (pymeshlab) is kept out of reach with
@@ -39,7 +39,7 @@ H, W, FOVY = 40, 48, 49.1
 
 
 def regularisers():
-    """the mirror's stand-ins for the two kiui.mesh_utils losses, loaded from the file alone (no package import)"""
+    """the mirror's restatements of the two kiui.mesh_utils losses (from the published kiui source; the wheel is absent), loaded from the file alone (no package import)"""
     src = open(os.path.join(ROOT, "comfyui-3d-pack_amd", "MVs_Algorithms", "DiffRastMesh", "diff_mesh.py")).read()
     ns = {"torch": torch, "F": torch.nn.functional}
     start = src.index("def laplacian_smooth_loss"); end = src.index("class DiffMesh:")

@@ -516,3 +516,49 @@ def test_exchange_world8_gloo_including_ranks_without_views():
         for v_, t in zip(ref.views, tot):
             v_.copy_(t)
         assert torch.equal(out[0][n_views][0], ref.flat)
+
+
+def test_kiui_mesh_regularisers_against_literal_restatements():
+    """laplacian_smooth_loss / normal_consistency (MVs_Algorithms/DiffRastMesh/diff_mesh.py; reference call site diff_mesh.py:126-127) against the literal
+    form of the published kiui.mesh_utils source in float64 -- the dense uniform Laplacian matrix, the edge-to-face table filled edge by edge with its
+    zero-initialised missing sides -- on an OPEN mesh (a grid patch: boundary edges, valences 2..6) and a closed one; values and gradients."""
+    from MVs_Algorithms.DiffRastMesh.diff_mesh import edge_to_face_mapping, laplacian_smooth_loss, normal_consistency
+    from c3d_hip import synthetic as S
+    g = torch.Generator().manual_seed(3)
+    n = 7
+    yy, xx = torch.meshgrid(torch.arange(n), torch.arange(n), indexing="ij")
+    v_open = torch.stack([xx.flatten().double(), yy.flatten().double(), 0.3 * torch.randn(n * n, generator=g).double()], 1)
+    idx = lambda r, c: r * n + c
+    f_open = torch.tensor([t for r in range(n - 1) for c in range(n - 1) for t in ([idx(r, c), idx(r + 1, c), idx(r, c + 1)], [idx(r, c + 1), idx(r + 1, c), idx(r + 1, c + 1)])], dtype=torch.int32)
+    vs, fs, _, _ = S.make_uv_sphere(6, 9)
+    for v0, f in ((v_open, f_open), (torch.tensor(vs).double() + 0.02 * torch.randn(vs.shape, generator=g).double(), torch.tensor(fs))):
+        V, fl = v0.shape[0], f.long()
+        # literal laplacian_uniform: L = D - A over the unique edge set
+        A = torch.zeros((V, V), dtype=torch.float64)
+        for t in fl.tolist():
+            for a, b in ((t[0], t[1]), (t[1], t[2]), (t[2], t[0])):
+                A[a, b] = A[b, a] = 1.0
+        L = torch.diag(A.sum(1)) - A
+        # literal compute_edge_to_face_mapping: zeros, column by walking direction
+        edges = {}
+        for ti, t in enumerate(fl.tolist()):
+            for a, b in ((t[0], t[1]), (t[1], t[2]), (t[2], t[0])):
+                edges.setdefault((min(a, b), max(a, b)), [0, 0])[1 if a > b else 0] = ti
+        keys = sorted(edges)
+        tpe_ref = torch.tensor([edges[k] for k in keys])
+        assert torch.equal(edge_to_face_mapping(f), tpe_ref)
+        has_boundary = any(sum(1 for t in fl.tolist() if (k[0] in t and k[1] in t)) == 1 for k in keys)
+        v = v0.clone().requires_grad_(True)
+        w = v0.clone().requires_grad_(True)
+        l1 = laplacian_smooth_loss(v, f)
+        l1_ref = (L @ w).norm(dim=1).mean()
+        fn = torch.cross(w[fl[:, 1]] - w[fl[:, 0]], w[fl[:, 2]] - w[fl[:, 0]], dim=-1)
+        fn = fn / torch.sqrt(torch.clamp((fn * fn).sum(-1, keepdim=True), min=1e-20))
+        l2 = normal_consistency(v, f)
+        l2_ref = (1.0 - torch.clamp((fn[tpe_ref[:, 0]] * fn[tpe_ref[:, 1]]).sum(-1), -1.0, 1.0)).abs().mean()
+        assert abs(float(l1) - float(l1_ref)) <= 1e-12 * max(1.0, abs(float(l1_ref))) and abs(float(l2) - float(l2_ref)) <= 1e-12
+        (l1 + l2).backward(); (l1_ref + l2_ref).backward()
+        assert torch.allclose(v.grad, w.grad, rtol=1e-10, atol=1e-12)
+        assert float(l1) > 0 and float(l2) > 0
+        if f is f_open:
+            assert has_boundary
