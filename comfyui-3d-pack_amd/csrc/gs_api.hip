@@ -115,10 +115,9 @@ size_t c3d_gs_binning_bytes(int64_t D, int32_t H, int32_t W) {
     return b.bytes;
 }
 size_t c3d_gs_image_bytes(int32_t H, int32_t W) { GsImage im; gs_carve_image(nullptr, W, H, im); return im.bytes; }
-// backward scratch = per (tile, splat) pair a group of FOUR 48-byte gradient records, one per 8x8 quadrant of the tile (the quadrant's wave writes its
-// own slot, the per-Gaussian pass adds them), then four "slot written" bytes per pair
-static size_t pairgrad_bytes(long long D) { return c3d_align(4 * sizeof(float) * GS_PAIR_FLOATS * (size_t)(D > 0 ? D : 1)); }
-size_t c3d_gs_backward_scratch_bytes(int32_t N, int64_t D) { (void)N; return pairgrad_bytes(D) + c3d_align(4 * (size_t)(D > 0 ? D : 1)); }
+static size_t pairgrad_bytes(long long D) { return c3d_align(sizeof(float) * GS_PAIR_FLOATS * (size_t)(D > 0 ? D : 1)); }
+// backward scratch = one 48-byte gradient record per (tile, splat) pair, then one "record written" byte per pair
+size_t c3d_gs_backward_scratch_bytes(int32_t N, int64_t D) { (void)N; return pairgrad_bytes(D) + c3d_align((size_t)(D > 0 ? D : 1)); }
 
 int c3d_gs_forward_project(const c3d_gs_settings* st, int32_t N, int32_t M, const float* means3D, const float* shs,
                            const float* colors_precomp, const float* opacities, const float* scales,
@@ -270,12 +269,12 @@ static void carve_step(char* base, int N, int H, int W, long long cap, StepWs& w
     w.radii = (int*)take(4 * n);
     w.color = (float*)take(12 * P); w.depth = (float*)take(4 * P); w.alpha = (float*)take(4 * P);
     w.dcolor = (float*)take(12 * P); w.dalpha = (float*)take(4 * P);
-    w.pairgrad = (float*)take(4 * sizeof(float) * GS_PAIR_FLOATS * (size_t)(cap > 0 ? cap : 1));     // four quadrant slots per pair (c3d_gs_backward_scratch_bytes)
-    w.pvalid = (uint8_t*)take(4 * (size_t)(cap > 0 ? cap : 1));
+    w.pairgrad = (float*)take(sizeof(float) * GS_PAIR_FLOATS * (size_t)(cap > 0 ? cap : 1));
+    w.pvalid = (uint8_t*)take((size_t)(cap > 0 ? cap : 1));
     w.dmeans2D = (float*)take(12 * n);
     w.gcol = (float*)take(12 * n);
     w.ms_ws = take(c3d_msssim_workspace_bytes(1, 3, H, W));       // MS-SSIM term of the pixel loss (w_ssim != 0)
-    w.tile_loss = (float*)take(16 * (size_t)(((W + C3D_TILE_X - 1) / C3D_TILE_X) * ((H + C3D_TILE_Y - 1) / C3D_TILE_Y)));   // per-(tile, quadrant) partial sums of the pixel loss
+    w.tile_loss = (float*)take(4 * (size_t)(((W + C3D_TILE_X - 1) / C3D_TILE_X) * ((H + C3D_TILE_Y - 1) / C3D_TILE_Y)));   // per-tile partial sums of the pixel loss
     w.bytes = off;
 }
 
@@ -513,7 +512,7 @@ int c3d_gs_train_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, c
     if (fuse_loss && loss_out) {   // the views' per-tile partial sums of the pixel loss -> loss_out, in a fixed order
         StepWs wf; carve_step((char*)workspace, N, views[0].image_height, views[0].image_width, pair_capacity, wf);
         const int tiles = ((views[0].image_width + C3D_TILE_X - 1) / C3D_TILE_X) * ((views[0].image_height + C3D_TILE_Y - 1) / C3D_TILE_Y);
-        if (gs_launch_sum_tile_loss(wf.tile_loss, w0.bytes, V, 4 * tiles, loss_out, s0)) return -1;
+        if (gs_launch_sum_tile_loss(wf.tile_loss, w0.bytes, V, tiles, loss_out, s0)) return -1;
     }
     if (accumulate & 2) return 0;   // the caller runs the per-Gaussian pass itself, range by range (c3d_gs_step_param_backward_range)
     return step_a8_all_views(views, V, N, w0.bytes, workspace, pair_capacity, means3D, f_dc, f_rest, scaling_raw, rotation_raw, dL_dmeans3D, dL_df_dc, dL_df_rest,

@@ -91,6 +91,13 @@ __device__ __forceinline__ void wave_reduce10(float v0, float v1, float v2, floa
 // kernels of the other view lanes (radix scatter 38 KB, preprocess 50 KB) cannot co-reside with the compositing: 2100 -> 2170 Mpixels/s; 32 is slower again.
 #define BWD_ROUND 64
 
+// Round 3, measured and dropped (commit a5d0b08, profiles/r03/r03b_*): this kernel as ONE WAVE PER QUADRANT (64-lane workgroups, no barriers, a wave-private
+// compacted list as in k_composite_fwd_w, one record per (quadrant, pair) in a four-slot record group that A8 adds up).  k_composite_bwd_w<true,false> 0.371 ms
+// against 0.393 ms for this kernel on the same box (-5.5 %): the 25 % of wave-round slots that wait at this kernel's barriers are not lost time -- eight
+// waves per SIMD from several workgroups keep the VALU pipe 92 % busy either way -- while A8 went 0.58 -> 0.99 ms per 8-view step over the 2.2 x as many
+// records and their four valid bytes per pair.  Net -4 % on the step: reverted.  What bounds this kernel is the VALU cost of a walked pair on gfx950
+// (profiles/r01f_valu_rate_microbench.txt): ~127 cycles of per-pixel arithmetic + ~144 of the ten-value wave reduction (8 v_permlane swaps at 8.3,
+// 12 DPP adds at 4.1, 9 adds at 2.9) = the 271 the SQ counters show.
 // DEPTH: some caller-supplied dL/ddepth exists.  The fused training step has none (the reference's loss reads image and alpha only, main_3DGS.py:184-192):
 // its instance drops the depth channel from the per-splat dot product, from the products and from the ten-value reduction (nine values).
 template <bool LOSS, bool DEPTH>
@@ -152,7 +159,7 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
         l = c3d_wave_sum(l * pl.scale);
         if (lane == 0) s_loss[wave] = l;
         __syncthreads();
-        if (threadIdx.x < 4 && pl.tile_loss) pl.tile_loss[4 * tile + threadIdx.x] = s_loss[threadIdx.x];   // one partial per (tile, quadrant), as k_composite_bwd_w writes them
+        if (threadIdx.x == 0 && pl.tile_loss) pl.tile_loss[tile] = s_loss[0] + s_loss[1] + s_loss[2] + s_loss[3];
     }
     const float bg_dot = p.bg[0] * dLp0 + p.bg[1] * dLp1 + p.bg[2] * dLp2;
     float Rdot = T_final * bg_dot;
@@ -254,180 +261,14 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
 #pragma unroll
                         for (int q = 0; q < GS_PAIR_FLOATS; q++) r[q] += acc[w][q][j];
                     }
-                float4* out = pairgrad + (size_t)se[j] * 4 * 3;      // the pair's four quadrant slots: this kernel sums the quadrants itself and uses slot 0
+                float4* out = pairgrad + (size_t)se[j] * 3;
                 out[0] = make_float4(r[0], r[1], r[2], r[3]);
                 out[1] = make_float4(r[4], r[5], r[6], r[7]);
                 out[2] = make_float4(r[8], r[9], r[10], r[11]);
-                pvalid[4 * (size_t)se[j]] = 1;
+                pvalid[se[j]] = 1;
             }
         }
     }
-}
-
-// ------------------------------------------------------------------------------------------
-// A7, wave-autonomous form (round 3, the default): ONE WAVE per 8x8 quadrant, like k_composite_fwd_w -- a 64-lane workgroup that shares nothing
-// with the other three quadrants of its tile.  What the 256-lane kernel above pays for its tile-wide rounds: three workgroup barriers per 64
-// list positions, and every round lasts as long as the busiest of the four quadrants (profiles/r03 analysis of the BASELINE view: 414 k
-// wave-round-slots for 332 k walked (quadrant, splat) pairs, 25 % of the kernel spent waiting at barriers).  Here a wave
-//   * walks ITS quadrant's blended pairs only: 64 list positions at a time, back to front, it reads its byte plane of the forward pass's
-//     activity record, gathers id / record / emit index for the active positions (two-deep software pipeline: the next chunk's gathers are in
-//     flight while this one is walked) and compacts them into a wave-private LDS list,
-//   * runs the same per-pair arithmetic as above (one spelling: gs_bwd_pair) with LDS broadcast reads in a counted loop,
-//   * and writes ONE 48-byte record per (quadrant, pair) into the quadrant's slot of the pair's record group [pair][quadrant]; the per-Gaussian
-//     pass (A8) adds the up-to-four slots of a pair in quadrant order -- still no atomics, still bit-reproducible.
-// The price: A8 reads 2.2 records per blended pair instead of one (+69 MB per BASELINE view).
-// ------------------------------------------------------------------------------------------
-template <bool LOSS, bool DEPTH>
-__global__ void __launch_bounds__(64) k_composite_bwd_w(GsParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-                                                         const uint4* __restrict__ einfo, const float4* __restrict__ rec, const float* __restrict__ final_T,
-                                                         const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor,
-                                                         const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha_px,
-                                                         const uint8_t* __restrict__ pact, size_t pstride, float4* __restrict__ pairgrad, uint8_t* __restrict__ pvalid,
-                                                         uint32_t cap, int sh, GsPixelLoss pl) {
-    __shared__ float4 c0[64];      // (px, py, -log2e/2 A, -log2e B)
-    __shared__ float4 c1[64];      // (-log2e/2 C, opacity, r, g)
-    __shared__ float4 c2[64];      // (b, view depth, list position k as int bits, emit index as uint bits)
-    __shared__ float acc[GS_PAIR_FLOATS][64 + 1];
-    const int b = blockIdx.x, q = (b >> 3) & 3;
-    int tx, ty;
-    if (!gs_block_tile((b & 7) | ((b >> 5) << 3), p.gx, p.gy, tx, ty, sh)) return;
-    const int tile = ty * p.gx + tx, lane = (int)threadIdx.x;
-    const int pxi = tx * C3D_TILE_X + ((q & 1) << 3) + (lane & 7), pyi = ty * C3D_TILE_Y + ((q >> 1) << 3) + (lane >> 3);
-    const bool inside = pxi < p.W && pyi < p.H;
-    const float pxf = (float)pxi, pyf = (float)pyi;
-    const uint2 rg = ranges[tile];
-    const size_t P = (size_t)p.W * p.H, pid = (size_t)pyi * p.W + pxi;
-
-    const float T_final = inside ? final_T[pid] : 0.f;
-    float T = T_final;
-    const int last = inside ? (int)n_contrib[pid] : 0;
-    float dLp0 = 0.f, dLp1 = 0.f, dLp2 = 0.f, dLd = 0.f, dLa = 0.f;
-    if (inside) {
-        if (dL_dcolor) { dLp0 = dL_dcolor[pid]; dLp1 = dL_dcolor[P + pid]; dLp2 = dL_dcolor[2 * P + pid]; }
-        dLd = (DEPTH && dL_ddepth) ? dL_ddepth[pid] : 0.f;
-        dLa = dL_dalpha_px ? dL_dalpha_px[pid] : 0.f;
-    }
-    if (LOSS) {   // the step's pixel loss, term by term as k_loss_grad; one partial sum per (tile, quadrant)
-        float l = 0.f;
-        if (inside) {
-            const float inv3p = 1.f / (3.f * (float)P), invp = 1.f / (float)P;
-            const float mk = pl.cmask ? pl.cmask[pid] : 1.f;
-            float gch[3];
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++) {
-                const float c = pl.color[ch * P + pid];
-                const float cc = fminf(fmaxf(c, 0.f), 1.f);
-                const float d = (cc - pl.tcolor[ch * P + pid]) * mk;
-                l += (pl.w_l1 * fabsf(d) + pl.w_l2 * d * d) * inv3p;
-                const float pass = (c >= 0.f && c <= 1.f) ? 1.f : 0.f;
-                const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-                gch[ch] = pl.scale * pass * mk * (pl.w_l1 * sg + 2.f * pl.w_l2 * d) * inv3p;
-            }
-            dLp0 += gch[0]; dLp1 += gch[1]; dLp2 += gch[2];
-            if (pl.talpha) { const float d = pl.alpha[pid] - pl.talpha[pid]; l += pl.w_a * d * d * invp; dLa += pl.scale * 2.f * pl.w_a * d * invp; }
-        }
-        l = c3d_wave_sum(l * pl.scale);
-        if (lane == 0 && pl.tile_loss) pl.tile_loss[4 * tile + q] = l;
-    }
-    const float bg_dot = p.bg[0] * dLp0 + p.bg[1] * dLp1 + p.bg[2] * dLp2;
-    float Rdot = T_final * bg_dot;
-
-    int upto = last;                                   // deepest list position (+1) a pixel of this quadrant blended: its forward wave walked every position below
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) upto = max(upto, __shfl_xor(upto, d, 64));
-    if (upto == 0) return;
-    const uint8_t* plane = pact + (size_t)q * pstride + rg.x;
-    const uint32_t* list = point_list + rg.x;
-
-    // two-deep gather pipeline over the chunks: stage 1 = (activity byte, Gaussian id) of a list position, stage 2 = (record, emit index) of an active one
-    bool a1_act = false; uint32_t a1_id = 0;            // stage 1 of the chunk after next
-    bool a2_act = false; float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0; uint32_t e2 = 0;   // stage 2 of the next chunk
-    auto stage1 = [&](int base) {
-        const int kk = upto - 1 - base - lane;
-        a1_act = false;
-        if (kk >= 0 && base < upto) { a1_act = (plane[kk] & 1u) != 0; a1_id = list[kk]; }
-    };
-    auto stage2 = [&]() {
-        a2_act = a1_act;
-        if (a1_act) {
-            const size_t id = a1_id;
-            r0 = rec[4 * id]; r1 = rec[4 * id + 1]; r2 = rec[4 * id + 2];
-            const uint4 ei = einfo[id];
-            const int ex0 = (int)(ei.y & 0xFFFFu), ey0 = (int)(ei.y >> 16), ex1 = (int)(ei.z & 0xFFFFu);
-            e2 = ei.w + (uint32_t)((ty - ey0) * (ex1 - ex0) + (tx - ex0));      // the Gaussian's record base + row-major position of this tile inside its rect
-        }
-    };
-    stage1(0);
-    stage2();
-    stage1(64);
-    for (int base = 0; base < upto; base += 64) {
-        const bool act = a2_act;
-        const float4 b0 = r0, b1 = r1, b2 = r2;
-        const uint32_t se = e2;
-        stage2();                                       // chunk base + 64: records and emit indices start to arrive while this chunk is walked
-        stage1(base + 128);
-        const uint64_t m = __ballot(act);
-        const int n = __popcll(m);
-        if (n == 0) continue;
-        const int pos = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        __syncthreads();                                // one wave: orders these LDS writes behind the previous chunk's reads
-        if (act) {
-            c0[pos] = make_float4(b0.x, b0.y, GS_CONIC_HALF * b0.z, GS_CONIC_FULL * b0.w);
-            c1[pos] = make_float4(GS_CONIC_HALF * b1.x, b1.y, b1.z, b1.w);
-            c2[pos] = make_float4(b2.x, b2.y, __int_as_float(upto - 1 - base - lane), __uint_as_float(se));
-        }
-        __syncthreads();
-        for (int i = 0; i < n; i++) {
-            const float4 a0 = c0[i], a1 = c1[i], a2 = c2[i];
-            const int k = __builtin_amdgcn_readfirstlane(__float_as_int(a2.z));      // list position of this splat (wave-uniform)
-            const float dx = a0.x - pxf, dy = a0.y - pyf;
-            const float power = gs_power(a0, a1.x, dx, dy);      // log2(e) * (-q/2)
-            const float G = __builtin_amdgcn_exp2f(power);
-            const float alpha = fminf(0.99f, a1.y * G);
-            uint64_t am;
-            {
-                uint64_t k0, k1, k2;
-                asm("v_cmp_lt_i32_e64 %0, %1, %2" : "=s"(k0) : "s"(k), "v"(last));
-                asm("v_cmp_ge_f32_e64 %0, 0, %1" : "=s"(k1) : "v"(power));
-                asm("v_cmp_le_f32_e64 %0, %1, %2" : "=s"(k2) : "v"(1.f / 255.f), "v"(alpha));
-                am = k0 & k1 & k2;
-            }
-            float t0, t1, t2;
-            const float inv = __builtin_amdgcn_rcpf(1.f - alpha);
-            const float Tn = T * inv;
-            T = sel64(am, Tn, T);
-            const float w = sel64z(am, alpha * Tn);
-            const float sdot = DEPTH ? a1.z * dLp0 + a1.w * dLp1 + a2.x * dLp2 + a2.y * dLd + dLa : a1.z * dLp0 + a1.w * dLp1 + a2.x * dLp2 + dLa;
-            const float dL_dalpha = Tn * sdot - Rdot * inv;
-            Rdot += w * sdot;
-            const float m0 = sel64z(am, a1.y * G * dL_dalpha);
-            const float m1x = m0 * dx, m1y = m0 * dy;
-            wave_reduce10(w * dLp0, w * dLp1, w * dLp2, DEPTH ? w * dLd : 0.f, m0, m1x, m1y, m1x * dx, m1x * dy, m1y * dy, t0, t1, t2);
-            // t0 rows: c0, c2, c1, depth   t1 rows: m0, m1y, m1x, m2xx   t2 rows: m2xy, 0, m2yy, 0
-            if ((lane & 15) == 0) {
-                const int row = lane >> 4;
-                acc[row][i] = t0; acc[4 + row][i] = t1; acc[8 + row][i] = t2;
-            }
-        }
-        __syncthreads();
-        if (lane < n) {                                 // lane c: the record of compact entry c, three 16-byte stores into this quadrant's slot of the pair
-            const uint32_t e = __float_as_uint(c2[lane].w);
-            if (e < cap) {
-                float4* out = pairgrad + ((size_t)e * 4 + q) * 3;
-                out[0] = make_float4(acc[0][lane], acc[1][lane], acc[2][lane], acc[3][lane]);
-                out[1] = make_float4(acc[4][lane], acc[5][lane], acc[6][lane], acc[7][lane]);
-                out[2] = make_float4(acc[8][lane], acc[9][lane], acc[10][lane], acc[11][lane]);
-                pvalid[4 * (size_t)e + q] = 1;
-            }
-        }
-    }
-}
-
-// which backward compositing kernel: C3D_BWD_KERNEL = 1 (default) wave per quadrant (k_composite_bwd_w) | 0 workgroup per tile (k_composite_bwd)
-static int gs_bwd_kernel() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("C3D_BWD_KERNEL"); v = e ? atoi(e) : 1; if (v != 0 && v != 1) v = 1; }
-    return v;
 }
 
 __global__ void __launch_bounds__(1024) k_sum_tile_loss(const float* __restrict__ first_view, size_t stride, int V, int tiles, float* __restrict__ loss_out) {
@@ -457,18 +298,7 @@ int gs_launch_composite_bwd(const GsParams& p, const GsGeom& g, const GsBinning&
                             float* pairgrad, uint8_t* pvalid, long long pairs, hipStream_t s, uint32_t cap, const GsPixelLoss* pixel_loss) {
     const int tiles = p.gx * p.gy;
     if (tiles == 0) return 0;
-    C3D_CHECK(hipMemsetAsync(pvalid, 0, 4 * (size_t)(pairs > 0 ? pairs : 1), s));      // one valid byte per (pair, quadrant)
-    if (gs_bwd_kernel() == 1) {
-        const dim3 grid(4 * gs_block_count(p.gx, p.gy, gs_supertile_shift()));
-#define GS_BWD_LAUNCH_W(LOSS_, DEPTH_, PL_)                                                                                                                       \
-    hipLaunchKernelGGL((k_composite_bwd_w<LOSS_, DEPTH_>), grid, dim3(64), 0, s, p, b.ranges, b.tval[res], g.einfo, g.rec0, im.final_T, im.n_contrib, dL_dcolor,   \
-                       dL_ddepth, dL_dalpha, gs_pair_activity(b, res), b.pair_stride, (float4*)pairgrad, pvalid, cap, gs_supertile_shift(), PL_)
-        if (pixel_loss) { if (dL_ddepth) GS_BWD_LAUNCH_W(true, true, *pixel_loss); else GS_BWD_LAUNCH_W(true, false, *pixel_loss); }
-        else            { if (dL_ddepth) GS_BWD_LAUNCH_W(false, true, GsPixelLoss{}); else GS_BWD_LAUNCH_W(false, false, GsPixelLoss{}); }
-#undef GS_BWD_LAUNCH_W
-        C3D_LAUNCH_CHECK();
-        return 0;
-    }
+    C3D_CHECK(hipMemsetAsync(pvalid, 0, (size_t)(pairs > 0 ? pairs : 1), s));
     const dim3 grid(gs_block_count(p.gx, p.gy, gs_supertile_shift()));
 #define GS_BWD_LAUNCH(LOSS_, DEPTH_, PL_)                                                                                                                        \
     hipLaunchKernelGGL((k_composite_bwd<LOSS_, DEPTH_>), grid, dim3(256), gs_lds_pad(true), s, p, b.ranges, b.tval[res], g.einfo, g.rec0, g.rec1, g.rec2, im.final_T, \
@@ -630,17 +460,11 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GsParams p, GsGeom g, co
         const uint32_t cnt = g.tiles[idx];
         const uint32_t e0 = g.rbase[idx], e1 = min(e0 + cnt, cap);   // cap: capacity of the pair buffers (overflow is reported, never read)
         for (uint32_t e = e0; e < e1; e++) {
-            const uint32_t pv = reinterpret_cast<const uint32_t*>(pvalid)[e];     // one valid byte per quadrant slot
-            if (!pv) continue;
-#pragma unroll
-            for (int qd = 0; qd < 4; qd++) {                                     // quadrant order: the same sum every run
-                if (!((pv >> (8 * qd)) & 1u)) continue;
-                const float4* rp = pairgrad + ((size_t)e * 4 + qd) * 3;
-                const float4 v0 = rp[0], v1 = rp[1], v2 = rp[2];
-                pr[0] += v0.x; pr[1] += v0.y; pr[2] += v0.z; pr[3] += v0.w;
-                pr[4] += v1.x; pr[5] += v1.y; pr[6] += v1.z; pr[7] += v1.w;
-                pr[8] += v2.x; pr[10] += v2.z;
-            }
+            if (!pvalid[e]) continue;
+            const float4 v0 = pairgrad[(size_t)e * 3], v1 = pairgrad[(size_t)e * 3 + 1], v2 = pairgrad[(size_t)e * 3 + 2];
+            pr[0] += v0.x; pr[1] += v0.y; pr[2] += v0.z; pr[3] += v0.w;
+            pr[4] += v1.x; pr[5] += v1.y; pr[6] += v1.z; pr[7] += v1.w;
+            pr[8] += v2.x; pr[10] += v2.z;
         }
     }
     const float gcol[3] = {pr[0], pr[2], pr[1]};          // record rows: c0, c2, c1
@@ -794,17 +618,11 @@ __global__ void __launch_bounds__(256, 2) k_preprocess_bwd_views(GsParams p, GsB
                 const uint32_t cnt = vw.tiles[idx];
                 const uint32_t e0 = vw.rbase[idx], e1 = min(e0 + cnt, cap);
                 for (uint32_t e = e0; e < e1; e++) {
-                    const uint32_t pv = reinterpret_cast<const uint32_t*>(vw.pvalid)[e];
-                    if (!pv) continue;
-#pragma unroll
-                    for (int qd = 0; qd < 4; qd++) {
-                        if (!((pv >> (8 * qd)) & 1u)) continue;
-                        const float4* rp = vw.pairgrad + ((size_t)e * 4 + qd) * 3;
-                        const float4 v0 = rp[0], v1 = rp[1], v2 = rp[2];
-                        pr[0] += v0.x; pr[1] += v0.y; pr[2] += v0.z; pr[3] += v0.w;
-                        pr[4] += v1.x; pr[5] += v1.y; pr[6] += v1.z; pr[7] += v1.w;
-                        pr[8] += v2.x; pr[10] += v2.z;
-                    }
+                    if (!vw.pvalid[e]) continue;
+                    const float4 v0 = vw.pairgrad[(size_t)e * 3], v1 = vw.pairgrad[(size_t)e * 3 + 1], v2 = vw.pairgrad[(size_t)e * 3 + 2];
+                    pr[0] += v0.x; pr[1] += v0.y; pr[2] += v0.z; pr[3] += v0.w;
+                    pr[4] += v1.x; pr[5] += v1.y; pr[6] += v1.z; pr[7] += v1.w;
+                    pr[8] += v2.x; pr[10] += v2.z;
                 }
             }
             const float gcol[3] = {pr[0], pr[2], pr[1]};          // record rows: c0, c2, c1
@@ -912,26 +730,21 @@ __global__ void __launch_bounds__(256, MINB) k_bwd_views_geom(GsParams p, GsBwdV
         if (rad > 0) {
             const uint32_t e1 = min(e0 + cnt, cap);
             for (uint32_t e = e0; e < e1; e += CHUNK) {
-                uint32_t pv[CHUNK];                                               // four valid bytes per pair: one per quadrant slot of its record group
+                uint8_t pv[CHUNK];
 #pragma unroll
-                for (int i = 0; i < CHUNK; i++) pv[i] = (e + i < e1) ? reinterpret_cast<const uint32_t*>(vw.pvalid)[e + i] : 0u;
+                for (int i = 0; i < CHUNK; i++) pv[i] = (e + i < e1) ? vw.pvalid[e + i] : (uint8_t)0;
+                float4 r0[CHUNK], r1[CHUNK], r2[CHUNK];
 #pragma unroll
                 for (int i = 0; i < CHUNK; i++) {
-                    if (!pv[i]) continue;
-                    any = true;
-                    const float4* rg4 = vw.pairgrad + (size_t)(e + i) * 4 * 3;
-                    float4 r0[4], r1[4], r2[4];
+                    r0[i] = r1[i] = r2[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (pv[i]) { const float4* rp = vw.pairgrad + (size_t)(e + i) * 3; r0[i] = rp[0]; r1[i] = rp[1]; r2[i] = rp[2]; }
+                }
 #pragma unroll
-                    for (int qd = 0; qd < 4; qd++) {                               // the valid slots' loads go out together ...
-                        r0[qd] = r1[qd] = r2[qd] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if ((pv[i] >> (8 * qd)) & 1u) { r0[qd] = rg4[3 * qd]; r1[qd] = rg4[3 * qd + 1]; r2[qd] = rg4[3 * qd + 2]; }
-                    }
-#pragma unroll
-                    for (int qd = 0; qd < 4; qd++) {                               // ... and are added in quadrant order (zeros of an empty slot change nothing)
-                        pr[0] += r0[qd].x; pr[1] += r0[qd].y; pr[2] += r0[qd].z; pr[3] += r0[qd].w;
-                        pr[4] += r1[qd].x; pr[5] += r1[qd].y; pr[6] += r1[qd].z; pr[7] += r1[qd].w;
-                        pr[8] += r2[qd].x; pr[10] += r2[qd].z;
-                    }
+                for (int i = 0; i < CHUNK; i++) {   // adding the zeros of an invalid slot changes nothing (x + 0 = x; the sums start at +0)
+                    any = any || pv[i];
+                    pr[0] += r0[i].x; pr[1] += r0[i].y; pr[2] += r0[i].z; pr[3] += r0[i].w;
+                    pr[4] += r1[i].x; pr[5] += r1[i].y; pr[6] += r1[i].z; pr[7] += r1[i].w;
+                    pr[8] += r2[i].x; pr[10] += r2[i].z;
                 }
             }
         }
