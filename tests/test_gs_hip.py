@@ -349,9 +349,9 @@ def test_baseline_size_1M_1080p_forward_backward_vs_float64_oracle():
     # kernel: the float32 build of the ORACLE against its float64 build shows max-norm 1.4e-3 / relative L2 1.6e-4 already at 100k Gaussians
     # (measured in the build container), the kernel 1.7e-4 / 3.5e-5 on the same scene (test_medium_cloud_fwd_bwd).
     for k in ("means3D", "opacities", "shs", "scales", "rotations"):
-        r = assert_grad_close(inp[k].grad.cpu().numpy(), og[k], "%s 1M/1080p" % k, max_frac=LARGE_FRAC, hard=1e9)
+        r = assert_grad_close(inp[k].grad.cpu().numpy(), og[k], "%s 1M/1080p" % k, max_frac=LARGE_FRAC, hard=2000.0)      # round 2: 1e9.  Worst measured 628 x; where the tail comes from: tests/test_zz_baseline_1m.py
         assert r["max_norm"] <= 1e-2, (k, r)
-    r = assert_grad_close(m2d.grad.cpu().numpy(), og["means2D"], "means2D 1M/1080p", max_frac=LARGE_FRAC, hard=1e9)
+    r = assert_grad_close(m2d.grad.cpu().numpy(), og["means2D"], "means2D 1M/1080p", max_frac=LARGE_FRAC, hard=2000.0)
     assert r["max_norm"] <= 1e-2, r
 
 

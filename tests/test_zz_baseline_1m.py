@@ -14,7 +14,8 @@ with the float64 build of oracle/gs_oracle.c:
   (d) the tail: a float32 rasterizer and a float64 one take a few discrete decisions differently -- per pixel and splat alpha >= 1/255 and T < 1e-4, per
       Gaussian ceil(3 sigma) and the colour clamp max(0, SH + 0.5).  The fragile set is found two ways: the ORACLE ITSELF run in float32 against its
       float64 build (pixels whose n_contrib differs, Gaussians whose radius or clamp pattern differs), and the kernel's images against the float64
-      ones (a flipped decision moves a pixel by far more than rounding noise).  Gaussians blended into a fragile pixel (oracle/gs_oracle.c:
+      ones (a flipped decision moves a pixel by far more than rounding noise); pixels within rounding of a kink of the loss (|clamp(C) - t| at C = t,
+      render()'s clamp at 0 and 1) join them.  Gaussians blended into a fragile pixel (oracle/gs_oracle.c:
       gs_oracle_taint) or fragile themselves are "tainted"; the test prints how the rows beyond TAIL x the element-wise tolerance split between tainted
       and untainted Gaussians, holds the untainted ones to a hard bound, and replaces the old `hard = 1e9` by numbers.
 
@@ -35,9 +36,10 @@ N, W, H = 1_000_000, 1920, 1080
 POSES = [(-30.0, 45.0), (-30.0, 202.5), (0.0, 0.0), (0.0, 157.5), (30.0, 22.5), (30.0, 270.0), (60.0, 90.0), (60.0, 315.0)]   # (elevation, azimuth) of the 64-camera orbit
 RAW_NAMES = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")
 ALPHA_FLIP, COLOR_FLIP = 1e-5, 3e-5          # a pixel whose alpha / colour is off by more than this took a different per-splat decision (rounding noise: ~1e-6)
+LOSS_KINK = 3e-6                             # |clamp(C) - target|, |C|, |C - 1| below this: float32 and float64 may sit on different sides of a kink of the loss
 TAIL = 30.0                                  # rows beyond TAIL x the element-wise tolerance are "the tail" the test attributes
 HARD = 2000.0                                # no entry at all may be off by more than this many tolerances (was 1e9 in round 2) ...
-UNTAINTED_HARD = 600.0                       # ... and none of a Gaussian no fragile pixel touches by more than this
+UNTAINTED_HARD = 60.0                        # ... and none of a Gaussian no fragile pixel touches by more than this (measured: <= 6)
 
 
 def _chain_to_raw(og, raw):
@@ -101,12 +103,16 @@ def full(oracle_built):
         frag_g = (orad32 != orad) | ((g32["rgb"] == 0) != (g64["rgb"] == 0)).any(1) | (g32["tiles_touched"] != g64["tiles_touched"])
         del ost32, g32, g64
         flags = (np.abs(alpha[v, 0] - oa[0]) > ALPHA_FLIP) | (np.abs(color[v] - oc).max(0) > COLOR_FLIP)
-        n_img, n_o32 = int(flags.sum()), int(flags32.sum())
-        flags |= flags32
+        # ... and the LOSS has kinks of its own: |clamp(C) - t| at C = t, and render()'s clamp at 0 and 1.  A pixel within rounding of one of them gets the
+        # other one-sided derivative in float32 (with random targets ~1e-6 of the pixel-channels: a hundred per 8 views)
+        tc64 = tcs[v].astype(np.float64)
+        kink = ((np.abs(np.clip(oc, 0.0, 1.0) - tc64) < LOSS_KINK) | (np.abs(oc) < LOSS_KINK) | (np.abs(oc - 1.0) < LOSS_KINK)).any(0) & (oa[0] > 0)
+        n_img, n_o32, n_kink = int(flags.sum()), int(flags32.sum()), int(kink.sum())
+        flags |= flags32 | kink
         tainted = O.taint(ost, flags, tainted)
         tainted |= (radii[v] != orad) | frag_g
         out["views"].append(dict(l1_color=float(np.abs(color[v] - oc).mean()), l1_alpha=float(np.abs(alpha[v] - oa).mean()), l1_depth=float(np.abs(depth[v] - od).mean()),
-                                 max_color=float(np.abs(color[v] - oc).max()), radii_diff=int((radii[v] != orad).sum()), flagged=n_img, flagged_o32=n_o32, frag_gauss=int(frag_g.sum()),
+                                 max_color=float(np.abs(color[v] - oc).max()), radii_diff=int((radii[v] != orad).sum()), flagged=n_img, flagged_o32=n_o32, flagged_kink=n_kink, frag_gauss=int(frag_g.sum()),
                                  n_vis=int((orad > 0).sum()), D=int(ost.num_rendered)))
         val, dC, dA = _pixel_loss(oc, oa[0], tcs[v].astype(np.float64), tas[v][0].astype(np.float64), 1.0 / V, 0.8, 3.0)
         loss_sum += val
@@ -144,8 +150,8 @@ def full(oracle_built):
 
 def test_render_views_raw_matches_oracle_on_eight_cameras(full):
     for (el, az), r in zip(POSES, full["views"]):
-        print("[1M view el %g az %g] L1 colour %.2e alpha %.2e depth %.2e, max colour %.2e, radii differ %d | fragile: %d pixels by image difference, %d by float32-vs-float64 oracle n_contrib, %d Gaussians (radius / clamp / tiles) | N_vis %d, D(oracle) %d"
-              % (el, az, r["l1_color"], r["l1_alpha"], r["l1_depth"], r["max_color"], r["radii_diff"], r["flagged"], r["flagged_o32"], r["frag_gauss"], r["n_vis"], r["D"]))
+        print("[1M view el %g az %g] L1 colour %.2e alpha %.2e depth %.2e, max colour %.2e, radii differ %d | fragile: %d pixels by image difference, %d by float32-vs-float64 oracle n_contrib, %d on a kink of the loss, %d Gaussians (radius / clamp / tiles) | N_vis %d, D(oracle) %d"
+              % (el, az, r["l1_color"], r["l1_alpha"], r["l1_depth"], r["max_color"], r["radii_diff"], r["flagged"], r["flagged_o32"], r["flagged_kink"], r["frag_gauss"], r["n_vis"], r["D"]))
     for r in full["views"]:
         assert r["l1_color"] <= 1e-4 and r["l1_alpha"] <= 1e-4 and r["l1_depth"] <= 1e-4, r
         assert r["radii_diff"] <= 20, r
@@ -173,9 +179,8 @@ def _check(name, loss, loss_ref, grads, ref, tainted):
         assert r["worst"] <= HARD, (k, r)
         assert r_un <= UNTAINTED_HARD, (k, r_un)
         assert int(bad_rows.sum()) <= 5e-4 * N, (k, int(bad_rows.sum()))
-        # the tail concentrates on the tainted Gaussians: their share among the tail rows is a multiple of their share of the cloud
-        if int(bad_rows.sum()) >= 20:
-            assert (bad_rows & tainted).sum() / bad_rows.sum() >= 2.0 * tainted.mean(), (k, int((bad_rows & tainted).sum()), int(bad_rows.sum()), float(tainted.mean()))
+        # the tail IS the tainted Gaussians (a few rows of slack for a decision class the fragile sets do not model)
+        assert int((bad_rows & ~tainted).sum()) <= max(3, int(0.03 * bad_rows.sum())), (k, int((bad_rows & tainted).sum()), int(bad_rows.sum()), float(tainted.mean()))
 
 
 @pytest.mark.parametrize("lanes", [4, 1])
