@@ -286,6 +286,7 @@ struct LanePool {
     bool init = false; hipStream_t st[C3D_MAX_LANES - 1]; hipEvent_t fork, join[C3D_MAX_LANES - 1];
     // forward-only rendering in groups of L views: a projection stream running two groups ahead of the lanes (render_views_grouped)
     hipStream_t pre; hipEvent_t pre_done[2], lane_done[2][C3D_MAX_LANES];
+    hipEvent_t bin_done[16];      // binning chains running ahead of the compositing lanes (train_views): view v -> bin_done[v % 16]
 };
 LanePool g_lanes[16];
 std::mutex g_lane_mu;
@@ -306,6 +307,7 @@ int lane_pool(LanePool** out) {
             C3D_CHECK(hipEventCreateWithFlags(&lp.pre_done[i], hipEventDisableTiming));
             for (int l = 0; l < C3D_MAX_LANES; l++) C3D_CHECK(hipEventCreateWithFlags(&lp.lane_done[i][l], hipEventDisableTiming));
         }
+        for (int i = 0; i < 16; i++) C3D_CHECK(hipEventCreateWithFlags(&lp.bin_done[i], hipEventDisableTiming));
         lp.init = true;
     }
     *out = &lp;
@@ -358,20 +360,33 @@ int c3d_lanes_join(hipStream_t caller, const hipStream_t* streams, int L, const 
 // forward of one view of the fused paths (A1-A6), everything on stream s, no host synchronisation: the pair count stays on the device
 // (g.meta[0]) and every launch that depends on it is sized for the pair capacity.
 // `projected`: A1 of this view has already run (step_preprocess_all)
+// A2-A5 of one view (the latency-bound part of its chain: scans, two radix sorts, emit, ranges), sync-free
+static int step_view_binning(const GsParams& p, GsGeom& g, GsBinning& b, int* radii, uint32_t cap, uint32_t* status, hipStream_t s, int* res_out) {
+    int rc;
+    if ((rc = binning_front(g, p.N, cap, status, s))) return rc;
+    return binning_back(p, g, b, radii, (long long)cap, cap, (const uint32_t*)g.meta, status, s, res_out);
+}
 static int step_view_forward(const GsParams& p, const float* means3D, const float* f_dc, const float* f_rest, const float* opacity_raw, const float* scaling_raw,
                              const float* rotation_raw, GsGeom& g, GsBinning& b, GsImage& im, int* radii, uint32_t cap, uint32_t* status, float* color, float* depth,
-                             float* alpha, bool record_activity, hipStream_t s, int* res_out, bool projected = false) {
-    int rc, res = 0;
+                             float* alpha, bool record_activity, hipStream_t s, int* res_out, bool projected = false, bool binned = false) {
+    int rc, res = binned ? *res_out : 0;
     if (!projected) {
         C3dProfScope ps(C3D_P_PREPROCESS, s);
         if ((rc = gs_launch_preprocess_raw(p, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, g, radii, s))) return rc;
     }
-    if ((rc = binning_front(g, p.N, cap, status, s))) return rc;
-    if ((rc = binning_back(p, g, b, radii, (long long)cap, cap, (const uint32_t*)g.meta, status, s, &res))) return rc;
+    if (!binned && (rc = step_view_binning(p, g, b, radii, cap, status, s, &res))) return rc;
     { C3dProfScope ps(C3D_P_COMPOSITE_FWD, s);
       if ((rc = gs_launch_composite_fwd(p, g, b, res, im, color, depth, alpha, record_activity, s))) return rc; }
     *res_out = res;
     return 0;
+}
+// Binning ahead (round 3): with all views projected up front, the views' binning chains -- 15 launches of 10-30 us each that cannot fill the machine -- run on
+// the pool's streams the compositing lanes do NOT use, every chain from the start of the step, instead of at the head of each view on its lane: under four
+// lanes in lockstep the chains of four views coincided and left the machine idle twice per 8-view step (2 x 0.33 ms of 6.1).  C3D_BIN_AHEAD=0 keeps the chain on the lane.
+static bool bin_ahead() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("C3D_BIN_AHEAD"); v = e ? atoi(e) != 0 : 1; }
+    return v != 0;
 }
 
 // A1 of every view of a step whose views keep their own workspace slice: the parameters are streamed once for up to GS_MAX_BWD_VIEWS views
@@ -466,6 +481,11 @@ int c3d_gs_train_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, c
     Lanes ln;
     if (ln.fork(s0, lanes, V)) return -1;
     int rc_all = 0;
+    const int n_bin = C3D_MAX_LANES - ln.L;                       // pool streams the lanes leave free
+    const bool ahead = projected && bin_ahead() && ln.L > 1 && n_bin > 0 && V > 1;
+    if (ahead)
+        for (int i = 0; i < n_bin && i < V; i++)
+            if (hipStreamWaitEvent(ln.lp->st[ln.L - 1 + i], ln.lp->fork, 0) != hipSuccess) { c3d_set_error("c3d_gs_train_views_raw: fork failed"); rc_all = -1; }
     for (int v = 0; v < V && !rc_all; v++) {
         hipStream_t s = ln.ls[v % ln.L];
         GsParams p;
@@ -478,7 +498,12 @@ int c3d_gs_train_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, c
         GsImage im; gs_carve_image(w.image, p.W, p.H, im);
         int rc = 0, res = 0;
         do {
-            if ((rc = step_view_forward(p, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, g, b, im, w.radii, cap, status, w.color, w.depth, w.alpha, true, s, &res, projected))) break;
+            if (ahead) {      // this view's binning chain on a free stream; its lane waits for it and goes straight to the compositing
+                hipStream_t sb = ln.lp->st[ln.L - 1 + (v % n_bin)];
+                if ((rc = step_view_binning(p, g, b, w.radii, cap, status, sb, &res))) break;
+                if (hipEventRecord(ln.lp->bin_done[v % 16], sb) != hipSuccess || hipStreamWaitEvent(s, ln.lp->bin_done[v % 16], 0) != hipSuccess) { c3d_set_error("c3d_gs_train_views_raw: event failed"); rc = -1; break; }
+            }
+            if ((rc = step_view_forward(p, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, g, b, im, w.radii, cap, status, w.color, w.depth, w.alpha, true, s, &res, projected, ahead))) break;
             // pixel loss and its gradient.  Default: inside the backward compositing kernel (GsPixelLoss); C3D_FUSE_LOSS=0 keeps the separate launch.
             const float* tal = target_alpha ? target_alpha[v] : nullptr;
             const float* cmk = color_mask ? color_mask[v] : nullptr;
@@ -507,6 +532,12 @@ int c3d_gs_train_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, c
         } while (0);
         rc_all = rc;
     }
+    if (ahead)      // the binning streams too end in the caller's stream (every chain already has a consumer on a lane; this keeps error paths ordered as well)
+        for (int i = 0; i < n_bin && i < V; i++)
+            if (hipEventRecord(ln.lp->join[ln.L - 1 + i], ln.lp->st[ln.L - 1 + i]) != hipSuccess || hipStreamWaitEvent(s0, ln.lp->join[ln.L - 1 + i], 0) != hipSuccess) {
+                (void)hipDeviceSynchronize();
+                if (!rc_all) { c3d_set_error("c3d_gs_train_views_raw: binning stream join failed"); rc_all = -1; }
+            }
     if (ln.join("c3d_gs_train_views_raw") && !rc_all) rc_all = -1;
     if (rc_all) return rc_all;
     if (fuse_loss && loss_out) {   // the views' per-tile partial sums of the pixel loss -> loss_out, in a fixed order
