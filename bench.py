@@ -67,7 +67,12 @@ def parse():
     ap.add_argument("--defer-status", choices=["on", "off"], default="on",
                     help="fused step: examine a step's overflow / fault words when the next step starts instead of waiting for them (what the trainer does; the last "
                          "step is examined before the timed region ends).  off: one host synchronisation per step")
-    ap.add_argument("--workload", choices=["gs", "mesh"], default="gs", help="gs = BASELINE configs 2-4 (the metric); mesh = config 5 (DiffRastMesh)")
+    ap.add_argument("--targets", choices=["on", "off"], default="on",
+                    help="N = 1, fwdbwd / train: after the timed region also run BASELINE config 2 (forward only, all 64 orbit cameras) and report the north star's forward-raster roofline figure in `targets`")
+    ap.add_argument("--workload", choices=["gs", "mesh", "ref-default"], default="gs",
+                    help="gs = BASELINE configs 2-4 (the metric); mesh = config 5 (DiffRastMesh); ref-default = the reference node's OWN default training run "
+                         "(/root/reference/nodes.py:1175-1198: 10,000 initial Gaussians, batch 1, every default of GSParams incl. densification from step 500), --ref-res square images: it/s")
+    ap.add_argument("--ref-res", type=int, default=512, help="--workload ref-default: reference image size (the node takes what it is given: 512 and 1024 are typical)")
     ap.add_argument("--loss", choices=["auto", "l1alpha", "full", "full-torch"], default="auto",
                     help="pixel loss of the step path: l1alpha = 0.8 L1 + 3 MSE(alpha) inside c3d_gs_train_views_raw; full = BASELINE config 3's loss, the reference's default "
                          "(main_3DGS.py:184-192): + 0.2 (1 - MS-SSIM), masked by the target alpha, through c3d_gs_forward_views_raw -> torch -> c3d_gs_backward_views_raw.  "
@@ -95,6 +100,33 @@ def code_digest():
     return c3d_hip.code_digest()
 
 
+def load_calibration():
+    """newest committed profiles/*_pmc_calibration.json (profiles/microbench/pmc_calib.hip under rocprofv3): counter bytes / known bytes per access pattern"""
+    try:
+        cand = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_calibration.json"))
+        return (json.load(open(os.path.join(ROOT, "profiles", cand[-1]))), cand[-1]) if cand else ({}, None)
+    except Exception:
+        return {}, None
+
+
+# which calibration pattern describes a kernel's reads / writes (profiles/microbench/pmc_calib.hip); None = the guide's x2 for reads, raw for writes
+PMC_PATTERN = {"k_composite_bwd": ("k_cal_gather64", "k_cal_record_write48"), "k_composite_fwd_w": ("k_cal_gather64", "k_cal_stream_write"),
+               "k_composite_fwd": ("k_cal_gather64", "k_cal_stream_write"), "k_preprocess_views": ("k_cal_stream_read", "k_cal_stream_write"),
+               "k_bwd_views_geom": ("k_cal_gather64", "k_cal_stream_write"), "k_bwd_views_sh": ("k_cal_stream_read", "k_cal_stream_write"),
+               "k_emit": ("k_cal_gather64", "k_cal_stream_write"), "k_adam": ("k_cal_stream_read", "k_cal_stream_write")}
+
+
+def calibrated_bytes(rec, kernel_name, cal):
+    """PMC record of one kernel (fetch_MB_raw, write_MB) -> (bytes, note): raw counters divided by the measured counter/known ratio of the kernel's access pattern"""
+    base = kernel_name.split("<")[0].strip()
+    pat = PMC_PATTERN.get(base)
+    fr, wr = rec["fetch_MB_raw"] * 1e6, rec["write_MB"] * 1e6
+    if cal and pat and cal.get(pat[0], {}).get("fetch_over_known") and cal.get(pat[1], {}).get("write_over_known"):
+        ff, wf = cal[pat[0]]["fetch_over_known"], cal[pat[1]]["write_over_known"]
+        return fr / ff + wr / wf, "FETCH_SIZE / %.3f (%s) + WRITE_SIZE / %.3f (%s)" % (ff, pat[0], wf, pat[1])
+    return 2.0 * fr + wr, "2 x FETCH_SIZE (MI355X_MICROARCH.md: wide streaming reads are tallied at half) + WRITE_SIZE raw; no calibration file for this pattern"
+
+
 def load_profile_json(suffix, exclude=None):
     """newest committed profiles/*<suffix> whose `_meta.code_digest` is the digest of the code that is running -> (dict, file name, stale digest | None).
     Traffic measured on other kernel code is refused (VERDICT r1, weak #8): the line then says traffic: null, stale: <digest>."""
@@ -109,6 +141,70 @@ def load_profile_json(suffix, exclude=None):
         return d, cand[-1], None
     except Exception:
         return {}, None, None
+
+
+def main_ref_default(a, world, rank, dev, dist):
+    """The reference's default 3DGS training workload: Gaussian_Splatting_3D with every node default -- 10,000 random-ball
+    Gaussians, SH degree 3, batch 1, loss 0.8 L1 + 3 MSE(alpha) + 0.2 (1 - MS-SSIM), white/black background per view, densify every 100 steps from step
+    500, opacity reset at 3000 -- through this repo's mirror of GaussianSplatting3D.training (the fused one-call step).  Targets: renders of a denser
+    synthetic cloud from 8 orbit poses.  A step is launch bound at this size (~150 launches, ~10-30 us kernels): the line reports it/s and what the host
+    needs to enqueue a step next to the GPU time of the step's kernels."""
+    import c3d_hip
+    from c3d_hip import synthetic as S
+    from c3d_hip.gs_step import FusedViewRender
+    import diff_gaussian_rasterization as dgr
+    from MVs_Algorithms.GaussianSplatting.main_3DGS import GaussianSplatting3D, GSParams
+    R = a.ref_res
+    t = lambda x: torch.as_tensor(np.asarray(x, dtype=np.float32)).to(dev)
+    np.random.seed(0); torch.manual_seed(0)
+    poses = [(1.75, float(e), float(az), 0.0, 0.0, 0.0) for e in (-15, 20) for az in (0, 90, 180, 270)]
+    tgt = S.make_cloud(100_000, seed=4321, log_scale_mean=float(np.log(0.012)), radius=0.5, activated=False)
+    rs = []
+    for (r_, e_, az_, *_c) in poses:
+        st = S.camera_settings(R, R, 49.1, e_, az_, r_, bg=(1.0, 1.0, 1.0))
+        rs.append(dgr.GaussianRasterizationSettings(R, R, st["tanfovx"], st["tanfovy"], t(st["bg"]), 1.0, t(st["viewmatrix"]).reshape(4, 4), t(st["projmatrix"]).reshape(4, 4), 3, t(st["campos"]), False, False))
+    tp = [t(tgt["means3D"]), t(tgt["shs"][:, :1]), t(tgt["shs"][:, 1:]), t(tgt["opacities"]), t(tgt["scales"]), t(tgt["rotations"])]
+    with torch.no_grad():
+        color, _, alpha, _ = FusedViewRender(100_000, R, R, dev, lanes=4).run(rs, tp)
+    refs = [color[i].clamp(0, 1).permute(1, 2, 0).contiguous() for i in range(len(poses))]          # node layout: [H, W, 3]
+    masks = [(alpha[i, 0] > 0.5).float() for i in range(len(poses))]
+    gp = GSParams()                                                # every default of the node
+    tr = GaussianSplatting3D(gp, None, device=dev)
+    tr.prepare_training(refs, masks, poses, 49.1)
+    import random
+    rng = random.Random(0)
+    n0 = tr.renderer.gaussians._xyz.shape[0]
+    host = []
+
+    def run(first, count):
+        for step in range(first, first + count):
+            tr.training_step(step, [rng.randint(0, len(poses) - 1) for _ in range(gp.batch_size)])
+            if tr._step is not None and hasattr(tr._step, "last_host_ms"):
+                host.append(tr._step.last_host_ms)
+    run(0, a.warmup)
+    torch.cuda.synchronize(dev)
+    host.clear()
+    c3d_hip.prof_enable(a.timed_prof == "on")
+    t0 = time.perf_counter()
+    run(a.warmup, a.steps)
+    if tr._step is not None:
+        tr._step.finish()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    prof = c3d_hip.prof_read() if a.timed_prof == "on" else {}
+    c3d_hip.prof_enable(False)
+    n1 = tr.renderer.gaussians._xyz.shape[0]
+    kern_ms = sum(ms for ms, _ in prof.values()) / max(a.steps, 1)
+    out = {"metric": "it/s, the reference node's default 3DGS training run (10k initial Gaussians, batch 1, %dx%d)" % (R, R), "value": round(a.steps / dt, 2), "unit": "it/s",
+           "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "GaussianSplatting3D.training with the node defaults (nodes.py:1175-1198): %d -> %d Gaussians over steps %d..%d, SH 3, batch 1, %dx%d, 8 reference views, "
+                                  "loss 0.8 L1 + 3 MSE(alpha) + 0.2 (1 - MS-SSIM), densify from 500 every 100" % (n0, n1, a.warmup, a.warmup + a.steps, R, R),
+                      "host_enqueue_ms_per_step": round(float(np.mean(host)), 4) if host else None, "kernel_ms_per_step": round(kern_ms, 4) if prof else None,
+                      "step_over_kernel_time": round(dt / a.steps * 1e3 / kern_ms, 2) if prof and kern_ms > 0 else None, "points_start": n0, "points_end": n1},
+           "roofline": None, "cpu_baseline": None, "kernels": {k: {"ms_per_step": round(ms / a.steps, 4), "launches_per_step": round(n / a.steps, 1)} for k, (ms, n) in prof.items()},
+           "code_digest": code_digest()}
+    print(json.dumps(out))
 
 
 def main_mesh(a, world, rank, dev, dist):
@@ -299,6 +395,8 @@ def main():
 
     if a.workload == "mesh":
         return main_mesh(a, world, rank, dev, dist)
+    if a.workload == "ref-default":
+        return main_ref_default(a, world, rank, dev, dist)
     import c3d_hip
     from c3d_hip import synthetic as S
     import diff_gaussian_rasterization as dgr
@@ -538,13 +636,29 @@ def main():
     tot = sum(ms for ms, _ in prof.values()) or 1.0
     for name, (ms, n) in prof.items():
         kern[name]["share"] = round(ms / tot, 3)
+    # next to every algorithmic rate the rate the memory system really saw: PMC bytes (calibrated per access pattern) / the kernel's duration in the PMC pass.
+    # The batched kernels stream the parameters once per LAUNCH while SURVEY 8(d) credits them per VIEW: their alg_GBps is a contract figure, not an HBM rate.
+    cal, cal_file = load_calibration()
+    pmc_all, pmc_all_file, _ = load_profile_json("_pmc_traffic.json", exclude="_mesh_")
+    group_kernels = {"gs_composite_bwd": ["k_composite_bwd"], "gs_composite_fwd": ["k_composite_fwd_w", "k_composite_fwd"], "gs_preprocess": ["k_preprocess_views", "k_preprocess"],
+                     "gs_preprocess_bwd": ["k_bwd_views_geom", "k_bwd_views_sh"], "gs_emit": ["k_emit"], "adam": ["k_adam"]}
+    for name, bases in group_kernels.items():
+        if name not in kern:
+            continue
+        byts, us = 0.0, 0.0
+        for kname, rec in pmc_all.items():
+            if kname.startswith("_") or kname.split("<")[0].strip() not in bases:
+                continue
+            bb, _ = calibrated_bytes(rec, kname, cal)
+            byts += bb * rec["launches"]; us += rec["avg_us"] * rec["launches"]
+        kern[name]["hbm_GBps"] = round(byts / (us * 1e-6) / 1e9, 1) if us > 0 else None
     roof = None
     # HBM traffic of the dominant kernel: rocprofv3 PMC counters cannot be read from inside the process, so the per-launch figure comes
     # from the committed summary of two separate --pmc passes over this same command (profiles/summarize_pmc.py; FETCH_SIZE raw + WRITE_SIZE,
     # MI355X_MICROARCH.md: FETCH_SIZE under-reports wide streaming reads by 2x on gfx950 -- both figures are in the file).
     pmc, pmc_file, pmc_stale = load_profile_json("_pmc_traffic.json", exclude="_mesh_")
     # kernel behind a profiling group; template instances ("k_composite_bwd<true>": with the fused pixel loss) are matched by base name, most launches first
-    pmc_base = {"gs_composite_bwd": "k_composite_bwd", "gs_composite_fwd": "k_composite_fwd", "gs_preprocess": "k_preprocess_views",
+    pmc_base = {"gs_composite_bwd": "k_composite_bwd", "gs_composite_fwd": "k_composite_fwd_w", "gs_preprocess": "k_preprocess_views",
                 "gs_preprocess_bwd": "k_bwd_views_geom", "gs_emit": "k_emit"}
 
     def kernel_row(table, group, launches=lambda r: r.get("launches", 0)):
@@ -561,8 +675,11 @@ def main():
         rec_name = kernel_row(pmc, dom)
         rec = pmc.get(rec_name) if rec_name else None
         if rec and a.workload == "gs" and N == 1_000_000 and (W, H) == (1920, 1080):
-            roof["traffic"] = int((rec["fetch_MB_raw"] + rec["write_MB"]) * 1e6)
-            roof["traffic_note"] = "FETCH_SIZE(raw)+WRITE_SIZE per launch of %s from profiles/%s (same code digest); fetch x2-corrected: %d" % (rec_name, pmc_file, int((rec["fetch_MB_x2"] + rec["write_MB"]) * 1e6))
+            tb, tnote = calibrated_bytes(rec, rec_name, cal)
+            roof["traffic"] = int(tb)
+            roof["traffic_note"] = "per launch of %s from profiles/%s (same code digest): %s%s; raw FETCH_SIZE + WRITE_SIZE = %d" % (
+                rec_name, pmc_file, tnote, (" [profiles/%s]" % cal_file) if cal_file else "", int((rec["fetch_MB_raw"] + rec["write_MB"]) * 1e6))
+            roof["hbm_GBps"] = round(tb / (rec["avg_us"] * 1e-6) / 1e9, 1)
         elif pmc_stale:
             roof["stale"] = "profiles/%s was measured on code %s, this is %s" % (pmc_file, pmc_stale, code_digest())
 
@@ -601,6 +718,13 @@ def main():
         chain = {"what": "SURVEY 8(d) algorithmic bytes of one view (%s) / wall time per view in the timed region" % ("B_fwd" if a.mode == "fwd" else "B_fwd + B_bwd"),
                  "bytes_per_view": int(b_view), "ms_per_view": round(per_view_s * 1e3, 4), "achieved": round(b_view / per_view_s / 1e9, 1), "peak": HBM_PEAK_GBPS,
                  "unit": "GB/s", "frac": round(b_view / per_view_s / 1e9 / HBM_PEAK_GBPS, 4), "target_frac": 0.6 if a.mode == "fwd" else None}
+        # the same with the parameter set counted once per LAUNCH that streams it (k_preprocess_views / k_bwd_views_*: once per step, or once per group of
+        # `lanes` views forward-only) instead of once per view as the contract formula does: what the memory system is really asked for
+        share = a.views_per_gpu if a.mode != "fwd" else max(1, min(a.lanes, a.views_per_gpu))
+        par = N * (44 + 12 * K)
+        b_once = b_view - par * (1 if a.mode == "fwd" else 3) * (1.0 - 1.0 / share)
+        chain["bytes_per_view_params_once_per_launch"] = int(b_once)
+        chain["frac_params_once_per_launch"] = round(b_once / per_view_s / 1e9 / HBM_PEAK_GBPS, 4)
     kern_conc = None
     if prof_conc:
         kern_conc = {name: round(ms / n, 4) for name, (ms, n) in prof_conc.items()}
@@ -624,6 +748,36 @@ def main():
         except Exception as ex:   # the baseline leg must never take the bench down
             cpu = {"value": None, "unit": "Mpixels/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (ex,)}
 
+    # north-star target carried into THIS line: ">= 60 % of MI355X HBM roofline on 1M-Gaussian 1080p forward raster" is a statement about
+    # BASELINE config 2 -- forward only, the 64 orbit cameras.  Run it here, after the timed region, so that the driver's record holds the number.
+    targets = None
+    if rank == 0 and world == 1 and a.mode != "fwd" and a.targets == "on" and use_renderer and a.render_path == "step":
+        try:
+            from c3d_hip.gs_step import FusedViewRender
+            all_settings = []
+            for (r_, e_, az_) in poses:
+                st = S.camera_settings(W, H, 49.1, e_, az_, r_, bg=(1.0, 1.0, 1.0), sh_degree=deg)
+                all_settings.append(dgr.GaussianRasterizationSettings(H, W, st["tanfovx"], st["tanfovy"], t(st["bg"]), 1.0, t(st["viewmatrix"]).reshape(4, 4),
+                                                                      t(st["projmatrix"]).reshape(4, 4), deg, t(st["campos"]), False, False))
+            vr = FusedViewRender(N, H, W, dev, lanes=8)
+            pl_ = [q.detach() for q in plist]
+            with torch.no_grad():
+                vr.run(all_settings, pl_); vr.run(all_settings, pl_)          # capacity fit + warm-up
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    vr.run(all_settings, pl_)
+                torch.cuda.synchronize(dev)
+                tf = (time.perf_counter() - t1) / 3
+            pv = tf / len(all_settings)
+            targets = {"what": "BASELINE config 2 after the timed region: forward only, the 64 orbit cameras in one c3d_gs_render_views_raw call (8 view lanes), 3 passes",
+                       "fwd_Mpx": round(len(all_settings) * P / tf / 1e6, 1), "fwd_ms_per_view": round(pv * 1e3, 4),
+                       "fwd_chain_frac": round(b_fwd / pv / 1e9 / HBM_PEAK_GBPS, 4), "fwd_chain_GBps": round(b_fwd / pv / 1e9, 1), "fwd_bytes_per_view": int(b_fwd),
+                       "target_frac": 0.6, "north_star": ">= 60 % of MI355X HBM roofline on 1M-Gaussian 1080p forward raster (SURVEY 8d algorithmic bytes B_fwd / wall time per view / 8 TB/s)"}
+            del vr
+        except Exception as ex:      # never take the headline down
+            targets = {"error": repr(ex)}
+
     if rank == 0:
         out = {
             "metric": "Mpixels/s 3DGS forward+backward @1M Gaussians 1080p" if a.mode == "fwdbwd" else
@@ -642,7 +796,7 @@ def main():
                        "defer_status": (fused_step.defer_status if fused_step is not None else None),
                        "gpu_span_ms_last_step": (round(getattr(fused_step, "last_gpu_ms", 0.0), 3) if fused_step is not None else None),
                        "n_visible": n_vis, "tile_splat_pairs": D},
-            "roofline": roof, "roofline_chain": chain, "cpu_baseline": cpu, "kernels": kern, "kernels_concurrent_avg_ms": kern_conc,
+            "roofline": roof, "roofline_chain": chain, "targets": targets, "cpu_baseline": cpu, "kernels": kern, "kernels_concurrent_avg_ms": kern_conc,
             "code_digest": code_digest(),
         }
         print(json.dumps(out))
