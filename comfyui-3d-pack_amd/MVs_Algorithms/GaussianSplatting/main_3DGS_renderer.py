@@ -229,6 +229,7 @@ class GaussianModel:
     # surviving point of the result names the point it is copied from and what it is (kept / clone / split child), and each array is
     # rebuilt with a single gather.  The outcome (set and order of points, parameter values, optimizer state, statistics) is the reference's.
     _NAMES = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")
+    use_device_densify = True        # HIP device: include/c3d_densify.h; False keeps the torch form (tests compare the two)
 
     def _param_dict(self):
         return dict(zip(self._NAMES, (self._xyz, self._features_dc, self._features_rest, self._opacity, self._scaling, self._rotation)))
@@ -297,10 +298,88 @@ class GaussianModel:
         self._install(tensors, mom)
         return tensors
 
-    def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size, generator=None):
+    def _densify_and_prune_device(self, max_grad, min_opacity, extent, max_screen_size, generator, noise):
+        """The same result on a HIP device through include/c3d_densify.h: classification and the four prefix sums on the device, ONE host
+        read (six counts: the new point count has to be known to allocate), the source-index list written by one kernel, and ONE gather launch for the six
+        parameters, their twelve Adam moments and init_xyz -- where the reference needs a device -> host synchronisation per boolean mask and a
+        torch.cat per array.  Children are positioned with a few torch ops on the gathered rows (no synchronisation)."""
+        import ctypes as C
+        import c3d_hip as _h
+        lib, dev = _h.lib(), self._xyz.device
+        N = self._xyz.shape[0]
+        u8 = dict(dtype=torch.uint8, device=dev)
+        with torch.no_grad(), torch.cuda.device(dev):
+            st = _h.stream(dev)
+            plan = torch.empty((lib.c3d_densify_plan_bytes(N),), **u8)
+            counts = torch.empty((8,), dtype=torch.int32, device=dev)
+            old = {k: v.detach().contiguous() for k, v in self._param_dict().items()}
+            _h.check(lib.c3d_densify_plan(N, _h.ptr(self.xyz_gradient_accum.contiguous()), _h.ptr(self.denom.contiguous()), _h.ptr(old["scaling"]), _h.ptr(old["opacity"]),
+                                          float(max_grad), float(self.percent_dense * extent), float(min_opacity), float(0.1 * extent if max_screen_size else 0.0),
+                                          _h.ptr(plan), _h.ptr(counts), st), "c3d_densify_plan")
+            nK, nC, nS, nS_all, nC_all = counts.tolist()[:5]                  # the one host synchronisation of the step
+            M = nK + nC + 2 * nS
+            src = torch.empty((max(M, 1),), dtype=torch.int32, device=dev)
+            fresh = torch.empty((max(M, 1),), **u8)
+            crank = torch.empty((max(2 * nS, 1),), dtype=torch.int32, device=dev)
+            _h.check(lib.c3d_densify_fill(N, _h.ptr(plan), (C.c_uint32 * 8)(nK, nC, nS, nS_all, nC_all, 0, 0, 0), _h.ptr(src), _h.ptr(fresh), _h.ptr(crank), st), "c3d_densify_fill")
+            # every per-point array through ONE gather launch
+            names = list(self._NAMES)
+            srcs, dsts, rows, zero = [], [], [], []
+            new = {k: torch.empty((M,) + tuple(old[k].shape[1:]), dtype=torch.float32, device=dev) for k in names}
+            moms = {}
+            for group in self.optimizer.param_groups:
+                stt = self.optimizer.state.get(group["params"][0])
+                if stt is not None and len(stt):
+                    moms[group["name"]] = {k: (stt[k].contiguous(), torch.empty_like(new[group["name"]])) for k in ("exp_avg", "exp_avg_sq")}
+            new_init = torch.empty((M, 3), dtype=torch.float32, device=dev)
+            for k in names:
+                srcs.append(old[k]); dsts.append(new[k]); rows.append(old[k][0].numel() if N else 1); zero.append(0)
+                for kk in moms.get(k, {}).values():
+                    srcs.append(kk[0]); dsts.append(kk[1]); rows.append(old[k][0].numel() if N else 1); zero.append(1)     # clones / children start with zero moments
+            srcs.append(self.init_xyz.contiguous()); dsts.append(new_init); rows.append(3); zero.append(0)
+            if M:
+                na = len(srcs)
+                _h.check(lib.c3d_gather_rows(na, (C.c_void_p * na)(*[t_.data_ptr() for t_ in srcs]), (C.c_void_p * na)(*[t_.data_ptr() for t_ in dsts]), (C.c_int32 * na)(*rows),
+                                             (C.c_int32 * na)(*zero), _h.ptr(src), _h.ptr(fresh), M, st), "c3d_gather_rows")
+            if nS:
+                # split children (reference :641-670, N = 2): position sampled from the parent's Gaussian, scale / (0.8 * 2).  The noise tensor has the
+                # reference's shape (2 x ALL split parents, 3) and row (child, parent rank), so that an equally seeded generator gives the same samples
+                if noise is None:
+                    noise = torch.randn((2 * nS_all, 3), device=dev, generator=generator)
+                lo = nK + nC
+                par = src[lo:lo + 2 * nS].long()
+                row = (torch.arange(2 * nS, device=dev) >= nS).long() * nS_all + crank[:2 * nS].long()
+                std = torch.exp(old["scaling"][par])
+                rot = build_rotation(old["rotation"][par])
+                new["xyz"][lo:lo + 2 * nS] = torch.bmm(rot, (noise[row] * std).unsqueeze(-1)).squeeze(-1) + old["xyz"][par]
+                new["scaling"][lo:lo + 2 * nS] = self.scaling_inverse_activation(std / 1.6)
+            self.init_xyz = new_init
+            mom_new = {k: {kk: vv[1] for kk, vv in m.items()} for k, m in moms.items()}
+            for group in self.optimizer.param_groups:          # install: parameters and moments are already gathered
+                oldp = group["params"][0]
+                newp = nn.Parameter(new[group["name"]].requires_grad_(True))
+                stt = self.optimizer.state.pop(oldp, None)
+                if stt is not None and len(stt):
+                    stt["exp_avg"], stt["exp_avg_sq"] = mom_new[group["name"]]["exp_avg"], mom_new[group["name"]]["exp_avg_sq"]
+                    self.optimizer.state[newp] = stt
+                group["params"][0] = newp
+                new[group["name"]] = newp
+            self._xyz, self._features_dc, self._features_rest = new["xyz"], new["f_dc"], new["f_rest"]
+            self._opacity, self._scaling, self._rotation = new["opacity"], new["scaling"], new["rotation"]
+            self.xyz_gradient_accum = torch.zeros((M, 1), device=dev)
+            self.denom = torch.zeros((M, 1), device=dev)
+            self.max_radii2D = torch.zeros((M,), device=dev)
+        n_keep_all = N - nS_all
+        return {"cloned": int(nC_all), "split": int(nS_all), "pruned": int((n_keep_all - nK) + (nC_all - nC) + 2 * (nS_all - nS)), "points": int(M)}
+
+    def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size, generator=None, noise=None):
         """clone small / split large high-gradient points, then prune (reference densify_and_prune :748-750 = clone :672-690, split
         :641-670 with N=2, prune :771-781), in one pass.  Statistics are zeroed as densification_postfix does (:634-637) -- which is
-        also why the reference's screen-size criterion never fires: max_radii2D is all zero by the time prune() looks at it."""
+        also why the reference's screen-size criterion never fires: max_radii2D is all zero by the time prune() looks at it.
+        On a HIP device the index construction and the gather run in the library (_densify_and_prune_device); this torch form is the CPU path of the
+        host-logic tests and the statement both are held to.  `noise` (tests): the [2 * split, 3] normal samples instead of a draw from `generator`."""
+        if self._xyz.is_cuda and self._xyz.shape[0] > 0 and self.use_device_densify:
+            return self._densify_and_prune_device(max_grad, min_opacity, extent, max_screen_size, generator, noise)
         N = self._xyz.shape[0]
         dev = self._xyz.device
         with torch.no_grad():
@@ -329,7 +408,7 @@ class GaussianModel:
             # split children: position sampled from the parent's Gaussian, scale / (0.8 * 2)
             if nS:
                 std = scal[i_split].repeat(2, 1)
-                noise = torch.randn(std.shape, device=dev, generator=generator) * std
+                noise = (torch.randn(std.shape, device=dev, generator=generator) if noise is None else noise) * std
                 rot = build_rotation(self._rotation.detach()[i_split]).repeat(2, 1, 1)
                 child_xyz = torch.bmm(rot, noise.unsqueeze(-1)).squeeze(-1) + self._xyz.detach()[i_split].repeat(2, 1)
                 child_scaling = self.scaling_inverse_activation(std / 1.6)

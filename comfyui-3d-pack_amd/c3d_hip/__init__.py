@@ -61,6 +61,10 @@ _SIGNATURES = {
     "c3d_msssim_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "c3d_msssim_value_grad": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp]),
     "c3d_reduce_ranks_f32": (C.c_int, [vp, vp, i32, i64, C.c_float, vp]),
+    "c3d_densify_plan_bytes": (sz, [i32]),
+    "c3d_densify_plan": (C.c_int, [i32, vp, vp, vp, vp, f32, f32, f32, f32, vp, vp, vp]),
+    "c3d_densify_fill": (C.c_int, [i32, vp, C.POINTER(C.c_uint32), vp, vp, vp, vp]),
+    "c3d_gather_rows": (C.c_int, [i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(i32), C.POINTER(i32), vp, vp, i64, vp]),
     "c3d_prof_enable": (C.c_int, [C.c_int]),
     "c3d_prof_select": (C.c_int, [C.c_ulonglong]),
     "c3d_prof_slots": (C.c_int, []),

@@ -973,6 +973,57 @@ def test_trainer_densify_prune_schedule():
         assert abs(a - b) <= 0.02 * b
 
 
+def test_device_densify_equals_the_torch_form():
+    """include/c3d_densify.h (classification + single-pass prefix sums + one source-index kernel + ONE gather launch for 6 parameters, 12 moments and
+    init_xyz) against GaussianModel.densify_and_prune's torch form -- itself held to a run of the reference's densify_and_prune by
+    tests/test_ref_conventions.py -- on the same model state and the same normal samples: same points in the same order, same values bit for bit,
+    same Adam moments, same counts; with and without the scale criterion, and when nothing / everything is hot."""
+    import copy
+    from MVs_Algorithms.GaussianSplatting.main_3DGS_renderer import GaussianModel
+    from MVs_Algorithms.GaussianSplatting.main_3DGS import GSParams
+    rng = np.random.default_rng(12)
+    N = 20011
+    raw = S.make_cloud(N, seed=5, log_scale_mean=np.log(0.02), activated=False)
+
+    def build():
+        m = GaussianModel(3, device="cuda")
+        m.create_from_tensors(torch.tensor(raw["means3D"]), torch.tensor(raw["shs"]), torch.tensor(raw["scales"]), torch.tensor(raw["rotations"]), torch.tensor(raw["opacities"]))
+        m.training_setup(GSParams())
+        for grp in m.optimizer.param_groups:            # moments as after a few Adam steps
+            q = grp["params"][0]
+            g_ = torch.Generator(device="cpu").manual_seed(len(grp["name"]))
+            m.optimizer.state[q] = {"step": 3, "exp_avg": torch.randn(q.shape, generator=g_).cuda(), "exp_avg_sq": torch.rand(q.shape, generator=g_).cuda()}
+        m.init_xyz = m._xyz.detach().clone()
+        return m
+
+    grad = torch.tensor(rng.uniform(0, 4e-4, size=(N, 1)).astype(np.float32)).cuda()
+    den = torch.tensor(rng.integers(0, 3, size=(N, 1)).astype(np.float32)).cuda()          # zeros: 0 / 0 -> NaN -> 0
+    for max_grad, max_screen in ((2e-4, 1), (2e-4, 0), (1.0, 1), (0.0, 1)):
+        res = []
+        noise = None
+        for device_path in (False, True):
+            m = build()
+            m.use_device_densify = device_path
+            m.xyz_gradient_accum, m.denom = grad.clone(), den.clone()
+            if noise is None:
+                g = m.xyz_gradient_accum / m.denom
+                g[g.isnan()] = 0
+                hot = g.norm(dim=-1) >= max_grad
+                n_split = int((hot & ~(m.get_scaling.detach().max(dim=1).values <= m.percent_dense * 4)).sum())
+                noise = torch.randn((2 * n_split, 3), generator=torch.Generator(device="cpu").manual_seed(1)).cuda()
+            info = m.densify_and_prune(max_grad, min_opacity=0.3, extent=4, max_screen_size=max_screen, noise=noise.clone())
+            res.append((info, m))
+        (ia, a), (ib, b) = res
+        assert ia == ib, (ia, ib)
+        assert ib["points"] == b._xyz.shape[0] and (max_grad >= 1.0 or ib["cloned"] + ib["split"] > 0)
+        for qa, qb in zip((a._xyz, a._features_dc, a._features_rest, a._opacity, a._scaling, a._rotation, a.init_xyz, a.xyz_gradient_accum, a.denom, a.max_radii2D),
+                          (b._xyz, b._features_dc, b._features_rest, b._opacity, b._scaling, b._rotation, b.init_xyz, b.xyz_gradient_accum, b.denom, b.max_radii2D)):
+            assert qa.shape == qb.shape and torch.equal(qa.detach(), qb.detach())
+        for ga, gb in zip(a.optimizer.param_groups, b.optimizer.param_groups):
+            sa, sb = a.optimizer.state[ga["params"][0]], b.optimizer.state[gb["params"][0]]
+            assert sa["step"] == sb["step"] and torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"])
+
+
 def _minicam_for(tr, pose):
     from shared_utils.camera_utils import MiniCam, orbit_camera
     ctl = tr.cam_controller
