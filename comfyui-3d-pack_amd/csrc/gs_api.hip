@@ -380,12 +380,14 @@ static int step_view_forward(const GsParams& p, const float* means3D, const floa
     *res_out = res;
     return 0;
 }
-// Binning ahead (round 3): with all views projected up front, the views' binning chains -- 15 launches of 10-30 us each that cannot fill the machine -- run on
-// the pool's streams the compositing lanes do NOT use, every chain from the start of the step, instead of at the head of each view on its lane: under four
-// lanes in lockstep the chains of four views coincided and left the machine idle twice per 8-view step (2 x 0.33 ms of 6.1).  C3D_BIN_AHEAD=0 keeps the chain on the lane.
+// Binning ahead (round 3, measured and left OFF): with all views projected up front, the views' binning chains -- 15 launches of 10-30 us each that cannot
+// fill the machine -- can run on the pool's streams the compositing lanes do not use, every chain from the start of the step, instead of at the head of each
+// view on its lane (under four lanes in lockstep the chains of four views coincide twice per 8-view step).  On the MI355X box: 6.50 ms per step against 5.89 ms
+// with the chains on the lanes (profiles/r03/r03c_bench_binahead_on.json / _off.json): eight streams share four hardware queues, and a lane's compositing
+// kernel then waits behind another stream's chain in its queue.  C3D_BIN_AHEAD=1 enables it (worth re-measuring with GPU_MAX_HW_QUEUES=8).
 static bool bin_ahead() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("C3D_BIN_AHEAD"); v = e ? atoi(e) != 0 : 1; }
+    if (v < 0) { const char* e = getenv("C3D_BIN_AHEAD"); v = e ? atoi(e) != 0 : 0; }
     return v != 0;
 }
 
