@@ -25,13 +25,14 @@ SIGNATURES = {
     "c3d_mesh_rasterize_bwd_gather": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
     "c3d_mesh_interpolate_fwd": (C.c_int, [vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
     "c3d_mesh_interpolate_bwd": (C.c_int, [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]),
+    "c3d_mesh_interpolate_da_bwd": (C.c_int, [vp, i32, vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp]),
     "c3d_mesh_texture_fwd": (C.c_int, [vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
     "c3d_mesh_texture_bwd": (C.c_int, [vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
     "c3d_mesh_mip_info": (i32, [i32, i32, i32, vp, vp]),
     "c3d_mesh_mip_build": (C.c_int, [vp, i32, i32, i32, i32, i32, vp, vp]),
     "c3d_mesh_mip_build_bwd": (C.c_int, [vp, i32, i32, i32, i32, i32, vp, vp]),
     "c3d_mesh_texture_mip_fwd": (C.c_int, [vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
-    "c3d_mesh_texture_mip_bwd": (C.c_int, [vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
+    "c3d_mesh_texture_mip_bwd": (C.c_int, [vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
     "c3d_mesh_transform_fwd": (C.c_int, [vp, vp, i32, vp, vp]),
     "c3d_mesh_transform_bwd": (C.c_int, [vp, vp, i32, vp, vp]),
     "c3d_mesh_shade_fwd": (C.c_int, [vp, vp, vp, C.c_int64, vp, vp, vp]),

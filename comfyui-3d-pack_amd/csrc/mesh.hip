@@ -447,6 +447,30 @@ __global__ void __launch_bounds__(256) k_interp_bwd(const float* __restrict__ at
     drast[gid] = make_float4(gu, gv, 0.f, 0.f);
 }
 
+// backward of the pixel differentials: out_da[k] = ((a0 - a2) db.x + (a1 - a2) db.z, (a0 - a2) db.y + (a1 - a2) db.w) for attribute diff[k]
+__global__ void __launch_bounds__(256) k_interp_da_bwd(const float* __restrict__ attr, int Ba, const float4* __restrict__ rast, const int3* __restrict__ tri,
+                                                        const float4* __restrict__ rast_db, const int* __restrict__ diff, int nd, const float* __restrict__ dout_da,
+                                                        long long BP, long long P, int V, int A, float* __restrict__ dattr, float4* __restrict__ drast_db) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= BP) return;
+    const int t = (int)rast[gid].w - 1;
+    if (t < 0) { drast_db[gid] = make_float4(0.f, 0.f, 0.f, 0.f); return; }
+    const size_t ab = (size_t)(Ba > 1 ? (gid / P) : 0) * V * A;
+    const int3 vi = tri[t];
+    const size_t i0 = ab + (size_t)vi.x * A, i1 = ab + (size_t)vi.y * A, i2 = ab + (size_t)vi.z * A;
+    const float4 db = rast_db[gid];
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < nd; k++) {
+        const int a = diff[k];
+        const float gx = dout_da[(gid * nd + k) * 2], gy = dout_da[(gid * nd + k) * 2 + 1];
+        const float dsdu = attr[i0 + a] - attr[i2 + a], dsdv = attr[i1 + a] - attr[i2 + a];
+        const float gu = gx * db.x + gy * db.y, gv = gx * db.z + gy * db.w;
+        if (dattr && (gu != 0.f || gv != 0.f)) { atomicAdd(&dattr[i0 + a], gu); atomicAdd(&dattr[i1 + a], gv); atomicAdd(&dattr[i2 + a], -(gu + gv)); }
+        g.x += gx * dsdu; g.y += gy * dsdu; g.z += gx * dsdv; g.w += gy * dsdv;
+    }
+    drast_db[gid] = g;
+}
+
 // ------------------------------------------------------------------------------------------ texture
 __device__ __forceinline__ int wrapi(int i, int n, int boundary) {
     if (boundary == 0) { i %= n; if (i < 0) i += n; return i; }
@@ -647,6 +671,28 @@ __device__ __forceinline__ int mip_select(const float4* __restrict__ da, const f
     f = fl - (float)l0;
     return l0;
 }
+// d(level) / d(uv_da) where the level lies strictly inside (0, L) before clamping (mirror of mip_select; oracle: mip_level_grad in mesh_oracle.c).
+// -> true when inside: gda = dlevel * d level / d uv_da, and the bias receives dlevel itself.
+__device__ __forceinline__ bool mip_level_grad(const float4* __restrict__ da, const float* __restrict__ bias, long long gid, int Ht, int Wt, int L, float dlevel, float4& gda) {
+    float fl = 0.f, major = 1.f, A = 0.f, Bq = 0.f, Cq = 0.f, sq = 0.f, dsdx = 0.f, dsdy = 0.f, dtdx = 0.f, dtdy = 0.f;
+    gda = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (da) {
+        const float4 d = da[gid];
+        dsdx = d.x * Wt; dsdy = d.y * Wt; dtdx = d.z * Ht; dtdy = d.w * Ht;
+        A = dsdx * dsdx + dtdx * dtdx; Bq = dsdy * dsdy + dtdy * dtdy; Cq = dsdx * dsdy + dtdx * dtdy;
+        sq = sqrtf(0.25f * (A - Bq) * (A - Bq) + Cq * Cq);
+        major = 0.5f * (A + Bq) + sq;
+        fl = 0.5f * log2f(major);
+    }
+    if (bias) fl += bias[gid];
+    if (!(fl > 0.f) || !(fl < (float)L)) return false;
+    if (da) {
+        const float gm = dlevel * 0.5f / (major * 0.6931471805599453f);
+        const float t = sq > 0.f ? 0.25f * (A - Bq) / sq : 0.f, gA = gm * (0.5f + t), gB = gm * (0.5f - t), gC = sq > 0.f ? gm * Cq / sq : 0.f;
+        gda = make_float4((2.f * dsdx * gA + dsdy * gC) * Wt, (2.f * dsdy * gB + dsdx * gC) * Wt, (2.f * dtdx * gA + dtdy * gC) * Ht, (2.f * dtdy * gB + dtdx * gC) * Ht);
+    }
+    return true;
+}
 // the four bilinear taps of one level as virtual texel indices + weights
 struct MipTaps { uint32_t k[4]; float fu, fv; int w, h; };
 __device__ __forceinline__ MipTaps mip_taps(float2 q, int Ht, int Wt, int l, int boundary) {
@@ -737,7 +783,7 @@ template <int CT>
 __global__ void __launch_bounds__(256) k_tex_mip_bwd(const float* __restrict__ tex, const float* __restrict__ stack, int Bt, const float2* __restrict__ uv,
                                                       const float4* __restrict__ da, const float* __restrict__ bias, const float* __restrict__ dy, int H, int W,
                                                       int Ht, int Wt, int Crt, int L, long long total, int filter, int boundary, float* __restrict__ dtex,
-                                                      float* __restrict__ dstack, float2* __restrict__ duv) {
+                                                      float* __restrict__ dstack, float2* __restrict__ duv, float4* __restrict__ dda, float* __restrict__ dbias) {
     constexpr int CS = CT > 0 ? CT : 1;
     __shared__ uint32_t keys[CT > 0 ? MIPT_SLOTS : 1];
     __shared__ float vals[CT > 0 ? MIPT_SLOTS : 1][CS];
@@ -765,6 +811,7 @@ __global__ void __launch_bounds__(256) k_tex_mip_bwd(const float* __restrict__ t
         const float2 q = uv[gid];
         const float* g = dy + gid * C;
         float gu = 0.f, gv = 0.f;
+        float sdot[2] = {0.f, 0.f};
         const int nl = (l1 != l0 && f != 0.f) ? 2 : 1;
         const MipTaps t0 = mip_taps(q, Ht, Wt, l0, boundary);
         const bool use_hash = CT > 0 && tex_taps_shared(t0.k);        // decided on the finer level: the coarser one shares at least as much
@@ -774,14 +821,19 @@ __global__ void __launch_bounds__(256) k_tex_mip_bwd(const float* __restrict__ t
             const float tw[4] = {(1.f - t.fu) * (1.f - t.fv), t.fu * (1.f - t.fv), (1.f - t.fu) * t.fv, t.fu * t.fv};
             const float *p00 = mip_texel(tb, sb, HW, t.k[0], C), *p10 = mip_texel(tb, sb, HW, t.k[1], C);
             const float *p01 = mip_texel(tb, sb, HW, t.k[2], C), *p11 = mip_texel(tb, sb, HW, t.k[3], C);
-            float lu = 0.f, lv = 0.f;
+            float lu = 0.f, lv = 0.f, sd = 0.f;
             bool any = false;
             for (int c = 0; c < C; c++) {
                 const float gc = g[c] * wl;
                 any = any || gc != 0.f;
                 lu += gc * ((p10[c] - p00[c]) * (1.f - t.fv) + (p11[c] - p01[c]) * t.fv);
                 lv += gc * ((p01[c] - p00[c]) * (1.f - t.fu) + (p11[c] - p10[c]) * t.fu);
+                if (dda || dbias) {                                   // dy . sample(level): the level gradient is the difference of the two levels' dots
+                    const float top = p00[c] + t.fu * (p10[c] - p00[c]), bot = p01[c] + t.fu * (p11[c] - p01[c]);
+                    sd += g[c] * (top + t.fv * (bot - top));
+                }
             }
+            sdot[lev] = sd;
             gu += lu * t.w; gv += lv * t.h;
             if (!any) continue;
 #pragma unroll
@@ -805,6 +857,13 @@ __global__ void __launch_bounds__(256) k_tex_mip_bwd(const float* __restrict__ t
             }
         }
         duv[gid] = make_float2(gu, gv);
+        if (dda || dbias) {      // gradients w.r.t. uv_da / mip_level_bias: only 'linear-mipmap-linear' (3) with two distinct levels and an unclamped level
+            float4 gda;
+            const float dl = sdot[1] - sdot[0];
+            const bool in = filter == 3 && nl == 2 && mip_level_grad(da, bias, gid, Ht, Wt, L, dl, gda);
+            if (dda) dda[gid] = in ? gda : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (dbias) dbias[gid] = in ? dl : 0.f;
+        }
     }
     if (CT > 0) {
         __syncthreads();
@@ -1177,6 +1236,20 @@ int c3d_mesh_interpolate_bwd(const float* attr, int32_t Ba, const float* rast, c
     return 0;
 }
 
+int c3d_mesh_interpolate_da_bwd(const float* attr, int32_t Ba, const float* rast, const int32_t* tri, const float* rast_db, const int32_t* diff_attrs, int32_t n_diff,
+                                const float* dout_da, int32_t B, int32_t V, int32_t A, int32_t H, int32_t W, float* dattr, float* drast_db, c3d_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    const long long P = (long long)H * W, BP = P * B;
+    MESH_REQUIRE(Ba == 1 || Ba == B, "attribute batch must be 1 or B");
+    if (BP == 0 || n_diff == 0) return 0;
+    MESH_REQUIRE(attr && rast && tri && rast_db && diff_attrs && dout_da && drast_db, "NULL pointer");
+    C3dProfScope ps(C3D_P_MESH_INTERPOLATE_BWD, s);
+    hipLaunchKernelGGL(k_interp_da_bwd, dim3(c3d_cdiv(BP, 256)), dim3(256), 0, s, attr, Ba, (const float4*)rast, (const int3*)tri, (const float4*)rast_db, diff_attrs, n_diff,
+                       dout_da, BP, P, V, A, dattr, (float4*)drast_db);
+    C3D_LAUNCH_CHECK();
+    return 0;
+}
+
 int c3d_mesh_texture_fwd(const float* tex, int32_t Bt, const float* uv, int32_t B, int32_t H, int32_t W, int32_t Ht, int32_t Wt, int32_t C, int32_t filter,
                          int32_t boundary, float* out, c3d_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
@@ -1289,12 +1362,13 @@ int c3d_mesh_texture_mip_fwd(const float* tex, const float* stack, int32_t Bt, c
 }
 int c3d_mesh_texture_mip_bwd(const float* tex, const float* stack, int32_t Bt, const float* uv, const float* uv_da, const float* mip_level_bias, const float* dy,
                              int32_t B, int32_t H, int32_t W, int32_t Ht, int32_t Wt, int32_t C, int32_t filter, int32_t boundary, int32_t max_mip_level,
-                             float* dtex, float* dstack, float* duv, c3d_stream_t stream) {
+                             float* dtex, float* dstack, float* duv, float* d_uv_da, float* d_bias, c3d_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     const long long P = (long long)H * W, BP = P * B;
     MIP_SHAPE(m);
     MESH_REQUIRE(Bt == 1 || Bt == B, "texture batch must be 1 or B");
     MESH_REQUIRE((filter == 2 || filter == 3) && (boundary == 0 || boundary == 1), "unsupported filter/boundary mode");
+    MESH_REQUIRE((!d_uv_da || uv_da) && (!d_bias || mip_level_bias), "a gradient was asked for an input that is absent");
     C3dProfScope ps(C3D_P_MESH_TEXTURE_BWD, s);
     if ((long long)Bt * C > 0) {
         MESH_REQUIRE(dtex && (dstack || m.L == 0), "NULL dtex / dstack");
@@ -1308,7 +1382,7 @@ int c3d_mesh_texture_mip_bwd(const float* tex, const float* stack, int32_t Bt, c
     const float* st = stack ? stack : tex;
     float* dst = dstack ? dstack : dtex;
 #define MIP_BWD(CT) hipLaunchKernelGGL((k_tex_mip_bwd<CT>), grid, dim3(256), 0, s, tex, st, Bt, (const float2*)uv, (const float4*)uv_da, mip_level_bias, dy, H, W, \
-                                       Ht, Wt, C, m.L, m.total, filter, boundary, dtex, dst, (float2*)duv)
+                                       Ht, Wt, C, m.L, m.total, filter, boundary, dtex, dst, (float2*)duv, (float4*)d_uv_da, d_bias)
     if (C == 1) MIP_BWD(1); else if (C == 3) MIP_BWD(3); else if (C == 4) MIP_BWD(4); else MIP_BWD(0);
 #undef MIP_BWD
     C3D_LAUNCH_CHECK();

@@ -11,8 +11,9 @@ Same function names, argument meaning and return shapes as the module the refere
 The arithmetic runs in libc3d_hip.so; this file allocates tensors and wires autograd.  There is no CPU path.
     rasterize(..., ranges=[B,2]) / antialias with pos [V,4]: range (instanced) mode, composed on the host from the B = 1 kernels
     boundary modes 'wrap' | 'clamp' | 'zero' ('zero' for the nearest / linear filters, composed from a zero-padded texture + 'clamp')
-Not built (raise NotImplementedError): cube maps (boundary 'cube'), 'zero' with the mip-mapped filters; gradients w.r.t.
-rast_db / out_da / uv_da / mip_level_bias are not propagated (no consumer on the reference's path).
+Not built (raise NotImplementedError): cube maps (boundary 'cube'), 'zero' with the mip-mapped filters.  Gradients w.r.t. uv_da and
+mip_level_bias ('linear-mipmap-linear') and through interpolate's pixel differentials out_da to the attributes and to rast_db are propagated;
+rasterize itself does not take a gradient for rast_db (the dependency's grad_db).
 """
 import torch
 
@@ -245,24 +246,31 @@ class _Interpolate(torch.autograd.Function):
             _h.check(lib.c3d_mesh_interpolate_fwd(_h.ptr(a3), Ba, _h.ptr(rast_c), _h.ptr(tri_c), _h.ptr(_h.f32c(rast_db)) if nd else None,
                                                   _h.ptr(diff) if nd else None, nd, B, V, A, H, W, _h.ptr(out), _h.ptr(out_da) if nd else None,
                                                   _h.stream(dev)), "c3d_mesh_interpolate_fwd")
-        ctx.save_for_backward(a3, rast_c, tri_c)
+        ctx.save_for_backward(a3, rast_c, tri_c, _h.f32c(rast_db) if nd else None, diff if nd else None)
         ctx.attr_shape = tuple(attr.shape)
+        ctx.nd = nd
         return out, out_da
 
     @staticmethod
     def backward(ctx, dy, dda):
         lib = _h.lib()
-        a3, rast, tri = ctx.saved_tensors
+        a3, rast, tri, rast_db, diff = ctx.saved_tensors
         Ba, V, A = a3.shape
         B, H, W, _ = rast.shape
         dev = rast.device
         need_attr = ctx.needs_input_grad[0]      # constant attributes (texture coordinates) need no vertex scatter at all
+        drast_db = None
         with torch.cuda.device(dev):
             dattr = torch.empty_like(a3) if need_attr else None
             drast = torch.empty_like(rast)
             _h.check(lib.c3d_mesh_interpolate_bwd(_h.ptr(a3), Ba, _h.ptr(rast), _h.ptr(tri), _h.ptr(_h.f32c(dy)), B, V, A, H, W,
                                                   _h.ptr(dattr) if need_attr else None, _h.ptr(drast), _h.stream(dev)), "c3d_mesh_interpolate_bwd")
-        return (dattr.reshape(ctx.attr_shape) if need_attr else None), drast, None, None, None
+            if ctx.nd and dda is not None and (need_attr or ctx.needs_input_grad[3]):
+                # the pixel differentials out_da are linear in the attributes and in rast_db: what a mip-mapped texture() sends back for uv_da goes on to both
+                drast_db = torch.empty_like(rast_db)
+                _h.check(lib.c3d_mesh_interpolate_da_bwd(_h.ptr(a3), Ba, _h.ptr(rast), _h.ptr(tri), _h.ptr(rast_db), _h.ptr(diff), ctx.nd, _h.ptr(_h.f32c(dda)), B, V, A, H, W,
+                                                         _h.ptr(dattr) if need_attr else None, _h.ptr(drast_db), _h.stream(dev)), "c3d_mesh_interpolate_da_bwd")
+        return (dattr.reshape(ctx.attr_shape) if need_attr else None), drast, None, (drast_db if ctx.needs_input_grad[3] else None), None
 
 
 def interpolate(attr, rast, tri, rast_db=None, diff_attrs=None):
@@ -385,6 +393,8 @@ class _TextureMip(torch.autograd.Function):
         ctx.save_for_backward(tex_c, stack_c, uv_c, da_c, bias_c)
         ctx.modes = (filter_id, boundary_id, max_level)
         ctx.stack_shape = tuple(stack.shape)
+        ctx.level_grads = (uv_da is not None and uv_da.requires_grad, bias is not None and bias.requires_grad)
+        ctx.in_shapes = (None if uv_da is None else tuple(uv_da.shape), None if bias is None else tuple(bias.shape))
         return out
 
     @staticmethod
@@ -397,10 +407,17 @@ class _TextureMip(torch.autograd.Function):
         with torch.cuda.device(dev):
             dtex, duv = torch.empty_like(tex), torch.empty_like(uv)
             dstack = torch.empty(ctx.stack_shape, dtype=torch.float32, device=dev)
+            # the pixel differentials and the level bias steer the level: 'linear-mipmap-linear' has a gradient w.r.t. both (the dependency propagates it)
+            dda = torch.empty((B, H, W, 4), dtype=torch.float32, device=dev) if ctx.level_grads[0] else None
+            dbias = torch.empty((B, H, W), dtype=torch.float32, device=dev) if ctx.level_grads[1] else None
             _h.check(lib.c3d_mesh_texture_mip_bwd(_h.ptr(tex), _h.ptr(stack), Bt, _h.ptr(uv), _h.ptr(da), _h.ptr(bias), _h.ptr(_h.f32c(dy)),
                                                   B, H, W, Ht, Wt, C, ctx.modes[0], ctx.modes[1], ctx.modes[2], _h.ptr(dtex),
-                                                  _h.ptr(dstack if dstack.numel() else None), _h.ptr(duv), _h.stream(dev)), "c3d_mesh_texture_mip_bwd")
-        return dtex, dstack, duv, None, None, None, None, None
+                                                  _h.ptr(dstack if dstack.numel() else None), _h.ptr(duv), _h.ptr(dda), _h.ptr(dbias), _h.stream(dev)), "c3d_mesh_texture_mip_bwd")
+        if dda is not None:
+            dda = dda.reshape(ctx.in_shapes[0])
+        if dbias is not None:
+            dbias = dbias.reshape(ctx.in_shapes[1])
+        return dtex, dstack, duv, dda, dbias, None, None, None
 
 
 def _mip_stack(tex, mip, max_mip_level):

@@ -66,6 +66,13 @@ int c3d_mesh_interpolate_bwd(const float* attr, int32_t Ba, const float* rast, c
                              int32_t B, int32_t V, int32_t A, int32_t H, int32_t W, float* dattr, float* drast,
                              c3d_stream_t stream);
 
+/* backward of interpolate's pixel differentials out_da (what a mip-mapped texture() hands back as d uv_da): dout_da [B,H,W,2 n_diff] ->
+ * dattr [Ba,V,A] ADDED to (call after c3d_mesh_interpolate_bwd; NULL = not wanted), drast_db [B,H,W,4] written in full.  (rasterize does not
+ * propagate drast_db further: grad_db of the dependency's rasterize is not built.) */
+int c3d_mesh_interpolate_da_bwd(const float* attr, int32_t Ba, const float* rast, const int32_t* tri, const float* rast_db,
+                                const int32_t* diff_attrs, int32_t n_diff, const float* dout_da, int32_t B, int32_t V, int32_t A,
+                                int32_t H, int32_t W, float* dattr, float* drast_db, c3d_stream_t stream);
+
 /* texture: tex [Bt,Ht,Wt,C], Bt in {1,B}; uv [B,H,W,2]; filter 0 = nearest, 1 = linear; boundary 0 = wrap, 1 = clamp */
 int c3d_mesh_texture_fwd(const float* tex, int32_t Bt, const float* uv, int32_t B, int32_t H, int32_t W, int32_t Ht,
                          int32_t Wt, int32_t C, int32_t filter, int32_t boundary, float* out, c3d_stream_t stream);
@@ -92,11 +99,14 @@ int c3d_mesh_mip_build_bwd(float* dstack, int32_t Bt, int32_t Ht, int32_t Wt, in
 int c3d_mesh_texture_mip_fwd(const float* tex, const float* stack, int32_t Bt, const float* uv, const float* uv_da,
                              const float* mip_level_bias, int32_t B, int32_t H, int32_t W, int32_t Ht, int32_t Wt, int32_t C,
                              int32_t filter, int32_t boundary, int32_t max_mip_level, float* out, c3d_stream_t stream);
-/* dtex (level-0 taps) and dstack (levels >= 1) accumulated; duv [B,H,W,2] written in full; uv_da / bias receive no gradient */
+/* dtex (level-0 taps) and dstack (levels >= 1) accumulated; duv [B,H,W,2] written in full.  d_uv_da [B,H,W,4] / d_bias [B,H,W] (each may be NULL;
+ * written in full): gradients w.r.t. the pixel differentials and the level bias -- 'linear-mipmap-linear' blends two levels by the fraction of the
+ * level, so d out / d level = sample(level + 1) - sample(level) where the level is not clamped; zero for 'linear-mipmap-nearest'
+ * (the dependency's texture() propagates both: nvdiffrast/torch/ops.py texture, filter_mode 'linear-mipmap-linear'). */
 int c3d_mesh_texture_mip_bwd(const float* tex, const float* stack, int32_t Bt, const float* uv, const float* uv_da,
                              const float* mip_level_bias, const float* dy, int32_t B, int32_t H, int32_t W, int32_t Ht, int32_t Wt,
                              int32_t C, int32_t filter, int32_t boundary, int32_t max_mip_level, float* dtex, float* dstack, float* duv,
-                             c3d_stream_t stream);
+                             float* d_uv_da, float* d_bias, c3d_stream_t stream);
 
 /* antialias: scratch = edge hash of the topology.  c3d_mesh_antialias_build_topology fills it from `tri` (the dependency's
  * antialias_construct_topology_hash); it stays valid for as long as `tri` is unchanged and is shared by forward and backward. */

@@ -269,6 +269,30 @@ void mesh_interpolate_fwd(const real *attr, int Ba, const real *rast, const int3
         }
 }
 /* dattr [Ba,V,A] and drast [B,H,W,4] zero-initialised by the caller */
+/* backward of the pixel differentials interpolate() returns: out_da[k] = (ds/du * du/dX + ds/dv * dv/dX, ds/du * du/dY + ds/dv * dv/dY) with
+ * ds/du = a0 - a2, ds/dv = a1 - a2 for attribute diff[k].  dout_da [B,H,W,2 nd] -> dattr [Ba,V,A] (accumulated), drast_db [B,H,W,4] (written in full). */
+void mesh_interpolate_da_bwd(const real *attr, int Ba, const real *rast, const int32_t *tri, const real *rast_db, const int32_t *diff, int nd,
+                             const real *dout_da, int B, int V, int A, int H, int W, real *dattr, real *drast_db) {
+    size_t P = (size_t)H * W;
+    for (int b = 0; b < B; b++) for (size_t pid = 0; pid < P; pid++) {
+        size_t o = (size_t)b * P + pid;
+        real *gdb = drast_db + 4 * o;
+        gdb[0] = gdb[1] = gdb[2] = gdb[3] = 0;
+        int t = (int)rast[4 * o + 3] - 1;
+        if (t < 0) continue;
+        size_t ab = (size_t)(Ba > 1 ? b : 0) * V * A;
+        const int32_t *vi = tri + 3 * (size_t)t;
+        const real *db = rast_db + 4 * o;
+        for (int k = 0; k < nd; k++) {
+            int a = diff[k];
+            real gx = dout_da[(o * nd + k) * 2], gy = dout_da[(o * nd + k) * 2 + 1];
+            real dsdu = attr[ab + (size_t)vi[0] * A + a] - attr[ab + (size_t)vi[2] * A + a], dsdv = attr[ab + (size_t)vi[1] * A + a] - attr[ab + (size_t)vi[2] * A + a];
+            real g_dsdu = gx * db[0] + gy * db[1], g_dsdv = gx * db[2] + gy * db[3];
+            dattr[ab + (size_t)vi[0] * A + a] += g_dsdu; dattr[ab + (size_t)vi[1] * A + a] += g_dsdv; dattr[ab + (size_t)vi[2] * A + a] -= g_dsdu + g_dsdv;
+            gdb[0] += gx * dsdu; gdb[1] += gy * dsdu; gdb[2] += gx * dsdv; gdb[3] += gy * dsdv;
+        }
+    }
+}
 void mesh_interpolate_bwd(const real *attr, int Ba, const real *rast, const int32_t *tri, const real *dy, int B, int V, int A, int H, int W,
                           real *dattr, real *drast) {
     size_t P = (size_t)H * W;
@@ -483,9 +507,34 @@ int mesh_texture_mip_fwd(const real *tex, const real *stack, int Bt, const real 
     }
     return 0;
 }
-/* dtex [Bt,Ht,Wt,C], dstack [Bt,total,C], duv [B,H,W,2]: zero-initialised by the caller */
+/* d(level)/d(uv_da) of mip_select where the level is strictly inside (0, L) before clamping: level = log2(major)/2 + bias with major the larger
+ * eigenvalue of J J^T.  gda[4] receives dlevel times that derivative; returns 1 when the level is inside (the bias then receives dlevel itself). */
+static int mip_level_grad(const real *da, const real *bias, int Ht, int Wt, int L, real dlevel, real *gda) {
+    real fl = 0, major = 1, A = 0, Bq = 0, Cq = 0, s = 0, dsdx = 0, dsdy = 0, dtdx = 0, dtdy = 0;
+    gda[0] = gda[1] = gda[2] = gda[3] = 0;
+    if (da) {
+        dsdx = da[0] * Wt; dsdy = da[1] * Wt; dtdx = da[2] * Ht; dtdy = da[3] * Ht;
+        A = dsdx * dsdx + dtdx * dtdx; Bq = dsdy * dsdy + dtdy * dtdy; Cq = dsdx * dsdy + dtdx * dtdy;
+        s = (real)sqrt((double)((real)0.25 * (A - Bq) * (A - Bq) + Cq * Cq));
+        major = (real)0.5 * (A + Bq) + s;
+        fl = (real)0.5 * (real)log2((double)major);
+    }
+    if (bias) fl += *bias;
+    if (!(fl > 0) || !(fl < (real)L)) return 0;            /* clamped (or NaN): the level does not move */
+    if (da) {
+        real gm = dlevel * (real)0.5 / (major * (real)0.6931471805599453);       /* d level / d major */
+        real t = s > 0 ? (real)0.25 * (A - Bq) / s : 0, gA = gm * ((real)0.5 + t), gB = gm * ((real)0.5 - t), gC = s > 0 ? gm * Cq / s : 0;
+        gda[0] = ((real)2 * dsdx * gA + dsdy * gC) * Wt; gda[1] = ((real)2 * dsdy * gB + dsdx * gC) * Wt;
+        gda[2] = ((real)2 * dtdx * gA + dtdy * gC) * Ht; gda[3] = ((real)2 * dtdy * gB + dtdx * gC) * Ht;
+    }
+    return 1;
+}
+/* dtex [Bt,Ht,Wt,C], dstack [Bt,total,C], duv [B,H,W,2]: zero-initialised by the caller.  dda [B,H,W,4] / dbias [B,H,W] (optional, written in full):
+ * gradients w.r.t. uv_da and mip_level_bias -- 'linear-mipmap-linear' blends two levels by the fraction of the level, so d out / d level =
+ * sample(level1) - sample(level0) wherever the two levels differ and the level is not clamped; zero for 'linear-mipmap-nearest'. */
 int mesh_texture_mip_bwd(const real *tex, const real *stack, int Bt, const real *uv, const real *uv_da, const real *bias, const real *dy,
-                         int B, int H, int W, int Ht, int Wt, int C, int filter, int boundary, int max_level, real *dtex, real *dstack, real *duv) {
+                         int B, int H, int W, int Ht, int Wt, int C, int filter, int boundary, int max_level, real *dtex, real *dstack, real *duv,
+                         real *dda, real *dbias) {
     if (boundary != 0 && boundary != 1) return -1;
     mip_t m; if (mip_info(Ht, Wt, max_level, &m)) return -1;
     size_t P = (size_t)H * W;
@@ -494,9 +543,12 @@ int mesh_texture_mip_bwd(const real *tex, const real *stack, int Bt, const real 
         int l1; real f;
         int l0 = mip_select(uv_da ? uv_da + 4 * o : NULL, bias ? bias + o : NULL, Ht, Wt, m.L, filter, &l1, &f);
         const real *g = dy + o * C;
+        real sdot[2] = {0, 0};                                      /* dy . sample(level k) */
+        int nlev = 1;
         for (int k = 0; k < 2; k++) {
             int l = k ? l1 : l0; real wl = k ? f : (real)1 - f;
             if (k && (l1 == l0 || f == 0)) break;
+            nlev = k + 1;
             int bt = Bt > 1 ? b : 0;
             const real *tb = mip_level_c(tex, stack, &m, l, bt, C);
             real *db = mip_level(dtex, dstack, &m, l, bt, C);
@@ -514,8 +566,16 @@ int mesh_texture_mip_bwd(const real *tex, const real *stack, int Bt, const real 
                 db[i01] += gc * ((real)1 - fu) * fv; db[i11] += gc * fu * fv;
                 gu += gc * ((tb[i10] - tb[i00]) * ((real)1 - fv) + (tb[i11] - tb[i01]) * fv);
                 gv += gc * ((tb[i01] - tb[i00]) * ((real)1 - fu) + (tb[i11] - tb[i10]) * fu);
+                real top = tb[i00] + fu * (tb[i10] - tb[i00]), bot = tb[i01] + fu * (tb[i11] - tb[i01]);
+                sdot[k] += g[c] * (top + fv * (bot - top));
             }
             duv[2 * o] += gu * wl_; duv[2 * o + 1] += gv * hl_;
+        }
+        if (dda || dbias) {
+            real gda[4] = {0, 0, 0, 0};
+            int inside = (filter == 3 && nlev == 2) ? mip_level_grad(uv_da ? uv_da + 4 * o : NULL, bias ? bias + o : NULL, Ht, Wt, m.L, sdot[1] - sdot[0], gda) : 0;
+            if (dda) for (int i = 0; i < 4; i++) dda[4 * o + i] = inside ? gda[i] : 0;
+            if (dbias) dbias[o] = inside ? sdot[1] - sdot[0] : 0;
         }
     }
     return 0;

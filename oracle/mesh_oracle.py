@@ -118,6 +118,21 @@ def interpolate_bwd(attr, rast, tri, dy, dtype=np.float32):
     return (dattr[0] if squeeze else dattr), drast
 
 
+def interpolate_da_bwd(attr, rast, tri, rast_db, diff_attrs, dout_da, dtype=np.float32):
+    """backward of interpolate()'s pixel differentials -> (dattr, drast_db)"""
+    lib = _lib(dtype)
+    attr, rast, tri, db, g = _a(attr, dtype), _a(rast, dtype), _a(tri, np.int32), _a(rast_db, dtype), _a(dout_da, dtype)
+    squeeze = attr.ndim == 2
+    if squeeze:
+        attr = attr[None]
+    Ba, V, A = attr.shape
+    B, H, W, _ = rast.shape
+    diff = np.arange(A, dtype=np.int32) if (isinstance(diff_attrs, str) and diff_attrs == "all") else _a(diff_attrs, np.int32)
+    dattr = np.zeros_like(attr); ddb = np.zeros_like(db)
+    lib.mesh_interpolate_da_bwd(_p(attr), I(Ba), _p(rast), _p(tri), _p(db), _p(diff), I(diff.shape[0]), _p(g), I(B), I(V), I(A), I(H), I(W), _p(dattr), _p(ddb))
+    return (dattr[0] if squeeze else dattr), ddb
+
+
 _FILTER = {"nearest": 0, "linear": 1}
 _BOUNDARY = {"wrap": 0, "clamp": 1, "zero": 2}
 
@@ -193,9 +208,9 @@ def texture_mip(tex, uv, uv_da=None, mip_level_bias=None, stack=None, filter_mod
 
 
 def texture_mip_bwd(tex, uv, dy, uv_da=None, mip_level_bias=None, stack=None, filter_mode="linear-mipmap-linear", boundary_mode="wrap",
-                    max_mip_level=None, dtype=np.float32):
-    """-> dtex (level-0 taps only), dstack (levels >= 1), duv.  The gradient of the base texture of an internally built pyramid is
-    dtex + mip_build_bwd(dstack)."""
+                    max_mip_level=None, dtype=np.float32, level_grads=False):
+    """-> dtex (level-0 taps only), dstack (levels >= 1), duv [, d uv_da, d mip_level_bias with level_grads=True].  The gradient of the base texture
+    of an internally built pyramid is dtex + mip_build_bwd(dstack)."""
     lib = _lib(dtype)
     tex, uv, dy = _a(tex, dtype), _a(uv, dtype), _a(dy, dtype)
     Bt, Ht, Wt, Cc = tex.shape
@@ -204,10 +219,12 @@ def texture_mip_bwd(tex, uv, dy, uv_da=None, mip_level_bias=None, stack=None, fi
     da = None if uv_da is None else _a(uv_da, dtype)
     bias = None if mip_level_bias is None else _a(mip_level_bias, dtype)
     dtex = np.zeros_like(tex); dstack = np.zeros_like(stack); duv = np.zeros_like(uv)
+    dda = np.zeros((B, H, W, 4), dtype) if level_grads else None
+    dbias = np.zeros((B, H, W), dtype) if level_grads else None
     assert lib.mesh_texture_mip_bwd(_p(tex), _p(stack), I(Bt), _p(uv), _p(da), _p(bias), _p(dy), I(B), I(H), I(W), I(Ht), I(Wt), I(Cc),
                                     I(_MIP_FILTER[filter_mode]), I(_BOUNDARY[boundary_mode]), I(-1 if max_mip_level is None else max_mip_level),
-                                    _p(dtex), _p(dstack), _p(duv)) == 0
-    return dtex, dstack, duv
+                                    _p(dtex), _p(dstack), _p(duv), _p(dda), _p(dbias)) == 0
+    return (dtex, dstack, duv, dda, dbias) if level_grads else (dtex, dstack, duv)
 
 
 def antialias(color, rast, pos, tri, dtype=np.float32):

@@ -278,6 +278,58 @@ def test_mip_gradients_by_finite_differences(boundary, filter_mode):
         assert abs(v_ - dstack2.reshape(-1)[i]) < 1e-8
 
 
+def test_interpolate_pixel_differentials_backward_by_finite_differences():
+    """out_da = interpolate(attr, rast, tri, rast_db, diff_attrs)[1] is bilinear in (attr, rast_db): its backward against central differences"""
+    rng = np.random.default_rng(2)
+    pos, tri = _quad(z=0.1)
+    rast, rast_db = M.rasterize(pos, tri, (9, 11), dtype=np.float64)
+    attr = rng.normal(size=(4, 3))
+    db = rast_db + 0.01 * rng.normal(size=rast_db.shape)
+    diff = [2, 0]
+    _, oda = M.interpolate(attr, rast, tri, db, diff, dtype=np.float64)
+    g = rng.normal(size=oda.shape)
+    dattr, ddb = M.interpolate_da_bwd(attr, rast, tri, db, diff, g, dtype=np.float64)
+    num = _fd(lambda a_: M.interpolate(a_, rast, tri, db, diff, dtype=np.float64)[1], attr.copy(), g, 1e-6, range(attr.size))
+    for i, v_ in num.items():
+        assert abs(v_ - dattr.reshape(-1)[i]) < 1e-7 * max(1.0, abs(v_)), (i, v_, dattr.reshape(-1)[i])
+    num = _fd(lambda d_: M.interpolate(attr, rast, tri, d_, diff, dtype=np.float64)[1], db.copy(), g, 1e-6, range(0, db.size, 7))
+    for i, v_ in num.items():
+        assert abs(v_ - ddb.reshape(-1)[i]) < 1e-7 * max(1.0, abs(v_)), (i, v_, ddb.reshape(-1)[i])
+    assert np.abs(dattr[:, 1]).sum() == 0                        # attribute 1 has no differential requested
+
+
+def test_mip_level_gradients_by_finite_differences():
+    """gradients w.r.t. uv_da and mip_level_bias (consumers that hand the rasterizer's pixel differentials to a mip-mapped fetch:
+    Gen_3D_Modules/Hunyuan3D_V2/hy3dgen/texgen/differentiable_renderer/mesh_render.py:363, Hunyuan3D_2_1/hy3dpaint/DifferentiableRenderer/MeshRender.py:332).
+    'linear-mipmap-linear' blends two levels by the fraction of the level: d out / d level = sample(level + 1) - sample(level) wherever the level is
+    not clamped; the level depends on uv_da through the major axis of the pixel footprint and on the bias directly.  Central differences in float64;
+    'linear-mipmap-nearest' and clamped levels have zero gradient."""
+    rng = np.random.default_rng(8)
+    Ht, Wt, H, W = 16, 32, 7, 6
+    tex = rng.normal(size=(1, Ht, Wt, 3)); uv = rng.uniform(0.0, 1.0, size=(1, H, W, 2))
+    da = rng.normal(size=(1, H, W, 4)) * 0.12
+    da[0, 0, 0] = 1e-4 * rng.normal(size=4)                    # level clamped at 0
+    da[0, 0, 1] = 50.0 * rng.normal(size=4)                    # level clamped at L
+    bias = rng.uniform(-0.3, 0.3, size=(1, H, W))
+    for use_da, use_bias in ((True, True), (True, False), (False, True)):
+        kw = dict(uv_da=da if use_da else None, mip_level_bias=(bias + (0.0 if use_da else 1.7)) if use_bias else None, filter_mode="linear-mipmap-linear", boundary_mode="wrap", dtype=np.float64)
+        out = M.texture_mip(tex, uv, **kw); g = rng.normal(size=out.shape)
+        _, _, _, dda, dbias = M.texture_mip_bwd(tex, uv, g, level_grads=True, **kw)
+        if use_da:
+            assert np.abs(dda).sum() > 0 and (dda[0, 0, 0] == 0).all() and (dda[0, 0, 1] == 0).all()
+            num = _fd(lambda d_: M.texture_mip(tex, uv, **dict(kw, uv_da=d_)), da.copy(), g, 1e-7, range(8, da.size, 3))
+            bad = sum(abs(v_ - dda.reshape(-1)[i]) > 1e-5 * max(1.0, abs(v_)) for i, v_ in num.items())
+            assert bad <= 2, bad                                # a central difference that straddles an integer level sees both slopes
+        if use_bias:
+            b0 = kw["mip_level_bias"]
+            num = _fd(lambda b_: M.texture_mip(tex, uv, **dict(kw, mip_level_bias=b_)), b0.copy(), g, 1e-7, range(2, b0.size, 2))
+            bad = sum(abs(v_ - dbias.reshape(-1)[i]) > 1e-5 * max(1.0, abs(v_)) for i, v_ in num.items())
+            assert bad <= 2 and np.abs(dbias).sum() > 0, bad
+    kw = dict(uv_da=da, mip_level_bias=bias, filter_mode="linear-mipmap-nearest", boundary_mode="wrap", dtype=np.float64)
+    _, _, _, dda, dbias = M.texture_mip_bwd(tex, uv, rng.normal(size=(1, H, W, 3)), level_grads=True, **kw)
+    assert (dda == 0).all() and (dbias == 0).all()
+
+
 # ------------------------------------------------------------------------------------------------ depth peeling
 def test_depth_peeling_known_answers():
     near, tri = _quad(z=-0.5)

@@ -104,6 +104,50 @@ def test_trilinear_forward_and_gradients(gpu, C, Bt, boundary):
 
 
 @pytest.mark.gpu
+def test_gradients_wrt_uv_da_mip_level_bias_and_through_out_da(gpu):
+    """'linear-mipmap-linear' propagates to uv_da and mip_level_bias (d out / d level = sample(level + 1) - sample(level) where the level is
+    not clamped), and interpolate() passes what arrives at its pixel differentials on to the attributes and to rast_db -- the chain the reference's
+    texture bakers build (Gen_3D_Modules/Hunyuan3D_V2/hy3dgen/texgen/differentiable_renderer/mesh_render.py:363: texture(tex, uv, uv_da, 'linear-mipmap-linear')
+    behind interpolate(uv, rast, tri, rast_db, diff_attrs='all')).  HIP through nvdiffrast.torch against the float64 oracle."""
+    import nvdiffrast.torch as dr
+    rng = np.random.default_rng(31)
+    tex, uv, da, bias = _inputs(rng, 1, 2, 32, 64, 3, 37, 45)
+    tt, tu, tda, tb = T(tex, grad=True), T(uv, grad=True), T(da, grad=True), T(bias, grad=True)
+    out = dr.texture(tt, tu, uv_da=tda, mip_level_bias=tb)
+    g = rng.normal(size=out.shape).astype(np.float32)
+    (out * T(g)).sum().backward()
+    _, _, duv, dda, dbias = M.texture_mip_bwd(tex, uv, g, da, bias, dtype=np.float64, level_grads=True)
+    assert np.abs(dda).sum() > 0 and np.abs(dbias).sum() > 0
+    # a pixel whose float32 level sits within rounding of an integer takes the other pair of levels: allow a handful of such pixels
+    for got, ref in ((tda.grad.cpu().numpy(), dda), (tb.grad.cpu().numpy(), dbias)):
+        err = np.abs(got - ref)
+        tol = GRAD_REL * np.abs(ref).max()
+        assert (err > tol).sum() <= 4, int((err > tol).sum())
+    assert rel_err(tu.grad.cpu().numpy(), duv) <= GRAD_REL
+    # nearest-level mode: no level gradient
+    tda2, tb2 = T(da, grad=True), T(bias, grad=True)
+    (dr.texture(T(tex), T(uv), uv_da=tda2, mip_level_bias=tb2, filter_mode="linear-mipmap-nearest") * T(g)).sum().backward()
+    assert float(tda2.grad.abs().max()) == 0.0 and float(tb2.grad.abs().max()) == 0.0
+    # interpolate: out_da -> attributes and rast_db, on a rasterized mesh
+    v, f, vt, _ = S.make_uv_sphere(12, 18)
+    pos, _, _ = S.mesh_clip_positions(v, 20.0, 40.0, 2.2, 96, 80)
+    ctx = dr.RasterizeCudaContext(device="cuda")
+    rast, rast_db = dr.rasterize(ctx, T(pos), T(f, dtype=torch.int32), (80, 96))
+    attr = np.concatenate([vt, rng.normal(size=(vt.shape[0], 1)).astype(np.float32)], 1)            # 3 attributes, differentials of the first two
+    ta = T(attr, grad=True)
+    db = rast_db.detach().clone().requires_grad_(True)
+    o, o_da = dr.interpolate(ta, rast, T(f, dtype=torch.int32), rast_db=db, diff_attrs=[0, 1])
+    g1, g2 = rng.normal(size=tuple(o.shape)).astype(np.float32), rng.normal(size=tuple(o_da.shape)).astype(np.float32)
+    ((o * T(g1)).sum() + (o_da * T(g2)).sum()).backward()
+    r_np, db_np = rast.detach().cpu().numpy(), rast_db.detach().cpu().numpy()
+    d1, _ = M.interpolate_bwd(attr, r_np, f, g1, dtype=np.float64)
+    d2, ddb = M.interpolate_da_bwd(attr, r_np, f, db_np, [0, 1], g2, dtype=np.float64)
+    assert np.abs(d2).sum() > 0 and np.abs(ddb).sum() > 0
+    assert rel_err(ta.grad.cpu().numpy(), d1 + d2) <= GRAD_REL
+    assert rel_err(db.grad.cpu().numpy(), ddb) <= GRAD_REL
+
+
+@pytest.mark.gpu
 def test_nearest_level_mode_prebuilt_and_custom_stacks(gpu):
     import nvdiffrast.torch as dr
     rng = np.random.default_rng(20)
