@@ -671,7 +671,7 @@ __device__ __forceinline__ int mip_select(const float4* __restrict__ da, const f
     f = fl - (float)l0;
     return l0;
 }
-// d(level) / d(uv_da) where the level lies strictly inside (0, L) before clamping (mirror of mip_select; oracle: mip_level_grad in mesh_oracle.c).
+// d(level) / d(uv_da) where the level lies strictly inside (0, L) before clamping (mirror of mip_select).
 // -> true when inside: gda = dlevel * d level / d uv_da, and the bias receives dlevel itself.
 __device__ __forceinline__ bool mip_level_grad(const float4* __restrict__ da, const float* __restrict__ bias, long long gid, int Ht, int Wt, int L, float dlevel, float4& gda) {
     float fl = 0.f, major = 1.f, A = 0.f, Bq = 0.f, Cq = 0.f, sq = 0.f, dsdx = 0.f, dsdy = 0.f, dtdx = 0.f, dtdy = 0.f;
