@@ -192,9 +192,21 @@ class DiffRastRenderer(nn.Module):
         pose_inv_np = np.linalg.inv(pose_np).astype(np.float32)
         proj_np = proj.astype(np.float32)
         fused = mesh.v.is_cuda and ssaa == 1 and self.fused_glue
-        if fused and self.fused_view and texture_filter == 'linear':
+        if mesh.v.is_cuda and self.fused_glue and self.fused_view and texture_filter == 'linear':
             # the fused view adds the offsets inside its transform kernel; `v` (one more launch and autograd node per view) only exists if depth / normal are read
-            return self._render_fused_view(None, pose_np, pose_inv_np, proj_np, h, w, bg_color, optional_render_types)
+            res = self._render_fused_view(None, pose_np, pose_inv_np, proj_np, h, w, bg_color, optional_render_types)
+            if ssaa == 1:
+                return res
+            # super-sampling (reference :142-149): the view runs at the super-sampled size -- still ONE library call each way -- and image / alpha (and,
+            # on demand, depth / normal / viewcos) are brought down with the reference's bilinear scale_img_hwc.  The reference scales the composite and
+            # clamps afterwards; composite and scaled composite of values in [0, 1] stay in [0, 1], the fused view's clamp before the scaling is the same image.
+            out = LazyResults()
+            out['image'] = scale_img_hwc(res['image'], (h0, w0)).clamp(0, 1)
+            out['alpha'] = scale_img_hwc(res['alpha'], (h0, w0))
+            for k in ('depth', 'normal', 'viewcos'):
+                if k in res:
+                    out.defer(k, (lambda kk: (lambda: scale_img_hwc(res[kk], (h0, w0))))(k))
+            return out
         v = mesh.v + self.v_offsets if self.train_geo else mesh.v
         mats = torch.from_numpy(np.stack((pose_np, pose_inv_np, proj_np, proj_np @ pose_inv_np))).to(v.device)
         pose, pose_inv, proj, clip_from_world = mats[0], mats[1], mats[2], mats[3]

@@ -582,6 +582,24 @@ def test_renderer_fused_glue_equals_torch_chain():
     (o1["image"] * gi).sum().backward(); (o2["image"] * gi).sum().backward()
     assert (o1["image"] - o2["image"]).abs().max().item() <= 2e-3 and rel_err(r.raw_albedo.grad.cpu().numpy(), r2.raw_albedo.grad.cpu().numpy()) <= GRAD_REL
     assert r.v_offsets.grad is None or r.v_offsets.grad.abs().max().item() == 0
+    # super-sampling (reference diff_mesh_renderer.py:14-36,142-149): the fused view at the super-sampled size + the reference's bilinear down-scaling,
+    # against the torch chain; ssaa = 1.5 makes the super-sampled size (rounded up to a multiple of 8) a non-integer multiple of the output size
+    h0, w0 = 72, 96
+    cam2 = OrbitCamera(w0, h0, fovy=49.1)
+    g2 = torch.tensor(rng.normal(size=(h0, w0, 3)).astype(np.float32), device="cuda")
+    for ssaa in (2, 1.5):
+        res = []
+        for fv in (True, False):
+            r = DiffRastRenderer(_torch_mesh(), force_cuda_rast=True).cuda()
+            r.train_geo, r.fused_view, r.fused_glue = True, fv, fv
+            o = r.render(pose, cam2.perspective, h0, w0, ssaa=ssaa, bg_color=bg)
+            ((o["image"] * g2).sum() + o["alpha"].sum()).backward()
+            res.append((o["image"].detach(), o["alpha"].detach(), o["depth"].detach(), o["normal"].detach(), r.raw_albedo.grad.clone(), r.v_offsets.grad.clone()))
+        a, b = res
+        assert a[0].shape == (h0, w0, 3) and a[1].shape == (h0, w0, 1) and a[2].shape == b[2].shape and a[3].shape == b[3].shape
+        for x, y, name in zip(a[:4], b[:4], ("image", "alpha", "depth", "normal")):
+            assert (x - y).abs().mean().item() <= 1e-5 and (x - y).abs().max().item() <= 2e-3, (ssaa, name)
+        assert rel_err(a[4].cpu().numpy(), b[4].cpu().numpy()) <= GRAD_REL and rel_err(a[5].cpu().numpy(), b[5].cpu().numpy()) <= 5e-3, ssaa
 
 
 def test_other_in_tree_consumers_op_sequences():
