@@ -16,7 +16,7 @@ void c3d_set_error(const char* fmt, ...) {
 
 // msssim.hip: out_word += va + vb * mean MS-SSIM(x, y_eff), dL_dy (+)= grad_scale * d mean / dy
 int ms_value_grad(const float* x, const float* y, const float* mask, int clamp_y, int B, int C, int H, int W, float grad_scale, int accumulate, float* dL_dy,
-                  float va, float vb, float* ms_out, void* workspace, hipStream_t s);
+                  float va, float vb, float* ms_out, void* workspace, hipStream_t s, int store_value = 0);
 static int tile_sort_bits(int tiles) {
     int bits = 0;
     while ((1ll << bits) < (long long)tiles) bits++;
@@ -274,7 +274,7 @@ static void carve_step(char* base, int N, int H, int W, long long cap, StepWs& w
     w.dmeans2D = (float*)take(12 * n);
     w.gcol = (float*)take(12 * n);
     w.ms_ws = take(c3d_msssim_workspace_bytes(1, 3, H, W));       // MS-SSIM term of the pixel loss (w_ssim != 0)
-    w.tile_loss = (float*)take(4 * (size_t)(((W + C3D_TILE_X - 1) / C3D_TILE_X) * ((H + C3D_TILE_Y - 1) / C3D_TILE_Y)));   // per-tile partial sums of the pixel loss
+    w.tile_loss = (float*)take(4 * (size_t)(((W + C3D_TILE_X - 1) / C3D_TILE_X) * ((H + C3D_TILE_Y - 1) / C3D_TILE_Y) + 1));   // per-tile partial sums of the pixel loss + one slot for the view's MS-SSIM term
     w.bytes = off;
 }
 
@@ -287,6 +287,7 @@ struct LanePool {
     // forward-only rendering in groups of L views: a projection stream running two groups ahead of the lanes (render_views_grouped)
     hipStream_t pre; hipEvent_t pre_done[2], lane_done[2][C3D_MAX_LANES];
     hipEvent_t bin_done[16];      // binning chains running ahead of the compositing lanes (train_views): view v -> bin_done[v % 16]
+    std::mutex busy;              // held from a call's fork to its join: two host threads (or two step objects) on one device take turns instead of re-recording each other's events
 };
 LanePool g_lanes[16];
 std::mutex g_lane_mu;
@@ -315,15 +316,21 @@ int lane_pool(LanePool** out) {
 }
 struct Lanes {
     int L = 1; LanePool* lp = nullptr; hipStream_t s0 = nullptr; hipStream_t ls[C3D_MAX_LANES];
+    bool locked = false;
     int fork(hipStream_t caller, int lanes, int V) {
         s0 = caller; L = lanes < V ? lanes : V; ls[0] = s0;
+        if (lane_pool(&lp)) return -1;
+        lp->busy.lock(); locked = true;           // the pool's streams and events are this call's until join()
         if (L > 1) {
-            if (lane_pool(&lp)) return -1;
-            C3D_CHECK(hipEventRecord(lp->fork, s0));
-            for (int l = 1; l < L; l++) { ls[l] = lp->st[l - 1]; C3D_CHECK(hipStreamWaitEvent(ls[l], lp->fork, 0)); }
+            if (hipEventRecord(lp->fork, s0) != hipSuccess) { unlock(); c3d_set_error("lane fork failed"); return -1; }
+            for (int l = 1; l < L; l++) {
+                ls[l] = lp->st[l - 1];
+                if (hipStreamWaitEvent(ls[l], lp->fork, 0) != hipSuccess) { unlock(); c3d_set_error("lane fork failed"); return -1; }
+            }
         }
         return 0;
     }
+    void unlock() { if (locked && lp) { lp->busy.unlock(); locked = false; } }
     int need_pool() { return lp ? 0 : lane_pool(&lp); }
     // always executed, so the caller's stream never runs ahead of work queued on the lanes (also after an error)
     int join(const char* who) {
@@ -334,6 +341,7 @@ struct Lanes {
                 c3d_set_error("%s: lane join failed", who); rc = -1;
             }
         }
+        unlock();
         return rc;
     }
 };
@@ -346,13 +354,14 @@ int c3d_lanes_fork(hipStream_t caller, int lanes, int n_views, hipStream_t* stre
     if (ln.fork(caller, lanes, n_views)) return -1;
     for (int l = 0; l < ln.L; l++) streams[l] = ln.ls[l];
     *L = ln.L;
-    return 0;
+    return 0;                                      // the pool stays locked: c3d_lanes_join (same thread) releases it
 }
 int c3d_lanes_join(hipStream_t caller, const hipStream_t* streams, int L, const char* who) {
     Lanes ln;
     ln.s0 = caller; ln.L = L;
     for (int l = 0; l < L; l++) ln.ls[l] = streams[l];
-    if (L > 1 && ln.need_pool()) return -1;
+    if (ln.need_pool()) return -1;
+    ln.locked = true;                              // taken by the matching c3d_lanes_fork
     return ln.join(who);
 }
 }  // extern "C++"
@@ -520,7 +529,9 @@ int c3d_gs_train_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, c
             if (ssim) {
                 C3dProfScope ps(C3D_P_OTHER, s);
                 const float ws_ = loss->scale * loss->w_ssim;
-                if ((rc = ms_value_grad(target_color[v], w.color, cmk, 1, 1, 3, p.H, p.W, -ws_, fuse_loss ? 0 : 1, w.dcolor, ws_, -ws_, loss_out, w.ms_ws, s))) break;
+                // fused loss: the value goes into this view's own slot behind its tile partials (k_sum_tile_loss adds the views in order); otherwise to the shared word
+                const bool slot = fuse_loss && loss_out;
+                if ((rc = ms_value_grad(target_color[v], w.color, cmk, 1, 1, 3, p.H, p.W, -ws_, fuse_loss ? 0 : 1, w.dcolor, ws_, -ws_, slot ? w.tile_loss + tiles : loss_out, w.ms_ws, s, slot ? 1 : 0))) break;
             }
             // backward down to the per-(tile, splat) records of this view
             { C3dProfScope ps(C3D_P_COMPOSITE_BWD, s);
@@ -545,7 +556,7 @@ int c3d_gs_train_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, c
     if (fuse_loss && loss_out) {   // the views' per-tile partial sums of the pixel loss -> loss_out, in a fixed order
         StepWs wf; carve_step((char*)workspace, N, views[0].image_height, views[0].image_width, pair_capacity, wf);
         const int tiles = ((views[0].image_width + C3D_TILE_X - 1) / C3D_TILE_X) * ((views[0].image_height + C3D_TILE_Y - 1) / C3D_TILE_Y);
-        if (gs_launch_sum_tile_loss(wf.tile_loss, w0.bytes, V, tiles, loss_out, s0)) return -1;
+        if (gs_launch_sum_tile_loss(wf.tile_loss, w0.bytes, V, tiles + (loss->w_ssim != 0.f ? 1 : 0), loss_out, s0)) return -1;
     }
     if (accumulate & 2) return 0;   // the caller runs the per-Gaussian pass itself, range by range (c3d_gs_step_param_backward_range)
     return step_a8_all_views(views, V, N, w0.bytes, workspace, pair_capacity, means3D, f_dc, f_rest, scaling_raw, rotation_raw, dL_dmeans3D, dL_df_dc, dL_df_rest,

@@ -1718,7 +1718,7 @@ static int mesh_view_bwd(const c3d_mesh_view* d, const int32_t* f, const float* 
 // ------------------------------------------------------------------------------------------------------------------------------------------
 #include "../../include/c3d_loss.h"
 int ms_value_grad(const float* x, const float* y, const float* mask, int clamp_y, int B, int C, int H, int W, float grad_scale, int accumulate, float* dL_dy,
-                  float va, float vb, float* ms_out, void* workspace, hipStream_t s);
+                  float va, float vb, float* ms_out, void* workspace, hipStream_t s, int store_value = 0);
 
 // image [H,W,3] -> planes [3,H,W] (what the MS-SSIM kernels read)
 __global__ void __launch_bounds__(256) k_mesh_hwc_to_chw(const float* __restrict__ hwc, long long P, float* __restrict__ chw) {
@@ -1745,7 +1745,23 @@ __global__ void __launch_bounds__(256) k_mesh_pixel_loss(const float* __restrict
     l = c3d_wave_sum(l * w * inv);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = l;
     __syncthreads();
-    if (threadIdx.x == 0 && loss_out) atomicAdd(loss_out, red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0 && loss_out) loss_out[blockIdx.x] = red[0] + red[1] + red[2] + red[3];      // one partial per workgroup (k_mesh_sum_loss adds them in a fixed order)
+}
+#define MESH_LOSS_SLOTS 1032      // per view: <= 1024 workgroup partials of the pixel loss, then the view's MS-SSIM term at [1024]
+__global__ void __launch_bounds__(256) k_mesh_sum_loss(const float* __restrict__ parts, int n_views, int nblk, int ssim, float* __restrict__ loss_out) {
+    __shared__ float red[4];
+    float total = 0.f;
+    for (int v = 0; v < n_views; v++) {            // views in order, partials strided over the lanes, fixed tree: the same value every run
+        const float* q = parts + (size_t)v * MESH_LOSS_SLOTS;
+        float l = 0.f;
+        for (int i = threadIdx.x; i < nblk; i += 256) l += q[i];
+        l = c3d_wave_sum(l);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = l;
+        __syncthreads();
+        if (threadIdx.x == 0) total += (red[0] + red[1] + red[2] + red[3]) + (ssim ? q[1024] : 0.f);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(loss_out, total);      // ONE add per call
 }
 // out (+)= sum_k in_k, k in fixed order (lane buffers of the texture gradient; per-view buffers of the vertex gradient)
 struct MeshSumSrc { int n; const float* p[64]; };
@@ -1759,7 +1775,7 @@ __global__ void __launch_bounds__(256) k_mesh_sum(MeshSumSrc src, long long coun
 
 namespace {
 struct MeshStepLane { char* state; char* bwd; char* raster; float* image; float* alpha; float* image_chw; float* dssim; float* dimage; char* ms_ws; float* d_ra; };
-struct MeshStepWs { MeshStepLane lane[C3D_MAX_LANES]; float* d_v; size_t d_v_stride; size_t bytes; };
+struct MeshStepWs { MeshStepLane lane[C3D_MAX_LANES]; float* d_v; size_t d_v_stride; float* loss_part; size_t bytes; };
 void carve_mesh_step(char* base, int V, int T, int H, int W, int Ht, int Wt, int n_views, int lanes, MeshStepWs& w) {
     size_t off = 0;
     const size_t P = (size_t)H * W;
@@ -1775,6 +1791,7 @@ void carve_mesh_step(char* base, int V, int T, int H, int W, int Ht, int Wt, int
     }
     w.d_v_stride = c3d_align(12 * (size_t)(V > 0 ? V : 1));
     w.d_v = (float*)take(w.d_v_stride * (size_t)(n_views > 0 ? n_views : 1));
+    w.loss_part = (float*)take(sizeof(float) * MESH_LOSS_SLOTS * (size_t)(n_views > 0 ? n_views : 1));
     w.bytes = off;
 }
 }  // namespace
@@ -1807,6 +1824,7 @@ int c3d_mesh_train_views(const c3d_mesh_view* views, int32_t n_views, const floa
     const bool ssim = loss->w_ssim != 0.f;
     MESH_REQUIRE(!ssim || (d0.H > 160 && d0.W > 160), "c3d_mesh_train_views: the MS-SSIM term needs image sides > 160");
     const long long P = (long long)d0.H * d0.W;
+    const int nblk = c3d_cdiv(P, 256) < 1024 ? c3d_cdiv(P, 256) : 1024;
     const size_t ntex = 3 * (size_t)d0.Ht * d0.Wt;
     hipStream_t ls[C3D_MAX_LANES];
     int L = 1;
@@ -1821,6 +1839,7 @@ int c3d_mesh_train_views(const c3d_mesh_view* views, int32_t n_views, const floa
         MeshStepLane& q = w.lane[i % L];
         const c3d_mesh_view* d = &views[i];
         const float* mk = mask ? mask[i] : nullptr;
+        float* lp = w.loss_part + (size_t)i * MESH_LOSS_SLOTS;      // this view's loss partials: the value is summed in a fixed order after the join
         int rc = 0;
         do {
             if ((rc = c3d_mesh_view_fwd(d, v, v_offsets, f, vt, ft, raw_albedo, aa_topology, q.raster, q.state, q.image, q.alpha, (c3d_stream_t)s))) break;
@@ -1829,10 +1848,10 @@ int c3d_mesh_train_views(const c3d_mesh_view* views, int32_t n_views, const floa
                 if (ssim) {   // + scale * w_ssim * (1 - MS-SSIM(target m, image m)) of this view: value into loss_out, gradient (planes) into q.dssim
                     const float ws_ = loss->scale * loss->w_ssim;
                     hipLaunchKernelGGL(k_mesh_hwc_to_chw, dim3(c3d_cdiv(P, 256)), dim3(256), 0, s, q.image, P, q.image_chw);
-                    if ((rc = ms_value_grad(target_chw[i], q.image_chw, mk, 0, 1, 3, d->H, d->W, -ws_, 0, q.dssim, ws_, -ws_, loss_out, q.ms_ws, s))) break;
+                    if ((rc = ms_value_grad(target_chw[i], q.image_chw, mk, 0, 1, 3, d->H, d->W, -ws_, 0, q.dssim, ws_, -ws_, loss_out ? lp + 1024 : nullptr, q.ms_ws, s, 1))) break;
                 }
-                hipLaunchKernelGGL(k_mesh_pixel_loss, dim3((unsigned)(c3d_cdiv(P, 256) < 1024 ? c3d_cdiv(P, 256) : 1024)), dim3(256), 0, s, q.image, target_chw[i], mk, P,
-                                   loss->scale * loss->w_mse, ssim ? q.dssim : (const float*)nullptr, q.dimage, loss_out);
+                hipLaunchKernelGGL(k_mesh_pixel_loss, dim3((unsigned)nblk), dim3(256), 0, s, q.image, target_chw[i], mk, P,
+                                   loss->scale * loss->w_mse, ssim ? q.dssim : (const float*)nullptr, q.dimage, loss_out ? lp : (float*)nullptr);
             }
             float* dv = d_v_offsets ? (float*)((char*)w.d_v + (size_t)i * w.d_v_stride) : nullptr;
             if ((rc = mesh_view_bwd(d, f, vt, ft, raw_albedo, aa_topology, vertex_topology, q.bwd, q.state, q.dimage, nullptr, q.d_ra, dv, (c3d_stream_t)s, false))) break;
@@ -1851,6 +1870,7 @@ int c3d_mesh_train_views(const c3d_mesh_view* views, int32_t n_views, const floa
             for (int i = 0; i < n_views; i++) b.p[i] = (const float*)((const char*)w.d_v + (size_t)i * w.d_v_stride);
             hipLaunchKernelGGL(k_mesh_sum, dim3(c3d_cdiv(3ll * d0.V, 256)), dim3(256), 0, s0, b, 3ll * d0.V, accumulate, d_v_offsets);
         }
+        if (loss_out) hipLaunchKernelGGL(k_mesh_sum_loss, dim3(1), dim3(256), 0, s0, w.loss_part, n_views, nblk, ssim ? 1 : 0, loss_out);
     }
     C3D_LAUNCH_CHECK();
     return 0;

@@ -185,23 +185,26 @@ __global__ void __launch_bounds__(256) k_ms_finalize(MsFinal f, int P, float gra
             if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
             __syncthreads();
         }
-        v[l] = fmaxf(red[0] * f.inv_npix[l], 0.f);       // relu(mean)
+        { const float mean = red[0] * f.inv_npix[l]; v[l] = mean != mean ? mean : fmaxf(mean, 0.f); }      // relu(mean); a NaN mean stays NaN (a non-finite render must show in the loss)
         __syncthreads();
     }
     if (threadIdx.x == 0) {
         float ms = 1.f;
-        bool pos = true;
-        for (int l = 0; l < MS_LEVELS; l++) { pos = pos && v[l] > 0.f; ms *= powf(v[l], f.wts[l]); }
+        bool pos = true, bad = false;
+        for (int l = 0; l < MS_LEVELS; l++) { bad = bad || v[l] != v[l]; pos = pos && v[l] > 0.f; ms *= powf(v[l], f.wts[l]); }
         if (!pos) ms = 0.f;
+        if (bad) ms = __builtin_nanf("");
         ms_plane[plane] = ms;
-        for (int l = 0; l < MS_LEVELS; l++) g[(size_t)l * P + plane] = pos ? grad_scale * (f.wts[l] * ms / v[l]) * f.inv_npix[l] / (float)P : 0.f;
+        for (int l = 0; l < MS_LEVELS; l++) g[(size_t)l * P + plane] = bad ? ms : (pos ? grad_scale * (f.wts[l] * ms / v[l]) * f.inv_npix[l] / (float)P : 0.f);
     }
 }
-// value: out += a + b * mean(ms) (fixed-order mean; the add is atomic because several view lanes of a training step share one loss word)
-__global__ void k_ms_mean(const float* __restrict__ ms_plane, int P, float a, float b, float* __restrict__ out) {
+// value: out (+)= a + b * mean(ms), a fixed-order mean.  store = 1: the word is the caller's own slot (the fused training steps keep one slot per view and add the
+// views up in view order: the loss VALUE is then bit-reproducible like the gradients); store = 0: added atomically to a word other launches may add to as well.
+__global__ void k_ms_mean(const float* __restrict__ ms_plane, int P, float a, float b, float* __restrict__ out, int store) {
     float s = 0.f;
     for (int p = 0; p < P; p++) s += ms_plane[p];
-    atomicAdd(out, a + b * (s / (float)P));
+    const float val = a + b * (s / (float)P);
+    if (store) *out = val; else atomicAdd(out, val);
 }
 
 // backward of one level: gradient w.r.t. the level's y over the whole image (+ the pooled parent level's gradient)
@@ -325,7 +328,7 @@ MsWin ms_window() {
 }  // namespace
 
 int ms_value_grad(const float* x, const float* y, const float* mask, int clamp_y, int B, int C, int H, int W, float grad_scale, int accumulate, float* dL_dy,
-                  float va, float vb, float* ms_out, void* workspace, hipStream_t s);
+                  float va, float vb, float* ms_out, void* workspace, hipStream_t s, int store_value = 0);
 
 extern "C" {
 
@@ -344,7 +347,7 @@ int c3d_msssim_value_grad(const float* x, const float* y, const float* mask, int
 
 // out_word += va + vb * mean MS-SSIM  (va = 0, vb = 1: the plain value; the fused training step passes the loss term's weights)
 int ms_value_grad(const float* x, const float* y, const float* mask, int clamp_y, int B, int C, int H, int W, float grad_scale, int accumulate, float* dL_dy,
-                  float va, float vb, float* ms_out, void* workspace, hipStream_t s) {
+                  float va, float vb, float* ms_out, void* workspace, hipStream_t s, int store_value) {
     if (B <= 0 || C <= 0) return 0;
     if (!x || !y || !dL_dy || !workspace) { c3d_set_error("c3d_msssim_value_grad: NULL pointer"); return -1; }
     if ((H < W ? H : W) <= (2 * MS_R) * (1 << (MS_LEVELS - 1))) { c3d_set_error("c3d_msssim_value_grad: image sides must exceed %d for %d scales", (2 * MS_R) << (MS_LEVELS - 1), MS_LEVELS); return -1; }
@@ -379,7 +382,7 @@ int ms_value_grad(const float* x, const float* y, const float* mask, int clamp_y
     float* g = (float*)(ws + pl.off_g);
     float* msp = (float*)(ws + pl.off_ms);
     hipLaunchKernelGGL(k_ms_finalize, dim3(P), dim3(256), 0, s, fin, P, grad_scale, g, msp);
-    if (ms_out) hipLaunchKernelGGL(k_ms_mean, dim3(1), dim3(1), 0, s, msp, P, va, vb, ms_out);
+    if (ms_out) hipLaunchKernelGGL(k_ms_mean, dim3(1), dim3(1), 0, s, msp, P, va, vb, ms_out, store_value);
     for (int l = MS_LEVELS - 1; l >= 0; l--) {
         const MsLevel& L = pl.lv[l];
         const size_t val = (size_t)P * L.Hv * L.Wv;
