@@ -556,9 +556,14 @@ __device__ __forceinline__ bool tex_taps_shared(const uint32_t tk[4]) {
         for (int j = 0; j < 4; j++) share = share || nk[i] == tk[j];
     return 4 * __popcll(__ballot(share)) >= __popcll(__ballot(true));
 }
+// Fused-view extras (round 3; all NULL for the plain dr.texture backward):
+//   sig    the sigmoid output the fetched value went through (albedo = sigmoid(texture)): dy is multiplied by s (1 - s) on load (was its own pass over the image);
+//   rast / vt / ft / drast  interpolate's backward for the texture-coordinate attribute folded into the epilogue: drast = (duv . (vt0 - vt2), duv . (vt1 - vt2), 0, 0)
+//   written instead of duv (was a pass of its own).
+struct TexBwdFused { const float* sig; const float4* rast; const float2* vt; const int3* ft; float4* drast; };
 template <int C>
 __global__ void __launch_bounds__(256) k_tex_bwd_tiled(const float* __restrict__ tex, int Bt, const float2* __restrict__ uv, const float* __restrict__ dy,
-                                                        int H, int W, int Ht, int Wt, int boundary, float* __restrict__ dtex, float2* __restrict__ duv) {
+                                                        int H, int W, int Ht, int Wt, int boundary, float* __restrict__ dtex, float2* __restrict__ duv, TexBwdFused fz) {
     __shared__ uint32_t keys[TEXT_SLOTS];
     __shared__ float vals[TEXT_SLOTS][C];
     for (int i = threadIdx.x; i < TEXT_SLOTS; i += 256) {
@@ -582,7 +587,11 @@ __global__ void __launch_bounds__(256) k_tex_bwd_tiled(const float* __restrict__
         float g[C];
         bool any = false;
 #pragma unroll
-        for (int c = 0; c < C; c++) { g[c] = dy[gid * C + c]; any = any || g[c] != 0.f; }
+        for (int c = 0; c < C; c++) {
+            g[c] = dy[gid * C + c];
+            if (fz.sig) { const float sv = fz.sig[gid * C + c]; g[c] *= sv * (1.f - sv); }
+            any = any || g[c] != 0.f;
+        }
         float gu = 0.f, gv = 0.f;
 #pragma unroll
         for (int c = 0; c < C; c++) {
@@ -591,7 +600,18 @@ __global__ void __launch_bounds__(256) k_tex_bwd_tiled(const float* __restrict__
             gu += g[c] * ((t10 - t00) * (1.f - fv) + (t11 - t01) * fv);
             gv += g[c] * ((t01 - t00) * (1.f - fu) + (t11 - t10) * fu);
         }
-        duv[gid] = make_float2(gu * Wt, gv * Ht);
+        if (fz.drast) {      // k_interp_bwd for the two texture-coordinate attributes, same statements
+            const int t = (int)fz.rast[gid].w - 1;
+            float4 dr = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t >= 0) {
+                const int3 vi = fz.ft[t];
+                const float2 a0 = fz.vt[vi.x], a1 = fz.vt[vi.y], a2 = fz.vt[vi.z];
+                const float g0 = gu * Wt, g1 = gv * Ht;
+                dr.x = g0 * (a0.x - a2.x) + g1 * (a0.y - a2.y);
+                dr.y = g0 * (a1.x - a2.x) + g1 * (a1.y - a2.y);
+            }
+            fz.drast[gid] = dr;
+        } else duv[gid] = make_float2(gu * Wt, gv * Ht);
         const bool use_hash = tex_taps_shared(tk);
         if (any) {
 #pragma unroll
@@ -1116,8 +1136,15 @@ int c3d_mesh_rasterize_fwd(const float* pos, const int32_t* tri, int32_t B, int3
                            float* rast_db, c3d_stream_t stream) {
     return c3d_mesh_rasterize_peel_fwd(pos, tri, B, V, T, H, W, nullptr, scratch, rast, rast_db, stream);
 }
+// `resolve` = false: stop after the depth | id buffer is complete (the fused view resolves inside its own pixel pass)
+static int mesh_rasterize_impl(const float* pos, const int32_t* tri, int32_t B, int32_t V, int32_t T, int32_t H, int32_t W, const void* prev_scratch,
+                               void* scratch, float* rast, float* rast_db, c3d_stream_t stream, bool resolve);
 int c3d_mesh_rasterize_peel_fwd(const float* pos, const int32_t* tri, int32_t B, int32_t V, int32_t T, int32_t H, int32_t W, const void* prev_scratch,
                                 void* scratch, float* rast, float* rast_db, c3d_stream_t stream) {
+    return mesh_rasterize_impl(pos, tri, B, V, T, H, W, prev_scratch, scratch, rast, rast_db, stream, true);
+}
+static int mesh_rasterize_impl(const float* pos, const int32_t* tri, int32_t B, int32_t V, int32_t T, int32_t H, int32_t W, const void* prev_scratch,
+                               void* scratch, float* rast, float* rast_db, c3d_stream_t stream, bool resolve) {
     hipStream_t s = (hipStream_t)stream;
     const unsigned long long* peel = (const unsigned long long*)prev_scratch;   // the previous layer's depth|id words lead its scratch
     MESH_REQUIRE(prev_scratch != scratch || !scratch, "depth peeling needs two scratch buffers");
@@ -1138,7 +1165,7 @@ int c3d_mesh_rasterize_peel_fwd(const float* pos, const int32_t* tri, int32_t B,
         hipLaunchKernelGGL(k_ras_tri, dim3(c3d_cdiv((long long)B * T, 256)), dim3(256), 0, s, (const float4*)pos, (const int3*)tri, B, V, T, H, W, zbuf, queue, count, peel);
         hipLaunchKernelGGL(k_ras_big, dim3(2048), dim3(256), 0, s, (const float4*)pos, (const int3*)tri, V, T, H, W, zbuf, queue, count, peel);
     }
-    hipLaunchKernelGGL(k_ras_resolve, dim3(c3d_cdiv(BP, 256)), dim3(256), 0, s, (const float4*)pos, (const int3*)tri, B, V, H, W, zbuf, (float4*)rast, (float4*)rast_db);
+    if (resolve) hipLaunchKernelGGL(k_ras_resolve, dim3(c3d_cdiv(BP, 256)), dim3(256), 0, s, (const float4*)pos, (const int3*)tri, B, V, H, W, zbuf, (float4*)rast, (float4*)rast_db);
     C3D_LAUNCH_CHECK();
     return 0;
 }
@@ -1264,14 +1291,14 @@ int c3d_mesh_texture_fwd(const float* tex, int32_t Bt, const float* uv, int32_t 
     return 0;
 }
 static int mesh_texture_bwd(const float* tex, int32_t Bt, const float* uv, const float* dy, int32_t B, int32_t H, int32_t W, int32_t Ht, int32_t Wt, int32_t C,
-                            int32_t filter, int32_t boundary, float* dtex, float* duv, c3d_stream_t stream, bool zero_dtex);
+                            int32_t filter, int32_t boundary, float* dtex, float* duv, c3d_stream_t stream, bool zero_dtex, TexBwdFused fz = TexBwdFused{nullptr, nullptr, nullptr, nullptr, nullptr});
 int c3d_mesh_texture_bwd(const float* tex, int32_t Bt, const float* uv, const float* dy, int32_t B, int32_t H, int32_t W, int32_t Ht, int32_t Wt, int32_t C,
                          int32_t filter, int32_t boundary, float* dtex, float* duv, c3d_stream_t stream) {
     return mesh_texture_bwd(tex, Bt, uv, dy, B, H, W, Ht, Wt, C, filter, boundary, dtex, duv, stream, true);
 }
 // zero_dtex = false: the texel gradients are ADDED to what dtex holds (the multi-view step accumulates the views of a lane in one buffer)
 static int mesh_texture_bwd(const float* tex, int32_t Bt, const float* uv, const float* dy, int32_t B, int32_t H, int32_t W, int32_t Ht, int32_t Wt, int32_t C,
-                            int32_t filter, int32_t boundary, float* dtex, float* duv, c3d_stream_t stream, bool zero_dtex) {
+                            int32_t filter, int32_t boundary, float* dtex, float* duv, c3d_stream_t stream, bool zero_dtex, TexBwdFused fz) {
     hipStream_t s = (hipStream_t)stream;
     const long long P = (long long)H * W, BP = P * B;
     MESH_REQUIRE(Bt == 1 || Bt == B, "texture batch must be 1 or B");
@@ -1279,12 +1306,13 @@ static int mesh_texture_bwd(const float* tex, int32_t Bt, const float* uv, const
     C3dProfScope ps(C3D_P_MESH_TEXTURE_BWD, s);
     if ((long long)Bt * Ht * Wt * C > 0) { MESH_REQUIRE(dtex, "NULL dtex"); if (zero_dtex) C3D_CHECK(hipMemsetAsync(dtex, 0, sizeof(float) * (size_t)Bt * Ht * Wt * C, s)); }
     if (BP == 0 || C == 0) return 0;
-    MESH_REQUIRE(tex && uv && dy && duv, "NULL pointer");
+    MESH_REQUIRE(tex && uv && dy && (duv || fz.drast), "NULL pointer");
+    MESH_REQUIRE((!fz.sig && !fz.drast) || (filter == 1 && C == 3), "internal: the fused-view extras exist for the tiled 3-channel linear backward only");
     if (filter == 1 && (C == 1 || C == 3 || C == 4) && (long long)Ht * Wt < 0xFFFFFFFFll) {
         const dim3 grid(c3d_cdiv(W, 16), c3d_cdiv(H, 16), B);
-        if (C == 1) hipLaunchKernelGGL((k_tex_bwd_tiled<1>), grid, dim3(256), 0, s, tex, Bt, (const float2*)uv, dy, H, W, Ht, Wt, boundary, dtex, (float2*)duv);
-        else if (C == 3) hipLaunchKernelGGL((k_tex_bwd_tiled<3>), grid, dim3(256), 0, s, tex, Bt, (const float2*)uv, dy, H, W, Ht, Wt, boundary, dtex, (float2*)duv);
-        else hipLaunchKernelGGL((k_tex_bwd_tiled<4>), grid, dim3(256), 0, s, tex, Bt, (const float2*)uv, dy, H, W, Ht, Wt, boundary, dtex, (float2*)duv);
+        if (C == 1) hipLaunchKernelGGL((k_tex_bwd_tiled<1>), grid, dim3(256), 0, s, tex, Bt, (const float2*)uv, dy, H, W, Ht, Wt, boundary, dtex, (float2*)duv, fz);
+        else if (C == 3) hipLaunchKernelGGL((k_tex_bwd_tiled<3>), grid, dim3(256), 0, s, tex, Bt, (const float2*)uv, dy, H, W, Ht, Wt, boundary, dtex, (float2*)duv, fz);
+        else hipLaunchKernelGGL((k_tex_bwd_tiled<4>), grid, dim3(256), 0, s, tex, Bt, (const float2*)uv, dy, H, W, Ht, Wt, boundary, dtex, (float2*)duv, fz);
     } else {
         hipLaunchKernelGGL(k_tex_bwd, dim3(c3d_cdiv(BP, 256)), dim3(256), 0, s, tex, Bt, (const float2*)uv, dy, BP, P, Ht, Wt, C, filter, boundary, dtex, (float2*)duv);
     }
@@ -1509,6 +1537,49 @@ __global__ void __launch_bounds__(256) k_view_sigmoid_seed(float* __restrict__ a
     for (int c = 0; c < 3; c++) { const float s = 1.f / (1.f + __expf(-albedo[3 * i + c])); albedo[3 * i + c] = s; albedo_aa[3 * i + c] = s; }
     cov_aa[i] = rast[i].w > 0.f ? 1.f : 0.f;
 }
+// Round 3: ONE pixel pass for rasterize's resolve -> interpolate(uv) -> texture('linear', wrap) -> sigmoid -> antialias seeds, which were five passes through HBM
+// (k_ras_resolve 12.6 us + k_interp_fwd 11.6 + k_tex_fwd 12.1 + k_view_sigmoid_seed 10.5 per 1024^2 view, profiles/r02z_mesh_kernel_stats.csv).  Statement by
+// statement the arithmetic of those kernels (an empty pixel interpolates uv = (0, 0) and fetches there, exactly as the op sequence does: the antialias blend
+// across a silhouette reads it).
+__global__ void __launch_bounds__(256) k_view_pixel_fwd(const float4* __restrict__ pos, const int3* __restrict__ tri, const float2* __restrict__ vt, const int3* __restrict__ ft,
+                                                         const float* __restrict__ tex, int H, int W, int Ht, int Wt, const unsigned long long* __restrict__ zbuf,
+                                                         float4* __restrict__ rast, float4* __restrict__ rast_db, float2* __restrict__ texc, float* __restrict__ albedo0,
+                                                         float* __restrict__ albedo_aa, float* __restrict__ cov_aa) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long long)H * W) return;
+    const unsigned long long key = zbuf[gid];
+    float2 q = make_float2(0.f, 0.f);
+    float cov = 0.f;
+    if (key == MESH_EMPTY_KEY) {
+        rast[gid] = make_float4(0.f, 0.f, 0.f, 0.f);
+        rast_db[gid] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+        const int px = (int)(gid % W), py = (int)(gid / W);
+        const uint32_t t = (uint32_t)(key & 0xFFFFFFFFull);
+        const int3 vi = tri[t];
+        const float xs = 2.f / W, ys = 2.f / H;
+        const Frag f = mesh_shade(pos[vi.x], pos[vi.y], pos[vi.z], xs * ((float)px + 0.5f) - 1.f, ys * ((float)py + 0.5f) - 1.f, xs, ys);
+        const float u = fminf(fmaxf(f.b0, 0.f), 1.f), v = fminf(fmaxf(f.b1, 0.f), 1.f), w2 = 1.f - u - v;
+        rast[gid] = make_float4(u, v, fminf(fmaxf(f.zw, -1.f), 1.f), (float)(t + 1));
+        rast_db[gid] = make_float4(f.dudx, f.dudy, f.dvdx, f.dvdy);
+        const int3 ti = ft[t];
+        const float2 a0 = vt[ti.x], a1 = vt[ti.y], a2 = vt[ti.z];
+        q = make_float2(u * a0.x + v * a1.x + w2 * a2.x, u * a0.y + v * a1.y + w2 * a2.y);
+        cov = 1.f;
+    }
+    texc[gid] = q;
+    const float uu = q.x * Wt - 0.5f, vv = q.y * Ht - 0.5f;
+    const float fu0 = floorf(uu), fv0 = floorf(vv), fu = uu - fu0, fv = vv - fv0;
+    const int iu0 = wrapi((int)fu0, Wt, 0), iu1 = wrapi((int)fu0 + 1, Wt, 0), iv0 = wrapi((int)fv0, Ht, 0), iv1 = wrapi((int)fv0 + 1, Ht, 0);
+    const float *t00 = tex + ((size_t)iv0 * Wt + iu0) * 3, *t10 = tex + ((size_t)iv0 * Wt + iu1) * 3, *t01 = tex + ((size_t)iv1 * Wt + iu0) * 3, *t11 = tex + ((size_t)iv1 * Wt + iu1) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float top = t00[c] + fu * (t10[c] - t00[c]), bot = t01[c] + fu * (t11[c] - t01[c]);
+        const float sg = 1.f / (1.f + __expf(-(top + fv * (bot - top))));
+        albedo0[3 * gid + c] = sg; albedo_aa[3 * gid + c] = sg;
+    }
+    cov_aa[gid] = cov;
+}
 // both antialias calls of the view in one pass over the pixel pairs
 __global__ void __launch_bounds__(256) k_aa2_fwd(const float* __restrict__ albedo, const float4* __restrict__ rast, const float4* __restrict__ pos,
                                                   const int3* __restrict__ tri, const EdgeSlot* __restrict__ table, uint32_t mask, int H, int W,
@@ -1601,11 +1672,48 @@ __global__ void __launch_bounds__(256) k_view_shade_bwd(const float* __restrict_
     }
     dalpha[i] = (ar >= 0.f && ar <= 1.f) ? da : 0.f;
 }
+// Round 3: the training step's pixel loss (k_mesh_pixel_loss) and the shade backward in ONE pass: d/dimage never goes through HBM.
+// L_v = w * mean_{c,p} ((image - target) m)^2 (+ the MS-SSIM gradient planes, when there are any); one loss partial per workgroup.
+struct ViewLossIn { const float* image; const float* target_chw; const float* mask; const float* dssim_chw; float w; float* loss_part; };
+__global__ void __launch_bounds__(256) k_view_loss_shade_bwd(const float* __restrict__ albedo, const float* __restrict__ alpha, ViewBg bg, long long P, ViewLossIn li,
+                                                              float* __restrict__ dalbedo_aa, float* __restrict__ dalbedo0, float* __restrict__ dalpha) {
+    __shared__ float red[4];
+    float l = 0.f;
+    const float inv = 1.f / (3.f * (float)P);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (long long)gridDim.x * blockDim.x) {
+        const float m = li.mask ? li.mask[i] : 1.f;
+        const float ar = alpha[i], a = fminf(fmaxf(ar, 0.f), 1.f);
+        float da = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float d = (li.image[3 * i + c] - li.target_chw[c * P + i]) * m;
+            l += d * d;
+            const float dimg = 2.f * li.w * inv * d * m + (li.dssim_chw ? li.dssim_chw[c * P + i] : 0.f);
+            const float al = albedo[3 * i + c], val = a * al + (1.f - a) * bg.c[c];
+            const float g = (val >= 0.f && val <= 1.f) ? dimg : 0.f;
+            dalbedo_aa[3 * i + c] = g * a;
+            dalbedo0[3 * i + c] = g * a;
+            da += g * (al - bg.c[c]);
+        }
+        dalpha[i] = (ar >= 0.f && ar <= 1.f) ? da : 0.f;
+    }
+    l = c3d_wave_sum(l * li.w * inv);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = l;
+    __syncthreads();
+    if (threadIdx.x == 0 && li.loss_part) li.loss_part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
 __global__ void __launch_bounds__(256) k_view_sigmoid_bwd(const float* __restrict__ s, float* __restrict__ g, long long n) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { const float v = s[i]; g[i] *= v * (1.f - v); }
 }
 
+// C3D_MESH_PIXEL_FUSED = 1 (default): the fused pixel passes of the view (k_view_pixel_fwd; sigmoid' and interpolate-backward inside the texture backward) | 0: one
+// launch per op as in round 2 (tests compare the two)
+static bool view_pixel_fused() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("C3D_MESH_PIXEL_FUSED"); v = e ? atoi(e) != 0 : 1; }
+    return v != 0;
+}
 namespace {
 struct ViewState { float* vclip; float* rast; float* rast_db; float* texc; float* albedo0; float* albedo_aa; float* cov_aa; uint8_t* hit; size_t bytes; };
 void carve_view_state(char* base, int V, int H, int W, ViewState& st) {
@@ -1646,13 +1754,22 @@ int c3d_mesh_view_fwd(const c3d_mesh_view* d, const float* v, const float* v_off
     ViewBg bg; for (int i = 0; i < 3; i++) bg.c[i] = d->bg[i];
     int rc;
     hipLaunchKernelGGL(k_view_transform_fwd, dim3(c3d_cdiv(V, 256)), dim3(256), 0, s, v, v_offsets, M, V, (float4*)st.vclip);
-    if ((rc = c3d_mesh_rasterize_fwd(st.vclip, f, 1, V, T, H, W, raster_scratch, st.rast, st.rast_db, stream))) return rc;
-    // texture(..., filter_mode='linear') ignores uv_da (diff_mesh_renderer.py:110 passes it all the same): no pixel differentials are produced here
-    if ((rc = c3d_mesh_interpolate_fwd(vt, 1, st.rast, ft, nullptr, nullptr, 0, 1, d->Vt, 2, H, W, st.texc, nullptr, stream))) return rc;
-    if ((rc = c3d_mesh_texture_fwd(raw_albedo, 1, st.texc, 1, H, W, d->Ht, d->Wt, 3, 1, 0, st.albedo0, stream))) return rc;
-    {
+    if (view_pixel_fused()) {
+        // depth | id buffer, then ONE pixel pass: resolve -> interpolate(uv) -> texture -> sigmoid -> antialias seeds (k_view_pixel_fwd).
+        // texture(..., filter_mode='linear') ignores uv_da (diff_mesh_renderer.py:110 passes it all the same): no pixel differentials of uv are produced
+        if ((rc = mesh_rasterize_impl(st.vclip, f, 1, V, T, H, W, nullptr, raster_scratch, st.rast, st.rast_db, stream, false))) return rc;
+        C3dProfScope ps(C3D_P_MESH_INTERPOLATE, s);
+        hipLaunchKernelGGL(k_view_pixel_fwd, dim3(c3d_cdiv(P, 256)), dim3(256), 0, s, (const float4*)st.vclip, (const int3*)f, (const float2*)vt, (const int3*)ft, raw_albedo, H, W,
+                           d->Ht, d->Wt, (const unsigned long long*)raster_scratch, (float4*)st.rast, (float4*)st.rast_db, (float2*)st.texc, st.albedo0, st.albedo_aa, st.cov_aa);
+    } else {
+        if ((rc = c3d_mesh_rasterize_fwd(st.vclip, f, 1, V, T, H, W, raster_scratch, st.rast, st.rast_db, stream))) return rc;
+        if ((rc = c3d_mesh_interpolate_fwd(vt, 1, st.rast, ft, nullptr, nullptr, 0, 1, d->Vt, 2, H, W, st.texc, nullptr, stream))) return rc;
+        if ((rc = c3d_mesh_texture_fwd(raw_albedo, 1, st.texc, 1, H, W, d->Ht, d->Wt, 3, 1, 0, st.albedo0, stream))) return rc;
         C3dProfScope ps(C3D_P_MESH_ANTIALIAS, s);
         hipLaunchKernelGGL(k_view_sigmoid_seed, dim3(c3d_cdiv(P, 256)), dim3(256), 0, s, st.albedo0, (const float4*)st.rast, P, st.albedo_aa, st.cov_aa);
+    }
+    {
+        C3dProfScope ps(C3D_P_MESH_ANTIALIAS, s);
         hipLaunchKernelGGL(k_aa2_fwd, dim3(c3d_cdiv(P * 2, 256)), dim3(256), 0, s, st.albedo0, (const float4*)st.rast, (const float4*)st.vclip, (const int3*)f,
                            (const EdgeSlot*)aa_topology, edge_table_size(T) - 1, H, W, st.albedo_aa, st.cov_aa, st.hit);
     }
@@ -1666,7 +1783,7 @@ int c3d_mesh_view_fwd(const c3d_mesh_view* d, const float* v, const float* v_off
 
 static int mesh_view_bwd(const c3d_mesh_view* d, const int32_t* f, const float* vt, const int32_t* ft, const float* raw_albedo,
                          const void* aa_topology, const void* vertex_topology, void* scratch, const void* state, const float* dimage, const float* dalpha,
-                         float* d_raw_albedo, float* d_v, c3d_stream_t stream, bool zero_dtex);
+                         float* d_raw_albedo, float* d_v, c3d_stream_t stream, bool zero_dtex, const ViewLossIn* li = nullptr, int loss_blocks = 0);
 int c3d_mesh_view_bwd(const c3d_mesh_view* d, const float* v, const float* v_offsets, const int32_t* f, const float* vt, const int32_t* ft, const float* raw_albedo,
                       const void* aa_topology, const void* vertex_topology, void* scratch, const void* state, const float* dimage, const float* dalpha,
                       float* d_raw_albedo, float* d_v, c3d_stream_t stream) {
@@ -1675,10 +1792,10 @@ int c3d_mesh_view_bwd(const c3d_mesh_view* d, const float* v, const float* v_off
 }
 static int mesh_view_bwd(const c3d_mesh_view* d, const int32_t* f, const float* vt, const int32_t* ft, const float* raw_albedo,
                          const void* aa_topology, const void* vertex_topology, void* scratch, const void* state, const float* dimage, const float* dalpha,
-                         float* d_raw_albedo, float* d_v, c3d_stream_t stream, bool zero_dtex) {
+                         float* d_raw_albedo, float* d_v, c3d_stream_t stream, bool zero_dtex, const ViewLossIn* li, int loss_blocks) {
     hipStream_t s = (hipStream_t)stream;
     MESH_REQUIRE(d && f && vt && ft && raw_albedo && aa_topology && scratch && state && d_raw_albedo, "c3d_mesh_view_bwd: NULL pointer");
-    MESH_REQUIRE(dimage || dalpha, "c3d_mesh_view_bwd: no upstream gradient");
+    MESH_REQUIRE(dimage || dalpha || li, "c3d_mesh_view_bwd: no upstream gradient");
     MESH_REQUIRE(!d_v || vertex_topology, "c3d_mesh_view_bwd: the geometry gradient needs the vertex topology");
     const int V = d->V, T = d->T, H = d->H, W = d->W;
     const long long P = (long long)H * W;
@@ -1689,18 +1806,23 @@ static int mesh_view_bwd(const c3d_mesh_view* d, const int32_t* f, const float* 
     int rc;
     {
         C3dProfScope ps(C3D_P_OTHER, s);
-        hipLaunchKernelGGL(k_view_shade_bwd, dim3(c3d_cdiv(P, 256)), dim3(256), 0, s, st.albedo_aa, st.cov_aa, bg, P, dimage, dalpha, sc.dalbedo_aa, sc.dalbedo0, sc.dcov);
+        if (li) hipLaunchKernelGGL(k_view_loss_shade_bwd, dim3((unsigned)loss_blocks), dim3(256), 0, s, st.albedo_aa, st.cov_aa, bg, P, *li, sc.dalbedo_aa, sc.dalbedo0, sc.dcov);
+        else hipLaunchKernelGGL(k_view_shade_bwd, dim3(c3d_cdiv(P, 256)), dim3(256), 0, s, st.albedo_aa, st.cov_aa, bg, P, dimage, dalpha, sc.dalbedo_aa, sc.dalbedo0, sc.dcov);
     }
     {
         C3dProfScope ps(C3D_P_MESH_ANTIALIAS_BWD, s);
         if (d_v) C3D_CHECK(hipMemsetAsync(sc.dpos_aa, 0, 16 * (size_t)V, s));
         hipLaunchKernelGGL(k_aa2_bwd, dim3(c3d_cdiv(P * 2, 256)), dim3(256), 0, s, st.albedo0, (const float4*)st.rast, (const float4*)st.vclip, (const int3*)f,
                            (const EdgeSlot*)aa_topology, edge_table_size(T) - 1, sc.dalbedo_aa, sc.dcov, V, H, W, sc.dalbedo0, d_v ? sc.dpos_aa : nullptr, st.hit);
-        hipLaunchKernelGGL(k_view_sigmoid_bwd, dim3(c3d_cdiv(P * 3, 256)), dim3(256), 0, s, st.albedo0, sc.dalbedo0, P * 3);
+        if (!view_pixel_fused()) hipLaunchKernelGGL(k_view_sigmoid_bwd, dim3(c3d_cdiv(P * 3, 256)), dim3(256), 0, s, st.albedo0, sc.dalbedo0, P * 3);
     }
-    if ((rc = mesh_texture_bwd(raw_albedo, 1, st.texc, sc.dalbedo0, 1, H, W, d->Ht, d->Wt, 3, 1, 0, d_raw_albedo, sc.duv, stream, zero_dtex))) return rc;
+    if (view_pixel_fused()) {
+        // the sigmoid's derivative rides on the texture backward's load of dy, interpolate's backward for the uv attribute on its epilogue (drast instead of duv)
+        const TexBwdFused fz{st.albedo0, d_v ? (const float4*)st.rast : nullptr, d_v ? (const float2*)vt : nullptr, d_v ? (const int3*)ft : nullptr, d_v ? (float4*)sc.drast : nullptr};
+        if ((rc = mesh_texture_bwd(raw_albedo, 1, st.texc, sc.dalbedo0, 1, H, W, d->Ht, d->Wt, 3, 1, 0, d_raw_albedo, sc.duv, stream, zero_dtex, fz))) return rc;
+    } else if ((rc = mesh_texture_bwd(raw_albedo, 1, st.texc, sc.dalbedo0, 1, H, W, d->Ht, d->Wt, 3, 1, 0, d_raw_albedo, sc.duv, stream, zero_dtex))) return rc;
     if (d_v) {
-        if ((rc = c3d_mesh_interpolate_bwd(vt, 1, st.rast, ft, sc.duv, 1, d->Vt, 2, H, W, nullptr, sc.drast, stream))) return rc;
+        if (!view_pixel_fused() && (rc = c3d_mesh_interpolate_bwd(vt, 1, st.rast, ft, sc.duv, 1, d->Vt, 2, H, W, nullptr, sc.drast, stream))) return rc;
         if ((rc = c3d_mesh_rasterize_bwd_gather(st.vclip, f, st.rast, sc.drast, 1, V, T, H, W, vertex_topology, sc.ras, sc.dpos_r, stream))) return rc;
         hipLaunchKernelGGL(k_view_transform_bwd, dim3(c3d_cdiv(V, 256)), dim3(256), 0, s, M, (const float4*)sc.dpos_aa, (const float4*)sc.dpos_r, V, d_v);
     }
@@ -1850,11 +1972,15 @@ int c3d_mesh_train_views(const c3d_mesh_view* views, int32_t n_views, const floa
                     hipLaunchKernelGGL(k_mesh_hwc_to_chw, dim3(c3d_cdiv(P, 256)), dim3(256), 0, s, q.image, P, q.image_chw);
                     if ((rc = ms_value_grad(target_chw[i], q.image_chw, mk, 0, 1, 3, d->H, d->W, -ws_, 0, q.dssim, ws_, -ws_, loss_out ? lp + 1024 : nullptr, q.ms_ws, s, 1))) break;
                 }
-                hipLaunchKernelGGL(k_mesh_pixel_loss, dim3((unsigned)nblk), dim3(256), 0, s, q.image, target_chw[i], mk, P,
-                                   loss->scale * loss->w_mse, ssim ? q.dssim : (const float*)nullptr, q.dimage, loss_out ? lp : (float*)nullptr);
+                if (!view_pixel_fused())
+                    hipLaunchKernelGGL(k_mesh_pixel_loss, dim3((unsigned)nblk), dim3(256), 0, s, q.image, target_chw[i], mk, P,
+                                       loss->scale * loss->w_mse, ssim ? q.dssim : (const float*)nullptr, q.dimage, loss_out ? lp : (float*)nullptr);
             }
             float* dv = d_v_offsets ? (float*)((char*)w.d_v + (size_t)i * w.d_v_stride) : nullptr;
-            if ((rc = mesh_view_bwd(d, f, vt, ft, raw_albedo, aa_topology, vertex_topology, q.bwd, q.state, q.dimage, nullptr, q.d_ra, dv, (c3d_stream_t)s, false))) break;
+            if (view_pixel_fused()) {      // the pixel loss inside the backward pass's first kernel: d/dimage is never materialised
+                const ViewLossIn li{q.image, target_chw[i], mk, ssim ? q.dssim : (const float*)nullptr, loss->scale * loss->w_mse, loss_out ? lp : (float*)nullptr};
+                if ((rc = mesh_view_bwd(d, f, vt, ft, raw_albedo, aa_topology, vertex_topology, q.bwd, q.state, nullptr, nullptr, q.d_ra, dv, (c3d_stream_t)s, false, &li, nblk))) break;
+            } else if ((rc = mesh_view_bwd(d, f, vt, ft, raw_albedo, aa_topology, vertex_topology, q.bwd, q.state, q.dimage, nullptr, q.d_ra, dv, (c3d_stream_t)s, false))) break;
         } while (0);
         rc_all = rc;
     }
