@@ -76,7 +76,7 @@ _SIGNATURES = {
 }
 
 
-ABI_VERSION = 300      # c3d_version() of the library these signatures describe
+ABI_VERSION = 301      # c3d_version() of the library these signatures describe
 
 
 def exported_symbols():

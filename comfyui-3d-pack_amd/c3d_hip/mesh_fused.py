@@ -99,7 +99,7 @@ class _RenderView(torch.autograd.Function):
         d_ra = torch.empty_like(ra_c)
         d_v = torch.empty_like(v_c) if ctx.geo else None
         topo = ctx.glctx.vertex_topology(f, d.V) if ctx.geo else None
-        scratch = torch.empty((lib.c3d_mesh_view_bwd_scratch_bytes(d.V, d.T, d.H, d.W),), dtype=torch.uint8, device=dev)
+        scratch = torch.empty((lib.c3d_mesh_view_bwd_scratch_bytes(d.V, d.T, d.H, d.W, d.Ht, d.Wt),), dtype=torch.uint8, device=dev)
         di = _h.f32c(dimage) if dimage is not None else None
         da = _h.f32c(dalpha) if dalpha is not None else None
         with torch.cuda.device(dev):

@@ -106,7 +106,7 @@ static int project_tail(GsGeom& g, int N, int64_t* num_rendered, hipStream_t s) 
 extern "C" {
 
 const char* c3d_last_error(void) { return g_err; }
-int c3d_version(void) { return 300; }
+int c3d_version(void) { return 301; }
 
 size_t c3d_gs_geom_bytes(int32_t N) { GsGeom g; gs_carve_geom(nullptr, N, g); return g.bytes; }
 size_t c3d_gs_binning_bytes(int64_t D, int32_t H, int32_t W) {

@@ -283,9 +283,79 @@ __device__ __forceinline__ void ras_bwd_pixel(const float4 p0, const float4 p1, 
     RB_ACC(1, da0 * p2y + da2 * (-p0y), da0 * (-p2x) + da2 * p0x);
     RB_ACC(2, da0 * (-p1y) + da1 * p0y, da0 * p1x + da1 * (-p0x));
 }
+// ---- the antialias pass of the fused view as gathers (round 3) ------------------------------------------------------------------------------
+// The silhouette analysis (k_aa2_pairs) leaves per pixel pair (first pixel p, direction d: second = p + 1 | p + W) a flag byte -- bit 0 hit, bit 1 "the first pixel
+// is pixel a" (the one that owns the nearer triangle), bits 2-3 the silhouette edge's first corner in a's triangle -- and the blend weight alpha = s - 0.5.
+// A pixel belongs to four pairs: (p, 0), (p, 1), (p - 1, 0), (p - W, 1).  Forward blend, colour gradient and position gradient each GATHER over those four in that
+// order instead of scattering with float atomics: no atomics, one summation order, the same bits every run.
+struct AaPair { bool hit; int k; float alpha, sgn; size_t ia, ib, idst; };
+__device__ __forceinline__ AaPair aa_pair_load(const uint8_t* __restrict__ hit, const float* __restrict__ pair_alpha, size_t first, int d, int W) {
+    AaPair r;
+    const size_t gid = 2 * first + (size_t)d;
+    const uint32_t f = hit[gid];
+    r.hit = (f & 1u) != 0;
+    if (!r.hit) return r;
+    const size_t second = first + (d == 0 ? (size_t)1 : (size_t)W);
+    const bool a_first = (f & 2u) != 0;
+    r.k = (int)((f >> 2) & 3u);
+    r.sgn = a_first ? 1.f : -1.f;
+    r.ia = a_first ? first : second; r.ib = a_first ? second : first;
+    r.alpha = pair_alpha[gid];
+    r.idst = r.alpha > 0.f ? r.ib : r.ia;
+    return r;
+}
+// pair j = 0..3 of pixel (px, py): its first pixel, its direction, and whether it exists
+__device__ __forceinline__ bool aa_pair_of(int j, int px, int py, int W, size_t pid, size_t& first, int& d) {
+    d = j & 1;
+    if (j < 2) { first = pid; return true; }
+    if (j == 2) { first = pid - 1; return px > 0; }
+    first = pid - (size_t)W; return py > 0;
+}
+// what the position gradient of the antialias needs besides the pair records: the colours that were blended and the gradients of the two antialias outputs
+struct AaBwdIn { const uint8_t* hit; const uint8_t* pflag; const float* pair_alpha; const float* albedo0; const float* dy3; const float* dy1; };      // pflag: k_view_shade_fwd_g
+// position gradient of the pairs whose pixel a is `pid` (owned by the triangle with corners p0, p1, p2) -- the algebra of k_aa2_bwd, accumulated per corner
+__device__ __forceinline__ void aa_bwd_pixel(const AaBwdIn& aa, const float4* __restrict__ rast, const float4 pc[3], int px, int py, size_t pid, int H, int W,
+                                             float ax[3], float ay[3], float aw[3]) {
+    const uint32_t pf = aa.pflag[pid] & 15u;      // bit j: pair j is a hit and this pixel is its pixel a (one byte per pixel; nearly always zero)
+    if (!pf) return;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (!(pf >> j & 1u)) continue;
+        size_t first; int d;
+        aa_pair_of(j, px, py, W, pid, first, d);
+        const AaPair pr = aa_pair_load(aa.hit, aa.pair_alpha, first, d, W);
+        float dalpha = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; c++) dalpha += aa.dy3[3 * pr.idst + c] * (aa.albedo0[3 * pr.ia + c] - aa.albedo0[3 * pr.ib + c]);
+        const float cb = rast[pr.ib].w > 0.f ? 1.f : 0.f;
+        dalpha += aa.dy1[pr.idst] * (1.f - cb);
+        const int k0 = pr.k, k1 = pr.k == 2 ? 0 : pr.k + 1;
+        const float4 pa = k0 == 0 ? pc[0] : (k0 == 1 ? pc[1] : pc[2]), pv = k1 == 0 ? pc[0] : (k1 == 1 ? pc[1] : pc[2]);
+        const float xa = pa.x / pa.w, ya = pa.y / pa.w, xb = pv.x / pv.w, yb = pv.y / pv.w;
+        const float cx = ((float)px + 0.5f) * (2.f / W) - 1.f, cy = ((float)py + 0.5f) * (2.f / H) - 1.f;
+        const float hh = d == 0 ? 2.f / W : 2.f / H;
+        const float gs = dalpha * pr.sgn / hh;
+        float gxa, gya, gxb, gyb;
+        if (d == 0) {
+            const float da = ya - cy, db = yb - cy, den = da - db, te = da / den, gte = gs * (xb - xa);
+            gxa = gs * (1.f - te); gxb = gs * te;
+            gya = gte * (-db / (den * den)); gyb = gte * (da / (den * den));
+        } else {
+            const float da = xa - cx, db = xb - cx, den = da - db, te = da / den, gte = gs * (yb - ya);
+            gya = gs * (1.f - te); gyb = gs * te;
+            gxa = gte * (-db / (den * den)); gxb = gte * (da / (den * den));
+        }
+        const float a3[3] = {gxa / pa.w, gya / pa.w, -(gxa * xa + gya * ya) / pa.w}, b3[3] = {gxb / pv.w, gyb / pv.w, -(gxb * xb + gyb * yb) / pv.w};
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            if (k == k0) { ax[k] += a3[0]; ay[k] += a3[1]; aw[k] += a3[2]; }
+            if (k == k1) { ax[k] += b3[0]; ay[k] += b3[1]; aw[k] += b3[2]; }
+        }
+    }
+}
 __global__ void __launch_bounds__(256) k_ras_bwd_tri(const float4* __restrict__ pos, const int3* __restrict__ tri, const float4* __restrict__ rast,
                                                       const float4* __restrict__ dy, int B, int V, int T, int H, int W, float4* __restrict__ rec,
-                                                      uint32_t* __restrict__ big_queue, uint32_t* __restrict__ big_count) {
+                                                      uint32_t* __restrict__ big_queue, uint32_t* __restrict__ big_count, AaBwdIn aa) {
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (long long)B * T) return;
     const int b = (int)(gid / T), t = (int)(gid % T);
@@ -307,15 +377,15 @@ __global__ void __launch_bounds__(256) k_ras_bwd_tri(const float4* __restrict__ 
             const size_t pid = pbase + (size_t)py * W + px;
             if (rast[pid].w != idf) continue;
             const float4 g = dy[pid];
-            if (g.x == 0.f && g.y == 0.f) continue;
-            ras_bwd_pixel(p0, p1, p2, xs * ((float)px + 0.5f) - 1.f, ys * ((float)py + 0.5f) - 1.f, g.x, g.y, ax, ay, aw);
+            if (g.x != 0.f || g.y != 0.f) ras_bwd_pixel(p0, p1, p2, xs * ((float)px + 0.5f) - 1.f, ys * ((float)py + 0.5f) - 1.f, g.x, g.y, ax, ay, aw);
+            if (aa.hit) { const float4 pc[3] = {p0, p1, p2}; aa_bwd_pixel(aa, rast, pc, px, py, pid, H, W, ax, ay, aw); }      // fused view only (B = 1)
         }
 #pragma unroll
     for (int k = 0; k < 3; k++) out[k] = make_float4(ax[k], ay[k], 0.f, aw[k]);
 }
 __global__ void __launch_bounds__(256) k_ras_bwd_big(const float4* __restrict__ pos, const int3* __restrict__ tri, const float4* __restrict__ rast,
                                                       const float4* __restrict__ dy, int V, int T, int H, int W, float4* __restrict__ rec,
-                                                      const uint32_t* __restrict__ big_queue, const uint32_t* __restrict__ big_count) {
+                                                      const uint32_t* __restrict__ big_queue, const uint32_t* __restrict__ big_count, AaBwdIn aa) {
     __shared__ float red[4][9];
     const uint32_t n = *big_count;
     const float xs = 2.f / W, ys = 2.f / H;
@@ -336,8 +406,8 @@ __global__ void __launch_bounds__(256) k_ras_bwd_big(const float4* __restrict__ 
             const size_t pid = pbase + (size_t)py * W + px;
             if (rast[pid].w != idf) continue;
             const float4 g = dy[pid];
-            if (g.x == 0.f && g.y == 0.f) continue;
-            ras_bwd_pixel(p0, p1, p2, xs * ((float)px + 0.5f) - 1.f, ys * ((float)py + 0.5f) - 1.f, g.x, g.y, ax, ay, aw);
+            if (g.x != 0.f || g.y != 0.f) ras_bwd_pixel(p0, p1, p2, xs * ((float)px + 0.5f) - 1.f, ys * ((float)py + 0.5f) - 1.f, g.x, g.y, ax, ay, aw);
+            if (aa.hit) { const float4 pc[3] = {p0, p1, p2}; aa_bwd_pixel(aa, rast, pc, px, py, pid, H, W, ax, ay, aw); }
         }
         float v9[9] = {ax[0], ay[0], aw[0], ax[1], ay[1], aw[1], ax[2], ay[2], aw[2]};
         __syncthreads();
@@ -556,14 +626,9 @@ __device__ __forceinline__ bool tex_taps_shared(const uint32_t tk[4]) {
         for (int j = 0; j < 4; j++) share = share || nk[i] == tk[j];
     return 4 * __popcll(__ballot(share)) >= __popcll(__ballot(true));
 }
-// Fused-view extras (round 3; all NULL for the plain dr.texture backward):
-//   sig    the sigmoid output the fetched value went through (albedo = sigmoid(texture)): dy is multiplied by s (1 - s) on load (was its own pass over the image);
-//   rast / vt / ft / drast  interpolate's backward for the texture-coordinate attribute folded into the epilogue: drast = (duv . (vt0 - vt2), duv . (vt1 - vt2), 0, 0)
-//   written instead of duv (was a pass of its own).
-struct TexBwdFused { const float* sig; const float4* rast; const float2* vt; const int3* ft; float4* drast; };
 template <int C>
 __global__ void __launch_bounds__(256) k_tex_bwd_tiled(const float* __restrict__ tex, int Bt, const float2* __restrict__ uv, const float* __restrict__ dy,
-                                                        int H, int W, int Ht, int Wt, int boundary, float* __restrict__ dtex, float2* __restrict__ duv, TexBwdFused fz) {
+                                                        int H, int W, int Ht, int Wt, int boundary, float* __restrict__ dtex, float2* __restrict__ duv) {
     __shared__ uint32_t keys[TEXT_SLOTS];
     __shared__ float vals[TEXT_SLOTS][C];
     for (int i = threadIdx.x; i < TEXT_SLOTS; i += 256) {
@@ -589,7 +654,6 @@ __global__ void __launch_bounds__(256) k_tex_bwd_tiled(const float* __restrict__
 #pragma unroll
         for (int c = 0; c < C; c++) {
             g[c] = dy[gid * C + c];
-            if (fz.sig) { const float sv = fz.sig[gid * C + c]; g[c] *= sv * (1.f - sv); }
             any = any || g[c] != 0.f;
         }
         float gu = 0.f, gv = 0.f;
@@ -600,18 +664,7 @@ __global__ void __launch_bounds__(256) k_tex_bwd_tiled(const float* __restrict__
             gu += g[c] * ((t10 - t00) * (1.f - fv) + (t11 - t01) * fv);
             gv += g[c] * ((t01 - t00) * (1.f - fu) + (t11 - t10) * fu);
         }
-        if (fz.drast) {      // k_interp_bwd for the two texture-coordinate attributes, same statements
-            const int t = (int)fz.rast[gid].w - 1;
-            float4 dr = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (t >= 0) {
-                const int3 vi = fz.ft[t];
-                const float2 a0 = fz.vt[vi.x], a1 = fz.vt[vi.y], a2 = fz.vt[vi.z];
-                const float g0 = gu * Wt, g1 = gv * Ht;
-                dr.x = g0 * (a0.x - a2.x) + g1 * (a0.y - a2.y);
-                dr.y = g0 * (a1.x - a2.x) + g1 * (a1.y - a2.y);
-            }
-            fz.drast[gid] = dr;
-        } else duv[gid] = make_float2(gu * Wt, gv * Ht);
+        duv[gid] = make_float2(gu * Wt, gv * Ht);
         const bool use_hash = tex_taps_shared(tk);
         if (any) {
 #pragma unroll
@@ -956,7 +1009,7 @@ __device__ __forceinline__ int other_opposite(const EdgeSlot* __restrict__ table
     return -1;
 }
 
-struct AaHit { int ax, ay, bx, by, va, vb; float s, sgn; };
+struct AaHit { int ax, ay, bx, by, va, vb, ek; float s, sgn; };      // ek: the silhouette edge runs from corner ek to corner (ek + 1) % 3 of pixel a's triangle
 __device__ __forceinline__ bool aa_analyze(const float4* __restrict__ pb, const int3* __restrict__ tri, const EdgeSlot* __restrict__ table, uint32_t mask,
                                            const float4* __restrict__ rast_b, int H, int W, int px, int py, int d, AaHit& hit) {
     const int qx = px + (d == 0), qy = py + (d == 1);
@@ -1011,7 +1064,7 @@ __device__ __forceinline__ bool aa_analyze(const float4* __restrict__ pb, const 
             const float s_other = ex * (oy - ny[ia]) - ey * (ox - nx[ia]);
             if (!(s_this * s_other > 0.f)) continue;
         }
-        if (!found || s < best) { found = true; best = s; hit.va = vi[ia]; hit.vb = vi[ib]; }
+        if (!found || s < best) { found = true; best = s; hit.va = vi[ia]; hit.vb = vi[ib]; hit.ek = k; }
     }
     if (!found) return false;
     hit.ax = ax; hit.ay = ay; hit.bx = a_is_p ? qx : px; hit.by = a_is_p ? qy : py; hit.s = best; hit.sgn = sgn;
@@ -1207,8 +1260,15 @@ size_t c3d_mesh_rasterize_bwd_scratch_bytes(int32_t B, int32_t T) {
     const size_t bt = (size_t)(B > 0 ? B : 1) * (size_t)(T > 0 ? T : 1);
     return c3d_align(sizeof(float4) * 3 * bt) + c3d_align(4 * bt) + c3d_align(64);
 }
+static int mesh_rasterize_bwd_gather(const float* pos, const int32_t* tri, const float* rast, const float* dy, int32_t B, int32_t V, int32_t T, int32_t H,
+                                     int32_t W, const void* topology, void* scratch, float* dpos, c3d_stream_t stream, AaBwdIn aa);
 int c3d_mesh_rasterize_bwd_gather(const float* pos, const int32_t* tri, const float* rast, const float* dy, int32_t B, int32_t V, int32_t T, int32_t H,
                                   int32_t W, const void* topology, void* scratch, float* dpos, c3d_stream_t stream) {
+    return mesh_rasterize_bwd_gather(pos, tri, rast, dy, B, V, T, H, W, topology, scratch, dpos, stream, AaBwdIn{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr});
+}
+// aa.hit != NULL (fused view, B = 1): the antialias pass's position gradient is accumulated into the same per-corner records
+static int mesh_rasterize_bwd_gather(const float* pos, const int32_t* tri, const float* rast, const float* dy, int32_t B, int32_t V, int32_t T, int32_t H,
+                                     int32_t W, const void* topology, void* scratch, float* dpos, c3d_stream_t stream, AaBwdIn aa) {
     hipStream_t s = (hipStream_t)stream;
     if ((long long)B * V == 0) return 0;
     MESH_REQUIRE(dpos, "NULL dpos");
@@ -1223,8 +1283,8 @@ int c3d_mesh_rasterize_bwd_gather(const float* pos, const int32_t* tri, const fl
     uint32_t* count = (uint32_t*)((char*)queue + c3d_align(4 * bt));
     C3D_CHECK(hipMemsetAsync(count, 0, 8, s));
     hipLaunchKernelGGL(k_ras_bwd_tri, dim3(c3d_cdiv((long long)bt, 256)), dim3(256), 0, s, (const float4*)pos, (const int3*)tri, (const float4*)rast, (const float4*)dy,
-                       B, V, T, H, W, rec, queue, count);
-    hipLaunchKernelGGL(k_ras_bwd_big, dim3(1024), dim3(256), 0, s, (const float4*)pos, (const int3*)tri, (const float4*)rast, (const float4*)dy, V, T, H, W, rec, queue, count);
+                       B, V, T, H, W, rec, queue, count, aa);
+    hipLaunchKernelGGL(k_ras_bwd_big, dim3(1024), dim3(256), 0, s, (const float4*)pos, (const int3*)tri, (const float4*)rast, (const float4*)dy, V, T, H, W, rec, queue, count, aa);
     // the sorted corner list sits in val[res]; res is a host constant of the build (same digit count): recompute it instead of reading meta
     int bits = 1;
     while ((1ll << bits) <= (long long)V) bits++;
@@ -1291,14 +1351,14 @@ int c3d_mesh_texture_fwd(const float* tex, int32_t Bt, const float* uv, int32_t 
     return 0;
 }
 static int mesh_texture_bwd(const float* tex, int32_t Bt, const float* uv, const float* dy, int32_t B, int32_t H, int32_t W, int32_t Ht, int32_t Wt, int32_t C,
-                            int32_t filter, int32_t boundary, float* dtex, float* duv, c3d_stream_t stream, bool zero_dtex, TexBwdFused fz = TexBwdFused{nullptr, nullptr, nullptr, nullptr, nullptr});
+                            int32_t filter, int32_t boundary, float* dtex, float* duv, c3d_stream_t stream, bool zero_dtex);
 int c3d_mesh_texture_bwd(const float* tex, int32_t Bt, const float* uv, const float* dy, int32_t B, int32_t H, int32_t W, int32_t Ht, int32_t Wt, int32_t C,
                          int32_t filter, int32_t boundary, float* dtex, float* duv, c3d_stream_t stream) {
     return mesh_texture_bwd(tex, Bt, uv, dy, B, H, W, Ht, Wt, C, filter, boundary, dtex, duv, stream, true);
 }
 // zero_dtex = false: the texel gradients are ADDED to what dtex holds (the multi-view step accumulates the views of a lane in one buffer)
 static int mesh_texture_bwd(const float* tex, int32_t Bt, const float* uv, const float* dy, int32_t B, int32_t H, int32_t W, int32_t Ht, int32_t Wt, int32_t C,
-                            int32_t filter, int32_t boundary, float* dtex, float* duv, c3d_stream_t stream, bool zero_dtex, TexBwdFused fz) {
+                            int32_t filter, int32_t boundary, float* dtex, float* duv, c3d_stream_t stream, bool zero_dtex) {
     hipStream_t s = (hipStream_t)stream;
     const long long P = (long long)H * W, BP = P * B;
     MESH_REQUIRE(Bt == 1 || Bt == B, "texture batch must be 1 or B");
@@ -1306,13 +1366,12 @@ static int mesh_texture_bwd(const float* tex, int32_t Bt, const float* uv, const
     C3dProfScope ps(C3D_P_MESH_TEXTURE_BWD, s);
     if ((long long)Bt * Ht * Wt * C > 0) { MESH_REQUIRE(dtex, "NULL dtex"); if (zero_dtex) C3D_CHECK(hipMemsetAsync(dtex, 0, sizeof(float) * (size_t)Bt * Ht * Wt * C, s)); }
     if (BP == 0 || C == 0) return 0;
-    MESH_REQUIRE(tex && uv && dy && (duv || fz.drast), "NULL pointer");
-    MESH_REQUIRE((!fz.sig && !fz.drast) || (filter == 1 && C == 3), "internal: the fused-view extras exist for the tiled 3-channel linear backward only");
+    MESH_REQUIRE(tex && uv && dy && duv, "NULL pointer");
     if (filter == 1 && (C == 1 || C == 3 || C == 4) && (long long)Ht * Wt < 0xFFFFFFFFll) {
         const dim3 grid(c3d_cdiv(W, 16), c3d_cdiv(H, 16), B);
-        if (C == 1) hipLaunchKernelGGL((k_tex_bwd_tiled<1>), grid, dim3(256), 0, s, tex, Bt, (const float2*)uv, dy, H, W, Ht, Wt, boundary, dtex, (float2*)duv, fz);
-        else if (C == 3) hipLaunchKernelGGL((k_tex_bwd_tiled<3>), grid, dim3(256), 0, s, tex, Bt, (const float2*)uv, dy, H, W, Ht, Wt, boundary, dtex, (float2*)duv, fz);
-        else hipLaunchKernelGGL((k_tex_bwd_tiled<4>), grid, dim3(256), 0, s, tex, Bt, (const float2*)uv, dy, H, W, Ht, Wt, boundary, dtex, (float2*)duv, fz);
+        if (C == 1) hipLaunchKernelGGL((k_tex_bwd_tiled<1>), grid, dim3(256), 0, s, tex, Bt, (const float2*)uv, dy, H, W, Ht, Wt, boundary, dtex, (float2*)duv);
+        else if (C == 3) hipLaunchKernelGGL((k_tex_bwd_tiled<3>), grid, dim3(256), 0, s, tex, Bt, (const float2*)uv, dy, H, W, Ht, Wt, boundary, dtex, (float2*)duv);
+        else hipLaunchKernelGGL((k_tex_bwd_tiled<4>), grid, dim3(256), 0, s, tex, Bt, (const float2*)uv, dy, H, W, Ht, Wt, boundary, dtex, (float2*)duv);
     } else {
         hipLaunchKernelGGL(k_tex_bwd, dim3(c3d_cdiv(BP, 256)), dim3(256), 0, s, tex, Bt, (const float2*)uv, dy, BP, P, Ht, Wt, C, filter, boundary, dtex, (float2*)duv);
     }
@@ -1522,7 +1581,7 @@ __global__ void __launch_bounds__(256) k_view_transform_fwd(const float* __restr
 __global__ void __launch_bounds__(256) k_view_transform_bwd(ViewMat M, const float4* __restrict__ da, const float4* __restrict__ db, int V, float* __restrict__ dv) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= V) return;
-    float4 g = da[i];
+    float4 g = da ? da[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     if (db) { const float4 h = db[i]; g.x += h.x; g.y += h.y; g.z += h.z; g.w += h.w; }
     dv[3 * i] = M.m[0] * g.x + M.m[4] * g.y + M.m[8] * g.z + M.m[12] * g.w;
     dv[3 * i + 1] = M.m[1] * g.x + M.m[5] * g.y + M.m[9] * g.z + M.m[13] * g.w;
@@ -1576,9 +1635,10 @@ __global__ void __launch_bounds__(256) k_view_pixel_fwd(const float4* __restrict
     for (int c = 0; c < 3; c++) {
         const float top = t00[c] + fu * (t10[c] - t00[c]), bot = t01[c] + fu * (t11[c] - t01[c]);
         const float sg = 1.f / (1.f + __expf(-(top + fv * (bot - top))));
-        albedo0[3 * gid + c] = sg; albedo_aa[3 * gid + c] = sg;
+        albedo0[3 * gid + c] = sg;
+        if (albedo_aa) albedo_aa[3 * gid + c] = sg;
     }
-    cov_aa[gid] = cov;
+    if (cov_aa) cov_aa[gid] = cov;      // the gathering antialias (k_view_shade_fwd_g) needs no seeds
 }
 // both antialias calls of the view in one pass over the pixel pairs
 __global__ void __launch_bounds__(256) k_aa2_fwd(const float* __restrict__ albedo, const float4* __restrict__ rast, const float4* __restrict__ pos,
@@ -1644,8 +1704,166 @@ __global__ void __launch_bounds__(256) k_aa2_bwd(const float* __restrict__ albed
     atomicAdd(dA + 0, gxa / pa.w); atomicAdd(dA + 1, gya / pa.w); atomicAdd(dA + 3, -(gxa * xa + gya * ya) / pa.w);
     atomicAdd(dB + 0, gxb / pv.w); atomicAdd(dB + 1, gyb / pv.w); atomicAdd(dB + 3, -(gxb * xb + gyb * yb) / pv.w);
 }
-// shade with the background as a kernel argument; backward also seeds the antialias backward (dalbedo0 = dalbedo_aa) and applies nothing else
+// ---- round 3: the same pass without atomics (aa_pair_load above) ----
+// silhouette analysis only: one flag byte + one blend weight per pixel pair
+__global__ void __launch_bounds__(256) k_aa2_pairs(const float4* __restrict__ rast, const float4* __restrict__ pos, const int3* __restrict__ tri,
+                                                    const EdgeSlot* __restrict__ table, uint32_t mask, int H, int W, float* __restrict__ pair_alpha, uint8_t* __restrict__ hit) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long P = (long long)H * W;
+    if (gid >= P * 2) return;
+    const int d = (int)(gid & 1), pid = (int)(gid >> 1), px = pid % W, py = pid / W;
+    AaHit h;
+    const bool found = aa_analyze(pos, tri, table, mask, rast, H, W, px, py, d, h);
+    hit[gid] = found ? (uint8_t)(1 | (h.sgn > 0.f ? 2 : 0) | (h.ek << 2)) : (uint8_t)0;
+    if (found) pair_alpha[gid] = h.s - 0.5f;
+}
 struct ViewBg { float c[3]; };
+// both antialias outputs of a pixel gathered from its four pairs, then the shade (k_view_shade_fwd's statements): albedo_aa / cov_aa are written once, by their owner
+__global__ void __launch_bounds__(256) k_view_shade_fwd_g(const float* __restrict__ albedo0, const float4* __restrict__ rast, const uint8_t* __restrict__ hit,
+                                                          const float* __restrict__ pair_alpha, ViewBg bg, int H, int W, float* __restrict__ albedo_aa,
+                                                          float* __restrict__ cov_aa, float* __restrict__ image, float* __restrict__ alpha_out, uint8_t* __restrict__ pflag) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)H * W) return;
+    const int px = (int)(i % W), py = (int)(i / W);
+    float acc[3] = {albedo0[3 * i], albedo0[3 * i + 1], albedo0[3 * i + 2]};
+    float cov = rast[i].w > 0.f ? 1.f : 0.f;
+    uint32_t pf = 0;        // for the backward passes: bit j = pair j is a hit with this pixel as its pixel a, bit 4 + j = pair j is a hit at all
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        size_t first; int d;
+        if (!aa_pair_of(j, px, py, W, (size_t)i, first, d)) continue;
+        const AaPair pr = aa_pair_load(hit, pair_alpha, first, d, W);
+        if (!pr.hit) continue;
+        pf |= (16u | (pr.ia == (size_t)i ? 1u : 0u)) << j;
+        if (pr.idst != (size_t)i) continue;
+#pragma unroll
+        for (int c = 0; c < 3; c++) acc[c] += pr.alpha * (albedo0[3 * pr.ia + c] - albedo0[3 * pr.ib + c]);
+        const float cb = rast[pr.ib].w > 0.f ? 1.f : 0.f;         // pixel a owns the nearer triangle: its coverage is 1
+        if (cb != 1.f) cov += pr.alpha * (1.f - cb);
+    }
+    cov_aa[i] = cov;
+    pflag[i] = (uint8_t)pf;
+    const float a = fminf(fmaxf(cov, 0.f), 1.f);
+    alpha_out[i] = a;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        albedo_aa[3 * i + c] = acc[c];
+        image[3 * i + c] = fminf(fmaxf(a * acc[c] + (1.f - a) * bg.c[c], 0.f), 1.f);
+    }
+}
+// ---- texel gradients of the fused view without float atomics ----
+// Float adds do not commute in rounding, so any scatter with float atomics gives run-to-run different bits.  Integer adds do: a contribution w is split into
+// hi = rint(w 2^16) (an integer count of 2^-16, exact) and lo = w - hi 2^-16 (|lo| <= 2^-17, exact), and lo is added as rint(lo 2^56) (resolution 1.4e-17, 2^24
+// such terms fit 63 bits) to a 64-bit word per texel channel, hi -- zero for every |w| < 7.6e-6, i.e. for all of a mean-reduced image loss's texel gradients --
+// to a second word.  Integer atomics are exact whatever their order, so ALL views and lanes of a step add into ONE pair of planes and the result has the same
+// bits every run; k_tex_acc_finalize turns the planes into floats once.  Not finite / |w| >= 2^46: a flag, and the finalize pass writes NaN.
+#define TEX_ACC_LO 72057594037927936.0      // 2^56
+#define TEX_ACC_HI 65536.0                  // 2^16
+struct TexAcc { long long* lo; long long* hi; uint32_t* bad; };
+__device__ __forceinline__ void tex_acc_split(float w, long long& hi, long long& lo, bool& bad) {
+    if (!(fabsf(w) < 7.0e13f)) { bad = true; hi = 0; lo = 0; return; }
+    const double wd = (double)w;
+    hi = __double2ll_rn(wd * TEX_ACC_HI);
+    lo = __double2ll_rn((wd - (double)hi * (1.0 / TEX_ACC_HI)) * TEX_ACC_LO);
+}
+__global__ void __launch_bounds__(256) k_tex_acc_finalize(TexAcc acc, long long n, int accumulate, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double v = (double)acc.hi[i] * (1.0 / TEX_ACC_HI) + (double)acc.lo[i] * (1.0 / TEX_ACC_LO);
+    const float r = *acc.bad ? __int_as_float(0x7fc00000) : (float)v;
+    out[i] = accumulate ? out[i] + r : r;
+}
+// k_tex_bwd_tiled<3> ('linear', wrap) for the fused view: dy is gathered on load -- the antialias pass's colour gradient (own dalbedo_aa + the four pairs' blends)
+// times the sigmoid's derivative --, the tile's taps are pre-combined in an LDS table of 64-bit words, one integer atomic per distinct (texel, channel) goes out,
+// and interpolate's backward for the texture coordinates is the epilogue (drast).
+struct ViewTexBwd { const float* G; const uint8_t* hit; const uint8_t* pflag; const float* pair_alpha; const float* sig; const float4* rast; const float2* vt; const int3* ft; float4* drast; TexAcc acc; };
+__global__ void __launch_bounds__(256) k_view_tex_bwd(const float* __restrict__ tex, const float2* __restrict__ uv, int H, int W, int Ht, int Wt, ViewTexBwd z) {
+    __shared__ uint32_t keys[TEXT_SLOTS];
+    __shared__ unsigned long long vals[TEXT_SLOTS][3];
+    for (int i = threadIdx.x; i < TEXT_SLOTS; i += 256) { keys[i] = TEXT_EMPTY; vals[i][0] = 0ull; vals[i][1] = 0ull; vals[i][2] = 0ull; }
+    __syncthreads();
+    const int px = blockIdx.x * 16 + (threadIdx.x & 15), py = blockIdx.y * 16 + (threadIdx.x >> 4);
+    bool bad = false;
+    if (px < W && py < H) {
+        const size_t gid = (size_t)py * W + px;
+        const float2 q = uv[gid];
+        const float u = q.x * Wt - 0.5f, v = q.y * Ht - 0.5f;
+        const float fu0 = floorf(u), fv0 = floorf(v), fu = u - fu0, fv = v - fv0;
+        const int iu0 = wrapi((int)fu0, Wt, 0), iu1 = wrapi((int)fu0 + 1, Wt, 0), iv0 = wrapi((int)fv0, Ht, 0), iv1 = wrapi((int)fv0 + 1, Ht, 0);
+        const uint32_t tk[4] = {(uint32_t)(iv0 * Wt + iu0), (uint32_t)(iv0 * Wt + iu1), (uint32_t)(iv1 * Wt + iu0), (uint32_t)(iv1 * Wt + iu1)};
+        const float tw[4] = {(1.f - fu) * (1.f - fv), fu * (1.f - fv), (1.f - fu) * fv, fu * fv};
+        float g[3] = {z.G[3 * gid], z.G[3 * gid + 1], z.G[3 * gid + 2]};
+        const uint32_t pf = (uint32_t)z.pflag[gid] >> 4;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {      // d albedo0 of this pixel: + alpha dy[dst] where it is pixel a of the pair, - alpha dy[dst] where it is pixel b
+            if (!(pf >> j & 1u)) continue;
+            size_t first; int d;
+            aa_pair_of(j, px, py, W, gid, first, d);
+            const AaPair pr = aa_pair_load(z.hit, z.pair_alpha, first, d, W);
+            const float sa = pr.ia == gid ? pr.alpha : -pr.alpha;
+#pragma unroll
+            for (int c = 0; c < 3; c++) g[c] += sa * z.G[3 * pr.idst + c];
+        }
+        bool any = false;
+#pragma unroll
+        for (int c = 0; c < 3; c++) { const float sv = z.sig[3 * gid + c]; g[c] *= sv * (1.f - sv); any = any || g[c] != 0.f; }
+        float gu = 0.f, gv = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float t00 = tex[(size_t)tk[0] * 3 + c], t10 = tex[(size_t)tk[1] * 3 + c], t01 = tex[(size_t)tk[2] * 3 + c], t11 = tex[(size_t)tk[3] * 3 + c];
+            gu += g[c] * ((t10 - t00) * (1.f - fv) + (t11 - t01) * fv);
+            gv += g[c] * ((t01 - t00) * (1.f - fu) + (t11 - t10) * fu);
+        }
+        if (z.drast) {      // k_interp_bwd for the two texture-coordinate attributes, same statements
+            const int t = (int)z.rast[gid].w - 1;
+            float4 dr = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t >= 0) {
+                const int3 vi = z.ft[t];
+                const float2 a0 = z.vt[vi.x], a1 = z.vt[vi.y], a2 = z.vt[vi.z];
+                const float g0 = gu * Wt, g1 = gv * Ht;
+                dr.x = g0 * (a0.x - a2.x) + g1 * (a0.y - a2.y);
+                dr.y = g0 * (a1.x - a2.x) + g1 * (a1.y - a2.y);
+            }
+            z.drast[gid] = dr;
+        }
+        const bool use_hash = tex_taps_shared(tk);
+        if (any) {
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                uint32_t h = (tk[t] * 2654435761u) >> 22;           // 10 bits
+                int slot = -1;
+                for (int probe = 0; use_hash && probe < 32; probe++) {   // bounded: a full table falls back to the direct scatter
+                    const uint32_t old = atomicCAS(&keys[h], TEXT_EMPTY, tk[t]);
+                    if (old == TEXT_EMPTY || old == tk[t]) { slot = (int)h; break; }
+                    h = (h + 1) & (TEXT_SLOTS - 1);
+                }
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const float w = g[c] * tw[t];
+                    if (w == 0.f) continue;
+                    long long hi, lo;
+                    tex_acc_split(w, hi, lo, bad);
+                    if (hi) atomicAdd((unsigned long long*)&z.acc.hi[(size_t)tk[t] * 3 + c], (unsigned long long)hi);
+                    if (!lo) continue;
+                    if (slot >= 0) atomicAdd(&vals[slot][c], (unsigned long long)lo);
+                    else atomicAdd((unsigned long long*)&z.acc.lo[(size_t)tk[t] * 3 + c], (unsigned long long)lo);
+                }
+            }
+        }
+    }
+    if (bad) *z.acc.bad = 1u;
+    __syncthreads();
+    for (int i = threadIdx.x; i < TEXT_SLOTS; i += 256) {
+        const uint32_t k = keys[i];
+        if (k == TEXT_EMPTY) continue;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const unsigned long long v = vals[i][c];
+            if (v) atomicAdd((unsigned long long*)&z.acc.lo[(size_t)k * 3 + c], v);
+        }
+    }
+}
+// shade with the background as a kernel argument; backward also seeds the antialias backward (dalbedo0 = dalbedo_aa) and applies nothing else
 __global__ void __launch_bounds__(256) k_view_shade_fwd(const float* __restrict__ albedo, const float* __restrict__ alpha, ViewBg bg, long long P,
                                                         float* __restrict__ image, float* __restrict__ alpha_out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1667,7 +1885,7 @@ __global__ void __launch_bounds__(256) k_view_shade_bwd(const float* __restrict_
         const float al = albedo[3 * i + c], val = a * al + (1.f - a) * bg.c[c];
         const float g = (val >= 0.f && val <= 1.f) ? (dimage ? dimage[3 * i + c] : 0.f) : 0.f;     // torch.clamp passes the gradient on the closed interval
         dalbedo_aa[3 * i + c] = g * a;
-        dalbedo0[3 * i + c] = g * a;        // antialias backward: dcolor starts as a copy of dy, the blends are added on top
+        if (dalbedo0) dalbedo0[3 * i + c] = g * a;        // scattering antialias backward: dcolor starts as a copy of dy, the blends are added on top
         da += g * (al - bg.c[c]);
     }
     dalpha[i] = (ar >= 0.f && ar <= 1.f) ? da : 0.f;
@@ -1692,7 +1910,7 @@ __global__ void __launch_bounds__(256) k_view_loss_shade_bwd(const float* __rest
             const float al = albedo[3 * i + c], val = a * al + (1.f - a) * bg.c[c];
             const float g = (val >= 0.f && val <= 1.f) ? dimg : 0.f;
             dalbedo_aa[3 * i + c] = g * a;
-            dalbedo0[3 * i + c] = g * a;
+            if (dalbedo0) dalbedo0[3 * i + c] = g * a;
             da += g * (al - bg.c[c]);
         }
         dalpha[i] = (ar >= 0.f && ar <= 1.f) ? da : 0.f;
@@ -1707,15 +1925,16 @@ __global__ void __launch_bounds__(256) k_view_sigmoid_bwd(const float* __restric
     if (i < n) { const float v = s[i]; g[i] *= v * (1.f - v); }
 }
 
-// C3D_MESH_PIXEL_FUSED = 1 (default): the fused pixel passes of the view (k_view_pixel_fwd; sigmoid' and interpolate-backward inside the texture backward) | 0: one
-// launch per op as in round 2 (tests compare the two)
+// C3D_MESH_PIXEL_FUSED = 1 (default): the round-3 view -- fused pixel passes (k_view_pixel_fwd; the pixel loss in the shade backward; sigmoid', the antialias colour
+// gradient and interpolate's backward inside the texture backward) and NO float atomics (gathering antialias, integer texel-gradient planes): bit-reproducible.
+// 0: one launch per op with scattering atomics, as in round 2 (tests compare the two)
 static bool view_pixel_fused() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("C3D_MESH_PIXEL_FUSED"); v = e ? atoi(e) != 0 : 1; }
     return v != 0;
 }
 namespace {
-struct ViewState { float* vclip; float* rast; float* rast_db; float* texc; float* albedo0; float* albedo_aa; float* cov_aa; uint8_t* hit; size_t bytes; };
+struct ViewState { float* vclip; float* rast; float* rast_db; float* texc; float* albedo0; float* albedo_aa; float* cov_aa; uint8_t* hit; float* pair_alpha; uint8_t* pflag; size_t bytes; };
 void carve_view_state(char* base, int V, int H, int W, ViewState& st) {
     size_t off = 0;
     const size_t P = (size_t)H * W;
@@ -1723,16 +1942,22 @@ void carve_view_state(char* base, int V, int H, int W, ViewState& st) {
     st.vclip = take(16 * (size_t)(V > 0 ? V : 1)); st.rast = take(16 * P); st.rast_db = take(16 * P); st.texc = take(8 * P);
     st.albedo0 = take(12 * P); st.albedo_aa = take(12 * P); st.cov_aa = take(4 * P);
     st.hit = (uint8_t*)take(2 * P);
+    st.pair_alpha = take(8 * P);
+    st.pflag = (uint8_t*)take(P);
     st.bytes = off;
 }
-struct ViewBwdScratch { float* dalbedo_aa; float* dalbedo0; float* dcov; float* duv; float* drast; float* dpos_aa; float* dpos_r; void* ras; size_t bytes; };
-void carve_view_bwd(char* base, int V, int T, int H, int W, ViewBwdScratch& sc) {
+struct ViewBwdScratch { float* dalbedo_aa; float* dalbedo0; float* dcov; float* duv; float* drast; float* dpos_aa; float* dpos_r; void* ras; TexAcc acc; size_t bytes; };
+// Ht, Wt > 0: the scratch also holds the integer planes of the texel gradient (a single view's backward; the multi-view step owns ONE pair for all its views)
+void carve_view_bwd(char* base, int V, int T, int H, int W, int Ht, int Wt, ViewBwdScratch& sc) {
     size_t off = 0;
     const size_t P = (size_t)H * W, v = (size_t)(V > 0 ? V : 1);
     auto take = [&](size_t b) { char* p = base ? base + off : nullptr; off += c3d_align(b); return p; };
     sc.dalbedo_aa = (float*)take(12 * P); sc.dalbedo0 = (float*)take(12 * P); sc.dcov = (float*)take(4 * P); sc.duv = (float*)take(8 * P); sc.drast = (float*)take(16 * P);
     sc.dpos_aa = (float*)take(16 * v); sc.dpos_r = (float*)take(16 * v);
     sc.ras = take(c3d_mesh_rasterize_bwd_scratch_bytes(1, T));
+    const size_t ntex = 3 * (size_t)(Ht > 0 ? Ht : 0) * (size_t)(Wt > 0 ? Wt : 0);
+    sc.acc.lo = sc.acc.hi = nullptr; sc.acc.bad = nullptr;
+    if (ntex) { sc.acc.lo = (long long*)take(8 * ntex + 64); sc.acc.hi = (long long*)take(8 * ntex); sc.acc.bad = base ? (uint32_t*)(sc.acc.lo + ntex) : nullptr; }   // the flag word rides behind the first plane: one memset covers both
     sc.bytes = off;
 }
 }  // namespace
@@ -1740,7 +1965,7 @@ void carve_view_bwd(char* base, int V, int T, int H, int W, ViewBwdScratch& sc) 
 extern "C" {
 
 size_t c3d_mesh_view_state_bytes(int32_t V, int32_t H, int32_t W) { ViewState st; carve_view_state(nullptr, V, H, W, st); return st.bytes; }
-size_t c3d_mesh_view_bwd_scratch_bytes(int32_t V, int32_t T, int32_t H, int32_t W) { ViewBwdScratch sc; carve_view_bwd(nullptr, V, T, H, W, sc); return sc.bytes; }
+size_t c3d_mesh_view_bwd_scratch_bytes(int32_t V, int32_t T, int32_t H, int32_t W, int32_t Ht, int32_t Wt) { ViewBwdScratch sc; carve_view_bwd(nullptr, V, T, H, W, Ht, Wt, sc); return sc.bytes; }
 
 int c3d_mesh_view_fwd(const c3d_mesh_view* d, const float* v, const float* v_offsets, const int32_t* f, const float* vt, const int32_t* ft, const float* raw_albedo,
                       const void* aa_topology, void* raster_scratch, void* state, float* image, float* alpha, c3d_stream_t stream) {
@@ -1760,7 +1985,7 @@ int c3d_mesh_view_fwd(const c3d_mesh_view* d, const float* v, const float* v_off
         if ((rc = mesh_rasterize_impl(st.vclip, f, 1, V, T, H, W, nullptr, raster_scratch, st.rast, st.rast_db, stream, false))) return rc;
         C3dProfScope ps(C3D_P_MESH_INTERPOLATE, s);
         hipLaunchKernelGGL(k_view_pixel_fwd, dim3(c3d_cdiv(P, 256)), dim3(256), 0, s, (const float4*)st.vclip, (const int3*)f, (const float2*)vt, (const int3*)ft, raw_albedo, H, W,
-                           d->Ht, d->Wt, (const unsigned long long*)raster_scratch, (float4*)st.rast, (float4*)st.rast_db, (float2*)st.texc, st.albedo0, st.albedo_aa, st.cov_aa);
+                           d->Ht, d->Wt, (const unsigned long long*)raster_scratch, (float4*)st.rast, (float4*)st.rast_db, (float2*)st.texc, st.albedo0, (float*)nullptr, (float*)nullptr);
     } else {
         if ((rc = c3d_mesh_rasterize_fwd(st.vclip, f, 1, V, T, H, W, raster_scratch, st.rast, st.rast_db, stream))) return rc;
         if ((rc = c3d_mesh_interpolate_fwd(vt, 1, st.rast, ft, nullptr, nullptr, 0, 1, d->Vt, 2, H, W, st.texc, nullptr, stream))) return rc;
@@ -1768,12 +1993,18 @@ int c3d_mesh_view_fwd(const c3d_mesh_view* d, const float* v, const float* v_off
         C3dProfScope ps(C3D_P_MESH_ANTIALIAS, s);
         hipLaunchKernelGGL(k_view_sigmoid_seed, dim3(c3d_cdiv(P, 256)), dim3(256), 0, s, st.albedo0, (const float4*)st.rast, P, st.albedo_aa, st.cov_aa);
     }
-    {
+    if (view_pixel_fused()) {      // silhouette analysis per pair, then every pixel gathers its blends and shades: no atomics (k_view_shade_fwd_g)
         C3dProfScope ps(C3D_P_MESH_ANTIALIAS, s);
-        hipLaunchKernelGGL(k_aa2_fwd, dim3(c3d_cdiv(P * 2, 256)), dim3(256), 0, s, st.albedo0, (const float4*)st.rast, (const float4*)st.vclip, (const int3*)f,
-                           (const EdgeSlot*)aa_topology, edge_table_size(T) - 1, H, W, st.albedo_aa, st.cov_aa, st.hit);
-    }
-    {
+        hipLaunchKernelGGL(k_aa2_pairs, dim3(c3d_cdiv(P * 2, 256)), dim3(256), 0, s, (const float4*)st.rast, (const float4*)st.vclip, (const int3*)f,
+                           (const EdgeSlot*)aa_topology, edge_table_size(T) - 1, H, W, st.pair_alpha, st.hit);
+        hipLaunchKernelGGL(k_view_shade_fwd_g, dim3(c3d_cdiv(P, 256)), dim3(256), 0, s, st.albedo0, (const float4*)st.rast, st.hit, st.pair_alpha, bg, H, W,
+                           st.albedo_aa, st.cov_aa, image, alpha, st.pflag);
+    } else {
+        {
+            C3dProfScope ps(C3D_P_MESH_ANTIALIAS, s);
+            hipLaunchKernelGGL(k_aa2_fwd, dim3(c3d_cdiv(P * 2, 256)), dim3(256), 0, s, st.albedo0, (const float4*)st.rast, (const float4*)st.vclip, (const int3*)f,
+                               (const EdgeSlot*)aa_topology, edge_table_size(T) - 1, H, W, st.albedo_aa, st.cov_aa, st.hit);
+        }
         C3dProfScope ps(C3D_P_OTHER, s);
         hipLaunchKernelGGL(k_view_shade_fwd, dim3(c3d_cdiv(P, 256)), dim3(256), 0, s, st.albedo_aa, st.cov_aa, bg, P, image, alpha);
     }
@@ -1783,7 +2014,7 @@ int c3d_mesh_view_fwd(const c3d_mesh_view* d, const float* v, const float* v_off
 
 static int mesh_view_bwd(const c3d_mesh_view* d, const int32_t* f, const float* vt, const int32_t* ft, const float* raw_albedo,
                          const void* aa_topology, const void* vertex_topology, void* scratch, const void* state, const float* dimage, const float* dalpha,
-                         float* d_raw_albedo, float* d_v, c3d_stream_t stream, bool zero_dtex, const ViewLossIn* li = nullptr, int loss_blocks = 0);
+                         float* d_raw_albedo, float* d_v, c3d_stream_t stream, bool zero_dtex, const ViewLossIn* li = nullptr, int loss_blocks = 0, const TexAcc* step_acc = nullptr);
 int c3d_mesh_view_bwd(const c3d_mesh_view* d, const float* v, const float* v_offsets, const int32_t* f, const float* vt, const int32_t* ft, const float* raw_albedo,
                       const void* aa_topology, const void* vertex_topology, void* scratch, const void* state, const float* dimage, const float* dalpha,
                       float* d_raw_albedo, float* d_v, c3d_stream_t stream) {
@@ -1792,7 +2023,7 @@ int c3d_mesh_view_bwd(const c3d_mesh_view* d, const float* v, const float* v_off
 }
 static int mesh_view_bwd(const c3d_mesh_view* d, const int32_t* f, const float* vt, const int32_t* ft, const float* raw_albedo,
                          const void* aa_topology, const void* vertex_topology, void* scratch, const void* state, const float* dimage, const float* dalpha,
-                         float* d_raw_albedo, float* d_v, c3d_stream_t stream, bool zero_dtex, const ViewLossIn* li, int loss_blocks) {
+                         float* d_raw_albedo, float* d_v, c3d_stream_t stream, bool zero_dtex, const ViewLossIn* li, int loss_blocks, const TexAcc* step_acc) {
     hipStream_t s = (hipStream_t)stream;
     MESH_REQUIRE(d && f && vt && ft && raw_albedo && aa_topology && scratch && state && d_raw_albedo, "c3d_mesh_view_bwd: NULL pointer");
     MESH_REQUIRE(dimage || dalpha || li, "c3d_mesh_view_bwd: no upstream gradient");
@@ -1800,29 +2031,48 @@ static int mesh_view_bwd(const c3d_mesh_view* d, const int32_t* f, const float* 
     const int V = d->V, T = d->T, H = d->H, W = d->W;
     const long long P = (long long)H * W;
     ViewState st; carve_view_state((char*)state, V, H, W, st);
-    ViewBwdScratch sc; carve_view_bwd((char*)scratch, V, T, H, W, sc);
+    const bool fused = view_pixel_fused();
+    ViewBwdScratch sc; carve_view_bwd((char*)scratch, V, T, H, W, step_acc ? 0 : d->Ht, step_acc ? 0 : d->Wt, sc);
     ViewMat M; for (int i = 0; i < 16; i++) M.m[i] = d->clip_from_world[i];
     ViewBg bg; for (int i = 0; i < 3; i++) bg.c[i] = d->bg[i];
     int rc;
     {
         C3dProfScope ps(C3D_P_OTHER, s);
-        if (li) hipLaunchKernelGGL(k_view_loss_shade_bwd, dim3((unsigned)loss_blocks), dim3(256), 0, s, st.albedo_aa, st.cov_aa, bg, P, *li, sc.dalbedo_aa, sc.dalbedo0, sc.dcov);
-        else hipLaunchKernelGGL(k_view_shade_bwd, dim3(c3d_cdiv(P, 256)), dim3(256), 0, s, st.albedo_aa, st.cov_aa, bg, P, dimage, dalpha, sc.dalbedo_aa, sc.dalbedo0, sc.dcov);
+        float* seed = fused ? (float*)nullptr : sc.dalbedo0;
+        if (li) hipLaunchKernelGGL(k_view_loss_shade_bwd, dim3((unsigned)loss_blocks), dim3(256), 0, s, st.albedo_aa, st.cov_aa, bg, P, *li, sc.dalbedo_aa, seed, sc.dcov);
+        else hipLaunchKernelGGL(k_view_shade_bwd, dim3(c3d_cdiv(P, 256)), dim3(256), 0, s, st.albedo_aa, st.cov_aa, bg, P, dimage, dalpha, sc.dalbedo_aa, seed, sc.dcov);
+    }
+    if (fused) {
+        // Gathers all the way (round 3): the texture backward gathers the antialias pass's colour gradient on load (x sigmoid'), adds the texel gradients into
+        // integer planes and leaves drast; the per-triangle pass of the rasterizer's backward also gathers the antialias pass's position gradient.
+        const size_t ntex = 3 * (size_t)d->Ht * d->Wt;
+        const TexAcc acc = step_acc ? *step_acc : sc.acc;
+        {
+            C3dProfScope ps(C3D_P_MESH_TEXTURE_BWD, s);
+            if (!step_acc) { C3D_CHECK(hipMemsetAsync(acc.lo, 0, 8 * ntex + 64, s)); C3D_CHECK(hipMemsetAsync(acc.hi, 0, 8 * ntex, s)); }
+            const ViewTexBwd z{sc.dalbedo_aa, st.hit, st.pflag, st.pair_alpha, st.albedo0, d_v ? (const float4*)st.rast : nullptr, d_v ? (const float2*)vt : nullptr,
+                               d_v ? (const int3*)ft : nullptr, d_v ? (float4*)sc.drast : nullptr, acc};
+            hipLaunchKernelGGL(k_view_tex_bwd, dim3(c3d_cdiv(W, 16), c3d_cdiv(H, 16)), dim3(256), 0, s, raw_albedo, (const float2*)st.texc, H, W, d->Ht, d->Wt, z);
+            if (!step_acc) hipLaunchKernelGGL(k_tex_acc_finalize, dim3(c3d_cdiv((long long)ntex, 256)), dim3(256), 0, s, acc, (long long)ntex, zero_dtex ? 0 : 1, d_raw_albedo);
+        }
+        if (d_v) {
+            const AaBwdIn aa{st.hit, st.pflag, st.pair_alpha, st.albedo0, sc.dalbedo_aa, sc.dcov};
+            if ((rc = mesh_rasterize_bwd_gather(st.vclip, f, st.rast, sc.drast, 1, V, T, H, W, vertex_topology, sc.ras, sc.dpos_r, stream, aa))) return rc;
+            hipLaunchKernelGGL(k_view_transform_bwd, dim3(c3d_cdiv(V, 256)), dim3(256), 0, s, M, (const float4*)nullptr, (const float4*)sc.dpos_r, V, d_v);
+        }
+        C3D_LAUNCH_CHECK();
+        return 0;
     }
     {
         C3dProfScope ps(C3D_P_MESH_ANTIALIAS_BWD, s);
         if (d_v) C3D_CHECK(hipMemsetAsync(sc.dpos_aa, 0, 16 * (size_t)V, s));
         hipLaunchKernelGGL(k_aa2_bwd, dim3(c3d_cdiv(P * 2, 256)), dim3(256), 0, s, st.albedo0, (const float4*)st.rast, (const float4*)st.vclip, (const int3*)f,
                            (const EdgeSlot*)aa_topology, edge_table_size(T) - 1, sc.dalbedo_aa, sc.dcov, V, H, W, sc.dalbedo0, d_v ? sc.dpos_aa : nullptr, st.hit);
-        if (!view_pixel_fused()) hipLaunchKernelGGL(k_view_sigmoid_bwd, dim3(c3d_cdiv(P * 3, 256)), dim3(256), 0, s, st.albedo0, sc.dalbedo0, P * 3);
+        hipLaunchKernelGGL(k_view_sigmoid_bwd, dim3(c3d_cdiv(P * 3, 256)), dim3(256), 0, s, st.albedo0, sc.dalbedo0, P * 3);
     }
-    if (view_pixel_fused()) {
-        // the sigmoid's derivative rides on the texture backward's load of dy, interpolate's backward for the uv attribute on its epilogue (drast instead of duv)
-        const TexBwdFused fz{st.albedo0, d_v ? (const float4*)st.rast : nullptr, d_v ? (const float2*)vt : nullptr, d_v ? (const int3*)ft : nullptr, d_v ? (float4*)sc.drast : nullptr};
-        if ((rc = mesh_texture_bwd(raw_albedo, 1, st.texc, sc.dalbedo0, 1, H, W, d->Ht, d->Wt, 3, 1, 0, d_raw_albedo, sc.duv, stream, zero_dtex, fz))) return rc;
-    } else if ((rc = mesh_texture_bwd(raw_albedo, 1, st.texc, sc.dalbedo0, 1, H, W, d->Ht, d->Wt, 3, 1, 0, d_raw_albedo, sc.duv, stream, zero_dtex))) return rc;
+    if ((rc = mesh_texture_bwd(raw_albedo, 1, st.texc, sc.dalbedo0, 1, H, W, d->Ht, d->Wt, 3, 1, 0, d_raw_albedo, sc.duv, stream, zero_dtex))) return rc;
     if (d_v) {
-        if (!view_pixel_fused() && (rc = c3d_mesh_interpolate_bwd(vt, 1, st.rast, ft, sc.duv, 1, d->Vt, 2, H, W, nullptr, sc.drast, stream))) return rc;
+        if ((rc = c3d_mesh_interpolate_bwd(vt, 1, st.rast, ft, sc.duv, 1, d->Vt, 2, H, W, nullptr, sc.drast, stream))) return rc;
         if ((rc = c3d_mesh_rasterize_bwd_gather(st.vclip, f, st.rast, sc.drast, 1, V, T, H, W, vertex_topology, sc.ras, sc.dpos_r, stream))) return rc;
         hipLaunchKernelGGL(k_view_transform_bwd, dim3(c3d_cdiv(V, 256)), dim3(256), 0, s, M, (const float4*)sc.dpos_aa, (const float4*)sc.dpos_r, V, d_v);
     }
@@ -1897,15 +2147,18 @@ __global__ void __launch_bounds__(256) k_mesh_sum(MeshSumSrc src, long long coun
 
 namespace {
 struct MeshStepLane { char* state; char* bwd; char* raster; float* image; float* alpha; float* image_chw; float* dssim; float* dimage; char* ms_ws; float* d_ra; };
-struct MeshStepWs { MeshStepLane lane[C3D_MAX_LANES]; float* d_v; size_t d_v_stride; float* loss_part; size_t bytes; };
+struct MeshStepWs { TexAcc acc; MeshStepLane lane[C3D_MAX_LANES]; float* d_v; size_t d_v_stride; float* loss_part; size_t bytes; };
 void carve_mesh_step(char* base, int V, int T, int H, int W, int Ht, int Wt, int n_views, int lanes, MeshStepWs& w) {
     size_t off = 0;
     const size_t P = (size_t)H * W;
     auto take = [&](size_t b) { char* p = base ? base + off : nullptr; off += c3d_align(b); return p; };
+    const size_t ntex = 3 * (size_t)Ht * Wt;
+    // first, so that its address does not depend on the lane count: the integer planes ALL views of the step add their texel gradients into (k_view_tex_bwd)
+    w.acc.lo = (long long*)take(8 * ntex + 64); w.acc.hi = (long long*)take(8 * ntex); w.acc.bad = base ? (uint32_t*)(w.acc.lo + ntex) : nullptr;
     for (int l = 0; l < lanes; l++) {
         MeshStepLane& q = w.lane[l];
         q.state = take(c3d_mesh_view_state_bytes(V, H, W));
-        q.bwd = take(c3d_mesh_view_bwd_scratch_bytes(V, T, H, W));
+        q.bwd = take(c3d_mesh_view_bwd_scratch_bytes(V, T, H, W, 0, 0));
         q.raster = take(c3d_mesh_raster_scratch_bytes(1, H, W, T));
         q.image = (float*)take(12 * P); q.alpha = (float*)take(4 * P); q.image_chw = (float*)take(12 * P); q.dssim = (float*)take(12 * P); q.dimage = (float*)take(12 * P);
         q.ms_ws = take(c3d_msssim_workspace_bytes(1, 3, H, W));
@@ -1950,11 +2203,17 @@ int c3d_mesh_train_views(const c3d_mesh_view* views, int32_t n_views, const floa
     const size_t ntex = 3 * (size_t)d0.Ht * d0.Wt;
     hipStream_t ls[C3D_MAX_LANES];
     int L = 1;
-    if (c3d_lanes_fork(s0, lanes, n_views, ls, &L)) return -1;
     MeshStepWs w;
+    const bool fused = view_pixel_fused();
+    if (fused) {      // the shared integer planes are cleared on the caller's stream BEFORE the lanes fork from it
+        carve_mesh_step((char*)workspace, d0.V, d0.T, d0.H, d0.W, d0.Ht, d0.Wt, n_views, 1, w);
+        C3D_CHECK(hipMemsetAsync(w.acc.lo, 0, 8 * ntex + 64, s0));
+        C3D_CHECK(hipMemsetAsync(w.acc.hi, 0, 8 * ntex, s0));
+    }
+    if (c3d_lanes_fork(s0, lanes, n_views, ls, &L)) return -1;
     carve_mesh_step((char*)workspace, d0.V, d0.T, d0.H, d0.W, d0.Ht, d0.Wt, n_views, L, w);
     int rc_all = 0;
-    for (int l = 0; l < L && !rc_all; l++)
+    for (int l = 0; l < L && !rc_all && !fused; l++)
         if (hipMemsetAsync(w.lane[l].d_ra, 0, sizeof(float) * ntex, ls[l]) != hipSuccess) { c3d_set_error("c3d_mesh_train_views: memset failed"); rc_all = -1; }
     for (int i = 0; i < n_views && !rc_all; i++) {
         hipStream_t s = ls[i % L];
@@ -1972,14 +2231,14 @@ int c3d_mesh_train_views(const c3d_mesh_view* views, int32_t n_views, const floa
                     hipLaunchKernelGGL(k_mesh_hwc_to_chw, dim3(c3d_cdiv(P, 256)), dim3(256), 0, s, q.image, P, q.image_chw);
                     if ((rc = ms_value_grad(target_chw[i], q.image_chw, mk, 0, 1, 3, d->H, d->W, -ws_, 0, q.dssim, ws_, -ws_, loss_out ? lp + 1024 : nullptr, q.ms_ws, s, 1))) break;
                 }
-                if (!view_pixel_fused())
+                if (!fused)
                     hipLaunchKernelGGL(k_mesh_pixel_loss, dim3((unsigned)nblk), dim3(256), 0, s, q.image, target_chw[i], mk, P,
                                        loss->scale * loss->w_mse, ssim ? q.dssim : (const float*)nullptr, q.dimage, loss_out ? lp : (float*)nullptr);
             }
             float* dv = d_v_offsets ? (float*)((char*)w.d_v + (size_t)i * w.d_v_stride) : nullptr;
-            if (view_pixel_fused()) {      // the pixel loss inside the backward pass's first kernel: d/dimage is never materialised
+            if (fused) {      // the pixel loss inside the backward pass's first kernel: d/dimage is never materialised
                 const ViewLossIn li{q.image, target_chw[i], mk, ssim ? q.dssim : (const float*)nullptr, loss->scale * loss->w_mse, loss_out ? lp : (float*)nullptr};
-                if ((rc = mesh_view_bwd(d, f, vt, ft, raw_albedo, aa_topology, vertex_topology, q.bwd, q.state, nullptr, nullptr, q.d_ra, dv, (c3d_stream_t)s, false, &li, nblk))) break;
+                if ((rc = mesh_view_bwd(d, f, vt, ft, raw_albedo, aa_topology, vertex_topology, q.bwd, q.state, nullptr, nullptr, q.d_ra, dv, (c3d_stream_t)s, false, &li, nblk, &w.acc))) break;
             } else if ((rc = mesh_view_bwd(d, f, vt, ft, raw_albedo, aa_topology, vertex_topology, q.bwd, q.state, q.dimage, nullptr, q.d_ra, dv, (c3d_stream_t)s, false))) break;
         } while (0);
         rc_all = rc;
@@ -1988,9 +2247,12 @@ int c3d_mesh_train_views(const c3d_mesh_view* views, int32_t n_views, const floa
     if (rc_all) return rc_all;
     {
         C3dProfScope ps(C3D_P_OTHER, s0);
-        MeshSumSrc a; a.n = L;
-        for (int l = 0; l < L; l++) a.p[l] = w.lane[l].d_ra;
-        hipLaunchKernelGGL(k_mesh_sum, dim3(c3d_cdiv((long long)ntex, 256)), dim3(256), 0, s0, a, (long long)ntex, accumulate, d_raw_albedo);
+        if (fused) hipLaunchKernelGGL(k_tex_acc_finalize, dim3(c3d_cdiv((long long)ntex, 256)), dim3(256), 0, s0, w.acc, (long long)ntex, accumulate, d_raw_albedo);
+        else {
+            MeshSumSrc a; a.n = L;
+            for (int l = 0; l < L; l++) a.p[l] = w.lane[l].d_ra;
+            hipLaunchKernelGGL(k_mesh_sum, dim3(c3d_cdiv((long long)ntex, 256)), dim3(256), 0, s0, a, (long long)ntex, accumulate, d_raw_albedo);
+        }
         if (d_v_offsets) {
             MeshSumSrc b; b.n = n_views;
             for (int i = 0; i < n_views; i++) b.p[i] = (const float*)((const char*)w.d_v + (size_t)i * w.d_v_stride);

@@ -142,14 +142,16 @@ int c3d_mesh_shade_bwd(const float* albedo, const float* alpha, const float* bg,
  *             may read rast ([H,W,4] floats at byte offset align256(16 V)) for the depth / normal outputs the reference produces on demand
  *   aa_topology / vertex_topology : c3d_mesh_antialias_build_topology / c3d_mesh_build_vertex_topology of `f`
  *   _bwd    : dimage [H,W,3], dalpha [H,W,1] (either may be NULL) -> d_raw_albedo [Ht,Wt,3] WRITTEN IN FULL, d_v [V,3] written in full
- *             (NULL: geometry not trained; vertex_topology may then be NULL).  scratch: c3d_mesh_view_bwd_scratch_bytes(V, T, H, W). */
+ *             (NULL: geometry not trained; vertex_topology may then be NULL).  scratch: c3d_mesh_view_bwd_scratch_bytes(V, T, H, W, Ht, Wt).
+ *             Round 3 (ABI 301): no float atomics anywhere on this path -- the antialias blends, their colour and position gradients are gathers over a
+ *             pixel's four pairs, texel gradients are added as 64-bit integers (two planes of Ht Wt 3 words in `scratch`): same bits every run. */
 typedef struct c3d_mesh_view {
     int32_t V, T, Vt, H, W, Ht, Wt;
     float clip_from_world[16];      /* row-major 4x4 */
     float bg[3];
 } c3d_mesh_view;
 size_t c3d_mesh_view_state_bytes(int32_t V, int32_t H, int32_t W);
-size_t c3d_mesh_view_bwd_scratch_bytes(int32_t V, int32_t T, int32_t H, int32_t W);
+size_t c3d_mesh_view_bwd_scratch_bytes(int32_t V, int32_t T, int32_t H, int32_t W, int32_t Ht, int32_t Wt);
 int c3d_mesh_view_fwd(const c3d_mesh_view* d, const float* v, const float* v_offsets, const int32_t* f, const float* vt, const int32_t* ft,
                       const float* raw_albedo, const void* aa_topology, void* raster_scratch, void* state, float* image, float* alpha,
                       c3d_stream_t stream);

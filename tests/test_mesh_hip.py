@@ -1,6 +1,7 @@
 """Parity tests (-m gpu) of the HIP mesh ops behind `nvdiffrast.torch`, through the C-ABI, against oracle/mesh_oracle.c.
 Integers (triangle ids) exact up to a vanishing number of depth near-ties; images L1 <= 1e-4; gradients <= 1e-3 relative."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -388,20 +389,17 @@ def test_diffmesh_fused_step_equals_per_view_autograd_step(lam, geo, lanes):
     assert torch.allclose(a0, a1, atol=0.11) and float((a0 - a1).abs().mean()) <= 2e-3
 
 
-def test_fused_mesh_step_accumulate_lanes_and_argument_checks():
-    """c3d_mesh_train_views through FusedMeshStep: accumulate=True adds to the gradient buffers, the result does not depend on the number of view
-    lanes beyond the rounding of the texture gradient's float atomics, a rank without views leaves zero gradients, and bad arguments are refused
-    with a message (NULL pointers, the MS-SSIM term on images that are too small for its five scales)."""
-    from c3d_hip.mesh_step import FusedMeshStep
-    from c3d_hip.mesh_sigs import MeshStepLoss, MeshView
+def _small_mesh_step_case():
+    """three views (two backgrounds, masks of all kinds) of the test mesh with a 64^2 texture and vertex offsets, 192^2"""
     from shared_utils.camera_utils import OrbitCamera, orbit_camera
     import nvdiffrast.torch as dr
     H = W = 192
     mesh = _torch_mesh()
     mesh.albedo = None
     mesh.set_new_albedo(64, 64)
-    raw = torch.randn((64, 64, 3), device="cuda") * 0.5
-    off = torch.randn_like(mesh.v) * 1e-3
+    g = torch.Generator(device="cpu").manual_seed(11)
+    raw = (torch.randn((64, 64, 3), generator=g) * 0.5).cuda()
+    off = (torch.randn(tuple(mesh.v.shape), generator=g) * 1e-3).cuda()
     cam = OrbitCamera(W, H, fovy=49.1)
     proj = cam.perspective.astype(np.float32)
     views = [((proj @ np.linalg.inv(orbit_camera(-20.0, az, 2.0).astype(np.float32)).astype(np.float32)).astype(np.float32), bg) for az, bg in ((0.0, (1, 1, 1)), (100.0, (0, 0, 0)), (-130.0, (1, 1, 1)))]
@@ -409,7 +407,53 @@ def test_fused_mesh_step_accumulate_lanes_and_argument_checks():
     targets = [T(rng.uniform(size=(3, H, W)).astype(np.float32)) for _ in views]
     masks = [T(rng.uniform(0.3, 1.0, size=(1, H, W)).astype(np.float32)), None, T(np.ones((1, H, W), np.float32))]
     f, ft, vt = mesh.f.to(torch.int32).contiguous(), mesh.ft.to(torch.int32).contiguous(), mesh.vt.float().contiguous()
-    glctx = dr.RasterizeCudaContext()
+    return H, W, mesh, raw, off, views, targets, masks, f, ft, vt, dr.RasterizeCudaContext()
+
+
+def _run_small_mesh_step(lanes, out=None):
+    """one fused step of the case above -> (loss, d_raw_albedo, d_v_offsets) as numpy; also the entry point of the child process of the test below"""
+    from c3d_hip.mesh_step import FusedMeshStep
+    H, W, mesh, raw, off, views, targets, masks, f, ft, vt, glctx = _small_mesh_step_case()
+    st = FusedMeshStep("cuda", lanes=lanes)
+    d_ra, d_vo = torch.empty_like(raw), torch.empty_like(off)
+    loss = st.run(views, mesh.v, off, f, vt, ft, raw, glctx, targets, masks, d_ra, d_vo, H, W, w_mse=0.7, w_ssim=0.3, scale=1 / 3)
+    r = dict(loss=loss.detach().cpu().numpy().copy(), d_ra=d_ra.cpu().numpy(), d_vo=d_vo.cpu().numpy())
+    if out:
+        np.savez(out, **r)
+    return r
+
+
+def test_fused_mesh_step_is_bit_reproducible_and_equals_the_scattering_kernels():
+    """Round 3: the fused view has no float atomics left (the antialias blends and their gradients are gathers over a pixel's four pairs, texel gradients
+    are added as 64-bit integers): loss, texture gradient and vertex gradient have the SAME BITS on every run and for every number of view lanes.  The
+    round-2 kernels (one launch per op, scattering float atomics: C3D_MESH_PIXEL_FUSED=0, read at first use, hence a child process) give the same values
+    to rounding."""
+    import subprocess, sys, tempfile
+    runs = [_run_small_mesh_step(l) for l in (3, 3, 1, 2)]
+    assert float(np.abs(runs[0]["d_ra"]).max()) > 0 and float(np.abs(runs[0]["d_vo"]).max()) > 0
+    for r in runs[1:]:
+        for k in ("loss", "d_ra", "d_vo"):
+            assert np.array_equal(runs[0][k], r[k]), k
+    here = os.path.dirname(os.path.abspath(__file__))
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "o.npz")
+        code = ("import sys; sys.path[:0] = [%r, %r, %r]; import test_mesh_hip as M; M._run_small_mesh_step(2, %r)\n"
+                % (here, os.path.dirname(here), os.path.join(os.path.dirname(here), "comfyui-3d-pack_amd"), out))
+        subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, C3D_MESH_PIXEL_FUSED="0"), timeout=600)
+        other = np.load(out)
+        l0, l1 = float(np.asarray(runs[0]["loss"]).reshape(-1)[0]), float(np.asarray(other["loss"]).reshape(-1)[0])
+        assert abs(l1 - l0) <= 1e-5 * abs(l0)
+        assert rel_err(runs[0]["d_ra"], other["d_ra"]) <= 2e-5 and rel_err(runs[0]["d_vo"], other["d_vo"]) <= 2e-5
+
+
+def test_fused_mesh_step_accumulate_lanes_and_argument_checks():
+    """c3d_mesh_train_views through FusedMeshStep: accumulate=True adds to the gradient buffers, the result does not depend on the number of view
+    lanes, a rank without views leaves zero gradients, and bad arguments are refused with a message (NULL pointers, the MS-SSIM term on images that
+    are too small for its five scales)."""
+    from c3d_hip.mesh_step import FusedMeshStep
+    from c3d_hip.mesh_sigs import MeshStepLoss, MeshView
+    import nvdiffrast.torch as dr
+    H, W, mesh, raw, off, views, targets, masks, f, ft, vt, glctx = _small_mesh_step_case()
     res = {}
     for lanes in (1, 3):
         st = FusedMeshStep("cuda", lanes=lanes)
