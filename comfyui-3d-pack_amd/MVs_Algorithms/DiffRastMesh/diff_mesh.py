@@ -82,7 +82,8 @@ class DiffMesh:
                  exchange="allreduce"):
         self.device = torch.device(device)
         self.train_mesh_geometry, self.remesh_after_n_iteration = train_mesh_geometry, remesh_after_n_iteration
-        if train_mesh_geometry and remesh_after_n_iteration and remesh_after_n_iteration < training_iterations:
+        self.remesh_skipped = bool(train_mesh_geometry and remesh_after_n_iteration and remesh_after_n_iteration < training_iterations)   # the node reports it in its output
+        if self.remesh_skipped:
             # validated here, not 512 steps into a run: the pymeshlab remesh is CPU asset tooling outside this path
             warnings.warn("DiffMesh: remesh_after_n_iteration=%d < training_iterations=%d asks for the periodic pymeshlab remesh, which this "
                           "implementation does not contain; geometry training continues on the input topology without it"

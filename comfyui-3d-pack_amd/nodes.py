@@ -309,7 +309,11 @@ class Fitting_Mesh_With_Multiview_Images:
                               ms_ssim_loss_weight, remesh_after_n_iteration, invert_background_probability, force_cuda_rasterize)
             fitter.prepare_training(reference_images, reference_masks, reference_orbit_camera_poses, reference_orbit_camera_fovy)
             fitter.training()
-            return fitter.get_mesh_and_texture()
+            out = fitter.get_mesh_and_texture()
+        if fitter.remesh_skipped:      # the reference remeshes every remesh_after_n_iteration steps (pymeshlab, diff_mesh.py:132-141): not part of this implementation
+            return {"ui": {"text": ["Fitting_Mesh_With_Multiview_Images: the periodic remesh (every %d iterations) was SKIPPED -- the returned mesh keeps the input "
+                                    "topology (%d vertices, %d faces)" % (remesh_after_n_iteration, int(out[0].v.shape[0]), int(out[0].f.shape[0]))]}, "result": out}
+        return out
 
 
 NODE_CLASS_MAPPINGS = {"[Comfy3D] " + n.replace("_", " "): c for n, c in

@@ -376,6 +376,10 @@ def test_diffmesh_validates_the_remesh_interval_up_front():
     assert "raise NotImplementedError" not in src                                 # nothing aborts 512 steps into a run any more
     ctor = src[src.index("class DiffMesh:"):src.index("def prepare_training")]
     assert "warnings.warn(" in ctor and "remesh_after_n_iteration < training_iterations" in ctor
+    # the skip is also surfaced in the node's output (a ComfyUI "ui" text entry), not only as a Python warning
+    node = open(os.path.join(PKG, "nodes.py")).read()
+    body = node[node.index("def fitting_mesh"):node.index("NODE_CLASS_MAPPINGS")]
+    assert "fitter.remesh_skipped" in body and '"ui"' in body and '"result": out' in body
 
 
 # ---------------------------------------------------------------- ZeRO-1 and wider worlds
