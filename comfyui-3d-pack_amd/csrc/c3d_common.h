@@ -58,7 +58,10 @@ int c3d_scan_u32(const uint32_t* in, uint32_t* out, size_t n, bool exclusive, vo
 // tail_status (optional): [0] |= 1 when total > tail_cap, [1] = max(total).
 int c3d_scan_gather_u32(const uint32_t* in, const uint32_t* idx, uint32_t* out, size_t n, bool exclusive, void* tmp, hipStream_t s, bool zero_state,
                         uint32_t* tail_meta, uint32_t* tail_status, uint32_t tail_cap, uint32_t* err = nullptr);
-int c3d_scan_u32_einfo(const uint32_t* in, uint32_t* out, size_t n, void* tmp, hipStream_t s, bool zero_state, uint32_t* err, const uint2* rect, uint4* einfo);
+int c3d_scan_u32_einfo(const uint32_t* in, uint32_t* out, size_t n, void* tmp, hipStream_t s, bool zero_state, uint32_t* err, const uint2* rect, uint4* einfo,
+                       uint32_t* tail_meta = nullptr, uint32_t* tail_status = nullptr, uint32_t tail_cap = 0xFFFFFFFFu);   // tail_*: the grand total, as c3d_scan_gather_u32 leaves it
+// every segment [ranges[t].x, ranges[t].y) of vals reordered by key_table[val], ascending, stable; vbuf1: scratch as long as vals
+int c3d_segment_sort_u32(const uint2* ranges, int nseg, const uint32_t* key_table, uint32_t* vals, uint32_t* vbuf1, hipStream_t s);
 uint32_t* c3d_scan_error_word(void* tmp);
 
 // Stable LSD radix sort of (key,val) uint32 pairs over key bits [0, end_bit), n < 2^30.

@@ -58,10 +58,24 @@ static int check_inputs(int N, int M, int deg, const float* means3D, const float
 // A2-A4' shared by every forward entry point: record bases (scan in Gaussian-id order), depth sort, emit offsets (scan in depth-rank
 // order, gather folded in).  Three single-pass primitives, their state cleared by ONE memset; 7 launches where round 1 issued 21.
 // cap / status: pair capacity and status words of the sync-free paths (the pair count then stays on the device in g.meta[0]).
+// C3D_BIN_LOCAL = 0 (default): global depth sort of the Gaussians, second scan in depth-rank order, rank-ordered emission, tile sort, ranges.
+// 1 (round 3, built and measured): ONE scan (record bases = emission offsets in Gaussian-id order), emission in id order, tile sort, ranges, then the depth order
+// per tile (c3d_segment_sort_u32) -- the same lists bit for bit, five latency-bound launches fewer per view.  It loses: ordering AFTER duplication sorts 4.0 M
+// (tile, splat) pairs instead of 1.0 M Gaussians, and the ballot ranking costs ~1 VALU instruction per element and pass -- throughput-bound work (0.10 ms per view)
+// in exchange for latency-bound work (0.13 + 0.025 ms) that the view lanes were hiding anyway: 5.94 vs 5.88 ms per step (profiles/r03/r03g_*).
+static bool gs_bin_local() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("C3D_BIN_LOCAL"); v = e ? atoi(e) != 0 : 0; }
+    return v != 0;
+}
 static int binning_front(GsGeom& g, int N, uint32_t cap, uint32_t* status, hipStream_t s) {
     int rc, res = 0;
     C3D_CHECK(hipMemsetAsync(g.meta, 0, g.zero_bytes, s));
     uint32_t* err = status ? status : (uint32_t*)g.meta + 2;      // a timed-out look-back (bounded spins) surfaces as C3D_ERR_LOOKBACK
+    if (gs_bin_local()) {
+        C3dProfScope ps(C3D_P_SCAN, s);
+        return c3d_scan_u32_einfo(g.tiles, g.rbase, (size_t)N, g.tmp_scan_a, s, false, err, g.rect, g.einfo, (uint32_t*)g.meta, status, cap);
+    }
     { C3dProfScope ps(C3D_P_SCAN, s);
       if ((rc = c3d_scan_u32_einfo(g.tiles, g.rbase, (size_t)N, g.tmp_scan_a, s, false, err, g.rect, g.einfo))) return rc; }
     { C3dProfScope ps(C3D_P_DEPTH_SORT, s);
@@ -81,12 +95,16 @@ static int binning_back(const GsParams& p, GsGeom& g, GsBinning& b, const int* r
     if (D <= 0) return 0;
     uint32_t* err = status ? status : (uint32_t*)g.meta + 2;
     { C3dProfScope ps(C3D_P_EMIT, s);
-      if ((rc = gs_launch_emit(p, g, sort_result_index(32), radii, b, s, cap))) return rc; }
+      if ((rc = gs_launch_emit(p, g, gs_bin_local() ? -1 : sort_result_index(32), radii, b, s, cap))) return rc; }
     { C3dProfScope ps(C3D_P_TILE_SORT, s);
       if ((rc = c3d_sort_pairs_u32(b.tkey[0], b.tkey[1], b.tval[0], b.tval[1], false, (size_t)D, tile_sort_bits(tiles), b.tmp, &res, s, d_dev, false, err))) return rc; }
     if (res != sort_result_index(tile_sort_bits(tiles))) { c3d_set_error("internal: tile sort buffer parity"); return -2; }
     { C3dProfScope ps(C3D_P_RANGES, s);
       if ((rc = gs_launch_ranges(b, res, D, tiles, s, d_dev))) return rc; }
+    if (gs_bin_local()) {      // depth order inside every tile's list (keys: the depth bits k_preprocess left per Gaussian); the idle value buffer is the scratch of long lists
+        C3dProfScope ps(C3D_P_DEPTH_SORT, s);
+        if ((rc = c3d_segment_sort_u32(b.ranges, tiles, g.key[0], b.tval[res], b.tval[res ^ 1], s))) return rc;
+    }
     *res_out = res;
     return 0;
 }
@@ -784,6 +802,17 @@ int c3d_test_scan_u32(const uint32_t* in, uint32_t* out, int64_t n, int32_t excl
     return rc;
 }
 int c3d_test_sort_phases(uint64_t* stamps) { return c3d_sort_set_debug((unsigned long long*)stamps); }
+int c3d_test_segment_sort_u32(const uint32_t* ranges, int32_t nseg, const uint32_t* key_table, uint32_t* vals, int64_t n, c3d_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (n <= 0 || nseg <= 0) return 0;
+    if (!ranges || !key_table || !vals) { c3d_set_error("c3d_test_segment_sort_u32: NULL pointer"); return -1; }
+    uint32_t* v1 = nullptr;
+    C3D_CHECK(hipMalloc(&v1, 4 * (size_t)n));
+    int rc = c3d_segment_sort_u32((const uint2*)ranges, nseg, key_table, vals, v1, s);
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(v1);
+    return rc;
+}
 int c3d_test_sort_pairs_u32(uint32_t* keys, uint32_t* vals, int64_t n, int32_t end_bit, c3d_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     if (n <= 0) return 0;

@@ -226,10 +226,26 @@ __global__ void __launch_bounds__(256) k_emit(GsParams p, const uint32_t* __rest
             off++;
         }
 }
+// Round 3 (gs_bin_local): emission in Gaussian-ID order -- a Gaussian's pairs start at its record base (the ONE scan of the chain), reads are coalesced -- and the depth
+// order is established per tile afterwards (c3d_segment_sort_u32); no global depth sort, no second scan.
+__global__ void __launch_bounds__(256) k_emit_id(GsParams p, const uint32_t* __restrict__ tiles, const uint4* __restrict__ einfo, uint32_t* __restrict__ tkey,
+                                                  uint32_t* __restrict__ tval, uint32_t cap) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= p.N || tiles[gid] == 0u) return;
+    const uint4 ei = einfo[gid];
+    uint32_t off = ei.w;
+    const int x0 = (int)(ei.y & 0xFFFFu), y0 = (int)(ei.y >> 16), x1 = (int)(ei.z & 0xFFFFu), y1 = (int)(ei.z >> 16);
+    for (int y = y0; y < y1; y++)
+        for (int x = x0; x < x1; x++) {
+            if (off < cap) { tkey[off] = (uint32_t)(y * p.gx + x); tval[off] = (uint32_t)gid; }
+            off++;
+        }
+}
 int gs_launch_emit(const GsParams& p, const GsGeom& g, int res, const int* radii, GsBinning& b, hipStream_t s, uint32_t cap) {
     (void)radii;
     if (p.N == 0) return 0;
-    hipLaunchKernelGGL(k_emit, dim3(c3d_cdiv(p.N, 256)), dim3(256), 0, s, p, g.order[res], g.offsets, g.einfo, b.tkey[0], b.tval[0], cap);
+    if (res < 0) hipLaunchKernelGGL(k_emit_id, dim3(c3d_cdiv(p.N, 256)), dim3(256), 0, s, p, g.tiles, g.einfo, b.tkey[0], b.tval[0], cap);      // res < 0: id order
+    else hipLaunchKernelGGL(k_emit, dim3(c3d_cdiv(p.N, 256)), dim3(256), 0, s, p, g.order[res], g.offsets, g.einfo, b.tkey[0], b.tval[0], cap);
     C3D_LAUNCH_CHECK();
     return 0;
 }

@@ -154,8 +154,9 @@ int c3d_scan_u32(const uint32_t* in, uint32_t* out, size_t n, bool exclusive, vo
     return scan_launch(in, nullptr, out, n, exclusive, tmp, s, zero_state, ScanTail{nullptr, nullptr, 0u, nullptr, nullptr}, err);
 }
 // exclusive scan of `in` (tile counts in Gaussian-id order) -> out (record bases), plus einfo[i] = {0, rect[i].x, rect[i].y, out[i]} where in[i] != 0
-int c3d_scan_u32_einfo(const uint32_t* in, uint32_t* out, size_t n, void* tmp, hipStream_t s, bool zero_state, uint32_t* err, const uint2* rect, uint4* einfo) {
-    return scan_launch(in, nullptr, out, n, true, tmp, s, zero_state, ScanTail{nullptr, nullptr, 0u, rect, einfo}, err);
+int c3d_scan_u32_einfo(const uint32_t* in, uint32_t* out, size_t n, void* tmp, hipStream_t s, bool zero_state, uint32_t* err, const uint2* rect, uint4* einfo,
+                       uint32_t* tail_meta, uint32_t* tail_status, uint32_t tail_cap) {
+    return scan_launch(in, nullptr, out, n, true, tmp, s, zero_state, ScanTail{tail_meta, tail_status, tail_cap, rect, einfo}, err);
 }
 int c3d_scan_gather_u32(const uint32_t* in, const uint32_t* idx, uint32_t* out, size_t n, bool exclusive, void* tmp, hipStream_t s, bool zero_state,
                         uint32_t* tail_meta, uint32_t* tail_status, uint32_t tail_cap, uint32_t* err) {
@@ -428,6 +429,234 @@ int c3d_sort_pairs_u32(uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32
         cur ^= 1;
     }
     *result_buf = cur;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Segmented sort (round 3): every segment [ranges[t].x, ranges[t].y) of `vals` is reordered by key_table[val], ascending and STABLE (equal keys keep their
+// input order).  The 3DGS binning uses it for the depth order INSIDE each tile's list -- the lists leave the tile sort in Gaussian-id order -- in place of a global
+// depth sort of all Gaussians before emission (five latency-bound launches + a second chained scan per view).  One 256-thread workgroup per segment.
+//   n <= SEG_CAP: LSD radix sort on 8-bit digits entirely in LDS: ballot ranking as in k_onesweep (each wave owns a contiguous chunk -> stable), keys and values
+//                 live in registers between passes, digits on which all keys of the segment agree (the high bytes of a tile's depths, usually) are skipped;
+//   n >  SEG_CAP: the same ranking chunk by chunk through a global ping-pong of the values (vals <-> vbuf1; keys are re-gathered from the table; four passes, the
+//                 result ends in vals); rare (a tile with more than 4096 splats) and correct rather than fast.
+// ------------------------------------------------------------------------------------------
+#define SEG_CAP 4096
+#define SEG_ITEMS (SEG_CAP / 256)
+// rank of each of the wave's items among the items of this workgroup chunk that precede it with the same digit, within the wave (+ the wave's running count of the
+// digit in whist[wave][]); item i of lane l is element i * 64 + l of the wave's contiguous run.  whist must be zero on entry.
+// Element p = first + i * 64 + lane exists iff p < n.
+__device__ __forceinline__ void seg_rank(const uint32_t key[SEG_ITEMS], uint32_t first, uint32_t n, int items, int shift, uint32_t (*whist)[RS_RADIX], int wave, int lane,
+                                         uint32_t rank[SEG_ITEMS]) {
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int i = 0; i < SEG_ITEMS; i++) {
+        if (i < items) {
+            const bool ok = first + (uint32_t)i * 64u + (uint32_t)lane < n;
+            const uint32_t d = (key[i] >> shift) & (RS_RADIX - 1);
+            uint64_t peers = __ballot(ok);
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                const uint64_t m = __ballot((d >> b) & 1u);
+                peers &= ((d >> b) & 1u) ? m : ~m;
+            }
+            const uint32_t prefix = whist[wave][d];
+            const uint32_t r = (uint32_t)__popcll(peers & lt_mask);
+            if (ok && r == 0) whist[wave][d] = prefix + (uint32_t)__popcll(peers);
+            rank[i] = prefix + r;
+        }
+    }
+}
+// Segments of up to SEGW_CAP elements: ONE WAVE per segment (64-thread workgroups), nothing to synchronise with -- a tile's list is ~500 entries, and the
+// 256-thread kernel below spends its time in ~7 barriers per pass and in per-pass costs that do not shrink with the segment (256-digit tables for 4 waves).
+#define SEGW_CAP 1024
+__global__ void __launch_bounds__(64, 8) k_segment_sort_w(const uint2* __restrict__ ranges, int nseg, const uint32_t* __restrict__ key_table, uint32_t* __restrict__ vals) {
+    __shared__ uint32_t cnt[1][RS_RADIX];
+    __shared__ uint32_t skey[SEGW_CAP];
+    __shared__ uint32_t sval[SEGW_CAP];
+    const int t = blockIdx.x;
+    if (t >= nseg) return;
+    const uint2 rg = ranges[t];
+    const uint32_t n = rg.y > rg.x ? rg.y - rg.x : 0u;
+    if (n <= 1u || n > SEGW_CAP) return;
+    const int lane = threadIdx.x;
+    const int items = (int)((n + 63u) / 64u);
+    uint32_t key[SEG_ITEMS], val[SEG_ITEMS], rank[SEG_ITEMS];
+    uint32_t vor = 0u, vand = 0xFFFFFFFFu;
+#pragma unroll
+    for (int i = 0; i < SEG_ITEMS; i++) {
+        key[i] = 0xFFFFFFFFu; val[i] = 0u;
+        if (i < items) {
+            const uint32_t p = (uint32_t)i * 64u + (uint32_t)lane;
+            if (p < n) { val[i] = vals[rg.x + p]; key[i] = key_table[val[i]]; vor |= key[i]; vand &= key[i]; }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { vor |= (uint32_t)__shfl_xor((int)vor, o, 64); vand &= (uint32_t)__shfl_xor((int)vand, o, 64); }
+    const uint32_t diff = vor & ~vand;
+    for (int pass = 0; pass < 4; pass++) {
+        const int shift = 8 * pass;
+        if (!((diff >> shift) & 0xFFu)) continue;
+        __syncthreads();                                   // one wave: these cost nothing and keep the LDS accesses of the phases in program order
+#pragma unroll
+        for (int k = 0; k < 4; k++) cnt[0][k * 64 + lane] = 0u;
+        __syncthreads();
+        seg_rank(key, 0u, n, items, shift, cnt, 0, lane, rank);
+        __syncthreads();
+        {   // lane l owns digits 4l .. 4l+3: counts -> starts
+            const uint32_t c0 = cnt[0][4 * lane], c1 = cnt[0][4 * lane + 1], c2 = cnt[0][4 * lane + 2], c3 = cnt[0][4 * lane + 3];
+            const uint32_t tot = c0 + c1 + c2 + c3;
+            const uint32_t ex = c3d_wave_incl_scan(tot) - tot;
+            cnt[0][4 * lane] = ex; cnt[0][4 * lane + 1] = ex + c0; cnt[0][4 * lane + 2] = ex + c0 + c1; cnt[0][4 * lane + 3] = ex + c0 + c1 + c2;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < SEG_ITEMS; i++)
+            if (i < items && (uint32_t)i * 64u + (uint32_t)lane < n) {
+                const uint32_t lp = cnt[0][(key[i] >> shift) & (RS_RADIX - 1)] + rank[i];
+                skey[lp] = key[i]; sval[lp] = val[i];
+            }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < SEG_ITEMS; i++) {
+            const uint32_t p = (uint32_t)i * 64u + (uint32_t)lane;
+            if (i < items && p < n) { key[i] = skey[p]; val[i] = sval[p]; }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < SEG_ITEMS; i++) {
+        const uint32_t p = (uint32_t)i * 64u + (uint32_t)lane;
+        if (i < items && p < n) vals[rg.x + p] = val[i];
+    }
+}
+__global__ void __launch_bounds__(256, 4) k_segment_sort(const uint2* __restrict__ ranges, int nseg, const uint32_t* __restrict__ key_table, uint32_t* __restrict__ vals,
+                                                       uint32_t* __restrict__ vbuf1) {
+    __shared__ uint32_t whist[4][RS_RADIX];
+    __shared__ uint32_t dstart[RS_RADIX];     // big path: where the next element of each digit goes
+    __shared__ uint32_t skey[SEG_CAP];
+    __shared__ uint32_t sval[SEG_CAP];
+    __shared__ uint32_t scan_lds[4];
+    __shared__ uint32_t s_or[4], s_and[4];
+    const int t = blockIdx.x;
+    if (t >= nseg) return;
+    const uint2 rg = ranges[t];
+    const uint32_t n = rg.y > rg.x ? rg.y - rg.x : 0u;
+    if (n <= SEGW_CAP) return;                                  // k_segment_sort_w's
+    const int lane = c3d_lane(), wave = threadIdx.x >> 6;
+    uint32_t key[SEG_ITEMS], val[SEG_ITEMS], rank[SEG_ITEMS];
+    if (n <= SEG_CAP) {
+        const int items = (int)((n + 255u) / 256u);               // per lane; a wave's run is items * 64 consecutive elements
+        const uint32_t wbase = (uint32_t)wave * (uint32_t)items * 64u;
+        uint32_t vor = 0u, vand = 0xFFFFFFFFu;
+#pragma unroll
+        for (int i = 0; i < SEG_ITEMS; i++) {
+            key[i] = 0xFFFFFFFFu; val[i] = 0u;
+            if (i < items) {
+                const uint32_t p = wbase + (uint32_t)i * 64u + (uint32_t)lane;
+                if (p < n) { val[i] = vals[rg.x + p]; key[i] = key_table[val[i]]; vor |= key[i]; vand &= key[i]; }
+            }
+        }
+        // bits on which the keys of the segment differ: a digit with none is a pass that would not move anything
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { vor |= (uint32_t)__shfl_xor((int)vor, o, 64); vand &= (uint32_t)__shfl_xor((int)vand, o, 64); }
+        if (lane == 0) { s_or[wave] = vor; s_and[wave] = vand; }
+        __syncthreads();
+        const uint32_t diff = (s_or[0] | s_or[1] | s_or[2] | s_or[3]) & ~(s_and[0] & s_and[1] & s_and[2] & s_and[3]);
+        for (int pass = 0; pass < 4; pass++) {
+            const int shift = 8 * pass;
+            if (!((diff >> shift) & 0xFFu)) continue;            // uniform over the workgroup
+            __syncthreads();
+            for (int i = threadIdx.x; i < 4 * RS_RADIX; i += 256) (&whist[0][0])[i] = 0;
+            __syncthreads();
+            seg_rank(key, wbase, n, items, shift, whist, wave, lane, rank);
+            __syncthreads();
+            {   // thread d owns digit d: block-local start of every (wave, digit) run
+                const int d = threadIdx.x;
+                uint32_t c[4], tot = 0, dummy;
+#pragma unroll
+                for (int w = 0; w < 4; w++) { c[w] = whist[w][d]; tot += c[w]; }
+                uint32_t ls = block_excl_scan(tot, scan_lds, &dummy);
+#pragma unroll
+                for (int w = 0; w < 4; w++) { whist[w][d] = ls; ls += c[w]; }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < SEG_ITEMS; i++)
+                if (i < items && wbase + (uint32_t)i * 64u + (uint32_t)lane < n) {
+                    const uint32_t lp = whist[wave][(key[i] >> shift) & (RS_RADIX - 1)] + rank[i];
+                    skey[lp] = key[i]; sval[lp] = val[i];
+                }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < SEG_ITEMS; i++) {
+                const uint32_t p = wbase + (uint32_t)i * 64u + (uint32_t)lane;
+                if (i < items && p < n) { key[i] = skey[p]; val[i] = sval[p]; }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < SEG_ITEMS; i++) {
+            const uint32_t p = wbase + (uint32_t)i * 64u + (uint32_t)lane;
+            if (i < items && p < n) vals[rg.x + p] = val[i];
+        }
+        return;
+    }
+    // ---- more than SEG_CAP elements: four passes through a global ping-pong of the values, chunk by chunk in order (agent-scope accesses: the workgroup re-reads
+    //      what its other waves wrote in the previous pass)
+    uint32_t *vsrc = vals + rg.x, *vdst = vbuf1 + rg.x;
+    for (int pass = 0; pass < 4; pass++) {
+        const int shift = 8 * pass;
+        dstart[threadIdx.x] = 0;
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < n; j += 256) atomicAdd(&dstart[(key_table[ld_agent32(vsrc + j)] >> shift) & (RS_RADIX - 1)], 1u);
+        __syncthreads();
+        {
+            uint32_t dummy;
+            const uint32_t cnt = dstart[threadIdx.x];
+            const uint32_t ex = block_excl_scan(cnt, scan_lds, &dummy);
+            __syncthreads();
+            dstart[threadIdx.x] = ex;
+        }
+        __syncthreads();
+        for (uint32_t cbase = 0; cbase < n; cbase += SEG_CAP) {
+            for (int i = threadIdx.x; i < 4 * RS_RADIX; i += 256) (&whist[0][0])[i] = 0;
+            __syncthreads();
+            const uint32_t wbase = cbase + (uint32_t)wave * (SEG_CAP / 4);
+#pragma unroll
+            for (int i = 0; i < SEG_ITEMS; i++) {
+                const uint32_t p = wbase + (uint32_t)i * 64u + (uint32_t)lane;
+                val[i] = p < n ? ld_agent32(vsrc + p) : 0u;
+                key[i] = p < n ? key_table[val[i]] : 0xFFFFFFFFu;
+            }
+            seg_rank(key, wbase, n, SEG_ITEMS, shift, whist, wave, lane, rank);
+            __syncthreads();
+            {   // thread d: this chunk's elements of digit d go to dstart[d] .. in wave order
+                const int d = threadIdx.x;
+                uint32_t ls = dstart[d], tot = 0;
+#pragma unroll
+                for (int w = 0; w < 4; w++) { const uint32_t c = whist[w][d]; whist[w][d] = ls + tot; tot += c; }
+                dstart[d] = ls + tot;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < SEG_ITEMS; i++)
+                if (wbase + (uint32_t)i * 64u + (uint32_t)lane < n) {
+                    const uint32_t pos = whist[wave][(key[i] >> shift) & (RS_RADIX - 1)] + rank[i];
+                    st_agent32(vdst + pos, val[i]);
+                }
+            __syncthreads();
+        }
+        __threadfence();
+        __syncthreads();
+        { uint32_t* x = vsrc; vsrc = vdst; vdst = x; }
+    }
+    // four passes: the result is back in vals
+}
+// vals: in / out.  vbuf1: scratch of at least the same length as vals (touched only by segments longer than 4096).
+int c3d_segment_sort_u32(const uint2* ranges, int nseg, const uint32_t* key_table, uint32_t* vals, uint32_t* vbuf1, hipStream_t s) {
+    if (nseg <= 0) return 0;
+    hipLaunchKernelGGL(k_segment_sort_w, dim3(nseg), dim3(64), 0, s, ranges, nseg, key_table, vals);
+    hipLaunchKernelGGL(k_segment_sort, dim3(nseg), dim3(256), 0, s, ranges, nseg, key_table, vals, vbuf1);
+    C3D_LAUNCH_CHECK();
     return 0;
 }
 
