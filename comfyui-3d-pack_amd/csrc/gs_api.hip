@@ -292,7 +292,7 @@ static void carve_step(char* base, int N, int H, int W, long long cap, StepWs& w
     w.dmeans2D = (float*)take(12 * n);
     w.gcol = (float*)take(12 * n);
     w.ms_ws = take(c3d_msssim_workspace_bytes(1, 3, H, W));       // MS-SSIM term of the pixel loss (w_ssim != 0)
-    w.tile_loss = (float*)take(4 * (size_t)(((W + C3D_TILE_X - 1) / C3D_TILE_X) * ((H + C3D_TILE_Y - 1) / C3D_TILE_Y) + 1));   // per-tile partial sums of the pixel loss + one slot for the view's MS-SSIM term
+    w.tile_loss = (float*)take(4 * (size_t)(((W + C3D_TILE_X - 1) / C3D_TILE_X) * ((H + C3D_TILE_Y - 1) / C3D_TILE_Y) + 2));   // per-tile partial sums of the pixel loss + one slot for the view's MS-SSIM term + one for the view's sum
     w.bytes = off;
 }
 
@@ -425,9 +425,20 @@ static bool pre_multiview() {
     if (v < 0) { const char* e = getenv("C3D_PRE_MULTIVIEW"); v = e ? atoi(e) != 0 : 1; }
     return v != 0;
 }
+// Staggered projection (round 3, C3D_PRE_SPLIT=1; measured, OFF by default): only the first `lanes` views are projected before the fork; the rest is projected on
+// lane 0's stream right behind view 0's binning chain, i.e. while ALL lanes sit in their first, latency-bound binning chains; the lanes wait for it (one event)
+// before their second view.  The serial head of the step shrinks from a V-view projection to an L-view one -- and the step does not: 5.946 / 6.002 ms against
+// 5.945 / 5.924 ms on the same box (profiles/r03/r03i_*): the projection kernel fills every CU (128-thread workgroups, 25 KB of LDS each) and the other lanes'
+// binning chains then queue behind it for slots, i.e. what the head saves the first binning round loses.
+static bool pre_split() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("C3D_PRE_SPLIT"); v = e ? atoi(e) != 0 : 0; }
+    return v != 0;
+}
 static int step_preprocess_all(const c3d_gs_settings* views, int V, int N, size_t slice_bytes, void* workspace, long long pair_capacity, const float* means3D,
-                               const float* f_dc, const float* f_rest, const float* opacity_raw, const float* scaling_raw, const float* rotation_raw, hipStream_t s0) {
-    for (int v0 = 0; v0 < V; v0 += GS_MAX_BWD_VIEWS) {
+                               const float* f_dc, const float* f_rest, const float* opacity_raw, const float* scaling_raw, const float* rotation_raw, hipStream_t s0,
+                               int first = 0) {
+    for (int v0 = first; v0 < V; v0 += GS_MAX_BWD_VIEWS) {
         const int nv = (V - v0) < GS_MAX_BWD_VIEWS ? (V - v0) : GS_MAX_BWD_VIEWS;
         GsParams ps[GS_MAX_BWD_VIEWS];
         GsGeom gs[GS_MAX_BWD_VIEWS];
@@ -506,7 +517,9 @@ int c3d_gs_train_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, c
     const bool projected = pre_multiview();
     static int fuse_loss = -1;
     if (fuse_loss < 0) { const char* e = getenv("C3D_FUSE_LOSS"); fuse_loss = e ? atoi(e) != 0 : 1; }
-    if (projected && step_preprocess_all(views, V, N, w0.bytes, workspace, pair_capacity, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, s0)) return -1;
+    const int L_ = lanes < V ? lanes : V;
+    const bool split = projected && pre_split() && L_ > 1 && V > L_ && !bin_ahead();
+    if (projected && step_preprocess_all(views, split ? L_ : V, N, w0.bytes, workspace, pair_capacity, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, s0)) return -1;
     Lanes ln;
     if (ln.fork(s0, lanes, V)) return -1;
     int rc_all = 0;
@@ -532,7 +545,16 @@ int c3d_gs_train_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, c
                 if ((rc = step_view_binning(p, g, b, w.radii, cap, status, sb, &res))) break;
                 if (hipEventRecord(ln.lp->bin_done[v % 16], sb) != hipSuccess || hipStreamWaitEvent(s, ln.lp->bin_done[v % 16], 0) != hipSuccess) { c3d_set_error("c3d_gs_train_views_raw: event failed"); rc = -1; break; }
             }
-            if ((rc = step_view_forward(p, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, g, b, im, w.radii, cap, status, w.color, w.depth, w.alpha, true, s, &res, projected, ahead))) break;
+            bool binned = ahead;
+            if (split && v == 0) {      // view 0's binning, then the projection of views L.. on this lane (lane 0); the other lanes wait for it before their second view
+                if ((rc = step_view_binning(p, g, b, w.radii, cap, status, s, &res))) break;
+                if ((rc = step_preprocess_all(views, V, N, w0.bytes, workspace, pair_capacity, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, s, ln.L))) break;
+                if (hipEventRecord(ln.lp->pre_done[0], s) != hipSuccess) { c3d_set_error("c3d_gs_train_views_raw: event failed"); rc = -1; break; }
+                binned = true;
+            } else if (split && v >= ln.L && v < 2 * ln.L && (v % ln.L) != 0) {
+                if (hipStreamWaitEvent(s, ln.lp->pre_done[0], 0) != hipSuccess) { c3d_set_error("c3d_gs_train_views_raw: event failed"); rc = -1; break; }
+            }
+            if ((rc = step_view_forward(p, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, g, b, im, w.radii, cap, status, w.color, w.depth, w.alpha, true, s, &res, projected, binned))) break;
             // pixel loss and its gradient.  Default: inside the backward compositing kernel (GsPixelLoss); C3D_FUSE_LOSS=0 keeps the separate launch.
             const float* tal = target_alpha ? target_alpha[v] : nullptr;
             const float* cmk = color_mask ? color_mask[v] : nullptr;
@@ -559,7 +581,8 @@ int c3d_gs_train_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, c
               } else {
                   rc = gs_launch_composite_bwd(p, g, b, res, im, w.dcolor, nullptr, w.dalpha, w.pairgrad, w.pvalid, (long long)cap, s, cap);
               }
-              if (rc) break; }
+              if (rc) break;
+              if (fuse_loss && loss_out && (rc = gs_launch_sum_view_loss(w.tile_loss, tiles + (ssim ? 1 : 0), w.tile_loss + tiles + 1, s))) break; }   // this view's loss value, on its lane
         } while (0);
         rc_all = rc;
     }
@@ -574,7 +597,7 @@ int c3d_gs_train_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, c
     if (fuse_loss && loss_out) {   // the views' per-tile partial sums of the pixel loss -> loss_out, in a fixed order
         StepWs wf; carve_step((char*)workspace, N, views[0].image_height, views[0].image_width, pair_capacity, wf);
         const int tiles = ((views[0].image_width + C3D_TILE_X - 1) / C3D_TILE_X) * ((views[0].image_height + C3D_TILE_Y - 1) / C3D_TILE_Y);
-        if (gs_launch_sum_tile_loss(wf.tile_loss, w0.bytes, V, tiles + (loss->w_ssim != 0.f ? 1 : 0), loss_out, s0)) return -1;
+        if (gs_launch_sum_tile_loss(wf.tile_loss + tiles + 1, w0.bytes, V, loss_out, s0)) return -1;
     }
     if (accumulate & 2) return 0;   // the caller runs the per-Gaussian pass itself, range by range (c3d_gs_step_param_backward_range)
     return step_a8_all_views(views, V, N, w0.bytes, workspace, pair_capacity, means3D, f_dc, f_rest, scaling_raw, rotation_raw, dL_dmeans3D, dL_df_dc, dL_df_rest,

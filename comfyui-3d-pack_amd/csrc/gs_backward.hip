@@ -271,24 +271,33 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
     }
 }
 
-__global__ void __launch_bounds__(1024) k_sum_tile_loss(const float* __restrict__ first_view, size_t stride, int V, int tiles, float* __restrict__ loss_out) {
+// Two stages, both with a fixed order (the same loss bits every run).  Round 2 summed all views in one workgroup after the join: 8 dependent rounds of loads, reduce,
+// barrier = 0.108 ms on the step's critical path (profiles/r03/r03b_kernel_stats_lanes1.csv).  Now every view sums ITS terms on its own lane, right behind its
+// backward compositing kernel (hidden under the other lanes' work), and one wave adds the V view sums after the join.
+__global__ void __launch_bounds__(1024) k_sum_view_loss(const float* __restrict__ t, int n, float* __restrict__ out) {
     __shared__ float red[16];
-    float acc = 0.f;
-    for (int v = 0; v < V; v++) {   // views in order, tiles strided over the lanes, then a fixed tree: the same sum every run
-        const float* t = (const float*)((const char*)first_view + (size_t)v * stride);
-        float l = 0.f;
-        for (int i = threadIdx.x; i < tiles; i += 1024) l += t[i];
-        l = c3d_wave_sum(l);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = l;
-        __syncthreads();
-        if (threadIdx.x == 0) { float q = 0.f; for (int w = 0; w < 16; w++) q += red[w]; acc += q; }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) atomicAdd(loss_out, acc);   // one atomic per step; other terms (MS-SSIM) add theirs
+    float l = 0.f;
+    for (int i = threadIdx.x; i < n; i += 1024) l += t[i];      // terms strided over the lanes, then a fixed tree
+    l = c3d_wave_sum(l);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = l;
+    __syncthreads();
+    if (threadIdx.x == 0) { float q = 0.f; for (int w = 0; w < 16; w++) q += red[w]; out[0] = q; }
 }
-int gs_launch_sum_tile_loss(const float* first_view, size_t view_stride_bytes, int V, int tiles, float* loss_out, hipStream_t s) {
-    if (V == 0 || tiles == 0 || !loss_out) return 0;
-    hipLaunchKernelGGL(k_sum_tile_loss, dim3(1), dim3(1024), 0, s, first_view, view_stride_bytes, V, tiles, loss_out);
+__global__ void __launch_bounds__(64) k_sum_views_loss(const float* __restrict__ first_view_sum, size_t stride, int V, float* __restrict__ loss_out) {
+    if (threadIdx.x != 0) return;
+    float acc = 0.f;
+    for (int v = 0; v < V; v++) acc += *(const float*)((const char*)first_view_sum + (size_t)v * stride);      // views in order
+    atomicAdd(loss_out, acc);   // one atomic per step
+}
+int gs_launch_sum_view_loss(const float* terms, int n, float* view_sum, hipStream_t s) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_sum_view_loss, dim3(1), dim3(1024), 0, s, terms, n, view_sum);
+    C3D_LAUNCH_CHECK();
+    return 0;
+}
+int gs_launch_sum_tile_loss(const float* first_view_sum, size_t view_stride_bytes, int V, float* loss_out, hipStream_t s) {
+    if (V == 0 || !loss_out) return 0;
+    hipLaunchKernelGGL(k_sum_views_loss, dim3(1), dim3(64), 0, s, first_view_sum, view_stride_bytes, V, loss_out);
     C3D_LAUNCH_CHECK();
     return 0;
 }

@@ -163,7 +163,8 @@ int gs_launch_composite_fwd(const GsParams& p, const GsGeom& g, const GsBinning&
 struct GsPixelLoss { const float* color; const float* alpha; const float* tcolor; const float* talpha; const float* cmask; float w_l1, w_l2, w_a, scale; float* tile_loss; };
 // tile_loss [tiles]: every tile WRITES its partial sum (8160 float atomics per view on one address cost the step 1.6 %); gs_launch_sum_tile_loss adds the
 // partials of all views to *loss_out in a fixed order (one workgroup): the pixel-loss value is bit-reproducible.
-int gs_launch_sum_tile_loss(const float* first_view, size_t view_stride_bytes, int V, int tiles, float* loss_out, hipStream_t s);
+int gs_launch_sum_view_loss(const float* terms, int n, float* view_sum, hipStream_t s);      // on the view's lane: its per-tile partials (+ MS-SSIM term) -> one float
+int gs_launch_sum_tile_loss(const float* first_view_sum, size_t view_stride_bytes, int V, float* loss_out, hipStream_t s);   // after the join: the V view sums, in order
 int gs_launch_composite_bwd(const GsParams& p, const GsGeom& g, const GsBinning& b, int res, const GsImage& im,
                             const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
                             float* pairgrad /* [D][12] */, uint8_t* pvalid /* [D], cleared here */, long long pairs, hipStream_t s, uint32_t cap = 0xFFFFFFFFu,

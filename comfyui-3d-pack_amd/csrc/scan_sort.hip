@@ -470,7 +470,7 @@ __device__ __forceinline__ void seg_rank(const uint32_t key[SEG_ITEMS], uint32_t
 // Segments of up to SEGW_CAP elements: ONE WAVE per segment (64-thread workgroups), nothing to synchronise with -- a tile's list is ~500 entries, and the
 // 256-thread kernel below spends its time in ~7 barriers per pass and in per-pass costs that do not shrink with the segment (256-digit tables for 4 waves).
 #define SEGW_CAP 1024
-__global__ void __launch_bounds__(64, 8) k_segment_sort_w(const uint2* __restrict__ ranges, int nseg, const uint32_t* __restrict__ key_table, uint32_t* __restrict__ vals) {
+__global__ void __launch_bounds__(64, 4) k_segment_sort_w(const uint2* __restrict__ ranges, int nseg, const uint32_t* __restrict__ key_table, uint32_t* __restrict__ vals) {
     __shared__ uint32_t cnt[1][RS_RADIX];
     __shared__ uint32_t skey[SEGW_CAP];
     __shared__ uint32_t sval[SEGW_CAP];
