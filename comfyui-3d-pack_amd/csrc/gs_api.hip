@@ -305,6 +305,7 @@ struct LanePool {
     // forward-only rendering in groups of L views: a projection stream running two groups ahead of the lanes (render_views_grouped)
     hipStream_t pre; hipEvent_t pre_done[2], lane_done[2][C3D_MAX_LANES];
     hipEvent_t bin_done[16];      // binning chains running ahead of the compositing lanes (train_views): view v -> bin_done[v % 16]
+    hipEvent_t comp_done[16];     // compositing token (train_views): view v's compositing kernels are done -> comp_done[v % 16]
     std::mutex busy;              // held from a call's fork to its join: two host threads (or two step objects) on one device take turns instead of re-recording each other's events
 };
 LanePool g_lanes[16];
@@ -327,6 +328,7 @@ int lane_pool(LanePool** out) {
             for (int l = 0; l < C3D_MAX_LANES; l++) C3D_CHECK(hipEventCreateWithFlags(&lp.lane_done[i][l], hipEventDisableTiming));
         }
         for (int i = 0; i < 16; i++) C3D_CHECK(hipEventCreateWithFlags(&lp.bin_done[i], hipEventDisableTiming));
+        for (int i = 0; i < 16; i++) C3D_CHECK(hipEventCreateWithFlags(&lp.comp_done[i], hipEventDisableTiming));
         lp.init = true;
     }
     *out = &lp;
@@ -434,6 +436,17 @@ static bool pre_split() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("C3D_PRE_SPLIT"); v = e ? atoi(e) != 0 : 0; }
     return v != 0;
+}
+// Compositing tokens (round 3).  Hypothesis: left alone the lanes run in lockstep -- they finish their binning chains together, their compositing kernels share the
+// machine and finish together, and all of them sit in the next latency-bound binning chain together.  With k tokens view v's compositing kernels wait for those of
+// view v - k.  Measured (profiles/r03/r03k_*, ms per 8-view step, two runs each): unconstrained 5.878 / 5.894, k = 1 (a strict chain of compositing kernels)
+// 6.306 / 6.311, k = 2 5.843 / 5.838; training step 8.027 / 9.259 / 8.001.  The strict chain LOSES 0.42 ms: kernels of one chain leave a 15-50 us hole at
+// every boundary (memset + dependent dispatch + the tail of the grid) that only a second, independent chain fills -- the step's 0.7 ms above the sum of its
+// throughput-bound kernels is those ~20 boundaries, not lockstep.  Two tokens keep two chains in flight and win a little.  C3D_COMP_TOKENS=k, 0 = unconstrained.
+static int comp_tokens() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("C3D_COMP_TOKENS"); v = e ? atoi(e) : 2; if (v < 0 || v > 8) v = 0; }
+    return v;
 }
 static int step_preprocess_all(const c3d_gs_settings* views, int V, int N, size_t slice_bytes, void* workspace, long long pair_capacity, const float* means3D,
                                const float* f_dc, const float* f_rest, const float* opacity_raw, const float* scaling_raw, const float* rotation_raw, hipStream_t s0,
@@ -554,6 +567,11 @@ int c3d_gs_train_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, c
             } else if (split && v >= ln.L && v < 2 * ln.L && (v % ln.L) != 0) {
                 if (hipStreamWaitEvent(s, ln.lp->pre_done[0], 0) != hipSuccess) { c3d_set_error("c3d_gs_train_views_raw: event failed"); rc = -1; break; }
             }
+            const int tok = (projected && ln.L > 1) ? comp_tokens() : 0;
+            if (tok && v >= tok) {      // binning first (unconstrained), then wait for the token: the compositing kernels of view v - tok are done
+                if (!binned) { if ((rc = step_view_binning(p, g, b, w.radii, cap, status, s, &res))) break; binned = true; }
+                if (hipStreamWaitEvent(s, ln.lp->comp_done[(v - tok) % 16], 0) != hipSuccess) { c3d_set_error("c3d_gs_train_views_raw: event failed"); rc = -1; break; }
+            }
             if ((rc = step_view_forward(p, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, g, b, im, w.radii, cap, status, w.color, w.depth, w.alpha, true, s, &res, projected, binned))) break;
             // pixel loss and its gradient.  Default: inside the backward compositing kernel (GsPixelLoss); C3D_FUSE_LOSS=0 keeps the separate launch.
             const float* tal = target_alpha ? target_alpha[v] : nullptr;
@@ -582,6 +600,7 @@ int c3d_gs_train_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, c
                   rc = gs_launch_composite_bwd(p, g, b, res, im, w.dcolor, nullptr, w.dalpha, w.pairgrad, w.pvalid, (long long)cap, s, cap);
               }
               if (rc) break;
+              if (projected && ln.L > 1 && comp_tokens() && hipEventRecord(ln.lp->comp_done[v % 16], s) != hipSuccess) { c3d_set_error("c3d_gs_train_views_raw: event failed"); rc = -1; break; }
               if (fuse_loss && loss_out && (rc = gs_launch_sum_view_loss(w.tile_loss, tiles + (ssim ? 1 : 0), w.tile_loss + tiles + 1, s))) break; }   // this view's loss value, on its lane
         } while (0);
         rc_all = rc;
