@@ -567,6 +567,8 @@ int c3d_gs_train_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, c
             } else if (split && v >= ln.L && v < 2 * ln.L && (v % ln.L) != 0) {
                 if (hipStreamWaitEvent(s, ln.lp->pre_done[0], 0) != hipSuccess) { c3d_set_error("c3d_gs_train_views_raw: event failed"); rc = -1; break; }
             }
+            // the "record written" bytes of the backward pass are cleared here, inside / ahead of the binning chain, not between the two compositing kernels
+            if (hipMemsetAsync(w.pvalid, 0, (size_t)cap, s) != hipSuccess) { c3d_set_error("c3d_gs_train_views_raw: memset failed"); rc = -1; break; }
             const int tok = (projected && ln.L > 1) ? comp_tokens() : 0;
             if (tok && v >= tok) {      // binning first (unconstrained), then wait for the token: the compositing kernels of view v - tok are done
                 if (!binned) { if ((rc = step_view_binning(p, g, b, w.radii, cap, status, s, &res))) break; binned = true; }
@@ -595,9 +597,9 @@ int c3d_gs_train_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, c
             { C3dProfScope ps(C3D_P_COMPOSITE_BWD, s);
               if (fuse_loss) {
                   const GsPixelLoss pl{w.color, w.alpha, target_color[v], tal, cmk, loss->w_l1, loss->w_l2, loss->w_alpha_mse, loss->scale, loss_out ? w.tile_loss : nullptr};
-                  rc = gs_launch_composite_bwd(p, g, b, res, im, ssim ? w.dcolor : nullptr, nullptr, nullptr, w.pairgrad, w.pvalid, (long long)cap, s, cap, &pl);
+                  rc = gs_launch_composite_bwd(p, g, b, res, im, ssim ? w.dcolor : nullptr, nullptr, nullptr, w.pairgrad, w.pvalid, (long long)cap, s, cap, &pl, true);
               } else {
-                  rc = gs_launch_composite_bwd(p, g, b, res, im, w.dcolor, nullptr, w.dalpha, w.pairgrad, w.pvalid, (long long)cap, s, cap);
+                  rc = gs_launch_composite_bwd(p, g, b, res, im, w.dcolor, nullptr, w.dalpha, w.pairgrad, w.pvalid, (long long)cap, s, cap, nullptr, true);
               }
               if (rc) break;
               if (projected && ln.L > 1 && comp_tokens() && hipEventRecord(ln.lp->comp_done[v % 16], s) != hipSuccess) { c3d_set_error("c3d_gs_train_views_raw: event failed"); rc = -1; break; }

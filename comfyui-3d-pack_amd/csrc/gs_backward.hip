@@ -304,10 +304,12 @@ int gs_launch_sum_tile_loss(const float* first_view_sum, size_t view_stride_byte
 
 int gs_launch_composite_bwd(const GsParams& p, const GsGeom& g, const GsBinning& b, int res, const GsImage& im,
                             const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
-                            float* pairgrad, uint8_t* pvalid, long long pairs, hipStream_t s, uint32_t cap, const GsPixelLoss* pixel_loss) {
+                            float* pairgrad, uint8_t* pvalid, long long pairs, hipStream_t s, uint32_t cap, const GsPixelLoss* pixel_loss, bool pvalid_cleared) {
     const int tiles = p.gx * p.gy;
     if (tiles == 0) return 0;
-    C3D_CHECK(hipMemsetAsync(pvalid, 0, (size_t)(pairs > 0 ? pairs : 1), s));
+    // pvalid_cleared: the fused step clears the "record written" bytes inside the view's binning chain (latency-bound anyway) -- one boundary less between the two
+    // compositing kernels
+    if (!pvalid_cleared) C3D_CHECK(hipMemsetAsync(pvalid, 0, (size_t)(pairs > 0 ? pairs : 1), s));
     const dim3 grid(gs_block_count(p.gx, p.gy, gs_supertile_shift()));
 #define GS_BWD_LAUNCH(LOSS_, DEPTH_, PL_)                                                                                                                        \
     hipLaunchKernelGGL((k_composite_bwd<LOSS_, DEPTH_>), grid, dim3(256), gs_lds_pad(true), s, p, b.ranges, b.tval[res], g.einfo, g.rec0, g.rec1, g.rec2, im.final_T, \

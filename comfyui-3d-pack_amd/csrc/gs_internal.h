@@ -168,7 +168,7 @@ int gs_launch_sum_tile_loss(const float* first_view_sum, size_t view_stride_byte
 int gs_launch_composite_bwd(const GsParams& p, const GsGeom& g, const GsBinning& b, int res, const GsImage& im,
                             const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
                             float* pairgrad /* [D][12] */, uint8_t* pvalid /* [D], cleared here */, long long pairs, hipStream_t s, uint32_t cap = 0xFFFFFFFFu,
-                            const GsPixelLoss* pixel_loss = nullptr);
+                            const GsPixelLoss* pixel_loss = nullptr, bool pvalid_cleared = false);
 int gs_launch_preprocess_bwd(const GsParams& p, const GsGeom& g, const int* radii, const float* means3D, const float* shs,
                              const float* colors_precomp, const float* scales, const float* rotations, const float* cov3D_precomp,
                              const float* pairgrad, const uint8_t* pvalid, float* dL_dmean2D, float* dL_dcolors, float* dL_dopacity,

@@ -32,10 +32,11 @@ for k in sorted(f, key=lambda k: -f[k][1] * f[k][0]):
     wr = w.get(k, (0, 0, 0))[1] * 1024 / 1e6
     out[k] = {"launches": f[k][0], "fetch_MB_raw": round(fe, 2), "fetch_MB_x2": round(2 * fe, 2), "write_MB": round(wr, 2), "avg_us": round(f[k][2] / 1e3, 1)}
     print("%s,%d,%.2f,%.2f,%.2f,%.1f" % (k, f[k][0], fe, 2 * fe, wr, f[k][2] / 1e3))
-MESH_GROUPS = {
-    "mesh_rasterize": ("k_ras_tri", "k_ras_big", "k_ras_resolve", "k_view_transform_fwd"), "mesh_interpolate": ("k_interp_fwd",), "mesh_texture": ("k_tex_fwd",),
-    "mesh_antialias": ("k_view_sigmoid_seed", "k_aa2_fwd", "k_aa_fwd"), "other": ("k_view_shade_fwd", "k_view_shade_bwd", "k_shade_fwd", "k_shade_bwd", "k_mesh_pixel_loss", "k_mesh_sum", "k_mesh_hwc_to_chw"),
-    "mesh_antialias_bwd": ("k_aa2_bwd", "k_view_sigmoid_bwd", "k_aa_bwd"), "mesh_texture_bwd": ("k_tex_bwd_tiled", "k_tex_bwd"), "mesh_interpolate_bwd": ("k_interp_bwd",),
+MESH_GROUPS = {      # kernels of bench.py's profiling groups; round 3 added the fused pixel passes (k_view_pixel_fwd, k_aa2_pairs, k_view_shade_fwd_g, k_view_loss_shade_bwd, k_view_tex_bwd)
+    "mesh_rasterize": ("k_ras_tri", "k_ras_big", "k_ras_resolve", "k_view_transform_fwd"), "mesh_interpolate": ("k_interp_fwd", "k_view_pixel_fwd"), "mesh_texture": ("k_tex_fwd",),
+    "mesh_antialias": ("k_view_sigmoid_seed", "k_aa2_fwd", "k_aa_fwd", "k_aa2_pairs", "k_view_shade_fwd_g"),
+    "other": ("k_view_shade_fwd", "k_view_shade_bwd", "k_view_loss_shade_bwd", "k_shade_fwd", "k_shade_bwd", "k_mesh_pixel_loss", "k_mesh_sum", "k_mesh_hwc_to_chw", "k_tex_acc_finalize"),
+    "mesh_antialias_bwd": ("k_aa2_bwd", "k_view_sigmoid_bwd", "k_aa_bwd"), "mesh_texture_bwd": ("k_tex_bwd_tiled", "k_tex_bwd", "k_view_tex_bwd"), "mesh_interpolate_bwd": ("k_interp_bwd",),
     "mesh_rasterize_bwd": ("k_ras_bwd_tri", "k_ras_bwd_big", "k_vertex_gather4", "k_vertex_gather4_heavy", "k_view_transform_bwd")}
 if len(sys.argv) > 4 and sys.argv[4] == "mesh":
     groups = {}
