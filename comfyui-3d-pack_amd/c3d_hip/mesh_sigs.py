@@ -18,11 +18,11 @@ SIGNATURES = {
     "c3d_mesh_raster_scratch_bytes": (sz, [i32, i32, i32, i32]),
     "c3d_mesh_rasterize_fwd": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
     "c3d_mesh_rasterize_peel_fwd": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
-    "c3d_mesh_rasterize_bwd": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
+    "c3d_mesh_rasterize_bwd": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
     "c3d_mesh_vertex_topology_bytes": (sz, [i32, i32]),
     "c3d_mesh_build_vertex_topology": (C.c_int, [vp, i32, i32, vp, vp]),
     "c3d_mesh_rasterize_bwd_scratch_bytes": (sz, [i32, i32]),
-    "c3d_mesh_rasterize_bwd_gather": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
+    "c3d_mesh_rasterize_bwd_gather": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
     "c3d_mesh_interpolate_fwd": (C.c_int, [vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
     "c3d_mesh_interpolate_bwd": (C.c_int, [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]),
     "c3d_mesh_interpolate_da_bwd": (C.c_int, [vp, i32, vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp]),

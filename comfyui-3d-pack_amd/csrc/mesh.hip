@@ -203,22 +203,13 @@ __global__ void __launch_bounds__(256) k_ras_resolve(const float4* __restrict__ 
     if (rast_db) rast_db[gid] = make_float4(f.dudx, f.dudy, f.dvdx, f.dvdy);
 }
 
-__global__ void __launch_bounds__(256) k_ras_bwd(const float4* __restrict__ pos, const int3* __restrict__ tri, const float4* __restrict__ rast,
-                                                  const float4* __restrict__ dy, int B, int V, int H, int W, float* __restrict__ dpos) {
-    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long P = (long long)H * W;
-    if (gid >= (long long)B * P) return;
-    const float4 r = rast[gid];
-    const int t = (int)r.w - 1;
-    if (t < 0) return;
-    const float4 g = dy[gid];
-    float g0 = g.x, g1 = g.y;
-    if (g0 == 0.f && g1 == 0.f) return;
-    const int b = (int)(gid / P), pid = (int)(gid % P), px = pid % W, py = pid / W;
-    const int3 vi = tri[t];
-    const float4* pb = pos + (size_t)b * V;
-    const float4 p0 = pb[vi.x], p1 = pb[vi.y], p2 = pb[vi.z];
-    const float fx = (2.f / W) * ((float)px + 0.5f) - 1.f, fy = (2.f / H) * ((float)py + 0.5f) - 1.f;
+// Gradient of one pixel w.r.t. the three clip-space corners: g0, g1 = d/d(u, v) (not through a clamped value), G = d/d rast_db = d/d(du/dX, du/dY, dv/dX, dv/dY)
+// (round 3: the dependency's grad_db path -- what texture(uv_da) -> interpolate(rast_db) hands back; zero = absent).  With A_kx = d a_k / d fx, A_ky = d a_k / d fy
+// (functions of the un-shifted x, y, w) and T = their sums: du/dX = xs iw (b0 Tx - A0x), ...; the chain rule runs through b0, b1, iw and the six A terms.
+// Accumulates into ax / ay / aw (x, y, w components of the corners' gradients).
+template <bool DB>
+__device__ __forceinline__ void ras_bwd_corner_grads(const float4 p0, const float4 p1, const float4 p2, float fx, float fy, float xs, float ys, float g0, float g1,
+                                                     const float4 G, float ax[3], float ay[3], float aw[3]) {
     const float p0x = p0.x - fx * p0.w, p0y = p0.y - fy * p0.w;
     const float p1x = p1.x - fx * p1.w, p1y = p1.y - fy * p1.w;
     const float p2x = p2.x - fx * p2.w, p2y = p2.y - fy * p2.w;
@@ -226,14 +217,56 @@ __global__ void __launch_bounds__(256) k_ras_bwd(const float4* __restrict__ pos,
     const float iw = 1.f / (a0 + a1 + a2), b0 = a0 * iw, b1 = a1 * iw;
     if (b0 < 0.f || b0 > 1.f) g0 = 0.f;   // forward clamps u,v: no gradient through a clamped value
     if (b1 < 0.f || b1 > 1.f) g1 = 0.f;
-    const float da0 = (g0 * (1.f - b0) - g1 * b1) * iw, da1 = (-g0 * b0 + g1 * (1.f - b1)) * iw, da2 = (-g0 * b0 - g1 * b1) * iw;
+    float da0 = (g0 * (1.f - b0) - g1 * b1) * iw, da1 = (-g0 * b0 + g1 * (1.f - b1)) * iw, da2 = (-g0 * b0 - g1 * b1) * iw;
+    if (DB) {
+        const float A0x = p1.w * p2.y - p1.y * p2.w, A0y = p1.x * p2.w - p2.x * p1.w;
+        const float A1x = p0.y * p2.w - p2.y * p0.w, A1y = p2.x * p0.w - p0.x * p2.w;
+        const float A2x = p1.y * p0.w - p0.y * p1.w, A2y = p0.x * p1.w - p1.x * p0.w;
+        const float Tx = A0x + A1x + A2x, Ty = A0y + A1y + A2y, al = xs * iw, be = ys * iw;
+        const float dudx = al * (b0 * Tx - A0x), dudy = be * (b0 * Ty - A0y), dvdx = al * (b1 * Tx - A1x), dvdy = be * (b1 * Ty - A1y);
+        const float gb0 = G.x * al * Tx + G.y * be * Ty, gb1 = G.z * al * Tx + G.w * be * Ty;
+        const float gTx = al * (G.x * b0 + G.z * b1), gTy = be * (G.y * b0 + G.w * b1);
+        const float Lv = G.x * dudx + G.y * dudy + G.z * dvdx + G.w * dvdy;
+        const float gi = Lv / iw + gb0 * a0 + gb1 * a1, gS = -iw * iw * gi;
+        da0 += gb0 * iw + gS; da1 += gb1 * iw + gS; da2 += gS;
+        const float gx[3] = {gTx - al * G.x, gTx - al * G.z, gTx}, gy[3] = {gTy - be * G.y, gTy - be * G.w, gTy};
+        const float4 pp[3] = {p0, p1, p2};
+#pragma unroll
+        for (int k = 0; k < 3; k++) {      // A_kx = y_m w_l - y_l w_m, A_ky = x_l w_m - x_m w_l with (l, m) = (k + 1, k + 2) mod 3
+            const int l = (k + 1) % 3, m = (k + 2) % 3;
+            ay[m] += gx[k] * pp[l].w; aw[l] += gx[k] * pp[m].y; ay[l] -= gx[k] * pp[m].w; aw[m] -= gx[k] * pp[l].y;
+            ax[l] += gy[k] * pp[m].w; aw[m] += gy[k] * pp[l].x; ax[m] -= gy[k] * pp[l].w; aw[l] -= gy[k] * pp[m].x;
+        }
+    }
     const float dx[3] = {da1 * (-p2y) + da2 * p1y, da0 * p2y + da2 * (-p0y), da0 * (-p1y) + da1 * p0y};
     const float dyv[3] = {da1 * p2x + da2 * (-p1x), da0 * (-p2x) + da2 * p0x, da0 * p1x + da1 * (-p0x)};
+#pragma unroll
+    for (int k = 0; k < 3; k++) { ax[k] += dx[k]; ay[k] += dyv[k]; aw[k] += -fx * dx[k] - fy * dyv[k]; }
+}
+__global__ void __launch_bounds__(256) k_ras_bwd(const float4* __restrict__ pos, const int3* __restrict__ tri, const float4* __restrict__ rast,
+                                                  const float4* __restrict__ dy, const float4* __restrict__ ddb, int B, int V, int H, int W, float* __restrict__ dpos) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long P = (long long)H * W;
+    if (gid >= (long long)B * P) return;
+    const float4 r = rast[gid];
+    const int t = (int)r.w - 1;
+    if (t < 0) return;
+    const float4 g = dy ? dy[gid] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 G = ddb ? ddb[gid] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool with_db = G.x != 0.f || G.y != 0.f || G.z != 0.f || G.w != 0.f;
+    if (g.x == 0.f && g.y == 0.f && !with_db) return;
+    const int b = (int)(gid / P), pid = (int)(gid % P), px = pid % W, py = pid / W;
+    const int3 vi = tri[t];
+    const float4* pb = pos + (size_t)b * V;
+    float ax[3] = {0.f, 0.f, 0.f}, ay[3] = {0.f, 0.f, 0.f}, aw[3] = {0.f, 0.f, 0.f};
+    const float fx = (2.f / W) * ((float)px + 0.5f) - 1.f, fy = (2.f / H) * ((float)py + 0.5f) - 1.f;
+    if (with_db) ras_bwd_corner_grads<true>(pb[vi.x], pb[vi.y], pb[vi.z], fx, fy, 2.f / W, 2.f / H, g.x, g.y, G, ax, ay, aw);
+    else ras_bwd_corner_grads<false>(pb[vi.x], pb[vi.y], pb[vi.z], fx, fy, 2.f / W, 2.f / H, g.x, g.y, G, ax, ay, aw);
     const int vv[3] = {vi.x, vi.y, vi.z};
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         float* d = dpos + ((size_t)b * V + vv[k]) * 4;
-        atomicAdd(d + 0, dx[k]); atomicAdd(d + 1, dyv[k]); atomicAdd(d + 3, -fx * dx[k] - fy * dyv[k]);
+        atomicAdd(d + 0, ax[k]); atomicAdd(d + 1, ay[k]); atomicAdd(d + 3, aw[k]);
     }
 }
 
@@ -268,21 +301,6 @@ __global__ void __launch_bounds__(256) k_topo_starts(const uint32_t* __restrict_
     for (long long v = prev + 1; v <= cur && v <= (long long)V + 1; v++) start[v] = (uint32_t)i;   // start[v] = first sorted slot with key >= v
 }
 
-#define RB_ACC(k, dxk, dyk) { ax[k] += (dxk); ay[k] += (dyk); aw[k] += -fx * (dxk) - fy * (dyk); }
-// gradient of one owned pixel w.r.t. the three clip-space corners (same algebra as k_ras_bwd)
-__device__ __forceinline__ void ras_bwd_pixel(const float4 p0, const float4 p1, const float4 p2, float fx, float fy, float g0, float g1, float ax[3], float ay[3], float aw[3]) {
-    const float p0x = p0.x - fx * p0.w, p0y = p0.y - fy * p0.w;
-    const float p1x = p1.x - fx * p1.w, p1y = p1.y - fy * p1.w;
-    const float p2x = p2.x - fx * p2.w, p2y = p2.y - fy * p2.w;
-    const float a0 = p1x * p2y - p1y * p2x, a1 = p2x * p0y - p2y * p0x, a2 = p0x * p1y - p0y * p1x;
-    const float iw = 1.f / (a0 + a1 + a2), b0 = a0 * iw, b1 = a1 * iw;
-    if (b0 < 0.f || b0 > 1.f) g0 = 0.f;   // forward clamps u,v: no gradient through a clamped value
-    if (b1 < 0.f || b1 > 1.f) g1 = 0.f;
-    const float da0 = (g0 * (1.f - b0) - g1 * b1) * iw, da1 = (-g0 * b0 + g1 * (1.f - b1)) * iw, da2 = (-g0 * b0 - g1 * b1) * iw;
-    RB_ACC(0, da1 * (-p2y) + da2 * p1y, da1 * p2x + da2 * (-p1x));
-    RB_ACC(1, da0 * p2y + da2 * (-p0y), da0 * (-p2x) + da2 * p0x);
-    RB_ACC(2, da0 * (-p1y) + da1 * p0y, da0 * p1x + da1 * (-p0x));
-}
 // ---- the antialias pass of the fused view as gathers (round 3) ------------------------------------------------------------------------------
 // The silhouette analysis (k_aa2_pairs) leaves per pixel pair (first pixel p, direction d: second = p + 1 | p + W) a flag byte -- bit 0 hit, bit 1 "the first pixel
 // is pixel a" (the one that owns the nearer triangle), bits 2-3 the silhouette edge's first corner in a's triangle -- and the blend weight alpha = s - 0.5.
@@ -353,9 +371,10 @@ __device__ __forceinline__ void aa_bwd_pixel(const AaBwdIn& aa, const float4* __
         }
     }
 }
+template <bool DB>
 __global__ void __launch_bounds__(256) k_ras_bwd_tri(const float4* __restrict__ pos, const int3* __restrict__ tri, const float4* __restrict__ rast,
-                                                      const float4* __restrict__ dy, int B, int V, int T, int H, int W, float4* __restrict__ rec,
-                                                      uint32_t* __restrict__ big_queue, uint32_t* __restrict__ big_count, AaBwdIn aa) {
+                                                      const float4* __restrict__ dy, const float4* __restrict__ ddb, int B, int V, int T, int H, int W,
+                                                      float4* __restrict__ rec, uint32_t* __restrict__ big_queue, uint32_t* __restrict__ big_count, AaBwdIn aa) {
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (long long)B * T) return;
     const int b = (int)(gid / T), t = (int)(gid % T);
@@ -376,15 +395,18 @@ __global__ void __launch_bounds__(256) k_ras_bwd_tri(const float4* __restrict__ 
         for (int px = ts.px0; px <= ts.px1; px++) {
             const size_t pid = pbase + (size_t)py * W + px;
             if (rast[pid].w != idf) continue;
-            const float4 g = dy[pid];
-            if (g.x != 0.f || g.y != 0.f) ras_bwd_pixel(p0, p1, p2, xs * ((float)px + 0.5f) - 1.f, ys * ((float)py + 0.5f) - 1.f, g.x, g.y, ax, ay, aw);
+            const float4 g = dy ? dy[pid] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 G = DB ? ddb[pid] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (g.x != 0.f || g.y != 0.f || (DB && (G.x != 0.f || G.y != 0.f || G.z != 0.f || G.w != 0.f)))
+                ras_bwd_corner_grads<DB>(p0, p1, p2, xs * ((float)px + 0.5f) - 1.f, ys * ((float)py + 0.5f) - 1.f, xs, ys, g.x, g.y, G, ax, ay, aw);
             if (aa.hit) { const float4 pc[3] = {p0, p1, p2}; aa_bwd_pixel(aa, rast, pc, px, py, pid, H, W, ax, ay, aw); }      // fused view only (B = 1)
         }
 #pragma unroll
     for (int k = 0; k < 3; k++) out[k] = make_float4(ax[k], ay[k], 0.f, aw[k]);
 }
+template <bool DB>
 __global__ void __launch_bounds__(256) k_ras_bwd_big(const float4* __restrict__ pos, const int3* __restrict__ tri, const float4* __restrict__ rast,
-                                                      const float4* __restrict__ dy, int V, int T, int H, int W, float4* __restrict__ rec,
+                                                      const float4* __restrict__ dy, const float4* __restrict__ ddb, int V, int T, int H, int W, float4* __restrict__ rec,
                                                       const uint32_t* __restrict__ big_queue, const uint32_t* __restrict__ big_count, AaBwdIn aa) {
     __shared__ float red[4][9];
     const uint32_t n = *big_count;
@@ -405,8 +427,10 @@ __global__ void __launch_bounds__(256) k_ras_bwd_big(const float4* __restrict__ 
             const int px = ts.px0 + (int)(i % bw), py = ts.py0 + (int)(i / bw);
             const size_t pid = pbase + (size_t)py * W + px;
             if (rast[pid].w != idf) continue;
-            const float4 g = dy[pid];
-            if (g.x != 0.f || g.y != 0.f) ras_bwd_pixel(p0, p1, p2, xs * ((float)px + 0.5f) - 1.f, ys * ((float)py + 0.5f) - 1.f, g.x, g.y, ax, ay, aw);
+            const float4 g = dy ? dy[pid] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 G = DB ? ddb[pid] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (g.x != 0.f || g.y != 0.f || (DB && (G.x != 0.f || G.y != 0.f || G.z != 0.f || G.w != 0.f)))
+                ras_bwd_corner_grads<DB>(p0, p1, p2, xs * ((float)px + 0.5f) - 1.f, ys * ((float)py + 0.5f) - 1.f, xs, ys, g.x, g.y, G, ax, ay, aw);
             if (aa.hit) { const float4 pc[3] = {p0, p1, p2}; aa_bwd_pixel(aa, rast, pc, px, py, pid, H, W, ax, ay, aw); }
         }
         float v9[9] = {ax[0], ay[0], aw[0], ax[1], ay[1], aw[1], ax[2], ay[2], aw[2]};
@@ -767,7 +791,9 @@ __device__ __forceinline__ bool mip_level_grad(const float4* __restrict__ da, co
     return true;
 }
 // the four bilinear taps of one level as virtual texel indices + weights
-struct MipTaps { uint32_t k[4]; float fu, fv; int w, h; };
+// ok: bit k = tap k lies inside the level (always under wrap / clamp; boundary 2 = 'zero': a tap outside reads 0 and receives no gradient -- its index is parked
+// on the level's first texel)
+struct MipTaps { uint32_t k[4]; float fu, fv; int w, h; uint32_t ok; };
 __device__ __forceinline__ MipTaps mip_taps(float2 q, int Ht, int Wt, int l, int boundary) {
     MipTaps t;
     t.w = mip_w(Wt, l); t.h = mip_w(Ht, l);
@@ -775,12 +801,22 @@ __device__ __forceinline__ MipTaps mip_taps(float2 q, int Ht, int Wt, int l, int
     const float u = q.x * t.w - 0.5f, v = q.y * t.h - 0.5f;
     const float fu0 = floorf(u), fv0 = floorf(v);
     t.fu = u - fu0; t.fv = v - fv0;
-    const int iu0 = wrapi((int)fu0, t.w, boundary), iu1 = wrapi((int)fu0 + 1, t.w, boundary);
-    const int iv0 = wrapi((int)fv0, t.h, boundary), iv1 = wrapi((int)fv0 + 1, t.h, boundary);
+    int iu0, iu1, iv0, iv1;
+    t.ok = 15u;
+    if (boundary == 2) {
+        iu0 = (int)fu0; iu1 = iu0 + 1; iv0 = (int)fv0; iv1 = iv0 + 1;
+        const bool x0 = iu0 >= 0 && iu0 < t.w, x1 = iu1 >= 0 && iu1 < t.w, y0 = iv0 >= 0 && iv0 < t.h, y1 = iv1 >= 0 && iv1 < t.h;
+        t.ok = (x0 && y0 ? 1u : 0u) | (x1 && y0 ? 2u : 0u) | (x0 && y1 ? 4u : 0u) | (x1 && y1 ? 8u : 0u);
+        if (!x0) iu0 = 0; if (!x1) iu1 = 0; if (!y0) iv0 = 0; if (!y1) iv1 = 0;
+    } else {
+        iu0 = wrapi((int)fu0, t.w, boundary); iu1 = wrapi((int)fu0 + 1, t.w, boundary);
+        iv0 = wrapi((int)fv0, t.h, boundary); iv1 = wrapi((int)fv0 + 1, t.h, boundary);
+    }
     t.k[0] = base + (uint32_t)(iv0 * t.w + iu0); t.k[1] = base + (uint32_t)(iv0 * t.w + iu1);
     t.k[2] = base + (uint32_t)(iv1 * t.w + iu0); t.k[3] = base + (uint32_t)(iv1 * t.w + iu1);
     return t;
 }
+#define MIP_V(t, k, p, c) (((t).ok >> (k)) & 1u ? (p)[c] : 0.f)
 // address of channel 0 of virtual texel k: tb = this batch item's base texture, sb = its stack, HW = Ht*Wt
 template <typename T>
 __device__ __forceinline__ T* mip_texel(T* tb, T* sb, uint32_t HW, uint32_t k, int C) {
@@ -833,7 +869,8 @@ __global__ void __launch_bounds__(256) k_tex_mip_fwd(const float* __restrict__ t
     const bool two = l1 != l0 && f != 0.f;
     if (!two) {
         for (int c = 0; c < C; c++) {
-            const float top = a00[c] + a.fu * (a10[c] - a00[c]), bot = a01[c] + a.fu * (a11[c] - a01[c]);
+            const float v00 = MIP_V(a, 0, a00, c), v10 = MIP_V(a, 1, a10, c), v01 = MIP_V(a, 2, a01, c), v11 = MIP_V(a, 3, a11, c);
+            const float top = v00 + a.fu * (v10 - v00), bot = v01 + a.fu * (v11 - v01);
             po[c] = top + a.fv * (bot - top);
         }
         return;
@@ -842,8 +879,10 @@ __global__ void __launch_bounds__(256) k_tex_mip_fwd(const float* __restrict__ t
     const float *b00 = mip_texel(tb, sb, HW, b.k[0], C), *b10 = mip_texel(tb, sb, HW, b.k[1], C);
     const float *b01 = mip_texel(tb, sb, HW, b.k[2], C), *b11 = mip_texel(tb, sb, HW, b.k[3], C);
     for (int c = 0; c < C; c++) {
-        const float ta = a00[c] + a.fu * (a10[c] - a00[c]), ba = a01[c] + a.fu * (a11[c] - a01[c]);
-        const float tb_ = b00[c] + b.fu * (b10[c] - b00[c]), bb = b01[c] + b.fu * (b11[c] - b01[c]);
+        const float v00 = MIP_V(a, 0, a00, c), v10 = MIP_V(a, 1, a10, c), v01 = MIP_V(a, 2, a01, c), v11 = MIP_V(a, 3, a11, c);
+        const float w00 = MIP_V(b, 0, b00, c), w10 = MIP_V(b, 1, b10, c), w01 = MIP_V(b, 2, b01, c), w11 = MIP_V(b, 3, b11, c);
+        const float ta = v00 + a.fu * (v10 - v00), ba = v01 + a.fu * (v11 - v01);
+        const float tb_ = w00 + b.fu * (w10 - w00), bb = w01 + b.fu * (w11 - w01);
         po[c] = (1.f - f) * (ta + a.fv * (ba - ta)) + f * (tb_ + b.fv * (bb - tb_));
     }
 }
@@ -899,10 +938,11 @@ __global__ void __launch_bounds__(256) k_tex_mip_bwd(const float* __restrict__ t
             for (int c = 0; c < C; c++) {
                 const float gc = g[c] * wl;
                 any = any || gc != 0.f;
-                lu += gc * ((p10[c] - p00[c]) * (1.f - t.fv) + (p11[c] - p01[c]) * t.fv);
-                lv += gc * ((p01[c] - p00[c]) * (1.f - t.fu) + (p11[c] - p10[c]) * t.fu);
+                const float v00 = MIP_V(t, 0, p00, c), v10 = MIP_V(t, 1, p10, c), v01 = MIP_V(t, 2, p01, c), v11 = MIP_V(t, 3, p11, c);
+                lu += gc * ((v10 - v00) * (1.f - t.fv) + (v11 - v01) * t.fv);
+                lv += gc * ((v01 - v00) * (1.f - t.fu) + (v11 - v10) * t.fu);
                 if (dda || dbias) {                                   // dy . sample(level): the level gradient is the difference of the two levels' dots
-                    const float top = p00[c] + t.fu * (p10[c] - p00[c]), bot = p01[c] + t.fu * (p11[c] - p01[c]);
+                    const float top = v00 + t.fu * (v10 - v00), bot = v01 + t.fu * (v11 - v01);
                     sd += g[c] * (top + t.fv * (bot - top));
                 }
             }
@@ -911,6 +951,7 @@ __global__ void __launch_bounds__(256) k_tex_mip_bwd(const float* __restrict__ t
             if (!any) continue;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
+                if (!((t.ok >> k) & 1u)) continue;                   // 'zero': nothing behind this tap
                 int slot = -1;
                 if (use_hash) {
                     uint32_t h = (t.k[k] * 2654435761u) >> 21;       // 11 bits
@@ -1223,7 +1264,7 @@ static int mesh_rasterize_impl(const float* pos, const int32_t* tri, int32_t B, 
     return 0;
 }
 
-int c3d_mesh_rasterize_bwd(const float* pos, const int32_t* tri, const float* rast, const float* dy, int32_t B, int32_t V, int32_t T, int32_t H,
+int c3d_mesh_rasterize_bwd(const float* pos, const int32_t* tri, const float* rast, const float* dy, const float* ddb, int32_t B, int32_t V, int32_t T, int32_t H,
                            int32_t W, float* dpos, c3d_stream_t stream) {
     (void)T;
     hipStream_t s = (hipStream_t)stream;
@@ -1233,8 +1274,8 @@ int c3d_mesh_rasterize_bwd(const float* pos, const int32_t* tri, const float* ra
     C3D_CHECK(hipMemsetAsync(dpos, 0, sizeof(float) * 4 * (size_t)B * V, s));
     const long long BP = (long long)B * H * W;
     if (BP == 0) return 0;
-    MESH_REQUIRE(pos && tri && rast && dy, "NULL pointer");
-    hipLaunchKernelGGL(k_ras_bwd, dim3(c3d_cdiv(BP, 256)), dim3(256), 0, s, (const float4*)pos, (const int3*)tri, (const float4*)rast, (const float4*)dy, B, V, H, W, dpos);
+    MESH_REQUIRE(pos && tri && rast && (dy || ddb), "NULL pointer");
+    hipLaunchKernelGGL(k_ras_bwd, dim3(c3d_cdiv(BP, 256)), dim3(256), 0, s, (const float4*)pos, (const int3*)tri, (const float4*)rast, (const float4*)dy, (const float4*)ddb, B, V, H, W, dpos);
     C3D_LAUNCH_CHECK();
     return 0;
 }
@@ -1260,14 +1301,14 @@ size_t c3d_mesh_rasterize_bwd_scratch_bytes(int32_t B, int32_t T) {
     const size_t bt = (size_t)(B > 0 ? B : 1) * (size_t)(T > 0 ? T : 1);
     return c3d_align(sizeof(float4) * 3 * bt) + c3d_align(4 * bt) + c3d_align(64);
 }
-static int mesh_rasterize_bwd_gather(const float* pos, const int32_t* tri, const float* rast, const float* dy, int32_t B, int32_t V, int32_t T, int32_t H,
+static int mesh_rasterize_bwd_gather(const float* pos, const int32_t* tri, const float* rast, const float* dy, const float* ddb, int32_t B, int32_t V, int32_t T, int32_t H,
                                      int32_t W, const void* topology, void* scratch, float* dpos, c3d_stream_t stream, AaBwdIn aa);
-int c3d_mesh_rasterize_bwd_gather(const float* pos, const int32_t* tri, const float* rast, const float* dy, int32_t B, int32_t V, int32_t T, int32_t H,
+int c3d_mesh_rasterize_bwd_gather(const float* pos, const int32_t* tri, const float* rast, const float* dy, const float* ddb, int32_t B, int32_t V, int32_t T, int32_t H,
                                   int32_t W, const void* topology, void* scratch, float* dpos, c3d_stream_t stream) {
-    return mesh_rasterize_bwd_gather(pos, tri, rast, dy, B, V, T, H, W, topology, scratch, dpos, stream, AaBwdIn{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr});
+    return mesh_rasterize_bwd_gather(pos, tri, rast, dy, ddb, B, V, T, H, W, topology, scratch, dpos, stream, AaBwdIn{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr});
 }
 // aa.hit != NULL (fused view, B = 1): the antialias pass's position gradient is accumulated into the same per-corner records
-static int mesh_rasterize_bwd_gather(const float* pos, const int32_t* tri, const float* rast, const float* dy, int32_t B, int32_t V, int32_t T, int32_t H,
+static int mesh_rasterize_bwd_gather(const float* pos, const int32_t* tri, const float* rast, const float* dy, const float* ddb, int32_t B, int32_t V, int32_t T, int32_t H,
                                      int32_t W, const void* topology, void* scratch, float* dpos, c3d_stream_t stream, AaBwdIn aa) {
     hipStream_t s = (hipStream_t)stream;
     if ((long long)B * V == 0) return 0;
@@ -1275,16 +1316,20 @@ static int mesh_rasterize_bwd_gather(const float* pos, const int32_t* tri, const
     C3dProfScope ps(C3D_P_MESH_RASTERIZE_BWD, s);
     const long long BP = (long long)B * H * W;
     if (BP == 0 || T == 0) { C3D_CHECK(hipMemsetAsync(dpos, 0, sizeof(float) * 4 * (size_t)B * V, s)); return 0; }
-    MESH_REQUIRE(pos && tri && rast && dy && topology && scratch, "NULL pointer");
+    MESH_REQUIRE(pos && tri && rast && (dy || ddb) && topology && scratch, "NULL pointer");
     VertexTopo t; carve_vertex_topo((char*)topology, V, T, t);
     const size_t bt = (size_t)B * T;
     float4* rec = (float4*)scratch;
     uint32_t* queue = (uint32_t*)((char*)scratch + c3d_align(sizeof(float4) * 3 * bt));
     uint32_t* count = (uint32_t*)((char*)queue + c3d_align(4 * bt));
     C3D_CHECK(hipMemsetAsync(count, 0, 8, s));
-    hipLaunchKernelGGL(k_ras_bwd_tri, dim3(c3d_cdiv((long long)bt, 256)), dim3(256), 0, s, (const float4*)pos, (const int3*)tri, (const float4*)rast, (const float4*)dy,
-                       B, V, T, H, W, rec, queue, count, aa);
-    hipLaunchKernelGGL(k_ras_bwd_big, dim3(1024), dim3(256), 0, s, (const float4*)pos, (const int3*)tri, (const float4*)rast, (const float4*)dy, V, T, H, W, rec, queue, count, aa);
+#define RAS_BWD_LAUNCH(DB_)                                                                                                                                          \
+    hipLaunchKernelGGL((k_ras_bwd_tri<DB_>), dim3(c3d_cdiv((long long)bt, 256)), dim3(256), 0, s, (const float4*)pos, (const int3*)tri, (const float4*)rast, (const float4*)dy, \
+                       (const float4*)ddb, B, V, T, H, W, rec, queue, count, aa);                                                                                          \
+    hipLaunchKernelGGL((k_ras_bwd_big<DB_>), dim3(1024), dim3(256), 0, s, (const float4*)pos, (const int3*)tri, (const float4*)rast, (const float4*)dy, (const float4*)ddb, V, T, H, W, \
+                       rec, queue, count, aa)
+    if (ddb) { RAS_BWD_LAUNCH(true); } else { RAS_BWD_LAUNCH(false); }
+#undef RAS_BWD_LAUNCH
     // the sorted corner list sits in val[res]; res is a host constant of the build (same digit count): recompute it instead of reading meta
     int bits = 1;
     while ((1ll << bits) <= (long long)V) bits++;
@@ -1440,7 +1485,7 @@ int c3d_mesh_texture_mip_fwd(const float* tex, const float* stack, int32_t Bt, c
     MESH_REQUIRE(tex && uv && out && (stack || m.L == 0), "NULL pointer");
     MESH_REQUIRE(uv_da || mip_level_bias, "mip-mapped filter modes need uv_da or mip_level_bias");
     MESH_REQUIRE(Bt == 1 || Bt == B, "texture batch must be 1 or B");
-    MESH_REQUIRE((filter == 2 || filter == 3) && (boundary == 0 || boundary == 1), "unsupported filter/boundary mode");
+    MESH_REQUIRE((filter == 2 || filter == 3) && (boundary >= 0 && boundary <= 2), "unsupported filter/boundary mode");
     C3dProfScope ps(C3D_P_MESH_TEXTURE, s);
     hipLaunchKernelGGL(k_tex_mip_fwd, dim3(c3d_cdiv(BP, 256)), dim3(256), 0, s, tex, stack ? stack : tex, Bt, (const float2*)uv, (const float4*)uv_da, mip_level_bias,
                        BP, P, Ht, Wt, C, m.L, m.total, filter, boundary, out);
@@ -1454,7 +1499,7 @@ int c3d_mesh_texture_mip_bwd(const float* tex, const float* stack, int32_t Bt, c
     const long long P = (long long)H * W, BP = P * B;
     MIP_SHAPE(m);
     MESH_REQUIRE(Bt == 1 || Bt == B, "texture batch must be 1 or B");
-    MESH_REQUIRE((filter == 2 || filter == 3) && (boundary == 0 || boundary == 1), "unsupported filter/boundary mode");
+    MESH_REQUIRE((filter == 2 || filter == 3) && (boundary >= 0 && boundary <= 2), "unsupported filter/boundary mode");
     MESH_REQUIRE((!d_uv_da || uv_da) && (!d_bias || mip_level_bias), "a gradient was asked for an input that is absent");
     C3dProfScope ps(C3D_P_MESH_TEXTURE_BWD, s);
     if ((long long)Bt * C > 0) {
@@ -2057,7 +2102,7 @@ static int mesh_view_bwd(const c3d_mesh_view* d, const int32_t* f, const float* 
         }
         if (d_v) {
             const AaBwdIn aa{st.hit, st.pflag, st.pair_alpha, st.albedo0, sc.dalbedo_aa, sc.dcov};
-            if ((rc = mesh_rasterize_bwd_gather(st.vclip, f, st.rast, sc.drast, 1, V, T, H, W, vertex_topology, sc.ras, sc.dpos_r, stream, aa))) return rc;
+            if ((rc = mesh_rasterize_bwd_gather(st.vclip, f, st.rast, sc.drast, nullptr, 1, V, T, H, W, vertex_topology, sc.ras, sc.dpos_r, stream, aa))) return rc;
             hipLaunchKernelGGL(k_view_transform_bwd, dim3(c3d_cdiv(V, 256)), dim3(256), 0, s, M, (const float4*)nullptr, (const float4*)sc.dpos_r, V, d_v);
         }
         C3D_LAUNCH_CHECK();
@@ -2073,7 +2118,7 @@ static int mesh_view_bwd(const c3d_mesh_view* d, const int32_t* f, const float* 
     if ((rc = mesh_texture_bwd(raw_albedo, 1, st.texc, sc.dalbedo0, 1, H, W, d->Ht, d->Wt, 3, 1, 0, d_raw_albedo, sc.duv, stream, zero_dtex))) return rc;
     if (d_v) {
         if ((rc = c3d_mesh_interpolate_bwd(vt, 1, st.rast, ft, sc.duv, 1, d->Vt, 2, H, W, nullptr, sc.drast, stream))) return rc;
-        if ((rc = c3d_mesh_rasterize_bwd_gather(st.vclip, f, st.rast, sc.drast, 1, V, T, H, W, vertex_topology, sc.ras, sc.dpos_r, stream))) return rc;
+        if ((rc = c3d_mesh_rasterize_bwd_gather(st.vclip, f, st.rast, sc.drast, nullptr, 1, V, T, H, W, vertex_topology, sc.ras, sc.dpos_r, stream))) return rc;
         hipLaunchKernelGGL(k_view_transform_bwd, dim3(c3d_cdiv(V, 256)), dim3(256), 0, s, M, (const float4*)sc.dpos_aa, (const float4*)sc.dpos_r, V, d_v);
     }
     C3D_LAUNCH_CHECK();

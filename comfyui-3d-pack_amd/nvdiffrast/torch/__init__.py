@@ -11,9 +11,9 @@ Same function names, argument meaning and return shapes as the module the refere
 The arithmetic runs in libc3d_hip.so; this file allocates tensors and wires autograd.  There is no CPU path.
     rasterize(..., ranges=[B,2]) / antialias with pos [V,4]: range (instanced) mode, composed on the host from the B = 1 kernels
     boundary modes 'wrap' | 'clamp' | 'zero' ('zero' for the nearest / linear filters, composed from a zero-padded texture + 'clamp')
-Not built (raise NotImplementedError): cube maps (boundary 'cube'), 'zero' with the mip-mapped filters.  Gradients w.r.t. uv_da and
-mip_level_bias ('linear-mipmap-linear') and through interpolate's pixel differentials out_da to the attributes and to rast_db are propagated;
-rasterize itself does not take a gradient for rast_db (the dependency's grad_db).
+Not built (raise NotImplementedError): cube maps (boundary 'cube').  Gradients w.r.t. uv_da and
+mip_level_bias ('linear-mipmap-linear') and through interpolate's pixel differentials out_da to the attributes and to rast_db are propagated, and
+rasterize(grad_db=True, the default) passes what arrives at rast_db on to the positions.
 """
 import torch
 
@@ -91,6 +91,7 @@ class _Rasterize(torch.autograd.Function):
         ctx.save_for_backward(pos_c if pos_c is not None else pos, tri_c, rast)
         ctx.dims = (B, V, T, H, W)
         ctx.glctx = glctx
+        ctx.grad_db = bool(grad_db)
         return rast, rast_db
 
     @staticmethod
@@ -99,18 +100,21 @@ class _Rasterize(torch.autograd.Function):
         pos, tri, rast = ctx.saved_tensors
         B, V, T, H, W = ctx.dims
         dev = pos.device
+        # grad_db (the dependency's default): what arrives at rast_db -- interpolate's backward for its pixel differentials -- reaches the positions too
+        dy_c = _h.f32c(dy) if dy is not None else None
+        ddb_c = _h.f32c(ddb) if (ddb is not None and ctx.grad_db) else None
         with torch.cuda.device(dev):
             dpos = torch.empty((B, V, 4), dtype=torch.float32, device=dev)
-            if T == 0:
-                dpos.zero_()                                          # nothing was drawn (an empty range)
+            if T == 0 or (dy_c is None and ddb_c is None):
+                dpos.zero_()                                          # nothing was drawn (an empty range) / nothing arrived
             elif ATOMIC_FREE_BACKWARD:
                 # gather formulation: per-triangle corner records, then a fixed-order sum per vertex (no atomics, bit-reproducible)
                 topo = ctx.glctx.vertex_topology(tri, V)
                 scratch = torch.empty((lib.c3d_mesh_rasterize_bwd_scratch_bytes(B, T),), dtype=torch.uint8, device=dev)
-                _h.check(lib.c3d_mesh_rasterize_bwd_gather(_h.ptr(pos), _h.ptr(tri), _h.ptr(rast), _h.ptr(_h.f32c(dy)), B, V, T, H, W, _h.ptr(topo),
+                _h.check(lib.c3d_mesh_rasterize_bwd_gather(_h.ptr(pos), _h.ptr(tri), _h.ptr(rast), _h.ptr(dy_c), _h.ptr(ddb_c), B, V, T, H, W, _h.ptr(topo),
                                                            _h.ptr(scratch), _h.ptr(dpos), _h.stream(dev)), "c3d_mesh_rasterize_bwd_gather")
             else:
-                _h.check(lib.c3d_mesh_rasterize_bwd(_h.ptr(pos), _h.ptr(tri if T else None), _h.ptr(rast), _h.ptr(_h.f32c(dy)), B, V, T, H, W,
+                _h.check(lib.c3d_mesh_rasterize_bwd(_h.ptr(pos), _h.ptr(tri if T else None), _h.ptr(rast), _h.ptr(dy_c), _h.ptr(ddb_c), B, V, T, H, W,
                                                     _h.ptr(dpos), _h.stream(dev)), "c3d_mesh_rasterize_bwd")
         return None, dpos, None, None, None, None
 
@@ -472,9 +476,7 @@ def texture(tex, uv, uv_da=None, mip_level_bias=None, mip=None, filter_mode='aut
         raise NotImplementedError("texture: boundary_mode %r is not built" % (boundary_mode,))
     if tex.dim() != 4:
         raise NotImplementedError("texture: cube maps are not built")
-    if boundary_mode == 'zero':
-        if filter_mode not in _FILTER:
-            raise NotImplementedError("texture: boundary_mode 'zero' is built for the 'nearest' and 'linear' filters only")
+    if boundary_mode == 'zero' and filter_mode in _FILTER:
         padded, uv_p = zero_boundary_as_clamp(tex, uv)
         return _Texture.apply(padded, uv_p, _FILTER[filter_mode], _BOUNDARY['clamp'])
     if filter_mode in _FILTER:
@@ -482,7 +484,8 @@ def texture(tex, uv, uv_da=None, mip_level_bias=None, mip=None, filter_mode='aut
     if uv_da is None and mip_level_bias is None:
         raise ValueError("texture: filter_mode %r needs uv_da or mip_level_bias" % (filter_mode,))
     stack, ml = _mip_stack(tex, mip, max_mip_level)
-    return _TextureMip.apply(tex, stack, uv, uv_da, mip_level_bias, _MIP_FILTER[filter_mode], _BOUNDARY[boundary_mode], ml)
+    # 'zero' with the mip-mapped filters: the kernels read 0 for a tap outside the level it belongs to (boundary code 2), level by level as nvdiffrast does
+    return _TextureMip.apply(tex, stack, uv, uv_da, mip_level_bias, _MIP_FILTER[filter_mode], 2 if boundary_mode == 'zero' else _BOUNDARY[boundary_mode], ml)
 
 
 # topology (edge hash) cache: the reference rebuilds it on every antialias call because it never passes topology_hash; the table only

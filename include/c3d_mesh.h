@@ -39,8 +39,9 @@ int c3d_mesh_rasterize_fwd(const float* pos, const int32_t* tri, int32_t B, int3
  * (untouched since); NULL = first layer = c3d_mesh_rasterize_fwd.  prev_scratch and scratch must be different buffers. */
 int c3d_mesh_rasterize_peel_fwd(const float* pos, const int32_t* tri, int32_t B, int32_t V, int32_t T, int32_t H, int32_t W,
                                 const void* prev_scratch, void* scratch, float* rast, float* rast_db, c3d_stream_t stream);
-/* dy = dL/drast [B,H,W,4] (only u,v channels are differentiable); dpos [B,V,4] accumulated */
-int c3d_mesh_rasterize_bwd(const float* pos, const int32_t* tri, const float* rast, const float* dy, int32_t B, int32_t V,
+/* dy = dL/drast [B,H,W,4] (only u,v channels are differentiable), ddb = dL/drast_db [B,H,W,4] (the dependency's grad_db path; ABI 301); either may be NULL;
+ * dpos [B,V,4] written in full */
+int c3d_mesh_rasterize_bwd(const float* pos, const int32_t* tri, const float* rast, const float* dy, const float* ddb, int32_t B, int32_t V,
                            int32_t T, int32_t H, int32_t W, float* dpos, c3d_stream_t stream);
 
 /* Atomic-free, bit-reproducible rasterize backward.  topology = vertex -> (triangle, corner) adjacency of `tri`
@@ -51,7 +52,7 @@ int c3d_mesh_rasterize_bwd(const float* pos, const int32_t* tri, const float* ra
 size_t c3d_mesh_vertex_topology_bytes(int32_t V, int32_t T);
 int c3d_mesh_build_vertex_topology(const int32_t* tri, int32_t V, int32_t T, void* topology, c3d_stream_t stream);
 size_t c3d_mesh_rasterize_bwd_scratch_bytes(int32_t B, int32_t T);
-int c3d_mesh_rasterize_bwd_gather(const float* pos, const int32_t* tri, const float* rast, const float* dy, int32_t B, int32_t V,
+int c3d_mesh_rasterize_bwd_gather(const float* pos, const int32_t* tri, const float* rast, const float* dy, const float* ddb, int32_t B, int32_t V,
                                   int32_t T, int32_t H, int32_t W, const void* topology, void* scratch, float* dpos,
                                   c3d_stream_t stream);
 

@@ -204,7 +204,9 @@ void mesh_rasterize_peel_fwd(const real *pos, const int32_t *tri, int B, int V, 
 }
 
 /* dL/dpos from dL/d(u,v) (dy[...,0:2]); dpos [B,V,4] must be zero-initialised */
-void mesh_rasterize_bwd(const real *pos, const int32_t *tri, const real *rast, const real *dy, int B, int V, int T, int H, int W, real *dpos) {
+/* ddb (optional, [B,H,W,4]): gradient w.r.t. rast_db = (du/dX, du/dY, dv/dX, dv/dY) (the dependency's grad_db path).  With A_kx = d a_k / d fx etc. as in the forward
+ * pass: du/dX = xs iw (b0 Tx - A0x), ... ; the chain rule below goes through b0, b1, iw and the six A terms (functions of the un-shifted x, y, w). */
+void mesh_rasterize_bwd(const real *pos, const int32_t *tri, const real *rast, const real *dy, const real *ddb, int B, int V, int T, int H, int W, real *dpos) {
     (void)T;
     const real xs = (real)2 / W, ys = (real)2 / H;
     size_t P = (size_t)H * W;
@@ -214,8 +216,10 @@ void mesh_rasterize_bwd(const real *pos, const int32_t *tri, const real *rast, c
                 size_t o = ((size_t)b * P + (size_t)py * W + px) * 4;
                 int t = (int)rast[o + 3] - 1;
                 if (t < 0) continue;
-                real g0 = dy[o], g1 = dy[o + 1];
-                if (g0 == 0 && g1 == 0) continue;
+                real g0 = dy ? dy[o] : 0, g1 = dy ? dy[o + 1] : 0;
+                real G[4] = {0, 0, 0, 0};
+                if (ddb) for (int k = 0; k < 4; k++) G[k] = ddb[o + k];
+                if (g0 == 0 && g1 == 0 && G[0] == 0 && G[1] == 0 && G[2] == 0 && G[3] == 0) continue;
                 int vi[3] = {tri[3 * t], tri[3 * t + 1], tri[3 * t + 2]};
                 const real *pb = pos + (size_t)b * V * 4;
                 const real *p0 = pb + 4 * vi[0], *p1 = pb + 4 * vi[1], *p2 = pb + 4 * vi[2];
@@ -230,6 +234,22 @@ void mesh_rasterize_bwd(const real *pos, const int32_t *tri, const real *rast, c
                 real da0 = (g0 * ((real)1 - b0) - g1 * b1) * iw;
                 real da1 = (-g0 * b0 + g1 * ((real)1 - b1)) * iw;
                 real da2 = (-g0 * b0 - g1 * b1) * iw;
+                real dA[3][2] = {{0, 0}, {0, 0}, {0, 0}};          /* gradients of A_kx, A_ky */
+                if (ddb) {
+                    real A0x = p1[3] * p2[1] - p1[1] * p2[3], A0y = p1[0] * p2[3] - p2[0] * p1[3];
+                    real A1x = p0[1] * p2[3] - p2[1] * p0[3], A1y = p2[0] * p0[3] - p0[0] * p2[3];
+                    real A2x = p1[1] * p0[3] - p0[1] * p1[3], A2y = p0[0] * p1[3] - p1[0] * p0[3];
+                    real Tx = A0x + A1x + A2x, Ty = A0y + A1y + A2y, al = xs * iw, be = ys * iw;
+                    real dudx = al * (b0 * Tx - A0x), dudy = be * (b0 * Ty - A0y), dvdx = al * (b1 * Tx - A1x), dvdy = be * (b1 * Ty - A1y);
+                    real gb0 = G[0] * al * Tx + G[1] * be * Ty, gb1 = G[2] * al * Tx + G[3] * be * Ty;
+                    real gTx = al * (G[0] * b0 + G[2] * b1), gTy = be * (G[1] * b0 + G[3] * b1);
+                    real L = G[0] * dudx + G[1] * dudy + G[2] * dvdx + G[3] * dvdy;
+                    real gi = L / iw + gb0 * a0 + gb1 * a1, gS = -iw * iw * gi;
+                    da0 += gb0 * iw + gS; da1 += gb1 * iw + gS; da2 += gS;
+                    dA[0][0] = gTx - al * G[0]; dA[0][1] = gTy - be * G[1];
+                    dA[1][0] = gTx - al * G[2]; dA[1][1] = gTy - be * G[3];
+                    dA[2][0] = gTx; dA[2][1] = gTy;
+                }
                 /* a0 = p1x p2y - p1y p2x ; a1 = p2x p0y - p2y p0x ; a2 = p0x p1y - p0y p1x */
                 real d0x = da1 * (-p2y) + da2 * p1y, d0y = da1 * p2x + da2 * (-p1x);
                 real d1x = da0 * p2y + da2 * (-p0y), d1y = da0 * (-p2x) + da2 * p0x;
@@ -238,6 +258,16 @@ void mesh_rasterize_bwd(const real *pos, const int32_t *tri, const real *rast, c
                 for (int k = 0; k < 3; k++) {
                     real *d = dpos + ((size_t)b * V + vi[k]) * 4;
                     d[0] += dxs[k]; d[1] += dys[k]; d[3] += -fx * dxs[k] - fy * dys[k];
+                }
+                if (ddb) {      /* A_kx = y_m w_l - y_l w_m, A_ky = x_l w_m - x_m w_l with (l, m) = (k+1, k+2) mod 3 */
+                    const real *pp[3] = {p0, p1, p2};
+                    for (int k = 0; k < 3; k++) {
+                        int l = (k + 1) % 3, m = (k + 2) % 3;
+                        real *dl = dpos + ((size_t)b * V + vi[l]) * 4, *dm = dpos + ((size_t)b * V + vi[m]) * 4;
+                        real gx = dA[k][0], gy = dA[k][1];
+                        dm[1] += gx * pp[l][3]; dl[3] += gx * pp[m][1]; dl[1] -= gx * pp[m][3]; dm[3] -= gx * pp[l][1];
+                        dl[0] += gy * pp[m][3]; dm[3] += gy * pp[l][0]; dm[0] -= gy * pp[l][3]; dl[3] -= gy * pp[m][0];
+                    }
                 }
             }
 }
@@ -479,7 +509,7 @@ static int mip_select(const real *da, const real *bias, int Ht, int Wt, int L, i
 /* filter: 2 = linear-mipmap-nearest, 3 = linear-mipmap-linear.  uv_da [B,H,W,4] or NULL, bias [B,H,W] or NULL (not both NULL). */
 int mesh_texture_mip_fwd(const real *tex, const real *stack, int Bt, const real *uv, const real *uv_da, const real *bias, int B, int H, int W,
                          int Ht, int Wt, int C, int filter, int boundary, int max_level, real *out) {
-    if (boundary != 0 && boundary != 1) return -1;                   /* 'zero' exists for the plain fetch only */
+    if (boundary < 0 || boundary > 2) return -1;                     /* 2 = 'zero': a tap outside THIS level's texels reads 0 */
     mip_t m; if (mip_info(Ht, Wt, max_level, &m)) return -1;
     size_t P = (size_t)H * W;
     for (int b = 0; b < B; b++) for (size_t pid = 0; pid < P; pid++) {
@@ -497,9 +527,9 @@ int mesh_texture_mip_fwd(const real *tex, const real *stack, int Bt, const real 
             real fu0 = (real)floor((double)u), fv0 = (real)floor((double)v), fu = u - fu0, fv = v - fv0;
             int iu0 = wrapi((int)fu0, wl_, boundary), iu1 = wrapi((int)fu0 + 1, wl_, boundary);
             int iv0 = wrapi((int)fv0, hl_, boundary), iv1 = wrapi((int)fv0 + 1, hl_, boundary);
+#define MIP_TX(iv, iu) (((iv) < 0 || (iu) < 0) ? (real)0 : tb[((size_t)(iv) * wl_ + (iu)) * C + c])
             for (int c = 0; c < C; c++) {
-                real t00 = tb[((size_t)iv0 * wl_ + iu0) * C + c], t10 = tb[((size_t)iv0 * wl_ + iu1) * C + c];
-                real t01 = tb[((size_t)iv1 * wl_ + iu0) * C + c], t11 = tb[((size_t)iv1 * wl_ + iu1) * C + c];
+                real t00 = MIP_TX(iv0, iu0), t10 = MIP_TX(iv0, iu1), t01 = MIP_TX(iv1, iu0), t11 = MIP_TX(iv1, iu1);
                 real top = t00 + fu * (t10 - t00), bot = t01 + fu * (t11 - t01);
                 po[c] += wl * (top + fv * (bot - top));
             }
@@ -535,7 +565,7 @@ static int mip_level_grad(const real *da, const real *bias, int Ht, int Wt, int 
 int mesh_texture_mip_bwd(const real *tex, const real *stack, int Bt, const real *uv, const real *uv_da, const real *bias, const real *dy,
                          int B, int H, int W, int Ht, int Wt, int C, int filter, int boundary, int max_level, real *dtex, real *dstack, real *duv,
                          real *dda, real *dbias) {
-    if (boundary != 0 && boundary != 1) return -1;
+    if (boundary < 0 || boundary > 2) return -1;
     mip_t m; if (mip_info(Ht, Wt, max_level, &m)) return -1;
     size_t P = (size_t)H * W;
     for (int b = 0; b < B; b++) for (size_t pid = 0; pid < P; pid++) {
@@ -558,15 +588,19 @@ int mesh_texture_mip_bwd(const real *tex, const real *stack, int Bt, const real 
             int iu0 = wrapi((int)fu0, wl_, boundary), iu1 = wrapi((int)fu0 + 1, wl_, boundary);
             int iv0 = wrapi((int)fv0, hl_, boundary), iv1 = wrapi((int)fv0 + 1, hl_, boundary);
             real gu = 0, gv = 0;
+            int ok00 = iv0 >= 0 && iu0 >= 0, ok10 = iv0 >= 0 && iu1 >= 0, ok01 = iv1 >= 0 && iu0 >= 0, ok11 = iv1 >= 0 && iu1 >= 0;      /* 'zero': taps outside the level */
             for (int c = 0; c < C; c++) {
                 size_t i00 = ((size_t)iv0 * wl_ + iu0) * C + c, i10 = ((size_t)iv0 * wl_ + iu1) * C + c;
                 size_t i01 = ((size_t)iv1 * wl_ + iu0) * C + c, i11 = ((size_t)iv1 * wl_ + iu1) * C + c;
                 real gc = g[c] * wl;
-                db[i00] += gc * ((real)1 - fu) * ((real)1 - fv); db[i10] += gc * fu * ((real)1 - fv);
-                db[i01] += gc * ((real)1 - fu) * fv; db[i11] += gc * fu * fv;
-                gu += gc * ((tb[i10] - tb[i00]) * ((real)1 - fv) + (tb[i11] - tb[i01]) * fv);
-                gv += gc * ((tb[i01] - tb[i00]) * ((real)1 - fu) + (tb[i11] - tb[i10]) * fu);
-                real top = tb[i00] + fu * (tb[i10] - tb[i00]), bot = tb[i01] + fu * (tb[i11] - tb[i01]);
+                if (ok00) db[i00] += gc * ((real)1 - fu) * ((real)1 - fv);
+                if (ok10) db[i10] += gc * fu * ((real)1 - fv);
+                if (ok01) db[i01] += gc * ((real)1 - fu) * fv;
+                if (ok11) db[i11] += gc * fu * fv;
+                real t00 = ok00 ? tb[i00] : 0, t10 = ok10 ? tb[i10] : 0, t01 = ok01 ? tb[i01] : 0, t11 = ok11 ? tb[i11] : 0;
+                gu += gc * ((t10 - t00) * ((real)1 - fv) + (t11 - t01) * fv);
+                gv += gc * ((t01 - t00) * ((real)1 - fu) + (t11 - t10) * fu);
+                real top = t00 + fu * (t10 - t00), bot = t01 + fu * (t11 - t01);
                 sdot[k] += g[c] * (top + fv * (bot - top));
             }
             duv[2 * o] += gu * wl_; duv[2 * o + 1] += gv * hl_;

@@ -73,13 +73,15 @@ def rasterize_next_layer(pos, tri, resolution, prev_rast, dtype=np.float32):
     return rast, db
 
 
-def rasterize_bwd(pos, tri, rast, dy, dtype=np.float32):
+def rasterize_bwd(pos, tri, rast, dy, ddb=None, dtype=np.float32):
+    """ddb: gradient w.r.t. rast_db (optional; the dependency's grad_db path)"""
     lib = _lib(dtype)
     pos, tri, rast, dy = _a(pos, dtype), _a(tri, np.int32), _a(rast, dtype), _a(dy, dtype)
+    ddb = None if ddb is None else _a(ddb, dtype)
     B, V, _ = pos.shape
     _, H, W, _ = rast.shape
     dpos = np.zeros_like(pos)
-    lib.mesh_rasterize_bwd(_p(pos), _p(tri), _p(rast), _p(dy), I(B), I(V), I(tri.shape[0]), I(H), I(W), _p(dpos))
+    lib.mesh_rasterize_bwd(_p(pos), _p(tri), _p(rast), _p(dy), _p(ddb) if ddb is not None else None, I(B), I(V), I(tri.shape[0]), I(H), I(W), _p(dpos))
     return dpos
 
 

@@ -156,6 +156,20 @@ def test_gradients_by_finite_differences():
     for i in pick:
         assert abs(num[i] - dpos.reshape(-1)[i]) <= 1e-5 * max(1.0, abs(num[i])), (i, num[i], dpos.reshape(-1)[i])
     assert np.abs(dpos[..., 2]).max() == 0                           # z gets no gradient from (u, v)
+    # ---- rasterize: d(sum gdb * rast_db) / dpos (the dependency's grad_db path), alone and together with the (u, v) gradient
+    gdb = rng.normal(size=db.shape)
+    dpos_db = M.rasterize_bwd(pos, f, rast, np.zeros_like(g), ddb=gdb, dtype=np.float64)
+
+    def ras_db(p):
+        r, d_ = M.rasterize(p, f, (H, W), dtype=np.float64)
+        d_ = d_.copy(); d_[r[..., 3] != ids] = 0
+        return d_
+    num = _fd(ras_db, pos.copy(), gdb, 1e-7, pick)
+    assert np.abs(dpos_db).max() > 0
+    for i in pick:
+        assert abs(num[i] - dpos_db.reshape(-1)[i]) <= 2e-5 * max(1.0, abs(num[i])), (i, num[i], dpos_db.reshape(-1)[i])
+    assert np.abs(dpos_db[..., 2]).max() == 0
+    np.testing.assert_allclose(M.rasterize_bwd(pos, f, rast, g, ddb=gdb, dtype=np.float64), dpos + dpos_db, rtol=1e-12, atol=1e-12)
     # ---- interpolate
     attr = rng.normal(size=(V, 3))
     out, _ = M.interpolate(attr, rast, f, dtype=np.float64)
@@ -251,10 +265,17 @@ def test_mip_level_selection_known_answers():
     np.testing.assert_allclose(M.texture_mip(const, uv, uv_da=da, dtype=np.float64), 0.37, atol=1e-14)
 
 
-@pytest.mark.parametrize("boundary", ["wrap", "clamp"])
+@pytest.mark.parametrize("boundary", ["wrap", "clamp", "zero"])
 @pytest.mark.parametrize("filter_mode", ["linear-mipmap-linear", "linear-mipmap-nearest"])
 def test_mip_gradients_by_finite_differences(boundary, filter_mode):
+    """'zero' (round 3): a tap outside the level it belongs to reads 0 and receives no gradient, level by level"""
     rng = np.random.default_rng(5)
+    if boundary == "zero":      # known answers: far outside every level -> 0; a constant texture fades to 0 across the border of the level that is sampled
+        const = np.full((1, 8, 8, 2), 0.5)
+        far = np.full((1, 1, 2, 2), 7.3)
+        assert np.all(M.texture_mip(const, far, mip_level_bias=np.array([[[0.0, 2.5]]]), boundary_mode="zero", dtype=np.float64) == 0.0)
+        edge = np.array([[[[0.0, 0.5], [0.0, 0.5]]]])     # u = 0: halfway between the first texel and the zero outside, on level 0 and on level 2 alike
+        np.testing.assert_allclose(M.texture_mip(const, edge, mip_level_bias=np.array([[[0.0, 2.0]]]), boundary_mode="zero", dtype=np.float64), 0.25, atol=1e-14)
     Ht, Wt, H, W = 8, 16, 6, 9
     tex = rng.normal(size=(1, Ht, Wt, 3)); uv = rng.uniform(-0.4, 1.4, size=(1, H, W, 2))
     da = rng.normal(size=(1, H, W, 4)) * 0.08                  # levels 0 .. 2 and fractions in between
@@ -431,8 +452,9 @@ def test_texture_zero_boundary_known_answers_gradients_and_the_clamp_composition
     num = _fd(lambda u_: M.texture(tex, u_, "linear", "zero", dtype=d), uv.copy(), g, 1e-7, range(0, uv.size, 7))
     for i, v_ in num.items():
         assert abs(v_ - duv.reshape(-1)[i]) < 1e-5 * max(1.0, abs(v_))
-    with pytest.raises(AssertionError):
-        M.texture_mip(tex, uv, mip_level_bias=np.zeros((2, 11, 13)), boundary_mode="zero", max_mip_level=0, dtype=d)
+    # round 3: 'zero' exists for the mip-mapped filters too; on level 0 alone (bias 0, no coarser level) it is the plain 'zero' fetch
+    np.testing.assert_allclose(M.texture_mip(tex, uv, mip_level_bias=np.zeros((2, 11, 13)), boundary_mode="zero", max_mip_level=0, dtype=d),
+                               M.texture(tex, uv, "linear", "zero", dtype=d), atol=1e-14)
 
 
 def _near_plane_scene():

@@ -79,7 +79,7 @@ def test_pyramid_matches_oracle_and_its_backward_is_the_transpose(gpu):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("C,Bt", [(3, 1), (4, 2), (2, 2), (1, 1)])
-@pytest.mark.parametrize("boundary", ["wrap", "clamp"])
+@pytest.mark.parametrize("boundary", ["wrap", "clamp", "zero"])
 def test_trilinear_forward_and_gradients(gpu, C, Bt, boundary):
     """C = 1, 3, 4 take the LDS-combined backward, C = 2 the direct-atomics one."""
     import nvdiffrast.torch as dr
@@ -197,14 +197,14 @@ def test_textured_mesh_with_auto_mipmapping(gpu):
     rng = np.random.default_rng(2)
     tex = rng.normal(size=(1, 256, 256, 3)).astype(np.float32)                                          # minified: several texels per pixel
     ctx = dr.RasterizeCudaContext()
-    ttex, tvt, ttri = T(tex, grad=True), T(vt[None], grad=True), T(f, torch.int32)
-    rast, db = dr.rasterize(ctx, T(pos), ttri, (H, W))
+    ttex, tvt, ttri, tpos = T(tex, grad=True), T(vt[None], grad=True), T(f, torch.int32), T(pos, grad=True)
+    rast, db = dr.rasterize(ctx, tpos, ttri, (H, W))
     texc, texd = dr.interpolate(tvt, rast, ttri, rast_db=db, diff_attrs='all')
     col = dr.texture(ttex, texc, texd)                                                                   # uv_da positional, filter 'auto'
     orast, odb = M.rasterize(pos, f, (H, W))
     otexc, otexd = M.interpolate(vt[None], orast, f, odb, "all")
     ocol = M.texture_mip(tex, otexc, otexd)
-    assert (rast.cpu().numpy()[..., 3] != orast[..., 3]).sum() <= 2
+    assert (rast.detach().cpu().numpy()[..., 3] != orast[..., 3]).sum() <= 2
     assert np.abs(col.detach().cpu().numpy() - ocol).mean() <= IMG_L1
     lin = M.texture(tex, otexc)
     assert np.abs(ocol - lin).mean() > 0.05                                                              # the pyramid is really in play
@@ -214,12 +214,22 @@ def test_textured_mesh_with_auto_mipmapping(gpu):
     r64, db64 = M.rasterize(pos, f, (H, W), dtype=d)
     texc64, texd64 = M.interpolate(vt[None], r64, f, db64, "all", dtype=d)
     dtex, dstack, duv, dda, _ = M.texture_mip_bwd(tex, texc64, g, texd64, None, dtype=d, level_grads=True)
-    dvt, _ = M.interpolate_bwd(vt[None], r64, f, duv, dtype=d)
+    dvt, drast = M.interpolate_bwd(vt[None], r64, f, duv, dtype=d)
     # the texture coordinates also steer the mip LEVEL through their pixel differentials: texture() hands d/d(uv_da) back, interpolate() passes it on to vt
-    dvt_da, _ = M.interpolate_da_bwd(vt[None], r64, f, db64, "all", dda, dtype=d)
+    dvt_da, ddb = M.interpolate_da_bwd(vt[None], r64, f, db64, "all", dda, dtype=d)
     assert np.abs(dvt_da).max() > 1e-3 * np.abs(dvt).max()
     assert rel_err(ttex.grad.cpu().numpy(), dtex + M.mip_build_bwd(dstack, tex.shape, dtype=d)) <= GRAD_REL
     assert rel_err(tvt.grad.cpu().numpy(), dvt + dvt_da) <= 3 * GRAD_REL      # a white-noise texture: d out / d level is as large as the signal, float32 levels differ in the last bits
+    # ... and rasterize(grad_db=True) passes what arrives at rast_db on to the positions (round 3), next to the (u, v) path
+    dpos_uv = M.rasterize_bwd(pos, f, r64, drast, dtype=d)
+    dpos = M.rasterize_bwd(pos, f, r64, drast, ddb=ddb, dtype=d)
+    assert np.abs(dpos - dpos_uv).max() > 1e-3 * np.abs(dpos_uv).max()
+    assert rel_err(tpos.grad.cpu().numpy(), dpos) <= 4 * GRAD_REL
+    tpos2 = T(pos, grad=True)          # grad_db=False: only the (u, v) path
+    r2, db2 = dr.rasterize(ctx, tpos2, ttri, (H, W), grad_db=False)
+    t2, d2 = dr.interpolate(T(vt[None]), r2, ttri, rast_db=db2, diff_attrs='all')
+    (dr.texture(T(tex), t2, d2) * T(g)).sum().backward()
+    assert rel_err(tpos2.grad.cpu().numpy(), dpos_uv) <= 4 * GRAD_REL
 
 
 @pytest.mark.gpu
