@@ -1050,6 +1050,17 @@ __device__ __forceinline__ int other_opposite(const EdgeSlot* __restrict__ table
     return -1;
 }
 
+// Round 3: the answer of other_opposite() for every (triangle, edge), computed once per topology behind the hash table (int32 [T][3]): the per-view silhouette
+// analysis reads one coalesced triple per triangle instead of probing the hash (a random 32-byte gather + key compare per crossing edge).
+__global__ void __launch_bounds__(256) k_aa_adj_build(const int3* __restrict__ tri, int T, const EdgeSlot* __restrict__ table, uint32_t mask, int* __restrict__ adj) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= 3 * T) return;
+    const int t = gid / 3, k = gid % 3;
+    const int3 vi = tri[t];
+    const int vv[3] = {vi.x, vi.y, vi.z};
+    adj[gid] = other_opposite(table, mask, vv[k], vv[(k + 1) % 3], t);
+}
+__device__ __forceinline__ const int* aa_adjacency(const EdgeSlot* table, uint32_t mask) { return (const int*)(table + (size_t)mask + 1); }
 struct AaHit { int ax, ay, bx, by, va, vb, ek; float s, sgn; };      // ek: the silhouette edge runs from corner ek to corner (ek + 1) % 3 of pixel a's triangle
 __device__ __forceinline__ bool aa_analyze(const float4* __restrict__ pb, const int3* __restrict__ tri, const EdgeSlot* __restrict__ table, uint32_t mask,
                                            const float4* __restrict__ rast_b, int H, int W, int px, int py, int d, AaHit& hit) {
@@ -1095,7 +1106,7 @@ __device__ __forceinline__ bool aa_analyze(const float4* __restrict__ pb, const 
             s = sgn * ((ny[ia] + te * ey) - cy) / h;
         }
         if (!(s >= 0.f && s <= 1.f)) continue;
-        const int opp = other_opposite(table, mask, vi[ia], vi[ib], t);
+        const int opp = aa_adjacency(table, mask)[3 * t + k];      // = other_opposite(table, mask, vi[ia], vi[ib], t)
         if (opp == -2) continue;
         if (opp >= 0) {   // interior edge: silhouette only if both triangles lie on the same side of it
             const float4 q = pb[opp];
@@ -1551,7 +1562,7 @@ int c3d_mesh_shade_bwd(const float* albedo, const float* alpha, const float* bg,
     return 0;
 }
 
-size_t c3d_mesh_antialias_scratch_bytes(int32_t T) { return c3d_align(sizeof(EdgeSlot) * (size_t)edge_table_size(T)); }
+size_t c3d_mesh_antialias_scratch_bytes(int32_t T) { return c3d_align(sizeof(EdgeSlot) * (size_t)edge_table_size(T)) + c3d_align(sizeof(int) * 3 * (size_t)(T > 0 ? T : 1)); }
 
 int c3d_mesh_antialias_build_topology(const int32_t* tri, int32_t T, void* scratch, c3d_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
@@ -1563,6 +1574,7 @@ int c3d_mesh_antialias_build_topology(const int32_t* tri, int32_t T, void* scrat
     if (T > 0) {
         MESH_REQUIRE(tri, "NULL tri");
         hipLaunchKernelGGL(k_aa_hash_build, dim3(c3d_cdiv(3ll * T, 256)), dim3(256), 0, s, (const int3*)tri, T, table, n - 1);
+        hipLaunchKernelGGL(k_aa_adj_build, dim3(c3d_cdiv(3ll * T, 256)), dim3(256), 0, s, (const int3*)tri, T, (const EdgeSlot*)table, n - 1, (int*)(table + n));
     }
     C3D_LAUNCH_CHECK();
     return 0;
