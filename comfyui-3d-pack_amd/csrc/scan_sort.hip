@@ -239,8 +239,9 @@ __device__ __forceinline__ uint32_t rs_wait(const uint32_t* p, uint32_t x, uint3
     return x;
 }
 
-template <bool IOTA>
-__global__ void __launch_bounds__(RS_THREADS, 4) k_onesweep(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+// ITEMS keys per thread: 16 (4096 keys and 39 KB of LDS per workgroup: four workgroups per CU) or 8 (2048 keys, 22 KB: seven per CU, twice the tiles) -- C3D_SORT_ITEMS
+template <bool IOTA, int ITEMS>
+__global__ void __launch_bounds__(RS_THREADS, ITEMS > 16 ? 2 : 4) k_onesweep(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                              uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                              const uint32_t* __restrict__ ghist, uint32_t* __restrict__ ticket, uint32_t* __restrict__ err,
                                                              uint32_t* __restrict__ tile_words, uint32_t* __restrict__ group_words, size_t n,
@@ -248,8 +249,8 @@ __global__ void __launch_bounds__(RS_THREADS, 4) k_onesweep(const uint32_t* __re
     __shared__ uint32_t whist[RS_THREADS / 64][RS_RADIX];
     __shared__ uint32_t lstart[RS_RADIX];    // first local slot of each digit
     __shared__ uint32_t gbase[RS_RADIX];     // global position of that slot
-    __shared__ uint32_t skey[RS_TILE];
-    __shared__ uint32_t sval[RS_TILE];
+    __shared__ uint32_t skey[RS_THREADS * ITEMS];
+    __shared__ uint32_t sval[RS_THREADS * ITEMS];
     __shared__ uint32_t scan_lds[4];
     __shared__ uint32_t s_tile;
     if (n_dev) n = min((size_t)*n_dev, n);
@@ -258,24 +259,24 @@ __global__ void __launch_bounds__(RS_THREADS, 4) k_onesweep(const uint32_t* __re
     for (int i = threadIdx.x; i < (RS_THREADS / 64) * RS_RADIX; i += RS_THREADS) (&whist[0][0])[i] = 0;
     __syncthreads();
     const uint32_t tile = s_tile;
-    const size_t bbase = (size_t)tile * RS_TILE;
+    const size_t bbase = (size_t)tile * (RS_THREADS * ITEMS);
     if (bbase >= n) return;                  // capacity-sized launch: tickets beyond the data leave at once (nobody waits for them)
 #define RS_STAMP(k) do { if (dbg && threadIdx.x == 0) dbg[(size_t)tile * 8 + (k)] = (unsigned long long)wall_clock64(); } while (0)   // profiling hook (profiles/microbench/sort_phases.py)
     RS_STAMP(0);
-    const size_t wbase = bbase + (size_t)wave * (RS_TILE / 4);
-    uint32_t key[RS_ITEMS], val[RS_ITEMS], rank[RS_ITEMS];
+    const size_t wbase = bbase + (size_t)wave * (RS_THREADS * ITEMS / 4);
+    uint32_t key[ITEMS], val[ITEMS], rank[ITEMS];
 #pragma unroll
-    for (int i = 0; i < RS_ITEMS; i++) {
+    for (int i = 0; i < ITEMS; i++) {
         size_t idx = wbase + (size_t)i * 64 + lane;
         bool ok = idx < n;
         key[i] = ok ? keys_in[idx] : 0xFFFFFFFFu;
         val[i] = IOTA ? (uint32_t)idx : (ok ? vals_in[idx] : 0u);
     }
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    if (dbg) { uint32_t x = 0; for (int i = 0; i < RS_ITEMS; i++) x ^= key[i] ^ val[i]; if (x == 0x12345u) dbg[7] = 1; }   // wait for the loads before stamping
+    if (dbg) { uint32_t x = 0; for (int i = 0; i < ITEMS; i++) x ^= key[i] ^ val[i]; if (x == 0x12345u) dbg[7] = 1; }   // wait for the loads before stamping
     RS_STAMP(1);
 #pragma unroll
-    for (int i = 0; i < RS_ITEMS; i++) {
+    for (int i = 0; i < ITEMS; i++) {
         size_t idx = wbase + (size_t)i * 64 + lane;
         bool ok = idx < n;
         uint32_t d = (key[i] >> shift) & (RS_RADIX - 1);
@@ -316,7 +317,7 @@ __global__ void __launch_bounds__(RS_THREADS, 4) k_onesweep(const uint32_t* __re
     __syncthreads();
     // block-local reorder first: it needs no global prefix and frees the key / val / rank registers for the scan's loads
 #pragma unroll
-    for (int i = 0; i < RS_ITEMS; i++) {
+    for (int i = 0; i < ITEMS; i++) {
         size_t idx = wbase + (size_t)i * 64 + lane;
         if (idx < n) {
             uint32_t dd = (key[i] >> shift) & (RS_RADIX - 1);
@@ -370,9 +371,9 @@ __global__ void __launch_bounds__(RS_THREADS, 4) k_onesweep(const uint32_t* __re
     }
     __syncthreads();
     RS_STAMP(4);
-    const int cnt = (int)((n - bbase) < (size_t)RS_TILE ? (n - bbase) : (size_t)RS_TILE);
+    const int cnt = (int)((n - bbase) < (size_t)(RS_THREADS * ITEMS) ? (n - bbase) : (size_t)(RS_THREADS * ITEMS));
 #pragma unroll
-    for (int i = 0; i < RS_ITEMS; i++) {
+    for (int i = 0; i < ITEMS; i++) {
         const int lp = i * RS_THREADS + threadIdx.x;     // consecutive lanes -> consecutive slots of a digit run
         if (lp < cnt) {
             const uint32_t k = skey[lp];
@@ -388,8 +389,14 @@ __global__ void __launch_bounds__(RS_THREADS, 4) k_onesweep(const uint32_t* __re
 
 static unsigned long long* g_sort_dbg = nullptr;     // profiling hook: [pass][tile][8] wall_clock64 stamps (100 MHz), see c3d_test_sort_phases
 static inline size_t sort_head_bytes() { return c3d_align(sizeof(uint32_t) * (RS_HIST_SPLIT * RS_RADIX * RS_MAX_PASSES + RS_MAX_PASSES + 4)); }
+static int sort_items() {      // keys per thread of k_onesweep (see there)
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("C3D_SORT_ITEMS"); v = e ? atoi(e) : 16; if (v != 8 && v != 16 && v != 32) v = 16; }
+    return v;
+}
+#define RS_MIN_TILE (RS_THREADS * 8)      // the state is sized for the smaller tile
 size_t c3d_sort_tmp_bytes(size_t n) {
-    const size_t nb = (size_t)c3d_cdiv((long long)(n ? n : 1), RS_TILE);
+    const size_t nb = (size_t)c3d_cdiv((long long)(n ? n : 1), RS_MIN_TILE);
     return sort_head_bytes() + c3d_align(sizeof(uint32_t) * sort_pass_words(nb) * RS_MAX_PASSES);
 }
 uint32_t* c3d_sort_error_word(void* tmp) { return (uint32_t*)tmp + RS_HIST_SPLIT * RS_RADIX * RS_MAX_PASSES + RS_MAX_PASSES; }
@@ -397,7 +404,7 @@ size_t c3d_sort_state_bytes(size_t n, int end_bit) {
     int passes = (end_bit + 7) / 8;
     if (passes < 1) passes = 1;
     if (passes > RS_MAX_PASSES) passes = RS_MAX_PASSES;
-    return sort_head_bytes() + sizeof(uint32_t) * sort_pass_words((size_t)c3d_cdiv((long long)(n ? n : 1), RS_TILE)) * passes;
+    return sort_head_bytes() + sizeof(uint32_t) * sort_pass_words((size_t)c3d_cdiv((long long)(n ? n : 1), RS_MIN_TILE)) * passes;
 }
 
 int c3d_sort_pairs_u32(uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32_t* vals1, bool iota_vals,
@@ -408,7 +415,8 @@ int c3d_sort_pairs_u32(uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32
     if (n > (size_t)RS_VALUE_MASK) { c3d_set_error("c3d_sort_pairs_u32: %zu elements exceed the 2^30 - 1 the chained scan's status words hold", n); return -1; }
     int passes = (end_bit + 7) / 8;
     if (passes < 1) passes = 1;
-    const int nb = c3d_cdiv((long long)n, RS_TILE);
+    const int items = sort_items();
+    const int nb = c3d_cdiv((long long)n, RS_THREADS * items), nb_hist = c3d_cdiv((long long)n, RS_TILE);
     uint32_t* ghist = (uint32_t*)tmp;
     uint32_t* tickets = ghist + RS_HIST_SPLIT * RS_RADIX * RS_MAX_PASSES;
     uint32_t* err = err_out ? err_out : c3d_sort_error_word(tmp);
@@ -416,15 +424,16 @@ int c3d_sort_pairs_u32(uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32
     if (zero_state) C3D_CHECK(hipMemsetAsync(tmp, 0, c3d_sort_state_bytes(n, end_bit), s));
     uint32_t* k[2] = {keys0, keys1};
     uint32_t* v[2] = {vals0, vals1};
-    hipLaunchKernelGGL(k_radix_hist_all, dim3(nb), dim3(RS_THREADS), 0, s, keys0, ghist, n, n_dev, passes);
+    hipLaunchKernelGGL(k_radix_hist_all, dim3(nb_hist), dim3(RS_THREADS), 0, s, keys0, ghist, n, n_dev, passes);
     int cur = 0;
     for (int pass = 0; pass < passes; pass++) {
         uint32_t* tw = status + (size_t)pass * sort_pass_words((size_t)nb);
         uint32_t* gw = tw + (size_t)RS_RADIX * nb;
-        if (pass == 0 && iota_vals)
-            hipLaunchKernelGGL(k_onesweep<true>, dim3(nb), dim3(RS_THREADS), 0, s, k[cur], v[cur], k[cur ^ 1], v[cur ^ 1], ghist + pass * RS_RADIX, tickets + pass, err, tw, gw, n, n_dev, 8 * pass, g_sort_dbg ? g_sort_dbg + (size_t)pass * nb * 8 : nullptr);
-        else
-            hipLaunchKernelGGL(k_onesweep<false>, dim3(nb), dim3(RS_THREADS), 0, s, k[cur], v[cur], k[cur ^ 1], v[cur ^ 1], ghist + pass * RS_RADIX, tickets + pass, err, tw, gw, n, n_dev, 8 * pass, g_sort_dbg ? g_sort_dbg + (size_t)pass * nb * 8 : nullptr);
+#define RS_SWEEP(IOTA_, ITEMS_) hipLaunchKernelGGL((k_onesweep<IOTA_, ITEMS_>), dim3(nb), dim3(RS_THREADS), 0, s, k[cur], v[cur], k[cur ^ 1], v[cur ^ 1], ghist + pass * RS_RADIX, \
+                                                   tickets + pass, err, tw, gw, n, n_dev, 8 * pass, g_sort_dbg ? g_sort_dbg + (size_t)pass * nb * 8 : nullptr)
+        if (pass == 0 && iota_vals) { if (items == 8) RS_SWEEP(true, 8); else if (items == 32) RS_SWEEP(true, 32); else RS_SWEEP(true, 16); }
+        else { if (items == 8) RS_SWEEP(false, 8); else if (items == 32) RS_SWEEP(false, 32); else RS_SWEEP(false, 16); }
+#undef RS_SWEEP
         C3D_LAUNCH_CHECK();
         cur ^= 1;
     }
