@@ -6,4 +6,4 @@ for line in sys.stdin:
     if not line.startswith("{"):
         continue
     d = json.loads(line)
-    print(d["config"].get("view_lanes"), d["value"], d["ms_per_step"], {k: round(v["avg_ms"], 4) for k, v in d.get("kernels", {}).items()})
+    print(d["config"].get("view_lanes"), d["value"], d["ms_per_step"], {k: round(v["avg_ms"], 4) for k, v in d.get("kernels", {}).items() if isinstance(v, dict) and "avg_ms" in v})
