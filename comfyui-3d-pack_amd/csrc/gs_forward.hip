@@ -171,6 +171,54 @@ __global__ void __launch_bounds__(128) k_preprocess_views(GsParams p, GsPreViews
     for (int v = 0; v < vs.V; v++)
         gs_project_one(idx, m, c3, [&]() { return opac; }, sh, (const float*)nullptr, vs.v[v].cam, p.W, p.H, p.gx, p.gy, p.deg, vs.v[v].out);
 }
+// Round 3: the same kernel with the lane's 48 SH coefficients in REGISTERS.  The LDS image above (196 B per lane) caps the kernel at 13 waves per CU (3 per SIMD)
+// -- half of its time is VALU work, half memory, and with so few waves the two do not overlap.  Here LDS is only the transposition buffer of the coalesced load
+// (44 rows at a time: 8.6 KB per workgroup), the coefficients move on into registers (28 + 48 VGPRs -> 6 waves per SIMD).  Same arithmetic: gs_project_one reads
+// sh[k] either way.
+#define PRE_ROWS 44      // multiple of 4: the 16-byte loads of sh_stage_in_split stay aligned
+__global__ void __launch_bounds__(128) k_preprocess_views_r(GsParams p, GsPreViews vs, const float* __restrict__ means3D, const float* __restrict__ f_dc,
+                                                             const float* __restrict__ f_rest, const float* __restrict__ opacities,
+                                                             const float* __restrict__ scales, const float* __restrict__ rotations) {
+    __shared__ float sh_lds[PRE_ROWS * SH_ROW];
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    float sh[SH_M3];
+#pragma unroll
+    for (int k = 0; k < SH_M3; k++) sh[k] = 0.f;
+    {
+        const size_t g0 = (size_t)blockIdx.x * blockDim.x;
+        const int count = min((int)blockDim.x, p.N - (int)g0);
+        for (int r0 = 0; r0 < count; r0 += PRE_ROWS) {
+            const int rows = min(PRE_ROWS, count - r0);
+            sh_stage_in_split(f_dc, f_rest, g0 + r0, rows, sh_lds);
+            __syncthreads();
+            const int mine = (int)threadIdx.x - r0;
+            if (mine >= 0 && mine < rows) {
+#pragma unroll
+                for (int k = 0; k < SH_M3; k++) sh[k] = sh_lds[mine * SH_ROW + k];
+            }
+            __syncthreads();
+        }
+    }
+    if (idx >= p.N) return;
+    const float3 m = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
+    float c3[6];
+    {
+        float3 s = make_float3(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]);
+        float4 q = *reinterpret_cast<const float4*>(rotations + 4 * idx);
+        s = make_float3(expf(s.x), expf(s.y), expf(s.z));
+        const float inv = 1.f / fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
+        q = make_float4(q.x * inv, q.y * inv, q.z * inv, q.w * inv);
+        cov3d_from_scale_rot(s, p.scale_modifier, q, c3);
+    }
+    const float opac = 1.f / (1.f + expf(-opacities[idx]));
+    for (int v = 0; v < vs.V; v++)
+        gs_project_one(idx, m, c3, [&]() { return opac; }, sh, (const float*)nullptr, vs.v[v].cam, p.W, p.H, p.gx, p.gy, p.deg, vs.v[v].out);
+}
+static bool pre_sh_regs() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("C3D_PRE_REGS"); v = e ? atoi(e) != 0 : 1; }
+    return v != 0;
+}
 // geoms[v] / radii[v]: the state buffers of view v; views[v]: its camera (GsParams of that view; N, W, H, scale_modifier, deg must agree)
 int gs_launch_preprocess_views(const GsParams* views, int V, const GsGeom* geoms, int* const* radii, const float* means3D, const float* f_dc, const float* f_rest,
                                const float* opacity_raw, const float* scaling_raw, const float* rotation_raw, hipStream_t s) {
@@ -184,8 +232,11 @@ int gs_launch_preprocess_views(const GsParams* views, int V, const GsGeom* geoms
                             GsPreOut{geoms[i].rec0, geoms[i].tiles, geoms[i].rect, geoms[i].key[0], geoms[i].clamped, radii[i]}};
     }
     const int T = 128;
-    hipLaunchKernelGGL(k_preprocess_views, dim3(c3d_cdiv(views[0].N, T)), dim3(T), T * SH_ROW * sizeof(float), s, views[0], pv, means3D, f_dc, f_rest,
-                       opacity_raw, scaling_raw, rotation_raw);
+    if (pre_sh_regs())
+        hipLaunchKernelGGL(k_preprocess_views_r, dim3(c3d_cdiv(views[0].N, T)), dim3(T), 0, s, views[0], pv, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw);
+    else
+        hipLaunchKernelGGL(k_preprocess_views, dim3(c3d_cdiv(views[0].N, T)), dim3(T), T * SH_ROW * sizeof(float), s, views[0], pv, means3D, f_dc, f_rest,
+                           opacity_raw, scaling_raw, rotation_raw);
     C3D_LAUNCH_CHECK();
     return 0;
 }
