@@ -33,6 +33,14 @@ class GsLoss(C.Structure):
     _fields_ = [("w_l1", f32), ("w_l2", f32), ("w_alpha_mse", f32), ("scale", f32), ("w_ssim", f32)]
 
 
+class AdamTensor(C.Structure):
+    """struct c3d_adam_tensor (include/c3d_optim.h)"""
+    _fields_ = [("param", vp), ("grad", vp), ("exp_avg", vp), ("exp_avg_sq", vp), ("n", i64), ("step", i64),
+                ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double)]
+
+
+ADAM_MAX_TENSORS = 16      # C3D_ADAM_MAX_TENSORS
+
 _SIGNATURES = {
     # name: (restype, argtypes)
     "c3d_last_error": (C.c_char_p, []),
@@ -56,6 +64,7 @@ _SIGNATURES = {
     "c3d_gs_mark_visible": (C.c_int, [i32, vp, vp, vp, vp, vp]),
     "c3d_gs_debug_state": (C.c_int, [i32, i32, i32, vp, i64, vp] + [vp] * 7 + [vp]),
     "c3d_adam_step": (C.c_int, [vp, vp, vp, vp, i64, C.c_double, C.c_double, C.c_double, C.c_double, i64, vp]),
+    "c3d_adam_step_multi": (C.c_int, [C.POINTER(AdamTensor), i32, vp]),
     "c3d_knn_scratch_bytes": (sz, [i32]),
     "c3d_knn3_mean_dist2": (C.c_int, [vp, i32, C.POINTER(C.c_float), C.POINTER(C.c_float), vp, vp, vp]),
     "c3d_msssim_workspace_bytes": (sz, [i32, i32, i32, i32]),

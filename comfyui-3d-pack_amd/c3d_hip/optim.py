@@ -2,7 +2,8 @@
 
 Drop-in for the `torch.optim.Adam(l, lr=0.0, eps=1e-15)` the reference builds at
 MVs_Algorithms/GaussianSplatting/main_3DGS_renderer.py:449: same param_groups (incl. the "name" keys the LR scheduler and the
-densifier look up), same state keys ("step", "exp_avg", "exp_avg_sq"), same update rule.  One kernel launch per tensor."""
+densifier look up), same state keys ("step", "exp_avg", "exp_avg_sq"), same update rule.  ONE kernel launch for all tensors of a device
+(c3d_adam_step_multi; round 2 issued one per tensor: six launches of ~7 us at the reference's default scene size)."""
 import torch
 
 import c3d_hip as _h
@@ -19,6 +20,7 @@ class FusedAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         lib = _h.lib()
+        per_device = {}          # device -> ([c3d_adam_tensor], [tensors kept alive until the launch])
         for group in self.param_groups:
             b1, b2 = group["betas"]
             for p in group["params"]:
@@ -32,9 +34,15 @@ class FusedAdam(torch.optim.Optimizer):
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 st["step"] += 1
+                if p.numel() == 0:
+                    continue
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                with torch.cuda.device(p.device):
-                    _h.check(lib.c3d_adam_step(_h.ptr(p.data), _h.ptr(g), _h.ptr(st["exp_avg"]), _h.ptr(st["exp_avg_sq"]), p.numel(),
-                                               float(group["lr"]), float(b1), float(b2), float(group["eps"]), int(st["step"]),
-                                               _h.stream(p.device)), "c3d_adam_step")
+                recs, keep = per_device.setdefault(p.device, ([], []))
+                recs.append(_h.AdamTensor(_h.ptr(p.data), _h.ptr(g), _h.ptr(st["exp_avg"]), _h.ptr(st["exp_avg_sq"]), p.numel(), int(st["step"]),
+                                          float(group["lr"]), float(b1), float(b2), float(group["eps"])))
+                keep.append(g)
+        for dev, (recs, keep) in per_device.items():
+            arr = (_h.AdamTensor * len(recs))(*recs)
+            with torch.cuda.device(dev):
+                _h.check(lib.c3d_adam_step_multi(arr, len(recs), _h.stream(dev)), "c3d_adam_step_multi")
         return loss

@@ -646,6 +646,21 @@ def test_fused_adam_matches_torch():
     for p, q in zip(a, b):
         assert torch.allclose(p, q, rtol=2e-5, atol=1e-7), (p - q).abs().max().item()
         assert torch.allclose(oa.state[p]["exp_avg_sq"], ob.state[q]["exp_avg_sq"], rtol=1e-6, atol=1e-12)
+    # the one-launch update of all tensors (c3d_adam_step_multi, what FusedAdam.step issues) has the bits of one c3d_adam_step call per tensor; 20 tensors = two launches
+    import c3d_hip as h
+    lib = h.lib()
+    shapes = [(257, 3), (1001,), (64, 15, 3), (5,)] * 5
+    ps = [torch.randn(s, device="cuda") for s in shapes]
+    gs = [torch.randn(s, device="cuda") for s in shapes]
+    single = [(p.clone(), torch.zeros_like(p), torch.zeros_like(p)) for p in ps]
+    multi = [(p.clone(), torch.zeros_like(p), torch.zeros_like(p)) for p in ps]
+    for step in (1, 2, 3):
+        for i, ((p, m, v), g) in enumerate(zip(single, gs)):
+            h.check(lib.c3d_adam_step(h.ptr(p), h.ptr(g), h.ptr(m), h.ptr(v), p.numel(), 1e-3 * (i + 1), 0.9, 0.999, 1e-15, step, h.stream()), "adam")
+        recs = [h.AdamTensor(h.ptr(p), h.ptr(g), h.ptr(m), h.ptr(v), p.numel(), step, 1e-3 * (i + 1), 0.9, 0.999, 1e-15) for i, ((p, m, v), g) in enumerate(zip(multi, gs))]
+        h.check(lib.c3d_adam_step_multi((h.AdamTensor * len(recs))(*recs), len(recs), h.stream()), "adam multi")
+    for (p, m, v), (q, n_, w) in zip(single, multi):
+        assert torch.equal(p, q) and torch.equal(m, n_) and torch.equal(v, w)
 
 
 def test_renderer_and_trainer_mirror_reduce_the_loss():
