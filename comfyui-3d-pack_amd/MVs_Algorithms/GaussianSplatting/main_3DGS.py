@@ -108,6 +108,7 @@ class GaussianSplatting3D:
         self.cam_controller = GaussianSplattingCameraController(self.renderer, self.ref_size_W, self.ref_size_H,
                                                                 reference_orbit_camera_fovy, self.gs_params.invert_bg_prob, None, self.device)
         self.all_ref_cam_poses = reference_orbit_camera_poses
+        self._ref_cams = {}          # view index -> MiniCam of that reference pose (fused step): the poses are fixed for the run
         H, W = self.ref_size_H, self.ref_size_W
         self.ref_imgs_torch = torch.cat([_fit(im.unsqueeze(0), H, W, self.device) for im in reference_images], dim=0)            # [V,3,H,W]
         self.ref_masks_torch = torch.cat([_fit(m.unsqueeze(2).unsqueeze(0), H, W, self.device) for m in reference_masks], dim=0)  # [V,1,H,W]
@@ -243,9 +244,16 @@ class GaussianSplatting3D:
                 self._step_grads = self._flat_grads.views
         views = []
         for i in mine:
-            radius, elev, azim, cx, cy, cz = self.all_ref_cam_poses[i]
-            cam = MiniCam(orbit_camera(elev, azim, radius, target=np.array([cx, cy, cz], dtype=np.float32)), W, H, ctl.cam.fovy, ctl.cam.fovx,
-                          ctl.cam.near, ctl.cam.far, ctl.projection_matrix, device=self.device)
+            # The reference builds a MiniCam per render (camera_utils.py:253-262): three matrices uploaded and one 4x4 product on the device, every iteration, for
+            # a pose that never changes.  At the node's default scene size those six launches are 8 % of an iteration: built once per reference view here.
+            if getattr(self, "_ref_cams", None) is None:
+                self._ref_cams = {}
+            cam = self._ref_cams.get(i)
+            if cam is None:
+                radius, elev, azim, cx, cy, cz = self.all_ref_cam_poses[i]
+                cam = MiniCam(orbit_camera(elev, azim, radius, target=np.array([cx, cy, cz], dtype=np.float32)), W, H, ctl.cam.fovy, ctl.cam.fovx,
+                              ctl.cam.near, ctl.cam.far, ctl.projection_matrix, device=self.device)
+                self._ref_cams[i] = cam
             # the background of this view: one np.random draw per view, in view order, as render_at_pose (camera_utils.py:246-249)
             bg = ctl.static_bg if ctl.static_bg is not None else (ctl.white_bg if np.random.rand() > ctl.invert_bg_prob else ctl.black_bg)
             views.append(GaussianRasterizationSettings(H, W, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), bg, 1.0,
