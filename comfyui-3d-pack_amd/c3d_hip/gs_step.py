@@ -23,8 +23,9 @@ class FusedViewStep:
         self.lanes = max(1, min(8, int(lanes)))
         self.views = max(1, int(views))
         self.capacity = int(pair_capacity or max(8 * N, 1 << 22))
-        self.status = torch.zeros(2, dtype=torch.int32, device=self.device)
-        self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self._words = torch.zeros(4, dtype=torch.int32, device=self.device)      # status words and the loss value side by side: ONE fill per step clears both
+        self.status = self._words[0:2]
+        self.loss = self._words[2:3].view(torch.float32)
         self._fitted = False
         self._chunks_went_out = False
         self._fwd = None
@@ -102,7 +103,7 @@ class FusedViewStep:
             loss = _h.GsLoss(float(w_l1), float(w_l2), float(w_alpha_mse), float(scale), float(w_ssim))
             if accumulate:
                 snapshot = [g.clone() for g in grads] if attempt == 0 else snapshot     # to redo the step after an overflow
-            self.status.zero_(); self.loss.zero_()
+            self._words.zero_()
             t_host = time.perf_counter()
             if self.time_events:
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
