@@ -34,6 +34,10 @@ for _p in (ROOT, os.path.join(ROOT, "comfyui-3d-pack_amd")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# kernel arguments in device memory: a ROCm runtime switch, read when the runtime initialises.  Every line of this bench is a chain of dependent launches; with it
+# the dispatch of each is ~2 us shorter: 8-view step 5.99 -> 5.90 ms, mesh step 1.81 -> 1.77 ms, the node-default training run 1299 -> 1435 it/s (same box,
+# profiles/r03/r03u_kernarg.txt).  c3d_hip sets the same default for every user of the package; an explicit HIP_FORCE_DEV_KERNARG=0 in the environment wins.
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 import numpy as np
 import torch
