@@ -288,7 +288,7 @@ class FusedViewRender:
         self._alloc()
 
     def _alloc(self):
-        nbytes = _h.lib().c3d_gs_step_workspace_bytes(self.N, self.H, self.W, self.capacity, 2 * self.lanes)     # two slice sets: see c3d_gs_render_views_raw
+        nbytes = _h.lib().c3d_gs_render_workspace_bytes(self.N, self.H, self.W, self.capacity, 2 * self.lanes)     # two sets of forward-only slices: see c3d_gs_render_views_raw
         self.workspace = torch.empty((nbytes,), dtype=torch.uint8, device=self.device)
 
     def run(self, raster_settings, params, want_radii=False, max_retries=3):

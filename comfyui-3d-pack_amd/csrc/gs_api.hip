@@ -276,7 +276,9 @@ struct StepWs {
     float* dmeans2D; float* gcol; char* ms_ws; float* tile_loss;
     size_t bytes;
 };
-static void carve_step(char* base, int N, int H, int W, long long cap, StepWs& w) {
+// fwd_only (c3d_gs_render_views_raw: no backward pass will read the slice): the gradient records, their valid bytes, the loss buffers and the MS-SSIM workspace --
+// three quarters of a training slice at the BASELINE size -- are left out
+static void carve_step(char* base, int N, int H, int W, long long cap, StepWs& w, bool fwd_only = false) {
     size_t off = 0;
     auto take = [&](size_t b) { char* p = base ? base + off : nullptr; off += c3d_align(b); return p; };
     const size_t P = (size_t)H * W, n = (size_t)(N > 0 ? N : 1);
@@ -286,13 +288,16 @@ static void carve_step(char* base, int N, int H, int W, long long cap, StepWs& w
     w.geom = take(g.bytes); w.binning = take(b.bytes); w.image = take(im.bytes);
     w.radii = (int*)take(4 * n);
     w.color = (float*)take(12 * P); w.depth = (float*)take(4 * P); w.alpha = (float*)take(4 * P);
-    w.dcolor = (float*)take(12 * P); w.dalpha = (float*)take(4 * P);
-    w.pairgrad = (float*)take(sizeof(float) * GS_PAIR_FLOATS * (size_t)(cap > 0 ? cap : 1));
-    w.pvalid = (uint8_t*)take((size_t)(cap > 0 ? cap : 1));
-    w.dmeans2D = (float*)take(12 * n);
-    w.gcol = (float*)take(12 * n);
-    w.ms_ws = take(c3d_msssim_workspace_bytes(1, 3, H, W));       // MS-SSIM term of the pixel loss (w_ssim != 0)
-    w.tile_loss = (float*)take(4 * (size_t)(((W + C3D_TILE_X - 1) / C3D_TILE_X) * ((H + C3D_TILE_Y - 1) / C3D_TILE_Y) + 2));   // per-tile partial sums of the pixel loss + one slot for the view's MS-SSIM term + one for the view's sum
+    w.dcolor = w.dalpha = w.pairgrad = w.dmeans2D = w.gcol = w.tile_loss = nullptr; w.pvalid = nullptr; w.ms_ws = nullptr;
+    if (!fwd_only) {
+        w.dcolor = (float*)take(12 * P); w.dalpha = (float*)take(4 * P);
+        w.pairgrad = (float*)take(sizeof(float) * GS_PAIR_FLOATS * (size_t)(cap > 0 ? cap : 1));
+        w.pvalid = (uint8_t*)take((size_t)(cap > 0 ? cap : 1));
+        w.dmeans2D = (float*)take(12 * n);
+        w.gcol = (float*)take(12 * n);
+        w.ms_ws = take(c3d_msssim_workspace_bytes(1, 3, H, W));       // MS-SSIM term of the pixel loss (w_ssim != 0)
+        w.tile_loss = (float*)take(4 * (size_t)(((W + C3D_TILE_X - 1) / C3D_TILE_X) * ((H + C3D_TILE_Y - 1) / C3D_TILE_Y) + 2));   // per-tile partial sums of the pixel loss + one slot for the view's MS-SSIM term + one for the view's sum
+    }
     w.bytes = off;
 }
 
@@ -512,6 +517,10 @@ size_t c3d_gs_step_workspace_bytes(int32_t N, int32_t H, int32_t W, int64_t pair
     StepWs w; carve_step(nullptr, N, H, W, pair_capacity, w);
     return (size_t)(views > 0 ? views : 1) * w.bytes;
 }
+size_t c3d_gs_render_workspace_bytes(int32_t N, int32_t H, int32_t W, int64_t pair_capacity, int32_t slices) {
+    StepWs w; carve_step(nullptr, N, H, W, pair_capacity, w, true);
+    return (size_t)(slices > 0 ? slices : 1) * w.bytes;
+}
 
 int c3d_gs_train_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, const float* means3D, const float* f_dc, const float* f_rest,
                            const float* opacity_raw, const float* scaling_raw, const float* rotation_raw, const float* const* target_color,
@@ -651,7 +660,8 @@ static int views_forward(const char* who, const c3d_gs_settings* views, int32_t 
     if (!means3D || !f_dc || !f_rest || !opacity_raw || !scaling_raw || !rotation_raw) { c3d_set_error("%s: NULL parameter pointer", who); return -1; }
     if ((uintptr_t)f_rest % 16 || (uintptr_t)rotation_raw % 16) { c3d_set_error("%s: f_rest / rotation tensors must be 16-byte aligned", who); return -1; }
     const uint32_t cap = (uint32_t)pair_capacity;
-    StepWs w0; carve_step(nullptr, N, views[0].image_height, views[0].image_width, pair_capacity, w0);
+    const bool fwd_only = !keep_state;       // c3d_gs_render_views_raw: slices without the backward pass's buffers (c3d_gs_render_workspace_bytes)
+    StepWs w0; carve_step(nullptr, N, views[0].image_height, views[0].image_width, pair_capacity, w0, fwd_only);
     const bool projected = pre_multiview();
     if (projected && keep_state && step_preprocess_all(views, V, N, w0.bytes, workspace, pair_capacity, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, s0)) return -1;
     Lanes ln;
@@ -668,7 +678,7 @@ static int views_forward(const char* who, const c3d_gs_settings* views, int32_t 
         GsParams ps[C3D_MAX_LANES]; GsGeom gs[C3D_MAX_LANES]; int* rd[C3D_MAX_LANES];
         for (int i = 0; i < nv; i++) {
             if (make_params(&views[v0 + i], N, 16, ps[i])) return -1;
-            StepWs w; carve_step((char*)workspace + (size_t)((k & 1) * L + i) * w0.bytes, N, ps[i].H, ps[i].W, pair_capacity, w);
+            StepWs w; carve_step((char*)workspace + (size_t)((k & 1) * L + i) * w0.bytes, N, ps[i].H, ps[i].W, pair_capacity, w, fwd_only);
             gs_carve_geom(w.geom, N, gs[i]);
             rd[i] = (out_radii && out_radii[v0 + i]) ? out_radii[v0 + i] : w.radii;
         }
@@ -693,7 +703,7 @@ static int views_forward(const char* who, const c3d_gs_settings* views, int32_t 
         if (make_params(&views[v], N, 16, p)) { rc_all = -1; break; }
         if (!out_color[v] || !out_alpha[v]) { c3d_set_error("%s: output %d is NULL", who, v); rc_all = -1; break; }
         const int slice = keep_state ? v : (grouped ? (k & 1) * L + lane : lane);
-        StepWs w; carve_step((char*)workspace + (size_t)slice * w0.bytes, N, p.H, p.W, pair_capacity, w);
+        StepWs w; carve_step((char*)workspace + (size_t)slice * w0.bytes, N, p.H, p.W, pair_capacity, w, fwd_only);
         GsGeom g; gs_carve_geom(w.geom, N, g);
         GsBinning b; gs_carve_binning(w.binning, pair_capacity, p.gx * p.gy, b);
         GsImage im; gs_carve_image(w.image, p.W, p.H, im);
@@ -729,7 +739,7 @@ int c3d_gs_render_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, 
                              uint32_t* status, c3d_stream_t stream) {
     if (V > 0 && N > 0 && !out_depth) { c3d_set_error("c3d_gs_render_views_raw: NULL pointer"); return -1; }
     if (V > 0 && N > 0 && views && lanes >= 1 && pair_capacity > 0) {      // the slice count decides the schedule: say what the buffer holds instead of trusting a convention
-        const size_t one = c3d_gs_step_workspace_bytes(N, views[0].image_height, views[0].image_width, pair_capacity, 1);
+        const size_t one = c3d_gs_render_workspace_bytes(N, views[0].image_height, views[0].image_width, pair_capacity, 1);
         const int L = lanes < V ? lanes : V;
         if (workspace_bytes < (int64_t)(one * (size_t)L)) { c3d_set_error("c3d_gs_render_views_raw: workspace of %lld bytes holds fewer than %d slices of %zu bytes", (long long)workspace_bytes, L, one); return -1; }
         const bool two_sets = workspace_bytes >= (int64_t)(one * (size_t)(2 * L));

@@ -163,9 +163,11 @@ int c3d_gs_step_param_backward_range(const c3d_gs_settings* views /* host [V] */
  * orbit-renderer node over GaussianSplattingRenderer.render, main_3DGS_renderer.py:927-936), raw parameters, no host synchronisation,
  * views dealt onto `lanes` streams as above.  HOST arrays of V device pointers: out_color [3,H,W], out_depth [1,H,W], out_alpha [1,H,W];
  * out_radii (array or entries may be NULL) [N] int32.  workspace_bytes says what the workspace holds (ABI 202): with
- * c3d_gs_step_workspace_bytes(N, H, W, pair_capacity, 2 * lanes) bytes -- two slices per lane -- the views go in groups of `lanes`, and while the lanes bin
+ * c3d_gs_render_workspace_bytes(N, H, W, pair_capacity, 2 * lanes) bytes -- two FORWARD-ONLY slices per lane (ABI 301: two fifths of a training slice, no gradient
+ * records / loss buffers; a buffer sized with c3d_gs_step_workspace_bytes is simply larger than needed) -- the views go in groups of `lanes`, and while the lanes bin
  * and composite group k a projection stream already fills the other slice set with groups k + 1 / k + 2 (one pass over the parameters per group instead
  * of one per view); with one slice per lane every view is projected by its own launch; less is an error.  status as for c3d_gs_train_views_raw: on overflow the images of the affected views are incomplete. */
+size_t c3d_gs_render_workspace_bytes(int32_t N, int32_t image_height, int32_t image_width, int64_t pair_capacity, int32_t slices);
 int c3d_gs_render_views_raw(const c3d_gs_settings* views /* host [V] */, int32_t V, int32_t N, const float* means3D, const float* f_dc,
                             const float* f_rest, const float* opacity_raw, const float* scaling_raw, const float* rotation_raw,
                             float* const* out_color, float* const* out_depth, float* const* out_alpha, int32_t* const* out_radii,
