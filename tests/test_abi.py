@@ -60,6 +60,12 @@ def test_state_buffer_sizes_are_host_callable():
     assert n2 > n1 >= 1000 * 40
     assert lib.c3d_gs_image_bytes(1080, 1920) >= 1080 * 1920 * 8
     assert lib.c3d_gs_binning_bytes(10 ** 6, 1080, 1920) >= 16 * 10 ** 6
+    # a forward-only slice (c3d_gs_render_views_raw) leaves out the backward pass's buffers: well under half of a training slice at the BASELINE size, and linear in the slice count
+    step = lib.c3d_gs_step_workspace_bytes(10 ** 6, 1080, 1920, 5 * 10 ** 6, 1)
+    fwd = lib.c3d_gs_render_workspace_bytes(10 ** 6, 1080, 1920, 5 * 10 ** 6, 1)
+    assert 0 < fwd < 0.5 * step and lib.c3d_gs_render_workspace_bytes(10 ** 6, 1080, 1920, 5 * 10 ** 6, 16) == 16 * fwd
+    # mesh: the single-view backward scratch holds the two integer planes of the texel gradient, the multi-view step one pair for all lanes
+    assert lib.c3d_mesh_view_bwd_scratch_bytes(1000, 2000, 256, 256, 512, 512) - lib.c3d_mesh_view_bwd_scratch_bytes(1000, 2000, 256, 256, 0, 0) >= 2 * 8 * 3 * 512 * 512
 
 
 def test_python_boundary_names():
