@@ -180,6 +180,7 @@ def _build_cpu_trainer(group, exchange):
 
 
 VIEWS = [[s % 4, (s + 2) % 4] for s in range(10)]
+VIEWS4 = [[(s + i) % 4 for i in range(4)] for s in range(10)]      # world 4: a global batch of four views, one per rank
 
 
 def _snap(t):
@@ -197,7 +198,7 @@ def _rank_worker(rank, world, port, exchange, out):
     np.random.seed(7); torch.manual_seed(7)
     t = _build_cpu_trainer(dist.group.WORLD, exchange)
     early = None
-    for s, v in enumerate(VIEWS):
+    for s, v in enumerate(VIEWS4 if world == 4 else VIEWS):
         t.training_step(s, v)
         if s == 5:
             early = _snap(t)
@@ -224,6 +225,33 @@ def test_two_gloo_ranks_train_like_one_process_and_stay_identical(exchange):
     t = _build_cpu_trainer(None, exchange)
     for s in range(6):
         t.training_step(s, VIEWS[s])
+    for a, b in zip(_snap(t), e0):
+        assert a.shape == b.shape
+        torch.testing.assert_close(a, b, rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("exchange", ["allreduce", "zero1"])
+def test_four_gloo_ranks_train_like_one_process_and_stay_identical(exchange):
+    """The same at world 4 (nothing beyond two ranks was exercised at trainer level): a global batch of four views, one per rank; all-reduce (ring over
+    four ranks) and ZeRO-1 (four parameter segments).  Replicas bit-identical through densification, and equal to the single-process run of the same global batch up
+    to the first densification."""
+    import torch.multiprocessing as mp
+    world, port = 4, _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_rank_worker, args=(world, port, exchange, out), nprocs=world, join=True)
+    e0, f0, n0 = out[0]
+    assert n0 > 160
+    for r in range(1, world):
+        er, fr, nr = out[r]
+        assert nr == n0
+        for a, b in zip(f0, fr):
+            assert torch.equal(a, b)
+        for a, b in zip(e0, er):
+            assert torch.equal(a, b)
+    np.random.seed(7); torch.manual_seed(7)
+    t = _build_cpu_trainer(None, exchange)
+    for s in range(6):
+        t.training_step(s, VIEWS4[s])
     for a, b in zip(_snap(t), e0):
         assert a.shape == b.shape
         torch.testing.assert_close(a, b, rtol=2e-5, atol=2e-6)
