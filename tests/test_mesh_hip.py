@@ -446,6 +446,34 @@ def test_fused_mesh_step_is_bit_reproducible_and_equals_the_scattering_kernels()
         assert rel_err(runs[0]["d_ra"], other["d_ra"]) <= 2e-5 and rel_err(runs[0]["d_vo"], other["d_vo"]) <= 2e-5
 
 
+def test_fused_mesh_step_is_bit_reproducible_at_config5_size():
+    """The same at BASELINE config 5's size (499 k triangles, 1024^2 texture, 1024 x 1024, eight views, MSE + MS-SSIM): two runs on four lanes and one on two lanes
+    give the same bits for the loss, the 3 M texel gradients and the 250 k vertex gradients -- with ~4 M integer atomics per view landing in one pair of planes."""
+    from c3d_hip.mesh_step import FusedMeshStep
+    from shared_utils.camera_utils import OrbitCamera, orbit_camera
+    import nvdiffrast.torch as dr
+    H = W = 1024
+    v, f, vt, _ = S.make_uv_sphere(500, 500, radius=0.7, displacement=0.05)
+    g = torch.Generator(device="cpu").manual_seed(7)
+    raw = torch.randn((1024, 1024, 3), generator=g).cuda()
+    tv, tf, tvt = T(v), T(f, torch.int32), T(vt)
+    off = (torch.randn(tuple(tv.shape), generator=g) * 1e-4).cuda()
+    cam = OrbitCamera(W, H, fovy=49.1)
+    proj = cam.perspective.astype(np.float32)
+    views = [((proj @ np.linalg.inv(orbit_camera(e, az, 2.0).astype(np.float32)).astype(np.float32)).astype(np.float32), (1.0, 1.0, 1.0)) for e in (-20.0, 20.0) for az in (0.0, 90.0, 180.0, 270.0)]
+    targets = [torch.rand((3, H, W), generator=g).cuda() for _ in views]
+    glctx = dr.RasterizeCudaContext()
+    outs = []
+    for lanes in (4, 4, 2):
+        st = FusedMeshStep("cuda", lanes=lanes)
+        d_ra, d_vo = torch.empty_like(raw), torch.empty_like(off)
+        loss = st.run(views, tv, off, tf, tvt, tf, raw, glctx, targets, None, d_ra, d_vo, H, W, w_mse=0.7, w_ssim=0.3, scale=1.0 / len(views)).clone()
+        outs.append((loss, d_ra.clone(), d_vo.clone()))
+    assert float(outs[0][1].abs().max()) > 0 and float(outs[0][2].abs().max()) > 0 and bool(torch.isfinite(outs[0][0]).all())
+    for o in outs[1:]:
+        assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1]) and torch.equal(o[2], outs[0][2])
+
+
 def test_fused_mesh_step_accumulate_lanes_and_argument_checks():
     """c3d_mesh_train_views through FusedMeshStep: accumulate=True adds to the gradient buffers, the result does not depend on the number of view
     lanes, a rank without views leaves zero gradients, and bad arguments are refused with a message (NULL pointers, the MS-SSIM term on images that
