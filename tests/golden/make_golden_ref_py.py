@@ -183,6 +183,14 @@ def generate():
     out["lr_delayed"] = np.array([f2(int(t)) for t in steps], np.float64)
     out["lr_constant"] = np.array([f3(int(t)) for t in steps], np.float64)
     out.update(densify_case(ren, rng))
+    # ---- degree 4 of eval_sh (the reference's host function goes to 4, sh_utils.py:101-111; the rasterizer stops at 3).  Its own generator: the entries above keep
+    # their values
+    rng4 = np.random.default_rng(2025)
+    coef4 = rng4.normal(size=(48, 3, 25)).astype(np.float32)
+    dirs4 = rng4.normal(size=(48, 3)).astype(np.float32)
+    dirs4 /= np.linalg.norm(dirs4, axis=1, keepdims=True)
+    out["sh4_coef"], out["sh4_dirs"] = coef4, dirs4
+    out["sh_eval_deg4"] = sh.eval_sh(4, torch.from_numpy(coef4), torch.from_numpy(dirs4)).numpy()
     return {k: np.asarray(v) for k, v in out.items()}
 
 

@@ -44,6 +44,9 @@ def test_sh_helpers_match_reference(g):
         got = SH.eval_sh(deg, coef[..., :K], dirs).numpy()
         assert np.abs(got - g["sh_eval_deg%d" % deg]).max() <= 2e-6, deg
         assert np.abs(SH.eval_sh(deg, coef, dirs).numpy() - g["sh_eval_deg%d" % deg]).max() <= 2e-6          # surplus coefficients are ignored
+    # degree 4: the reference's host function goes that far (sh_utils.py:101-111); the rasterizer kernels stop at 3
+    got4 = SH.eval_sh(4, torch.from_numpy(g["sh4_coef"]), torch.from_numpy(g["sh4_dirs"])).numpy()
+    assert np.abs(got4 - g["sh_eval_deg4"]).max() <= 5e-6
     np.testing.assert_allclose(SH.RGB2SH(torch.from_numpy(g["rgb"])).numpy(), g["rgb2sh"], atol=1e-6)
     np.testing.assert_allclose(SH.SH2RGB(torch.from_numpy(g["rgb"])).numpy(), g["sh2rgb"], atol=1e-6)
     with pytest.raises(ValueError):
