@@ -63,8 +63,9 @@ def parse():
     ap.add_argument("--exchange-chunks", type=int, default=4,
                     help="N > 1, --exchange allreduce: Gaussian ranges of the per-Gaussian backward pass, each range's collective overlapping the next range's kernels (1 = one all-reduce after the step)")
     ap.add_argument("--timed-prof", choices=["on", "off"], default="on", help="HIP-event kernel timing inside the timed region")
-    ap.add_argument("--lanes", type=int, default=0, help="HIP streams the views of a step are dealt onto (fused step path); 0 = the library's defaults: 4 with a backward pass "
-                                                       "(more lanes only evict each other's compositing kernels), 8 forward-only (the chain is mostly latency: +2.5 %% over 4)")
+    ap.add_argument("--lanes", type=int, default=0, help="view GROUPS in flight (HIP streams) on the fused step path; 0 = the defaults: 1 with a backward pass (all views of the step go through "
+                                                       "every stage of the chain in ONE launch each), 2 forward-only (one group's binning stages run underneath the other's compositing)")
+    ap.add_argument("--group", type=int, default=8, help="--mode fwd: views per launch of every stage (<= 16)")
     ap.add_argument("--render-path", choices=["step", "fused", "accessor", "boundary"], default="step",
                     help="step: c3d_gs_train_views_raw, all views of the step forward+loss+backward in one sync-free library call (product default for training); fused: GaussianSplattingRenderer.render with activations folded into the kernels (product default); accessor: the same "
                          "API through the reference's op-by-op accessors; boundary: bare diff_gaussian_rasterization call on pre-activated leaves")
@@ -169,7 +170,7 @@ def main_ref_default(a, world, rank, dev, dist):
         rs.append(dgr.GaussianRasterizationSettings(R, R, st["tanfovx"], st["tanfovy"], t(st["bg"]), 1.0, t(st["viewmatrix"]).reshape(4, 4), t(st["projmatrix"]).reshape(4, 4), 3, t(st["campos"]), False, False))
     tp = [t(tgt["means3D"]), t(tgt["shs"][:, :1]), t(tgt["shs"][:, 1:]), t(tgt["opacities"]), t(tgt["scales"]), t(tgt["rotations"])]
     with torch.no_grad():
-        color, _, alpha, _ = FusedViewRender(100_000, R, R, dev, lanes=4).run(rs, tp)
+        color, _, alpha, _ = FusedViewRender(100_000, R, R, dev, lanes=1, group=4).run(rs, tp)
     refs = [color[i].clamp(0, 1).permute(1, 2, 0).contiguous() for i in range(len(poses))]          # node layout: [H, W, 3]
     masks = [(alpha[i, 0] > 0.5).float() for i in range(len(poses))]
     gp = GSParams()                                                # every default of the node
@@ -409,7 +410,7 @@ def main():
     import diff_gaussian_rasterization as dgr
 
     if a.lanes <= 0:
-        a.lanes = 8 if a.mode == "fwd" else 4
+        a.lanes = 2 if a.mode == "fwd" else 1
     N, W, H, deg = a.gaussians, a.width, a.height, a.sh_degree
     K, P = (deg + 1) ** 2, a.width * a.height
     use_renderer = a.render_path != "boundary"
@@ -499,7 +500,7 @@ def main():
     view_render = None
     if a.render_path == "step" and a.mode == "fwd":
         from c3d_hip.gs_step import FusedViewRender
-        view_render = FusedViewRender(N, H, W, dev, lanes=a.lanes)     # all views of the step in one library call
+        view_render = FusedViewRender(N, H, W, dev, lanes=a.lanes, group=a.group)     # all views of the step in one library call
 
     def step(collect=False):
         nonlocal fused_step, view_render
@@ -608,7 +609,7 @@ def main():
             keep_obj, fused_step = fused_step, FusedViewStep(N, H, W, dev, lanes=1, pair_capacity=fused_step.capacity, views=len(settings))
             fused_step._fitted = True
         else:
-            keep_obj, view_render = view_render, FusedViewRender(N, H, W, dev, lanes=1, pair_capacity=view_render.capacity)
+            keep_obj, view_render = view_render, FusedViewRender(N, H, W, dev, lanes=1, group=a.group, pair_capacity=view_render.capacity)
             view_render._fitted = True
         step()
         sync()
@@ -766,7 +767,7 @@ def main():
                 st = S.camera_settings(W, H, 49.1, e_, az_, r_, bg=(1.0, 1.0, 1.0), sh_degree=deg)
                 all_settings.append(dgr.GaussianRasterizationSettings(H, W, st["tanfovx"], st["tanfovy"], t(st["bg"]), 1.0, t(st["viewmatrix"]).reshape(4, 4),
                                                                       t(st["projmatrix"]).reshape(4, 4), deg, t(st["campos"]), False, False))
-            vr = FusedViewRender(N, H, W, dev, lanes=8)
+            vr = FusedViewRender(N, H, W, dev, lanes=2, group=8)
             pl_ = [q.detach() for q in plist]
             with torch.no_grad():
                 vr.run(all_settings, pl_); vr.run(all_settings, pl_)          # capacity fit + warm-up

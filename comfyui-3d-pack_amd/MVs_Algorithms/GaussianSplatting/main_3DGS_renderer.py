@@ -492,9 +492,9 @@ class GaussianSplattingRenderer:
         else:
             raise TypeError("initialize(): pass None, a GS PlyData, a PointCloud, a Mesh or a dict of raw tensors (the UV-grid initialiser is not built)")
 
-    def render_views(self, viewpoint_cameras, bg_colors=None, scaling_modifier=1.0, lanes=8):
-        """Inference-only batch of render(): all cameras in ONE library call (c3d_gs_render_views_raw; views dealt onto `lanes` HIP
-        streams, no host synchronisation between views).  Same per-view results as render() -- the orbit-renderer loop of the reference's
+    def render_views(self, viewpoint_cameras, bg_colors=None, scaling_modifier=1.0, lanes=2, group=8):
+        """Inference-only batch of render(): all cameras in ONE library call (c3d_gs_render_views_raw; `group` views per launch of every stage,
+        `lanes` groups in flight, no host synchronisation between views).  Same per-view results as render() -- the orbit-renderer loop of the reference's
         nodes without its per-view launch gaps.  bg_colors: None, one [3] tensor or one per camera.
         -> dict(image [V,3,H,W] clamped, depth [V,1,H,W], alpha [V,1,H,W], radii [V,N], visibility_filter [V,N])"""
         from diff_gaussian_rasterization import GaussianRasterizationSettings
@@ -509,9 +509,9 @@ class GaussianSplattingRenderer:
         settings = [GaussianRasterizationSettings(H, W, math.tan(c.FoVx * 0.5), math.tan(c.FoVy * 0.5), bg, scaling_modifier, c.world_view_transform,
                                                   c.full_proj_transform, g.active_sh_degree, c.camera_center, False, False)
                     for c, bg in zip(viewpoint_cameras, bg_colors)]
-        key = (g._xyz.shape[0], H, W, int(lanes))
+        key = (g._xyz.shape[0], H, W, int(lanes), int(group))
         if getattr(self, "_view_render_key", None) != key:
-            self._view_render, self._view_render_key = FusedViewRender(key[0], H, W, self.device, lanes=lanes), key
+            self._view_render, self._view_render_key = FusedViewRender(key[0], H, W, self.device, lanes=lanes, group=group), key
         with torch.no_grad():
             color, depth, alpha, radii = self._view_render.run(settings, [g._xyz, g._features_dc, g._features_rest, g._opacity, g._scaling, g._rotation], want_radii=True)
             return {"image": color.clamp_(0, 1), "depth": depth, "alpha": alpha, "radii": radii, "visibility_filter": radii > 0}

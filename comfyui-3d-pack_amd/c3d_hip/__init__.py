@@ -8,9 +8,8 @@ import ctypes as C
 import os
 import threading
 
-# Kernel arguments in device memory (ROCm runtime switch, read when the runtime initialises -- so before torch touches the device): every call into this library is a
-# chain of small dependent launches, and each dispatch gets ~2 us shorter (profiles/r03/r03u_kernarg.txt).  An explicit value in the environment wins.
-os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+# The library sets no process-wide runtime switches.  HIP_FORCE_DEV_KERNARG=1 (kernel arguments in device memory: ~2 us off every dependent dispatch,
+# profiles/r03/r03u_kernarg.txt) is a recommendation for the HOST process, documented in INTEGRATION.md; bench.py sets it for itself.
 
 import torch
 
@@ -87,11 +86,10 @@ _SIGNATURES = {
     "c3d_test_scan_u32": (C.c_int, [vp, vp, i64, i32, vp]),
     "c3d_test_sort_pairs_u32": (C.c_int, [vp, vp, i64, i32, vp]),
     "c3d_test_sort_phases": (C.c_int, [vp]),
-    "c3d_test_segment_sort_u32": (C.c_int, [vp, i32, vp, vp, i64, vp]),
 }
 
 
-ABI_VERSION = 301      # c3d_version() of the library these signatures describe
+ABI_VERSION = 400      # c3d_version() of the library these signatures describe
 
 
 def exported_symbols():

@@ -25,11 +25,24 @@ void c3d_set_error(const char* fmt, ...);
 static inline size_t c3d_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 static inline int c3d_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
-// ---- view lanes (gs_api.hip): library-owned HIP streams forked from / joined into the caller's stream; shared by the 3DGS and the mesh multi-view steps ----
+// ---- view lanes (lanes.hip): library-owned HIP streams forked from / joined into the caller's stream; shared by the 3DGS and the mesh multi-view steps ----
+// A call that wants to run independent chains side by side forks up to C3D_MAX_LANES streams from the caller's stream (lane 0 IS the caller's stream) and joins
+// them back before it returns, so the call keeps stream semantics.  The pool (streams + events, per device) belongs to ONE call at a time: fork() takes the
+// pool's mutex and join() -- or the destructor, on any early return -- joins the streams and releases it.  fork and join must run on the same host thread
+// (std::mutex); two host threads driving one device take turns.  With lanes == 1 nothing is forked and nothing is locked.
 #define C3D_MAX_LANES 8
-// streams[0] = caller; returns the number of lanes L = min(lanes, n_views) through *L, or -1
-int c3d_lanes_fork(hipStream_t caller, int lanes, int n_views, hipStream_t* streams, int* L);
-int c3d_lanes_join(hipStream_t caller, const hipStream_t* streams, int L, const char* who);   // always call after a fork, also on error paths
+struct C3dLanes {
+    int L = 1;                              // lanes in use after fork(): min(lanes, n_chains)
+    hipStream_t s[C3D_MAX_LANES] = {};      // s[0] = the caller's stream
+    int fork(hipStream_t caller, int lanes, int n_chains);       // 0 on success
+    int join(const char* who);                                   // idempotent; 0 on success
+    ~C3dLanes() { (void)join("c3d"); }
+    C3dLanes() = default;
+    C3dLanes(const C3dLanes&) = delete;
+    C3dLanes& operator=(const C3dLanes&) = delete;
+private:
+    void* pool_ = nullptr;                  // the device's pool while this object holds its mutex
+};
 
 // ---- optional event timing (prof.hip) ----
 #define C3D_PROF_SLOTS 21
@@ -47,38 +60,44 @@ struct C3dProfScope {
 
 // ---- scan / sort primitives (scan_sort.hip) ----
 // Single-pass (decoupled look-back) kernels.  Each primitive keeps a small state block at the head of `tmp` that must be zero when
-// its kernels start: with zero_state = true (default) the call issues the hipMemsetAsync itself; a caller that runs several
-// primitives of one view clears all their state blocks with ONE memset and passes false.
+// its kernels start: with zero_state = true (default, one view only) the call issues the hipMemsetAsync itself; a caller that runs several
+// primitives of one view -- or of V views -- clears all their state blocks with ONE launch (c3d_zero_views) and passes false.
 // A timed-out inter-workgroup wait (every spin is bounded) ORs C3D_ERR_LOOKBACK into `err` (device; nullptr: the primitive's own error word).
+// V / vs: the launch covers V views (blockIdx.y); every pointer is that of view 0 and view v's lies v * vs bytes behind it (workspace
+// slices at a uniform stride).  `err`, `tail_status` are shared by the views.
 #define C3D_ERR_LOOKBACK 2u
 // Inclusive or exclusive prefix sum of n uint32 values. `tmp` needs c3d_scan_tmp_bytes(n).
 size_t c3d_scan_tmp_bytes(size_t n);
 int c3d_scan_u32(const uint32_t* in, uint32_t* out, size_t n, bool exclusive, void* tmp, hipStream_t s, bool zero_state = true, uint32_t* err = nullptr);
-// the same over in[idx[i]] (gather folded into the load).  tail_meta (optional, device): receives min(total, tail_cap) in [0];
-// tail_status (optional): [0] |= 1 when total > tail_cap, [1] = max(total).
-int c3d_scan_gather_u32(const uint32_t* in, const uint32_t* idx, uint32_t* out, size_t n, bool exclusive, void* tmp, hipStream_t s, bool zero_state,
-                        uint32_t* tail_meta, uint32_t* tail_status, uint32_t tail_cap, uint32_t* err = nullptr);
+// inclusive scan of the areas of the tile rects rect[idx[i]] ({x0 | y0 << 16, x1 | y1 << 16}; the gather is folded into the load) -> out; the gathered rects are left
+// in rsort[i].  tail_meta (optional, device): receives min(total, tail_cap) in [0]; tail_status (optional): [0] |= 1 when total > tail_cap, [1] = max(total).
+int c3d_scan_rect_gather(const uint2* rect, const uint32_t* idx, uint32_t* out, uint2* rsort, size_t n, void* tmp, hipStream_t s, bool zero_state,
+                         uint32_t* tail_meta, uint32_t* tail_status, uint32_t tail_cap, uint32_t* err = nullptr, int V = 1, size_t vs = 0);
+// exclusive scan of `in` -> out, plus einfo[i] = {0, rect[i].x, rect[i].y, out[i]} where in[i] != 0 (coalesced epilogue)
 int c3d_scan_u32_einfo(const uint32_t* in, uint32_t* out, size_t n, void* tmp, hipStream_t s, bool zero_state, uint32_t* err, const uint2* rect, uint4* einfo,
-                       uint32_t* tail_meta = nullptr, uint32_t* tail_status = nullptr, uint32_t tail_cap = 0xFFFFFFFFu);   // tail_*: the grand total, as c3d_scan_gather_u32 leaves it
-// every segment [ranges[t].x, ranges[t].y) of vals reordered by key_table[val], ascending, stable; vbuf1: scratch as long as vals
-int c3d_segment_sort_u32(const uint2* ranges, int nseg, const uint32_t* key_table, uint32_t* vals, uint32_t* vbuf1, hipStream_t s);
+                       int V = 1, size_t vs = 0);
 uint32_t* c3d_scan_error_word(void* tmp);
+// up to three byte regions (off[r], bytes[r]: 16-byte aligned, multiples of 4) cleared in each of V slices, one launch
+int c3d_zero_views(void* base0, size_t vs, int V, const size_t* off, const size_t* bytes, int regions, hipStream_t s);
 
 // Stable LSD radix sort of (key,val) uint32 pairs over key bits [0, end_bit), n < 2^30.
 // keys/vals are ping-pong buffers [2][n]; result index (0 or 1) is returned through *result_buf.
 // iota_vals => the values are the element indices (vals0 is not read).  tmp: c3d_sort_tmp_bytes(n); the part that must be zero is
 // the first c3d_sort_state_bytes(n, end_bit) bytes.
-// n_dev (optional, device): the real element count is min(*n_dev, n) -- n is then the capacity the launch is sized for, so a
+// n_dev (optional, device, per view): the real element count is min(*n_dev, n) -- n is then the capacity the launch is sized for, so a
 // data-dependent count never has to come back to the host.
 size_t c3d_sort_tmp_bytes(size_t n);
 size_t c3d_sort_state_bytes(size_t n, int end_bit);
 uint32_t* c3d_sort_error_word(void* tmp);
-int c3d_sort_set_debug(unsigned long long* stamps);   // profiling hook (nullptr = off): [pass][tile][8] wall_clock64 stamps
+int c3d_sort_set_debug(unsigned long long* stamps);   // profiling hook (nullptr = off): [pass][tile][8] wall_clock64 stamps (single-view sorts)
 int c3d_sort_pairs_u32(uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32_t* vals1, bool iota_vals,
-                       size_t n, int end_bit, void* tmp, int* result_buf, hipStream_t s, const uint32_t* n_dev = nullptr, bool zero_state = true, uint32_t* err = nullptr);
+                       size_t n, int end_bit, void* tmp, int* result_buf, hipStream_t s, const uint32_t* n_dev = nullptr, bool zero_state = true, uint32_t* err = nullptr,
+                       int V = 1, size_t vs = 0);
 
 // ---- device helpers ----
 #ifdef __HIPCC__
+// multi-view launches: blockIdx.y = view; per-view pointers are given for view 0 and view v's lies v * vs bytes behind it (NULL stays NULL)
+template <class T> __device__ __forceinline__ T* c3d_view_ptr(T* p, size_t vs) { return p ? (T*)((char*)p + (size_t)blockIdx.y * vs) : p; }
 __device__ __forceinline__ int c3d_lane() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
 // wave-wide inclusive scan (64 lanes) of a uint32

@@ -2,7 +2,6 @@
 #include "../../include/c3d_gs.h"
 #include "../../include/c3d_loss.h"
 #include "gs_internal.h"
-#include <mutex>
 #include <stdarg.h>
 #include <stdio.h>
 
@@ -56,55 +55,44 @@ static int check_inputs(int N, int M, int deg, const float* means3D, const float
 }
 
 // A2-A4' shared by every forward entry point: record bases (scan in Gaussian-id order), depth sort, emit offsets (scan in depth-rank
-// order, gather folded in).  Three single-pass primitives, their state cleared by ONE memset; 7 launches where round 1 issued 21.
+// order, gather folded in).  Three single-pass primitives whose state is cleared by ONE memset (one view) or by the caller's c3d_zero_views
+// (`cleared`, V views).  V / vs: the chain of V views in one launch per stage (g = view 0's state, view v's lies v * vs bytes behind).
 // cap / status: pair capacity and status words of the sync-free paths (the pair count then stays on the device in g.meta[0]).
-// C3D_BIN_LOCAL = 0 (default): global depth sort of the Gaussians, second scan in depth-rank order, rank-ordered emission, tile sort, ranges.
-// 1 (round 3, built and measured): ONE scan (record bases = emission offsets in Gaussian-id order), emission in id order, tile sort, ranges, then the depth order
-// per tile (c3d_segment_sort_u32) -- the same lists bit for bit, five latency-bound launches fewer per view.  It loses: ordering AFTER duplication sorts 4.0 M
-// (tile, splat) pairs instead of 1.0 M Gaussians, and the ballot ranking costs ~1 VALU instruction per element and pass -- throughput-bound work (0.10 ms per view)
-// in exchange for latency-bound work (0.13 + 0.025 ms) that the view lanes were hiding anyway: 5.94 vs 5.88 ms per step (profiles/r03/r03g_*).
-static bool gs_bin_local() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("C3D_BIN_LOCAL"); v = e ? atoi(e) != 0 : 0; }
-    return v != 0;
-}
-static int binning_front(GsGeom& g, int N, uint32_t cap, uint32_t* status, hipStream_t s) {
+static int binning_front(GsGeom& g, int N, uint32_t cap, uint32_t* status, hipStream_t s, int V = 1, size_t vs = 0, bool cleared = false) {
     int rc, res = 0;
-    C3D_CHECK(hipMemsetAsync(g.meta, 0, g.zero_bytes, s));
-    uint32_t* err = status ? status : (uint32_t*)g.meta + 2;      // a timed-out look-back (bounded spins) surfaces as C3D_ERR_LOOKBACK
-    if (gs_bin_local()) {
-        C3dProfScope ps(C3D_P_SCAN, s);
-        return c3d_scan_u32_einfo(g.tiles, g.rbase, (size_t)N, g.tmp_scan_a, s, false, err, g.rect, g.einfo, (uint32_t*)g.meta, status, cap);
+    if (!cleared) {
+        if (V != 1) { c3d_set_error("internal: a multi-view binning chain needs its state cleared by the caller"); return -2; }
+        C3D_CHECK(hipMemsetAsync(g.meta, 0, g.zero_bytes, s));
     }
+    uint32_t* err = status ? status : (uint32_t*)g.meta + 2;      // a timed-out look-back (bounded spins) surfaces as C3D_ERR_LOOKBACK
     { C3dProfScope ps(C3D_P_SCAN, s);
-      if ((rc = c3d_scan_u32_einfo(g.tiles, g.rbase, (size_t)N, g.tmp_scan_a, s, false, err, g.rect, g.einfo))) return rc; }
+      if ((rc = c3d_scan_u32_einfo(g.tiles, g.rbase, (size_t)N, g.tmp_scan_a, s, false, err, g.rect, g.einfo, V, vs))) return rc; }
     { C3dProfScope ps(C3D_P_DEPTH_SORT, s);
-      if ((rc = c3d_sort_pairs_u32(g.key[0], g.key[1], g.order[0], g.order[1], true, (size_t)N, 32, g.tmp_sort, &res, s, nullptr, false, err))) return rc; }
+      if ((rc = c3d_sort_pairs_u32(g.key[0], g.key[1], g.order[0], g.order[1], true, (size_t)N, 32, g.tmp_sort, &res, s, nullptr, false, err, V, vs))) return rc; }
     if (res != sort_result_index(32)) { c3d_set_error("internal: depth sort buffer parity"); return -2; }
     { C3dProfScope ps(C3D_P_SCAN, s);
-      if ((rc = c3d_scan_gather_u32(g.tiles, g.order[res], g.offsets, (size_t)N, false, g.tmp_scan_b, s, false, (uint32_t*)g.meta, status, cap, err))) return rc; }
+      if ((rc = c3d_scan_rect_gather(g.rect, g.order[res], g.offsets, g.rsort, (size_t)N, g.tmp_scan_b, s, false, (uint32_t*)g.meta, status, cap, err, V, vs))) return rc; }
     return 0;
 }
-// tile sort + per-tile ranges; D = pair count on the host, or the capacity when d_dev (device count) is given
-static int binning_back(const GsParams& p, GsGeom& g, GsBinning& b, const int* radii, long long D, uint32_t cap, const uint32_t* d_dev, uint32_t* status,
-                        hipStream_t s, int* res_out) {
+// emit + tile sort + per-tile ranges; D = pair count on the host, or the capacity when d_dev (device count, per view) is given
+static int binning_back(const GsParams& p, GsGeom& g, GsBinning& b, long long D, uint32_t cap, const uint32_t* d_dev, uint32_t* status,
+                        hipStream_t s, int* res_out, int V = 1, size_t vs = 0, bool cleared = false) {
     const int tiles = p.gx * p.gy;
     int rc, res = 0;
-    C3D_CHECK(hipMemsetAsync(b.ranges, 0, b.zero_bytes, s));
+    if (!cleared) {
+        if (V != 1) { c3d_set_error("internal: a multi-view binning chain needs its state cleared by the caller"); return -2; }
+        C3D_CHECK(hipMemsetAsync(b.ranges, 0, b.zero_bytes, s));
+    }
     *res_out = 0;
     if (D <= 0) return 0;
     uint32_t* err = status ? status : (uint32_t*)g.meta + 2;
     { C3dProfScope ps(C3D_P_EMIT, s);
-      if ((rc = gs_launch_emit(p, g, gs_bin_local() ? -1 : sort_result_index(32), radii, b, s, cap))) return rc; }
+      if ((rc = gs_launch_emit(p, g, sort_result_index(32), b, s, cap, V, vs))) return rc; }
     { C3dProfScope ps(C3D_P_TILE_SORT, s);
-      if ((rc = c3d_sort_pairs_u32(b.tkey[0], b.tkey[1], b.tval[0], b.tval[1], false, (size_t)D, tile_sort_bits(tiles), b.tmp, &res, s, d_dev, false, err))) return rc; }
+      if ((rc = c3d_sort_pairs_u32(b.tkey[0], b.tkey[1], b.tval[0], b.tval[1], false, (size_t)D, tile_sort_bits(tiles), b.tmp, &res, s, d_dev, false, err, V, vs))) return rc; }
     if (res != sort_result_index(tile_sort_bits(tiles))) { c3d_set_error("internal: tile sort buffer parity"); return -2; }
     { C3dProfScope ps(C3D_P_RANGES, s);
-      if ((rc = gs_launch_ranges(b, res, D, tiles, s, d_dev))) return rc; }
-    if (gs_bin_local()) {      // depth order inside every tile's list (keys: the depth bits k_preprocess left per Gaussian); the idle value buffer is the scratch of long lists
-        C3dProfScope ps(C3D_P_DEPTH_SORT, s);
-        if ((rc = c3d_segment_sort_u32(b.ranges, tiles, g.key[0], b.tval[res], b.tval[res ^ 1], s))) return rc;
-    }
+      if ((rc = gs_launch_ranges(b, res, D, s, d_dev, V, vs))) return rc; }
     *res_out = res;
     return 0;
 }
@@ -124,7 +112,7 @@ static int project_tail(GsGeom& g, int N, int64_t* num_rendered, hipStream_t s) 
 extern "C" {
 
 const char* c3d_last_error(void) { return g_err; }
-int c3d_version(void) { return 301; }
+int c3d_version(void) { return 400; }
 
 size_t c3d_gs_geom_bytes(int32_t N) { GsGeom g; gs_carve_geom(nullptr, N, g); return g.bytes; }
 size_t c3d_gs_binning_bytes(int64_t D, int32_t H, int32_t W) {
@@ -193,9 +181,11 @@ int c3d_gs_forward_render(const c3d_gs_settings* st, int32_t N, int32_t M, const
     gs_carve_image((char*)image_buffer, p.W, p.H, im);
     int rc, res = 0;
     if (num_rendered > 0 && (!geom_buffer || !radii)) { c3d_set_error("c3d_gs_forward_render: NULL geometry"); return -1; }
-    if ((rc = binning_back(p, g, b, radii, num_rendered, 0xFFFFFFFFu, nullptr, nullptr, s, &res))) return rc;
+    if ((rc = binning_back(p, g, b, num_rendered, 0xFFFFFFFFu, nullptr, nullptr, s, &res))) return rc;
     C3dProfScope ps(C3D_P_COMPOSITE_FWD, s);
-    return gs_launch_composite_fwd(p, g, b, res, im, out_color, out_depth, out_alpha, true, s);   // a backward call may follow: record the blended (quadrant, splat) pairs
+    GsFwdViews vp{};
+    vp.bg[0] = p.bg; vp.color[0] = out_color; vp.depth[0] = out_depth; vp.alpha[0] = out_alpha;
+    return gs_launch_composite_fwd(p, g, b, res, im, vp, 1, 0, true, s);   // a backward call may follow: record the blended (quadrant, splat) pairs
 }
 
 int c3d_gs_backward(const c3d_gs_settings* st, int32_t N, int32_t M, const float* means3D, const float* shs,
@@ -230,7 +220,10 @@ int c3d_gs_backward(const c3d_gs_settings* st, int32_t N, int32_t M, const float
         if (!binning_buffer || !image_buffer) { c3d_set_error("c3d_gs_backward: NULL state buffer"); return -1; }
         const int res = sort_result_index(tile_sort_bits(tiles));
         C3dProfScope ps(C3D_P_COMPOSITE_BWD, s);
-        if ((rc = gs_launch_composite_bwd(p, g, b, res, im, dL_dcolor, dL_ddepth, dL_dalpha, pairgrad, pvalid, num_rendered, s))) return rc;
+        C3D_CHECK(hipMemsetAsync(pvalid, 0, (size_t)num_rendered, s));
+        GsBwdPix px{};
+        px.bg[0] = p.bg; px.dcolor[0] = dL_dcolor; px.ddepth[0] = dL_ddepth; px.dalpha[0] = dL_dalpha;
+        if ((rc = gs_launch_composite_bwd(p, g, b, res, im, px, dL_ddepth != nullptr, pairgrad, pvalid, s))) return rc;
     }
     C3dProfScope ps(C3D_P_PREPROCESS_BWD, s);
     return gs_launch_preprocess_bwd(p, g, radii, means3D, shs, colors_precomp, scales, rotations, cov3D_precomp, pairgrad, pvalid, dL_dmeans2D,
@@ -263,7 +256,10 @@ int c3d_gs_backward_raw(const c3d_gs_settings* st, int32_t N, const float* means
         if (!binning_buffer || !image_buffer) { c3d_set_error("c3d_gs_backward_raw: NULL state buffer"); return -1; }
         const int res = sort_result_index(tile_sort_bits(tiles));
         C3dProfScope ps(C3D_P_COMPOSITE_BWD, s);
-        if ((rc = gs_launch_composite_bwd(p, g, b, res, im, dL_dcolor, dL_ddepth, dL_dalpha, pairgrad, pvalid, num_rendered, s))) return rc;
+        C3D_CHECK(hipMemsetAsync(pvalid, 0, (size_t)num_rendered, s));
+        GsBwdPix px{};
+        px.bg[0] = p.bg; px.dcolor[0] = dL_dcolor; px.ddepth[0] = dL_ddepth; px.dalpha[0] = dL_dalpha;
+        if ((rc = gs_launch_composite_bwd(p, g, b, res, im, px, dL_ddepth != nullptr, pairgrad, pvalid, s))) return rc;
     }
     C3dProfScope ps(C3D_P_PREPROCESS_BWD, s);
     return gs_launch_preprocess_bwd_raw(p, g, radii, means3D, f_dc, f_rest, scaling_raw, rotation_raw, pairgrad, pvalid, dL_dmeans2D, dL_dopacity_raw,
@@ -272,7 +268,7 @@ int c3d_gs_backward_raw(const c3d_gs_settings* st, int32_t N, const float* means
 
 // ---- fused multi-view paths (no host synchronisation inside) ----------------------------------------------------------------
 struct StepWs {
-    char* geom; char* binning; char* image; int* radii; float* color; float* depth; float* alpha; float* dcolor; float* dalpha; float* pairgrad; uint8_t* pvalid;
+    char* geom; char* binning; char* image; int* radii; float* color; float* depth; float* alpha; float* dcolor; float* pairgrad; uint8_t* pvalid;
     float* dmeans2D; float* gcol; char* ms_ws; float* tile_loss;
     size_t bytes;
 };
@@ -288,9 +284,9 @@ static void carve_step(char* base, int N, int H, int W, long long cap, StepWs& w
     w.geom = take(g.bytes); w.binning = take(b.bytes); w.image = take(im.bytes);
     w.radii = (int*)take(4 * n);
     w.color = (float*)take(12 * P); w.depth = (float*)take(4 * P); w.alpha = (float*)take(4 * P);
-    w.dcolor = w.dalpha = w.pairgrad = w.dmeans2D = w.gcol = w.tile_loss = nullptr; w.pvalid = nullptr; w.ms_ws = nullptr;
+    w.dcolor = w.pairgrad = w.dmeans2D = w.gcol = w.tile_loss = nullptr; w.pvalid = nullptr; w.ms_ws = nullptr;
     if (!fwd_only) {
-        w.dcolor = (float*)take(12 * P); w.dalpha = (float*)take(4 * P);
+        w.dcolor = (float*)take(12 * P);
         w.pairgrad = (float*)take(sizeof(float) * GS_PAIR_FLOATS * (size_t)(cap > 0 ? cap : 1));
         w.pvalid = (uint8_t*)take((size_t)(cap > 0 ? cap : 1));
         w.dmeans2D = (float*)take(12 * n);
@@ -301,177 +297,67 @@ static void carve_step(char* base, int N, int H, int W, long long cap, StepWs& w
     w.bytes = off;
 }
 
-// ---- view lanes: the V views of a call are dealt round-robin onto `lanes` HIP streams (lane 0 = the caller's stream) so that the latency-bound
-// sort / scan chains of one view run underneath the VALU-bound compositing kernels of another.  Every view owns a workspace slice; after the
-// join ONE pass over the Gaussians turns all views' pair records into the parameter gradients.
-namespace {
-struct LanePool {
-    bool init = false; hipStream_t st[C3D_MAX_LANES - 1]; hipEvent_t fork, join[C3D_MAX_LANES - 1];
-    // forward-only rendering in groups of L views: a projection stream running two groups ahead of the lanes (render_views_grouped)
-    hipStream_t pre; hipEvent_t pre_done[2], lane_done[2][C3D_MAX_LANES];
-    hipEvent_t bin_done[16];      // binning chains running ahead of the compositing lanes (train_views): view v -> bin_done[v % 16]
-    hipEvent_t comp_done[16];     // compositing token (train_views): view v's compositing kernels are done -> comp_done[v % 16]
-    std::mutex busy;              // held from a call's fork to its join: two host threads (or two step objects) on one device take turns instead of re-recording each other's events
+// ---- view groups (round 4) ---------------------------------------------------------------------------------------------------------------------
+// G consecutive views of a call (G <= GS_MAX_GROUP) whose state lives in G consecutive workspace slices go through every stage of the chain TOGETHER:
+// ONE launch per stage with blockIdx.y = view -- projection (parameters streamed once for the group), one clear of all state blocks, scan, depth sort
+// (histogram + 4 onesweep passes), scan, emit, tile sort (histogram + 2 passes), ranges, compositing forward [, pixel loss + compositing backward, loss sums]:
+// 15 launches forward, 17 forward + backward, whatever G is.  Rounds 1-3 ran one such chain PER VIEW on a pool of streams ("view lanes") to hide the chain's
+// latency-bound kernels (a 1 M-key radix pass is 16 MB of traffic and ~17 us of fixed latencies) under other views' compositing: ~170 launches per 8-view
+// step and a 15-50 us hole at every kernel boundary of every chain.  A stage over 8 views is bandwidth-sized work instead.
+// `lanes` survives as the number of GROUPS in flight: lanes = 1 puts all views of a step in one group on the caller's stream.
+struct ViewGroup {
+    int G = 0, N = 0, tiles = 0; size_t vs = 0; char* slice0 = nullptr; uint32_t cap = 0;
+    GsParams p[GS_MAX_GROUP]; StepWs w[GS_MAX_GROUP]; GsGeom g0; GsBinning b0; GsImage im0;
 };
-LanePool g_lanes[16];
-std::mutex g_lane_mu;
-int lane_pool(LanePool** out) {
-    int dev = 0;
-    C3D_CHECK(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 16) { c3d_set_error("c3d: device ordinal %d out of range", dev); return -1; }
-    std::lock_guard<std::mutex> lk(g_lane_mu);
-    LanePool& lp = g_lanes[dev];
-    if (!lp.init) {
-        C3D_CHECK(hipEventCreateWithFlags(&lp.fork, hipEventDisableTiming));
-        for (int i = 0; i < C3D_MAX_LANES - 1; i++) {
-            C3D_CHECK(hipStreamCreateWithFlags(&lp.st[i], hipStreamNonBlocking));
-            C3D_CHECK(hipEventCreateWithFlags(&lp.join[i], hipEventDisableTiming));
-        }
-        C3D_CHECK(hipStreamCreateWithFlags(&lp.pre, hipStreamNonBlocking));
-        for (int i = 0; i < 2; i++) {
-            C3D_CHECK(hipEventCreateWithFlags(&lp.pre_done[i], hipEventDisableTiming));
-            for (int l = 0; l < C3D_MAX_LANES; l++) C3D_CHECK(hipEventCreateWithFlags(&lp.lane_done[i][l], hipEventDisableTiming));
-        }
-        for (int i = 0; i < 16; i++) C3D_CHECK(hipEventCreateWithFlags(&lp.bin_done[i], hipEventDisableTiming));
-        for (int i = 0; i < 16; i++) C3D_CHECK(hipEventCreateWithFlags(&lp.comp_done[i], hipEventDisableTiming));
-        lp.init = true;
+static int group_setup(ViewGroup& q, const c3d_gs_settings* views, int G, int N, char* slice0, size_t vs, long long pair_capacity, bool fwd_only) {
+    if (G < 1 || G > GS_MAX_GROUP) { c3d_set_error("internal: group of %d views", G); return -2; }
+    q.G = G; q.N = N; q.vs = G > 1 ? vs : 0; q.slice0 = slice0; q.cap = (uint32_t)pair_capacity;
+    for (int i = 0; i < G; i++) {
+        if (make_params(&views[i], N, 16, q.p[i])) return -1;
+        carve_step(slice0 + (size_t)i * vs, N, q.p[i].H, q.p[i].W, pair_capacity, q.w[i], fwd_only);
     }
-    *out = &lp;
+    q.tiles = q.p[0].gx * q.p[0].gy;
+    gs_carve_geom(q.w[0].geom, N, q.g0);
+    gs_carve_binning(q.w[0].binning, pair_capacity, q.tiles, q.b0);
+    gs_carve_image(q.w[0].image, q.p[0].W, q.p[0].H, q.im0);
     return 0;
 }
-struct Lanes {
-    int L = 1; LanePool* lp = nullptr; hipStream_t s0 = nullptr; hipStream_t ls[C3D_MAX_LANES];
-    bool locked = false;
-    int fork(hipStream_t caller, int lanes, int V) {
-        s0 = caller; L = lanes < V ? lanes : V; ls[0] = s0;
-        if (lane_pool(&lp)) return -1;
-        lp->busy.lock(); locked = true;           // the pool's streams and events are this call's until join()
-        if (L > 1) {
-            if (hipEventRecord(lp->fork, s0) != hipSuccess) { unlock(); c3d_set_error("lane fork failed"); return -1; }
-            for (int l = 1; l < L; l++) {
-                ls[l] = lp->st[l - 1];
-                if (hipStreamWaitEvent(ls[l], lp->fork, 0) != hipSuccess) { unlock(); c3d_set_error("lane fork failed"); return -1; }
-            }
-        }
-        return 0;
+// A1 of the group: parameters read once, 93 B of projected state written per Gaussian and view.  radii_out[i] (optional): where view i's radii go instead of its slice.
+static int group_project(ViewGroup& q, const float* means3D, const float* f_dc, const float* f_rest, const float* opacity_raw, const float* scaling_raw,
+                         const float* rotation_raw, int32_t* const* radii_out, hipStream_t s) {
+    GsGeom gs[GS_MAX_GROUP];
+    int* rd[GS_MAX_GROUP];
+    for (int i = 0; i < q.G; i++) {
+        gs_carve_geom(q.w[i].geom, q.N, gs[i]);
+        rd[i] = (radii_out && radii_out[i]) ? radii_out[i] : q.w[i].radii;
     }
-    void unlock() { if (locked && lp) { lp->busy.unlock(); locked = false; } }
-    int need_pool() { return lp ? 0 : lane_pool(&lp); }
-    // always executed, so the caller's stream never runs ahead of work queued on the lanes (also after an error)
-    int join(const char* who) {
-        int rc = 0;
-        for (int l = 1; l < L; l++) {
-            if (hipEventRecord(lp->join[l - 1], ls[l]) != hipSuccess || hipStreamWaitEvent(s0, lp->join[l - 1], 0) != hipSuccess) {
-                (void)hipDeviceSynchronize();
-                c3d_set_error("%s: lane join failed", who); rc = -1;
-            }
-        }
-        unlock();
-        return rc;
-    }
-};
-}  // namespace
-
-// the same lanes for the other multi-view step of the library (mesh.hip)
-extern "C++" {
-int c3d_lanes_fork(hipStream_t caller, int lanes, int n_views, hipStream_t* streams, int* L) {
-    Lanes ln;
-    if (ln.fork(caller, lanes, n_views)) return -1;
-    for (int l = 0; l < ln.L; l++) streams[l] = ln.ls[l];
-    *L = ln.L;
-    return 0;                                      // the pool stays locked: c3d_lanes_join (same thread) releases it
+    C3dProfScope sc(C3D_P_PREPROCESS, s);
+    return gs_launch_preprocess_views(q.p, q.G, gs, rd, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, s);
 }
-int c3d_lanes_join(hipStream_t caller, const hipStream_t* streams, int L, const char* who) {
-    Lanes ln;
-    ln.s0 = caller; ln.L = L;
-    for (int l = 0; l < L; l++) ln.ls[l] = streams[l];
-    if (ln.need_pool()) return -1;
-    ln.locked = true;                              // taken by the matching c3d_lanes_fork
-    return ln.join(who);
-}
-}  // extern "C++"
-
-// forward of one view of the fused paths (A1-A6), everything on stream s, no host synchronisation: the pair count stays on the device
-// (g.meta[0]) and every launch that depends on it is sized for the pair capacity.
-// `projected`: A1 of this view has already run (step_preprocess_all)
-// A2-A5 of one view (the latency-bound part of its chain: scans, two radix sorts, emit, ranges), sync-free
-static int step_view_binning(const GsParams& p, GsGeom& g, GsBinning& b, int* radii, uint32_t cap, uint32_t* status, hipStream_t s, int* res_out) {
+// A2-A5 of the group, sync-free: ONE clear of every view's state blocks (+ the backward pass's "record written" bytes), then one launch per stage
+static int group_bin(ViewGroup& q, uint32_t* status, bool clear_pvalid, hipStream_t s, int* res_out) {
     int rc;
-    if ((rc = binning_front(g, p.N, cap, status, s))) return rc;
-    return binning_back(p, g, b, radii, (long long)cap, cap, (const uint32_t*)g.meta, status, s, res_out);
-}
-static int step_view_forward(const GsParams& p, const float* means3D, const float* f_dc, const float* f_rest, const float* opacity_raw, const float* scaling_raw,
-                             const float* rotation_raw, GsGeom& g, GsBinning& b, GsImage& im, int* radii, uint32_t cap, uint32_t* status, float* color, float* depth,
-                             float* alpha, bool record_activity, hipStream_t s, int* res_out, bool projected = false, bool binned = false) {
-    int rc, res = binned ? *res_out : 0;
-    if (!projected) {
-        C3dProfScope ps(C3D_P_PREPROCESS, s);
-        if ((rc = gs_launch_preprocess_raw(p, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, g, radii, s))) return rc;
+    {
+        C3dProfScope ps(C3D_P_OTHER, s);
+        const size_t off[3] = {(size_t)(q.w[0].geom - q.slice0) + q.g0.zero_off, (size_t)(q.w[0].binning - q.slice0) + q.b0.zero_off,
+                               clear_pvalid ? (size_t)((char*)q.w[0].pvalid - q.slice0) : 0};
+        const size_t bytes[3] = {q.g0.zero_bytes, q.b0.zero_bytes, clear_pvalid ? (((size_t)q.cap + 15) & ~(size_t)15) : 0};
+        if ((rc = c3d_zero_views(q.slice0, q.vs, q.G, off, bytes, clear_pvalid ? 3 : 2, s))) return rc;
     }
-    if (!binned && (rc = step_view_binning(p, g, b, radii, cap, status, s, &res))) return rc;
-    { C3dProfScope ps(C3D_P_COMPOSITE_FWD, s);
-      if ((rc = gs_launch_composite_fwd(p, g, b, res, im, color, depth, alpha, record_activity, s))) return rc; }
-    *res_out = res;
-    return 0;
+    if ((rc = binning_front(q.g0, q.N, q.cap, status, s, q.G, q.vs, true))) return rc;
+    return binning_back(q.p[0], q.g0, q.b0, (long long)q.cap, q.cap, (const uint32_t*)q.g0.meta, status, s, res_out, q.G, q.vs, true);
 }
-// Binning ahead (round 3, measured and left OFF): with all views projected up front, the views' binning chains -- 15 launches of 10-30 us each that cannot
-// fill the machine -- can run on the pool's streams the compositing lanes do not use, every chain from the start of the step, instead of at the head of each
-// view on its lane (under four lanes in lockstep the chains of four views coincide twice per 8-view step).  On the MI355X box: 6.50 ms per step against 5.89 ms
-// with the chains on the lanes (profiles/r03/r03c_bench_binahead_on.json / _off.json): eight streams share four hardware queues, and a lane's compositing
-// kernel then waits behind another stream's chain in its queue.  C3D_BIN_AHEAD=1 enables it (worth re-measuring with GPU_MAX_HW_QUEUES=8).
-static bool bin_ahead() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("C3D_BIN_AHEAD"); v = e ? atoi(e) != 0 : 0; }
-    return v != 0;
-}
-
-// A1 of every view of a step whose views keep their own workspace slice: the parameters are streamed once for up to GS_MAX_BWD_VIEWS views
-// (k_preprocess_views) instead of once per view.  Runs on the caller's stream BEFORE the lanes fork.  C3D_PRE_MULTIVIEW=0 keeps the per-view launches.
-static bool pre_multiview() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("C3D_PRE_MULTIVIEW"); v = e ? atoi(e) != 0 : 1; }
-    return v != 0;
-}
-// Staggered projection (round 3, C3D_PRE_SPLIT=1; measured, OFF by default): only the first `lanes` views are projected before the fork; the rest is projected on
-// lane 0's stream right behind view 0's binning chain, i.e. while ALL lanes sit in their first, latency-bound binning chains; the lanes wait for it (one event)
-// before their second view.  The serial head of the step shrinks from a V-view projection to an L-view one -- and the step does not: 5.946 / 6.002 ms against
-// 5.945 / 5.924 ms on the same box (profiles/r03/r03i_*): the projection kernel fills every CU (128-thread workgroups, 25 KB of LDS each) and the other lanes'
-// binning chains then queue behind it for slots, i.e. what the head saves the first binning round loses.
-static bool pre_split() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("C3D_PRE_SPLIT"); v = e ? atoi(e) != 0 : 0; }
-    return v != 0;
-}
-// Compositing tokens (round 3).  Hypothesis: left alone the lanes run in lockstep -- they finish their binning chains together, their compositing kernels share the
-// machine and finish together, and all of them sit in the next latency-bound binning chain together.  With k tokens view v's compositing kernels wait for those of
-// view v - k.  Measured (profiles/r03/r03k_*, ms per 8-view step, two runs each): unconstrained 5.878 / 5.894, k = 1 (a strict chain of compositing kernels)
-// 6.306 / 6.311, k = 2 5.843 / 5.838; training step 8.027 / 9.259 / 8.001.  The strict chain LOSES 0.42 ms: kernels of one chain leave a 15-50 us hole at
-// every boundary (memset + dependent dispatch + the tail of the grid) that only a second, independent chain fills -- the step's 0.7 ms above the sum of its
-// throughput-bound kernels is those ~20 boundaries, not lockstep.  Two tokens keep two chains in flight and win a little.  C3D_COMP_TOKENS=k, 0 = unconstrained.
-static int comp_tokens() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("C3D_COMP_TOKENS"); v = e ? atoi(e) : 2; if (v < 0 || v > 8) v = 0; }
-    return v;
-}
-static int step_preprocess_all(const c3d_gs_settings* views, int V, int N, size_t slice_bytes, void* workspace, long long pair_capacity, const float* means3D,
-                               const float* f_dc, const float* f_rest, const float* opacity_raw, const float* scaling_raw, const float* rotation_raw, hipStream_t s0,
-                               int first = 0) {
-    for (int v0 = first; v0 < V; v0 += GS_MAX_BWD_VIEWS) {
-        const int nv = (V - v0) < GS_MAX_BWD_VIEWS ? (V - v0) : GS_MAX_BWD_VIEWS;
-        GsParams ps[GS_MAX_BWD_VIEWS];
-        GsGeom gs[GS_MAX_BWD_VIEWS];
-        int* radii[GS_MAX_BWD_VIEWS];
-        for (int i = 0; i < nv; i++) {
-            if (make_params(&views[v0 + i], N, 16, ps[i])) return -1;
-            StepWs w; carve_step((char*)workspace + (size_t)(v0 + i) * slice_bytes, N, ps[i].H, ps[i].W, pair_capacity, w);
-            gs_carve_geom(w.geom, N, gs[i]);
-            radii[i] = w.radii;
-        }
-        C3dProfScope sc(C3D_P_PREPROCESS, s0);
-        int rc;
-        if ((rc = gs_launch_preprocess_views(ps, nv, gs, radii, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, s0))) return rc;
+// A6 of the group.  out_*[i] (arrays or entries may be NULL): the caller's planes of view i; otherwise the slice's own.
+static int group_composite_fwd(ViewGroup& q, int res, float* const* out_color, float* const* out_depth, float* const* out_alpha, bool record, hipStream_t s) {
+    GsFwdViews vp{};
+    for (int i = 0; i < q.G; i++) {
+        vp.bg[i] = q.p[i].bg;
+        vp.color[i] = (out_color && out_color[i]) ? out_color[i] : q.w[i].color;
+        vp.depth[i] = (out_depth && out_depth[i]) ? out_depth[i] : q.w[i].depth;
+        vp.alpha[i] = (out_alpha && out_alpha[i]) ? out_alpha[i] : q.w[i].alpha;
     }
-    return 0;
+    C3dProfScope ps(C3D_P_COMPOSITE_FWD, s);
+    return gs_launch_composite_fwd(q.p[0], q.g0, q.b0, res, q.im0, vp, q.G, q.vs, record, s);
 }
 
 // per-Gaussian chain rule over all views of a step, every gradient written once (chunks of GS_MAX_BWD_VIEWS views); stream s0, after the join
@@ -512,6 +398,11 @@ static int check_step_args(const char* who, const c3d_gs_settings* views, int V,
             views[v].scale_modifier != views[0].scale_modifier) { c3d_set_error("%s: all views must share resolution, sh_degree and scale_modifier", who); return -1; }
     return 0;
 }
+// views per group when V views are spread over `lanes` groups in flight
+static int group_width(int V, int lanes) {
+    int G = (V + lanes - 1) / lanes;
+    return G > GS_MAX_GROUP ? GS_MAX_GROUP : (G < 1 ? 1 : G);
+}
 
 size_t c3d_gs_step_workspace_bytes(int32_t N, int32_t H, int32_t W, int64_t pair_capacity, int32_t views) {
     StepWs w; carve_step(nullptr, N, H, W, pair_capacity, w);
@@ -534,103 +425,61 @@ int c3d_gs_train_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, c
     if (!means3D || !f_dc || !f_rest || !opacity_raw || !scaling_raw || !rotation_raw || !dL_dmeans3D || !dL_df_dc || !dL_df_rest || !dL_dopacity_raw ||
         !dL_dscaling_raw || !dL_drotation_raw) { c3d_set_error("c3d_gs_train_views_raw: NULL parameter / gradient pointer"); return -1; }
     if ((uintptr_t)f_rest % 16 || (uintptr_t)dL_df_rest % 16 || (uintptr_t)rotation_raw % 16 || (uintptr_t)dL_drotation_raw % 16) { c3d_set_error("c3d_gs_train_views_raw: f_rest / rotation tensors must be 16-byte aligned"); return -1; }
-    const uint32_t cap = (uint32_t)pair_capacity;
+    for (int v = 0; v < V; v++) if (!target_color[v]) { c3d_set_error("c3d_gs_train_views_raw: target_color[%d] is NULL", v); return -1; }
     StepWs w0; carve_step(nullptr, N, views[0].image_height, views[0].image_width, pair_capacity, w0);
-    const bool projected = pre_multiview();
-    static int fuse_loss = -1;
-    if (fuse_loss < 0) { const char* e = getenv("C3D_FUSE_LOSS"); fuse_loss = e ? atoi(e) != 0 : 1; }
-    const int L_ = lanes < V ? lanes : V;
-    const bool split = projected && pre_split() && L_ > 1 && V > L_ && !bin_ahead();
-    if (projected && step_preprocess_all(views, split ? L_ : V, N, w0.bytes, workspace, pair_capacity, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, s0)) return -1;
-    Lanes ln;
-    if (ln.fork(s0, lanes, V)) return -1;
+    const size_t vs = w0.bytes;
+    const bool ssim = loss->w_ssim != 0.f;
+    const int G = group_width(V, lanes), groups = (V + G - 1) / G;
     int rc_all = 0;
-    const int n_bin = C3D_MAX_LANES - ln.L;                       // pool streams the lanes leave free
-    const bool ahead = projected && bin_ahead() && ln.L > 1 && n_bin > 0 && V > 1;
-    if (ahead)
-        for (int i = 0; i < n_bin && i < V; i++)
-            if (hipStreamWaitEvent(ln.lp->st[ln.L - 1 + i], ln.lp->fork, 0) != hipSuccess) { c3d_set_error("c3d_gs_train_views_raw: fork failed"); rc_all = -1; }
-    for (int v = 0; v < V && !rc_all; v++) {
-        hipStream_t s = ln.ls[v % ln.L];
-        GsParams p;
-        if (make_params(&views[v], N, 16, p)) { rc_all = -1; break; }
-        if (!target_color[v]) { c3d_set_error("c3d_gs_train_views_raw: target_color[%d] is NULL", v); rc_all = -1; break; }
-        const int tiles = p.gx * p.gy;
-        StepWs w; carve_step((char*)workspace + (size_t)v * w0.bytes, N, p.H, p.W, pair_capacity, w);
-        GsGeom g; gs_carve_geom(w.geom, N, g);
-        GsBinning b; gs_carve_binning(w.binning, pair_capacity, tiles, b);
-        GsImage im; gs_carve_image(w.image, p.W, p.H, im);
-        int rc = 0, res = 0;
-        do {
-            if (ahead) {      // this view's binning chain on a free stream; its lane waits for it and goes straight to the compositing
-                hipStream_t sb = ln.lp->st[ln.L - 1 + (v % n_bin)];
-                if ((rc = step_view_binning(p, g, b, w.radii, cap, status, sb, &res))) break;
-                if (hipEventRecord(ln.lp->bin_done[v % 16], sb) != hipSuccess || hipStreamWaitEvent(s, ln.lp->bin_done[v % 16], 0) != hipSuccess) { c3d_set_error("c3d_gs_train_views_raw: event failed"); rc = -1; break; }
-            }
-            bool binned = ahead;
-            if (split && v == 0) {      // view 0's binning, then the projection of views L.. on this lane (lane 0); the other lanes wait for it before their second view
-                if ((rc = step_view_binning(p, g, b, w.radii, cap, status, s, &res))) break;
-                if ((rc = step_preprocess_all(views, V, N, w0.bytes, workspace, pair_capacity, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, s, ln.L))) break;
-                if (hipEventRecord(ln.lp->pre_done[0], s) != hipSuccess) { c3d_set_error("c3d_gs_train_views_raw: event failed"); rc = -1; break; }
-                binned = true;
-            } else if (split && v >= ln.L && v < 2 * ln.L && (v % ln.L) != 0) {
-                if (hipStreamWaitEvent(s, ln.lp->pre_done[0], 0) != hipSuccess) { c3d_set_error("c3d_gs_train_views_raw: event failed"); rc = -1; break; }
-            }
-            // the "record written" bytes of the backward pass are cleared here, inside / ahead of the binning chain, not between the two compositing kernels
-            if (hipMemsetAsync(w.pvalid, 0, (size_t)cap, s) != hipSuccess) { c3d_set_error("c3d_gs_train_views_raw: memset failed"); rc = -1; break; }
-            const int tok = (projected && ln.L > 1) ? comp_tokens() : 0;
-            if (tok && v >= tok) {      // binning first (unconstrained), then wait for the token: the compositing kernels of view v - tok are done
-                if (!binned) { if ((rc = step_view_binning(p, g, b, w.radii, cap, status, s, &res))) break; binned = true; }
-                if (hipStreamWaitEvent(s, ln.lp->comp_done[(v - tok) % 16], 0) != hipSuccess) { c3d_set_error("c3d_gs_train_views_raw: event failed"); rc = -1; break; }
-            }
-            if ((rc = step_view_forward(p, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, g, b, im, w.radii, cap, status, w.color, w.depth, w.alpha, true, s, &res, projected, binned))) break;
-            // pixel loss and its gradient.  Default: inside the backward compositing kernel (GsPixelLoss); C3D_FUSE_LOSS=0 keeps the separate launch.
-            const float* tal = target_alpha ? target_alpha[v] : nullptr;
-            const float* cmk = color_mask ? color_mask[v] : nullptr;
-            const bool ssim = loss->w_ssim != 0.f;
-            if (!fuse_loss) {
-                C3dProfScope ps(C3D_P_OTHER, s);
-                if ((rc = gs_launch_loss_grad(w.color, w.alpha, target_color[v], tal, cmk, (long long)p.W * p.H, loss->w_l1, loss->w_l2, loss->w_alpha_mse, loss->scale,
-                                              w.dcolor, w.dalpha, loss_out, s))) break;
-            }
-            // + scale * w_ssim * (1 - MS-SSIM(target * mask, clamp(C) * mask)) of this view (the batch mean of the reference, main_3DGS.py:192, is the mean of
-            // the per-image values): value into loss_out, gradient into (fused loss) / added to (separate launch) dL/dcolor -- ~20 launches on this view's lane
-            if (ssim) {
-                C3dProfScope ps(C3D_P_OTHER, s);
-                const float ws_ = loss->scale * loss->w_ssim;
-                // fused loss: the value goes into this view's own slot behind its tile partials (k_sum_tile_loss adds the views in order); otherwise to the shared word
-                const bool slot = fuse_loss && loss_out;
-                if ((rc = ms_value_grad(target_color[v], w.color, cmk, 1, 1, 3, p.H, p.W, -ws_, fuse_loss ? 0 : 1, w.dcolor, ws_, -ws_, slot ? w.tile_loss + tiles : loss_out, w.ms_ws, s, slot ? 1 : 0))) break;
-            }
-            // backward down to the per-(tile, splat) records of this view
-            { C3dProfScope ps(C3D_P_COMPOSITE_BWD, s);
-              if (fuse_loss) {
-                  const GsPixelLoss pl{w.color, w.alpha, target_color[v], tal, cmk, loss->w_l1, loss->w_l2, loss->w_alpha_mse, loss->scale, loss_out ? w.tile_loss : nullptr};
-                  rc = gs_launch_composite_bwd(p, g, b, res, im, ssim ? w.dcolor : nullptr, nullptr, nullptr, w.pairgrad, w.pvalid, (long long)cap, s, cap, &pl, true);
-              } else {
-                  rc = gs_launch_composite_bwd(p, g, b, res, im, w.dcolor, nullptr, w.dalpha, w.pairgrad, w.pvalid, (long long)cap, s, cap, nullptr, true);
-              }
-              if (rc) break;
-              if (projected && ln.L > 1 && comp_tokens() && hipEventRecord(ln.lp->comp_done[v % 16], s) != hipSuccess) { c3d_set_error("c3d_gs_train_views_raw: event failed"); rc = -1; break; }
-              if (fuse_loss && loss_out && (rc = gs_launch_sum_view_loss(w.tile_loss, tiles + (ssim ? 1 : 0), w.tile_loss + tiles + 1, s))) break; }   // this view's loss value, on its lane
-        } while (0);
-        rc_all = rc;
+    {
+        C3dLanes ln;
+        if (ln.fork(s0, lanes, groups)) return -1;
+        for (int k = 0; k < groups && !rc_all; k++) {
+            hipStream_t s = ln.s[k % ln.L];
+            const int v0 = k * G, g = (V - v0) < G ? (V - v0) : G;
+            ViewGroup q;
+            int rc = 0, res = 0;
+            do {
+                if ((rc = group_setup(q, views + v0, g, N, (char*)workspace + (size_t)v0 * vs, vs, pair_capacity, false))) break;
+                if ((rc = group_project(q, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, nullptr, s))) break;
+                if ((rc = group_bin(q, status, true, s, &res))) break;
+                if ((rc = group_composite_fwd(q, res, nullptr, nullptr, nullptr, true, s))) break;
+                // + scale * w_ssim * (1 - MS-SSIM(target * mask, clamp(C) * mask)) of every view (the batch mean of the reference, main_3DGS.py:192, is the mean of
+                // the per-image values): the value goes into the view's own slot behind its tile partials, the gradient into the slice's dL/dcolor plane
+                if (ssim) {
+                    C3dProfScope ps(C3D_P_MSSSIM, s);
+                    const float ws_ = loss->scale * loss->w_ssim;
+                    for (int i = 0; i < g && !rc; i++)
+                        rc = ms_value_grad(target_color[v0 + i], q.w[i].color, color_mask ? color_mask[v0 + i] : nullptr, 1, 1, 3, q.p[i].H, q.p[i].W, -ws_, 0, q.w[i].dcolor, ws_, -ws_,
+                                           loss_out ? q.w[i].tile_loss + q.tiles : nullptr, q.w[i].ms_ws, s, 1);
+                    if (rc) break;
+                }
+                // pixel loss + backward down to the per-(tile, splat) records, all views of the group in one launch
+                { C3dProfScope ps(C3D_P_COMPOSITE_BWD, s);
+                  GsBwdPix px{};
+                  for (int i = 0; i < g; i++) {
+                      px.bg[i] = q.p[i].bg; px.dcolor[i] = ssim ? q.w[i].dcolor : nullptr; px.ddepth[i] = nullptr; px.dalpha[i] = nullptr;
+                      px.color[i] = q.w[i].color; px.alpha[i] = q.w[i].alpha; px.tcolor[i] = target_color[v0 + i];
+                      px.talpha[i] = target_alpha ? target_alpha[v0 + i] : nullptr; px.cmask[i] = color_mask ? color_mask[v0 + i] : nullptr;
+                  }
+                  const GsPixelLossW plw{loss->w_l1, loss->w_l2, loss->w_alpha_mse, loss->scale, loss_out ? q.w[0].tile_loss : nullptr};
+                  if ((rc = gs_launch_composite_bwd(q.p[0], q.g0, q.b0, res, q.im0, px, false, q.w[0].pairgrad, q.w[0].pvalid, s, q.cap, &plw, q.G, q.vs))) break; }
+                if (loss_out) { C3dProfScope ps(C3D_P_OTHER, s);
+                                if ((rc = gs_launch_sum_view_loss(q.w[0].tile_loss, q.tiles + (ssim ? 1 : 0), q.w[0].tile_loss + q.tiles + 1, q.G, q.vs, s))) break; }
+            } while (0);
+            rc_all = rc;
+        }
+        if (ln.join("c3d_gs_train_views_raw") && !rc_all) rc_all = -1;
     }
-    if (ahead)      // the binning streams too end in the caller's stream (every chain already has a consumer on a lane; this keeps error paths ordered as well)
-        for (int i = 0; i < n_bin && i < V; i++)
-            if (hipEventRecord(ln.lp->join[ln.L - 1 + i], ln.lp->st[ln.L - 1 + i]) != hipSuccess || hipStreamWaitEvent(s0, ln.lp->join[ln.L - 1 + i], 0) != hipSuccess) {
-                (void)hipDeviceSynchronize();
-                if (!rc_all) { c3d_set_error("c3d_gs_train_views_raw: binning stream join failed"); rc_all = -1; }
-            }
-    if (ln.join("c3d_gs_train_views_raw") && !rc_all) rc_all = -1;
     if (rc_all) return rc_all;
-    if (fuse_loss && loss_out) {   // the views' per-tile partial sums of the pixel loss -> loss_out, in a fixed order
+    if (loss_out) {   // the views' loss values -> loss_out, in view order
         StepWs wf; carve_step((char*)workspace, N, views[0].image_height, views[0].image_width, pair_capacity, wf);
         const int tiles = ((views[0].image_width + C3D_TILE_X - 1) / C3D_TILE_X) * ((views[0].image_height + C3D_TILE_Y - 1) / C3D_TILE_Y);
-        if (gs_launch_sum_tile_loss(wf.tile_loss + tiles + 1, w0.bytes, V, loss_out, s0)) return -1;
+        C3dProfScope ps(C3D_P_OTHER, s0);
+        if (gs_launch_sum_tile_loss(wf.tile_loss + tiles + 1, vs, V, loss_out, s0)) return -1;
     }
     if (accumulate & 2) return 0;   // the caller runs the per-Gaussian pass itself, range by range (c3d_gs_step_param_backward_range)
-    return step_a8_all_views(views, V, N, w0.bytes, workspace, pair_capacity, means3D, f_dc, f_rest, scaling_raw, rotation_raw, dL_dmeans3D, dL_df_dc, dL_df_rest,
+    return step_a8_all_views(views, V, N, vs, workspace, pair_capacity, means3D, f_dc, f_rest, scaling_raw, rotation_raw, dL_dmeans3D, dL_df_dc, dL_df_rest,
                              dL_dopacity_raw, dL_dscaling_raw, dL_drotation_raw, (accumulate & 1) != 0, s0);
 }
 
@@ -649,85 +498,48 @@ int c3d_gs_step_param_backward_range(const c3d_gs_settings* views, int32_t V, in
                              dL_dopacity_raw, dL_dscaling_raw, dL_drotation_raw, accumulate != 0, (hipStream_t)stream, first, count);
 }
 
-// forward of V views; keep_state: view v uses workspace slice v (what c3d_gs_backward_views_raw reads), otherwise a lane reuses its slice view after view
+// forward of V views in groups.  keep_state: view v uses workspace slice v (what c3d_gs_backward_views_raw reads); otherwise the workspace holds `slices` forward-only
+// slices and group k of a lane reuses that lane's slice set (stream order keeps the reuse safe).
 static int views_forward(const char* who, const c3d_gs_settings* views, int32_t V, int32_t N, const float* means3D, const float* f_dc, const float* f_rest,
                          const float* opacity_raw, const float* scaling_raw, const float* rotation_raw, float* const* out_color, float* const* out_depth,
                          float* const* out_alpha, int32_t* const* out_radii, int64_t pair_capacity, int32_t lanes, void* workspace, uint32_t* status,
-                         hipStream_t s0, bool keep_state, bool two_slice_sets = false) {
+                         hipStream_t s0, bool keep_state, int slices) {
     if (V <= 0 || N <= 0) return 0;
     if (!out_color || !out_alpha || !status) { c3d_set_error("%s: NULL pointer", who); return -1; }
     if (check_step_args(who, views, V, pair_capacity, lanes, workspace)) return -1;
     if (!means3D || !f_dc || !f_rest || !opacity_raw || !scaling_raw || !rotation_raw) { c3d_set_error("%s: NULL parameter pointer", who); return -1; }
     if ((uintptr_t)f_rest % 16 || (uintptr_t)rotation_raw % 16) { c3d_set_error("%s: f_rest / rotation tensors must be 16-byte aligned", who); return -1; }
-    const uint32_t cap = (uint32_t)pair_capacity;
+    for (int v = 0; v < V; v++) if (!out_color[v] || !out_alpha[v]) { c3d_set_error("%s: output %d is NULL", who, v); return -1; }
     const bool fwd_only = !keep_state;       // c3d_gs_render_views_raw: slices without the backward pass's buffers (c3d_gs_render_workspace_bytes)
     StepWs w0; carve_step(nullptr, N, views[0].image_height, views[0].image_width, pair_capacity, w0, fwd_only);
-    const bool projected = pre_multiview();
-    if (projected && keep_state && step_preprocess_all(views, V, N, w0.bytes, workspace, pair_capacity, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, s0)) return -1;
-    Lanes ln;
-    if (ln.fork(s0, lanes, V)) return -1;
-    const int L = ln.L;
+    const size_t vs = w0.bytes;
+    int L = lanes, G;
+    if (keep_state) G = group_width(V, L);
+    else {      // forward only: L slice sets of G slices each
+        if (L > slices) L = slices;
+        G = group_width(V, L);
+        if (G > slices / L) G = slices / L;
+    }
+    const int groups = (V + G - 1) / G;
     int rc_all = 0;
-    // Forward only (no state kept): a lane reuses workspace slices view after view.  The views go in groups of L (one per lane); group k lives in
-    // slice set k % 2, and a projection stream runs k_preprocess_views for whole groups two ahead of the lanes: parameters are streamed once per
-    // L views, and group k + 2 is projected as soon as every lane has finished its view of group k.
-    const bool grouped = projected && !keep_state && two_slice_sets;      // forward only, and the workspace has the second slice set the projection stream fills ahead
-    hipStream_t sp = nullptr;
-    auto project_group = [&](int k) -> int {
-        const int v0 = k * L, nv = (V - v0) < L ? (V - v0) : L;
-        GsParams ps[C3D_MAX_LANES]; GsGeom gs[C3D_MAX_LANES]; int* rd[C3D_MAX_LANES];
-        for (int i = 0; i < nv; i++) {
-            if (make_params(&views[v0 + i], N, 16, ps[i])) return -1;
-            StepWs w; carve_step((char*)workspace + (size_t)((k & 1) * L + i) * w0.bytes, N, ps[i].H, ps[i].W, pair_capacity, w, fwd_only);
-            gs_carve_geom(w.geom, N, gs[i]);
-            rd[i] = (out_radii && out_radii[v0 + i]) ? out_radii[v0 + i] : w.radii;
-        }
-        { C3dProfScope sc(C3D_P_PREPROCESS, sp);
-          if (gs_launch_preprocess_views(ps, nv, gs, rd, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, sp)) return -1; }
-        C3D_CHECK(hipEventRecord(ln.lp->pre_done[k & 1], sp));
-        return 0;
-    };
-    const int groups = (V + L - 1) / L;
-    if (grouped) {
-        if (ln.need_pool()) rc_all = -1;
-        else {
-            sp = ln.lp->pre;
-            if (hipEventRecord(ln.lp->fork, s0) != hipSuccess || hipStreamWaitEvent(sp, ln.lp->fork, 0) != hipSuccess) { c3d_set_error("%s: fork failed", who); rc_all = -1; }
-            for (int k = 0; k < 2 && k < groups && !rc_all; k++) rc_all = project_group(k);
-        }
-    }
-    for (int v = 0; v < V && !rc_all; v++) {
-        const int lane = v % L, k = v / L;
-        hipStream_t s = ln.ls[lane];
-        GsParams p;
-        if (make_params(&views[v], N, 16, p)) { rc_all = -1; break; }
-        if (!out_color[v] || !out_alpha[v]) { c3d_set_error("%s: output %d is NULL", who, v); rc_all = -1; break; }
-        const int slice = keep_state ? v : (grouped ? (k & 1) * L + lane : lane);
-        StepWs w; carve_step((char*)workspace + (size_t)slice * w0.bytes, N, p.H, p.W, pair_capacity, w, fwd_only);
-        GsGeom g; gs_carve_geom(w.geom, N, g);
-        GsBinning b; gs_carve_binning(w.binning, pair_capacity, p.gx * p.gy, b);
-        GsImage im; gs_carve_image(w.image, p.W, p.H, im);
+    C3dLanes ln;
+    if (ln.fork(s0, L, groups)) return -1;
+    for (int k = 0; k < groups && !rc_all; k++) {
+        const int lane = k % ln.L;
+        hipStream_t s = ln.s[lane];
+        const int v0 = k * G, g = (V - v0) < G ? (V - v0) : G;
+        ViewGroup q;
         int res = 0;
-        int* radii = (!keep_state && out_radii && out_radii[v]) ? out_radii[v] : w.radii;      // kept state: the backward pass reads the slice's copy
-        float* depth = (out_depth && out_depth[v]) ? out_depth[v] : w.depth;
-        if (grouped && hipStreamWaitEvent(s, ln.lp->pre_done[k & 1], 0) != hipSuccess) { c3d_set_error("%s: wait failed", who); rc_all = -1; break; }
-        rc_all = step_view_forward(p, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, g, b, im, radii, cap, status, out_color[v], depth, out_alpha[v], keep_state, s, &res, keep_state ? projected : grouped);
-        if (!rc_all && keep_state && out_radii && out_radii[v] &&
-            hipMemcpyAsync(out_radii[v], w.radii, sizeof(int) * (size_t)N, hipMemcpyDeviceToDevice, s) != hipSuccess) {
-            c3d_set_error("%s: radii copy failed", who); rc_all = -1;       // no early return: the lanes must still be joined
-        }
-        if (grouped && !rc_all) {
-            if (hipEventRecord(ln.lp->lane_done[k & 1][lane], s) != hipSuccess) { c3d_set_error("%s: record failed", who); rc_all = -1; break; }
-            const bool last_of_group = (lane == L - 1) || (v == V - 1);
-            if (last_of_group && k + 2 < groups) {      // slice set k % 2 is free once every lane is through group k: project group k + 2 into it
-                for (int l = 0; l <= lane && !rc_all; l++)
-                    if (hipStreamWaitEvent(sp, ln.lp->lane_done[k & 1][l], 0) != hipSuccess) { c3d_set_error("%s: wait failed", who); rc_all = -1; }
-                if (!rc_all) rc_all = project_group(k + 2);
+        char* slice0 = (char*)workspace + (size_t)(keep_state ? v0 : lane * G) * vs;
+        if ((rc_all = group_setup(q, views + v0, g, N, slice0, vs, pair_capacity, fwd_only))) break;
+        // kept state: the backward pass reads the slice's copy of the radii; forward only: straight into the caller's buffer where there is one
+        if ((rc_all = group_project(q, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, (!keep_state && out_radii) ? out_radii + v0 : nullptr, s))) break;
+        if ((rc_all = group_bin(q, status, keep_state, s, &res))) break;
+        if ((rc_all = group_composite_fwd(q, res, out_color + v0, out_depth ? out_depth + v0 : nullptr, out_alpha + v0, keep_state, s))) break;
+        for (int i = 0; i < g && keep_state && out_radii && !rc_all; i++)
+            if (out_radii[v0 + i] && hipMemcpyAsync(out_radii[v0 + i], q.w[i].radii, sizeof(int) * (size_t)N, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+                c3d_set_error("%s: radii copy failed", who); rc_all = -1;       // no early return: the lanes must still be joined
             }
-        }
-    }
-    if (grouped && sp) {   // nothing may be left running on the projection stream when the caller's stream continues (error paths included)
-        if (hipEventRecord(ln.lp->pre_done[0], sp) != hipSuccess || hipStreamWaitEvent(s0, ln.lp->pre_done[0], 0) != hipSuccess) { (void)hipDeviceSynchronize(); if (!rc_all) { c3d_set_error("%s: join failed", who); rc_all = -1; } }
     }
     if (ln.join(who) && !rc_all) rc_all = -1;
     return rc_all;
@@ -737,17 +549,15 @@ int c3d_gs_render_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, 
                              const float* opacity_raw, const float* scaling_raw, const float* rotation_raw, float* const* out_color, float* const* out_depth,
                              float* const* out_alpha, int32_t* const* out_radii, int64_t pair_capacity, int32_t lanes, void* workspace, int64_t workspace_bytes,
                              uint32_t* status, c3d_stream_t stream) {
-    if (V > 0 && N > 0 && !out_depth) { c3d_set_error("c3d_gs_render_views_raw: NULL pointer"); return -1; }
+    int slices = 1;
     if (V > 0 && N > 0 && views && lanes >= 1 && pair_capacity > 0) {      // the slice count decides the schedule: say what the buffer holds instead of trusting a convention
         const size_t one = c3d_gs_render_workspace_bytes(N, views[0].image_height, views[0].image_width, pair_capacity, 1);
-        const int L = lanes < V ? lanes : V;
-        if (workspace_bytes < (int64_t)(one * (size_t)L)) { c3d_set_error("c3d_gs_render_views_raw: workspace of %lld bytes holds fewer than %d slices of %zu bytes", (long long)workspace_bytes, L, one); return -1; }
-        const bool two_sets = workspace_bytes >= (int64_t)(one * (size_t)(2 * L));
-        return views_forward("c3d_gs_render_views_raw", views, V, N, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, out_color, out_depth, out_alpha, out_radii,
-                             pair_capacity, lanes, workspace, status, (hipStream_t)stream, false, two_sets);
+        if (workspace_bytes < (int64_t)one) { c3d_set_error("c3d_gs_render_views_raw: workspace of %lld bytes holds less than one slice of %zu bytes", (long long)workspace_bytes, one); return -1; }
+        const int64_t n = workspace_bytes / (int64_t)one;
+        slices = n > 1024 ? 1024 : (int)n;
     }
     return views_forward("c3d_gs_render_views_raw", views, V, N, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, out_color, out_depth, out_alpha, out_radii,
-                         pair_capacity, lanes, workspace, status, (hipStream_t)stream, false, false);
+                         pair_capacity, lanes, workspace, status, (hipStream_t)stream, false, slices);
 }
 
 int c3d_gs_forward_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, const float* means3D, const float* f_dc, const float* f_rest,
@@ -755,7 +565,7 @@ int c3d_gs_forward_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N,
                               float* const* out_alpha, int32_t* const* out_radii, int64_t pair_capacity, int32_t lanes, void* workspace, uint32_t* status,
                               c3d_stream_t stream) {
     return views_forward("c3d_gs_forward_views_raw", views, V, N, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, out_color, out_depth, out_alpha, out_radii,
-                         pair_capacity, lanes, workspace, status, (hipStream_t)stream, true);
+                         pair_capacity, lanes, workspace, status, (hipStream_t)stream, true, V);
 }
 
 int c3d_gs_backward_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, const float* means3D, const float* f_dc, const float* f_rest,
@@ -769,28 +579,33 @@ int c3d_gs_backward_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N
     if (!means3D || !f_dc || !f_rest || !scaling_raw || !rotation_raw || !dL_dmeans3D || !dL_df_dc || !dL_df_rest || !dL_dopacity_raw || !dL_dscaling_raw ||
         !dL_drotation_raw) { c3d_set_error("c3d_gs_backward_views_raw: NULL parameter / gradient pointer"); return -1; }
     if ((uintptr_t)f_rest % 16 || (uintptr_t)dL_df_rest % 16 || (uintptr_t)rotation_raw % 16 || (uintptr_t)dL_drotation_raw % 16) { c3d_set_error("c3d_gs_backward_views_raw: f_rest / rotation tensors must be 16-byte aligned"); return -1; }
-    const uint32_t cap = (uint32_t)pair_capacity;
+    for (int v = 0; v < V; v++) if (!dL_dcolor[v]) { c3d_set_error("c3d_gs_backward_views_raw: dL_dcolor[%d] is NULL", v); return -1; }
     StepWs w0; carve_step(nullptr, N, views[0].image_height, views[0].image_width, pair_capacity, w0);
-    Lanes ln;
-    if (ln.fork(s0, lanes, V)) return -1;
+    const size_t vs = w0.bytes;
+    const int G = group_width(V, lanes), groups = (V + G - 1) / G;
     int rc_all = 0;
-    for (int v = 0; v < V && !rc_all; v++) {
-        hipStream_t s = ln.ls[v % ln.L];
-        GsParams p;
-        if (make_params(&views[v], N, 16, p)) { rc_all = -1; break; }
-        if (!dL_dcolor[v]) { c3d_set_error("c3d_gs_backward_views_raw: dL_dcolor[%d] is NULL", v); rc_all = -1; break; }
-        const int tiles = p.gx * p.gy;
-        StepWs w; carve_step((char*)workspace + (size_t)v * w0.bytes, N, p.H, p.W, pair_capacity, w);
-        GsGeom g; gs_carve_geom(w.geom, N, g);
-        GsBinning b; gs_carve_binning(w.binning, pair_capacity, tiles, b);
-        GsImage im; gs_carve_image(w.image, p.W, p.H, im);
-        C3dProfScope ps(C3D_P_COMPOSITE_BWD, s);
-        rc_all = gs_launch_composite_bwd(p, g, b, sort_result_index(tile_sort_bits(tiles)), im, dL_dcolor[v], dL_ddepth ? dL_ddepth[v] : nullptr,
-                                         dL_dalpha ? dL_dalpha[v] : nullptr, w.pairgrad, w.pvalid, (long long)cap, s, cap);
+    {
+        C3dLanes ln;
+        if (ln.fork(s0, lanes, groups)) return -1;
+        for (int k = 0; k < groups && !rc_all; k++) {
+            hipStream_t s = ln.s[k % ln.L];
+            const int v0 = k * G, g = (V - v0) < G ? (V - v0) : G;
+            ViewGroup q;
+            if ((rc_all = group_setup(q, views + v0, g, N, (char*)workspace + (size_t)v0 * vs, vs, pair_capacity, false))) break;
+            GsBwdPix px{};
+            bool depth = false;
+            for (int i = 0; i < g; i++) {
+                px.bg[i] = q.p[i].bg; px.dcolor[i] = dL_dcolor[v0 + i];
+                px.ddepth[i] = dL_ddepth ? dL_ddepth[v0 + i] : nullptr; px.dalpha[i] = dL_dalpha ? dL_dalpha[v0 + i] : nullptr;
+                depth = depth || px.ddepth[i];
+            }
+            C3dProfScope ps(C3D_P_COMPOSITE_BWD, s);
+            rc_all = gs_launch_composite_bwd(q.p[0], q.g0, q.b0, sort_result_index(tile_sort_bits(q.tiles)), q.im0, px, depth, q.w[0].pairgrad, q.w[0].pvalid, s, q.cap, nullptr, q.G, q.vs);
+        }
+        if (ln.join("c3d_gs_backward_views_raw") && !rc_all) rc_all = -1;
     }
-    if (ln.join("c3d_gs_backward_views_raw") && !rc_all) rc_all = -1;
     if (rc_all) return rc_all;
-    return step_a8_all_views(views, V, N, w0.bytes, workspace, pair_capacity, means3D, f_dc, f_rest, scaling_raw, rotation_raw, dL_dmeans3D, dL_df_dc, dL_df_rest,
+    return step_a8_all_views(views, V, N, vs, workspace, pair_capacity, means3D, f_dc, f_rest, scaling_raw, rotation_raw, dL_dmeans3D, dL_df_dc, dL_df_rest,
                              dL_dopacity_raw, dL_dscaling_raw, dL_drotation_raw, accumulate != 0, s0);
 }
 
@@ -856,17 +671,6 @@ int c3d_test_scan_u32(const uint32_t* in, uint32_t* out, int64_t n, int32_t excl
     return rc;
 }
 int c3d_test_sort_phases(uint64_t* stamps) { return c3d_sort_set_debug((unsigned long long*)stamps); }
-int c3d_test_segment_sort_u32(const uint32_t* ranges, int32_t nseg, const uint32_t* key_table, uint32_t* vals, int64_t n, c3d_stream_t stream) {
-    hipStream_t s = (hipStream_t)stream;
-    if (n <= 0 || nseg <= 0) return 0;
-    if (!ranges || !key_table || !vals) { c3d_set_error("c3d_test_segment_sort_u32: NULL pointer"); return -1; }
-    uint32_t* v1 = nullptr;
-    C3D_CHECK(hipMalloc(&v1, 4 * (size_t)n));
-    int rc = c3d_segment_sort_u32((const uint2*)ranges, nseg, key_table, vals, v1, s);
-    (void)hipStreamSynchronize(s);
-    (void)hipFree(v1);
-    return rc;
-}
 int c3d_test_sort_pairs_u32(uint32_t* keys, uint32_t* vals, int64_t n, int32_t end_bit, c3d_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     if (n <= 0) return 0;

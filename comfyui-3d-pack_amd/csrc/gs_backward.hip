@@ -3,7 +3,6 @@
 // Function behind main_3DGS_renderer.py:927-936 (reference call site) must return.
 #include "gs_internal.h"
 #include "gs_math.h"
-#include <stdlib.h>
 
 // --- wave64 reductions -------------------------------------------------------------------------------
 // Four per-lane values are summed across the 64 lanes for the price of ~2.5 VALU ops per value:
@@ -77,6 +76,49 @@ __device__ __forceinline__ void wave_reduce10(float v0, float v1, float v2, floa
     t0 = v0; t1 = v4; t2 = v8;
 }
 
+// --- wave64 reduction through LDS (round 4, the default) ----------------------------------------------------------------------------------------
+// The DPP / permlane reduction above costs ~144 VALU cycles per walked (wave, splat) pair -- more than the chain rule that produces the ten values
+// (profiles/r03z_sq_*).  Here the ten per-lane values are TRANSPOSED through a wave-private LDS tile instead of being folded across lanes:
+//   * every lane stores value k into row k of the tile, at column = its lane: ds_write_addtid_b32 (address = M0 + offset + 4 * lane: no address VGPR, 2 issue
+//     cycles per store against 4 for ds_write_b32); rows are padded to 68 dwords so that the reads below are conflict-free;
+//   * lane L then owns quarter (L & 3) of row (L >> 2): four ds_read_b128 = 16 columns, 15 adds, and two quad-permute DPP adds join the four quarters.
+//     Rows NV..15 do not exist: those lanes re-read row NV - 1 and are ignored.
+// ~52 VALU cycles + 34 LDS-array cycles per pair.  The order of the additions is fixed: results are bit-reproducible (and differ in the last bits from
+// the DPP tree's).  LDS operations of one wave execute in order, so the reads see this splat's stores and the next splat's stores come after them.
+#define BWD_RED_ROW 68      // dwords per tile row: 64 lanes + 4 (16 lanes of a ds_read_b128 group then hit 16 different four-bank groups)
+__device__ __forceinline__ uint32_t lds_scalar_address(const void* p) {   // LDS byte address (low half of the generic address) as a scalar, for M0
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)p);
+}
+// base = lds_scalar_address(tile), taken once per kernel.  M0 is not in the clobber list: the compiler reserves it and loads it itself in front of every
+// instruction of its own that reads it.  The s_nop is the wait state the ISA demands between an SALU write of M0 and an LDS "add-TID" instruction (the
+// compiler's hazard recogniser does not look inside inline asm; without it the first store of a wave goes to whatever M0 held before).
+template <int NV>
+__device__ __forceinline__ float wave_reduce_lds(const float* tile /* [NV][BWD_RED_ROW], wave-private */, uint32_t base, const float (&v)[NV], int lane) {
+    static_assert(NV == 9 || NV == 10, "nine values, ten with the depth channel");
+    if (NV == 10)
+        asm volatile("s_mov_b32 m0, %10\n\t"
+                     "s_nop 0\n\t"
+                     "ds_write_addtid_b32 %0 offset:0\n\t" "ds_write_addtid_b32 %1 offset:272\n\t" "ds_write_addtid_b32 %2 offset:544\n\t"
+                     "ds_write_addtid_b32 %3 offset:816\n\t" "ds_write_addtid_b32 %4 offset:1088\n\t" "ds_write_addtid_b32 %5 offset:1360\n\t"
+                     "ds_write_addtid_b32 %6 offset:1632\n\t" "ds_write_addtid_b32 %7 offset:1904\n\t" "ds_write_addtid_b32 %8 offset:2176\n\t"
+                     "ds_write_addtid_b32 %9 offset:2448"
+                     :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]), "v"(v[NV - 1]), "s"(base) : "memory");
+    else
+        asm volatile("s_mov_b32 m0, %9\n\t"
+                     "s_nop 0\n\t"
+                     "ds_write_addtid_b32 %0 offset:0\n\t" "ds_write_addtid_b32 %1 offset:272\n\t" "ds_write_addtid_b32 %2 offset:544\n\t"
+                     "ds_write_addtid_b32 %3 offset:816\n\t" "ds_write_addtid_b32 %4 offset:1088\n\t" "ds_write_addtid_b32 %5 offset:1360\n\t"
+                     "ds_write_addtid_b32 %6 offset:1632\n\t" "ds_write_addtid_b32 %7 offset:1904\n\t" "ds_write_addtid_b32 %8 offset:2176"
+                     :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]), "s"(base) : "memory");
+    const int row = min(lane >> 2, NV - 1), quarter = lane & 3;
+    const float4* rp = reinterpret_cast<const float4*>(tile + row * BWD_RED_ROW + quarter * 16);
+    const float4 a = rp[0], b = rp[1], c = rp[2], d = rp[3];
+    float t = (((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w))) + (((c.x + c.y) + (c.z + c.w)) + ((d.x + d.y) + (d.z + d.w)));
+    t = dpp_add<0xB1>(t);               // quad_perm [1,0,3,2]
+    t = dpp_add<0x4E>(t);               // quad_perm [2,3,0,1]
+    return t;                           // lanes 4r .. 4r+3 hold the wave's sum of value r (r < NV)
+}
+
 // ------------------------------------------------------------------------------------------
 // A7 composite backward: same tiling and per-wave ballot-compacted splat lists as the forward pass
 // (wave w = 8x8 quadrant, one pixel per lane), splats visited back to front in rounds of BWD_ROUND (64).
@@ -100,24 +142,36 @@ __device__ __forceinline__ void wave_reduce10(float v0, float v1, float v2, floa
 // 12 DPP adds at 4.1, 9 adds at 2.9) = the 271 the SQ counters show.
 // DEPTH: some caller-supplied dL/ddepth exists.  The fused training step has none (the reference's loss reads image and alpha only, main_3DGS.py:184-192):
 // its instance drops the depth channel from the per-splat dot product, from the products and from the ten-value reduction (nine values).
+// blockIdx.y = view of a multi-view launch: the state pointers are view 0's (view v lies v * vs bytes behind), pixel-space inputs come from the per-view table `px`.
 template <bool LOSS, bool DEPTH>
 __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                                                         const uint4* __restrict__ einfo,
                                                         const float4* __restrict__ rec0, const float4* __restrict__ rec1,
                                                         const float4* __restrict__ rec2, const float* __restrict__ final_T,
-                                                        const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor,
-                                                        const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha_px,
-                                                        const uint8_t* __restrict__ pact, size_t pstride, float4* __restrict__ pairgrad, uint8_t* __restrict__ pvalid, uint32_t cap, int sh,
-                                                        GsPixelLoss pl) {
+                                                        const uint32_t* __restrict__ n_contrib, GsBwdPix px,
+                                                        const uint8_t* __restrict__ pact, size_t pstride, float4* __restrict__ pairgrad, uint8_t* __restrict__ pvalid, uint32_t cap,
+                                                        GsPixelLossW plw, size_t vs) {
+    ranges = c3d_view_ptr(ranges, vs); point_list = c3d_view_ptr(point_list, vs); einfo = c3d_view_ptr(einfo, vs);
+    rec0 = c3d_view_ptr(rec0, vs); rec1 = c3d_view_ptr(rec1, vs); rec2 = c3d_view_ptr(rec2, vs); final_T = c3d_view_ptr(final_T, vs);
+    n_contrib = c3d_view_ptr(n_contrib, vs); pact = c3d_view_ptr(pact, vs); pairgrad = c3d_view_ptr(pairgrad, vs); pvalid = c3d_view_ptr(pvalid, vs);
+    const int vw = blockIdx.y;
+    const float* __restrict__ bg = px.bg[vw];
+    const float* __restrict__ dL_dcolor = px.dcolor[vw];
+    const float* __restrict__ dL_ddepth = px.ddepth[vw];
+    const float* __restrict__ dL_dalpha_px = px.dalpha[vw];
     __shared__ float4 s0[BWD_ROUND];
     __shared__ float4 s1[BWD_ROUND];
     __shared__ float4 s2[BWD_ROUND];
     __shared__ uint32_t se[BWD_ROUND];
     __shared__ uint32_t smask[BWD_ROUND];
-    __shared__ float acc[4][GS_PAIR_FLOATS][BWD_ROUND + 1];   // +1: the four row-writers of a wave (lanes 0,16,32,48) land in different banks
+    constexpr int NV = DEPTH ? 10 : 9;                          // values summed per walked pair: colour 3 [, depth], m0, m1 x 2, m2 x 3
+    __shared__ float acc[4][NV][BWD_ROUND + 1];                 // per wave and value: the sums of the round's splats (+1: the writers of a wave -- lanes 0, 4, 8, ... -- land in different banks)
+#ifndef GS_BWD_REDUCE_DPP
+    __shared__ __attribute__((aligned(16))) float red[4][NV][BWD_RED_ROW];   // wave_reduce_lds's transposition tile, one per wave
+#endif
     __shared__ int s_uptow[4];   // per quadrant: the deepest list position (+1) one of its pixels blended = how far its plane of the activity record is valid
     int tx, ty;
-    if (!gs_block_tile(blockIdx.x, p.gx, p.gy, tx, ty, sh)) return;
+    if (!gs_block_tile(blockIdx.x, p.gx, p.gy, tx, ty)) return;
     const int tile = ty * p.gx + tx;
     const int lane = c3d_lane(), wave = threadIdx.x >> 6;
     const int X0 = tx * C3D_TILE_X, Y0 = ty * C3D_TILE_Y;
@@ -136,8 +190,10 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
         dLd = (DEPTH && dL_ddepth) ? dL_ddepth[pid] : 0.f;
         dLa = dL_dalpha_px ? dL_dalpha_px[pid] : 0.f;
     }
-    if (LOSS) {   // the step's pixel loss, term by term as k_loss_grad
+    if (LOSS) {   // the step's pixel loss: clamp, optional mask, L1 / L2 / alpha-MSE value and gradient
         __shared__ float s_loss[4];
+        struct { const float *color, *alpha, *tcolor, *talpha, *cmask; float w_l1, w_l2, w_a, scale; float* tile_loss; } pl =
+            {px.color[vw], px.alpha[vw], px.tcolor[vw], px.talpha[vw], px.cmask[vw], plw.w_l1, plw.w_l2, plw.w_a, plw.scale, c3d_view_ptr(plw.tile_loss, vs)};
         float l = 0.f;
         if (inside) {
             const float inv3p = 1.f / (3.f * (float)P), invp = 1.f / (float)P;
@@ -161,7 +217,10 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
         __syncthreads();
         if (threadIdx.x == 0 && pl.tile_loss) pl.tile_loss[tile] = s_loss[0] + s_loss[1] + s_loss[2] + s_loss[3];
     }
-    const float bg_dot = p.bg[0] * dLp0 + p.bg[1] * dLp1 + p.bg[2] * dLp2;
+#ifndef GS_BWD_REDUCE_DPP
+    const uint32_t red_base = lds_scalar_address(&red[wave][0][0]);
+#endif
+    const float bg_dot = bg[0] * dLp0 + bg[1] * dLp1 + bg[2] * dLp2;
     float Rdot = T_final * bg_dot;
 
     // list positions no pixel of the tile reached need no work and get no record
@@ -238,12 +297,25 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
                     // screen-space part as raw moments of w2 = dL/dG * G; turned into mean/conic/opacity gradients per Gaussian in A8
                     const float m0 = sel64z(am, a1.y * G * dL_dalpha);
                     const float m1x = m0 * dx, m1y = m0 * dy;
+#ifdef GS_BWD_REDUCE_DPP
                     wave_reduce10(w * dLp0, w * dLp1, w * dLp2, DEPTH ? w * dLd : 0.f, m0, m1x, m1y, m1x * dx, m1x * dy, m1y * dy, t0, t1, t2);
-                    // t0 rows: c0, c2, c1, depth   t1 rows: m0, m1y, m1x, m2xx   t2 rows: m2xy, 0, m2yy, 0
+                    // t0 rows: c0, c2, c1, depth   t1 rows: m0, m1y, m1x, m2xx   t2 rows: m2xy, 0, m2yy, 0  -> value index of wave_reduce_lds's order
                     if ((lane & 15) == 0) {   // lanes 0,16,32,48: one row each
                         const int row = lane >> 4;
-                        acc[wave][row][j] = t0; acc[wave][4 + row][j] = t1; acc[wave][8 + row][j] = t2;
+                        const int k0 = row == 0 ? 0 : (row == 1 ? 2 : (row == 2 ? 1 : 9)), k1 = row == 0 ? 3 : (row == 1 ? 5 : (row == 2 ? 4 : 6)), k2 = row == 0 ? 7 : 8;
+                        if (row < 3 || DEPTH) acc[wave][DEPTH || row < 3 ? k0 : 0][j] = t0;
+                        acc[wave][k1][j] = t1;
+                        if (!(row & 1)) acc[wave][k2][j] = t2;
                     }
+#else
+                    (void)t0; (void)t1; (void)t2;
+                    float vals[NV];
+                    vals[0] = w * dLp0; vals[1] = w * dLp1; vals[2] = w * dLp2; vals[3] = m0; vals[4] = m1x; vals[5] = m1y;
+                    vals[6] = m1x * dx; vals[7] = m1x * dy; vals[8] = m1y * dy;
+                    if (DEPTH) vals[NV - 1] = w * dLd;
+                    const float tsum = wave_reduce_lds<NV>(&red[wave][0][0], red_base, vals, lane);
+                    if ((lane & 3) == 0 && lane < 4 * NV) acc[wave][lane >> 2][j] = tsum;
+#endif
                 }
             }
         }
@@ -252,30 +324,31 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
             const int j = threadIdx.x;
             const uint32_t mk = smask[j];
             if (mk && se[j] < cap) {
-                float r[GS_PAIR_FLOATS];
+                float r[NV];
 #pragma unroll
-                for (int q = 0; q < GS_PAIR_FLOATS; q++) r[q] = 0.f;
+                for (int q = 0; q < NV; q++) r[q] = 0.f;
 #pragma unroll
                 for (int w = 0; w < 4; w++)
                     if ((mk >> w) & 1u) {   // the other waves left nothing in acc
 #pragma unroll
-                        for (int q = 0; q < GS_PAIR_FLOATS; q++) r[q] += acc[w][q][j];
+                        for (int q = 0; q < NV; q++) r[q] += acc[w][q][j];
                     }
+                // record layout (read by the per-Gaussian pass): [c0, c2, c1, depth | m0, m1y, m1x, m2xx | m2xy, 0, m2yy, 0]
                 float4* out = pairgrad + (size_t)se[j] * 3;
-                out[0] = make_float4(r[0], r[1], r[2], r[3]);
-                out[1] = make_float4(r[4], r[5], r[6], r[7]);
-                out[2] = make_float4(r[8], r[9], r[10], r[11]);
+                out[0] = make_float4(r[0], r[2], r[1], DEPTH ? r[NV - 1] : 0.f);
+                out[1] = make_float4(r[3], r[5], r[4], r[6]);
+                out[2] = make_float4(r[7], 0.f, r[8], 0.f);
                 pvalid[se[j]] = 1;
             }
         }
     }
 }
 
-// Two stages, both with a fixed order (the same loss bits every run).  Round 2 summed all views in one workgroup after the join: 8 dependent rounds of loads, reduce,
-// barrier = 0.108 ms on the step's critical path (profiles/r03/r03b_kernel_stats_lanes1.csv).  Now every view sums ITS terms on its own lane, right behind its
-// backward compositing kernel (hidden under the other lanes' work), and one wave adds the V view sums after the join.
-__global__ void __launch_bounds__(1024) k_sum_view_loss(const float* __restrict__ t, int n, float* __restrict__ out) {
+// Two stages, both with a fixed order (the same loss bits every run): every view sums ITS terms (per-tile partials + the MS-SSIM term's slot) in one
+// workgroup of ONE launch for all views of a group (blockIdx.x = view), and one lane adds the V view sums, in view order, after the last group.
+__global__ void __launch_bounds__(1024) k_sum_view_loss(const float* __restrict__ t, int n, float* __restrict__ out, size_t vs) {
     __shared__ float red[16];
+    t = (const float*)((const char*)t + (size_t)blockIdx.x * vs); out = (float*)((char*)out + (size_t)blockIdx.x * vs);
     float l = 0.f;
     for (int i = threadIdx.x; i < n; i += 1024) l += t[i];      // terms strided over the lanes, then a fixed tree
     l = c3d_wave_sum(l);
@@ -287,11 +360,11 @@ __global__ void __launch_bounds__(64) k_sum_views_loss(const float* __restrict__
     if (threadIdx.x != 0) return;
     float acc = 0.f;
     for (int v = 0; v < V; v++) acc += *(const float*)((const char*)first_view_sum + (size_t)v * stride);      // views in order
-    atomicAdd(loss_out, acc);   // one atomic per step
+    loss_out[0] += acc;             // one writer: the launch is ordered behind everything else that touches *loss_out on this stream
 }
-int gs_launch_sum_view_loss(const float* terms, int n, float* view_sum, hipStream_t s) {
-    if (n <= 0) return 0;
-    hipLaunchKernelGGL(k_sum_view_loss, dim3(1), dim3(1024), 0, s, terms, n, view_sum);
+int gs_launch_sum_view_loss(const float* terms, int n, float* view_sum, int V, size_t vs, hipStream_t s) {
+    if (n <= 0 || V <= 0) return 0;
+    hipLaunchKernelGGL(k_sum_view_loss, dim3(V), dim3(1024), 0, s, terms, n, view_sum, vs);
     C3D_LAUNCH_CHECK();
     return 0;
 }
@@ -302,20 +375,17 @@ int gs_launch_sum_tile_loss(const float* first_view_sum, size_t view_stride_byte
     return 0;
 }
 
-int gs_launch_composite_bwd(const GsParams& p, const GsGeom& g, const GsBinning& b, int res, const GsImage& im,
-                            const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
-                            float* pairgrad, uint8_t* pvalid, long long pairs, hipStream_t s, uint32_t cap, const GsPixelLoss* pixel_loss, bool pvalid_cleared) {
+// V views per launch (grid.y).  pvalid must be clear on entry (the fused paths clear it with the binning state: c3d_zero_views; the drop-in path below).
+int gs_launch_composite_bwd(const GsParams& p, const GsGeom& g, const GsBinning& b, int res, const GsImage& im, const GsBwdPix& px, bool depth,
+                            float* pairgrad, uint8_t* pvalid, hipStream_t s, uint32_t cap, const GsPixelLossW* plw, int V, size_t vs) {
     const int tiles = p.gx * p.gy;
-    if (tiles == 0) return 0;
-    // pvalid_cleared: the fused step clears the "record written" bytes inside the view's binning chain (latency-bound anyway) -- one boundary less between the two
-    // compositing kernels
-    if (!pvalid_cleared) C3D_CHECK(hipMemsetAsync(pvalid, 0, (size_t)(pairs > 0 ? pairs : 1), s));
-    const dim3 grid(gs_block_count(p.gx, p.gy, gs_supertile_shift()));
+    if (tiles == 0 || V <= 0) return 0;
+    const dim3 grid(gs_block_count(p.gx, p.gy), V);
 #define GS_BWD_LAUNCH(LOSS_, DEPTH_, PL_)                                                                                                                        \
-    hipLaunchKernelGGL((k_composite_bwd<LOSS_, DEPTH_>), grid, dim3(256), gs_lds_pad(true), s, p, b.ranges, b.tval[res], g.einfo, g.rec0, g.rec1, g.rec2, im.final_T, \
-                       im.n_contrib, dL_dcolor, dL_ddepth, dL_dalpha, gs_pair_activity(b, res), b.pair_stride, (float4*)pairgrad, pvalid, cap, gs_supertile_shift(), PL_)
-    if (pixel_loss) { if (dL_ddepth) GS_BWD_LAUNCH(true, true, *pixel_loss); else GS_BWD_LAUNCH(true, false, *pixel_loss); }
-    else            { if (dL_ddepth) GS_BWD_LAUNCH(false, true, GsPixelLoss{}); else GS_BWD_LAUNCH(false, false, GsPixelLoss{}); }
+    hipLaunchKernelGGL((k_composite_bwd<LOSS_, DEPTH_>), grid, dim3(256), 0, s, p, b.ranges, b.tval[res], g.einfo, g.rec0, g.rec1, g.rec2, im.final_T, \
+                       im.n_contrib, px, gs_pair_activity(b, res), b.pair_stride, (float4*)pairgrad, pvalid, cap, PL_, vs)
+    if (plw) { if (depth) GS_BWD_LAUNCH(true, true, *plw); else GS_BWD_LAUNCH(true, false, *plw); }
+    else     { if (depth) GS_BWD_LAUNCH(false, true, GsPixelLossW{}); else GS_BWD_LAUNCH(false, false, GsPixelLossW{}); }
 #undef GS_BWD_LAUNCH
     C3D_LAUNCH_CHECK();
     return 0;
@@ -588,121 +658,10 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GsParams p, GsGeom g, co
 // launches of k_preprocess_bwd<.,.,ACC> this removes (V-1) read-modify-write sweeps over the 236 B/Gaussian gradient set and (V-1) reads of
 // the 192 B/Gaussian SH coefficients.  View-independent work (exp / normalize, cov3D, cov3D -> scale / quaternion chain, activation
 // derivatives) is done once, on the summed covariance gradient (the chain is linear in it).
-// SH: coefficients stay in the block's LDS image (read per view); the 48 gradient sums live in registers and replace the row at the end.
+// Two kernels (one kernel holding 48 SH gradient sums per lane next to the whole geometric chain needed 256 VGPRs: two waves per SIMD, ~2.3 TB/s; round 2):
+// (G) the geometric chain, which needs no LDS and ~100 VGPRs, hands the masked colour gradient of every view over in a 12 B/Gaussian/view array;
+// (S) the SH part keeps the coefficients in LDS and only the 48 sums + a direction in registers.
 // ------------------------------------------------------------------------------------------
-template <bool ACC>
-__global__ void __launch_bounds__(256, 2) k_preprocess_bwd_views(GsParams p, GsBwdViews vs, const float* __restrict__ means3D, const float* __restrict__ f_dc,
-                                                               const float* __restrict__ f_rest, const float* __restrict__ scales, const float* __restrict__ rotations,
-                                                               float* __restrict__ dL_dopacity, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_df_dc,
-                                                               float* __restrict__ dL_df_rest, float* __restrict__ dL_dscales, float* __restrict__ dL_drots, uint32_t cap) {
-    extern __shared__ float sh_lds[];
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t g0 = (size_t)blockIdx.x * blockDim.x;
-    const int gcount = min((int)blockDim.x, p.N - (int)g0);
-    float* shl = sh_lds + threadIdx.x * SH_ROW;
-    sh_stage_in_split(f_dc, f_rest, g0, gcount, sh_lds);
-    __syncthreads();
-    float gsh[SH_M3];
-#pragma unroll
-    for (int k = 0; k < SH_M3; k++) gsh[k] = 0.f;
-    if (idx < p.N) {
-        const float3 m = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
-        float3 sc = make_float3(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]);
-        float4 q = *reinterpret_cast<const float4*>(rotations + 4 * idx);
-        sc = make_float3(expf(sc.x), expf(sc.y), expf(sc.z));
-        const float qnorm = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
-        {
-            const float inv = 1.f / qnorm;
-            q = make_float4(q.x * inv, q.y * inv, q.z * inv, q.w * inv);
-        }
-        float c3[6];
-        cov3d_from_scale_rot(sc, p.scale_modifier, q, c3);
-        float dmean[3] = {0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dopac = 0.f;
-        for (int v = 0; v < vs.V; v++) {
-            const GsBwdView& vw = vs.v[v];
-            float* d2 = vw.dmean2D + 3 * (size_t)idx;
-            if (vw.radii[idx] <= 0) { d2[0] = 0.f; d2[1] = 0.f; d2[2] = 0.f; continue; }
-            float pr[GS_PAIR_FLOATS];
-#pragma unroll
-            for (int k = 0; k < GS_PAIR_FLOATS; k++) pr[k] = 0.f;
-            {
-                const uint32_t cnt = vw.tiles[idx];
-                const uint32_t e0 = vw.rbase[idx], e1 = min(e0 + cnt, cap);
-                for (uint32_t e = e0; e < e1; e++) {
-                    if (!vw.pvalid[e]) continue;
-                    const float4 v0 = vw.pairgrad[(size_t)e * 3], v1 = vw.pairgrad[(size_t)e * 3 + 1], v2 = vw.pairgrad[(size_t)e * 3 + 2];
-                    pr[0] += v0.x; pr[1] += v0.y; pr[2] += v0.z; pr[3] += v0.w;
-                    pr[4] += v1.x; pr[5] += v1.y; pr[6] += v1.z; pr[7] += v1.w;
-                    pr[8] += v2.x; pr[10] += v2.z;
-                }
-            }
-            const float gcol[3] = {pr[0], pr[2], pr[1]};          // record rows: c0, c2, c1
-            const float4 q0 = vw.rec0[GS_REC(idx)], q1 = vw.rec1[GS_REC(idx)];
-            const float opac = q1.y;
-            {
-                const float go = (opac > 0.f) ? pr[4] / opac : 0.f;
-                dopac += go * opac * (1.f - opac);                  // sigmoid'
-            }
-            const Mat16 V = load_mat16(vw.view), PJ = load_mat16(vw.proj);
-            float g2x, g2y, dm[3], dc[6];
-            bwd_geom_chain(m, c3, V, PJ, vw.tanfovx, vw.tanfovy, vw.focal_x, vw.focal_y, p.W, p.H, q0.z, q0.w, q1.x, pr[6], pr[5], pr[7], pr[8], pr[10], pr[3], g2x, g2y, dm, dc);
-            d2[0] = g2x; d2[1] = g2y; d2[2] = 0.f;
-#pragma unroll
-            for (int i = 0; i < 6; i++) dcov[i] += dc[i];
-            // colour -> SH coefficients and view direction
-            const float vx = m.x - vw.campos[0], vy = m.y - vw.campos[1], vz = m.z - vw.campos[2];
-            const float s2 = vx * vx + vy * vy + vz * vz;
-            const float len = sqrtf(s2);
-            const float dxn = vx / len, dyn = vy / len, dzn = vz / len;
-            const uint8_t cl = vw.clamped[idx];
-            const float dR0 = (cl & 1) ? 0.f : gcol[0], dR1 = (cl & 2) ? 0.f : gcol[1], dR2 = (cl & 4) ? 0.f : gcol[2];
-            float dd0 = 0.f, dd1 = 0.f, dd2 = 0.f;
-#define GS_BWDV_TERM(k, Bk, dBx, dBy, dBz)                                                              \
-    {                                                                                                   \
-        const float b_ = (Bk);                                                                          \
-        const float w_ = shl[3 * (k)] * dR0 + shl[3 * (k) + 1] * dR1 + shl[3 * (k) + 2] * dR2;          \
-        gsh[3 * (k)] += b_ * dR0; gsh[3 * (k) + 1] += b_ * dR1; gsh[3 * (k) + 2] += b_ * dR2;           \
-        dd0 += (dBx) * w_; dd1 += (dBy) * w_; dd2 += (dBz) * w_;                                        \
-    }
-            SH_FOREACH(p.deg, dxn, dyn, dzn, GS_BWDV_TERM);
-#undef GS_BWDV_TERM
-            const float inv32 = 1.f / sqrtf(s2 * s2 * s2);
-            dmean[0] += dm[0] + ((s2 - vx * vx) * dd0 - vy * vx * dd1 - vz * vx * dd2) * inv32;
-            dmean[1] += dm[1] + (-vx * vy * dd0 + (s2 - vy * vy) * dd1 - vz * vy * dd2) * inv32;
-            dmean[2] += dm[2] + (-vx * vz * dd0 - vy * vz * dd1 + (s2 - vz * vz) * dd2) * inv32;
-        }
-        // view-independent tail: cov3D -> scale (exp') and quaternion (normalisation), then the single write of every gradient
-        float gs3[3];
-        float4 dq;
-        bwd_cov_to_scale_rot(dcov, sc, q, p.scale_modifier, p.dscale_mod, gs3, dq);
-        gs3[0] *= sc.x; gs3[1] *= sc.y; gs3[2] *= sc.z;
-        {
-            const float dot = dq.x * q.x + dq.y * q.y + dq.z * q.z + dq.w * q.w, inv = 1.f / qnorm;
-            dq = make_float4((dq.x - q.x * dot) * inv, (dq.y - q.y * dot) * inv, (dq.z - q.z * dot) * inv, (dq.w - q.w * dot) * inv);
-        }
-        if (ACC) {
-            dopac += dL_dopacity[idx];
-#pragma unroll
-            for (int j = 0; j < 3; j++) { dmean[j] += dL_dmeans3D[3 * idx + j]; gs3[j] += dL_dscales[3 * idx + j]; }
-            const float4 o4 = *reinterpret_cast<const float4*>(dL_drots + 4 * idx);
-            dq.x += o4.x; dq.y += o4.y; dq.z += o4.z; dq.w += o4.w;
-        }
-        dL_dopacity[idx] = dopac;
-#pragma unroll
-        for (int j = 0; j < 3; j++) { dL_dmeans3D[3 * idx + j] = dmean[j]; dL_dscales[3 * idx + j] = gs3[j]; }
-        *reinterpret_cast<float4*>(dL_drots + 4 * idx) = dq;
-    }
-    // the coefficients are no longer needed: the gradient sums take their place in the LDS image (own row only: no barrier needed before)
-#pragma unroll
-    for (int k = 0; k < SH_M3; k++) shl[k] = gsh[k];
-    __syncthreads();
-    sh_stage_out_split<ACC>(dL_df_dc, dL_df_rest, g0, gcount, sh_lds);
-}
-
-// ---- the same pass as two lighter kernels ----------------------------------------------------------------------------------------------
-// k_preprocess_bwd_views holds 48 SH gradient sums per lane next to the whole geometric chain: 256 VGPRs, two waves per SIMD, and it streams
-// at ~2.3 TB/s.  Split: (G) the geometric chain, which needs no LDS and ~100 VGPRs, hands the masked colour gradient of every view over in a
-// 12 B/Gaussian/view array; (S) the SH part keeps the coefficients in LDS and only the 48 sums + a direction in registers.
 template <bool ACC, int CHUNK, int MINB>
 __global__ void __launch_bounds__(256, MINB) k_bwd_views_geom(GsParams p, GsBwdViews vs, const float* __restrict__ means3D, const float* __restrict__ scales,
                                                           const float* __restrict__ rotations, float* __restrict__ dL_dopacity, float* __restrict__ dL_dmeans3D,
@@ -852,46 +811,29 @@ __global__ void __launch_bounds__(256) k_bwd_views_sh(int first, int last, int d
     sh_stage_out_split<ACC>(dL_df_dc, dL_df_rest, g0, gcount, sh_lds);
 }
 
-static bool gs_a8_split() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("C3D_A8_SPLIT"); v = e ? atoi(e) != 0 : 1; }
-    return v != 0;
-}
-
 int gs_launch_preprocess_bwd_views(const GsParams& p0, const GsBwdViews& views, const float* means3D, const float* f_dc, const float* f_rest,
                                    const float* scaling_raw, const float* rotation_raw, float* dL_dopacity_raw, float* dL_dmeans3D, float* dL_df_dc,
                                    float* dL_df_rest, float* dL_dscaling_raw, float* dL_drotation_raw, bool accumulate, hipStream_t s, uint32_t cap, int first, int count) {
     if (p0.N == 0 || views.V == 0) return 0;
-    const bool whole = (first == 0 && (count < 0 || count >= p0.N));
     if (count < 0) count = p0.N - first;
     if (first < 0 || count < 0 || first + count > p0.N || (first & 3)) { c3d_set_error("gs_launch_preprocess_bwd_views: bad Gaussian range [%d, %d + %d)", first, first, count); return -1; }
     if (count == 0) return 0;
     const int last = first + count;
     const dim3 grid(c3d_cdiv(count, 256)), block(256);
     const size_t lds = 256 * SH_ROW * sizeof(float);
-    if (gs_a8_split() || !whole) {
-        GsShViews sv;
-        sv.V = views.V;
-        for (int i = 0; i < views.V; i++) { sv.campos[i] = views.v[i].campos; sv.gcol[i] = views.v[i].gcol; }
-        // four pairs in flight, four workgroups per CU (128 VGPRs): eight in flight (160 VGPRs) and two or three (96, spilling) measure the same or worse
+    GsShViews sv;
+    sv.V = views.V;
+    for (int i = 0; i < views.V; i++) { sv.campos[i] = views.v[i].campos; sv.gcol[i] = views.v[i].gcol; }
+    // four pairs in flight, four workgroups per CU (128 VGPRs): eight in flight (160 VGPRs) and two or three (96, spilling) measure the same or worse
 #define GS_A8_GEOM(ACC_) hipLaunchKernelGGL((k_bwd_views_geom<ACC_, 4, 4>), grid, block, 0, s, p0, views, means3D, scaling_raw, rotation_raw, dL_dopacity_raw, dL_dmeans3D, dL_dscaling_raw, dL_drotation_raw, cap, first, last)
-        if (accumulate) {
-            GS_A8_GEOM(true);
-            hipLaunchKernelGGL((k_bwd_views_sh<true>), grid, block, lds, s, first, last, p0.deg, sv, means3D, f_dc, f_rest, dL_dmeans3D, dL_df_dc, dL_df_rest);
-        } else {
-            GS_A8_GEOM(false);
-            hipLaunchKernelGGL((k_bwd_views_sh<false>), grid, block, lds, s, first, last, p0.deg, sv, means3D, f_dc, f_rest, dL_dmeans3D, dL_df_dc, dL_df_rest);
-        }
-#undef GS_A8_GEOM
-        C3D_LAUNCH_CHECK();
-        return 0;
+    if (accumulate) {
+        GS_A8_GEOM(true);
+        hipLaunchKernelGGL((k_bwd_views_sh<true>), grid, block, lds, s, first, last, p0.deg, sv, means3D, f_dc, f_rest, dL_dmeans3D, dL_df_dc, dL_df_rest);
+    } else {
+        GS_A8_GEOM(false);
+        hipLaunchKernelGGL((k_bwd_views_sh<false>), grid, block, lds, s, first, last, p0.deg, sv, means3D, f_dc, f_rest, dL_dmeans3D, dL_df_dc, dL_df_rest);
     }
-    if (accumulate)
-        hipLaunchKernelGGL((k_preprocess_bwd_views<true>), grid, block, lds, s, p0, views, means3D, f_dc, f_rest, scaling_raw, rotation_raw, dL_dopacity_raw,
-                           dL_dmeans3D, dL_df_dc, dL_df_rest, dL_dscaling_raw, dL_drotation_raw, cap);
-    else
-        hipLaunchKernelGGL((k_preprocess_bwd_views<false>), grid, block, lds, s, p0, views, means3D, f_dc, f_rest, scaling_raw, rotation_raw, dL_dopacity_raw,
-                           dL_dmeans3D, dL_df_dc, dL_df_rest, dL_dscaling_raw, dL_drotation_raw, cap);
+#undef GS_A8_GEOM
     C3D_LAUNCH_CHECK();
     return 0;
 }

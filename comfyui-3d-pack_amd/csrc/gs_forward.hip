@@ -75,6 +75,7 @@ __device__ __forceinline__ void gs_project_one(int idx, const float3 m, const fl
         o.rect[idx] = make_uint2((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)x1 | ((uint32_t)y1 << 16));
         key = nt ? __float_as_uint(pv.z) : 0xFFFFFFFFu;
     } while (false);
+    if (rad == 0) o.rect[idx] = make_uint2(0u, 0u);      // culled: an empty rect (the emit-offset scan takes the tile count from the rect)
     o.radii[idx] = rad;
     o.tiles[idx] = nt;
     o.key0[idx] = key;
@@ -140,41 +141,13 @@ int gs_launch_preprocess(const GsParams& p, const float* means3D, const float* s
 }
 // ---- A1 for all views of a step at once ---------------------------------------------------------------------------------------------------
 // The per-view kernel streams 44 + 192 B of parameters per Gaussian for every view; over the 8 views of a training step that is 1.9 GB of the
-// same 236 MB.  Here a lane keeps its Gaussian (mean, 3D covariance, opacity in registers, the 48 SH coefficients in LDS) and walks the views:
-// parameters are read once per step, what is left per view is the 93 B of projected state it writes.  Same arithmetic, statement by statement,
-// as k_preprocess<true, true> (the per-view paths and the tests hold the two together).
+// same 236 MB.  Here a lane keeps its Gaussian (mean, 3D covariance, opacity and the 48 SH coefficients in registers) and walks the views:
+// parameters are read once per launch, what is left per view is the 93 B of projected state it writes.  Same arithmetic, statement by statement,
+// as k_preprocess<true, true> (both call gs_project_one; the tests hold the two together).
 struct GsPreView { GsPreCam cam; GsPreOut out; };
 struct GsPreViews { int V; GsPreView v[GS_MAX_BWD_VIEWS]; };
-__global__ void __launch_bounds__(128) k_preprocess_views(GsParams p, GsPreViews vs, const float* __restrict__ means3D, const float* __restrict__ f_dc,
-                                                           const float* __restrict__ f_rest, const float* __restrict__ opacities,
-                                                           const float* __restrict__ scales, const float* __restrict__ rotations) {
-    extern __shared__ float sh_lds[];
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    {
-        const size_t g0 = (size_t)blockIdx.x * blockDim.x;
-        sh_stage_in_split(f_dc, f_rest, g0, min((int)blockDim.x, p.N - (int)g0), sh_lds);
-        __syncthreads();
-    }
-    if (idx >= p.N) return;
-    const float3 m = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
-    float c3[6];
-    {
-        float3 s = make_float3(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]);
-        float4 q = *reinterpret_cast<const float4*>(rotations + 4 * idx);
-        s = make_float3(expf(s.x), expf(s.y), expf(s.z));
-        const float inv = 1.f / fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
-        q = make_float4(q.x * inv, q.y * inv, q.z * inv, q.w * inv);
-        cov3d_from_scale_rot(s, p.scale_modifier, q, c3);
-    }
-    const float opac = 1.f / (1.f + expf(-opacities[idx]));
-    const float* sh = sh_lds + threadIdx.x * SH_ROW;
-    for (int v = 0; v < vs.V; v++)
-        gs_project_one(idx, m, c3, [&]() { return opac; }, sh, (const float*)nullptr, vs.v[v].cam, p.W, p.H, p.gx, p.gy, p.deg, vs.v[v].out);
-}
-// Round 3: the same kernel with the lane's 48 SH coefficients in REGISTERS.  The LDS image above (196 B per lane) caps the kernel at 13 waves per CU (3 per SIMD)
-// -- half of its time is VALU work, half memory, and with so few waves the two do not overlap.  Here LDS is only the transposition buffer of the coalesced load
-// (44 rows at a time: 8.6 KB per workgroup), the coefficients move on into registers (28 + 48 VGPRs -> 6 waves per SIMD).  Same arithmetic: gs_project_one reads
-// sh[k] either way.
+// LDS is only the transposition buffer of the coalesced SH load (44 rows at a time: 8.6 KB per workgroup); the coefficients move on into registers
+// (28 + 48 VGPRs -> 5-6 waves per SIMD).  Round 3's first version kept a 196 B per lane LDS image instead: 3 waves per SIMD, 4 % slower (profiles/r03/).
 #define PRE_ROWS 44      // multiple of 4: the 16-byte loads of sh_stage_in_split stay aligned
 __global__ void __launch_bounds__(128) k_preprocess_views_r(GsParams p, GsPreViews vs, const float* __restrict__ means3D, const float* __restrict__ f_dc,
                                                              const float* __restrict__ f_rest, const float* __restrict__ opacities,
@@ -214,11 +187,6 @@ __global__ void __launch_bounds__(128) k_preprocess_views_r(GsParams p, GsPreVie
     for (int v = 0; v < vs.V; v++)
         gs_project_one(idx, m, c3, [&]() { return opac; }, sh, (const float*)nullptr, vs.v[v].cam, p.W, p.H, p.gx, p.gy, p.deg, vs.v[v].out);
 }
-static bool pre_sh_regs() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("C3D_PRE_REGS"); v = e ? atoi(e) != 0 : 1; }
-    return v != 0;
-}
 // geoms[v] / radii[v]: the state buffers of view v; views[v]: its camera (GsParams of that view; N, W, H, scale_modifier, deg must agree)
 int gs_launch_preprocess_views(const GsParams* views, int V, const GsGeom* geoms, int* const* radii, const float* means3D, const float* f_dc, const float* f_rest,
                                const float* opacity_raw, const float* scaling_raw, const float* rotation_raw, hipStream_t s) {
@@ -232,26 +200,17 @@ int gs_launch_preprocess_views(const GsParams* views, int V, const GsGeom* geoms
                             GsPreOut{geoms[i].rec0, geoms[i].tiles, geoms[i].rect, geoms[i].key[0], geoms[i].clamped, radii[i]}};
     }
     const int T = 128;
-    if (pre_sh_regs())
-        hipLaunchKernelGGL(k_preprocess_views_r, dim3(c3d_cdiv(views[0].N, T)), dim3(T), 0, s, views[0], pv, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw);
-    else
-        hipLaunchKernelGGL(k_preprocess_views, dim3(c3d_cdiv(views[0].N, T)), dim3(T), T * SH_ROW * sizeof(float), s, views[0], pv, means3D, f_dc, f_rest,
-                           opacity_raw, scaling_raw, rotation_raw);
+    hipLaunchKernelGGL(k_preprocess_views_r, dim3(c3d_cdiv(views[0].N, T)), dim3(T), 0, s, views[0], pv, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw);
     C3D_LAUNCH_CHECK();
     return 0;
 }
 
-// workgroup size of the raw-parameter preprocess (C3D_PRE_THREADS = 64 | 128 (default) | 256): the kernel stages 196 B of SH per lane in LDS, so smaller
-// workgroups interleave the load and compute phases of more workgroups per CU at the same wave count
-static int gs_pre_threads() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("C3D_PRE_THREADS"); v = e ? atoi(e) : 128; if (v != 64 && v != 128 && v != 256) v = 128; }
-    return v;
-}
+// 128-lane workgroups: the kernel stages 196 B of SH per lane in LDS, so smaller workgroups interleave the load and compute phases of more
+// workgroups per CU at the same wave count (64 and 256 measured worse, profiles/r02*)
 int gs_launch_preprocess_raw(const GsParams& p, const float* means3D, const float* f_dc, const float* f_rest, const float* opacity_raw,
                              const float* scaling_raw, const float* rotation_raw, GsGeom& g, int* radii, hipStream_t s) {
     if (p.N == 0) return 0;
-    const int T = gs_pre_threads();
+    const int T = 128;
     hipLaunchKernelGGL((k_preprocess<true, true>), dim3(c3d_cdiv(p.N, T)), dim3(T), T * SH_ROW * sizeof(float), s, p, means3D, f_dc, f_rest,
                        (const float*)nullptr, opacity_raw, scaling_raw, rotation_raw, (const float*)nullptr, g, radii);
     C3D_LAUNCH_CHECK();
@@ -259,50 +218,50 @@ int gs_launch_preprocess_raw(const GsParams& p, const float* means3D, const floa
 }
 
 // ------------------------------------------------------------------------------------------
-// A3 emit: Gaussians are visited in ascending (depth, id) rank, each writes one (tile, id) pair per
-// touched tile.  A stable sort by tile id afterwards leaves every tile's list depth-ordered.
+// A3 emit: Gaussians are visited in ascending (depth, id) rank, each contributes one (tile, id) pair per touched tile, row-major over its tile rect.
+// A stable sort by tile id afterwards leaves every tile's list depth-ordered.  blockIdx.y = view of a multi-view launch.
+// Load-balanced expansion (round 4): a workgroup owns 256 consecutive ranks = one contiguous stretch [B0, B1) of the pair list.  Their offsets, ids and
+// rects (all rank-ordered: coalesced loads, the one gather of the chain happened in the emit-offset scan) go to LDS, and the 256 lanes then walk the
+// OUTPUT positions -- lane t writes pairs B0 + t, B0 + t + 256, ... after an 8-step search for the Gaussian that owns each -- so every store instruction
+// writes 64 consecutive words and a Gaussian with 500 tiles costs its workgroup two extra iterations instead of parking one lane of a wave for 500.
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_emit(GsParams p, const uint32_t* __restrict__ order, const uint32_t* __restrict__ offsets,
-                                               const uint4* __restrict__ einfo, uint32_t* __restrict__ tkey, uint32_t* __restrict__ tval, uint32_t cap) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= p.N) return;
-    uint32_t off = (r == 0) ? 0u : offsets[r - 1];
-    if (offsets[r] == off) return;   // culled, or narrowed to no tiles
-    const uint32_t gid = order[r];
-    const uint4 ei = einfo[gid];     // ONE 16-byte gather per Gaussian: the tile rect (record-base scan, c3d_scan_u32's epilogue)
-    const int x0 = (int)(ei.y & 0xFFFFu), y0 = (int)(ei.y >> 16), x1 = (int)(ei.z & 0xFFFFu), y1 = (int)(ei.z >> 16);
-    for (int y = y0; y < y1; y++)
-        for (int x = x0; x < x1; x++) {
-            if (off < cap) { tkey[off] = (uint32_t)(y * p.gx + x); tval[off] = gid; }
-            off++;
-        }
+#define EMIT_RANKS 256
+__global__ void __launch_bounds__(EMIT_RANKS) k_emit(int N, int gx, const uint32_t* __restrict__ order, const uint32_t* __restrict__ offsets,
+                                                      const uint2* __restrict__ rsort, uint32_t* __restrict__ tkey, uint32_t* __restrict__ tval, uint32_t cap, size_t vs) {
+    __shared__ uint32_t s_end[EMIT_RANKS];      // inclusive scan: end of rank r's pairs
+    __shared__ uint32_t s_gid[EMIT_RANKS];
+    __shared__ uint2 s_rect[EMIT_RANKS];
+    order = c3d_view_ptr(order, vs); offsets = c3d_view_ptr(offsets, vs); rsort = c3d_view_ptr(rsort, vs); tkey = c3d_view_ptr(tkey, vs); tval = c3d_view_ptr(tval, vs);
+    const int r0 = blockIdx.x * EMIT_RANKS, t = threadIdx.x;
+    const int r = min(r0 + t, N - 1);           // ranks past the end repeat the last one's END: empty stretches
+    s_end[t] = offsets[r];
+    if (r0 + t < N) { s_gid[t] = order[r]; s_rect[t] = rsort[r]; }
+    const uint32_t B0 = r0 ? offsets[r0 - 1] : 0u;
+    __syncthreads();
+    const uint32_t B1 = min(s_end[EMIT_RANKS - 1], cap);
+    for (uint32_t o = B0 + (uint32_t)t; o < B1; o += EMIT_RANKS) {
+        int j = 0;                               // first rank whose end lies beyond o
+#pragma unroll
+        for (int step = EMIT_RANKS / 2; step >= 1; step >>= 1) j += (s_end[j + step - 1] <= o) ? step : 0;
+        const uint32_t start = j ? s_end[j - 1] : B0;
+        const uint2 rc = s_rect[j];
+        const uint32_t x0 = rc.x & 0xFFFFu, y0 = rc.x >> 16, w = (rc.y & 0xFFFFu) - x0, i = o - start;
+        uint32_t q = (uint32_t)__fdividef((float)i, (float)w);      // i < 2^24 (a rect holds at most gx * gy tiles): exact to +-1
+        if (q * w > i) q--; else if ((q + 1u) * w <= i) q++;
+        tkey[o] = (y0 + q) * (uint32_t)gx + x0 + (i - q * w);
+        tval[o] = s_gid[j];
+    }
 }
-// Round 3 (gs_bin_local): emission in Gaussian-ID order -- a Gaussian's pairs start at its record base (the ONE scan of the chain), reads are coalesced -- and the depth
-// order is established per tile afterwards (c3d_segment_sort_u32); no global depth sort, no second scan.
-__global__ void __launch_bounds__(256) k_emit_id(GsParams p, const uint32_t* __restrict__ tiles, const uint4* __restrict__ einfo, uint32_t* __restrict__ tkey,
-                                                  uint32_t* __restrict__ tval, uint32_t cap) {
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= p.N || tiles[gid] == 0u) return;
-    const uint4 ei = einfo[gid];
-    uint32_t off = ei.w;
-    const int x0 = (int)(ei.y & 0xFFFFu), y0 = (int)(ei.y >> 16), x1 = (int)(ei.z & 0xFFFFu), y1 = (int)(ei.z >> 16);
-    for (int y = y0; y < y1; y++)
-        for (int x = x0; x < x1; x++) {
-            if (off < cap) { tkey[off] = (uint32_t)(y * p.gx + x); tval[off] = (uint32_t)gid; }
-            off++;
-        }
-}
-int gs_launch_emit(const GsParams& p, const GsGeom& g, int res, const int* radii, GsBinning& b, hipStream_t s, uint32_t cap) {
-    (void)radii;
-    if (p.N == 0) return 0;
-    if (res < 0) hipLaunchKernelGGL(k_emit_id, dim3(c3d_cdiv(p.N, 256)), dim3(256), 0, s, p, g.tiles, g.einfo, b.tkey[0], b.tval[0], cap);      // res < 0: id order
-    else hipLaunchKernelGGL(k_emit, dim3(c3d_cdiv(p.N, 256)), dim3(256), 0, s, p, g.order[res], g.offsets, g.einfo, b.tkey[0], b.tval[0], cap);
+int gs_launch_emit(const GsParams& p, const GsGeom& g, int res, GsBinning& b, hipStream_t s, uint32_t cap, int V, size_t vs) {
+    if (p.N == 0 || V <= 0) return 0;
+    hipLaunchKernelGGL(k_emit, dim3(c3d_cdiv(p.N, EMIT_RANKS), V), dim3(EMIT_RANKS), 0, s, p.N, p.gx, g.order[res], g.offsets, g.rsort, b.tkey[0], b.tval[0], cap, vs);
     C3D_LAUNCH_CHECK();
     return 0;
 }
 
 // A5: [start,end) of every tile in the sorted pair list
-__global__ void __launch_bounds__(256) k_ranges(const uint32_t* __restrict__ tkey, uint2* __restrict__ ranges, long long D, const uint32_t* __restrict__ d_dev) {
+__global__ void __launch_bounds__(256) k_ranges(const uint32_t* __restrict__ tkey, uint2* __restrict__ ranges, long long D, const uint32_t* __restrict__ d_dev, size_t vs) {
+    tkey = c3d_view_ptr(tkey, vs); ranges = c3d_view_ptr(ranges, vs); d_dev = c3d_view_ptr(d_dev, vs);
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (d_dev) D = min((long long)*d_dev, D);
     if (i >= D) return;
@@ -311,124 +270,19 @@ __global__ void __launch_bounds__(256) k_ranges(const uint32_t* __restrict__ tke
     if (i == D - 1 || tkey[i + 1] != t) ranges[t].y = (uint32_t)(i + 1);
 }
 // `ranges` must be zero on entry: the binning stage clears it together with the tile-sort state (GsBinning::zero_bytes)
-int gs_launch_ranges(const GsBinning& b, int res, long long D, int tiles, hipStream_t s, const uint32_t* d_dev) {
-    (void)tiles;
-    if (D == 0) return 0;
-    hipLaunchKernelGGL(k_ranges, dim3(c3d_cdiv(D, 256)), dim3(256), 0, s, b.tkey[res], b.ranges, D, d_dev);
+int gs_launch_ranges(const GsBinning& b, int res, long long D, hipStream_t s, const uint32_t* d_dev, int V, size_t vs) {
+    if (D == 0 || V <= 0) return 0;
+    hipLaunchKernelGGL(k_ranges, dim3(c3d_cdiv(D, 256), V), dim3(256), 0, s, b.tkey[res], b.ranges, D, d_dev, vs);
     C3D_LAUNCH_CHECK();
     return 0;
 }
 
 // ------------------------------------------------------------------------------------------
-// A6 composite forward.  One 256-lane workgroup per 16x16 tile; wave w owns the 8x8 pixel quadrant
-// (w&1, w>>1), one pixel per lane.  Splat records are staged through LDS in rounds of 256 together
-// with a 4-bit "quadrants this splat can touch" mask (alpha >= 1/255 box vs quadrant).  Each wave turns
-// the masks into a 64-bit ballot per 64 staged splats and walks only its set bits (scalar loop), so a
-// wave never evaluates a splat that cannot contribute to its quadrant; the per-splat data is
-// wave-uniform in the inner loop (LDS broadcast reads).
-// ------------------------------------------------------------------------------------------
-#define FWD_ROUND 256   // splats staged per round (128 measures the same within noise)
-// RECORD: the walk also notes, per list position, which of the four quadrants blended the splat into at least one pixel (`pact`, one byte
-// per (tile, splat) pair, bit w = wave w).  The backward pass walks exactly those (quadrant, splat) pairs: at the BASELINE workload half of
-// the pairs that pass the geometric quadrant test are blended nowhere (occluded, or below 1/255 on the pixel grid), and deciding that
-// again cost the backward kernel a sixth of its VALU time.  Inference launches use RECORD = false and are unchanged.
-template <bool RECORD>
-__global__ void __launch_bounds__(256) k_composite_fwd(GsParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-                                                        const float4* __restrict__ rec0, const float4* __restrict__ rec1,
-                                                        const float4* __restrict__ rec2, float* __restrict__ out_color,
-                                                        float* __restrict__ out_depth, float* __restrict__ out_alpha,
-                                                        float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, uint8_t* __restrict__ pact, size_t pstride, int sh) {
-    __shared__ float4 s0[FWD_ROUND];
-    __shared__ float4 s1[FWD_ROUND];
-    __shared__ float4 s2[FWD_ROUND];
-    __shared__ uint32_t smask[FWD_ROUND];
-    __shared__ uint32_t sact[RECORD ? FWD_ROUND : 1];   // byte w of sact[j]: wave w blended slot j
-    int tx, ty;   // XCD-aware, load-balanced tile order (gs_block_tile).  Speed only, never correctness.
-    if (!gs_block_tile(blockIdx.x, p.gx, p.gy, tx, ty, sh)) return;
-    const int tile = ty * p.gx + tx;
-    const int lane = c3d_lane(), wave = threadIdx.x >> 6;
-    const int X0 = tx * C3D_TILE_X, Y0 = ty * C3D_TILE_Y;
-    const int pxi = X0 + ((wave & 1) << 3) + (lane & 7), pyi = Y0 + ((wave >> 1) << 3) + (lane >> 3);
-    const bool inside = pxi < p.W && pyi < p.H;
-    // A finished pixel (saturated, or outside the image) is parked at x = GS_PARKED: every later splat then evaluates to alpha = 0 there and
-    // fails the 1/255 test by itself, so the walk needs no per-splat bookkeeping of a `done` lane mask (the kernel is bound by instruction
-    // issue, scalar instructions included: this removes 9 of them per evaluation).
-    float pxf = inside ? (float)pxi : GS_PARKED;
-    const float pyf = (float)pyi;
-    const size_t pid = (size_t)pyi * p.W + pxi;     // formed here so that only the float coordinates stay live in the loop
-    const uint2 rg = ranges[tile];
-    const int todo = (int)(rg.y - rg.x);
-    float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f, A = 0.f;
-    uint32_t last = 0;
-
-    for (int base = 0; base < todo; base += FWD_ROUND) {
-        if (__syncthreads_count(pxf == GS_PARKED) == 256) break;
-        const int n = min(FWD_ROUND, todo - base);
-        gs_stage_round(point_list + rg.x + base, n, rec0, s0, s1, s2);
-        __syncthreads();
-        if ((int)threadIdx.x < n) {
-            const float4 a0 = s0[threadIdx.x], a1 = s1[threadIdx.x], a2 = s2[threadIdx.x];
-            smask[threadIdx.x] = gs_quadrant_mask(a0, a1, a2, X0, Y0);
-            // the conic stays in LDS pre-scaled by -log2(e)/2 (xx, yy) and -log2(e) (xy): the loop then feeds v_exp_f32 directly
-            s0[threadIdx.x] = make_float4(a0.x, a0.y, GS_CONIC_HALF * a0.z, GS_CONIC_FULL * a0.w);
-            s1[threadIdx.x].x = GS_CONIC_HALF * a1.x;
-        }
-        if (RECORD) sact[threadIdx.x] = 0u;
-        __syncthreads();
-        for (int c = 0; c < n; c += 64) {
-            const int jj = c + lane;
-            uint64_t m = __ballot(jj < n && ((smask[jj] >> wave) & 1u));
-            if (__ballot(pxf != GS_PARKED) == 0ull) break;           // every pixel of this quadrant has saturated
-            while (m) {
-                const int bitpos = (int)__builtin_ctzll(m);
-                const int j = c + bitpos;
-                m = gs_clear_bit64(m, bitpos);
-                const float4 a0 = s0[j], a1 = s1[j];
-                const float dx = a0.x - pxf, dy = a0.y - pyf;
-                const float power = gs_power(a0, a1.x, dx, dy);      // log2(e) * (-q/2): same sign as the exponent
-                const float alpha = fminf(0.99f, a1.y * __builtin_amdgcn_exp2f(power));
-                const bool ok = power <= 0.f && alpha >= 1.f / 255.f;
-                const float testT = T * (1.f - alpha);
-                const bool stop = ok && testT < 0.0001f;
-                pxf = stop ? GS_PARKED : pxf;
-                if (ok && !stop) {
-                    if (RECORD) ((uint8_t*)sact)[4 * j + wave] = 1;   // every blending lane stores the same byte: one LDS pass, no ballot
-                    const float4 a2 = s2[j];
-                    const float w = alpha * T;
-                    C0 += a1.z * w; C1 += a1.w * w; C2 += a2.x * w;
-                    Dp += a2.y * w; A += w;
-                    T = testT;
-                    last = (uint32_t)(base + j + 1);
-                }
-            }
-        }
-        if (RECORD) {
-            __syncthreads();
-            if ((int)threadIdx.x < n) {
-                const uint32_t a = sact[threadIdx.x];
-#pragma unroll
-                for (int w = 0; w < 4; w++) pact[(size_t)w * pstride + rg.x + base + threadIdx.x] = (uint8_t)((a >> (8 * w)) & 1u);   // one byte plane per quadrant (gs_pair_activity)
-            }
-        }
-    }
-    if (inside) {
-        const size_t P = (size_t)p.W * p.H;
-        final_T[pid] = T;
-        n_contrib[pid] = last;
-        out_color[pid] = C0 + T * p.bg[0];
-        out_color[P + pid] = C1 + T * p.bg[1];
-        out_color[2 * P + pid] = C2 + T * p.bg[2];
-        out_depth[pid] = Dp;
-        out_alpha[pid] = A;
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// A6, wave-autonomous form (round 3, the default): ONE WAVE per 8x8 pixel quadrant of a 16x16 tile -- a 64-lane workgroup, no workgroup-level
-// staging, no barrier, nothing shared with the other three quadrants of the tile but the tile's sorted splat list.
-// Why: profiles/r02z_sq_instruction_mix_lanes1.csv -- the 256-lane kernel above issues 26 VALU + 16-20 scalar + 4 LDS instructions per walked
-// (quadrant, splat) pair: a third of its issue slots are the scalar walk over a ballot (find-first-set, clear, address, exec save / restore around
-// the blend) and every round costs three workgroup barriers.  Here a wave
+// A6 composite forward: ONE WAVE per 8x8 pixel quadrant of a 16x16 tile -- a 64-lane workgroup, no workgroup-level staging, no barrier, nothing
+// shared with the other three quadrants of the tile but the tile's sorted splat list.  blockIdx.y = view of a multi-view launch.
+// Why (profiles/r02z_sq_instruction_mix_lanes1.csv): round 2's 256-lane kernel (one workgroup per tile, splat rounds staged through LDS) issued 26 VALU +
+// 16-20 scalar + 4 LDS instructions per walked (quadrant, splat) pair: a third of its issue slots were the scalar walk over a ballot (find-first-set,
+// clear, address, exec save / restore around the blend) and every round cost three workgroup barriers.  Here a wave
 //   * takes 64 list entries at a time, one per lane (id + the 48-B record straight into registers; the NEXT chunk's loads are issued before the
 //     current chunk is walked, so the gathers' latency hides under the walk),
 //   * tests its own quadrant only (gs_rect_hit: exact ellipse-vs-rectangle, the same test as gs_quadrant_mask), and COMPACTS the hits -- records,
@@ -441,22 +295,27 @@ __global__ void __launch_bounds__(256) k_composite_fwd(GsParams p, const uint2* 
 // (quadrant, splat) pair of which 44 % of the lanes blend.  Fewer instructions per pair is the only lever left in this decomposition.
 // RECORD: one scalar bit per walked list entry ("some lane blended it": s_cmp_lg_u64 + two s_addc_u32 shift it into a 64-bit mask), written out as
 // the quadrant's byte plane of the pair-activity record (gs_pair_activity) -- one coalesced byte store per 64 list entries.
-// Per-pixel arithmetic as k_composite_fwd (same images, n_contrib and gradients: tests/test_gs_hip.py::test_forward_kernels_agree) except the alpha
-// output, which this kernel takes from the telescoped sum 1 - T_final instead of a sixth accumulator (equal to rounding).
+// The alpha output is the telescoped sum 1 - T_final of the blend weights alpha_i T_i = T_i - T_{i+1} instead of a sixth accumulator (equal to rounding;
+// weights below ~6e-8 flush to 0 either way; tests/test_gs_hip.py holds it to the float64 restatement's accumulated sum).
 // ------------------------------------------------------------------------------------------
 #define FWQ_PAD 4
 #define FWQ_SLOTS (64 + FWQ_PAD)
 template <bool RECORD>
 __global__ void __launch_bounds__(64, 8) k_composite_fwd_w(GsParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-                                                            const float4* __restrict__ rec, float* __restrict__ out_color, float* __restrict__ out_depth,
-                                                            float* __restrict__ out_alpha, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-                                                            uint8_t* __restrict__ pact, size_t pstride, int sh) {
+                                                            const float4* __restrict__ rec, GsFwdViews vp, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+                                                            uint8_t* __restrict__ pact, size_t pstride, size_t vs) {
+    ranges = c3d_view_ptr(ranges, vs); point_list = c3d_view_ptr(point_list, vs); rec = c3d_view_ptr(rec, vs); final_T = c3d_view_ptr(final_T, vs);
+    n_contrib = c3d_view_ptr(n_contrib, vs); pact = c3d_view_ptr(pact, vs);
+    const float* __restrict__ bg = vp.bg[blockIdx.y];
+    float* __restrict__ out_color = vp.color[blockIdx.y];
+    float* __restrict__ out_depth = vp.depth[blockIdx.y];
+    float* __restrict__ out_alpha = vp.alpha[blockIdx.y];
     // the wave's compacted splat list, three 16-byte parts per entry at ONE running offset:
     //   part 0 (px, py, -log2e/2 A, -log2e B)   part 1 (-log2e/2 C, opacity, r, g)   part 2 (b, view depth, list position + 1 as int bits, -)
     __shared__ float4 cl[3][FWQ_SLOTS];
     const int b = blockIdx.x, q = (b >> 3) & 3;   // the four quadrants of a tile sit on ONE XCD (b & 7): they gather the same records
     int tx, ty;
-    if (!gs_block_tile((b & 7) | ((b >> 5) << 3), p.gx, p.gy, tx, ty, sh)) return;
+    if (!gs_block_tile((b & 7) | ((b >> 5) << 3), p.gx, p.gy, tx, ty)) return;
     const int tile = ty * p.gx + tx, lane = (int)threadIdx.x;
     const int QX = tx * C3D_TILE_X + ((q & 1) << 3), QY = ty * C3D_TILE_Y + ((q >> 1) << 3);
     const int pxi = QX + (lane & 7), pyi = QY + (lane >> 3);
@@ -551,79 +410,25 @@ __global__ void __launch_bounds__(64, 8) k_composite_fwd_w(GsParams p, const uin
         const size_t P = (size_t)p.W * p.H;
         final_T[pid] = T;
         n_contrib[pid] = (uint32_t)last;
-        out_color[pid] = C0 + T * p.bg[0];
-        out_color[P + pid] = C1 + T * p.bg[1];
-        out_color[2 * P + pid] = C2 + T * p.bg[2];
-        out_depth[pid] = Dp;
+        out_color[pid] = C0 + T * bg[0];
+        out_color[P + pid] = C1 + T * bg[1];
+        out_color[2 * P + pid] = C2 + T * bg[2];
+        if (out_depth) out_depth[pid] = Dp;
         out_alpha[pid] = 1.f - T;                 // sum of the blend weights alpha_i T_i = T_0 - T_final, telescoped (the weights are T_i - T_{i+1})
     }
 }
 
-// which forward compositing kernel: C3D_FWD_KERNEL = 1 (default) wave per quadrant (k_composite_fwd_w) | 0 workgroup per tile (k_composite_fwd)
-static int gs_fwd_kernel() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("C3D_FWD_KERNEL"); v = e ? atoi(e) : 1; if (v != 0 && v != 1) v = 1; }
-    return v;
-}
-int gs_launch_composite_fwd(const GsParams& p, const GsGeom& g, const GsBinning& b, int res, GsImage& im,
-                            float* out_color, float* out_depth, float* out_alpha, bool record_activity, hipStream_t s) {
+// One launch for V views (grid.y): view v's state lies v * vs bytes behind the pointers of g / b / im; its background and output planes come from vp.
+int gs_launch_composite_fwd(const GsParams& p, const GsGeom& g, const GsBinning& b, int res, GsImage& im, const GsFwdViews& vp, int V, size_t vs,
+                            bool record_activity, hipStream_t s) {
     const int tiles = p.gx * p.gy;
-    if (tiles == 0) return 0;
+    if (tiles == 0 || V <= 0) return 0;
     uint8_t* pact = record_activity ? gs_pair_activity(b, res) : nullptr;
-    if (gs_fwd_kernel() == 1) {
-        const dim3 grid(4 * gs_block_count(p.gx, p.gy, gs_supertile_shift()));
-        if (record_activity)
-            hipLaunchKernelGGL(k_composite_fwd_w<true>, grid, dim3(64), 0, s, p, b.ranges, b.tval[res], g.rec0, out_color, out_depth, out_alpha, im.final_T, im.n_contrib,
-                               pact, b.pair_stride, gs_supertile_shift());
-        else
-            hipLaunchKernelGGL(k_composite_fwd_w<false>, grid, dim3(64), 0, s, p, b.ranges, b.tval[res], g.rec0, out_color, out_depth, out_alpha, im.final_T, im.n_contrib,
-                               pact, b.pair_stride, gs_supertile_shift());
-    } else if (record_activity)
-        hipLaunchKernelGGL(k_composite_fwd<true>, dim3(gs_block_count(p.gx, p.gy, gs_supertile_shift())), dim3(256), gs_lds_pad(false), s, p, b.ranges, b.tval[res], g.rec0, g.rec1, g.rec2,
-                           out_color, out_depth, out_alpha, im.final_T, im.n_contrib, pact, b.pair_stride, gs_supertile_shift());
+    const dim3 grid(4 * gs_block_count(p.gx, p.gy), V);      // a multiple of 32 blocks per view: the XCD of a block (dispatch order % 8) does not depend on the view
+    if (record_activity)
+        hipLaunchKernelGGL(k_composite_fwd_w<true>, grid, dim3(64), 0, s, p, b.ranges, b.tval[res], g.rec0, vp, im.final_T, im.n_contrib, pact, b.pair_stride, vs);
     else
-        hipLaunchKernelGGL(k_composite_fwd<false>, dim3(gs_block_count(p.gx, p.gy, gs_supertile_shift())), dim3(256), gs_lds_pad(false), s, p, b.ranges, b.tval[res], g.rec0, g.rec1, g.rec2,
-                           out_color, out_depth, out_alpha, im.final_T, im.n_contrib, pact, b.pair_stride, gs_supertile_shift());
-    C3D_LAUNCH_CHECK();
-    return 0;
-}
-
-// ------------------------------------------------------------------------------------------
-// Pixel loss of the fused training step: L = scale * [ w_l1 mean|c - t| + w_l2 mean (c - t)^2 + w_a mean (alpha - ta)^2 ], with the rendered
-// colour clamped to [0,1] first (GaussianSplattingRenderer.render returns image.clamp(0,1)).  Writes dL/dcolor, dL/dalpha and adds the
-// loss value to *loss_out.
-// ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_loss_grad(const float* __restrict__ color, const float* __restrict__ alpha, const float* __restrict__ tcolor,
-                                                    const float* __restrict__ talpha, const float* __restrict__ cmask, long long P, float w_l1, float w_l2, float w_a, float scale,
-                                                    float* __restrict__ dcolor, float* __restrict__ dalpha, float* __restrict__ loss_out) {
-    __shared__ float red[4];
-    float l = 0.f;
-    const float inv3p = 1.f / (3.f * (float)P), invp = 1.f / (float)P;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (long long)gridDim.x * blockDim.x) {
-#pragma unroll
-        for (int ch = 0; ch < 3; ch++) {
-            const float c = color[ch * P + i];
-            const float cc = fminf(fmaxf(c, 0.f), 1.f);
-            const float mk = cmask ? cmask[i] : 1.f;              // optional per-pixel weight: loss on (image * mask) vs (target * mask)
-            const float d = (cc - tcolor[ch * P + i]) * mk;
-            l += (w_l1 * fabsf(d) + w_l2 * d * d) * inv3p;
-            const float pass = (c >= 0.f && c <= 1.f) ? 1.f : 0.f;
-            const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-            dcolor[ch * P + i] = scale * pass * mk * (w_l1 * sg + 2.f * w_l2 * d) * inv3p;
-        }
-        float da = 0.f;
-        if (talpha) { const float d = alpha[i] - talpha[i]; l += w_a * d * d * invp; da = scale * 2.f * w_a * d * invp; }
-        dalpha[i] = da;
-    }
-    l = c3d_wave_sum(l * scale);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = l;
-    __syncthreads();
-    if (threadIdx.x == 0 && loss_out) atomicAdd(loss_out, red[0] + red[1] + red[2] + red[3]);   // one atomic per workgroup, <= 1024 workgroups
-}
-int gs_launch_loss_grad(const float* color, const float* alpha, const float* tcolor, const float* talpha, const float* cmask, long long P, float w_l1, float w_l2, float w_a,
-                        float scale, float* dcolor, float* dalpha, float* loss_out, hipStream_t s) {
-    if (P == 0) return 0;
-    hipLaunchKernelGGL(k_loss_grad, dim3(min(c3d_cdiv(P, 256), 1024)), dim3(256), 0, s, color, alpha, tcolor, talpha, cmask, P, w_l1, w_l2, w_a, scale, dcolor, dalpha, loss_out);
+        hipLaunchKernelGGL(k_composite_fwd_w<false>, grid, dim3(64), 0, s, p, b.ranges, b.tval[res], g.rec0, vp, im.final_T, im.n_contrib, pact, b.pair_stride, vs);
     C3D_LAUNCH_CHECK();
     return 0;
 }

@@ -26,9 +26,10 @@ struct GsGeom {
     float4* rec1;
     float4* rec2;
     uint32_t* tiles;        // tiles touched per Gaussian (0 = culled)
-    uint2* rect;            // the tile rect those tiles form: {x0 | y0 << 16, x1 | y1 << 16} (written with `tiles`; undefined for culled Gaussians)
+    uint2* rect;            // the tile rect those tiles form: {x0 | y0 << 16, x1 | y1 << 16} (written with `tiles`; {0, 0} for culled Gaussians)
     uint32_t* key[2];       // depth-sort keys (float bits of view depth; 0xFFFFFFFF = culled)
     uint32_t* order[2];     // Gaussian ids, ping-pong; after stage 1 order[res] is rank -> id
+    uint2* rsort;           // the tile rects in depth-rank order (left behind by the emit-offset scan, which gathers them; read by k_emit)
     uint32_t* offsets;      // inclusive scan of the tile counts in depth-rank order
     uint4* einfo;           // per Gaussian with tiles: {0, x0 | y0<<16, x1 | y1<<16, record base} of its tile rect -- written by the record-base scan (coalesced)
     uint32_t* rbase;        // exclusive scan of `tiles` in Gaussian-id order: where this Gaussian's backward gradient records start
@@ -38,6 +39,7 @@ struct GsGeom {
     void* tmp_scan_a;       //   exclusive scan of `tiles` in Gaussian-id order -> rbase
     void* tmp_sort;         //   depth sort
     void* tmp_scan_b;       //   inclusive scan of the tile counts in depth-rank order -> offsets
+    size_t zero_off;        // byte offset of `meta` inside the buffer
     size_t zero_bytes;      // bytes to clear, starting at `meta`
     size_t bytes;
 };
@@ -53,6 +55,7 @@ static inline void gs_carve_geom(char* base, int N, GsGeom& g) {
     g.key[1] = (uint32_t*)take(4 * n);
     g.order[0] = (uint32_t*)take(4 * n);
     g.order[1] = (uint32_t*)take(4 * n);
+    g.rsort = (uint2*)take(8 * n);
     g.offsets = (uint32_t*)take(4 * n);
     g.einfo = (uint4*)take(16 * n);
     g.rbase = (uint32_t*)take(4 * n);
@@ -62,6 +65,7 @@ static inline void gs_carve_geom(char* base, int N, GsGeom& g) {
     g.tmp = g.tmp_scan_a = take(c3d_scan_tmp_bytes(n));
     g.tmp_scan_b = take(c3d_scan_tmp_bytes(n));
     g.tmp_sort = take(c3d_sort_tmp_bytes(n));                       // last: only its first c3d_sort_state_bytes need clearing
+    g.zero_off = meta_off;
     g.zero_bytes = (off - c3d_sort_tmp_bytes(n)) - meta_off + c3d_sort_state_bytes(n, 32);
     g.bytes = off;
 }
@@ -78,6 +82,7 @@ struct GsBinning {
     int* meta;
     void* tmp;       // tile-sort state; `ranges`, `meta` and the state are adjacent: ONE memset of zero_bytes from `ranges` clears them
     size_t pair_stride;   // elements between the four byte planes of the pair-activity record (gs_pair_activity)
+    size_t zero_off;      // byte offset of `ranges` inside the buffer
     size_t zero_bytes;
     size_t bytes;
 };
@@ -95,6 +100,7 @@ static inline void gs_carve_binning(char* base, long long D, int tiles, GsBinnin
     b.tmp = take(c3d_sort_tmp_bytes(d));
     int bits = 1;
     while ((1ll << bits) < (long long)tiles) bits++;
+    b.zero_off = ranges_off;
     b.zero_bytes = (off - c3d_sort_tmp_bytes(d)) - ranges_off + c3d_sort_state_bytes(d, bits);
     b.bytes = off;
 }
@@ -134,7 +140,24 @@ struct GsBwdView {
 };
 struct GsBwdViews { int V; GsBwdView v[GS_MAX_BWD_VIEWS]; };
 
-// kernels' launchers (gs_forward.hip / gs_backward.hip)
+// ---- multi-view launches (round 4) -----------------------------------------------------------------------------------------------------
+// The views of a group (<= GS_MAX_GROUP) keep their state in workspace slices at a uniform stride `vs`; every stage of the chain is ONE launch with
+// blockIdx.y = view, state pointers given for the group's first view.  What does not live in the slices -- the caller's output planes, loss targets,
+// pixel gradients, the per-view background -- travels as a table of per-view pointers in the kernel arguments.
+#define GS_MAX_GROUP GS_MAX_BWD_VIEWS
+struct GsFwdViews { const float* bg[GS_MAX_GROUP]; float* color[GS_MAX_GROUP]; float* depth[GS_MAX_GROUP]; float* alpha[GS_MAX_GROUP]; };
+// A7: pixel-space inputs of each view.  dcolor / ddepth / dalpha: caller-supplied gradients (NULL = zero).  The rest feeds the pixel loss of the fused training
+// step (LOSS instances), evaluated in the kernel's prologue where every lane owns one pixel anyway:
+//   L = scale * [ w_l1 mean|clamp(c) - t| m + w_l2 mean((clamp(c) - t) m)^2 + w_a mean(alpha - ta)^2 ],  m = cmask or 1
+// its gradient is ADDED to what dcolor holds (the MS-SSIM term's gradient, when there is one).  tile_loss [tiles] (view 0's, in the slice): every tile WRITES
+// its partial sum (8160 float atomics per view on one address cost the step 1.6 %); the sums are added in a fixed order afterwards: bit-reproducible.
+struct GsBwdPix {
+    const float* bg[GS_MAX_GROUP]; const float* dcolor[GS_MAX_GROUP]; const float* ddepth[GS_MAX_GROUP]; const float* dalpha[GS_MAX_GROUP];
+    const float* color[GS_MAX_GROUP]; const float* alpha[GS_MAX_GROUP]; const float* tcolor[GS_MAX_GROUP]; const float* talpha[GS_MAX_GROUP]; const float* cmask[GS_MAX_GROUP];
+};
+struct GsPixelLossW { float w_l1, w_l2, w_a, scale; float* tile_loss; };
+
+// kernels' launchers (gs_forward.hip / gs_backward.hip); V / vs: views of the launch and the byte stride between their slices (1 / 0 = one view)
 int gs_launch_preprocess_bwd_views(const GsParams& p0, const GsBwdViews& views, const float* means3D, const float* f_dc, const float* f_rest,
                                    const float* scaling_raw, const float* rotation_raw, float* dL_dopacity_raw, float* dL_dmeans3D, float* dL_df_dc,
                                    float* dL_df_rest, float* dL_dscaling_raw, float* dL_drotation_raw, bool accumulate, hipStream_t s, uint32_t cap,
@@ -150,25 +173,15 @@ int gs_launch_preprocess_bwd_raw(const GsParams& p, const GsGeom& g, const int* 
                                  const float* scaling_raw, const float* rotation_raw, const float* pairgrad, const uint8_t* pvalid, float* dL_dmean2D,
                                  float* dL_dopacity_raw, float* dL_dmeans3D, float* dL_df_dc, float* dL_df_rest, float* dL_dscaling_raw,
                                  float* dL_drotation_raw, bool accumulate, hipStream_t s, uint32_t cap = 0xFFFFFFFFu);
-int gs_launch_emit(const GsParams& p, const GsGeom& g, int res, const int* radii, GsBinning& b, hipStream_t s, uint32_t cap = 0xFFFFFFFFu);
-int gs_launch_loss_grad(const float* color, const float* alpha, const float* tcolor, const float* talpha, const float* cmask, long long P, float w_l1, float w_l2, float w_a,
-                        float scale, float* dcolor, float* dalpha, float* loss_out, hipStream_t s);
-int gs_launch_ranges(const GsBinning& b, int res, long long D, int tiles, hipStream_t s, const uint32_t* d_dev = nullptr);
-int gs_launch_composite_fwd(const GsParams& p, const GsGeom& g, const GsBinning& b, int res, GsImage& im,
-                            float* out_color, float* out_depth, float* out_alpha, bool record_activity, hipStream_t s);
-// Pixel loss of the fused training step, evaluated inside the backward compositing kernel's prologue (every lane owns one pixel there):
-//   L = scale * [ w_l1 mean|clamp(c) - t| m + w_l2 mean((clamp(c) - t) m)^2 + w_a mean(alpha - ta)^2 ],  m = cmask or 1
-// its gradient is ADDED to what dL_dcolor holds (NULL = nothing: the MS-SSIM term's gradient, when there is one) and the value to *loss_out.
-// Replaces a separate launch that wrote dL/dcolor, dL/dalpha (16 B per pixel) for this kernel to read back.
-struct GsPixelLoss { const float* color; const float* alpha; const float* tcolor; const float* talpha; const float* cmask; float w_l1, w_l2, w_a, scale; float* tile_loss; };
-// tile_loss [tiles]: every tile WRITES its partial sum (8160 float atomics per view on one address cost the step 1.6 %); gs_launch_sum_tile_loss adds the
-// partials of all views to *loss_out in a fixed order (one workgroup): the pixel-loss value is bit-reproducible.
-int gs_launch_sum_view_loss(const float* terms, int n, float* view_sum, hipStream_t s);      // on the view's lane: its per-tile partials (+ MS-SSIM term) -> one float
-int gs_launch_sum_tile_loss(const float* first_view_sum, size_t view_stride_bytes, int V, float* loss_out, hipStream_t s);   // after the join: the V view sums, in order
-int gs_launch_composite_bwd(const GsParams& p, const GsGeom& g, const GsBinning& b, int res, const GsImage& im,
-                            const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
-                            float* pairgrad /* [D][12] */, uint8_t* pvalid /* [D], cleared here */, long long pairs, hipStream_t s, uint32_t cap = 0xFFFFFFFFu,
-                            const GsPixelLoss* pixel_loss = nullptr, bool pvalid_cleared = false);
+int gs_launch_emit(const GsParams& p, const GsGeom& g, int res, GsBinning& b, hipStream_t s, uint32_t cap = 0xFFFFFFFFu, int V = 1, size_t vs = 0);
+int gs_launch_ranges(const GsBinning& b, int res, long long D, hipStream_t s, const uint32_t* d_dev = nullptr, int V = 1, size_t vs = 0);
+int gs_launch_composite_fwd(const GsParams& p, const GsGeom& g, const GsBinning& b, int res, GsImage& im, const GsFwdViews& vp, int V, size_t vs,
+                            bool record_activity, hipStream_t s);
+int gs_launch_sum_view_loss(const float* terms, int n, float* view_sum, int V, size_t vs, hipStream_t s);   // per view: its per-tile partials (+ MS-SSIM term) -> one float
+int gs_launch_sum_tile_loss(const float* first_view_sum, size_t view_stride_bytes, int V, float* loss_out, hipStream_t s);   // the V view sums, in order, added to *loss_out
+int gs_launch_composite_bwd(const GsParams& p, const GsGeom& g, const GsBinning& b, int res, const GsImage& im, const GsBwdPix& px, bool depth,
+                            float* pairgrad /* [D][12] */, uint8_t* pvalid /* [D], clear on entry */, hipStream_t s, uint32_t cap = 0xFFFFFFFFu,
+                            const GsPixelLossW* pixel_loss = nullptr, int V = 1, size_t vs = 0);
 int gs_launch_preprocess_bwd(const GsParams& p, const GsGeom& g, const int* radii, const float* means3D, const float* shs,
                              const float* colors_precomp, const float* scales, const float* rotations, const float* cov3D_precomp,
                              const float* pairgrad, const uint8_t* pvalid, float* dL_dmean2D, float* dL_dcolors, float* dL_dopacity,

@@ -3,7 +3,6 @@
 // MVs_Algorithms/GaussianSplatting/main_3DGS_renderer.py:927-936 calls); SH basis and signs as in
 // shared_utils/sh_utils.py:26-43,57-100; quaternion (w,x,y,z) as in main_3DGS_renderer.py:84-102.
 #pragma once
-#include <stdlib.h>
 #include "c3d_common.h"
 
 #define GS_SH_C0 0.28209479177387814f
@@ -150,10 +149,6 @@ __device__ __forceinline__ float alpha_extent(float opacity, float var) {
 #define GS_CONIC_HALF (-0.72134752044448170368f)   // -log2(e) / 2
 #define GS_CONIC_FULL (-1.44269504088896340736f)   // -log2(e)
 
-// x coordinate of a pixel that takes no further splats (k_composite_fwd): far enough that any conic gives exp2(-huge) = 0, small enough that
-// nothing overflows (1e9^2 * |conic| stays far below FLT_MAX, so no inf - inf)
-#define GS_PARKED 1.0e9f
-
 // clear one bit of a wave-uniform 64-bit mask: one scalar instruction (hipcc expands m &= m - 1 into add / addc / and)
 __device__ __forceinline__ uint64_t gs_clear_bit64(uint64_t m, int bit) {
     asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(bit));
@@ -186,19 +181,7 @@ __device__ __forceinline__ bool gs_block_tile(int b, int gx, int gy, int& tx, in
     ty = (sy << sh) + (sub >> sh);
     return tx < gx && ty < gy;
 }
-static inline int gs_supertile_shift() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("C3D_SUPERTILE_SHIFT"); v = e ? atoi(e) : 1; if (v < 0 || v > 3) v = 1; }
-    return v;
-}
-// Extra (unused) dynamic LDS per compositing workgroup: caps how many of them a CU holds, so that the kernels of the other view lanes
-// (latency-bound sorts, streaming preprocess) find wave slots beside them instead of waiting for the compositing grid to drain.
-// C3D_FWD_LDS_PAD / C3D_BWD_LDS_PAD in bytes (experiment knobs; defaults chosen from profiles/r02*_lds_pad_sweep.txt).
-static inline int gs_lds_pad(bool bwd) {
-    static int v[2] = {-1, -1};
-    if (v[bwd] < 0) { const char* e = getenv(bwd ? "C3D_BWD_LDS_PAD" : "C3D_FWD_LDS_PAD"); v[bwd] = e ? atoi(e) : 0; if (v[bwd] < 0 || v[bwd] > 100000) v[bwd] = 0; }
-    return v[bwd];
-}
+// (supertile sizes 1x1 ... 4x4 measure alike, 8x8 loses the balance again: profiles/r02*; sh = 1 is what every launch uses)
 static inline int gs_block_count(int gx, int gy, int sh = 1) {
     const int S = ((gx + (1 << sh) - 1) >> sh) * ((gy + (1 << sh) - 1) >> sh);
     return 8 * (1 << (2 * sh)) * ((S + 7) / 8);
@@ -241,14 +224,6 @@ __device__ __forceinline__ bool gs_rect_hit(const float4 a0, const float4 a1, co
     const float thr = 2.f * __logf(255.f * a1.y) * 1.0005f + 1e-3f;
     return quad_form_min_on_rect(a0.z, a0.w, a1.x, a0.x, a0.y, rx0, rx0 + w, ry0, ry0 + h) <= thr;
 }
-__device__ __forceinline__ uint32_t gs_quadrant_mask(const float4 a0, const float4 a1, const float4 a2, int X0, int Y0) {
-    uint32_t m = 0;
-#pragma unroll
-    for (int q = 0; q < 4; q++)
-        if (gs_rect_hit(a0, a1, a2, (float)(X0 + 8 * (q & 1)), (float)(Y0 + 8 * (q >> 1)))) m |= 1u << q;
-    return m;
-}
-
 // ---- lane selects on wave masks held in SGPR pairs ----------------------------------------------------------------------------------
 // Written as asm because hipcc picks the VOP2 form that reads VCC (v_cndmask_b32_e32 ..., vcc), which issues ~5x slower on gfx950 than the
 // VOP3 form with an SGPR-pair mask (profiles/r01f_valu_rate_microbench.txt: 22.9 vs 4.7 cycles per wave-instruction).

@@ -2258,8 +2258,7 @@ int c3d_mesh_train_views(const c3d_mesh_view* views, int32_t n_views, const floa
     const long long P = (long long)d0.H * d0.W;
     const int nblk = c3d_cdiv(P, 256) < 1024 ? c3d_cdiv(P, 256) : 1024;
     const size_t ntex = 3 * (size_t)d0.Ht * d0.Wt;
-    hipStream_t ls[C3D_MAX_LANES];
-    int L = 1;
+    C3dLanes ln;
     MeshStepWs w;
     const bool fused = view_pixel_fused();
     if (fused) {      // the shared integer planes are cleared on the caller's stream BEFORE the lanes fork from it
@@ -2267,7 +2266,9 @@ int c3d_mesh_train_views(const c3d_mesh_view* views, int32_t n_views, const floa
         C3D_CHECK(hipMemsetAsync(w.acc.lo, 0, 8 * ntex + 64, s0));
         C3D_CHECK(hipMemsetAsync(w.acc.hi, 0, 8 * ntex, s0));
     }
-    if (c3d_lanes_fork(s0, lanes, n_views, ls, &L)) return -1;
+    if (ln.fork(s0, lanes, n_views)) return -1;
+    hipStream_t* ls = ln.s;
+    const int L = ln.L;
     carve_mesh_step((char*)workspace, d0.V, d0.T, d0.H, d0.W, d0.Ht, d0.Wt, n_views, L, w);
     int rc_all = 0;
     for (int l = 0; l < L && !rc_all && !fused; l++)
@@ -2300,7 +2301,7 @@ int c3d_mesh_train_views(const c3d_mesh_view* views, int32_t n_views, const floa
         } while (0);
         rc_all = rc;
     }
-    if (c3d_lanes_join(s0, ls, L, "c3d_mesh_train_views") && !rc_all) rc_all = -1;
+    if (ln.join("c3d_mesh_train_views") && !rc_all) rc_all = -1;
     if (rc_all) return rc_all;
     {
         C3dProfScope ps(C3D_P_OTHER, s0);

@@ -14,7 +14,13 @@
 //   * what a tile publishes is ONE self-contained word {flag, value} written and polled with relaxed agent-scope atomics (sc1:
 //     write-through / L1-bypassing on gfx950), so no fence is needed and the 8 non-coherent XCD L2s cannot serve a stale flag;
 //   * every spin is bounded: on a timeout the kernel raises an error word the host turns into an exception, it never hangs the GPU.
+//
+// Round 4: every kernel takes a VIEW dimension (blockIdx.y = view, `vs` = bytes between the workspace slices of consecutive views; all per-view
+// pointers -- keys, values, state, device-resident counts -- are given for view 0 and advanced by blockIdx.y * vs).  The V views of a step are
+// sorted / scanned by ONE launch per stage: a 1 M-key pass is 16 MB of traffic and 17 us of fixed latencies, eight of them in one launch are
+// bandwidth-sized work.  Tickets, status words and look-backs are per view (a workgroup only ever waits for lower tickets of ITS view); the error word is shared.
 #include "c3d_common.h"
+
 
 #define SCAN_THREADS 256
 #define SCAN_ITEMS 8
@@ -47,36 +53,75 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* lds, u
 // ------------------------------------------------------------------------------------------
 // Single-pass scan.  State (zeroed before every launch): [0] ticket, [1] error, then one 64-bit word per tile:
 // flag << 32 | value with flag 1 = "tile aggregate", 2 = "inclusive prefix".  Wave 0 looks back over 64 predecessors per step.
-// GATHER: element i of the input is in[idx[i]] (the tile counts read in depth-rank order: the gather kernel is folded in).
+// GATHER (the emit-offset scan): element i of the input is the AREA of the tile rect rect[idx[i]] (in = the rects as uint2 {x0 | y0 << 16, x1 | y1 << 16},
+// idx = the depth order), and the gathered rect is left behind in rank order (tail.rsort[i], coalesced) so that the emission needs no gather of its own: ONE random
+// 8-byte access per Gaussian and view instead of two (a 4-byte count here, a 16-byte rect in k_emit), each of which costs a whole 64-byte line.
 // `tail` (optional): what used to be k_pair_count -- the workgroup that owns element n-1 knows the grand total and leaves
 // min(total, cap) in tail_meta[0], the overflow flag / largest total in tail_status.
 // ------------------------------------------------------------------------------------------
 #define LB_AGG 1ull
 #define LB_INCL 2ull
-struct ScanTail { uint32_t* meta; uint32_t* status; uint32_t cap; const uint2* rect; uint4* einfo; };   // rect / einfo: see c3d_scan_u32_einfo
+struct ScanTail { uint32_t* meta; uint32_t* status; uint32_t cap; const uint2* rect; uint4* einfo; uint2* rsort; };   // rect / einfo: see c3d_scan_u32_einfo; rsort: GATHER
+__device__ __forceinline__ uint32_t rect_area(uint2 r) { return ((r.y & 0xFFFFu) - (r.x & 0xFFFFu)) * ((r.y >> 16) - (r.x >> 16)); }
 
+// Data movement (round 4: with V views per launch the scans are bandwidth-sized work, and eight 4-byte accesses per lane at a 32-byte lane stride cost eight
+// partially used cache lines per wave instruction): a tile is two halves of 1024 elements and lane t owns elements [4t, 4t + 4) of EACH half -- every load / store
+// is 16 bytes per lane on consecutive addresses.  The block scan runs over the (first-half sum, second-half sum) pair of every lane at once.
 template <bool EXCL, bool GATHER>
 __global__ void __launch_bounds__(SCAN_THREADS) k_scan_lb(const uint32_t* __restrict__ in, const uint32_t* __restrict__ idx, uint32_t* __restrict__ out, size_t n,
-                                                           uint32_t* __restrict__ state, uint32_t* __restrict__ err, ScanTail tail) {
-    __shared__ uint32_t lds[4];
+                                                           uint32_t* __restrict__ state, uint32_t* __restrict__ err, ScanTail tail, size_t vs) {
+    __shared__ uint32_t lds[2][4];
     __shared__ uint32_t s_tile, s_prefix;
+    in = c3d_view_ptr(in, vs); idx = c3d_view_ptr(idx, vs); out = c3d_view_ptr(out, vs); state = c3d_view_ptr(state, vs);
+    tail.meta = c3d_view_ptr(tail.meta, vs); tail.rect = c3d_view_ptr(tail.rect, vs); tail.einfo = c3d_view_ptr(tail.einfo, vs);   // err / tail.status: shared by the views
+    tail.rsort = c3d_view_ptr(tail.rsort, vs);
     unsigned long long* status = reinterpret_cast<unsigned long long*>(state + 2);
     if (threadIdx.x == 0) s_tile = atomicAdd(&state[0], 1u);
     __syncthreads();
     const uint32_t tile = s_tile;
-    const size_t base = (size_t)tile * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
     if ((size_t)tile * SCAN_TILE >= n) return;
-    uint32_t v[SCAN_ITEMS];
-    uint32_t s = 0;
+    const int lane = c3d_lane(), wave = threadIdx.x >> 6;
+    uint32_t v[2][4];
+    uint32_t hs[2];
 #pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; i++) {
-        v[i] = (base + i < n) ? (GATHER ? in[idx[base + i]] : in[base + i]) : 0u;
-        s += v[i];
+    for (int h = 0; h < 2; h++) {
+        const size_t b = (size_t)tile * SCAN_TILE + (size_t)h * (SCAN_TILE / 2) + (size_t)threadIdx.x * 4;
+        if (GATHER) {
+            const uint2* rects = reinterpret_cast<const uint2*>(in);
+            uint2 rc[4];
+            if (b + 3 < n) {
+                const uint4 j = *reinterpret_cast<const uint4*>(idx + b);
+                rc[0] = rects[j.x]; rc[1] = rects[j.y]; rc[2] = rects[j.z]; rc[3] = rects[j.w];
+                *reinterpret_cast<uint4*>(tail.rsort + b) = make_uint4(rc[0].x, rc[0].y, rc[1].x, rc[1].y);
+                *reinterpret_cast<uint4*>(tail.rsort + b + 2) = make_uint4(rc[2].x, rc[2].y, rc[3].x, rc[3].y);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; i++) { rc[i] = (b + i < n) ? rects[idx[b + i]] : make_uint2(0u, 0u); if (b + i < n) tail.rsort[b + i] = rc[i]; }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) v[h][i] = rect_area(rc[i]);
+        } else if (b + 3 < n) {
+            const uint4 q = *reinterpret_cast<const uint4*>(in + b); v[h][0] = q.x; v[h][1] = q.y; v[h][2] = q.z; v[h][3] = q.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) v[h][i] = (b + i < n) ? in[b + i] : 0u;
+        }
+        hs[h] = v[h][0] + v[h][1] + v[h][2] + v[h][3];
     }
-    uint32_t tot;
-    const uint32_t ex = block_excl_scan(s, lds, &tot);
+    // block-wide exclusive scan of both half sums at once
+    uint32_t inc0 = c3d_wave_incl_scan(hs[0]), inc1 = c3d_wave_incl_scan(hs[1]);
+    if (lane == 63) { lds[0][wave] = inc0; lds[1][wave] = inc1; }
+    __syncthreads();
+    uint32_t ex[2] = {inc0 - hs[0], inc1 - hs[1]}, tot0 = 0, tot1 = 0;
+#pragma unroll
+    for (int w = 0; w < SCAN_THREADS / 64; w++) {
+        const uint32_t t0 = lds[0][w], t1 = lds[1][w];
+        if (w < wave) { ex[0] += t0; ex[1] += t1; }
+        tot0 += t0; tot1 += t1;
+    }
+    ex[1] += tot0;                                   // the second half follows the whole first half
+    const uint32_t tot = tot0 + tot1;
     if (threadIdx.x < 64) {
-        const int lane = threadIdx.x;
         if (lane == 0) st_agent64(&status[tile], ((tile == 0 ? LB_INCL : LB_AGG) << 32) | tot);
         uint32_t prefix = 0;
         if (tile > 0) {
@@ -110,57 +155,103 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_lb(const uint32_t* __rest
         if (lane == 0) s_prefix = prefix;
     }
     __syncthreads();
-    uint32_t run = ex + s_prefix;
+    const uint32_t pre = s_prefix;
 #pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; i++) {
-        if (EXCL) { if (base + i < n) out[base + i] = run; run += v[i]; }
-        else      { run += v[i]; if (base + i < n) out[base + i] = run; }
-    }
-    if (tail.einfo) {   // epilogue of the record-base scan: {0, tile rect, record base} per element, coalesced (what k_emit and the backward pass gather)
-        uint32_t rb = ex + s_prefix;
+    for (int h = 0; h < 2; h++) {
+        const size_t b = (size_t)tile * SCAN_TILE + (size_t)h * (SCAN_TILE / 2) + (size_t)threadIdx.x * 4;
+        uint32_t run = pre + ex[h], o[4], e[4];
 #pragma unroll
-        for (int i = 0; i < SCAN_ITEMS; i++) {
-            if (base + i < n && v[i]) { const uint2 rc = tail.rect[base + i]; tail.einfo[base + i] = make_uint4(0u, rc.x, rc.y, rb); }
-            rb += v[i];
+        for (int i = 0; i < 4; i++) { e[i] = run; run += v[h][i]; o[i] = EXCL ? e[i] : run; }
+        if (b + 3 < n) *reinterpret_cast<uint4*>(out + b) = make_uint4(o[0], o[1], o[2], o[3]);
+        else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) if (b + i < n) out[b + i] = o[i];
         }
-    }
-    if (tail.meta && base < n && base + SCAN_ITEMS >= n) {      // this thread owns element n-1: `run` is the grand total
-        const uint32_t total = run;
-        tail.meta[0] = total < tail.cap ? total : tail.cap;
-        if (tail.status) { if (total > tail.cap) atomicOr(&tail.status[0], 1u); atomicMax(&tail.status[1], total); }
+        if (tail.einfo) {   // epilogue of the record-base scan: {0, tile rect, record base} per element (what k_emit and the backward pass gather)
+            if (b + 3 < n) {
+                const uint4 r01 = *reinterpret_cast<const uint4*>(tail.rect + b), r23 = *reinterpret_cast<const uint4*>(tail.rect + b + 2);
+                if (v[h][0]) tail.einfo[b] = make_uint4(0u, r01.x, r01.y, e[0]);
+                if (v[h][1]) tail.einfo[b + 1] = make_uint4(0u, r01.z, r01.w, e[1]);
+                if (v[h][2]) tail.einfo[b + 2] = make_uint4(0u, r23.x, r23.y, e[2]);
+                if (v[h][3]) tail.einfo[b + 3] = make_uint4(0u, r23.z, r23.w, e[3]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; i++) if (b + i < n && v[h][i]) { const uint2 rc = tail.rect[b + i]; tail.einfo[b + i] = make_uint4(0u, rc.x, rc.y, e[i]); }
+            }
+        }
+        if (tail.meta && b < n && b + 4 >= n) {      // this lane owns element n-1: `run` is the grand total (elements past n are zeros)
+            const uint32_t total = run;
+            tail.meta[0] = total < tail.cap ? total : tail.cap;
+            if (tail.status) { if (total > tail.cap) atomicOr(&tail.status[0], 1u); atomicMax(&tail.status[1], total); }
+        }
     }
 }
 
 size_t c3d_scan_tmp_bytes(size_t n) { return c3d_align(8 + sizeof(unsigned long long) * (size_t)(c3d_cdiv((long long)(n ? n : 1), SCAN_TILE) + 1)); }
 
 // `zero_state`: false when the caller has already cleared tmp (one memset for several primitives of a view)
-static int scan_launch(const uint32_t* in, const uint32_t* idx, uint32_t* out, size_t n, bool exclusive, void* tmp, hipStream_t s, bool zero_state, ScanTail tail, uint32_t* err) {
-    if (n == 0) return 0;
-    if (zero_state) C3D_CHECK(hipMemsetAsync(tmp, 0, c3d_scan_tmp_bytes(n), s));
-    const int nb = c3d_cdiv((long long)n, SCAN_TILE);
+static int scan_launch(const uint32_t* in, const uint32_t* idx, uint32_t* out, size_t n, bool exclusive, void* tmp, hipStream_t s, bool zero_state, ScanTail tail, uint32_t* err,
+                       int V = 1, size_t vs = 0) {
+    if (n == 0 || V <= 0) return 0;
+    if (zero_state) {
+        if (V != 1) { c3d_set_error("scan: a multi-view launch clears its state through c3d_zero_views"); return -1; }
+        C3D_CHECK(hipMemsetAsync(tmp, 0, c3d_scan_tmp_bytes(n), s));
+    }
+    const dim3 grid(c3d_cdiv((long long)n, SCAN_TILE), V);
     uint32_t* st = (uint32_t*)tmp;
     if (!err) err = st + 1;
     if (idx) {
-        if (exclusive) hipLaunchKernelGGL((k_scan_lb<true, true>), dim3(nb), dim3(SCAN_THREADS), 0, s, in, idx, out, n, st, err, tail);
-        else           hipLaunchKernelGGL((k_scan_lb<false, true>), dim3(nb), dim3(SCAN_THREADS), 0, s, in, idx, out, n, st, err, tail);
+        hipLaunchKernelGGL((k_scan_lb<false, true>), grid, dim3(SCAN_THREADS), 0, s, in, idx, out, n, st, err, tail, vs);
     } else {
-        if (exclusive) hipLaunchKernelGGL((k_scan_lb<true, false>), dim3(nb), dim3(SCAN_THREADS), 0, s, in, idx, out, n, st, err, tail);
-        else           hipLaunchKernelGGL((k_scan_lb<false, false>), dim3(nb), dim3(SCAN_THREADS), 0, s, in, idx, out, n, st, err, tail);
+        if (exclusive) hipLaunchKernelGGL((k_scan_lb<true, false>), grid, dim3(SCAN_THREADS), 0, s, in, idx, out, n, st, err, tail, vs);
+        else           hipLaunchKernelGGL((k_scan_lb<false, false>), grid, dim3(SCAN_THREADS), 0, s, in, idx, out, n, st, err, tail, vs);
     }
     C3D_LAUNCH_CHECK();
     return 0;
 }
 int c3d_scan_u32(const uint32_t* in, uint32_t* out, size_t n, bool exclusive, void* tmp, hipStream_t s, bool zero_state, uint32_t* err) {
-    return scan_launch(in, nullptr, out, n, exclusive, tmp, s, zero_state, ScanTail{nullptr, nullptr, 0u, nullptr, nullptr}, err);
+    return scan_launch(in, nullptr, out, n, exclusive, tmp, s, zero_state, ScanTail{nullptr, nullptr, 0u, nullptr, nullptr, nullptr}, err);
+}
+
+// ------------------------------------------------------------------------------------------
+// ONE launch clears up to three byte regions in each of V workspace slices (the states of a view's single-pass primitives, its tile ranges, its
+// "record written" bytes): region r of view v = base0 + v * vs + off[r], bytes[r] long (multiples of 4; 16-byte aligned starts).
+// Replaces 3 V hipMemsetAsync calls (each of them a kernel launch of its own).
+// ------------------------------------------------------------------------------------------
+struct ZeroRegions { size_t off[3], bytes[3]; };
+__global__ void __launch_bounds__(256) k_zero_views(char* __restrict__ base0, size_t vs, ZeroRegions zr) {
+    const int r = blockIdx.z;
+    char* p = base0 + (size_t)blockIdx.y * vs + zr.off[r];
+    const size_t n16 = zr.bytes[r] / 16, n4 = (zr.bytes[r] % 16) / 4;
+    uint4* p16 = reinterpret_cast<uint4*>(p);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) p16[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (blockIdx.x == 0 && threadIdx.x < n4) reinterpret_cast<uint32_t*>(p + n16 * 16)[threadIdx.x] = 0u;
+}
+int c3d_zero_views(void* base0, size_t vs, int V, const size_t* off, const size_t* bytes, int regions, hipStream_t s) {
+    if (V <= 0 || regions <= 0) return 0;
+    if (regions > 3) { c3d_set_error("c3d_zero_views: at most three regions"); return -1; }
+    ZeroRegions zr{};
+    size_t most = 0;
+    for (int r = 0; r < regions; r++) {
+        if ((off[r] & 15) || (bytes[r] & 3)) { c3d_set_error("c3d_zero_views: region %d is not 16-byte aligned / a multiple of 4 bytes", r); return -1; }
+        zr.off[r] = off[r]; zr.bytes[r] = bytes[r];
+        if (bytes[r] > most) most = bytes[r];
+    }
+    int nb = c3d_cdiv((long long)(most / 16 + 1), 256 * 4);      // four 16-byte stores per thread
+    if (nb < 1) nb = 1;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(k_zero_views, dim3(nb, V, regions), dim3(256), 0, s, (char*)base0, vs, zr);
+    C3D_LAUNCH_CHECK();
+    return 0;
 }
 // exclusive scan of `in` (tile counts in Gaussian-id order) -> out (record bases), plus einfo[i] = {0, rect[i].x, rect[i].y, out[i]} where in[i] != 0
 int c3d_scan_u32_einfo(const uint32_t* in, uint32_t* out, size_t n, void* tmp, hipStream_t s, bool zero_state, uint32_t* err, const uint2* rect, uint4* einfo,
-                       uint32_t* tail_meta, uint32_t* tail_status, uint32_t tail_cap) {
-    return scan_launch(in, nullptr, out, n, true, tmp, s, zero_state, ScanTail{tail_meta, tail_status, tail_cap, rect, einfo}, err);
+                       int V, size_t vs) {
+    return scan_launch(in, nullptr, out, n, true, tmp, s, zero_state, ScanTail{nullptr, nullptr, 0xFFFFFFFFu, rect, einfo, nullptr}, err, V, vs);
 }
-int c3d_scan_gather_u32(const uint32_t* in, const uint32_t* idx, uint32_t* out, size_t n, bool exclusive, void* tmp, hipStream_t s, bool zero_state,
-                        uint32_t* tail_meta, uint32_t* tail_status, uint32_t tail_cap, uint32_t* err) {
-    return scan_launch(in, idx, out, n, exclusive, tmp, s, zero_state, ScanTail{tail_meta, tail_status, tail_cap, nullptr, nullptr}, err);
+int c3d_scan_rect_gather(const uint2* rect, const uint32_t* idx, uint32_t* out, uint2* rsort, size_t n, void* tmp, hipStream_t s, bool zero_state,
+                         uint32_t* tail_meta, uint32_t* tail_status, uint32_t tail_cap, uint32_t* err, int V, size_t vs) {
+    return scan_launch(reinterpret_cast<const uint32_t*>(rect), idx, out, n, false, tmp, s, zero_state, ScanTail{tail_meta, tail_status, tail_cap, nullptr, nullptr, rsort}, err, V, vs);
 }
 uint32_t* c3d_scan_error_word(void* tmp) { return (uint32_t*)tmp + 1; }
 
@@ -196,8 +287,9 @@ uint32_t* c3d_scan_error_word(void* tmp) { return (uint32_t*)tmp + 1; }
 static inline size_t sort_pass_words(size_t nb) { return RS_RADIX * (nb + nb / RS_GROUP + 1); }
 
 __global__ void __launch_bounds__(RS_THREADS) k_radix_hist_all(const uint32_t* __restrict__ keys, uint32_t* __restrict__ ghist, size_t n,
-                                                                const uint32_t* __restrict__ n_dev, int passes) {
+                                                                const uint32_t* __restrict__ n_dev, int passes, size_t vs) {
     __shared__ uint32_t h[RS_MAX_PASSES][RS_RADIX];
+    keys = c3d_view_ptr(keys, vs); ghist = c3d_view_ptr(ghist, vs); n_dev = c3d_view_ptr(n_dev, vs);
     if (n_dev) n = min((size_t)*n_dev, n);      // element count resident on the device (no host round trip)
     const size_t base = (size_t)blockIdx.x * RS_TILE;
     if (base >= n) return;                      // capacity-sized launch: nothing here
@@ -239,14 +331,17 @@ __device__ __forceinline__ uint32_t rs_wait(const uint32_t* p, uint32_t x, uint3
     return x;
 }
 
-// ITEMS keys per thread: 16 (4096 keys and 39 KB of LDS per workgroup: four workgroups per CU) or 8 (2048 keys, 22 KB: seven per CU, twice the tiles) -- C3D_SORT_ITEMS
+// 16 keys per thread: 4096 keys and 39 KB of LDS per workgroup, four workgroups per CU (8 and 32 keys per thread measured worse in round 3: profiles/r03/)
 template <bool IOTA, int ITEMS>
-__global__ void __launch_bounds__(RS_THREADS, ITEMS > 16 ? 2 : 4) k_onesweep(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+__global__ void __launch_bounds__(RS_THREADS, 4) k_onesweep(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                              uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                              const uint32_t* __restrict__ ghist, uint32_t* __restrict__ ticket, uint32_t* __restrict__ err,
                                                              uint32_t* __restrict__ tile_words, uint32_t* __restrict__ group_words, size_t n,
-                                                             const uint32_t* __restrict__ n_dev, int shift, unsigned long long* __restrict__ dbg) {
+                                                             const uint32_t* __restrict__ n_dev, int shift, unsigned long long* __restrict__ dbg, size_t vs) {
     __shared__ uint32_t whist[RS_THREADS / 64][RS_RADIX];
+    keys_in = c3d_view_ptr(keys_in, vs); vals_in = c3d_view_ptr(vals_in, vs); keys_out = c3d_view_ptr(keys_out, vs); vals_out = c3d_view_ptr(vals_out, vs);
+    ghist = c3d_view_ptr(ghist, vs); ticket = c3d_view_ptr(ticket, vs); tile_words = c3d_view_ptr(tile_words, vs); group_words = c3d_view_ptr(group_words, vs);
+    n_dev = c3d_view_ptr(n_dev, vs);
     __shared__ uint32_t lstart[RS_RADIX];    // first local slot of each digit
     __shared__ uint32_t gbase[RS_RADIX];     // global position of that slot
     __shared__ uint32_t skey[RS_THREADS * ITEMS];
@@ -389,12 +484,7 @@ __global__ void __launch_bounds__(RS_THREADS, ITEMS > 16 ? 2 : 4) k_onesweep(con
 
 static unsigned long long* g_sort_dbg = nullptr;     // profiling hook: [pass][tile][8] wall_clock64 stamps (100 MHz), see c3d_test_sort_phases
 static inline size_t sort_head_bytes() { return c3d_align(sizeof(uint32_t) * (RS_HIST_SPLIT * RS_RADIX * RS_MAX_PASSES + RS_MAX_PASSES + 4)); }
-static int sort_items() {      // keys per thread of k_onesweep (see there)
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("C3D_SORT_ITEMS"); v = e ? atoi(e) : 16; if (v != 8 && v != 16 && v != 32) v = 16; }
-    return v;
-}
-#define RS_MIN_TILE (RS_THREADS * 8)      // the state is sized for the smaller tile
+#define RS_MIN_TILE RS_TILE
 size_t c3d_sort_tmp_bytes(size_t n) {
     const size_t nb = (size_t)c3d_cdiv((long long)(n ? n : 1), RS_MIN_TILE);
     return sort_head_bytes() + c3d_align(sizeof(uint32_t) * sort_pass_words(nb) * RS_MAX_PASSES);
@@ -408,15 +498,15 @@ size_t c3d_sort_state_bytes(size_t n, int end_bit) {
 }
 
 int c3d_sort_pairs_u32(uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32_t* vals1, bool iota_vals,
-                       size_t n, int end_bit, void* tmp, int* result_buf, hipStream_t s, const uint32_t* n_dev, bool zero_state, uint32_t* err_out) {
+                       size_t n, int end_bit, void* tmp, int* result_buf, hipStream_t s, const uint32_t* n_dev, bool zero_state, uint32_t* err_out, int V, size_t vs) {
     *result_buf = 0;
-    if (n == 0) return 0;
+    if (n == 0 || V <= 0) return 0;
+    if (zero_state && V != 1) { c3d_set_error("c3d_sort_pairs_u32: a multi-view launch clears its state through c3d_zero_views"); return -1; }
     if (end_bit > 8 * RS_MAX_PASSES) { c3d_set_error("c3d_sort_pairs_u32: end_bit %d > %d", end_bit, 8 * RS_MAX_PASSES); return -1; }
     if (n > (size_t)RS_VALUE_MASK) { c3d_set_error("c3d_sort_pairs_u32: %zu elements exceed the 2^30 - 1 the chained scan's status words hold", n); return -1; }
     int passes = (end_bit + 7) / 8;
     if (passes < 1) passes = 1;
-    const int items = sort_items();
-    const int nb = c3d_cdiv((long long)n, RS_THREADS * items), nb_hist = c3d_cdiv((long long)n, RS_TILE);
+    const int nb = c3d_cdiv((long long)n, RS_TILE), nb_hist = nb;
     uint32_t* ghist = (uint32_t*)tmp;
     uint32_t* tickets = ghist + RS_HIST_SPLIT * RS_RADIX * RS_MAX_PASSES;
     uint32_t* err = err_out ? err_out : c3d_sort_error_word(tmp);
@@ -424,248 +514,19 @@ int c3d_sort_pairs_u32(uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32
     if (zero_state) C3D_CHECK(hipMemsetAsync(tmp, 0, c3d_sort_state_bytes(n, end_bit), s));
     uint32_t* k[2] = {keys0, keys1};
     uint32_t* v[2] = {vals0, vals1};
-    hipLaunchKernelGGL(k_radix_hist_all, dim3(nb_hist), dim3(RS_THREADS), 0, s, keys0, ghist, n, n_dev, passes);
+    hipLaunchKernelGGL(k_radix_hist_all, dim3(nb_hist, V), dim3(RS_THREADS), 0, s, keys0, ghist, n, n_dev, passes, vs);
     int cur = 0;
     for (int pass = 0; pass < passes; pass++) {
         uint32_t* tw = status + (size_t)pass * sort_pass_words((size_t)nb);
         uint32_t* gw = tw + (size_t)RS_RADIX * nb;
-#define RS_SWEEP(IOTA_, ITEMS_) hipLaunchKernelGGL((k_onesweep<IOTA_, ITEMS_>), dim3(nb), dim3(RS_THREADS), 0, s, k[cur], v[cur], k[cur ^ 1], v[cur ^ 1], ghist + pass * RS_RADIX, \
-                                                   tickets + pass, err, tw, gw, n, n_dev, 8 * pass, g_sort_dbg ? g_sort_dbg + (size_t)pass * nb * 8 : nullptr)
-        if (pass == 0 && iota_vals) { if (items == 8) RS_SWEEP(true, 8); else if (items == 32) RS_SWEEP(true, 32); else RS_SWEEP(true, 16); }
-        else { if (items == 8) RS_SWEEP(false, 8); else if (items == 32) RS_SWEEP(false, 32); else RS_SWEEP(false, 16); }
+#define RS_SWEEP(IOTA_) hipLaunchKernelGGL((k_onesweep<IOTA_, RS_ITEMS>), dim3(nb, V), dim3(RS_THREADS), 0, s, k[cur], v[cur], k[cur ^ 1], v[cur ^ 1], ghist + pass * RS_RADIX, \
+                                           tickets + pass, err, tw, gw, n, n_dev, 8 * pass, (g_sort_dbg && V == 1) ? g_sort_dbg + (size_t)pass * nb * 8 : nullptr, vs)
+        if (pass == 0 && iota_vals) RS_SWEEP(true); else RS_SWEEP(false);
 #undef RS_SWEEP
         C3D_LAUNCH_CHECK();
         cur ^= 1;
     }
     *result_buf = cur;
-    return 0;
-}
-
-// ------------------------------------------------------------------------------------------
-// Segmented sort (round 3): every segment [ranges[t].x, ranges[t].y) of `vals` is reordered by key_table[val], ascending and STABLE (equal keys keep their
-// input order).  The 3DGS binning uses it for the depth order INSIDE each tile's list -- the lists leave the tile sort in Gaussian-id order -- in place of a global
-// depth sort of all Gaussians before emission (five latency-bound launches + a second chained scan per view).  One 256-thread workgroup per segment.
-//   n <= SEG_CAP: LSD radix sort on 8-bit digits entirely in LDS: ballot ranking as in k_onesweep (each wave owns a contiguous chunk -> stable), keys and values
-//                 live in registers between passes, digits on which all keys of the segment agree (the high bytes of a tile's depths, usually) are skipped;
-//   n >  SEG_CAP: the same ranking chunk by chunk through a global ping-pong of the values (vals <-> vbuf1; keys are re-gathered from the table; four passes, the
-//                 result ends in vals); rare (a tile with more than 4096 splats) and correct rather than fast.
-// ------------------------------------------------------------------------------------------
-#define SEG_CAP 4096
-#define SEG_ITEMS (SEG_CAP / 256)
-// rank of each of the wave's items among the items of this workgroup chunk that precede it with the same digit, within the wave (+ the wave's running count of the
-// digit in whist[wave][]); item i of lane l is element i * 64 + l of the wave's contiguous run.  whist must be zero on entry.
-// Element p = first + i * 64 + lane exists iff p < n.
-__device__ __forceinline__ void seg_rank(const uint32_t key[SEG_ITEMS], uint32_t first, uint32_t n, int items, int shift, uint32_t (*whist)[RS_RADIX], int wave, int lane,
-                                         uint32_t rank[SEG_ITEMS]) {
-    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-#pragma unroll
-    for (int i = 0; i < SEG_ITEMS; i++) {
-        if (i < items) {
-            const bool ok = first + (uint32_t)i * 64u + (uint32_t)lane < n;
-            const uint32_t d = (key[i] >> shift) & (RS_RADIX - 1);
-            uint64_t peers = __ballot(ok);
-#pragma unroll
-            for (int b = 0; b < 8; b++) {
-                const uint64_t m = __ballot((d >> b) & 1u);
-                peers &= ((d >> b) & 1u) ? m : ~m;
-            }
-            const uint32_t prefix = whist[wave][d];
-            const uint32_t r = (uint32_t)__popcll(peers & lt_mask);
-            if (ok && r == 0) whist[wave][d] = prefix + (uint32_t)__popcll(peers);
-            rank[i] = prefix + r;
-        }
-    }
-}
-// Segments of up to SEGW_CAP elements: ONE WAVE per segment (64-thread workgroups), nothing to synchronise with -- a tile's list is ~500 entries, and the
-// 256-thread kernel below spends its time in ~7 barriers per pass and in per-pass costs that do not shrink with the segment (256-digit tables for 4 waves).
-#define SEGW_CAP 1024
-__global__ void __launch_bounds__(64, 4) k_segment_sort_w(const uint2* __restrict__ ranges, int nseg, const uint32_t* __restrict__ key_table, uint32_t* __restrict__ vals) {
-    __shared__ uint32_t cnt[1][RS_RADIX];
-    __shared__ uint32_t skey[SEGW_CAP];
-    __shared__ uint32_t sval[SEGW_CAP];
-    const int t = blockIdx.x;
-    if (t >= nseg) return;
-    const uint2 rg = ranges[t];
-    const uint32_t n = rg.y > rg.x ? rg.y - rg.x : 0u;
-    if (n <= 1u || n > SEGW_CAP) return;
-    const int lane = threadIdx.x;
-    const int items = (int)((n + 63u) / 64u);
-    uint32_t key[SEG_ITEMS], val[SEG_ITEMS], rank[SEG_ITEMS];
-    uint32_t vor = 0u, vand = 0xFFFFFFFFu;
-#pragma unroll
-    for (int i = 0; i < SEG_ITEMS; i++) {
-        key[i] = 0xFFFFFFFFu; val[i] = 0u;
-        if (i < items) {
-            const uint32_t p = (uint32_t)i * 64u + (uint32_t)lane;
-            if (p < n) { val[i] = vals[rg.x + p]; key[i] = key_table[val[i]]; vor |= key[i]; vand &= key[i]; }
-        }
-    }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) { vor |= (uint32_t)__shfl_xor((int)vor, o, 64); vand &= (uint32_t)__shfl_xor((int)vand, o, 64); }
-    const uint32_t diff = vor & ~vand;
-    for (int pass = 0; pass < 4; pass++) {
-        const int shift = 8 * pass;
-        if (!((diff >> shift) & 0xFFu)) continue;
-        __syncthreads();                                   // one wave: these cost nothing and keep the LDS accesses of the phases in program order
-#pragma unroll
-        for (int k = 0; k < 4; k++) cnt[0][k * 64 + lane] = 0u;
-        __syncthreads();
-        seg_rank(key, 0u, n, items, shift, cnt, 0, lane, rank);
-        __syncthreads();
-        {   // lane l owns digits 4l .. 4l+3: counts -> starts
-            const uint32_t c0 = cnt[0][4 * lane], c1 = cnt[0][4 * lane + 1], c2 = cnt[0][4 * lane + 2], c3 = cnt[0][4 * lane + 3];
-            const uint32_t tot = c0 + c1 + c2 + c3;
-            const uint32_t ex = c3d_wave_incl_scan(tot) - tot;
-            cnt[0][4 * lane] = ex; cnt[0][4 * lane + 1] = ex + c0; cnt[0][4 * lane + 2] = ex + c0 + c1; cnt[0][4 * lane + 3] = ex + c0 + c1 + c2;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < SEG_ITEMS; i++)
-            if (i < items && (uint32_t)i * 64u + (uint32_t)lane < n) {
-                const uint32_t lp = cnt[0][(key[i] >> shift) & (RS_RADIX - 1)] + rank[i];
-                skey[lp] = key[i]; sval[lp] = val[i];
-            }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < SEG_ITEMS; i++) {
-            const uint32_t p = (uint32_t)i * 64u + (uint32_t)lane;
-            if (i < items && p < n) { key[i] = skey[p]; val[i] = sval[p]; }
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < SEG_ITEMS; i++) {
-        const uint32_t p = (uint32_t)i * 64u + (uint32_t)lane;
-        if (i < items && p < n) vals[rg.x + p] = val[i];
-    }
-}
-__global__ void __launch_bounds__(256, 4) k_segment_sort(const uint2* __restrict__ ranges, int nseg, const uint32_t* __restrict__ key_table, uint32_t* __restrict__ vals,
-                                                       uint32_t* __restrict__ vbuf1) {
-    __shared__ uint32_t whist[4][RS_RADIX];
-    __shared__ uint32_t dstart[RS_RADIX];     // big path: where the next element of each digit goes
-    __shared__ uint32_t skey[SEG_CAP];
-    __shared__ uint32_t sval[SEG_CAP];
-    __shared__ uint32_t scan_lds[4];
-    __shared__ uint32_t s_or[4], s_and[4];
-    const int t = blockIdx.x;
-    if (t >= nseg) return;
-    const uint2 rg = ranges[t];
-    const uint32_t n = rg.y > rg.x ? rg.y - rg.x : 0u;
-    if (n <= SEGW_CAP) return;                                  // k_segment_sort_w's
-    const int lane = c3d_lane(), wave = threadIdx.x >> 6;
-    uint32_t key[SEG_ITEMS], val[SEG_ITEMS], rank[SEG_ITEMS];
-    if (n <= SEG_CAP) {
-        const int items = (int)((n + 255u) / 256u);               // per lane; a wave's run is items * 64 consecutive elements
-        const uint32_t wbase = (uint32_t)wave * (uint32_t)items * 64u;
-        uint32_t vor = 0u, vand = 0xFFFFFFFFu;
-#pragma unroll
-        for (int i = 0; i < SEG_ITEMS; i++) {
-            key[i] = 0xFFFFFFFFu; val[i] = 0u;
-            if (i < items) {
-                const uint32_t p = wbase + (uint32_t)i * 64u + (uint32_t)lane;
-                if (p < n) { val[i] = vals[rg.x + p]; key[i] = key_table[val[i]]; vor |= key[i]; vand &= key[i]; }
-            }
-        }
-        // bits on which the keys of the segment differ: a digit with none is a pass that would not move anything
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) { vor |= (uint32_t)__shfl_xor((int)vor, o, 64); vand &= (uint32_t)__shfl_xor((int)vand, o, 64); }
-        if (lane == 0) { s_or[wave] = vor; s_and[wave] = vand; }
-        __syncthreads();
-        const uint32_t diff = (s_or[0] | s_or[1] | s_or[2] | s_or[3]) & ~(s_and[0] & s_and[1] & s_and[2] & s_and[3]);
-        for (int pass = 0; pass < 4; pass++) {
-            const int shift = 8 * pass;
-            if (!((diff >> shift) & 0xFFu)) continue;            // uniform over the workgroup
-            __syncthreads();
-            for (int i = threadIdx.x; i < 4 * RS_RADIX; i += 256) (&whist[0][0])[i] = 0;
-            __syncthreads();
-            seg_rank(key, wbase, n, items, shift, whist, wave, lane, rank);
-            __syncthreads();
-            {   // thread d owns digit d: block-local start of every (wave, digit) run
-                const int d = threadIdx.x;
-                uint32_t c[4], tot = 0, dummy;
-#pragma unroll
-                for (int w = 0; w < 4; w++) { c[w] = whist[w][d]; tot += c[w]; }
-                uint32_t ls = block_excl_scan(tot, scan_lds, &dummy);
-#pragma unroll
-                for (int w = 0; w < 4; w++) { whist[w][d] = ls; ls += c[w]; }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < SEG_ITEMS; i++)
-                if (i < items && wbase + (uint32_t)i * 64u + (uint32_t)lane < n) {
-                    const uint32_t lp = whist[wave][(key[i] >> shift) & (RS_RADIX - 1)] + rank[i];
-                    skey[lp] = key[i]; sval[lp] = val[i];
-                }
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < SEG_ITEMS; i++) {
-                const uint32_t p = wbase + (uint32_t)i * 64u + (uint32_t)lane;
-                if (i < items && p < n) { key[i] = skey[p]; val[i] = sval[p]; }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < SEG_ITEMS; i++) {
-            const uint32_t p = wbase + (uint32_t)i * 64u + (uint32_t)lane;
-            if (i < items && p < n) vals[rg.x + p] = val[i];
-        }
-        return;
-    }
-    // ---- more than SEG_CAP elements: four passes through a global ping-pong of the values, chunk by chunk in order (agent-scope accesses: the workgroup re-reads
-    //      what its other waves wrote in the previous pass)
-    uint32_t *vsrc = vals + rg.x, *vdst = vbuf1 + rg.x;
-    for (int pass = 0; pass < 4; pass++) {
-        const int shift = 8 * pass;
-        dstart[threadIdx.x] = 0;
-        __syncthreads();
-        for (uint32_t j = threadIdx.x; j < n; j += 256) atomicAdd(&dstart[(key_table[ld_agent32(vsrc + j)] >> shift) & (RS_RADIX - 1)], 1u);
-        __syncthreads();
-        {
-            uint32_t dummy;
-            const uint32_t cnt = dstart[threadIdx.x];
-            const uint32_t ex = block_excl_scan(cnt, scan_lds, &dummy);
-            __syncthreads();
-            dstart[threadIdx.x] = ex;
-        }
-        __syncthreads();
-        for (uint32_t cbase = 0; cbase < n; cbase += SEG_CAP) {
-            for (int i = threadIdx.x; i < 4 * RS_RADIX; i += 256) (&whist[0][0])[i] = 0;
-            __syncthreads();
-            const uint32_t wbase = cbase + (uint32_t)wave * (SEG_CAP / 4);
-#pragma unroll
-            for (int i = 0; i < SEG_ITEMS; i++) {
-                const uint32_t p = wbase + (uint32_t)i * 64u + (uint32_t)lane;
-                val[i] = p < n ? ld_agent32(vsrc + p) : 0u;
-                key[i] = p < n ? key_table[val[i]] : 0xFFFFFFFFu;
-            }
-            seg_rank(key, wbase, n, SEG_ITEMS, shift, whist, wave, lane, rank);
-            __syncthreads();
-            {   // thread d: this chunk's elements of digit d go to dstart[d] .. in wave order
-                const int d = threadIdx.x;
-                uint32_t ls = dstart[d], tot = 0;
-#pragma unroll
-                for (int w = 0; w < 4; w++) { const uint32_t c = whist[w][d]; whist[w][d] = ls + tot; tot += c; }
-                dstart[d] = ls + tot;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < SEG_ITEMS; i++)
-                if (wbase + (uint32_t)i * 64u + (uint32_t)lane < n) {
-                    const uint32_t pos = whist[wave][(key[i] >> shift) & (RS_RADIX - 1)] + rank[i];
-                    st_agent32(vdst + pos, val[i]);
-                }
-            __syncthreads();
-        }
-        __threadfence();
-        __syncthreads();
-        { uint32_t* x = vsrc; vsrc = vdst; vdst = x; }
-    }
-    // four passes: the result is back in vals
-}
-// vals: in / out.  vbuf1: scratch of at least the same length as vals (touched only by segments longer than 4096).
-int c3d_segment_sort_u32(const uint2* ranges, int nseg, const uint32_t* key_table, uint32_t* vals, uint32_t* vbuf1, hipStream_t s) {
-    if (nseg <= 0) return 0;
-    hipLaunchKernelGGL(k_segment_sort_w, dim3(nseg), dim3(64), 0, s, ranges, nseg, key_table, vals);
-    hipLaunchKernelGGL(k_segment_sort, dim3(nseg), dim3(256), 0, s, ranges, nseg, key_table, vals, vbuf1);
-    C3D_LAUNCH_CHECK();
     return 0;
 }
 

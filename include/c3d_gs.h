@@ -227,8 +227,6 @@ int c3d_prof_read(int slot, double* total_ms, long long* launches);
 /* primitives exported for unit tests of the binning machinery (device pointers) */
 int c3d_test_scan_u32(const uint32_t* in, uint32_t* out, int64_t n, int32_t exclusive, c3d_stream_t stream);
 int c3d_test_sort_pairs_u32(uint32_t* keys, uint32_t* vals, int64_t n, int32_t end_bit, c3d_stream_t stream);
-/* every segment [ranges[2t], ranges[2t+1]) of vals (length n) reordered by key_table[val], ascending and stable (the per-tile depth order of the binning chain) */
-int c3d_test_segment_sort_u32(const uint32_t* ranges, int32_t nseg, const uint32_t* key_table, uint32_t* vals, int64_t n, c3d_stream_t stream);
 /* profiling hook of the radix sort: stamps (device, [passes][tiles][8] uint64, or NULL = off) receive wall_clock64 ticks per phase */
 int c3d_test_sort_phases(uint64_t* stamps);
 

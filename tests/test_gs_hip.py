@@ -69,33 +69,6 @@ def test_sort_pairs_is_stable_and_correct(n, bits):
     assert (vt.cpu().numpy().view(np.uint32) == v[order]).all()
 
 
-def test_segment_sort_is_stable_and_correct_for_every_length():
-    """The per-tile depth order of the round-3 binning chain (c3d_segment_sort_u32): segments of every interesting length -- empty, 1, 2, below / at / above one
-    wave, 255-257, 4095 / 4096 (the LDS path's capacity), 4097, 9000 and 20000 (the global ping-pong path), keys with many ties and with constant high bytes
-    (skipped digits) -- against a stable argsort per segment."""
-    import c3d_hip as h
-    rng = np.random.default_rng(5)
-    lens = [0, 1, 2, 3, 63, 64, 65, 200, 255, 256, 257, 511, 1000, 1024, 3000, 4095, 4096, 4097, 9000, 0, 20000, 17, 5000, 700]
-    table_n = 50000
-    table = rng.integers(0, 1 << 32, size=table_n, dtype=np.uint64).astype(np.uint32)
-    table[: table_n // 2] = (table[: table_n // 2] & np.uint32(0x0000FFFF)) | np.uint32(0x3F800000)       # two constant high bytes: depth-like keys
-    table[rng.integers(0, table_n, size=table_n // 4)] = table[7]                                           # ties
-    starts = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint32)
-    n = int(starts[-1])
-    ranges = np.stack([starts[:-1], starts[1:]], 1).astype(np.uint32)
-    ranges[lens.index(0)] = (0, 0)
-    vals = np.concatenate([np.sort(rng.choice(table_n, size=l, replace=False)).astype(np.uint32) if l else np.zeros(0, np.uint32) for l in lens])   # id order inside a segment
-    vals[starts[3]:starts[3] + 3] = vals[starts[3]]        # duplicate values inside one segment are fine too
-    dev = lambda a: torch.tensor(a.astype(np.int64), device="cuda").to(torch.int32)
-    rt, tt, vt = dev(ranges.reshape(-1)), dev(table), dev(vals)
-    h.check(h.lib().c3d_test_segment_sort_u32(h.ptr(rt), len(lens), h.ptr(tt), h.ptr(vt), n, h.stream()), "segment sort")
-    got = vt.cpu().numpy().view(np.uint32)
-    for (a, b), l in zip(ranges, lens):
-        seg = vals[a:b]
-        want = seg[np.argsort(table[seg], kind="stable")]
-        assert np.array_equal(got[a:b], want), l
-
-
 # ---------------------------------------------------------------- forward parity
 CASES = [
     dict(N=48, W=48, H=32, el=-20, az=30, rad=2.0, seed=7, deg=3),
@@ -564,68 +537,6 @@ def test_recorded_pair_activity_loses_nothing():
     quads = float(bits.sum()) / max(int(bits.any(0).sum()), 1)
     print("[activity] %d pairs; of the %d list positions a tile reached %.0f %% blended somewhere, %.2f quadrants each" % (D, int(reached.sum()), 100 * frac_any, quads))
     assert 0.05 < frac_any < 0.98 and 1.0 <= quads < 3.5
-
-
-def test_forward_kernels_agree():
-    """The wave-per-quadrant compositing kernels (default) and the workgroup-per-tile ones (C3D_FWD_KERNEL=0, C3D_BWD_KERNEL=0) are the same per-pixel
-    arithmetic: identical colour and depth images, alpha and gradients equal to rounding (different summation association only).  The switches are
-    environment variables read at first use, so the other pair of kernels runs in a child process."""
-    import subprocess, sys, tempfile
-    sc = S.make_cloud(150000, seed=9, log_scale_mean=np.log(0.01))
-    W, H = 500, 300                                   # not multiples of 16: partial tiles and fully outside quadrants
-    st = S.camera_settings(W, H, 49.1, -25.0, 200.0, 2.2, bg=(0.2, 0.5, 0.9))
-    gC = np.random.default_rng(4).normal(size=(3, H, W)).astype(np.float32)
-    color, radii, depth, alpha, inp, m2d = hip_forward(sc, st, requires_grad=True)
-    ((color * _dev(gC, torch.float32)).sum() + alpha.sum() + depth.sum()).backward()
-    mine = dict(color=color.detach().cpu().numpy(), alpha=alpha.detach().cpu().numpy(), depth=depth.detach().cpu().numpy(),
-                **{"g_" + k: inp[k].grad.cpu().numpy() for k in GS_KEYS})
-    here = os.path.dirname(os.path.abspath(__file__))
-    with tempfile.TemporaryDirectory() as td:
-        out = os.path.join(td, "o.npz")
-        code = ("import sys, os, numpy as np, torch; sys.path[:0] = [%r, %r, %r]; from c3d_hip import synthetic as S; from helpers import hip_forward, GS_KEYS\n"
-                "sc = S.make_cloud(150000, seed=9, log_scale_mean=np.log(0.01)); st = S.camera_settings(%d, %d, 49.1, -25.0, 200.0, 2.2, bg=(0.2, 0.5, 0.9))\n"
-                "gC = torch.tensor(np.random.default_rng(4).normal(size=(3, %d, %d)).astype(np.float32), device='cuda')\n"
-                "color, radii, depth, alpha, inp, m2d = hip_forward(sc, st, requires_grad=True); ((color * gC).sum() + alpha.sum() + depth.sum()).backward()\n"
-                "np.savez(%r, color=color.detach().cpu().numpy(), alpha=alpha.detach().cpu().numpy(), depth=depth.detach().cpu().numpy(), **{'g_' + k: inp[k].grad.cpu().numpy() for k in GS_KEYS})\n"
-                % (here, os.path.dirname(here), os.path.join(os.path.dirname(here), "comfyui-3d-pack_amd"), W, H, H, W, out))
-        env = dict(os.environ, C3D_FWD_KERNEL="0", C3D_BWD_KERNEL="0")
-        subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=600)
-        other = np.load(out)
-        for k, v in mine.items():
-            if k == "alpha":      # the wave-per-quadrant kernel takes alpha from the telescoped sum 1 - T_final, the other one accumulates it: equal to rounding
-                assert np.abs(v - other[k]).max() <= 2e-6
-            elif k.startswith("g_"):   # the backward kernels (C3D_BWD_KERNEL follows its own default in the child) add a pair's quadrants in a different association
-                assert np.abs(v - other[k]).max() <= 2e-5 * max(np.abs(v).max(), 1e-30), k
-            else:
-                assert np.array_equal(v, other[k]), k
-
-
-def test_binning_chains_agree():
-    """The per-tile depth order chain (C3D_BIN_LOCAL=1: one scan, emission in id order, tile sort, c3d_segment_sort_u32 per tile) builds the SAME lists as the default
-    chain (global depth sort, rank-ordered emission): images, radii and gradients are identical bit for bit.  Environment switch read at first use -> child process.
-    A 32x32 image with 30 k Gaussians puts > 4096 splats on a tile (the segment sort's global ping-pong path)."""
-    import subprocess, sys, tempfile
-    here = os.path.dirname(os.path.abspath(__file__))
-    for (n, W, H, rad, ls) in ((60000, 500, 300, 2.2, 0.01), (30000, 32, 32, 2.0, 0.02)):
-        sc = S.make_cloud(n, seed=9, log_scale_mean=np.log(ls))
-        st = S.camera_settings(W, H, 49.1, -25.0, 200.0, rad, bg=(0.2, 0.5, 0.9))
-        gC = np.random.default_rng(4).normal(size=(3, H, W)).astype(np.float32)
-        color, radii, depth, alpha, inp, m2d = hip_forward(sc, st, requires_grad=True)
-        ((color * _dev(gC, torch.float32)).sum() + alpha.sum() + depth.sum()).backward()
-        mine = dict(color=color.detach().cpu().numpy(), alpha=alpha.detach().cpu().numpy(), depth=depth.detach().cpu().numpy(), radii=radii.cpu().numpy(),
-                    **{"g_" + k: inp[k].grad.cpu().numpy() for k in GS_KEYS})
-        with tempfile.TemporaryDirectory() as td:
-            out = os.path.join(td, "o.npz")
-            code = ("import sys, os, numpy as np, torch; sys.path[:0] = [%r, %r, %r]; from c3d_hip import synthetic as S; from helpers import hip_forward, GS_KEYS\n"
-                    "sc = S.make_cloud(%d, seed=9, log_scale_mean=np.log(%r)); st = S.camera_settings(%d, %d, 49.1, -25.0, 200.0, %r, bg=(0.2, 0.5, 0.9))\n"
-                    "gC = torch.tensor(np.random.default_rng(4).normal(size=(3, %d, %d)).astype(np.float32), device='cuda')\n"
-                    "color, radii, depth, alpha, inp, m2d = hip_forward(sc, st, requires_grad=True); ((color * gC).sum() + alpha.sum() + depth.sum()).backward()\n"
-                    "np.savez(%r, color=color.detach().cpu().numpy(), alpha=alpha.detach().cpu().numpy(), depth=depth.detach().cpu().numpy(), radii=radii.cpu().numpy(), **{'g_' + k: inp[k].grad.cpu().numpy() for k in GS_KEYS})\n"
-                    % (here, os.path.dirname(here), os.path.join(os.path.dirname(here), "comfyui-3d-pack_amd"), n, ls, W, H, rad, H, W, out))
-            subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, C3D_BIN_LOCAL="1"), timeout=600)
-            other = np.load(out)
-            for k, v in mine.items():
-                assert np.array_equal(v, other[k]), (n, k)
 
 
 # ---------------------------------------------------------------- training-step pieces (SURVEY 8a a6/a7)
@@ -1124,10 +1035,11 @@ def test_reduce_ranks_fixed_order_sum():
     assert float(fg.flat.sum()) == sum((i + 1) * p.numel() for i, p in enumerate(ps))
 
 
-@pytest.mark.parametrize("lanes,res", [(1, (200, 136)), (3, (200, 136)), (4, (251, 143))])
-def test_render_views_equals_per_view_render(lanes, res):
-    """c3d_gs_render_views_raw (a whole orbit in one call, views on `lanes` streams) gives exactly what the per-view render() gives;
-    the camera controller takes that path when autograd is off."""
+@pytest.mark.parametrize("lanes,group,res", [(1, 8, (200, 136)), (2, 2, (200, 136)), (3, 1, (200, 136)), (2, 3, (251, 143))])
+def test_render_views_equals_per_view_render(lanes, group, res):
+    """c3d_gs_render_views_raw (a whole orbit in one call: `group` views per launch of every stage of the chain, `lanes` groups in flight) gives exactly what
+    the per-view render() gives -- one group of all five views, groups of 2 + 2 + 1 on two streams, single views on three, 3 + 2; the camera controller takes
+    that path when autograd is off."""
     from MVs_Algorithms.GaussianSplatting.main_3DGS_renderer import GaussianSplattingRenderer
     from MVs_Algorithms.GaussianSplatting.main_3DGS import GaussianSplattingCameraController
     raw = S.make_cloud(30000, seed=8, log_scale_mean=np.log(0.02), activated=False)
@@ -1144,7 +1056,7 @@ def test_render_views_equals_per_view_render(lanes, res):
         for radius, el, az, cx, cy, cz in poses:
             cams.append(MiniCam(orbit_camera(el, az, radius, target=np.array([cx, cy, cz], dtype=np.float32)), W, H, ctl.cam.fovy, ctl.cam.fovx, ctl.cam.near, ctl.cam.far,
                                 ctl.projection_matrix, device="cuda"))
-        out = r.render_views(cams, ctl.static_bg, lanes=lanes)
+        out = r.render_views(cams, ctl.static_bg, lanes=lanes, group=group)
         images, masks, extra = ctl.render_all_pose(poses)            # autograd off -> batched path
     for i, pv in enumerate(per_view):
         for k in ("image", "depth", "alpha"):
@@ -1155,21 +1067,22 @@ def test_render_views_equals_per_view_render(lanes, res):
     # with autograd on the controller falls back to the per-view loop and keeps the graph
     images2, _, extra2 = ctl.render_all_pose(poses[:2])
     assert images2.requires_grad and "viewspace_points" in extra2
-    # the workspace's size picks the schedule: one slice per lane = every view projected by its own launch (same images); less than that is refused
+    # the workspace's size picks the schedule: with fewer slices than lanes * group the groups get narrower (same images); less than one slice is refused
     with torch.no_grad():
-        r.render_views(cams, ctl.static_bg, lanes=lanes)              # (the controller call above left an 8-lane object behind: make the `lanes` one current)
+        r.render_views(cams, ctl.static_bg, lanes=lanes, group=group)              # (the controller call above left a default object behind: make this one current)
     vr = r._view_render
-    assert vr.lanes == lanes and vr._fitted
+    assert vr.lanes == lanes and vr.group == group and vr._fitted
     full = vr.workspace
-    one = vr.workspace.numel() // (2 * vr.lanes)
+    one = vr.workspace.numel() // (vr.lanes * vr.group)
     with torch.no_grad():
-        vr.workspace = full[:one * vr.lanes]
-        out1 = r.render_views(cams, ctl.static_bg, lanes=lanes)
-        for k in ("image", "depth", "alpha"):
-            assert torch.equal(out1[k], out[k]), k
-        vr.workspace = full[:one * min(vr.lanes, len(cams)) - 256]
-        with pytest.raises(RuntimeError, match="fewer than"):
-            r.render_views(cams, ctl.static_bg, lanes=lanes)
+        for keep in sorted({1, max(1, vr.lanes * vr.group - 1)}):
+            vr.workspace = full[:one * keep]
+            out1 = r.render_views(cams, ctl.static_bg, lanes=lanes, group=group)
+            for k in ("image", "depth", "alpha"):
+                assert torch.equal(out1[k], out[k]), (k, keep)
+        vr.workspace = full[:one - 256]
+        with pytest.raises(RuntimeError, match="less than one slice"):
+            r.render_views(cams, ctl.static_bg, lanes=lanes, group=group)
         vr.workspace = full
 
 

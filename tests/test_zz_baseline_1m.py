@@ -80,7 +80,7 @@ def full(oracle_built):
     rs = [hip_settings(st, "cuda") for st in sts]
     V = len(rs)
     # ---- (b) forward-only entry point: eight lanes, projection stream
-    ren = FusedViewRender(N, H, W, "cuda", lanes=8)
+    ren = FusedViewRender(N, H, W, "cuda", lanes=2, group=4)
     color, depth, alpha, radii = ren.run(rs, plist, want_radii=True)
     color, depth, alpha, radii = color.cpu().numpy(), depth.cpu().numpy(), alpha.cpu().numpy(), radii.cpu().numpy()
     del ren
