@@ -14,8 +14,8 @@ void c3d_set_error(const char* fmt, ...) {
 }
 
 // msssim.hip: out_word += va + vb * mean MS-SSIM(x, y_eff), dL_dy (+)= grad_scale * d mean / dy
-int ms_value_grad(const float* x, const float* y, const float* mask, int clamp_y, int B, int C, int H, int W, float grad_scale, int accumulate, float* dL_dy,
-                  float va, float vb, float* ms_out, void* workspace, hipStream_t s, int store_value = 0);
+int ms_value_grad_images(const float* const* x, const float* const* y, const float* const* mask, float* const* dy, int clamp_y, int B, int C, int H, int W, float grad_scale,
+                         int accumulate, float va, float vb, float* out0, size_t out_stride, void* workspace, hipStream_t s);
 static int tile_sort_bits(int tiles) {
     int bits = 0;
     while ((1ll << bits) < (long long)tiles) bits++;
@@ -269,7 +269,7 @@ int c3d_gs_backward_raw(const c3d_gs_settings* st, int32_t N, const float* means
 // ---- fused multi-view paths (no host synchronisation inside) ----------------------------------------------------------------
 struct StepWs {
     char* geom; char* binning; char* image; int* radii; float* color; float* depth; float* alpha; float* dcolor; float* pairgrad; uint8_t* pvalid;
-    float* dmeans2D; float* gcol; char* ms_ws; float* tile_loss;
+    float* dmeans2D; float* gcol; float* tile_loss;
     size_t bytes;
 };
 // fwd_only (c3d_gs_render_views_raw: no backward pass will read the slice): the gradient records, their valid bytes, the loss buffers and the MS-SSIM workspace --
@@ -284,14 +284,13 @@ static void carve_step(char* base, int N, int H, int W, long long cap, StepWs& w
     w.geom = take(g.bytes); w.binning = take(b.bytes); w.image = take(im.bytes);
     w.radii = (int*)take(4 * n);
     w.color = (float*)take(12 * P); w.depth = (float*)take(4 * P); w.alpha = (float*)take(4 * P);
-    w.dcolor = w.pairgrad = w.dmeans2D = w.gcol = w.tile_loss = nullptr; w.pvalid = nullptr; w.ms_ws = nullptr;
+    w.dcolor = w.pairgrad = w.dmeans2D = w.gcol = w.tile_loss = nullptr; w.pvalid = nullptr;
     if (!fwd_only) {
         w.dcolor = (float*)take(12 * P);
         w.pairgrad = (float*)take(sizeof(float) * GS_PAIR_FLOATS * (size_t)(cap > 0 ? cap : 1));
         w.pvalid = (uint8_t*)take((size_t)(cap > 0 ? cap : 1));
         w.dmeans2D = (float*)take(12 * n);
         w.gcol = (float*)take(12 * n);
-        w.ms_ws = take(c3d_msssim_workspace_bytes(1, 3, H, W));       // MS-SSIM term of the pixel loss (w_ssim != 0)
         w.tile_loss = (float*)take(4 * (size_t)(((W + C3D_TILE_X - 1) / C3D_TILE_X) * ((H + C3D_TILE_Y - 1) / C3D_TILE_Y) + 2));   // per-tile partial sums of the pixel loss + one slot for the view's MS-SSIM term + one for the view's sum
     }
     w.bytes = off;
@@ -404,9 +403,12 @@ static int group_width(int V, int lanes) {
     return G > GS_MAX_GROUP ? GS_MAX_GROUP : (G < 1 ? 1 : G);
 }
 
+// training workspace of V views: V slices at a uniform stride, then the MS-SSIM workspace of the step's loss term (w_ssim != 0): one per-image share per view; a
+// group of g views starting at view v0 uses the shares [v0, v0 + g) as ONE batched workspace (c3d_msssim_workspace_bytes(g, ..) <= g shares: the plan only pads less)
+static size_t ms_share_bytes(int H, int W) { return (H > 160 && W > 160) ? c3d_msssim_workspace_bytes(1, 3, H, W) : 0; }
 size_t c3d_gs_step_workspace_bytes(int32_t N, int32_t H, int32_t W, int64_t pair_capacity, int32_t views) {
     StepWs w; carve_step(nullptr, N, H, W, pair_capacity, w);
-    return (size_t)(views > 0 ? views : 1) * w.bytes;
+    return (size_t)(views > 0 ? views : 1) * (w.bytes + ms_share_bytes(H, W));
 }
 size_t c3d_gs_render_workspace_bytes(int32_t N, int32_t H, int32_t W, int64_t pair_capacity, int32_t slices) {
     StepWs w; carve_step(nullptr, N, H, W, pair_capacity, w, true);
@@ -429,6 +431,7 @@ int c3d_gs_train_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, c
     StepWs w0; carve_step(nullptr, N, views[0].image_height, views[0].image_width, pair_capacity, w0);
     const size_t vs = w0.bytes;
     const bool ssim = loss->w_ssim != 0.f;
+    if (ssim && !(views[0].image_height > 160 && views[0].image_width > 160)) { c3d_set_error("c3d_gs_train_views_raw: the MS-SSIM term needs image sides > 160"); return -1; }
     const int G = group_width(V, lanes), groups = (V + G - 1) / G;
     int rc_all = 0;
     {
@@ -446,13 +449,13 @@ int c3d_gs_train_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, c
                 if ((rc = group_composite_fwd(q, res, nullptr, nullptr, nullptr, true, s))) break;
                 // + scale * w_ssim * (1 - MS-SSIM(target * mask, clamp(C) * mask)) of every view (the batch mean of the reference, main_3DGS.py:192, is the mean of
                 // the per-image values): the value goes into the view's own slot behind its tile partials, the gradient into the slice's dL/dcolor plane
-                if (ssim) {
-                    C3dProfScope ps(C3D_P_MSSSIM, s);
+                if (ssim) {      // all views of the group in one set of ~20 launches (the views' images, targets, masks and gradient planes as per-image pointer tables)
                     const float ws_ = loss->scale * loss->w_ssim;
-                    for (int i = 0; i < g && !rc; i++)
-                        rc = ms_value_grad(target_color[v0 + i], q.w[i].color, color_mask ? color_mask[v0 + i] : nullptr, 1, 1, 3, q.p[i].H, q.p[i].W, -ws_, 0, q.w[i].dcolor, ws_, -ws_,
-                                           loss_out ? q.w[i].tile_loss + q.tiles : nullptr, q.w[i].ms_ws, s, 1);
-                    if (rc) break;
+                    const float* ys[GS_MAX_GROUP]; float* dys[GS_MAX_GROUP];
+                    for (int i = 0; i < g; i++) { ys[i] = q.w[i].color; dys[i] = q.w[i].dcolor; }
+                    char* ms_ws = (char*)workspace + (size_t)V * vs + (size_t)v0 * ms_share_bytes(q.p[0].H, q.p[0].W);
+                    if ((rc = ms_value_grad_images(target_color + v0, ys, color_mask ? color_mask + v0 : nullptr, dys, 1, g, 3, q.p[0].H, q.p[0].W, -ws_, 0, ws_, -ws_,
+                                                   loss_out ? q.w[0].tile_loss + q.tiles : nullptr, q.vs ? q.vs : vs, ms_ws, s))) break;
                 }
                 // pixel loss + backward down to the per-(tile, splat) records, all views of the group in one launch
                 { C3dProfScope ps(C3D_P_COMPOSITE_BWD, s);

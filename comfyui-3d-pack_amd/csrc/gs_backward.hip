@@ -113,7 +113,12 @@ __device__ __forceinline__ float wave_reduce_lds(const float* tile /* [NV][BWD_R
     const int row = min(lane >> 2, NV - 1), quarter = lane & 3;
     const float4* rp = reinterpret_cast<const float4*>(tile + row * BWD_RED_ROW + quarter * 16);
     const float4 a = rp[0], b = rp[1], c = rp[2], d = rp[3];
-    float t = (((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w))) + (((c.x + c.y) + (c.z + c.w)) + ((d.x + d.y) + (d.z + d.w)));
+    // 16 -> 1 with packed adds (v_pk_add_f32: two sums per instruction at ~1.6x the issue cost of one): 7 packed + 1 plain instead of 15 plain
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const v2f p0 = v2f{a.x, a.y} + v2f{a.z, a.w}, p1 = v2f{b.x, b.y} + v2f{b.z, b.w}, p2 = v2f{c.x, c.y} + v2f{c.z, c.w}, p3 = v2f{d.x, d.y} + v2f{d.z, d.w};
+    const v2f q0 = p0 + p1, q1 = p2 + p3;
+    const v2f r0 = q0 + q1;
+    float t = r0.x + r0.y;
     t = dpp_add<0xB1>(t);               // quad_perm [1,0,3,2]
     t = dpp_add<0x4E>(t);               // quad_perm [2,3,0,1]
     return t;                           // lanes 4r .. 4r+3 hold the wave's sum of value r (r < NV)
@@ -271,31 +276,36 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
                 const float dx = a0.x - pxf, dy = a0.y - pyf;
                 const float power = gs_power(a0, a1.x, dx, dy);      // log2(e) * (-q/2)
                 const float G = __builtin_amdgcn_exp2f(power);
-                const float alpha = fminf(0.99f, a1.y * G);
+                const float oG = a1.y * G;                               // alpha before the 0.99 cap
                 // act = (k < last) && (power <= 0) && (alpha >= 1/255) as a wave mask in an SGPR pair: the compares are written as asm so that the
-                // mask can feed v_cndmask_b32_e64 directly (a ballot of the C++ bool costs a select + compare round trip through a VGPR)
+                // mask can feed v_cndmask_b32_e64 directly (a ballot of the C++ bool costs a select + compare round trip through a VGPR).
+                // min(0.99, oG) >= 1/255  <=>  oG >= 1/255: the test reads oG, the same bits the forward pass's decision was taken on.
                 uint64_t am;
                 {
                     uint64_t c0, c1, c2;
                     asm("v_cmp_lt_i32_e64 %0, %1, %2" : "=s"(c0) : "s"(k), "v"(last));     // k is wave-uniform: scalar operand, no v_mov
                     asm("v_cmp_ge_f32_e64 %0, 0, %1" : "=s"(c1) : "v"(power));
-                    asm("v_cmp_le_f32_e64 %0, %1, %2" : "=s"(c2) : "v"(1.f / 255.f), "v"(alpha));
+                    asm("v_cmp_le_f32_e64 %0, %1, %2" : "=s"(c2) : "v"(1.f / 255.f), "v"(oG));
                     am = c0 & c1 & c2;
                 }
                 {   // no branch on am: it is non-zero for every recorded pair (and were it not, the sums below would come out as zeros)
                     float t0, t1, t2;
                     // dL/dalpha_k = T_k (c_k . dL) - [sum_{j behind k} (c_j . dL) alpha_j T_j + T_final bg . dL] / (1 - alpha_k)
-                    // with (c . dL) taken over colour, depth and alpha channels; Rdot carries the bracket.  Inactive lanes run the
-                    // same instructions with a zero weight (no exec-masked branch, no zero-initialised temporaries).
+                    // with (c . dL) taken over colour, depth and alpha channels; Rdot carries the bracket.
+                    // ONE select per pair (round 4; three before): an inactive lane continues with oG = 0, hence alpha = 0, 1 / (1 - alpha) = 1 exactly, T unchanged,
+                    // weight 0 and moments 0 -- the same instructions for every lane, no exec-masked branch, no zero-initialised temporaries.
+                    const float oGe = sel64z(am, oG);
+                    const float alpha = fminf(0.99f, oGe);
                     const float inv = __builtin_amdgcn_rcpf(1.f - alpha);
                     const float Tn = T * inv;
-                    T = sel64(am, Tn, T);
-                    const float w = sel64z(am, alpha * Tn);
-                    const float sdot = DEPTH ? a1.z * dLp0 + a1.w * dLp1 + a2.x * dLp2 + a2.y * dLd + dLa : a1.z * dLp0 + a1.w * dLp1 + a2.x * dLp2 + dLa;
+                    T = Tn;
+                    const float w = alpha * Tn;
+                    const float sdot = DEPTH ? __builtin_fmaf(a1.z, dLp0, __builtin_fmaf(a1.w, dLp1, __builtin_fmaf(a2.x, dLp2, __builtin_fmaf(a2.y, dLd, dLa))))
+                                             : __builtin_fmaf(a1.z, dLp0, __builtin_fmaf(a1.w, dLp1, __builtin_fmaf(a2.x, dLp2, dLa)));
                     const float dL_dalpha = Tn * sdot - Rdot * inv;
                     Rdot += w * sdot;
                     // screen-space part as raw moments of w2 = dL/dG * G; turned into mean/conic/opacity gradients per Gaussian in A8
-                    const float m0 = sel64z(am, a1.y * G * dL_dalpha);
+                    const float m0 = oGe * dL_dalpha;
                     const float m1x = m0 * dx, m1y = m0 * dy;
 #ifdef GS_BWD_REDUCE_DPP
                     wave_reduce10(w * dLp0, w * dLp1, w * dLp2, DEPTH ? w * dLd : 0.f, m0, m1x, m1y, m1x * dx, m1x * dy, m1y * dy, t0, t1, t2);

@@ -259,20 +259,34 @@ int gs_launch_emit(const GsParams& p, const GsGeom& g, int res, GsBinning& b, hi
     return 0;
 }
 
-// A5: [start,end) of every tile in the sorted pair list
+// A5: [start,end) of every tile in the sorted pair list.  Four consecutive positions per lane (one 16-byte load + the two neighbours): with one position per
+// lane the launch was half a million three-load waves and bound by their latency, not by the 16 MB it reads per view.
+#define RANGES_PER_LANE 4
 __global__ void __launch_bounds__(256) k_ranges(const uint32_t* __restrict__ tkey, uint2* __restrict__ ranges, long long D, const uint32_t* __restrict__ d_dev, size_t vs) {
     tkey = c3d_view_ptr(tkey, vs); ranges = c3d_view_ptr(ranges, vs); d_dev = c3d_view_ptr(d_dev, vs);
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long i0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * RANGES_PER_LANE;
     if (d_dev) D = min((long long)*d_dev, D);
-    if (i >= D) return;
-    const uint32_t t = tkey[i];
-    if (i == 0 || tkey[i - 1] != t) ranges[t].x = (uint32_t)i;
-    if (i == D - 1 || tkey[i + 1] != t) ranges[t].y = (uint32_t)(i + 1);
+    if (i0 >= D) return;
+    uint32_t t[RANGES_PER_LANE + 2];
+    if (i0 + RANGES_PER_LANE <= D) { const uint4 q = *reinterpret_cast<const uint4*>(tkey + i0); t[1] = q.x; t[2] = q.y; t[3] = q.z; t[4] = q.w; }
+    else {
+#pragma unroll
+        for (int k = 0; k < RANGES_PER_LANE; k++) t[1 + k] = (i0 + k < D) ? tkey[i0 + k] : 0xFFFFFFFFu;
+    }
+    t[0] = i0 > 0 ? tkey[i0 - 1] : 0xFFFFFFFFu;
+    t[RANGES_PER_LANE + 1] = (i0 + RANGES_PER_LANE < D) ? tkey[i0 + RANGES_PER_LANE] : 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 0; k < RANGES_PER_LANE; k++) {
+        const long long i = i0 + k;
+        if (i >= D) break;
+        if (i == 0 || t[k] != t[k + 1]) ranges[t[k + 1]].x = (uint32_t)i;
+        if (i == D - 1 || t[k + 2] != t[k + 1]) ranges[t[k + 1]].y = (uint32_t)(i + 1);
+    }
 }
 // `ranges` must be zero on entry: the binning stage clears it together with the tile-sort state (GsBinning::zero_bytes)
 int gs_launch_ranges(const GsBinning& b, int res, long long D, hipStream_t s, const uint32_t* d_dev, int V, size_t vs) {
     if (D == 0 || V <= 0) return 0;
-    hipLaunchKernelGGL(k_ranges, dim3(c3d_cdiv(D, 256), V), dim3(256), 0, s, b.tkey[res], b.ranges, D, d_dev, vs);
+    hipLaunchKernelGGL(k_ranges, dim3(c3d_cdiv(D, 256 * RANGES_PER_LANE), V), dim3(256), 0, s, b.tkey[res], b.ranges, D, d_dev, vs);
     C3D_LAUNCH_CHECK();
     return 0;
 }

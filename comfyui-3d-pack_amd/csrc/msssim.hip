@@ -31,6 +31,19 @@ __device__ __forceinline__ v2f ms_fma2(float w, v2f a, v2f b) { return __builtin
 struct MsWin { float w[2 * MS_R + 1]; };
 struct MsLevel { int H, W, Hv, Wv, tx, ty; };          // image size, valid (filtered) size, tiles over the valid size
 
+// Level-0 tensors of a multi-image call whose images are NOT one contiguous [B, C, H, W] block (the fused 3DGS training step: every view has its own target, its
+// own rendered image inside its workspace slice, its own mask and gradient plane): per-image base pointers in the kernel arguments.  n = 0: contiguous tensors.
+#define MS_TAB_MAX 16
+struct MsTab { int n; const float* x[MS_TAB_MAX]; const float* y[MS_TAB_MAX]; const float* mask[MS_TAB_MAX]; float* dy[MS_TAB_MAX]; };
+// the level-0 kernels index X / Y / out with plane * HW and the mask with (plane / C) * HW: rebase the pointers of this plane's image so that the same indexing lands in it
+struct MsBase { const float* x; const float* y; const float* mask; float* out; };
+__device__ __forceinline__ MsBase ms_rebase(const MsTab& tab, int plane, int C, size_t HW, const float* X, const float* Y, const float* mask, float* out) {
+    if (!tab.n) return MsBase{X, Y, mask, out};
+    const int img = plane / C, ch = plane - img * C;
+    const ptrdiff_t shift = ((ptrdiff_t)ch - (ptrdiff_t)plane) * (ptrdiff_t)HW;
+    return MsBase{tab.x[img] + shift, tab.y[img] + shift, tab.mask[img] ? tab.mask[img] - (ptrdiff_t)img * (ptrdiff_t)HW : nullptr, tab.dy[img] + shift};
+}
+
 // level-0 input transform: x * mask, clamp(y) * mask
 template <bool L0>
 __device__ __forceinline__ void ms_load(const float* __restrict__ X, const float* __restrict__ Y, const float* __restrict__ mask, int clamp_y, int C,
@@ -46,8 +59,9 @@ __device__ __forceinline__ void ms_load(const float* __restrict__ X, const float
 // 2 x 2 average pooling with padding = size % 2 on both sides, zeros counted (torch avg_pool2d defaults): level l -> l + 1, x and y together
 template <bool L0>
 __global__ void __launch_bounds__(256) k_ms_pool(const float* __restrict__ X, const float* __restrict__ Y, const float* __restrict__ mask, int clamp_y, int C,
-                                                 int H, int W, int H2, int W2, float* __restrict__ X2, float* __restrict__ Y2) {
+                                                 int H, int W, int H2, int W2, float* __restrict__ X2, float* __restrict__ Y2, MsTab tab) {
     const int plane = blockIdx.z;
+    if (L0) { const MsBase b = ms_rebase(tab, plane, C, (size_t)H * W, X, Y, mask, nullptr); X = b.x; Y = b.y; mask = b.mask; }
     const int j = blockIdx.x * 64 + (threadIdx.x & 63), i = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (i >= H2 || j >= W2) return;
     const int py = H & 1, px = W & 1;
@@ -71,7 +85,7 @@ __global__ void __launch_bounds__(256) k_ms_pool(const float* __restrict__ X, co
 template <bool LAST, bool L0>
 __global__ void __launch_bounds__(256) k_ms_fwd(const float* __restrict__ X, const float* __restrict__ Y, const float* __restrict__ mask, int clamp_y, int C,
                                                 MsLevel lv, MsWin win, float* __restrict__ mapA, float* __restrict__ mapB, float* __restrict__ mapC,
-                                                float* __restrict__ partial) {
+                                                float* __restrict__ partial, MsTab tab) {
     // Quantities travel in pairs -- (x, y), (x^2, y^2) -- so that one v_pk_fma_f32 filters two of them (the kernel is VALU bound: 3 instructions
     // per tap and output instead of the 7 of the scalar form with its products inside the loop); xy goes alone.
     __shared__ v2f sxy[MS_INY][MS_IN + 1];
@@ -81,6 +95,7 @@ __global__ void __launch_bounds__(256) k_ms_fwd(const float* __restrict__ X, con
     __shared__ float red[4];
     const int plane = blockIdx.z, ox = blockIdx.x * MS_T, oy = blockIdx.y * MS_TY;
     const size_t HW = (size_t)lv.H * lv.W;
+    if (L0) { const MsBase b = ms_rebase(tab, plane, C, HW, X, Y, mask, nullptr); X = b.x; Y = b.y; mask = b.mask; }
     {   // all of a lane's loads are issued before the first LDS store (an un-unrolled loop waits for each load in turn)
         constexpr int NL = (MS_INY * MS_IN + 255) / 256;
         float xs_[NL], ys_[NL];
@@ -172,7 +187,8 @@ __global__ void __launch_bounds__(256) k_ms_fwd(const float* __restrict__ X, con
 
 // per plane: level means (fixed-order sums of the tile partials) -> ms, and the scalar dL/d(map pixel) of every level
 struct MsFinal { const float* partial[MS_LEVELS]; int tiles[MS_LEVELS]; float inv_npix[MS_LEVELS]; float wts[MS_LEVELS]; };
-__global__ void __launch_bounds__(256) k_ms_finalize(MsFinal f, int P, float grad_scale, float* __restrict__ g /* [levels][P] */, float* __restrict__ ms_plane) {
+// pmean: planes the value is a mean over (P for one mean over the whole batch; C when every image of the batch is its own loss term)
+__global__ void __launch_bounds__(256) k_ms_finalize(MsFinal f, int P, int pmean, float grad_scale, float* __restrict__ g /* [levels][P] */, float* __restrict__ ms_plane) {
     __shared__ float red[256];
     const int plane = blockIdx.x;
     float v[MS_LEVELS];
@@ -195,7 +211,7 @@ __global__ void __launch_bounds__(256) k_ms_finalize(MsFinal f, int P, float gra
         if (!pos) ms = 0.f;
         if (bad) ms = __builtin_nanf("");
         ms_plane[plane] = ms;
-        for (int l = 0; l < MS_LEVELS; l++) g[(size_t)l * P + plane] = bad ? ms : (pos ? grad_scale * (f.wts[l] * ms / v[l]) * f.inv_npix[l] / (float)P : 0.f);
+        for (int l = 0; l < MS_LEVELS; l++) g[(size_t)l * P + plane] = bad ? ms : (pos ? grad_scale * (f.wts[l] * ms / v[l]) * f.inv_npix[l] / (float)pmean : 0.f);
     }
 }
 // value: out (+)= a + b * mean(ms), a fixed-order mean.  store = 1: the word is the caller's own slot (the fused training steps keep one slot per view and add the
@@ -206,12 +222,20 @@ __global__ void k_ms_mean(const float* __restrict__ ms_plane, int P, float a, fl
     const float val = a + b * (s / (float)P);
     if (store) *out = val; else atomicAdd(out, val);
 }
+// one value per image (thread = image): out0 + image * stride bytes <- a + b * mean of the image's C planes
+__global__ void k_ms_mean_images(const float* __restrict__ ms_plane, int B, int C, float a, float b, float* __restrict__ out0, size_t stride) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    float s = 0.f;
+    for (int c = 0; c < C; c++) s += ms_plane[i * C + c];
+    *(float*)((char*)out0 + (size_t)i * stride) = a + b * (s / (float)C);
+}
 
 // backward of one level: gradient w.r.t. the level's y over the whole image (+ the pooled parent level's gradient)
 template <bool L0>
 __global__ void __launch_bounds__(256) k_ms_bwd(const float* __restrict__ X, const float* __restrict__ Y, const float* __restrict__ mask, int clamp_y, int C,
                                                 MsLevel lv, MsWin win, const float* __restrict__ mapA, const float* __restrict__ mapB, const float* __restrict__ mapC,
-                                                const float* __restrict__ g, const float* __restrict__ parent, int H2, int W2, float* __restrict__ out, int accumulate) {
+                                                const float* __restrict__ g, const float* __restrict__ parent, int H2, int W2, float* __restrict__ out, int accumulate, MsTab tab) {
     __shared__ v2f smab[MS_INY][MS_IN + 1];    // maps A, B as a pair (one packed FMA filters both), C alone
     __shared__ float smc[MS_INY][MS_IN + 1];
     __shared__ v2f hab[MS_INY][MS_T + 1];
@@ -273,6 +297,7 @@ __global__ void __launch_bounds__(256) k_ms_bwd(const float* __restrict__ X, con
     }
     const float gl = g[plane];
     const size_t HW = (size_t)lv.H * lv.W;
+    if (L0) { const MsBase b = ms_rebase(tab, plane, C, HW, X, Y, mask, out); X = b.x; Y = b.y; mask = b.mask; out = b.out; }
 #pragma unroll
     for (int j = 0; j < MS_VO; j++) {
         const int r = r0 + j;
@@ -329,6 +354,8 @@ MsWin ms_window() {
 
 int ms_value_grad(const float* x, const float* y, const float* mask, int clamp_y, int B, int C, int H, int W, float grad_scale, int accumulate, float* dL_dy,
                   float va, float vb, float* ms_out, void* workspace, hipStream_t s, int store_value = 0);
+static int ms_run(const float* x, const float* y, const float* mask, const MsTab& tab, int clamp_y, int B, int C, int H, int W, float grad_scale, int accumulate, float* dL_dy,
+                  float va, float vb, float* ms_out, size_t out_stride, bool per_image, void* workspace, hipStream_t s, int store_value);
 
 extern "C" {
 
@@ -350,6 +377,27 @@ int ms_value_grad(const float* x, const float* y, const float* mask, int clamp_y
                   float va, float vb, float* ms_out, void* workspace, hipStream_t s, int store_value) {
     if (B <= 0 || C <= 0) return 0;
     if (!x || !y || !dL_dy || !workspace) { c3d_set_error("c3d_msssim_value_grad: NULL pointer"); return -1; }
+    MsTab tab{};
+    return ms_run(x, y, mask, tab, clamp_y, B, C, H, W, grad_scale, accumulate, dL_dy, va, vb, ms_out, 0, false, workspace, s, store_value);
+}
+// The MS-SSIM terms of B <= 16 images that live in separate buffers, EVERY image its own loss term (the views of a fused 3DGS training step), in one set of launches:
+// image i: x[i] / y[i] / mask[i] (NULL = none) / dy[i] are [C, H, W] planes ([1, H, W] for the mask);  *(out0 + i * out_stride bytes) = va + vb * MS-SSIM(image i),
+// dy[i] (+)= grad_scale * d MS-SSIM(image i) / dy.  Same values, bit for bit, as B calls of ms_value_grad with B = 1 (planes never mix; the per-image mean is over C).
+int ms_value_grad_images(const float* const* x, const float* const* y, const float* const* mask, float* const* dy, int clamp_y, int B, int C, int H, int W, float grad_scale,
+                         int accumulate, float va, float vb, float* out0, size_t out_stride, void* workspace, hipStream_t s) {
+    if (B <= 0 || C <= 0) return 0;
+    if (B > MS_TAB_MAX) { c3d_set_error("ms_value_grad_images: at most %d images per call", MS_TAB_MAX); return -1; }
+    if (!x || !y || !dy || !workspace) { c3d_set_error("ms_value_grad_images: NULL pointer"); return -1; }
+    MsTab tab{};
+    tab.n = B;
+    for (int i = 0; i < B; i++) {
+        if (!x[i] || !y[i] || !dy[i]) { c3d_set_error("ms_value_grad_images: NULL image %d", i); return -1; }
+        tab.x[i] = x[i]; tab.y[i] = y[i]; tab.mask[i] = mask ? mask[i] : nullptr; tab.dy[i] = dy[i];
+    }
+    return ms_run(nullptr, nullptr, nullptr, tab, clamp_y, B, C, H, W, grad_scale, accumulate, nullptr, va, vb, out0, out_stride, true, workspace, s, 1);
+}
+static int ms_run(const float* x, const float* y, const float* mask, const MsTab& tab, int clamp_y, int B, int C, int H, int W, float grad_scale, int accumulate, float* dL_dy,
+                  float va, float vb, float* ms_out, size_t out_stride, bool per_image, void* workspace, hipStream_t s, int store_value) {
     if ((H < W ? H : W) <= (2 * MS_R) * (1 << (MS_LEVELS - 1))) { c3d_set_error("c3d_msssim_value_grad: image sides must exceed %d for %d scales", (2 * MS_R) << (MS_LEVELS - 1), MS_LEVELS); return -1; }
     const int P = B * C;
     MsPlan pl;
@@ -360,6 +408,7 @@ int ms_value_grad(const float* x, const float* y, const float* mask, int clamp_y
     X[0] = x; Y[0] = y;
     for (int l = 1; l < MS_LEVELS; l++) { X[l] = (const float*)(ws + pl.off_x[l]); Y[l] = (const float*)(ws + pl.off_y[l]); }
     static const float wts[MS_LEVELS] = {0.0448f, 0.2856f, 0.3001f, 0.2363f, 0.1333f};
+    const MsTab none{};
     MsFinal fin;
     C3dProfScope ps(C3D_P_MSSSIM, s);
     for (int l = 0; l < MS_LEVELS; l++) {
@@ -368,21 +417,22 @@ int ms_value_grad(const float* x, const float* y, const float* mask, int clamp_y
         float* mA = (float*)(ws + pl.off_map[l]); float* mB = mA + val; float* mC = mB + val;
         float* part = (float*)(ws + pl.off_part[l]);
         const dim3 grid(L.tx, L.ty, P);
-        if (l == 0)                    hipLaunchKernelGGL((k_ms_fwd<false, true>), grid, dim3(256), 0, s, X[l], Y[l], mask, clamp_y, C, L, win, mA, mB, mC, part);
-        else if (l < MS_LEVELS - 1)    hipLaunchKernelGGL((k_ms_fwd<false, false>), grid, dim3(256), 0, s, X[l], Y[l], (const float*)nullptr, 0, C, L, win, mA, mB, mC, part);
-        else                           hipLaunchKernelGGL((k_ms_fwd<true, false>), grid, dim3(256), 0, s, X[l], Y[l], (const float*)nullptr, 0, C, L, win, mA, mB, mC, part);
+        if (l == 0)                    hipLaunchKernelGGL((k_ms_fwd<false, true>), grid, dim3(256), 0, s, X[l], Y[l], mask, clamp_y, C, L, win, mA, mB, mC, part, tab);
+        else if (l < MS_LEVELS - 1)    hipLaunchKernelGGL((k_ms_fwd<false, false>), grid, dim3(256), 0, s, X[l], Y[l], (const float*)nullptr, 0, C, L, win, mA, mB, mC, part, none);
+        else                           hipLaunchKernelGGL((k_ms_fwd<true, false>), grid, dim3(256), 0, s, X[l], Y[l], (const float*)nullptr, 0, C, L, win, mA, mB, mC, part, none);
         fin.partial[l] = part; fin.tiles[l] = L.tx * L.ty; fin.inv_npix[l] = 1.f / ((float)L.Hv * (float)L.Wv); fin.wts[l] = wts[l];
         if (l < MS_LEVELS - 1) {
             const MsLevel& N = pl.lv[l + 1];
             const dim3 pg(c3d_cdiv(N.W, 64), c3d_cdiv(N.H, 4), P);
-            if (l == 0) hipLaunchKernelGGL((k_ms_pool<true>), pg, dim3(256), 0, s, X[l], Y[l], mask, clamp_y, C, L.H, L.W, N.H, N.W, (float*)(ws + pl.off_x[l + 1]), (float*)(ws + pl.off_y[l + 1]));
-            else        hipLaunchKernelGGL((k_ms_pool<false>), pg, dim3(256), 0, s, X[l], Y[l], (const float*)nullptr, 0, C, L.H, L.W, N.H, N.W, (float*)(ws + pl.off_x[l + 1]), (float*)(ws + pl.off_y[l + 1]));
+            if (l == 0) hipLaunchKernelGGL((k_ms_pool<true>), pg, dim3(256), 0, s, X[l], Y[l], mask, clamp_y, C, L.H, L.W, N.H, N.W, (float*)(ws + pl.off_x[l + 1]), (float*)(ws + pl.off_y[l + 1]), tab);
+            else        hipLaunchKernelGGL((k_ms_pool<false>), pg, dim3(256), 0, s, X[l], Y[l], (const float*)nullptr, 0, C, L.H, L.W, N.H, N.W, (float*)(ws + pl.off_x[l + 1]), (float*)(ws + pl.off_y[l + 1]), none);
         }
     }
     float* g = (float*)(ws + pl.off_g);
     float* msp = (float*)(ws + pl.off_ms);
-    hipLaunchKernelGGL(k_ms_finalize, dim3(P), dim3(256), 0, s, fin, P, grad_scale, g, msp);
-    if (ms_out) hipLaunchKernelGGL(k_ms_mean, dim3(1), dim3(1), 0, s, msp, P, va, vb, ms_out, store_value);
+    hipLaunchKernelGGL(k_ms_finalize, dim3(P), dim3(256), 0, s, fin, P, per_image ? C : P, grad_scale, g, msp);
+    if (ms_out && per_image) hipLaunchKernelGGL(k_ms_mean_images, dim3(1), dim3(64), 0, s, msp, B, C, va, vb, ms_out, out_stride);
+    else if (ms_out) hipLaunchKernelGGL(k_ms_mean, dim3(1), dim3(1), 0, s, msp, P, va, vb, ms_out, store_value);
     for (int l = MS_LEVELS - 1; l >= 0; l--) {
         const MsLevel& L = pl.lv[l];
         const size_t val = (size_t)P * L.Hv * L.Wv;
@@ -390,8 +440,8 @@ int ms_value_grad(const float* x, const float* y, const float* mask, int clamp_y
         const float* parent = l < MS_LEVELS - 1 ? (const float*)(ws + pl.off_grad[l + 1]) : nullptr;
         const int H2 = l < MS_LEVELS - 1 ? pl.lv[l + 1].H : 0, W2 = l < MS_LEVELS - 1 ? pl.lv[l + 1].W : 0;
         const dim3 grid(c3d_cdiv(L.W, MS_T), c3d_cdiv(L.H, MS_TY), P);
-        if (l == 0) hipLaunchKernelGGL((k_ms_bwd<true>), grid, dim3(256), 0, s, X[l], Y[l], mask, clamp_y, C, L, win, mA, mB, mC, g + (size_t)l * P, parent, H2, W2, dL_dy, accumulate);
-        else        hipLaunchKernelGGL((k_ms_bwd<false>), grid, dim3(256), 0, s, X[l], Y[l], (const float*)nullptr, 0, C, L, win, mA, mB, mC, g + (size_t)l * P, parent, H2, W2, (float*)(ws + pl.off_grad[l]), 0);
+        if (l == 0) hipLaunchKernelGGL((k_ms_bwd<true>), grid, dim3(256), 0, s, X[l], Y[l], mask, clamp_y, C, L, win, mA, mB, mC, g + (size_t)l * P, parent, H2, W2, dL_dy, accumulate, tab);
+        else        hipLaunchKernelGGL((k_ms_bwd<false>), grid, dim3(256), 0, s, X[l], Y[l], (const float*)nullptr, 0, C, L, win, mA, mB, mC, g + (size_t)l * P, parent, H2, W2, (float*)(ws + pl.off_grad[l]), 0, none);
     }
     C3D_LAUNCH_CHECK();
     return 0;

@@ -23,7 +23,10 @@
 
 
 #define SCAN_THREADS 256
-#define SCAN_ITEMS 8
+#ifndef SCAN_VEC
+#define SCAN_VEC 4                       // 16-byte chunks per lane: a tile is SCAN_VEC sub-tiles of 1024 elements
+#endif
+#define SCAN_ITEMS (4 * SCAN_VEC)
 #define SCAN_TILE (SCAN_THREADS * SCAN_ITEMS)
 #define LB_SPIN_LIMIT (1u << 21)     // polls of one word before a workgroup gives up (~0.1 s): bounded, never a hang
 
@@ -65,12 +68,12 @@ struct ScanTail { uint32_t* meta; uint32_t* status; uint32_t cap; const uint2* r
 __device__ __forceinline__ uint32_t rect_area(uint2 r) { return ((r.y & 0xFFFFu) - (r.x & 0xFFFFu)) * ((r.y >> 16) - (r.x >> 16)); }
 
 // Data movement (round 4: with V views per launch the scans are bandwidth-sized work, and eight 4-byte accesses per lane at a 32-byte lane stride cost eight
-// partially used cache lines per wave instruction): a tile is two halves of 1024 elements and lane t owns elements [4t, 4t + 4) of EACH half -- every load / store
-// is 16 bytes per lane on consecutive addresses.  The block scan runs over the (first-half sum, second-half sum) pair of every lane at once.
+// partially used cache lines per wave instruction): a tile is SCAN_VEC sub-tiles of 1024 elements and lane t owns elements [4t, 4t + 4) of EACH sub-tile -- every
+// load / store is 16 bytes per lane on consecutive addresses.  The block scan runs over the SCAN_VEC sub-tile sums of every lane at once.
 template <bool EXCL, bool GATHER>
 __global__ void __launch_bounds__(SCAN_THREADS) k_scan_lb(const uint32_t* __restrict__ in, const uint32_t* __restrict__ idx, uint32_t* __restrict__ out, size_t n,
                                                            uint32_t* __restrict__ state, uint32_t* __restrict__ err, ScanTail tail, size_t vs) {
-    __shared__ uint32_t lds[2][4];
+    __shared__ uint32_t lds[SCAN_VEC][4];
     __shared__ uint32_t s_tile, s_prefix;
     in = c3d_view_ptr(in, vs); idx = c3d_view_ptr(idx, vs); out = c3d_view_ptr(out, vs); state = c3d_view_ptr(state, vs);
     tail.meta = c3d_view_ptr(tail.meta, vs); tail.rect = c3d_view_ptr(tail.rect, vs); tail.einfo = c3d_view_ptr(tail.einfo, vs);   // err / tail.status: shared by the views
@@ -81,11 +84,11 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_lb(const uint32_t* __rest
     const uint32_t tile = s_tile;
     if ((size_t)tile * SCAN_TILE >= n) return;
     const int lane = c3d_lane(), wave = threadIdx.x >> 6;
-    uint32_t v[2][4];
-    uint32_t hs[2];
+    uint32_t v[SCAN_VEC][4];
+    uint32_t hs[SCAN_VEC];
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
-        const size_t b = (size_t)tile * SCAN_TILE + (size_t)h * (SCAN_TILE / 2) + (size_t)threadIdx.x * 4;
+    for (int h = 0; h < SCAN_VEC; h++) {
+        const size_t b = (size_t)tile * SCAN_TILE + (size_t)h * (SCAN_THREADS * 4) + (size_t)threadIdx.x * 4;
         if (GATHER) {
             const uint2* rects = reinterpret_cast<const uint2*>(in);
             uint2 rc[4];
@@ -108,19 +111,25 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_lb(const uint32_t* __rest
         }
         hs[h] = v[h][0] + v[h][1] + v[h][2] + v[h][3];
     }
-    // block-wide exclusive scan of both half sums at once
-    uint32_t inc0 = c3d_wave_incl_scan(hs[0]), inc1 = c3d_wave_incl_scan(hs[1]);
-    if (lane == 63) { lds[0][wave] = inc0; lds[1][wave] = inc1; }
-    __syncthreads();
-    uint32_t ex[2] = {inc0 - hs[0], inc1 - hs[1]}, tot0 = 0, tot1 = 0;
+    // block-wide exclusive scan of all sub-tile sums at once
+    uint32_t ex[SCAN_VEC], tot = 0;
 #pragma unroll
-    for (int w = 0; w < SCAN_THREADS / 64; w++) {
-        const uint32_t t0 = lds[0][w], t1 = lds[1][w];
-        if (w < wave) { ex[0] += t0; ex[1] += t1; }
-        tot0 += t0; tot1 += t1;
+    for (int h = 0; h < SCAN_VEC; h++) {
+        const uint32_t inc = c3d_wave_incl_scan(hs[h]);
+        if (lane == 63) lds[h][wave] = inc;
+        ex[h] = inc - hs[h];
     }
-    ex[1] += tot0;                                   // the second half follows the whole first half
-    const uint32_t tot = tot0 + tot1;
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < SCAN_VEC; h++) {
+        ex[h] += tot;                                // a sub-tile follows all of the sub-tiles before it
+#pragma unroll
+        for (int w = 0; w < SCAN_THREADS / 64; w++) {
+            const uint32_t t = lds[h][w];
+            if (w < wave) ex[h] += t;
+            tot += t;
+        }
+    }
     if (threadIdx.x < 64) {
         if (lane == 0) st_agent64(&status[tile], ((tile == 0 ? LB_INCL : LB_AGG) << 32) | tot);
         uint32_t prefix = 0;
@@ -157,8 +166,8 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_lb(const uint32_t* __rest
     __syncthreads();
     const uint32_t pre = s_prefix;
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
-        const size_t b = (size_t)tile * SCAN_TILE + (size_t)h * (SCAN_TILE / 2) + (size_t)threadIdx.x * 4;
+    for (int h = 0; h < SCAN_VEC; h++) {
+        const size_t b = (size_t)tile * SCAN_TILE + (size_t)h * (SCAN_THREADS * 4) + (size_t)threadIdx.x * 4;
         uint32_t run = pre + ex[h], o[4], e[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) { e[i] = run; run += v[h][i]; o[i] = EXCL ? e[i] : run; }
@@ -273,7 +282,9 @@ uint32_t* c3d_scan_error_word(void* tmp) { return (uint32_t*)tmp + 1; }
 // [tiles/16 + 1][256]; a word = flag << 30 | count, flag 1 = aggregate, 2 = inclusive.
 // ------------------------------------------------------------------------------------------
 #define RS_THREADS 256
+#ifndef RS_ITEMS
 #define RS_ITEMS 16
+#endif
 #define RS_TILE (RS_THREADS * RS_ITEMS)
 #define RS_RADIX 256
 #define RS_MAX_PASSES 4
@@ -331,7 +342,9 @@ __device__ __forceinline__ uint32_t rs_wait(const uint32_t* p, uint32_t x, uint3
     return x;
 }
 
-// 16 keys per thread: 4096 keys and 39 KB of LDS per workgroup, four workgroups per CU (8 and 32 keys per thread measured worse in round 3: profiles/r03/)
+// 16 keys per thread: 4096 keys and 39 KB of LDS per workgroup, four workgroups per CU.  Measured and dropped: 8 keys per thread (twice the tiles: the tile sort of an
+// 8-view step 0.48 -> 0.82 ms, profiles/r04 -- a pass is bound by tiles in flight x tile lifetime, and the lifetime does not shrink with the tile); ONE 16 KB reorder
+// buffer used for the keys and then for the values (23 KB: seven workgroups per CU -- but the kernel wants ~126 VGPRs, and capped at 72-96 it spills: 0.48 -> 0.8-1.06 ms).
 template <bool IOTA, int ITEMS>
 __global__ void __launch_bounds__(RS_THREADS, 4) k_onesweep(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                              uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
