@@ -116,7 +116,7 @@ def load_calibration():
 
 # which calibration pattern describes a kernel's reads / writes (profiles/microbench/pmc_calib.hip); None = the guide's x2 for reads, raw for writes
 PMC_PATTERN = {"k_composite_bwd": ("k_cal_gather64", "k_cal_record_write48"), "k_composite_fwd_w": ("k_cal_gather64", "k_cal_stream_write"),
-               "k_composite_fwd": ("k_cal_gather64", "k_cal_stream_write"), "k_preprocess_views": ("k_cal_stream_read", "k_cal_stream_write"),
+               "k_preprocess_views_r": ("k_cal_stream_read", "k_cal_stream_write"),
                "k_bwd_views_geom": ("k_cal_gather64", "k_cal_stream_write"), "k_bwd_views_sh": ("k_cal_stream_read", "k_cal_stream_write"),
                "k_emit": ("k_cal_gather64", "k_cal_stream_write"), "k_adam": ("k_cal_stream_read", "k_cal_stream_write")}
 
@@ -335,6 +335,13 @@ def main_mesh(a, world, rank, dev, dist):
             roof["traffic_note"] = "FETCH_SIZE(raw)+WRITE_SIZE per view over the kernels of this group, profiles/%s; fetch x2-corrected: %d" % (pmc_file, int((grp["fetch_MB_x2"] + grp["write_MB"]) * 1e6))
         elif stale:
             roof["stale"] = "profiles/%s was measured on code %s" % (pmc_file, stale)
+    # whole-chain figure by SURVEY 8(d)'s op-level mesh formula: B_mesh_fwd = 16 V + 12 T + 220 P, backward = 2 x the image-space terms + 24 V + 12 Ht Wt
+    Ht = Wt = 1024
+    b_view = (16 * V + 12 * T + 220 * P) + (2 * 220 * P + 24 * V + 12 * Ht * Wt)
+    per_view_s = dt / max(a.steps * a.views_per_gpu, 1)
+    chain = {"what": "SURVEY 8(d) op-level compulsory bytes of one mesh view (forward + backward: what the UNFUSED op graph must move) / wall time per view in the timed region",
+             "bytes_per_view": int(b_view), "ms_per_view": round(per_view_s * 1e3, 4), "achieved": round(b_view / per_view_s / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+             "frac": round(b_view / per_view_s / 1e9 / HBM_PEAK_GBPS, 4)} if per_view_s > 0 else None
     cpu = None
     if rank == 0 and world == 1 and a.cpu_baseline != "off":
         cpu = mesh_cpu_baseline(v, f, vt, H, W)
@@ -345,7 +352,7 @@ def main_mesh(a, world, rank, dev, dist):
                           "config": {"workload": "DiffRastMesh fwd+bwd, %d-triangle displaced sphere, 1024^2 albedo, 1024x1024, %d views/GPU/step" % (T, a.views_per_gpu),
                                      "render_path": ("step: c3d_mesh_train_views, %d view lanes" % mstep.lanes) if use_step else "fused: one autograd call per view",
                                      "parallelism": "view-parallel dp%d" % world, "host_enqueue_ms_per_step": round(t_enq / a.steps * 1e3, 3)},
-                          "roofline": roof, "cpu_baseline": cpu, "kernels": kern, "code_digest": code_digest()}))
+                          "roofline": roof, "roofline_chain": chain, "cpu_baseline": cpu, "kernels": kern, "code_digest": code_digest()}))
     if world > 1:
         dist.destroy_process_group()
 
@@ -394,7 +401,14 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    # test hook: C3D_BENCH_FORCE_DIST=1 under torchrun with ONE rank creates the nccl group and issues every collective of the N > 1 path anyway (RCCL on HIP memory
+    # on a one-GPU box: tests/test_zz_rccl_world1.py); timings of such a run carry the (pointless) collectives
+    force_dist = os.environ.get("C3D_BENCH_FORCE_DIST") == "1" and world == 1 and "RANK" in os.environ
+    if force_dist:
+        from c3d_hip import parallel as _par
+        _par.SKIP_SINGLE_RANK = False
+    dist_on = world > 1 or force_dist        # the step ends with a gradient exchange
+    if dist_on:
         import torch.distributed as dist
         if share:
             dist.init_process_group("gloo")
@@ -512,7 +526,7 @@ def main():
             full = loss_kind == "full"      # BASELINE config 3's loss: masked by the target alpha, + 0.2 (1 - MS-SSIM), all inside the library call
             # N > 1, all-reduce mode: the per-Gaussian backward pass runs in `--exchange-chunks` Gaussian ranges and each range's f_rest rows (76 % of the
             # gradient bytes) start their all-reduce as soon as they are enqueued, underneath the next range's kernels (FlatGrads.exchange_rows)
-            overlap = world > 1 and a.exchange == "allreduce" and a.exchange_chunks > 1
+            overlap = dist_on and a.exchange == "allreduce" and a.exchange_chunks > 1
             fused_step.run(settings, [q.detach() for q in plist], step_grads, [tg[0] for tg in targets], [tg[1] for tg in targets], ([tg[1] for tg in targets] if full else None),
                            w_l1=0.8, w_l2=0.0, w_alpha_mse=3.0, scale=1.0 / (a.views_per_gpu * world), accumulate=False, w_ssim=(0.2 if full else 0.0),
                            param_chunks=(a.exchange_chunks if overlap else 1), after_chunk=(flat_grads.exchange_rows if overlap else None))
@@ -548,9 +562,9 @@ def main():
             return
         if exchanged:
             pass
-        elif a.mode != "fwd" and world > 1 and fused_step is not None and not collect:
+        elif a.mode != "fwd" and dist_on and fused_step is not None and not collect:
             flat_grads.exchange(None, a.exchange, average=False)
-        elif a.mode != "fwd" and world > 1:
+        elif a.mode != "fwd" and dist_on:
             flat = torch.cat([q.grad.reshape(N, -1) for q in plist], dim=1)   # [N, 59] dense gradient
             if a.exchange == "allgather":
                 buf = torch.empty((world * N, flat.shape[1]), device=dev)
@@ -576,7 +590,7 @@ def main():
         if fused_step is not None:
             fused_step.finish()              # a deferred step's status words: examined INSIDE the timed region
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if dist_on:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -624,7 +638,7 @@ def main():
             fused_step = keep_obj
         else:
             view_render = keep_obj
-    if world > 1:
+    if dist_on:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -638,8 +652,9 @@ def main():
     kern = {}
     for name, (ms, n) in prof.items():
         avg = ms / n
-        vpl = prof_views / n if name in ("gs_preprocess", "gs_preprocess_bwd") else 1.0     # these two cover several views per launch (all views of a step / of a group)
-        kern[name] = {"avg_ms": round(avg, 4), "launches": n, "share": 0.0, "ms_per_view": round(ms / max(prof_views, 1), 4),
+        # every stage of the chain is ONE launch for all views of a group (round 4): the units a launch processes = views per timed scope
+        vpl = prof_views / n if name in ("gs_preprocess", "gs_preprocess_bwd", "gs_depth_sort", "gs_emit", "gs_tile_sort", "gs_ranges", "gs_composite_fwd", "gs_composite_bwd") else 1.0
+        kern[name] = {"avg_ms": round(avg, 4), "launches": n, "views_per_launch": round(vpl, 2), "share": 0.0, "ms_per_view": round(ms / max(prof_views, 1), 4),
                       "alg_GBps": round(alg.get(name, 0) * vpl / (avg * 1e-3) / 1e9, 1) if avg > 0 else None}
     tot = sum(ms for ms, _ in prof.values()) or 1.0
     for name, (ms, n) in prof.items():
@@ -648,7 +663,7 @@ def main():
     # The batched kernels stream the parameters once per LAUNCH while SURVEY 8(d) credits them per VIEW: their alg_GBps is a contract figure, not an HBM rate.
     cal, cal_file = load_calibration()
     pmc_all, pmc_all_file, _ = load_profile_json("_pmc_traffic.json", exclude="_mesh_")
-    group_kernels = {"gs_composite_bwd": ["k_composite_bwd"], "gs_composite_fwd": ["k_composite_fwd_w", "k_composite_fwd"], "gs_preprocess": ["k_preprocess_views", "k_preprocess"],
+    group_kernels = {"gs_composite_bwd": ["k_composite_bwd"], "gs_composite_fwd": ["k_composite_fwd_w"], "gs_preprocess": ["k_preprocess_views_r", "k_preprocess"],
                      "gs_preprocess_bwd": ["k_bwd_views_geom", "k_bwd_views_sh"], "gs_emit": ["k_emit"], "adam": ["k_adam"]}
     for name, bases in group_kernels.items():
         if name not in kern:
@@ -666,20 +681,25 @@ def main():
     # MI355X_MICROARCH.md: FETCH_SIZE under-reports wide streaming reads by 2x on gfx950 -- both figures are in the file).
     pmc, pmc_file, pmc_stale = load_profile_json("_pmc_traffic.json", exclude="_mesh_")
     # kernel behind a profiling group; template instances ("k_composite_bwd<true>": with the fused pixel loss) are matched by base name, most launches first
-    pmc_base = {"gs_composite_bwd": "k_composite_bwd", "gs_composite_fwd": "k_composite_fwd_w", "gs_preprocess": "k_preprocess_views",
+    pmc_base = {"gs_composite_bwd": "k_composite_bwd", "gs_composite_fwd": "k_composite_fwd_w", "gs_preprocess": "k_preprocess_views_r",
                 "gs_preprocess_bwd": "k_bwd_views_geom", "gs_emit": "k_emit"}
 
-    def kernel_row(table, group, launches=lambda r: r.get("launches", 0)):
+    def kernel_row(table, group, launches=None):
+        # the template instance of the group's kernel that took the most time in the profiled command (the multi-view launches of the timed path, not the per-view
+        # launches of the warm-up's statistics pass)
         base = pmc_base.get(group)
         cand = [k for k in table if not k.startswith("_") and k.split("<")[0].strip() == base]
-        return max(cand, key=lambda k: float(launches(table[k]))) if cand else None
+        return max(cand, key=lambda k: float(table[k].get("launches", 0)) * float(table[k].get("avg_us", 0) or 0)) if cand else None
     if prof:
         dom = max(prof, key=lambda k: prof[k][0])
         avg_s = prof[dom][0] / prof[dom][1] * 1e-3
-        ach = alg.get(dom, 0) / avg_s / 1e9
+        dom_vpl = kern[dom]["views_per_launch"]
+        dom_bytes = alg.get(dom, 0) * dom_vpl                 # SURVEY 8(d)'s per-view figure x the views one launch processes
+        ach = dom_bytes / avg_s / 1e9
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None, "avg_ms": round(avg_s * 1e3, 4),
-                "alg_bytes_per_launch": int(alg.get(dom, 0))}
+                "alg_bytes_per_launch": int(dom_bytes), "alg_bytes_per_view": int(alg.get(dom, 0)), "views_per_launch": dom_vpl,
+                "measured": "HIP events on the launch stream inside the timed region (one group of views per launch: the kernel runs alone)"}
         rec_name = kernel_row(pmc, dom)
         rec = pmc.get(rec_name) if rec_name else None
         if rec and a.workload == "gs" and N == 1_000_000 and (W, H) == (1920, 1080):
@@ -707,12 +727,28 @@ def main():
                     if True:
                         n_ins = sum(float(row[c]) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_BRANCH", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM")) / 32.0
                         roof["issue"] = {"instructions_per_simd": int(n_ins), "valu": int(float(row["SQ_INSTS_VALU"]) / 32), "salu": int(float(row["SQ_INSTS_SALU"]) / 32),
+                                         "lds": int(float(row["SQ_INSTS_LDS"]) / 32),
                                          "busy_cycles": int(float(row["SQ_BUSY_CYCLES"])), "cycles_per_instruction": round(float(row["SQ_BUSY_CYCLES"]) / n_ins, 2),
                                          "kernel": hit, "source": "profiles/" + sq[-1]}
+                        # the secondary roofline of SURVEY 8(d): FP32 vector issue.  One VALU instruction = 64 lane operations; the chip's peak is 157.3 TFLOP/s with
+                        # every instruction an FMA = 78.6 T lane-operations per second.  valu_frac = cycles the VALU pipes were busy / kernel cycles (pipe-activity pass).
+                        us = float(row.get("avg_us", 0) or 0)
+                        if us > 0:
+                            ops = float(row["SQ_INSTS_VALU"]) * 32.0 * 64.0 / (us * 1e-6)     # counters are per shader engine: x 32 engines, x 64 lanes
+                            roof["issue"]["valu_lane_ops_per_s"] = round(ops, -9)
+                            roof["issue"]["valu_lane_ops_frac_of_78.6T"] = round(ops / 78.6e12, 4)
+                        pa_file = sq[-1].replace("_sq_instruction_mix_", "_sq_pipe_activity_")
+                        if os.path.exists(os.path.join(ROOT, "profiles", pa_file)):
+                            pa = {r_["kernel"]: r_ for r_ in csv.DictReader(open(os.path.join(ROOT, "profiles", pa_file)))}
+                            if hit in pa:
+                                # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the 32 SIMDs of a shader engine; SQ_BUSY_CYCLES are the engine's cycles
+                                roof["issue"]["valu_frac"] = round(float(pa[hit]["SQ_ACTIVE_INST_VALU"]) * 4.0 / 32.0 / float(row["SQ_BUSY_CYCLES"]), 4)
+                                roof["issue"]["lds_frac"] = round(float(pa[hit]["SQ_LDS_IDX_ACTIVE"]) / 8.0 / float(row["SQ_BUSY_CYCLES"]), 4)
+                                roof["issue"]["pipe_source"] = "profiles/" + pa_file
         except Exception:
             pass
         if prof_conc is not None:
-            roof["measured"] = "single-lane pass after the timed region (kernels run alone); timed region used %d view lanes" % a.lanes
+            roof["measured"] = "single-group pass after the timed region (kernels run alone); the timed region had %d view groups in flight" % a.lanes
             if prof_conc and dom in prof_conc:
                 roof["avg_ms_concurrent"] = round(prof_conc[dom][0] / prof_conc[dom][1], 4)
     # whole-chain figure: SURVEY 8(d)'s algorithmic bytes of a VIEW over the wall time a view takes in the timed
@@ -750,9 +786,12 @@ def main():
             if a.mode != "fwd":
                 O.backward(ost, np.ones((3, H, W), np.float32) / P, nthreads=ncore)
             tc = time.perf_counter() - t1
-            cpu = {"value": round(P / tc / 1e6, 4), "unit": "Mpixels/s", "cores": ncore, "kind": "port",
-                   "sample": "1 view of the same workload (%d Gaussians, %dx%d, %s) on the CPU oracle, %.1f s; OpenMP over Gaussians / tiles, but the pair sort is ONE "
-                             "serial qsort, so `cores` overstates what runs in parallel -- a stated baseline, not a target" % (N, W, H, a.mode, tc)}
+            t_sort = O.last_sort_seconds(np.float32)
+            cpu = {"value": round(P / tc / 1e6, 4), "unit": "Mpixels/s", "cores": ncore, "kind": "port", "seconds": round(tc, 2), "serial_sort_seconds": round(t_sort, 2),
+                   "value_without_serial_sort": round(P / max(tc - t_sort, 1e-9) / 1e6, 4),
+                   "sample": "1 view of the same workload (%d Gaussians, %dx%d, %s) on the CPU oracle, %.1f s of which %.1f s are ONE serial qsort of the (tile, depth) pairs; the rest "
+                             "(projection, compositing, backward) runs OpenMP over Gaussians / tiles on %d threads.  `value_without_serial_sort` is what those threads do; a stated "
+                             "baseline, not a target" % (N, W, H, a.mode, tc, t_sort, ncore)}
         except Exception as ex:   # the baseline leg must never take the bench down
             cpu = {"value": None, "unit": "Mpixels/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (ex,)}
 
@@ -796,8 +835,8 @@ def main():
             "config": {"workload": "3DGS %s, %d synthetic Gaussians (seed 1234) SH deg %d, %dx%d, %d orbit views/GPU/step of the 64-camera orbit"
                                    % (a.mode, N, deg, W, H, a.views_per_gpu),
                        "global_views_per_step": a.views_per_gpu * world, "parallelism": "view-parallel dp%d" % world,
-                       "exchange": (a.exchange if world > 1 and a.mode != "fwd" else "none"),
-                       "exchange_chunks": (a.exchange_chunks if world > 1 and a.mode != "fwd" and a.exchange == "allreduce" and fused_step is not None else 1), "render_path": a.render_path,
+                       "exchange": (a.exchange if dist_on and a.mode != "fwd" else "none"), "dist_backend": (dist.get_backend() if dist_on else None),
+                       "exchange_chunks": (a.exchange_chunks if dist_on and a.mode != "fwd" and a.exchange == "allreduce" and fused_step is not None else 1), "render_path": a.render_path,
                        "loss": (None if a.mode == "fwd" else ("0.8 L1 + 3 MSE(alpha) + 0.2 (1 - MS-SSIM), masked (BASELINE config 3)%s" % (", MS-SSIM by torch ops" if ms_ssim is not None else ", fused HIP")
                                                                 if loss_kind != "l1alpha" and a.render_path == "step" else "0.8 L1 + 3 MSE(alpha)")), "view_lanes": (a.lanes if a.render_path == "step" else 1),
                        "host_enqueue_ms_per_step": (round(fused_step.last_host_ms, 3) if fused_step is not None else None),
@@ -808,7 +847,7 @@ def main():
             "code_digest": code_digest(),
         }
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

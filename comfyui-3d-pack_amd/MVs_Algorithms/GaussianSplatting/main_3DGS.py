@@ -324,6 +324,9 @@ class GaussianSplatting3D:
                 progress(step + 1)
         if self._step is not None:
             self._step.finish()
+        if self._zero is not None:      # ZeRO-1: hand the sharded Adam moments back to the optimizer (capture() / state_dict() after training must see them)
+            self._zero.unshard()
+            self._zero = None
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
         self.need_update = True

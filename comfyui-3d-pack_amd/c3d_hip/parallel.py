@@ -19,6 +19,27 @@ import math
 import torch
 import torch.distributed as dist
 
+# A process group of ONE rank has nothing to exchange and every function below returns early for it.  Set to False to issue the collectives anyway: a
+# world-1 "nccl" group on a single GPU then drives every RCCL call of this module on HIP memory (tests/test_zz_rccl_world1.py) -- the only RCCL the
+# one-GPU boxes of the build loop can run.
+SKIP_SINGLE_RANK = True
+
+# Bytes per rank and step at N Gaussians (F = 59 N floats = 236 MB at N = 1e6, SH degree 3) over n ranks, and what they cost on xGMI (7 links x ~153 GB/s per GPU,
+# point to point; MI355X_MICROARCH / DESIGN 6) -- the model the exchange modes were chosen with:
+#   allreduce  ring: sends 2 (n - 1) / n x 4F bytes, per-link bound: n = 8 -> 413 MB / ~153 GB/s per link direction ~ 2.7 ms if one ring, ~0.4 ms over 7 rings
+#   allgather  receives (n - 1) x 4F bytes (1.65 GB at n = 8) over 7 links in parallel: ~1.5 ms, + a 1.9 GB streaming sum (~0.4 ms): fixed summation order
+#   zero1      all-to-all: sends (n - 1) / n x 4F (seven single-hop transfers of F / 8 each: ~0.2 ms), Adam on 1 / n, all-gather of (n - 1) / n x 4F back: ~0.2 ms
+def exchange_bytes(n_floats, world, mode):
+    """bytes one rank SENDS per step for a gradient of n_floats float32 values"""
+    f = 4.0 * n_floats
+    if world <= 1:
+        return 0.0
+    return {"allreduce": 2.0 * (world - 1) / world * f, "allgather": (world - 1) * f, "zero1": 2.0 * (world - 1) / world * f}[mode]
+
+
+def _single(world):
+    return world == 1 and SKIP_SINGLE_RANK
+
 
 def shard_views(indices, rank, world):
     """views of this rank: a strided slice, so every rank gets the same count when len(indices) % world == 0"""
@@ -48,7 +69,7 @@ def exchange_gradients(params, group=None, mode="allgather", average=False):
     if not dist.is_available() or not dist.is_initialized():
         return
     world = dist.get_world_size(group)
-    if world == 1:
+    if _single(world):
         return
     flat = flatten_grads(params).contiguous()
     if mode == "allgather":
@@ -102,7 +123,7 @@ class FlatGrads:
         if not dist.is_available() or not dist.is_initialized():
             return
         world = dist.get_world_size(group)
-        if world == 1:
+        if _single(world):
             return
         flat, n = self.flat, self.flat.numel()
         scale = 1.0 / world if average else 1.0
@@ -133,7 +154,7 @@ class FlatGrads:
         """Rows [g0, g1) of the big gradient tensors are final on the current stream: start their all-reduce now (async: the backend's stream waits
         for what the current stream has enqueued so far, then runs underneath whatever is enqueued next -- the next Gaussian range of the
         per-Gaussian backward pass).  Pair with exchange_finish()."""
-        if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1 or g1 <= g0:
+        if not dist.is_available() or not dist.is_initialized() or _single(dist.get_world_size(group)) or g1 <= g0:
             return
         for i in self._big:
             self._works.append(dist.all_reduce(self.views[i][g0:g1], group=group, async_op=True))
@@ -143,7 +164,7 @@ class FlatGrads:
         if not dist.is_available() or not dist.is_initialized():
             return
         world = dist.get_world_size(group)
-        if world == 1:
+        if _single(world):
             return
         for a, b in self._rest_spans:
             self._works.append(dist.all_reduce(self.flat[a:b], group=group, async_op=True))
@@ -204,7 +225,8 @@ class ZeroOneAdam:
         self.m = torch.zeros((self.chunk,), dtype=torch.float32, device=dev)
         self.v = torch.zeros((self.chunk,), dtype=torch.float32, device=dev)
         self.gsum = torch.zeros((self.chunk,), dtype=torch.float32, device=dev)
-        self.recv = torch.empty((total,), dtype=torch.float32, device=dev) if self.world > 1 else None
+        self.collective = on and not _single(self.world)
+        self.recv = torch.empty((total,), dtype=torch.float32, device=dev) if self.collective else None
         self.t = 0
         self.group_of = {}
         for gr in optimizer.param_groups:
@@ -237,7 +259,7 @@ class ZeroOneAdam:
 
     def step(self):
         scale = 1.0 / self.world if self.average else 1.0
-        if self.world > 1:
+        if self.collective:
             dist.all_to_all_single(self.recv, self.flat_g, group=self.group)       # recv[r * chunk : (r + 1) * chunk] = rank r's copy of MY slice
             if self.flat_g.is_cuda:
                 import c3d_hip as _h
@@ -263,18 +285,25 @@ class ZeroOneAdam:
                                                     int(self.t), _h.stream(ps.device)), "c3d_adam_step")
             else:
                 adam_reference_(ps, gs, ms, vs, float(gr["lr"]), float(b1), float(b2), float(gr["eps"]), self.t)
-        if self.world > 1:
-            dist.all_gather_into_tensor(self.flat_p, self.flat_p[self.lo:self.hi].clone(), group=self.group)
+        if self.collective:
+            # in place on a HIP device (RCCL / NCCL define the in-place all-gather: the input IS the rank's slot of the output) -- no 1 / n-sized copy per step;
+            # gloo (the CPU tests) gets a separate input tensor
+            mine = self.flat_p[self.lo:self.hi]
+            dist.all_gather_into_tensor(self.flat_p, mine if self.flat_p.is_cuda else mine.clone(), group=self.group)
 
     def unshard(self):
         """all-gather the moments and hand them to the wrapped optimizer in torch.optim.Adam's layout (densification surgery, checkpoints)"""
         fm, fv = self.m, self.v
-        if self.world > 1:
+        if self.collective:
             fm, fv = torch.empty_like(self.flat_p), torch.empty_like(self.flat_p)
             dist.all_gather_into_tensor(fm, self.m, group=self.group)
             dist.all_gather_into_tensor(fv, self.v, group=self.group)
+        # torch.optim.Adam keeps `step` as a float32 tensor and rejects anything else ("state_steps must contain singleton tensors"); the fused optimizer
+        # (c3d_hip.optim.FusedAdam) counts with a Python int
+        as_tensor = isinstance(self.opt, torch.optim.Adam)
         for p, off in zip(self.params, self.offsets):
-            self.opt.state[p] = {"step": self.t, "exp_avg": fm[off:off + p.numel()].view(p.shape).clone(), "exp_avg_sq": fv[off:off + p.numel()].view(p.shape).clone()}
+            self.opt.state[p] = {"step": torch.tensor(float(self.t)) if as_tensor else self.t,
+                                 "exp_avg": fm[off:off + p.numel()].view(p.shape).clone(), "exp_avg_sq": fv[off:off + p.numel()].view(p.shape).clone()}
 
 
 def broadcast_parameters(params, src=0, group=None):

@@ -297,6 +297,11 @@ const real *gs_oracle_final_T(const gs_state *st) { return st->final_T; }
 const uint32_t *gs_oracle_n_contrib(const gs_state *st) { return st->n_contrib; }
 int gs_oracle_sizeof_real(void) { return (int)sizeof(real); }
 
+/* wall time of the (serial) pair sort of the last gs_oracle_forward call: bench.py's cpu_baseline reports it beside the total, because it is the one
+ * stage of this port that does not use the cores it is given */
+static double g_last_sort_seconds = 0.0;
+double gs_oracle_last_sort_seconds(void) { return g_last_sort_seconds; }
+
 /* Forward: A1 preprocess, A2-A5 binning, A6 composite.  Exactly one of shs / colors_precomp and
  * one of (scales, rotations) / cov3D_precomp is non-NULL (boundary rule of the upstream Python
  * wrapper).  Returns an opaque state used by gs_oracle_backward. */
@@ -384,7 +389,7 @@ gs_state *gs_oracle_forward(int N, int M, int deg, int W, int H, real tanfovx, r
                     kv[off].id = (uint32_t)i; off++;
                 }
         }
-        qsort(kv, (size_t)D, sizeof(kv_t), kv_cmp);
+        { const double t_ = omp_get_wtime(); qsort(kv, (size_t)D, sizeof(kv_t), kv_cmp); g_last_sort_seconds = omp_get_wtime() - t_; }
         for (int64_t i = 0; i < D; i++) {
             st->point_list[i] = kv[i].id;
             uint32_t t = (uint32_t)(kv[i].key >> 32);
@@ -405,7 +410,7 @@ gs_state *gs_oracle_forward(int N, int M, int deg, int W, int H, real tanfovx, r
                     kv[off].id = (uint32_t)i; off++;
                 }
         }
-        qsort(kv, (size_t)D, sizeof(kvd_t), kvd_cmp);
+        { const double t_ = omp_get_wtime(); qsort(kv, (size_t)D, sizeof(kvd_t), kvd_cmp); g_last_sort_seconds = omp_get_wtime() - t_; }
         for (int64_t i = 0; i < D; i++) {
             st->point_list[i] = kv[i].id;
             uint32_t t = kv[i].tile;

@@ -49,11 +49,18 @@ def _lib(dtype):
         f.restype = P
         f.argtypes = [P]
     lib.gs_oracle_mark_visible.argtypes = [C.c_int, P, P, P, P]
+    lib.gs_oracle_last_sort_seconds.restype = C.c_double
+    lib.gs_oracle_last_sort_seconds.argtypes = []
     lib.gs_oracle_taint.restype = None
     lib.gs_oracle_taint.argtypes = [P, P, P]
     assert lib.gs_oracle_sizeof_real() == dtype.itemsize
     _LIBS[dtype] = lib
     return lib
+
+
+def last_sort_seconds(dtype=np.float32):
+    """wall seconds of the serial pair sort inside the last forward() of the `dtype` build (the CPU baseline's one single-threaded stage)"""
+    return float(_lib(dtype).gs_oracle_last_sort_seconds())
 
 
 def set_exact_dscale(on):
