@@ -65,7 +65,7 @@ class GaussianSplattingCameraController(BaseCameraController):
         """orbit rendering (reference camera_utils.py:160-175 via the renderer nodes): without autograd and without per-view options the whole
         orbit goes through ONE batched library call; otherwise the reference's per-view loop."""
         g = self.renderer.gaussians
-        if kwargs or torch.is_grad_enabled() or not (g._xyz.is_cuda and g.max_sh_degree == 3) or len(all_cam_poses) == 0:
+        if kwargs or torch.is_grad_enabled() or not g._xyz.is_cuda or len(all_cam_poses) == 0:
             return super().render_all_pose(all_cam_poses, **kwargs)
         cams, bgs = [], []
         for radius, elevation, azimuth, cx, cy, cz in all_cam_poses:
@@ -216,7 +216,7 @@ class GaussianSplatting3D:
         MS-SSIM inside c3d_gs_train_views_raw (`image_loss_in_torch` switches to the forward / backward halves with torch's loss in between).
         Backgrounds are per view, drawn exactly as BaseCameraController.render_at_pose draws them."""
         g = self.renderer.gaussians
-        return self.use_fused_step and self.device.type == "cuda" and g.max_sh_degree == 3
+        return self.use_fused_step and self.device.type == "cuda" and 0 <= g.max_sh_degree <= 3
 
     def _image_loss(self, colors, alphas, mine):
         """the reference's batch loss on stacked tensors (main_3DGS.py:169-192): masked images, L1 + alpha MSE + (1 - MS-SSIM)"""
@@ -257,7 +257,7 @@ class GaussianSplatting3D:
             # the background of this view: one np.random draw per view, in view order, as render_at_pose (camera_utils.py:246-249)
             bg = ctl.static_bg if ctl.static_bg is not None else (ctl.white_bg if np.random.rand() > ctl.invert_bg_prob else ctl.black_bg)
             views.append(GaussianRasterizationSettings(H, W, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), bg, 1.0,
-                                                       cam.world_view_transform, cam.full_proj_transform, 3, cam.camera_center, False, False))
+                                                       cam.world_view_transform, cam.full_proj_transform, g.active_sh_degree, cam.camera_center, False, False))
         n_mine = max(len(mine), 1)
         overlapped = False
         plist = [q.detach() for q in self.params]

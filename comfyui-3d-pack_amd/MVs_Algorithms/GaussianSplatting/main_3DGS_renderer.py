@@ -500,8 +500,8 @@ class GaussianSplattingRenderer:
         from diff_gaussian_rasterization import GaussianRasterizationSettings
         from c3d_hip.gs_step import FusedViewRender
         g = self.gaussians
-        if not (g._xyz.is_cuda and g.max_sh_degree == 3):
-            raise RuntimeError("render_views needs a HIP-resident model with SH degree-3 storage; use render() otherwise")
+        if not g._xyz.is_cuda:
+            raise RuntimeError("render_views needs a HIP-resident model; there is no CPU path")
         V = len(viewpoint_cameras)
         if bg_colors is None or torch.is_tensor(bg_colors):
             bg_colors = [self.bg_color if bg_colors is None else bg_colors] * V
@@ -529,7 +529,7 @@ class GaussianSplattingRenderer:
             bg=self.bg_color if bg_color is None else bg_color, scale_modifier=scaling_modifier,
             viewmatrix=viewpoint_camera.world_view_transform, projmatrix=viewpoint_camera.full_proj_transform,
             sh_degree=g.active_sh_degree, campos=viewpoint_camera.camera_center, prefiltered=False, debug=False)
-        fused = (gaussain_idx is None and override_color is None and not compute_cov3D_python and g.max_sh_degree == 3 and g._xyz.is_cuda
+        fused = (gaussain_idx is None and override_color is None and not compute_cov3D_python and 0 <= g.max_sh_degree <= 3 and g._xyz.is_cuda
                  and not self.force_unfused)
         xyz = g.get_xyz if gaussain_idx is None else g.get_xyz[gaussain_idx]
         # zero tensor whose gradient is the screen-space positional gradient (densification statistic)

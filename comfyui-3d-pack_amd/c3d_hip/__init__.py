@@ -25,7 +25,7 @@ class GsSettings(C.Structure):
     """struct c3d_gs_settings (include/c3d_gs.h)"""
     _fields_ = [("image_height", i32), ("image_width", i32), ("tanfovx", f32), ("tanfovy", f32),
                 ("scale_modifier", f32), ("sh_degree", i32), ("prefiltered", i32), ("debug", i32),
-                ("bg", vp), ("viewmatrix", vp), ("projmatrix", vp), ("campos", vp), ("flags", i32), ("reserved0", i32)]
+                ("bg", vp), ("viewmatrix", vp), ("projmatrix", vp), ("campos", vp), ("flags", i32), ("sh_coeffs", i32)]
 
 
 GS_FLAG_EXACT_DSCALE = 1      # C3D_GS_FLAG_EXACT_DSCALE

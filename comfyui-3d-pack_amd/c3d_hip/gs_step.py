@@ -57,11 +57,13 @@ class FusedViewStep:
             self._alloc()       # the finished step's buffers stay alive through self._last until the next step replaces them
 
     @staticmethod
-    def _settings(rs_list, keep):
+    def _settings(rs_list, keep, params=None):
+        """params: the raw parameter list of the call -- its f_dc / f_rest pair says how many SH coefficients the storage holds (any PLY degree 0..3)"""
         import diff_gaussian_rasterization as dgr
+        K = dgr.raw_sh_coeffs(params[1], params[2]) if params is not None else 0
         arr = (_h.GsSettings * len(rs_list))()
         for i, rs in enumerate(rs_list):
-            arr[i] = dgr._settings_struct(rs, keep)
+            arr[i] = dgr._settings_struct(rs, keep, K)
         return arr
 
     def run(self, raster_settings, params, grads, target_color, target_alpha=None, color_mask=None, w_l1=1.0, w_l2=0.0, w_alpha_mse=0.0, scale=1.0, max_retries=3,
@@ -97,7 +99,7 @@ class FusedViewStep:
             self._alloc()
         for attempt in range(max_retries + 1):
             keep = []
-            views = self._settings(raster_settings, keep)
+            views = self._settings(raster_settings, keep, params)
             tc = (C.c_void_p * V)(*[t.data_ptr() for t in target_color])
             ta = (C.c_void_p * V)(*[t.data_ptr() for t in target_alpha]) if target_alpha is not None else None
             cm = (C.c_void_p * V)(*[t.data_ptr() for t in color_mask]) if color_mask is not None else None
@@ -223,7 +225,7 @@ class FusedViewStep:
         pin = [_h.f32c(p) for p in params]
         for attempt in range(max_retries + 1):
             keep = []
-            views = self._settings(raster_settings, keep)
+            views = self._settings(raster_settings, keep, params)
             self.status.zero_()
             t_host = time.perf_counter()
             with torch.cuda.device(self.device):
@@ -305,7 +307,7 @@ class FusedViewRender:
         arr = lambda t: (C.c_void_p * V)(*[t[i].data_ptr() for i in range(V)])
         for attempt in range(max_retries + 1):
             keep = []
-            views = FusedViewStep._settings(raster_settings, keep)
+            views = FusedViewStep._settings(raster_settings, keep, params)
             self.status.zero_()
             with torch.cuda.device(self.device):
                 _h.check(lib.c3d_gs_render_views_raw(views, V, self.N, *[_h.ptr(_h.f32c(p)) for p in params], arr(color), arr(depth), arr(alpha),

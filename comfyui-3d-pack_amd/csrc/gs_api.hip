@@ -41,6 +41,14 @@ static int make_params(const c3d_gs_settings* st, int N, int M, GsParams& p) {
     p.bg = st->bg; p.view = st->viewmatrix; p.proj = st->projmatrix; p.campos = st->campos;
     return 0;
 }
+// SH coefficients per channel the raw parameters store (c3d_gs_settings::sh_coeffs; 0 = 16); -1 + message if it is not one of 1, 4, 9, 16
+static int raw_coeffs(const c3d_gs_settings* st) {
+    if (!st) { c3d_set_error("c3d_gs: settings is NULL"); return -1; }
+    const int k = st->sh_coeffs ? st->sh_coeffs : 16;
+    if (k != 1 && k != 4 && k != 9 && k != 16) { c3d_set_error("c3d_gs: settings.sh_coeffs = %d (raw parameters store 1, 4, 9 or 16 SH coefficients per channel)", st->sh_coeffs); return -1; }
+    if ((st->sh_degree + 1) * (st->sh_degree + 1) > k) { c3d_set_error("c3d_gs: sh_degree %d needs %d coefficients, the raw parameters store %d", st->sh_degree, (st->sh_degree + 1) * (st->sh_degree + 1), k); return -1; }
+    return k;
+}
 static int check_inputs(int N, int M, int deg, const float* means3D, const float* shs, const float* colors_precomp,
                         const float* scales, const float* rotations, const float* cov3D_precomp) {
     if (N == 0) return 0;
@@ -150,11 +158,12 @@ int c3d_gs_forward_project_raw(const c3d_gs_settings* st, int32_t N, const float
                                void* geom_buffer, int64_t* num_rendered, c3d_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     GsParams p;
-    if (make_params(st, N, 16, p)) return -1;
+    const int K = raw_coeffs(st);
+    if (K < 0 || make_params(st, N, K, p)) return -1;
     if (!num_rendered) { c3d_set_error("c3d_gs_forward_project_raw: num_rendered (host) is NULL"); return -1; }
     *num_rendered = 0;
     if (N == 0) return 0;
-    if (!means3D || !f_dc || !f_rest || !opacity_raw || !scaling_raw || !rotation_raw || !radii || !geom_buffer) { c3d_set_error("c3d_gs_forward_project_raw: NULL pointer"); return -1; }
+    if (!means3D || !f_dc || (!f_rest && K > 1) || !opacity_raw || !scaling_raw || !rotation_raw || !radii || !geom_buffer) { c3d_set_error("c3d_gs_forward_project_raw: NULL pointer"); return -1; }
     if ((uintptr_t)f_rest % 16 || (uintptr_t)rotation_raw % 16) { c3d_set_error("c3d_gs_forward_project_raw: f_rest / rotation must be 16-byte aligned"); return -1; }
     GsGeom g;
     gs_carve_geom((char*)geom_buffer, N, g);
@@ -237,10 +246,11 @@ int c3d_gs_backward_raw(const c3d_gs_settings* st, int32_t N, const float* means
                         float* dL_drotation_raw, void* scratch, int32_t accumulate, c3d_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     GsParams p;
-    if (make_params(st, N, 16, p)) return -1;
+    const int K = raw_coeffs(st);
+    if (K < 0 || make_params(st, N, K, p)) return -1;
     if (N == 0) return 0;
-    if (!means3D || !f_dc || !f_rest || !scaling_raw || !rotation_raw || !radii || !geom_buffer || !dL_dcolor || !dL_dmeans2D || !dL_dmeans3D ||
-        !dL_df_dc || !dL_df_rest || !dL_dopacity_raw || !dL_dscaling_raw || !dL_drotation_raw || !scratch) { c3d_set_error("c3d_gs_backward_raw: NULL pointer"); return -1; }
+    if (!means3D || !f_dc || (!f_rest && K > 1) || !scaling_raw || !rotation_raw || !radii || !geom_buffer || !dL_dcolor || !dL_dmeans2D || !dL_dmeans3D ||
+        !dL_df_dc || (!dL_df_rest && K > 1) || !dL_dopacity_raw || !dL_dscaling_raw || !dL_drotation_raw || !scratch) { c3d_set_error("c3d_gs_backward_raw: NULL pointer"); return -1; }
     if ((uintptr_t)f_rest % 16 || (uintptr_t)dL_df_rest % 16 || (uintptr_t)rotation_raw % 16 || (uintptr_t)dL_drotation_raw % 16) { c3d_set_error("c3d_gs_backward_raw: f_rest / rotation tensors must be 16-byte aligned"); return -1; }
     const int tiles = p.gx * p.gy;
     GsGeom g;
@@ -312,7 +322,8 @@ static int group_setup(ViewGroup& q, const c3d_gs_settings* views, int G, int N,
     if (G < 1 || G > GS_MAX_GROUP) { c3d_set_error("internal: group of %d views", G); return -2; }
     q.G = G; q.N = N; q.vs = G > 1 ? vs : 0; q.slice0 = slice0; q.cap = (uint32_t)pair_capacity;
     for (int i = 0; i < G; i++) {
-        if (make_params(&views[i], N, 16, q.p[i])) return -1;
+        const int K = raw_coeffs(&views[i]);
+        if (K < 0 || make_params(&views[i], N, K, q.p[i])) return -1;
         carve_step(slice0 + (size_t)i * vs, N, q.p[i].H, q.p[i].W, pair_capacity, q.w[i], fwd_only);
     }
     q.tiles = q.p[0].gx * q.p[0].gy;
@@ -371,7 +382,8 @@ static int step_a8_all_views(const c3d_gs_settings* views, int V, int N, size_t 
         bv.V = (V - v0) < GS_MAX_BWD_VIEWS ? (V - v0) : GS_MAX_BWD_VIEWS;
         for (int i = 0; i < bv.V; i++) {
             GsParams p;
-            if (make_params(&views[v0 + i], N, 16, p)) return -1;
+            const int K = raw_coeffs(&views[v0 + i]);
+            if (K < 0 || make_params(&views[v0 + i], N, K, p)) return -1;
             if (v0 + i == 0) p_first = p;
             StepWs w; carve_step((char*)workspace + (size_t)(v0 + i) * slice_bytes, N, p.H, p.W, pair_capacity, w);
             GsGeom g; gs_carve_geom(w.geom, N, g);
@@ -394,7 +406,7 @@ static int check_step_args(const char* who, const c3d_gs_settings* views, int V,
     if (lanes < 1 || lanes > C3D_MAX_LANES) { c3d_set_error("%s: lanes must be in [1, %d]", who, C3D_MAX_LANES); return -1; }
     for (int v = 1; v < V; v++)
         if (views[v].image_width != views[0].image_width || views[v].image_height != views[0].image_height || views[v].sh_degree != views[0].sh_degree ||
-            views[v].scale_modifier != views[0].scale_modifier) { c3d_set_error("%s: all views must share resolution, sh_degree and scale_modifier", who); return -1; }
+            views[v].sh_coeffs != views[0].sh_coeffs || views[v].scale_modifier != views[0].scale_modifier) { c3d_set_error("%s: all views must share resolution, sh_degree, sh_coeffs and scale_modifier", who); return -1; }
     return 0;
 }
 // views per group when V views are spread over `lanes` groups in flight
@@ -424,7 +436,8 @@ int c3d_gs_train_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, c
     if (V <= 0 || N <= 0) return 0;
     if (!loss || !target_color || !status) { c3d_set_error("c3d_gs_train_views_raw: NULL pointer"); return -1; }
     if (check_step_args("c3d_gs_train_views_raw", views, V, pair_capacity, lanes, workspace)) return -1;
-    if (!means3D || !f_dc || !f_rest || !opacity_raw || !scaling_raw || !rotation_raw || !dL_dmeans3D || !dL_df_dc || !dL_df_rest || !dL_dopacity_raw ||
+    const bool dc_only = views[0].sh_coeffs == 1;      // degree-0 storage: there is no f_rest
+    if (!means3D || !f_dc || (!f_rest && !dc_only) || !opacity_raw || !scaling_raw || !rotation_raw || !dL_dmeans3D || !dL_df_dc || (!dL_df_rest && !dc_only) || !dL_dopacity_raw ||
         !dL_dscaling_raw || !dL_drotation_raw) { c3d_set_error("c3d_gs_train_views_raw: NULL parameter / gradient pointer"); return -1; }
     if ((uintptr_t)f_rest % 16 || (uintptr_t)dL_df_rest % 16 || (uintptr_t)rotation_raw % 16 || (uintptr_t)dL_drotation_raw % 16) { c3d_set_error("c3d_gs_train_views_raw: f_rest / rotation tensors must be 16-byte aligned"); return -1; }
     for (int v = 0; v < V; v++) if (!target_color[v]) { c3d_set_error("c3d_gs_train_views_raw: target_color[%d] is NULL", v); return -1; }
@@ -492,7 +505,8 @@ int c3d_gs_step_param_backward_range(const c3d_gs_settings* views, int32_t V, in
                                      int32_t count, c3d_stream_t stream) {
     if (V <= 0 || N <= 0 || count == 0) return 0;
     if (check_step_args("c3d_gs_step_param_backward_range", views, V, pair_capacity, 1, workspace)) return -1;
-    if (!means3D || !f_dc || !f_rest || !scaling_raw || !rotation_raw || !dL_dmeans3D || !dL_df_dc || !dL_df_rest || !dL_dopacity_raw || !dL_dscaling_raw || !dL_drotation_raw) {
+    const bool dc_only = views[0].sh_coeffs == 1;
+    if (!means3D || !f_dc || (!f_rest && !dc_only) || !scaling_raw || !rotation_raw || !dL_dmeans3D || !dL_df_dc || (!dL_df_rest && !dc_only) || !dL_dopacity_raw || !dL_dscaling_raw || !dL_drotation_raw) {
         c3d_set_error("c3d_gs_step_param_backward_range: NULL parameter / gradient pointer"); return -1; }
     if ((uintptr_t)f_rest % 16 || (uintptr_t)dL_df_rest % 16 || (uintptr_t)rotation_raw % 16 || (uintptr_t)dL_drotation_raw % 16) { c3d_set_error("c3d_gs_step_param_backward_range: f_rest / rotation tensors must be 16-byte aligned"); return -1; }
     if (first < 0 || count < 0 || (first & 3) || (long long)first + count > N) { c3d_set_error("c3d_gs_step_param_backward_range: range [%d, %d + %d) must lie inside [0, N) and start at a multiple of 4", first, first, count); return -1; }
@@ -510,7 +524,7 @@ static int views_forward(const char* who, const c3d_gs_settings* views, int32_t 
     if (V <= 0 || N <= 0) return 0;
     if (!out_color || !out_alpha || !status) { c3d_set_error("%s: NULL pointer", who); return -1; }
     if (check_step_args(who, views, V, pair_capacity, lanes, workspace)) return -1;
-    if (!means3D || !f_dc || !f_rest || !opacity_raw || !scaling_raw || !rotation_raw) { c3d_set_error("%s: NULL parameter pointer", who); return -1; }
+    if (!means3D || !f_dc || (!f_rest && views[0].sh_coeffs != 1) || !opacity_raw || !scaling_raw || !rotation_raw) { c3d_set_error("%s: NULL parameter pointer", who); return -1; }
     if ((uintptr_t)f_rest % 16 || (uintptr_t)rotation_raw % 16) { c3d_set_error("%s: f_rest / rotation tensors must be 16-byte aligned", who); return -1; }
     for (int v = 0; v < V; v++) if (!out_color[v] || !out_alpha[v]) { c3d_set_error("%s: output %d is NULL", who, v); return -1; }
     const bool fwd_only = !keep_state;       // c3d_gs_render_views_raw: slices without the backward pass's buffers (c3d_gs_render_workspace_bytes)
@@ -579,7 +593,8 @@ int c3d_gs_backward_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N
     if (V <= 0 || N <= 0) return 0;
     if (!dL_dcolor) { c3d_set_error("c3d_gs_backward_views_raw: NULL pointer"); return -1; }
     if (check_step_args("c3d_gs_backward_views_raw", views, V, pair_capacity, lanes, workspace)) return -1;
-    if (!means3D || !f_dc || !f_rest || !scaling_raw || !rotation_raw || !dL_dmeans3D || !dL_df_dc || !dL_df_rest || !dL_dopacity_raw || !dL_dscaling_raw ||
+    const bool dc_only = views[0].sh_coeffs == 1;
+    if (!means3D || !f_dc || (!f_rest && !dc_only) || !scaling_raw || !rotation_raw || !dL_dmeans3D || !dL_df_dc || (!dL_df_rest && !dc_only) || !dL_dopacity_raw || !dL_dscaling_raw ||
         !dL_drotation_raw) { c3d_set_error("c3d_gs_backward_views_raw: NULL parameter / gradient pointer"); return -1; }
     if ((uintptr_t)f_rest % 16 || (uintptr_t)dL_df_rest % 16 || (uintptr_t)rotation_raw % 16 || (uintptr_t)dL_drotation_raw % 16) { c3d_set_error("c3d_gs_backward_views_raw: f_rest / rotation tensors must be 16-byte aligned"); return -1; }
     for (int v = 0; v < V; v++) if (!dL_dcolor[v]) { c3d_set_error("c3d_gs_backward_views_raw: dL_dcolor[%d] is NULL", v); return -1; }

@@ -495,7 +495,7 @@ __device__ __forceinline__ void bwd_cov_to_scale_rot(const float dcov[6], const 
 // RAW: inputs are the raw parameters (see k_preprocess) and the outputs are gradients w.r.t. them: the exp / sigmoid / normalize
 // backward passes of the GaussianModel accessors are applied here; dL/dSH goes to the split dL_dsh (= d f_dc) / dL_df_rest pair.
 // ACC: add into the existing contents of the parameter-gradient outputs (view loops) instead of overwriting.
-template <bool STAGED, bool RAW, bool ACC>
+template <bool STAGED, bool RAW, bool ACC, int REST3 = SH_REST>
 __global__ void __launch_bounds__(256) k_preprocess_bwd(GsParams p, GsGeom g, const int* __restrict__ radii, const float* __restrict__ means3D,
                                                          const float* __restrict__ shs, const float* __restrict__ f_rest, const float* __restrict__ colors_precomp,
                                                          const float* __restrict__ scales, const float* __restrict__ rotations,
@@ -510,7 +510,7 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GsParams p, GsGeom g, co
     const int gcount = min((int)blockDim.x, p.N - (int)g0);
     float* shl = sh_lds + threadIdx.x * SH_ROW;
     if (STAGED) {
-        if (RAW) sh_stage_in_split(shs, f_rest, g0, gcount, sh_lds);
+        if (RAW) sh_stage_in_split<REST3>(shs, f_rest, g0, gcount, sh_lds);
         else     sh_stage_in(shs, g0, gcount, sh_lds);
         __syncthreads();
     }
@@ -657,7 +657,7 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GsParams p, GsGeom g, co
     }   // visible Gaussian
     if (STAGED) {
         __syncthreads();
-        if (RAW) sh_stage_out_split<ACC>(dL_dsh, dL_df_rest, g0, gcount, sh_lds);
+        if (RAW) sh_stage_out_split<ACC, REST3>(dL_dsh, dL_df_rest, g0, gcount, sh_lds);
         else     sh_stage_out(dL_dsh, g0, gcount, sh_lds);
     }
 }
@@ -771,8 +771,8 @@ __global__ void __launch_bounds__(256, MINB) k_bwd_views_geom(GsParams p, GsBwdV
 
 struct GsShViews { int V; const float* campos[GS_MAX_BWD_VIEWS]; const float* gcol[GS_MAX_BWD_VIEWS]; };
 // dL/dSH over all views + the view-direction term of dL/dmean (added to what k_bwd_views_geom wrote)
-template <bool ACC>
-__global__ void __launch_bounds__(256) k_bwd_views_sh(int first, int last, int deg, GsShViews vs, const float* __restrict__ means3D, const float* __restrict__ f_dc,
+template <bool ACC, int REST3>
+__global__ void __launch_bounds__(256) k_bwd_views_sh(int first, int last, int deg_in, GsShViews vs, const float* __restrict__ means3D, const float* __restrict__ f_dc,
                                                         const float* __restrict__ f_rest, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_df_dc,
                                                         float* __restrict__ dL_df_rest) {
     extern __shared__ float sh_lds[];
@@ -781,8 +781,9 @@ __global__ void __launch_bounds__(256) k_bwd_views_sh(int first, int last, int d
     const size_t g0 = (size_t)first + (size_t)blockIdx.x * blockDim.x;
     const int gcount = min((int)blockDim.x, N - (int)g0);
     float* shl = sh_lds + threadIdx.x * SH_ROW;
-    sh_stage_in_split(f_dc, f_rest, g0, gcount, sh_lds);
+    sh_stage_in_split<REST3>(f_dc, f_rest, g0, gcount, sh_lds);
     __syncthreads();
+    const int deg = min(deg_in, REST3 >= 45 ? 3 : (REST3 >= 24 ? 2 : (REST3 >= 9 ? 1 : 0)));      // never above the storage's degree: the unused bands compile out
     float gsh[SH_M3];
 #pragma unroll
     for (int k = 0; k < SH_M3; k++) gsh[k] = 0.f;
@@ -816,9 +817,9 @@ __global__ void __launch_bounds__(256) k_bwd_views_sh(int first, int last, int d
         dL_dmeans3D[3 * idx] += dmx; dL_dmeans3D[3 * idx + 1] += dmy; dL_dmeans3D[3 * idx + 2] += dmz;
     }
 #pragma unroll
-    for (int k = 0; k < SH_M3; k++) shl[k] = gsh[k];
+    for (int k = 0; k < 3 + REST3; k++) shl[k] = gsh[k];
     __syncthreads();
-    sh_stage_out_split<ACC>(dL_df_dc, dL_df_rest, g0, gcount, sh_lds);
+    sh_stage_out_split<ACC, REST3>(dL_df_dc, dL_df_rest, g0, gcount, sh_lds);
 }
 
 int gs_launch_preprocess_bwd_views(const GsParams& p0, const GsBwdViews& views, const float* means3D, const float* f_dc, const float* f_rest,
@@ -836,13 +837,17 @@ int gs_launch_preprocess_bwd_views(const GsParams& p0, const GsBwdViews& views, 
     for (int i = 0; i < views.V; i++) { sv.campos[i] = views.v[i].campos; sv.gcol[i] = views.v[i].gcol; }
     // four pairs in flight, four workgroups per CU (128 VGPRs): eight in flight (160 VGPRs) and two or three (96, spilling) measure the same or worse
 #define GS_A8_GEOM(ACC_) hipLaunchKernelGGL((k_bwd_views_geom<ACC_, 4, 4>), grid, block, 0, s, p0, views, means3D, scaling_raw, rotation_raw, dL_dopacity_raw, dL_dmeans3D, dL_dscaling_raw, dL_drotation_raw, cap, first, last)
+#define GS_A8_SH_ACC(R3_) hipLaunchKernelGGL((k_bwd_views_sh<true, R3_>), grid, block, lds, s, first, last, p0.deg, sv, means3D, f_dc, f_rest, dL_dmeans3D, dL_df_dc, dL_df_rest)
+#define GS_A8_SH_SET(R3_) hipLaunchKernelGGL((k_bwd_views_sh<false, R3_>), grid, block, lds, s, first, last, p0.deg, sv, means3D, f_dc, f_rest, dL_dmeans3D, dL_df_dc, dL_df_rest)
     if (accumulate) {
         GS_A8_GEOM(true);
-        hipLaunchKernelGGL((k_bwd_views_sh<true>), grid, block, lds, s, first, last, p0.deg, sv, means3D, f_dc, f_rest, dL_dmeans3D, dL_df_dc, dL_df_rest);
+        GS_BY_SH_COEFFS(p0.M, GS_A8_SH_ACC);
     } else {
         GS_A8_GEOM(false);
-        hipLaunchKernelGGL((k_bwd_views_sh<false>), grid, block, lds, s, first, last, p0.deg, sv, means3D, f_dc, f_rest, dL_dmeans3D, dL_df_dc, dL_df_rest);
+        GS_BY_SH_COEFFS(p0.M, GS_A8_SH_SET);
     }
+#undef GS_A8_SH_ACC
+#undef GS_A8_SH_SET
 #undef GS_A8_GEOM
     C3D_LAUNCH_CHECK();
     return 0;
@@ -870,14 +875,16 @@ int gs_launch_preprocess_bwd_raw(const GsParams& p, const GsGeom& g, const int* 
                                  float* dL_dopacity_raw, float* dL_dmeans3D, float* dL_df_dc, float* dL_df_rest, float* dL_dscaling_raw,
                                  float* dL_drotation_raw, bool accumulate, hipStream_t s, uint32_t cap) {
     if (p.N == 0) return 0;
-    if (accumulate)
-        hipLaunchKernelGGL((k_preprocess_bwd<true, true, true>), dim3(c3d_cdiv(p.N, 256)), dim3(256), 256 * SH_ROW * sizeof(float), s, p, g, radii, means3D, f_dc, f_rest,
-                           (const float*)nullptr, scaling_raw, rotation_raw, (const float*)nullptr, (const float4*)pairgrad, pvalid, dL_dmean2D, (float*)nullptr,
-                           dL_dopacity_raw, dL_dmeans3D, (float*)nullptr, dL_df_dc, dL_df_rest, dL_dscaling_raw, dL_drotation_raw, cap);
-    else
-        hipLaunchKernelGGL((k_preprocess_bwd<true, true, false>), dim3(c3d_cdiv(p.N, 256)), dim3(256), 256 * SH_ROW * sizeof(float), s, p, g, radii, means3D, f_dc, f_rest,
-                           (const float*)nullptr, scaling_raw, rotation_raw, (const float*)nullptr, (const float4*)pairgrad, pvalid, dL_dmean2D, (float*)nullptr,
-                           dL_dopacity_raw, dL_dmeans3D, (float*)nullptr, dL_df_dc, dL_df_rest, dL_dscaling_raw, dL_drotation_raw, cap);
+#define GS_A8_RAW(ACC_, R3_) hipLaunchKernelGGL((k_preprocess_bwd<true, true, ACC_, R3_>), dim3(c3d_cdiv(p.N, 256)), dim3(256), 256 * SH_ROW * sizeof(float), s, p, g, radii, means3D, f_dc, f_rest, \
+                           (const float*)nullptr, scaling_raw, rotation_raw, (const float*)nullptr, (const float4*)pairgrad, pvalid, dL_dmean2D, (float*)nullptr,                          \
+                           dL_dopacity_raw, dL_dmeans3D, (float*)nullptr, dL_df_dc, dL_df_rest, dL_dscaling_raw, dL_drotation_raw, cap)
+#define GS_A8_RAW_ACC(R3_) GS_A8_RAW(true, R3_)
+#define GS_A8_RAW_SET(R3_) GS_A8_RAW(false, R3_)
+    if (accumulate) { GS_BY_SH_COEFFS(p.M, GS_A8_RAW_ACC); }
+    else            { GS_BY_SH_COEFFS(p.M, GS_A8_RAW_SET); }
+#undef GS_A8_RAW_ACC
+#undef GS_A8_RAW_SET
+#undef GS_A8_RAW
     C3D_LAUNCH_CHECK();
     return 0;
 }

@@ -87,11 +87,9 @@ __device__ __forceinline__ void gs_project_one(int idx, const float3 m, const fl
 // coefficients are brought in with fully coalesced 16-B loads through LDS (sh_stage_in) instead of
 // 64 lanes striding 192 B apart.
 // ------------------------------------------------------------------------------------------
-// RAW: the inputs are the reference's raw parameters -- scales = exp(.), opacity = sigmoid(.), rotation = normalize(.) are applied here
-// (GaussianModel accessors, main_3DGS_renderer.py:294-321) and SH comes as the split f_dc / f_rest pair (`shs` = f_dc, `f_rest` extra).
-template <bool STAGED, bool RAW>
+// (The raw-parameter form -- exp / sigmoid / normalize folded in, split f_dc / f_rest storage -- is k_preprocess_views_r below, also for one view.)
+template <bool STAGED>
 __global__ void __launch_bounds__(256) k_preprocess(GsParams p, const float* __restrict__ means3D, const float* __restrict__ shs,
-                                                     const float* __restrict__ f_rest,
                                                      const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
                                                      const float* __restrict__ scales, const float* __restrict__ rotations,
                                                      const float* __restrict__ cov3D_precomp, GsGeom g, int* __restrict__ radii) {
@@ -99,8 +97,7 @@ __global__ void __launch_bounds__(256) k_preprocess(GsParams p, const float* __r
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (STAGED) {
         const size_t g0 = (size_t)blockIdx.x * blockDim.x;
-        if (RAW) sh_stage_in_split(shs, f_rest, g0, min((int)blockDim.x, p.N - (int)g0), sh_lds);
-        else     sh_stage_in(shs, g0, min((int)blockDim.x, p.N - (int)g0), sh_lds);
+        sh_stage_in(shs, g0, min((int)blockDim.x, p.N - (int)g0), sh_lds);
         __syncthreads();
     }
     if (idx >= p.N) return;
@@ -112,15 +109,10 @@ __global__ void __launch_bounds__(256) k_preprocess(GsParams p, const float* __r
     } else {
         float3 s = make_float3(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]);
         float4 q = *reinterpret_cast<const float4*>(rotations + 4 * idx);
-        if (RAW) {
-            s = make_float3(expf(s.x), expf(s.y), expf(s.z));
-            const float inv = 1.f / fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
-            q = make_float4(q.x * inv, q.y * inv, q.z * inv, q.w * inv);
-        }
         cov3d_from_scale_rot(s, p.scale_modifier, q, c3);
     }
     const float* sh = STAGED ? sh_lds + threadIdx.x * SH_ROW : shs + (size_t)idx * p.M * 3;
-    gs_project_one(idx, m, c3, [&]() { return RAW ? 1.f / (1.f + expf(-opacities[idx])) : opacities[idx]; }, sh, colors_precomp,
+    gs_project_one(idx, m, c3, [&]() { return opacities[idx]; }, sh, colors_precomp,
                    GsPreCam{p.view, p.proj, p.campos, p.tanfovx, p.tanfovy, p.focal_x, p.focal_y}, p.W, p.H, p.gx, p.gy, p.deg,
                    GsPreOut{g.rec0, g.tiles, g.rect, g.key[0], g.clamped, radii});
 }
@@ -131,10 +123,10 @@ int gs_launch_preprocess(const GsParams& p, const float* means3D, const float* s
     if (p.N == 0) return 0;
     const bool staged = shs && !colors_precomp && p.M == 16 && ((uintptr_t)shs % 16 == 0);
     if (staged)
-        hipLaunchKernelGGL((k_preprocess<true, false>), dim3(c3d_cdiv(p.N, 256)), dim3(256), 256 * SH_ROW * sizeof(float), s, p, means3D, shs,
-                           (const float*)nullptr, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, radii);
+        hipLaunchKernelGGL((k_preprocess<true>), dim3(c3d_cdiv(p.N, 256)), dim3(256), 256 * SH_ROW * sizeof(float), s, p, means3D, shs,
+                           colors_precomp, opacities, scales, rotations, cov3D_precomp, g, radii);
     else
-        hipLaunchKernelGGL((k_preprocess<false, false>), dim3(c3d_cdiv(p.N, 256)), dim3(256), 0, s, p, means3D, shs, (const float*)nullptr,
+        hipLaunchKernelGGL((k_preprocess<false>), dim3(c3d_cdiv(p.N, 256)), dim3(256), 0, s, p, means3D, shs,
                            colors_precomp, opacities, scales, rotations, cov3D_precomp, g, radii);
     C3D_LAUNCH_CHECK();
     return 0;
@@ -143,12 +135,15 @@ int gs_launch_preprocess(const GsParams& p, const float* means3D, const float* s
 // The per-view kernel streams 44 + 192 B of parameters per Gaussian for every view; over the 8 views of a training step that is 1.9 GB of the
 // same 236 MB.  Here a lane keeps its Gaussian (mean, 3D covariance, opacity and the 48 SH coefficients in registers) and walks the views:
 // parameters are read once per launch, what is left per view is the 93 B of projected state it writes.  Same arithmetic, statement by statement,
-// as k_preprocess<true, true> (both call gs_project_one; the tests hold the two together).
+// as the plain-boundary kernel k_preprocess (both call gs_project_one; the tests hold the two together).
 struct GsPreView { GsPreCam cam; GsPreOut out; };
 struct GsPreViews { int V; GsPreView v[GS_MAX_BWD_VIEWS]; };
 // LDS is only the transposition buffer of the coalesced SH load (44 rows at a time: 8.6 KB per workgroup); the coefficients move on into registers
 // (28 + 48 VGPRs -> 5-6 waves per SIMD).  Round 3's first version kept a 196 B per lane LDS image instead: 3 waves per SIMD, 4 % slower (profiles/r03/).
 #define PRE_ROWS 44      // multiple of 4: the 16-byte loads of sh_stage_in_split stay aligned
+// degree of the storage with K coefficients per channel (REST3 = 3 (K - 1)): the compiler then drops the SH bands a model of that storage cannot have
+__host__ __device__ constexpr int sh_storage_degree(int rest3) { return rest3 >= 45 ? 3 : (rest3 >= 24 ? 2 : (rest3 >= 9 ? 1 : 0)); }
+template <int REST3>
 __global__ void __launch_bounds__(128) k_preprocess_views_r(GsParams p, GsPreViews vs, const float* __restrict__ means3D, const float* __restrict__ f_dc,
                                                              const float* __restrict__ f_rest, const float* __restrict__ opacities,
                                                              const float* __restrict__ scales, const float* __restrict__ rotations) {
@@ -162,12 +157,12 @@ __global__ void __launch_bounds__(128) k_preprocess_views_r(GsParams p, GsPreVie
         const int count = min((int)blockDim.x, p.N - (int)g0);
         for (int r0 = 0; r0 < count; r0 += PRE_ROWS) {
             const int rows = min(PRE_ROWS, count - r0);
-            sh_stage_in_split(f_dc, f_rest, g0 + r0, rows, sh_lds);
+            sh_stage_in_split<REST3>(f_dc, f_rest, g0 + r0, rows, sh_lds);
             __syncthreads();
             const int mine = (int)threadIdx.x - r0;
             if (mine >= 0 && mine < rows) {
 #pragma unroll
-                for (int k = 0; k < SH_M3; k++) sh[k] = sh_lds[mine * SH_ROW + k];
+                for (int k = 0; k < 3 + REST3; k++) sh[k] = sh_lds[mine * SH_ROW + k];
             }
             __syncthreads();
         }
@@ -184,8 +179,9 @@ __global__ void __launch_bounds__(128) k_preprocess_views_r(GsParams p, GsPreVie
         cov3d_from_scale_rot(s, p.scale_modifier, q, c3);
     }
     const float opac = 1.f / (1.f + expf(-opacities[idx]));
+    const int deg = min(p.deg, sh_storage_degree(REST3));
     for (int v = 0; v < vs.V; v++)
-        gs_project_one(idx, m, c3, [&]() { return opac; }, sh, (const float*)nullptr, vs.v[v].cam, p.W, p.H, p.gx, p.gy, p.deg, vs.v[v].out);
+        gs_project_one(idx, m, c3, [&]() { return opac; }, sh, (const float*)nullptr, vs.v[v].cam, p.W, p.H, p.gx, p.gy, deg, vs.v[v].out);
 }
 // geoms[v] / radii[v]: the state buffers of view v; views[v]: its camera (GsParams of that view; N, W, H, scale_modifier, deg must agree)
 int gs_launch_preprocess_views(const GsParams* views, int V, const GsGeom* geoms, int* const* radii, const float* means3D, const float* f_dc, const float* f_rest,
@@ -200,21 +196,20 @@ int gs_launch_preprocess_views(const GsParams* views, int V, const GsGeom* geoms
                             GsPreOut{geoms[i].rec0, geoms[i].tiles, geoms[i].rect, geoms[i].key[0], geoms[i].clamped, radii[i]}};
     }
     const int T = 128;
-    hipLaunchKernelGGL(k_preprocess_views_r, dim3(c3d_cdiv(views[0].N, T)), dim3(T), 0, s, views[0], pv, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw);
+#define GS_PRE_VIEWS(R3_) hipLaunchKernelGGL(k_preprocess_views_r<R3_>, dim3(c3d_cdiv(views[0].N, T)), dim3(T), 0, s, views[0], pv, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw)
+    GS_BY_SH_COEFFS(views[0].M, GS_PRE_VIEWS);
+#undef GS_PRE_VIEWS
     C3D_LAUNCH_CHECK();
     return 0;
 }
 
-// 128-lane workgroups: the kernel stages 196 B of SH per lane in LDS, so smaller workgroups interleave the load and compute phases of more
-// workgroups per CU at the same wave count (64 and 256 measured worse, profiles/r02*)
+// raw parameters, one view: the multi-view kernel with V = 1 -- the per-view drop-in path and the fused multi-view paths then run the SAME instructions per
+// Gaussian (bit-identical projected state for every SH storage degree, by construction)
 int gs_launch_preprocess_raw(const GsParams& p, const float* means3D, const float* f_dc, const float* f_rest, const float* opacity_raw,
                              const float* scaling_raw, const float* rotation_raw, GsGeom& g, int* radii, hipStream_t s) {
     if (p.N == 0) return 0;
-    const int T = 128;
-    hipLaunchKernelGGL((k_preprocess<true, true>), dim3(c3d_cdiv(p.N, T)), dim3(T), T * SH_ROW * sizeof(float), s, p, means3D, f_dc, f_rest,
-                       (const float*)nullptr, opacity_raw, scaling_raw, rotation_raw, (const float*)nullptr, g, radii);
-    C3D_LAUNCH_CHECK();
-    return 0;
+    int* rd[1] = {radii};
+    return gs_launch_preprocess_views(&p, 1, &g, rd, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, s);
 }
 
 // ------------------------------------------------------------------------------------------

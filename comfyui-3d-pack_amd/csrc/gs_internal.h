@@ -140,6 +140,16 @@ struct GsBwdView {
 };
 struct GsBwdViews { int V; GsBwdView v[GS_MAX_BWD_VIEWS]; };
 
+// raw-parameter paths: launch a kernel template instance by the number of stored SH coefficients per channel (GsParams::M: 16 / 9 / 4 / 1 -> 3 (M - 1) floats of f_rest)
+#define GS_BY_SH_COEFFS(M_, CALL_)                                                                                          \
+    switch (M_) {                                                                                                           \
+        case 16: CALL_(45); break;                                                                                          \
+        case 9: CALL_(24); break;                                                                                           \
+        case 4: CALL_(9); break;                                                                                            \
+        case 1: CALL_(0); break;                                                                                            \
+        default: c3d_set_error("c3d_gs: %d SH coefficients per channel (raw parameter paths take 1, 4, 9 or 16)", (int)(M_)); return -1; \
+    }
+
 // ---- multi-view launches (round 4) -----------------------------------------------------------------------------------------------------
 // The views of a group (<= GS_MAX_GROUP) keep their state in workspace slices at a uniform stride `vs`; every stage of the chain is ONE launch with
 // blockIdx.y = view, state pointers given for the group's first view.  What does not live in the slices -- the caller's output planes, loss targets,

@@ -288,37 +288,46 @@ __device__ __forceinline__ void sh_stage_in(const float* __restrict__ shs, size_
         d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
 }
-// split storage of the reference's GaussianModel: f_dc [N,1,3] and f_rest [N,15,3] (main_3DGS_renderer.py:314-317 concatenates them
-// on every render; staging both straight into the same LDS rows removes that 192 MB copy)
+// split storage of the reference's GaussianModel: f_dc [N,1,3] and f_rest [N,K-1,3] (main_3DGS_renderer.py:314-317 concatenates them
+// on every render; staging both straight into the same LDS rows removes that copy).  REST3 = 3 (K - 1) floats of f_rest per Gaussian: 45 for the
+// degree-3 storage the trainer uses, 24 / 9 / 0 for PLYs of degree 2 / 1 / 0 (mesh_processer/mesh_utils.py:346-350 loads any of them; LGM writes degree 0).
+// Coefficient k of a Gaussian sits at lds[row * SH_ROW + 3 k + channel] whatever K is; rows are not cleared beyond 3 K (nothing reads there: the active
+// degree never exceeds the storage degree).
 #define SH_REST 45
+__host__ __device__ constexpr int sh_rest3_of(int coeffs) { return 3 * (coeffs - 1); }
+template <int REST3 = SH_REST>
 __device__ __forceinline__ void sh_stage_in_split(const float* __restrict__ f_dc, const float* __restrict__ f_rest, size_t g0, int count, float* lds) {
-    const float4* src = reinterpret_cast<const float4*>(f_rest + g0 * SH_REST);
-    const int n4 = (count * SH_REST) / 4, tail = (count * SH_REST) & 3;
-    for (int e4 = threadIdx.x; e4 < n4; e4 += blockDim.x) {
-        const float4 v = src[e4];
-        const float vv[4] = {v.x, v.y, v.z, v.w};
+    if (REST3 > 0) {
+        const float4* src = reinterpret_cast<const float4*>(f_rest + g0 * REST3);      // g0 is a multiple of 4: 16-byte aligned for every REST3
+        const int n4 = (count * REST3) / 4, tail = (count * REST3) & 3;
+        for (int e4 = threadIdx.x; e4 < n4; e4 += blockDim.x) {
+            const float4 v = src[e4];
+            const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (int c = 0; c < 4; c++) { const int e = e4 * 4 + c, gl = e / SH_REST; lds[gl * SH_ROW + 3 + (e - gl * SH_REST)] = vv[c]; }
+            for (int c = 0; c < 4; c++) { const int e = e4 * 4 + c, gl = e / (REST3 > 0 ? REST3 : 1); lds[gl * SH_ROW + 3 + (e - gl * REST3)] = vv[c]; }
+        }
+        if ((int)threadIdx.x < tail) { const int e = n4 * 4 + threadIdx.x, gl = e / (REST3 > 0 ? REST3 : 1); lds[gl * SH_ROW + 3 + (e - gl * REST3)] = f_rest[g0 * REST3 + e]; }
     }
-    if ((int)threadIdx.x < tail) { const int e = n4 * 4 + threadIdx.x, gl = e / SH_REST; lds[gl * SH_ROW + 3 + (e - gl * SH_REST)] = f_rest[g0 * SH_REST + e]; }
     for (int e = threadIdx.x; e < count * 3; e += blockDim.x) { const int gl = e / 3; lds[gl * SH_ROW + (e - gl * 3)] = f_dc[g0 * 3 + e]; }
 }
-template <bool ACC>
+template <bool ACC, int REST3 = SH_REST>
 __device__ __forceinline__ void sh_stage_out_split(float* __restrict__ d_dc, float* __restrict__ d_rest, size_t g0, int count, const float* lds) {
-    float4* dst = reinterpret_cast<float4*>(d_rest + g0 * SH_REST);
-    const int n4 = (count * SH_REST) / 4, tail = (count * SH_REST) & 3;
-    for (int e4 = threadIdx.x; e4 < n4; e4 += blockDim.x) {
-        float vv[4];
+    if (REST3 > 0) {
+        float4* dst = reinterpret_cast<float4*>(d_rest + g0 * REST3);
+        const int n4 = (count * REST3) / 4, tail = (count * REST3) & 3;
+        for (int e4 = threadIdx.x; e4 < n4; e4 += blockDim.x) {
+            float vv[4];
 #pragma unroll
-        for (int c = 0; c < 4; c++) { const int e = e4 * 4 + c, gl = e / SH_REST; vv[c] = lds[gl * SH_ROW + 3 + (e - gl * SH_REST)]; }
-        float4 o = make_float4(vv[0], vv[1], vv[2], vv[3]);
-        if (ACC) { const float4 old = dst[e4]; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
-        dst[e4] = o;
-    }
-    if ((int)threadIdx.x < tail) {
-        const int e = n4 * 4 + threadIdx.x, gl = e / SH_REST;
-        const float v = lds[gl * SH_ROW + 3 + (e - gl * SH_REST)];
-        d_rest[g0 * SH_REST + e] = ACC ? d_rest[g0 * SH_REST + e] + v : v;
+            for (int c = 0; c < 4; c++) { const int e = e4 * 4 + c, gl = e / (REST3 > 0 ? REST3 : 1); vv[c] = lds[gl * SH_ROW + 3 + (e - gl * REST3)]; }
+            float4 o = make_float4(vv[0], vv[1], vv[2], vv[3]);
+            if (ACC) { const float4 old = dst[e4]; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+            dst[e4] = o;
+        }
+        if ((int)threadIdx.x < tail) {
+            const int e = n4 * 4 + threadIdx.x, gl = e / (REST3 > 0 ? REST3 : 1);
+            const float v = lds[gl * SH_ROW + 3 + (e - gl * REST3)];
+            d_rest[g0 * REST3 + e] = ACC ? d_rest[g0 * REST3 + e] + v : v;
+        }
     }
     for (int e = threadIdx.x; e < count * 3; e += blockDim.x) {
         const int gl = e / 3;

@@ -31,13 +31,14 @@ class GaussianRasterizationSettings(NamedTuple):
     debug: bool
 
 
-def _settings_struct(rs, keep):
+def _settings_struct(rs, keep, sh_coeffs=0):
+    """sh_coeffs: SH coefficients per channel the RAW parameters of the call store (f_rest.shape[1] + 1); 0 for the entry points that take M explicitly"""
     dev = rs.viewmatrix.device
     bg = _h.f32c(rs.bg.to(dev)); vm = _h.f32c(rs.viewmatrix); pm = _h.f32c(rs.projmatrix.to(dev)); cp = _h.f32c(rs.campos.to(dev))
     keep.extend([bg, vm, pm, cp])
     return _h.GsSettings(int(rs.image_height), int(rs.image_width), float(rs.tanfovx), float(rs.tanfovy),
                          float(rs.scale_modifier), int(rs.sh_degree), int(bool(rs.prefiltered)), int(bool(rs.debug)),
-                         _h.ptr(bg), _h.ptr(vm), _h.ptr(pm), _h.ptr(cp), _h.GS_FLAG_EXACT_DSCALE if getattr(rs, "exact_dscale", False) else 0, 0)
+                         _h.ptr(bg), _h.ptr(vm), _h.ptr(pm), _h.ptr(cp), _h.GS_FLAG_EXACT_DSCALE if getattr(rs, "exact_dscale", False) else 0, int(sh_coeffs))
 
 
 class _ExactDscaleSettings(GaussianRasterizationSettings):
@@ -148,14 +149,13 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         dev = means3D.device
         if not means3D.is_cuda:
             raise RuntimeError("diff_gaussian_rasterization (MI355X): tensors must live on a HIP device; there is no CPU path")
-        if f_rest.shape[1:] != (15, 3) or f_dc.shape[1:] != (1, 3):
-            raise ValueError("rasterize_gaussians_raw needs SH degree 3 storage: f_dc [N,1,3], f_rest [N,15,3]")
+        K = raw_sh_coeffs(f_dc, f_rest)
         H, W = int(rs.image_height), int(rs.image_width)
         t = [_h.f32c(x) for x in (means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw)]
         N = means3D.shape[0]
         keep = []
         with torch.cuda.device(dev):
-            st = _settings_struct(rs, keep)
+            st = _settings_struct(rs, keep, K)
             s = _h.stream(dev)
             u8 = dict(dtype=torch.uint8, device=dev)
             radii = torch.empty((N,), dtype=torch.int32, device=dev)
@@ -171,9 +171,9 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
             color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
             depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
             alpha = torch.empty((1, H, W), dtype=torch.float32, device=dev)
-            _h.check(lib.c3d_gs_forward_render(C.byref(st), N, 16, _h.ptr(radii), _h.ptr(geom), num_rendered, _h.ptr(binning), _h.ptr(img),
+            _h.check(lib.c3d_gs_forward_render(C.byref(st), N, K, _h.ptr(radii), _h.ptr(geom), num_rendered, _h.ptr(binning), _h.ptr(img),
                                                _h.ptr(color), _h.ptr(depth), _h.ptr(alpha), s), "c3d_gs_forward_render")
-        ctx.raster_settings, ctx.num_rendered, ctx.N = rs, num_rendered, N
+        ctx.raster_settings, ctx.num_rendered, ctx.N, ctx.K = rs, num_rendered, N, K
         e = torch.empty(0, device=dev)
         ctx.save_for_backward(*(x if x is not None else e for x in t), radii, geom, binning, img)
         ctx.mark_non_differentiable(radii)
@@ -187,26 +187,33 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         dev = geom.device
         keep = []
         with torch.cuda.device(dev):
-            st = _settings_struct(rs, keep)
+            st = _settings_struct(rs, keep, ctx.K)
             f = dict(dtype=torch.float32, device=dev)
             g_m2d, g_m3d = torch.empty((N, 3), **f), torch.empty((N, 3), **f)
-            g_dc, g_rest = torch.empty((N, 1, 3), **f), torch.empty((N, 15, 3), **f)
+            g_dc, g_rest = torch.empty((N, 1, 3), **f), torch.empty((N, ctx.K - 1, 3), **f)
             g_op, g_sc, g_rot = torch.empty((N, 1), **f), torch.empty((N, 3), **f), torch.empty((N, 4), **f)
             scratch = torch.empty((lib.c3d_gs_backward_scratch_bytes(N, ctx.num_rendered),), dtype=torch.uint8, device=dev)
             gc = _h.f32c(grad_color)
             if gc is None:
                 gc = torch.zeros((3, int(rs.image_height), int(rs.image_width)), **f)
-            nz = lambda x: x if N else None
+            nz = lambda x: x if (N and x.numel()) else None
             _h.check(lib.c3d_gs_backward_raw(C.byref(st), N, _h.ptr(nz(means3D)), _h.ptr(nz(f_dc)), _h.ptr(nz(f_rest)), _h.ptr(nz(scaling_raw)),
                                              _h.ptr(nz(rotation_raw)), _h.ptr(radii), _h.ptr(geom), ctx.num_rendered, _h.ptr(binning), _h.ptr(img),
                                              _h.ptr(gc), _h.ptr(_h.f32c(grad_depth)), _h.ptr(_h.f32c(grad_alpha)), _h.ptr(g_m2d), _h.ptr(g_m3d),
-                                             _h.ptr(g_dc), _h.ptr(g_rest), _h.ptr(g_op), _h.ptr(g_sc), _h.ptr(g_rot), _h.ptr(scratch), 0,
+                                             _h.ptr(g_dc), _h.ptr(nz(g_rest)), _h.ptr(g_op), _h.ptr(g_sc), _h.ptr(g_rot), _h.ptr(scratch), 0,
                                              _h.stream(dev)), "c3d_gs_backward_raw")
         return g_m3d, g_m2d, g_dc, g_rest, g_op, g_sc, g_rot, None
 
 
+def raw_sh_coeffs(f_dc, f_rest):
+    """SH coefficients per channel a GaussianModel's split storage holds (f_dc [N,1,3] + f_rest [N,K-1,3]): 16, 9, 4 or 1 -- what c3d_gs_settings.sh_coeffs carries"""
+    if f_dc.dim() != 3 or f_dc.shape[1:] != (1, 3) or f_rest.dim() != 3 or f_rest.shape[2] != 3 or f_rest.shape[1] + 1 not in (1, 4, 9, 16):
+        raise ValueError("raw SH storage must be f_dc [N,1,3] + f_rest [N,K-1,3] with K in (1, 4, 9, 16); got %s / %s" % (tuple(f_dc.shape), tuple(f_rest.shape)))
+    return int(f_rest.shape[1]) + 1
+
+
 def rasterize_gaussians_raw(means3D, means2D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, raster_settings):
-    """(color, radii, depth, alpha) from RAW GaussianModel parameters (SH degree 3 storage).  Equivalent to
+    """(color, radii, depth, alpha) from RAW GaussianModel parameters (SH storage of degree 0..3).  Equivalent to
     GaussianRasterizer(settings)(means3D, means2D, sigmoid(opacity_raw), shs=cat(f_dc, f_rest), scales=exp(scaling_raw),
     rotations=normalize(rotation_raw)) -- one kernel instead of five torch ops each way."""
     return _RasterizeGaussiansRaw.apply(means3D, means2D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, raster_settings)

@@ -58,7 +58,9 @@ typedef struct c3d_gs_settings {
     const float* projmatrix; /* device [16] */
     const float* campos;     /* device [3]  */
     int32_t flags;           /* C3D_GS_FLAG_*; 0 = the dependency's behaviour */
-    int32_t reserved0;       /* must be 0 */
+    int32_t sh_coeffs;       /* raw-parameter entry points (*_raw): SH coefficients per channel the f_dc / f_rest pair STORES: 16 (or 0: the same), 9, 4 or 1, i.e.
+                              * f_rest is [N, sh_coeffs - 1, 3] (NULL for 1) -- a PLY of any degree 0..3 (mesh_processer/mesh_utils.py:346-350; LGM writes degree 0).
+                              * sh_degree is the ACTIVE degree, (sh_degree + 1)^2 <= sh_coeffs.  Ignored by the entry points that take M explicitly. */
 } c3d_gs_settings;
 
 /* flags.  C3D_GS_FLAG_EXACT_DSCALE -- dL/dscale convention of the backward entry points that receive these settings.  Clear (default): as the
@@ -108,7 +110,7 @@ int c3d_gs_backward(const c3d_gs_settings* st, int32_t N, int32_t M, const float
 /* ---- fused-activation variants (extension) -------------------------------------------------------------
  * The reference applies exp / sigmoid / normalize and concatenates f_dc with f_rest in separate torch ops on every render
  * (GaussianModel accessors, main_3DGS_renderer.py:294-321, called from render() :866-868) and back-propagates through them.
- * These two entry points take the RAW parameters of GaussianModel (SH degree 3 storage: f_dc [N,1,3], f_rest [N,15,3]) and fold
+ * These two entry points take the RAW parameters of GaussianModel (f_dc [N,1,3], f_rest [N,K-1,3], K = settings.sh_coeffs: 16 by default) and fold
  * those activations and their backward passes into the projection kernels; outputs and state buffers are exactly those of the
  * plain entry points, c3d_gs_forward_render is shared.  `accumulate` != 0 adds the parameter gradients into the given buffers
  * (loops over views) instead of overwriting them; dL_dmeans2D is always overwritten. */
