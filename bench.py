@@ -65,7 +65,7 @@ def parse():
     ap.add_argument("--timed-prof", choices=["on", "off"], default="on", help="HIP-event kernel timing inside the timed region")
     ap.add_argument("--lanes", type=int, default=0, help="view GROUPS in flight (HIP streams) on the fused step path; 0 = the defaults: 1 with a backward pass (all views of the step go through "
                                                        "every stage of the chain in ONE launch each), 2 forward-only (one group's binning stages run underneath the other's compositing)")
-    ap.add_argument("--group", type=int, default=8, help="--mode fwd: views per launch of every stage (<= 16)")
+    ap.add_argument("--group", type=int, default=16, help="--mode fwd: views per launch of every stage (<= 16)")
     ap.add_argument("--render-path", choices=["step", "fused", "accessor", "boundary"], default="step",
                     help="step: c3d_gs_train_views_raw, all views of the step forward+loss+backward in one sync-free library call (product default for training); fused: GaussianSplattingRenderer.render with activations folded into the kernels (product default); accessor: the same "
                          "API through the reference's op-by-op accessors; boundary: bare diff_gaussian_rasterization call on pre-activated leaves")
@@ -424,7 +424,7 @@ def main():
     import diff_gaussian_rasterization as dgr
 
     if a.lanes <= 0:
-        a.lanes = 2 if a.mode == "fwd" else 1
+        a.lanes = 1
     N, W, H, deg = a.gaussians, a.width, a.height, a.sh_degree
     K, P = (deg + 1) ** 2, a.width * a.height
     use_renderer = a.render_path != "boundary"
@@ -806,7 +806,7 @@ def main():
                 st = S.camera_settings(W, H, 49.1, e_, az_, r_, bg=(1.0, 1.0, 1.0), sh_degree=deg)
                 all_settings.append(dgr.GaussianRasterizationSettings(H, W, st["tanfovx"], st["tanfovy"], t(st["bg"]), 1.0, t(st["viewmatrix"]).reshape(4, 4),
                                                                       t(st["projmatrix"]).reshape(4, 4), deg, t(st["campos"]), False, False))
-            vr = FusedViewRender(N, H, W, dev, lanes=2, group=8)
+            vr = FusedViewRender(N, H, W, dev, lanes=1, group=16)
             pl_ = [q.detach() for q in plist]
             with torch.no_grad():
                 vr.run(all_settings, pl_); vr.run(all_settings, pl_)          # capacity fit + warm-up

@@ -492,9 +492,9 @@ class GaussianSplattingRenderer:
         else:
             raise TypeError("initialize(): pass None, a GS PlyData, a PointCloud, a Mesh or a dict of raw tensors (the UV-grid initialiser is not built)")
 
-    def render_views(self, viewpoint_cameras, bg_colors=None, scaling_modifier=1.0, lanes=2, group=8):
-        """Inference-only batch of render(): all cameras in ONE library call (c3d_gs_render_views_raw; `group` views per launch of every stage,
-        `lanes` groups in flight, no host synchronisation between views).  Same per-view results as render() -- the orbit-renderer loop of the reference's
+    def render_views(self, viewpoint_cameras, bg_colors=None, scaling_modifier=1.0, lanes=1, group=16):
+        """Inference-only batch of render(): all cameras in ONE library call (c3d_gs_render_views_raw; `group` views per launch of every stage, no host
+        synchronisation between views).  Same per-view results as render() -- the orbit-renderer loop of the reference's
         nodes without its per-view launch gaps.  bg_colors: None, one [3] tensor or one per camera.
         -> dict(image [V,3,H,W] clamped, depth [V,1,H,W], alpha [V,1,H,W], radii [V,N], visibility_filter [V,N])"""
         from diff_gaussian_rasterization import GaussianRasterizationSettings

@@ -17,9 +17,9 @@ import c3d_hip as _h
 
 class FusedViewStep:
     def __init__(self, N, H, W, device, pair_capacity=None, lanes=1, views=1):
-        """lanes: number of view GROUPS in flight (1..8): the V views of a step go through every stage of the chain together, ceil(V / lanes) views per launch;
-        1 (default) = all views of the step in one group on the caller's stream.  views: views per step the workspace is sized for (it grows on demand);
-        see include/c3d_gs.h."""
+        """lanes: number of view GROUPS the step is cut into (1..8): ceil(V / lanes) views go through every stage of the chain together (one launch per stage), the
+        groups one after the other on the caller's stream.  1 (default) = all views of the step in one group.  views: views per step the workspace is sized for (it
+        grows on demand); see include/c3d_gs.h."""
         self.N, self.H, self.W, self.device = N, H, W, torch.device(device)
         self.lanes = max(1, min(8, int(lanes)))
         self.views = max(1, int(views))
@@ -280,19 +280,20 @@ class FusedViewRender:
     """Forward only: V views of one cloud per library call (c3d_gs_render_views_raw), `group` views per launch of every stage, `lanes` groups in flight, no host
     synchronisation between views -- the orbit-rendering loop of the reference's renderer nodes in one call."""
 
-    def __init__(self, N, H, W, device, pair_capacity=None, lanes=2, group=8):
-        """group: views that go through the chain together (one launch per stage; <= 16); lanes: groups in flight (HIP streams; the binning stages of one group
-        run underneath the compositing of another).  The workspace holds lanes * group forward-only slices."""
+    def __init__(self, N, H, W, device, pair_capacity=None, lanes=1, group=16):
+        """group: views that go through the chain together (one launch per stage; <= 16); the groups follow each other on the caller's stream and reuse the workspace's
+        `group` forward-only slices.  lanes: kept for callers of earlier rounds (a lower bound on the number of groups a call is cut into)."""
         self.N, self.H, self.W, self.device = N, H, W, torch.device(device)
         self.lanes = max(1, min(8, int(lanes)))
         self.group = max(1, min(16, int(group)))
+        self.slices = self.group
         self.capacity = int(pair_capacity or max(8 * N, 1 << 22))
         self.status = torch.zeros(2, dtype=torch.int32, device=self.device)
         self._fitted = False
         self._alloc()
 
     def _alloc(self):
-        nbytes = _h.lib().c3d_gs_render_workspace_bytes(self.N, self.H, self.W, self.capacity, self.lanes * self.group)     # one set of `group` forward-only slices per lane: see c3d_gs_render_views_raw
+        nbytes = _h.lib().c3d_gs_render_workspace_bytes(self.N, self.H, self.W, self.capacity, self.slices)     # one or two sets of `group` forward-only slices: see c3d_gs_render_views_raw
         self.workspace = torch.empty((nbytes,), dtype=torch.uint8, device=self.device)
 
     def run(self, raster_settings, params, want_radii=False, max_retries=3):

@@ -448,17 +448,20 @@ int c3d_gs_train_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, c
     const int G = group_width(V, lanes), groups = (V + G - 1) / G;
     int rc_all = 0;
     {
-        C3dLanes ln;
-        if (ln.fork(s0, lanes, groups)) return -1;
+        // The groups follow each other on the caller's stream.  Measured and dropped (round 4, profiles/r04*): a two-stage pipeline with projection + binning of
+        // group k + 1 on a high-priority stream underneath the compositing of group k -- 6.93 ms against 5.52 ms for the 8-view step (two groups of four), and no gain
+        // forward-only: the chained-scan kernels of the sorts need their workgroups resident TOGETHER (a tile spins until its predecessors have published), and next to a
+        // compositing grid that holds every wave slot they trickle in and wait for each other.  Rounds 1-3 hid the chains under other views' compositing at the price of a
+        // hole per kernel boundary; one launch per stage for all views leaves neither the holes nor anything worth hiding.
+        hipStream_t sf = s0, s = s0;
         for (int k = 0; k < groups && !rc_all; k++) {
-            hipStream_t s = ln.s[k % ln.L];
             const int v0 = k * G, g = (V - v0) < G ? (V - v0) : G;
             ViewGroup q;
             int rc = 0, res = 0;
             do {
                 if ((rc = group_setup(q, views + v0, g, N, (char*)workspace + (size_t)v0 * vs, vs, pair_capacity, false))) break;
-                if ((rc = group_project(q, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, nullptr, s))) break;
-                if ((rc = group_bin(q, status, true, s, &res))) break;
+                if ((rc = group_project(q, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, nullptr, sf))) break;
+                if ((rc = group_bin(q, status, true, sf, &res))) break;
                 if ((rc = group_composite_fwd(q, res, nullptr, nullptr, nullptr, true, s))) break;
                 // + scale * w_ssim * (1 - MS-SSIM(target * mask, clamp(C) * mask)) of every view (the batch mean of the reference, main_3DGS.py:192, is the mean of
                 // the per-image values): the value goes into the view's own slot behind its tile partials, the gradient into the slice's dL/dcolor plane
@@ -485,7 +488,6 @@ int c3d_gs_train_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, c
             } while (0);
             rc_all = rc;
         }
-        if (ln.join("c3d_gs_train_views_raw") && !rc_all) rc_all = -1;
     }
     if (rc_all) return rc_all;
     if (loss_out) {   // the views' loss values -> loss_out, in view order
@@ -530,24 +532,18 @@ static int views_forward(const char* who, const c3d_gs_settings* views, int32_t 
     const bool fwd_only = !keep_state;       // c3d_gs_render_views_raw: slices without the backward pass's buffers (c3d_gs_render_workspace_bytes)
     StepWs w0; carve_step(nullptr, N, views[0].image_height, views[0].image_width, pair_capacity, w0, fwd_only);
     const size_t vs = w0.bytes;
-    int L = lanes, G;
-    if (keep_state) G = group_width(V, L);
-    else {      // forward only: L slice sets of G slices each
-        if (L > slices) L = slices;
-        G = group_width(V, L);
-        if (G > slices / L) G = slices / L;
-    }
+    // `lanes` groups, one after the other on the caller's stream (see c3d_gs_train_views_raw for the pipeline that was measured and dropped).  Forward only: every group
+    // reuses the workspace's slices (stream order keeps that safe), so the slice count bounds the group width.
+    int G = group_width(V, lanes);
+    if (!keep_state && G > slices) G = slices < 1 ? 1 : slices;
     const int groups = (V + G - 1) / G;
     int rc_all = 0;
-    C3dLanes ln;
-    if (ln.fork(s0, L, groups)) return -1;
+    hipStream_t s = s0;
     for (int k = 0; k < groups && !rc_all; k++) {
-        const int lane = k % ln.L;
-        hipStream_t s = ln.s[lane];
         const int v0 = k * G, g = (V - v0) < G ? (V - v0) : G;
         ViewGroup q;
         int res = 0;
-        char* slice0 = (char*)workspace + (size_t)(keep_state ? v0 : lane * G) * vs;
+        char* slice0 = (char*)workspace + (size_t)(keep_state ? v0 : 0) * vs;
         if ((rc_all = group_setup(q, views + v0, g, N, slice0, vs, pair_capacity, fwd_only))) break;
         // kept state: the backward pass reads the slice's copy of the radii; forward only: straight into the caller's buffer where there is one
         if ((rc_all = group_project(q, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, (!keep_state && out_radii) ? out_radii + v0 : nullptr, s))) break;
@@ -555,10 +551,9 @@ static int views_forward(const char* who, const c3d_gs_settings* views, int32_t 
         if ((rc_all = group_composite_fwd(q, res, out_color + v0, out_depth ? out_depth + v0 : nullptr, out_alpha + v0, keep_state, s))) break;
         for (int i = 0; i < g && keep_state && out_radii && !rc_all; i++)
             if (out_radii[v0 + i] && hipMemcpyAsync(out_radii[v0 + i], q.w[i].radii, sizeof(int) * (size_t)N, hipMemcpyDeviceToDevice, s) != hipSuccess) {
-                c3d_set_error("%s: radii copy failed", who); rc_all = -1;       // no early return: the lanes must still be joined
+                c3d_set_error("%s: radii copy failed", who); rc_all = -1;
             }
     }
-    if (ln.join(who) && !rc_all) rc_all = -1;
     return rc_all;
 }
 
@@ -603,10 +598,8 @@ int c3d_gs_backward_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N
     const int G = group_width(V, lanes), groups = (V + G - 1) / G;
     int rc_all = 0;
     {
-        C3dLanes ln;
-        if (ln.fork(s0, lanes, groups)) return -1;
+        hipStream_t s = s0;      // the backward compositing kernels are VALU-bound: nothing to overlap, the groups follow each other on the caller's stream
         for (int k = 0; k < groups && !rc_all; k++) {
-            hipStream_t s = ln.s[k % ln.L];
             const int v0 = k * G, g = (V - v0) < G ? (V - v0) : G;
             ViewGroup q;
             if ((rc_all = group_setup(q, views + v0, g, N, (char*)workspace + (size_t)v0 * vs, vs, pair_capacity, false))) break;
@@ -620,7 +613,6 @@ int c3d_gs_backward_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N
             C3dProfScope ps(C3D_P_COMPOSITE_BWD, s);
             rc_all = gs_launch_composite_bwd(q.p[0], q.g0, q.b0, sort_result_index(tile_sort_bits(q.tiles)), q.im0, px, depth, q.w[0].pairgrad, q.w[0].pvalid, s, q.cap, nullptr, q.G, q.vs);
         }
-        if (ln.join("c3d_gs_backward_views_raw") && !rc_all) rc_all = -1;
     }
     if (rc_all) return rc_all;
     return step_a8_all_views(views, V, N, vs, workspace, pair_capacity, means3D, f_dc, f_rest, scaling_raw, rotation_raw, dL_dmeans3D, dL_df_dc, dL_df_rest,

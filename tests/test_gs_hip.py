@@ -1143,9 +1143,9 @@ def test_render_views_equals_per_view_render(lanes, group, res):
     vr = r._view_render
     assert vr.lanes == lanes and vr.group == group and vr._fitted
     full = vr.workspace
-    one = vr.workspace.numel() // (vr.lanes * vr.group)
+    one = vr.workspace.numel() // vr.slices
     with torch.no_grad():
-        for keep in sorted({1, max(1, vr.lanes * vr.group - 1)}):
+        for keep in sorted({1, max(1, vr.slices - 1)}):
             vr.workspace = full[:one * keep]
             out1 = r.render_views(cams, ctl.static_bg, lanes=lanes, group=group)
             for k in ("image", "depth", "alpha"):
