@@ -145,6 +145,9 @@ __device__ __forceinline__ float wave_reduce_lds(const float* tile /* [NV][BWD_R
 // records and their four valid bytes per pair.  Net -4 % on the step: reverted.  What bounds this kernel is the VALU cost of a walked pair on gfx950
 // (profiles/r01f_valu_rate_microbench.txt): ~127 cycles of per-pixel arithmetic + ~144 of the ten-value wave reduction (8 v_permlane swaps at 8.3,
 // 12 DPP adds at 4.1, 9 adds at 2.9) = the 271 the SQ counters show.
+// Round 4, measured and dropped (profiles/r04*, same-box A/B): reading the list in windows of 256 positions, compacting each to the pairs some quadrant blended (30 % of
+// the positions a pixel reached) and staging only those -- rounds of 64 BLENDED pairs instead of 64 list positions: 2.45-2.47 ms against 2.41-2.42 ms per 8-view launch.
+// The per-round work (record gather, record index, barriers, epilogue) is not where the time goes; the walk is.
 // DEPTH: some caller-supplied dL/ddepth exists.  The fused training step has none (the reference's loss reads image and alpha only, main_3DGS.py:184-192):
 // its instance drops the depth channel from the per-splat dot product, from the products and from the ten-value reduction (nine values).
 // blockIdx.y = view of a multi-view launch: the state pointers are view 0's (view v lies v * vs bytes behind), pixel-space inputs come from the per-view table `px`.
