@@ -1,5 +1,6 @@
 """Fused multi-view training step of DiffMesh: all views of a step -- render, image loss, backward, gradients summed over the views -- in ONE sync-free
-library call (include/c3d_mesh.h: c3d_mesh_train_views), the views dealt onto the library's view lanes.  MI355X-first replacement of the per-view loop
+library call (include/c3d_mesh.h: c3d_mesh_train_views), the views going through every stage together (one launch per stage for up to 16 views; `lanes`
+is kept for the round-2/3 signature and no longer changes anything).  MI355X-first replacement of the per-view loop
 of the reference's trainer (MVs_Algorithms/DiffRastMesh/diff_mesh.py:98-125): the per-view autograd path is host bound at the BASELINE size (~35
 launches per view enqueued from Python plus torch's own for the loss and the gradient accumulation)."""
 import ctypes as C

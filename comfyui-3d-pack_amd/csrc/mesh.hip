@@ -331,7 +331,7 @@ __device__ __forceinline__ bool aa_pair_of(int j, int px, int py, int W, size_t 
 }
 // what the position gradient of the antialias needs besides the pair records: the colours that were blended and the gradients of the two antialias outputs
 struct AaBwdIn { const uint8_t* hit; const uint8_t* pflag; const float* pair_alpha; const float* albedo0; const float* dy3; const float* dy1; };      // pflag: k_view_shade_fwd_g
-// position gradient of the pairs whose pixel a is `pid` (owned by the triangle with corners p0, p1, p2) -- the algebra of k_aa2_bwd, accumulated per corner
+// position gradient of the pairs whose pixel a is `pid` (owned by the triangle with corners p0, p1, p2) -- the algebra of k_aa_bwd (the standalone antialias backward), accumulated per corner
 __device__ __forceinline__ void aa_bwd_pixel(const AaBwdIn& aa, const float4* __restrict__ rast, const float4 pc[3], int px, int py, size_t pid, int H, int W,
                                              float ax[3], float ay[3], float aw[3]) {
     const uint32_t pf = aa.pflag[pid] & 15u;      // bit j: pair j is a hit and this pixel is its pixel a (one byte per pixel; nearly always zero)
@@ -1625,44 +1625,51 @@ int c3d_mesh_antialias_bwd(const float* color, const float* rast, const float* p
 // composite over the background, clamps -- is enqueued from C without returning to Python, the camera matrix and background travel as kernel
 // arguments (no upload), and the two antialias calls of the reference (coverage, :105; albedo, :138) share ONE silhouette analysis per pixel
 // pair, forward and backward: the coverage "colour" is just (triangle id > 0) and is never materialised.
+// Round 4: every kernel of the fused view takes a VIEW dimension (blockIdx.y, or the high part of a flat pixel index): the views of a training step live in
+// batched arrays [B, ...] and go through each stage in ONE launch (the rasterizer's kernels were batch-capable already: B = views).  The step was host-bound --
+// ~15 launches per view, 0.5 ms of enqueue time per 1.8 ms 8-view step; per-view camera matrices, backgrounds, targets travel as tables in the kernel arguments.
+#define MESH_MAX_VIEWS 16      // views per launch (kernel-argument tables)
 struct ViewMat { float m[16]; };
-__global__ void __launch_bounds__(256) k_view_transform_fwd(const float* __restrict__ v, const float* __restrict__ voff, ViewMat M, int V, float4* __restrict__ out) {
+struct ViewMats { ViewMat v[MESH_MAX_VIEWS]; };
+__global__ void __launch_bounds__(256) k_view_transform_fwd(const float* __restrict__ v, const float* __restrict__ voff, ViewMats Ms, int V, float4* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= V) return;
+    const ViewMat& M = Ms.v[blockIdx.y];
+    out += (size_t)blockIdx.y * V;
     float x = v[3 * i], y = v[3 * i + 1], z = v[3 * i + 2];
     if (voff) { x += voff[3 * i]; y += voff[3 * i + 1]; z += voff[3 * i + 2]; }
     out[i] = make_float4(M.m[0] * x + M.m[1] * y + M.m[2] * z + M.m[3], M.m[4] * x + M.m[5] * y + M.m[6] * z + M.m[7],
                          M.m[8] * x + M.m[9] * y + M.m[10] * z + M.m[11], M.m[12] * x + M.m[13] * y + M.m[14] * z + M.m[15]);
 }
 // dv += M^T (d_a + d_b): the two position gradients (antialias: scattered; rasterize: gathered) are summed on the way
-__global__ void __launch_bounds__(256) k_view_transform_bwd(ViewMat M, const float4* __restrict__ da, const float4* __restrict__ db, int V, float* __restrict__ dv) {
+// view b: gradients at da / db + b * V, result at dv + b * dv_stride floats
+__global__ void __launch_bounds__(256) k_view_transform_bwd(ViewMats Ms, const float4* __restrict__ da, const float4* __restrict__ db, int V, float* __restrict__ dv, size_t dv_stride) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= V) return;
+    const ViewMat& M = Ms.v[blockIdx.y];
+    if (da) da += (size_t)blockIdx.y * V;
+    if (db) db += (size_t)blockIdx.y * V;
+    dv += (size_t)blockIdx.y * dv_stride;
     float4 g = da ? da[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     if (db) { const float4 h = db[i]; g.x += h.x; g.y += h.y; g.z += h.z; g.w += h.w; }
     dv[3 * i] = M.m[0] * g.x + M.m[4] * g.y + M.m[8] * g.z + M.m[12] * g.w;
     dv[3 * i + 1] = M.m[1] * g.x + M.m[5] * g.y + M.m[9] * g.z + M.m[13] * g.w;
     dv[3 * i + 2] = M.m[2] * g.x + M.m[6] * g.y + M.m[10] * g.z + M.m[14] * g.w;
 }
-// albedo = sigmoid(texture fetch), in place; also seeds the antialias outputs: albedo_aa = albedo, cov_aa = (id > 0)
-__global__ void __launch_bounds__(256) k_view_sigmoid_seed(float* __restrict__ albedo, const float4* __restrict__ rast, long long P, float* __restrict__ albedo_aa,
-                                                           float* __restrict__ cov_aa) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
-#pragma unroll
-    for (int c = 0; c < 3; c++) { const float s = 1.f / (1.f + __expf(-albedo[3 * i + c])); albedo[3 * i + c] = s; albedo_aa[3 * i + c] = s; }
-    cov_aa[i] = rast[i].w > 0.f ? 1.f : 0.f;
-}
 // Round 3: ONE pixel pass for rasterize's resolve -> interpolate(uv) -> texture('linear', wrap) -> sigmoid -> antialias seeds, which were five passes through HBM
 // (k_ras_resolve 12.6 us + k_interp_fwd 11.6 + k_tex_fwd 12.1 + k_view_sigmoid_seed 10.5 per 1024^2 view, profiles/r02z_mesh_kernel_stats.csv).  Statement by
 // statement the arithmetic of those kernels (an empty pixel interpolates uv = (0, 0) and fetches there, exactly as the op sequence does: the antialias blend
 // across a silhouette reads it).
 __global__ void __launch_bounds__(256) k_view_pixel_fwd(const float4* __restrict__ pos, const int3* __restrict__ tri, const float2* __restrict__ vt, const int3* __restrict__ ft,
-                                                         const float* __restrict__ tex, int H, int W, int Ht, int Wt, const unsigned long long* __restrict__ zbuf,
+                                                         const float* __restrict__ tex, int B, int V, int H, int W, int Ht, int Wt, const unsigned long long* __restrict__ zbuf,
                                                          float4* __restrict__ rast, float4* __restrict__ rast_db, float2* __restrict__ texc, float* __restrict__ albedo0,
                                                          float* __restrict__ albedo_aa, float* __restrict__ cov_aa) {
-    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (long long)H * W) return;
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // view * H * W + pixel: all arrays are [B, H * W, ..]
+    const long long Pv = (long long)H * W;
+    if (gid >= (long long)B * Pv) return;
+    const int bview = (int)(gid / Pv);
+    const long long lp = gid - (long long)bview * Pv;
+    pos += (size_t)bview * V;
     const unsigned long long key = zbuf[gid];
     float2 q = make_float2(0.f, 0.f);
     float cov = 0.f;
@@ -1670,7 +1677,7 @@ __global__ void __launch_bounds__(256) k_view_pixel_fwd(const float4* __restrict
         rast[gid] = make_float4(0.f, 0.f, 0.f, 0.f);
         rast_db[gid] = make_float4(0.f, 0.f, 0.f, 0.f);
     } else {
-        const int px = (int)(gid % W), py = (int)(gid / W);
+        const int px = (int)(lp % W), py = (int)(lp / W);
         const uint32_t t = (uint32_t)(key & 0xFFFFFFFFull);
         const int3 vi = tri[t];
         const float xs = 2.f / W, ys = 2.f / H;
@@ -1697,91 +1704,34 @@ __global__ void __launch_bounds__(256) k_view_pixel_fwd(const float4* __restrict
     }
     if (cov_aa) cov_aa[gid] = cov;      // the gathering antialias (k_view_shade_fwd_g) needs no seeds
 }
-// both antialias calls of the view in one pass over the pixel pairs
-__global__ void __launch_bounds__(256) k_aa2_fwd(const float* __restrict__ albedo, const float4* __restrict__ rast, const float4* __restrict__ pos,
-                                                  const int3* __restrict__ tri, const EdgeSlot* __restrict__ table, uint32_t mask, int H, int W,
-                                                  float* __restrict__ albedo_aa, float* __restrict__ cov_aa, uint8_t* __restrict__ hit) {
-    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long P = (long long)H * W;
-    if (gid >= P * 2) return;
-    const int d = (int)(gid & 1), pid = (int)(gid >> 1), px = pid % W, py = pid / W;
-    AaHit h;
-    // On a mesh of ~2-pixel triangles nearly EVERY pixel pair has two different ids and runs the whole analysis (vertex loads, edge-hash lookups)
-    // only to find an interior, non-silhouette edge.  One byte per pair remembers the outcome: the backward pass re-analyses the hits only.
-    const bool found = aa_analyze(pos, tri, table, mask, rast, H, W, px, py, d, h);
-    hit[gid] = found ? 1 : 0;
-    if (!found) return;
-    const float alpha = h.s - 0.5f;
-    const size_t ia = (size_t)h.ay * W + h.ax, ib = (size_t)h.by * W + h.bx, idst = alpha > 0.f ? ib : ia;
-#pragma unroll
-    for (int c = 0; c < 3; c++) atomicAdd(&albedo_aa[3 * idst + c], alpha * (albedo[3 * ia + c] - albedo[3 * ib + c]));
-    const float cb = rast[ib].w > 0.f ? 1.f : 0.f;         // pixel a owns the nearer triangle: its coverage is 1
-    if (cb != 1.f) atomicAdd(&cov_aa[idst], alpha * (1.f - cb));
-}
-__global__ void __launch_bounds__(256) k_aa2_bwd(const float* __restrict__ albedo, const float4* __restrict__ rast, const float4* __restrict__ pos,
-                                                  const int3* __restrict__ tri, const EdgeSlot* __restrict__ table, uint32_t mask, const float* __restrict__ dy3,
-                                                  const float* __restrict__ dy1, int V, int H, int W, float* __restrict__ dalbedo, float* __restrict__ dpos,
-                                                  const uint8_t* __restrict__ hit) {
-    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long P = (long long)H * W;
-    if (gid >= P * 2) return;
-    if (!hit[gid]) return;
-    const int d = (int)(gid & 1), pid = (int)(gid >> 1), px = pid % W, py = pid / W;
-    AaHit h;
-    if (!aa_analyze(pos, tri, table, mask, rast, H, W, px, py, d, h)) return;
-    const float alpha = h.s - 0.5f;
-    const size_t ia = (size_t)h.ay * W + h.ax, ib = (size_t)h.by * W + h.bx, idst = alpha > 0.f ? ib : ia;
-    float dalpha = 0.f;
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        const float g = dy3[3 * idst + c];
-        atomicAdd(&dalbedo[3 * ia + c], alpha * g); atomicAdd(&dalbedo[3 * ib + c], -alpha * g);
-        dalpha += g * (albedo[3 * ia + c] - albedo[3 * ib + c]);
-    }
-    const float cb = rast[ib].w > 0.f ? 1.f : 0.f;
-    dalpha += dy1[idst] * (1.f - cb);
-    if (!dpos) return;
-    const float4 pa = pos[h.va], pv = pos[h.vb];
-    const float xa = pa.x / pa.w, ya = pa.y / pa.w, xb = pv.x / pv.w, yb = pv.y / pv.w;
-    const float cx = ((float)h.ax + 0.5f) * (2.f / W) - 1.f, cy = ((float)h.ay + 0.5f) * (2.f / H) - 1.f;
-    const float hh = d == 0 ? 2.f / W : 2.f / H;
-    const float gs = dalpha * h.sgn / hh;
-    float gxa, gya, gxb, gyb;
-    if (d == 0) {
-        const float da = ya - cy, db = yb - cy, den = da - db, te = da / den, gte = gs * (xb - xa);
-        gxa = gs * (1.f - te); gxb = gs * te;
-        gya = gte * (-db / (den * den)); gyb = gte * (da / (den * den));
-    } else {
-        const float da = xa - cx, db = xb - cx, den = da - db, te = da / den, gte = gs * (yb - ya);
-        gya = gs * (1.f - te); gyb = gs * te;
-        gxa = gte * (-db / (den * den)); gxb = gte * (da / (den * den));
-    }
-    float* dA = dpos + (size_t)h.va * 4;
-    float* dB = dpos + (size_t)h.vb * 4;
-    atomicAdd(dA + 0, gxa / pa.w); atomicAdd(dA + 1, gya / pa.w); atomicAdd(dA + 3, -(gxa * xa + gya * ya) / pa.w);
-    atomicAdd(dB + 0, gxb / pv.w); atomicAdd(dB + 1, gyb / pv.w); atomicAdd(dB + 3, -(gxb * xb + gyb * yb) / pv.w);
-}
 // ---- round 3: the same pass without atomics (aa_pair_load above) ----
 // silhouette analysis only: one flag byte + one blend weight per pixel pair
 __global__ void __launch_bounds__(256) k_aa2_pairs(const float4* __restrict__ rast, const float4* __restrict__ pos, const int3* __restrict__ tri,
-                                                    const EdgeSlot* __restrict__ table, uint32_t mask, int H, int W, float* __restrict__ pair_alpha, uint8_t* __restrict__ hit) {
-    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+                                                    const EdgeSlot* __restrict__ table, uint32_t mask, int B, int V, int H, int W, float* __restrict__ pair_alpha, uint8_t* __restrict__ hit) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // view * 2 P + pair
     const long long P = (long long)H * W;
-    if (gid >= P * 2) return;
-    const int d = (int)(gid & 1), pid = (int)(gid >> 1), px = pid % W, py = pid / W;
+    if (gid >= (long long)B * P * 2) return;
+    const int bview = (int)(gid / (2 * P));
+    const long long lg = gid - (long long)bview * 2 * P;
+    const int d = (int)(lg & 1), pid = (int)(lg >> 1), px = pid % W, py = pid / W;
     AaHit h;
-    const bool found = aa_analyze(pos, tri, table, mask, rast, H, W, px, py, d, h);
+    const bool found = aa_analyze(pos + (size_t)bview * V, tri, table, mask, rast + (size_t)bview * P, H, W, px, py, d, h);
     hit[gid] = found ? (uint8_t)(1 | (h.sgn > 0.f ? 2 : 0) | (h.ek << 2)) : (uint8_t)0;
     if (found) pair_alpha[gid] = h.s - 0.5f;
 }
 struct ViewBg { float c[3]; };
+struct ViewBgs { ViewBg v[MESH_MAX_VIEWS]; };
 // both antialias outputs of a pixel gathered from its four pairs, then the shade (k_view_shade_fwd's statements): albedo_aa / cov_aa are written once, by their owner
 __global__ void __launch_bounds__(256) k_view_shade_fwd_g(const float* __restrict__ albedo0, const float4* __restrict__ rast, const uint8_t* __restrict__ hit,
-                                                          const float* __restrict__ pair_alpha, ViewBg bg, int H, int W, float* __restrict__ albedo_aa,
+                                                          const float* __restrict__ pair_alpha, ViewBgs bgs, int B, int H, int W, float* __restrict__ albedo_aa,
                                                           float* __restrict__ cov_aa, float* __restrict__ image, float* __restrict__ alpha_out, uint8_t* __restrict__ pflag) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long long)H * W) return;
-    const int px = (int)(i % W), py = (int)(i / W);
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;        // view * P + pixel; a pixel's pairs and neighbours lie inside its view's block of every array
+    const long long Pv = (long long)H * W;
+    if (i >= (long long)B * Pv) return;
+    const int bview = (int)(i / Pv);
+    const ViewBg bg = bgs.v[bview];
+    const long long lp = i - (long long)bview * Pv;
+    const int px = (int)(lp % W), py = (int)(lp / W);
     float acc[3] = {albedo0[3 * i], albedo0[3 * i + 1], albedo0[3 * i + 2]};
     float cov = rast[i].w > 0.f ? 1.f : 0.f;
     uint32_t pf = 0;        // for the backward passes: bit j = pair j is a hit with this pixel as its pixel a, bit 4 + j = pair j is a hit at all
@@ -1840,6 +1790,12 @@ __global__ void __launch_bounds__(256) k_view_tex_bwd(const float* __restrict__ 
     for (int i = threadIdx.x; i < TEXT_SLOTS; i += 256) { keys[i] = TEXT_EMPTY; vals[i][0] = 0ull; vals[i][1] = 0ull; vals[i][2] = 0ull; }
     __syncthreads();
     const int px = blockIdx.x * 16 + (threadIdx.x & 15), py = blockIdx.y * 16 + (threadIdx.x >> 4);
+    {   // blockIdx.z = view: the view's block of every pixel array (the texel planes are shared by all views)
+        const size_t o = (size_t)blockIdx.z * H * W;
+        uv += o; z.G += 3 * o; z.hit += 2 * o; z.pflag += o; z.pair_alpha += 2 * o; z.sig += 3 * o;
+        if (z.rast) z.rast += o;
+        if (z.drast) z.drast += o;
+    }
     bool bad = false;
     if (px < W && py < H) {
         const size_t gid = (size_t)py * W + px;
@@ -1920,17 +1876,8 @@ __global__ void __launch_bounds__(256) k_view_tex_bwd(const float* __restrict__ 
         }
     }
 }
-// shade with the background as a kernel argument; backward also seeds the antialias backward (dalbedo0 = dalbedo_aa) and applies nothing else
-__global__ void __launch_bounds__(256) k_view_shade_fwd(const float* __restrict__ albedo, const float* __restrict__ alpha, ViewBg bg, long long P,
-                                                        float* __restrict__ image, float* __restrict__ alpha_out) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
-    const float a = fminf(fmaxf(alpha[i], 0.f), 1.f);
-    alpha_out[i] = a;
-#pragma unroll
-    for (int c = 0; c < 3; c++) image[3 * i + c] = fminf(fmaxf(a * albedo[3 * i + c] + (1.f - a) * bg.c[c], 0.f), 1.f);
-}
-__global__ void __launch_bounds__(256) k_view_shade_bwd(const float* __restrict__ albedo, const float* __restrict__ alpha, ViewBg bg, long long P,
+// shade backward for caller-supplied image gradients (c3d_mesh_view_bwd; the training step uses k_view_loss_shade_bwd)
+__global__ void __launch_bounds__(256) k_view_shade_bwd(const float* __restrict__ albedo, const float* __restrict__ alpha, ViewBg bg, long long P,   /* single view */
                                                         const float* __restrict__ dimage, const float* __restrict__ dalpha_out, float* __restrict__ dalbedo_aa,
                                                         float* __restrict__ dalbedo0, float* __restrict__ dalpha) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1949,10 +1896,18 @@ __global__ void __launch_bounds__(256) k_view_shade_bwd(const float* __restrict_
 }
 // Round 3: the training step's pixel loss (k_mesh_pixel_loss) and the shade backward in ONE pass: d/dimage never goes through HBM.
 // L_v = w * mean_{c,p} ((image - target) m)^2 (+ the MS-SSIM gradient planes, when there are any); one loss partial per workgroup.
-struct ViewLossIn { const float* image; const float* target_chw; const float* mask; const float* dssim_chw; float w; float* loss_part; };
-__global__ void __launch_bounds__(256) k_view_loss_shade_bwd(const float* __restrict__ albedo, const float* __restrict__ alpha, ViewBg bg, long long P, ViewLossIn li,
+// per view (blockIdx.y): image / dssim_chw / loss_part are the batch arrays' bases (view b at + b * 3 P, + b * 3 P, + b * loss_stride), targets and masks per-view pointers
+struct ViewLossIn { const float* image; const float* target_chw[MESH_MAX_VIEWS]; const float* mask[MESH_MAX_VIEWS]; const float* dssim_chw; float w; float* loss_part; size_t loss_stride; };
+__global__ void __launch_bounds__(256) k_view_loss_shade_bwd(const float* __restrict__ albedo, const float* __restrict__ alpha, ViewBgs bgs, long long P, ViewLossIn lin,
                                                               float* __restrict__ dalbedo_aa, float* __restrict__ dalbedo0, float* __restrict__ dalpha) {
     __shared__ float red[4];
+    const int bview = blockIdx.y;
+    const ViewBg bg = bgs.v[bview];
+    struct { const float* image; const float* target_chw; const float* mask; const float* dssim_chw; float w; float* loss_part; } li =
+        {lin.image + 3 * (size_t)bview * P, lin.target_chw[bview], lin.mask[bview], lin.dssim_chw ? lin.dssim_chw + 3 * (size_t)bview * P : nullptr, lin.w,
+         lin.loss_part ? lin.loss_part + (size_t)bview * lin.loss_stride : nullptr};
+    albedo += 3 * (size_t)bview * P; alpha += (size_t)bview * P; dalbedo_aa += 3 * (size_t)bview * P; dalpha += (size_t)bview * P;
+    if (dalbedo0) dalbedo0 += 3 * (size_t)bview * P;
     float l = 0.f;
     const float inv = 1.f / (3.f * (float)P);
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (long long)gridDim.x * blockDim.x) {
@@ -1977,164 +1932,127 @@ __global__ void __launch_bounds__(256) k_view_loss_shade_bwd(const float* __rest
     __syncthreads();
     if (threadIdx.x == 0 && li.loss_part) li.loss_part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
-__global__ void __launch_bounds__(256) k_view_sigmoid_bwd(const float* __restrict__ s, float* __restrict__ g, long long n) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { const float v = s[i]; g[i] *= v * (1.f - v); }
-}
-
-// C3D_MESH_PIXEL_FUSED = 1 (default): the round-3 view -- fused pixel passes (k_view_pixel_fwd; the pixel loss in the shade backward; sigmoid', the antialias colour
-// gradient and interpolate's backward inside the texture backward) and NO float atomics (gathering antialias, integer texel-gradient planes): bit-reproducible.
-// 0: one launch per op with scattering atomics, as in round 2 (tests compare the two)
-static bool view_pixel_fused() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("C3D_MESH_PIXEL_FUSED"); v = e ? atoi(e) != 0 : 1; }
-    return v != 0;
-}
+// The fused view has ONE form (round 3's): fused pixel passes (k_view_pixel_fwd; the pixel loss in the shade backward; sigmoid', the antialias colour gradient and
+// interpolate's backward inside the texture backward) and NO float atomics (gathering antialias, integer texel-gradient planes): bit-reproducible.  Round 2's
+// one-launch-per-op variant with scattering atomics (C3D_MESH_PIXEL_FUSED=0) is gone; profiles/r03 holds the comparison.
 namespace {
+// state of B views, every array [B, ...] (B = 1: the layout c3d_hip/mesh_fused.py reads rast / v_clip from)
 struct ViewState { float* vclip; float* rast; float* rast_db; float* texc; float* albedo0; float* albedo_aa; float* cov_aa; uint8_t* hit; float* pair_alpha; uint8_t* pflag; size_t bytes; };
-void carve_view_state(char* base, int V, int H, int W, ViewState& st) {
+void carve_view_state(char* base, int B, int V, int H, int W, ViewState& st) {
     size_t off = 0;
-    const size_t P = (size_t)H * W;
+    const size_t P = (size_t)B * H * W;
     auto take = [&](size_t b) { char* p = base ? base + off : nullptr; off += c3d_align(b); return (float*)p; };
-    st.vclip = take(16 * (size_t)(V > 0 ? V : 1)); st.rast = take(16 * P); st.rast_db = take(16 * P); st.texc = take(8 * P);
+    st.vclip = take(16 * (size_t)B * (size_t)(V > 0 ? V : 1)); st.rast = take(16 * P); st.rast_db = take(16 * P); st.texc = take(8 * P);
     st.albedo0 = take(12 * P); st.albedo_aa = take(12 * P); st.cov_aa = take(4 * P);
     st.hit = (uint8_t*)take(2 * P);
     st.pair_alpha = take(8 * P);
     st.pflag = (uint8_t*)take(P);
     st.bytes = off;
 }
-struct ViewBwdScratch { float* dalbedo_aa; float* dalbedo0; float* dcov; float* duv; float* drast; float* dpos_aa; float* dpos_r; void* ras; TexAcc acc; size_t bytes; };
+struct ViewBwdScratch { float* dalbedo_aa; float* dcov; float* drast; float* dpos_r; void* ras; TexAcc acc; size_t bytes; };
 // Ht, Wt > 0: the scratch also holds the integer planes of the texel gradient (a single view's backward; the multi-view step owns ONE pair for all its views)
-void carve_view_bwd(char* base, int V, int T, int H, int W, int Ht, int Wt, ViewBwdScratch& sc) {
+void carve_view_bwd(char* base, int B, int V, int T, int H, int W, int Ht, int Wt, ViewBwdScratch& sc) {
     size_t off = 0;
-    const size_t P = (size_t)H * W, v = (size_t)(V > 0 ? V : 1);
+    const size_t P = (size_t)B * H * W, v = (size_t)B * (size_t)(V > 0 ? V : 1);
     auto take = [&](size_t b) { char* p = base ? base + off : nullptr; off += c3d_align(b); return p; };
-    sc.dalbedo_aa = (float*)take(12 * P); sc.dalbedo0 = (float*)take(12 * P); sc.dcov = (float*)take(4 * P); sc.duv = (float*)take(8 * P); sc.drast = (float*)take(16 * P);
-    sc.dpos_aa = (float*)take(16 * v); sc.dpos_r = (float*)take(16 * v);
-    sc.ras = take(c3d_mesh_rasterize_bwd_scratch_bytes(1, T));
+    sc.dalbedo_aa = (float*)take(12 * P); sc.dcov = (float*)take(4 * P); sc.drast = (float*)take(16 * P);
+    sc.dpos_r = (float*)take(16 * v);
+    sc.ras = take(c3d_mesh_rasterize_bwd_scratch_bytes(B, T));
     const size_t ntex = 3 * (size_t)(Ht > 0 ? Ht : 0) * (size_t)(Wt > 0 ? Wt : 0);
     sc.acc.lo = sc.acc.hi = nullptr; sc.acc.bad = nullptr;
     if (ntex) { sc.acc.lo = (long long*)take(8 * ntex + 64); sc.acc.hi = (long long*)take(8 * ntex); sc.acc.bad = base ? (uint32_t*)(sc.acc.lo + ntex) : nullptr; }   // the flag word rides behind the first plane: one memset covers both
     sc.bytes = off;
 }
+
+// forward of B <= MESH_MAX_VIEWS views of one mesh: 6 launches + 2 clears whatever B is.  image [B, H, W, 3], alpha [B, H, W, 1].
+int mesh_views_fwd(const c3d_mesh_view* views, int B, const float* v, const float* v_offsets, const int32_t* f, const float* vt, const int32_t* ft, const float* raw_albedo,
+                   const void* aa_topology, void* raster_scratch, void* state, float* image, float* alpha, hipStream_t s) {
+    const c3d_mesh_view* d = &views[0];
+    const int V = d->V, T = d->T, H = d->H, W = d->W;
+    const long long P = (long long)H * W, BP = P * B;
+    ViewState st; carve_view_state((char*)state, B, V, H, W, st);
+    ViewMats Ms; ViewBgs bgs;
+    for (int b = 0; b < B; b++) { for (int i = 0; i < 16; i++) Ms.v[b].m[i] = views[b].clip_from_world[i]; for (int i = 0; i < 3; i++) bgs.v[b].c[i] = views[b].bg[i]; }
+    int rc;
+    hipLaunchKernelGGL(k_view_transform_fwd, dim3(c3d_cdiv(V, 256), B), dim3(256), 0, s, v, v_offsets, Ms, V, (float4*)st.vclip);
+    // depth | id buffer of all views (the rasterizer's kernels take a batch), then ONE pixel pass: resolve -> interpolate(uv) -> texture -> sigmoid (k_view_pixel_fwd).
+    // texture(..., filter_mode='linear') ignores uv_da (diff_mesh_renderer.py:110 passes it all the same): no pixel differentials of uv are produced
+    if ((rc = mesh_rasterize_impl(st.vclip, f, B, V, T, H, W, nullptr, raster_scratch, st.rast, st.rast_db, (c3d_stream_t)s, false))) return rc;
+    { C3dProfScope ps(C3D_P_MESH_INTERPOLATE, s);
+      hipLaunchKernelGGL(k_view_pixel_fwd, dim3(c3d_cdiv(BP, 256)), dim3(256), 0, s, (const float4*)st.vclip, (const int3*)f, (const float2*)vt, (const int3*)ft, raw_albedo, B, V, H, W,
+                         d->Ht, d->Wt, (const unsigned long long*)raster_scratch, (float4*)st.rast, (float4*)st.rast_db, (float2*)st.texc, st.albedo0, (float*)nullptr, (float*)nullptr); }
+    {   // silhouette analysis per pair, then every pixel gathers its blends and shades: no atomics (k_view_shade_fwd_g)
+        C3dProfScope ps(C3D_P_MESH_ANTIALIAS, s);
+        hipLaunchKernelGGL(k_aa2_pairs, dim3(c3d_cdiv(BP * 2, 256)), dim3(256), 0, s, (const float4*)st.rast, (const float4*)st.vclip, (const int3*)f,
+                           (const EdgeSlot*)aa_topology, edge_table_size(T) - 1, B, V, H, W, st.pair_alpha, st.hit);
+        hipLaunchKernelGGL(k_view_shade_fwd_g, dim3(c3d_cdiv(BP, 256)), dim3(256), 0, s, st.albedo0, (const float4*)st.rast, st.hit, st.pair_alpha, bgs, B, H, W,
+                           st.albedo_aa, st.cov_aa, image, alpha, st.pflag);
+    }
+    C3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// backward of the same B views.  li (training step): the pixel loss of every view is evaluated in the first kernel; otherwise B = 1 and dimage / dalpha come from the caller.
+// d_v (optional): view b's vertex gradient at d_v + b * d_v_stride floats.  step_acc: the step's shared integer texel planes (the caller finalizes them); NULL: this
+// call owns a pair in its scratch, clears and finalizes it into d_raw_albedo.
+int mesh_views_bwd(const c3d_mesh_view* views, int B, const int32_t* f, const float* vt, const int32_t* ft, const float* raw_albedo, const void* vertex_topology, void* scratch,
+                   const void* state, const float* dimage, const float* dalpha, float* d_raw_albedo, float* d_v, size_t d_v_stride, hipStream_t s, bool zero_dtex,
+                   const ViewLossIn* li, int loss_blocks, const TexAcc* step_acc) {
+    const c3d_mesh_view* d = &views[0];
+    const int V = d->V, T = d->T, H = d->H, W = d->W;
+    const long long P = (long long)H * W;
+    ViewState st; carve_view_state((char*)state, B, V, H, W, st);
+    ViewBwdScratch sc; carve_view_bwd((char*)scratch, B, V, T, H, W, step_acc ? 0 : d->Ht, step_acc ? 0 : d->Wt, sc);
+    ViewMats Ms; ViewBgs bgs;
+    for (int b = 0; b < B; b++) { for (int i = 0; i < 16; i++) Ms.v[b].m[i] = views[b].clip_from_world[i]; for (int i = 0; i < 3; i++) bgs.v[b].c[i] = views[b].bg[i]; }
+    int rc;
+    {
+        C3dProfScope ps(C3D_P_OTHER, s);
+        if (li) hipLaunchKernelGGL(k_view_loss_shade_bwd, dim3((unsigned)loss_blocks, B), dim3(256), 0, s, st.albedo_aa, st.cov_aa, bgs, P, *li, sc.dalbedo_aa, (float*)nullptr, sc.dcov);
+        else hipLaunchKernelGGL(k_view_shade_bwd, dim3(c3d_cdiv(P, 256)), dim3(256), 0, s, st.albedo_aa, st.cov_aa, bgs.v[0], P, dimage, dalpha, sc.dalbedo_aa, (float*)nullptr, sc.dcov);
+    }
+    // Gathers all the way (round 3): the texture backward gathers the antialias pass's colour gradient on load (x sigmoid'), adds the texel gradients into
+    // integer planes and leaves drast; the per-triangle pass of the rasterizer's backward also gathers the antialias pass's position gradient.
+    const size_t ntex = 3 * (size_t)d->Ht * d->Wt;
+    const TexAcc acc = step_acc ? *step_acc : sc.acc;
+    {
+        C3dProfScope ps(C3D_P_MESH_TEXTURE_BWD, s);
+        if (!step_acc) { C3D_CHECK(hipMemsetAsync(acc.lo, 0, 8 * ntex + 64, s)); C3D_CHECK(hipMemsetAsync(acc.hi, 0, 8 * ntex, s)); }
+        const ViewTexBwd z{sc.dalbedo_aa, st.hit, st.pflag, st.pair_alpha, st.albedo0, d_v ? (const float4*)st.rast : nullptr, d_v ? (const float2*)vt : nullptr,
+                           d_v ? (const int3*)ft : nullptr, d_v ? (float4*)sc.drast : nullptr, acc};
+        hipLaunchKernelGGL(k_view_tex_bwd, dim3(c3d_cdiv(W, 16), c3d_cdiv(H, 16), B), dim3(256), 0, s, raw_albedo, (const float2*)st.texc, H, W, d->Ht, d->Wt, z);
+        if (!step_acc) hipLaunchKernelGGL(k_tex_acc_finalize, dim3(c3d_cdiv((long long)ntex, 256)), dim3(256), 0, s, acc, (long long)ntex, zero_dtex ? 0 : 1, d_raw_albedo);
+    }
+    if (d_v) {
+        const AaBwdIn aa{st.hit, st.pflag, st.pair_alpha, st.albedo0, sc.dalbedo_aa, sc.dcov};
+        if ((rc = mesh_rasterize_bwd_gather(st.vclip, f, st.rast, sc.drast, nullptr, B, V, T, H, W, vertex_topology, sc.ras, sc.dpos_r, (c3d_stream_t)s, aa))) return rc;
+        hipLaunchKernelGGL(k_view_transform_bwd, dim3(c3d_cdiv(V, 256), B), dim3(256), 0, s, Ms, (const float4*)nullptr, (const float4*)sc.dpos_r, V, d_v, d_v_stride);
+    }
+    C3D_LAUNCH_CHECK();
+    return 0;
+}
 }  // namespace
 
 extern "C" {
 
-size_t c3d_mesh_view_state_bytes(int32_t V, int32_t H, int32_t W) { ViewState st; carve_view_state(nullptr, V, H, W, st); return st.bytes; }
-size_t c3d_mesh_view_bwd_scratch_bytes(int32_t V, int32_t T, int32_t H, int32_t W, int32_t Ht, int32_t Wt) { ViewBwdScratch sc; carve_view_bwd(nullptr, V, T, H, W, Ht, Wt, sc); return sc.bytes; }
+size_t c3d_mesh_view_state_bytes(int32_t V, int32_t H, int32_t W) { ViewState st; carve_view_state(nullptr, 1, V, H, W, st); return st.bytes; }
+size_t c3d_mesh_view_bwd_scratch_bytes(int32_t V, int32_t T, int32_t H, int32_t W, int32_t Ht, int32_t Wt) { ViewBwdScratch sc; carve_view_bwd(nullptr, 1, V, T, H, W, Ht, Wt, sc); return sc.bytes; }
 
 int c3d_mesh_view_fwd(const c3d_mesh_view* d, const float* v, const float* v_offsets, const int32_t* f, const float* vt, const int32_t* ft, const float* raw_albedo,
                       const void* aa_topology, void* raster_scratch, void* state, float* image, float* alpha, c3d_stream_t stream) {
-    hipStream_t s = (hipStream_t)stream;
     MESH_REQUIRE(d && v && f && vt && ft && raw_albedo && aa_topology && raster_scratch && state && image && alpha, "c3d_mesh_view_fwd: NULL pointer");
     MESH_REQUIRE(d->V > 0 && d->T > 0 && d->H > 0 && d->W > 0 && d->Ht > 0 && d->Wt > 0 && d->Vt > 0, "c3d_mesh_view_fwd: empty mesh / image / texture");
-    const int V = d->V, T = d->T, H = d->H, W = d->W;
-    const long long P = (long long)H * W;
-    ViewState st; carve_view_state((char*)state, V, H, W, st);
-    ViewMat M; for (int i = 0; i < 16; i++) M.m[i] = d->clip_from_world[i];
-    ViewBg bg; for (int i = 0; i < 3; i++) bg.c[i] = d->bg[i];
-    int rc;
-    hipLaunchKernelGGL(k_view_transform_fwd, dim3(c3d_cdiv(V, 256)), dim3(256), 0, s, v, v_offsets, M, V, (float4*)st.vclip);
-    if (view_pixel_fused()) {
-        // depth | id buffer, then ONE pixel pass: resolve -> interpolate(uv) -> texture -> sigmoid -> antialias seeds (k_view_pixel_fwd).
-        // texture(..., filter_mode='linear') ignores uv_da (diff_mesh_renderer.py:110 passes it all the same): no pixel differentials of uv are produced
-        if ((rc = mesh_rasterize_impl(st.vclip, f, 1, V, T, H, W, nullptr, raster_scratch, st.rast, st.rast_db, stream, false))) return rc;
-        C3dProfScope ps(C3D_P_MESH_INTERPOLATE, s);
-        hipLaunchKernelGGL(k_view_pixel_fwd, dim3(c3d_cdiv(P, 256)), dim3(256), 0, s, (const float4*)st.vclip, (const int3*)f, (const float2*)vt, (const int3*)ft, raw_albedo, H, W,
-                           d->Ht, d->Wt, (const unsigned long long*)raster_scratch, (float4*)st.rast, (float4*)st.rast_db, (float2*)st.texc, st.albedo0, (float*)nullptr, (float*)nullptr);
-    } else {
-        if ((rc = c3d_mesh_rasterize_fwd(st.vclip, f, 1, V, T, H, W, raster_scratch, st.rast, st.rast_db, stream))) return rc;
-        if ((rc = c3d_mesh_interpolate_fwd(vt, 1, st.rast, ft, nullptr, nullptr, 0, 1, d->Vt, 2, H, W, st.texc, nullptr, stream))) return rc;
-        if ((rc = c3d_mesh_texture_fwd(raw_albedo, 1, st.texc, 1, H, W, d->Ht, d->Wt, 3, 1, 0, st.albedo0, stream))) return rc;
-        C3dProfScope ps(C3D_P_MESH_ANTIALIAS, s);
-        hipLaunchKernelGGL(k_view_sigmoid_seed, dim3(c3d_cdiv(P, 256)), dim3(256), 0, s, st.albedo0, (const float4*)st.rast, P, st.albedo_aa, st.cov_aa);
-    }
-    if (view_pixel_fused()) {      // silhouette analysis per pair, then every pixel gathers its blends and shades: no atomics (k_view_shade_fwd_g)
-        C3dProfScope ps(C3D_P_MESH_ANTIALIAS, s);
-        hipLaunchKernelGGL(k_aa2_pairs, dim3(c3d_cdiv(P * 2, 256)), dim3(256), 0, s, (const float4*)st.rast, (const float4*)st.vclip, (const int3*)f,
-                           (const EdgeSlot*)aa_topology, edge_table_size(T) - 1, H, W, st.pair_alpha, st.hit);
-        hipLaunchKernelGGL(k_view_shade_fwd_g, dim3(c3d_cdiv(P, 256)), dim3(256), 0, s, st.albedo0, (const float4*)st.rast, st.hit, st.pair_alpha, bg, H, W,
-                           st.albedo_aa, st.cov_aa, image, alpha, st.pflag);
-    } else {
-        {
-            C3dProfScope ps(C3D_P_MESH_ANTIALIAS, s);
-            hipLaunchKernelGGL(k_aa2_fwd, dim3(c3d_cdiv(P * 2, 256)), dim3(256), 0, s, st.albedo0, (const float4*)st.rast, (const float4*)st.vclip, (const int3*)f,
-                               (const EdgeSlot*)aa_topology, edge_table_size(T) - 1, H, W, st.albedo_aa, st.cov_aa, st.hit);
-        }
-        C3dProfScope ps(C3D_P_OTHER, s);
-        hipLaunchKernelGGL(k_view_shade_fwd, dim3(c3d_cdiv(P, 256)), dim3(256), 0, s, st.albedo_aa, st.cov_aa, bg, P, image, alpha);
-    }
-    C3D_LAUNCH_CHECK();
-    return 0;
+    return mesh_views_fwd(d, 1, v, v_offsets, f, vt, ft, raw_albedo, aa_topology, raster_scratch, state, image, alpha, (hipStream_t)stream);
 }
 
-static int mesh_view_bwd(const c3d_mesh_view* d, const int32_t* f, const float* vt, const int32_t* ft, const float* raw_albedo,
-                         const void* aa_topology, const void* vertex_topology, void* scratch, const void* state, const float* dimage, const float* dalpha,
-                         float* d_raw_albedo, float* d_v, c3d_stream_t stream, bool zero_dtex, const ViewLossIn* li = nullptr, int loss_blocks = 0, const TexAcc* step_acc = nullptr);
 int c3d_mesh_view_bwd(const c3d_mesh_view* d, const float* v, const float* v_offsets, const int32_t* f, const float* vt, const int32_t* ft, const float* raw_albedo,
                       const void* aa_topology, const void* vertex_topology, void* scratch, const void* state, const float* dimage, const float* dalpha,
                       float* d_raw_albedo, float* d_v, c3d_stream_t stream) {
     (void)v; (void)v_offsets;
-    return mesh_view_bwd(d, f, vt, ft, raw_albedo, aa_topology, vertex_topology, scratch, state, dimage, dalpha, d_raw_albedo, d_v, stream, true);
-}
-static int mesh_view_bwd(const c3d_mesh_view* d, const int32_t* f, const float* vt, const int32_t* ft, const float* raw_albedo,
-                         const void* aa_topology, const void* vertex_topology, void* scratch, const void* state, const float* dimage, const float* dalpha,
-                         float* d_raw_albedo, float* d_v, c3d_stream_t stream, bool zero_dtex, const ViewLossIn* li, int loss_blocks, const TexAcc* step_acc) {
-    hipStream_t s = (hipStream_t)stream;
     MESH_REQUIRE(d && f && vt && ft && raw_albedo && aa_topology && scratch && state && d_raw_albedo, "c3d_mesh_view_bwd: NULL pointer");
-    MESH_REQUIRE(dimage || dalpha || li, "c3d_mesh_view_bwd: no upstream gradient");
+    MESH_REQUIRE(dimage || dalpha, "c3d_mesh_view_bwd: no upstream gradient");
     MESH_REQUIRE(!d_v || vertex_topology, "c3d_mesh_view_bwd: the geometry gradient needs the vertex topology");
-    const int V = d->V, T = d->T, H = d->H, W = d->W;
-    const long long P = (long long)H * W;
-    ViewState st; carve_view_state((char*)state, V, H, W, st);
-    const bool fused = view_pixel_fused();
-    ViewBwdScratch sc; carve_view_bwd((char*)scratch, V, T, H, W, step_acc ? 0 : d->Ht, step_acc ? 0 : d->Wt, sc);
-    ViewMat M; for (int i = 0; i < 16; i++) M.m[i] = d->clip_from_world[i];
-    ViewBg bg; for (int i = 0; i < 3; i++) bg.c[i] = d->bg[i];
-    int rc;
-    {
-        C3dProfScope ps(C3D_P_OTHER, s);
-        float* seed = fused ? (float*)nullptr : sc.dalbedo0;
-        if (li) hipLaunchKernelGGL(k_view_loss_shade_bwd, dim3((unsigned)loss_blocks), dim3(256), 0, s, st.albedo_aa, st.cov_aa, bg, P, *li, sc.dalbedo_aa, seed, sc.dcov);
-        else hipLaunchKernelGGL(k_view_shade_bwd, dim3(c3d_cdiv(P, 256)), dim3(256), 0, s, st.albedo_aa, st.cov_aa, bg, P, dimage, dalpha, sc.dalbedo_aa, seed, sc.dcov);
-    }
-    if (fused) {
-        // Gathers all the way (round 3): the texture backward gathers the antialias pass's colour gradient on load (x sigmoid'), adds the texel gradients into
-        // integer planes and leaves drast; the per-triangle pass of the rasterizer's backward also gathers the antialias pass's position gradient.
-        const size_t ntex = 3 * (size_t)d->Ht * d->Wt;
-        const TexAcc acc = step_acc ? *step_acc : sc.acc;
-        {
-            C3dProfScope ps(C3D_P_MESH_TEXTURE_BWD, s);
-            if (!step_acc) { C3D_CHECK(hipMemsetAsync(acc.lo, 0, 8 * ntex + 64, s)); C3D_CHECK(hipMemsetAsync(acc.hi, 0, 8 * ntex, s)); }
-            const ViewTexBwd z{sc.dalbedo_aa, st.hit, st.pflag, st.pair_alpha, st.albedo0, d_v ? (const float4*)st.rast : nullptr, d_v ? (const float2*)vt : nullptr,
-                               d_v ? (const int3*)ft : nullptr, d_v ? (float4*)sc.drast : nullptr, acc};
-            hipLaunchKernelGGL(k_view_tex_bwd, dim3(c3d_cdiv(W, 16), c3d_cdiv(H, 16)), dim3(256), 0, s, raw_albedo, (const float2*)st.texc, H, W, d->Ht, d->Wt, z);
-            if (!step_acc) hipLaunchKernelGGL(k_tex_acc_finalize, dim3(c3d_cdiv((long long)ntex, 256)), dim3(256), 0, s, acc, (long long)ntex, zero_dtex ? 0 : 1, d_raw_albedo);
-        }
-        if (d_v) {
-            const AaBwdIn aa{st.hit, st.pflag, st.pair_alpha, st.albedo0, sc.dalbedo_aa, sc.dcov};
-            if ((rc = mesh_rasterize_bwd_gather(st.vclip, f, st.rast, sc.drast, nullptr, 1, V, T, H, W, vertex_topology, sc.ras, sc.dpos_r, stream, aa))) return rc;
-            hipLaunchKernelGGL(k_view_transform_bwd, dim3(c3d_cdiv(V, 256)), dim3(256), 0, s, M, (const float4*)nullptr, (const float4*)sc.dpos_r, V, d_v);
-        }
-        C3D_LAUNCH_CHECK();
-        return 0;
-    }
-    {
-        C3dProfScope ps(C3D_P_MESH_ANTIALIAS_BWD, s);
-        if (d_v) C3D_CHECK(hipMemsetAsync(sc.dpos_aa, 0, 16 * (size_t)V, s));
-        hipLaunchKernelGGL(k_aa2_bwd, dim3(c3d_cdiv(P * 2, 256)), dim3(256), 0, s, st.albedo0, (const float4*)st.rast, (const float4*)st.vclip, (const int3*)f,
-                           (const EdgeSlot*)aa_topology, edge_table_size(T) - 1, sc.dalbedo_aa, sc.dcov, V, H, W, sc.dalbedo0, d_v ? sc.dpos_aa : nullptr, st.hit);
-        hipLaunchKernelGGL(k_view_sigmoid_bwd, dim3(c3d_cdiv(P * 3, 256)), dim3(256), 0, s, st.albedo0, sc.dalbedo0, P * 3);
-    }
-    if ((rc = mesh_texture_bwd(raw_albedo, 1, st.texc, sc.dalbedo0, 1, H, W, d->Ht, d->Wt, 3, 1, 0, d_raw_albedo, sc.duv, stream, zero_dtex))) return rc;
-    if (d_v) {
-        if ((rc = c3d_mesh_interpolate_bwd(vt, 1, st.rast, ft, sc.duv, 1, d->Vt, 2, H, W, nullptr, sc.drast, stream))) return rc;
-        if ((rc = c3d_mesh_rasterize_bwd_gather(st.vclip, f, st.rast, sc.drast, nullptr, 1, V, T, H, W, vertex_topology, sc.ras, sc.dpos_r, stream))) return rc;
-        hipLaunchKernelGGL(k_view_transform_bwd, dim3(c3d_cdiv(V, 256)), dim3(256), 0, s, M, (const float4*)sc.dpos_aa, (const float4*)sc.dpos_r, V, d_v);
-    }
-    C3D_LAUNCH_CHECK();
-    return 0;
+    return mesh_views_bwd(d, 1, f, vt, ft, raw_albedo, vertex_topology, scratch, state, dimage, dalpha, d_raw_albedo, d_v, 0, (hipStream_t)stream, true, nullptr, 0, nullptr);
 }
 
 }  // extern "C"
@@ -2142,39 +2060,20 @@ static int mesh_view_bwd(const c3d_mesh_view* d, const int32_t* f, const float* 
 // ------------------------------------------------------------------------------------------------------------------------------------------
 // Fused multi-view training step of DiffMesh (include/c3d_mesh.h: c3d_mesh_train_views): what DiffMesh.training_step does per step --
 // render every view of the batch, image loss, backward, gradients summed over the views (diff_mesh.py:98-125 in the reference) -- as ONE
-// library call.  The per-view autograd path is host bound at this size (~35 launches per view enqueued from Python, plus torch's own for the
-// loss and the gradient accumulation); here the views are dealt onto the library's view lanes and nothing returns to the host language.
+// library call.  Round 4: the views go through every stage TOGETHER (groups of <= MESH_MAX_VIEWS views, one launch per stage: ~16 launches per group
+// where rounds 2-3 enqueued ~15 per VIEW on a pool of streams and were bound by the host's enqueue rate).
 // ------------------------------------------------------------------------------------------------------------------------------------------
 #include "../../include/c3d_loss.h"
-int ms_value_grad(const float* x, const float* y, const float* mask, int clamp_y, int B, int C, int H, int W, float grad_scale, int accumulate, float* dL_dy,
-                  float va, float vb, float* ms_out, void* workspace, hipStream_t s, int store_value = 0);
+int ms_value_grad_images(const float* const* x, const float* const* y, const float* const* mask, float* const* dy, int clamp_y, int B, int C, int H, int W, float grad_scale,
+                         int accumulate, float va, float vb, float* out0, size_t out_stride, void* workspace, hipStream_t s);
 
-// image [H,W,3] -> planes [3,H,W] (what the MS-SSIM kernels read)
+// images [B, H, W, 3] -> planes [B, 3, H, W] (what the MS-SSIM kernels read)
 __global__ void __launch_bounds__(256) k_mesh_hwc_to_chw(const float* __restrict__ hwc, long long P, float* __restrict__ chw) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
+    hwc += 3 * (size_t)blockIdx.y * P; chw += 3 * (size_t)blockIdx.y * P;
 #pragma unroll
     for (int c = 0; c < 3; c++) chw[c * P + i] = hwc[3 * i + c];
-}
-// L_v = scale * w_mse * mean_{c,p} ((image - target) m)^2: value into *loss_out, d/dimage [H,W,3] = that gradient + (dssim [3,H,W], or nothing)
-__global__ void __launch_bounds__(256) k_mesh_pixel_loss(const float* __restrict__ image, const float* __restrict__ target_chw, const float* __restrict__ mask, long long P,
-                                                          float w, const float* __restrict__ dssim_chw, float* __restrict__ dimage, float* __restrict__ loss_out) {
-    __shared__ float red[4];
-    float l = 0.f;
-    const float inv = 1.f / (3.f * (float)P);
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (long long)gridDim.x * blockDim.x) {
-        const float m = mask ? mask[i] : 1.f;
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            const float d = (image[3 * i + c] - target_chw[c * P + i]) * m;
-            l += d * d;
-            dimage[3 * i + c] = 2.f * w * inv * d * m + (dssim_chw ? dssim_chw[c * P + i] : 0.f);
-        }
-    }
-    l = c3d_wave_sum(l * w * inv);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = l;
-    __syncthreads();
-    if (threadIdx.x == 0 && loss_out) loss_out[blockIdx.x] = red[0] + red[1] + red[2] + red[3];      // one partial per workgroup (k_mesh_sum_loss adds them in a fixed order)
 }
 #define MESH_LOSS_SLOTS 1032      // per view: <= 1024 workgroup partials of the pixel loss, then the view's MS-SSIM term at [1024]
 __global__ void __launch_bounds__(256) k_mesh_sum_loss(const float* __restrict__ parts, int n_views, int nblk, int ssim, float* __restrict__ loss_out) {
@@ -2192,7 +2091,7 @@ __global__ void __launch_bounds__(256) k_mesh_sum_loss(const float* __restrict__
     }
     if (threadIdx.x == 0) atomicAdd(loss_out, total);      // ONE add per call
 }
-// out (+)= sum_k in_k, k in fixed order (lane buffers of the texture gradient; per-view buffers of the vertex gradient)
+// out (+)= sum_k in_k, k in fixed order (per-view buffers of the vertex gradient)
 struct MeshSumSrc { int n; const float* p[64]; };
 __global__ void __launch_bounds__(256) k_mesh_sum(MeshSumSrc src, long long count, int accumulate, float* __restrict__ out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2203,24 +2102,20 @@ __global__ void __launch_bounds__(256) k_mesh_sum(MeshSumSrc src, long long coun
 }
 
 namespace {
-struct MeshStepLane { char* state; char* bwd; char* raster; float* image; float* alpha; float* image_chw; float* dssim; float* dimage; char* ms_ws; float* d_ra; };
-struct MeshStepWs { TexAcc acc; MeshStepLane lane[C3D_MAX_LANES]; float* d_v; size_t d_v_stride; float* loss_part; size_t bytes; };
-void carve_mesh_step(char* base, int V, int T, int H, int W, int Ht, int Wt, int n_views, int lanes, MeshStepWs& w) {
+struct MeshStepWs { TexAcc acc; char* state; char* bwd; char* raster; float* image; float* alpha; float* image_chw; float* dssim; char* ms_ws; float* d_v; size_t d_v_stride; float* loss_part; size_t bytes; };
+// G = views per group (<= MESH_MAX_VIEWS): the batched state of ONE group, reused by the groups of a step in stream order
+void carve_mesh_step(char* base, int V, int T, int H, int W, int Ht, int Wt, int n_views, MeshStepWs& w) {
     size_t off = 0;
-    const size_t P = (size_t)H * W;
+    const int G = n_views < 1 ? 1 : (n_views > MESH_MAX_VIEWS ? MESH_MAX_VIEWS : n_views);
+    const size_t P = (size_t)G * H * W;
     auto take = [&](size_t b) { char* p = base ? base + off : nullptr; off += c3d_align(b); return p; };
     const size_t ntex = 3 * (size_t)Ht * Wt;
-    // first, so that its address does not depend on the lane count: the integer planes ALL views of the step add their texel gradients into (k_view_tex_bwd)
-    w.acc.lo = (long long*)take(8 * ntex + 64); w.acc.hi = (long long*)take(8 * ntex); w.acc.bad = base ? (uint32_t*)(w.acc.lo + ntex) : nullptr;
-    for (int l = 0; l < lanes; l++) {
-        MeshStepLane& q = w.lane[l];
-        q.state = take(c3d_mesh_view_state_bytes(V, H, W));
-        q.bwd = take(c3d_mesh_view_bwd_scratch_bytes(V, T, H, W, 0, 0));
-        q.raster = take(c3d_mesh_raster_scratch_bytes(1, H, W, T));
-        q.image = (float*)take(12 * P); q.alpha = (float*)take(4 * P); q.image_chw = (float*)take(12 * P); q.dssim = (float*)take(12 * P); q.dimage = (float*)take(12 * P);
-        q.ms_ws = take(c3d_msssim_workspace_bytes(1, 3, H, W));
-        q.d_ra = (float*)take(12 * (size_t)Ht * Wt);
-    }
+    w.acc.lo = (long long*)take(8 * ntex + 64); w.acc.hi = (long long*)take(8 * ntex); w.acc.bad = base ? (uint32_t*)(w.acc.lo + ntex) : nullptr;      // the integer planes ALL views of the step add their texel gradients into
+    { ViewState st; carve_view_state(nullptr, G, V, H, W, st); w.state = take(st.bytes); }
+    { ViewBwdScratch sc; carve_view_bwd(nullptr, G, V, T, H, W, 0, 0, sc); w.bwd = take(sc.bytes); }
+    w.raster = take(c3d_mesh_raster_scratch_bytes(G, H, W, T));
+    w.image = (float*)take(12 * P); w.alpha = (float*)take(4 * P); w.image_chw = (float*)take(12 * P); w.dssim = (float*)take(12 * P);
+    w.ms_ws = take((H > 160 && W > 160) ? c3d_msssim_workspace_bytes(G, 3, H, W) : 0);
     w.d_v_stride = c3d_align(12 * (size_t)(V > 0 ? V : 1));
     w.d_v = (float*)take(w.d_v_stride * (size_t)(n_views > 0 ? n_views : 1));
     w.loss_part = (float*)take(sizeof(float) * MESH_LOSS_SLOTS * (size_t)(n_views > 0 ? n_views : 1));
@@ -2231,8 +2126,9 @@ void carve_mesh_step(char* base, int V, int T, int H, int W, int Ht, int Wt, int
 extern "C" {
 
 size_t c3d_mesh_step_workspace_bytes(int32_t V, int32_t T, int32_t H, int32_t W, int32_t Ht, int32_t Wt, int32_t n_views, int32_t lanes) {
+    (void)lanes;      // kept in the signature (ABI of rounds 2-3): the views of a step now go through every stage together instead of on a pool of streams
     MeshStepWs w;
-    carve_mesh_step(nullptr, V, T, H, W, Ht, Wt, n_views, lanes < 1 ? 1 : (lanes > C3D_MAX_LANES ? C3D_MAX_LANES : lanes), w);
+    carve_mesh_step(nullptr, V, T, H, W, Ht, Wt, n_views, w);
     return w.bytes;
 }
 
@@ -2258,59 +2154,35 @@ int c3d_mesh_train_views(const c3d_mesh_view* views, int32_t n_views, const floa
     const long long P = (long long)d0.H * d0.W;
     const int nblk = c3d_cdiv(P, 256) < 1024 ? c3d_cdiv(P, 256) : 1024;
     const size_t ntex = 3 * (size_t)d0.Ht * d0.Wt;
-    C3dLanes ln;
     MeshStepWs w;
-    const bool fused = view_pixel_fused();
-    if (fused) {      // the shared integer planes are cleared on the caller's stream BEFORE the lanes fork from it
-        carve_mesh_step((char*)workspace, d0.V, d0.T, d0.H, d0.W, d0.Ht, d0.Wt, n_views, 1, w);
-        C3D_CHECK(hipMemsetAsync(w.acc.lo, 0, 8 * ntex + 64, s0));
-        C3D_CHECK(hipMemsetAsync(w.acc.hi, 0, 8 * ntex, s0));
+    carve_mesh_step((char*)workspace, d0.V, d0.T, d0.H, d0.W, d0.Ht, d0.Wt, n_views, w);
+    // the shared integer planes are cleared once per step
+    C3D_CHECK(hipMemsetAsync(w.acc.lo, 0, 8 * ntex + 64, s0));
+    C3D_CHECK(hipMemsetAsync(w.acc.hi, 0, 8 * ntex, s0));
+    const int G = n_views > MESH_MAX_VIEWS ? MESH_MAX_VIEWS : n_views;
+    for (int v0 = 0; v0 < n_views; v0 += G) {
+        const int g = (n_views - v0) < G ? (n_views - v0) : G;
+        int rc;
+        if ((rc = mesh_views_fwd(views + v0, g, v, v_offsets, f, vt, ft, raw_albedo, aa_topology, w.raster, w.state, w.image, w.alpha, s0))) return rc;
+        float* lp = w.loss_part + (size_t)v0 * MESH_LOSS_SLOTS;      // these views' loss partials: the value is summed in a fixed order at the end
+        if (ssim) {   // + scale * w_ssim * (1 - MS-SSIM(target m, image m)) of every view: values into the views' slots, gradients (planes) into w.dssim -- one batched call
+            C3dProfScope ps(C3D_P_OTHER, s0);
+            const float ws_ = loss->scale * loss->w_ssim;
+            hipLaunchKernelGGL(k_mesh_hwc_to_chw, dim3(c3d_cdiv(P, 256), g), dim3(256), 0, s0, w.image, P, w.image_chw);
+            const float* ys[MESH_MAX_VIEWS]; float* dys[MESH_MAX_VIEWS];
+            for (int i = 0; i < g; i++) { ys[i] = w.image_chw + 3 * (size_t)i * P; dys[i] = w.dssim + 3 * (size_t)i * P; }
+            if ((rc = ms_value_grad_images(target_chw + v0, ys, mask ? mask + v0 : nullptr, dys, 0, g, 3, d0.H, d0.W, -ws_, 0, ws_, -ws_, loss_out ? lp + 1024 : nullptr,
+                                           sizeof(float) * MESH_LOSS_SLOTS, w.ms_ws, s0))) return rc;
+        }
+        ViewLossIn li{};      // the pixel loss inside the backward pass's first kernel: d/dimage is never materialised
+        li.image = w.image; li.dssim_chw = ssim ? w.dssim : nullptr; li.w = loss->scale * loss->w_mse; li.loss_part = loss_out ? lp : nullptr; li.loss_stride = MESH_LOSS_SLOTS;
+        for (int i = 0; i < g; i++) { li.target_chw[i] = target_chw[v0 + i]; li.mask[i] = mask ? mask[v0 + i] : nullptr; }
+        float* dv = d_v_offsets ? (float*)((char*)w.d_v + (size_t)v0 * w.d_v_stride) : nullptr;
+        if ((rc = mesh_views_bwd(views + v0, g, f, vt, ft, raw_albedo, vertex_topology, w.bwd, w.state, nullptr, nullptr, nullptr, dv, w.d_v_stride / sizeof(float), s0, false, &li, nblk, &w.acc))) return rc;
     }
-    if (ln.fork(s0, lanes, n_views)) return -1;
-    hipStream_t* ls = ln.s;
-    const int L = ln.L;
-    carve_mesh_step((char*)workspace, d0.V, d0.T, d0.H, d0.W, d0.Ht, d0.Wt, n_views, L, w);
-    int rc_all = 0;
-    for (int l = 0; l < L && !rc_all && !fused; l++)
-        if (hipMemsetAsync(w.lane[l].d_ra, 0, sizeof(float) * ntex, ls[l]) != hipSuccess) { c3d_set_error("c3d_mesh_train_views: memset failed"); rc_all = -1; }
-    for (int i = 0; i < n_views && !rc_all; i++) {
-        hipStream_t s = ls[i % L];
-        MeshStepLane& q = w.lane[i % L];
-        const c3d_mesh_view* d = &views[i];
-        const float* mk = mask ? mask[i] : nullptr;
-        float* lp = w.loss_part + (size_t)i * MESH_LOSS_SLOTS;      // this view's loss partials: the value is summed in a fixed order after the join
-        int rc = 0;
-        do {
-            if ((rc = c3d_mesh_view_fwd(d, v, v_offsets, f, vt, ft, raw_albedo, aa_topology, q.raster, q.state, q.image, q.alpha, (c3d_stream_t)s))) break;
-            {
-                C3dProfScope ps(C3D_P_OTHER, s);
-                if (ssim) {   // + scale * w_ssim * (1 - MS-SSIM(target m, image m)) of this view: value into loss_out, gradient (planes) into q.dssim
-                    const float ws_ = loss->scale * loss->w_ssim;
-                    hipLaunchKernelGGL(k_mesh_hwc_to_chw, dim3(c3d_cdiv(P, 256)), dim3(256), 0, s, q.image, P, q.image_chw);
-                    if ((rc = ms_value_grad(target_chw[i], q.image_chw, mk, 0, 1, 3, d->H, d->W, -ws_, 0, q.dssim, ws_, -ws_, loss_out ? lp + 1024 : nullptr, q.ms_ws, s, 1))) break;
-                }
-                if (!fused)
-                    hipLaunchKernelGGL(k_mesh_pixel_loss, dim3((unsigned)nblk), dim3(256), 0, s, q.image, target_chw[i], mk, P,
-                                       loss->scale * loss->w_mse, ssim ? q.dssim : (const float*)nullptr, q.dimage, loss_out ? lp : (float*)nullptr);
-            }
-            float* dv = d_v_offsets ? (float*)((char*)w.d_v + (size_t)i * w.d_v_stride) : nullptr;
-            if (fused) {      // the pixel loss inside the backward pass's first kernel: d/dimage is never materialised
-                const ViewLossIn li{q.image, target_chw[i], mk, ssim ? q.dssim : (const float*)nullptr, loss->scale * loss->w_mse, loss_out ? lp : (float*)nullptr};
-                if ((rc = mesh_view_bwd(d, f, vt, ft, raw_albedo, aa_topology, vertex_topology, q.bwd, q.state, nullptr, nullptr, q.d_ra, dv, (c3d_stream_t)s, false, &li, nblk, &w.acc))) break;
-            } else if ((rc = mesh_view_bwd(d, f, vt, ft, raw_albedo, aa_topology, vertex_topology, q.bwd, q.state, q.dimage, nullptr, q.d_ra, dv, (c3d_stream_t)s, false))) break;
-        } while (0);
-        rc_all = rc;
-    }
-    if (ln.join("c3d_mesh_train_views") && !rc_all) rc_all = -1;
-    if (rc_all) return rc_all;
     {
         C3dProfScope ps(C3D_P_OTHER, s0);
-        if (fused) hipLaunchKernelGGL(k_tex_acc_finalize, dim3(c3d_cdiv((long long)ntex, 256)), dim3(256), 0, s0, w.acc, (long long)ntex, accumulate, d_raw_albedo);
-        else {
-            MeshSumSrc a; a.n = L;
-            for (int l = 0; l < L; l++) a.p[l] = w.lane[l].d_ra;
-            hipLaunchKernelGGL(k_mesh_sum, dim3(c3d_cdiv((long long)ntex, 256)), dim3(256), 0, s0, a, (long long)ntex, accumulate, d_raw_albedo);
-        }
+        hipLaunchKernelGGL(k_tex_acc_finalize, dim3(c3d_cdiv((long long)ntex, 256)), dim3(256), 0, s0, w.acc, (long long)ntex, accumulate, d_raw_albedo);
         if (d_v_offsets) {
             MeshSumSrc b; b.n = n_views;
             for (int i = 0; i < n_views; i++) b.p[i] = (const float*)((const char*)w.d_v + (size_t)i * w.d_v_stride);

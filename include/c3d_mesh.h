@@ -68,8 +68,8 @@ int c3d_mesh_interpolate_bwd(const float* attr, int32_t Ba, const float* rast, c
                              c3d_stream_t stream);
 
 /* backward of interpolate's pixel differentials out_da (what a mip-mapped texture() hands back as d uv_da): dout_da [B,H,W,2 n_diff] ->
- * dattr [Ba,V,A] ADDED to (call after c3d_mesh_interpolate_bwd; NULL = not wanted), drast_db [B,H,W,4] written in full.  (rasterize does not
- * propagate drast_db further: grad_db of the dependency's rasterize is not built.) */
+ * dattr [Ba,V,A] ADDED to (call after c3d_mesh_interpolate_bwd; NULL = not wanted), drast_db [B,H,W,4] written in full: hand it to
+ * c3d_mesh_rasterize_bwd as `ddb` (the dependency's grad_db path, ABI 301) to carry it on to the vertex positions. */
 int c3d_mesh_interpolate_da_bwd(const float* attr, int32_t Ba, const float* rast, const int32_t* tri, const float* rast_db,
                                 const int32_t* diff_attrs, int32_t n_diff, const float* dout_da, int32_t B, int32_t V, int32_t A,
                                 int32_t H, int32_t W, float* dattr, float* drast_db, c3d_stream_t stream);
@@ -162,13 +162,15 @@ int c3d_mesh_view_bwd(const c3d_mesh_view* d, const float* v, const float* v_off
 
 /* ---- fused multi-view training step (extension) ----------------------------------------------------------------------------------------
  * One call = what DiffMesh.training_step does for the views of a step (reference: MVs_Algorithms/DiffRastMesh/diff_mesh.py:98-125): for each view
- * c3d_mesh_view_fwd -> image loss -> backward, the gradients summed over the views.  The views are dealt onto `lanes` (1..8) library-owned HIP
- * streams forked from / joined into `stream`; nothing synchronises with the host.  Loss, per view v of n:
+ * c3d_mesh_view_fwd -> image loss -> backward, the gradients summed over the views.  ABI 400: the views go through every stage TOGETHER (groups of
+ * up to 16 views, one launch per stage with the view as a grid dimension, everything on `stream`; nothing synchronises with the host).  `lanes`
+ * (1..8; rounds 2-3 dealt the views onto that many library-owned streams) is still checked but no longer changes anything.  Loss, per view v of n:
  *   scale * [ w_mse * mean_{c,p} ((image_v - target_v) m_v)^2  +  w_ssim * (1 - MS_SSIM(target_v m_v, image_v m_v)) ]        (include/c3d_loss.h; sides > 160)
  * with scale = 1 / n this is the reference's batch loss (1 - lambda) F.mse_loss(imgs, refs) + lambda (1 - ms_ssim(refs, imgs)), lambda = w_ssim.
  * target_chw / mask: HOST arrays of n DEVICE pointers, [3,H,W] / [1,H,W] (mask or its entries may be NULL = 1).  loss_out (device float) accumulates
  * the value.  d_raw_albedo [Ht,Wt,3], d_v_offsets [V,3] (NULL: geometry not trained): overwritten, or added to when accumulate != 0.  The texture
- * gradient of a lane's views accumulates with float atomics (as in c3d_mesh_texture_bwd); lanes and views are summed in a fixed order.
+ * gradient of all views accumulates in one pair of 64-bit integer planes, vertex gradients and loss terms are summed over the views in a fixed
+ * order: the same bits every run.
  * workspace: c3d_mesh_step_workspace_bytes(V, T, H, W, Ht, Wt, n_views, lanes).  At most 64 views per call. */
 typedef struct c3d_mesh_step_loss { float w_mse; float w_ssim; float scale; } c3d_mesh_step_loss;
 size_t c3d_mesh_step_workspace_bytes(int32_t V, int32_t T, int32_t H, int32_t W, int32_t Ht, int32_t Wt, int32_t n_views, int32_t lanes);
