@@ -7,8 +7,9 @@
 Workload (config.workload): BASELINE.md section 3 configs 2-4 -- 1,000,000 synthetic Gaussians (seed 1234), SH degree 3,
 1920x1080, the 64-camera orbit.  A "step" = one pass of the hot path over one batch of views on every rank:
 `--views-per-gpu` (default 8) views rasterized forward and backward through the C-ABI -- by default in ONE fused library call
-(`--render-path step`: c3d_gs_train_views_raw, views dealt onto `--lanes` HIP streams, pixel loss and its gradient inside, one
-per-Gaussian backward pass for all views); `--render-path boundary | fused | accessor` time the plain drop-in API one autograd call
+(`--render-path step`: c3d_gs_train_views_raw, the views of a step through every stage in ONE launch -- view = a grid dimension, groups of
+`--group` views (default 16), `--lanes` groups in flight (default 1) -- pixel loss and its gradient inside, one per-Gaussian backward pass
+for all views); `--render-path boundary | fused | accessor` time the plain drop-in API one autograd call
 per view instead.  For N > 1 the step ends with the one gradient exchange of the shared-Gaussian training loop (`--exchange allreduce`,
 default, or `allgather`: every rank's dense gradient + fixed-order local sum).  Per-GPU work is fixed as N grows ("weak"): at N = 8
 this is config 4 (64 views/step, 8 per GPU).  Inputs are resident in HBM before the timed region.
@@ -17,9 +18,10 @@ and say so in `metric`; `--workload mesh` runs BASELINE config 5 (DiffRastMesh).
 
 value = views * W * H over all ranks / wall seconds / 1e6  (wall = max over ranks, barrier + synchronize on both sides).
 roofline = the dominant kernel group (largest share of in-library GPU time, measured with HIP events on the launch streams),
-algorithmic bytes per launch (DESIGN.md "Algorithmic bytes") / its average duration.  With view lanes > 1 the kernels of different views
-share the CUs inside the timed region, so the duration used is that of an extra single-lane pass over the same step (kernels alone);
-the in-region figures are reported as `kernels_concurrent_avg_ms` / `roofline.avg_ms_concurrent`.  `roofline.traffic` (PMC) and
+algorithmic bytes per launch (DESIGN.md "Algorithmic bytes": per view x the views one launch covers) / its average duration.  Only with
+`--lanes` > 1 (several groups in flight; not the default) do kernels of different groups share the CUs inside the timed region; the duration
+used is then that of an extra single-group pass over the same step, the in-region figures go to `kernels_concurrent_avg_ms` /
+`roofline.avg_ms_concurrent`.  `roofline.traffic` (PMC) and
 `roofline.issue` (SQ counters) come from the newest committed rocprofv3 summaries under profiles/.
 cpu_baseline = the CPU oracle (a port: the reference has no CPU path) on ONE view of the same workload.
 """
@@ -242,11 +244,11 @@ def main_mesh(a, world, rank, dev, dist):
     half = torch.full((H, W, 1), 0.5, device=dev)
     seed_grad = torch.tensor(1.0 / (a.views_per_gpu * world), device=dev)      # d(step loss) / d(view loss): the 1 / views factor without a division kernel per view
     # --render-path step (default): the whole step -- render, image loss (MSE against the target images), backward of every view, gradients summed -- as ONE
-    # library call on view lanes (c3d_mesh_train_views, what DiffMesh.training_step uses on a HIP device); fused: one autograd call per view, loss in torch
+    # library call (c3d_mesh_train_views, every stage one launch over all views; what DiffMesh.training_step uses on a HIP device); fused: one autograd call per view, loss in torch
     use_step = a.render_path == "step"
     if use_step:
         from c3d_hip.mesh_step import FusedMeshStep
-        mstep = FusedMeshStep(dev, lanes=(a.lanes if a.lanes > 0 else 4))
+        mstep = FusedMeshStep(dev, lanes=1)      # round 4: the views of a step go through every stage in one launch; the library ignores `lanes`
         proj32 = cam.perspective.astype(np.float32)
         sviews = [((proj32 @ np.linalg.inv(p.astype(np.float32)).astype(np.float32)).astype(np.float32), (1.0, 1.0, 1.0)) for p in mine]
         tg_chw = [tg.permute(2, 0, 1).contiguous() for tg in targets]
@@ -291,7 +293,7 @@ def main_mesh(a, world, rank, dev, dist):
     prof_dom = c3d_hip.prof_read() if a.timed_prof == "on" else {}
     c3d_hip.prof_enable(False)
     prof = {}
-    concurrent = use_step and mstep.lanes > 1        # under view lanes a kernel's wall duration is not its own cost: the table comes from a single-lane pass
+    concurrent = False      # (rounds 2-3 ran the views on concurrent lanes and needed a separate single-lane pass for per-kernel durations)
     if a.timed_prof == "on":
         if concurrent:
             keep_step, mstep = mstep, FusedMeshStep(dev, lanes=1)
@@ -316,14 +318,15 @@ def main_mesh(a, world, rank, dev, dist):
            "mesh_antialias": (16 + 4 * 2 + 4 * 2) * P,
            "mesh_rasterize_bwd": 32 * P + 16 * V, "mesh_interpolate_bwd": (16 + 24 + 16) * P + 24 * V, "mesh_texture_bwd": (8 + 12 + 8) * P + 12 * 1024 * 1024,
            "mesh_antialias_bwd": (16 + 16 + 16) * P + 16 * V}
-    kern = {k: {"avg_ms": round(ms / n, 4), "launches": n, "ms_per_view": round(ms / (a.steps * a.views_per_gpu), 4)} for k, (ms, n) in prof.items()}
+    vpl = min(a.views_per_gpu, 16) if use_step else 1      # views per launch
+    kern = {k: {"avg_ms": round(ms / n, 4), "launches": n, "ms_per_view": round(ms / (a.steps * a.views_per_gpu), 4), "views_per_launch": vpl} for k, (ms, n) in prof.items()}
     dom = max(prof, key=lambda k: prof[k][0]) if prof else None
     roof = None
     if dom:
         per_view_ms = prof[dom][0] / (a.steps * a.views_per_gpu)
         ach = alg.get(dom, 0) / (per_view_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
-                "traffic": None, "avg_ms": round(per_view_ms, 4), "alg_bytes_per_launch": int(alg.get(dom, 0)), "note": "per view (a view issues several launches of this group)"}
+                "traffic": None, "avg_ms": round(per_view_ms, 4), "alg_bytes_per_launch": int(alg.get(dom, 0)), "note": "per view: the group's time in the timed region / views (a launch covers %d views; the group is several kernels)" % vpl}
         if concurrent:
             roof["measured"] = "single-lane pass after the timed region (kernels run alone); timed region used %d view lanes" % mstep.lanes
             if prof_dom.get(dom, (0, 0))[1]:
@@ -350,7 +353,7 @@ def main_mesh(a, world, rank, dev, dist):
                           "unit": "Mpixels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                           "config": {"workload": "DiffRastMesh fwd+bwd, %d-triangle displaced sphere, 1024^2 albedo, 1024x1024, %d views/GPU/step" % (T, a.views_per_gpu),
-                                     "render_path": ("step: c3d_mesh_train_views, %d view lanes" % mstep.lanes) if use_step else "fused: one autograd call per view",
+                                     "render_path": ("step: c3d_mesh_train_views, %d views per launch" % vpl) if use_step else "fused: one autograd call per view",
                                      "parallelism": "view-parallel dp%d" % world, "host_enqueue_ms_per_step": round(t_enq / a.steps * 1e3, 3)},
                           "roofline": roof, "roofline_chain": chain, "cpu_baseline": cpu, "kernels": kern, "code_digest": code_digest()}))
     if world > 1:
