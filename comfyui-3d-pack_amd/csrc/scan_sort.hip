@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_lb(const uint32_t* __rest
 #pragma unroll
             for (int i = 0; i < 4; i++) if (b + i < n) out[b + i] = o[i];
         }
-        if (tail.einfo) {   // epilogue of the record-base scan: {0, tile rect, record base} per element (what k_emit and the backward pass gather)
+        if (tail.einfo) {   // epilogue of the record-base scan: {0, tile rect, record base} per element (what the backward compositing gathers)
             if (b + 3 < n) {
                 const uint4 r01 = *reinterpret_cast<const uint4*>(tail.rect + b), r23 = *reinterpret_cast<const uint4*>(tail.rect + b + 2);
                 if (v[h][0]) tail.einfo[b] = make_uint4(0u, r01.x, r01.y, e[0]);
