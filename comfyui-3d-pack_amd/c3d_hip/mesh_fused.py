@@ -76,7 +76,7 @@ class _RenderView(torch.autograd.Function):
         V, T, Vt = int(v.shape[0]), int(f.shape[0]), int(vt.shape[0])
         Ht, Wt = int(raw_albedo.shape[0]), int(raw_albedo.shape[1])
         d = MeshView(V, T, Vt, int(H), int(W), Ht, Wt, (C.c_float * 16)(*[float(x) for x in clip_from_world.reshape(-1)]), (C.c_float * 3)(*[float(x) for x in bg]))
-        state = torch.empty((lib.c3d_mesh_view_state_bytes(V, H, W),), dtype=torch.uint8, device=dev)
+        state = torch.empty((lib.c3d_mesh_view_state_bytes(V, T, H, W),), dtype=torch.uint8, device=dev)
         image = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
         alpha = torch.empty((H, W, 1), dtype=torch.float32, device=dev)
         scratch = glctx.scratch(lib.c3d_mesh_raster_scratch_bytes(1, H, W, T), dev)

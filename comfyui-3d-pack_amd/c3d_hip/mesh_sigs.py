@@ -40,7 +40,7 @@ SIGNATURES = {
     "c3d_mesh_antialias_scratch_bytes": (sz, [i32]),
     "c3d_mesh_antialias_build_topology": (C.c_int, [vp, i32, vp, vp]),
     "c3d_mesh_antialias_fwd": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
-    "c3d_mesh_view_state_bytes": (sz, [i32, i32, i32]),
+    "c3d_mesh_view_state_bytes": (sz, [i32, i32, i32, i32]),
     "c3d_mesh_view_bwd_scratch_bytes": (sz, [i32, i32, i32, i32, i32, i32]),
     "c3d_mesh_view_fwd": (C.c_int, [C.POINTER(MeshView), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "c3d_mesh_view_bwd": (C.c_int, [C.POINTER(MeshView), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),

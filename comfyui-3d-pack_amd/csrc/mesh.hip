@@ -329,6 +329,13 @@ __device__ __forceinline__ bool aa_pair_of(int j, int px, int py, int W, size_t 
     if (j == 2) { first = pid - 1; return px > 0; }
     first = pid - (size_t)W; return py > 0;
 }
+// Bit t of view b's row: some pixel of the view carries triangle t's id (set by the fused view's pixel pass).  With ~2-pixel triangles more than half of a closed
+// mesh's triangles own no pixel (back faces, hidden, off screen): their gradient record is zero, and the backward pass neither computes nor stores nor gathers it.
+// bits == NULL (the stand-alone op, which has no forward state): every triangle counts as an owner.
+struct TriOwned {
+    const uint32_t* bits; int words;      // words per view
+    __device__ __forceinline__ bool has(int b, int t) const { return !bits || ((bits[(size_t)b * words + (t >> 5)] >> (t & 31)) & 1u); }
+};
 // what the position gradient of the antialias needs besides the pair records: the colours that were blended and the gradients of the two antialias outputs
 struct AaBwdIn { const uint8_t* hit; const uint8_t* pflag; const float* pair_alpha; const float* albedo0; const float* dy3; const float* dy1; };      // pflag: k_view_shade_fwd_g
 // position gradient of the pairs whose pixel a is `pid` (owned by the triangle with corners p0, p1, p2) -- the algebra of k_aa_bwd (the standalone antialias backward), accumulated per corner
@@ -374,10 +381,11 @@ __device__ __forceinline__ void aa_bwd_pixel(const AaBwdIn& aa, const float4* __
 template <bool DB>
 __global__ void __launch_bounds__(256) k_ras_bwd_tri(const float4* __restrict__ pos, const int3* __restrict__ tri, const float4* __restrict__ rast,
                                                       const float4* __restrict__ dy, const float4* __restrict__ ddb, int B, int V, int T, int H, int W,
-                                                      float4* __restrict__ rec, uint32_t* __restrict__ big_queue, uint32_t* __restrict__ big_count, AaBwdIn aa) {
+                                                      float4* __restrict__ rec, uint32_t* __restrict__ big_queue, uint32_t* __restrict__ big_count, AaBwdIn aa, TriOwned own) {
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (long long)B * T) return;
     const int b = (int)(gid / T), t = (int)(gid % T);
+    if (!own.has(b, t)) return;      // no pixel carries this triangle's id: its record is all zero, it is neither written here nor read by the vertex gather
     float4* out = rec + (size_t)gid * 3;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const int3 vi = tri[t];
@@ -455,7 +463,7 @@ __global__ void __launch_bounds__(256) k_ras_bwd_big(const float4* __restrict__ 
 // kernel's duration (0.14 ms for two pole vertices).
 #define VG_HEAVY 32
 __global__ void __launch_bounds__(256) k_vertex_gather4(const float4* __restrict__ rec, const uint32_t* __restrict__ start, const uint32_t* __restrict__ corner,
-                                                         int B, int V, int T, float4* __restrict__ out, uint32_t* __restrict__ heavy_queue, uint32_t* __restrict__ heavy_count) {
+                                                         int B, int V, int T, float4* __restrict__ out, uint32_t* __restrict__ heavy_queue, uint32_t* __restrict__ heavy_count, TriOwned own) {
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (long long)B * V) return;
     const int b = (int)(gid / V), v = (int)(gid % V);
@@ -463,16 +471,24 @@ __global__ void __launch_bounds__(256) k_vertex_gather4(const float4* __restrict
     if (i1 - i0 > VG_HEAVY) { heavy_queue[atomicAdd(heavy_count, 1u)] = (uint32_t)gid; return; }
     const float4* rb = rec + (size_t)b * T * 3;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (uint32_t i = i0; i < i1; i++) {
-        const float4 r = rb[corner[i]];
-        a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w;
+    // eight corners at a time, three rounds of independent loads (corner ids, owner bits, records) instead of a chain of dependent pairs per corner; summed in list order
+    for (uint32_t i = i0; i < i1; i += 8) {
+        uint32_t c[8]; bool on[8]; float4 r[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) c[k] = i + k < i1 ? corner[i + k] : 0xFFFFFFFFu;
+#pragma unroll
+        for (int k = 0; k < 8; k++) on[k] = c[k] != 0xFFFFFFFFu && own.has(b, (int)(c[k] / 3u));
+#pragma unroll
+        for (int k = 0; k < 8; k++) r[k] = on[k] ? rb[c[k]] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 8; k++) { a.x += r[k].x; a.y += r[k].y; a.z += r[k].z; a.w += r[k].w; }
     }
     out[gid] = a;
 }
 // one wave per queued vertex: lane l takes corners l, l + 64, ... (fixed assignment), then a fixed-shape wave reduction -> still deterministic
 __global__ void __launch_bounds__(256) k_vertex_gather4_heavy(const float4* __restrict__ rec, const uint32_t* __restrict__ start, const uint32_t* __restrict__ corner,
                                                                int V, int T, float4* __restrict__ out, const uint32_t* __restrict__ heavy_queue,
-                                                               const uint32_t* __restrict__ heavy_count) {
+                                                               const uint32_t* __restrict__ heavy_count, TriOwned own) {
     const uint32_t n = *heavy_count;
     const int lane = threadIdx.x & 63;
     for (uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6); q < n; q += gridDim.x * 4) {
@@ -481,7 +497,9 @@ __global__ void __launch_bounds__(256) k_vertex_gather4_heavy(const float4* __re
         const float4* rb = rec + (size_t)b * T * 3;
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
         for (uint32_t i = start[v] + lane, e = start[v + 1]; i < e; i += 64) {
-            const float4 r = rb[corner[i]];
+            const uint32_t c = corner[i];
+            if (!own.has(b, (int)(c / 3u))) continue;
+            const float4 r = rb[c];
             a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w;
         }
         a.x = c3d_wave_sum(a.x); a.y = c3d_wave_sum(a.y); a.z = c3d_wave_sum(a.z); a.w = c3d_wave_sum(a.w);
@@ -1313,14 +1331,14 @@ size_t c3d_mesh_rasterize_bwd_scratch_bytes(int32_t B, int32_t T) {
     return c3d_align(sizeof(float4) * 3 * bt) + c3d_align(4 * bt) + c3d_align(64);
 }
 static int mesh_rasterize_bwd_gather(const float* pos, const int32_t* tri, const float* rast, const float* dy, const float* ddb, int32_t B, int32_t V, int32_t T, int32_t H,
-                                     int32_t W, const void* topology, void* scratch, float* dpos, c3d_stream_t stream, AaBwdIn aa);
+                                     int32_t W, const void* topology, void* scratch, float* dpos, c3d_stream_t stream, AaBwdIn aa, TriOwned own);
 int c3d_mesh_rasterize_bwd_gather(const float* pos, const int32_t* tri, const float* rast, const float* dy, const float* ddb, int32_t B, int32_t V, int32_t T, int32_t H,
                                   int32_t W, const void* topology, void* scratch, float* dpos, c3d_stream_t stream) {
-    return mesh_rasterize_bwd_gather(pos, tri, rast, dy, ddb, B, V, T, H, W, topology, scratch, dpos, stream, AaBwdIn{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr});
+    return mesh_rasterize_bwd_gather(pos, tri, rast, dy, ddb, B, V, T, H, W, topology, scratch, dpos, stream, AaBwdIn{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, TriOwned{nullptr, 0});
 }
-// aa.hit != NULL (fused view, B = 1): the antialias pass's position gradient is accumulated into the same per-corner records
+// aa.hit != NULL (fused views): the antialias pass's position gradient is accumulated into the same per-corner records; own: see TriOwned
 static int mesh_rasterize_bwd_gather(const float* pos, const int32_t* tri, const float* rast, const float* dy, const float* ddb, int32_t B, int32_t V, int32_t T, int32_t H,
-                                     int32_t W, const void* topology, void* scratch, float* dpos, c3d_stream_t stream, AaBwdIn aa) {
+                                     int32_t W, const void* topology, void* scratch, float* dpos, c3d_stream_t stream, AaBwdIn aa, TriOwned own) {
     hipStream_t s = (hipStream_t)stream;
     if ((long long)B * V == 0) return 0;
     MESH_REQUIRE(dpos, "NULL dpos");
@@ -1336,7 +1354,7 @@ static int mesh_rasterize_bwd_gather(const float* pos, const int32_t* tri, const
     C3D_CHECK(hipMemsetAsync(count, 0, 8, s));
 #define RAS_BWD_LAUNCH(DB_)                                                                                                                                          \
     hipLaunchKernelGGL((k_ras_bwd_tri<DB_>), dim3(c3d_cdiv((long long)bt, 256)), dim3(256), 0, s, (const float4*)pos, (const int3*)tri, (const float4*)rast, (const float4*)dy, \
-                       (const float4*)ddb, B, V, T, H, W, rec, queue, count, aa);                                                                                          \
+                       (const float4*)ddb, B, V, T, H, W, rec, queue, count, aa, own);                                                                                       \
     hipLaunchKernelGGL((k_ras_bwd_big<DB_>), dim3(1024), dim3(256), 0, s, (const float4*)pos, (const int3*)tri, (const float4*)rast, (const float4*)dy, (const float4*)ddb, V, T, H, W, \
                        rec, queue, count, aa)
     if (ddb) { RAS_BWD_LAUNCH(true); } else { RAS_BWD_LAUNCH(false); }
@@ -1346,8 +1364,8 @@ static int mesh_rasterize_bwd_gather(const float* pos, const int32_t* tri, const
     while ((1ll << bits) <= (long long)V) bits++;
     const int res = ((bits + 7) / 8) & 1;
     // the large-triangle queue has been consumed: its storage and the second counter word serve the heavy-vertex queue
-    hipLaunchKernelGGL(k_vertex_gather4, dim3(c3d_cdiv((long long)B * V, 256)), dim3(256), 0, s, (const float4*)rec, t.start, t.val[res], B, V, T, (float4*)dpos, queue, count + 1);
-    hipLaunchKernelGGL(k_vertex_gather4_heavy, dim3(64), dim3(256), 0, s, (const float4*)rec, t.start, t.val[res], V, T, (float4*)dpos, queue, count + 1);
+    hipLaunchKernelGGL(k_vertex_gather4, dim3(c3d_cdiv((long long)B * V, 256)), dim3(256), 0, s, (const float4*)rec, t.start, t.val[res], B, V, T, (float4*)dpos, queue, count + 1, own);
+    hipLaunchKernelGGL(k_vertex_gather4_heavy, dim3(64), dim3(256), 0, s, (const float4*)rec, t.start, t.val[res], V, T, (float4*)dpos, queue, count + 1, own);
     C3D_LAUNCH_CHECK();
     return 0;
 }
@@ -1662,8 +1680,7 @@ __global__ void __launch_bounds__(256) k_view_transform_bwd(ViewMats Ms, const f
 // across a silhouette reads it).
 __global__ void __launch_bounds__(256) k_view_pixel_fwd(const float4* __restrict__ pos, const int3* __restrict__ tri, const float2* __restrict__ vt, const int3* __restrict__ ft,
                                                          const float* __restrict__ tex, int B, int V, int H, int W, int Ht, int Wt, const unsigned long long* __restrict__ zbuf,
-                                                         float4* __restrict__ rast, float4* __restrict__ rast_db, float2* __restrict__ texc, float* __restrict__ albedo0,
-                                                         float* __restrict__ albedo_aa, float* __restrict__ cov_aa) {
+                                                         float4* __restrict__ rast, float2* __restrict__ texc, float* __restrict__ albedo0, uint32_t* __restrict__ owned, int owned_words) {
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // view * H * W + pixel: all arrays are [B, H * W, ..]
     const long long Pv = (long long)H * W;
     if (gid >= (long long)B * Pv) return;
@@ -1672,10 +1689,9 @@ __global__ void __launch_bounds__(256) k_view_pixel_fwd(const float4* __restrict
     pos += (size_t)bview * V;
     const unsigned long long key = zbuf[gid];
     float2 q = make_float2(0.f, 0.f);
-    float cov = 0.f;
+    const uint32_t left_id = __shfl_up(key == MESH_EMPTY_KEY ? 0xFFFFFFFFu : (uint32_t)(key & 0xFFFFFFFFull), 1);      // by all lanes, before the branch
     if (key == MESH_EMPTY_KEY) {
         rast[gid] = make_float4(0.f, 0.f, 0.f, 0.f);
-        rast_db[gid] = make_float4(0.f, 0.f, 0.f, 0.f);
     } else {
         const int px = (int)(lp % W), py = (int)(lp / W);
         const uint32_t t = (uint32_t)(key & 0xFFFFFFFFull);
@@ -1683,12 +1699,12 @@ __global__ void __launch_bounds__(256) k_view_pixel_fwd(const float4* __restrict
         const float xs = 2.f / W, ys = 2.f / H;
         const Frag f = mesh_shade(pos[vi.x], pos[vi.y], pos[vi.z], xs * ((float)px + 0.5f) - 1.f, ys * ((float)py + 0.5f) - 1.f, xs, ys);
         const float u = fminf(fmaxf(f.b0, 0.f), 1.f), v = fminf(fmaxf(f.b1, 0.f), 1.f), w2 = 1.f - u - v;
-        rast[gid] = make_float4(u, v, fminf(fmaxf(f.zw, -1.f), 1.f), (float)(t + 1));
-        rast_db[gid] = make_float4(f.dudx, f.dudy, f.dvdx, f.dvdy);
+        // TriOwned: one atomicOr per run of equal ids in the wave's row of pixels (neighbours mostly share the triangle)
+        if ((threadIdx.x & 63) == 0 || left_id != t) atomicOr(&owned[(size_t)bview * owned_words + (t >> 5)], 1u << (t & 31));
+        rast[gid] = make_float4(u, v, fminf(fmaxf(f.zw, -1.f), 1.f), (float)(t + 1));      // (no rast_db: the linear texture filter has no use for pixel differentials, round 4 stopped writing them)
         const int3 ti = ft[t];
         const float2 a0 = vt[ti.x], a1 = vt[ti.y], a2 = vt[ti.z];
         q = make_float2(u * a0.x + v * a1.x + w2 * a2.x, u * a0.y + v * a1.y + w2 * a2.y);
-        cov = 1.f;
     }
     texc[gid] = q;
     const float uu = q.x * Wt - 0.5f, vv = q.y * Ht - 0.5f;
@@ -1700,9 +1716,7 @@ __global__ void __launch_bounds__(256) k_view_pixel_fwd(const float4* __restrict
         const float top = t00[c] + fu * (t10[c] - t00[c]), bot = t01[c] + fu * (t11[c] - t01[c]);
         const float sg = 1.f / (1.f + __expf(-(top + fv * (bot - top))));
         albedo0[3 * gid + c] = sg;
-        if (albedo_aa) albedo_aa[3 * gid + c] = sg;
     }
-    if (cov_aa) cov_aa[gid] = cov;      // the gathering antialias (k_view_shade_fwd_g) needs no seeds
 }
 // ---- round 3: the same pass without atomics (aa_pair_load above) ----
 // silhouette analysis only: one flag byte + one blend weight per pixel pair
@@ -1937,16 +1951,18 @@ __global__ void __launch_bounds__(256) k_view_loss_shade_bwd(const float* __rest
 // one-launch-per-op variant with scattering atomics (C3D_MESH_PIXEL_FUSED=0) is gone; profiles/r03 holds the comparison.
 namespace {
 // state of B views, every array [B, ...] (B = 1: the layout c3d_hip/mesh_fused.py reads rast / v_clip from)
-struct ViewState { float* vclip; float* rast; float* rast_db; float* texc; float* albedo0; float* albedo_aa; float* cov_aa; uint8_t* hit; float* pair_alpha; uint8_t* pflag; size_t bytes; };
-void carve_view_state(char* base, int B, int V, int H, int W, ViewState& st) {
+struct ViewState { float* vclip; float* rast; float* texc; float* albedo0; float* albedo_aa; float* cov_aa; uint8_t* hit; float* pair_alpha; uint8_t* pflag; uint32_t* owned; int owned_words; size_t bytes; };
+void carve_view_state(char* base, int B, int V, int T, int H, int W, ViewState& st) {
     size_t off = 0;
     const size_t P = (size_t)B * H * W;
     auto take = [&](size_t b) { char* p = base ? base + off : nullptr; off += c3d_align(b); return (float*)p; };
-    st.vclip = take(16 * (size_t)B * (size_t)(V > 0 ? V : 1)); st.rast = take(16 * P); st.rast_db = take(16 * P); st.texc = take(8 * P);
+    st.vclip = take(16 * (size_t)B * (size_t)(V > 0 ? V : 1)); st.rast = take(16 * P); st.texc = take(8 * P);
     st.albedo0 = take(12 * P); st.albedo_aa = take(12 * P); st.cov_aa = take(4 * P);
     st.hit = (uint8_t*)take(2 * P);
     st.pair_alpha = take(8 * P);
     st.pflag = (uint8_t*)take(P);
+    st.owned_words = ((T > 0 ? T : 1) + 31) / 32;
+    st.owned = (uint32_t*)take(4 * (size_t)B * st.owned_words);      // TriOwned
     st.bytes = off;
 }
 struct ViewBwdScratch { float* dalbedo_aa; float* dcov; float* drast; float* dpos_r; void* ras; TexAcc acc; size_t bytes; };
@@ -1970,17 +1986,18 @@ int mesh_views_fwd(const c3d_mesh_view* views, int B, const float* v, const floa
     const c3d_mesh_view* d = &views[0];
     const int V = d->V, T = d->T, H = d->H, W = d->W;
     const long long P = (long long)H * W, BP = P * B;
-    ViewState st; carve_view_state((char*)state, B, V, H, W, st);
+    ViewState st; carve_view_state((char*)state, B, V, T, H, W, st);
     ViewMats Ms; ViewBgs bgs;
     for (int b = 0; b < B; b++) { for (int i = 0; i < 16; i++) Ms.v[b].m[i] = views[b].clip_from_world[i]; for (int i = 0; i < 3; i++) bgs.v[b].c[i] = views[b].bg[i]; }
     int rc;
     hipLaunchKernelGGL(k_view_transform_fwd, dim3(c3d_cdiv(V, 256), B), dim3(256), 0, s, v, v_offsets, Ms, V, (float4*)st.vclip);
     // depth | id buffer of all views (the rasterizer's kernels take a batch), then ONE pixel pass: resolve -> interpolate(uv) -> texture -> sigmoid (k_view_pixel_fwd).
     // texture(..., filter_mode='linear') ignores uv_da (diff_mesh_renderer.py:110 passes it all the same): no pixel differentials of uv are produced
-    if ((rc = mesh_rasterize_impl(st.vclip, f, B, V, T, H, W, nullptr, raster_scratch, st.rast, st.rast_db, (c3d_stream_t)s, false))) return rc;
+    C3D_CHECK(hipMemsetAsync(st.owned, 0, 4 * (size_t)B * st.owned_words, s));
+    if ((rc = mesh_rasterize_impl(st.vclip, f, B, V, T, H, W, nullptr, raster_scratch, st.rast, nullptr, (c3d_stream_t)s, false))) return rc;
     { C3dProfScope ps(C3D_P_MESH_INTERPOLATE, s);
       hipLaunchKernelGGL(k_view_pixel_fwd, dim3(c3d_cdiv(BP, 256)), dim3(256), 0, s, (const float4*)st.vclip, (const int3*)f, (const float2*)vt, (const int3*)ft, raw_albedo, B, V, H, W,
-                         d->Ht, d->Wt, (const unsigned long long*)raster_scratch, (float4*)st.rast, (float4*)st.rast_db, (float2*)st.texc, st.albedo0, (float*)nullptr, (float*)nullptr); }
+                         d->Ht, d->Wt, (const unsigned long long*)raster_scratch, (float4*)st.rast, (float2*)st.texc, st.albedo0, st.owned, st.owned_words); }
     {   // silhouette analysis per pair, then every pixel gathers its blends and shades: no atomics (k_view_shade_fwd_g)
         C3dProfScope ps(C3D_P_MESH_ANTIALIAS, s);
         hipLaunchKernelGGL(k_aa2_pairs, dim3(c3d_cdiv(BP * 2, 256)), dim3(256), 0, s, (const float4*)st.rast, (const float4*)st.vclip, (const int3*)f,
@@ -2001,7 +2018,7 @@ int mesh_views_bwd(const c3d_mesh_view* views, int B, const int32_t* f, const fl
     const c3d_mesh_view* d = &views[0];
     const int V = d->V, T = d->T, H = d->H, W = d->W;
     const long long P = (long long)H * W;
-    ViewState st; carve_view_state((char*)state, B, V, H, W, st);
+    ViewState st; carve_view_state((char*)state, B, V, T, H, W, st);
     ViewBwdScratch sc; carve_view_bwd((char*)scratch, B, V, T, H, W, step_acc ? 0 : d->Ht, step_acc ? 0 : d->Wt, sc);
     ViewMats Ms; ViewBgs bgs;
     for (int b = 0; b < B; b++) { for (int i = 0; i < 16; i++) Ms.v[b].m[i] = views[b].clip_from_world[i]; for (int i = 0; i < 3; i++) bgs.v[b].c[i] = views[b].bg[i]; }
@@ -2025,7 +2042,7 @@ int mesh_views_bwd(const c3d_mesh_view* views, int B, const int32_t* f, const fl
     }
     if (d_v) {
         const AaBwdIn aa{st.hit, st.pflag, st.pair_alpha, st.albedo0, sc.dalbedo_aa, sc.dcov};
-        if ((rc = mesh_rasterize_bwd_gather(st.vclip, f, st.rast, sc.drast, nullptr, B, V, T, H, W, vertex_topology, sc.ras, sc.dpos_r, (c3d_stream_t)s, aa))) return rc;
+        if ((rc = mesh_rasterize_bwd_gather(st.vclip, f, st.rast, sc.drast, nullptr, B, V, T, H, W, vertex_topology, sc.ras, sc.dpos_r, (c3d_stream_t)s, aa, TriOwned{st.owned, st.owned_words}))) return rc;
         hipLaunchKernelGGL(k_view_transform_bwd, dim3(c3d_cdiv(V, 256), B), dim3(256), 0, s, Ms, (const float4*)nullptr, (const float4*)sc.dpos_r, V, d_v, d_v_stride);
     }
     C3D_LAUNCH_CHECK();
@@ -2035,7 +2052,7 @@ int mesh_views_bwd(const c3d_mesh_view* views, int B, const int32_t* f, const fl
 
 extern "C" {
 
-size_t c3d_mesh_view_state_bytes(int32_t V, int32_t H, int32_t W) { ViewState st; carve_view_state(nullptr, 1, V, H, W, st); return st.bytes; }
+size_t c3d_mesh_view_state_bytes(int32_t V, int32_t T, int32_t H, int32_t W) { ViewState st; carve_view_state(nullptr, 1, V, T, H, W, st); return st.bytes; }
 size_t c3d_mesh_view_bwd_scratch_bytes(int32_t V, int32_t T, int32_t H, int32_t W, int32_t Ht, int32_t Wt) { ViewBwdScratch sc; carve_view_bwd(nullptr, 1, V, T, H, W, Ht, Wt, sc); return sc.bytes; }
 
 int c3d_mesh_view_fwd(const c3d_mesh_view* d, const float* v, const float* v_offsets, const int32_t* f, const float* vt, const int32_t* ft, const float* raw_albedo,
@@ -2111,7 +2128,7 @@ void carve_mesh_step(char* base, int V, int T, int H, int W, int Ht, int Wt, int
     auto take = [&](size_t b) { char* p = base ? base + off : nullptr; off += c3d_align(b); return p; };
     const size_t ntex = 3 * (size_t)Ht * Wt;
     w.acc.lo = (long long*)take(8 * ntex + 64); w.acc.hi = (long long*)take(8 * ntex); w.acc.bad = base ? (uint32_t*)(w.acc.lo + ntex) : nullptr;      // the integer planes ALL views of the step add their texel gradients into
-    { ViewState st; carve_view_state(nullptr, G, V, H, W, st); w.state = take(st.bytes); }
+    { ViewState st; carve_view_state(nullptr, G, V, T, H, W, st); w.state = take(st.bytes); }
     { ViewBwdScratch sc; carve_view_bwd(nullptr, G, V, T, H, W, 0, 0, sc); w.bwd = take(sc.bytes); }
     w.raster = take(c3d_mesh_raster_scratch_bytes(G, H, W, T));
     w.image = (float*)take(12 * P); w.alpha = (float*)take(4 * P); w.image_chw = (float*)take(12 * P); w.dssim = (float*)take(12 * P);

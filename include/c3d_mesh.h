@@ -139,7 +139,7 @@ int c3d_mesh_shade_bwd(const float* albedo, const float* alpha, const float* bg,
  *   a = clamp(alpha, 0, 1);  image = clamp(a * albedo + (1 - a) * bg, 0, 1)            -> image [H,W,3], alpha [H,W,1] (= a)
  * enqueued from C without returning to the host language, camera matrix and background as plain struct fields (no upload), and the two
  * antialias calls sharing one silhouette analysis per pixel pair.  Same values as the op-by-op path (tests/test_mesh_hip.py).
- *   state   : c3d_mesh_view_state_bytes(V, H, W) bytes written by _fwd and read by _bwd (v_clip, rast, rast_db, uv, albedo, ...); the caller
+ *   state   : c3d_mesh_view_state_bytes(V, T, H, W) bytes written by _fwd and read by _bwd (v_clip, rast, uv, albedo, ..., one bit per triangle: owns a pixel); the caller
  *             may read rast ([H,W,4] floats at byte offset align256(16 V)) for the depth / normal outputs the reference produces on demand
  *   aa_topology / vertex_topology : c3d_mesh_antialias_build_topology / c3d_mesh_build_vertex_topology of `f`
  *   _bwd    : dimage [H,W,3], dalpha [H,W,1] (either may be NULL) -> d_raw_albedo [Ht,Wt,3] WRITTEN IN FULL, d_v [V,3] written in full
@@ -151,7 +151,7 @@ typedef struct c3d_mesh_view {
     float clip_from_world[16];      /* row-major 4x4 */
     float bg[3];
 } c3d_mesh_view;
-size_t c3d_mesh_view_state_bytes(int32_t V, int32_t H, int32_t W);
+size_t c3d_mesh_view_state_bytes(int32_t V, int32_t T, int32_t H, int32_t W);
 size_t c3d_mesh_view_bwd_scratch_bytes(int32_t V, int32_t T, int32_t H, int32_t W, int32_t Ht, int32_t Wt);
 int c3d_mesh_view_fwd(const c3d_mesh_view* d, const float* v, const float* v_offsets, const int32_t* f, const float* vt, const int32_t* ft,
                       const float* raw_albedo, const void* aa_topology, void* raster_scratch, void* state, float* image, float* alpha,
