@@ -1798,10 +1798,30 @@ __global__ void __launch_bounds__(256) k_tex_acc_finalize(TexAcc acc, long long 
 // times the sigmoid's derivative --, the tile's taps are pre-combined in an LDS table of 64-bit words, one integer atomic per distinct (texel, channel) goes out,
 // and interpolate's backward for the texture coordinates is the epilogue (drast).
 struct ViewTexBwd { const float* G; const uint8_t* hit; const uint8_t* pflag; const float* pair_alpha; const float* sig; const float4* rast; const float2* vt; const int3* ft; float4* drast; TexAcc acc; };
+#define VTB_BITS 10
+#define VTB_SLOTS (1 << VTB_BITS)      // slots of the workgroup's texel table (24 B of sums each + 4 B of key)
+// The workgroup's 16 x 16 pixels add their texel gradients in LDS first, then flush one global 64-bit atomic per touched texel channel.  Round 4 (profiles/r04:
+// elimination runs, 8 views 1024^2): of the kernel's 0.397 ms the flush was 0.22 and the hash probing (CAS loop) 0.06.  The flush walked the table in HASH order --
+// every lane of an atomic instruction in a different 64-B line, and agent-scope atomics execute at the memory side, a line per request.  So: the texels a
+// tile touches are nearly always a small rectangle of the texture.  WINDOW mode: the workgroup reduces the bounding box of its (unwrapped) taps; if it fits the table,
+// slot = row-major position in the box (no keys, no probing) and the flush runs in texel order, three lanes per texel: neighbouring lanes, neighbouring addresses.
+// A box that does not fit (minified or scattered uv) takes the hashed route as before.  Both routes add the same integers: the planes come out bit-identical.
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = min(v, __shfl_xor(v, d, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d, 64));
+    return v;
+}
 __global__ void __launch_bounds__(256) k_view_tex_bwd(const float* __restrict__ tex, const float2* __restrict__ uv, int H, int W, int Ht, int Wt, ViewTexBwd z) {
-    __shared__ uint32_t keys[TEXT_SLOTS];
-    __shared__ unsigned long long vals[TEXT_SLOTS][3];
-    for (int i = threadIdx.x; i < TEXT_SLOTS; i += 256) { keys[i] = TEXT_EMPTY; vals[i][0] = 0ull; vals[i][1] = 0ull; vals[i][2] = 0ull; }
+    __shared__ uint32_t keys[VTB_SLOTS];
+    __shared__ unsigned long long vals[VTB_SLOTS][3];
+    __shared__ int box[4];      // min u, min v, max u, max v of the base taps (unwrapped texel coordinates) of the pixels that contribute
+    for (int i = threadIdx.x; i < VTB_SLOTS; i += 256) { keys[i] = TEXT_EMPTY; vals[i][0] = 0ull; vals[i][1] = 0ull; vals[i][2] = 0ull; }
+    if (threadIdx.x == 0) { box[0] = INT_MAX; box[1] = INT_MAX; box[2] = INT_MIN; box[3] = INT_MIN; }
     __syncthreads();
     const int px = blockIdx.x * 16 + (threadIdx.x & 15), py = blockIdx.y * 16 + (threadIdx.x >> 4);
     {   // blockIdx.z = view: the view's block of every pixel array (the texel planes are shared by all views)
@@ -1810,16 +1830,20 @@ __global__ void __launch_bounds__(256) k_view_tex_bwd(const float* __restrict__ 
         if (z.rast) z.rast += o;
         if (z.drast) z.drast += o;
     }
-    bool bad = false;
+    bool bad = false, any = false;
+    int bu = 0, bv = 0;
+    uint32_t tk[4] = {0u, 0u, 0u, 0u};
+    float tw[4] = {0.f, 0.f, 0.f, 0.f}, g[3] = {0.f, 0.f, 0.f};
     if (px < W && py < H) {
         const size_t gid = (size_t)py * W + px;
         const float2 q = uv[gid];
         const float u = q.x * Wt - 0.5f, v = q.y * Ht - 0.5f;
         const float fu0 = floorf(u), fv0 = floorf(v), fu = u - fu0, fv = v - fv0;
-        const int iu0 = wrapi((int)fu0, Wt, 0), iu1 = wrapi((int)fu0 + 1, Wt, 0), iv0 = wrapi((int)fv0, Ht, 0), iv1 = wrapi((int)fv0 + 1, Ht, 0);
-        const uint32_t tk[4] = {(uint32_t)(iv0 * Wt + iu0), (uint32_t)(iv0 * Wt + iu1), (uint32_t)(iv1 * Wt + iu0), (uint32_t)(iv1 * Wt + iu1)};
-        const float tw[4] = {(1.f - fu) * (1.f - fv), fu * (1.f - fv), (1.f - fu) * fv, fu * fv};
-        float g[3] = {z.G[3 * gid], z.G[3 * gid + 1], z.G[3 * gid + 2]};
+        bu = (int)fu0; bv = (int)fv0;
+        const int iu0 = wrapi(bu, Wt, 0), iu1 = wrapi(bu + 1, Wt, 0), iv0 = wrapi(bv, Ht, 0), iv1 = wrapi(bv + 1, Ht, 0);
+        tk[0] = (uint32_t)(iv0 * Wt + iu0); tk[1] = (uint32_t)(iv0 * Wt + iu1); tk[2] = (uint32_t)(iv1 * Wt + iu0); tk[3] = (uint32_t)(iv1 * Wt + iu1);
+        tw[0] = (1.f - fu) * (1.f - fv); tw[1] = fu * (1.f - fv); tw[2] = (1.f - fu) * fv; tw[3] = fu * fv;
+        g[0] = z.G[3 * gid]; g[1] = z.G[3 * gid + 1]; g[2] = z.G[3 * gid + 2];
         const uint32_t pf = (uint32_t)z.pflag[gid] >> 4;
 #pragma unroll
         for (int j = 0; j < 4; j++) {      // d albedo0 of this pixel: + alpha dy[dst] where it is pixel a of the pair, - alpha dy[dst] where it is pixel b
@@ -1831,7 +1855,6 @@ __global__ void __launch_bounds__(256) k_view_tex_bwd(const float* __restrict__ 
 #pragma unroll
             for (int c = 0; c < 3; c++) g[c] += sa * z.G[3 * pr.idst + c];
         }
-        bool any = false;
 #pragma unroll
         for (int c = 0; c < 3; c++) { const float sv = z.sig[3 * gid + c]; g[c] *= sv * (1.f - sv); any = any || g[c] != 0.f; }
         float gu = 0.f, gv = 0.f;
@@ -1853,34 +1876,57 @@ __global__ void __launch_bounds__(256) k_view_tex_bwd(const float* __restrict__ 
             }
             z.drast[gid] = dr;
         }
-        const bool use_hash = tex_taps_shared(tk);
-        if (any) {
+    }
+    {   // the box of the contributing pixels' base taps, reduced per wave, then four LDS atomics per wave
+        const int lo_u = wave_min_i(any ? bu : INT_MAX), lo_v = wave_min_i(any ? bv : INT_MAX), hi_u = wave_max_i(any ? bu : INT_MIN), hi_v = wave_max_i(any ? bv : INT_MIN);
+        if ((threadIdx.x & 63) == 0 && lo_u != INT_MAX) { atomicMin(&box[0], lo_u); atomicMin(&box[1], lo_v); atomicMax(&box[2], hi_u); atomicMax(&box[3], hi_v); }
+    }
+    const bool use_hash = tex_taps_shared(tk);      // (hashed route only: does a lane share taps with its neighbour at all?)
+    __syncthreads();
+    const int u0 = box[0], v0 = box[1];
+    const long long bw = (long long)box[2] + 2 - u0, bh = (long long)box[3] + 2 - v0;      // + the second tap of the last column / row
+    const bool window = u0 != INT_MAX && bw * bh <= VTB_SLOTS;
+    if (any) {
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
-                uint32_t h = (tk[t] * 2654435761u) >> 22;           // 10 bits
-                int slot = -1;
+        for (int t = 0; t < 4; t++) {
+            int slot = -1;
+            if (window) slot = (bv + (t >> 1) - v0) * (int)bw + (bu + (t & 1) - u0);
+            else {
+                uint32_t h = (tk[t] * 2654435761u) >> (32 - VTB_BITS);
                 for (int probe = 0; use_hash && probe < 32; probe++) {   // bounded: a full table falls back to the direct scatter
                     const uint32_t old = atomicCAS(&keys[h], TEXT_EMPTY, tk[t]);
                     if (old == TEXT_EMPTY || old == tk[t]) { slot = (int)h; break; }
-                    h = (h + 1) & (TEXT_SLOTS - 1);
+                    h = (h + 1) & (VTB_SLOTS - 1);
                 }
+            }
 #pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    const float w = g[c] * tw[t];
-                    if (w == 0.f) continue;
-                    long long hi, lo;
-                    tex_acc_split(w, hi, lo, bad);
-                    if (hi) atomicAdd((unsigned long long*)&z.acc.hi[(size_t)tk[t] * 3 + c], (unsigned long long)hi);
-                    if (!lo) continue;
-                    if (slot >= 0) atomicAdd(&vals[slot][c], (unsigned long long)lo);
-                    else atomicAdd((unsigned long long*)&z.acc.lo[(size_t)tk[t] * 3 + c], (unsigned long long)lo);
-                }
+            for (int c = 0; c < 3; c++) {
+                const float w = g[c] * tw[t];
+                if (w == 0.f) continue;
+                long long hi, lo;
+                tex_acc_split(w, hi, lo, bad);
+                if (hi) atomicAdd((unsigned long long*)&z.acc.hi[(size_t)tk[t] * 3 + c], (unsigned long long)hi);
+                if (!lo) continue;
+                if (slot >= 0) atomicAdd(&vals[slot][c], (unsigned long long)lo);
+                else atomicAdd((unsigned long long*)&z.acc.lo[(size_t)tk[t] * 3 + c], (unsigned long long)lo);
             }
         }
     }
     if (bad) *z.acc.bad = 1u;
     __syncthreads();
-    for (int i = threadIdx.x; i < TEXT_SLOTS; i += 256) {
+    if (window) {      // texel order, lane = (texel, channel): the atomics of one instruction fall into a few 64-B lines
+        const int n = (int)(bw * bh) * 3;
+        const unsigned long long* flat = &vals[0][0];
+        for (int e = threadIdx.x; e < n; e += 256) {
+            const unsigned long long v = flat[e];
+            if (!v) continue;
+            const int slot = e / 3, c = e - 3 * slot, ty = slot / (int)bw, tx = slot - ty * (int)bw;
+            const size_t texel = (size_t)wrapi(v0 + ty, Ht, 0) * Wt + wrapi(u0 + tx, Wt, 0);
+            atomicAdd((unsigned long long*)&z.acc.lo[texel * 3 + c], v);
+        }
+        return;
+    }
+    for (int i = threadIdx.x; i < VTB_SLOTS; i += 256) {
         const uint32_t k = keys[i];
         if (k == TEXT_EMPTY) continue;
 #pragma unroll
