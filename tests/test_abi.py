@@ -49,6 +49,18 @@ def test_no_process_wide_switches_in_the_abi():
     assert "g_exact_dscale" not in src
     hdr = open(os.path.join(ROOT, "include", "c3d_gs.h")).read()
     assert "C3D_GS_FLAG_EXACT_DSCALE" in hdr and "int32_t flags;" in hdr
+    # ... and none read from the environment: what the library computes (and which kernels it runs) must not depend on the process's environment variables.
+    # Round 3 shipped ten experiment switches read with getenv(); round 4 removed them all (compile-time macros for A/B runs, documented in profiles/).
+    import glob
+    reads = {}
+    for f in sorted(glob.glob(os.path.join(ROOT, "comfyui-3d-pack_amd", "csrc", "*"))):
+        n = sum(open(f, errors="replace").read().count(w) for w in ("getenv", "secure_getenv", "environ"))
+        if n:
+            reads[os.path.basename(f)] = n
+    assert reads == {}, reads
+    # the Python package does not change the process's environment at import either (round 3 set HIP_FORCE_DEV_KERNARG there; INTEGRATION.md now recommends it instead)
+    init = open(os.path.join(ROOT, "comfyui-3d-pack_amd", "c3d_hip", "__init__.py")).read()
+    assert "os.environ[" not in init and "environ.setdefault" not in init and "putenv" not in init
 
 
 def test_state_buffer_sizes_are_host_callable():
