@@ -119,8 +119,18 @@ __device__ __forceinline__ float wave_reduce_lds(const float* tile /* [NV][BWD_R
     const v2f q0 = p0 + p1, q1 = p2 + p3;
     const v2f r0 = q0 + q1;
     float t = r0.x + r0.y;
+#ifdef GS_BWD_NO_TRIM
     t = dpp_add<0xB1>(t);               // quad_perm [1,0,3,2]
     t = dpp_add<0x4E>(t);               // quad_perm [2,3,0,1]
+#else
+    // the two quad steps as ONE asm block (round 4): left to the compiler, the second add is split into v_mov_b32 0 + v_mov_b32_dpp + a v_add_f32 sunk into the
+    // caller's "lane writes acc" branch -- two VALU instructions more per walked pair in an issue-bound loop.  s_nop 1 = the VALU write -> DPP read wait states.
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+                 : "+v"(t));
+#endif
     return t;                           // lanes 4r .. 4r+3 hold the wave's sum of value r (r < NV)
 }
 
@@ -298,7 +308,12 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
                     // ONE select per pair (round 4; three before): an inactive lane continues with oG = 0, hence alpha = 0, 1 / (1 - alpha) = 1 exactly, T unchanged,
                     // weight 0 and moments 0 -- the same instructions for every lane, no exec-masked branch, no zero-initialised temporaries.
                     const float oGe = sel64z(am, oG);
+#ifdef GS_BWD_NO_TRIM
                     const float alpha = fminf(0.99f, oGe);
+#else
+                    float alpha;   // fminf(0.99f, oGe) without the v_max_f32 x, x the compiler puts in front of it (oGe comes out of inline asm: it cannot know the value is canonical)
+                    asm("v_min_f32_e32 %0, 0x3f7d70a4, %1" : "=v"(alpha) : "v"(oGe));
+#endif
                     const float inv = __builtin_amdgcn_rcpf(1.f - alpha);
                     const float Tn = T * inv;
                     T = Tn;
@@ -327,7 +342,13 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
                     vals[6] = m1x * dx; vals[7] = m1x * dy; vals[8] = m1y * dy;
                     if (DEPTH) vals[NV - 1] = w * dLd;
                     const float tsum = wave_reduce_lds<NV>(&red[wave][0][0], red_base, vals, lane);
+#ifdef GS_BWD_NO_TRIM
                     if ((lane & 3) == 0 && lane < 4 * NV) acc[wave][lane >> 2][j] = tsum;
+#else
+                    // every lane stores: the four lanes of a quad hold the same sum and lanes past row NV - 1 hold row NV - 1's (wave_reduce_lds), so all writers of
+                    // an address carry the same bits -- no exec save / branch / restore around one store per walked pair
+                    acc[wave][min(lane >> 2, NV - 1)][j] = tsum;
+#endif
 #endif
                 }
             }
