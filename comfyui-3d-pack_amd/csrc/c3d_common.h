@@ -25,24 +25,10 @@ void c3d_set_error(const char* fmt, ...);
 static inline size_t c3d_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 static inline int c3d_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
-// ---- view lanes (lanes.hip): library-owned HIP streams forked from / joined into the caller's stream; shared by the 3DGS and the mesh multi-view steps ----
-// A call that wants to run independent chains side by side forks up to C3D_MAX_LANES streams from the caller's stream (lane 0 IS the caller's stream) and joins
-// them back before it returns, so the call keeps stream semantics.  The pool (streams + events, per device) belongs to ONE call at a time: fork() takes the
-// pool's mutex and join() -- or the destructor, on any early return -- joins the streams and releases it.  fork and join must run on the same host thread
-// (std::mutex); two host threads driving one device take turns.  With lanes == 1 nothing is forked and nothing is locked.
+// `lanes` arguments of the multi-view entry points: the number of view GROUPS a call splits its views into (every stage of the chain is one launch per group, the
+// groups follow each other on the caller's stream).  Rounds 1-3 ran one chain per view on a pool of library-owned streams; that pool is gone (round 4): no call
+// creates streams or events of its own any more.
 #define C3D_MAX_LANES 8
-struct C3dLanes {
-    int L = 1;                              // lanes in use after fork(): min(lanes, n_chains)
-    hipStream_t s[C3D_MAX_LANES] = {};      // s[0] = the caller's stream
-    int fork(hipStream_t caller, int lanes, int n_chains);       // 0 on success
-    int join(const char* who);                                   // idempotent; 0 on success
-    ~C3dLanes() { (void)join("c3d"); }
-    C3dLanes() = default;
-    C3dLanes(const C3dLanes&) = delete;
-    C3dLanes& operator=(const C3dLanes&) = delete;
-private:
-    void* pool_ = nullptr;                  // the device's pool while this object holds its mutex
-};
 
 // ---- optional event timing (prof.hip) ----
 #define C3D_PROF_SLOTS 21
