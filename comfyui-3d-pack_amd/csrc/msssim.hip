@@ -22,6 +22,11 @@
 #define MS_IN (MS_T + 2 * MS_R)         // input columns of a tile
 #define MS_INY (MS_TY + 2 * MS_R)       // input rows
 #define MS_VO (MS_TY / 8)               // vertically adjacent outputs per lane in the vertical pass (256 lanes = 32 columns x 8 row groups)
+// workgroups per CU the filter kernels are compiled for: the prefetch registers of the next tile (round 4) bring them to ~125 VGPRs = 4 workgroups per CU (6 by LDS);
+// capped at 5 or 6 they spill 76-190 bytes per lane
+#ifndef MS_MIN_BLOCKS
+#define MS_MIN_BLOCKS 4
+#endif
 #define MS_C1 (0.01f * 0.01f)
 #define MS_C2 (0.03f * 0.03f)
 
@@ -82,10 +87,14 @@ __global__ void __launch_bounds__(256) k_ms_pool(const float* __restrict__ X, co
 }
 
 // forward of one level: derivative maps + the tile's sum of cs (levels 0-3) or ssim (last level)
+// Round 4: a workgroup walks NT horizontally adjacent tiles and issues tile t + 1's global loads (raw values into registers) BEFORE it filters tile t.  With one tile
+// per workgroup the three phases of a tile -- global loads, horizontal pass, vertical pass -- sit behind barriers and their times ADD (level 0 at 1080p, 8 views:
+// 0.62 ms for ~0.3 ms of HBM time, ~0.15 of VALU, ~0.15 of LDS; profiles/r04n_train_kernel_stats.csv): every wave of a CU waits out the same HBM round trip.
+// Same arithmetic per output, tile by tile: results are bit-identical to the one-tile form.
 template <bool LAST, bool L0>
-__global__ void __launch_bounds__(256) k_ms_fwd(const float* __restrict__ X, const float* __restrict__ Y, const float* __restrict__ mask, int clamp_y, int C,
+__global__ void __launch_bounds__(256, MS_MIN_BLOCKS) k_ms_fwd(const float* __restrict__ X, const float* __restrict__ Y, const float* __restrict__ mask, int clamp_y, int C,
                                                 MsLevel lv, MsWin win, float* __restrict__ mapA, float* __restrict__ mapB, float* __restrict__ mapC,
-                                                float* __restrict__ partial, MsTab tab) {
+                                                float* __restrict__ partial, MsTab tab, int NT) {
     // Quantities travel in pairs -- (x, y), (x^2, y^2) -- so that one v_pk_fma_f32 filters two of them (the kernel is VALU bound: 3 instructions
     // per tap and output instead of the 7 of the scalar form with its products inside the loop); xy goes alone.
     __shared__ v2f sxy[MS_INY][MS_IN + 1];
@@ -93,96 +102,118 @@ __global__ void __launch_bounds__(256) k_ms_fwd(const float* __restrict__ X, con
     __shared__ v2f h23[MS_INY][MS_T + 1];      //                       (x^2, y^2)
     __shared__ float h4[MS_INY][MS_T + 1];     //                       xy
     __shared__ float red[4];
-    const int plane = blockIdx.z, ox = blockIdx.x * MS_T, oy = blockIdx.y * MS_TY;
+    const int plane = blockIdx.z, oy = blockIdx.y * MS_TY;
+    const int t0 = blockIdx.x * NT, t1 = min(t0 + NT, lv.tx);
     const size_t HW = (size_t)lv.H * lv.W;
     if (L0) { const MsBase b = ms_rebase(tab, plane, C, HW, X, Y, mask, nullptr); X = b.x; Y = b.y; mask = b.mask; }
-    {   // all of a lane's loads are issued before the first LDS store (an un-unrolled loop waits for each load in turn)
-        constexpr int NL = (MS_INY * MS_IN + 255) / 256;
-        float xs_[NL], ys_[NL];
+    constexpr int NL = (MS_INY * MS_IN + 255) / 256;
+    float xr[NL], yr[NL], mr[NL];
+    // all of a lane's loads are issued together, raw; the level-0 transform (clamp, mask) is applied when the values move on into LDS
+    auto fetch = [&](int t) {
+        const int ox = t * MS_T;
 #pragma unroll
         for (int i = 0; i < NL; i++) {
             const int e = threadIdx.x + 256 * i;
             const int r = e / MS_IN, c = e - r * MS_IN;
             const int iy = oy + r, ix = ox + c;
-            xs_[i] = 0.f; ys_[i] = 0.f;
-            if (e < MS_INY * MS_IN && iy < lv.H && ix < lv.W) ms_load<L0>(X, Y, mask, clamp_y, C, plane, HW, (size_t)iy * lv.W + ix, xs_[i], ys_[i]);
+            xr[i] = 0.f; yr[i] = 0.f; mr[i] = 1.f;
+            if (e < MS_INY * MS_IN && iy < lv.H && ix < lv.W) {
+                const size_t off = (size_t)iy * lv.W + ix;
+                xr[i] = X[(size_t)plane * HW + off];
+                yr[i] = Y[(size_t)plane * HW + off];
+                if (L0 && mask) mr[i] = mask[(size_t)(plane / C) * HW + off];
+            }
         }
+    };
+    fetch(t0);
+    for (int t = t0; t < t1; t++) {
+        const int ox = t * MS_T;
 #pragma unroll
         for (int i = 0; i < NL; i++) {
             const int e = threadIdx.x + 256 * i;
-            if (e < MS_INY * MS_IN) { const int r = e / MS_IN, c = e - r * MS_IN; sxy[r][c] = v2f{xs_[i], ys_[i]}; }
-        }
-    }
-    __syncthreads();
-    // horizontal pass, four adjacent outputs per item: the 14 inputs they share are read once (one 8-byte LDS read each) and squared once
-    for (int e = threadIdx.x; e < MS_INY * (MS_T / 4); e += 256) {
-        const int r = e >> 3, c0 = (e & 7) * 4;
-        v2f p[14], q[14];
-        float xy[14];
-#pragma unroll
-        for (int k = 0; k < 14; k++) { p[k] = sxy[r][c0 + k]; q[k] = p[k] * p[k]; xy[k] = p[k].x * p[k].y; }
-#pragma unroll
-        for (int o = 0; o < 4; o++) {
-            v2f a01 = v2f{0.f, 0.f}, a23 = v2f{0.f, 0.f};
-            float a4 = 0.f;
-#pragma unroll
-            for (int k = 0; k < 2 * MS_R + 1; k++) {
-                const float w = win.w[k];
-                a01 = ms_fma2(w, p[o + k], a01); a23 = ms_fma2(w, q[o + k], a23); a4 = __builtin_fmaf(w, xy[o + k], a4);
+            if (e < MS_INY * MS_IN) {
+                const int r = e / MS_IN, c = e - r * MS_IN;
+                float x = xr[i], y = yr[i];
+                if (L0) {
+                    if (clamp_y) y = fminf(fmaxf(y, 0.f), 1.f);
+                    if (mask) { x *= mr[i]; y *= mr[i]; }
+                }
+                sxy[r][c] = v2f{x, y};
             }
-            h01[r][c0 + o] = a01; h23[r][c0 + o] = a23; h4[r][c0 + o] = a4;
         }
-    }
-    __syncthreads();
-    // vertical pass, MS_VO vertically adjacent outputs per lane: 10 + MS_VO rows of the intermediate per quantity
-    const int c = threadIdx.x & 31, r0 = (threadIdx.x >> 5) * MS_VO;
-    float acc[MS_VO][5];
-    {
-        v2f c01[2 * MS_R + MS_VO], c23[2 * MS_R + MS_VO];
-        float c4[2 * MS_R + MS_VO];
+        __syncthreads();                       // also: every lane is done with the previous tile's vertical pass (h01 / h23 / h4 may be overwritten)
+        if (t + 1 < t1) fetch(t + 1);          // in flight while this tile is filtered
+        // horizontal pass, four adjacent outputs per item: the 14 inputs they share are read once (one 8-byte LDS read each) and squared once
+        for (int e = threadIdx.x; e < MS_INY * (MS_T / 4); e += 256) {
+            const int r = e >> 3, c0 = (e & 7) * 4;
+            v2f p[14], q[14];
+            float xy[14];
 #pragma unroll
-        for (int k = 0; k < 2 * MS_R + MS_VO; k++) { c01[k] = h01[r0 + k][c]; c23[k] = h23[r0 + k][c]; c4[k] = h4[r0 + k][c]; }
+            for (int k = 0; k < 14; k++) { p[k] = sxy[r][c0 + k]; q[k] = p[k] * p[k]; xy[k] = p[k].x * p[k].y; }
 #pragma unroll
-        for (int o = 0; o < MS_VO; o++) {
-            v2f a01 = v2f{0.f, 0.f}, a23 = v2f{0.f, 0.f};
-            float a4 = 0.f;
+            for (int o = 0; o < 4; o++) {
+                v2f a01 = v2f{0.f, 0.f}, a23 = v2f{0.f, 0.f};
+                float a4 = 0.f;
 #pragma unroll
-            for (int k = 0; k < 2 * MS_R + 1; k++) {
-                const float w = win.w[k];
-                a01 = ms_fma2(w, c01[o + k], a01); a23 = ms_fma2(w, c23[o + k], a23); a4 = __builtin_fmaf(w, c4[o + k], a4);
+                for (int k = 0; k < 2 * MS_R + 1; k++) {
+                    const float w = win.w[k];
+                    a01 = ms_fma2(w, p[o + k], a01); a23 = ms_fma2(w, q[o + k], a23); a4 = __builtin_fmaf(w, xy[o + k], a4);
+                }
+                h01[r][c0 + o] = a01; h23[r][c0 + o] = a23; h4[r][c0 + o] = a4;
             }
-            acc[o][0] = a01.x; acc[o][1] = a01.y; acc[o][2] = a23.x; acc[o][3] = a23.y; acc[o][4] = a4;
         }
-    }
-    float local = 0.f;
+        __syncthreads();                       // also: every lane is done reading sxy (the next tile's values may move in)
+        // vertical pass, MS_VO vertically adjacent outputs per lane: 10 + MS_VO rows of the intermediate per quantity
+        const int c = threadIdx.x & 31, r0 = (threadIdx.x >> 5) * MS_VO;
+        float acc[MS_VO][5];
+        {
+            v2f c01[2 * MS_R + MS_VO], c23[2 * MS_R + MS_VO];
+            float c4[2 * MS_R + MS_VO];
 #pragma unroll
-    for (int j = 0; j < MS_VO; j++) {
-        const int r = r0 + j;
-        const float m1 = acc[j][0], m2 = acc[j][1], e11 = acc[j][2], e22 = acc[j][3], e12 = acc[j][4];
-        const int vy = oy + r, vx = ox + c;
-        if (vy < lv.Hv && vx < lv.Wv) {
-            const float s1 = e11 - m1 * m1, s2 = e22 - m2 * m2, s12 = e12 - m1 * m2;
-            const float dcs = 1.f / (s1 + s2 + MS_C2);
-            const float cs = (2.f * s12 + MS_C2) * dcs;
-            // d cs / d E[xy] = 2 / D,  d cs / d E[y^2] = -cs / D,  d cs / d mu_y = (2 cs mu_y - 2 mu_x) / D
-            float dA = (2.f * cs * m2 - 2.f * m1) * dcs, dB = -cs * dcs, dC = 2.f * dcs, val = cs;
-            if (LAST) {
-                const float dl = 1.f / (m1 * m1 + m2 * m2 + MS_C1);
-                const float l = (2.f * m1 * m2 + MS_C1) * dl;
-                dA = l * dA + cs * (2.f * m1 - 2.f * l * m2) * dl;      // ssim = l * cs
-                dB *= l; dC *= l; val = l * cs;
+            for (int k = 0; k < 2 * MS_R + MS_VO; k++) { c01[k] = h01[r0 + k][c]; c23[k] = h23[r0 + k][c]; c4[k] = h4[r0 + k][c]; }
+#pragma unroll
+            for (int o = 0; o < MS_VO; o++) {
+                v2f a01 = v2f{0.f, 0.f}, a23 = v2f{0.f, 0.f};
+                float a4 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 2 * MS_R + 1; k++) {
+                    const float w = win.w[k];
+                    a01 = ms_fma2(w, c01[o + k], a01); a23 = ms_fma2(w, c23[o + k], a23); a4 = __builtin_fmaf(w, c4[o + k], a4);
+                }
+                acc[o][0] = a01.x; acc[o][1] = a01.y; acc[o][2] = a23.x; acc[o][3] = a23.y; acc[o][4] = a4;
             }
-            const size_t o = ((size_t)plane * lv.Hv + vy) * lv.Wv + vx;
-            mapA[o] = dA; mapB[o] = dB; mapC[o] = dC;
-            local += val;
         }
-    }
-    // fixed-order block sum
+        float local = 0.f;
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) local += __shfl_xor(local, o, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local;
-    __syncthreads();
-    if (threadIdx.x == 0) partial[((size_t)plane * lv.ty + blockIdx.y) * lv.tx + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+        for (int j = 0; j < MS_VO; j++) {
+            const int r = r0 + j;
+            const float m1 = acc[j][0], m2 = acc[j][1], e11 = acc[j][2], e22 = acc[j][3], e12 = acc[j][4];
+            const int vy = oy + r, vx = ox + c;
+            if (vy < lv.Hv && vx < lv.Wv) {
+                const float s1 = e11 - m1 * m1, s2 = e22 - m2 * m2, s12 = e12 - m1 * m2;
+                const float dcs = 1.f / (s1 + s2 + MS_C2);
+                const float cs = (2.f * s12 + MS_C2) * dcs;
+                // d cs / d E[xy] = 2 / D,  d cs / d E[y^2] = -cs / D,  d cs / d mu_y = (2 cs mu_y - 2 mu_x) / D
+                float dA = (2.f * cs * m2 - 2.f * m1) * dcs, dB = -cs * dcs, dC = 2.f * dcs, val = cs;
+                if (LAST) {
+                    const float dl = 1.f / (m1 * m1 + m2 * m2 + MS_C1);
+                    const float l = (2.f * m1 * m2 + MS_C1) * dl;
+                    dA = l * dA + cs * (2.f * m1 - 2.f * l * m2) * dl;      // ssim = l * cs
+                    dB *= l; dC *= l; val = l * cs;
+                }
+                const size_t o = ((size_t)plane * lv.Hv + vy) * lv.Wv + vx;
+                mapA[o] = dA; mapB[o] = dB; mapC[o] = dC;
+                local += val;
+            }
+        }
+        // fixed-order block sum
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) local += __shfl_xor(local, o, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local;
+        __syncthreads();
+        if (threadIdx.x == 0) partial[((size_t)plane * lv.ty + blockIdx.y) * lv.tx + t] = (red[0] + red[1]) + (red[2] + red[3]);
+        // (red is rewritten two barriers further on: lane 0 has read it by then)
+    }
 }
 
 // per plane: level means (fixed-order sums of the tile partials) -> ms, and the scalar dL/d(map pixel) of every level
@@ -232,19 +263,27 @@ __global__ void k_ms_mean_images(const float* __restrict__ ms_plane, int B, int 
 }
 
 // backward of one level: gradient w.r.t. the level's y over the whole image (+ the pooled parent level's gradient)
+// Round 4: NT horizontally adjacent tiles per workgroup; tile t + 1's maps and tile t's epilogue inputs (x, y, mask, parent gradient, the old output when
+// accumulating) are requested before tile t is filtered (see k_ms_fwd).  Same arithmetic per output: bit-identical to the one-tile form.
 template <bool L0>
-__global__ void __launch_bounds__(256) k_ms_bwd(const float* __restrict__ X, const float* __restrict__ Y, const float* __restrict__ mask, int clamp_y, int C,
+__global__ void __launch_bounds__(256, MS_MIN_BLOCKS) k_ms_bwd(const float* __restrict__ X, const float* __restrict__ Y, const float* __restrict__ mask, int clamp_y, int C,
                                                 MsLevel lv, MsWin win, const float* __restrict__ mapA, const float* __restrict__ mapB, const float* __restrict__ mapC,
-                                                const float* __restrict__ g, const float* __restrict__ parent, int H2, int W2, float* __restrict__ out, int accumulate, MsTab tab) {
+                                                const float* __restrict__ g, const float* __restrict__ parent, int H2, int W2, float* __restrict__ out, int accumulate, MsTab tab, int NT) {
     __shared__ v2f smab[MS_INY][MS_IN + 1];    // maps A, B as a pair (one packed FMA filters both), C alone
     __shared__ float smc[MS_INY][MS_IN + 1];
     __shared__ v2f hab[MS_INY][MS_T + 1];
     __shared__ float hc[MS_INY][MS_T + 1];
-    const int plane = blockIdx.z, ox = blockIdx.x * MS_T, oy = blockIdx.y * MS_TY;
+    const int plane = blockIdx.z, oy = blockIdx.y * MS_TY;
+    const int ntx = (lv.W + MS_T - 1) / MS_T;
+    const int t0 = blockIdx.x * NT, t1 = min(t0 + NT, ntx);
+    const float gl = g[plane];
+    const size_t HW = (size_t)lv.H * lv.W;
+    if (L0) { const MsBase b = ms_rebase(tab, plane, C, HW, X, Y, mask, out); X = b.x; Y = b.y; mask = b.mask; out = b.out; }
+    constexpr int NL = (MS_INY * MS_IN + 255) / 256;
+    float a_[NL], b_[NL], c_[NL];
     // d in(q) = sum_k w[k] M(q - 10 + k): LDS row 0 <-> map row oy - 10
-    {   // loads first, LDS stores after (see k_ms_fwd)
-        constexpr int NL = (MS_INY * MS_IN + 255) / 256;
-        float a_[NL], b_[NL], c_[NL];
+    auto fetch = [&](int t) {
+        const int ox = t * MS_T;
 #pragma unroll
         for (int i = 0; i < NL; i++) {
             const int e = threadIdx.x + 256 * i;
@@ -256,65 +295,82 @@ __global__ void __launch_bounds__(256) k_ms_bwd(const float* __restrict__ X, con
                 a_[i] = mapA[o]; b_[i] = mapB[o]; c_[i] = mapC[o];
             }
         }
+    };
+    const int c = threadIdx.x & 31, r0 = (threadIdx.x >> 5) * MS_VO;     // this lane's outputs: column c, rows r0 .. r0 + MS_VO - 1 of every tile
+    fetch(t0);
+    for (int t = t0; t < t1; t++) {
+        const int ox = t * MS_T;
 #pragma unroll
         for (int i = 0; i < NL; i++) {
             const int e = threadIdx.x + 256 * i;
-            if (e < MS_INY * MS_IN) { const int r = e / MS_IN, c = e - r * MS_IN; smab[r][c] = v2f{a_[i], b_[i]}; smc[r][c] = c_[i]; }
+            if (e < MS_INY * MS_IN) { const int r = e / MS_IN, cc = e - r * MS_IN; smab[r][cc] = v2f{a_[i], b_[i]}; smc[r][cc] = c_[i]; }
         }
-    }
-    __syncthreads();
-    for (int e = threadIdx.x; e < MS_INY * (MS_T / 4); e += 256) {     // horizontal, four adjacent outputs per item
-        const int r = e >> 3, c0 = (e & 7) * 4;
-        v2f vab[14];
-        float vc[14];
+        __syncthreads();                       // also: every lane is done with the previous tile's vertical pass
+        if (t + 1 < t1) fetch(t + 1);
+        // this tile's epilogue inputs, requested now, used after the two filter passes
+        float ex[MS_VO], ey[MS_VO], em[MS_VO], ep[MS_VO], eo[MS_VO];
 #pragma unroll
-        for (int k = 0; k < 14; k++) { vab[k] = smab[r][c0 + k]; vc[k] = smc[r][c0 + k]; }
-#pragma unroll
-        for (int o = 0; o < 4; o++) {
-            v2f fab = v2f{0.f, 0.f};
-            float fc = 0.f;
-#pragma unroll
-            for (int k = 0; k < 2 * MS_R + 1; k++) { fab = ms_fma2(win.w[k], vab[o + k], fab); fc = __builtin_fmaf(win.w[k], vc[o + k], fc); }
-            hab[r][c0 + o] = fab; hc[r][c0 + o] = fc;
+        for (int j = 0; j < MS_VO; j++) {
+            const int qy = oy + r0 + j, qx = ox + c;
+            ex[j] = 0.f; ey[j] = 0.f; em[j] = 1.f; ep[j] = 0.f; eo[j] = 0.f;
+            if (qy < lv.H && qx < lv.W) {
+                const size_t off = (size_t)qy * lv.W + qx;
+                ex[j] = X[(size_t)plane * HW + off];
+                ey[j] = Y[(size_t)plane * HW + off];
+                if (L0 && mask) em[j] = mask[(size_t)(plane / C) * HW + off];
+                if (parent) ep[j] = parent[((size_t)plane * H2 + ((qy + (lv.H & 1)) >> 1)) * W2 + ((qx + (lv.W & 1)) >> 1)];
+                if (accumulate) eo[j] = out[(size_t)plane * HW + off];
+            }
         }
-    }
-    __syncthreads();
-    const int c = threadIdx.x & 31, r0 = (threadIdx.x >> 5) * MS_VO;     // vertical, MS_VO vertically adjacent outputs per lane
-    float acc[MS_VO][3];
-    {
-        v2f cab[2 * MS_R + MS_VO];
-        float cc[2 * MS_R + MS_VO];
+        for (int e = threadIdx.x; e < MS_INY * (MS_T / 4); e += 256) {     // horizontal, four adjacent outputs per item
+            const int r = e >> 3, c0 = (e & 7) * 4;
+            v2f vab[14];
+            float vc[14];
 #pragma unroll
-        for (int k = 0; k < 2 * MS_R + MS_VO; k++) { cab[k] = hab[r0 + k][c]; cc[k] = hc[r0 + k][c]; }
+            for (int k = 0; k < 14; k++) { vab[k] = smab[r][c0 + k]; vc[k] = smc[r][c0 + k]; }
 #pragma unroll
-        for (int o = 0; o < MS_VO; o++) {
-            v2f fab = v2f{0.f, 0.f};
-            float fc = 0.f;
+            for (int o = 0; o < 4; o++) {
+                v2f fab = v2f{0.f, 0.f};
+                float fc = 0.f;
 #pragma unroll
-            for (int k = 0; k < 2 * MS_R + 1; k++) { fab = ms_fma2(win.w[k], cab[o + k], fab); fc = __builtin_fmaf(win.w[k], cc[o + k], fc); }
-            acc[o][0] = fab.x; acc[o][1] = fab.y; acc[o][2] = fc;
+                for (int k = 0; k < 2 * MS_R + 1; k++) { fab = ms_fma2(win.w[k], vab[o + k], fab); fc = __builtin_fmaf(win.w[k], vc[o + k], fc); }
+                hab[r][c0 + o] = fab; hc[r][c0 + o] = fc;
+            }
         }
-    }
-    const float gl = g[plane];
-    const size_t HW = (size_t)lv.H * lv.W;
-    if (L0) { const MsBase b = ms_rebase(tab, plane, C, HW, X, Y, mask, out); X = b.x; Y = b.y; mask = b.mask; out = b.out; }
+        __syncthreads();                       // also: every lane is done reading smab / smc
+        float acc[MS_VO][3];                   // vertical, MS_VO vertically adjacent outputs per lane
+        {
+            v2f cab[2 * MS_R + MS_VO];
+            float cc[2 * MS_R + MS_VO];
 #pragma unroll
-    for (int j = 0; j < MS_VO; j++) {
-        const int r = r0 + j;
-        const int qy = oy + r, qx = ox + c;
-        if (qy >= lv.H || qx >= lv.W) continue;
-        const float fa = acc[j][0], fb = acc[j][1], fc = acc[j][2];
-        float x, y;
-        const size_t off = (size_t)qy * lv.W + qx;
-        ms_load<L0>(X, Y, mask, clamp_y, C, plane, HW, off, x, y);
-        float gr = gl * (fa + 2.f * y * fb + x * fc);
-        if (parent) gr += 0.25f * parent[((size_t)plane * H2 + ((qy + (lv.H & 1)) >> 1)) * W2 + ((qx + (lv.W & 1)) >> 1)];
-        if (L0) {   // chain through y_eff = clamp(y) * mask
-            if (mask) gr *= mask[(size_t)(plane / C) * HW + off];
-            if (clamp_y) { const float yr = Y[(size_t)plane * HW + off]; if (!(yr >= 0.f && yr <= 1.f)) gr = 0.f; }
+            for (int k = 0; k < 2 * MS_R + MS_VO; k++) { cab[k] = hab[r0 + k][c]; cc[k] = hc[r0 + k][c]; }
+#pragma unroll
+            for (int o = 0; o < MS_VO; o++) {
+                v2f fab = v2f{0.f, 0.f};
+                float fc = 0.f;
+#pragma unroll
+                for (int k = 0; k < 2 * MS_R + 1; k++) { fab = ms_fma2(win.w[k], cab[o + k], fab); fc = __builtin_fmaf(win.w[k], cc[o + k], fc); }
+                acc[o][0] = fab.x; acc[o][1] = fab.y; acc[o][2] = fc;
+            }
         }
-        float* o = out + (size_t)plane * HW + off;
-        *o = accumulate ? *o + gr : gr;
+#pragma unroll
+        for (int j = 0; j < MS_VO; j++) {
+            const int qy = oy + r0 + j, qx = ox + c;
+            if (qy >= lv.H || qx >= lv.W) continue;
+            const float fa = acc[j][0], fb = acc[j][1], fc = acc[j][2];
+            float x = ex[j], y = ey[j];
+            if (L0) {      // level-0 input transform: x * mask, clamp(y) * mask
+                if (clamp_y) y = fminf(fmaxf(y, 0.f), 1.f);
+                if (mask) { x *= em[j]; y *= em[j]; }
+            }
+            float gr = gl * (fa + 2.f * y * fb + x * fc);
+            if (parent) gr += 0.25f * ep[j];
+            if (L0) {   // chain through y_eff = clamp(y) * mask
+                if (mask) gr *= em[j];
+                if (clamp_y) { const float yr = ey[j]; if (!(yr >= 0.f && yr <= 1.f)) gr = 0.f; }
+            }
+            out[(size_t)plane * HW + (size_t)qy * lv.W + qx] = accumulate ? eo[j] + gr : gr;
+        }
     }
 }
 
@@ -342,6 +398,16 @@ void ms_plan(int P, int H, int W, MsPlan& pl) {
     pl.off_g = take(sizeof(float) * MS_LEVELS * (size_t)P);
     pl.off_ms = take(sizeof(float) * (size_t)P);
     pl.bytes = off;
+}
+// tiles a workgroup walks (k_ms_fwd / k_ms_bwd): four while the launch still has several workgroups per residency slot (256 CUs x 6 workgroups), else fewer
+#ifndef MS_TILES_PER_GROUP
+#define MS_TILES_PER_GROUP 4
+#endif
+int ms_tiles_per_group(int tx, int ty, int planes) {
+    const long long tiles = (long long)tx * ty * planes;
+    int nt = MS_TILES_PER_GROUP;
+    while (nt > 1 && tiles < (long long)nt * 2 * 1536) nt >>= 1;
+    return nt;
 }
 MsWin ms_window() {
     MsWin w;
@@ -416,10 +482,11 @@ static int ms_run(const float* x, const float* y, const float* mask, const MsTab
         const size_t val = (size_t)P * L.Hv * L.Wv;
         float* mA = (float*)(ws + pl.off_map[l]); float* mB = mA + val; float* mC = mB + val;
         float* part = (float*)(ws + pl.off_part[l]);
-        const dim3 grid(L.tx, L.ty, P);
-        if (l == 0)                    hipLaunchKernelGGL((k_ms_fwd<false, true>), grid, dim3(256), 0, s, X[l], Y[l], mask, clamp_y, C, L, win, mA, mB, mC, part, tab);
-        else if (l < MS_LEVELS - 1)    hipLaunchKernelGGL((k_ms_fwd<false, false>), grid, dim3(256), 0, s, X[l], Y[l], (const float*)nullptr, 0, C, L, win, mA, mB, mC, part, none);
-        else                           hipLaunchKernelGGL((k_ms_fwd<true, false>), grid, dim3(256), 0, s, X[l], Y[l], (const float*)nullptr, 0, C, L, win, mA, mB, mC, part, none);
+        const int nt = ms_tiles_per_group(L.tx, L.ty, P);
+        const dim3 grid(c3d_cdiv(L.tx, nt), L.ty, P);
+        if (l == 0)                    hipLaunchKernelGGL((k_ms_fwd<false, true>), grid, dim3(256), 0, s, X[l], Y[l], mask, clamp_y, C, L, win, mA, mB, mC, part, tab, nt);
+        else if (l < MS_LEVELS - 1)    hipLaunchKernelGGL((k_ms_fwd<false, false>), grid, dim3(256), 0, s, X[l], Y[l], (const float*)nullptr, 0, C, L, win, mA, mB, mC, part, none, nt);
+        else                           hipLaunchKernelGGL((k_ms_fwd<true, false>), grid, dim3(256), 0, s, X[l], Y[l], (const float*)nullptr, 0, C, L, win, mA, mB, mC, part, none, nt);
         fin.partial[l] = part; fin.tiles[l] = L.tx * L.ty; fin.inv_npix[l] = 1.f / ((float)L.Hv * (float)L.Wv); fin.wts[l] = wts[l];
         if (l < MS_LEVELS - 1) {
             const MsLevel& N = pl.lv[l + 1];
@@ -439,9 +506,10 @@ static int ms_run(const float* x, const float* y, const float* mask, const MsTab
         const float* mA = (const float*)(ws + pl.off_map[l]); const float* mB = mA + val; const float* mC = mB + val;
         const float* parent = l < MS_LEVELS - 1 ? (const float*)(ws + pl.off_grad[l + 1]) : nullptr;
         const int H2 = l < MS_LEVELS - 1 ? pl.lv[l + 1].H : 0, W2 = l < MS_LEVELS - 1 ? pl.lv[l + 1].W : 0;
-        const dim3 grid(c3d_cdiv(L.W, MS_T), c3d_cdiv(L.H, MS_TY), P);
-        if (l == 0) hipLaunchKernelGGL((k_ms_bwd<true>), grid, dim3(256), 0, s, X[l], Y[l], mask, clamp_y, C, L, win, mA, mB, mC, g + (size_t)l * P, parent, H2, W2, dL_dy, accumulate, tab);
-        else        hipLaunchKernelGGL((k_ms_bwd<false>), grid, dim3(256), 0, s, X[l], Y[l], (const float*)nullptr, 0, C, L, win, mA, mB, mC, g + (size_t)l * P, parent, H2, W2, (float*)(ws + pl.off_grad[l]), 0, none);
+        const int ntx = c3d_cdiv(L.W, MS_T), nty = c3d_cdiv(L.H, MS_TY), nt = ms_tiles_per_group(ntx, nty, P);
+        const dim3 grid(c3d_cdiv(ntx, nt), nty, P);
+        if (l == 0) hipLaunchKernelGGL((k_ms_bwd<true>), grid, dim3(256), 0, s, X[l], Y[l], mask, clamp_y, C, L, win, mA, mB, mC, g + (size_t)l * P, parent, H2, W2, dL_dy, accumulate, tab, nt);
+        else        hipLaunchKernelGGL((k_ms_bwd<false>), grid, dim3(256), 0, s, X[l], Y[l], (const float*)nullptr, 0, C, L, win, mA, mB, mC, g + (size_t)l * P, parent, H2, W2, (float*)(ws + pl.off_grad[l]), 0, none, nt);
     }
     C3D_LAUNCH_CHECK();
     return 0;
