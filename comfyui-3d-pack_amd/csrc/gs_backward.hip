@@ -134,6 +134,60 @@ __device__ __forceinline__ float wave_reduce_lds(const float* tile /* [NV][BWD_R
     return t;                           // lanes 4r .. 4r+3 hold the wave's sum of value r (r < NV)
 }
 
+// --- the same reduction with ONE DPP fold in front of the transposition (round 4, second half; the default) ------------------------------------------------------
+// SQ counters of the transposing kernel (profiles/r04y_sq_*): LDS pipe 81 % busy (48 LDS-array cycles per walked pair: 10 for the splat record, 18 for the nine
+// stores, 16 for the four 16-byte reads, 4 for the result) while its 49 VALU instructions per pair leave the vector pipe room -- the reduction had moved the kernel
+// from VALU-bound to LDS-bound.  Here neighbouring values are folded pairwise BEFORE they go through LDS: within every 16-lane row, lanes 0-7 take
+// a[l] + a[l + 8] of the even value and lanes 8-15 take b[l] + b[l - 8] of the odd one (two v_add_f32_dpp row_ror:8, the second writing banks 2-3 only), so five
+// registers carry nine (ten) values: 5 stores + 2 reads of 16 bytes per lane (8 columns) instead of 9 + 4: 32 LDS-array cycles per pair, +9 DPP adds - 4 packed adds.
+// Lane L owns value L >> 2 and lane-row L & 3: columns 16 r + 8 (k & 1) .. + 7 of row k >> 1.  Fixed order of additions: bit-reproducible.
+#define BWD_FOLD_ROWS 5
+template <int NV>
+__device__ __forceinline__ float wave_reduce_fold(const float* tile /* [BWD_FOLD_ROWS][BWD_RED_ROW], wave-private */, uint32_t base, float (&v)[NV], int lane) {
+    static_assert(NV == 9 || NV == 10, "nine values, ten with the depth channel");
+    // s_nop 1: the wait states between the VALU writes of the products and the first DPP read; every later DPP source was written before the block as well
+    if (NV == 10)
+        asm volatile("s_nop 1\n\t"
+                     "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t" "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n\t" "v_add_f32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_add_f32_dpp %0, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xc\n\t" "v_add_f32_dpp %1, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+                     "v_add_f32_dpp %2, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xc\n\t" "v_add_f32_dpp %3, %8, %8 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+                     "v_add_f32_dpp %4, %9, %9 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+                     "s_mov_b32 m0, %10\n\t"
+                     "s_nop 0\n\t"
+                     "ds_write_addtid_b32 %0 offset:0\n\t" "ds_write_addtid_b32 %1 offset:272\n\t" "ds_write_addtid_b32 %2 offset:544\n\t"
+                     "ds_write_addtid_b32 %3 offset:816\n\t" "ds_write_addtid_b32 %4 offset:1088"
+                     : "+v"(v[0]), "+v"(v[2]), "+v"(v[4]), "+v"(v[6]), "+v"(v[8])
+                     : "v"(v[1]), "v"(v[3]), "v"(v[5]), "v"(v[7]), "v"(v[NV - 1]), "s"(base) : "memory");
+    else
+        asm volatile("s_nop 1\n\t"
+                     "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t" "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n\t" "v_add_f32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_add_f32_dpp %0, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xc\n\t" "v_add_f32_dpp %1, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+                     "v_add_f32_dpp %2, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xc\n\t" "v_add_f32_dpp %3, %8, %8 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+                     "s_mov_b32 m0, %9\n\t"
+                     "s_nop 0\n\t"
+                     "ds_write_addtid_b32 %0 offset:0\n\t" "ds_write_addtid_b32 %1 offset:272\n\t" "ds_write_addtid_b32 %2 offset:544\n\t"
+                     "ds_write_addtid_b32 %3 offset:816\n\t" "ds_write_addtid_b32 %4 offset:1088"
+                     : "+v"(v[0]), "+v"(v[2]), "+v"(v[4]), "+v"(v[6]), "+v"(v[8])
+                     : "v"(v[1]), "v"(v[3]), "v"(v[5]), "v"(v[7]), "s"(base) : "memory");
+    const int k = min(lane >> 2, NV - 1), r = lane & 3;
+    const float4* rp = reinterpret_cast<const float4*>(tile + (k >> 1) * BWD_RED_ROW + 16 * r + 8 * (k & 1));
+    const float4 a = rp[0], b = rp[1];
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const v2f p0 = v2f{a.x, a.y} + v2f{a.z, a.w}, p1 = v2f{b.x, b.y} + v2f{b.z, b.w};
+    const v2f q0 = p0 + p1;
+    float t = q0.x + q0.y;
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+                 : "+v"(t));
+    return t;                           // lanes 4k .. 4k+3 hold the wave's sum of value k (k < NV); lanes past 4 NV - 1 repeat value NV - 1
+}
+
 // ------------------------------------------------------------------------------------------
 // A7 composite backward: same tiling and per-wave ballot-compacted splat lists as the forward pass
 // (wave w = 8x8 quadrant, one pixel per lane), splats visited back to front in rounds of BWD_ROUND (64).
@@ -184,8 +238,10 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
     __shared__ uint32_t smask[BWD_ROUND];
     constexpr int NV = DEPTH ? 10 : 9;                          // values summed per walked pair: colour 3 [, depth], m0, m1 x 2, m2 x 3
     __shared__ float acc[4][NV][BWD_ROUND + 1];                 // per wave and value: the sums of the round's splats (+1: the writers of a wave -- lanes 0, 4, 8, ... -- land in different banks)
-#ifndef GS_BWD_REDUCE_DPP
+#if defined(GS_BWD_REDUCE_LDS9)
     __shared__ __attribute__((aligned(16))) float red[4][NV][BWD_RED_ROW];   // wave_reduce_lds's transposition tile, one per wave
+#elif !defined(GS_BWD_REDUCE_DPP)
+    __shared__ __attribute__((aligned(16))) float red[4][BWD_FOLD_ROWS][BWD_RED_ROW];   // wave_reduce_fold's transposition tile, one per wave (18.4 KB per workgroup in all: eight per CU)
 #endif
     __shared__ int s_uptow[4];   // per quadrant: the deepest list position (+1) one of its pixels blended = how far its plane of the activity record is valid
     int tx, ty;
@@ -341,7 +397,11 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
                     vals[0] = w * dLp0; vals[1] = w * dLp1; vals[2] = w * dLp2; vals[3] = m0; vals[4] = m1x; vals[5] = m1y;
                     vals[6] = m1x * dx; vals[7] = m1x * dy; vals[8] = m1y * dy;
                     if (DEPTH) vals[NV - 1] = w * dLd;
+#ifdef GS_BWD_REDUCE_LDS9
                     const float tsum = wave_reduce_lds<NV>(&red[wave][0][0], red_base, vals, lane);
+#else
+                    const float tsum = wave_reduce_fold<NV>(&red[wave][0][0], red_base, vals, lane);
+#endif
 #ifdef GS_BWD_NO_TRIM
                     if ((lane & 3) == 0 && lane < 4 * NV) acc[wave][lane >> 2][j] = tsum;
 #else

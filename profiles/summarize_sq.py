@@ -13,7 +13,7 @@ lines = ["kernel,launches,avg_us," + ",".join(cols)]
 for k in sorted(tab, key=lambda k: -tab[k]["launches"] * tab[k]["avg_us"]):
     if "k_" not in k[:24]:
         continue
-    lines.append("%s,%d,%.1f," % (k, tab[k]["launches"], tab[k]["avg_us"]) + ",".join("%.4g" % tab[k].get(cn, float("nan")) for cn in cols))
+    lines.append("\"%s\",%d,%.1f," % (k, tab[k]["launches"], tab[k]["avg_us"]) + ",".join("%.4g" % tab[k].get(cn, float("nan")) for cn in cols))      # quoted: template argument lists contain commas
 print("\n".join(lines))
 if len(sys.argv) > 2:
     open(sys.argv[2], "w").write("\n".join(lines) + "\n")
