@@ -140,12 +140,21 @@ __device__ __forceinline__ float wave_reduce_lds(const float* tile /* [NV][BWD_R
 // from VALU-bound to LDS-bound.  Here neighbouring values are folded pairwise BEFORE they go through LDS: within every 16-lane row, lanes 0-7 take
 // a[l] + a[l + 8] of the even value and lanes 8-15 take b[l] + b[l - 8] of the odd one (two v_add_f32_dpp row_ror:8, the second writing banks 2-3 only), so five
 // registers carry nine (ten) values: 5 stores + 2 reads of 16 bytes per lane (8 columns) instead of 9 + 4: 32 LDS-array cycles per pair, +9 DPP adds - 4 packed adds.
-// Lane L owns value L >> 2 and lane-row L & 3: columns 16 r + 8 (k & 1) .. + 7 of row k >> 1.  Fixed order of additions: bit-reproducible.
+// Lane L owns value k = L >> 2 and lane-row r = L & 3: eight columns from bwd_fold_slot(k) + 16 r.  Fixed order of additions: bit-reproducible.
 #define BWD_FOLD_ROWS 5
+// Which (row, half) a value travels in is chosen so that the 16-byte reads are free of bank conflicts: ds_read_b128 serves lanes {0-3, 12-15, 20-27} -- values 0, 3, 5, 6 --
+// in one LDS cycle and {4-11, 16-19, 28-31} -- values 1, 2, 4, 7 -- in the next; a lane's four banks start at (row * 68 + 8 half + 16 r) mod 64, so the four values of
+// a group need four different (row * 4 + 8 half) mod 16.  With value k -> (row, half):  0 (0,0)  3 (1,0)  5 (0,1)  6 (1,1)  |  1 (2,1)  2 (3,1)  4 (2,0)  7 (3,0)  |  8 (4,0)  9 (4,1)
+// they are 0, 4, 8, 12 in both groups.  (The obvious k -> (k / 2, k % 2) costs a second cycle on 14 % of the LDS time: SQ_LDS_BANK_CONFLICT, profiles/r04s_sq_*.)
+__device__ __forceinline__ int bwd_fold_slot(int k) {      // dword offset of value k's first column inside the tile (lane-row 0)
+    const int row = (int)((0x4431021320ull >> (4 * k)) & 15ull), half = (0x266 >> k) & 1;     // rows 0,2,3,1,2,0,1,3,4,4   halves 0,1,1,0,0,1,1,0,0,1  for k = 0..9
+    return row * BWD_RED_ROW + 8 * half;
+}
 template <int NV>
 __device__ __forceinline__ float wave_reduce_fold(const float* tile /* [BWD_FOLD_ROWS][BWD_RED_ROW], wave-private */, uint32_t base, float (&v)[NV], int lane) {
     static_assert(NV == 9 || NV == 10, "nine values, ten with the depth channel");
-    // s_nop 1: the wait states between the VALU writes of the products and the first DPP read; every later DPP source was written before the block as well
+    // rows: (v0 | v5) (v3 | v6) (v4 | v1) (v7 | v2) (v8 | v9).  s_nop 1: the wait states between the VALU writes of the products and the first DPP read; every later
+    // DPP source was written before the block as well
     if (NV == 10)
         asm volatile("s_nop 1\n\t"
                      "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t" "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
@@ -158,8 +167,8 @@ __device__ __forceinline__ float wave_reduce_fold(const float* tile /* [BWD_FOLD
                      "s_nop 0\n\t"
                      "ds_write_addtid_b32 %0 offset:0\n\t" "ds_write_addtid_b32 %1 offset:272\n\t" "ds_write_addtid_b32 %2 offset:544\n\t"
                      "ds_write_addtid_b32 %3 offset:816\n\t" "ds_write_addtid_b32 %4 offset:1088"
-                     : "+v"(v[0]), "+v"(v[2]), "+v"(v[4]), "+v"(v[6]), "+v"(v[8])
-                     : "v"(v[1]), "v"(v[3]), "v"(v[5]), "v"(v[7]), "v"(v[NV - 1]), "s"(base) : "memory");
+                     : "+v"(v[0]), "+v"(v[3]), "+v"(v[4]), "+v"(v[7]), "+v"(v[8])
+                     : "v"(v[5]), "v"(v[6]), "v"(v[1]), "v"(v[2]), "v"(v[NV - 1]), "s"(base) : "memory");
     else
         asm volatile("s_nop 1\n\t"
                      "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t" "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
@@ -171,10 +180,10 @@ __device__ __forceinline__ float wave_reduce_fold(const float* tile /* [BWD_FOLD
                      "s_nop 0\n\t"
                      "ds_write_addtid_b32 %0 offset:0\n\t" "ds_write_addtid_b32 %1 offset:272\n\t" "ds_write_addtid_b32 %2 offset:544\n\t"
                      "ds_write_addtid_b32 %3 offset:816\n\t" "ds_write_addtid_b32 %4 offset:1088"
-                     : "+v"(v[0]), "+v"(v[2]), "+v"(v[4]), "+v"(v[6]), "+v"(v[8])
-                     : "v"(v[1]), "v"(v[3]), "v"(v[5]), "v"(v[7]), "s"(base) : "memory");
+                     : "+v"(v[0]), "+v"(v[3]), "+v"(v[4]), "+v"(v[7]), "+v"(v[8])
+                     : "v"(v[5]), "v"(v[6]), "v"(v[1]), "v"(v[2]), "s"(base) : "memory");
     const int k = min(lane >> 2, NV - 1), r = lane & 3;
-    const float4* rp = reinterpret_cast<const float4*>(tile + (k >> 1) * BWD_RED_ROW + 16 * r + 8 * (k & 1));
+    const float4* rp = reinterpret_cast<const float4*>(tile + bwd_fold_slot(k) + 16 * r);
     const float4 a = rp[0], b = rp[1];
     typedef float v2f __attribute__((ext_vector_type(2)));
     const v2f p0 = v2f{a.x, a.y} + v2f{a.z, a.w}, p1 = v2f{b.x, b.y} + v2f{b.z, b.w};
