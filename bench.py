@@ -744,8 +744,11 @@ def main():
                         if os.path.exists(os.path.join(ROOT, "profiles", pa_file)):
                             pa = {r_["kernel"]: r_ for r_ in csv.DictReader(open(os.path.join(ROOT, "profiles", pa_file)))}
                             if hit in pa:
-                                # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the 32 SIMDs of a shader engine; SQ_BUSY_CYCLES are the engine's cycles
-                                roof["issue"]["valu_frac"] = round(float(pa[hit]["SQ_ACTIVE_INST_VALU"]) * 4.0 / 32.0 / float(row["SQ_BUSY_CYCLES"]), 4)
+                                # SQ_ACTIVE_INST_VALU counts one unit per issued wave instruction, summed over the 32 SIMDs the counter row covers; a wave64 instruction
+                                # occupies a CDNA4 SIMD (32 lanes) for 2 cycles -- the x4 of the SIMD-16 parts' "VALUBusy" formula gives fractions above 1 here (1.58 for the
+                                # forward compositing kernel).  SQ_BUSY_CYCLES are the cycles of the launch.
+                                roof["issue"]["valu_frac"] = round(float(pa[hit]["SQ_ACTIVE_INST_VALU"]) * 2.0 / 32.0 / float(row["SQ_BUSY_CYCLES"]), 4)
+                                roof["issue"]["cycles_per_valu_instruction"] = round(float(row["SQ_BUSY_CYCLES"]) / (float(row["SQ_INSTS_VALU"]) / 32.0), 2)
                                 roof["issue"]["lds_frac"] = round(float(pa[hit]["SQ_LDS_IDX_ACTIVE"]) / 8.0 / float(row["SQ_BUSY_CYCLES"]), 4)
                                 roof["issue"]["pipe_source"] = "profiles/" + pa_file
         except Exception:

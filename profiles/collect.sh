@@ -23,7 +23,7 @@ timeout 240 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_
 python $R/profiles/summarize_sq.py $(find /tmp/sqa -name "*.db" | head -1) $OUT/${TAG}_sq_instruction_mix_lanes1.csv | head -6
 timeout 240 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES -d /tmp/sqb -o sqb -- python $R/bench.py --lanes 1 --steps 2 --warmup 1 --cpu-baseline off --timed-prof off < /dev/null > /tmp/sqb.log 2>&1
 python $R/profiles/summarize_sq.py $(find /tmp/sqb -name "*.db" | head -1) $OUT/${TAG}_sq_pipe_activity_lanes1.csv | head -6
-cp $OUT/${TAG}_pmc_traffic.json $OUT/${TAG}_mesh_pmc_traffic.json $OUT/${TAG}_sq_instruction_mix_lanes1.csv $OUT/${TAG}_sq_instruction_mix_lanes1.csv.meta.json $R/profiles/
+cp $OUT/${TAG}_pmc_traffic.json $OUT/${TAG}_mesh_pmc_traffic.json $OUT/${TAG}_sq_instruction_mix_lanes1.csv $OUT/${TAG}_sq_instruction_mix_lanes1.csv.meta.json $OUT/${TAG}_sq_pipe_activity_lanes1.csv $OUT/${TAG}_sq_pipe_activity_lanes1.csv.meta.json $R/profiles/
 # --- kernel stats (timeout 240 rocprofv3 --kernel-trace of the default command and of the mesh workload)
 rm -rf /tmp/kt /tmp/km /tmp/ktt
 timeout 240 rocprofv3 --kernel-trace -d /tmp/kt -o kt -- python $R/bench.py --steps 3 --warmup 1 --cpu-baseline off < /dev/null > /tmp/kt.log 2>&1
