@@ -345,6 +345,10 @@ __device__ __forceinline__ uint32_t rs_wait(const uint32_t* p, uint32_t x, uint3
 // 16 keys per thread: 4096 keys and 39 KB of LDS per workgroup, four workgroups per CU.  Measured and dropped: 8 keys per thread (twice the tiles: the tile sort of an
 // 8-view step 0.48 -> 0.82 ms, profiles/r04 -- a pass is bound by tiles in flight x tile lifetime, and the lifetime does not shrink with the tile); ONE 16 KB reorder
 // buffer used for the keys and then for the values (23 KB: seven workgroups per CU -- but the kernel wants ~126 VGPRs, and capped at 72-96 it spills: 0.48 -> 0.8-1.06 ms).
+// Round 4, second half, measured and dropped (profiles/r04u_*): a workgroup that KEEPS GOING -- draws the ticket of its next tile and requests that tile's keys before it ranks
+// the current one, the recipe that took a third off the MS-SSIM kernels.  Tile sort of an 8-view step 0.48 -> 2.0 ms (4.7 ms where the extra registers spill).  A ticket drawn
+// early is a tile whose aggregate is published LATE (after the workgroup's current tile, look-back wait included), and every higher ticket waits for it: the decoupled look-back
+// lives on aggregates appearing at once, in parallel; holding tickets serialises it.
 template <bool IOTA, int ITEMS>
 __global__ void __launch_bounds__(RS_THREADS, 4) k_onesweep(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                              uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
