@@ -1083,8 +1083,11 @@ __global__ void __launch_bounds__(256) k_aa_adj_build(const int3* __restrict__ t
 }
 __device__ __forceinline__ const int* aa_adjacency(const EdgeSlot* table, uint32_t mask) { return (const int*)(table + (size_t)mask + 1); }
 struct AaHit { int ax, ay, bx, by, va, vb, ek; float s, sgn; };      // ek: the silhouette edge runs from corner ek to corner (ek + 1) % 3 of pixel a's triangle
+// sil_b (optional, the fused view): per triangle of THIS view, bit k = edge k is a silhouette edge (k_aa_sil_bits below, one lane per triangle, once per view).  On a mesh
+// of ~2-pixel triangles nearly every pixel pair has two different ids and ~1 % of them straddle a silhouette: with the bits a pair whose nearer triangle has no
+// silhouette edge costs one byte gather instead of its index triple, three vertex positions and the crossing tests.  Same decisions, same bits.
 __device__ __forceinline__ bool aa_analyze(const float4* __restrict__ pb, const int3* __restrict__ tri, const EdgeSlot* __restrict__ table, uint32_t mask,
-                                           const float4* __restrict__ rast_b, int H, int W, int px, int py, int d, AaHit& hit) {
+                                           const float4* __restrict__ rast_b, int H, int W, int px, int py, int d, AaHit& hit, const uint8_t* __restrict__ sil_b = nullptr) {
     const int qx = px + (d == 0), qy = py + (d == 1);
     if (qx >= W || qy >= H) return false;
     const float4 r0 = rast_b[(size_t)py * W + px], r1 = rast_b[(size_t)qy * W + qx];
@@ -1094,6 +1097,8 @@ __device__ __forceinline__ bool aa_analyze(const float4* __restrict__ pb, const 
     if (id0 > 0 && id1 > 0) a_is_p = r0.z < r1.z;
     else a_is_p = id0 > 0;
     const int t = (a_is_p ? id0 : id1) - 1;
+    uint32_t silb = 7u;
+    if (sil_b) { silb = sil_b[t]; if (!silb) return false; }
     const int ax = a_is_p ? px : qx, ay = a_is_p ? py : qy;
     const float sgn = a_is_p ? 1.f : -1.f;
     const int3 vi3 = tri[t];
@@ -1112,6 +1117,7 @@ __device__ __forceinline__ bool aa_analyze(const float4* __restrict__ pb, const 
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const int ia = k, ib = (k + 1) % 3, io = (k + 2) % 3;
+        if (!((silb >> k) & 1u)) continue;
         const float ex = nx[ib] - nx[ia], ey = ny[ib] - ny[ia];
         // cheap geometric test first, hash lookup only for edges that cross the centre-to-centre segment
         float s;
@@ -1127,7 +1133,7 @@ __device__ __forceinline__ bool aa_analyze(const float4* __restrict__ pb, const 
             s = sgn * ((ny[ia] + te * ey) - cy) / h;
         }
         if (!(s >= 0.f && s <= 1.f)) continue;
-        const int opp = aa_adjacency(table, mask)[3 * t + k];      // = other_opposite(table, mask, vi[ia], vi[ib], t)
+        const int opp = sil_b ? -1 : aa_adjacency(table, mask)[3 * t + k];      // = other_opposite(table, mask, vi[ia], vi[ib], t); with the bits the edge is already known to be a silhouette
         if (opp == -2) continue;
         if (opp >= 0) {   // interior edge: silhouette only if both triangles lie on the same side of it
             const float4 q = pb[opp];
@@ -1142,6 +1148,45 @@ __device__ __forceinline__ bool aa_analyze(const float4* __restrict__ pb, const 
     if (!found) return false;
     hit.ax = ax; hit.ay = ay; hit.bx = a_is_p ? qx : px; hit.by = a_is_p ? qy : py; hit.s = best; hit.sgn = sgn;
     return true;
+}
+
+// silhouette bits of one view's triangles (blockIdx.y = view): the per-edge part of aa_analyze -- all three vertices in front of the camera, the neighbour across the
+// edge absent (boundary) or on the same side of it -- evaluated once per triangle instead of once per pixel pair.  The expressions are aa_analyze's, term by term.
+__global__ void __launch_bounds__(256) k_aa_sil_bits(const float4* __restrict__ pos, const int3* __restrict__ tri, const EdgeSlot* __restrict__ table, uint32_t mask, int V, int T,
+                                                      uint8_t* __restrict__ sil) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const float4* __restrict__ pb = pos + (size_t)blockIdx.y * V;
+    const int3 vi3 = tri[t];
+    const int vi[3] = {vi3.x, vi3.y, vi3.z};
+    float nx[3], ny[3];
+    bool front = true;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float4 p = pb[vi[k]];
+        front = front && (p.w > 0.f);
+        nx[k] = p.x / p.w; ny[k] = p.y / p.w;
+    }
+    uint32_t bits = 0;
+    if (front) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int ia = k, ib = (k + 1) % 3, io = (k + 2) % 3;
+            const float ex = nx[ib] - nx[ia], ey = ny[ib] - ny[ia];
+            const int opp = aa_adjacency(table, mask)[3 * t + k];
+            if (opp == -2) continue;
+            if (opp >= 0) {
+                const float4 q = pb[opp];
+                if (!(q.w > 0.f)) continue;
+                const float ox = q.x / q.w, oy = q.y / q.w;
+                const float s_this = ex * (ny[io] - ny[ia]) - ey * (nx[io] - nx[ia]);
+                const float s_other = ex * (oy - ny[ia]) - ey * (ox - nx[ia]);
+                if (!(s_this * s_other > 0.f)) continue;
+            }
+            bits |= 1u << k;
+        }
+    }
+    sil[(size_t)blockIdx.y * T + t] = (uint8_t)bits;
 }
 
 __global__ void __launch_bounds__(256) k_aa_fwd(const float* __restrict__ color, const float4* __restrict__ rast, const float4* __restrict__ pos,
@@ -1724,7 +1769,8 @@ __global__ void __launch_bounds__(256) k_view_pixel_fwd(const float4* __restrict
 // ---- round 3: the same pass without atomics (aa_pair_load above) ----
 // silhouette analysis only: one flag byte + one blend weight per pixel pair
 __global__ void __launch_bounds__(256) k_aa2_pairs(const float4* __restrict__ rast, const float4* __restrict__ pos, const int3* __restrict__ tri,
-                                                    const EdgeSlot* __restrict__ table, uint32_t mask, int B, int V, int H, int W, float* __restrict__ pair_alpha, uint8_t* __restrict__ hit) {
+                                                    const EdgeSlot* __restrict__ table, uint32_t mask, int B, int V, int H, int W, float* __restrict__ pair_alpha, uint8_t* __restrict__ hit,
+                                                    const uint8_t* __restrict__ sil, int T) {
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // view * 2 P + pair
     const long long P = (long long)H * W;
     if (gid >= (long long)B * P * 2) return;
@@ -1732,7 +1778,7 @@ __global__ void __launch_bounds__(256) k_aa2_pairs(const float4* __restrict__ ra
     const long long lg = gid - (long long)bview * 2 * P;
     const int d = (int)(lg & 1), pid = (int)(lg >> 1), px = pid % W, py = pid / W;
     AaHit h;
-    const bool found = aa_analyze(pos + (size_t)bview * V, tri, table, mask, rast + (size_t)bview * P, H, W, px, py, d, h);
+    const bool found = aa_analyze(pos + (size_t)bview * V, tri, table, mask, rast + (size_t)bview * P, H, W, px, py, d, h, sil ? sil + (size_t)bview * T : nullptr);
     hit[gid] = found ? (uint8_t)(1 | (h.sgn > 0.f ? 2 : 0) | (h.ek << 2)) : (uint8_t)0;
     if (found) pair_alpha[gid] = h.s - 0.5f;
 }
@@ -2000,7 +2046,7 @@ __global__ void __launch_bounds__(256) k_view_loss_shade_bwd(const float* __rest
 // one-launch-per-op variant with scattering atomics (C3D_MESH_PIXEL_FUSED=0) is gone; profiles/r03 holds the comparison.
 namespace {
 // state of B views, every array [B, ...] (B = 1: the layout c3d_hip/mesh_fused.py reads rast / v_clip from)
-struct ViewState { float* vclip; float* rast; float* texc; float* albedo0; float* albedo_aa; float* cov_aa; uint8_t* hit; float* pair_alpha; uint8_t* pflag; uint32_t* owned; int owned_words; size_t bytes; };
+struct ViewState { float* vclip; float* rast; float* texc; float* albedo0; float* albedo_aa; float* cov_aa; uint8_t* hit; float* pair_alpha; uint8_t* pflag; uint32_t* owned; int owned_words; uint8_t* sil; size_t bytes; };
 void carve_view_state(char* base, int B, int V, int T, int H, int W, ViewState& st) {
     size_t off = 0;
     const size_t P = (size_t)B * H * W;
@@ -2012,6 +2058,7 @@ void carve_view_state(char* base, int B, int V, int T, int H, int W, ViewState& 
     st.pflag = (uint8_t*)take(P);
     st.owned_words = ((T > 0 ? T : 1) + 31) / 32;
     st.owned = (uint32_t*)take(4 * (size_t)B * st.owned_words);      // TriOwned
+    st.sil = (uint8_t*)take((size_t)B * (size_t)(T > 0 ? T : 1));    // silhouette bits per view and triangle (k_aa_sil_bits); last: the offsets c3d_hip/mesh_fused.py reads rast / v_clip at stay
     st.bytes = off;
 }
 struct ViewBwdScratch { float* dalbedo_aa; float* dcov; float* drast; float* dpos_r; void* ras; TexAcc acc; size_t bytes; };
@@ -2049,8 +2096,14 @@ int mesh_views_fwd(const c3d_mesh_view* views, int B, const float* v, const floa
                          d->Ht, d->Wt, (const unsigned long long*)raster_scratch, (float4*)st.rast, (float2*)st.texc, st.albedo0, st.owned, st.owned_words); }
     {   // silhouette analysis per pair, then every pixel gathers its blends and shades: no atomics (k_view_shade_fwd_g)
         C3dProfScope ps(C3D_P_MESH_ANTIALIAS, s);
+#ifndef MESH_NO_SIL_BITS
+        const uint8_t* sil = st.sil;
+        hipLaunchKernelGGL(k_aa_sil_bits, dim3(c3d_cdiv(T, 256), B), dim3(256), 0, s, (const float4*)st.vclip, (const int3*)f, (const EdgeSlot*)aa_topology, edge_table_size(T) - 1, V, T, st.sil);
+#else
+        const uint8_t* sil = nullptr;
+#endif
         hipLaunchKernelGGL(k_aa2_pairs, dim3(c3d_cdiv(BP * 2, 256)), dim3(256), 0, s, (const float4*)st.rast, (const float4*)st.vclip, (const int3*)f,
-                           (const EdgeSlot*)aa_topology, edge_table_size(T) - 1, B, V, H, W, st.pair_alpha, st.hit);
+                           (const EdgeSlot*)aa_topology, edge_table_size(T) - 1, B, V, H, W, st.pair_alpha, st.hit, sil, T);
         hipLaunchKernelGGL(k_view_shade_fwd_g, dim3(c3d_cdiv(BP, 256)), dim3(256), 0, s, st.albedo0, (const float4*)st.rast, st.hit, st.pair_alpha, bgs, B, H, W,
                            st.albedo_aa, st.cov_aa, image, alpha, st.pflag);
     }
