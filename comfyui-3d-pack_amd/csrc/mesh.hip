@@ -1090,11 +1090,12 @@ __device__ __forceinline__ bool aa_analyze(const float4* __restrict__ pb, const 
                                            const float4* __restrict__ rast_b, int H, int W, int px, int py, int d, AaHit& hit, const uint8_t* __restrict__ sil_b = nullptr) {
     const int qx = px + (d == 0), qy = py + (d == 1);
     if (qx >= W || qy >= H) return false;
-    const float4 r0 = rast_b[(size_t)py * W + px], r1 = rast_b[(size_t)qy * W + qx];
-    const int id0 = (int)r0.w, id1 = (int)r1.w;
+    // only (z/w, id) of the two pixels: the upper half of each 16-byte rast entry
+    const float2 r0 = reinterpret_cast<const float2*>(rast_b + ((size_t)py * W + px))[1], r1 = reinterpret_cast<const float2*>(rast_b + ((size_t)qy * W + qx))[1];
+    const int id0 = (int)r0.y, id1 = (int)r1.y;
     if (id0 == id1) return false;
     bool a_is_p;
-    if (id0 > 0 && id1 > 0) a_is_p = r0.z < r1.z;
+    if (id0 > 0 && id1 > 0) a_is_p = r0.x < r1.x;
     else a_is_p = id0 > 0;
     const int t = (a_is_p ? id0 : id1) - 1;
     uint32_t silb = 7u;
