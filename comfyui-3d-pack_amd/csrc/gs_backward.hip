@@ -4,137 +4,21 @@
 #include "gs_internal.h"
 #include "gs_math.h"
 
-// --- wave64 reductions -------------------------------------------------------------------------------
-// Four per-lane values are summed across the 64 lanes for the price of ~2.5 VALU ops per value:
-// v_permlane32_swap / v_permlane16_swap (gfx950) fold two registers into one while halving the lane span,
-// then four DPP adds finish inside each 16-lane row.  Result register: every lane of row 0 holds sum(a),
-// row 1 sum(c), row 2 sum(b), row 3 sum(d).   (The swaps are issued as inline asm: hipcc 7.2's builtins
-// __builtin_amdgcn_permlane{16,32}_swap return the first result in both elements.)
-template <int CTRL>
-__device__ __forceinline__ float dpp_add(float v) {
-    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
-}
-__device__ __forceinline__ void swap32(float& a, float& b) {   // a[32..63] <-> b[0..31]
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));   // s_nop: VALU write -> permlane read hazard
-}
-__device__ __forceinline__ void swap16(float& a, float& b) {   // rows 1,3 of a <-> rows 0,2 of b
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-}
-__device__ __forceinline__ float wave_reduce4(float a, float b, float c, float d) {
-    swap32(a, b); float p = a + b;      // lanes 0-31: a folded to 32 partials | lanes 32-63: b
-    swap32(c, d); float q = c + d;      // c | d
-    swap16(p, q); float t = p + q;      // rows: a, c, b, d  (16 partials each)
-    t = dpp_add<0xB1>(t);               // quad_perm [1,0,3,2]
-    t = dpp_add<0x4E>(t);               // quad_perm [2,3,0,1]
-    t = dpp_add<0x141>(t);              // row_half_mirror
-    t = dpp_add<0x140>(t);              // row_mirror
-    return t;
-}
-// Ten values at once (the backward pass's per-splat sums): the permlane swaps of the three groups are issued back to back so that
-// the VALU-write -> permlane-read wait state is paid once per level instead of once per swap.
-// t0 rows: v0, v2, v1, v3   t1 rows: v4, v6, v5, v7   t2 rows: v8, 0, v9, 0
-__device__ __forceinline__ void wave_reduce10(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7, float v8, float v9,
-                                              float& t0, float& t1, float& t2) {
-    // One asm block: the kernel is bound by instruction issue, and split into C++-level pieces this reduction carried seven s_nop (four of
-    // ours, three from the compiler's hazard recogniser around the blocks).  Inside one block every producer is >= 2 instructions ahead of its
-    // consumer (VALU write -> permlane / DPP read needs 2 wait states), so a single s_nop for the freshly multiplied inputs remains:
-    //   level 32: five swaps, then the five folds (the first fold reads what the first swap wrote four instructions earlier);
-    //   level 16: three swaps on (v0,v2) (v4,v6) (v8,v9 = 0), then three folds -> v0, v4, v8;
-    //   rows    : the three DPP butterfly chains interleaved.
-    asm volatile("s_nop 1\n\t"
-                 "v_permlane32_swap_b32 %0, %1\n\t"
-                 "v_permlane32_swap_b32 %2, %3\n\t"
-                 "v_permlane32_swap_b32 %4, %5\n\t"
-                 "v_permlane32_swap_b32 %6, %7\n\t"
-                 "v_permlane32_swap_b32 %8, %9\n\t"
-                 "v_add_f32 %0, %0, %1\n\t"
-                 "v_add_f32 %2, %2, %3\n\t"
-                 "v_add_f32 %4, %4, %5\n\t"
-                 "v_add_f32 %6, %6, %7\n\t"
-                 "v_add_f32 %8, %8, %9\n\t"
-                 "v_mov_b32 %9, 0\n\t"
-                 "v_permlane16_swap_b32 %0, %2\n\t"
-                 "v_permlane16_swap_b32 %4, %6\n\t"
-                 "v_permlane16_swap_b32 %8, %9\n\t"
-                 "v_add_f32 %0, %0, %2\n\t"
-                 "v_add_f32 %4, %4, %6\n\t"
-                 "v_add_f32 %8, %8, %9\n\t"
-                 "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                 "v_add_f32_dpp %4, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                 "v_add_f32_dpp %8, %8, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                 "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                 "v_add_f32_dpp %4, %4, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                 "v_add_f32_dpp %8, %8, %8 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                 "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-                 "v_add_f32_dpp %4, %4, %4 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-                 "v_add_f32_dpp %8, %8, %8 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-                 "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
-                 "v_add_f32_dpp %4, %4, %4 row_mirror row_mask:0xf bank_mask:0xf\n\t"
-                 "v_add_f32_dpp %8, %8, %8 row_mirror row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 1"
-                 : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7), "+v"(v8), "+v"(v9));
-    t0 = v0; t1 = v4; t2 = v8;
-}
-
-// --- wave64 reduction through LDS (round 4, the default) ----------------------------------------------------------------------------------------
-// The DPP / permlane reduction above costs ~144 VALU cycles per walked (wave, splat) pair -- more than the chain rule that produces the ten values
-// (profiles/r03z_sq_*).  Here the ten per-lane values are TRANSPOSED through a wave-private LDS tile instead of being folded across lanes:
-//   * every lane stores value k into row k of the tile, at column = its lane: ds_write_addtid_b32 (address = M0 + offset + 4 * lane: no address VGPR, 2 issue
-//     cycles per store against 4 for ds_write_b32); rows are padded to 68 dwords so that the reads below are conflict-free;
-//   * lane L then owns quarter (L & 3) of row (L >> 2): four ds_read_b128 = 16 columns, 15 adds, and two quad-permute DPP adds join the four quarters.
-//     Rows NV..15 do not exist: those lanes re-read row NV - 1 and are ignored.
-// ~52 VALU cycles + 34 LDS-array cycles per pair.  The order of the additions is fixed: results are bit-reproducible (and differ in the last bits from
-// the DPP tree's).  LDS operations of one wave execute in order, so the reads see this splat's stores and the next splat's stores come after them.
+// --- wave64 reduction of the backward pass's per-pair sums ------------------------------------------------------------------------------------------
+// Rounds 1-3 folded the values across lanes with v_permlane32/16_swap + DPP butterflies (69 VALU instructions per walked pair, 144 cycles of them the reduction);
+// round 4 first transposed all nine values through a wave-private LDS tile (9 ds_write_addtid_b32 + 4 ds_read_b128 per lane: 49 VALU / 17 LDS instructions per pair)
+// -- which the SQ counters showed LDS-bound (LDS pipe 81 % busy, profiles/r04y_sq_*) -- and then put one DPP fold in front of the transposition (below).  The two
+// earlier forms are gone from the source; their measurements are profiles/r03z_*, r04l_*, r04q_* (same-box A/B of the last two).
 #define BWD_RED_ROW 68      // dwords per tile row: 64 lanes + 4 (16 lanes of a ds_read_b128 group then hit 16 different four-bank groups)
 __device__ __forceinline__ uint32_t lds_scalar_address(const void* p) {   // LDS byte address (low half of the generic address) as a scalar, for M0
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)p);
 }
 // base = lds_scalar_address(tile), taken once per kernel.  M0 is not in the clobber list: the compiler reserves it and loads it itself in front of every
-// instruction of its own that reads it.  The s_nop is the wait state the ISA demands between an SALU write of M0 and an LDS "add-TID" instruction (the
-// compiler's hazard recogniser does not look inside inline asm; without it the first store of a wave goes to whatever M0 held before).
-template <int NV>
-__device__ __forceinline__ float wave_reduce_lds(const float* tile /* [NV][BWD_RED_ROW], wave-private */, uint32_t base, const float (&v)[NV], int lane) {
-    static_assert(NV == 9 || NV == 10, "nine values, ten with the depth channel");
-    if (NV == 10)
-        asm volatile("s_mov_b32 m0, %10\n\t"
-                     "s_nop 0\n\t"
-                     "ds_write_addtid_b32 %0 offset:0\n\t" "ds_write_addtid_b32 %1 offset:272\n\t" "ds_write_addtid_b32 %2 offset:544\n\t"
-                     "ds_write_addtid_b32 %3 offset:816\n\t" "ds_write_addtid_b32 %4 offset:1088\n\t" "ds_write_addtid_b32 %5 offset:1360\n\t"
-                     "ds_write_addtid_b32 %6 offset:1632\n\t" "ds_write_addtid_b32 %7 offset:1904\n\t" "ds_write_addtid_b32 %8 offset:2176\n\t"
-                     "ds_write_addtid_b32 %9 offset:2448"
-                     :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]), "v"(v[NV - 1]), "s"(base) : "memory");
-    else
-        asm volatile("s_mov_b32 m0, %9\n\t"
-                     "s_nop 0\n\t"
-                     "ds_write_addtid_b32 %0 offset:0\n\t" "ds_write_addtid_b32 %1 offset:272\n\t" "ds_write_addtid_b32 %2 offset:544\n\t"
-                     "ds_write_addtid_b32 %3 offset:816\n\t" "ds_write_addtid_b32 %4 offset:1088\n\t" "ds_write_addtid_b32 %5 offset:1360\n\t"
-                     "ds_write_addtid_b32 %6 offset:1632\n\t" "ds_write_addtid_b32 %7 offset:1904\n\t" "ds_write_addtid_b32 %8 offset:2176"
-                     :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]), "s"(base) : "memory");
-    const int row = min(lane >> 2, NV - 1), quarter = lane & 3;
-    const float4* rp = reinterpret_cast<const float4*>(tile + row * BWD_RED_ROW + quarter * 16);
-    const float4 a = rp[0], b = rp[1], c = rp[2], d = rp[3];
-    // 16 -> 1 with packed adds (v_pk_add_f32: two sums per instruction at ~1.6x the issue cost of one): 7 packed + 1 plain instead of 15 plain
-    typedef float v2f __attribute__((ext_vector_type(2)));
-    const v2f p0 = v2f{a.x, a.y} + v2f{a.z, a.w}, p1 = v2f{b.x, b.y} + v2f{b.z, b.w}, p2 = v2f{c.x, c.y} + v2f{c.z, c.w}, p3 = v2f{d.x, d.y} + v2f{d.z, d.w};
-    const v2f q0 = p0 + p1, q1 = p2 + p3;
-    const v2f r0 = q0 + q1;
-    float t = r0.x + r0.y;
-#ifdef GS_BWD_NO_TRIM
-    t = dpp_add<0xB1>(t);               // quad_perm [1,0,3,2]
-    t = dpp_add<0x4E>(t);               // quad_perm [2,3,0,1]
-#else
-    // the two quad steps as ONE asm block (round 4): left to the compiler, the second add is split into v_mov_b32 0 + v_mov_b32_dpp + a v_add_f32 sunk into the
-    // caller's "lane writes acc" branch -- two VALU instructions more per walked pair in an issue-bound loop.  s_nop 1 = the VALU write -> DPP read wait states.
-    asm volatile("s_nop 1\n\t"
-                 "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 1\n\t"
-                 "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
-                 : "+v"(t));
-#endif
-    return t;                           // lanes 4r .. 4r+3 hold the wave's sum of value r (r < NV)
-}
-
-// --- the same reduction with ONE DPP fold in front of the transposition (round 4, second half; the default) ------------------------------------------------------
+// instruction of its own that reads it.  The s_nop 0 inside the block is the wait state the ISA demands between an SALU write of M0 and an LDS "add-TID" instruction
+// (the compiler's hazard recogniser does not look inside inline asm; without it the first store of a wave goes to whatever M0 held before).  ds_write_addtid_b32:
+// address = M0 + offset + 4 * lane -- no address VGPR, 2 LDS cycles per store against 4 for ds_write_b32.  LDS operations of one wave execute in order, so the reads
+// see this pair's stores and the next pair's stores come after them.
+// --- ONE DPP fold, then the transposition ---------------------------------------------------------------------------------------------------------------
 // SQ counters of the transposing kernel (profiles/r04y_sq_*): LDS pipe 81 % busy (48 LDS-array cycles per walked pair: 10 for the splat record, 18 for the nine
 // stores, 16 for the four 16-byte reads, 4 for the result) while its 49 VALU instructions per pair leave the vector pipe room -- the reduction had moved the kernel
 // from VALU-bound to LDS-bound.  Here neighbouring values are folded pairwise BEFORE they go through LDS: within every 16-lane row, lanes 0-7 take
@@ -198,17 +82,14 @@ __device__ __forceinline__ float wave_reduce_fold(const float* tile /* [BWD_FOLD
 }
 
 // ------------------------------------------------------------------------------------------
-// A7 composite backward: same tiling and per-wave ballot-compacted splat lists as the forward pass
-// (wave w = 8x8 quadrant, one pixel per lane), splats visited back to front in rounds of BWD_ROUND (64).
-// Every lane re-derives alpha/T for its pixel.  The ten per-splat partial gradients are summed across the
-// wave (wave_reduce4), parked in LDS per (wave, splat), summed over the four waves in a fixed order and
-// written ONCE as a 48-byte record per (tile, splat) pair at the pair's emit index.  The pairs of one
-// Gaussian are contiguous there, so the per-Gaussian kernel (A8) sums them without a single atomic:
-// the whole backward pass is deterministic.
+// A7 composite backward: a workgroup per 16x16 tile, wave w = its 8x8 quadrant w, one pixel per lane; the tile's list is visited back to front in rounds of
+// BWD_ROUND (64) positions staged through LDS, and a wave walks exactly the positions its quadrant blended (the forward pass's activity bytes).  Every lane
+// re-derives alpha / T for its pixel; the nine (ten with a depth gradient) per-pair partial sums are summed over the wave (wave_reduce_fold), parked in LDS per
+// (wave, position), added over the four waves in a fixed order and written ONCE as a 48-byte record per (tile, splat) pair at the pair's record index.  The records
+// of one Gaussian are contiguous there, so the per-Gaussian kernel (A8) sums them without a single atomic: the whole backward pass is deterministic.
 // record layout (GS_PAIR_FLOATS = 12): [c0, c2, c1, depth | m0, m1y, m1x, m2xx | m2xy, 0, m2yy, 0]  (m* = moments of dL/dG*G about the pixel)
 // ------------------------------------------------------------------------------------------
-// Splats per staging round.  64 keeps a workgroup at 16 KB of LDS: with 128 (31.7 KB) five resident workgroups fill a CU's 160 KB and the small
-// kernels of the other view lanes (radix scatter 38 KB, preprocess 50 KB) cannot co-reside with the compositing: 2100 -> 2170 Mpixels/s; 32 is slower again.
+// Positions per staging round.  64 keeps a workgroup at 18.4 KB of LDS (eight workgroups = 32 waves per CU); 128 and 32 measured slower in rounds 1-2.
 #define BWD_ROUND 64
 
 // Round 3, measured and dropped (commit a5d0b08, profiles/r03/r03b_*): this kernel as ONE WAVE PER QUADRANT (64-lane workgroups, no barriers, a wave-private
@@ -247,11 +128,7 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
     __shared__ uint32_t smask[BWD_ROUND];
     constexpr int NV = DEPTH ? 10 : 9;                          // values summed per walked pair: colour 3 [, depth], m0, m1 x 2, m2 x 3
     __shared__ float acc[4][NV][BWD_ROUND + 1];                 // per wave and value: the sums of the round's splats (+1: the writers of a wave -- lanes 0, 4, 8, ... -- land in different banks)
-#if defined(GS_BWD_REDUCE_LDS9)
-    __shared__ __attribute__((aligned(16))) float red[4][NV][BWD_RED_ROW];   // wave_reduce_lds's transposition tile, one per wave
-#elif !defined(GS_BWD_REDUCE_DPP)
     __shared__ __attribute__((aligned(16))) float red[4][BWD_FOLD_ROWS][BWD_RED_ROW];   // wave_reduce_fold's transposition tile, one per wave (18.4 KB per workgroup in all: eight per CU)
-#endif
     __shared__ int s_uptow[4];   // per quadrant: the deepest list position (+1) one of its pixels blended = how far its plane of the activity record is valid
     int tx, ty;
     if (!gs_block_tile(blockIdx.x, p.gx, p.gy, tx, ty)) return;
@@ -300,9 +177,7 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
         __syncthreads();
         if (threadIdx.x == 0 && pl.tile_loss) pl.tile_loss[tile] = s_loss[0] + s_loss[1] + s_loss[2] + s_loss[3];
     }
-#ifndef GS_BWD_REDUCE_DPP
     const uint32_t red_base = lds_scalar_address(&red[wave][0][0]);
-#endif
     const float bg_dot = bg[0] * dLp0 + bg[1] * dLp1 + bg[2] * dLp2;
     float Rdot = T_final * bg_dot;
 
@@ -367,18 +242,13 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
                     am = c0 & c1 & c2;
                 }
                 {   // no branch on am: it is non-zero for every recorded pair (and were it not, the sums below would come out as zeros)
-                    float t0, t1, t2;
                     // dL/dalpha_k = T_k (c_k . dL) - [sum_{j behind k} (c_j . dL) alpha_j T_j + T_final bg . dL] / (1 - alpha_k)
                     // with (c . dL) taken over colour, depth and alpha channels; Rdot carries the bracket.
                     // ONE select per pair (round 4; three before): an inactive lane continues with oG = 0, hence alpha = 0, 1 / (1 - alpha) = 1 exactly, T unchanged,
                     // weight 0 and moments 0 -- the same instructions for every lane, no exec-masked branch, no zero-initialised temporaries.
                     const float oGe = sel64z(am, oG);
-#ifdef GS_BWD_NO_TRIM
-                    const float alpha = fminf(0.99f, oGe);
-#else
                     float alpha;   // fminf(0.99f, oGe) without the v_max_f32 x, x the compiler puts in front of it (oGe comes out of inline asm: it cannot know the value is canonical)
                     asm("v_min_f32_e32 %0, 0x3f7d70a4, %1" : "=v"(alpha) : "v"(oGe));
-#endif
                     const float inv = __builtin_amdgcn_rcpf(1.f - alpha);
                     const float Tn = T * inv;
                     T = Tn;
@@ -390,35 +260,14 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
                     // screen-space part as raw moments of w2 = dL/dG * G; turned into mean/conic/opacity gradients per Gaussian in A8
                     const float m0 = oGe * dL_dalpha;
                     const float m1x = m0 * dx, m1y = m0 * dy;
-#ifdef GS_BWD_REDUCE_DPP
-                    wave_reduce10(w * dLp0, w * dLp1, w * dLp2, DEPTH ? w * dLd : 0.f, m0, m1x, m1y, m1x * dx, m1x * dy, m1y * dy, t0, t1, t2);
-                    // t0 rows: c0, c2, c1, depth   t1 rows: m0, m1y, m1x, m2xx   t2 rows: m2xy, 0, m2yy, 0  -> value index of wave_reduce_lds's order
-                    if ((lane & 15) == 0) {   // lanes 0,16,32,48: one row each
-                        const int row = lane >> 4;
-                        const int k0 = row == 0 ? 0 : (row == 1 ? 2 : (row == 2 ? 1 : 9)), k1 = row == 0 ? 3 : (row == 1 ? 5 : (row == 2 ? 4 : 6)), k2 = row == 0 ? 7 : 8;
-                        if (row < 3 || DEPTH) acc[wave][DEPTH || row < 3 ? k0 : 0][j] = t0;
-                        acc[wave][k1][j] = t1;
-                        if (!(row & 1)) acc[wave][k2][j] = t2;
-                    }
-#else
-                    (void)t0; (void)t1; (void)t2;
                     float vals[NV];
                     vals[0] = w * dLp0; vals[1] = w * dLp1; vals[2] = w * dLp2; vals[3] = m0; vals[4] = m1x; vals[5] = m1y;
                     vals[6] = m1x * dx; vals[7] = m1x * dy; vals[8] = m1y * dy;
                     if (DEPTH) vals[NV - 1] = w * dLd;
-#ifdef GS_BWD_REDUCE_LDS9
-                    const float tsum = wave_reduce_lds<NV>(&red[wave][0][0], red_base, vals, lane);
-#else
                     const float tsum = wave_reduce_fold<NV>(&red[wave][0][0], red_base, vals, lane);
-#endif
-#ifdef GS_BWD_NO_TRIM
-                    if ((lane & 3) == 0 && lane < 4 * NV) acc[wave][lane >> 2][j] = tsum;
-#else
-                    // every lane stores: the four lanes of a quad hold the same sum and lanes past row NV - 1 hold row NV - 1's (wave_reduce_lds), so all writers of
+                    // every lane stores: the four lanes of a quad hold the same sum and lanes past value NV - 1 hold value NV - 1's (wave_reduce_fold), so all writers of
                     // an address carry the same bits -- no exec save / branch / restore around one store per walked pair
                     acc[wave][min(lane >> 2, NV - 1)][j] = tsum;
-#endif
-#endif
                 }
             }
         }

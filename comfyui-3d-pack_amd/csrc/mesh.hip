@@ -2097,12 +2097,8 @@ int mesh_views_fwd(const c3d_mesh_view* views, int B, const float* v, const floa
                          d->Ht, d->Wt, (const unsigned long long*)raster_scratch, (float4*)st.rast, (float2*)st.texc, st.albedo0, st.owned, st.owned_words); }
     {   // silhouette analysis per pair, then every pixel gathers its blends and shades: no atomics (k_view_shade_fwd_g)
         C3dProfScope ps(C3D_P_MESH_ANTIALIAS, s);
-#ifndef MESH_NO_SIL_BITS
         const uint8_t* sil = st.sil;
         hipLaunchKernelGGL(k_aa_sil_bits, dim3(c3d_cdiv(T, 256), B), dim3(256), 0, s, (const float4*)st.vclip, (const int3*)f, (const EdgeSlot*)aa_topology, edge_table_size(T) - 1, V, T, st.sil);
-#else
-        const uint8_t* sil = nullptr;
-#endif
         hipLaunchKernelGGL(k_aa2_pairs, dim3(c3d_cdiv(BP * 2, 256)), dim3(256), 0, s, (const float4*)st.rast, (const float4*)st.vclip, (const int3*)f,
                            (const EdgeSlot*)aa_topology, edge_table_size(T) - 1, B, V, H, W, st.pair_alpha, st.hit, sil, T);
         hipLaunchKernelGGL(k_view_shade_fwd_g, dim3(c3d_cdiv(BP, 256)), dim3(256), 0, s, st.albedo0, (const float4*)st.rast, st.hit, st.pair_alpha, bgs, B, H, W,
