@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(256) k_ms_pool(const float* __restrict__ X, co
 template <bool LAST, bool L0>
 __global__ void __launch_bounds__(256, MS_MIN_BLOCKS) k_ms_fwd(const float* __restrict__ X, const float* __restrict__ Y, const float* __restrict__ mask, int clamp_y, int C,
                                                 MsLevel lv, MsWin win, float* __restrict__ mapA, float* __restrict__ mapB, float* __restrict__ mapC,
-                                                float* __restrict__ partial, MsTab tab, int NT) {
+                                                float* __restrict__ partial, MsTab tab, int NT, float* __restrict__ X2, float* __restrict__ Y2, int H2, int W2) {
     // Quantities travel in pairs -- (x, y), (x^2, y^2) -- so that one v_pk_fma_f32 filters two of them (the kernel is VALU bound: 3 instructions
     // per tap and output instead of the 7 of the scalar form with its products inside the loop); xy goes alone.
     __shared__ v2f sxy[MS_INY][MS_IN + 1];
@@ -143,6 +143,20 @@ __global__ void __launch_bounds__(256, MS_MIN_BLOCKS) k_ms_fwd(const float* __re
         }
         __syncthreads();                       // also: every lane is done with the previous tile's vertical pass (h01 / h23 / h4 may be overwritten)
         if (t + 1 < t1) fetch(t + 1);          // in flight while this tile is filtered
+        // X2 != NULL (even image sides): the 2 x 2 average pooling to the next level rides here -- the tile is in LDS anyway (with the level-0 transform applied), so the
+        // pooling kernel's second read of x and y (0.16 ms per 8 views at 1080p) disappears.  A tile pools its own 32 x 16 block; the last tile of a row / column also the
+        // part of its halo that reaches the image's edge (tiles cover the VALID size, H - 10 x W - 10).  Same order of additions as k_ms_pool: same bits.
+        if (X2) {
+            const int nrow = ((int)blockIdx.y == lv.ty - 1 ? lv.H - oy : MS_TY) >> 1, ncol = (t == lv.tx - 1 ? lv.W - ox : MS_T) >> 1;
+            for (int e = threadIdx.x; e < nrow * ncol; e += 256) {
+                const int pr = e / ncol, pc = e - pr * ncol;
+                const v2f a = sxy[2 * pr][2 * pc], b = sxy[2 * pr][2 * pc + 1], c = sxy[2 * pr + 1][2 * pc], d = sxy[2 * pr + 1][2 * pc + 1];
+                float sx = 0.f, sy = 0.f;
+                sx += a.x; sy += a.y; sx += b.x; sy += b.y; sx += c.x; sy += c.y; sx += d.x; sy += d.y;
+                const size_t o = ((size_t)plane * H2 + (oy >> 1) + pr) * W2 + (ox >> 1) + pc;
+                X2[o] = 0.25f * sx; Y2[o] = 0.25f * sy;
+            }
+        }
         // horizontal pass, four adjacent outputs per item: the 14 inputs they share are read once (one 8-byte LDS read each) and squared once
         for (int e = threadIdx.x; e < MS_INY * (MS_T / 4); e += 256) {
             const int r = e >> 3, c0 = (e & 7) * 4;
@@ -484,11 +498,15 @@ static int ms_run(const float* x, const float* y, const float* mask, const MsTab
         float* part = (float*)(ws + pl.off_part[l]);
         const int nt = ms_tiles_per_group(L.tx, L.ty, P);
         const dim3 grid(c3d_cdiv(L.tx, nt), L.ty, P);
-        if (l == 0)                    hipLaunchKernelGGL((k_ms_fwd<false, true>), grid, dim3(256), 0, s, X[l], Y[l], mask, clamp_y, C, L, win, mA, mB, mC, part, tab, nt);
-        else if (l < MS_LEVELS - 1)    hipLaunchKernelGGL((k_ms_fwd<false, false>), grid, dim3(256), 0, s, X[l], Y[l], (const float*)nullptr, 0, C, L, win, mA, mB, mC, part, none, nt);
-        else                           hipLaunchKernelGGL((k_ms_fwd<true, false>), grid, dim3(256), 0, s, X[l], Y[l], (const float*)nullptr, 0, C, L, win, mA, mB, mC, part, none, nt);
+        // pooling to the next level inside the forward kernel when both sides are even (no padding row / column: a pooled pixel is a whole 2 x 2 block of one tile)
+        const bool pool_here = l < MS_LEVELS - 1 && !(L.H & 1) && !(L.W & 1);
+        float* X2 = pool_here ? (float*)(ws + pl.off_x[l + 1]) : nullptr; float* Y2 = pool_here ? (float*)(ws + pl.off_y[l + 1]) : nullptr;
+        const int H2 = l < MS_LEVELS - 1 ? pl.lv[l + 1].H : 0, W2 = l < MS_LEVELS - 1 ? pl.lv[l + 1].W : 0;
+        if (l == 0)                    hipLaunchKernelGGL((k_ms_fwd<false, true>), grid, dim3(256), 0, s, X[l], Y[l], mask, clamp_y, C, L, win, mA, mB, mC, part, tab, nt, X2, Y2, H2, W2);
+        else if (l < MS_LEVELS - 1)    hipLaunchKernelGGL((k_ms_fwd<false, false>), grid, dim3(256), 0, s, X[l], Y[l], (const float*)nullptr, 0, C, L, win, mA, mB, mC, part, none, nt, X2, Y2, H2, W2);
+        else                           hipLaunchKernelGGL((k_ms_fwd<true, false>), grid, dim3(256), 0, s, X[l], Y[l], (const float*)nullptr, 0, C, L, win, mA, mB, mC, part, none, nt, X2, Y2, H2, W2);
         fin.partial[l] = part; fin.tiles[l] = L.tx * L.ty; fin.inv_npix[l] = 1.f / ((float)L.Hv * (float)L.Wv); fin.wts[l] = wts[l];
-        if (l < MS_LEVELS - 1) {
+        if (l < MS_LEVELS - 1 && !pool_here) {
             const MsLevel& N = pl.lv[l + 1];
             const dim3 pg(c3d_cdiv(N.W, 64), c3d_cdiv(N.H, 4), P);
             if (l == 0) hipLaunchKernelGGL((k_ms_pool<true>), pg, dim3(256), 0, s, X[l], Y[l], mask, clamp_y, C, L.H, L.W, N.H, N.W, (float*)(ws + pl.off_x[l + 1]), (float*)(ws + pl.off_y[l + 1]), tab);
