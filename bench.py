@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- Mpixels/s of the 3DGS forward+backward hot path on BASELINE.json's workload.
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W        (N > 1 without a launcher: starts its own N ranks under torch.distributed.run, 127.0.0.1, a free port)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Workload (config.workload): BASELINE.md section 3 configs 2-4 -- 1,000,000 synthetic Gaussians (seed 1234), SH degree 3,
@@ -354,7 +354,8 @@ def main_mesh(a, world, rank, dev, dist):
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                           "config": {"workload": "DiffRastMesh fwd+bwd, %d-triangle displaced sphere, 1024^2 albedo, 1024x1024, %d views/GPU/step" % (T, a.views_per_gpu),
                                      "render_path": ("step: c3d_mesh_train_views, %d views per launch" % vpl) if use_step else "fused: one autograd call per view",
-                                     "parallelism": "view-parallel dp%d" % world, "host_enqueue_ms_per_step": round(t_enq / a.steps * 1e3, 3)},
+                                     "parallelism": "view-parallel dp%d" % world, "host_enqueue_ms_per_step": round(t_enq / a.steps * 1e3, 3),
+                                     "dist_backend": (dist.get_backend() if dist is not None else None), "rccl_ranks": (dist.get_world_size() if dist is not None else 1)},
                           "roofline": roof, "roofline_chain": chain, "cpu_baseline": cpu, "kernels": kern, "code_digest": code_digest()}))
     if world > 1:
         dist.destroy_process_group()
@@ -387,14 +388,30 @@ def mesh_cpu_baseline(v, f, vt, H, W):
         return {"value": None, "unit": "Mpixels/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (ex,)}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this same command line, one per GPU, under torch.distributed.run on a free
+    loopback port (what the driver's torchrun form does), pass rank 0's JSON line through and return the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "8")          # torchrun would set 1 (and say so on stderr); the CPU-baseline leg does not run at N > 1
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "RANK" not in os.environ and a.gpus > 1:
+        return self_launch(a.gpus)
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (a.gpus, a.gpus))
+        raise SystemExit("bench.py --gpus %d runs under WORLD_SIZE=%d: the two must agree (plain `python bench.py --gpus N` starts its own N ranks)" % (a.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the MI355X path has no CPU fallback")
     # test hook: C3D_BENCH_SHARE_DEVICE=1 puts every rank on GPU 0 and talks gloo, so the N>1 control flow (sharding, barriers, exchange,
@@ -842,6 +859,7 @@ def main():
                                    % (a.mode, N, deg, W, H, a.views_per_gpu),
                        "global_views_per_step": a.views_per_gpu * world, "parallelism": "view-parallel dp%d" % world,
                        "exchange": (a.exchange if dist_on and a.mode != "fwd" else "none"), "dist_backend": (dist.get_backend() if dist_on else None),
+                       "rccl_ranks": (dist.get_world_size() if dist_on else 1),
                        "exchange_chunks": (a.exchange_chunks if dist_on and a.mode != "fwd" and a.exchange == "allreduce" and fused_step is not None else 1), "render_path": a.render_path,
                        "loss": (None if a.mode == "fwd" else ("0.8 L1 + 3 MSE(alpha) + 0.2 (1 - MS-SSIM), masked (BASELINE config 3)%s" % (", MS-SSIM by torch ops" if ms_ssim is not None else ", fused HIP")
                                                                 if loss_kind != "l1alpha" and a.render_path == "step" else "0.8 L1 + 3 MSE(alpha)")), "view_lanes": (a.lanes if a.render_path == "step" else 1),

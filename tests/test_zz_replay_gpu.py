@@ -128,3 +128,23 @@ def test_bench_two_ranks_sharing_the_device():
         assert d["config"]["global_views_per_step"] == 4 and d["config"]["exchange"] == exchange and d["config"]["parallelism"] == "view-parallel dp2"
         assert d["value"] > 0 and abs(d["value"] - 4 * 640 * 360 / (d["ms_per_step"] * 1e-3) / 1e6) <= 0.01 * d["value"]
         assert d["roofline"] is not None and d["cpu_baseline"] is None and d["vs_baseline"] is None
+
+
+def test_bench_starts_its_own_ranks():
+    """the driver's N = 1 command is plain `python3 bench.py --gpus 1 ...`; the same form with --gpus 2 must start its own two ranks
+    (bench.self_launch: torch.distributed.run on a free loopback port) and still print ONE JSON line, with the world size the process group saw in
+    config.rccl_ranks.  Both ranks share GPU 0 and talk gloo here (C3D_BENCH_SHARE_DEVICE=1); on a node the same command binds rank r to GPU r with nccl."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(C3D_BENCH_SHARE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--gaussians", "200000", "--width", "640", "--height", "360",
+           "--views-per-gpu", "2", "--cpu-baseline", "off"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["rccl_ranks"] == 2 and d["config"]["dist_backend"] == "gloo" and d["config"]["global_views_per_step"] == 4
+    assert d["value"] > 0
