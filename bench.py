@@ -65,8 +65,8 @@ def parse():
     ap.add_argument("--exchange-chunks", type=int, default=4,
                     help="N > 1, --exchange allreduce: Gaussian ranges of the per-Gaussian backward pass, each range's collective overlapping the next range's kernels (1 = one all-reduce after the step)")
     ap.add_argument("--timed-prof", choices=["on", "off"], default="on", help="HIP-event kernel timing inside the timed region")
-    ap.add_argument("--lanes", type=int, default=0, help="view GROUPS in flight (HIP streams) on the fused step path; 0 = the defaults: 1 with a backward pass (all views of the step go through "
-                                                       "every stage of the chain in ONE launch each), 2 forward-only (one group's binning stages run underneath the other's compositing)")
+    ap.add_argument("--lanes", type=int, default=0, help="view GROUPS a fused call splits its views into (ceil(views / lanes) views per launch of every stage, the groups one after the "
+                                                       "other on the same stream; the library owns no streams); 0 = 1: all views of the step through every stage in ONE launch each, in every mode")
     ap.add_argument("--group", type=int, default=16, help="--mode fwd: views per launch of every stage (<= 16)")
     ap.add_argument("--render-path", choices=["step", "fused", "accessor", "boundary"], default="step",
                     help="step: c3d_gs_train_views_raw, all views of the step forward+loss+backward in one sync-free library call (product default for training); fused: GaussianSplattingRenderer.render with activations folded into the kernels (product default); accessor: the same "
@@ -572,6 +572,7 @@ def main():
                 color, radii, depth, alpha = render(i)
                 if collect:
                     stats["n_vis"].append(int((radii > 0).sum().item()))
+                    dgr.flush()                      # the pair count of a sync-free forward call reaches the host asynchronously
                     stats["D"].append(int(dgr.last_num_rendered))
                 if a.mode != "fwd":
                     tc, ta = targets[i]

@@ -65,8 +65,8 @@ class GaussianSplattingCameraController(BaseCameraController):
         """orbit rendering (reference camera_utils.py:160-175 via the renderer nodes): without autograd and without per-view options the whole
         orbit goes through ONE batched library call; otherwise the reference's per-view loop."""
         g = self.renderer.gaussians
-        if kwargs or torch.is_grad_enabled() or not g._xyz.is_cuda or len(all_cam_poses) == 0:
-            return super().render_all_pose(all_cam_poses, **kwargs)
+        if kwargs or torch.is_grad_enabled() or not g._xyz.is_cuda or len(all_cam_poses) == 0 or not self.renderer.raw_storage_ok():
+            return super().render_all_pose(all_cam_poses, **kwargs)      # (a storage the raw-parameter kernels do not take -- SH degree > 3, odd f_rest shapes -- goes view by view through render())
         cams, bgs = [], []
         for radius, elevation, azimuth, cx, cy, cz in all_cam_poses:
             pose = orbit_camera(elevation, azimuth, radius, target=np.array([cx, cy, cz], dtype=np.float32))

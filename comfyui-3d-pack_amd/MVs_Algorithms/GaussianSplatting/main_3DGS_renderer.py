@@ -492,6 +492,16 @@ class GaussianSplattingRenderer:
         else:
             raise TypeError("initialize(): pass None, a GS PlyData, a PointCloud, a Mesh or a dict of raw tensors (the UV-grid initialiser is not built)")
 
+    def raw_storage_ok(self):
+        """can the raw-parameter kernels (render()'s fused path, render_views, the fused training step) read this model's storage?  SH degree 0-3, f_dc [N,1,3] and
+        f_rest [N,K-1,3] with K in (1, 4, 9, 16) coefficients per channel, enough of them for the active degree (diff_gaussian_rasterization.raw_sh_coeffs)"""
+        g = self.gaussians
+        fd, fr = g._features_dc, g._features_rest
+        if not (0 <= g.max_sh_degree <= 3 and fd.dim() == 3 and tuple(fd.shape[1:]) == (1, 3) and fr.dim() == 3 and fr.shape[2] == 3):
+            return False
+        K = int(fr.shape[1]) + 1
+        return K in (1, 4, 9, 16) and (g.active_sh_degree + 1) ** 2 <= K
+
     def render_views(self, viewpoint_cameras, bg_colors=None, scaling_modifier=1.0, lanes=1, group=16):
         """Inference-only batch of render(): all cameras in ONE library call (c3d_gs_render_views_raw; `group` views per launch of every stage, no host
         synchronisation between views).  Same per-view results as render() -- the orbit-renderer loop of the reference's
@@ -502,6 +512,11 @@ class GaussianSplattingRenderer:
         g = self.gaussians
         if not g._xyz.is_cuda:
             raise RuntimeError("render_views needs a HIP-resident model; there is no CPU path")
+        if not self.raw_storage_ok():      # the per-view loop over render() (which takes the accessor path for such a model)
+            outs = [self.render(c, scaling_modifier, bg_color=(bg_colors[i] if isinstance(bg_colors, (list, tuple)) else bg_colors)) for i, c in enumerate(viewpoint_cameras)]
+            with torch.no_grad():
+                return {"image": torch.stack([o["image"] for o in outs]), "depth": torch.stack([o["depth"] for o in outs]), "alpha": torch.stack([o["alpha"] for o in outs]),
+                        "radii": torch.stack([o["radii"] for o in outs]), "visibility_filter": torch.stack([o["visibility_filter"] for o in outs])}
         V = len(viewpoint_cameras)
         if bg_colors is None or torch.is_tensor(bg_colors):
             bg_colors = [self.bg_color if bg_colors is None else bg_colors] * V
@@ -529,7 +544,7 @@ class GaussianSplattingRenderer:
             bg=self.bg_color if bg_color is None else bg_color, scale_modifier=scaling_modifier,
             viewmatrix=viewpoint_camera.world_view_transform, projmatrix=viewpoint_camera.full_proj_transform,
             sh_degree=g.active_sh_degree, campos=viewpoint_camera.camera_center, prefiltered=False, debug=False)
-        fused = (gaussain_idx is None and override_color is None and not compute_cov3D_python and 0 <= g.max_sh_degree <= 3 and g._xyz.is_cuda
+        fused = (gaussain_idx is None and override_color is None and not compute_cov3D_python and self.raw_storage_ok() and g._xyz.is_cuda
                  and not self.force_unfused)
         xyz = g.get_xyz if gaussain_idx is None else g.get_xyz[gaussain_idx]
         # zero tensor whose gradient is the screen-space positional gradient (densification statistic)

@@ -16,6 +16,9 @@ void c3d_set_error(const char* fmt, ...) {
 // msssim.hip: out_word += va + vb * mean MS-SSIM(x, y_eff), dL_dy (+)= grad_scale * d mean / dy
 int ms_value_grad_images(const float* const* x, const float* const* y, const float* const* mask, float* const* dy, int clamp_y, int B, int C, int H, int W, float grad_scale,
                          int accumulate, float va, float vb, float* out0, size_t out_stride, void* workspace, hipStream_t s);
+// record indices are bounded by the pair count the state buffers were sized for: the exact count of c3d_gs_forward_project, or the capacity of a sync-free forward
+// (whose real count stays on the device and may -- reported through its status words -- have exceeded it)
+static inline uint32_t pair_cap(int64_t num_rendered) { return num_rendered >= 0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)(num_rendered > 0 ? num_rendered : 0); }
 static int tile_sort_bits(int tiles) {
     int bits = 0;
     while ((1ll << bits) < (long long)tiles) bits++;
@@ -121,7 +124,7 @@ static int project_tail(GsGeom& g, int N, int64_t* num_rendered, hipStream_t s) 
 extern "C" {
 
 const char* c3d_last_error(void) { return g_err; }
-int c3d_version(void) { return 400; }
+int c3d_version(void) { return 500; }
 
 size_t c3d_gs_geom_bytes(int32_t N) { GsGeom g; gs_carve_geom(nullptr, N, g); return g.bytes; }
 size_t c3d_gs_binning_bytes(int64_t D, int32_t H, int32_t W) {
@@ -165,7 +168,7 @@ int c3d_gs_forward_project_raw(const c3d_gs_settings* st, int32_t N, const float
     *num_rendered = 0;
     if (N == 0) return 0;
     if (!means3D || !f_dc || (!f_rest && K > 1) || !opacity_raw || !scaling_raw || !rotation_raw || !radii || !geom_buffer) { c3d_set_error("c3d_gs_forward_project_raw: NULL pointer"); return -1; }
-    if ((uintptr_t)f_rest % 16 || (uintptr_t)rotation_raw % 16) { c3d_set_error("c3d_gs_forward_project_raw: f_rest / rotation must be 16-byte aligned"); return -1; }
+    if ((K > 1 && (uintptr_t)f_rest % 16) || (uintptr_t)rotation_raw % 16) { c3d_set_error("c3d_gs_forward_project_raw: f_rest / rotation must be 16-byte aligned"); return -1; }
     GsGeom g;
     gs_carve_geom((char*)geom_buffer, N, g);
     int rc;
@@ -196,6 +199,67 @@ int c3d_gs_forward_render(const c3d_gs_settings* st, int32_t N, int32_t M, const
     GsFwdViews vp{};
     vp.bg[0] = p.bg; vp.color[0] = out_color; vp.depth[0] = out_depth; vp.alpha[0] = out_alpha;
     return gs_launch_composite_fwd(p, g, b, res, im, vp, 1, 0, true, s);   // a backward call may follow: record the blended (quadrant, splat) pairs
+}
+
+// A2-A6 of ONE view without the host: launches sized for `cap` pairs, the pair count read from g.meta[0] on the device (what the multi-view paths do per group)
+static int forward_tail_nosync(const GsParams& p, GsGeom& g, int N, int64_t pair_capacity, void* binning_buffer, void* image_buffer, float* out_color, float* out_depth,
+                               float* out_alpha, uint32_t* status, hipStream_t s) {
+    const int tiles = p.gx * p.gy;
+    const uint32_t cap = (uint32_t)pair_capacity;
+    GsBinning b;
+    gs_carve_binning((char*)binning_buffer, pair_capacity, tiles, b);
+    GsImage im;
+    gs_carve_image((char*)image_buffer, p.W, p.H, im);
+    int rc, res = 0;
+    if ((rc = binning_front(g, N, cap, status, s))) return rc;
+    if ((rc = binning_back(p, g, b, pair_capacity, cap, (const uint32_t*)g.meta, status, s, &res))) return rc;
+    C3dProfScope ps(C3D_P_COMPOSITE_FWD, s);
+    GsFwdViews vp{};
+    vp.bg[0] = p.bg; vp.color[0] = out_color; vp.depth[0] = out_depth; vp.alpha[0] = out_alpha;
+    return gs_launch_composite_fwd(p, g, b, res, im, vp, 1, 0, true, s);
+}
+static int check_nosync_args(const char* who, int64_t pair_capacity, const void* radii, const void* geom_buffer, const void* binning_buffer, const void* image_buffer,
+                             const float* out_color, const float* out_depth, const float* out_alpha, const uint32_t* status) {
+    if (pair_capacity <= 0 || pair_capacity > (int64_t)0x3FFFFFF0ll) { c3d_set_error("%s: pair_capacity out of range (1 .. 2^30 - 16)", who); return -1; }
+    if (!radii || !geom_buffer || !binning_buffer || !image_buffer || !out_color || !out_depth || !out_alpha || !status) { c3d_set_error("%s: NULL buffer", who); return -1; }
+    return 0;
+}
+
+int c3d_gs_forward_nosync(const c3d_gs_settings* st, int32_t N, int32_t M, const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+                          const float* scales, const float* rotations, const float* cov3D_precomp, int32_t* radii, void* geom_buffer, int64_t pair_capacity,
+                          void* binning_buffer, void* image_buffer, float* out_color, float* out_depth, float* out_alpha, uint32_t* status, c3d_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    GsParams p;
+    if (make_params(st, N, M, p)) return -1;
+    if (check_inputs(N, M, p.deg, means3D, shs, colors_precomp, scales, rotations, cov3D_precomp)) return -1;
+    if (N == 0 || p.gx * p.gy == 0) { c3d_set_error("c3d_gs_forward_nosync: empty cloud / image (take c3d_gs_forward_project + c3d_gs_forward_render)"); return -1; }
+    if (check_nosync_args("c3d_gs_forward_nosync", pair_capacity, radii, geom_buffer, binning_buffer, image_buffer, out_color, out_depth, out_alpha, status)) return -1;
+    if (!opacities) { c3d_set_error("c3d_gs_forward_nosync: opacities is NULL"); return -1; }
+    GsGeom g;
+    gs_carve_geom((char*)geom_buffer, N, g);
+    int rc;
+    { C3dProfScope ps(C3D_P_PREPROCESS, s);
+    if ((rc = gs_launch_preprocess(p, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, radii, s))) return rc; }
+    return forward_tail_nosync(p, g, N, pair_capacity, binning_buffer, image_buffer, out_color, out_depth, out_alpha, status, s);
+}
+
+int c3d_gs_forward_raw_nosync(const c3d_gs_settings* st, int32_t N, const float* means3D, const float* f_dc, const float* f_rest, const float* opacity_raw,
+                              const float* scaling_raw, const float* rotation_raw, int32_t* radii, void* geom_buffer, int64_t pair_capacity, void* binning_buffer,
+                              void* image_buffer, float* out_color, float* out_depth, float* out_alpha, uint32_t* status, c3d_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    GsParams p;
+    const int K = raw_coeffs(st);
+    if (K < 0 || make_params(st, N, K, p)) return -1;
+    if (N == 0 || p.gx * p.gy == 0) { c3d_set_error("c3d_gs_forward_raw_nosync: empty cloud / image (take c3d_gs_forward_project_raw + c3d_gs_forward_render)"); return -1; }
+    if (check_nosync_args("c3d_gs_forward_raw_nosync", pair_capacity, radii, geom_buffer, binning_buffer, image_buffer, out_color, out_depth, out_alpha, status)) return -1;
+    if (!means3D || !f_dc || (!f_rest && K > 1) || !opacity_raw || !scaling_raw || !rotation_raw) { c3d_set_error("c3d_gs_forward_raw_nosync: NULL pointer"); return -1; }
+    if ((K > 1 && (uintptr_t)f_rest % 16) || (uintptr_t)rotation_raw % 16) { c3d_set_error("c3d_gs_forward_raw_nosync: f_rest / rotation must be 16-byte aligned"); return -1; }
+    GsGeom g;
+    gs_carve_geom((char*)geom_buffer, N, g);
+    int rc;
+    { C3dProfScope ps(C3D_P_PREPROCESS, s);
+    if ((rc = gs_launch_preprocess_raw(p, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, g, radii, s))) return rc; }
+    return forward_tail_nosync(p, g, N, pair_capacity, binning_buffer, image_buffer, out_color, out_depth, out_alpha, status, s);
 }
 
 int c3d_gs_backward(const c3d_gs_settings* st, int32_t N, int32_t M, const float* means3D, const float* shs,
@@ -233,11 +297,11 @@ int c3d_gs_backward(const c3d_gs_settings* st, int32_t N, int32_t M, const float
         C3D_CHECK(hipMemsetAsync(pvalid, 0, (size_t)num_rendered, s));
         GsBwdPix px{};
         px.bg[0] = p.bg; px.dcolor[0] = dL_dcolor; px.ddepth[0] = dL_ddepth; px.dalpha[0] = dL_dalpha;
-        if ((rc = gs_launch_composite_bwd(p, g, b, res, im, px, dL_ddepth != nullptr, pairgrad, pvalid, s))) return rc;
+        if ((rc = gs_launch_composite_bwd(p, g, b, res, im, px, dL_ddepth != nullptr, pairgrad, pvalid, s, pair_cap(num_rendered)))) return rc;
     }
     C3dProfScope ps(C3D_P_PREPROCESS_BWD, s);
     return gs_launch_preprocess_bwd(p, g, radii, means3D, shs, colors_precomp, scales, rotations, cov3D_precomp, pairgrad, pvalid, dL_dmeans2D,
-                                    dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, s);
+                                    dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, s, pair_cap(num_rendered));
 }
 
 int c3d_gs_backward_raw(const c3d_gs_settings* st, int32_t N, const float* means3D, const float* f_dc, const float* f_rest,
@@ -252,7 +316,7 @@ int c3d_gs_backward_raw(const c3d_gs_settings* st, int32_t N, const float* means
     if (N == 0) return 0;
     if (!means3D || !f_dc || (!f_rest && K > 1) || !scaling_raw || !rotation_raw || !radii || !geom_buffer || !dL_dcolor || !dL_dmeans2D || !dL_dmeans3D ||
         !dL_df_dc || (!dL_df_rest && K > 1) || !dL_dopacity_raw || !dL_dscaling_raw || !dL_drotation_raw || !scratch) { c3d_set_error("c3d_gs_backward_raw: NULL pointer"); return -1; }
-    if ((uintptr_t)f_rest % 16 || (uintptr_t)dL_df_rest % 16 || (uintptr_t)rotation_raw % 16 || (uintptr_t)dL_drotation_raw % 16) { c3d_set_error("c3d_gs_backward_raw: f_rest / rotation tensors must be 16-byte aligned"); return -1; }
+    if ((K > 1 && ((uintptr_t)f_rest % 16 || (uintptr_t)dL_df_rest % 16)) || (uintptr_t)rotation_raw % 16 || (uintptr_t)dL_drotation_raw % 16) { c3d_set_error("c3d_gs_backward_raw: f_rest / rotation tensors must be 16-byte aligned"); return -1; }
     const int tiles = p.gx * p.gy;
     GsGeom g;
     gs_carve_geom((char*)geom_buffer, N, g);
@@ -270,11 +334,11 @@ int c3d_gs_backward_raw(const c3d_gs_settings* st, int32_t N, const float* means
         C3D_CHECK(hipMemsetAsync(pvalid, 0, (size_t)num_rendered, s));
         GsBwdPix px{};
         px.bg[0] = p.bg; px.dcolor[0] = dL_dcolor; px.ddepth[0] = dL_ddepth; px.dalpha[0] = dL_dalpha;
-        if ((rc = gs_launch_composite_bwd(p, g, b, res, im, px, dL_ddepth != nullptr, pairgrad, pvalid, s))) return rc;
+        if ((rc = gs_launch_composite_bwd(p, g, b, res, im, px, dL_ddepth != nullptr, pairgrad, pvalid, s, pair_cap(num_rendered)))) return rc;
     }
     C3dProfScope ps(C3D_P_PREPROCESS_BWD, s);
     return gs_launch_preprocess_bwd_raw(p, g, radii, means3D, f_dc, f_rest, scaling_raw, rotation_raw, pairgrad, pvalid, dL_dmeans2D, dL_dopacity_raw,
-                                        dL_dmeans3D, dL_df_dc, dL_df_rest, dL_dscaling_raw, dL_drotation_raw, accumulate != 0, s);
+                                        dL_dmeans3D, dL_df_dc, dL_df_rest, dL_dscaling_raw, dL_drotation_raw, accumulate != 0, s, pair_cap(num_rendered));
 }
 
 // ---- fused multi-view paths (no host synchronisation inside) ----------------------------------------------------------------
@@ -407,7 +471,7 @@ static int check_step_args(const char* who, const c3d_gs_settings* views, int V,
     if (lanes < 1 || lanes > C3D_MAX_LANES) { c3d_set_error("%s: lanes must be in [1, %d]", who, C3D_MAX_LANES); return -1; }
     for (int v = 1; v < V; v++)
         if (views[v].image_width != views[0].image_width || views[v].image_height != views[0].image_height || views[v].sh_degree != views[0].sh_degree ||
-            views[v].sh_coeffs != views[0].sh_coeffs || views[v].scale_modifier != views[0].scale_modifier) { c3d_set_error("%s: all views must share resolution, sh_degree, sh_coeffs and scale_modifier", who); return -1; }
+            (views[v].sh_coeffs ? views[v].sh_coeffs : 16) != (views[0].sh_coeffs ? views[0].sh_coeffs : 16) || views[v].scale_modifier != views[0].scale_modifier) { c3d_set_error("%s: all views must share resolution, sh_degree, sh_coeffs and scale_modifier", who); return -1; }
     return 0;
 }
 // views per group when V views are spread over `lanes` groups in flight
@@ -440,7 +504,7 @@ int c3d_gs_train_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, c
     const bool dc_only = views[0].sh_coeffs == 1;      // degree-0 storage: there is no f_rest
     if (!means3D || !f_dc || (!f_rest && !dc_only) || !opacity_raw || !scaling_raw || !rotation_raw || !dL_dmeans3D || !dL_df_dc || (!dL_df_rest && !dc_only) || !dL_dopacity_raw ||
         !dL_dscaling_raw || !dL_drotation_raw) { c3d_set_error("c3d_gs_train_views_raw: NULL parameter / gradient pointer"); return -1; }
-    if ((uintptr_t)f_rest % 16 || (uintptr_t)dL_df_rest % 16 || (uintptr_t)rotation_raw % 16 || (uintptr_t)dL_drotation_raw % 16) { c3d_set_error("c3d_gs_train_views_raw: f_rest / rotation tensors must be 16-byte aligned"); return -1; }
+    if ((!dc_only && ((uintptr_t)f_rest % 16 || (uintptr_t)dL_df_rest % 16)) || (uintptr_t)rotation_raw % 16 || (uintptr_t)dL_drotation_raw % 16) { c3d_set_error("c3d_gs_train_views_raw: f_rest / rotation tensors must be 16-byte aligned"); return -1; }
     for (int v = 0; v < V; v++) if (!target_color[v]) { c3d_set_error("c3d_gs_train_views_raw: target_color[%d] is NULL", v); return -1; }
     StepWs w0; carve_step(nullptr, N, views[0].image_height, views[0].image_width, pair_capacity, w0);
     const size_t vs = w0.bytes;
@@ -511,7 +575,7 @@ int c3d_gs_step_param_backward_range(const c3d_gs_settings* views, int32_t V, in
     const bool dc_only = views[0].sh_coeffs == 1;
     if (!means3D || !f_dc || (!f_rest && !dc_only) || !scaling_raw || !rotation_raw || !dL_dmeans3D || !dL_df_dc || (!dL_df_rest && !dc_only) || !dL_dopacity_raw || !dL_dscaling_raw || !dL_drotation_raw) {
         c3d_set_error("c3d_gs_step_param_backward_range: NULL parameter / gradient pointer"); return -1; }
-    if ((uintptr_t)f_rest % 16 || (uintptr_t)dL_df_rest % 16 || (uintptr_t)rotation_raw % 16 || (uintptr_t)dL_drotation_raw % 16) { c3d_set_error("c3d_gs_step_param_backward_range: f_rest / rotation tensors must be 16-byte aligned"); return -1; }
+    if ((!dc_only && ((uintptr_t)f_rest % 16 || (uintptr_t)dL_df_rest % 16)) || (uintptr_t)rotation_raw % 16 || (uintptr_t)dL_drotation_raw % 16) { c3d_set_error("c3d_gs_step_param_backward_range: f_rest / rotation tensors must be 16-byte aligned"); return -1; }
     if (first < 0 || count < 0 || (first & 3) || (long long)first + count > N) { c3d_set_error("c3d_gs_step_param_backward_range: range [%d, %d + %d) must lie inside [0, N) and start at a multiple of 4", first, first, count); return -1; }
     StepWs w0; carve_step(nullptr, N, views[0].image_height, views[0].image_width, pair_capacity, w0);
     return step_a8_all_views(views, V, N, w0.bytes, workspace, pair_capacity, means3D, f_dc, f_rest, scaling_raw, rotation_raw, dL_dmeans3D, dL_df_dc, dL_df_rest,
@@ -528,7 +592,7 @@ static int views_forward(const char* who, const c3d_gs_settings* views, int32_t 
     if (!out_color || !out_alpha || !status) { c3d_set_error("%s: NULL pointer", who); return -1; }
     if (check_step_args(who, views, V, pair_capacity, lanes, workspace)) return -1;
     if (!means3D || !f_dc || (!f_rest && views[0].sh_coeffs != 1) || !opacity_raw || !scaling_raw || !rotation_raw) { c3d_set_error("%s: NULL parameter pointer", who); return -1; }
-    if ((uintptr_t)f_rest % 16 || (uintptr_t)rotation_raw % 16) { c3d_set_error("%s: f_rest / rotation tensors must be 16-byte aligned", who); return -1; }
+    if ((views[0].sh_coeffs != 1 && (uintptr_t)f_rest % 16) || (uintptr_t)rotation_raw % 16) { c3d_set_error("%s: f_rest / rotation tensors must be 16-byte aligned", who); return -1; }
     for (int v = 0; v < V; v++) if (!out_color[v] || !out_alpha[v]) { c3d_set_error("%s: output %d is NULL", who, v); return -1; }
     const bool fwd_only = !keep_state;       // c3d_gs_render_views_raw: slices without the backward pass's buffers (c3d_gs_render_workspace_bytes)
     StepWs w0; carve_step(nullptr, N, views[0].image_height, views[0].image_width, pair_capacity, w0, fwd_only);
@@ -592,7 +656,7 @@ int c3d_gs_backward_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N
     const bool dc_only = views[0].sh_coeffs == 1;
     if (!means3D || !f_dc || (!f_rest && !dc_only) || !scaling_raw || !rotation_raw || !dL_dmeans3D || !dL_df_dc || (!dL_df_rest && !dc_only) || !dL_dopacity_raw || !dL_dscaling_raw ||
         !dL_drotation_raw) { c3d_set_error("c3d_gs_backward_views_raw: NULL parameter / gradient pointer"); return -1; }
-    if ((uintptr_t)f_rest % 16 || (uintptr_t)dL_df_rest % 16 || (uintptr_t)rotation_raw % 16 || (uintptr_t)dL_drotation_raw % 16) { c3d_set_error("c3d_gs_backward_views_raw: f_rest / rotation tensors must be 16-byte aligned"); return -1; }
+    if ((!dc_only && ((uintptr_t)f_rest % 16 || (uintptr_t)dL_df_rest % 16)) || (uintptr_t)rotation_raw % 16 || (uintptr_t)dL_drotation_raw % 16) { c3d_set_error("c3d_gs_backward_views_raw: f_rest / rotation tensors must be 16-byte aligned"); return -1; }
     for (int v = 0; v < V; v++) if (!dL_dcolor[v]) { c3d_set_error("c3d_gs_backward_views_raw: dL_dcolor[%d] is NULL", v); return -1; }
     StepWs w0; carve_step(nullptr, N, views[0].image_height, views[0].image_width, pair_capacity, w0);
     const size_t vs = w0.bytes;
@@ -604,6 +668,12 @@ int c3d_gs_backward_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N
             const int v0 = k * G, g = (V - v0) < G ? (V - v0) : G;
             ViewGroup q;
             if ((rc_all = group_setup(q, views + v0, g, N, (char*)workspace + (size_t)v0 * vs, vs, pair_capacity, false))) break;
+            {   // the compositing kernel marks the pairs it writes a record for and expects the bytes clear: a call in between on these slices (or an earlier backward
+                // over different gradients) must not leave stale marks behind
+                C3dProfScope pz(C3D_P_OTHER, s);
+                const size_t off[1] = {(size_t)((char*)q.w[0].pvalid - q.slice0)}, bytes[1] = {((size_t)q.cap + 15) & ~(size_t)15};
+                if ((rc_all = c3d_zero_views(q.slice0, q.vs, q.G, off, bytes, 1, s))) break;
+            }
             GsBwdPix px{};
             bool depth = false;
             for (int i = 0; i < g; i++) {

@@ -13,8 +13,8 @@
 __device__ __forceinline__ uint32_t lds_scalar_address(const void* p) {   // LDS byte address (low half of the generic address) as a scalar, for M0
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)p);
 }
-// base = lds_scalar_address(tile), taken once per kernel.  M0 is not in the clobber list: the compiler reserves it and loads it itself in front of every
-// instruction of its own that reads it.  The s_nop 0 inside the block is the wait state the ISA demands between an SALU write of M0 and an LDS "add-TID" instruction
+// base = lds_scalar_address(tile), taken once per kernel.  M0 is in the clobber list (the backend merges / hoists identical M0 initialisations of its own and must
+// not assume an earlier value survives the block).  The s_nop 0 inside the block is the wait state the ISA demands between an SALU write of M0 and an LDS "add-TID" instruction
 // (the compiler's hazard recogniser does not look inside inline asm; without it the first store of a wave goes to whatever M0 held before).  ds_write_addtid_b32:
 // address = M0 + offset + 4 * lane -- no address VGPR, 2 LDS cycles per store against 4 for ds_write_b32.  LDS operations of one wave execute in order, so the reads
 // see this pair's stores and the next pair's stores come after them.
@@ -34,6 +34,9 @@ __device__ __forceinline__ int bwd_fold_slot(int k) {      // dword offset of va
     const int row = (int)((0x4431021320ull >> (4 * k)) & 15ull), half = (0x266 >> k) & 1;     // rows 0,2,3,1,2,0,1,3,4,4   halves 0,1,1,0,0,1,1,0,0,1  for k = 0..9
     return row * BWD_RED_ROW + 8 * half;
 }
+// (clang warns that M0 is a reserved register it will not save around the block -- which is what is wanted: the clobber only tells it the value is gone)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
 template <int NV>
 __device__ __forceinline__ float wave_reduce_fold(const float* tile /* [BWD_FOLD_ROWS][BWD_RED_ROW], wave-private */, uint32_t base, float (&v)[NV], int lane) {
     static_assert(NV == 9 || NV == 10, "nine values, ten with the depth channel");
@@ -52,7 +55,7 @@ __device__ __forceinline__ float wave_reduce_fold(const float* tile /* [BWD_FOLD
                      "ds_write_addtid_b32 %0 offset:0\n\t" "ds_write_addtid_b32 %1 offset:272\n\t" "ds_write_addtid_b32 %2 offset:544\n\t"
                      "ds_write_addtid_b32 %3 offset:816\n\t" "ds_write_addtid_b32 %4 offset:1088"
                      : "+v"(v[0]), "+v"(v[3]), "+v"(v[4]), "+v"(v[7]), "+v"(v[8])
-                     : "v"(v[5]), "v"(v[6]), "v"(v[1]), "v"(v[2]), "v"(v[NV - 1]), "s"(base) : "memory");
+                     : "v"(v[5]), "v"(v[6]), "v"(v[1]), "v"(v[2]), "v"(v[NV - 1]), "s"(base) : "memory", "m0");
     else
         asm volatile("s_nop 1\n\t"
                      "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t" "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
@@ -65,7 +68,7 @@ __device__ __forceinline__ float wave_reduce_fold(const float* tile /* [BWD_FOLD
                      "ds_write_addtid_b32 %0 offset:0\n\t" "ds_write_addtid_b32 %1 offset:272\n\t" "ds_write_addtid_b32 %2 offset:544\n\t"
                      "ds_write_addtid_b32 %3 offset:816\n\t" "ds_write_addtid_b32 %4 offset:1088"
                      : "+v"(v[0]), "+v"(v[3]), "+v"(v[4]), "+v"(v[7]), "+v"(v[8])
-                     : "v"(v[5]), "v"(v[6]), "v"(v[1]), "v"(v[2]), "s"(base) : "memory");
+                     : "v"(v[5]), "v"(v[6]), "v"(v[1]), "v"(v[2]), "s"(base) : "memory", "m0");
     const int k = min(lane >> 2, NV - 1), r = lane & 3;
     const float4* rp = reinterpret_cast<const float4*>(tile + bwd_fold_slot(k) + 16 * r);
     const float4 a = rp[0], b = rp[1];
@@ -80,6 +83,7 @@ __device__ __forceinline__ float wave_reduce_fold(const float* tile /* [BWD_FOLD
                  : "+v"(t));
     return t;                           // lanes 4k .. 4k+3 hold the wave's sum of value k (k < NV); lanes past 4 NV - 1 repeat value NV - 1
 }
+#pragma clang diagnostic pop
 
 // ------------------------------------------------------------------------------------------
 // A7 composite backward: a workgroup per 16x16 tile, wave w = its 8x8 quadrant w, one pixel per lane; the tile's list is visited back to front in rounds of
@@ -798,17 +802,17 @@ int gs_launch_preprocess_bwd_views(const GsParams& p0, const GsBwdViews& views, 
 int gs_launch_preprocess_bwd(const GsParams& p, const GsGeom& g, const int* radii, const float* means3D, const float* shs,
                              const float* colors_precomp, const float* scales, const float* rotations, const float* cov3D_precomp,
                              const float* pairgrad, const uint8_t* pvalid, float* dL_dmean2D, float* dL_dcolors, float* dL_dopacity,
-                             float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscales, float* dL_drots, hipStream_t s) {
+                             float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscales, float* dL_drots, hipStream_t s, uint32_t cap) {
     if (p.N == 0) return 0;
     const bool staged = shs && !colors_precomp && p.M == 16 && ((uintptr_t)shs % 16 == 0) && ((uintptr_t)dL_dsh % 16 == 0);
     if (staged)
         hipLaunchKernelGGL((k_preprocess_bwd<true, false, false>), dim3(c3d_cdiv(p.N, 256)), dim3(256), 256 * SH_ROW * sizeof(float), s, p, g, radii, means3D, shs,
                            (const float*)nullptr, colors_precomp, scales, rotations, cov3D_precomp, (const float4*)pairgrad, pvalid, dL_dmean2D, dL_dcolors, dL_dopacity,
-                           dL_dmeans3D, dL_dcov3D, dL_dsh, (float*)nullptr, dL_dscales, dL_drots, 0xFFFFFFFFu);
+                           dL_dmeans3D, dL_dcov3D, dL_dsh, (float*)nullptr, dL_dscales, dL_drots, cap);
     else
         hipLaunchKernelGGL((k_preprocess_bwd<false, false, false>), dim3(c3d_cdiv(p.N, 256)), dim3(256), 0, s, p, g, radii, means3D, shs,
                            (const float*)nullptr, colors_precomp, scales, rotations, cov3D_precomp, (const float4*)pairgrad, pvalid, dL_dmean2D, dL_dcolors, dL_dopacity,
-                           dL_dmeans3D, dL_dcov3D, dL_dsh, (float*)nullptr, dL_dscales, dL_drots, 0xFFFFFFFFu);
+                           dL_dmeans3D, dL_dcov3D, dL_dsh, (float*)nullptr, dL_dscales, dL_drots, cap);
     C3D_LAUNCH_CHECK();
     return 0;
 }

@@ -195,5 +195,5 @@ int gs_launch_composite_bwd(const GsParams& p, const GsGeom& g, const GsBinning&
 int gs_launch_preprocess_bwd(const GsParams& p, const GsGeom& g, const int* radii, const float* means3D, const float* shs,
                              const float* colors_precomp, const float* scales, const float* rotations, const float* cov3D_precomp,
                              const float* pairgrad, const uint8_t* pvalid, float* dL_dmean2D, float* dL_dcolors, float* dL_dopacity,
-                             float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscales, float* dL_drots, hipStream_t s);
+                             float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscales, float* dL_drots, hipStream_t s, uint32_t cap = 0xFFFFFFFFu);
 int gs_launch_mark_visible(int N, const float* means3D, const float* view, const float* proj, uint8_t* present, hipStream_t s);

@@ -13,7 +13,78 @@ import torch.nn as nn
 
 import c3d_hip as _h
 
-last_num_rendered = 0   # (tile, splat) pairs of the most recent forward -- bench/telemetry only
+last_num_rendered = 0   # (tile, splat) pairs of the most recent forward whose count has reached the host -- bench/telemetry only
+
+# ---- pair capacity: the forward pass without its host round trip -----------------------------------------------------------------------------------
+# The wheel sizes its binning buffer from the exact pair count and stalls the host for that one number on every call (so did rounds 1-4 here:
+# c3d_gs_forward_project).  Here the first call of a (device, N, H, W) shape takes that synchronous path and LEARNS the count; later calls of the shape go through
+# c3d_gs_forward_nosync with buffers and launches sized for a capacity 1.5 x above the largest count seen, the count stays on the device, and the two status words
+# of the call come back through pinned memory and are examined when a later call starts -- the host runs ahead of the GPU instead of waiting for it once per view.
+# A view that needs more pairs than the capacity is rendered incompletely (pairs beyond it are dropped); that is noticed one call late: a RuntimeWarning says so
+# and the capacity is regrown at once.  Counts drift slowly along a training run and between the cameras of an orbit, and the capacity follows them upwards as soon
+# as a call uses more than GROW_AT of it, so in practice only a jump of > 50 % between two consecutive calls of one shape can overflow.  sync_free(False) restores
+# the wheel's behaviour (exact count, one synchronisation per call) for callers that cannot accept that.
+import warnings
+
+_SYNC_FREE = True
+_GROW_AT, _HEADROOM = 0.6, 1.5
+_cap = {}        # (device index, N, H, W) -> pair capacity
+_pending = []    # [(event, pinned [2] int32, key, capacity)] status words on their way to the host, oldest first
+
+
+def sync_free(on=True):
+    """False: every forward takes the wheel's synchronous path (exact pair count read back per call).  Returns the previous setting."""
+    global _SYNC_FREE
+    prev, _SYNC_FREE = _SYNC_FREE, bool(on)
+    return prev
+
+
+def flush():
+    """wait for the status words of every sync-free forward call issued so far and examine them (warns / raises as described above); afterwards
+    last_num_rendered is the pair count of the most recent forward call"""
+    _examine(block=True)
+
+
+def _learn(key, seen):
+    """a pair count of this shape has reached the host: keep the capacity 1.5 x above the largest count seen"""
+    global last_num_rendered
+    last_num_rendered = int(seen)
+    cap = _cap.get(key, 0)
+    if seen > _GROW_AT * cap:
+        _cap[key] = min(int(seen * _HEADROOM) + (1 << 16), 0x3FFFFFF0)
+
+
+def _examine(block=False):
+    """look at the status words of earlier sync-free calls that have arrived (block: wait for all of them)"""
+    while _pending:
+        ev, pin, key, cap = _pending[0]
+        if not block and len(_pending) <= 16 and not ev.query():
+            break
+        ev.synchronize()
+        _pending.pop(0)
+        flags, seen = int(pin[0]), int(pin[1]) & 0xFFFFFFFF
+        if flags & 2:
+            raise RuntimeError("diff_gaussian_rasterization (MI355X): a chained-scan look-back of an earlier forward call timed out in the binning stage (device fault or a wedged workgroup)")
+        _learn(key, seen)
+        if flags & 1:
+            warnings.warn("diff_gaussian_rasterization (MI355X): an earlier sync-free forward call needed %d (tile, splat) pairs, its buffers held %d -- that image (and its "
+                          "gradient) is incomplete.  The capacity has been regrown; diff_gaussian_rasterization.sync_free(False) restores the exact synchronous path."
+                          % (seen, cap), RuntimeWarning, stacklevel=3)
+
+
+def _capacity_for(key):
+    """-> pair capacity for a sync-free forward of this shape, or None: take the synchronous path (and learn the count)"""
+    _examine()
+    return _cap.get(key) if _SYNC_FREE else None
+
+
+def _watch(status, key, cap, dev):
+    pin = torch.empty((2,), dtype=torch.int32).pin_memory()
+    pin.copy_(status, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev))
+    _pending.append((ev, pin, key, cap))
+
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -78,20 +149,30 @@ class _RasterizeGaussians(torch.autograd.Function):
             u8 = dict(dtype=torch.uint8, device=dev)
             radii = torch.empty((N,), dtype=torch.int32, device=dev)
             geom = torch.empty((lib.c3d_gs_geom_bytes(N),), **u8)
-            nr = C.c_int64(0)
-            _h.check(lib.c3d_gs_forward_project(C.byref(st), N, M, _h.ptr(means3D_c), _h.ptr(sh_c), _h.ptr(col_c), _h.ptr(op_c),
-                                                _h.ptr(sc_c), _h.ptr(rot_c), _h.ptr(cov_c), _h.ptr(radii), _h.ptr(geom),
-                                                C.byref(nr), s), "c3d_gs_forward_project")
-            num_rendered = int(nr.value)
-            global last_num_rendered
-            last_num_rendered = num_rendered
-            binning = torch.empty((lib.c3d_gs_binning_bytes(num_rendered, H, W),), **u8)
             img = torch.empty((lib.c3d_gs_image_bytes(H, W),), **u8)
             color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
             depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
             alpha = torch.empty((1, H, W), dtype=torch.float32, device=dev)
-            _h.check(lib.c3d_gs_forward_render(C.byref(st), N, M, _h.ptr(radii), _h.ptr(geom), num_rendered, _h.ptr(binning),
-                                               _h.ptr(img), _h.ptr(color), _h.ptr(depth), _h.ptr(alpha), s), "c3d_gs_forward_render")
+            key = (dev.index, N, H, W)
+            cap = _capacity_for(key) if (N > 0 and H > 0 and W > 0) else None
+            if cap is not None:      # sync-free: launches sized for the capacity, the pair count stays on the device (see _cap above)
+                num_rendered = cap
+                binning = torch.empty((lib.c3d_gs_binning_bytes(cap, H, W),), **u8)
+                status = torch.zeros((2,), dtype=torch.int32, device=dev)
+                _h.check(lib.c3d_gs_forward_nosync(C.byref(st), N, M, _h.ptr(means3D_c), _h.ptr(sh_c), _h.ptr(col_c), _h.ptr(op_c), _h.ptr(sc_c), _h.ptr(rot_c),
+                                                   _h.ptr(cov_c), _h.ptr(radii), _h.ptr(geom), cap, _h.ptr(binning), _h.ptr(img), _h.ptr(color), _h.ptr(depth),
+                                                   _h.ptr(alpha), _h.ptr(status), s), "c3d_gs_forward_nosync")
+                _watch(status, key, cap, dev)
+            else:
+                nr = C.c_int64(0)
+                _h.check(lib.c3d_gs_forward_project(C.byref(st), N, M, _h.ptr(means3D_c), _h.ptr(sh_c), _h.ptr(col_c), _h.ptr(op_c),
+                                                    _h.ptr(sc_c), _h.ptr(rot_c), _h.ptr(cov_c), _h.ptr(radii), _h.ptr(geom),
+                                                    C.byref(nr), s), "c3d_gs_forward_project")
+                num_rendered = int(nr.value)
+                _learn(key, num_rendered)
+                binning = torch.empty((lib.c3d_gs_binning_bytes(num_rendered, H, W),), **u8)
+                _h.check(lib.c3d_gs_forward_render(C.byref(st), N, M, _h.ptr(radii), _h.ptr(geom), num_rendered, _h.ptr(binning),
+                                                   _h.ptr(img), _h.ptr(color), _h.ptr(depth), _h.ptr(alpha), s), "c3d_gs_forward_render")
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.sizes = (N, M)
@@ -160,19 +241,28 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
             u8 = dict(dtype=torch.uint8, device=dev)
             radii = torch.empty((N,), dtype=torch.int32, device=dev)
             geom = torch.empty((lib.c3d_gs_geom_bytes(N),), **u8)
-            nr = C.c_int64(0)
-            _h.check(lib.c3d_gs_forward_project_raw(C.byref(st), N, *[_h.ptr(x) for x in t], _h.ptr(radii), _h.ptr(geom), C.byref(nr), s),
-                     "c3d_gs_forward_project_raw")
-            num_rendered = int(nr.value)
-            global last_num_rendered
-            last_num_rendered = num_rendered
-            binning = torch.empty((lib.c3d_gs_binning_bytes(num_rendered, H, W),), **u8)
             img = torch.empty((lib.c3d_gs_image_bytes(H, W),), **u8)
             color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
             depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
             alpha = torch.empty((1, H, W), dtype=torch.float32, device=dev)
-            _h.check(lib.c3d_gs_forward_render(C.byref(st), N, K, _h.ptr(radii), _h.ptr(geom), num_rendered, _h.ptr(binning), _h.ptr(img),
-                                               _h.ptr(color), _h.ptr(depth), _h.ptr(alpha), s), "c3d_gs_forward_render")
+            key = (dev.index, N, H, W)
+            cap = _capacity_for(key) if (N > 0 and H > 0 and W > 0) else None
+            if cap is not None:      # sync-free (see _cap above)
+                num_rendered = cap
+                binning = torch.empty((lib.c3d_gs_binning_bytes(cap, H, W),), **u8)
+                status = torch.zeros((2,), dtype=torch.int32, device=dev)
+                _h.check(lib.c3d_gs_forward_raw_nosync(C.byref(st), N, *[_h.ptr(x) for x in t], _h.ptr(radii), _h.ptr(geom), cap, _h.ptr(binning), _h.ptr(img),
+                                                       _h.ptr(color), _h.ptr(depth), _h.ptr(alpha), _h.ptr(status), s), "c3d_gs_forward_raw_nosync")
+                _watch(status, key, cap, dev)
+            else:
+                nr = C.c_int64(0)
+                _h.check(lib.c3d_gs_forward_project_raw(C.byref(st), N, *[_h.ptr(x) for x in t], _h.ptr(radii), _h.ptr(geom), C.byref(nr), s),
+                         "c3d_gs_forward_project_raw")
+                num_rendered = int(nr.value)
+                _learn(key, num_rendered)
+                binning = torch.empty((lib.c3d_gs_binning_bytes(num_rendered, H, W),), **u8)
+                _h.check(lib.c3d_gs_forward_render(C.byref(st), N, K, _h.ptr(radii), _h.ptr(geom), num_rendered, _h.ptr(binning), _h.ptr(img),
+                                                   _h.ptr(color), _h.ptr(depth), _h.ptr(alpha), s), "c3d_gs_forward_render")
         ctx.raster_settings, ctx.num_rendered, ctx.N, ctx.K = rs, num_rendered, N, K
         e = torch.empty(0, device=dev)
         ctx.save_for_backward(*(x if x is not None else e for x in t), radii, geom, binning, img)

@@ -94,10 +94,22 @@ int c3d_gs_forward_render(const c3d_gs_settings* st, int32_t N, int32_t M, const
                           int64_t num_rendered, void* binning_buffer, void* image_buffer, float* out_color,
                           float* out_depth, float* out_alpha, c3d_stream_t stream);
 
+/* Forward in ONE call without host synchronisation (ABI 500): parts 1 + 2 with every launch sized for `pair_capacity` (tile, splat) pairs instead of the exact
+ * count -- the count stays on the device, so the rasterizer call of main_3DGS_renderer.py:927-936 (and of LGM core/gs.py:27-80, TRELLIS gaussian_render.py:62-130)
+ * no longer stalls the host once per view.  binning_buffer: c3d_gs_binning_bytes(pair_capacity, H, W) bytes.  status (DEVICE, two words, zero on entry): [0] bit 0 =
+ * the view needed more pairs than pair_capacity (the outputs are then incomplete: render again with a larger capacity), bit 1 = a bounded inter-workgroup wait timed
+ * out (device fault); [1] = the pair count.  The caller reads them whenever it likes (the Python boundary: asynchronously, one call late).  A backward call on this
+ * state passes num_rendered = pair_capacity and scratch of c3d_gs_backward_scratch_bytes(N, pair_capacity).  N > 0 and a non-empty image only. */
+int c3d_gs_forward_nosync(const c3d_gs_settings* st, int32_t N, int32_t M, const float* means3D, const float* shs, const float* colors_precomp,
+                          const float* opacities, const float* scales, const float* rotations, const float* cov3D_precomp, int32_t* radii,
+                          void* geom_buffer, int64_t pair_capacity, void* binning_buffer, void* image_buffer, float* out_color, float* out_depth,
+                          float* out_alpha, uint32_t* status /* device [2] */, c3d_stream_t stream);
+
 /* Backward (A7 + A8).  Pixel gradients dL_dcolor[3,H,W], dL_ddepth[1,H,W] (may be NULL),
  * dL_dalpha[1,H,W] (may be NULL).  Outputs (all written in full by the library, no pre-zeroing needed):
  * dL_dmeans2D[N,3] dL_dcolors[N,3] dL_dopacity[N,1] dL_dmeans3D[N,3] dL_dcov3D[N,6] dL_dsh[N,M,3]
- * dL_dscales[N,3] dL_drotations[N,4].  scratch: c3d_gs_backward_scratch_bytes(N, num_rendered) bytes (one 48-byte gradient
+ * dL_dscales[N,3] dL_drotations[N,4].  num_rendered: the pair count the state buffers were sized for (the exact count of c3d_gs_forward_project, or the
+ * pair_capacity of c3d_gs_forward_nosync); no record beyond it is read or written.  scratch: c3d_gs_backward_scratch_bytes(N, num_rendered) bytes (one 48-byte gradient
  * record per (tile, splat) pair + one "record written" byte per pair; the backward pass uses no atomics and is bit-reproducible). */
 int c3d_gs_backward(const c3d_gs_settings* st, int32_t N, int32_t M, const float* means3D, const float* shs,
                     const float* colors_precomp, const float* scales, const float* rotations,
@@ -117,6 +129,11 @@ int c3d_gs_backward(const c3d_gs_settings* st, int32_t N, int32_t M, const float
 int c3d_gs_forward_project_raw(const c3d_gs_settings* st, int32_t N, const float* means3D, const float* f_dc, const float* f_rest,
                                const float* opacity_raw, const float* scaling_raw, const float* rotation_raw, int32_t* radii,
                                void* geom_buffer, int64_t* num_rendered /* host */, c3d_stream_t stream);
+/* c3d_gs_forward_nosync for the raw parameters */
+int c3d_gs_forward_raw_nosync(const c3d_gs_settings* st, int32_t N, const float* means3D, const float* f_dc, const float* f_rest,
+                              const float* opacity_raw, const float* scaling_raw, const float* rotation_raw, int32_t* radii, void* geom_buffer,
+                              int64_t pair_capacity, void* binning_buffer, void* image_buffer, float* out_color, float* out_depth, float* out_alpha,
+                              uint32_t* status /* device [2] */, c3d_stream_t stream);
 int c3d_gs_backward_raw(const c3d_gs_settings* st, int32_t N, const float* means3D, const float* f_dc, const float* f_rest,
                         const float* scaling_raw, const float* rotation_raw, const int32_t* radii, const void* geom_buffer,
                         int64_t num_rendered, const void* binning_buffer, const void* image_buffer, const float* dL_dcolor,
@@ -137,11 +154,14 @@ int c3d_gs_backward_raw(const c3d_gs_settings* st, int32_t N, const float* means
  * target_color / target_alpha / color_mask: HOST arrays of V device pointers ([3,H,W] / [1,H,W] / [1,H,W]); target_alpha and color_mask may be
  * NULL.  With color_mask the colour terms compare (C * mask) with (Ct * mask), the reference's masked loss (main_3DGS.py:169-186). */
 typedef struct c3d_gs_loss { float w_l1; float w_l2; float w_alpha_mse; float scale; float w_ssim; } c3d_gs_loss;
-/* The workspace holds one slice per view (state of every view stays alive until the single per-Gaussian backward pass at the end).
- * lanes (1..8): the V views are dealt round-robin onto `lanes` HIP streams (lane 0 = `stream`; the others are library-owned, forked from and
- * joined back into `stream` with events, so the call keeps stream semantics) -- the latency-bound sort/scan chain of one view then runs underneath
- * the compositing kernels of another.  After the join ONE kernel walks the Gaussians, sums each view's (tile, splat) gradient records in a fixed
- * order and writes every parameter gradient once: results are bit-reproducible and independent of `lanes`.
+/* The workspace holds one slice per view (state of every view stays alive until the single per-Gaussian backward pass at the end), followed -- when
+ * loss->w_ssim != 0 -- by one MS-SSIM share per view; c3d_gs_step_workspace_bytes counts both.
+ * lanes (1..8) = the number of view GROUPS the V views are split into (ABI 400): G = ceil(V / lanes) views, at most 16, go through every stage of the chain
+ * together -- ONE launch per stage with the view as a grid dimension (projection with the parameters read once for the group, one clear of all state blocks, scan,
+ * depth sort, scan, emit, tile sort, ranges, compositing forward, pixel loss + compositing backward, loss sums) -- and the groups follow each other on the
+ * caller's `stream`.  The library creates no streams or events of its own; lanes = 1 (all views of a step in one group) is what bench.py and the trainer use.
+ * After the last group ONE pass walks the Gaussians, sums each view's (tile, splat) gradient records in a fixed order and writes every parameter gradient
+ * once: results are bit-reproducible and independent of `lanes`.
  * accumulate bit 0: add to the contents of the gradient buffers; clear: overwrite them (no zero-fill needed).
  * accumulate bit 1 (value 2): stop after the per-view passes -- the per-(tile, splat) records of all views are then in the workspace and the caller
  * runs the per-Gaussian pass itself with c3d_gs_step_param_backward_range, one Gaussian range after the other, e.g. to start the gradient
@@ -162,13 +182,13 @@ int c3d_gs_step_param_backward_range(const c3d_gs_settings* views /* host [V] */
                                      int32_t accumulate, void* workspace, int32_t first, int32_t count, c3d_stream_t stream);
 
 /* Forward only, V views of the same cloud in one call (orbit rendering of a trained model: the per-camera loop of the reference's
- * orbit-renderer node over GaussianSplattingRenderer.render, main_3DGS_renderer.py:927-936), raw parameters, no host synchronisation,
- * views dealt onto `lanes` streams as above.  HOST arrays of V device pointers: out_color [3,H,W], out_depth [1,H,W], out_alpha [1,H,W];
- * out_radii (array or entries may be NULL) [N] int32.  workspace_bytes says what the workspace holds (ABI 202): with
- * c3d_gs_render_workspace_bytes(N, H, W, pair_capacity, 2 * lanes) bytes -- two FORWARD-ONLY slices per lane (ABI 301: two fifths of a training slice, no gradient
- * records / loss buffers; a buffer sized with c3d_gs_step_workspace_bytes is simply larger than needed) -- the views go in groups of `lanes`, and while the lanes bin
- * and composite group k a projection stream already fills the other slice set with groups k + 1 / k + 2 (one pass over the parameters per group instead
- * of one per view); with one slice per lane every view is projected by its own launch; less is an error.  status as for c3d_gs_train_views_raw: on overflow the images of the affected views are incomplete. */
+ * orbit-renderer node over GaussianSplattingRenderer.render, main_3DGS_renderer.py:927-936), raw parameters, no host synchronisation, everything on the
+ * caller's `stream`.  HOST arrays of V device pointers: out_color [3,H,W], out_depth [1,H,W], out_alpha [1,H,W]; out_radii (array or entries may be NULL) [N] int32.
+ * The workspace holds FORWARD-ONLY slices (two fifths of a training slice: no gradient records / loss buffers; c3d_gs_render_workspace_bytes(N, H, W,
+ * pair_capacity, slices)), and workspace_bytes says how many: the views go through the chain in groups of min(ceil(V / lanes), slices, 16) views -- one launch
+ * per stage and group, the parameters read once per group -- and every group reuses the same slices (stream order keeps that safe).  So the slice count, not
+ * `lanes`, bounds the group width: for a 64-camera orbit pass lanes = 4 and 16 slices (4.5 GB at the BASELINE size); one slice renders view by view; less than
+ * one slice is an error.  status as for c3d_gs_train_views_raw: on overflow the images of the affected views are incomplete. */
 size_t c3d_gs_render_workspace_bytes(int32_t N, int32_t image_height, int32_t image_width, int64_t pair_capacity, int32_t slices);
 int c3d_gs_render_views_raw(const c3d_gs_settings* views /* host [V] */, int32_t V, int32_t N, const float* means3D, const float* f_dc,
                             const float* f_rest, const float* opacity_raw, const float* scaling_raw, const float* rotation_raw,
@@ -178,14 +198,16 @@ int c3d_gs_render_views_raw(const c3d_gs_settings* views /* host [V] */, int32_t
 
 /* ---- the same step split at the image (round 2): any loss torch can differentiate --------------------------------------------
  * The reference's default loss adds 0.2 * (1 - MS-SSIM) to the L1 / alpha-MSE terms and draws a white or black background per view
- * (main_3DGS.py:184-192, camera_utils.py:246-249; node defaults nodes.py:1177,1181).  MS-SSIM stays a torch op; so that the
+ * (main_3DGS.py:184-192, camera_utils.py:246-249; node defaults nodes.py:1177,1181).  Any loss torch can differentiate (a perceptual term, a different MS-SSIM) stays a torch op; so that the
  * rasterizer side of such a step is still ONE sync-free call per direction, the fused step is also offered in two halves:
  *   c3d_gs_forward_views_raw   = c3d_gs_render_views_raw, but view v keeps its state in workspace slice v
- *                                (c3d_gs_step_workspace_bytes(N, H, W, pair_capacity, V)); every view has its own settings, incl. bg
+ *                                (c3d_gs_step_workspace_bytes(N, H, W, pair_capacity, V)); every view has its own settings, incl. bg;
+ *                                groups of ceil(V / lanes) <= 16 views per launch as in c3d_gs_train_views_raw
  *   c3d_gs_backward_views_raw  = the backward half of c3d_gs_train_views_raw for caller-supplied image gradients: HOST arrays of V
  *                                device pointers dL_dcolor [3,H,W] (w.r.t. the UNclamped colour output), dL_ddepth [1,H,W] and
  *                                dL_dalpha [1,H,W] (either array, or entries of it, may be NULL = zero).  Must follow a
- *                                c3d_gs_forward_views_raw call with the same views / N / pair_capacity / workspace whose status was clean.
+ *                                c3d_gs_forward_views_raw call with the same views / N / pair_capacity / workspace whose status was clean, with
+ *                                no other call on those workspace slices in between (it may be repeated: every call clears the "record written" bytes itself).
  * c3d_gs_step_read_view serves both.  out_depth (array or entries) may be NULL here. */
 int c3d_gs_forward_views_raw(const c3d_gs_settings* views /* host [V] */, int32_t V, int32_t N, const float* means3D, const float* f_dc,
                              const float* f_rest, const float* opacity_raw, const float* scaling_raw, const float* rotation_raw,

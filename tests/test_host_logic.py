@@ -55,6 +55,26 @@ def test_gaussian_model_groups_and_lr_schedule():
     assert math.isclose(g.update_learning_rate(15000), math.sqrt(1.6e-3 * 1.6e-5), rel_tol=1e-6)
 
 
+def test_raw_storage_guard_sends_unsupported_sh_storage_down_the_per_view_path():
+    """render() / render_views / render_all_pose take the raw-parameter kernels only for SH storage they can read (degree 0-3, K in 1/4/9/16, K >= (active + 1)^2)"""
+    from MVs_Algorithms.GaussianSplatting.main_3DGS_renderer import GaussianSplattingRenderer
+    np.random.seed(0)
+    for deg, ok in ((0, True), (1, True), (3, True), (4, False)):
+        r = GaussianSplattingRenderer(sh_degree=deg, device="cpu")
+        r.initialize(None, num_pts=50)
+        assert r.raw_storage_ok() is ok, deg
+    r = GaussianSplattingRenderer(sh_degree=3, device="cpu")
+    r.initialize(None, num_pts=50)
+    g = r.gaussians
+    g._features_rest = torch.nn.Parameter(g._features_rest.data[:, :5].contiguous())      # six coefficients per channel: no kernel instance reads that
+    assert not r.raw_storage_ok()
+    g._features_rest = torch.nn.Parameter(g._features_rest.data[:, :3].contiguous())      # a degree-1 PLY in a degree-3 renderer: fine while the active degree fits
+    g.active_sh_degree = 1
+    assert r.raw_storage_ok()
+    g.active_sh_degree = 2
+    assert not r.raw_storage_ok()
+
+
 def test_ms_ssim_properties():
     from shared_utils.msssim import MS_SSIM
     torch.manual_seed(0)
