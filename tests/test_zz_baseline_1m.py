@@ -19,6 +19,10 @@ with the float64 build of oracle/gs_oracle.c:
       gs_oracle_taint) or fragile themselves are "tainted"; the test prints how the rows beyond TAIL x the element-wise tolerance split between tainted
       and untainted Gaussians, holds the untainted ones to a hard bound, and replaces the old `hard = 1e9` by numbers.
 
+  (e) round 5: the float32 build of the oracle runs the same eight views forward AND backward through the same loss; its gradients against the float64 build's
+      are printed beside the kernel's (relative L2, max-norm, tail rows and how many of them the two tails share), and the kernel's max-norm / relative-L2 error
+      must stay within 1.5 x the float32 oracle's own: the tail is what float32 does to this algorithm, not what this implementation adds.
+
 Reference call sites: /root/reference/MVs_Algorithms/GaussianSplatting/main_3DGS.py:158-207 (the training step), shared_utils/camera_utils.py:253-274
 (the orbit loop).  The oracle takes ~3.5 s per view (forward + backward) on the GPU box's host cores."""
 import os
@@ -89,6 +93,7 @@ def full(oracle_built):
     tas = [rng.uniform(size=(1, H, W)).astype(np.float32) for _ in range(V)]
     out = dict(views=[], raw=raw)
     og_sum = None
+    og32_sum = None
     og_full = None
     loss_sum, loss_full = 0.0, 0.0
     tainted = np.zeros((N,), bool)
@@ -97,11 +102,18 @@ def full(oracle_built):
     for v in range(V):
         oc, orad, od, oa, ost = oracle_forward(act, sts[v], dtype=np.float64, nthreads=nt)
         # the oracle against itself: which decisions does float32 take differently?
-        _, orad32, _, _, ost32 = oracle_forward(act, sts[v], dtype=np.float32, nthreads=nt)
+        oc32, orad32, _, oa32, ost32 = oracle_forward(act, sts[v], dtype=np.float32, nthreads=nt)
         flags32 = ost32.image_state()["n_contrib"].reshape(H, W) != ost.image_state()["n_contrib"].reshape(H, W)
         g32, g64 = ost32.geometry(), ost.geometry()
         frag_g = (orad32 != orad) | ((g32["rgb"] == 0) != (g64["rgb"] == 0)).any(1) | (g32["tiles_touched"] != g64["tiles_touched"])
-        del ost32, g32, g64
+        # (e) the float32 build of the SAME oracle through the SAME loss, backward included (VERDICT r4, next-round 4 i): what a float32 rasterizer of this
+        # algorithm -- the reference's CUDA kernels are float32 too -- leaves against float64, measured instead of argued.  Its loss gradient comes from its own
+        # float32 image, as the kernel's does; the per-view gradients are summed in float64 (the kernel sums them in float32: the comparison favours the oracle).
+        _, dC32, dA32 = _pixel_loss(oc32.astype(np.float64), oa32[0].astype(np.float64), tcs[v].astype(np.float64), tas[v][0].astype(np.float64), 1.0 / V, 0.8, 3.0)
+        og32 = O.backward(ost32, dC32.astype(np.float32), None, dA32.astype(np.float32), nthreads=nt)
+        og32 = {k: np.asarray(og32[k], np.float64) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+        og32_sum = og32 if og32_sum is None else {k: og32_sum[k] + og32[k] for k in og32}
+        del ost32, g32, g64, og32
         flags = (np.abs(alpha[v, 0] - oa[0]) > ALPHA_FLIP) | (np.abs(color[v] - oc).max(0) > COLOR_FLIP)
         # ... and the LOSS has kinks of its own: |clamp(C) - t| at C = t, and render()'s clamp at 0 and 1.  A pixel within rounding of one of them gets the
         # other one-sided derivative in float32 (with random targets ~1e-6 of the pixel-channels: a hundred per 8 views)
@@ -132,7 +144,8 @@ def full(oracle_built):
             ogf = {k: ogf[k] for k in ("means3D", "opacities", "shs", "scales", "rotations")}
             og_full = ogf if og_full is None else {k: og_full[k] + ogf[k] for k in ogf}
         del ost
-    out.update(ref=_chain_to_raw(og_sum, raw), ref_full=_chain_to_raw(og_full, raw), loss_ref=loss_sum, loss_full_ref=loss_full, tainted=tainted)
+    out.update(ref=_chain_to_raw(og_sum, raw), ref_full=_chain_to_raw(og_full, raw), loss_ref=loss_sum, loss_full_ref=loss_full, tainted=tainted,
+               ref32=_chain_to_raw(og32_sum, raw))
     # ---- (a) the benched call: c3d_gs_train_views_raw, loss "0.8 L1 + 3 MSE(alpha)" as bench.py's default line, 8 views
     tcd, tad = [dev(t) for t in tcs], [dev(t) for t in tas]
     for lanes in (4, 1):
@@ -159,7 +172,10 @@ def test_render_views_raw_matches_oracle_on_eight_cameras(full):
         assert r["flagged"] <= 2e-3 * W * H, r
 
 
-def _check(name, loss, loss_ref, grads, ref, tainted):
+F32_SLACK = 1.5      # the kernel's max-norm error against float64 may exceed the float32 ORACLE's own by this factor at most (+ 1e-5 of the tensor's scale)
+
+
+def _check(name, loss, loss_ref, grads, ref, tainted, ref32=None):
     print("[1M %s] loss %.8f vs float64 oracle %.8f; %d of %d Gaussians are blended into a pixel with a flipped float32/float64 decision" % (name, loss, loss_ref, int(tainted.sum()), N))
     assert abs(loss - loss_ref) <= 2e-5 * max(1.0, abs(loss_ref))
     for k, g in zip(RAW_NAMES, grads):
@@ -174,6 +190,17 @@ def _check(name, loss, loss_ref, grads, ref, tainted):
         frac_un = float((ratio[~tainted] > 1.0).mean()) if (~tainted).any() else 0.0
         print("[1M %s] %-8s relL2 %.2e, outside tol %.2e of entries (worst %.0f x), max-norm %.2e | rows beyond %g x tol: %d, of them tainted: %d | untainted Gaussians: worst %.1f x tol, %.2e outside"
               % (name, k, r["rel_l2"], r["frac_viol"], r["worst"], r["max_norm"], TAIL, int(bad_rows.sum()), int((bad_rows & tainted).sum()), r_un, frac_un))
+        if ref32 is not None:      # the float32 build of the oracle against its float64 build, same metric, side by side
+            o32 = np.asarray(ref32[k], np.float64).reshape(N, -1)
+            r32 = grad_report(o32, want)
+            ratio32 = np.abs(o32 - want) / tol
+            bad32 = (ratio32 > TAIL).any(1)
+            both = int((bad_rows & bad32).sum())
+            print("[1M %s] %-8s   float32 ORACLE vs float64: relL2 %.2e, outside tol %.2e (worst %.0f x), max-norm %.2e, rows beyond %g x tol: %d (%d of them also in the kernel's tail) | kernel / float32-oracle: relL2 %.2f x, max-norm %.2f x"
+                  % (name, k, r32["rel_l2"], r32["frac_viol"], r32["worst"], r32["max_norm"], TAIL, int(bad32.sum()), both,
+                     r["rel_l2"] / max(r32["rel_l2"], 1e-30), r["max_norm"] / max(r32["max_norm"], 1e-30)))
+            assert r["max_norm"] <= F32_SLACK * r32["max_norm"] + 1e-5, (k, r["max_norm"], r32["max_norm"])
+            assert r["rel_l2"] <= F32_SLACK * r32["rel_l2"] + 1e-5, (k, r["rel_l2"], r32["rel_l2"])
         assert r["rel_l2"] <= 1e-3, (k, r)
         assert r["frac_viol"] <= 3e-3, (k, r)
         assert r["worst"] <= HARD, (k, r)
@@ -186,7 +213,7 @@ def _check(name, loss, loss_ref, grads, ref, tainted):
 @pytest.mark.parametrize("lanes", [4, 1])
 def test_train_views_raw_gradients_match_sum_of_float64_oracle_views(full, lanes):
     loss, grads = full["step%d" % lanes]
-    _check("train_views lanes %d" % lanes, loss, full["loss_ref"], grads, full["ref"], full["tainted"])
+    _check("train_views lanes %d" % lanes, loss, full["loss_ref"], grads, full["ref"], full["tainted"], full["ref32"])
 
 
 def test_train_views_raw_full_loss_with_msssim_matches_oracle_plus_torch(full):
