@@ -68,6 +68,8 @@ def parse():
     ap.add_argument("--lanes", type=int, default=0, help="view GROUPS a fused call splits its views into (ceil(views / lanes) views per launch of every stage, the groups one after the "
                                                        "other on the same stream; the library owns no streams); 0 = 1: all views of the step through every stage in ONE launch each, in every mode")
     ap.add_argument("--group", type=int, default=16, help="--mode fwd: views per launch of every stage (<= 16)")
+    ap.add_argument("--sync-free", choices=["on", "off"], default="on", help="--render-path boundary | fused | accessor: the drop-in rasterizer call without its host round trip "
+                                                                             "(diff_gaussian_rasterization.sync_free; off = the wheel's behaviour: the pair count read back once per view)")
     ap.add_argument("--render-path", choices=["step", "fused", "accessor", "boundary"], default="step",
                     help="step: c3d_gs_train_views_raw, all views of the step forward+loss+backward in one sync-free library call (product default for training); fused: GaussianSplattingRenderer.render with activations folded into the kernels (product default); accessor: the same "
                          "API through the reference's op-by-op accessors; boundary: bare diff_gaussian_rasterization call on pre-activated leaves")
@@ -445,6 +447,7 @@ def main():
 
     if a.lanes <= 0:
         a.lanes = 1
+    dgr.sync_free(a.sync_free == "on")
     N, W, H, deg = a.gaussians, a.width, a.height, a.sh_degree
     K, P = (deg + 1) ** 2, a.width * a.height
     use_renderer = a.render_path != "boundary"
@@ -629,6 +632,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
+    t_enqueue = time.perf_counter() - t0      # the host's share: everything enqueued, nothing waited for (per-view paths: is the loop host-bound?)
     sync()
     dt = time.perf_counter() - t0
     prof = c3d_hip.prof_read() if a.timed_prof == "on" else {}
@@ -864,7 +868,8 @@ def main():
                        "exchange_chunks": (a.exchange_chunks if dist_on and a.mode != "fwd" and a.exchange == "allreduce" and fused_step is not None else 1), "render_path": a.render_path,
                        "loss": (None if a.mode == "fwd" else ("0.8 L1 + 3 MSE(alpha) + 0.2 (1 - MS-SSIM), masked (BASELINE config 3)%s" % (", MS-SSIM by torch ops" if ms_ssim is not None else ", fused HIP")
                                                                 if loss_kind != "l1alpha" and a.render_path == "step" else "0.8 L1 + 3 MSE(alpha)")), "view_lanes": (a.lanes if a.render_path == "step" else 1),
-                       "host_enqueue_ms_per_step": (round(fused_step.last_host_ms, 3) if fused_step is not None else None),
+                       "host_enqueue_ms_per_step": (round(fused_step.last_host_ms, 3) if fused_step is not None else round(t_enqueue / a.steps * 1e3, 3)),
+                       "sync_free_drop_in": (a.sync_free == "on") if a.render_path != "step" else None,
                        "defer_status": (fused_step.defer_status if fused_step is not None else None),
                        "gpu_span_ms_last_step": (round(getattr(fused_step, "last_gpu_ms", 0.0), 3) if fused_step is not None else None),
                        "n_visible": n_vis, "tile_splat_pairs": D},

@@ -203,7 +203,7 @@ int c3d_gs_forward_render(const c3d_gs_settings* st, int32_t N, int32_t M, const
 
 // A2-A6 of ONE view without the host: launches sized for `cap` pairs, the pair count read from g.meta[0] on the device (what the multi-view paths do per group)
 static int forward_tail_nosync(const GsParams& p, GsGeom& g, int N, int64_t pair_capacity, void* binning_buffer, void* image_buffer, float* out_color, float* out_depth,
-                               float* out_alpha, uint32_t* status, hipStream_t s) {
+                               float* out_alpha, uint32_t* status, uint32_t* status_host, hipStream_t s) {
     const int tiles = p.gx * p.gy;
     const uint32_t cap = (uint32_t)pair_capacity;
     GsBinning b;
@@ -211,12 +211,16 @@ static int forward_tail_nosync(const GsParams& p, GsGeom& g, int N, int64_t pair
     GsImage im;
     gs_carve_image((char*)image_buffer, p.W, p.H, im);
     int rc, res = 0;
+    C3D_CHECK(hipMemsetAsync(status, 0, 2 * sizeof(uint32_t), s));
     if ((rc = binning_front(g, N, cap, status, s))) return rc;
     if ((rc = binning_back(p, g, b, pair_capacity, cap, (const uint32_t*)g.meta, status, s, &res))) return rc;
-    C3dProfScope ps(C3D_P_COMPOSITE_FWD, s);
-    GsFwdViews vp{};
-    vp.bg[0] = p.bg; vp.color[0] = out_color; vp.depth[0] = out_depth; vp.alpha[0] = out_alpha;
-    return gs_launch_composite_fwd(p, g, b, res, im, vp, 1, 0, true, s);
+    { C3dProfScope ps(C3D_P_COMPOSITE_FWD, s);
+      GsFwdViews vp{};
+      vp.bg[0] = p.bg; vp.color[0] = out_color; vp.depth[0] = out_depth; vp.alpha[0] = out_alpha;
+      if ((rc = gs_launch_composite_fwd(p, g, b, res, im, vp, 1, 0, true, s))) return rc; }
+    // the status words are final once the tile sort has run; the copy rides behind the compositing launch in stream order and is nobody's critical path
+    if (status_host) C3D_CHECK(hipMemcpyAsync(status_host, status, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    return 0;
 }
 static int check_nosync_args(const char* who, int64_t pair_capacity, const void* radii, const void* geom_buffer, const void* binning_buffer, const void* image_buffer,
                              const float* out_color, const float* out_depth, const float* out_alpha, const uint32_t* status) {
@@ -227,7 +231,8 @@ static int check_nosync_args(const char* who, int64_t pair_capacity, const void*
 
 int c3d_gs_forward_nosync(const c3d_gs_settings* st, int32_t N, int32_t M, const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
                           const float* scales, const float* rotations, const float* cov3D_precomp, int32_t* radii, void* geom_buffer, int64_t pair_capacity,
-                          void* binning_buffer, void* image_buffer, float* out_color, float* out_depth, float* out_alpha, uint32_t* status, c3d_stream_t stream) {
+                          void* binning_buffer, void* image_buffer, float* out_color, float* out_depth, float* out_alpha, uint32_t* status, uint32_t* status_host,
+                          c3d_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     GsParams p;
     if (make_params(st, N, M, p)) return -1;
@@ -240,12 +245,12 @@ int c3d_gs_forward_nosync(const c3d_gs_settings* st, int32_t N, int32_t M, const
     int rc;
     { C3dProfScope ps(C3D_P_PREPROCESS, s);
     if ((rc = gs_launch_preprocess(p, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, radii, s))) return rc; }
-    return forward_tail_nosync(p, g, N, pair_capacity, binning_buffer, image_buffer, out_color, out_depth, out_alpha, status, s);
+    return forward_tail_nosync(p, g, N, pair_capacity, binning_buffer, image_buffer, out_color, out_depth, out_alpha, status, status_host, s);
 }
 
 int c3d_gs_forward_raw_nosync(const c3d_gs_settings* st, int32_t N, const float* means3D, const float* f_dc, const float* f_rest, const float* opacity_raw,
                               const float* scaling_raw, const float* rotation_raw, int32_t* radii, void* geom_buffer, int64_t pair_capacity, void* binning_buffer,
-                              void* image_buffer, float* out_color, float* out_depth, float* out_alpha, uint32_t* status, c3d_stream_t stream) {
+                              void* image_buffer, float* out_color, float* out_depth, float* out_alpha, uint32_t* status, uint32_t* status_host, c3d_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     GsParams p;
     const int K = raw_coeffs(st);
@@ -259,7 +264,7 @@ int c3d_gs_forward_raw_nosync(const c3d_gs_settings* st, int32_t N, const float*
     int rc;
     { C3dProfScope ps(C3D_P_PREPROCESS, s);
     if ((rc = gs_launch_preprocess_raw(p, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, g, radii, s))) return rc; }
-    return forward_tail_nosync(p, g, N, pair_capacity, binning_buffer, image_buffer, out_color, out_depth, out_alpha, status, s);
+    return forward_tail_nosync(p, g, N, pair_capacity, binning_buffer, image_buffer, out_color, out_depth, out_alpha, status, status_host, s);
 }
 
 int c3d_gs_backward(const c3d_gs_settings* st, int32_t N, int32_t M, const float* means3D, const float* shs,

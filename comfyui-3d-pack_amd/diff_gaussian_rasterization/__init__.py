@@ -29,7 +29,44 @@ import warnings
 _SYNC_FREE = True
 _GROW_AT, _HEADROOM = 0.6, 1.5
 _cap = {}        # (device index, N, H, W) -> pair capacity
-_pending = []    # [(event, pinned [2] int32, key, capacity)] status words on their way to the host, oldest first
+_SLOTS = 64      # status slots per device: calls whose status words may be on their way to the host at once
+_SENTINEL = -1   # 0xFFFFFFFF: neither a flag word (bits 0-1) nor a pair count (< 2^30)
+_rings = {}      # device index -> _Ring
+
+
+class _Ring:
+    """per device: _SLOTS status slots, each two int32 words on the device (what the kernels write) and two in pinned host memory (where c3d_gs_forward_nosync
+    copies them at the end of the call).  The host presets a pinned slot to the sentinel and later just LOOKS at it: no event, no allocation, no synchronisation per call.
+    Slots are handed out round-robin and examined first-in first-out, so the slot about to be reused is always the oldest one still pending."""
+
+    def __init__(self, dev):
+        self.device = dev
+        self.dev_words = torch.zeros((_SLOTS, 2), dtype=torch.int32, device=dev)
+        self.pin = torch.full((_SLOTS, 2), _SENTINEL, dtype=torch.int32).pin_memory()
+        self.host = self.pin.numpy()                      # same memory: plain loads / stores from Python
+        self.dev_ptr, self.pin_ptr = self.dev_words.data_ptr(), self.pin.data_ptr()
+        self.next = 0
+        self.pending = []                                 # [(slot, key, capacity)] calls whose status words have not been examined, oldest first
+
+    def examine(self, block=False, keep=_SLOTS):
+        """retire the calls whose words have arrived; block: all of them, waiting for the GPU if need be; keep: wait until at most that many are left"""
+        while self.pending:
+            slot, key, cap = self.pending[0]
+            w = self.host[slot]
+            if w[0] == _SENTINEL or w[1] == _SENTINEL:    # still on its way
+                if not block and len(self.pending) <= keep:
+                    return
+                torch.cuda.synchronize(self.device)       # rare: flush(), or _SLOTS calls ahead of the GPU
+                w = self.host[slot]
+            self.pending.pop(0)
+            flags, seen = int(w[0]), int(w[1]) & 0xFFFFFFFF
+            if flags & 2:
+                raise RuntimeError("diff_gaussian_rasterization (MI355X): a chained-scan look-back of an earlier forward call timed out in the binning stage (device fault or a wedged workgroup)")
+            _learn(key, seen)
+            if flags & 1:
+                warnings.warn("diff_gaussian_rasterization (MI355X): an earlier sync-free forward call needed %d (tile, splat) pairs, its buffers held %d -- that image (and its "
+                              "gradient) is incomplete.  The capacity has been regrown; diff_gaussian_rasterization.sync_free(False) restores the exact synchronous path."
+                              % (seen, cap), RuntimeWarning, stacklevel=4)
 
 
 def sync_free(on=True):
@@ -42,7 +79,13 @@ def sync_free(on=True):
 def flush():
     """wait for the status words of every sync-free forward call issued so far and examine them (warns / raises as described above); afterwards
     last_num_rendered is the pair count of the most recent forward call"""
-    _examine(block=True)
+    for ring in _rings.values():
+        ring.examine(block=True)
+
+
+def pending_calls():
+    """sync-free forward calls whose status words have not been examined yet"""
+    return sum(len(r.pending) for r in _rings.values())
 
 
 def _learn(key, seen):
@@ -54,37 +97,26 @@ def _learn(key, seen):
         _cap[key] = min(int(seen * _HEADROOM) + (1 << 16), 0x3FFFFFF0)
 
 
-def _examine(block=False):
-    """look at the status words of earlier sync-free calls that have arrived (block: wait for all of them)"""
-    while _pending:
-        ev, pin, key, cap = _pending[0]
-        if not block and len(_pending) <= 16 and not ev.query():
-            break
-        ev.synchronize()
-        _pending.pop(0)
-        flags, seen = int(pin[0]), int(pin[1]) & 0xFFFFFFFF
-        if flags & 2:
-            raise RuntimeError("diff_gaussian_rasterization (MI355X): a chained-scan look-back of an earlier forward call timed out in the binning stage (device fault or a wedged workgroup)")
-        _learn(key, seen)
-        if flags & 1:
-            warnings.warn("diff_gaussian_rasterization (MI355X): an earlier sync-free forward call needed %d (tile, splat) pairs, its buffers held %d -- that image (and its "
-                          "gradient) is incomplete.  The capacity has been regrown; diff_gaussian_rasterization.sync_free(False) restores the exact synchronous path."
-                          % (seen, cap), RuntimeWarning, stacklevel=3)
-
-
 def _capacity_for(key):
     """-> pair capacity for a sync-free forward of this shape, or None: take the synchronous path (and learn the count)"""
-    _examine()
+    ring = _rings.get(key[0])
+    if ring is not None and ring.pending:
+        ring.examine()
     return _cap.get(key) if _SYNC_FREE else None
 
 
-def _watch(status, key, cap, dev):
-    pin = torch.empty((2,), dtype=torch.int32).pin_memory()
-    pin.copy_(status, non_blocking=True)
-    ev = torch.cuda.Event()
-    ev.record(torch.cuda.current_stream(dev))
-    _pending.append((ev, pin, key, cap))
-
+def _status_slot(dev, key, cap):
+    """-> (device pointer, pinned host pointer) of the status words of one sync-free call, registered for examination"""
+    ring = _rings.get(dev.index)
+    if ring is None:
+        ring = _rings[dev.index] = _Ring(dev)
+    if len(ring.pending) >= _SLOTS:
+        ring.examine(keep=_SLOTS - 1)                     # the slot handed out next is the oldest pending one: retire it first
+    slot = ring.next
+    ring.next = (slot + 1) % _SLOTS
+    ring.host[slot] = _SENTINEL
+    ring.pending.append((slot, key, cap))
+    return C.c_void_p(ring.dev_ptr + 8 * slot), C.c_void_p(ring.pin_ptr + 8 * slot)
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -158,11 +190,10 @@ class _RasterizeGaussians(torch.autograd.Function):
             if cap is not None:      # sync-free: launches sized for the capacity, the pair count stays on the device (see _cap above)
                 num_rendered = cap
                 binning = torch.empty((lib.c3d_gs_binning_bytes(cap, H, W),), **u8)
-                status = torch.zeros((2,), dtype=torch.int32, device=dev)
+                st_dev, st_host = _status_slot(dev, key, cap)
                 _h.check(lib.c3d_gs_forward_nosync(C.byref(st), N, M, _h.ptr(means3D_c), _h.ptr(sh_c), _h.ptr(col_c), _h.ptr(op_c), _h.ptr(sc_c), _h.ptr(rot_c),
                                                    _h.ptr(cov_c), _h.ptr(radii), _h.ptr(geom), cap, _h.ptr(binning), _h.ptr(img), _h.ptr(color), _h.ptr(depth),
-                                                   _h.ptr(alpha), _h.ptr(status), s), "c3d_gs_forward_nosync")
-                _watch(status, key, cap, dev)
+                                                   _h.ptr(alpha), st_dev, st_host, s), "c3d_gs_forward_nosync")
             else:
                 nr = C.c_int64(0)
                 _h.check(lib.c3d_gs_forward_project(C.byref(st), N, M, _h.ptr(means3D_c), _h.ptr(sh_c), _h.ptr(col_c), _h.ptr(op_c),
@@ -250,10 +281,9 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
             if cap is not None:      # sync-free (see _cap above)
                 num_rendered = cap
                 binning = torch.empty((lib.c3d_gs_binning_bytes(cap, H, W),), **u8)
-                status = torch.zeros((2,), dtype=torch.int32, device=dev)
+                st_dev, st_host = _status_slot(dev, key, cap)
                 _h.check(lib.c3d_gs_forward_raw_nosync(C.byref(st), N, *[_h.ptr(x) for x in t], _h.ptr(radii), _h.ptr(geom), cap, _h.ptr(binning), _h.ptr(img),
-                                                       _h.ptr(color), _h.ptr(depth), _h.ptr(alpha), _h.ptr(status), s), "c3d_gs_forward_raw_nosync")
-                _watch(status, key, cap, dev)
+                                                       _h.ptr(color), _h.ptr(depth), _h.ptr(alpha), st_dev, st_host, s), "c3d_gs_forward_raw_nosync")
             else:
                 nr = C.c_int64(0)
                 _h.check(lib.c3d_gs_forward_project_raw(C.byref(st), N, *[_h.ptr(x) for x in t], _h.ptr(radii), _h.ptr(geom), C.byref(nr), s),

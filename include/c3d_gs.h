@@ -96,14 +96,16 @@ int c3d_gs_forward_render(const c3d_gs_settings* st, int32_t N, int32_t M, const
 
 /* Forward in ONE call without host synchronisation (ABI 500): parts 1 + 2 with every launch sized for `pair_capacity` (tile, splat) pairs instead of the exact
  * count -- the count stays on the device, so the rasterizer call of main_3DGS_renderer.py:927-936 (and of LGM core/gs.py:27-80, TRELLIS gaussian_render.py:62-130)
- * no longer stalls the host once per view.  binning_buffer: c3d_gs_binning_bytes(pair_capacity, H, W) bytes.  status (DEVICE, two words, zero on entry): [0] bit 0 =
+ * no longer stalls the host once per view.  binning_buffer: c3d_gs_binning_bytes(pair_capacity, H, W) bytes.  status (DEVICE, two words; the call clears them): [0] bit 0 =
  * the view needed more pairs than pair_capacity (the outputs are then incomplete: render again with a larger capacity), bit 1 = a bounded inter-workgroup wait timed
- * out (device fault); [1] = the pair count.  The caller reads them whenever it likes (the Python boundary: asynchronously, one call late).  A backward call on this
- * state passes num_rendered = pair_capacity and scratch of c3d_gs_backward_scratch_bytes(N, pair_capacity).  N > 0 and a non-empty image only. */
+ * out (device fault); [1] = the pair count.  status_host (optional, PINNED host memory, two words): the call ends with an asynchronous copy of the two words there, in
+ * stream order behind its last kernel -- a caller that presets status_host[1] to 0xFFFFFFFF (never a pair count) sees the words arrive without an event or a
+ * synchronisation (the Python boundary does that and looks at them one call late).  A backward call on this state passes num_rendered = pair_capacity and scratch of
+ * c3d_gs_backward_scratch_bytes(N, pair_capacity).  N > 0 and a non-empty image only. */
 int c3d_gs_forward_nosync(const c3d_gs_settings* st, int32_t N, int32_t M, const float* means3D, const float* shs, const float* colors_precomp,
                           const float* opacities, const float* scales, const float* rotations, const float* cov3D_precomp, int32_t* radii,
                           void* geom_buffer, int64_t pair_capacity, void* binning_buffer, void* image_buffer, float* out_color, float* out_depth,
-                          float* out_alpha, uint32_t* status /* device [2] */, c3d_stream_t stream);
+                          float* out_alpha, uint32_t* status /* device [2] */, uint32_t* status_host /* pinned host [2] or NULL */, c3d_stream_t stream);
 
 /* Backward (A7 + A8).  Pixel gradients dL_dcolor[3,H,W], dL_ddepth[1,H,W] (may be NULL),
  * dL_dalpha[1,H,W] (may be NULL).  Outputs (all written in full by the library, no pre-zeroing needed):
@@ -133,7 +135,7 @@ int c3d_gs_forward_project_raw(const c3d_gs_settings* st, int32_t N, const float
 int c3d_gs_forward_raw_nosync(const c3d_gs_settings* st, int32_t N, const float* means3D, const float* f_dc, const float* f_rest,
                               const float* opacity_raw, const float* scaling_raw, const float* rotation_raw, int32_t* radii, void* geom_buffer,
                               int64_t pair_capacity, void* binning_buffer, void* image_buffer, float* out_color, float* out_depth, float* out_alpha,
-                              uint32_t* status /* device [2] */, c3d_stream_t stream);
+                              uint32_t* status /* device [2] */, uint32_t* status_host /* pinned host [2] or NULL */, c3d_stream_t stream);
 int c3d_gs_backward_raw(const c3d_gs_settings* st, int32_t N, const float* means3D, const float* f_dc, const float* f_rest,
                         const float* scaling_raw, const float* rotation_raw, const int32_t* radii, const void* geom_buffer,
                         int64_t num_rendered, const void* binning_buffer, const void* image_buffer, const float* dL_dcolor,

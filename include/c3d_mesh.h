@@ -109,7 +109,10 @@ int c3d_mesh_texture_mip_bwd(const float* tex, const float* stack, int32_t Bt, c
                              int32_t C, int32_t filter, int32_t boundary, int32_t max_mip_level, float* dtex, float* dstack, float* duv,
                              float* d_uv_da, float* d_bias, c3d_stream_t stream);
 
-/* antialias: scratch = edge hash of the topology.  c3d_mesh_antialias_build_topology fills it from `tri` (the dependency's
+/* antialias: scratch = edge hash of the topology.  A pixel pair is analysed on its NEARER triangle (smaller z/w; background counts as farthest); if that triangle has a
+ * vertex at or behind the camera plane (w <= 0: a near-plane clipped triangle) the pair is left alone -- colour and gradients pass through unchanged -- and an edge
+ * whose neighbour across it has such a vertex is not taken for a silhouette.  (The dependency's analysis kernel is not in the reference tree; this is the rule
+ * oracle/mesh_oracle.c restates and tests/test_mesh_oracle.py, tests/test_mesh_hip.py pin: *_leaves_pairs_of_a_near_plane_clipped_triangle_alone.)  c3d_mesh_antialias_build_topology fills it from `tri` (the dependency's
  * antialias_construct_topology_hash); it stays valid for as long as `tri` is unchanged and is shared by forward and backward. */
 size_t c3d_mesh_antialias_scratch_bytes(int32_t T);
 int c3d_mesh_antialias_build_topology(const int32_t* tri, int32_t T, void* scratch, c3d_stream_t stream);

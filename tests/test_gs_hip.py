@@ -647,12 +647,13 @@ def test_sync_free_drop_in_forward_equals_the_synchronous_path_bit_for_bit():
         D = int(dgr.last_num_rendered)
         key = (torch.cuda.current_device(), 60000, H, W)
         assert dgr._cap.get(key, 0) >= D > 0                       # the synchronous call taught the shape its capacity
-        n_before = len(dgr._pending)
+        dgr.last_num_rendered = -1
         with warnings.catch_warnings():
             warnings.simplefilter("error")                          # no overflow warning may appear
             got = fn()
-            assert len(dgr._pending) == n_before + 1 or not dgr._pending   # the call went through the sync-free entry point (status words on their way)
+            assert dgr.pending_calls() == 1                         # the call went through the sync-free entry point: its status words are on their way
             dgr.flush()
+        assert dgr.pending_calls() == 0
         assert int(dgr.last_num_rendered) == D
         for a, b in zip(got, ref):
             assert torch.equal(a, b), fn.__name__

@@ -721,6 +721,32 @@ def test_other_in_tree_consumers_op_sequences():
     assert np.abs(np.linalg.norm(xyzs.cpu().numpy()[0][m[0]], axis=-1) - 0.7).max() <= 0.1 + 1e-3     # baked positions lie on the displaced sphere
 
 
+def test_antialias_leaves_pairs_of_a_near_plane_clipped_triangle_alone():
+    """VERDICT r4, next-round 4 ii: what the HIP antialias does with a pixel pair whose nearer triangle is near-plane clipped, pinned: the pair is skipped (colour and
+    gradient pass through), as the oracle does (tests/test_mesh_oracle.py holds the rule and its control case); the stand-alone op and the fused view agree."""
+    import nvdiffrast.torch as dr
+    from test_mesh_oracle import _clipped_edge_scene
+    ctx = dr.RasterizeCudaContext()
+    for clipped in (False, True):
+        pos64, tri, (H, W) = _clipped_edge_scene(clipped, W=32, H=24, xe_px=17.25)
+        tp = T(pos64.astype(np.float32), grad=True)
+        tt = T(tri, torch.int32)
+        rast, _ = dr.rasterize(ctx, tp, tt, (H, W))
+        orast, _ = M.rasterize(pos64.astype(np.float32), tri, (H, W))
+        assert (rast.detach().cpu().numpy()[..., 3] == orast[..., 3]).all()
+        col = (rast[..., 3:] > 0).float().detach().requires_grad_(True)
+        out = dr.antialias(col, rast.detach(), tp, tt)
+        oout = M.antialias(col.detach().cpu().numpy(), orast, pos64.astype(np.float32), tri)
+        assert np.abs(out.detach().cpu().numpy() - oout).max() <= 1e-6
+        out.sum().backward()
+        if clipped:
+            assert torch.equal(out.detach(), col.detach())
+            assert bool((col.grad == 1).all()) and bool((tp.grad == 0).all())
+        else:
+            rows = slice(10, 14)
+            assert np.allclose(out.detach().cpu().numpy()[0, rows, 17, 0], 0.25, atol=1e-5) and float(tp.grad.abs().max()) > 0
+
+
 def test_near_plane_clipping_matches_oracle_forward_and_backward():
     """Triangles with vertices at / behind the camera plane (w <= 0) are clipped against the near plane, not dropped:
     HIP against the oracle (which tests/test_mesh_oracle.py holds to hand-clipped geometry) -- ids, barycentrics, depth; the gradient of the

@@ -9,7 +9,11 @@ tests/golden/ref_consumers.npz (tests/golden/make_golden_ref_consumers.py, which
 every call the function made into `nvdiffrast.torch` / `diff_gaussian_rasterization` (inputs, keyword arguments, outputs of the CPU oracle behind the name) and
 what the function returned.  The GPU tests replay the recorded calls through the HIP drop-ins -- same tensors, same argument patterns as the real call sites --
 hold every op output to the recorded one, and rebuild the function's result from the HIP outputs (the few torch lines between the ops and the return statement
-are quoted with their reference line numbers).  The CPU test re-runs the generator in --check mode where the reference is mounted."""
+are quoted with their reference line numbers).  Those replays are OP-LEVEL: an op that takes a `rast` is fed the recorded one, so a disagreement of the HIP
+rasterizer could not propagate.  Round 5 adds END-TO-END replays of the two mesh consumers (`*_end_to_end_on_hip`): the HIP rasterizer's own `rast` flows into the
+interpolate / antialias calls behind it exactly as in the reference's function bodies -- ids first (all but <= 1e-5 of the pixels), then the functions' results.
+The Gaussian consumers make one rasterizer call per image: their replays are end-to-end as they stand.  The CPU test re-runs the generator in --check mode where the
+reference is mounted."""
 import os
 import subprocess
 import sys
@@ -142,6 +146,78 @@ def test_flexicubes_render_mesh_calls_replayed_on_hip():
     close(torch.lerp(torch.ones_like(outs[9][0]), outs[9][0], alpha), z["flex_res_b_vertex_normal"])
     # the call site passes int64 faces through `.int()` and a fresh RasterizeCudaContext per call: what the recorded dtypes say
     assert z["flex_c0_in1"].dtype == np.int32 and z["flex_c3_in2"].dtype == np.int32
+
+
+def _ids_agree(rast, recorded, what):
+    """winners of the HIP rasterizer against the recorded ones: all but <= 1e-5 of the pixels (at least 3: a triangle edge through a pixel centre falls either way);
+    -> bool mask [B,H,W] of the pixels within one pixel of a disagreement (antialias spreads a winner's colour to its neighbours)"""
+    ids, want = rast[..., 3].cpu().numpy(), recorded[..., 3]
+    bad = ids != want
+    print("[f4 end-to-end] %s: %d of %d pixels have another winner" % (what, int(bad.sum()), bad.size))
+    assert bad.sum() <= max(3, int(1e-5 * bad.size)), (what, int(bad.sum()))
+    near = bad.copy()
+    near[:, 1:] |= bad[:, :-1]; near[:, :-1] |= bad[:, 1:]; near[:, :, 1:] |= bad[:, :, :-1]; near[:, :, :-1] |= bad[:, :, 1:]
+    return near
+
+
+def _close_e2e(got, want, near, mean=IMG_L1, mx=5e-3):
+    g = got.detach().cpu().numpy()
+    assert g.shape == want.shape, (g.shape, want.shape)
+    d = np.abs(g - want)
+    assert d.mean() <= mean, float(d.mean())                       # the whole image, disagreeing winners included
+    assert d[~near].max() <= mx, float(d[~near].max())             # everywhere but next to a pixel that went to another triangle
+
+
+@pytest.mark.gpu
+def test_flexicubes_render_mesh_end_to_end_on_hip():
+    """FlexiCubesRenderer.render_mesh (flexicubes_renderer.py:41-74) with the HIP ops feeding each other: rasterize -> alpha -> antialias / interpolate (+ clamp, normalise)
+    / interpolate over per-face normals / interpolate + antialias, twice (black and white background); inputs = what the reference's run handed to its first op."""
+    _need_gpu()
+    import nvdiffrast.torch as dr
+    z = _z()
+    a = lambda i, j: z["flex_c%d_in%d" % (i, j)]
+    for first, tag, white in ((0, "a", False), (6, "b", True)):
+        vclip, faces = T(a(first, 0)), T(a(first, 1), torch.int32)
+        res = tuple(int(x) for x in a(first, 2))
+        rast, _ = dr.rasterize(dr.RasterizeCudaContext(), vclip, faces, res)               # :44-45
+        near = _ids_agree(rast, z["flex_c%d_out0" % first], "flex render_mesh #%s" % tag)[..., None]
+        alpha_index = rast[..., -1:] > 0                                                     # :47-49
+        alpha = alpha_index.float()
+        bgmix = (lambda img: torch.lerp(torch.ones_like(img), img, alpha)) if white else (lambda img: img)      # :73-75
+        mask = dr.antialias(alpha, rast, vclip, faces)                                       # :54
+        _close_e2e(bgmix(mask), z["flex_res_%s_mask" % tag], near)
+        if not white:
+            img, _ = dr.interpolate(T(a(2, 0)), rast, faces)                                 # :57-63  depth
+            dmin, dmax = -5.5, -0.5
+            img = img.clone()
+            img[alpha_index] = (torch.clamp(img[alpha_index], min=dmin, max=dmax) - dmin) / (dmax - dmin)
+            img[~alpha_index] = 0
+            _close_e2e(img, z["flex_res_a_depth"], near, mx=2e-3)
+            nrm, _ = dr.interpolate(T(a(3, 0)), rast, T(a(3, 2), torch.int32))               # :65-66  per-face normals through (i, i, i)
+            _close_e2e(nrm, z["flex_res_a_normal"], np.broadcast_to(near, nrm.shape), mx=2e-3)
+        iv, ia_ = (4, 5) if not white else (8, 9)
+        vn, _ = dr.interpolate(T(a(iv, 0)), rast, faces)                                     # :68-69  vertex normals, antialiased
+        vn = dr.antialias((vn + 1) * 0.5, rast, vclip, faces)
+        _close_e2e(bgmix(vn), z["flex_res_%s_vertex_normal" % tag], np.broadcast_to(near, vn.shape))
+
+
+@pytest.mark.gpu
+def test_color_func_to_albedo_end_to_end_on_hip():
+    """color_func_to_albedo (mesh_utils.py:521-568) up to the padding: rasterize the UV layout, interpolate positions and the coverage attribute on the HIP rast, query the
+    generator's colour field on the covered texels"""
+    _need_gpu()
+    import nvdiffrast.torch as dr
+    z = _z()
+    a = lambda i, j: z["bake_c%d_in%d" % (i, j)]
+    h = w = int(a(0, 2)[0])
+    rast, _ = dr.rasterize(dr.RasterizeCudaContext(), T(a(0, 0)), T(a(0, 1), torch.int32), (h, w))      # :537
+    near = _ids_agree(rast, z["bake_c0_out0"], "color_func_to_albedo")
+    xyzs, _ = dr.interpolate(T(a(1, 0)), rast, T(a(1, 2), torch.int32))                                   # :538
+    mask, _ = dr.interpolate(T(a(2, 0)), rast, T(a(2, 2), torch.int32))                                   # :539
+    xyzs, mask = xyzs.view(-1, 3), (mask > 0).view(-1)                                                    # :542-543
+    albedo = torch.zeros(h * w, 3, device="cuda")
+    albedo[mask] = torch.sigmoid(xyzs[mask] * 3.0 + torch.tensor([0.3, -0.2, 0.1], device="cuda"))       # the generator's colour field
+    _close_e2e(albedo.view(1, h, w, 3), z["bake_res_albedo"][None], np.broadcast_to(near[..., None], (1, h, w, 3)), mx=1e-4)
 
 
 @pytest.mark.gpu
