@@ -154,6 +154,15 @@ class GaussianModel:
         shs = np.random.random((xyz.shape[0], 3)) / 255.0
         self.create_from_pcd(PointCloud(points=xyz, colors=SH2RGB(shs), normals=np.zeros_like(xyz)), 10)
 
+    def create_from_uv_data(self, uv_grids_data):
+        """one Gaussian per texel of a mesh's UV grid (reference :526-539): uv_grids_data = (uv_coords, uv_coords_3d, uv_normals_3d); only the 3D positions
+        are used, colours are the same random near-black as the other initialisers, learning-rate scale 10"""
+        if uv_grids_data is None or len(uv_grids_data) != 3:
+            raise TypeError("create_from_uv_data(): pass (uv_coords, uv_coords_3d, uv_normals_3d)")
+        xyz = np.asarray([np.asarray(p, dtype=np.float64) for p in uv_grids_data[1]], dtype=np.float64).reshape(-1, 3)
+        shs = np.random.random((xyz.shape[0], 3)) / 255.0
+        self.create_from_pcd(PointCloud(points=xyz, colors=SH2RGB(shs), normals=np.zeros_like(xyz)), 10)
+
     def create_from_tensors(self, xyz, features, scaling_raw, rotation_raw, opacity_raw, spatial_lr_scale=1.0):
         """raw tensors in the layout create_from_ply produces (:486-498): features [N,K,3]"""
         self.spatial_lr_scale = spatial_lr_scale
@@ -489,8 +498,8 @@ class GaussianSplattingRenderer:
             self.gaussians.create_from_tensors(**input)
         elif hasattr(input, "v") and hasattr(input, "f"):        # mesh_processer.mesh.Mesh
             self.gaussians.create_from_mesh(input, num_pts)
-        else:
-            raise TypeError("initialize(): pass None, a GS PlyData, a PointCloud, a Mesh or a dict of raw tensors (the UV-grid initialiser is not built)")
+        else:      # anything else is the UV-grid triple, as in the reference (:827-828)
+            self.gaussians.create_from_uv_data(input)
 
     def raw_storage_ok(self):
         """can the raw-parameter kernels (render()'s fused path, render_views, the fused training step) read this model's storage?  SH degree 0-3, f_dc [N,1,3] and

@@ -59,9 +59,6 @@ int c3d_scan_u32(const uint32_t* in, uint32_t* out, size_t n, bool exclusive, vo
 // in rsort[i].  tail_meta (optional, device): receives min(total, tail_cap) in [0]; tail_status (optional): [0] |= 1 when total > tail_cap, [1] = max(total).
 int c3d_scan_rect_gather(const uint2* rect, const uint32_t* idx, uint32_t* out, uint2* rsort, size_t n, void* tmp, hipStream_t s, bool zero_state,
                          uint32_t* tail_meta, uint32_t* tail_status, uint32_t tail_cap, uint32_t* err = nullptr, int V = 1, size_t vs = 0);
-// exclusive scan of `in` -> out, plus einfo[i] = {0, rect[i].x, rect[i].y, out[i]} where in[i] != 0 (coalesced epilogue)
-int c3d_scan_u32_einfo(const uint32_t* in, uint32_t* out, size_t n, void* tmp, hipStream_t s, bool zero_state, uint32_t* err, const uint2* rect, uint4* einfo,
-                       int V = 1, size_t vs = 0);
 uint32_t* c3d_scan_error_word(void* tmp);
 // up to three byte regions (off[r], bytes[r]: 16-byte aligned, multiples of 4) cleared in each of V slices, one launch
 int c3d_zero_views(void* base0, size_t vs, int V, const size_t* off, const size_t* bytes, int regions, hipStream_t s);

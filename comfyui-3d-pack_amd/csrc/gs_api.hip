@@ -69,16 +69,14 @@ static int check_inputs(int N, int M, int deg, const float* means3D, const float
 // order, gather folded in).  Three single-pass primitives whose state is cleared by ONE memset (one view) or by the caller's c3d_zero_views
 // (`cleared`, V views).  V / vs: the chain of V views in one launch per stage (g = view 0's state, view v's lies v * vs bytes behind).
 // cap / status: pair capacity and status words of the sync-free paths (the pair count then stays on the device in g.meta[0]).
-// records: the backward pass will run on this state (record bases + einfo of every Gaussian); a forward-only render skips that scan
-static int binning_front(GsGeom& g, int N, uint32_t cap, uint32_t* status, hipStream_t s, int V = 1, size_t vs = 0, bool cleared = false, bool records = true) {
+// (the record-base scan of the backward pass -- rbase, einfo -- is not on this chain any more: it rides in the recording forward compositing launch, scan_wave.h)
+static int binning_front(GsGeom& g, int N, uint32_t cap, uint32_t* status, hipStream_t s, int V = 1, size_t vs = 0, bool cleared = false) {
     int rc, res = 0;
     if (!cleared) {
         if (V != 1) { c3d_set_error("internal: a multi-view binning chain needs its state cleared by the caller"); return -2; }
         C3D_CHECK(hipMemsetAsync(g.meta, 0, g.zero_bytes, s));
     }
     uint32_t* err = status ? status : (uint32_t*)g.meta + 2;      // a timed-out look-back (bounded spins) surfaces as C3D_ERR_LOOKBACK
-    if (records) { C3dProfScope ps(C3D_P_SCAN, s);
-      if ((rc = c3d_scan_u32_einfo(g.tiles, g.rbase, (size_t)N, g.tmp_scan_a, s, false, err, g.rect, g.einfo, V, vs))) return rc; }
     { C3dProfScope ps(C3D_P_DEPTH_SORT, s);
       if ((rc = c3d_sort_pairs_u32(g.key[0], g.key[1], g.order[0], g.order[1], true, (size_t)N, 32, g.tmp_sort, &res, s, nullptr, false, err, V, vs))) return rc; }
     if (res != sort_result_index(32)) { c3d_set_error("internal: depth sort buffer parity"); return -2; }
@@ -217,7 +215,7 @@ static int forward_tail_nosync(const GsParams& p, GsGeom& g, int N, int64_t pair
     { C3dProfScope ps(C3D_P_COMPOSITE_FWD, s);
       GsFwdViews vp{};
       vp.bg[0] = p.bg; vp.color[0] = out_color; vp.depth[0] = out_depth; vp.alpha[0] = out_alpha;
-      if ((rc = gs_launch_composite_fwd(p, g, b, res, im, vp, 1, 0, true, s))) return rc; }
+      if ((rc = gs_launch_composite_fwd(p, g, b, res, im, vp, 1, 0, true, s, status))) return rc; }
     // the status words are final once the tile sort has run; the copy rides behind the compositing launch in stream order and is nobody's critical path
     if (status_host) C3D_CHECK(hipMemcpyAsync(status_host, status, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     return 0;
@@ -415,7 +413,7 @@ static int group_project(ViewGroup& q, const float* means3D, const float* f_dc, 
     return gs_launch_preprocess_views(q.p, q.G, gs, rd, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, s);
 }
 // A2-A5 of the group, sync-free: ONE clear of every view's state blocks (+ the backward pass's "record written" bytes), then one launch per stage
-static int group_bin(ViewGroup& q, uint32_t* status, bool clear_pvalid, hipStream_t s, int* res_out, bool records = true) {
+static int group_bin(ViewGroup& q, uint32_t* status, bool clear_pvalid, hipStream_t s, int* res_out) {
     int rc;
     {
         C3dProfScope ps(C3D_P_OTHER, s);
@@ -424,11 +422,11 @@ static int group_bin(ViewGroup& q, uint32_t* status, bool clear_pvalid, hipStrea
         const size_t bytes[3] = {q.g0.zero_bytes, q.b0.zero_bytes, clear_pvalid ? (((size_t)q.cap + 15) & ~(size_t)15) : 0};
         if ((rc = c3d_zero_views(q.slice0, q.vs, q.G, off, bytes, clear_pvalid ? 3 : 2, s))) return rc;
     }
-    if ((rc = binning_front(q.g0, q.N, q.cap, status, s, q.G, q.vs, true, records))) return rc;
+    if ((rc = binning_front(q.g0, q.N, q.cap, status, s, q.G, q.vs, true))) return rc;
     return binning_back(q.p[0], q.g0, q.b0, (long long)q.cap, q.cap, (const uint32_t*)q.g0.meta, status, s, res_out, q.G, q.vs, true);
 }
 // A6 of the group.  out_*[i] (arrays or entries may be NULL): the caller's planes of view i; otherwise the slice's own.
-static int group_composite_fwd(ViewGroup& q, int res, float* const* out_color, float* const* out_depth, float* const* out_alpha, bool record, hipStream_t s) {
+static int group_composite_fwd(ViewGroup& q, int res, float* const* out_color, float* const* out_depth, float* const* out_alpha, bool record, hipStream_t s, uint32_t* status) {
     GsFwdViews vp{};
     for (int i = 0; i < q.G; i++) {
         vp.bg[i] = q.p[i].bg;
@@ -437,7 +435,7 @@ static int group_composite_fwd(ViewGroup& q, int res, float* const* out_color, f
         vp.alpha[i] = (out_alpha && out_alpha[i]) ? out_alpha[i] : q.w[i].alpha;
     }
     C3dProfScope ps(C3D_P_COMPOSITE_FWD, s);
-    return gs_launch_composite_fwd(q.p[0], q.g0, q.b0, res, q.im0, vp, q.G, q.vs, record, s);
+    return gs_launch_composite_fwd(q.p[0], q.g0, q.b0, res, q.im0, vp, q.G, q.vs, record, s, status);
 }
 
 // per-Gaussian chain rule over all views of a step, every gradient written once (chunks of GS_MAX_BWD_VIEWS views); stream s0, after the join
@@ -532,7 +530,7 @@ int c3d_gs_train_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, c
                 if ((rc = group_setup(q, views + v0, g, N, (char*)workspace + (size_t)v0 * vs, vs, pair_capacity, false))) break;
                 if ((rc = group_project(q, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, nullptr, sf))) break;
                 if ((rc = group_bin(q, status, true, sf, &res))) break;
-                if ((rc = group_composite_fwd(q, res, nullptr, nullptr, nullptr, true, s))) break;
+                if ((rc = group_composite_fwd(q, res, nullptr, nullptr, nullptr, true, s, status))) break;
                 // + scale * w_ssim * (1 - MS-SSIM(target * mask, clamp(C) * mask)) of every view (the batch mean of the reference, main_3DGS.py:192, is the mean of
                 // the per-image values): the value goes into the view's own slot behind its tile partials, the gradient into the slice's dL/dcolor plane
                 if (ssim) {      // all views of the group in one set of ~20 launches (the views' images, targets, masks and gradient planes as per-image pointer tables)
@@ -617,8 +615,8 @@ static int views_forward(const char* who, const c3d_gs_settings* views, int32_t 
         if ((rc_all = group_setup(q, views + v0, g, N, slice0, vs, pair_capacity, fwd_only))) break;
         // kept state: the backward pass reads the slice's copy of the radii; forward only: straight into the caller's buffer where there is one
         if ((rc_all = group_project(q, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, (!keep_state && out_radii) ? out_radii + v0 : nullptr, s))) break;
-        if ((rc_all = group_bin(q, status, keep_state, s, &res, keep_state))) break;
-        if ((rc_all = group_composite_fwd(q, res, out_color + v0, out_depth ? out_depth + v0 : nullptr, out_alpha + v0, keep_state, s))) break;
+        if ((rc_all = group_bin(q, status, keep_state, s, &res))) break;
+        if ((rc_all = group_composite_fwd(q, res, out_color + v0, out_depth ? out_depth + v0 : nullptr, out_alpha + v0, keep_state, s, status))) break;
         for (int i = 0; i < g && keep_state && out_radii && !rc_all; i++)
             if (out_radii[v0 + i] && hipMemcpyAsync(out_radii[v0 + i], q.w[i].radii, sizeof(int) * (size_t)N, hipMemcpyDeviceToDevice, s) != hipSuccess) {
                 c3d_set_error("%s: radii copy failed", who); rc_all = -1;

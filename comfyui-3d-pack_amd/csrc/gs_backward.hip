@@ -640,72 +640,22 @@ __global__ void __launch_bounds__(256, MINB) k_bwd_views_geom(GsParams p, GsBwdV
     // the NEXT view is fetched while this one is worked on, the valid bytes and the records of four pairs are in flight together, and a Gaussian
     // that no pixel of the view blended (no valid record: roughly every other one at the BASELINE workload) skips the splat record, the two
     // matrices and the whole geometric chain -- all its sums are zero.
-#ifdef GS_A8_PIPE
-    // Software pipeline two views deep (round 5): the span (radius, count, record base) of view v + 2 and the first CHUNK valid bytes of view v + 1 are requested while
-    // view v's records are in flight, so a view costs ONE dependent round trip (records + splat record) instead of two (valid bytes, then records).
     int n_rad = vs.v[0].radii[idx];
     uint32_t n_cnt = vs.v[0].tiles[idx], n_e0 = vs.v[0].rbase[idx];
-    int nn_rad = 0;
-    uint32_t nn_cnt = 0, nn_e0 = 0;
-    if (vs.V > 1) { nn_rad = vs.v[1].radii[idx]; nn_cnt = vs.v[1].tiles[idx]; nn_e0 = vs.v[1].rbase[idx]; }
-    uint8_t n_pv[CHUNK];
-    {
-        const uint32_t e1 = n_rad > 0 ? min(n_e0 + n_cnt, cap) : 0u;
-#pragma unroll
-        for (int i = 0; i < CHUNK; i++) n_pv[i] = (n_rad > 0 && n_e0 + i < e1) ? vs.v[0].pvalid[n_e0 + i] : (uint8_t)0;
-    }
-#else
-    int n_rad = vs.v[0].radii[idx];
-    uint32_t n_cnt = vs.v[0].tiles[idx], n_e0 = vs.v[0].rbase[idx];
-#endif
     for (int v = 0; v < vs.V; v++) {
         const GsBwdView& vw = vs.v[v];
         float* d2 = vw.dmean2D + 3 * (size_t)idx;
         float* gc = vw.gcol + 3 * (size_t)idx;
         const int rad = n_rad;
         const uint32_t cnt = n_cnt, e0 = n_e0;
-#ifdef GS_A8_PIPE
-        uint8_t pv0[CHUNK];
-#pragma unroll
-        for (int i = 0; i < CHUNK; i++) pv0[i] = n_pv[i];
-        n_rad = nn_rad; n_cnt = nn_cnt; n_e0 = nn_e0;
-#else
         if (v + 1 < vs.V) { const GsBwdView& nx = vs.v[v + 1]; n_rad = nx.radii[idx]; n_cnt = nx.tiles[idx]; n_e0 = nx.rbase[idx]; }
-#endif
         float pr[GS_PAIR_FLOATS];
 #pragma unroll
         for (int k = 0; k < GS_PAIR_FLOATS; k++) pr[k] = 0.f;
         bool any = false;
-#ifdef GS_A8_PIPE
-        {   // first chunk: its valid bytes arrived during the previous view; its records go out first, the prefetches for the next two views right behind them
-            float4 r0[CHUNK], r1[CHUNK], r2[CHUNK];
-#pragma unroll
-            for (int i = 0; i < CHUNK; i++) {
-                r0[i] = r1[i] = r2[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (pv0[i]) { const float4* rp = vw.pairgrad + (size_t)(e0 + i) * 3; r0[i] = rp[0]; r1[i] = rp[1]; r2[i] = rp[2]; }
-            }
-            if (v + 2 < vs.V) { const GsBwdView& nx = vs.v[v + 2]; nn_rad = nx.radii[idx]; nn_cnt = nx.tiles[idx]; nn_e0 = nx.rbase[idx]; }
-            if (v + 1 < vs.V) {
-                const uint32_t f1 = n_rad > 0 ? min(n_e0 + n_cnt, cap) : 0u;
-#pragma unroll
-                for (int i = 0; i < CHUNK; i++) n_pv[i] = (n_rad > 0 && n_e0 + i < f1) ? vs.v[v + 1].pvalid[n_e0 + i] : (uint8_t)0;
-            }
-#pragma unroll
-            for (int i = 0; i < CHUNK; i++) {
-                any = any || pv0[i];
-                pr[0] += r0[i].x; pr[1] += r0[i].y; pr[2] += r0[i].z; pr[3] += r0[i].w;
-                pr[4] += r1[i].x; pr[5] += r1[i].y; pr[6] += r1[i].z; pr[7] += r1[i].w;
-                pr[8] += r2[i].x; pr[10] += r2[i].z;
-            }
-        }
-#endif
         if (rad > 0) {
             const uint32_t e1 = min(e0 + cnt, cap);
-#ifdef GS_A8_PIPE
-            for (uint32_t e = e0 + CHUNK; e < e1; e += CHUNK) {
-#else
             for (uint32_t e = e0; e < e1; e += CHUNK) {
-#endif
                 uint8_t pv[CHUNK];
 #pragma unroll
                 for (int i = 0; i < CHUNK; i++) pv[i] = (e + i < e1) ? vw.pvalid[e + i] : (uint8_t)0;
@@ -831,11 +781,11 @@ int gs_launch_preprocess_bwd_views(const GsParams& p0, const GsBwdViews& views, 
     GsShViews sv;
     sv.V = views.V;
     for (int i = 0; i < views.V; i++) { sv.campos[i] = views.v[i].campos; sv.gcol[i] = views.v[i].gcol; }
-    // four pairs in flight, four workgroups per CU (128 VGPRs): eight in flight (160 VGPRs) and two or three (96, spilling) measure the same or worse
-#ifndef GS_A8_MINB
-#define GS_A8_MINB 4
-#endif
-#define GS_A8_GEOM(ACC_) hipLaunchKernelGGL((k_bwd_views_geom<ACC_, 4, GS_A8_MINB>), grid, block, 0, s, p0, views, means3D, scaling_raw, rotation_raw, dL_dopacity_raw, dL_dmeans3D, dL_dscaling_raw, dL_drotation_raw, cap, first, last)
+    // four pairs in flight, four workgroups per CU (128 VGPRs): eight in flight (160 VGPRs) and two or three (96, spilling) measure the same or worse.
+    // Round 5, measured and dropped (profiles/r05b_a8_variants.txt, same box, 8-view step): three workgroups per CU (136 VGPRs, no scratch) 0.589 -> 0.633 ms; a
+    // two-view software pipeline (the next view's valid bytes and the span of the one after requested under this view's records: one dependent round trip per
+    // view instead of two) 0.599 ms at four workgroups (36 B of scratch), 0.656 ms at three -- the walk is not bound by the depth of its dependent-load chain
+#define GS_A8_GEOM(ACC_) hipLaunchKernelGGL((k_bwd_views_geom<ACC_, 4, 4>), grid, block, 0, s, p0, views, means3D, scaling_raw, rotation_raw, dL_dopacity_raw, dL_dmeans3D, dL_dscaling_raw, dL_drotation_raw, cap, first, last)
 #define GS_A8_SH_ACC(R3_) hipLaunchKernelGGL((k_bwd_views_sh<true, R3_>), grid, block, lds, s, first, last, p0.deg, sv, means3D, f_dc, f_rest, dL_dmeans3D, dL_df_dc, dL_df_rest)
 #define GS_A8_SH_SET(R3_) hipLaunchKernelGGL((k_bwd_views_sh<false, R3_>), grid, block, lds, s, first, last, p0.deg, sv, means3D, f_dc, f_rest, dL_dmeans3D, dL_df_dc, dL_df_rest)
     if (accumulate) {

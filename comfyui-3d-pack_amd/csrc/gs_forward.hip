@@ -4,6 +4,7 @@
 // MVs_Algorithms/GaussianSplatting/main_3DGS_renderer.py:927-936 (reference).
 #include "gs_internal.h"
 #include "gs_math.h"
+#include "scan_wave.h"
 
 // ------------------------------------------------------------------------------------------
 // A1, the part that depends on the view: projection, EWA covariance, radius, tile rect, SH colour of ONE Gaussian (mean m, 3D covariance c3,
@@ -314,7 +315,10 @@ int gs_launch_ranges(const GsBinning& b, int res, long long D, hipStream_t s, co
 template <bool RECORD>
 __global__ void __launch_bounds__(64, 8) k_composite_fwd_w(GsParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                                                             const float4* __restrict__ rec, GsFwdViews vp, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-                                                            uint8_t* __restrict__ pact, size_t pstride, size_t vs) {
+                                                            uint8_t* __restrict__ pact, size_t pstride, size_t vs, ScanWaveJob sj) {
+    // RECORD launches carry the record-base scan of the backward pass in their first sj.blocks workgroups (scan_wave.h): latency-bound look-back chains that cost
+    // the forward pass nothing underneath 0.9 ms of VALU-bound compositing, instead of 0.12 ms on its critical path
+    if (RECORD && (int)blockIdx.x < sj.blocks) { scan_wave_tile(sj, vs); return; }
     ranges = c3d_view_ptr(ranges, vs); point_list = c3d_view_ptr(point_list, vs); rec = c3d_view_ptr(rec, vs); final_T = c3d_view_ptr(final_T, vs);
     n_contrib = c3d_view_ptr(n_contrib, vs); pact = c3d_view_ptr(pact, vs);
     const float* __restrict__ bg = vp.bg[blockIdx.y];
@@ -324,7 +328,7 @@ __global__ void __launch_bounds__(64, 8) k_composite_fwd_w(GsParams p, const uin
     // the wave's compacted splat list, three 16-byte parts per entry at ONE running offset:
     //   part 0 (px, py, -log2e/2 A, -log2e B)   part 1 (-log2e/2 C, opacity, r, g)   part 2 (b, view depth, list position + 1 as int bits, -)
     __shared__ float4 cl[3][FWQ_SLOTS];
-    const int b = blockIdx.x, q = (b >> 3) & 3;   // the four quadrants of a tile sit on ONE XCD (b & 7): they gather the same records
+    const int b = (int)blockIdx.x - (RECORD ? sj.blocks : 0), q = (b >> 3) & 3;   // the four quadrants of a tile sit on ONE XCD (b & 7; sj.blocks is a multiple of 32): they gather the same records
     int tx, ty;
     if (!gs_block_tile((b & 7) | ((b >> 5) << 3), p.gx, p.gy, tx, ty)) return;
     const int tile = ty * p.gx + tx, lane = (int)threadIdx.x;
@@ -430,16 +434,21 @@ __global__ void __launch_bounds__(64, 8) k_composite_fwd_w(GsParams p, const uin
 }
 
 // One launch for V views (grid.y): view v's state lies v * vs bytes behind the pointers of g / b / im; its background and output planes come from vp.
+// record_activity: a backward pass may follow -- the launch records the blended (quadrant, splat) pairs AND runs the record-base scan (rbase, einfo of g; state
+// g.tmp_scan_a, cleared with the rest of the view's binning state) in its first workgroups.  err: error word of a timed-out look-back (nullptr: the view's own, g.meta[2]).
 int gs_launch_composite_fwd(const GsParams& p, const GsGeom& g, const GsBinning& b, int res, GsImage& im, const GsFwdViews& vp, int V, size_t vs,
-                            bool record_activity, hipStream_t s) {
+                            bool record_activity, hipStream_t s, uint32_t* err) {
     const int tiles = p.gx * p.gy;
     if (tiles == 0 || V <= 0) return 0;
     uint8_t* pact = record_activity ? gs_pair_activity(b, res) : nullptr;
-    const dim3 grid(4 * gs_block_count(p.gx, p.gy), V);      // a multiple of 32 blocks per view: the XCD of a block (dispatch order % 8) does not depend on the view
+    ScanWaveJob sj{};
+    if (record_activity && p.N > 0)
+        sj = ScanWaveJob{g.tiles, g.rbase, g.rect, g.einfo, (uint32_t*)g.tmp_scan_a, err ? err : (uint32_t*)g.meta + 2, (uint32_t)p.N, scan_wave_blocks((size_t)p.N)};
+    const dim3 grid(sj.blocks + 4 * gs_block_count(p.gx, p.gy), V);      // a multiple of 32 blocks per view: the XCD of a block (dispatch order % 8) does not depend on the view
     if (record_activity)
-        hipLaunchKernelGGL(k_composite_fwd_w<true>, grid, dim3(64), 0, s, p, b.ranges, b.tval[res], g.rec0, vp, im.final_T, im.n_contrib, pact, b.pair_stride, vs);
+        hipLaunchKernelGGL(k_composite_fwd_w<true>, grid, dim3(64), 0, s, p, b.ranges, b.tval[res], g.rec0, vp, im.final_T, im.n_contrib, pact, b.pair_stride, vs, sj);
     else
-        hipLaunchKernelGGL(k_composite_fwd_w<false>, grid, dim3(64), 0, s, p, b.ranges, b.tval[res], g.rec0, vp, im.final_T, im.n_contrib, pact, b.pair_stride, vs);
+        hipLaunchKernelGGL(k_composite_fwd_w<false>, grid, dim3(64), 0, s, p, b.ranges, b.tval[res], g.rec0, vp, im.final_T, im.n_contrib, pact, b.pair_stride, vs, sj);
     C3D_LAUNCH_CHECK();
     return 0;
 }

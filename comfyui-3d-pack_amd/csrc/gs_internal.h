@@ -1,6 +1,7 @@
 // gs_internal.h -- internal types of the 3DGS rasterizer (not part of the C-ABI; see include/c3d_gs.h)
 #pragma once
 #include "c3d_common.h"
+#include "scan_wave.h"
 
 #define GS_PAIR_FLOATS 12   // per (tile, splat) gradient record: colour3, depth, mean2D2, conic3, opacity (+2 pad)
 
@@ -31,7 +32,7 @@ struct GsGeom {
     uint32_t* order[2];     // Gaussian ids, ping-pong; after stage 1 order[res] is rank -> id
     uint2* rsort;           // the tile rects in depth-rank order (left behind by the emit-offset scan, which gathers them; read by k_emit)
     uint32_t* offsets;      // inclusive scan of the tile counts in depth-rank order
-    uint4* einfo;           // per Gaussian with tiles: {0, x0 | y0<<16, x1 | y1<<16, record base} of its tile rect -- written by the record-base scan (coalesced)
+    uint4* einfo;           // per Gaussian with tiles: {0, x0 | y0<<16, x1 | y1<<16, record base} of its tile rect -- written by the record-base scan (coalesced; the scan runs inside the recording forward compositing launch)
     uint32_t* rbase;        // exclusive scan of `tiles` in Gaussian-id order: where this Gaussian's backward gradient records start
     uint8_t* clamped;       // 3 bits per Gaussian: SH colour channel clamped at 0
     int* meta;              // [0] = min(num_rendered, capacity) (device copy)  [2] = error word of the binning chain (C3D_ERR_LOOKBACK)
@@ -62,7 +63,7 @@ static inline void gs_carve_geom(char* base, int N, GsGeom& g) {
     g.clamped = (uint8_t*)take(n);
     const size_t meta_off = off;
     g.meta = (int*)take(64);
-    g.tmp = g.tmp_scan_a = take(c3d_scan_tmp_bytes(n));
+    g.tmp = g.tmp_scan_a = take(scan_wave_tmp_bytes(n));            // one-wave tiles: the scan rides in the recording forward compositing launch (scan_wave.h)
     g.tmp_scan_b = take(c3d_scan_tmp_bytes(n));
     g.tmp_sort = take(c3d_sort_tmp_bytes(n));                       // last: only its first c3d_sort_state_bytes need clearing
     g.zero_off = meta_off;
@@ -186,7 +187,7 @@ int gs_launch_preprocess_bwd_raw(const GsParams& p, const GsGeom& g, const int* 
 int gs_launch_emit(const GsParams& p, const GsGeom& g, int res, GsBinning& b, hipStream_t s, uint32_t cap = 0xFFFFFFFFu, int V = 1, size_t vs = 0);
 int gs_launch_ranges(const GsBinning& b, int res, long long D, hipStream_t s, const uint32_t* d_dev = nullptr, int V = 1, size_t vs = 0);
 int gs_launch_composite_fwd(const GsParams& p, const GsGeom& g, const GsBinning& b, int res, GsImage& im, const GsFwdViews& vp, int V, size_t vs,
-                            bool record_activity, hipStream_t s);
+                            bool record_activity, hipStream_t s, uint32_t* err = nullptr);
 int gs_launch_sum_view_loss(const float* terms, int n, float* view_sum, int V, size_t vs, hipStream_t s);   // per view: its per-tile partials (+ MS-SSIM term) -> one float
 int gs_launch_sum_tile_loss(const float* first_view_sum, size_t view_stride_bytes, int V, float* loss_out, hipStream_t s);   // the V view sums, in order, added to *loss_out
 int gs_launch_composite_bwd(const GsParams& p, const GsGeom& g, const GsBinning& b, int res, const GsImage& im, const GsBwdPix& px, bool depth,

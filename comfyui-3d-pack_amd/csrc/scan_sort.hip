@@ -64,7 +64,7 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* lds, u
 // ------------------------------------------------------------------------------------------
 #define LB_AGG 1ull
 #define LB_INCL 2ull
-struct ScanTail { uint32_t* meta; uint32_t* status; uint32_t cap; const uint2* rect; uint4* einfo; uint2* rsort; };   // rect / einfo: see c3d_scan_u32_einfo; rsort: GATHER
+struct ScanTail { uint32_t* meta; uint32_t* status; uint32_t cap; uint2* rsort; };   // rsort: GATHER
 __device__ __forceinline__ uint32_t rect_area(uint2 r) { return ((r.y & 0xFFFFu) - (r.x & 0xFFFFu)) * ((r.y >> 16) - (r.x >> 16)); }
 
 // Data movement (round 4: with V views per launch the scans are bandwidth-sized work, and eight 4-byte accesses per lane at a 32-byte lane stride cost eight
@@ -76,8 +76,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_lb(const uint32_t* __rest
     __shared__ uint32_t lds[SCAN_VEC][4];
     __shared__ uint32_t s_tile, s_prefix;
     in = c3d_view_ptr(in, vs); idx = c3d_view_ptr(idx, vs); out = c3d_view_ptr(out, vs); state = c3d_view_ptr(state, vs);
-    tail.meta = c3d_view_ptr(tail.meta, vs); tail.rect = c3d_view_ptr(tail.rect, vs); tail.einfo = c3d_view_ptr(tail.einfo, vs);   // err / tail.status: shared by the views
-    tail.rsort = c3d_view_ptr(tail.rsort, vs);
+    tail.meta = c3d_view_ptr(tail.meta, vs); tail.rsort = c3d_view_ptr(tail.rsort, vs);   // err / tail.status: shared by the views
     unsigned long long* status = reinterpret_cast<unsigned long long*>(state + 2);
     if (threadIdx.x == 0) s_tile = atomicAdd(&state[0], 1u);
     __syncthreads();
@@ -168,25 +167,13 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_lb(const uint32_t* __rest
 #pragma unroll
     for (int h = 0; h < SCAN_VEC; h++) {
         const size_t b = (size_t)tile * SCAN_TILE + (size_t)h * (SCAN_THREADS * 4) + (size_t)threadIdx.x * 4;
-        uint32_t run = pre + ex[h], o[4], e[4];
+        uint32_t run = pre + ex[h], o[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) { e[i] = run; run += v[h][i]; o[i] = EXCL ? e[i] : run; }
+        for (int i = 0; i < 4; i++) { const uint32_t e = run; run += v[h][i]; o[i] = EXCL ? e : run; }
         if (b + 3 < n) *reinterpret_cast<uint4*>(out + b) = make_uint4(o[0], o[1], o[2], o[3]);
         else {
 #pragma unroll
             for (int i = 0; i < 4; i++) if (b + i < n) out[b + i] = o[i];
-        }
-        if (tail.einfo) {   // epilogue of the record-base scan: {0, tile rect, record base} per element (what the backward compositing gathers)
-            if (b + 3 < n) {
-                const uint4 r01 = *reinterpret_cast<const uint4*>(tail.rect + b), r23 = *reinterpret_cast<const uint4*>(tail.rect + b + 2);
-                if (v[h][0]) tail.einfo[b] = make_uint4(0u, r01.x, r01.y, e[0]);
-                if (v[h][1]) tail.einfo[b + 1] = make_uint4(0u, r01.z, r01.w, e[1]);
-                if (v[h][2]) tail.einfo[b + 2] = make_uint4(0u, r23.x, r23.y, e[2]);
-                if (v[h][3]) tail.einfo[b + 3] = make_uint4(0u, r23.z, r23.w, e[3]);
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; i++) if (b + i < n && v[h][i]) { const uint2 rc = tail.rect[b + i]; tail.einfo[b + i] = make_uint4(0u, rc.x, rc.y, e[i]); }
-            }
         }
         if (tail.meta && b < n && b + 4 >= n) {      // this lane owns element n-1: `run` is the grand total (elements past n are zeros)
             const uint32_t total = run;
@@ -219,7 +206,7 @@ static int scan_launch(const uint32_t* in, const uint32_t* idx, uint32_t* out, s
     return 0;
 }
 int c3d_scan_u32(const uint32_t* in, uint32_t* out, size_t n, bool exclusive, void* tmp, hipStream_t s, bool zero_state, uint32_t* err) {
-    return scan_launch(in, nullptr, out, n, exclusive, tmp, s, zero_state, ScanTail{nullptr, nullptr, 0u, nullptr, nullptr, nullptr}, err);
+    return scan_launch(in, nullptr, out, n, exclusive, tmp, s, zero_state, ScanTail{nullptr, nullptr, 0u, nullptr}, err);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -253,14 +240,9 @@ int c3d_zero_views(void* base0, size_t vs, int V, const size_t* off, const size_
     C3D_LAUNCH_CHECK();
     return 0;
 }
-// exclusive scan of `in` (tile counts in Gaussian-id order) -> out (record bases), plus einfo[i] = {0, rect[i].x, rect[i].y, out[i]} where in[i] != 0
-int c3d_scan_u32_einfo(const uint32_t* in, uint32_t* out, size_t n, void* tmp, hipStream_t s, bool zero_state, uint32_t* err, const uint2* rect, uint4* einfo,
-                       int V, size_t vs) {
-    return scan_launch(in, nullptr, out, n, true, tmp, s, zero_state, ScanTail{nullptr, nullptr, 0xFFFFFFFFu, rect, einfo, nullptr}, err, V, vs);
-}
 int c3d_scan_rect_gather(const uint2* rect, const uint32_t* idx, uint32_t* out, uint2* rsort, size_t n, void* tmp, hipStream_t s, bool zero_state,
                          uint32_t* tail_meta, uint32_t* tail_status, uint32_t tail_cap, uint32_t* err, int V, size_t vs) {
-    return scan_launch(reinterpret_cast<const uint32_t*>(rect), idx, out, n, false, tmp, s, zero_state, ScanTail{tail_meta, tail_status, tail_cap, nullptr, nullptr, rsort}, err, V, vs);
+    return scan_launch(reinterpret_cast<const uint32_t*>(rect), idx, out, n, false, tmp, s, zero_state, ScanTail{tail_meta, tail_status, tail_cap, rsort}, err, V, vs);
 }
 uint32_t* c3d_scan_error_word(void* tmp) { return (uint32_t*)tmp + 1; }
 

@@ -581,6 +581,27 @@ def test_gaussian_splatting_3d_node_accepts_every_initialiser(init):
     assert torch.isfinite(out).all() and out.shape == (1, H, W, 3)
 
 
+def test_renderer_initialises_from_a_uv_grid_triple():
+    """GaussianSplattingRenderer.initialize with the UV-grid triple (reference main_3DGS_renderer.py:526-539, :827-828: the `else` branch of initialize): one Gaussian
+    per texel position, random near-black colours, the k-nn scale, learning-rate scale 10 -- the same model create_from_pcd builds from those points"""
+    from MVs_Algorithms.GaussianSplatting.main_3DGS_renderer import GaussianSplattingRenderer, PointCloud, SH2RGB
+    rng = np.random.default_rng(0)
+    pts = rng.uniform(-0.5, 0.5, size=(700, 3))
+    uv = (rng.uniform(size=(700, 2)), [p for p in pts], rng.normal(size=(700, 3)))
+    np.random.seed(3)
+    a = GaussianSplattingRenderer(sh_degree=3, device="cuda")
+    a.initialize(uv)
+    np.random.seed(3)
+    b = GaussianSplattingRenderer(sh_degree=3, device="cuda")
+    b.gaussians.create_from_pcd(PointCloud(points=pts, colors=SH2RGB(np.random.random((700, 3)) / 255.0), normals=np.zeros((700, 3))), 10)
+    ga, gb = a.gaussians, b.gaussians
+    assert ga._xyz.shape == (700, 3) and ga.spatial_lr_scale == 10
+    for x, y in ((ga._xyz, gb._xyz), (ga._features_dc, gb._features_dc), (ga._scaling, gb._scaling), (ga._opacity, gb._opacity), (ga._rotation, gb._rotation)):
+        assert torch.equal(x, y)
+    with pytest.raises(TypeError):
+        a.initialize((1, 2))
+
+
 @pytest.mark.parametrize("sc", [(130, 97, 24, 40), (256, 256, 64, 128), (96, 96, 2, 3)])
 def test_rasterize_backward_gather_equals_scatter(sc):
     """The atomic-free rasterize backward (per-triangle corner records + fixed-order per-vertex sum; large triangles by a workgroup) against
