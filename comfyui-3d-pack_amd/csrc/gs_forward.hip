@@ -434,6 +434,9 @@ __global__ void __launch_bounds__(64, 8) k_composite_fwd_w(GsParams p, const uin
 }
 
 // One launch for V views (grid.y): view v's state lies v * vs bytes behind the pointers of g / b / im; its background and output planes come from vp.
+#ifdef GS_SCAN_A_SEPARATE      // A/B: the same one-wave tiles as a launch of their own in front of the compositing kernel
+__global__ void __launch_bounds__(64) k_scan_wave(ScanWaveJob sj, size_t vs) { scan_wave_tile(sj, vs); }
+#endif
 // record_activity: a backward pass may follow -- the launch records the blended (quadrant, splat) pairs AND runs the record-base scan (rbase, einfo of g; state
 // g.tmp_scan_a, cleared with the rest of the view's binning state) in its first workgroups.  err: error word of a timed-out look-back (nullptr: the view's own, g.meta[2]).
 int gs_launch_composite_fwd(const GsParams& p, const GsGeom& g, const GsBinning& b, int res, GsImage& im, const GsFwdViews& vp, int V, size_t vs,
@@ -444,6 +447,9 @@ int gs_launch_composite_fwd(const GsParams& p, const GsGeom& g, const GsBinning&
     ScanWaveJob sj{};
     if (record_activity && p.N > 0)
         sj = ScanWaveJob{g.tiles, g.rbase, g.rect, g.einfo, (uint32_t*)g.tmp_scan_a, err ? err : (uint32_t*)g.meta + 2, (uint32_t)p.N, scan_wave_blocks((size_t)p.N)};
+#ifdef GS_SCAN_A_SEPARATE
+    if (sj.blocks) { hipLaunchKernelGGL(k_scan_wave, dim3(sj.blocks, V), dim3(64), 0, s, sj, vs); sj.blocks = 0; }
+#endif
     const dim3 grid(sj.blocks + 4 * gs_block_count(p.gx, p.gy), V);      // a multiple of 32 blocks per view: the XCD of a block (dispatch order % 8) does not depend on the view
     if (record_activity)
         hipLaunchKernelGGL(k_composite_fwd_w<true>, grid, dim3(64), 0, s, p, b.ranges, b.tval[res], g.rec0, vp, im.final_T, im.n_contrib, pact, b.pair_stride, vs, sj);

@@ -1087,491 +1087,6 @@ def test_fused_forward_backward_halves_match_autograd():
             assert torch.equal(a, b)
 
 
-def test_sync_free_drop_in_forward_equals_the_synchronous_path_bit_for_bit():
-    """Round 5: after the first call of a (device, N, H, W) shape the drop-in rasterizer runs c3d_gs_forward_nosync / c3d_gs_forward_raw_nosync -- launches
-    sized for a pair capacity, the count left on the device, status words examined one call late -- instead of stalling the host for num_rendered.  Same kernels,
-    same arithmetic: images, radii and every gradient must have the same BITS as the synchronous path's, on the plain and on the raw-parameter entry points."""
-    import warnings
-    import diff_gaussian_rasterization as dgr
-    sc = S.make_cloud(60000, seed=8, log_scale_mean=np.log(0.012))
-    raw = S.make_cloud(60000, seed=8, log_scale_mean=np.log(0.012), activated=False)
-    W, H = 400, 232
-    st = S.camera_settings(W, H, 49.1, -12.0, 70.0, 2.2)
-    rs = hip_settings(st, "cuda")
-    gC = _dev(np.random.default_rng(3).normal(size=(3, H, W)).astype(np.float32), torch.float32)
-
-    def plain():
-        color, radii, depth, alpha, inp, m2d = hip_forward(sc, st, requires_grad=True)
-        ((color * gC).sum() + alpha.sum() + 0.1 * depth.sum()).backward()
-        return [color.detach(), radii, depth.detach(), alpha.detach(), m2d.grad] + [inp[k].grad for k in ("means3D", "opacities", "shs", "scales", "rotations")]
-
-    def rawp():
-        t = [torch.tensor(raw[k] if k != "shs" else raw["shs"][:, :1], dtype=torch.float32, device="cuda", requires_grad=True) for k in ("means3D", "shs")]
-        f_rest = torch.tensor(raw["shs"][:, 1:], dtype=torch.float32, device="cuda", requires_grad=True)
-        rest = [torch.tensor(raw[k], dtype=torch.float32, device="cuda", requires_grad=True) for k in ("opacities", "scales", "rotations")]
-        m2d = torch.zeros_like(t[0], requires_grad=True)
-        color, radii, depth, alpha = dgr.rasterize_gaussians_raw(t[0], m2d, t[1], f_rest, rest[0], rest[1], rest[2], rs)
-        ((color * gC).sum() + alpha.sum() + 0.1 * depth.sum()).backward()
-        return [color.detach(), radii, depth.detach(), alpha.detach(), m2d.grad, t[0].grad, t[1].grad, f_rest.grad] + [x.grad for x in rest]
-
-    for fn in (plain, rawp):
-        was = dgr.sync_free(False)
-        try:
-            ref = fn()
-        finally:
-            dgr.sync_free(was)
-        dgr.flush()
-        D = int(dgr.last_num_rendered)
-        key = (torch.cuda.current_device(), 60000, H, W)
-        assert dgr._cap.get(key, 0) >= D > 0                       # the synchronous call taught the shape its capacity
-        n_before = len(dgr._pending)
-        with warnings.catch_warnings():
-            warnings.simplefilter("error")                          # no overflow warning may appear
-            got = fn()
-            assert len(dgr._pending) == n_before + 1 or not dgr._pending   # the call went through the sync-free entry point (status words on their way)
-            dgr.flush()
-        assert int(dgr.last_num_rendered) == D
-        for a, b in zip(got, ref):
-            assert torch.equal(a, b), fn.__name__
-
-
-def test_sync_free_overflow_is_reported_one_call_late_and_the_capacity_regrows():
-    """a view that needs more pairs than the learnt capacity: the call completes (pairs beyond the capacity are dropped, no out-of-bounds access in either
-    direction), the next examination warns and regrows, and the call after that is exact again"""
-    import warnings
-    import diff_gaussian_rasterization as dgr
-    sc = S.make_cloud(50000, seed=18, log_scale_mean=np.log(0.015))
-    W, H = 360, 200
-    st = S.camera_settings(W, H, 49.1, 5.0, -40.0, 2.2)
-    gC = _dev(np.random.default_rng(5).normal(size=(3, H, W)).astype(np.float32), torch.float32)
-    was = dgr.sync_free(False)
-    try:
-        color0, radii0, depth0, alpha0, inp0, _ = hip_forward(sc, st, requires_grad=True)
-        (color0 * gC).sum().backward()
-    finally:
-        dgr.sync_free(was)
-    D = int(dgr.last_num_rendered)
-    key = (torch.cuda.current_device(), 50000, H, W)
-    dgr._cap[key] = max(4096, D // 3)                               # far too small
-    color1, radii1, depth1, alpha1, inp1, _ = hip_forward(sc, st, requires_grad=True)
-    (color1 * gC).sum().backward()                                  # must not fault: record indices beyond the capacity are neither written nor read
-    torch.cuda.synchronize()
-    assert torch.isfinite(color1).all() and all(torch.isfinite(inp1[k].grad).all() for k in inp1)
-    with warnings.catch_warnings(record=True) as w:
-        warnings.simplefilter("always")
-        dgr.flush()
-    assert any(issubclass(x.category, RuntimeWarning) and "incomplete" in str(x.message) for x in w)
-    assert dgr._cap[key] >= D
-    with warnings.catch_warnings():
-        warnings.simplefilter("error")
-        color2, radii2, depth2, alpha2, inp2, _ = hip_forward(sc, st, requires_grad=True)
-        (color2 * gC).sum().backward()
-        dgr.flush()
-    assert torch.equal(color2, color0) and torch.equal(radii2, radii0) and torch.equal(alpha2, alpha0)
-    for k in inp0:
-        assert torch.equal(inp2[k].grad, inp0[k].grad), k
-
-
-def test_fused_activation_path_equals_accessor_path():
-    """rasterize_gaussians_raw (exp / sigmoid / normalize / cat folded into the kernels) against the op-by-op accessor path of
-    GaussianSplattingRenderer.render: same images, same gradients on the raw parameters."""
-    from MVs_Algorithms.GaussianSplatting.main_3DGS_renderer import GaussianSplattingRenderer
-    from shared_utils.camera_utils import MiniCam, OrbitCamera, orbit_camera
-    raw = S.make_cloud(30000, seed=11, log_scale_mean=np.log(0.02), activated=False)
-    W, H = 320, 200
-    cam = OrbitCamera(W, H, fovy=49.1)
-    mc = MiniCam(orbit_camera(-15.0, 50.0, 2.2), W, H, cam.fovy, cam.fovx, 0.01, 100, device="cuda")
-    gC = _dev(np.random.default_rng(4).normal(size=(3, H, W)).astype(np.float32), torch.float32)
-    outs = []
-    for unfused in (False, True):
-        r = GaussianSplattingRenderer(sh_degree=3, device="cuda")
-        r.initialize({"xyz": raw["means3D"], "features": raw["shs"], "scaling_raw": raw["scales"], "rotation_raw": raw["rotations"] * 3.0,
-                      "opacity_raw": raw["opacities"]})
-        r.force_unfused = unfused
-        out = r.render(mc, scaling_modifier=0.9)
-        ((out["image"] * gC).sum() + out["alpha"].sum() + 0.1 * out["depth"].sum()).backward()
-        g = r.gaussians
-        outs.append((out, [t.grad.clone() for t in (g._xyz, g._features_dc, g._features_rest, g._opacity, g._scaling, g._rotation)],
-                     out["viewspace_points"].grad.clone()))
-    (o1, g1, v1), (o2, g2, v2) = outs
-    assert torch.equal(o1["radii"], o2["radii"])
-    assert (o1["image"] - o2["image"]).abs().mean().item() <= 1e-6 and (o1["alpha"] - o2["alpha"]).abs().max().item() <= 1e-5
-    for a, b, name in zip(g1, g2, ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")):
-        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) <= 2e-4, name
-    assert rel_err(v1.cpu().numpy(), v2.cpu().numpy()) <= 2e-4
-
-
-@pytest.mark.parametrize("deg", [0, 1, 2])
-def test_raw_parameter_paths_take_any_sh_storage_degree(deg):
-    """A PLY of SH degree 0, 1 or 2 (mesh_processer/mesh_utils.py:346-350 of the reference loads any; LGM's converter writes degree 0: f_rest [N, K-1, 3] with
-    K = (deg + 1)^2, empty for degree 0) takes the SAME fused paths as the degree-3 storage of the trainer -- rasterize_gaussians_raw, c3d_gs_render_views_raw,
-    c3d_gs_train_views_raw -- and each is held to the op-by-op accessor path through the plain boundary (which the float64 restatement tests above cover)."""
-    from MVs_Algorithms.GaussianSplatting.main_3DGS_renderer import GaussianSplattingRenderer
-    from c3d_hip.gs_step import FusedViewStep
-    from shared_utils.camera_utils import MiniCam, OrbitCamera, orbit_camera
-    K = (deg + 1) ** 2
-    raw = S.make_cloud(30000, seed=13, log_scale_mean=np.log(0.02), activated=False)
-    W, H = 320, 200
-    cam = OrbitCamera(W, H, fovy=49.1)
-    cams = [MiniCam(orbit_camera(el, az, 2.2), W, H, cam.fovy, cam.fovx, 0.01, 100, device="cuda") for el, az in ((-15.0, 50.0), (20.0, -120.0), (45.0, 170.0))]
-    rng = np.random.default_rng(4)
-    gC = _dev(rng.normal(size=(3, H, W)).astype(np.float32), torch.float32)
-
-    def make():
-        r = GaussianSplattingRenderer(sh_degree=deg, device="cuda")
-        r.initialize({"xyz": raw["means3D"], "features": raw["shs"][:, :K], "scaling_raw": raw["scales"], "rotation_raw": raw["rotations"], "opacity_raw": raw["opacities"]})
-        g = r.gaussians
-        assert g.max_sh_degree == deg and tuple(g._features_rest.shape[1:]) == (K - 1, 3)
-        return r, [g._xyz, g._features_dc, g._features_rest, g._opacity, g._scaling, g._rotation]
-
-    # (1) one view through autograd: fused raw entry point vs accessor path
-    outs = []
-    for unfused in (False, True):
-        r, plist = make()
-        r.force_unfused = unfused
-        out = r.render(cams[0])
-        ((out["image"] * gC).sum() + out["alpha"].sum() + 0.1 * out["depth"].sum()).backward()
-        outs.append((out, [t.grad.clone() if t.grad is not None else torch.zeros_like(t) for t in plist]))
-    (o1, g1), (o2, g2) = outs
-    assert torch.equal(o1["radii"], o2["radii"])
-    # the two paths run different instances of the projection kernel (other FMA contractions: last-bit differences in conic / opacity), so a splat that sits
-    # exactly at the alpha = 1/255 threshold of a pixel may be taken by one and dropped by the other: <= 1/255 there, nothing elsewhere
-    assert (o1["image"] - o2["image"]).abs().mean().item() <= 1e-6 and (o1["alpha"] - o2["alpha"]).abs().mean().item() <= 1e-6
-    assert (o1["alpha"] - o2["alpha"]).abs().max().item() <= 1.05 / 255
-    for a, b, name in zip(g1, g2, ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")):
-        if a.numel():
-            e = rel_err(a.cpu().numpy(), b.cpu().numpy())
-            assert e <= GRAD_REL, (name, deg, e)          # a threshold flip shows in the gradients too: the north star's bound, not the 2e-4 of identical decisions
-    # (2) the multi-view forward call: bit-equal to the per-view fused render
-    r, plist = make()
-    with torch.no_grad():
-        per_view = [r.render(c) for c in cams]
-        batch = r.render_views(cams, lanes=1, group=3)
-    for i, pv in enumerate(per_view):
-        for k in ("image", "depth", "alpha", "radii"):
-            assert torch.equal(batch[k][i], pv[k]), (k, i)
-    # (3) the fused training step against autograd over the accessor path, same loss
-    import diff_gaussian_rasterization as dgr
-    import math
-    tcs = [_dev(rng.uniform(size=(3, H, W)).astype(np.float32), torch.float32) for _ in cams]
-    tas = [_dev(rng.uniform(size=(1, H, W)).astype(np.float32), torch.float32) for _ in cams]
-    r.force_unfused = True
-    for c, tc, ta in zip(cams, tcs, tas):
-        out = r.render(c)
-        ((0.8 * (out["image"] - tc).abs().mean() + 3.0 * ((out["alpha"] - ta) ** 2).mean()) / len(cams)).backward()
-    ref = [t.grad.clone() if t.grad is not None else torch.zeros_like(t) for t in plist]
-    rs = [dgr.GaussianRasterizationSettings(H, W, math.tan(c.FoVx * 0.5), math.tan(c.FoVy * 0.5), r.bg_color, 1.0, c.world_view_transform, c.full_proj_transform,
-                                            deg, c.camera_center, False, False) for c in cams]
-    step = FusedViewStep(30000, H, W, "cuda", lanes=1)
-    grads = [torch.empty_like(t) for t in plist]
-    step.run(rs, [t.detach() for t in plist], grads, tcs, tas, None, w_l1=0.8, w_alpha_mse=3.0, scale=1.0 / len(cams), accumulate=False)
-    for a, b, name in zip(grads, ref, ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")):
-        if a.numel():
-            e = rel_err(a.cpu().numpy(), b.cpu().numpy())
-            assert e <= GRAD_REL, (name, deg, e)
-
-
-@pytest.mark.parametrize("lanes", [1, 2, 4])
-def test_fused_multi_view_step_matches_autograd(lanes):
-    """c3d_gs_train_views_raw (V views, pixel loss and backward in one sync-free call, views dealt onto `lanes` HIP streams) against the
-    per-view autograd path with the same loss; also the overflow / regrow path and run-to-run bit reproducibility."""
-    from MVs_Algorithms.GaussianSplatting.main_3DGS_renderer import GaussianSplattingRenderer
-    from c3d_hip.gs_step import FusedViewStep
-    import diff_gaussian_rasterization as dgr
-    raw = S.make_cloud(40000, seed=21, log_scale_mean=np.log(0.015), activated=False)
-    W, H, V = 256, 160, 5          # 5 views: with lanes > 1 the per-Gaussian pass runs in two chunks (views 0-3, then 4)
-    r = GaussianSplattingRenderer(sh_degree=3, device="cuda")
-    r.initialize({"xyz": raw["means3D"], "features": raw["shs"], "scaling_raw": raw["scales"], "rotation_raw": raw["rotations"], "opacity_raw": raw["opacities"]})
-    g = r.gaussians
-    plist = [g._xyz, g._features_dc, g._features_rest, g._opacity, g._scaling, g._rotation]
-    rs_list, cams = [], []
-    for (el, az) in [(-20.0, 10.0), (15.0, 130.0), (40.0, -100.0), (0.0, 60.0), (-35.0, -30.0)]:
-        st = S.camera_settings(W, H, 49.1, el, az, 2.2, bg=(1, 1, 1))
-        rs = hip_settings(st, "cuda")
-        rs_list.append(rs)
-        cams.append(type("Cam", (), dict(image_height=H, image_width=W, FoVx=2 * np.arctan(st["tanfovx"]), FoVy=2 * np.arctan(st["tanfovy"]),
-                                         world_view_transform=rs.viewmatrix, full_proj_transform=rs.projmatrix, camera_center=rs.campos))())
-    rng = np.random.default_rng(0)
-    tcs = [_dev(rng.uniform(size=(3, H, W)).astype(np.float32), torch.float32) for _ in range(V)]
-    tas = [_dev(rng.uniform(size=(1, H, W)).astype(np.float32), torch.float32) for _ in range(V)]
-    white = torch.ones(3, device="cuda")
-    # reference: autograd over the renderer API
-    total = 0.0
-    for i in range(V):
-        out = r.render(cams[i], bg_color=white)
-        loss = 0.5 * (0.8 * (out["image"] - tcs[i]).abs().mean() + 0.3 * ((out["image"] - tcs[i]) ** 2).mean() + 3.0 * ((out["alpha"] - tas[i]) ** 2).mean())
-        loss.backward()
-        total += loss.item()
-    ref = [p.grad.clone() for p in plist]
-    for p in plist:
-        p.grad = None
-    # fused step, deliberately tiny capacity first to exercise the regrow path
-    step = FusedViewStep(40000, H, W, "cuda", pair_capacity=5000, lanes=lanes)
-    grads = [torch.zeros_like(p) for p in plist]
-    lv = step.run(rs_list, [p.detach() for p in plist], grads, tcs, tas, None, w_l1=0.8, w_l2=0.3, w_alpha_mse=3.0, scale=0.5)
-    assert step.capacity > 5000
-    assert abs(lv.item() - total) <= 1e-4 * max(1.0, abs(total))
-    for a, b, name in zip(grads, ref, ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")):
-        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) <= 5e-4, name
-    # second call accumulates on top
-    lv2 = step.run(rs_list, [p.detach() for p in plist], grads, tcs, tas, None, w_l1=0.8, w_l2=0.3, w_alpha_mse=3.0, scale=0.5)
-    for a, b in zip(grads, ref):
-        assert rel_err(a.cpu().numpy(), 2 * b.cpu().numpy()) <= 5e-4
-    # fixed lane count -> fixed summation order -> identical bits from run to run
-    runs = []
-    for _ in range(2):
-        gz = [torch.zeros_like(p) for p in plist]
-        step.run(rs_list, [p.detach() for p in plist], gz, tcs, tas, None, w_l1=0.8, w_l2=0.3, w_alpha_mse=3.0, scale=0.5)
-        runs.append(gz)
-    for a, b in zip(*runs):
-        assert torch.equal(a, b)
-
-
-def test_fused_step_deferred_status():
-    """defer_status: a fitted step does not wait for its own overflow / fault words; the next run() (or finish()) examines them.  Same gradients as the
-    synchronous mode; an overflow between two steps is noticed one step late, loudly, and the capacity regrown."""
-    import warnings
-    from MVs_Algorithms.GaussianSplatting.main_3DGS_renderer import GaussianSplattingRenderer
-    from c3d_hip.gs_step import FusedViewStep
-    raw = S.make_cloud(30000, seed=5, log_scale_mean=np.log(0.015), activated=False)
-    W, H = 192, 128
-    r = GaussianSplattingRenderer(sh_degree=3, device="cuda")
-    r.initialize({"xyz": raw["means3D"], "features": raw["shs"], "scaling_raw": raw["scales"], "rotation_raw": raw["rotations"], "opacity_raw": raw["opacities"]})
-    g = r.gaussians
-    plist = [q.detach() for q in (g._xyz, g._features_dc, g._features_rest, g._opacity, g._scaling, g._rotation)]
-    rs = [hip_settings(S.camera_settings(W, H, 49.1, el, az, 2.2, bg=(1, 1, 1)), "cuda") for el, az in ((-20.0, 10.0), (15.0, 130.0), (40.0, -100.0))]
-    rng = np.random.default_rng(0)
-    tcs = [_dev(rng.uniform(size=(3, H, W)).astype(np.float32), torch.float32) for _ in rs]
-    tas = [_dev(rng.uniform(size=(1, H, W)).astype(np.float32), torch.float32) for _ in rs]
-    outs = []
-    for defer in (False, True):
-        step = FusedViewStep(30000, H, W, "cuda", lanes=2)
-        step.defer_status = defer
-        grads = [torch.empty_like(q) for q in plist]
-        losses = [step.run(rs, plist, grads, tcs, tas, None, w_l1=0.8, w_alpha_mse=3.0, scale=1 / 3, accumulate=False) for _ in range(3)]
-        assert (step._pending is not None) == defer               # the first run fits the capacity synchronously, later ones are deferred
-        step.finish()
-        assert step._pending is None
-        outs.append(([l.item() for l in losses], [q.clone() for q in grads]))
-    assert np.allclose(outs[0][0], outs[1][0], rtol=1e-6)            # the loss VALUE is summed with float atomics (one per workgroup): last-bit differences
-    for a, b in zip(outs[0][1], outs[1][1]):
-        assert torch.equal(a, b)
-    # overflow noticed one step late: by the next run() (which then redoes itself with the regrown capacity) ...
-    step.capacity = 2000
-    step._alloc()
-    with warnings.catch_warnings(record=True) as wlist:
-        warnings.simplefilter("always")
-        step.run(rs, plist, grads, tcs, tas, None, w_l1=0.8, w_alpha_mse=3.0, scale=1 / 3, accumulate=False)
-        assert not wlist
-        step.run(rs, plist, grads, tcs, tas, None, w_l1=0.8, w_alpha_mse=3.0, scale=1 / 3, accumulate=False)
-    assert any("incomplete" in str(w.message) for w in wlist) and step.capacity > 2000
-    step.finish()
-    for a, b in zip(grads, outs[0][1]):
-        assert torch.equal(a, b)
-
-
-def test_fused_step_param_backward_by_gaussian_ranges():
-    """run(param_chunks=K, after_chunk=...): the per-Gaussian backward pass range by range (c3d_gs_step_param_backward_range) -- what the multi-GPU
-    step uses to start a range's gradient exchange underneath the next range's kernels.  Same bits as the one-launch pass; the callback sees
-    every row exactly once, in order, and (here) checks that the rows it is handed are already final on the stream."""
-    from MVs_Algorithms.GaussianSplatting.main_3DGS_renderer import GaussianSplattingRenderer
-    from c3d_hip.gs_step import FusedViewStep
-    N = 30001                                                           # not a multiple of the 256-Gaussian range granularity
-    raw = S.make_cloud(N, seed=6, log_scale_mean=np.log(0.015), activated=False)
-    W, H = 192, 128
-    r = GaussianSplattingRenderer(sh_degree=3, device="cuda")
-    r.initialize({"xyz": raw["means3D"], "features": raw["shs"], "scaling_raw": raw["scales"], "rotation_raw": raw["rotations"], "opacity_raw": raw["opacities"]})
-    g = r.gaussians
-    plist = [q.detach() for q in (g._xyz, g._features_dc, g._features_rest, g._opacity, g._scaling, g._rotation)]
-    rs = [hip_settings(S.camera_settings(W, H, 49.1, el, az, 2.2, bg=(1, 1, 1)), "cuda") for el, az in ((-20.0, 10.0), (15.0, 130.0), (40.0, -100.0))]
-    rng = np.random.default_rng(0)
-    tcs = [_dev(rng.uniform(size=(3, H, W)).astype(np.float32), torch.float32) for _ in rs]
-    tas = [_dev(rng.uniform(size=(1, H, W)).astype(np.float32), torch.float32) for _ in rs]
-    step = FusedViewStep(N, H, W, "cuda", lanes=2)
-    ref = [torch.empty_like(q) for q in plist]
-    l0 = step.run(rs, plist, ref, tcs, tas, None, w_l1=0.8, w_alpha_mse=3.0, scale=1 / 3, accumulate=False)      # fits the capacity; one launch
-    assert step._fitted
-    for chunks in (1, 3, 7):
-        grads = [torch.full_like(q, float("nan")) for q in plist]
-        seen, snaps = [], []
-
-        def after(g0, g1):
-            seen.append((g0, g1))
-            snaps.append([q[g0:g1].clone() for q in grads])             # stream-ordered copy: what a collective launched here would read
-        l1 = step.run(rs, plist, grads, tcs, tas, None, w_l1=0.8, w_alpha_mse=3.0, scale=1 / 3, accumulate=False, param_chunks=chunks, after_chunk=after)
-        assert len(seen) == chunks and seen[0][0] == 0 and seen[-1][1] == N and all(a[1] == b[0] for a, b in zip(seen[:-1], seen[1:]))
-        assert all(a % 256 == 0 for a, _ in seen)
-        assert torch.equal(l0, l1)
-        for a, b in zip(grads, ref):
-            assert torch.equal(a, b)
-        for (g0, g1), snap in zip(seen, snaps):
-            for a, b in zip(snap, ref):
-                assert torch.equal(a, b[g0:g1])
-    import c3d_hip
-    lib = c3d_hip.lib()
-    assert lib.c3d_gs_step_param_backward_range(None, 1, N, *([None] * 5), *([None] * 6), 100, 0, None, 2, 10, None) != 0      # argument checks come first
-    assert b"NULL" in lib.c3d_last_error()
-
-
-@pytest.mark.parametrize("lambda_ssim,offsets", [(0.0, False), (0.2, False), (0.2, True)])
-def test_trainer_fused_step_equals_autograd_step(lambda_ssim, offsets):
-    """GaussianSplatting3D.training_step with the reference's node defaults -- lambda_ssim 0.2, invert_bg_prob 0.5 (nodes.py:1177,1181) -- and
-    without MS-SSIM: the fused library step and the per-view autograd path draw the same backgrounds, produce the same loss and leave the
-    same parameters after an Adam step.  Masks are SOFT (rembg alpha / the bilinear resize of _fit): (c - ref) * mask, not c*mask - ref*mask^2."""
-    from MVs_Algorithms.GaussianSplatting.main_3DGS import GSParams, GaussianSplatting3D
-    H = W = 192                                                     # 5-scale MS-SSIM needs sides > 160
-    poses = [[1.75, -10.0, az, 0.0, 0.0, 0.0] for az in (0.0, 120.0, -120.0)]
-    rng = np.random.default_rng(1)
-    refs = [torch.tensor(rng.uniform(size=(H, W, 3)).astype(np.float32)) for _ in poses]
-    masks = [torch.tensor(np.clip(rng.uniform(size=(H, W)) * 1.6 - 0.3, 0, 1).astype(np.float32)) for _ in poses]
-    results = []
-    for variant in ("library", "halves", "autograd"):
-        fused = variant != "autograd"
-        np.random.seed(3); torch.manual_seed(3)
-        p = GSParams(training_iterations=2, batch_size=3, lambda_ssim=lambda_ssim, num_pts=5000, density_start_iter=10 ** 9, density_end_iter=-1, invert_bg_prob=0.5,
-                     lambda_offset=0.5 if offsets else 0.0, lambda_offset_opacity=0.3 if offsets else 0.0)
-        tr = GaussianSplatting3D(p, None, device="cuda")
-        tr.use_fused_step = fused
-        tr.image_loss_in_torch = variant == "halves"        # library: L1 + alpha MSE + MS-SSIM inside c3d_gs_train_views_raw; halves: torch's loss between the two halves
-        tr.ms_ssim_loss.use_hip = False                      # wherever torch computes the loss here it is the plain-torch MS-SSIM: an independent check of the HIP one
-        tr.prepare_training(refs, masks, poses, 49.1)
-        assert tr._can_fuse() == fused
-        np.random.seed(17)                                           # the per-view background draws
-        losses = [tr.training_step(s, [0, 1, 2]).item() for s in range(2)]
-        results.append((losses, [q.detach().clone() for q in tr.params]))
-    (l2, p2) = results[-1]
-    for (l1, p1) in results[:-1]:
-        assert abs(l1[0] - l2[0]) <= 1e-5 * max(1, abs(l2[0])) and abs(l1[1] - l2[1]) <= 1e-4 * max(1, abs(l2[1])), (l1, l2)
-        for a, b in zip(p1, p2):
-            assert (a - b).abs().max().item() <= 2e-4 * max(1.0, b.abs().max().item())
-
-
-@pytest.mark.parametrize("shape,masked", [((2, 3, 201, 183), False), ((2, 3, 201, 183), True), ((1, 3, 1080, 1920), True), ((3, 1, 176, 320), False),
-                                          ((2, 3, 186, 330), True)])      # 186 = 16 * 11 + 10, 330 = 32 * 10 + 10: the last tile of a row / column pools its whole halo (round 4: pooling inside the forward kernel)
-def test_msssim_hip_matches_the_torch_restatement(shape, masked):
-    """include/c3d_loss.h: value and d/dy of mean MS-SSIM(x, y) from the fused HIP kernels against the plain-torch restatement of the published
-    algorithm (shared_utils/msssim.py, the stand-in for pytorch_msssim.MS_SSIM the reference calls at main_3DGS.py:192) -- odd sizes (the padded
-    2 x 2 pooling), the level-0 transform x * mask, clamp(y) * mask with its chain rule, gradient accumulation, bit reproducibility."""
-    import c3d_hip as h
-    from shared_utils.msssim import MS_SSIM
-    B, C, H, W = shape
-    gen = torch.Generator(device="cpu").manual_seed(B * H + W)
-    base = torch.rand((B, C, H, W), generator=gen)
-    x = (0.6 * base + 0.4 * torch.rand((B, C, H, W), generator=gen)).cuda()
-    y = (0.6 * base + 0.4 * torch.rand((B, C, H, W), generator=gen) * 1.3 - 0.1).cuda()      # some values outside [0, 1]: the clamp matters
-    m = torch.rand((B, 1, H, W), generator=gen).cuda() if masked else None
-    ms = MS_SSIM(data_range=1, size_average=True, channel=C)
-    ms.use_hip = False
-    yt = y.clone().requires_grad_(True)
-    ref = ms(x * m, yt.clamp(0, 1) * m) if masked else ms(x, yt)
-    ref.backward()
-    lib = h.lib()
-    ws = torch.empty((lib.c3d_msssim_workspace_bytes(B, C, H, W),), dtype=torch.uint8, device="cuda")
-    grads = []
-    for rep in range(2):
-        g = torch.full_like(y, 7.0)
-        val = torch.zeros(1, device="cuda")
-        h.check(lib.c3d_msssim_value_grad(h.ptr(x), h.ptr(y), h.ptr(m) if masked else None, 1 if masked else 0, B, C, H, W, 1.0, 0, h.ptr(g), h.ptr(val), h.ptr(ws), h.stream()), "msssim")
-        grads.append(g)
-    assert torch.equal(grads[0], grads[1])                              # no atomics: identical bits
-    assert abs(val.item() - ref.item()) <= 2e-5 * max(abs(ref.item()), 1e-3), (val.item(), ref.item())
-    err = (grads[0] - yt.grad).abs()
-    scale = yt.grad.abs().max().item()
-    print("[msssim %s masked=%s] value %.6f (torch %.6f), grad max err %.2e of max %.2e, rel L2 %.2e"
-          % (shape, masked, val.item(), ref.item(), err.max().item(), scale, (err.norm() / yt.grad.norm()).item()))
-    assert (err.norm() / yt.grad.norm()).item() <= 1e-3 and err.max().item() <= 2e-3 * scale
-    # accumulate with a scale
-    g = torch.ones_like(y)
-    h.check(lib.c3d_msssim_value_grad(h.ptr(x), h.ptr(y), h.ptr(m) if masked else None, 1 if masked else 0, B, C, H, W, -0.5, 1, h.ptr(g), None, h.ptr(ws), h.stream()), "msssim")
-    assert torch.allclose(g, 1.0 - 0.5 * grads[0], rtol=1e-5, atol=1e-7 * max(scale, 1e-30) + 1e-12)
-    # the autograd front end (what the trainers call): MS_SSIM(x, y) -> HIP, gradient through backward()
-    ms_h = MS_SSIM(data_range=1, size_average=True, channel=C)
-    yh = (y.clamp(0, 1) * m if masked else y).detach().clone().requires_grad_(True)
-    v = ms_h(x * m if masked else x, yh)
-    (3.0 * v).backward()
-    yr = yh.detach().clone().requires_grad_(True)
-    vr = ms(x * m if masked else x, yr)
-    vr.backward()
-    assert abs(v.item() - vr.item()) <= 2e-5 and ((yh.grad - 3.0 * yr.grad).norm() / (3.0 * yr.grad.norm())).item() <= 1e-3
-
-
-def test_fused_forward_backward_halves_match_autograd():
-    """c3d_gs_forward_views_raw + c3d_gs_backward_views_raw (the fused step split at the image, per-view backgrounds, caller-supplied
-    dL/dcolor, dL/ddepth, dL/dalpha) against the per-view autograd path over the same renderer."""
-    from MVs_Algorithms.GaussianSplatting.main_3DGS_renderer import GaussianSplattingRenderer
-    from c3d_hip.gs_step import FusedViewStep
-    raw = S.make_cloud(40000, seed=21, log_scale_mean=np.log(0.015), activated=False)
-    W, H, V = 256, 160, 5
-    r = GaussianSplattingRenderer(sh_degree=3, device="cuda")
-    r.initialize({"xyz": raw["means3D"], "features": raw["shs"], "scaling_raw": raw["scales"], "rotation_raw": raw["rotations"], "opacity_raw": raw["opacities"]})
-    g = r.gaussians
-    plist = [g._xyz, g._features_dc, g._features_rest, g._opacity, g._scaling, g._rotation]
-    rs_list, cams, bgs = [], [], []
-    for i, (el, az) in enumerate([(-20.0, 10.0), (15.0, 130.0), (40.0, -100.0), (0.0, 60.0), (-35.0, -30.0)]):
-        bg = (1.0, 1.0, 1.0) if i % 2 == 0 else (0.0, 0.0, 0.0)
-        st = S.camera_settings(W, H, 49.1, el, az, 2.2, bg=bg)
-        rs = hip_settings(st, "cuda")
-        rs_list.append(rs); bgs.append(rs.bg)
-        cams.append(type("Cam", (), dict(image_height=H, image_width=W, FoVx=2 * np.arctan(st["tanfovx"]), FoVy=2 * np.arctan(st["tanfovy"]),
-                                         world_view_transform=rs.viewmatrix, full_proj_transform=rs.projmatrix, camera_center=rs.campos))())
-    rng = np.random.default_rng(0)
-    gC = _dev(rng.normal(size=(V, 3, H, W)).astype(np.float32), torch.float32)
-    gD = _dev(rng.normal(size=(V, 1, H, W)).astype(np.float32), torch.float32)
-    gA = _dev(rng.normal(size=(V, 1, H, W)).astype(np.float32), torch.float32)
-    imgs = []
-    for i in range(V):
-        out = r.render(cams[i], bg_color=bgs[i])
-        imgs.append((out["image"].detach().clone(), out["alpha"].detach().clone(), out["depth"].detach().clone(), out["radii"].clone()))
-        # render() clamps the image; the fused halves hand out the unclamped colour, so differentiate through the same clamp on both sides
-        ((out["image"] * gC[i]).sum() + (out["depth"] * gD[i]).sum() + (out["alpha"] * gA[i]).sum()).backward()
-    ref = [p.grad.clone() for p in plist]
-    for p in plist:
-        p.grad = None
-    for lanes in (1, 4):
-        step = FusedViewStep(40000, H, W, "cuda", pair_capacity=5000, lanes=lanes)      # tiny capacity: the regrow path of forward()
-        color, depth, alpha, radii = step.forward(rs_list, [p.detach() for p in plist], want_depth=True, want_radii=True)
-        assert step.capacity > 5000
-        for i in range(V):
-            # the step projects all its views in one kernel (k_preprocess_views), the renderer one view per launch: the same statements, but two
-            # compilations of them (float32 contraction / ordering may differ in the last bit), hence "equal to a few ulp" and not torch.equal
-            for got, want in ((color[i].clamp(0, 1), imgs[i][0]), (alpha[i], imgs[i][1]), (depth[i], imgs[i][2])):
-                assert torch.allclose(got, want, rtol=1e-5, atol=1e-5), float((got - want).abs().max())
-            assert int((radii[i] != imgs[i][3]).sum()) <= 2
-            print("[halves] view %d lanes %d: max |dcolor| %.1e, bit-equal %s" % (i, lanes, float((color[i].clamp(0, 1) - imgs[i][0]).abs().max()), torch.equal(color[i].clamp(0, 1), imgs[i][0])))
-        dcolor = gC * ((color >= 0) & (color <= 1))                  # d clamp
-        grads = [torch.empty_like(p) for p in plist]
-        step.backward(grads, dcolor, gA, gD, accumulate=False)
-        for a, b, name in zip(grads, ref, ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")):
-            assert rel_err(a.cpu().numpy(), b.cpu().numpy()) <= 5e-4, (name, lanes)
-        step.backward(grads, dcolor, gA, gD, accumulate=True)        # ... and on top
-        for a, b in zip(grads, ref):
-            assert rel_err(a.cpu().numpy(), 2 * b.cpu().numpy()) <= 5e-4
-        rg, g2 = step.read_view(V - 1)
-        assert int((rg != imgs[V - 1][3]).sum()) <= 2 and torch.isfinite(g2).all()
-        # ADVICE r4: the backward half clears the "record written" bytes itself.  Stale marks -- here: every byte set, as a call in between on these slices could leave
-        # them -- would make the per-Gaussian pass add records nobody wrote this time.
-        import c3d_hip as h
-        lib = h.lib()
-        cap = step.capacity
-        slice_bytes = lib.c3d_gs_step_workspace_bytes(40000, H, W, cap, 1)
-        ws = step.workspace
-        marks = torch.zeros((), dtype=torch.uint8, device="cuda")
-        ref_grads = [t.clone() for t in grads]
-        step.backward(grads, dcolor, gA, gD, accumulate=False)
-        once = [t.clone() for t in grads]
-        # find the pvalid region of view 0 through its content: the only place where a fill changes the result is what the clear must cover, so poison the WHOLE tail of
-        # every slice that the forward state does not need for a second backward: simpler and stricter -- set all bytes that are 0/1 flags by filling pairgrad + pvalid with 1s
-        fwd_only = lib.c3d_gs_render_workspace_bytes(40000, H, W, cap, 1)
-        for v in range(V):
-            seg = ws[v * slice_bytes + fwd_only + 12 * H * W: (v + 1) * slice_bytes]          # behind the forward state and the dL/dcolour plane: gradient records, valid bytes, per-view hand-over arrays, loss partials
-            keep = seg.clone()
-            seg.fill_(1)
-            del keep
-        step.backward(grads, dcolor, gA, gD, accumulate=False)
-        for a, b in zip(grads, once):
-            assert torch.equal(a, b)
-
-
 def test_trainer_densify_prune_schedule():
     """The reference's default schedule densifies (main_3DGS.py:209-224): statistics from the step's last view, clone/split/prune at the
     interval, opacity reset -- through the fused step (statistics read back with c3d_gs_step_read_view) and through the autograd path.
