@@ -316,8 +316,9 @@ template <bool RECORD>
 __global__ void __launch_bounds__(64, 8) k_composite_fwd_w(GsParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                                                             const float4* __restrict__ rec, GsFwdViews vp, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
                                                             uint8_t* __restrict__ pact, size_t pstride, size_t vs, ScanWaveJob sj) {
-    // RECORD launches carry the record-base scan of the backward pass in their first sj.blocks workgroups (scan_wave.h): latency-bound look-back chains that cost
-    // the forward pass nothing underneath 0.9 ms of VALU-bound compositing, instead of 0.12 ms on its critical path
+    // RECORD launches carry the record-base scan of the backward pass in their first sj.blocks workgroups (scan_wave.h).  Measured (profiles/r05f_scan_in_composite_ab.txt,
+    // same box, three alternations): the launch grows by 0.09 ms -- the scan's 256 MB per 8 views are not free underneath the compositing waves' record gathers -- where
+    // the scan's own launch took 0.125: step 5.134 -> 5.075 ms.  One launch less on the chain; the gain is the tail and the dependent-launch gap, not the traffic.
     if (RECORD && (int)blockIdx.x < sj.blocks) { scan_wave_tile(sj, vs); return; }
     ranges = c3d_view_ptr(ranges, vs); point_list = c3d_view_ptr(point_list, vs); rec = c3d_view_ptr(rec, vs); final_T = c3d_view_ptr(final_T, vs);
     n_contrib = c3d_view_ptr(n_contrib, vs); pact = c3d_view_ptr(pact, vs);
@@ -434,9 +435,6 @@ __global__ void __launch_bounds__(64, 8) k_composite_fwd_w(GsParams p, const uin
 }
 
 // One launch for V views (grid.y): view v's state lies v * vs bytes behind the pointers of g / b / im; its background and output planes come from vp.
-#ifdef GS_SCAN_A_SEPARATE      // A/B: the same one-wave tiles as a launch of their own in front of the compositing kernel
-__global__ void __launch_bounds__(64) k_scan_wave(ScanWaveJob sj, size_t vs) { scan_wave_tile(sj, vs); }
-#endif
 // record_activity: a backward pass may follow -- the launch records the blended (quadrant, splat) pairs AND runs the record-base scan (rbase, einfo of g; state
 // g.tmp_scan_a, cleared with the rest of the view's binning state) in its first workgroups.  err: error word of a timed-out look-back (nullptr: the view's own, g.meta[2]).
 int gs_launch_composite_fwd(const GsParams& p, const GsGeom& g, const GsBinning& b, int res, GsImage& im, const GsFwdViews& vp, int V, size_t vs,
@@ -447,9 +445,6 @@ int gs_launch_composite_fwd(const GsParams& p, const GsGeom& g, const GsBinning&
     ScanWaveJob sj{};
     if (record_activity && p.N > 0)
         sj = ScanWaveJob{g.tiles, g.rbase, g.rect, g.einfo, (uint32_t*)g.tmp_scan_a, err ? err : (uint32_t*)g.meta + 2, (uint32_t)p.N, scan_wave_blocks((size_t)p.N)};
-#ifdef GS_SCAN_A_SEPARATE
-    if (sj.blocks) { hipLaunchKernelGGL(k_scan_wave, dim3(sj.blocks, V), dim3(64), 0, s, sj, vs); sj.blocks = 0; }
-#endif
     const dim3 grid(sj.blocks + 4 * gs_block_count(p.gx, p.gy), V);      // a multiple of 32 blocks per view: the XCD of a block (dispatch order % 8) does not depend on the view
     if (record_activity)
         hipLaunchKernelGGL(k_composite_fwd_w<true>, grid, dim3(64), 0, s, p, b.ranges, b.tval[res], g.rec0, vp, im.final_T, im.n_contrib, pact, b.pair_stride, vs, sj);

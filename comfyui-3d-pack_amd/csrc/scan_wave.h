@@ -1,23 +1,41 @@
 // scan_wave.h -- the record-base scan (A2) as a ONE-WAVE-per-tile chained scan that rides in another kernel's launch (round 5).
 //
-// The exclusive scan of `tiles` in Gaussian-id order (-> rbase, einfo) feeds the BACKWARD pass only; as a launch of its own (k_scan_lb<true, false>, 0.124 ms per
-// 8-view step) it sat on the forward chain's critical path for nothing, and like every single-pass chained scan it is bound by look-back latency, not by the 32 bytes
-// per Gaussian it moves.  Its tiles now occupy the first blocks of the recording forward compositing launch: 64-thread workgroups like the compositing waves, one wave
-// = one 1024-element tile, dispatched ahead of the quadrant waves, which fill every other wave slot and keep the vector pipe busy while the scan's waves wait for their
-// predecessors.  Same protocol as scan_sort.hip (ticket counter, one {flag, value} word per tile, relaxed agent-scope atomics, bounded spins).
+// The exclusive scan of `tiles` in Gaussian-id order (-> rbase, einfo) feeds the BACKWARD pass only; as a launch of its own (k_scan_lb<true, false>, 0.125 ms per
+// 8-view step) it sat on the forward chain's critical path for nothing.  Its tiles now occupy the first blocks of the recording forward compositing launch: 64-thread
+// workgroups like the compositing waves, one wave = one 1024-element tile, dispatched ahead of each view's quadrant waves.  Same inter-workgroup rules as scan_sort.hip
+// (ticket counter, one {flag, value} word per published quantity, relaxed agent-scope atomics, bounded spins).  What it buys, measured on one box in alternation
+// (profiles/r05f_scan_in_composite_ab.txt): the compositing launch 0.925 -> 1.012 ms, the scan launch gone: 8-view step 5.134 -> 5.075 ms (1.2 %).
 #pragma once
 #include "c3d_common.h"
 
 #define SCANW_TILE 1024            // elements per wave: 4 sub-tiles of 256, lane t owns elements [4t, 4t + 4) of each (16-byte loads / stores on consecutive addresses)
+#define SCANW_GROUP 64             // tiles per group of the two-level hand-over
 #define SCANW_SPIN_LIMIT (1u << 21)
-// state block: [0] ticket, [1] error word (unused here: the caller passes its own), then one 64-bit word per tile; zero before the launch
-static inline size_t scan_wave_tmp_bytes(size_t n) { return c3d_align(8 + sizeof(unsigned long long) * ((n ? n : 1) / SCANW_TILE + 2)); }
-static inline int scan_wave_blocks(size_t n) { return (int)(((n + SCANW_TILE - 1) / SCANW_TILE + 31) / 32 * 32); }      // a multiple of 32: the compositing blocks behind keep their XCD / quadrant mapping
+// Hand-over between tiles: NOT the windowed decoupled look-back of scan_sort.hip.  With ~1000 one-wave tiles per view all resident at once, walking 64 predecessors per
+// dependent step cost a late tile ~15 round trips through the memory-side cache (measured: the fused scan added its whole stand-alone time, 0.1 ms per 8-view step, to
+// the compositing launch, profiles/r05e_*).  Here every load a tile needs is independent of the others' VALUES: tile t adds up the aggregates of the tiles before it in
+// its group of 64 (one load per lane) and the totals of all earlier groups (one load per lane per 64 groups; a group's total is published by its last tile from the
+// same in-group sum -- no chain).  Two hand-overs deep whatever the tile count.  Every wait is on a tile with a lower ticket (already running) and bounded.
+// state block: [0] ticket, [1] unused, then one 64-bit word per tile (flag << 32 | aggregate) and one per group (flag << 32 | total); zero before the launch
+static inline size_t scan_wave_tiles(size_t n) { return ((n ? n : 1) + SCANW_TILE - 1) / SCANW_TILE; }
+static inline size_t scan_wave_tmp_bytes(size_t n) { return c3d_align(8 + sizeof(unsigned long long) * (scan_wave_tiles(n) + scan_wave_tiles(n) / SCANW_GROUP + 2)); }
+static inline int scan_wave_blocks(size_t n) { return (int)((scan_wave_tiles(n) + 31) / 32 * 32); }      // a multiple of 32: the compositing blocks behind keep their XCD / quadrant mapping
 
 #ifdef __HIPCC__
 struct ScanWaveJob {      // all pointers: view 0's (view v lies v * vs bytes behind); blocks == 0: no job
     const uint32_t* in; uint32_t* out; const uint2* rect; uint4* einfo; uint32_t* state; uint32_t* err; uint32_t n; int blocks;
 };
+// value of a published word (polls until its flag is set; bounded)
+__device__ __forceinline__ uint32_t scan_wave_wait(const unsigned long long* p, uint32_t* err) {
+    unsigned long long w = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t spins = 0;
+    while ((uint32_t)(w >> 32) == 0u) {
+        if (++spins > SCANW_SPIN_LIMIT) { atomicOr(err, C3D_ERR_LOOKBACK); return 0u; }
+        __builtin_amdgcn_s_sleep(2);
+        w = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return (uint32_t)w;
+}
 // out[i] = exclusive prefix of in[0..i); einfo[i] = {0, rect[i].x, rect[i].y, out[i]} where in[i] != 0.  Called by a whole 64-lane workgroup.
 __device__ __forceinline__ void scan_wave_tile(const ScanWaveJob& j, size_t vs) {
     const uint32_t* __restrict__ in = c3d_view_ptr(j.in, vs);
@@ -25,13 +43,15 @@ __device__ __forceinline__ void scan_wave_tile(const ScanWaveJob& j, size_t vs) 
     const uint2* __restrict__ rect = c3d_view_ptr(j.rect, vs);
     uint4* __restrict__ einfo = c3d_view_ptr(j.einfo, vs);
     uint32_t* state = c3d_view_ptr(j.state, vs);
-    unsigned long long* status = reinterpret_cast<unsigned long long*>(state + 2);
     const int lane = (int)threadIdx.x;
     const size_t n = j.n;
+    const uint32_t tiles = (uint32_t)((n + SCANW_TILE - 1) / SCANW_TILE);
+    unsigned long long* tile_words = reinterpret_cast<unsigned long long*>(state + 2);
+    unsigned long long* group_words = tile_words + tiles;
     uint32_t tk = 0;
     if (lane == 0) tk = atomicAdd(&state[0], 1u);
     const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
-    if ((size_t)tile * SCANW_TILE >= n) return;
+    if (tile >= tiles) return;
     uint32_t v[4][4], hs[4];
 #pragma unroll
     for (int h = 0; h < 4; h++) {
@@ -50,36 +70,22 @@ __device__ __forceinline__ void scan_wave_tile(const ScanWaveJob& j, size_t vs) 
         ex[h] = tot + inc - hs[h];                                                   // a sub-tile follows all of the sub-tiles before it
         tot += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
     }
-    if (lane == 0) __hip_atomic_store(&status[tile], ((tile == 0 ? 2ull : 1ull) << 32) | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    uint32_t prefix = 0;
-    if (tile > 0) {      // decoupled look-back, 64 predecessors per step: flag 1 = tile aggregate, 2 = inclusive prefix
-        long long t0 = (long long)tile - 1;
-        for (;;) {
-            const long long t = t0 - lane;
-            unsigned long long w = t >= 0 ? __hip_atomic_load(&status[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2ull << 32);      // below tile 0: an inclusive prefix of zero
-            uint64_t incl_mask;
-            int first_incl;
-            uint32_t spins = 0;
-            for (;;) {
-                const uint32_t flag = (uint32_t)(w >> 32);
-                incl_mask = __ballot(flag == 2u);
-                const uint64_t notready = __ballot(flag == 0u);
-                first_incl = incl_mask ? (int)__builtin_ctzll(incl_mask) : 63;
-                const uint64_t relevant = first_incl >= 63 ? ~0ull : ((2ull << first_incl) - 1ull);
-                if ((notready & relevant) == 0ull) break;
-                if (++spins > SCANW_SPIN_LIMIT) { if (lane == 0) atomicOr(j.err, C3D_ERR_LOOKBACK); incl_mask = 1ull; first_incl = 0; w = 0; break; }
-                __builtin_amdgcn_s_sleep(2);
-                if (flag == 0u) w = __hip_atomic_load(&status[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            uint32_t contrib = (lane <= first_incl) ? (uint32_t)w : 0u;
+    if (lane == 0) __hip_atomic_store(&tile_words[tile], (1ull << 32) | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t grp = tile / SCANW_GROUP, r = tile % SCANW_GROUP;
+    // (1) the tiles before this one in its group: one word per lane, all loads in flight together
+    uint32_t in_sum = ((uint32_t)lane < r) ? scan_wave_wait(&tile_words[(size_t)grp * SCANW_GROUP + lane], j.err) : 0u;
 #pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) contrib += __shfl_xor(contrib, o, 64);
-            prefix += contrib;
-            if (incl_mask) break;
-            t0 -= 64;
-        }
-        if (lane == 0) __hip_atomic_store(&status[tile], (2ull << 32) | (uint32_t)(prefix + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    for (int o = 32; o >= 1; o >>= 1) in_sum += __shfl_xor(in_sum, o, 64);
+    // the last tile of a group (with successors) publishes the group's total straight away: it depends on the group's own tiles only, not on earlier groups -- no chain
+    if (r == SCANW_GROUP - 1 && tile + 1 < tiles && lane == 0)
+        __hip_atomic_store(&group_words[grp], (1ull << 32) | (uint32_t)(in_sum + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (2) the totals of the earlier groups, 64 per step (independent loads as well)
+    uint32_t g_sum = 0;
+    for (uint32_t g0 = 0; g0 < grp; g0 += 64)
+        if (g0 + (uint32_t)lane < grp) g_sum += scan_wave_wait(&group_words[g0 + lane], j.err);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) g_sum += __shfl_xor(g_sum, o, 64);
+    const uint32_t prefix = in_sum + g_sum;
 #pragma unroll
     for (int h = 0; h < 4; h++) {
         const size_t b = (size_t)tile * SCANW_TILE + (size_t)h * 256 + (size_t)lane * 4;
