@@ -239,7 +239,11 @@ int c3d_gs_debug_state(int32_t N, int32_t image_height, int32_t image_width, con
                        float* xy, float* depths, float* conic_opacity, float* rgb, uint32_t* tiles_touched,
                        c3d_stream_t stream);
 
-/* Optional per-kernel timing: HIP events recorded on the launch stream around each kernel group.
+/* The ONLY process-wide state of the library (tests/test_abi.py lists it): the debug / measurement hooks below -- c3d_prof_enable + c3d_prof_select (which kernel
+ * groups get a pair of HIP events around them) and c3d_test_sort_phases (phase stamps of the radix sort).  They change what is MEASURED, never what is computed or
+ * which kernels run; off by default, off costs one predictable branch per launch.  A host that embeds the library next to other users of it should leave them alone or
+ * serialise its measurements: the switch is not per stream or per context.
+ * Optional per-kernel timing: HIP events recorded on the launch stream around each kernel group.
  * c3d_prof_enable(1) resets and starts, c3d_prof_read(slot, &ms, &n) synchronises the recorded events and returns the
  * accumulated milliseconds / launches of a slot; slot names via c3d_prof_name (e.g. "gs_composite_bwd"). */
 int c3d_prof_enable(int on);

@@ -45,6 +45,20 @@ def test_no_process_wide_switches_in_the_abi():
     import c3d_hip
     setters = [n for n in c3d_hip.exported_symbols() if "_set_" in n or n.endswith("_set")]
     assert setters == [], setters
+    # every exported entry point that takes NO stream and NO buffer can only act on library-global state: sizes / names / versions (pure functions) and -- the one
+    # documented exception (include/c3d_gs.h says so) -- the measurement hooks.  A new switch of any other name fails here.
+    import ctypes as C
+    pure = {"c3d_last_error", "c3d_version", "c3d_prof_slots", "c3d_prof_name"}
+    hooks = {"c3d_prof_enable", "c3d_prof_select", "c3d_prof_read", "c3d_test_sort_phases"}
+    stateful = set()
+    for n, (res, args) in c3d_hip.exported_symbols().items():
+        if n.endswith("_bytes") or n in pure:
+            continue
+        if not any(a is C.c_void_p or (isinstance(a, type) and issubclass(a, C._Pointer)) for a in args):
+            stateful.add(n)
+    assert stateful <= hooks, stateful - hooks
+    hdr_gs = open(os.path.join(ROOT, "include", "c3d_gs.h")).read()
+    assert "The ONLY process-wide state of the library" in hdr_gs and all(h in hdr_gs for h in ("c3d_prof_enable", "c3d_prof_select", "c3d_test_sort_phases"))
     src = open(os.path.join(ROOT, "comfyui-3d-pack_amd", "csrc", "gs_api.hip")).read()
     assert "g_exact_dscale" not in src
     hdr = open(os.path.join(ROOT, "include", "c3d_gs.h")).read()
