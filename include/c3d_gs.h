@@ -89,7 +89,8 @@ int c3d_gs_forward_project(const c3d_gs_settings* st, int32_t N, int32_t M, cons
                            int64_t* num_rendered /* host */, c3d_stream_t stream);
 
 /* Forward, part 2 (A3-A6): bins, orders and composites.  out_color[3,H,W], out_depth[1,H,W],
- * out_alpha[1,H,W]. */
+ * out_alpha[1,H,W].  The compositing launch also records which (quadrant, splat) pairs blended and carries the record-base scan of the backward pass in its first
+ * workgroups (ABI 500: both feed c3d_gs_backward only, neither is on the forward chain's critical path). */
 int c3d_gs_forward_render(const c3d_gs_settings* st, int32_t N, int32_t M, const int32_t* radii, void* geom_buffer,
                           int64_t num_rendered, void* binning_buffer, void* image_buffer, float* out_color,
                           float* out_depth, float* out_alpha, c3d_stream_t stream);
