@@ -45,9 +45,11 @@ if [ -z "$QUICK" ]; then
   timeout 300 python bench.py --mode train --loss l1alpha --steps 20 --warmup 5 --cpu-baseline off --targets off < /dev/null 2>/dev/null | tail -1 > $OUT/${TAG}_bench_train_l1alpha_n1.json
   timeout 300 python bench.py --render-path fused --steps 20 --warmup 5 --cpu-baseline off --targets off < /dev/null 2>/dev/null | tail -1 > $OUT/${TAG}_bench_renderer_api_n1.json
   timeout 300 python bench.py --render-path boundary --steps 20 --warmup 5 --cpu-baseline off --targets off < /dev/null 2>/dev/null | tail -1 > $OUT/${TAG}_bench_boundary_api_n1.json
+  timeout 300 python bench.py --render-path boundary --sync-free off --steps 20 --warmup 5 --cpu-baseline off --targets off < /dev/null 2>/dev/null | tail -1 > $OUT/${TAG}_bench_boundary_api_syncfree_off_n1.json
   timeout 300 python bench.py --workload ref-default --ref-res 512 --steps 700 --warmup 50 --cpu-baseline off < /dev/null 2>/dev/null | tail -1 > $OUT/${TAG}_bench_ref_default_512.json
   timeout 120 python profiles/microbench/sort_phases.py < /dev/null > $OUT/${TAG}_sort_phases.txt 2>&1
 fi
+if [ -z "$QUICK" ]; then timeout 900 python -m pytest tests -m gpu -q -s < /dev/null > $OUT/${TAG}_gpu_pytest.log 2>&1; tail -3 $OUT/${TAG}_gpu_pytest.log; fi
 head -12 $OUT/${TAG}_fwdbwd_kernel_stats.csv
 head -12 $OUT/${TAG}_pmc_traffic.csv
 for f in $OUT/${TAG}_bench_*.json; do echo $f; timeout 20 python profiles/benchline.py < $f; done
