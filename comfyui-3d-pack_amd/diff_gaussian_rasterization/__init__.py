@@ -24,8 +24,10 @@ last_num_rendered = 0   # (tile, splat) pairs of the most recent forward whose c
 # and the capacity is regrown at once.  Counts drift slowly along a training run and between the cameras of an orbit, and the capacity follows them upwards as soon
 # as a call uses more than GROW_AT of it, so in practice only a jump of > 50 % between two consecutive calls of one shape can overflow.  sync_free(False) restores
 # the wheel's behaviour (exact count, one synchronisation per call) for callers that cannot accept that.
+import threading
 import warnings
 
+_lock = threading.RLock()      # ComfyUI may run nodes on several threads: slot hand-out and examination are serialised (a few dictionary / list operations per call)
 _SYNC_FREE = True
 _GROW_AT, _HEADROOM = 0.6, 1.5
 _cap = {}        # (device index, N, H, W) -> pair capacity
@@ -58,6 +60,9 @@ class _Ring:
                     return
                 torch.cuda.synchronize(self.device)       # rare: flush(), or _SLOTS calls ahead of the GPU
                 w = self.host[slot]
+                if w[0] == _SENTINEL or w[1] == _SENTINEL:     # the device is idle and the words never came: that call failed before its copy was enqueued (it raised there)
+                    self.pending.pop(0)
+                    continue
             self.pending.pop(0)
             flags, seen = int(w[0]), int(w[1]) & 0xFFFFFFFF
             if flags & 2:
@@ -79,44 +84,49 @@ def sync_free(on=True):
 def flush():
     """wait for the status words of every sync-free forward call issued so far and examine them (warns / raises as described above); afterwards
     last_num_rendered is the pair count of the most recent forward call"""
-    for ring in _rings.values():
-        ring.examine(block=True)
+    with _lock:
+        for ring in list(_rings.values()):
+            ring.examine(block=True)
 
 
 def pending_calls():
     """sync-free forward calls whose status words have not been examined yet"""
-    return sum(len(r.pending) for r in _rings.values())
+    with _lock:
+        return sum(len(r.pending) for r in _rings.values())
 
 
 def _learn(key, seen):
     """a pair count of this shape has reached the host: keep the capacity 1.5 x above the largest count seen"""
     global last_num_rendered
-    last_num_rendered = int(seen)
-    cap = _cap.get(key, 0)
-    if seen > _GROW_AT * cap:
-        _cap[key] = min(int(seen * _HEADROOM) + (1 << 16), 0x3FFFFFF0)
+    with _lock:
+        last_num_rendered = int(seen)
+        cap = _cap.get(key, 0)
+        if seen > _GROW_AT * cap:
+            _cap[key] = min(int(seen * _HEADROOM) + (1 << 16), 0x3FFFFFF0)
 
 
 def _capacity_for(key):
     """-> pair capacity for a sync-free forward of this shape, or None: take the synchronous path (and learn the count)"""
-    ring = _rings.get(key[0])
-    if ring is not None and ring.pending:
-        ring.examine()
-    return _cap.get(key) if _SYNC_FREE else None
+    with _lock:
+        ring = _rings.get(key[0])
+        if ring is not None and ring.pending:
+            ring.examine()
+        return _cap.get(key) if _SYNC_FREE else None
 
 
 def _status_slot(dev, key, cap):
     """-> (device pointer, pinned host pointer) of the status words of one sync-free call, registered for examination"""
-    ring = _rings.get(dev.index)
-    if ring is None:
-        ring = _rings[dev.index] = _Ring(dev)
-    if len(ring.pending) >= _SLOTS:
-        ring.examine(keep=_SLOTS - 1)                     # the slot handed out next is the oldest pending one: retire it first
-    slot = ring.next
-    ring.next = (slot + 1) % _SLOTS
-    ring.host[slot] = _SENTINEL
-    ring.pending.append((slot, key, cap))
-    return C.c_void_p(ring.dev_ptr + 8 * slot), C.c_void_p(ring.pin_ptr + 8 * slot)
+    with _lock:
+        ring = _rings.get(dev.index)
+        if ring is None:
+            ring = _rings[dev.index] = _Ring(dev)
+        if len(ring.pending) >= _SLOTS:
+            ring.examine(keep=_SLOTS - 1)                 # the slot handed out next is the oldest pending one: retire it first
+        slot = ring.next
+        ring.next = (slot + 1) % _SLOTS
+        ring.host[slot] = _SENTINEL
+        ring.pending.append((slot, key, cap))
+        return C.c_void_p(ring.dev_ptr + 8 * slot), C.c_void_p(ring.pin_ptr + 8 * slot)
 
 
 class GaussianRasterizationSettings(NamedTuple):
