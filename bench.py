@@ -284,7 +284,7 @@ def main_mesh(a, world, rank, dev, dist):
     sync()
     # inside the timed region only the dominant group is event-timed (every timed launch costs two event records on a host-bound step: timing all
     # nine groups cost 15 %); the per-group table comes from a separate pass right after it
-    dom_groups = ["mesh_texture_bwd", "mesh_rasterize_bwd"]       # the two candidates for the dominant group (round 3: the rasterizer's backward carries the antialias position gradient)
+    dom_groups = ["mesh_texture_bwd", "mesh_rasterize_bwd", "mesh_ras_tri"]       # the candidates for the dominant group + the dominant kernel itself (k_ras_tri, a slot of its own)
     c3d_hip.prof_enable(a.timed_prof == "on", only=dom_groups)
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -321,9 +321,26 @@ def main_mesh(a, world, rank, dev, dist):
            "mesh_rasterize_bwd": 32 * P + 16 * V, "mesh_interpolate_bwd": (16 + 24 + 16) * P + 24 * V, "mesh_texture_bwd": (8 + 12 + 8) * P + 12 * 1024 * 1024,
            "mesh_antialias_bwd": (16 + 16 + 16) * P + 16 * V}
     vpl = min(a.views_per_gpu, 16) if use_step else 1      # views per launch
+    ras_tri = prof.pop("mesh_ras_tri", None)      # k_ras_tri alone (a slot nested inside the rasterize group): the step's longest kernel
     kern = {k: {"avg_ms": round(ms / n, 4), "launches": n, "ms_per_view": round(ms / (a.steps * a.views_per_gpu), 4), "views_per_launch": vpl} for k, (ms, n) in prof.items()}
     dom = max(prof, key=lambda k: prof[k][0]) if prof else None
     roof = None
+    roof_kernel = None
+    if ras_tri and ras_tri[1]:
+        # per LAUNCH of the dominant kernel: compulsory bytes of k_ras_tri = the vertices (16 V) and index triples (12 T) it reads and one 8-byte
+        # depth | id word per pixel (the rest of SURVEY 8(d)'s 32 P of the rasterize op -- rast, rast_db -- belongs to the resolve / pixel pass), x the views of a launch
+        avg_ms = ras_tri[0] / ras_tri[1]
+        bpl = (16 * V + 12 * T + 8 * P) * vpl
+        roof_kernel = {"bound": "hbm", "kernel": "k_ras_tri", "achieved": round(bpl / (avg_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                       "frac": round(bpl / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None, "avg_ms": round(avg_ms, 4), "alg_bytes_per_launch": int(bpl),
+                       "views_per_launch": vpl, "measured": "HIP events around the kernel on the launch stream, %d launches" % ras_tri[1]}
+        pmc_k, pmc_k_file, stale_k = load_profile_json("_mesh_pmc_traffic.json")
+        rec = (pmc_k.get("k_ras_tri") or {}).get("long")
+        if rec and vpl > 1:
+            roof_kernel["traffic"] = int((rec["fetch_MB_raw"] + rec["write_MB"]) * 1e6)
+            roof_kernel["traffic_note"] = "FETCH_SIZE (raw) + WRITE_SIZE per LONG launch of k_ras_tri (the step's launches over %d views; %d of them), profiles/%s" % (vpl, rec["launches"], pmc_k_file)
+        elif stale_k:
+            roof_kernel["stale"] = "profiles/%s was measured on code %s" % (pmc_k_file, stale_k)
     if dom:
         per_view_ms = prof[dom][0] / (a.steps * a.views_per_gpu)
         ach = alg.get(dom, 0) / (per_view_ms * 1e-3) / 1e9
@@ -335,9 +352,9 @@ def main_mesh(a, world, rank, dev, dist):
                 roof["avg_ms_concurrent"] = round(prof_dom[dom][0] / (a.steps * a.views_per_gpu), 4)
         pmc, pmc_file, stale = load_profile_json("_mesh_pmc_traffic.json")
         grp = (pmc.get("_groups") or {}).get(dom)
-        if grp:
-            roof["traffic"] = int((grp["fetch_MB_raw"] + grp["write_MB"]) * 1e6)
-            roof["traffic_note"] = "FETCH_SIZE(raw)+WRITE_SIZE per view over the kernels of this group, profiles/%s; fetch x2-corrected: %d" % (pmc_file, int((grp["fetch_MB_x2"] + grp["write_MB"]) * 1e6))
+        if grp and grp.get("long") and use_step:
+            roof["traffic"] = int((grp["long"]["fetch_MB_raw"] + grp["long"]["write_MB"]) * 1e6 / vpl)
+            roof["traffic_note"] = ("FETCH_SIZE (raw) + WRITE_SIZE of the group's kernels per LONG launch (the step's launches over %d views) / %d views, profiles/%s" % (vpl, vpl, pmc_file))
         elif stale:
             roof["stale"] = "profiles/%s was measured on code %s" % (pmc_file, stale)
     # whole-chain figure by SURVEY 8(d)'s op-level mesh formula: B_mesh_fwd = 16 V + 12 T + 220 P, backward = 2 x the image-space terms + 24 V + 12 Ht Wt
@@ -358,7 +375,8 @@ def main_mesh(a, world, rank, dev, dist):
                                      "render_path": ("step: c3d_mesh_train_views, %d views per launch" % vpl) if use_step else "fused: one autograd call per view",
                                      "parallelism": "view-parallel dp%d" % world, "host_enqueue_ms_per_step": round(t_enq / a.steps * 1e3, 3),
                                      "dist_backend": (dist.get_backend() if dist is not None else None), "rccl_ranks": (dist.get_world_size() if dist is not None else 1)},
-                          "roofline": roof, "roofline_chain": chain, "cpu_baseline": cpu, "kernels": kern, "code_digest": code_digest()}))
+                          "roofline": roof_kernel or roof, "roofline_group": (roof if roof_kernel else None), "roofline_chain": chain, "cpu_baseline": cpu, "kernels": kern,
+                          "code_digest": code_digest()}))
     if world > 1:
         dist.destroy_process_group()
 

@@ -31,11 +31,12 @@ static inline int c3d_cdiv(long long a, long long b) { return (int)((a + b - 1) 
 #define C3D_MAX_LANES 8
 
 // ---- optional event timing (prof.hip) ----
-#define C3D_PROF_SLOTS 21
+#define C3D_PROF_SLOTS 22
 enum { C3D_P_PREPROCESS = 0, C3D_P_DEPTH_SORT, C3D_P_SCAN, C3D_P_EMIT, C3D_P_TILE_SORT, C3D_P_RANGES, C3D_P_COMPOSITE_FWD,
        C3D_P_COMPOSITE_BWD, C3D_P_PREPROCESS_BWD, C3D_P_ADAM, C3D_P_MESH_RASTERIZE, C3D_P_MESH_INTERPOLATE, C3D_P_MESH_TEXTURE,
        C3D_P_MESH_ANTIALIAS, C3D_P_MESH_BWD, C3D_P_OTHER, C3D_P_MESH_RASTERIZE_BWD, C3D_P_MESH_INTERPOLATE_BWD,
-       C3D_P_MESH_TEXTURE_BWD, C3D_P_MESH_ANTIALIAS_BWD, C3D_P_MSSSIM };
+       C3D_P_MESH_TEXTURE_BWD, C3D_P_MESH_ANTIALIAS_BWD, C3D_P_MSSSIM,
+       C3D_P_MESH_RAS_TRI /* k_ras_tri alone, nested inside the rasterize group: the mesh line's per-kernel roofline */ };
 void* c3d_prof_begin(int slot, hipStream_t s);
 void c3d_prof_end(void* h, hipStream_t s);
 struct C3dProfScope {

@@ -1334,7 +1334,8 @@ static int mesh_rasterize_impl(const float* pos, const int32_t* tri, int32_t B, 
     C3D_CHECK(hipMemsetAsync(count, 0, 4, s));
     if (T > 0 && V > 0) {
         MESH_REQUIRE(pos && tri, "NULL geometry");
-        hipLaunchKernelGGL(k_ras_tri, dim3(c3d_cdiv((long long)B * T, 256)), dim3(256), 0, s, (const float4*)pos, (const int3*)tri, B, V, T, H, W, zbuf, queue, count, peel);
+        { C3dProfScope pt(C3D_P_MESH_RAS_TRI, s);
+          hipLaunchKernelGGL(k_ras_tri, dim3(c3d_cdiv((long long)B * T, 256)), dim3(256), 0, s, (const float4*)pos, (const int3*)tri, B, V, T, H, W, zbuf, queue, count, peel); }
         hipLaunchKernelGGL(k_ras_big, dim3(2048), dim3(256), 0, s, (const float4*)pos, (const int3*)tri, V, T, H, W, zbuf, queue, count, peel);
     }
     if (resolve) hipLaunchKernelGGL(k_ras_resolve, dim3(c3d_cdiv(BP, 256)), dim3(256), 0, s, (const float4*)pos, (const int3*)tri, B, V, H, W, zbuf, (float4*)rast, (float4*)rast_db);

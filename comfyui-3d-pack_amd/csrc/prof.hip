@@ -10,7 +10,7 @@ struct Rec { int slot; hipEvent_t e0, e1; };
 const char* kNames[C3D_PROF_SLOTS] = {"gs_preprocess", "gs_depth_sort", "gs_offsets_scan", "gs_emit", "gs_tile_sort", "gs_ranges",
                                       "gs_composite_fwd", "gs_composite_bwd", "gs_preprocess_bwd", "adam", "mesh_rasterize",
                                       "mesh_interpolate", "mesh_texture", "mesh_antialias", "mesh_bwd", "other", "mesh_rasterize_bwd",
-                                      "mesh_interpolate_bwd", "mesh_texture_bwd", "mesh_antialias_bwd", "msssim"};
+                                      "mesh_interpolate_bwd", "mesh_texture_bwd", "mesh_antialias_bwd", "msssim", "mesh_ras_tri"};
 bool g_on = false;
 unsigned long long g_mask = ~0ull;   // slots that are timed while profiling is on (c3d_prof_select)
 std::mutex g_mu;
