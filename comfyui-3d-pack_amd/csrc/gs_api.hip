@@ -426,12 +426,14 @@ static int group_bin(ViewGroup& q, uint32_t* status, bool clear_pvalid, hipStrea
     return binning_back(q.p[0], q.g0, q.b0, (long long)q.cap, q.cap, (const uint32_t*)q.g0.meta, status, s, res_out, q.G, q.vs, true);
 }
 // A6 of the group.  out_*[i] (arrays or entries may be NULL): the caller's planes of view i; otherwise the slice's own.
+// a view without a caller's depth plane gets none (nothing reads a slice's own: c3d_gs_step_read_view hands out radii and dL/dmeans2D); a group in which no view wants depth
+// runs the kernel instance without the accumulator -- the fused training step, whose loss reads image and alpha only
 static int group_composite_fwd(ViewGroup& q, int res, float* const* out_color, float* const* out_depth, float* const* out_alpha, bool record, hipStream_t s, uint32_t* status) {
     GsFwdViews vp{};
     for (int i = 0; i < q.G; i++) {
         vp.bg[i] = q.p[i].bg;
         vp.color[i] = (out_color && out_color[i]) ? out_color[i] : q.w[i].color;
-        vp.depth[i] = (out_depth && out_depth[i]) ? out_depth[i] : q.w[i].depth;
+        vp.depth[i] = (out_depth && out_depth[i]) ? out_depth[i] : nullptr;
         vp.alpha[i] = (out_alpha && out_alpha[i]) ? out_alpha[i] : q.w[i].alpha;
     }
     C3dProfScope ps(C3D_P_COMPOSITE_FWD, s);

@@ -640,20 +640,20 @@ __global__ void __launch_bounds__(256, MINB) k_bwd_views_geom(GsParams p, GsBwdV
     // the NEXT view is fetched while this one is worked on, the valid bytes and the records of four pairs are in flight together, and a Gaussian
     // that no pixel of the view blended (no valid record: roughly every other one at the BASELINE workload) skips the splat record, the two
     // matrices and the whole geometric chain -- all its sums are zero.
-    int n_rad = vs.v[0].radii[idx];
+    // (a culled Gaussian has tiles == 0, a visible one whose alpha box misses every tile too: the tile count alone says whether there is anything to walk -- the radius
+    //  is not read, one load less at the head of every view's dependent chain)
     uint32_t n_cnt = vs.v[0].tiles[idx], n_e0 = vs.v[0].rbase[idx];
     for (int v = 0; v < vs.V; v++) {
         const GsBwdView& vw = vs.v[v];
         float* d2 = vw.dmean2D + 3 * (size_t)idx;
         float* gc = vw.gcol + 3 * (size_t)idx;
-        const int rad = n_rad;
         const uint32_t cnt = n_cnt, e0 = n_e0;
-        if (v + 1 < vs.V) { const GsBwdView& nx = vs.v[v + 1]; n_rad = nx.radii[idx]; n_cnt = nx.tiles[idx]; n_e0 = nx.rbase[idx]; }
+        if (v + 1 < vs.V) { const GsBwdView& nx = vs.v[v + 1]; n_cnt = nx.tiles[idx]; n_e0 = nx.rbase[idx]; }
         float pr[GS_PAIR_FLOATS];
 #pragma unroll
         for (int k = 0; k < GS_PAIR_FLOATS; k++) pr[k] = 0.f;
         bool any = false;
-        if (rad > 0) {
+        if (cnt > 0) {
             const uint32_t e1 = min(e0 + cnt, cap);
             for (uint32_t e = e0; e < e1; e += CHUNK) {
                 uint8_t pv[CHUNK];

@@ -312,7 +312,8 @@ int gs_launch_ranges(const GsBinning& b, int res, long long D, hipStream_t s, co
 // ------------------------------------------------------------------------------------------
 #define FWQ_PAD 4
 #define FWQ_SLOTS (64 + FWQ_PAD)
-template <bool RECORD>
+// DEPTH: the depth output is wanted.  The fused training step's loss reads image and alpha only (main_3DGS.py:184-192): its instance drops the accumulator and the plane.
+template <bool RECORD, bool DEPTH>
 __global__ void __launch_bounds__(64, 8) k_composite_fwd_w(GsParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                                                             const float4* __restrict__ rec, GsFwdViews vp, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
                                                             uint8_t* __restrict__ pact, size_t pstride, size_t vs, ScanWaveJob sj) {
@@ -407,7 +408,7 @@ __global__ void __launch_bounds__(64, 8) k_composite_fwd_w(GsParams p, const uin
                     const float w = sel64z(ok, alpha * T);
                     T = sel64(ok, testT, T);
                     C0 += s1.z * w; C1 += s1.w * w; C2 += s2.x * w;
-                    Dp += s2.y * w;
+                    if (DEPTH) Dp += s2.y * w;
                     last = sel64i(ok, __float_as_int(s2.z), last);
                     if (RECORD)                                              // act = (act << 1) | (some lane blended this entry): SCC rides the carry chain
                         asm volatile("s_cmp_lg_u64 %2, 0\n\ts_addc_u32 %0, %0, %0\n\ts_addc_u32 %1, %1, %1" : "+s"(act_lo), "+s"(act_hi) : "s"(ok) : "scc");
@@ -429,7 +430,7 @@ __global__ void __launch_bounds__(64, 8) k_composite_fwd_w(GsParams p, const uin
         out_color[pid] = C0 + T * bg[0];
         out_color[P + pid] = C1 + T * bg[1];
         out_color[2 * P + pid] = C2 + T * bg[2];
-        if (out_depth) out_depth[pid] = Dp;
+        if (DEPTH && out_depth) out_depth[pid] = Dp;
         out_alpha[pid] = 1.f - T;                 // sum of the blend weights alpha_i T_i = T_0 - T_final, telescoped (the weights are T_i - T_{i+1})
     }
 }
@@ -446,10 +447,12 @@ int gs_launch_composite_fwd(const GsParams& p, const GsGeom& g, const GsBinning&
     if (record_activity && p.N > 0)
         sj = ScanWaveJob{g.tiles, g.rbase, g.rect, g.einfo, (uint32_t*)g.tmp_scan_a, err ? err : (uint32_t*)g.meta + 2, (uint32_t)p.N, scan_wave_blocks((size_t)p.N)};
     const dim3 grid(sj.blocks + 4 * gs_block_count(p.gx, p.gy), V);      // a multiple of 32 blocks per view: the XCD of a block (dispatch order % 8) does not depend on the view
-    if (record_activity)
-        hipLaunchKernelGGL(k_composite_fwd_w<true>, grid, dim3(64), 0, s, p, b.ranges, b.tval[res], g.rec0, vp, im.final_T, im.n_contrib, pact, b.pair_stride, vs, sj);
-    else
-        hipLaunchKernelGGL(k_composite_fwd_w<false>, grid, dim3(64), 0, s, p, b.ranges, b.tval[res], g.rec0, vp, im.final_T, im.n_contrib, pact, b.pair_stride, vs, sj);
+    bool depth = false;
+    for (int v = 0; v < V; v++) depth = depth || vp.depth[v] != nullptr;
+#define GS_FWD_LAUNCH(REC_, DEP_) hipLaunchKernelGGL((k_composite_fwd_w<REC_, DEP_>), grid, dim3(64), 0, s, p, b.ranges, b.tval[res], g.rec0, vp, im.final_T, im.n_contrib, pact, b.pair_stride, vs, sj)
+    if (record_activity) { if (depth) GS_FWD_LAUNCH(true, true); else GS_FWD_LAUNCH(true, false); }
+    else                 { if (depth) GS_FWD_LAUNCH(false, true); else GS_FWD_LAUNCH(false, false); }
+#undef GS_FWD_LAUNCH
     C3D_LAUNCH_CHECK();
     return 0;
 }
