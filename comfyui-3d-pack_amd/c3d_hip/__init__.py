@@ -88,6 +88,7 @@ _SIGNATURES = {
     "c3d_test_scan_u32": (C.c_int, [vp, vp, i64, i32, vp]),
     "c3d_test_sort_pairs_u32": (C.c_int, [vp, vp, i64, i32, vp]),
     "c3d_test_sort_phases": (C.c_int, [vp]),
+    "c3d_test_scan_wave": (C.c_int, [vp, vp, vp, vp, i64, vp]),
 }
 
 

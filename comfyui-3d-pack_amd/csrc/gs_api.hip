@@ -757,6 +757,26 @@ int c3d_test_scan_u32(const uint32_t* in, uint32_t* out, int64_t n, int32_t excl
     return rc;
 }
 int c3d_test_sort_phases(uint64_t* stamps) { return c3d_sort_set_debug((unsigned long long*)stamps); }
+// the record-base scan that rides in the recording forward compositing launch (scan_wave.h), as a launch of its own: out[i] = exclusive prefix of in, einfo[i] = {0, rect[i], out[i]} where in[i] != 0
+__global__ void __launch_bounds__(64) k_test_scan_wave(ScanWaveJob sj) { scan_wave_tile(sj, 0); }
+int c3d_test_scan_wave(const uint32_t* in, const uint32_t* rect, uint32_t* out, uint32_t* einfo, int64_t n, c3d_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (n <= 0) return 0;
+    if (!in || !rect || !out || !einfo || n >= (1ll << 32)) { c3d_set_error("c3d_test_scan_wave: bad argument"); return -1; }
+    void* tmp = nullptr;
+    C3D_CHECK(hipMalloc(&tmp, scan_wave_tmp_bytes((size_t)n) + 64));
+    C3D_CHECK(hipMemsetAsync(tmp, 0, scan_wave_tmp_bytes((size_t)n) + 64, s));
+    uint32_t* err = (uint32_t*)((char*)tmp + scan_wave_tmp_bytes((size_t)n));
+    const ScanWaveJob sj{in, out, (const uint2*)rect, (uint4*)einfo, (uint32_t*)tmp, err, (uint32_t)n, scan_wave_blocks((size_t)n)};
+    hipLaunchKernelGGL(k_test_scan_wave, dim3(sj.blocks), dim3(64), 0, s, sj);
+    uint32_t e = 0;
+    hipError_t rc = hipMemcpyAsync(&e, err, 4, hipMemcpyDeviceToHost, s);
+    if (rc == hipSuccess) rc = hipStreamSynchronize(s);
+    (void)hipFree(tmp);
+    if (rc != hipSuccess) { c3d_set_error("c3d_test_scan_wave: %s", hipGetErrorString(rc)); return (int)rc; }
+    if (e) { c3d_set_error("c3d_test_scan_wave: a hand-over timed out"); return -3; }
+    return 0;
+}
 int c3d_test_sort_pairs_u32(uint32_t* keys, uint32_t* vals, int64_t n, int32_t end_bit, c3d_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     if (n <= 0) return 0;

@@ -52,6 +52,28 @@ def test_scan(n, excl):
     assert (got == (ref & 0xFFFFFFFF).astype(np.uint32)).all()
 
 
+@pytest.mark.parametrize("n", [1, 63, 1024, 1025, 65543, 1 << 20, 4_200_000 + 777, 9_000_001])
+def test_record_base_scan_one_wave_tiles(n):
+    """csrc/scan_wave.h -- the record-base scan that rides in the recording forward compositing launch -- on its own: one-wave tiles of 1024 elements, two-level direct
+    hand-over (groups of 64 tiles; beyond 64 groups, i.e. above 4.19 M elements, a tile sums the group totals in more than one step of 64)"""
+    import c3d_hip as h
+    rng = np.random.default_rng(n)
+    a = rng.integers(0, 7, size=n).astype(np.uint32)
+    a[rng.random(n) < 0.3] = 0
+    rect = rng.integers(0, 1 << 30, size=(n, 2)).astype(np.uint32)
+    d_in, d_rect = _dev(a.view(np.int32), torch.int32), _dev(rect.view(np.int32), torch.int32)
+    out = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    einfo = torch.full((n, 4), -1, dtype=torch.int32, device="cuda")
+    h.check(h.lib().c3d_test_scan_wave(h.ptr(d_in), h.ptr(d_rect), h.ptr(out), h.ptr(einfo), n, h.stream()), "c3d_test_scan_wave")
+    want = np.concatenate([[0], np.cumsum(a.astype(np.int64))[:-1]]).astype(np.uint32)
+    got = out.cpu().numpy().view(np.uint32)
+    assert (got == want).all()
+    e = einfo.cpu().numpy().view(np.uint32)
+    nz = a != 0
+    assert (e[nz, 0] == 0).all() and (e[nz, 1] == rect[nz, 0]).all() and (e[nz, 2] == rect[nz, 1]).all() and (e[nz, 3] == want[nz]).all()
+    assert (e[~nz] == 0xFFFFFFFF).all()                       # elements without tiles get no record
+
+
 @pytest.mark.parametrize("n,bits", [(1, 32), (100, 32), (4096, 32), (4097, 8), (100000, 13), (1 << 20, 32), (3000001, 15)])
 def test_sort_pairs_is_stable_and_correct(n, bits):
     import c3d_hip as h
