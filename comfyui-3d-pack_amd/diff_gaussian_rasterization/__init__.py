@@ -18,19 +18,20 @@ last_num_rendered = 0   # (tile, splat) pairs of the most recent forward whose c
 # ---- pair capacity: the forward pass without its host round trip -----------------------------------------------------------------------------------
 # The wheel sizes its binning buffer from the exact pair count and stalls the host for that one number on every call (so did rounds 1-4 here:
 # c3d_gs_forward_project).  Here the first call of a (device, N, H, W) shape takes that synchronous path and LEARNS the count; later calls of the shape go through
-# c3d_gs_forward_nosync with buffers and launches sized for a capacity 1.5 x above the largest count seen, the count stays on the device, and the two status words
+# c3d_gs_forward_nosync with buffers and launches sized for a capacity above the largest count seen, the count stays on the device, and the two status words
 # of the call come back through pinned memory and are examined when a later call starts -- the host runs ahead of the GPU instead of waiting for it once per view.
 # A view that needs more pairs than the capacity is rendered incompletely (pairs beyond it are dropped); that is noticed one call late: a RuntimeWarning says so
-# and the capacity is regrown at once.  Counts drift slowly along a training run and between the cameras of an orbit, and the capacity follows them upwards as soon
-# as a call uses more than GROW_AT of it, so in practice only a jump of > 50 % between two consecutive calls of one shape can overflow.  sync_free(False) restores
-# the wheel's behaviour (exact count, one synchronisation per call) for callers that cannot accept that.
+# and the capacity regrows at once.  Headroom: 1.5 x the largest count seen when the call is differentiated (a training loop: counts drift slowly, and one incomplete
+# gradient step is harmless), 3 x when it is not (inference through LGM / TGS / TRELLIS-style callers: the next object may be larger, and an incomplete image is what the
+# user gets) -- empty capacity costs a few early-exiting workgroups per sort pass and bytes of a 288 GB memory.  sync_free(False) restores the wheel's behaviour (exact
+# count, one synchronisation per call) for callers that cannot accept any of that.
 import threading
 import warnings
 
 _lock = threading.RLock()      # ComfyUI may run nodes on several threads: slot hand-out and examination are serialised (a few dictionary / list operations per call)
 _SYNC_FREE = True
-_GROW_AT, _HEADROOM = 0.6, 1.5
-_cap = {}        # (device index, N, H, W) -> pair capacity
+_HEADROOM_GRAD, _HEADROOM_NOGRAD, _SLACK = 1.5, 3.0, 1 << 16      # capacity = headroom x largest count seen + slack
+_cap = {}        # (device index, N, H, W) -> largest pair count seen for the shape
 _SLOTS = 64      # status slots per device: calls whose status words may be on their way to the host at once
 _SENTINEL = -1   # 0xFFFFFFFF: neither a flag word (bits 0-1) nor a pair count (< 2^30)
 _rings = {}      # device index -> _Ring
@@ -96,22 +97,24 @@ def pending_calls():
 
 
 def _learn(key, seen):
-    """a pair count of this shape has reached the host: keep the capacity 1.5 x above the largest count seen"""
+    """a pair count of this shape has reached the host"""
     global last_num_rendered
     with _lock:
         last_num_rendered = int(seen)
-        cap = _cap.get(key, 0)
-        if seen > _GROW_AT * cap:
-            _cap[key] = min(int(seen * _HEADROOM) + (1 << 16), 0x3FFFFFF0)
+        if seen > _cap.get(key, -1):
+            _cap[key] = int(seen)
 
 
-def _capacity_for(key):
+def _capacity_for(key, differentiated):
     """-> pair capacity for a sync-free forward of this shape, or None: take the synchronous path (and learn the count)"""
     with _lock:
         ring = _rings.get(key[0])
         if ring is not None and ring.pending:
             ring.examine()
-        return _cap.get(key) if _SYNC_FREE else None
+        seen = _cap.get(key)
+        if seen is None or not _SYNC_FREE:
+            return None
+        return min(int(seen * (_HEADROOM_GRAD if differentiated else _HEADROOM_NOGRAD)) + _SLACK, 0x3FFFFFF0)
 
 
 def _status_slot(dev, key, cap):
@@ -196,7 +199,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
             alpha = torch.empty((1, H, W), dtype=torch.float32, device=dev)
             key = (dev.index, N, H, W)
-            cap = _capacity_for(key) if (N > 0 and H > 0 and W > 0) else None
+            cap = _capacity_for(key, any(ctx.needs_input_grad)) if (N > 0 and H > 0 and W > 0) else None
             if cap is not None:      # sync-free: launches sized for the capacity, the pair count stays on the device (see _cap above)
                 num_rendered = cap
                 binning = torch.empty((lib.c3d_gs_binning_bytes(cap, H, W),), **u8)
@@ -287,7 +290,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
             depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
             alpha = torch.empty((1, H, W), dtype=torch.float32, device=dev)
             key = (dev.index, N, H, W)
-            cap = _capacity_for(key) if (N > 0 and H > 0 and W > 0) else None
+            cap = _capacity_for(key, any(ctx.needs_input_grad)) if (N > 0 and H > 0 and W > 0) else None
             if cap is not None:      # sync-free (see _cap above)
                 num_rendered = cap
                 binning = torch.empty((lib.c3d_gs_binning_bytes(cap, H, W),), **u8)
