@@ -50,6 +50,12 @@ def main():
                                rg.ctypes.data_as(C.c_void_p), nc.ctypes.data_as(C.c_void_p), nt, out.ctypes.data_as(C.c_void_p))
         lines.append(fmt("view el %g az %g (%.0f s)" % (el, az, time.time() - t0), out))
         tot += out
+        fw = np.zeros(5)
+        lib.fwd_walk_stats(W, H, (W + 15) // 16, (H + 15) // 16, xy.ctypes.data_as(C.c_void_p), co.ctypes.data_as(C.c_void_p), pl.ctypes.data_as(C.c_void_p),
+                           rg.ctypes.data_as(C.c_void_p), nt, fw.ctypes.data_as(C.c_void_p))
+        lines.append("    forward walk: %.3f M rectangle hits walked while a pixel of the quadrant is alive, %.3f M of them blend into a pixel (%.1f %%); hits against the alive pixels' bounding box (per 64-entry chunk): "
+                     "%.3f M (%.3f x); hits that reach 1/255 on a pixel CENTRE: %.3f M (%.3f x), on the centre of a pixel alive at the chunk start: %.3f M (%.3f x)"
+                     % (fw[0] / 1e6, fw[1] / 1e6, 100 * fw[1] / fw[0], fw[2] / 1e6, fw[2] / fw[0], fw[3] / 1e6, fw[3] / fw[0], fw[4] / 1e6, fw[4] / fw[0]))
         del ost
     lines.append(fmt("all %d views" % len(poses), tot))
     txt = "\n".join(["lane packing statistics of the backward compositing walk: %d Gaussians, %d x %d (oracle float32 lists)" % (N, W, H)] + lines)
