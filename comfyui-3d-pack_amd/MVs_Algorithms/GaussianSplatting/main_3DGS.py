@@ -168,28 +168,30 @@ class GaussianSplatting3D:
         p = self.gs_params
         return p.density_start_iter <= step <= p.density_end_iter
 
-    def _densify(self, step, stats):
+    def _densify(self, step, stats, stats_done=False):
         """stats = (radii [N], dL/dmeans2D [N,3]) of this rank's LAST view of the step (the reference looks at the last view only, :210-213),
-        or None when the rank rendered nothing.  With several ranks the statistics are combined (sum / max) so that replicas stay identical."""
+        or None when the rank rendered nothing.  With several ranks the statistics are combined (sum / max) so that replicas stay identical.
+        stats_done: the fused step has already accumulated them (FusedViewStep.accumulate_densify_stats)."""
         p, g = self.gs_params, self.renderer.gaussians
         if not self._in_density_window(step):
             return
         n = g._xyz.shape[0]
-        if stats is None:
-            radii, vg = torch.zeros((n,), dtype=torch.int32, device=self.device), torch.zeros((n, 3), device=self.device)
-        else:
-            radii, vg = stats
-        vis = radii > 0
-        if self.group is not None and torch.distributed.get_world_size(self.group) > 1:
-            add = torch.cat((torch.norm(vg[:, :2], dim=-1, keepdim=True) * vis.unsqueeze(-1), vis.unsqueeze(-1).float()), dim=1)
-            torch.distributed.all_reduce(add, group=self.group)
-            rmax = torch.where(vis, radii, torch.zeros_like(radii)).float()
-            torch.distributed.all_reduce(rmax, op=torch.distributed.ReduceOp.MAX, group=self.group)
-            g.xyz_gradient_accum += add[:, :1]
-            g.denom += add[:, 1:]
-            g.max_radii2D = torch.maximum(g.max_radii2D, rmax)
-        else:
-            g.add_densification_stats(vg, vis, radii)
+        if not stats_done:
+            if stats is None:
+                radii, vg = torch.zeros((n,), dtype=torch.int32, device=self.device), torch.zeros((n, 3), device=self.device)
+            else:
+                radii, vg = stats
+            vis = radii > 0
+            if self.group is not None and torch.distributed.get_world_size(self.group) > 1:
+                add = torch.cat((torch.norm(vg[:, :2], dim=-1, keepdim=True) * vis.unsqueeze(-1), vis.unsqueeze(-1).float()), dim=1)
+                torch.distributed.all_reduce(add, group=self.group)
+                rmax = torch.where(vis, radii, torch.zeros_like(radii)).float()
+                torch.distributed.all_reduce(rmax, op=torch.distributed.ReduceOp.MAX, group=self.group)
+                g.xyz_gradient_accum += add[:, :1]
+                g.denom += add[:, 1:]
+                g.max_radii2D = torch.maximum(g.max_radii2D, rmax)
+            else:
+                g.add_densification_stats(vg, vis, radii)
         changed = False
         if self._zero is not None and (step % p.densification_interval == 0 or step % p.opacity_reset_interval == 0):
             self._zero.unshard()                             # the surgery below edits whole moments (torch.optim layout); a new ZeroOneAdam adopts them afterwards
@@ -312,7 +314,15 @@ class GaussianSplatting3D:
         for q in self.params:
             q.grad = None
         if self._in_density_window(step):
-            self._densify(step, step_obj.read_view(len(mine) - 1) if len(mine) else None)
+            g = self.renderer.gaussians
+            single = self.group is None or torch.distributed.get_world_size(self.group) <= 1
+            if single and len(mine) and g.max_radii2D.dtype == torch.float32 and g.max_radii2D.numel() == g._xyz.shape[0]:
+                # one process: the statistics of the step's last view are accumulated by ONE kernel straight from the step's workspace (the node's default run is
+                # bound by its launch count: read_view + add_densification_stats were two copies and nine torch launches per iteration)
+                step_obj.accumulate_densify_stats(len(mine) - 1, g.xyz_gradient_accum, g.denom, g.max_radii2D)
+                self._densify(step, None, stats_done=True)
+            else:
+                self._densify(step, step_obj.read_view(len(mine) - 1) if len(mine) else None)
         return loss.detach()
 
     def training(self, progress=None):

@@ -67,6 +67,7 @@ _SIGNATURES = {
     "c3d_gs_step_param_backward_range": (C.c_int, [C.POINTER(GsSettings), i32, i32] + [vp] * 5 + [vp] * 6 + [i64, i32, vp, i32, i32, vp]),
     "c3d_gs_backward_views_raw": (C.c_int, [C.POINTER(GsSettings), i32, i32] + [vp] * 5 + [C.POINTER(vp)] * 3 + [vp] * 6 + [i64, i32, i32, vp, vp]),
     "c3d_gs_step_read_view": (C.c_int, [i32, i32, i32, i64, vp, i32, vp, vp, vp]),
+    "c3d_gs_step_accumulate_densify_stats": (C.c_int, [i32, i32, i32, i64, vp, i32, vp, vp, vp, vp]),
     "c3d_gs_mark_visible": (C.c_int, [i32, vp, vp, vp, vp, vp]),
     "c3d_gs_debug_state": (C.c_int, [i32, i32, i32, vp, i64, vp] + [vp] * 7 + [vp]),
     "c3d_adam_step": (C.c_int, [vp, vp, vp, vp, i64, C.c_double, C.c_double, C.c_double, C.c_double, i64, vp]),

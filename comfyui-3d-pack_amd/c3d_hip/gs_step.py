@@ -276,6 +276,18 @@ class FusedViewStep:
         return radii, g2
 
 
+    def accumulate_densify_stats(self, view, grad_accum, denom, max_radii=None):
+        """the reference trainer's densification statistics of view `view` of the last run() (GaussianModel.add_densification_stats + the max_radii2D update), added in place,
+        straight from the workspace: one launch (c3d_gs_step_accumulate_densify_stats) instead of read_view()'s two copies and the torch ops on them"""
+        ws, cap = self._last
+        for t in (grad_accum, denom, max_radii):
+            if t is not None and (t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != self.N):
+                raise ValueError("accumulate_densify_stats: float32 contiguous tensors of N elements")
+        with torch.cuda.device(self.device):
+            _h.check(_h.lib().c3d_gs_step_accumulate_densify_stats(self.N, self.H, self.W, cap, _h.ptr(ws), int(view), _h.ptr(grad_accum), _h.ptr(denom), _h.ptr(max_radii),
+                                                                  _h.stream(self.device)), "c3d_gs_step_accumulate_densify_stats")
+
+
 class FusedViewRender:
     """Forward only: V views of one cloud per library call (c3d_gs_render_views_raw), `group` views per launch of every stage, `lanes` groups in flight, no host
     synchronisation between views -- the orbit-rendering loop of the reference's renderer nodes in one call."""

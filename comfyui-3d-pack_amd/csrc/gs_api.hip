@@ -707,6 +707,33 @@ int c3d_gs_step_read_view(int32_t N, int32_t H, int32_t W, int64_t pair_capacity
     return 0;
 }
 
+// the reference's add_densification_stats + max_radii2D update (main_3DGS.py:210-213, main_3DGS_renderer.py:767-769) for ONE view of the last step, read straight out of
+// the step's workspace: per visible Gaussian (radius > 0)  grad_accum += |dL/dmean2D.xy|, denom += 1, max_radii = max(max_radii, radius).  One launch instead of two
+// device copies and nine torch ops per training iteration of the densification window (the node's default run is bound by its launch count).
+__global__ void __launch_bounds__(256) k_densify_stats(int N, const int* __restrict__ radii, const float* __restrict__ d2, float* __restrict__ grad_accum, float* __restrict__ denom,
+                                                        float* __restrict__ max_radii) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int r = radii[i];
+    if (r <= 0) return;
+    const float gx = d2[3 * (size_t)i], gy = d2[3 * (size_t)i + 1];
+    grad_accum[i] += sqrtf(gx * gx + gy * gy);
+    denom[i] += 1.f;
+    if (max_radii) max_radii[i] = fmaxf(max_radii[i], (float)r);
+}
+int c3d_gs_step_accumulate_densify_stats(int32_t N, int32_t H, int32_t W, int64_t pair_capacity, const void* workspace, int32_t view, float* grad_accum, float* denom,
+                                         float* max_radii, c3d_stream_t stream) {
+    if (N <= 0) return 0;
+    if (!workspace || view < 0 || !grad_accum || !denom) { c3d_set_error("c3d_gs_step_accumulate_densify_stats: bad argument"); return -1; }
+    StepWs w0; carve_step(nullptr, N, H, W, pair_capacity, w0);
+    StepWs w; carve_step((char*)workspace + (size_t)view * w0.bytes, N, H, W, pair_capacity, w);
+    hipStream_t s = (hipStream_t)stream;
+    C3dProfScope ps(C3D_P_OTHER, s);
+    hipLaunchKernelGGL(k_densify_stats, dim3(c3d_cdiv(N, 256)), dim3(256), 0, s, N, (const int*)w.radii, (const float*)w.dmeans2D, grad_accum, denom, max_radii);
+    C3D_LAUNCH_CHECK();
+    return 0;
+}
+
 int c3d_gs_mark_visible(int32_t N, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present, c3d_stream_t stream) {
     if (N > 0 && (!means3D || !viewmatrix || !present)) { c3d_set_error("c3d_gs_mark_visible: NULL pointer"); return -1; }
     return gs_launch_mark_visible(N, means3D, viewmatrix, projmatrix, present, (hipStream_t)stream);

@@ -228,6 +228,13 @@ int c3d_gs_backward_views_raw(const c3d_gs_settings* views /* host [V] */, int32
 int c3d_gs_step_read_view(int32_t N, int32_t image_height, int32_t image_width, int64_t pair_capacity, const void* workspace, int32_t view,
                           int32_t* radii_out, float* dL_dmeans2D_out, c3d_stream_t stream);
 
+/* The densification statistics of the reference's trainer (main_3DGS.py:210-213 -> GaussianModel.add_densification_stats, main_3DGS_renderer.py:767-769, and the
+ * max_radii2D update) accumulated straight from view `view` of the last c3d_gs_train_views_raw / c3d_gs_backward_views_raw call (same N / H / W / pair_capacity / workspace):
+ * for every Gaussian the view saw (radius > 0):  grad_accum[i] += ||dL/dmeans2D[i, 0:2]||,  denom[i] += 1,  max_radii[i] = max(max_radii[i], radius) (max_radii may be
+ * NULL).  grad_accum, denom: [N,1] float32; max_radii: [N] float32.  One launch instead of c3d_gs_step_read_view's two copies plus the torch ops on them. */
+int c3d_gs_step_accumulate_densify_stats(int32_t N, int32_t image_height, int32_t image_width, int64_t pair_capacity, const void* workspace, int32_t view,
+                                         float* grad_accum, float* denom, float* max_radii, c3d_stream_t stream);
+
 /* mark_visible: present[N] (uint8) = view-space z > 0.2 */
 int c3d_gs_mark_visible(int32_t N, const float* means3D, const float* viewmatrix, const float* projmatrix,
                         uint8_t* present, c3d_stream_t stream);

@@ -1112,6 +1112,40 @@ def test_fused_forward_backward_halves_match_autograd():
             assert torch.equal(a, b)
 
 
+def test_fused_densify_statistics_equal_the_torch_form():
+    """c3d_gs_step_accumulate_densify_stats (round 5: the statistics of the step's last view accumulated by one kernel straight from the workspace) against
+    c3d_gs_step_read_view + GaussianModel.add_densification_stats (reference main_3DGS.py:210-213, main_3DGS_renderer.py:767-769): same denominators and radii exactly, the
+    gradient norms to rounding (sqrt(x^2 + y^2) in one kernel against torch's norm reduction)"""
+    from MVs_Algorithms.GaussianSplatting.main_3DGS_renderer import GaussianSplattingRenderer
+    from c3d_hip.gs_step import FusedViewStep
+    raw = S.make_cloud(30000, seed=5, log_scale_mean=np.log(0.02), activated=False)
+    W, H, V = 200, 136, 3
+    r = GaussianSplattingRenderer(sh_degree=3, device="cuda")
+    r.initialize({"xyz": raw["means3D"], "features": raw["shs"], "scaling_raw": raw["scales"], "rotation_raw": raw["rotations"], "opacity_raw": raw["opacities"]})
+    g = r.gaussians
+    plist = [g._xyz, g._features_dc, g._features_rest, g._opacity, g._scaling, g._rotation]
+    rs = [hip_settings(S.camera_settings(W, H, 49.1, el, az, 2.2, bg=(1, 1, 1)), "cuda") for el, az in ((-10.0, 20.0), (25.0, 140.0), (5.0, -80.0))]
+    rng = np.random.default_rng(1)
+    tc = [_dev(rng.uniform(size=(3, H, W)).astype(np.float32), torch.float32) for _ in range(V)]
+    ta = [_dev(rng.uniform(size=(1, H, W)).astype(np.float32), torch.float32) for _ in range(V)]
+    step = FusedViewStep(30000, H, W, "cuda", views=V)
+    grads = [torch.empty_like(p) for p in plist]
+    step.run(rs, [p.detach() for p in plist], grads, tc, ta, None, w_l1=0.8, w_alpha_mse=3.0, scale=1.0 / V, accumulate=False)
+    for view in (V - 1, 0):
+        acc0 = _dev(rng.uniform(size=(30000, 1)).astype(np.float32), torch.float32)
+        den0 = _dev(rng.integers(0, 5, size=(30000, 1)).astype(np.float32), torch.float32)
+        mr0 = _dev(rng.integers(0, 30, size=(30000,)).astype(np.float32), torch.float32)
+        radii, vg = step.read_view(view)
+        assert int((radii > 0).sum()) > 10000 and float(vg.abs().max()) > 0
+        g.xyz_gradient_accum, g.denom, g.max_radii2D = acc0.clone(), den0.clone(), mr0.clone()
+        g.add_densification_stats(vg, radii > 0, radii)
+        a, d, m = acc0.clone(), den0.clone(), mr0.clone()
+        step.accumulate_densify_stats(view, a, d, m)
+        assert torch.equal(d, g.denom) and torch.equal(m, g.max_radii2D)
+        assert torch.allclose(a, g.xyz_gradient_accum, rtol=1e-6, atol=0.0)
+        assert not torch.equal(a, acc0)
+
+
 def test_trainer_densify_prune_schedule():
     """The reference's default schedule densifies (main_3DGS.py:209-224): statistics from the step's last view, clone/split/prune at the
     interval, opacity reset -- through the fused step (statistics read back with c3d_gs_step_read_view) and through the autograd path.
