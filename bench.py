@@ -179,6 +179,7 @@ def main_ref_default(a, world, rank, dev, dist):
     masks = [(alpha[i, 0] > 0.5).float() for i in range(len(poses))]
     gp = GSParams()                                                # every default of the node
     tr = GaussianSplatting3D(gp, None, device=dev)
+    tr.fused_densify_stats = os.environ.get("C3D_BENCH_TORCH_DENSIFY_STATS") != "1"      # A/B hook of this bench only (profiles/r05o_*): the statistics as torch ops, as before round 5
     tr.prepare_training(refs, masks, poses, 49.1)
     import random
     rng = random.Random(0)

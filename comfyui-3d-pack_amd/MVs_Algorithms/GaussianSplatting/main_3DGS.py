@@ -101,6 +101,7 @@ class GaussianSplatting3D:
         self._zero = None                                    # exchange == "zero1": parallel.ZeroOneAdam (sharded moments; rebuilt after every densification)
         self.defer_step_status = True                        # fused step: no host synchronisation per step once the pair capacity is fitted (c3d_hip/gs_step.py)
         self.image_loss_in_torch = False                     # True: fused forward / backward halves with the image loss (incl. MS-SSIM) as torch ops in between
+        self.fused_densify_stats = True                      # densification statistics of the step's last view by one kernel from the step's workspace (False: read_view + torch ops)
 
     def prepare_training(self, reference_images, reference_masks, reference_orbit_camera_poses, reference_orbit_camera_fovy):
         self.ref_imgs_num = len(reference_images)
@@ -316,7 +317,7 @@ class GaussianSplatting3D:
         if self._in_density_window(step):
             g = self.renderer.gaussians
             single = self.group is None or torch.distributed.get_world_size(self.group) <= 1
-            if single and len(mine) and g.max_radii2D.dtype == torch.float32 and g.max_radii2D.numel() == g._xyz.shape[0]:
+            if self.fused_densify_stats and single and len(mine) and g.max_radii2D.dtype == torch.float32 and g.max_radii2D.numel() == g._xyz.shape[0]:
                 # one process: the statistics of the step's last view are accumulated by ONE kernel straight from the step's workspace (the node's default run is
                 # bound by its launch count: read_view + add_densification_stats were two copies and nine torch launches per iteration)
                 step_obj.accumulate_densify_stats(len(mine) - 1, g.xyz_gradient_accum, g.denom, g.max_radii2D)

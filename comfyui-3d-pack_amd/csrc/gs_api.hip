@@ -553,7 +553,7 @@ int c3d_gs_train_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, c
                   }
                   const GsPixelLossW plw{loss->w_l1, loss->w_l2, loss->w_alpha_mse, loss->scale, loss_out ? q.w[0].tile_loss : nullptr};
                   if ((rc = gs_launch_composite_bwd(q.p[0], q.g0, q.b0, res, q.im0, px, false, q.w[0].pairgrad, q.w[0].pvalid, s, q.cap, &plw, q.G, q.vs))) break; }
-                if (loss_out) { C3dProfScope ps(C3D_P_OTHER, s);
+                if (loss_out && groups > 1) { C3dProfScope ps(C3D_P_OTHER, s);
                                 if ((rc = gs_launch_sum_view_loss(q.w[0].tile_loss, q.tiles + (ssim ? 1 : 0), q.w[0].tile_loss + q.tiles + 1, q.G, q.vs, s))) break; }
             } while (0);
             rc_all = rc;
@@ -564,7 +564,8 @@ int c3d_gs_train_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, c
         StepWs wf; carve_step((char*)workspace, N, views[0].image_height, views[0].image_width, pair_capacity, wf);
         const int tiles = ((views[0].image_width + C3D_TILE_X - 1) / C3D_TILE_X) * ((views[0].image_height + C3D_TILE_Y - 1) / C3D_TILE_Y);
         C3dProfScope ps(C3D_P_OTHER, s0);
-        if (gs_launch_sum_tile_loss(wf.tile_loss + tiles + 1, vs, V, loss_out, s0)) return -1;
+        if (groups == 1) { if (gs_launch_sum_group_loss(wf.tile_loss, tiles + (ssim ? 1 : 0), V, V > 1 ? vs : 0, loss_out, s0)) return -1; }      // one launch for both stages
+        else if (gs_launch_sum_tile_loss(wf.tile_loss + tiles + 1, vs, V, loss_out, s0)) return -1;
     }
     if (accumulate & 2) return 0;   // the caller runs the per-Gaussian pass itself, range by range (c3d_gs_step_param_backward_range)
     return step_a8_all_views(views, V, N, vs, workspace, pair_capacity, means3D, f_dc, f_rest, scaling_raw, rotation_raw, dL_dmeans3D, dL_df_dc, dL_df_rest,

@@ -318,6 +318,28 @@ __global__ void __launch_bounds__(64) k_sum_views_loss(const float* __restrict__
     for (int v = 0; v < V; v++) acc += *(const float*)((const char*)first_view_sum + (size_t)v * stride);      // views in order
     loss_out[0] += acc;             // one writer: the launch is ordered behind everything else that touches *loss_out on this stream
 }
+// both stages in one launch when all views of the step went through ONE group (the usual case): the same per-view pattern, the views one after the other, the same bits
+__global__ void __launch_bounds__(1024) k_sum_group_loss(const float* __restrict__ t0, int n, size_t vs, int V, float* __restrict__ loss_out) {
+    __shared__ float red[16];
+    float acc = 0.f;
+    for (int v = 0; v < V; v++) {
+        const float* t = (const float*)((const char*)t0 + (size_t)v * vs);
+        float l = 0.f;
+        for (int i = threadIdx.x; i < n; i += 1024) l += t[i];
+        l = c3d_wave_sum(l);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = l;
+        __syncthreads();
+        if (threadIdx.x == 0) { float q = 0.f; for (int w = 0; w < 16; w++) q += red[w]; acc += q; }
+    }
+    if (threadIdx.x == 0) loss_out[0] += acc;
+}
+int gs_launch_sum_group_loss(const float* terms, int n, int V, size_t vs, float* loss_out, hipStream_t s) {
+    if (n <= 0 || V <= 0 || !loss_out) return 0;
+    hipLaunchKernelGGL(k_sum_group_loss, dim3(1), dim3(1024), 0, s, terms, n, vs, V, loss_out);
+    C3D_LAUNCH_CHECK();
+    return 0;
+}
 int gs_launch_sum_view_loss(const float* terms, int n, float* view_sum, int V, size_t vs, hipStream_t s) {
     if (n <= 0 || V <= 0) return 0;
     hipLaunchKernelGGL(k_sum_view_loss, dim3(V), dim3(1024), 0, s, terms, n, view_sum, vs);
