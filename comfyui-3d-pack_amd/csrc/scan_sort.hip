@@ -19,6 +19,7 @@
 // pointers -- keys, values, state, device-resident counts -- are given for view 0 and advanced by blockIdx.y * vs).  The V views of a step are
 // sorted / scanned by ONE launch per stage: a 1 M-key pass is 16 MB of traffic and 17 us of fixed latencies, eight of them in one launch are
 // bandwidth-sized work.  Tickets, status words and look-backs are per view (a workgroup only ever waits for lower tickets of ITS view); the error word is shared.
+#include <type_traits>
 #include "c3d_common.h"
 
 
@@ -75,8 +76,13 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_lb(const uint32_t* __rest
                                                            uint32_t* __restrict__ state, uint32_t* __restrict__ err, ScanTail tail, size_t vs) {
     __shared__ uint32_t lds[SCAN_VEC][4];
     __shared__ uint32_t s_tile, s_prefix;
-    in = c3d_view_ptr(in, vs); idx = c3d_view_ptr(idx, vs); out = c3d_view_ptr(out, vs); state = c3d_view_ptr(state, vs);
-    tail.meta = c3d_view_ptr(tail.meta, vs); tail.rsort = c3d_view_ptr(tail.rsort, vs);   // err / tail.status: shared by the views
+    // view = (linear block id) % V: one XCD per view at V = 8 (see k_onesweep) -- the gather of the emit-offset scan then finds half of a view's 8 MB of rects in its
+    // XCD's L2 instead of an eighth of eight views': 0.153 -> 0.133 ms for the 8-view step (profiles/r05r_*).  All views hold N elements: no stealing needed.
+    const size_t view_off = (size_t)((blockIdx.x + gridDim.x * blockIdx.y) % gridDim.y) * vs;
+#define SC_VP(p_) ((p_) ? (decltype(p_))((char*)(p_) + view_off) : (p_))
+    in = SC_VP(in); idx = SC_VP(idx); out = SC_VP(out); state = SC_VP(state);
+    tail.meta = SC_VP(tail.meta); tail.rsort = SC_VP(tail.rsort);   // err / tail.status: shared by the views
+#undef SC_VP
     unsigned long long* status = reinterpret_cast<unsigned long long*>(state + 2);
     if (threadIdx.x == 0) s_tile = atomicAdd(&state[0], 1u);
     __syncthreads();
@@ -275,6 +281,7 @@ uint32_t* c3d_scan_error_word(void* tmp) { return (uint32_t*)tmp + 1; }
 #define RS_VALUE_MASK ((1u << 30) - 1u)
 #define RS_GROUP 16
 #define RS_LOOKBACK 32
+#define RS_SLOTS 1024             // workgroups of k_onesweep resident at once: 256 CUs x 4
 #define RS_HIST_SPLIT 16      // copies of the global histogram (workgroup b adds to copy b % 16): 245 - 1000 workgroups adding to ONE set of 256 counters serialise at the
                               // memory-side atomic unit (measured: 23 us for 1 M keys, profiles/r02c); consumers add the 16 copies up
 static inline size_t sort_pass_words(size_t nb) { return RS_RADIX * (nb + nb / RS_GROUP + 1); }
@@ -282,9 +289,10 @@ static inline size_t sort_pass_words(size_t nb) { return RS_RADIX * (nb + nb / R
 __global__ void __launch_bounds__(RS_THREADS) k_radix_hist_all(const uint32_t* __restrict__ keys, uint32_t* __restrict__ ghist, size_t n,
                                                                 const uint32_t* __restrict__ n_dev, int passes, size_t vs) {
     __shared__ uint32_t h[RS_MAX_PASSES][RS_RADIX];
-    keys = c3d_view_ptr(keys, vs); ghist = c3d_view_ptr(ghist, vs); n_dev = c3d_view_ptr(n_dev, vs);
+    keys = c3d_view_ptr(keys, vs); ghist = c3d_view_ptr(ghist, vs); n_dev = c3d_view_ptr(n_dev, vs);      // (view = XCD as in k_onesweep: measured, no difference -- it only reads)
+    const uint32_t htile = blockIdx.x;
     if (n_dev) n = min((size_t)*n_dev, n);      // element count resident on the device (no host round trip)
-    const size_t base = (size_t)blockIdx.x * RS_TILE;
+    const size_t base = (size_t)htile * RS_TILE;
     if (base >= n) return;                      // capacity-sized launch: nothing here
     for (int p = 0; p < passes; p++) h[p][threadIdx.x] = 0;
     __syncthreads();
@@ -306,22 +314,27 @@ __global__ void __launch_bounds__(RS_THREADS) k_radix_hist_all(const uint32_t* _
         }
     }
     __syncthreads();
-    uint32_t* mine = ghist + (size_t)(blockIdx.x % RS_HIST_SPLIT) * RS_MAX_PASSES * RS_RADIX;
+    uint32_t* mine = ghist + (size_t)(htile % RS_HIST_SPLIT) * RS_MAX_PASSES * RS_RADIX;
     for (int p = 0; p < passes; p++) {
         const uint32_t c = h[p][threadIdx.x];
         if (c) atomicAdd(&mine[p * RS_RADIX + threadIdx.x], c);
     }
 }
 
-// poll one status word until its flag is at least `need` (1 = any, 2 = inclusive); bounded
-__device__ __forceinline__ uint32_t rs_wait(const uint32_t* p, uint32_t x, uint32_t need, uint32_t* err) {
-    uint32_t spins = 0;
-    while ((x >> 30) < need) {
+// poll one status word until its flag is at least `need` (1 = any, 2 = inclusive); bounded.  The spin itself is ONE out-of-line function: inlined at its 48 call sites (which the
+// unrolled look-back batches multiply further) it was 432 copies of the loop and most of the kernel's 58 KB -- against a 64 KB instruction cache shared by two CUs whose
+// workgroups sit in different phases of the tile.
+__device__ __attribute__((noinline)) uint32_t rs_wait_slow(const uint32_t* p, uint32_t need, uint32_t* err) {
+    uint32_t x, spins = 0;
+    do {
         if (++spins > LB_SPIN_LIMIT) { atomicOr(err, C3D_ERR_LOOKBACK); return RS_FLAG_INCL; }
         __builtin_amdgcn_s_sleep(2);
         x = ld_agent32(p);
-    }
+    } while ((x >> 30) < need);
     return x;
+}
+__device__ __forceinline__ uint32_t rs_wait(const uint32_t* p, uint32_t x, uint32_t need, uint32_t* err) {
+    return ((x >> 30) < need) ? rs_wait_slow(p, need, err) : x;
 }
 
 // 16 keys per thread: 4096 keys and 39 KB of LDS per workgroup, four workgroups per CU.  Measured and dropped: 8 keys per thread (twice the tiles: the tile sort of an
@@ -331,69 +344,136 @@ __device__ __forceinline__ uint32_t rs_wait(const uint32_t* p, uint32_t x, uint3
 // the current one, the recipe that took a third off the MS-SSIM kernels.  Tile sort of an 8-view step 0.48 -> 2.0 ms (4.7 ms where the extra registers spill).  A ticket drawn
 // early is a tile whose aggregate is published LATE (after the workgroup's current tile, look-back wait included), and every higher ticket waits for it: the decoupled look-back
 // lives on aggregates appearing at once, in parallel; holding tickets serialises it.
-template <bool IOTA, int ITEMS>
-__global__ void __launch_bounds__(RS_THREADS, 4) k_onesweep(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-                                                             uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
-                                                             const uint32_t* __restrict__ ghist, uint32_t* __restrict__ ticket, uint32_t* __restrict__ err,
-                                                             uint32_t* __restrict__ tile_words, uint32_t* __restrict__ group_words, size_t n,
+// Round 5 (profiles/r05q_*): ranking through v_bitop3_b32 and tiles without bounds tests (see `front` below): 126 -> 81 VGPRs, rank phase of a lone wave 3.3 -> 2.3 us,
+// depth sort of an 8-view step 0.256 -> 0.237 ms, tile sort 0.488 -> 0.470 ms on one box.  With 81 VGPRs the ONE-reorder-buffer form (keys, then values, through one 16 KB buffer
+// and back into registers before the chained scan: 22.5 KB) fits five and six workgroups per CU without spilling -- measured on the same box: 0.236 / 0.478 ms at five, 0.241 / 0.477
+// at six.  Tiles in flight are not what bounds a pass (same finding as the lean kernel of profiles/r05ij); not kept.
+template <bool IOTA, int ITEMS, bool STAY>
+__global__ void __launch_bounds__(RS_THREADS, 4) k_onesweep(const uint32_t* __restrict__ keys_in0, const uint32_t* __restrict__ vals_in0,
+                                                             uint32_t* __restrict__ keys_out0, uint32_t* __restrict__ vals_out0,
+                                                             const uint32_t* __restrict__ ghist0, uint32_t* __restrict__ ticket, uint32_t* __restrict__ err,
+                                                             uint32_t* __restrict__ tile_words0, uint32_t* __restrict__ group_words0, size_t n_cap,
                                                              const uint32_t* __restrict__ n_dev, int shift, unsigned long long* __restrict__ dbg, size_t vs) {
     __shared__ uint32_t whist[RS_THREADS / 64][RS_RADIX];
-    keys_in = c3d_view_ptr(keys_in, vs); vals_in = c3d_view_ptr(vals_in, vs); keys_out = c3d_view_ptr(keys_out, vs); vals_out = c3d_view_ptr(vals_out, vs);
-    ghist = c3d_view_ptr(ghist, vs); ticket = c3d_view_ptr(ticket, vs); tile_words = c3d_view_ptr(tile_words, vs); group_words = c3d_view_ptr(group_words, vs);
-    n_dev = c3d_view_ptr(n_dev, vs);
     __shared__ uint32_t lstart[RS_RADIX];    // first local slot of each digit
     __shared__ uint32_t gbase[RS_RADIX];     // global position of that slot
     __shared__ uint32_t skey[RS_THREADS * ITEMS];
     __shared__ uint32_t sval[RS_THREADS * ITEMS];
     __shared__ uint32_t scan_lds[4];
-    __shared__ uint32_t s_tile;
-    if (n_dev) n = min((size_t)*n_dev, n);
-    if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+    __shared__ uint32_t s_tile, s_view;
+    // Which view a workgroup of a V-view launch serves (round 5, profiles/r05r_* ... r05y_*): its HOME view is (linear block id) % V, not blockIdx.y.  Block b runs on XCD b % 8, so
+    // with V = 8 each view has ONE XCD (V = 16: two views per XCD; V = 4: two XCDs per view), and the half-line digit runs that neighbouring tiles of a view write next to each
+    // other meet in one L2 instead of leaving eight L2s as partial lines: tile sort of the 8-view step 0.460 -> 0.371 ms, depth sort 0.232 -> 0.218 ms on one box.
+    // A workgroup STAYS (round 5): it draws a ticket of its view, sorts that tile, draws the next -- the launch is one workgroup per residency slot, not one per tile of the
+    // pair CAPACITY.  (With a grid sized for the capacity, half of the workgroups of the 8-view step found no tile: 977 same-address ticket atomics per view and pass just to
+    // learn that, 12 ns each.)  When its view has no tile left it looks at the other views' counters ONCE (lane v of wave 0 reads view v's) and carries on with the first that
+    // has: work stealing, without which a pass of unequal views would last as long as its largest view on one XCD.  Only after the PREVIOUS tile is finished is the next ticket
+    // drawn -- a ticket held early is an aggregate published late (see above) -- and whoever holds a ticket is running: every wait of the chained scan is on a resident workgroup.
+    const uint32_t V = gridDim.y;
+    uint32_t view = (blockIdx.x + gridDim.x * blockIdx.y) % V;
     const int lane = c3d_lane(), wave = threadIdx.x >> 6;
+    uint32_t gview = 0xFFFFFFFFu, gtotal = 0, digit_base = 0;      // thread d: occurrences of digit d in the view's input and where the digit starts in the output -- kept while the view stays
+#define RS_AT(p_, v_) ((decltype(p_))((char*)(p_) + (size_t)(v_) * vs))
+#define RS_COUNT(v_) (n_dev ? min((size_t)*RS_AT(n_dev, v_), n_cap) : n_cap)      /* element count resident on the device (no host round trip) */
+    // STAY: the grid does not cover the capacity, tiles are drawn until none is left.  A launch of at most two rounds (2 x RS_SLOTS tiles: the depth sort of <= 8 views) runs the
+    // instance without the loop, one workgroup per tile -- there a staying workgroup's last, failed draw is a measurable tail (0.205 -> 0.224 ms for the four depth passes
+    // of the 8-view step), and nobody steals: a workgroup without a tile leaves.
+  for (;;) {
+    size_t n = RS_COUNT(view);               // requested BEFORE the ticket (behind the barrier it is a dependent scalar load on every tile's critical path)
+    if (STAY) __syncthreads();               // the previous tile's scatter has read skey / sval / gbase / lstart
+    if (threadIdx.x == 0) s_tile = atomicAdd(RS_AT(ticket, view), 1u);
     for (int i = threadIdx.x; i < (RS_THREADS / 64) * RS_RADIX; i += RS_THREADS) (&whist[0][0])[i] = 0;
     __syncthreads();
-    const uint32_t tile = s_tile;
+    uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_tile);      // uniform by construction; in a scalar register the tile's base pointers are scalar too
+    while ((size_t)tile * (RS_THREADS * ITEMS) >= n) {      // this view has no tile left
+        if (!STAY || V == 1) return;
+        // one look at the other views' counters (lane v of wave 0 reads view v's), then a ticket of the first view that has tiles.  Only now: the counters are the words the
+        // ticket atomics serialise on, and a look per tile (tried: next to every draw, so that a failed draw would know at once where to go) queues behind them -- tile sort
+        // 0.377 -> 0.57 ms (profiles/r05zz_*)
+        __syncthreads();                     // everybody has read s_tile
+        if (threadIdx.x < 64) {
+            bool has = false;
+            if ((uint32_t)lane < V && (uint32_t)lane != view) has = (size_t)ld_agent32(RS_AT(ticket, lane)) * (RS_THREADS * ITEMS) < RS_COUNT(lane);
+            const uint64_t m = __ballot(has);
+            if (lane == 0) {
+                const uint64_t above = (view + 1 < 64) ? (m >> (view + 1)) : 0ull;      // the next view upwards first, so that thieves spread over the views
+                const uint32_t pick = !m ? 0xFFFFFFFFu : (above ? view + 1 + (uint32_t)__builtin_ctzll(above) : (uint32_t)__builtin_ctzll(m));
+                s_view = pick;
+                if (m) s_tile = atomicAdd(RS_AT(ticket, pick), 1u);
+            }
+        }
+        __syncthreads();
+        if (s_view == 0xFFFFFFFFu) return;   // every view is done
+        view = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_view);
+        tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_tile);
+        n = RS_COUNT(view);
+    }
+    const uint32_t* keys_in = RS_AT(keys_in0, view); const uint32_t* vals_in = IOTA ? vals_in0 : RS_AT(vals_in0, view);
+    uint32_t* keys_out = RS_AT(keys_out0, view); uint32_t* vals_out = RS_AT(vals_out0, view);
+    const uint32_t* ghist = RS_AT(ghist0, view); uint32_t* tile_words = RS_AT(tile_words0, view); uint32_t* group_words = RS_AT(group_words0, view);
     const size_t bbase = (size_t)tile * (RS_THREADS * ITEMS);
-    if (bbase >= n) return;                  // capacity-sized launch: tickets beyond the data leave at once (nobody waits for them)
 #define RS_STAMP(k) do { if (dbg && threadIdx.x == 0) dbg[(size_t)tile * 8 + (k)] = (unsigned long long)wall_clock64(); } while (0)   // profiling hook (profiles/microbench/sort_phases.py)
     RS_STAMP(0);
-    const size_t wbase = bbase + (size_t)wave * (RS_THREADS * ITEMS / 4);
+    // Everything below addresses the tile with 32-bit offsets from scalar base pointers.  `full` (all tiles of a pass but the last) is a uniform branch around
+    // two instances of the same code: the full one carries no bounds test at all (round 5: 16 exec-masked load blocks with 64-bit compares, a ballot and a
+    // select per item gone).
+    const uint32_t cnt = (uint32_t)((n - bbase) < (size_t)(RS_THREADS * ITEMS) ? (n - bbase) : (size_t)(RS_THREADS * ITEMS));      // keys in this tile
+    const uint32_t* kin = keys_in + bbase;
+    const uint32_t* vin = vals_in + bbase;
+    const uint32_t woff = (uint32_t)wave * (RS_THREADS * ITEMS / 4) + (uint32_t)lane;      // the lane's first key: wave w owns keys [1024 w, 1024 w + 1024) of the tile
     uint32_t key[ITEMS], val[ITEMS], rank[ITEMS];
+    auto front = [&](auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
-    for (int i = 0; i < ITEMS; i++) {
-        size_t idx = wbase + (size_t)i * 64 + lane;
-        bool ok = idx < n;
-        key[i] = ok ? keys_in[idx] : 0xFFFFFFFFu;
-        val[i] = IOTA ? (uint32_t)idx : (ok ? vals_in[idx] : 0u);
-    }
-    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    if (dbg) { uint32_t x = 0; for (int i = 0; i < ITEMS; i++) x ^= key[i] ^ val[i]; if (x == 0x12345u) dbg[7] = 1; }   // wait for the loads before stamping
-    RS_STAMP(1);
-#pragma unroll
-    for (int i = 0; i < ITEMS; i++) {
-        size_t idx = wbase + (size_t)i * 64 + lane;
-        bool ok = idx < n;
-        uint32_t d = (key[i] >> shift) & (RS_RADIX - 1);
-        uint64_t peers = __ballot(ok);
-#pragma unroll
-        for (int b = 0; b < 8; b++) {
-            uint64_t m = __ballot((d >> b) & 1u);
-            peers &= ((d >> b) & 1u) ? m : ~m;
+        for (int i = 0; i < ITEMS; i++) {
+            const uint32_t off = woff + (uint32_t)i * 64u;
+            const bool ok = FULL || off < cnt;
+            const uint32_t offc = FULL ? off : (ok ? off : 0u);      // a clamped address and a select instead of a branch per load
+            const uint32_t k = kin[offc];
+            key[i] = ok ? k : 0xFFFFFFFFu;
+            if (IOTA) val[i] = (uint32_t)bbase + off;
+            else { const uint32_t v = vin[offc]; val[i] = ok ? v : 0u; }
         }
-        uint32_t prefix = whist[wave][d];
-        uint32_t r = (uint32_t)__popcll(peers & lt_mask);
-        if (ok && r == 0) whist[wave][d] = prefix + (uint32_t)__popcll(peers);  // lowest peer lane updates
-        rank[i] = prefix + r;
-    }
+        if (dbg) { uint32_t x = 0; for (int i = 0; i < ITEMS; i++) x ^= key[i] ^ val[i]; if (x == 0x12345u) dbg[7] = 1; }   // wait for the loads before stamping
+        RS_STAMP(1);
+        // ranking: the lanes holding the same digit, found bit by bit.  Per bit one sign-extending field extract (t = 0 / ~0), one ballot, and per mask half ONE
+        // v_bitop3_b32 (gfx950): peers & ~(ballot ^ t) -- keep the lanes whose bit equals mine (0x90 = a & ~(b ^ c)).  The generic spelling
+        // (peers &= bit ? m : ~m) compiled to 10 VALU instructions per bit, this is 5; a lone wave issues one VALU instruction per ~4 cycles, so the
+        // 16 x 8 bits were most of the phase.  The rank among the peers is mbcnt (bits of the mask below my lane), no lane mask needed.
+#pragma unroll
+        for (int i = 0; i < ITEMS; i++) {
+            const bool ok = FULL || (woff + (uint32_t)i * 64u) < cnt;
+            const uint32_t ds = key[i] >> shift;
+            uint32_t plo = ~0u, phi = ~0u;
+            if (!FULL) { const uint64_t okm = __ballot(ok); plo = (uint32_t)okm; phi = (uint32_t)(okm >> 32); }
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                const int t = __builtin_amdgcn_sbfe((int)ds, b, 1);
+                const uint64_t m = __ballot(t != 0);
+                plo = __builtin_amdgcn_bitop3_b32(plo, (uint32_t)m, (uint32_t)t, 0x90);
+                phi = __builtin_amdgcn_bitop3_b32(phi, (uint32_t)(m >> 32), (uint32_t)t, 0x90);
+            }
+            const uint32_t d = ds & (RS_RADIX - 1);
+            const uint32_t prefix = whist[wave][d];
+            const uint32_t r = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
+            if (ok && r == 0) whist[wave][d] = prefix + (uint32_t)__popc(plo) + (uint32_t)__popc(phi);  // lowest peer lane updates
+            rank[i] = prefix + r;
+        }
+    };
+    const bool full = cnt == (uint32_t)(RS_THREADS * ITEMS);
+    if (full) front(std::true_type{}); else front(std::false_type{});
     __syncthreads();
     RS_STAMP(2);
     // thread d owns digit d: count over the 4 waves, published at once (successors can already add it up), then the block-local layout
     const int d = threadIdx.x;
     const uint32_t grp = tile / RS_GROUP, gr = tile % RS_GROUP;
     const bool leader = gr == RS_GROUP - 1;
-    uint32_t gtotal = 0;                                 // occurrences of this digit in the whole input
+    const bool new_view = gview != view;                 // (uniform) the digit totals of the view's input and the digit starts: once per view a workgroup serves
+    if (new_view) {
+        gtotal = 0;
 #pragma unroll
-    for (int c = 0; c < RS_HIST_SPLIT; c++) gtotal += ghist[(size_t)c * RS_MAX_PASSES * RS_RADIX + d];
+        for (int c = 0; c < RS_HIST_SPLIT; c++) gtotal += ghist[(size_t)c * RS_MAX_PASSES * RS_RADIX + d];
+    }
     uint32_t tot = 0;
     {
         uint32_t c[RS_THREADS / 64];
@@ -402,7 +482,7 @@ __global__ void __launch_bounds__(RS_THREADS, 4) k_onesweep(const uint32_t* __re
         if (gtotal) st_agent32(tile_words + (size_t)tile * RS_RADIX + d, RS_FLAG_AGG | tot);
         uint32_t blk_total, dummy;
         uint32_t ls = block_excl_scan(tot, scan_lds, &blk_total);
-        const uint32_t digit_base = block_excl_scan(gtotal, scan_lds, &dummy);   // where digit d starts in the output
+        if (new_view) { digit_base = block_excl_scan(gtotal, scan_lds, &dummy); gview = view; }   // where digit d starts in the output
         lstart[d] = ls;
         gbase[d] = digit_base;
 #pragma unroll
@@ -412,8 +492,7 @@ __global__ void __launch_bounds__(RS_THREADS, 4) k_onesweep(const uint32_t* __re
     // block-local reorder first: it needs no global prefix and frees the key / val / rank registers for the scan's loads
 #pragma unroll
     for (int i = 0; i < ITEMS; i++) {
-        size_t idx = wbase + (size_t)i * 64 + lane;
-        if (idx < n) {
+        if (full || (woff + (uint32_t)i * 64u) < cnt) {
             uint32_t dd = (key[i] >> shift) & (RS_RADIX - 1);
             uint32_t lp = whist[wave][dd] + rank[i];
             skey[lp] = key[i];
@@ -465,20 +544,23 @@ __global__ void __launch_bounds__(RS_THREADS, 4) k_onesweep(const uint32_t* __re
     }
     __syncthreads();
     RS_STAMP(4);
-    const int cnt = (int)((n - bbase) < (size_t)(RS_THREADS * ITEMS) ? (n - bbase) : (size_t)(RS_THREADS * ITEMS));
 #pragma unroll
     for (int i = 0; i < ITEMS; i++) {
-        const int lp = i * RS_THREADS + threadIdx.x;     // consecutive lanes -> consecutive slots of a digit run
-        if (lp < cnt) {
-            const uint32_t k = skey[lp];
+        const uint32_t lp = (uint32_t)i * RS_THREADS + threadIdx.x;     // consecutive lanes -> consecutive slots of a digit run
+        if (full || lp < cnt) {
+            const uint32_t k = skey[lp], v = sval[lp];
             const uint32_t dd = (k >> shift) & (RS_RADIX - 1);
             const uint32_t pos = gbase[dd] + ((uint32_t)lp - lstart[dd]);
             keys_out[pos] = k;
-            vals_out[pos] = sval[lp];
+            vals_out[pos] = v;
         }
     }
     RS_STAMP(5);
+    if (!STAY) return;
+  }
 #undef RS_STAMP
+#undef RS_AT
+#undef RS_COUNT
 }
 
 static unsigned long long* g_sort_dbg = nullptr;     // profiling hook: [pass][tile][8] wall_clock64 stamps (100 MHz), see c3d_test_sort_phases
@@ -506,6 +588,9 @@ int c3d_sort_pairs_u32(uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32
     int passes = (end_bit + 7) / 8;
     if (passes < 1) passes = 1;
     const int nb = c3d_cdiv((long long)n, RS_TILE), nb_hist = nb;
+    // k_onesweep's workgroups stay and draw tile after tile: one per residency slot of the chip (MI355X: 256 CUs x 4 workgroups of 39 KB LDS), spread evenly over the views
+    const bool stay = (long long)nb * V > 2 * RS_SLOTS;       // (at most two rounds: one workgroup per tile, see STAY)
+    const int nbx = !stay ? nb : (RS_SLOTS / V > 0 ? RS_SLOTS / V : 1);
     uint32_t* ghist = (uint32_t*)tmp;
     uint32_t* tickets = ghist + RS_HIST_SPLIT * RS_RADIX * RS_MAX_PASSES;
     uint32_t* err = err_out ? err_out : c3d_sort_error_word(tmp);
@@ -518,9 +603,10 @@ int c3d_sort_pairs_u32(uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32
     for (int pass = 0; pass < passes; pass++) {
         uint32_t* tw = status + (size_t)pass * sort_pass_words((size_t)nb);
         uint32_t* gw = tw + (size_t)RS_RADIX * nb;
-#define RS_SWEEP(IOTA_) hipLaunchKernelGGL((k_onesweep<IOTA_, RS_ITEMS>), dim3(nb, V), dim3(RS_THREADS), 0, s, k[cur], v[cur], k[cur ^ 1], v[cur ^ 1], ghist + pass * RS_RADIX, \
+#define RS_SWEEP(IOTA_, STAY_) hipLaunchKernelGGL((k_onesweep<IOTA_, RS_ITEMS, STAY_>), dim3(nbx, V), dim3(RS_THREADS), 0, s, k[cur], v[cur], k[cur ^ 1], v[cur ^ 1], ghist + pass * RS_RADIX, \
                                            tickets + pass, err, tw, gw, n, n_dev, 8 * pass, (g_sort_dbg && V == 1) ? g_sort_dbg + (size_t)pass * nb * 8 : nullptr, vs)
-        if (pass == 0 && iota_vals) RS_SWEEP(true); else RS_SWEEP(false);
+        if (pass == 0 && iota_vals) { if (stay) RS_SWEEP(true, true); else RS_SWEEP(true, false); }
+        else { if (stay) RS_SWEEP(false, true); else RS_SWEEP(false, false); }
 #undef RS_SWEEP
         C3D_LAUNCH_CHECK();
         cur ^= 1;

@@ -21,7 +21,7 @@ last_num_rendered = 0   # (tile, splat) pairs of the most recent forward whose c
 # c3d_gs_forward_nosync with buffers and launches sized for a capacity above the largest count seen, the count stays on the device, and the two status words
 # of the call come back through pinned memory and are examined when a later call starts -- the host runs ahead of the GPU instead of waiting for it once per view.
 # A view that needs more pairs than the capacity is rendered incompletely (pairs beyond it are dropped); that is noticed one call late: a RuntimeWarning says so
-# and the capacity regrows at once.  Headroom: 1.5 x the largest count seen when the call is differentiated (a training loop: counts drift slowly, and one incomplete
+# and the capacity regrows at once (calls still pending when the interpreter exits are examined then: flush() / atexit).  Headroom: 1.5 x the largest count seen when the call is differentiated (a training loop: counts drift slowly, and one incomplete
 # gradient step is harmless), 3 x when it is not (inference through LGM / TGS / TRELLIS-style callers: the next object may be larger, and an incomplete image is what the
 # user gets) -- empty capacity costs a few early-exiting workgroups per sort pass and bytes of a 288 GB memory.  sync_free(False) restores the wheel's behaviour (exact
 # count, one synchronisation per call) for callers that cannot accept any of that.
@@ -90,6 +90,15 @@ def flush():
             ring.examine(block=True)
 
 
+def _flush_at_exit():
+    """a process whose LAST forward call overflowed would otherwise never hear of it: examine what is pending before the interpreter goes"""
+    try:
+        if pending_calls():
+            flush()
+    except Exception as e:      # a fault reported this late can only be printed
+        warnings.warn("diff_gaussian_rasterization (MI355X): %s" % e, RuntimeWarning)
+
+
 def pending_calls():
     """sync-free forward calls whose status words have not been examined yet"""
     with _lock:
@@ -130,6 +139,10 @@ def _status_slot(dev, key, cap):
         ring.host[slot] = _SENTINEL
         ring.pending.append((slot, key, cap))
         return C.c_void_p(ring.dev_ptr + 8 * slot), C.c_void_p(ring.pin_ptr + 8 * slot)
+
+
+import atexit
+atexit.register(_flush_at_exit)
 
 
 class GaussianRasterizationSettings(NamedTuple):

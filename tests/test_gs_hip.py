@@ -74,8 +74,9 @@ def test_record_base_scan_one_wave_tiles(n):
     assert (e[~nz] == 0xFFFFFFFF).all()                       # elements without tiles get no record
 
 
-@pytest.mark.parametrize("n,bits", [(1, 32), (100, 32), (4096, 32), (4097, 8), (100000, 13), (1 << 20, 32), (3000001, 15)])
+@pytest.mark.parametrize("n,bits", [(1, 32), (100, 32), (4096, 32), (4097, 8), (100000, 13), (1 << 20, 32), (3000001, 15), (9000001, 16)])
 def test_sort_pairs_is_stable_and_correct(n, bits):
+    """(the last case is more than two rounds of tiles for the chip: the pass instance whose workgroups stay and draw tile after tile, with one view)"""
     import c3d_hip as h
     rng = np.random.default_rng(n + bits)
     hi = (1 << bits) - 1
@@ -721,6 +722,36 @@ def test_sync_free_overflow_is_reported_one_call_late_and_the_capacity_regrows()
         assert torch.equal(inp2[k].grad, inp0[k].grad), k
 
 
+def test_sync_free_overflow_of_the_last_call_of_a_process_is_reported_at_exit(tmp_path):
+    """a caller that never issues another forward (and never calls flush()) still hears of an overflow: the pending status words are examined when the interpreter exits"""
+    import subprocess
+    import sys
+    prog = tmp_path / "last_call.py"
+    prog.write_text(
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "import diff_gaussian_rasterization as dgr\n"
+        "from c3d_hip import synthetic as S\n"
+        "sc = S.make_cloud(50000, seed=18, log_scale_mean=np.log(0.015))\n"
+        "st = S.camera_settings(360, 200, 49.1, 5.0, -40.0, 2.2)\n"
+        "t = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float32)).cuda()\n"
+        "rs = dgr.GaussianRasterizationSettings(200, 360, st['tanfovx'], st['tanfovy'], t(st['bg']), 1.0, t(st['viewmatrix']).reshape(4, 4),\n"
+        "                                       t(st['projmatrix']).reshape(4, 4), st['sh_degree'], t(st['campos']), False, False)\n"
+        "def render():\n"
+        "    with torch.no_grad():\n"
+        "        return dgr.GaussianRasterizer(rs)(means3D=t(sc['means3D']), means2D=None, opacities=t(sc['opacities']), shs=t(sc['shs']), scales=t(sc['scales']),\n"
+        "                                          rotations=t(sc['rotations']))\n"
+        "render()\n"                                              # synchronous first call: learns the count
+        "key = (torch.cuda.current_device(), 50000, 200, 360)\n"
+        "dgr._cap[key] = max(2048, dgr._cap[key] // 8); dgr._SLACK = 0\n"
+        "render()\n"                                              # sync-free, capacity far too small, and nothing examines it
+        "assert dgr.pending_calls() == 1\n"
+        % os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "comfyui-3d-pack_amd"))
+    r = subprocess.run([sys.executable, "-W", "always", str(prog)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "RuntimeWarning" in r.stderr and "incomplete" in r.stderr, r.stderr[-2000:]
+
+
 def test_fused_activation_path_equals_accessor_path():
     """rasterize_gaussians_raw (exp / sigmoid / normalize / cat folded into the kernels) against the op-by-op accessor path of
     GaussianSplattingRenderer.render: same images, same gradients on the raw parameters."""
@@ -1266,6 +1297,38 @@ def test_reduce_ranks_fixed_order_sum():
         assert v.shape == ps[i].shape and v.is_contiguous() and v.data_ptr() % 16 == 0
         v.fill_(float(i + 1))
     assert float(fg.flat.sum()) == sum((i + 1) * p.numel() for i, p in enumerate(ps))
+
+
+def test_views_of_very_unequal_size_in_one_launch_equal_their_per_view_renders():
+    """the workgroups of a multi-view sort pass serve view (linear block id) % V and, once their view has no tile left, draw tickets of views that have (k_onesweep):
+    eight views whose pair counts differ by more than an order of magnitude -- close-ups next to far shots -- through ONE launch per stage, bit-identical to
+    the per-view path"""
+    from MVs_Algorithms.GaussianSplatting.main_3DGS_renderer import GaussianSplattingRenderer
+    from MVs_Algorithms.GaussianSplatting.main_3DGS import GaussianSplattingCameraController
+    from shared_utils.camera_utils import MiniCam, orbit_camera
+    raw = S.make_cloud(120000, seed=21, log_scale_mean=np.log(0.012), activated=False)
+    r = GaussianSplattingRenderer(sh_degree=3, device="cuda")
+    r.initialize({"xyz": raw["means3D"], "features": raw["shs"], "scaling_raw": raw["scales"], "rotation_raw": raw["rotations"], "opacity_raw": raw["opacities"]})
+    W, H = 400, 304
+    ctl = GaussianSplattingCameraController(r, W, H, 49.1, static_bg=[0.1, 0.1, 0.1])
+    poses = [[rad, el, az, 0.0, 0.0, 0.0] for rad, el, az in ((1.25, 0.0, 0.0), (9.0, 10.0, 40.0), (1.3, -20.0, 90.0), (7.0, 30.0, 130.0), (12.0, 0.0, 180.0), (1.4, 45.0, -140.0),
+                                                            (5.0, -35.0, -90.0), (2.5, 5.0, -30.0))]
+    import diff_gaussian_rasterization as dgr
+    counts = []
+    with torch.no_grad():
+        per_view = []
+        for p in poses:
+            per_view.append(ctl.render_at_pose(p))
+            dgr.flush()
+            counts.append(int(dgr.last_num_rendered))
+        cams = [MiniCam(orbit_camera(el, az, rad, target=np.zeros(3, dtype=np.float32)), W, H, ctl.cam.fovy, ctl.cam.fovx, ctl.cam.near, ctl.cam.far, ctl.projection_matrix, device="cuda")
+                for rad, el, az, *_ in poses]
+        out = r.render_views(cams, ctl.static_bg, lanes=1, group=8)
+    assert max(counts) > 2.5 * min(counts) and min(counts) > 0, counts
+    for i, pv in enumerate(per_view):
+        for k in ("image", "depth", "alpha"):
+            assert torch.equal(out[k][i], pv[k]), (k, i, counts)
+        assert torch.equal(out["radii"][i], pv["radii"])
 
 
 @pytest.mark.parametrize("lanes,group,res", [(1, 8, (200, 136)), (2, 2, (200, 136)), (3, 1, (200, 136)), (2, 3, (251, 143))])
