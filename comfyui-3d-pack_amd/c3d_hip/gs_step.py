@@ -154,7 +154,7 @@ class FusedViewStep:
             if st[0] == 0:
                 seen = st[1] & 0xFFFFFFFF
                 self._last = (self.workspace, self.capacity)     # what read_view() looks into
-                if not self._fitted and self.capacity > 2 * max(seen, 1 << 16):
+                if not self._fitted and self.capacity > 1.6 * max(seen, 1 << 16):      # (every launch of the binning chain is sized for the capacity: more than 1.6 x the need is worth one reallocation)
                     # first successful step: every launch is sized for the capacity, so bring it down to what the scene needs (+30 %)
                     self.capacity = int(seen * 1.3) + 4096
                     self._alloc()
@@ -236,7 +236,7 @@ class FusedViewStep:
             self._raise_on_fault(st)
             seen = st[1] & 0xFFFFFFFF
             if st[0] == 0:
-                if not self._fitted and self.capacity > 2 * max(seen, 1 << 16):
+                if not self._fitted and self.capacity > 1.6 * max(seen, 1 << 16):      # (every launch of the binning chain is sized for the capacity: more than 1.6 x the need is worth one reallocation)
                     self._fitted = True
                     self.capacity = int(seen * 1.3) + 4096      # first success: every launch is sized for the capacity -> fit it (+30 %) and redo
                     self._alloc()
@@ -331,7 +331,7 @@ class FusedViewRender:
                 raise RuntimeError("c3d: a bounded inter-workgroup wait of the binning stage timed out (status %r): device fault" % (st,))
             seen = st[1] & 0xFFFFFFFF
             if st[0] == 0:
-                if not self._fitted and self.capacity > 2 * max(seen, 1 << 16):
+                if not self._fitted and self.capacity > 1.6 * max(seen, 1 << 16):      # (every launch of the binning chain is sized for the capacity: more than 1.6 x the need is worth one reallocation)
                     self.capacity = int(seen * 1.3) + 4096
                     self._alloc()
                 self._fitted = True
