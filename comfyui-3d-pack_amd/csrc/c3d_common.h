@@ -74,9 +74,15 @@ size_t c3d_sort_tmp_bytes(size_t n);
 size_t c3d_sort_state_bytes(size_t n, int end_bit);
 uint32_t* c3d_sort_error_word(void* tmp);
 int c3d_sort_set_debug(unsigned long long* stamps);   // profiling hook (nullptr = off): [pass][tile][8] wall_clock64 stamps (single-view sorts)
+// hist_done: the digit histograms of the keys are already in `tmp` -- the kernel that PRODUCED the keys counted them (k_emit for the tile sort: the keys are in its registers when it
+// stores them) -- so the sort does not read the keys a first time.  Layout at the head of tmp (zeroed with the rest of the state, before the producer runs): uint32
+// [C3D_SORT_HIST_SPLIT copies][C3D_SORT_MAX_PASSES][256]; a producer workgroup adds the count of digit d of pass p (key bits [8p, 8p + 8)) to ONE copy (any; spread them), the sort
+// adds the copies up.
+#define C3D_SORT_HIST_SPLIT 16
+#define C3D_SORT_MAX_PASSES 4
 int c3d_sort_pairs_u32(uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32_t* vals1, bool iota_vals,
                        size_t n, int end_bit, void* tmp, int* result_buf, hipStream_t s, const uint32_t* n_dev = nullptr, bool zero_state = true, uint32_t* err = nullptr,
-                       int V = 1, size_t vs = 0);
+                       int V = 1, size_t vs = 0, bool hist_done = false);
 
 // ---- device helpers ----
 #ifdef __HIPCC__

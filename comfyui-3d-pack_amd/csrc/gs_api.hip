@@ -97,9 +97,9 @@ static int binning_back(const GsParams& p, GsGeom& g, GsBinning& b, long long D,
     if (D <= 0) return 0;
     uint32_t* err = status ? status : (uint32_t*)g.meta + 2;
     { C3dProfScope ps(C3D_P_EMIT, s);
-      if ((rc = gs_launch_emit(p, g, sort_result_index(32), b, s, cap, V, vs))) return rc; }
+      if ((rc = gs_launch_emit(p, g, sort_result_index(32), b, s, cap, V, vs, (tile_sort_bits(tiles) + 7) / 8))) return rc; }      // (also counts the digits of the keys it writes)
     { C3dProfScope ps(C3D_P_TILE_SORT, s);
-      if ((rc = c3d_sort_pairs_u32(b.tkey[0], b.tkey[1], b.tval[0], b.tval[1], false, (size_t)D, tile_sort_bits(tiles), b.tmp, &res, s, d_dev, false, err, V, vs))) return rc; }
+      if ((rc = c3d_sort_pairs_u32(b.tkey[0], b.tkey[1], b.tval[0], b.tval[1], false, (size_t)D, tile_sort_bits(tiles), b.tmp, &res, s, d_dev, false, err, V, vs, true))) return rc; }
     if (res != sort_result_index(tile_sort_bits(tiles))) { c3d_set_error("internal: tile sort buffer parity"); return -2; }
     { C3dProfScope ps(C3D_P_RANGES, s);
       if ((rc = gs_launch_ranges(b, res, D, s, d_dev, V, vs))) return rc; }

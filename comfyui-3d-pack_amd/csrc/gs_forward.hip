@@ -224,35 +224,61 @@ int gs_launch_preprocess_raw(const GsParams& p, const float* means3D, const floa
 // writes 64 consecutive words and a Gaussian with 500 tiles costs its workgroup two extra iterations instead of parking one lane of a wave for 500.
 // ------------------------------------------------------------------------------------------
 #define EMIT_RANKS 256
+#define EMIT_SLOTS 2048      // workgroups resident at once: 256 CUs x 8 (8 KB of LDS, 256 lanes)
+// Round 5: the kernel also COUNTS what it writes -- the digit histograms of the tile sort (c3d_common.h: hist_done), taken while the key is in a register, instead of a
+// histogram kernel that reads the 32 M keys of an 8-view step back.  For that the workgroups STAY (one per residency slot, chunk after chunk at a stride): the counters live in
+// LDS for the workgroup's whole life and go out once -- 2048 x <= 512 global atomics per launch; one workgroup per chunk (31 K of them) would flush 9 M.
+// Home view of a workgroup = (linear block id) % V as in the sort passes.  Pairs beyond the capacity are neither written nor counted.
 __global__ void __launch_bounds__(EMIT_RANKS) k_emit(int N, int gx, const uint32_t* __restrict__ order, const uint32_t* __restrict__ offsets,
-                                                      const uint2* __restrict__ rsort, uint32_t* __restrict__ tkey, uint32_t* __restrict__ tval, uint32_t cap, size_t vs) {
+                                                      const uint2* __restrict__ rsort, uint32_t* __restrict__ tkey, uint32_t* __restrict__ tval, uint32_t cap,
+                                                      uint32_t* __restrict__ ghist, int passes, size_t vs) {
     __shared__ uint32_t s_end[EMIT_RANKS];      // inclusive scan: end of rank r's pairs
     __shared__ uint32_t s_gid[EMIT_RANKS];
     __shared__ uint2 s_rect[EMIT_RANKS];
-    order = c3d_view_ptr(order, vs); offsets = c3d_view_ptr(offsets, vs); rsort = c3d_view_ptr(rsort, vs); tkey = c3d_view_ptr(tkey, vs); tval = c3d_view_ptr(tval, vs);
-    const int r0 = blockIdx.x * EMIT_RANKS, t = threadIdx.x;
-    const int r = min(r0 + t, N - 1);           // ranks past the end repeat the last one's END: empty stretches
-    s_end[t] = offsets[r];
-    if (r0 + t < N) { s_gid[t] = order[r]; s_rect[t] = rsort[r]; }
-    const uint32_t B0 = r0 ? offsets[r0 - 1] : 0u;
-    __syncthreads();
-    const uint32_t B1 = min(s_end[EMIT_RANKS - 1], cap);
-    for (uint32_t o = B0 + (uint32_t)t; o < B1; o += EMIT_RANKS) {
-        int j = 0;                               // first rank whose end lies beyond o
+    __shared__ uint32_t s_hist[C3D_SORT_MAX_PASSES][256];
+    const uint32_t lin = blockIdx.x + gridDim.x * blockIdx.y, view = lin % gridDim.y, wg = lin / gridDim.y;      // wg: 0 .. gridDim.x - 1 within the view
+    const size_t voff = (size_t)view * vs;
+    order = (const uint32_t*)((const char*)order + voff); offsets = (const uint32_t*)((const char*)offsets + voff); rsort = (const uint2*)((const char*)rsort + voff);
+    tkey = (uint32_t*)((char*)tkey + voff); tval = (uint32_t*)((char*)tval + voff); ghist = (uint32_t*)((char*)ghist + voff);
+    const int t = threadIdx.x;
+    for (int p = 0; p < passes; p++) s_hist[p][t] = 0;
+    for (int r0 = (int)wg * EMIT_RANKS; r0 < N; r0 += (int)gridDim.x * EMIT_RANKS) {
+        __syncthreads();                         // the previous chunk's walk has read s_end / s_gid / s_rect (first chunk: the counters are zero)
+        const int r = min(r0 + t, N - 1);       // ranks past the end repeat the last one's END: empty stretches
+        s_end[t] = offsets[r];
+        if (r0 + t < N) { s_gid[t] = order[r]; s_rect[t] = rsort[r]; }
+        const uint32_t B0 = r0 ? offsets[r0 - 1] : 0u;
+        __syncthreads();
+        const uint32_t B1 = min(s_end[EMIT_RANKS - 1], cap);
+        for (uint32_t o = B0 + (uint32_t)t; o < B1; o += EMIT_RANKS) {
+            int j = 0;                           // first rank whose end lies beyond o
 #pragma unroll
-        for (int step = EMIT_RANKS / 2; step >= 1; step >>= 1) j += (s_end[j + step - 1] <= o) ? step : 0;
-        const uint32_t start = j ? s_end[j - 1] : B0;
-        const uint2 rc = s_rect[j];
-        const uint32_t x0 = rc.x & 0xFFFFu, y0 = rc.x >> 16, w = (rc.y & 0xFFFFu) - x0, i = o - start;
-        uint32_t q = (uint32_t)__fdividef((float)i, (float)w);      // i < 2^24 (a rect holds at most gx * gy tiles): exact to +-1
-        if (q * w > i) q--; else if ((q + 1u) * w <= i) q++;
-        tkey[o] = (y0 + q) * (uint32_t)gx + x0 + (i - q * w);
-        tval[o] = s_gid[j];
+            for (int step = EMIT_RANKS / 2; step >= 1; step >>= 1) j += (s_end[j + step - 1] <= o) ? step : 0;
+            const uint32_t start = j ? s_end[j - 1] : B0;
+            const uint2 rc = s_rect[j];
+            const uint32_t x0 = rc.x & 0xFFFFu, y0 = rc.x >> 16, w = (rc.y & 0xFFFFu) - x0, i = o - start;
+            uint32_t q = (uint32_t)__fdividef((float)i, (float)w);      // i < 2^24 (a rect holds at most gx * gy tiles): exact to +-1
+            if (q * w > i) q--; else if ((q + 1u) * w <= i) q++;
+            const uint32_t key = (y0 + q) * (uint32_t)gx + x0 + (i - q * w);
+            tkey[o] = key;
+            tval[o] = s_gid[j];
+            for (int p = 0; p < passes; p++) atomicAdd(&s_hist[p][(key >> (8 * p)) & 255u], 1u);
+        }
+    }
+    __syncthreads();
+    uint32_t* mine = ghist + (size_t)(wg % C3D_SORT_HIST_SPLIT) * C3D_SORT_MAX_PASSES * 256;
+    for (int p = 0; p < passes; p++) {
+        const uint32_t c = s_hist[p][t];
+        if (c) atomicAdd(&mine[p * 256 + t], c);
     }
 }
-int gs_launch_emit(const GsParams& p, const GsGeom& g, int res, GsBinning& b, hipStream_t s, uint32_t cap, int V, size_t vs) {
+// ghist: the head of the tile sort's state block (zero on entry: the binning stage clears it before this launch); passes = sort passes of the tile id
+int gs_launch_emit(const GsParams& p, const GsGeom& g, int res, GsBinning& b, hipStream_t s, uint32_t cap, int V, size_t vs, int passes) {
     if (p.N == 0 || V <= 0) return 0;
-    hipLaunchKernelGGL(k_emit, dim3(c3d_cdiv(p.N, EMIT_RANKS), V), dim3(EMIT_RANKS), 0, s, p.N, p.gx, g.order[res], g.offsets, g.rsort, b.tkey[0], b.tval[0], cap, vs);
+    if (passes < 1 || passes > C3D_SORT_MAX_PASSES) { c3d_set_error("internal: %d sort passes for the tile id", passes); return -2; }
+    const int chunks = c3d_cdiv(p.N, EMIT_RANKS);
+    const int nbx = (long long)chunks * V <= EMIT_SLOTS ? chunks : (EMIT_SLOTS / V > 0 ? EMIT_SLOTS / V : 1);
+    hipLaunchKernelGGL(k_emit, dim3(nbx, V), dim3(EMIT_RANKS), 0, s, p.N, p.gx, g.order[res], g.offsets, g.rsort, b.tkey[0], b.tval[0], cap, (uint32_t*)b.tmp, passes, vs);
     C3D_LAUNCH_CHECK();
     return 0;
 }

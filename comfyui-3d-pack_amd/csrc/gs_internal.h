@@ -184,7 +184,7 @@ int gs_launch_preprocess_bwd_raw(const GsParams& p, const GsGeom& g, const int* 
                                  const float* scaling_raw, const float* rotation_raw, const float* pairgrad, const uint8_t* pvalid, float* dL_dmean2D,
                                  float* dL_dopacity_raw, float* dL_dmeans3D, float* dL_df_dc, float* dL_df_rest, float* dL_dscaling_raw,
                                  float* dL_drotation_raw, bool accumulate, hipStream_t s, uint32_t cap = 0xFFFFFFFFu);
-int gs_launch_emit(const GsParams& p, const GsGeom& g, int res, GsBinning& b, hipStream_t s, uint32_t cap = 0xFFFFFFFFu, int V = 1, size_t vs = 0);
+int gs_launch_emit(const GsParams& p, const GsGeom& g, int res, GsBinning& b, hipStream_t s, uint32_t cap, int V, size_t vs, int passes);
 int gs_launch_ranges(const GsBinning& b, int res, long long D, hipStream_t s, const uint32_t* d_dev = nullptr, int V = 1, size_t vs = 0);
 int gs_launch_composite_fwd(const GsParams& p, const GsGeom& g, const GsBinning& b, int res, GsImage& im, const GsFwdViews& vp, int V, size_t vs,
                             bool record_activity, hipStream_t s, uint32_t* err = nullptr);

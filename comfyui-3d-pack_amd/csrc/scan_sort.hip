@@ -275,14 +275,14 @@ uint32_t* c3d_scan_error_word(void* tmp) { return (uint32_t*)tmp + 1; }
 #endif
 #define RS_TILE (RS_THREADS * RS_ITEMS)
 #define RS_RADIX 256
-#define RS_MAX_PASSES 4
+#define RS_MAX_PASSES C3D_SORT_MAX_PASSES
 #define RS_FLAG_AGG (1u << 30)
 #define RS_FLAG_INCL (2u << 30)
 #define RS_VALUE_MASK ((1u << 30) - 1u)
 #define RS_GROUP 16
 #define RS_LOOKBACK 32
 #define RS_SLOTS 1024             // workgroups of k_onesweep resident at once: 256 CUs x 4
-#define RS_HIST_SPLIT 16      // copies of the global histogram (workgroup b adds to copy b % 16): 245 - 1000 workgroups adding to ONE set of 256 counters serialise at the
+#define RS_HIST_SPLIT C3D_SORT_HIST_SPLIT      // copies of the global histogram (workgroup b adds to copy b % 16): 245 - 1000 workgroups adding to ONE set of 256 counters serialise at the
                               // memory-side atomic unit (measured: 23 us for 1 M keys, profiles/r02c); consumers add the 16 copies up
 static inline size_t sort_pass_words(size_t nb) { return RS_RADIX * (nb + nb / RS_GROUP + 1); }
 
@@ -579,7 +579,7 @@ size_t c3d_sort_state_bytes(size_t n, int end_bit) {
 }
 
 int c3d_sort_pairs_u32(uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32_t* vals1, bool iota_vals,
-                       size_t n, int end_bit, void* tmp, int* result_buf, hipStream_t s, const uint32_t* n_dev, bool zero_state, uint32_t* err_out, int V, size_t vs) {
+                       size_t n, int end_bit, void* tmp, int* result_buf, hipStream_t s, const uint32_t* n_dev, bool zero_state, uint32_t* err_out, int V, size_t vs, bool hist_done) {
     *result_buf = 0;
     if (n == 0 || V <= 0) return 0;
     if (zero_state && V != 1) { c3d_set_error("c3d_sort_pairs_u32: a multi-view launch clears its state through c3d_zero_views"); return -1; }
@@ -598,7 +598,8 @@ int c3d_sort_pairs_u32(uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32
     if (zero_state) C3D_CHECK(hipMemsetAsync(tmp, 0, c3d_sort_state_bytes(n, end_bit), s));
     uint32_t* k[2] = {keys0, keys1};
     uint32_t* v[2] = {vals0, vals1};
-    hipLaunchKernelGGL(k_radix_hist_all, dim3(nb_hist, V), dim3(RS_THREADS), 0, s, keys0, ghist, n, n_dev, passes, vs);
+    if (hist_done && zero_state) { c3d_set_error("c3d_sort_pairs_u32: hist_done with zero_state would clear the producer's histograms"); return -1; }
+    if (!hist_done) hipLaunchKernelGGL(k_radix_hist_all, dim3(nb_hist, V), dim3(RS_THREADS), 0, s, keys0, ghist, n, n_dev, passes, vs);
     int cur = 0;
     for (int pass = 0; pass < passes; pass++) {
         uint32_t* tw = status + (size_t)pass * sort_pass_words((size_t)nb);
