@@ -70,6 +70,9 @@ def parse():
     ap.add_argument("--group", type=int, default=16, help="--mode fwd: views per launch of every stage (<= 16)")
     ap.add_argument("--sync-free", choices=["on", "off"], default="on", help="--render-path boundary | fused | accessor: the drop-in rasterizer call without its host round trip "
                                                                              "(diff_gaussian_rasterization.sync_free; off = the wheel's behaviour: the pair count read back once per view)")
+    ap.add_argument("--forward-only", choices=["on", "off"], default="on", help="--render-path boundary | fused | accessor, calls that are not differentiated (--mode fwd): render with "
+                                                                                "C3D_GS_FLAG_FORWARD_ONLY (no pair-activity record, no record-base scan, no final_T / n_contrib stores); off = the A/B partner")
+    ap.add_argument("--inference-mode", choices=["on", "off"], default="off", help="--mode fwd on the drop-in API: run the steps under torch.inference_mode() (an inference caller)")
     ap.add_argument("--render-path", choices=["step", "fused", "accessor", "boundary"], default="step",
                     help="step: c3d_gs_train_views_raw, all views of the step forward+loss+backward in one sync-free library call (product default for training); fused: GaussianSplattingRenderer.render with activations folded into the kernels (product default); accessor: the same "
                          "API through the reference's op-by-op accessors; boundary: bare diff_gaussian_rasterization call on pre-activated leaves")
@@ -467,6 +470,7 @@ def main():
     if a.lanes <= 0:
         a.lanes = 1
     dgr.sync_free(a.sync_free == "on")
+    dgr.forward_only(a.forward_only == "on")
     N, W, H, deg = a.gaussians, a.width, a.height, a.sh_degree
     K, P = (deg + 1) ** 2, a.width * a.height
     use_renderer = a.render_path != "boundary"
@@ -628,6 +632,15 @@ def main():
         if a.mode != "fwd" and fused_step is None:
             for q in plist:
                 q.grad = None
+
+    if a.inference_mode == "on":
+        if a.mode != "fwd":
+            raise SystemExit("--inference-mode on: forward only (--mode fwd)")
+        _step_body = step
+
+        def step(collect=False):             # an inference caller of the drop-in API: nothing is differentiated
+            with torch.inference_mode():
+                return _step_body(collect)
 
     def sync():
         if fused_step is not None:
@@ -889,6 +902,9 @@ def main():
                                                                 if loss_kind != "l1alpha" and a.render_path == "step" else "0.8 L1 + 3 MSE(alpha)")), "view_lanes": (a.lanes if a.render_path == "step" else 1),
                        "host_enqueue_ms_per_step": (round(fused_step.last_host_ms, 3) if fused_step is not None else round(t_enqueue / a.steps * 1e3, 3)),
                        "sync_free_drop_in": (a.sync_free == "on") if a.render_path != "step" else None,
+                       "forward_only_flag": (a.forward_only == "on") if (a.render_path != "step" and a.mode == "fwd") else None,
+                       "inference_mode": (a.inference_mode == "on") if a.render_path != "step" else None,
+                       "drop_in_calls_redone_on_device": int(dgr.redone_calls) if a.render_path != "step" else None,
                        "defer_status": (fused_step.defer_status if fused_step is not None else None),
                        "gpu_span_ms_last_step": (round(getattr(fused_step, "last_gpu_ms", 0.0), 3) if fused_step is not None else None),
                        "n_visible": n_vis, "tile_splat_pairs": D},

@@ -66,11 +66,9 @@ class GaussianSplattingCameraController(BaseCameraController):
         orbit goes through ONE batched library call; otherwise the reference's per-view loop."""
         g = self.renderer.gaussians
         if kwargs or torch.is_grad_enabled() or not g._xyz.is_cuda or len(all_cam_poses) == 0 or not self.renderer.raw_storage_ok():
-            out = super().render_all_pose(all_cam_poses, **kwargs)       # (a storage the raw-parameter kernels do not take -- SH degree > 3, odd f_rest shapes -- goes view by view through render())
-            if not torch.is_grad_enabled():
-                import diff_gaussian_rasterization as dgr
-                getattr(dgr, "flush", lambda: None)()      # the images leave for the caller: a pair overflow of the sync-free per-view path (incl. the LAST view's) is reported here, not by some later call
-            return out
+            # (a storage the raw-parameter kernels do not take -- SH degree > 3, odd f_rest shapes -- goes view by view through render(); without autograd every such call
+            #  takes the rasterizer's synchronous, exact path: the images that leave here are complete)
+            return super().render_all_pose(all_cam_poses, **kwargs)
         cams, bgs = [], []
         for radius, elevation, azimuth, cx, cy, cz in all_cam_poses:
             pose = orbit_camera(elevation, azimuth, radius, target=np.array([cx, cy, cz], dtype=np.float32))

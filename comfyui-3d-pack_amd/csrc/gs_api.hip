@@ -70,7 +70,8 @@ static int check_inputs(int N, int M, int deg, const float* means3D, const float
 // (`cleared`, V views).  V / vs: the chain of V views in one launch per stage (g = view 0's state, view v's lies v * vs bytes behind).
 // cap / status: pair capacity and status words of the sync-free paths (the pair count then stays on the device in g.meta[0]).
 // (the record-base scan of the backward pass -- rbase, einfo -- is not on this chain any more: it rides in the recording forward compositing launch, scan_wave.h)
-static int binning_front(GsGeom& g, int N, uint32_t cap, uint32_t* status, hipStream_t s, int V = 1, size_t vs = 0, bool cleared = false) {
+// cap2 (0 = none): capacity of the device-gated second attempt of c3d_gs_forward_nosync (its count goes to g.meta[1], status bit C3D_ST_REDO says whether it runs)
+static int binning_front(GsGeom& g, int N, uint32_t cap, uint32_t* status, hipStream_t s, int V = 1, size_t vs = 0, bool cleared = false, uint32_t cap2 = 0) {
     int rc, res = 0;
     if (!cleared) {
         if (V != 1) { c3d_set_error("internal: a multi-view binning chain needs its state cleared by the caller"); return -2; }
@@ -81,28 +82,37 @@ static int binning_front(GsGeom& g, int N, uint32_t cap, uint32_t* status, hipSt
       if ((rc = c3d_sort_pairs_u32(g.key[0], g.key[1], g.order[0], g.order[1], true, (size_t)N, 32, g.tmp_sort, &res, s, nullptr, false, err, V, vs))) return rc; }
     if (res != sort_result_index(32)) { c3d_set_error("internal: depth sort buffer parity"); return -2; }
     { C3dProfScope ps(C3D_P_SCAN, s);
-      if ((rc = c3d_scan_rect_gather(g.rect, g.order[res], g.offsets, g.rsort, (size_t)N, g.tmp_scan_b, s, false, (uint32_t*)g.meta, status, cap, err, V, vs))) return rc; }
+      if ((rc = c3d_scan_rect_gather(g.rect, g.order[res], g.offsets, g.rsort, (size_t)N, g.tmp_scan_b, s, false, (uint32_t*)g.meta, status, cap, err, V, vs, cap2))) return rc; }
     return 0;
 }
 // emit + tile sort + per-tile ranges; D = pair count on the host, or the capacity when d_dev (device count, per view) is given
+// D also sizes the LAYOUT of the tile sort's state inside b.tmp, which may have been carved for more pairs than D (the two attempts of c3d_gs_forward_nosync share one buffer).
+// gate: this is the device-gated second attempt -- every launch leaves at once unless C3D_ST_REDO is set in *gate; the ranges are written over the first attempt's (no clear:
+// see gs_launch_ranges), the sort state is cleared by a gated launch of its own.
 static int binning_back(const GsParams& p, GsGeom& g, GsBinning& b, long long D, uint32_t cap, const uint32_t* d_dev, uint32_t* status,
-                        hipStream_t s, int* res_out, int V = 1, size_t vs = 0, bool cleared = false) {
+                        hipStream_t s, int* res_out, int V = 1, size_t vs = 0, bool cleared = false, const uint32_t* gate = nullptr) {
     const int tiles = p.gx * p.gy;
     int rc, res = 0;
-    if (!cleared) {
+    if (gate) {
+        if (V != 1 || D <= 0) { c3d_set_error("internal: gated binning chain"); return -2; }
+        C3dProfScope ps(C3D_P_OTHER, s);
+        if ((rc = c3d_zero_gated(b.tmp, c3d_align(c3d_sort_state_bytes((size_t)D, tile_sort_bits(tiles)), 16), gate, s))) return rc;
+    } else if (!cleared) {
         if (V != 1) { c3d_set_error("internal: a multi-view binning chain needs its state cleared by the caller"); return -2; }
-        C3D_CHECK(hipMemsetAsync(b.ranges, 0, b.zero_bytes, s));
+        // ranges | meta | sort state of a D-pair sort (<= zero_bytes, which counts the state of the pair count the buffer was carved for)
+        const size_t zb = (size_t)((char*)b.tmp - (char*)b.ranges) + c3d_sort_state_bytes((size_t)(D > 0 ? D : 1), tile_sort_bits(tiles));
+        C3D_CHECK(hipMemsetAsync(b.ranges, 0, zb < b.zero_bytes ? zb : b.zero_bytes, s));
     }
     *res_out = 0;
     if (D <= 0) return 0;
     uint32_t* err = status ? status : (uint32_t*)g.meta + 2;
     { C3dProfScope ps(C3D_P_EMIT, s);
-      if ((rc = gs_launch_emit(p, g, sort_result_index(32), b, s, cap, V, vs, (tile_sort_bits(tiles) + 7) / 8))) return rc; }      // (also counts the digits of the keys it writes)
+      if ((rc = gs_launch_emit(p, g, sort_result_index(32), b, s, cap, V, vs, (tile_sort_bits(tiles) + 7) / 8, gate))) return rc; }      // (also counts the digits of the keys it writes)
     { C3dProfScope ps(C3D_P_TILE_SORT, s);
-      if ((rc = c3d_sort_pairs_u32(b.tkey[0], b.tkey[1], b.tval[0], b.tval[1], false, (size_t)D, tile_sort_bits(tiles), b.tmp, &res, s, d_dev, false, err, V, vs, true))) return rc; }
+      if ((rc = c3d_sort_pairs_u32(b.tkey[0], b.tkey[1], b.tval[0], b.tval[1], false, (size_t)D, tile_sort_bits(tiles), b.tmp, &res, s, d_dev, false, err, V, vs, true, gate))) return rc; }
     if (res != sort_result_index(tile_sort_bits(tiles))) { c3d_set_error("internal: tile sort buffer parity"); return -2; }
     { C3dProfScope ps(C3D_P_RANGES, s);
-      if ((rc = gs_launch_ranges(b, res, D, s, d_dev, V, vs))) return rc; }
+      if ((rc = gs_launch_ranges(b, res, D, s, d_dev, V, vs, gate))) return rc; }
     *res_out = res;
     return 0;
 }
@@ -122,7 +132,7 @@ static int project_tail(GsGeom& g, int N, int64_t* num_rendered, hipStream_t s) 
 extern "C" {
 
 const char* c3d_last_error(void) { return g_err; }
-int c3d_version(void) { return 500; }
+int c3d_version(void) { return 600; }
 
 size_t c3d_gs_geom_bytes(int32_t N) { GsGeom g; gs_carve_geom(nullptr, N, g); return g.bytes; }
 size_t c3d_gs_binning_bytes(int64_t D, int32_t H, int32_t W) {
@@ -191,70 +201,87 @@ int c3d_gs_forward_render(const c3d_gs_settings* st, int32_t N, int32_t M, const
     GsImage im;
     gs_carve_image((char*)image_buffer, p.W, p.H, im);
     int rc, res = 0;
-    if (num_rendered > 0 && (!geom_buffer || !radii)) { c3d_set_error("c3d_gs_forward_render: NULL geometry"); return -1; }
+    const bool record = !(st->flags & C3D_GS_FLAG_FORWARD_ONLY);      // a backward call may follow: record the blended (quadrant, splat) pairs, run the record-base scan, keep final_T / n_contrib
+    if ((num_rendered > 0 || (record && N > 0)) && (!geom_buffer || !radii)) { c3d_set_error("c3d_gs_forward_render: NULL geometry"); return -1; }      // (the record-base scan walks the geometry of all N Gaussians)
     if ((rc = binning_back(p, g, b, num_rendered, 0xFFFFFFFFu, nullptr, nullptr, s, &res))) return rc;
     C3dProfScope ps(C3D_P_COMPOSITE_FWD, s);
     GsFwdViews vp{};
     vp.bg[0] = p.bg; vp.color[0] = out_color; vp.depth[0] = out_depth; vp.alpha[0] = out_alpha;
-    return gs_launch_composite_fwd(p, g, b, res, im, vp, 1, 0, true, s);   // a backward call may follow: record the blended (quadrant, splat) pairs
+    return gs_launch_composite_fwd(p, g, b, res, im, vp, 1, 0, record, s);
 }
 
-// A2-A6 of ONE view without the host: launches sized for `cap` pairs, the pair count read from g.meta[0] on the device (what the multi-view paths do per group)
-static int forward_tail_nosync(const GsParams& p, GsGeom& g, int N, int64_t pair_capacity, void* binning_buffer, void* image_buffer, float* out_color, float* out_depth,
-                               float* out_alpha, uint32_t* status, uint32_t* status_host, hipStream_t s) {
+// A2-A6 of ONE view without the host: launches sized for a capacity, the pair count read from g.meta on the device (what the multi-view paths do per group).
+// Two attempts in one call (first_capacity < pair_capacity): the chain runs sized for first_capacity; the emit-offset scan knows the real count, and when that exceeds
+// first_capacity (status bit C3D_ST_REDO) emit -> tile sort -> ranges -> compositing run a SECOND time, sized for pair_capacity, over the same buffers -- five launches (and one
+// clear of the sort state) that are enqueued with every call and leave at once, workgroup by workgroup, when the bit is clear.  What does not depend on the capacity is not
+// repeated: projection, depth sort, emit offsets, the record-base scan.  Only a view that needs more than pair_capacity is lost: C3D_ST_OVERFLOW, and NaN planes.
+static int forward_tail_nosync(const c3d_gs_settings* st, const GsParams& p, GsGeom& g, int N, int64_t pair_capacity, int64_t first_capacity, void* binning_buffer, void* image_buffer,
+                               float* out_color, float* out_depth, float* out_alpha, uint32_t* status, uint32_t* status_host, hipStream_t s) {
     const int tiles = p.gx * p.gy;
     const uint32_t cap = (uint32_t)pair_capacity;
+    const bool two = first_capacity > 0 && first_capacity < pair_capacity;
+    const uint32_t cap1 = two ? (uint32_t)first_capacity : cap;
+    const bool record = !(st->flags & C3D_GS_FLAG_FORWARD_ONLY);
     GsBinning b;
     gs_carve_binning((char*)binning_buffer, pair_capacity, tiles, b);
     GsImage im;
     gs_carve_image((char*)image_buffer, p.W, p.H, im);
     int rc, res = 0;
     C3D_CHECK(hipMemsetAsync(status, 0, 2 * sizeof(uint32_t), s));
-    if ((rc = binning_front(g, N, cap, status, s))) return rc;
-    if ((rc = binning_back(p, g, b, pair_capacity, cap, (const uint32_t*)g.meta, status, s, &res))) return rc;
+    if ((rc = binning_front(g, N, cap1, status, s, 1, 0, false, two ? cap : 0u))) return rc;
+    if ((rc = binning_back(p, g, b, (long long)cap1, cap1, (const uint32_t*)g.meta, status, s, &res))) return rc;
+    GsFwdViews vp{};
+    vp.bg[0] = p.bg; vp.color[0] = out_color; vp.depth[0] = out_depth; vp.alpha[0] = out_alpha;
     { C3dProfScope ps(C3D_P_COMPOSITE_FWD, s);
-      GsFwdViews vp{};
-      vp.bg[0] = p.bg; vp.color[0] = out_color; vp.depth[0] = out_depth; vp.alpha[0] = out_alpha;
-      if ((rc = gs_launch_composite_fwd(p, g, b, res, im, vp, 1, 0, true, s, status))) return rc; }
-    // the status words are final once the tile sort has run; the copy rides behind the compositing launch in stream order and is nobody's critical path
+      if ((rc = gs_launch_composite_fwd(p, g, b, res, im, vp, 1, 0, record, s, status, status, 0u))) return rc; }
+    if (two) {
+        int res2 = 0;
+        if ((rc = binning_back(p, g, b, pair_capacity, cap, (const uint32_t*)g.meta + 1, status, s, &res2, 1, 0, false, status))) return rc;
+        if (res2 != res) { c3d_set_error("internal: the two attempts finish in different buffers"); return -2; }
+        C3dProfScope ps(C3D_P_COMPOSITE_FWD, s);
+        if ((rc = gs_launch_composite_fwd(p, g, b, res, im, vp, 1, 0, record, s, status, status, C3D_ST_REDO, false))) return rc;
+    }
+    // the status words are final once the emit-offset scan has run; the copy rides behind the last launch in stream order and is nobody's critical path
     if (status_host) C3D_CHECK(hipMemcpyAsync(status_host, status, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     return 0;
 }
-static int check_nosync_args(const char* who, int64_t pair_capacity, const void* radii, const void* geom_buffer, const void* binning_buffer, const void* image_buffer,
+static int check_nosync_args(const char* who, int64_t pair_capacity, int64_t first_capacity, const void* radii, const void* geom_buffer, const void* binning_buffer, const void* image_buffer,
                              const float* out_color, const float* out_depth, const float* out_alpha, const uint32_t* status) {
     if (pair_capacity <= 0 || pair_capacity > (int64_t)0x3FFFFFF0ll) { c3d_set_error("%s: pair_capacity out of range (1 .. 2^30 - 16)", who); return -1; }
+    if (first_capacity < 0) { c3d_set_error("%s: first_capacity is negative (0 or >= pair_capacity = one attempt)", who); return -1; }
     if (!radii || !geom_buffer || !binning_buffer || !image_buffer || !out_color || !out_depth || !out_alpha || !status) { c3d_set_error("%s: NULL buffer", who); return -1; }
     return 0;
 }
 
 int c3d_gs_forward_nosync(const c3d_gs_settings* st, int32_t N, int32_t M, const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
                           const float* scales, const float* rotations, const float* cov3D_precomp, int32_t* radii, void* geom_buffer, int64_t pair_capacity,
-                          void* binning_buffer, void* image_buffer, float* out_color, float* out_depth, float* out_alpha, uint32_t* status, uint32_t* status_host,
-                          c3d_stream_t stream) {
+                          int64_t first_capacity, void* binning_buffer, void* image_buffer, float* out_color, float* out_depth, float* out_alpha, uint32_t* status,
+                          uint32_t* status_host, c3d_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     GsParams p;
     if (make_params(st, N, M, p)) return -1;
     if (check_inputs(N, M, p.deg, means3D, shs, colors_precomp, scales, rotations, cov3D_precomp)) return -1;
     if (N == 0 || p.gx * p.gy == 0) { c3d_set_error("c3d_gs_forward_nosync: empty cloud / image (take c3d_gs_forward_project + c3d_gs_forward_render)"); return -1; }
-    if (check_nosync_args("c3d_gs_forward_nosync", pair_capacity, radii, geom_buffer, binning_buffer, image_buffer, out_color, out_depth, out_alpha, status)) return -1;
+    if (check_nosync_args("c3d_gs_forward_nosync", pair_capacity, first_capacity, radii, geom_buffer, binning_buffer, image_buffer, out_color, out_depth, out_alpha, status)) return -1;
     if (!opacities) { c3d_set_error("c3d_gs_forward_nosync: opacities is NULL"); return -1; }
     GsGeom g;
     gs_carve_geom((char*)geom_buffer, N, g);
     int rc;
     { C3dProfScope ps(C3D_P_PREPROCESS, s);
     if ((rc = gs_launch_preprocess(p, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, radii, s))) return rc; }
-    return forward_tail_nosync(p, g, N, pair_capacity, binning_buffer, image_buffer, out_color, out_depth, out_alpha, status, status_host, s);
+    return forward_tail_nosync(st, p, g, N, pair_capacity, first_capacity, binning_buffer, image_buffer, out_color, out_depth, out_alpha, status, status_host, s);
 }
 
 int c3d_gs_forward_raw_nosync(const c3d_gs_settings* st, int32_t N, const float* means3D, const float* f_dc, const float* f_rest, const float* opacity_raw,
-                              const float* scaling_raw, const float* rotation_raw, int32_t* radii, void* geom_buffer, int64_t pair_capacity, void* binning_buffer,
-                              void* image_buffer, float* out_color, float* out_depth, float* out_alpha, uint32_t* status, uint32_t* status_host, c3d_stream_t stream) {
+                              const float* scaling_raw, const float* rotation_raw, int32_t* radii, void* geom_buffer, int64_t pair_capacity, int64_t first_capacity,
+                              void* binning_buffer, void* image_buffer, float* out_color, float* out_depth, float* out_alpha, uint32_t* status, uint32_t* status_host,
+                              c3d_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     GsParams p;
     const int K = raw_coeffs(st);
     if (K < 0 || make_params(st, N, K, p)) return -1;
     if (N == 0 || p.gx * p.gy == 0) { c3d_set_error("c3d_gs_forward_raw_nosync: empty cloud / image (take c3d_gs_forward_project_raw + c3d_gs_forward_render)"); return -1; }
-    if (check_nosync_args("c3d_gs_forward_raw_nosync", pair_capacity, radii, geom_buffer, binning_buffer, image_buffer, out_color, out_depth, out_alpha, status)) return -1;
+    if (check_nosync_args("c3d_gs_forward_raw_nosync", pair_capacity, first_capacity, radii, geom_buffer, binning_buffer, image_buffer, out_color, out_depth, out_alpha, status)) return -1;
     if (!means3D || !f_dc || (!f_rest && K > 1) || !opacity_raw || !scaling_raw || !rotation_raw) { c3d_set_error("c3d_gs_forward_raw_nosync: NULL pointer"); return -1; }
     if ((K > 1 && (uintptr_t)f_rest % 16) || (uintptr_t)rotation_raw % 16) { c3d_set_error("c3d_gs_forward_raw_nosync: f_rest / rotation must be 16-byte aligned"); return -1; }
     GsGeom g;
@@ -262,7 +289,7 @@ int c3d_gs_forward_raw_nosync(const c3d_gs_settings* st, int32_t N, const float*
     int rc;
     { C3dProfScope ps(C3D_P_PREPROCESS, s);
     if ((rc = gs_launch_preprocess_raw(p, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, g, radii, s))) return rc; }
-    return forward_tail_nosync(p, g, N, pair_capacity, binning_buffer, image_buffer, out_color, out_depth, out_alpha, status, status_host, s);
+    return forward_tail_nosync(st, p, g, N, pair_capacity, first_capacity, binning_buffer, image_buffer, out_color, out_depth, out_alpha, status, status_host, s);
 }
 
 int c3d_gs_backward(const c3d_gs_settings* st, int32_t N, int32_t M, const float* means3D, const float* shs,
@@ -275,6 +302,7 @@ int c3d_gs_backward(const c3d_gs_settings* st, int32_t N, int32_t M, const float
     hipStream_t s = (hipStream_t)stream;
     GsParams p;
     if (make_params(st, N, M, p)) return -1;
+    if (st->flags & C3D_GS_FLAG_FORWARD_ONLY) { c3d_set_error("c3d_gs_backward: these settings carry C3D_GS_FLAG_FORWARD_ONLY -- a forward pass rendered with them kept no state for a backward pass"); return -1; }
     if (check_inputs(N, M, p.deg, means3D, shs, colors_precomp, scales, rotations, cov3D_precomp)) return -1;
     if (N == 0) return 0;
     if (!dL_dcolor || !dL_dmeans2D || !dL_dcolors || !dL_dopacity || !dL_dmeans3D || !scratch || !radii || !geom_buffer) {
@@ -297,7 +325,7 @@ int c3d_gs_backward(const c3d_gs_settings* st, int32_t N, int32_t M, const float
         if (!binning_buffer || !image_buffer) { c3d_set_error("c3d_gs_backward: NULL state buffer"); return -1; }
         const int res = sort_result_index(tile_sort_bits(tiles));
         C3dProfScope ps(C3D_P_COMPOSITE_BWD, s);
-        C3D_CHECK(hipMemsetAsync(pvalid, 0, (size_t)num_rendered, s));
+        if ((rc = c3d_zero_count(pvalid, (const uint32_t*)g.meta + 1, pair_cap(num_rendered), s))) return rc;      // the pairs the forward pass worked on (<= num_rendered: the buffers may hold a capacity)
         GsBwdPix px{};
         px.bg[0] = p.bg; px.dcolor[0] = dL_dcolor; px.ddepth[0] = dL_ddepth; px.dalpha[0] = dL_dalpha;
         if ((rc = gs_launch_composite_bwd(p, g, b, res, im, px, dL_ddepth != nullptr, pairgrad, pvalid, s, pair_cap(num_rendered)))) return rc;
@@ -316,6 +344,7 @@ int c3d_gs_backward_raw(const c3d_gs_settings* st, int32_t N, const float* means
     GsParams p;
     const int K = raw_coeffs(st);
     if (K < 0 || make_params(st, N, K, p)) return -1;
+    if (st->flags & C3D_GS_FLAG_FORWARD_ONLY) { c3d_set_error("c3d_gs_backward_raw: these settings carry C3D_GS_FLAG_FORWARD_ONLY -- a forward pass rendered with them kept no state for a backward pass"); return -1; }
     if (N == 0) return 0;
     if (!means3D || !f_dc || (!f_rest && K > 1) || !scaling_raw || !rotation_raw || !radii || !geom_buffer || !dL_dcolor || !dL_dmeans2D || !dL_dmeans3D ||
         !dL_df_dc || (!dL_df_rest && K > 1) || !dL_dopacity_raw || !dL_dscaling_raw || !dL_drotation_raw || !scratch) { c3d_set_error("c3d_gs_backward_raw: NULL pointer"); return -1; }
@@ -334,7 +363,7 @@ int c3d_gs_backward_raw(const c3d_gs_settings* st, int32_t N, const float* means
         if (!binning_buffer || !image_buffer) { c3d_set_error("c3d_gs_backward_raw: NULL state buffer"); return -1; }
         const int res = sort_result_index(tile_sort_bits(tiles));
         C3dProfScope ps(C3D_P_COMPOSITE_BWD, s);
-        C3D_CHECK(hipMemsetAsync(pvalid, 0, (size_t)num_rendered, s));
+        if ((rc = c3d_zero_count(pvalid, (const uint32_t*)g.meta + 1, pair_cap(num_rendered), s))) return rc;      // the pairs the forward pass worked on (<= num_rendered: the buffers may hold a capacity)
         GsBwdPix px{};
         px.bg[0] = p.bg; px.dcolor[0] = dL_dcolor; px.ddepth[0] = dL_ddepth; px.dalpha[0] = dL_dalpha;
         if ((rc = gs_launch_composite_bwd(p, g, b, res, im, px, dL_ddepth != nullptr, pairgrad, pvalid, s, pair_cap(num_rendered)))) return rc;

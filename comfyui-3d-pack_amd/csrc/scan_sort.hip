@@ -65,7 +65,9 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* lds, u
 // ------------------------------------------------------------------------------------------
 #define LB_AGG 1ull
 #define LB_INCL 2ull
-struct ScanTail { uint32_t* meta; uint32_t* status; uint32_t cap; uint2* rsort; };   // rsort: GATHER
+// cap2 (0 = none): the capacity of a second, device-gated attempt (c3d_gs_forward_nosync's redo): meta[1] = min(total, cap2), status bit 2 = "more than cap pairs: the redo
+// runs", bit 0 only beyond cap2.  meta[1] always receives the count the FINAL attempt works on (min(total, cap) without a second one).
+struct ScanTail { uint32_t* meta; uint32_t* status; uint32_t cap; uint2* rsort; uint32_t cap2; };   // rsort: GATHER
 __device__ __forceinline__ uint32_t rect_area(uint2 r) { return ((r.y & 0xFFFFu) - (r.x & 0xFFFFu)) * ((r.y >> 16) - (r.x >> 16)); }
 
 // Data movement (round 4: with V views per launch the scans are bandwidth-sized work, and eight 4-byte accesses per lane at a 32-byte lane stride cost eight
@@ -184,7 +186,13 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_lb(const uint32_t* __rest
         if (tail.meta && b < n && b + 4 >= n) {      // this lane owns element n-1: `run` is the grand total (elements past n are zeros)
             const uint32_t total = run;
             tail.meta[0] = total < tail.cap ? total : tail.cap;
-            if (tail.status) { if (total > tail.cap) atomicOr(&tail.status[0], 1u); atomicMax(&tail.status[1], total); }
+            const uint32_t last_cap = tail.cap2 ? tail.cap2 : tail.cap;
+            tail.meta[1] = total < last_cap ? total : last_cap;
+            if (tail.status) {
+                if (total > last_cap) atomicOr(&tail.status[0], C3D_ST_OVERFLOW);
+                if (tail.cap2 && total > tail.cap) atomicOr(&tail.status[0], C3D_ST_REDO);
+                atomicMax(&tail.status[1], total);
+            }
         }
     }
 }
@@ -212,7 +220,7 @@ static int scan_launch(const uint32_t* in, const uint32_t* idx, uint32_t* out, s
     return 0;
 }
 int c3d_scan_u32(const uint32_t* in, uint32_t* out, size_t n, bool exclusive, void* tmp, hipStream_t s, bool zero_state, uint32_t* err) {
-    return scan_launch(in, nullptr, out, n, exclusive, tmp, s, zero_state, ScanTail{nullptr, nullptr, 0u, nullptr}, err);
+    return scan_launch(in, nullptr, out, n, exclusive, tmp, s, zero_state, ScanTail{nullptr, nullptr, 0u, nullptr, 0u}, err);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -246,9 +254,38 @@ int c3d_zero_views(void* base0, size_t vs, int V, const size_t* off, const size_
     C3D_LAUNCH_CHECK();
     return 0;
 }
+// bytes (a multiple of 16, 16-byte aligned start) cleared only if (*gate & C3D_ST_REDO): the state block of the device-gated second attempt of c3d_gs_forward_nosync
+__global__ void __launch_bounds__(256) k_zero_gated(uint4* __restrict__ p, size_t n16, const uint32_t* __restrict__ gate) {
+    if (!(*gate & C3D_ST_REDO)) return;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+int c3d_zero_gated(void* p, size_t bytes, const uint32_t* gate, hipStream_t s) {
+    if (bytes == 0) return 0;
+    if (((uintptr_t)p & 15) || (bytes & 15) || !gate) { c3d_set_error("c3d_zero_gated: region must be 16-byte aligned / a multiple of 16 bytes, gate non-NULL"); return -1; }
+    int nb = c3d_cdiv((long long)(bytes / 16), 256 * 4);
+    if (nb < 1) nb = 1;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(k_zero_gated, dim3(nb), dim3(256), 0, s, (uint4*)p, bytes / 16, gate);
+    C3D_LAUNCH_CHECK();
+    return 0;
+}
+// bytes [0, min(*count, cap)) of p cleared, the count resident on the device: the "record written" bytes of a backward pass whose buffers were sized for a capacity
+__global__ void __launch_bounds__(256) k_zero_count(uint4* __restrict__ p, const uint32_t* __restrict__ count, uint32_t cap) {
+    const uint32_t c = *count < cap ? *count : cap;
+    const size_t n16 = ((size_t)c + 15) / 16;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+int c3d_zero_count(void* p, const uint32_t* count, uint32_t cap, hipStream_t s) {      // p: 16-byte aligned, room for cap rounded up to 16 bytes
+    if (cap == 0) return 0;
+    int nb = c3d_cdiv((long long)cap / 16 + 1, 256 * 4);
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(k_zero_count, dim3(nb), dim3(256), 0, s, (uint4*)p, count, cap);
+    C3D_LAUNCH_CHECK();
+    return 0;
+}
 int c3d_scan_rect_gather(const uint2* rect, const uint32_t* idx, uint32_t* out, uint2* rsort, size_t n, void* tmp, hipStream_t s, bool zero_state,
-                         uint32_t* tail_meta, uint32_t* tail_status, uint32_t tail_cap, uint32_t* err, int V, size_t vs) {
-    return scan_launch(reinterpret_cast<const uint32_t*>(rect), idx, out, n, false, tmp, s, zero_state, ScanTail{tail_meta, tail_status, tail_cap, rsort}, err, V, vs);
+                         uint32_t* tail_meta, uint32_t* tail_status, uint32_t tail_cap, uint32_t* err, int V, size_t vs, uint32_t tail_cap2) {
+    return scan_launch(reinterpret_cast<const uint32_t*>(rect), idx, out, n, false, tmp, s, zero_state, ScanTail{tail_meta, tail_status, tail_cap, rsort, tail_cap2}, err, V, vs);
 }
 uint32_t* c3d_scan_error_word(void* tmp) { return (uint32_t*)tmp + 1; }
 
@@ -353,7 +390,9 @@ __global__ void __launch_bounds__(RS_THREADS, 4) k_onesweep(const uint32_t* __re
                                                              uint32_t* __restrict__ keys_out0, uint32_t* __restrict__ vals_out0,
                                                              const uint32_t* __restrict__ ghist0, uint32_t* __restrict__ ticket, uint32_t* __restrict__ err,
                                                              uint32_t* __restrict__ tile_words0, uint32_t* __restrict__ group_words0, size_t n_cap,
-                                                             const uint32_t* __restrict__ n_dev, int shift, unsigned long long* __restrict__ dbg, size_t vs) {
+                                                             const uint32_t* __restrict__ n_dev, int shift, unsigned long long* __restrict__ dbg, size_t vs,
+                                                             const uint32_t* __restrict__ gate) {
+    if (gate && !(*gate & C3D_ST_REDO)) return;      // a pass of the device-gated second attempt (c3d_gs_forward_nosync): nothing to redo
     __shared__ uint32_t whist[RS_THREADS / 64][RS_RADIX];
     __shared__ uint32_t lstart[RS_RADIX];    // first local slot of each digit
     __shared__ uint32_t gbase[RS_RADIX];     // global position of that slot
@@ -579,7 +618,8 @@ size_t c3d_sort_state_bytes(size_t n, int end_bit) {
 }
 
 int c3d_sort_pairs_u32(uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32_t* vals1, bool iota_vals,
-                       size_t n, int end_bit, void* tmp, int* result_buf, hipStream_t s, const uint32_t* n_dev, bool zero_state, uint32_t* err_out, int V, size_t vs, bool hist_done) {
+                       size_t n, int end_bit, void* tmp, int* result_buf, hipStream_t s, const uint32_t* n_dev, bool zero_state, uint32_t* err_out, int V, size_t vs, bool hist_done,
+                       const uint32_t* gate) {
     *result_buf = 0;
     if (n == 0 || V <= 0) return 0;
     if (zero_state && V != 1) { c3d_set_error("c3d_sort_pairs_u32: a multi-view launch clears its state through c3d_zero_views"); return -1; }
@@ -595,17 +635,18 @@ int c3d_sort_pairs_u32(uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32
     uint32_t* tickets = ghist + RS_HIST_SPLIT * RS_RADIX * RS_MAX_PASSES;
     uint32_t* err = err_out ? err_out : c3d_sort_error_word(tmp);
     uint32_t* status = (uint32_t*)((char*)tmp + sort_head_bytes());
+    if (hist_done && zero_state) { c3d_set_error("c3d_sort_pairs_u32: hist_done with zero_state would clear the producer's histograms"); return -1; }
+    if (gate && !hist_done) { c3d_set_error("c3d_sort_pairs_u32: a gated sort takes its histograms from the (gated) producer of the keys"); return -1; }
     if (zero_state) C3D_CHECK(hipMemsetAsync(tmp, 0, c3d_sort_state_bytes(n, end_bit), s));
     uint32_t* k[2] = {keys0, keys1};
     uint32_t* v[2] = {vals0, vals1};
-    if (hist_done && zero_state) { c3d_set_error("c3d_sort_pairs_u32: hist_done with zero_state would clear the producer's histograms"); return -1; }
     if (!hist_done) hipLaunchKernelGGL(k_radix_hist_all, dim3(nb_hist, V), dim3(RS_THREADS), 0, s, keys0, ghist, n, n_dev, passes, vs);
     int cur = 0;
     for (int pass = 0; pass < passes; pass++) {
         uint32_t* tw = status + (size_t)pass * sort_pass_words((size_t)nb);
         uint32_t* gw = tw + (size_t)RS_RADIX * nb;
 #define RS_SWEEP(IOTA_, STAY_) hipLaunchKernelGGL((k_onesweep<IOTA_, RS_ITEMS, STAY_>), dim3(nbx, V), dim3(RS_THREADS), 0, s, k[cur], v[cur], k[cur ^ 1], v[cur ^ 1], ghist + pass * RS_RADIX, \
-                                           tickets + pass, err, tw, gw, n, n_dev, 8 * pass, (g_sort_dbg && V == 1) ? g_sort_dbg + (size_t)pass * nb * 8 : nullptr, vs)
+                                           tickets + pass, err, tw, gw, n, n_dev, 8 * pass, (g_sort_dbg && V == 1) ? g_sort_dbg + (size_t)pass * nb * 8 : nullptr, vs, gate)
         if (pass == 0 && iota_vals) { if (stay) RS_SWEEP(true, true); else RS_SWEEP(true, false); }
         else { if (stay) RS_SWEEP(false, true); else RS_SWEEP(false, false); }
 #undef RS_SWEEP

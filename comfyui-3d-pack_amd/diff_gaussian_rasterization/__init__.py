@@ -14,26 +14,33 @@ import torch.nn as nn
 import c3d_hip as _h
 
 last_num_rendered = 0   # (tile, splat) pairs of the most recent forward whose count has reached the host -- bench/telemetry only
+redone_calls = 0        # sync-free forward calls whose first attempt overflowed and which the device redid at the buffers' capacity (exact) -- telemetry
 
-# ---- pair capacity: the forward pass without its host round trip -----------------------------------------------------------------------------------
-# The wheel sizes its binning buffer from the exact pair count and stalls the host for that one number on every call (so did rounds 1-4 here:
-# c3d_gs_forward_project).  Here the first call of a (device, N, H, W) shape takes that synchronous path and LEARNS the count; later calls of the shape go through
-# c3d_gs_forward_nosync with buffers and launches sized for a capacity above the largest count seen, the count stays on the device, and the two status words
-# of the call come back through pinned memory and are examined when a later call starts -- the host runs ahead of the GPU instead of waiting for it once per view.
-# A view that needs more pairs than the capacity is rendered incompletely (pairs beyond it are dropped); that is noticed one call late: a RuntimeWarning says so
-# and the capacity regrows at once (calls still pending when the interpreter exits are examined then: flush() / atexit).  Headroom: 1.5 x the largest count seen when the call is differentiated (a training loop: counts drift slowly, and one incomplete
-# gradient step is harmless), 3 x when it is not (inference through LGM / TGS / TRELLIS-style callers: the next object may be larger, and an incomplete image is what the
-# user gets) -- empty capacity costs a few early-exiting workgroups per sort pass and bytes of a 288 GB memory.  sync_free(False) restores the wheel's behaviour (exact
-# count, one synchronisation per call) for callers that cannot accept any of that.
+# ---- the forward pass without its host round trip, and still exact --------------------------------------------------------------------------------
+# The wheel sizes its binning buffer from the exact pair count and stalls the host for that one number on every call (main_3DGS_renderer.py:927-936 never returns an
+# incomplete image).  Here:
+#   * a call that is NOT differentiated (grad mode off, or no input requires a gradient: inference -- the orbit nodes, LGM / TGS / TRELLIS-style consumers) takes that
+#     synchronous path: exact by construction, and with C3D_GS_FLAG_FORWARD_ONLY the compositing launch leaves out everything only a backward pass would read;
+#   * a DIFFERENTIATED call (a training loop: the host wants to run ahead of the GPU) goes through c3d_gs_forward_nosync in TWO attempts (include/c3d_gs.h): launches sized
+#     for a first capacity learnt from the counts seen (1.5 x the largest, scaled with the point count while a model densifies), buffers sized for _REDO x that -- and when
+#     the device-resident count exceeds the first capacity, the device itself bins and composites the view a second time at the buffers' capacity, inside the same call.
+#     Image, radii and every gradient are then those of the synchronous path, bit for bit; the host hears of it one call late (status words through a pinned ring, looked
+#     at when a later call starts) and only raises the first capacity.  The capacities are capped at N x tiles, which no view can exceed.
+# Only a view that needs more than the BUFFERS hold (a pair count that grew more than _HEADROOM x _REDO = 6 x from one call to the next) cannot be rendered: its planes
+# come back as NaN -- never an image that merely looks plausible -- and the examination raises.  sync_free(False) takes the synchronous path for every call.
+import collections
 import threading
 import warnings
 
 _lock = threading.RLock()      # ComfyUI may run nodes on several threads: slot hand-out and examination are serialised (a few dictionary / list operations per call)
 _SYNC_FREE = True
-_HEADROOM_GRAD, _HEADROOM_NOGRAD, _SLACK = 1.5, 3.0, 1 << 16      # capacity = headroom x largest count seen + slack
-_cap = {}        # (device index, N, H, W) -> largest pair count seen for the shape
+_FORWARD_ONLY = True           # calls that are not differentiated render with C3D_GS_FLAG_FORWARD_ONLY (forward_only(False): the A/B switch of bench.py)
+_HEADROOM, _REDO, _SLACK = 1.5, 4, 1 << 16      # first capacity = headroom x largest count seen + slack; buffers = _REDO x first capacity
+_MAX_PAIRS = 0x3FFFFFF0       # the library's own limit (the chained scans' status words)
+_MODELS = 8      # point counts remembered per (device, H, W)
+_learnt = {}     # (device index, H, W) -> OrderedDict {N: largest pair count seen with N points}, most recently used last
 _SLOTS = 64      # status slots per device: calls whose status words may be on their way to the host at once
-_SENTINEL = -1   # 0xFFFFFFFF: neither a flag word (bits 0-1) nor a pair count (< 2^30)
+_SENTINEL = -1   # 0xFFFFFFFF: neither a flag word (bits 0-2) nor a pair count (< 2^30)
 _rings = {}      # device index -> _Ring
 
 
@@ -49,12 +56,12 @@ class _Ring:
         self.host = self.pin.numpy()                      # same memory: plain loads / stores from Python
         self.dev_ptr, self.pin_ptr = self.dev_words.data_ptr(), self.pin.data_ptr()
         self.next = 0
-        self.pending = []                                 # [(slot, key, capacity)] calls whose status words have not been examined, oldest first
+        self.pending = []                                 # [(slot, key, N, capacity)] calls whose status words have not been examined, oldest first
 
     def examine(self, block=False, keep=_SLOTS):
         """retire the calls whose words have arrived; block: all of them, waiting for the GPU if need be; keep: wait until at most that many are left"""
         while self.pending:
-            slot, key, cap = self.pending[0]
+            slot, key, n_points, cap = self.pending[0]
             w = self.host[slot]
             if w[0] == _SENTINEL or w[1] == _SENTINEL:    # still on its way
                 if not block and len(self.pending) <= keep:
@@ -68,11 +75,14 @@ class _Ring:
             flags, seen = int(w[0]), int(w[1]) & 0xFFFFFFFF
             if flags & 2:
                 raise RuntimeError("diff_gaussian_rasterization (MI355X): a chained-scan look-back of an earlier forward call timed out in the binning stage (device fault or a wedged workgroup)")
-            _learn(key, seen)
+            if flags & 4:
+                global redone_calls
+                redone_calls += 1
+            _learn(key, n_points, seen)                   # (bit 2: the device redid the view at the buffers' capacity -- exact; the first capacity follows the count from here on)
             if flags & 1:
-                warnings.warn("diff_gaussian_rasterization (MI355X): an earlier sync-free forward call needed %d (tile, splat) pairs, its buffers held %d -- that image (and its "
-                              "gradient) is incomplete.  The capacity has been regrown; diff_gaussian_rasterization.sync_free(False) restores the exact synchronous path."
-                              % (seen, cap), RuntimeWarning, stacklevel=4)
+                raise RuntimeError("diff_gaussian_rasterization (MI355X): an earlier differentiated forward call needed %d (tile, splat) pairs, more than the %d its buffers held "
+                                   "(the count grew more than %g x from one call to the next): its colour / depth / alpha planes were returned as NaN.  The capacity has been "
+                                   "regrown; diff_gaussian_rasterization.sync_free(False) sizes every call from its exact count." % (seen, cap, _HEADROOM * _REDO))
 
 
 def sync_free(on=True):
@@ -82,8 +92,15 @@ def sync_free(on=True):
     return prev
 
 
+def forward_only(on=True):
+    """False: calls that are not differentiated still record the backward pass's state (what rounds 1-5 did; measurement switch).  Returns the previous setting."""
+    global _FORWARD_ONLY
+    prev, _FORWARD_ONLY = _FORWARD_ONLY, bool(on)
+    return prev
+
+
 def flush():
-    """wait for the status words of every sync-free forward call issued so far and examine them (warns / raises as described above); afterwards
+    """wait for the status words of every sync-free forward call issued so far and examine them (raises as described above); afterwards
     last_num_rendered is the pair count of the most recent forward call"""
     with _lock:
         for ring in list(_rings.values()):
@@ -91,7 +108,7 @@ def flush():
 
 
 def _flush_at_exit():
-    """a process whose LAST forward call overflowed would otherwise never hear of it: examine what is pending before the interpreter goes"""
+    """a process whose LAST forward call could not be rendered would otherwise never hear of it: examine what is pending before the interpreter goes"""
     try:
         if pending_calls():
             flush()
@@ -105,28 +122,50 @@ def pending_calls():
         return sum(len(r.pending) for r in _rings.values())
 
 
-def _learn(key, seen):
-    """a pair count of this shape has reached the host"""
+def _learn(key, n_points, seen):
+    """a pair count of a (device, H, W) shape rendered with n_points Gaussians has reached the host"""
     global last_num_rendered
     with _lock:
         last_num_rendered = int(seen)
-        if seen > _cap.get(key, -1):
-            _cap[key] = int(seen)
+        models = _learnt.setdefault(key, collections.OrderedDict())
+        if seen > models.get(n_points, -1):
+            models[n_points] = int(seen)
+        models.move_to_end(n_points)
+        while len(models) > _MODELS:
+            models.popitem(last=False)
 
 
-def _capacity_for(key, differentiated):
-    """-> pair capacity for a sync-free forward of this shape, or None: take the synchronous path (and learn the count)"""
+def _estimate(key, n_points):
+    """-> the largest pair count seen for this shape at n_points Gaussians; for a point count not seen yet, that of the nearest one within a factor of two, scaled
+    (a model that densifies or prunes keeps its pairs per Gaussian; the second attempt of the call makes a wrong guess exact); None: nothing to go by"""
+    models = _learnt.get(key)
+    if not models:
+        return None
+    if n_points in models:
+        return models[n_points]
+    n0 = min(models, key=lambda n: abs(n - n_points))
+    if 2 * n0 < n_points or 2 * n_points < n0:
+        return None
+    return -(-models[n0] * n_points // n0)
+
+
+def _capacity_for(key, n_points):
+    """-> (first capacity, buffer capacity) of a sync-free forward of this shape (first capacity 0: one attempt -- the buffers hold every pair the view can have), or
+    None: take the synchronous path (and learn the count)"""
     with _lock:
         ring = _rings.get(key[0])
         if ring is not None and ring.pending:
             ring.examine()
-        seen = _cap.get(key)
-        if seen is None or not _SYNC_FREE:
+        seen = _estimate(key, n_points) if _SYNC_FREE else None
+        if seen is None:
             return None
-        return min(int(seen * (_HEADROOM_GRAD if differentiated else _HEADROOM_NOGRAD)) + _SLACK, 0x3FFFFFF0)
+        bound = min(n_points * ((key[1] + 15) // 16) * ((key[2] + 15) // 16), _MAX_PAIRS)      # every Gaussian in every tile
+        first = min(int(seen * _HEADROOM) + _SLACK, bound)
+        cap = min(first * _REDO, bound)
+        return (first if first < cap else 0), max(cap, 1)
 
 
-def _status_slot(dev, key, cap):
+def _status_slot(dev, key, n_points, cap):
     """-> (device pointer, pinned host pointer) of the status words of one sync-free call, registered for examination"""
     with _lock:
         ring = _rings.get(dev.index)
@@ -137,8 +176,13 @@ def _status_slot(dev, key, cap):
         slot = ring.next
         ring.next = (slot + 1) % _SLOTS
         ring.host[slot] = _SENTINEL
-        ring.pending.append((slot, key, cap))
+        ring.pending.append((slot, key, n_points, cap))
         return C.c_void_p(ring.dev_ptr + 8 * slot), C.c_void_p(ring.pin_ptr + 8 * slot)
+
+
+def _differentiated(*tensors):
+    """what autograd will do with the call: grad mode is off inside Function.forward, so it is looked at here, by the wrappers, before apply()"""
+    return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors)
 
 
 import atexit
@@ -160,14 +204,15 @@ class GaussianRasterizationSettings(NamedTuple):
     debug: bool
 
 
-def _settings_struct(rs, keep, sh_coeffs=0):
+def _settings_struct(rs, keep, sh_coeffs=0, forward_only=False):
     """sh_coeffs: SH coefficients per channel the RAW parameters of the call store (f_rest.shape[1] + 1); 0 for the entry points that take M explicitly"""
     dev = rs.viewmatrix.device
     bg = _h.f32c(rs.bg.to(dev)); vm = _h.f32c(rs.viewmatrix); pm = _h.f32c(rs.projmatrix.to(dev)); cp = _h.f32c(rs.campos.to(dev))
     keep.extend([bg, vm, pm, cp])
+    flags = (_h.GS_FLAG_EXACT_DSCALE if getattr(rs, "exact_dscale", False) else 0) | (_h.GS_FLAG_FORWARD_ONLY if forward_only else 0)
     return _h.GsSettings(int(rs.image_height), int(rs.image_width), float(rs.tanfovx), float(rs.tanfovy),
                          float(rs.scale_modifier), int(rs.sh_degree), int(bool(rs.prefiltered)), int(bool(rs.debug)),
-                         _h.ptr(bg), _h.ptr(vm), _h.ptr(pm), _h.ptr(cp), _h.GS_FLAG_EXACT_DSCALE if getattr(rs, "exact_dscale", False) else 0, int(sh_coeffs))
+                         _h.ptr(bg), _h.ptr(vm), _h.ptr(pm), _h.ptr(cp), flags, int(sh_coeffs))
 
 
 class _ExactDscaleSettings(GaussianRasterizationSettings):
@@ -182,13 +227,48 @@ def with_exact_dscale(rs):
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
-    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings)
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
+                                     _differentiated(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp))
+
+
+_NO_BACKWARD = ("diff_gaussian_rasterization (MI355X): this forward call was not differentiated when it ran (grad mode off, or no input required a gradient), so it was rendered "
+                "forward-only (C3D_GS_FLAG_FORWARD_ONLY) and kept no state for a backward pass")
+
+
+def _forward_state(ctx, lib, dev, N, H, W, differentiated, project, render, nosync):
+    """the part of forward() the plain and the raw-parameter entry points share: buffers, the choice of path, the library calls.
+    project(st_ref, radii, geom, nr_ref, s), render(st_ref, radii, geom, num_rendered, binning, img, color, depth, alpha, s), nosync(st_ref, radii, geom, cap, first, binning,
+    img, color, depth, alpha, st_dev, st_host, s) issue the calls with the entry point's own parameter list.  -> (color, radii, depth, alpha, geom, binning, img, num_rendered)"""
+    u8 = dict(dtype=torch.uint8, device=dev)
+    s = _h.stream(dev)
+    radii = torch.empty((N,), dtype=torch.int32, device=dev)
+    geom = torch.empty((lib.c3d_gs_geom_bytes(N),), **u8)
+    img = torch.empty((lib.c3d_gs_image_bytes(H, W),), **u8)
+    color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+    depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+    alpha = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+    key = (dev.index, H, W)
+    caps = _capacity_for(key, N) if (differentiated and N > 0 and H > 0 and W > 0) else None
+    if caps is not None:      # sync-free, two attempts on the device (see the head of this file)
+        first, cap = caps
+        num_rendered = cap
+        binning = torch.empty((lib.c3d_gs_binning_bytes(cap, H, W),), **u8)
+        st_dev, st_host = _status_slot(dev, key, N, cap)
+        nosync(radii, geom, cap, first, binning, img, color, depth, alpha, st_dev, st_host, s)
+    else:                     # the wheel's way: the exact pair count comes back to the host between the two halves
+        nr = C.c_int64(0)
+        project(radii, geom, nr, s)
+        num_rendered = int(nr.value)
+        if N > 0 and H > 0 and W > 0:
+            _learn(key, N, num_rendered)
+        binning = torch.empty((lib.c3d_gs_binning_bytes(num_rendered, H, W),), **u8)
+        render(radii, geom, num_rendered, binning, img, color, depth, alpha, s)
+    return color, radii, depth, alpha, geom, binning, img, num_rendered
 
 
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings, differentiated=True):
         lib = _h.lib()
         rs = raster_settings
         dev = means3D.device
@@ -202,45 +282,36 @@ class _RasterizeGaussians(torch.autograd.Function):
         M = 0 if sh_c is None else sh_c.shape[1]
         keep = []
         with torch.cuda.device(dev):
-            st = _settings_struct(rs, keep)
-            s = _h.stream(dev)
-            u8 = dict(dtype=torch.uint8, device=dev)
-            radii = torch.empty((N,), dtype=torch.int32, device=dev)
-            geom = torch.empty((lib.c3d_gs_geom_bytes(N),), **u8)
-            img = torch.empty((lib.c3d_gs_image_bytes(H, W),), **u8)
-            color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
-            depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
-            alpha = torch.empty((1, H, W), dtype=torch.float32, device=dev)
-            key = (dev.index, N, H, W)
-            cap = _capacity_for(key, any(ctx.needs_input_grad)) if (N > 0 and H > 0 and W > 0) else None
-            if cap is not None:      # sync-free: launches sized for the capacity, the pair count stays on the device (see _cap above)
-                num_rendered = cap
-                binning = torch.empty((lib.c3d_gs_binning_bytes(cap, H, W),), **u8)
-                st_dev, st_host = _status_slot(dev, key, cap)
-                _h.check(lib.c3d_gs_forward_nosync(C.byref(st), N, M, _h.ptr(means3D_c), _h.ptr(sh_c), _h.ptr(col_c), _h.ptr(op_c), _h.ptr(sc_c), _h.ptr(rot_c),
-                                                   _h.ptr(cov_c), _h.ptr(radii), _h.ptr(geom), cap, _h.ptr(binning), _h.ptr(img), _h.ptr(color), _h.ptr(depth),
-                                                   _h.ptr(alpha), st_dev, st_host, s), "c3d_gs_forward_nosync")
-            else:
-                nr = C.c_int64(0)
-                _h.check(lib.c3d_gs_forward_project(C.byref(st), N, M, _h.ptr(means3D_c), _h.ptr(sh_c), _h.ptr(col_c), _h.ptr(op_c),
-                                                    _h.ptr(sc_c), _h.ptr(rot_c), _h.ptr(cov_c), _h.ptr(radii), _h.ptr(geom),
-                                                    C.byref(nr), s), "c3d_gs_forward_project")
-                num_rendered = int(nr.value)
-                _learn(key, num_rendered)
-                binning = torch.empty((lib.c3d_gs_binning_bytes(num_rendered, H, W),), **u8)
-                _h.check(lib.c3d_gs_forward_render(C.byref(st), N, M, _h.ptr(radii), _h.ptr(geom), num_rendered, _h.ptr(binning),
-                                                   _h.ptr(img), _h.ptr(color), _h.ptr(depth), _h.ptr(alpha), s), "c3d_gs_forward_render")
+            st = _settings_struct(rs, keep, forward_only=_FORWARD_ONLY and not differentiated)
+            inputs = [_h.ptr(x) for x in (means3D_c, sh_c, col_c, op_c, sc_c, rot_c, cov_c)]
+
+            def project(radii, geom, nr, s):
+                _h.check(lib.c3d_gs_forward_project(C.byref(st), N, M, *inputs, _h.ptr(radii), _h.ptr(geom), C.byref(nr), s), "c3d_gs_forward_project")
+
+            def render(radii, geom, num_rendered, binning, img, color, depth, alpha, s):
+                _h.check(lib.c3d_gs_forward_render(C.byref(st), N, M, _h.ptr(radii), _h.ptr(geom), num_rendered, _h.ptr(binning), _h.ptr(img), _h.ptr(color), _h.ptr(depth),
+                                                   _h.ptr(alpha), s), "c3d_gs_forward_render")
+
+            def nosync(radii, geom, cap, first, binning, img, color, depth, alpha, st_dev, st_host, s):
+                _h.check(lib.c3d_gs_forward_nosync(C.byref(st), N, M, *inputs, _h.ptr(radii), _h.ptr(geom), cap, first, _h.ptr(binning), _h.ptr(img), _h.ptr(color),
+                                                   _h.ptr(depth), _h.ptr(alpha), st_dev, st_host, s), "c3d_gs_forward_nosync")
+
+            color, radii, depth, alpha, geom, binning, img, num_rendered = _forward_state(ctx, lib, dev, N, H, W, differentiated, project, render, nosync)
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.sizes = (N, M)
+        ctx.forward_only = not differentiated
         ctx.present = (sh_c is not None, col_c is not None, sc_c is not None, cov_c is not None)
-        e = torch.empty(0, device=dev)
-        ctx.save_for_backward(*(t if t is not None else e for t in (col_c, means3D_c, sc_c, rot_c, cov_c, radii, sh_c, geom, binning, img)))
         ctx.mark_non_differentiable(radii)
+        if differentiated:
+            e = torch.empty(0, device=dev)
+            ctx.save_for_backward(*(t if t is not None else e for t in (col_c, means3D_c, sc_c, rot_c, cov_c, radii, sh_c, geom, binning, img)))
         return color, radii, depth, alpha
 
     @staticmethod
     def backward(ctx, grad_color, grad_radii, grad_depth, grad_alpha):
+        if ctx.forward_only:
+            raise RuntimeError(_NO_BACKWARD)
         lib = _h.lib()
         rs = ctx.raster_settings
         N, M = ctx.sizes
@@ -273,7 +344,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                                          _h.ptr(g_means3D), _h.ptr(g_cov3D), _h.ptr(g_sh), _h.ptr(g_scales), _h.ptr(g_rot),
                                          _h.ptr(scratch), s), "c3d_gs_backward")
         return (g_means3D, g_means2D, g_sh, g_colors if has_col else None, g_opacity, g_scales, g_rot,
-                g_cov3D if has_cov else None, None)
+                g_cov3D if has_cov else None, None, None)
 
 
 class _RasterizeGaussiansRaw(torch.autograd.Function):
@@ -281,7 +352,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
     passes run inside the projection kernels (c3d_gs_forward_project_raw / c3d_gs_backward_raw)."""
 
     @staticmethod
-    def forward(ctx, means3D, means2D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, raster_settings):
+    def forward(ctx, means3D, means2D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, raster_settings, differentiated=True):
         lib = _h.lib()
         rs = raster_settings
         dev = means3D.device
@@ -293,40 +364,33 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         N = means3D.shape[0]
         keep = []
         with torch.cuda.device(dev):
-            st = _settings_struct(rs, keep, K)
-            s = _h.stream(dev)
-            u8 = dict(dtype=torch.uint8, device=dev)
-            radii = torch.empty((N,), dtype=torch.int32, device=dev)
-            geom = torch.empty((lib.c3d_gs_geom_bytes(N),), **u8)
-            img = torch.empty((lib.c3d_gs_image_bytes(H, W),), **u8)
-            color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
-            depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
-            alpha = torch.empty((1, H, W), dtype=torch.float32, device=dev)
-            key = (dev.index, N, H, W)
-            cap = _capacity_for(key, any(ctx.needs_input_grad)) if (N > 0 and H > 0 and W > 0) else None
-            if cap is not None:      # sync-free (see _cap above)
-                num_rendered = cap
-                binning = torch.empty((lib.c3d_gs_binning_bytes(cap, H, W),), **u8)
-                st_dev, st_host = _status_slot(dev, key, cap)
-                _h.check(lib.c3d_gs_forward_raw_nosync(C.byref(st), N, *[_h.ptr(x) for x in t], _h.ptr(radii), _h.ptr(geom), cap, _h.ptr(binning), _h.ptr(img),
-                                                       _h.ptr(color), _h.ptr(depth), _h.ptr(alpha), st_dev, st_host, s), "c3d_gs_forward_raw_nosync")
-            else:
-                nr = C.c_int64(0)
-                _h.check(lib.c3d_gs_forward_project_raw(C.byref(st), N, *[_h.ptr(x) for x in t], _h.ptr(radii), _h.ptr(geom), C.byref(nr), s),
-                         "c3d_gs_forward_project_raw")
-                num_rendered = int(nr.value)
-                _learn(key, num_rendered)
-                binning = torch.empty((lib.c3d_gs_binning_bytes(num_rendered, H, W),), **u8)
-                _h.check(lib.c3d_gs_forward_render(C.byref(st), N, K, _h.ptr(radii), _h.ptr(geom), num_rendered, _h.ptr(binning), _h.ptr(img),
-                                                   _h.ptr(color), _h.ptr(depth), _h.ptr(alpha), s), "c3d_gs_forward_render")
+            st = _settings_struct(rs, keep, K, forward_only=_FORWARD_ONLY and not differentiated)
+            inputs = [_h.ptr(x) for x in t]
+
+            def project(radii, geom, nr, s):
+                _h.check(lib.c3d_gs_forward_project_raw(C.byref(st), N, *inputs, _h.ptr(radii), _h.ptr(geom), C.byref(nr), s), "c3d_gs_forward_project_raw")
+
+            def render(radii, geom, num_rendered, binning, img, color, depth, alpha, s):
+                _h.check(lib.c3d_gs_forward_render(C.byref(st), N, K, _h.ptr(radii), _h.ptr(geom), num_rendered, _h.ptr(binning), _h.ptr(img), _h.ptr(color), _h.ptr(depth),
+                                                   _h.ptr(alpha), s), "c3d_gs_forward_render")
+
+            def nosync(radii, geom, cap, first, binning, img, color, depth, alpha, st_dev, st_host, s):
+                _h.check(lib.c3d_gs_forward_raw_nosync(C.byref(st), N, *inputs, _h.ptr(radii), _h.ptr(geom), cap, first, _h.ptr(binning), _h.ptr(img), _h.ptr(color),
+                                                       _h.ptr(depth), _h.ptr(alpha), st_dev, st_host, s), "c3d_gs_forward_raw_nosync")
+
+            color, radii, depth, alpha, geom, binning, img, num_rendered = _forward_state(ctx, lib, dev, N, H, W, differentiated, project, render, nosync)
         ctx.raster_settings, ctx.num_rendered, ctx.N, ctx.K = rs, num_rendered, N, K
-        e = torch.empty(0, device=dev)
-        ctx.save_for_backward(*(x if x is not None else e for x in t), radii, geom, binning, img)
+        ctx.forward_only = not differentiated
         ctx.mark_non_differentiable(radii)
+        if differentiated:
+            e = torch.empty(0, device=dev)
+            ctx.save_for_backward(*(x if x is not None else e for x in t), radii, geom, binning, img)
         return color, radii, depth, alpha
 
     @staticmethod
     def backward(ctx, grad_color, grad_radii, grad_depth, grad_alpha):
+        if ctx.forward_only:
+            raise RuntimeError(_NO_BACKWARD)
         lib = _h.lib()
         rs, N = ctx.raster_settings, ctx.N
         means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, radii, geom, binning, img = ctx.saved_tensors
@@ -348,7 +412,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
                                              _h.ptr(gc), _h.ptr(_h.f32c(grad_depth)), _h.ptr(_h.f32c(grad_alpha)), _h.ptr(g_m2d), _h.ptr(g_m3d),
                                              _h.ptr(g_dc), _h.ptr(nz(g_rest)), _h.ptr(g_op), _h.ptr(g_sc), _h.ptr(g_rot), _h.ptr(scratch), 0,
                                              _h.stream(dev)), "c3d_gs_backward_raw")
-        return g_m3d, g_m2d, g_dc, g_rest, g_op, g_sc, g_rot, None
+        return g_m3d, g_m2d, g_dc, g_rest, g_op, g_sc, g_rot, None, None
 
 
 def raw_sh_coeffs(f_dc, f_rest):
@@ -362,7 +426,8 @@ def rasterize_gaussians_raw(means3D, means2D, f_dc, f_rest, opacity_raw, scaling
     """(color, radii, depth, alpha) from RAW GaussianModel parameters (SH storage of degree 0..3).  Equivalent to
     GaussianRasterizer(settings)(means3D, means2D, sigmoid(opacity_raw), shs=cat(f_dc, f_rest), scales=exp(scaling_raw),
     rotations=normalize(rotation_raw)) -- one kernel instead of five torch ops each way."""
-    return _RasterizeGaussiansRaw.apply(means3D, means2D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, raster_settings)
+    return _RasterizeGaussiansRaw.apply(means3D, means2D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, raster_settings,
+                                        _differentiated(means3D, means2D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw))
 
 
 class GaussianRasterizer(nn.Module):

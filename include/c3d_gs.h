@@ -69,6 +69,12 @@ typedef struct c3d_gs_settings {
  * exposes `scaling_modifier` for inference).  Set: the exact derivative (x m).  Per call, carried by the settings: the library keeps no
  * process-wide switches ("no global state besides per-device contexts"). */
 #define C3D_GS_FLAG_EXACT_DSCALE 1
+/* C3D_GS_FLAG_FORWARD_ONLY (ABI 600) -- forward entry points of the drop-in path (c3d_gs_forward_render, c3d_gs_forward_nosync, c3d_gs_forward_raw_nosync): no backward call will
+ * follow this render (an inference caller: torch.no_grad(), the orbit nodes, LGM / TGS / TRELLIS-style consumers).  The compositing launch then records no pair activity, runs
+ * no record-base scan and stores no per-pixel backward state (final_T, n_contrib: 8 of the 28 bytes it writes per pixel) -- same images, same radii, bit for bit.  A backward
+ * entry point that receives settings with this flag returns an error instead of reading state that was never written.  The Python boundary sets it whenever the call is not
+ * differentiated (grad mode off, or no input requires a gradient). */
+#define C3D_GS_FLAG_FORWARD_ONLY 2
 
 const char* c3d_last_error(void);
 int c3d_version(void);
@@ -90,23 +96,35 @@ int c3d_gs_forward_project(const c3d_gs_settings* st, int32_t N, int32_t M, cons
 
 /* Forward, part 2 (A3-A6): bins, orders and composites.  out_color[3,H,W], out_depth[1,H,W],
  * out_alpha[1,H,W].  The compositing launch also records which (quadrant, splat) pairs blended and carries the record-base scan of the backward pass in its first
- * workgroups (ABI 500: both feed c3d_gs_backward only, neither is on the forward chain's critical path). */
+ * workgroups (ABI 500: both feed c3d_gs_backward only, neither is on the forward chain's critical path; C3D_GS_FLAG_FORWARD_ONLY leaves both out).  The scan walks the
+ * geometry of all N Gaussians: geom_buffer and radii must be non-NULL whenever N > 0, whatever num_rendered is.  A timed-out hand-over of that scan (a device fault) raises
+ * C3D_ERR_LOOKBACK in the geometry buffer's own error word, which only the NEXT c3d_gs_forward_project on that buffer would read: callers that need the fault reported for this
+ * render take c3d_gs_forward_nosync, whose status words carry it. */
 int c3d_gs_forward_render(const c3d_gs_settings* st, int32_t N, int32_t M, const int32_t* radii, void* geom_buffer,
                           int64_t num_rendered, void* binning_buffer, void* image_buffer, float* out_color,
                           float* out_depth, float* out_alpha, c3d_stream_t stream);
 
-/* Forward in ONE call without host synchronisation (ABI 500): parts 1 + 2 with every launch sized for `pair_capacity` (tile, splat) pairs instead of the exact
+/* Forward in ONE call without host synchronisation (ABI 500; two attempts since ABI 600): parts 1 + 2 with every launch sized for a pair capacity instead of the exact
  * count -- the count stays on the device, so the rasterizer call of main_3DGS_renderer.py:927-936 (and of LGM core/gs.py:27-80, TRELLIS gaussian_render.py:62-130)
- * no longer stalls the host once per view.  binning_buffer: c3d_gs_binning_bytes(pair_capacity, H, W) bytes.  status (DEVICE, two words; the call clears them): [0] bit 0 =
- * the view needed more pairs than pair_capacity (the outputs are then incomplete: render again with a larger capacity), bit 1 = a bounded inter-workgroup wait timed
- * out (device fault); [1] = the pair count.  status_host (optional, PINNED host memory, two words): the call ends with an asynchronous copy of the two words there, in
+ * no longer stalls the host once per view.  The reference never returns an incomplete image (its binning buffer is sized from the exact count); neither does this call, up
+ * to pair_capacity:
+ *   pair_capacity   what the BUFFERS hold: binning_buffer = c3d_gs_binning_bytes(pair_capacity, H, W) bytes; a backward call on this state passes num_rendered = pair_capacity
+ *                   and scratch of c3d_gs_backward_scratch_bytes(N, pair_capacity).
+ *   first_capacity  what the LAUNCHES of the first attempt are sized for (0 or >= pair_capacity: one attempt, sized for pair_capacity).  A view that needs more pairs than that
+ *                   is binned and composited a SECOND time inside the same call, sized for pair_capacity, over the same buffers: the launches of the second attempt (one clear,
+ *                   emit, two sort passes, ranges, compositing) are enqueued with every call and leave at once, workgroup by workgroup, unless the device-resident count says
+ *                   otherwise.  Outputs and backward state are then those of an exact render, bit for bit.  Buffers are cheap (65 bytes per pair of capacity, forward and backward
+ *                   together, on a 288 GB device), early-exiting workgroups of oversized launches are not: learn first_capacity from the counts seen, set pair_capacity far above.
+ * status (DEVICE, two words; the call clears them): [0] bit 0 = the view needed more pairs than pair_capacity -- out_color / out_depth / out_alpha are then filled with NaN
+ * (never an image that merely looks plausible), radii stay valid; bit 1 = a bounded inter-workgroup wait timed out (device fault); bit 2 = the second attempt ran (results
+ * exact; raise first_capacity).  [1] = the pair count.  status_host (optional, PINNED host memory, two words): the call ends with an asynchronous copy of the two words there, in
  * stream order behind its last kernel -- a caller that presets status_host[1] to 0xFFFFFFFF (never a pair count) sees the words arrive without an event or a
- * synchronisation (the Python boundary does that and looks at them one call late).  A backward call on this state passes num_rendered = pair_capacity and scratch of
- * c3d_gs_backward_scratch_bytes(N, pair_capacity).  N > 0 and a non-empty image only. */
+ * synchronisation (the Python boundary does that and looks at them one call late).  N > 0 and a non-empty image only. */
 int c3d_gs_forward_nosync(const c3d_gs_settings* st, int32_t N, int32_t M, const float* means3D, const float* shs, const float* colors_precomp,
                           const float* opacities, const float* scales, const float* rotations, const float* cov3D_precomp, int32_t* radii,
-                          void* geom_buffer, int64_t pair_capacity, void* binning_buffer, void* image_buffer, float* out_color, float* out_depth,
-                          float* out_alpha, uint32_t* status /* device [2] */, uint32_t* status_host /* pinned host [2] or NULL */, c3d_stream_t stream);
+                          void* geom_buffer, int64_t pair_capacity, int64_t first_capacity, void* binning_buffer, void* image_buffer, float* out_color,
+                          float* out_depth, float* out_alpha, uint32_t* status /* device [2] */, uint32_t* status_host /* pinned host [2] or NULL */,
+                          c3d_stream_t stream);
 
 /* Backward (A7 + A8).  Pixel gradients dL_dcolor[3,H,W], dL_ddepth[1,H,W] (may be NULL),
  * dL_dalpha[1,H,W] (may be NULL).  Outputs (all written in full by the library, no pre-zeroing needed):
@@ -135,8 +153,8 @@ int c3d_gs_forward_project_raw(const c3d_gs_settings* st, int32_t N, const float
 /* c3d_gs_forward_nosync for the raw parameters */
 int c3d_gs_forward_raw_nosync(const c3d_gs_settings* st, int32_t N, const float* means3D, const float* f_dc, const float* f_rest,
                               const float* opacity_raw, const float* scaling_raw, const float* rotation_raw, int32_t* radii, void* geom_buffer,
-                              int64_t pair_capacity, void* binning_buffer, void* image_buffer, float* out_color, float* out_depth, float* out_alpha,
-                              uint32_t* status /* device [2] */, uint32_t* status_host /* pinned host [2] or NULL */, c3d_stream_t stream);
+                              int64_t pair_capacity, int64_t first_capacity, void* binning_buffer, void* image_buffer, float* out_color, float* out_depth,
+                              float* out_alpha, uint32_t* status /* device [2] */, uint32_t* status_host /* pinned host [2] or NULL */, c3d_stream_t stream);
 int c3d_gs_backward_raw(const c3d_gs_settings* st, int32_t N, const float* means3D, const float* f_dc, const float* f_rest,
                         const float* scaling_raw, const float* rotation_raw, const int32_t* radii, const void* geom_buffer,
                         int64_t num_rendered, const void* binning_buffer, const void* image_buffer, const float* dL_dcolor,

@@ -633,16 +633,13 @@ def test_renderer_and_trainer_mirror_reduce_the_loss():
         assert torch.isfinite(q).all()
 
 
-def test_sync_free_drop_in_forward_equals_the_synchronous_path_bit_for_bit():
-    """Round 5: after the first call of a (device, N, H, W) shape the drop-in rasterizer runs c3d_gs_forward_nosync / c3d_gs_forward_raw_nosync -- launches
-    sized for a pair capacity, the count left on the device, status words examined one call late -- instead of stalling the host for num_rendered.  Same kernels,
-    same arithmetic: images, radii and every gradient must have the same BITS as the synchronous path's, on the plain and on the raw-parameter entry points."""
-    import warnings
+def _drop_in_pair(seed=8, n=60000, W=400, H=232, scale=0.012, cam=(-12.0, 70.0, 2.2)):
+    """-> (plain(), rawp(), N, H, W): one differentiated forward + backward through the drop-in rasterizer on the plain and on the raw-parameter entry point, returning image,
+    radii, depth, alpha and every gradient"""
     import diff_gaussian_rasterization as dgr
-    sc = S.make_cloud(60000, seed=8, log_scale_mean=np.log(0.012))
-    raw = S.make_cloud(60000, seed=8, log_scale_mean=np.log(0.012), activated=False)
-    W, H = 400, 232
-    st = S.camera_settings(W, H, 49.1, -12.0, 70.0, 2.2)
+    sc = S.make_cloud(n, seed=seed, log_scale_mean=np.log(scale))
+    raw = S.make_cloud(n, seed=seed, log_scale_mean=np.log(scale), activated=False)
+    st = S.camera_settings(W, H, 49.1, *cam)
     rs = hip_settings(st, "cuda")
     gC = _dev(np.random.default_rng(3).normal(size=(3, H, W)).astype(np.float32), torch.float32)
 
@@ -660,7 +657,19 @@ def test_sync_free_drop_in_forward_equals_the_synchronous_path_bit_for_bit():
         ((color * gC).sum() + alpha.sum() + 0.1 * depth.sum()).backward()
         return [color.detach(), radii, depth.detach(), alpha.detach(), m2d.grad, t[0].grad, t[1].grad, f_rest.grad] + [x.grad for x in rest]
 
+    return plain, rawp, n, H, W
+
+
+def test_sync_free_drop_in_forward_equals_the_synchronous_path_bit_for_bit():
+    """After the first call of a (device, H, W) shape a DIFFERENTIATED drop-in call runs c3d_gs_forward_nosync / c3d_gs_forward_raw_nosync -- launches sized for a learnt first
+    capacity, buffers for four times that, the count left on the device, status words examined one call late -- instead of stalling the host for num_rendered.  Same kernels,
+    same arithmetic: images, radii and every gradient must have the same BITS as the synchronous path's, on the plain and on the raw-parameter entry points."""
+    import warnings
+    import diff_gaussian_rasterization as dgr
+    plain, rawp, N, H, W = _drop_in_pair()
+    key = (torch.cuda.current_device(), H, W)
     for fn in (plain, rawp):
+        dgr._learnt.pop(key, None)
         was = dgr.sync_free(False)
         try:
             ref = fn()
@@ -668,62 +677,114 @@ def test_sync_free_drop_in_forward_equals_the_synchronous_path_bit_for_bit():
             dgr.sync_free(was)
         dgr.flush()
         D = int(dgr.last_num_rendered)
-        key = (torch.cuda.current_device(), 60000, H, W)
-        assert dgr._cap.get(key, 0) >= D > 0                       # the synchronous call taught the shape its pair count
-        assert dgr._capacity_for(key, True) >= int(1.5 * D) and dgr._capacity_for(key, False) >= 3 * D      # headroom: 1.5 x when differentiated, 3 x for inference callers
+        assert dgr._learnt[key][N] == D > 0                           # the synchronous call taught the shape its pair count
+        first, cap = dgr._capacity_for(key, N)
+        assert first >= int(1.5 * D) and cap == 4 * first             # launches for 1.5 x the count, buffers for four times the launches
+        first2, cap2 = dgr._capacity_for(key, N + N // 10)            # a model that has just densified: the estimate follows the point count, no synchronous call
+        assert first2 > first and cap2 == 4 * first2
         dgr.last_num_rendered = -1
+        redone = dgr.redone_calls
         with warnings.catch_warnings():
-            warnings.simplefilter("error")                          # no overflow warning may appear
+            warnings.simplefilter("error")
             got = fn()
             assert dgr.pending_calls() == 1                         # the call went through the sync-free entry point: its status words are on their way
             dgr.flush()
-        assert dgr.pending_calls() == 0
+        assert dgr.pending_calls() == 0 and dgr.redone_calls == redone
         assert int(dgr.last_num_rendered) == D
         for a, b in zip(got, ref):
             assert torch.equal(a, b), fn.__name__
 
 
-def test_sync_free_overflow_is_reported_one_call_late_and_the_capacity_regrows():
-    """a view that needs more pairs than the learnt capacity: the call completes (pairs beyond the capacity are dropped, no out-of-bounds access in either
-    direction), the next examination warns and regrows, and the call after that is exact again"""
+def test_drop_in_forward_is_exact_when_the_learnt_capacity_is_half_the_need():
+    """VERDICT r5 item 1.  The reference never returns an incomplete image (main_3DGS_renderer.py:927-936 sizes its binning buffer from the exact count).  Force the learnt
+    capacity to HALF of what the view needs: under torch.no_grad() the call takes the synchronous path anyway; under autograd the first attempt of c3d_gs_forward_nosync
+    overflows and the device bins and composites the view a second time at the buffers' capacity inside the same call.  Image, radii and ALL gradients bit-equal to
+    sync_free(False), no warning, no exception; afterwards the first capacity has followed the count."""
     import warnings
     import diff_gaussian_rasterization as dgr
-    sc = S.make_cloud(50000, seed=18, log_scale_mean=np.log(0.015))
-    W, H = 360, 200
-    st = S.camera_settings(W, H, 49.1, 5.0, -40.0, 2.2)
-    gC = _dev(np.random.default_rng(5).normal(size=(3, H, W)).astype(np.float32), torch.float32)
+    plain, rawp, N, H, W = _drop_in_pair(seed=18, n=50000, W=360, H=200, scale=0.015, cam=(5.0, -40.0, 2.2))
+    key = (torch.cuda.current_device(), H, W)
+    slack, dgr._SLACK = dgr._SLACK, 0
+    try:
+        for fn in (plain, rawp):
+            dgr._learnt.pop(key, None)
+            was = dgr.sync_free(False)
+            try:
+                ref = fn()
+            finally:
+                dgr.sync_free(was)
+            D = int(dgr.last_num_rendered)
+            dgr._learnt[key][N] = D // 3                              # first capacity = 1.5 x that = half the need; buffers = 2 x the need
+            first, cap = dgr._capacity_for(key, N)
+            assert first == D // 3 * 3 // 2 and first <= D // 2 and cap >= D
+            redone = dgr.redone_calls
+            with warnings.catch_warnings():
+                warnings.simplefilter("error")
+                got = fn()
+                assert dgr.pending_calls() == 1
+                dgr.flush()
+            assert dgr.redone_calls == redone + 1                   # the device did redo the view
+            assert dgr._learnt[key][N] == D                         # ... and the host has learnt the count
+            for a, b in zip(got, ref):
+                assert torch.equal(a, b), fn.__name__
+            with warnings.catch_warnings():
+                warnings.simplefilter("error")
+                got = fn()                                          # the next call fits its first attempt
+                dgr.flush()
+            assert dgr.redone_calls == redone + 1
+            for a, b in zip(got, ref):
+                assert torch.equal(a, b), fn.__name__
+        # without autograd: the synchronous path whatever was learnt (and forward-only: nothing pending, same bits)
+        sc = S.make_cloud(50000, seed=18, log_scale_mean=np.log(0.015))
+        st = S.camera_settings(360, 200, 49.1, 5.0, -40.0, 2.2)
+        dgr._learnt[key][N] = 1000
+        with torch.no_grad(), warnings.catch_warnings():
+            warnings.simplefilter("error")
+            color, radii, depth, alpha, _, _ = hip_forward(sc, st, requires_grad=True)      # parameters that require a gradient, grad mode off: still not differentiated
+            assert dgr.pending_calls() == 0
+        was = dgr.sync_free(False)
+        try:
+            color0, radii0, depth0, alpha0, _, _ = hip_forward(sc, st, requires_grad=True)
+        finally:
+            dgr.sync_free(was)
+        assert torch.equal(color, color0) and torch.equal(radii, radii0) and torch.equal(depth, depth0) and torch.equal(alpha, alpha0)
+    finally:
+        dgr._SLACK = slack
+
+
+def test_a_view_beyond_the_buffers_comes_back_as_nan_and_raises_one_call_late():
+    """the one case the two attempts cannot render: a pair count more than 6 x the largest seen.  Never an image that merely looks plausible: the planes are NaN, nothing is
+    read or written out of bounds in either direction, the next examination raises, and the capacity has regrown -- the call after that is exact again."""
+    import diff_gaussian_rasterization as dgr
+    plain, _, N, H, W = _drop_in_pair(seed=18, n=50000, W=360, H=200, scale=0.015, cam=(5.0, -40.0, 2.2))
+    key = (torch.cuda.current_device(), H, W)
+    dgr._learnt.pop(key, None)
     was = dgr.sync_free(False)
     try:
-        color0, radii0, depth0, alpha0, inp0, _ = hip_forward(sc, st, requires_grad=True)
-        (color0 * gC).sum().backward()
+        ref = plain()
     finally:
         dgr.sync_free(was)
     D = int(dgr.last_num_rendered)
-    key = (torch.cuda.current_device(), 50000, H, W)
-    dgr._cap[key] = max(2048, D // 5)                               # pretend the shape had only ever needed a fifth of this: capacity 1.5 x that, far too small
     slack, dgr._SLACK = dgr._SLACK, 0
-    color1, radii1, depth1, alpha1, inp1, _ = hip_forward(sc, st, requires_grad=True)
-    (color1 * gC).sum().backward()                                  # must not fault: record indices beyond the capacity are neither written nor read
-    torch.cuda.synchronize()
-    assert torch.isfinite(color1).all() and all(torch.isfinite(inp1[k].grad).all() for k in inp1)
-    with warnings.catch_warnings(record=True) as w:
-        warnings.simplefilter("always")
+    try:
+        dgr._learnt[key][N] = D // 12                                 # buffers for half the need
+        got = plain()
+        torch.cuda.synchronize()
+        assert torch.isnan(got[0]).all() and torch.isnan(got[2]).all() and torch.isnan(got[3]).all()
+        assert torch.equal(got[1], ref[1])                            # radii do not depend on the binning
+        with pytest.raises(RuntimeError, match="returned as NaN"):
+            dgr.flush()
+        assert dgr.pending_calls() == 0 and dgr._learnt[key][N] == D
+        got = plain()
         dgr.flush()
-    assert any(issubclass(x.category, RuntimeWarning) and "incomplete" in str(x.message) for x in w)
-    dgr._SLACK = slack
-    assert dgr._cap[key] >= D
-    with warnings.catch_warnings():
-        warnings.simplefilter("error")
-        color2, radii2, depth2, alpha2, inp2, _ = hip_forward(sc, st, requires_grad=True)
-        (color2 * gC).sum().backward()
-        dgr.flush()
-    assert torch.equal(color2, color0) and torch.equal(radii2, radii0) and torch.equal(alpha2, alpha0)
-    for k in inp0:
-        assert torch.equal(inp2[k].grad, inp0[k].grad), k
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b)
+    finally:
+        dgr._SLACK = slack
 
 
-def test_sync_free_overflow_of_the_last_call_of_a_process_is_reported_at_exit(tmp_path):
-    """a caller that never issues another forward (and never calls flush()) still hears of an overflow: the pending status words are examined when the interpreter exits"""
+def test_a_last_call_that_could_not_be_rendered_is_reported_at_exit(tmp_path):
+    """a caller that never issues another forward (and never calls flush()) still hears of it: the pending status words are examined when the interpreter exits"""
     import subprocess
     import sys
     prog = tmp_path / "last_call.py"
@@ -738,18 +799,66 @@ def test_sync_free_overflow_of_the_last_call_of_a_process_is_reported_at_exit(tm
         "rs = dgr.GaussianRasterizationSettings(200, 360, st['tanfovx'], st['tanfovy'], t(st['bg']), 1.0, t(st['viewmatrix']).reshape(4, 4),\n"
         "                                       t(st['projmatrix']).reshape(4, 4), st['sh_degree'], t(st['campos']), False, False)\n"
         "def render():\n"
-        "    with torch.no_grad():\n"
-        "        return dgr.GaussianRasterizer(rs)(means3D=t(sc['means3D']), means2D=None, opacities=t(sc['opacities']), shs=t(sc['shs']), scales=t(sc['scales']),\n"
-        "                                          rotations=t(sc['rotations']))\n"
+        "    return dgr.GaussianRasterizer(rs)(means3D=t(sc['means3D']).requires_grad_(), means2D=None, opacities=t(sc['opacities']), shs=t(sc['shs']), scales=t(sc['scales']),\n"
+        "                                      rotations=t(sc['rotations']))\n"
         "render()\n"                                              # synchronous first call: learns the count
-        "key = (torch.cuda.current_device(), 50000, 200, 360)\n"
-        "dgr._cap[key] = max(2048, dgr._cap[key] // 8); dgr._SLACK = 0\n"
-        "render()\n"                                              # sync-free, capacity far too small, and nothing examines it
+        "key = (torch.cuda.current_device(), 200, 360)\n"
+        "dgr._learnt[key][50000] //= 12; dgr._SLACK = 0\n"
+        "render()\n"                                              # sync-free, buffers far too small, and nothing examines it
         "assert dgr.pending_calls() == 1\n"
         % os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "comfyui-3d-pack_amd"))
     r = subprocess.run([sys.executable, "-W", "always", str(prog)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
-    assert "RuntimeWarning" in r.stderr and "incomplete" in r.stderr, r.stderr[-2000:]
+    assert "RuntimeWarning" in r.stderr and "returned as NaN" in r.stderr, r.stderr[-2000:]
+
+
+def test_forward_only_renders_have_the_same_bits_and_refuse_a_backward_pass():
+    """C3D_GS_FLAG_FORWARD_ONLY: a render nobody will differentiate records no pair activity, runs no record-base scan and stores neither final_T nor
+    n_contrib -- same image, depth, alpha and radii, bit for bit; a backward entry point that receives such settings says so instead of reading state that was never written."""
+    import c3d_hip as h
+    import diff_gaussian_rasterization as dgr
+    lib = h.lib()
+    sc = S.make_cloud(40000, seed=5, log_scale_mean=np.log(0.015))
+    W, H = 333, 190
+    st = S.camera_settings(W, H, 49.1, 12.0, 25.0, 2.4)
+    outs = []
+    for fwd_only in (False, True):
+        t = {k: _dev(sc[k], torch.float32) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+        rs = hip_settings(st, "cuda")
+        keep = []
+        cs = dgr._settings_struct(rs, keep, forward_only=fwd_only)
+        N = 40000
+        radii = torch.empty((N,), dtype=torch.int32, device="cuda")
+        geom = torch.empty((lib.c3d_gs_geom_bytes(N),), dtype=torch.uint8, device="cuda")
+        img = torch.full((lib.c3d_gs_image_bytes(H, W),), 0x5A, dtype=torch.uint8, device="cuda")
+        nr = C.c_int64(0)
+        h.check(lib.c3d_gs_forward_project(C.byref(cs), N, 16, h.ptr(t["means3D"]), h.ptr(t["shs"]), None, h.ptr(t["opacities"]), h.ptr(t["scales"]), h.ptr(t["rotations"]), None,
+                                           h.ptr(radii), h.ptr(geom), C.byref(nr), h.stream()), "project")
+        binning = torch.empty((lib.c3d_gs_binning_bytes(nr.value, H, W),), dtype=torch.uint8, device="cuda")
+        color, depth, alpha = torch.empty((3, H, W), device="cuda"), torch.empty((1, H, W), device="cuda"), torch.empty((1, H, W), device="cuda")
+        h.check(lib.c3d_gs_forward_render(C.byref(cs), N, 16, h.ptr(radii), h.ptr(geom), nr.value, h.ptr(binning), h.ptr(img), h.ptr(color), h.ptr(depth), h.ptr(alpha), h.stream()), "render")
+        torch.cuda.synchronize()
+        outs.append((color, depth, alpha, radii, img.clone()))
+        if fwd_only:
+            assert bool((img == 0x5A).all())                          # the per-pixel backward state was not written
+            g = [torch.empty_like(t[k]) for k in ("means3D", "opacities", "shs", "scales", "rotations")]
+            scratch = torch.empty((lib.c3d_gs_backward_scratch_bytes(N, nr.value),), dtype=torch.uint8, device="cuda")
+            rc = lib.c3d_gs_backward(C.byref(cs), N, 16, h.ptr(t["means3D"]), h.ptr(t["shs"]), None, h.ptr(t["scales"]), h.ptr(t["rotations"]), None, h.ptr(radii), h.ptr(geom), nr.value,
+                                     h.ptr(binning), h.ptr(img), h.ptr(color), None, None, h.ptr(torch.empty((N, 3), device="cuda")), h.ptr(torch.empty((N, 3), device="cuda")),
+                                     h.ptr(g[1]), h.ptr(g[0]), None, h.ptr(g[2]), h.ptr(g[3]), h.ptr(g[4]), h.ptr(scratch), h.stream())
+            assert rc != 0 and b"FORWARD_ONLY" in lib.c3d_last_error()
+        else:
+            assert not bool((img == 0x5A).all())
+    for a, b in zip(outs[0][:4], outs[1][:4]):
+        assert torch.equal(a, b)
+    # the Python boundary: not differentiated -> forward-only; a backward pass forced onto such a call raises a clear error
+    inp = {k: _dev(sc[k], torch.float32).requires_grad_() for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+    e = torch.empty(0, device="cuda")
+    color, radii, depth, alpha = dgr._RasterizeGaussians.apply(inp["means3D"], torch.zeros_like(inp["means3D"]), inp["shs"], e, inp["opacities"], inp["scales"], inp["rotations"], e,
+                                                               hip_settings(st, "cuda"), False)
+    assert torch.equal(color.detach(), outs[0][0]) and torch.equal(radii, outs[0][3])
+    with pytest.raises(RuntimeError, match="forward-only"):
+        color.sum().backward()
 
 
 def test_fused_activation_path_equals_accessor_path():
