@@ -68,8 +68,10 @@ def parse():
     ap.add_argument("--lanes", type=int, default=0, help="view GROUPS a fused call splits its views into (ceil(views / lanes) views per launch of every stage, the groups one after the "
                                                        "other on the same stream; the library owns no streams); 0 = 1: all views of the step through every stage in ONE launch each, in every mode")
     ap.add_argument("--group", type=int, default=16, help="--mode fwd: views per launch of every stage (<= 16)")
-    ap.add_argument("--sync-free", choices=["on", "off"], default="on", help="--render-path boundary | fused | accessor: the drop-in rasterizer call without its host round trip "
-                                                                             "(diff_gaussian_rasterization.sync_free; off = the wheel's behaviour: the pair count read back once per view)")
+    ap.add_argument("--sync-free", choices=["on", "verified", "unverified", "off"], default="on",
+                    help="--render-path boundary | fused | accessor: how the drop-in rasterizer call learns its pair count (diff_gaussian_rasterization.sync_free).  on = verified (product "
+                         "default): the whole forward enqueued at once, the host waits for the count word only and renders a view that did not fit again -- always exact; unverified: no "
+                         "wait at all; off = the wheel's behaviour: project, read the count back, enqueue the second half")
     ap.add_argument("--forward-only", choices=["on", "off"], default="on", help="--render-path boundary | fused | accessor, calls that are not differentiated (--mode fwd): render with "
                                                                                 "C3D_GS_FLAG_FORWARD_ONLY (no pair-activity record, no record-base scan, no final_T / n_contrib stores); off = the A/B partner")
     ap.add_argument("--inference-mode", choices=["on", "off"], default="off", help="--mode fwd on the drop-in API: run the steps under torch.inference_mode() (an inference caller)")
@@ -220,7 +222,7 @@ def main_ref_default(a, world, rank, dev, dist):
     print(json.dumps(out))
 
 
-def main_mesh(a, world, rank, dev, dist):
+def main_mesh(a, world, rank, dev, dist, emit=True):
     """BASELINE config 5: 499,000-triangle displaced lat-long sphere, 1024^2 albedo, 1024x1024, 32 cameras (elev {-20,20} x 16
     azimuths, radius 2.0); one step = `--views-per-gpu` views of DiffRastRenderer.render forward + backward w.r.t. raw_albedo
     and v_offsets (rasterize + 2x antialias + 3x interpolate + texture + the torch elementwise ops around them)."""
@@ -371,8 +373,9 @@ def main_mesh(a, world, rank, dev, dist):
     cpu = None
     if rank == 0 and world == 1 and a.cpu_baseline != "off":
         cpu = mesh_cpu_baseline(v, f, vt, H, W)
+    line = None
     if rank == 0:
-        print(json.dumps({"metric": "Mpixels/s DiffRastMesh forward+backward @500k triangles 1024x1024", "value": round(a.views_per_gpu * world * a.steps * P / dt / 1e6, 2),
+        line = ({"metric": "Mpixels/s DiffRastMesh forward+backward @500k triangles 1024x1024", "value": round(a.views_per_gpu * world * a.steps * P / dt / 1e6, 2),
                           "unit": "Mpixels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                           "config": {"workload": "DiffRastMesh fwd+bwd, %d-triangle displaced sphere, 1024^2 albedo, 1024x1024, %d views/GPU/step" % (T, a.views_per_gpu),
@@ -380,9 +383,12 @@ def main_mesh(a, world, rank, dev, dist):
                                      "parallelism": "view-parallel dp%d" % world, "host_enqueue_ms_per_step": round(t_enq / a.steps * 1e3, 3),
                                      "dist_backend": (dist.get_backend() if dist is not None else None), "rccl_ranks": (dist.get_world_size() if dist is not None else 1)},
                           "roofline": roof_kernel or roof, "roofline_group": (roof if roof_kernel else None), "roofline_chain": chain, "cpu_baseline": cpu, "kernels": kern,
-                          "code_digest": code_digest()}))
-    if world > 1:
+                          "code_digest": code_digest()})
+        if emit:
+            print(json.dumps(line))
+    if world > 1 and emit:
         dist.destroy_process_group()
+    return line
 
 
 def mesh_cpu_baseline(v, f, vt, H, W):
@@ -469,7 +475,7 @@ def main():
 
     if a.lanes <= 0:
         a.lanes = 1
-    dgr.sync_free(a.sync_free == "on")
+    dgr.sync_free({"on": "verified", "off": False}.get(a.sync_free, a.sync_free))
     dgr.forward_only(a.forward_only == "on")
     N, W, H, deg = a.gaussians, a.width, a.height, a.sh_degree
     K, P = (deg + 1) ** 2, a.width * a.height
@@ -551,7 +557,8 @@ def main():
         fused_step = FusedViewStep(N, H, W, dev, lanes=a.lanes, views=len(settings))
         fused_step.time_events = True
         fused_step.defer_status = a.defer_status == "on"
-        from c3d_hip.parallel import FlatGrads
+        from c3d_hip.parallel import FlatGrads, status_max
+        fused_step.status_sync = status_max(None) if dist_on else None      # N > 1: every rank decides about a step (fit, regrow, redo) from the same status words
         flat_grads = FlatGrads(plist) if zero is None else None        # one buffer: the kernels write into what the collective sends
         step_grads = flat_grads.views if zero is None else zero.grads
         for q, gq in zip(plist, step_grads):
@@ -695,7 +702,16 @@ def main():
             fused_step = keep_obj
         else:
             view_render = keep_obj
+    per_rank = None
     if dist_on:
+        # every rank's own step time and pair counts into the one line: rank r renders one elevation band of the orbit, the step is as slow as the slowest band
+        mine_ = torch.tensor([dt / a.steps * 1e3, float(np.mean(stats["D"])) if stats["D"] else 0.0, float(np.mean(stats["n_vis"])) if stats["n_vis"] else 0.0], device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine_) for _ in range(dist.get_world_size())]
+        dist.all_gather(allr, mine_)
+        rows = [x.tolist() for x in allr]
+        per_rank = {"ms_per_step": [round(r_[0], 3) for r_ in rows], "ms_per_step_min": round(min(r_[0] for r_ in rows), 3), "ms_per_step_max": round(max(r_[0] for r_ in rows), 3),
+                    "tile_splat_pairs_per_view": [int(r_[1]) for r_ in rows], "n_visible_per_view": [int(r_[2]) for r_ in rows],
+                    "views": ["rank %d: orbit cameras %s" % (r_, [(rank_pose[1], rank_pose[2]) for rank_pose in [poses[(r_ * a.views_per_gpu + i) % len(poses)] for i in range(a.views_per_gpu)]][:2] + ["..."]) for r_ in range(dist.get_world_size())]}
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -857,7 +873,9 @@ def main():
 
     # north-star target carried into THIS line: ">= 60 % of MI355X HBM roofline on 1M-Gaussian 1080p forward raster" is a statement about
     # BASELINE config 2 -- forward only, the 64 orbit cameras.  Run it here, after the timed region, so that the driver's record holds the number.
-    targets = None
+    targets_out = None
+    host_ms_timed = (round(fused_step.last_host_ms, 3) if fused_step is not None else round(t_enqueue / a.steps * 1e3, 3))      # (the extra passes below run more steps)
+    gpu_span_timed = (round(getattr(fused_step, "last_gpu_ms", 0.0), 3) if fused_step is not None else None)
     if rank == 0 and world == 1 and a.mode != "fwd" and a.targets == "on" and use_renderer and a.render_path == "step":
         try:
             from c3d_hip.gs_step import FusedViewRender
@@ -877,13 +895,45 @@ def main():
                 torch.cuda.synchronize(dev)
                 tf = (time.perf_counter() - t1) / 3
             pv = tf / len(all_settings)
-            targets = {"what": "BASELINE config 2 after the timed region: forward only, the 64 orbit cameras in one c3d_gs_render_views_raw call (8 view lanes), 3 passes",
+            targets_out = {"what": "BASELINE config 2 after the timed region: forward only, the 64 orbit cameras in one c3d_gs_render_views_raw call (8 view lanes), 3 passes",
                        "fwd_Mpx": round(len(all_settings) * P / tf / 1e6, 1), "fwd_ms_per_view": round(pv * 1e3, 4),
                        "fwd_chain_frac": round(b_fwd / pv / 1e9 / HBM_PEAK_GBPS, 4), "fwd_chain_GBps": round(b_fwd / pv / 1e9, 1), "fwd_bytes_per_view": int(b_fwd),
                        "target_frac": 0.6, "north_star": ">= 60 % of MI355X HBM roofline on 1M-Gaussian 1080p forward raster (SURVEY 8d algorithmic bytes B_fwd / wall time per view / 8 TB/s)"}
             del vr
         except Exception as ex:      # never take the headline down
-            targets = {"error": repr(ex)}
+            targets_out = {"error": repr(ex)}
+        # BASELINE configs 3 and 5 in the driver's line as well: the same commands as `--mode train` and `--workload mesh`, a few steps each, after the timed region
+        if a.mode == "fwdbwd" and fused_step is not None and a.loss == "auto" and not dist_on:
+            try:
+                from c3d_hip.optim import FusedAdam
+                opt = FusedAdam([{"params": [q], "lr": lr} for q, lr in zip(plist, lr_list)], lr=0.0, eps=1e-15)
+                a.mode, loss_kind = "train", "full"       # (step() reads both: config 3's loss inside the library call + the fused Adam step)
+                for _ in range(3):
+                    step()
+                sync()
+                t1 = time.perf_counter()
+                for _ in range(5):
+                    step()
+                sync()
+                tt = (time.perf_counter() - t1) / 5
+                targets_out.update({"train_what": "BASELINE config 3 after the timed region: 5 steps of `--mode train` (8 views: forward, 0.8 L1 + 3 MSE(alpha) + 0.2 (1 - MS-SSIM) masked, backward, fused Adam)",
+                                "train_Mpx": round(a.views_per_gpu * P / tt / 1e6, 1), "train_ms_per_step": round(tt * 1e3, 3)})
+            except Exception as ex:
+                targets_out["train_error"] = repr(ex)
+            finally:
+                a.mode, loss_kind, opt = "fwdbwd", "l1alpha", None
+                for q in plist:
+                    q.grad = None
+            try:
+                import copy
+                am = copy.copy(a)
+                am.workload, am.steps, am.warmup, am.cpu_baseline, am.views_per_gpu, am.render_path = "mesh", 10, 3, "off", 8, "step"
+                ml = main_mesh(am, 1, 0, dev, None, emit=False)
+                targets_out.update({"mesh_what": "BASELINE config 5 after the timed region: 10 steps of `--workload mesh` (499k triangles, 1024x1024, 8 views per step, forward + backward)",
+                                "mesh_Mpx": ml["value"], "mesh_ms_per_step": ml["ms_per_step"], "mesh_chain_frac": (ml["roofline_chain"] or {}).get("frac"),
+                                "mesh_dominant_kernel": {k: (ml["roofline"] or {}).get(k) for k in ("kernel", "avg_ms", "frac", "traffic")}})
+            except Exception as ex:
+                targets_out["mesh_error"] = repr(ex)
 
     if rank == 0:
         out = {
@@ -896,19 +946,20 @@ def main():
                                    % (a.mode, N, deg, W, H, a.views_per_gpu),
                        "global_views_per_step": a.views_per_gpu * world, "parallelism": "view-parallel dp%d" % world,
                        "exchange": (a.exchange if dist_on and a.mode != "fwd" else "none"), "dist_backend": (dist.get_backend() if dist_on else None),
-                       "rccl_ranks": (dist.get_world_size() if dist_on else 1),
+                       "rccl_ranks": (dist.get_world_size() if dist_on else 1), "per_rank": per_rank,
                        "exchange_chunks": (a.exchange_chunks if dist_on and a.mode != "fwd" and a.exchange == "allreduce" and fused_step is not None else 1), "render_path": a.render_path,
                        "loss": (None if a.mode == "fwd" else ("0.8 L1 + 3 MSE(alpha) + 0.2 (1 - MS-SSIM), masked (BASELINE config 3)%s" % (", MS-SSIM by torch ops" if ms_ssim is not None else ", fused HIP")
                                                                 if loss_kind != "l1alpha" and a.render_path == "step" else "0.8 L1 + 3 MSE(alpha)")), "view_lanes": (a.lanes if a.render_path == "step" else 1),
-                       "host_enqueue_ms_per_step": (round(fused_step.last_host_ms, 3) if fused_step is not None else round(t_enqueue / a.steps * 1e3, 3)),
-                       "sync_free_drop_in": (a.sync_free == "on") if a.render_path != "step" else None,
+                       "host_enqueue_ms_per_step": host_ms_timed,
+                       "sync_free_drop_in": ({"on": "verified", "off": False}.get(a.sync_free, a.sync_free)) if a.render_path != "step" else None,
                        "forward_only_flag": (a.forward_only == "on") if (a.render_path != "step" and a.mode == "fwd") else None,
                        "inference_mode": (a.inference_mode == "on") if a.render_path != "step" else None,
-                       "drop_in_calls_redone_on_device": int(dgr.redone_calls) if a.render_path != "step" else None,
+                       "drop_in_calls_rendered_twice": int(dgr.redone_calls) if a.render_path != "step" else None,
+                       "drop_in_calls_beyond_launch_hint": int(dgr.beyond_hint_calls) if a.render_path != "step" else None,
                        "defer_status": (fused_step.defer_status if fused_step is not None else None),
-                       "gpu_span_ms_last_step": (round(getattr(fused_step, "last_gpu_ms", 0.0), 3) if fused_step is not None else None),
+                       "gpu_span_ms_last_step": gpu_span_timed,
                        "n_visible": n_vis, "tile_splat_pairs": D},
-            "roofline": roof, "roofline_chain": chain, "targets": targets, "cpu_baseline": cpu, "kernels": kern, "kernels_concurrent_avg_ms": kern_conc,
+            "roofline": roof, "roofline_chain": chain, "targets": targets_out, "cpu_baseline": cpu, "kernels": kern, "kernels_concurrent_avg_ms": kern_conc,
             "code_digest": code_digest(),
         }
         print(json.dumps(out))

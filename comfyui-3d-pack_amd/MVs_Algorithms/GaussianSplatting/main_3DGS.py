@@ -242,6 +242,7 @@ class GaussianSplatting3D:
         if self._step is None:
             self._step = FusedViewStep(self.params[0].shape[0], H, W, self.device)
             self._step.defer_status = self.defer_step_status
+            self._step.status_sync = parallel.status_max(self.group) if world > 1 else None      # every rank decides about a step (fit, regrow, redo) from the same status words
             if self.exchange == "zero1":
                 self._flat_grads, self._step_grads = None, self._zero_adam().grads      # the kernels write into what the all-to-all sends
             else:

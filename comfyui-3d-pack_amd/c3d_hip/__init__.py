@@ -30,6 +30,7 @@ class GsSettings(C.Structure):
 
 GS_FLAG_EXACT_DSCALE = 1      # C3D_GS_FLAG_EXACT_DSCALE
 GS_FLAG_FORWARD_ONLY = 2      # C3D_GS_FLAG_FORWARD_ONLY
+GS_FLAG_KEEP_RECORD_BASES = 4      # C3D_GS_FLAG_KEEP_RECORD_BASES
 
 
 class GsLoss(C.Structure):
@@ -55,8 +56,9 @@ _SIGNATURES = {
     "c3d_gs_backward_scratch_bytes": (sz, [i32, i64]),
     "c3d_gs_forward_project": (C.c_int, [C.POINTER(GsSettings), i32, i32] + [vp] * 7 + [vp, vp, C.POINTER(i64), vp]),
     "c3d_gs_forward_render": (C.c_int, [C.POINTER(GsSettings), i32, i32, vp, vp, i64, vp, vp, vp, vp, vp, vp]),
-    "c3d_gs_forward_nosync": (C.c_int, [C.POINTER(GsSettings), i32, i32] + [vp] * 7 + [vp, vp, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp]),
-    "c3d_gs_forward_raw_nosync": (C.c_int, [C.POINTER(GsSettings), i32] + [vp] * 6 + [vp, vp, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "c3d_gs_forward_nosync": (C.c_int, [C.POINTER(GsSettings), i32, i32] + [vp] * 7 + [vp, vp, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "c3d_gs_forward_raw_nosync": (C.c_int, [C.POINTER(GsSettings), i32] + [vp] * 6 + [vp, vp, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "c3d_gs_wait_count": (C.c_int, [vp, C.c_uint32, i64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "c3d_gs_backward": (C.c_int, [C.POINTER(GsSettings), i32, i32] + [vp] * 6 + [vp, vp, i64, vp, vp] + [vp] * 3 + [vp] * 8 + [vp, vp]),
     "c3d_gs_forward_project_raw": (C.c_int, [C.POINTER(GsSettings), i32] + [vp] * 6 + [vp, vp, C.POINTER(i64), vp]),
     "c3d_gs_backward_raw": (C.c_int, [C.POINTER(GsSettings), i32] + [vp] * 5 + [vp, vp, i64, vp, vp] + [vp] * 3 + [vp] * 7 + [vp, i32, vp]),

@@ -39,6 +39,9 @@ class FusedViewStep:
         # the largest pair count of the step), it is regrown to 1.3 x that count BEFORE the next step -- splat footprints that grow gradually over a run
         # never reach the limit; only a jump of > 25 % between two consecutive steps can still overflow.  Off by default; the trainer and bench.py turn it on.
         self.defer_status = False
+        # multi-GPU: a callable that replaces three int32 device words by their MAXIMUM over the ranks, in place and in stream order (c3d_hip.parallel.status_max(group)).
+        # Every decision about a step -- fit, regrow, redo -- is then taken from the same numbers on every rank; see run().
+        self.status_sync = None
         self._pending = None
         self._pinned = None
         self._flip = 0
@@ -66,28 +69,50 @@ class FusedViewStep:
             arr[i] = dgr._settings_struct(rs, keep, K)
         return arr
 
+    def _status_words(self):
+        """-> the step's status on the device: this rank's own two words, or as three int32 words {overflow, fault, largest pair count} -- with status_sync set (multi-GPU) -- the maximum over
+        the ranks, so that every rank takes the same decision about the step (and sizes the same capacity)"""
+        st = self.status
+        if self.status_sync is None:
+            return st                     # {flags, count}: decoded on the host (_decode), no extra launch on the single-GPU path
+        words = torch.stack([st[0] & 1, (st[0] >> 1) & 1, st[1]])
+        self.status_sync(words)
+        return words
+
+    @staticmethod
+    def _decode(words):
+        """host copy of _status_words() -> (overflow, fault, largest pair count)"""
+        w = [int(x) for x in words]
+        if len(w) == 2:
+            return w[0] & 1, w[0] & 2, w[1] & 0xFFFFFFFF
+        return w[0], w[1], w[2] & 0xFFFFFFFF
+
     def run(self, raster_settings, params, grads, target_color, target_alpha=None, color_mask=None, w_l1=1.0, w_l2=0.0, w_alpha_mse=0.0, scale=1.0, max_retries=3,
             accumulate=True, w_ssim=0.0, param_chunks=1, after_chunk=None):
         """params / grads: (xyz, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw) tensors; accumulate=True adds to the grads (zero them per
         step), False overwrites them (no zero-fill needed).  -> loss tensor (device scalar, the sum over the views).  Synchronises once, at
-        the end, to read the overflow flag.
+        the end, to read the overflow flag (not at all with defer_status).
         after_chunk(g0, g1): called when the gradient rows [g0, g1) of every tensor have been ENQUEUED in final form on the current stream, for the
         SAME sequence of `param_chunks` ranges on every call (so that ranks which start a collective per range stay in step, whatever their local
         state): with a fitted capacity and accumulate=False the per-Gaussian pass runs range by range and the callback follows each range (the
         multi-GPU trainer starts that range's collective there, underneath the next range's kernels); otherwise -- first step, no views on this
-        rank -- the ranges are handed over one after the other once the whole pass has been enqueued and found good."""
+        rank -- the ranges are handed over one after the other once the whole pass has been enqueued and found good.
+        Multi-GPU (status_sync set): the status words every decision below is taken from are the MAXIMUM over the ranks, so a view that exceeds the pair capacity on one rank
+        makes ALL ranks regrow and redo the step together (the ranges' collectives are then issued a second time, by everybody) instead of raising on that rank and
+        leaving the others in a collective nobody will join."""
         lib = _h.lib()
         V = len(raster_settings)
         K = max(1, int(param_chunks)) if self.N >= 1024 * max(1, int(param_chunks)) else 1
         bounds = [min(self.N, (self.N * i // K + 255) // 256 * 256) for i in range(K)] + [self.N]
         ranges = list(zip(bounds[:-1], bounds[1:]))
+        together = self.status_sync is not None
 
         def hand_over():
             if after_chunk is not None:
                 for g0, g1 in ranges:
                     after_chunk(g0, g1)
         prev, self._pending = self._pending, None      # a deferred previous step: examined AFTER this one is enqueued, so the GPU never waits for the host
-        if V == 0:
+        if V == 0 and not together:
             self._examine(prev)                       # a rank without views this step still owns well-defined gradients
             if not accumulate:
                 for g in grads:
@@ -99,11 +124,12 @@ class FusedViewStep:
             self._alloc()
         for attempt in range(max_retries + 1):
             keep = []
-            views = self._settings(raster_settings, keep, params)
-            tc = (C.c_void_p * V)(*[t.data_ptr() for t in target_color])
-            ta = (C.c_void_p * V)(*[t.data_ptr() for t in target_alpha]) if target_alpha is not None else None
-            cm = (C.c_void_p * V)(*[t.data_ptr() for t in color_mask]) if color_mask is not None else None
-            loss = _h.GsLoss(float(w_l1), float(w_l2), float(w_alpha_mse), float(scale), float(w_ssim))
+            if V:
+                views = self._settings(raster_settings, keep, params)
+                tc = (C.c_void_p * V)(*[t.data_ptr() for t in target_color])
+                ta = (C.c_void_p * V)(*[t.data_ptr() for t in target_alpha]) if target_alpha is not None else None
+                cm = (C.c_void_p * V)(*[t.data_ptr() for t in color_mask]) if color_mask is not None else None
+                loss = _h.GsLoss(float(w_l1), float(w_l2), float(w_alpha_mse), float(scale), float(w_ssim))
             if accumulate:
                 snapshot = [g.clone() for g in grads] if attempt == 0 else snapshot     # to redo the step after an overflow
             self._words.zero_()
@@ -113,25 +139,33 @@ class FusedViewStep:
                 ev0.record(torch.cuda.current_stream(self.device))
             chunked = K > 1 and after_chunk is not None and self._fitted and not accumulate
             self._chunks_went_out = chunked
-            with torch.cuda.device(self.device):
-                pp = [_h.ptr(_h.f32c(p)) for p in params]
-                _h.check(lib.c3d_gs_train_views_raw(views, V, self.N, *pp, tc, ta, cm, C.byref(loss),
-                                                    *[_h.ptr(g) for g in grads], _h.ptr(self.loss), self.capacity, self.lanes, (1 if accumulate else 0) | (2 if chunked else 0),
-                                                    _h.ptr(self.workspace), _h.ptr(self.status), _h.stream(self.device)), "c3d_gs_train_views_raw")
+            if V:
+                with torch.cuda.device(self.device):
+                    pp = [_h.ptr(_h.f32c(p)) for p in params]
+                    _h.check(lib.c3d_gs_train_views_raw(views, V, self.N, *pp, tc, ta, cm, C.byref(loss),
+                                                        *[_h.ptr(g) for g in grads], _h.ptr(self.loss), self.capacity, self.lanes, (1 if accumulate else 0) | (2 if chunked else 0),
+                                                        _h.ptr(self.workspace), _h.ptr(self.status), _h.stream(self.device)), "c3d_gs_train_views_raw")
+                    if chunked:
+                        for g0, g1 in ranges:
+                            _h.check(lib.c3d_gs_step_param_backward_range(views, V, self.N, pp[0], pp[1], pp[2], pp[4], pp[5], *[_h.ptr(g) for g in grads], self.capacity, 0,
+                                                                          _h.ptr(self.workspace), g0, g1 - g0, _h.stream(self.device)), "c3d_gs_step_param_backward_range")
+                            after_chunk(g0, g1)
+            else:      # a rank without views this step (multi-GPU): zero gradients, and the same sequence of range hand-overs at the same point as everybody else
+                if not accumulate:
+                    for g in grads:
+                        g.zero_()
                 if chunked:
-                    for g0, g1 in ranges:
-                        _h.check(lib.c3d_gs_step_param_backward_range(views, V, self.N, pp[0], pp[1], pp[2], pp[4], pp[5], *[_h.ptr(g) for g in grads], self.capacity, 0,
-                                                                      _h.ptr(self.workspace), g0, g1 - g0, _h.stream(self.device)), "c3d_gs_step_param_backward_range")
-                        after_chunk(g0, g1)
+                    hand_over()
             self.last_host_ms = (time.perf_counter() - t_host) * 1e3      # host time to enqueue the whole step (no sync inside)
             if self.time_events:
                 ev1.record(torch.cuda.current_stream(self.device))
+            words = self._status_words()
             if self.defer_status and self._fitted and not accumulate:
                 if self._pinned is None:
-                    self._pinned = [torch.empty((2,), dtype=torch.int32).pin_memory() for _ in range(2)]
+                    self._pinned = [torch.empty((3,), dtype=torch.int32).pin_memory() for _ in range(2)]
                 self._flip ^= 1
-                pin = self._pinned[self._flip]
-                pin.copy_(self.status, non_blocking=True)
+                pin = self._pinned[self._flip][:words.numel()]
+                pin.copy_(words, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream(self.device))
                 self._pending = (ev, (ev0, ev1) if self.time_events else None, pin)
@@ -140,19 +174,18 @@ class FusedViewStep:
                 if prev is not None and not self._examine(prev):
                     prev = None
                     self._pending = None
-                    continue             # the previous step had overflowed (capacity regrown): this one certainly did too -- redo it, synchronously
+                    continue             # the previous step had overflowed (capacity regrown): this one certainly did too -- redo it, synchronously (multi-GPU: on every rank)
                 if not chunked:
                     hand_over()
                 return out
             if prev is not None:
                 self._examine(prev)
                 prev = None
-            st = self.status.tolist()       # the single host sync of the step
+            ovf, fault, seen = self._decode(words.tolist())       # the single host sync of the step
             if self.time_events:
                 self.last_gpu_ms = ev0.elapsed_time(ev1)                  # GPU span of the library call: wall time beyond it is host-side bubble
-            self._raise_on_fault(st)
-            if st[0] == 0:
-                seen = st[1] & 0xFFFFFFFF
+            self._raise_on_fault(fault, seen)
+            if not ovf:
                 self._last = (self.workspace, self.capacity)     # what read_view() looks into
                 if not self._fitted and self.capacity > 1.6 * max(seen, 1 << 16):      # (every launch of the binning chain is sized for the capacity: more than 1.6 x the need is worth one reallocation)
                     # first successful step: every launch is sized for the capacity, so bring it down to what the scene needs (+30 %)
@@ -163,9 +196,9 @@ class FusedViewStep:
                 if not chunked:
                     hand_over()
                 return self.loss.clone()
-            if chunked:
-                raise RuntimeError("c3d FusedViewStep: a step whose gradient ranges had already been handed to after_chunk exceeded the pair capacity (%d pairs)" % (st[1] & 0xFFFFFFFF))
-            self.capacity = int(max(st[1] & 0xFFFFFFFF, self.capacity) * 1.25) + 1024
+            if chunked and not together:
+                raise RuntimeError("c3d FusedViewStep: a step whose gradient ranges had already been handed to after_chunk exceeded the pair capacity (%d pairs)" % seen)
+            self.capacity = int(max(seen, self.capacity) * 1.25) + 1024
             self._alloc()
             if accumulate:
                 for g, s0 in zip(grads, snapshot):
@@ -185,26 +218,25 @@ class FusedViewStep:
         ev.synchronize()
         if tev is not None:
             self.last_gpu_ms = tev[0].elapsed_time(tev[1])
-        st = pin.tolist()
-        self._raise_on_fault(st)
-        if st[0] != 0:
+        ovf, fault, seen = self._decode(pin.tolist())
+        self._raise_on_fault(fault, seen)
+        if ovf:
             import warnings
-            seen = st[1] & 0xFFFFFFFF
             self.capacity = int(max(seen, self.capacity) * 1.25) + 1024
             self._alloc()
-            if self._chunks_went_out:      # a redo would issue the ranges' collectives a second time on this rank only: fail here, not in a hung collective
+            if self._chunks_went_out and self.status_sync is None:      # a redo would issue the ranges' collectives a second time on this rank only: fail here, not in a hung collective
                 raise RuntimeError("c3d FusedViewStep: a step whose gradient ranges had already been handed to after_chunk needed %d (tile, splat) pairs, more "
-                                   "than the fitted capacity; size pair_capacity explicitly for chunked multi-GPU steps" % seen)
+                                   "than the fitted capacity; set status_sync (c3d_hip.parallel.status_max) so that the ranks redo such a step together" % seen)
             warnings.warn("c3d FusedViewStep: the previous step needed %d (tile, splat) pairs, more than the fitted capacity; its gradient was incomplete "
                           "(noticed one step late because defer_status is on); capacity regrown to %d" % (seen, self.capacity), RuntimeWarning)
             return False
-        self._follow(st[1] & 0xFFFFFFFF)
+        self._follow(seen)
         return True
 
     # ---- the step split at the image --------------------------------------------------------------------------------------------------------
-    def _raise_on_fault(self, st):
-        if st[0] & 2:
-            raise RuntimeError("c3d: a bounded inter-workgroup wait of the binning stage timed out (status %r): device fault" % (st,))
+    def _raise_on_fault(self, fault, seen=0):
+        if fault:
+            raise RuntimeError("c3d: a bounded inter-workgroup wait of the binning stage timed out (pair count word %r): device fault" % (seen,))
 
     def forward(self, raster_settings, params, want_depth=False, want_radii=False, max_retries=3):
         """All V views forward, state kept per view for backward().  params: (xyz, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw).
@@ -233,7 +265,7 @@ class FusedViewStep:
                                                       self.lanes, _h.ptr(self.workspace), _h.ptr(self.status), _h.stream(self.device)), "c3d_gs_forward_views_raw")
             self.last_host_ms = (time.perf_counter() - t_host) * 1e3
             st = self.status.tolist()       # the single host sync of the forward half
-            self._raise_on_fault(st)
+            self._raise_on_fault(st[0] & 2, st[1])
             seen = st[1] & 0xFFFFFFFF
             if st[0] == 0:
                 if not self._fitted and self.capacity > 1.6 * max(seen, 1 << 16):      # (every launch of the binning chain is sized for the capacity: more than 1.6 x the need is worth one reallocation)

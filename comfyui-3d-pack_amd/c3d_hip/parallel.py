@@ -175,6 +175,15 @@ class FlatGrads:
             self.flat.mul_(1.0 / world)
 
 
+def status_max(group=None):
+    """-> the `status_sync` of a FusedViewStep whose step ends in a collective: replaces a small int32 device tensor by its maximum over the ranks of `group` (None for one
+    rank: nothing to agree on).  4-byte words, one all-reduce per step, in stream order behind the step's kernels; with it an overflow of the pair capacity on ONE rank makes
+    EVERY rank regrow and redo the step, where round 5 raised on that rank and left the others waiting in a collective."""
+    if not dist.is_available() or not dist.is_initialized() or _single(dist.get_world_size(group)):
+        return None
+    return lambda words: dist.all_reduce(words, op=dist.ReduceOp.MAX, group=group)
+
+
 def adam_reference_(p, g, m, v, lr, b1, b2, eps, t):
     """torch.optim.Adam's single-tensor update (no weight decay, no amsgrad), statement by statement, on CPU tensors or slices of them:
     what ZeroOneAdam runs on its owned slice where there is no HIP device (the gloo tests); bit-identical to torch.optim.Adam(foreach=False)"""

@@ -59,13 +59,15 @@ int c3d_scan_u32(const uint32_t* in, uint32_t* out, size_t n, bool exclusive, vo
 // inclusive scan of the areas of the tile rects rect[idx[i]] ({x0 | y0 << 16, x1 | y1 << 16}; the gather is folded into the load) -> out; the gathered rects are left
 // in rsort[i].  tail_meta (optional, device): receives min(total, tail_cap) in [0]; tail_status (optional): [0] |= 1 when total > tail_cap, [1] = max(total).
 int c3d_scan_rect_gather(const uint2* rect, const uint32_t* idx, uint32_t* out, uint2* rsort, size_t n, void* tmp, hipStream_t s, bool zero_state,
-                         uint32_t* tail_meta, uint32_t* tail_status, uint32_t tail_cap, uint32_t* err = nullptr, int V = 1, size_t vs = 0, uint32_t tail_cap2 = 0);
-// tail_cap2 (0 = none): capacity of a device-gated SECOND attempt (c3d_gs_forward_nosync).  tail_meta[1] = the count the final attempt works on, min(total, tail_cap2 ? tail_cap2 :
-// tail_cap); tail_status[0] |= C3D_ST_REDO when total > tail_cap and a second attempt exists, |= C3D_ST_OVERFLOW only when total exceeds the final capacity.
+                         uint32_t* tail_meta, uint32_t* tail_status, uint32_t tail_cap, uint32_t* err = nullptr, int V = 1, size_t vs = 0, uint32_t tail_hint = 0,
+                         unsigned long long* tail_early = nullptr);
+// tail_hint (0 = none): the count the launches of the chain were sized for; tail_status[0] |= C3D_ST_BEYOND_HINT when the total exceeds it (information: workgroups looped),
+// |= C3D_ST_OVERFLOW when it exceeds tail_cap (the buffers).  tail_early (optional): device-visible address of 8 bytes of pinned host memory that receives total << 32 | bits.
 #define C3D_ST_OVERFLOW 1u
-#define C3D_ST_REDO 4u
-int c3d_zero_gated(void* p, size_t bytes, const uint32_t* gate, hipStream_t s);            // cleared only if (*gate & C3D_ST_REDO)
+#define C3D_ST_BEYOND_HINT 4u
 int c3d_zero_count(void* p, const uint32_t* count, uint32_t cap, hipStream_t s);            // bytes [0, min(*count, cap)) cleared, the count resident on the device
+// the state of a sort laid out for n elements, cleared for the min(*n_dev, n) that are there (+ pre_bytes in front of tmp); launch sized for n_hint elements
+int c3d_sort_zero_state_counted(void* tmp, size_t n, int end_bit, const uint32_t* n_dev, size_t n_hint, void* pre, size_t pre_bytes, hipStream_t s);
 uint32_t* c3d_scan_error_word(void* tmp);
 // up to three byte regions (off[r], bytes[r]: 16-byte aligned, multiples of 4) cleared in each of V slices, one launch
 int c3d_zero_views(void* base0, size_t vs, int V, const size_t* off, const size_t* bytes, int regions, hipStream_t s);
@@ -88,7 +90,7 @@ int c3d_sort_set_debug(unsigned long long* stamps);   // profiling hook (nullptr
 #define C3D_SORT_MAX_PASSES 4
 int c3d_sort_pairs_u32(uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32_t* vals1, bool iota_vals,
                        size_t n, int end_bit, void* tmp, int* result_buf, hipStream_t s, const uint32_t* n_dev = nullptr, bool zero_state = true, uint32_t* err = nullptr,
-                       int V = 1, size_t vs = 0, bool hist_done = false, const uint32_t* gate = nullptr);      // gate: every pass leaves at once unless (*gate & C3D_ST_REDO)
+                       int V = 1, size_t vs = 0, bool hist_done = false, size_t n_hint = 0);      // n_hint (one view, n_dev given): size the launches for n_hint < n elements; a larger count loops
 
 // ---- device helpers ----
 #ifdef __HIPCC__

@@ -4,6 +4,8 @@
 #include "gs_internal.h"
 #include <stdarg.h>
 #include <stdio.h>
+#include <sched.h>
+#include <time.h>
 
 static thread_local char g_err[1024] = "";
 void c3d_set_error(const char* fmt, ...) {
@@ -70,8 +72,9 @@ static int check_inputs(int N, int M, int deg, const float* means3D, const float
 // (`cleared`, V views).  V / vs: the chain of V views in one launch per stage (g = view 0's state, view v's lies v * vs bytes behind).
 // cap / status: pair capacity and status words of the sync-free paths (the pair count then stays on the device in g.meta[0]).
 // (the record-base scan of the backward pass -- rbase, einfo -- is not on this chain any more: it rides in the recording forward compositing launch, scan_wave.h)
-// cap2 (0 = none): capacity of the device-gated second attempt of c3d_gs_forward_nosync (its count goes to g.meta[1], status bit C3D_ST_REDO says whether it runs)
-static int binning_front(GsGeom& g, int N, uint32_t cap, uint32_t* status, hipStream_t s, int V = 1, size_t vs = 0, bool cleared = false, uint32_t cap2 = 0) {
+// hint / early: c3d_gs_forward_nosync -- the pair count its launches are sized for, and where the scan's tail leaves {bits, count} for the host (c3d_scan_rect_gather)
+static int binning_front(GsGeom& g, int N, uint32_t cap, uint32_t* status, hipStream_t s, int V = 1, size_t vs = 0, bool cleared = false, uint32_t hint = 0,
+                         unsigned long long* early = nullptr) {
     int rc, res = 0;
     if (!cleared) {
         if (V != 1) { c3d_set_error("internal: a multi-view binning chain needs its state cleared by the caller"); return -2; }
@@ -82,37 +85,35 @@ static int binning_front(GsGeom& g, int N, uint32_t cap, uint32_t* status, hipSt
       if ((rc = c3d_sort_pairs_u32(g.key[0], g.key[1], g.order[0], g.order[1], true, (size_t)N, 32, g.tmp_sort, &res, s, nullptr, false, err, V, vs))) return rc; }
     if (res != sort_result_index(32)) { c3d_set_error("internal: depth sort buffer parity"); return -2; }
     { C3dProfScope ps(C3D_P_SCAN, s);
-      if ((rc = c3d_scan_rect_gather(g.rect, g.order[res], g.offsets, g.rsort, (size_t)N, g.tmp_scan_b, s, false, (uint32_t*)g.meta, status, cap, err, V, vs, cap2))) return rc; }
+      if ((rc = c3d_scan_rect_gather(g.rect, g.order[res], g.offsets, g.rsort, (size_t)N, g.tmp_scan_b, s, false, (uint32_t*)g.meta, status, cap, err, V, vs, hint, early))) return rc; }
     return 0;
 }
 // emit + tile sort + per-tile ranges; D = pair count on the host, or the capacity when d_dev (device count, per view) is given
-// D also sizes the LAYOUT of the tile sort's state inside b.tmp, which may have been carved for more pairs than D (the two attempts of c3d_gs_forward_nosync share one buffer).
-// gate: this is the device-gated second attempt -- every launch leaves at once unless C3D_ST_REDO is set in *gate; the ranges are written over the first attempt's (no clear:
-// see gs_launch_ranges), the sort state is cleared by a gated launch of its own.
+// D_hint (0 = none; one view, count on the device): the launches are sized for D_hint pairs although the buffers hold D -- workgroups loop when the count exceeds the hint,
+// and the state is cleared for the count that is really there (c3d_sort_zero_state_counted) instead of a memset sized for D.
 static int binning_back(const GsParams& p, GsGeom& g, GsBinning& b, long long D, uint32_t cap, const uint32_t* d_dev, uint32_t* status,
-                        hipStream_t s, int* res_out, int V = 1, size_t vs = 0, bool cleared = false, const uint32_t* gate = nullptr) {
+                        hipStream_t s, int* res_out, int V = 1, size_t vs = 0, bool cleared = false, long long D_hint = 0) {
     const int tiles = p.gx * p.gy;
     int rc, res = 0;
-    if (gate) {
-        if (V != 1 || D <= 0) { c3d_set_error("internal: gated binning chain"); return -2; }
-        C3dProfScope ps(C3D_P_OTHER, s);
-        if ((rc = c3d_zero_gated(b.tmp, c3d_align(c3d_sort_state_bytes((size_t)D, tile_sort_bits(tiles)), 16), gate, s))) return rc;
+    const bool hinted = D_hint > 0 && D_hint < D && V == 1 && d_dev;
+    if (hinted) {
+        C3dProfScope ps(C3D_P_EMIT, s);      // (the clear belongs to the emission's group: no timing scope -- two event records -- of its own)
+        if ((rc = c3d_sort_zero_state_counted(b.tmp, (size_t)D, tile_sort_bits(tiles), d_dev, (size_t)D_hint, b.ranges, (size_t)((char*)b.tmp - (char*)b.ranges), s))) return rc;
     } else if (!cleared) {
         if (V != 1) { c3d_set_error("internal: a multi-view binning chain needs its state cleared by the caller"); return -2; }
-        // ranges | meta | sort state of a D-pair sort (<= zero_bytes, which counts the state of the pair count the buffer was carved for)
-        const size_t zb = (size_t)((char*)b.tmp - (char*)b.ranges) + c3d_sort_state_bytes((size_t)(D > 0 ? D : 1), tile_sort_bits(tiles));
-        C3D_CHECK(hipMemsetAsync(b.ranges, 0, zb < b.zero_bytes ? zb : b.zero_bytes, s));
+        C3D_CHECK(hipMemsetAsync(b.ranges, 0, b.zero_bytes, s));
     }
     *res_out = 0;
     if (D <= 0) return 0;
     uint32_t* err = status ? status : (uint32_t*)g.meta + 2;
     { C3dProfScope ps(C3D_P_EMIT, s);
-      if ((rc = gs_launch_emit(p, g, sort_result_index(32), b, s, cap, V, vs, (tile_sort_bits(tiles) + 7) / 8, gate))) return rc; }      // (also counts the digits of the keys it writes)
+      if ((rc = gs_launch_emit(p, g, sort_result_index(32), b, s, cap, V, vs, (tile_sort_bits(tiles) + 7) / 8))) return rc; }      // (also counts the digits of the keys it writes)
     { C3dProfScope ps(C3D_P_TILE_SORT, s);
-      if ((rc = c3d_sort_pairs_u32(b.tkey[0], b.tkey[1], b.tval[0], b.tval[1], false, (size_t)D, tile_sort_bits(tiles), b.tmp, &res, s, d_dev, false, err, V, vs, true, gate))) return rc; }
+      if ((rc = c3d_sort_pairs_u32(b.tkey[0], b.tkey[1], b.tval[0], b.tval[1], false, (size_t)D, tile_sort_bits(tiles), b.tmp, &res, s, d_dev, false, err, V, vs, true,
+                                   hinted ? (size_t)D_hint : 0))) return rc; }
     if (res != sort_result_index(tile_sort_bits(tiles))) { c3d_set_error("internal: tile sort buffer parity"); return -2; }
     { C3dProfScope ps(C3D_P_RANGES, s);
-      if ((rc = gs_launch_ranges(b, res, D, s, d_dev, V, vs, gate))) return rc; }
+      if ((rc = gs_launch_ranges(b, res, D, s, d_dev, V, vs, hinted ? D_hint : 0))) return rc; }
     *res_out = res;
     return 0;
 }
@@ -203,52 +204,56 @@ int c3d_gs_forward_render(const c3d_gs_settings* st, int32_t N, int32_t M, const
     int rc, res = 0;
     const bool record = !(st->flags & C3D_GS_FLAG_FORWARD_ONLY);      // a backward call may follow: record the blended (quadrant, splat) pairs, run the record-base scan, keep final_T / n_contrib
     if ((num_rendered > 0 || (record && N > 0)) && (!geom_buffer || !radii)) { c3d_set_error("c3d_gs_forward_render: NULL geometry"); return -1; }      // (the record-base scan walks the geometry of all N Gaussians)
+    if ((st->flags & C3D_GS_FLAG_KEEP_RECORD_BASES) && geom_buffer)      // a second rendering at the exact count: the device copy of the count (the backward pass clears its "record written" bytes by it) still holds the first attempt's capacity
+        C3D_CHECK(hipMemsetD32Async((hipDeviceptr_t)g.meta, (int)(uint32_t)pair_cap(num_rendered), 1, s));
     if ((rc = binning_back(p, g, b, num_rendered, 0xFFFFFFFFu, nullptr, nullptr, s, &res))) return rc;
     C3dProfScope ps(C3D_P_COMPOSITE_FWD, s);
     GsFwdViews vp{};
     vp.bg[0] = p.bg; vp.color[0] = out_color; vp.depth[0] = out_depth; vp.alpha[0] = out_alpha;
-    return gs_launch_composite_fwd(p, g, b, res, im, vp, 1, 0, record, s);
+    return gs_launch_composite_fwd(p, g, b, res, im, vp, 1, 0, record, s, nullptr, !(st->flags & C3D_GS_FLAG_KEEP_RECORD_BASES));
 }
 
-// A2-A6 of ONE view without the host: launches sized for a capacity, the pair count read from g.meta on the device (what the multi-view paths do per group).
-// Two attempts in one call (first_capacity < pair_capacity): the chain runs sized for first_capacity; the emit-offset scan knows the real count, and when that exceeds
-// first_capacity (status bit C3D_ST_REDO) emit -> tile sort -> ranges -> compositing run a SECOND time, sized for pair_capacity, over the same buffers -- five launches (and one
-// clear of the sort state) that are enqueued with every call and leave at once, workgroup by workgroup, when the bit is clear.  What does not depend on the capacity is not
-// repeated: projection, depth sort, emit offsets, the record-base scan.  Only a view that needs more than pair_capacity is lost: C3D_ST_OVERFLOW, and NaN planes.
+// A2-A6 of ONE view without the host.  The pair count stays on the device (g.meta[0]); the BUFFERS hold pair_capacity pairs, the LAUNCHES are sized for first_capacity (a hint
+// learnt from earlier counts): a count beyond the hint is served by workgroups that loop (k_onesweep STAY == 2, k_ranges, the counted clear), so every count the buffers hold
+// is rendered exactly, at no cost when the hint was right.  Only a view that needs more than pair_capacity is lost: C3D_ST_OVERFLOW, and NaN planes.
 static int forward_tail_nosync(const c3d_gs_settings* st, const GsParams& p, GsGeom& g, int N, int64_t pair_capacity, int64_t first_capacity, void* binning_buffer, void* image_buffer,
-                               float* out_color, float* out_depth, float* out_alpha, uint32_t* status, uint32_t* status_host, hipStream_t s) {
+                               float* out_color, float* out_depth, float* out_alpha, uint32_t* status, uint32_t* status_host, uint32_t* count_host, hipStream_t s) {
     const int tiles = p.gx * p.gy;
     const uint32_t cap = (uint32_t)pair_capacity;
-    const bool two = first_capacity > 0 && first_capacity < pair_capacity;
-    const uint32_t cap1 = two ? (uint32_t)first_capacity : cap;
+    const long long hint = (first_capacity > 0 && first_capacity < pair_capacity) ? (long long)first_capacity : 0;
     const bool record = !(st->flags & C3D_GS_FLAG_FORWARD_ONLY);
     GsBinning b;
     gs_carve_binning((char*)binning_buffer, pair_capacity, tiles, b);
     GsImage im;
     gs_carve_image((char*)image_buffer, p.W, p.H, im);
+    unsigned long long* early = nullptr;
+    if (count_host) {      // pinned host memory the device can address: the scan's tail stores the count there itself (no copy in the stream between the scan and the emission)
+        void* dp = nullptr;
+        if (((uintptr_t)count_host & 7) || hipHostGetDevicePointer(&dp, count_host, 0) != hipSuccess || !dp) {
+            (void)hipGetLastError();
+            c3d_set_error("c3d_gs_forward_nosync: count_host must be 8-byte aligned pinned host memory mapped into the device's address space (hipHostMalloc / hipHostRegister)");
+            return -1;
+        }
+        early = (unsigned long long*)dp;
+    }
     int rc, res = 0;
     C3D_CHECK(hipMemsetAsync(status, 0, 2 * sizeof(uint32_t), s));
-    if ((rc = binning_front(g, N, cap1, status, s, 1, 0, false, two ? cap : 0u))) return rc;
-    if ((rc = binning_back(p, g, b, (long long)cap1, cap1, (const uint32_t*)g.meta, status, s, &res))) return rc;
-    GsFwdViews vp{};
-    vp.bg[0] = p.bg; vp.color[0] = out_color; vp.depth[0] = out_depth; vp.alpha[0] = out_alpha;
+    if ((rc = binning_front(g, N, cap, status, s, 1, 0, false, (uint32_t)hint, early))) return rc;
+    if ((rc = binning_back(p, g, b, pair_capacity, cap, (const uint32_t*)g.meta, status, s, &res, 1, 0, false, hint))) return rc;
     { C3dProfScope ps(C3D_P_COMPOSITE_FWD, s);
-      if ((rc = gs_launch_composite_fwd(p, g, b, res, im, vp, 1, 0, record, s, status, status, 0u))) return rc; }
-    if (two) {
-        int res2 = 0;
-        if ((rc = binning_back(p, g, b, pair_capacity, cap, (const uint32_t*)g.meta + 1, status, s, &res2, 1, 0, false, status))) return rc;
-        if (res2 != res) { c3d_set_error("internal: the two attempts finish in different buffers"); return -2; }
-        C3dProfScope ps(C3D_P_COMPOSITE_FWD, s);
-        if ((rc = gs_launch_composite_fwd(p, g, b, res, im, vp, 1, 0, record, s, status, status, C3D_ST_REDO, false))) return rc;
-    }
-    // the status words are final once the emit-offset scan has run; the copy rides behind the last launch in stream order and is nobody's critical path
+      GsFwdViews vp{};
+      vp.bg[0] = p.bg; vp.color[0] = out_color; vp.depth[0] = out_depth; vp.alpha[0] = out_alpha;
+      if ((rc = gs_launch_composite_fwd(p, g, b, res, im, vp, 1, 0, record, s, status))) return rc;
+      // a caller that waits for the count (count_host) deals with a view beyond its buffers itself; one that does not must never see an image that merely looks plausible
+      if (!count_host && (rc = gs_launch_poison_on_overflow(status, out_color, out_depth, out_alpha, p.W, p.H, s))) return rc; }
+    // the copy rides behind the last launch in stream order and is nobody's critical path (the fault bit of a bounded wait can be raised by any kernel of the chain)
     if (status_host) C3D_CHECK(hipMemcpyAsync(status_host, status, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     return 0;
 }
 static int check_nosync_args(const char* who, int64_t pair_capacity, int64_t first_capacity, const void* radii, const void* geom_buffer, const void* binning_buffer, const void* image_buffer,
                              const float* out_color, const float* out_depth, const float* out_alpha, const uint32_t* status) {
     if (pair_capacity <= 0 || pair_capacity > (int64_t)0x3FFFFFF0ll) { c3d_set_error("%s: pair_capacity out of range (1 .. 2^30 - 16)", who); return -1; }
-    if (first_capacity < 0) { c3d_set_error("%s: first_capacity is negative (0 or >= pair_capacity = one attempt)", who); return -1; }
+    if (first_capacity < 0) { c3d_set_error("%s: first_capacity is negative (0 or >= pair_capacity: launches sized for pair_capacity)", who); return -1; }
     if (!radii || !geom_buffer || !binning_buffer || !image_buffer || !out_color || !out_depth || !out_alpha || !status) { c3d_set_error("%s: NULL buffer", who); return -1; }
     return 0;
 }
@@ -256,7 +261,7 @@ static int check_nosync_args(const char* who, int64_t pair_capacity, int64_t fir
 int c3d_gs_forward_nosync(const c3d_gs_settings* st, int32_t N, int32_t M, const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
                           const float* scales, const float* rotations, const float* cov3D_precomp, int32_t* radii, void* geom_buffer, int64_t pair_capacity,
                           int64_t first_capacity, void* binning_buffer, void* image_buffer, float* out_color, float* out_depth, float* out_alpha, uint32_t* status,
-                          uint32_t* status_host, c3d_stream_t stream) {
+                          uint32_t* status_host, uint32_t* count_host, c3d_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     GsParams p;
     if (make_params(st, N, M, p)) return -1;
@@ -269,13 +274,13 @@ int c3d_gs_forward_nosync(const c3d_gs_settings* st, int32_t N, int32_t M, const
     int rc;
     { C3dProfScope ps(C3D_P_PREPROCESS, s);
     if ((rc = gs_launch_preprocess(p, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, radii, s))) return rc; }
-    return forward_tail_nosync(st, p, g, N, pair_capacity, first_capacity, binning_buffer, image_buffer, out_color, out_depth, out_alpha, status, status_host, s);
+    return forward_tail_nosync(st, p, g, N, pair_capacity, first_capacity, binning_buffer, image_buffer, out_color, out_depth, out_alpha, status, status_host, count_host, s);
 }
 
 int c3d_gs_forward_raw_nosync(const c3d_gs_settings* st, int32_t N, const float* means3D, const float* f_dc, const float* f_rest, const float* opacity_raw,
                               const float* scaling_raw, const float* rotation_raw, int32_t* radii, void* geom_buffer, int64_t pair_capacity, int64_t first_capacity,
                               void* binning_buffer, void* image_buffer, float* out_color, float* out_depth, float* out_alpha, uint32_t* status, uint32_t* status_host,
-                              c3d_stream_t stream) {
+                              uint32_t* count_host, c3d_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     GsParams p;
     const int K = raw_coeffs(st);
@@ -289,7 +294,28 @@ int c3d_gs_forward_raw_nosync(const c3d_gs_settings* st, int32_t N, const float*
     int rc;
     { C3dProfScope ps(C3D_P_PREPROCESS, s);
     if ((rc = gs_launch_preprocess_raw(p, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, g, radii, s))) return rc; }
-    return forward_tail_nosync(st, p, g, N, pair_capacity, first_capacity, binning_buffer, image_buffer, out_color, out_depth, out_alpha, status, status_host, s);
+    return forward_tail_nosync(st, p, g, N, pair_capacity, first_capacity, binning_buffer, image_buffer, out_color, out_depth, out_alpha, status, status_host, count_host, s);
+}
+
+// the host's side of count_host: spin (the calling thread only; ctypes has released the GIL) until the scan of the call has stored its words
+int c3d_gs_wait_count(const uint32_t* count_host, uint32_t sentinel, int64_t timeout_us, uint32_t* bits, uint32_t* count) {
+    if (!count_host) { c3d_set_error("c3d_gs_wait_count: NULL pointer"); return -1; }
+    const volatile unsigned long long* w = (const volatile unsigned long long*)count_host;
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (unsigned spins = 0;; spins++) {
+        const unsigned long long v = __atomic_load_n(w, __ATOMIC_ACQUIRE);
+        if ((uint32_t)(v >> 32) != sentinel) {
+            if (bits) *bits = (uint32_t)v;
+            if (count) *count = (uint32_t)(v >> 32);
+            return 0;
+        }
+        if ((spins & 63) == 63) {
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            if (timeout_us >= 0 && (t1.tv_sec - t0.tv_sec) * 1000000ll + (t1.tv_nsec - t0.tv_nsec) / 1000 > timeout_us) { c3d_set_error("c3d_gs_wait_count: timed out"); return -4; }
+            sched_yield();
+        }
+    }
 }
 
 int c3d_gs_backward(const c3d_gs_settings* st, int32_t N, int32_t M, const float* means3D, const float* shs,
@@ -325,7 +351,7 @@ int c3d_gs_backward(const c3d_gs_settings* st, int32_t N, int32_t M, const float
         if (!binning_buffer || !image_buffer) { c3d_set_error("c3d_gs_backward: NULL state buffer"); return -1; }
         const int res = sort_result_index(tile_sort_bits(tiles));
         C3dProfScope ps(C3D_P_COMPOSITE_BWD, s);
-        if ((rc = c3d_zero_count(pvalid, (const uint32_t*)g.meta + 1, pair_cap(num_rendered), s))) return rc;      // the pairs the forward pass worked on (<= num_rendered: the buffers may hold a capacity)
+        if ((rc = c3d_zero_count(pvalid, (const uint32_t*)g.meta, pair_cap(num_rendered), s))) return rc;      // the pairs the forward pass worked on (<= num_rendered: the buffers may hold a capacity)
         GsBwdPix px{};
         px.bg[0] = p.bg; px.dcolor[0] = dL_dcolor; px.ddepth[0] = dL_ddepth; px.dalpha[0] = dL_dalpha;
         if ((rc = gs_launch_composite_bwd(p, g, b, res, im, px, dL_ddepth != nullptr, pairgrad, pvalid, s, pair_cap(num_rendered)))) return rc;
@@ -363,7 +389,7 @@ int c3d_gs_backward_raw(const c3d_gs_settings* st, int32_t N, const float* means
         if (!binning_buffer || !image_buffer) { c3d_set_error("c3d_gs_backward_raw: NULL state buffer"); return -1; }
         const int res = sort_result_index(tile_sort_bits(tiles));
         C3dProfScope ps(C3D_P_COMPOSITE_BWD, s);
-        if ((rc = c3d_zero_count(pvalid, (const uint32_t*)g.meta + 1, pair_cap(num_rendered), s))) return rc;      // the pairs the forward pass worked on (<= num_rendered: the buffers may hold a capacity)
+        if ((rc = c3d_zero_count(pvalid, (const uint32_t*)g.meta, pair_cap(num_rendered), s))) return rc;      // the pairs the forward pass worked on (<= num_rendered: the buffers may hold a capacity)
         GsBwdPix px{};
         px.bg[0] = p.bg; px.dcolor[0] = dL_dcolor; px.ddepth[0] = dL_ddepth; px.dalpha[0] = dL_dalpha;
         if ((rc = gs_launch_composite_bwd(p, g, b, res, im, px, dL_ddepth != nullptr, pairgrad, pvalid, s, pair_cap(num_rendered)))) return rc;

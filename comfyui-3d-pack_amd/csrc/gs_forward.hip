@@ -231,8 +231,7 @@ int gs_launch_preprocess_raw(const GsParams& p, const float* means3D, const floa
 // Home view of a workgroup = (linear block id) % V as in the sort passes.  Pairs beyond the capacity are neither written nor counted.
 __global__ void __launch_bounds__(EMIT_RANKS) k_emit(int N, int gx, const uint32_t* __restrict__ order, const uint32_t* __restrict__ offsets,
                                                       const uint2* __restrict__ rsort, uint32_t* __restrict__ tkey, uint32_t* __restrict__ tval, uint32_t cap,
-                                                      uint32_t* __restrict__ ghist, int passes, size_t vs, const uint32_t* __restrict__ gate) {
-    if (gate && !(*gate & C3D_ST_REDO)) return;      // the device-gated second attempt of c3d_gs_forward_nosync: the first one held every pair
+                                                      uint32_t* __restrict__ ghist, int passes, size_t vs) {
     __shared__ uint32_t s_end[EMIT_RANKS];      // inclusive scan: end of rank r's pairs
     __shared__ uint32_t s_gid[EMIT_RANKS];
     __shared__ uint2 s_rect[EMIT_RANKS];
@@ -274,12 +273,12 @@ __global__ void __launch_bounds__(EMIT_RANKS) k_emit(int N, int gx, const uint32
     }
 }
 // ghist: the head of the tile sort's state block (zero on entry: the binning stage clears it before this launch); passes = sort passes of the tile id
-int gs_launch_emit(const GsParams& p, const GsGeom& g, int res, GsBinning& b, hipStream_t s, uint32_t cap, int V, size_t vs, int passes, const uint32_t* gate) {
+int gs_launch_emit(const GsParams& p, const GsGeom& g, int res, GsBinning& b, hipStream_t s, uint32_t cap, int V, size_t vs, int passes) {
     if (p.N == 0 || V <= 0) return 0;
     if (passes < 1 || passes > C3D_SORT_MAX_PASSES) { c3d_set_error("internal: %d sort passes for the tile id", passes); return -2; }
     const int chunks = c3d_cdiv(p.N, EMIT_RANKS);
     const int nbx = (long long)chunks * V <= EMIT_SLOTS ? chunks : (EMIT_SLOTS / V > 0 ? EMIT_SLOTS / V : 1);
-    hipLaunchKernelGGL(k_emit, dim3(nbx, V), dim3(EMIT_RANKS), 0, s, p.N, p.gx, g.order[res], g.offsets, g.rsort, b.tkey[0], b.tval[0], cap, (uint32_t*)b.tmp, passes, vs, gate);
+    hipLaunchKernelGGL(k_emit, dim3(nbx, V), dim3(EMIT_RANKS), 0, s, p.N, p.gx, g.order[res], g.offsets, g.rsort, b.tkey[0], b.tval[0], cap, (uint32_t*)b.tmp, passes, vs);
     C3D_LAUNCH_CHECK();
     return 0;
 }
@@ -287,35 +286,33 @@ int gs_launch_emit(const GsParams& p, const GsGeom& g, int res, GsBinning& b, hi
 // A5: [start,end) of every tile in the sorted pair list.  Four consecutive positions per lane (one 16-byte load + the two neighbours): with one position per
 // lane the launch was half a million three-load waves and bound by their latency, not by the 16 MB it reads per view.
 #define RANGES_PER_LANE 4
-__global__ void __launch_bounds__(256) k_ranges(const uint32_t* __restrict__ tkey, uint2* __restrict__ ranges, long long D, const uint32_t* __restrict__ d_dev, size_t vs,
-                                                const uint32_t* __restrict__ gate) {
-    if (gate && !(*gate & C3D_ST_REDO)) return;
+// (grid-stride: a launch sized for a HINT of the pair count -- c3d_gs_forward_nosync -- covers every count the buffers hold; sized for D it is one trip)
+__global__ void __launch_bounds__(256) k_ranges(const uint32_t* __restrict__ tkey, uint2* __restrict__ ranges, long long D, const uint32_t* __restrict__ d_dev, size_t vs) {
     tkey = c3d_view_ptr(tkey, vs); ranges = c3d_view_ptr(ranges, vs); d_dev = c3d_view_ptr(d_dev, vs);
-    const long long i0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * RANGES_PER_LANE;
     if (d_dev) D = min((long long)*d_dev, D);
-    if (i0 >= D) return;
-    uint32_t t[RANGES_PER_LANE + 2];
-    if (i0 + RANGES_PER_LANE <= D) { const uint4 q = *reinterpret_cast<const uint4*>(tkey + i0); t[1] = q.x; t[2] = q.y; t[3] = q.z; t[4] = q.w; }
-    else {
+    for (long long i0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * RANGES_PER_LANE; i0 < D; i0 += (long long)gridDim.x * blockDim.x * RANGES_PER_LANE) {
+        uint32_t t[RANGES_PER_LANE + 2];
+        if (i0 + RANGES_PER_LANE <= D) { const uint4 q = *reinterpret_cast<const uint4*>(tkey + i0); t[1] = q.x; t[2] = q.y; t[3] = q.z; t[4] = q.w; }
+        else {
 #pragma unroll
-        for (int k = 0; k < RANGES_PER_LANE; k++) t[1 + k] = (i0 + k < D) ? tkey[i0 + k] : 0xFFFFFFFFu;
-    }
-    t[0] = i0 > 0 ? tkey[i0 - 1] : 0xFFFFFFFFu;
-    t[RANGES_PER_LANE + 1] = (i0 + RANGES_PER_LANE < D) ? tkey[i0 + RANGES_PER_LANE] : 0xFFFFFFFFu;
+            for (int k = 0; k < RANGES_PER_LANE; k++) t[1 + k] = (i0 + k < D) ? tkey[i0 + k] : 0xFFFFFFFFu;
+        }
+        t[0] = i0 > 0 ? tkey[i0 - 1] : 0xFFFFFFFFu;
+        t[RANGES_PER_LANE + 1] = (i0 + RANGES_PER_LANE < D) ? tkey[i0 + RANGES_PER_LANE] : 0xFFFFFFFFu;
 #pragma unroll
-    for (int k = 0; k < RANGES_PER_LANE; k++) {
-        const long long i = i0 + k;
-        if (i >= D) break;
-        if (i == 0 || t[k] != t[k + 1]) ranges[t[k + 1]].x = (uint32_t)i;
-        if (i == D - 1 || t[k + 2] != t[k + 1]) ranges[t[k + 1]].y = (uint32_t)(i + 1);
+        for (int k = 0; k < RANGES_PER_LANE; k++) {
+            const long long i = i0 + k;
+            if (i >= D) break;
+            if (i == 0 || t[k] != t[k + 1]) ranges[t[k + 1]].x = (uint32_t)i;
+            if (i == D - 1 || t[k + 2] != t[k + 1]) ranges[t[k + 1]].y = (uint32_t)(i + 1);
+        }
     }
 }
-// `ranges` must be zero on entry: the binning stage clears it together with the tile-sort state (GsBinning::zero_bytes).  (The gated second attempt of c3d_gs_forward_nosync
-// writes over the first attempt's ranges without a clear in between: its pair list is a superset of the first one's per tile, so every tile the first attempt wrote is written
-// again, and a tile neither attempt writes stays {0, 0}.)
-int gs_launch_ranges(const GsBinning& b, int res, long long D, hipStream_t s, const uint32_t* d_dev, int V, size_t vs, const uint32_t* gate) {
+// `ranges` must be zero on entry: the binning stage clears it together with the tile-sort state.  D_launch (0 = D): the pair count the grid is sized for (a hint; D bounds the count)
+int gs_launch_ranges(const GsBinning& b, int res, long long D, hipStream_t s, const uint32_t* d_dev, int V, size_t vs, long long D_launch) {
     if (D == 0 || V <= 0) return 0;
-    hipLaunchKernelGGL(k_ranges, dim3(c3d_cdiv(D, 256 * RANGES_PER_LANE), V), dim3(256), 0, s, b.tkey[res], b.ranges, D, d_dev, vs, gate);
+    if (D_launch <= 0 || D_launch > D) D_launch = D;
+    hipLaunchKernelGGL(k_ranges, dim3(c3d_cdiv(D_launch, 256 * RANGES_PER_LANE), V), dim3(256), 0, s, b.tkey[res], b.ranges, D, d_dev, vs);
     C3D_LAUNCH_CHECK();
     return 0;
 }
@@ -347,17 +344,7 @@ int gs_launch_ranges(const GsBinning& b, int res, long long D, hipStream_t s, co
 template <bool RECORD, bool DEPTH>
 __global__ void __launch_bounds__(64, 8) k_composite_fwd_w(GsParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                                                             const float4* __restrict__ rec, GsFwdViews vp, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-                                                            uint8_t* __restrict__ pact, size_t pstride, size_t vs, ScanWaveJob sj,
-                                                            const uint32_t* __restrict__ gate, uint32_t gate_need) {
-    // gate (the sync-free drop-in forward, c3d_gs_forward_nosync; nullptr everywhere else): the call's first status word.  The compositing launch of the device-gated SECOND
-    // attempt (gate_need = C3D_ST_REDO) leaves at once unless the first attempt's capacity was exceeded; and a view that needed more pairs than the LAST attempt's capacity
-    // (C3D_ST_OVERFLOW) gets NaN planes instead of an image that merely looks plausible.
-    uint32_t poison = 0;
-    if (gate) {
-        const uint32_t gw = *gate;
-        if ((gw & gate_need) != gate_need) return;
-        poison = gw & C3D_ST_OVERFLOW;
-    }
+                                                            uint8_t* __restrict__ pact, size_t pstride, size_t vs, ScanWaveJob sj) {
     // RECORD launches carry the record-base scan of the backward pass in their first sj.blocks workgroups (scan_wave.h).  Measured (profiles/r05f_scan_in_composite_ab.txt,
     // same box, three alternations): the launch grows by 0.09 ms -- the scan's 256 MB per 8 views are not free underneath the compositing waves' record gathers -- where
     // the scan's own launch took 0.125: step 5.134 -> 5.075 ms.  One launch less on the chain; the gain is the tail and the dependent-launch gap, not the traffic.
@@ -470,7 +457,6 @@ __global__ void __launch_bounds__(64, 8) k_composite_fwd_w(GsParams p, const uin
             final_T[pid] = T;
             n_contrib[pid] = (uint32_t)last;
         }
-        if (poison) { C0 = C1 = C2 = Dp = T = __int_as_float(0x7FC00000); }
         out_color[pid] = C0 + T * bg[0];
         out_color[P + pid] = C1 + T * bg[1];
         out_color[2 * P + pid] = C2 + T * bg[2];
@@ -482,10 +468,10 @@ __global__ void __launch_bounds__(64, 8) k_composite_fwd_w(GsParams p, const uin
 // One launch for V views (grid.y): view v's state lies v * vs bytes behind the pointers of g / b / im; its background and output planes come from vp.
 // record_activity: a backward pass may follow -- the launch records the blended (quadrant, splat) pairs AND runs the record-base scan (rbase, einfo of g; state
 // g.tmp_scan_a, cleared with the rest of the view's binning state) in its first workgroups.  err: error word of a timed-out look-back (nullptr: the view's own, g.meta[2]).
-// gate / gate_need: see the kernel (c3d_gs_forward_nosync only).  scan: false = a RECORD launch WITHOUT the record-base scan (the gated second attempt: rbase / einfo do not depend
-// on the pair capacity, the first attempt's launch has written them).
+// scan: false = a RECORD launch WITHOUT the record-base scan (a second rendering of a geometry whose first compositing launch
+// has written rbase / einfo already -- C3D_GS_FLAG_KEEP_RECORD_BASES: they do not depend on the pair buffers, and the scan's state is spent).
 int gs_launch_composite_fwd(const GsParams& p, const GsGeom& g, const GsBinning& b, int res, GsImage& im, const GsFwdViews& vp, int V, size_t vs,
-                            bool record_activity, hipStream_t s, uint32_t* err, const uint32_t* gate, uint32_t gate_need, bool scan) {
+                            bool record_activity, hipStream_t s, uint32_t* err, bool scan) {
     const int tiles = p.gx * p.gy;
     if (tiles == 0 || V <= 0) return 0;
     uint8_t* pact = record_activity ? gs_pair_activity(b, res) : nullptr;
@@ -495,10 +481,28 @@ int gs_launch_composite_fwd(const GsParams& p, const GsGeom& g, const GsBinning&
     const dim3 grid(sj.blocks + 4 * gs_block_count(p.gx, p.gy), V);      // a multiple of 32 blocks per view: the XCD of a block (dispatch order % 8) does not depend on the view
     bool depth = false;
     for (int v = 0; v < V; v++) depth = depth || vp.depth[v] != nullptr;
-#define GS_FWD_LAUNCH(REC_, DEP_) hipLaunchKernelGGL((k_composite_fwd_w<REC_, DEP_>), grid, dim3(64), 0, s, p, b.ranges, b.tval[res], g.rec0, vp, im.final_T, im.n_contrib, pact, b.pair_stride, vs, sj, gate, gate_need)
+#define GS_FWD_LAUNCH(REC_, DEP_) hipLaunchKernelGGL((k_composite_fwd_w<REC_, DEP_>), grid, dim3(64), 0, s, p, b.ranges, b.tval[res], g.rec0, vp, im.final_T, im.n_contrib, pact, b.pair_stride, vs, sj)
     if (record_activity) { if (depth) GS_FWD_LAUNCH(true, true); else GS_FWD_LAUNCH(true, false); }
     else                 { if (depth) GS_FWD_LAUNCH(false, true); else GS_FWD_LAUNCH(false, false); }
 #undef GS_FWD_LAUNCH
+    C3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// c3d_gs_forward_nosync for a caller that does not wait for the count: a view that needed more pairs than its buffers hold (C3D_ST_OVERFLOW in the call's first status word)
+// gets NaN planes instead of an image that merely looks plausible.  One launch that leaves at once otherwise.
+__global__ void __launch_bounds__(256) k_poison_on_overflow(const uint32_t* __restrict__ status, float* __restrict__ color, float* __restrict__ depth, float* __restrict__ alpha, size_t P) {
+    if (!(*status & C3D_ST_OVERFLOW)) return;
+    const float nan = __int_as_float(0x7FC00000);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < P; i += (size_t)gridDim.x * 256) {
+        color[i] = nan; color[P + i] = nan; color[2 * P + i] = nan; alpha[i] = nan;
+        if (depth) depth[i] = nan;
+    }
+}
+int gs_launch_poison_on_overflow(const uint32_t* status, float* color, float* depth, float* alpha, int W, int H, hipStream_t s) {
+    const size_t P = (size_t)W * H;
+    if (P == 0) return 0;
+    hipLaunchKernelGGL(k_poison_on_overflow, dim3(256), dim3(256), 0, s, status, color, depth, alpha, P);
     C3D_LAUNCH_CHECK();
     return 0;
 }

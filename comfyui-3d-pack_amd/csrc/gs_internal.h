@@ -184,11 +184,11 @@ int gs_launch_preprocess_bwd_raw(const GsParams& p, const GsGeom& g, const int* 
                                  const float* scaling_raw, const float* rotation_raw, const float* pairgrad, const uint8_t* pvalid, float* dL_dmean2D,
                                  float* dL_dopacity_raw, float* dL_dmeans3D, float* dL_df_dc, float* dL_df_rest, float* dL_dscaling_raw,
                                  float* dL_drotation_raw, bool accumulate, hipStream_t s, uint32_t cap = 0xFFFFFFFFu);
-// gate (device, c3d_gs_forward_nosync's first status word; nullptr = none): the launch belongs to the device-gated SECOND attempt and leaves at once unless C3D_ST_REDO is set there
-int gs_launch_emit(const GsParams& p, const GsGeom& g, int res, GsBinning& b, hipStream_t s, uint32_t cap, int V, size_t vs, int passes, const uint32_t* gate = nullptr);
-int gs_launch_ranges(const GsBinning& b, int res, long long D, hipStream_t s, const uint32_t* d_dev = nullptr, int V = 1, size_t vs = 0, const uint32_t* gate = nullptr);
+int gs_launch_emit(const GsParams& p, const GsGeom& g, int res, GsBinning& b, hipStream_t s, uint32_t cap, int V, size_t vs, int passes);
+int gs_launch_ranges(const GsBinning& b, int res, long long D, hipStream_t s, const uint32_t* d_dev = nullptr, int V = 1, size_t vs = 0, long long D_launch = 0);
 int gs_launch_composite_fwd(const GsParams& p, const GsGeom& g, const GsBinning& b, int res, GsImage& im, const GsFwdViews& vp, int V, size_t vs,
-                            bool record_activity, hipStream_t s, uint32_t* err = nullptr, const uint32_t* gate = nullptr, uint32_t gate_need = 0, bool scan = true);
+                            bool record_activity, hipStream_t s, uint32_t* err = nullptr, bool scan = true);
+int gs_launch_poison_on_overflow(const uint32_t* status, float* color, float* depth, float* alpha, int W, int H, hipStream_t s);
 int gs_launch_sum_group_loss(const float* terms, int n, int V, size_t vs, float* loss_out, hipStream_t s);   // ONE group holds all views: both stages below in one launch (same bits)
 int gs_launch_sum_view_loss(const float* terms, int n, float* view_sum, int V, size_t vs, hipStream_t s);   // per view: its per-tile partials (+ MS-SSIM term) -> one float
 int gs_launch_sum_tile_loss(const float* first_view_sum, size_t view_stride_bytes, int V, float* loss_out, hipStream_t s);   // the V view sums, in order, added to *loss_out

@@ -65,9 +65,10 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* lds, u
 // ------------------------------------------------------------------------------------------
 #define LB_AGG 1ull
 #define LB_INCL 2ull
-// cap2 (0 = none): the capacity of a second, device-gated attempt (c3d_gs_forward_nosync's redo): meta[1] = min(total, cap2), status bit 2 = "more than cap pairs: the redo
-// runs", bit 0 only beyond cap2.  meta[1] always receives the count the FINAL attempt works on (min(total, cap) without a second one).
-struct ScanTail { uint32_t* meta; uint32_t* status; uint32_t cap; uint2* rsort; uint32_t cap2; };   // rsort: GATHER
+// hint (0 = none): the pair count the LAUNCHES of the chain were sized for (c3d_gs_forward_nosync: first_capacity < cap); a larger count is served by workgroups that loop --
+// status bit C3D_ST_BEYOND_HINT only says so.  early (optional): DEVICE-VISIBLE address of two words of pinned host memory; the tail stores {overflow / hint bits, total} there
+// itself, as ONE 64-bit system-scope store -- the host sees the count of a call while the rest of its chain is still running, without a copy in the stream.
+struct ScanTail { uint32_t* meta; uint32_t* status; uint32_t cap; uint2* rsort; uint32_t hint; unsigned long long* early; };   // rsort: GATHER
 __device__ __forceinline__ uint32_t rect_area(uint2 r) { return ((r.y & 0xFFFFu) - (r.x & 0xFFFFu)) * ((r.y >> 16) - (r.x >> 16)); }
 
 // Data movement (round 4: with V views per launch the scans are bandwidth-sized work, and eight 4-byte accesses per lane at a 32-byte lane stride cost eight
@@ -186,13 +187,9 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_lb(const uint32_t* __rest
         if (tail.meta && b < n && b + 4 >= n) {      // this lane owns element n-1: `run` is the grand total (elements past n are zeros)
             const uint32_t total = run;
             tail.meta[0] = total < tail.cap ? total : tail.cap;
-            const uint32_t last_cap = tail.cap2 ? tail.cap2 : tail.cap;
-            tail.meta[1] = total < last_cap ? total : last_cap;
-            if (tail.status) {
-                if (total > last_cap) atomicOr(&tail.status[0], C3D_ST_OVERFLOW);
-                if (tail.cap2 && total > tail.cap) atomicOr(&tail.status[0], C3D_ST_REDO);
-                atomicMax(&tail.status[1], total);
-            }
+            const uint32_t bits = (total > tail.cap ? C3D_ST_OVERFLOW : 0u) | ((tail.hint && total > tail.hint) ? C3D_ST_BEYOND_HINT : 0u);
+            if (tail.status) { if (bits) atomicOr(&tail.status[0], bits); atomicMax(&tail.status[1], total); }
+            if (tail.early) __hip_atomic_store(tail.early, ((unsigned long long)total << 32) | bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
@@ -220,7 +217,7 @@ static int scan_launch(const uint32_t* in, const uint32_t* idx, uint32_t* out, s
     return 0;
 }
 int c3d_scan_u32(const uint32_t* in, uint32_t* out, size_t n, bool exclusive, void* tmp, hipStream_t s, bool zero_state, uint32_t* err) {
-    return scan_launch(in, nullptr, out, n, exclusive, tmp, s, zero_state, ScanTail{nullptr, nullptr, 0u, nullptr, 0u}, err);
+    return scan_launch(in, nullptr, out, n, exclusive, tmp, s, zero_state, ScanTail{nullptr, nullptr, 0u, nullptr, 0u, nullptr}, err);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -254,21 +251,6 @@ int c3d_zero_views(void* base0, size_t vs, int V, const size_t* off, const size_
     C3D_LAUNCH_CHECK();
     return 0;
 }
-// bytes (a multiple of 16, 16-byte aligned start) cleared only if (*gate & C3D_ST_REDO): the state block of the device-gated second attempt of c3d_gs_forward_nosync
-__global__ void __launch_bounds__(256) k_zero_gated(uint4* __restrict__ p, size_t n16, const uint32_t* __restrict__ gate) {
-    if (!(*gate & C3D_ST_REDO)) return;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) p[i] = make_uint4(0u, 0u, 0u, 0u);
-}
-int c3d_zero_gated(void* p, size_t bytes, const uint32_t* gate, hipStream_t s) {
-    if (bytes == 0) return 0;
-    if (((uintptr_t)p & 15) || (bytes & 15) || !gate) { c3d_set_error("c3d_zero_gated: region must be 16-byte aligned / a multiple of 16 bytes, gate non-NULL"); return -1; }
-    int nb = c3d_cdiv((long long)(bytes / 16), 256 * 4);
-    if (nb < 1) nb = 1;
-    if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(k_zero_gated, dim3(nb), dim3(256), 0, s, (uint4*)p, bytes / 16, gate);
-    C3D_LAUNCH_CHECK();
-    return 0;
-}
 // bytes [0, min(*count, cap)) of p cleared, the count resident on the device: the "record written" bytes of a backward pass whose buffers were sized for a capacity
 __global__ void __launch_bounds__(256) k_zero_count(uint4* __restrict__ p, const uint32_t* __restrict__ count, uint32_t cap) {
     const uint32_t c = *count < cap ? *count : cap;
@@ -284,8 +266,8 @@ int c3d_zero_count(void* p, const uint32_t* count, uint32_t cap, hipStream_t s) 
     return 0;
 }
 int c3d_scan_rect_gather(const uint2* rect, const uint32_t* idx, uint32_t* out, uint2* rsort, size_t n, void* tmp, hipStream_t s, bool zero_state,
-                         uint32_t* tail_meta, uint32_t* tail_status, uint32_t tail_cap, uint32_t* err, int V, size_t vs, uint32_t tail_cap2) {
-    return scan_launch(reinterpret_cast<const uint32_t*>(rect), idx, out, n, false, tmp, s, zero_state, ScanTail{tail_meta, tail_status, tail_cap, rsort, tail_cap2}, err, V, vs);
+                         uint32_t* tail_meta, uint32_t* tail_status, uint32_t tail_cap, uint32_t* err, int V, size_t vs, uint32_t tail_hint, unsigned long long* tail_early) {
+    return scan_launch(reinterpret_cast<const uint32_t*>(rect), idx, out, n, false, tmp, s, zero_state, ScanTail{tail_meta, tail_status, tail_cap, rsort, tail_hint, tail_early}, err, V, vs);
 }
 uint32_t* c3d_scan_error_word(void* tmp) { return (uint32_t*)tmp + 1; }
 
@@ -321,7 +303,7 @@ uint32_t* c3d_scan_error_word(void* tmp) { return (uint32_t*)tmp + 1; }
 #define RS_SLOTS 1024             // workgroups of k_onesweep resident at once: 256 CUs x 4
 #define RS_HIST_SPLIT C3D_SORT_HIST_SPLIT      // copies of the global histogram (workgroup b adds to copy b % 16): 245 - 1000 workgroups adding to ONE set of 256 counters serialise at the
                               // memory-side atomic unit (measured: 23 us for 1 M keys, profiles/r02c); consumers add the 16 copies up
-static inline size_t sort_pass_words(size_t nb) { return RS_RADIX * (nb + nb / RS_GROUP + 1); }
+__host__ __device__ static inline size_t sort_pass_words(size_t nb) { return RS_RADIX * (nb + nb / RS_GROUP + 1); }
 
 __global__ void __launch_bounds__(RS_THREADS) k_radix_hist_all(const uint32_t* __restrict__ keys, uint32_t* __restrict__ ghist, size_t n,
                                                                 const uint32_t* __restrict__ n_dev, int passes, size_t vs) {
@@ -385,14 +367,12 @@ __device__ __forceinline__ uint32_t rs_wait(const uint32_t* p, uint32_t x, uint3
 // depth sort of an 8-view step 0.256 -> 0.237 ms, tile sort 0.488 -> 0.470 ms on one box.  With 81 VGPRs the ONE-reorder-buffer form (keys, then values, through one 16 KB buffer
 // and back into registers before the chained scan: 22.5 KB) fits five and six workgroups per CU without spilling -- measured on the same box: 0.236 / 0.478 ms at five, 0.241 / 0.477
 // at six.  Tiles in flight are not what bounds a pass (same finding as the lean kernel of profiles/r05ij); not kept.
-template <bool IOTA, int ITEMS, bool STAY>
+template <bool IOTA, int ITEMS, int STAY>
 __global__ void __launch_bounds__(RS_THREADS, 4) k_onesweep(const uint32_t* __restrict__ keys_in0, const uint32_t* __restrict__ vals_in0,
                                                              uint32_t* __restrict__ keys_out0, uint32_t* __restrict__ vals_out0,
                                                              const uint32_t* __restrict__ ghist0, uint32_t* __restrict__ ticket, uint32_t* __restrict__ err,
                                                              uint32_t* __restrict__ tile_words0, uint32_t* __restrict__ group_words0, size_t n_cap,
-                                                             const uint32_t* __restrict__ n_dev, int shift, unsigned long long* __restrict__ dbg, size_t vs,
-                                                             const uint32_t* __restrict__ gate) {
-    if (gate && !(*gate & C3D_ST_REDO)) return;      // a pass of the device-gated second attempt (c3d_gs_forward_nosync): nothing to redo
+                                                             const uint32_t* __restrict__ n_dev, int shift, unsigned long long* __restrict__ dbg, size_t vs) {
     __shared__ uint32_t whist[RS_THREADS / 64][RS_RADIX];
     __shared__ uint32_t lstart[RS_RADIX];    // first local slot of each digit
     __shared__ uint32_t gbase[RS_RADIX];     // global position of that slot
@@ -419,7 +399,7 @@ __global__ void __launch_bounds__(RS_THREADS, 4) k_onesweep(const uint32_t* __re
     // of the 8-view step), and nobody steals: a workgroup without a tile leaves.
   for (;;) {
     size_t n = RS_COUNT(view);               // requested BEFORE the ticket (behind the barrier it is a dependent scalar load on every tile's critical path)
-    if (STAY) __syncthreads();               // the previous tile's scatter has read skey / sval / gbase / lstart
+    if (STAY == 1) __syncthreads();          // the previous tile's scatter has read skey / sval / gbase / lstart
     if (threadIdx.x == 0) s_tile = atomicAdd(RS_AT(ticket, view), 1u);
     for (int i = threadIdx.x; i < (RS_THREADS / 64) * RS_RADIX; i += RS_THREADS) (&whist[0][0])[i] = 0;
     __syncthreads();
@@ -595,7 +575,10 @@ __global__ void __launch_bounds__(RS_THREADS, 4) k_onesweep(const uint32_t* __re
         }
     }
     RS_STAMP(5);
-    if (!STAY) return;
+    if (STAY == 0) return;
+    // STAY == 2 (one view; c3d_gs_forward_nosync): the grid was sized for a HINT of the element count.  A count the grid covers -- the usual case -- is one tile per workgroup and
+    // no failed draw, exactly the STAY == 0 launch; a larger count makes the workgroups stay and draw on, so the pass is correct for every count the buffers hold.
+    if (STAY == 2) { if ((size_t)gridDim.x * (RS_THREADS * ITEMS) >= n) return; __syncthreads(); }      // (the barrier STAY == 1 has at the head of the loop)
   }
 #undef RS_STAMP
 #undef RS_AT
@@ -617,9 +600,43 @@ size_t c3d_sort_state_bytes(size_t n, int end_bit) {
     return sort_head_bytes() + sizeof(uint32_t) * sort_pass_words((size_t)c3d_cdiv((long long)(n ? n : 1), RS_MIN_TILE)) * passes;
 }
 
+// The state of a sort whose layout holds n elements, cleared for the min(*n_dev, n) elements that are really there: the fixed head (histograms, tickets) and, per pass, the
+// tile words of the tiles in use and the group words of their groups -- what a launch sized for a hint of the count needs, whatever the buffers hold (a memset of the whole
+// state is 1 KB per 4096 elements of CAPACITY and pass).  `pre`: bytes in front of tmp cleared by the same launch (the tile ranges + meta words of the binning state; 16-byte
+// aligned, a multiple of 16).
+__global__ void __launch_bounds__(256) k_sort_zero_state(uint4* __restrict__ pre, size_t pre16, uint32_t* __restrict__ status, size_t nb, int passes, size_t n_cap,
+                                                          const uint32_t* __restrict__ n_dev) {
+    const size_t n = min((size_t)*n_dev, n_cap);
+    const size_t tiles = (n + RS_TILE - 1) / RS_TILE, groups = tiles / RS_GROUP + 1;
+    const int seg = blockIdx.y;
+    uint4* p; size_t cnt;
+    if (seg == 0) { p = pre; cnt = pre16; }
+    else {
+        uint32_t* tw = status + (size_t)((seg - 1) >> 1) * sort_pass_words(nb);
+        if ((seg - 1) & 1) { p = reinterpret_cast<uint4*>(tw + (size_t)RS_RADIX * nb); cnt = groups * (RS_RADIX / 4); }
+        else { p = reinterpret_cast<uint4*>(tw); cnt = tiles * (RS_RADIX / 4); }
+    }
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < cnt; i += (size_t)gridDim.x * 256) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+int c3d_sort_zero_state_counted(void* tmp, size_t n, int end_bit, const uint32_t* n_dev, size_t n_hint, void* pre, size_t pre_bytes, hipStream_t s) {
+    int passes = (end_bit + 7) / 8;
+    if (passes < 1) passes = 1;
+    if (passes > RS_MAX_PASSES || !n_dev || ((uintptr_t)pre & 15) || (pre_bytes & 15) || (char*)pre + pre_bytes != (char*)tmp) {
+        c3d_set_error("c3d_sort_zero_state_counted: bad argument (pre must end where tmp starts, 16-byte granules)"); return -1; }
+    const size_t nb = (size_t)c3d_cdiv((long long)(n ? n : 1), RS_TILE);
+    const size_t nb_hint = (size_t)c3d_cdiv((long long)(n_hint ? n_hint : n), RS_TILE);
+    int gx = (int)((nb_hint * (RS_RADIX / 4) + 1023) / 1024);      // four 16-byte stores per thread at the hinted count; a larger count loops
+    if (gx < 16) gx = 16;
+    if (gx > 1024) gx = 1024;
+    // segment 0 = pre + the sort's head (contiguous), then tile words / group words of every pass
+    hipLaunchKernelGGL(k_sort_zero_state, dim3(gx, 1 + 2 * passes), dim3(256), 0, s, (uint4*)pre, (pre_bytes + sort_head_bytes()) / 16, (uint32_t*)((char*)tmp + sort_head_bytes()), nb, passes, n, n_dev);
+    C3D_LAUNCH_CHECK();
+    return 0;
+}
+
 int c3d_sort_pairs_u32(uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32_t* vals1, bool iota_vals,
                        size_t n, int end_bit, void* tmp, int* result_buf, hipStream_t s, const uint32_t* n_dev, bool zero_state, uint32_t* err_out, int V, size_t vs, bool hist_done,
-                       const uint32_t* gate) {
+                       size_t n_hint) {
     *result_buf = 0;
     if (n == 0 || V <= 0) return 0;
     if (zero_state && V != 1) { c3d_set_error("c3d_sort_pairs_u32: a multi-view launch clears its state through c3d_zero_views"); return -1; }
@@ -629,14 +646,17 @@ int c3d_sort_pairs_u32(uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32
     if (passes < 1) passes = 1;
     const int nb = c3d_cdiv((long long)n, RS_TILE), nb_hist = nb;
     // k_onesweep's workgroups stay and draw tile after tile: one per residency slot of the chip (MI355X: 256 CUs x 4 workgroups of 39 KB LDS), spread evenly over the views
-    const bool stay = (long long)nb * V > 2 * RS_SLOTS;       // (at most two rounds: one workgroup per tile, see STAY)
-    const int nbx = !stay ? nb : (RS_SLOTS / V > 0 ? RS_SLOTS / V : 1);
+    // n_hint (one view, with n_dev): the launch is sized for n_hint elements although the buffers (and the state layout) hold n -- workgroups loop if the count exceeds the hint (STAY == 2)
+    const bool hinted = n_hint > 0 && n_hint < n && V == 1 && n_dev != nullptr;
+    const int nb_launch = hinted ? c3d_cdiv((long long)n_hint, RS_TILE) : nb;
+    const bool stay = (long long)nb_launch * V > 2 * RS_SLOTS;       // (at most two rounds: one workgroup per tile, see STAY)
+    const int nbx = !stay ? nb_launch : (RS_SLOTS / V > 0 ? RS_SLOTS / V : 1);
+    const int mode = stay ? 1 : (hinted ? 2 : 0);
     uint32_t* ghist = (uint32_t*)tmp;
     uint32_t* tickets = ghist + RS_HIST_SPLIT * RS_RADIX * RS_MAX_PASSES;
     uint32_t* err = err_out ? err_out : c3d_sort_error_word(tmp);
     uint32_t* status = (uint32_t*)((char*)tmp + sort_head_bytes());
     if (hist_done && zero_state) { c3d_set_error("c3d_sort_pairs_u32: hist_done with zero_state would clear the producer's histograms"); return -1; }
-    if (gate && !hist_done) { c3d_set_error("c3d_sort_pairs_u32: a gated sort takes its histograms from the (gated) producer of the keys"); return -1; }
     if (zero_state) C3D_CHECK(hipMemsetAsync(tmp, 0, c3d_sort_state_bytes(n, end_bit), s));
     uint32_t* k[2] = {keys0, keys1};
     uint32_t* v[2] = {vals0, vals1};
@@ -646,9 +666,9 @@ int c3d_sort_pairs_u32(uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32
         uint32_t* tw = status + (size_t)pass * sort_pass_words((size_t)nb);
         uint32_t* gw = tw + (size_t)RS_RADIX * nb;
 #define RS_SWEEP(IOTA_, STAY_) hipLaunchKernelGGL((k_onesweep<IOTA_, RS_ITEMS, STAY_>), dim3(nbx, V), dim3(RS_THREADS), 0, s, k[cur], v[cur], k[cur ^ 1], v[cur ^ 1], ghist + pass * RS_RADIX, \
-                                           tickets + pass, err, tw, gw, n, n_dev, 8 * pass, (g_sort_dbg && V == 1) ? g_sort_dbg + (size_t)pass * nb * 8 : nullptr, vs, gate)
-        if (pass == 0 && iota_vals) { if (stay) RS_SWEEP(true, true); else RS_SWEEP(true, false); }
-        else { if (stay) RS_SWEEP(false, true); else RS_SWEEP(false, false); }
+                                           tickets + pass, err, tw, gw, n, n_dev, 8 * pass, (g_sort_dbg && V == 1) ? g_sort_dbg + (size_t)pass * nb * 8 : nullptr, vs)
+        if (pass == 0 && iota_vals) { if (mode == 1) RS_SWEEP(true, 1); else if (mode == 2) RS_SWEEP(true, 2); else RS_SWEEP(true, 0); }
+        else { if (mode == 1) RS_SWEEP(false, 1); else if (mode == 2) RS_SWEEP(false, 2); else RS_SWEEP(false, 0); }
 #undef RS_SWEEP
         C3D_LAUNCH_CHECK();
         cur ^= 1;

@@ -14,29 +14,33 @@ import torch.nn as nn
 import c3d_hip as _h
 
 last_num_rendered = 0   # (tile, splat) pairs of the most recent forward whose count has reached the host -- bench/telemetry only
-redone_calls = 0        # sync-free forward calls whose first attempt overflowed and which the device redid at the buffers' capacity (exact) -- telemetry
+redone_calls = 0        # sync-free forward calls whose view did not fit its buffers and was rendered again at the exact count before forward() returned -- telemetry
+beyond_hint_calls = 0   # ... whose pair count exceeded the launch hint (workgroups looped; exact) -- telemetry
+sync_free_calls = 0     # forward calls that went through c3d_gs_forward_nosync / c3d_gs_forward_raw_nosync -- telemetry
 
-# ---- the forward pass without its host round trip, and still exact --------------------------------------------------------------------------------
-# The wheel sizes its binning buffer from the exact pair count and stalls the host for that one number on every call (main_3DGS_renderer.py:927-936 never returns an
-# incomplete image).  Here:
-#   * a call that is NOT differentiated (grad mode off, or no input requires a gradient: inference -- the orbit nodes, LGM / TGS / TRELLIS-style consumers) takes that
-#     synchronous path: exact by construction, and with C3D_GS_FLAG_FORWARD_ONLY the compositing launch leaves out everything only a backward pass would read;
-#   * a DIFFERENTIATED call (a training loop: the host wants to run ahead of the GPU) goes through c3d_gs_forward_nosync in TWO attempts (include/c3d_gs.h): launches sized
-#     for a first capacity learnt from the counts seen (1.5 x the largest, scaled with the point count while a model densifies), buffers sized for _REDO x that -- and when
-#     the device-resident count exceeds the first capacity, the device itself bins and composites the view a second time at the buffers' capacity, inside the same call.
-#     Image, radii and every gradient are then those of the synchronous path, bit for bit; the host hears of it one call late (status words through a pinned ring, looked
-#     at when a later call starts) and only raises the first capacity.  The capacities are capped at N x tiles, which no view can exceed.
-# Only a view that needs more than the BUFFERS hold (a pair count that grew more than _HEADROOM x _REDO = 6 x from one call to the next) cannot be rendered: its planes
-# come back as NaN -- never an image that merely looks plausible -- and the examination raises.  sync_free(False) takes the synchronous path for every call.
+# ---- the forward pass without stalling the GPU, and still exact -------------------------------------------------------------------------------------
+# The wheel sizes its binning buffer from the exact pair count: project, copy one number to the host, WAIT, allocate, enqueue the second half -- the GPU idles through the
+# round trip on every view.  main_3DGS_renderer.py:927-936 never returns an incomplete image; neither does this module.  After the first call of a (device, H, W) shape:
+#   * the whole forward is enqueued at once (c3d_gs_forward_nosync, include/c3d_gs.h): launches sized for a HINT (1.25 x the largest pair count seen, scaled with the point
+#     count while a model densifies), buffers for _ROOM x that, workgroups that loop when the count exceeds the hint -- every count the buffers hold is rendered exactly, and a
+#     count within the hint costs nothing extra;
+#   * the kernel that finds the pair count stores it straight into pinned host memory, and forward() WAITS for that word before it returns (c3d_gs_wait_count): by then
+#     emission, tile sort and compositing are queued behind it, so the GPU never idles -- and the host knows, before the image leaves, whether the view fitted its buffers.
+#     If not (a count more than _HEADROOM x _ROOM = 5 x the largest seen), the second half is rendered again at the exact count on the geometry already projected.
+# Result: exact for every call, differentiated or not, bit for bit the synchronous path -- and the host still runs ahead of the GPU by everything behind the scan.
+# sync_free("unverified") skips the wait (the host may run whole calls ahead; status words are looked at one call late; a view beyond its buffers comes back as NaN planes
+# and the examination raises); sync_free(False) is the wheel's synchronous path for every call.  Calls that are not differentiated (grad mode off, or no input requires a
+# gradient) render with C3D_GS_FLAG_FORWARD_ONLY: nothing a backward pass would read is recorded.
 import collections
 import threading
 import warnings
 
 _lock = threading.RLock()      # ComfyUI may run nodes on several threads: slot hand-out and examination are serialised (a few dictionary / list operations per call)
-_SYNC_FREE = True
+_SYNC_FREE = "verified"        # "verified" | "unverified" | False
 _FORWARD_ONLY = True           # calls that are not differentiated render with C3D_GS_FLAG_FORWARD_ONLY (forward_only(False): the A/B switch of bench.py)
-_HEADROOM, _REDO, _SLACK = 1.5, 4, 1 << 16      # first capacity = headroom x largest count seen + slack; buffers = _REDO x first capacity
+_HEADROOM, _ROOM, _SLACK = 1.25, 4, 1 << 16      # launch hint = headroom x largest count seen + slack; buffers = _ROOM x hint
 _MAX_PAIRS = 0x3FFFFFF0       # the library's own limit (the chained scans' status words)
+_WAIT_US = 20_000_000         # c3d_gs_wait_count gives up after 20 s (a wedged device)
 _MODELS = 8      # point counts remembered per (device, H, W)
 _learnt = {}     # (device index, H, W) -> OrderedDict {N: largest pair count seen with N points}, most recently used last
 _SLOTS = 64      # status slots per device: calls whose status words may be on their way to the host at once
@@ -45,23 +49,26 @@ _rings = {}      # device index -> _Ring
 
 
 class _Ring:
-    """per device: _SLOTS status slots, each two int32 words on the device (what the kernels write) and two in pinned host memory (where c3d_gs_forward_nosync
-    copies them at the end of the call).  The host presets a pinned slot to the sentinel and later just LOOKS at it: no event, no allocation, no synchronisation per call.
-    Slots are handed out round-robin and examined first-in first-out, so the slot about to be reused is always the oldest one still pending."""
+    """per device: _SLOTS status slots.  Each has two int32 words on the device (what the kernels write), two in pinned host memory where c3d_gs_forward_nosync copies them
+    at the END of the call (`pin`: the fault bit can be raised by any kernel), and two more pinned words the emit-offset scan stores {bits, pair count} into ITSELF, early
+    (`cnt`).  The host presets pinned words to the sentinel and later just looks at them: no event, no allocation per call.  Slots are handed out round-robin and examined
+    first-in first-out, so the slot about to be reused is always the oldest one still pending."""
 
     def __init__(self, dev):
         self.device = dev
         self.dev_words = torch.zeros((_SLOTS, 2), dtype=torch.int32, device=dev)
         self.pin = torch.full((_SLOTS, 2), _SENTINEL, dtype=torch.int32).pin_memory()
-        self.host = self.pin.numpy()                      # same memory: plain loads / stores from Python
-        self.dev_ptr, self.pin_ptr = self.dev_words.data_ptr(), self.pin.data_ptr()
+        self.cnt = torch.full((_SLOTS, 2), _SENTINEL, dtype=torch.int32).pin_memory()
+        self.host, self.cnt_host = self.pin.numpy(), self.cnt.numpy()      # same memory: plain loads / stores from Python
+        self.dev_ptr, self.pin_ptr, self.cnt_ptr = self.dev_words.data_ptr(), self.pin.data_ptr(), self.cnt.data_ptr()
         self.next = 0
-        self.pending = []                                 # [(slot, key, N, capacity)] calls whose status words have not been examined, oldest first
+        self.pending = []                                 # [[slot, key, N, capacity, verified]] calls whose final status words have not been examined, oldest first
 
     def examine(self, block=False, keep=_SLOTS):
         """retire the calls whose words have arrived; block: all of them, waiting for the GPU if need be; keep: wait until at most that many are left"""
+        global beyond_hint_calls
         while self.pending:
-            slot, key, n_points, cap = self.pending[0]
+            slot, key, n_points, cap, verified = self.pending[0]
             w = self.host[slot]
             if w[0] == _SENTINEL or w[1] == _SENTINEL:    # still on its way
                 if not block and len(self.pending) <= keep:
@@ -75,20 +82,26 @@ class _Ring:
             flags, seen = int(w[0]), int(w[1]) & 0xFFFFFFFF
             if flags & 2:
                 raise RuntimeError("diff_gaussian_rasterization (MI355X): a chained-scan look-back of an earlier forward call timed out in the binning stage (device fault or a wedged workgroup)")
+            if verified:
+                continue                                  # count and overflow were dealt with inside that call
             if flags & 4:
-                global redone_calls
-                redone_calls += 1
-            _learn(key, n_points, seen)                   # (bit 2: the device redid the view at the buffers' capacity -- exact; the first capacity follows the count from here on)
+                beyond_hint_calls += 1
+            _learn(key, n_points, seen)
             if flags & 1:
-                raise RuntimeError("diff_gaussian_rasterization (MI355X): an earlier differentiated forward call needed %d (tile, splat) pairs, more than the %d its buffers held "
-                                   "(the count grew more than %g x from one call to the next): its colour / depth / alpha planes were returned as NaN.  The capacity has been "
-                                   "regrown; diff_gaussian_rasterization.sync_free(False) sizes every call from its exact count." % (seen, cap, _HEADROOM * _REDO))
+                raise RuntimeError("diff_gaussian_rasterization (MI355X): an earlier forward call (sync_free('unverified')) needed %d (tile, splat) pairs, more than the %d its "
+                                   "buffers held (the count grew more than %g x from one call to the next): its colour / depth / alpha planes were returned as NaN.  The capacity "
+                                   "has been regrown; the default sync_free('verified') renders such a view again at its exact count before the image leaves." % (seen, cap, _HEADROOM * _ROOM))
 
 
-def sync_free(on=True):
-    """False: every forward takes the wheel's synchronous path (exact pair count read back per call).  Returns the previous setting."""
+def sync_free(mode="verified"):
+    """"verified" (default; True means the same): one enqueue per forward, the host waits for the pair count only and redoes a view that did not fit -- always exact.
+    "unverified": no wait at all (see the head of this file).  False: the wheel's synchronous path (exact pair count read back between the two halves).  Returns the previous setting."""
     global _SYNC_FREE
-    prev, _SYNC_FREE = _SYNC_FREE, bool(on)
+    if mode is True:
+        mode = "verified"
+    if mode not in ("verified", "unverified", False):
+        raise ValueError("sync_free: 'verified', 'unverified' or False")
+    prev, _SYNC_FREE = _SYNC_FREE, mode
     return prev
 
 
@@ -100,7 +113,7 @@ def forward_only(on=True):
 
 
 def flush():
-    """wait for the status words of every sync-free forward call issued so far and examine them (raises as described above); afterwards
+    """wait for the final status words of every sync-free forward call issued so far and examine them (raises as described above); afterwards
     last_num_rendered is the pair count of the most recent forward call"""
     with _lock:
         for ring in list(_rings.values()):
@@ -108,7 +121,7 @@ def flush():
 
 
 def _flush_at_exit():
-    """a process whose LAST forward call could not be rendered would otherwise never hear of it: examine what is pending before the interpreter goes"""
+    """a process whose LAST forward call faulted would otherwise never hear of it: examine what is pending before the interpreter goes"""
     try:
         if pending_calls():
             flush()
@@ -117,7 +130,7 @@ def _flush_at_exit():
 
 
 def pending_calls():
-    """sync-free forward calls whose status words have not been examined yet"""
+    """sync-free forward calls whose final status words have not been examined yet"""
     with _lock:
         return sum(len(r.pending) for r in _rings.values())
 
@@ -137,7 +150,7 @@ def _learn(key, n_points, seen):
 
 def _estimate(key, n_points):
     """-> the largest pair count seen for this shape at n_points Gaussians; for a point count not seen yet, that of the nearest one within a factor of two, scaled
-    (a model that densifies or prunes keeps its pairs per Gaussian; the second attempt of the call makes a wrong guess exact); None: nothing to go by"""
+    (a model that densifies or prunes keeps its pairs per Gaussian; looping workgroups and, beyond the buffers, the second rendering make a wrong guess exact); None: nothing to go by"""
     models = _learnt.get(key)
     if not models:
         return None
@@ -150,7 +163,7 @@ def _estimate(key, n_points):
 
 
 def _capacity_for(key, n_points):
-    """-> (first capacity, buffer capacity) of a sync-free forward of this shape (first capacity 0: one attempt -- the buffers hold every pair the view can have), or
+    """-> (launch hint, buffer capacity) of a sync-free forward of this shape (hint 0: launches sized for the buffers -- they hold every pair the view can have), or
     None: take the synchronous path (and learn the count)"""
     with _lock:
         ring = _rings.get(key[0])
@@ -161,13 +174,15 @@ def _capacity_for(key, n_points):
             return None
         bound = min(n_points * ((key[1] + 15) // 16) * ((key[2] + 15) // 16), _MAX_PAIRS)      # every Gaussian in every tile
         first = min(int(seen * _HEADROOM) + _SLACK, bound)
-        cap = min(first * _REDO, bound)
+        cap = min(first * _ROOM, bound)
         return (first if first < cap else 0), max(cap, 1)
 
 
-def _status_slot(dev, key, n_points, cap):
-    """-> (device pointer, pinned host pointer) of the status words of one sync-free call, registered for examination"""
+def _status_slot(dev, key, n_points, cap, verified):
+    """-> (pending entry, device pointer, pinned pointer of the final words, pinned pointer of the early count words) of one sync-free call, registered for examination"""
+    global sync_free_calls
     with _lock:
+        sync_free_calls += 1
         ring = _rings.get(dev.index)
         if ring is None:
             ring = _rings[dev.index] = _Ring(dev)
@@ -176,8 +191,9 @@ def _status_slot(dev, key, n_points, cap):
         slot = ring.next
         ring.next = (slot + 1) % _SLOTS
         ring.host[slot] = _SENTINEL
-        ring.pending.append((slot, key, n_points, cap))
-        return C.c_void_p(ring.dev_ptr + 8 * slot), C.c_void_p(ring.pin_ptr + 8 * slot)
+        ring.cnt_host[slot] = _SENTINEL
+        ring.pending.append([slot, key, n_points, cap, verified])
+        return C.c_void_p(ring.dev_ptr + 8 * slot), C.c_void_p(ring.pin_ptr + 8 * slot), C.c_void_p(ring.cnt_ptr + 8 * slot)
 
 
 def _differentiated(*tensors):
@@ -235,10 +251,12 @@ _NO_BACKWARD = ("diff_gaussian_rasterization (MI355X): this forward call was not
                 "forward-only (C3D_GS_FLAG_FORWARD_ONLY) and kept no state for a backward pass")
 
 
-def _forward_state(ctx, lib, dev, N, H, W, differentiated, project, render, nosync):
+def _forward_state(lib, dev, N, H, W, st, project, render, nosync):
     """the part of forward() the plain and the raw-parameter entry points share: buffers, the choice of path, the library calls.
-    project(st_ref, radii, geom, nr_ref, s), render(st_ref, radii, geom, num_rendered, binning, img, color, depth, alpha, s), nosync(st_ref, radii, geom, cap, first, binning,
-    img, color, depth, alpha, st_dev, st_host, s) issue the calls with the entry point's own parameter list.  -> (color, radii, depth, alpha, geom, binning, img, num_rendered)"""
+    project(radii, geom, nr_ref, s), render(radii, geom, num_rendered, binning, img, color, depth, alpha, s), nosync(radii, geom, cap, first, binning, img, color, depth, alpha,
+    st_dev, st_host, cnt_host, s) issue the calls with the entry point's own parameter list; st: the call's settings struct (its flags are amended for a second rendering).
+    -> (color, radii, depth, alpha, geom, binning, img, num_rendered)"""
+    global redone_calls, beyond_hint_calls
     u8 = dict(dtype=torch.uint8, device=dev)
     s = _h.stream(dev)
     radii = torch.empty((N,), dtype=torch.int32, device=dev)
@@ -248,13 +266,29 @@ def _forward_state(ctx, lib, dev, N, H, W, differentiated, project, render, nosy
     depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
     alpha = torch.empty((1, H, W), dtype=torch.float32, device=dev)
     key = (dev.index, H, W)
-    caps = _capacity_for(key, N) if (differentiated and N > 0 and H > 0 and W > 0) else None
-    if caps is not None:      # sync-free, two attempts on the device (see the head of this file)
+    caps = _capacity_for(key, N) if (N > 0 and H > 0 and W > 0) else None
+    if caps is not None:      # one enqueue for the whole forward (see the head of this file)
         first, cap = caps
+        verified = _SYNC_FREE == "verified"
         num_rendered = cap
         binning = torch.empty((lib.c3d_gs_binning_bytes(cap, H, W),), **u8)
-        st_dev, st_host = _status_slot(dev, key, N, cap)
-        nosync(radii, geom, cap, first, binning, img, color, depth, alpha, st_dev, st_host, s)
+        st_dev, st_host, cnt_host = _status_slot(dev, key, N, cap, verified)
+        nosync(radii, geom, cap, first, binning, img, color, depth, alpha, st_dev, st_host, cnt_host if verified else None, s)
+        if verified:          # the pair count, straight from the kernel that found it; everything behind that kernel is still queued or running
+            bits, count = C.c_uint32(0), C.c_uint32(0)
+            _h.check(lib.c3d_gs_wait_count(cnt_host, 0xFFFFFFFF, _WAIT_US, C.byref(bits), C.byref(count)), "c3d_gs_wait_count")
+            _learn(key, N, count.value)
+            if bits.value & 4:
+                beyond_hint_calls += 1
+            if bits.value & 1:      # more pairs than the buffers hold: the second half again, on the geometry already projected, at the exact count
+                redone_calls += 1
+                num_rendered = int(count.value)
+                binning = torch.empty((lib.c3d_gs_binning_bytes(num_rendered, H, W),), **u8)
+                st.flags |= _h.GS_FLAG_KEEP_RECORD_BASES
+                try:
+                    render(radii, geom, num_rendered, binning, img, color, depth, alpha, s)
+                finally:
+                    st.flags &= ~_h.GS_FLAG_KEEP_RECORD_BASES
     else:                     # the wheel's way: the exact pair count comes back to the host between the two halves
         nr = C.c_int64(0)
         project(radii, geom, nr, s)
@@ -292,11 +326,11 @@ class _RasterizeGaussians(torch.autograd.Function):
                 _h.check(lib.c3d_gs_forward_render(C.byref(st), N, M, _h.ptr(radii), _h.ptr(geom), num_rendered, _h.ptr(binning), _h.ptr(img), _h.ptr(color), _h.ptr(depth),
                                                    _h.ptr(alpha), s), "c3d_gs_forward_render")
 
-            def nosync(radii, geom, cap, first, binning, img, color, depth, alpha, st_dev, st_host, s):
+            def nosync(radii, geom, cap, first, binning, img, color, depth, alpha, st_dev, st_host, cnt_host, s):
                 _h.check(lib.c3d_gs_forward_nosync(C.byref(st), N, M, *inputs, _h.ptr(radii), _h.ptr(geom), cap, first, _h.ptr(binning), _h.ptr(img), _h.ptr(color),
-                                                   _h.ptr(depth), _h.ptr(alpha), st_dev, st_host, s), "c3d_gs_forward_nosync")
+                                                   _h.ptr(depth), _h.ptr(alpha), st_dev, st_host, cnt_host, s), "c3d_gs_forward_nosync")
 
-            color, radii, depth, alpha, geom, binning, img, num_rendered = _forward_state(ctx, lib, dev, N, H, W, differentiated, project, render, nosync)
+            color, radii, depth, alpha, geom, binning, img, num_rendered = _forward_state(lib, dev, N, H, W, st, project, render, nosync)
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.sizes = (N, M)
@@ -374,11 +408,11 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
                 _h.check(lib.c3d_gs_forward_render(C.byref(st), N, K, _h.ptr(radii), _h.ptr(geom), num_rendered, _h.ptr(binning), _h.ptr(img), _h.ptr(color), _h.ptr(depth),
                                                    _h.ptr(alpha), s), "c3d_gs_forward_render")
 
-            def nosync(radii, geom, cap, first, binning, img, color, depth, alpha, st_dev, st_host, s):
+            def nosync(radii, geom, cap, first, binning, img, color, depth, alpha, st_dev, st_host, cnt_host, s):
                 _h.check(lib.c3d_gs_forward_raw_nosync(C.byref(st), N, *inputs, _h.ptr(radii), _h.ptr(geom), cap, first, _h.ptr(binning), _h.ptr(img), _h.ptr(color),
-                                                       _h.ptr(depth), _h.ptr(alpha), st_dev, st_host, s), "c3d_gs_forward_raw_nosync")
+                                                       _h.ptr(depth), _h.ptr(alpha), st_dev, st_host, cnt_host, s), "c3d_gs_forward_raw_nosync")
 
-            color, radii, depth, alpha, geom, binning, img, num_rendered = _forward_state(ctx, lib, dev, N, H, W, differentiated, project, render, nosync)
+            color, radii, depth, alpha, geom, binning, img, num_rendered = _forward_state(lib, dev, N, H, W, st, project, render, nosync)
         ctx.raster_settings, ctx.num_rendered, ctx.N, ctx.K = rs, num_rendered, N, K
         ctx.forward_only = not differentiated
         ctx.mark_non_differentiable(radii)

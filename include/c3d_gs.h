@@ -75,6 +75,11 @@ typedef struct c3d_gs_settings {
  * entry point that receives settings with this flag returns an error instead of reading state that was never written.  The Python boundary sets it whenever the call is not
  * differentiated (grad mode off, or no input requires a gradient). */
 #define C3D_GS_FLAG_FORWARD_ONLY 2
+/* C3D_GS_FLAG_KEEP_RECORD_BASES (ABI 600) -- c3d_gs_forward_render on a geometry buffer whose view has been composited once already (c3d_gs_forward_nosync reported through its
+ * count words that the view needs more pairs than its buffers held: the caller allocates a binning buffer for the exact count and renders the second half again): the
+ * record-base scan of the first compositing launch is kept (its results do not depend on the pair buffers, its single-pass state is spent), and the device copy of the pair
+ * count is set to num_rendered. */
+#define C3D_GS_FLAG_KEEP_RECORD_BASES 4
 
 const char* c3d_last_error(void);
 int c3d_version(void);
@@ -104,27 +109,33 @@ int c3d_gs_forward_render(const c3d_gs_settings* st, int32_t N, int32_t M, const
                           int64_t num_rendered, void* binning_buffer, void* image_buffer, float* out_color,
                           float* out_depth, float* out_alpha, c3d_stream_t stream);
 
-/* Forward in ONE call without host synchronisation (ABI 500; two attempts since ABI 600): parts 1 + 2 with every launch sized for a pair capacity instead of the exact
- * count -- the count stays on the device, so the rasterizer call of main_3DGS_renderer.py:927-936 (and of LGM core/gs.py:27-80, TRELLIS gaussian_render.py:62-130)
- * no longer stalls the host once per view.  The reference never returns an incomplete image (its binning buffer is sized from the exact count); neither does this call, up
- * to pair_capacity:
+/* Forward in ONE call without host synchronisation (ABI 500; hint-sized launches and count words since ABI 600): parts 1 + 2 with the pair count left on the device, so the
+ * rasterizer call of main_3DGS_renderer.py:927-936 (and of LGM core/gs.py:27-80, TRELLIS gaussian_render.py:62-130) no longer stalls the GPU once per view while the host
+ * reads one number.  The reference never returns an incomplete image (its binning buffer is sized from the exact count); this call gives its caller the means to guarantee the same:
  *   pair_capacity   what the BUFFERS hold: binning_buffer = c3d_gs_binning_bytes(pair_capacity, H, W) bytes; a backward call on this state passes num_rendered = pair_capacity
  *                   and scratch of c3d_gs_backward_scratch_bytes(N, pair_capacity).
- *   first_capacity  what the LAUNCHES of the first attempt are sized for (0 or >= pair_capacity: one attempt, sized for pair_capacity).  A view that needs more pairs than that
- *                   is binned and composited a SECOND time inside the same call, sized for pair_capacity, over the same buffers: the launches of the second attempt (one clear,
- *                   emit, two sort passes, ranges, compositing) are enqueued with every call and leave at once, workgroup by workgroup, unless the device-resident count says
- *                   otherwise.  Outputs and backward state are then those of an exact render, bit for bit.  Buffers are cheap (65 bytes per pair of capacity, forward and backward
- *                   together, on a 288 GB device), early-exiting workgroups of oversized launches are not: learn first_capacity from the counts seen, set pair_capacity far above.
- * status (DEVICE, two words; the call clears them): [0] bit 0 = the view needed more pairs than pair_capacity -- out_color / out_depth / out_alpha are then filled with NaN
- * (never an image that merely looks plausible), radii stay valid; bit 1 = a bounded inter-workgroup wait timed out (device fault); bit 2 = the second attempt ran (results
- * exact; raise first_capacity).  [1] = the pair count.  status_host (optional, PINNED host memory, two words): the call ends with an asynchronous copy of the two words there, in
- * stream order behind its last kernel -- a caller that presets status_host[1] to 0xFFFFFFFF (never a pair count) sees the words arrive without an event or a
- * synchronisation (the Python boundary does that and looks at them one call late).  N > 0 and a non-empty image only. */
+ *   first_capacity  what the LAUNCHES are sized for (0 or >= pair_capacity: for pair_capacity): a hint, not a limit.  A view with more pairs than the hint is served by
+ *                   workgroups that loop -- every count up to pair_capacity is rendered exactly, bit for bit the synchronous path's result, and a count within the hint costs
+ *                   nothing extra (no second launch, no gate).  Buffers are cheap (65 bytes per pair of capacity, forward and backward together, on a 288 GB device); idle
+ *                   workgroups of oversized launches and clears sized for a capacity are not: learn first_capacity from the counts seen, set pair_capacity well above.
+ *   count_host      (optional) 8 bytes of PINNED host memory the device can address (hipHostMalloc / hipHostRegister; torch's pin_memory()): the kernel that finds the pair
+ *                   count stores {bits of status[0] known at that point (0 and 2), count} there itself, ONE 64-bit store, while emission, tile sort and compositing of the
+ *                   call are still to run.  A caller that presets the second word to 0xFFFFFFFF (never a count) and waits for it to change (c3d_gs_wait_count) knows before it
+ *                   hands the image on whether the view fitted -- and if not, renders the second half again at the exact count (c3d_gs_forward_render with
+ *                   C3D_GS_FLAG_KEEP_RECORD_BASES): always exact, with the GPU never idle behind the host.  The Python boundary does exactly that.
+ * status (DEVICE, two words; the call clears them): [0] bit 0 = the view needed more pairs than pair_capacity -- without count_host (a caller that cannot know
+ * before it hands the image on) out_color / out_depth / out_alpha are then filled with NaN, never an image that merely looks plausible; radii stay valid; bit 1 = a bounded inter-workgroup wait timed out (device fault); bit 2 = the count exceeded first_capacity
+ * (results exact; raise the hint).  [1] = the pair count.  status_host (optional, pinned host memory, two words): the call ends with an asynchronous copy of the two words
+ * there, in stream order behind its last kernel (a caller that never waits looks at them one call late: the fault bit can be raised by any kernel of the chain).
+ * N > 0 and a non-empty image only. */
 int c3d_gs_forward_nosync(const c3d_gs_settings* st, int32_t N, int32_t M, const float* means3D, const float* shs, const float* colors_precomp,
                           const float* opacities, const float* scales, const float* rotations, const float* cov3D_precomp, int32_t* radii,
                           void* geom_buffer, int64_t pair_capacity, int64_t first_capacity, void* binning_buffer, void* image_buffer, float* out_color,
                           float* out_depth, float* out_alpha, uint32_t* status /* device [2] */, uint32_t* status_host /* pinned host [2] or NULL */,
-                          c3d_stream_t stream);
+                          uint32_t* count_host /* pinned, device-mapped host [2] or NULL */, c3d_stream_t stream);
+/* host side of count_host: returns once its second word differs from `sentinel` (0) -- *bits = first word, *count = second --, or after timeout_us microseconds (-4; < 0: never).
+ * Spins on the calling thread, touches no HIP state. */
+int c3d_gs_wait_count(const uint32_t* count_host, uint32_t sentinel, int64_t timeout_us, uint32_t* bits /* host, may be NULL */, uint32_t* count /* host, may be NULL */);
 
 /* Backward (A7 + A8).  Pixel gradients dL_dcolor[3,H,W], dL_ddepth[1,H,W] (may be NULL),
  * dL_dalpha[1,H,W] (may be NULL).  Outputs (all written in full by the library, no pre-zeroing needed):
@@ -154,7 +165,8 @@ int c3d_gs_forward_project_raw(const c3d_gs_settings* st, int32_t N, const float
 int c3d_gs_forward_raw_nosync(const c3d_gs_settings* st, int32_t N, const float* means3D, const float* f_dc, const float* f_rest,
                               const float* opacity_raw, const float* scaling_raw, const float* rotation_raw, int32_t* radii, void* geom_buffer,
                               int64_t pair_capacity, int64_t first_capacity, void* binning_buffer, void* image_buffer, float* out_color, float* out_depth,
-                              float* out_alpha, uint32_t* status /* device [2] */, uint32_t* status_host /* pinned host [2] or NULL */, c3d_stream_t stream);
+                              float* out_alpha, uint32_t* status /* device [2] */, uint32_t* status_host /* pinned host [2] or NULL */,
+                              uint32_t* count_host /* pinned, device-mapped host [2] or NULL */, c3d_stream_t stream);
 int c3d_gs_backward_raw(const c3d_gs_settings* st, int32_t N, const float* means3D, const float* f_dc, const float* f_rest,
                         const float* scaling_raw, const float* rotation_raw, const int32_t* radii, const void* geom_buffer,
                         int64_t num_rendered, const void* binning_buffer, const void* image_buffer, const float* dL_dcolor,

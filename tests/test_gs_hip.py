@@ -660,88 +660,100 @@ def _drop_in_pair(seed=8, n=60000, W=400, H=232, scale=0.012, cam=(-12.0, 70.0, 
     return plain, rawp, n, H, W
 
 
-def test_sync_free_drop_in_forward_equals_the_synchronous_path_bit_for_bit():
-    """After the first call of a (device, H, W) shape a DIFFERENTIATED drop-in call runs c3d_gs_forward_nosync / c3d_gs_forward_raw_nosync -- launches sized for a learnt first
-    capacity, buffers for four times that, the count left on the device, status words examined one call late -- instead of stalling the host for num_rendered.  Same kernels,
-    same arithmetic: images, radii and every gradient must have the same BITS as the synchronous path's, on the plain and on the raw-parameter entry points."""
+def _sync_reference(dgr, fn, key):
+    """one run of fn on the wheel's synchronous path with nothing learnt for the shape -> (results, pair count)"""
+    dgr._learnt.pop(key, None)
+    was = dgr.sync_free(False)
+    try:
+        ref = fn()
+    finally:
+        dgr.sync_free(was)
+    return ref, int(dgr.last_num_rendered)
+
+
+@pytest.mark.parametrize("mode", ["verified", "unverified"])
+def test_sync_free_drop_in_forward_equals_the_synchronous_path_bit_for_bit(mode):
+    """After the first call of a (device, H, W) shape the drop-in rasterizer enqueues its whole forward at once (c3d_gs_forward_nosync / c3d_gs_forward_raw_nosync): launches
+    sized for a learnt hint, buffers for four times that, the count left on the device -- and, in the default mode, forward() waits only for the count word the scan stores
+    into pinned memory.  Same kernels, same arithmetic: images, radii and every gradient must have the same BITS as the synchronous path's, on both entry points."""
     import warnings
     import diff_gaussian_rasterization as dgr
     plain, rawp, N, H, W = _drop_in_pair()
     key = (torch.cuda.current_device(), H, W)
-    for fn in (plain, rawp):
-        dgr._learnt.pop(key, None)
-        was = dgr.sync_free(False)
-        try:
-            ref = fn()
-        finally:
-            dgr.sync_free(was)
-        dgr.flush()
-        D = int(dgr.last_num_rendered)
-        assert dgr._learnt[key][N] == D > 0                           # the synchronous call taught the shape its pair count
-        first, cap = dgr._capacity_for(key, N)
-        assert first >= int(1.5 * D) and cap == 4 * first             # launches for 1.5 x the count, buffers for four times the launches
-        first2, cap2 = dgr._capacity_for(key, N + N // 10)            # a model that has just densified: the estimate follows the point count, no synchronous call
-        assert first2 > first and cap2 == 4 * first2
-        dgr.last_num_rendered = -1
-        redone = dgr.redone_calls
-        with warnings.catch_warnings():
-            warnings.simplefilter("error")
-            got = fn()
-            assert dgr.pending_calls() == 1                         # the call went through the sync-free entry point: its status words are on their way
+    was_mode = dgr.sync_free(mode)
+    try:
+        for fn in (plain, rawp):
+            ref, D = _sync_reference(dgr, fn, key)
             dgr.flush()
-        assert dgr.pending_calls() == 0 and dgr.redone_calls == redone
-        assert int(dgr.last_num_rendered) == D
-        for a, b in zip(got, ref):
-            assert torch.equal(a, b), fn.__name__
+            assert dgr._learnt[key][N] == D > 0                           # the synchronous call taught the shape its pair count
+            first, cap = dgr._capacity_for(key, N)
+            assert first >= int(dgr._HEADROOM * D) and cap == dgr._ROOM * first      # launches for 1.25 x the count, buffers for four times the launches
+            first2, cap2 = dgr._capacity_for(key, N + N // 10)            # a model that has just densified: the estimate follows the point count, no synchronous call
+            assert first2 > first and cap2 == dgr._ROOM * first2
+            dgr.last_num_rendered = -1
+            redone, beyond = dgr.redone_calls, dgr.beyond_hint_calls
+            with warnings.catch_warnings():
+                warnings.simplefilter("error")
+                got = fn()
+                assert dgr.pending_calls() == 1                         # the call went through the sync-free entry point: its final status words are on their way
+                if mode == "verified":
+                    assert int(dgr.last_num_rendered) == D              # ... and forward() has had its count already
+                dgr.flush()
+            assert dgr.pending_calls() == 0 and (dgr.redone_calls, dgr.beyond_hint_calls) == (redone, beyond)
+            assert int(dgr.last_num_rendered) == D
+            for a, b in zip(got, ref):
+                assert torch.equal(a, b), fn.__name__
+    finally:
+        dgr.sync_free(was_mode)
 
 
-def test_drop_in_forward_is_exact_when_the_learnt_capacity_is_half_the_need():
+@pytest.mark.parametrize("mode", ["verified", "unverified"])
+def test_drop_in_forward_is_exact_when_the_learnt_capacity_is_half_the_need(mode):
     """VERDICT r5 item 1.  The reference never returns an incomplete image (main_3DGS_renderer.py:927-936 sizes its binning buffer from the exact count).  Force the learnt
-    capacity to HALF of what the view needs: under torch.no_grad() the call takes the synchronous path anyway; under autograd the first attempt of c3d_gs_forward_nosync
-    overflows and the device bins and composites the view a second time at the buffers' capacity inside the same call.  Image, radii and ALL gradients bit-equal to
-    sync_free(False), no warning, no exception; afterwards the first capacity has followed the count."""
+    capacity -- the size of the LAUNCHES -- to half of what the view needs, under autograd and under torch.no_grad(): the sort workgroups stay and draw on, the ranges kernel
+    strides, the clear follows the count.  Image, radii and ALL gradients bit-equal to sync_free(False), no warning, no exception, no second rendering; afterwards the hint
+    has followed the count."""
     import warnings
     import diff_gaussian_rasterization as dgr
     plain, rawp, N, H, W = _drop_in_pair(seed=18, n=50000, W=360, H=200, scale=0.015, cam=(5.0, -40.0, 2.2))
     key = (torch.cuda.current_device(), H, W)
     slack, dgr._SLACK = dgr._SLACK, 0
+    was_mode = dgr.sync_free(mode)
     try:
         for fn in (plain, rawp):
-            dgr._learnt.pop(key, None)
-            was = dgr.sync_free(False)
-            try:
-                ref = fn()
-            finally:
-                dgr.sync_free(was)
-            D = int(dgr.last_num_rendered)
-            dgr._learnt[key][N] = D // 3                              # first capacity = 1.5 x that = half the need; buffers = 2 x the need
+            ref, D = _sync_reference(dgr, fn, key)
+            dgr._learnt[key][N] = int(D / (2 * dgr._HEADROOM))          # launch hint = half the need; buffers = 2 x the need
             first, cap = dgr._capacity_for(key, N)
-            assert first == D // 3 * 3 // 2 and first <= D // 2 and cap >= D
-            redone = dgr.redone_calls
+            assert first <= D // 2 and D <= cap <= 2 * D
+            redone, beyond = dgr.redone_calls, dgr.beyond_hint_calls
             with warnings.catch_warnings():
                 warnings.simplefilter("error")
                 got = fn()
                 assert dgr.pending_calls() == 1
                 dgr.flush()
-            assert dgr.redone_calls == redone + 1                   # the device did redo the view
+            assert (dgr.redone_calls, dgr.beyond_hint_calls) == (redone, beyond + 1)      # the count exceeded the hint, the buffers held it: nothing rendered twice
             assert dgr._learnt[key][N] == D                         # ... and the host has learnt the count
             for a, b in zip(got, ref):
                 assert torch.equal(a, b), fn.__name__
             with warnings.catch_warnings():
                 warnings.simplefilter("error")
-                got = fn()                                          # the next call fits its first attempt
+                got = fn()                                          # the next call fits its hint
                 dgr.flush()
-            assert dgr.redone_calls == redone + 1
+            assert (dgr.redone_calls, dgr.beyond_hint_calls) == (redone, beyond + 1)
             for a, b in zip(got, ref):
                 assert torch.equal(a, b), fn.__name__
-        # without autograd: the synchronous path whatever was learnt (and forward-only: nothing pending, same bits)
+        # without autograd (parameters that require a gradient, grad mode off: not differentiated -> forward-only, same bits)
         sc = S.make_cloud(50000, seed=18, log_scale_mean=np.log(0.015))
         st = S.camera_settings(360, 200, 49.1, 5.0, -40.0, 2.2)
-        dgr._learnt[key][N] = 1000
+        D = dgr._learnt[key][N]
+        dgr._learnt[key][N] = int(D / (2 * dgr._HEADROOM))
+        beyond = dgr.beyond_hint_calls
         with torch.no_grad(), warnings.catch_warnings():
             warnings.simplefilter("error")
-            color, radii, depth, alpha, _, _ = hip_forward(sc, st, requires_grad=True)      # parameters that require a gradient, grad mode off: still not differentiated
-            assert dgr.pending_calls() == 0
+            color, radii, depth, alpha, _, _ = hip_forward(sc, st, requires_grad=True)
+            assert dgr.pending_calls() == 1
+            dgr.flush()
+        assert dgr.beyond_hint_calls == beyond + 1 and not color.requires_grad
         was = dgr.sync_free(False)
         try:
             color0, radii0, depth0, alpha0, _, _ = hip_forward(sc, st, requires_grad=True)
@@ -750,24 +762,60 @@ def test_drop_in_forward_is_exact_when_the_learnt_capacity_is_half_the_need():
         assert torch.equal(color, color0) and torch.equal(radii, radii0) and torch.equal(depth, depth0) and torch.equal(alpha, alpha0)
     finally:
         dgr._SLACK = slack
+        dgr.sync_free(was_mode)
 
 
-def test_a_view_beyond_the_buffers_comes_back_as_nan_and_raises_one_call_late():
-    """the one case the two attempts cannot render: a pair count more than 6 x the largest seen.  Never an image that merely looks plausible: the planes are NaN, nothing is
-    read or written out of bounds in either direction, the next examination raises, and the capacity has regrown -- the call after that is exact again."""
+def test_a_view_beyond_its_buffers_is_rendered_again_at_the_exact_count():
+    """the default mode's last line of defence: a pair count more than 6 x the largest seen does not fit the call's buffers.  forward() has waited for the count, so it knows --
+    and renders the second half again at the exact count, on the geometry already projected, before anything leaves: image, radii and every gradient bit-equal to the
+    synchronous path, under autograd and without (no caller ever receives a truncated image)."""
+    import warnings
+    import diff_gaussian_rasterization as dgr
+    plain, rawp, N, H, W = _drop_in_pair(seed=18, n=50000, W=360, H=200, scale=0.015, cam=(5.0, -40.0, 2.2))
+    key = (torch.cuda.current_device(), H, W)
+    slack, dgr._SLACK = dgr._SLACK, 0
+    was_mode = dgr.sync_free("verified")
+    try:
+        for fn in (plain, rawp):
+            ref, D = _sync_reference(dgr, fn, key)
+            dgr._learnt[key][N] = int(D / (2 * dgr._HEADROOM * dgr._ROOM))      # buffers for half the need
+            redone = dgr.redone_calls
+            with warnings.catch_warnings():
+                warnings.simplefilter("error")
+                got = fn()
+                dgr.flush()
+            assert dgr.redone_calls == redone + 1 and dgr._learnt[key][N] == D
+            for a, b in zip(got, ref):
+                assert torch.equal(a, b), fn.__name__
+        sc = S.make_cloud(50000, seed=18, log_scale_mean=np.log(0.015))
+        st = S.camera_settings(360, 200, 49.1, 5.0, -40.0, 2.2)
+        dgr._learnt[key][N] = int(D / (2 * dgr._HEADROOM * dgr._ROOM))
+        with torch.no_grad():
+            color, radii, depth, alpha, _, _ = hip_forward(sc, st)
+        assert dgr.redone_calls == redone + 2
+        was = dgr.sync_free(False)
+        try:
+            with torch.no_grad():
+                color0, radii0, depth0, alpha0, _, _ = hip_forward(sc, st)
+        finally:
+            dgr.sync_free(was)
+        assert torch.equal(color, color0) and torch.equal(radii, radii0) and torch.equal(depth, depth0) and torch.equal(alpha, alpha0)
+    finally:
+        dgr._SLACK = slack
+        dgr.sync_free(was_mode)
+
+
+def test_unverified_mode_returns_nan_for_a_view_beyond_its_buffers_and_raises_one_call_late():
+    """sync_free('unverified') -- the host never waits -- cannot render a view whose pair count exceeds its buffers.  Never an image that merely looks plausible: the planes are
+    NaN, nothing is read or written out of bounds in either direction, the next examination raises, and the capacity has regrown -- the call after that is exact again."""
     import diff_gaussian_rasterization as dgr
     plain, _, N, H, W = _drop_in_pair(seed=18, n=50000, W=360, H=200, scale=0.015, cam=(5.0, -40.0, 2.2))
     key = (torch.cuda.current_device(), H, W)
-    dgr._learnt.pop(key, None)
-    was = dgr.sync_free(False)
-    try:
-        ref = plain()
-    finally:
-        dgr.sync_free(was)
-    D = int(dgr.last_num_rendered)
+    ref, D = _sync_reference(dgr, plain, key)
     slack, dgr._SLACK = dgr._SLACK, 0
+    was_mode = dgr.sync_free("unverified")
     try:
-        dgr._learnt[key][N] = D // 12                                 # buffers for half the need
+        dgr._learnt[key][N] = int(D / (2 * dgr._HEADROOM * dgr._ROOM))      # buffers for half the need
         got = plain()
         torch.cuda.synchronize()
         assert torch.isnan(got[0]).all() and torch.isnan(got[2]).all() and torch.isnan(got[3]).all()
@@ -781,10 +829,11 @@ def test_a_view_beyond_the_buffers_comes_back_as_nan_and_raises_one_call_late():
             assert torch.equal(a, b)
     finally:
         dgr._SLACK = slack
+        dgr.sync_free(was_mode)
 
 
 def test_a_last_call_that_could_not_be_rendered_is_reported_at_exit(tmp_path):
-    """a caller that never issues another forward (and never calls flush()) still hears of it: the pending status words are examined when the interpreter exits"""
+    """sync_free('unverified'): a caller that never issues another forward (and never calls flush()) still hears of it -- the pending status words are examined when the interpreter exits"""
     import subprocess
     import sys
     prog = tmp_path / "last_call.py"
@@ -799,12 +848,14 @@ def test_a_last_call_that_could_not_be_rendered_is_reported_at_exit(tmp_path):
         "rs = dgr.GaussianRasterizationSettings(200, 360, st['tanfovx'], st['tanfovy'], t(st['bg']), 1.0, t(st['viewmatrix']).reshape(4, 4),\n"
         "                                       t(st['projmatrix']).reshape(4, 4), st['sh_degree'], t(st['campos']), False, False)\n"
         "def render():\n"
-        "    return dgr.GaussianRasterizer(rs)(means3D=t(sc['means3D']).requires_grad_(), means2D=None, opacities=t(sc['opacities']), shs=t(sc['shs']), scales=t(sc['scales']),\n"
-        "                                      rotations=t(sc['rotations']))\n"
+        "    with torch.no_grad():\n"
+        "        return dgr.GaussianRasterizer(rs)(means3D=t(sc['means3D']), means2D=None, opacities=t(sc['opacities']), shs=t(sc['shs']), scales=t(sc['scales']),\n"
+        "                                          rotations=t(sc['rotations']))\n"
         "render()\n"                                              # synchronous first call: learns the count
+        "dgr.sync_free('unverified')\n"
         "key = (torch.cuda.current_device(), 200, 360)\n"
         "dgr._learnt[key][50000] //= 12; dgr._SLACK = 0\n"
-        "render()\n"                                              # sync-free, buffers far too small, and nothing examines it
+        "render()\n"                                              # never waited for, buffers far too small, and nothing examines it
         "assert dgr.pending_calls() == 1\n"
         % os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "comfyui-3d-pack_amd"))
     r = subprocess.run([sys.executable, "-W", "always", str(prog)], capture_output=True, text=True, timeout=300)

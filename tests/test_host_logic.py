@@ -590,7 +590,7 @@ def test_kiui_mesh_regularisers_against_literal_restatements():
 
 def test_drop_in_rasterizer_capacity_bookkeeping():
     """host side of the sync-free drop-in forward (diff_gaussian_rasterization/__init__.py): what is learnt per (device, H, W) shape, how a point count not seen yet is
-    estimated, the two capacities of a call, and who counts as differentiated (grad MODE, not only requires_grad -- ADVICE r5)"""
+    estimated, the launch hint and the buffer capacity of a call, and who counts as differentiated (grad MODE, not only requires_grad -- ADVICE r5)"""
     import diff_gaussian_rasterization as dgr
     key = (0, 1080, 1920)
     saved, dgr._learnt = dgr._learnt, {}
@@ -600,11 +600,11 @@ def test_drop_in_rasterizer_capacity_bookkeeping():
         dgr._learn(key, 1000000, 3900000)                                      # the largest count stays
         assert dgr._learnt[key][1000000] == 4000000 and dgr.last_num_rendered == 3900000
         first, cap = dgr._capacity_for(key, 1000000)
-        assert first == int(4000000 * dgr._HEADROOM) + dgr._SLACK and cap == dgr._REDO * first
+        assert first == int(4000000 * dgr._HEADROOM) + dgr._SLACK and cap == dgr._ROOM * first
         # a model that densified (+10 %) or was pruned (-30 %): the estimate follows the point count; beyond a factor of two it is another model -> learn again
         assert dgr._estimate(key, 1100000) == 4400000 and dgr._estimate(key, 700000) == 2800000
         assert dgr._estimate(key, 2000001) is None and dgr._estimate(key, 499999) is None and dgr._capacity_for(key, 10000) is None
-        # no view holds more pairs than N x tiles: a small scene gets ONE attempt at that bound
+        # no view holds more pairs than N x tiles: a small scene gets launches and buffers of that bound (hint 0)
         dgr._learn((0, 64, 64), 100, 900)
         assert dgr._capacity_for((0, 64, 64), 100) == (0, 100 * 16)
         # at most _MODELS point counts per shape, least recently used first out
@@ -614,6 +614,7 @@ def test_drop_in_rasterizer_capacity_bookkeeping():
         was = dgr.sync_free(False)
         try:
             assert dgr._capacity_for(key, 3000001) is None
+            assert dgr.sync_free("unverified") is False and dgr.sync_free(True) == "unverified" and dgr.sync_free(False) == "verified"
         finally:
             dgr.sync_free(was)
         p = torch.nn.Parameter(torch.zeros(3))

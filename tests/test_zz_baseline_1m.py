@@ -221,3 +221,63 @@ def test_train_views_raw_gradients_match_sum_of_float64_oracle_views(full, lanes
 def test_train_views_raw_full_loss_with_msssim_matches_oracle_plus_torch(full):
     loss, grads = full["full"]
     _check("full loss (MS-SSIM inside)", loss, full["loss_full_ref"], grads, full["ref_full"], full["tainted"])
+
+
+def test_drop_in_raw_entry_point_sync_free_matches_the_float64_oracle_on_eight_cameras(full):
+    """the drop-in path at BASELINE size.  One autograd call per view through diff_gaussian_rasterization.rasterize_gaussians_raw -- after the shape's first
+    call that is c3d_gs_forward_raw_nosync (hint-sized launches, the count word in pinned memory) + c3d_gs_backward_raw --, the loss of bench.py's default line spelled in torch,
+    gradients accumulated over the eight views by autograd: same check, same bounds as the fused entry point."""
+    import diff_gaussian_rasterization as dgr
+    raw = full["raw"]
+    dev = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device="cuda")
+    params = [dev(raw["means3D"]), dev(raw["shs"][:, :1]), dev(raw["shs"][:, 1:]), dev(raw["opacities"]), dev(raw["scales"]), dev(raw["rotations"])]
+    for p in params:
+        p.requires_grad_(True)
+    rs = [hip_settings(S.camera_settings(W, H, 49.1, el, az, 2.2, bg=(1, 1, 1)), "cuda") for el, az in POSES]
+    V = len(rs)
+    rng = np.random.default_rng(77)      # the fixture's targets
+    tcs = [rng.uniform(size=(3, H, W)).astype(np.float32) for _ in range(V)]
+    tas = [rng.uniform(size=(1, H, W)).astype(np.float32) for _ in range(V)]
+    with torch.no_grad():                # the shape's first call takes the synchronous path and learns the count
+        dgr.rasterize_gaussians_raw(params[0], None, params[1], params[2], params[3], params[4], params[5], rs[0])
+    calls0 = dgr.sync_free_calls
+    loss_total = 0.0
+    for v in range(V):
+        m2d = torch.zeros_like(params[0], requires_grad=True)
+        color, radii, depth, alpha = dgr.rasterize_gaussians_raw(params[0], m2d, params[1], params[2], params[3], params[4], params[5], rs[v])
+        loss = (0.8 * (color.clamp(0, 1) - dev(tcs[v])).abs().mean() + 3.0 * ((alpha - dev(tas[v])) ** 2).mean()) / V
+        loss.backward()
+        loss_total += float(loss.item())
+    assert dgr.sync_free_calls - calls0 == V      # every differentiated call went through the sync-free entry point
+    dgr.flush()
+    _check("drop-in raw, sync-free", loss_total, full["loss_ref"], [p.grad.cpu().numpy() for p in params], full["ref"], full["tainted"], full["ref32"])
+
+
+def test_render_views_raw_matches_oracle_forward_on_all_64_orbit_cameras(oracle_built):
+    """BASELINE config 2 IS the 64 orbit cameras; the fixture above holds eight of them forward and backward.  Here all 64 go through
+    c3d_gs_render_views_raw (groups of 16, as bench.py's forward target runs them) and every image, alpha, depth and radius is held to one float64 pass of the oracle
+    (forward only: ~1.5 s per camera on the box's host cores)."""
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a HIP device (no CPU fallback exists)")
+    from c3d_hip.gs_step import FusedViewRender
+    nt = os.cpu_count() or 8
+    raw = S.make_cloud(N, seed=1234, activated=False)
+    act = S.make_cloud(N, seed=1234, activated=True)
+    dev = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device="cuda")
+    plist = [dev(raw["means3D"]), dev(raw["shs"][:, :1]), dev(raw["shs"][:, 1:]), dev(raw["opacities"]), dev(raw["scales"]), dev(raw["rotations"])]
+    poses = S.orbit_poses_64()
+    assert len(poses) == 64
+    sts = [S.camera_settings(W, H, 49.1, e, az, r, bg=(1, 1, 1)) for (r, e, az) in poses]
+    ren = FusedViewRender(N, H, W, "cuda", lanes=1, group=16)
+    color, depth, alpha, radii = ren.run([hip_settings(st, "cuda") for st in sts], plist, want_radii=True)
+    color, depth, alpha, radii = color.cpu().numpy(), depth.cpu().numpy(), alpha.cpu().numpy(), radii.cpu().numpy()
+    del ren
+    worst = dict(l1=0.0, a=0.0, d=0.0, mx=0.0, rad=0)
+    for v, st in enumerate(sts):
+        oc, orad, od, oa, ost = oracle_forward(act, st, dtype=np.float64, nthreads=nt)
+        del ost
+        l1, la, ld, mx, rd = float(np.abs(color[v] - oc).mean()), float(np.abs(alpha[v] - oa).mean()), float(np.abs(depth[v] - od).mean()), float(np.abs(color[v] - oc).max()), int((radii[v] != orad).sum())
+        worst = dict(l1=max(worst["l1"], l1), a=max(worst["a"], la), d=max(worst["d"], ld), mx=max(worst["mx"], mx), rad=max(worst["rad"], rd))
+        assert l1 <= 1e-4 and la <= 1e-4 and ld <= 1e-4, (poses[v], l1, la, ld)
+        assert rd <= 20 and mx <= 2e-2, (poses[v], rd, mx)
+    print("[1M forward, 64 cameras] worst L1 colour %.2e alpha %.2e depth %.2e, worst max colour %.2e, most radii differing in a view %d" % (worst["l1"], worst["a"], worst["d"], worst["mx"], worst["rad"]))

@@ -148,3 +148,109 @@ def test_bench_starts_its_own_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["rccl_ranks"] == 2 and d["config"]["dist_backend"] == "gloo" and d["config"]["global_views_per_step"] == 4
     assert d["value"] > 0
+
+
+_OVERFLOW_TWO_RANKS = r'''
+import os, sys, warnings
+import numpy as np, torch
+import torch.distributed as dist
+sys.path.insert(0, %(pkg)r); sys.path.insert(0, %(tests)r)
+from c3d_hip import synthetic as S, parallel
+from c3d_hip.gs_step import FusedViewStep
+from helpers import hip_settings
+torch.cuda.set_device(0)
+dist.init_process_group("gloo")
+rank = dist.get_rank()
+N, W, H = 40000, 320, 200
+raw = S.make_cloud(N, seed=5, log_scale_mean=np.log(0.015), activated=False)
+dev = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device="cuda")
+plist = [dev(raw["means3D"]), dev(raw["shs"][:, :1]), dev(raw["shs"][:, 1:]), dev(raw["opacities"]), dev(raw["scales"]), dev(raw["rotations"])]
+cams = lambda radius, r: [hip_settings(S.camera_settings(W, H, 49.1, el, az, radius, bg=(1, 1, 1)), "cuda") for el, az in ((10.0 + 20 * r, 30.0 + 90 * r), (-15.0, 200.0 + 40 * r))]
+rng = np.random.default_rng(3 + rank)
+tcs = [dev(rng.uniform(size=(3, H, W))) for _ in range(2)]
+tas = [dev(rng.uniform(size=(1, H, W))) for _ in range(2)]
+step = FusedViewStep(N, H, W, "cuda", views=2)
+step.defer_status = True
+step.status_sync = parallel.status_max(None)
+assert step.status_sync is not None
+fg = parallel.FlatGrads(plist)
+def run(rs):
+    step.run(rs, plist, fg.views, tcs, tas, None, w_l1=0.8, w_alpha_mse=3.0, scale=0.25, accumulate=False, param_chunks=4, after_chunk=fg.exchange_rows)
+    fg.exchange_finish()
+    return fg.flat.clone()
+far, near = cams(6.0, rank), cams(1.4, rank)
+for _ in range(3):
+    run(far)                                    # fit, then the deferred steady state: the ranges' all-reduces go out under the per-Gaussian pass
+cap0 = step.capacity
+with warnings.catch_warnings(record=True) as w:
+    warnings.simplefilter("always")
+    run(near if rank == 1 else far)             # rank 1's views need ~18 x the pairs: overflow on ONE rank, noticed one step late
+    got = run(near if rank == 1 else far)       # ... by EVERY rank (max over ranks of the status words): all regrow, all redo this step together
+    step.finish()
+assert any("incomplete" in str(x.message) for x in w), [str(x.message) for x in w]
+assert step.capacity > 4 * cap0, (cap0, step.capacity)
+caps = [None, None]
+dist.all_gather_object(caps, step.capacity)
+assert caps[0] == caps[1], caps                 # the capacity follows the max over ranks: the same on every rank
+sums = [None, None]
+dist.all_gather_object(sums, float(got.double().abs().sum().item()))
+assert sums[0] == sums[1], sums                 # replicas identical
+# against ONE process that renders all four views of the step itself
+allv = cams(6.0, 0) + cams(1.4, 1)
+tc_all, ta_all = [], []
+for r in range(2):
+    g = np.random.default_rng(3 + r)
+    tc_all += [dev(g.uniform(size=(3, H, W))) for _ in range(2)]
+    ta_all += [dev(g.uniform(size=(1, H, W))) for _ in range(2)]
+ref = FusedViewStep(N, H, W, "cuda", views=4)
+gr = [torch.empty_like(p) for p in plist]
+ref.run(allv, plist, gr, tc_all, ta_all, None, w_l1=0.8, w_alpha_mse=3.0, scale=0.25, accumulate=False)
+for a, b, name in zip(fg.views, gr, ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")):
+    err = float((a - b).double().norm() / b.double().norm().clamp_min(1e-30))
+    assert err <= 1e-5, (name, err)
+print("OVERFLOW-TOGETHER-OK rank %%d capacity %%d -> %%d" %% (rank, cap0, step.capacity))
+dist.destroy_process_group()
+'''
+
+
+def test_pair_overflow_on_one_rank_makes_all_ranks_redo_the_step_together(tmp_path):
+    """VERDICT r5 item 7a.  Two ranks (gloo, both on GPU 0), the overlapped chunked exchange and deferred status words -- the configuration in which round 5 RAISED on the rank
+    whose views exceeded the fitted pair capacity, after its ranges' collectives had gone out: a dead job on eight ranks.  Now the status words every decision is taken from
+    are the maximum over the ranks (one 12-byte all-reduce per step): all ranks regrow to the same capacity and redo the step together; the result equals one process
+    rendering all four views."""
+    import socket
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = tmp_path / "overflow_two_ranks.py"
+    prog.write_text(_OVERFLOW_TWO_RANKS % dict(pkg=os.path.join(root, "comfyui-3d-pack_amd"), tests=os.path.join(root, "tests")))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port), str(prog)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    assert r.stdout.count("OVERFLOW-TOGETHER-OK") == 2, r.stdout[-2000:]
+
+
+def test_the_drivers_eight_rank_command_with_the_all_gather_exchange():
+    """VERDICT r5 item 7c.  The driver's exact multi-GPU command -- python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py
+    --gpus 8 --steps K --warmup W -- at BASELINE size with the north star's wording of the exchange (--exchange allgather), eight ranks sharing the one GPU and talking
+    gloo (C3D_BENCH_SHARE_DEVICE=1): the world the process group saw, every rank's own step time and pair counts in the one line."""
+    import json
+    import socket
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, C3D_BENCH_SHARE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "2", "--exchange", "allgather"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    c = d["config"]
+    assert d["n_gpus"] == 8 and c["rccl_ranks"] == 8 and c["exchange"] == "allgather" and c["global_views_per_step"] == 64 and d["scaling"] == "weak"
+    pr = c["per_rank"]
+    assert len(pr["ms_per_step"]) == 8 and len(pr["tile_splat_pairs_per_view"]) == 8 and min(pr["tile_splat_pairs_per_view"]) > 0
+    assert pr["ms_per_step_min"] <= pr["ms_per_step_max"] and d["ms_per_step"] >= pr["ms_per_step_max"] * 0.999
+    print("[8 ranks on one GPU, gloo] per-rank ms %s, pairs per view %s" % (pr["ms_per_step"], pr["tile_splat_pairs_per_view"]))
