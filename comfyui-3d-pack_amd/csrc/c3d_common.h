@@ -60,7 +60,7 @@ int c3d_scan_u32(const uint32_t* in, uint32_t* out, size_t n, bool exclusive, vo
 // in rsort[i].  tail_meta (optional, device): receives min(total, tail_cap) in [0]; tail_status (optional): [0] |= 1 when total > tail_cap, [1] = max(total).
 int c3d_scan_rect_gather(const uint2* rect, const uint32_t* idx, uint32_t* out, uint2* rsort, size_t n, void* tmp, hipStream_t s, bool zero_state,
                          uint32_t* tail_meta, uint32_t* tail_status, uint32_t tail_cap, uint32_t* err = nullptr, int V = 1, size_t vs = 0, uint32_t tail_hint = 0,
-                         unsigned long long* tail_early = nullptr);
+                         unsigned long long* tail_early = nullptr, bool rect4 = false);      // rect4: `rect` holds 4-byte packed rects (c3d_rect_pack); rsort receives them unpacked
 // tail_hint (0 = none): the count the launches of the chain were sized for; tail_status[0] |= C3D_ST_BEYOND_HINT when the total exceeds it (information: workgroups looped),
 // |= C3D_ST_OVERFLOW when it exceeds tail_cap (the buffers).  tail_early (optional): device-visible address of 8 bytes of pinned host memory that receives total << 32 | bits.
 #define C3D_ST_OVERFLOW 1u
@@ -90,10 +90,16 @@ int c3d_sort_set_debug(unsigned long long* stamps);   // profiling hook (nullptr
 #define C3D_SORT_MAX_PASSES 4
 int c3d_sort_pairs_u32(uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32_t* vals1, bool iota_vals,
                        size_t n, int end_bit, void* tmp, int* result_buf, hipStream_t s, const uint32_t* n_dev = nullptr, bool zero_state = true, uint32_t* err = nullptr,
-                       int V = 1, size_t vs = 0, bool hist_done = false, size_t n_hint = 0);      // n_hint (one view, n_dev given): size the launches for n_hint < n elements; a larger count loops
+                       int V = 1, size_t vs = 0, bool hist_done = false, size_t n_hint = 0,      // n_hint (one view, n_dev given): size the launches for n_hint < n elements; a larger count loops
+                       uint2* ranges = nullptr);      // ranges (per view, cleared): the last pass leaves {~first position, last position + 1} of every key value there (atomicMax; {0, 0} = no such key)
 
 // ---- device helpers ----
 #ifdef __HIPCC__
+// tile rect of a Gaussian, {x0 | y0 << 16, x1 | y1 << 16}, in FOUR bytes x0 | y0 << 8 | x1 << 16 | y1 << 24 when the tile grid is at most 255 x 255 (images up to 4080 px a side;
+// GsParams::rect4): the one random access of the binning chain -- the emit-offset scan gathers rect[order[i]] -- then runs over a 4 MB table per 1 M Gaussians instead of 8 MB,
+// which one XCD's L2 holds (round 5's counters: 838 MB fetched per 16-view launch for 190 MB of useful input, one 64-byte line per 8-byte gather)
+__device__ __forceinline__ uint32_t c3d_rect_pack(uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1) { return x0 | (y0 << 8) | (x1 << 16) | (y1 << 24); }
+__device__ __forceinline__ uint2 c3d_rect_unpack(uint32_t r) { return make_uint2((r & 0xFFu) | ((r & 0xFF00u) << 8), ((r >> 16) & 0xFFu) | ((r >> 24) << 16)); }
 // multi-view launches: blockIdx.y = view; per-view pointers are given for view 0 and view v's lies v * vs bytes behind it (NULL stays NULL)
 template <class T> __device__ __forceinline__ T* c3d_view_ptr(T* p, size_t vs) { return p ? (T*)((char*)p + (size_t)blockIdx.y * vs) : p; }
 __device__ __forceinline__ int c3d_lane() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }

@@ -44,6 +44,7 @@ static int make_params(const c3d_gs_settings* st, int N, int M, GsParams& p) {
     p.scale_modifier = st->scale_modifier;
     p.dscale_mod = (st->flags & C3D_GS_FLAG_EXACT_DSCALE) ? st->scale_modifier : 1.0f;
     p.bg = st->bg; p.view = st->viewmatrix; p.proj = st->projmatrix; p.campos = st->campos;
+    p.rect4 = (p.gx <= 255 && p.gy <= 255) ? 1 : 0;
     return 0;
 }
 // SH coefficients per channel the raw parameters store (c3d_gs_settings::sh_coeffs; 0 = 16); -1 + message if it is not one of 1, 4, 9, 16
@@ -73,7 +74,7 @@ static int check_inputs(int N, int M, int deg, const float* means3D, const float
 // cap / status: pair capacity and status words of the sync-free paths (the pair count then stays on the device in g.meta[0]).
 // (the record-base scan of the backward pass -- rbase, einfo -- is not on this chain any more: it rides in the recording forward compositing launch, scan_wave.h)
 // hint / early: c3d_gs_forward_nosync -- the pair count its launches are sized for, and where the scan's tail leaves {bits, count} for the host (c3d_scan_rect_gather)
-static int binning_front(GsGeom& g, int N, uint32_t cap, uint32_t* status, hipStream_t s, int V = 1, size_t vs = 0, bool cleared = false, uint32_t hint = 0,
+static int binning_front(const GsParams& p, GsGeom& g, int N, uint32_t cap, uint32_t* status, hipStream_t s, int V = 1, size_t vs = 0, bool cleared = false, uint32_t hint = 0,
                          unsigned long long* early = nullptr) {
     int rc, res = 0;
     if (!cleared) {
@@ -85,7 +86,7 @@ static int binning_front(GsGeom& g, int N, uint32_t cap, uint32_t* status, hipSt
       if ((rc = c3d_sort_pairs_u32(g.key[0], g.key[1], g.order[0], g.order[1], true, (size_t)N, 32, g.tmp_sort, &res, s, nullptr, false, err, V, vs))) return rc; }
     if (res != sort_result_index(32)) { c3d_set_error("internal: depth sort buffer parity"); return -2; }
     { C3dProfScope ps(C3D_P_SCAN, s);
-      if ((rc = c3d_scan_rect_gather(g.rect, g.order[res], g.offsets, g.rsort, (size_t)N, g.tmp_scan_b, s, false, (uint32_t*)g.meta, status, cap, err, V, vs, hint, early))) return rc; }
+      if ((rc = c3d_scan_rect_gather(g.rect, g.order[res], g.offsets, g.rsort, (size_t)N, g.tmp_scan_b, s, false, (uint32_t*)g.meta, status, cap, err, V, vs, hint, early, p.rect4 != 0))) return rc; }
     return 0;
 }
 // emit + tile sort + per-tile ranges; D = pair count on the host, or the capacity when d_dev (device count, per view) is given
@@ -110,18 +111,16 @@ static int binning_back(const GsParams& p, GsGeom& g, GsBinning& b, long long D,
       if ((rc = gs_launch_emit(p, g, sort_result_index(32), b, s, cap, V, vs, (tile_sort_bits(tiles) + 7) / 8))) return rc; }      // (also counts the digits of the keys it writes)
     { C3dProfScope ps(C3D_P_TILE_SORT, s);
       if ((rc = c3d_sort_pairs_u32(b.tkey[0], b.tkey[1], b.tval[0], b.tval[1], false, (size_t)D, tile_sort_bits(tiles), b.tmp, &res, s, d_dev, false, err, V, vs, true,
-                                   hinted ? (size_t)D_hint : 0))) return rc; }
+                                   hinted ? (size_t)D_hint : 0, b.ranges))) return rc; }      // (the last pass leaves the per-tile ranges: A5)
     if (res != sort_result_index(tile_sort_bits(tiles))) { c3d_set_error("internal: tile sort buffer parity"); return -2; }
-    { C3dProfScope ps(C3D_P_RANGES, s);
-      if ((rc = gs_launch_ranges(b, res, D, s, d_dev, V, vs, hinted ? D_hint : 0))) return rc; }
     *res_out = res;
     return 0;
 }
 
 // drop-in path: the single D2H read of the pair count (the wheel has the same synchronisation) also brings back the error word
-static int project_tail(GsGeom& g, int N, int64_t* num_rendered, hipStream_t s) {
+static int project_tail(const GsParams& p, GsGeom& g, int N, int64_t* num_rendered, hipStream_t s) {
     int rc;
-    if ((rc = binning_front(g, N, 0xFFFFFFFFu, nullptr, s))) return rc;
+    if ((rc = binning_front(p, g, N, 0xFFFFFFFFu, nullptr, s))) return rc;
     uint32_t host[4] = {0, 0, 0, 0};
     C3D_CHECK(hipMemcpyAsync(host, g.meta, sizeof(host), hipMemcpyDeviceToHost, s));
     C3D_CHECK(hipStreamSynchronize(s));
@@ -163,7 +162,7 @@ int c3d_gs_forward_project(const c3d_gs_settings* st, int32_t N, int32_t M, cons
     int rc;
     { C3dProfScope ps(C3D_P_PREPROCESS, s);
     if ((rc = gs_launch_preprocess(p, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, radii, s))) return rc; }
-    return project_tail(g, N, num_rendered, s);
+    return project_tail(p, g, N, num_rendered, s);
 }
 
 int c3d_gs_forward_project_raw(const c3d_gs_settings* st, int32_t N, const float* means3D, const float* f_dc, const float* f_rest,
@@ -183,7 +182,7 @@ int c3d_gs_forward_project_raw(const c3d_gs_settings* st, int32_t N, const float
     int rc;
     { C3dProfScope ps(C3D_P_PREPROCESS, s);
     if ((rc = gs_launch_preprocess_raw(p, means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, g, radii, s))) return rc; }
-    return project_tail(g, N, num_rendered, s);
+    return project_tail(p, g, N, num_rendered, s);
 }
 
 int c3d_gs_forward_render(const c3d_gs_settings* st, int32_t N, int32_t M, const int32_t* radii, void* geom_buffer,
@@ -238,7 +237,7 @@ static int forward_tail_nosync(const c3d_gs_settings* st, const GsParams& p, GsG
     }
     int rc, res = 0;
     C3D_CHECK(hipMemsetAsync(status, 0, 2 * sizeof(uint32_t), s));
-    if ((rc = binning_front(g, N, cap, status, s, 1, 0, false, (uint32_t)hint, early))) return rc;
+    if ((rc = binning_front(p, g, N, cap, status, s, 1, 0, false, (uint32_t)hint, early))) return rc;
     if ((rc = binning_back(p, g, b, pair_capacity, cap, (const uint32_t*)g.meta, status, s, &res, 1, 0, false, hint))) return rc;
     { C3dProfScope ps(C3D_P_COMPOSITE_FWD, s);
       GsFwdViews vp{};
@@ -477,7 +476,7 @@ static int group_bin(ViewGroup& q, uint32_t* status, bool clear_pvalid, hipStrea
         const size_t bytes[3] = {q.g0.zero_bytes, q.b0.zero_bytes, clear_pvalid ? (((size_t)q.cap + 15) & ~(size_t)15) : 0};
         if ((rc = c3d_zero_views(q.slice0, q.vs, q.G, off, bytes, clear_pvalid ? 3 : 2, s))) return rc;
     }
-    if ((rc = binning_front(q.g0, q.N, q.cap, status, s, q.G, q.vs, true))) return rc;
+    if ((rc = binning_front(q.p[0], q.g0, q.N, q.cap, status, s, q.G, q.vs, true))) return rc;
     return binning_back(q.p[0], q.g0, q.b0, (long long)q.cap, q.cap, (const uint32_t*)q.g0.meta, status, s, res_out, q.G, q.vs, true);
 }
 // A6 of the group.  out_*[i] (arrays or entries may be NULL): the caller's planes of view i; otherwise the slice's own.
@@ -808,6 +807,10 @@ __global__ void k_debug_unpack(int N, GsGeom g, float* xy, float* depths, float*
     if (rgb) { rgb[3 * i] = a1.z; rgb[3 * i + 1] = a1.w; rgb[3 * i + 2] = a2.x; }
     if (tiles) tiles[i] = g.tiles[i];
 }
+__global__ void k_debug_ranges(int tiles, const uint2* __restrict__ raw, uint2* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < tiles) out[i] = gs_tile_range(raw[i]);
+}
 int c3d_gs_debug_state(int32_t N, int32_t H, int32_t W, const void* geom_buffer, int64_t D, const void* binning_buffer,
                        uint32_t* point_list, uint32_t* ranges, float* xy, float* depths, float* conic_opacity, float* rgb,
                        uint32_t* tiles_touched, c3d_stream_t stream) {
@@ -824,7 +827,7 @@ int c3d_gs_debug_state(int32_t N, int32_t H, int32_t W, const void* geom_buffer,
         gs_carve_binning((char*)binning_buffer, D, tiles, b);
         const int res = sort_result_index(tile_sort_bits(tiles));
         if (point_list && D > 0) C3D_CHECK(hipMemcpyAsync(point_list, b.tval[res], sizeof(uint32_t) * (size_t)D, hipMemcpyDeviceToDevice, s));
-        if (ranges) C3D_CHECK(hipMemcpyAsync(ranges, b.ranges, sizeof(uint2) * (size_t)tiles, hipMemcpyDeviceToDevice, s));
+        if (ranges) { hipLaunchKernelGGL(k_debug_ranges, dim3(c3d_cdiv(tiles, 256)), dim3(256), 0, s, tiles, (const uint2*)b.ranges, (uint2*)ranges); C3D_LAUNCH_CHECK(); }
     }
     return 0;
 }
@@ -850,7 +853,7 @@ int c3d_test_scan_wave(const uint32_t* in, const uint32_t* rect, uint32_t* out, 
     C3D_CHECK(hipMalloc(&tmp, scan_wave_tmp_bytes((size_t)n) + 64));
     C3D_CHECK(hipMemsetAsync(tmp, 0, scan_wave_tmp_bytes((size_t)n) + 64, s));
     uint32_t* err = (uint32_t*)((char*)tmp + scan_wave_tmp_bytes((size_t)n));
-    const ScanWaveJob sj{in, out, (const uint2*)rect, (uint4*)einfo, (uint32_t*)tmp, err, (uint32_t)n, scan_wave_blocks((size_t)n)};
+    const ScanWaveJob sj{in, out, (const uint2*)rect, (uint4*)einfo, (uint32_t*)tmp, err, (uint32_t)n, scan_wave_blocks((size_t)n), 0};
     hipLaunchKernelGGL(k_test_scan_wave, dim3(sj.blocks), dim3(64), 0, s, sj);
     uint32_t e = 0;
     hipError_t rc = hipMemcpyAsync(&e, err, 4, hipMemcpyDeviceToHost, s);

@@ -109,7 +109,8 @@ __device__ __forceinline__ float wave_reduce_fold(const float* tile /* [BWD_FOLD
 // DEPTH: some caller-supplied dL/ddepth exists.  The fused training step has none (the reference's loss reads image and alpha only, main_3DGS.py:184-192):
 // its instance drops the depth channel from the per-splat dot product, from the products and from the ten-value reduction (nine values).
 // blockIdx.y = view of a multi-view launch: the state pointers are view 0's (view v lies v * vs bytes behind), pixel-space inputs come from the per-view table `px`.
-template <bool LOSS, bool DEPTH>
+// RECT4: einfo holds eight bytes per Gaussian, {packed rect, record base} (GsParams::rect4) -- a compile-time switch: as a uniform branch at the gather it cost the kernel 1.5 %
+template <bool LOSS, bool DEPTH, bool RECT4>
 __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                                                         const uint4* __restrict__ einfo,
                                                         const float4* __restrict__ rec0, const float4* __restrict__ rec1,
@@ -142,7 +143,7 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
     const int pxi = X0 + ((wave & 1) << 3) + (lane & 7), pyi = Y0 + ((wave >> 1) << 3) + (lane >> 3);
     const bool inside = pxi < p.W && pyi < p.H;
     const float pxf = (float)pxi, pyf = (float)pyi;
-    const uint2 rg = ranges[tile];
+    const uint2 rg = gs_tile_range(ranges[tile]);
     const size_t P = (size_t)p.W * p.H, pid = (size_t)pyi * p.W + pxi;
 
     const float T_final = inside ? final_T[pid] : 0.f;
@@ -194,6 +195,11 @@ __global__ void __launch_bounds__(256) k_composite_bwd(GsParams p, const uint2* 
     const int upto = max(max(up0, up1), max(up2, up3));   // positions [0, upto) matter
     // record index of the pair (this tile, Gaussian gid): the Gaussian's record base + row-major position of the tile inside its rect
     auto emit_index = [&](uint32_t gid) -> uint32_t {
+        if (RECT4) {      // {packed rect, record base}: eight bytes per Gaussian -- the table this gather runs over is half the size
+            const uint2 e8 = reinterpret_cast<const uint2*>(einfo)[gid];
+            const int ex0 = (int)(e8.x & 0xFFu), ey0 = (int)((e8.x >> 8) & 0xFFu), ex1 = (int)((e8.x >> 16) & 0xFFu);
+            return e8.y + (uint32_t)((ty - ey0) * (ex1 - ex0) + (tx - ex0));
+        }
         const uint4 ei = einfo[gid];
         const int ex0 = (int)(ei.y & 0xFFFFu), ey0 = (int)(ei.y >> 16), ex1 = (int)(ei.z & 0xFFFFu);
         return ei.w + (uint32_t)((ty - ey0) * (ex1 - ex0) + (tx - ex0));
@@ -360,8 +366,10 @@ int gs_launch_composite_bwd(const GsParams& p, const GsGeom& g, const GsBinning&
     if (tiles == 0 || V <= 0) return 0;
     const dim3 grid(gs_block_count(p.gx, p.gy), V);
 #define GS_BWD_LAUNCH(LOSS_, DEPTH_, PL_)                                                                                                                        \
-    hipLaunchKernelGGL((k_composite_bwd<LOSS_, DEPTH_>), grid, dim3(256), 0, s, p, b.ranges, b.tval[res], g.einfo, g.rec0, g.rec1, g.rec2, im.final_T, \
-                       im.n_contrib, px, gs_pair_activity(b, res), b.pair_stride, (float4*)pairgrad, pvalid, cap, PL_, vs)
+    do { if (p.rect4) hipLaunchKernelGGL((k_composite_bwd<LOSS_, DEPTH_, true>), grid, dim3(256), 0, s, p, b.ranges, b.tval[res], g.einfo, g.rec0, g.rec1, g.rec2, im.final_T, \
+                       im.n_contrib, px, gs_pair_activity(b, res), b.pair_stride, (float4*)pairgrad, pvalid, cap, PL_, vs);                                         \
+         else hipLaunchKernelGGL((k_composite_bwd<LOSS_, DEPTH_, false>), grid, dim3(256), 0, s, p, b.ranges, b.tval[res], g.einfo, g.rec0, g.rec1, g.rec2, im.final_T, \
+                       im.n_contrib, px, gs_pair_activity(b, res), b.pair_stride, (float4*)pairgrad, pvalid, cap, PL_, vs); } while (0)
     if (plw) { if (depth) GS_BWD_LAUNCH(true, true, *plw); else GS_BWD_LAUNCH(true, false, *plw); }
     else     { if (depth) GS_BWD_LAUNCH(false, true, GsPixelLossW{}); else GS_BWD_LAUNCH(false, false, GsPixelLossW{}); }
 #undef GS_BWD_LAUNCH

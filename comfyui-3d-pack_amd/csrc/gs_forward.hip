@@ -15,7 +15,7 @@ struct GsPreCam { const float* view; const float* proj; const float* campos; flo
 struct GsPreOut { float4* rec0; uint32_t* tiles; uint2* rect; uint32_t* key0; uint8_t* clamped; int* radii; };
 template <class OpacityFn>
 __device__ __forceinline__ void gs_project_one(int idx, const float3 m, const float c3[6], OpacityFn opacity, const float* __restrict__ sh, const float* __restrict__ colors_precomp,
-                                               const GsPreCam& cam, int W, int H, int gx, int gy, int deg, const GsPreOut& o) {
+                                               const GsPreCam& cam, int W, int H, int gx, int gy, int deg, const GsPreOut& o, int rect4) {
     int rad = 0;
     uint32_t nt = 0, key = 0xFFFFFFFFu;
     do {   // `break` = culled: radius 0, no tiles, key 0xFFFFFFFF
@@ -75,10 +75,11 @@ __device__ __forceinline__ void gs_project_one(int idx, const float3 m, const fl
         o.clamped[idx] = cl;
         rad = r;
         nt = (uint32_t)((x1 - x0) * (y1 - y0));
-        o.rect[idx] = make_uint2((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)x1 | ((uint32_t)y1 << 16));
+        if (rect4) reinterpret_cast<uint32_t*>(o.rect)[idx] = c3d_rect_pack((uint32_t)x0, (uint32_t)y0, (uint32_t)x1, (uint32_t)y1);
+        else o.rect[idx] = make_uint2((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)x1 | ((uint32_t)y1 << 16));
         key = nt ? __float_as_uint(pv.z) : 0xFFFFFFFFu;
     } while (false);
-    if (rad == 0) o.rect[idx] = make_uint2(0u, 0u);      // culled: an empty rect (the emit-offset scan takes the tile count from the rect)
+    if (rad == 0) { if (rect4) reinterpret_cast<uint32_t*>(o.rect)[idx] = 0u; else o.rect[idx] = make_uint2(0u, 0u); }      // culled: an empty rect (the emit-offset scan takes the tile count from the rect)
     o.radii[idx] = rad;
     o.tiles[idx] = nt;
     o.key0[idx] = key;
@@ -117,7 +118,7 @@ __global__ void __launch_bounds__(256) k_preprocess(GsParams p, const float* __r
     const float* sh = STAGED ? sh_lds + threadIdx.x * SH_ROW : shs + (size_t)idx * p.M * 3;
     gs_project_one(idx, m, c3, [&]() { return opacities[idx]; }, sh, colors_precomp,
                    GsPreCam{p.view, p.proj, p.campos, p.tanfovx, p.tanfovy, p.focal_x, p.focal_y}, p.W, p.H, p.gx, p.gy, p.deg,
-                   GsPreOut{g.rec0, g.tiles, g.rect, g.key[0], g.clamped, radii});
+                   GsPreOut{g.rec0, g.tiles, g.rect, g.key[0], g.clamped, radii}, p.rect4);
 }
 
 int gs_launch_preprocess(const GsParams& p, const float* means3D, const float* shs, const float* colors_precomp,
@@ -184,7 +185,7 @@ __global__ void __launch_bounds__(128) k_preprocess_views_r(GsParams p, GsPreVie
     const float opac = 1.f / (1.f + expf(-opacities[idx]));
     const int deg = min(p.deg, sh_storage_degree(REST3));
     for (int v = 0; v < vs.V; v++)
-        gs_project_one(idx, m, c3, [&]() { return opac; }, sh, (const float*)nullptr, vs.v[v].cam, p.W, p.H, p.gx, p.gy, deg, vs.v[v].out);
+        gs_project_one(idx, m, c3, [&]() { return opac; }, sh, (const float*)nullptr, vs.v[v].cam, p.W, p.H, p.gx, p.gy, deg, vs.v[v].out, p.rect4);
 }
 // geoms[v] / radii[v]: the state buffers of view v; views[v]: its camera (GsParams of that view; N, W, H, scale_modifier, deg must agree)
 int gs_launch_preprocess_views(const GsParams* views, int V, const GsGeom* geoms, int* const* radii, const float* means3D, const float* f_dc, const float* f_rest,
@@ -283,39 +284,8 @@ int gs_launch_emit(const GsParams& p, const GsGeom& g, int res, GsBinning& b, hi
     return 0;
 }
 
-// A5: [start,end) of every tile in the sorted pair list.  Four consecutive positions per lane (one 16-byte load + the two neighbours): with one position per
-// lane the launch was half a million three-load waves and bound by their latency, not by the 16 MB it reads per view.
-#define RANGES_PER_LANE 4
-// (grid-stride: a launch sized for a HINT of the pair count -- c3d_gs_forward_nosync -- covers every count the buffers hold; sized for D it is one trip)
-__global__ void __launch_bounds__(256) k_ranges(const uint32_t* __restrict__ tkey, uint2* __restrict__ ranges, long long D, const uint32_t* __restrict__ d_dev, size_t vs) {
-    tkey = c3d_view_ptr(tkey, vs); ranges = c3d_view_ptr(ranges, vs); d_dev = c3d_view_ptr(d_dev, vs);
-    if (d_dev) D = min((long long)*d_dev, D);
-    for (long long i0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * RANGES_PER_LANE; i0 < D; i0 += (long long)gridDim.x * blockDim.x * RANGES_PER_LANE) {
-        uint32_t t[RANGES_PER_LANE + 2];
-        if (i0 + RANGES_PER_LANE <= D) { const uint4 q = *reinterpret_cast<const uint4*>(tkey + i0); t[1] = q.x; t[2] = q.y; t[3] = q.z; t[4] = q.w; }
-        else {
-#pragma unroll
-            for (int k = 0; k < RANGES_PER_LANE; k++) t[1 + k] = (i0 + k < D) ? tkey[i0 + k] : 0xFFFFFFFFu;
-        }
-        t[0] = i0 > 0 ? tkey[i0 - 1] : 0xFFFFFFFFu;
-        t[RANGES_PER_LANE + 1] = (i0 + RANGES_PER_LANE < D) ? tkey[i0 + RANGES_PER_LANE] : 0xFFFFFFFFu;
-#pragma unroll
-        for (int k = 0; k < RANGES_PER_LANE; k++) {
-            const long long i = i0 + k;
-            if (i >= D) break;
-            if (i == 0 || t[k] != t[k + 1]) ranges[t[k + 1]].x = (uint32_t)i;
-            if (i == D - 1 || t[k + 2] != t[k + 1]) ranges[t[k + 1]].y = (uint32_t)(i + 1);
-        }
-    }
-}
-// `ranges` must be zero on entry: the binning stage clears it together with the tile-sort state.  D_launch (0 = D): the pair count the grid is sized for (a hint; D bounds the count)
-int gs_launch_ranges(const GsBinning& b, int res, long long D, hipStream_t s, const uint32_t* d_dev, int V, size_t vs, long long D_launch) {
-    if (D == 0 || V <= 0) return 0;
-    if (D_launch <= 0 || D_launch > D) D_launch = D;
-    hipLaunchKernelGGL(k_ranges, dim3(c3d_cdiv(D_launch, 256 * RANGES_PER_LANE), V), dim3(256), 0, s, b.tkey[res], b.ranges, D, d_dev, vs);
-    C3D_LAUNCH_CHECK();
-    return 0;
-}
+// A5, the [start, end) of every tile in the sorted pair list, is no kernel of its own any more (round 6): the last pass of the tile sort leaves the ranges behind
+// (k_onesweep RANGES, csrc/scan_sort.hip); readers decode them with gs_tile_range.
 
 // ------------------------------------------------------------------------------------------
 // A6 composite forward: ONE WAVE per 8x8 pixel quadrant of a 16x16 tile -- a 64-lane workgroup, no workgroup-level staging, no barrier, nothing
@@ -368,7 +338,7 @@ __global__ void __launch_bounds__(64, 8) k_composite_fwd_w(GsParams p, const uin
     const float pxf = (float)pxi, pyf = (float)pyi;
     const size_t pid = (size_t)pyi * p.W + pxi;
     const float rx0 = (float)QX, ry0 = (float)QY;
-    const uint2 rg = ranges[tile];
+    const uint2 rg = gs_tile_range(ranges[tile]);
     const int todo = (int)(rg.y - rg.x);
     float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
     int last = 0;
@@ -477,7 +447,7 @@ int gs_launch_composite_fwd(const GsParams& p, const GsGeom& g, const GsBinning&
     uint8_t* pact = record_activity ? gs_pair_activity(b, res) : nullptr;
     ScanWaveJob sj{};
     if (record_activity && scan && p.N > 0)
-        sj = ScanWaveJob{g.tiles, g.rbase, g.rect, g.einfo, (uint32_t*)g.tmp_scan_a, err ? err : (uint32_t*)g.meta + 2, (uint32_t)p.N, scan_wave_blocks((size_t)p.N)};
+        sj = ScanWaveJob{g.tiles, g.rbase, g.rect, g.einfo, (uint32_t*)g.tmp_scan_a, err ? err : (uint32_t*)g.meta + 2, (uint32_t)p.N, scan_wave_blocks((size_t)p.N), p.rect4};
     const dim3 grid(sj.blocks + 4 * gs_block_count(p.gx, p.gy), V);      // a multiple of 32 blocks per view: the XCD of a block (dispatch order % 8) does not depend on the view
     bool depth = false;
     for (int v = 0; v < V; v++) depth = depth || vp.depth[v] != nullptr;

@@ -9,6 +9,7 @@ struct GsParams {
     int N, M, deg, W, H, gx, gy;
     float tanfovx, tanfovy, focal_x, focal_y, scale_modifier;
     float dscale_mod;    // factor on dL/dscale: 1 = as the dependency's backward (default), scale_modifier = exact derivative
+    int rect4;           // the tile grid is at most 255 x 255: GsGeom::rect holds 4-byte packed rects (c3d_rect_pack)
     const float* bg;     // [3]   device
     const float* view;   // [16]  device, row-major storage of w2c^T (camera_utils.py:205)
     const float* proj;   // [16]  device, full projection, same storage (camera_utils.py:213)
@@ -27,12 +28,13 @@ struct GsGeom {
     float4* rec1;
     float4* rec2;
     uint32_t* tiles;        // tiles touched per Gaussian (0 = culled)
-    uint2* rect;            // the tile rect those tiles form: {x0 | y0 << 16, x1 | y1 << 16} (written with `tiles`; {0, 0} for culled Gaussians)
+    uint2* rect;            // the tile rect those tiles form: {x0 | y0 << 16, x1 | y1 << 16} (written with `tiles`; {0, 0} for culled Gaussians) -- or, GsParams::rect4, one packed uint32 per Gaussian
     uint32_t* key[2];       // depth-sort keys (float bits of view depth; 0xFFFFFFFF = culled)
     uint32_t* order[2];     // Gaussian ids, ping-pong; after stage 1 order[res] is rank -> id
     uint2* rsort;           // the tile rects in depth-rank order (left behind by the emit-offset scan, which gathers them; read by k_emit)
     uint32_t* offsets;      // inclusive scan of the tile counts in depth-rank order
-    uint4* einfo;           // per Gaussian with tiles: {0, x0 | y0<<16, x1 | y1<<16, record base} of its tile rect -- written by the record-base scan (coalesced; the scan runs inside the recording forward compositing launch)
+    uint4* einfo;           // per Gaussian with tiles: {0, x0 | y0<<16, x1 | y1<<16, record base} of its tile rect -- written by the record-base scan (coalesced; the scan runs inside the recording forward compositing launch);
+                            // GsParams::rect4: EIGHT bytes per Gaussian, {packed rect, record base} (scan_wave.h)
     uint32_t* rbase;        // exclusive scan of `tiles` in Gaussian-id order: where this Gaussian's backward gradient records start
     uint8_t* clamped;       // 3 bits per Gaussian: SH colour channel clamped at 0
     int* meta;              // [0] = min(num_rendered, capacity) (device copy)  [2] = error word of the binning chain (C3D_ERR_LOOKBACK)
@@ -79,7 +81,7 @@ static inline void gs_carve_geom(char* base, int N, GsGeom& g) {
 struct GsBinning {
     uint32_t* tkey[2];
     uint32_t* tval[2];
-    uint2* ranges;   // [tiles]
+    uint2* ranges;   // [tiles] as the last tile-sort pass leaves them: {~start, end}, {0, 0} = an empty tile -- read through gs_tile_range
     int* meta;
     void* tmp;       // tile-sort state; `ranges`, `meta` and the state are adjacent: ONE memset of zero_bytes from `ranges` clears them
     size_t pair_stride;   // elements between the four byte planes of the pair-activity record (gs_pair_activity)
@@ -105,6 +107,11 @@ static inline void gs_carve_binning(char* base, long long D, int tiles, GsBinnin
     b.zero_bytes = (off - c3d_sort_tmp_bytes(d)) - ranges_off + c3d_sort_state_bytes(d, bits);
     b.bytes = off;
 }
+
+#ifdef __HIPCC__
+// [start, end) of a tile in the sorted pair list from the stored words (both grown by atomicMax out of the cleared state {0, 0}, c3d_sort_pairs_u32)
+__device__ __forceinline__ uint2 gs_tile_range(uint2 raw) { return raw.y ? make_uint2(~raw.x, raw.y) : make_uint2(0u, 0u); }
+#endif
 
 // Pair activity, written by the recording forward compositing and read by the backward one: FOUR byte planes of b.pair_stride bytes each, plane w
 // byte i = quadrant w blended the splat at sorted list position i into at least one of its pixels.  A quadrant's wave writes its plane only for the
@@ -185,7 +192,6 @@ int gs_launch_preprocess_bwd_raw(const GsParams& p, const GsGeom& g, const int* 
                                  float* dL_dopacity_raw, float* dL_dmeans3D, float* dL_df_dc, float* dL_df_rest, float* dL_dscaling_raw,
                                  float* dL_drotation_raw, bool accumulate, hipStream_t s, uint32_t cap = 0xFFFFFFFFu);
 int gs_launch_emit(const GsParams& p, const GsGeom& g, int res, GsBinning& b, hipStream_t s, uint32_t cap, int V, size_t vs, int passes);
-int gs_launch_ranges(const GsBinning& b, int res, long long D, hipStream_t s, const uint32_t* d_dev = nullptr, int V = 1, size_t vs = 0, long long D_launch = 0);
 int gs_launch_composite_fwd(const GsParams& p, const GsGeom& g, const GsBinning& b, int res, GsImage& im, const GsFwdViews& vp, int V, size_t vs,
                             bool record_activity, hipStream_t s, uint32_t* err = nullptr, bool scan = true);
 int gs_launch_poison_on_overflow(const uint32_t* status, float* color, float* depth, float* alpha, int W, int H, hipStream_t s);

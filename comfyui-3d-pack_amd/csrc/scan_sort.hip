@@ -68,7 +68,7 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* lds, u
 // hint (0 = none): the pair count the LAUNCHES of the chain were sized for (c3d_gs_forward_nosync: first_capacity < cap); a larger count is served by workgroups that loop --
 // status bit C3D_ST_BEYOND_HINT only says so.  early (optional): DEVICE-VISIBLE address of two words of pinned host memory; the tail stores {overflow / hint bits, total} there
 // itself, as ONE 64-bit system-scope store -- the host sees the count of a call while the rest of its chain is still running, without a copy in the stream.
-struct ScanTail { uint32_t* meta; uint32_t* status; uint32_t cap; uint2* rsort; uint32_t hint; unsigned long long* early; };   // rsort: GATHER
+struct ScanTail { uint32_t* meta; uint32_t* status; uint32_t cap; uint2* rsort; uint32_t hint; unsigned long long* early; int rect4; };   // rsort, rect4 (the input holds packed 4-byte rects): GATHER
 __device__ __forceinline__ uint32_t rect_area(uint2 r) { return ((r.y & 0xFFFFu) - (r.x & 0xFFFFu)) * ((r.y >> 16) - (r.x >> 16)); }
 
 // Data movement (round 4: with V views per launch the scans are bandwidth-sized work, and eight 4-byte accesses per lane at a 32-byte lane stride cost eight
@@ -100,7 +100,18 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_lb(const uint32_t* __rest
         if (GATHER) {
             const uint2* rects = reinterpret_cast<const uint2*>(in);
             uint2 rc[4];
-            if (b + 3 < n) {
+            if (tail.rect4) {      // (uniform) 4-byte packed rects: the gather table of a view is half the size
+                if (b + 3 < n) {
+                    const uint4 j = *reinterpret_cast<const uint4*>(idx + b);
+                    const uint32_t q0 = in[j.x], q1 = in[j.y], q2 = in[j.z], q3 = in[j.w];
+                    rc[0] = c3d_rect_unpack(q0); rc[1] = c3d_rect_unpack(q1); rc[2] = c3d_rect_unpack(q2); rc[3] = c3d_rect_unpack(q3);
+                    *reinterpret_cast<uint4*>(tail.rsort + b) = make_uint4(rc[0].x, rc[0].y, rc[1].x, rc[1].y);
+                    *reinterpret_cast<uint4*>(tail.rsort + b + 2) = make_uint4(rc[2].x, rc[2].y, rc[3].x, rc[3].y);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) { rc[i] = (b + i < n) ? c3d_rect_unpack(in[idx[b + i]]) : make_uint2(0u, 0u); if (b + i < n) tail.rsort[b + i] = rc[i]; }
+                }
+            } else if (b + 3 < n) {
                 const uint4 j = *reinterpret_cast<const uint4*>(idx + b);
                 rc[0] = rects[j.x]; rc[1] = rects[j.y]; rc[2] = rects[j.z]; rc[3] = rects[j.w];
                 *reinterpret_cast<uint4*>(tail.rsort + b) = make_uint4(rc[0].x, rc[0].y, rc[1].x, rc[1].y);
@@ -217,7 +228,7 @@ static int scan_launch(const uint32_t* in, const uint32_t* idx, uint32_t* out, s
     return 0;
 }
 int c3d_scan_u32(const uint32_t* in, uint32_t* out, size_t n, bool exclusive, void* tmp, hipStream_t s, bool zero_state, uint32_t* err) {
-    return scan_launch(in, nullptr, out, n, exclusive, tmp, s, zero_state, ScanTail{nullptr, nullptr, 0u, nullptr, 0u, nullptr}, err);
+    return scan_launch(in, nullptr, out, n, exclusive, tmp, s, zero_state, ScanTail{nullptr, nullptr, 0u, nullptr, 0u, nullptr, 0}, err);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -266,8 +277,8 @@ int c3d_zero_count(void* p, const uint32_t* count, uint32_t cap, hipStream_t s) 
     return 0;
 }
 int c3d_scan_rect_gather(const uint2* rect, const uint32_t* idx, uint32_t* out, uint2* rsort, size_t n, void* tmp, hipStream_t s, bool zero_state,
-                         uint32_t* tail_meta, uint32_t* tail_status, uint32_t tail_cap, uint32_t* err, int V, size_t vs, uint32_t tail_hint, unsigned long long* tail_early) {
-    return scan_launch(reinterpret_cast<const uint32_t*>(rect), idx, out, n, false, tmp, s, zero_state, ScanTail{tail_meta, tail_status, tail_cap, rsort, tail_hint, tail_early}, err, V, vs);
+                         uint32_t* tail_meta, uint32_t* tail_status, uint32_t tail_cap, uint32_t* err, int V, size_t vs, uint32_t tail_hint, unsigned long long* tail_early, bool rect4) {
+    return scan_launch(reinterpret_cast<const uint32_t*>(rect), idx, out, n, false, tmp, s, zero_state, ScanTail{tail_meta, tail_status, tail_cap, rsort, tail_hint, tail_early, rect4 ? 1 : 0}, err, V, vs);
 }
 uint32_t* c3d_scan_error_word(void* tmp) { return (uint32_t*)tmp + 1; }
 
@@ -367,12 +378,17 @@ __device__ __forceinline__ uint32_t rs_wait(const uint32_t* p, uint32_t x, uint3
 // depth sort of an 8-view step 0.256 -> 0.237 ms, tile sort 0.488 -> 0.470 ms on one box.  With 81 VGPRs the ONE-reorder-buffer form (keys, then values, through one 16 KB buffer
 // and back into registers before the chained scan: 22.5 KB) fits five and six workgroups per CU without spilling -- measured on the same box: 0.236 / 0.478 ms at five, 0.241 / 0.477
 // at six.  Tiles in flight are not what bounds a pass (same finding as the lean kernel of profiles/r05ij); not kept.
-template <bool IOTA, int ITEMS, int STAY>
+// RANGES (the LAST pass of the tile sort): the pass also leaves the per-tile ranges of the sorted list -- what a separate kernel used to find by reading the sorted keys back (k_ranges:
+// one more launch on the chain and 16 MB per view).  Equal keys sit next to each other in the workgroup's reorder buffer and go to consecutive output positions, so an element whose
+// LDS neighbour holds another key (or none) is the first / last of ITS workgroup's stretch of that key: it grows the tile's {~start, end} words by atomicMax from the cleared state
+// {0, 0} -- a few dozen atomics per 4096 keys (the input of the last pass is ordered by the low digit: a workgroup's keys are a few image tiles).
+template <bool IOTA, int ITEMS, int STAY, bool RANGES = false>
 __global__ void __launch_bounds__(RS_THREADS, 4) k_onesweep(const uint32_t* __restrict__ keys_in0, const uint32_t* __restrict__ vals_in0,
                                                              uint32_t* __restrict__ keys_out0, uint32_t* __restrict__ vals_out0,
                                                              const uint32_t* __restrict__ ghist0, uint32_t* __restrict__ ticket, uint32_t* __restrict__ err,
                                                              uint32_t* __restrict__ tile_words0, uint32_t* __restrict__ group_words0, size_t n_cap,
-                                                             const uint32_t* __restrict__ n_dev, int shift, unsigned long long* __restrict__ dbg, size_t vs) {
+                                                             const uint32_t* __restrict__ n_dev, int shift, unsigned long long* __restrict__ dbg, size_t vs,
+                                                             uint2* __restrict__ ranges0) {
     __shared__ uint32_t whist[RS_THREADS / 64][RS_RADIX];
     __shared__ uint32_t lstart[RS_RADIX];    // first local slot of each digit
     __shared__ uint32_t gbase[RS_RADIX];     // global position of that slot
@@ -572,6 +588,17 @@ __global__ void __launch_bounds__(RS_THREADS, 4) k_onesweep(const uint32_t* __re
             const uint32_t pos = gbase[dd] + ((uint32_t)lp - lstart[dd]);
             keys_out[pos] = k;
             vals_out[pos] = v;
+            if (RANGES) {      // a slot whose predecessor holds another key starts its key's stretch here -- and ends the predecessor's: both words from the one compare
+                const uint32_t kp = lp ? skey[lp - 1u] : ~k;
+                if (kp != k) {
+                    atomicMax(&(RS_AT(ranges0, view) + k)->x, ~pos);
+                    if (lp) {
+                        const uint32_t dp = (kp >> shift) & (RS_RADIX - 1);
+                        atomicMax(&(RS_AT(ranges0, view) + kp)->y, gbase[dp] + ((uint32_t)lp - 1u - lstart[dp]) + 1u);
+                    }
+                }
+                if (lp + 1u == cnt) atomicMax(&(RS_AT(ranges0, view) + k)->y, pos + 1u);
+            }
         }
     }
     RS_STAMP(5);
@@ -636,11 +663,12 @@ int c3d_sort_zero_state_counted(void* tmp, size_t n, int end_bit, const uint32_t
 
 int c3d_sort_pairs_u32(uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32_t* vals1, bool iota_vals,
                        size_t n, int end_bit, void* tmp, int* result_buf, hipStream_t s, const uint32_t* n_dev, bool zero_state, uint32_t* err_out, int V, size_t vs, bool hist_done,
-                       size_t n_hint) {
+                       size_t n_hint, uint2* ranges) {
     *result_buf = 0;
     if (n == 0 || V <= 0) return 0;
     if (zero_state && V != 1) { c3d_set_error("c3d_sort_pairs_u32: a multi-view launch clears its state through c3d_zero_views"); return -1; }
     if (end_bit > 8 * RS_MAX_PASSES) { c3d_set_error("c3d_sort_pairs_u32: end_bit %d > %d", end_bit, 8 * RS_MAX_PASSES); return -1; }
+    if (ranges && iota_vals && end_bit <= 8) { c3d_set_error("c3d_sort_pairs_u32: ranges with a one-pass iota sort"); return -1; }
     if (n > (size_t)RS_VALUE_MASK) { c3d_set_error("c3d_sort_pairs_u32: %zu elements exceed the 2^30 - 1 the chained scan's status words hold", n); return -1; }
     int passes = (end_bit + 7) / 8;
     if (passes < 1) passes = 1;
@@ -665,10 +693,11 @@ int c3d_sort_pairs_u32(uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32
     for (int pass = 0; pass < passes; pass++) {
         uint32_t* tw = status + (size_t)pass * sort_pass_words((size_t)nb);
         uint32_t* gw = tw + (size_t)RS_RADIX * nb;
-#define RS_SWEEP(IOTA_, STAY_) hipLaunchKernelGGL((k_onesweep<IOTA_, RS_ITEMS, STAY_>), dim3(nbx, V), dim3(RS_THREADS), 0, s, k[cur], v[cur], k[cur ^ 1], v[cur ^ 1], ghist + pass * RS_RADIX, \
-                                           tickets + pass, err, tw, gw, n, n_dev, 8 * pass, (g_sort_dbg && V == 1) ? g_sort_dbg + (size_t)pass * nb * 8 : nullptr, vs)
-        if (pass == 0 && iota_vals) { if (mode == 1) RS_SWEEP(true, 1); else if (mode == 2) RS_SWEEP(true, 2); else RS_SWEEP(true, 0); }
-        else { if (mode == 1) RS_SWEEP(false, 1); else if (mode == 2) RS_SWEEP(false, 2); else RS_SWEEP(false, 0); }
+#define RS_SWEEP(IOTA_, STAY_, RNG_) hipLaunchKernelGGL((k_onesweep<IOTA_, RS_ITEMS, STAY_, RNG_>), dim3(nbx, V), dim3(RS_THREADS), 0, s, k[cur], v[cur], k[cur ^ 1], v[cur ^ 1], ghist + pass * RS_RADIX, \
+                                           tickets + pass, err, tw, gw, n, n_dev, 8 * pass, (g_sort_dbg && V == 1) ? g_sort_dbg + (size_t)pass * nb * 8 : nullptr, vs, ranges)
+        if (pass == 0 && iota_vals) { if (mode == 1) RS_SWEEP(true, 1, false); else if (mode == 2) RS_SWEEP(true, 2, false); else RS_SWEEP(true, 0, false); }
+        else if (ranges && pass == passes - 1) { if (mode == 1) RS_SWEEP(false, 1, true); else if (mode == 2) RS_SWEEP(false, 2, true); else RS_SWEEP(false, 0, true); }
+        else { if (mode == 1) RS_SWEEP(false, 1, false); else if (mode == 2) RS_SWEEP(false, 2, false); else RS_SWEEP(false, 0, false); }
 #undef RS_SWEEP
         C3D_LAUNCH_CHECK();
         cur ^= 1;

@@ -24,6 +24,8 @@ static inline int scan_wave_blocks(size_t n) { return (int)((scan_wave_tiles(n) 
 #ifdef __HIPCC__
 struct ScanWaveJob {      // all pointers: view 0's (view v lies v * vs bytes behind); blocks == 0: no job
     const uint32_t* in; uint32_t* out; const uint2* rect; uint4* einfo; uint32_t* state; uint32_t* err; uint32_t n; int blocks;
+    int rect4;      // `rect` holds 4-byte packed rects (c3d_rect_pack): the element count is the rect's area (`in` is not read) and einfo is EIGHT bytes per element,
+                    // {packed rect, out[i]} -- half the scan's traffic (16 instead of 32 bytes per element), and half the table the backward compositing gathers from
 };
 // value of a published word (polls until its flag is set; bounded)
 __device__ __forceinline__ uint32_t scan_wave_wait(const unsigned long long* p, uint32_t* err) {
@@ -36,7 +38,7 @@ __device__ __forceinline__ uint32_t scan_wave_wait(const unsigned long long* p, 
     }
     return (uint32_t)w;
 }
-// out[i] = exclusive prefix of in[0..i); einfo[i] = {0, rect[i].x, rect[i].y, out[i]} where in[i] != 0.  Called by a whole 64-lane workgroup.
+// out[i] = exclusive prefix of in[0..i); einfo[i] = {0, rect[i].x, rect[i].y, out[i]} where in[i] != 0 (rect4: see ScanWaveJob).  Called by a whole 64-lane workgroup.
 __device__ __forceinline__ void scan_wave_tile(const ScanWaveJob& j, size_t vs) {
     const uint32_t* __restrict__ in = c3d_view_ptr(j.in, vs);
     uint32_t* __restrict__ out = c3d_view_ptr(j.out, vs);
@@ -53,10 +55,21 @@ __device__ __forceinline__ void scan_wave_tile(const ScanWaveJob& j, size_t vs) 
     const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
     if (tile >= tiles) return;
     uint32_t v[4][4], hs[4];
+    const uint32_t* __restrict__ rect4 = reinterpret_cast<const uint32_t*>(rect);
+    uint32_t rq[4][4];      // rect4: the packed rects of the lane's elements (the counts come out of them, and they go into einfo)
+    auto area4 = [](uint32_t r) { return (((r >> 16) & 0xFFu) - (r & 0xFFu)) * ((r >> 24) - ((r >> 8) & 0xFFu)); };
 #pragma unroll
     for (int h = 0; h < 4; h++) {
         const size_t b = (size_t)tile * SCANW_TILE + (size_t)h * 256 + (size_t)lane * 4;
-        if (b + 3 < n) { const uint4 q = *reinterpret_cast<const uint4*>(in + b); v[h][0] = q.x; v[h][1] = q.y; v[h][2] = q.z; v[h][3] = q.w; }
+        if (j.rect4) {
+            if (b + 3 < n) { const uint4 q = *reinterpret_cast<const uint4*>(rect4 + b); rq[h][0] = q.x; rq[h][1] = q.y; rq[h][2] = q.z; rq[h][3] = q.w; }
+            else {
+#pragma unroll
+                for (int i = 0; i < 4; i++) rq[h][i] = (b + i < n) ? rect4[b + i] : 0u;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) v[h][i] = area4(rq[h][i]);
+        } else if (b + 3 < n) { const uint4 q = *reinterpret_cast<const uint4*>(in + b); v[h][0] = q.x; v[h][1] = q.y; v[h][2] = q.z; v[h][3] = q.w; }
         else {
 #pragma unroll
             for (int i = 0; i < 4; i++) v[h][i] = (b + i < n) ? in[b + i] : 0u;
@@ -92,7 +105,19 @@ __device__ __forceinline__ void scan_wave_tile(const ScanWaveJob& j, size_t vs) 
         uint32_t run = prefix + ex[h], e[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) { e[i] = run; run += v[h][i]; }
-        if (b + 3 < n) {
+        if (j.rect4) {
+            uint2* __restrict__ e8 = reinterpret_cast<uint2*>(einfo);
+            if (b + 3 < n) {
+                *reinterpret_cast<uint4*>(out + b) = make_uint4(e[0], e[1], e[2], e[3]);
+                // (entries of culled elements are written too: two 16-byte stores per lane instead of four predicated 8-byte ones; nobody reads them)
+                *reinterpret_cast<uint4*>(e8 + b) = make_uint4(rq[h][0], e[0], rq[h][1], e[1]);
+                *reinterpret_cast<uint4*>(e8 + b + 2) = make_uint4(rq[h][2], e[2], rq[h][3], e[3]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    if (b + i < n) { out[b + i] = e[i]; e8[b + i] = make_uint2(rq[h][i], e[i]); }
+            }
+        } else if (b + 3 < n) {
             *reinterpret_cast<uint4*>(out + b) = make_uint4(e[0], e[1], e[2], e[3]);
             const uint4 r01 = *reinterpret_cast<const uint4*>(rect + b), r23 = *reinterpret_cast<const uint4*>(rect + b + 2);
             if (v[h][0]) einfo[b] = make_uint4(0u, r01.x, r01.y, e[0]);

@@ -205,6 +205,26 @@ def test_precomputed_colour_and_covariance_paths():
     assert rel_err(inp["means3D"].grad.cpu().numpy(), og["means3D"]) <= GRAD_REL
 
 
+def test_tile_grids_wider_than_255_take_the_unpacked_rect_path():
+    """Up to 255 x 255 tiles (4080 px a side) the tile rect of a Gaussian travels in four bytes and the backward pass's per-Gaussian record info in eight (c3d_rect_pack,
+    GsParams::rect4); a wider grid keeps the 8- / 16-byte forms.  A 4128 x 512 strip (258 x 32 tiles) through forward and backward against the float64 oracle, and the same
+    scene at 4064 x 512 (254 tiles: packed) for the pair."""
+    sc = S.make_small_scene(N=2500, seed=9, scale=0.06)
+    for W in (4128, 4064):
+        st = S.camera_settings(W, 512, 20.0, 5.0, 20.0, 2.0)
+        color, radii, depth, alpha, inp, m2d = hip_forward(sc, st, requires_grad=True)
+        oc, orad, od, oa, ost = oracle_forward(sc, st, dtype=np.float64)
+        assert ost.num_rendered > 2000
+        assert np.abs(color.detach().cpu().numpy() - oc).mean() <= IMG_L1 and (radii.cpu().numpy() == orad).all()
+        assert np.abs(alpha.detach().cpu().numpy() - oa).mean() <= IMG_L1 and np.abs(depth.detach().cpu().numpy() - od).mean() <= IMG_L1
+        gC = np.random.default_rng(1).normal(size=oc.shape).astype(np.float32)
+        (color * _dev(gC, torch.float32)).sum().backward()
+        og = O.backward(ost, gC)
+        for k in ("means3D", "opacities", "shs", "scales", "rotations"):      # (an 8 : 1 strip at 20 degrees vertically is a 110 degree horizontal field of view)
+            assert rel_err(inp[k].grad.cpu().numpy(), og[k]) <= 2 * GRAD_REL, (W, k)
+        assert rel_err(m2d.grad.cpu().numpy(), og["means2D"]) <= 2 * GRAD_REL, W
+
+
 def test_call_patterns_of_the_other_consumers_in_the_reference():
     """The rasterizer has three more callers in the reference tree besides the MVs path; each drives it a little differently.  Their call sequences,
     statement by statement, against the oracle (forward and, where the caller differentiates, backward):
@@ -556,7 +576,7 @@ def test_recorded_pair_activity_loses_nothing():
     upto = pad.reshape(gy, 2, 8, gx, 2, 8).permute(0, 3, 1, 4, 2, 5).reshape(gy * gx, 4, 64).max(dim=2).values      # [tile, quadrant]
     ranges = binning.data[4 * d_al:4 * d_al + 8 * gx * gy].view(torch.int32).reshape(gx * gy, 2)
     tile_of = keys[res].long()
-    posn = torch.arange(D, device="cuda") - ranges[tile_of, 0].long()
+    posn = torch.arange(D, device="cuda") - (~ranges[tile_of, 0]).long()      # the stored words are {~start, end} (gs_tile_range, csrc/gs_internal.h)
     valid = torch.stack([posn < upto[tile_of, w].long() for w in range(4)])
     bits = torch.stack([(before[w] & 1).bool() for w in range(4)]) & valid
     reached = valid.any(0)
