@@ -259,6 +259,11 @@ class GaussianSplatting3D:
                 radius, elev, azim, cx, cy, cz = self.all_ref_cam_poses[i]
                 cam = MiniCam(orbit_camera(elev, azim, radius, target=np.array([cx, cy, cz], dtype=np.float32)), W, H, ctl.cam.fovy, ctl.cam.fovx,
                               ctl.cam.near, ctl.cam.far, ctl.projection_matrix, device=self.device)
+                # MiniCam keeps the reference's transposed VIEW of w2c: handing that to the rasterizer costs a strided-copy launch per view and iteration -- one of the ~25
+                # launches of an iteration at the node's default scene size.  Same values, contiguous float32, made once per reference pose.
+                cam.world_view_transform = cam.world_view_transform.float().contiguous()
+                cam.full_proj_transform = cam.full_proj_transform.float().contiguous()
+                cam.camera_center = cam.camera_center.float().contiguous()
                 self._ref_cams[i] = cam
             # the background of this view: one np.random draw per view, in view order, as render_at_pose (camera_utils.py:246-249)
             bg = ctl.static_bg if ctl.static_bg is not None else (ctl.white_bg if np.random.rand() > ctl.invert_bg_prob else ctl.black_bg)

@@ -64,7 +64,7 @@ _SIGNATURES = {
     "c3d_gs_backward_raw": (C.c_int, [C.POINTER(GsSettings), i32] + [vp] * 5 + [vp, vp, i64, vp, vp] + [vp] * 3 + [vp] * 7 + [vp, i32, vp]),
     "c3d_gs_step_workspace_bytes": (sz, [i32, i32, i32, i64, i32]),
     "c3d_gs_render_workspace_bytes": (sz, [i32, i32, i32, i64, i32]),
-    "c3d_gs_train_views_raw": (C.c_int, [C.POINTER(GsSettings), i32, i32] + [vp] * 6 + [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(GsLoss)] + [vp] * 6 + [vp, i64, i32, i32, vp, vp, vp]),
+    "c3d_gs_train_views_raw": (C.c_int, [C.POINTER(GsSettings), i32, i32] + [vp] * 6 + [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(GsLoss)] + [vp] * 6 + [vp, i64, i32, i32, vp, vp, vp, vp]),
     "c3d_gs_render_views_raw": (C.c_int, [C.POINTER(GsSettings), i32, i32] + [vp] * 6 + [C.POINTER(vp)] * 4 + [i64, i32, vp, i64, vp, vp]),
     "c3d_gs_forward_views_raw": (C.c_int, [C.POINTER(GsSettings), i32, i32] + [vp] * 6 + [C.POINTER(vp)] * 4 + [i64, i32, vp, vp, vp]),
     "c3d_gs_step_param_backward_range": (C.c_int, [C.POINTER(GsSettings), i32, i32] + [vp] * 5 + [vp] * 6 + [i64, i32, vp, i32, i32, vp]),

@@ -24,9 +24,11 @@ class FusedViewStep:
         self.lanes = max(1, min(8, int(lanes)))
         self.views = max(1, int(views))
         self.capacity = int(pair_capacity or max(8 * N, 1 << 22))
-        self._words = torch.zeros(4, dtype=torch.int32, device=self.device)      # status words and the loss value side by side: ONE fill per step clears both
-        self.status = self._words[0:2]
-        self.loss = self._words[2:3].view(torch.float32)
+        # status words and the loss value of a step side by side, every step a FRESH, zero-initialised slot of a ring (a new ring when one is used up: old loss tensors keep
+        # theirs alive): no fill launch and no clone launch per step -- the node's default scene is ~30 launches of 4-80 us per iteration, and these were two of them
+        self._ring, self._ring_next = None, 0
+        self._host_ring, self._host_next = None, 0      # pinned, device-mapped: where the step's loss launch leaves the status words for the host (c3d_gs_train_views_raw: status_host)
+        self._new_words()
         self._fitted = False
         self._chunks_went_out = False
         self._fwd = None
@@ -48,6 +50,25 @@ class FusedViewStep:
         self._alloc()
 
     GROW_AT = 0.8      # regrow the pair capacity when a step used more than this share of it
+    RING = 1024        # steps per ring of device words / pinned host words
+
+    def _new_words(self):
+        if self._ring is None or self._ring_next >= self.RING:
+            self._ring, self._ring_next = torch.zeros((self.RING, 4), dtype=torch.int32, device=self.device), 0
+        self._words = self._ring[self._ring_next]
+        self._ring_next += 1
+        self.status = self._words[0:2]
+        self.loss = self._words[2:3].view(torch.float32)
+
+    def _host_slot(self):
+        """-> (numpy view of two pinned int32 words preset to the sentinel, their address)"""
+        if self._host_ring is None:
+            self._host_pin = torch.full((self.RING, 2), -1, dtype=torch.int32).pin_memory()
+            self._host_ring = self._host_pin.numpy()
+        i = self._host_next
+        self._host_next = (i + 1) % self.RING
+        self._host_ring[i] = -1
+        return self._host_ring[i], self._host_pin.data_ptr() + 8 * i
 
     def _alloc(self):
         nbytes = _h.lib().c3d_gs_step_workspace_bytes(self.N, self.H, self.W, self.capacity, self.views)
@@ -132,19 +153,25 @@ class FusedViewStep:
                 loss = _h.GsLoss(float(w_l1), float(w_l2), float(w_alpha_mse), float(scale), float(w_ssim))
             if accumulate:
                 snapshot = [g.clone() for g in grads] if attempt == 0 else snapshot     # to redo the step after an overflow
-            self._words.zero_()
+            self._new_words()
             t_host = time.perf_counter()
             if self.time_events:
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record(torch.cuda.current_stream(self.device))
             chunked = K > 1 and after_chunk is not None and self._fitted and not accumulate
             self._chunks_went_out = chunked
+            deferred = self.defer_status and self._fitted and not accumulate
+            # one GPU, deferred status, nobody timing the call: the step's loss launch stores the status words into pinned memory itself, and the NEXT step waits for those
+            # words only (they are final two kernels before the step ends) -- no copy launch, no event
+            early = deferred and not together and not self.time_events and V > 0
+            host_words, host_ptr = self._host_slot() if early else (None, None)
             if V:
                 with torch.cuda.device(self.device):
                     pp = [_h.ptr(_h.f32c(p)) for p in params]
                     _h.check(lib.c3d_gs_train_views_raw(views, V, self.N, *pp, tc, ta, cm, C.byref(loss),
                                                         *[_h.ptr(g) for g in grads], _h.ptr(self.loss), self.capacity, self.lanes, (1 if accumulate else 0) | (2 if chunked else 0),
-                                                        _h.ptr(self.workspace), _h.ptr(self.status), _h.stream(self.device)), "c3d_gs_train_views_raw")
+                                                        _h.ptr(self.workspace), _h.ptr(self.status), C.c_void_p(host_ptr) if early else None, _h.stream(self.device)),
+                             "c3d_gs_train_views_raw")
                     if chunked:
                         for g0, g1 in ranges:
                             _h.check(lib.c3d_gs_step_param_backward_range(views, V, self.N, pp[0], pp[1], pp[2], pp[4], pp[5], *[_h.ptr(g) for g in grads], self.capacity, 0,
@@ -159,18 +186,21 @@ class FusedViewStep:
             self.last_host_ms = (time.perf_counter() - t_host) * 1e3      # host time to enqueue the whole step (no sync inside)
             if self.time_events:
                 ev1.record(torch.cuda.current_stream(self.device))
-            words = self._status_words()
-            if self.defer_status and self._fitted and not accumulate:
-                if self._pinned is None:
-                    self._pinned = [torch.empty((3,), dtype=torch.int32).pin_memory() for _ in range(2)]
-                self._flip ^= 1
-                pin = self._pinned[self._flip][:words.numel()]
-                pin.copy_(words, non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream(self.device))
-                self._pending = (ev, (ev0, ev1) if self.time_events else None, pin)
+            if deferred:
+                if early:
+                    self._pending = (None, None, host_words)
+                else:
+                    words = self._status_words()
+                    if self._pinned is None:
+                        self._pinned = [torch.empty((3,), dtype=torch.int32).pin_memory() for _ in range(2)]
+                    self._flip ^= 1
+                    pin = self._pinned[self._flip][:words.numel()]
+                    pin.copy_(words, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream(self.device))
+                    self._pending = (ev, (ev0, ev1) if self.time_events else None, pin)
                 self._last = (self.workspace, self.capacity)
-                out = self.loss.clone()
+                out = self.loss
                 if prev is not None and not self._examine(prev):
                     prev = None
                     self._pending = None
@@ -181,6 +211,7 @@ class FusedViewStep:
             if prev is not None:
                 self._examine(prev)
                 prev = None
+            words = self._status_words()
             ovf, fault, seen = self._decode(words.tolist())       # the single host sync of the step
             if self.time_events:
                 self.last_gpu_ms = ev0.elapsed_time(ev1)                  # GPU span of the library call: wall time beyond it is host-side bubble
@@ -195,7 +226,7 @@ class FusedViewStep:
                 self._follow(seen)
                 if not chunked:
                     hand_over()
-                return self.loss.clone()
+                return self.loss
             if chunked and not together:
                 raise RuntimeError("c3d FusedViewStep: a step whose gradient ranges had already been handed to after_chunk exceeded the pair capacity (%d pairs)" % seen)
             self.capacity = int(max(seen, self.capacity) * 1.25) + 1024
@@ -215,7 +246,10 @@ class FusedViewStep:
         if pending is None:
             return True
         ev, tev, pin = pending
-        ev.synchronize()
+        if ev is None:      # the words come straight from the step's loss launch (pinned memory): wait for them, not for the step
+            _h.check(_h.lib().c3d_gs_wait_count(C.c_void_p(pin.ctypes.data), 0xFFFFFFFF, 20_000_000, None, None), "c3d_gs_wait_count")
+        else:
+            ev.synchronize()
         if tev is not None:
             self.last_gpu_ms = tev[0].elapsed_time(tev[1])
         ovf, fault, seen = self._decode(pin.tolist())

@@ -555,9 +555,19 @@ int c3d_gs_train_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, c
                            const float* opacity_raw, const float* scaling_raw, const float* rotation_raw, const float* const* target_color,
                            const float* const* target_alpha, const float* const* color_mask, const c3d_gs_loss* loss, float* dL_dmeans3D, float* dL_df_dc, float* dL_df_rest,
                            float* dL_dopacity_raw, float* dL_dscaling_raw, float* dL_drotation_raw, float* loss_out, int64_t pair_capacity, int32_t lanes,
-                           int32_t accumulate, void* workspace, uint32_t* status, c3d_stream_t stream) {
+                           int32_t accumulate, void* workspace, uint32_t* status, uint32_t* status_host, c3d_stream_t stream) {
     hipStream_t s0 = (hipStream_t)stream;
     if (V <= 0 || N <= 0) return 0;
+    unsigned long long* sh_dev = nullptr;
+    if (status_host) {      // pinned host memory the device can address: the step's last loss launch stores the status words there itself (no copy in the stream)
+        void* dp = nullptr;
+        if (((uintptr_t)status_host & 7) || hipHostGetDevicePointer(&dp, status_host, 0) != hipSuccess || !dp) {
+            (void)hipGetLastError();
+            c3d_set_error("c3d_gs_train_views_raw: status_host must be 8-byte aligned pinned host memory mapped into the device's address space");
+            return -1;
+        }
+        sh_dev = (unsigned long long*)dp;
+    }
     if (!loss || !target_color || !status) { c3d_set_error("c3d_gs_train_views_raw: NULL pointer"); return -1; }
     if (check_step_args("c3d_gs_train_views_raw", views, V, pair_capacity, lanes, workspace)) return -1;
     const bool dc_only = views[0].sh_coeffs == 1;      // degree-0 storage: there is no f_rest
@@ -618,9 +628,9 @@ int c3d_gs_train_views_raw(const c3d_gs_settings* views, int32_t V, int32_t N, c
         StepWs wf; carve_step((char*)workspace, N, views[0].image_height, views[0].image_width, pair_capacity, wf);
         const int tiles = ((views[0].image_width + C3D_TILE_X - 1) / C3D_TILE_X) * ((views[0].image_height + C3D_TILE_Y - 1) / C3D_TILE_Y);
         C3dProfScope ps(C3D_P_OTHER, s0);
-        if (groups == 1) { if (gs_launch_sum_group_loss(wf.tile_loss, tiles + (ssim ? 1 : 0), V, V > 1 ? vs : 0, loss_out, s0)) return -1; }      // one launch for both stages
-        else if (gs_launch_sum_tile_loss(wf.tile_loss + tiles + 1, vs, V, loss_out, s0)) return -1;
-    }
+        if (groups == 1) { if (gs_launch_sum_group_loss(wf.tile_loss, tiles + (ssim ? 1 : 0), V, V > 1 ? vs : 0, loss_out, s0, status, sh_dev)) return -1; }      // one launch for both stages
+        else if (gs_launch_sum_tile_loss(wf.tile_loss + tiles + 1, vs, V, loss_out, s0, status, sh_dev)) return -1;
+    } else if (status_host) C3D_CHECK(hipMemcpyAsync(status_host, status, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s0));      // (no loss launch to ride in)
     if (accumulate & 2) return 0;   // the caller runs the per-Gaussian pass itself, range by range (c3d_gs_step_param_backward_range)
     return step_a8_all_views(views, V, N, vs, workspace, pair_capacity, means3D, f_dc, f_rest, scaling_raw, rotation_raw, dL_dmeans3D, dL_df_dc, dL_df_rest,
                              dL_dopacity_raw, dL_dscaling_raw, dL_drotation_raw, (accumulate & 1) != 0, s0);

@@ -318,14 +318,23 @@ __global__ void __launch_bounds__(1024) k_sum_view_loss(const float* __restrict_
     __syncthreads();
     if (threadIdx.x == 0) { float q = 0.f; for (int w = 0; w < 16; w++) q += red[w]; out[0] = q; }
 }
-__global__ void __launch_bounds__(64) k_sum_views_loss(const float* __restrict__ first_view_sum, size_t stride, int V, float* __restrict__ loss_out) {
+// status / status_host (optional): the step's two status words are final when this launch runs (it is ordered behind every kernel that can raise a bit) -- lane 0 stores them,
+// {flags, largest pair count}, as ONE 64-bit system-scope store into pinned host memory the device can address: the host of a launch-bound training loop learns how the step
+// went without a copy launch in the stream, and two kernels (per-Gaussian pass, optimizer) before the step's last kernel has finished
+__device__ __forceinline__ void gs_status_to_host(const uint32_t* status, unsigned long long* status_host) {
+    if (status_host) __hip_atomic_store(status_host, ((unsigned long long)status[1] << 32) | status[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void __launch_bounds__(64) k_sum_views_loss(const float* __restrict__ first_view_sum, size_t stride, int V, float* __restrict__ loss_out,
+                                                        const uint32_t* __restrict__ status, unsigned long long* __restrict__ status_host) {
     if (threadIdx.x != 0) return;
     float acc = 0.f;
     for (int v = 0; v < V; v++) acc += *(const float*)((const char*)first_view_sum + (size_t)v * stride);      // views in order
     loss_out[0] += acc;             // one writer: the launch is ordered behind everything else that touches *loss_out on this stream
+    gs_status_to_host(status, status_host);
 }
 // both stages in one launch when all views of the step went through ONE group (the usual case): the same per-view pattern, the views one after the other, the same bits
-__global__ void __launch_bounds__(1024) k_sum_group_loss(const float* __restrict__ t0, int n, size_t vs, int V, float* __restrict__ loss_out) {
+__global__ void __launch_bounds__(1024) k_sum_group_loss(const float* __restrict__ t0, int n, size_t vs, int V, float* __restrict__ loss_out,
+                                                         const uint32_t* __restrict__ status, unsigned long long* __restrict__ status_host) {
     __shared__ float red[16];
     float acc = 0.f;
     for (int v = 0; v < V; v++) {
@@ -338,11 +347,11 @@ __global__ void __launch_bounds__(1024) k_sum_group_loss(const float* __restrict
         __syncthreads();
         if (threadIdx.x == 0) { float q = 0.f; for (int w = 0; w < 16; w++) q += red[w]; acc += q; }
     }
-    if (threadIdx.x == 0) loss_out[0] += acc;
+    if (threadIdx.x == 0) { loss_out[0] += acc; gs_status_to_host(status, status_host); }
 }
-int gs_launch_sum_group_loss(const float* terms, int n, int V, size_t vs, float* loss_out, hipStream_t s) {
+int gs_launch_sum_group_loss(const float* terms, int n, int V, size_t vs, float* loss_out, hipStream_t s, const uint32_t* status, unsigned long long* status_host) {
     if (n <= 0 || V <= 0 || !loss_out) return 0;
-    hipLaunchKernelGGL(k_sum_group_loss, dim3(1), dim3(1024), 0, s, terms, n, vs, V, loss_out);
+    hipLaunchKernelGGL(k_sum_group_loss, dim3(1), dim3(1024), 0, s, terms, n, vs, V, loss_out, status, status_host);
     C3D_LAUNCH_CHECK();
     return 0;
 }
@@ -352,9 +361,9 @@ int gs_launch_sum_view_loss(const float* terms, int n, float* view_sum, int V, s
     C3D_LAUNCH_CHECK();
     return 0;
 }
-int gs_launch_sum_tile_loss(const float* first_view_sum, size_t view_stride_bytes, int V, float* loss_out, hipStream_t s) {
+int gs_launch_sum_tile_loss(const float* first_view_sum, size_t view_stride_bytes, int V, float* loss_out, hipStream_t s, const uint32_t* status, unsigned long long* status_host) {
     if (V == 0 || !loss_out) return 0;
-    hipLaunchKernelGGL(k_sum_views_loss, dim3(1), dim3(64), 0, s, first_view_sum, view_stride_bytes, V, loss_out);
+    hipLaunchKernelGGL(k_sum_views_loss, dim3(1), dim3(64), 0, s, first_view_sum, view_stride_bytes, V, loss_out, status, status_host);
     C3D_LAUNCH_CHECK();
     return 0;
 }

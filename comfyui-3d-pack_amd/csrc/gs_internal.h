@@ -195,9 +195,10 @@ int gs_launch_emit(const GsParams& p, const GsGeom& g, int res, GsBinning& b, hi
 int gs_launch_composite_fwd(const GsParams& p, const GsGeom& g, const GsBinning& b, int res, GsImage& im, const GsFwdViews& vp, int V, size_t vs,
                             bool record_activity, hipStream_t s, uint32_t* err = nullptr, bool scan = true);
 int gs_launch_poison_on_overflow(const uint32_t* status, float* color, float* depth, float* alpha, int W, int H, hipStream_t s);
-int gs_launch_sum_group_loss(const float* terms, int n, int V, size_t vs, float* loss_out, hipStream_t s);   // ONE group holds all views: both stages below in one launch (same bits)
+// status / status_host (device-visible address of 8 bytes of pinned host memory; optional): the final loss launch also leaves the step's status words on the host
+int gs_launch_sum_group_loss(const float* terms, int n, int V, size_t vs, float* loss_out, hipStream_t s, const uint32_t* status = nullptr, unsigned long long* status_host = nullptr);   // ONE group holds all views: both stages below in one launch (same bits)
 int gs_launch_sum_view_loss(const float* terms, int n, float* view_sum, int V, size_t vs, hipStream_t s);   // per view: its per-tile partials (+ MS-SSIM term) -> one float
-int gs_launch_sum_tile_loss(const float* first_view_sum, size_t view_stride_bytes, int V, float* loss_out, hipStream_t s);   // the V view sums, in order, added to *loss_out
+int gs_launch_sum_tile_loss(const float* first_view_sum, size_t view_stride_bytes, int V, float* loss_out, hipStream_t s, const uint32_t* status = nullptr, unsigned long long* status_host = nullptr);   // the V view sums, in order, added to *loss_out
 int gs_launch_composite_bwd(const GsParams& p, const GsGeom& g, const GsBinning& b, int res, const GsImage& im, const GsBwdPix& px, bool depth,
                             float* pairgrad /* [D][12] */, uint8_t* pvalid /* [D], clear on entry */, hipStream_t s, uint32_t cap = 0xFFFFFFFFu,
                             const GsPixelLossW* pixel_loss = nullptr, int V = 1, size_t vs = 0);

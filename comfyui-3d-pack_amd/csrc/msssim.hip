@@ -233,31 +233,49 @@ __global__ void __launch_bounds__(256, MS_MIN_BLOCKS) k_ms_fwd(const float* __re
 // per plane: level means (fixed-order sums of the tile partials) -> ms, and the scalar dL/d(map pixel) of every level
 struct MsFinal { const float* partial[MS_LEVELS]; int tiles[MS_LEVELS]; float inv_npix[MS_LEVELS]; float wts[MS_LEVELS]; };
 // pmean: planes the value is a mean over (P for one mean over the whole batch; C when every image of the batch is its own loss term)
-__global__ void __launch_bounds__(256) k_ms_finalize(MsFinal f, int P, int pmean, float grad_scale, float* __restrict__ g /* [levels][P] */, float* __restrict__ ms_plane) {
-    __shared__ float red[256];
-    const int plane = blockIdx.x;
+// img_C > 0 (every image its own loss term, the fused 3DGS training steps): a workgroup per IMAGE, 256 lanes per plane (img_C <= 4 planes side by side; more: one after the
+// other), also leaves the image's value, *(out0 + image * stride bytes) = a + b * mean of its planes' ms -- what k_ms_mean_images did in a launch of its own.  Per plane the
+// same 256-lane strided sums and the same tree as the plane-per-workgroup form: the same bits.
+__global__ void __launch_bounds__(1024) k_ms_finalize(MsFinal f, int P, int pmean, float grad_scale, float* __restrict__ g /* [levels][P] */, float* __restrict__ ms_plane,
+                                                       int img_C, float a, float b, float* __restrict__ out0, size_t stride) {
+    __shared__ float red[4][256];
+    __shared__ float s_ms[4];
+    const int sub = threadIdx.x >> 8, tid = threadIdx.x & 255, side = blockDim.x >> 8;      // `side` planes at a time
+    float img_sum = 0.f;
+    const int planes = img_C > 0 ? img_C : 1;
+  for (int p0 = 0; p0 < planes; p0 += side) {
+    const int pc = p0 + sub;
+    const bool live = pc < planes;
+    const int plane = img_C > 0 ? (int)blockIdx.x * img_C + (live ? pc : 0) : (int)blockIdx.x;
     float v[MS_LEVELS];
     for (int l = 0; l < MS_LEVELS; l++) {
         float s = 0.f;
-        for (int t = threadIdx.x; t < f.tiles[l]; t += 256) s += f.partial[l][(size_t)plane * f.tiles[l] + t];
-        red[threadIdx.x] = s;
+        for (int t = tid; t < f.tiles[l]; t += 256) s += f.partial[l][(size_t)plane * f.tiles[l] + t];
+        red[sub][tid] = s;
         __syncthreads();
         for (int o = 128; o >= 1; o >>= 1) {
-            if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            if (tid < o) red[sub][tid] += red[sub][tid + o];
             __syncthreads();
         }
-        { const float mean = red[0] * f.inv_npix[l]; v[l] = mean != mean ? mean : fmaxf(mean, 0.f); }      // relu(mean); a NaN mean stays NaN (a non-finite render must show in the loss)
+        { const float mean = red[sub][0] * f.inv_npix[l]; v[l] = mean != mean ? mean : fmaxf(mean, 0.f); }      // relu(mean); a NaN mean stays NaN (a non-finite render must show in the loss)
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
+    if (tid == 0 && live) {
         float ms = 1.f;
         bool pos = true, bad = false;
         for (int l = 0; l < MS_LEVELS; l++) { bad = bad || v[l] != v[l]; pos = pos && v[l] > 0.f; ms *= powf(v[l], f.wts[l]); }
         if (!pos) ms = 0.f;
         if (bad) ms = __builtin_nanf("");
         ms_plane[plane] = ms;
+        s_ms[sub] = ms;
         for (int l = 0; l < MS_LEVELS; l++) g[(size_t)l * P + plane] = bad ? ms : (pos ? grad_scale * (f.wts[l] * ms / v[l]) * f.inv_npix[l] / (float)pmean : 0.f);
     }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int q = 0; q < side && p0 + q < planes; q++) img_sum += s_ms[q];      // planes in order
+    __syncthreads();
+  }
+    if (img_C > 0 && out0 && threadIdx.x == 0) *(float*)((char*)out0 + (size_t)blockIdx.x * stride) = a + b * (img_sum / (float)img_C);
 }
 // value: out (+)= a + b * mean(ms), a fixed-order mean.  store = 1: the word is the caller's own slot (the fused training steps keep one slot per view and add the
 // views up in view order: the loss VALUE is then bit-reproducible like the gradients); store = 0: added atomically to a word other launches may add to as well.
@@ -267,15 +285,6 @@ __global__ void k_ms_mean(const float* __restrict__ ms_plane, int P, float a, fl
     const float val = a + b * (s / (float)P);
     if (store) *out = val; else atomicAdd(out, val);
 }
-// one value per image (thread = image): out0 + image * stride bytes <- a + b * mean of the image's C planes
-__global__ void k_ms_mean_images(const float* __restrict__ ms_plane, int B, int C, float a, float b, float* __restrict__ out0, size_t stride) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B) return;
-    float s = 0.f;
-    for (int c = 0; c < C; c++) s += ms_plane[i * C + c];
-    *(float*)((char*)out0 + (size_t)i * stride) = a + b * (s / (float)C);
-}
-
 // backward of one level: gradient w.r.t. the level's y over the whole image (+ the pooled parent level's gradient)
 // Round 4: NT horizontally adjacent tiles per workgroup; tile t + 1's maps and tile t's epilogue inputs (x, y, mask, parent gradient, the old output when
 // accumulating) are requested before tile t is filtered (see k_ms_fwd).  Same arithmetic per output: bit-identical to the one-tile form.
@@ -515,9 +524,9 @@ static int ms_run(const float* x, const float* y, const float* mask, const MsTab
     }
     float* g = (float*)(ws + pl.off_g);
     float* msp = (float*)(ws + pl.off_ms);
-    hipLaunchKernelGGL(k_ms_finalize, dim3(P), dim3(256), 0, s, fin, P, per_image ? C : P, grad_scale, g, msp);
-    if (ms_out && per_image) hipLaunchKernelGGL(k_ms_mean_images, dim3(1), dim3(64), 0, s, msp, B, C, va, vb, ms_out, out_stride);
-    else if (ms_out) hipLaunchKernelGGL(k_ms_mean, dim3(1), dim3(1), 0, s, msp, P, va, vb, ms_out, store_value);
+    if (per_image) hipLaunchKernelGGL(k_ms_finalize, dim3(B), dim3(256 * (C < 4 ? C : 4)), 0, s, fin, P, C, grad_scale, g, msp, C, va, vb, ms_out, out_stride);      // (the images' values in the same launch)
+    else hipLaunchKernelGGL(k_ms_finalize, dim3(P), dim3(256), 0, s, fin, P, P, grad_scale, g, msp, 0, 0.f, 0.f, (float*)nullptr, (size_t)0);
+    if (ms_out && !per_image) hipLaunchKernelGGL(k_ms_mean, dim3(1), dim3(1), 0, s, msp, P, va, vb, ms_out, store_value);
     for (int l = MS_LEVELS - 1; l >= 0; l--) {
         const MsLevel& L = pl.lv[l];
         const size_t val = (size_t)P * L.Hv * L.Wv;

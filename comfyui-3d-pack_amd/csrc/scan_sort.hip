@@ -612,6 +612,101 @@ __global__ void __launch_bounds__(RS_THREADS, 4) k_onesweep(const uint32_t* __re
 #undef RS_COUNT
 }
 
+// ------------------------------------------------------------------------------------------
+// Small sorts (round 6): up to 16384 keys per view, values = the element indices.  The node's own default scene (10 000 Gaussians, /root/reference/nodes.py:1175-1198) made the
+// depth sort a histogram launch and four onesweep launches of THREE tiles each -- 55 us of a 410 us training iteration for 80 KB of keys, every launch the minimum a launch costs.
+// Here ONE workgroup per view (16 waves) does all passes: a lane keeps its 16 (key, id) pairs in registers, ranks them by ballot as k_onesweep does, and the whole array changes
+// places through LDS (128 KB of the CU's 160) between passes -- no state in memory, no clear, no chained scan, no histogram kernel; keys and ids reach HBM once, sorted.
+// ------------------------------------------------------------------------------------------
+#define SS_THREADS 1024
+#define SS_ITEMS 16
+#define SS_MAX (SS_THREADS * SS_ITEMS)
+__global__ void __launch_bounds__(SS_THREADS) k_sort_small(const uint32_t* __restrict__ keys_in0, uint32_t* __restrict__ keys_out0, uint32_t* __restrict__ vals_out0, uint32_t n,
+                                                            int passes, size_t vs) {
+    __shared__ uint32_t skey[SS_MAX];
+    __shared__ uint32_t sval[SS_MAX];
+    __shared__ uint32_t whist[SS_THREADS / 64][RS_RADIX];      // per wave and digit: count, then the position of the wave's first key of that digit
+    __shared__ uint32_t scan_lds[4];
+    const uint32_t* keys_in = c3d_view_ptr(keys_in0, vs);
+    uint32_t* keys_out = c3d_view_ptr(keys_out0, vs);
+    uint32_t* vals_out = c3d_view_ptr(vals_out0, vs);
+    const int lane = c3d_lane(), wave = threadIdx.x >> 6;
+    // every wave owns the same number of 64-element rows, R = ceil(n / 1024) <= 16, of a contiguous stretch of the array (ranking is stable by construction): 10 000 keys are
+    // 10 rows in each of the 16 waves, not 16 rows in ten of them
+    const int R = (int)((n + SS_THREADS - 1) / SS_THREADS);
+    const uint32_t woff = (uint32_t)wave * (uint32_t)(64 * R) + (uint32_t)lane;
+    uint32_t key[SS_ITEMS], val[SS_ITEMS], rank[SS_ITEMS];
+#pragma unroll
+    for (int i = 0; i < SS_ITEMS; i++) {
+        const uint32_t idx = woff + (uint32_t)i * 64u;
+        const bool ok = i < R && idx < n;
+        key[i] = ok ? keys_in[idx] : 0xFFFFFFFFu;
+        val[i] = idx;
+    }
+    for (int pass = 0; pass < passes; pass++) {
+        const int shift = 8 * pass;
+        for (int i = threadIdx.x; i < (SS_THREADS / 64) * RS_RADIX; i += SS_THREADS) (&whist[0][0])[i] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < SS_ITEMS; i++) {
+            if (i < R) {      // (uniform)
+                const bool ok = woff + (uint32_t)i * 64u < n;      // elements past the end take no part: n elements are ranked, n positions are filled
+                const uint64_t okm = __ballot(ok);
+                const uint32_t ds = key[i] >> shift;
+                uint32_t plo = (uint32_t)okm, phi = (uint32_t)(okm >> 32);
+#pragma unroll
+                for (int b = 0; b < 8; b++) {
+                    const int t = __builtin_amdgcn_sbfe((int)ds, b, 1);
+                    const uint64_t m = __ballot(t != 0);
+                    plo = __builtin_amdgcn_bitop3_b32(plo, (uint32_t)m, (uint32_t)t, 0x90);
+                    phi = __builtin_amdgcn_bitop3_b32(phi, (uint32_t)(m >> 32), (uint32_t)t, 0x90);
+                }
+                const uint32_t d = ds & (RS_RADIX - 1);
+                const uint32_t prefix = whist[wave][d];
+                const uint32_t r = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
+                if (ok && r == 0) whist[wave][d] = prefix + (uint32_t)__popc(plo) + (uint32_t)__popc(phi);
+                rank[i] = prefix + r;
+            }
+        }
+        __syncthreads();
+        // thread d < 256: where digit d starts (exclusive scan of the digit totals over waves 0-3), then where each wave's keys of that digit start
+        uint32_t c[SS_THREADS / 64], tot = 0, incl = 0;
+        if (threadIdx.x < RS_RADIX) {
+#pragma unroll
+            for (int w = 0; w < SS_THREADS / 64; w++) { c[w] = whist[w][threadIdx.x]; tot += c[w]; }
+            incl = c3d_wave_incl_scan(tot);
+            if (lane == 63) scan_lds[wave] = incl;
+        }
+        __syncthreads();
+        if (threadIdx.x < RS_RADIX) {
+            uint32_t base = incl - tot;
+            for (int w = 0; w < wave; w++) base += scan_lds[w];
+#pragma unroll
+            for (int w = 0; w < SS_THREADS / 64; w++) { whist[w][threadIdx.x] = base; base += c[w]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < SS_ITEMS; i++) {
+            if (i < R && woff + (uint32_t)i * 64u < n) {
+                const uint32_t pos = whist[wave][(key[i] >> shift) & (RS_RADIX - 1)] + rank[i];
+                skey[pos] = key[i];
+                sval[pos] = val[i];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < SS_ITEMS; i++) {
+            const uint32_t idx = woff + (uint32_t)i * 64u;
+            if (i < R && idx < n) { key[i] = skey[idx]; val[i] = sval[idx]; }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < SS_ITEMS; i++) {
+        const uint32_t idx = woff + (uint32_t)i * 64u;
+        if (i < R && idx < n) { keys_out[idx] = key[i]; vals_out[idx] = val[i]; }
+    }
+}
+
 static unsigned long long* g_sort_dbg = nullptr;     // profiling hook: [pass][tile][8] wall_clock64 stamps (100 MHz), see c3d_test_sort_phases
 static inline size_t sort_head_bytes() { return c3d_align(sizeof(uint32_t) * (RS_HIST_SPLIT * RS_RADIX * RS_MAX_PASSES + RS_MAX_PASSES + 4)); }
 #define RS_MIN_TILE RS_TILE
@@ -672,6 +767,12 @@ int c3d_sort_pairs_u32(uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32
     if (n > (size_t)RS_VALUE_MASK) { c3d_set_error("c3d_sort_pairs_u32: %zu elements exceed the 2^30 - 1 the chained scan's status words hold", n); return -1; }
     int passes = (end_bit + 7) / 8;
     if (passes < 1) passes = 1;
+    if (iota_vals && n <= (size_t)SS_MAX && !n_dev && !hist_done && !ranges && !g_sort_dbg) {      // a small sort: one workgroup per view, all passes in one launch, no state (k_sort_small)
+        hipLaunchKernelGGL(k_sort_small, dim3(1, V), dim3(SS_THREADS), 0, s, (const uint32_t*)keys0, (passes & 1) ? keys1 : keys0, (passes & 1) ? vals1 : vals0, (uint32_t)n, passes, vs);
+        C3D_LAUNCH_CHECK();
+        *result_buf = passes & 1;
+        return 0;
+    }
     const int nb = c3d_cdiv((long long)n, RS_TILE), nb_hist = nb;
     // k_onesweep's workgroups stay and draw tile after tile: one per residency slot of the chip (MI355X: 256 CUs x 4 workgroups of 39 KB LDS), spread evenly over the views
     // n_hint (one view, with n_dev): the launch is sized for n_hint elements although the buffers (and the state layout) hold n -- workgroups loop if the count exceeds the hint (STAY == 2)

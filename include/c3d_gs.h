@@ -200,6 +200,10 @@ typedef struct c3d_gs_loss { float w_l1; float w_l2; float w_alpha_mse; float sc
  * runs the per-Gaussian pass itself with c3d_gs_step_param_backward_range, one Gaussian range after the other, e.g. to start the gradient
  * exchange of a range (multi-GPU) while the next range is still being computed.  The ranges together must cover [0, N) once; each
  * starts at a multiple of 4.  Results are bit-identical to the unchunked call. */
+/* status_host (optional, ABI 600): 8 bytes of PINNED host memory the device can address.  The launch that adds up the step's loss -- ordered behind every kernel that can raise
+ * a status bit, in front of the per-Gaussian pass -- stores the two status words there itself (one 64-bit store; without loss_out: a copy at the end of the call): a training loop of
+ * small scenes, whose iteration is three dozen launches of 4-80 us, learns how the step went without a copy launch in the stream and before the step's last kernels have run
+ * (preset the second word to 0xFFFFFFFF and wait for it to change: c3d_gs_wait_count). */
 size_t c3d_gs_step_workspace_bytes(int32_t N, int32_t image_height, int32_t image_width, int64_t pair_capacity, int32_t views);
 int c3d_gs_train_views_raw(const c3d_gs_settings* views /* host [V] */, int32_t V, int32_t N, const float* means3D, const float* f_dc,
                            const float* f_rest, const float* opacity_raw, const float* scaling_raw, const float* rotation_raw,
@@ -207,7 +211,7 @@ int c3d_gs_train_views_raw(const c3d_gs_settings* views /* host [V] */, int32_t 
                            const c3d_gs_loss* loss,
                            float* dL_dmeans3D, float* dL_df_dc, float* dL_df_rest, float* dL_dopacity_raw, float* dL_dscaling_raw,
                            float* dL_drotation_raw, float* loss_out, int64_t pair_capacity, int32_t lanes, int32_t accumulate, void* workspace,
-                           uint32_t* status /* device [2] */, c3d_stream_t stream);
+                           uint32_t* status /* device [2] */, uint32_t* status_host /* pinned, device-mapped host [2] or NULL */, c3d_stream_t stream);
 
 int c3d_gs_step_param_backward_range(const c3d_gs_settings* views /* host [V] */, int32_t V, int32_t N, const float* means3D, const float* f_dc,
                                      const float* f_rest, const float* scaling_raw, const float* rotation_raw, float* dL_dmeans3D, float* dL_df_dc,
