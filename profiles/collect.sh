@@ -26,8 +26,12 @@ python $R/profiles/summarize_sq.py $(find /tmp/sqb -name "*.db" | head -1) $OUT/
 cp $OUT/${TAG}_pmc_traffic.json $OUT/${TAG}_mesh_pmc_traffic.json $OUT/${TAG}_sq_instruction_mix_lanes1.csv $OUT/${TAG}_sq_instruction_mix_lanes1.csv.meta.json $OUT/${TAG}_sq_pipe_activity_lanes1.csv $OUT/${TAG}_sq_pipe_activity_lanes1.csv.meta.json $R/profiles/
 # --- kernel stats (timeout 240 rocprofv3 --kernel-trace of the default command and of the mesh workload)
 rm -rf /tmp/kt /tmp/km /tmp/ktt
-timeout 240 rocprofv3 --kernel-trace -d /tmp/kt -o kt -- python $R/bench.py --steps 3 --warmup 1 --cpu-baseline off < /dev/null > /tmp/kt.log 2>&1
+# (round 6: the step's kernels and the forward target's in TWO tables -- the default command also renders the 64-camera forward target, trains and runs the mesh step after its timed region)
+timeout 240 rocprofv3 --kernel-trace -d /tmp/kt -o kt -- python $R/bench.py --steps 3 --warmup 1 --cpu-baseline off --targets off < /dev/null > /tmp/kt.log 2>&1
 python $R/profiles/summarize_rocpd.py $(find /tmp/kt -name "*.db" | head -1) > $OUT/${TAG}_fwdbwd_kernel_stats.csv
+rm -rf /tmp/kf
+timeout 240 rocprofv3 --kernel-trace -d /tmp/kf -o kf -- python $R/bench.py --mode fwd --views-per-gpu 64 --steps 3 --warmup 1 --cpu-baseline off --targets off < /dev/null > /tmp/kf.log 2>&1
+python $R/profiles/summarize_rocpd.py $(find /tmp/kf -name "*.db" | head -1) > $OUT/${TAG}_fwd64_kernel_stats.csv
 timeout 240 rocprofv3 --kernel-trace -d /tmp/ktt -o ktt -- python $R/bench.py --mode train --steps 3 --warmup 1 --cpu-baseline off < /dev/null > /tmp/ktt.log 2>&1
 python $R/profiles/summarize_rocpd.py $(find /tmp/ktt -name "*.db" | head -1) > $OUT/${TAG}_train_kernel_stats.csv
 timeout 240 rocprofv3 --kernel-trace -d /tmp/km -o km -- python $R/bench.py --workload mesh --steps 2 --warmup 1 --cpu-baseline off < /dev/null > /tmp/km.log 2>&1
@@ -46,10 +50,14 @@ if [ -z "$QUICK" ]; then
   timeout 300 python bench.py --render-path fused --steps 20 --warmup 5 --cpu-baseline off --targets off < /dev/null 2>/dev/null | tail -1 > $OUT/${TAG}_bench_renderer_api_n1.json
   timeout 300 python bench.py --render-path boundary --steps 20 --warmup 5 --cpu-baseline off --targets off < /dev/null 2>/dev/null | tail -1 > $OUT/${TAG}_bench_boundary_api_n1.json
   timeout 300 python bench.py --render-path boundary --sync-free off --steps 20 --warmup 5 --cpu-baseline off --targets off < /dev/null 2>/dev/null | tail -1 > $OUT/${TAG}_bench_boundary_api_syncfree_off_n1.json
+  timeout 300 python bench.py --render-path boundary --sync-free unverified --steps 20 --warmup 5 --cpu-baseline off --targets off < /dev/null 2>/dev/null | tail -1 > $OUT/${TAG}_bench_boundary_api_unverified_n1.json
+  timeout 300 python bench.py --render-path boundary --mode fwd --inference-mode on --steps 20 --warmup 5 --cpu-baseline off --targets off < /dev/null 2>/dev/null | tail -1 > $OUT/${TAG}_bench_boundary_inference_n1.json
+  timeout 300 python bench.py --render-path boundary --mode fwd --inference-mode on --forward-only off --steps 20 --warmup 5 --cpu-baseline off --targets off < /dev/null 2>/dev/null | tail -1 > $OUT/${TAG}_bench_boundary_inference_forward_only_off_n1.json
   timeout 300 python bench.py --workload ref-default --ref-res 512 --steps 700 --warmup 50 --cpu-baseline off < /dev/null 2>/dev/null | tail -1 > $OUT/${TAG}_bench_ref_default_512.json
   timeout 120 python profiles/microbench/sort_phases.py < /dev/null > $OUT/${TAG}_sort_phases.txt 2>&1
+  (cd /tmp && rm -rf /tmp/kr && timeout 600 rocprofv3 --kernel-trace -d /tmp/kr -o kr -- python $R/bench.py --workload ref-default --ref-res 512 --steps 400 --warmup 50 --cpu-baseline off --timed-prof off < /dev/null > /tmp/kr.log 2>&1; python $R/profiles/iteration_timeline.py $(find /tmp/kr -name "*.db" | head -1) 20 > $OUT/${TAG}_ref_default_iteration_timeline.txt)
 fi
-if [ -z "$QUICK" ]; then timeout 900 python -m pytest tests -m gpu -q -s < /dev/null > $OUT/${TAG}_gpu_pytest.log 2>&1; tail -3 $OUT/${TAG}_gpu_pytest.log; fi
+if [ -z "$QUICK" ]; then timeout 1800 python -m pytest tests -m gpu -q -s < /dev/null > $OUT/${TAG}_gpu_pytest.log 2>&1; tail -3 $OUT/${TAG}_gpu_pytest.log; fi
 head -12 $OUT/${TAG}_fwdbwd_kernel_stats.csv
 head -12 $OUT/${TAG}_pmc_traffic.csv
 for f in $OUT/${TAG}_bench_*.json; do echo $f; timeout 20 python profiles/benchline.py < $f; done
