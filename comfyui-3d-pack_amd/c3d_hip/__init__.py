@@ -91,6 +91,7 @@ _SIGNATURES = {
     "c3d_prof_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     "c3d_test_scan_u32": (C.c_int, [vp, vp, i64, i32, vp]),
     "c3d_test_sort_pairs_u32": (C.c_int, [vp, vp, i64, i32, vp]),
+    "c3d_test_sort_iota_u32": (C.c_int, [vp, vp, i64, i32, vp]),
     "c3d_test_sort_phases": (C.c_int, [vp]),
     "c3d_test_scan_wave": (C.c_int, [vp, vp, vp, vp, i64, vp]),
 }

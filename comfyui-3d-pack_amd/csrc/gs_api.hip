@@ -311,8 +311,11 @@ int c3d_gs_wait_count(const uint32_t* count_host, uint32_t sentinel, int64_t tim
         }
         if ((spins & 63) == 63) {
             clock_gettime(CLOCK_MONOTONIC, &t1);
-            if (timeout_us >= 0 && (t1.tv_sec - t0.tv_sec) * 1000000ll + (t1.tv_nsec - t0.tv_nsec) / 1000 > timeout_us) { c3d_set_error("c3d_gs_wait_count: timed out"); return -4; }
-            sched_yield();
+            const long long us = (t1.tv_sec - t0.tv_sec) * 1000000ll + (t1.tv_nsec - t0.tv_nsec) / 1000;
+            if (timeout_us >= 0 && us > timeout_us) { c3d_set_error("c3d_gs_wait_count: timed out"); return -4; }
+            // the word usually arrives within a few microseconds (the host is one scan ahead of the GPU); a host that is a whole queue of kernels ahead does not burn its core
+            // on the poll: after 50 us it sleeps 20 us between looks
+            if (us > 50) { const struct timespec nap = {0, 20000}; nanosleep(&nap, nullptr); } else sched_yield();
         }
     }
 }
@@ -872,6 +875,26 @@ int c3d_test_scan_wave(const uint32_t* in, const uint32_t* rect, uint32_t* out, 
     if (rc != hipSuccess) { c3d_set_error("c3d_test_scan_wave: %s", hipGetErrorString(rc)); return (int)rc; }
     if (e) { c3d_set_error("c3d_test_scan_wave: a hand-over timed out"); return -3; }
     return 0;
+}
+// keys sorted in place, vals = the permutation (element indices): the form the depth sort and the topology builders use -- up to 16384 keys it is ONE launch of ONE workgroup (k_sort_small)
+int c3d_test_sort_iota_u32(uint32_t* keys, uint32_t* vals, int64_t n, int32_t end_bit, c3d_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (n <= 0) return 0;
+    if (!keys || !vals) { c3d_set_error("c3d_test_sort_iota_u32: NULL pointer"); return -1; }
+    uint32_t *k1 = nullptr, *v1 = nullptr;
+    void* tmp = nullptr;
+    C3D_CHECK(hipMalloc(&k1, 4 * (size_t)n));
+    C3D_CHECK(hipMalloc(&v1, 4 * (size_t)n));
+    C3D_CHECK(hipMalloc(&tmp, c3d_sort_tmp_bytes((size_t)n)));
+    int res = 0;
+    int rc = c3d_sort_pairs_u32(keys, k1, vals, v1, true, (size_t)n, end_bit, tmp, &res, s);
+    if (!rc && res == 1) {
+        (void)hipMemcpyAsync(keys, k1, 4 * (size_t)n, hipMemcpyDeviceToDevice, s);
+        (void)hipMemcpyAsync(vals, v1, 4 * (size_t)n, hipMemcpyDeviceToDevice, s);
+    }
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(k1); (void)hipFree(v1); (void)hipFree(tmp);
+    return rc;
 }
 int c3d_test_sort_pairs_u32(uint32_t* keys, uint32_t* vals, int64_t n, int32_t end_bit, c3d_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;

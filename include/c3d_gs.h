@@ -299,6 +299,8 @@ int c3d_prof_read(int slot, double* total_ms, long long* launches);
 /* primitives exported for unit tests of the binning machinery (device pointers) */
 int c3d_test_scan_u32(const uint32_t* in, uint32_t* out, int64_t n, int32_t exclusive, c3d_stream_t stream);
 int c3d_test_sort_pairs_u32(uint32_t* keys, uint32_t* vals, int64_t n, int32_t end_bit, c3d_stream_t stream);
+/* the same with vals = the element indices on entry (not read): keys sorted in place, vals = the permutation.  Up to 16384 keys: one launch of one workgroup (round 6) */
+int c3d_test_sort_iota_u32(uint32_t* keys, uint32_t* vals, int64_t n, int32_t end_bit, c3d_stream_t stream);
 /* the record-base scan of the backward pass (it normally rides inside the recording forward compositing launch) as a launch of its own: out[n] = exclusive prefix of
  * in[n]; einfo[n][4] = {0, rect[i][0], rect[i][1], out[i]} where in[i] != 0 (other entries untouched); rect [n][2] */
 int c3d_test_scan_wave(const uint32_t* in, const uint32_t* rect, uint32_t* out, uint32_t* einfo, int64_t n, c3d_stream_t stream);

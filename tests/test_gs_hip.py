@@ -93,6 +93,23 @@ def test_sort_pairs_is_stable_and_correct(n, bits):
 
 
 # ---------------------------------------------------------------- forward parity
+@pytest.mark.parametrize("n,bits", [(1, 32), (63, 32), (64, 8), (65, 32), (1023, 13), (1024, 32), (1025, 32), (10000, 32), (16383, 32), (16384, 32), (16384, 5), (16385, 32), (40000, 32)])
+def test_sort_with_index_values_small_and_large(n, bits):
+    """the form of the sort the depth ordering and the topology builders use (values = element indices): up to 16384 keys ONE workgroup per view does every pass through LDS
+    (k_sort_small, round 6), above that the histogram + onesweep launches -- both stable, both against numpy's stable argsort; duplicate-heavy keys included"""
+    import c3d_hip as h
+    rng = np.random.default_rng(n * 31 + bits)
+    hi = (1 << bits) - 1 if bits < 32 else 0xFFFFFFFF
+    for kind in ("uniform", "few"):
+        a = (rng.integers(0, hi + 1, size=n, dtype=np.uint64) if kind == "uniform" else rng.integers(0, 7, size=n, dtype=np.uint64) * (hi // 7 if hi >= 7 else 1)).astype(np.uint32)
+        k = torch.tensor(a.astype(np.int64), device="cuda").to(torch.int32)
+        v = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+        h.check(h.lib().c3d_test_sort_iota_u32(h.ptr(k), h.ptr(v), n, bits, h.stream()), "sort")
+        order = np.argsort(a, kind="stable")
+        assert (k.cpu().numpy().view(np.uint32) == a[order]).all(), (n, bits, kind)
+        assert (v.cpu().numpy() == order).all(), (n, bits, kind)
+
+
 CASES = [
     dict(N=48, W=48, H=32, el=-20, az=30, rad=2.0, seed=7, deg=3),
     dict(N=300, W=100, H=70, el=35, az=200, rad=1.6, seed=3, deg=2),     # W,H not multiples of 16
