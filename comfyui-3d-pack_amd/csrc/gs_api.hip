@@ -313,9 +313,9 @@ int c3d_gs_wait_count(const uint32_t* count_host, uint32_t sentinel, int64_t tim
             clock_gettime(CLOCK_MONOTONIC, &t1);
             const long long us = (t1.tv_sec - t0.tv_sec) * 1000000ll + (t1.tv_nsec - t0.tv_nsec) / 1000;
             if (timeout_us >= 0 && us > timeout_us) { c3d_set_error("c3d_gs_wait_count: timed out"); return -4; }
-            // the word usually arrives within a few microseconds (the host is one scan ahead of the GPU); a host that is a whole queue of kernels ahead does not burn its core
-            // on the poll: after 50 us it sleeps 20 us between looks
-            if (us > 50) { const struct timespec nap = {0, 20000}; nanosleep(&nap, nullptr); } else sched_yield();
+            // the word arrives within a view's worth of GPU work (<= ~1 ms on the per-view loops): spin, yielding -- a 20 us nap after 50 us of waiting, tried first, came back
+            // 50-70 us late and cost the inference loop 8 % (profiles/r06/r06m_*).  Only a host that is a whole queue of kernels ahead (> 2 ms) stops burning its core on the poll
+            if (us > 2000) { const struct timespec nap = {0, 50000}; nanosleep(&nap, nullptr); } else sched_yield();
         }
     }
 }
