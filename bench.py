@@ -678,12 +678,17 @@ def main():
     multi = fused_step if fused_step is not None else view_render
     only_dom = ["gs_composite_fwd" if a.mode == "fwd" else "gs_composite_bwd"] if (multi is not None and multi.lanes > 1) else None
     c3d_hip.prof_enable(a.timed_prof == "on", only=only_dom)
+    ms0 = torch.cuda.memory_stats(dev)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
     t_enqueue = time.perf_counter() - t0      # the host's share: everything enqueued, nothing waited for (per-view paths: is the loop host-bound?)
     sync()
     dt = time.perf_counter() - t0
+    ms1 = torch.cuda.memory_stats(dev)
+    # hipMalloc / hipFree calls of torch's caching allocator inside the timed region (each synchronises the device): a per-view loop whose buffer sizes change keeps paying them
+    allocator = {"device_mallocs": int(ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0)), "device_frees": int(ms1.get("num_device_free", 0) - ms0.get("num_device_free", 0)),
+                 "reserved_GB": round(ms1.get("reserved_bytes.all.current", 0) / 1e9, 2)}
     prof = c3d_hip.prof_read() if a.timed_prof == "on" else {}
     c3d_hip.prof_enable(False)
     # With view lanes > 1 the kernels of different views share the CUs, so a kernel's wall duration inside the timed region is no longer
@@ -964,7 +969,7 @@ def main():
                        "sync_free_drop_in": ({"on": "verified", "off": False}.get(a.sync_free, a.sync_free)) if a.render_path != "step" else None,
                        "forward_only_flag": (a.forward_only == "on") if (a.render_path != "step" and a.mode == "fwd") else None,
                        "inference_mode": (a.inference_mode == "on") if a.render_path != "step" else None,
-                       "drop_in_calls_rendered_twice": int(dgr.redone_calls) if a.render_path != "step" else None,
+                       "allocator_in_timed_region": allocator, "drop_in_calls_rendered_twice": int(dgr.redone_calls) if a.render_path != "step" else None,
                        "drop_in_calls_beyond_launch_hint": int(dgr.beyond_hint_calls) if a.render_path != "step" else None,
                        "defer_status": (fused_step.defer_status if fused_step is not None else None),
                        "gpu_span_ms_last_step": gpu_span_timed,
