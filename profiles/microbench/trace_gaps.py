@@ -1,3 +1,5 @@
+"""Where does the GPU idle in a kernel trace?  Busy share of the last 60 % of a rocprofv3 --kernel-trace database and the largest gaps by (kernel before, kernel after):
+  python profiles/microbench/trace_gaps.py <results.db>"""
 import sqlite3, sys
 c = sqlite3.connect(sys.argv[1])
 rows = c.execute("select name, start, end from kernels order by start").fetchall()
