@@ -37,6 +37,7 @@ enum { C3D_P_PREPROCESS = 0, C3D_P_DEPTH_SORT, C3D_P_SCAN, C3D_P_EMIT, C3D_P_TIL
        C3D_P_MESH_ANTIALIAS, C3D_P_MESH_BWD, C3D_P_OTHER, C3D_P_MESH_RASTERIZE_BWD, C3D_P_MESH_INTERPOLATE_BWD,
        C3D_P_MESH_TEXTURE_BWD, C3D_P_MESH_ANTIALIAS_BWD, C3D_P_MSSSIM,
        C3D_P_MESH_RAS_TRI /* k_ras_tri alone, nested inside the rasterize group: the mesh line's per-kernel roofline */ };
+// (C3D_P_RANGES has had no kernel since round 6 -- the last tile-sort pass leaves the per-tile ranges -- and keeps its slot so that the slot numbers of the others stay put)
 void* c3d_prof_begin(int slot, hipStream_t s);
 void c3d_prof_end(void* h, hipStream_t s);
 struct C3dProfScope {

@@ -213,7 +213,7 @@ int c3d_gs_forward_render(const c3d_gs_settings* st, int32_t N, int32_t M, const
 }
 
 // A2-A6 of ONE view without the host.  The pair count stays on the device (g.meta[0]); the BUFFERS hold pair_capacity pairs, the LAUNCHES are sized for first_capacity (a hint
-// learnt from earlier counts): a count beyond the hint is served by workgroups that loop (k_onesweep STAY == 2, k_ranges, the counted clear), so every count the buffers hold
+// learnt from earlier counts): a count beyond the hint is served by workgroups that loop (k_onesweep STAY == 2, the counted clear), so every count the buffers hold
 // is rendered exactly, at no cost when the hint was right.  Only a view that needs more than pair_capacity is lost: C3D_ST_OVERFLOW, and NaN planes.
 static int forward_tail_nosync(const c3d_gs_settings* st, const GsParams& p, GsGeom& g, int N, int64_t pair_capacity, int64_t first_capacity, void* binning_buffer, void* image_buffer,
                                float* out_color, float* out_depth, float* out_alpha, uint32_t* status, uint32_t* status_host, uint32_t* count_host, hipStream_t s) {
