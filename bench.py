@@ -68,6 +68,8 @@ def parse():
     ap.add_argument("--lanes", type=int, default=0, help="view GROUPS a fused call splits its views into (ceil(views / lanes) views per launch of every stage, the groups one after the "
                                                        "other on the same stream; the library owns no streams); 0 = 1: all views of the step through every stage in ONE launch each, in every mode")
     ap.add_argument("--group", type=int, default=16, help="--mode fwd: views per launch of every stage (<= 16)")
+    ap.add_argument("--streams", type=int, default=4, help="--mode fwd (render path step): HIP streams the views of a call are spread over, one library call per stream (FusedViewRender: one part's "
+                                                          "binning chain runs underneath another part's compositing); 1 = one call on one stream")
     ap.add_argument("--sync-free", choices=["on", "verified", "unverified", "off"], default="on",
                     help="--render-path boundary | fused | accessor: how the drop-in rasterizer call learns its pair count (diff_gaussian_rasterization.sync_free).  on = verified (product "
                          "default): the whole forward enqueued at once, the host waits for the count word only and renders a view that did not fit again -- always exact; unverified: no "
@@ -577,7 +579,7 @@ def main():
     view_render = None
     if a.render_path == "step" and a.mode == "fwd":
         from c3d_hip.gs_step import FusedViewRender
-        view_render = FusedViewRender(N, H, W, dev, lanes=a.lanes, group=a.group)     # all views of the step in one library call
+        view_render = FusedViewRender(N, H, W, dev, lanes=a.lanes, group=a.group, streams=a.streams)     # all views of the step in one call (one library call per stream)
 
     def step(collect=False):
         nonlocal fused_step, view_render
@@ -676,7 +678,8 @@ def main():
     # Inside the timed region only the dominant kernel is timed (two event records per timed launch; timing all ~20 launches of a view costs
     # the multi-stream schedule ~2.5 %, profiles/README.md); the full per-kernel table comes from the separate pass below.
     multi = fused_step if fused_step is not None else view_render
-    only_dom = ["gs_composite_fwd" if a.mode == "fwd" else "gs_composite_bwd"] if (multi is not None and multi.lanes > 1) else None
+    concurrent_groups = multi is not None and (multi.lanes > 1 or (getattr(multi, "streams", 1) > 1 and multi._plan(a.views_per_gpu)[0] > 1))
+    only_dom = ["gs_composite_fwd" if a.mode == "fwd" else "gs_composite_bwd"] if concurrent_groups else None
     c3d_hip.prof_enable(a.timed_prof == "on", only=only_dom)
     ms0 = torch.cuda.memory_stats(dev)
     t0 = time.perf_counter()
@@ -696,7 +699,7 @@ def main():
     # kernels); the concurrent durations of the timed region are reported next to it as "kernels_concurrent".
     prof_conc = None
     prof_views = a.steps * a.views_per_gpu          # views the `prof` table covers
-    if multi is not None and multi.lanes > 1:
+    if concurrent_groups:
         prof_conc = {k: v for k, v in prof.items() if v[1]}
         if fused_step is not None:
             keep_obj, fused_step = fused_step, FusedViewStep(N, H, W, dev, lanes=1, pair_capacity=fused_step.capacity, views=len(settings))
@@ -839,7 +842,7 @@ def main():
         except Exception:
             pass
         if prof_conc is not None:
-            roof["measured"] = "single-group pass after the timed region (kernels run alone); the timed region had %d view groups in flight" % a.lanes
+            roof["measured"] = "single-stream pass after the timed region (kernels run alone); the timed region had %d groups of views in flight" % max(a.lanes, multi._plan(a.views_per_gpu)[0] if hasattr(multi, "_plan") else 1)
             if prof_conc and dom in prof_conc:
                 roof["avg_ms_concurrent"] = round(prof_conc[dom][0] / prof_conc[dom][1], 4)
     # whole-chain figure: SURVEY 8(d)'s algorithmic bytes of a VIEW over the wall time a view takes in the timed
@@ -899,7 +902,7 @@ def main():
                 st = S.camera_settings(W, H, 49.1, e_, az_, r_, bg=(1.0, 1.0, 1.0), sh_degree=deg)
                 all_settings.append(dgr.GaussianRasterizationSettings(H, W, st["tanfovx"], st["tanfovy"], t(st["bg"]), 1.0, t(st["viewmatrix"]).reshape(4, 4),
                                                                       t(st["projmatrix"]).reshape(4, 4), deg, t(st["campos"]), False, False))
-            vr = FusedViewRender(N, H, W, dev, lanes=1, group=16)
+            vr = FusedViewRender(N, H, W, dev, lanes=1, group=16, streams=a.streams)
             pl_ = [q.detach() for q in plist]
             with torch.no_grad():
                 vr.run(all_settings, pl_); vr.run(all_settings, pl_)          # capacity fit + warm-up
@@ -910,7 +913,7 @@ def main():
                 torch.cuda.synchronize(dev)
                 tf = (time.perf_counter() - t1) / 3
             pv = tf / len(all_settings)
-            targets_out = {"what": "BASELINE config 2 after the timed region: forward only, the 64 orbit cameras in one c3d_gs_render_views_raw call (8 view lanes), 3 passes",
+            targets_out = {"what": "BASELINE config 2 after the timed region: forward only, the 64 orbit cameras in one FusedViewRender.run (%d HIP streams, one c3d_gs_render_views_raw call of 16-view launches each), 3 passes" % vr._plan(len(all_settings))[0],
                        "fwd_Mpx": round(len(all_settings) * P / tf / 1e6, 1), "fwd_ms_per_view": round(pv * 1e3, 4),
                        "fwd_chain_frac": round(b_fwd / pv / 1e9 / HBM_PEAK_GBPS, 4), "fwd_chain_GBps": round(b_fwd / pv / 1e9, 1), "fwd_bytes_per_view": int(b_fwd),
                        "target_frac": 0.6, "north_star": ">= 60 % of MI355X HBM roofline on 1M-Gaussian 1080p forward raster (SURVEY 8d algorithmic bytes B_fwd / wall time per view / 8 TB/s)"}
@@ -965,6 +968,7 @@ def main():
                        "exchange_chunks": (a.exchange_chunks if dist_on and a.mode != "fwd" and a.exchange == "allreduce" and fused_step is not None else 1), "render_path": a.render_path,
                        "loss": (None if a.mode == "fwd" else ("0.8 L1 + 3 MSE(alpha) + 0.2 (1 - MS-SSIM), masked (BASELINE config 3)%s" % (", MS-SSIM by torch ops" if ms_ssim is not None else ", fused HIP")
                                                                 if loss_kind != "l1alpha" and a.render_path == "step" else "0.8 L1 + 3 MSE(alpha)")), "view_lanes": (a.lanes if a.render_path == "step" else 1),
+                       "hip_streams": (view_render._plan(a.views_per_gpu)[0] if view_render is not None else 1),
                        "host_enqueue_ms_per_step": host_ms_timed,
                        "sync_free_drop_in": ({"on": "verified", "off": False}.get(a.sync_free, a.sync_free)) if a.render_path != "step" else None,
                        "forward_only_flag": (a.forward_only == "on") if (a.render_path != "step" and a.mode == "fwd") else None,

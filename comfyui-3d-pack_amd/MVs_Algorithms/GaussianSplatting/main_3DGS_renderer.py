@@ -511,10 +511,11 @@ class GaussianSplattingRenderer:
         K = int(fr.shape[1]) + 1
         return K in (1, 4, 9, 16) and (g.active_sh_degree + 1) ** 2 <= K
 
-    def render_views(self, viewpoint_cameras, bg_colors=None, scaling_modifier=1.0, lanes=1, group=16):
+    def render_views(self, viewpoint_cameras, bg_colors=None, scaling_modifier=1.0, lanes=1, group=16, streams=4):
         """Inference-only batch of render(): all cameras in ONE library call (c3d_gs_render_views_raw; `group` views per launch of every stage, no host
         synchronisation between views).  Same per-view results as render() -- the orbit-renderer loop of the reference's
-        nodes without its per-view launch gaps.  bg_colors: None, one [3] tensor or one per camera.
+        nodes without its per-view launch gaps.  bg_colors: None, one [3] tensor or one per camera.  streams > 1 (default 4; at least 8 views per part): the views in that many parts on HIP streams of their own
+        (c3d_hip.gs_step.FusedViewRender: one part's binning underneath another part's compositing; same bits, `streams` workspaces).
         -> dict(image [V,3,H,W] clamped, depth [V,1,H,W], alpha [V,1,H,W], radii [V,N], visibility_filter [V,N])"""
         from diff_gaussian_rasterization import GaussianRasterizationSettings
         from c3d_hip.gs_step import FusedViewRender
@@ -533,9 +534,9 @@ class GaussianSplattingRenderer:
         settings = [GaussianRasterizationSettings(H, W, math.tan(c.FoVx * 0.5), math.tan(c.FoVy * 0.5), bg, scaling_modifier, c.world_view_transform,
                                                   c.full_proj_transform, g.active_sh_degree, c.camera_center, False, False)
                     for c, bg in zip(viewpoint_cameras, bg_colors)]
-        key = (g._xyz.shape[0], H, W, int(lanes), int(group))
+        key = (g._xyz.shape[0], H, W, int(lanes), int(group), int(streams))
         if getattr(self, "_view_render_key", None) != key:
-            self._view_render, self._view_render_key = FusedViewRender(key[0], H, W, self.device, lanes=lanes, group=group), key
+            self._view_render, self._view_render_key = FusedViewRender(key[0], H, W, self.device, lanes=lanes, group=group, streams=streams), key
         with torch.no_grad():
             color, depth, alpha, radii = self._view_render.run(settings, [g._xyz, g._features_dc, g._features_rest, g._opacity, g._scaling, g._rotation], want_radii=True)
             return {"image": color.clamp_(0, 1), "depth": depth, "alpha": alpha, "radii": radii, "visibility_filter": radii > 0}

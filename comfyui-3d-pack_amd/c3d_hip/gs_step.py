@@ -355,53 +355,110 @@ class FusedViewStep:
 
 
 class FusedViewRender:
-    """Forward only: V views of one cloud per library call (c3d_gs_render_views_raw), `group` views per launch of every stage, `lanes` groups in flight, no host
-    synchronisation between views -- the orbit-rendering loop of the reference's renderer nodes in one call."""
+    """Forward only: V views of one cloud per library call (c3d_gs_render_views_raw), `group` views per launch of every stage, no host synchronisation between views --
+    the orbit-rendering loop of the reference's renderer nodes in one call.
+    streams > 1 (round 6): the views are cut into up to `streams` contiguous parts of >= 8 views, each part one library call on a HIP stream of its own (own workspace),
+    forked from and joined back into the caller's stream.  The binning chain of a part -- launches that are latency or memory bound -- then runs underneath the compositing of
+    another part, which is bound by instruction issue: BASELINE config 2 (64 cameras) 15.15 -> 14.39 ms on one box with four streams, the images bit-identical
+    (profiles/r06/r06t_two_streams_fwd64.txt).  The library itself still owns no stream."""
 
-    def __init__(self, N, H, W, device, pair_capacity=None, lanes=1, group=16):
-        """group: views that go through the chain together (one launch per stage; <= 16); the groups follow each other on the caller's stream and reuse the workspace's
-        `group` forward-only slices.  lanes: kept for callers of earlier rounds (a lower bound on the number of groups a call is cut into)."""
+    MIN_PART = 8       # views per part: narrower launches cost more than further overlap brings (4 parts of 8 views: +35 % on a 10 k-Gaussian 512^2 orbit, +3.5 % at 200 k / 1024^2, +6 % at config 2)
+
+    def __init__(self, N, H, W, device, pair_capacity=None, lanes=1, group=16, streams=1):
+        """group: views that go through the chain together (one launch per stage; <= 16); the groups follow each other on their stream and reuse the workspace's
+        `group` forward-only slices.  lanes: kept for callers of earlier rounds (a lower bound on the number of groups a call is cut into).  streams: see the class."""
         self.N, self.H, self.W, self.device = N, H, W, torch.device(device)
         self.lanes = max(1, min(8, int(lanes)))
         self.group = max(1, min(16, int(group)))
+        self.streams = max(1, min(8, int(streams)))
         self.slices = self.group
         self.capacity = int(pair_capacity or max(8 * N, 1 << 22))
         self.status = torch.zeros(2, dtype=torch.int32, device=self.device)
         self._fitted = False
-        self._alloc()
+        self._parts, self._side = [], []
+        self.workspace = None
+        if self.streams == 1:
+            self._alloc()
 
     def _alloc(self):
-        nbytes = _h.lib().c3d_gs_render_workspace_bytes(self.N, self.H, self.W, self.capacity, self.slices)     # one or two sets of `group` forward-only slices: see c3d_gs_render_views_raw
+        nbytes = _h.lib().c3d_gs_render_workspace_bytes(self.N, self.H, self.W, self.capacity, self.slices)     # `group` forward-only slices: see c3d_gs_render_views_raw
         self.workspace = torch.empty((nbytes,), dtype=torch.uint8, device=self.device)
+
+    def _enqueue(self, raster_settings, params, color, depth, alpha, radii, keep):
+        """one library call for these views on the CURRENT stream; nothing is waited for.  keep: list that holds what the call's arguments point at"""
+        V = len(raster_settings)
+        arr = lambda t: (C.c_void_p * V)(*[t[i].data_ptr() for i in range(V)])
+        views = FusedViewStep._settings(raster_settings, keep, params)
+        keep.append(views)
+        self.status.zero_()
+        with torch.cuda.device(self.device):
+            _h.check(_h.lib().c3d_gs_render_views_raw(views, V, self.N, *[_h.ptr(_h.f32c(p)) for p in params], arr(color), arr(depth), arr(alpha),
+                                                      arr(radii) if radii is not None else None, self.capacity, self.lanes, _h.ptr(self.workspace), self.workspace.numel(),
+                                                      _h.ptr(self.status), _h.stream(self.device)), "c3d_gs_render_views_raw")
+
+    def _plan(self, V):
+        """-> (number of parts, views per part)"""
+        S = max(1, min(self.streams, V // self.MIN_PART))
+        return S, (V + S - 1) // S
+
+    def _make_parts(self, S, per):
+        g = min(self.group, per)
+        if len(self._parts) != S or any(p.group != g or p.capacity != self.capacity for p in self._parts):
+            self._parts = []      # (frees the old workspaces first)
+            self._parts = [FusedViewRender(self.N, self.H, self.W, self.device, pair_capacity=self.capacity, lanes=self.lanes, group=g) for _ in range(S)]
+        while len(self._side) < S:
+            self._side.append(torch.cuda.Stream(self.device))
 
     def run(self, raster_settings, params, want_radii=False, max_retries=3):
         """params: (xyz, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw) -> color [V,3,H,W], depth [V,1,H,W], alpha [V,1,H,W], radii [V,N] | None"""
-        lib = _h.lib()
         V = len(raster_settings)
         f32 = dict(dtype=torch.float32, device=self.device)
         color, depth, alpha = torch.empty((V, 3, self.H, self.W), **f32), torch.empty((V, 1, self.H, self.W), **f32), torch.empty((V, 1, self.H, self.W), **f32)
         radii = torch.empty((V, self.N), dtype=torch.int32, device=self.device) if want_radii else None
         if V == 0:
             return color, depth, alpha, radii
-        arr = lambda t: (C.c_void_p * V)(*[t[i].data_ptr() for i in range(V)])
+        S, per = self._plan(V)
         for attempt in range(max_retries + 1):
             keep = []
-            views = FusedViewStep._settings(raster_settings, keep, params)
-            self.status.zero_()
-            with torch.cuda.device(self.device):
-                _h.check(lib.c3d_gs_render_views_raw(views, V, self.N, *[_h.ptr(_h.f32c(p)) for p in params], arr(color), arr(depth), arr(alpha),
-                                                     arr(radii) if want_radii else None, self.capacity, self.lanes, _h.ptr(self.workspace), self.workspace.numel(), _h.ptr(self.status),
-                                                     _h.stream(self.device)), "c3d_gs_render_views_raw")
-            st = self.status.tolist()       # the single host sync of the call
+            if S == 1:
+                if self.workspace is None:
+                    self._alloc()
+                self._enqueue(raster_settings, params, color, depth, alpha, radii, keep)
+                st = self.status.tolist()       # the single host sync of the call
+            else:
+                self._make_parts(S, per)
+                cur, ran = torch.cuda.current_stream(self.device), []
+                for h, part in enumerate(self._parts):      # fork: every part on its own stream, behind what the caller's stream holds so far
+                    v0, v1 = h * per, min(V, (h + 1) * per)
+                    if v0 >= v1:
+                        continue
+                    ran.append(part)
+                    side = self._side[h]
+                    side.wait_stream(cur)
+                    with torch.cuda.stream(side):
+                        part._enqueue(raster_settings[v0:v1], params, color[v0:v1], depth[v0:v1], alpha[v0:v1], radii[v0:v1] if radii is not None else None, keep)
+                for h in range(S):                           # join: the caller's stream carries on when all parts are done (outputs, parameters and workspaces are safe to reuse)
+                    cur.wait_stream(self._side[h])
+                sts = torch.stack([part.status for part in ran]).tolist()       # the single host sync of the call
+                st = [0, 0]
+                for w in sts:
+                    st = [st[0] | w[0], max(st[1], w[1] & 0xFFFFFFFF)]
             if st[0] & 2:
                 raise RuntimeError("c3d: a bounded inter-workgroup wait of the binning stage timed out (status %r): device fault" % (st,))
             seen = st[1] & 0xFFFFFFFF
             if st[0] == 0:
                 if not self._fitted and self.capacity > 1.6 * max(seen, 1 << 16):      # (every launch of the binning chain is sized for the capacity: more than 1.6 x the need is worth one reallocation)
                     self.capacity = int(seen * 1.3) + 4096
-                    self._alloc()
+                    self._realloc()
                 self._fitted = True
                 return color, depth, alpha, radii
             self.capacity = int(max(seen, self.capacity) * 1.25) + 1024
-            self._alloc()
+            self._realloc()
         raise RuntimeError("c3d FusedViewRender: pair capacity still exceeded after %d retries" % max_retries)
+
+    def _realloc(self):
+        """the buffers again at self.capacity (the parts are rebuilt by the next multi-stream run)"""
+        self._parts = []
+        self.workspace = None
+        if self.streams == 1:
+            self._alloc()

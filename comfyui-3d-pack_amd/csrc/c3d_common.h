@@ -92,7 +92,7 @@ int c3d_sort_set_debug(unsigned long long* stamps);   // profiling hook (nullptr
 int c3d_sort_pairs_u32(uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32_t* vals1, bool iota_vals,
                        size_t n, int end_bit, void* tmp, int* result_buf, hipStream_t s, const uint32_t* n_dev = nullptr, bool zero_state = true, uint32_t* err = nullptr,
                        int V = 1, size_t vs = 0, bool hist_done = false, size_t n_hint = 0,      // n_hint (one view, n_dev given): size the launches for n_hint < n elements; a larger count loops
-                       uint2* ranges = nullptr);      // ranges (per view, cleared): the last pass leaves {~first position, last position + 1} of every key value there (atomicMax; {0, 0} = no such key)
+                       uint2* ranges = nullptr);      // ranges (per view, cleared): the last pass leaves {~first position, last position + 1} of every key value there (atomicMax; {0, 0} = no such key) -- and writes NO sorted keys, only the values
 
 // ---- device helpers ----
 #ifdef __HIPCC__

@@ -335,22 +335,46 @@ __global__ void __launch_bounds__(64) k_sum_views_loss(const float* __restrict__
 // both stages in one launch when all views of the step went through ONE group (the usual case): the same per-view pattern, the views one after the other, the same bits
 __global__ void __launch_bounds__(1024) k_sum_group_loss(const float* __restrict__ t0, int n, size_t vs, int V, float* __restrict__ loss_out,
                                                          const uint32_t* __restrict__ status, unsigned long long* __restrict__ status_host) {
-    __shared__ float red[16];
-    float acc = 0.f;
-    for (int v = 0; v < V; v++) {
-        const float* t = (const float*)((const char*)t0 + (size_t)v * vs);
-        float l = 0.f;
-        for (int i = threadIdx.x; i < n; i += 1024) l += t[i];
-        l = c3d_wave_sum(l);
-        __syncthreads();
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = l;
-        __syncthreads();
-        if (threadIdx.x == 0) { float q = 0.f; for (int w = 0; w < 16; w++) q += red[w]; acc += q; }
+    // The launch is ONE workgroup on the step's critical path: the views' terms are requested together (four strides of every view in flight per lane) -- view after view
+    // with a barrier pair each, the dependent round trips were 34 us of the 8-view step (profiles/r06z_fwdbwd_kernel_stats.csv).  The additions are those of the loop
+    // `for v: for i: l += t_v[i]` in the same order (a term past the end adds +0 to a sum that is never -0).
+    __shared__ float red[GS_MAX_BWD_VIEWS][16];
+    float l[GS_MAX_BWD_VIEWS];
+#pragma unroll
+    for (int v = 0; v < GS_MAX_BWD_VIEWS; v++) l[v] = 0.f;
+    for (int i0 = threadIdx.x; i0 < n; i0 += 4 * 1024) {
+        float x[4][GS_MAX_BWD_VIEWS];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = i0 + u * 1024;
+#pragma unroll
+            for (int v = 0; v < GS_MAX_BWD_VIEWS; v++)
+                x[u][v] = (v < V && i < n) ? ((const float*)((const char*)t0 + (size_t)v * vs))[i] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+#pragma unroll
+            for (int v = 0; v < GS_MAX_BWD_VIEWS; v++) l[v] += x[u][v];
+        }
     }
-    if (threadIdx.x == 0) { loss_out[0] += acc; gs_status_to_host(status, status_host); }
+#pragma unroll
+    for (int v = 0; v < GS_MAX_BWD_VIEWS; v++) {
+        if (v < V) {      // (uniform)
+            const float s = c3d_wave_sum(l[v]);
+            if ((threadIdx.x & 63) == 0) red[v][threadIdx.x >> 6] = s;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float acc = 0.f;
+        for (int v = 0; v < V; v++) { float q = 0.f; for (int w = 0; w < 16; w++) q += red[v][w]; acc += q; }
+        loss_out[0] += acc;
+        gs_status_to_host(status, status_host);
+    }
 }
 int gs_launch_sum_group_loss(const float* terms, int n, int V, size_t vs, float* loss_out, hipStream_t s, const uint32_t* status, unsigned long long* status_host) {
     if (n <= 0 || V <= 0 || !loss_out) return 0;
+    if (V > GS_MAX_BWD_VIEWS) { c3d_set_error("gs_launch_sum_group_loss: %d views in one group (at most %d)", V, GS_MAX_BWD_VIEWS); return -1; }
     hipLaunchKernelGGL(k_sum_group_loss, dim3(1), dim3(1024), 0, s, terms, n, vs, V, loss_out, status, status_host);
     C3D_LAUNCH_CHECK();
     return 0;

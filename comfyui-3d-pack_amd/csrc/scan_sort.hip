@@ -316,6 +316,9 @@ uint32_t* c3d_scan_error_word(void* tmp) { return (uint32_t*)tmp + 1; }
                               // memory-side atomic unit (measured: 23 us for 1 M keys, profiles/r02c); consumers add the 16 copies up
 __host__ __device__ static inline size_t sort_pass_words(size_t nb) { return RS_RADIX * (nb + nb / RS_GROUP + 1); }
 
+// (Round 6, measured and dropped, profiles/r06/r06s_*: a workgroup counting 2-8 consecutive tiles before it adds its counters to the global copies -- a quarter of the memory-side
+//  atomics -- made the depth sort of the 8-view step 0.198 -> 0.209 ms; what is kept of it is that a tile's 16 keys per lane are all requested before the first is counted:
+//  one-view sort 0.0907 -> 0.0876 ms.)
 __global__ void __launch_bounds__(RS_THREADS) k_radix_hist_all(const uint32_t* __restrict__ keys, uint32_t* __restrict__ ghist, size_t n,
                                                                 const uint32_t* __restrict__ n_dev, int passes, size_t vs) {
     __shared__ uint32_t h[RS_MAX_PASSES][RS_RADIX];
@@ -325,13 +328,18 @@ __global__ void __launch_bounds__(RS_THREADS) k_radix_hist_all(const uint32_t* _
     const size_t base = (size_t)htile * RS_TILE;
     if (base >= n) return;                      // capacity-sized launch: nothing here
     for (int p = 0; p < passes; p++) h[p][threadIdx.x] = 0;
-    __syncthreads();
     const int lane = c3d_lane();
-#pragma unroll 4
+    uint32_t key[RS_ITEMS];
+#pragma unroll
     for (int i = 0; i < RS_ITEMS; i++) {
         const size_t idx = base + (size_t)i * RS_THREADS + threadIdx.x;
-        const bool ok = idx < n;
-        const uint32_t k = ok ? keys[idx] : 0u;
+        key[i] = idx < n ? keys[idx] : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS; i++) {
+        const bool ok = base + (size_t)i * RS_THREADS + threadIdx.x < n;
+        const uint32_t k = key[i];
         const uint64_t okm = __ballot(ok);
         for (int p = 0; p < passes; p++) {
             const uint32_t d = (k >> (8 * p)) & (RS_RADIX - 1);
@@ -586,7 +594,7 @@ __global__ void __launch_bounds__(RS_THREADS, 4) k_onesweep(const uint32_t* __re
             const uint32_t k = skey[lp], v = sval[lp];
             const uint32_t dd = (k >> shift) & (RS_RADIX - 1);
             const uint32_t pos = gbase[dd] + ((uint32_t)lp - lstart[dd]);
-            keys_out[pos] = k;
+            if (!RANGES) keys_out[pos] = k;      // the ranges are what the sorted keys were read for: the last pass of a tile sort leaves no keys (4 of its 16 bytes per pair)
             vals_out[pos] = v;
             if (RANGES) {      // a slot whose predecessor holds another key starts its key's stretch here -- and ends the predecessor's: both words from the one compare
                 const uint32_t kp = lp ? skey[lp - 1u] : ~k;

@@ -569,11 +569,10 @@ def test_recorded_pair_activity_loses_nothing():
     D = int(dgr.last_num_rendered)
     node = _rasterize_node(color)
     binning, img = node.saved_tensors[-2], node.saved_tensors[-1]
-    # binning buffer (gs_carve_binning): tkey[0] | tkey[1] | tval[0] | tval[1] | ...; the sorted keys ended in one key buffer, the four planes live in the other
+    # binning buffer (gs_carve_binning): tkey[0] | tkey[1] | tval[0] | tval[1] | ranges ...; the four planes live in the key buffer the sort's last pass did NOT read
+    # (that pass writes no keys: the per-tile ranges are all that is left of them) -- 800 x 450 is 50 x 29 tiles, two passes, result index 0
     d_al = (4 * D + 255) // 256 * 256
-    keys = [binning.data[i * d_al:i * d_al + 4 * D].view(torch.int32) for i in range(2)]
-    res = 0 if bool((keys[0][1:] >= keys[0][:-1]).all()) else 1
-    assert bool((keys[res][1:] >= keys[res][:-1]).all())
+    res = 0
     stride = d_al // 4
     dead = binning.data[(1 - res) * d_al:(2 - res) * d_al]      # .data: the in-place overwrite below must not trip autograd's version check of the saved buffer
     planes = [dead[w * stride:w * stride + D] for w in range(4)]
@@ -592,7 +591,12 @@ def test_recorded_pair_activity_loses_nothing():
     pad[:H, :W] = ncon
     upto = pad.reshape(gy, 2, 8, gx, 2, 8).permute(0, 3, 1, 4, 2, 5).reshape(gy * gx, 4, 64).max(dim=2).values      # [tile, quadrant]
     ranges = binning.data[4 * d_al:4 * d_al + 8 * gx * gy].view(torch.int32).reshape(gx * gy, 2)
-    tile_of = keys[res].long()
+    starts, ends = (~ranges[:, 0]).long(), ranges[:, 1].long()
+    nonempty = ends > 0      # {0, 0} in the stored words = no pair of that tile
+    counts = torch.where(nonempty, ends - starts, torch.zeros_like(ends))
+    assert int(counts.sum()) == D
+    tile_of = torch.repeat_interleave(torch.arange(gx * gy, device="cuda"), counts)      # the sorted list is tile after tile
+    assert bool((torch.arange(D, device="cuda") >= starts[tile_of]).all()) and bool((torch.arange(D, device="cuda") < ends[tile_of]).all())
     posn = torch.arange(D, device="cuda") - (~ranges[tile_of, 0]).long()      # the stored words are {~start, end} (gs_tile_range, csrc/gs_internal.h)
     valid = torch.stack([posn < upto[tile_of, w].long() for w in range(4)])
     bits = torch.stack([(before[w] & 1).bool() for w in range(4)]) & valid
@@ -1607,4 +1611,48 @@ def test_trainer_longer_run_with_densification(lambda_ssim):
     assert len(set(ns)) >= 3 and ns[-1] != 100000
     g = tr.renderer.gaussians
     for t in (g._xyz, g._features_dc, g._features_rest, g._opacity, g._scaling, g._rotation):
-        assert torch.isfinite(t).all() and t.shape[0] == ns[-1]
+        assert torch.isfinite(t).all() and t.shape[0] == ns[-1]@pytest.mark.gpu
+@pytest.mark.parametrize("streams,V", [(4, 33), (2, 19), (8, 7)])
+def test_render_views_on_several_streams_equals_the_one_stream_call(streams, V):
+    """FusedViewRender(streams=S): the views in S contiguous parts (>= 8 views each), one library call per part on a HIP stream of its own, forked from and joined into the
+    caller's stream -- bit for bit the one-stream call, radii included, through the first call's capacity fit and through a forced overflow (all parts regrow and go again)."""
+    from c3d_hip.gs_step import FusedViewRender
+    import diff_gaussian_rasterization as dgr
+    raw = S.make_cloud(40000, seed=11, log_scale_mean=np.log(0.02), activated=False)
+    W, H = 320, 200
+    t = lambda x: torch.as_tensor(np.asarray(x, dtype=np.float32)).cuda()
+    sh = t(raw["shs"])
+    params = [t(raw["means3D"]), sh[:, :1].contiguous(), sh[:, 1:].contiguous(), t(raw["opacities"]), t(raw["scales"]), t(raw["rotations"])]
+    rs = []
+    for i in range(V):
+        st = S.camera_settings(W, H, 49.1, -30.0 + 7.0 * i, 20.0 * i, 2.0 + 0.05 * i, bg=(0.1 * (i % 5), 0.3, 0.8), sh_degree=3)
+        rs.append(dgr.GaussianRasterizationSettings(H, W, st["tanfovx"], st["tanfovy"], t(st["bg"]), 1.0, t(st["viewmatrix"]).reshape(4, 4), t(st["projmatrix"]).reshape(4, 4), 3,
+                                                    t(st["campos"]), False, False))
+    one = FusedViewRender(40000, H, W, "cuda", group=4)
+    many = FusedViewRender(40000, H, W, "cuda", group=4, streams=streams)
+    S_, per = many._plan(V)
+    assert S_ == max(1, min(streams, V // 8)) and per * S_ >= V
+    with torch.no_grad():
+        ref = one.run(rs, params, want_radii=True)
+        for attempt in range(2):      # the first call fits the capacity (and rebuilds the parts), the second runs on the fitted buffers
+            out = many.run(rs, params, want_radii=True)
+            for a, b in zip(out, ref):
+                assert torch.equal(a, b)
+        assert many._fitted and (S_ == 1 or len(many._parts) == S_)
+        need = many.capacity
+        many.capacity = need // 4      # too small: every part reports the overflow, the call regrows all of them and renders again
+        many._realloc()
+        out = many.run(rs, params, want_radii=True)
+        for a, b in zip(out, ref):
+            assert torch.equal(a, b)
+        assert many.capacity > need // 4
+        # work queued on the caller's stream before and after the call is ordered with it
+        x = torch.zeros(8, device="cuda")
+        p2 = [q.clone() for q in params]
+        p2[0].mul_(1.0)      # (a write the parts must wait for)
+        out2 = many.run(rs, p2, want_radii=False)
+        y = out2[0].sum() + x.sum()
+        assert torch.isfinite(y) and torch.equal(out2[0], ref[0])
+
+
+
