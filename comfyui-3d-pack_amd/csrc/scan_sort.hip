@@ -318,7 +318,8 @@ __host__ __device__ static inline size_t sort_pass_words(size_t nb) { return RS_
 
 // (Round 6, measured and dropped, profiles/r06/r06s_*: a workgroup counting 2-8 consecutive tiles before it adds its counters to the global copies -- a quarter of the memory-side
 //  atomics -- made the depth sort of the 8-view step 0.198 -> 0.209 ms; what is kept of it is that a tile's 16 keys per lane are all requested before the first is counted:
-//  one-view sort 0.0907 -> 0.0876 ms.)
+//  one-view sort 0.0907 -> 0.0876 ms.  Also dropped, r06v_*: counting the upper digits -- two or three values per view -- by ballot instead of 64 lanes adding to two LDS counters:
+//  0.202 -> 0.210 ms per 8 views; the LDS atomics are not what the kernel waits for either.)
 __global__ void __launch_bounds__(RS_THREADS) k_radix_hist_all(const uint32_t* __restrict__ keys, uint32_t* __restrict__ ghist, size_t n,
                                                                 const uint32_t* __restrict__ n_dev, int passes, size_t vs) {
     __shared__ uint32_t h[RS_MAX_PASSES][RS_RADIX];
@@ -651,6 +652,26 @@ __global__ void __launch_bounds__(SS_THREADS) k_sort_small(const uint32_t* __res
         key[i] = ok ? keys_in[idx] : 0xFFFFFFFFu;
         val[i] = idx;
     }
+    // The digits are taken from key - (smallest key) -- the same order, ties included -- with the keys 0xFFFFFFFF (culled Gaussians; elements past the end) mapped to the value behind
+    // the largest other key: depth keys of one view span a factor < 4 in depth, 24 bits of the float pattern, so the fourth pass has nothing to move and is not run (a uniform
+    // trip count: everything lives in this workgroup).  The keys that are written are the original ones.
+    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+#pragma unroll
+    for (int i = 0; i < SS_ITEMS; i++)
+        if (key[i] != 0xFFFFFFFFu) { kmin = min(kmin, key[i]); kmax = max(kmax, key[i]); }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, o, 64)); kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, o, 64)); }
+    if (lane == 0) { whist[0][wave] = kmin; whist[1][wave] = kmax; }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < SS_THREADS / 64; w++) { kmin = min(kmin, whist[0][w]); kmax = max(kmax, whist[1][w]); }
+    __syncthreads();                                     // whist is cleared by the first pass
+    const uint32_t top = kmin <= kmax ? (kmax - kmin) + 1u : 0u;      // what a culled key maps to (no other key at all: everything maps to 0)
+    if (kmin > kmax) kmin = 0xFFFFFFFFu;
+    {
+        const int bits = 32 - __builtin_clz(top | 1u);
+        passes = min(passes, max(1, (bits + 7) >> 3));
+    }
     for (int pass = 0; pass < passes; pass++) {
         const int shift = 8 * pass;
         for (int i = threadIdx.x; i < (SS_THREADS / 64) * RS_RADIX; i += SS_THREADS) (&whist[0][0])[i] = 0;
@@ -660,7 +681,7 @@ __global__ void __launch_bounds__(SS_THREADS) k_sort_small(const uint32_t* __res
             if (i < R) {      // (uniform)
                 const bool ok = woff + (uint32_t)i * 64u < n;      // elements past the end take no part: n elements are ranked, n positions are filled
                 const uint64_t okm = __ballot(ok);
-                const uint32_t ds = key[i] >> shift;
+                const uint32_t ds = (key[i] == 0xFFFFFFFFu ? top : key[i] - kmin) >> shift;
                 uint32_t plo = (uint32_t)okm, phi = (uint32_t)(okm >> 32);
 #pragma unroll
                 for (int b = 0; b < 8; b++) {
@@ -696,7 +717,7 @@ __global__ void __launch_bounds__(SS_THREADS) k_sort_small(const uint32_t* __res
 #pragma unroll
         for (int i = 0; i < SS_ITEMS; i++) {
             if (i < R && woff + (uint32_t)i * 64u < n) {
-                const uint32_t pos = whist[wave][(key[i] >> shift) & (RS_RADIX - 1)] + rank[i];
+                const uint32_t pos = whist[wave][((key[i] == 0xFFFFFFFFu ? top : key[i] - kmin) >> shift) & (RS_RADIX - 1)] + rank[i];
                 skey[pos] = key[i];
                 sval[pos] = val[i];
             }

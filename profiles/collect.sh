@@ -30,7 +30,8 @@ rm -rf /tmp/kt /tmp/km /tmp/ktt
 timeout 240 rocprofv3 --kernel-trace -d /tmp/kt -o kt -- python $R/bench.py --steps 3 --warmup 1 --cpu-baseline off --targets off < /dev/null > /tmp/kt.log 2>&1
 python $R/profiles/summarize_rocpd.py $(find /tmp/kt -name "*.db" | head -1) > $OUT/${TAG}_fwdbwd_kernel_stats.csv
 rm -rf /tmp/kf
-timeout 240 rocprofv3 --kernel-trace -d /tmp/kf -o kf -- python $R/bench.py --mode fwd --views-per-gpu 64 --steps 3 --warmup 1 --cpu-baseline off --targets off < /dev/null > /tmp/kf.log 2>&1
+# (--streams 1: the kernels of the table run alone; the bench line of config 2 below runs the product default, four HIP streams)
+timeout 240 rocprofv3 --kernel-trace -d /tmp/kf -o kf -- python $R/bench.py --mode fwd --views-per-gpu 64 --streams 1 --steps 3 --warmup 1 --cpu-baseline off --targets off < /dev/null > /tmp/kf.log 2>&1
 python $R/profiles/summarize_rocpd.py $(find /tmp/kf -name "*.db" | head -1) > $OUT/${TAG}_fwd64_kernel_stats.csv
 timeout 240 rocprofv3 --kernel-trace -d /tmp/ktt -o ktt -- python $R/bench.py --mode train --steps 3 --warmup 1 --cpu-baseline off < /dev/null > /tmp/ktt.log 2>&1
 python $R/profiles/summarize_rocpd.py $(find /tmp/ktt -name "*.db" | head -1) > $OUT/${TAG}_train_kernel_stats.csv
@@ -41,6 +42,7 @@ cd $R
 timeout 400 python bench.py --steps 20 --warmup 5 < /dev/null 2>/dev/null | tail -1 > $OUT/${TAG}_bench_n1.json
 timeout 300 python bench.py --mode fwd --steps 20 --warmup 5 --cpu-baseline off --targets off < /dev/null 2>/dev/null | tail -1 > $OUT/${TAG}_bench_fwd_n1.json
 timeout 300 python bench.py --mode fwd --views-per-gpu 64 --steps 20 --warmup 3 --cpu-baseline off --targets off < /dev/null 2>/dev/null | tail -1 > $OUT/${TAG}_bench_fwd64_n1.json
+timeout 300 python bench.py --mode fwd --views-per-gpu 64 --streams 1 --steps 20 --warmup 3 --cpu-baseline off --targets off < /dev/null 2>/dev/null | tail -1 > $OUT/${TAG}_bench_fwd64_one_stream_n1.json
 timeout 300 python bench.py --mode train --steps 20 --warmup 5 --cpu-baseline off --targets off < /dev/null 2>/dev/null | tail -1 > $OUT/${TAG}_bench_train_n1.json
 timeout 400 python bench.py --workload mesh --steps 40 --warmup 5 < /dev/null 2>/dev/null | tail -1 > $OUT/${TAG}_bench_mesh_n1.json
 timeout 300 python bench.py --workload mesh --render-path fused --steps 20 --warmup 5 --cpu-baseline off < /dev/null 2>/dev/null | tail -1 > $OUT/${TAG}_bench_mesh_view_api_n1.json

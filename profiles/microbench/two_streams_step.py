@@ -18,6 +18,7 @@ from c3d_hip.parallel import FlatGrads  # noqa: E402
 import diff_gaussian_rasterization as dgr  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+SSIM = float(os.environ.get("C3D_EXP_SSIM", "0"))      # round 6: 0.2 = BASELINE config 3's loss (masked, + 0.2 (1 - MS-SSIM)) in the upper block; the joined block is skipped then
 dev = torch.device("cuda", 0)
 N, W, H, deg, V = 1_000_000, 1920, 1080, 3, 8
 raw = S.make_cloud(N, seed=1234, sh_degree=deg, activated=False)
@@ -56,7 +57,7 @@ def variant(parts, concurrent):
             e.record(main)
         for o, f, s, (a, b) in zip(objs, flats, streams, ranges):
             def go():
-                o.run(settings[a:b], plist, f.views, tc[a:b], ta[a:b], None, w_l1=0.8, w_alpha_mse=3.0, scale=1.0 / V, accumulate=False)
+                o.run(settings[a:b], plist, f.views, tc[a:b], ta[a:b], (ta[a:b] if SSIM else None), w_l1=0.8, w_alpha_mse=3.0, scale=1.0 / V, accumulate=False, w_ssim=SSIM)
             if s is None:
                 go()
             else:
@@ -90,6 +91,10 @@ for rep in range(2):
                               ("2+2+2+2 views, four streams", [2, 2, 2, 2], True), ("5 + 3 views, two streams", [5, 3], True)):
         ms = variant(parts, conc)
         print("%-32s %.3f ms per step  %.0f Mpx/s" % (name, ms, V * W * H / ms / 1e3), flush=True)
+
+
+if SSIM:
+    sys.exit(0)
 
 
 def joined(parts, concurrent=True, steps_=None):

@@ -255,7 +255,7 @@ def test_drop_in_raw_entry_point_sync_free_matches_the_float64_oracle_on_eight_c
 
 def test_render_views_raw_matches_oracle_forward_on_all_64_orbit_cameras(oracle_built):
     """BASELINE config 2 IS the 64 orbit cameras; the fixture above holds eight of them forward and backward.  Here all 64 go through
-    c3d_gs_render_views_raw (groups of 16, as bench.py's forward target runs them) and every image, alpha, depth and radius is held to one float64 pass of the oracle
+    c3d_gs_render_views_raw (groups of 16 on four HIP streams, as bench.py's forward target runs them) and every image, alpha, depth and radius is held to one float64 pass of the oracle
     (forward only: ~1.5 s per camera on the box's host cores)."""
     if not torch.cuda.is_available():
         pytest.fail("-m gpu tests need a HIP device (no CPU fallback exists)")
@@ -268,10 +268,16 @@ def test_render_views_raw_matches_oracle_forward_on_all_64_orbit_cameras(oracle_
     poses = S.orbit_poses_64()
     assert len(poses) == 64
     sts = [S.camera_settings(W, H, 49.1, e, az, r, bg=(1, 1, 1)) for (r, e, az) in poses]
-    ren = FusedViewRender(N, H, W, "cuda", lanes=1, group=16)
-    color, depth, alpha, radii = ren.run([hip_settings(st, "cuda") for st in sts], plist, want_radii=True)
-    color, depth, alpha, radii = color.cpu().numpy(), depth.cpu().numpy(), alpha.cpu().numpy(), radii.cpu().numpy()
+    ren = FusedViewRender(N, H, W, "cuda", lanes=1, group=16, streams=4)      # as bench.py's forward target and render_views run them: four parts of 16 views on four HIP streams
+    rs = [hip_settings(st, "cuda") for st in sts]
+    color, depth, alpha, radii = ren.run(rs, plist, want_radii=True)
+    assert len(ren._parts) == 4
     del ren
+    one = FusedViewRender(N, H, W, "cuda", lanes=1, group=16)                 # ... and the same bits as the one-stream call
+    for a_, b_ in zip(one.run(rs, plist, want_radii=True), (color, depth, alpha, radii)):
+        assert torch.equal(a_, b_)
+    del one, a_, b_
+    color, depth, alpha, radii = color.cpu().numpy(), depth.cpu().numpy(), alpha.cpu().numpy(), radii.cpu().numpy()
     worst = dict(l1=0.0, a=0.0, d=0.0, mx=0.0, rad=0)
     for v, st in enumerate(sts):
         oc, orad, od, oa, ost = oracle_forward(act, st, dtype=np.float64, nthreads=nt)
