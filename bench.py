@@ -858,7 +858,7 @@ def main():
                  "unit": "GB/s", "frac": round(b_view / per_view_s / 1e9 / HBM_PEAK_GBPS, 4), "target_frac": 0.6 if a.mode == "fwd" else None}
         # the same with the parameter set counted once per LAUNCH that streams it (k_preprocess_views / k_bwd_views_*: once per step, or once per group of
         # `lanes` views forward-only) instead of once per view as the contract formula does: what the memory system is really asked for
-        share = a.views_per_gpu if a.mode != "fwd" else max(1, min(a.lanes, a.views_per_gpu))
+        share = a.views_per_gpu if a.mode != "fwd" else (max(1, min(a.group, view_render._plan(a.views_per_gpu)[1])) if view_render is not None else 1)      # forward-only: once per group of views
         par = N * (44 + 12 * K)
         b_once = b_view - par * (1 if a.mode == "fwd" else 3) * (1.0 - 1.0 / share)
         chain["bytes_per_view_params_once_per_launch"] = int(b_once)

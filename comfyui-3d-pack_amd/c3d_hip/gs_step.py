@@ -449,16 +449,17 @@ class FusedViewRender:
             if st[0] == 0:
                 if not self._fitted and self.capacity > 1.6 * max(seen, 1 << 16):      # (every launch of the binning chain is sized for the capacity: more than 1.6 x the need is worth one reallocation)
                     self.capacity = int(seen * 1.3) + 4096
-                    self._realloc()
+                    self._realloc(S == 1)
                 self._fitted = True
                 return color, depth, alpha, radii
             self.capacity = int(max(seen, self.capacity) * 1.25) + 1024
-            self._realloc()
+            self._realloc(S == 1)
         raise RuntimeError("c3d FusedViewRender: pair capacity still exceeded after %d retries" % max_retries)
 
-    def _realloc(self):
-        """the buffers again at self.capacity (the parts are rebuilt by the next multi-stream run)"""
+    def _realloc(self, single=None):
+        """the buffers again at self.capacity: the one-call workspace at once when that is what the caller uses (single; None: when the object has one stream), the parts'
+        workspaces when the next multi-stream run builds them"""
         self._parts = []
         self.workspace = None
-        if self.streams == 1:
+        if single or (single is None and self.streams == 1):
             self._alloc()

@@ -271,7 +271,7 @@ def test_render_views_raw_matches_oracle_forward_on_all_64_orbit_cameras(oracle_
     ren = FusedViewRender(N, H, W, "cuda", lanes=1, group=16, streams=4)      # as bench.py's forward target and render_views run them: four parts of 16 views on four HIP streams
     rs = [hip_settings(st, "cuda") for st in sts]
     color, depth, alpha, radii = ren.run(rs, plist, want_radii=True)
-    assert len(ren._parts) == 4
+    assert ren._plan(len(rs)) == (4, 16)
     del ren
     one = FusedViewRender(N, H, W, "cuda", lanes=1, group=16)                 # ... and the same bits as the one-stream call
     for a_, b_ in zip(one.run(rs, plist, want_radii=True), (color, depth, alpha, radii)):

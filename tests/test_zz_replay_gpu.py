@@ -241,6 +241,8 @@ def test_the_drivers_eight_rank_command_with_the_all_gather_exchange():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, C3D_BENCH_SHARE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import gc
+    gc.collect(); torch.cuda.empty_cache()      # eight ranks at BASELINE size are about to share this GPU with whatever this process still holds
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "2", "--exchange", "allgather"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
