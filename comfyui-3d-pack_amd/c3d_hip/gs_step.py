@@ -428,17 +428,19 @@ class FusedViewRender:
             else:
                 self._make_parts(S, per)
                 cur, ran = torch.cuda.current_stream(self.device), []
-                for h, part in enumerate(self._parts):      # fork: every part on its own stream, behind what the caller's stream holds so far
-                    v0, v1 = h * per, min(V, (h + 1) * per)
-                    if v0 >= v1:
-                        continue
-                    ran.append(part)
-                    side = self._side[h]
-                    side.wait_stream(cur)
-                    with torch.cuda.stream(side):
-                        part._enqueue(raster_settings[v0:v1], params, color[v0:v1], depth[v0:v1], alpha[v0:v1], radii[v0:v1] if radii is not None else None, keep)
-                for h in range(S):                           # join: the caller's stream carries on when all parts are done (outputs, parameters and workspaces are safe to reuse)
-                    cur.wait_stream(self._side[h])
+                try:
+                    for h, part in enumerate(self._parts):      # fork: every part on its own stream, behind what the caller's stream holds so far
+                        v0, v1 = h * per, min(V, (h + 1) * per)
+                        if v0 >= v1:
+                            continue
+                        ran.append(part)
+                        side = self._side[h]
+                        side.wait_stream(cur)
+                        with torch.cuda.stream(side):
+                            part._enqueue(raster_settings[v0:v1], params, color[v0:v1], depth[v0:v1], alpha[v0:v1], radii[v0:v1] if radii is not None else None, keep)
+                finally:                                         # join, also when a part's call raised: the caller's stream carries on when everything that was enqueued is
+                    for h in range(S):                           # done (outputs, parameters and workspaces are safe to reuse or free)
+                        cur.wait_stream(self._side[h])
                 sts = torch.stack([part.status for part in ran]).tolist()       # the single host sync of the call
                 st = [0, 0]
                 for w in sts:
