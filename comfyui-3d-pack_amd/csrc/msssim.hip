@@ -34,7 +34,9 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // w * a + b on two lanes of a register pair: v_pk_fma_f32 with the scalar weight broadcast
 __device__ __forceinline__ v2f ms_fma2(float w, v2f a, v2f b) { return __builtin_elementwise_fma(v2f{w, w}, a, b); }
 struct MsWin { float w[2 * MS_R + 1]; };
-struct MsLevel { int H, W, Hv, Wv, tx, ty; };          // image size, valid (filtered) size, tiles over the valid size
+struct MsLevel { int H, W, Hv, Wv, tx, ty, Wp; };      // image size, valid (filtered) size, tiles over the valid size; Wp: row pitch of the derivative maps, a multiple of the tile
+                                                       // width -- a tile's row of a map is then ONE whole 128-byte line (with pitch = Wv = W - 10 every such row straddled two or three
+                                                       // lines: level 0 of an 8-view step wrote 977 MB for 700 MB of maps + pooled planes, profiles/r06z_pmc_traffic.csv)
 
 // Level-0 tensors of a multi-image call whose images are NOT one contiguous [B, C, H, W] block (the fused 3DGS training step: every view has its own target, its
 // own rendered image inside its workspace slice, its own mask and gradient plane): per-image base pointers in the kernel arguments.  n = 0: contiguous tensors.
@@ -215,7 +217,7 @@ __global__ void __launch_bounds__(256, MS_MIN_BLOCKS) k_ms_fwd(const float* __re
                     dA = l * dA + cs * (2.f * m1 - 2.f * l * m2) * dl;      // ssim = l * cs
                     dB *= l; dC *= l; val = l * cs;
                 }
-                const size_t o = ((size_t)plane * lv.Hv + vy) * lv.Wv + vx;
+                const size_t o = ((size_t)plane * lv.Hv + vy) * lv.Wp + vx;
                 mapA[o] = dA; mapB[o] = dB; mapC[o] = dC;
                 local += val;
             }
@@ -314,7 +316,7 @@ __global__ void __launch_bounds__(256, MS_MIN_BLOCKS) k_ms_bwd(const float* __re
             const int uy = oy - 2 * MS_R + r, ux = ox - 2 * MS_R + c;
             a_[i] = 0.f; b_[i] = 0.f; c_[i] = 0.f;
             if (e < MS_INY * MS_IN && uy >= 0 && uy < lv.Hv && ux >= 0 && ux < lv.Wv) {
-                const size_t o = ((size_t)plane * lv.Hv + uy) * lv.Wv + ux;
+                const size_t o = ((size_t)plane * lv.Hv + uy) * lv.Wp + ux;
                 a_[i] = mapA[o]; b_[i] = mapB[o]; c_[i] = mapC[o];
             }
         }
@@ -410,7 +412,12 @@ void ms_plan(int P, int H, int W, MsPlan& pl) {
         MsLevel& L = pl.lv[l];
         L.H = h; L.W = w; L.Hv = h - 2 * MS_R; L.Wv = w - 2 * MS_R;
         L.tx = (L.Wv + MS_T - 1) / MS_T; L.ty = (L.Hv + MS_TY - 1) / MS_TY;
-        const size_t img = sizeof(float) * (size_t)P * h * w, val = sizeof(float) * (size_t)P * (size_t)(L.Hv > 0 ? L.Hv : 0) * (size_t)(L.Wv > 0 ? L.Wv : 0);
+#ifdef C3D_MS_NO_PITCH      // (A/B switch of profiles/r06/r06y_*)
+        L.Wp = L.Wv > 0 ? L.Wv : 0;
+#else
+        L.Wp = L.Wv > 0 ? L.tx * MS_T : 0;
+#endif
+        const size_t img = sizeof(float) * (size_t)P * h * w, val = sizeof(float) * (size_t)P * (size_t)(L.Hv > 0 ? L.Hv : 0) * (size_t)L.Wp;
         pl.off_x[l] = l ? take(img) : 0; pl.off_y[l] = l ? take(img) : 0;
         pl.off_map[l] = take(3 * val);
         pl.off_grad[l] = l ? take(img) : 0;
@@ -502,7 +509,7 @@ static int ms_run(const float* x, const float* y, const float* mask, const MsTab
     C3dProfScope ps(C3D_P_MSSSIM, s);
     for (int l = 0; l < MS_LEVELS; l++) {
         const MsLevel& L = pl.lv[l];
-        const size_t val = (size_t)P * L.Hv * L.Wv;
+        const size_t val = (size_t)P * L.Hv * L.Wp;
         float* mA = (float*)(ws + pl.off_map[l]); float* mB = mA + val; float* mC = mB + val;
         float* part = (float*)(ws + pl.off_part[l]);
         const int nt = ms_tiles_per_group(L.tx, L.ty, P);
@@ -529,7 +536,7 @@ static int ms_run(const float* x, const float* y, const float* mask, const MsTab
     if (ms_out && !per_image) hipLaunchKernelGGL(k_ms_mean, dim3(1), dim3(1), 0, s, msp, P, va, vb, ms_out, store_value);
     for (int l = MS_LEVELS - 1; l >= 0; l--) {
         const MsLevel& L = pl.lv[l];
-        const size_t val = (size_t)P * L.Hv * L.Wv;
+        const size_t val = (size_t)P * L.Hv * L.Wp;
         const float* mA = (const float*)(ws + pl.off_map[l]); const float* mB = mA + val; const float* mC = mB + val;
         const float* parent = l < MS_LEVELS - 1 ? (const float*)(ws + pl.off_grad[l + 1]) : nullptr;
         const int H2 = l < MS_LEVELS - 1 ? pl.lv[l + 1].H : 0, W2 = l < MS_LEVELS - 1 ? pl.lv[l + 1].W : 0;
