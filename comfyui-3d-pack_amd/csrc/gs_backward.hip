@@ -609,7 +609,8 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GsParams p, GsGeom g, co
     }
     // colour -> SH coefficients and view direction
     if (!colors_precomp) {
-        const float vx = m.x - p.campos[0], vy = m.y - p.campos[1], vz = m.z - p.campos[2];
+        const float3 cp_ = load_vec3_const(p.campos);
+        const float vx = m.x - cp_.x, vy = m.y - cp_.y, vz = m.z - cp_.z;
         const float s2 = vx * vx + vy * vy + vz * vz;
         const float len = sqrtf(s2);
         const float dxn = vx / len, dyn = vy / len, dzn = vz / len;
@@ -803,8 +804,8 @@ __global__ void __launch_bounds__(256) k_bwd_views_sh(int first, int last, int d
             const float* gc = vs.gcol[v] + 3 * (size_t)idx;
             const float dR0 = gc[0], dR1 = gc[1], dR2 = gc[2];
             if (dR0 == 0.f && dR1 == 0.f && dR2 == 0.f) continue;
-            const float* cp = vs.campos[v];
-            const float vx = m.x - cp[0], vy = m.y - cp[1], vz = m.z - cp[2];
+            const float3 cp = load_vec3_const(vs.campos[v]);
+            const float vx = m.x - cp.x, vy = m.y - cp.y, vz = m.z - cp.z;
             const float s2 = vx * vx + vy * vy + vz * vz;
             const float len = sqrtf(s2);
             const float dxn = vx / len, dyn = vy / len, dzn = vz / len;

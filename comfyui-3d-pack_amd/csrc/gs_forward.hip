@@ -53,7 +53,8 @@ __device__ __forceinline__ void gs_project_one(int idx, const float3 m, const fl
         if (colors_precomp) {
             r0 = colors_precomp[3 * idx]; r1 = colors_precomp[3 * idx + 1]; r2 = colors_precomp[3 * idx + 2];
         } else {
-            float dx = m.x - cam.campos[0], dy = m.y - cam.campos[1], dz = m.z - cam.campos[2];
+            const float3 cpos = load_vec3_const(cam.campos);
+            float dx = m.x - cpos.x, dy = m.y - cpos.y, dz = m.z - cpos.z;
             const float len = sqrtf(dx * dx + dy * dy + dz * dz);
             dx /= len; dy /= len; dz /= len;
 #define GS_FWD_TERM(k, Bk, dBx, dBy, dBz)                                                             \

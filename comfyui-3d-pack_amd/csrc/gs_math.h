@@ -22,11 +22,32 @@
 
 struct Mat16 { float m[16]; };
 
+// Read-only kernel inputs at a wave-uniform address (camera matrices, camera position) are read through the CONSTANT address space: the compiler may then use scalar loads
+// (s_load_dwordx16, counted by lgkmcnt) whatever stores surround them.  As plain `const float*` reads inside the multi-view kernels' loops -- next to stores the compiler cannot
+// tell apart from them -- they were VECTOR loads, and the s_waitcnt vmcnt(0) in front of their first use also waited for every store of the previous view (gfx9-family: loads
+// and stores share the counter): the projection kernel's stores (0.12 ms of its 0.28 per 8 views) could not overlap the next view's arithmetic
+// (profiles/r06/r06aa_projection_store_ablation.txt, r06ab_*).  The memory must not be written by the kernel that reads it this way (the scalar cache is not coherent with it).
+typedef const float __attribute__((address_space(4)))* c3d_const_f32p;
+__device__ __forceinline__ c3d_const_f32p c3d_as_const(const float* p) { return (c3d_const_f32p)(uintptr_t)p; }
 __device__ __forceinline__ Mat16 load_mat16(const float* __restrict__ p) {
     Mat16 r;
+#ifdef C3D_NO_CONST_LOADS      // (A/B switch of profiles/r06/r06ab_*)
 #pragma unroll
-    for (int i = 0; i < 16; i++) r.m[i] = p[i];   // wave-uniform address -> scalar loads
+    for (int i = 0; i < 16; i++) r.m[i] = p[i];
+#else
+    c3d_const_f32p q = c3d_as_const(p);
+#pragma unroll
+    for (int i = 0; i < 16; i++) r.m[i] = q[i];
+#endif
     return r;
+}
+__device__ __forceinline__ float3 load_vec3_const(const float* __restrict__ p) {
+#ifdef C3D_NO_CONST_LOADS
+    return make_float3(p[0], p[1], p[2]);
+#else
+    c3d_const_f32p q = c3d_as_const(p);
+    return make_float3(q[0], q[1], q[2]);
+#endif
 }
 // row vector (p,1) times the matrix as stored: out_i = sum_j p_j m[4j+i] + m[12+i]
 __device__ __forceinline__ float3 xform4x3(const float3 p, const Mat16& v) {
