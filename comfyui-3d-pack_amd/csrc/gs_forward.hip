@@ -244,12 +244,26 @@ __global__ void __launch_bounds__(EMIT_RANKS) k_emit(int N, int gx, const uint32
     tkey = (uint32_t*)((char*)tkey + voff); tval = (uint32_t*)((char*)tval + voff); ghist = (uint32_t*)((char*)ghist + voff);
     const int t = threadIdx.x;
     for (int p = 0; p < passes; p++) s_hist[p][t] = 0;
-    for (int r0 = (int)wg * EMIT_RANKS; r0 < N; r0 += (int)gridDim.x * EMIT_RANKS) {
-        __syncthreads();                         // the previous chunk's walk has read s_end / s_gid / s_rect (first chunk: the counters are zero)
+    // The NEXT chunk's inputs are requested before this chunk's pairs are written (round 6): behind the walk they were loads that wait -- vmcnt counts loads and stores alike on
+    // this ISA -- for every store of the walk before the chunk can even start.
+    const int stride = (int)gridDim.x * EMIT_RANKS;
+    uint32_t n_end = 0, n_gid = 0, n_B0 = 0; uint2 n_rect = make_uint2(0u, 0u);
+    auto fetch = [&](int r0) {
+        if (r0 >= N) return;      // (uniform)
         const int r = min(r0 + t, N - 1);       // ranks past the end repeat the last one's END: empty stretches
-        s_end[t] = offsets[r];
-        if (r0 + t < N) { s_gid[t] = order[r]; s_rect[t] = rsort[r]; }
-        const uint32_t B0 = r0 ? offsets[r0 - 1] : 0u;
+        n_end = offsets[r];
+        if (r0 + t < N) { n_gid = order[r]; n_rect = rsort[r]; }
+        n_B0 = r0 ? offsets[r0 - 1] : 0u;
+    };
+    fetch((int)wg * EMIT_RANKS);
+    for (int r0 = (int)wg * EMIT_RANKS; r0 < N; r0 += stride) {
+        __syncthreads();                         // the previous chunk's walk has read s_end / s_gid / s_rect (first chunk: the counters are zero)
+        s_end[t] = n_end;
+        if (r0 + t < N) { s_gid[t] = n_gid; s_rect[t] = n_rect; }
+        const uint32_t B0 = n_B0;
+#ifndef C3D_EMIT_NO_PREFETCH      // (A/B switch of profiles/r06/r06ad_*)
+        fetch(r0 + stride);
+#endif
         __syncthreads();
         const uint32_t B1 = min(s_end[EMIT_RANKS - 1], cap);
         for (uint32_t o = B0 + (uint32_t)t; o < B1; o += EMIT_RANKS) {
@@ -266,6 +280,9 @@ __global__ void __launch_bounds__(EMIT_RANKS) k_emit(int N, int gx, const uint32
             tval[o] = s_gid[j];
             for (int p = 0; p < passes; p++) atomicAdd(&s_hist[p][(key >> (8 * p)) & 255u], 1u);
         }
+#ifdef C3D_EMIT_NO_PREFETCH
+        fetch(r0 + stride);
+#endif
     }
     __syncthreads();
     uint32_t* mine = ghist + (size_t)(wg % C3D_SORT_HIST_SPLIT) * C3D_SORT_MAX_PASSES * 256;
