@@ -360,7 +360,7 @@ class FusedViewRender:
     streams > 1 (round 6): the views are cut into up to `streams` contiguous parts of >= 8 views, each part one library call on a HIP stream of its own (own workspace),
     forked from and joined back into the caller's stream.  The binning chain of a part -- launches that are latency or memory bound -- then runs underneath the compositing of
     another part, which is bound by instruction issue: BASELINE config 2 (64 cameras) 15.15 -> 14.39 ms on one box with four streams, the images bit-identical
-    (profiles/r06/r06t_two_streams_fwd64.txt).  The library itself still owns no stream."""
+    (profiles/r06/r06s_t_small_launches_and_streams.txt, r06t_streams_*.txt).  The library itself still owns no stream."""
 
     MIN_PART = 8       # views per part: narrower launches cost more than further overlap brings (4 parts of 8 views: +35 % on a 10 k-Gaussian 512^2 orbit, +3.5 % at 200 k / 1024^2, +6 % at config 2)
 
