@@ -1655,3 +1655,24 @@ def test_render_views_on_several_streams_equals_the_one_stream_call(streams, V):
         out2 = many.run(rs, p2, want_radii=False)
         y = out2[0].sum() + x.sum()
         assert torch.isfinite(y) and torch.equal(out2[0], ref[0])
+
+
+def test_orbit_of_seventeen_poses_through_the_controller_takes_two_streams_and_equals_the_per_view_renders():
+    """The product default of the orbit path: GaussianSplattingCameraController.render_all_pose without autograd -> render_views(streams=4) -> at 17 cameras two parts
+    (9 + 8 views) on two HIP streams; every image, mask and radius equals the per-view render() of the same pose bit for bit."""
+    from MVs_Algorithms.GaussianSplatting.main_3DGS_renderer import GaussianSplattingRenderer
+    from MVs_Algorithms.GaussianSplatting.main_3DGS import GaussianSplattingCameraController
+    raw = S.make_cloud(20000, seed=21, log_scale_mean=np.log(0.025), activated=False)
+    r = GaussianSplattingRenderer(sh_degree=3, device="cuda")
+    r.initialize({"xyz": raw["means3D"], "features": raw["shs"], "scaling_raw": raw["scales"], "rotation_raw": raw["rotations"], "opacity_raw": raw["opacities"]})
+    ctl = GaussianSplattingCameraController(r, 240, 160, 49.1, static_bg=[0.1, 0.2, 0.3])
+    poses = [[2.0 + 0.03 * i, -40.0 + 6.0 * i, 21.0 * i, 0.0, 0.0, 0.0] for i in range(17)]
+    with torch.no_grad():
+        images, masks, extra = ctl.render_all_pose(poses)
+        vr = r._view_render
+        assert vr.streams == 4 and vr._plan(len(poses)) == (2, 9)
+        for i, p in enumerate(poses):
+            pv = ctl.render_at_pose(p)
+            assert torch.equal(images[i], pv["image"]) and torch.equal(masks[i], pv["alpha"]) and torch.equal(extra["radii"][i], pv["radii"]), i
+        images2, _, _ = ctl.render_all_pose(poses)      # fitted buffers, same parts
+        assert torch.equal(images2, images) and len(vr._parts) == 2
