@@ -67,6 +67,8 @@ def parse():
     ap.add_argument("--timed-prof", choices=["on", "off"], default="on", help="HIP-event kernel timing inside the timed region")
     ap.add_argument("--lanes", type=int, default=0, help="view GROUPS a fused call splits its views into (ceil(views / lanes) views per launch of every stage, the groups one after the "
                                                        "other on the same stream; the library owns no streams); 0 = 1: all views of the step through every stage in ONE launch each, in every mode")
+    ap.add_argument("--as-rank", type=int, default=-1, help="one-GPU runs: render the cameras rank R of an N-GPU run would (rank r = orbit cameras [r * views-per-gpu, (r + 1) * views-per-gpu): "
+                                                            "ranks of an 8-GPU run are elevation bands); default: this process's own rank")
     ap.add_argument("--group", type=int, default=16, help="--mode fwd: views per launch of every stage (<= 16)")
     ap.add_argument("--streams", type=int, default=4, help="--mode fwd (render path step): HIP streams the views of a call are spread over, one library call per stream (FusedViewRender: one part's "
                                                           "binning chain runs underneath another part's compositing); 1 = one call on one stream")
@@ -494,7 +496,8 @@ def main():
     use_renderer = a.render_path != "boundary"
     cloud = S.make_cloud(N, seed=1234, sh_degree=deg, activated=True)          # what the rasterizer consumes (cpu_baseline leg, boundary path)
     poses = S.orbit_poses_64()
-    my_poses = [poses[(rank * a.views_per_gpu + i) % len(poses)] for i in range(a.views_per_gpu)]
+    pose_rank = a.as_rank if (a.as_rank >= 0 and world == 1) else rank
+    my_poses = [poses[(pose_rank * a.views_per_gpu + i) % len(poses)] for i in range(a.views_per_gpu)]
     t = lambda x: torch.as_tensor(np.asarray(x, dtype=np.float32)).to(dev)
     settings, cams = [], []
     for (r, e, az) in my_poses:
